@@ -1,0 +1,1150 @@
+/*
+ * oracle/nrmc_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C, single-threaded CPU restatement of the reference's analytic ray tracer
+ * (NuRadioMC/SignalProp/analyticraytracing.py, pure-Python path, use_cpp=False) and of the
+ * attenuation-length models (NuRadioMC/utilities/attenuation.py).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load the library built from this
+ * file; the product path (nuradiomc_amd/) never does.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this file against
+ *   - the reference's own golden vectors (tests/golden/ref_C0_SP.npz from
+ *     NuRadioMC/test/SignalProp/reference_C0.pkl; ref_single_events_1e18.npz from
+ *     NuRadioMC/test/SingleEvents/1e18_output_reference.hdf5), and
+ *   - outputs of the reference itself run in the build container
+ *     (tests/golden/raytrace_{A,B,C}.npz, generator tests/golden/gen/gen_raytrace.py).
+ *
+ * The reference delegates three numerical kernels to SciPy (unpinned "*" in pyproject.toml; the
+ * build container has SciPy 1.15.3).  Their published algorithms are restated here:
+ *   - scipy.optimize.root(method='hybr')  = MINPACK HYBRD (More', Garbow, Hillstrom 1980), n = 1
+ *     (call site analyticraytracing.py:1479)
+ *   - scipy.optimize.brentq               = Brent 1973 as implemented in scipy/optimize/Zeros/brentq.c
+ *     (call sites :1504, :1526)
+ *   - scipy.integrate.quad                = QUADPACK DQAGSE / DQAGPE with DQK21, DQELG, DQPSRT
+ *     (Piessens et al. 1983) (call site :1071)
+ */
+#include <math.h>
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { double n_ice, delta_n, z_0; } ice_t;
+
+#define SPEED_OF_LIGHT 0.299792458 /* m/ns, analyticraytracing.py:56 */
+
+/* ------------------------------------------------------------------------------------------
+ * 2-D analytic ray path helpers (analyticraytracing.py:99-370)
+ * ---------------------------------------------------------------------------------------- */
+static double n_of_z(double z, const ice_t *m) { return m->n_ice - m->delta_n * exp(z / m->z_0); } /* :358 */
+static double get_gamma(double z, const ice_t *m) { return m->delta_n * exp(z / m->z_0); }        /* :127 */
+static double C0_from_log(double logC0, const ice_t *m) { return exp(logC0) + 1. / m->n_ice; }    /* :99 */
+
+/* :105-125 */
+static double get_y(double gamma, double C0, double C1, const ice_t *m)
+{
+    double b = 2 * m->n_ice;
+    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double root = fabs(gamma * gamma - gamma * b + c);
+    double logargument = gamma / (2 * sqrt(c) * sqrt(root) - b * gamma + 2 * c);
+    return m->z_0 * pow(m->n_ice * m->n_ice * C0 * C0 - 1, -0.5) * log(logargument) + C1;
+}
+
+/* :133-158 */
+static void get_turning_point(double c, const ice_t *m, double *gamma_turn, double *z_turn)
+{
+    double b = 2 * m->n_ice;
+    double gamma2 = b * 0.5 - sqrt(0.25 * b * b - c);
+    double z2 = log(gamma2 / m->delta_n) * m->z_0;
+    if (z2 > 0) {
+        z2 = 0;
+        gamma2 = get_gamma(z2, m);
+    }
+    *gamma_turn = gamma2;
+    *z_turn = z2;
+}
+
+/* :160-184 */
+static double get_y_with_z_mirror(double z, double C0, const ice_t *m, double C1)
+{
+    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double gamma_turn, z_turn;
+    get_turning_point(c, m, &gamma_turn, &z_turn);
+    double y_turn = get_y(gamma_turn, C0, C1, m);
+    if (z < z_turn)
+        return get_y(get_gamma(z, m), C0, C1, m);
+    return 2 * y_turn - get_y(get_gamma(2 * z_turn - z, m), C0, C1, m);
+}
+
+static double get_C1(const double x1[2], double C0, const ice_t *m) /* :487 */
+{
+    return x1[0] - get_y_with_z_mirror(x1[1], C0, m, 0.0);
+}
+
+/* :204-272 with reflection == 0 */
+static double get_delta_y(double C0, const double x1[2], const double x2[2], const ice_t *m)
+{
+    if (C0 < 1. / m->n_ice || C0 > INFINITY)
+        return -INFINITY;
+    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double C1 = x1[0] - get_y_with_z_mirror(x1[1], C0, m, 0.0);
+    double gamma_turn, z_turn;
+    get_turning_point(c, m, &gamma_turn, &z_turn);
+    double y_turn = get_y(gamma_turn, C0, C1, m);
+    if (z_turn < x2[1]) {
+        double dz = z_turn - x2[1], dy = y_turn - x2[0];
+        double diff = sqrt(dz * dz + dy * dy) + 10 * fabs(z_turn - x2[1]);
+        return -diff;
+    }
+    if (y_turn > x2[0]) {
+        double y2_fit = get_y(get_gamma(x2[1], m), C0, C1, m);
+        return x2[0] - y2_fit;
+    } else {
+        double y2_raw = get_y(get_gamma(x2[1], m), C0, C1, m);
+        double y2_fit = 2 * y_turn - y2_raw;
+        return -1 * (x2[0] - y2_fit);
+    }
+}
+
+typedef struct { const double *x1, *x2; const ice_t *m; long nfev; } obj_t;
+
+static double obj_delta_y(double logC0, void *p) /* :1357 */
+{
+    obj_t *o = (obj_t *)p;
+    o->nfev++;
+    return get_delta_y(C0_from_log(logC0, o->m), o->x1, o->x2, o->m);
+}
+static double obj_delta_y_square(double logC0, void *p) /* :274 */
+{
+    double d = obj_delta_y(logC0, p);
+    return d * d;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * MINPACK HYBRD restated for n = 1, as driven by scipy.optimize.root(method='hybr', tol=xtol):
+ * maxfev = 200*(n+1), ml = mu = n-1, epsfcn = machine eps, factor = 100, mode = 1.
+ * For n = 1:  QR of the 1x1 Jacobian a gives Q = -1, R = -a (Householder sign convention of QRFAC),
+ * the dogleg step is the Newton step clipped to the trust region, R1UPDT is r += u*v and the
+ * Givens sweeps of R1UPDT / R1MPYQ are empty.
+ * ---------------------------------------------------------------------------------------- */
+typedef double (*fun1_t)(double, void *);
+
+int orc_hybrd1(fun1_t fcn, void *p, double *x_io, double *fvec_out, double xtol, int *nfev_out)
+{
+    const double epsmch = DBL_EPSILON;
+    const double p1 = .1, p5 = .5, p001 = .001, p0001 = 1e-4, factor = 100.;
+    const int maxfev = 400;
+    double x = *x_io;
+    int info = 0, nfev = 0;
+    double fvec = fcn(x, p);
+    nfev = 1;
+    double fnorm = fabs(fvec);
+    int iter = 1, ncsuc = 0, ncfail = 0, nslow1 = 0, nslow2 = 0;
+    double diag = 0, delta = 0, xnorm = 0;
+    double r = 0, qtf = 0, fjac = 0;
+    for (;;) { /* outer loop: (re)compute the Jacobian by forward difference (FDJAC1) */
+        int jeval = 1;
+        double eps = sqrt(epsmch); /* epsfcn = epsmch */
+        double h = eps * fabs(x);
+        if (h == 0.) h = eps;
+        double wa1f = fcn(x + h, p);
+        nfev += 1;
+        double a = (wa1f - fvec) / h;
+        /* QRFAC on 1x1: acnorm = |a|; rdiag = -a; householder vector element = 2 (if a != 0) */
+        double acnorm = fabs(a);
+        double hh = (a != 0.) ? 2. : 0.; /* fjac(1,1) after qrfac: a/ajnorm + 1 */
+        double rdiag = -a;              /* -ajnorm with ajnorm carrying the sign of a */
+        if (a == 0.) rdiag = -0.0;
+        if (iter == 1) {
+            diag = acnorm;
+            if (acnorm == 0.) diag = 1.;
+            xnorm = fabs(diag * x);
+            delta = factor * xnorm;
+            if (delta == 0.) delta = factor;
+        }
+        /* qtf = Q^T fvec */
+        double wa4 = fvec;
+        if (hh != 0.) {
+            double sum = hh * wa4;
+            double temp = -sum / hh;
+            wa4 += hh * temp;
+        }
+        qtf = wa4;
+        r = rdiag;
+        /* QFORM: Q = I - v v^T / v1 -> 1 - 2*2/2 = -1 ; if a == 0 the column is zero -> Q = 1 */
+        fjac = (hh != 0.) ? -1. : 1.;
+        if (acnorm > diag) diag = acnorm; /* mode 1 rescale */
+        for (;;) { /* inner loop */
+            /* DOGLEG (n = 1) */
+            double temp = r;
+            if (temp == 0.) {
+                temp = epsmch * fabs(r); /* epsmch * max column abs */
+                if (temp == 0.) temp = epsmch;
+            }
+            double xs = qtf / temp; /* Gauss-Newton direction */
+            double qnorm = fabs(diag * xs);
+            if (qnorm > delta) {
+                double g = r * qtf / diag; /* scaled gradient */
+                double gnorm = fabs(g);
+                double sgnorm = 0., alpha = delta / qnorm;
+                double w1 = g;
+                if (gnorm != 0.) {
+                    w1 = (g / gnorm) / diag;
+                    double w2 = r * w1;
+                    double t = fabs(w2);
+                    sgnorm = (gnorm / t) / t;
+                    alpha = 0.;
+                    if (sgnorm < delta) {
+                        double bnorm = fabs(qtf);
+                        double tt = (bnorm / gnorm) * (bnorm / qnorm) * (sgnorm / delta);
+                        double dq = delta / qnorm, sd = sgnorm / delta;
+                        tt = tt - dq * (sd * sd) + sqrt((tt - dq) * (tt - dq) + (1. - dq * dq) * (1. - sd * sd));
+                        alpha = (dq * (1. - sd * sd)) / tt;
+                    }
+                }
+                double t2 = (1. - alpha) * fmin(sgnorm, delta);
+                xs = t2 * w1 + alpha * xs;
+            }
+            double wa1 = -xs;         /* step p */
+            double wa2 = x + wa1;     /* trial point */
+            double wa3 = diag * wa1;
+            double pnorm = fabs(wa3);
+            if (iter == 1) delta = fmin(delta, pnorm);
+            double f_new = fcn(wa2, p);
+            nfev += 1;
+            double fnorm1 = fabs(f_new);
+            double actred = -1.;
+            if (fnorm1 < fnorm) actred = 1. - (fnorm1 / fnorm) * (fnorm1 / fnorm);
+            /* predicted reduction: |r*p + qtf| */
+            double w3 = qtf + r * wa1;
+            double tnorm = fabs(w3);
+            double prered = 0.;
+            if (tnorm < fnorm) prered = 1. - (tnorm / fnorm) * (tnorm / fnorm);
+            double ratio = 0.;
+            if (prered > 0.) ratio = actred / prered;
+            if (ratio < p1) {
+                ncsuc = 0;
+                ncfail++;
+                delta = p5 * delta;
+            } else {
+                ncfail = 0;
+                ncsuc++;
+                if (ratio >= p5 || ncsuc > 1) delta = fmax(delta, pnorm / p5);
+                if (fabs(ratio - 1.) <= p1) delta = pnorm / p5;
+            }
+            if (ratio >= p0001) { /* successful iteration */
+                x = wa2;
+                fvec = f_new;
+                xnorm = fabs(diag * x);
+                fnorm = fnorm1;
+                iter++;
+            }
+            nslow1++;
+            if (actred >= p001) nslow1 = 0;
+            if (jeval) nslow2++;
+            if (actred >= p1) nslow2 = 0;
+            if (delta <= xtol * xnorm || fnorm == 0.) info = 1;
+            if (info != 0) goto done;
+            if (nfev >= maxfev) info = 2;
+            if (p1 * fmax(p1 * delta, pnorm) <= epsmch * xnorm) info = 3;
+            if (nslow2 == 5) info = 4;
+            if (nslow1 == 10) info = 5;
+            if (info != 0) goto done;
+            if (ncfail == 2) break; /* recompute Jacobian */
+            /* rank-one (Broyden) update of R, and of qtf */
+            double sum = fjac * f_new;
+            double v = (sum - w3) / pnorm;
+            double u = diag * ((diag * wa1) / pnorm);
+            if (ratio >= p0001) qtf = sum;
+            r = r + u * v; /* R1UPDT, n = 1 */
+            jeval = 0;
+        }
+    }
+done:
+    *x_io = x;
+    *fvec_out = fvec;
+    if (nfev_out) *nfev_out = nfev;
+    return info;
+}
+
+/* scipy/optimize/Zeros/brentq.c restated; xtol = 2e-12, rtol = 4*eps, maxiter = 100 (scipy defaults) */
+int orc_brentq(fun1_t f, void *p, double xa, double xb, double *root)
+{
+    const double xtol = 2e-12, rtol = 8.881784197001252e-16;
+    const int maxiter = 100;
+    double xpre = xa, xcur = xb, xblk = 0., fpre, fcur, fblk = 0., spre = 0., scur = 0., sbis;
+    double delta, stry, dpre, dblk;
+    fpre = f(xpre, p);
+    fcur = f(xcur, p);
+    if (fpre == 0) { *root = xpre; return 0; }
+    if (fcur == 0) { *root = xcur; return 0; }
+    if (signbit(fpre) == signbit(fcur)) { *root = NAN; return -1; }
+    for (int i = 0; i < maxiter; i++) {
+        if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
+            xblk = xpre;
+            fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur; xcur = xblk; xblk = xpre;
+            fpre = fcur; fcur = fblk; fblk = fpre;
+        }
+        delta = (xtol + rtol * fabs(xcur)) / 2;
+        sbis = (xblk - xcur) / 2;
+        if (fcur == 0 || fabs(sbis) < delta) { *root = xcur; return 0; }
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                dpre = (fpre - fcur) / (xpre - xcur);
+                dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            if (2 * fabs(stry) < fmin(fabs(spre), 3 * fabs(sbis) - delta)) {
+                spre = scur; scur = stry;
+            } else {
+                spre = sbis; scur = sbis;
+            }
+        } else {
+            spre = sbis; scur = sbis;
+        }
+        xpre = xcur; fpre = fcur;
+        if (fabs(scur) > delta) xcur += scur;
+        else xcur += (sbis > 0 ? delta : -delta);
+        fcur = f(xcur, p);
+    }
+    *root = xcur;
+    return -2;
+}
+
+/* np.sign semantics incl. NaN (np.sign(nan) = nan, and nan != anything is True) */
+static int sign_differs(double a, double b)
+{
+    if (isnan(a) || isnan(b)) return 1;
+    double sa = (a > 0) - (a < 0), sb = (b > 0) - (b < 0);
+    return sa != sb;
+}
+
+/* :1365-1398 */
+static int determine_solution_type(const double x1[2], const double x2[2], double C0, const ice_t *m)
+{
+    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double C1 = get_C1(x1, C0, m);
+    double gamma_turn, z_turn;
+    get_turning_point(c, m, &gamma_turn, &z_turn);
+    double y_turn = get_y(gamma_turn, C0, C1, m);
+    if (x2[0] < y_turn) return 1;     /* direct */
+    if (z_turn == 0) return 3;        /* reflected */
+    return 2;                         /* refracted */
+}
+
+/* ray_tracing_2D.find_solutions, Python branch (:1433-1547), reflection = 0, receiver in ice.
+ * Returns number of solutions (<= 3) sorted by C0; hybr diagnostics optional. */
+int orc_find_solutions_2d(const double x1[2], const double x2[2], const double ice[3],
+                          double *C0s, double *C1s, int *types, double *hybr_x, double *hybr_fun, int *nfev)
+{
+    ice_t m = { ice[0], ice[1], ice[2] };
+    obj_t o = { x1, x2, &m, 0 };
+    int n = 0;
+    double logC0[3];
+    if (x2[1] > 0) return 0; /* ice->air special case (:1437-1460) not restated */
+    double xr = -1.;
+    double fun;
+    int nf;
+    orc_hybrd1(obj_delta_y_square, &o, &xr, &fun, 1e-6, &nf);
+    if (hybr_x) *hybr_x = xr;
+    if (hybr_fun) *hybr_fun = fun;
+    if (fun < 1e-7) logC0[n++] = xr;
+    {
+        double a = xr + 0.0001, b = 100.;
+        double da = obj_delta_y(a, &o), db = obj_delta_y(b, &o);
+        if (sign_differs(da, db)) {
+            double rt;
+            orc_brentq(obj_delta_y, &o, a, b, &rt);
+            logC0[n++] = rt;
+        }
+    }
+    {
+        double a = -100., b = xr - 0.0001;
+        double da = obj_delta_y(a, &o), db = obj_delta_y(b, &o);
+        if (sign_differs(da, db)) {
+            double rt;
+            orc_brentq(obj_delta_y, &o, a, b, &rt);
+            logC0[n++] = rt;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        C0s[i] = C0_from_log(logC0[i], &m);
+        types[i] = determine_solution_type(x1, x2, C0s[i], &m);
+        C1s[i] = get_C1(x1, C0s[i], &m);
+    }
+    /* sorted(results, key=('reflection','C0')) -- stable insertion sort */
+    for (int i = 1; i < n; i++)
+        for (int j = i; j > 0 && C0s[j] < C0s[j - 1]; j--) {
+            double t = C0s[j]; C0s[j] = C0s[j - 1]; C0s[j - 1] = t;
+            t = C1s[j]; C1s[j] = C1s[j - 1]; C1s[j - 1] = t;
+            int k = types[j]; types[j] = types[j - 1]; types[j - 1] = k;
+        }
+    if (nfev) *nfev = (int)o.nfev;
+    return n;
+}
+
+/* :496-511 */
+static double get_z_mirrored(const double x1[2], const double x2[2], double C0, const ice_t *m)
+{
+    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double C1 = get_C1(x1, C0, m);
+    double gamma_turn, z_turn;
+    get_turning_point(c, m, &gamma_turn, &z_turn);
+    double y_turn = get_y(gamma_turn, C0, C1, m);
+    double zstop = x2[1];
+    if (y_turn < x2[0]) zstop = x1[1] + fabs(z_turn - x1[1]) + fabs(z_turn - x2[1]);
+    return zstop;
+}
+
+/* :293-304 */
+static double get_z_unmirrored(double z, double C0, const ice_t *m)
+{
+    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double gamma_turn, z_turn;
+    get_turning_point(c, m, &gamma_turn, &z_turn);
+    if (z > z_turn) return 2 * z_turn - z;
+    return z;
+}
+
+/* :306-355 (in_air = False) */
+static double get_y_diff(double z_raw, double C0, const ice_t *m)
+{
+    double z = get_z_unmirrored(z_raw, C0, m);
+    double n_z = n_of_z(z, m);
+    double res;
+    if (C0 * C0 * n_z * n_z > 1) res = 1 / sqrt(C0 * C0 * n_z * n_z - 1);
+    else res = INFINITY;
+    if (z != z_raw) res *= -1;
+    return res;
+}
+
+/* :1161-1199 */
+static double get_angle(const double x[2], const double x_start[2], double C0, const ice_t *m)
+{
+    double z = get_z_mirrored(x_start, x, C0, m);
+    double dy = get_y_diff(z, C0, m);
+    double angle = atan(dy);
+    if (angle < 0) angle = M_PI + angle;
+    return angle;
+}
+static double get_launch_angle(const double x1[2], double C0, const ice_t *m) { return get_angle(x1, x1, C0, m); }
+static double get_receive_angle(const double x1[2], const double x2[2], double C0, const ice_t *m)
+{
+    return M_PI - get_angle(x2, x1, C0, m);
+}
+
+/* :1201-1237, reflection = 0: returns NaN for "None" */
+static double get_reflection_angle(const double x1[2], const double x2[2], double C0, const ice_t *m)
+{
+    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double gamma_turn, z_turn;
+    get_turning_point(c, m, &gamma_turn, &z_turn);
+    double C1 = get_C1(x1, C0, m);
+    double y_turn = get_y(gamma_turn, C0, C1, m); /* get_y_turn :186 */
+    if (z_turn >= 0 && y_turn > x1[0] && y_turn < x2[0]) {
+        double xs[2] = { y_turn, 0. };
+        return get_angle(xs, x1, C0, m);
+    }
+    return NAN;
+}
+
+/* :602-690 and :692-783, reflection = 0, receiver in ice */
+static void path_length_and_time(const double x1[2], const double x2[2], double C0, const ice_t *m,
+                                 double *D, double *T)
+{
+    double z1 = x1[1], z2 = x2[1];
+    int solution_type = determine_solution_type(x1, x2, C0, m);
+    double launch_angle = get_launch_angle(x1, C0, m);
+    double n_ice = m->n_ice, z_0 = m->z_0;
+    double n1 = n_of_z(z1, m);
+    double beta = n1 * sin(launch_angle);
+    double alpha = n_ice * n_ice - beta * beta;
+    double zz[3] = { z1, z2, 0. };
+    double s[3], ct[3];
+    if (solution_type == 2) {
+        double g, zt;
+        get_turning_point(n_ice * n_ice - pow(C0, -2.), m, &g, &zt);
+        zz[2] = zt;
+    }
+    for (int i = 0; i < 3; i++) {
+        double nz = n_of_z(zz[i], m);
+        double gamma = fmax(0., nz * nz - beta * beta);
+        double l1 = sqrt(alpha * gamma) + n_ice * nz - beta * beta;
+        double l2 = sqrt(gamma) + nz;
+        s[i] = n_ice / sqrt(alpha) * (zz[i] - z_0 * log(l1)) + z_0 * log(l2);
+        ct[i] = z_0 * (sqrt(gamma) - n_ice * n_ice / sqrt(alpha) * log(l1) + n_ice * log(l2))
+                + n_ice * n_ice * zz[i] / sqrt(alpha);
+    }
+    if (solution_type == 1) {
+        *D = s[1] - s[0];
+        *T = (ct[1] - ct[0]) / SPEED_OF_LIGHT;
+    } else {
+        *D = 2 * s[2] - s[0] - s[1];
+        *T = (2 * ct[2] - ct[0] - ct[1]) / SPEED_OF_LIGHT;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * attenuation length (NuRadioMC/utilities/attenuation.py:145-262), scalar branch
+ * model ints follow attenuation.py:14  {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4, "GL3": 5}
+ * ---------------------------------------------------------------------------------------- */
+double orc_attenuation_length(double z, double frequency, int model)
+{
+    double L;
+    if (model == 1) { /* SP1 :168-192 */
+        double z2 = fabs(z);
+        double t = 1.83415e-09 * pow(z2, 3) + (-1.59061e-08 * pow(z2, 2)) + 0.00267687 * z2 + (-51.0696);
+        double f0 = 0.0001, f2 = 3.16;
+        double w0 = log(f0), w1 = 0.0, w2 = log(f2);
+        double w = log(frequency);
+        double b0 = -6.74890 + t * (0.026709 - t * 0.000884);
+        double b1 = -6.22121 - t * (0.070927 + t * 0.001773);
+        double b2 = -4.09468 - t * (0.002213 + t * 0.000332);
+        double a, bb;
+        if (frequency < 1.) {
+            a = (b1 * w0 - b0 * w1) / (w0 - w1);
+            bb = (b1 - b0) / (w1 - w0);
+        } else {
+            a = (b2 * w1 - b1 * w2) / (w1 - w2);
+            bb = (b2 - b1) / (w2 - w1);
+        }
+        L = 1. / exp(a + bb * w);
+    } else if (model == 2) { /* GL1 :99-128, :194-196 (Python clamps the 75 MHz length at 100 m) */
+        static const double fit[6] = { 1.16052586e+03, 6.87257150e-02, -9.82378264e-05,
+                                       -3.50628312e-07, -2.21040482e-10, -3.63912864e-14 };
+        double att = 0;
+        for (int p = 0; p < 6; p++) att += fit[p] * pow(z, p);
+        if (att < 100.) att = 100.;
+        L = att - 0.55 * (frequency / 1e-3 - 75);
+    } else if (model == 4) { /* GL2 :198-204 */
+        static const double fit[6] = { 1.20547286e+00, 1.58815679e-05, -2.58901767e-07,
+                                       -5.16435542e-10, -2.89124473e-13, -4.58987344e-17 };
+        double bulk = 852.0 + (-0.54 / 1e-3) * frequency;
+        double poly = 0; /* np.poly1d(flip(fit))(z): Horner from highest power */
+        for (int p = 5; p >= 0; p--) poly = poly * z + fit[p];
+        L = bulk * poly;
+    } else if (model == 3) { /* MB1 :224-244 */
+        double R = 0.82, d_ice = 576.;
+        L = 460. - 180. * frequency;
+        L *= pow(1 + L / (2 * d_ice) * log(R), -1);
+        double d = -z * 420. / d_ice;
+        double LL = (1250. * 0.08886 * exp(-0.048827 * (225.6746 - 86.517596 * log10(848.870 - (d)))));
+        L *= LL / 231.21;
+    } else {
+        return NAN; /* GL3 needs data/GL3_params.csv: not restated */
+    }
+    if (L < 1.) L = 1.;
+    if (z > 0) L = INFINITY;
+    return L;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * QUADPACK restatement (DQK21, DQPSRT, DQELG, DQAGSE, DQAGPE)
+ * ---------------------------------------------------------------------------------------- */
+typedef double (*integrand_t)(double, void *);
+
+static const double XGK[11] = {
+    0.995657163025808080735527280689003, 0.973906528517171720077964012084452,
+    0.930157491355708226001207180059508, 0.865063366688984510732096688423493,
+    0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
+    0.562757134668604683339000099272694, 0.433395394129247190799265943165784,
+    0.294392862701460198131126603103866, 0.148874338981631210884826001129720,
+    0.000000000000000000000000000000000 };
+static const double WGK[11] = {
+    0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
+    0.054755896574351996031381300244580, 0.075039674810919952767043140916190,
+    0.093125454583697605535065465083366, 0.109387158802297641899210590325805,
+    0.123491976262065851077958109585166, 0.134709217311473325928054001771707,
+    0.142775938577060080797094273138717, 0.147739104901338491374841515972068,
+    0.149445554002916905664936468389821 };
+static const double WG[5] = {
+    0.066671344308688137593568809893332, 0.149451349150580593145776339657697,
+    0.219086362515982043995534934228163, 0.269266719309996355091226921569469,
+    0.295524224714752870173815619188769 };
+
+static void dqk21(integrand_t f, void *p, double a, double b, double *result, double *abserr,
+                  double *resabs, double *resasc)
+{
+    const double epmach = DBL_EPSILON, uflow = DBL_MIN;
+    double fv1[10], fv2[10];
+    double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
+    double resg = 0.;
+    double fc = f(centr, p);
+    double resk = WGK[10] * fc;
+    *resabs = fabs(resk);
+    for (int j = 0; j < 5; j++) {
+        int jtw = 2 * j + 1;
+        double absc = hlgth * XGK[jtw];
+        double fval1 = f(centr - absc, p), fval2 = f(centr + absc, p);
+        fv1[jtw] = fval1; fv2[jtw] = fval2;
+        double fsum = fval1 + fval2;
+        resg += WG[j] * fsum;
+        resk += WGK[jtw] * fsum;
+        *resabs += WGK[jtw] * (fabs(fval1) + fabs(fval2));
+    }
+    for (int j = 0; j < 5; j++) {
+        int jtwm1 = 2 * j;
+        double absc = hlgth * XGK[jtwm1];
+        double fval1 = f(centr - absc, p), fval2 = f(centr + absc, p);
+        fv1[jtwm1] = fval1; fv2[jtwm1] = fval2;
+        double fsum = fval1 + fval2;
+        resk += WGK[jtwm1] * fsum;
+        *resabs += WGK[jtwm1] * (fabs(fval1) + fabs(fval2));
+    }
+    double reskh = resk * 0.5;
+    *resasc = WGK[10] * fabs(fc - reskh);
+    for (int j = 0; j < 10; j++) *resasc += WGK[j] * (fabs(fv1[j] - reskh) + fabs(fv2[j] - reskh));
+    *result = resk * hlgth;
+    *resabs *= dhlgth;
+    *resasc *= dhlgth;
+    *abserr = fabs((resk - resg) * hlgth);
+    if (*resasc != 0. && *abserr != 0.) *abserr = *resasc * fmin(1., pow(200. * *abserr / *resasc, 1.5));
+    if (*resabs > uflow / (50. * epmach)) *abserr = fmax((epmach * 50.) * *resabs, *abserr);
+}
+
+/* 1-based index arithmetic kept as in the Fortran; arrays are [0..limit] with slot 0 unused */
+static void dqpsrt(int limit, int last, int *maxerr, double *ermax, const double *elist, int *iord, int *nrmax)
+{
+    double errmax, errmin;
+    int i, ibeg, ido, isucc, j, jbnd, jupbn, k;
+    if (last <= 2) {
+        iord[1] = 1;
+        iord[2] = 2;
+        goto L90;
+    }
+    errmax = elist[*maxerr];
+    if (*nrmax != 1) {
+        ido = *nrmax - 1;
+        for (i = 1; i <= ido; i++) {
+            isucc = iord[*nrmax - 1];
+            if (errmax <= elist[isucc]) break;
+            iord[*nrmax] = isucc;
+            (*nrmax)--;
+        }
+    }
+    jupbn = last;
+    if (last > (limit / 2 + 2)) jupbn = limit + 3 - last;
+    errmin = elist[last];
+    jbnd = jupbn - 1;
+    ibeg = *nrmax + 1;
+    if (ibeg <= jbnd) {
+        for (i = ibeg; i <= jbnd; i++) {
+            isucc = iord[i];
+            if (errmax >= elist[isucc]) goto L60;
+            iord[i - 1] = isucc;
+        }
+    }
+    iord[jbnd] = *maxerr;
+    iord[jupbn] = last;
+    goto L90;
+L60:
+    iord[i - 1] = *maxerr;
+    k = jbnd;
+    for (j = i; j <= jbnd; j++) {
+        isucc = iord[k];
+        if (errmin < elist[isucc]) {
+            iord[k + 1] = last;
+            goto L90;
+        }
+        iord[k + 1] = isucc;
+        k--;
+    }
+    iord[i] = last;
+L90:
+    *maxerr = iord[*nrmax];
+    *ermax = elist[*maxerr];
+}
+
+/* epstab is 1-based [1..52], res3la 1-based [1..3] */
+static void dqelg(int *n, double *epstab, double *result, double *abserr, double *res3la, int *nres)
+{
+    const double epmach = DBL_EPSILON, oflow = DBL_MAX;
+    int i, ib, ib2, ie, indx, k1, k2, k3, limexp, newelm, num;
+    double delta1, delta2, delta3, epsinf, error, err1, err2, err3, e0, e1, e1abs, e2, e3, res, ss, tol1, tol2, tol3;
+    (*nres)++;
+    *abserr = oflow;
+    *result = epstab[*n];
+    if (*n < 3) goto L100;
+    limexp = 50;
+    epstab[*n + 2] = epstab[*n];
+    newelm = (*n - 1) / 2;
+    epstab[*n] = oflow;
+    num = *n;
+    k1 = *n;
+    for (i = 1; i <= newelm; i++) {
+        k2 = k1 - 1;
+        k3 = k1 - 2;
+        res = epstab[k1 + 2];
+        e0 = epstab[k3];
+        e1 = epstab[k2];
+        e2 = res;
+        e1abs = fabs(e1);
+        delta2 = e2 - e1;
+        err2 = fabs(delta2);
+        tol2 = fmax(fabs(e2), e1abs) * epmach;
+        delta3 = e1 - e0;
+        err3 = fabs(delta3);
+        tol3 = fmax(e1abs, fabs(e0)) * epmach;
+        if (!(err2 > tol2 || err3 > tol3)) {
+            *result = res;
+            *abserr = err2 + err3;
+            *abserr = fmax(*abserr, 5. * epmach * fabs(*result));
+            goto L100;
+        }
+        e3 = epstab[k1];
+        epstab[k1] = e1;
+        delta1 = e1 - e3;
+        err1 = fabs(delta1);
+        tol1 = fmax(e1abs, fabs(e3)) * epmach;
+        if (err1 <= tol1 || err2 <= tol2 || err3 <= tol3) {
+            *n = i + i - 1;
+            break;
+        }
+        ss = 1. / delta1 + 1. / delta2 - 1. / delta3;
+        epsinf = fabs(ss * e1);
+        if (!(epsinf > 1e-4)) {
+            *n = i + i - 1;
+            break;
+        }
+        res = e1 + 1. / ss;
+        epstab[k1] = res;
+        k1 -= 2;
+        error = err2 + fabs(res - e2) + err3;
+        if (error > *abserr) continue;
+        *abserr = error;
+        *result = res;
+    }
+    if (*n == limexp) *n = 2 * (limexp / 2) - 1;
+    ib = 1;
+    if ((num / 2) * 2 == num) ib = 2;
+    ie = newelm + 1;
+    for (i = 1; i <= ie; i++) {
+        ib2 = ib + 2;
+        epstab[ib] = epstab[ib2];
+        ib = ib2;
+    }
+    if (num != *n) {
+        indx = num - *n + 1;
+        for (i = 1; i <= *n; i++) {
+            epstab[i] = epstab[indx];
+            indx++;
+        }
+    }
+    if (*nres < 4) {
+        res3la[*nres] = *result;
+        *abserr = oflow;
+        goto L100;
+    }
+    *abserr = fabs(*result - res3la[3]) + fabs(*result - res3la[2]) + fabs(*result - res3la[1]);
+    res3la[1] = res3la[2];
+    res3la[2] = res3la[3];
+    res3la[3] = *result;
+L100:
+    *abserr = fmax(*abserr, 5. * epmach * fabs(*result));
+}
+
+#define QLIMIT 50
+/* DQAGSE when npts == 0, DQAGPE when npts == 1 (one interior break point), as scipy.integrate.quad
+ * dispatches (points=None -> _qagse ; points=[p] -> _qagpe).  limit = 50, epsabs = 1.49e-8. */
+int orc_quad(integrand_t f, void *p, double a, double b, int npts, double point, double epsabs,
+             double epsrel, double *result_out, double *abserr_out, int *neval_out, int *last_out)
+{
+    const double epmach = DBL_EPSILON, uflow = DBL_MIN, oflow = DBL_MAX;
+    const int limit = QLIMIT;
+    double alist[QLIMIT + 2], blist[QLIMIT + 2], rlist[QLIMIT + 2], elist[QLIMIT + 2];
+    int iord[QLIMIT + 2], level[QLIMIT + 2], ndin[4];
+    double rlist2[53], res3la[4];
+    double abseps = 0, area, area1, area12, area2, a1, a2, b1, b2, correc = 0, defabs, defab1, defab2, dres,
+           erlarg = 0, erlast, errbnd, errmax, error1, error2, erro12, errsum, ertest = 0, resabs, reseps = 0, result,
+           abserr, small = 0, resa;
+    int ier = 0, ierro = 0, iroff1 = 0, iroff2 = 0, iroff3 = 0, k, ksgn, ktmin = 0, last, maxerr, neval = 0,
+        nres = 0, nrmax, numrl2, extrap = 0, noext = 0, levmax = 1, levcur = 0, id, jupbnd;
+    double sign = 1.;
+    int qagp = (npts > 0);
+    int npts2 = npts + 2, nint = npts + 1;
+    result = 0.; abserr = 0.;
+    if (qagp) {
+        double pts[3];
+        if (a > b) sign = -1.;
+        pts[0] = fmin(a, b); pts[1] = point; pts[2] = fmax(a, b);
+        resabs = 0.;
+        a1 = pts[0];
+        for (int i = 1; i <= nint; i++) {
+            b1 = pts[i];
+            dqk21(f, p, a1, b1, &area1, &error1, &defabs, &resa);
+            abserr += error1;
+            result += area1;
+            ndin[i] = 0;
+            if (error1 == resa && error1 != 0.) ndin[i] = 1;
+            resabs += defabs;
+            level[i] = 0;
+            elist[i] = error1;
+            alist[i] = a1;
+            blist[i] = b1;
+            rlist[i] = area1;
+            iord[i] = i;
+            a1 = b1;
+        }
+        errsum = 0.;
+        for (int i = 1; i <= nint; i++) {
+            if (ndin[i] == 1) elist[i] = abserr;
+            errsum += elist[i];
+        }
+        last = nint;
+        neval = 21 * nint;
+        dres = fabs(result);
+        errbnd = fmax(epsabs, epsrel * dres);
+        if (abserr <= 100. * epmach * resabs && abserr > errbnd) ier = 2;
+        if (nint != 1) {
+            for (int i = 1; i <= npts; i++) {
+                int jlow = i + 1, ind1 = iord[i], ind2, kk = i;
+                for (int j = jlow; j <= nint; j++) {
+                    ind2 = iord[j];
+                    if (elist[ind1] > elist[ind2]) continue;
+                    ind1 = ind2;
+                    kk = j;
+                }
+                if (ind1 != iord[i]) {
+                    iord[kk] = iord[i];
+                    iord[i] = ind1;
+                }
+            }
+            if (limit < npts2) ier = 1;
+        }
+        if (ier != 0 || abserr <= errbnd) goto L210;
+        rlist2[1] = result;
+        maxerr = iord[1];
+        errmax = elist[maxerr];
+        area = result;
+        nrmax = 1;
+        nres = 0;
+        numrl2 = 1;
+        ktmin = 0;
+        extrap = 0;
+        noext = 0;
+        erlarg = errsum;
+        ertest = errbnd;
+        levmax = 1;
+        abserr = oflow;
+        ksgn = -1;
+        if (dres >= (1. - 50. * epmach) * resabs) ksgn = 1;
+        last = npts2;
+    } else {
+        alist[1] = a; blist[1] = b; rlist[1] = 0.; elist[1] = 0.;
+        dqk21(f, p, a, b, &result, &abserr, &defabs, &resabs);
+        dres = fabs(result);
+        errbnd = fmax(epsabs, epsrel * dres);
+        last = 1;
+        rlist[1] = result;
+        elist[1] = abserr;
+        iord[1] = 1;
+        if (abserr <= 100. * epmach * defabs && abserr > errbnd) ier = 2;
+        if (limit == 1) ier = 1;
+        if (ier != 0 || (abserr <= errbnd && abserr != resabs) || abserr == 0.) goto L140;
+        rlist2[1] = result;
+        errmax = abserr;
+        maxerr = 1;
+        area = result;
+        errsum = abserr;
+        abserr = oflow;
+        nrmax = 1;
+        nres = 0;
+        numrl2 = 2;
+        ktmin = 0;
+        extrap = 0;
+        noext = 0;
+        ksgn = -1;
+        if (dres >= (1. - 50. * epmach) * defabs) ksgn = 1;
+        resabs = defabs; /* used in the divergence test below (qagse tests against defabs) */
+        last = 2;
+    }
+    /* main loop */
+    for (; last <= limit; last++) {
+        if (qagp) levcur = level[maxerr] + 1;
+        a1 = alist[maxerr];
+        b1 = 0.5 * (alist[maxerr] + blist[maxerr]);
+        a2 = b1;
+        b2 = blist[maxerr];
+        erlast = errmax;
+        dqk21(f, p, a1, b1, &area1, &error1, &resa, &defab1);
+        dqk21(f, p, a2, b2, &area2, &error2, &resa, &defab2);
+        neval += 42;
+        area12 = area1 + area2;
+        erro12 = error1 + error2;
+        errsum = errsum + erro12 - errmax;
+        area = area + area12 - rlist[maxerr];
+        if (defab1 != error1 && defab2 != error2) {
+            if (fabs(rlist[maxerr] - area12) <= 1e-5 * fabs(area12) && erro12 >= 0.99 * errmax) {
+                if (extrap) iroff2++;
+                else iroff1++;
+            }
+            if (last > 10 && erro12 > errmax) iroff3++;
+        }
+        if (qagp) {
+            level[maxerr] = levcur;
+            level[last] = levcur;
+        }
+        rlist[maxerr] = area1;
+        rlist[last] = area2;
+        errbnd = fmax(epsabs, epsrel * fabs(area));
+        if (iroff1 + iroff2 >= 10 || iroff3 >= 20) ier = 2;
+        if (iroff2 >= 5) ierro = 3;
+        if (last == limit) ier = 1;
+        if (fmax(fabs(a1), fabs(b2)) <= (1. + 100. * epmach) * (fabs(a2) + 1000. * uflow)) ier = 4;
+        if (error2 > error1) {
+            alist[maxerr] = a2;
+            alist[last] = a1;
+            blist[last] = b1;
+            rlist[maxerr] = area2;
+            rlist[last] = area1;
+            elist[maxerr] = error2;
+            elist[last] = error1;
+        } else {
+            alist[last] = a2;
+            blist[maxerr] = b1;
+            blist[last] = b2;
+            elist[maxerr] = error1;
+            elist[last] = error2;
+        }
+        dqpsrt(limit, last, &maxerr, &errmax, elist, iord, &nrmax);
+        if (errsum <= errbnd) goto L190;
+        if (ier != 0) goto L170;
+        if (!qagp && last == 2) {
+            small = fabs(b - a) * 0.375;
+            erlarg = errsum;
+            ertest = errbnd;
+            rlist2[2] = area;
+            continue;
+        }
+        if (noext) continue;
+        erlarg -= erlast;
+        if (qagp) {
+            if (levcur + 1 <= levmax) erlarg += erro12;
+        } else {
+            if (fabs(b1 - a1) > small) erlarg += erro12;
+        }
+        if (!extrap) {
+            if (qagp) {
+                if (level[maxerr] + 1 <= levmax) continue;
+            } else {
+                if (fabs(blist[maxerr] - alist[maxerr]) > small) continue;
+            }
+            extrap = 1;
+            nrmax = 2;
+        }
+        if (!(ierro == 3 || erlarg <= ertest)) {
+            id = nrmax;
+            jupbnd = last;
+            if (last > (2 + limit / 2)) jupbnd = limit + 3 - last;
+            int cont = 0;
+            for (k = id; k <= jupbnd; k++) {
+                maxerr = iord[nrmax];
+                errmax = elist[maxerr];
+                if (qagp) {
+                    if (level[maxerr] + 1 <= levmax) { cont = 1; break; }
+                } else {
+                    if (fabs(blist[maxerr] - alist[maxerr]) > small) { cont = 1; break; }
+                }
+                nrmax++;
+            }
+            if (cont) continue;
+        }
+        /* perform extrapolation */
+        numrl2++;
+        rlist2[numrl2] = area;
+        if (qagp && numrl2 <= 2) goto L155;
+        dqelg(&numrl2, rlist2, &reseps, &abseps, res3la, &nres);
+        ktmin++;
+        if (ktmin > 5 && abserr < 1e-3 * errsum) ier = 5;
+        if (abseps < abserr) {
+            ktmin = 0;
+            abserr = abseps;
+            result = reseps;
+            correc = erlarg;
+            ertest = fmax(epsabs, epsrel * fabs(reseps));
+            if (qagp) { if (abserr < ertest) goto L170; }
+            else      { if (abserr <= ertest) goto L170; }
+        }
+        if (numrl2 == 1) noext = 1;
+        if (qagp) { if (ier >= 5) goto L170; }
+        else      { if (ier == 5) goto L170; }
+    L155:
+        maxerr = iord[1];
+        errmax = elist[maxerr];
+        nrmax = 1;
+        extrap = 0;
+        if (qagp) levmax++;
+        else small *= 0.5;
+        erlarg = errsum;
+    }
+    last = limit; /* loop fell through (Fortran DO leaves last = limit + 1; results use 1..limit) */
+L170:
+    if (last > limit) last = limit;
+    if (abserr == oflow) goto L190;
+    if (ier + ierro != 0) {
+        if (ierro == 3) abserr += correc;
+        if (ier == 0) ier = 3;
+        if (result != 0. && area != 0.) {
+            if (abserr / fabs(result) > errsum / fabs(area)) goto L190;
+        } else {
+            if (abserr > errsum) goto L190;
+            if (area == 0.) goto L210;
+        }
+    }
+    /* test on divergence */
+    if (ksgn == -1 && fmax(fabs(result), fabs(area)) <= resabs * 0.01) goto L210;
+    if (0.01 > (result / area) || (result / area) > 100. || errsum > fabs(area)) ier = 6;
+    goto L210;
+L190:
+    if (last > limit) last = limit;
+    result = 0.;
+    for (k = 1; k <= last; k++) result += rlist[k];
+    abserr = errsum;
+L210:
+    if (ier > 2) ier--;
+    if (qagp) result *= sign;
+    else neval = 42 * last - 21;
+    goto L999;
+L140:
+    neval = 42 * last - 21;
+L999:
+    *result_out = result;
+    if (abserr_out) *abserr_out = abserr;
+    if (neval_out) *neval_out = neval;
+    if (last_out) *last_out = last;
+    return ier;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * attenuation along the path (:933-1089, Python branch, non-"optimized" models), reflection = 0
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double C0, f; const ice_t *m; int model; long nev; } att_t;
+
+static double att_integrand(double t, void *p) /* dt() :986-988 with ds() :513-517 */
+{
+    att_t *a = (att_t *)p;
+    a->nev++;
+    double z = get_z_unmirrored(t, a->C0, a->m);
+    double yd = get_y_diff(t, a->C0, a->m);
+    double ds = sqrt(yd * yd + 1);
+    return ds / orc_attenuation_length(z, a->f, a->model);
+}
+
+/* x1, x2: 2-D points; freqs: the sparse frequency vector (already chosen); att: exp(-integral) */
+void orc_attenuation_2d(const double x1[2], const double x2[2], double C0, const double ice[3], int model,
+                        int n_freq, const double *freqs, double *att, int *neval)
+{
+    ice_t m = { ice[0], ice[1], ice[2] };
+    double x2m = get_z_mirrored(x1, x2, C0, &m);
+    double g, z_turn;
+    get_turning_point(m.n_ice * m.n_ice - pow(C0, -2.), &m, &g, &z_turn);
+    int npts = (x1[1] < z_turn && z_turn < x2m) ? 1 : 0;
+    for (int i = 0; i < n_freq; i++) {
+        att_t a = { C0, freqs[i], &m, model, 0 };
+        double res, err;
+        int ne, la;
+        orc_quad(att_integrand, &a, x1[1], x2m, npts, z_turn, 1.49e-8, 1e-2, &res, &err, &ne, &la);
+        att[i] = exp(-1 * res);
+        if (neval) neval[i] = ne;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * 3-D wrapper (class ray_tracing, :2057-2090, :2118-2130, :2560-2624, :2650-2742)
+ * Fixed stride MAXS = 2 solutions per pair (2 + 4*n_reflections with n_reflections = 0).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double X1[3], X2[3], R[9], x1[2], x2[2]; int swap; } geom_t;
+
+static void set_start_and_end_point(const double x1[3], const double x2[3], geom_t *g)
+{
+    g->swap = 0;
+    memcpy(g->X1, x1, 24);
+    memcpy(g->X2, x2, 24);
+    if (g->X2[2] < g->X1[2]) {
+        g->swap = 1;
+        memcpy(g->X2, x1, 24);
+        memcpy(g->X1, x2, 24);
+    }
+    double dX[3] = { g->X2[0] - g->X1[0], g->X2[1] - g->X1[1], g->X2[2] - g->X1[2] };
+    double dPhi = -atan2(dX[1], dX[0]);
+    double c = cos(dPhi), s = sin(dPhi);
+    double R[9] = { c, -s, 0, s, c, 0, 0, 0, 1 };
+    memcpy(g->R, R, sizeof R);
+    double X2r[3];
+    for (int i = 0; i < 3; i++) X2r[i] = R[3 * i] * dX[0] + R[3 * i + 1] * dX[1] + R[3 * i + 2] * dX[2] + g->X1[i];
+    g->x1[0] = g->X1[0]; g->x1[1] = g->X1[2];
+    g->x2[0] = X2r[0];   g->x2[1] = X2r[2];
+}
+
+static void rotate_back(const geom_t *g, const double v2d[3], double out[3]) /* np.dot(R.T, v) */
+{
+    for (int i = 0; i < 3; i++) out[i] = g->R[i] * v2d[0] + g->R[3 + i] * v2d[1] + g->R[6 + i] * v2d[2];
+}
+
+#define MAXS 2
+
+/* batch over pairs; arrays are [n][MAXS](...) with NaN / 0 padding like the reference's HDF5 tables */
+void orc_raytrace_batch(long n, const double *x1, const double *x2, const double ice[3],
+                        int *n_sol, int *type, double *C0, double *C1, double *D, double *T,
+                        double *launch, double *receive, double *refl_angle, double *hybr_x)
+{
+    ice_t m = { ice[0], ice[1], ice[2] };
+    for (long i = 0; i < n; i++) {
+        geom_t g;
+        set_start_and_end_point(x1 + 3 * i, x2 + 3 * i, &g);
+        double c0[3], c1[3], hx, hf;
+        int ty[3];
+        int ns = orc_find_solutions_2d(g.x1, g.x2, ice, c0, c1, ty, &hx, &hf, NULL);
+        if (hybr_x) hybr_x[i] = hx;
+        if (ns > MAXS) ns = 0; /* :2127-2130 */
+        n_sol[i] = ns;
+        for (int s = 0; s < MAXS; s++) {
+            long k = i * MAXS + s;
+            type[k] = 0;
+            C0[k] = C1[k] = D[k] = T[k] = refl_angle[k] = NAN;
+            for (int d = 0; d < 3; d++) launch[3 * k + d] = receive[3 * k + d] = NAN;
+            if (s >= ns) continue;
+            type[k] = ty[s];
+            C0[k] = c0[s];
+            C1[k] = c1[s];
+            path_length_and_time(g.x1, g.x2, c0[s], &m, &D[k], &T[k]);
+            double la = get_launch_angle(g.x1, c0[s], &m), ra = get_receive_angle(g.x1, g.x2, c0[s], &m);
+            double lv[3] = { sin(la), 0, cos(la) }, rv[3] = { -sin(ra), 0, cos(ra) };
+            if (g.swap) {
+                lv[0] = -sin(ra); lv[2] = cos(ra);
+                rv[0] = sin(la);  rv[2] = cos(la);
+            }
+            rotate_back(&g, lv, launch + 3 * k);
+            rotate_back(&g, rv, receive + 3 * k);
+            refl_angle[k] = get_reflection_angle(g.x1, g.x2, c0[s], &m);
+        }
+    }
+}
+
+/* attenuation for a batch of rays given 3-D end points and C0 (get_attenuation :2744) */
+void orc_attenuation_batch(long n, const double *x1, const double *x2, const double *C0, const double ice[3],
+                           int model, int n_freq, const double *freqs, double *att, int *neval)
+{
+    for (long i = 0; i < n; i++) {
+        geom_t g;
+        set_start_and_end_point(x1 + 3 * i, x2 + 3 * i, &g);
+        if (isnan(C0[i])) {
+            for (int k = 0; k < n_freq; k++) att[i * n_freq + k] = NAN;
+            continue;
+        }
+        orc_attenuation_2d(g.x1, g.x2, C0[i], ice, model, n_freq, freqs, att + i * n_freq,
+                           neval ? neval + i * n_freq : NULL);
+    }
+}
+
+/* test hooks */
+double orc_delta_y(double logC0, const double x1[2], const double x2[2], const double ice[3])
+{
+    ice_t m = { ice[0], ice[1], ice[2] };
+    return get_delta_y(C0_from_log(logC0, &m), x1, x2, &m);
+}
