@@ -1,0 +1,6 @@
+"""nuradiomc_amd -- MI355X-native hot path for NuRadioMC-style simulations (ray tracing ->
+Askaryan emission -> antenna/amplifier response), host side in Python over the libnrhip.so C ABI."""
+from .context import Context, ATTENUATION_MODEL_TO_INT  # noqa: F401
+from ._lib import NrhipError, LIB_PATH  # noqa: F401
+
+__version__ = "0.1.0"

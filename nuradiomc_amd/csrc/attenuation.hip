@@ -1,0 +1,617 @@
+// attenuation.hip -- exp(-int_path ds / L_att(z, f)) per (ray, coarse frequency) on MI355X (gfx950).
+//
+// One LANE per (ray, frequency) item, item = ray * n_freq + i_freq, so the 25..37 frequencies of one
+// ray sit in adjacent lanes: they share the ray geometry (same loads, broadcast from L1) and mostly
+// the same control flow.  Each lane runs the adaptive Gauss-Kronrod (21-point) quadrature with the
+// same subdivision / epsilon-extrapolation decisions as QUADPACK's QAGS (no break point) or QAGP (one
+// break point at the turning depth) at epsabs 1.49e-8, epsrel 1e-2, limit 50 -- what
+// scipy.integrate.quad does at analyticraytracing.py:1067-1072 -- because with epsrel = 1e-2 the
+// reference's result is NOT the converged integral (it can be off by 1e-3), and parity at 1e-6 needs
+// the same estimate, not a better one.  About 40 % of the items bisect at least once.
+//
+// FP64 VALU bound: 21..462 integrand evaluations (2 exp, 2 sqrt, 3 div each) per item against 8 B
+// written; the per-lane interval lists (2.2 KB) live in scratch.
+#include "ray_device.h"
+#include "nrhip_internal.h"
+
+namespace nrhip {
+
+// attenuation length L(z, f) [m]; model ids as NuRadioMC/utilities/attenuation.py:14
+struct AttLane {
+    int model;
+    double f;   // frequency [GHz]
+    double w;   // ln f  (SP1)
+};
+
+__device__ inline double attenuation_length(double z, const AttLane& a)
+{
+    double L;
+    if (a.model == 1) {  // SP1 (attenuation.py:130-142, :168-192)
+        double z2 = fabs(z);
+        double t = 1.83415e-09 * (z2 * z2 * z2) + (-1.59061e-08 * (z2 * z2)) + 0.00267687 * z2 + (-51.0696);
+        const double w0 = -9.210340371976182;  // ln 1e-4
+        const double w2 = 1.1505720275988207;  // ln 3.16
+        double b0 = -6.74890 + t * (0.026709 - t * 0.000884);
+        double b1 = -6.22121 - t * (0.070927 + t * 0.001773);
+        double b2 = -4.09468 - t * (0.002213 + t * 0.000332);
+        double aa, bb;
+        if (a.f < 1.) {
+            aa = (b1 * w0 - b0 * 0.0) / (w0 - 0.0);
+            bb = (b1 - b0) / (0.0 - w0);
+        } else {
+            aa = (b2 * 0.0 - b1 * w2) / (0.0 - w2);
+            bb = (b2 - b1) / (w2 - 0.0);
+        }
+        L = 1. / exp(aa + bb * a.w);
+    } else if (a.model == 2) {  // GL1 (attenuation.py:99-128, :194-196), 75 MHz length clamped at 100 m
+        const double fit[6] = {1.16052586e+03, 6.87257150e-02, -9.82378264e-05,
+                               -3.50628312e-07, -2.21040482e-10, -3.63912864e-14};
+        double att = 0, zp = 1;
+        for (int p = 0; p < 6; p++) { att += fit[p] * zp; zp *= z; }
+        if (att < 100.) att = 100.;
+        L = att - 0.55 * (a.f / 1e-3 - 75);
+    } else if (a.model == 4) {  // GL2 (:198-204)
+        const double fit[6] = {1.20547286e+00, 1.58815679e-05, -2.58901767e-07,
+                               -5.16435542e-10, -2.89124473e-13, -4.58987344e-17};
+        double bulk = 852.0 + (-0.54 / 1e-3) * a.f;
+        double poly = 0;
+        for (int p = 5; p >= 0; p--) poly = poly * z + fit[p];
+        L = bulk * poly;
+    } else {  // MB1 (:224-244)
+        const double R = 0.82, d_ice = 576.;
+        L = 460. - 180. * a.f;
+        L *= 1. / (1 + L / (2 * d_ice) * log(R));
+        double d = -z * 420. / d_ice;
+        double LL = (1250. * 0.08886 * exp(-0.048827 * (225.6746 - 86.517596 * log10(848.870 - (d)))));
+        L *= LL / 231.21;
+    }
+    if (L < 1.) L = 1.;
+    if (z > 0) L = INFINITY;
+    return L;
+}
+
+struct AttItem {
+    double C0, z_turn;
+    AttLane lane;
+};
+
+// dt(t) = ds(t) / L(z(t), f)  (analyticraytracing.py:986-988, :513-517)
+__device__ inline double integrand(double t, const AttItem& it, const IceConst& m)
+{
+    double z = (t > it.z_turn) ? 2 * it.z_turn - t : t;
+    double nz = n_of_z(z, m);
+    double q = (it.C0 * it.C0) * (nz * nz);
+    double yd = (q > 1) ? 1 / sqrt(q - 1) : INFINITY;
+    double ds = sqrt(yd * yd + 1);
+    return ds / attenuation_length(z, it.lane);
+}
+
+struct GK { double result, abserr, resabs, resasc; };
+
+// 21-point Gauss-Kronrod rule, accumulation order of QUADPACK's DQK21
+__device__ inline GK gk21(double a, double b, const AttItem& it, const IceConst& m)
+{
+    const double XGK[11] = {
+        0.995657163025808080735527280689003, 0.973906528517171720077964012084452,
+        0.930157491355708226001207180059508, 0.865063366688984510732096688423493,
+        0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
+        0.562757134668604683339000099272694, 0.433395394129247190799265943165784,
+        0.294392862701460198131126603103866, 0.148874338981631210884826001129720, 0.};
+    const double WGK[11] = {
+        0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
+        0.054755896574351996031381300244580, 0.075039674810919952767043140916190,
+        0.093125454583697605535065465083366, 0.109387158802297641899210590325805,
+        0.123491976262065851077958109585166, 0.134709217311473325928054001771707,
+        0.142775938577060080797094273138717, 0.147739104901338491374841515972068,
+        0.149445554002916905664936468389821};
+    const double WG[5] = {
+        0.066671344308688137593568809893332, 0.149451349150580593145776339657697,
+        0.219086362515982043995534934228163, 0.269266719309996355091226921569469,
+        0.295524224714752870173815619188769};
+    const double epmach = 2.220446049250313e-16, uflow = 2.2250738585072014e-308;
+    double fv1[10], fv2[10];
+    double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
+    double resg = 0.;
+    double fc = integrand(centr, it, m);
+    double resk = WGK[10] * fc;
+    double resabs = fabs(resk);
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int jtw = 2 * j + 1;
+        double absc = hlgth * XGK[jtw];
+        double f1 = integrand(centr - absc, it, m), f2 = integrand(centr + absc, it, m);
+        fv1[jtw] = f1; fv2[jtw] = f2;
+        double fsum = f1 + f2;
+        resg += WG[j] * fsum;
+        resk += WGK[jtw] * fsum;
+        resabs += WGK[jtw] * (fabs(f1) + fabs(f2));
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int jtwm1 = 2 * j;
+        double absc = hlgth * XGK[jtwm1];
+        double f1 = integrand(centr - absc, it, m), f2 = integrand(centr + absc, it, m);
+        fv1[jtwm1] = f1; fv2[jtwm1] = f2;
+        double fsum = f1 + f2;
+        resk += WGK[jtwm1] * fsum;
+        resabs += WGK[jtwm1] * (fabs(f1) + fabs(f2));
+    }
+    double reskh = resk * 0.5;
+    double resasc = WGK[10] * fabs(fc - reskh);
+#pragma unroll
+    for (int j = 0; j < 10; j++) resasc += WGK[j] * (fabs(fv1[j] - reskh) + fabs(fv2[j] - reskh));
+    GK o;
+    o.result = resk * hlgth;
+    o.resabs = resabs * dhlgth;
+    o.resasc = resasc * dhlgth;
+    o.abserr = fabs((resk - resg) * hlgth);
+    if (o.resasc != 0. && o.abserr != 0.) {
+        double r = 200. * o.abserr / o.resasc;
+        o.abserr = o.resasc * fmin(1., r * sqrt(r));  // r ** 1.5
+    }
+    if (o.resabs > uflow / (50. * epmach)) o.abserr = fmax((epmach * 50.) * o.resabs, o.abserr);
+    return o;
+}
+
+#define QLIM 50
+
+// keep the error list ordered (QUADPACK DQPSRT); 1-based indices
+__device__ inline void sort_errors(int last, int& maxerr, double& ermax, const double* elist, int* iord, int& nrmax)
+{
+    const int limit = QLIM;
+    if (last <= 2) {
+        iord[1] = 1;
+        iord[2] = 2;
+    } else {
+        double errmax = elist[maxerr];
+        if (nrmax != 1) {
+            int ido = nrmax - 1;
+            for (int i = 1; i <= ido; i++) {
+                int isucc = iord[nrmax - 1];
+                if (errmax <= elist[isucc]) break;
+                iord[nrmax] = isucc;
+                nrmax--;
+            }
+        }
+        int jupbn = last;
+        if (last > (limit / 2 + 2)) jupbn = limit + 3 - last;
+        double errmin = elist[last];
+        int jbnd = jupbn - 1;
+        int ibeg = nrmax + 1;
+        int i = ibeg;
+        bool found = false;
+        for (; i <= jbnd; i++) {
+            int isucc = iord[i];
+            if (errmax >= elist[isucc]) { found = true; break; }
+            iord[i - 1] = isucc;
+        }
+        if (!found) {
+            iord[jbnd] = maxerr;
+            iord[jupbn] = last;
+        } else {
+            iord[i - 1] = maxerr;
+            int k = jbnd;
+            bool placed = false;
+            for (int j = i; j <= jbnd; j++) {
+                int isucc = iord[k];
+                if (errmin < elist[isucc]) {
+                    iord[k + 1] = last;
+                    placed = true;
+                    break;
+                }
+                iord[k + 1] = isucc;
+                k--;
+            }
+            if (!placed) iord[i] = last;
+        }
+    }
+    maxerr = iord[nrmax];
+    ermax = elist[maxerr];
+}
+
+// Wynn epsilon algorithm (QUADPACK DQELG); epstab 1-based [1..52], res3la 1-based
+__device__ inline void epsilon_extrap(int& n, double* epstab, double& result, double& abserr, double* res3la, int& nres)
+{
+    const double epmach = 2.220446049250313e-16, oflow = 1.7976931348623157e+308;
+    nres++;
+    abserr = oflow;
+    result = epstab[n];
+    if (n >= 3) {
+        const int limexp = 50;
+        epstab[n + 2] = epstab[n];
+        int newelm = (n - 1) / 2;
+        epstab[n] = oflow;
+        int num = n, k1 = n;
+        bool early = false;
+        for (int i = 1; i <= newelm; i++) {
+            int k2 = k1 - 1, k3 = k1 - 2;
+            double res = epstab[k1 + 2];
+            double e0 = epstab[k3], e1 = epstab[k2], e2 = res;
+            double e1abs = fabs(e1);
+            double delta2 = e2 - e1, err2 = fabs(delta2), tol2 = fmax(fabs(e2), e1abs) * epmach;
+            double delta3 = e1 - e0, err3 = fabs(delta3), tol3 = fmax(e1abs, fabs(e0)) * epmach;
+            if (!(err2 > tol2 || err3 > tol3)) {  // converged to machine accuracy
+                result = res;
+                abserr = fmax(err2 + err3, 5. * epmach * fabs(result));
+                early = true;
+                break;
+            }
+            double e3 = epstab[k1];
+            epstab[k1] = e1;
+            double delta1 = e1 - e3, err1 = fabs(delta1), tol1 = fmax(e1abs, fabs(e3)) * epmach;
+            if (err1 <= tol1 || err2 <= tol2 || err3 <= tol3) { n = i + i - 1; break; }
+            double ss = 1. / delta1 + 1. / delta2 - 1. / delta3;
+            double epsinf = fabs(ss * e1);
+            if (!(epsinf > 1e-4)) { n = i + i - 1; break; }
+            res = e1 + 1. / ss;
+            epstab[k1] = res;
+            k1 -= 2;
+            double error = err2 + fabs(res - e2) + err3;
+            if (error > abserr) continue;
+            abserr = error;
+            result = res;
+        }
+        if (early) return;  // (abserr already floored)
+        if (n == limexp) n = 2 * (limexp / 2) - 1;
+        int ib = ((num / 2) * 2 == num) ? 2 : 1;
+        int ie = newelm + 1;
+        for (int i = 1; i <= ie; i++) {
+            epstab[ib] = epstab[ib + 2];
+            ib += 2;
+        }
+        if (num != n) {
+            int indx = num - n + 1;
+            for (int i = 1; i <= n; i++) epstab[i] = epstab[indx++];
+        }
+        if (nres < 4) {
+            res3la[nres] = result;
+            abserr = oflow;
+        } else {
+            abserr = fabs(result - res3la[3]) + fabs(result - res3la[2]) + fabs(result - res3la[1]);
+            res3la[1] = res3la[2];
+            res3la[2] = res3la[3];
+            res3la[3] = result;
+        }
+    }
+    abserr = fmax(abserr, 5. * epmach * fabs(result));
+}
+
+// adaptive integration over [a, b] with optional interior break point; returns the integral estimate
+__device__ inline double quad_gk21(double a, double b, bool with_point, double point, const AttItem& it,
+                                   const IceConst& m, int* neval_out)
+{
+    const double epmach = 2.220446049250313e-16, uflow = 2.2250738585072014e-308, oflow = 1.7976931348623157e+308;
+    const double epsabs = 1.49e-8, epsrel = 1e-2;
+    const int limit = QLIM;
+    double alist[QLIM + 2], blist[QLIM + 2], rlist[QLIM + 2], elist[QLIM + 2];
+    int iord[QLIM + 2];
+    unsigned char level[QLIM + 2];
+    double rlist2[53], res3la[4];
+    double result = 0., abserr = 0., resabs = 0., errsum = 0., errbnd, errmax, area, dres;
+    double erlarg = 0., ertest = 0., correc = 0., small = 0., reseps = 0., abseps = 0.;
+    int ier = 0, ierro = 0, iroff1 = 0, iroff2 = 0, iroff3 = 0, ksgn, ktmin = 0, last, maxerr, neval = 0, nres = 0,
+        nrmax, numrl2, levmax = 1, levcur = 0;
+    bool extrap = false, noext = false;
+    double sign = 1.;
+    const bool qagp = with_point;
+    bool finished = false;  // true -> result/abserr final (label 210 / 140 of the Fortran)
+    if (qagp) {
+        if (a > b) sign = -1.;
+        double pts[3] = {fmin(a, b), point, fmax(a, b)};
+        bool nd[3] = {false, false, false};
+        double a1 = pts[0];
+        for (int i = 1; i <= 2; i++) {
+            double b1 = pts[i];
+            GK g = gk21(a1, b1, it, m);
+            abserr += g.abserr;
+            result += g.result;
+            nd[i] = (g.abserr == g.resasc && g.abserr != 0.);
+            resabs += g.resabs;
+            level[i] = 0;
+            elist[i] = g.abserr;
+            alist[i] = a1;
+            blist[i] = b1;
+            rlist[i] = g.result;
+            iord[i] = i;
+            a1 = b1;
+        }
+        for (int i = 1; i <= 2; i++) {
+            if (nd[i]) elist[i] = abserr;
+            errsum += elist[i];
+        }
+        last = 2;
+        neval = 42;
+        dres = fabs(result);
+        errbnd = fmax(epsabs, epsrel * dres);
+        if (abserr <= 100. * epmach * resabs && abserr > errbnd) ier = 2;
+        if (!(elist[iord[1]] > elist[iord[2]])) { int t = iord[1]; iord[1] = iord[2]; iord[2] = t; }
+        if (ier != 0 || abserr <= errbnd) finished = true;
+        else {
+            rlist2[1] = result;
+            maxerr = iord[1];
+            errmax = elist[maxerr];
+            area = result;
+            nrmax = 1;
+            numrl2 = 1;
+            erlarg = errsum;
+            ertest = errbnd;
+            abserr = oflow;
+            ksgn = (dres >= (1. - 50. * epmach) * resabs) ? 1 : -1;
+            last = 3;
+        }
+    } else {
+        GK g = gk21(a, b, it, m);
+        result = g.result;
+        abserr = g.abserr;
+        double defabs = g.resabs;
+        dres = fabs(result);
+        errbnd = fmax(epsabs, epsrel * dres);
+        last = 1;
+        alist[1] = a; blist[1] = b; rlist[1] = result; elist[1] = abserr; iord[1] = 1;
+        if (abserr <= 100. * epmach * defabs && abserr > errbnd) ier = 2;
+        if (ier != 0 || (abserr <= errbnd && abserr != g.resasc) || abserr == 0.) {
+            finished = true;
+            neval = 21;
+        } else {
+            rlist2[1] = result;
+            errmax = abserr;
+            maxerr = 1;
+            area = result;
+            errsum = abserr;
+            abserr = oflow;
+            nrmax = 1;
+            numrl2 = 2;
+            ksgn = (dres >= (1. - 50. * epmach) * defabs) ? 1 : -1;
+            resabs = defabs;
+            last = 2;
+        }
+    }
+    if (!finished) {
+        int exit_code = 0;  // 1: sum the list (label 190 / 115); 2: final-result logic (label 170 / 100)
+        for (; last <= limit; last++) {
+            if (qagp) levcur = level[maxerr] + 1;
+            double a1 = alist[maxerr], b1 = 0.5 * (alist[maxerr] + blist[maxerr]);
+            double a2 = b1, b2 = blist[maxerr];
+            double erlast = errmax;
+            GK g1 = gk21(a1, b1, it, m);
+            GK g2 = gk21(a2, b2, it, m);
+            neval += 42;
+            double area12 = g1.result + g2.result;
+            double erro12 = g1.abserr + g2.abserr;
+            errsum = errsum + erro12 - errmax;
+            area = area + area12 - rlist[maxerr];
+            if (g1.resasc != g1.abserr && g2.resasc != g2.abserr) {
+                if (fabs(rlist[maxerr] - area12) <= 1e-5 * fabs(area12) && erro12 >= 0.99 * errmax) {
+                    if (extrap) iroff2++;
+                    else iroff1++;
+                }
+                if (last > 10 && erro12 > errmax) iroff3++;
+            }
+            if (qagp) {
+                level[maxerr] = (unsigned char)levcur;
+                level[last] = (unsigned char)levcur;
+            }
+            rlist[maxerr] = g1.result;
+            rlist[last] = g2.result;
+            errbnd = fmax(epsabs, epsrel * fabs(area));
+            if (iroff1 + iroff2 >= 10 || iroff3 >= 20) ier = 2;
+            if (iroff2 >= 5) ierro = 3;
+            if (last == limit) ier = 1;
+            if (fmax(fabs(a1), fabs(b2)) <= (1. + 100. * epmach) * (fabs(a2) + 1000. * uflow)) ier = 4;
+            if (g2.abserr > g1.abserr) {
+                alist[maxerr] = a2;
+                alist[last] = a1;
+                blist[last] = b1;
+                rlist[maxerr] = g2.result;
+                rlist[last] = g1.result;
+                elist[maxerr] = g2.abserr;
+                elist[last] = g1.abserr;
+            } else {
+                alist[last] = a2;
+                blist[maxerr] = b1;
+                blist[last] = b2;
+                elist[maxerr] = g1.abserr;
+                elist[last] = g2.abserr;
+            }
+            sort_errors(last, maxerr, errmax, elist, iord, nrmax);
+            if (errsum <= errbnd) { exit_code = 1; break; }
+            if (ier != 0) { exit_code = 2; break; }
+            if (!qagp && last == 2) {
+                small = fabs(b - a) * 0.375;
+                erlarg = errsum;
+                ertest = errbnd;
+                rlist2[2] = area;
+                continue;
+            }
+            if (noext) continue;
+            erlarg -= erlast;
+            if (qagp) { if (levcur + 1 <= levmax) erlarg += erro12; }
+            else      { if (fabs(b1 - a1) > small) erlarg += erro12; }
+            if (!extrap) {
+                bool is_smallest = qagp ? !(level[maxerr] + 1 <= levmax)
+                                        : !(fabs(blist[maxerr] - alist[maxerr]) > small);
+                if (!is_smallest) continue;
+                extrap = true;
+                nrmax = 2;
+            }
+            if (!(ierro == 3 || erlarg <= ertest)) {
+                int jupbnd = last;
+                if (last > (2 + limit / 2)) jupbnd = limit + 3 - last;
+                bool cont = false;
+                for (int k = nrmax; k <= jupbnd; k++) {
+                    maxerr = iord[nrmax];
+                    errmax = elist[maxerr];
+                    bool big = qagp ? (level[maxerr] + 1 <= levmax) : (fabs(blist[maxerr] - alist[maxerr]) > small);
+                    if (big) { cont = true; break; }
+                    nrmax++;
+                }
+                if (cont) continue;
+            }
+            numrl2++;
+            rlist2[numrl2] = area;
+            bool skip_eps = qagp && numrl2 <= 2;
+            if (!skip_eps) {
+                epsilon_extrap(numrl2, rlist2, reseps, abseps, res3la, nres);
+                ktmin++;
+                if (ktmin > 5 && abserr < 1e-3 * errsum) ier = 5;
+                if (abseps < abserr) {
+                    ktmin = 0;
+                    abserr = abseps;
+                    result = reseps;
+                    correc = erlarg;
+                    ertest = fmax(epsabs, epsrel * fabs(reseps));
+                    if (qagp ? (abserr < ertest) : (abserr <= ertest)) { exit_code = 2; break; }
+                }
+                if (numrl2 == 1) noext = true;
+                if (qagp ? (ier >= 5) : (ier == 5)) { exit_code = 2; break; }
+            }
+            maxerr = iord[1];
+            errmax = elist[maxerr];
+            nrmax = 1;
+            extrap = false;
+            if (qagp) levmax++;
+            else small *= 0.5;
+            erlarg = errsum;
+        }
+        if (last > limit) last = limit;
+        bool sum_list = (exit_code == 1);
+        if (!sum_list) {  // label 170 / 100
+            if (abserr == oflow) sum_list = true;
+            else {
+                bool to_div_test = true;
+                if (ier + ierro != 0) {
+                    if (ierro == 3) abserr += correc;
+                    if (ier == 0) ier = 3;
+                    if (result != 0. && area != 0.) {
+                        if (abserr / fabs(result) > errsum / fabs(area)) { sum_list = true; to_div_test = false; }
+                    } else {
+                        if (abserr > errsum) { sum_list = true; to_div_test = false; }
+                        else if (area == 0.) to_div_test = false;
+                    }
+                }
+                if (to_div_test) {
+                    if (!(ksgn == -1 && fmax(fabs(result), fabs(area)) <= resabs * 0.01)) {
+                        if (0.01 > (result / area) || (result / area) > 100. || errsum > fabs(area)) ier = 6;
+                    }
+                }
+            }
+        }
+        if (sum_list) {
+            result = 0.;
+            for (int k = 1; k <= last; k++) result += rlist[k];
+            abserr = errsum;
+        }
+        if (!qagp) neval = 42 * last - 21;
+    }
+    if (qagp) result *= sign;
+    if (neval_out) *neval_out = neval;
+    return result;
+}
+
+// zint: per ray {z_start, z_stop_mirrored, z_turn}
+__global__ void __launch_bounds__(256)
+attenuation_kernel(long n_rays, const double* __restrict__ C0, const double* __restrict__ zint, int n_freq,
+                   const double* __restrict__ freqs, int model, IceConst m, double* __restrict__ att,
+                   int* __restrict__ neval)
+{
+    long n_items = n_rays * n_freq;
+    for (long item = blockIdx.x * (long)blockDim.x + threadIdx.x; item < n_items;
+         item += (long)gridDim.x * blockDim.x) {
+        long ray = item / n_freq;
+        int jf = (int)(item - ray * n_freq);
+        AttItem it;
+        it.C0 = C0[ray];
+        double z1 = zint[3 * ray], z2m = zint[3 * ray + 1];
+        it.z_turn = zint[3 * ray + 2];
+        it.lane.model = model;
+        it.lane.f = freqs[jf];
+        it.lane.w = log(it.lane.f);
+        if (isnan(it.C0)) {
+            att[item] = NAN;
+            if (neval) neval[item] = 0;
+            continue;
+        }
+        bool with_point = (z1 < it.z_turn && it.z_turn < z2m);
+        int ne;
+        double integral = quad_gk21(z1, z2m, with_point, it.z_turn, it, m, &ne);
+        att[item] = exp(-1 * integral);
+        if (neval) neval[item] = ne;
+    }
+}
+
+// per-ray integration limits from (pair geometry, C0): {z1, get_z_mirrored(...)[1], z_turn}
+__global__ void __launch_bounds__(256)
+ray_limits_kernel(long n_rays, const double* __restrict__ x1, const double* __restrict__ x2,
+                  const double* __restrict__ C0, IceConst m, double* __restrict__ zint)
+{
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n_rays) return;
+    double A[3] = {x1[3 * i], x1[3 * i + 1], x1[3 * i + 2]};
+    double B[3] = {x2[3 * i], x2[3 * i + 1], x2[3 * i + 2]};
+    if (B[2] < A[2]) {
+        for (int d = 0; d < 3; d++) { double t = A[d]; A[d] = B[d]; B[d] = t; }
+    }
+    double dX[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+    double dPhi = -atan2(dX[1], dX[0]);
+    double cph = cos(dPhi), sph = sin(dPhi);
+    Pair2D p;
+    p.y1 = A[0];
+    p.z1 = A[2];
+    p.y2 = (cph * dX[0] + (-sph) * dX[1] + 0 * dX[2]) + A[0];
+    p.z2 = (0 * dX[0] + 0 * dX[1] + 1 * dX[2]) + A[2];
+    p.g1 = gamma_of_z(p.z1, m);
+    p.g2 = gamma_of_z(p.z2, m);
+    double c0 = C0[i];
+    if (isnan(c0)) {
+        zint[3 * i] = zint[3 * i + 1] = zint[3 * i + 2] = NAN;
+        return;
+    }
+    C0State st = make_c0(c0, m);
+    double C1 = C1_of(st, p, m);
+    zint[3 * i] = p.z1;
+    zint[3 * i + 1] = z_mirrored(p.y2, p.z2, st, C1, p);
+    zint[3 * i + 2] = st.z_turn;
+}
+
+__global__ void attenuation_length_kernel(long n, const double* __restrict__ z, const double* __restrict__ f,
+                                          int model, double* __restrict__ L)
+{
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    AttLane a;
+    a.model = model;
+    a.f = f[i];
+    a.w = log(a.f);
+    L[i] = attenuation_length(z[i], a);
+}
+
+void launch_attenuation_length(hipStream_t stream, long n, const double* z, const double* f, int model, double* L)
+{
+    if (n <= 0) return;
+    int block = 256;
+    long grid = (n + block - 1) / block;
+    hipLaunchKernelGGL(attenuation_length_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n, z, f, model, L);
+}
+
+void launch_ray_limits(hipStream_t stream, long n_rays, const double* x1, const double* x2, const double* C0,
+                       const IceConst& m, double* zint)
+{
+    if (n_rays <= 0) return;
+    int block = 256;
+    long grid = (n_rays + block - 1) / block;
+    hipLaunchKernelGGL(ray_limits_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, x1, x2, C0, m, zint);
+}
+
+void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
+                              const double* freqs, int model, const IceConst& m, double* att, int* neval)
+{
+    long n_items = n_rays * n_freq;
+    if (n_items <= 0) return;
+    int block = 256;
+    long grid = (n_items + block - 1) / block;
+    if (grid > 256L * 64) grid = 256L * 64;
+    hipLaunchKernelGGL(attenuation_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, zint, n_freq,
+                       freqs, model, m, att, neval);
+}
+
+}  // namespace nrhip

@@ -1,0 +1,296 @@
+// raytrace.hip -- batched find_solutions + per-solution geometry on MI355X (gfx950).
+//
+// One LANE per (vertex, channel) pair: the reference's solution finder is an inherently serial
+// procedure (a MINPACK hybrid-Powell iteration on (delta y)^2 started at logC0 = -1, followed by two
+// Brent searches either side of where it stopped -- analyticraytracing.py:1477-1547), and WHICH roots
+// are reported depends on where that first iteration stops.  To report the same solutions as the
+// reference the kernel runs the same procedure per pair; 64 independent pairs per wavefront keep all
+// lanes busy, and consecutive lanes are the channels of one event, so branches are mostly coherent.
+// Inputs are read once, coalesced (24 B per lane), outputs are written once ([pair][2] records).
+//
+// The kernel is FP64-VALU / transcendental bound (about 1e2 objective evaluations x ~1e2 flops per
+// pair against ~320 B of HBM traffic), not HBM bound.
+#include "ray_device.h"
+#include "nrhip_internal.h"
+
+namespace nrhip {
+
+// ---- MINPACK HYBRD, n = 1 (scipy.optimize.root(method='hybr', tol=1e-6): factor 100, mode 1, --------
+// ---- maxfev 400, forward-difference Jacobian with eps = sqrt(machine eps), Broyden updates) ---------
+// For one unknown the QR factor of the Jacobian a is Q = -1, R = -a, the dogleg step is the Newton
+// step clipped to the trust radius, and the rank-one update is r += u v.
+template <class F>
+__device__ inline double hybrd1(F&& fcn, double x, double xtol, double* f_out)
+{
+    const double epsmch = 2.220446049250313e-16;
+    const double p1 = .1, p5 = .5, p001 = .001, p0001 = 1e-4;
+    const int maxfev = 400;
+    double fvec = fcn(x);
+    int nfev = 1;
+    double fnorm = fabs(fvec);
+    int iter = 1, ncsuc = 0, ncfail = 0, nslow1 = 0, nslow2 = 0;
+    double diag = 0, delta = 0, xnorm = 0;
+    const double eps = 1.4901161193847656e-08;  // sqrt(epsmch)
+    bool done = false;
+    while (!done) {
+        bool jeval = true;
+        double h = eps * fabs(x);
+        if (h == 0.) h = eps;
+        double a = (fcn(x + h) - fvec) / h;
+        nfev++;
+        double acnorm = fabs(a);
+        bool nz = (a != 0.);
+        if (iter == 1) {
+            diag = nz ? acnorm : 1.;
+            xnorm = fabs(diag * x);
+            delta = 100. * xnorm;
+            if (delta == 0.) delta = 100.;
+        }
+        // Q^T f : Householder reflection with v = 2 maps f -> f + 2 * (-(2 f) / 2) = -f
+        double qtf = fvec;
+        if (nz) qtf += 2. * (-(2. * fvec) / 2.);
+        double r = -a;
+        double q = nz ? -1. : 1.;
+        if (acnorm > diag) diag = acnorm;
+        for (;;) {
+            double temp = r;
+            if (temp == 0.) {
+                temp = epsmch * fabs(r);
+                if (temp == 0.) temp = epsmch;
+            }
+            double xs = qtf / temp;
+            double qnorm = fabs(diag * xs);
+            if (qnorm > delta) {  // clip to the trust region (dogleg, n = 1)
+                double g = r * qtf / diag;
+                double gnorm = fabs(g);
+                double sgnorm = 0., alpha = delta / qnorm, w1 = g;
+                if (gnorm != 0.) {
+                    w1 = (g / gnorm) / diag;
+                    double t = fabs(r * w1);
+                    sgnorm = (gnorm / t) / t;
+                    alpha = 0.;
+                    if (sgnorm < delta) {
+                        double bnorm = fabs(qtf);
+                        double tt = (bnorm / gnorm) * (bnorm / qnorm) * (sgnorm / delta);
+                        double dq = delta / qnorm, sd = sgnorm / delta;
+                        tt = tt - dq * (sd * sd) + sqrt((tt - dq) * (tt - dq) + (1. - dq * dq) * (1. - sd * sd));
+                        alpha = (dq * (1. - sd * sd)) / tt;
+                    }
+                }
+                xs = (1. - alpha) * fmin(sgnorm, delta) * w1 + alpha * xs;
+            }
+            double step = -xs;
+            double xt = x + step;
+            double pnorm = fabs(diag * step);
+            if (iter == 1) delta = fmin(delta, pnorm);
+            double f_new = fcn(xt);
+            nfev++;
+            double fnorm1 = fabs(f_new);
+            double actred = -1.;
+            if (fnorm1 < fnorm) actred = 1. - (fnorm1 / fnorm) * (fnorm1 / fnorm);
+            double w3 = qtf + r * step;
+            double tnorm = fabs(w3);
+            double prered = 0.;
+            if (tnorm < fnorm) prered = 1. - (tnorm / fnorm) * (tnorm / fnorm);
+            double ratio = (prered > 0.) ? actred / prered : 0.;
+            if (ratio < p1) {
+                ncsuc = 0;
+                ncfail++;
+                delta = p5 * delta;
+            } else {
+                ncfail = 0;
+                ncsuc++;
+                if (ratio >= p5 || ncsuc > 1) delta = fmax(delta, pnorm / p5);
+                if (fabs(ratio - 1.) <= p1) delta = pnorm / p5;
+            }
+            if (ratio >= p0001) {
+                x = xt;
+                fvec = f_new;
+                xnorm = fabs(diag * x);
+                fnorm = fnorm1;
+                iter++;
+            }
+            nslow1++;
+            if (actred >= p001) nslow1 = 0;
+            if (jeval) nslow2++;
+            if (actred >= p1) nslow2 = 0;
+            if (delta <= xtol * xnorm || fnorm == 0.) { done = true; break; }
+            if (nfev >= maxfev || p1 * fmax(p1 * delta, pnorm) <= epsmch * xnorm || nslow2 == 5 || nslow1 == 10) {
+                done = true;
+                break;
+            }
+            if (ncfail == 2) break;  // re-evaluate the Jacobian
+            double sum = q * f_new;
+            double v = (sum - w3) / pnorm;
+            double u = diag * ((diag * step) / pnorm);
+            if (ratio >= p0001) qtf = sum;
+            r = r + u * v;
+            jeval = false;
+        }
+    }
+    *f_out = fvec;
+    return x;
+}
+
+// ---- Brent's method as in scipy/optimize/Zeros/brentq.c (xtol 2e-12, rtol 4 eps, 100 iterations) -----
+// fa, fb are the already-evaluated end point values (the reference evaluates them for its sign test).
+template <class F>
+__device__ inline double brentq(F&& f, double xa, double xb, double fa, double fb)
+{
+    const double xtol = 2e-12, rtol = 8.881784197001252e-16;
+    double xpre = xa, xcur = xb, xblk = 0., fpre = fa, fcur = fb, fblk = 0., spre = 0., scur = 0.;
+    if (fpre == 0) return xpre;
+    if (fcur == 0) return xcur;
+    for (int i = 0; i < 100; i++) {
+        if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
+            xblk = xpre;
+            fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur; xcur = xblk; xblk = xpre;
+            fpre = fcur; fcur = fblk; fblk = fpre;
+        }
+        double delta = (xtol + rtol * fabs(xcur)) / 2;
+        double sbis = (xblk - xcur) / 2;
+        if (fcur == 0 || fabs(sbis) < delta) return xcur;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            double stry;
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                double dpre = (fpre - fcur) / (xpre - xcur);
+                double dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            if (2 * fabs(stry) < fmin(fabs(spre), 3 * fabs(sbis) - delta)) {
+                spre = scur;
+                scur = stry;
+            } else {
+                spre = sbis;
+                scur = sbis;
+            }
+        } else {
+            spre = sbis;
+            scur = sbis;
+        }
+        xpre = xcur;
+        fpre = fcur;
+        if (fabs(scur) > delta) xcur += scur;
+        else xcur += (sbis > 0 ? delta : -delta);
+        fcur = f(xcur);
+    }
+    return xcur;
+}
+
+__device__ inline bool np_sign_differs(double a, double b)
+{
+    if (isnan(a) || isnan(b)) return true;  // np.sign(nan) != anything
+    int sa = (a > 0) - (a < 0), sb = (b > 0) - (b < 0);
+    return sa != sb;
+}
+
+// Kernel: pair i = (event i / n_ch, channel i % n_ch) when n_ch > 0, else x2 is per pair.
+__global__ void __launch_bounds__(256)
+raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
+                IceConst m, RayRecords out)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_pairs; i += (long)gridDim.x * blockDim.x) {
+        long i1 = (n_ch > 0) ? i / n_ch : i;
+        long i2 = (n_ch > 0) ? i % n_ch : i;
+        double A[3] = {x1[3 * i1], x1[3 * i1 + 1], x1[3 * i1 + 2]};
+        double B[3] = {x2[3 * i2], x2[3 * i2 + 1], x2[3 * i2 + 2]};
+        // set_start_and_end_point (:2057-2090): the higher point becomes the stop point
+        bool swap = B[2] < A[2];
+        if (swap) {
+            for (int d = 0; d < 3; d++) { double t = A[d]; A[d] = B[d]; B[d] = t; }
+        }
+        double dX[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+        double dPhi = -atan2(dX[1], dX[0]);
+        double cph = cos(dPhi), sph = sin(dPhi);
+        Pair2D p;
+        p.y1 = A[0];
+        p.z1 = A[2];
+        p.y2 = (cph * dX[0] + (-sph) * dX[1] + 0 * dX[2]) + A[0];
+        p.z2 = (0 * dX[0] + 0 * dX[1] + 1 * dX[2]) + A[2];
+        p.g1 = gamma_of_z(p.z1, m);
+        p.g2 = gamma_of_z(p.z2, m);
+
+        int ns = 0;
+        double lc[3];
+        if (!(p.z2 > 0)) {  // receiver in air: special branch of the reference (:1437-1460) not provided
+            auto dy = [&](double l) { return delta_y(l, p, m); };
+            auto dy2 = [&](double l) { double d = delta_y(l, p, m); return d * d; };
+            double fun;
+            double xr = hybrd1(dy2, -1., 1e-6, &fun);
+            if (fun < 1e-7) lc[ns++] = xr;
+            {
+                double a = xr + 0.0001, b = 100.;
+                double fa = dy(a), fb = dy(b);
+                if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) lc[ns++] = brentq(dy, a, b, fa, fb);
+            }
+            {
+                double a = -100., b = xr - 0.0001;
+                double fa = dy(a), fb = dy(b);
+                if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) lc[ns++] = brentq(dy, a, b, fa, fb);
+            }
+        }
+        double c0[3];
+        for (int k = 0; k < ns; k++) c0[k] = exp(lc[k]) + m.inv_n;
+        // sorted by C0 (insertion sort, <= 3 entries)
+        for (int a = 1; a < ns; a++)
+            for (int b = a; b > 0 && c0[b] < c0[b - 1]; b--) { double t = c0[b]; c0[b] = c0[b - 1]; c0[b - 1] = t; }
+        if (ns > NRHIP_MAXS) ns = 0;  // "too many solutions -> none" (:2127-2130)
+        out.n_sol[i] = ns;
+        for (int s = 0; s < NRHIP_MAXS; s++) {
+            long k = i * NRHIP_MAXS + s;
+            if (s >= ns) {
+                out.type[k] = 0;
+                out.C0[k] = out.C1[k] = out.D[k] = out.T[k] = out.refl_angle[k] = NAN;
+                for (int d = 0; d < 3; d++) out.launch[3 * k + d] = out.receive[3 * k + d] = NAN;
+                continue;
+            }
+            C0State st = make_c0(c0[s], m);
+            double C1 = C1_of(st, p, m);
+            int type = solution_type(st, C1, p);
+            double la = ray_angle(p.y1, p.z1, st, C1, p, m);          // get_launch_angle  (:1195)
+            double ra = M_PI - ray_angle(p.y2, p.z2, st, C1, p, m);   // get_receive_angle (:1198)
+            double D, T;
+            path_length_time(st, C1, type, la, p, m, &D, &T);
+            // 2-D -> 3-D via R^T (:2560-2624); for swapped end points launch and receive exchange roles
+            double lv0 = sin(la), lv2 = cos(la), rv0 = -sin(ra), rv2 = cos(ra);
+            if (swap) {
+                lv0 = -sin(ra); lv2 = cos(ra);
+                rv0 = sin(la);  rv2 = cos(la);
+            }
+            out.type[k] = type;
+            out.C0[k] = c0[s];
+            out.C1[k] = C1;
+            out.D[k] = D;
+            out.T[k] = T;
+            out.launch[3 * k + 0] = cph * lv0;
+            out.launch[3 * k + 1] = -sph * lv0;
+            out.launch[3 * k + 2] = lv2;
+            out.receive[3 * k + 0] = cph * rv0;
+            out.receive[3 * k + 1] = -sph * rv0;
+            out.receive[3 * k + 2] = rv2;
+            // surface reflection angle (:1201-1237); NaN encodes the reference's None
+            double y_turn = st.y_turn0 + C1;
+            double refl = NAN;
+            if (st.z_turn >= 0 && y_turn > p.y1 && y_turn < p.y2) refl = ray_angle(y_turn, 0., st, C1, p, m);
+            out.refl_angle[k] = refl;
+        }
+    }
+}
+
+void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
+                     const IceConst& m, const RayRecords& out)
+{
+    if (n_pairs <= 0) return;
+    int block = 256;
+    long grid = (n_pairs + block - 1) / block;
+    if (grid > 256L * 64) grid = 256L * 64;
+    hipLaunchKernelGGL(raytrace_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out);
+}
+
+}  // namespace nrhip

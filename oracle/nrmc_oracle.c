@@ -359,8 +359,7 @@ int orc_find_solutions_2d(const double x1[2], const double x2[2], const double i
         double da = obj_delta_y(a, &o), db = obj_delta_y(b, &o);
         if (sign_differs(da, db)) {
             double rt;
-            orc_brentq(obj_delta_y, &o, a, b, &rt);
-            logC0[n++] = rt;
+            if (orc_brentq(obj_delta_y, &o, a, b, &rt) != -1) logC0[n++] = rt; /* -1: scipy raises ValueError */
         }
     }
     {
@@ -368,8 +367,7 @@ int orc_find_solutions_2d(const double x1[2], const double x2[2], const double i
         double da = obj_delta_y(a, &o), db = obj_delta_y(b, &o);
         if (sign_differs(da, db)) {
             double rt;
-            orc_brentq(obj_delta_y, &o, a, b, &rt);
-            logC0[n++] = rt;
+            if (orc_brentq(obj_delta_y, &o, a, b, &rt) != -1) logC0[n++] = rt; /* -1: scipy raises ValueError */
         }
     }
     for (int i = 0; i < n; i++) {
@@ -417,7 +415,7 @@ static double get_y_diff(double z_raw, double C0, const ice_t *m)
     double z = get_z_unmirrored(z_raw, C0, m);
     double n_z = n_of_z(z, m);
     double res;
-    if (C0 * C0 * n_z * n_z > 1) res = 1 / sqrt(C0 * C0 * n_z * n_z - 1);
+    if ((C0 * C0) * (n_z * n_z) > 1) res = 1 / sqrt((C0 * C0) * (n_z * n_z) - 1); /* C_0**2 * n_z**2 */
     else res = INFINITY;
     if (z != z_raw) res *= -1;
     return res;
@@ -1091,7 +1089,7 @@ static void rotate_back(const geom_t *g, const double v2d[3], double out[3]) /* 
 /* batch over pairs; arrays are [n][MAXS](...) with NaN / 0 padding like the reference's HDF5 tables */
 void orc_raytrace_batch(long n, const double *x1, const double *x2, const double ice[3],
                         int *n_sol, int *type, double *C0, double *C1, double *D, double *T,
-                        double *launch, double *receive, double *refl_angle, double *hybr_x)
+                        double *launch, double *receive, double *refl_angle, double *hybr_x, double *hybr_fun)
 {
     ice_t m = { ice[0], ice[1], ice[2] };
     for (long i = 0; i < n; i++) {
@@ -1101,6 +1099,7 @@ void orc_raytrace_batch(long n, const double *x1, const double *x2, const double
         int ty[3];
         int ns = orc_find_solutions_2d(g.x1, g.x2, ice, c0, c1, ty, &hx, &hf, NULL);
         if (hybr_x) hybr_x[i] = hx;
+        if (hybr_fun) hybr_fun[i] = hf;
         if (ns > MAXS) ns = 0; /* :2127-2130 */
         n_sol[i] = ns;
         for (int s = 0; s < MAXS; s++) {

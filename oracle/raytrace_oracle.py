@@ -1,0 +1,90 @@
+"""ctypes front-end of oracle/nrmc_oracle.c (TEST INFRASTRUCTURE ONLY, never imported by nuradiomc_amd).
+
+Parity status: PINNED against the reference's golden vectors and against outputs of the reference's
+pure-Python path (tests/test_oracle_golden.py; fixtures under tests/golden/).
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, '_build', 'liboracle.so')
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+MAXS = 2
+MODEL_TO_INT = {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4}
+
+
+def build(force=False):
+    src = os.path.join(_HERE, 'nrmc_oracle.c')
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(_SO), exist_ok=True)
+        subprocess.check_call(['gcc', '-O2', '-fPIC', '-shared', '-std=gnu11', '-ffp-contract=off', '-o', _SO, src,
+                               '-lm'])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        _lib.orc_raytrace_batch.argtypes = [ctypes.c_long] + [_dp] * 3 + [_ip, _ip] + [_dp] * 9
+        _lib.orc_raytrace_batch.restype = None
+        _lib.orc_attenuation_batch.argtypes = [ctypes.c_long, _dp, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp,
+                                               _ip]
+        _lib.orc_attenuation_batch.restype = None
+        _lib.orc_attenuation_length.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int]
+        _lib.orc_attenuation_length.restype = ctypes.c_double
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def raytrace_batch(x1, x2, ice):
+    """find_solutions + geometry for pairs x1[i] -> x2[i]; same output dict as Context.find_solutions_batch."""
+    x1 = np.ascontiguousarray(x1, float).reshape(-1, 3)
+    x2 = np.ascontiguousarray(x2, float).reshape(-1, 3)
+    ice = np.ascontiguousarray(ice, float)
+    n = len(x1)
+    o = dict(n_sol=np.zeros(n, np.int32), type=np.zeros((n, MAXS), np.int32), hybr_x=np.zeros(n), hybr_fun=np.zeros(n))
+    for k in ('C0', 'C1', 'D', 'T', 'refl_angle'):
+        o[k] = np.full((n, MAXS), np.nan)
+    for k in ('launch', 'receive'):
+        o[k] = np.full((n, MAXS, 3), np.nan)
+    lib().orc_raytrace_batch(n, _d(x1), _d(x2), _d(ice), _i(o['n_sol']), _i(o['type']), _d(o['C0']), _d(o['C1']),
+                             _d(o['D']), _d(o['T']), _d(o['launch']), _d(o['receive']), _d(o['refl_angle']),
+                             _d(o['hybr_x']), _d(o['hybr_fun']))
+    return o
+
+
+def attenuation_batch(x1, x2, C0, ice, model, freqs, return_neval=False):
+    x1 = np.ascontiguousarray(x1, float).reshape(-1, 3)
+    x2 = np.ascontiguousarray(x2, float).reshape(-1, 3)
+    C0 = np.ascontiguousarray(C0, float).reshape(-1)
+    ice = np.ascontiguousarray(ice, float)
+    freqs = np.ascontiguousarray(freqs, float)
+    n = len(C0)
+    att = np.zeros((n, len(freqs)))
+    nev = np.zeros((n, len(freqs)), np.int32)
+    lib().orc_attenuation_batch(n, _d(x1), _d(x2), _d(C0), _d(ice), MODEL_TO_INT[model], len(freqs), _d(freqs),
+                                _d(att), _i(nev))
+    return (att, nev) if return_neval else att
+
+
+def attenuation_length(z, f, model):
+    z, f = np.broadcast_arrays(np.asarray(z, float), np.asarray(f, float))
+    out = np.zeros(z.shape)
+    L = lib()
+    for idx in np.ndindex(z.shape):
+        out[idx] = L.orc_attenuation_length(float(z[idx]), float(f[idx]), MODEL_TO_INT[model])
+    return out

@@ -1,0 +1,99 @@
+"""HIP ray tracer + attenuation through the C ABI vs the oracle and the committed golden vectors."""
+import numpy as np
+import pytest
+from conftest import golden, max_rel
+from oracle import raytrace_oracle as orc
+from test_oracle_golden import _subset_ok
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare_ray_tables(o, g, count_tol=0.005):
+    bad = o['n_sol'] != g['n_sol']
+    assert bad.mean() <= count_tol, "solution-count mismatches: %d of %d" % (bad.sum(), len(bad))
+    for i in np.where(bad)[0]:
+        assert _subset_ok(o['C0'][i], g['C0'][i])
+    ok = ~bad
+    assert np.array_equal(o['type'][ok], g['type'][ok])
+    assert max_rel(o['C0'][ok], g['C0'][ok]) < 1e-6
+    assert max_rel(o['D'][ok], g['D'][ok]) < 1e-6
+    assert max_rel(o['T'][ok], g['T'][ok]) < 1e-6
+    for k in ('launch', 'receive'):
+        assert np.array_equal(np.isnan(o[k][ok]), np.isnan(g[k][ok]))
+        assert np.nanmax(np.abs(o[k][ok] - g[k][ok])) < 1e-6
+    assert np.nanmax(np.abs(o['C1'][ok] - g['C1'][ok])) < 1e-3
+    assert max_rel(o['refl_angle'][ok], g['refl_angle'][ok]) < 1e-6
+    return bad.sum()
+
+
+@pytest.mark.parametrize('name', ['A', 'B', 'C'])
+def test_find_solutions_vs_reference_fixture(gpu_ctx_factory, name):
+    g = golden('raytrace_%s.npz' % name)
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    o = ctx.find_solutions_batch(g['x1'], g['x2'])
+    _compare_ray_tables(o, g)
+
+
+def test_find_solutions_vs_oracle_survey_geometry(gpu_ctx_factory):
+    """2e4 events x 5 channels of the BASELINE config-2 geometry, outer-product addressing."""
+    rng = np.random.default_rng(123)
+    n = 20000
+    r = np.sqrt(rng.uniform(0, 4000. ** 2, n))
+    ph = rng.uniform(0, 2 * np.pi, n)
+    vert = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-2700, 0, n)], axis=1)
+    chan = np.array([[0., 0., -100. - i] for i in range(5)])
+    ice = (1.78, 0.423, 77.)
+    ctx = gpu_ctx_factory(ice)
+    o = ctx.find_solutions_batch(vert, chan, outer=True)
+    ref = orc.raytrace_batch(np.repeat(vert, 5, axis=0), np.tile(chan, (n, 1)), ice)
+    nbad = _compare_ray_tables(o, ref)
+    print("count mismatches vs oracle: %d / %d" % (nbad, 5 * n))
+    assert (o['n_sol'] == 2).mean() > 0.3
+
+
+def test_find_solutions_edge_cases(gpu_ctx_factory):
+    ice = (1.78, 0.423, 77.)
+    ctx = gpu_ctx_factory(ice)
+    # empty batch
+    o = ctx.find_solutions_batch(np.zeros((0, 3)), np.zeros((0, 3)))
+    assert o['n_sol'].shape == (0,)
+    # swapped end points (emitter above receiver), vertical pair, shadow-zone pair (no solution)
+    x1 = np.array([[100., 50., -10.], [0., 0., -500.], [3900., 0., -5.], [-300., 200., -1200.]])
+    x2 = np.array([[0., 0., -300.], [0.5, 0., -100.], [0., 0., -100.], [0., 0., -100.]])
+    o = ctx.find_solutions_batch(x1, x2)
+    ref = orc.raytrace_batch(x1, x2, ice)
+    assert np.array_equal(o['n_sol'], ref['n_sol'])
+    assert np.array_equal(o['type'], ref['type'])
+    assert max_rel(o['T'], ref['T']) < 1e-6
+    assert np.nanmax(np.abs(o['launch'] - ref['launch'])) < 1e-6
+    assert o['n_sol'][2] == 0 and np.all(np.isnan(o['C0'][2])) and np.all(o['type'][2] == 0)
+
+
+@pytest.mark.parametrize('name', ['A', 'B', 'C'])
+def test_attenuation_vs_reference_fixture(gpu_ctx_factory, name):
+    g = golden('raytrace_%s.npz' % name)
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    att = g['att']
+    na, _, nf = att.shape
+    x1 = np.repeat(g['x1'][:na], 2, axis=0)
+    x2 = np.repeat(g['x2'][:na], 2, axis=0)
+    C0 = g['C0'][:na].reshape(-1)
+    out, nev = ctx.attenuation_batch(x1, x2, C0, g['fcoarse'], return_neval=True)
+    ref = att.reshape(na * 2, nf)
+    assert max_rel(out, ref) < 1e-6
+    # same adaptive decisions as the reference's QUADPACK (oracle reports scipy's neval)
+    _, nev_o = orc.attenuation_batch(x1, x2, C0, g['ice'], str(g['att_model']), g['fcoarse'], return_neval=True)
+    m = np.isfinite(ref)
+    assert (nev[m] != nev_o[m]).mean() < 1e-3
+
+
+def test_attenuation_length_models(gpu_ctx_factory):
+    z = np.linspace(-2800., 5., 57)
+    f = np.array([0.05, 0.3, 0.999, 1.0, 1.7])[:, None] * np.ones_like(z)[None, :]
+    for model in ('SP1', 'GL1', 'MB1', 'GL2'):
+        ctx = gpu_ctx_factory((1.78, 0.423, 77.), model)
+        got = ctx.attenuation_length(z[None, :] * np.ones_like(f), f)
+        ref = orc.attenuation_length(z[None, :] * np.ones_like(f), f, model)
+        assert np.array_equal(np.isinf(got), np.isinf(ref))
+        m = np.isfinite(ref)
+        assert np.max(np.abs(got[m] - ref[m]) / np.abs(ref[m])) < 1e-12, model
