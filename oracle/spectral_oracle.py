@@ -1,0 +1,486 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the spectral half of the reference's hot path.
+
+Askaryan emission -> polarisation -> propagation effects -> antenna response (per efield and combined on
+the event's common time grid) -> filter -> threshold trigger, with the sequencing of
+NuRadioMC/simulation/simulation.py (calculate_sim_efield :93-292, apply_det_response_sim :465-527,
+apply_det_response :530-609, run :1454-1600).  Ray tracing and attenuation come from the C restatement
+(oracle/raytrace_oracle.py).  FFTs are numpy's (pocketfft) exactly as in NuRadioReco/utilities/fft.py, the
+Butterworth responses are scipy.signal's exactly as in NuRadioReco/utilities/signal_processing.py:289-290.
+
+Never imported by nuradiomc_amd/.  Parity status: PINNED against outputs of the reference itself
+(tests/golden/chain_*.npz, generator tests/golden/gen/gen_chain.py; tests/test_oracle_chain.py) and against the
+reference's own Askaryan golden vectors (tests/golden/ref_askaryan_v2.npz from
+NuRadioMC/test/SignalGen/reference_v2.npy).
+"""
+import numpy as np
+from scipy import signal
+from scipy.signal.windows import hann
+
+from . import raytrace_oracle as rto
+
+
+# ---- NuRadioReco/utilities/units.py (metre = ns = eV = rad = volt = 1) -----------------------------------
+class units:
+    m = 1
+    cm = 0.01
+    mm = 0.001
+    ns = 1
+    s = 1e9 * 1
+    GHz = 1e9 * (1 / (1e9 * 1))
+    MHz = 1e6 * (1 / (1e9 * 1))
+    eV = 1
+    MeV = 1e6 * 1
+    TeV = 1e12 * 1
+    V = 1.0
+    deg = (3.14159265358979323846 / 180) * 1
+    joule = 1 / 1.602176462e-19
+    kilogram = joule * s * s / (1 * 1)
+    g = 1e-3 * kilogram
+    kelvin = 1
+    ohm = 1.0 / ((1 / 1.602176462e-19 * 1) / (s))  # volt / ampere, ampere = coulomb / second
+    k_B = 1.380649e-23 * joule / kelvin               # scipy.constants.k
+
+
+speed_of_light = 299792458.0 * units.m / units.s
+
+
+# ---- FFT conventions (NuRadioReco/utilities/fft.py:55-92) ---------------------------------------------------
+def time2freq(trace, fs):
+    return np.fft.rfft(trace, axis=-1) / fs * 2 ** 0.5
+
+
+def freq2time(spec, fs, n=None):
+    return np.fft.irfft(spec, axis=-1, n=n) * fs / 2 ** 0.5
+
+
+# ---- radiotools pieces (un-vendored dependency; trivial trigonometry) --------------------------------------
+def spherical_to_cartesian(zenith, azimuth):
+    return np.array([np.sin(zenith) * np.cos(azimuth), np.sin(zenith) * np.sin(azimuth), np.cos(zenith)])
+
+
+def cartesian_to_spherical(x, y, z):
+    r = np.sqrt(x ** 2 + y ** 2 + z ** 2)
+    theta = np.arccos(z / r) if z / r < 1 else 0
+    phi = np.arctan2(y, x)
+    while phi >= 2 * np.pi:
+        phi -= 2 * np.pi
+    while phi < 0:
+        phi += 2 * np.pi
+    return theta, phi
+
+
+def get_angle(v1, v2):
+    c = np.dot(v1, v2) / (np.linalg.norm(v1) * np.linalg.norm(v2))
+    return np.arccos(min(1, max(-1, c)))
+
+
+def onsky_matrix(zenith, azimuth):
+    """rows e_r, e_theta, e_phi -- the matrix spelled out at analyticraytracing.py:2363-2365"""
+    ct, st, cp, sp = np.cos(zenith), np.sin(zenith), np.cos(azimuth), np.sin(azimuth)
+    return np.array([[st * cp, st * sp, ct], [ct * cp, ct * sp, -st], [-sp, cp, 0]])
+
+
+# ---- Askaryan parametrisations (NuRadioMC/SignalGen/parametrizations.py) ------------------------------------
+def alvarez2009_kL_distribution(energy):
+    """(log10 mean, sigma) of k_L for EM showers (:141-158); the reference draws 10**normal(mean, sigma)."""
+    sigma_0, log10_E_sigma, delta_0, delta_1 = 3.39e-2, 14.99, 0, 2.25e-2
+    log10_E_0 = np.log10(energy / units.eV)
+    if log10_E_0 < log10_E_sigma:
+        sigma = sigma_0 + delta_0 * (log10_E_0 - log10_E_sigma)
+    else:
+        sigma = sigma_0 + delta_1 * (log10_E_0 - log10_E_sigma)
+    log10_k_0, log10_E_LPM, gamma_0, gamma_1 = 1.52, 16.61, 5.59e-2, 0.39
+    if log10_E_0 < log10_E_LPM:
+        mean = log10_k_0 + gamma_0 * (log10_E_0 - log10_E_LPM)
+    else:
+        mean = log10_k_0 + gamma_1 * (log10_E_0 - log10_E_LPM)
+    return mean, sigma
+
+
+def askaryan_time_trace(energy, theta, N, dt, shower_type, n_index, R, model, k_L=None):
+    """parametrizations.get_time_trace (:29-278); EM k_L must be supplied (the draw stays on the host)."""
+    if model == 'Alvarez2009':
+        freqs = np.fft.rfftfreq(N, dt)[1:]
+        E_C = 73.1 * units.MeV
+        rho = 0.924 * units.g / units.cm ** 3
+        X_0 = 36.08 * units.g / units.cm ** 2
+        R_M = 10.57 * units.g / units.cm ** 2
+        c = speed_of_light
+        if shower_type == 'HAD':
+            k_E_0 = 4.13e-16 * units.V / units.cm / units.MHz ** 2
+            k_E_bar = k_E_0 * np.tanh((np.log10(energy / units.eV) - 10.60) / 2.54)
+        elif shower_type == 'EM':
+            k_E_bar = 4.65e-16 * units.V / units.cm / units.MHz ** 2
+        else:
+            raise NotImplementedError(shower_type)
+        A = k_E_bar * energy / E_C * X_0 / rho * np.sin(theta) * freqs
+        if shower_type == 'HAD':
+            k_L = 31.25 * (energy / (1.e15 * units.eV)) ** 3.01e-2
+        elif k_L is None:
+            raise ValueError("EM shower needs k_L")
+        nu_L = rho / k_L / X_0
+        cher_cut = 1.e-8
+        if np.abs(1 - n_index * np.cos(theta)) < cher_cut:
+            nu_L *= c / cher_cut
+        else:
+            nu_L *= c / np.abs(1 - n_index * np.cos(theta))
+        beta = 2.57 if shower_type == 'HAD' else 2.74
+        d_L = 1 / (1 + (freqs / nu_L) ** beta)
+        if shower_type == 'HAD':
+            k_R_bar = 2.73 + np.tanh((12.92 - np.log10(energy / units.eV)) / 1.72)
+        else:
+            k_R_bar = 1.54
+        nu_R = rho / k_R_bar / R_M * c / np.sqrt(n_index ** 2 - 1)
+        d_R = 1 / (1 + (freqs / nu_R) ** 1.27)
+        spectrum = A * d_L * d_R
+        spectrum *= 0.5
+        spectrum /= R
+        spectrum = np.insert(spectrum, 0, 0)
+        trace = np.fft.irfft(spectrum * np.exp(0.5j * np.pi)) / dt
+        trace = np.roll(trace, len(trace) // 2)
+        return trace, k_L
+    if model == 'Alvarez2000':
+        freqs = np.fft.rfftfreq(N, dt)[1:]
+        cherenkov_angle = np.arccos(1. / n_index)
+        Elpm = 2e15 * units.eV
+        dThetaEM = 2.7 * units.deg * 500 * units.MHz / freqs * (Elpm / (0.14 * energy + Elpm)) ** 0.3
+        epsilon = np.log10(energy / units.TeV)
+        dThetaHad = 0
+        if 0 <= epsilon <= 2:
+            dThetaHad = 500 * units.MHz / freqs * (2.07 - 0.33 * epsilon + 7.5e-2 * epsilon ** 2) * units.deg
+        elif 2 < epsilon <= 5:
+            dThetaHad = 500 * units.MHz / freqs * (1.74 - 1.21e-2 * epsilon) * units.deg
+        elif 5 < epsilon <= 7:
+            dThetaHad = 500 * units.MHz / freqs * (4.23 - 0.785 * epsilon + 5.5e-2 * epsilon ** 2) * units.deg
+        elif epsilon > 7:
+            dThetaHad = 500 * units.MHz / freqs * (4.23 - 0.785 * 7 + 5.5e-2 * 7 ** 2) * \
+                (1 + (epsilon - 7) * 0.075) * units.deg
+        f0 = 1.15 * units.GHz
+        E = 2.53e-7 * energy / units.TeV * freqs / f0 / (1 + (freqs / f0) ** 1.44)
+        E *= units.V / units.m / units.MHz
+        E *= np.sin(theta) / np.sin(cherenkov_angle)
+        tmp = np.zeros(len(freqs) + 1)
+        if shower_type == 'EM':
+            tmp[1:] = E * np.exp(-np.log(2) * ((theta - cherenkov_angle) / dThetaEM) ** 2) / R
+        elif shower_type == 'HAD':
+            if np.any(dThetaHad != 0):
+                tmp[1:] = E * np.exp(-np.log(2) * ((theta - cherenkov_angle) / dThetaHad) ** 2) / R
+                eps = np.log10(energy / units.TeV)
+                f_eps = -1.27e-2 - 4.76e-2 * (eps + 3)
+                f_eps += -2.07e-3 * (eps + 3) ** 2 + 0.52 * np.sqrt(eps + 3)
+                tmp[1:] *= f_eps
+        else:
+            raise NotImplementedError(shower_type)
+        tmp *= 0.5
+        trace = np.fft.irfft(tmp * np.exp(0.5j * np.pi)) / dt
+        trace = np.roll(trace, len(trace) // 2)
+        return trace, None
+    if model == 'ZHS1992':
+        freqs = np.fft.rfftfreq(N, dt)
+        vv0 = freqs / (0.5 * units.GHz)
+        cherenkov_angle = np.arccos(1. / n_index)
+        domega = theta - cherenkov_angle
+        tmp = np.exp(+0.5j * np.pi)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            tmp = tmp * 1.1e-7 * energy / units.TeV * vv0 * 1. / \
+                (1 + 0.4 * (vv0) ** 2) * np.exp(-0.5 * (domega / (2.4 * units.deg / vv0)) ** 2) * \
+                units.V / units.m / (R / units.m) / units.MHz
+        trace = 0.5 * np.fft.irfft(tmp) / dt
+        trace = np.roll(trace, int(2 * units.ns / dt))
+        return trace, None
+    raise NotImplementedError("model {} unknown".format(model))
+
+
+def askaryan_frequency_spectrum(energy, theta, N, dt, shower_type, n_index, R, model, k_L=None):
+    """askaryan.get_frequency_spectrum (NuRadioMC/SignalGen/askaryan.py:143-213)"""
+    trace, k_L = askaryan_time_trace(energy, theta, N, dt, shower_type, n_index, R, model, k_L)
+    return time2freq(trace, 1 / dt), k_L
+
+
+# ---- polarisation (simulation.py:798-829, 'auto') ------------------------------------------------------------
+def polarization_onsky(shower_axis, launch_vector):
+    pol = np.cross(launch_vector, np.cross(shower_axis, launch_vector))
+    pol = pol / np.linalg.norm(pol)
+    return np.dot(onsky_matrix(*cartesian_to_spherical(*launch_vector)), pol)
+
+
+# ---- Fresnel reflection off the surface (geometryUtilities.py:208-263, numpy.lib.scimath.sqrt) -----------------
+def fresnel_r_p(zenith, n_2, n_1):
+    n = n_2 / n_1
+    s = np.lib.scimath.sqrt(n ** 2 - np.sin(zenith) ** 2)
+    return np.conjugate((n ** 2 * np.cos(zenith) - s) / (n ** 2 * np.cos(zenith) + s))
+
+
+def fresnel_r_s(zenith, n_2, n_1):
+    n = n_2 / n_1
+    s = np.lib.scimath.sqrt(n ** 2 - np.sin(zenith) ** 2)
+    return np.conjugate((np.cos(zenith) - s) / (np.cos(zenith) + s))
+
+
+# ---- attenuation frequency grid (analyticraytracing.py:885-931) and interpolation (:1077-1078) -----------------
+def attenuation_frequencies(frequency, n_freq, max_detector_freq=None):
+    non_null = frequency > 0
+    n = min(n_freq, np.sum(non_null))
+    freqs = np.linspace(frequency[non_null].min(), frequency[non_null].max(), n)
+    if n < np.sum(non_null) and max_detector_freq is not None:
+        det_mask = frequency <= max_detector_freq
+        total = det_mask & non_null
+        n = min(n_freq, np.sum(total))
+        freqs = np.linspace(frequency[total].min(), frequency[total].max(), n)
+        if np.sum(~det_mask) > 1:
+            freqs = np.append(freqs, np.linspace(frequency[~det_mask].min(), frequency[~det_mask].max(), n // 2))
+    return freqs
+
+
+def attenuation_on_grid(frequency, fcoarse, att_coarse):
+    out = np.ones_like(frequency)
+    mask = frequency > 0
+    out[mask] = np.interp(frequency[mask], fcoarse, att_coarse)
+    return out
+
+
+# ---- analytic antennas (NuRadioReco/detector/antennapattern.py:1190-1307, :1580-1768) ---------------------------
+def _antenna_rotation(ori):
+    e1 = spherical_to_cartesian(0., 0.)
+    e2 = spherical_to_cartesian(90 * units.deg, 0.)
+    E = np.array([e1, e2, np.cross(e1, e2)])
+    a1 = spherical_to_cartesian(ori[0], ori[1])
+    a2 = spherical_to_cartesian(ori[2], ori[3])
+    A = np.array([a1, a2, np.cross(a1, a2)])
+    return np.matmul(np.linalg.inv(E), A)
+
+
+def vel_raw(model, freq, theta, phi):
+    fmask = freq > 0
+    gain = np.ones_like(freq)
+    if model == 'analytic_VPol':
+        cutoff, max_vel = 220 * units.MHz, 0.18 * units.m
+        index = np.argmax(freq > cutoff)
+        gain_filter = hann(2 * index)
+        gain[fmask] /= np.sqrt(freq[fmask])
+        VEL_theta = np.zeros_like(gain)
+        VEL_theta[fmask] = np.sqrt(gain[fmask]) / freq[fmask]
+        VEL_theta[:index] *= gain_filter[:index]
+        VEL_theta[fmask] *= max_vel / max(VEL_theta[fmask])
+        VEL_theta *= np.sin(theta)
+        VEL_phi = np.zeros_like(gain)
+        phase = 2.086 - 117.917 * freq + 74.567 / 2 * freq ** 2 - 64.343 / 3 * freq ** 3
+        VEL_theta = VEL_theta.astype(complex)
+        VEL_theta *= np.exp(1j * phase)
+        return VEL_theta, VEL_phi
+    if model == 'analytic_HPol':
+        peak_freq, max_vel = 500 * units.MHz, 0.055 * units.m
+        VEL_theta = np.zeros_like(gain)
+        VEL_phi = np.zeros_like(gain)
+        VEL_phi[fmask] = np.sqrt(gain[fmask]) * np.sin(freq[fmask] / peak_freq * np.pi / 2) ** 2
+        VEL_phi[freq > peak_freq * 2] = 0
+        VEL_phi[fmask] *= max_vel / max(VEL_phi[fmask])
+        VEL_phi *= np.sin(theta) ** 2
+        phase = 0.321 - 11.400 * freq + 39.590 / 2 * freq ** 2 - 38.181 / 3 * freq ** 3
+        VEL_phi = VEL_phi.astype(complex)
+        VEL_phi *= np.exp(1j * phase)
+        return VEL_theta, VEL_phi
+    raise NotImplementedError(model)
+
+
+def antenna_response(model, freq, zenith, azimuth, ori):
+    """get_antenna_response_vectorized (:1246-1307) -> (VEL_theta, VEL_phi) in the on-sky basis of the arrival"""
+    rot = _antenna_rotation(ori)
+    inc = np.dot(rot, spherical_to_cartesian(zenith, azimuth).T).T
+    theta, phi = cartesian_to_spherical(*inc)
+    Vt, Vp = vel_raw(model, freq, theta, phi)
+    V_xyz_raw = np.dot(np.linalg.inv(onsky_matrix(theta, phi)), np.array([np.zeros(Vt.shape[0]), Vt, Vp]))
+    V_xyz = np.dot(np.linalg.inv(rot), V_xyz_raw)
+    V_onsky = np.dot(onsky_matrix(zenith, azimuth), V_xyz)
+    return V_onsky[1], V_onsky[2]
+
+
+# ---- filters (signal_processing.get_filter_response :237-333, butter) and Vrms (simulation.py:1301-1376) -------
+DEFAULT_FILTERS = (dict(passband=(80 * units.MHz, 1000 * units.GHz), order=2),
+                   dict(passband=(0, 500 * units.MHz), order=10))
+
+
+def butter_ba(passband, order):
+    if passband[0] == 0:
+        return signal.butter(order, passband[1], 'lowpass', analog=True)
+    return signal.butter(order, list(passband), 'bandpass', analog=True)
+
+
+def filter_response(freqs, filters=DEFAULT_FILTERS):
+    H = np.ones_like(freqs, dtype=complex)
+    for flt in filters:
+        f = np.zeros_like(freqs, dtype=complex)
+        mask = freqs > 0
+        b, a = butter_ba(flt['passband'], flt['order'])
+        _, h = signal.freqs(b, a, freqs[mask])
+        f[mask] = h
+        H = H * f
+    return H
+
+
+def vrms_from_filters(fs, filters=DEFAULT_FILTERS, noise_temperature=300.):
+    ff = np.linspace(0, 0.5 * fs, 10000)
+    filt = filter_response(ff, filters)
+    bandwidth = np.trapz(np.abs(filt) ** 2, ff)
+    vrms = (noise_temperature * (50 * units.ohm) * bandwidth * units.k_B) ** 0.5
+    return vrms, vrms / np.abs(filt).max() / units.m
+
+
+# ---- the per-event chain ------------------------------------------------------------------------------------
+class Station:
+    def __init__(self, pos, antenna='analytic_VPol', orientation=(0., 0., 90 * units.deg, 90 * units.deg),
+                 cable_delay=0., n_samples=4096, fs=2.0):
+        self.pos = np.asarray(pos, float).reshape(-1, 3)
+        self.n_ch = len(self.pos)
+        self.antenna = antenna
+        self.orientation = tuple(orientation)
+        cd = np.asarray(cable_delay, float)
+        self.cable_delay = np.broadcast_to(cd, (self.n_ch,)).copy()
+        self.n_samples = n_samples
+        self.fs = fs
+
+
+def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model='SP1', n_freq=25,
+                          model='Alvarez2009', delta_C_cut=0.698, vertex_time=0., rays=None):
+    """calculate_sim_efield (simulation.py:93-292) for every channel of one single-shower event.
+    `rays` may carry precomputed ray tables (dict like raytrace_oracle.raytrace_batch output, one row per channel).
+    Returns a list of dicts (one per kept ray, channel-major then solution)."""
+    N, dt = st.n_samples, 1. / st.fs
+    x1 = np.asarray(vertex, float)
+    shower_axis = spherical_to_cartesian(zenith, azimuth)
+    shower_direction = -1 * shower_axis
+    n_index = ice[0] - ice[1] * np.exp(x1[2] / ice[2]) if x1[2] <= 0 else 1.
+    cherenkov = np.arccos(1. / n_index)
+    if rays is None:
+        rays = rto.raytrace_batch(np.tile(x1, (st.n_ch, 1)), st.pos, ice)
+    ff = np.fft.rfftfreq(N, dt)
+    fcoarse = attenuation_frequencies(ff, n_freq, 0.5 * st.fs)
+    out = []
+    for ch in range(st.n_ch):
+        ns = rays['n_sol'][ch]
+        if ns == 0:
+            continue
+        view = np.array([get_angle(shower_direction, rays['launch'][ch, s]) for s in range(ns)])
+        dC = view - cherenkov
+        if min(np.abs(dC)) > delta_C_cut:
+            continue
+        for s in range(ns):
+            if np.abs(dC[s]) > delta_C_cut:
+                continue
+            D, T = rays['D'][ch, s], rays['T'][ch, s]
+            spectrum, _ = askaryan_frequency_spectrum(energy, view[s], N, dt, shower_type, n_index, D, model, k_L=k_L)
+            pol = polarization_onsky(shower_direction, rays['launch'][ch, s])
+            spec = np.outer(pol, spectrum)
+            att = rto.attenuation_batch(x1[None], st.pos[ch][None], [rays['C0'][ch, s]], ice, att_model, fcoarse)[0]
+            spec = spec * attenuation_on_grid(ff, fcoarse, att)
+            r_theta = r_phi = 1.
+            ra = rays['refl_angle'][ch, s]
+            if not np.isnan(ra):
+                n1 = ice[0] - ice[1] * np.exp(-1 * units.cm / ice[2])
+                r_theta = fresnel_r_p(ra, n_2=1., n_1=n1)
+                r_phi = fresnel_r_s(ra, n_2=1., n_1=n1)
+                spec[1] = spec[1] * r_theta
+                spec[2] = spec[2] * r_phi
+            zen_r, az_r = cartesian_to_spherical(*rays['receive'][ch, s])
+            t0 = vertex_time + T - 0.5 * N / st.fs
+            trace = freq2time(spec, st.fs)
+            out.append(dict(channel=ch, iS=s, C0=rays['C0'][ch, s], type=rays['type'][ch, s], D=D, T=T, view=view[s],
+                            pol=pol, zenith=zen_r, azimuth=az_r, t0=t0, spec=spec, r_theta=r_theta, r_phi=r_phi,
+                            max_efield=np.max(np.abs(trace))))
+    return out
+
+
+def per_efield_voltage(ef, st, filters=DEFAULT_FILTERS):
+    """efieldToVoltageConverterPerEfield.run (:28-101) + filter chain + Hilbert-envelope maximum
+    (simulation._calculate_amp_per_ray_solution :1868-1886); native N grid."""
+    ff = np.fft.rfftfreq(st.n_samples, 1. / st.fs)
+    Vt, Vp = antenna_response(st.antenna, ff, ef['zenith'], ef['azimuth'], st.orientation)
+    v = Vt * ef['spec'][1] + Vp * ef['spec'][2]
+    v[ff < 5 * units.MHz] = 0.
+    v = v * filter_response(ff, filters)
+    trace = freq2time(v, st.fs)
+    return v, np.abs(signal.hilbert(trace)).max()
+
+
+def combined_voltage(efields, st, filters=DEFAULT_FILTERS, pre_pulse_time=200., post_pulse_time=400.):
+    """efieldToVoltageConverter.run (:111-345) for all channels + filter chain -> (V[n_ch, L], t_min, L)"""
+    fs = st.fs
+    N = st.n_samples
+    tmin, tmax = [], []
+    for ch in range(st.n_ch):
+        for ef in efields:
+            if ef['channel'] != ch:
+                continue
+            t0 = ef['t0'] + st.cable_delay[ch]
+            tmin.append(t0)
+            tmax.append(t0 + N / fs)
+    times_min, times_max = np.min(tmin), np.max(tmax)
+    max_len = st.n_samples / st.fs
+    times_min -= pre_pulse_time
+    times_max += post_pulse_time
+    while times_max - times_min < max_len:
+        times_max += post_pulse_time
+    res = 1. / fs
+    L = int(round((times_max - times_min) / res))
+    if L % 2 != 0:
+        L += 1
+    ffL = np.fft.rfftfreq(L, res)
+    H = filter_response(ffL, filters)
+    V = np.zeros((st.n_ch, L))
+    for ch in range(st.n_ch):
+        spec_ch = None
+        for ef in efields:
+            if ef['channel'] != ch:
+                continue
+            new_trace = np.zeros((3, L))
+            start_time = ef['t0'] - times_min + st.cable_delay[ch] + 0
+            start_bin = int(round(start_time / res))
+            rem = start_time - start_bin * res
+            tr = freq2time(ef['spec'], fs)
+            # BaseTrace.apply_time_shift (base_trace.py:246-276)
+            if abs(round(rem * fs) - rem * fs) < 1e-5:
+                tr = np.roll(tr, int(round(rem * fs)), axis=-1)
+            else:
+                sp = time2freq(tr, fs)
+                sp = sp * np.exp(-2.j * np.pi * rem * np.fft.rfftfreq(N, res))
+                tr = freq2time(sp, fs)
+            stop_bin = start_bin + N
+            if stop_bin > L:
+                stop_bin = L
+                tr = tr[:, :stop_bin - start_bin]
+            if start_bin < 0:
+                tr = tr[:, -start_bin:]
+                start_bin = 0
+            new_trace[:, start_bin:stop_bin] = tr
+            efield_fft = time2freq(new_trace, fs)
+            Vt, Vp = antenna_response(st.antenna, ffL, ef['zenith'], ef['azimuth'], st.orientation)
+            v = Vt * efield_fft[1] + Vp * efield_fft[2]
+            v[ffL < 5 * units.MHz] = 0.
+            spec_ch = v if spec_ch is None else spec_ch + v
+        if spec_ch is not None:
+            V[ch] = freq2time(spec_ch * H, fs)
+    return V, times_min, L
+
+
+def threshold_trigger(V, threshold):
+    """simpleThreshold + highLowThreshold.get_majority_logic with number_concidences = 1: the sliding-window
+    reshaping there drops the LAST sample of the trace (num_frames = n - 1)."""
+    return bool(np.any(np.abs(V[:, :-1]) >= threshold))
+
+
+def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, vrms, vrms_efield, att_model='SP1',
+                   n_freq=25, model='Alvarez2009', filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0,
+                   min_efield_amplitude=2.0, rays=None):
+    """One single-shower event group through simulation.run()'s sequence (:1454-1600)."""
+    efs = sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model, n_freq, model,
+                                delta_C_cut, rays=rays)
+    out = dict(rays=efs, candidate=False, triggered=False, L=0, t_min=np.nan)
+    for ef in efs:
+        if ef['max_efield'] > min_efield_amplitude * vrms_efield:
+            out['candidate'] = True
+        ef['simch_spec'], ef['max_amp_ray'] = per_efield_voltage(ef, st, filters)
+    if not efs or not out['candidate']:
+        return out
+    V, t_min, L = combined_voltage(efs, st, filters)
+    out.update(V=V, t_min=t_min, L=L, triggered=threshold_trigger(V, trigger_sigma * vrms))
+    return out

@@ -1,0 +1,87 @@
+"""Golden vectors for the whole per-event hot path, produced by the reference's own functions.
+
+    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=tests/golden/gen/shims:/tmp/refcopy python tests/golden/gen/gen_chain.py
+
+Every event goes through refharness.simulate_event, i.e. simulation.calculate_sim_efield (simulation.py:93),
+apply_det_response_sim (:465), apply_det_response (:530) and trigger/simpleThreshold.py, on station S5
+(SURVEY.md section 8d): ray tracing -> Askaryan (Alvarez2009) -> attenuation / Fresnel -> per-efield voltages
+-> combined channel voltages on the event's common time grid -> Butterworth 80-500 MHz -> 3 Vrms threshold.
+"""
+import os
+import sys
+import time
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import refharness as rh  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+
+
+def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4, model='Alvarez2009',
+        antenna='analytic_VPol', cable_delay=0., rmax=4000.):
+    det = rh.StationS5(n_samples=N, fs=2.0, antenna=antenna, cable_delay=cable_delay)
+    cfg = rh.default_config(model=model)
+    ice, prop = rh.make_propagator(cfg, det)
+    vrms, vrms_e = rh.vrms_from_filters(cfg)
+    ev = rh.random_events(n_events, seed, energy=energy, rmax=rmax)
+    stype = np.array(['EM' if (em_every and i % em_every == 0) else 'HAD' for i in range(n_events)])
+    rays = []
+    evo = dict(candidate=np.zeros(n_events, bool), triggered=np.zeros(n_events, bool), L=np.zeros(n_events, np.int64),
+               t_min=np.full(n_events, np.nan), k_L=np.full(n_events, np.nan), n_rays=np.zeros(n_events, np.int32),
+               maxV=np.zeros((n_events, 5)), argmaxV=np.zeros((n_events, 5), np.int64), sumV2=np.zeros((n_events, 5)))
+    V_list, V_ev = [], []
+    spec_list, sim_list, full_idx = [], [], []
+    t0 = time.time()
+    for i in range(n_events):
+        sh = rh.make_shower(i, ev['vertex'][i], ev['zenith'][i], ev['azimuth'][i], ev['energy'][i], stype[i])
+        o = rh.simulate_event(i, sh, det, prop, ice, cfg, vrms, vrms_e)
+        evo['candidate'][i] = o['candidate']
+        evo['triggered'][i] = o['triggered']
+        evo['L'][i] = o['L']
+        evo['t_min'][i] = o['t_min']
+        evo['k_L'][i] = o['k_L']
+        evo['n_rays'][i] = len(o['rays'])
+        for r in o['rays']:
+            r['event'] = i
+            if len(full_idx) < full_rays:
+                full_idx.append(len(rays))
+                spec_list.append(r['spec'][1:])          # eTheta, ePhi after propagation effects
+                sim_list.append(r['simch_spec'])         # per-efield voltage spectrum after filters (N grid)
+            rays.append(r)
+        if 'V' in o:
+            V = o['V']
+            evo['maxV'][i] = np.max(np.abs(V), axis=1)
+            evo['argmaxV'][i] = np.argmax(np.abs(V), axis=1)
+            evo['sumV2'][i] = np.sum(V ** 2, axis=1)
+            if len(V_ev) < full_events:
+                V_ev.append(i)
+                V_list.append(V)
+    print(name, '%d events, %d rays, %d candidates, %d triggered, %.1f s' % (
+        n_events, len(rays), evo['candidate'].sum(), evo['triggered'].sum(), time.time() - t0))
+    R = {k: np.array([r[k] for r in rays]) for k in
+         ('event', 'channel', 'iS', 'C0', 'C1', 'type', 'zenith', 'azimuth', 'D', 'T', 'view', 'pol_angle', 'launch',
+          't0', 'r_theta', 'r_phi', 'max_efield', 'simch_t0', 'max_amp_ray')}
+    out = dict(N=N, fs=2.0, vrms=vrms, vrms_efield=vrms_e, ice=np.array([ice.n_ice, ice.delta_n, ice.z_0]),
+               att_model='SP1', n_freq=25, askaryan_model=model, antenna=antenna, cable_delay=cable_delay,
+               det_pos=det.pos, det_orientation=np.array(det.orientation), delta_C_cut=0.698,
+               trigger_sigma=3.0, min_efield_amplitude=2.0,
+               vertex=ev['vertex'], zenith=ev['zenith'], azimuth=ev['azimuth'], energy=ev['energy'],
+               shower_type=stype, full_ray_index=np.array(full_idx, np.int64),
+               full_spec=np.array(spec_list), full_simch=np.array(sim_list),
+               V_events=np.array(V_ev, np.int64), V_offsets=np.cumsum([0] + [v.shape[1] for v in V_list]),
+               V_concat=np.concatenate(V_list, axis=1) if V_list else np.zeros((5, 0)))
+    out.update({'ev_' + k: v for k, v in evo.items()})
+    out.update({'ray_' + k: v for k, v in R.items()})
+    np.savez_compressed(os.path.join(OUT, 'chain_%s.npz' % name), **out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['N256', 'N4096', 'N256_hpol']
+    if 'N256' in which:
+        run('N256', n_events=300, seed=21, N=256, full_rays=400, full_events=12)
+    if 'N4096' in which:
+        run('N4096', n_events=120, seed=22, N=4096, full_rays=6, full_events=3, rmax=2500.)
+    if 'N256_hpol' in which:  # HPol antennas + unequal cable delays: exercises ePhi, Fresnel r_s and the sub-sample shift
+        run('N256_hpol', n_events=150, seed=23, N=256, full_rays=200, full_events=8, antenna='analytic_HPol',
+            cable_delay=[0., 3.3, 7.77, 12.2, 19.8], rmax=2500.)

@@ -1,0 +1,102 @@
+"""The spectral oracle (oracle/spectral_oracle.py, numpy) against whole-chain outputs of the reference itself
+(tests/golden/chain_*.npz made by tests/golden/gen/gen_chain.py) and against the reference's own Askaryan golden
+vectors (NuRadioMC/test/SignalGen/reference_v2.npy).  CPU only.
+
+The ray-tracing launch parameters of the kept rays are taken from the fixture (the reference's values), so that
+this test isolates the spectral half: with identical (C0, D, T, launch) the voltages must agree to 1e-6.
+"""
+import numpy as np
+import pytest
+from conftest import golden
+from oracle import raytrace_oracle as rto
+from oracle import spectral_oracle as so
+
+
+def test_askaryan_reference_golden():
+    """U01unit_test.py: Alvarez2009 / Alvarez2000 time traces, assert_almost_equal (7 decimals) there."""
+    g = golden('ref_askaryan_v2.npz')
+    rng = np.random.RandomState(int(g['seed']))  # parametrizations.py:90-91: one generator per model
+    n = 0
+    for i in range(len(g['model'])):
+        model, st, E, th = str(g['model'][i]), str(g['shower_type'][i]), float(g['energy'][i]), float(g['theta'][i])
+        k_L = None
+        if model == 'Alvarez2009' and st == 'EM':
+            mean, sigma = so.alvarez2009_kL_distribution(E)
+            k_L = 10 ** rng.normal(mean, sigma)
+        tr, _ = so.askaryan_time_trace(E, th, int(g['N']), float(g['dt']), st, float(g['n_index']), float(g['R']),
+                                       model, k_L=k_L)
+        ref = g['trace'][i]
+        assert np.max(np.abs(tr - ref)) <= 1e-12 * max(np.max(np.abs(ref)), 1e-30), (model, st, E, th)
+        n += 1
+    assert n == 200
+
+
+def _station(g):
+    return so.Station(g['det_pos'], antenna=str(g['antenna']), orientation=tuple(g['det_orientation']),
+                      cable_delay=g['cable_delay'], n_samples=int(g['N']), fs=float(g['fs']))
+
+
+def _rays_with_reference_launch_parameters(g, ev, st, ice):
+    rays = rto.raytrace_batch(np.tile(g['vertex'][ev], (st.n_ch, 1)), st.pos, ice)
+    sel = np.where(g['ray_event'] == ev)[0]
+    for k in sel:
+        ch, s = int(g['ray_channel'][k]), int(g['ray_iS'][k])
+        if rays['n_sol'][ch] <= s:
+            return None, sel  # the reference's solution count differs here (its own first-root noise)
+        for key in ('C0', 'D', 'T', 'launch'):
+            rays[key][ch, s] = g['ray_' + key][k]
+        rays['receive'][ch, s] = so.spherical_to_cartesian(g['ray_zenith'][k], g['ray_azimuth'][k])
+    return rays, sel
+
+
+@pytest.mark.parametrize('name', ['N256', 'N256_hpol', 'N4096'])
+def test_chain_vs_reference(name):
+    g = golden('chain_%s.npz' % name)
+    st = _station(g)
+    ice = g['ice']
+    vrms, vrms_e = so.vrms_from_filters(st.fs)
+    assert vrms == float(g['vrms']) and vrms_e == float(g['vrms_efield'])
+    full = {int(k): i for i, k in enumerate(g['full_ray_index'])}
+    vev = {int(e): i for i, e in enumerate(g['V_events'])}
+    n_checked = n_trig = n_traces = 0
+    n_events = len(g['vertex']) if name != 'N4096' else 40
+    for ev in range(n_events):
+        rays, sel = _rays_with_reference_launch_parameters(g, ev, st, ice)
+        if rays is None:
+            continue
+        k_L = None if np.isnan(g['ev_k_L'][ev]) else float(g['ev_k_L'][ev])
+        if str(g['shower_type'][ev]) == 'EM' and k_L is None:
+            assert len(sel) == 0
+            continue
+        o = so.simulate_event(g['vertex'][ev], g['zenith'][ev], g['azimuth'][ev], g['energy'][ev],
+                              str(g['shower_type'][ev]), k_L, st, ice, vrms, vrms_e, rays=rays)
+        assert [(r['channel'], r['iS']) for r in o['rays']] == [(int(g['ray_channel'][k]), int(g['ray_iS'][k])) for k in sel]
+        for r, k in zip(o['rays'], sel):
+            assert abs(r['view'] - g['ray_view'][k]) < 1e-12
+            assert abs(np.arctan2(r['pol'][2], r['pol'][1]) - g['ray_pol_angle'][k]) < 1e-9
+            assert abs(r['zenith'] - g['ray_zenith'][k]) < 1e-9 and abs(r['azimuth'] - g['ray_azimuth'][k]) < 1e-9
+            assert abs(r['t0'] - g['ray_t0'][k]) < 1e-9
+            assert abs(r['r_theta'] - g['ray_r_theta'][k]) < 1e-9 and abs(r['r_phi'] - g['ray_r_phi'][k]) < 1e-9
+            assert abs(r['max_efield'] - g['ray_max_efield'][k]) <= 1e-6 * g['ray_max_efield'][k]
+            assert abs(r['max_amp_ray'] - g['ray_max_amp_ray'][k]) <= 1e-6 * g['ray_max_amp_ray'][k]
+            if int(k) in full:
+                ref = g['full_spec'][full[int(k)]]
+                assert np.max(np.abs(r['spec'][1:] - ref)) <= 1e-6 * np.max(np.abs(ref))
+                ref = g['full_simch'][full[int(k)]]
+                assert np.max(np.abs(r['simch_spec'] - ref)) <= 1e-6 * np.max(np.abs(ref))
+            n_checked += 1
+        assert o['candidate'] == bool(g['ev_candidate'][ev])
+        assert o['triggered'] == bool(g['ev_triggered'][ev])
+        if o['candidate']:
+            assert o['L'] == int(g['ev_L'][ev])
+            assert abs(o['t_min'] - g['ev_t_min'][ev]) < 1e-9
+            mv = np.max(np.abs(o['V']), axis=1)
+            assert np.all(np.abs(mv - g['ev_maxV'][ev]) <= 1e-6 * np.max(g['ev_maxV'][ev]))
+            if ev in vev:
+                i = vev[ev]
+                ref = g['V_concat'][:, g['V_offsets'][i]:g['V_offsets'][i + 1]]
+                assert np.max(np.abs(o['V'] - ref)) <= 1e-6 * np.max(np.abs(ref))
+                n_traces += 1
+        n_trig += o['triggered']
+    assert n_checked > 50 and n_traces >= 1
+    print(name, 'rays checked', n_checked, 'triggered', n_trig, 'full traces', n_traces)
