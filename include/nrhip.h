@@ -96,6 +96,86 @@ int nrhip_attenuation_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, co
  * replacing wrapper.pyx get_attenuation_length (:33-34); elementwise over n values.  HOST.         */
 int nrhip_attenuation_length(nrhip_ctx* ctx, int64_t n, const double* z, const double* freq, double* L);
 
+/* ---- Askaryan emission ------------------------------------------------------------------------------
+ * Batched askaryan.get_frequency_spectrum(energy, theta, N, dt, shower_type, n_index, R, model, k_L=...)
+ * (NuRadioMC/SignalGen/askaryan.py:143-213 -> parametrizations.py:29-278): spectrum is [n][N/2+1] complex
+ * (interleaved re, im).  shower_type NRHIP_SHOWER_*, model NRHIP_ASK_*; k_L is read for Alvarez2009 EM
+ * showers only (the random draw of parametrizations.py:160-173 stays on the host).  All pointers HOST.   */
+int nrhip_askaryan_spectrum_batch(nrhip_ctx* ctx, int64_t n, const double* energy, const double* theta,
+                                  const int32_t* shower_type, const double* n_index, const double* R,
+                                  const double* k_L, int32_t model, int32_t N, double dt, double* spectrum);
+
+/* ---- station + whole hot path -----------------------------------------------------------------------
+ * A station is the flat-array form of what the reference reads from `det` for one station
+ * (get_relative_position / get_cable_delay / get_antenna_model / get_antenna_orientation /
+ * get_number_of_samples / get_sampling_frequency), plus the analog filter chain that the user's
+ * _detector_simulation_filter_amp applies (NuRadioMC/examples/01_Veff_simulation/T02RunSimulation.py:18-22)
+ * as rational responses polyval(b, j f) / polyval(a, j f), coefficients highest power first, rows of
+ * NRHIP_MAX_POLY doubles.                                                                                */
+#define NRHIP_MAX_POLY 24
+#define NRHIP_MAX_FILTERS 4
+
+typedef struct {
+    int32_t n_channels;
+    const double* position;       /* [n_channels][3]  relative + absolute station position             */
+    const double* cable_delay;    /* [n_channels]                                                       */
+    const int32_t* antenna_model; /* [n_channels]     NRHIP_ANT_*                                       */
+    const double* orientation;    /* [n_channels][4]  orientation theta, phi, rotation theta, phi [rad] */
+    int32_t n_samples;            /* N: samples per simulated trace at the internal sampling rate (even) */
+    double sampling_rate;         /* internal sampling rate [GHz]                                       */
+    double readout_length;        /* longest detector readout window [ns] (n_samples / sampling frequency) */
+    double pre_pulse_time;        /* efieldToVoltageConverter.begin(pre_pulse_time = 200 ns)            */
+    double post_pulse_time;       /* efieldToVoltageConverter.begin(post_pulse_time = 400 ns)           */
+    int32_t n_att_freq;           /* coarse attenuation grid (analyticraytracing.py:885-931)            */
+    const double* att_freq;
+    int32_t n_filters;
+    const int32_t* filter_nb;
+    const int32_t* filter_na;
+    const double* filter_b;       /* [n_filters][NRHIP_MAX_POLY]                                        */
+    const double* filter_a;
+} nrhip_station_desc;
+
+typedef struct {
+    int32_t askaryan_model;       /* NRHIP_ASK_*                                                        */
+    double delta_C_cut;           /* config speedup.delta_C_cut [rad]                                   */
+    double min_efield_amplitude;  /* absolute candidate cut [V/m] = speedup.min_efield_amplitude * Vrms_efield */
+    double trigger_threshold;     /* simple threshold [V] on any channel                                */
+    int32_t dump_traces;          /* != 0: keep the channel voltage traces of the chunk for nrhip_sim_fetch */
+} nrhip_sim_config;
+
+typedef struct {
+    int64_t n_events, n_pairs, n_rays, n_candidate_events, n_triggered, n_channel_items, n_distinct_lengths;
+    int32_t max_length;
+} nrhip_sim_stats;
+
+typedef struct nrhip_station nrhip_station;
+
+int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* desc, nrhip_station** out);
+void nrhip_station_destroy(nrhip_station* st);
+
+/* The per-event hot path for single-shower event groups, in the order of simulation.run()
+ * (NuRadioMC/simulation/simulation.py:1454-1600): for every channel calculate_sim_efield (:93-292: ray
+ * tracing, delta_C cut, Askaryan spectrum, polarisation, attenuation, Fresnel, candidate cut), then
+ * efieldToVoltageConverter.run (efieldToVoltageConverter.py:111-345) on the event's common time grid, the
+ * filter chain and a simple threshold trigger (trigger/simpleThreshold.py).
+ * Event inputs are DEV pointers (resident in HBM): vertex [n][3], zenith / azimuth of the shower axis,
+ * shower energy, shower_type (int32), k_L.  triggered is a DEV uint8 [n] mask.  stats is HOST (may be NULL). */
+int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_config* cfg, int64_t n_events,
+                          const double* vertex, const double* zenith, const double* azimuth,
+                          const double* energy, const int32_t* shower_type, const double* k_L,
+                          uint8_t* triggered, nrhip_sim_stats* stats);
+
+/* Copy one intermediate table of the LAST nrhip_simulate_events call to HOST memory (parity tests,
+ * output writers).  Names: ray_event ray_channel ray_solution ray_view ray_pol_theta ray_pol_phi ray_zenith
+ * ray_azimuth ray_t0 ray_r_theta ray_r_phi ray_att ray_max_efield ray_C0 ray_D (int32 / double / complex);
+ * ev_n_rays ev_L ev_candidate ev_t_min; item_event item_maxV trace_offset trace.
+ * Returns the number of bytes available (>= 0) or < 0; copies min(bytes, available).                     */
+int64_t nrhip_sim_fetch(nrhip_station* st, const char* name, void* host_dst, uint64_t bytes);
+
+/* test hook for the in-LDS chirp-z transform: out[b][k] = sum_j in[b][j] exp(sgn 2 pi i j k / Q). HOST. */
+int nrhip_debug_czt(nrhip_ctx* ctx, int32_t n_batch, int32_t n_in, int32_t n_out, int32_t Q, double sgn,
+                    const double* in, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,7 @@
 import ctypes
 import numpy as np
 from . import _lib as L
+from . import station as _station  # noqa: F401  (registers the station entry points)
 
 #: NuRadioMC/utilities/attenuation.py:14
 ATTENUATION_MODEL_TO_INT = {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4}
@@ -33,6 +34,63 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    # ---- device memory ---------------------------------------------------------------------------
+    def malloc(self, nbytes):
+        p = ctypes.c_void_p()
+        L.check(self._lib.nrhip_malloc(self._h, int(nbytes), ctypes.byref(p)))
+        return p.value
+
+    def free(self, dev_ptr):
+        L.check(self._lib.nrhip_free(self._h, ctypes.c_void_p(dev_ptr)))
+
+    def to_device(self, a):
+        a = np.ascontiguousarray(a)
+        p = self.malloc(max(a.nbytes, 8))
+        if a.nbytes:
+            L.check(self._lib.nrhip_memcpy_h2d(self._h, ctypes.c_void_p(p), a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+        return p
+
+    def to_host(self, out, dev_ptr):
+        if out.nbytes:
+            L.check(self._lib.nrhip_memcpy_d2h(self._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(dev_ptr),
+                                               out.nbytes))
+        return out
+
+    def synchronize(self):
+        L.check(self._lib.nrhip_synchronize(self._h))
+
+    # ---- Askaryan --------------------------------------------------------------------------------
+    def askaryan_spectrum_batch(self, energy, theta, N, dt, shower_type, n_index, R, model, k_L=None):
+        """[n, N/2+1] complex spectra of askaryan.get_frequency_spectrum for arrays of showers / viewing angles."""
+        from .station import ASKARYAN_TO_INT, SHOWER_TO_INT
+        if model not in ASKARYAN_TO_INT:
+            raise NotImplementedError("model {} unknown".format(model))
+        energy, theta, n_index, R = np.broadcast_arrays(L.f64(energy), L.f64(theta), L.f64(n_index), L.f64(R))
+        n = energy.size
+        st = np.broadcast_to(shower_type, energy.shape).reshape(-1)
+        sti = np.zeros(n, np.int32)
+        for i, s in enumerate(st):
+            s = str(s).upper()
+            if s not in SHOWER_TO_INT:
+                raise NotImplementedError("shower type {} is not implemented in {} model.".format(s, model))
+            sti[i] = SHOWER_TO_INT[s]
+        kL = np.ascontiguousarray(np.broadcast_to(1.0 if k_L is None else L.f64(k_L), energy.shape).reshape(-1), float)
+        if model == 'Alvarez2009' and k_L is None and np.any(sti == 1):
+            raise ValueError("Alvarez2009 EM showers need k_L (the random draw stays on the host)")
+        out = np.zeros((n, N // 2 + 1), np.complex128)
+        a = [np.ascontiguousarray(v.reshape(-1), float) for v in (energy, theta, n_index, R)]
+        L.check(self._lib.nrhip_askaryan_spectrum_batch(self._h, n, L.dptr(a[0]), L.dptr(a[1]), L.iptr(sti), L.dptr(a[2]),
+                                                        L.dptr(a[3]), L.dptr(kL), ASKARYAN_TO_INT[model], int(N), float(dt),
+                                                        out.ctypes.data_as(L.c_double_p)))
+        return out
+
+    def debug_czt(self, x, n_out, Q, sgn):
+        x = np.ascontiguousarray(x, np.complex128).reshape(-1, x.shape[-1])
+        out = np.zeros((x.shape[0], n_out), np.complex128)
+        L.check(self._lib.nrhip_debug_czt(self._h, x.shape[0], x.shape[1], n_out, int(Q), float(sgn),
+                                          x.ctypes.data_as(L.c_double_p), out.ctypes.data_as(L.c_double_p)))
+        return out
 
     # ---- ray tracing -----------------------------------------------------------------------------
     def find_solutions_batch(self, x1, x2, outer=False):

@@ -1,6 +1,7 @@
 // api.hip -- C-ABI layer of libnrhip.so (see include/nrhip.h for the contract).
 #include "../../include/nrhip.h"
 #include "nrhip_internal.h"
+#include "ctx.h"
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -8,35 +9,22 @@
 namespace nrhip {
 void launch_ray_limits(hipStream_t stream, long n_rays, const double* x1, const double* x2, const double* C0,
                        const IceConst& m, double* zint);
-void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
-                              const double* freqs, int model, const IceConst& m, double* att, int* neval);
 void launch_attenuation_length(hipStream_t stream, long n, const double* z, const double* f, int model, double* L);
 }  // namespace nrhip
 
 static thread_local char g_err[512] = "";
 
-static int fail(const char* what, hipError_t e)
+int nrhip_fail(const char* what, hipError_t e)
 {
     snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
     return -1;
 }
-static int fail_msg(const char* what)
+int nrhip_fail_msg(const char* what)
 {
     snprintf(g_err, sizeof g_err, "%s", what);
     return -2;
 }
-#define HIPCHK(x)                                   \
-    do {                                            \
-        hipError_t e_ = (x);                        \
-        if (e_ != hipSuccess) return fail(#x, e_);  \
-    } while (0)
-
-struct nrhip_ctx {
-    int device;
-    hipStream_t stream;
-    nrhip::IceConst ice;
-    int att_model;
-};
+static int fail_msg(const char* what) { return nrhip_fail_msg(what); }
 
 // RAII device buffer for the host-pointer convenience entry points
 struct DevBuf {
@@ -75,7 +63,7 @@ int nrhip_ctx_create(int device, double n_ice, double delta_n, double z_0, int a
     hipError_t e = hipStreamCreate(&c->stream);
     if (e != hipSuccess) {
         delete c;
-        return fail("hipStreamCreate", e);
+        return nrhip_fail("hipStreamCreate", e);
     }
     *out = c;
     return 0;
@@ -87,6 +75,7 @@ void nrhip_ctx_destroy(nrhip_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->twiddle) (void)hipFree(ctx->twiddle);
     delete ctx;
 }
 

@@ -1,0 +1,55 @@
+// ctx.h -- the opaque context / station objects behind include/nrhip.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "spectral.h"
+
+struct nrhip_ctx {
+    int device;
+    hipStream_t stream;
+    nrhip::IceConst ice;
+    int att_model;
+    double2* twiddle = nullptr;  // exp(-2 pi i k / FFT_MAX), k < FFT_MAX / 2
+};
+
+int nrhip_fail(const char* what, hipError_t e);
+int nrhip_fail_msg(const char* what);
+#define HIPCHK(x)                                         \
+    do {                                                  \
+        hipError_t e_ = (x);                              \
+        if (e_ != hipSuccess) return nrhip_fail(#x, e_);  \
+    } while (0)
+
+// grow-only device buffer
+struct DevArray {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct nrhip_station {
+    nrhip_ctx* ctx;
+    nrhip::StationDev dev;
+    nrhip::FilterSet filters;
+    std::vector<double> h_pos, h_cable;
+    DevArray d_pos, d_cable, d_model, d_rot, d_rot_inv, d_fc;
+    // workspace of the last simulated chunk (kept for nrhip_sim_fetch and reused between calls)
+    std::map<std::string, DevArray> ws;
+    std::map<std::string, size_t> ws_bytes;  // valid bytes of the last chunk
+    std::vector<int> h_lengths;              // distinct trace lengths of the last chunk
+    DevArray& buf(const std::string& name) { return ws[name]; }
+};

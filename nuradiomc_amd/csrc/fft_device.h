@@ -1,0 +1,110 @@
+// fft_device.h -- block-cooperative complex128 FFTs and chirp-z transforms held entirely in LDS.
+//
+// MI355X (gfx950): 160 KB LDS per CU holds one 8192-point complex128 working set (128 KB), so a whole
+// arbitrary-length DFT (Bluestein: chirp multiply -> FFT -> pointwise multiply -> inverse FFT -> chirp
+// multiply) runs without touching HBM for intermediates.  The event-dependent trace length L of
+// efieldToVoltageConverter (NuRadioReco/modules/efieldToVoltageConverter.py:147-169, e.g. 5296 =
+// 2^4 * 331) is therefore never an FFT "plan" parameter: every L uses the same power-of-two kernels and
+// only a per-L chirp table (built on device, fft tables.hip) differs.
+//
+// Radix-2 decimation-in-frequency forward (natural -> bit-reversed) paired with decimation-in-time
+// inverse (bit-reversed -> natural): the pointwise product of a convolution happens in bit-reversed
+// order on both operands, so no reordering pass exists.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nrhip {
+
+constexpr int FFT_LOG2_MAX = 13;
+constexpr int FFT_MAX = 1 << FFT_LOG2_MAX;  // 8192 complex128 = 128 KB of LDS
+
+__device__ inline double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ inline double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ inline double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ inline double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+__device__ inline double2 cscale(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
+
+// tw[k] = exp(-2 pi i k / FFT_MAX), k < FFT_MAX / 2 (global memory, L1/L2 resident, built on the host in
+// extended precision).  Twiddle of a sub-size M transform: W_M^p = tw[p * (FFT_MAX / M)].
+// Decimation in frequency: natural-order input, bit-reversed output.  inverse -> conjugate twiddles (no 1/M).
+__device__ inline void fft_dif(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
+{
+    const int M = 1 << log2m;
+    for (int s = 0; s < log2m; s++) {
+        const int span = M >> (s + 1);
+        const int tstride = (FFT_MAX / 2) / span;
+        for (int t = threadIdx.x; t < M / 2; t += blockDim.x) {
+            int pos = t & (span - 1);
+            int i0 = ((t - pos) << 1) + pos, i1 = i0 + span;
+            double2 a = x[i0], b = x[i1];
+            double2 w = tw[pos * tstride];
+            if (inverse) w.y = -w.y;
+            x[i0] = cadd(a, b);
+            x[i1] = cmul(csub(a, b), w);
+        }
+        __syncthreads();
+    }
+}
+
+// Decimation in time: bit-reversed input, natural-order output.
+__device__ inline void fft_dit(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
+{
+    const int M = 1 << log2m;
+    for (int s = 0; s < log2m; s++) {
+        const int span = 1 << s;
+        const int tstride = (FFT_MAX / 2) / span;
+        for (int t = threadIdx.x; t < M / 2; t += blockDim.x) {
+            int pos = t & (span - 1);
+            int i0 = ((t - pos) << 1) + pos, i1 = i0 + span;
+            double2 w = tw[pos * tstride];
+            if (inverse) w.y = -w.y;
+            double2 a = x[i0], b = cmul(x[i1], w);
+            x[i0] = cadd(a, b);
+            x[i1] = csub(a, b);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ inline int bitrev(int i, int log2m) { return (int)(__brev((unsigned)i) >> (32 - log2m)); }
+
+// exp(sgn * i pi n^2 / Q) with the phase reduced exactly in integers (n^2 mod 2Q) before sincospi
+__device__ inline double2 chirp(long long n, long long Q, double sgn)
+{
+    long long r = (n * n) % (2 * Q);
+    double s, c;
+    sincospi((double)r / (double)Q, &s, &c);
+    return make_double2(c, sgn * s);
+}
+
+// Bluestein kernel table for out[k] = sum_{j < n_in} in[j] exp(sgn 2 pi i j k / Q'), k < n_out, where the
+// exponent is written sgn * i pi (2 j k) / Q with Q = Q' :  2jk = j^2 + k^2 - (k - j)^2.
+// b[n] = conj(chirp(n)) for n in [-(n_in - 1), n_out - 1] (index n mod M), zero elsewhere; returns FFT(b) in
+// bit-reversed order in x (LDS).  Needs M >= n_in + n_out - 1.
+__device__ inline void czt_build_table(double2* x, int log2m, int n_in, int n_out, long long Q, double sgn,
+                                       const double2* __restrict__ tw)
+{
+    const int M = 1 << log2m;
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        double2 v = make_double2(0., 0.);
+        if (i < n_out) v = cconj(chirp(i, Q, sgn));
+        else if (i > M - n_in) v = cconj(chirp((long long)(M - i), Q, sgn));
+        x[i] = v;
+    }
+    __syncthreads();
+    fft_dif(x, log2m, tw, false);
+}
+
+// x holds in[j] * chirp(j) for j < n_in and zeros up to M (caller fills, then __syncthreads()).
+// On return x[k] = (1 / M-scaled) convolution; the caller multiplies by chirp(k) and 1/M when reading.
+__device__ inline void czt_convolve(double2* x, int log2m, const double2* __restrict__ Btab,
+                                    const double2* __restrict__ tw)
+{
+    const int M = 1 << log2m;
+    fft_dif(x, log2m, tw, false);
+    for (int i = threadIdx.x; i < M; i += blockDim.x) x[i] = cmul(x[i], Btab[i]);
+    __syncthreads();
+    fft_dit(x, log2m, tw, true);
+}
+
+}  // namespace nrhip

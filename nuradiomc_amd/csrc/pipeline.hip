@@ -1,0 +1,426 @@
+// pipeline.hip -- host orchestration of the per-event hot path and its C-ABI entry points.
+//
+// All event data stays resident in HBM; one call processes the whole batch (1e6 events of a 5-channel station
+// need ~4 GB of the 288 GB).  Two small device->host hand-offs per call size the later launches: the number
+// of kept rays (4 B) and the per-event trace length + candidate flag (5 B per event), from which the host builds
+// the list of distinct trace lengths (each needs one chirp table, built on device).
+#include "../../include/nrhip.h"
+#include "ctx.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace nrhip;
+
+static int ensure_twiddle(nrhip_ctx* ctx)
+{
+    if (ctx->twiddle) return 0;
+    std::vector<double2> h(FFT_MAX / 2);
+    for (int k = 0; k < FFT_MAX / 2; k++) {
+        long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)FFT_MAX;
+        h[k] = make_double2((double)cosl(a), (double)sinl(a));
+    }
+    HIPCHK(hipMalloc((void**)&ctx->twiddle, sizeof(double2) * h.size()));
+    HIPCHK(hipMemcpyAsync(ctx->twiddle, h.data(), sizeof(double2) * h.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static void sph2cart_h(double zen, double az, double v[3])
+{
+    v[0] = std::sin(zen) * std::cos(az);
+    v[1] = std::sin(zen) * std::sin(az);
+    v[2] = std::cos(zen);
+}
+static void cross_h(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static bool inv3(const double A[9], double o[9])
+{
+    double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+    if (std::fabs(det) < 1e-12) return false;
+    double id = 1.0 / det;
+    o[0] = (A[4] * A[8] - A[5] * A[7]) * id;
+    o[1] = (A[2] * A[7] - A[1] * A[8]) * id;
+    o[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    o[3] = (A[5] * A[6] - A[3] * A[8]) * id;
+    o[4] = (A[0] * A[8] - A[2] * A[6]) * id;
+    o[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    o[6] = (A[3] * A[7] - A[4] * A[6]) * id;
+    o[7] = (A[1] * A[6] - A[0] * A[7]) * id;
+    o[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+    return true;
+}
+static void mat3mul(const double A[9], const double B[9], double o[9])
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) o[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+template <class T>
+static int upload(nrhip_ctx* ctx, DevArray& d, const T* h, size_t n)
+{
+    HIPCHK(d.reserve(n * sizeof(T)));
+    HIPCHK(hipMemcpyAsync(d.p, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+extern "C" {
+
+int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_station** out)
+{
+    if (!ctx || !d || !out) return nrhip_fail_msg("nrhip_station_create: NULL argument");
+    if (d->n_channels <= 0) return nrhip_fail_msg("nrhip_station_create: station has no channels");
+    if (d->n_samples <= 0 || d->n_samples % 2 != 0)
+        return nrhip_fail_msg("nrhip_station_create: traces must have an even number of samples");
+    int nh = d->n_samples / 2;
+    if ((nh & (nh - 1)) != 0 || nh < 8 || nh > FFT_MAX / 2)
+        return nrhip_fail_msg("nrhip_station_create: n_samples must be a power of two between 16 and 8192");
+    if (d->n_att_freq <= 0 || d->n_att_freq > NRHIP_MAX_NFC) return nrhip_fail_msg("nrhip_station_create: bad n_att_freq");
+    if (d->n_filters < 0 || d->n_filters > NRHIP_MAX_FILTERS) return nrhip_fail_msg("nrhip_station_create: too many filters");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ensure_twiddle(ctx)) return -1;
+    nrhip_station* s = new nrhip_station();
+    s->ctx = ctx;
+    int n = d->n_channels;
+    std::vector<double> rot(9 * n), roti(9 * n);
+    // model frame of the analytic antennas: boresight (0, 0), tines normal (90 deg, 0) (antennapattern.py:1612-1636)
+    double e1[3], e2[3], e3[3];
+    sph2cart_h(0., 0., e1);
+    sph2cart_h(90 * 0.017453292519943295, 0., e2);
+    cross_h(e1, e2, e3);
+    double E[9] = {e1[0], e1[1], e1[2], e2[0], e2[1], e2[2], e3[0], e3[1], e3[2]}, Ei[9];
+    if (!inv3(E, Ei)) { delete s; return nrhip_fail_msg("nrhip_station_create: singular antenna model frame"); }
+    for (int c = 0; c < n; c++) {
+        if (d->antenna_model[c] != NRHIP_ANT_VPOL && d->antenna_model[c] != NRHIP_ANT_HPOL) {
+            delete s;
+            return nrhip_fail_msg("nrhip_station_create: antenna model not implemented (analytic_VPol, analytic_HPol)");
+        }
+        const double* o = d->orientation + 4 * c;
+        double a1[3], a2[3], a3[3];
+        sph2cart_h(o[0], o[1], a1);
+        sph2cart_h(o[2], o[3], a2);
+        cross_h(a1, a2, a3);
+        double nrm = std::sqrt(a3[0] * a3[0] + a3[1] * a3[1] + a3[2] * a3[2]);
+        if (nrm < 0.9) {  // antennapattern.py:1209-1211
+            delete s;
+            return nrhip_fail_msg("orientation of antenna not properly defined detector description");
+        }
+        double A[9] = {a1[0], a1[1], a1[2], a2[0], a2[1], a2[2], a3[0], a3[1], a3[2]};
+        mat3mul(Ei, A, &rot[9 * c]);
+        if (!inv3(&rot[9 * c], &roti[9 * c])) { delete s; return nrhip_fail_msg("nrhip_station_create: singular antenna rotation"); }
+    }
+    s->h_pos.assign(d->position, d->position + 3 * n);
+    s->h_cable.assign(d->cable_delay, d->cable_delay + n);
+    if (upload(ctx, s->d_pos, d->position, 3 * n) || upload(ctx, s->d_cable, d->cable_delay, n) ||
+        upload(ctx, s->d_model, d->antenna_model, n) || upload(ctx, s->d_rot, rot.data(), 9 * n) ||
+        upload(ctx, s->d_rot_inv, roti.data(), 9 * n) || upload(ctx, s->d_fc, d->att_freq, d->n_att_freq)) {
+        delete s;
+        return -1;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    StationDev& v = s->dev;
+    v.n_ch = n;
+    v.N = d->n_samples;
+    v.n_fc = d->n_att_freq;
+    v.fs = d->sampling_rate;
+    v.pre_pulse = d->pre_pulse_time;
+    v.post_pulse = d->post_pulse_time;
+    v.readout_length = d->readout_length;
+    v.pos = s->d_pos.as<double>();
+    v.cable = s->d_cable.as<double>();
+    v.ant_model = s->d_model.as<int>();
+    v.rot = s->d_rot.as<double>();
+    v.rot_inv = s->d_rot_inv.as<double>();
+    v.fcoarse = s->d_fc.as<double>();
+    FilterSet& f = s->filters;
+    memset(&f, 0, sizeof f);
+    f.n = d->n_filters;
+    for (int i = 0; i < f.n; i++) {
+        f.nb[i] = d->filter_nb[i];
+        f.na[i] = d->filter_na[i];
+        if (f.nb[i] < 1 || f.nb[i] > NRHIP_MAX_POLY || f.na[i] < 1 || f.na[i] > NRHIP_MAX_POLY) {
+            delete s;
+            return nrhip_fail_msg("nrhip_station_create: filter polynomial too long");
+        }
+        memcpy(f.b[i], d->filter_b + (size_t)i * NRHIP_MAX_POLY, sizeof(double) * f.nb[i]);
+        memcpy(f.a[i], d->filter_a + (size_t)i * NRHIP_MAX_POLY, sizeof(double) * f.na[i]);
+    }
+    *out = s;
+    return 0;
+}
+
+void nrhip_station_destroy(nrhip_station* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    for (auto& kv : s->ws) kv.second.release();
+    s->d_pos.release(); s->d_cable.release(); s->d_model.release();
+    s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release();
+    delete s;
+}
+
+#define WS(name, type, count)                                                                       \
+    ([&]() -> type* {                                                                               \
+        DevArray& b_ = st->buf(name);                                                               \
+        if (b_.reserve((size_t)(count) * sizeof(type) + 16) != hipSuccess) return (type*)nullptr;   \
+        st->ws_bytes[name] = (size_t)(count) * sizeof(type);                                        \
+        return b_.as<type>();                                                                       \
+    })()
+#define NEED(ptr) if (!(ptr)) return nrhip_fail_msg("nrhip_simulate_events: out of device memory")
+
+int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_config* cfg, int64_t n_events,
+                          const double* vertex, const double* zenith, const double* azimuth, const double* energy,
+                          const int32_t* shower_type, const double* k_L, uint8_t* triggered, nrhip_sim_stats* stats)
+{
+    if (!ctx || !st || !cfg) return nrhip_fail_msg("nrhip_simulate_events: NULL argument");
+    if (st->ctx != ctx) return nrhip_fail_msg("nrhip_simulate_events: station belongs to another context");
+    if (n_events < 0) return nrhip_fail_msg("nrhip_simulate_events: negative size");
+    if (cfg->askaryan_model < 0 || cfg->askaryan_model > 2)
+        return nrhip_fail_msg("nrhip_simulate_events: Askaryan model not implemented");
+    nrhip_sim_stats S;
+    memset(&S, 0, sizeof S);
+    S.n_events = n_events;
+    st->ws_bytes.clear();
+    if (stats) *stats = S;
+    if (n_events == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t sm = ctx->stream;
+    const StationDev& sd = st->dev;
+    const int n_ch = sd.n_ch;
+    const long n_pairs = n_events * n_ch, n_slots = n_pairs * NRHIP_MAXS;
+    if (n_slots > 2000000000L) return nrhip_fail_msg("nrhip_simulate_events: batch too large, split the event list");
+    S.n_pairs = n_pairs;
+    HIPCHK(hipMemsetAsync(triggered, 0, n_events, sm));
+
+    // 1. ray tracing for every (event, channel) pair
+    RayRecords rec;
+    NEED(rec.n_sol = WS("pair_n_sol", int, n_pairs));
+    NEED(rec.type = WS("slot_type", int, n_slots));
+    NEED(rec.C0 = WS("slot_C0", double, n_slots));
+    NEED(rec.C1 = WS("slot_C1", double, n_slots));
+    NEED(rec.D = WS("slot_D", double, n_slots));
+    NEED(rec.T = WS("slot_T", double, n_slots));
+    NEED(rec.launch = WS("slot_launch", double, 3 * n_slots));
+    NEED(rec.receive = WS("slot_receive", double, 3 * n_slots));
+    NEED(rec.refl_angle = WS("slot_refl_angle", double, n_slots));
+    launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec);
+
+    // 2. delta_C cut -> ordered list of kept rays
+    int *keep, *offset;
+    NEED(keep = WS("slot_keep", int, n_slots + 1));
+    NEED(offset = WS("slot_offset", int, n_slots + 1));
+    HIPCHK(hipMemsetAsync(keep + n_slots, 0, sizeof(int), sm));
+    launch_select_rays(sm, n_pairs, n_ch, vertex, zenith, azimuth, rec, ctx->ice, cfg->delta_C_cut, keep);
+    size_t tmp_bytes = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, keep, offset, (int)(n_slots + 1), sm));
+    void* tmp;
+    NEED(tmp = WS("scan_tmp", unsigned char, tmp_bytes));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, keep, offset, (int)(n_slots + 1), sm));
+    int n_rays = 0;
+    HIPCHK(hipMemcpyAsync(&n_rays, offset + n_slots, sizeof(int), hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipStreamSynchronize(sm));
+    S.n_rays = n_rays;
+
+    EventOut ev;
+    NEED(ev.n_rays = WS("ev_n_rays", int, n_events));
+    NEED(ev.ray_begin = WS("ev_ray_begin", int, n_events));
+    NEED(ev.L = WS("ev_L", int, n_events));
+    NEED(ev.candidate = WS("ev_candidate", unsigned char, n_events));
+    NEED(ev.t_min = WS("ev_t_min", double, n_events));
+    EventIn evin{energy, shower_type, k_L};
+
+    RayWork w;
+    const size_t nr = (size_t)std::max(n_rays, 1);
+    int* ray_slot;
+    NEED(ray_slot = WS("ray_slot", int, nr));
+    NEED(w.ev = WS("ray_event", int, nr));
+    NEED(w.ch = WS("ray_channel", int, nr));
+    NEED(w.sol = WS("ray_solution", int, nr));
+    NEED(w.slot = WS("ray_slot2", int, nr));
+    NEED(w.view = WS("ray_view", double, nr));
+    NEED(w.n_index = WS("ray_n_index", double, nr));
+    NEED(w.R = WS("ray_D", double, nr));
+    NEED(w.t0 = WS("ray_t0", double, nr));
+    NEED(w.C0 = WS("ray_C0", double, nr));
+    NEED(w.pol_theta = WS("ray_pol_theta", double, nr));
+    NEED(w.pol_phi = WS("ray_pol_phi", double, nr));
+    NEED(w.r_theta = WS("ray_r_theta", double2, nr));
+    NEED(w.r_phi = WS("ray_r_phi", double2, nr));
+    NEED(w.zen = WS("ray_zenith", double, nr));
+    NEED(w.az = WS("ray_azimuth", double, nr));
+    NEED(w.vel_T = WS("ray_vel_T", double, 4 * nr));
+    NEED(w.theta_ant = WS("ray_theta_ant", double, nr));
+    NEED(w.att = WS("ray_att", double, nr * sd.n_fc));
+    double *zint, *max_efield;
+    NEED(zint = WS("ray_zint", double, 3 * nr));
+    NEED(max_efield = WS("ray_max_efield", double, nr));
+
+    if (n_rays > 0) {
+        launch_scatter_slots(sm, n_slots, keep, offset, ray_slot);
+        launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w);
+        // 3. attenuation on the coarse frequency grid
+        launch_ray_limits_from_slots(sm, n_rays, n_ch, ray_slot, vertex, sd.pos, rec, ctx->ice, zint);
+        launch_attenuation_items(sm, n_rays, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr);
+        // 4. candidate cut on max |E(t)|
+        launch_efield_max(sm, n_rays, w, evin, sd, cfg->askaryan_model, ctx->twiddle, max_efield);
+    }
+    // 5. common time grid per event
+    launch_event_grid(sm, (int)n_events, n_ch, offset, w, sd, max_efield, cfg->min_efield_amplitude, ev);
+    HIPCHK(hipGetLastError());
+    std::vector<int> hL(n_events);
+    std::vector<unsigned char> hc(n_events);
+    HIPCHK(hipMemcpyAsync(hL.data(), ev.L, sizeof(int) * n_events, hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipMemcpyAsync(hc.data(), ev.candidate, n_events, hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipStreamSynchronize(sm));
+
+    // host: candidate event list, distinct trace lengths
+    std::vector<int> cand;
+    cand.reserve(n_events / 8 + 16);
+    int maxL = 0;
+    for (int64_t e = 0; e < n_events; e++)
+        if (hc[e]) {
+            cand.push_back((int)e);
+            maxL = std::max(maxL, hL[e]);
+        }
+    S.n_candidate_events = (int64_t)cand.size();
+    S.max_length = maxL;
+    st->h_lengths.clear();
+    if (!cand.empty()) {
+        const int nh = sd.N / 2;
+        const int m_max = std::min(FFT_MAX - nh + 1, NRHIP_SPEC_STRIDE - 1);
+        if (maxL / 2 > m_max)
+            return nrhip_fail_msg("nrhip_simulate_events: an event's common trace is longer than the 8192-point chirp-z supports");
+        std::vector<int> lens;
+        lens.reserve(cand.size());
+        for (int e : cand) lens.push_back(hL[e]);
+        std::sort(lens.begin(), lens.end());
+        lens.erase(std::unique(lens.begin(), lens.end()), lens.end());
+        std::vector<int> len_index(n_events, -1);
+        for (int e : cand) len_index[e] = (int)(std::lower_bound(lens.begin(), lens.end(), hL[e]) - lens.begin());
+        S.n_distinct_lengths = (int64_t)lens.size();
+        st->h_lengths = lens;
+        int *d_lens, *d_len_index, *d_cand;
+        NEED(d_lens = WS("lengths", int, lens.size()));
+        NEED(d_len_index = WS("ev_len_index", int, n_events));
+        NEED(d_cand = WS("item_event", int, cand.size()));
+        HIPCHK(hipMemcpyAsync(d_lens, lens.data(), sizeof(int) * lens.size(), hipMemcpyHostToDevice, sm));
+        HIPCHK(hipMemcpyAsync(d_len_index, len_index.data(), sizeof(int) * n_events, hipMemcpyHostToDevice, sm));
+        HIPCHK(hipMemcpyAsync(d_cand, cand.data(), sizeof(int) * cand.size(), hipMemcpyHostToDevice, sm));
+        LengthTables tab;
+        NEED(tab.B_fwd = WS("tab_B_fwd", double2, lens.size() * (size_t)FFT_MAX));
+        NEED(tab.B_inv = WS("tab_B_inv", double2, lens.size() * (size_t)FFT_MAX));
+        NEED(tab.vel = WS("tab_vel", double2, lens.size() * 2 * (size_t)NRHIP_SPEC_STRIDE));
+        launch_length_tables(sm, (int)lens.size(), d_lens, sd, ctx->twiddle, tab);
+        // 6. channel voltages + trigger
+        const int n_items = (int)cand.size() * n_ch;
+        S.n_channel_items = n_items;
+        ChannelOut co;
+        NEED(co.maxV = WS("item_maxV", double, n_items));
+        co.triggered = triggered;
+        co.trace = nullptr;
+        co.trace_offset = nullptr;
+        if (cfg->dump_traces) {
+            std::vector<long> off(n_items + 1, 0);
+            for (int i = 0; i < n_items; i++) off[i + 1] = off[i] + hL[cand[i / n_ch]];
+            long* d_off;
+            NEED(d_off = WS("trace_offset", long, n_items + 1));
+            HIPCHK(hipMemcpyAsync(d_off, off.data(), sizeof(long) * (n_items + 1), hipMemcpyHostToDevice, sm));
+            NEED(co.trace = WS("trace", double, std::max<long>(off[n_items], 1)));
+            co.trace_offset = d_off;
+            HIPCHK(hipStreamSynchronize(sm));  // `off` goes out of scope
+        }
+        double2* scratch;
+        NEED(scratch = WS("channel_scratch", double2, (size_t)channel_grid_blocks() * NRHIP_SPEC_STRIDE));
+        launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, cfg->askaryan_model,
+                       cfg->trigger_threshold, ctx->twiddle, tab, scratch, co);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here
+    }
+    if (stats) {
+        // count triggers on device-resident mask (cheap D2H of n bytes only when asked for stats)
+        std::vector<unsigned char> ht(n_events);
+        HIPCHK(hipMemcpyAsync(ht.data(), triggered, n_events, hipMemcpyDeviceToHost, sm));
+        HIPCHK(hipStreamSynchronize(sm));
+        int64_t nt = 0;
+        for (unsigned char t : ht) nt += t;
+        S.n_triggered = nt;
+        *stats = S;
+    } else {
+        HIPCHK(hipStreamSynchronize(sm));
+    }
+    return 0;
+}
+
+int64_t nrhip_sim_fetch(nrhip_station* st, const char* name, void* host_dst, uint64_t bytes)
+{
+    if (!st || !name) return nrhip_fail_msg("nrhip_sim_fetch: NULL argument");
+    auto it = st->ws_bytes.find(name);
+    if (it == st->ws_bytes.end()) return nrhip_fail_msg("nrhip_sim_fetch: no such table in the last simulated batch");
+    size_t avail = it->second;
+    size_t n = std::min<size_t>(avail, bytes);
+    if (n && host_dst) {
+        if (hipSetDevice(st->ctx->device) != hipSuccess) return -1;
+        hipError_t e = hipMemcpy(host_dst, st->ws[name].p, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return nrhip_fail("hipMemcpy", e);
+    }
+    return (int64_t)avail;
+}
+
+int nrhip_askaryan_spectrum_batch(nrhip_ctx* ctx, int64_t n, const double* energy, const double* theta,
+                                  const int32_t* shower_type, const double* n_index, const double* R, const double* k_L,
+                                  int32_t model, int32_t N, double dt, double* spectrum)
+{
+    if (!ctx) return nrhip_fail_msg("nrhip_askaryan_spectrum_batch: ctx is NULL");
+    if (model < 0 || model > 2) return nrhip_fail_msg("model unknown");  // NotImplementedError in askaryan.py:136
+    if (N <= 0 || N % 2) return nrhip_fail_msg("nrhip_askaryan_spectrum_batch: N must be even");
+    if (n <= 0) return 0;
+    for (int64_t i = 0; i < n; i++)
+        if (shower_type[i] != NRHIP_SHOWER_HAD && shower_type[i] != NRHIP_SHOWER_EM)
+            return nrhip_fail_msg("shower type is not implemented");  // parametrizations.py:130
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nf = N / 2 + 1;
+    DevArray dE, dth, dty, dn, dR, dk, ds;
+    int rc = upload(ctx, dE, energy, n) || upload(ctx, dth, theta, n) || upload(ctx, dty, shower_type, n) ||
+             upload(ctx, dn, n_index, n) || upload(ctx, dR, R, n) || upload(ctx, dk, k_L, n);
+    if (!rc && ds.reserve(n * nf * 16) != hipSuccess) rc = nrhip_fail_msg("out of device memory");
+    if (!rc) {
+        launch_askaryan_spectrum(ctx->stream, (int)n, dE.as<double>(), dth.as<double>(), dty.as<int>(), dn.as<double>(),
+                                 dR.as<double>(), dk.as<double>(), model, N, dt, ds.as<double2>());
+        hipError_t e = hipMemcpyAsync(spectrum, ds.p, n * nf * 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = nrhip_fail("askaryan copy", e);
+    }
+    dE.release(); dth.release(); dty.release(); dn.release(); dR.release(); dk.release(); ds.release();
+    return rc;
+}
+
+int nrhip_debug_czt(nrhip_ctx* ctx, int32_t n_batch, int32_t n_in, int32_t n_out, int32_t Q, double sgn, const double* in,
+                    double* out)
+{
+    if (!ctx) return nrhip_fail_msg("nrhip_debug_czt: ctx is NULL");
+    if (n_in + n_out - 1 > FFT_MAX) return nrhip_fail_msg("nrhip_debug_czt: n_in + n_out - 1 exceeds 8192");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ensure_twiddle(ctx)) return -1;
+    int grid = std::min(n_batch, 64);
+    DevArray di, dout, dB;
+    int rc = upload(ctx, di, (const double2*)in, (size_t)n_batch * n_in);
+    if (!rc && (dout.reserve((size_t)n_batch * n_out * 16) != hipSuccess || dB.reserve((size_t)grid * FFT_MAX * 16) != hipSuccess))
+        rc = nrhip_fail_msg("out of device memory");
+    if (!rc) {
+        launch_czt_test(ctx->stream, n_batch, n_in, n_out, Q, sgn, di.as<double2>(), dout.as<double2>(), ctx->twiddle,
+                        dB.as<double2>(), grid);
+        hipError_t e = hipMemcpyAsync(out, dout.p, (size_t)n_batch * n_out * 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = nrhip_fail("czt", e);
+    }
+    di.release(); dout.release(); dB.release();
+    return rc;
+}
+
+}  // extern "C"

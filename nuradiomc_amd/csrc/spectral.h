@@ -1,0 +1,95 @@
+// spectral.h -- device-side tables of the spectral stages (shared by spectral.hip and pipeline.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "nrhip_internal.h"
+#include "fft_device.h"
+
+#define NRHIP_MAX_NFC 64        // coarse attenuation frequencies per ray (n_freq + n_freq / 2 <= 64)
+#define NRHIP_MAX_FILTERS 4
+#define NRHIP_MAX_POLY 24
+#define NRHIP_SPEC_STRIDE 6146  // max L / 2 + 1 spectrum bins per channel (L <= 12290 with the 8192-point chirp-z)
+
+namespace nrhip {
+
+// station description in HBM (small, read through the scalar / L1 caches)
+struct StationDev {
+    int n_ch, N, n_fc;
+    double fs, pre_pulse, post_pulse, readout_length;
+    const double* pos;        // [n_ch][3]
+    const double* cable;      // [n_ch]
+    const int* ant_model;     // [n_ch]   0 analytic_VPol, 1 analytic_HPol
+    const double* rot;        // [n_ch][9] inv(E) A   (antennapattern.py:1190-1216)
+    const double* rot_inv;    // [n_ch][9]
+    const double* fcoarse;    // [n_fc] attenuation frequency grid
+};
+
+// analog filter chain: response_i(f) = polyval(b_i, j f) / polyval(a_i, j f), highest power first
+struct FilterSet {
+    int n;
+    int nb[NRHIP_MAX_FILTERS], na[NRHIP_MAX_FILTERS];
+    double b[NRHIP_MAX_FILTERS][NRHIP_MAX_POLY], a[NRHIP_MAX_FILTERS][NRHIP_MAX_POLY];
+};
+
+// per kept ray (SoA, ordered by event, channel, solution)
+struct RayWork {
+    int *ev, *ch, *sol, *slot;
+    double *view, *n_index, *R, *t0, *C0;
+    double *pol_theta, *pol_phi;
+    double2 *r_theta, *r_phi;
+    double *zen, *az;
+    double *vel_T;       // [n][4]
+    double *theta_ant;
+    double *att;         // [n][n_fc]
+};
+
+struct EventIn {
+    const double* energy;
+    const int* shower_type;  // 0 HAD, 1 EM
+    const double* k_L;       // Alvarez2009 EM showers; ignored otherwise
+};
+
+struct EventOut {
+    int *n_rays, *ray_begin, *L;
+    unsigned char* candidate;
+    double* t_min;
+};
+
+struct LengthTables {
+    double2* B_fwd;  // [n_len][FFT_MAX]
+    double2* B_inv;  // [n_len][FFT_MAX]
+    double2* vel;    // [n_len][2][NRHIP_SPEC_STRIDE]
+};
+
+struct ChannelOut {
+    double* maxV;               // [n_items]
+    unsigned char* triggered;   // [n_events]
+    double* trace;              // optional dump
+    const long* trace_offset;   // [n_items]
+};
+
+void launch_select_rays(hipStream_t s, long n_pairs, int n_ch, const double* vertex, const double* zen, const double* az,
+                        const RayRecords& rec, const IceConst& m, double cut, int* keep);
+void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const int* offset, int* ray_slot);
+void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex, const double* zen,
+                      const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w);
+void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
+                                  const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint);
+void launch_efield_max(hipStream_t s, int n_rays, const RayWork& w, const EventIn& evin, const StationDev& st,
+                       int ask_model, const double2* tw, double* max_efield);
+void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
+                       const double* max_efield, double min_efield, const EventOut& ev);
+void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const double2* tw,
+                          const LengthTables& tab);
+int channel_grid_blocks();
+void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
+                    const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
+                    double threshold, const double2* tw, const LengthTables& tab, double2* scratch, const ChannelOut& out);
+void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const double* theta, const int* type,
+                              const double* n_index, const double* R, const double* k_L, int model, int N, double dt,
+                              double2* spec);
+void launch_czt_test(hipStream_t s, int n_batch, int n_in, int n_out, int Q, double sgn, const double2* in, double2* out,
+                     const double2* tw, double2* Bscratch, int grid);
+void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
+                              const double* freqs, int model, const IceConst& m, double* att, int* neval);
+
+}  // namespace nrhip

@@ -1,0 +1,888 @@
+// spectral.hip -- Askaryan emission, propagation effects, antenna + amplifier response and the threshold
+// trigger on MI355X (gfx950), all FFT work staged in LDS (fft_device.h).
+//
+// Reference behaviour being provided (paths in nu-radio/NuRadioMC):
+//   * NuRadioMC/simulation/simulation.py:187-206 (viewing angle, delta_C cut), :244-246 + :798-819
+//     (polarisation), :259-285 (trace start time, candidate amplitude cut)
+//   * NuRadioMC/SignalGen/parametrizations.py:92-275 via askaryan.get_frequency_spectrum (askaryan.py:143)
+//   * NuRadioMC/SignalProp/analyticraytracing.py:2937-3033 (attenuation interpolation, Fresnel)
+//   * NuRadioReco/modules/efieldToVoltageConverter.py:111-345 (common time grid of event-dependent length L,
+//     sub-sample shift, rfft(L), VEL, 5 MHz cut, sum over rays)
+//   * NuRadioReco/detector/antennapattern.py:1190-1307, :1580-1768 (analytic VPol / HPol)
+//   * NuRadioReco/utilities/signal_processing.py:282-292 (analog Butterworth response)
+//   * NuRadioReco/modules/trigger/simpleThreshold.py + highLowThreshold.get_majority_logic (:82-142)
+//
+// Kernel roles and rooflines are in DESIGN.md; in short every kernel here is LDS/FP64 bound, not HBM bound:
+// per ray only ~0.5 KB of parameters enter and 8..100 B leave, the N- and L-point transforms never leave LDS.
+#include "fft_device.h"
+#include "spectral.h"
+
+namespace nrhip {
+
+// ---------------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline void sph2cart(double zen, double az, double v[3])
+{
+    double sz = sin(zen);
+    v[0] = sz * cos(az);
+    v[1] = sz * sin(az);
+    v[2] = cos(zen);
+}
+
+// radiotools.helper.cartesian_to_spherical: theta = arccos(z / r) (0 if z / r >= 1), phi in [0, 2 pi)
+__device__ inline void cart2sph(const double v[3], double* zen, double* az)
+{
+    double r = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    double q = v[2] / r;
+    *zen = (q < 1) ? acos(q) : 0.;
+    double phi = atan2(v[1], v[0]);
+    const double twopi = 2 * M_PI;
+    while (phi >= twopi) phi -= twopi;
+    while (phi < 0) phi += twopi;
+    *az = phi;
+}
+
+// rows e_r, e_theta, e_phi (radiotools cstrafo; analyticraytracing.py:2363-2365)
+__device__ inline void onsky_matrix(double zen, double az, double Mx[9])
+{
+    double ct = cos(zen), st = sin(zen), cp = cos(az), sp = sin(az);
+    Mx[0] = st * cp; Mx[1] = st * sp; Mx[2] = ct;
+    Mx[3] = ct * cp; Mx[4] = ct * sp; Mx[5] = -st;
+    Mx[6] = -sp;     Mx[7] = cp;      Mx[8] = 0;
+}
+
+__device__ inline void mat3vec(const double A[9], const double v[3], double o[3])
+{
+    for (int i = 0; i < 3; i++) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ray selection: viewing angle + delta_C cut  (simulation.py:187-206)
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline double viewing_angle(const double sd[3], const double* lv)
+{
+    double dot = sd[0] * lv[0] + sd[1] * lv[1] + sd[2] * lv[2];
+    double n1 = sqrt(sd[0] * sd[0] + sd[1] * sd[1] + sd[2] * sd[2]);
+    double n2 = sqrt(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]);
+    double c = dot / (n1 * n2);
+    if (c > 1) c = 1;
+    if (c < -1) c = -1;
+    return acos(c);
+}
+
+__device__ inline double n_index_at(double z, const IceConst& m) { return (z <= 0) ? n_of_z(z, m) : 1.; }
+
+__global__ void __launch_bounds__(256)
+select_rays_kernel(long n_pairs, int n_ch, const double* __restrict__ vertex, const double* __restrict__ zenith,
+                   const double* __restrict__ azimuth, RayRecords rec, IceConst m, double delta_C_cut,
+                   int* __restrict__ keep)
+{
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    long e = i / n_ch;
+    int ns = rec.n_sol[i];
+    double axis[3], sd[3];
+    sph2cart(zenith[e], azimuth[e], axis);
+    for (int d = 0; d < 3; d++) sd[d] = -1 * axis[d];
+    double n_index = n_index_at(vertex[3 * e + 2], m);
+    double cherenkov = acos(1. / n_index);
+    for (int s = 0; s < NRHIP_MAXS; s++) {
+        int k = 0;
+        if (s < ns) {
+            double view = viewing_angle(sd, rec.launch + 3 * (i * NRHIP_MAXS + s));
+            k = !(fabs(view - cherenkov) > delta_C_cut);
+        }
+        keep[i * NRHIP_MAXS + s] = k;
+    }
+}
+
+// keep flags + exclusive scan -> list of kept slots (ordered: event, channel, solution)
+__global__ void scatter_slots_kernel(long n_slots, const int* __restrict__ keep, const int* __restrict__ offset,
+                                     int* __restrict__ ray_slot)
+{
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    if (keep[i]) ray_slot[offset[i]] = (int)i;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-ray parameters
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const double* __restrict__ vertex,
+                 const double* __restrict__ zenith, const double* __restrict__ azimuth, RayRecords rec, IceConst m,
+                 StationDev st, RayWork w)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    int slot = ray_slot[r];
+    long pair = slot / NRHIP_MAXS;
+    long e = pair / n_ch;
+    int ch = (int)(pair - e * n_ch);
+    double axis[3], sd[3];
+    sph2cart(zenith[e], azimuth[e], axis);
+    for (int d = 0; d < 3; d++) sd[d] = -1 * axis[d];
+    const double* lv = rec.launch + 3 * (long)slot;
+    const double* rv = rec.receive + 3 * (long)slot;
+    w.ev[r] = (int)e;
+    w.ch[r] = ch;
+    w.sol[r] = slot % NRHIP_MAXS;
+    w.view[r] = viewing_angle(sd, lv);
+    w.n_index[r] = n_index_at(vertex[3 * e + 2], m);
+    w.R[r] = rec.D[slot];
+    w.t0[r] = 0. + rec.T[slot] - 0.5 * st.N / st.fs;  // vertex_time = 0 (simulation.py:259-268)
+    w.C0[r] = rec.C0[slot];
+    // polarisation = l x (s x l), normalised, in the on-sky basis of the launch direction (simulation.py:816-819)
+    double sxl[3] = {sd[1] * lv[2] - sd[2] * lv[1], sd[2] * lv[0] - sd[0] * lv[2], sd[0] * lv[1] - sd[1] * lv[0]};
+    double pol[3] = {lv[1] * sxl[2] - lv[2] * sxl[1], lv[2] * sxl[0] - lv[0] * sxl[2], lv[0] * sxl[1] - lv[1] * sxl[0]};
+    double pn = sqrt(pol[0] * pol[0] + pol[1] * pol[1] + pol[2] * pol[2]);
+    for (int d = 0; d < 3; d++) pol[d] /= pn;
+    double lz, la, Mx[9], po[3];
+    cart2sph(lv, &lz, &la);
+    onsky_matrix(lz, la, Mx);
+    mat3vec(Mx, pol, po);
+    w.pol_theta[r] = po[1];
+    w.pol_phi[r] = po[2];
+    // arrival direction (simulation.py:270)
+    double zen, az;
+    cart2sph(rv, &zen, &az);
+    w.zen[r] = zen;
+    w.az[r] = az;
+    // Fresnel reflection off the surface, n_1 = n(-1 cm), n_2 = 1 (analyticraytracing.py:2990-2997,
+    // geometryUtilities.py:208-263: conjugated coefficients, complex under total internal reflection)
+    double ra = rec.refl_angle[slot];
+    double2 rth = make_double2(1., 0.), rph = make_double2(1., 0.);
+    if (!isnan(ra)) {
+        double n1 = n_of_z(-0.01, m);
+        double n = 1. / n1;
+        double n2 = n * n;
+        double sa = sin(ra), ca = cos(ra);
+        double arg = n2 - sa * sa;
+        double2 s = (arg >= 0) ? make_double2(sqrt(arg), 0.) : make_double2(0., sqrt(-arg));
+        double2 num = make_double2(n2 * ca - s.x, -s.y), den = make_double2(n2 * ca + s.x, s.y);
+        double dd = den.x * den.x + den.y * den.y;
+        double2 q = make_double2((num.x * den.x + num.y * den.y) / dd, (num.y * den.x - num.x * den.y) / dd);
+        rth = cconj(q);
+        num = make_double2(ca - s.x, -s.y);
+        den = make_double2(ca + s.x, s.y);
+        dd = den.x * den.x + den.y * den.y;
+        q = make_double2((num.x * den.x + num.y * den.y) / dd, (num.y * den.x - num.x * den.y) / dd);
+        rph = cconj(q);
+    }
+    w.r_theta[r] = rth;
+    w.r_phi[r] = rph;
+    // antenna frame: incoming direction in the antenna-model frame and the 2x2 map raw (theta, phi) -> on-sky
+    // (antennapattern.py:1218-1307); orthonormal bases are inverted by transposition
+    const double* rot = st.rot + 9 * ch;
+    const double* roti = st.rot_inv + 9 * ch;
+    double inc[3], incw[3], th_a, ph_a;
+    sph2cart(zen, az, inc);
+    mat3vec(rot, inc, incw);
+    cart2sph(incw, &th_a, &ph_a);
+    double Ma[9], Ms[9];
+    onsky_matrix(th_a, ph_a, Ma);
+    onsky_matrix(zen, az, Ms);
+    double T[4];
+    for (int c = 0; c < 2; c++) {  // raw component c+1 (theta, phi) = row c+1 of Ma as a cartesian vector
+        double v[3] = {Ma[3 * (c + 1)], Ma[3 * (c + 1) + 1], Ma[3 * (c + 1) + 2]}, g[3], o[3];
+        mat3vec(roti, v, g);
+        mat3vec(Ms, g, o);
+        T[0 + c] = o[1];
+        T[2 + c] = o[2];
+    }
+    for (int c = 0; c < 4; c++) w.vel_T[4 * (long)r + c] = T[c];
+    w.theta_ant[r] = th_a;
+    w.slot[r] = slot;
+}
+
+// integration limits for the attenuation kernel from the ray records
+__global__ void __launch_bounds__(256)
+ray_limits_from_slots_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const double* __restrict__ vertex,
+                             const double* __restrict__ chan_pos, RayRecords rec, IceConst m, double* __restrict__ zint)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    int slot = ray_slot[r];
+    long pair = slot / NRHIP_MAXS;
+    long e = pair / n_ch;
+    int ch = (int)(pair - e * n_ch);
+    double A[3] = {vertex[3 * e], vertex[3 * e + 1], vertex[3 * e + 2]};
+    double B[3] = {chan_pos[3 * ch], chan_pos[3 * ch + 1], chan_pos[3 * ch + 2]};
+    if (B[2] < A[2]) {
+        for (int d = 0; d < 3; d++) { double t = A[d]; A[d] = B[d]; B[d] = t; }
+    }
+    double dX[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+    double dPhi = -atan2(dX[1], dX[0]);
+    double cph = cos(dPhi), sph = sin(dPhi);
+    Pair2D p;
+    p.y1 = A[0];
+    p.z1 = A[2];
+    p.y2 = (cph * dX[0] + (-sph) * dX[1] + 0 * dX[2]) + A[0];
+    p.z2 = (0 * dX[0] + 0 * dX[1] + 1 * dX[2]) + A[2];
+    p.g1 = gamma_of_z(p.z1, m);
+    p.g2 = gamma_of_z(p.z2, m);
+    C0State s = make_c0(rec.C0[slot], m);
+    double C1 = C1_of(s, p, m);
+    zint[3 * r] = p.z1;
+    zint[3 * r + 1] = z_mirrored(p.y2, p.z2, s, C1, p);
+    zint[3 * r + 2] = s.z_turn;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Askaryan amplitude: the reference's irfft -> roll(N/2) -> rfft detour (parametrizations.py:208-214,
+// askaryan.py:209-213) is the identity spec_k = i * X_k * (-1)^k * sqrt(2) for 0 < k < N/2 and 0 at DC and
+// Nyquist, so only the real amplitude X_k is evaluated.
+// ---------------------------------------------------------------------------------------------------------
+struct AskaryanConst {
+    int model;      // 0 Alvarez2009, 1 Alvarez2000, 2 ZHS1992
+    double a_pref;  // everything that multiplies f
+    double nu_L, beta, nu_R, alpha;  // Alvarez2009
+    double dth, cher, theta, f0, scale, roll;  // Alvarez2000 / ZHS1992
+    int had;
+};
+
+__device__ inline AskaryanConst askaryan_setup(int model, double energy, double theta, int shower_type,
+                                               double n_index, double R, double k_L_in)
+{
+    AskaryanConst a;
+    a.model = model;
+    a.had = (shower_type == 0);
+    const double eV = 1., MeV = 1e6, TeV = 1e12, cm = 0.01, MHz = 1e-3, GHz = 1., deg = 0.017453292519943295;
+    const double g = 6.241509744511525e+33;  // NuRadioReco/utilities/units.py gram
+    if (model == 0) {  // parametrizations.py:110-218
+        const double E_C = 73.1 * MeV;
+        const double rho = 0.924 * g / (cm * cm * cm);
+        const double X_0 = 36.08 * g / (cm * cm);
+        const double R_M = 10.57 * g / (cm * cm);
+        const double c = 0.299792458;
+        double k_E_bar, k_L, k_R_bar;
+        double lE = log10(energy / eV);
+        if (a.had) {
+            double k_E_0 = 4.13e-16 * 1. / cm / (MHz * MHz);
+            k_E_bar = k_E_0 * tanh((lE - 10.60) / 2.54);
+            k_L = 31.25 * pow(energy / (1.e15 * eV), 3.01e-2);
+            k_R_bar = 2.73 + tanh((12.92 - lE) / 1.72);
+            a.beta = 2.57;
+        } else {
+            k_E_bar = 4.65e-16 * 1. / cm / (MHz * MHz);
+            k_L = k_L_in;
+            k_R_bar = 1.54;
+            a.beta = 2.74;
+        }
+        a.a_pref = k_E_bar * energy / E_C * X_0 / rho * sin(theta);
+        double nu_L = rho / k_L / X_0;
+        double q = fabs(1 - n_index * cos(theta));
+        const double cher_cut = 1.e-8;
+        if (q < cher_cut) nu_L *= c / cher_cut;
+        else nu_L *= c / q;
+        a.nu_L = nu_L;
+        a.nu_R = rho / k_R_bar / R_M * c / sqrt(n_index * n_index - 1);
+        a.alpha = 1.27;
+        a.scale = R;
+    } else if (model == 1) {  // Alvarez2000, parametrizations.py:220-275
+        a.cher = acos(1. / n_index);
+        a.theta = theta;
+        const double Elpm = 2e15 * eV;
+        double eps = log10(energy / TeV);
+        double dth;  // angular width * f / (500 MHz)  [rad]
+        if (!a.had) {
+            dth = 2.7 * deg * 500 * MHz * pow(Elpm / (0.14 * energy + Elpm), 0.3);
+            a.scale = 1.;
+        } else {
+            double dd = 0;
+            if (eps >= 0 && eps <= 2) dd = 500 * MHz * (2.07 - 0.33 * eps + 7.5e-2 * eps * eps) * deg;
+            else if (eps > 2 && eps <= 5) dd = 500 * MHz * (1.74 - 1.21e-2 * eps) * deg;
+            else if (eps > 5 && eps <= 7) dd = 500 * MHz * (4.23 - 0.785 * eps + 5.5e-2 * eps * eps) * deg;
+            else if (eps > 7) dd = 500 * MHz * (4.23 - 0.785 * 7 + 5.5e-2 * 49) * (1 + (eps - 7) * 0.075) * deg;
+            dth = dd;
+            double f_eps = -1.27e-2 - 4.76e-2 * (eps + 3);
+            f_eps += -2.07e-3 * (eps + 3) * (eps + 3) + 0.52 * sqrt(eps + 3);
+            a.scale = (dd != 0) ? f_eps : 0.;
+        }
+        a.dth = dth;
+        a.f0 = 1.15 * GHz;
+        a.a_pref = 2.53e-7 * energy / TeV / MHz * (sin(theta) / sin(a.cher)) / R;
+    } else {  // ZHS1992, parametrizations.py:92-108
+        a.cher = acos(1. / n_index);
+        a.theta = theta;
+        a.a_pref = 1.1e-7 * energy / TeV / R / MHz;
+    }
+    return a;
+}
+
+// real amplitude X(f) such that the reference's spectrum bin is i * X * (-1)^k * sqrt(2) (ZHS1992: see phase)
+__device__ inline double askaryan_amplitude(double f, const AskaryanConst& a)
+{
+    if (a.model == 0) {
+        double A = a.a_pref * f;
+        double d_L = 1 / (1 + pow(f / a.nu_L, a.beta));
+        double d_R = 1 / (1 + pow(f / a.nu_R, a.alpha));
+        double s = A * d_L * d_R;
+        s *= 0.5;
+        s /= a.scale;
+        return s;
+    } else if (a.model == 1) {
+        if (a.scale == 0.) return 0.;
+        double E = a.a_pref * f / a.f0 / (1 + pow(f / a.f0, 1.44));
+        double w = (a.theta - a.cher) / (a.dth / f);
+        return 0.5 * a.scale * E * exp(-0.6931471805599453 * w * w);
+    } else {
+        double vv0 = f / 0.5;
+        double w = (a.theta - a.cher) / (2.4 * 0.017453292519943295 / vv0);
+        return 0.5 * a.a_pref * vv0 / (1 + 0.4 * vv0 * vv0) * exp(-0.5 * w * w);
+    }
+}
+
+// np.interp(f, xp, fp) on the coarse attenuation grid (analyticraytracing.py:1078)
+__device__ inline double interp_att(double f, int n, const double* __restrict__ xp, const double* fp)
+{
+    if (f <= xp[0]) return fp[0];
+    if (f >= xp[n - 1]) return fp[n - 1];
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (f >= xp[mid]) lo = mid;
+        else hi = mid;
+    }
+    double slope = (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]);
+    return slope * (f - xp[lo]) + fp[lo];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Building blocks shared by the efield-maximum kernel and the channel kernel (block-cooperative, LDS)
+// ---------------------------------------------------------------------------------------------------------
+struct RayShared {
+    AskaryanConst ask;
+    double att[NRHIP_MAX_NFC];
+};
+
+// amp[k] = X_k * att(f_k) for k <= N/2 (0 at k = 0 and N/2): the real, component-independent part of the field
+__device__ inline void fill_amplitude(double* amp, int N, double fs, const RayShared& rs, int n_fc,
+                                      const double* __restrict__ fcoarse)
+{
+    const int nh = N / 2;
+    const double df = 1.0 / (N * (1. / fs));
+    for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
+        double v = 0.;
+        if (k > 0 && k < nh) {
+            double f = k * df;
+            v = askaryan_amplitude(f, rs.ask) * interp_att(f, n_fc, fcoarse, rs.att);
+        }
+        amp[k] = v;
+    }
+    __syncthreads();
+}
+
+// G(k): spectrum bin k (0..N/2) of one on-sky component, optionally with the sub-sample shift phase ramp
+// exp(-2 pi i f rem) of BaseTrace.apply_time_shift (base_trace.py:246-276)
+__device__ inline double2 field_bin(int k, double amp_k, int N, double fs, double pol, double2 rc, double rem,
+                                    bool shift, int ask_model, double roll_bins)
+{
+    const int nh = N / 2;
+    if (k <= 0 || k >= nh) return make_double2(0., 0.);
+    double a = amp_k * 1.4142135623730951;
+    double2 s;
+    if (ask_model == 2) {  // ZHS1992: +90 deg phase, roll by int(2 ns / dt) bins instead of N/2
+        double sn, cs;
+        sincospi(-2.0 * k * roll_bins / N, &sn, &cs);
+        s = make_double2(-a * sn, a * cs);  // i * a * exp(-2 pi i k m / N)
+    } else {
+        s = make_double2(0., (k & 1) ? -a : a);  // i * a * (-1)^k
+    }
+    s = cscale(s, pol);
+    s = cmul(s, rc);
+    if (shift) {
+        double f = k * (1.0 / (N * (1. / fs)));
+        double sn, cs;
+        sincos(-2. * M_PI * rem * f, &sn, &cs);
+        s = cmul(s, make_double2(cs, sn));
+    }
+    return s;
+}
+
+// y_j = e[2j] + i e[2j+1] (j < N/2) of e = irfft_N(G) * fs / sqrt(2), left in x[bitrev(j)] (x in LDS, >= N/2)
+__device__ inline void field_time_domain(double2* x, const double* amp, int N, int log2nh, double fs, double pol,
+                                         double2 rc, double rem, bool shift, int ask_model, double roll_bins,
+                                         const double2* __restrict__ tw)
+{
+    const int nh = N / 2;
+    for (int k = threadIdx.x; k < nh; k += blockDim.x) {
+        double2 Gk = field_bin(k, amp[k], N, fs, pol, rc, rem, shift, ask_model, roll_bins);
+        double2 Gc = cconj(field_bin(nh - k, amp[nh - k], N, fs, pol, rc, rem, shift, ask_model, roll_bins));
+        double2 ge = cscale(cadd(Gk, Gc), 0.5);
+        double2 d = cscale(csub(Gk, Gc), 0.5);
+        double2 wk = tw[k * (FFT_MAX / N)];      // exp(-2 pi i k / N)
+        double2 go = cmul(d, cconj(wk));         // * exp(+2 pi i k / N)
+        x[k] = make_double2(ge.x - go.y, ge.y + go.x);  // ge + i go
+    }
+    __syncthreads();
+    fft_dif(x, log2nh, tw, true);  // inverse, natural -> bit-reversed; scale applied by the reader
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel: max |E(t)| per ray (candidate cut, simulation.py:283-285).  One block per ray.
+// LDS: N/2 complex + (N/2 + 1) doubles.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+efield_max_kernel(int n_rays, RayWork w, EventIn evin, StationDev st, int ask_model, const double2* __restrict__ tw,
+                  int log2nh, double* __restrict__ max_efield)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = st.N, nh = N / 2;
+    double2* x = (double2*)smem;
+    double* amp = (double*)(x + nh);
+    __shared__ RayShared rs;
+    __shared__ double red[256];
+    for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
+        int e = w.ev[r];
+        if (threadIdx.x == 0)
+            rs.ask = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r], w.R[r],
+                                    evin.k_L[e]);
+        for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
+        __syncthreads();
+        fill_amplitude(amp, N, st.fs, rs, st.n_fc, st.fcoarse);
+        double mx = 0.;
+        const double scale = st.fs / 1.4142135623730951 / nh;
+        for (int comp = 0; comp < 2; comp++) {
+            double pol = comp ? w.pol_phi[r] : w.pol_theta[r];
+            double2 rc = comp ? w.r_phi[r] : w.r_theta[r];
+            field_time_domain(x, amp, N, log2nh, st.fs, pol, rc, 0., false, ask_model, floor(2.0 * st.fs), tw);
+            for (int j = threadIdx.x; j < nh; j += blockDim.x) {
+                double2 y = x[j];
+                mx = fmax(mx, fmax(fabs(y.x * scale), fabs(y.y * scale)));
+            }
+            __syncthreads();
+        }
+        red[threadIdx.x] = mx;
+        __syncthreads();
+        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) max_efield[r] = red[0];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel: per event common time grid (efieldToVoltageConverter.py:120-169) + candidate flag
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+event_grid_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, RayWork w, StationDev st,
+                  const double* __restrict__ max_efield, double min_efield, EventOut ev)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_events) return;
+    long s0 = (long)e * n_ch * NRHIP_MAXS, s1 = (long)(e + 1) * n_ch * NRHIP_MAXS;
+    int r0 = slot_offset[s0], r1 = slot_offset[s1];
+    double tmin = INFINITY, tmax = -INFINITY;
+    int cand = 0;
+    for (int r = r0; r < r1; r++) {
+        double t0 = w.t0[r] + st.cable[w.ch[r]];
+        tmin = fmin(tmin, t0);
+        tmax = fmax(tmax, t0 + st.N / st.fs);
+        if (max_efield[r] > min_efield) cand = 1;
+    }
+    int L = 0;
+    if (r1 > r0) {
+        double max_len = st.readout_length;  // longest detector readout window (n_samples / sampling rate)
+        tmin -= st.pre_pulse;
+        tmax += st.post_pulse;
+        while (tmax - tmin < max_len) tmax += st.post_pulse;
+        double res = 1. / st.fs;
+        L = (int)rint((tmax - tmin) / res);
+        if (L % 2 != 0) L += 1;
+    }
+    ev.n_rays[e] = r1 - r0;
+    ev.ray_begin[e] = r0;
+    ev.candidate[e] = (unsigned char)(cand && r1 > r0);
+    ev.L[e] = L;
+    ev.t_min[e] = (r1 > r0) ? tmin : NAN;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel: per distinct trace length L -- Bluestein tables and the analytic antenna magnitudes on the L grid
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, const double2* __restrict__ tw,
+                     LengthTables tab)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* x = (double2*)smem;
+    __shared__ double red[1024];
+    const int M = FFT_MAX, nh = st.N / 2;
+    for (int il = blockIdx.x; il < n_len; il += gridDim.x) {
+        const int L = lengths[il], m = L / 2;
+        // forward transform of the packed N/2-point block onto m output bins, modulus m, sign -1
+        czt_build_table(x, FFT_LOG2_MAX, nh, m, m, -1., tw);
+        for (int i = threadIdx.x; i < M; i += blockDim.x) tab.B_fwd[(long)il * M + i] = x[i];
+        __syncthreads();
+        // inverse transform of m + 1 bins onto blocks of P = M - (m + 1) + 1 samples, modulus L, sign +1
+        int P = M - m;
+        czt_build_table(x, FFT_LOG2_MAX, m + 1, P, L, +1., tw);
+        for (int i = threadIdx.x; i < M; i += blockDim.x) tab.B_inv[(long)il * M + i] = x[i];
+        __syncthreads();
+        // analytic antenna magnitude * phase on the L grid (antennapattern.py:1672-1768), models 0 VPol, 1 HPol
+        const double df = 1.0 / (L * (1. / st.fs));
+        for (int model = 0; model < 2; model++) {
+            double* mag = (double*)smem;
+            int index = 0;
+            if (model == 0) {
+                index = m + 1;
+                for (int k = 0; k <= m; k++) {  // np.argmax(freq > cutoff): first bin above 220 MHz (0 if none)
+                    if (k * df > 0.22) { index = k; break; }
+                }
+                if (index == m + 1) index = 0;
+            }
+            double lmax = 0.;
+            for (int k = threadIdx.x; k <= m; k += blockDim.x) {
+                double f = k * df, v = 0.;
+                if (k > 0) {
+                    if (model == 0) {
+                        double gain = 1.0 / sqrt(f);
+                        v = sqrt(gain) / f;
+                        if (k < index) v *= 0.5 - 0.5 * cos(2. * M_PI * k / (2 * index - 1));  // hann(2 index)[k]
+                    } else {
+                        double sn = sin(f / 0.5 * M_PI / 2);
+                        v = 1.0 * (sn * sn);
+                        if (f > 0.5 * 2) v = 0.;
+                    }
+                    lmax = fmax(lmax, v);
+                } else if (model == 0 && index > 0) {
+                    v = 0.;
+                }
+                mag[k] = v;
+            }
+            red[threadIdx.x] = lmax;
+            __syncthreads();
+            for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+                if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+                __syncthreads();
+            }
+            double vmax = red[0];
+            double max_vel = model == 0 ? 0.18 : 0.055;
+            for (int k = threadIdx.x; k <= m; k += blockDim.x) {
+                double f = k * df, v = mag[k];
+                if (k > 0) v *= max_vel / vmax;
+                double ph = model == 0 ? 2.086 - 117.917 * f + 74.567 / 2 * (f * f) - 64.343 / 3 * (f * f * f)
+                                       : 0.321 - 11.400 * f + 39.590 / 2 * (f * f) - 38.181 / 3 * (f * f * f);
+                double sn, cs;
+                sincos(ph, &sn, &cs);
+                tab.vel[((long)il * 2 + model) * NRHIP_SPEC_STRIDE + k] = make_double2(v * cs, v * sn);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// complex rational filter response prod_i B_i(j f) / A_i(j f) applied successively (signal.freqs)
+__device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl)
+{
+    for (int i = 0; i < fl.n; i++) {
+        if (!(f > 0)) return make_double2(0., 0.);
+        double2 num = make_double2(0., 0.), den = make_double2(0., 0.);
+        const double2 jw = make_double2(0., f);
+        for (int k = 0; k < fl.nb[i]; k++) num = cadd(cmul(num, jw), make_double2(fl.b[i][k], 0.));
+        for (int k = 0; k < fl.na[i]; k++) den = cadd(cmul(den, jw), make_double2(fl.a[i][k], 0.));
+        double dd = den.x * den.x + den.y * den.y;
+        double2 h = make_double2((num.x * den.x + num.y * den.y) / dd, (num.y * den.x - num.x * den.y) / dd);
+        v = cmul(v, h);
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel: one (candidate event, channel) item per block iteration.
+//   for every ray of the channel and both on-sky components:
+//       N-point field in time domain (with sub-sample shift) -> chirp-z onto the event's L grid
+//       -> * VEL -> accumulate channel spectrum (global scratch of this block, L2 resident)
+//   * filters -> chirp-z back to L samples -> |V| >= threshold (last sample excluded, see majority logic)
+// LDS: FFT_MAX complex (128 KB) + (N/2 + 1) doubles.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
+               const int* __restrict__ ev_len_index, StationDev st, FilterSet fl, int ask_model, double threshold,
+               const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
+               ChannelOut out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int M = FFT_MAX, N = st.N, nh = N / 2;
+    double2* x = (double2*)smem;
+    double* amp = (double*)(x + M);
+    __shared__ RayShared rs;
+    __shared__ double red[1024];
+    __shared__ int s_trig;
+    double2* acc = scratch + (long)blockIdx.x * NRHIP_SPEC_STRIDE;
+    const long vel_stride = NRHIP_SPEC_STRIDE;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
+        const int L = ev.L[e], m = L / 2, il = ev_len_index[e];
+        const double t_min = ev.t_min[e];
+        const double res = 1. / st.fs;
+        const double2* Bf = tab.B_fwd + (long)il * M;
+        const double2* Bi = tab.B_inv + (long)il * M;
+        const double2* vel = tab.vel + ((long)il * 2 + st.ant_model[ch]) * vel_stride;
+        for (int k = threadIdx.x; k <= m; k += blockDim.x) acc[k] = make_double2(0., 0.);
+        if (threadIdx.x == 0) s_trig = 0;
+        __syncthreads();
+        int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
+        int n_used = 0;
+        for (int r = r0; r < r1; r++) {
+            if (w.ch[r] != ch) continue;
+            n_used++;
+            if (threadIdx.x == 0)
+                rs.ask = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r],
+                                        w.R[r], evin.k_L[e]);
+            for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
+            __syncthreads();
+            fill_amplitude(amp, N, st.fs, rs, st.n_fc, st.fcoarse);
+            // start bin and sub-sample remainder (efieldToVoltageConverter.py:214-218)
+            double start_time = w.t0[r] - t_min + st.cable[ch] + 0;
+            long start_bin = (long)rint(start_time / res);
+            double rem = start_time - start_bin * res;
+            bool shift = !(fabs(rint(rem * st.fs) - rem * st.fs) < 1e-5);
+            const double* T = w.vel_T + 4 * (long)r;
+            const double th_a = w.theta_ant[r];
+            const int am = st.ant_model[ch];
+            const double dir = (am == 0) ? sin(th_a) : sin(th_a) * sin(th_a);
+            // raw VEL has one non-zero component: VPol -> theta (column 0 of T), HPol -> phi (column 1 of T)
+            const double Tt = (am == 0) ? T[0] : T[1], Tp = (am == 0) ? T[2] : T[3];
+            for (int comp = 0; comp < 2; comp++) {
+                double pol = comp ? w.pol_phi[r] : w.pol_theta[r];
+                double2 rc = comp ? w.r_phi[r] : w.r_theta[r];
+                double vfac = (comp ? Tp : Tt) * dir;
+                if (vfac == 0. || pol == 0.) continue;
+                field_time_domain(x, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
+                // gather y_j (bit-reversed positions) -> registers, then lay out a_j = y_j * chirp_j, zero pad
+                const double sc = 1.0 / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
+                double2 yreg[4];
+                int cnt = 0;
+                for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = x[bitrev(j, log2nh)];
+                __syncthreads();
+                cnt = 0;
+                for (int j = threadIdx.x; j < M; j += blockDim.x) {
+                    double2 v = make_double2(0., 0.);
+                    if (j < nh) v = cmul(cscale(yreg[cnt++], sc), chirp(j, m, -1.));
+                    x[j] = v;
+                }
+                __syncthreads();
+                czt_convolve(x, FFT_LOG2_MAX, Bf, tw);
+                // Z(k) = chirp(k) x[k] / M ; untangle even/odd samples, apply the start-bin phase, VEL, 5 MHz cut
+                for (int k = threadIdx.x; k <= m; k += blockDim.x) {
+                    int k1 = (k == m) ? 0 : k, k2 = (k == 0 || k == m) ? 0 : m - k;
+                    double2 Z1 = cscale(cmul(x[k1], chirp(k1, m, -1.)), 1.0 / M);
+                    double2 Z2 = cconj(cscale(cmul(x[k2], chirp(k2, m, -1.)), 1.0 / M));
+                    double2 Ee = cscale(cadd(Z1, Z2), 0.5);
+                    double2 d = cscale(csub(Z1, Z2), 0.5);
+                    double2 Eo = make_double2(d.y, -d.x);  // d / i
+                    double sn, cs;
+                    sincospi(-2.0 * (double)k / (double)L, &sn, &cs);
+                    double2 X = cadd(Ee, cmul(Eo, make_double2(cs, sn)));
+                    long ks = ((long)k * start_bin) % L;
+                    sincospi(-2.0 * (double)ks / (double)L, &sn, &cs);
+                    X = cmul(X, make_double2(cs, sn));
+                    double f = k * (1.0 / (L * res));
+                    double2 v = cmul(cscale(vel[k], vfac), X);
+                    if (f < 0.005) v = make_double2(0., 0.);
+                    acc[k] = cadd(acc[k], v);
+                }
+                __syncthreads();
+            }
+        }
+        // filters, then back to the time domain in blocks of P samples
+        double vmax = 0.;
+        int trig = 0;
+        if (n_used > 0) {
+            const int P = M - m;
+            const double scale = st.fs / 1.4142135623730951 / L;
+            for (int n0 = 0; n0 < L; n0 += P) {
+                for (int k = threadIdx.x; k < M; k += blockDim.x) {
+                    double2 v = make_double2(0., 0.);
+                    if (k <= m) {
+                        double f = k * (1.0 / (L * res));
+                        v = apply_filters(acc[k], f, fl);
+                        // Hermitian folding of irfft: DC and Nyquist real and single, the rest doubled
+                        if (k == 0 || k == m) v = make_double2(v.x, 0.);
+                        else v = cscale(v, 2.);
+                        double sn, cs;
+                        long kn = ((long)k * n0) % L;
+                        sincospi(2.0 * (double)kn / (double)L, &sn, &cs);
+                        v = cmul(v, make_double2(cs, sn));
+                        v = cmul(v, chirp(k, L, +1.));
+                    }
+                    x[k] = v;
+                }
+                __syncthreads();
+                czt_convolve(x, FFT_LOG2_MAX, Bi, tw);
+                int np = min(P, L - n0);
+                for (int n = threadIdx.x; n < np; n += blockDim.x) {
+                    double2 u = cmul(x[n], chirp(n, L, +1.));
+                    double v = u.x * (1.0 / M) * scale;
+                    int ng = n0 + n;
+                    if (out.trace) out.trace[out.trace_offset[item] + ng] = v;
+                    double av = fabs(v);
+                    vmax = fmax(vmax, av);
+                    if (ng < L - 1 && av >= threshold) trig = 1;
+                }
+                __syncthreads();
+            }
+        }
+        red[threadIdx.x] = vmax;
+        if (trig) s_trig = 1;
+        __syncthreads();
+        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            out.maxV[item] = red[0];
+            if (s_trig) out.triggered[e] = 1;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// stand-alone Askaryan spectrum (askaryan.get_frequency_spectrum) for the drop-in Python API
+// ---------------------------------------------------------------------------------------------------------
+__global__ void askaryan_spectrum_kernel(int n, const double* __restrict__ energy, const double* __restrict__ theta,
+                                         const int* __restrict__ shower_type, const double* __restrict__ n_index,
+                                         const double* __restrict__ R, const double* __restrict__ k_L, int model, int N,
+                                         double dt, double2* __restrict__ spec)
+{
+    const int nf = N / 2 + 1;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        __shared__ AskaryanConst a;
+        if (threadIdx.x == 0) a = askaryan_setup(model, energy[i], theta[i], shower_type[i], n_index[i], R[i], k_L[i]);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nf; k += blockDim.x) {
+            double amp1 = (k > 0 && k < N / 2) ? askaryan_amplitude(k * (1.0 / (N * dt)), a) : 0.;
+            spec[(long)i * nf + k] = field_bin(k, amp1, N, 1. / dt, 1.0, make_double2(1., 0.), 0., false, model,
+                                               floor(2.0 / dt));
+        }
+        __syncthreads();
+    }
+}
+
+// test hook: out[k] = sum_j in[j] exp(sgn 2 pi i j k / Q), k < n_out, one transform per block
+__global__ void __launch_bounds__(1024)
+czt_test_kernel(int n_batch, int n_in, int n_out, int Q, double sgn, const double2* __restrict__ in,
+                double2* __restrict__ outp, const double2* __restrict__ tw, double2* __restrict__ Bscratch)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* x = (double2*)smem;
+    const int M = FFT_MAX;
+    double2* B = Bscratch + (long)blockIdx.x * M;
+    czt_build_table(x, FFT_LOG2_MAX, n_in, n_out, Q, sgn, tw);
+    for (int i = threadIdx.x; i < M; i += blockDim.x) B[i] = x[i];
+    __syncthreads();
+    for (int b = blockIdx.x; b < n_batch; b += gridDim.x) {
+        for (int j = threadIdx.x; j < M; j += blockDim.x)
+            x[j] = (j < n_in) ? cmul(in[(long)b * n_in + j], chirp(j, Q, sgn)) : make_double2(0., 0.);
+        __syncthreads();
+        czt_convolve(x, FFT_LOG2_MAX, B, tw);
+        for (int k = threadIdx.x; k < n_out; k += blockDim.x)
+            outp[(long)b * n_out + k] = cscale(cmul(x[k], chirp(k, Q, sgn)), 1.0 / M);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+static inline unsigned grid_for(long n, int block) { return (unsigned)((n + block - 1) / block); }
+
+void launch_select_rays(hipStream_t s, long n_pairs, int n_ch, const double* vertex, const double* zen, const double* az,
+                        const RayRecords& rec, const IceConst& m, double cut, int* keep)
+{
+    if (n_pairs <= 0) return;
+    hipLaunchKernelGGL(select_rays_kernel, dim3(grid_for(n_pairs, 256)), dim3(256), 0, s, n_pairs, n_ch, vertex, zen, az,
+                       rec, m, cut, keep);
+}
+void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const int* offset, int* ray_slot)
+{
+    if (n_slots <= 0) return;
+    hipLaunchKernelGGL(scatter_slots_kernel, dim3(grid_for(n_slots, 256)), dim3(256), 0, s, n_slots, keep, offset, ray_slot);
+}
+void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex, const double* zen,
+                      const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w)
+{
+    if (n_rays <= 0) return;
+    hipLaunchKernelGGL(ray_setup_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, n_ch, ray_slot, vertex, zen,
+                       az, rec, m, st, w);
+}
+void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
+                                  const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint)
+{
+    if (n_rays <= 0) return;
+    hipLaunchKernelGGL(ray_limits_from_slots_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, n_ch, ray_slot,
+                       vertex, chan_pos, rec, m, zint);
+}
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
+
+void launch_efield_max(hipStream_t s, int n_rays, const RayWork& w, const EventIn& evin, const StationDev& st,
+                       int ask_model, const double2* tw, double* max_efield)
+{
+    if (n_rays <= 0) return;
+    int nh = st.N / 2;
+    size_t lds = (size_t)nh * 16 + (size_t)(nh + 1) * 8;
+    int grid = n_rays < 256 * 16 ? n_rays : 256 * 16;
+    hipLaunchKernelGGL(efield_max_kernel, dim3(grid), dim3(256), lds, s, n_rays, w, evin, st, ask_model, tw, ilog2(nh),
+                       max_efield);
+}
+void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
+                       const double* max_efield, double min_efield, const EventOut& ev)
+{
+    if (n_events <= 0) return;
+    hipLaunchKernelGGL(event_grid_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, n_ch, slot_offset, w, st,
+                       max_efield, min_efield, ev);
+}
+static bool g_attr_set = false;
+static void set_big_lds()
+{
+    if (g_attr_set) return;
+    (void)hipFuncSetAttribute((const void*)length_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+    (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+    (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+    g_attr_set = true;
+}
+void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const double2* tw,
+                          const LengthTables& tab)
+{
+    if (n_len <= 0) return;
+    set_big_lds();
+    int grid = n_len < 256 ? n_len : 256;
+    hipLaunchKernelGGL(length_tables_kernel, dim3(grid), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lengths, st, tw, tab);
+}
+int channel_grid_blocks() { return 256; }
+void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
+                    const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
+                    double threshold, const double2* tw, const LengthTables& tab, double2* scratch, const ChannelOut& out)
+{
+    if (n_items <= 0) return;
+    set_big_lds();
+    int nh = st.N / 2;
+    size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
+    int grid = n_items < channel_grid_blocks() ? n_items : channel_grid_blocks();
+    hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(1024), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
+                       ask_model, threshold, tw, tab, scratch, ilog2(nh), out);
+}
+void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const double* theta, const int* type,
+                              const double* n_index, const double* R, const double* k_L, int model, int N, double dt,
+                              double2* spec)
+{
+    if (n <= 0) return;
+    int grid = n < 4096 ? n : 4096;
+    hipLaunchKernelGGL(askaryan_spectrum_kernel, dim3(grid), dim3(256), 0, s, n, energy, theta, type, n_index, R, k_L, model,
+                       N, dt, spec);
+}
+void launch_czt_test(hipStream_t s, int n_batch, int n_in, int n_out, int Q, double sgn, const double2* in, double2* out,
+                     const double2* tw, double2* Bscratch, int grid)
+{
+    set_big_lds();
+    hipLaunchKernelGGL(czt_test_kernel, dim3(grid), dim3(1024), (size_t)FFT_MAX * 16, s, n_batch, n_in, n_out, Q, sgn, in,
+                       out, tw, Bscratch);
+}
+
+}  // namespace nrhip

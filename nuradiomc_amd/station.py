@@ -1,0 +1,178 @@
+"""Station = flat-array detector description + filter chain handed to libnrhip (nrhip_station_desc)."""
+import ctypes
+import numpy as np
+from . import _lib as L
+from . import filters as flt
+
+ANTENNA_TO_INT = {'analytic_VPol': 0, 'analytic_HPol': 1}
+ASKARYAN_TO_INT = {'Alvarez2009': 0, 'Alvarez2000': 1, 'ZHS1992': 2}
+SHOWER_TO_INT = {'HAD': 0, 'EM': 1}
+
+
+class StationDesc(ctypes.Structure):
+    _fields_ = [('n_channels', ctypes.c_int32), ('position', L.c_double_p), ('cable_delay', L.c_double_p),
+                ('antenna_model', L.c_int32_p), ('orientation', L.c_double_p), ('n_samples', ctypes.c_int32),
+                ('sampling_rate', ctypes.c_double), ('readout_length', ctypes.c_double),
+                ('pre_pulse_time', ctypes.c_double), ('post_pulse_time', ctypes.c_double),
+                ('n_att_freq', ctypes.c_int32), ('att_freq', L.c_double_p), ('n_filters', ctypes.c_int32),
+                ('filter_nb', L.c_int32_p), ('filter_na', L.c_int32_p), ('filter_b', L.c_double_p),
+                ('filter_a', L.c_double_p)]
+
+
+class SimConfig(ctypes.Structure):
+    _fields_ = [('askaryan_model', ctypes.c_int32), ('delta_C_cut', ctypes.c_double),
+                ('min_efield_amplitude', ctypes.c_double), ('trigger_threshold', ctypes.c_double),
+                ('dump_traces', ctypes.c_int32)]
+
+
+class SimStats(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int64) for k in ('n_events', 'n_pairs', 'n_rays', 'n_candidate_events', 'n_triggered',
+                                              'n_channel_items', 'n_distinct_lengths')] + [('max_length', ctypes.c_int32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+L._OPTIONAL.update({
+    'nrhip_station_create': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StationDesc), L.c_void_pp]),
+    'nrhip_station_destroy': (None, [ctypes.c_void_p]),
+    'nrhip_simulate_events': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(SimConfig), ctypes.c_int64]
+                              + [ctypes.c_void_p] * 7 + [ctypes.POINTER(SimStats)]),
+    'nrhip_sim_fetch': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64]),
+    'nrhip_askaryan_spectrum_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, L.c_double_p, L.c_double_p,
+                                                     L.c_int32_p, L.c_double_p, L.c_double_p, L.c_double_p, ctypes.c_int32,
+                                                     ctypes.c_int32, ctypes.c_double, L.c_double_p]),
+    'nrhip_debug_czt': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.c_double, L.c_double_p, L.c_double_p]),
+})
+
+
+def attenuation_frequencies(frequency, n_freq, max_detector_freq=None):
+    """Sparse frequency grid of the attenuation calculation (NuRadioMC/SignalProp/analyticraytracing.py:885-931)."""
+    frequency = np.asarray(frequency, float)
+    non_null = frequency > 0
+    n = min(n_freq, int(np.sum(non_null)))
+    freqs = np.linspace(frequency[non_null].min(), frequency[non_null].max(), n)
+    if n < np.sum(non_null) and max_detector_freq is not None:
+        det_mask = frequency <= max_detector_freq
+        total = det_mask & non_null
+        n = min(n_freq, int(np.sum(total)))
+        freqs = np.linspace(frequency[total].min(), frequency[total].max(), n)
+        if np.sum(~det_mask) > 1:
+            freqs = np.append(freqs, np.linspace(frequency[~det_mask].min(), frequency[~det_mask].max(), n // 2))
+    return freqs
+
+
+DEFAULT_FILTERS = ((2, (0.08, 1000.)), (10, (0., 0.5)))  # NuRadioMC/examples/01_Veff_simulation/T02RunSimulation.py:18-22
+
+
+class Station:
+    """One station on one Context.
+
+    position [n_ch, 3] (m), antenna in {'analytic_VPol', 'analytic_HPol'} (one name or a list),
+    orientation (theta, phi, rotation theta, rotation phi) in rad (one tuple or [n_ch, 4]), cable_delay (ns),
+    n_samples / sampling_rate: the simulated trace grid; detector_sampling_rate: the detector's own ADC rate
+    (sets the attenuation grid's max_detector_freq, propagation_base_class.py:66-80);
+    filters: sequence of (order, (f_lo, f_hi)) Butterworth stages (f_lo = 0: low-pass) applied in order.
+    """
+
+    def __init__(self, ctx, position, antenna='analytic_VPol', orientation=(0., 0., np.pi / 2, np.pi / 2),
+                 cable_delay=0., n_samples=4096, sampling_rate=2.0, detector_sampling_rate=None, n_freq=25,
+                 filters=DEFAULT_FILTERS, pre_pulse_time=200., post_pulse_time=400., readout_length=None):
+        self.ctx = ctx
+        self._lib = L.load()
+        pos = L.f64(position).reshape(-1, 3)
+        n = len(pos)
+        names = [antenna] * n if isinstance(antenna, str) else list(antenna)
+        for a in names:
+            if a not in ANTENNA_TO_INT:
+                raise NotImplementedError("antenna model {} is not available (analytic_VPol, analytic_HPol)".format(a))
+        model = np.array([ANTENNA_TO_INT[a] for a in names], np.int32)
+        ori = np.ascontiguousarray(np.broadcast_to(L.f64(orientation), (n, 4)))
+        cab = np.ascontiguousarray(np.broadcast_to(L.f64(cable_delay), (n,)))
+        self.position, self.antenna, self.orientation, self.cable_delay = pos, names, ori, cab
+        self.n_samples, self.sampling_rate = int(n_samples), float(sampling_rate)
+        det_fs = float(detector_sampling_rate or sampling_rate)
+        ff = np.fft.rfftfreq(self.n_samples, 1. / self.sampling_rate)
+        self.att_freq = np.ascontiguousarray(attenuation_frequencies(ff, n_freq, 0.5 * det_fs))
+        self.filters = [flt.butter_analog(order, pb) for order, pb in filters]
+        nb = np.array([len(b) for b, _ in self.filters], np.int32)
+        na = np.array([len(a) for _, a in self.filters], np.int32)
+        fb = np.zeros((max(len(self.filters), 1), flt.MAX_POLY))
+        fa = np.zeros((max(len(self.filters), 1), flt.MAX_POLY))
+        for i, (b, a) in enumerate(self.filters):
+            fb[i, :len(b)] = b
+            fa[i, :len(a)] = a
+        self._keep = (pos, cab, model, ori, self.att_freq, nb, na, fb, fa)
+        d = StationDesc(n, L.dptr(pos), L.dptr(cab), L.iptr(model), L.dptr(ori), self.n_samples, self.sampling_rate,
+                        float(readout_length if readout_length is not None else self.n_samples / self.sampling_rate),
+                        float(pre_pulse_time), float(post_pulse_time), len(self.att_freq), L.dptr(self.att_freq),
+                        len(self.filters), L.iptr(nb), L.iptr(na), L.dptr(fb), L.dptr(fa))
+        h = ctypes.c_void_p()
+        L.check(self._lib.nrhip_station_create(ctx._h, ctypes.byref(d), ctypes.byref(h)))
+        self._h = h
+        self.vrms, self.vrms_efield = flt.vrms_from_filters(self.sampling_rate, self.filters)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.nrhip_station_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the hot path --------------------------------------------------------------------------------------
+    def simulate_events_dev(self, n_events, d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL, d_triggered,
+                            askaryan_model='Alvarez2009', delta_C_cut=0.698, min_efield_amplitude=None,
+                            trigger_threshold=None, dump_traces=False, want_stats=True):
+        """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None)."""
+        cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
+                        float(2.0 * self.vrms_efield if min_efield_amplitude is None else min_efield_amplitude),
+                        float(3.0 * self.vrms if trigger_threshold is None else trigger_threshold), int(bool(dump_traces)))
+        stats = SimStats()
+        L.check(self._lib.nrhip_simulate_events(self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith,
+                                                d_azimuth, d_energy, d_type, d_kL, d_triggered,
+                                                ctypes.byref(stats) if want_stats else None))
+        return stats.as_dict() if want_stats else None
+
+    def simulate_events(self, vertex, zenith, azimuth, energy, shower_type, k_L=None, **kw):
+        """Host-array convenience form: uploads the event list, runs the hot path, returns (triggered mask, stats)."""
+        ctx = self.ctx
+        vertex = L.f64(vertex).reshape(-1, 3)
+        n = len(vertex)
+        st = np.ascontiguousarray([SHOWER_TO_INT[str(s).upper()] if not isinstance(s, (int, np.integer)) else int(s)
+                                   for s in np.broadcast_to(shower_type, (n,))], dtype=np.int32)
+        kL = np.ascontiguousarray(np.broadcast_to(np.nan if k_L is None else L.f64(k_L), (n,)), dtype=np.float64)
+        kL = np.where(np.isnan(kL), 1.0, kL)
+        arrs = [vertex, np.ascontiguousarray(np.broadcast_to(L.f64(zenith), (n,))),
+                np.ascontiguousarray(np.broadcast_to(L.f64(azimuth), (n,))),
+                np.ascontiguousarray(np.broadcast_to(L.f64(energy), (n,))), st, np.ascontiguousarray(kL)]
+        dptrs = [ctx.to_device(a) for a in arrs]
+        dtrig = ctx.malloc(max(n, 1))
+        try:
+            stats = self.simulate_events_dev(n, *dptrs, dtrig, **kw)
+            trig = np.zeros(n, np.uint8)
+            ctx.to_host(trig, dtrig)
+        finally:
+            for p in dptrs + [dtrig]:
+                ctx.free(p)
+        return trig.astype(bool), stats
+
+    _FETCH_DTYPES = {'ray_event': np.int32, 'ray_channel': np.int32, 'ray_solution': np.int32, 'ev_n_rays': np.int32,
+                     'ev_L': np.int32, 'ev_candidate': np.uint8, 'item_event': np.int32, 'trace_offset': np.int64,
+                     'ray_r_theta': np.complex128, 'ray_r_phi': np.complex128, 'lengths': np.int32,
+                     'pair_n_sol': np.int32, 'slot_type': np.int32, 'ev_ray_begin': np.int32}
+
+    def fetch(self, name):
+        """One table of the last simulated batch as a numpy array (see include/nrhip.h: nrhip_sim_fetch)."""
+        n = self._lib.nrhip_sim_fetch(self._h, name.encode(), None, 0)
+        if n < 0:
+            raise L.NrhipError(self._lib.nrhip_last_error().decode())
+        dt = np.dtype(self._FETCH_DTYPES.get(name, np.float64))
+        out = np.zeros(n // dt.itemsize, dt)
+        if n:
+            self._lib.nrhip_sim_fetch(self._h, name.encode(), out.ctypes.data_as(ctypes.c_void_p), n)
+        return out
