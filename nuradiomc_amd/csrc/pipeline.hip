@@ -6,7 +6,6 @@
 // the list of distinct trace lengths (each needs one chirp table, built on device).
 #include "../../include/nrhip.h"
 #include "ctx.h"
-#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -173,6 +172,11 @@ void nrhip_station_destroy(nrhip_station* s)
         return b_.as<type>();                                                                       \
     })()
 #define NEED(ptr) if (!(ptr)) return nrhip_fail_msg("nrhip_simulate_events: out of device memory")
+#define LCHK(what)                                                          \
+    do {                                                                    \
+        hipError_t e_ = hipGetLastError();                                  \
+        if (e_ != hipSuccess) return nrhip_fail("launch " what, e_);        \
+    } while (0)
 
 int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_config* cfg, int64_t n_events,
                           const double* vertex, const double* zenith, const double* azimuth, const double* energy,
@@ -210,6 +214,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     NEED(rec.receive = WS("slot_receive", double, 3 * n_slots));
     NEED(rec.refl_angle = WS("slot_refl_angle", double, n_slots));
     launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec);
+    LCHK("raytrace");
 
     // 2. delta_C cut -> ordered list of kept rays
     int *keep, *offset;
@@ -217,11 +222,11 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     NEED(offset = WS("slot_offset", int, n_slots + 1));
     HIPCHK(hipMemsetAsync(keep + n_slots, 0, sizeof(int), sm));
     launch_select_rays(sm, n_pairs, n_ch, vertex, zenith, azimuth, rec, ctx->ice, cfg->delta_C_cut, keep);
-    size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, keep, offset, (int)(n_slots + 1), sm));
-    void* tmp;
-    NEED(tmp = WS("scan_tmp", unsigned char, tmp_bytes));
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, keep, offset, (int)(n_slots + 1), sm));
+    LCHK("select_rays");
+    int* scan_tmp;
+    NEED(scan_tmp = WS("scan_tmp", int, scan_tiles(n_slots + 1)));
+    launch_exclusive_scan(sm, n_slots + 1, keep, offset, scan_tmp);
+    LCHK("scan");
     int n_rays = 0;
     HIPCHK(hipMemcpyAsync(&n_rays, offset + n_slots, sizeof(int), hipMemcpyDeviceToHost, sm));
     HIPCHK(hipStreamSynchronize(sm));
@@ -263,16 +268,21 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
 
     if (n_rays > 0) {
         launch_scatter_slots(sm, n_slots, keep, offset, ray_slot);
+        LCHK("scatter");
         launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w);
+        LCHK("ray_setup");
         // 3. attenuation on the coarse frequency grid
         launch_ray_limits_from_slots(sm, n_rays, n_ch, ray_slot, vertex, sd.pos, rec, ctx->ice, zint);
+        LCHK("ray_limits");
         launch_attenuation_items(sm, n_rays, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr);
+        LCHK("attenuation");
         // 4. candidate cut on max |E(t)|
         launch_efield_max(sm, n_rays, w, evin, sd, cfg->askaryan_model, ctx->twiddle, max_efield);
+        LCHK("efield_max");
     }
     // 5. common time grid per event
     launch_event_grid(sm, (int)n_events, n_ch, offset, w, sd, max_efield, cfg->min_efield_amplitude, ev);
-    HIPCHK(hipGetLastError());
+    LCHK("event_grid");
     std::vector<int> hL(n_events);
     std::vector<unsigned char> hc(n_events);
     HIPCHK(hipMemcpyAsync(hL.data(), ev.L, sizeof(int) * n_events, hipMemcpyDeviceToHost, sm));
@@ -317,6 +327,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         NEED(tab.B_inv = WS("tab_B_inv", double2, lens.size() * (size_t)FFT_MAX));
         NEED(tab.vel = WS("tab_vel", double2, lens.size() * 2 * (size_t)NRHIP_SPEC_STRIDE));
         launch_length_tables(sm, (int)lens.size(), d_lens, sd, ctx->twiddle, tab);
+        LCHK("length_tables");
         // 6. channel voltages + trigger
         const int n_items = (int)cand.size() * n_ch;
         S.n_channel_items = n_items;
@@ -339,7 +350,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         NEED(scratch = WS("channel_scratch", double2, (size_t)channel_grid_blocks() * NRHIP_SPEC_STRIDE));
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, cfg->askaryan_model,
                        cfg->trigger_threshold, ctx->twiddle, tab, scratch, co);
-        HIPCHK(hipGetLastError());
+        LCHK("channel");
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here
     }
     if (stats) {

@@ -69,6 +69,8 @@ struct ChannelOut {
 
 void launch_select_rays(hipStream_t s, long n_pairs, int n_ch, const double* vertex, const double* zen, const double* az,
                         const RayRecords& rec, const IceConst& m, double cut, int* keep);
+long scan_tiles(long n);
+void launch_exclusive_scan(hipStream_t s, long n, const int* in, int* out, int* tile_tmp);
 void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const int* offset, int* ray_slot);
 void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex, const double* zen,
                       const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w);

@@ -97,6 +97,80 @@ select_rays_kernel(long n_pairs, int n_ch, const double* __restrict__ vertex, co
     }
 }
 
+// exclusive prefix sum of int flags, three small kernels (tile sums -> scan of tile sums -> per-tile scan)
+constexpr int SCAN_TILE = 2048;
+
+__global__ void __launch_bounds__(256) scan_tile_sums_kernel(long n, const int* __restrict__ in, int* __restrict__ tile_sum)
+{
+    __shared__ int red[256];
+    long base = (long)blockIdx.x * SCAN_TILE;
+    int s = 0;
+    for (int i = threadIdx.x; i < SCAN_TILE; i += 256) {
+        long k = base + i;
+        if (k < n) s += in[k];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(1024) scan_tile_offsets_kernel(int n_tiles, int* __restrict__ tile_sum)
+{
+    __shared__ int buf[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        int i = base + threadIdx.x;
+        int v = (i < n_tiles) ? tile_sum[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+            int t = ((int)threadIdx.x >= off) ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int incl = buf[threadIdx.x];
+        if (i < n_tiles) tile_sum[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) scan_within_tiles_kernel(long n, const int* __restrict__ in,
+                                                                const int* __restrict__ tile_off, int* __restrict__ out)
+{
+    // each thread owns 8 consecutive elements of the tile
+    __shared__ int part[256];
+    long base = (long)blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+    int v[8], s = 0;
+    for (int j = 0; j < 8; j++) {
+        long k = base + j;
+        v[j] = (k < n) ? in[k] : 0;
+        s += v[j];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int t = ((int)threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = tile_off[blockIdx.x] + part[threadIdx.x] - s;
+    for (int j = 0; j < 8; j++) {
+        long k = base + j;
+        if (k < n) out[k] = run;
+        run += v[j];
+    }
+}
+
 // keep flags + exclusive scan -> list of kept slots (ordered: event, channel, solution)
 __global__ void scatter_slots_kernel(long n_slots, const int* __restrict__ keep, const int* __restrict__ offset,
                                      int* __restrict__ ray_slot)
@@ -800,6 +874,15 @@ void launch_select_rays(hipStream_t s, long n_pairs, int n_ch, const double* ver
     hipLaunchKernelGGL(select_rays_kernel, dim3(grid_for(n_pairs, 256)), dim3(256), 0, s, n_pairs, n_ch, vertex, zen, az,
                        rec, m, cut, keep);
 }
+long scan_tiles(long n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+void launch_exclusive_scan(hipStream_t s, long n, const int* in, int* out, int* tile_tmp)
+{
+    if (n <= 0) return;
+    long nt = scan_tiles(n);
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)nt), dim3(256), 0, s, n, in, tile_tmp);
+    hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(1024), 0, s, (int)nt, tile_tmp);
+    hipLaunchKernelGGL(scan_within_tiles_kernel, dim3((unsigned)nt), dim3(256), 0, s, n, in, tile_tmp, out);
+}
 void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const int* offset, int* ray_slot)
 {
     if (n_slots <= 0) return;
@@ -842,9 +925,12 @@ static bool g_attr_set = false;
 static void set_big_lds()
 {
     if (g_attr_set) return;
-    (void)hipFuncSetAttribute((const void*)length_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
-    (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
-    (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+    // static + dynamic LDS must stay within the 160 KB (163840 B) of a CU
+    (void)hipFuncSetAttribute((const void*)length_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              FFT_MAX * 16 + (FFT_MAX / 2 + 1) * 8);
+    (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    (void)hipGetLastError();
     g_attr_set = true;
 }
 void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const double2* tw,
