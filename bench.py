@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path on BASELINE config 2: 1e6 events, 1 EeV-class showers, one 5-channel dipole
+station (S5), South-Pole exponential ice, SP1 attenuation, Alvarez2009, 4096-sample traces at 2 GHz.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the whole per-event hot path (ray tracing -> delta_C cut -> attenuation -> Askaryan ->
+candidate cut -> antenna + filter response on the event's common time grid -> threshold trigger) over one batch of
+synthetic events that is already resident in HBM.  Events shard across ranks (weak scaling: every rank owns
+`--events` events); the only collective is one all-gather of the per-rank triggered masks (RCCL via
+torch.distributed, backend nccl) after the timed loop's barrier -- there is no exchange inside the compute.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the step; `cpu_baseline` times the
+oracle (C ray tracer + numpy spectral chain, one thread) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ICE = (1.78, 0.423, 77.)           # southpole_2015 (NuRadioMC/utilities/medium.py:69)
+N_SAMPLES, FS = 4096, 2.0
+CHANNELS = np.array([[0., 0., -100. - i] for i in range(5)])
+ENERGY = 3e17                       # shower energy [eV] of a 1 EeV neutrino at <y> ~ 0.3
+HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s
+# algorithmic HBM bytes of the un-fused formulation, N = 4096, L = 5296
+B_RAY, B_CHANNEL, B_PAIR = 601216, 169504, 320
+
+
+def make_events(n, seed):
+    """uniform in r^2 <= (4 km)^2 and z in [-2.7 km, 0], isotropic directions, hadronic showers"""
+    rng = np.random.default_rng(seed)
+    r = np.sqrt(rng.uniform(0, 4000. ** 2, n))
+    phi = rng.uniform(0, 2 * np.pi, n)
+    vertex = np.stack([r * np.cos(phi), r * np.sin(phi), rng.uniform(-2700., 0., n)], axis=1)
+    zenith = np.arccos(rng.uniform(-1, 1, n))
+    azimuth = rng.uniform(0, 2 * np.pi, n)
+    return vertex, zenith, azimuth
+
+
+def cpu_baseline(n_sample, seed):
+    """The oracle on one host thread over the first n_sample events of the same synthetic list."""
+    from oracle import spectral_oracle as so  # checker / baseline only
+    vertex, zenith, azimuth = make_events(n_sample, seed)
+    st = so.Station(CHANNELS, n_samples=N_SAMPLES, fs=FS)
+    vrms, vrms_e = so.vrms_from_filters(FS)
+    t0 = time.time()
+    n_trig = 0
+    for i in range(n_sample):
+        o = so.simulate_event(vertex[i], zenith[i], azimuth[i], ENERGY, 'HAD', None, st, ICE, vrms, vrms_e)
+        n_trig += o['triggered']
+        if time.time() - t0 > 40:
+            n_sample = i + 1
+            break
+    dt = time.time() - t0
+    return dict(value=n_sample / dt, unit="events/s", cores=1, kind="port",
+                sample="%d events of the same synthetic list (oracle: C ray tracer + numpy chain), %.1f s, %d triggered"
+                       % (n_sample, dt, n_trig))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--events', type=int, default=1000000, help='events per rank and step')
+    ap.add_argument('--cpu-sample', type=int, default=3000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+
+    import nuradiomc_amd
+    ctx = nuradiomc_amd.Context(ICE, 'SP1', device=local_rank)
+    st = nuradiomc_amd.Station(ctx, CHANNELS, antenna='analytic_VPol', n_samples=N_SAMPLES, sampling_rate=FS, n_freq=25)
+    n = args.events
+    vertex, zenith, azimuth = make_events(n, 10 + rank)
+    d_in = [ctx.to_device(a) for a in (vertex, zenith, azimuth, np.full(n, ENERGY), np.zeros(n, np.int32), np.ones(n))]
+    if world > 1:
+        trig_t = torch.zeros(n, dtype=torch.uint8, device='cuda')
+        d_trig = trig_t.data_ptr()
+    else:
+        d_trig = ctx.malloc(n)
+
+    def barrier():
+        ctx.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step(want_stats):
+        return st.simulate_events_dev(n, *d_in, d_trig, askaryan_model='Alvarez2009', want_stats=want_stats)
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    stats = None
+    for k in range(args.steps):
+        stats = step(k == args.steps - 1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    n_trig_total = stats['n_triggered']
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        gathered = torch.empty(world * n, dtype=torch.uint8, device='cuda')
+        dist.all_gather_into_tensor(gathered, trig_t)  # the one collective: triggered masks over xGMI
+        n_trig_total = int(gathered.sum().item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+        value = world * n * args.steps / elapsed
+        sm = stats['stage_ms']
+        dom = max((k for k in sm if k != 'total'), key=lambda k: sm[k])
+        kernel_of = {'raytrace': 'raytrace_kernel', 'ray_setup': 'select/scan/ray_setup kernels',
+                     'attenuation': 'attenuation_kernel', 'efield_max': 'efield_max_kernel',
+                     'event_grid': 'event_grid_kernel + host hand-off', 'length_tables': 'length_tables_kernel',
+                     'channel': 'channel_kernel'}
+        units = {'raytrace': B_PAIR * stats['n_pairs'],
+                 'attenuation': 8 * 25 * stats['n_rays'] + 32 * stats['n_rays'],
+                 'efield_max': (2 * 2049 * 16 + 2 * 2049 * 16 + 2 * 4096 * 8) * stats['n_rays'],
+                 'channel': (B_RAY - (2 * 2049 * 16 + 2 * 2049 * 16 + 2 * 4096 * 8)) * stats['n_candidate_rays']
+                            + B_CHANNEL * stats['n_channel_items']}
+        alg_bytes = units.get(dom, 0)
+        achieved = alg_bytes / (sm[dom] * 1e-3) / 1e9 if sm[dom] > 0 else 0.
+        b_event = B_RAY * stats['n_rays'] + B_CHANNEL * stats['n_channel_items'] + B_PAIR * stats['n_pairs']
+        out = {
+            "metric": "simulated events/sec (1e6-evt 1 EeV SP survey)", "value": value, "unit": "events/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d events/GPU, 3e17 eV hadronic showers, 5-ch analytic_VPol "
+                                   "station at -100..-104 m, southpole_2015 ice, SP1, Alvarez2009, 4096 samples @ 2 GHz, "
+                                   "Butterworth 80-500 MHz, 3 Vrms threshold" % n,
+                       "events_per_gpu": n, "n_pairs": stats['n_pairs'], "n_rays": stats['n_rays'],
+                       "n_candidate_events": stats['n_candidate_events'], "n_triggered_rank0": stats['n_triggered'],
+                       "n_triggered_all": n_trig_total, "n_distinct_trace_lengths": stats['n_distinct_lengths'],
+                       "triggered_events_per_s": n_trig_total / (elapsed / max(args.steps, 1)),
+                       "stage_ms_last_step": {k: round(v, 3) for k, v in sm.items()}},
+            "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": sm[dom],
+                         "whole_step_equivalent_GBs": b_event / (sm['total'] * 1e-3) / 1e9 if sm['total'] > 0 else 0.,
+                         "note": "kernels are FP64-VALU/LDS bound; bytes are SURVEY 8(d)'s un-fused algorithmic traffic"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 10)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

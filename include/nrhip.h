@@ -143,9 +143,16 @@ typedef struct {
     int32_t dump_traces;          /* != 0: keep the channel voltage traces of the chunk for nrhip_sim_fetch */
 } nrhip_sim_config;
 
+#define NRHIP_N_STAGES 8
+/* stage_ms: device time (HIP events on the context's stream) of 0 ray tracing, 1 ray selection + setup,
+ * 2 attenuation, 3 candidate cut (efield maximum), 4 event grid (+ host hand-off), 5 per-length tables,
+ * 6 channel voltages + trigger, 7 whole call.                                                            */
 typedef struct {
     int64_t n_events, n_pairs, n_rays, n_candidate_events, n_triggered, n_channel_items, n_distinct_lengths;
+    int64_t n_candidate_rays;
     int32_t max_length;
+    int32_t reserved;
+    double stage_ms[NRHIP_N_STAGES];
 } nrhip_sim_stats;
 
 typedef struct nrhip_station nrhip_station;

@@ -51,5 +51,6 @@ struct nrhip_station {
     std::map<std::string, DevArray> ws;
     std::map<std::string, size_t> ws_bytes;  // valid bytes of the last chunk
     std::vector<int> h_lengths;              // distinct trace lengths of the last chunk
+    hipEvent_t evt[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevArray& buf(const std::string& name) { return ws[name]; }
 };

@@ -159,6 +159,7 @@ void nrhip_station_destroy(nrhip_station* s)
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (auto& kv : s->ws) kv.second.release();
+    for (auto& e : s->evt) if (e) (void)hipEventDestroy(e);
     s->d_pos.release(); s->d_cable.release(); s->d_model.release();
     s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release();
     delete s;
@@ -200,6 +201,9 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     const long n_pairs = n_events * n_ch, n_slots = n_pairs * NRHIP_MAXS;
     if (n_slots > 2000000000L) return nrhip_fail_msg("nrhip_simulate_events: batch too large, split the event list");
     S.n_pairs = n_pairs;
+    for (auto& e : st->evt) if (!e) HIPCHK(hipEventCreate(&e));
+#define MARK(i) HIPCHK(hipEventRecord(st->evt[i], sm))
+    MARK(0);
     HIPCHK(hipMemsetAsync(triggered, 0, n_events, sm));
 
     // 1. ray tracing for every (event, channel) pair
@@ -215,6 +219,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     NEED(rec.refl_angle = WS("slot_refl_angle", double, n_slots));
     launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec);
     LCHK("raytrace");
+    MARK(1);
 
     // 2. delta_C cut -> ordered list of kept rays
     int *keep, *offset;
@@ -271,15 +276,22 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         LCHK("scatter");
         launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w);
         LCHK("ray_setup");
+    }
+    MARK(2);
+    if (n_rays > 0) {
         // 3. attenuation on the coarse frequency grid
         launch_ray_limits_from_slots(sm, n_rays, n_ch, ray_slot, vertex, sd.pos, rec, ctx->ice, zint);
         LCHK("ray_limits");
         launch_attenuation_items(sm, n_rays, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr);
         LCHK("attenuation");
+    }
+    MARK(3);
+    if (n_rays > 0) {
         // 4. candidate cut on max |E(t)|
         launch_efield_max(sm, n_rays, w, evin, sd, cfg->askaryan_model, ctx->twiddle, max_efield);
         LCHK("efield_max");
     }
+    MARK(4);
     // 5. common time grid per event
     launch_event_grid(sm, (int)n_events, n_ch, offset, w, sd, max_efield, cfg->min_efield_amplitude, ev);
     LCHK("event_grid");
@@ -289,6 +301,9 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     HIPCHK(hipMemcpyAsync(hc.data(), ev.candidate, n_events, hipMemcpyDeviceToHost, sm));
     HIPCHK(hipStreamSynchronize(sm));
 
+    MARK(5);
+    MARK(6);
+    MARK(7);
     // host: candidate event list, distinct trace lengths
     std::vector<int> cand;
     cand.reserve(n_events / 8 + 16);
@@ -322,12 +337,22 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         HIPCHK(hipMemcpyAsync(d_lens, lens.data(), sizeof(int) * lens.size(), hipMemcpyHostToDevice, sm));
         HIPCHK(hipMemcpyAsync(d_len_index, len_index.data(), sizeof(int) * n_events, hipMemcpyHostToDevice, sm));
         HIPCHK(hipMemcpyAsync(d_cand, cand.data(), sizeof(int) * cand.size(), hipMemcpyHostToDevice, sm));
+        int64_t ncr = 0;
+        {
+            std::vector<int> hn(n_events);
+            HIPCHK(hipMemcpyAsync(hn.data(), ev.n_rays, sizeof(int) * n_events, hipMemcpyDeviceToHost, sm));
+            HIPCHK(hipStreamSynchronize(sm));
+            for (int e : cand) ncr += hn[e];
+        }
+        S.n_candidate_rays = ncr;
+        MARK(5);
         LengthTables tab;
         NEED(tab.B_fwd = WS("tab_B_fwd", double2, lens.size() * (size_t)FFT_MAX));
         NEED(tab.B_inv = WS("tab_B_inv", double2, lens.size() * (size_t)FFT_MAX));
         NEED(tab.vel = WS("tab_vel", double2, lens.size() * 2 * (size_t)NRHIP_SPEC_STRIDE));
         launch_length_tables(sm, (int)lens.size(), d_lens, sd, ctx->twiddle, tab);
         LCHK("length_tables");
+        MARK(6);
         // 6. channel voltages + trigger
         const int n_items = (int)cand.size() * n_ch;
         S.n_channel_items = n_items;
@@ -351,8 +376,10 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, cfg->askaryan_model,
                        cfg->trigger_threshold, ctx->twiddle, tab, scratch, co);
         LCHK("channel");
+        MARK(7);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here
     }
+    MARK(8);
     if (stats) {
         // count triggers on device-resident mask (cheap D2H of n bytes only when asked for stats)
         std::vector<unsigned char> ht(n_events);
@@ -361,6 +388,12 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         int64_t nt = 0;
         for (unsigned char t : ht) nt += t;
         S.n_triggered = nt;
+        for (int i = 0; i < 7; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, st->evt[i], st->evt[i + 1]) == hipSuccess) S.stage_ms[i] = ms;
+        }
+        float tot = 0.f;
+        if (hipEventElapsedTime(&tot, st->evt[0], st->evt[8]) == hipSuccess) S.stage_ms[7] = tot;
         *stats = S;
     } else {
         HIPCHK(hipStreamSynchronize(sm));

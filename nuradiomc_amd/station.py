@@ -27,10 +27,15 @@ class SimConfig(ctypes.Structure):
 
 class SimStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int64) for k in ('n_events', 'n_pairs', 'n_rays', 'n_candidate_events', 'n_triggered',
-                                              'n_channel_items', 'n_distinct_lengths')] + [('max_length', ctypes.c_int32)]
+                                              'n_channel_items', 'n_distinct_lengths', 'n_candidate_rays')] + \
+               [('max_length', ctypes.c_int32), ('reserved', ctypes.c_int32), ('stage_ms', ctypes.c_double * 8)]
+
+    STAGES = ('raytrace', 'ray_setup', 'attenuation', 'efield_max', 'event_grid', 'length_tables', 'channel', 'total')
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_[:9]}
+        d['stage_ms'] = {n: float(self.stage_ms[i]) for i, n in enumerate(self.STAGES)}
+        return d
 
 
 L._OPTIONAL.update({
