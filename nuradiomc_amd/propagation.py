@@ -1,0 +1,232 @@
+"""Drop-in for the reference's analytic ray tracer plugin.
+
+`ray_tracing` has the constructor and methods of NuRadioMC.SignalProp.analyticraytracing.ray_tracing
+(NuRadioMC/SignalProp/analyticraytracing.py:1932-3052) / ray_tracing_base
+(NuRadioMC/SignalProp/propagation_base_class.py), with the same argument meaning and error behaviour, and runs
+every computation on the GPU through libnrhip.  `get_propagation_module('analytic')` mirrors
+NuRadioMC/SignalProp/propagation.py:21-56 so that `simulation.py:1237` can take the class from here.
+
+Per-pair calls are thin wrappers over the batch entry points; the batched path a simulation should use is
+`Context.find_solutions_batch` / `Station.simulate_events`.
+"""
+import logging
+import numpy as np
+from .context import Context
+
+solution_types = {1: 'direct', 2: 'refracted', 3: 'reflected'}
+solution_types_revert = {v: k for k, v in solution_types.items()}
+available_modules = ['analytic']
+
+_contexts = {}
+
+
+def _context_for(medium, attenuation_model, device=0):
+    key = (float(medium.n_ice), float(medium.delta_n), float(medium.z_0), attenuation_model, device)
+    if key not in _contexts:
+        _contexts[key] = Context(key[:3], attenuation_model, device=device)
+    return _contexts[key]
+
+
+def get_propagation_module(name=None):
+    if name == 'analytic':
+        return ray_tracing
+    raise NotImplementedError("Module '{}' not implemented. Available modules: {}".format(name, str(available_modules)))
+
+
+def _fresnel(zenith, n_2, n_1):
+    """get_fresnel_r_p / get_fresnel_r_s (NuRadioReco/utilities/geometryUtilities.py:208-263)"""
+    n = n_2 / n_1
+    s = np.lib.scimath.sqrt(n ** 2 - np.sin(zenith) ** 2)
+    r_p = np.conjugate((n ** 2 * np.cos(zenith) - s) / (n ** 2 * np.cos(zenith) + s))
+    r_s = np.conjugate((np.cos(zenith) - s) / (np.cos(zenith) + s))
+    return r_p, r_s
+
+
+class ray_tracing:
+    def __init__(self, medium, attenuation_model=None, log_level=logging.NOTSET, n_frequencies_integration=None,
+                 n_reflections=None, config=None, detector=None, ray_tracing_2D_kwards={}, use_cpp=None,
+                 compile_numba=None, device=0):
+        self.__logger = logging.getLogger('nuradiomc_amd.ray_tracing')
+        self.__logger.setLevel(log_level)
+        for attr in ('n_ice', 'delta_n', 'z_0'):
+            if not hasattr(medium, attr):
+                raise TypeError("The analytic raytracer can only handle ice model of the type 'IceModelSimple'")
+        if not medium.delta_n > 0:
+            raise RuntimeError('Analytic raytracer does not work with a uniform ice model. '
+                               'Abort.... ! Use direct raytracing or a non-uniform ice model instead.')
+        self._medium = medium
+        self._config = config
+        # propagation_base_class.py:86-133: config values override constructor arguments
+        self._n_frequencies_integration = None
+        self._n_reflections = None
+        self._attenuation_model = None
+        if config is not None:
+            prop = config['propagation']
+            self._n_frequencies_integration = prop.get('n_freq')
+            self._n_reflections = prop.get('n_reflections')
+            self._attenuation_model = prop.get('attenuation_model')
+        if self._n_frequencies_integration is None:
+            self._n_frequencies_integration = n_frequencies_integration or 100
+        if self._n_reflections is None:
+            self._n_reflections = n_reflections or 0
+        if self._attenuation_model is None:
+            self._attenuation_model = attenuation_model or 'SP1'
+        if self._n_reflections:
+            if getattr(medium, 'reflection', None) is None:
+                self.__logger.warning("Ray paths with bottom reflections requested but medium does not have any "
+                                      "reflective layer, setting number of reflections to zero.")
+                self._n_reflections = 0
+            else:
+                raise NotImplementedError("bottom reflections (n_reflections > 0) are not provided yet")
+        self.set_config(config)
+        self._detector = detector
+        self._max_detector_frequency = None
+        if detector is not None:  # propagation_base_class.py:66-80
+            for station_id in detector.get_station_ids():
+                ch0 = detector.get_channel_ids(station_id)[0]
+                fs = detector.get_sampling_frequency(station_id, ch0)
+                if self._max_detector_frequency is None or fs * .5 > self._max_detector_frequency:
+                    self._max_detector_frequency = fs * .5
+        self._ctx = _context_for(medium, self._attenuation_model, device)
+        self.use_cpp = False
+        self.reset_solutions()
+
+    # ---- state ---------------------------------------------------------------------------------------------
+    def reset_solutions(self):
+        self._X1 = None
+        self._X2 = None
+        self._results = None
+        self._tab = None
+
+    def set_start_and_end_point(self, x1, x2):
+        self.reset_solutions()
+        self._X1 = np.array(x1, dtype=float)
+        self._X2 = np.array(x2, dtype=float)
+
+    def use_optional_function(self, function_name, *args, **kwargs):
+        if hasattr(self, function_name):
+            getattr(self, function_name)(*args, **kwargs)
+
+    def set_solution(self, raytracing_results):
+        raise NotImplementedError("set_solution is not provided (re-run find_solutions)")
+
+    def find_solutions(self):
+        if self._X2[2] > 0 or self._X1[2] > 0:
+            raise NotImplementedError("ice-to-air / air-to-ice ray tracing is not provided yet")
+        t = self._ctx.find_solutions_batch(self._X1[None], self._X2[None])
+        self._tab = {k: v[0] for k, v in t.items()}
+        n = int(self._tab['n_sol'])
+        self._results = [{'type': int(self._tab['type'][i]), 'C0': float(self._tab['C0'][i]),
+                          'C1': float(self._tab['C1'][i]), 'reflection': 0, 'reflection_case': 1} for i in range(n)]
+
+    def has_solution(self):
+        return len(self._results) > 0
+
+    def get_number_of_solutions(self):
+        return len(self._results)
+
+    def get_results(self):
+        return self._results
+
+    def get_number_of_raytracing_solutions(self):
+        return 2 + 4 * self._n_reflections
+
+    def _check(self, iS):
+        n = self.get_number_of_solutions()
+        if iS >= n:
+            self.__logger.error("solution number {:d} requested but only {:d} solutions exist".format(iS + 1, n))
+            raise IndexError
+
+    def get_solution_type(self, iS):
+        self._check(iS)
+        return int(self._tab['type'][iS])
+
+    def get_launch_vector(self, iS):
+        self._check(iS)
+        return self._tab['launch'][iS].copy()
+
+    def get_receive_vector(self, iS):
+        self._check(iS)
+        return self._tab['receive'][iS].copy()
+
+    def get_reflection_angle(self, iS):
+        self._check(iS)
+        a = self._tab['refl_angle'][iS]
+        return None if np.isnan(a) else float(a)
+
+    def get_path_length(self, iS, analytic=True):
+        self._check(iS)
+        return float(self._tab['D'][iS])
+
+    def get_travel_time(self, iS, analytic=True):
+        self._check(iS)
+        return float(self._tab['T'][iS])
+
+    def get_path(self, iS, n_points=1000):
+        raise NotImplementedError("get_path is a plotting helper and is not provided")
+
+    def get_attenuation(self, iS, frequency, max_detector_freq=None):
+        """analyticraytracing.py:2744 -> :933-1089: coarse grid on the GPU, np.interp on the host, DC = 1"""
+        from .station import attenuation_frequencies
+        self._check(iS)
+        frequency = np.asarray(frequency, float)
+        freqs = attenuation_frequencies(frequency, self._n_frequencies_integration, max_detector_freq)
+        coarse = self._ctx.attenuation_batch(self._X1[None], self._X2[None], [self._results[iS]['C0']], freqs)[0]
+        out = np.ones_like(frequency)
+        mask = frequency > 0
+        out[mask] = np.interp(frequency[mask], freqs, coarse)
+        return out
+
+    def get_focusing(self, iS, dz=-0.01, limit=2., analytic=False):
+        raise NotImplementedError("focusing is not provided yet")
+
+    def get_output_parameters(self):
+        return [{'name': 'ray_tracing_C0', 'ndim': 1}, {'name': 'ray_tracing_C1', 'ndim': 1},
+                {'name': 'focusing_factor', 'ndim': 1}, {'name': 'ray_tracing_reflection', 'ndim': 1},
+                {'name': 'ray_tracing_reflection_case', 'ndim': 1}, {'name': 'ray_tracing_solution_type', 'ndim': 1}]
+
+    def get_raytracing_output(self, i_solution):
+        self._check(i_solution)
+        if self._config['propagation']['focusing']:
+            raise NotImplementedError("focusing is not provided yet")
+        r = self._results[i_solution]
+        return {'ray_tracing_C0': r['C0'], 'ray_tracing_C1': r['C1'], 'ray_tracing_reflection': r['reflection'],
+                'ray_tracing_reflection_case': r['reflection_case'],
+                'ray_tracing_solution_type': self.get_solution_type(i_solution), 'focusing_factor': 1}
+
+    def apply_propagation_effects(self, efield, i_solution):
+        """analyticraytracing.py:2937-3033 for in-ice rays: attenuation and surface-reflection Fresnel factors.
+        `efield` is any object with get_frequency_spectrum / get_frequencies / get_sampling_rate /
+        set_frequency_spectrum (the reference's ElectricField)."""
+        spec = efield.get_frequency_spectrum()
+        prop = self._config['propagation']
+        if prop['attenuate_ice']:
+            max_freq = np.max(efield.get_frequencies()) if self._max_detector_frequency is None \
+                else self._max_detector_frequency
+            spec *= self.get_attenuation(i_solution, efield.get_frequencies(), max_freq)
+        zenith_reflection = self.get_reflection_angle(i_solution)
+        if zenith_reflection is not None:
+            n1 = self._medium.n_ice - self._medium.delta_n * np.exp(-0.01 / self._medium.z_0)
+            r_theta, r_phi = _fresnel(zenith_reflection, n_2=1., n_1=n1)
+            try:
+                from NuRadioReco.framework.parameters import electricFieldParameters as efp
+                efield[efp.reflection_coefficient_theta] = r_theta
+                efield[efp.reflection_coefficient_phi] = r_phi
+            except Exception:
+                pass
+            spec[1] *= r_theta
+            spec[2] *= r_phi
+        if prop.get('focusing') or prop.get('birefringence'):
+            raise NotImplementedError("focusing / birefringence are not provided yet")
+        efield.set_frequency_spectrum(spec, efield.get_sampling_rate())
+        return efield
+
+    def get_config(self):
+        return self._config
+
+    def set_config(self, config):
+        if config is None:
+            self._config = {'propagation': {'attenuate_ice': True, 'focusing_limit': 2, 'focusing': False,
+                                            'birefringence': False}}
+        else:
+            self._config = config

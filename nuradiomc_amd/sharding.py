@@ -1,0 +1,32 @@
+"""Event sharding across ranks (one process per GPU) and the gather of triggered masks.
+
+Events are independent, so rank r of W owns the contiguous index range shard_range(n, r, W); nothing is exchanged
+during the compute.  `gather_triggered` is the only collective: an all-gather of the per-rank uint8 masks
+(RCCL over xGMI with backend 'nccl' on GPUs, gloo in the CPU tests)."""
+import numpy as np
+
+
+def shard_range(n_events, rank, world_size):
+    """contiguous, balanced: the first n % W ranks get one extra event"""
+    base, extra = divmod(int(n_events), int(world_size))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def gather_triggered(local_mask, n_events, dist=None, device=None):
+    """all-gather variable-length uint8 masks into the full [n_events] mask (same on every rank)"""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return np.asarray(local_mask, np.uint8).copy()
+    W, r = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(n_events, k, W)[1] - shard_range(n_events, k, W)[0] for k in range(W)]
+    pad = max(sizes)
+    t = torch.zeros(pad, dtype=torch.uint8, device=device)
+    if isinstance(local_mask, torch.Tensor):
+        t[:sizes[r]] = local_mask[:sizes[r]]
+    else:
+        t[:sizes[r]] = torch.from_numpy(np.ascontiguousarray(local_mask, dtype=np.uint8)).to(t.device)[:sizes[r]]
+    out = torch.empty(W * pad, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(out, t)
+    out = out.cpu().numpy().reshape(W, pad)
+    return np.concatenate([out[k, :sizes[k]] for k in range(W)])

@@ -1,0 +1,120 @@
+"""The host-side mirrors of the reference's plugin interfaces, written like the reference's own tests."""
+import numpy as np
+import pytest
+from conftest import golden, max_rel
+from oracle import raytrace_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+class _Ice:
+    def __init__(self, n_ice, delta_n, z_0):
+        self.n_ice, self.delta_n, self.z_0 = n_ice, delta_n, z_0
+        self.reflection = None
+
+
+def test_askaryan_unit_test_like_U01():
+    """NuRadioMC/test/SignalGen/U01unit_test.py: get_time_trace for 2 models x 5 energies x {EM, HAD} x 10 angles
+    against NuRadioMC/test/SignalGen/reference_v2.npy (assert_almost_equal, 7 decimals), including the EM k_L random
+    stream (seed 1234, one RandomState per model)."""
+    from nuradiomc_amd import askaryan
+    askaryan._random_generators.clear()
+    g = golden('ref_askaryan_v2.npz')
+    for i in range(len(g['model'])):
+        trace = askaryan.get_time_trace(float(g['energy'][i]), float(g['theta'][i]), int(g['N']), float(g['dt']),
+                                        str(g['shower_type'][i]), float(g['n_index']), float(g['R']), str(g['model'][i]),
+                                        seed=int(g['seed']))
+        np.testing.assert_almost_equal(trace, g['trace'][i], decimal=7)
+        ref = g['trace'][i]
+        assert np.max(np.abs(trace - ref)) <= 1e-9 * max(np.max(np.abs(ref)), 1e-300)
+    with pytest.raises(NotImplementedError):
+        askaryan.get_frequency_spectrum(1e18, 1., 256, 0.5, 'HAD', 1.78, 1000., 'ARZ2020')
+
+
+def test_ray_tracing_class_like_T05():
+    """NuRadioMC/test/SignalProp/T05unit_test_C0_SP.py through the drop-in class, first 150 vertices."""
+    from nuradiomc_amd import propagation
+    g = golden('ref_C0_SP.npz')
+    ice = _Ice(*g['ice'])
+    r = propagation.get_propagation_module('analytic')(ice)
+    n = 150
+    C0 = np.zeros((n, 2))
+    for iX, x in enumerate(g['points'][:n]):
+        r.set_start_and_end_point(x, g['x_receiver'])
+        r.find_solutions()
+        if r.has_solution():
+            for iS in range(r.get_number_of_solutions()):
+                C0[iX, iS] = r.get_results()[iS]['C0']
+    np.testing.assert_allclose(C0, g['C0_ref'][:n], rtol=1e-6, atol=1e-8)
+
+
+def test_ray_tracing_class_api_and_errors():
+    from nuradiomc_amd import propagation
+    g = golden('raytrace_A.npz')
+    ice = _Ice(*g['ice'])
+    cfg = {'propagation': {'attenuate_ice': True, 'focusing': False, 'focusing_limit': 2, 'birefringence': False,
+                           'n_freq': 25, 'attenuation_model': 'SP1', 'n_reflections': 0}}
+    r = propagation.ray_tracing(ice, config=cfg)
+    i = int(np.where(g['n_sol'] == 2)[0][0])
+    r.set_start_and_end_point(g['x1'][i], g['x2'][i])
+    r.find_solutions()
+    assert r.get_number_of_solutions() == 2 and r.get_number_of_raytracing_solutions() == 2
+    for iS in range(2):
+        assert r.get_solution_type(iS) == g['type'][i, iS]
+        assert abs(r.get_path_length(iS) - g['D'][i, iS]) < 1e-6 * g['D'][i, iS]
+        assert abs(r.get_travel_time(iS) - g['T'][i, iS]) < 1e-6 * g['T'][i, iS]
+        assert np.max(np.abs(r.get_launch_vector(iS) - g['launch'][i, iS])) < 1e-6
+        assert np.max(np.abs(r.get_receive_vector(iS) - g['receive'][i, iS])) < 1e-6
+        ra = r.get_reflection_angle(iS)
+        assert (ra is None) == bool(np.isnan(g['refl_angle'][i, iS]))
+        out = r.get_raytracing_output(iS)
+        assert out['ray_tracing_solution_type'] == g['type'][i, iS] and out['focusing_factor'] == 1
+    if i < g['att'].shape[0]:
+        ff = np.fft.rfftfreq(4096, 0.5)
+        att = r.get_attenuation(0, ff, 1.0)
+        ref = np.ones_like(ff)
+        ref[1:] = np.interp(ff[1:], g['fcoarse'], g['att'][i, 0])
+        assert att[0] == 1 and np.max(np.abs(att - ref) / ref) < 1e-6
+    with pytest.raises(IndexError):
+        r.get_launch_vector(2)
+    with pytest.raises(TypeError):
+        propagation.ray_tracing(object())
+    with pytest.raises(NotImplementedError):
+        propagation.get_propagation_module('radiopropa')
+    # a pair in the shadow zone: no solution
+    j = int(np.where(g['n_sol'] == 0)[0][0])
+    r.set_start_and_end_point(g['x1'][j], g['x2'][j])
+    r.find_solutions()
+    assert not r.has_solution() and r.get_results() == []
+
+
+def test_apply_propagation_effects_like_reference():
+    """apply_propagation_effects on a duck-typed ElectricField: attenuation * Fresnel (reflected ray)"""
+    from nuradiomc_amd import propagation
+    g = golden('raytrace_B.npz')  # shallow receiver -> reflected rays exist
+    ice = _Ice(*g['ice'])
+    cfg = {'propagation': {'attenuate_ice': True, 'focusing': False, 'focusing_limit': 2, 'birefringence': False,
+                           'n_freq': 25, 'attenuation_model': 'SP1'}}
+    r = propagation.ray_tracing(ice, config=cfg)
+    i, s = [(a, b) for a, b in zip(*np.where(g['type'][:g['att'].shape[0]] == 3))][0]
+    r.set_start_and_end_point(g['x1'][i], g['x2'][i])
+    r.find_solutions()
+
+    class EF:
+        def __init__(self):
+            self.fs = 2.0
+            self.spec = np.ones((3, 2049), complex)
+        def get_frequency_spectrum(self): return self.spec
+        def get_frequencies(self): return np.fft.rfftfreq(4096, 0.5)
+        def get_sampling_rate(self): return self.fs
+        def set_frequency_spectrum(self, s, fs): self.spec = s
+        def __setitem__(self, k, v): pass
+    ef = r.apply_propagation_effects(EF(), int(s))
+    ff = ef.get_frequencies()
+    att = np.ones_like(ff)
+    att[1:] = np.interp(ff[1:], g['fcoarse'], g['att'][i, s])
+    from oracle import spectral_oracle as so
+    n1 = ice.n_ice - ice.delta_n * np.exp(-0.01 / ice.z_0)
+    rp, rs = so.fresnel_r_p(g['refl_angle'][i, s], 1., n1), so.fresnel_r_s(g['refl_angle'][i, s], 1., n1)
+    assert np.max(np.abs(ef.spec[0] - att)) < 1e-6
+    assert np.max(np.abs(ef.spec[1] - att * rp)) < 1e-6 and np.max(np.abs(ef.spec[2] - att * rs)) < 1e-6

@@ -1,0 +1,45 @@
+"""N > 1 path on CPU: world size 2, gloo.  Shard ranges tile the event list; the all-gather of triggered masks
+reassembles the global mask in event order on every rank."""
+import os
+import sys
+import numpy as np
+import torch.multiprocessing as mp
+from conftest import ROOT
+from nuradiomc_amd.sharding import shard_range
+
+
+def test_shard_ranges_tile_the_event_list():
+    for n in (0, 1, 7, 1000, 1000003):
+        for W in (1, 2, 3, 8):
+            r = [shard_range(n, k, W) for k in range(W)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(W - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, n, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from nuradiomc_amd.sharding import shard_range, gather_triggered
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    full = (np.arange(n) * 7919 % 13 == 0).astype(np.uint8)   # what a single process would have produced
+    a, b = shard_range(n, rank, world)
+    got = gather_triggered(full[a:b], n, dist=dist)
+    q.put((rank, bool(np.array_equal(got, full))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_triggered_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, 1001, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == {0: True, 1: True}
