@@ -141,6 +141,8 @@ typedef struct {
     double min_efield_amplitude;  /* absolute candidate cut [V/m] = speedup.min_efield_amplitude * Vrms_efield */
     double trigger_threshold;     /* simple threshold [V] on any channel                                */
     int32_t dump_traces;          /* != 0: keep the channel voltage traces of the chunk for nrhip_sim_fetch */
+    int32_t no_pruning;           /* != 0: evaluate attenuation and max |E(t)| for EVERY kept ray (parity tests); by
+                                     default rays of events that provably cannot pass the candidate cut are skipped */
 } nrhip_sim_config;
 
 #define NRHIP_N_STAGES 8
@@ -150,6 +152,7 @@ typedef struct {
 typedef struct {
     int64_t n_events, n_pairs, n_rays, n_candidate_events, n_triggered, n_channel_items, n_distinct_lengths;
     int64_t n_candidate_rays;
+    int64_t n_active_rays;        /* rays that went through the attenuation quadrature */
     int32_t max_length;
     int32_t reserved;
     double stage_ms[NRHIP_N_STAGES];

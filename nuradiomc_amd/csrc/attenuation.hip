@@ -512,13 +512,15 @@ __device__ inline double quad_gk21(double a, double b, bool with_point, double p
 __global__ void __launch_bounds__(256)
 attenuation_kernel(long n_rays, const double* __restrict__ C0, const double* __restrict__ zint, int n_freq,
                    const double* __restrict__ freqs, int model, IceConst m, double* __restrict__ att,
-                   int* __restrict__ neval)
+                   int* __restrict__ neval, const int* __restrict__ ray_index)
 {
     long n_items = n_rays * n_freq;
-    for (long item = blockIdx.x * (long)blockDim.x + threadIdx.x; item < n_items;
-         item += (long)gridDim.x * blockDim.x) {
-        long ray = item / n_freq;
-        int jf = (int)(item - ray * n_freq);
+    for (long it0 = blockIdx.x * (long)blockDim.x + threadIdx.x; it0 < n_items;
+         it0 += (long)gridDim.x * blockDim.x) {
+        long ray = it0 / n_freq;
+        int jf = (int)(it0 - ray * n_freq);
+        if (ray_index) ray = ray_index[ray];  // optional indirection: only the listed rays are integrated
+        const long item = ray * n_freq + jf;
         AttItem it;
         it.C0 = C0[ray];
         double z1 = zint[3 * ray], z2m = zint[3 * ray + 1];
@@ -603,7 +605,8 @@ void launch_ray_limits(hipStream_t stream, long n_rays, const double* x1, const 
 }
 
 void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
-                              const double* freqs, int model, const IceConst& m, double* att, int* neval)
+                              const double* freqs, int model, const IceConst& m, double* att, int* neval,
+                              const int* ray_index)
 {
     long n_items = n_rays * n_freq;
     if (n_items <= 0) return;
@@ -611,7 +614,7 @@ void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0,
     long grid = (n_items + block - 1) / block;
     if (grid > 256L * 64) grid = 256L * 64;
     hipLaunchKernelGGL(attenuation_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, zint, n_freq,
-                       freqs, model, m, att, neval);
+                       freqs, model, m, att, neval, ray_index);
 }
 
 }  // namespace nrhip

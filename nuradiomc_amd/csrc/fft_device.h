@@ -30,7 +30,28 @@ __device__ inline double2 cscale(double2 a, double s) { return make_double2(a.x 
 __device__ inline void fft_dif(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
 {
     const int M = 1 << log2m;
-    for (int s = 0; s < log2m; s++) {
+    int s = 0;
+    // two radix-2 stages fused in registers (same operations, same rounding as two separate stages): half the LDS
+    // traffic and half the barriers
+    for (; s + 1 < log2m; s += 2) {
+        const int q = M >> (s + 2);             // span of the second stage; the first stage has span 2q
+        const int ts1 = (FFT_MAX / 2) / (2 * q), ts2 = (FFT_MAX / 2) / q;
+        for (int t = threadIdx.x; t < M / 4; t += blockDim.x) {
+            int pos = t & (q - 1);
+            int i0 = ((t - pos) << 2) + pos, i1 = i0 + q, i2 = i1 + q, i3 = i2 + q;
+            double2 a0 = x[i0], a1 = x[i1], a2 = x[i2], a3 = x[i3];
+            double2 wa = tw[pos * ts1], wb = tw[(pos + q) * ts1], wc = tw[pos * ts2];
+            if (inverse) { wa.y = -wa.y; wb.y = -wb.y; wc.y = -wc.y; }
+            double2 b0 = cadd(a0, a2), b2 = cmul(csub(a0, a2), wa);
+            double2 b1 = cadd(a1, a3), b3 = cmul(csub(a1, a3), wb);
+            x[i0] = cadd(b0, b1);
+            x[i1] = cmul(csub(b0, b1), wc);
+            x[i2] = cadd(b2, b3);
+            x[i3] = cmul(csub(b2, b3), wc);
+        }
+        __syncthreads();
+    }
+    for (; s < log2m; s++) {
         const int span = M >> (s + 1);
         const int tstride = (FFT_MAX / 2) / span;
         for (int t = threadIdx.x; t < M / 2; t += blockDim.x) {
@@ -50,17 +71,34 @@ __device__ inline void fft_dif(double2* x, int log2m, const double2* __restrict_
 __device__ inline void fft_dit(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
 {
     const int M = 1 << log2m;
-    for (int s = 0; s < log2m; s++) {
-        const int span = 1 << s;
-        const int tstride = (FFT_MAX / 2) / span;
+    int s = 0;
+    if (log2m & 1) {  // odd number of stages: one plain radix-2 stage first (span 1)
         for (int t = threadIdx.x; t < M / 2; t += blockDim.x) {
-            int pos = t & (span - 1);
-            int i0 = ((t - pos) << 1) + pos, i1 = i0 + span;
-            double2 w = tw[pos * tstride];
+            int i0 = t << 1, i1 = i0 + 1;
+            double2 w = tw[0];
             if (inverse) w.y = -w.y;
             double2 a = x[i0], b = cmul(x[i1], w);
             x[i0] = cadd(a, b);
             x[i1] = csub(a, b);
+        }
+        __syncthreads();
+        s = 1;
+    }
+    for (; s + 1 < log2m; s += 2) {  // two radix-2 stages (spans q and 2q) fused in registers
+        const int q = 1 << s;
+        const int ts1 = (FFT_MAX / 2) / q, ts2 = (FFT_MAX / 2) / (2 * q);
+        for (int t = threadIdx.x; t < M / 4; t += blockDim.x) {
+            int pos = t & (q - 1);
+            int i0 = ((t - pos) << 2) + pos, i1 = i0 + q, i2 = i1 + q, i3 = i2 + q;
+            double2 wa = tw[pos * ts1], wb = tw[pos * ts2], wc = tw[(pos + q) * ts2];
+            if (inverse) { wa.y = -wa.y; wb.y = -wb.y; wc.y = -wc.y; }
+            double2 a0 = x[i0], a1 = cmul(x[i1], wa), a2 = x[i2], a3 = cmul(x[i3], wa);
+            double2 b0 = cadd(a0, a1), b1 = csub(a0, a1), b2 = cadd(a2, a3), b3 = csub(a2, a3);
+            double2 c2 = cmul(b2, wb), c3 = cmul(b3, wc);
+            x[i0] = cadd(b0, c2);
+            x[i2] = csub(b0, c2);
+            x[i1] = cadd(b1, c3);
+            x[i3] = csub(b1, c3);
         }
         __syncthreads();
     }

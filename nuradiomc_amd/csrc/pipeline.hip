@@ -113,11 +113,17 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
         mat3mul(Ei, A, &rot[9 * c]);
         if (!inv3(&rot[9 * c], &roti[9 * c])) { delete s; return nrhip_fail_msg("nrhip_station_create: singular antenna rotation"); }
     }
+    std::vector<double> lnf(nh + 1, 0.);
+    {
+        const double df = 1.0 / (d->n_samples * (1. / d->sampling_rate));
+        for (int k = 1; k <= nh; k++) lnf[k] = std::log(k * df);
+    }
     s->h_pos.assign(d->position, d->position + 3 * n);
     s->h_cable.assign(d->cable_delay, d->cable_delay + n);
     if (upload(ctx, s->d_pos, d->position, 3 * n) || upload(ctx, s->d_cable, d->cable_delay, n) ||
         upload(ctx, s->d_model, d->antenna_model, n) || upload(ctx, s->d_rot, rot.data(), 9 * n) ||
-        upload(ctx, s->d_rot_inv, roti.data(), 9 * n) || upload(ctx, s->d_fc, d->att_freq, d->n_att_freq)) {
+        upload(ctx, s->d_rot_inv, roti.data(), 9 * n) || upload(ctx, s->d_fc, d->att_freq, d->n_att_freq) ||
+        upload(ctx, s->d_lnf, lnf.data(), lnf.size())) {
         delete s;
         return -1;
     }
@@ -136,6 +142,7 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     v.rot = s->d_rot.as<double>();
     v.rot_inv = s->d_rot_inv.as<double>();
     v.fcoarse = s->d_fc.as<double>();
+    v.lnf = s->d_lnf.as<double>();
     FilterSet& f = s->filters;
     memset(&f, 0, sizeof f);
     f.n = d->n_filters;
@@ -161,7 +168,7 @@ void nrhip_station_destroy(nrhip_station* s)
     for (auto& kv : s->ws) kv.second.release();
     for (auto& e : s->evt) if (e) (void)hipEventDestroy(e);
     s->d_pos.release(); s->d_cable.release(); s->d_model.release();
-    s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release();
+    s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release(); s->d_lnf.release();
     delete s;
 }
 
@@ -278,17 +285,44 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         LCHK("ray_setup");
     }
     MARK(2);
+    // 3. which rays can matter at all?  un-attenuated sum-of-magnitudes bound per ray -> per event -> active ray list
+    int n_active = 0;
+    int* active_list = nullptr;
+    double* bound;
+    NEED(bound = WS("ray_bound", double, nr));
     if (n_rays > 0) {
-        // 3. attenuation on the coarse frequency grid
+        int *ractive, *roff, *rtmp;
+        NEED(ractive = WS("ray_active", int, nr + 1));
+        NEED(roff = WS("ray_active_offset", int, nr + 1));
+        NEED(rtmp = WS("scan_tmp2", int, scan_tiles(n_rays + 1)));
+        NEED(active_list = WS("ray_active_list", int, nr));
+        launch_amp_bound(sm, n_rays, w, evin, sd, cfg->askaryan_model, bound, max_efield);
+        LCHK("amp_bound");
+        launch_event_possible(sm, (int)n_events, n_ch, offset, bound, cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude,
+                              ractive);
+        LCHK("event_possible");
+        HIPCHK(hipMemsetAsync(ractive + n_rays, 0, sizeof(int), sm));
+        launch_exclusive_scan(sm, n_rays + 1, ractive, roff, rtmp);
+        launch_scatter_active(sm, n_rays, ractive, roff, active_list);
+        LCHK("active list");
+        HIPCHK(hipMemcpyAsync(&n_active, roff + n_rays, sizeof(int), hipMemcpyDeviceToHost, sm));
+        HIPCHK(hipMemsetAsync(w.att, 0xFF, nr * sd.n_fc * sizeof(double), sm));  // NaN = not evaluated
+        HIPCHK(hipStreamSynchronize(sm));
+    }
+    S.n_active_rays = n_active;
+    if (n_active > 0) {
+        // attenuation on the coarse frequency grid, active rays only
         launch_ray_limits_from_slots(sm, n_rays, n_ch, ray_slot, vertex, sd.pos, rec, ctx->ice, zint);
         LCHK("ray_limits");
-        launch_attenuation_items(sm, n_rays, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr);
+        launch_attenuation_items(sm, n_active, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr,
+                                 active_list);
         LCHK("attenuation");
     }
     MARK(3);
-    if (n_rays > 0) {
+    if (n_active > 0) {
         // 4. candidate cut on max |E(t)|
-        launch_efield_max(sm, n_rays, w, evin, sd, cfg->askaryan_model, ctx->twiddle, max_efield);
+        launch_efield_max(sm, n_active, active_list, w, evin, sd, cfg->askaryan_model, ctx->twiddle,
+                          cfg->min_efield_amplitude, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, max_efield);
         LCHK("efield_max");
     }
     MARK(4);

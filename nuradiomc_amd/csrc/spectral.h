@@ -21,6 +21,7 @@ struct StationDev {
     const double* rot;        // [n_ch][9] inv(E) A   (antennapattern.py:1190-1216)
     const double* rot_inv;    // [n_ch][9]
     const double* fcoarse;    // [n_fc] attenuation frequency grid
+    const double* lnf;        // [N/2 + 1] ln f_k of the N-sample grid (entry 0 unused)
 };
 
 // analog filter chain: response_i(f) = polyval(b_i, j f) / polyval(a_i, j f), highest power first
@@ -76,8 +77,14 @@ void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, 
                       const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w);
 void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
                                   const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint);
-void launch_efield_max(hipStream_t s, int n_rays, const RayWork& w, const EventIn& evin, const StationDev& st,
-                       int ask_model, const double2* tw, double* max_efield);
+void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const EventIn& evin, const StationDev& st,
+                      int ask_model, double* bound, double* max_efield);
+void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
+                           double min_efield, int* ray_active);
+void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const int* offset, int* list);
+void launch_efield_max(hipStream_t s, int n_active, const int* active_list, const RayWork& w, const EventIn& evin,
+                       const StationDev& st, int ask_model, const double2* tw, double min_efield, int exact,
+                       double* max_efield);
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev);
 void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const double2* tw,
@@ -92,6 +99,7 @@ void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const 
 void launch_czt_test(hipStream_t s, int n_batch, int n_in, int n_out, int Q, double sgn, const double2* in, double2* out,
                      const double2* tw, double2* Bscratch, int grid);
 void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
-                              const double* freqs, int model, const IceConst& m, double* att, int* neval);
+                              const double* freqs, int model, const IceConst& m, double* att, int* neval,
+                              const int* ray_index = nullptr);
 
 }  // namespace nrhip

@@ -313,6 +313,7 @@ struct AskaryanConst {
     double a_pref;  // everything that multiplies f
     double nu_L, beta, nu_R, alpha;  // Alvarez2009
     double dth, cher, theta, f0, scale, roll;  // Alvarez2000 / ZHS1992
+    double ln_nu_L, ln_nu_R;
     int had;
 };
 
@@ -354,6 +355,8 @@ __device__ inline AskaryanConst askaryan_setup(int model, double energy, double 
         a.nu_R = rho / k_R_bar / R_M * c / sqrt(n_index * n_index - 1);
         a.alpha = 1.27;
         a.scale = R;
+        a.ln_nu_L = log(a.nu_L);
+        a.ln_nu_R = log(a.nu_R);
     } else if (model == 1) {  // Alvarez2000, parametrizations.py:220-275
         a.cher = acos(1. / n_index);
         a.theta = theta;
@@ -386,19 +389,20 @@ __device__ inline AskaryanConst askaryan_setup(int model, double energy, double 
 }
 
 // real amplitude X(f) such that the reference's spectrum bin is i * X * (-1)^k * sqrt(2) (ZHS1992: see phase)
-__device__ inline double askaryan_amplitude(double f, const AskaryanConst& a)
+// lnf = ln f: (f / nu)^beta is evaluated as exp(beta (ln f - ln nu)), ln f coming from a per-station table
+__device__ inline double askaryan_amplitude(double f, double lnf, const AskaryanConst& a)
 {
     if (a.model == 0) {
         double A = a.a_pref * f;
-        double d_L = 1 / (1 + pow(f / a.nu_L, a.beta));
-        double d_R = 1 / (1 + pow(f / a.nu_R, a.alpha));
+        double d_L = 1 / (1 + exp(a.beta * (lnf - a.ln_nu_L)));
+        double d_R = 1 / (1 + exp(a.alpha * (lnf - a.ln_nu_R)));
         double s = A * d_L * d_R;
         s *= 0.5;
         s /= a.scale;
         return s;
     } else if (a.model == 1) {
         if (a.scale == 0.) return 0.;
-        double E = a.a_pref * f / a.f0 / (1 + pow(f / a.f0, 1.44));
+        double E = a.a_pref * f / a.f0 / (1 + exp(1.44 * (lnf - log(a.f0))));
         double w = (a.theta - a.cher) / (a.dth / f);
         return 0.5 * a.scale * E * exp(-0.6931471805599453 * w * w);
     } else {
@@ -431,21 +435,60 @@ struct RayShared {
     double att[NRHIP_MAX_NFC];
 };
 
-// amp[k] = X_k * att(f_k) for k <= N/2 (0 at k = 0 and N/2): the real, component-independent part of the field
-__device__ inline void fill_amplitude(double* amp, int N, double fs, const RayShared& rs, int n_fc,
-                                      const double* __restrict__ fcoarse)
+// amp[k] = X_k * att(f_k) for k <= N/2 (0 at k = 0 and N/2): the real, component-independent part of the field.
+// Returns this thread's partial sum of amp (for the sum-of-magnitudes bound on max |E(t)|).
+__device__ inline double fill_amplitude(double* amp, int N, double fs, const RayShared& rs, int n_fc,
+                                        const double* __restrict__ fcoarse, const double* __restrict__ lnf, bool with_att)
 {
     const int nh = N / 2;
     const double df = 1.0 / (N * (1. / fs));
+    double part = 0.;
     for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
         double v = 0.;
         if (k > 0 && k < nh) {
             double f = k * df;
-            v = askaryan_amplitude(f, rs.ask) * interp_att(f, n_fc, fcoarse, rs.att);
+            v = askaryan_amplitude(f, lnf[k], rs.ask);
+            if (with_att) v *= interp_att(f, n_fc, fcoarse, rs.att);
         }
-        amp[k] = v;
+        if (amp) amp[k] = v;
+        part += v;
     }
     __syncthreads();
+    return part;
+}
+
+// block-wide sum / max through LDS (red has blockDim.x doubles)
+__device__ inline double block_sum(double v, double* red)
+{
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    double r = red[0];
+    __syncthreads();
+    return r;
+}
+__device__ inline double block_max(double v, double* red)
+{
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ inline double cabs2(double2 a) { return sqrt(a.x * a.x + a.y * a.y); }
+
+// max |E(t)| <= (fs / sqrt 2) (1 / N) 2 sum_k |G_k|,  |G_k| = sqrt 2 |pol r| amp_k   (triangle inequality on irfft)
+__device__ inline double efield_bound(double amp_sum, int N, double fs, double cmax)
+{
+    return (fs / 1.4142135623730951) * (2.0 / N) * (1.4142135623730951 * cmax * amp_sum);
 }
 
 // G(k): spectrum bin k (0..N/2) of one on-sky component, optionally with the sub-sample shift phase ramp
@@ -495,17 +538,14 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// kernel: max |E(t)| per ray (candidate cut, simulation.py:283-285).  One block per ray.
-// LDS: N/2 complex + (N/2 + 1) doubles.
+// kernel: rigorous upper bound on max |E(t)| per ray WITHOUT attenuation (attenuation factors are <= 1): events whose
+// rays all stay below the candidate cut even un-attenuated can never become candidates (simulation.py:283-285), so
+// their rays skip the attenuation quadrature and the time-domain transform.  One block per ray.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-efield_max_kernel(int n_rays, RayWork w, EventIn evin, StationDev st, int ask_model, const double2* __restrict__ tw,
-                  int log2nh, double* __restrict__ max_efield)
+amp_bound_kernel(int n_rays, RayWork w, EventIn evin, StationDev st, int ask_model, double* __restrict__ bound,
+                 double* __restrict__ max_efield)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int N = st.N, nh = N / 2;
-    double2* x = (double2*)smem;
-    double* amp = (double*)(x + nh);
     __shared__ RayShared rs;
     __shared__ double red[256];
     for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
@@ -513,29 +553,103 @@ efield_max_kernel(int n_rays, RayWork w, EventIn evin, StationDev st, int ask_mo
         if (threadIdx.x == 0)
             rs.ask = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r], w.R[r],
                                     evin.k_L[e]);
+        __syncthreads();
+        double part = fill_amplitude(nullptr, st.N, st.fs, rs, st.n_fc, st.fcoarse, st.lnf, false);
+        double sum = block_sum(part, red);
+        if (threadIdx.x == 0) {
+            double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
+            double b = efield_bound(sum, st.N, st.fs, cmax);
+            bound[r] = b;
+            max_efield[r] = -b;  // "not evaluated, at most b" until efield_max_kernel overwrites it
+        }
+    }
+}
+
+// per event: can any ray exceed the cut?  (1 + 1e-6 absorbs rounding of the bound and of exp(-integral) <= 1)
+__global__ void __launch_bounds__(256)
+event_possible_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, const double* __restrict__ bound,
+                      double min_efield, int* __restrict__ ray_active)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_events) return;
+    long s0 = (long)e * n_ch * NRHIP_MAXS, s1 = (long)(e + 1) * n_ch * NRHIP_MAXS;
+    int r0 = slot_offset[s0], r1 = slot_offset[s1];
+    int possible = 0;
+    for (int r = r0; r < r1; r++)
+        if (bound[r] * (1 + 1e-6) > min_efield) possible = 1;
+    for (int r = r0; r < r1; r++) ray_active[r] = possible;
+}
+
+__global__ void scatter_active_kernel(int n_rays, const int* __restrict__ active, const int* __restrict__ offset,
+                                      int* __restrict__ list)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    if (active[r]) list[offset[r]] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel: max |E(t)| per ray (candidate cut, simulation.py:283-285).  One block per active ray.
+// With attenuation known the sum-of-magnitudes bound is re-evaluated; only rays whose bound exceeds the cut pay for
+// the time-domain transform (others report the negated bound).  Real reflection coefficients make both on-sky
+// components proportional to one real pulse: a single transform serves both.
+// LDS: N/2 complex + (N/2 + 1) doubles.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+efield_max_kernel(int n_active, const int* __restrict__ active_list, RayWork w, EventIn evin, StationDev st,
+                  int ask_model, const double2* __restrict__ tw, int log2nh, double min_efield, int exact,
+                  double* __restrict__ max_efield)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = st.N, nh = N / 2;
+    double2* x = (double2*)smem;
+    double* amp = (double*)(x + nh);
+    __shared__ RayShared rs;
+    __shared__ double red[256];
+    for (int ia = blockIdx.x; ia < n_active; ia += gridDim.x) {
+        const int r = active_list[ia];
+        int e = w.ev[r];
+        if (threadIdx.x == 0)
+            rs.ask = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r], w.R[r],
+                                    evin.k_L[e]);
         for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
         __syncthreads();
-        fill_amplitude(amp, N, st.fs, rs, st.n_fc, st.fcoarse);
+        double part = fill_amplitude(amp, N, st.fs, rs, st.n_fc, st.fcoarse, st.lnf, true);
+        double sum = block_sum(part, red);
+        const double2 rt = w.r_theta[r], rp = w.r_phi[r];
+        const double pt = w.pol_theta[r], pp = w.pol_phi[r];
+        double cmax = fmax(fabs(pt) * cabs2(rt), fabs(pp) * cabs2(rp));
+        double bnd = efield_bound(sum, N, st.fs, cmax);
+        if (!exact && !(bnd * (1 + 1e-6) > min_efield)) {
+            if (threadIdx.x == 0) max_efield[r] = -bnd;
+            continue;
+        }
         double mx = 0.;
         const double scale = st.fs / 1.4142135623730951 / nh;
-        for (int comp = 0; comp < 2; comp++) {
-            double pol = comp ? w.pol_phi[r] : w.pol_theta[r];
-            double2 rc = comp ? w.r_phi[r] : w.r_theta[r];
-            field_time_domain(x, amp, N, log2nh, st.fs, pol, rc, 0., false, ask_model, floor(2.0 * st.fs), tw);
+        const bool both_real = (rt.y == 0. && rp.y == 0.);
+        if (both_real) {
+            field_time_domain(x, amp, N, log2nh, st.fs, 1.0, make_double2(1., 0.), 0., false, ask_model,
+                              floor(2.0 * st.fs), tw);
+            double cm = fmax(fabs(pt * rt.x), fabs(pp * rp.x));
             for (int j = threadIdx.x; j < nh; j += blockDim.x) {
                 double2 y = x[j];
                 mx = fmax(mx, fmax(fabs(y.x * scale), fabs(y.y * scale)));
             }
+            mx *= cm;
             __syncthreads();
+        } else {
+            for (int comp = 0; comp < 2; comp++) {
+                field_time_domain(x, amp, N, log2nh, st.fs, comp ? pp : pt, comp ? rp : rt, 0., false, ask_model,
+                                  floor(2.0 * st.fs), tw);
+                for (int j = threadIdx.x; j < nh; j += blockDim.x) {
+                    double2 y = x[j];
+                    mx = fmax(mx, fmax(fabs(y.x * scale), fabs(y.y * scale)));
+                }
+                __syncthreads();
+            }
         }
-        red[threadIdx.x] = mx;
-        __syncthreads();
-        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) max_efield[r] = red[0];
-        __syncthreads();
+        mx = block_max(mx, red);
+        if (threadIdx.x == 0) max_efield[r] = mx;
     }
 }
 
@@ -710,7 +824,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                                         w.R[r], evin.k_L[e]);
             for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
             __syncthreads();
-            fill_amplitude(amp, N, st.fs, rs, st.n_fc, st.fcoarse);
+            fill_amplitude(amp, N, st.fs, rs, st.n_fc, st.fcoarse, st.lnf, true);
             // start bin and sub-sample remainder (efieldToVoltageConverter.py:214-218)
             double start_time = w.t0[r] - t_min + st.cable[ch] + 0;
             long start_bin = (long)rint(start_time / res);
@@ -722,11 +836,15 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
             const double dir = (am == 0) ? sin(th_a) : sin(th_a) * sin(th_a);
             // raw VEL has one non-zero component: VPol -> theta (column 0 of T), HPol -> phi (column 1 of T)
             const double Tt = (am == 0) ? T[0] : T[1], Tp = (am == 0) ? T[2] : T[3];
+            // weight of each on-sky component in the channel voltage; a component below 1e-13 of the other one
+            // (e.g. the e_phi response of a vertical dipole, 1e-17 from the rotation round-off) is not transformed
+            const double wt = fabs(Tt * dir * w.pol_theta[r]) * cabs2(w.r_theta[r]);
+            const double wp = fabs(Tp * dir * w.pol_phi[r]) * cabs2(w.r_phi[r]);
             for (int comp = 0; comp < 2; comp++) {
                 double pol = comp ? w.pol_phi[r] : w.pol_theta[r];
                 double2 rc = comp ? w.r_phi[r] : w.r_theta[r];
                 double vfac = (comp ? Tp : Tt) * dir;
-                if (vfac == 0. || pol == 0.) continue;
+                if ((comp ? wp : wt) <= 1e-13 * (comp ? wt : wp)) continue;
                 field_time_domain(x, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
                 // gather y_j (bit-reversed positions) -> registers, then lay out a_j = y_j * chirp_j, zero pad
                 const double sc = 1.0 / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
@@ -831,7 +949,7 @@ __global__ void askaryan_spectrum_kernel(int n, const double* __restrict__ energ
         if (threadIdx.x == 0) a = askaryan_setup(model, energy[i], theta[i], shower_type[i], n_index[i], R[i], k_L[i]);
         __syncthreads();
         for (int k = threadIdx.x; k < nf; k += blockDim.x) {
-            double amp1 = (k > 0 && k < N / 2) ? askaryan_amplitude(k * (1.0 / (N * dt)), a) : 0.;
+            double amp1 = (k > 0 && k < N / 2) ? askaryan_amplitude(k * (1.0 / (N * dt)), log(k * (1.0 / (N * dt))), a) : 0.;
             spec[(long)i * nf + k] = field_bin(k, amp1, N, 1. / dt, 1.0, make_double2(1., 0.), 0., false, model,
                                                floor(2.0 / dt));
         }
@@ -904,15 +1022,35 @@ void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
-void launch_efield_max(hipStream_t s, int n_rays, const RayWork& w, const EventIn& evin, const StationDev& st,
-                       int ask_model, const double2* tw, double* max_efield)
+void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const EventIn& evin, const StationDev& st,
+                      int ask_model, double* bound, double* max_efield)
 {
     if (n_rays <= 0) return;
+    int grid = n_rays < 256 * 32 ? n_rays : 256 * 32;
+    hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, evin, st, ask_model, bound, max_efield);
+}
+void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
+                           double min_efield, int* ray_active)
+{
+    if (n_events <= 0) return;
+    hipLaunchKernelGGL(event_possible_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, n_ch, slot_offset,
+                       bound, min_efield, ray_active);
+}
+void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const int* offset, int* list)
+{
+    if (n_rays <= 0) return;
+    hipLaunchKernelGGL(scatter_active_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, active, offset, list);
+}
+void launch_efield_max(hipStream_t s, int n_active, const int* active_list, const RayWork& w, const EventIn& evin,
+                       const StationDev& st, int ask_model, const double2* tw, double min_efield, int exact,
+                       double* max_efield)
+{
+    if (n_active <= 0) return;
     int nh = st.N / 2;
     size_t lds = (size_t)nh * 16 + (size_t)(nh + 1) * 8;
-    int grid = n_rays < 256 * 16 ? n_rays : 256 * 16;
-    hipLaunchKernelGGL(efield_max_kernel, dim3(grid), dim3(256), lds, s, n_rays, w, evin, st, ask_model, tw, ilog2(nh),
-                       max_efield);
+    int grid = n_active < 256 * 16 ? n_active : 256 * 16;
+    hipLaunchKernelGGL(efield_max_kernel, dim3(grid), dim3(256), lds, s, n_active, active_list, w, evin, st, ask_model, tw,
+                       ilog2(nh), min_efield, exact, max_efield);
 }
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev)

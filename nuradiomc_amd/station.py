@@ -22,18 +22,18 @@ class StationDesc(ctypes.Structure):
 class SimConfig(ctypes.Structure):
     _fields_ = [('askaryan_model', ctypes.c_int32), ('delta_C_cut', ctypes.c_double),
                 ('min_efield_amplitude', ctypes.c_double), ('trigger_threshold', ctypes.c_double),
-                ('dump_traces', ctypes.c_int32)]
+                ('dump_traces', ctypes.c_int32), ('no_pruning', ctypes.c_int32)]
 
 
 class SimStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int64) for k in ('n_events', 'n_pairs', 'n_rays', 'n_candidate_events', 'n_triggered',
-                                              'n_channel_items', 'n_distinct_lengths', 'n_candidate_rays')] + \
+                                              'n_channel_items', 'n_distinct_lengths', 'n_candidate_rays', 'n_active_rays')] + \
                [('max_length', ctypes.c_int32), ('reserved', ctypes.c_int32), ('stage_ms', ctypes.c_double * 8)]
 
     STAGES = ('raytrace', 'ray_setup', 'attenuation', 'efield_max', 'event_grid', 'length_tables', 'channel', 'total')
 
     def as_dict(self):
-        d = {k: int(getattr(self, k)) for k, _ in self._fields_[:9]}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_[:10]}
         d['stage_ms'] = {n: float(self.stage_ms[i]) for i, n in enumerate(self.STAGES)}
         return d
 
@@ -132,11 +132,12 @@ class Station:
     # ---- the hot path --------------------------------------------------------------------------------------
     def simulate_events_dev(self, n_events, d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL, d_triggered,
                             askaryan_model='Alvarez2009', delta_C_cut=0.698, min_efield_amplitude=None,
-                            trigger_threshold=None, dump_traces=False, want_stats=True):
+                            trigger_threshold=None, dump_traces=False, no_pruning=False, want_stats=True):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None)."""
         cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
                         float(2.0 * self.vrms_efield if min_efield_amplitude is None else min_efield_amplitude),
-                        float(3.0 * self.vrms if trigger_threshold is None else trigger_threshold), int(bool(dump_traces)))
+                        float(3.0 * self.vrms if trigger_threshold is None else trigger_threshold), int(bool(dump_traces)),
+                        int(bool(no_pruning)))
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_events(self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith,
                                                 d_azimuth, d_energy, d_type, d_kL, d_triggered,

@@ -52,7 +52,7 @@ def _station(ctx, g):
                                  n_freq=int(g['n_freq']))
 
 
-def _run_fixture(gpu_ctx_factory, name, n_events):
+def _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=False):
     g = golden('chain_%s.npz' % name)
     ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
     st = _station(ctx, g)
@@ -60,7 +60,8 @@ def _run_fixture(gpu_ctx_factory, name, n_events):
     sl = slice(0, n_events)
     kL = np.where(np.isnan(g['ev_k_L'][sl]), 1.0, g['ev_k_L'][sl])
     trig, stats = st.simulate_events(g['vertex'][sl], g['zenith'][sl], g['azimuth'][sl], g['energy'][sl],
-                                     g['shower_type'][sl], kL, askaryan_model=str(g['askaryan_model']), dump_traces=True)
+                                     g['shower_type'][sl], kL, askaryan_model=str(g['askaryan_model']), dump_traces=True,
+                                     no_pruning=no_pruning)
     return g, ctx, st, trig, stats, kL
 
 
@@ -68,7 +69,7 @@ def _run_fixture(gpu_ctx_factory, name, n_events):
 def test_spectral_stages_vs_oracle_on_identical_rays(gpu_ctx_factory, name, n_events):
     """Feed the ORACLE with the ray tables the GPU produced, so that every later stage sees identical
     (C0, D, T, launch, receive) on both sides: kept rays exact, amplitudes / traces to 1e-6."""
-    g, ctx, st, trig, stats, kL = _run_fixture(gpu_ctx_factory, name, n_events)
+    g, ctx, st, trig, stats, kL = _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=True)
     n_ch = len(g['det_pos'])
     ost = so.Station(g['det_pos'], antenna=str(g['antenna']), orientation=tuple(g['det_orientation']),
                      cable_delay=g['cable_delay'], n_samples=int(g['N']), fs=float(g['fs']))
@@ -150,3 +151,24 @@ def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
         if both[ev]:
             ref = g['ev_maxV'][ev]
             assert np.all(np.abs(maxV[i] - ref) <= 5e-3 * np.max(ref)), ev
+
+
+@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N4096', 120)])
+def test_pruning_changes_no_result(gpu_ctx_factory, name, n_events):
+    """Skipping rays of events that provably cannot pass the candidate cut (un-attenuated sum-of-magnitudes bound)
+    and skipping transforms whose bound is below the cut must leave every decision and every trace unchanged."""
+    g, ctx, st, trig_a, stats_a, kL = _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=True)
+    A = {k: st.fetch(k) for k in ('ev_candidate', 'ev_L', 'ev_t_min', 'item_event', 'item_maxV', 'trace', 'ray_max_efield')}
+    g, ctx, st, trig_b, stats_b, kL = _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=False)
+    B = {k: st.fetch(k) for k in ('ev_candidate', 'ev_L', 'ev_t_min', 'item_event', 'item_maxV', 'trace', 'ray_max_efield',
+                                  'ray_bound', 'ray_active', 'ray_att')}
+    assert np.array_equal(trig_a, trig_b)
+    for k in ('ev_candidate', 'ev_L', 'item_event', 'item_maxV', 'trace'):
+        assert np.array_equal(A[k], B[k]), k
+    assert stats_b['n_active_rays'] < stats_a['n_active_rays'] == stats_a['n_rays']
+    act = B['ray_active'][:stats_b['n_rays']].astype(bool)
+    att = B['ray_att'].reshape(stats_b['n_rays'], -1)
+    assert np.all(np.isnan(att[~act])) and not np.any(np.isnan(att[act]))
+    # the bound really is an upper bound on the exact maximum (no_pruning run), and pruned rays are below the cut
+    assert np.all(B['ray_bound'] * (1 + 1e-6) >= A['ray_max_efield'])
+    assert np.all(A['ray_max_efield'][~act] <= 2.0 * st.vrms_efield)
