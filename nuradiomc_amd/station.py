@@ -170,7 +170,8 @@ class Station:
     _FETCH_DTYPES = {'ray_event': np.int32, 'ray_channel': np.int32, 'ray_solution': np.int32, 'ev_n_rays': np.int32,
                      'ev_L': np.int32, 'ev_candidate': np.uint8, 'item_event': np.int32, 'trace_offset': np.int64,
                      'ray_r_theta': np.complex128, 'ray_r_phi': np.complex128, 'lengths': np.int32,
-                     'pair_n_sol': np.int32, 'slot_type': np.int32, 'ev_ray_begin': np.int32}
+                     'pair_n_sol': np.int32, 'slot_type': np.int32, 'ev_ray_begin': np.int32, 'ray_active': np.int32,
+                     'ray_active_list': np.int32, 'ray_slot': np.int32, 'slot_keep': np.int32, 'slot_offset': np.int32}
 
     def fetch(self, name):
         """One table of the last simulated batch as a numpy array (see include/nrhip.h: nrhip_sim_fetch)."""
@@ -178,7 +179,7 @@ class Station:
         if n < 0:
             raise L.NrhipError(self._lib.nrhip_last_error().decode())
         dt = np.dtype(self._FETCH_DTYPES.get(name, np.float64))
-        out = np.zeros(n // dt.itemsize, dt)
+        raw = np.zeros(n, np.uint8)
         if n:
-            self._lib.nrhip_sim_fetch(self._h, name.encode(), out.ctypes.data_as(ctypes.c_void_p), n)
-        return out
+            self._lib.nrhip_sim_fetch(self._h, name.encode(), raw.ctypes.data_as(ctypes.c_void_p), n)
+        return raw[:(n // dt.itemsize) * dt.itemsize].view(dt)
