@@ -42,7 +42,7 @@ __device__ inline double attenuation_length(double z, const AttLane& a)
             aa = (b2 * 0.0 - b1 * w2) / (0.0 - w2);
             bb = (b2 - b1) / (w2 - 0.0);
         }
-        L = 1. / exp(aa + bb * a.w);
+        L = 1. / det_exp(aa + bb * a.w);
     } else if (a.model == 2) {  // GL1 (attenuation.py:99-128, :194-196), 75 MHz length clamped at 100 m
         const double fit[6] = {1.16052586e+03, 6.87257150e-02, -9.82378264e-05,
                                -3.50628312e-07, -2.21040482e-10, -3.63912864e-14};
@@ -60,9 +60,9 @@ __device__ inline double attenuation_length(double z, const AttLane& a)
     } else {  // MB1 (:224-244)
         const double R = 0.82, d_ice = 576.;
         L = 460. - 180. * a.f;
-        L *= 1. / (1 + L / (2 * d_ice) * log(R));
+        L *= 1. / (1 + L / (2 * d_ice) * det_log(R));
         double d = -z * 420. / d_ice;
-        double LL = (1250. * 0.08886 * exp(-0.048827 * (225.6746 - 86.517596 * log10(848.870 - (d)))));
+        double LL = (1250. * 0.08886 * det_exp(-0.048827 * (225.6746 - 86.517596 * (det_log(848.870 - (d)) / 2.302585092994046))));
         L *= LL / 231.21;
     }
     if (L < 1.) L = 1.;
@@ -527,7 +527,7 @@ attenuation_kernel(long n_rays, const double* __restrict__ C0, const double* __r
         it.z_turn = zint[3 * ray + 2];
         it.lane.model = model;
         it.lane.f = freqs[jf];
-        it.lane.w = log(it.lane.f);
+        it.lane.w = det_log(it.lane.f);
         if (isnan(it.C0)) {
             att[item] = NAN;
             if (neval) neval[item] = 0;
@@ -536,7 +536,7 @@ attenuation_kernel(long n_rays, const double* __restrict__ C0, const double* __r
         bool with_point = (z1 < it.z_turn && it.z_turn < z2m);
         int ne;
         double integral = quad_gk21(z1, z2m, with_point, it.z_turn, it, m, &ne);
-        att[item] = exp(-1 * integral);
+        att[item] = det_exp(-1 * integral);
         if (neval) neval[item] = ne;
     }
 }
@@ -554,8 +554,12 @@ ray_limits_kernel(long n_rays, const double* __restrict__ x1, const double* __re
         for (int d = 0; d < 3; d++) { double t = A[d]; A[d] = B[d]; B[d] = t; }
     }
     double dX[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
-    double dPhi = -atan2(dX[1], dX[0]);
-    double cph = cos(dPhi), sph = sin(dPhi);
+    double rho = sqrt(dX[0] * dX[0] + dX[1] * dX[1]);
+    double cph = 1., sph = 0.;
+    if (rho > 0) {
+        cph = dX[0] / rho;
+        sph = -(dX[1] / rho);
+    }
     Pair2D p;
     p.y1 = A[0];
     p.z1 = A[2];
@@ -583,7 +587,7 @@ __global__ void attenuation_length_kernel(long n, const double* __restrict__ z, 
     AttLane a;
     a.model = model;
     a.f = f[i];
-    a.w = log(a.f);
+    a.w = det_log(a.f);
     L[i] = attenuation_length(z[i], a);
 }
 

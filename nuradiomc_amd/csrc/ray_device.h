@@ -12,6 +12,7 @@
 //   get_travel_time_analytic :692.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "detmath.h"
 
 namespace nrhip {
 
@@ -36,8 +37,9 @@ __host__ __device__ inline IceConst make_ice(double n_ice, double delta_n, doubl
     return m;
 }
 
-__device__ inline double gamma_of_z(double z, const IceConst& m) { return m.delta_n * exp(z / m.z_0); }
-__device__ inline double n_of_z(double z, const IceConst& m) { return m.n_ice - m.delta_n * exp(z / m.z_0); }
+// exp / log on this path are the bit-reproducible ones of detmath.h (see there why)
+__device__ inline double gamma_of_z(double z, const IceConst& m) { return m.delta_n * det_exp(z / m.z_0); }
+__device__ inline double n_of_z(double z, const IceConst& m) { return m.n_ice - m.delta_n * det_exp(z / m.z_0); }
 
 // Everything the path function needs for one value of C0.
 struct C0State {
@@ -56,7 +58,7 @@ __device__ inline double y_of_gamma(double g, const C0State& s, const IceConst& 
 {
     double root = fabs(g * g - g * m.b + s.c);
     double logarg = g / (s.two_sc * sqrt(root) - m.b * g + s.two_c);
-    return s.pref * log(logarg);
+    return s.pref * det_log(logarg);
 }
 
 __device__ inline C0State make_c0(double C0, const IceConst& m)
@@ -68,7 +70,7 @@ __device__ inline C0State make_c0(double C0, const IceConst& m)
     s.two_c = 2 * s.c;
     s.pref = m.z_0 / sqrt(m.n2 * C0 * C0 - 1);
     double g2 = m.b * 0.5 - sqrt(m.qb2 - s.c);
-    double z2 = log(g2 / m.delta_n) * m.z_0;
+    double z2 = det_log(g2 / m.delta_n) * m.z_0;
     if (z2 > 0) {  // a surface reflection is a turning point at z = 0
         z2 = 0;
         g2 = m.delta_n;
@@ -94,7 +96,7 @@ struct Pair2D {
 // signed miss distance at x2 of the ray launched from x1 with parameter C0 (:204-272, reflection = 0)
 __device__ inline double delta_y(double logC0, const Pair2D& p, const IceConst& m)
 {
-    double C0 = exp(logC0) + m.inv_n;
+    double C0 = det_exp(logC0) + m.inv_n;
     if (C0 < m.inv_n) return -INFINITY;
     C0State s = make_c0(C0, m);
     double C1 = p.y1 - y_mirror0(p.z1, p.g1, s, m);
@@ -126,7 +128,7 @@ __device__ inline int solution_type(const C0State& s, double C1, const Pair2D& p
 __device__ inline double abs_dydz(double z, double C0, const IceConst& m)
 {
     double nz = n_of_z(z, m);
-    double q = C0 * C0 * nz * nz;
+    double q = (C0 * C0) * (nz * nz);  // C_0**2 * n_z**2
     return (q > 1) ? 1 / sqrt(q - 1) : INFINITY;
 }
 
@@ -138,26 +140,33 @@ __device__ inline double z_mirrored(double y, double z, const C0State& s, double
     return z;
 }
 
-// get_angle(x, x1, C0) (:1161-1193): angle to the +z axis of the ray at (y, z)
-__device__ inline double ray_angle(double y, double z, const C0State& s, double C1, const Pair2D& p,
-                                   const IceConst& m)
+// get_angle(x, x1, C0) (:1161-1193) as (sin, cos) of the angle to the +z axis of the ray at (y, z): the reference's
+// arctan(dy/dz) (+ pi if negative) followed by sin / cos is evaluated algebraically (sqrt and division only), so that
+// launch / receive vectors and beta = n sin(theta) are bit-reproducible.
+__device__ inline void ray_sincos(double y, double z, const C0State& s, double C1, const Pair2D& p, const IceConst& m,
+                                  double* sn, double* cs)
 {
     double zm = z_mirrored(y, z, s, C1, p);
     double zu = (zm > s.z_turn) ? 2 * s.z_turn - zm : zm;
     double dy = abs_dydz(zu, s.C0, m);
-    if (zu != zm) dy *= -1;
-    double a = atan(dy);
-    if (a < 0) a = M_PI + a;
-    return a;
+    bool neg = (zu != zm);
+    if (isinf(dy)) {
+        *sn = 1.;
+        *cs = 0.;
+        return;
+    }
+    double h = sqrt(1 + dy * dy);
+    *sn = dy / h;
+    *cs = (neg ? -1. : 1.) / h;
 }
 
 // closed-form path length [m] and travel time [ns] (:602-783, Bouma thesis), receiver in ice
-__device__ inline void path_length_time(const C0State& s, double C1, int type, double launch_angle,
+__device__ inline void path_length_time(const C0State& s, double C1, int type, double sin_launch,
                                         const Pair2D& p, const IceConst& m, double* D, double* T)
 {
     const double c_light = 0.299792458;
     double n1 = n_of_z(p.z1, m);
-    double beta = n1 * sin(launch_angle);
+    double beta = n1 * sin_launch;
     double beta2 = beta * beta;
     double alpha = m.n2 - beta2;
     double sa = sqrt(alpha);
@@ -170,7 +179,7 @@ __device__ inline void path_length_time(const C0State& s, double C1, int type, d
         double sg = sqrt(gam);
         double l1 = sqrt(alpha * gam) + m.n_ice * nz - beta2;
         double l2 = sg + nz;
-        double ll1 = log(l1), ll2 = log(l2);
+        double ll1 = det_log(l1), ll2 = det_log(l2);
         sv[i] = m.n_ice / sa * (zz[i] - m.z_0 * ll1) + m.z_0 * ll2;
         cv[i] = m.z_0 * (sg - m.n2 / sa * ll1 + m.n_ice * ll2) + m.n2 * zz[i] / sa;
     }

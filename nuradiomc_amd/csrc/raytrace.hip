@@ -206,8 +206,13 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
             for (int d = 0; d < 3; d++) { double t = A[d]; A[d] = B[d]; B[d] = t; }
         }
         double dX[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
-        double dPhi = -atan2(dX[1], dX[0]);
-        double cph = cos(dPhi), sph = sin(dPhi);
+        // rotation by dPhi = -atan2(dy, dx) into the y-z plane, cos / sin taken algebraically (bit-reproducible)
+        double rho = sqrt(dX[0] * dX[0] + dX[1] * dX[1]);
+        double cph = 1., sph = 0.;
+        if (rho > 0) {
+            cph = dX[0] / rho;
+            sph = -(dX[1] / rho);
+        }
         Pair2D p;
         p.y1 = A[0];
         p.z1 = A[2];
@@ -236,7 +241,7 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
             }
         }
         double c0[3];
-        for (int k = 0; k < ns; k++) c0[k] = exp(lc[k]) + m.inv_n;
+        for (int k = 0; k < ns; k++) c0[k] = det_exp(lc[k]) + m.inv_n;
         // sorted by C0 (insertion sort, <= 3 entries)
         for (int a = 1; a < ns; a++)
             for (int b = a; b > 0 && c0[b] < c0[b - 1]; b--) { double t = c0[b]; c0[b] = c0[b - 1]; c0[b - 1] = t; }
@@ -253,15 +258,16 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
             C0State st = make_c0(c0[s], m);
             double C1 = C1_of(st, p, m);
             int type = solution_type(st, C1, p);
-            double la = ray_angle(p.y1, p.z1, st, C1, p, m);          // get_launch_angle  (:1195)
-            double ra = M_PI - ray_angle(p.y2, p.z2, st, C1, p, m);   // get_receive_angle (:1198)
+            double sL, cL, s2, c2;
+            ray_sincos(p.y1, p.z1, st, C1, p, m, &sL, &cL);  // launch angle  (:1195)
+            ray_sincos(p.y2, p.z2, st, C1, p, m, &s2, &c2);  // receive angle = pi - this one (:1198)
             double D, T;
-            path_length_time(st, C1, type, la, p, m, &D, &T);
+            path_length_time(st, C1, type, sL, p, m, &D, &T);
             // 2-D -> 3-D via R^T (:2560-2624); for swapped end points launch and receive exchange roles
-            double lv0 = sin(la), lv2 = cos(la), rv0 = -sin(ra), rv2 = cos(ra);
+            double lv0 = sL, lv2 = cL, rv0 = -s2, rv2 = -c2;
             if (swap) {
-                lv0 = -sin(ra); lv2 = cos(ra);
-                rv0 = sin(la);  rv2 = cos(la);
+                lv0 = -s2; lv2 = -c2;
+                rv0 = sL;  rv2 = cL;
             }
             out.type[k] = type;
             out.C0[k] = c0[s];
@@ -277,7 +283,11 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
             // surface reflection angle (:1201-1237); NaN encodes the reference's None
             double y_turn = st.y_turn0 + C1;
             double refl = NAN;
-            if (st.z_turn >= 0 && y_turn > p.y1 && y_turn < p.y2) refl = ray_angle(y_turn, 0., st, C1, p, m);
+            if (st.z_turn >= 0 && y_turn > p.y1 && y_turn < p.y2) {
+                double sr, cr;
+                ray_sincos(y_turn, 0., st, C1, p, m, &sr, &cr);
+                refl = atan2(sr, cr);
+            }
             out.refl_angle[k] = refl;
         }
     }

@@ -287,8 +287,12 @@ ray_limits_from_slots_kernel(int n_rays, int n_ch, const int* __restrict__ ray_s
         for (int d = 0; d < 3; d++) { double t = A[d]; A[d] = B[d]; B[d] = t; }
     }
     double dX[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
-    double dPhi = -atan2(dX[1], dX[0]);
-    double cph = cos(dPhi), sph = sin(dPhi);
+    double rho = sqrt(dX[0] * dX[0] + dX[1] * dX[1]);
+    double cph = 1., sph = 0.;
+    if (rho > 0) {
+        cph = dX[0] / rho;
+        sph = -(dX[1] / rho);
+    }
     Pair2D p;
     p.y1 = A[0];
     p.z1 = A[2];

@@ -27,26 +27,33 @@
 #include <float.h>
 #include <stdlib.h>
 #include <string.h>
+#include "detmath_c.h"
 
 typedef struct { double n_ice, delta_n, z_0; } ice_t;
 
 #define SPEED_OF_LIGHT 0.299792458 /* m/ns, analyticraytracing.py:56 */
 
 /* ------------------------------------------------------------------------------------------
- * 2-D analytic ray path helpers (analyticraytracing.py:99-370)
+ * 2-D analytic ray path helpers (analyticraytracing.py:99-370).
+ *
+ * Arithmetic conventions (so that this file is bit-reproducible on any IEEE-754 machine):
+ * exp / log are orc_exp / orc_log (detmath_c.h); x ** 0.5 is sqrt(x), x ** -0.5 is 1 / sqrt(x), x ** -2 is
+ * 1 / (x * x); sin / cos of arctan(.) are taken algebraically.  Each differs from the reference's libm call by
+ * at most ~1 ulp -- far below the reference's own 1e-7 first-root noise -- and the golden-vector tests pin it.
  * ---------------------------------------------------------------------------------------- */
-static double n_of_z(double z, const ice_t *m) { return m->n_ice - m->delta_n * exp(z / m->z_0); } /* :358 */
-static double get_gamma(double z, const ice_t *m) { return m->delta_n * exp(z / m->z_0); }        /* :127 */
-static double C0_from_log(double logC0, const ice_t *m) { return exp(logC0) + 1. / m->n_ice; }    /* :99 */
+static double n_of_z(double z, const ice_t *m) { return m->n_ice - m->delta_n * orc_exp(z / m->z_0); } /* :358 */
+static double get_gamma(double z, const ice_t *m) { return m->delta_n * orc_exp(z / m->z_0); }        /* :127 */
+static double C0_from_log(double logC0, const ice_t *m) { return orc_exp(logC0) + 1. / m->n_ice; }    /* :99 */
 
 /* :105-125 */
 static double get_y(double gamma, double C0, double C1, const ice_t *m)
 {
     double b = 2 * m->n_ice;
-    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
     double root = fabs(gamma * gamma - gamma * b + c);
     double logargument = gamma / (2 * sqrt(c) * sqrt(root) - b * gamma + 2 * c);
-    return m->z_0 * pow(m->n_ice * m->n_ice * C0 * C0 - 1, -0.5) * log(logargument) + C1;
+    double pref = m->z_0 / sqrt(m->n_ice * m->n_ice * C0 * C0 - 1);
+    return pref * orc_log(logargument) + C1;
 }
 
 /* :133-158 */
@@ -54,10 +61,10 @@ static void get_turning_point(double c, const ice_t *m, double *gamma_turn, doub
 {
     double b = 2 * m->n_ice;
     double gamma2 = b * 0.5 - sqrt(0.25 * b * b - c);
-    double z2 = log(gamma2 / m->delta_n) * m->z_0;
+    double z2 = orc_log(gamma2 / m->delta_n) * m->z_0;
     if (z2 > 0) {
         z2 = 0;
-        gamma2 = get_gamma(z2, m);
+        gamma2 = m->delta_n; /* get_gamma(0) = delta_n * exp(0) */
     }
     *gamma_turn = gamma2;
     *z_turn = z2;
@@ -66,7 +73,7 @@ static void get_turning_point(double c, const ice_t *m, double *gamma_turn, doub
 /* :160-184 */
 static double get_y_with_z_mirror(double z, double C0, const ice_t *m, double C1)
 {
-    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
     double gamma_turn, z_turn;
     get_turning_point(c, m, &gamma_turn, &z_turn);
     double y_turn = get_y(gamma_turn, C0, C1, m);
@@ -85,14 +92,14 @@ static double get_delta_y(double C0, const double x1[2], const double x2[2], con
 {
     if (C0 < 1. / m->n_ice || C0 > INFINITY)
         return -INFINITY;
-    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
     double C1 = x1[0] - get_y_with_z_mirror(x1[1], C0, m, 0.0);
     double gamma_turn, z_turn;
     get_turning_point(c, m, &gamma_turn, &z_turn);
     double y_turn = get_y(gamma_turn, C0, C1, m);
     if (z_turn < x2[1]) {
         double dz = z_turn - x2[1], dy = y_turn - x2[0];
-        double diff = sqrt(dz * dz + dy * dy) + 10 * fabs(z_turn - x2[1]);
+        double diff = sqrt(dz * dz + dy * dy) + 10 * fabs(dz);
         return -diff;
     }
     if (y_turn > x2[0]) {
@@ -327,7 +334,7 @@ static int sign_differs(double a, double b)
 /* :1365-1398 */
 static int determine_solution_type(const double x1[2], const double x2[2], double C0, const ice_t *m)
 {
-    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
     double C1 = get_C1(x1, C0, m);
     double gamma_turn, z_turn;
     get_turning_point(c, m, &gamma_turn, &z_turn);
@@ -389,7 +396,7 @@ int orc_find_solutions_2d(const double x1[2], const double x2[2], const double i
 /* :496-511 */
 static double get_z_mirrored(const double x1[2], const double x2[2], double C0, const ice_t *m)
 {
-    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
     double C1 = get_C1(x1, C0, m);
     double gamma_turn, z_turn;
     get_turning_point(c, m, &gamma_turn, &z_turn);
@@ -402,7 +409,7 @@ static double get_z_mirrored(const double x1[2], const double x2[2], double C0, 
 /* :293-304 */
 static double get_z_unmirrored(double z, double C0, const ice_t *m)
 {
-    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
     double gamma_turn, z_turn;
     get_turning_point(c, m, &gamma_turn, &z_turn);
     if (z > z_turn) return 2 * z_turn - z;
@@ -421,32 +428,34 @@ static double get_y_diff(double z_raw, double C0, const ice_t *m)
     return res;
 }
 
-/* :1161-1199 */
-static double get_angle(const double x[2], const double x_start[2], double C0, const ice_t *m)
+/* :1161-1199: (sin, cos) of the angle to the +z axis of the ray at x, taken algebraically from dy/dz */
+static void get_angle_sincos(const double x[2], const double x_start[2], double C0, const ice_t *m, double *sn, double *cs)
 {
     double z = get_z_mirrored(x_start, x, C0, m);
-    double dy = get_y_diff(z, C0, m);
-    double angle = atan(dy);
-    if (angle < 0) angle = M_PI + angle;
-    return angle;
-}
-static double get_launch_angle(const double x1[2], double C0, const ice_t *m) { return get_angle(x1, x1, C0, m); }
-static double get_receive_angle(const double x1[2], const double x2[2], double C0, const ice_t *m)
-{
-    return M_PI - get_angle(x2, x1, C0, m);
+    double dy = get_y_diff(z, C0, m); /* signed: negative on the mirrored branch */
+    if (isinf(dy)) {
+        *sn = 1.;
+        *cs = 0.;
+        return;
+    }
+    double a = fabs(dy);
+    double h = sqrt(1 + a * a);
+    *sn = a / h;                     /* angle = arctan(dy), + pi if negative: sin >= 0 */
+    *cs = (dy < 0 ? -1. : 1.) / h;
 }
 
 /* :1201-1237, reflection = 0: returns NaN for "None" */
 static double get_reflection_angle(const double x1[2], const double x2[2], double C0, const ice_t *m)
 {
-    double c = m->n_ice * m->n_ice - pow(C0, -2.);
+    double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
     double gamma_turn, z_turn;
     get_turning_point(c, m, &gamma_turn, &z_turn);
     double C1 = get_C1(x1, C0, m);
     double y_turn = get_y(gamma_turn, C0, C1, m); /* get_y_turn :186 */
     if (z_turn >= 0 && y_turn > x1[0] && y_turn < x2[0]) {
-        double xs[2] = { y_turn, 0. };
-        return get_angle(xs, x1, C0, m);
+        double xs[2] = { y_turn, 0. }, sn, cs;
+        get_angle_sincos(xs, x1, C0, m, &sn, &cs);
+        return atan2(sn, cs);
     }
     return NAN;
 }
@@ -457,16 +466,17 @@ static void path_length_and_time(const double x1[2], const double x2[2], double 
 {
     double z1 = x1[1], z2 = x2[1];
     int solution_type = determine_solution_type(x1, x2, C0, m);
-    double launch_angle = get_launch_angle(x1, C0, m);
+    double sin_launch, cos_launch;
+    get_angle_sincos(x1, x1, C0, m, &sin_launch, &cos_launch);
     double n_ice = m->n_ice, z_0 = m->z_0;
     double n1 = n_of_z(z1, m);
-    double beta = n1 * sin(launch_angle);
+    double beta = n1 * sin_launch;
     double alpha = n_ice * n_ice - beta * beta;
     double zz[3] = { z1, z2, 0. };
     double s[3], ct[3];
     if (solution_type == 2) {
         double g, zt;
-        get_turning_point(n_ice * n_ice - pow(C0, -2.), m, &g, &zt);
+        get_turning_point(n_ice * n_ice - 1. / (C0 * C0), m, &g, &zt);
         zz[2] = zt;
     }
     for (int i = 0; i < 3; i++) {
@@ -474,9 +484,9 @@ static void path_length_and_time(const double x1[2], const double x2[2], double 
         double gamma = fmax(0., nz * nz - beta * beta);
         double l1 = sqrt(alpha * gamma) + n_ice * nz - beta * beta;
         double l2 = sqrt(gamma) + nz;
-        s[i] = n_ice / sqrt(alpha) * (zz[i] - z_0 * log(l1)) + z_0 * log(l2);
-        ct[i] = z_0 * (sqrt(gamma) - n_ice * n_ice / sqrt(alpha) * log(l1) + n_ice * log(l2))
-                + n_ice * n_ice * zz[i] / sqrt(alpha);
+        double ll1 = orc_log(l1), ll2 = orc_log(l2), sa = sqrt(alpha);
+        s[i] = n_ice / sa * (zz[i] - z_0 * ll1) + z_0 * ll2;
+        ct[i] = z_0 * (sqrt(gamma) - n_ice * n_ice / sa * ll1 + n_ice * ll2) + n_ice * n_ice * zz[i] / sa;
     }
     if (solution_type == 1) {
         *D = s[1] - s[0];
@@ -496,10 +506,11 @@ double orc_attenuation_length(double z, double frequency, int model)
     double L;
     if (model == 1) { /* SP1 :168-192 */
         double z2 = fabs(z);
-        double t = 1.83415e-09 * pow(z2, 3) + (-1.59061e-08 * pow(z2, 2)) + 0.00267687 * z2 + (-51.0696);
+        double t = 1.83415e-09 * (z2 * z2 * z2) + (-1.59061e-08 * (z2 * z2)) + 0.00267687 * z2 + (-51.0696);
         double f0 = 0.0001, f2 = 3.16;
-        double w0 = log(f0), w1 = 0.0, w2 = log(f2);
-        double w = log(frequency);
+        double w0 = -9.210340371976182, w1 = 0.0, w2 = 1.1505720275988207; /* ln 1e-4, ln 3.16 */
+        double w = orc_log(frequency);
+        (void)f0; (void)f2;
         double b0 = -6.74890 + t * (0.026709 - t * 0.000884);
         double b1 = -6.22121 - t * (0.070927 + t * 0.001773);
         double b2 = -4.09468 - t * (0.002213 + t * 0.000332);
@@ -511,12 +522,12 @@ double orc_attenuation_length(double z, double frequency, int model)
             a = (b2 * w1 - b1 * w2) / (w1 - w2);
             bb = (b2 - b1) / (w2 - w1);
         }
-        L = 1. / exp(a + bb * w);
+        L = 1. / orc_exp(a + bb * w);
     } else if (model == 2) { /* GL1 :99-128, :194-196 (Python clamps the 75 MHz length at 100 m) */
         static const double fit[6] = { 1.16052586e+03, 6.87257150e-02, -9.82378264e-05,
                                        -3.50628312e-07, -2.21040482e-10, -3.63912864e-14 };
-        double att = 0;
-        for (int p = 0; p < 6; p++) att += fit[p] * pow(z, p);
+        double att = 0, zp = 1;
+        for (int p = 0; p < 6; p++) { att += fit[p] * zp; zp *= z; }
         if (att < 100.) att = 100.;
         L = att - 0.55 * (frequency / 1e-3 - 75);
     } else if (model == 4) { /* GL2 :198-204 */
@@ -529,9 +540,9 @@ double orc_attenuation_length(double z, double frequency, int model)
     } else if (model == 3) { /* MB1 :224-244 */
         double R = 0.82, d_ice = 576.;
         L = 460. - 180. * frequency;
-        L *= pow(1 + L / (2 * d_ice) * log(R), -1);
+        L *= 1. / (1 + L / (2 * d_ice) * orc_log(R));
         double d = -z * 420. / d_ice;
-        double LL = (1250. * 0.08886 * exp(-0.048827 * (225.6746 - 86.517596 * log10(848.870 - (d)))));
+        double LL = (1250. * 0.08886 * orc_exp(-0.048827 * (225.6746 - 86.517596 * (orc_log(848.870 - (d)) / 2.302585092994046))));
         L *= LL / 231.21;
     } else {
         return NAN; /* GL3 needs data/GL3_params.csv: not restated */
@@ -601,7 +612,10 @@ static void dqk21(integrand_t f, void *p, double a, double b, double *result, do
     *resabs *= dhlgth;
     *resasc *= dhlgth;
     *abserr = fabs((resk - resg) * hlgth);
-    if (*resasc != 0. && *abserr != 0.) *abserr = *resasc * fmin(1., pow(200. * *abserr / *resasc, 1.5));
+    if (*resasc != 0. && *abserr != 0.) {
+        double r = 200. * *abserr / *resasc;
+        *abserr = *resasc * fmin(1., r * sqrt(r)); /* r ** 1.5 */
+    }
     if (*resabs > uflow / (50. * epmach)) *abserr = fmax((epmach * 50.) * *resabs, *abserr);
 }
 
@@ -1040,14 +1054,14 @@ void orc_attenuation_2d(const double x1[2], const double x2[2], double C0, const
     ice_t m = { ice[0], ice[1], ice[2] };
     double x2m = get_z_mirrored(x1, x2, C0, &m);
     double g, z_turn;
-    get_turning_point(m.n_ice * m.n_ice - pow(C0, -2.), &m, &g, &z_turn);
+    get_turning_point(m.n_ice * m.n_ice - 1. / (C0 * C0), &m, &g, &z_turn);
     int npts = (x1[1] < z_turn && z_turn < x2m) ? 1 : 0;
     for (int i = 0; i < n_freq; i++) {
         att_t a = { C0, freqs[i], &m, model, 0 };
         double res, err;
         int ne, la;
         orc_quad(att_integrand, &a, x1[1], x2m, npts, z_turn, 1.49e-8, 1e-2, &res, &err, &ne, &la);
-        att[i] = exp(-1 * res);
+        att[i] = orc_exp(-1 * res);
         if (neval) neval[i] = ne;
     }
 }
@@ -1069,8 +1083,13 @@ static void set_start_and_end_point(const double x1[3], const double x2[3], geom
         memcpy(g->X1, x2, 24);
     }
     double dX[3] = { g->X2[0] - g->X1[0], g->X2[1] - g->X1[1], g->X2[2] - g->X1[2] };
-    double dPhi = -atan2(dX[1], dX[0]);
-    double c = cos(dPhi), s = sin(dPhi);
+    /* rotation by dPhi = -arctan2(dy, dx): cos / sin taken algebraically */
+    double rho = sqrt(dX[0] * dX[0] + dX[1] * dX[1]);
+    double c = 1., s = 0.;
+    if (rho > 0) {
+        c = dX[0] / rho;
+        s = -(dX[1] / rho);
+    }
     double R[9] = { c, -s, 0, s, c, 0, 0, 0, 1 };
     memcpy(g->R, R, sizeof R);
     double X2r[3];
@@ -1112,11 +1131,14 @@ void orc_raytrace_batch(long n, const double *x1, const double *x2, const double
             C0[k] = c0[s];
             C1[k] = c1[s];
             path_length_and_time(g.x1, g.x2, c0[s], &m, &D[k], &T[k]);
-            double la = get_launch_angle(g.x1, c0[s], &m), ra = get_receive_angle(g.x1, g.x2, c0[s], &m);
-            double lv[3] = { sin(la), 0, cos(la) }, rv[3] = { -sin(ra), 0, cos(ra) };
+            /* launch angle la; receive angle ra = pi - angle at x2: sin ra = s2, cos ra = -c2 */
+            double sL, cL, s2, c2;
+            get_angle_sincos(g.x1, g.x1, c0[s], &m, &sL, &cL);
+            get_angle_sincos(g.x2, g.x1, c0[s], &m, &s2, &c2);
+            double lv[3] = { sL, 0, cL }, rv[3] = { -s2, 0, -c2 };
             if (g.swap) {
-                lv[0] = -sin(ra); lv[2] = cos(ra);
-                rv[0] = sin(la);  rv[2] = cos(la);
+                lv[0] = -s2; lv[2] = -c2;
+                rv[0] = sL;  rv[2] = cL;
             }
             rotate_back(&g, lv, launch + 3 * k);
             rotate_back(&g, rv, receive + 3 * k);

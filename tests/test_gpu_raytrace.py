@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _compare_ray_tables(o, g, count_tol=0.005):
+    """against the reference's outputs: the reference's own first-root noise applies (tests/test_oracle_golden.py)"""
     bad = o['n_sol'] != g['n_sol']
     assert bad.mean() <= count_tol, "solution-count mismatches: %d of %d" % (bad.sum(), len(bad))
     for i in np.where(bad)[0]:
@@ -16,17 +17,28 @@ def _compare_ray_tables(o, g, count_tol=0.005):
     ok = ~bad
     assert np.array_equal(o['type'][ok], g['type'][ok])
     assert max_rel(o['C0'][ok], g['C0'][ok]) < 1e-6
-    # D and T are ill-conditioned for nearly horizontal rays (sqrt of a cancelling difference at the turning
-    # point, analyticraytracing.py:657-668): the reference's own value moves by ~1e-6 with libm's last bit there
-    assert max_rel(o['D'][ok], g['D'][ok]) < 1e-5
-    assert max_rel(o['T'][ok], g['T'][ok]) < 1e-5
-    assert np.nanmedian(np.abs(o['T'][ok] - g['T'][ok]) / g['T'][ok]) < 1e-9
+    for k in ('D', 'T'):
+        rel = np.abs(o[k][ok] - g[k][ok]) / np.abs(g[k][ok])
+        rel = rel[np.isfinite(rel)]
+        assert rel.max() < 1e-5 and (rel > 1e-6).mean() <= 0.002, k
     for k in ('launch', 'receive'):
         assert np.array_equal(np.isnan(o[k][ok]), np.isnan(g[k][ok]))
-        assert np.nanmax(np.abs(o[k][ok] - g[k][ok])) < 5e-6
-    assert np.nanmax(np.abs(o['C1'][ok] - g['C1'][ok])) < 1e-2
+        assert np.nanmax(np.abs(o[k][ok] - g[k][ok])) < 1e-6
+    assert np.nanmax(np.abs(o['C1'][ok] - g['C1'][ok])) < 1e-3
     assert max_rel(o['refl_angle'][ok], g['refl_angle'][ok]) < 1e-6
     return bad.sum()
+
+
+def _assert_identical_to_oracle(o, ref):
+    """The kernels and the oracle use the same bit-reproducible exp / log and the same operation order, so the
+    whole ray table is EQUAL, not close: counts, types and every float64 bit (NaN padding included).  Only the
+    reflection angle goes through libm's atan2 on both sides (output only)."""
+    assert np.array_equal(o['n_sol'], ref['n_sol'])
+    assert np.array_equal(o['type'], ref['type'])
+    for k in ('C0', 'C1', 'D', 'T', 'launch', 'receive'):
+        assert np.array_equal(o[k], ref[k], equal_nan=True), k
+    assert np.array_equal(np.isnan(o['refl_angle']), np.isnan(ref['refl_angle']))
+    assert np.nanmax(np.abs(o['refl_angle'] - ref['refl_angle']), initial=0.) < 1e-14
 
 
 @pytest.mark.parametrize('name', ['A', 'B', 'C'])
@@ -35,6 +47,7 @@ def test_find_solutions_vs_reference_fixture(gpu_ctx_factory, name):
     ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
     o = ctx.find_solutions_batch(g['x1'], g['x2'])
     _compare_ray_tables(o, g)
+    _assert_identical_to_oracle(o, orc.raytrace_batch(g['x1'], g['x2'], g['ice']))
 
 
 def test_find_solutions_vs_oracle_survey_geometry(gpu_ctx_factory):
@@ -49,8 +62,7 @@ def test_find_solutions_vs_oracle_survey_geometry(gpu_ctx_factory):
     ctx = gpu_ctx_factory(ice)
     o = ctx.find_solutions_batch(vert, chan, outer=True)
     ref = orc.raytrace_batch(np.repeat(vert, 5, axis=0), np.tile(chan, (n, 1)), ice)
-    nbad = _compare_ray_tables(o, ref)
-    print("count mismatches vs oracle: %d / %d" % (nbad, 5 * n))
+    _assert_identical_to_oracle(o, ref)
     assert (o['n_sol'] == 2).mean() > 0.3
 
 
@@ -65,10 +77,7 @@ def test_find_solutions_edge_cases(gpu_ctx_factory):
     x2 = np.array([[0., 0., -300.], [0.5, 0., -100.], [0., 0., -100.], [0., 0., -100.]])
     o = ctx.find_solutions_batch(x1, x2)
     ref = orc.raytrace_batch(x1, x2, ice)
-    assert np.array_equal(o['n_sol'], ref['n_sol'])
-    assert np.array_equal(o['type'], ref['type'])
-    assert max_rel(o['T'], ref['T']) < 1e-6
-    assert np.nanmax(np.abs(o['launch'] - ref['launch'])) < 1e-6
+    _assert_identical_to_oracle(o, ref)
     assert o['n_sol'][2] == 0 and np.all(np.isnan(o['C0'][2])) and np.all(o['type'][2] == 0)
 
 
@@ -84,10 +93,11 @@ def test_attenuation_vs_reference_fixture(gpu_ctx_factory, name):
     out, nev = ctx.attenuation_batch(x1, x2, C0, g['fcoarse'], return_neval=True)
     ref = att.reshape(na * 2, nf)
     assert max_rel(out, ref) < 1e-6
-    # same adaptive decisions as the reference's QUADPACK (oracle reports scipy's neval)
-    _, nev_o = orc.attenuation_batch(x1, x2, C0, g['ice'], str(g['att_model']), g['fcoarse'], return_neval=True)
+    # identical adaptive decisions and identical bits as the oracle's QUADPACK restatement
+    out_o, nev_o = orc.attenuation_batch(x1, x2, C0, g['ice'], str(g['att_model']), g['fcoarse'], return_neval=True)
     m = np.isfinite(ref)
-    assert (nev[m] != nev_o[m]).mean() < 1e-3
+    assert np.array_equal(nev[m], nev_o[m])
+    assert np.array_equal(out, out_o, equal_nan=True)
 
 
 def test_attenuation_length_models(gpu_ctx_factory):
