@@ -509,7 +509,7 @@ __device__ inline double quad_gk21(double a, double b, bool with_point, double p
 }
 
 // zint: per ray {z_start, z_stop_mirrored, z_turn}
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 attenuation_kernel(long n_rays, const double* __restrict__ C0, const double* __restrict__ zint, int n_freq,
                    const double* __restrict__ freqs, int model, IceConst m, double* __restrict__ att,
                    int* __restrict__ neval, const int* __restrict__ ray_index)
