@@ -13,6 +13,7 @@
 // written; the per-lane interval lists (2.2 KB) live in scratch.
 #include "ray_device.h"
 #include "nrhip_internal.h"
+#include <cstdlib>
 
 namespace nrhip {
 
@@ -276,9 +277,212 @@ __device__ inline void epsilon_extrap(int& n, double* epstab, double& result, do
     abserr = fmax(abserr, 5. * epmach * fabs(result));
 }
 
-// adaptive integration over [a, b] with optional interior break point; returns the integral estimate
-__device__ inline double quad_gk21(double a, double b, bool with_point, double point, const AttItem& it,
-                                   const IceConst& m, int* neval_out)
+// ---- evaluation policies -------------------------------------------------------------------------------
+// The adaptive driver below asks for Gauss-Kronrod estimates on one or two intervals at a time.  Two ways to
+// provide them:
+//   LaneEval   every lane evaluates its own 21 (42) integrand values;
+//   GroupEval  the G lanes holding the frequencies of ONE ray cooperate: the subdivision pattern of a ray is
+//              (almost always) the same for all its frequencies, and ds(z), the ice temperature polynomial etc. do
+//              not depend on the frequency.  When every busy lane of the group asks for the same interval, lane n
+//              computes the frequency-independent part of node n once and the group shares it by wave shuffles;
+//              each lane then finishes its own 21-term sums (same values, same order -> same bits).  When lanes of a
+//              group disagree on the interval (rare), each falls back to LaneEval.
+struct NodeShared {
+    double ds;     // path element ds/dz at the node
+    double z;      // un-mirrored depth
+    double p[4];   // model dependent, frequency independent (SP1: a, b of both frequency branches)
+};
+
+__device__ inline NodeShared node_shared(double t, const AttItem& it, const IceConst& m)
+{
+    NodeShared n;
+    double z = (t > it.z_turn) ? 2 * it.z_turn - t : t;
+    double nz = n_of_z(z, m);
+    double q = (it.C0 * it.C0) * (nz * nz);
+    double yd = (q > 1) ? 1 / sqrt(q - 1) : INFINITY;
+    n.ds = sqrt(yd * yd + 1);
+    n.z = z;
+    n.p[0] = n.p[1] = n.p[2] = n.p[3] = 0.;
+    if (it.lane.model == 1) {  // SP1: everything up to (a, b) of both branches is frequency independent
+        double z2 = fabs(z);
+        double t_ = 1.83415e-09 * (z2 * z2 * z2) + (-1.59061e-08 * (z2 * z2)) + 0.00267687 * z2 + (-51.0696);
+        const double w0 = -9.210340371976182, w2 = 1.1505720275988207;
+        double b0 = -6.74890 + t_ * (0.026709 - t_ * 0.000884);
+        double b1 = -6.22121 - t_ * (0.070927 + t_ * 0.001773);
+        double b2 = -4.09468 - t_ * (0.002213 + t_ * 0.000332);
+        n.p[0] = (b1 * w0 - b0 * 0.0) / (w0 - 0.0);
+        n.p[1] = (b1 - b0) / (0.0 - w0);
+        n.p[2] = (b2 * 0.0 - b1 * w2) / (0.0 - w2);
+        n.p[3] = (b2 - b1) / (w2 - 0.0);
+    }
+    return n;
+}
+
+// integrand value of one lane (frequency) from the shared node data: ds / L(z, f)
+__device__ inline double node_finish(double ds, double z, double p0, double p1, double p2, double p3, const AttLane& a)
+{
+    if (a.model == 1) {
+        double aa = (a.f < 1.) ? p0 : p2, bb = (a.f < 1.) ? p1 : p3;
+        double L = 1. / det_exp(aa + bb * a.w);
+        if (L < 1.) L = 1.;
+        if (z > 0) L = INFINITY;
+        return ds / L;
+    }
+    return ds / attenuation_length(z, a);
+}
+
+// abscissa of node n (0 = centre, then QUADPACK's evaluation order: Gauss nodes first, then the Kronrod-only ones)
+__device__ inline double gk_node(int n, double a, double b)
+{
+    const double XGK[11] = {
+        0.995657163025808080735527280689003, 0.973906528517171720077964012084452,
+        0.930157491355708226001207180059508, 0.865063366688984510732096688423493,
+        0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
+        0.562757134668604683339000099272694, 0.433395394129247190799265943165784,
+        0.294392862701460198131126603103866, 0.148874338981631210884826001129720, 0.};
+    double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a);
+    if (n == 0) return centr;
+    int j = (n - 1) >> 1;                       // 0..9
+    int idx = (j < 5) ? 2 * j + 1 : 2 * (j - 5);  // xgk index
+    double absc = hlgth * XGK[idx];
+    return ((n - 1) & 1) ? centr + absc : centr - absc;
+}
+
+// finish a 21-point rule from per-node integrand values f(n) (n as in gk_node); identical accumulation to gk21()
+template <class F>
+__device__ inline GK gk21_from_nodes(double a, double b, F&& fval)
+{
+    const double WGK[11] = {
+        0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
+        0.054755896574351996031381300244580, 0.075039674810919952767043140916190,
+        0.093125454583697605535065465083366, 0.109387158802297641899210590325805,
+        0.123491976262065851077958109585166, 0.134709217311473325928054001771707,
+        0.142775938577060080797094273138717, 0.147739104901338491374841515972068,
+        0.149445554002916905664936468389821};
+    const double WG[5] = {
+        0.066671344308688137593568809893332, 0.149451349150580593145776339657697,
+        0.219086362515982043995534934228163, 0.269266719309996355091226921569469,
+        0.295524224714752870173815619188769};
+    const double epmach = 2.220446049250313e-16, uflow = 2.2250738585072014e-308;
+    double fv1[10], fv2[10];
+    double hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
+    double resg = 0.;
+    double fc = fval(0);
+    double resk = WGK[10] * fc;
+    double resabs = fabs(resk);
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int jtw = 2 * j + 1;
+        double f1 = fval(1 + 2 * j), f2 = fval(2 + 2 * j);
+        fv1[jtw] = f1; fv2[jtw] = f2;
+        double fsum = f1 + f2;
+        resg += WG[j] * fsum;
+        resk += WGK[jtw] * fsum;
+        resabs += WGK[jtw] * (fabs(f1) + fabs(f2));
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int jtwm1 = 2 * j;
+        double f1 = fval(11 + 2 * j), f2 = fval(12 + 2 * j);
+        fv1[jtwm1] = f1; fv2[jtwm1] = f2;
+        double fsum = f1 + f2;
+        resk += WGK[jtwm1] * fsum;
+        resabs += WGK[jtwm1] * (fabs(f1) + fabs(f2));
+    }
+    double reskh = resk * 0.5;
+    double resasc = WGK[10] * fabs(fc - reskh);
+#pragma unroll
+    for (int j = 0; j < 10; j++) resasc += WGK[j] * (fabs(fv1[j] - reskh) + fabs(fv2[j] - reskh));
+    GK o;
+    o.result = resk * hlgth;
+    o.resabs = resabs * dhlgth;
+    o.resasc = resasc * dhlgth;
+    o.abserr = fabs((resk - resg) * hlgth);
+    if (o.resasc != 0. && o.abserr != 0.) {
+        double r = 200. * o.abserr / o.resasc;
+        o.abserr = o.resasc * fmin(1., r * sqrt(r));  // r ** 1.5
+    }
+    if (o.resabs > uflow / (50. * epmach)) o.abserr = fmax((epmach * 50.) * o.resabs, o.abserr);
+    return o;
+}
+
+struct LaneEval {
+    __device__ inline bool any(bool busy) const { return busy; }
+    __device__ inline void pair(bool want, bool two, double a1, double b1, double a2, double b2, const AttItem& it,
+                                const IceConst& m, GK& g1, GK& g2) const
+    {
+        if (!want) return;
+        g1 = gk21(a1, b1, it, m);
+        if (two) g2 = gk21(a2, b2, it, m);
+    }
+};
+
+template <int G>
+struct GroupEval {
+    int lane, gl, gb;               // lane in wave, lane in group, first lane of the group
+    unsigned long long gmask;       // lanes of this group
+    __device__ inline void init()
+    {
+        lane = threadIdx.x & 63;
+        gl = lane & (G - 1);
+        gb = lane - gl;
+        gmask = (G == 64) ? ~0ULL : (((1ULL << G) - 1ULL) << gb);
+    }
+    __device__ inline bool any(bool busy) const { return (__ballot(busy) & gmask) != 0ULL; }
+    __device__ inline void pair(bool want, bool two, double a1, double b1, double a2, double b2, const AttItem& it,
+                                const IceConst& m, GK& g1, GK& g2) const
+    {
+        unsigned long long wm = __ballot(want) & gmask;
+        if (wm == 0ULL) return;
+        int leader = __ffsll((long long)wm) - 1;
+        double la1 = __shfl(a1, leader), lb1 = __shfl(b1, leader), la2 = __shfl(a2, leader), lb2 = __shfl(b2, leader);
+        two = (__shfl((int)two, leader) != 0);  // group-uniform (lanes without work may carry another value)
+        const double lC0 = __shfl(it.C0, leader), lzt = __shfl(it.z_turn, leader);  // the group's ray
+        bool same = !want || (a1 == la1 && b1 == lb1 && (!two || (a2 == la2 && b2 == lb2)));
+        bool allsame = ((__ballot(same) & gmask) == gmask);
+        if (allsame) {
+            // lane gl evaluates node gl of both intervals with the leader's (== everybody's) ray and interval
+            NodeShared n1, n2;
+            n1.ds = n1.z = n2.ds = n2.z = 0.;
+            for (int k = 0; k < 4; k++) n1.p[k] = n2.p[k] = 0.;
+            if (gl < 21) {
+                AttItem li = it;
+                li.C0 = lC0;
+                li.z_turn = lzt;
+                n1 = node_shared(gk_node(gl, la1, lb1), li, m);
+                if (two) n2 = node_shared(gk_node(gl, la2, lb2), li, m);
+            }
+            // every lane pulls the 21 nodes in turn (shuffles are executed by all lanes of the group)
+            double f1v[21], f2v[21];
+#pragma unroll
+            for (int n = 0; n < 21; n++) {
+                double ds = __shfl(n1.ds, gb + n), z = __shfl(n1.z, gb + n);
+                double p0 = __shfl(n1.p[0], gb + n), p1 = __shfl(n1.p[1], gb + n);
+                double p2 = __shfl(n1.p[2], gb + n), p3 = __shfl(n1.p[3], gb + n);
+                f1v[n] = want ? node_finish(ds, z, p0, p1, p2, p3, it.lane) : 0.;
+                if (two) {
+                    ds = __shfl(n2.ds, gb + n); z = __shfl(n2.z, gb + n);
+                    p0 = __shfl(n2.p[0], gb + n); p1 = __shfl(n2.p[1], gb + n);
+                    p2 = __shfl(n2.p[2], gb + n); p3 = __shfl(n2.p[3], gb + n);
+                    f2v[n] = want ? node_finish(ds, z, p0, p1, p2, p3, it.lane) : 0.;
+                }
+            }
+            if (want) {
+                g1 = gk21_from_nodes(a1, b1, [&](int n) { return f1v[n]; });
+                if (two) g2 = gk21_from_nodes(a2, b2, [&](int n) { return f2v[n]; });
+            }
+        } else if (want) {
+            g1 = gk21(a1, b1, it, m);
+            if (two) g2 = gk21(a2, b2, it, m);
+        }
+    }
+};
+
+// adaptive integration over [a, b] with optional interior break point (QUADPACK QAGS / QAGP decisions); every lane of
+// an evaluation group must call this together (lanes without work pass valid = false).  Returns the integral estimate.
+template <class EV>
+__device__ inline double quad_gk21(bool valid, double a, double b, bool with_point, double point, const AttItem& it,
+                                   const IceConst& m, int* neval_out, const EV& ev)
 {
     const double epmach = 2.220446049250313e-16, uflow = 2.2250738585072014e-308, oflow = 1.7976931348623157e+308;
     const double epsabs = 1.49e-8, epsrel = 1e-2;
@@ -287,192 +491,212 @@ __device__ inline double quad_gk21(double a, double b, bool with_point, double p
     int iord[QLIM + 2];
     unsigned char level[QLIM + 2];
     double rlist2[53], res3la[4];
-    double result = 0., abserr = 0., resabs = 0., errsum = 0., errbnd, errmax, area, dres;
+    double result = 0., abserr = 0., resabs = 0., errsum = 0., errbnd = 0., errmax = 0., area = 0., dres;
     double erlarg = 0., ertest = 0., correc = 0., small = 0., reseps = 0., abseps = 0.;
-    int ier = 0, ierro = 0, iroff1 = 0, iroff2 = 0, iroff3 = 0, ksgn, ktmin = 0, last, maxerr, neval = 0, nres = 0,
-        nrmax, numrl2, levmax = 1, levcur = 0;
+    int ier = 0, ierro = 0, iroff1 = 0, iroff2 = 0, iroff3 = 0, ksgn = 1, ktmin = 0, last = 0, maxerr = 1, neval = 0,
+        nres = 0, nrmax = 1, numrl2 = 1, levmax = 1, levcur = 0;
     bool extrap = false, noext = false;
     double sign = 1.;
     const bool qagp = with_point;
-    bool finished = false;  // true -> result/abserr final (label 210 / 140 of the Fortran)
-    if (qagp) {
-        if (a > b) sign = -1.;
-        double pts[3] = {fmin(a, b), point, fmax(a, b)};
-        bool nd[3] = {false, false, false};
-        double a1 = pts[0];
-        for (int i = 1; i <= 2; i++) {
-            double b1 = pts[i];
-            GK g = gk21(a1, b1, it, m);
-            abserr += g.abserr;
-            result += g.result;
-            nd[i] = (g.abserr == g.resasc && g.abserr != 0.);
-            resabs += g.resabs;
-            level[i] = 0;
-            elist[i] = g.abserr;
-            alist[i] = a1;
-            blist[i] = b1;
-            rlist[i] = g.result;
-            iord[i] = i;
-            a1 = b1;
-        }
-        for (int i = 1; i <= 2; i++) {
-            if (nd[i]) elist[i] = abserr;
-            errsum += elist[i];
-        }
-        last = 2;
-        neval = 42;
-        dres = fabs(result);
-        errbnd = fmax(epsabs, epsrel * dres);
-        if (abserr <= 100. * epmach * resabs && abserr > errbnd) ier = 2;
-        if (!(elist[iord[1]] > elist[iord[2]])) { int t = iord[1]; iord[1] = iord[2]; iord[2] = t; }
-        if (ier != 0 || abserr <= errbnd) finished = true;
-        else {
-            rlist2[1] = result;
-            maxerr = iord[1];
-            errmax = elist[maxerr];
-            area = result;
-            nrmax = 1;
-            numrl2 = 1;
-            erlarg = errsum;
-            ertest = errbnd;
-            abserr = oflow;
-            ksgn = (dres >= (1. - 50. * epmach) * resabs) ? 1 : -1;
-            last = 3;
-        }
-    } else {
-        GK g = gk21(a, b, it, m);
-        result = g.result;
-        abserr = g.abserr;
-        double defabs = g.resabs;
-        dres = fabs(result);
-        errbnd = fmax(epsabs, epsrel * dres);
-        last = 1;
-        alist[1] = a; blist[1] = b; rlist[1] = result; elist[1] = abserr; iord[1] = 1;
-        if (abserr <= 100. * epmach * defabs && abserr > errbnd) ier = 2;
-        if (ier != 0 || (abserr <= errbnd && abserr != g.resasc) || abserr == 0.) {
-            finished = true;
-            neval = 21;
-        } else {
-            rlist2[1] = result;
-            errmax = abserr;
-            maxerr = 1;
-            area = result;
-            errsum = abserr;
-            abserr = oflow;
-            nrmax = 1;
-            numrl2 = 2;
-            ksgn = (dres >= (1. - 50. * epmach) * defabs) ? 1 : -1;
-            resabs = defabs;
+    bool busy = false;
+    int exit_code = 0;  // 1: sum the list (label 190 / 115); 2: final-result logic (label 170 / 100)
+    // ---- first estimate(s): (a, b) or (a, point), (point, b) ------------------------------------------------
+    GK g1, g2;
+    g1.result = g1.abserr = g1.resabs = g1.resasc = 0.;
+    g2 = g1;
+    {
+        double lo = fmin(a, b), hi = fmax(a, b);
+        double a1 = qagp ? lo : a, b1 = qagp ? point : b, a2 = point, b2 = hi;
+        ev.pair(valid, qagp, a1, b1, a2, b2, it, m, g1, g2);
+        if (valid && qagp) {
+            if (a > b) sign = -1.;
+            const GK gg[3] = {g1, g1, g2};
+            const double aa[3] = {0., a1, a2}, bb[3] = {0., b1, b2};
+            bool nd[3] = {false, false, false};
+            for (int i = 1; i <= 2; i++) {
+                const GK& g = gg[i];
+                abserr += g.abserr;
+                result += g.result;
+                nd[i] = (g.abserr == g.resasc && g.abserr != 0.);
+                resabs += g.resabs;
+                level[i] = 0;
+                elist[i] = g.abserr;
+                alist[i] = aa[i];
+                blist[i] = bb[i];
+                rlist[i] = g.result;
+                iord[i] = i;
+            }
+            for (int i = 1; i <= 2; i++) {
+                if (nd[i]) elist[i] = abserr;
+                errsum += elist[i];
+            }
             last = 2;
-        }
-    }
-    if (!finished) {
-        int exit_code = 0;  // 1: sum the list (label 190 / 115); 2: final-result logic (label 170 / 100)
-        for (; last <= limit; last++) {
-            if (qagp) levcur = level[maxerr] + 1;
-            double a1 = alist[maxerr], b1 = 0.5 * (alist[maxerr] + blist[maxerr]);
-            double a2 = b1, b2 = blist[maxerr];
-            double erlast = errmax;
-            GK g1 = gk21(a1, b1, it, m);
-            GK g2 = gk21(a2, b2, it, m);
-            neval += 42;
-            double area12 = g1.result + g2.result;
-            double erro12 = g1.abserr + g2.abserr;
-            errsum = errsum + erro12 - errmax;
-            area = area + area12 - rlist[maxerr];
-            if (g1.resasc != g1.abserr && g2.resasc != g2.abserr) {
-                if (fabs(rlist[maxerr] - area12) <= 1e-5 * fabs(area12) && erro12 >= 0.99 * errmax) {
-                    if (extrap) iroff2++;
-                    else iroff1++;
-                }
-                if (last > 10 && erro12 > errmax) iroff3++;
-            }
-            if (qagp) {
-                level[maxerr] = (unsigned char)levcur;
-                level[last] = (unsigned char)levcur;
-            }
-            rlist[maxerr] = g1.result;
-            rlist[last] = g2.result;
-            errbnd = fmax(epsabs, epsrel * fabs(area));
-            if (iroff1 + iroff2 >= 10 || iroff3 >= 20) ier = 2;
-            if (iroff2 >= 5) ierro = 3;
-            if (last == limit) ier = 1;
-            if (fmax(fabs(a1), fabs(b2)) <= (1. + 100. * epmach) * (fabs(a2) + 1000. * uflow)) ier = 4;
-            if (g2.abserr > g1.abserr) {
-                alist[maxerr] = a2;
-                alist[last] = a1;
-                blist[last] = b1;
-                rlist[maxerr] = g2.result;
-                rlist[last] = g1.result;
-                elist[maxerr] = g2.abserr;
-                elist[last] = g1.abserr;
-            } else {
-                alist[last] = a2;
-                blist[maxerr] = b1;
-                blist[last] = b2;
-                elist[maxerr] = g1.abserr;
-                elist[last] = g2.abserr;
-            }
-            sort_errors(last, maxerr, errmax, elist, iord, nrmax);
-            if (errsum <= errbnd) { exit_code = 1; break; }
-            if (ier != 0) { exit_code = 2; break; }
-            if (!qagp && last == 2) {
-                small = fabs(b - a) * 0.375;
+            neval = 42;
+            dres = fabs(result);
+            errbnd = fmax(epsabs, epsrel * dres);
+            if (abserr <= 100. * epmach * resabs && abserr > errbnd) ier = 2;
+            if (!(elist[iord[1]] > elist[iord[2]])) { int t = iord[1]; iord[1] = iord[2]; iord[2] = t; }
+            if (!(ier != 0 || abserr <= errbnd)) {
+                rlist2[1] = result;
+                maxerr = iord[1];
+                errmax = elist[maxerr];
+                area = result;
+                nrmax = 1;
+                numrl2 = 1;
                 erlarg = errsum;
                 ertest = errbnd;
-                rlist2[2] = area;
-                continue;
+                abserr = oflow;
+                ksgn = (dres >= (1. - 50. * epmach) * resabs) ? 1 : -1;
+                last = 3;
+                busy = true;
             }
-            if (noext) continue;
-            erlarg -= erlast;
-            if (qagp) { if (levcur + 1 <= levmax) erlarg += erro12; }
-            else      { if (fabs(b1 - a1) > small) erlarg += erro12; }
-            if (!extrap) {
-                bool is_smallest = qagp ? !(level[maxerr] + 1 <= levmax)
-                                        : !(fabs(blist[maxerr] - alist[maxerr]) > small);
-                if (!is_smallest) continue;
-                extrap = true;
-                nrmax = 2;
+        } else if (valid) {
+            result = g1.result;
+            abserr = g1.abserr;
+            double defabs = g1.resabs;
+            dres = fabs(result);
+            errbnd = fmax(epsabs, epsrel * dres);
+            last = 1;
+            alist[1] = a; blist[1] = b; rlist[1] = result; elist[1] = abserr; iord[1] = 1;
+            if (abserr <= 100. * epmach * defabs && abserr > errbnd) ier = 2;
+            if (ier != 0 || (abserr <= errbnd && abserr != g1.resasc) || abserr == 0.) {
+                neval = 21;
+            } else {
+                rlist2[1] = result;
+                errmax = abserr;
+                maxerr = 1;
+                area = result;
+                errsum = abserr;
+                abserr = oflow;
+                nrmax = 1;
+                numrl2 = 2;
+                ksgn = (dres >= (1. - 50. * epmach) * defabs) ? 1 : -1;
+                resabs = defabs;
+                last = 2;
+                busy = true;
             }
-            if (!(ierro == 3 || erlarg <= ertest)) {
-                int jupbnd = last;
-                if (last > (2 + limit / 2)) jupbnd = limit + 3 - last;
-                bool cont = false;
-                for (int k = nrmax; k <= jupbnd; k++) {
-                    maxerr = iord[nrmax];
-                    errmax = elist[maxerr];
-                    bool big = qagp ? (level[maxerr] + 1 <= levmax) : (fabs(blist[maxerr] - alist[maxerr]) > small);
-                    if (big) { cont = true; break; }
-                    nrmax++;
-                }
-                if (cont) continue;
-            }
-            numrl2++;
-            rlist2[numrl2] = area;
-            bool skip_eps = qagp && numrl2 <= 2;
-            if (!skip_eps) {
-                epsilon_extrap(numrl2, rlist2, reseps, abseps, res3la, nres);
-                ktmin++;
-                if (ktmin > 5 && abserr < 1e-3 * errsum) ier = 5;
-                if (abseps < abserr) {
-                    ktmin = 0;
-                    abserr = abseps;
-                    result = reseps;
-                    correc = erlarg;
-                    ertest = fmax(epsabs, epsrel * fabs(reseps));
-                    if (qagp ? (abserr < ertest) : (abserr <= ertest)) { exit_code = 2; break; }
-                }
-                if (numrl2 == 1) noext = true;
-                if (qagp ? (ier >= 5) : (ier == 5)) { exit_code = 2; break; }
-            }
-            maxerr = iord[1];
-            errmax = elist[maxerr];
-            nrmax = 1;
-            extrap = false;
-            if (qagp) levmax++;
-            else small *= 0.5;
-            erlarg = errsum;
         }
+    }
+    const bool entered_loop = busy;
+    // ---- main loop: bisect the interval with the largest error estimate --------------------------------------
+    while (ev.any(busy)) {
+        double a1 = 0., b1 = 0., a2 = 0., b2 = 0., erlast = 0.;
+        if (busy) {
+            if (qagp) levcur = level[maxerr] + 1;
+            a1 = alist[maxerr];
+            b1 = 0.5 * (alist[maxerr] + blist[maxerr]);
+            a2 = b1;
+            b2 = blist[maxerr];
+            erlast = errmax;
+        }
+        ev.pair(busy, true, a1, b1, a2, b2, it, m, g1, g2);
+        if (busy) {
+            do {
+                neval += 42;
+                double area12 = g1.result + g2.result;
+                double erro12 = g1.abserr + g2.abserr;
+                errsum = errsum + erro12 - errmax;
+                area = area + area12 - rlist[maxerr];
+                if (g1.resasc != g1.abserr && g2.resasc != g2.abserr) {
+                    if (fabs(rlist[maxerr] - area12) <= 1e-5 * fabs(area12) && erro12 >= 0.99 * errmax) {
+                        if (extrap) iroff2++;
+                        else iroff1++;
+                    }
+                    if (last > 10 && erro12 > errmax) iroff3++;
+                }
+                if (qagp) {
+                    level[maxerr] = (unsigned char)levcur;
+                    level[last] = (unsigned char)levcur;
+                }
+                rlist[maxerr] = g1.result;
+                rlist[last] = g2.result;
+                errbnd = fmax(epsabs, epsrel * fabs(area));
+                if (iroff1 + iroff2 >= 10 || iroff3 >= 20) ier = 2;
+                if (iroff2 >= 5) ierro = 3;
+                if (last == limit) ier = 1;
+                if (fmax(fabs(a1), fabs(b2)) <= (1. + 100. * epmach) * (fabs(a2) + 1000. * uflow)) ier = 4;
+                if (g2.abserr > g1.abserr) {
+                    alist[maxerr] = a2;
+                    alist[last] = a1;
+                    blist[last] = b1;
+                    rlist[maxerr] = g2.result;
+                    rlist[last] = g1.result;
+                    elist[maxerr] = g2.abserr;
+                    elist[last] = g1.abserr;
+                } else {
+                    alist[last] = a2;
+                    blist[maxerr] = b1;
+                    blist[last] = b2;
+                    elist[maxerr] = g1.abserr;
+                    elist[last] = g2.abserr;
+                }
+                sort_errors(last, maxerr, errmax, elist, iord, nrmax);
+                if (errsum <= errbnd) { exit_code = 1; busy = false; break; }
+                if (ier != 0) { exit_code = 2; busy = false; break; }
+                if (!qagp && last == 2) {
+                    small = fabs(b - a) * 0.375;
+                    erlarg = errsum;
+                    ertest = errbnd;
+                    rlist2[2] = area;
+                    break;  // continue
+                }
+                if (noext) break;  // continue
+                erlarg -= erlast;
+                if (qagp) { if (levcur + 1 <= levmax) erlarg += erro12; }
+                else      { if (fabs(b1 - a1) > small) erlarg += erro12; }
+                if (!extrap) {
+                    bool is_smallest = qagp ? !(level[maxerr] + 1 <= levmax)
+                                            : !(fabs(blist[maxerr] - alist[maxerr]) > small);
+                    if (!is_smallest) break;  // continue
+                    extrap = true;
+                    nrmax = 2;
+                }
+                if (!(ierro == 3 || erlarg <= ertest)) {
+                    int jupbnd = last;
+                    if (last > (2 + limit / 2)) jupbnd = limit + 3 - last;
+                    bool cont = false;
+                    for (int k = nrmax; k <= jupbnd; k++) {
+                        maxerr = iord[nrmax];
+                        errmax = elist[maxerr];
+                        bool big = qagp ? (level[maxerr] + 1 <= levmax) : (fabs(blist[maxerr] - alist[maxerr]) > small);
+                        if (big) { cont = true; break; }
+                        nrmax++;
+                    }
+                    if (cont) break;  // continue
+                }
+                numrl2++;
+                rlist2[numrl2] = area;
+                bool skip_eps = qagp && numrl2 <= 2;
+                if (!skip_eps) {
+                    epsilon_extrap(numrl2, rlist2, reseps, abseps, res3la, nres);
+                    ktmin++;
+                    if (ktmin > 5 && abserr < 1e-3 * errsum) ier = 5;
+                    if (abseps < abserr) {
+                        ktmin = 0;
+                        abserr = abseps;
+                        result = reseps;
+                        correc = erlarg;
+                        ertest = fmax(epsabs, epsrel * fabs(reseps));
+                        if (qagp ? (abserr < ertest) : (abserr <= ertest)) { exit_code = 2; busy = false; break; }
+                    }
+                    if (numrl2 == 1) noext = true;
+                    if (qagp ? (ier >= 5) : (ier == 5)) { exit_code = 2; busy = false; break; }
+                }
+                maxerr = iord[1];
+                errmax = elist[maxerr];
+                nrmax = 1;
+                extrap = false;
+                if (qagp) levmax++;
+                else small *= 0.5;
+                erlarg = errsum;
+            } while (0);
+            if (busy) {
+                last++;
+                if (last > limit) busy = false;  // cannot happen (ier = 1 at last == limit), kept as a guard
+            }
+        }
+    }
+    if (valid && entered_loop) {
         if (last > limit) last = limit;
         bool sum_list = (exit_code == 1);
         if (!sum_list) {  // label 170 / 100
@@ -508,13 +732,14 @@ __device__ inline double quad_gk21(double a, double b, bool with_point, double p
     return result;
 }
 
-// zint: per ray {z_start, z_stop_mirrored, z_turn}
+// zint: per ray {z_start, z_stop_mirrored, z_turn}; one lane per (ray, frequency)
 __global__ void __launch_bounds__(256, 2)
 attenuation_kernel(long n_rays, const double* __restrict__ C0, const double* __restrict__ zint, int n_freq,
                    const double* __restrict__ freqs, int model, IceConst m, double* __restrict__ att,
                    int* __restrict__ neval, const int* __restrict__ ray_index)
 {
     long n_items = n_rays * n_freq;
+    LaneEval ev;
     for (long it0 = blockIdx.x * (long)blockDim.x + threadIdx.x; it0 < n_items;
          it0 += (long)gridDim.x * blockDim.x) {
         long ray = it0 / n_freq;
@@ -535,9 +760,45 @@ attenuation_kernel(long n_rays, const double* __restrict__ C0, const double* __r
         }
         bool with_point = (z1 < it.z_turn && it.z_turn < z2m);
         int ne;
-        double integral = quad_gk21(z1, z2m, with_point, it.z_turn, it, m, &ne);
+        double integral = quad_gk21(true, z1, z2m, with_point, it.z_turn, it, m, &ne, ev);
         att[item] = det_exp(-1 * integral);
         if (neval) neval[item] = ne;
+    }
+}
+
+// G lanes per ray (G = 32 for n_freq <= 32, else 64): the cooperative evaluation of GroupEval
+template <int G>
+__global__ void __launch_bounds__(256, 2)
+attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const double* __restrict__ zint, int n_freq,
+                         const double* __restrict__ freqs, int model, IceConst m, double* __restrict__ att,
+                         int* __restrict__ neval, const int* __restrict__ ray_index)
+{
+    GroupEval<G> ev;
+    ev.init();
+    const long groups_per_block = blockDim.x / G;
+    const long n_iter = (n_rays + (long)gridDim.x * groups_per_block - 1) / ((long)gridDim.x * groups_per_block);
+    for (long iter = 0; iter < n_iter; iter++) {  // uniform trip count: every lane takes part in the shuffles
+        long g = (iter * gridDim.x + blockIdx.x) * groups_per_block + threadIdx.x / G;
+        int jf = threadIdx.x & (G - 1);
+        bool ray_ok = g < n_rays;
+        long ray = 0;
+        if (ray_ok) ray = ray_index ? ray_index[g] : g;
+        AttItem it;
+        it.C0 = ray_ok ? C0[ray] : NAN;
+        double z1 = ray_ok ? zint[3 * ray] : 0., z2m = ray_ok ? zint[3 * ray + 1] : 0.;
+        it.z_turn = ray_ok ? zint[3 * ray + 2] : 0.;
+        it.lane.model = model;
+        it.lane.f = (jf < n_freq) ? freqs[jf] : 1.;
+        it.lane.w = det_log(it.lane.f);
+        bool valid = ray_ok && jf < n_freq && !isnan(it.C0);
+        bool with_point = (z1 < it.z_turn && it.z_turn < z2m);
+        int ne = 0;
+        double integral = quad_gk21(valid, z1, z2m, with_point, it.z_turn, it, m, &ne, ev);
+        if (ray_ok && jf < n_freq) {
+            const long item = ray * n_freq + jf;
+            att[item] = valid ? det_exp(-1 * integral) : NAN;
+            if (neval) neval[item] = ne;
+        }
     }
 }
 
@@ -615,6 +876,18 @@ void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0,
     long n_items = n_rays * n_freq;
     if (n_items <= 0) return;
     int block = 256;
+    if (n_freq <= 64 && !getenv("NRHIP_ATT_LANES")) {
+        int G = (n_freq <= 32) ? 32 : 64;
+        long grid = (n_rays + block / G - 1) / (block / G);
+        if (grid > 256L * 64) grid = 256L * 64;
+        if (G == 32)
+            hipLaunchKernelGGL(attenuation_group_kernel<32>, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, zint,
+                               n_freq, freqs, model, m, att, neval, ray_index);
+        else
+            hipLaunchKernelGGL(attenuation_group_kernel<64>, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, zint,
+                               n_freq, freqs, model, m, att, neval, ray_index);
+        return;
+    }
     long grid = (n_items + block - 1) / block;
     if (grid > 256L * 64) grid = 256L * 64;
     hipLaunchKernelGGL(attenuation_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, zint, n_freq,

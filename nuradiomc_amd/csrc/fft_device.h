@@ -104,6 +104,136 @@ __device__ inline void fft_dit(double2* x, int log2m, const double2* __restrict_
     }
 }
 
+// Compile-time-sized variants (M = 2^LOG2M points, NT threads per block): all quads of a pass are loaded
+// (LDS data + twiddles from global) before any is computed, so the ~2 x 7 independent loads per thread overlap
+// instead of serialising on L2 latency.  Same operations and rounding as fft_dif / fft_dit.
+template <int LOG2M, int NT>
+__device__ inline void fft_dif_t(double2* x, const double2* __restrict__ tw, bool inverse)
+{
+    constexpr int M = 1 << LOG2M;
+    constexpr int QT = (M / 4 + NT - 1) / NT;  // quads per thread and pass
+    int s = 0;
+#pragma unroll
+    for (; s + 1 < LOG2M; s += 2) {
+        const int q = M >> (s + 2);
+        const int ts1 = (FFT_MAX / 2) / (2 * q), ts2 = (FFT_MAX / 2) / q;
+        double2 a[QT][4], w[QT][3];
+        int idx[QT];
+#pragma unroll
+        for (int u = 0; u < QT; u++) {
+            int t = threadIdx.x + u * NT;
+            int pos = t & (q - 1);
+            int i0 = ((t - pos) << 2) + pos;
+            idx[u] = (M / 4 % NT == 0 || t < M / 4) ? i0 : -1;
+            if (idx[u] >= 0) {
+                w[u][0] = tw[pos * ts1]; w[u][1] = tw[(pos + q) * ts1]; w[u][2] = tw[pos * ts2];
+                a[u][0] = x[i0]; a[u][1] = x[i0 + q]; a[u][2] = x[i0 + 2 * q]; a[u][3] = x[i0 + 3 * q];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QT; u++) {
+            if (idx[u] < 0) continue;
+            double2 wa = w[u][0], wb = w[u][1], wc = w[u][2];
+            if (inverse) { wa.y = -wa.y; wb.y = -wb.y; wc.y = -wc.y; }
+            double2 b0 = cadd(a[u][0], a[u][2]), b2 = cmul(csub(a[u][0], a[u][2]), wa);
+            double2 b1 = cadd(a[u][1], a[u][3]), b3 = cmul(csub(a[u][1], a[u][3]), wb);
+            int i0 = idx[u];
+            x[i0] = cadd(b0, b1);
+            x[i0 + q] = cmul(csub(b0, b1), wc);
+            x[i0 + 2 * q] = cadd(b2, b3);
+            x[i0 + 3 * q] = cmul(csub(b2, b3), wc);
+        }
+        __syncthreads();
+    }
+    if (LOG2M & 1) {  // last single stage, span 1 (twiddle 1)
+        constexpr int PT = (M / 2 + NT - 1) / NT;
+#pragma unroll
+        for (int u = 0; u < PT; u++) {
+            int t = threadIdx.x + u * NT;
+            if (M / 2 % NT == 0 || t < M / 2) {
+                double2 a0 = x[2 * t], a1 = x[2 * t + 1];
+                double2 w0 = tw[0];
+                if (inverse) w0.y = -w0.y;
+                x[2 * t] = cadd(a0, a1);
+                x[2 * t + 1] = cmul(csub(a0, a1), w0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int LOG2M, int NT>
+__device__ inline void fft_dit_t(double2* x, const double2* __restrict__ tw, bool inverse)
+{
+    constexpr int M = 1 << LOG2M;
+    constexpr int QT = (M / 4 + NT - 1) / NT;
+    int s = 0;
+    if (LOG2M & 1) {
+        constexpr int PT = (M / 2 + NT - 1) / NT;
+#pragma unroll
+        for (int u = 0; u < PT; u++) {
+            int t = threadIdx.x + u * NT;
+            if (M / 2 % NT == 0 || t < M / 2) {
+                double2 w0 = tw[0];
+                if (inverse) w0.y = -w0.y;
+                double2 a0 = x[2 * t], b = cmul(x[2 * t + 1], w0);
+                x[2 * t] = cadd(a0, b);
+                x[2 * t + 1] = csub(a0, b);
+            }
+        }
+        __syncthreads();
+        s = 1;
+    }
+#pragma unroll
+    for (; s + 1 < LOG2M; s += 2) {
+        const int q = 1 << s;
+        const int ts1 = (FFT_MAX / 2) / q, ts2 = (FFT_MAX / 2) / (2 * q);
+        double2 a[QT][4], w[QT][3];
+        int idx[QT];
+#pragma unroll
+        for (int u = 0; u < QT; u++) {
+            int t = threadIdx.x + u * NT;
+            int pos = t & (q - 1);
+            int i0 = ((t - pos) << 2) + pos;
+            idx[u] = (M / 4 % NT == 0 || t < M / 4) ? i0 : -1;
+            if (idx[u] >= 0) {
+                w[u][0] = tw[pos * ts1]; w[u][1] = tw[pos * ts2]; w[u][2] = tw[(pos + q) * ts2];
+                a[u][0] = x[i0]; a[u][1] = x[i0 + q]; a[u][2] = x[i0 + 2 * q]; a[u][3] = x[i0 + 3 * q];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QT; u++) {
+            if (idx[u] < 0) continue;
+            double2 wa = w[u][0], wb = w[u][1], wc = w[u][2];
+            if (inverse) { wa.y = -wa.y; wb.y = -wb.y; wc.y = -wc.y; }
+            double2 a0 = a[u][0], a1 = cmul(a[u][1], wa), a2 = a[u][2], a3 = cmul(a[u][3], wa);
+            double2 b0 = cadd(a0, a1), b1 = csub(a0, a1), b2 = cadd(a2, a3), b3 = csub(a2, a3);
+            double2 c2 = cmul(b2, wb), c3 = cmul(b3, wc);
+            int i0 = idx[u];
+            x[i0] = cadd(b0, c2);
+            x[i0 + 2 * q] = csub(b0, c2);
+            x[i0 + q] = cadd(b1, c3);
+            x[i0 + 3 * q] = csub(b1, c3);
+        }
+        __syncthreads();
+    }
+}
+
+// 8192-point convolution with a bit-reversed spectrum table, NT threads
+template <int NT>
+__device__ inline void czt_convolve_t(double2* x, const double2* __restrict__ Btab, const double2* __restrict__ tw)
+{
+    constexpr int M = FFT_MAX;
+    fft_dif_t<FFT_LOG2_MAX, NT>(x, tw, false);
+#pragma unroll
+    for (int u = 0; u < M / NT; u++) {
+        int i = threadIdx.x + u * NT;
+        x[i] = cmul(x[i], Btab[i]);
+    }
+    __syncthreads();
+    fft_dit_t<FFT_LOG2_MAX, NT>(x, tw, true);
+}
+
 __device__ inline int bitrev(int i, int log2m) { return (int)(__brev((unsigned)i) >> (32 - log2m)); }
 
 // exp(sgn * i pi n^2 / Q) with the phase reduced exactly in integers (n^2 mod 2Q) before sincospi

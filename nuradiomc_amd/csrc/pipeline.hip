@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 using namespace nrhip;
 
@@ -362,6 +363,8 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         lens.erase(std::unique(lens.begin(), lens.end()), lens.end());
         std::vector<int> len_index(n_events, -1);
         for (int e : cand) len_index[e] = (int)(std::lower_bound(lens.begin(), lens.end(), hL[e]) - lens.begin());
+        // items of equal length run back to back: their chirp / phase / filter tables stay in L2
+        std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return hL[a] < hL[b]; });
         S.n_distinct_lengths = (int64_t)lens.size();
         st->h_lengths = lens;
         int *d_lens, *d_len_index, *d_cand;
@@ -384,7 +387,11 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         NEED(tab.B_fwd = WS("tab_B_fwd", double2, lens.size() * (size_t)FFT_MAX));
         NEED(tab.B_inv = WS("tab_B_inv", double2, lens.size() * (size_t)FFT_MAX));
         NEED(tab.vel = WS("tab_vel", double2, lens.size() * 2 * (size_t)NRHIP_SPEC_STRIDE));
-        launch_length_tables(sm, (int)lens.size(), d_lens, sd, ctx->twiddle, tab);
+        NEED(tab.E = WS("tab_E", double2, lens.size() * (size_t)NRHIP_E_STRIDE));
+        NEED(tab.H = WS("tab_H", double2, lens.size() * (size_t)NRHIP_SPEC_STRIDE));
+        NEED(tab.Cf = WS("tab_Cf", double2, lens.size() * (size_t)NRHIP_SPEC_STRIDE));
+        NEED(tab.Ci = WS("tab_Ci", double2, lens.size() * (size_t)FFT_MAX));
+        launch_length_tables(sm, (int)lens.size(), d_lens, sd, st->filters, ctx->twiddle, tab);
         LCHK("length_tables");
         MARK(6);
         // 6. channel voltages + trigger

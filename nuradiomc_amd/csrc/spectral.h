@@ -8,6 +8,7 @@
 #define NRHIP_MAX_FILTERS 4
 #define NRHIP_MAX_POLY 24
 #define NRHIP_SPEC_STRIDE 6146  // max L / 2 + 1 spectrum bins per channel (L <= 12290 with the 8192-point chirp-z)
+#define NRHIP_E_STRIDE 24584    // 2 L phase-table entries per length
 
 namespace nrhip {
 
@@ -58,7 +59,11 @@ struct EventOut {
 struct LengthTables {
     double2* B_fwd;  // [n_len][FFT_MAX]
     double2* B_inv;  // [n_len][FFT_MAX]
-    double2* vel;    // [n_len][2][NRHIP_SPEC_STRIDE]
+    double2* vel;    // [n_len][2][NRHIP_SPEC_STRIDE]  analytic antenna response on the L grid (0 below 5 MHz)
+    double2* E;      // [n_len][NRHIP_E_STRIDE]        exp(-2 pi i j / (2 L)), j < 2 L: every chirp / phase factor
+    double2* H;      // [n_len][NRHIP_SPEC_STRIDE]     filter chain response on the L grid
+    double2* Cf;     // [n_len][NRHIP_SPEC_STRIDE]     forward chirp exp(-i pi k^2 / (L/2)), contiguous in k
+    double2* Ci;     // [n_len][FFT_MAX]               inverse chirp exp(+i pi n^2 / L), contiguous in n
 };
 
 struct ChannelOut {
@@ -87,8 +92,8 @@ void launch_efield_max(hipStream_t s, int n_active, const int* active_list, cons
                        double* max_efield);
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev);
-void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const double2* tw,
-                          const LengthTables& tab);
+void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet& fl,
+                          const double2* tw, const LengthTables& tab);
 int channel_grid_blocks();
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,

@@ -16,6 +16,7 @@
 // per ray only ~0.5 KB of parameters enter and 8..100 B leave, the N- and L-point transforms never leave LDS.
 #include "fft_device.h"
 #include "spectral.h"
+#include <cstdlib>
 
 namespace nrhip {
 
@@ -693,12 +694,28 @@ event_grid_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, R
     ev.t_min[e] = (r1 > r0) ? tmin : NAN;
 }
 
+// complex rational filter response prod_i B_i(j f) / A_i(j f) applied successively (signal.freqs)
+__device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl)
+{
+    for (int i = 0; i < fl.n; i++) {
+        if (!(f > 0)) return make_double2(0., 0.);
+        double2 num = make_double2(0., 0.), den = make_double2(0., 0.);
+        const double2 jw = make_double2(0., f);
+        for (int k = 0; k < fl.nb[i]; k++) num = cadd(cmul(num, jw), make_double2(fl.b[i][k], 0.));
+        for (int k = 0; k < fl.na[i]; k++) den = cadd(cmul(den, jw), make_double2(fl.a[i][k], 0.));
+        double dd = den.x * den.x + den.y * den.y;
+        double2 h = make_double2((num.x * den.x + num.y * den.y) / dd, (num.y * den.x - num.x * den.y) / dd);
+        v = cmul(v, h);
+    }
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // kernel: per distinct trace length L -- Bluestein tables and the analytic antenna magnitudes on the L grid
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, const double2* __restrict__ tw,
-                     LengthTables tab)
+length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, FilterSet fl,
+                     const double2* __restrict__ tw, LengthTables tab)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double2* x = (double2*)smem;
@@ -715,8 +732,20 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
         czt_build_table(x, FFT_LOG2_MAX, m + 1, P, L, +1., tw);
         for (int i = threadIdx.x; i < M; i += blockDim.x) tab.B_inv[(long)il * M + i] = x[i];
         __syncthreads();
-        // analytic antenna magnitude * phase on the L grid (antennapattern.py:1672-1768), models 0 VPol, 1 HPol
+        // every phase factor of this length: E[j] = exp(-2 pi i j / (2 L)); filter chain on the L grid
+        for (int j = threadIdx.x; j < 2 * L; j += blockDim.x) {
+            double sn, cs;
+            sincospi((double)j / (double)L, &sn, &cs);
+            tab.E[(long)il * NRHIP_E_STRIDE + j] = make_double2(cs, -sn);
+        }
         const double df = 1.0 / (L * (1. / st.fs));
+        for (int k = threadIdx.x; k <= m; k += blockDim.x)
+            tab.H[(long)il * NRHIP_SPEC_STRIDE + k] = apply_filters(make_double2(1., 0.), k * df, fl);
+        for (int k = threadIdx.x; k < NRHIP_SPEC_STRIDE; k += blockDim.x)
+            tab.Cf[(long)il * NRHIP_SPEC_STRIDE + k] = chirp(k, m, -1.);
+        for (int n = threadIdx.x; n < FFT_MAX; n += blockDim.x) tab.Ci[(long)il * FFT_MAX + n] = chirp(n, L, +1.);
+        // analytic antenna magnitude * phase on the L grid (antennapattern.py:1672-1768), models 0 VPol, 1 HPol;
+        // the "remove DC offset" cut below 5 MHz (efieldToVoltageConverter.py:313) is folded in
         for (int model = 0; model < 2; model++) {
             double* mag = (double*)smem;
             int index = 0;
@@ -761,27 +790,12 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
                                        : 0.321 - 11.400 * f + 39.590 / 2 * (f * f) - 38.181 / 3 * (f * f * f);
                 double sn, cs;
                 sincos(ph, &sn, &cs);
+                if (f < 0.005) v = 0.;
                 tab.vel[((long)il * 2 + model) * NRHIP_SPEC_STRIDE + k] = make_double2(v * cs, v * sn);
             }
             __syncthreads();
         }
     }
-}
-
-// complex rational filter response prod_i B_i(j f) / A_i(j f) applied successively (signal.freqs)
-__device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl)
-{
-    for (int i = 0; i < fl.n; i++) {
-        if (!(f > 0)) return make_double2(0., 0.);
-        double2 num = make_double2(0., 0.), den = make_double2(0., 0.);
-        const double2 jw = make_double2(0., f);
-        for (int k = 0; k < fl.nb[i]; k++) num = cadd(cmul(num, jw), make_double2(fl.b[i][k], 0.));
-        for (int k = 0; k < fl.na[i]; k++) den = cadd(cmul(den, jw), make_double2(fl.a[i][k], 0.));
-        double dd = den.x * den.x + den.y * den.y;
-        double2 h = make_double2((num.x * den.x + num.y * den.y) / dd, (num.y * den.x - num.x * den.y) / dd);
-        v = cmul(v, h);
-    }
-    return v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -792,7 +806,7 @@ __device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl
 //   * filters -> chirp-z back to L samples -> |V| >= threshold (last sample excluded, see majority logic)
 // LDS: FFT_MAX complex (128 KB) + (N/2 + 1) doubles.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(512)
 channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                const int* __restrict__ ev_len_index, StationDev st, FilterSet fl, int ask_model, double threshold,
                const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
@@ -805,7 +819,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
     __shared__ RayShared rs;
     __shared__ double red[1024];
     __shared__ int s_trig;
-    double2* acc = scratch + (long)blockIdx.x * NRHIP_SPEC_STRIDE;
+    double2* __restrict__ acc = scratch + (long)blockIdx.x * NRHIP_SPEC_STRIDE;
     const long vel_stride = NRHIP_SPEC_STRIDE;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
@@ -815,6 +829,11 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
         const double2* Bf = tab.B_fwd + (long)il * M;
         const double2* Bi = tab.B_inv + (long)il * M;
         const double2* vel = tab.vel + ((long)il * 2 + st.ant_model[ch]) * vel_stride;
+        const double2* E = tab.E + (long)il * NRHIP_E_STRIDE;   // E[j] = exp(-2 pi i j / (2 L))
+        const double2* Hf = tab.H + (long)il * NRHIP_SPEC_STRIDE;
+        const double2* Cf = tab.Cf + (long)il * NRHIP_SPEC_STRIDE;
+        const double2* Ci = tab.Ci + (long)il * FFT_MAX;
+        const unsigned LL = (unsigned)L;
         for (int k = threadIdx.x; k <= m; k += blockDim.x) acc[k] = make_double2(0., 0.);
         if (threadIdx.x == 0) s_trig = 0;
         __syncthreads();
@@ -832,6 +851,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
             // start bin and sub-sample remainder (efieldToVoltageConverter.py:214-218)
             double start_time = w.t0[r] - t_min + st.cable[ch] + 0;
             long start_bin = (long)rint(start_time / res);
+            const unsigned sbin = (unsigned)(((start_bin % (long)L) + (long)L) % (long)L);
             double rem = start_time - start_bin * res;
             bool shift = !(fabs(rint(rem * st.fs) - rem * st.fs) < 1e-5);
             const double* T = w.vel_T + 4 * (long)r;
@@ -852,35 +872,32 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                 field_time_domain(x, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
                 // gather y_j (bit-reversed positions) -> registers, then lay out a_j = y_j * chirp_j, zero pad
                 const double sc = 1.0 / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
-                double2 yreg[4];
+                double2 yreg[8];
                 int cnt = 0;
                 for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = x[bitrev(j, log2nh)];
                 __syncthreads();
                 cnt = 0;
+#pragma unroll 4
                 for (int j = threadIdx.x; j < M; j += blockDim.x) {
                     double2 v = make_double2(0., 0.);
-                    if (j < nh) v = cmul(cscale(yreg[cnt++], sc), chirp(j, m, -1.));
+                    if (j < nh) v = cmul(cscale(yreg[cnt++], sc), Cf[j]);  // chirp(j; m, -)
                     x[j] = v;
                 }
                 __syncthreads();
-                czt_convolve(x, FFT_LOG2_MAX, Bf, tw);
+                czt_convolve_t<512>(x, Bf, tw);
                 // Z(k) = chirp(k) x[k] / M ; untangle even/odd samples, apply the start-bin phase, VEL, 5 MHz cut
+#pragma unroll 4
                 for (int k = threadIdx.x; k <= m; k += blockDim.x) {
                     int k1 = (k == m) ? 0 : k, k2 = (k == 0 || k == m) ? 0 : m - k;
-                    double2 Z1 = cscale(cmul(x[k1], chirp(k1, m, -1.)), 1.0 / M);
-                    double2 Z2 = cconj(cscale(cmul(x[k2], chirp(k2, m, -1.)), 1.0 / M));
+                    double2 Z1 = cscale(cmul(x[k1], Cf[k1]), 1.0 / M);
+                    double2 Z2 = cconj(cscale(cmul(x[k2], Cf[k2]), 1.0 / M));
                     double2 Ee = cscale(cadd(Z1, Z2), 0.5);
                     double2 d = cscale(csub(Z1, Z2), 0.5);
                     double2 Eo = make_double2(d.y, -d.x);  // d / i
-                    double sn, cs;
-                    sincospi(-2.0 * (double)k / (double)L, &sn, &cs);
-                    double2 X = cadd(Ee, cmul(Eo, make_double2(cs, sn)));
-                    long ks = ((long)k * start_bin) % L;
-                    sincospi(-2.0 * (double)ks / (double)L, &sn, &cs);
-                    X = cmul(X, make_double2(cs, sn));
-                    double f = k * (1.0 / (L * res));
+                    double2 X = cadd(Ee, cmul(Eo, E[2 * k]));                 // exp(-2 pi i k / L)
+                    unsigned ks = ((unsigned)k * sbin) % LL;                     // both factors < 2^14
+                    X = cmul(X, E[2 * ks]);                                       // exp(-2 pi i k s / L)
                     double2 v = cmul(cscale(vel[k], vfac), X);
-                    if (f < 0.005) v = make_double2(0., 0.);
                     acc[k] = cadd(acc[k], v);
                 }
                 __syncthreads();
@@ -893,27 +910,26 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
             const int P = M - m;
             const double scale = st.fs / 1.4142135623730951 / L;
             for (int n0 = 0; n0 < L; n0 += P) {
+#pragma unroll 4
                 for (int k = threadIdx.x; k < M; k += blockDim.x) {
                     double2 v = make_double2(0., 0.);
                     if (k <= m) {
-                        double f = k * (1.0 / (L * res));
-                        v = apply_filters(acc[k], f, fl);
+                        v = cmul(acc[k], Hf[k]);
                         // Hermitian folding of irfft: DC and Nyquist real and single, the rest doubled
                         if (k == 0 || k == m) v = make_double2(v.x, 0.);
                         else v = cscale(v, 2.);
-                        double sn, cs;
-                        long kn = ((long)k * n0) % L;
-                        sincospi(2.0 * (double)kn / (double)L, &sn, &cs);
-                        v = cmul(v, make_double2(cs, sn));
-                        v = cmul(v, chirp(k, L, +1.));
+                        unsigned kn = ((unsigned)k * (unsigned)n0) % LL;
+                        v = cmul(v, cconj(E[2 * kn]));                             // exp(+2 pi i k n0 / L)
+                        v = cmul(v, Ci[k]);                                        // chirp(k; L, +)
                     }
                     x[k] = v;
                 }
                 __syncthreads();
-                czt_convolve(x, FFT_LOG2_MAX, Bi, tw);
+                czt_convolve_t<512>(x, Bi, tw);
                 int np = min(P, L - n0);
+#pragma unroll 4
                 for (int n = threadIdx.x; n < np; n += blockDim.x) {
-                    double2 u = cmul(x[n], chirp(n, L, +1.));
+                    double2 u = cmul(x[n], Ci[n]);
                     double v = u.x * (1.0 / M) * scale;
                     int ng = n0 + n;
                     if (out.trace) out.trace[out.trace_offset[item] + ng] = v;
@@ -1075,13 +1091,13 @@ static void set_big_lds()
     (void)hipGetLastError();
     g_attr_set = true;
 }
-void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const double2* tw,
-                          const LengthTables& tab)
+void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet& fl,
+                          const double2* tw, const LengthTables& tab)
 {
     if (n_len <= 0) return;
     set_big_lds();
     int grid = n_len < 256 ? n_len : 256;
-    hipLaunchKernelGGL(length_tables_kernel, dim3(grid), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lengths, st, tw, tab);
+    hipLaunchKernelGGL(length_tables_kernel, dim3(grid), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lengths, st, fl, tw, tab);
 }
 int channel_grid_blocks() { return 256; }
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
@@ -1093,7 +1109,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     int nh = st.N / 2;
     size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
     int grid = n_items < channel_grid_blocks() ? n_items : channel_grid_blocks();
-    hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(1024), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
+    hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
                        ask_model, threshold, tw, tab, scratch, ilog2(nh), out);
 }
 void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const double* theta, const int* type,
