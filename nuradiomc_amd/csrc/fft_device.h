@@ -113,7 +113,7 @@ __device__ inline void fft_dif_t(double2* x, const double2* __restrict__ tw, boo
     constexpr int M = 1 << LOG2M;
     constexpr int QT = (M / 4 + NT - 1) / NT;  // quads per thread and pass
     int s = 0;
-#pragma unroll
+#pragma unroll 1
     for (; s + 1 < LOG2M; s += 2) {
         const int q = M >> (s + 2);
         const int ts1 = (FFT_MAX / 2) / (2 * q), ts2 = (FFT_MAX / 2) / q;
@@ -184,7 +184,7 @@ __device__ inline void fft_dit_t(double2* x, const double2* __restrict__ tw, boo
         __syncthreads();
         s = 1;
     }
-#pragma unroll
+#pragma unroll 1
     for (; s + 1 < LOG2M; s += 2) {
         const int q = 1 << s;
         const int ts1 = (FFT_MAX / 2) / q, ts2 = (FFT_MAX / 2) / (2 * q);

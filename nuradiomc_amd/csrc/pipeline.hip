@@ -415,7 +415,8 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         double2* scratch;
         NEED(scratch = WS("channel_scratch", double2, (size_t)channel_grid_blocks() * NRHIP_SPEC_STRIDE));
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, cfg->askaryan_model,
-                       cfg->trigger_threshold, ctx->twiddle, tab, scratch, co);
+                       cfg->trigger_threshold, ctx->twiddle, tab, scratch, co,
+                       (cfg->no_pruning || cfg->dump_traces) ? 1 : 0);
         LCHK("channel");
         MARK(7);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here

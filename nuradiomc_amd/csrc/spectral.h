@@ -97,7 +97,8 @@ void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const St
 int channel_grid_blocks();
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
-                    double threshold, const double2* tw, const LengthTables& tab, double2* scratch, const ChannelOut& out);
+                    double threshold, const double2* tw, const LengthTables& tab, double2* scratch, const ChannelOut& out,
+                    int exact);
 void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const double* theta, const int* type,
                               const double* n_index, const double* R, const double* k_L, int model, int N, double dt,
                               double2* spec);

@@ -810,7 +810,7 @@ __global__ void __launch_bounds__(512)
 channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                const int* __restrict__ ev_len_index, StationDev st, FilterSet fl, int ask_model, double threshold,
                const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
-               ChannelOut out)
+               ChannelOut out, int exact)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M = FFT_MAX, N = st.N, nh = N / 2;
@@ -903,10 +903,25 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                 __syncthreads();
             }
         }
-        // filters, then back to the time domain in blocks of P samples
+        // filters, then back to the time domain in blocks of P samples -- unless the sum-of-magnitudes bound
+        // max |V(t)| <= (fs / sqrt 2) (1 / L) (|V_0| + |V_m| + 2 sum |V_k|) already shows that no sample can reach the
+        // threshold (the trace then is not needed: its maximum is reported as the negated bound)
         double vmax = 0.;
         int trig = 0;
-        if (n_used > 0) {
+        bool need_trace = (n_used > 0);
+        if (n_used > 0 && !exact) {
+            double part = 0.;
+            for (int k = threadIdx.x; k <= m; k += blockDim.x) {
+                double2 v = cmul(acc[k], Hf[k]);
+                part += ((k == 0 || k == m) ? fabs(v.x) : 2. * cabs2(v));
+            }
+            double bnd = block_sum(part, red) * (st.fs / 1.4142135623730951 / L);
+            if (!(bnd * (1 + 1e-9) >= threshold)) {
+                need_trace = false;
+                vmax = -bnd;
+            }
+        }
+        if (need_trace) {
             const int P = M - m;
             const double scale = st.fs / 1.4142135623730951 / L;
             for (int n0 = 0; n0 < L; n0 += P) {
@@ -940,15 +955,10 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                 __syncthreads();
             }
         }
-        red[threadIdx.x] = vmax;
         if (trig) s_trig = 1;
-        __syncthreads();
-        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
-            __syncthreads();
-        }
+        double vm = need_trace ? block_max(vmax, red) : vmax;
         if (threadIdx.x == 0) {
-            out.maxV[item] = red[0];
+            out.maxV[item] = vm;
             if (s_trig) out.triggered[e] = 1;
         }
         __syncthreads();
@@ -1102,7 +1112,8 @@ void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const St
 int channel_grid_blocks() { return 256; }
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
-                    double threshold, const double2* tw, const LengthTables& tab, double2* scratch, const ChannelOut& out)
+                    double threshold, const double2* tw, const LengthTables& tab, double2* scratch, const ChannelOut& out,
+                    int exact)
 {
     if (n_items <= 0) return;
     set_big_lds();
@@ -1110,7 +1121,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
     int grid = n_items < channel_grid_blocks() ? n_items : channel_grid_blocks();
     hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
-                       ask_model, threshold, tw, tab, scratch, ilog2(nh), out);
+                       ask_model, threshold, tw, tab, scratch, ilog2(nh), out, exact);
 }
 void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const double* theta, const int* type,
                               const double* n_index, const double* R, const double* k_L, int model, int N, double dt,

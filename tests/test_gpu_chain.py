@@ -52,7 +52,7 @@ def _station(ctx, g):
                                  n_freq=int(g['n_freq']))
 
 
-def _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=False):
+def _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=False, dump_traces=True):
     g = golden('chain_%s.npz' % name)
     ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
     st = _station(ctx, g)
@@ -60,7 +60,7 @@ def _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=False):
     sl = slice(0, n_events)
     kL = np.where(np.isnan(g['ev_k_L'][sl]), 1.0, g['ev_k_L'][sl])
     trig, stats = st.simulate_events(g['vertex'][sl], g['zenith'][sl], g['azimuth'][sl], g['energy'][sl],
-                                     g['shower_type'][sl], kL, askaryan_model=str(g['askaryan_model']), dump_traces=True,
+                                     g['shower_type'][sl], kL, askaryan_model=str(g['askaryan_model']), dump_traces=dump_traces,
                                      no_pruning=no_pruning)
     return g, ctx, st, trig, stats, kL
 
@@ -172,3 +172,18 @@ def test_pruning_changes_no_result(gpu_ctx_factory, name, n_events):
     # the bound really is an upper bound on the exact maximum (no_pruning run), and pruned rays are below the cut
     assert np.all(B['ray_bound'] * (1 + 1e-6) >= A['ray_max_efield'])
     assert np.all(A['ray_max_efield'][~act] <= 2.0 * st.vrms_efield)
+    # production mode (no trace dump): transforms whose bound stays below the cut / threshold are skipped and report the
+    # negated bound; decisions are unchanged, bounds really bound, exact values agree where they were evaluated
+    g, ctx, st, trig_c, stats_c, kL = _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=False, dump_traces=False)
+    C = {k: st.fetch(k) for k in ('ev_candidate', 'ev_L', 'item_event', 'item_maxV', 'ray_max_efield')}
+    assert np.array_equal(trig_a, trig_c)
+    for k in ('ev_candidate', 'ev_L', 'item_event'):
+        assert np.array_equal(A[k], C[k]), k
+    ex = C['item_maxV'] >= 0
+    assert np.array_equal(C['item_maxV'][ex], A['item_maxV'][ex])
+    assert np.all(-C['item_maxV'][~ex] * (1 + 1e-9) >= A['item_maxV'][~ex])
+    assert np.all(-C['item_maxV'][~ex] < 3.0 * st.vrms)
+    exr = C['ray_max_efield'] >= 0
+    assert np.allclose(C['ray_max_efield'][exr], A['ray_max_efield'][exr], rtol=1e-12, atol=0)
+    assert np.all(-C['ray_max_efield'][~exr] * (1 + 1e-6) >= A['ray_max_efield'][~exr])
+    print(name, 'channels evaluated exactly: %d of %d' % (ex.sum(), len(ex)), 'rays: %d of %d' % (exr.sum(), len(exr)))
