@@ -257,6 +257,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     const size_t nr = (size_t)std::max(n_rays, 1);
     int* ray_slot;
     NEED(ray_slot = WS("ray_slot", int, nr));
+    NEED(w.ask = WS("ray_askaryan", AskaryanConst, nr));
     NEED(w.ev = WS("ray_event", int, nr));
     NEED(w.ch = WS("ray_channel", int, nr));
     NEED(w.sol = WS("ray_solution", int, nr));
@@ -282,7 +283,8 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     if (n_rays > 0) {
         launch_scatter_slots(sm, n_slots, keep, offset, ray_slot);
         LCHK("scatter");
-        launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w);
+        launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w, evin,
+                         cfg->askaryan_model);
         LCHK("ray_setup");
     }
     MARK(2);
@@ -297,7 +299,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         NEED(roff = WS("ray_active_offset", int, nr + 1));
         NEED(rtmp = WS("scan_tmp2", int, scan_tiles(n_rays + 1)));
         NEED(active_list = WS("ray_active_list", int, nr));
-        launch_amp_bound(sm, n_rays, w, evin, sd, cfg->askaryan_model, bound, max_efield);
+        launch_amp_bound(sm, n_rays, w, sd, bound, max_efield);
         LCHK("amp_bound");
         launch_event_possible(sm, (int)n_events, n_ch, offset, bound, cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude,
                               ractive);

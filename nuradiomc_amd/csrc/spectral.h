@@ -32,8 +32,19 @@ struct FilterSet {
     double b[NRHIP_MAX_FILTERS][NRHIP_MAX_POLY], a[NRHIP_MAX_FILTERS][NRHIP_MAX_POLY];
 };
 
+// Askaryan emission constants of one ray (everything of the parametrisation that does not depend on frequency)
+struct AskaryanConst {
+    int model;      // 0 Alvarez2009, 1 Alvarez2000, 2 ZHS1992
+    int had;
+    double a_pref;  // everything that multiplies f
+    double nu_L, beta, nu_R, alpha;  // Alvarez2009
+    double dth, cher, theta, f0, scale, roll;  // Alvarez2000 / ZHS1992
+    double ln_nu_L, ln_nu_R;
+};
+
 // per kept ray (SoA, ordered by event, channel, solution)
 struct RayWork {
+    AskaryanConst* ask;  // [n]
     int *ev, *ch, *sol, *slot;
     double *view, *n_index, *R, *t0, *C0;
     double *pol_theta, *pol_phi;
@@ -79,11 +90,11 @@ long scan_tiles(long n);
 void launch_exclusive_scan(hipStream_t s, long n, const int* in, int* out, int* tile_tmp);
 void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const int* offset, int* ray_slot);
 void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex, const double* zen,
-                      const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w);
+                      const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w,
+                      const EventIn& evin, int ask_model);
 void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
                                   const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint);
-void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const EventIn& evin, const StationDev& st,
-                      int ask_model, double* bound, double* max_efield);
+void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, double* bound, double* max_efield);
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
                            double min_efield, int* ray_active);
 void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const int* offset, int* list);

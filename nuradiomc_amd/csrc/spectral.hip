@@ -181,13 +181,85 @@ __global__ void scatter_slots_kernel(long n_slots, const int* __restrict__ keep,
     if (keep[i]) ray_slot[offset[i]] = (int)i;
 }
 
+// Askaryan constants per ray: parametrizations.py:110-275 up to the frequency dependence
+__device__ inline AskaryanConst askaryan_setup(int model, double energy, double theta, int shower_type,
+                                               double n_index, double R, double k_L_in)
+{
+    AskaryanConst a;
+    a.model = model;
+    a.had = (shower_type == 0);
+    const double eV = 1., MeV = 1e6, TeV = 1e12, cm = 0.01, MHz = 1e-3, GHz = 1., deg = 0.017453292519943295;
+    const double g = 6.241509744511525e+33;  // NuRadioReco/utilities/units.py gram
+    if (model == 0) {  // parametrizations.py:110-218
+        const double E_C = 73.1 * MeV;
+        const double rho = 0.924 * g / (cm * cm * cm);
+        const double X_0 = 36.08 * g / (cm * cm);
+        const double R_M = 10.57 * g / (cm * cm);
+        const double c = 0.299792458;
+        double k_E_bar, k_L, k_R_bar;
+        double lE = log10(energy / eV);
+        if (a.had) {
+            double k_E_0 = 4.13e-16 * 1. / cm / (MHz * MHz);
+            k_E_bar = k_E_0 * tanh((lE - 10.60) / 2.54);
+            k_L = 31.25 * pow(energy / (1.e15 * eV), 3.01e-2);
+            k_R_bar = 2.73 + tanh((12.92 - lE) / 1.72);
+            a.beta = 2.57;
+        } else {
+            k_E_bar = 4.65e-16 * 1. / cm / (MHz * MHz);
+            k_L = k_L_in;
+            k_R_bar = 1.54;
+            a.beta = 2.74;
+        }
+        a.a_pref = k_E_bar * energy / E_C * X_0 / rho * sin(theta);
+        double nu_L = rho / k_L / X_0;
+        double q = fabs(1 - n_index * cos(theta));
+        const double cher_cut = 1.e-8;
+        if (q < cher_cut) nu_L *= c / cher_cut;
+        else nu_L *= c / q;
+        a.nu_L = nu_L;
+        a.nu_R = rho / k_R_bar / R_M * c / sqrt(n_index * n_index - 1);
+        a.alpha = 1.27;
+        a.scale = R;
+        a.ln_nu_L = log(a.nu_L);
+        a.ln_nu_R = log(a.nu_R);
+    } else if (model == 1) {  // Alvarez2000, parametrizations.py:220-275
+        a.cher = acos(1. / n_index);
+        a.theta = theta;
+        const double Elpm = 2e15 * eV;
+        double eps = log10(energy / TeV);
+        double dth;  // angular width * f / (500 MHz)  [rad]
+        if (!a.had) {
+            dth = 2.7 * deg * 500 * MHz * pow(Elpm / (0.14 * energy + Elpm), 0.3);
+            a.scale = 1.;
+        } else {
+            double dd = 0;
+            if (eps >= 0 && eps <= 2) dd = 500 * MHz * (2.07 - 0.33 * eps + 7.5e-2 * eps * eps) * deg;
+            else if (eps > 2 && eps <= 5) dd = 500 * MHz * (1.74 - 1.21e-2 * eps) * deg;
+            else if (eps > 5 && eps <= 7) dd = 500 * MHz * (4.23 - 0.785 * eps + 5.5e-2 * eps * eps) * deg;
+            else if (eps > 7) dd = 500 * MHz * (4.23 - 0.785 * 7 + 5.5e-2 * 49) * (1 + (eps - 7) * 0.075) * deg;
+            dth = dd;
+            double f_eps = -1.27e-2 - 4.76e-2 * (eps + 3);
+            f_eps += -2.07e-3 * (eps + 3) * (eps + 3) + 0.52 * sqrt(eps + 3);
+            a.scale = (dd != 0) ? f_eps : 0.;
+        }
+        a.dth = dth;
+        a.f0 = 1.15 * GHz;
+        a.a_pref = 2.53e-7 * energy / TeV / MHz * (sin(theta) / sin(a.cher)) / R;
+    } else {  // ZHS1992, parametrizations.py:92-108
+        a.cher = acos(1. / n_index);
+        a.theta = theta;
+        a.a_pref = 1.1e-7 * energy / TeV / R / MHz;
+    }
+    return a;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // per-ray parameters
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const double* __restrict__ vertex,
                  const double* __restrict__ zenith, const double* __restrict__ azimuth, RayRecords rec, IceConst m,
-                 StationDev st, RayWork w)
+                 StationDev st, RayWork w, EventIn evin, int ask_model)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
@@ -269,6 +341,8 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
     for (int c = 0; c < 4; c++) w.vel_T[4 * (long)r + c] = T[c];
     w.theta_ant[r] = th_a;
     w.slot[r] = slot;
+    w.ask[r] = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r], w.R[r],
+                              evin.k_L[e]);
 }
 
 // integration limits for the attenuation kernel from the ray records
@@ -313,85 +387,6 @@ ray_limits_from_slots_kernel(int n_rays, int n_ch, const int* __restrict__ ray_s
 // askaryan.py:209-213) is the identity spec_k = i * X_k * (-1)^k * sqrt(2) for 0 < k < N/2 and 0 at DC and
 // Nyquist, so only the real amplitude X_k is evaluated.
 // ---------------------------------------------------------------------------------------------------------
-struct AskaryanConst {
-    int model;      // 0 Alvarez2009, 1 Alvarez2000, 2 ZHS1992
-    double a_pref;  // everything that multiplies f
-    double nu_L, beta, nu_R, alpha;  // Alvarez2009
-    double dth, cher, theta, f0, scale, roll;  // Alvarez2000 / ZHS1992
-    double ln_nu_L, ln_nu_R;
-    int had;
-};
-
-__device__ inline AskaryanConst askaryan_setup(int model, double energy, double theta, int shower_type,
-                                               double n_index, double R, double k_L_in)
-{
-    AskaryanConst a;
-    a.model = model;
-    a.had = (shower_type == 0);
-    const double eV = 1., MeV = 1e6, TeV = 1e12, cm = 0.01, MHz = 1e-3, GHz = 1., deg = 0.017453292519943295;
-    const double g = 6.241509744511525e+33;  // NuRadioReco/utilities/units.py gram
-    if (model == 0) {  // parametrizations.py:110-218
-        const double E_C = 73.1 * MeV;
-        const double rho = 0.924 * g / (cm * cm * cm);
-        const double X_0 = 36.08 * g / (cm * cm);
-        const double R_M = 10.57 * g / (cm * cm);
-        const double c = 0.299792458;
-        double k_E_bar, k_L, k_R_bar;
-        double lE = log10(energy / eV);
-        if (a.had) {
-            double k_E_0 = 4.13e-16 * 1. / cm / (MHz * MHz);
-            k_E_bar = k_E_0 * tanh((lE - 10.60) / 2.54);
-            k_L = 31.25 * pow(energy / (1.e15 * eV), 3.01e-2);
-            k_R_bar = 2.73 + tanh((12.92 - lE) / 1.72);
-            a.beta = 2.57;
-        } else {
-            k_E_bar = 4.65e-16 * 1. / cm / (MHz * MHz);
-            k_L = k_L_in;
-            k_R_bar = 1.54;
-            a.beta = 2.74;
-        }
-        a.a_pref = k_E_bar * energy / E_C * X_0 / rho * sin(theta);
-        double nu_L = rho / k_L / X_0;
-        double q = fabs(1 - n_index * cos(theta));
-        const double cher_cut = 1.e-8;
-        if (q < cher_cut) nu_L *= c / cher_cut;
-        else nu_L *= c / q;
-        a.nu_L = nu_L;
-        a.nu_R = rho / k_R_bar / R_M * c / sqrt(n_index * n_index - 1);
-        a.alpha = 1.27;
-        a.scale = R;
-        a.ln_nu_L = log(a.nu_L);
-        a.ln_nu_R = log(a.nu_R);
-    } else if (model == 1) {  // Alvarez2000, parametrizations.py:220-275
-        a.cher = acos(1. / n_index);
-        a.theta = theta;
-        const double Elpm = 2e15 * eV;
-        double eps = log10(energy / TeV);
-        double dth;  // angular width * f / (500 MHz)  [rad]
-        if (!a.had) {
-            dth = 2.7 * deg * 500 * MHz * pow(Elpm / (0.14 * energy + Elpm), 0.3);
-            a.scale = 1.;
-        } else {
-            double dd = 0;
-            if (eps >= 0 && eps <= 2) dd = 500 * MHz * (2.07 - 0.33 * eps + 7.5e-2 * eps * eps) * deg;
-            else if (eps > 2 && eps <= 5) dd = 500 * MHz * (1.74 - 1.21e-2 * eps) * deg;
-            else if (eps > 5 && eps <= 7) dd = 500 * MHz * (4.23 - 0.785 * eps + 5.5e-2 * eps * eps) * deg;
-            else if (eps > 7) dd = 500 * MHz * (4.23 - 0.785 * 7 + 5.5e-2 * 49) * (1 + (eps - 7) * 0.075) * deg;
-            dth = dd;
-            double f_eps = -1.27e-2 - 4.76e-2 * (eps + 3);
-            f_eps += -2.07e-3 * (eps + 3) * (eps + 3) + 0.52 * sqrt(eps + 3);
-            a.scale = (dd != 0) ? f_eps : 0.;
-        }
-        a.dth = dth;
-        a.f0 = 1.15 * GHz;
-        a.a_pref = 2.53e-7 * energy / TeV / MHz * (sin(theta) / sin(a.cher)) / R;
-    } else {  // ZHS1992, parametrizations.py:92-108
-        a.cher = acos(1. / n_index);
-        a.theta = theta;
-        a.a_pref = 1.1e-7 * energy / TeV / R / MHz;
-    }
-    return a;
-}
 
 // real amplitude X(f) such that the reference's spectrum bin is i * X * (-1)^k * sqrt(2) (ZHS1992: see phase)
 // lnf = ln f: (f / nu)^beta is evaluated as exp(beta (ln f - ln nu)), ln f coming from a per-station table
@@ -417,17 +412,17 @@ __device__ inline double askaryan_amplitude(double f, double lnf, const Askaryan
     }
 }
 
-// np.interp(f, xp, fp) on the coarse attenuation grid (analyticraytracing.py:1078)
+// np.interp(f, xp, fp) on the coarse attenuation grid (analyticraytracing.py:1078).  The grid is a linspace, so
+// the segment index is guessed arithmetically and then corrected to the exact xp[lo] <= f < xp[lo+1]
 __device__ inline double interp_att(double f, int n, const double* __restrict__ xp, const double* fp)
 {
     if (f <= xp[0]) return fp[0];
     if (f >= xp[n - 1]) return fp[n - 1];
-    int lo = 0, hi = n - 1;
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (f >= xp[mid]) lo = mid;
-        else hi = mid;
-    }
+    int lo = (int)((f - xp[0]) / (xp[n - 1] - xp[0]) * (n - 1));
+    if (lo > n - 2) lo = n - 2;
+    if (lo < 0) lo = 0;
+    while (lo > 0 && f < xp[lo]) lo--;
+    while (lo < n - 2 && f >= xp[lo + 1]) lo++;
     double slope = (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]);
     return slope * (f - xp[lo]) + fp[lo];
 }
@@ -548,22 +543,19 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
 // their rays skip the attenuation quadrature and the time-domain transform.  One block per ray.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-amp_bound_kernel(int n_rays, RayWork w, EventIn evin, StationDev st, int ask_model, double* __restrict__ bound,
-                 double* __restrict__ max_efield)
+amp_bound_kernel(int n_rays, RayWork w, StationDev st, double* __restrict__ bound, double* __restrict__ max_efield)
 {
-    __shared__ RayShared rs;
-    __shared__ double red[256];
-    for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
-        int e = w.ev[r];
-        if (threadIdx.x == 0)
-            rs.ask = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r], w.R[r],
-                                    evin.k_L[e]);
-        __syncthreads();
-        double part = fill_amplitude(nullptr, st.N, st.fs, rs, st.n_fc, st.fcoarse, st.lnf, false);
-        double sum = block_sum(part, red);
-        if (threadIdx.x == 0) {
+    const int lane = threadIdx.x & 63;
+    const int nh = st.N / 2;
+    const double df = 1.0 / (st.N * (1. / st.fs));
+    for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < n_rays; r += gridDim.x * (blockDim.x >> 6)) {
+        const AskaryanConst a = w.ask[r];
+        double part = 0.;
+        for (int k = 1 + lane; k < nh; k += 64) part += askaryan_amplitude(k * df, st.lnf[k], a);
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == 0) {
             double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
-            double b = efield_bound(sum, st.N, st.fs, cmax);
+            double b = efield_bound(part, st.N, st.fs, cmax);
             bound[r] = b;
             max_efield[r] = -b;  // "not evaluated, at most b" until efield_max_kernel overwrites it
         }
@@ -613,10 +605,7 @@ efield_max_kernel(int n_active, const int* __restrict__ active_list, RayWork w, 
     __shared__ double red[256];
     for (int ia = blockIdx.x; ia < n_active; ia += gridDim.x) {
         const int r = active_list[ia];
-        int e = w.ev[r];
-        if (threadIdx.x == 0)
-            rs.ask = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r], w.R[r],
-                                    evin.k_L[e]);
+        if (threadIdx.x == 0) rs.ask = w.ask[r];
         for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
         __syncthreads();
         double part = fill_amplitude(amp, N, st.fs, rs, st.n_fc, st.fcoarse, st.lnf, true);
@@ -842,9 +831,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
         for (int r = r0; r < r1; r++) {
             if (w.ch[r] != ch) continue;
             n_used++;
-            if (threadIdx.x == 0)
-                rs.ask = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r],
-                                        w.R[r], evin.k_L[e]);
+            if (threadIdx.x == 0) rs.ask = w.ask[r];
             for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
             __syncthreads();
             fill_amplitude(amp, N, st.fs, rs, st.n_fc, st.fcoarse, st.lnf, true);
@@ -933,8 +920,10 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                         // Hermitian folding of irfft: DC and Nyquist real and single, the rest doubled
                         if (k == 0 || k == m) v = make_double2(v.x, 0.);
                         else v = cscale(v, 2.);
-                        unsigned kn = ((unsigned)k * (unsigned)n0) % LL;
-                        v = cmul(v, cconj(E[2 * kn]));                             // exp(+2 pi i k n0 / L)
+                        if (n0 != 0) {
+                            unsigned kn = ((unsigned)k * (unsigned)n0) % LL;
+                            v = cmul(v, cconj(E[2 * kn]));                         // exp(+2 pi i k n0 / L)
+                        }
                         v = cmul(v, Ci[k]);                                        // chirp(k; L, +)
                     }
                     x[k] = v;
@@ -1037,11 +1026,12 @@ void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const in
     hipLaunchKernelGGL(scatter_slots_kernel, dim3(grid_for(n_slots, 256)), dim3(256), 0, s, n_slots, keep, offset, ray_slot);
 }
 void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex, const double* zen,
-                      const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w)
+                      const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w,
+                      const EventIn& evin, int ask_model)
 {
     if (n_rays <= 0) return;
     hipLaunchKernelGGL(ray_setup_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, n_ch, ray_slot, vertex, zen,
-                       az, rec, m, st, w);
+                       az, rec, m, st, w, evin, ask_model);
 }
 void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
                                   const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint)
@@ -1052,12 +1042,12 @@ void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
-void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const EventIn& evin, const StationDev& st,
-                      int ask_model, double* bound, double* max_efield)
+void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, double* bound, double* max_efield)
 {
     if (n_rays <= 0) return;
-    int grid = n_rays < 256 * 32 ? n_rays : 256 * 32;
-    hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, evin, st, ask_model, bound, max_efield);
+    int grid = (n_rays + 3) / 4;
+    if (grid > 256 * 64) grid = 256 * 64;
+    hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, bound, max_efield);
 }
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
                            double min_efield, int* ray_active)
