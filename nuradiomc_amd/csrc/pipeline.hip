@@ -276,6 +276,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     NEED(w.vel_T = WS("ray_vel_T", double, 4 * nr));
     NEED(w.theta_ant = WS("ray_theta_ant", double, nr));
     NEED(w.att = WS("ray_att", double, nr * sd.n_fc));
+    NEED(w.e_norm = WS("ray_e_norm", double, nr));
     double *zint, *max_efield;
     NEED(zint = WS("ray_zint", double, 3 * nr));
     NEED(max_efield = WS("ray_max_efield", double, nr));
@@ -393,6 +394,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         NEED(tab.H = WS("tab_H", double2, lens.size() * (size_t)NRHIP_SPEC_STRIDE));
         NEED(tab.Cf = WS("tab_Cf", double2, lens.size() * (size_t)NRHIP_SPEC_STRIDE));
         NEED(tab.Ci = WS("tab_Ci", double2, lens.size() * (size_t)FFT_MAX));
+        NEED(tab.hnorm = WS("tab_hnorm", double, lens.size() * 2));
         launch_length_tables(sm, (int)lens.size(), d_lens, sd, st->filters, ctx->twiddle, tab);
         LCHK("length_tables");
         MARK(6);

@@ -53,6 +53,7 @@ struct RayWork {
     double *vel_T;       // [n][4]
     double *theta_ant;
     double *att;         // [n][n_fc]
+    double *e_norm;      // [n] L2 norm of the unit-polarisation field trace, sqrt(sum_t s(t)^2) (set by efield_max_kernel)
 };
 
 struct EventIn {
@@ -75,6 +76,7 @@ struct LengthTables {
     double2* H;      // [n_len][NRHIP_SPEC_STRIDE]     filter chain response on the L grid
     double2* Cf;     // [n_len][NRHIP_SPEC_STRIDE]     forward chirp exp(-i pi k^2 / (L/2)), contiguous in k
     double2* Ci;     // [n_len][FFT_MAX]               inverse chirp exp(+i pi n^2 / L), contiguous in n
+    double* hnorm;   // [n_len][2]                     L2 norm of the (antenna x filter) impulse response on the L grid
 };
 
 struct ChannelOut {

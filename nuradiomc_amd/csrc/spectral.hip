@@ -610,6 +610,12 @@ efield_max_kernel(int n_active, const int* __restrict__ active_list, RayWork w, 
         __syncthreads();
         double part = fill_amplitude(amp, N, st.fs, rs, st.n_fc, st.fcoarse, st.lnf, true);
         double sum = block_sum(part, red);
+        {   // Parseval: sum_t s(t)^2 = (fs^2 / 2) (1 / N) 2 sum_k |G_k|^2 with |G_k| = sqrt(2) amp_k
+            double p2 = 0.;
+            for (int k = threadIdx.x; k <= nh; k += blockDim.x) p2 += amp[k] * amp[k];
+            double s2 = block_sum(p2, red);
+            if (threadIdx.x == 0) w.e_norm[r] = sqrt((st.fs * st.fs / N) * 2. * s2);
+        }
         const double2 rt = w.r_theta[r], rp = w.r_phi[r];
         const double pt = w.pol_theta[r], pp = w.pol_phi[r];
         double cmax = fmax(fabs(pt) * cabs2(rt), fabs(pp) * cabs2(rp));
@@ -772,6 +778,7 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
             }
             double vmax = red[0];
             double max_vel = model == 0 ? 0.18 : 0.055;
+            double h2 = 0.;
             for (int k = threadIdx.x; k <= m; k += blockDim.x) {
                 double f = k * df, v = mag[k];
                 if (k > 0) v *= max_vel / vmax;
@@ -780,9 +787,15 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
                 double sn, cs;
                 sincos(ph, &sn, &cs);
                 if (f < 0.005) v = 0.;
-                tab.vel[((long)il * 2 + model) * NRHIP_SPEC_STRIDE + k] = make_double2(v * cs, v * sn);
+                double2 vv = make_double2(v * cs, v * sn);
+                tab.vel[((long)il * 2 + model) * NRHIP_SPEC_STRIDE + k] = vv;
+                // |antenna x filter|^2 for the impulse-response norm (irfft keeps only the real part of DC / Nyquist)
+                double2 hk = cmul(vv, apply_filters(make_double2(1., 0.), f, fl));
+                h2 += (k == 0 || k == m) ? hk.x * hk.x : 2. * (hk.x * hk.x + hk.y * hk.y);
             }
             __syncthreads();
+            h2 = block_sum(h2, red);
+            if (threadIdx.x == 0) tab.hnorm[(long)il * 2 + model] = sqrt(h2 / L);
         }
     }
 }
@@ -823,10 +836,30 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
         const double2* Cf = tab.Cf + (long)il * NRHIP_SPEC_STRIDE;
         const double2* Ci = tab.Ci + (long)il * FFT_MAX;
         const unsigned LL = (unsigned)L;
+        int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
+        if (!exact) {
+            // Cauchy-Schwarz: the channel trace is sum_r vfac_r (e_r (*) h_L), so |V(t)| <= ||h_L||_2 sum_r |vfac_r| ||e_r||_2.
+            // If even that cannot reach the threshold nothing of this item needs to be transformed.
+            double cs = 0.;
+            for (int r = r0; r < r1; r++) {
+                if (w.ch[r] != ch) continue;
+                const double* T = w.vel_T + 4 * (long)r;
+                const int am = st.ant_model[ch];
+                const double th_a = w.theta_ant[r];
+                const double dir = (am == 0) ? sin(th_a) : sin(th_a) * sin(th_a);
+                const double Tt = (am == 0) ? T[0] : T[1], Tp = (am == 0) ? T[2] : T[3];
+                cs += w.e_norm[r] * (fabs(Tt * dir * w.pol_theta[r]) * cabs2(w.r_theta[r]) +
+                                     fabs(Tp * dir * w.pol_phi[r]) * cabs2(w.r_phi[r]));
+            }
+            double bnd = cs * tab.hnorm[(long)il * 2 + st.ant_model[ch]];
+            if (!(bnd * (1 + 1e-9) >= threshold)) {
+                if (threadIdx.x == 0) out.maxV[item] = -bnd;
+                continue;
+            }
+        }
         for (int k = threadIdx.x; k <= m; k += blockDim.x) acc[k] = make_double2(0., 0.);
         if (threadIdx.x == 0) s_trig = 0;
         __syncthreads();
-        int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
         int n_used = 0;
         for (int r = r0; r < r1; r++) {
             if (w.ch[r] != ch) continue;
