@@ -133,17 +133,23 @@ def main():
         sm = stats['stage_ms']
         dom = max((k for k in sm if k != 'total'), key=lambda k: sm[k])
         kernel_of = {'raytrace': 'raytrace_kernel', 'ray_setup': 'select/scan/ray_setup kernels',
-                     'attenuation': 'attenuation_kernel', 'efield_max': 'efield_max_kernel',
-                     'event_grid': 'event_grid_kernel + host hand-off', 'length_tables': 'length_tables_kernel',
-                     'channel': 'channel_kernel'}
-        units = {'raytrace': B_PAIR * stats['n_pairs'],
-                 'attenuation': 8 * 25 * stats['n_rays'] + 32 * stats['n_rays'],
-                 'efield_max': (2 * 2049 * 16 + 2 * 2049 * 16 + 2 * 4096 * 8) * stats['n_rays'],
-                 'channel': (B_RAY - (2 * 2049 * 16 + 2 * 2049 * 16 + 2 * 4096 * 8)) * stats['n_candidate_rays']
-                            + B_CHANNEL * stats['n_channel_items']}
-        alg_bytes = units.get(dom, 0)
+                     'amp_bound': 'amp_bound_kernel', 'attenuation': 'attenuation_group_kernel<32>',
+                     'efield_max': 'efield_max_kernel', 'event_grid': 'event_grid_kernel + host hand-off',
+                     'length_tables': 'length_tables_kernel', 'channel': 'channel_kernel'}
+        # algorithmic HBM bytes per launch
+        b_field = 2 * 2049 * 16 + 2 * 2049 * 16 + 2 * 4096 * 8     # write spec_N, c2r N in/out per ray
+        alg = {'raytrace': B_PAIR * stats['n_pairs'],
+               'amp_bound': 136 * stats['n_rays'] + 8 * stats['n_rays'],
+               'attenuation': (32 + 8 * 25) * stats['n_active_rays'],
+               'efield_max': b_field * stats['n_active_rays'],
+               'channel': (B_RAY - b_field) * stats['n_candidate_rays'] + B_CHANNEL * stats['n_channel_items']}
+        alg_bytes = alg.get(dom, 0)
         achieved = alg_bytes / (sm[dom] * 1e-3) / 1e9 if sm[dom] > 0 else 0.
         b_event = B_RAY * stats['n_rays'] + B_CHANNEL * stats['n_channel_items'] + B_PAIR * stats['n_pairs']
+        # FP64 view of the attenuation quadrature: one integrand evaluation = frequency-independent node part (shared
+        # by the 25 lanes of a ray, ~110 flop incl. exp, 2 sqrt, 2 div) / 25 + per-lane exp + div (~45 flop)
+        flop_per_eval = 110. / 25. + 45.
+        fp64 = stats['n_integrand_evals'] * flop_per_eval / (sm['attenuation'] * 1e-3) / 1e12 if sm['attenuation'] > 0 else 0.
         out = {
             "metric": "simulated events/sec (1e6-evt 1 EeV SP survey)", "value": value, "unit": "events/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -152,15 +158,20 @@ def main():
                                    "station at -100..-104 m, southpole_2015 ice, SP1, Alvarez2009, 4096 samples @ 2 GHz, "
                                    "Butterworth 80-500 MHz, 3 Vrms threshold" % n,
                        "events_per_gpu": n, "n_pairs": stats['n_pairs'], "n_rays": stats['n_rays'],
-                       "n_candidate_events": stats['n_candidate_events'], "n_triggered_rank0": stats['n_triggered'],
-                       "n_triggered_all": n_trig_total, "n_distinct_trace_lengths": stats['n_distinct_lengths'],
+                       "n_active_rays": stats['n_active_rays'], "n_candidate_events": stats['n_candidate_events'],
+                       "n_triggered_rank0": stats['n_triggered'], "n_triggered_all": n_trig_total,
+                       "n_distinct_trace_lengths": stats['n_distinct_lengths'],
                        "triggered_events_per_s": n_trig_total / (elapsed / max(args.steps, 1)),
                        "stage_ms_last_step": {k: round(v, 3) for k, v in sm.items()}},
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": sm[dom],
                          "whole_step_equivalent_GBs": b_event / (sm['total'] * 1e-3) / 1e9 if sm['total'] > 0 else 0.,
-                         "note": "kernels are FP64-VALU/LDS bound; bytes are SURVEY 8(d)'s un-fused algorithmic traffic"},
+                         "whole_step_equivalent_frac": b_event / (sm['total'] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm['total'] > 0 else 0.,
+                         "attenuation_integrand_evals": stats['n_integrand_evals'],
+                         "attenuation_fp64_tflops_est": fp64, "fp64_vector_peak_tflops": 78.6,
+                         "note": "every kernel of the path is FP64-VALU/LDS bound: the fused kernels move ~1e-3 of the "
+                                 "un-fused algorithmic bytes of SURVEY 8(d) that 'achieved' is priced on"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 10)

@@ -145,14 +145,15 @@ typedef struct {
                                      default rays of events that provably cannot pass the candidate cut are skipped */
 } nrhip_sim_config;
 
-#define NRHIP_N_STAGES 8
+#define NRHIP_N_STAGES 9
 /* stage_ms: device time (HIP events on the context's stream) of 0 ray tracing, 1 ray selection + setup,
- * 2 attenuation, 3 candidate cut (efield maximum), 4 event grid (+ host hand-off), 5 per-length tables,
- * 6 channel voltages + trigger, 7 whole call.                                                            */
+ * 2 un-attenuated amplitude bound + active-ray list, 3 attenuation, 4 candidate cut (efield maximum),
+ * 5 event grid (+ host hand-off), 6 per-length tables, 7 channel voltages + trigger, 8 whole call.       */
 typedef struct {
     int64_t n_events, n_pairs, n_rays, n_candidate_events, n_triggered, n_channel_items, n_distinct_lengths;
     int64_t n_candidate_rays;
     int64_t n_active_rays;        /* rays that went through the attenuation quadrature */
+    int64_t n_integrand_evals;    /* attenuation integrand evaluations (QUADPACK's neval summed over all items) */
     int32_t max_length;
     int32_t reserved;
     double stage_ms[NRHIP_N_STAGES];

@@ -11,7 +11,7 @@ void launch_ray_limits(hipStream_t stream, long n_rays, const double* x1, const 
                        const IceConst& m, double* zint);
 void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
                               const double* freqs, int model, const IceConst& m, double* att, int* neval,
-                              const int* ray_index);
+                              const int* ray_index, unsigned long long* eval_counter);
 void launch_attenuation_length(hipStream_t stream, long n, const double* z, const double* f, int model, double* L);
 }  // namespace nrhip
 
@@ -184,7 +184,7 @@ int nrhip_attenuation_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, co
     nrhip::launch_ray_limits(ctx->stream, n_rays, dx1.as<double>(), dx2.as<double>(), dC0.as<double>(), ctx->ice,
                              dz.as<double>());
     nrhip::launch_attenuation_items(ctx->stream, n_rays, dC0.as<double>(), dz.as<double>(), n_freq, df.as<double>(),
-                                    ctx->att_model, ctx->ice, da.as<double>(), dn.as<int>(), nullptr);
+                                    ctx->att_model, ctx->ice, da.as<double>(), dn.as<int>(), nullptr, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(att, da.p, n_rays * n_freq * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (neval) HIPCHK(hipMemcpyAsync(neval, dn.p, n_rays * n_freq * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -771,10 +771,12 @@ template <int G>
 __global__ void __launch_bounds__(256, 2)
 attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const double* __restrict__ zint, int n_freq,
                          const double* __restrict__ freqs, int model, IceConst m, double* __restrict__ att,
-                         int* __restrict__ neval, const int* __restrict__ ray_index)
+                         int* __restrict__ neval, const int* __restrict__ ray_index,
+                         unsigned long long* __restrict__ eval_counter)
 {
     GroupEval<G> ev;
     ev.init();
+    unsigned long long my_evals = 0;
     const long groups_per_block = blockDim.x / G;
     const long n_iter = (n_rays + (long)gridDim.x * groups_per_block - 1) / ((long)gridDim.x * groups_per_block);
     for (long iter = 0; iter < n_iter; iter++) {  // uniform trip count: every lane takes part in the shuffles
@@ -798,7 +800,12 @@ attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const doubl
             const long item = ray * n_freq + jf;
             att[item] = valid ? det_exp(-1 * integral) : NAN;
             if (neval) neval[item] = ne;
+            my_evals += (unsigned long long)ne;
         }
+    }
+    if (eval_counter) {  // integrand evaluations QUADPACK would count (for the FP64 rate reported by bench.py)
+        for (int off = 32; off > 0; off >>= 1) my_evals += __shfl_xor(my_evals, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(eval_counter, my_evals);
     }
 }
 
@@ -871,7 +878,7 @@ void launch_ray_limits(hipStream_t stream, long n_rays, const double* x1, const 
 
 void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
                               const double* freqs, int model, const IceConst& m, double* att, int* neval,
-                              const int* ray_index)
+                              const int* ray_index, unsigned long long* eval_counter)
 {
     long n_items = n_rays * n_freq;
     if (n_items <= 0) return;
@@ -882,10 +889,10 @@ void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0,
         if (grid > 256L * 64) grid = 256L * 64;
         if (G == 32)
             hipLaunchKernelGGL(attenuation_group_kernel<32>, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, zint,
-                               n_freq, freqs, model, m, att, neval, ray_index);
+                               n_freq, freqs, model, m, att, neval, ray_index, eval_counter);
         else
             hipLaunchKernelGGL(attenuation_group_kernel<64>, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, zint,
-                               n_freq, freqs, model, m, att, neval, ray_index);
+                               n_freq, freqs, model, m, att, neval, ray_index, eval_counter);
         return;
     }
     long grid = (n_items + block - 1) / block;

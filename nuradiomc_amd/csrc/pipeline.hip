@@ -314,22 +314,26 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         HIPCHK(hipStreamSynchronize(sm));
     }
     S.n_active_rays = n_active;
+    unsigned long long* eval_counter = nullptr;
+    MARK(3);
     if (n_active > 0) {
         // attenuation on the coarse frequency grid, active rays only
         launch_ray_limits_from_slots(sm, n_rays, n_ch, ray_slot, vertex, sd.pos, rec, ctx->ice, zint);
         LCHK("ray_limits");
+        NEED(eval_counter = WS("att_eval_counter", unsigned long long, 1));
+        HIPCHK(hipMemsetAsync(eval_counter, 0, sizeof(unsigned long long), sm));
         launch_attenuation_items(sm, n_active, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr,
-                                 active_list);
+                                 active_list, eval_counter);
         LCHK("attenuation");
     }
-    MARK(3);
+    MARK(4);
     if (n_active > 0) {
         // 4. candidate cut on max |E(t)|
         launch_efield_max(sm, n_active, active_list, w, evin, sd, cfg->askaryan_model, ctx->twiddle,
                           cfg->min_efield_amplitude, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, max_efield);
         LCHK("efield_max");
     }
-    MARK(4);
+    MARK(5);
     // 5. common time grid per event
     launch_event_grid(sm, (int)n_events, n_ch, offset, w, sd, max_efield, cfg->min_efield_amplitude, ev);
     LCHK("event_grid");
@@ -339,9 +343,9 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     HIPCHK(hipMemcpyAsync(hc.data(), ev.candidate, n_events, hipMemcpyDeviceToHost, sm));
     HIPCHK(hipStreamSynchronize(sm));
 
-    MARK(5);
     MARK(6);
     MARK(7);
+    MARK(8);
     // host: candidate event list, distinct trace lengths
     std::vector<int> cand;
     cand.reserve(n_events / 8 + 16);
@@ -385,7 +389,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
             for (int e : cand) ncr += hn[e];
         }
         S.n_candidate_rays = ncr;
-        MARK(5);
+        MARK(6);
         LengthTables tab;
         NEED(tab.B_fwd = WS("tab_B_fwd", double2, lens.size() * (size_t)FFT_MAX));
         NEED(tab.B_inv = WS("tab_B_inv", double2, lens.size() * (size_t)FFT_MAX));
@@ -397,7 +401,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         NEED(tab.hnorm = WS("tab_hnorm", double, lens.size() * 2));
         launch_length_tables(sm, (int)lens.size(), d_lens, sd, st->filters, ctx->twiddle, tab);
         LCHK("length_tables");
-        MARK(6);
+        MARK(7);
         // 6. channel voltages + trigger
         const int n_items = (int)cand.size() * n_ch;
         S.n_channel_items = n_items;
@@ -422,10 +426,10 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
                        cfg->trigger_threshold, ctx->twiddle, tab, scratch, co,
                        (cfg->no_pruning || cfg->dump_traces) ? 1 : 0);
         LCHK("channel");
-        MARK(7);
+        MARK(8);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here
     }
-    MARK(8);
+    MARK(9);
     if (stats) {
         // count triggers on device-resident mask (cheap D2H of n bytes only when asked for stats)
         std::vector<unsigned char> ht(n_events);
@@ -434,12 +438,17 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         int64_t nt = 0;
         for (unsigned char t : ht) nt += t;
         S.n_triggered = nt;
-        for (int i = 0; i < 7; i++) {
+        if (eval_counter) {
+            unsigned long long ne = 0;
+            HIPCHK(hipMemcpy(&ne, eval_counter, sizeof ne, hipMemcpyDeviceToHost));
+            S.n_integrand_evals = (int64_t)ne;
+        }
+        for (int i = 0; i < 8; i++) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, st->evt[i], st->evt[i + 1]) == hipSuccess) S.stage_ms[i] = ms;
         }
         float tot = 0.f;
-        if (hipEventElapsedTime(&tot, st->evt[0], st->evt[8]) == hipSuccess) S.stage_ms[7] = tot;
+        if (hipEventElapsedTime(&tot, st->evt[0], st->evt[9]) == hipSuccess) S.stage_ms[8] = tot;
         *stats = S;
     } else {
         HIPCHK(hipStreamSynchronize(sm));
