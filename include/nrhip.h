@@ -128,6 +128,10 @@ typedef struct {
     double post_pulse_time;       /* efieldToVoltageConverter.begin(post_pulse_time = 400 ns)           */
     int32_t n_att_freq;           /* coarse attenuation grid (analyticraytracing.py:885-931)            */
     const double* att_freq;
+    const double* att_bound_inv_length; /* [n_att_freq] or NULL: 1 / (largest attenuation length between the surface and
+                                     att_bound_depth at that frequency) [1/m].  Only used to prune: exp(-0.95 D / L_max)
+                                     bounds the attenuation factor of a ray of path length D from above            */
+    double att_bound_depth;       /* [m] > 0: the bound is applied to rays that stay above -att_bound_depth          */
     int32_t n_filters;
     const int32_t* filter_nb;
     const int32_t* filter_na;

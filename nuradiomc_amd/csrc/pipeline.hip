@@ -119,12 +119,15 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
         const double df = 1.0 / (d->n_samples * (1. / d->sampling_rate));
         for (int k = 1; k <= nh; k++) lnf[k] = std::log(k * df);
     }
+    std::vector<double> invl(d->n_att_freq, 0.);
+    if (d->att_bound_inv_length)
+        for (int k = 0; k < d->n_att_freq; k++) invl[k] = d->att_bound_inv_length[k] > 0 ? d->att_bound_inv_length[k] : 0.;
     s->h_pos.assign(d->position, d->position + 3 * n);
     s->h_cable.assign(d->cable_delay, d->cable_delay + n);
     if (upload(ctx, s->d_pos, d->position, 3 * n) || upload(ctx, s->d_cable, d->cable_delay, n) ||
         upload(ctx, s->d_model, d->antenna_model, n) || upload(ctx, s->d_rot, rot.data(), 9 * n) ||
         upload(ctx, s->d_rot_inv, roti.data(), 9 * n) || upload(ctx, s->d_fc, d->att_freq, d->n_att_freq) ||
-        upload(ctx, s->d_lnf, lnf.data(), lnf.size())) {
+        upload(ctx, s->d_lnf, lnf.data(), lnf.size()) || upload(ctx, s->d_invl, invl.data(), invl.size())) {
         delete s;
         return -1;
     }
@@ -137,6 +140,7 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     v.pre_pulse = d->pre_pulse_time;
     v.post_pulse = d->post_pulse_time;
     v.readout_length = d->readout_length;
+    v.att_bound_depth = (d->att_bound_inv_length && d->att_bound_depth > 0) ? d->att_bound_depth : -1.;
     v.pos = s->d_pos.as<double>();
     v.cable = s->d_cable.as<double>();
     v.ant_model = s->d_model.as<int>();
@@ -144,6 +148,7 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     v.rot_inv = s->d_rot_inv.as<double>();
     v.fcoarse = s->d_fc.as<double>();
     v.lnf = s->d_lnf.as<double>();
+    v.inv_lmax = s->d_invl.as<double>();
     FilterSet& f = s->filters;
     memset(&f, 0, sizeof f);
     f.n = d->n_filters;
@@ -169,7 +174,7 @@ void nrhip_station_destroy(nrhip_station* s)
     for (auto& kv : s->ws) kv.second.release();
     for (auto& e : s->evt) if (e) (void)hipEventDestroy(e);
     s->d_pos.release(); s->d_cable.release(); s->d_model.release();
-    s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release(); s->d_lnf.release();
+    s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release(); s->d_lnf.release(); s->d_invl.release();
     delete s;
 }
 
@@ -300,7 +305,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         NEED(roff = WS("ray_active_offset", int, nr + 1));
         NEED(rtmp = WS("scan_tmp2", int, scan_tiles(n_rays + 1)));
         NEED(active_list = WS("ray_active_list", int, nr));
-        launch_amp_bound(sm, n_rays, w, sd, bound, max_efield);
+        launch_amp_bound(sm, n_rays, w, sd, vertex, bound, max_efield);
         LCHK("amp_bound");
         launch_event_possible(sm, (int)n_events, n_ch, offset, bound, cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude,
                               ractive);

@@ -15,7 +15,7 @@ namespace nrhip {
 // station description in HBM (small, read through the scalar / L1 caches)
 struct StationDev {
     int n_ch, N, n_fc;
-    double fs, pre_pulse, post_pulse, readout_length;
+    double fs, pre_pulse, post_pulse, readout_length, att_bound_depth;
     const double* pos;        // [n_ch][3]
     const double* cable;      // [n_ch]
     const int* ant_model;     // [n_ch]   0 analytic_VPol, 1 analytic_HPol
@@ -23,6 +23,7 @@ struct StationDev {
     const double* rot_inv;    // [n_ch][9]
     const double* fcoarse;    // [n_fc] attenuation frequency grid
     const double* lnf;        // [N/2 + 1] ln f_k of the N-sample grid (entry 0 unused)
+    const double* inv_lmax;   // [n_fc] 1 / max_z L_att(z, f) (0 = unknown): upper bound exp(-0.95 D / L_max) on attenuation
 };
 
 // analog filter chain: response_i(f) = polyval(b_i, j f) / polyval(a_i, j f), highest power first
@@ -96,7 +97,8 @@ void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, 
                       const EventIn& evin, int ask_model);
 void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
                                   const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint);
-void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, double* bound, double* max_efield);
+void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, const double* vertex, double* bound,
+                      double* max_efield);
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
                            double min_efield, int* ray_active);
 void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const int* offset, int* list);

@@ -543,22 +543,44 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
 // their rays skip the attenuation quadrature and the time-domain transform.  One block per ray.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-amp_bound_kernel(int n_rays, RayWork w, StationDev st, double* __restrict__ bound, double* __restrict__ max_efield)
+amp_bound_kernel(int n_rays, RayWork w, StationDev st, const double* __restrict__ vertex, double* __restrict__ bound,
+                 double* __restrict__ max_efield)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ double ub[4][NRHIP_MAX_NFC];  // per wave: upper bounds of the coarse attenuation factors
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nh = st.N / 2;
     const double df = 1.0 / (st.N * (1. / st.fs));
-    for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < n_rays; r += gridDim.x * (blockDim.x >> 6)) {
-        const AskaryanConst a = w.ask[r];
-        double part = 0.;
-        for (int k = 1 + lane; k < nh; k += 64) part += askaryan_amplitude(k * df, st.lnf[k], a);
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-        if (lane == 0) {
-            double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
-            double b = efield_bound(part, st.N, st.fs, cmax);
-            bound[r] = b;
-            max_efield[r] = -b;  // "not evaluated, at most b" until efield_max_kernel overwrites it
+    const int n_iter = (n_rays + gridDim.x * 4 - 1) / (gridDim.x * 4);
+    for (int it = 0; it < n_iter; it++) {
+        const int r = (it * gridDim.x + blockIdx.x) * 4 + wv;
+        const bool ok = r < n_rays;
+        // attenuation factor <= exp(-int ds / L) <= exp(-D / L_max(f)); 0.95 covers the reference's 1e-2 quadrature
+        // tolerance; linear interpolation of upper bounds bounds the interpolated attenuation
+        if (lane < st.n_fc) {
+            double u = 0.;
+            if (ok) {
+                double zlo = fmin(vertex[3 * (long)w.ev[r] + 2], st.pos[3 * w.ch[r] + 2]);  // deepest point of the path
+                u = (zlo >= -st.att_bound_depth) ? exp(-0.95 * w.R[r] * st.inv_lmax[lane]) : 1.;
+            }
+            ub[wv][lane] = u;
         }
+        __syncthreads();
+        if (ok) {
+            const AskaryanConst a = w.ask[r];
+            double part = 0.;
+            for (int k = 1 + lane; k < nh; k += 64) {
+                double f = k * df;
+                part += askaryan_amplitude(f, st.lnf[k], a) * interp_att(f, st.n_fc, st.fcoarse, ub[wv]);
+            }
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0) {
+                double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
+                double b = efield_bound(part, st.N, st.fs, cmax);
+                bound[r] = b;
+                max_efield[r] = -b;  // "not evaluated, at most b" until efield_max_kernel overwrites it
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1075,12 +1097,13 @@ void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
-void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, double* bound, double* max_efield)
+void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, const double* vertex, double* bound,
+                      double* max_efield)
 {
     if (n_rays <= 0) return;
     int grid = (n_rays + 3) / 4;
     if (grid > 256 * 64) grid = 256 * 64;
-    hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, bound, max_efield);
+    hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, vertex, bound, max_efield);
 }
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
                            double min_efield, int* ray_active)

@@ -14,7 +14,8 @@ class StationDesc(ctypes.Structure):
                 ('antenna_model', L.c_int32_p), ('orientation', L.c_double_p), ('n_samples', ctypes.c_int32),
                 ('sampling_rate', ctypes.c_double), ('readout_length', ctypes.c_double),
                 ('pre_pulse_time', ctypes.c_double), ('post_pulse_time', ctypes.c_double),
-                ('n_att_freq', ctypes.c_int32), ('att_freq', L.c_double_p), ('n_filters', ctypes.c_int32),
+                ('n_att_freq', ctypes.c_int32), ('att_freq', L.c_double_p), ('att_bound_inv_length', L.c_double_p),
+                ('att_bound_depth', ctypes.c_double), ('n_filters', ctypes.c_int32),
                 ('filter_nb', L.c_int32_p), ('filter_na', L.c_int32_p), ('filter_b', L.c_double_p),
                 ('filter_a', L.c_double_p)]
 
@@ -85,7 +86,8 @@ class Station:
 
     def __init__(self, ctx, position, antenna='analytic_VPol', orientation=(0., 0., np.pi / 2, np.pi / 2),
                  cable_delay=0., n_samples=4096, sampling_rate=2.0, detector_sampling_rate=None, n_freq=25,
-                 filters=DEFAULT_FILTERS, pre_pulse_time=200., post_pulse_time=400., readout_length=None):
+                 filters=DEFAULT_FILTERS, pre_pulse_time=200., post_pulse_time=400., readout_length=None,
+                 att_bound_depth=3000.):
         self.ctx = ctx
         self._lib = L.load()
         pos = L.f64(position).reshape(-1, 3)
@@ -110,11 +112,17 @@ class Station:
         for i, (b, a) in enumerate(self.filters):
             fb[i, :len(b)] = b
             fa[i, :len(a)] = a
-        self._keep = (pos, cab, model, ori, self.att_freq, nb, na, fb, fa)
+        # largest attenuation length between the surface and att_bound_depth per coarse frequency (1 m grid): lets the
+        # library bound a ray's attenuation factor by exp(-0.95 D / L_max) before paying for the path integral
+        self.att_bound_depth = float(att_bound_depth)
+        zz = np.linspace(-self.att_bound_depth, 0., int(self.att_bound_depth) + 1)
+        lmax = np.array([np.max(ctx.attenuation_length(zz, f)) for f in self.att_freq])
+        self.att_bound_inv_length = np.ascontiguousarray(1.0 / (lmax * (1 + 1e-3)))
+        self._keep = (pos, cab, model, ori, self.att_freq, nb, na, fb, fa, self.att_bound_inv_length)
         d = StationDesc(n, L.dptr(pos), L.dptr(cab), L.iptr(model), L.dptr(ori), self.n_samples, self.sampling_rate,
                         float(readout_length if readout_length is not None else self.n_samples / self.sampling_rate),
                         float(pre_pulse_time), float(post_pulse_time), len(self.att_freq), L.dptr(self.att_freq),
-                        len(self.filters), L.iptr(nb), L.iptr(na), L.dptr(fb), L.dptr(fa))
+                        L.dptr(self.att_bound_inv_length), self.att_bound_depth, len(self.filters), L.iptr(nb), L.iptr(na), L.dptr(fb), L.dptr(fa))
         h = ctypes.c_void_p()
         L.check(self._lib.nrhip_station_create(ctx._h, ctypes.byref(d), ctypes.byref(h)))
         self._h = h

@@ -187,3 +187,69 @@ def test_pruning_changes_no_result(gpu_ctx_factory, name, n_events):
     assert np.allclose(C['ray_max_efield'][exr], A['ray_max_efield'][exr], rtol=1e-12, atol=0)
     assert np.all(-C['ray_max_efield'][~exr] * (1 + 1e-6) >= A['ray_max_efield'][~exr])
     print(name, 'channels evaluated exactly: %d of %d' % (ex.sum(), len(ex)), 'rays: %d of %d' % (exr.sum(), len(exr)))
+
+
+def test_pruning_rigorous_on_survey_sample(gpu_ctx_factory):
+    """2e4 synthetic survey events (bench.py's generator, EM showers mixed in, 512-sample traces): the production
+    path (all bounds active) and the exhaustive path must give the same candidate flags, trace lengths and trigger mask,
+    and every bound must dominate the exactly evaluated quantity."""
+    import bench
+    ctx = gpu_ctx_factory(bench.ICE, 'SP1')
+    st = nuradiomc_amd.Station(ctx, bench.CHANNELS, n_samples=512, sampling_rate=2.0)
+    n = 20000
+    v, z, a = bench.make_events(n, 77)
+    rng = np.random.default_rng(5)
+    typ = np.where(rng.random(n) < 0.3, 'EM', 'HAD')
+    kL = 10 ** rng.normal(1.9, 0.05, n)
+    en = 10 ** rng.uniform(17, 18.5, n)
+    trig_a, sa = st.simulate_events(v, z, a, en, typ, kL, no_pruning=True)
+    A = {k: st.fetch(k) for k in ('ev_candidate', 'ev_L', 'item_event', 'item_maxV', 'ray_max_efield')}
+    trig_b, sb = st.simulate_events(v, z, a, en, typ, kL)
+    B = {k: st.fetch(k) for k in ('ev_candidate', 'ev_L', 'item_event', 'item_maxV', 'ray_max_efield', 'ray_bound')}
+    assert trig_a.sum() > 20 and sa['n_candidate_events'] > 300
+    assert np.array_equal(trig_a, trig_b)
+    assert np.array_equal(A['ev_candidate'], B['ev_candidate']) and np.array_equal(A['ev_L'], B['ev_L'])
+    assert np.array_equal(A['item_event'], B['item_event'])
+    assert sb['n_active_rays'] < 0.8 * sa['n_active_rays']
+    assert np.all(B['ray_bound'] * (1 + 1e-6) >= A['ray_max_efield'])
+    skipped = B['ray_max_efield'] < 0
+    assert np.all(-B['ray_max_efield'][skipped] * (1 + 1e-6) >= A['ray_max_efield'][skipped])
+    sk = B['item_maxV'] < 0
+    assert sk.mean() > 0.3
+    assert np.all(-B['item_maxV'][sk] * (1 + 1e-9) >= A['item_maxV'][sk])
+    assert np.array_equal(B['item_maxV'][~sk], A['item_maxV'][~sk])
+
+
+def test_simulate_events_edge_cases(gpu_ctx_factory):
+    import bench
+    ctx = gpu_ctx_factory(bench.ICE, 'SP1')
+    st = nuradiomc_amd.Station(ctx, bench.CHANNELS, n_samples=256, sampling_rate=2.0)
+    # empty event list
+    trig, stats = st.simulate_events(np.zeros((0, 3)), np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0, np.int32))
+    assert trig.shape == (0,) and stats['n_events'] == 0
+    # events without any ray solution (shadow zone) and events whose rays all fail the viewing-angle cut
+    v = np.array([[3900., 0., -5.], [3800., 100., -3.], [0., 50., -1500.]])
+    zen = np.array([0.3, 1.0, 0.0])  # third: shower along the vertical axis, far off the Cherenkov cone
+    trig, stats = st.simulate_events(v, zen, np.zeros(3), 1e18, 'HAD')
+    assert not trig.any() and stats['n_candidate_events'] == 0 and stats['n_channel_items'] == 0
+    assert np.array_equal(st.fetch('ev_L')[:2], [0, 0]) and np.all(np.isnan(st.fetch('ev_t_min')[:2]))
+    # one bright event right on the cone: candidate and triggered; zero-energy shower: rays but no signal
+    from oracle import spectral_oracle as so
+    v = np.array([[300., 100., -400.], [300., 100., -400.]])
+    ost = so.Station(bench.CHANNELS, n_samples=256, fs=2.0)
+    vr, ve = so.vrms_from_filters(2.0)
+    for zen_, az_ in [(2.2, 0.3), (1.0, 3.4)]:
+        trig, stats = st.simulate_events(v, zen_, az_, np.array([1e19, 1e15]), 'HAD')
+        ref = [so.simulate_event(v[i], zen_, az_, [1e19, 1e15][i], 'HAD', None, ost, bench.ICE, vr, ve)['triggered']
+               for i in range(2)]
+        assert list(trig) == ref
+    # a station whose traces would exceed the supported common-trace length fails loudly, not silently
+    far = nuradiomc_amd.Station(ctx, np.array([[0., 0., -100.], [0., 0., -2400.]]), n_samples=4096, sampling_rate=2.0)
+    with pytest.raises(nuradiomc_amd.NrhipError):
+        far.simulate_events(np.array([[200., 0., -1200.]]), 1.5, 0.2, 1e20, 'HAD', trigger_threshold=1e-9,
+                            min_efield_amplitude=1e-12)
+    # unsupported configurations raise like the reference does
+    with pytest.raises(NotImplementedError):
+        nuradiomc_amd.Station(ctx, bench.CHANNELS, antenna='createLPDA_100MHz_InfFirn')
+    with pytest.raises(NotImplementedError):
+        nuradiomc_amd.Context(bench.ICE, 'GL3')
