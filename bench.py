@@ -144,6 +144,14 @@ def main():
                'efield_max': b_field * stats['n_active_rays'],
                'channel': (B_RAY - b_field) * stats['n_candidate_rays'] + B_CHANNEL * stats['n_channel_items']}
         alg_bytes = alg.get(dom, 0)
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, see the file header);
+        # only meaningful for the workload they were measured on
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_rocprofv3_pmc_hbm_traffic.csv')
+        if n == 1000000 and os.path.exists(pmc):
+            for line in open(pmc):
+                if line.startswith('nrhip::') and line.split(',')[0].split('::')[1].split('<')[0] in kernel_of[dom]:
+                    traffic = float(line.strip().split(',')[3]) / 1e9
         achieved = alg_bytes / (sm[dom] * 1e-3) / 1e9 if sm[dom] > 0 else 0.
         b_event = B_RAY * stats['n_rays'] + B_CHANNEL * stats['n_channel_items'] + B_PAIR * stats['n_pairs']
         # FP64 view of the attenuation quadrature: one integrand evaluation = frequency-independent node part (shared
@@ -164,7 +172,8 @@ def main():
                        "triggered_events_per_s": n_trig_total / (elapsed / max(args.steps, 1)),
                        "stage_ms_last_step": {k: round(v, 3) for k, v in sm.items()}},
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/r01_rocprofv3_pmc_hbm_traffic.csv)",
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": sm[dom],
                          "whole_step_equivalent_GBs": b_event / (sm['total'] * 1e-3) / 1e9 if sm['total'] > 0 else 0.,
                          "whole_step_equivalent_frac": b_event / (sm['total'] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm['total'] > 0 else 0.,
