@@ -187,6 +187,17 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
  * Returns the number of bytes available (>= 0) or < 0; copies min(bytes, available).                     */
 int64_t nrhip_sim_fetch(nrhip_station* st, const char* name, void* host_dst, uint64_t bytes);
 
+/* efieldToVoltageConverter.run(evt, station, det) (NuRadioReco/modules/efieldToVoltageConverter.py:111-345) for ONE
+ * station event on arbitrary electric fields -- the module-level drop-in.  efield e: time-domain traces
+ * traces[e][0] = eTheta, traces[e][1] = ePhi (n_samples of the station each), trace start time t0[e] [ns], arrival
+ * direction, channel index (position in the station).  The caller passes the common time grid of the event (t_min, L),
+ * computed as the module does (:120-169).  V receives [n_channels][L] voltage traces (channels without efield: zeros).
+ * apply_filters != 0 additionally applies the station's filter chain (what a following channelBandPassFilter.run does).
+ * All pointers HOST.  n_samples <= 4096.                                                                          */
+int nrhip_efield_to_voltage(nrhip_ctx* ctx, nrhip_station* st, int32_t n_efields, const double* traces,
+                            const double* t0, const double* zenith, const double* azimuth, const int32_t* channel,
+                            int32_t apply_filters, int32_t L, double t_min, double* V);
+
 /* test hook for the in-LDS chirp-z transform: out[b][k] = sum_j in[b][j] exp(sgn 2 pi i j k / Q). HOST. */
 int nrhip_debug_czt(nrhip_ctx* ctx, int32_t n_batch, int32_t n_in, int32_t n_out, int32_t Q, double sgn,
                     const double* in, double* out);

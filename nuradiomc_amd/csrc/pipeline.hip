@@ -476,6 +476,59 @@ int64_t nrhip_sim_fetch(nrhip_station* st, const char* name, void* host_dst, uin
     return (int64_t)avail;
 }
 
+int nrhip_efield_to_voltage(nrhip_ctx* ctx, nrhip_station* st, int32_t n_efields, const double* traces, const double* t0,
+                            const double* zenith, const double* azimuth, const int32_t* channel, int32_t apply_filters,
+                            int32_t L, double t_min, double* V)
+{
+    if (!ctx || !st || !V) return nrhip_fail_msg("nrhip_efield_to_voltage: NULL argument");
+    if (st->ctx != ctx) return nrhip_fail_msg("nrhip_efield_to_voltage: station belongs to another context");
+    const StationDev& sd = st->dev;
+    if (n_efields <= 0) return nrhip_fail_msg("station has no efields");  // LookupError in the reference (:117-118)
+    if (sd.N > 4096) return nrhip_fail_msg("nrhip_efield_to_voltage: traces longer than 4096 samples are not supported");
+    const int nh = sd.N / 2;
+    if (L <= 0 || L % 2 != 0 || L / 2 > std::min(FFT_MAX - nh + 1, NRHIP_SPEC_STRIDE - 1))
+        return nrhip_fail_msg("nrhip_efield_to_voltage: common trace length unsupported (odd, or longer than the 8192-point chirp-z allows)");
+    for (int e = 0; e < n_efields; e++)
+        if (channel[e] < 0 || channel[e] >= sd.n_ch) return nrhip_fail_msg("nrhip_efield_to_voltage: bad channel index");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t sm = ctx->stream;
+    st->ws_bytes.clear();
+    double *d_tr, *d_t0, *d_zen, *d_az, *d_V;
+    int *d_ch, *d_len;
+    NEED(d_tr = WS("ev_traces", double, (size_t)n_efields * 2 * sd.N));
+    NEED(d_t0 = WS("ev_t0", double, n_efields));
+    NEED(d_zen = WS("ev_zen", double, n_efields));
+    NEED(d_az = WS("ev_az", double, n_efields));
+    NEED(d_ch = WS("ev_ch", int, n_efields));
+    NEED(d_V = WS("ev_V", double, (size_t)sd.n_ch * L));
+    NEED(d_len = WS("lengths", int, 1));
+    HIPCHK(hipMemcpyAsync(d_tr, traces, sizeof(double) * n_efields * 2 * sd.N, hipMemcpyHostToDevice, sm));
+    HIPCHK(hipMemcpyAsync(d_t0, t0, sizeof(double) * n_efields, hipMemcpyHostToDevice, sm));
+    HIPCHK(hipMemcpyAsync(d_zen, zenith, sizeof(double) * n_efields, hipMemcpyHostToDevice, sm));
+    HIPCHK(hipMemcpyAsync(d_az, azimuth, sizeof(double) * n_efields, hipMemcpyHostToDevice, sm));
+    HIPCHK(hipMemcpyAsync(d_ch, channel, sizeof(int) * n_efields, hipMemcpyHostToDevice, sm));
+    HIPCHK(hipMemcpyAsync(d_len, &L, sizeof(int), hipMemcpyHostToDevice, sm));
+    LengthTables tab;
+    NEED(tab.B_fwd = WS("tab_B_fwd", double2, (size_t)FFT_MAX));
+    NEED(tab.B_inv = WS("tab_B_inv", double2, (size_t)FFT_MAX));
+    NEED(tab.vel = WS("tab_vel", double2, 2 * (size_t)NRHIP_SPEC_STRIDE));
+    NEED(tab.E = WS("tab_E", double2, (size_t)NRHIP_E_STRIDE));
+    NEED(tab.H = WS("tab_H", double2, (size_t)NRHIP_SPEC_STRIDE));
+    NEED(tab.Cf = WS("tab_Cf", double2, (size_t)NRHIP_SPEC_STRIDE));
+    NEED(tab.Ci = WS("tab_Ci", double2, (size_t)FFT_MAX));
+    NEED(tab.hnorm = WS("tab_hnorm", double, 2));
+    launch_length_tables(sm, 1, d_len, sd, st->filters, ctx->twiddle, tab);
+    LCHK("length_tables");
+    double2* scratch;
+    NEED(scratch = WS("channel_scratch", double2, (size_t)std::max(sd.n_ch, channel_grid_blocks()) * NRHIP_SPEC_STRIDE));
+    launch_efield_channel(sm, n_efields, d_tr, d_t0, d_zen, d_az, d_ch, sd, L, t_min, apply_filters, ctx->twiddle, tab,
+                          scratch, d_V);
+    LCHK("efield_channel");
+    HIPCHK(hipMemcpyAsync(V, d_V, sizeof(double) * sd.n_ch * L, hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipStreamSynchronize(sm));
+    return 0;
+}
+
 int nrhip_askaryan_spectrum_batch(nrhip_ctx* ctx, int64_t n, const double* energy, const double* theta,
                                   const int32_t* shower_type, const double* n_index, const double* R, const double* k_L,
                                   int32_t model, int32_t N, double dt, double* spectrum)

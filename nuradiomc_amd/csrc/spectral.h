@@ -114,6 +114,9 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     double threshold, const double2* tw, const LengthTables& tab, double2* scratch, const ChannelOut& out,
                     int exact);
+void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
+                           const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,
+                           const double2* tw, const LengthTables& tab, double2* scratch, double* V);
 void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const double* theta, const int* type,
                               const double* n_index, const double* R, const double* k_L, int model, int N, double dt,
                               double2* spec);

@@ -58,6 +58,29 @@ __device__ inline void mat3vec(const double A[9], const double v[3], double o[3]
     for (int i = 0; i < 3; i++) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
 }
 
+// antenna frame: incoming direction in the antenna-model frame (theta_ant) and the 2x2 map T from the raw
+// (theta, phi) components of the model's VEL to the on-sky basis of the arrival direction
+// (antennapattern.py:1218-1307); orthonormal bases are inverted by transposition
+__device__ inline void antenna_frame(double zen, double az, const double* rot, const double* roti, double T[4],
+                                     double* theta_ant)
+{
+    double inc[3], incw[3], th_a, ph_a;
+    sph2cart(zen, az, inc);
+    mat3vec(rot, inc, incw);
+    cart2sph(incw, &th_a, &ph_a);
+    double Ma[9], Ms[9];
+    onsky_matrix(th_a, ph_a, Ma);
+    onsky_matrix(zen, az, Ms);
+    for (int c = 0; c < 2; c++) {  // raw component c+1 (theta, phi) = row c+1 of Ma as a cartesian vector
+        double v[3] = {Ma[3 * (c + 1)], Ma[3 * (c + 1) + 1], Ma[3 * (c + 1) + 2]}, g[3], o[3];
+        mat3vec(roti, v, g);
+        mat3vec(Ms, g, o);
+        T[0 + c] = o[1];
+        T[2 + c] = o[2];
+    }
+    *theta_ant = th_a;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // ray selection: viewing angle + delta_C cut  (simulation.py:187-206)
 // ---------------------------------------------------------------------------------------------------------
@@ -319,25 +342,8 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
     }
     w.r_theta[r] = rth;
     w.r_phi[r] = rph;
-    // antenna frame: incoming direction in the antenna-model frame and the 2x2 map raw (theta, phi) -> on-sky
-    // (antennapattern.py:1218-1307); orthonormal bases are inverted by transposition
-    const double* rot = st.rot + 9 * ch;
-    const double* roti = st.rot_inv + 9 * ch;
-    double inc[3], incw[3], th_a, ph_a;
-    sph2cart(zen, az, inc);
-    mat3vec(rot, inc, incw);
-    cart2sph(incw, &th_a, &ph_a);
-    double Ma[9], Ms[9];
-    onsky_matrix(th_a, ph_a, Ma);
-    onsky_matrix(zen, az, Ms);
-    double T[4];
-    for (int c = 0; c < 2; c++) {  // raw component c+1 (theta, phi) = row c+1 of Ma as a cartesian vector
-        double v[3] = {Ma[3 * (c + 1)], Ma[3 * (c + 1) + 1], Ma[3 * (c + 1) + 2]}, g[3], o[3];
-        mat3vec(roti, v, g);
-        mat3vec(Ms, g, o);
-        T[0 + c] = o[1];
-        T[2 + c] = o[2];
-    }
+    double T[4], th_a;
+    antenna_frame(zen, az, st.rot + 9 * ch, st.rot_inv + 9 * ch, T, &th_a);
     for (int c = 0; c < 4; c++) w.vel_T[4 * (long)r + c] = T[c];
     w.theta_ant[r] = th_a;
     w.slot[r] = slot;
@@ -1010,6 +1016,141 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// kernel: efieldToVoltageConverter.run (efieldToVoltageConverter.py:111-345) for ONE station event on arbitrary
+// electric-field traces (the module-level drop-in; the simulation path uses channel_kernel, which generates the
+// fields itself).  One block (512) per channel; every efield of the channel: sub-sample shift (FFT phase ramp on the
+// N grid, skipped within 1e-5 of a sample like BaseTrace.apply_time_shift), chirp-z onto the L grid, VEL, 5 MHz cut,
+// sum; optionally the station's filter chain; back to L samples.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+efield_channel_kernel(int n_efields, const double* __restrict__ traces, const double* __restrict__ t0,
+                      const double* __restrict__ zenith, const double* __restrict__ azimuth,
+                      const int* __restrict__ channel, StationDev st, int L, double t_min, int apply_filter,
+                      const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
+                      double* __restrict__ V)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int M = FFT_MAX, N = st.N, nh = N / 2, m = L / 2;
+    const int ch = blockIdx.x;
+    double2* x = (double2*)smem;
+    double2* acc = scratch + (long)blockIdx.x * NRHIP_SPEC_STRIDE;
+    const double2 *Bf = tab.B_fwd, *Bi = tab.B_inv, *E = tab.E, *Hf = tab.H, *Cf = tab.Cf, *Ci = tab.Ci;
+    const double2* vel = tab.vel + (long)st.ant_model[ch] * NRHIP_SPEC_STRIDE;
+    const unsigned LL = (unsigned)L;
+    const double res = 1. / st.fs;
+    __shared__ double sT[4], s_th;
+    for (int k = threadIdx.x; k <= m; k += blockDim.x) acc[k] = make_double2(0., 0.);
+    __syncthreads();
+    int n_used = 0;
+    for (int e = 0; e < n_efields; e++) {
+        if (channel[e] != ch) continue;
+        n_used++;
+        if (threadIdx.x == 0) antenna_frame(zenith[e], azimuth[e], st.rot + 9 * ch, st.rot_inv + 9 * ch, sT, &s_th);
+        __syncthreads();
+        double start_time = t0[e] - t_min + st.cable[ch] + 0;
+        long start_bin = (long)rint(start_time / res);
+        const unsigned sbin = (unsigned)(((start_bin % (long)L) + (long)L) % (long)L);
+        double rem = start_time - start_bin * res;
+        bool shift = !(fabs(rint(rem * st.fs) - rem * st.fs) < 1e-5);
+        const int am = st.ant_model[ch];
+        const double dir = (am == 0) ? sin(s_th) : sin(s_th) * sin(s_th);
+        const double Tt = (am == 0) ? sT[0] : sT[1], Tp = (am == 0) ? sT[2] : sT[3];
+        for (int comp = 0; comp < 2; comp++) {
+            const double vfac = (comp ? Tp : Tt) * dir;
+            if (vfac == 0.) continue;
+            const double* tr = traces + ((long)e * 2 + comp) * N;
+            // y_j = e[2j] + i e[2j+1]
+            for (int j = threadIdx.x; j < nh; j += blockDim.x) x[j] = make_double2(tr[2 * j], tr[2 * j + 1]);
+            __syncthreads();
+            if (shift) {
+                // rfft -> * exp(-2 pi i f rem) -> irfft on the N grid (base_trace.py:273-276)
+                fft_dif(x, log2nh, tw, false);  // Y in bit-reversed order
+                double2* G = x + M / 2;          // G'(k), k = 0..nh, in the upper half of the buffer
+                for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
+                    int ka = (k == nh) ? 0 : k, kb = (k == 0 || k == nh) ? 0 : nh - k;
+                    double2 Y1 = x[bitrev(ka, log2nh)], Y2 = cconj(x[bitrev(kb, log2nh)]);
+                    double2 ge = cscale(cadd(Y1, Y2), 0.5);
+                    double2 d = cscale(csub(Y1, Y2), 0.5);
+                    double2 go = make_double2(d.y, -d.x);  // d / i
+                    double2 wk = (k == nh) ? make_double2(-1., 0.) : tw[k * (FFT_MAX / N)];  // exp(-2 pi i k / N)
+                    double2 g = cadd(ge, cmul(go, wk));
+                    double f = k * (1.0 / (N * res));
+                    double sn, cs;
+                    sincos(-2. * M_PI * rem * f, &sn, &cs);
+                    g = cmul(g, make_double2(cs, sn));
+                    if (k == 0 || k == nh) g.y = 0.;  // irfft uses the real part of DC and Nyquist only
+                    G[k] = g;
+                }
+                __syncthreads();
+                for (int k = threadIdx.x; k < nh; k += blockDim.x) {
+                    double2 Gk = G[k], Gc = cconj(G[nh - k]);
+                    double2 ge = cscale(cadd(Gk, Gc), 0.5);
+                    double2 d = cscale(csub(Gk, Gc), 0.5);
+                    double2 go = cmul(d, cconj(tw[k * (FFT_MAX / N)]));
+                    x[k] = make_double2(ge.x - go.y, ge.y + go.x);
+                }
+                __syncthreads();
+                fft_dif(x, log2nh, tw, true);
+            }
+            // a_j = y_j chirp_j * sqrt(2) / fs (time2freq), zero padded
+            const double sc = (shift ? 1.0 / nh : 1.0) * (1.4142135623730951 / st.fs);
+            double2 yreg[8];
+            int cnt = 0;
+            for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = shift ? x[bitrev(j, log2nh)] : x[j];
+            __syncthreads();
+            cnt = 0;
+            for (int j = threadIdx.x; j < M; j += blockDim.x) {
+                double2 v = make_double2(0., 0.);
+                if (j < nh) v = cmul(cscale(yreg[cnt++], sc), Cf[j]);
+                x[j] = v;
+            }
+            __syncthreads();
+            czt_convolve_t<512>(x, Bf, tw);
+            for (int k = threadIdx.x; k <= m; k += blockDim.x) {
+                int k1 = (k == m) ? 0 : k, k2 = (k == 0 || k == m) ? 0 : m - k;
+                double2 Z1 = cscale(cmul(x[k1], Cf[k1]), 1.0 / M);
+                double2 Z2 = cconj(cscale(cmul(x[k2], Cf[k2]), 1.0 / M));
+                double2 Ee = cscale(cadd(Z1, Z2), 0.5);
+                double2 d = cscale(csub(Z1, Z2), 0.5);
+                double2 Eo = make_double2(d.y, -d.x);
+                double2 X = cadd(Ee, cmul(Eo, E[2 * k]));
+                unsigned ks = ((unsigned)k * sbin) % LL;
+                X = cmul(X, E[2 * ks]);
+                acc[k] = cadd(acc[k], cmul(cscale(vel[k], vfac), X));
+            }
+            __syncthreads();
+        }
+    }
+    // back to the time domain (freq2time: irfft * fs / sqrt 2)
+    const int P = M - m;
+    const double scale = st.fs / 1.4142135623730951 / L;
+    for (int n0 = 0; n0 < L; n0 += P) {
+        for (int k = threadIdx.x; k < M; k += blockDim.x) {
+            double2 v = make_double2(0., 0.);
+            if (k <= m && n_used > 0) {
+                v = apply_filter ? cmul(acc[k], Hf[k]) : acc[k];
+                if (k == 0 || k == m) v = make_double2(v.x, 0.);
+                else v = cscale(v, 2.);
+                if (n0 != 0) {
+                    unsigned kn = ((unsigned)k * (unsigned)n0) % LL;
+                    v = cmul(v, cconj(E[2 * kn]));
+                }
+                v = cmul(v, Ci[k]);
+            }
+            x[k] = v;
+        }
+        __syncthreads();
+        czt_convolve_t<512>(x, Bi, tw);
+        int np = min(P, L - n0);
+        for (int n = threadIdx.x; n < np; n += blockDim.x) {
+            double2 u = cmul(x[n], Ci[n]);
+            V[(long)ch * L + n0 + n] = u.x * (1.0 / M) * scale;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // stand-alone Askaryan spectrum (askaryan.get_frequency_spectrum) for the drop-in Python API
 // ---------------------------------------------------------------------------------------------------------
 __global__ void askaryan_spectrum_kernel(int n, const double* __restrict__ energy, const double* __restrict__ theta,
@@ -1144,6 +1285,7 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               FFT_MAX * 16 + (FFT_MAX / 2 + 1) * 8);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)efield_channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipGetLastError();
     g_attr_set = true;
 }
@@ -1168,6 +1310,15 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     int grid = n_items < channel_grid_blocks() ? n_items : channel_grid_blocks();
     hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
                        ask_model, threshold, tw, tab, scratch, ilog2(nh), out, exact);
+}
+void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
+                           const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,
+                           const double2* tw, const LengthTables& tab, double2* scratch, double* V)
+{
+    set_big_lds();
+    int nh = st.N / 2;
+    hipLaunchKernelGGL(efield_channel_kernel, dim3(st.n_ch), dim3(512), (size_t)FFT_MAX * 16, s, n_efields, traces, t0, zen, az,
+                       channel, st, L, t_min, apply_filter, tw, tab, scratch, ilog2(nh), V);
 }
 void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const double* theta, const int* type,
                               const double* n_index, const double* R, const double* k_L, int model, int N, double dt,

@@ -50,6 +50,9 @@ L._OPTIONAL.update({
     'nrhip_askaryan_spectrum_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, L.c_double_p, L.c_double_p,
                                                      L.c_int32_p, L.c_double_p, L.c_double_p, L.c_double_p, ctypes.c_int32,
                                                      ctypes.c_int32, ctypes.c_double, L.c_double_p]),
+    'nrhip_efield_to_voltage': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, L.c_double_p, L.c_double_p,
+                                               L.c_double_p, L.c_double_p, L.c_int32_p, ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_double, L.c_double_p]),
     'nrhip_debug_czt': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_double, L.c_double_p, L.c_double_p]),
 })
@@ -101,6 +104,8 @@ class Station:
         cab = np.ascontiguousarray(np.broadcast_to(L.f64(cable_delay), (n,)))
         self.position, self.antenna, self.orientation, self.cable_delay = pos, names, ori, cab
         self.n_samples, self.sampling_rate = int(n_samples), float(sampling_rate)
+        self.pre_pulse_time, self.post_pulse_time = float(pre_pulse_time), float(post_pulse_time)
+        self.readout_length = float(readout_length if readout_length is not None else self.n_samples / self.sampling_rate)
         det_fs = float(detector_sampling_rate or sampling_rate)
         ff = np.fft.rfftfreq(self.n_samples, 1. / self.sampling_rate)
         self.att_freq = np.ascontiguousarray(attenuation_frequencies(ff, n_freq, 0.5 * det_fs))
@@ -176,6 +181,40 @@ class Station:
             for p in dptrs + [dtrig]:
                 ctx.free(p)
         return trig.astype(bool), stats
+
+    def common_time_grid(self, t0, channel):
+        """t_min and L of efieldToVoltageConverter.run (efieldToVoltageConverter.py:120-169)"""
+        t0 = np.asarray(t0, float) + self.cable_delay[np.asarray(channel, int)]
+        times_min = np.min(t0)
+        times_max = np.max(t0 + self.n_samples / self.sampling_rate)
+        max_len = self.readout_length
+        times_min -= self.pre_pulse_time
+        times_max += self.post_pulse_time
+        while times_max - times_min < max_len:
+            times_max += self.post_pulse_time
+        res = 1. / self.sampling_rate
+        n = int(round((times_max - times_min) / res))
+        if n % 2 != 0:
+            n += 1
+        return times_min, n
+
+    def efield_to_voltage(self, traces, t0, zenith, azimuth, channel, apply_filters=False):
+        """Channel voltages of ONE station event from arbitrary efield traces [n, 2 (eTheta, ePhi), n_samples];
+        returns (V [n_channels, L], t_min)."""
+        traces = L.f64(traces)
+        n = traces.shape[0]
+        if n == 0:
+            raise LookupError("station has no efields")
+        if traces.shape[1:] != (2, self.n_samples):
+            raise ValueError("traces must be [n, 2, %d]" % self.n_samples)
+        t0, zenith, azimuth = (np.ascontiguousarray(np.broadcast_to(L.f64(a), (n,))) for a in (t0, zenith, azimuth))
+        ch = np.ascontiguousarray(np.broadcast_to(channel, (n,)), dtype=np.int32)
+        t_min, Lc = self.common_time_grid(t0, ch)
+        V = np.zeros((len(self.position), Lc))
+        L.check(self._lib.nrhip_efield_to_voltage(self.ctx._h, self._h, n, L.dptr(traces), L.dptr(t0), L.dptr(zenith),
+                                                  L.dptr(azimuth), L.iptr(ch), int(bool(apply_filters)), Lc, float(t_min),
+                                                  L.dptr(V)))
+        return V, t_min
 
     _FETCH_DTYPES = {'ray_event': np.int32, 'ray_channel': np.int32, 'ray_solution': np.int32, 'ev_n_rays': np.int32,
                      'ev_L': np.int32, 'ev_candidate': np.uint8, 'item_event': np.int32, 'trace_offset': np.int64,

@@ -118,3 +118,89 @@ def test_apply_propagation_effects_like_reference():
     rp, rs = so.fresnel_r_p(g['refl_angle'][i, s], 1., n1), so.fresnel_r_s(g['refl_angle'][i, s], 1., n1)
     assert np.max(np.abs(ef.spec[0] - att)) < 1e-6
     assert np.max(np.abs(ef.spec[1] - att * rp)) < 1e-6 and np.max(np.abs(ef.spec[2] - att * rs)) < 1e-6
+
+
+class _FakeEfield:
+    def __init__(self, ch_pos, trace, t0, fs, zen, az):
+        self._p, self._tr, self._t0, self._fs, self._par = ch_pos, trace, t0, fs, {'zenith': zen, 'azimuth': az}
+    def get_position(self): return self._p
+    def get_trace(self): return self._tr
+    def get_trace_start_time(self): return self._t0
+    def get_sampling_rate(self): return self._fs
+    def get_number_of_samples(self): return self._tr.shape[-1]
+    def __getitem__(self, k): return self._par[getattr(k, 'name', k)]
+
+
+class _FakeChannel:
+    def __init__(self, cid): self.cid = cid
+    def set_trace(self, tr, fs): self.trace, self.fs = np.array(tr), fs
+    def set_trace_start_time(self, t): self.t0 = t
+    def get_id(self): return self.cid
+
+
+class _FakeSimStation:
+    def __init__(self, efields): self._ef = efields
+    def get_id(self): return 101
+    def get_electric_fields(self): return [e for v in self._ef.values() for e in v]
+    def get_electric_fields_for_channels(self, ids): return [e for c in ids for e in self._ef.get(c, [])]
+
+
+class _FakeStation:
+    def __init__(self, sim): self._sim, self.channels = sim, {}
+    def get_id(self): return 101
+    def get_sim_station(self): return self._sim
+    def add_channel(self, ch): self.channels[ch.get_id()] = ch
+
+
+class _FakeDet:
+    def __init__(self, pos, antenna, cable, n, fs):
+        self.pos, self.antenna, self.cable, self.n, self.fs = pos, antenna, cable, n, fs
+    def get_channel_ids(self, sid): return list(range(len(self.pos)))
+    def get_relative_position(self, sid, c): return self.pos[c]
+    def get_cable_delay(self, sid, c): return self.cable[c]
+    def get_antenna_model(self, sid, c, zen=None): return self.antenna
+    def get_antenna_orientation(self, sid, c): return [0., 0., np.pi / 2, np.pi / 2]
+    def get_number_of_samples(self, sid, c): return self.n
+    def get_sampling_frequency(self, sid, c): return self.fs
+
+
+@pytest.mark.parametrize('antenna,cable', [('analytic_VPol', [0.] * 5), ('analytic_HPol', [0., 3.3, 7.77, 12.2, 19.8])])
+def test_efieldToVoltageConverter_module(antenna, cable):
+    """The module-level drop-in on arbitrary ElectricField-like objects vs the oracle's restatement of
+    efieldToVoltageConverter.run (no filter), incl. the sub-sample Fourier shift (unequal cable delays)."""
+    from nuradiomc_amd import modules
+    from oracle import spectral_oracle as so
+    N, fs = 256, 2.0
+    pos = np.array([[0., 0., -100. - i] for i in range(5)])
+    ice = (1.78, 0.423, 77.)
+    ost = so.Station(pos, antenna=antenna, cable_delay=cable, n_samples=N, fs=fs)
+    det = _FakeDet(pos, antenna, cable, N, fs)
+    conv = modules.efieldToVoltageConverter(channel_factory=_FakeChannel)
+    conv.begin(caching=False)
+    rng = np.random.default_rng(9)
+    n_done = 0
+    for ev in range(40):
+        r, ph = np.sqrt(rng.uniform(0, 1500. ** 2)), rng.uniform(0, 2 * np.pi)
+        vertex = np.array([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1500, -50)])
+        efs = so.sim_efields_for_event(vertex, np.arccos(rng.uniform(-1, 1)), rng.uniform(0, 2 * np.pi), 1e18, 'HAD', None,
+                                       ost, ice, n_freq=25)
+        if not efs:
+            continue
+        by_ch = {}
+        for ef in efs:
+            tr = so.freq2time(ef['spec'], fs)
+            by_ch.setdefault(ef['channel'], []).append(_FakeEfield(pos[ef['channel']], tr, ef['t0'], fs, ef['zenith'],
+                                                                   ef['azimuth']))
+        station = _FakeStation(_FakeSimStation(by_ch))
+        conv.run(None, station, det)
+        V_ref, t_min, L = so.combined_voltage(efs, ost, filters=())
+        assert sorted(station.channels) == list(range(5))
+        scale = np.max(np.abs(V_ref))
+        for c in range(5):
+            ch = station.channels[c]
+            assert ch.t0 == t_min and len(ch.trace) == L and ch.fs == fs
+            assert np.max(np.abs(ch.trace - V_ref[c])) <= 1e-6 * scale, (ev, c)
+        n_done += 1
+    assert n_done >= 10
+    with pytest.raises(LookupError):
+        conv.run(None, _FakeStation(_FakeSimStation({})), det)
