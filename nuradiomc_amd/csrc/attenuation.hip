@@ -71,6 +71,41 @@ __device__ inline double attenuation_length(double z, const AttLane& a)
     return L;
 }
 
+// SP1: exponent x of L = 1 / exp(x), x = a + b ln f with (a, b) of the frequency branch (attenuation.py:168-192)
+__device__ inline void sp1_coefficients(double z, double p[4])
+{
+    double z2 = fabs(z);
+    double t_ = 1.83415e-09 * (z2 * z2 * z2) + (-1.59061e-08 * (z2 * z2)) + 0.00267687 * z2 + (-51.0696);
+    const double w0 = -9.210340371976182, w2 = 1.1505720275988207;
+    double b0 = -6.74890 + t_ * (0.026709 - t_ * 0.000884);
+    double b1 = -6.22121 - t_ * (0.070927 + t_ * 0.001773);
+    double b2 = -4.09468 - t_ * (0.002213 + t_ * 0.000332);
+    p[0] = (b1 * w0 - b0 * 0.0) / (w0 - 0.0);
+    p[1] = (b1 - b0) / (0.0 - w0);
+    p[2] = (b2 * 0.0 - b1 * w2) / (0.0 - w2);
+    p[3] = (b2 - b1) / (w2 - 0.0);
+}
+
+// ds / L(z, f).  SP1: L = max(1 / exp(x), 1), infinite above the surface, hence ds / L = ds * min(exp(x), 1) --
+// the same number without the two divisions (the CPU checker's integrand is written the same way).
+__device__ inline double sp1_ds_over_length(double ds, double z, double aa, double bb, double w)
+{
+    double e = det_exp(aa + bb * w);
+    if (e > 1.) e = 1.;
+    if (z > 0) e = 0.;
+    return ds * e;
+}
+
+__device__ inline double ds_over_length(double ds, double z, const AttLane& a)
+{
+    if (a.model == 1) {
+        double p[4];
+        sp1_coefficients(z, p);
+        return sp1_ds_over_length(ds, z, (a.f < 1.) ? p[0] : p[2], (a.f < 1.) ? p[1] : p[3], a.w);
+    }
+    return ds / attenuation_length(z, a);
+}
+
 struct AttItem {
     double C0, z_turn;
     AttLane lane;
@@ -84,7 +119,7 @@ __device__ inline double integrand(double t, const AttItem& it, const IceConst& 
     double q = (it.C0 * it.C0) * (nz * nz);
     double yd = (q > 1) ? 1 / sqrt(q - 1) : INFINITY;
     double ds = sqrt(yd * yd + 1);
-    return ds / attenuation_length(z, it.lane);
+    return ds_over_length(ds, z, it.lane);
 }
 
 struct GK { double result, abserr, resabs, resasc; };
@@ -303,31 +338,14 @@ __device__ inline NodeShared node_shared(double t, const AttItem& it, const IceC
     n.ds = sqrt(yd * yd + 1);
     n.z = z;
     n.p[0] = n.p[1] = n.p[2] = n.p[3] = 0.;
-    if (it.lane.model == 1) {  // SP1: everything up to (a, b) of both branches is frequency independent
-        double z2 = fabs(z);
-        double t_ = 1.83415e-09 * (z2 * z2 * z2) + (-1.59061e-08 * (z2 * z2)) + 0.00267687 * z2 + (-51.0696);
-        const double w0 = -9.210340371976182, w2 = 1.1505720275988207;
-        double b0 = -6.74890 + t_ * (0.026709 - t_ * 0.000884);
-        double b1 = -6.22121 - t_ * (0.070927 + t_ * 0.001773);
-        double b2 = -4.09468 - t_ * (0.002213 + t_ * 0.000332);
-        n.p[0] = (b1 * w0 - b0 * 0.0) / (w0 - 0.0);
-        n.p[1] = (b1 - b0) / (0.0 - w0);
-        n.p[2] = (b2 * 0.0 - b1 * w2) / (0.0 - w2);
-        n.p[3] = (b2 - b1) / (w2 - 0.0);
-    }
+    if (it.lane.model == 1) sp1_coefficients(z, n.p);  // frequency independent: (a, b) of both branches
     return n;
 }
 
 // integrand value of one lane (frequency) from the shared node data: ds / L(z, f)
 __device__ inline double node_finish(double ds, double z, double p0, double p1, double p2, double p3, const AttLane& a)
 {
-    if (a.model == 1) {
-        double aa = (a.f < 1.) ? p0 : p2, bb = (a.f < 1.) ? p1 : p3;
-        double L = 1. / det_exp(aa + bb * a.w);
-        if (L < 1.) L = 1.;
-        if (z > 0) L = INFINITY;
-        return ds / L;
-    }
+    if (a.model == 1) return sp1_ds_over_length(ds, z, (a.f < 1.) ? p0 : p2, (a.f < 1.) ? p1 : p3, a.w);
     return ds / attenuation_length(z, a);
 }
 
@@ -421,12 +439,14 @@ template <int G>
 struct GroupEval {
     int lane, gl, gb;               // lane in wave, lane in group, first lane of the group
     unsigned long long gmask;       // lanes of this group
-    __device__ inline void init()
+    NodeShared* nodes;              // LDS: 2 x 21 node records of this group
+    __device__ inline void init(NodeShared* lds)
     {
         lane = threadIdx.x & 63;
         gl = lane & (G - 1);
         gb = lane - gl;
         gmask = (G == 64) ? ~0ULL : (((1ULL << G) - 1ULL) << gb);
+        nodes = lds + (threadIdx.x / G) * 42;
     }
     __device__ inline bool any(bool busy) const { return (__ballot(busy) & gmask) != 0ULL; }
     __device__ inline void pair(bool want, bool two, double a1, double b1, double a2, double b2, const AttItem& it,
@@ -441,36 +461,33 @@ struct GroupEval {
         bool same = !want || (a1 == la1 && b1 == lb1 && (!two || (a2 == la2 && b2 == lb2)));
         bool allsame = ((__ballot(same) & gmask) == gmask);
         if (allsame) {
-            // lane gl evaluates node gl of both intervals with the leader's (== everybody's) ray and interval
-            NodeShared n1, n2;
-            n1.ds = n1.z = n2.ds = n2.z = 0.;
-            for (int k = 0; k < 4; k++) n1.p[k] = n2.p[k] = 0.;
+            // lane gl evaluates node gl of both intervals with the leader's (== everybody's) ray and interval and
+            // leaves the record in LDS; the group is part of one wave, whose LDS operations execute in order
             if (gl < 21) {
                 AttItem li = it;
                 li.C0 = lC0;
                 li.z_turn = lzt;
-                n1 = node_shared(gk_node(gl, la1, lb1), li, m);
-                if (two) n2 = node_shared(gk_node(gl, la2, lb2), li, m);
+                nodes[gl] = node_shared(gk_node(gl, la1, lb1), li, m);
+                if (two) nodes[21 + gl] = node_shared(gk_node(gl, la2, lb2), li, m);
             }
-            // every lane pulls the 21 nodes in turn (shuffles are executed by all lanes of the group)
-            double f1v[21], f2v[21];
-#pragma unroll
-            for (int n = 0; n < 21; n++) {
-                double ds = __shfl(n1.ds, gb + n), z = __shfl(n1.z, gb + n);
-                double p0 = __shfl(n1.p[0], gb + n), p1 = __shfl(n1.p[1], gb + n);
-                double p2 = __shfl(n1.p[2], gb + n), p3 = __shfl(n1.p[3], gb + n);
-                f1v[n] = want ? node_finish(ds, z, p0, p1, p2, p3, it.lane) : 0.;
-                if (two) {
-                    ds = __shfl(n2.ds, gb + n); z = __shfl(n2.z, gb + n);
-                    p0 = __shfl(n2.p[0], gb + n); p1 = __shfl(n2.p[1], gb + n);
-                    p2 = __shfl(n2.p[2], gb + n); p3 = __shfl(n2.p[3], gb + n);
-                    f2v[n] = want ? node_finish(ds, z, p0, p1, p2, p3, it.lane) : 0.;
-                }
-            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (want) {
-                g1 = gk21_from_nodes(a1, b1, [&](int n) { return f1v[n]; });
-                if (two) g2 = gk21_from_nodes(a2, b2, [&](int n) { return f2v[n]; });
+                // every lane reads the 21 records (same address in all lanes: LDS broadcast) and finishes its own sums
+                const int sel = (it.lane.model == 1 && !(it.lane.f < 1.)) ? 2 : 0;
+                g1 = gk21_from_nodes(a1, b1, [&](int n) {
+                    const NodeShared& s = nodes[n];
+                    return node_finish(s.ds, s.z, s.p[sel], s.p[sel + 1], s.p[sel], s.p[sel + 1], it.lane);
+                });
+                if (two)
+                    g2 = gk21_from_nodes(a2, b2, [&](int n) {
+                        const NodeShared& s = nodes[21 + n];
+                        return node_finish(s.ds, s.z, s.p[sel], s.p[sel + 1], s.p[sel], s.p[sel + 1], it.lane);
+                    });
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         } else if (want) {
             g1 = gk21(a1, b1, it, m);
             if (two) g2 = gk21(a2, b2, it, m);
@@ -767,15 +784,17 @@ attenuation_kernel(long n_rays, const double* __restrict__ C0, const double* __r
 }
 
 // G lanes per ray (G = 32 for n_freq <= 32, else 64): the cooperative evaluation of GroupEval
-template <int G>
+template <int G, int MODEL>
 __global__ void __launch_bounds__(256, 2)
 attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const double* __restrict__ zint, int n_freq,
                          const double* __restrict__ freqs, int model, IceConst m, double* __restrict__ att,
                          int* __restrict__ neval, const int* __restrict__ ray_index,
                          unsigned long long* __restrict__ eval_counter)
 {
+    __shared__ NodeShared sh_nodes[(256 / G) * 42];
     GroupEval<G> ev;
-    ev.init();
+    ev.init(sh_nodes);
+    model = MODEL;  // compile-time: the branches on the ice model fold away
     unsigned long long my_evals = 0;
     const long groups_per_block = blockDim.x / G;
     const long n_iter = (n_rays + (long)gridDim.x * groups_per_block - 1) / ((long)gridDim.x * groups_per_block);
@@ -887,12 +906,17 @@ void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0,
         int G = (n_freq <= 32) ? 32 : 64;
         long grid = (n_rays + block / G - 1) / (block / G);
         if (grid > 256L * 64) grid = 256L * 64;
-        if (G == 32)
-            hipLaunchKernelGGL(attenuation_group_kernel<32>, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, zint,
-                               n_freq, freqs, model, m, att, neval, ray_index, eval_counter);
-        else
-            hipLaunchKernelGGL(attenuation_group_kernel<64>, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, zint,
-                               n_freq, freqs, model, m, att, neval, ray_index, eval_counter);
+#define NRHIP_ATT_LAUNCH(GG, MM)                                                                                   \
+    hipLaunchKernelGGL((attenuation_group_kernel<GG, MM>), dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, \
+                       zint, n_freq, freqs, model, m, att, neval, ray_index, eval_counter)
+#define NRHIP_ATT_MODELS(GG)                                                              \
+    switch (model) {                                                                      \
+        case 1: NRHIP_ATT_LAUNCH(GG, 1); break;                                           \
+        case 2: NRHIP_ATT_LAUNCH(GG, 2); break;                                           \
+        case 4: NRHIP_ATT_LAUNCH(GG, 4); break;                                           \
+        default: NRHIP_ATT_LAUNCH(GG, 3); break;                                          \
+    }
+        if (G == 32) { NRHIP_ATT_MODELS(32) } else { NRHIP_ATT_MODELS(64) }
         return;
     }
     long grid = (n_items + block - 1) / block;

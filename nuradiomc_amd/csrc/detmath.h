@@ -3,11 +3,12 @@
 // The ray-solution finder the reference uses is numerically chaotic at the 1e-7 level: its
 // MINPACK iteration on (delta y)^2 stops at an iteration count that flips with the last bit of exp / log, and that
 // decides C0 to ~1e-7 and, rarely, whether a root is reported at all.  A vendor libm differs from the host libm in
-// those last bits, so results would differ between GPU and CPU.  These two functions follow the classic
-// table-free algorithms of Sun's fdlibm (e_exp.c: k ln2 + r reduction and a degree-5 Remez rational; e_log.c:
-// s = f / (2 + f) series with the Lg1..Lg7 minimax coefficients), whose every step is a correctly rounded basic
-// operation -- so any IEEE machine that does not fuse multiply-adds (-ffp-contract=off) produces the same bits.
-// Accuracy is < 1 ulp, the same class as the reference's numpy / libm.
+// those last bits, so results would differ between GPU and CPU.  These two functions are table-free and every step
+// is a correctly rounded IEEE operation (+, -, *, /, and EXPLICIT fused multiply-adds, which are exactly rounded on
+// any machine; the compiler is kept from fusing anything else with -ffp-contract=off), so any IEEE host and the device produce
+// the same bits.  det_exp: k ln2 + r reduction and a Taylor polynomial (division-free: 16 FMAs); det_log: fdlibm's
+// e_log.c (s = f / (2 + f) series with the Lg1..Lg7 minimax coefficients).  Accuracy is <= 1 ulp, the same class as
+// the reference's numpy / libm.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -15,41 +16,31 @@ namespace nrhip {
 
 __device__ inline double det_exp(double x)
 {
+    // k = nearest integer to x / ln2, r = x - k ln2 (two exact-product FMAs), exp(r) by its degree-13 Taylor
+    // polynomial in Horner form with FMAs (|r| <= 0.3466: truncation 4e-18), result scaled by 2^k (ldexp).
     const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                  invln2 = 1.44269504088896338700e+00;
-    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
-                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
     if (x != x) return x;
     if (x > 7.09782712893383973096e+02) return INFINITY;
     if (x < -7.45133219101941108420e+02) return 0.0;
-    double hi = 0., lo = 0.;
-    int k = 0;
-    double ax = fabs(x);
-    if (ax > 0.34657359027997264) {  // 0.5 ln2
-        if (ax < 1.0397207708399179) {  // 1.5 ln2
-            if (x > 0) { hi = x - ln2HI; lo = ln2LO; k = 1; }
-            else       { hi = x + ln2HI; lo = -ln2LO; k = -1; }
-        } else {
-            k = (int)(invln2 * x + (x > 0 ? 0.5 : -0.5));
-            double t = k;
-            hi = x - t * ln2HI;
-            lo = t * ln2LO;
-        }
-        x = hi - lo;
-    } else if (ax < 3.725290298461914e-09) {  // 2^-28
-        return 1.0 + x;
-    }
-    double t = x * x;
-    double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
-    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
-    long long bits = __double_as_longlong(y);
-    if (k >= -1021) {
-        bits += (long long)k << 52;
-        return __longlong_as_double(bits);
-    }
-    bits += (long long)(k + 1000) << 52;
-    return __longlong_as_double(bits) * 9.33263618503218878990e-302;
+    const double kd = rint(x * invln2);
+    double r = __builtin_fma(-kd, ln2HI, x);
+    r = __builtin_fma(-kd, ln2LO, r);
+    double p = 1.6059043836821613e-10;               // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878681e-09);   // 1/12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);
+    p = __builtin_fma(p, r, 2.755731922398589e-07);
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);
+    p = __builtin_fma(p, r, 2.48015873015873e-05);
+    p = __builtin_fma(p, r, 0.0001984126984126984);
+    p = __builtin_fma(p, r, 0.001388888888888889);
+    p = __builtin_fma(p, r, 0.008333333333333333);
+    p = __builtin_fma(p, r, 0.041666666666666664);
+    p = __builtin_fma(p, r, 0.16666666666666666);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p, (int)kd);
 }
 
 __device__ inline double det_log(double x)

@@ -1,6 +1,7 @@
-/* oracle/detmath_c.h -- TEST INFRASTRUCTURE.  exp / log from IEEE basic operations only (Sun fdlibm's published
- * e_exp.c / e_log.c algorithms), so that the oracle's ray tracer produces the same bits on any IEEE-754 host or
- * device compiled without fused multiply-add contraction.  Accuracy < 1 ulp (checked against libm in
+/* oracle/detmath_c.h -- TEST INFRASTRUCTURE.  exp / log from correctly rounded IEEE operations only (+, -, *, /,
+ * explicit fma; exp = k ln2 + r reduction and a degree-13 Taylor polynomial, log = Sun fdlibm's published e_log.c),
+ * so that the oracle's ray tracer produces the same bits on any IEEE-754 host or device compiled without implicit
+ * multiply-add contraction.  Accuracy <= 1 ulp (checked against libm in
  * tests/test_oracle_golden.py).  See DESIGN.md section 2 for why last bits matter on this path. */
 #ifndef ORC_DETMATH_C_H
 #define ORC_DETMATH_C_H
@@ -11,45 +12,34 @@
 static inline int64_t orc_bits(double x) { int64_t b; memcpy(&b, &x, 8); return b; }
 static inline double orc_from_bits(int64_t b) { double x; memcpy(&x, &b, 8); return x; }
 
-static double orc_exp(double x)
+/* the "fma" clone inlines the hardware instruction, the default clone calls libm's (exactly rounded) fma: same bits */
+__attribute__((target_clones("fma", "default")))
+double orc_exp(double x)
 {
     static const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                         invln2 = 1.44269504088896338700e+00;
-    static const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
-                        P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
-                        P5 = 4.13813679705723846039e-08;
-    double hi = 0., lo = 0., ax, t, c, y;
-    int k = 0;
-    int64_t bits;
+    double kd, r, p;
     if (x != x) return x;
     if (x > 7.09782712893383973096e+02) return INFINITY;
     if (x < -7.45133219101941108420e+02) return 0.0;
-    ax = fabs(x);
-    if (ax > 0.34657359027997264) {
-        if (ax < 1.0397207708399179) {
-            if (x > 0) { hi = x - ln2HI; lo = ln2LO; k = 1; }
-            else       { hi = x + ln2HI; lo = -ln2LO; k = -1; }
-        } else {
-            k = (int)(invln2 * x + (x > 0 ? 0.5 : -0.5));
-            t = k;
-            hi = x - t * ln2HI;
-            lo = t * ln2LO;
-        }
-        x = hi - lo;
-    } else if (ax < 3.725290298461914e-09) {
-        return 1.0 + x;
-    }
-    t = x * x;
-    c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
-    y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
-    bits = orc_bits(y);
-    if (k >= -1021) {
-        bits += (int64_t)k << 52;
-        return orc_from_bits(bits);
-    }
-    bits += (int64_t)(k + 1000) << 52;
-    return orc_from_bits(bits) * 9.33263618503218878990e-302;
+    kd = rint(x * invln2);
+    r = __builtin_fma(-kd, ln2HI, x);
+    r = __builtin_fma(-kd, ln2LO, r);
+    p = 1.6059043836821613e-10;
+    p = __builtin_fma(p, r, 2.08767569878681e-09);
+    p = __builtin_fma(p, r, 2.505210838544172e-08);
+    p = __builtin_fma(p, r, 2.755731922398589e-07);
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);
+    p = __builtin_fma(p, r, 2.48015873015873e-05);
+    p = __builtin_fma(p, r, 0.0001984126984126984);
+    p = __builtin_fma(p, r, 0.001388888888888889);
+    p = __builtin_fma(p, r, 0.008333333333333333);
+    p = __builtin_fma(p, r, 0.041666666666666664);
+    p = __builtin_fma(p, r, 0.16666666666666666);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p, (int)kd);
 }
 
 static double orc_log(double x)

@@ -501,6 +501,42 @@ static void path_length_and_time(const double x1[2], const double x2[2], double 
  * attenuation length (NuRadioMC/utilities/attenuation.py:145-262), scalar branch
  * model ints follow attenuation.py:14  {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4, "GL3": 5}
  * ---------------------------------------------------------------------------------------- */
+double orc_attenuation_length(double z, double frequency, int model);
+
+/* SP1 :168-192: the attenuation length is 1 / exp(a + b ln f); this returns the exponent a + b ln f */
+static double sp1_exponent(double z, double frequency)
+{
+    double z2 = fabs(z);
+    double t = 1.83415e-09 * (z2 * z2 * z2) + (-1.59061e-08 * (z2 * z2)) + 0.00267687 * z2 + (-51.0696);
+    double w0 = -9.210340371976182, w1 = 0.0, w2 = 1.1505720275988207; /* ln 1e-4, ln 3.16 */
+    double w = orc_log(frequency);
+    double b0 = -6.74890 + t * (0.026709 - t * 0.000884);
+    double b1 = -6.22121 - t * (0.070927 + t * 0.001773);
+    double b2 = -4.09468 - t * (0.002213 + t * 0.000332);
+    double a, bb;
+    if (frequency < 1.) {
+        a = (b1 * w0 - b0 * w1) / (w0 - w1);
+        bb = (b1 - b0) / (w1 - w0);
+    } else {
+        a = (b2 * w1 - b1 * w2) / (w1 - w2);
+        bb = (b2 - b1) / (w2 - w1);
+    }
+    return a + bb * w;
+}
+
+/* ds / L(z, f) of the path integrand.  For SP1, L = max(1 / exp(x), 1) (and infinity above the surface), so
+ * ds / L = ds * min(exp(x), 1): the same number without the two divisions (the device kernel does the same). */
+static double ds_over_length(double ds, double z, double frequency, int model)
+{
+    if (model == 1) {
+        double e = orc_exp(sp1_exponent(z, frequency));
+        if (e > 1.) e = 1.;
+        if (z > 0) e = 0.;
+        return ds * e;
+    }
+    return ds / orc_attenuation_length(z, frequency, model);
+}
+
 double orc_attenuation_length(double z, double frequency, int model)
 {
     double L;
@@ -1044,7 +1080,7 @@ static double att_integrand(double t, void *p) /* dt() :986-988 with ds() :513-5
     double z = get_z_unmirrored(t, a->C0, a->m);
     double yd = get_y_diff(t, a->C0, a->m);
     double ds = sqrt(yd * yd + 1);
-    return ds / orc_attenuation_length(z, a->f, a->model);
+    return ds_over_length(ds, z, a->f, a->model);
 }
 
 /* x1, x2: 2-D points; freqs: the sparse frequency vector (already chosen); att: exp(-integral) */
