@@ -125,7 +125,7 @@ __device__ inline double integrand(double t, const AttItem& it, const IceConst& 
 struct GK { double result, abserr, resabs, resasc; };
 
 // 21-point Gauss-Kronrod rule, accumulation order of QUADPACK's DQK21
-__device__ inline GK gk21(double a, double b, const AttItem& it, const IceConst& m)
+__device__ __noinline__ GK gk21(double a, double b, const AttItem& it, const IceConst& m)
 {
     const double XGK[11] = {
         0.995657163025808080735527280689003, 0.973906528517171720077964012084452,
@@ -449,8 +449,8 @@ struct GroupEval {
         nodes = lds + (threadIdx.x / G) * 42;
     }
     __device__ inline bool any(bool busy) const { return (__ballot(busy) & gmask) != 0ULL; }
-    __device__ inline void pair(bool want, bool two, double a1, double b1, double a2, double b2, const AttItem& it,
-                                const IceConst& m, GK& g1, GK& g2) const
+    __device__ __forceinline__ void pair(bool want, bool two, double a1, double b1, double a2, double b2,
+                                         const AttItem& it, const IceConst& m, GK& g1, GK& g2) const
     {
         unsigned long long wm = __ballot(want) & gmask;
         if (wm == 0ULL) return;
@@ -480,6 +480,7 @@ struct GroupEval {
                     const NodeShared& s = nodes[n];
                     return node_finish(s.ds, s.z, s.p[sel], s.p[sel + 1], s.p[sel], s.p[sel + 1], it.lane);
                 });
+                __builtin_amdgcn_sched_barrier(0);  // finish interval 1 before interval 2: halves the live values
                 if (two)
                     g2 = gk21_from_nodes(a2, b2, [&](int n) {
                         const NodeShared& s = nodes[21 + n];
@@ -498,7 +499,7 @@ struct GroupEval {
 // adaptive integration over [a, b] with optional interior break point (QUADPACK QAGS / QAGP decisions); every lane of
 // an evaluation group must call this together (lanes without work pass valid = false).  Returns the integral estimate.
 template <class EV>
-__device__ inline double quad_gk21(bool valid, double a, double b, bool with_point, double point, const AttItem& it,
+__device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool with_point, double point, const AttItem& it,
                                    const IceConst& m, int* neval_out, const EV& ev)
 {
     const double epmach = 2.220446049250313e-16, uflow = 2.2250738585072014e-308, oflow = 1.7976931348623157e+308;

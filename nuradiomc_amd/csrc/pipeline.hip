@@ -300,21 +300,24 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     double* bound;
     NEED(bound = WS("ray_bound", double, nr));
     if (n_rays > 0) {
-        int *ractive, *roff, *rtmp;
+        int *ractive, *roff, *rtmp, *cflags;
         NEED(ractive = WS("ray_active", int, nr + 1));
-        NEED(roff = WS("ray_active_offset", int, nr + 1));
-        NEED(rtmp = WS("scan_tmp2", int, scan_tiles(n_rays + 1)));
+        NEED(cflags = WS("ray_active_class", int, 3 * nr + 1));
+        NEED(roff = WS("ray_active_offset", int, 3 * nr + 1));
+        NEED(rtmp = WS("scan_tmp2", int, scan_tiles(3L * n_rays + 1)));
         NEED(active_list = WS("ray_active_list", int, nr));
         launch_amp_bound(sm, n_rays, w, sd, vertex, bound, max_efield);
         LCHK("amp_bound");
         launch_event_possible(sm, (int)n_events, n_ch, offset, bound, cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude,
                               ractive);
         LCHK("event_possible");
-        HIPCHK(hipMemsetAsync(ractive + n_rays, 0, sizeof(int), sm));
-        launch_exclusive_scan(sm, n_rays + 1, ractive, roff, rtmp);
-        launch_scatter_active(sm, n_rays, ractive, roff, active_list);
+        // active rays listed by work class (direct, reflected, refracted): wave-mates in the quadrature do similar work
+        launch_active_class_flags(sm, n_rays, ractive, w.slot, rec.type, cflags);
+        HIPCHK(hipMemsetAsync(cflags + 3L * n_rays, 0, sizeof(int), sm));
+        launch_exclusive_scan(sm, 3L * n_rays + 1, cflags, roff, rtmp);
+        launch_scatter_active_class(sm, n_rays, cflags, roff, active_list);
         LCHK("active list");
-        HIPCHK(hipMemcpyAsync(&n_active, roff + n_rays, sizeof(int), hipMemcpyDeviceToHost, sm));
+        HIPCHK(hipMemcpyAsync(&n_active, roff + 3L * n_rays, sizeof(int), hipMemcpyDeviceToHost, sm));
         HIPCHK(hipMemsetAsync(w.att, 0xFF, nr * sd.n_fc * sizeof(double), sm));  // NaN = not evaluated
         HIPCHK(hipStreamSynchronize(sm));
     }

@@ -102,6 +102,9 @@ void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const Station
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
                            double min_efield, int* ray_active);
 void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const int* offset, int* list);
+void launch_active_class_flags(hipStream_t s, int n_rays, const int* active, const int* ray_slot2, const int* slot_type,
+                               int* flags);
+void launch_scatter_active_class(hipStream_t s, int n_rays, const int* flags, const int* offset, int* list);
 void launch_efield_max(hipStream_t s, int n_active, const int* active_list, const RayWork& w, const EventIn& evin,
                        const StationDev& st, int ask_model, const double2* tw, double min_efield, int exact,
                        double* max_efield);

@@ -613,6 +613,29 @@ __global__ void scatter_active_kernel(int n_rays, const int* __restrict__ active
     if (active[r]) list[offset[r]] = r;
 }
 
+// The attenuation quadrature of direct rays needs ~1 interval, of reflected rays a few, of refracted rays ~10
+// (break point at the turning depth): list the active rays class by class so that the rays sharing a wave do similar
+// work.  flags has 3 n_rays + 1 entries (class-major); its exclusive scan gives the list positions.
+__device__ inline int work_class(int type) { return type == 1 ? 0 : (type == 3 ? 1 : 2); }
+
+__global__ void active_class_flags_kernel(int n_rays, const int* __restrict__ active, const int* __restrict__ ray_slot2,
+                                          const int* __restrict__ slot_type, int* __restrict__ flags)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    int c = work_class(slot_type[ray_slot2[r]]);
+    int a = active[r] ? 1 : 0;
+    for (int k = 0; k < 3; k++) flags[(long)k * n_rays + r] = (k == c) ? a : 0;
+}
+
+__global__ void scatter_active_class_kernel(int n_rays, const int* __restrict__ flags, const int* __restrict__ offset,
+                                            int* __restrict__ list)
+{
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= 3L * n_rays) return;
+    if (flags[i]) list[offset[i]] = (int)(i % n_rays);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // kernel: max |E(t)| per ray (candidate cut, simulation.py:283-285).  One block per active ray.
 // With attenuation known the sum-of-magnitudes bound is re-evaluated; only rays whose bound exceeds the cut pay for
@@ -1252,6 +1275,19 @@ void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slo
     if (n_events <= 0) return;
     hipLaunchKernelGGL(event_possible_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, n_ch, slot_offset,
                        bound, min_efield, ray_active);
+}
+void launch_active_class_flags(hipStream_t s, int n_rays, const int* active, const int* ray_slot2, const int* slot_type,
+                               int* flags)
+{
+    if (n_rays <= 0) return;
+    hipLaunchKernelGGL(active_class_flags_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, active,
+                       ray_slot2, slot_type, flags);
+}
+void launch_scatter_active_class(hipStream_t s, int n_rays, const int* flags, const int* offset, int* list)
+{
+    if (n_rays <= 0) return;
+    hipLaunchKernelGGL(scatter_active_class_kernel, dim3(grid_for(3L * n_rays, 256)), dim3(256), 0, s, n_rays, flags,
+                       offset, list);
 }
 void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const int* offset, int* list)
 {
