@@ -119,6 +119,21 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
         const double df = 1.0 / (d->n_samples * (1. / d->sampling_rate));
         for (int k = 1; k <= nh; k++) lnf[k] = std::log(k * df);
     }
+    // tables on the N-sample frequency grid: f^p of the Alvarez2009 form factors, coarse-grid segment of np.interp
+    std::vector<double> fpow(3 * (size_t)(nh + 1), 0.);
+    std::vector<unsigned char> seg(nh + 1, 0);
+    {
+        const double df = 1.0 / (d->n_samples * (1. / d->sampling_rate));
+        const double pw[3] = {2.57, 2.74, 1.27};
+        const int nfc = d->n_att_freq;
+        for (int k = 1; k <= nh; k++) {
+            const double f = k * df;
+            for (int r = 0; r < 3; r++) fpow[r * (size_t)(nh + 1) + k] = std::pow(f, pw[r]);
+            int lo = 0;
+            while (lo < nfc - 2 && f >= d->att_freq[lo + 1]) lo++;
+            seg[k] = (unsigned char)lo;
+        }
+    }
     std::vector<double> invl(d->n_att_freq, 0.);
     if (d->att_bound_inv_length)
         for (int k = 0; k < d->n_att_freq; k++) invl[k] = d->att_bound_inv_length[k] > 0 ? d->att_bound_inv_length[k] : 0.;
@@ -127,7 +142,8 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     if (upload(ctx, s->d_pos, d->position, 3 * n) || upload(ctx, s->d_cable, d->cable_delay, n) ||
         upload(ctx, s->d_model, d->antenna_model, n) || upload(ctx, s->d_rot, rot.data(), 9 * n) ||
         upload(ctx, s->d_rot_inv, roti.data(), 9 * n) || upload(ctx, s->d_fc, d->att_freq, d->n_att_freq) ||
-        upload(ctx, s->d_lnf, lnf.data(), lnf.size()) || upload(ctx, s->d_invl, invl.data(), invl.size())) {
+        upload(ctx, s->d_lnf, lnf.data(), lnf.size()) || upload(ctx, s->d_invl, invl.data(), invl.size()) ||
+        upload(ctx, s->d_fpow, fpow.data(), fpow.size()) || upload(ctx, s->d_seg, seg.data(), seg.size())) {
         delete s;
         return -1;
     }
@@ -149,6 +165,8 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     v.fcoarse = s->d_fc.as<double>();
     v.lnf = s->d_lnf.as<double>();
     v.inv_lmax = s->d_invl.as<double>();
+    v.fpow = s->d_fpow.as<double>();
+    v.seg = s->d_seg.as<unsigned char>();
     FilterSet& f = s->filters;
     memset(&f, 0, sizeof f);
     f.n = d->n_filters;
@@ -175,6 +193,7 @@ void nrhip_station_destroy(nrhip_station* s)
     for (auto& e : s->evt) if (e) (void)hipEventDestroy(e);
     s->d_pos.release(); s->d_cable.release(); s->d_model.release();
     s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release(); s->d_lnf.release(); s->d_invl.release();
+    s->d_fpow.release(); s->d_seg.release();
     delete s;
 }
 

@@ -24,6 +24,8 @@ struct StationDev {
     const double* fcoarse;    // [n_fc] attenuation frequency grid
     const double* lnf;        // [N/2 + 1] ln f_k of the N-sample grid (entry 0 unused)
     const double* inv_lmax;   // [n_fc] 1 / max_z L_att(z, f) (0 = unknown): upper bound exp(-0.95 D / L_max) on attenuation
+    const double* fpow;       // [3][N/2 + 1] f_k^p for p = 2.57, 2.74, 1.27 (Alvarez2009: beta had / em, alpha)
+    const unsigned char* seg; // [N/2 + 1] coarse-grid segment lo of f_k: fcoarse[lo] <= f_k < fcoarse[lo + 1]
 };
 
 // analog filter chain: response_i(f) = polyval(b_i, j f) / polyval(a_i, j f), highest power first
@@ -41,6 +43,7 @@ struct AskaryanConst {
     double nu_L, beta, nu_R, alpha;  // Alvarez2009
     double dth, cher, theta, f0, scale, roll;  // Alvarez2000 / ZHS1992
     double ln_nu_L, ln_nu_R;
+    double cL, cR, pref2;  // Alvarez2009 on the station's frequency grid: nu_L^-beta, nu_R^-alpha, a_pref / (2 scale)
 };
 
 // per kept ray (SoA, ordered by event, channel, solution)

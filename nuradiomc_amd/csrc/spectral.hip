@@ -245,6 +245,9 @@ __device__ inline AskaryanConst askaryan_setup(int model, double energy, double 
         a.scale = R;
         a.ln_nu_L = log(a.nu_L);
         a.ln_nu_R = log(a.nu_R);
+        a.cL = exp(-a.beta * a.ln_nu_L);
+        a.cR = exp(-a.alpha * a.ln_nu_R);
+        a.pref2 = 0.5 * a.a_pref / a.scale;
     } else if (model == 1) {  // Alvarez2000, parametrizations.py:220-275
         a.cher = acos(1. / n_index);
         a.theta = theta;
@@ -433,28 +436,54 @@ __device__ inline double interp_att(double f, int n, const double* __restrict__ 
     return slope * (f - xp[lo]) + fp[lo];
 }
 
+// the same value with the segment index from the station's table and the segment slopes precomputed per ray
+__device__ inline double interp_seg(double f, int lo, int n, const double* xp, const double* fp, const double* slope)
+{
+    if (f <= xp[0]) return fp[0];
+    if (f >= xp[n - 1]) return fp[n - 1];
+    return slope[lo] * (f - xp[lo]) + fp[lo];
+}
+
+// X(f_k) on the station's N-sample grid: Alvarez2009 from the f^p tables (one division per bin), others directly
+__device__ inline double amplitude_bin(int k, double f, const AskaryanConst& a, const StationDev& st)
+{
+    if (a.model == 0) {
+        const int stride = st.N / 2 + 1;
+        double x = st.fpow[(a.had ? 0 : stride) + k] * a.cL;   // (f / nu_L)^beta
+        double y = st.fpow[2 * stride + k] * a.cR;             // (f / nu_R)^alpha
+        return a.pref2 * f / ((1 + x) * (1 + y));
+    }
+    return askaryan_amplitude(f, st.lnf[k], a);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Building blocks shared by the efield-maximum kernel and the channel kernel (block-cooperative, LDS)
 // ---------------------------------------------------------------------------------------------------------
 struct RayShared {
     AskaryanConst ask;
     double att[NRHIP_MAX_NFC];
+    double slope[NRHIP_MAX_NFC];
+    double xp[NRHIP_MAX_NFC];
 };
 
 // amp[k] = X_k * att(f_k) for k <= N/2 (0 at k = 0 and N/2): the real, component-independent part of the field.
-// Returns this thread's partial sum of amp (for the sum-of-magnitudes bound on max |E(t)|).
-__device__ inline double fill_amplitude(double* amp, int N, double fs, const RayShared& rs, int n_fc,
-                                        const double* __restrict__ fcoarse, const double* __restrict__ lnf, bool with_att)
+// rs.ask and rs.att must be set (and synchronised) by the caller.  Returns this thread's partial sum of amp (for the
+// sum-of-magnitudes bound on max |E(t)|).
+__device__ inline double fill_amplitude(double* amp, const StationDev& st, RayShared& rs)
 {
-    const int nh = N / 2;
-    const double df = 1.0 / (N * (1. / fs));
+    const int N = st.N, nh = N / 2, n_fc = st.n_fc;
+    const double df = 1.0 / (N * (1. / st.fs));
+    for (int j = threadIdx.x; j < n_fc; j += blockDim.x) {
+        rs.xp[j] = st.fcoarse[j];
+        if (j < n_fc - 1) rs.slope[j] = (rs.att[j + 1] - rs.att[j]) / (st.fcoarse[j + 1] - st.fcoarse[j]);
+    }
+    __syncthreads();
     double part = 0.;
     for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
         double v = 0.;
         if (k > 0 && k < nh) {
             double f = k * df;
-            v = askaryan_amplitude(f, lnf[k], rs.ask);
-            if (with_att) v *= interp_att(f, n_fc, fcoarse, rs.att);
+            v = amplitude_bin(k, f, rs.ask, st) * interp_seg(f, st.seg[k], n_fc, rs.xp, rs.att, rs.slope);
         }
         if (amp) amp[k] = v;
         part += v;
@@ -553,6 +582,9 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, const double* __restrict_
                  double* __restrict__ max_efield)
 {
     __shared__ double ub[4][NRHIP_MAX_NFC];  // per wave: upper bounds of the coarse attenuation factors
+    __shared__ double ub_slope[4][NRHIP_MAX_NFC];
+    __shared__ double s_xp[NRHIP_MAX_NFC];
+    for (int j = threadIdx.x; j < st.n_fc; j += blockDim.x) s_xp[j] = st.fcoarse[j];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nh = st.N / 2;
     const double df = 1.0 / (st.N * (1. / st.fs));
@@ -571,12 +603,14 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, const double* __restrict_
             ub[wv][lane] = u;
         }
         __syncthreads();
+        if (lane < st.n_fc - 1) ub_slope[wv][lane] = (ub[wv][lane + 1] - ub[wv][lane]) / (s_xp[lane + 1] - s_xp[lane]);
+        __syncthreads();
         if (ok) {
             const AskaryanConst a = w.ask[r];
             double part = 0.;
             for (int k = 1 + lane; k < nh; k += 64) {
                 double f = k * df;
-                part += askaryan_amplitude(f, st.lnf[k], a) * interp_att(f, st.n_fc, st.fcoarse, ub[wv]);
+                part += amplitude_bin(k, f, a, st) * interp_seg(f, st.seg[k], st.n_fc, s_xp, ub[wv], ub_slope[wv]);
             }
             for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
             if (lane == 0) {
@@ -659,7 +693,7 @@ efield_max_kernel(int n_active, const int* __restrict__ active_list, RayWork w, 
         if (threadIdx.x == 0) rs.ask = w.ask[r];
         for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
         __syncthreads();
-        double part = fill_amplitude(amp, N, st.fs, rs, st.n_fc, st.fcoarse, st.lnf, true);
+        double part = fill_amplitude(amp, st, rs);
         double sum = block_sum(part, red);
         {   // Parseval: sum_t s(t)^2 = (fs^2 / 2) (1 / N) 2 sum_k |G_k|^2 with |G_k| = sqrt(2) amp_k
             double p2 = 0.;
@@ -918,7 +952,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
             if (threadIdx.x == 0) rs.ask = w.ask[r];
             for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
             __syncthreads();
-            fill_amplitude(amp, N, st.fs, rs, st.n_fc, st.fcoarse, st.lnf, true);
+            fill_amplitude(amp, st, rs);
             // start bin and sub-sample remainder (efieldToVoltageConverter.py:214-218)
             double start_time = w.t0[r] - t_min + st.cable[ch] + 0;
             long start_bin = (long)rint(start_time / res);
