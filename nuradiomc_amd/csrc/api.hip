@@ -79,6 +79,7 @@ void nrhip_ctx_destroy(nrhip_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->twiddle) (void)hipFree(ctx->twiddle);
+    if (ctx->w16) (void)hipFree(ctx->w16);
     delete ctx;
 }
 

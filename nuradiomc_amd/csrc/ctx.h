@@ -12,6 +12,7 @@ struct nrhip_ctx {
     nrhip::IceConst ice;
     int att_model;
     double2* twiddle = nullptr;  // exp(-2 pi i k / FFT_MAX), k < FFT_MAX / 2
+    double2* w16 = nullptr;      // exp(-2 pi i k / (2 FFT_MAX)), k <= FFT_MAX / 2 (real <-> packed-complex FFT split)
 };
 
 int nrhip_fail(const char* what, hipError_t e);

@@ -23,6 +23,13 @@ static int ensure_twiddle(nrhip_ctx* ctx)
     }
     HIPCHK(hipMalloc((void**)&ctx->twiddle, sizeof(double2) * h.size()));
     HIPCHK(hipMemcpyAsync(ctx->twiddle, h.data(), sizeof(double2) * h.size(), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<double2> h2(FFT_MAX / 2 + 1);
+    for (int k = 0; k <= FFT_MAX / 2; k++) {
+        long double a = -3.14159265358979323846264338327950288L * (long double)k / (long double)FFT_MAX;
+        h2[k] = make_double2((double)cosl(a), (double)sinl(a));
+    }
+    HIPCHK(hipMalloc((void**)&ctx->w16, sizeof(double2) * h2.size()));
+    HIPCHK(hipMemcpyAsync(ctx->w16, h2.data(), sizeof(double2) * h2.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -426,7 +433,8 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         NEED(tab.Cf = WS("tab_Cf", double2, lens.size() * (size_t)NRHIP_SPEC_STRIDE));
         NEED(tab.Ci = WS("tab_Ci", double2, lens.size() * (size_t)FFT_MAX));
         NEED(tab.hnorm = WS("tab_hnorm", double, lens.size() * 2));
-        launch_length_tables(sm, (int)lens.size(), d_lens, sd, st->filters, ctx->twiddle, tab);
+        NEED(tab.G = WS("tab_G", double2, lens.size() * 2 * (size_t)NRHIP_G_STRIDE));
+        launch_length_tables(sm, (int)lens.size(), d_lens, sd, st->filters, ctx->twiddle, ctx->w16, tab);
         LCHK("length_tables");
         MARK(7);
         // 6. channel voltages + trigger
@@ -450,8 +458,8 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         double2* scratch;
         NEED(scratch = WS("channel_scratch", double2, (size_t)channel_grid_blocks() * NRHIP_SPEC_STRIDE));
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, cfg->askaryan_model,
-                       cfg->trigger_threshold, ctx->twiddle, tab, scratch, co,
-                       (cfg->no_pruning || cfg->dump_traces) ? 1 : 0);
+                       cfg->trigger_threshold, ctx->twiddle, ctx->w16, tab, scratch, co,
+                       (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, maxL);
         LCHK("channel");
         MARK(8);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here
@@ -539,7 +547,8 @@ int nrhip_efield_to_voltage(nrhip_ctx* ctx, nrhip_station* st, int32_t n_efields
     NEED(tab.Cf = WS("tab_Cf", double2, (size_t)NRHIP_SPEC_STRIDE));
     NEED(tab.Ci = WS("tab_Ci", double2, (size_t)FFT_MAX));
     NEED(tab.hnorm = WS("tab_hnorm", double, 2));
-    launch_length_tables(sm, 1, d_len, sd, st->filters, ctx->twiddle, tab);
+    tab.G = nullptr;  // the generic path always goes through the chirp-z kernel
+    launch_length_tables(sm, 1, d_len, sd, st->filters, ctx->twiddle, ctx->w16, tab);
     LCHK("length_tables");
     double2* scratch;
     NEED(scratch = WS("channel_scratch", double2, (size_t)std::max(sd.n_ch, channel_grid_blocks()) * NRHIP_SPEC_STRIDE));

@@ -9,6 +9,7 @@
 #define NRHIP_MAX_POLY 24
 #define NRHIP_SPEC_STRIDE 6146  // max L / 2 + 1 spectrum bins per channel (L <= 12290 with the 8192-point chirp-z)
 #define NRHIP_E_STRIDE 24584    // 2 L phase-table entries per length
+#define NRHIP_G_STRIDE 8200     // FFT_MAX + 1 bins of the 2 FFT_MAX-point real transform of the impulse response (padded)
 
 namespace nrhip {
 
@@ -81,6 +82,8 @@ struct LengthTables {
     double2* Cf;     // [n_len][NRHIP_SPEC_STRIDE]     forward chirp exp(-i pi k^2 / (L/2)), contiguous in k
     double2* Ci;     // [n_len][FFT_MAX]               inverse chirp exp(+i pi n^2 / L), contiguous in n
     double* hnorm;   // [n_len][2]                     L2 norm of the (antenna x filter) impulse response on the L grid
+    double2* G;      // [n_len][2][NRHIP_G_STRIDE]     (L <= FFT_MAX) spectrum on the 2 FFT_MAX grid of the L-periodic impulse
+                     //                                response irfft_L(antenna x filter), all scale factors folded in
 };
 
 struct ChannelOut {
@@ -114,12 +117,12 @@ void launch_efield_max(hipStream_t s, int n_active, const int* active_list, cons
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev);
 void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet& fl,
-                          const double2* tw, const LengthTables& tab);
+                          const double2* tw, const double2* w16, const LengthTables& tab);
 int channel_grid_blocks();
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
-                    double threshold, const double2* tw, const LengthTables& tab, double2* scratch, const ChannelOut& out,
-                    int exact);
+                    double threshold, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
+                    const ChannelOut& out, int exact, int max_length);
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,
                            const double2* tw, const LengthTables& tab, double2* scratch, double* V);

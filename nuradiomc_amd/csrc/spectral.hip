@@ -795,7 +795,7 @@ __device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
 length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, FilterSet fl,
-                     const double2* __restrict__ tw, LengthTables tab)
+                     const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double2* x = (double2*)smem;
@@ -882,6 +882,204 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
             h2 = block_sum(h2, red);
             if (threadIdx.x == 0) tab.hnorm[(long)il * 2 + model] = sqrt(h2 / L);
         }
+        // Lengths up to FFT_MAX: the channel voltage is the circular convolution (period L) of the summed, placed field
+        // traces with g = (fs / sqrt 2) irfft_L(antenna x filter).  g comes from one chirp-z inverse; its spectrum on the
+        // 2 FFT_MAX-point grid (real transform via the packed FFT_MAX-point complex one) is what channel_conv_kernel
+        // multiplies with.  Factors folded in: 1/2 of each even/odd split (two of them), 1/FFT_MAX of the inverse.
+        if (tab.G && L <= FFT_MAX) {
+            const double2* E = tab.E + (long)il * NRHIP_E_STRIDE;
+            const double2* Hf = tab.H + (long)il * NRHIP_SPEC_STRIDE;
+            const double2* Ci = tab.Ci + (long)il * FFT_MAX;
+            const double2* Bi = tab.B_inv + (long)il * M;
+            const unsigned LL = (unsigned)L;
+            const int P = M - m;
+            const double scale = st.fs / 1.4142135623730951 / L;
+            for (int model = 0; model < 2; model++) {
+                const double2* vel = tab.vel + ((long)il * 2 + model) * NRHIP_SPEC_STRIDE;
+                double2* G = tab.G + ((long)il * 2 + model) * NRHIP_G_STRIDE;
+                double* gtmp = (double*)G;  // L doubles of the impulse response, overwritten by its spectrum below
+                __syncthreads();
+                for (int n0 = 0; n0 < L; n0 += P) {
+                    for (int k = threadIdx.x; k < M; k += blockDim.x) {
+                        double2 v = make_double2(0., 0.);
+                        if (k <= m) {
+                            v = cmul(vel[k], Hf[k]);
+                            if (k == 0 || k == m) v = make_double2(v.x, 0.);
+                            else v = cscale(v, 2.);
+                            if (n0 != 0) {
+                                unsigned kn = ((unsigned)k * (unsigned)n0) % LL;
+                                v = cmul(v, cconj(E[2 * kn]));
+                            }
+                            v = cmul(v, Ci[k]);
+                        }
+                        x[k] = v;
+                    }
+                    __syncthreads();
+                    czt_convolve(x, FFT_LOG2_MAX, Bi, tw);
+                    int np = min(P, L - n0);
+                    for (int n = threadIdx.x; n < np; n += blockDim.x) {
+                        double2 u = cmul(x[n], Ci[n]);
+                        gtmp[n0 + n] = u.x * (1.0 / M) * scale;
+                    }
+                    __syncthreads();
+                }
+                for (int j = threadIdx.x; j < M; j += blockDim.x)
+                    x[j] = (j < m) ? make_double2(gtmp[2 * j], gtmp[2 * j + 1]) : make_double2(0., 0.);
+                __syncthreads();
+                fft_dif(x, FFT_LOG2_MAX, tw, false);
+                const double nrm = 1.0 / (8.0 * M);
+                for (int k = threadIdx.x; k <= M / 2; k += blockDim.x) {
+                    int p = bitrev(k, FFT_LOG2_MAX), q = (k == 0) ? p : bitrev(M - k, FFT_LOG2_MAX);
+                    double2 A = x[p], Bc = cconj(x[q]);
+                    double2 Ee = cadd(A, Bc), D = csub(A, Bc);
+                    double2 O = make_double2(D.y, -D.x);
+                    double2 wO = cmul(w16[k], O);
+                    double2 Xk = cscale(cadd(Ee, wO), nrm), Xm = cscale(cconj(csub(Ee, wO)), nrm);
+                    if (k == 0) { Xk.y = 0.; Xm.y = 0.; }
+                    G[k] = Xk;
+                    G[M - k] = Xm;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel: one (candidate event, channel) item per block iteration, trace lengths L <= FFT_MAX and N <= FFT_MAX / 2.
+//   S[n] (LDS, real, period L) = sum over the channel's rays and on-sky components of
+//                                vfac * (N-point field in the time domain, with sub-sample shift) placed at the start bin
+//   V = S (*)_L g  through ONE real 2 FFT_MAX-point transform pair (packed complex FFT_MAX-point FFTs in LDS):
+//       rfft(S zero-padded) * G  ->  irfft  ->  V[n] = y[n] + y[n + L]
+//   |V| >= threshold (last sample excluded, see majority logic)
+// Mathematically the reference's rfft_L / * VEL / sum / * filter / irfft_L (efieldToVoltageConverter.py:214-341 and
+// channelBandPassFilter), without any length-L transform per item.  LDS: FFT_MAX complex (128 KB); the N/2-point field
+// buffer and the amplitude array live in its upper half until the big transform starts.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+channel_conv_kernel(int n_items, const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
+                    const int* __restrict__ ev_len_index, StationDev st, int ask_model, double threshold,
+                    const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab, int log2nh,
+                    ChannelOut out, int exact)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int M = FFT_MAX;
+    const int N = st.N, nh = N / 2;
+    double2* z = (double2*)smem;
+    double* S = (double*)smem;
+    double2* xs = z + M / 2;
+    double* amp = (double*)(xs + nh);
+    __shared__ RayShared rs;
+    __shared__ double red[512];
+    __shared__ int s_trig;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
+        const int L = ev.L[e], il = ev_len_index[e];
+        if (L > M) continue;  // long traces: chirp-z kernel
+        const double t_min = ev.t_min[e];
+        const double res = 1. / st.fs;
+        const int am = st.ant_model[ch];
+        const double2* G = tab.G + ((long)il * 2 + am) * NRHIP_G_STRIDE;
+        int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
+        if (!exact) {
+            // Cauchy-Schwarz: |V(t)| <= ||g||_2 sum_r |vfac_r| ||e_r||_2 -- nothing to transform if that stays below threshold
+            double cs = 0.;
+            for (int r = r0; r < r1; r++) {
+                if (w.ch[r] != ch) continue;
+                const double* T = w.vel_T + 4 * (long)r;
+                const double th_a = w.theta_ant[r];
+                const double dir = (am == 0) ? sin(th_a) : sin(th_a) * sin(th_a);
+                const double Tt = (am == 0) ? T[0] : T[1], Tp = (am == 0) ? T[2] : T[3];
+                cs += w.e_norm[r] * (fabs(Tt * dir * w.pol_theta[r]) * cabs2(w.r_theta[r]) +
+                                     fabs(Tp * dir * w.pol_phi[r]) * cabs2(w.r_phi[r]));
+            }
+            double bnd = cs * tab.hnorm[(long)il * 2 + am];
+            if (!(bnd * (1 + 1e-9) >= threshold)) {
+                if (threadIdx.x == 0) out.maxV[item] = -bnd;
+                continue;
+            }
+        }
+        for (int n = threadIdx.x; n < L; n += blockDim.x) S[n] = 0.;
+        if (threadIdx.x == 0) s_trig = 0;
+        __syncthreads();
+        int n_used = 0;
+        for (int r = r0; r < r1; r++) {
+            if (w.ch[r] != ch) continue;
+            n_used++;
+            if (threadIdx.x == 0) rs.ask = w.ask[r];
+            for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
+            __syncthreads();
+            fill_amplitude(amp, st, rs);
+            // start bin and sub-sample remainder (efieldToVoltageConverter.py:214-218)
+            double start_time = w.t0[r] - t_min + st.cable[ch] + 0;
+            long start_bin = (long)rint(start_time / res);
+            const int sbin = (int)(((start_bin % (long)L) + (long)L) % (long)L);
+            double rem = start_time - start_bin * res;
+            bool shift = !(fabs(rint(rem * st.fs) - rem * st.fs) < 1e-5);
+            const double* T = w.vel_T + 4 * (long)r;
+            const double th_a = w.theta_ant[r];
+            const double dir = (am == 0) ? sin(th_a) : sin(th_a) * sin(th_a);
+            const double Tt = (am == 0) ? T[0] : T[1], Tp = (am == 0) ? T[2] : T[3];
+            const double wt = fabs(Tt * dir * w.pol_theta[r]) * cabs2(w.r_theta[r]);
+            const double wp = fabs(Tp * dir * w.pol_phi[r]) * cabs2(w.r_phi[r]);
+            for (int comp = 0; comp < 2; comp++) {
+                double pol = comp ? w.pol_phi[r] : w.pol_theta[r];
+                double2 rc = comp ? w.r_phi[r] : w.r_theta[r];
+                double vfac = (comp ? Tp : Tt) * dir;
+                if ((comp ? wp : wt) <= 1e-13 * (comp ? wt : wp)) continue;
+                field_time_domain(xs, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
+                const double c = vfac / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
+                for (int j = threadIdx.x; j < nh; j += blockDim.x) {
+                    double2 y = xs[bitrev(j, log2nh)];
+                    int i0 = sbin + 2 * j;
+                    if (i0 >= L) i0 -= L;
+                    int i1 = i0 + 1;
+                    if (i1 >= L) i1 -= L;
+                    S[i0] += y.x * c;
+                    S[i1] += y.y * c;
+                }
+                __syncthreads();
+            }
+        }
+        double vmax = 0.;
+        int trig = 0;
+        if (n_used > 0) {
+            for (int n = L + threadIdx.x; n < 2 * M; n += blockDim.x) S[n] = 0.;
+            __syncthreads();
+            fft_dif_t<FFT_LOG2_MAX, 512>(z, tw, false);
+            // split the packed transform into the real one, multiply with G, merge back -- in place on the
+            // bit-reversed positions of the pairs (k, M - k)
+            for (int k = threadIdx.x; k <= M / 2; k += blockDim.x) {
+                const int p = bitrev(k, FFT_LOG2_MAX), q = (k == 0) ? p : bitrev(M - k, FFT_LOG2_MAX);
+                const double2 A = z[p], Bc = cconj(z[q]);
+                const double2 Ee = cadd(A, Bc), D = csub(A, Bc);
+                const double2 O = make_double2(D.y, -D.x);
+                const double2 wk = w16[k];
+                const double2 wO = cmul(wk, O);
+                const double2 Yk = cmul(cadd(Ee, wO), G[k]);
+                const double2 Ymc = cconj(cmul(cconj(csub(Ee, wO)), G[M - k]));
+                const double2 E2 = cadd(Yk, Ymc);
+                const double2 D2 = cmul(csub(Yk, Ymc), cconj(wk));
+                z[p] = make_double2(E2.x - D2.y, E2.y + D2.x);
+                if (q != p) z[q] = make_double2(E2.x + D2.y, D2.x - E2.y);
+            }
+            __syncthreads();
+            fft_dit_t<FFT_LOG2_MAX, 512>(z, tw, true);
+            for (int n = threadIdx.x; n < L; n += blockDim.x) {
+                double v = S[n] + S[n + L];
+                if (out.trace) out.trace[out.trace_offset[item] + n] = v;
+                double av = fabs(v);
+                vmax = fmax(vmax, av);
+                if (n < L - 1 && av >= threshold) trig = 1;
+            }
+        }
+        if (trig) s_trig = 1;
+        double vm = block_max(vmax, red);
+        if (threadIdx.x == 0) {
+            out.maxV[item] = vm;
+            if (s_trig) out.triggered[e] = 1;
+        }
+        __syncthreads();
     }
 }
 
@@ -897,7 +1095,7 @@ __global__ void __launch_bounds__(512)
 channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                const int* __restrict__ ev_len_index, StationDev st, FilterSet fl, int ask_model, double threshold,
                const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
-               ChannelOut out, int exact)
+               ChannelOut out, int exact, int skip_upto)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M = FFT_MAX, N = st.N, nh = N / 2;
@@ -911,6 +1109,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
         const int L = ev.L[e], m = L / 2, il = ev_len_index[e];
+        if (L <= skip_upto) continue;  // done by channel_conv_kernel
         const double t_min = ev.t_min[e];
         const double res = 1. / st.fs;
         const double2* Bf = tab.B_fwd + (long)il * M;
@@ -1354,32 +1553,41 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)length_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               FFT_MAX * 16 + (FFT_MAX / 2 + 1) * 8);
+    (void)hipFuncSetAttribute((const void*)channel_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)efield_channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipGetLastError();
     g_attr_set = true;
 }
 void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet& fl,
-                          const double2* tw, const LengthTables& tab)
+                          const double2* tw, const double2* w16, const LengthTables& tab)
 {
     if (n_len <= 0) return;
     set_big_lds();
     int grid = n_len < 256 ? n_len : 256;
-    hipLaunchKernelGGL(length_tables_kernel, dim3(grid), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lengths, st, fl, tw, tab);
+    hipLaunchKernelGGL(length_tables_kernel, dim3(grid), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lengths, st, fl, tw, w16, tab);
 }
 int channel_grid_blocks() { return 256; }
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
-                    double threshold, const double2* tw, const LengthTables& tab, double2* scratch, const ChannelOut& out,
-                    int exact)
+                    double threshold, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
+                    const ChannelOut& out, int exact, int max_length)
 {
     if (n_items <= 0) return;
     set_big_lds();
     int nh = st.N / 2;
-    size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
     int grid = n_items < channel_grid_blocks() ? n_items : channel_grid_blocks();
+    // traces up to FFT_MAX samples: one real convolution per item; longer ones (or NRHIP_CHANNEL_CZT=1): chirp-z per ray
+    int skip_upto = 0;
+    if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT")) {
+        hipLaunchKernelGGL(channel_conv_kernel, dim3(grid), dim3(512), (size_t)FFT_MAX * 16, s, n_items, item_event, w, evin,
+                           ev, ev_len_index, st, ask_model, threshold, tw, w16, tab, ilog2(nh), out, exact);
+        skip_upto = FFT_MAX;
+        if (max_length <= FFT_MAX) return;
+    }
+    size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
     hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
-                       ask_model, threshold, tw, tab, scratch, ilog2(nh), out, exact);
+                       ask_model, threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto);
 }
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,

@@ -253,3 +253,18 @@ def test_simulate_events_edge_cases(gpu_ctx_factory):
         nuradiomc_amd.Station(ctx, bench.CHANNELS, antenna='createLPDA_100MHz_InfFirn')
     with pytest.raises(NotImplementedError):
         nuradiomc_amd.Context(bench.ICE, 'GL3')
+
+
+@pytest.mark.parametrize('name,n_events', [('N256', 200), ('N256_hpol', 150), ('N4096', 60)])
+def test_channel_kernels_agree(gpu_ctx_factory, name, n_events, monkeypatch):
+    """Traces up to 8192 samples go through one real convolution per channel (channel_conv_kernel), longer ones through
+    the per-ray chirp-z kernel; NRHIP_CHANNEL_CZT=1 sends everything through the latter.  Same traces, same decisions."""
+    g, ctx, st, trig_a, stats_a, kL = _run_fixture(gpu_ctx_factory, name, n_events)
+    tr_a, mv_a, off = st.fetch('trace').copy(), st.fetch('item_maxV').copy(), st.fetch('trace_offset').copy()
+    monkeypatch.setenv('NRHIP_CHANNEL_CZT', '1')
+    g, ctx, st, trig_b, stats_b, kL = _run_fixture(gpu_ctx_factory, name, n_events)
+    tr_b, mv_b = st.fetch('trace'), st.fetch('item_maxV')
+    assert np.array_equal(trig_a, trig_b)
+    assert len(tr_a) == len(tr_b) == off[-1] and len(mv_a) > 0
+    assert np.max(np.abs(tr_a - tr_b)) <= 1e-9 * np.max(np.abs(tr_b))
+    assert np.max(np.abs(mv_a - mv_b)) <= 1e-9 * np.max(np.abs(mv_b))
