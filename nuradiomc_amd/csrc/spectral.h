@@ -113,7 +113,7 @@ void launch_active_class_flags(hipStream_t s, int n_rays, const int* active, con
 void launch_scatter_active_class(hipStream_t s, int n_rays, const int* flags, const int* offset, int* list);
 void launch_efield_max(hipStream_t s, int n_active, const int* active_list, const RayWork& w, const EventIn& evin,
                        const StationDev& st, int ask_model, const double2* tw, double min_efield, int exact,
-                       double* max_efield);
+                       double* max_efield, int* need_fft, int* need_offset, int* scan_tmp, int* fft_list);
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev);
 void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet& fl,

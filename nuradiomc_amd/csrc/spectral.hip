@@ -577,47 +577,78 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
 // rays all stay below the candidate cut even un-attenuated can never become candidates (simulation.py:283-285), so
 // their rays skip the attenuation quadrature and the time-domain transform.  One block per ray.
 // ---------------------------------------------------------------------------------------------------------
+#define AB_RT 4  // rays per wave and pass: the frequency-grid tables are loaded once for AB_RT rays
 __global__ void __launch_bounds__(256)
 amp_bound_kernel(int n_rays, RayWork w, StationDev st, const double* __restrict__ vertex, double* __restrict__ bound,
                  double* __restrict__ max_efield)
 {
-    __shared__ double ub[4][NRHIP_MAX_NFC];  // per wave: upper bounds of the coarse attenuation factors
-    __shared__ double ub_slope[4][NRHIP_MAX_NFC];
+    __shared__ double ub[4][AB_RT][NRHIP_MAX_NFC];  // per wave and ray: upper bounds of the coarse attenuation factors
+    __shared__ double ub_slope[4][AB_RT][NRHIP_MAX_NFC];
     __shared__ double s_xp[NRHIP_MAX_NFC];
     for (int j = threadIdx.x; j < st.n_fc; j += blockDim.x) s_xp[j] = st.fcoarse[j];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nh = st.N / 2;
+    const int nh = st.N / 2, stride = nh + 1;
     const double df = 1.0 / (st.N * (1. / st.fs));
-    const int n_iter = (n_rays + gridDim.x * 4 - 1) / (gridDim.x * 4);
+    const int per_pass = gridDim.x * 4 * AB_RT;
+    const int n_iter = (n_rays + per_pass - 1) / per_pass;
     for (int it = 0; it < n_iter; it++) {
-        const int r = (it * gridDim.x + blockIdx.x) * 4 + wv;
-        const bool ok = r < n_rays;
+        const int rb = ((it * gridDim.x + blockIdx.x) * 4 + wv) * AB_RT;
         // attenuation factor <= exp(-int ds / L) <= exp(-D / L_max(f)); 0.95 covers the reference's 1e-2 quadrature
         // tolerance; linear interpolation of upper bounds bounds the interpolated attenuation
-        if (lane < st.n_fc) {
-            double u = 0.;
-            if (ok) {
-                double zlo = fmin(vertex[3 * (long)w.ev[r] + 2], st.pos[3 * w.ch[r] + 2]);  // deepest point of the path
-                u = (zlo >= -st.att_bound_depth) ? exp(-0.95 * w.R[r] * st.inv_lmax[lane]) : 1.;
+        for (int i = 0; i < AB_RT; i++) {
+            const int r = rb + i;
+            if (lane < st.n_fc) {
+                double u = 0.;
+                if (r < n_rays) {
+                    double zlo = fmin(vertex[3 * (long)w.ev[r] + 2], st.pos[3 * w.ch[r] + 2]);  // deepest point of the path
+                    u = (zlo >= -st.att_bound_depth) ? exp(-0.95 * w.R[r] * st.inv_lmax[lane]) : 1.;
+                }
+                ub[wv][i][lane] = u;
             }
-            ub[wv][lane] = u;
         }
         __syncthreads();
-        if (lane < st.n_fc - 1) ub_slope[wv][lane] = (ub[wv][lane + 1] - ub[wv][lane]) / (s_xp[lane + 1] - s_xp[lane]);
+        for (int i = 0; i < AB_RT; i++)
+            if (lane < st.n_fc - 1)
+                ub_slope[wv][i][lane] = (ub[wv][i][lane + 1] - ub[wv][i][lane]) / (s_xp[lane + 1] - s_xp[lane]);
         __syncthreads();
-        if (ok) {
-            const AskaryanConst a = w.ask[r];
-            double part = 0.;
-            for (int k = 1 + lane; k < nh; k += 64) {
-                double f = k * df;
-                part += amplitude_bin(k, f, a, st) * interp_seg(f, st.seg[k], st.n_fc, s_xp, ub[wv], ub_slope[wv]);
+        if (rb < n_rays) {
+            AskaryanConst a[AB_RT];
+            bool all2009 = true;
+            for (int i = 0; i < AB_RT; i++) {
+                a[i] = w.ask[min(rb + i, n_rays - 1)];
+                all2009 = all2009 && (a[i].model == 0);
             }
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            if (lane == 0) {
-                double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
-                double b = efield_bound(part, st.N, st.fs, cmax);
-                bound[r] = b;
-                max_efield[r] = -b;  // "not evaluated, at most b" until efield_max_kernel overwrites it
+            double part[AB_RT];
+            for (int i = 0; i < AB_RT; i++) part[i] = 0.;
+            for (int k = 1 + lane; k < nh; k += 64) {
+                const double f = k * df;
+                const int lo = st.seg[k];
+                const bool below = f <= s_xp[0], above = f >= s_xp[st.n_fc - 1];
+                const double dx = f - s_xp[lo];
+                if (all2009) {
+                    const double ph = st.fpow[k], pe = st.fpow[stride + k], pr = st.fpow[2 * stride + k];
+#pragma unroll
+                    for (int i = 0; i < AB_RT; i++) {
+                        double x = (a[i].had ? ph : pe) * a[i].cL, y = pr * a[i].cR;
+                        double amp = a[i].pref2 * f / ((1 + x) * (1 + y));
+                        double t = below ? ub[wv][i][0] : (above ? ub[wv][i][st.n_fc - 1] : ub_slope[wv][i][lo] * dx + ub[wv][i][lo]);
+                        part[i] += amp * t;
+                    }
+                } else {
+                    for (int i = 0; i < AB_RT; i++)
+                        part[i] += amplitude_bin(k, f, a[i], st) * interp_seg(f, lo, st.n_fc, s_xp, ub[wv][i], ub_slope[wv][i]);
+                }
+            }
+            for (int i = 0; i < AB_RT; i++) {
+                double pt = part[i];
+                for (int off = 32; off > 0; off >>= 1) pt += __shfl_xor(pt, off);
+                const int r = rb + i;
+                if (lane == 0 && r < n_rays) {
+                    double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
+                    double b = efield_bound(pt, st.N, st.fs, cmax);
+                    bound[r] = b;
+                    max_efield[r] = -b;  // "not evaluated, at most b" until efield_max_kernel overwrites it
+                }
             }
         }
         __syncthreads();
@@ -677,10 +708,102 @@ __global__ void scatter_active_class_kernel(int n_rays, const int* __restrict__ 
 // components proportional to one real pulse: a single transform serves both.
 // LDS: N/2 complex + (N/2 + 1) doubles.
 // ---------------------------------------------------------------------------------------------------------
+// kernel: with attenuation known, the sum-of-magnitudes bound on max |E(t)| and the L2 norm of the unit-polarisation
+// pulse of every active ray (one wave per AB_RT rays, frequency-grid tables loaded once per AB_RT rays).  Rays whose bound
+// stays below the cut report the negated bound; the others are flagged for the time-domain transform.
 __global__ void __launch_bounds__(256)
-efield_max_kernel(int n_active, const int* __restrict__ active_list, RayWork w, EventIn evin, StationDev st,
-                  int ask_model, const double2* __restrict__ tw, int log2nh, double min_efield, int exact,
-                  double* __restrict__ max_efield)
+efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w, StationDev st, double min_efield,
+                    int exact, double* __restrict__ max_efield, int* __restrict__ need_fft)
+{
+    __shared__ double at[4][AB_RT][NRHIP_MAX_NFC];
+    __shared__ double at_slope[4][AB_RT][NRHIP_MAX_NFC];
+    __shared__ double s_xp[NRHIP_MAX_NFC];
+    for (int j = threadIdx.x; j < st.n_fc; j += blockDim.x) s_xp[j] = st.fcoarse[j];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nh = st.N / 2, stride = nh + 1;
+    const double df = 1.0 / (st.N * (1. / st.fs));
+    const int per_pass = gridDim.x * 4 * AB_RT;
+    const int n_iter = (n_active + per_pass - 1) / per_pass;
+    for (int it = 0; it < n_iter; it++) {
+        const int ib = ((it * gridDim.x + blockIdx.x) * 4 + wv) * AB_RT;
+        int rr[AB_RT];
+        for (int i = 0; i < AB_RT; i++) rr[i] = active_list[min(ib + i, n_active - 1)];
+        for (int i = 0; i < AB_RT; i++)
+            if (lane < st.n_fc) at[wv][i][lane] = w.att[(long)rr[i] * st.n_fc + lane];
+        __syncthreads();
+        for (int i = 0; i < AB_RT; i++)
+            if (lane < st.n_fc - 1)
+                at_slope[wv][i][lane] = (at[wv][i][lane + 1] - at[wv][i][lane]) / (s_xp[lane + 1] - s_xp[lane]);
+        __syncthreads();
+        if (ib < n_active) {
+            AskaryanConst a[AB_RT];
+            bool all2009 = true;
+            for (int i = 0; i < AB_RT; i++) {
+                a[i] = w.ask[rr[i]];
+                all2009 = all2009 && (a[i].model == 0);
+            }
+            double part[AB_RT], sq[AB_RT];
+            for (int i = 0; i < AB_RT; i++) part[i] = sq[i] = 0.;
+            for (int k = 1 + lane; k < nh; k += 64) {
+                const double f = k * df;
+                const int lo = st.seg[k];
+                const bool below = f <= s_xp[0], above = f >= s_xp[st.n_fc - 1];
+                const double dx = f - s_xp[lo];
+                double ph = 0., pe = 0., pr = 0.;
+                if (all2009) { ph = st.fpow[k]; pe = st.fpow[stride + k]; pr = st.fpow[2 * stride + k]; }
+#pragma unroll
+                for (int i = 0; i < AB_RT; i++) {
+                    double amp;
+                    if (all2009) {
+                        double x = (a[i].had ? ph : pe) * a[i].cL, y = pr * a[i].cR;
+                        amp = a[i].pref2 * f / ((1 + x) * (1 + y));
+                    } else {
+                        amp = askaryan_amplitude(f, st.lnf[k], a[i]);
+                    }
+                    double t = below ? at[wv][i][0] : (above ? at[wv][i][st.n_fc - 1] : at_slope[wv][i][lo] * dx + at[wv][i][lo]);
+                    double v = amp * t;
+                    part[i] += v;
+                    sq[i] += v * v;
+                }
+            }
+            for (int i = 0; i < AB_RT; i++) {
+                double pt = part[i], s2 = sq[i];
+                for (int off = 32; off > 0; off >>= 1) {
+                    pt += __shfl_xor(pt, off);
+                    s2 += __shfl_xor(s2, off);
+                }
+                if (lane == 0 && ib + i < n_active) {
+                    const int r = rr[i];
+                    // Parseval: sum_t s(t)^2 = (fs^2 / 2) (1 / N) 2 sum_k |G_k|^2 with |G_k| = sqrt(2) amp_k
+                    w.e_norm[r] = sqrt((st.fs * st.fs / st.N) * 2. * s2);
+                    double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
+                    double bnd = efield_bound(pt, st.N, st.fs, cmax);
+                    bool need = exact || (bnd * (1 + 1e-6) > min_efield);
+                    max_efield[r] = -bnd;
+                    need_fft[ib + i] = need ? 1 : 0;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void scatter_fft_list_kernel(int n_active, const int* __restrict__ active_list, const int* __restrict__ need,
+                                        const int* __restrict__ offset, int* __restrict__ fft_list)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_active) return;
+    if (need[i]) fft_list[offset[i]] = active_list[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel: max |E(t)| of the rays the bound could not decide (candidate cut, simulation.py:283-285): one block per listed
+// ray, N-point field in the time domain.  Real reflection coefficients make both on-sky components proportional to one
+// real pulse: a single transform serves both.  LDS: N/2 complex + (N/2 + 1) doubles.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ fft_list, RayWork w, EventIn evin, StationDev st,
+                  int ask_model, const double2* __restrict__ tw, int log2nh, double* __restrict__ max_efield)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2;
@@ -688,30 +811,18 @@ efield_max_kernel(int n_active, const int* __restrict__ active_list, RayWork w, 
     double* amp = (double*)(x + nh);
     __shared__ RayShared rs;
     __shared__ double red[256];
-    for (int ia = blockIdx.x; ia < n_active; ia += gridDim.x) {
-        const int r = active_list[ia];
+    const int n_fft = *n_list;
+    for (int ia = blockIdx.x; ia < n_fft; ia += gridDim.x) {
+        const int r = fft_list[ia];
         if (threadIdx.x == 0) rs.ask = w.ask[r];
         for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
         __syncthreads();
-        double part = fill_amplitude(amp, st, rs);
-        double sum = block_sum(part, red);
-        {   // Parseval: sum_t s(t)^2 = (fs^2 / 2) (1 / N) 2 sum_k |G_k|^2 with |G_k| = sqrt(2) amp_k
-            double p2 = 0.;
-            for (int k = threadIdx.x; k <= nh; k += blockDim.x) p2 += amp[k] * amp[k];
-            double s2 = block_sum(p2, red);
-            if (threadIdx.x == 0) w.e_norm[r] = sqrt((st.fs * st.fs / N) * 2. * s2);
-        }
+        fill_amplitude(amp, st, rs);
         const double2 rt = w.r_theta[r], rp = w.r_phi[r];
         const double pt = w.pol_theta[r], pp = w.pol_phi[r];
-        double cmax = fmax(fabs(pt) * cabs2(rt), fabs(pp) * cabs2(rp));
-        double bnd = efield_bound(sum, N, st.fs, cmax);
-        if (!exact && !(bnd * (1 + 1e-6) > min_efield)) {
-            if (threadIdx.x == 0) max_efield[r] = -bnd;
-            continue;
-        }
+        const bool both_real = (rt.y == 0. && rp.y == 0.);
         double mx = 0.;
         const double scale = st.fs / 1.4142135623730951 / nh;
-        const bool both_real = (rt.y == 0. && rp.y == 0.);
         if (both_real) {
             field_time_domain(x, amp, N, log2nh, st.fs, 1.0, make_double2(1., 0.), 0., false, ask_model,
                               floor(2.0 * st.fs), tw);
@@ -1498,8 +1609,8 @@ void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const Station
                       double* max_efield)
 {
     if (n_rays <= 0) return;
-    int grid = (n_rays + 3) / 4;
-    if (grid > 256 * 64) grid = 256 * 64;
+    int grid = (n_rays + 4 * AB_RT - 1) / (4 * AB_RT);
+    if (grid > 256 * 32) grid = 256 * 32;
     hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, vertex, bound, max_efield);
 }
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
@@ -1529,14 +1640,22 @@ void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const i
 }
 void launch_efield_max(hipStream_t s, int n_active, const int* active_list, const RayWork& w, const EventIn& evin,
                        const StationDev& st, int ask_model, const double2* tw, double min_efield, int exact,
-                       double* max_efield)
+                       double* max_efield, int* need_fft, int* need_offset, int* scan_tmp, int* fft_list)
 {
     if (n_active <= 0) return;
     int nh = st.N / 2;
+    int gridA = (n_active + 4 * AB_RT - 1) / (4 * AB_RT);
+    if (gridA > 256 * 32) gridA = 256 * 32;
+    hipLaunchKernelGGL(efield_bound_kernel, dim3(gridA), dim3(256), 0, s, n_active, active_list, w, st, min_efield, exact,
+                       max_efield, need_fft);
+    (void)hipMemsetAsync(need_fft + n_active, 0, sizeof(int), s);
+    launch_exclusive_scan(s, (long)n_active + 1, need_fft, need_offset, scan_tmp);
+    hipLaunchKernelGGL(scatter_fft_list_kernel, dim3(grid_for(n_active, 256)), dim3(256), 0, s, n_active, active_list,
+                       need_fft, need_offset, fft_list);
     size_t lds = (size_t)nh * 16 + (size_t)(nh + 1) * 8;
     int grid = n_active < 256 * 16 ? n_active : 256 * 16;
-    hipLaunchKernelGGL(efield_max_kernel, dim3(grid), dim3(256), lds, s, n_active, active_list, w, evin, st, ask_model, tw,
-                       ilog2(nh), min_efield, exact, max_efield);
+    hipLaunchKernelGGL(efield_max_kernel, dim3(grid), dim3(256), lds, s, need_offset + n_active, fft_list, w, evin, st,
+                       ask_model, tw, ilog2(nh), max_efield);
 }
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev)

@@ -183,10 +183,16 @@ def test_pruning_changes_no_result(gpu_ctx_factory, name, n_events):
     assert np.array_equal(C['item_maxV'][ex], A['item_maxV'][ex])
     assert np.all(-C['item_maxV'][~ex] * (1 + 1e-9) >= A['item_maxV'][~ex])
     assert np.all(-C['item_maxV'][~ex] < 3.0 * st.vrms)
+    # per ray: negative = "at most", positive = exact or "at least" (samples next to the pulse centre already above
+    # the cut); either way on the same side of the cut as the exact maximum
     exr = C['ray_max_efield'] >= 0
-    assert np.allclose(C['ray_max_efield'][exr], A['ray_max_efield'][exr], rtol=1e-12, atol=0)
+    cut = 2.0 * st.vrms_efield
+    assert np.all(C['ray_max_efield'][exr] <= A['ray_max_efield'][exr] * (1 + 1e-9))
+    assert np.array_equal(C['ray_max_efield'][exr] > cut, A['ray_max_efield'][exr] > cut)
     assert np.all(-C['ray_max_efield'][~exr] * (1 + 1e-6) >= A['ray_max_efield'][~exr])
-    print(name, 'channels evaluated exactly: %d of %d' % (ex.sum(), len(ex)), 'rays: %d of %d' % (exr.sum(), len(exr)))
+    n_lb = (C['ray_max_efield'][exr] < A['ray_max_efield'][exr] * (1 - 1e-9)).sum()
+    print(name, 'channels evaluated exactly: %d of %d' % (ex.sum(), len(ex)),
+          'rays: %d of %d (of which %d by the lower bound)' % (exr.sum(), len(exr), n_lb))
 
 
 def test_pruning_rigorous_on_survey_sample(gpu_ctx_factory):
@@ -214,6 +220,9 @@ def test_pruning_rigorous_on_survey_sample(gpu_ctx_factory):
     assert np.all(B['ray_bound'] * (1 + 1e-6) >= A['ray_max_efield'])
     skipped = B['ray_max_efield'] < 0
     assert np.all(-B['ray_max_efield'][skipped] * (1 + 1e-6) >= A['ray_max_efield'][skipped])
+    cut = 2.0 * st.vrms_efield
+    assert np.all(B['ray_max_efield'][~skipped] <= A['ray_max_efield'][~skipped] * (1 + 1e-9))
+    assert np.array_equal(B['ray_max_efield'][~skipped] > cut, A['ray_max_efield'][~skipped] > cut)
     sk = B['item_maxV'] < 0
     assert sk.mean() > 0.3
     assert np.all(-B['item_maxV'][sk] * (1 + 1e-9) >= A['item_maxV'][sk])
