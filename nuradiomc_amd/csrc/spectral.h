@@ -122,7 +122,8 @@ int channel_grid_blocks();
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     double threshold, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
-                    const ChannelOut& out, int exact, int max_length);
+                    const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
+                    int* item_list);
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,
                            const double2* tw, const LengthTables& tab, double2* scratch, double* V);

@@ -1057,6 +1057,52 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// kernel: one thread per (candidate event, channel) item -- Cauchy-Schwarz prefilter.  The channel trace is
+// sum_r vfac_r (e_r (*) g), so |V(t)| <= ||g||_2 sum_r |vfac_r| ||e_r||_2.  Items that cannot reach the threshold report the
+// negated bound; the others are flagged for channel_conv_kernel (L <= FFT_MAX only; longer traces stay with channel_kernel).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+channel_prefilter_kernel(int n_items, const int* __restrict__ item_event, RayWork w, EventOut ev,
+                         const int* __restrict__ ev_len_index, StationDev st, double threshold, const double* __restrict__ hnorm,
+                         int exact, double* __restrict__ maxV, int* __restrict__ need)
+{
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items) return;
+    const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
+    const int L = ev.L[e], il = ev_len_index[e];
+    if (L > FFT_MAX) { need[item] = 0; return; }
+    int flag = 1;
+    if (!exact) {
+        const int am = st.ant_model[ch];
+        const int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
+        double cs = 0.;
+        for (int r = r0; r < r1; r++) {
+            if (w.ch[r] != ch) continue;
+            const double* T = w.vel_T + 4 * (long)r;
+            const double th_a = w.theta_ant[r];
+            const double dir = (am == 0) ? sin(th_a) : sin(th_a) * sin(th_a);
+            const double Tt = (am == 0) ? T[0] : T[1], Tp = (am == 0) ? T[2] : T[3];
+            cs += w.e_norm[r] * (fabs(Tt * dir * w.pol_theta[r]) * cabs2(w.r_theta[r]) +
+                                 fabs(Tp * dir * w.pol_phi[r]) * cabs2(w.r_phi[r]));
+        }
+        const double bnd = cs * hnorm[(long)il * 2 + am];
+        if (!(bnd * (1 + 1e-9) >= threshold)) {
+            maxV[item] = -bnd;
+            flag = 0;
+        }
+    }
+    need[item] = flag;
+}
+
+__global__ void scatter_item_list_kernel(int n_items, const int* __restrict__ need, const int* __restrict__ offset,
+                                         int* __restrict__ list)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    if (need[i]) list[offset[i]] = i;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // kernel: one (candidate event, channel) item per block iteration, trace lengths L <= FFT_MAX and N <= FFT_MAX / 2.
 //   S[n] (LDS, real, period L) = sum over the channel's rays and on-sky components of
 //                                vfac * (N-point field in the time domain, with sub-sample shift) placed at the start bin
@@ -1068,7 +1114,8 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
 // buffer and the amplitude array live in its upper half until the big transform starts.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512)
-channel_conv_kernel(int n_items, const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
+channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list,
+                    const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                     const int* __restrict__ ev_len_index, StationDev st, int ask_model, double threshold,
                     const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab, int log2nh,
                     ChannelOut out, int exact)
@@ -1083,33 +1130,16 @@ channel_conv_kernel(int n_items, const int* __restrict__ item_event, RayWork w, 
     __shared__ RayShared rs;
     __shared__ double red[512];
     __shared__ int s_trig;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int n_list_items = *n_list;
+    for (int li = blockIdx.x; li < n_list_items; li += gridDim.x) {
+        const int item = item_list[li];
         const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
         const int L = ev.L[e], il = ev_len_index[e];
-        if (L > M) continue;  // long traces: chirp-z kernel
         const double t_min = ev.t_min[e];
         const double res = 1. / st.fs;
         const int am = st.ant_model[ch];
         const double2* G = tab.G + ((long)il * 2 + am) * NRHIP_G_STRIDE;
         int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
-        if (!exact) {
-            // Cauchy-Schwarz: |V(t)| <= ||g||_2 sum_r |vfac_r| ||e_r||_2 -- nothing to transform if that stays below threshold
-            double cs = 0.;
-            for (int r = r0; r < r1; r++) {
-                if (w.ch[r] != ch) continue;
-                const double* T = w.vel_T + 4 * (long)r;
-                const double th_a = w.theta_ant[r];
-                const double dir = (am == 0) ? sin(th_a) : sin(th_a) * sin(th_a);
-                const double Tt = (am == 0) ? T[0] : T[1], Tp = (am == 0) ? T[2] : T[3];
-                cs += w.e_norm[r] * (fabs(Tt * dir * w.pol_theta[r]) * cabs2(w.r_theta[r]) +
-                                     fabs(Tp * dir * w.pol_phi[r]) * cabs2(w.r_phi[r]));
-            }
-            double bnd = cs * tab.hnorm[(long)il * 2 + am];
-            if (!(bnd * (1 + 1e-9) >= threshold)) {
-                if (threadIdx.x == 0) out.maxV[item] = -bnd;
-                continue;
-            }
-        }
         for (int n = threadIdx.x; n < L; n += blockDim.x) S[n] = 0.;
         if (threadIdx.x == 0) s_trig = 0;
         __syncthreads();
@@ -1690,17 +1720,26 @@ int channel_grid_blocks() { return 256; }
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     double threshold, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
-                    const ChannelOut& out, int exact, int max_length)
+                    const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
+                    int* item_list)
 {
     if (n_items <= 0) return;
     set_big_lds();
     int nh = st.N / 2;
     int grid = n_items < channel_grid_blocks() ? n_items : channel_grid_blocks();
-    // traces up to FFT_MAX samples: one real convolution per item; longer ones (or NRHIP_CHANNEL_CZT=1): chirp-z per ray
+    // traces up to FFT_MAX samples: prefilter, then one real convolution per listed item; longer ones (or
+    // NRHIP_CHANNEL_CZT=1): chirp-z per ray
     int skip_upto = 0;
     if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT")) {
-        hipLaunchKernelGGL(channel_conv_kernel, dim3(grid), dim3(512), (size_t)FFT_MAX * 16, s, n_items, item_event, w, evin,
-                           ev, ev_len_index, st, ask_model, threshold, tw, w16, tab, ilog2(nh), out, exact);
+        hipLaunchKernelGGL(channel_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev,
+                           ev_len_index, st, threshold, tab.hnorm, exact, out.maxV, need);
+        (void)hipMemsetAsync(need + n_items, 0, sizeof(int), s);
+        launch_exclusive_scan(s, (long)n_items + 1, need, need_offset, scan_tmp);
+        hipLaunchKernelGGL(scatter_item_list_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, need, need_offset,
+                           item_list);
+        hipLaunchKernelGGL(channel_conv_kernel, dim3(grid), dim3(512), (size_t)FFT_MAX * 16, s, need_offset + n_items,
+                           item_list, item_event, w, evin, ev, ev_len_index, st, ask_model, threshold, tw, w16, tab, ilog2(nh),
+                           out, exact);
         skip_upto = FFT_MAX;
         if (max_length <= FFT_MAX) return;
     }
