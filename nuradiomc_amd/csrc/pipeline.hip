@@ -464,7 +464,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         double2* scratch;
         NEED(scratch = WS("channel_scratch", double2, (size_t)channel_grid_blocks() * NRHIP_SPEC_STRIDE));
         int *it_need, *it_off, *it_tmp, *it_list;
-        NEED(it_need = WS("item_need", int, (size_t)n_items + 1));
+        NEED(it_need = WS("item_need", int, (size_t)n_items + cand.size() + 2));
         NEED(it_off = WS("item_need_offset", int, (size_t)n_items + 1));
         NEED(it_tmp = WS("scan_tmp4", int, scan_tiles((long)n_items + 1)));
         NEED(it_list = WS("item_list", int, (size_t)n_items));

@@ -1102,6 +1102,16 @@ __global__ void scatter_item_list_kernel(int n_items, const int* __restrict__ ne
     if (need[i]) list[offset[i]] = i;
 }
 
+// candidate events with at least one channel left to evaluate (the unit of work of channel_conv_kernel)
+__global__ void channel_event_flags_kernel(int n_cand, int n_ch, const int* __restrict__ need, int* __restrict__ ev_need)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cand) return;
+    int any = 0;
+    for (int ch = 0; ch < n_ch; ch++) any |= need[c * n_ch + ch];
+    ev_need[c] = any;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // kernel: one (candidate event, channel) item per block iteration, trace lengths L <= FFT_MAX and N <= FFT_MAX / 2.
 //   S[n] (LDS, real, period L) = sum over the channel's rays and on-sky components of
@@ -1113,8 +1123,9 @@ __global__ void scatter_item_list_kernel(int n_items, const int* __restrict__ ne
 // channelBandPassFilter), without any length-L transform per item.  LDS: FFT_MAX complex (128 KB); the N/2-point field
 // buffer and the amplitude array live in its upper half until the big transform starts.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512)
-channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list,
+#define CONV_NT 512
+__global__ void __launch_bounds__(CONV_NT)
+channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list, const int* __restrict__ need,
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                     const int* __restrict__ ev_len_index, StationDev st, int ask_model, double threshold,
                     const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab, int log2nh,
@@ -1128,12 +1139,23 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     double2* xs = z + M / 2;
     double* amp = (double*)(xs + nh);
     __shared__ RayShared rs;
-    __shared__ double red[512];
+    __shared__ double red[CONV_NT];
     __shared__ int s_trig;
-    const int n_list_items = *n_list;
-    for (int li = blockIdx.x; li < n_list_items; li += gridDim.x) {
-        const int item = item_list[li];
-        const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
+    const int n_list_events = *n_list;
+    // unit of work: one candidate event; its channels are evaluated in sequence and -- the trigger being an OR over
+    // channels -- the remaining ones are skipped (maxV = NaN) once one has triggered, unless every trace is wanted
+    __shared__ int s_ev_trig;
+    for (int le = blockIdx.x; le < n_list_events; le += gridDim.x) {
+      if (threadIdx.x == 0) s_ev_trig = 0;
+      __syncthreads();
+      for (int ch = 0; ch < st.n_ch; ch++) {
+        const int item = item_list[le] * st.n_ch + ch;
+        if (!need[item]) continue;
+        const int e = item_event[item / st.n_ch];
+        if (!exact && s_ev_trig) {
+            if (threadIdx.x == 0) out.maxV[item] = NAN;
+            continue;
+        }
         const int L = ev.L[e], il = ev_len_index[e];
         const double t_min = ev.t_min[e];
         const double res = 1. / st.fs;
@@ -1187,7 +1209,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         if (n_used > 0) {
             for (int n = L + threadIdx.x; n < 2 * M; n += blockDim.x) S[n] = 0.;
             __syncthreads();
-            fft_dif_t<FFT_LOG2_MAX, 512>(z, tw, false);
+            fft_dif_t<FFT_LOG2_MAX, CONV_NT>(z, tw, false);
             // split the packed transform into the real one, multiply with G, merge back -- in place on the
             // bit-reversed positions of the pairs (k, M - k)
             for (int k = threadIdx.x; k <= M / 2; k += blockDim.x) {
@@ -1205,7 +1227,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 if (q != p) z[q] = make_double2(E2.x + D2.y, D2.x - E2.y);
             }
             __syncthreads();
-            fft_dit_t<FFT_LOG2_MAX, 512>(z, tw, true);
+            fft_dit_t<FFT_LOG2_MAX, CONV_NT>(z, tw, true);
             for (int n = threadIdx.x; n < L; n += blockDim.x) {
                 double v = S[n] + S[n + L];
                 if (out.trace) out.trace[out.trace_offset[item] + n] = v;
@@ -1218,9 +1240,10 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         double vm = block_max(vmax, red);
         if (threadIdx.x == 0) {
             out.maxV[item] = vm;
-            if (s_trig) out.triggered[e] = 1;
+            if (s_trig) { out.triggered[e] = 1; s_ev_trig = 1; }
         }
         __syncthreads();
+      }
     }
 }
 
@@ -1733,13 +1756,18 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT")) {
         hipLaunchKernelGGL(channel_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev,
                            ev_len_index, st, threshold, tab.hnorm, exact, out.maxV, need);
-        (void)hipMemsetAsync(need + n_items, 0, sizeof(int), s);
-        launch_exclusive_scan(s, (long)n_items + 1, need, need_offset, scan_tmp);
-        hipLaunchKernelGGL(scatter_item_list_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, need, need_offset,
+        const int n_cand = n_items / st.n_ch;
+        int* ev_need = need + n_items;  // [n_cand + 1]
+        hipLaunchKernelGGL(channel_event_flags_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, st.n_ch, need,
+                           ev_need);
+        (void)hipMemsetAsync(ev_need + n_cand, 0, sizeof(int), s);
+        launch_exclusive_scan(s, (long)n_cand + 1, ev_need, need_offset, scan_tmp);
+        hipLaunchKernelGGL(scatter_item_list_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, ev_need, need_offset,
                            item_list);
-        hipLaunchKernelGGL(channel_conv_kernel, dim3(grid), dim3(512), (size_t)FFT_MAX * 16, s, need_offset + n_items,
-                           item_list, item_event, w, evin, ev, ev_len_index, st, ask_model, threshold, tw, w16, tab, ilog2(nh),
-                           out, exact);
+        int cgrid = n_cand < channel_grid_blocks() ? n_cand : channel_grid_blocks();
+        hipLaunchKernelGGL(channel_conv_kernel, dim3(cgrid), dim3(CONV_NT), (size_t)FFT_MAX * 16, s, need_offset + n_cand,
+                           item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, threshold, tw, w16, tab,
+                           ilog2(nh), out, exact);
         skip_upto = FFT_MAX;
         if (max_length <= FFT_MAX) return;
     }
