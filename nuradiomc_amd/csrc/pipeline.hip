@@ -377,58 +377,55 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     // 5. common time grid per event
     launch_event_grid(sm, (int)n_events, n_ch, offset, w, sd, max_efield, cfg->min_efield_amplitude, ev);
     LCHK("event_grid");
-    std::vector<int> hL(n_events);
-    std::vector<unsigned char> hc(n_events);
-    HIPCHK(hipMemcpyAsync(hL.data(), ev.L, sizeof(int) * n_events, hipMemcpyDeviceToHost, sm));
-    HIPCHK(hipMemcpyAsync(hc.data(), ev.candidate, n_events, hipMemcpyDeviceToHost, sm));
+    // candidate list, distinct trace lengths and the per-event table index are built on the device; the host only
+    // learns the counts (and the few distinct lengths) it needs to size the next launches
+    const int n_half = NRHIP_SPEC_STRIDE;  // possible values of L / 2
+    int *cflag, *coff, *ctmp, *lflag, *loff, *ltmp, *d_lens, *d_len_index, *d_cand;
+    long long* d_ncr;
+    NEED(cflag = WS("cand_flag", int, n_events + 1));
+    NEED(coff = WS("cand_offset", int, n_events + 1));
+    NEED(ctmp = WS("scan_tmp5", int, scan_tiles(n_events + 1)));
+    NEED(lflag = WS("len_flag", int, n_half + 1));
+    NEED(loff = WS("len_offset", int, n_half + 1));
+    NEED(ltmp = WS("scan_tmp6", int, scan_tiles(n_half + 1)));
+    NEED(d_lens = WS("lengths", int, n_half));
+    NEED(d_len_index = WS("ev_len_index", int, n_events));
+    NEED(d_cand = WS("item_event", int, n_events));
+    NEED(d_ncr = WS("cand_ray_count", long long, 2));
+    HIPCHK(hipMemsetAsync(lflag, 0, sizeof(int) * (n_half + 1), sm));
+    HIPCHK(hipMemsetAsync(d_ncr, 0, 2 * sizeof(long long), sm));
+    launch_candidate_flags(sm, (int)n_events, n_half, ev, cflag, lflag, d_ncr);
+    launch_exclusive_scan(sm, n_events + 1, cflag, coff, ctmp);
+    launch_exclusive_scan(sm, n_half + 1, lflag, loff, ltmp);
+    launch_candidate_lists(sm, (int)n_events, n_half, ev, cflag, coff, lflag, loff, d_cand, d_len_index, d_lens);
+    LCHK("candidate lists");
+    int h_counts[2] = {0, 0};
+    long long h_ncr[2] = {0, 0};
+    std::vector<int> lens(n_half);
+    HIPCHK(hipMemcpyAsync(&h_counts[0], coff + n_events, sizeof(int), hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipMemcpyAsync(&h_counts[1], loff + n_half, sizeof(int), hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipMemcpyAsync(h_ncr, d_ncr, 2 * sizeof(long long), hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipMemcpyAsync(lens.data(), d_lens, sizeof(int) * n_half, hipMemcpyDeviceToHost, sm));
     HIPCHK(hipStreamSynchronize(sm));
+    const int n_cand = h_counts[0];
+    lens.resize(h_counts[1]);
+    st->ws_bytes["lengths"] = sizeof(int) * lens.size();
+    st->ws_bytes["item_event"] = sizeof(int) * (size_t)n_cand;
 
     MARK(6);
     MARK(7);
     MARK(8);
-    // host: candidate event list, distinct trace lengths
-    std::vector<int> cand;
-    cand.reserve(n_events / 8 + 16);
-    int maxL = 0;
-    for (int64_t e = 0; e < n_events; e++)
-        if (hc[e]) {
-            cand.push_back((int)e);
-            maxL = std::max(maxL, hL[e]);
-        }
-    S.n_candidate_events = (int64_t)cand.size();
+    const int maxL = h_ncr[1] > 0 ? (int)(2 * h_ncr[1]) : (lens.empty() ? 0 : lens.back());
+    S.n_candidate_events = n_cand;
     S.max_length = maxL;
-    st->h_lengths.clear();
-    if (!cand.empty()) {
+    S.n_candidate_rays = h_ncr[0];
+    st->h_lengths = lens;
+    if (n_cand > 0) {
         const int nh = sd.N / 2;
         const int m_max = std::min(FFT_MAX - nh + 1, NRHIP_SPEC_STRIDE - 1);
         if (maxL / 2 > m_max)
             return nrhip_fail_msg("nrhip_simulate_events: an event's common trace is longer than the 8192-point chirp-z supports");
-        std::vector<int> lens;
-        lens.reserve(cand.size());
-        for (int e : cand) lens.push_back(hL[e]);
-        std::sort(lens.begin(), lens.end());
-        lens.erase(std::unique(lens.begin(), lens.end()), lens.end());
-        std::vector<int> len_index(n_events, -1);
-        for (int e : cand) len_index[e] = (int)(std::lower_bound(lens.begin(), lens.end(), hL[e]) - lens.begin());
-        // items of equal length run back to back: their chirp / phase / filter tables stay in L2
-        std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return hL[a] < hL[b]; });
         S.n_distinct_lengths = (int64_t)lens.size();
-        st->h_lengths = lens;
-        int *d_lens, *d_len_index, *d_cand;
-        NEED(d_lens = WS("lengths", int, lens.size()));
-        NEED(d_len_index = WS("ev_len_index", int, n_events));
-        NEED(d_cand = WS("item_event", int, cand.size()));
-        HIPCHK(hipMemcpyAsync(d_lens, lens.data(), sizeof(int) * lens.size(), hipMemcpyHostToDevice, sm));
-        HIPCHK(hipMemcpyAsync(d_len_index, len_index.data(), sizeof(int) * n_events, hipMemcpyHostToDevice, sm));
-        HIPCHK(hipMemcpyAsync(d_cand, cand.data(), sizeof(int) * cand.size(), hipMemcpyHostToDevice, sm));
-        int64_t ncr = 0;
-        {
-            std::vector<int> hn(n_events);
-            HIPCHK(hipMemcpyAsync(hn.data(), ev.n_rays, sizeof(int) * n_events, hipMemcpyDeviceToHost, sm));
-            HIPCHK(hipStreamSynchronize(sm));
-            for (int e : cand) ncr += hn[e];
-        }
-        S.n_candidate_rays = ncr;
         MARK(6);
         LengthTables tab;
         NEED(tab.B_fwd = WS("tab_B_fwd", double2, lens.size() * (size_t)FFT_MAX));
@@ -444,7 +441,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         LCHK("length_tables");
         MARK(7);
         // 6. channel voltages + trigger
-        const int n_items = (int)cand.size() * n_ch;
+        const int n_items = n_cand * n_ch;
         S.n_channel_items = n_items;
         ChannelOut co;
         NEED(co.maxV = WS("item_maxV", double, n_items));
@@ -452,6 +449,10 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         co.trace = nullptr;
         co.trace_offset = nullptr;
         if (cfg->dump_traces) {
+            std::vector<int> hL(n_events), cand(n_cand);
+            HIPCHK(hipMemcpyAsync(hL.data(), ev.L, sizeof(int) * n_events, hipMemcpyDeviceToHost, sm));
+            HIPCHK(hipMemcpyAsync(cand.data(), d_cand, sizeof(int) * n_cand, hipMemcpyDeviceToHost, sm));
+            HIPCHK(hipStreamSynchronize(sm));
             std::vector<long> off(n_items + 1, 0);
             for (int i = 0; i < n_items; i++) off[i + 1] = off[i] + hL[cand[i / n_ch]];
             long* d_off;
@@ -464,7 +465,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         double2* scratch;
         NEED(scratch = WS("channel_scratch", double2, (size_t)channel_grid_blocks() * NRHIP_SPEC_STRIDE));
         int *it_need, *it_off, *it_tmp, *it_list;
-        NEED(it_need = WS("item_need", int, (size_t)n_items + cand.size() + 2));
+        NEED(it_need = WS("item_need", int, (size_t)n_items + n_cand + 2));
         NEED(it_off = WS("item_need_offset", int, (size_t)n_items + 1));
         NEED(it_tmp = WS("scan_tmp4", int, scan_tiles((long)n_items + 1)));
         NEED(it_list = WS("item_list", int, (size_t)n_items));

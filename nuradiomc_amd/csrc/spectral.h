@@ -116,6 +116,10 @@ void launch_efield_max(hipStream_t s, int n_active, const int* active_list, cons
                        double* max_efield, int* need_fft, int* need_offset, int* scan_tmp, int* fft_list);
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev);
+void launch_candidate_flags(hipStream_t s, int n_events, int n_half, const EventOut& ev, int* cflag, int* lflag,
+                            long long* n_cand_rays);  // n_cand_rays[2]: rays in candidate events, largest L / 2 >= n_half
+void launch_candidate_lists(hipStream_t s, int n_events, int n_half, const EventOut& ev, const int* cflag, const int* coff,
+                            const int* lflag, const int* loff, int* cand, int* len_index, int* lens);
 void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet& fl,
                           const double2* tw, const double2* w16, const LengthTables& tab);
 int channel_grid_blocks();

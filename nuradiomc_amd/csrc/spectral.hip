@@ -885,6 +885,48 @@ event_grid_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, R
     ev.t_min[e] = (r1 > r0) ? tmin : NAN;
 }
 
+// candidate events -> int flags, flags of the trace lengths in use (index L / 2), number of rays in candidate events
+__global__ void __launch_bounds__(256)
+candidate_flags_kernel(int n_events, int n_half, EventOut ev, int* __restrict__ cflag, int* __restrict__ lflag,
+                       long long* __restrict__ n_cand_rays)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    long long nr = 0;
+    if (e < n_events) {
+        int c = ev.candidate[e] ? 1 : 0;
+        cflag[e] = c;
+        if (c) {
+            const int h = ev.L[e] / 2;
+            if (h < n_half) lflag[h] = 1;
+            else atomicMax((unsigned long long*)(n_cand_rays + 1), (unsigned long long)h);  // too long: the host reports it
+            nr = ev.n_rays[e];
+        }
+    } else if (e == n_events) {
+        cflag[e] = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) nr += __shfl_xor(nr, off);
+    if ((threadIdx.x & 63) == 0 && nr) atomicAdd((unsigned long long*)n_cand_rays, (unsigned long long)nr);
+}
+
+// compacted candidate list (event order), ascending list of distinct lengths, per-event index into it
+__global__ void __launch_bounds__(256)
+candidate_lists_kernel(int n_events, int n_half, EventOut ev, const int* __restrict__ cflag, const int* __restrict__ coff,
+                       const int* __restrict__ lflag, const int* __restrict__ loff, int* __restrict__ cand,
+                       int* __restrict__ len_index, int* __restrict__ lens)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_events) {
+        int li = -1;
+        if (cflag[i]) {
+            cand[coff[i]] = i;
+            const int h = ev.L[i] / 2;
+            li = (h < n_half) ? loff[h] : -1;
+        }
+        len_index[i] = li;
+    }
+    if (i < n_half && lflag[i]) lens[loff[i]] = 2 * i;
+}
+
 // complex rational filter response prod_i B_i(j f) / A_i(j f) applied successively (signal.freqs)
 __device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl)
 {
@@ -1716,6 +1758,19 @@ void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_of
     if (n_events <= 0) return;
     hipLaunchKernelGGL(event_grid_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, n_ch, slot_offset, w, st,
                        max_efield, min_efield, ev);
+}
+void launch_candidate_flags(hipStream_t s, int n_events, int n_half, const EventOut& ev, int* cflag, int* lflag,
+                            long long* n_cand_rays)
+{
+    hipLaunchKernelGGL(candidate_flags_kernel, dim3(grid_for(n_events + 1, 256)), dim3(256), 0, s, n_events, n_half, ev, cflag,
+                       lflag, n_cand_rays);
+}
+void launch_candidate_lists(hipStream_t s, int n_events, int n_half, const EventOut& ev, const int* cflag, const int* coff,
+                            const int* lflag, const int* loff, int* cand, int* len_index, int* lens)
+{
+    int n = n_events > n_half ? n_events : n_half;
+    hipLaunchKernelGGL(candidate_lists_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, n_events, n_half, ev, cflag, coff,
+                       lflag, loff, cand, len_index, lens);
 }
 static bool g_attr_set = false;
 static void set_big_lds()
