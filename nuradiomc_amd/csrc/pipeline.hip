@@ -363,14 +363,15 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     MARK(4);
     if (n_active > 0) {
         // 4. candidate cut on max |E(t)|
-        int *need_fft, *need_off, *need_tmp, *fft_list;
-        NEED(need_fft = WS("fft_need", int, (size_t)n_active + 1));
-        NEED(need_off = WS("fft_need_offset", int, (size_t)n_active + 1));
-        NEED(need_tmp = WS("scan_tmp3", int, scan_tiles((long)n_active + 1)));
-        NEED(fft_list = WS("fft_list", int, (size_t)n_active));
-        launch_efield_max(sm, n_active, active_list, w, evin, sd, cfg->askaryan_model, ctx->twiddle,
-                          cfg->min_efield_amplitude, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, max_efield, need_fft,
-                          need_off, need_tmp, fft_list);
+        int *need_ray, *ev_need, *ev_off, *ev_tmp, *ev_list;
+        NEED(need_ray = WS("ray_need_transform", int, nr));
+        NEED(ev_need = WS("ev_need_transform", int, n_events + 1));
+        NEED(ev_off = WS("ev_need_offset", int, n_events + 1));
+        NEED(ev_tmp = WS("scan_tmp3", int, scan_tiles(n_events + 1)));
+        NEED(ev_list = WS("ev_transform_list", int, n_events));
+        launch_efield_max(sm, n_active, active_list, n_rays, (int)n_events, offset, w, evin, sd, cfg->askaryan_model,
+                          ctx->twiddle, cfg->min_efield_amplitude, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, max_efield,
+                          need_ray, ev_need, ev_off, ev_tmp, ev_list);
         LCHK("efield_max");
     }
     MARK(5);

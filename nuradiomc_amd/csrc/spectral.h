@@ -111,9 +111,10 @@ void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const i
 void launch_active_class_flags(hipStream_t s, int n_rays, const int* active, const int* ray_slot2, const int* slot_type,
                                int* flags);
 void launch_scatter_active_class(hipStream_t s, int n_rays, const int* flags, const int* offset, int* list);
-void launch_efield_max(hipStream_t s, int n_active, const int* active_list, const RayWork& w, const EventIn& evin,
-                       const StationDev& st, int ask_model, const double2* tw, double min_efield, int exact,
-                       double* max_efield, int* need_fft, int* need_offset, int* scan_tmp, int* fft_list);
+void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int n_rays, int n_events,
+                       const int* slot_offset, const RayWork& w, const EventIn& evin, const StationDev& st, int ask_model,
+                       const double2* tw, double min_efield, int exact, double* max_efield, int* need_ray, int* ev_need,
+                       int* ev_offset, int* scan_tmp, int* ev_list);
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev);
 void launch_candidate_flags(hipStream_t s, int n_events, int n_half, const EventOut& ev, int* cflag, int* lflag,

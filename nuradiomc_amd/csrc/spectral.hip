@@ -780,7 +780,7 @@ efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w
                     double bnd = efield_bound(pt, st.N, st.fs, cmax);
                     bool need = exact || (bnd * (1 + 1e-6) > min_efield);
                     max_efield[r] = -bnd;
-                    need_fft[ib + i] = need ? 1 : 0;
+                    need_fft[r] = need ? 1 : 0;  // per ray (zero-initialised for inactive rays)
                 }
             }
         }
@@ -788,12 +788,27 @@ efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w
     }
 }
 
-__global__ void scatter_fft_list_kernel(int n_active, const int* __restrict__ active_list, const int* __restrict__ need,
-                                        const int* __restrict__ offset, int* __restrict__ fft_list)
+// events with at least one undecided ray (the unit of work of efield_max_kernel)
+__global__ void __launch_bounds__(256)
+event_need_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, const int* __restrict__ need_ray,
+                  int* __restrict__ ev_need)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > n_events) return;
+    int any = 0;
+    if (e < n_events) {
+        long s0 = (long)e * n_ch * NRHIP_MAXS, s1 = (long)(e + 1) * n_ch * NRHIP_MAXS;
+        for (int r = slot_offset[s0]; r < slot_offset[s1]; r++) any |= need_ray[r];
+    }
+    ev_need[e] = any;
+}
+
+__global__ void scatter_flagged_kernel(int n, const int* __restrict__ flag, const int* __restrict__ offset,
+                                       int* __restrict__ list)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_active) return;
-    if (need[i]) fft_list[offset[i]] = active_list[i];
+    if (i >= n) return;
+    if (flag[i]) list[offset[i]] = i;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -802,8 +817,9 @@ __global__ void scatter_fft_list_kernel(int n_active, const int* __restrict__ ac
 // real pulse: a single transform serves both.  LDS: N/2 complex + (N/2 + 1) doubles.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ fft_list, RayWork w, EventIn evin, StationDev st,
-                  int ask_model, const double2* __restrict__ tw, int log2nh, double* __restrict__ max_efield)
+efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ ev_list, const int* __restrict__ need_ray,
+                  const int* __restrict__ slot_offset, RayWork w, EventIn evin, StationDev st, int ask_model,
+                  const double2* __restrict__ tw, int log2nh, double min_efield, int exact, double* __restrict__ max_efield)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2;
@@ -811,9 +827,16 @@ efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ fft_li
     double* amp = (double*)(x + nh);
     __shared__ RayShared rs;
     __shared__ double red[256];
-    const int n_fft = *n_list;
-    for (int ia = blockIdx.x; ia < n_fft; ia += gridDim.x) {
-        const int r = fft_list[ia];
+    const int n_ev = *n_list;
+    // unit of work: one event.  The candidate flag is an OR over the event's rays, so once one ray exceeds the cut the
+    // remaining undecided rays keep their "at most" value (unless every maximum is wanted).
+    for (int le = blockIdx.x; le < n_ev; le += gridDim.x) {
+      const int e = ev_list[le];
+      const long s0 = (long)e * st.n_ch * NRHIP_MAXS, s1 = (long)(e + 1) * st.n_ch * NRHIP_MAXS;
+      const int r0 = slot_offset[s0], r1 = slot_offset[s1];
+      bool done = false;
+      for (int r = r0; r < r1 && !done; r++) {
+        if (!need_ray[r]) continue;
         if (threadIdx.x == 0) rs.ask = w.ask[r];
         for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
         __syncthreads();
@@ -846,6 +869,8 @@ efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ fft_li
         }
         mx = block_max(mx, red);
         if (threadIdx.x == 0) max_efield[r] = mx;
+        if (!exact && mx > min_efield) done = true;  // block-uniform (block_max broadcasts)
+      }
     }
 }
 
@@ -1733,24 +1758,27 @@ void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const i
     if (n_rays <= 0) return;
     hipLaunchKernelGGL(scatter_active_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, active, offset, list);
 }
-void launch_efield_max(hipStream_t s, int n_active, const int* active_list, const RayWork& w, const EventIn& evin,
-                       const StationDev& st, int ask_model, const double2* tw, double min_efield, int exact,
-                       double* max_efield, int* need_fft, int* need_offset, int* scan_tmp, int* fft_list)
+void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int n_rays, int n_events,
+                       const int* slot_offset, const RayWork& w, const EventIn& evin, const StationDev& st, int ask_model,
+                       const double2* tw, double min_efield, int exact, double* max_efield, int* need_ray, int* ev_need,
+                       int* ev_offset, int* scan_tmp, int* ev_list)
 {
     if (n_active <= 0) return;
     int nh = st.N / 2;
+    (void)hipMemsetAsync(need_ray, 0, sizeof(int) * (size_t)n_rays, s);
     int gridA = (n_active + 4 * AB_RT - 1) / (4 * AB_RT);
     if (gridA > 256 * 32) gridA = 256 * 32;
     hipLaunchKernelGGL(efield_bound_kernel, dim3(gridA), dim3(256), 0, s, n_active, active_list, w, st, min_efield, exact,
-                       max_efield, need_fft);
-    (void)hipMemsetAsync(need_fft + n_active, 0, sizeof(int), s);
-    launch_exclusive_scan(s, (long)n_active + 1, need_fft, need_offset, scan_tmp);
-    hipLaunchKernelGGL(scatter_fft_list_kernel, dim3(grid_for(n_active, 256)), dim3(256), 0, s, n_active, active_list,
-                       need_fft, need_offset, fft_list);
+                       max_efield, need_ray);
+    hipLaunchKernelGGL(event_need_kernel, dim3(grid_for(n_events + 1, 256)), dim3(256), 0, s, n_events, st.n_ch, slot_offset,
+                       need_ray, ev_need);
+    launch_exclusive_scan(s, (long)n_events + 1, ev_need, ev_offset, scan_tmp);
+    hipLaunchKernelGGL(scatter_flagged_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, ev_need, ev_offset,
+                       ev_list);
     size_t lds = (size_t)nh * 16 + (size_t)(nh + 1) * 8;
-    int grid = n_active < 256 * 16 ? n_active : 256 * 16;
-    hipLaunchKernelGGL(efield_max_kernel, dim3(grid), dim3(256), lds, s, need_offset + n_active, fft_list, w, evin, st,
-                       ask_model, tw, ilog2(nh), max_efield);
+    int grid = n_events < 256 * 16 ? n_events : 256 * 16;
+    hipLaunchKernelGGL(efield_max_kernel, dim3(grid), dim3(256), lds, s, ev_offset + n_events, ev_list, need_ray, slot_offset,
+                       w, evin, st, ask_model, tw, ilog2(nh), min_efield, exact, max_efield);
 }
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev)
