@@ -137,6 +137,13 @@ typedef struct {
     const int32_t* filter_na;
     const double* filter_b;       /* [n_filters][NRHIP_MAX_POLY]                                        */
     const double* filter_a;
+    /* optional depth-resolved pruning bound: depth bins [-(b+1) w, -b w], b < n, w = att_bound_bin_width [m] (n <= 63);
+       att_bound_bin_inv_length[b][f] <= min over the bin of 1 / L_att(z, f).  A ray's attenuation factor then is bounded
+       from above by exp(-0.95 sum_b (path length inside bin b) * that) -- much tighter than the single-length bound, and
+       used instead of it when given (n = 0: not given) */
+    int32_t att_bound_n_bins;
+    double att_bound_bin_width;
+    const double* att_bound_bin_inv_length; /* [att_bound_n_bins][n_att_freq] */
 } nrhip_station_desc;
 
 typedef struct {

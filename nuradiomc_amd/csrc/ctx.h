@@ -47,7 +47,7 @@ struct nrhip_station {
     nrhip::StationDev dev;
     nrhip::FilterSet filters;
     std::vector<double> h_pos, h_cable;
-    DevArray d_pos, d_cable, d_model, d_rot, d_rot_inv, d_fc, d_lnf, d_invl, d_fpow, d_seg;
+    DevArray d_pos, d_cable, d_model, d_rot, d_rot_inv, d_fc, d_lnf, d_invl, d_fpow, d_seg, d_attbin;
     // workspace of the last simulated chunk (kept for nrhip_sim_fetch and reused between calls)
     std::map<std::string, DevArray> ws;
     std::map<std::string, size_t> ws_bytes;  // valid bytes of the last chunk

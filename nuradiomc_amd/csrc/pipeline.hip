@@ -154,8 +154,17 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
         delete s;
         return -1;
     }
+    int n_bins = 0;
+    if (d->att_bound_n_bins > 0 && d->att_bound_bin_inv_length && d->att_bound_bin_width > 0) {
+        if (d->att_bound_n_bins > 63) { delete s; return nrhip_fail_msg("nrhip_station_create: att_bound_n_bins > 63"); }
+        n_bins = d->att_bound_n_bins;
+        if (upload(ctx, s->d_attbin, d->att_bound_bin_inv_length, (size_t)n_bins * d->n_att_freq)) { delete s; return -1; }
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     StationDev& v = s->dev;
+    v.n_att_bins = n_bins;
+    v.att_bin_width = n_bins ? d->att_bound_bin_width : 0.;
+    v.att_bin_inv = n_bins ? s->d_attbin.as<double>() : nullptr;
     v.n_ch = n;
     v.N = d->n_samples;
     v.n_fc = d->n_att_freq;
@@ -200,7 +209,7 @@ void nrhip_station_destroy(nrhip_station* s)
     for (auto& e : s->evt) if (e) (void)hipEventDestroy(e);
     s->d_pos.release(); s->d_cable.release(); s->d_model.release();
     s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release(); s->d_lnf.release(); s->d_invl.release();
-    s->d_fpow.release(); s->d_seg.release();
+    s->d_fpow.release(); s->d_seg.release(); s->d_attbin.release();
     delete s;
 }
 
@@ -332,7 +341,9 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         NEED(roff = WS("ray_active_offset", int, 3 * nr + 1));
         NEED(rtmp = WS("scan_tmp2", int, scan_tiles(3L * n_rays + 1)));
         NEED(active_list = WS("ray_active_list", int, nr));
-        launch_amp_bound(sm, n_rays, w, sd, vertex, bound, max_efield);
+        launch_ray_limits_from_slots(sm, n_rays, n_ch, ray_slot, vertex, sd.pos, rec, ctx->ice, zint);
+        LCHK("ray_limits");
+        launch_amp_bound(sm, n_rays, w, sd, ctx->ice, vertex, zint, bound, max_efield);
         LCHK("amp_bound");
         launch_event_possible(sm, (int)n_events, n_ch, offset, bound, cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude,
                               ractive);
@@ -352,8 +363,6 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     MARK(3);
     if (n_active > 0) {
         // attenuation on the coarse frequency grid, active rays only
-        launch_ray_limits_from_slots(sm, n_rays, n_ch, ray_slot, vertex, sd.pos, rec, ctx->ice, zint);
-        LCHK("ray_limits");
         NEED(eval_counter = WS("att_eval_counter", unsigned long long, 1));
         HIPCHK(hipMemsetAsync(eval_counter, 0, sizeof(unsigned long long), sm));
         launch_attenuation_items(sm, n_active, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr,

@@ -25,6 +25,9 @@ struct StationDev {
     const double* fcoarse;    // [n_fc] attenuation frequency grid
     const double* lnf;        // [N/2 + 1] ln f_k of the N-sample grid (entry 0 unused)
     const double* inv_lmax;   // [n_fc] 1 / max_z L_att(z, f) (0 = unknown): upper bound exp(-0.95 D / L_max) on attenuation
+    int n_att_bins;           // depth-binned attenuation bound (0: not given)
+    double att_bin_width;
+    const double* att_bin_inv; // [n_att_bins][n_fc] lower bounds of 1 / L_att inside depth bin b
     const double* fpow;       // [3][N/2 + 1] f_k^p for p = 2.57, 2.74, 1.27 (Alvarez2009: beta had / em, alpha)
     const unsigned char* seg; // [N/2 + 1] coarse-grid segment lo of f_k: fcoarse[lo] <= f_k < fcoarse[lo + 1]
 };
@@ -103,8 +106,8 @@ void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, 
                       const EventIn& evin, int ask_model);
 void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
                                   const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint);
-void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, const double* vertex, double* bound,
-                      double* max_efield);
+void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, const IceConst& m,
+                      const double* vertex, const double* zint, double* bound, double* max_efield);
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
                            double min_efield, int* ray_active);
 void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const int* offset, int* list);

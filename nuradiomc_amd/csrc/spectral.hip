@@ -579,9 +579,14 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
 // ---------------------------------------------------------------------------------------------------------
 #define AB_RT 4  // rays per wave and pass: the frequency-grid tables are loaded once for AB_RT rays
 __global__ void __launch_bounds__(256)
-amp_bound_kernel(int n_rays, RayWork w, StationDev st, const double* __restrict__ vertex, double* __restrict__ bound,
-                 double* __restrict__ max_efield)
+amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double* __restrict__ vertex,
+                 const double* __restrict__ zint, double* __restrict__ bound, double* __restrict__ max_efield)
 {
+    __shared__ double blen[4][64];  // per wave: path length inside each depth bin
+    __shared__ double s_binv[63 * 32];  // the depth-bin table (n_fc <= 32; read from HBM otherwise)
+    const bool binv_lds = st.n_att_bins > 0 && st.n_fc <= 32;
+    if (binv_lds)
+        for (int j = threadIdx.x; j < st.n_att_bins * st.n_fc; j += blockDim.x) s_binv[j] = st.att_bin_inv[j];
     __shared__ double ub[4][AB_RT][NRHIP_MAX_NFC];  // per wave and ray: upper bounds of the coarse attenuation factors
     __shared__ double ub_slope[4][AB_RT][NRHIP_MAX_NFC];
     __shared__ double s_xp[NRHIP_MAX_NFC];
@@ -597,7 +602,49 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, const double* __restrict_
         // tolerance; linear interpolation of upper bounds bounds the interpolated attenuation
         for (int i = 0; i < AB_RT; i++) {
             const int r = rb + i;
-            if (lane < st.n_fc) {
+            if (st.n_att_bins > 0) {
+                // depth-resolved: int ds / L >= sum_b (path length inside depth bin b) * min_bin(1 / L).  The path climbs
+                // from z1 to min(z_turn, z2m) and, if it turns, descends again to 2 z_turn - z2m; s(z) is the closed-form
+                // path length (analyticraytracing.py:602-689) with n sin(theta) = 1 / C0.  Lane i evaluates both legs at
+                // the bin edge -i w; bins the path does not reach contribute 0, parts below the table are ignored.
+                // single precision suffices here (bin lengths to ~1e-5; the sum below is shrunk by 1e-3 to stay rigorous)
+                float s1 = 0.f, s2 = 0.f;
+                if (r < n_rays && lane <= st.n_att_bins) {
+                    const double C0 = w.C0[r], z1 = zint[3 * (long)r], z2m = zint[3 * (long)r + 1], zt = zint[3 * (long)r + 2];
+                    const double beta2d = 1. / (C0 * C0);
+                    const float beta2 = (float)beta2d, alpha = (float)(m.n2 - beta2d), sa = sqrtf(alpha);
+                    const float n_ice = (float)m.n_ice, dn = (float)m.delta_n, z0 = (float)m.z_0;
+                    const double edge = -lane * st.att_bin_width;
+                    const double top1 = fmin(zt, z2m), lo2 = (z2m > zt) ? 2 * zt - z2m : zt;
+                    const float zz[2] = {(float)fmin(fmax(edge, z1), top1), (float)fmin(fmax(edge, lo2), zt)};
+                    float sv[2];
+                    for (int q = 0; q < 2; q++) {
+                        float nz = n_ice - dn * __expf(zz[q] / z0);
+                        float gam = fmaxf(0.f, nz * nz - beta2);
+                        float l1 = sqrtf(alpha * gam) + n_ice * nz - beta2, l2 = sqrtf(gam) + nz;
+                        sv[q] = n_ice / sa * (zz[q] - z0 * __logf(l1)) + z0 * __logf(l2);
+                    }
+                    s1 = sv[0];
+                    s2 = sv[1];
+                }
+                const float d1 = s1 - __shfl_down(s1, 1), d2 = s2 - __shfl_down(s2, 1);
+                blen[wv][lane] = (lane < st.n_att_bins) ? (double)(fmaxf(0.f, d1) + fmaxf(0.f, d2)) : 0.;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < st.n_fc) {
+                    double u = 0.;
+                    if (r < n_rays) {
+                        double I = 0.;
+                        const double* binv = binv_lds ? s_binv : st.att_bin_inv;
+                        for (int b = 0; b < st.n_att_bins; b++) I += blen[wv][b] * binv[b * st.n_fc + lane];
+                        u = exp(-0.95 * (1 - 1e-3) * I);
+                    }
+                    ub[wv][i][lane] = u;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else if (lane < st.n_fc) {
                 double u = 0.;
                 if (r < n_rays) {
                     double zlo = fmin(vertex[3 * (long)w.ev[r] + 2], st.pos[3 * w.ch[r] + 2]);  // deepest point of the path
@@ -1725,13 +1772,13 @@ void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
-void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, const double* vertex, double* bound,
-                      double* max_efield)
+void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, const IceConst& m,
+                      const double* vertex, const double* zint, double* bound, double* max_efield)
 {
     if (n_rays <= 0) return;
     int grid = (n_rays + 4 * AB_RT - 1) / (4 * AB_RT);
     if (grid > 256 * 32) grid = 256 * 32;
-    hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, vertex, bound, max_efield);
+    hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, m, vertex, zint, bound, max_efield);
 }
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
                            double min_efield, int* ray_active)

@@ -17,7 +17,8 @@ class StationDesc(ctypes.Structure):
                 ('n_att_freq', ctypes.c_int32), ('att_freq', L.c_double_p), ('att_bound_inv_length', L.c_double_p),
                 ('att_bound_depth', ctypes.c_double), ('n_filters', ctypes.c_int32),
                 ('filter_nb', L.c_int32_p), ('filter_na', L.c_int32_p), ('filter_b', L.c_double_p),
-                ('filter_a', L.c_double_p)]
+                ('filter_a', L.c_double_p), ('att_bound_n_bins', ctypes.c_int32), ('att_bound_bin_width', ctypes.c_double),
+                ('att_bound_bin_inv_length', L.c_double_p)]
 
 
 class SimConfig(ctypes.Structure):
@@ -123,11 +124,22 @@ class Station:
         zz = np.linspace(-self.att_bound_depth, 0., int(self.att_bound_depth) + 1)
         lmax = np.array([np.max(ctx.attenuation_length(zz, f)) for f in self.att_freq])
         self.att_bound_inv_length = np.ascontiguousarray(1.0 / (lmax * (1 + 1e-3)))
-        self._keep = (pos, cab, model, ori, self.att_freq, nb, na, fb, fa, self.att_bound_inv_length)
+        # the same per 50 m depth bin (0.25 m grid, 1e-3 for what happens between grid points): the library sums
+        # (path length inside the bin) / L_max(bin) along the ray, a much tighter bound on the path integral
+        self.att_bound_bin_width = 50.
+        n_bins = min(63, int(np.ceil(self.att_bound_depth / self.att_bound_bin_width)))
+        per = int(round(self.att_bound_bin_width / 0.25))
+        zz = -np.arange(n_bins * per + 1) * 0.25
+        inv = np.array([1.0 / ctx.attenuation_length(zz, f) for f in self.att_freq])            # [n_fc][n_z]
+        idx = np.arange(n_bins)[:, None] * per + np.arange(per + 1)[None, :]
+        self.att_bound_bin_inv_length = np.ascontiguousarray(inv[:, idx].min(axis=2).T * (1 - 1e-3))  # [n_bins][n_fc]
+        self._keep = (pos, cab, model, ori, self.att_freq, nb, na, fb, fa, self.att_bound_inv_length,
+                      self.att_bound_bin_inv_length)
         d = StationDesc(n, L.dptr(pos), L.dptr(cab), L.iptr(model), L.dptr(ori), self.n_samples, self.sampling_rate,
                         float(readout_length if readout_length is not None else self.n_samples / self.sampling_rate),
                         float(pre_pulse_time), float(post_pulse_time), len(self.att_freq), L.dptr(self.att_freq),
-                        L.dptr(self.att_bound_inv_length), self.att_bound_depth, len(self.filters), L.iptr(nb), L.iptr(na), L.dptr(fb), L.dptr(fa))
+                        L.dptr(self.att_bound_inv_length), self.att_bound_depth, len(self.filters), L.iptr(nb), L.iptr(na), L.dptr(fb), L.dptr(fa),
+                        n_bins, self.att_bound_bin_width, L.dptr(self.att_bound_bin_inv_length))
         h = ctypes.c_void_p()
         L.check(self._lib.nrhip_station_create(ctx._h, ctypes.byref(d), ctypes.byref(h)))
         self._h = h
