@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(256)
 amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double* __restrict__ vertex,
                  const double* __restrict__ zint, double* __restrict__ bound, double* __restrict__ max_efield)
 {
-    __shared__ double blen[4][64];  // per wave: path length inside each depth bin
+    __shared__ double blen[4][AB_RT][64];  // per wave and ray: path length inside each depth bin
     __shared__ double s_binv[63 * 32];  // the depth-bin table (n_fc <= 32; read from HBM otherwise)
     const bool binv_lds = st.n_att_bins > 0 && st.n_fc <= 32;
     if (binv_lds)
@@ -600,14 +600,14 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
         const int rb = ((it * gridDim.x + blockIdx.x) * 4 + wv) * AB_RT;
         // attenuation factor <= exp(-int ds / L) <= exp(-D / L_max(f)); 0.95 covers the reference's 1e-2 quadrature
         // tolerance; linear interpolation of upper bounds bounds the interpolated attenuation
-        for (int i = 0; i < AB_RT; i++) {
-            const int r = rb + i;
-            if (st.n_att_bins > 0) {
-                // depth-resolved: int ds / L >= sum_b (path length inside depth bin b) * min_bin(1 / L).  The path climbs
-                // from z1 to min(z_turn, z2m) and, if it turns, descends again to 2 z_turn - z2m; s(z) is the closed-form
-                // path length (analyticraytracing.py:602-689) with n sin(theta) = 1 / C0.  Lane i evaluates both legs at
-                // the bin edge -i w; bins the path does not reach contribute 0, parts below the table are ignored.
-                // single precision suffices here (bin lengths to ~1e-5; the sum below is shrunk by 1e-3 to stay rigorous)
+        if (st.n_att_bins > 0) {
+            // depth-resolved: int ds / L >= sum_b (path length inside depth bin b) * min_bin(1 / L).  The path climbs
+            // from z1 to min(z_turn, z2m) and, if it turns, descends again to 2 z_turn - z2m; s(z) is the closed-form
+            // path length (analyticraytracing.py:602-689) with n sin(theta) = 1 / C0.  Lane i evaluates both legs at
+            // the bin edge -i w; bins the path does not reach contribute 0, parts below the table are ignored.
+            // Single precision suffices here (bin lengths to ~1e-5; the sum below is shrunk by 1e-3 to stay rigorous).
+            for (int i = 0; i < AB_RT; i++) {
+                const int r = rb + i;
                 float s1 = 0.f, s2 = 0.f;
                 if (r < n_rays && lane <= st.n_att_bins) {
                     const double C0 = w.C0[r], z1 = zint[3 * (long)r], z2m = zint[3 * (long)r + 1], zt = zint[3 * (long)r + 2];
@@ -628,23 +628,25 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
                     s2 = sv[1];
                 }
                 const float d1 = s1 - __shfl_down(s1, 1), d2 = s2 - __shfl_down(s2, 1);
-                blen[wv][lane] = (lane < st.n_att_bins) ? (double)(fmaxf(0.f, d1) + fmaxf(0.f, d2)) : 0.;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (lane < st.n_fc) {
-                    double u = 0.;
-                    if (r < n_rays) {
-                        double I = 0.;
-                        const double* binv = binv_lds ? s_binv : st.att_bin_inv;
-                        for (int b = 0; b < st.n_att_bins; b++) I += blen[wv][b] * binv[b * st.n_fc + lane];
-                        u = exp(-0.95 * (1 - 1e-3) * I);
-                    }
-                    ub[wv][i][lane] = u;
+                blen[wv][i][lane] = (lane < st.n_att_bins) ? (double)(fmaxf(0.f, d1) + fmaxf(0.f, d2)) : 0.;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < st.n_fc) {
+                double I[AB_RT];
+                for (int i = 0; i < AB_RT; i++) I[i] = 0.;
+                const double* binv = binv_lds ? s_binv : st.att_bin_inv;
+                for (int b = 0; b < st.n_att_bins; b++) {
+                    const double t = binv[b * st.n_fc + lane];
+#pragma unroll
+                    for (int i = 0; i < AB_RT; i++) I[i] += blen[wv][i][b] * t;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            } else if (lane < st.n_fc) {
+                for (int i = 0; i < AB_RT; i++) ub[wv][i][lane] = (rb + i < n_rays) ? exp(-0.95 * (1 - 1e-3) * I[i]) : 0.;
+            }
+        } else if (lane < st.n_fc) {
+            for (int i = 0; i < AB_RT; i++) {
+                const int r = rb + i;
                 double u = 0.;
                 if (r < n_rays) {
                     double zlo = fmin(vertex[3 * (long)w.ev[r] + 2], st.pos[3 * w.ch[r] + 2]);  // deepest point of the path
