@@ -94,7 +94,7 @@ struct Pair2D {
 };
 
 // signed miss distance at x2 of the ray launched from x1 with parameter C0 (:204-272, reflection = 0)
-__device__ inline double delta_y(double logC0, const Pair2D& p, const IceConst& m)
+__device__ __noinline__ double delta_y(double logC0, const Pair2D& p, const IceConst& m)
 {
     double C0 = det_exp(logC0) + m.inv_n;
     if (C0 < m.inv_n) return -INFINITY;

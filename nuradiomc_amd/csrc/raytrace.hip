@@ -191,7 +191,7 @@ __device__ inline bool np_sign_differs(double a, double b)
 }
 
 // Kernel: pair i = (event i / n_ch, channel i % n_ch) when n_ch > 0, else x2 is per pair.
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 6)
 raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
                 IceConst m, RayRecords out)
 {
