@@ -133,9 +133,9 @@ def main():
         sm = stats['stage_ms']
         dom = max((k for k in sm if k != 'total'), key=lambda k: sm[k])
         kernel_of = {'raytrace': 'raytrace_kernel', 'ray_setup': 'select/scan/ray_setup kernels',
-                     'amp_bound': 'amp_bound_kernel', 'attenuation': 'attenuation_group_kernel<32>',
-                     'efield_max': 'efield_max_kernel', 'event_grid': 'event_grid_kernel + host hand-off',
-                     'length_tables': 'length_tables_kernel', 'channel': 'channel_kernel'}
+                     'amp_bound': 'amp_bound_kernel', 'attenuation': 'attenuation_group_kernel<32, 1>',
+                     'efield_max': 'efield_bound_kernel + efield_max_kernel', 'event_grid': 'event_grid_kernel + candidate lists',
+                     'length_tables': 'length_tables_kernel', 'channel': 'channel_prefilter_kernel + channel_conv_kernel'}
         # algorithmic HBM bytes per launch
         b_field = 2 * 2049 * 16 + 2 * 2049 * 16 + 2 * 4096 * 8     # write spec_N, c2r N in/out per ray
         alg = {'raytrace': B_PAIR * stats['n_pairs'],
@@ -147,11 +147,12 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, see the file header);
         # only meaningful for the workload they were measured on
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_rocprofv3_pmc_hbm_traffic.csv')
+        pmc = os.path.join(ROOT, 'profiles', 'r01_rocprofv3_pmc_hbm_traffic_final.csv')
         if n == 1000000 and os.path.exists(pmc):
             for line in open(pmc):
-                if line.startswith('nrhip::') and line.split(',')[0].split('::')[1].split('<')[0] in kernel_of[dom]:
-                    traffic = float(line.strip().split(',')[3]) / 1e9
+                name, _, _, hbm = line.strip().rsplit(',', 3) if line.count(',') >= 3 else ('', 0, 0, 0)
+                if name.startswith('nrhip::') and name.split('::')[1].split('<')[0] in kernel_of[dom].split(' + ')[-1]:
+                    traffic = float(hbm) / 1e9
         achieved = alg_bytes / (sm[dom] * 1e-3) / 1e9 if sm[dom] > 0 else 0.
         b_event = B_RAY * stats['n_rays'] + B_CHANNEL * stats['n_channel_items'] + B_PAIR * stats['n_pairs']
         # FP64 view of the attenuation quadrature: one integrand evaluation = frequency-independent node part (shared
@@ -173,7 +174,7 @@ def main():
                        "stage_ms_last_step": {k: round(v, 3) for k, v in sm.items()}},
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/r01_rocprofv3_pmc_hbm_traffic.csv)",
+                         "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/r01_rocprofv3_pmc_hbm_traffic_final.csv)",
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": sm[dom],
                          "whole_step_equivalent_GBs": b_event / (sm['total'] * 1e-3) / 1e9 if sm['total'] > 0 else 0.,
                          "whole_step_equivalent_frac": b_event / (sm['total'] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm['total'] > 0 else 0.,

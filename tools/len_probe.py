@@ -13,3 +13,4 @@ Lc = L[c]
 print('candidates', c.sum(), 'L min/median/max', Lc.min(), np.median(Lc), Lc.max(), 'frac > 8192', (Lc > 8192).mean(), 'frac > 5544', (Lc > 5544).mean())
 print('percentiles', np.percentile(Lc, [50, 90, 99, 99.9]))
 mv = st.fetch('item_maxV'); print('items', len(mv), 'prefiltered (neg)', (mv < 0).sum())
+print('items evaluated (>=0)', (mv >= 0).sum(), 'NaN (skipped after trigger)', np.isnan(mv).sum(), 'bounded', (mv < 0).sum(), 'stage ms', out[1]['stage_ms'] if isinstance(out, tuple) else None)
