@@ -231,14 +231,26 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
                           const double* vertex, const double* zenith, const double* azimuth, const double* energy,
                           const int32_t* shower_type, const double* k_L, uint8_t* triggered, nrhip_sim_stats* stats)
 {
+    return nrhip_simulate_event_groups(ctx, st, cfg, n_events, vertex, zenith, azimuth, energy, shower_type, k_L, nullptr,
+                                       n_events, nullptr, triggered, stats);
+}
+
+int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_config* cfg, int64_t n_showers,
+                                const double* vertex, const double* zenith, const double* azimuth, const double* energy,
+                                const int32_t* shower_type, const double* k_L, const double* vertex_time,
+                                int64_t n_groups, const int32_t* group_begin, uint8_t* triggered, nrhip_sim_stats* stats)
+{
     if (!ctx || !st || !cfg) return nrhip_fail_msg("nrhip_simulate_events: NULL argument");
     if (st->ctx != ctx) return nrhip_fail_msg("nrhip_simulate_events: station belongs to another context");
-    if (n_events < 0) return nrhip_fail_msg("nrhip_simulate_events: negative size");
+    if (n_showers < 0 || n_groups < 0 || n_groups > n_showers) return nrhip_fail_msg("nrhip_simulate_events: bad sizes");
+    if (!group_begin && n_groups != n_showers)
+        return nrhip_fail_msg("nrhip_simulate_events: group_begin is required when groups hold several showers");
+    const int64_t n_events = n_showers;  // ray stages work per shower, decision stages per event group
     if (cfg->askaryan_model < 0 || cfg->askaryan_model > 2)
         return nrhip_fail_msg("nrhip_simulate_events: Askaryan model not implemented");
     nrhip_sim_stats S;
     memset(&S, 0, sizeof S);
-    S.n_events = n_events;
+    S.n_events = n_groups;
     st->ws_bytes.clear();
     if (stats) *stats = S;
     if (n_events == 0) return 0;
@@ -252,7 +264,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     for (auto& e : st->evt) if (!e) HIPCHK(hipEventCreate(&e));
 #define MARK(i) HIPCHK(hipEventRecord(st->evt[i], sm))
     MARK(0);
-    HIPCHK(hipMemsetAsync(triggered, 0, n_events, sm));
+    HIPCHK(hipMemsetAsync(triggered, 0, n_groups, sm));
 
     // 1. ray tracing for every (event, channel) pair
     RayRecords rec;
@@ -286,12 +298,17 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     S.n_rays = n_rays;
 
     EventOut ev;
-    NEED(ev.n_rays = WS("ev_n_rays", int, n_events));
-    NEED(ev.ray_begin = WS("ev_ray_begin", int, n_events));
-    NEED(ev.L = WS("ev_L", int, n_events));
-    NEED(ev.candidate = WS("ev_candidate", unsigned char, n_events));
-    NEED(ev.t_min = WS("ev_t_min", double, n_events));
-    EventIn evin{energy, shower_type, k_L};
+    NEED(ev.n_rays = WS("ev_n_rays", int, n_groups));
+    NEED(ev.ray_begin = WS("ev_ray_begin", int, n_groups));
+    NEED(ev.L = WS("ev_L", int, n_groups));
+    NEED(ev.candidate = WS("ev_candidate", unsigned char, n_groups));
+    NEED(ev.t_min = WS("ev_t_min", double, n_groups));
+    EventIn evin{energy, shower_type, k_L, vertex_time};
+    // ray range of every event group (rays are ordered by shower; a group's showers are consecutive)
+    int* grp_ray;
+    NEED(grp_ray = WS("group_ray_begin", int, n_groups + 1));
+    launch_group_ray_range(sm, (int)n_groups, group_begin, n_ch, offset, grp_ray);
+    LCHK("group ranges");
 
     RayWork w;
     const size_t nr = (size_t)std::max(n_rays, 1);
@@ -345,7 +362,7 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         LCHK("ray_limits");
         launch_amp_bound(sm, n_rays, w, sd, ctx->ice, vertex, zint, bound, max_efield);
         LCHK("amp_bound");
-        launch_event_possible(sm, (int)n_events, n_ch, offset, bound, cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude,
+        launch_event_possible(sm, (int)n_groups, n_ch, grp_ray, bound, cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude,
                               ractive);
         LCHK("event_possible");
         // active rays listed by work class (direct, reflected, refracted): wave-mates in the quadrature do similar work
@@ -374,45 +391,45 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         // 4. candidate cut on max |E(t)|
         int *need_ray, *ev_need, *ev_off, *ev_tmp, *ev_list;
         NEED(need_ray = WS("ray_need_transform", int, nr));
-        NEED(ev_need = WS("ev_need_transform", int, n_events + 1));
-        NEED(ev_off = WS("ev_need_offset", int, n_events + 1));
-        NEED(ev_tmp = WS("scan_tmp3", int, scan_tiles(n_events + 1)));
-        NEED(ev_list = WS("ev_transform_list", int, n_events));
-        launch_efield_max(sm, n_active, active_list, n_rays, (int)n_events, offset, w, evin, sd, cfg->askaryan_model,
+        NEED(ev_need = WS("ev_need_transform", int, n_groups + 1));
+        NEED(ev_off = WS("ev_need_offset", int, n_groups + 1));
+        NEED(ev_tmp = WS("scan_tmp3", int, scan_tiles(n_groups + 1)));
+        NEED(ev_list = WS("ev_transform_list", int, n_groups));
+        launch_efield_max(sm, n_active, active_list, n_rays, (int)n_groups, grp_ray, w, evin, sd, cfg->askaryan_model,
                           ctx->twiddle, cfg->min_efield_amplitude, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, max_efield,
                           need_ray, ev_need, ev_off, ev_tmp, ev_list);
         LCHK("efield_max");
     }
     MARK(5);
     // 5. common time grid per event
-    launch_event_grid(sm, (int)n_events, n_ch, offset, w, sd, max_efield, cfg->min_efield_amplitude, ev);
+    launch_event_grid(sm, (int)n_groups, n_ch, grp_ray, w, sd, max_efield, cfg->min_efield_amplitude, ev);
     LCHK("event_grid");
     // candidate list, distinct trace lengths and the per-event table index are built on the device; the host only
     // learns the counts (and the few distinct lengths) it needs to size the next launches
     const int n_half = NRHIP_SPEC_STRIDE;  // possible values of L / 2
     int *cflag, *coff, *ctmp, *lflag, *loff, *ltmp, *d_lens, *d_len_index, *d_cand;
     long long* d_ncr;
-    NEED(cflag = WS("cand_flag", int, n_events + 1));
-    NEED(coff = WS("cand_offset", int, n_events + 1));
-    NEED(ctmp = WS("scan_tmp5", int, scan_tiles(n_events + 1)));
+    NEED(cflag = WS("cand_flag", int, n_groups + 1));
+    NEED(coff = WS("cand_offset", int, n_groups + 1));
+    NEED(ctmp = WS("scan_tmp5", int, scan_tiles(n_groups + 1)));
     NEED(lflag = WS("len_flag", int, n_half + 1));
     NEED(loff = WS("len_offset", int, n_half + 1));
     NEED(ltmp = WS("scan_tmp6", int, scan_tiles(n_half + 1)));
     NEED(d_lens = WS("lengths", int, n_half));
-    NEED(d_len_index = WS("ev_len_index", int, n_events));
-    NEED(d_cand = WS("item_event", int, n_events));
+    NEED(d_len_index = WS("ev_len_index", int, n_groups));
+    NEED(d_cand = WS("item_event", int, n_groups));
     NEED(d_ncr = WS("cand_ray_count", long long, 2));
     HIPCHK(hipMemsetAsync(lflag, 0, sizeof(int) * (n_half + 1), sm));
     HIPCHK(hipMemsetAsync(d_ncr, 0, 2 * sizeof(long long), sm));
-    launch_candidate_flags(sm, (int)n_events, n_half, ev, cflag, lflag, d_ncr);
-    launch_exclusive_scan(sm, n_events + 1, cflag, coff, ctmp);
+    launch_candidate_flags(sm, (int)n_groups, n_half, ev, cflag, lflag, d_ncr);
+    launch_exclusive_scan(sm, n_groups + 1, cflag, coff, ctmp);
     launch_exclusive_scan(sm, n_half + 1, lflag, loff, ltmp);
-    launch_candidate_lists(sm, (int)n_events, n_half, ev, cflag, coff, lflag, loff, d_cand, d_len_index, d_lens);
+    launch_candidate_lists(sm, (int)n_groups, n_half, ev, cflag, coff, lflag, loff, d_cand, d_len_index, d_lens);
     LCHK("candidate lists");
     int h_counts[2] = {0, 0};
     long long h_ncr[2] = {0, 0};
     std::vector<int> lens(n_half);
-    HIPCHK(hipMemcpyAsync(&h_counts[0], coff + n_events, sizeof(int), hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipMemcpyAsync(&h_counts[0], coff + n_groups, sizeof(int), hipMemcpyDeviceToHost, sm));
     HIPCHK(hipMemcpyAsync(&h_counts[1], loff + n_half, sizeof(int), hipMemcpyDeviceToHost, sm));
     HIPCHK(hipMemcpyAsync(h_ncr, d_ncr, 2 * sizeof(long long), hipMemcpyDeviceToHost, sm));
     HIPCHK(hipMemcpyAsync(lens.data(), d_lens, sizeof(int) * n_half, hipMemcpyDeviceToHost, sm));
@@ -459,8 +476,8 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
         co.trace = nullptr;
         co.trace_offset = nullptr;
         if (cfg->dump_traces) {
-            std::vector<int> hL(n_events), cand(n_cand);
-            HIPCHK(hipMemcpyAsync(hL.data(), ev.L, sizeof(int) * n_events, hipMemcpyDeviceToHost, sm));
+            std::vector<int> hL(n_groups), cand(n_cand);
+            HIPCHK(hipMemcpyAsync(hL.data(), ev.L, sizeof(int) * n_groups, hipMemcpyDeviceToHost, sm));
             HIPCHK(hipMemcpyAsync(cand.data(), d_cand, sizeof(int) * n_cand, hipMemcpyDeviceToHost, sm));
             HIPCHK(hipStreamSynchronize(sm));
             std::vector<long> off(n_items + 1, 0);
@@ -489,8 +506,8 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
     MARK(9);
     if (stats) {
         // count triggers on device-resident mask (cheap D2H of n bytes only when asked for stats)
-        std::vector<unsigned char> ht(n_events);
-        HIPCHK(hipMemcpyAsync(ht.data(), triggered, n_events, hipMemcpyDeviceToHost, sm));
+        std::vector<unsigned char> ht(n_groups);
+        HIPCHK(hipMemcpyAsync(ht.data(), triggered, n_groups, hipMemcpyDeviceToHost, sm));
         HIPCHK(hipStreamSynchronize(sm));
         int64_t nt = 0;
         for (unsigned char t : ht) nt += t;

@@ -68,6 +68,7 @@ struct EventIn {
     const double* energy;
     const int* shower_type;  // 0 HAD, 1 EM
     const double* k_L;       // Alvarez2009 EM showers; ignored otherwise
+    const double* vertex_time;  // [n_showers] or nullptr (0)
 };
 
 struct EventOut {
@@ -108,6 +109,7 @@ void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int
                                   const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint);
 void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, const IceConst& m,
                       const double* vertex, const double* zint, double* bound, double* max_efield);
+void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin, int n_ch, const int* slot_offset, int* grp_ray);
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
                            double min_efield, int* ray_active);
 void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const int* offset, int* list);

@@ -304,7 +304,7 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
     w.view[r] = viewing_angle(sd, lv);
     w.n_index[r] = n_index_at(vertex[3 * e + 2], m);
     w.R[r] = rec.D[slot];
-    w.t0[r] = 0. + rec.T[slot] - 0.5 * st.N / st.fs;  // vertex_time = 0 (simulation.py:259-268)
+    w.t0[r] = (evin.vertex_time ? evin.vertex_time[e] : 0.) + rec.T[slot] - 0.5 * st.N / st.fs;  // simulation.py:259-268
     w.C0[r] = rec.C0[slot];
     // polarisation = l x (s x l), normalised, in the on-sky basis of the launch direction (simulation.py:816-819)
     double sxl[3] = {sd[1] * lv[2] - sd[2] * lv[1], sd[2] * lv[0] - sd[0] * lv[2], sd[0] * lv[1] - sd[1] * lv[0]};
@@ -704,6 +704,17 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
     }
 }
 
+// ray range of every event group: rays are ordered by shower, the showers of a group are consecutive.
+// group_begin == nullptr: every shower is its own group.
+__global__ void group_ray_range_kernel(int n_groups, const int* __restrict__ group_begin, int n_ch,
+                                       const int* __restrict__ slot_offset, int* __restrict__ grp_ray)
+{
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_groups) return;
+    long sh = group_begin ? group_begin[g] : g;
+    grp_ray[g] = slot_offset[sh * n_ch * NRHIP_MAXS];
+}
+
 // per event: can any ray exceed the cut?  (1 + 1e-6 absorbs rounding of the bound and of exp(-integral) <= 1)
 __global__ void __launch_bounds__(256)
 event_possible_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, const double* __restrict__ bound,
@@ -711,8 +722,7 @@ event_possible_kernel(int n_events, int n_ch, const int* __restrict__ slot_offse
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_events) return;
-    long s0 = (long)e * n_ch * NRHIP_MAXS, s1 = (long)(e + 1) * n_ch * NRHIP_MAXS;
-    int r0 = slot_offset[s0], r1 = slot_offset[s1];
+    int r0 = slot_offset[e], r1 = slot_offset[e + 1];  // ray range of the event group (group_ray_range_kernel)
     int possible = 0;
     for (int r = r0; r < r1; r++)
         if (bound[r] * (1 + 1e-6) > min_efield) possible = 1;
@@ -846,8 +856,7 @@ event_need_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, c
     if (e > n_events) return;
     int any = 0;
     if (e < n_events) {
-        long s0 = (long)e * n_ch * NRHIP_MAXS, s1 = (long)(e + 1) * n_ch * NRHIP_MAXS;
-        for (int r = slot_offset[s0]; r < slot_offset[s1]; r++) any |= need_ray[r];
+        for (int r = slot_offset[e]; r < slot_offset[e + 1]; r++) any |= need_ray[r];
     }
     ev_need[e] = any;
 }
@@ -881,8 +890,7 @@ efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ ev_lis
     // remaining undecided rays keep their "at most" value (unless every maximum is wanted).
     for (int le = blockIdx.x; le < n_ev; le += gridDim.x) {
       const int e = ev_list[le];
-      const long s0 = (long)e * st.n_ch * NRHIP_MAXS, s1 = (long)(e + 1) * st.n_ch * NRHIP_MAXS;
-      const int r0 = slot_offset[s0], r1 = slot_offset[s1];
+      const int r0 = slot_offset[e], r1 = slot_offset[e + 1];
       bool done = false;
       for (int r = r0; r < r1 && !done; r++) {
         if (!need_ray[r]) continue;
@@ -932,8 +940,7 @@ event_grid_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, R
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_events) return;
-    long s0 = (long)e * n_ch * NRHIP_MAXS, s1 = (long)(e + 1) * n_ch * NRHIP_MAXS;
-    int r0 = slot_offset[s0], r1 = slot_offset[s1];
+    int r0 = slot_offset[e], r1 = slot_offset[e + 1];  // ray range of the event group (group_ray_range_kernel)
     double tmin = INFINITY, tmax = -INFINITY;
     int cand = 0;
     for (int r = r0; r < r1; r++) {
@@ -1781,6 +1788,11 @@ void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const Station
     int grid = (n_rays + 4 * AB_RT - 1) / (4 * AB_RT);
     if (grid > 256 * 32) grid = 256 * 32;
     hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, m, vertex, zint, bound, max_efield);
+}
+void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin, int n_ch, const int* slot_offset, int* grp_ray)
+{
+    hipLaunchKernelGGL(group_ray_range_kernel, dim3(grid_for(n_groups + 1, 256)), dim3(256), 0, s, n_groups, group_begin, n_ch,
+                       slot_offset, grp_ray);
 }
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
                            double min_efield, int* ray_active)

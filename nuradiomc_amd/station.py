@@ -47,6 +47,9 @@ L._OPTIONAL.update({
     'nrhip_station_destroy': (None, [ctypes.c_void_p]),
     'nrhip_simulate_events': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(SimConfig), ctypes.c_int64]
                               + [ctypes.c_void_p] * 7 + [ctypes.POINTER(SimStats)]),
+    'nrhip_simulate_event_groups': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(SimConfig),
+                                                   ctypes.c_int64] + [ctypes.c_void_p] * 7 + [ctypes.c_int64]
+                                    + [ctypes.c_void_p] * 2 + [ctypes.POINTER(SimStats)]),
     'nrhip_sim_fetch': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64]),
     'nrhip_askaryan_spectrum_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, L.c_double_p, L.c_double_p,
                                                      L.c_int32_p, L.c_double_p, L.c_double_p, L.c_double_p, ctypes.c_int32,
@@ -159,23 +162,43 @@ class Station:
     # ---- the hot path --------------------------------------------------------------------------------------
     def simulate_events_dev(self, n_events, d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL, d_triggered,
                             askaryan_model='Alvarez2009', delta_C_cut=0.698, min_efield_amplitude=None,
-                            trigger_threshold=None, dump_traces=False, no_pruning=False, want_stats=True):
-        """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None)."""
+                            trigger_threshold=None, dump_traces=False, no_pruning=False, want_stats=True,
+                            d_vertex_time=None, n_groups=None, d_group_begin=None):
+        """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
+        Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
+        d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None."""
         cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
                         float(2.0 * self.vrms_efield if min_efield_amplitude is None else min_efield_amplitude),
                         float(3.0 * self.vrms if trigger_threshold is None else trigger_threshold), int(bool(dump_traces)),
                         int(bool(no_pruning)))
         stats = SimStats()
-        L.check(self._lib.nrhip_simulate_events(self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith,
-                                                d_azimuth, d_energy, d_type, d_kL, d_triggered,
-                                                ctypes.byref(stats) if want_stats else None))
+        L.check(self._lib.nrhip_simulate_event_groups(
+            self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,
+            d_vertex_time, int(n_events if n_groups is None else n_groups), d_group_begin, d_triggered,
+            ctypes.byref(stats) if want_stats else None))
         return stats.as_dict() if want_stats else None
 
-    def simulate_events(self, vertex, zenith, azimuth, energy, shower_type, k_L=None, **kw):
-        """Host-array convenience form: uploads the event list, runs the hot path, returns (triggered mask, stats)."""
+    def simulate_events(self, vertex, zenith, azimuth, energy, shower_type, k_L=None, vertex_time=None, group_id=None,
+                        **kw):
+        """Host-array convenience form: uploads the shower list, runs the hot path, returns (triggered mask, stats).
+        `group_id` [n] (equal ids consecutive, like the event_group_ids of the reference's input files) makes showers of
+        one id a single event group: their signals add up in the channels (simulation.py:143) and the mask has one entry
+        per group, in order of first appearance.  `vertex_time` [n] shifts a shower's signals (simulation.py:259-268)."""
         ctx = self.ctx
         vertex = L.f64(vertex).reshape(-1, 3)
         n = len(vertex)
+        n_groups, gb, vt = n, None, None
+        if group_id is not None and n:
+            gid = np.asarray(group_id).reshape(-1)
+            if len(gid) != n:
+                raise ValueError("group_id must have one entry per shower")
+            first = np.flatnonzero(np.concatenate([[True], gid[1:] != gid[:-1]]))
+            if len(np.unique(gid)) != len(first):
+                raise ValueError("showers of one event group must be consecutive")
+            gb = np.ascontiguousarray(np.concatenate([first, [n]]), dtype=np.int32)
+            n_groups = len(first)
+        if vertex_time is not None:
+            vt = np.ascontiguousarray(np.broadcast_to(L.f64(vertex_time), (n,)))
         st = np.ascontiguousarray([SHOWER_TO_INT[str(s).upper()] if not isinstance(s, (int, np.integer)) else int(s)
                                    for s in np.broadcast_to(shower_type, (n,))], dtype=np.int32)
         kL = np.ascontiguousarray(np.broadcast_to(np.nan if k_L is None else L.f64(k_L), (n,)), dtype=np.float64)
@@ -184,13 +207,15 @@ class Station:
                 np.ascontiguousarray(np.broadcast_to(L.f64(azimuth), (n,))),
                 np.ascontiguousarray(np.broadcast_to(L.f64(energy), (n,))), st, np.ascontiguousarray(kL)]
         dptrs = [ctx.to_device(a) for a in arrs]
-        dtrig = ctx.malloc(max(n, 1))
+        dtrig = ctx.malloc(max(n_groups, 1))
+        extra = [ctx.to_device(a) if a is not None else None for a in (vt, gb)]
         try:
-            stats = self.simulate_events_dev(n, *dptrs, dtrig, **kw)
-            trig = np.zeros(n, np.uint8)
+            stats = self.simulate_events_dev(n, *dptrs, dtrig, d_vertex_time=extra[0], n_groups=n_groups,
+                                             d_group_begin=extra[1], **kw)
+            trig = np.zeros(n_groups, np.uint8)
             ctx.to_host(trig, dtrig)
         finally:
-            for p in dptrs + [dtrig]:
+            for p in dptrs + [dtrig] + [e for e in extra if e is not None]:
                 ctx.free(p)
         return trig.astype(bool), stats
 

@@ -484,3 +484,26 @@ def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, v
     V, t_min, L = combined_voltage(efs, st, filters)
     out.update(V=V, t_min=t_min, L=L, triggered=threshold_trigger(V, trigger_sigma * vrms))
     return out
+
+
+def simulate_event_group(showers, st, ice, vrms, vrms_efield, att_model='SP1', n_freq=25, model='Alvarez2009',
+                         filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0, min_efield_amplitude=2.0):
+    """An event group of several showers through simulation.run()'s sequence (:1454-1600): calculate_sim_efield loops
+    over the showers per channel (:143), the candidate flag, the common time grid, the channel sums and the trigger are
+    per group.  `showers`: list of dicts with vertex, zenith, azimuth, energy, shower_type, k_L, vertex_time."""
+    efs = []
+    for i, sh in enumerate(showers):
+        e = sim_efields_for_event(sh['vertex'], sh['zenith'], sh['azimuth'], sh['energy'], sh['shower_type'], sh.get('k_L'),
+                                  st, ice, att_model, n_freq, model, delta_C_cut, vertex_time=sh.get('vertex_time', 0.))
+        for ef in e:
+            ef['shower'] = i
+        efs += e
+    out = dict(rays=efs, candidate=False, triggered=False, L=0, t_min=np.nan)
+    for ef in efs:
+        if ef['max_efield'] > min_efield_amplitude * vrms_efield:
+            out['candidate'] = True
+    if not efs or not out['candidate']:
+        return out
+    V, t_min, L = combined_voltage(efs, st, filters)
+    out.update(V=V, t_min=t_min, L=L, triggered=threshold_trigger(V, trigger_sigma * vrms))
+    return out

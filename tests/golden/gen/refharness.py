@@ -156,9 +156,11 @@ def make_propagator(config, det):
 
 def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, trigger_sigma=3.0):
     """One event group through the reference, following simulation.run() (simulation.py:1454-1600).
+    `shower` is one RadioShower or the list of showers of the event group.
 
     Returns a dict of everything the parity tests compare.
     """
+    showers = list(shower) if isinstance(shower, (list, tuple)) else [shower]
     sid = det.get_station_ids()[0]
     evt = NuRadioReco.framework.event.Event(ev_id, 0)
     station = NuRadioReco.framework.station.Station(sid)
@@ -166,13 +168,14 @@ def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, tri
     sim_station.set_is_neutrino()
     station.set_sim_station(sim_station)
     evt.set_station(station)
-    evt.add_sim_shower(shower)
+    for sh_ in showers:
+        evt.add_sim_shower(sh_)
 
     out = dict(rays=[], candidate=False, triggered=False, L=0, t_min=np.nan)
     candidate = False
     for ch in det.get_channel_ids(sid):
         ss = simulation.calculate_sim_efield(
-            showers=[shower], station_id=sid, channel_id=ch, det=det, propagator=prop, medium=ice,
+            showers=showers, station_id=sid, channel_id=ch, det=det, propagator=prop, medium=ice,
             config=config, min_efield_amplitude=float(config['speedup']['min_efield_amplitude']) * vrms_efield)
         if ss.is_candidate():
             candidate = True
@@ -183,7 +186,7 @@ def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, tri
             rt = ef[efp.raytracing_solution]
             spec = ef.get_frequency_spectrum().copy()
             out['rays'].append(dict(
-                channel=ch, iS=ef.get_ray_tracing_solution_id(),
+                channel=ch, iS=ef.get_ray_tracing_solution_id(), shower_id=ef.get_shower_id(),
                 C0=rt['ray_tracing_C0'], C1=rt['ray_tracing_C1'], type=rt['ray_tracing_solution_type'],
                 zenith=ef[efp.zenith], azimuth=ef[efp.azimuth], D=ef[efp.nu_vertex_distance],
                 T=ef[efp.nu_vertex_propagation_time], view=ef[efp.nu_viewing_angle],
@@ -202,7 +205,8 @@ def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, tri
             r['max_amp_ray'] = sc[chp.maximum_amplitude_envelope]
         station.add_sim_station(ss)
     out['candidate'] = candidate
-    out['k_L'] = shower[shp.k_L] if shower.has_parameter(shp.k_L) else np.nan
+    out['k_L'] = showers[0][shp.k_L] if showers[0].has_parameter(shp.k_L) else np.nan
+    out['k_L_all'] = [sh_[shp.k_L] if sh_.has_parameter(shp.k_L) else np.nan for sh_ in showers]
     if len(station.get_sim_station().get_electric_fields()) == 0 or not candidate:
         return out
     simulation.apply_det_response(evt, det, config, filter_amp, add_noise=False)
