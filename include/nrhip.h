@@ -154,7 +154,20 @@ typedef struct {
     int32_t dump_traces;          /* != 0: keep the channel voltage traces of the chunk for nrhip_sim_fetch */
     int32_t no_pruning;           /* != 0: evaluate attenuation and max |E(t)| for EVERY kept ray (parity tests); by
                                      default rays of events that provably cannot pass the candidate cut are skipped */
+    /* trigger (NuRadioReco/modules/trigger/simpleThreshold.py, highLowThreshold.py), all channels of the station:
+       NRHIP_TRIG_SIMPLE    per-sample |V| >= trigger_threshold;
+       NRHIP_TRIG_HIGH_LOW  a sample >= threshold_high AND a sample <= threshold_low inside a sliding window of
+                            high_low_window (get_high_low_triggers :13-80);
+       then get_majority_logic (:82-150): per-channel flags OR-dilated over coinc_window, summed over channels,
+       >= n_coincidences.  n_coincidences <= 1 with NRHIP_TRIG_SIMPLE is the plain OR (trigger_type 0 and all-zero
+       fields reproduce the previous behaviour).  trigger times: nrhip_sim_fetch("ev_trigger_time").              */
+    int32_t trigger_type;
+    int32_t n_coincidences;
+    double threshold_high, threshold_low;   /* [V] */
+    double high_low_window, coinc_window;   /* [ns] */
 } nrhip_sim_config;
+#define NRHIP_TRIG_SIMPLE 0
+#define NRHIP_TRIG_HIGH_LOW 1
 
 #define NRHIP_N_STAGES 9
 /* stage_ms: device time (HIP events on the context's stream) of 0 ray tracing, 1 ray selection + setup,

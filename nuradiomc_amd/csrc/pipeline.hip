@@ -303,6 +303,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     NEED(ev.L = WS("ev_L", int, n_groups));
     NEED(ev.candidate = WS("ev_candidate", unsigned char, n_groups));
     NEED(ev.t_min = WS("ev_t_min", double, n_groups));
+    int* trigger_bin;
+    NEED(trigger_bin = WS("ev_trigger_bin", int, n_groups));
+    HIPCHK(hipMemsetAsync(trigger_bin, 0xFF, sizeof(int) * n_groups, sm));
     EventIn evin{energy, shower_type, k_L, vertex_time};
     // ray range of every event group (rays are ordered by shower; a group's showers are consecutive)
     int* grp_ray;
@@ -470,8 +473,19 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         // 6. channel voltages + trigger
         const int n_items = n_cand * n_ch;
         S.n_channel_items = n_items;
+        TriggerDev trg;
+        trg.type = cfg->trigger_type == NRHIP_TRIG_HIGH_LOW ? 1 : 0;
+        trg.n_coinc = cfg->n_coincidences > 1 ? cfg->n_coincidences : 1;
+        trg.threshold = cfg->trigger_threshold;
+        trg.high = cfg->threshold_high;
+        trg.low = cfg->threshold_low;
+        trg.w_hl = std::max(1, (int)std::lrint(cfg->high_low_window * sd.fs));
+        trg.w_coinc = std::max(1, (int)std::lrint(cfg->coinc_window * sd.fs));
+        if (trg.coincidence() && (maxL > FFT_MAX || sd.N > FFT_MAX / 2 || getenv("NRHIP_CHANNEL_CZT")))
+            return nrhip_fail_msg("nrhip_simulate_events: high/low and coincidence triggers need traces of at most 8192 samples");
         ChannelOut co;
         NEED(co.maxV = WS("item_maxV", double, n_items));
+        co.trigger_bin = trigger_bin;
         co.triggered = triggered;
         co.trace = nullptr;
         co.trace_offset = nullptr;
@@ -496,9 +510,11 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(it_off = WS("item_need_offset", int, (size_t)n_items + 1));
         NEED(it_tmp = WS("scan_tmp4", int, scan_tiles((long)n_items + 1)));
         NEED(it_list = WS("item_list", int, (size_t)n_items));
-        launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, cfg->askaryan_model,
-                       cfg->trigger_threshold, ctx->twiddle, ctx->w16, tab, scratch, co,
-                       (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, maxL, it_need, it_off, it_tmp, it_list);
+        int* coinc_cnt;
+        NEED(coinc_cnt = WS("coincidence_count", int, trg.coincidence() ? (size_t)channel_grid_blocks() * FFT_MAX : 1));
+        launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, cfg->askaryan_model, trg,
+                       ctx->twiddle, ctx->w16, tab, scratch, co, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, maxL, it_need,
+                       it_off, it_tmp, it_list, coinc_cnt);
         LCHK("channel");
         MARK(8);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here

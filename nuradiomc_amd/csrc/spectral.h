@@ -90,7 +90,19 @@ struct LengthTables {
                      //                                response irfft_L(antenna x filter), all scale factors folded in
 };
 
+// trigger logic of the station (nrhip_sim_config), times in samples
+struct TriggerDev {
+    int type;            // 0 simple threshold, 1 high/low
+    int n_coinc;         // channels required inside the coincidence window
+    double threshold;    // simple: |V| >= threshold
+    double high, low;    // high/low: a sample >= high and a sample <= low inside w_hl samples
+    int w_hl, w_coinc;   // window lengths [samples]
+    __host__ __device__ bool coincidence() const { return type != 0 || n_coinc > 1; }  // anything but the plain OR of simple thresholds
+    __host__ __device__ double prefilter() const { return type == 0 ? threshold : (high > -low ? high : -low); }
+};
+
 struct ChannelOut {
+    int* trigger_bin;           // [n_events] first triggered sample of the event's common trace (-1: none / not evaluated)
     double* maxV;               // [n_items]
     unsigned char* triggered;   // [n_events]
     double* trace;              // optional dump
@@ -131,9 +143,9 @@ void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const St
 int channel_grid_blocks();
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
-                    double threshold, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
+                    const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
-                    int* item_list);
+                    int* item_list, int* coinc_cnt);
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,
                            const double2* tw, const LengthTables& tab, double2* scratch, double* V);

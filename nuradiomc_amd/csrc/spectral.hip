@@ -1250,12 +1250,17 @@ __global__ void channel_event_flags_kernel(int n_cand, int n_ch, const int* __re
 __global__ void __launch_bounds__(CONV_NT)
 channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list, const int* __restrict__ need,
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
-                    const int* __restrict__ ev_len_index, StationDev st, int ask_model, double threshold,
+                    const int* __restrict__ ev_len_index, StationDev st, int ask_model, TriggerDev trg,
                     const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab, int log2nh,
-                    ChannelOut out, int exact)
+                    ChannelOut out, int exact, int* __restrict__ coinc_cnt)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = FFT_MAX;
+    const double threshold = trg.threshold;
+    const bool coinc = trg.coincidence();
+    int* cnt = coinc_cnt + (long)blockIdx.x * FFT_MAX;  // per sample: channels whose dilated flag is set (coincidence modes)
+    __shared__ int s_scan[CONV_NT];
+    __shared__ int s_first;
     const int N = st.N, nh = N / 2;
     double2* z = (double2*)smem;
     double* S = (double*)smem;
@@ -1270,12 +1275,15 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     __shared__ int s_ev_trig;
     for (int le = blockIdx.x; le < n_list_events; le += gridDim.x) {
       if (threadIdx.x == 0) s_ev_trig = 0;
+      const int ev_e = item_event[item_list[le]], ev_L = ev.L[ev_e];
+      if (coinc)
+          for (int n = threadIdx.x; n < ev_L; n += blockDim.x) cnt[n] = 0;
       __syncthreads();
       for (int ch = 0; ch < st.n_ch; ch++) {
         const int item = item_list[le] * st.n_ch + ch;
         if (!need[item]) continue;
         const int e = item_event[item / st.n_ch];
-        if (!exact && s_ev_trig) {
+        if (!exact && !coinc && s_ev_trig) {
             if (threadIdx.x == 0) out.maxV[item] = NAN;
             continue;
         }
@@ -1351,12 +1359,65 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             }
             __syncthreads();
             fft_dit_t<FFT_LOG2_MAX, CONV_NT>(z, tw, true);
-            for (int n = threadIdx.x; n < L; n += blockDim.x) {
-                double v = S[n] + S[n + L];
-                if (out.trace) out.trace[out.trace_offset[item] + n] = v;
-                double av = fabs(v);
-                vmax = fmax(vmax, av);
-                if (n < L - 1 && av >= threshold) trig = 1;
+            if (!coinc) {
+                for (int n = threadIdx.x; n < L; n += blockDim.x) {
+                    double v = S[n] + S[n + L];
+                    if (out.trace) out.trace[out.trace_offset[item] + n] = v;
+                    double av = fabs(v);
+                    vmax = fmax(vmax, av);
+                    if (n < L - 1 && av >= threshold) trig = 1;
+                }
+            } else {
+                // per-channel flags (simpleThreshold.py:14-29 / highLowThreshold.py:13-80), OR-dilated over the coincidence
+                // window (get_majority_logic :82-150: flag i stays up for w_coinc samples), counted per sample in cnt
+                for (int n = threadIdx.x; n < L; n += blockDim.x) {
+                    double v = S[n] + S[n + L];
+                    if (out.trace) out.trace[out.trace_offset[item] + n] = v;
+                    vmax = fmax(vmax, fabs(v));
+                    S[n] = v;
+                }
+                __syncthreads();
+                int* A = (int*)(S + M);  // index of the last raised flag at or before sample i (-1: none)
+                const int nb = (trg.type == 0) ? L : L - 1;
+                for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+                    bool flag;
+                    if (trg.type == 0) {
+                        flag = fabs(S[i]) >= threshold;
+                    } else {
+                        bool hi = false, lo = false;
+                        for (int k = max(0, i - trg.w_hl + 1); k <= i; k++) {
+                            hi = hi || (S[k] >= trg.high);
+                            lo = lo || (S[k] <= trg.low);
+                        }
+                        if (i - trg.w_hl + 1 < 0) {  // the reference pads with zeros in front
+                            hi = hi || (0. >= trg.high);
+                            lo = lo || (0. <= trg.low);
+                        }
+                        flag = hi && lo;
+                    }
+                    A[i] = flag ? i : -1;
+                }
+                __syncthreads();
+                {   // inclusive running maximum of A[0 .. nb): contiguous chunk per thread, then a scan of the chunk maxima
+                    const int chunk = (nb + CONV_NT - 1) / CONV_NT, b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, nb);
+                    int run = -1;
+                    for (int i = b0; i < b1; i++) { run = max(run, A[i]); A[i] = run; }
+                    s_scan[threadIdx.x] = run;
+                    __syncthreads();
+                    for (int off = 1; off < CONV_NT; off <<= 1) {
+                        int v = ((int)threadIdx.x >= off) ? s_scan[threadIdx.x - off] : -1;
+                        __syncthreads();
+                        s_scan[threadIdx.x] = max(s_scan[threadIdx.x], v);
+                        __syncthreads();
+                    }
+                    const int before = threadIdx.x > 0 ? s_scan[threadIdx.x - 1] : -1;
+                    for (int i = b0; i < b1; i++) A[i] = max(A[i], before);
+                    __syncthreads();
+                }
+                const int wc = min(trg.w_coinc, nb);
+                for (int i = threadIdx.x; i < nb - 1; i += blockDim.x)
+                    if (A[i] >= 0 && i - A[i] < wc) cnt[i] += 1;
+                __syncthreads();
             }
         }
         if (trig) s_trig = 1;
@@ -1366,6 +1427,21 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             if (s_trig) { out.triggered[e] = 1; s_ev_trig = 1; }
         }
         __syncthreads();
+      }
+      if (coinc) {  // majority logic over the channels of the event
+          if (threadIdx.x == 0) s_first = 0x7fffffff;
+          __syncthreads();
+          const int nb = (trg.type == 0) ? ev_L : ev_L - 1;
+          int first = 0x7fffffff;
+          for (int i = threadIdx.x; i < nb - 1; i += blockDim.x)
+              if (cnt[i] >= trg.n_coinc) first = min(first, i);
+          if (first != 0x7fffffff) atomicMin(&s_first, first);
+          __syncthreads();
+          if (threadIdx.x == 0 && s_first != 0x7fffffff) {
+              out.triggered[ev_e] = 1;
+              out.trigger_bin[ev_e] = s_first;
+          }
+          __syncthreads();
       }
     }
 }
@@ -1886,20 +1962,20 @@ void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const St
 int channel_grid_blocks() { return 256; }
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
-                    double threshold, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
+                    const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
-                    int* item_list)
+                    int* item_list, int* coinc_cnt)
 {
     if (n_items <= 0) return;
     set_big_lds();
     int nh = st.N / 2;
     int grid = n_items < channel_grid_blocks() ? n_items : channel_grid_blocks();
     // traces up to FFT_MAX samples: prefilter, then one real convolution per listed item; longer ones (or
-    // NRHIP_CHANNEL_CZT=1): chirp-z per ray
+    // NRHIP_CHANNEL_CZT=1): chirp-z per ray (plain OR of simple thresholds only; the caller checks)
     int skip_upto = 0;
     if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT")) {
         hipLaunchKernelGGL(channel_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev,
-                           ev_len_index, st, threshold, tab.hnorm, exact, out.maxV, need);
+                           ev_len_index, st, trig.prefilter(), tab.hnorm, exact, out.maxV, need);
         const int n_cand = n_items / st.n_ch;
         int* ev_need = need + n_items;  // [n_cand + 1]
         hipLaunchKernelGGL(channel_event_flags_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, st.n_ch, need,
@@ -1910,14 +1986,14 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                            item_list);
         int cgrid = n_cand < channel_grid_blocks() ? n_cand : channel_grid_blocks();
         hipLaunchKernelGGL(channel_conv_kernel, dim3(cgrid), dim3(CONV_NT), (size_t)FFT_MAX * 16, s, need_offset + n_cand,
-                           item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, threshold, tw, w16, tab,
-                           ilog2(nh), out, exact);
+                           item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16, tab,
+                           ilog2(nh), out, exact, coinc_cnt);
         skip_upto = FFT_MAX;
         if (max_length <= FFT_MAX) return;
     }
     size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
     hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
-                       ask_model, threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto);
+                       ask_model, trig.threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto);
 }
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,

@@ -24,7 +24,9 @@ class StationDesc(ctypes.Structure):
 class SimConfig(ctypes.Structure):
     _fields_ = [('askaryan_model', ctypes.c_int32), ('delta_C_cut', ctypes.c_double),
                 ('min_efield_amplitude', ctypes.c_double), ('trigger_threshold', ctypes.c_double),
-                ('dump_traces', ctypes.c_int32), ('no_pruning', ctypes.c_int32)]
+                ('dump_traces', ctypes.c_int32), ('no_pruning', ctypes.c_int32), ('trigger_type', ctypes.c_int32),
+                ('n_coincidences', ctypes.c_int32), ('threshold_high', ctypes.c_double), ('threshold_low', ctypes.c_double),
+                ('high_low_window', ctypes.c_double), ('coinc_window', ctypes.c_double)]
 
 
 class SimStats(ctypes.Structure):
@@ -163,14 +165,22 @@ class Station:
     def simulate_events_dev(self, n_events, d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL, d_triggered,
                             askaryan_model='Alvarez2009', delta_C_cut=0.698, min_efield_amplitude=None,
                             trigger_threshold=None, dump_traces=False, no_pruning=False, want_stats=True,
-                            d_vertex_time=None, n_groups=None, d_group_begin=None):
+                            d_vertex_time=None, n_groups=None, d_group_begin=None, trigger='simple', n_coincidences=1,
+                            threshold_high=None, threshold_low=None, high_low_window=5., coinc_window=200.):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
-        d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None."""
+        d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
+        trigger: 'simple' (|V| >= trigger_threshold, simpleThreshold.py) or 'high_low' (highLowThreshold.py: threshold_high /
+        threshold_low inside high_low_window), both followed by the majority logic over coinc_window with n_coincidences."""
+        if trigger not in ('simple', 'high_low'):
+            raise NotImplementedError("trigger {} is not provided (simple, high_low)".format(trigger))
         cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
                         float(2.0 * self.vrms_efield if min_efield_amplitude is None else min_efield_amplitude),
                         float(3.0 * self.vrms if trigger_threshold is None else trigger_threshold), int(bool(dump_traces)),
-                        int(bool(no_pruning)))
+                        int(bool(no_pruning)), 1 if trigger == 'high_low' else 0, int(n_coincidences),
+                        float(3.0 * self.vrms if threshold_high is None else threshold_high),
+                        float(-3.0 * self.vrms if threshold_low is None else threshold_low), float(high_low_window),
+                        float(coinc_window))
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_event_groups(
             self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,
@@ -254,7 +264,7 @@ class Station:
         return V, t_min
 
     _FETCH_DTYPES = {'ray_event': np.int32, 'ray_channel': np.int32, 'ray_solution': np.int32, 'ev_n_rays': np.int32,
-                     'ev_L': np.int32, 'ev_candidate': np.uint8, 'item_event': np.int32, 'trace_offset': np.int64,
+                     'ev_L': np.int32, 'ev_candidate': np.uint8, 'ev_trigger_bin': np.int32, 'item_event': np.int32, 'trace_offset': np.int64,
                      'ray_r_theta': np.complex128, 'ray_r_phi': np.complex128, 'lengths': np.int32,
                      'pair_n_sol': np.int32, 'slot_type': np.int32, 'ev_ray_begin': np.int32, 'ray_active': np.int32,
                      'ray_active_list': np.int32, 'ray_slot': np.int32, 'slot_keep': np.int32, 'slot_offset': np.int32}

@@ -468,6 +468,37 @@ def threshold_trigger(V, threshold):
     return bool(np.any(np.abs(V[:, :-1]) >= threshold))
 
 
+def high_low_triggers(trace, high, low, window_bins):
+    """get_high_low_triggers (trigger/highLowThreshold.py:13-80), step 1, zero padded at the start: len(trace) - 1 flags"""
+    n = len(trace)
+    padded = np.concatenate([np.zeros(window_bins - 1), trace])
+    frames = np.lib.stride_tricks.sliding_window_view(padded, window_bins)[:n - 1]
+    return np.any(frames >= high, axis=1) & np.any(frames <= low, axis=1)
+
+
+def majority_logic(flags, n_coincidences, window_bins):
+    """get_majority_logic (trigger/highLowThreshold.py:82-150), step 1: (triggered, triggered bins)"""
+    n = len(flags[0])
+    w = min(window_bins, n)
+    tt = []
+    for f in flags:
+        padded = np.concatenate([np.zeros(w - 1, bool), np.asarray(f, bool)])
+        tt.append(np.any(np.lib.stride_tricks.sliding_window_view(padded, w)[:n - 1], axis=1))
+    ttt = np.sum(np.array(tt), axis=0) >= n_coincidences
+    return bool(np.any(ttt)), np.flatnonzero(ttt)
+
+
+def station_trigger(V, fs, trigger='simple', threshold=None, n_coincidences=1, threshold_high=None, threshold_low=None,
+                    high_low_window=5., coinc_window=200.):
+    """simpleThreshold.triggerSimulator.run / highLowThreshold.triggerSimulator.run on all channels: (triggered, bins)"""
+    dt = 1. / fs
+    if trigger == 'simple':
+        flags = [np.abs(v) >= threshold for v in V]
+    else:
+        flags = [high_low_triggers(v, threshold_high, threshold_low, int(np.round(high_low_window / dt))) for v in V]
+    return majority_logic(flags, n_coincidences, int(np.round(coinc_window / dt)))
+
+
 def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, vrms, vrms_efield, att_model='SP1',
                    n_freq=25, model='Alvarez2009', filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0,
                    min_efield_amplitude=2.0, rays=None):

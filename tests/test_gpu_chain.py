@@ -327,3 +327,42 @@ def test_event_groups(gpu_ctx_factory):
     assert np.array_equal(trig, trig_p) and np.array_equal(cand, st.fetch('ev_candidate'))
     with pytest.raises(ValueError):
         st.simulate_events(*args, group_id=np.roll(g['group'], 1))
+
+
+@pytest.mark.parametrize('kw', [dict(trigger='high_low', n_coincidences=2, hi=2.0, lo=-2.0, high_low_window=5., coinc_window=30.),
+                                dict(trigger='high_low', n_coincidences=1, hi=3.0, lo=-3.0, high_low_window=5., coinc_window=200.),
+                                dict(trigger='high_low', n_coincidences=3, hi=1.5, lo=-2.5, high_low_window=3., coinc_window=10.),
+                                dict(trigger='simple', n_coincidences=3, thr=2.0, coinc_window=20.),
+                                dict(trigger='simple', n_coincidences=2, thr=3.0, coinc_window=5000.)])
+def test_trigger_modes(gpu_ctx_factory, kw):
+    """high/low threshold and n-fold coincidence triggers (highLowThreshold.py:13-150, simpleThreshold.py) fused into the
+    channel kernel: the mask and the first triggered bin must be what the reference's logic (oracle restatement, pinned
+    bit-exactly by tests/golden/ref_trigger.npz) gives on the very traces the kernel produced; production mode (bounds,
+    no trace dump) gives the same mask."""
+    g = golden('chain_N256.npz')
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    n = 300
+    kL = np.where(np.isnan(g['ev_k_L'][:n]), 1.0, g['ev_k_L'][:n])
+    args = (g['vertex'][:n], g['zenith'][:n], g['azimuth'][:n], 3 * g['energy'][:n], g['shower_type'][:n], kL)
+    vr = st.vrms
+    opts = dict(trigger=kw['trigger'], n_coincidences=kw['n_coincidences'], coinc_window=kw['coinc_window'])
+    okw = dict(trigger=kw['trigger'], n_coincidences=kw['n_coincidences'], coinc_window=kw['coinc_window'])
+    if kw['trigger'] == 'high_low':
+        opts.update(threshold_high=kw['hi'] * vr, threshold_low=kw['lo'] * vr, high_low_window=kw['high_low_window'])
+        okw.update(threshold_high=kw['hi'] * vr, threshold_low=kw['lo'] * vr, high_low_window=kw['high_low_window'])
+    else:
+        opts.update(trigger_threshold=kw['thr'] * vr)
+        okw.update(threshold=kw['thr'] * vr)
+    trig, stats = st.simulate_events(*args, dump_traces=True, **opts)
+    item_event, tr, off, tbin = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset'), st.fetch('ev_trigger_bin')
+    n_ch = len(g['det_pos'])
+    expect = np.zeros(n, bool)
+    for i, e in enumerate(item_event):
+        V = np.array([tr[off[i * n_ch + c]:off[i * n_ch + c + 1]] for c in range(n_ch)])
+        t, bins = so.station_trigger(V, st.sampling_rate, **okw)
+        expect[e] = t
+        assert tbin[e] == (bins[0] if t else -1), e
+    assert np.array_equal(trig, expect) and 3 <= trig.sum() < len(item_event)
+    trig_p, _ = st.simulate_events(*args, **opts)
+    assert np.array_equal(trig_p, trig)

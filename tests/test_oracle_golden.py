@@ -101,3 +101,29 @@ def test_attenuation_vs_reference_python_path(name):
     assert np.isfinite(ref).sum() > 1000
     assert max_rel(out, ref) < 1e-9
     assert nev[np.isfinite(ref)].max() > 200  # the fixture exercises deep bisection + extrapolation
+
+
+def test_trigger_primitives_vs_reference():
+    """high/low threshold flags, simple threshold flags and the majority logic (coincidence window, n-fold) against
+    outputs of the reference's own functions (tests/golden/gen/gen_trigger.py); bit-exact, triggered bins included."""
+    from oracle import spectral_oracle as so
+    g = golden('ref_trigger.npz')
+    vrms, fs = float(g['vrms']), float(g['fs'])
+    params = [eval(p) for p in g['params']]  # dict literals written by the generator
+    n_trig = 0
+    for it in range(int(g['n_traces'])):
+        V = g['V_%d' % it]
+        for ip, p in enumerate(params):
+            if p['kind'] == 'high_low':
+                flags = [so.high_low_triggers(v, p['high'] * vrms, p['low'] * vrms, int(np.round(p['hl_win'] * fs))) for v in V]
+                trig, bins = so.station_trigger(V, fs, 'high_low', n_coincidences=p['ncoinc'], threshold_high=p['high'] * vrms,
+                                                threshold_low=p['low'] * vrms, high_low_window=p['hl_win'],
+                                                coinc_window=p['coinc'])
+            else:
+                flags = [np.abs(v) >= p['thr'] * vrms for v in V]
+                trig, bins = so.station_trigger(V, fs, 'simple', threshold=p['thr'] * vrms, n_coincidences=p['ncoinc'],
+                                                coinc_window=p['coinc'])
+            assert np.array_equal(np.array(flags), g['flags_%d_%d' % (it, ip)]), (it, ip)
+            assert trig == bool(g['trig_%d_%d' % (it, ip)]) and np.array_equal(bins, g['bins_%d_%d' % (it, ip)]), (it, ip)
+            n_trig += trig
+    assert n_trig > 20
