@@ -47,6 +47,7 @@ extern "C" {
 /* analytic antenna models (NuRadioReco/detector/antennapattern.py:1580-1768) */
 #define NRHIP_ANT_VPOL 0
 #define NRHIP_ANT_HPOL 1
+#define NRHIP_ANT_LPDA 2   /* analytic_LPDA (antennapattern.py:1676-1713): both VEL components, three phase regimes */
 
 typedef struct nrhip_ctx nrhip_ctx;
 

@@ -95,6 +95,7 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     s->ctx = ctx;
     int n = d->n_channels;
     std::vector<double> rot(9 * n), roti(9 * n);
+    int tab_mask = 0;
     // model frame of the analytic antennas: boresight (0, 0), tines normal (90 deg, 0) (antennapattern.py:1612-1636)
     double e1[3], e2[3], e3[3];
     sph2cart_h(0., 0., e1);
@@ -103,10 +104,12 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     double E[9] = {e1[0], e1[1], e1[2], e2[0], e2[1], e2[2], e3[0], e3[1], e3[2]}, Ei[9];
     if (!inv3(E, Ei)) { delete s; return nrhip_fail_msg("nrhip_station_create: singular antenna model frame"); }
     for (int c = 0; c < n; c++) {
-        if (d->antenna_model[c] != NRHIP_ANT_VPOL && d->antenna_model[c] != NRHIP_ANT_HPOL) {
+        if (d->antenna_model[c] != NRHIP_ANT_VPOL && d->antenna_model[c] != NRHIP_ANT_HPOL &&
+            d->antenna_model[c] != NRHIP_ANT_LPDA) {
             delete s;
-            return nrhip_fail_msg("nrhip_station_create: antenna model not implemented (analytic_VPol, analytic_HPol)");
+            return nrhip_fail_msg("nrhip_station_create: antenna model not implemented (analytic_VPol, analytic_HPol, analytic_LPDA)");
         }
+        tab_mask |= d->antenna_model[c] == NRHIP_ANT_LPDA ? 0x1c : (1 << d->antenna_model[c]);
         const double* o = d->orientation + 4 * c;
         double a1[3], a2[3], a3[3];
         sph2cart_h(o[0], o[1], a1);
@@ -166,6 +169,7 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     v.att_bin_width = n_bins ? d->att_bound_bin_width : 0.;
     v.att_bin_inv = n_bins ? s->d_attbin.as<double>() : nullptr;
     v.n_ch = n;
+    v.tab_mask = tab_mask;
     v.N = d->n_samples;
     v.n_fc = d->n_att_freq;
     v.fs = d->sampling_rate;
@@ -335,6 +339,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     NEED(w.az = WS("ray_azimuth", double, nr));
     NEED(w.vel_T = WS("ray_vel_T", double, 4 * nr));
     NEED(w.theta_ant = WS("ray_theta_ant", double, nr));
+    NEED(w.vfac_t = WS("ray_vfac_theta", double, nr));
+    NEED(w.vfac_p = WS("ray_vfac_phi", double, nr));
+    NEED(w.tab = WS("ray_antenna_table", int, nr));
     NEED(w.att = WS("ray_att", double, nr * sd.n_fc));
     NEED(w.e_norm = WS("ray_e_norm", double, nr));
     double *zint, *max_efield;
@@ -460,13 +467,13 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         LengthTables tab;
         NEED(tab.B_fwd = WS("tab_B_fwd", double2, lens.size() * (size_t)FFT_MAX));
         NEED(tab.B_inv = WS("tab_B_inv", double2, lens.size() * (size_t)FFT_MAX));
-        NEED(tab.vel = WS("tab_vel", double2, lens.size() * 2 * (size_t)NRHIP_SPEC_STRIDE));
+        NEED(tab.vel = WS("tab_vel", double2, lens.size() * NRHIP_N_ANT_TAB * (size_t)NRHIP_SPEC_STRIDE));
         NEED(tab.E = WS("tab_E", double2, lens.size() * (size_t)NRHIP_E_STRIDE));
         NEED(tab.H = WS("tab_H", double2, lens.size() * (size_t)NRHIP_SPEC_STRIDE));
         NEED(tab.Cf = WS("tab_Cf", double2, lens.size() * (size_t)NRHIP_SPEC_STRIDE));
         NEED(tab.Ci = WS("tab_Ci", double2, lens.size() * (size_t)FFT_MAX));
-        NEED(tab.hnorm = WS("tab_hnorm", double, lens.size() * 2));
-        NEED(tab.G = WS("tab_G", double2, lens.size() * 2 * (size_t)NRHIP_G_STRIDE));
+        NEED(tab.hnorm = WS("tab_hnorm", double, lens.size() * NRHIP_N_ANT_TAB));
+        NEED(tab.G = WS("tab_G", double2, lens.size() * NRHIP_N_ANT_TAB * (size_t)NRHIP_G_STRIDE));
         launch_length_tables(sm, (int)lens.size(), d_lens, sd, st->filters, ctx->twiddle, ctx->w16, tab);
         LCHK("length_tables");
         MARK(7);
@@ -510,11 +517,13 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(it_off = WS("item_need_offset", int, (size_t)n_items + 1));
         NEED(it_tmp = WS("scan_tmp4", int, scan_tiles((long)n_items + 1)));
         NEED(it_list = WS("item_list", int, (size_t)n_items));
+        double2* conv_acc;  // frequency-domain sum over antenna tables (LPDA channels seeing rays in different lobes)
+        NEED(conv_acc = WS("conv_table_sum", double2, (sd.tab_mask & 0x1c) ? (size_t)channel_grid_blocks() * FFT_MAX : 1));
         int* coinc_cnt;
         NEED(coinc_cnt = WS("coincidence_count", int, trg.coincidence() ? (size_t)channel_grid_blocks() * FFT_MAX : 1));
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, cfg->askaryan_model, trg,
                        ctx->twiddle, ctx->w16, tab, scratch, co, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, maxL, it_need,
-                       it_off, it_tmp, it_list, coinc_cnt);
+                       it_off, it_tmp, it_list, coinc_cnt, conv_acc);
         LCHK("channel");
         MARK(8);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here
@@ -596,12 +605,12 @@ int nrhip_efield_to_voltage(nrhip_ctx* ctx, nrhip_station* st, int32_t n_efields
     LengthTables tab;
     NEED(tab.B_fwd = WS("tab_B_fwd", double2, (size_t)FFT_MAX));
     NEED(tab.B_inv = WS("tab_B_inv", double2, (size_t)FFT_MAX));
-    NEED(tab.vel = WS("tab_vel", double2, 2 * (size_t)NRHIP_SPEC_STRIDE));
+    NEED(tab.vel = WS("tab_vel", double2, NRHIP_N_ANT_TAB * (size_t)NRHIP_SPEC_STRIDE));
     NEED(tab.E = WS("tab_E", double2, (size_t)NRHIP_E_STRIDE));
     NEED(tab.H = WS("tab_H", double2, (size_t)NRHIP_SPEC_STRIDE));
     NEED(tab.Cf = WS("tab_Cf", double2, (size_t)NRHIP_SPEC_STRIDE));
     NEED(tab.Ci = WS("tab_Ci", double2, (size_t)FFT_MAX));
-    NEED(tab.hnorm = WS("tab_hnorm", double, 2));
+    NEED(tab.hnorm = WS("tab_hnorm", double, NRHIP_N_ANT_TAB));
     tab.G = nullptr;  // the generic path always goes through the chirp-z kernel
     launch_length_tables(sm, 1, d_len, sd, st->filters, ctx->twiddle, ctx->w16, tab);
     LCHK("length_tables");

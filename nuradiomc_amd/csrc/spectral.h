@@ -9,6 +9,7 @@
 #define NRHIP_MAX_POLY 24
 #define NRHIP_SPEC_STRIDE 6146  // max L / 2 + 1 spectrum bins per channel (L <= 12290 with the 8192-point chirp-z)
 #define NRHIP_E_STRIDE 24584    // 2 L phase-table entries per length
+#define NRHIP_N_ANT_TAB 5       // antenna response tables per length: VPol, HPol, LPDA front / side / back lobe phase
 #define NRHIP_G_STRIDE 8200     // FFT_MAX + 1 bins of the 2 FFT_MAX-point real transform of the impulse response (padded)
 
 namespace nrhip {
@@ -19,7 +20,8 @@ struct StationDev {
     double fs, pre_pulse, post_pulse, readout_length, att_bound_depth;
     const double* pos;        // [n_ch][3]
     const double* cable;      // [n_ch]
-    const int* ant_model;     // [n_ch]   0 analytic_VPol, 1 analytic_HPol
+    const int* ant_model;     // [n_ch]   0 analytic_VPol, 1 analytic_HPol, 2 analytic_LPDA
+    int tab_mask;             // bit t set: antenna table t (NRHIP_N_ANT_TAB) is needed by some channel
     const double* rot;        // [n_ch][9] inv(E) A   (antennapattern.py:1190-1216)
     const double* rot_inv;    // [n_ch][9]
     const double* fcoarse;    // [n_fc] attenuation frequency grid
@@ -60,6 +62,8 @@ struct RayWork {
     double *zen, *az;
     double *vel_T;       // [n][4]
     double *theta_ant;
+    double *vfac_t, *vfac_p;  // [n] weight of the on-sky eTheta / ePhi field in the channel voltage (direction + frame)
+    int *tab;            // [n] antenna response table of the ray (0 VPol, 1 HPol, 2..4 LPDA phase regime)
     double *att;         // [n][n_fc]
     double *e_norm;      // [n] L2 norm of the unit-polarisation field trace, sqrt(sum_t s(t)^2) (set by efield_max_kernel)
 };
@@ -80,13 +84,13 @@ struct EventOut {
 struct LengthTables {
     double2* B_fwd;  // [n_len][FFT_MAX]
     double2* B_inv;  // [n_len][FFT_MAX]
-    double2* vel;    // [n_len][2][NRHIP_SPEC_STRIDE]  analytic antenna response on the L grid (0 below 5 MHz)
+    double2* vel;    // [n_len][NRHIP_N_ANT_TAB][NRHIP_SPEC_STRIDE]  analytic antenna response on the L grid (0 below 5 MHz)
     double2* E;      // [n_len][NRHIP_E_STRIDE]        exp(-2 pi i j / (2 L)), j < 2 L: every chirp / phase factor
     double2* H;      // [n_len][NRHIP_SPEC_STRIDE]     filter chain response on the L grid
     double2* Cf;     // [n_len][NRHIP_SPEC_STRIDE]     forward chirp exp(-i pi k^2 / (L/2)), contiguous in k
     double2* Ci;     // [n_len][FFT_MAX]               inverse chirp exp(+i pi n^2 / L), contiguous in n
-    double* hnorm;   // [n_len][2]                     L2 norm of the (antenna x filter) impulse response on the L grid
-    double2* G;      // [n_len][2][NRHIP_G_STRIDE]     (L <= FFT_MAX) spectrum on the 2 FFT_MAX grid of the L-periodic impulse
+    double* hnorm;   // [n_len][NRHIP_N_ANT_TAB]                   L2 norm of the (antenna x filter) impulse response on the L grid
+    double2* G;      // [n_len][NRHIP_N_ANT_TAB][NRHIP_G_STRIDE]    (L <= FFT_MAX) spectrum on the 2 FFT_MAX grid of the L-periodic impulse
                      //                                response irfft_L(antenna x filter), all scale factors folded in
 };
 
@@ -145,7 +149,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
-                    int* item_list, int* coinc_cnt);
+                    int* item_list, int* coinc_cnt, double2* conv_acc);
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,
                            const double2* tw, const LengthTables& tab, double2* scratch, double* V);

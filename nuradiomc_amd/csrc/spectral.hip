@@ -62,7 +62,7 @@ __device__ inline void mat3vec(const double A[9], const double v[3], double o[3]
 // (theta, phi) components of the model's VEL to the on-sky basis of the arrival direction
 // (antennapattern.py:1218-1307); orthonormal bases are inverted by transposition
 __device__ inline void antenna_frame(double zen, double az, const double* rot, const double* roti, double T[4],
-                                     double* theta_ant)
+                                     double* theta_ant, double* phi_ant = nullptr)
 {
     double inc[3], incw[3], th_a, ph_a;
     sph2cart(zen, az, inc);
@@ -79,6 +79,29 @@ __device__ inline void antenna_frame(double zen, double az, const double* rot, c
         T[2 + c] = o[2];
     }
     *theta_ant = th_a;
+    if (phi_ant) *phi_ant = ph_a;
+}
+
+// weights of the on-sky eTheta / ePhi field in the channel voltage and the response table of the ray.  The analytic
+// models factorise: VEL_raw(f; theta, phi) = B_table(f) * d(theta, phi) (antennapattern.py:1672-1768), and the rotation to
+// the on-sky basis (T) is frequency independent, so V(f) = B(f) (vfac_t E_theta(f) + vfac_p E_phi(f)).
+__device__ inline void antenna_factors(int model, const double T[4], double th_a, double ph_a, double* vfac_t,
+                                       double* vfac_p, int* table)
+{
+    double d_theta = 0., d_phi = 0.;
+    if (model == 0) {          // VPol: theta component, sin(theta)
+        d_theta = sin(th_a);
+        *table = 0;
+    } else if (model == 1) {   // HPol: phi component, sin^2(theta)
+        d_phi = sin(th_a) * sin(th_a);
+        *table = 1;
+    } else {                   // LPDA: both components; phase regime by theta (front <= 45 deg < side <= 90 deg < back)
+        d_theta = cos(th_a) * sin(ph_a) * cos(th_a / 2);
+        d_phi = cos(th_a / 2) * cos(ph_a);
+        *table = (th_a <= 45 * 0.017453292519943295) ? 2 : ((th_a <= 90 * 0.017453292519943295) ? 3 : 4);
+    }
+    *vfac_t = T[0] * d_theta + T[1] * d_phi;
+    *vfac_p = T[2] * d_theta + T[3] * d_phi;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -345,10 +368,11 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
     }
     w.r_theta[r] = rth;
     w.r_phi[r] = rph;
-    double T[4], th_a;
-    antenna_frame(zen, az, st.rot + 9 * ch, st.rot_inv + 9 * ch, T, &th_a);
+    double T[4], th_a, ph_a;
+    antenna_frame(zen, az, st.rot + 9 * ch, st.rot_inv + 9 * ch, T, &th_a, &ph_a);
     for (int c = 0; c < 4; c++) w.vel_T[4 * (long)r + c] = T[c];
     w.theta_ant[r] = th_a;
+    antenna_factors(st.ant_model[ch], T, th_a, ph_a, &w.vfac_t[r], &w.vfac_p[r], &w.tab[r]);
     w.slot[r] = slot;
     w.ask[r] = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r], w.R[r],
                               evin.k_L[e]);
@@ -1060,13 +1084,15 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
         for (int n = threadIdx.x; n < FFT_MAX; n += blockDim.x) tab.Ci[(long)il * FFT_MAX + n] = chirp(n, L, +1.);
         // analytic antenna magnitude * phase on the L grid (antennapattern.py:1672-1768), models 0 VPol, 1 HPol;
         // the "remove DC offset" cut below 5 MHz (efieldToVoltageConverter.py:313) is folded in
-        for (int model = 0; model < 2; model++) {
+        for (int model = 0; model < NRHIP_N_ANT_TAB; model++) {
+            if (!((st.tab_mask >> model) & 1)) continue;
             double* mag = (double*)smem;
             int index = 0;
-            if (model == 0) {
+            if (model != 1) {  // np.argmax(freq > cutoff): first bin above 220 MHz (VPol) / 110 MHz (LPDA), 0 if none
+                const double cutoff = (model == 0) ? 0.22 : 0.11;
                 index = m + 1;
-                for (int k = 0; k <= m; k++) {  // np.argmax(freq > cutoff): first bin above 220 MHz (0 if none)
-                    if (k * df > 0.22) { index = k; break; }
+                for (int k = 0; k <= m; k++) {
+                    if (k * df > cutoff) { index = k; break; }
                 }
                 if (index == m + 1) index = 0;
             }
@@ -1074,8 +1100,8 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
             for (int k = threadIdx.x; k <= m; k += blockDim.x) {
                 double f = k * df, v = 0.;
                 if (k > 0) {
-                    if (model == 0) {
-                        double gain = 1.0 / sqrt(f);
+                    if (model != 1) {
+                        double gain = (model == 0) ? 1.0 / sqrt(f) : 1.0;   // LPDA: flat gain
                         v = sqrt(gain) / f;
                         if (k < index) v *= 0.5 - 0.5 * cos(2. * M_PI * k / (2 * index - 1));  // hann(2 index)[k]
                     } else {
@@ -1084,8 +1110,6 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
                         if (f > 0.5 * 2) v = 0.;
                     }
                     lmax = fmax(lmax, v);
-                } else if (model == 0 && index > 0) {
-                    v = 0.;
                 }
                 mag[k] = v;
             }
@@ -1096,25 +1120,31 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
                 __syncthreads();
             }
             double vmax = red[0];
-            double max_vel = model == 0 ? 0.18 : 0.055;
+            double max_vel = model == 0 ? 0.18 : (model == 1 ? 0.055 : 0.55);
             double h2 = 0.;
             for (int k = threadIdx.x; k <= m; k += blockDim.x) {
                 double f = k * df, v = mag[k];
                 if (k > 0) v *= max_vel / vmax;
-                double ph = model == 0 ? 2.086 - 117.917 * f + 74.567 / 2 * (f * f) - 64.343 / 3 * (f * f * f)
-                                       : 0.321 - 11.400 * f + 39.590 / 2 * (f * f) - 38.181 / 3 * (f * f * f);
+                double ph;
+                if (model == 0) ph = 2.086 - 117.917 * f + 74.567 / 2 * (f * f) - 64.343 / 3 * (f * f * f);
+                else if (model == 1) ph = 0.321 - 11.400 * f + 39.590 / 2 * (f * f) - 38.181 / 3 * (f * f * f);
+                else if (model == 2) {  // parametric_phase (antennapattern.py:1643-1650): front lobe, side, back
+                    ph = 100 * ((f - 0.4) * (f - 0.4)) - 20;
+                    if (f > 0.4) ph -= 0.00007 * ((f - 0.4) * (f - 0.4));
+                } else if (model == 3) ph = 40 * ((f - 0.95) * (f - 0.95)) - 40;
+                else ph = 50 * ((f - 0.95) * (f - 0.95)) - 50;
                 double sn, cs;
                 sincos(ph, &sn, &cs);
                 if (f < 0.005) v = 0.;
                 double2 vv = make_double2(v * cs, v * sn);
-                tab.vel[((long)il * 2 + model) * NRHIP_SPEC_STRIDE + k] = vv;
+                tab.vel[((long)il * NRHIP_N_ANT_TAB + model) * NRHIP_SPEC_STRIDE + k] = vv;
                 // |antenna x filter|^2 for the impulse-response norm (irfft keeps only the real part of DC / Nyquist)
                 double2 hk = cmul(vv, apply_filters(make_double2(1., 0.), f, fl));
                 h2 += (k == 0 || k == m) ? hk.x * hk.x : 2. * (hk.x * hk.x + hk.y * hk.y);
             }
             __syncthreads();
             h2 = block_sum(h2, red);
-            if (threadIdx.x == 0) tab.hnorm[(long)il * 2 + model] = sqrt(h2 / L);
+            if (threadIdx.x == 0) tab.hnorm[(long)il * NRHIP_N_ANT_TAB + model] = sqrt(h2 / L);
         }
         // Lengths up to FFT_MAX: the channel voltage is the circular convolution (period L) of the summed, placed field
         // traces with g = (fs / sqrt 2) irfft_L(antenna x filter).  g comes from one chirp-z inverse; its spectrum on the
@@ -1128,9 +1158,10 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
             const unsigned LL = (unsigned)L;
             const int P = M - m;
             const double scale = st.fs / 1.4142135623730951 / L;
-            for (int model = 0; model < 2; model++) {
-                const double2* vel = tab.vel + ((long)il * 2 + model) * NRHIP_SPEC_STRIDE;
-                double2* G = tab.G + ((long)il * 2 + model) * NRHIP_G_STRIDE;
+            for (int model = 0; model < NRHIP_N_ANT_TAB; model++) {
+                if (!((st.tab_mask >> model) & 1)) continue;
+                const double2* vel = tab.vel + ((long)il * NRHIP_N_ANT_TAB + model) * NRHIP_SPEC_STRIDE;
+                double2* G = tab.G + ((long)il * NRHIP_N_ANT_TAB + model) * NRHIP_G_STRIDE;
                 double* gtmp = (double*)G;  // L doubles of the impulse response, overwritten by its spectrum below
                 __syncthreads();
                 for (int n0 = 0; n0 < L; n0 += P) {
@@ -1196,19 +1227,14 @@ channel_prefilter_kernel(int n_items, const int* __restrict__ item_event, RayWor
     if (L > FFT_MAX) { need[item] = 0; return; }
     int flag = 1;
     if (!exact) {
-        const int am = st.ant_model[ch];
         const int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
-        double cs = 0.;
+        double bnd = 0.;
         for (int r = r0; r < r1; r++) {
             if (w.ch[r] != ch) continue;
-            const double* T = w.vel_T + 4 * (long)r;
-            const double th_a = w.theta_ant[r];
-            const double dir = (am == 0) ? sin(th_a) : sin(th_a) * sin(th_a);
-            const double Tt = (am == 0) ? T[0] : T[1], Tp = (am == 0) ? T[2] : T[3];
-            cs += w.e_norm[r] * (fabs(Tt * dir * w.pol_theta[r]) * cabs2(w.r_theta[r]) +
-                                 fabs(Tp * dir * w.pol_phi[r]) * cabs2(w.r_phi[r]));
+            bnd += w.e_norm[r] * (fabs(w.vfac_t[r] * w.pol_theta[r]) * cabs2(w.r_theta[r]) +
+                                  fabs(w.vfac_p[r] * w.pol_phi[r]) * cabs2(w.r_phi[r])) *
+                   hnorm[(long)il * NRHIP_N_ANT_TAB + w.tab[r]];
         }
-        const double bnd = cs * hnorm[(long)il * 2 + am];
         if (!(bnd * (1 + 1e-9) >= threshold)) {
             maxV[item] = -bnd;
             flag = 0;
@@ -1252,12 +1278,13 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                     const int* __restrict__ ev_len_index, StationDev st, int ask_model, TriggerDev trg,
                     const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab, int log2nh,
-                    ChannelOut out, int exact, int* __restrict__ coinc_cnt)
+                    ChannelOut out, int exact, int* __restrict__ coinc_cnt, double2* __restrict__ conv_acc)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = FFT_MAX;
     const double threshold = trg.threshold;
     const bool coinc = trg.coincidence();
+    double2* acc = conv_acc + (long)blockIdx.x * FFT_MAX;
     int* cnt = coinc_cnt + (long)blockIdx.x * FFT_MAX;  // per sample: channels whose dilated flag is set (coincidence modes)
     __shared__ int s_scan[CONV_NT];
     __shared__ int s_first;
@@ -1290,54 +1317,57 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         const int L = ev.L[e], il = ev_len_index[e];
         const double t_min = ev.t_min[e];
         const double res = 1. / st.fs;
-        const int am = st.ant_model[ch];
-        const double2* G = tab.G + ((long)il * 2 + am) * NRHIP_G_STRIDE;
         int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
-        for (int n = threadIdx.x; n < L; n += blockDim.x) S[n] = 0.;
         if (threadIdx.x == 0) s_trig = 0;
-        __syncthreads();
-        int n_used = 0;
-        for (int r = r0; r < r1; r++) {
-            if (w.ch[r] != ch) continue;
-            n_used++;
-            if (threadIdx.x == 0) rs.ask = w.ask[r];
-            for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
+        // antenna response tables among this channel's rays (one, except for LPDAs seeing rays in different lobes)
+        int tabs = 0, n_used = 0;
+        for (int r = r0; r < r1; r++)
+            if (w.ch[r] == ch) { tabs |= 1 << w.tab[r]; n_used++; }
+        const bool multi = (tabs & (tabs - 1)) != 0;
+        bool first_tab = true;
+        for (int tb = 0; tb < NRHIP_N_ANT_TAB; tb++) {
+            if (!((tabs >> tb) & 1)) continue;
+            const double2* G = tab.G + ((long)il * NRHIP_N_ANT_TAB + tb) * NRHIP_G_STRIDE;
             __syncthreads();
-            fill_amplitude(amp, st, rs);
-            // start bin and sub-sample remainder (efieldToVoltageConverter.py:214-218)
-            double start_time = w.t0[r] - t_min + st.cable[ch] + 0;
-            long start_bin = (long)rint(start_time / res);
-            const int sbin = (int)(((start_bin % (long)L) + (long)L) % (long)L);
-            double rem = start_time - start_bin * res;
-            bool shift = !(fabs(rint(rem * st.fs) - rem * st.fs) < 1e-5);
-            const double* T = w.vel_T + 4 * (long)r;
-            const double th_a = w.theta_ant[r];
-            const double dir = (am == 0) ? sin(th_a) : sin(th_a) * sin(th_a);
-            const double Tt = (am == 0) ? T[0] : T[1], Tp = (am == 0) ? T[2] : T[3];
-            const double wt = fabs(Tt * dir * w.pol_theta[r]) * cabs2(w.r_theta[r]);
-            const double wp = fabs(Tp * dir * w.pol_phi[r]) * cabs2(w.r_phi[r]);
-            for (int comp = 0; comp < 2; comp++) {
-                double pol = comp ? w.pol_phi[r] : w.pol_theta[r];
-                double2 rc = comp ? w.r_phi[r] : w.r_theta[r];
-                double vfac = (comp ? Tp : Tt) * dir;
-                if ((comp ? wp : wt) <= 1e-13 * (comp ? wt : wp)) continue;
-                field_time_domain(xs, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
-                const double c = vfac / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
-                for (int j = threadIdx.x; j < nh; j += blockDim.x) {
-                    double2 y = xs[bitrev(j, log2nh)];
-                    int i0 = sbin + 2 * j;
-                    if (i0 >= L) i0 -= L;
-                    int i1 = i0 + 1;
-                    if (i1 >= L) i1 -= L;
-                    S[i0] += y.x * c;
-                    S[i1] += y.y * c;
-                }
+            for (int n = threadIdx.x; n < L; n += blockDim.x) S[n] = 0.;
+            __syncthreads();
+            for (int r = r0; r < r1; r++) {
+                if (w.ch[r] != ch || w.tab[r] != tb) continue;
+                if (threadIdx.x == 0) rs.ask = w.ask[r];
+                for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
                 __syncthreads();
+                fill_amplitude(amp, st, rs);
+                // start bin and sub-sample remainder (efieldToVoltageConverter.py:214-218)
+                double start_time = w.t0[r] - t_min + st.cable[ch] + 0;
+                long start_bin = (long)rint(start_time / res);
+                const int sbin = (int)(((start_bin % (long)L) + (long)L) % (long)L);
+                double rem = start_time - start_bin * res;
+                bool shift = !(fabs(rint(rem * st.fs) - rem * st.fs) < 1e-5);
+                const double vt = w.vfac_t[r], vp = w.vfac_p[r];
+                const double2 rt = w.r_theta[r], rp = w.r_phi[r];
+                const double pt = w.pol_theta[r], pp = w.pol_phi[r];
+                const double wt = fabs(vt * pt) * cabs2(rt), wp = fabs(vp * pp) * cabs2(rp);
+                // real reflection coefficients: both on-sky components are the same real pulse -> one transform
+                const bool one = (rt.y == 0. && rp.y == 0.);
+                for (int comp = 0; comp < (one ? 1 : 2); comp++) {
+                    double pol = one ? 1. : (comp ? pp : pt);
+                    double2 rc = one ? make_double2(1., 0.) : (comp ? rp : rt);
+                    double vfac = one ? (vt * pt * rt.x + vp * pp * rp.x) : (comp ? vp : vt);
+                    if (!one && (comp ? wp : wt) <= 1e-13 * (comp ? wt : wp)) continue;
+                    field_time_domain(xs, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
+                    const double c = vfac / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
+                    for (int j = threadIdx.x; j < nh; j += blockDim.x) {
+                        double2 y = xs[bitrev(j, log2nh)];
+                        int i0 = sbin + 2 * j;
+                        if (i0 >= L) i0 -= L;
+                        int i1 = i0 + 1;
+                        if (i1 >= L) i1 -= L;
+                        S[i0] += y.x * c;
+                        S[i1] += y.y * c;
+                    }
+                    __syncthreads();
+                }
             }
-        }
-        double vmax = 0.;
-        int trig = 0;
-        if (n_used > 0) {
             for (int n = L + threadIdx.x; n < 2 * M; n += blockDim.x) S[n] = 0.;
             __syncthreads();
             fft_dif_t<FFT_LOG2_MAX, CONV_NT>(z, tw, false);
@@ -1356,6 +1386,19 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 const double2 D2 = cmul(csub(Yk, Ymc), cconj(wk));
                 z[p] = make_double2(E2.x - D2.y, E2.y + D2.x);
                 if (q != p) z[q] = make_double2(E2.x + D2.y, D2.x - E2.y);
+            }
+            if (multi) {  // sum the tables' contributions in the frequency domain (global scratch of this block)
+                __syncthreads();
+                for (int k = threadIdx.x; k < M; k += blockDim.x) acc[k] = first_tab ? z[k] : cadd(acc[k], z[k]);
+                first_tab = false;
+            }
+        }
+        double vmax = 0.;
+        int trig = 0;
+        if (n_used > 0) {
+            if (multi) {
+                __syncthreads();
+                for (int k = threadIdx.x; k < M; k += blockDim.x) z[k] = acc[k];
             }
             __syncthreads();
             fft_dit_t<FFT_LOG2_MAX, CONV_NT>(z, tw, true);
@@ -1477,7 +1520,6 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
         const double res = 1. / st.fs;
         const double2* Bf = tab.B_fwd + (long)il * M;
         const double2* Bi = tab.B_inv + (long)il * M;
-        const double2* vel = tab.vel + ((long)il * 2 + st.ant_model[ch]) * vel_stride;
         const double2* E = tab.E + (long)il * NRHIP_E_STRIDE;   // E[j] = exp(-2 pi i j / (2 L))
         const double2* Hf = tab.H + (long)il * NRHIP_SPEC_STRIDE;
         const double2* Cf = tab.Cf + (long)il * NRHIP_SPEC_STRIDE;
@@ -1487,18 +1529,13 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
         if (!exact) {
             // Cauchy-Schwarz: the channel trace is sum_r vfac_r (e_r (*) h_L), so |V(t)| <= ||h_L||_2 sum_r |vfac_r| ||e_r||_2.
             // If even that cannot reach the threshold nothing of this item needs to be transformed.
-            double cs = 0.;
+            double bnd = 0.;
             for (int r = r0; r < r1; r++) {
                 if (w.ch[r] != ch) continue;
-                const double* T = w.vel_T + 4 * (long)r;
-                const int am = st.ant_model[ch];
-                const double th_a = w.theta_ant[r];
-                const double dir = (am == 0) ? sin(th_a) : sin(th_a) * sin(th_a);
-                const double Tt = (am == 0) ? T[0] : T[1], Tp = (am == 0) ? T[2] : T[3];
-                cs += w.e_norm[r] * (fabs(Tt * dir * w.pol_theta[r]) * cabs2(w.r_theta[r]) +
-                                     fabs(Tp * dir * w.pol_phi[r]) * cabs2(w.r_phi[r]));
+                bnd += w.e_norm[r] * (fabs(w.vfac_t[r] * w.pol_theta[r]) * cabs2(w.r_theta[r]) +
+                                      fabs(w.vfac_p[r] * w.pol_phi[r]) * cabs2(w.r_phi[r])) *
+                       tab.hnorm[(long)il * NRHIP_N_ANT_TAB + w.tab[r]];
             }
-            double bnd = cs * tab.hnorm[(long)il * 2 + st.ant_model[ch]];
             if (!(bnd * (1 + 1e-9) >= threshold)) {
                 if (threadIdx.x == 0) out.maxV[item] = -bnd;
                 continue;
@@ -1521,16 +1558,13 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
             const unsigned sbin = (unsigned)(((start_bin % (long)L) + (long)L) % (long)L);
             double rem = start_time - start_bin * res;
             bool shift = !(fabs(rint(rem * st.fs) - rem * st.fs) < 1e-5);
-            const double* T = w.vel_T + 4 * (long)r;
-            const double th_a = w.theta_ant[r];
-            const int am = st.ant_model[ch];
-            const double dir = (am == 0) ? sin(th_a) : sin(th_a) * sin(th_a);
-            // raw VEL has one non-zero component: VPol -> theta (column 0 of T), HPol -> phi (column 1 of T)
-            const double Tt = (am == 0) ? T[0] : T[1], Tp = (am == 0) ? T[2] : T[3];
+            const double2* vel = tab.vel + ((long)il * NRHIP_N_ANT_TAB + w.tab[r]) * vel_stride;
+            const double Tt = w.vfac_t[r], Tp = w.vfac_p[r];
+            const double dir = 1.;
             // weight of each on-sky component in the channel voltage; a component below 1e-13 of the other one
             // (e.g. the e_phi response of a vertical dipole, 1e-17 from the rotation round-off) is not transformed
-            const double wt = fabs(Tt * dir * w.pol_theta[r]) * cabs2(w.r_theta[r]);
-            const double wp = fabs(Tp * dir * w.pol_phi[r]) * cabs2(w.r_phi[r]);
+            const double wt = fabs(Tt * w.pol_theta[r]) * cabs2(w.r_theta[r]);
+            const double wp = fabs(Tp * w.pol_phi[r]) * cabs2(w.r_phi[r]);
             for (int comp = 0; comp < 2; comp++) {
                 double pol = comp ? w.pol_phi[r] : w.pol_theta[r];
                 double2 rc = comp ? w.r_phi[r] : w.r_theta[r];
@@ -1654,26 +1688,29 @@ efield_channel_kernel(int n_efields, const double* __restrict__ traces, const do
     double2* x = (double2*)smem;
     double2* acc = scratch + (long)blockIdx.x * NRHIP_SPEC_STRIDE;
     const double2 *Bf = tab.B_fwd, *Bi = tab.B_inv, *E = tab.E, *Hf = tab.H, *Cf = tab.Cf, *Ci = tab.Ci;
-    const double2* vel = tab.vel + (long)st.ant_model[ch] * NRHIP_SPEC_STRIDE;
     const unsigned LL = (unsigned)L;
     const double res = 1. / st.fs;
-    __shared__ double sT[4], s_th;
+    __shared__ double sT[4], s_th, s_vt, s_vp;
+    __shared__ int s_tab;
     for (int k = threadIdx.x; k <= m; k += blockDim.x) acc[k] = make_double2(0., 0.);
     __syncthreads();
     int n_used = 0;
     for (int e = 0; e < n_efields; e++) {
         if (channel[e] != ch) continue;
         n_used++;
-        if (threadIdx.x == 0) antenna_frame(zenith[e], azimuth[e], st.rot + 9 * ch, st.rot_inv + 9 * ch, sT, &s_th);
+        if (threadIdx.x == 0) {
+            double ph_a;
+            antenna_frame(zenith[e], azimuth[e], st.rot + 9 * ch, st.rot_inv + 9 * ch, sT, &s_th, &ph_a);
+            antenna_factors(st.ant_model[ch], sT, s_th, ph_a, &s_vt, &s_vp, &s_tab);
+        }
         __syncthreads();
         double start_time = t0[e] - t_min + st.cable[ch] + 0;
         long start_bin = (long)rint(start_time / res);
         const unsigned sbin = (unsigned)(((start_bin % (long)L) + (long)L) % (long)L);
         double rem = start_time - start_bin * res;
         bool shift = !(fabs(rint(rem * st.fs) - rem * st.fs) < 1e-5);
-        const int am = st.ant_model[ch];
-        const double dir = (am == 0) ? sin(s_th) : sin(s_th) * sin(s_th);
-        const double Tt = (am == 0) ? sT[0] : sT[1], Tp = (am == 0) ? sT[2] : sT[3];
+        const double dir = 1., Tt = s_vt, Tp = s_vp;
+        const double2* vel = tab.vel + (long)s_tab * NRHIP_SPEC_STRIDE;
         for (int comp = 0; comp < 2; comp++) {
             const double vfac = (comp ? Tp : Tt) * dir;
             if (vfac == 0.) continue;
@@ -1964,7 +2001,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
-                    int* item_list, int* coinc_cnt)
+                    int* item_list, int* coinc_cnt, double2* conv_acc)
 {
     if (n_items <= 0) return;
     set_big_lds();
@@ -1987,7 +2024,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
         int cgrid = n_cand < channel_grid_blocks() ? n_cand : channel_grid_blocks();
         hipLaunchKernelGGL(channel_conv_kernel, dim3(cgrid), dim3(CONV_NT), (size_t)FFT_MAX * 16, s, need_offset + n_cand,
                            item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16, tab,
-                           ilog2(nh), out, exact, coinc_cnt);
+                           ilog2(nh), out, exact, coinc_cnt, conv_acc);
         skip_upto = FFT_MAX;
         if (max_length <= FFT_MAX) return;
     }

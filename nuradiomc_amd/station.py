@@ -4,7 +4,7 @@ import numpy as np
 from . import _lib as L
 from . import filters as flt
 
-ANTENNA_TO_INT = {'analytic_VPol': 0, 'analytic_HPol': 1}
+ANTENNA_TO_INT = {'analytic_VPol': 0, 'analytic_HPol': 1, 'analytic_LPDA': 2}
 ASKARYAN_TO_INT = {'Alvarez2009': 0, 'Alvarez2000': 1, 'ZHS1992': 2}
 SHOWER_TO_INT = {'HAD': 0, 'EM': 1}
 
@@ -104,7 +104,7 @@ class Station:
         names = [antenna] * n if isinstance(antenna, str) else list(antenna)
         for a in names:
             if a not in ANTENNA_TO_INT:
-                raise NotImplementedError("antenna model {} is not available (analytic_VPol, analytic_HPol)".format(a))
+                raise NotImplementedError("antenna model {} is not available (analytic_VPol, analytic_HPol, analytic_LPDA)".format(a))
         model = np.array([ANTENNA_TO_INT[a] for a in names], np.int32)
         ori = np.ascontiguousarray(np.broadcast_to(L.f64(orientation), (n, 4)))
         cab = np.ascontiguousarray(np.broadcast_to(L.f64(cable_delay), (n,)))

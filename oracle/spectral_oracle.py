@@ -280,6 +280,24 @@ def vel_raw(model, freq, theta, phi):
         VEL_phi = VEL_phi.astype(complex)
         VEL_phi *= np.exp(1j * phase)
         return VEL_theta, VEL_phi
+    if model == 'analytic_LPDA':  # antennapattern.py:1676-1713 (+ parametric_phase :1643-1650)
+        cutoff, max_vel = 110 * units.MHz, 0.55 * units.m
+        index = np.argmax(freq > cutoff)
+        gain_filter = hann(2 * index)
+        base = np.zeros_like(gain)
+        base[fmask] = np.sqrt(gain[fmask]) / freq[fmask]
+        base[:index] *= gain_filter[:index]
+        base[fmask] *= max_vel / max(base[fmask])
+        VEL_theta = base * (np.cos(theta) * np.sin(phi) * np.cos(theta / 2))
+        VEL_phi = base * (np.cos(theta / 2) * np.cos(phi))
+        if theta <= 45 * units.deg:
+            a = 100 * (freq - 400 * units.MHz) ** 2 - 20
+            a[np.where(freq > 400 * units.MHz)] -= 0.00007 * (freq[np.where(freq > 400 * units.MHz)] - 400 * units.MHz) ** 2
+        elif theta <= 90 * units.deg:
+            a = 40 * (freq - 950 * units.MHz) ** 2 - 40
+        else:
+            a = 50 * (freq - 950 * units.MHz) ** 2 - 50
+        return VEL_theta.astype(complex) * np.exp(1j * a), VEL_phi.astype(complex) * np.exp(1j * a)
     raise NotImplementedError(model)
 
 
@@ -332,12 +350,16 @@ class Station:
                  cable_delay=0., n_samples=4096, fs=2.0):
         self.pos = np.asarray(pos, float).reshape(-1, 3)
         self.n_ch = len(self.pos)
-        self.antenna = antenna
-        self.orientation = tuple(orientation)
+        self.antenna = antenna                       # one model name or one per channel
+        ori = np.asarray(orientation, float)
+        self.orientation = np.broadcast_to(ori, (self.n_ch, 4)).copy()   # per channel
         cd = np.asarray(cable_delay, float)
         self.cable_delay = np.broadcast_to(cd, (self.n_ch,)).copy()
         self.n_samples = n_samples
         self.fs = fs
+
+    def antenna_of(self, ch):
+        return self.antenna if isinstance(self.antenna, str) else self.antenna[ch]
 
 
 def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model='SP1', n_freq=25,
@@ -394,7 +416,7 @@ def per_efield_voltage(ef, st, filters=DEFAULT_FILTERS):
     """efieldToVoltageConverterPerEfield.run (:28-101) + filter chain + Hilbert-envelope maximum
     (simulation._calculate_amp_per_ray_solution :1868-1886); native N grid."""
     ff = np.fft.rfftfreq(st.n_samples, 1. / st.fs)
-    Vt, Vp = antenna_response(st.antenna, ff, ef['zenith'], ef['azimuth'], st.orientation)
+    Vt, Vp = antenna_response(st.antenna_of(ef['channel']), ff, ef['zenith'], ef['azimuth'], st.orientation[ef['channel']])
     v = Vt * ef['spec'][1] + Vp * ef['spec'][2]
     v[ff < 5 * units.MHz] = 0.
     v = v * filter_response(ff, filters)
@@ -453,7 +475,7 @@ def combined_voltage(efields, st, filters=DEFAULT_FILTERS, pre_pulse_time=200., 
                 start_bin = 0
             new_trace[:, start_bin:stop_bin] = tr
             efield_fft = time2freq(new_trace, fs)
-            Vt, Vp = antenna_response(st.antenna, ffL, ef['zenith'], ef['azimuth'], st.orientation)
+            Vt, Vp = antenna_response(st.antenna_of(ef['channel']), ffL, ef['zenith'], ef['azimuth'], st.orientation[ef['channel']])
             v = Vt * efield_fft[1] + Vp * efield_fft[2]
             v[ffL < 5 * units.MHz] = 0.
             spec_ch = v if spec_ch is None else spec_ch + v

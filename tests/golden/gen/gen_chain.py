@@ -19,8 +19,8 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 
 
 def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4, model='Alvarez2009',
-        antenna='analytic_VPol', cable_delay=0., rmax=4000.):
-    det = rh.StationS5(n_samples=N, fs=2.0, antenna=antenna, cable_delay=cable_delay)
+        antenna='analytic_VPol', cable_delay=0., rmax=4000., orientation=None):
+    det = rh.StationS5(n_samples=N, fs=2.0, antenna=antenna, cable_delay=cable_delay, orientation=orientation)
     cfg = rh.default_config(model=model)
     ice, prop = rh.make_propagator(cfg, det)
     vrms, vrms_e = rh.vrms_from_filters(cfg)
@@ -64,7 +64,8 @@ def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4
           't0', 'r_theta', 'r_phi', 'max_efield', 'simch_t0', 'max_amp_ray')}
     out = dict(N=N, fs=2.0, vrms=vrms, vrms_efield=vrms_e, ice=np.array([ice.n_ice, ice.delta_n, ice.z_0]),
                att_model='SP1', n_freq=25, askaryan_model=model, antenna=antenna, cable_delay=cable_delay,
-               det_pos=det.pos, det_orientation=np.array(det.orientation), delta_C_cut=0.698,
+               det_pos=det.pos, det_orientation=np.array(det.orientation if orientation is None else orientation),
+               delta_C_cut=0.698,
                trigger_sigma=3.0, min_efield_amplitude=2.0,
                vertex=ev['vertex'], zenith=ev['zenith'], azimuth=ev['azimuth'], energy=ev['energy'],
                shower_type=stype, full_ray_index=np.array(full_idx, np.int64),
@@ -77,7 +78,7 @@ def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['N256', 'N4096', 'N256_hpol']
+    which = sys.argv[1:] or ['N256', 'N4096', 'N256_hpol', 'N256_lpda']
     if 'N256' in which:
         run('N256', n_events=300, seed=21, N=256, full_rays=400, full_events=12)
     if 'N4096' in which:
@@ -85,3 +86,9 @@ if __name__ == '__main__':
     if 'N256_hpol' in which:  # HPol antennas + unequal cable delays: exercises ePhi, Fresnel r_s and the sub-sample shift
         run('N256_hpol', n_events=150, seed=23, N=256, full_rays=200, full_events=8, antenna='analytic_HPol',
             cable_delay=[0., 3.3, 7.77, 12.2, 19.8], rmax=2500.)
+    if 'N256_lpda' in which:  # LPDAs in five orientations (both VEL components, three phase regimes) + one cable delay
+        d = np.pi / 180
+        ori = [[0., 0., 90 * d, 0.], [0., 0., 90 * d, 90 * d], [180 * d, 0., 90 * d, 0.], [90 * d, 0., 90 * d, 90 * d],
+               [90 * d, 120 * d, 0., 0.]]
+        run('N256_lpda', n_events=200, seed=24, N=256, full_rays=200, full_events=8, antenna='analytic_LPDA',
+            cable_delay=[0., 0., 4.4, 0., 0.], rmax=2500., orientation=ori, energy=1e17)

@@ -42,7 +42,7 @@ class StationS5:
     """
 
     def __init__(self, n_samples=4096, fs=2.0, n_ch=5, z_top=-100., dz=-1., station_id=101,
-                 antenna='analytic_VPol', cable_delay=0., xy=(0., 0.)):
+                 antenna='analytic_VPol', cable_delay=0., xy=(0., 0.), orientation=None):
         self.station_id = station_id
         self.n_samples = n_samples
         self.fs = fs
@@ -50,6 +50,7 @@ class StationS5:
         self.antenna = antenna if isinstance(antenna, (list, tuple)) else [antenna] * n_ch
         self.cable_delay = (list(cable_delay) if hasattr(cable_delay, '__len__') else [cable_delay] * n_ch)
         self.orientation = [0., 0., 90. * units.deg, 90. * units.deg]
+        self.orientations = None if orientation is None else [list(o) for o in orientation]  # per channel
 
     def get_station_ids(self):
         return [self.station_id]
@@ -76,7 +77,7 @@ class StationS5:
         return self.antenna[channel_id]
 
     def get_antenna_orientation(self, station_id, channel_id):
-        return list(self.orientation)
+        return list(self.orientation) if self.orientations is None else list(self.orientations[channel_id])
 
     def get_site(self, station_id):
         return 'southpole'

@@ -65,7 +65,7 @@ def _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=False, dump_traces=
     return g, ctx, st, trig, stats, kL
 
 
-@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N4096', 60)])
+@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N4096', 60)])
 def test_spectral_stages_vs_oracle_on_identical_rays(gpu_ctx_factory, name, n_events):
     """Feed the ORACLE with the ray tables the GPU produced, so that every later stage sees identical
     (C0, D, T, launch, receive) on both sides: kept rays exact, amplitudes / traces to 1e-6."""
@@ -129,7 +129,7 @@ def test_spectral_stages_vs_oracle_on_identical_rays(gpu_ctx_factory, name, n_ev
     assert stats['n_candidate_events'] == n_cand and stats['n_triggered'] == trig.sum()
 
 
-@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N4096', 120)])
+@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N4096', 120)])
 def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
     """End to end (GPU ray tracing included) against the reference's own outputs.  The reference's first ray
     root carries ~1e-7 of iteration noise (see tests/test_oracle_golden.py), which moves arrival times by up to
@@ -153,7 +153,7 @@ def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
             assert np.all(np.abs(maxV[i] - ref) <= 5e-3 * np.max(ref)), ev
 
 
-@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N4096', 120)])
+@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_lpda', 200), ('N4096', 120)])
 def test_pruning_changes_no_result(gpu_ctx_factory, name, n_events):
     """Skipping rays of events that provably cannot pass the candidate cut (un-attenuated sum-of-magnitudes bound)
     and skipping transforms whose bound is below the cut must leave every decision and every trace unchanged."""
@@ -271,7 +271,7 @@ def test_simulate_events_edge_cases(gpu_ctx_factory):
         nuradiomc_amd.Context(bench.ICE, 'GL3')
 
 
-@pytest.mark.parametrize('name,n_events', [('N256', 200), ('N256_hpol', 150), ('N4096', 60)])
+@pytest.mark.parametrize('name,n_events', [('N256', 200), ('N256_hpol', 150), ('N256_lpda', 200), ('N4096', 60)])
 def test_channel_kernels_agree(gpu_ctx_factory, name, n_events, monkeypatch):
     """Traces up to 8192 samples go through one real convolution per channel (channel_conv_kernel), longer ones through
     the per-ray chirp-z kernel; NRHIP_CHANNEL_CZT=1 sends everything through the latter.  Same traces, same decisions."""

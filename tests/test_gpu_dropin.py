@@ -164,7 +164,8 @@ class _FakeDet:
     def get_sampling_frequency(self, sid, c): return self.fs
 
 
-@pytest.mark.parametrize('antenna,cable', [('analytic_VPol', [0.] * 5), ('analytic_HPol', [0., 3.3, 7.77, 12.2, 19.8])])
+@pytest.mark.parametrize('antenna,cable', [('analytic_VPol', [0.] * 5), ('analytic_HPol', [0., 3.3, 7.77, 12.2, 19.8]),
+                                           ('analytic_LPDA', [0., 0., 4.4, 0., 1.1])])
 def test_efieldToVoltageConverter_module(antenna, cable):
     """The module-level drop-in on arbitrary ElectricField-like objects vs the oracle's restatement of
     efieldToVoltageConverter.run (no filter), incl. the sub-sample Fourier shift (unequal cable delays)."""

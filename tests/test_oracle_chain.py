@@ -49,7 +49,7 @@ def _rays_with_reference_launch_parameters(g, ev, st, ice):
     return rays, sel
 
 
-@pytest.mark.parametrize('name', ['N256', 'N256_hpol', 'N4096'])
+@pytest.mark.parametrize('name', ['N256', 'N256_hpol', 'N256_lpda', 'N4096'])
 def test_chain_vs_reference(name):
     g = golden('chain_%s.npz' % name)
     st = _station(g)
