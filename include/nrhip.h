@@ -166,6 +166,11 @@ typedef struct {
     int32_t n_coincidences;
     double threshold_high, threshold_low;   /* [V] */
     double high_low_window, coinc_window;   /* [ns] */
+    /* speedup.amp_per_ray_solution (simulation.py:523, _calculate_amp_per_ray_solution :1868-1886): for every ray of the
+       candidate event groups the per-efield voltage on the native N grid (efieldToVoltageConverterPerEfield.py:28-101,
+       cable delay, filter chain), its Hilbert-envelope maximum and the time of that maximum --
+       nrhip_sim_fetch("ray_max_amp_envelope" / "ray_signal_time"), NaN for rays of other events.                    */
+    int32_t amp_per_ray;
 } nrhip_sim_config;
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1

@@ -432,6 +432,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     HIPCHK(hipMemsetAsync(lflag, 0, sizeof(int) * (n_half + 1), sm));
     HIPCHK(hipMemsetAsync(d_ncr, 0, 2 * sizeof(long long), sm));
     launch_candidate_flags(sm, (int)n_groups, n_half, ev, cflag, lflag, d_ncr);
+    if (cfg->amp_per_ray)  // the per-efield voltages live on the N grid: tables of "L = N" are built with the others
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(lflag + sd.N / 2), 1, 1, sm));
     launch_exclusive_scan(sm, n_groups + 1, cflag, coff, ctmp);
     launch_exclusive_scan(sm, n_half + 1, lflag, loff, ltmp);
     launch_candidate_lists(sm, (int)n_groups, n_half, ev, cflag, coff, lflag, loff, d_cand, d_len_index, d_lens);
@@ -476,6 +478,16 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(tab.G = WS("tab_G", double2, lens.size() * NRHIP_N_ANT_TAB * (size_t)NRHIP_G_STRIDE));
         launch_length_tables(sm, (int)lens.size(), d_lens, sd, st->filters, ctx->twiddle, ctx->w16, tab);
         LCHK("length_tables");
+        if (cfg->amp_per_ray && n_rays > 0) {
+            double *max_env, *sig_time;
+            NEED(max_env = WS("ray_max_amp_envelope", double, nr));
+            NEED(sig_time = WS("ray_signal_time", double, nr));
+            HIPCHK(hipMemsetAsync(max_env, 0xFF, sizeof(double) * nr, sm));
+            HIPCHK(hipMemsetAsync(sig_time, 0xFF, sizeof(double) * nr, sm));
+            launch_ray_envelope(sm, n_cand, coff + n_groups, d_cand, w, ev, sd, cfg->askaryan_model, ctx->twiddle, tab,
+                                loff + sd.N / 2, max_env, sig_time);
+            LCHK("ray_envelope");
+        }
         MARK(7);
         // 6. channel voltages + trigger
         const int n_items = n_cand * n_ch;

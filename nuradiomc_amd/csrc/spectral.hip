@@ -1669,6 +1669,83 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// kernel: per-efield voltages on the native N grid and their Hilbert-envelope maximum
+// (efieldToVoltageConverterPerEfield.py:28-101 -> channelAddCableDelay -> filter chain ->
+// simulation._calculate_amp_per_ray_solution :1868-1886).  One block (256) per candidate event group, its rays in turn:
+// V_k = B_tab(f_k) H(f_k) (vfac_t G_theta,k + vfac_p G_phi,k) (5 MHz cut inside B), analytic signal = N-point complex
+// inverse transform of the one-sided spectrum (scipy.signal.hilbert), envelope maximum and the time of its first maximum.
+// The antenna / filter tables on the N grid are the length tables of "L = N".  LDS: N complex + (N/2 + 1) doubles.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item_event, RayWork w, EventOut ev,
+                    StationDev st, int ask_model, const double2* __restrict__ tw, LengthTables tab,
+                    const int* __restrict__ len_index_N, int log2n, double* __restrict__ max_env,
+                    double* __restrict__ signal_time)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = st.N, nh = N / 2;
+    double2* x = (double2*)smem;
+    double* amp = (double*)(x + N);
+    __shared__ RayShared rs;
+    __shared__ double red[256];
+    __shared__ int red_i[256];
+    const int il = *len_index_N;
+    const double2* Hf = tab.H + (long)il * NRHIP_SPEC_STRIDE;
+    const int n_ev = *n_cand;
+    for (int ie = blockIdx.x; ie < n_ev; ie += gridDim.x) {
+      const int e = item_event[ie];
+      const int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
+      for (int r = r0; r < r1; r++) {
+        if (threadIdx.x == 0) rs.ask = w.ask[r];
+        for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
+        __syncthreads();
+        fill_amplitude(amp, st, rs);
+        const double2* vel = tab.vel + ((long)il * NRHIP_N_ANT_TAB + w.tab[r]) * NRHIP_SPEC_STRIDE;
+        const double vt = w.vfac_t[r], vp = w.vfac_p[r], pt = w.pol_theta[r], pp = w.pol_phi[r];
+        const double2 rt = w.r_theta[r], rp = w.r_phi[r];
+        const double scale = st.fs / 1.4142135623730951 / N;  // freq2time
+        for (int k = threadIdx.x; k < N; k += blockDim.x) {
+            double2 v = make_double2(0., 0.);
+            if (k > 0 && k < nh) {
+                double2 Gt = field_bin(k, amp[k], N, st.fs, pt, rt, 0., false, ask_model, floor(2.0 * st.fs));
+                double2 Gp = field_bin(k, amp[k], N, st.fs, pp, rp, 0., false, ask_model, floor(2.0 * st.fs));
+                double2 E = cadd(cscale(Gt, vt), cscale(Gp, vp));
+                v = cscale(cmul(cmul(vel[k], Hf[k]), E), 2. * scale);
+            }
+            x[k] = v;
+        }
+        __syncthreads();
+        fft_dif(x, log2n, tw, true);  // inverse, natural -> bit-reversed
+        double mx = -1.;
+        int imx = 0;
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {  // n ascending per thread: first maximum kept
+            double a = cabs2(x[bitrev(n, log2n)]);
+            if (a > mx) { mx = a; imx = n; }
+        }
+        red[threadIdx.x] = mx;
+        red_i[threadIdx.x] = imx;
+        __syncthreads();
+        for (int s_ = blockDim.x / 2; s_ > 0; s_ >>= 1) {
+            if ((int)threadIdx.x < s_) {
+                double a = red[threadIdx.x + s_];
+                int ia = red_i[threadIdx.x + s_];
+                if (a > red[threadIdx.x] || (a == red[threadIdx.x] && ia < red_i[threadIdx.x])) {
+                    red[threadIdx.x] = a;
+                    red_i[threadIdx.x] = ia;
+                }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            max_env[r] = red[0];
+            signal_time[r] = w.t0[r] + st.cable[w.ch[r]] + red_i[0] / st.fs;
+        }
+        __syncthreads();
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // kernel: efieldToVoltageConverter.run (efieldToVoltageConverter.py:111-345) for ONE station event on arbitrary
 // electric-field traces (the module-level drop-in; the simulation path uses channel_kernel, which generates the
 // fields itself).  One block (512) per channel; every efield of the channel: sub-sample shift (FFT phase ramp on the
@@ -1983,6 +2060,8 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               FFT_MAX * 16 + (FFT_MAX / 2 + 1) * 8);
     (void)hipFuncSetAttribute((const void*)channel_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)ray_envelope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (FFT_MAX / 2) * 16 + (FFT_MAX / 4 + 1) * 8);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)efield_channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipGetLastError();
@@ -2031,6 +2110,17 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
     hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
                        ask_model, trig.threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto);
+}
+void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
+                         const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
+                         const int* len_index_N, double* max_env, double* signal_time)
+{
+    if (n_cand_max <= 0) return;
+    set_big_lds();
+    size_t lds = (size_t)st.N * 16 + (size_t)(st.N / 2 + 1) * 8;
+    int grid = n_cand_max < 256 * 4 ? n_cand_max : 256 * 4;
+    hipLaunchKernelGGL(ray_envelope_kernel, dim3(grid), dim3(256), lds, s, n_cand, item_event, w, ev, st, ask_model, tw, tab,
+                       len_index_N, ilog2(st.N), max_env, signal_time);
 }
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,

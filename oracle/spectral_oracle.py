@@ -339,7 +339,7 @@ def filter_response(freqs, filters=DEFAULT_FILTERS):
 def vrms_from_filters(fs, filters=DEFAULT_FILTERS, noise_temperature=300.):
     ff = np.linspace(0, 0.5 * fs, 10000)
     filt = filter_response(ff, filters)
-    bandwidth = np.trapz(np.abs(filt) ** 2, ff)
+    bandwidth = (np.trapezoid if hasattr(np, 'trapezoid') else np.trapz)(np.abs(filt) ** 2, ff)
     vrms = (noise_temperature * (50 * units.ohm) * bandwidth * units.k_B) ** 0.5
     return vrms, vrms / np.abs(filt).max() / units.m
 
@@ -421,7 +421,9 @@ def per_efield_voltage(ef, st, filters=DEFAULT_FILTERS):
     v[ff < 5 * units.MHz] = 0.
     v = v * filter_response(ff, filters)
     trace = freq2time(v, st.fs)
-    return v, np.abs(signal.hilbert(trace)).max()
+    h = np.abs(signal.hilbert(trace))
+    ef['signal_time'] = ef['t0'] + st.cable_delay[ef['channel']] + np.argmax(h) / st.fs   # channelAddCableDelay, :1885
+    return v, h.max()
 
 
 def combined_voltage(efields, st, filters=DEFAULT_FILTERS, pre_pulse_time=200., post_pulse_time=400.):

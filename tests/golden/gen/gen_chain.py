@@ -61,7 +61,7 @@ def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4
         n_events, len(rays), evo['candidate'].sum(), evo['triggered'].sum(), time.time() - t0))
     R = {k: np.array([r[k] for r in rays]) for k in
          ('event', 'channel', 'iS', 'C0', 'C1', 'type', 'zenith', 'azimuth', 'D', 'T', 'view', 'pol_angle', 'launch',
-          't0', 'r_theta', 'r_phi', 'max_efield', 'simch_t0', 'max_amp_ray')}
+          't0', 'r_theta', 'r_phi', 'max_efield', 'simch_t0', 'max_amp_ray', 'signal_time')}
     out = dict(N=N, fs=2.0, vrms=vrms, vrms_efield=vrms_e, ice=np.array([ice.n_ice, ice.delta_n, ice.z_0]),
                att_model='SP1', n_freq=25, askaryan_model=model, antenna=antenna, cable_delay=cable_delay,
                det_pos=det.pos, det_orientation=np.array(det.orientation if orientation is None else orientation),

@@ -204,6 +204,7 @@ def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, tri
             r['simch_spec'] = sc.get_frequency_spectrum().copy()
             r['simch_t0'] = sc.get_trace_start_time()
             r['max_amp_ray'] = sc[chp.maximum_amplitude_envelope]
+            r['signal_time'] = sc[chp.signal_time]
         station.add_sim_station(ss)
     out['candidate'] = candidate
     out['k_L'] = showers[0][shp.k_L] if showers[0].has_parameter(shp.k_L) else np.nan

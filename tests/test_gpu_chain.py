@@ -366,3 +366,39 @@ def test_trigger_modes(gpu_ctx_factory, kw):
     assert np.array_equal(trig, expect) and 3 <= trig.sum() < len(item_event)
     trig_p, _ = st.simulate_events(*args, **opts)
     assert np.array_equal(trig_p, trig)
+
+
+@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N4096', 60)])
+def test_amp_per_ray_solution(gpu_ctx_factory, name, n_events):
+    """speedup.amp_per_ray_solution: per-efield voltage on the N grid, Hilbert-envelope maximum and its time for every
+    ray of the candidate events -- vs the oracle on the same rays (1e-6) and vs the reference's own values (5e-3: they
+    carry the reference's first-root noise, see test_whole_path_vs_reference_fixture)."""
+    g = golden('chain_%s.npz' % name)
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    sl = slice(0, n_events)
+    kL = np.where(np.isnan(g['ev_k_L'][sl]), 1.0, g['ev_k_L'][sl])
+    trig, stats = st.simulate_events(g['vertex'][sl], g['zenith'][sl], g['azimuth'][sl], g['energy'][sl], g['shower_type'][sl],
+                                     kL, askaryan_model=str(g['askaryan_model']), amp_per_ray=True)
+    env, tsig = st.fetch('ray_max_amp_envelope'), st.fetch('ray_signal_time')
+    rev, rch, rsol = st.fetch('ray_event'), st.fetch('ray_channel'), st.fetch('ray_solution')
+    cand = st.fetch('ev_candidate').astype(bool)
+    assert np.all(np.isnan(env[~cand[rev]])) and not np.any(np.isnan(env[cand[rev]]))
+    ost = so.Station(g['det_pos'], antenna=str(g['antenna']), orientation=g['det_orientation'], cable_delay=g['cable_delay'],
+                     n_samples=int(g['N']), fs=float(g['fs']))
+    vrms, vrms_e = so.vrms_from_filters(ost.fs)
+    n_checked = n_ref = 0
+    for e in np.flatnonzero(cand):
+        o = so.simulate_event(g['vertex'][e], g['zenith'][e], g['azimuth'][e], g['energy'][e], str(g['shower_type'][e]),
+                              float(kL[e]), ost, g['ice'], vrms, vrms_e)
+        mine = np.flatnonzero(rev == e)
+        assert len(mine) == len(o['rays'])
+        for k, r in zip(mine, o['rays']):
+            assert (rch[k], rsol[k]) == (r['channel'], r['iS'])
+            assert abs(env[k] - r['max_amp_ray']) <= 1e-6 * r['max_amp_ray'] and abs(tsig[k] - r['signal_time']) < 1e-6
+            n_checked += 1
+        ref = np.flatnonzero(g['ray_event'] == e)
+        if len(ref) == len(mine):
+            assert np.all(np.abs(env[mine] - g['ray_max_amp_ray'][ref]) <= 5e-3 * g['ray_max_amp_ray'][ref])
+            n_ref += len(ref)
+    assert n_checked >= 30 and n_ref >= 30

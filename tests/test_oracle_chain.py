@@ -79,6 +79,8 @@ def test_chain_vs_reference(name):
             assert abs(r['r_theta'] - g['ray_r_theta'][k]) < 1e-9 and abs(r['r_phi'] - g['ray_r_phi'][k]) < 1e-9
             assert abs(r['max_efield'] - g['ray_max_efield'][k]) <= 1e-6 * g['ray_max_efield'][k]
             assert abs(r['max_amp_ray'] - g['ray_max_amp_ray'][k]) <= 1e-6 * g['ray_max_amp_ray'][k]
+            if 'ray_signal_time' in g:  # time of the Hilbert-envelope maximum (simulation.py:1885)
+                assert abs(r['signal_time'] - g['ray_signal_time'][k]) < 1e-9
             if int(k) in full:
                 ref = g['full_spec'][full[int(k)]]
                 assert np.max(np.abs(r['spec'][1:] - ref)) <= 1e-6 * np.max(np.abs(ref))
