@@ -178,7 +178,32 @@ class ray_tracing:
         return out
 
     def get_focusing(self, iS, dz=-0.01, limit=2., analytic=False):
-        raise NotImplementedError("focusing is not provided yet")
+        """analyticraytracing.py:2778-2888, numerical branch (the reference falls back to it whenever its analytic
+        formula fails): the ray to the receiver moved by dz is traced on the GPU as well; receiver and emitter in ice."""
+        self._check(iS)
+        rec_vec = -1.0 * self.get_receive_vector(iS)
+        rec_ang = np.arccos(rec_vec[2] / np.sqrt(rec_vec[0] ** 2 + rec_vec[1] ** 2 + rec_vec[2] ** 2))
+        lau_vec = self.get_launch_vector(iS)
+        lau_ang = np.arccos(lau_vec[2] / np.sqrt(lau_vec[0] ** 2 + lau_vec[1] ** 2 + lau_vec[2] ** 2))
+        vet_pos, rec_pos = self._X1, self._X2
+        rec_pos1 = np.array([rec_pos[0], rec_pos[1], rec_pos[2] + dz])
+        t1 = self._ctx.find_solutions_batch(vet_pos[None], rec_pos1[None])
+        if iS < int(t1['n_sol'][0]):
+            lau_vec1 = t1['launch'][0][iS]
+            lau_ang1 = np.arccos(lau_vec1[2] / np.sqrt(lau_vec1[0] ** 2 + lau_vec1[1] ** 2 + lau_vec1[2] ** 2))
+            distance = self.get_path_length(iS)
+            focusing = np.sqrt(distance / np.sin(rec_ang) * np.abs((lau_ang1 - lau_ang) / (rec_pos1[2] - rec_pos[2])))
+            radius = np.linalg.norm(rec_pos - vet_pos)
+            sin_theta = np.linalg.norm((rec_pos - vet_pos)[:-1]) / radius
+            focusing *= np.sqrt((distance * np.sin(lau_ang)) / (radius * sin_theta))
+        else:
+            focusing = 1.0
+            self.__logger.warning("too few ray tracing solutions, setting focusing factor to 1")
+        if focusing > limit:
+            focusing = limit
+        n1 = self._medium.n_ice - self._medium.delta_n * np.exp(vet_pos[2] / self._medium.z_0)
+        n2 = self._medium.n_ice - self._medium.delta_n * np.exp(rec_pos[2] / self._medium.z_0)
+        return focusing * (n1 / n2) ** 0.5
 
     def get_output_parameters(self):
         return [{'name': 'ray_tracing_C0', 'ndim': 1}, {'name': 'ray_tracing_C1', 'ndim': 1},
@@ -187,12 +212,13 @@ class ray_tracing:
 
     def get_raytracing_output(self, i_solution):
         self._check(i_solution)
+        focusing = 1
         if self._config['propagation']['focusing']:
-            raise NotImplementedError("focusing is not provided yet")
+            focusing = self.get_focusing(i_solution, limit=float(self._config['propagation']['focusing_limit']))
         r = self._results[i_solution]
         return {'ray_tracing_C0': r['C0'], 'ray_tracing_C1': r['C1'], 'ray_tracing_reflection': r['reflection'],
                 'ray_tracing_reflection_case': r['reflection_case'],
-                'ray_tracing_solution_type': self.get_solution_type(i_solution), 'focusing_factor': 1}
+                'ray_tracing_solution_type': self.get_solution_type(i_solution), 'focusing_factor': focusing}
 
     def apply_propagation_effects(self, efield, i_solution):
         """analyticraytracing.py:2937-3033 for in-ice rays: attenuation and surface-reflection Fresnel factors.
@@ -216,8 +242,10 @@ class ray_tracing:
                 pass
             spec[1] *= r_theta
             spec[2] *= r_phi
-        if prop.get('focusing') or prop.get('birefringence'):
-            raise NotImplementedError("focusing / birefringence are not provided yet")
+        if prop.get('focusing'):  # analyticraytracing.py:3011-3016
+            spec[1:] *= self.get_focusing(i_solution, limit=float(prop['focusing_limit']))
+        if prop.get('birefringence'):
+            raise NotImplementedError("birefringence is not provided yet")
         efield.set_frequency_spectrum(spec, efield.get_sampling_rate())
         return efield
 

@@ -88,3 +88,36 @@ def attenuation_length(z, f, model):
     for idx in np.ndindex(z.shape):
         out[idx] = L.orc_attenuation_length(float(z[idx]), float(f[idx]), MODEL_TO_INT[model])
     return out
+
+
+def focusing(x1, x2, ice, dz=-0.01, limit=2.):
+    """ray_tracing.get_focusing, numerical branch (analyticraytracing.py:2778-2888), receiver in ice: second trace to the
+    receiver moved by dz; [n, 2] (NaN where there is no solution).  x1 = emitter, x2 = receiver."""
+    x1 = np.asarray(x1, float).reshape(-1, 3)
+    x2 = np.asarray(x2, float).reshape(-1, 3)
+    a = raytrace_batch(x1, x2, ice)
+    x2b = x2.copy()
+    x2b[:, 2] += dz
+    b = raytrace_batch(x1, x2b, ice)
+    n_index = lambda z: ice[0] - ice[1] * np.exp(z / ice[2])
+    out = np.full((len(x1), 2), np.nan)
+    for i in range(len(x1)):
+        for s in range(a['n_sol'][i]):
+            rec = -1.0 * a['receive'][i, s]
+            rec_ang = np.arccos(rec[2] / np.sqrt(rec[0] ** 2 + rec[1] ** 2 + rec[2] ** 2))
+            lau = a['launch'][i, s]
+            lau_ang = np.arccos(lau[2] / np.sqrt(lau[0] ** 2 + lau[1] ** 2 + lau[2] ** 2))
+            if s < b['n_sol'][i]:
+                lau1 = b['launch'][i, s]
+                lau_ang1 = np.arccos(lau1[2] / np.sqrt(lau1[0] ** 2 + lau1[1] ** 2 + lau1[2] ** 2))
+                D = a['D'][i, s]
+                f = np.sqrt(D / np.sin(rec_ang) * np.abs((lau_ang1 - lau_ang) / (x2b[i, 2] - x2[i, 2])))
+                radius = np.linalg.norm(x2[i] - x1[i])
+                sin_theta = np.linalg.norm((x2[i] - x1[i])[:-1]) / radius
+                f *= np.sqrt((D * np.sin(lau_ang)) / (radius * sin_theta))
+            else:
+                f = 1.0
+            if f > limit:
+                f = limit
+            out[i, s] = f * (n_index(x1[i, 2]) / n_index(x2[i, 2])) ** 0.5
+    return out
