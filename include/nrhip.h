@@ -145,7 +145,14 @@ typedef struct {
     int32_t att_bound_n_bins;
     double att_bound_bin_width;
     const double* att_bound_bin_inv_length; /* [att_bound_n_bins][n_att_freq] */
+    /* [n_filters] or NULL (all rational): NRHIP_FILTER_RATIONAL b(jf)/a(jf) (butter, cheby1: signal.butter / cheby1
+       (analog=True) + freqs), NRHIP_FILTER_ABS its modulus (butterabs), NRHIP_FILTER_RECTANGULAR pass band
+       filter_b[0] <= f <= filter_b[1] (signal_processing.get_filter_response :237-333) */
+    const int32_t* filter_kind;
 } nrhip_station_desc;
+#define NRHIP_FILTER_RATIONAL 0
+#define NRHIP_FILTER_ABS 1
+#define NRHIP_FILTER_RECTANGULAR 2
 
 typedef struct {
     int32_t askaryan_model;       /* NRHIP_ASK_*                                                        */

@@ -191,6 +191,8 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     memset(&f, 0, sizeof f);
     f.n = d->n_filters;
     for (int i = 0; i < f.n; i++) {
+        f.kind[i] = d->filter_kind ? d->filter_kind[i] : 0;
+        if (f.kind[i] < 0 || f.kind[i] > 2) { delete s; return nrhip_fail_msg("nrhip_station_create: unknown filter kind"); }
         f.nb[i] = d->filter_nb[i];
         f.na[i] = d->filter_na[i];
         if (f.nb[i] < 1 || f.nb[i] > NRHIP_MAX_POLY || f.na[i] < 1 || f.na[i] > NRHIP_MAX_POLY) {

@@ -37,6 +37,7 @@ struct StationDev {
 // analog filter chain: response_i(f) = polyval(b_i, j f) / polyval(a_i, j f), highest power first
 struct FilterSet {
     int n;
+    int kind[NRHIP_MAX_FILTERS];  // 0 rational, 1 |rational|, 2 rectangular pass band b[0] <= f <= b[1]
     int nb[NRHIP_MAX_FILTERS], na[NRHIP_MAX_FILTERS];
     double b[NRHIP_MAX_FILTERS][NRHIP_MAX_POLY], a[NRHIP_MAX_FILTERS][NRHIP_MAX_POLY];
 };

@@ -1036,6 +1036,10 @@ candidate_lists_kernel(int n_events, int n_half, EventOut ev, const int* __restr
 __device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl)
 {
     for (int i = 0; i < fl.n; i++) {
+        if (fl.kind[i] == 2) {  // rectangular
+            if (!(fl.b[i][0] <= f && f <= fl.b[i][1])) return make_double2(0., 0.);
+            continue;
+        }
         if (!(f > 0)) return make_double2(0., 0.);
         double2 num = make_double2(0., 0.), den = make_double2(0., 0.);
         const double2 jw = make_double2(0., f);
@@ -1043,6 +1047,7 @@ __device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl
         for (int k = 0; k < fl.na[i]; k++) den = cadd(cmul(den, jw), make_double2(fl.a[i][k], 0.));
         double dd = den.x * den.x + den.y * den.y;
         double2 h = make_double2((num.x * den.x + num.y * den.y) / dd, (num.y * den.x - num.x * den.y) / dd);
+        if (fl.kind[i] == 1) h = make_double2(cabs2(h), 0.);
         v = cmul(v, h);
     }
     return v;

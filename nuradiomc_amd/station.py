@@ -18,7 +18,7 @@ class StationDesc(ctypes.Structure):
                 ('att_bound_depth', ctypes.c_double), ('n_filters', ctypes.c_int32),
                 ('filter_nb', L.c_int32_p), ('filter_na', L.c_int32_p), ('filter_b', L.c_double_p),
                 ('filter_a', L.c_double_p), ('att_bound_n_bins', ctypes.c_int32), ('att_bound_bin_width', ctypes.c_double),
-                ('att_bound_bin_inv_length', L.c_double_p)]
+                ('att_bound_bin_inv_length', L.c_double_p), ('filter_kind', L.c_int32_p)]
 
 
 class SimConfig(ctypes.Structure):
@@ -90,7 +90,8 @@ class Station:
     orientation (theta, phi, rotation theta, rotation phi) in rad (one tuple or [n_ch, 4]), cable_delay (ns),
     n_samples / sampling_rate: the simulated trace grid; detector_sampling_rate: the detector's own ADC rate
     (sets the attenuation grid's max_detector_freq, propagation_base_class.py:66-80);
-    filters: sequence of (order, (f_lo, f_hi)) Butterworth stages (f_lo = 0: low-pass) applied in order.
+    filters: sequence of (order, (f_lo, f_hi)) Butterworth stages (f_lo = 0: low-pass) or dicts {'type': 'butter' |
+    'butterabs' | 'cheby1' | 'rectangular', 'passband', 'order', 'rp'} (signal_processing.get_filter_response) applied in order.
     """
 
     def __init__(self, ctx, position, antenna='analytic_VPol', orientation=(0., 0., np.pi / 2, np.pi / 2),
@@ -115,12 +116,13 @@ class Station:
         det_fs = float(detector_sampling_rate or sampling_rate)
         ff = np.fft.rfftfreq(self.n_samples, 1. / self.sampling_rate)
         self.att_freq = np.ascontiguousarray(attenuation_frequencies(ff, n_freq, 0.5 * det_fs))
-        self.filters = [flt.butter_analog(order, pb) for order, pb in filters]
-        nb = np.array([len(b) for b, _ in self.filters], np.int32)
-        na = np.array([len(a) for _, a in self.filters], np.int32)
+        self.filters = [flt.design(spec) for spec in filters]   # (kind, b, a) per stage
+        fkind = np.array([k for k, _, _ in self.filters] or [0], np.int32)
+        nb = np.array([len(b) for _, b, _ in self.filters], np.int32)
+        na = np.array([len(a) for _, _, a in self.filters], np.int32)
         fb = np.zeros((max(len(self.filters), 1), flt.MAX_POLY))
         fa = np.zeros((max(len(self.filters), 1), flt.MAX_POLY))
-        for i, (b, a) in enumerate(self.filters):
+        for i, (_, b, a) in enumerate(self.filters):
             fb[i, :len(b)] = b
             fa[i, :len(a)] = a
         # largest attenuation length between the surface and att_bound_depth per coarse frequency (1 m grid): lets the
@@ -139,12 +141,12 @@ class Station:
         idx = np.arange(n_bins)[:, None] * per + np.arange(per + 1)[None, :]
         self.att_bound_bin_inv_length = np.ascontiguousarray(inv[:, idx].min(axis=2).T * (1 - 1e-3))  # [n_bins][n_fc]
         self._keep = (pos, cab, model, ori, self.att_freq, nb, na, fb, fa, self.att_bound_inv_length,
-                      self.att_bound_bin_inv_length)
+                      self.att_bound_bin_inv_length, fkind)
         d = StationDesc(n, L.dptr(pos), L.dptr(cab), L.iptr(model), L.dptr(ori), self.n_samples, self.sampling_rate,
                         float(readout_length if readout_length is not None else self.n_samples / self.sampling_rate),
                         float(pre_pulse_time), float(post_pulse_time), len(self.att_freq), L.dptr(self.att_freq),
                         L.dptr(self.att_bound_inv_length), self.att_bound_depth, len(self.filters), L.iptr(nb), L.iptr(na), L.dptr(fb), L.dptr(fa),
-                        n_bins, self.att_bound_bin_width, L.dptr(self.att_bound_bin_inv_length))
+                        n_bins, self.att_bound_bin_width, L.dptr(self.att_bound_bin_inv_length), L.iptr(fkind))
         h = ctypes.c_void_p()
         L.check(self._lib.nrhip_station_create(ctx._h, ctypes.byref(d), ctypes.byref(h)))
         self._h = h

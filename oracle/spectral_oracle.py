@@ -325,14 +325,24 @@ def butter_ba(passband, order):
 
 
 def filter_response(freqs, filters=DEFAULT_FILTERS):
+    """signal_processing.get_filter_response (:237-333) stage by stage: butter (default), butterabs, cheby1, rectangular"""
     H = np.ones_like(freqs, dtype=complex)
     for flt in filters:
+        typ = flt.get('type', 'butter')
+        pb = flt['passband']
+        if typ == 'rectangular':
+            H = H * np.where((pb[0] <= freqs) & (freqs <= pb[1]), 1, 0)
+            continue
         f = np.zeros_like(freqs, dtype=complex)
         mask = freqs > 0
-        b, a = butter_ba(flt['passband'], flt['order'])
+        args = [pb[1], 'lowpass'] if pb[0] == 0 else [list(pb), 'bandpass']
+        if typ == 'cheby1':
+            b, a = signal.cheby1(flt['order'], flt['rp'], *args, analog=True)
+        else:
+            b, a = signal.butter(flt['order'], *args, analog=True)
         _, h = signal.freqs(b, a, freqs[mask])
         f[mask] = h
-        H = H * f
+        H = H * (np.abs(f) if typ == 'butterabs' else f)
     return H
 
 

@@ -402,3 +402,35 @@ def test_amp_per_ray_solution(gpu_ctx_factory, name, n_events):
             assert np.all(np.abs(env[mine] - g['ray_max_amp_ray'][ref]) <= 5e-3 * g['ray_max_amp_ray'][ref])
             n_ref += len(ref)
     assert n_checked >= 30 and n_ref >= 30
+
+
+def test_filter_kinds(gpu_ctx_factory):
+    """A chain of rectangular + Chebyshev + |Butterworth| stages (signal_processing.get_filter_response types, pinned
+    against the reference by tests/test_oracle_golden.py::test_filter_responses_vs_reference) through the whole path:
+    Vrms, candidate cut, channel traces and trigger vs the oracle."""
+    g = golden('chain_N256.npz')
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    chain = [dict(type='rectangular', passband=(0.09, 0.7), order=0), dict(type='cheby1', passband=(0.12, 0.55), order=4, rp=0.5),
+             dict(type='butterabs', passband=(0., 0.6), order=6)]
+    st = nuradiomc_amd.Station(ctx, g['det_pos'], n_samples=int(g['N']), sampling_rate=float(g['fs']), filters=chain)
+    ost = so.Station(g['det_pos'], n_samples=int(g['N']), fs=float(g['fs']))
+    vrms, vrms_e = so.vrms_from_filters(ost.fs, chain)
+    assert abs(st.vrms - vrms) <= 1e-9 * vrms and abs(st.vrms_efield - vrms_e) <= 1e-9 * vrms_e
+    n = 200
+    kL = np.where(np.isnan(g['ev_k_L'][:n]), 1.0, g['ev_k_L'][:n])
+    trig, stats = st.simulate_events(g['vertex'][:n], g['zenith'][:n], g['azimuth'][:n], g['energy'][:n], g['shower_type'][:n],
+                                     kL, dump_traces=True, min_efield_amplitude=2 * vrms_e, trigger_threshold=3 * vrms)
+    cand, item_event, tr, off = st.fetch('ev_candidate'), st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    pos = {int(e): i for i, e in enumerate(item_event)}
+    n_cand = 0
+    for e in range(n):
+        o = so.simulate_event(g['vertex'][e], g['zenith'][e], g['azimuth'][e], g['energy'][e], str(g['shower_type'][e]),
+                              float(kL[e]), ost, g['ice'], vrms, vrms_e, filters=chain)
+        assert o['candidate'] == bool(cand[e]) and o['triggered'] == bool(trig[e]), e
+        if o['candidate']:
+            n_cand += 1
+            scale = np.max(np.abs(o['V']))
+            for ch in range(5):
+                it = pos[e] * 5 + ch
+                assert np.max(np.abs(tr[off[it]:off[it + 1]] - o['V'][ch])) <= 1e-6 * scale, (e, ch)
+    assert n_cand >= 8

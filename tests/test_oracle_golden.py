@@ -141,3 +141,20 @@ def test_focusing_vs_reference():
     rel = np.abs(f[both] - g['focusing'][both]) / g['focusing'][both]
     # (where the reference loses the first root of the displaced trace it falls back to focusing = 1: <= 1 % of rays)
     assert np.median(rel) < 1e-8 and np.mean(rel < 1e-4) > 0.85 and np.mean(rel < 5e-3) >= 0.99
+
+
+def test_filter_responses_vs_reference():
+    """butter / butterabs / cheby1 / rectangular stages: the oracle (scipy, like the reference) and the product's own
+    numpy-only designs (nuradiomc_amd/filters.py, host logic) against signal_processing.get_filter_response."""
+    from oracle import spectral_oracle as so
+    from nuradiomc_amd import filters as flt
+    g = golden('ref_filters.npz')
+    ff = g['ff']
+    for i, rep in enumerate(g['specs']):
+        spec = eval(rep)
+        ref = g['H_%d' % i]
+        scale = np.max(np.abs(ref))
+        assert np.max(np.abs(so.filter_response(ff, [spec]) - ref)) <= 1e-12 * scale, spec
+        assert np.max(np.abs(flt.response(ff, [flt.design(spec)]) - ref)) <= 1e-9 * scale, spec
+    with pytest.raises(NotImplementedError):
+        flt.design(dict(type='gaussian_tapered', passband=(0.1, 0.2), order=1))
