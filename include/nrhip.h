@@ -217,14 +217,17 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
  * calculate_sim_efield loops over the showers of the group per channel (simulation.py:143), every later step -- candidate
  * flag, common time grid, channel sums, trigger -- is per group.  Showers are given in group order; group_begin is a DEV
  * int32 [n_groups + 1] array of first-shower indices (NULL: one shower per group, n_groups == n_showers); vertex_time
- * [n_showers] DEV or NULL (0) enters the trace start time (simulation.py:259-268).  triggered: DEV uint8 [n_groups];
+ * [n_showers] DEV or NULL (0) enters the trace start time (simulation.py:259-268).  max_distance [n_showers] DEV or NULL:
+ * speedup.distance_cut (simulation.py:155-163, :1398-1409) -- a shower farther from an antenna than this is skipped for
+ * that channel (the host evaluates the energy polynomial, incl. the energy sum of neighbouring showers).
+ * triggered: DEV uint8 [n_groups];
  * the ev_* / item_* tables of nrhip_sim_fetch are per group.  All showers of a group must end up in ONE readout
  * (split_event_time_diff is not applied); a group whose common trace exceeds the supported length fails the call. */
 int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_config* cfg, int64_t n_showers,
                                 const double* vertex, const double* zenith, const double* azimuth,
                                 const double* energy, const int32_t* shower_type, const double* k_L,
-                                const double* vertex_time, int64_t n_groups, const int32_t* group_begin,
-                                uint8_t* triggered, nrhip_sim_stats* stats);
+                                const double* vertex_time, const double* max_distance, int64_t n_groups,
+                                const int32_t* group_begin, uint8_t* triggered, nrhip_sim_stats* stats);
 
 /* Copy one intermediate table of the LAST nrhip_simulate_events call to HOST memory (parity tests,
  * output writers).  Names: ray_event ray_channel ray_solution ray_view ray_pol_theta ray_pol_phi ray_zenith

@@ -23,7 +23,7 @@ struct RayRecords {
 };
 
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
-                     const IceConst& m, const RayRecords& out);
+                     const IceConst& m, const RayRecords& out, const double* max_dist = nullptr);
 
 
 }  // namespace nrhip

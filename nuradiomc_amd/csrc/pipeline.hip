@@ -238,13 +238,14 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
                           const int32_t* shower_type, const double* k_L, uint8_t* triggered, nrhip_sim_stats* stats)
 {
     return nrhip_simulate_event_groups(ctx, st, cfg, n_events, vertex, zenith, azimuth, energy, shower_type, k_L, nullptr,
-                                       n_events, nullptr, triggered, stats);
+                                       nullptr, n_events, nullptr, triggered, stats);
 }
 
 int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_config* cfg, int64_t n_showers,
                                 const double* vertex, const double* zenith, const double* azimuth, const double* energy,
                                 const int32_t* shower_type, const double* k_L, const double* vertex_time,
-                                int64_t n_groups, const int32_t* group_begin, uint8_t* triggered, nrhip_sim_stats* stats)
+                                const double* max_distance, int64_t n_groups, const int32_t* group_begin,
+                                uint8_t* triggered, nrhip_sim_stats* stats)
 {
     if (!ctx || !st || !cfg) return nrhip_fail_msg("nrhip_simulate_events: NULL argument");
     if (st->ctx != ctx) return nrhip_fail_msg("nrhip_simulate_events: station belongs to another context");
@@ -283,7 +284,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     NEED(rec.launch = WS("slot_launch", double, 3 * n_slots));
     NEED(rec.receive = WS("slot_receive", double, 3 * n_slots));
     NEED(rec.refl_angle = WS("slot_refl_angle", double, n_slots));
-    launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec);
+    launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance);
     LCHK("raytrace");
     MARK(1);
 

@@ -193,7 +193,7 @@ __device__ inline bool np_sign_differs(double a, double b)
 // Kernel: pair i = (event i / n_ch, channel i % n_ch) when n_ch > 0, else x2 is per pair.
 __global__ void __launch_bounds__(256, 6)
 raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
-                IceConst m, RayRecords out)
+                IceConst m, RayRecords out, const double* __restrict__ max_dist)
 {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_pairs; i += (long)gridDim.x * blockDim.x) {
         long i1 = (n_ch > 0) ? i / n_ch : i;
@@ -223,7 +223,9 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
 
         int ns = 0;
         double lc[3];
-        if (!(p.z2 > 0)) {  // receiver in air: special branch of the reference (:1437-1460) not provided
+        // speedup.distance_cut (simulation.py:155-163): showers farther from the antenna than their cut are not traced
+        const bool too_far = max_dist && sqrt(dX[0] * dX[0] + dX[1] * dX[1] + dX[2] * dX[2]) > max_dist[i1];
+        if (!(p.z2 > 0) && !too_far) {  // receiver in air: special branch of the reference (:1437-1460) not provided
             auto dy = [&](double l) { return delta_y(l, p, m); };
             auto dy2 = [&](double l) { double d = delta_y(l, p, m); return d * d; };
             double fun;
@@ -294,13 +296,13 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
 }
 
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
-                     const IceConst& m, const RayRecords& out)
+                     const IceConst& m, const RayRecords& out, const double* max_dist)
 {
     if (n_pairs <= 0) return;
     int block = 256;
     long grid = (n_pairs + block - 1) / block;
     if (grid > 256L * 64) grid = 256L * 64;
-    hipLaunchKernelGGL(raytrace_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out);
+    hipLaunchKernelGGL(raytrace_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist);
 }
 
 }  // namespace nrhip

@@ -50,7 +50,7 @@ L._OPTIONAL.update({
     'nrhip_simulate_events': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(SimConfig), ctypes.c_int64]
                               + [ctypes.c_void_p] * 7 + [ctypes.POINTER(SimStats)]),
     'nrhip_simulate_event_groups': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(SimConfig),
-                                                   ctypes.c_int64] + [ctypes.c_void_p] * 7 + [ctypes.c_int64]
+                                                   ctypes.c_int64] + [ctypes.c_void_p] * 8 + [ctypes.c_int64]
                                     + [ctypes.c_void_p] * 2 + [ctypes.POINTER(SimStats)]),
     'nrhip_sim_fetch': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64]),
     'nrhip_askaryan_spectrum_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, L.c_double_p, L.c_double_p,
@@ -81,6 +81,28 @@ def attenuation_frequencies(frequency, n_freq, max_detector_freq=None):
 
 
 DEFAULT_FILTERS = ((2, (0.08, 1000.)), (10, (0., 0.5)))  # NuRadioMC/examples/01_Veff_simulation/T02RunSimulation.py:18-22
+
+
+def distance_cut(vertex, energy, group_begin, coefficients, sum_length=10.):
+    """speedup.distance_cut (simulation.py:155-163, :1398-1409): per shower the largest vertex-antenna distance [m] that is
+    still simulated, max(100 m, 10 ** polynomial(log10(E_sum))), E_sum = energy of the showers of the same event group whose
+    distance to the group's first vertex differs by less than sum_length.  Host logic (one pass over the shower list)."""
+    vertex = np.asarray(vertex, float).reshape(-1, 3)
+    energy = np.asarray(energy, float)
+    n = len(vertex)
+    poly = np.polynomial.polynomial.Polynomial(coefficients)
+    e_sum = energy.copy()
+    if group_begin is not None:
+        for g in range(len(group_begin) - 1):
+            a, b = int(group_begin[g]), int(group_begin[g + 1])
+            if b - a > 1:
+                d = np.linalg.norm(vertex[a:b] - vertex[a], axis=1)
+                mask = np.abs(d[:, None] - d[None, :]) < sum_length
+                e_sum[a:b] = (mask * energy[a:b][None, :]).sum(axis=1)
+    out = np.full(n, 100.)
+    pos = e_sum > 0
+    out[pos] = np.maximum(100., 10 ** poly(np.log10(e_sum[pos])))
+    return np.ascontiguousarray(out)
 
 
 class Station:
@@ -168,7 +190,8 @@ class Station:
                             askaryan_model='Alvarez2009', delta_C_cut=0.698, min_efield_amplitude=None,
                             trigger_threshold=None, dump_traces=False, no_pruning=False, want_stats=True,
                             d_vertex_time=None, n_groups=None, d_group_begin=None, trigger='simple', n_coincidences=1,
-                            threshold_high=None, threshold_low=None, high_low_window=5., coinc_window=200., amp_per_ray=False):
+                            threshold_high=None, threshold_low=None, high_low_window=5., coinc_window=200., amp_per_ray=False,
+                            d_max_distance=None):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
         d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
@@ -186,12 +209,12 @@ class Station:
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_event_groups(
             self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,
-            d_vertex_time, int(n_events if n_groups is None else n_groups), d_group_begin, d_triggered,
+            d_vertex_time, d_max_distance, int(n_events if n_groups is None else n_groups), d_group_begin, d_triggered,
             ctypes.byref(stats) if want_stats else None))
         return stats.as_dict() if want_stats else None
 
     def simulate_events(self, vertex, zenith, azimuth, energy, shower_type, k_L=None, vertex_time=None, group_id=None,
-                        **kw):
+                        distance_cut_coefficients=None, distance_cut_sum_length=10., **kw):
         """Host-array convenience form: uploads the shower list, runs the hot path, returns (triggered mask, stats).
         `group_id` [n] (equal ids consecutive, like the event_group_ids of the reference's input files) makes showers of
         one id a single event group: their signals add up in the channels (simulation.py:143) and the mask has one entry
@@ -211,6 +234,10 @@ class Station:
             n_groups = len(first)
         if vertex_time is not None:
             vt = np.ascontiguousarray(np.broadcast_to(L.f64(vertex_time), (n,)))
+        md = None
+        if distance_cut_coefficients is not None and n:
+            md = distance_cut(vertex, np.broadcast_to(L.f64(energy), (n,)), gb, distance_cut_coefficients,
+                              distance_cut_sum_length)
         st = np.ascontiguousarray([SHOWER_TO_INT[str(s).upper()] if not isinstance(s, (int, np.integer)) else int(s)
                                    for s in np.broadcast_to(shower_type, (n,))], dtype=np.int32)
         kL = np.ascontiguousarray(np.broadcast_to(np.nan if k_L is None else L.f64(k_L), (n,)), dtype=np.float64)
@@ -220,10 +247,10 @@ class Station:
                 np.ascontiguousarray(np.broadcast_to(L.f64(energy), (n,))), st, np.ascontiguousarray(kL)]
         dptrs = [ctx.to_device(a) for a in arrs]
         dtrig = ctx.malloc(max(n_groups, 1))
-        extra = [ctx.to_device(a) if a is not None else None for a in (vt, gb)]
+        extra = [ctx.to_device(a) if a is not None else None for a in (vt, gb, md)]
         try:
             stats = self.simulate_events_dev(n, *dptrs, dtrig, d_vertex_time=extra[0], n_groups=n_groups,
-                                             d_group_begin=extra[1], **kw)
+                                             d_group_begin=extra[1], d_max_distance=extra[2], **kw)
             trig = np.zeros(n_groups, np.uint8)
             ctx.to_host(trig, dtrig)
         finally:

@@ -373,7 +373,7 @@ class Station:
 
 
 def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model='SP1', n_freq=25,
-                          model='Alvarez2009', delta_C_cut=0.698, vertex_time=0., rays=None):
+                          model='Alvarez2009', delta_C_cut=0.698, vertex_time=0., rays=None, max_distance=None):
     """calculate_sim_efield (simulation.py:93-292) for every channel of one single-shower event.
     `rays` may carry precomputed ray tables (dict like raytrace_oracle.raytrace_batch output, one row per channel).
     Returns a list of dicts (one per kept ray, channel-major then solution)."""
@@ -389,6 +389,8 @@ def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st,
     fcoarse = attenuation_frequencies(ff, n_freq, 0.5 * st.fs)
     out = []
     for ch in range(st.n_ch):
+        if max_distance is not None and np.linalg.norm(x1 - st.pos[ch]) > max_distance:  # simulation.py:155-163
+            continue
         ns = rays['n_sol'][ch]
         if ns == 0:
             continue
@@ -552,14 +554,25 @@ def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, v
 
 
 def simulate_event_group(showers, st, ice, vrms, vrms_efield, att_model='SP1', n_freq=25, model='Alvarez2009',
-                         filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0, min_efield_amplitude=2.0):
+                         filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0, min_efield_amplitude=2.0,
+                         distance_cut_coefficients=None, distance_cut_sum_length=10.):
     """An event group of several showers through simulation.run()'s sequence (:1454-1600): calculate_sim_efield loops
     over the showers per channel (:143), the candidate flag, the common time grid, the channel sums and the trigger are
     per group.  `showers`: list of dicts with vertex, zenith, azimuth, energy, shower_type, k_L, vertex_time."""
     efs = []
+    cuts = [None] * len(showers)
+    if distance_cut_coefficients is not None:  # simulation.py:1398-1409 and :125-131, :155-163
+        poly = np.polynomial.polynomial.Polynomial(distance_cut_coefficients)
+        vpos = np.array([sh['vertex'] for sh in showers], float)
+        en = np.array([sh['energy'] for sh in showers], float)
+        vd = np.linalg.norm(vpos - vpos[0], axis=1)
+        for i in range(len(showers)):
+            e_sum = np.sum(en[np.abs(vd - vd[i]) < distance_cut_sum_length])
+            cuts[i] = 100. if e_sum <= 0 else max(100., 10 ** poly(np.log10(e_sum)))
     for i, sh in enumerate(showers):
         e = sim_efields_for_event(sh['vertex'], sh['zenith'], sh['azimuth'], sh['energy'], sh['shower_type'], sh.get('k_L'),
-                                  st, ice, att_model, n_freq, model, delta_C_cut, vertex_time=sh.get('vertex_time', 0.))
+                                  st, ice, att_model, n_freq, model, delta_C_cut, vertex_time=sh.get('vertex_time', 0.),
+                                  max_distance=cuts[i])
         for ef in e:
             ef['shower'] = i
         efs += e

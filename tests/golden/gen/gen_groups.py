@@ -18,9 +18,15 @@ import refharness as rh  # noqa: E402
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 
 
-def run(name='groups_N256', n_groups=160, seed=31, N=256, full_events=10):
+def run(name='groups_N256', n_groups=160, seed=31, N=256, full_events=10, distance_cut=False, loge=(17.3, 18.7)):
     det = rh.StationS5(n_samples=N, fs=2.0)
     cfg = rh.default_config()
+    dcut = None
+    if distance_cut:
+        cfg['speedup']['distance_cut'] = True
+        cfg['speedup']['distance_cut_coefficients'] = [-1.56434411e+02, 2.54131322e+01, -1.34932379e+00, 2.39984185e-02]
+        cfg['speedup']['distance_cut_sum_length'] = 10.
+        dcut = rh.distance_cut_function(cfg)
     ice, prop = rh.make_propagator(cfg, det)
     vrms, vrms_e = rh.vrms_from_filters(cfg)
     rng = np.random.default_rng(seed)
@@ -29,7 +35,7 @@ def run(name='groups_N256', n_groups=160, seed=31, N=256, full_events=10):
     for g in range(n_groups):
         kind = g % 5
         v, zen, az = base['vertex'][g], base['zenith'][g], base['azimuth'][g]
-        e_tot = 10 ** rng.uniform(17.3, 18.7)
+        e_tot = 10 ** rng.uniform(*loge)
         if kind in (0, 1):      # one hadronic shower
             parts = [(v, e_tot, 'HAD', 0.)]
         elif kind in (2, 3):    # nu_e CC: hadronic + electromagnetic shower at the same vertex
@@ -58,7 +64,7 @@ def run(name='groups_N256', n_groups=160, seed=31, N=256, full_events=10):
         idx = np.flatnonzero(sh['group'] == g)
         showers = [rh.make_shower(int(i), sh['vertex'][i], sh['zenith'][i], sh['azimuth'][i], sh['energy'][i],
                                   str(sh['shower_type'][i]), vertex_time=float(sh['vertex_time'][i])) for i in idx]
-        o = rh.simulate_event(g, showers, det, prop, ice, cfg, vrms, vrms_e)
+        o = rh.simulate_event(g, showers, det, prop, ice, cfg, vrms, vrms_e, distance_cut=dcut)
         k_L[idx] = o['k_L_all']
         evo['candidate'][g] = o['candidate']
         evo['triggered'][g] = o['triggered']
@@ -77,6 +83,7 @@ def run(name='groups_N256', n_groups=160, seed=31, N=256, full_events=10):
     rr = np.array(ray_rows)
     out = dict(N=N, fs=2.0, vrms=vrms, vrms_efield=vrms_e, ice=np.array([ice.n_ice, ice.delta_n, ice.z_0]),
                att_model='SP1', n_freq=25, askaryan_model='Alvarez2009', antenna='analytic_VPol', cable_delay=0.,
+               distance_cut=distance_cut, distance_cut_coefficients=np.array(cfg['speedup'].get('distance_cut_coefficients', [])),
                det_pos=det.pos, det_orientation=np.array(det.orientation),
                vertex=sh['vertex'], zenith=sh['zenith'], azimuth=sh['azimuth'], energy=sh['energy'],
                shower_type=sh['shower_type'], vertex_time=sh['vertex_time'], group=sh['group'], k_L=k_L,
@@ -89,4 +96,8 @@ def run(name='groups_N256', n_groups=160, seed=31, N=256, full_events=10):
 
 
 if __name__ == '__main__':
-    run()
+    which = sys.argv[1:] or ['groups_N256', 'groups_dcut_N256']
+    if 'groups_N256' in which:
+        run()
+    if 'groups_dcut_N256' in which:  # speedup.distance_cut on, energies where it bites
+        run('groups_dcut_N256', n_groups=200, seed=32, distance_cut=True, loge=(16.0, 17.8), full_events=4)

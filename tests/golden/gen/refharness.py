@@ -125,6 +125,17 @@ def vrms_from_filters(config, noise_temperature=300.):
     return vrms, vrms / max_amp / units.m
 
 
+def distance_cut_function(config):
+    """simulation.py:1398-1409"""
+    poly = np.polynomial.polynomial.Polynomial(config['speedup']['distance_cut_coefficients'])
+
+    def get_distance_cut(shower_energy):
+        if shower_energy <= 0:
+            return 100 * units.m
+        return max(100 * units.m, 10 ** poly(np.log10(shower_energy)))
+    return get_distance_cut
+
+
 def make_shower(shower_id, vertex, zenith, azimuth, energy, shower_type, vertex_time=0.):
     sh = NuRadioReco.framework.radio_shower.RadioShower(shower_id)
     sh[shp.zenith] = zenith
@@ -155,7 +166,7 @@ def make_propagator(config, det):
     return ice, prop
 
 
-def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, trigger_sigma=3.0):
+def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, trigger_sigma=3.0, distance_cut=None):
     """One event group through the reference, following simulation.run() (simulation.py:1454-1600).
     `shower` is one RadioShower or the list of showers of the event group.
 
@@ -177,7 +188,8 @@ def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, tri
     for ch in det.get_channel_ids(sid):
         ss = simulation.calculate_sim_efield(
             showers=showers, station_id=sid, channel_id=ch, det=det, propagator=prop, medium=ice,
-            config=config, min_efield_amplitude=float(config['speedup']['min_efield_amplitude']) * vrms_efield)
+            config=config, min_efield_amplitude=float(config['speedup']['min_efield_amplitude']) * vrms_efield,
+            distance_cut=distance_cut)
         if ss.is_candidate():
             candidate = True
         if len(ss.get_electric_fields()) == 0:

@@ -286,18 +286,21 @@ def test_channel_kernels_agree(gpu_ctx_factory, name, n_events, monkeypatch):
     assert np.max(np.abs(mv_a - mv_b)) <= 1e-9 * np.max(np.abs(mv_b))
 
 
-def test_event_groups(gpu_ctx_factory):
+@pytest.mark.parametrize('name', ['groups_N256', 'groups_dcut_N256'])
+def test_event_groups(gpu_ctx_factory, name):
     """Multi-shower event groups through nrhip_simulate_event_groups: vs the oracle (same rays bit for bit, hence traces
     to 1e-6 and exact decisions) and vs the reference's own outputs (tests/golden/chain_groups_N256.npz); production and
     exhaustive mode give the same masks."""
-    g = golden('chain_groups_N256.npz')
+    g = golden('chain_%s.npz' % name)
+    dcut = g['distance_cut_coefficients'] if ('distance_cut' in g and bool(g['distance_cut'])) else None  # speedup.distance_cut
     ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
     st = _station(ctx, g)
     ost = so.Station(g['det_pos'], n_samples=int(g['N']), fs=float(g['fs']))
     vrms, vrms_e = so.vrms_from_filters(ost.fs)
     kL = np.where(np.isnan(g['k_L']), 1.0, g['k_L'])
     args = (g['vertex'], g['zenith'], g['azimuth'], g['energy'], g['shower_type'], kL)
-    trig, stats = st.simulate_events(*args, vertex_time=g['vertex_time'], group_id=g['group'], dump_traces=True)
+    trig, stats = st.simulate_events(*args, vertex_time=g['vertex_time'], group_id=g['group'], dump_traces=True,
+                                     distance_cut_coefficients=dcut)
     n_groups = len(g['ev_candidate'])
     assert trig.shape == (n_groups,) and stats['n_events'] == n_groups
     cand, L, t_min, n_rays = (st.fetch(k) for k in ('ev_candidate', 'ev_L', 'ev_t_min', 'ev_n_rays'))
@@ -310,7 +313,7 @@ def test_event_groups(gpu_ctx_factory):
         showers = [dict(vertex=g['vertex'][i], zenith=float(g['zenith'][i]), azimuth=float(g['azimuth'][i]),
                         energy=float(g['energy'][i]), shower_type=str(g['shower_type'][i]), k_L=float(kL[i]),
                         vertex_time=float(g['vertex_time'][i])) for i in idx]
-        o = so.simulate_event_group(showers, ost, g['ice'], vrms, vrms_e)
+        o = so.simulate_event_group(showers, ost, g['ice'], vrms, vrms_e, distance_cut_coefficients=dcut)
         assert len(o['rays']) == n_rays[gi] and o['candidate'] == bool(cand[gi]) and o['triggered'] == bool(trig[gi]), gi
         if o['candidate']:
             n_cand += 1
@@ -322,8 +325,8 @@ def test_event_groups(gpu_ctx_factory):
                 assert np.max(np.abs(tr[off[it]:off[it + 1]] - o['V'][ch])) <= 1e-6 * scale, (gi, ch)
         if n_rays[gi] == g['ev_n_rays'][gi]:  # the reference itself, where its first-root noise kept the ray count
             assert bool(cand[gi]) == bool(g['ev_candidate'][gi]) and bool(trig[gi]) == bool(g['ev_triggered'][gi])
-    assert n_cand >= 20 and n_multi >= 8 and trig.sum() >= 5
-    trig_p, _ = st.simulate_events(*args, vertex_time=g['vertex_time'], group_id=g['group'])
+    assert (n_cand >= 20 and n_multi >= 8 and trig.sum() >= 5) if dcut is None else (n_cand >= 10 and trig.sum() >= 1)
+    trig_p, _ = st.simulate_events(*args, vertex_time=g['vertex_time'], group_id=g['group'], distance_cut_coefficients=dcut)
     assert np.array_equal(trig, trig_p) and np.array_equal(cand, st.fetch('ev_candidate'))
     with pytest.raises(ValueError):
         st.simulate_events(*args, group_id=np.roll(g['group'], 1))

@@ -112,12 +112,14 @@ def _group_showers(g, gi):
             for i in idx]
 
 
-def test_event_groups_vs_reference():
+@pytest.mark.parametrize('name', ['groups_N256', 'groups_dcut_N256'])
+def test_event_groups_vs_reference(name):
     """Multi-shower event groups (HAD + EM at one vertex, two vertices with a time offset) against the reference's own
     calculate_sim_efield(showers=[...]) -> detector response -> trigger outputs (tests/golden/gen/gen_groups.py).
     The oracle traces its own rays here, so amplitudes carry the reference's first-root noise (5e-3, see
     test_gpu_chain.test_whole_path_vs_reference_fixture); decisions must agree wherever the ray counts do."""
-    g = golden('chain_groups_N256.npz')
+    g = golden('chain_%s.npz' % name)
+    dcut = g['distance_cut_coefficients'] if ('distance_cut' in g and bool(g['distance_cut'])) else None  # speedup.distance_cut
     st = _station(g)
     vrms, vrms_e = so.vrms_from_filters(st.fs)
     assert vrms == float(g['vrms']) and vrms_e == float(g['vrms_efield'])
@@ -126,7 +128,7 @@ def test_event_groups_vs_reference():
     n_same = n_cand = n_multi_cand = 0
     for gi in range(n_groups):
         showers = _group_showers(g, gi)
-        o = so.simulate_event_group(showers, st, g['ice'], vrms, vrms_e)
+        o = so.simulate_event_group(showers, st, g['ice'], vrms, vrms_e, distance_cut_coefficients=dcut)
         if len(o['rays']) != g['ev_n_rays'][gi]:
             continue
         n_same += 1
@@ -147,4 +149,9 @@ def test_event_groups_vs_reference():
             if gi in vev:
                 V_ref = g['V_concat'][:, g['V_offsets'][vev[gi]]:g['V_offsets'][vev[gi] + 1]]
                 assert np.max(np.abs(o['V'] - V_ref)) <= 5e-3 * np.max(np.abs(V_ref)), gi
-    assert n_same >= 0.97 * n_groups and n_cand >= 20 and n_multi_cand >= 8
+    assert n_same >= 0.97 * n_groups and n_cand >= (20 if dcut is None else 10) and n_multi_cand >= (8 if dcut is None else 3)
+    if dcut is not None:  # the cut really removed rays: without it the oracle keeps more
+        def filled(gi):  # EM showers the cut removed entirely never drew a k_L in the reference
+            return [dict(sh, k_L=50. if sh['k_L'] is None else sh['k_L']) for sh in _group_showers(g, gi)]
+        n_without = sum(len(so.simulate_event_group(filled(gi), st, g['ice'], vrms, vrms_e)['rays']) for gi in range(40))
+        assert n_without > g['ev_n_rays'][:40].sum()
