@@ -602,7 +602,7 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
 // their rays skip the attenuation quadrature and the time-domain transform.  One block per ray.
 // ---------------------------------------------------------------------------------------------------------
 #define AB_RT 4  // rays per wave and pass: the frequency-grid tables are loaded once for AB_RT rays
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double* __restrict__ vertex,
                  const double* __restrict__ zint, double* __restrict__ bound, double* __restrict__ max_efield)
 {
@@ -685,31 +685,37 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
                 ub_slope[wv][i][lane] = (ub[wv][i][lane + 1] - ub[wv][i][lane]) / (s_xp[lane + 1] - s_xp[lane]);
         __syncthreads();
         if (rb < n_rays) {
-            AskaryanConst a[AB_RT];
+            // per-ray scalars only (the full AskaryanConst records would cost ~40 VGPRs per ray)
+            double cL[AB_RT], cR[AB_RT], pf[AB_RT];
+            int had[AB_RT];
             bool all2009 = true;
             for (int i = 0; i < AB_RT; i++) {
-                a[i] = w.ask[min(rb + i, n_rays - 1)];
-                all2009 = all2009 && (a[i].model == 0);
+                const AskaryanConst& ai = w.ask[min(rb + i, n_rays - 1)];
+                all2009 = all2009 && (ai.model == 0);
+                cL[i] = ai.cL; cR[i] = ai.cR; pf[i] = ai.pref2; had[i] = ai.had;
             }
             double part[AB_RT];
             for (int i = 0; i < AB_RT; i++) part[i] = 0.;
+            const double x_first = s_xp[0], x_last = s_xp[st.n_fc - 1], dx_last = x_last - s_xp[st.n_fc - 2];
             for (int k = 1 + lane; k < nh; k += 64) {
                 const double f = k * df;
-                const int lo = st.seg[k];
-                const bool below = f <= s_xp[0], above = f >= s_xp[st.n_fc - 1];
-                const double dx = f - s_xp[lo];
+                // np.interp clamps outside the coarse grid: segment 0 at offset 0 / last segment at full length
+                int lo = st.seg[k];
+                double dx = f - s_xp[lo];
+                if (f <= x_first) { lo = 0; dx = 0.; }
+                if (f >= x_last) { lo = st.n_fc - 2; dx = dx_last; }
                 if (all2009) {
                     const double ph = st.fpow[k], pe = st.fpow[stride + k], pr = st.fpow[2 * stride + k];
 #pragma unroll
                     for (int i = 0; i < AB_RT; i++) {
-                        double x = (a[i].had ? ph : pe) * a[i].cL, y = pr * a[i].cR;
-                        double amp = a[i].pref2 * f / ((1 + x) * (1 + y));
-                        double t = below ? ub[wv][i][0] : (above ? ub[wv][i][st.n_fc - 1] : ub_slope[wv][i][lo] * dx + ub[wv][i][lo]);
-                        part[i] += amp * t;
+                        double x = (had[i] ? ph : pe) * cL[i], y = pr * cR[i];
+                        double amp = pf[i] * f / ((1 + x) * (1 + y));
+                        part[i] += amp * (ub_slope[wv][i][lo] * dx + ub[wv][i][lo]);
                     }
                 } else {
                     for (int i = 0; i < AB_RT; i++)
-                        part[i] += amplitude_bin(k, f, a[i], st) * interp_seg(f, lo, st.n_fc, s_xp, ub[wv][i], ub_slope[wv][i]);
+                        part[i] += amplitude_bin(k, f, w.ask[min(rb + i, n_rays - 1)], st) *
+                                   (ub_slope[wv][i][lo] * dx + ub[wv][i][lo]);
                 }
             }
             for (int i = 0; i < AB_RT; i++) {
@@ -794,7 +800,7 @@ __global__ void scatter_active_class_kernel(int n_rays, const int* __restrict__ 
 // kernel: with attenuation known, the sum-of-magnitudes bound on max |E(t)| and the L2 norm of the unit-polarisation
 // pulse of every active ray (one wave per AB_RT rays, frequency-grid tables loaded once per AB_RT rays).  Rays whose bound
 // stays below the cut report the negated bound; the others are flagged for the time-domain transform.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w, StationDev st, double min_efield,
                     int exact, double* __restrict__ max_efield, int* __restrict__ need_fft)
 {
@@ -819,32 +825,35 @@ efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w
                 at_slope[wv][i][lane] = (at[wv][i][lane + 1] - at[wv][i][lane]) / (s_xp[lane + 1] - s_xp[lane]);
         __syncthreads();
         if (ib < n_active) {
-            AskaryanConst a[AB_RT];
+            double cL[AB_RT], cR[AB_RT], pf[AB_RT];
+            int had[AB_RT];
             bool all2009 = true;
             for (int i = 0; i < AB_RT; i++) {
-                a[i] = w.ask[rr[i]];
-                all2009 = all2009 && (a[i].model == 0);
+                const AskaryanConst& ai = w.ask[rr[i]];
+                all2009 = all2009 && (ai.model == 0);
+                cL[i] = ai.cL; cR[i] = ai.cR; pf[i] = ai.pref2; had[i] = ai.had;
             }
             double part[AB_RT], sq[AB_RT];
             for (int i = 0; i < AB_RT; i++) part[i] = sq[i] = 0.;
+            const double x_first = s_xp[0], x_last = s_xp[st.n_fc - 1], dx_last = x_last - s_xp[st.n_fc - 2];
             for (int k = 1 + lane; k < nh; k += 64) {
                 const double f = k * df;
-                const int lo = st.seg[k];
-                const bool below = f <= s_xp[0], above = f >= s_xp[st.n_fc - 1];
-                const double dx = f - s_xp[lo];
+                int lo = st.seg[k];
+                double dx = f - s_xp[lo];
+                if (f <= x_first) { lo = 0; dx = 0.; }
+                if (f >= x_last) { lo = st.n_fc - 2; dx = dx_last; }
                 double ph = 0., pe = 0., pr = 0.;
                 if (all2009) { ph = st.fpow[k]; pe = st.fpow[stride + k]; pr = st.fpow[2 * stride + k]; }
 #pragma unroll
                 for (int i = 0; i < AB_RT; i++) {
                     double amp;
                     if (all2009) {
-                        double x = (a[i].had ? ph : pe) * a[i].cL, y = pr * a[i].cR;
-                        amp = a[i].pref2 * f / ((1 + x) * (1 + y));
+                        double x = (had[i] ? ph : pe) * cL[i], y = pr * cR[i];
+                        amp = pf[i] * f / ((1 + x) * (1 + y));
                     } else {
-                        amp = askaryan_amplitude(f, st.lnf[k], a[i]);
+                        amp = askaryan_amplitude(f, st.lnf[k], w.ask[rr[i]]);
                     }
-                    double t = below ? at[wv][i][0] : (above ? at[wv][i][st.n_fc - 1] : at_slope[wv][i][lo] * dx + at[wv][i][lo]);
-                    double v = amp * t;
+                    double v = amp * (at_slope[wv][i][lo] * dx + at[wv][i][lo]);
                     part[i] += v;
                     sq[i] += v * v;
                 }
@@ -1311,11 +1320,15 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       if (coinc)
           for (int n = threadIdx.x; n < ev_L; n += blockDim.x) cnt[n] = 0;
       __syncthreads();
+      // has an earlier channel of this event triggered?  A per-thread copy, refreshed between two barriers after every
+      // evaluated channel: the shared flag itself may already have been reset for the NEXT event by a wave that ran ahead
+      // through the barrier-free skip path below
+      bool ev_trig = false;
       for (int ch = 0; ch < st.n_ch; ch++) {
         const int item = item_list[le] * st.n_ch + ch;
         if (!need[item]) continue;
         const int e = item_event[item / st.n_ch];
-        if (!exact && !coinc && s_ev_trig) {
+        if (!exact && !coinc && ev_trig) {
             if (threadIdx.x == 0) out.maxV[item] = NAN;
             continue;
         }
@@ -1474,6 +1487,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             out.maxV[item] = vm;
             if (s_trig) { out.triggered[e] = 1; s_ev_trig = 1; }
         }
+        __syncthreads();
+        ev_trig = (s_ev_trig != 0);
         __syncthreads();
       }
       if (coinc) {  // majority logic over the channels of the event

@@ -437,3 +437,20 @@ def test_filter_kinds(gpu_ctx_factory):
                 it = pos[e] * 5 + ch
                 assert np.max(np.abs(tr[off[it]:off[it + 1]] - o['V'][ch])) <= 1e-6 * scale, (e, ch)
     assert n_cand >= 8
+
+
+def test_production_mode_is_deterministic(gpu_ctx_factory):
+    """Repeated production-mode calls on 2e5 survey events give one and the same trigger mask, equal to the exhaustive
+    mode's (regression: the per-event early exit once let a wave that ran ahead reset the block's "event has triggered"
+    flag while slower waves still had to read it)."""
+    import bench
+    ctx = gpu_ctx_factory(bench.ICE, 'SP1')
+    st = nuradiomc_amd.Station(ctx, bench.CHANNELS, n_samples=4096, sampling_rate=2.0)
+    n = 200000
+    v, z, a = bench.make_events(n, 10)
+    args = (v, z, a, np.full(n, bench.ENERGY), 'HAD')
+    ref, _ = st.simulate_events(*args, no_pruning=True)
+    assert ref.sum() > 1000
+    for _ in range(12):
+        trig, stats = st.simulate_events(*args)
+        assert np.array_equal(trig, ref)
