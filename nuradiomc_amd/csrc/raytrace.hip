@@ -193,11 +193,15 @@ __device__ inline bool np_sign_differs(double a, double b)
 // Kernel: pair i = (event i / n_ch, channel i % n_ch) when n_ch > 0, else x2 is per pair.
 __global__ void __launch_bounds__(256, 6)
 raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
-                IceConst m, RayRecords out, const double* __restrict__ max_dist)
+                IceConst m, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm)
 {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_pairs; i += (long)gridDim.x * blockDim.x) {
-        long i1 = (n_ch > 0) ? i / n_ch : i;
-        long i2 = (n_ch > 0) ? i % n_ch : i;
+    for (long iw = blockIdx.x * (long)blockDim.x + threadIdx.x; iw < n_pairs; iw += (long)gridDim.x * blockDim.x) {
+        // perm (optional): events in an order that puts similar geometries (distance, depth) next to each other, so that
+        // the lanes of a wave run similar numbers of root-finder iterations; results land at the original pair index
+        long i1 = (n_ch > 0) ? iw / n_ch : iw;
+        long i2 = (n_ch > 0) ? iw % n_ch : iw;
+        if (perm) i1 = perm[i1];
+        const long i = (n_ch > 0) ? i1 * n_ch + i2 : iw;
         double A[3] = {x1[3 * i1], x1[3 * i1 + 1], x1[3 * i1 + 2]};
         double B[3] = {x2[3 * i2], x2[3 * i2 + 1], x2[3 * i2 + 2]};
         // set_start_and_end_point (:2057-2090): the higher point becomes the stop point
@@ -295,14 +299,48 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
     }
 }
 
+// geometry cell of an event: 64 x 64 cells in (horizontal distance to the station's first antenna, vertex depth)
+#define NRHIP_GEO_CELLS 4096
+__global__ void __launch_bounds__(256)
+event_cell_kernel(int n_events, const double* __restrict__ vertex, const double* __restrict__ x2, int* __restrict__ cell,
+                  int* __restrict__ hist)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_events) return;
+    double dx = vertex[3 * (long)e] - x2[0], dy = vertex[3 * (long)e + 1] - x2[1];
+    int cr = (int)(sqrt(dx * dx + dy * dy) * (64. / 5000.)), cz = (int)(-vertex[3 * (long)e + 2] * (64. / 3000.));
+    cr = cr < 0 ? 0 : (cr > 63 ? 63 : cr);
+    cz = cz < 0 ? 0 : (cz > 63 ? 63 : cz);
+    int c = cz * 64 + cr;
+    cell[e] = c;
+    atomicAdd(&hist[c], 1);
+}
+
+__global__ void __launch_bounds__(256)
+event_perm_kernel(int n_events, const int* __restrict__ cell, int* __restrict__ cursor, int* __restrict__ perm)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_events) return;
+    perm[atomicAdd(&cursor[cell[e]], 1)] = e;  // order inside a cell is irrelevant: outputs go to the original index
+}
+
+void launch_event_cells(hipStream_t stream, int n_events, const double* vertex, const double* x2, int* cell, int* hist)
+{
+    hipLaunchKernelGGL(event_cell_kernel, dim3((n_events + 255) / 256), dim3(256), 0, stream, n_events, vertex, x2, cell, hist);
+}
+void launch_event_perm(hipStream_t stream, int n_events, const int* cell, int* cursor, int* perm)
+{
+    hipLaunchKernelGGL(event_perm_kernel, dim3((n_events + 255) / 256), dim3(256), 0, stream, n_events, cell, cursor, perm);
+}
+
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
-                     const IceConst& m, const RayRecords& out, const double* max_dist)
+                     const IceConst& m, const RayRecords& out, const double* max_dist, const int* perm)
 {
     if (n_pairs <= 0) return;
     int block = 256;
     long grid = (n_pairs + block - 1) / block;
     if (grid > 256L * 64) grid = 256L * 64;
-    hipLaunchKernelGGL(raytrace_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist);
+    hipLaunchKernelGGL(raytrace_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm);
 }
 
 }  // namespace nrhip
