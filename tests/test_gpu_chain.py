@@ -454,3 +454,58 @@ def test_production_mode_is_deterministic(gpu_ctx_factory):
     for _ in range(12):
         trig, stats = st.simulate_events(*args)
         assert np.array_equal(trig, ref)
+
+
+def test_rnog_like_station_24_channels(gpu_ctx_factory):
+    """A 24-channel station in the shape of RNO-G (BASELINE configs 3-5: deep VPol / HPol strings plus shallow LPDAs in
+    several orientations, unequal cable delays, Greenland ice with GL1 attenuation, 2-fold high/low coincidence):
+    decisions and channel traces vs the oracle."""
+    ice = (1.78, 0.51, 37.25)  # greenland_simple (medium.py:145)
+    d = np.pi / 180
+    pos, ant, ori = [], [], []
+    for i, z in enumerate([-95., -96., -97., -98., -80., -60., -40.]):           # power string: 4 VPol + 3 more VPol
+        pos.append([0., 0., z]); ant.append('analytic_VPol'); ori.append([0., 0., 90 * d, 90 * d])
+    for z in (-94., -79.):                                                           # two HPols on the power string
+        pos.append([0., 0., z]); ant.append('analytic_HPol'); ori.append([0., 0., 90 * d, 90 * d])
+    for x, y in ((-20., 30.), (25., 28.)):                                           # two helper strings
+        for z in (-95., -94., -93.):
+            pos.append([x, y, z]); ant.append('analytic_VPol' if z != -94. else 'analytic_HPol'); ori.append([0., 0., 90 * d, 90 * d])
+    for k in range(9):                                                               # 9 shallow LPDAs: 3 up, 6 tilted down
+        a = 2 * np.pi * k / 9
+        pos.append([12 * np.cos(a), 12 * np.sin(a), -3.])
+        ant.append('analytic_LPDA')
+        ori.append([0., 0., 90 * d, (90 + 40 * k) * d] if k % 3 == 0 else [120 * d, a, 90 * d, a + 90 * d])
+    pos, ori = np.array(pos), np.array(ori)
+    assert len(pos) == 24
+    cable = np.linspace(0., 37.3, 24)
+    ctx = gpu_ctx_factory(ice, 'GL1')
+    st = nuradiomc_amd.Station(ctx, pos, antenna=ant, orientation=ori, cable_delay=cable, n_samples=512, sampling_rate=2.0)
+    ost = so.Station(pos, antenna=ant, orientation=ori, cable_delay=cable, n_samples=512, fs=2.0)
+    vrms, vrms_e = so.vrms_from_filters(2.0)
+    rng = np.random.default_rng(12)
+    n = 160
+    r, ph = np.sqrt(rng.uniform(0, 1500. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    v = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1500., -10., n)], axis=1)
+    zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    en = 10 ** rng.uniform(16.5, 18., n)
+    opts = dict(trigger='high_low', n_coincidences=2, threshold_high=2.5 * vrms, threshold_low=-2.5 * vrms, coinc_window=60.)
+    trig, stats = st.simulate_events(v, zen, az, en, 'HAD', dump_traces=True, **opts)
+    cand, item_event, tr, off = st.fetch('ev_candidate'), st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    pos_of = {int(e): i for i, e in enumerate(item_event)}
+    n_cand = 0
+    for e in range(n):
+        o = so.simulate_event(v[e], zen[e], az[e], en[e], 'HAD', None, ost, ice, vrms, vrms_e, att_model='GL1')
+        assert o['candidate'] == bool(cand[e]), e
+        if not o['candidate']:
+            continue
+        n_cand += 1
+        scale = np.max(np.abs(o['V']))
+        for ch in range(24):
+            it = pos_of[e] * 24 + ch
+            assert np.max(np.abs(tr[off[it]:off[it + 1]] - o['V'][ch])) <= 1e-6 * scale, (e, ch)
+        t, _ = so.station_trigger(o['V'], 2.0, 'high_low', n_coincidences=2, threshold_high=2.5 * vrms,
+                                  threshold_low=-2.5 * vrms, coinc_window=60.)
+        assert t == bool(trig[e]), e
+    assert n_cand >= 15 and trig.sum() >= 3
+    trig_p, _ = st.simulate_events(v, zen, az, en, 'HAD', **opts)
+    assert np.array_equal(trig, trig_p)

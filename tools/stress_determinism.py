@@ -1,3 +1,7 @@
+"""Repeat the bench workload N times on one GPU and report any call whose trigger mask, candidate count or active-ray
+count deviates from the first call (how the barrier race of the per-event early exit was found):
+    python tools/stress_determinism.py 400
+"""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
