@@ -26,8 +26,16 @@ class Context:
 
     def close(self):
         if getattr(self, '_h', None):
+            for st in list(getattr(self, '_stations', ())):  # stations hold the context: destroy them first
+                st.close()
             self._lib.nrhip_ctx_destroy(self._h)
             self._h = None
+
+    def _register_station(self, station):
+        import weakref
+        if not hasattr(self, '_stations'):
+            self._stations = weakref.WeakSet()
+        self._stations.add(station)
 
     def __del__(self):
         try:

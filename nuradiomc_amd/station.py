@@ -172,6 +172,7 @@ class Station:
         h = ctypes.c_void_p()
         L.check(self._lib.nrhip_station_create(ctx._h, ctypes.byref(d), ctypes.byref(h)))
         self._h = h
+        ctx._register_station(self)
         self.vrms, self.vrms_efield = flt.vrms_from_filters(self.sampling_rate, self.filters)
 
     def close(self):

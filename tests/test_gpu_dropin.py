@@ -230,3 +230,14 @@ def test_get_focusing_and_raytracing_output(gpu_ctx_factory):
             assert rt.get_raytracing_output(iS)['focusing_factor'] == f
             n += 1
     assert n > 60
+
+
+def test_context_close_before_station():
+    """closing the context first must not leave the station with a dangling handle (a SIGBUS at interpreter exit once)"""
+    import nuradiomc_amd
+    ctx = nuradiomc_amd.Context((1.78, 0.423, 77.), 'SP1')
+    st = nuradiomc_amd.Station(ctx, np.array([[0., 0., -100.]]), n_samples=256, sampling_rate=2.0)
+    trig, _ = st.simulate_events(np.array([[200., 0., -300.]]), 1.0, 0.3, 1e18, 'HAD')
+    ctx.close()
+    st.close()
+    del st, ctx
