@@ -198,6 +198,7 @@ typedef struct {
 
 typedef struct nrhip_station nrhip_station;
 
+/* A station belongs to its context: destroy every station BEFORE nrhip_ctx_destroy of that context. */
 int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* desc, nrhip_station** out);
 void nrhip_station_destroy(nrhip_station* st);
 
@@ -205,7 +206,9 @@ void nrhip_station_destroy(nrhip_station* st);
  * (NuRadioMC/simulation/simulation.py:1454-1600): for every channel calculate_sim_efield (:93-292: ray
  * tracing, delta_C cut, Askaryan spectrum, polarisation, attenuation, Fresnel, candidate cut), then
  * efieldToVoltageConverter.run (efieldToVoltageConverter.py:111-345) on the event's common time grid, the
- * filter chain and a simple threshold trigger (trigger/simpleThreshold.py).
+ * filter chain and the trigger selected in cfg (simple threshold, high/low, n-fold coincidence).
+ * Production mode decides candidate / trigger per event and skips whatever a rigorous bound or the OR-logic of the
+ * decision makes unnecessary; cfg->dump_traces / cfg->no_pruning evaluate everything.
  * Event inputs are DEV pointers (resident in HBM): vertex [n][3], zenith / azimuth of the shower axis,
  * shower energy, shower_type (int32), k_L.  triggered is a DEV uint8 [n] mask.  stats is HOST (may be NULL). */
 int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_config* cfg, int64_t n_events,
@@ -232,7 +235,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
 /* Copy one intermediate table of the LAST nrhip_simulate_events call to HOST memory (parity tests,
  * output writers).  Names: ray_event ray_channel ray_solution ray_view ray_pol_theta ray_pol_phi ray_zenith
  * ray_azimuth ray_t0 ray_r_theta ray_r_phi ray_att ray_max_efield ray_C0 ray_D (int32 / double / complex);
- * ev_n_rays ev_L ev_candidate ev_t_min; item_event item_maxV trace_offset trace.
+ * ev_n_rays ev_L ev_candidate ev_t_min ev_trigger_bin; item_event item_maxV trace_offset trace;
+ * ray_max_amp_envelope ray_signal_time (cfg->amp_per_ray).  ray_max_efield: > 0 exact, < 0 "at most" (not evaluated);
+ * item_maxV: >= 0 exact, < 0 "at most", NaN not evaluated because an earlier channel of the event had triggered.
  * Returns the number of bytes available (>= 0) or < 0; copies min(bytes, available).                     */
 int64_t nrhip_sim_fetch(nrhip_station* st, const char* name, void* host_dst, uint64_t bytes);
 
