@@ -84,6 +84,13 @@ int nrhip_find_solutions_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1
                                double* D, double* T, double* launch, double* receive,
                                double* refl_angle);
 
+/* ray_tracing.set_solution (analyticraytracing.py:2092-2116): the same tables from launch parameters that were found
+ * earlier and stored (ray_tracing_C0 of the reference's output files): C0_in [n_pairs][NRHIP_MAX_SOLUTIONS], NaN = no
+ * solution in that slot; no root finding.  All pointers HOST.                                              */
+int nrhip_ray_records_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const double* x2, int32_t n_x2,
+                            const double* C0_in, int32_t* n_sol, int32_t* type, double* C0, double* C1, double* D,
+                            double* T, double* launch, double* receive, double* refl_angle);
+
 /* Batched ray_tracing.get_attenuation on an explicit frequency list
  * (analyticraytracing.py:2744 -> get_attenuation_along_path :933-1089, Python branch), replacing the
  * per-frequency wrapper.pyx get_attenuation_along_path (:30-31).

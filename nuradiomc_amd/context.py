@@ -101,11 +101,12 @@ class Context:
         return out
 
     # ---- ray tracing -----------------------------------------------------------------------------
-    def find_solutions_batch(self, x1, x2, outer=False):
+    def find_solutions_batch(self, x1, x2, outer=False, given_C0=None):
         """All ray solutions between x1[i] and x2[i] (or every x1 with every x2 if `outer`).
 
         Returns a dict of [n_pairs, 2(,3)] arrays: n_sol, type, C0, C1, D (path length), T (travel time),
         launch, receive, refl_angle -- NaN / 0 padded like the reference's HDF5 station tables.
+        given_C0 [n_pairs, 2] (NaN = none): no root finding, the tables of these launch parameters (set_solution).
         """
         x1 = L.f64(x1).reshape(-1, 3)
         x2 = L.f64(x2).reshape(-1, 3)
@@ -122,10 +123,13 @@ class Context:
             o[k] = np.full((n, MAXS), np.nan)
         for k in ('launch', 'receive'):
             o[k] = np.full((n, MAXS, 3), np.nan)
-        L.check(self._lib.nrhip_find_solutions_batch(
-            self._h, n, L.dptr(x1), L.dptr(x2), n_x2, L.iptr(o['n_sol']), L.iptr(o['type']), L.dptr(o['C0']),
-            L.dptr(o['C1']), L.dptr(o['D']), L.dptr(o['T']), L.dptr(o['launch']), L.dptr(o['receive']),
-            L.dptr(o['refl_angle'])))
+        outs = (L.iptr(o['n_sol']), L.iptr(o['type']), L.dptr(o['C0']), L.dptr(o['C1']), L.dptr(o['D']), L.dptr(o['T']),
+                L.dptr(o['launch']), L.dptr(o['receive']), L.dptr(o['refl_angle']))
+        if given_C0 is None:
+            L.check(self._lib.nrhip_find_solutions_batch(self._h, n, L.dptr(x1), L.dptr(x2), n_x2, *outs))
+        else:
+            g = np.ascontiguousarray(np.broadcast_to(L.f64(given_C0).reshape(-1, MAXS), (n, MAXS)))
+            L.check(self._lib.nrhip_ray_records_batch(self._h, n, L.dptr(x1), L.dptr(x2), n_x2, L.dptr(g), *outs))
         return o
 
     def attenuation_batch(self, x1, x2, C0, freqs, return_neval=False):

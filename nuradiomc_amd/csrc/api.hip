@@ -117,9 +117,28 @@ int nrhip_memcpy_d2h(nrhip_ctx* ctx, void* host_dst, const void* dev_src, uint64
     return 0;
 }
 
+static int ray_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const double* x2, int32_t n_x2, const double* C0_in,
+                     int32_t* n_sol, int32_t* type, double* C0, double* C1, double* D, double* T, double* launch,
+                     double* receive, double* refl_angle);
+
 int nrhip_find_solutions_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const double* x2, int32_t n_x2,
                                int32_t* n_sol, int32_t* type, double* C0, double* C1, double* D, double* T,
                                double* launch, double* receive, double* refl_angle)
+{
+    return ray_batch(ctx, n_pairs, x1, x2, n_x2, nullptr, n_sol, type, C0, C1, D, T, launch, receive, refl_angle);
+}
+
+int nrhip_ray_records_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const double* x2, int32_t n_x2,
+                            const double* C0_in, int32_t* n_sol, int32_t* type, double* C0, double* C1, double* D,
+                            double* T, double* launch, double* receive, double* refl_angle)
+{
+    if (!C0_in) return fail_msg("nrhip_ray_records_batch: C0_in is NULL");
+    return ray_batch(ctx, n_pairs, x1, x2, n_x2, C0_in, n_sol, type, C0, C1, D, T, launch, receive, refl_angle);
+}
+
+static int ray_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const double* x2, int32_t n_x2, const double* C0_in,
+                     int32_t* n_sol, int32_t* type, double* C0, double* C1, double* D, double* T, double* launch,
+                     double* receive, double* refl_angle)
 {
     if (!ctx) return fail_msg("nrhip_find_solutions_batch: ctx is NULL");
     if (n_pairs < 0 || n_x2 < 0) return fail_msg("nrhip_find_solutions_batch: negative size");
@@ -144,7 +163,13 @@ int nrhip_find_solutions_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1
     HIPCHK(hipMemcpyAsync(dx2.p, x2, n2 * 24, hipMemcpyHostToDevice, ctx->stream));
     nrhip::RayRecords r{dns.as<int>(), dty.as<int>(), dC0.as<double>(), dC1.as<double>(), dD.as<double>(),
                         dT.as<double>(), dla.as<double>(), dre.as<double>(), dra.as<double>()};
-    nrhip::launch_raytrace(ctx->stream, n_pairs, dx1.as<double>(), dx2.as<double>(), n_x2, ctx->ice, r);
+    DevBuf dgiven;
+    if (C0_in) {
+        HIPCHK(dgiven.alloc(n_pairs * S * 8));
+        HIPCHK(hipMemcpyAsync(dgiven.p, C0_in, n_pairs * S * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    nrhip::launch_raytrace(ctx->stream, n_pairs, dx1.as<double>(), dx2.as<double>(), n_x2, ctx->ice, r, nullptr, nullptr,
+                           C0_in ? dgiven.as<double>() : nullptr);
     HIPCHK(hipGetLastError());
 #define D2H(dst, src, bytes) if (dst) HIPCHK(hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToHost, ctx->stream))
     D2H(n_sol, dns, n_pairs * 4);

@@ -24,7 +24,7 @@ struct RayRecords {
 
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
                      const IceConst& m, const RayRecords& out, const double* max_dist = nullptr,
-                     const int* perm = nullptr);
+                     const int* perm = nullptr, const double* given_C0 = nullptr);
 void launch_event_cells(hipStream_t stream, int n_events, const double* vertex, const double* x2, int* cell, int* hist);
 void launch_event_perm(hipStream_t stream, int n_events, const int* cell, int* cursor, int* perm);
 

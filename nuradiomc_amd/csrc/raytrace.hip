@@ -193,7 +193,8 @@ __device__ inline bool np_sign_differs(double a, double b)
 // Kernel: pair i = (event i / n_ch, channel i % n_ch) when n_ch > 0, else x2 is per pair.
 __global__ void __launch_bounds__(256, 6)
 raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
-                IceConst m, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm)
+                IceConst m, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm,
+                const double* __restrict__ given_C0)
 {
     for (long iw = blockIdx.x * (long)blockDim.x + threadIdx.x; iw < n_pairs; iw += (long)gridDim.x * blockDim.x) {
         // perm (optional): events in an order that puts similar geometries (distance, depth) next to each other, so that
@@ -229,7 +230,7 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
         double lc[3];
         // speedup.distance_cut (simulation.py:155-163): showers farther from the antenna than their cut are not traced
         const bool too_far = max_dist && sqrt(dX[0] * dX[0] + dX[1] * dX[1] + dX[2] * dX[2]) > max_dist[i1];
-        if (!(p.z2 > 0) && !too_far) {  // receiver in air: special branch of the reference (:1437-1460) not provided
+        if (!(p.z2 > 0) && !too_far && !given_C0) {  // receiver in air: special branch of the reference (:1437-1460) not provided
             auto dy = [&](double l) { return delta_y(l, p, m); };
             auto dy2 = [&](double l) { double d = delta_y(l, p, m); return d * d; };
             double fun;
@@ -248,6 +249,13 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
         }
         double c0[3];
         for (int k = 0; k < ns; k++) c0[k] = det_exp(lc[k]) + m.inv_n;
+        if (given_C0) {  // ray_tracing.set_solution (:2092): launch parameters read back from a file, no root finding
+            ns = 0;
+            for (int k = 0; k < NRHIP_MAXS; k++) {
+                double v = given_C0[i * NRHIP_MAXS + k];
+                if (!isnan(v)) c0[ns++] = v;
+            }
+        }
         // sorted by C0 (insertion sort, <= 3 entries)
         for (int a = 1; a < ns; a++)
             for (int b = a; b > 0 && c0[b] < c0[b - 1]; b--) { double t = c0[b]; c0[b] = c0[b - 1]; c0[b - 1] = t; }
@@ -334,13 +342,13 @@ void launch_event_perm(hipStream_t stream, int n_events, const int* cell, int* c
 }
 
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
-                     const IceConst& m, const RayRecords& out, const double* max_dist, const int* perm)
+                     const IceConst& m, const RayRecords& out, const double* max_dist, const int* perm, const double* given_C0)
 {
     if (n_pairs <= 0) return;
     int block = 256;
     long grid = (n_pairs + block - 1) / block;
     if (grid > 256L * 64) grid = 256L * 64;
-    hipLaunchKernelGGL(raytrace_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm);
+    hipLaunchKernelGGL(raytrace_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, given_C0);
 }
 
 }  // namespace nrhip

@@ -108,7 +108,24 @@ class ray_tracing:
             getattr(self, function_name)(*args, **kwargs)
 
     def set_solution(self, raytracing_results):
-        raise NotImplementedError("set_solution is not provided (re-run find_solutions)")
+        """analyticraytracing.py:2092-2116: launch parameters read back from an output file instead of a new root search;
+        the per-solution tables (vectors, path length, travel time, ...) are rebuilt on the GPU from those C0."""
+        C0s = np.asarray(raytracing_results['ray_tracing_C0'], float).reshape(-1)
+        given = np.full(2, np.nan)
+        keep = C0s[~np.isnan(C0s)][:2]
+        given[:len(keep)] = keep
+        t = self._ctx.find_solutions_batch(self._X1[None], self._X2[None], given_C0=given[None])
+        self._tab = {k: v[0] for k, v in t.items()}
+        results = []
+        j = 0
+        for i in range(len(C0s)):
+            if not np.isnan(C0s[i]):
+                refl = raytracing_results['ray_tracing_reflection'][i] if 'ray_tracing_reflection' in raytracing_results else 0
+                case = raytracing_results['ray_tracing_reflection_case'][i] if 'ray_tracing_reflection' in raytracing_results else 0
+                results.append({'type': raytracing_results['ray_tracing_solution_type'][i], 'C0': C0s[i],
+                                'C1': raytracing_results['ray_tracing_C1'][i], 'reflection': refl, 'reflection_case': case})
+                j += 1
+        self._results = results[:2]
 
     def find_solutions(self):
         if self._X2[2] > 0 or self._X1[2] > 0:

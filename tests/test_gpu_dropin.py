@@ -241,3 +241,38 @@ def test_context_close_before_station():
     ctx.close()
     st.close()
     del st, ctx
+
+
+def test_set_solution_roundtrip(gpu_ctx_factory):
+    """ray_tracing.set_solution (analyticraytracing.py:2092): the tables rebuilt from stored launch parameters equal the
+    ones find_solutions produced, bit for bit (the order of the stored solutions is kept)."""
+    from nuradiomc_amd import propagation
+
+    class Ice:
+        n_ice, delta_n, z_0 = 1.78, 0.423, 77.
+    rt = propagation.ray_tracing(Ice(), attenuation_model='SP1')
+    rng = np.random.default_rng(4)
+    n = 0
+    for _ in range(60):
+        x1 = np.array([rng.uniform(-1500, 1500), rng.uniform(-1500, 1500), rng.uniform(-2000, -20)])
+        x2 = np.array([0., 0., rng.choice([-5., -100., -300.])])
+        rt.set_start_and_end_point(x1, x2)
+        rt.find_solutions()
+        ns = rt.get_number_of_solutions()
+        if ns == 0:
+            continue
+        ref = [(rt.get_solution_type(i), rt.get_launch_vector(i), rt.get_receive_vector(i), rt.get_path_length(i),
+                rt.get_travel_time(i), rt.get_reflection_angle(i)) for i in range(ns)]
+        stored = {k: np.array([rt.get_raytracing_output(i)[k] for i in range(ns)] + [np.nan] * (2 - ns)) for k in
+                  ('ray_tracing_C0', 'ray_tracing_C1', 'ray_tracing_reflection', 'ray_tracing_reflection_case',
+                   'ray_tracing_solution_type')}
+        rt.set_start_and_end_point(x1, x2)
+        rt.set_solution(stored)
+        assert rt.get_number_of_solutions() == ns
+        for i in range(ns):
+            got = (rt.get_solution_type(i), rt.get_launch_vector(i), rt.get_receive_vector(i), rt.get_path_length(i),
+                   rt.get_travel_time(i), rt.get_reflection_angle(i))
+            assert got[0] == ref[i][0] and np.array_equal(got[1], ref[i][1]) and np.array_equal(got[2], ref[i][2])
+            assert got[3] == ref[i][3] and got[4] == ref[i][4] and got[5] == ref[i][5]
+            n += 1
+    assert n > 40
