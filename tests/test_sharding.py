@@ -43,3 +43,28 @@ def test_gather_triggered_world2_gloo():
     for p in procs:
         p.join(60)
     assert res == {0: True, 1: True}
+
+
+def test_distance_cut_host_logic():
+    """nuradiomc_amd.station.distance_cut (host side of speedup.distance_cut) against the reference-generated fixture's
+    inputs: per shower max(100 m, 10 ** poly(log10(E_sum))) with the energy sum over showers of the same group whose
+    distance to the group's first vertex differs by < 10 m (simulation.py:125-131, :155-163, :1398-1409)."""
+    import numpy as np
+    from conftest import golden
+    from nuradiomc_amd.station import distance_cut
+    g = golden('chain_groups_dcut_N256.npz')
+    gid = g['group']
+    first = np.flatnonzero(np.concatenate([[True], gid[1:] != gid[:-1]]))
+    gb = np.concatenate([first, [len(gid)]]).astype(np.int32)
+    coef = g['distance_cut_coefficients']
+    got = distance_cut(g['vertex'], g['energy'], gb, coef, 10.)
+    poly = np.polynomial.polynomial.Polynomial(coef)
+    for a, b in zip(gb[:-1], gb[1:]):
+        d = np.linalg.norm(g['vertex'][a:b] - g['vertex'][a], axis=1)
+        for i in range(a, b):
+            e_sum = g['energy'][a:b][np.abs(d - d[i - a]) < 10.].sum()
+            assert abs(got[i] - max(100., 10 ** poly(np.log10(e_sum)))) <= 4e-16 * got[i]  # vector vs scalar pow: 1 ulp
+    # no groups: every shower on its own
+    single = distance_cut(g['vertex'], g['energy'], None, coef)
+    assert np.allclose(single, np.maximum(100., 10 ** poly(np.log10(g['energy']))), rtol=4e-16, atol=0)
+    assert distance_cut(np.zeros((1, 3)), [0.], None, coef)[0] == 100.
