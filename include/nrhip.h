@@ -29,11 +29,12 @@ extern "C" {
 
 #define NRHIP_MAX_SOLUTIONS 2 /* 2 + 4 * n_reflections, n_reflections = 0 (propagation_base_class.py:424-429) */
 
-/* attenuation model ids: NuRadioMC/utilities/attenuation.py:14 (SP1 1, GL1 2, MB1 3, GL2 4) */
+/* attenuation model ids: NuRadioMC/utilities/attenuation.py:14 (SP1 1, GL1 2, MB1 3, GL2 4, GL3 5) */
 #define NRHIP_ATT_SP1 1
 #define NRHIP_ATT_GL1 2
 #define NRHIP_ATT_MB1 3
 #define NRHIP_ATT_GL2 4
+#define NRHIP_ATT_GL3 5   /* needs nrhip_ctx_set_gl3_table */
 
 /* Askaryan models (NuRadioMC/SignalGen/parametrizations.py:24-26) */
 #define NRHIP_ASK_ALVAREZ2009 0
@@ -58,6 +59,12 @@ typedef struct nrhip_ctx nrhip_ctx;
 int nrhip_ctx_create(int device, double n_ice, double delta_n, double z_0, int attenuation_model,
                      nrhip_ctx** out);
 void nrhip_ctx_destroy(nrhip_ctx* ctx);
+
+/* GL3 (attenuation.py:206-221): L(z, f) = slope(depth) * f + offset(depth) with the depth table of
+ * NuRadioMC/utilities/data/GL3_params.csv (rows: depth [m, positive, increasing], slope, offset; linear interpolation,
+ * end values outside).  Its path integral follows the reference's speed-optimised scheme (analyticraytracing.py:998-1064:
+ * 10 m segment sums, QUADPACK on ds around the turning depth).  HOST pointers.                                        */
+int nrhip_ctx_set_gl3_table(nrhip_ctx* ctx, int32_t n, const double* depth, const double* slope, const double* offset);
 const char* nrhip_last_error(void);
 int nrhip_device_count(void);
 int nrhip_synchronize(nrhip_ctx* ctx);

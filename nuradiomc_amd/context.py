@@ -5,14 +5,16 @@ from . import _lib as L
 from . import station as _station  # noqa: F401  (registers the station entry points)
 
 #: NuRadioMC/utilities/attenuation.py:14
-ATTENUATION_MODEL_TO_INT = {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4}
+ATTENUATION_MODEL_TO_INT = {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4, "GL3": 5}
 MAXS = 2
 
 
 class Context:
     """Owns a `nrhip_ctx`.  `ice` is (n_ice, delta_n, z_0) of n(z) = n_ice - delta_n exp(z / z_0)."""
 
-    def __init__(self, ice, attenuation_model="SP1", device=0):
+    def __init__(self, ice, attenuation_model="SP1", device=0, gl3_table=None):
+        """gl3_table (GL3 only): the depth table of the model, an [n, 3] array (depth, slope, offset) or the path of
+        NuRadioMC/utilities/data/GL3_params.csv (comma separated) -- the model is defined by that file."""
         self._lib = L.load()
         if attenuation_model not in ATTENUATION_MODEL_TO_INT:
             raise NotImplementedError("attenuation model {} is not implemented".format(attenuation_model))
@@ -23,6 +25,12 @@ class Context:
         L.check(self._lib.nrhip_ctx_create(device, *self.ice, ATTENUATION_MODEL_TO_INT[attenuation_model],
                                            ctypes.byref(h)))
         self._h = h
+        if attenuation_model == 'GL3':
+            if gl3_table is None:
+                raise ValueError("attenuation model GL3 needs gl3_table (NuRadioMC/utilities/data/GL3_params.csv)")
+            t = np.genfromtxt(gl3_table, delimiter=',') if isinstance(gl3_table, str) else np.asarray(gl3_table, float)
+            d, sl, of = (np.ascontiguousarray(t[:, k]) for k in range(3))
+            L.check(self._lib.nrhip_ctx_set_gl3_table(h, len(t), L.dptr(d), L.dptr(sl), L.dptr(of)))
 
     def close(self):
         if getattr(self, '_h', None):

@@ -11,8 +11,9 @@ void launch_ray_limits(hipStream_t stream, long n_rays, const double* x1, const 
                        const IceConst& m, double* zint);
 void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
                               const double* freqs, int model, const IceConst& m, double* att, int* neval,
-                              const int* ray_index, unsigned long long* eval_counter);
-void launch_attenuation_length(hipStream_t stream, long n, const double* z, const double* f, int model, double* L);
+                              const int* ray_index, unsigned long long* eval_counter, const double* gl3, int gl3_n);
+void launch_attenuation_length(hipStream_t stream, long n, const double* z, const double* f, int model, double* L,
+                               const double* gl3, int gl3_n);
 }  // namespace nrhip
 
 static thread_local char g_err[512] = "";
@@ -53,8 +54,8 @@ int nrhip_ctx_create(int device, double n_ice, double delta_n, double z_0, int a
     if (!out) return fail_msg("nrhip_ctx_create: out is NULL");
     if (!(n_ice > 1.) || !(delta_n > 0.) || !(z_0 > 0.))
         return fail_msg("nrhip_ctx_create: the analytic ray tracer needs an exponential (non-uniform) ice model");
-    if (attenuation_model < 1 || attenuation_model > 4)
-        return fail_msg("nrhip_ctx_create: attenuation model not implemented (SP1=1, GL1=2, MB1=3, GL2=4)");
+    if (attenuation_model < 1 || attenuation_model > 5)
+        return fail_msg("nrhip_ctx_create: attenuation model not implemented (SP1=1, GL1=2, MB1=3, GL2=4, GL3=5)");
     int n = 0;
     HIPCHK(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail_msg("nrhip_ctx_create: no such GPU");
@@ -78,9 +79,27 @@ void nrhip_ctx_destroy(nrhip_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->gl3) (void)hipFree(ctx->gl3);
     if (ctx->twiddle) (void)hipFree(ctx->twiddle);
     if (ctx->w16) (void)hipFree(ctx->w16);
     delete ctx;
+}
+
+int nrhip_ctx_set_gl3_table(nrhip_ctx* ctx, int32_t n, const double* depth, const double* slope, const double* offset)
+{
+    if (!ctx || !depth || !slope || !offset) return fail_msg("nrhip_ctx_set_gl3_table: NULL argument");
+    if (n < 2 || n > 100000) return fail_msg("nrhip_ctx_set_gl3_table: bad table length");
+    for (int i = 1; i < n; i++)
+        if (!(depth[i] > depth[i - 1])) return fail_msg("nrhip_ctx_set_gl3_table: depths must increase");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->gl3) (void)hipFree(ctx->gl3);
+    ctx->gl3 = nullptr;
+    HIPCHK(hipMalloc((void**)&ctx->gl3, sizeof(double) * 3 * n));
+    HIPCHK(hipMemcpy(ctx->gl3, depth, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->gl3 + n, slope, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->gl3 + 2 * n, offset, sizeof(double) * n, hipMemcpyHostToDevice));
+    ctx->gl3_n = n;
+    return 0;
 }
 
 int nrhip_synchronize(nrhip_ctx* ctx)
@@ -210,7 +229,8 @@ int nrhip_attenuation_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, co
     nrhip::launch_ray_limits(ctx->stream, n_rays, dx1.as<double>(), dx2.as<double>(), dC0.as<double>(), ctx->ice,
                              dz.as<double>());
     nrhip::launch_attenuation_items(ctx->stream, n_rays, dC0.as<double>(), dz.as<double>(), n_freq, df.as<double>(),
-                                    ctx->att_model, ctx->ice, da.as<double>(), dn.as<int>(), nullptr, nullptr);
+                                    ctx->att_model, ctx->ice, da.as<double>(), dn.as<int>(), nullptr, nullptr, ctx->gl3,
+                                    ctx->gl3_n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(att, da.p, n_rays * n_freq * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (neval) HIPCHK(hipMemcpyAsync(neval, dn.p, n_rays * n_freq * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -229,7 +249,8 @@ int nrhip_attenuation_length(nrhip_ctx* ctx, int64_t n, const double* z, const d
     HIPCHK(dl.alloc(n * 8));
     HIPCHK(hipMemcpyAsync(dz.p, z, n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(df.p, freq, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    nrhip::launch_attenuation_length(ctx->stream, n, dz.as<double>(), df.as<double>(), ctx->att_model, dl.as<double>());
+    nrhip::launch_attenuation_length(ctx->stream, n, dz.as<double>(), df.as<double>(), ctx->att_model, dl.as<double>(),
+                                     ctx->gl3, ctx->gl3_n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(L, dl.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -22,7 +22,25 @@ struct AttLane {
     int model;
     double f;   // frequency [GHz]
     double w;   // ln f  (SP1)
+    const double* gl3;  // GL3 depth table: [3][gl3_n] depth (positive), slope, offset (attenuation.py:16-34)
+    int gl3_n;
 };
+
+// linear interpolation of one GL3 table column like scipy.interpolate.interp1d(bounds_error=False, fill_value=(first, last))
+__device__ inline double gl3_interp(double x, const double* __restrict__ d, const double* __restrict__ fp, int n)
+{
+    if (x < d[0]) return fp[0];
+    if (x > d[n - 1]) return fp[n - 1];
+    int lo = 0, hi = n;  // searchsorted(side='left'): first index with d[i] >= x
+    while (lo < hi) {
+        int mid = (lo + hi) / 2;
+        if (d[mid] < x) lo = mid + 1;
+        else hi = mid;
+    }
+    int idx = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    double slope = (fp[idx] - fp[idx - 1]) / (d[idx] - d[idx - 1]);
+    return slope * (x - d[idx - 1]) + fp[idx - 1];
+}
 
 __device__ inline double attenuation_length(double z, const AttLane& a)
 {
@@ -51,6 +69,9 @@ __device__ inline double attenuation_length(double z, const AttLane& a)
         for (int p = 0; p < 6; p++) { att += fit[p] * zp; zp *= z; }
         if (att < 100.) att = 100.;
         L = att - 0.55 * (a.f / 1e-3 - 75);
+    } else if (a.model == 5) {  // GL3 (:206-221): L = slope(depth) f + offset(depth)
+        if (!a.gl3 || a.gl3_n < 2) return NAN;
+        L = gl3_interp(-z, a.gl3, a.gl3 + a.gl3_n, a.gl3_n) * a.f + gl3_interp(-z, a.gl3, a.gl3 + 2 * a.gl3_n, a.gl3_n);
     } else if (a.model == 4) {  // GL2 (:198-204)
         const double fit[6] = {1.20547286e+00, 1.58815679e-05, -2.58901767e-07,
                                -5.16435542e-10, -2.89124473e-13, -4.58987344e-17};
@@ -98,6 +119,7 @@ __device__ inline double sp1_ds_over_length(double ds, double z, double aa, doub
 
 __device__ inline double ds_over_length(double ds, double z, const AttLane& a)
 {
+    if (a.model == 100) return ds;  // path length only (the turning-point segment of the segment-sum integration)
     if (a.model == 1) {
         double p[4];
         sp1_coefficients(z, p);
@@ -500,7 +522,7 @@ struct GroupEval {
 // an evaluation group must call this together (lanes without work pass valid = false).  Returns the integral estimate.
 template <class EV>
 __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool with_point, double point, const AttItem& it,
-                                   const IceConst& m, int* neval_out, const EV& ev)
+                                   const IceConst& m, int* neval_out, const EV& ev, bool qagp_no_point = false)
 {
     const double epmach = 2.220446049250313e-16, uflow = 2.2250738585072014e-308, oflow = 1.7976931348623157e+308;
     const double epsabs = 1.49e-8, epsrel = 1e-2;
@@ -515,7 +537,9 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
         nres = 0, nrmax = 1, numrl2 = 1, levmax = 1, levcur = 0;
     bool extrap = false, noext = false;
     double sign = 1.;
-    const bool qagp = with_point;
+    // qagp_no_point: DQAGPE on one interval (what scipy runs when the requested break point lies outside (a, b))
+    const bool qagp = with_point || qagp_no_point;
+    const int nint = with_point ? 2 : 1;
     bool busy = false;
     int exit_code = 0;  // 1: sum the list (label 190 / 115); 2: final-result logic (label 170 / 100)
     // ---- first estimate(s): (a, b) or (a, point), (point, b) ------------------------------------------------
@@ -524,14 +548,14 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
     g2 = g1;
     {
         double lo = fmin(a, b), hi = fmax(a, b);
-        double a1 = qagp ? lo : a, b1 = qagp ? point : b, a2 = point, b2 = hi;
-        ev.pair(valid, qagp, a1, b1, a2, b2, it, m, g1, g2);
+        double a1 = qagp ? lo : a, b1 = with_point ? point : (qagp ? hi : b), a2 = point, b2 = hi;
+        ev.pair(valid, with_point, a1, b1, a2, b2, it, m, g1, g2);
         if (valid && qagp) {
             if (a > b) sign = -1.;
             const GK gg[3] = {g1, g1, g2};
             const double aa[3] = {0., a1, a2}, bb[3] = {0., b1, b2};
             bool nd[3] = {false, false, false};
-            for (int i = 1; i <= 2; i++) {
+            for (int i = 1; i <= nint; i++) {
                 const GK& g = gg[i];
                 abserr += g.abserr;
                 result += g.result;
@@ -544,16 +568,16 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
                 rlist[i] = g.result;
                 iord[i] = i;
             }
-            for (int i = 1; i <= 2; i++) {
+            for (int i = 1; i <= nint; i++) {
                 if (nd[i]) elist[i] = abserr;
                 errsum += elist[i];
             }
-            last = 2;
-            neval = 42;
+            last = nint;
+            neval = 21 * nint;
             dres = fabs(result);
             errbnd = fmax(epsabs, epsrel * dres);
             if (abserr <= 100. * epmach * resabs && abserr > errbnd) ier = 2;
-            if (!(elist[iord[1]] > elist[iord[2]])) { int t = iord[1]; iord[1] = iord[2]; iord[2] = t; }
+            if (nint == 2 && !(elist[iord[1]] > elist[iord[2]])) { int t = iord[1]; iord[1] = iord[2]; iord[2] = t; }
             if (!(ier != 0 || abserr <= errbnd)) {
                 rlist2[1] = result;
                 maxerr = iord[1];
@@ -565,7 +589,7 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
                 ertest = errbnd;
                 abserr = oflow;
                 ksgn = (dres >= (1. - 50. * epmach) * resabs) ? 1 : -1;
-                last = 3;
+                last = nint + 1;
                 busy = true;
             }
         } else if (valid) {
@@ -769,6 +793,8 @@ attenuation_kernel(long n_rays, const double* __restrict__ C0, const double* __r
         double z1 = zint[3 * ray], z2m = zint[3 * ray + 1];
         it.z_turn = zint[3 * ray + 2];
         it.lane.model = model;
+        it.lane.gl3 = nullptr;
+        it.lane.gl3_n = 0;
         it.lane.f = freqs[jf];
         it.lane.w = det_log(it.lane.f);
         if (isnan(it.C0)) {
@@ -810,6 +836,8 @@ attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const doubl
         double z1 = ray_ok ? zint[3 * ray] : 0., z2m = ray_ok ? zint[3 * ray + 1] : 0.;
         it.z_turn = ray_ok ? zint[3 * ray + 2] : 0.;
         it.lane.model = model;
+        it.lane.gl3 = nullptr;
+        it.lane.gl3_n = 0;
         it.lane.f = (jf < n_freq) ? freqs[jf] : 1.;
         it.lane.w = det_log(it.lane.f);
         bool valid = ray_ok && jf < n_freq && !isnan(it.C0);
@@ -826,6 +854,115 @@ attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const doubl
     if (eval_counter) {  // integrand evaluations QUADPACK would count (for the FP64 rate reported by bench.py)
         for (int off = 32; off > 0; off >>= 1) my_evals += __shfl_xor(my_evals, off);
         if ((threadIdx.x & 63) == 0) atomicAdd(eval_counter, my_evals);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The reference's speed-optimised path integral for the models in speedup_attenuation_models (GL3),
+// analyticraytracing.py:998-1064: the path is cut into ~10 m depth segments (np.linspace), each contributes
+// ds(mid) / L(z(mid), f) * width; the segment around the turning depth (+- 10 m, where ds diverges) is replaced by
+// quad(ds) / L(z_turn, f) -- one QUADPACK run per ray, not per frequency.  32 lanes per ray: lane j evaluates the
+// frequency-independent part of segment c * 32 + j, the lanes (= frequencies) then add the 32 terms in order.
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline int n_steps_of(double a, double b, double dx)
+{
+    int n = (int)floor(fabs(a - b) / dx);
+    return n < 3 ? 3 : n;
+}
+// point i of np.linspace(a, b, n) ([a] if a == b, n = 1)
+__device__ inline double linspace_at(double a, double b, int n, int i)
+{
+    if (n == 1) return a;
+    if (i == n - 1) return b;
+    return i * ((b - a) / (n - 1)) + a;
+}
+
+__global__ void __launch_bounds__(256)
+attenuation_segments_kernel(long n_rays, const double* __restrict__ C0, const double* __restrict__ zint, int n_freq,
+                            const double* __restrict__ freqs, int model, IceConst m, double* __restrict__ att,
+                            int* __restrict__ neval, const int* __restrict__ ray_index, const double* __restrict__ gl3,
+                            int gl3_n)
+{
+    __shared__ double sh[8][32][3];  // per group: ds, width and (un-mirrored) depth of 32 segments
+    const int G = 32, grp = threadIdx.x / G, jf = threadIdx.x & (G - 1);
+    const long groups_per_block = blockDim.x / G;
+    const long n_iter = (n_rays + (long)gridDim.x * groups_per_block - 1) / ((long)gridDim.x * groups_per_block);
+    LaneEval ev;
+    for (long iter = 0; iter < n_iter; iter++) {
+        long g = (iter * gridDim.x + blockIdx.x) * groups_per_block + grp;
+        const bool ray_ok = g < n_rays;
+        long ray = 0;
+        if (ray_ok) ray = ray_index ? ray_index[g] : g;
+        const double c0 = ray_ok ? C0[ray] : NAN;
+        const double z1 = ray_ok ? zint[3 * ray] : 0., z2m = ray_ok ? zint[3 * ray + 1] : 0., zt = ray_ok ? zint[3 * ray + 2] : 0.;
+        const bool valid = ray_ok && !isnan(c0);
+        AttLane lane;
+        lane.model = model;
+        lane.f = (jf < n_freq) ? freqs[jf] : 1.;
+        lane.w = 0.;
+        lane.gl3 = gl3;
+        lane.gl3_n = gl3_n;
+        const double dx = 10., window = 20.;
+        const bool fallback = (z1 - window / 2 < zt && zt < z2m + window / 2);
+        // step list: linspace(z1, w0) ++ linspace(w1, z2m) (fallback) or linspace(z1, z2m)
+        const double w0 = fmax(z1, zt - window / 2), w1 = fmin(zt + window / 2, z2m);
+        const double a0 = z1, b0 = fallback ? w0 : z2m, a1 = w1, b1 = z2m;
+        const int n0 = (a0 == b0) ? 1 : n_steps_of(a0, b0, dx);
+        const int n1 = fallback ? ((a1 == b1) ? 1 : n_steps_of(a1, b1, dx)) : 0;
+        const int n = n0 + n1;
+        auto step_at = [&](int i) { return i < n0 ? linspace_at(a0, b0, n0, i) : linspace_at(a1, b1, n1, i - n0); };
+        int idx = -2;
+        double integrand = 0.;
+        int ne_quad = 0;
+        if (valid && fallback) {
+            int cnt = 0;  // np.digitize(z_turn, steps) - 1
+            for (int i = 0; i < n; i++) cnt += (step_at(i) <= zt) ? 1 : 0;
+            idx = cnt - 1;
+            if (idx == n - 1) idx -= 1;
+            else if (idx == -1) idx = 0;
+            const double lo = step_at(idx), hi = step_at(idx + 1);
+            const bool inside = (fmin(lo, hi) < zt && zt < fmax(lo, hi));
+            AttItem it;
+            it.C0 = c0;
+            it.z_turn = zt;
+            it.lane = lane;
+            it.lane.model = 100;  // ds only
+            integrand = quad_gk21(true, lo, hi, inside, zt, it, m, &ne_quad, ev, !inside);
+        }
+        double sum = 0.;
+        const int n_seg = valid ? n - 1 : 0;
+        for (int c0i = 0; c0i < n_seg; c0i += G) {  // (trip count differs between the groups of a block: no block barriers)
+            const int i = c0i + jf;
+            double dsdx = 0., zu = 0.;
+            if (i < n_seg) {
+                const double s0 = step_at(i), dxa = step_at(i + 1) - s0, mid = s0 + dxa / 2;
+                zu = (mid > zt) ? 2 * zt - mid : mid;
+                const double nz = n_of_z(zu, m);
+                const double q = (c0 * c0) * (nz * nz);
+                const double yd = (q > 1) ? 1 / sqrt(q - 1) : INFINITY;
+                dsdx = sqrt(yd * yd + 1);
+                sh[grp][jf][1] = dxa;
+                sh[grp][jf][2] = zu;
+            }
+            sh[grp][jf][0] = dsdx;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int k = 0; k < G && c0i + k < n_seg; k++) {
+                const double ds_k = sh[grp][k][0], dxa_k = sh[grp][k][1], z_k = sh[grp][k][2];
+                double term;
+                if (c0i + k == idx) term = integrand / attenuation_length(zt, lane);
+                else term = ds_k / attenuation_length(z_k, lane) * dxa_k;
+                sum += term;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (ray_ok && jf < n_freq) {
+            const long item = ray * n_freq + jf;
+            att[item] = valid ? det_exp(-1 * sum) : NAN;
+            if (neval) neval[item] = valid ? n - 1 + ne_quad : 0;
+        }
     }
 }
 
@@ -868,23 +1005,26 @@ ray_limits_kernel(long n_rays, const double* __restrict__ x1, const double* __re
 }
 
 __global__ void attenuation_length_kernel(long n, const double* __restrict__ z, const double* __restrict__ f,
-                                          int model, double* __restrict__ L)
+                                          int model, double* __restrict__ L, const double* __restrict__ gl3, int gl3_n)
 {
     long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= n) return;
     AttLane a;
+    a.gl3 = gl3;
+    a.gl3_n = gl3_n;
     a.model = model;
     a.f = f[i];
     a.w = det_log(a.f);
     L[i] = attenuation_length(z[i], a);
 }
 
-void launch_attenuation_length(hipStream_t stream, long n, const double* z, const double* f, int model, double* L)
+void launch_attenuation_length(hipStream_t stream, long n, const double* z, const double* f, int model, double* L,
+                               const double* gl3, int gl3_n)
 {
     if (n <= 0) return;
     int block = 256;
     long grid = (n + block - 1) / block;
-    hipLaunchKernelGGL(attenuation_length_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n, z, f, model, L);
+    hipLaunchKernelGGL(attenuation_length_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n, z, f, model, L, gl3, gl3_n);
 }
 
 void launch_ray_limits(hipStream_t stream, long n_rays, const double* x1, const double* x2, const double* C0,
@@ -898,11 +1038,18 @@ void launch_ray_limits(hipStream_t stream, long n_rays, const double* x1, const 
 
 void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
                               const double* freqs, int model, const IceConst& m, double* att, int* neval,
-                              const int* ray_index, unsigned long long* eval_counter)
+                              const int* ray_index, unsigned long long* eval_counter, const double* gl3, int gl3_n)
 {
     long n_items = n_rays * n_freq;
     if (n_items <= 0) return;
     int block = 256;
+    if (model == 5) {  // speedup_attenuation_models = ["GL3"]: segment sums (n_freq <= 32 checked by the caller)
+        long grid = (n_rays + 7) / 8;
+        if (grid > 256L * 64) grid = 256L * 64;
+        hipLaunchKernelGGL(attenuation_segments_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, zint, n_freq,
+                           freqs, model, m, att, neval, ray_index, gl3, gl3_n);
+        return;
+    }
     if (n_freq <= 64 && !getenv("NRHIP_ATT_LANES")) {
         int G = (n_freq <= 32) ? 32 : 64;
         long grid = (n_rays + block / G - 1) / (block / G);

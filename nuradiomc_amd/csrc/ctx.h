@@ -12,6 +12,8 @@ struct nrhip_ctx {
     nrhip::IceConst ice;
     int att_model;
     double2* twiddle = nullptr;  // exp(-2 pi i k / FFT_MAX), k < FFT_MAX / 2
+    double* gl3 = nullptr;       // GL3 depth table [3][gl3_n] (depth, slope, offset), nrhip_ctx_set_gl3_table
+    int gl3_n = 0;
     double2* w16 = nullptr;      // exp(-2 pi i k / (2 FFT_MAX)), k <= FFT_MAX / 2 (real <-> packed-complex FFT split)
 };
 

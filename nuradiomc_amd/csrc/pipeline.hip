@@ -407,8 +407,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         // attenuation on the coarse frequency grid, active rays only
         NEED(eval_counter = WS("att_eval_counter", unsigned long long, 1));
         HIPCHK(hipMemsetAsync(eval_counter, 0, sizeof(unsigned long long), sm));
+        if (ctx->att_model == NRHIP_ATT_GL3 && (!ctx->gl3 || sd.n_fc > 32))
+            return nrhip_fail_msg("nrhip_simulate_events: GL3 needs nrhip_ctx_set_gl3_table and at most 32 attenuation frequencies");
         launch_attenuation_items(sm, n_active, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr,
-                                 active_list, eval_counter);
+                                 active_list, eval_counter, ctx->gl3, ctx->gl3_n);
         LCHK("attenuation");
     }
     MARK(4);

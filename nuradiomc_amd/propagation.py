@@ -20,10 +20,15 @@ available_modules = ['analytic']
 _contexts = {}
 
 
-def _context_for(medium, attenuation_model, device=0):
+def _context_for(medium, attenuation_model, device=0, gl3_table=None):
     key = (float(medium.n_ice), float(medium.delta_n), float(medium.z_0), attenuation_model, device)
     if key not in _contexts:
-        _contexts[key] = Context(key[:3], attenuation_model, device=device)
+        if attenuation_model == 'GL3' and gl3_table is None:
+            # the model is defined by a data file of the NuRadioMC installation the drop-in is used in
+            import os
+            import NuRadioMC.utilities.attenuation as _att
+            gl3_table = os.path.join(os.path.dirname(_att.__file__), 'data', 'GL3_params.csv')
+        _contexts[key] = Context(key[:3], attenuation_model, device=device, gl3_table=gl3_table)
     return _contexts[key]
 
 

@@ -503,6 +503,26 @@ static void path_length_and_time(const double x1[2], const double x2[2], double 
  * ---------------------------------------------------------------------------------------- */
 double orc_attenuation_length(double z, double frequency, int model);
 
+/* GL3 depth table (NuRadioMC/utilities/data/GL3_params.csv: depth [m, positive], slope, offset), linear interpolation like
+ * scipy.interpolate.interp1d(bounds_error=False, fill_value=(first, last)) (attenuation.py:16-34) */
+static int gl3_n = 0;
+static double gl3_d[1024], gl3_s[1024], gl3_o[1024];
+void orc_set_gl3_table(int n, const double *depth, const double *slope, const double *offset)
+{
+    gl3_n = n > 1024 ? 1024 : n;
+    for (int i = 0; i < gl3_n; i++) { gl3_d[i] = depth[i]; gl3_s[i] = slope[i]; gl3_o[i] = offset[i]; }
+}
+static double gl3_interp(double x, const double *fp)
+{
+    if (x < gl3_d[0]) return fp[0];
+    if (x > gl3_d[gl3_n - 1]) return fp[gl3_n - 1];
+    int lo = 0, hi = gl3_n; /* searchsorted(side='left'): first index with d[i] >= x */
+    while (lo < hi) { int mid = (lo + hi) / 2; if (gl3_d[mid] < x) lo = mid + 1; else hi = mid; }
+    int idx = lo < 1 ? 1 : (lo > gl3_n - 1 ? gl3_n - 1 : lo);
+    double slope = (fp[idx] - fp[idx - 1]) / (gl3_d[idx] - gl3_d[idx - 1]);
+    return slope * (x - gl3_d[idx - 1]) + fp[idx - 1];
+}
+
 /* SP1 :168-192: the attenuation length is 1 / exp(a + b ln f); this returns the exponent a + b ln f */
 static double sp1_exponent(double z, double frequency)
 {
@@ -580,8 +600,11 @@ double orc_attenuation_length(double z, double frequency, int model)
         double d = -z * 420. / d_ice;
         double LL = (1250. * 0.08886 * orc_exp(-0.048827 * (225.6746 - 86.517596 * (orc_log(848.870 - (d)) / 2.302585092994046))));
         L *= LL / 231.21;
+    } else if (model == 5) { /* GL3 :206-221: L = slope(depth) f + offset(depth), depth table set by orc_set_gl3_table */
+        if (gl3_n < 2) return NAN;
+        L = gl3_interp(-z, gl3_s) * frequency + gl3_interp(-z, gl3_o);
     } else {
-        return NAN; /* GL3 needs data/GL3_params.csv: not restated */
+        return NAN;
     }
     if (L < 1.) L = 1.;
     if (z > 0) L = INFINITY;
@@ -797,7 +820,8 @@ L100:
 }
 
 #define QLIMIT 50
-/* DQAGSE when npts == 0, DQAGPE when npts == 1 (one interior break point), as scipy.integrate.quad
+/* DQAGSE when npts == 0, DQAGPE when npts == 1 (one interior break point) or npts == 2 (flag: DQAGPE, no interior
+ * point), as scipy.integrate.quad
  * dispatches (points=None -> _qagse ; points=[p] -> _qagpe).  limit = 50, epsabs = 1.49e-8. */
 int orc_quad(integrand_t f, void *p, double a, double b, int npts, double point, double epsabs,
              double epsrel, double *result_out, double *abserr_out, int *neval_out, int *last_out)
@@ -814,12 +838,14 @@ int orc_quad(integrand_t f, void *p, double a, double b, int npts, double point,
         nres = 0, nrmax, numrl2, extrap = 0, noext = 0, levmax = 1, levcur = 0, id, jupbnd;
     double sign = 1.;
     int qagp = (npts > 0);
+    if (npts == 2) npts = 0; /* DQAGPE without an interior break point: what scipy runs when points=[p] lies outside (a, b) */
     int npts2 = npts + 2, nint = npts + 1;
     result = 0.; abserr = 0.;
     if (qagp) {
         double pts[3];
         if (a > b) sign = -1.;
         pts[0] = fmin(a, b); pts[1] = point; pts[2] = fmax(a, b);
+        if (npts == 0) pts[1] = pts[2];
         resabs = 0.;
         a1 = pts[0];
         for (int i = 1; i <= nint; i++) {
@@ -1083,6 +1109,73 @@ static double att_integrand(double t, void *p) /* dt() :986-988 with ds() :513-5
     return ds_over_length(ds, z, a->f, a->model);
 }
 
+static double ds_only(double t, void *p) /* ds() :513-517 */
+{
+    att_t *a = (att_t *)p;
+    a->nev++;
+    double yd = get_y_diff(t, a->C0, a->m);
+    return sqrt(yd * yd + 1);
+}
+
+/* np.linspace(a, b, max(int(|a - b| // dx), 3)) or [a] (get_equidistant_steps :56-76); returns the number of points */
+static int equidistant_steps(double a, double b, double dx, double *out)
+{
+    if (a == b) { out[0] = a; return 1; }
+    int n = (int)floor(fabs(a - b) / dx);
+    if (n < 3) n = 3;
+    double step = (b - a) / (n - 1);
+    for (int i = 0; i < n; i++) out[i] = i * step + a;
+    out[n - 1] = b;
+    return n;
+}
+
+/* the speed-optimised path integral of models in speedup_attenuation_models (GL3), analyticraytracing.py:998-1064 */
+static void attenuation_segments_2d(const double x1[2], double x2m, double z_turn, double C0, const ice_t *m, int model,
+                                    int n_freq, const double *freqs, double *att, int *neval)
+{
+    static double steps[4096];
+    const double dx = 10., window = 20.;
+    int fallback = (x1[1] - window / 2 < z_turn && z_turn < x2m + window / 2), n;
+    if (fallback) {
+        double w0 = fmax(x1[1], z_turn - window / 2), w1 = fmin(z_turn + window / 2, x2m);
+        n = equidistant_steps(x1[1], w0, dx, steps);
+        n += equidistant_steps(w1, x2m, dx, steps + n);
+    } else {
+        n = equidistant_steps(x1[1], x2m, dx, steps);
+    }
+    int idx = -2;
+    double integrand = 0.;
+    int ne_quad = 0;
+    if (fallback) {
+        int cnt = 0; /* np.digitize(z_turn, steps) - 1 */
+        for (int i = 0; i < n; i++) if (steps[i] <= z_turn) cnt++;
+        idx = cnt - 1;
+        if (idx == n - 1) idx -= 1;
+        else if (idx == -1) idx = 0;
+        att_t a = { C0, 0., m, model, 0 };
+        double err; int la;
+        double lo = steps[idx], hi = steps[idx + 1];
+        int inside = (fmin(lo, hi) < z_turn && z_turn < fmax(lo, hi));
+        orc_quad(ds_only, &a, lo, hi, inside ? 1 : 2, z_turn, 1.49e-8, 1e-2, &integrand, &err, &ne_quad, &la);
+    }
+    for (int k = 0; k < n_freq; k++) {
+        double sum = 0.;
+        for (int i = 0; i + 1 < n; i++) {
+            double dxa = steps[i + 1] - steps[i], mid = steps[i] + dxa / 2, term;
+            if (i == idx) {
+                term = integrand / orc_attenuation_length(z_turn, freqs[k], model);
+            } else {
+                double z = get_z_unmirrored(mid, C0, m);
+                double yd = get_y_diff(mid, C0, m);
+                term = sqrt(yd * yd + 1) / orc_attenuation_length(z, freqs[k], model) * dxa;
+            }
+            sum += term;
+        }
+        att[k] = orc_exp(-1 * sum);
+        if (neval) neval[k] = n - 1 + ne_quad;
+    }
+}
+
 /* x1, x2: 2-D points; freqs: the sparse frequency vector (already chosen); att: exp(-integral) */
 void orc_attenuation_2d(const double x1[2], const double x2[2], double C0, const double ice[3], int model,
                         int n_freq, const double *freqs, double *att, int *neval)
@@ -1091,6 +1184,10 @@ void orc_attenuation_2d(const double x1[2], const double x2[2], double C0, const
     double x2m = get_z_mirrored(x1, x2, C0, &m);
     double g, z_turn;
     get_turning_point(m.n_ice * m.n_ice - 1. / (C0 * C0), &m, &g, &z_turn);
+    if (model == 5) { /* speedup_attenuation_models = ["GL3"] (:63) */
+        attenuation_segments_2d(x1, x2m, z_turn, C0, &m, model, n_freq, freqs, att, neval);
+        return;
+    }
     int npts = (x1[1] < z_turn && z_turn < x2m) ? 1 : 0;
     for (int i = 0; i < n_freq; i++) {
         att_t a = { C0, freqs[i], &m, model, 0 };

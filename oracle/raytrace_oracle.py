@@ -13,7 +13,7 @@ _SO = os.path.join(_HERE, '_build', 'liboracle.so')
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
 MAXS = 2
-MODEL_TO_INT = {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4}
+MODEL_TO_INT = {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4, "GL3": 5}
 
 
 def build(force=False):
@@ -65,6 +65,13 @@ def raytrace_batch(x1, x2, ice):
                              _d(o['D']), _d(o['T']), _d(o['launch']), _d(o['receive']), _d(o['refl_angle']),
                              _d(o['hybr_x']), _d(o['hybr_fun']))
     return o
+
+
+def set_gl3_table(table):
+    """depth table of the GL3 model, rows (depth [m], slope, offset) = NuRadioMC/utilities/data/GL3_params.csv"""
+    t = np.ascontiguousarray(np.asarray(table, float))
+    d, s_, o = (np.ascontiguousarray(t[:, k]) for k in range(3))
+    lib().orc_set_gl3_table(len(t), _d(d), _d(s_), _d(o))
 
 
 def attenuation_batch(x1, x2, C0, ice, model, freqs, return_neval=False):

@@ -35,8 +35,8 @@ def gpu_ctx_factory():
     import nuradiomc_amd
     made = []
 
-    def make(ice, attenuation_model='SP1'):
-        c = nuradiomc_amd.Context(ice, attenuation_model, device=0)
+    def make(ice, attenuation_model='SP1', **kw):
+        c = nuradiomc_amd.Context(ice, attenuation_model, device=0, **kw)
         made.append(c)
         return c
     yield make

@@ -268,7 +268,7 @@ def test_simulate_events_edge_cases(gpu_ctx_factory):
     with pytest.raises(NotImplementedError):
         nuradiomc_amd.Station(ctx, bench.CHANNELS, antenna='createLPDA_100MHz_InfFirn')
     with pytest.raises(NotImplementedError):
-        nuradiomc_amd.Context(bench.ICE, 'GL3')
+        nuradiomc_amd.Context(bench.ICE, 'GL9')
 
 
 @pytest.mark.parametrize('name,n_events', [('N256', 200), ('N256_hpol', 150), ('N256_lpda', 200), ('N4096', 60)])
@@ -456,7 +456,8 @@ def test_production_mode_is_deterministic(gpu_ctx_factory):
         assert np.array_equal(trig, ref)
 
 
-def test_rnog_like_station_24_channels(gpu_ctx_factory):
+@pytest.mark.parametrize('att_model', ['GL1', 'GL3'])
+def test_rnog_like_station_24_channels(gpu_ctx_factory, att_model):
     """A 24-channel station in the shape of RNO-G (BASELINE configs 3-5: deep VPol / HPol strings plus shallow LPDAs in
     several orientations, unequal cable delays, Greenland ice with GL1 attenuation, 2-fold high/low coincidence):
     decisions and channel traces vs the oracle."""
@@ -478,7 +479,11 @@ def test_rnog_like_station_24_channels(gpu_ctx_factory):
     pos, ori = np.array(pos), np.array(ori)
     assert len(pos) == 24
     cable = np.linspace(0., 37.3, 24)
-    ctx = gpu_ctx_factory(ice, 'GL1')
+    kw = {}
+    if att_model == 'GL3':
+        kw['gl3_table'] = golden('ref_gl3.npz')['gl3_table']
+        rto.set_gl3_table(kw['gl3_table'])
+    ctx = gpu_ctx_factory(ice, att_model, **kw)
     st = nuradiomc_amd.Station(ctx, pos, antenna=ant, orientation=ori, cable_delay=cable, n_samples=512, sampling_rate=2.0)
     ost = so.Station(pos, antenna=ant, orientation=ori, cable_delay=cable, n_samples=512, fs=2.0)
     vrms, vrms_e = so.vrms_from_filters(2.0)
@@ -494,7 +499,7 @@ def test_rnog_like_station_24_channels(gpu_ctx_factory):
     pos_of = {int(e): i for i, e in enumerate(item_event)}
     n_cand = 0
     for e in range(n):
-        o = so.simulate_event(v[e], zen[e], az[e], en[e], 'HAD', None, ost, ice, vrms, vrms_e, att_model='GL1')
+        o = so.simulate_event(v[e], zen[e], az[e], en[e], 'HAD', None, ost, ice, vrms, vrms_e, att_model=att_model)
         assert o['candidate'] == bool(cand[e]), e
         if not o['candidate']:
             continue

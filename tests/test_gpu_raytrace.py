@@ -110,3 +110,38 @@ def test_attenuation_length_models(gpu_ctx_factory):
         assert np.array_equal(np.isinf(got), np.isinf(ref))
         m = np.isfinite(ref)
         assert np.max(np.abs(got[m] - ref[m]) / np.abs(ref[m])) < 1e-12, model
+
+
+def test_gl3_attenuation(gpu_ctx_factory):
+    """GL3: attenuation length from the depth table and the segment-sum path integral (incl. the QUADPACK run on ds around
+    the turning depth, with and without the break point inside the segment) -- bit-equal to the oracle, which is pinned
+    against the reference (tests/test_oracle_golden.py::test_gl3_attenuation_vs_reference); and directly vs the fixture."""
+    g = golden('ref_gl3.npz')
+    orc.set_gl3_table(g['gl3_table'])
+    ctx = gpu_ctx_factory(g['ice'], 'GL3', gl3_table=g['gl3_table'])
+    zz = g['z_probe']
+    for j, f in enumerate(g['f_probe']):
+        L = ctx.attenuation_length(zz, np.full(len(zz), f))
+        assert np.array_equal(L, orc.attenuation_length(zz, np.full(len(zz), f), 'GL3'))
+    rng = np.random.default_rng(8)
+    n = 4000
+    r, ph = np.sqrt(rng.uniform(0, 3000. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    x1 = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-2900., -5., n)], axis=1)
+    x2 = np.stack([np.zeros(n), np.zeros(n), rng.choice([-3., -60., -100., -400.], n)], axis=1)
+    t = ctx.find_solutions_batch(x1, x2)
+    n_checked = 0
+    for s in range(2):
+        sel = np.flatnonzero(t['n_sol'] > s)
+        a_gpu, ne_gpu = ctx.attenuation_batch(x1[sel], x2[sel], t['C0'][sel, s], g['fcoarse'], return_neval=True)
+        a_ref, ne_ref = orc.attenuation_batch(x1[sel], x2[sel], t['C0'][sel, s], g['ice'], 'GL3', g['fcoarse'], return_neval=True)
+        assert np.array_equal(ne_gpu, ne_ref)
+        assert np.array_equal(a_gpu, a_ref), np.max(np.abs(a_gpu - a_ref) / a_ref)
+        n_checked += len(sel)
+    assert n_checked > 3000
+    for s in range(2):  # the reference's own numbers
+        sel = np.flatnonzero(~np.isnan(g['C0'][:, s]))
+        a = ctx.attenuation_batch(g['x1'][sel], g['x2'][sel], g['C0'][sel, s], g['fcoarse'])
+        assert np.max(np.abs(a - g['att'][sel, s]) / g['att'][sel, s]) < 1e-10
+    with pytest.raises(ValueError):
+        import nuradiomc_amd
+        nuradiomc_amd.Context(g['ice'], 'GL3')

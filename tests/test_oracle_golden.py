@@ -158,3 +158,26 @@ def test_filter_responses_vs_reference():
         assert np.max(np.abs(flt.response(ff, [flt.design(spec)]) - ref)) <= 1e-9 * scale, spec
     with pytest.raises(NotImplementedError):
         flt.design(dict(type='gaussian_tapered', passband=(0.1, 0.2), order=1))
+
+
+def test_gl3_attenuation_vs_reference():
+    """GL3 (Greenland 2021) attenuation length from the depth table and the reference's speed-optimised path integration
+    (10 m segment sums + QUADPACK on ds around the turning point, analyticraytracing.py:998-1064) on 210 rays x 25
+    frequencies, launch parameters taken from the fixture."""
+    from oracle import raytrace_oracle as rto
+    g = golden('ref_gl3.npz')
+    rto.set_gl3_table(g['gl3_table'])
+    zz, fp = g['z_probe'], g['f_probe']
+    for j, f in enumerate(fp):
+        L = rto.attenuation_length(zz, np.full(len(zz), f), 'GL3')
+        ref = g['L_probe'][:, j]
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(L), fin) and np.max(np.abs(L[fin] - ref[fin]) / ref[fin]) < 1e-13
+    n = 0
+    for s in range(2):
+        sel = np.flatnonzero(~np.isnan(g['C0'][:, s]))
+        att = rto.attenuation_batch(g['x1'][sel], g['x2'][sel], g['C0'][sel, s], g['ice'], 'GL3', g['fcoarse'])
+        ref = g['att'][sel, s]
+        assert np.max(np.abs(att - ref) / ref) < 1e-10, s
+        n += len(sel)
+    assert n == int(g['n_sol'].sum()) and n > 200
