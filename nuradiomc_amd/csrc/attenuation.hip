@@ -22,8 +22,12 @@ struct AttLane {
     int model;
     double f;   // frequency [GHz]
     double w;   // ln f  (SP1)
-    const double* gl3;  // GL3 depth table: [3][gl3_n] depth (positive), slope, offset (attenuation.py:16-34)
-    int gl3_n;
+};
+// GL3 depth table: [3][n] depth (positive), slope, offset (attenuation.py:16-34); kept out of AttLane so that the
+// quadrature kernels of the other models carry no extra registers
+struct Gl3Tab {
+    const double* t;
+    int n;
 };
 
 // linear interpolation of one GL3 table column like scipy.interpolate.interp1d(bounds_error=False, fill_value=(first, last))
@@ -42,7 +46,7 @@ __device__ inline double gl3_interp(double x, const double* __restrict__ d, cons
     return slope * (x - d[idx - 1]) + fp[idx - 1];
 }
 
-__device__ inline double attenuation_length(double z, const AttLane& a)
+__device__ inline double attenuation_length(double z, const AttLane& a, Gl3Tab gl3 = Gl3Tab{nullptr, 0})
 {
     double L;
     if (a.model == 1) {  // SP1 (attenuation.py:130-142, :168-192)
@@ -70,8 +74,8 @@ __device__ inline double attenuation_length(double z, const AttLane& a)
         if (att < 100.) att = 100.;
         L = att - 0.55 * (a.f / 1e-3 - 75);
     } else if (a.model == 5) {  // GL3 (:206-221): L = slope(depth) f + offset(depth)
-        if (!a.gl3 || a.gl3_n < 2) return NAN;
-        L = gl3_interp(-z, a.gl3, a.gl3 + a.gl3_n, a.gl3_n) * a.f + gl3_interp(-z, a.gl3, a.gl3 + 2 * a.gl3_n, a.gl3_n);
+        if (!gl3.t || gl3.n < 2) return NAN;
+        L = gl3_interp(-z, gl3.t, gl3.t + gl3.n, gl3.n) * a.f + gl3_interp(-z, gl3.t, gl3.t + 2 * gl3.n, gl3.n);
     } else if (a.model == 4) {  // GL2 (:198-204)
         const double fit[6] = {1.20547286e+00, 1.58815679e-05, -2.58901767e-07,
                                -5.16435542e-10, -2.89124473e-13, -4.58987344e-17};
@@ -520,7 +524,7 @@ struct GroupEval {
 
 // adaptive integration over [a, b] with optional interior break point (QUADPACK QAGS / QAGP decisions); every lane of
 // an evaluation group must call this together (lanes without work pass valid = false).  Returns the integral estimate.
-template <class EV>
+template <class EV, bool QAGP0 = false>
 __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool with_point, double point, const AttItem& it,
                                    const IceConst& m, int* neval_out, const EV& ev, bool qagp_no_point = false)
 {
@@ -538,8 +542,9 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
     bool extrap = false, noext = false;
     double sign = 1.;
     // qagp_no_point: DQAGPE on one interval (what scipy runs when the requested break point lies outside (a, b))
-    const bool qagp = with_point || qagp_no_point;
-    const int nint = with_point ? 2 : 1;
+    // (QAGP0 is a template flag so that the kernels which never need this mode compile exactly as before)
+    const bool qagp = with_point || (QAGP0 && qagp_no_point);
+    const int nint = (QAGP0 && !with_point) ? 1 : 2;
     bool busy = false;
     int exit_code = 0;  // 1: sum the list (label 190 / 115); 2: final-result logic (label 170 / 100)
     // ---- first estimate(s): (a, b) or (a, point), (point, b) ------------------------------------------------
@@ -793,8 +798,6 @@ attenuation_kernel(long n_rays, const double* __restrict__ C0, const double* __r
         double z1 = zint[3 * ray], z2m = zint[3 * ray + 1];
         it.z_turn = zint[3 * ray + 2];
         it.lane.model = model;
-        it.lane.gl3 = nullptr;
-        it.lane.gl3_n = 0;
         it.lane.f = freqs[jf];
         it.lane.w = det_log(it.lane.f);
         if (isnan(it.C0)) {
@@ -836,8 +839,6 @@ attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const doubl
         double z1 = ray_ok ? zint[3 * ray] : 0., z2m = ray_ok ? zint[3 * ray + 1] : 0.;
         it.z_turn = ray_ok ? zint[3 * ray + 2] : 0.;
         it.lane.model = model;
-        it.lane.gl3 = nullptr;
-        it.lane.gl3_n = 0;
         it.lane.f = (jf < n_freq) ? freqs[jf] : 1.;
         it.lane.w = det_log(it.lane.f);
         bool valid = ray_ok && jf < n_freq && !isnan(it.C0);
@@ -900,8 +901,7 @@ attenuation_segments_kernel(long n_rays, const double* __restrict__ C0, const do
         lane.model = model;
         lane.f = (jf < n_freq) ? freqs[jf] : 1.;
         lane.w = 0.;
-        lane.gl3 = gl3;
-        lane.gl3_n = gl3_n;
+        const Gl3Tab tab{gl3, gl3_n};
         const double dx = 10., window = 20.;
         const bool fallback = (z1 - window / 2 < zt && zt < z2m + window / 2);
         // step list: linspace(z1, w0) ++ linspace(w1, z2m) (fallback) or linspace(z1, z2m)
@@ -927,7 +927,7 @@ attenuation_segments_kernel(long n_rays, const double* __restrict__ C0, const do
             it.z_turn = zt;
             it.lane = lane;
             it.lane.model = 100;  // ds only
-            integrand = quad_gk21(true, lo, hi, inside, zt, it, m, &ne_quad, ev, !inside);
+            integrand = quad_gk21<LaneEval, true>(true, lo, hi, inside, zt, it, m, &ne_quad, ev, !inside);
         }
         double sum = 0.;
         const int n_seg = valid ? n - 1 : 0;
@@ -951,8 +951,8 @@ attenuation_segments_kernel(long n_rays, const double* __restrict__ C0, const do
             for (int k = 0; k < G && c0i + k < n_seg; k++) {
                 const double ds_k = sh[grp][k][0], dxa_k = sh[grp][k][1], z_k = sh[grp][k][2];
                 double term;
-                if (c0i + k == idx) term = integrand / attenuation_length(zt, lane);
-                else term = ds_k / attenuation_length(z_k, lane) * dxa_k;
+                if (c0i + k == idx) term = integrand / attenuation_length(zt, lane, tab);
+                else term = ds_k / attenuation_length(z_k, lane, tab) * dxa_k;
                 sum += term;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1010,12 +1010,10 @@ __global__ void attenuation_length_kernel(long n, const double* __restrict__ z, 
     long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= n) return;
     AttLane a;
-    a.gl3 = gl3;
-    a.gl3_n = gl3_n;
     a.model = model;
     a.f = f[i];
     a.w = det_log(a.f);
-    L[i] = attenuation_length(z[i], a);
+    L[i] = attenuation_length(z[i], a, Gl3Tab{gl3, gl3_n});
 }
 
 void launch_attenuation_length(hipStream_t stream, long n, const double* z, const double* f, int model, double* L,
