@@ -394,7 +394,7 @@ __device__ inline double gk_node(int n, double a, double b)
 
 // finish a 21-point rule from per-node integrand values f(n) (n as in gk_node); identical accumulation to gk21()
 template <class F>
-__device__ inline GK gk21_from_nodes(double a, double b, F&& fval)
+__device__ inline GK gk21_from_nodes(double a, double b, F&& fval, double* __restrict__ fbuf)
 {
     const double WGK[11] = {
         0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
@@ -408,7 +408,7 @@ __device__ inline GK gk21_from_nodes(double a, double b, F&& fval)
         0.219086362515982043995534934228163, 0.269266719309996355091226921569469,
         0.295524224714752870173815619188769};
     const double epmach = 2.220446049250313e-16, uflow = 2.2250738585072014e-308;
-    double fv1[10], fv2[10];
+    // the 20 node values needed again for resasc live in a lane-private LDS column (stride 256), not in registers
     double hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
     double resg = 0.;
     double fc = fval(0);
@@ -418,7 +418,7 @@ __device__ inline GK gk21_from_nodes(double a, double b, F&& fval)
     for (int j = 0; j < 5; j++) {
         const int jtw = 2 * j + 1;
         double f1 = fval(1 + 2 * j), f2 = fval(2 + 2 * j);
-        fv1[jtw] = f1; fv2[jtw] = f2;
+        fbuf[jtw * 256] = f1; fbuf[(10 + jtw) * 256] = f2;
         double fsum = f1 + f2;
         resg += WG[j] * fsum;
         resk += WGK[jtw] * fsum;
@@ -428,7 +428,7 @@ __device__ inline GK gk21_from_nodes(double a, double b, F&& fval)
     for (int j = 0; j < 5; j++) {
         const int jtwm1 = 2 * j;
         double f1 = fval(11 + 2 * j), f2 = fval(12 + 2 * j);
-        fv1[jtwm1] = f1; fv2[jtwm1] = f2;
+        fbuf[jtwm1 * 256] = f1; fbuf[(10 + jtwm1) * 256] = f2;
         double fsum = f1 + f2;
         resk += WGK[jtwm1] * fsum;
         resabs += WGK[jtwm1] * (fabs(f1) + fabs(f2));
@@ -436,7 +436,7 @@ __device__ inline GK gk21_from_nodes(double a, double b, F&& fval)
     double reskh = resk * 0.5;
     double resasc = WGK[10] * fabs(fc - reskh);
 #pragma unroll
-    for (int j = 0; j < 10; j++) resasc += WGK[j] * (fabs(fv1[j] - reskh) + fabs(fv2[j] - reskh));
+    for (int j = 0; j < 10; j++) resasc += WGK[j] * (fabs(fbuf[j * 256] - reskh) + fabs(fbuf[(10 + j) * 256] - reskh));
     GK o;
     o.result = resk * hlgth;
     o.resabs = resabs * dhlgth;
@@ -466,8 +466,10 @@ struct GroupEval {
     int lane, gl, gb;               // lane in wave, lane in group, first lane of the group
     unsigned long long gmask;       // lanes of this group
     NodeShared* nodes;              // LDS: 2 x 21 node records of this group
-    __device__ inline void init(NodeShared* lds)
+    double* fbuf;                   // LDS: this lane's column for the node values of one 21-point rule
+    __device__ inline void init(NodeShared* lds, double* lds_f)
     {
+        fbuf = lds_f + threadIdx.x;
         lane = threadIdx.x & 63;
         gl = lane & (G - 1);
         gb = lane - gl;
@@ -505,13 +507,13 @@ struct GroupEval {
                 g1 = gk21_from_nodes(a1, b1, [&](int n) {
                     const NodeShared& s = nodes[n];
                     return node_finish(s.ds, s.z, s.p[sel], s.p[sel + 1], s.p[sel], s.p[sel + 1], it.lane);
-                });
+                }, fbuf);
                 __builtin_amdgcn_sched_barrier(0);  // finish interval 1 before interval 2: halves the live values
                 if (two)
                     g2 = gk21_from_nodes(a2, b2, [&](int n) {
                         const NodeShared& s = nodes[21 + n];
                         return node_finish(s.ds, s.z, s.p[sel], s.p[sel + 1], s.p[sel], s.p[sel + 1], it.lane);
-                    });
+                    }, fbuf);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -822,8 +824,9 @@ attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const doubl
                          unsigned long long* __restrict__ eval_counter)
 {
     __shared__ NodeShared sh_nodes[(256 / G) * 42];
+    __shared__ double sh_f[20 * 256];
     GroupEval<G> ev;
-    ev.init(sh_nodes);
+    ev.init(sh_nodes, sh_f);
     model = MODEL;  // compile-time: the branches on the ice model fold away
     unsigned long long my_evals = 0;
     const long groups_per_block = blockDim.x / G;
