@@ -393,6 +393,12 @@ __device__ inline double gk_node(int n, double a, double b)
 }
 
 // finish a 21-point rule from per-node integrand values f(n) (n as in gk_node); identical accumulation to gk21()
+#ifndef ATT_BLOCK
+#define ATT_BLOCK 128  // threads per block of the cooperative quadrature kernel
+#endif
+#ifndef ATT_WAVES
+#define ATT_WAVES 2
+#endif
 template <class F>
 __device__ inline GK gk21_from_nodes(double a, double b, F&& fval, double* __restrict__ fbuf)
 {
@@ -418,7 +424,7 @@ __device__ inline GK gk21_from_nodes(double a, double b, F&& fval, double* __res
     for (int j = 0; j < 5; j++) {
         const int jtw = 2 * j + 1;
         double f1 = fval(1 + 2 * j), f2 = fval(2 + 2 * j);
-        fbuf[jtw * 256] = f1; fbuf[(10 + jtw) * 256] = f2;
+        fbuf[jtw * ATT_BLOCK] = f1; fbuf[(10 + jtw) * ATT_BLOCK] = f2;
         double fsum = f1 + f2;
         resg += WG[j] * fsum;
         resk += WGK[jtw] * fsum;
@@ -428,7 +434,7 @@ __device__ inline GK gk21_from_nodes(double a, double b, F&& fval, double* __res
     for (int j = 0; j < 5; j++) {
         const int jtwm1 = 2 * j;
         double f1 = fval(11 + 2 * j), f2 = fval(12 + 2 * j);
-        fbuf[jtwm1 * 256] = f1; fbuf[(10 + jtwm1) * 256] = f2;
+        fbuf[jtwm1 * ATT_BLOCK] = f1; fbuf[(10 + jtwm1) * ATT_BLOCK] = f2;
         double fsum = f1 + f2;
         resk += WGK[jtwm1] * fsum;
         resabs += WGK[jtwm1] * (fabs(f1) + fabs(f2));
@@ -436,7 +442,7 @@ __device__ inline GK gk21_from_nodes(double a, double b, F&& fval, double* __res
     double reskh = resk * 0.5;
     double resasc = WGK[10] * fabs(fc - reskh);
 #pragma unroll
-    for (int j = 0; j < 10; j++) resasc += WGK[j] * (fabs(fbuf[j * 256] - reskh) + fabs(fbuf[(10 + j) * 256] - reskh));
+    for (int j = 0; j < 10; j++) resasc += WGK[j] * (fabs(fbuf[j * ATT_BLOCK] - reskh) + fabs(fbuf[(10 + j) * ATT_BLOCK] - reskh));
     GK o;
     o.result = resk * hlgth;
     o.resabs = resabs * dhlgth;
@@ -817,14 +823,14 @@ attenuation_kernel(long n_rays, const double* __restrict__ C0, const double* __r
 
 // G lanes per ray (G = 32 for n_freq <= 32, else 64): the cooperative evaluation of GroupEval
 template <int G, int MODEL>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(ATT_BLOCK, ATT_WAVES)
 attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const double* __restrict__ zint, int n_freq,
                          const double* __restrict__ freqs, int model, IceConst m, double* __restrict__ att,
                          int* __restrict__ neval, const int* __restrict__ ray_index,
                          unsigned long long* __restrict__ eval_counter)
 {
-    __shared__ NodeShared sh_nodes[(256 / G) * 42];
-    __shared__ double sh_f[20 * 256];
+    __shared__ NodeShared sh_nodes[(ATT_BLOCK / G) * 42];
+    __shared__ double sh_f[20 * ATT_BLOCK];
     GroupEval<G> ev;
     ev.init(sh_nodes, sh_f);
     model = MODEL;  // compile-time: the branches on the ice model fold away
@@ -1052,6 +1058,7 @@ void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0,
         return;
     }
     if (n_freq <= 64 && !getenv("NRHIP_ATT_LANES")) {
+        block = ATT_BLOCK;
         int G = (n_freq <= 32) ? 32 : 64;
         long grid = (n_rays + block / G - 1) / (block / G);
         if (grid > 256L * 64) grid = 256L * 64;
