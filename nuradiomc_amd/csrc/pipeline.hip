@@ -284,16 +284,16 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     NEED(rec.launch = WS("slot_launch", double, 3 * n_slots));
     NEED(rec.receive = WS("slot_receive", double, 3 * n_slots));
     NEED(rec.refl_angle = WS("slot_refl_angle", double, n_slots));
-    // events in geometry-cell order for the root finders (counting sort over 4096 cells)
+    // events in geometry-cell order for the root finders (counting sort over 128 x 128 cells)
     int *geo_cell, *geo_hist, *geo_off, *geo_tmp, *geo_perm;
     NEED(geo_cell = WS("geo_cell", int, n_events));
-    NEED(geo_hist = WS("geo_hist", int, 4096 + 1));
-    NEED(geo_off = WS("geo_offset", int, 4096 + 1));
-    NEED(geo_tmp = WS("scan_tmp7", int, scan_tiles(4096 + 1)));
+    NEED(geo_hist = WS("geo_hist", int, 16384 + 1));
+    NEED(geo_off = WS("geo_offset", int, 16384 + 1));
+    NEED(geo_tmp = WS("scan_tmp7", int, scan_tiles(16384 + 1)));
     NEED(geo_perm = WS("geo_perm", int, n_events));
-    HIPCHK(hipMemsetAsync(geo_hist, 0, sizeof(int) * 4097, sm));
+    HIPCHK(hipMemsetAsync(geo_hist, 0, sizeof(int) * 16385, sm));
     launch_event_cells(sm, (int)n_events, vertex, sd.pos, geo_cell, geo_hist);
-    launch_exclusive_scan(sm, 4097, geo_hist, geo_off, geo_tmp);
+    launch_exclusive_scan(sm, 16385, geo_hist, geo_off, geo_tmp);
     launch_event_perm(sm, (int)n_events, geo_cell, geo_off, geo_perm);
     LCHK("geometry order");
     launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm);

@@ -307,8 +307,8 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
     }
 }
 
-// geometry cell of an event: 64 x 64 cells in (horizontal distance to the station's first antenna, vertex depth)
-#define NRHIP_GEO_CELLS 4096
+// geometry cell of an event: NRHIP_GEO_SIDE^2 cells in (horizontal distance to the station's first antenna, vertex depth)
+#define NRHIP_GEO_SIDE 128
 __global__ void __launch_bounds__(256)
 event_cell_kernel(int n_events, const double* __restrict__ vertex, const double* __restrict__ x2, int* __restrict__ cell,
                   int* __restrict__ hist)
@@ -316,10 +316,11 @@ event_cell_kernel(int n_events, const double* __restrict__ vertex, const double*
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_events) return;
     double dx = vertex[3 * (long)e] - x2[0], dy = vertex[3 * (long)e + 1] - x2[1];
-    int cr = (int)(sqrt(dx * dx + dy * dy) * (64. / 5000.)), cz = (int)(-vertex[3 * (long)e + 2] * (64. / 3000.));
-    cr = cr < 0 ? 0 : (cr > 63 ? 63 : cr);
-    cz = cz < 0 ? 0 : (cz > 63 ? 63 : cz);
-    int c = cz * 64 + cr;
+    const int S = NRHIP_GEO_SIDE;
+    int cr = (int)(sqrt(dx * dx + dy * dy) * (S / 5000.)), cz = (int)(-vertex[3 * (long)e + 2] * (S / 3000.));
+    cr = cr < 0 ? 0 : (cr > S - 1 ? S - 1 : cr);
+    cz = cz < 0 ? 0 : (cz > S - 1 ? S - 1 : cz);
+    int c = cz * S + cr;
     cell[e] = c;
     atomicAdd(&hist[c], 1);
 }
