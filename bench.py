@@ -141,8 +141,9 @@ def main():
         alg = {'raytrace': B_PAIR * stats['n_pairs'],
                'amp_bound': 136 * stats['n_rays'] + 8 * stats['n_rays'],
                'attenuation': (32 + 8 * 25) * stats['n_active_rays'],
-               'efield_max': b_field * stats['n_active_rays'],
-               'channel': (B_RAY - b_field) * stats['n_candidate_rays'] + B_CHANNEL * stats['n_channel_items']}
+               'efield_max': 232 * stats['n_active_rays'] + b_field * stats['n_efield_transforms'],
+               # only the transforms actually carried out are priced (pruned items move no algorithmic bytes)
+               'channel': (B_RAY - b_field) * stats['n_ray_transforms'] + B_CHANNEL * stats['n_channel_transforms']}
         alg_bytes = alg.get(dom, 0)
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, see the file header);
         # only meaningful for the workload they were measured on
@@ -168,6 +169,8 @@ def main():
                                    "Butterworth 80-500 MHz, 3 Vrms threshold" % n,
                        "events_per_gpu": n, "n_pairs": stats['n_pairs'], "n_rays": stats['n_rays'],
                        "n_active_rays": stats['n_active_rays'], "n_candidate_events": stats['n_candidate_events'],
+                       "n_channel_items": stats['n_channel_items'], "n_channel_transforms": stats['n_channel_transforms'],
+                       "n_ray_transforms": stats['n_ray_transforms'], "n_efield_transforms": stats['n_efield_transforms'],
                        "n_triggered_rank0": stats['n_triggered'], "n_triggered_all": n_trig_total,
                        "n_distinct_trace_lengths": stats['n_distinct_lengths'],
                        "triggered_events_per_s": n_trig_total / (elapsed / max(args.steps, 1)),

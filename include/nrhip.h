@@ -205,6 +205,9 @@ typedef struct {
     int64_t n_candidate_rays;
     int64_t n_active_rays;        /* rays that went through the attenuation quadrature */
     int64_t n_integrand_evals;    /* attenuation integrand evaluations (QUADPACK's neval summed over all items) */
+    int64_t n_channel_transforms; /* (event, channel) items whose voltage trace was actually computed              */
+    int64_t n_ray_transforms;     /* rays whose field went into one of those traces                                  */
+    int64_t n_efield_transforms;  /* rays whose field was transformed for the candidate cut                          */
     int32_t max_length;
     int32_t reserved;
     double stage_ms[NRHIP_N_STAGES];

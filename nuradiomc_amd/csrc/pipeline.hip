@@ -402,6 +402,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     }
     S.n_active_rays = n_active;
     unsigned long long* eval_counter = nullptr;
+    unsigned long long* xform_count;  // [0] channel traces computed, [1] rays in them, [2] rays transformed for the candidate cut
+    NEED(xform_count = WS("transform_count", unsigned long long, 3));
+    HIPCHK(hipMemsetAsync(xform_count, 0, 3 * sizeof(unsigned long long), sm));
     MARK(3);
     if (n_active > 0) {
         // attenuation on the coarse frequency grid, active rays only
@@ -424,7 +427,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(ev_list = WS("ev_transform_list", int, n_groups));
         launch_efield_max(sm, n_active, active_list, n_rays, (int)n_groups, grp_ray, w, evin, sd, cfg->askaryan_model,
                           ctx->twiddle, cfg->min_efield_amplitude, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, max_efield,
-                          need_ray, ev_need, ev_off, ev_tmp, ev_list);
+                          need_ray, ev_need, ev_off, ev_tmp, ev_list, xform_count);
         LCHK("efield_max");
     }
     MARK(5);
@@ -552,7 +555,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(coinc_cnt = WS("coincidence_count", int, trg.coincidence() ? (size_t)channel_grid_blocks() * FFT_MAX : 1));
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, cfg->askaryan_model, trg,
                        ctx->twiddle, ctx->w16, tab, scratch, co, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, maxL, it_need,
-                       it_off, it_tmp, it_list, coinc_cnt, conv_acc);
+                       it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count);
         LCHK("channel");
         MARK(8);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here
@@ -570,6 +573,13 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             unsigned long long ne = 0;
             HIPCHK(hipMemcpy(&ne, eval_counter, sizeof ne, hipMemcpyDeviceToHost));
             S.n_integrand_evals = (int64_t)ne;
+        }
+        {
+            unsigned long long xc[3] = {0, 0, 0};
+            HIPCHK(hipMemcpy(xc, xform_count, sizeof xc, hipMemcpyDeviceToHost));
+            S.n_channel_transforms = (int64_t)xc[0];
+            S.n_ray_transforms = (int64_t)xc[1];
+            S.n_efield_transforms = (int64_t)xc[2];
         }
         for (int i = 0; i < 8; i++) {
             float ms = 0.f;

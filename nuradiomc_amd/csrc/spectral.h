@@ -136,7 +136,7 @@ void launch_scatter_active_class(hipStream_t s, int n_rays, const int* flags, co
 void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int n_rays, int n_events,
                        const int* slot_offset, const RayWork& w, const EventIn& evin, const StationDev& st, int ask_model,
                        const double2* tw, double min_efield, int exact, double* max_efield, int* need_ray, int* ev_need,
-                       int* ev_offset, int* scan_tmp, int* ev_list);
+                       int* ev_offset, int* scan_tmp, int* ev_list, unsigned long long* xform_count);
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev);
 void launch_candidate_flags(hipStream_t s, int n_events, int n_half, const EventOut& ev, int* cflag, int* lflag,
@@ -150,7 +150,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
-                    int* item_list, int* coinc_cnt, double2* conv_acc);
+                    int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count);
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
                          const int* len_index_N, double* max_env, double* signal_time);

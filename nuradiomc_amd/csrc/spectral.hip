@@ -910,7 +910,8 @@ __global__ void scatter_flagged_kernel(int n, const int* __restrict__ flag, cons
 __global__ void __launch_bounds__(256)
 efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ ev_list, const int* __restrict__ need_ray,
                   const int* __restrict__ slot_offset, RayWork w, EventIn evin, StationDev st, int ask_model,
-                  const double2* __restrict__ tw, int log2nh, double min_efield, int exact, double* __restrict__ max_efield)
+                  const double2* __restrict__ tw, int log2nh, double min_efield, int exact, double* __restrict__ max_efield,
+                  unsigned long long* __restrict__ xform_count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2;
@@ -958,7 +959,10 @@ efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ ev_lis
             }
         }
         mx = block_max(mx, red);
-        if (threadIdx.x == 0) max_efield[r] = mx;
+        if (threadIdx.x == 0) {
+            max_efield[r] = mx;
+            if (xform_count) atomicAdd(&xform_count[2], 1ULL);
+        }
         if (!exact && mx > min_efield) done = true;  // block-uniform (block_max broadcasts)
       }
     }
@@ -1292,7 +1296,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                     const int* __restrict__ ev_len_index, StationDev st, int ask_model, TriggerDev trg,
                     const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab, int log2nh,
-                    ChannelOut out, int exact, int* __restrict__ coinc_cnt, double2* __restrict__ conv_acc)
+                    ChannelOut out, int exact, int* __restrict__ coinc_cnt, double2* __restrict__ conv_acc,
+                    unsigned long long* __restrict__ xform_count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = FFT_MAX;
@@ -1414,6 +1419,10 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         double vmax = 0.;
         int trig = 0;
         if (n_used > 0) {
+            if (threadIdx.x == 0 && xform_count) {  // work actually done (roofline accounting of bench.py)
+                atomicAdd(&xform_count[0], 1ULL);
+                atomicAdd(&xform_count[1], (unsigned long long)n_used);
+            }
             if (multi) {
                 __syncthreads();
                 for (int k = threadIdx.x; k < M; k += blockDim.x) z[k] = acc[k];
@@ -2032,7 +2041,7 @@ void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const i
 void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int n_rays, int n_events,
                        const int* slot_offset, const RayWork& w, const EventIn& evin, const StationDev& st, int ask_model,
                        const double2* tw, double min_efield, int exact, double* max_efield, int* need_ray, int* ev_need,
-                       int* ev_offset, int* scan_tmp, int* ev_list)
+                       int* ev_offset, int* scan_tmp, int* ev_list, unsigned long long* xform_count)
 {
     if (n_active <= 0) return;
     int nh = st.N / 2;
@@ -2049,7 +2058,7 @@ void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int 
     size_t lds = (size_t)nh * 16 + (size_t)(nh + 1) * 8;
     int grid = n_events < 256 * 16 ? n_events : 256 * 16;
     hipLaunchKernelGGL(efield_max_kernel, dim3(grid), dim3(256), lds, s, ev_offset + n_events, ev_list, need_ray, slot_offset,
-                       w, evin, st, ask_model, tw, ilog2(nh), min_efield, exact, max_efield);
+                       w, evin, st, ask_model, tw, ilog2(nh), min_efield, exact, max_efield, xform_count);
 }
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev)
@@ -2100,7 +2109,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
-                    int* item_list, int* coinc_cnt, double2* conv_acc)
+                    int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count)
 {
     if (n_items <= 0) return;
     set_big_lds();
@@ -2123,7 +2132,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
         int cgrid = n_cand < channel_grid_blocks() ? n_cand : channel_grid_blocks();
         hipLaunchKernelGGL(channel_conv_kernel, dim3(cgrid), dim3(CONV_NT), (size_t)FFT_MAX * 16, s, need_offset + n_cand,
                            item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16, tab,
-                           ilog2(nh), out, exact, coinc_cnt, conv_acc);
+                           ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count);
         skip_upto = FFT_MAX;
         if (max_length <= FFT_MAX) return;
     }

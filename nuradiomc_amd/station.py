@@ -32,14 +32,15 @@ class SimConfig(ctypes.Structure):
 class SimStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int64) for k in ('n_events', 'n_pairs', 'n_rays', 'n_candidate_events', 'n_triggered',
                                               'n_channel_items', 'n_distinct_lengths', 'n_candidate_rays', 'n_active_rays',
-                                              'n_integrand_evals')] + \
+                                              'n_integrand_evals', 'n_channel_transforms', 'n_ray_transforms',
+                                              'n_efield_transforms')] + \
                [('max_length', ctypes.c_int32), ('reserved', ctypes.c_int32), ('stage_ms', ctypes.c_double * 9)]
 
     STAGES = ('raytrace', 'ray_setup', 'amp_bound', 'attenuation', 'efield_max', 'event_grid', 'length_tables', 'channel',
               'total')
 
     def as_dict(self):
-        d = {k: int(getattr(self, k)) for k, _ in self._fields_[:11]}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_[:14]}
         d['stage_ms'] = {n: float(self.stage_ms[i]) for i, n in enumerate(self.STAGES)}
         return d
 
