@@ -192,6 +192,11 @@ typedef struct {
        cable delay, filter chain), its Hilbert-envelope maximum and the time of that maximum --
        nrhip_sim_fetch("ray_max_amp_envelope" / "ray_signal_time"), NaN for rays of other events.                    */
     int32_t amp_per_ray;
+    /* propagation.focusing / focusing_limit (analyticraytracing.py:2778-2888, :3011-3016): every ray's field is scaled by
+       the ray-convergence factor from a second trace to the receiver moved by 1 cm (numerical branch), at most
+       focusing_limit, times sqrt(n(vertex) / n(receiver)).  Doubles the ray-tracing work.                          */
+    int32_t focusing;
+    double focusing_limit;
 } nrhip_sim_config;
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1

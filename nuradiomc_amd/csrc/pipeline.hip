@@ -366,8 +366,34 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (n_rays > 0) {
         launch_scatter_slots(sm, n_slots, keep, offset, ray_slot);
         LCHK("scatter");
+        const int* foc_n_sol = nullptr;
+        const double* foc_launch = nullptr;
+        const double foc_dz = -0.01;  // get_focusing(dz = -1 cm)
+        if (cfg->focusing) {
+            // second trace to the receivers moved by dz (analyticraytracing.py:2778-2888); only n_sol and launch are used
+            RayRecords rec2;
+            double* pos2;
+            NEED(pos2 = WS("foc_positions", double, 3 * n_ch));
+            std::vector<double> hp(st->h_pos);
+            for (int c = 0; c < n_ch; c++) hp[3 * c + 2] += foc_dz;
+            HIPCHK(hipMemcpyAsync(pos2, hp.data(), sizeof(double) * 3 * n_ch, hipMemcpyHostToDevice, sm));
+            NEED(rec2.n_sol = WS("foc_n_sol", int, n_pairs));
+            NEED(rec2.type = WS("foc_type", int, n_slots));
+            NEED(rec2.C0 = WS("foc_C0", double, n_slots));
+            NEED(rec2.C1 = WS("foc_C1", double, n_slots));
+            NEED(rec2.D = WS("foc_D", double, n_slots));
+            NEED(rec2.T = WS("foc_T", double, n_slots));
+            NEED(rec2.launch = WS("foc_launch", double, 3 * n_slots));
+            NEED(rec2.receive = WS("foc_receive", double, 3 * n_slots));
+            NEED(rec2.refl_angle = WS("foc_refl_angle", double, n_slots));
+            launch_raytrace(sm, n_pairs, vertex, pos2, n_ch, ctx->ice, rec2, max_distance, geo_perm);
+            LCHK("raytrace (focusing)");
+            HIPCHK(hipStreamSynchronize(sm));  // hp goes out of scope
+            foc_n_sol = rec2.n_sol;
+            foc_launch = rec2.launch;
+        }
         launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w, evin,
-                         cfg->askaryan_model);
+                         cfg->askaryan_model, foc_n_sol, foc_launch, foc_dz, cfg->focusing_limit > 0 ? cfg->focusing_limit : 2.);
         LCHK("ray_setup");
     }
     MARK(2);

@@ -121,7 +121,8 @@ void launch_exclusive_scan(hipStream_t s, long n, const int* in, int* out, int* 
 void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const int* offset, int* ray_slot);
 void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex, const double* zen,
                       const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w,
-                      const EventIn& evin, int ask_model);
+                      const EventIn& evin, int ask_model, const int* foc_n_sol = nullptr, const double* foc_launch = nullptr,
+                      double foc_dz = 0., double foc_limit = 0.);
 void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
                                   const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint);
 void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, const IceConst& m,

@@ -308,7 +308,8 @@ __device__ inline AskaryanConst askaryan_setup(int model, double energy, double 
 __global__ void __launch_bounds__(256)
 ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const double* __restrict__ vertex,
                  const double* __restrict__ zenith, const double* __restrict__ azimuth, RayRecords rec, IceConst m,
-                 StationDev st, RayWork w, EventIn evin, int ask_model)
+                 StationDev st, RayWork w, EventIn evin, int ask_model, const int* __restrict__ foc_n_sol,
+                 const double* __restrict__ foc_launch, double foc_dz, double foc_limit)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
@@ -374,8 +375,32 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
     w.theta_ant[r] = th_a;
     antenna_factors(st.ant_model[ch], T, th_a, ph_a, &w.vfac_t[r], &w.vfac_p[r], &w.tab[r]);
     w.slot[r] = slot;
-    w.ask[r] = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r], w.R[r],
-                              evin.k_L[e]);
+    AskaryanConst ac = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r], w.R[r],
+                                      evin.k_L[e]);
+    if (foc_n_sol) {
+        // ray_tracing.get_focusing, numerical branch (analyticraytracing.py:2778-2888): launch angle of the same solution
+        // of the trace to the receiver moved by foc_dz (second ray-tracing pass, tables foc_*)
+        const double vz = vertex[3 * e + 2], cz = st.pos[3 * ch + 2];
+        const double rec_ang = acos(-rv[2] / sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]));
+        const double lau_ang = acos(lv[2] / sqrt(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]));
+        double f = 1.0;
+        if (slot % NRHIP_MAXS < foc_n_sol[pair]) {
+            const double* l1 = foc_launch + 3 * (long)slot;
+            const double lau_ang1 = acos(l1[2] / sqrt(l1[0] * l1[0] + l1[1] * l1[1] + l1[2] * l1[2]));
+            const double dzz = (cz + foc_dz) - cz;
+            const double D = rec.D[slot];
+            f = sqrt(D / sin(rec_ang) * fabs((lau_ang1 - lau_ang) / dzz));
+            const double dx = st.pos[3 * ch] - vertex[3 * e], dy = st.pos[3 * ch + 1] - vertex[3 * e + 1], dz = cz - vz;
+            const double radius = sqrt(dx * dx + dy * dy + dz * dz);
+            const double sin_theta = sqrt(dx * dx + dy * dy) / radius;
+            f *= sqrt((D * sin(lau_ang)) / (radius * sin_theta));
+        }
+        if (f > foc_limit) f = foc_limit;
+        f *= sqrt(n_index_at(vz, m) / n_index_at(cz, m));
+        ac.a_pref *= f;   // every parametrisation is linear in a_pref: spec[1:] *= focusing (:3011-3016)
+        ac.pref2 *= f;
+    }
+    w.ask[r] = ac;
 }
 
 // integration limits for the attenuation kernel from the ray records
@@ -1985,11 +2010,12 @@ void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const in
 }
 void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex, const double* zen,
                       const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w,
-                      const EventIn& evin, int ask_model)
+                      const EventIn& evin, int ask_model, const int* foc_n_sol, const double* foc_launch, double foc_dz,
+                      double foc_limit)
 {
     if (n_rays <= 0) return;
     hipLaunchKernelGGL(ray_setup_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, n_ch, ray_slot, vertex, zen,
-                       az, rec, m, st, w, evin, ask_model);
+                       az, rec, m, st, w, evin, ask_model, foc_n_sol, foc_launch, foc_dz, foc_limit);
 }
 void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
                                   const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint)

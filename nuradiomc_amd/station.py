@@ -26,7 +26,8 @@ class SimConfig(ctypes.Structure):
                 ('min_efield_amplitude', ctypes.c_double), ('trigger_threshold', ctypes.c_double),
                 ('dump_traces', ctypes.c_int32), ('no_pruning', ctypes.c_int32), ('trigger_type', ctypes.c_int32),
                 ('n_coincidences', ctypes.c_int32), ('threshold_high', ctypes.c_double), ('threshold_low', ctypes.c_double),
-                ('high_low_window', ctypes.c_double), ('coinc_window', ctypes.c_double), ('amp_per_ray', ctypes.c_int32)]
+                ('high_low_window', ctypes.c_double), ('coinc_window', ctypes.c_double), ('amp_per_ray', ctypes.c_int32),
+                ('focusing', ctypes.c_int32), ('focusing_limit', ctypes.c_double)]
 
 
 class SimStats(ctypes.Structure):
@@ -193,7 +194,7 @@ class Station:
                             trigger_threshold=None, dump_traces=False, no_pruning=False, want_stats=True,
                             d_vertex_time=None, n_groups=None, d_group_begin=None, trigger='simple', n_coincidences=1,
                             threshold_high=None, threshold_low=None, high_low_window=5., coinc_window=200., amp_per_ray=False,
-                            d_max_distance=None):
+                            d_max_distance=None, focusing=False, focusing_limit=2.):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
         d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
@@ -207,7 +208,7 @@ class Station:
                         int(bool(no_pruning)), 1 if trigger == 'high_low' else 0, int(n_coincidences),
                         float(3.0 * self.vrms if threshold_high is None else threshold_high),
                         float(-3.0 * self.vrms if threshold_low is None else threshold_low), float(high_low_window),
-                        float(coinc_window), int(bool(amp_per_ray)))
+                        float(coinc_window), int(bool(amp_per_ray)), int(bool(focusing)), float(focusing_limit))
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_event_groups(
             self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,

@@ -373,7 +373,8 @@ class Station:
 
 
 def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model='SP1', n_freq=25,
-                          model='Alvarez2009', delta_C_cut=0.698, vertex_time=0., rays=None, max_distance=None):
+                          model='Alvarez2009', delta_C_cut=0.698, vertex_time=0., rays=None, max_distance=None,
+                          focusing=False, focusing_limit=2.):
     """calculate_sim_efield (simulation.py:93-292) for every channel of one single-shower event.
     `rays` may carry precomputed ray tables (dict like raytrace_oracle.raytrace_batch output, one row per channel).
     Returns a list of dicts (one per kept ray, channel-major then solution)."""
@@ -415,6 +416,8 @@ def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st,
                 r_phi = fresnel_r_s(ra, n_2=1., n_1=n1)
                 spec[1] = spec[1] * r_theta
                 spec[2] = spec[2] * r_phi
+            if focusing:  # analyticraytracing.py:3011-3016
+                spec[1:] = spec[1:] * rto.focusing(x1[None], st.pos[ch][None], ice, -0.01, focusing_limit)[0, s]
             zen_r, az_r = cartesian_to_spherical(*rays['receive'][ch, s])
             t0 = vertex_time + T - 0.5 * N / st.fs
             trace = freq2time(spec, st.fs)
@@ -537,10 +540,10 @@ def station_trigger(V, fs, trigger='simple', threshold=None, n_coincidences=1, t
 
 def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, vrms, vrms_efield, att_model='SP1',
                    n_freq=25, model='Alvarez2009', filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0,
-                   min_efield_amplitude=2.0, rays=None):
+                   min_efield_amplitude=2.0, rays=None, focusing=False, focusing_limit=2.):
     """One single-shower event group through simulation.run()'s sequence (:1454-1600)."""
     efs = sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model, n_freq, model,
-                                delta_C_cut, rays=rays)
+                                delta_C_cut, rays=rays, focusing=focusing, focusing_limit=focusing_limit)
     out = dict(rays=efs, candidate=False, triggered=False, L=0, t_min=np.nan)
     for ef in efs:
         if ef['max_efield'] > min_efield_amplitude * vrms_efield:

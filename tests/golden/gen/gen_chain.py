@@ -19,9 +19,10 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 
 
 def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4, model='Alvarez2009',
-        antenna='analytic_VPol', cable_delay=0., rmax=4000., orientation=None):
+        antenna='analytic_VPol', cable_delay=0., rmax=4000., orientation=None, focusing=False):
     det = rh.StationS5(n_samples=N, fs=2.0, antenna=antenna, cable_delay=cable_delay, orientation=orientation)
     cfg = rh.default_config(model=model)
+    cfg['propagation']['focusing'] = bool(focusing)
     ice, prop = rh.make_propagator(cfg, det)
     vrms, vrms_e = rh.vrms_from_filters(cfg)
     ev = rh.random_events(n_events, seed, energy=energy, rmax=rmax)
@@ -64,6 +65,7 @@ def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4
           't0', 'r_theta', 'r_phi', 'max_efield', 'simch_t0', 'max_amp_ray', 'signal_time')}
     out = dict(N=N, fs=2.0, vrms=vrms, vrms_efield=vrms_e, ice=np.array([ice.n_ice, ice.delta_n, ice.z_0]),
                att_model='SP1', n_freq=25, askaryan_model=model, antenna=antenna, cable_delay=cable_delay,
+               focusing=bool(focusing), focusing_limit=2.,
                det_pos=det.pos, det_orientation=np.array(det.orientation if orientation is None else orientation),
                delta_C_cut=0.698,
                trigger_sigma=3.0, min_efield_amplitude=2.0,
@@ -78,7 +80,7 @@ def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['N256', 'N4096', 'N256_hpol', 'N256_lpda']
+    which = sys.argv[1:] or ['N256', 'N4096', 'N256_hpol', 'N256_lpda', 'N256_focus']
     if 'N256' in which:
         run('N256', n_events=300, seed=21, N=256, full_rays=400, full_events=12)
     if 'N4096' in which:
@@ -92,3 +94,5 @@ if __name__ == '__main__':
                [90 * d, 120 * d, 0., 0.]]
         run('N256_lpda', n_events=200, seed=24, N=256, full_rays=200, full_events=8, antenna='analytic_LPDA',
             cable_delay=[0., 0., 4.4, 0., 0.], rmax=2500., orientation=ori, energy=1e17)
+    if 'N256_focus' in which:  # propagation.focusing on (ray convergence factor from a second trace, limit 2)
+        run('N256_focus', n_events=200, seed=25, N=256, full_rays=100, full_events=6, rmax=2500., focusing=True)

@@ -514,3 +514,43 @@ def test_rnog_like_station_24_channels(gpu_ctx_factory, att_model):
     assert n_cand >= 15 and trig.sum() >= 3
     trig_p, _ = st.simulate_events(v, zen, az, en, 'HAD', **opts)
     assert np.array_equal(trig, trig_p)
+
+
+def test_focusing_batched(gpu_ctx_factory):
+    """propagation.focusing in the batched path (second ray-tracing pass to the receivers moved by 1 cm, factor applied to
+    the ray's amplitude): per-ray maxima, candidate flags, traces and triggers vs the oracle (both trace the same rays bit
+    for bit, so the finite difference is the same), and the factor really changes the amplitudes."""
+    g = golden('chain_N256_focus.npz')
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    ost = so.Station(g['det_pos'], n_samples=int(g['N']), fs=float(g['fs']))
+    vrms, vrms_e = so.vrms_from_filters(ost.fs)
+    n = 200
+    kL = np.where(np.isnan(g['ev_k_L'][:n]), 1.0, g['ev_k_L'][:n])
+    args = (g['vertex'][:n], g['zenith'][:n], g['azimuth'][:n], g['energy'][:n], g['shower_type'][:n], kL)
+    trig, stats = st.simulate_events(*args, focusing=True, focusing_limit=2., dump_traces=True, no_pruning=True)
+    mx, rev = st.fetch('ray_max_efield').copy(), st.fetch('ray_event').copy()
+    cand, item_event, tr, off = st.fetch('ev_candidate'), st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    pos = {int(e): i for i, e in enumerate(item_event)}
+    n_cand = n_rays = 0
+    for e in range(n):
+        o = so.simulate_event(g['vertex'][e], g['zenith'][e], g['azimuth'][e], g['energy'][e], str(g['shower_type'][e]),
+                              float(kL[e]), ost, g['ice'], vrms, vrms_e, focusing=True, focusing_limit=2.)
+        mine = np.flatnonzero(rev == e)
+        assert len(mine) == len(o['rays']) and o['candidate'] == bool(cand[e]) and o['triggered'] == bool(trig[e]), e
+        for k, r in zip(mine, o['rays']):
+            assert abs(mx[k] - r['max_efield']) <= 1e-6 * r['max_efield']
+            n_rays += 1
+        if o['candidate']:
+            n_cand += 1
+            scale = np.max(np.abs(o['V']))
+            for ch in range(5):
+                it = pos[e] * 5 + ch
+                assert np.max(np.abs(tr[off[it]:off[it + 1]] - o['V'][ch])) <= 1e-6 * scale, (e, ch)
+    assert n_cand >= 20 and n_rays > 500
+    trig0, _ = st.simulate_events(*args, dump_traces=True, no_pruning=True)
+    mx0 = st.fetch('ray_max_efield')
+    ratio = mx / mx0
+    assert np.all(ratio <= 2.0 * 1.2) and np.mean(np.abs(ratio - 1) > 1e-3) > 0.9
+    trig_p, _ = st.simulate_events(*args, focusing=True, focusing_limit=2.)
+    assert np.array_equal(trig_p, trig)

@@ -155,3 +155,46 @@ def test_event_groups_vs_reference(name):
             return [dict(sh, k_L=50. if sh['k_L'] is None else sh['k_L']) for sh in _group_showers(g, gi)]
         n_without = sum(len(so.simulate_event_group(filled(gi), st, g['ice'], vrms, vrms_e)['rays']) for gi in range(40))
         assert n_without > g['ev_n_rays'][:40].sum()
+
+
+def test_focusing_chain_vs_reference():
+    """propagation.focusing = True through the reference's whole chain (tests/golden/chain_N256_focus.npz).  The factor is
+    a finite difference of two launch angles over 1 cm, so the reference's own first-root noise (1e-7 in C0) shows at the
+    1e-2 level for that root (tests/test_oracle_golden.py::test_focusing_vs_reference): amplitudes are compared at 3e-2
+    (90 % of the rays within 1e-4), decisions wherever the event is not within that margin of a cut."""
+    g = golden('chain_N256_focus.npz')
+    assert bool(g['focusing'])
+    st = _station(g)
+    ice = g['ice']
+    vrms, vrms_e = so.vrms_from_filters(st.fs)
+    n_checked = n_cand = n_dec = 0
+    rel_all = []
+    for ev in range(len(g['vertex'])):
+        k_L = None if np.isnan(g['ev_k_L'][ev]) else float(g['ev_k_L'][ev])
+        sel = np.where(g['ray_event'] == ev)[0]
+        if str(g['shower_type'][ev]) == 'EM' and k_L is None:
+            continue
+        o = so.simulate_event(g['vertex'][ev], g['zenith'][ev], g['azimuth'][ev], g['energy'][ev], str(g['shower_type'][ev]),
+                              k_L, st, ice, vrms, vrms_e, focusing=True, focusing_limit=float(g['focusing_limit']))
+        if len(o['rays']) != len(sel):
+            continue
+        ref_max = g['ray_max_efield'][sel]
+        mine = np.array([r['max_efield'] for r in o['rays']])
+        rel = np.abs(mine - ref_max) / ref_max
+        rel_all += list(rel)
+        assert np.all(rel < 3e-2), (ev, rel)
+        n_checked += len(sel)
+        cut = 2 * vrms_e
+        marginal = np.any(np.abs(ref_max / cut - 1) < 5e-2)
+        if not marginal:
+            assert o['candidate'] == bool(g['ev_candidate'][ev])
+            n_dec += 1
+            if o['candidate']:
+                n_cand += 1
+                mv_ref = g['ev_maxV'][ev]
+                mv = np.max(np.abs(o['V']), axis=1)
+                assert np.all(np.abs(mv - mv_ref) <= 3e-2 * np.max(mv_ref)), ev
+                if np.all(np.abs(mv_ref / (3 * vrms) - 1) > 5e-2):
+                    assert o['triggered'] == bool(g['ev_triggered'][ev])
+    rel_all = np.array(rel_all)
+    assert n_checked > 500 and n_cand >= 15 and n_dec > 150 and np.mean(rel_all < 1e-4) > 0.85
