@@ -240,9 +240,11 @@ def attenuation_on_grid(frequency, fcoarse, att_coarse):
 
 
 # ---- analytic antennas (NuRadioReco/detector/antennapattern.py:1190-1307, :1580-1768) ---------------------------
-def _antenna_rotation(ori):
-    e1 = spherical_to_cartesian(0., 0.)
-    e2 = spherical_to_cartesian(90 * units.deg, 0.)
+def _antenna_rotation(ori, model_ori=(0., 0., 90 * units.deg, 0.)):
+    """antennapattern.py:1190-1216; model_ori = orientation of the pattern's own simulation frame (the analytic models:
+    boresight +z, tine-plane normal +x)"""
+    e1 = spherical_to_cartesian(model_ori[0], model_ori[1])
+    e2 = spherical_to_cartesian(model_ori[2], model_ori[3])
     E = np.array([e1, e2, np.cross(e1, e2)])
     a1 = spherical_to_cartesian(ori[0], ori[1])
     a2 = spherical_to_cartesian(ori[2], ori[3])
@@ -250,7 +252,65 @@ def _antenna_rotation(ori):
     return np.matmul(np.linalg.inv(E), A)
 
 
+def _lerp(x, x0, x1, y0, y1):
+    """interpolate_linear (antennapattern.py:19-59), 'complex' method"""
+    if np.ndim(x0) == 0:
+        return y0 if x0 == x1 else y0 + (y1 - y0) * (x - x0) / (x1 - x0)
+    x = np.asarray(x, float)
+    mask = x0 != x1
+    out = np.array(y0, complex)
+    out[mask] = y0[mask] + (y1[mask] - y0[mask]) * (x[mask] - x0[mask]) / (x1 - x0)[mask]
+    return out
+
+
+def vel_tabulated(tab, freq, theta, phi):
+    """AntennaPattern._get_antenna_response_vectorized_raw (antennapattern.py:1426-1577): tri-linear complex interpolation
+    on the regular (frequency, theta, phi) grid, flat index iF * nT * nP + iP * nT + iT; zero outside the frequency range,
+    (0, 0) outside the angular range.  tab: dict with freqs, thetas, phis, H_theta, H_phi."""
+    fr, th, ph = tab['freqs'], tab['thetas'], tab['phis']
+    nF, nT, nP = len(fr), len(th), len(ph)
+    while phi < ph[0]:
+        phi += 2 * np.pi
+    while phi > ph[-1]:
+        phi -= 2 * np.pi
+    is_equal = lambda a, b: (a == b) if (a == 0 or b == 0) else abs((a - b) / b) < 1e-5   # radiotools.helper.is_equal
+    if is_equal(theta, th[-1]):
+        theta = th[-1]
+    if is_equal(theta, th[0]):
+        theta = th[0]
+    if phi < ph[0] or phi > ph[-1] or theta < th[0] or theta > th[-1]:
+        return np.zeros(len(freq), complex), np.zeros(len(freq), complex)
+    if th[-1] == th[0]:
+        iT0 = iT1 = 0
+    else:
+        u = (theta - th[0]) / (th[-1] - th[0]) * (nT - 1)
+        iT0, iT1 = int(np.floor(u)), int(np.ceil(u))
+    if ph[-1] == ph[0]:
+        iP0 = iP1 = 0
+    else:
+        u = (phi - ph[0]) / (ph[-1] - ph[0]) * (nP - 1)
+        iP0, iP1 = int(np.floor(u)), int(np.ceil(u))
+    u = (freq - fr[0]) / (fr[-1] - fr[0]) * (nF - 1)
+    low, high = freq < fr[0], freq > fr[-1]
+    iF0, iF1 = np.floor(u).astype(int), np.ceil(u).astype(int)
+    iF0[low | high] = 0
+    iF1[low | high] = nF - 1
+    idx = lambda iF, iT, iP: iF * nT * nP + iP * nT + iT
+    out = []
+    for H in (tab['H_theta'], tab['H_phi']):
+        lo = _lerp(theta, th[iT0], th[iT1], _lerp(phi, ph[iP0], ph[iP1], H[idx(iF0, iT0, iP0)], H[idx(iF0, iT0, iP1)]),
+                   _lerp(phi, ph[iP0], ph[iP1], H[idx(iF0, iT1, iP0)], H[idx(iF0, iT1, iP1)]))
+        up = _lerp(theta, th[iT0], th[iT1], _lerp(phi, ph[iP0], ph[iP1], H[idx(iF1, iT0, iP0)], H[idx(iF1, iT0, iP1)]),
+                   _lerp(phi, ph[iP0], ph[iP1], H[idx(iF1, iT1, iP0)], H[idx(iF1, iT1, iP1)]))
+        v = _lerp(freq, fr[iF0], fr[iF1], lo, up)
+        v[low | high] = 0.
+        out.append(v)
+    return out[0], out[1]
+
+
 def vel_raw(model, freq, theta, phi):
+    if isinstance(model, dict):
+        return vel_tabulated(model, freq, theta, phi)
     fmask = freq > 0
     gain = np.ones_like(freq)
     if model == 'analytic_VPol':
@@ -303,7 +363,7 @@ def vel_raw(model, freq, theta, phi):
 
 def antenna_response(model, freq, zenith, azimuth, ori):
     """get_antenna_response_vectorized (:1246-1307) -> (VEL_theta, VEL_phi) in the on-sky basis of the arrival"""
-    rot = _antenna_rotation(ori)
+    rot = _antenna_rotation(ori, model['orientation']) if isinstance(model, dict) else _antenna_rotation(ori)
     inc = np.dot(rot, spherical_to_cartesian(zenith, azimuth).T).T
     theta, phi = cartesian_to_spherical(*inc)
     Vt, Vp = vel_raw(model, freq, theta, phi)
@@ -369,7 +429,7 @@ class Station:
         self.fs = fs
 
     def antenna_of(self, ch):
-        return self.antenna if isinstance(self.antenna, str) else self.antenna[ch]
+        return self.antenna if isinstance(self.antenna, (str, dict)) else self.antenna[ch]
 
 
 def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model='SP1', n_freq=25,

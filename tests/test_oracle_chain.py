@@ -32,7 +32,11 @@ def test_askaryan_reference_golden():
 
 
 def _station(g):
-    return so.Station(g['det_pos'], antenna=str(g['antenna']), orientation=tuple(g['det_orientation']),
+    antenna = str(g['antenna'])
+    if 'tab_freqs' in g:  # tabulated antenna pattern: the (synthetic) table travels inside the fixture
+        antenna = dict(freqs=g['tab_freqs'], thetas=g['tab_thetas'], phis=g['tab_phis'], H_theta=g['tab_H_theta'],
+                       H_phi=g['tab_H_phi'], orientation=g['tab_orientation'])
+    return so.Station(g['det_pos'], antenna=antenna, orientation=tuple(g['det_orientation']),
                       cable_delay=g['cable_delay'], n_samples=int(g['N']), fs=float(g['fs']))
 
 
@@ -49,7 +53,7 @@ def _rays_with_reference_launch_parameters(g, ev, st, ice):
     return rays, sel
 
 
-@pytest.mark.parametrize('name', ['N256', 'N256_hpol', 'N256_lpda', 'N4096'])
+@pytest.mark.parametrize('name', ['N256', 'N256_hpol', 'N256_lpda', 'N256_tab', 'N4096'])
 def test_chain_vs_reference(name):
     g = golden('chain_%s.npz' % name)
     st = _station(g)

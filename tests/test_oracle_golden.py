@@ -181,3 +181,22 @@ def test_gl3_attenuation_vs_reference():
         assert np.max(np.abs(att - ref) / ref) < 1e-10, s
         n += len(sel)
     assert n == int(g['n_sol'].sum()) and n > 200
+
+
+def _table_of(g):
+    return dict(freqs=g['tab_freqs'], thetas=g['tab_thetas'], phis=g['tab_phis'], H_theta=g['tab_H_theta'],
+                H_phi=g['tab_H_phi'], orientation=g['tab_orientation'])
+
+
+def test_tabulated_antenna_response_vs_reference():
+    """Tabulated vector effective lengths (tri-linear complex interpolation, orientation handling) against the
+    reference's AntennaPattern on a synthetic table: 5 antenna orientations x 16 arrival directions x 751 frequencies."""
+    from oracle import spectral_oracle as so
+    g = golden('chain_N256_tab.npz')
+    tab = _table_of(g)
+    scale = np.max(np.abs(g['resp']))
+    for io, ori in enumerate(g['resp_oris']):
+        for idr, (zen, az) in enumerate(g['resp_dirs']):
+            vt, vp = so.antenna_response(tab, g['resp_fgrid'], zen, az, ori)
+            assert np.max(np.abs(vt - g['resp'][io, idr, 0])) <= 1e-12 * scale, (io, idr)
+            assert np.max(np.abs(vp - g['resp'][io, idr, 1])) <= 1e-12 * scale, (io, idr)
