@@ -49,8 +49,24 @@ extern "C" {
 #define NRHIP_ANT_VPOL 0
 #define NRHIP_ANT_HPOL 1
 #define NRHIP_ANT_LPDA 2   /* analytic_LPDA (antennapattern.py:1676-1713): both VEL components, three phase regimes */
+#define NRHIP_ANT_TABLE 3  /* tabulated pattern (AntennaPattern, antennapattern.py:1338-1577): nrhip_antenna_table */
 
 typedef struct nrhip_ctx nrhip_ctx;
+
+/* A tabulated vector effective length on a regular (frequency, theta, phi) grid, the content of the reference's antenna
+ * pickles (get_pickle_antenna_response, antennapattern.py:540-632): tri-linear complex interpolation
+ * (_get_antenna_response_vectorized_raw :1426-1577), zero outside the frequency range.  Flat index of the complex
+ * tables: iF * n_theta * n_phi + iP * n_theta + iT; values interleaved (re, im).  orientation: boresight (theta, phi) and
+ * tine-plane normal (theta, phi) of the frame the table was simulated in (:1190-1216).  HOST pointers (copied).     */
+typedef struct {
+    int32_t n_freq, n_theta, n_phi;
+    const double* freqs;      /* [n_freq] ascending, equidistant [GHz] */
+    const double* thetas;     /* [n_theta] ascending, equidistant [rad] */
+    const double* phis;       /* [n_phi] ascending, equidistant [rad] */
+    const double* vel_theta;  /* [n_freq * n_theta * n_phi][2] */
+    const double* vel_phi;
+    double orientation[4];
+} nrhip_antenna_table;
 
 /* ---- context -------------------------------------------------------------------------------------
  * Stands in for constructing `ray_tracing(medium, attenuation_model, ...)`
@@ -163,6 +179,11 @@ typedef struct {
        (analog=True) + freqs), NRHIP_FILTER_ABS its modulus (butterabs), NRHIP_FILTER_RECTANGULAR pass band
        filter_b[0] <= f <= filter_b[1] (signal_processing.get_filter_response :237-333) */
     const int32_t* filter_kind;
+    /* tabulated antenna patterns: channels with antenna_model == NRHIP_ANT_TABLE use antenna_tables[antenna_table_index[c]].
+       Their voltages are computed per ray on the event's L grid (chirp-z kernel), without the pruning bounds.       */
+    int32_t n_antenna_tables;
+    const nrhip_antenna_table* antenna_tables;
+    const int32_t* antenna_table_index; /* [n_channels] or NULL */
 } nrhip_station_desc;
 #define NRHIP_FILTER_RATIONAL 0
 #define NRHIP_FILTER_ABS 1

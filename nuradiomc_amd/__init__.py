@@ -2,7 +2,7 @@
 Askaryan emission -> antenna/amplifier response), host side in Python over the libnrhip.so C ABI."""
 from .context import Context, ATTENUATION_MODEL_TO_INT  # noqa: F401
 from ._lib import NrhipError, LIB_PATH  # noqa: F401
-from .station import Station  # noqa: F401
+from .station import Station, TabulatedAntenna  # noqa: F401
 from . import filters  # noqa: F401
 
 __version__ = "0.1.0"

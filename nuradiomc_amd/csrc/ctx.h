@@ -49,7 +49,8 @@ struct nrhip_station {
     nrhip::StationDev dev;
     nrhip::FilterSet filters;
     std::vector<double> h_pos, h_cable;
-    DevArray d_pos, d_cable, d_model, d_rot, d_rot_inv, d_fc, d_lnf, d_invl, d_fpow, d_seg, d_attbin;
+    DevArray d_pos, d_cable, d_model, d_rot, d_rot_inv, d_fc, d_lnf, d_invl, d_fpow, d_seg, d_attbin, d_anttabs, d_anttab_index;
+    std::vector<DevArray> d_tabdata;  // arrays of the tabulated antenna patterns
     // workspace of the last simulated chunk (kept for nrhip_sim_fetch and reused between calls)
     std::map<std::string, DevArray> ws;
     std::map<std::string, size_t> ws_bytes;  // valid bytes of the last chunk

@@ -104,12 +104,33 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     double E[9] = {e1[0], e1[1], e1[2], e2[0], e2[1], e2[2], e3[0], e3[1], e3[2]}, Ei[9];
     if (!inv3(E, Ei)) { delete s; return nrhip_fail_msg("nrhip_station_create: singular antenna model frame"); }
     for (int c = 0; c < n; c++) {
-        if (d->antenna_model[c] != NRHIP_ANT_VPOL && d->antenna_model[c] != NRHIP_ANT_HPOL &&
-            d->antenna_model[c] != NRHIP_ANT_LPDA) {
+        const int am = d->antenna_model[c];
+        if (am != NRHIP_ANT_VPOL && am != NRHIP_ANT_HPOL && am != NRHIP_ANT_LPDA && am != NRHIP_ANT_TABLE) {
             delete s;
-            return nrhip_fail_msg("nrhip_station_create: antenna model not implemented (analytic_VPol, analytic_HPol, analytic_LPDA)");
+            return nrhip_fail_msg("nrhip_station_create: antenna model not implemented (analytic_VPol, analytic_HPol, analytic_LPDA, tabulated)");
         }
-        tab_mask |= d->antenna_model[c] == NRHIP_ANT_LPDA ? 0x1c : (1 << d->antenna_model[c]);
+        if (am == NRHIP_ANT_TABLE) {
+            if (!d->antenna_table_index || !d->antenna_tables || d->antenna_table_index[c] < 0 ||
+                d->antenna_table_index[c] >= d->n_antenna_tables) {
+                delete s;
+                return nrhip_fail_msg("nrhip_station_create: tabulated antenna without a valid table index");
+            }
+            // the table's own simulation frame (antennapattern.py:1190-1201)
+            const double* mo = d->antenna_tables[d->antenna_table_index[c]].orientation;
+            double m1[3], m2[3], m3[3];
+            sph2cart_h(mo[0], mo[1], m1);
+            sph2cart_h(mo[2], mo[3], m2);
+            cross_h(m1, m2, m3);
+            if (std::sqrt(m3[0] * m3[0] + m3[1] * m3[1] + m3[2] * m3[2]) < 0.9) {
+                delete s;
+                return nrhip_fail_msg("orientation of antenna not properly defined in WIPL-D orientation file");
+            }
+            double Em[9] = {m1[0], m1[1], m1[2], m2[0], m2[1], m2[2], m3[0], m3[1], m3[2]};
+            if (!inv3(Em, Ei)) { delete s; return nrhip_fail_msg("nrhip_station_create: singular antenna model frame"); }
+        } else {
+            inv3(E, Ei);
+            tab_mask |= am == NRHIP_ANT_LPDA ? 0x1c : (1 << am);
+        }
         const double* o = d->orientation + 4 * c;
         double a1[3], a2[3], a3[3];
         sph2cart_h(o[0], o[1], a1);
@@ -163,8 +184,42 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
         n_bins = d->att_bound_n_bins;
         if (upload(ctx, s->d_attbin, d->att_bound_bin_inv_length, (size_t)n_bins * d->n_att_freq)) { delete s; return -1; }
     }
+    // tabulated antenna patterns -> HBM
+    std::vector<AntTabDev> tabs(std::max(d->n_antenna_tables, 0));
+    int max_tab_freq = 0;
+    for (int t = 0; t < (int)tabs.size(); t++) {
+        const nrhip_antenna_table& a = d->antenna_tables[t];
+        if (a.n_freq < 2 || a.n_theta < 1 || a.n_phi < 1 || !a.freqs || !a.thetas || !a.phis || !a.vel_theta || !a.vel_phi) {
+            delete s;
+            return nrhip_fail_msg("nrhip_station_create: malformed antenna table");
+        }
+        const size_t nv = (size_t)a.n_freq * a.n_theta * a.n_phi;
+        s->d_tabdata.resize(s->d_tabdata.size() + 5);
+        DevArray* da = &s->d_tabdata[s->d_tabdata.size() - 5];
+        if (upload(ctx, da[0], a.freqs, a.n_freq) || upload(ctx, da[1], a.thetas, a.n_theta) || upload(ctx, da[2], a.phis, a.n_phi) ||
+            upload(ctx, da[3], a.vel_theta, 2 * nv) || upload(ctx, da[4], a.vel_phi, 2 * nv)) {
+            delete s;
+            return -1;
+        }
+        tabs[t] = AntTabDev{a.n_freq, a.n_theta, a.n_phi, da[0].as<double>(), da[1].as<double>(), da[2].as<double>(),
+                            da[3].as<double2>(), da[4].as<double2>()};
+        max_tab_freq = std::max(max_tab_freq, a.n_freq);
+    }
+    std::vector<int> tab_index(n, 0);
+    if (d->antenna_table_index)
+        for (int c = 0; c < n; c++) tab_index[c] = d->antenna_model[c] == NRHIP_ANT_TABLE ? d->antenna_table_index[c] : 0;
+    if (upload(ctx, s->d_anttab_index, tab_index.data(), n) ||
+        (!tabs.empty() && upload(ctx, s->d_anttabs, tabs.data(), tabs.size()))) {
+        delete s;
+        return -1;
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     StationDev& v = s->dev;
+    bool any_tab = false;
+    for (int c = 0; c < n; c++) any_tab |= d->antenna_model[c] == NRHIP_ANT_TABLE;
+    v.ant_tabs = any_tab ? s->d_anttabs.as<AntTabDev>() : nullptr;
+    v.ant_tab_index = s->d_anttab_index.as<int>();
+    v.max_tab_freq = max_tab_freq;
     v.n_att_bins = n_bins;
     v.att_bin_width = n_bins ? d->att_bound_bin_width : 0.;
     v.att_bin_inv = n_bins ? s->d_attbin.as<double>() : nullptr;
@@ -215,7 +270,8 @@ void nrhip_station_destroy(nrhip_station* s)
     for (auto& e : s->evt) if (e) (void)hipEventDestroy(e);
     s->d_pos.release(); s->d_cable.release(); s->d_model.release();
     s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release(); s->d_lnf.release(); s->d_invl.release();
-    s->d_fpow.release(); s->d_seg.release(); s->d_attbin.release();
+    s->d_fpow.release(); s->d_seg.release(); s->d_attbin.release(); s->d_anttabs.release(); s->d_anttab_index.release();
+    for (auto& a : s->d_tabdata) a.release();
     delete s;
 }
 
@@ -354,6 +410,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     NEED(w.az = WS("ray_azimuth", double, nr));
     NEED(w.vel_T = WS("ray_vel_T", double, 4 * nr));
     NEED(w.theta_ant = WS("ray_theta_ant", double, nr));
+    NEED(w.phi_ant = WS("ray_phi_ant", double, nr));
     NEED(w.vfac_t = WS("ray_vfac_theta", double, nr));
     NEED(w.vfac_p = WS("ray_vfac_phi", double, nr));
     NEED(w.tab = WS("ray_antenna_table", int, nr));
@@ -478,6 +535,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     HIPCHK(hipMemsetAsync(lflag, 0, sizeof(int) * (n_half + 1), sm));
     HIPCHK(hipMemsetAsync(d_ncr, 0, 2 * sizeof(long long), sm));
     launch_candidate_flags(sm, (int)n_groups, n_half, ev, cflag, lflag, d_ncr);
+    if (cfg->amp_per_ray && sd.ant_tabs)
+        return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray is not available with tabulated antenna patterns");
     if (cfg->amp_per_ray)  // the per-efield voltages live on the N grid: tables of "L = N" are built with the others
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(lflag + sd.N / 2), 1, 1, sm));
     launch_exclusive_scan(sm, n_groups + 1, cflag, coff, ctmp);
@@ -548,6 +607,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         trg.w_coinc = std::max(1, (int)std::lrint(cfg->coinc_window * sd.fs));
         if (trg.coincidence() && (maxL > FFT_MAX || sd.N > FFT_MAX / 2 || getenv("NRHIP_CHANNEL_CZT")))
             return nrhip_fail_msg("nrhip_simulate_events: high/low and coincidence triggers need traces of at most 8192 samples");
+        if (trg.coincidence() && sd.ant_tabs)
+            return nrhip_fail_msg("nrhip_simulate_events: high/low and coincidence triggers are not available with tabulated antenna patterns");
         ChannelOut co;
         NEED(co.maxV = WS("item_maxV", double, n_items));
         co.trigger_bin = trigger_bin;
@@ -579,9 +640,11 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(conv_acc = WS("conv_table_sum", double2, (sd.tab_mask & 0x1c) ? (size_t)channel_grid_blocks() * FFT_MAX : 1));
         int* coinc_cnt;
         NEED(coinc_cnt = WS("coincidence_count", int, trg.coincidence() ? (size_t)channel_grid_blocks() * FFT_MAX : 1));
+        double2* tab_nodes = nullptr;  // per block: the angular interpolation of a tabulated pattern at its frequency nodes
+        if (sd.ant_tabs) NEED(tab_nodes = WS("antenna_table_nodes", double2, (size_t)channel_grid_blocks() * 2 * sd.max_tab_freq));
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, cfg->askaryan_model, trg,
                        ctx->twiddle, ctx->w16, tab, scratch, co, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, maxL, it_need,
-                       it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count);
+                       it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes);
         LCHK("channel");
         MARK(8);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here

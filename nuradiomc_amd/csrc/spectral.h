@@ -14,6 +14,13 @@
 
 namespace nrhip {
 
+// tabulated antenna pattern in HBM (nrhip_antenna_table)
+struct AntTabDev {
+    int nF, nT, nP;
+    const double *fr, *th, *ph;
+    const double2 *vt, *vp;  // flat index iF * nT * nP + iP * nT + iT
+};
+
 // station description in HBM (small, read through the scalar / L1 caches)
 struct StationDev {
     int n_ch, N, n_fc;
@@ -21,6 +28,9 @@ struct StationDev {
     const double* pos;        // [n_ch][3]
     const double* cable;      // [n_ch]
     const int* ant_model;     // [n_ch]   0 analytic_VPol, 1 analytic_HPol, 2 analytic_LPDA
+    const AntTabDev* ant_tabs;   // tabulated patterns (ant_model 3): table of channel c = ant_tabs[ant_tab_index[c]]
+    const int* ant_tab_index;    // [n_ch]
+    int max_tab_freq;            // largest n_freq of the tables (scratch sizing)
     int tab_mask;             // bit t set: antenna table t (NRHIP_N_ANT_TAB) is needed by some channel
     const double* rot;        // [n_ch][9] inv(E) A   (antennapattern.py:1190-1216)
     const double* rot_inv;    // [n_ch][9]
@@ -62,7 +72,7 @@ struct RayWork {
     double2 *r_theta, *r_phi;
     double *zen, *az;
     double *vel_T;       // [n][4]
-    double *theta_ant;
+    double *theta_ant, *phi_ant;
     double *vfac_t, *vfac_p;  // [n] weight of the on-sky eTheta / ePhi field in the channel voltage (direction + frame)
     int *tab;            // [n] antenna response table of the ray (0 VPol, 1 HPol, 2..4 LPDA phase regime)
     double *att;         // [n][n_fc]
@@ -151,7 +161,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
-                    int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count);
+                    int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes);
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
                          const int* len_index_N, double* max_env, double* signal_time);

@@ -104,6 +104,79 @@ __device__ inline void antenna_factors(int model, const double T[4], double th_a
     *vfac_p = T[2] * d_theta + T[3] * d_phi;
 }
 
+// ---- tabulated antenna patterns (AntennaPattern._get_antenna_response_vectorized_raw, antennapattern.py:1426-1577) ----
+__device__ inline double2 clerp(double x, double x0, double x1, double2 y0, double2 y1)  // interpolate_linear, 'complex'
+{
+    if (x0 == x1) return y0;
+    const double t = (x - x0) / (x1 - x0);
+    // y0 + (y1 - y0) * (x - x0) / (x1 - x0), evaluated left to right like the reference
+    double2 d = csub(y1, y0);
+    d = cscale(d, x - x0);
+    d = make_double2(d.x / (x1 - x0), d.y / (x1 - x0));
+    (void)t;
+    return cadd(y0, d);
+}
+
+struct TabAngles {
+    bool ok;            // arrival direction inside the table's angular range
+    int iT0, iT1, iP0, iP1;
+    double theta, phi;  // after the reference's clamping / wrapping
+};
+
+__device__ inline TabAngles tab_angles(const AntTabDev& t, double theta, double phi)
+{
+    TabAngles a;
+    const double th_lo = t.th[0], th_hi = t.th[t.nT - 1], ph_lo = t.ph[0], ph_hi = t.ph[t.nP - 1];
+    while (phi < ph_lo) phi += 2 * M_PI;
+    while (phi > ph_hi) phi -= 2 * M_PI;
+    // radiotools.helper.is_equal(a, b, rel_precision = 1e-5)
+    auto is_equal = [](double u, double v) { return (u == 0 || v == 0) ? (u == v) : (fabs((u - v) / v) < 1e-5); };
+    if (is_equal(theta, th_hi)) theta = th_hi;
+    if (is_equal(theta, th_lo)) theta = th_lo;
+    a.ok = !(phi < ph_lo || phi > ph_hi || theta < th_lo || theta > th_hi);
+    a.theta = theta;
+    a.phi = phi;
+    a.iT0 = a.iT1 = a.iP0 = a.iP1 = 0;
+    if (a.ok) {
+        if (th_hi != th_lo) {
+            const double u = (theta - th_lo) / (th_hi - th_lo) * (t.nT - 1);
+            a.iT0 = (int)floor(u);
+            a.iT1 = (int)ceil(u);
+        }
+        if (ph_hi != ph_lo) {
+            const double u = (phi - ph_lo) / (ph_hi - ph_lo) * (t.nP - 1);
+            a.iP0 = (int)floor(u);
+            a.iP1 = (int)ceil(u);
+        }
+    }
+    return a;
+}
+
+// the angular part of the interpolation at frequency node iF: (VEL_theta, VEL_phi) of the table frame
+__device__ inline void tab_node(const AntTabDev& t, const TabAngles& a, int iF, double2* vt, double2* vp)
+{
+    const long base = (long)iF * t.nT * t.nP;
+    const long i00 = base + (long)a.iP0 * t.nT + a.iT0, i01 = base + (long)a.iP1 * t.nT + a.iT0;
+    const long i10 = base + (long)a.iP0 * t.nT + a.iT1, i11 = base + (long)a.iP1 * t.nT + a.iT1;
+    const double p0 = t.ph[a.iP0], p1 = t.ph[a.iP1], t0 = t.th[a.iT0], t1 = t.th[a.iT1];
+    *vt = clerp(a.theta, t0, t1, clerp(a.phi, p0, p1, t.vt[i00], t.vt[i01]), clerp(a.phi, p0, p1, t.vt[i10], t.vt[i11]));
+    *vp = clerp(a.theta, t0, t1, clerp(a.phi, p0, p1, t.vp[i00], t.vp[i01]), clerp(a.phi, p0, p1, t.vp[i10], t.vp[i11]));
+}
+
+// response at frequency f from the per-node angular results (nodes[0..nF) theta, nodes[nF..2nF) phi); zero out of range
+__device__ inline void tab_response(const AntTabDev& t, const double2* __restrict__ nodes, double f, double2* vt, double2* vp)
+{
+    const double f_lo = t.fr[0], f_hi = t.fr[t.nF - 1];
+    if (f < f_lo || f > f_hi) {
+        *vt = *vp = make_double2(0., 0.);
+        return;
+    }
+    const double u = (f - f_lo) / (f_hi - f_lo) * (t.nF - 1);
+    const int i0 = (int)floor(u), i1 = (int)ceil(u);
+    *vt = clerp(f, t.fr[i0], t.fr[i1], nodes[i0], nodes[i1]);
+    *vp = clerp(f, t.fr[i0], t.fr[i1], nodes[t.nF + i0], nodes[t.nF + i1]);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // ray selection: viewing angle + delta_C cut  (simulation.py:187-206)
 // ---------------------------------------------------------------------------------------------------------
@@ -373,7 +446,13 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
     antenna_frame(zen, az, st.rot + 9 * ch, st.rot_inv + 9 * ch, T, &th_a, &ph_a);
     for (int c = 0; c < 4; c++) w.vel_T[4 * (long)r + c] = T[c];
     w.theta_ant[r] = th_a;
-    antenna_factors(st.ant_model[ch], T, th_a, ph_a, &w.vfac_t[r], &w.vfac_p[r], &w.tab[r]);
+    w.phi_ant[r] = ph_a;
+    if (st.ant_model[ch] == 3) {  // tabulated pattern: frequency-dependent direction response, evaluated per ray later
+        w.vfac_t[r] = w.vfac_p[r] = 0.;
+        w.tab[r] = 0;
+    } else {
+        antenna_factors(st.ant_model[ch], T, th_a, ph_a, &w.vfac_t[r], &w.vfac_p[r], &w.tab[r]);
+    }
     w.slot[r] = slot;
     AskaryanConst ac = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r], w.R[r],
                                       evin.k_L[e]);
@@ -1267,7 +1346,7 @@ channel_prefilter_kernel(int n_items, const int* __restrict__ item_event, RayWor
     if (item >= n_items) return;
     const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
     const int L = ev.L[e], il = ev_len_index[e];
-    if (L > FFT_MAX) { need[item] = 0; return; }
+    if (L > FFT_MAX || st.ant_model[ch] == 3) { need[item] = 0; return; }  // chirp-z kernel: long traces, tabulated patterns
     int flag = 1;
     if (!exact) {
         const int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
@@ -1555,7 +1634,7 @@ __global__ void __launch_bounds__(512)
 channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                const int* __restrict__ ev_len_index, StationDev st, FilterSet fl, int ask_model, double threshold,
                const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
-               ChannelOut out, int exact, int skip_upto)
+               ChannelOut out, int exact, int skip_upto, double2* __restrict__ tab_nodes)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M = FFT_MAX, N = st.N, nh = N / 2;
@@ -1569,7 +1648,9 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
         const int L = ev.L[e], m = L / 2, il = ev_len_index[e];
-        if (L <= skip_upto) continue;  // done by channel_conv_kernel
+        const bool tabulated = (st.ant_model[ch] == 3);
+        if (L <= skip_upto && !tabulated) continue;  // done by channel_conv_kernel
+        double2* nodes = tab_nodes ? tab_nodes + (long)blockIdx.x * 2 * st.max_tab_freq : nullptr;
         const double t_min = ev.t_min[e];
         const double res = 1. / st.fs;
         const double2* Bf = tab.B_fwd + (long)il * M;
@@ -1580,7 +1661,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
         const double2* Ci = tab.Ci + (long)il * FFT_MAX;
         const unsigned LL = (unsigned)L;
         int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
-        if (!exact) {
+        if (!exact && !tabulated) {
             // Cauchy-Schwarz: the channel trace is sum_r vfac_r (e_r (*) h_L), so |V(t)| <= ||h_L||_2 sum_r |vfac_r| ||e_r||_2.
             // If even that cannot reach the threshold nothing of this item needs to be transformed.
             double bnd = 0.;
@@ -1613,8 +1694,20 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
             double rem = start_time - start_bin * res;
             bool shift = !(fabs(rint(rem * st.fs) - rem * st.fs) < 1e-5);
             const double2* vel = tab.vel + ((long)il * NRHIP_N_ANT_TAB + w.tab[r]) * vel_stride;
-            const double Tt = w.vfac_t[r], Tp = w.vfac_p[r];
+            double Tt = w.vfac_t[r], Tp = w.vfac_p[r];
             const double dir = 1.;
+            const double* TT = w.vel_T + 4 * (long)r;
+            const AntTabDev* at = tabulated ? &st.ant_tabs[st.ant_tab_index[ch]] : nullptr;
+            bool tab_ok = false;
+            if (tabulated) {
+                // angular interpolation once per frequency node of the table; the frequency interpolation follows per bin
+                const TabAngles ta = tab_angles(*at, w.theta_ant[r], w.phi_ant[r]);
+                tab_ok = ta.ok;
+                if (ta.ok)
+                    for (int iF = threadIdx.x; iF < at->nF; iF += blockDim.x) tab_node(*at, ta, iF, &nodes[iF], &nodes[at->nF + iF]);
+                Tt = Tp = 1.;  // both on-sky components are transformed
+                __syncthreads();
+            }
             // weight of each on-sky component in the channel voltage; a component below 1e-13 of the other one
             // (e.g. the e_phi response of a vertical dipole, 1e-17 from the rotation round-off) is not transformed
             const double wt = fabs(Tt * w.pol_theta[r]) * cabs2(w.r_theta[r]);
@@ -1652,7 +1745,17 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                     double2 X = cadd(Ee, cmul(Eo, E[2 * k]));                 // exp(-2 pi i k / L)
                     unsigned ks = ((unsigned)k * sbin) % LL;                     // both factors < 2^14
                     X = cmul(X, E[2 * ks]);                                       // exp(-2 pi i k s / L)
-                    double2 v = cmul(cscale(vel[k], vfac), X);
+                    double2 v;
+                    if (tabulated) {
+                        // VEL on the L grid for this ray, rotated to the on-sky basis (T), 5 MHz cut (efieldToVoltageConverter.py:313)
+                        const double f = k * (1.0 / (L * (1. / st.fs)));
+                        double2 vt = make_double2(0., 0.), vp = vt;
+                        if (tab_ok && !(f < 0.005)) tab_response(*at, nodes, f, &vt, &vp);
+                        const double2 coef = comp ? cadd(cscale(vt, TT[2]), cscale(vp, TT[3])) : cadd(cscale(vt, TT[0]), cscale(vp, TT[1]));
+                        v = cmul(coef, X);
+                    } else {
+                        v = cmul(cscale(vel[k], vfac), X);
+                    }
                     acc[k] = cadd(acc[k], v);
                 }
                 __syncthreads();
@@ -2135,7 +2238,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
-                    int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count)
+                    int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes)
 {
     if (n_items <= 0) return;
     set_big_lds();
@@ -2160,11 +2263,11 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                            item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16, tab,
                            ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count);
         skip_upto = FFT_MAX;
-        if (max_length <= FFT_MAX) return;
+        if (max_length <= FFT_MAX && !st.ant_tabs) return;
     }
     size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
     hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
-                       ask_model, trig.threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto);
+                       ask_model, trig.threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto, tab_nodes);
 }
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,

@@ -5,6 +5,7 @@ from . import _lib as L
 from . import filters as flt
 
 ANTENNA_TO_INT = {'analytic_VPol': 0, 'analytic_HPol': 1, 'analytic_LPDA': 2}
+ANTENNA_TABLE = 3   # NRHIP_ANT_TABLE
 ASKARYAN_TO_INT = {'Alvarez2009': 0, 'Alvarez2000': 1, 'ZHS1992': 2}
 SHOWER_TO_INT = {'HAD': 0, 'EM': 1}
 
@@ -18,7 +19,54 @@ class StationDesc(ctypes.Structure):
                 ('att_bound_depth', ctypes.c_double), ('n_filters', ctypes.c_int32),
                 ('filter_nb', L.c_int32_p), ('filter_na', L.c_int32_p), ('filter_b', L.c_double_p),
                 ('filter_a', L.c_double_p), ('att_bound_n_bins', ctypes.c_int32), ('att_bound_bin_width', ctypes.c_double),
-                ('att_bound_bin_inv_length', L.c_double_p), ('filter_kind', L.c_int32_p)]
+                ('att_bound_bin_inv_length', L.c_double_p), ('filter_kind', L.c_int32_p),
+                ('n_antenna_tables', ctypes.c_int32), ('antenna_tables', ctypes.c_void_p),
+                ('antenna_table_index', L.c_int32_p)]
+
+
+class AntennaTable(ctypes.Structure):   # nrhip_antenna_table
+    _fields_ = [('n_freq', ctypes.c_int32), ('n_theta', ctypes.c_int32), ('n_phi', ctypes.c_int32),
+                ('freqs', L.c_double_p), ('thetas', L.c_double_p), ('phis', L.c_double_p),
+                ('vel_theta', L.c_double_p), ('vel_phi', L.c_double_p), ('orientation', ctypes.c_double * 4)]
+
+
+class TabulatedAntenna:
+    """A tabulated antenna pattern (NuRadioReco/detector/antennapattern.py:1338-1424, AntennaPattern): complex vector
+    effective length H_theta / H_phi on a regular (frequency, theta, phi) grid, flat index iF * nT * nP + iP * nT + iT,
+    frequencies in GHz, angles in rad, orientation = (theta, phi, rotation theta, rotation phi) of the frame the
+    pattern was simulated in.  `from_pickle` reads the reference's antenna-model pickle files."""
+
+    def __init__(self, freqs, thetas, phis, H_theta, H_phi, orientation, name='tabulated'):
+        self.name = name
+        self.freqs = np.ascontiguousarray(freqs, float)
+        self.thetas = np.ascontiguousarray(thetas, float)
+        self.phis = np.ascontiguousarray(phis, float)
+        n = len(self.freqs) * len(self.thetas) * len(self.phis)
+        self.H_theta = np.ascontiguousarray(H_theta, complex).reshape(-1)
+        self.H_phi = np.ascontiguousarray(H_phi, complex).reshape(-1)
+        if len(self.H_theta) != n or len(self.H_phi) != n:
+            raise ValueError("antenna table: {} values expected, H_theta has {}, H_phi {}".format(
+                n, len(self.H_theta), len(self.H_phi)))
+        self.orientation = np.ascontiguousarray(orientation, float).reshape(4)
+
+    @classmethod
+    def from_pickle(cls, path, name=None):
+        """antennapattern.py:1362-1365: [orientation_theta, orientation_phi, rotation_theta, rotation_phi, ff, thetas,
+        phis, H_phi, H_theta] with the angles repeated per table entry."""
+        import pickle
+        with open(path, 'rb') as fin:
+            res = pickle.load(fin, encoding='latin1')
+        ot, op, rt, rp, ff, thetas, phis, H_phi, H_theta = res
+        return cls(np.unique(ff), np.unique(thetas), np.unique(phis), H_theta, H_phi, (ot, op, rt, rp),
+                   name=name or str(path))
+
+    def _ctypes(self):
+        t = AntennaTable(len(self.freqs), len(self.thetas), len(self.phis), L.dptr(self.freqs), L.dptr(self.thetas),
+                         L.dptr(self.phis), self.H_theta.view(float).ctypes.data_as(L.c_double_p),
+                         self.H_phi.view(float).ctypes.data_as(L.c_double_p))
+        for i in range(4):
+            t.orientation[i] = self.orientation[i]
+        return t
 
 
 class SimConfig(ctypes.Structure):
@@ -126,11 +174,18 @@ class Station:
         self._lib = L.load()
         pos = L.f64(position).reshape(-1, 3)
         n = len(pos)
-        names = [antenna] * n if isinstance(antenna, str) else list(antenna)
-        for a in names:
-            if a not in ANTENNA_TO_INT:
-                raise NotImplementedError("antenna model {} is not available (analytic_VPol, analytic_HPol, analytic_LPDA)".format(a))
-        model = np.array([ANTENNA_TO_INT[a] for a in names], np.int32)
+        names = [antenna] * n if isinstance(antenna, (str, TabulatedAntenna)) else list(antenna)
+        tables, tab_index = [], np.zeros(n, np.int32)
+        for c, a in enumerate(names):
+            if isinstance(a, TabulatedAntenna):
+                if not any(a is t for t in tables):
+                    tables.append(a)
+                tab_index[c] = [a is t for t in tables].index(True)
+            elif a not in ANTENNA_TO_INT:
+                raise NotImplementedError("antenna model {} is not available (analytic_VPol, analytic_HPol, analytic_LPDA, "
+                                          "or a TabulatedAntenna)".format(a))
+        model = np.array([ANTENNA_TABLE if isinstance(a, TabulatedAntenna) else ANTENNA_TO_INT[a] for a in names], np.int32)
+        ctabs = (AntennaTable * max(len(tables), 1))(*[t._ctypes() for t in tables])
         ori = np.ascontiguousarray(np.broadcast_to(L.f64(orientation), (n, 4)))
         cab = np.ascontiguousarray(np.broadcast_to(L.f64(cable_delay), (n,)))
         self.position, self.antenna, self.orientation, self.cable_delay = pos, names, ori, cab
@@ -165,12 +220,13 @@ class Station:
         idx = np.arange(n_bins)[:, None] * per + np.arange(per + 1)[None, :]
         self.att_bound_bin_inv_length = np.ascontiguousarray(inv[:, idx].min(axis=2).T * (1 - 1e-3))  # [n_bins][n_fc]
         self._keep = (pos, cab, model, ori, self.att_freq, nb, na, fb, fa, self.att_bound_inv_length,
-                      self.att_bound_bin_inv_length, fkind)
+                      self.att_bound_bin_inv_length, fkind, tables, tab_index, ctabs)
         d = StationDesc(n, L.dptr(pos), L.dptr(cab), L.iptr(model), L.dptr(ori), self.n_samples, self.sampling_rate,
                         float(readout_length if readout_length is not None else self.n_samples / self.sampling_rate),
                         float(pre_pulse_time), float(post_pulse_time), len(self.att_freq), L.dptr(self.att_freq),
                         L.dptr(self.att_bound_inv_length), self.att_bound_depth, len(self.filters), L.iptr(nb), L.iptr(na), L.dptr(fb), L.dptr(fa),
-                        n_bins, self.att_bound_bin_width, L.dptr(self.att_bound_bin_inv_length), L.iptr(fkind))
+                        n_bins, self.att_bound_bin_width, L.dptr(self.att_bound_bin_inv_length), L.iptr(fkind),
+                        len(tables), ctypes.cast(ctabs, ctypes.c_void_p), L.iptr(tab_index))
         h = ctypes.c_void_p()
         L.check(self._lib.nrhip_station_create(ctx._h, ctypes.byref(d), ctypes.byref(h)))
         self._h = h

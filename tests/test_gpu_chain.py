@@ -46,8 +46,19 @@ def test_askaryan_spectrum_vs_oracle(gpu_ctx_factory):
         ctx.askaryan_spectrum_batch(1e18, 1.0, 256, 0.5, 'TAU', 1.78, 1000., 'Alvarez2009')
 
 
+def _oracle_antenna(g):
+    if 'tab_freqs' in g:  # tabulated pattern: the synthetic table travels inside the fixture
+        return dict(freqs=g['tab_freqs'], thetas=g['tab_thetas'], phis=g['tab_phis'], H_theta=g['tab_H_theta'],
+                    H_phi=g['tab_H_phi'], orientation=g['tab_orientation'])
+    return str(g['antenna'])
+
+
 def _station(ctx, g):
-    return nuradiomc_amd.Station(ctx, g['det_pos'], antenna=str(g['antenna']), orientation=tuple(g['det_orientation']),
+    antenna = str(g['antenna'])
+    if 'tab_freqs' in g:
+        antenna = nuradiomc_amd.TabulatedAntenna(g['tab_freqs'], g['tab_thetas'], g['tab_phis'], g['tab_H_theta'],
+                                                 g['tab_H_phi'], g['tab_orientation'], name=antenna)
+    return nuradiomc_amd.Station(ctx, g['det_pos'], antenna=antenna, orientation=tuple(g['det_orientation']),
                                  cable_delay=g['cable_delay'], n_samples=int(g['N']), sampling_rate=float(g['fs']),
                                  n_freq=int(g['n_freq']))
 
@@ -65,13 +76,14 @@ def _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=False, dump_traces=
     return g, ctx, st, trig, stats, kL
 
 
-@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N4096', 60)])
+@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N256_tab', 160),
+                                           ('N4096', 60)])
 def test_spectral_stages_vs_oracle_on_identical_rays(gpu_ctx_factory, name, n_events):
     """Feed the ORACLE with the ray tables the GPU produced, so that every later stage sees identical
     (C0, D, T, launch, receive) on both sides: kept rays exact, amplitudes / traces to 1e-6."""
     g, ctx, st, trig, stats, kL = _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=True)
     n_ch = len(g['det_pos'])
-    ost = so.Station(g['det_pos'], antenna=str(g['antenna']), orientation=tuple(g['det_orientation']),
+    ost = so.Station(g['det_pos'], antenna=_oracle_antenna(g), orientation=tuple(g['det_orientation']),
                      cable_delay=g['cable_delay'], n_samples=int(g['N']), fs=float(g['fs']))
     T = {k: st.fetch(k) for k in ('pair_n_sol', 'slot_type', 'slot_C0', 'slot_D', 'slot_T', 'slot_launch', 'slot_receive',
                                   'slot_refl_angle', 'ray_event', 'ray_channel', 'ray_solution', 'ray_view',
@@ -129,7 +141,8 @@ def test_spectral_stages_vs_oracle_on_identical_rays(gpu_ctx_factory, name, n_ev
     assert stats['n_candidate_events'] == n_cand and stats['n_triggered'] == trig.sum()
 
 
-@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N4096', 120)])
+@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N256_tab', 160),
+                                           ('N4096', 120)])
 def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
     """End to end (GPU ray tracing included) against the reference's own outputs.  The reference's first ray
     root carries ~1e-7 of iteration noise (see tests/test_oracle_golden.py), which moves arrival times by up to
@@ -153,7 +166,7 @@ def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
             assert np.all(np.abs(maxV[i] - ref) <= 5e-3 * np.max(ref)), ev
 
 
-@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_lpda', 200), ('N4096', 120)])
+@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_lpda', 200), ('N256_tab', 160), ('N4096', 120)])
 def test_pruning_changes_no_result(gpu_ctx_factory, name, n_events):
     """Skipping rays of events that provably cannot pass the candidate cut (un-attenuated sum-of-magnitudes bound)
     and skipping transforms whose bound is below the cut must leave every decision and every trace unchanged."""
