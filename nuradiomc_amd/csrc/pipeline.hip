@@ -744,8 +744,10 @@ int nrhip_efield_to_voltage(nrhip_ctx* ctx, nrhip_station* st, int32_t n_efields
     LCHK("length_tables");
     double2* scratch;
     NEED(scratch = WS("channel_scratch", double2, (size_t)std::max(sd.n_ch, channel_grid_blocks()) * NRHIP_SPEC_STRIDE));
+    double2* tab_nodes = nullptr;
+    if (sd.ant_tabs) NEED(tab_nodes = WS("antenna_table_nodes", double2, (size_t)sd.n_ch * 2 * sd.max_tab_freq));
     launch_efield_channel(sm, n_efields, d_tr, d_t0, d_zen, d_az, d_ch, sd, L, t_min, apply_filters, ctx->twiddle, tab,
-                          scratch, d_V);
+                          scratch, d_V, tab_nodes);
     LCHK("efield_channel");
     HIPCHK(hipMemcpyAsync(V, d_V, sizeof(double) * sd.n_ch * L, hipMemcpyDeviceToHost, sm));
     HIPCHK(hipStreamSynchronize(sm));

@@ -167,7 +167,7 @@ void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const
                          const int* len_index_N, double* max_env, double* signal_time);
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,
-                           const double2* tw, const LengthTables& tab, double2* scratch, double* V);
+                           const double2* tw, const LengthTables& tab, double2* scratch, double* V, double2* tab_nodes);
 void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const double* theta, const int* type,
                               const double* n_index, const double* R, const double* k_L, int model, int N, double dt,
                               double2* spec);

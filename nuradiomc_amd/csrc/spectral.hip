@@ -1914,7 +1914,7 @@ efield_channel_kernel(int n_efields, const double* __restrict__ traces, const do
                       const double* __restrict__ zenith, const double* __restrict__ azimuth,
                       const int* __restrict__ channel, StationDev st, int L, double t_min, int apply_filter,
                       const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
-                      double* __restrict__ V)
+                      double* __restrict__ V, double2* __restrict__ tab_nodes)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M = FFT_MAX, N = st.N, nh = N / 2, m = L / 2;
@@ -1924,8 +1924,11 @@ efield_channel_kernel(int n_efields, const double* __restrict__ traces, const do
     const double2 *Bf = tab.B_fwd, *Bi = tab.B_inv, *E = tab.E, *Hf = tab.H, *Cf = tab.Cf, *Ci = tab.Ci;
     const unsigned LL = (unsigned)L;
     const double res = 1. / st.fs;
-    __shared__ double sT[4], s_th, s_vt, s_vp;
+    __shared__ double sT[4], s_th, s_ph, s_vt, s_vp;
     __shared__ int s_tab;
+    const bool tabulated = (st.ant_model[ch] == 3);
+    const AntTabDev* at = tabulated ? &st.ant_tabs[st.ant_tab_index[ch]] : nullptr;
+    double2* nodes = tabulated ? tab_nodes + (long)blockIdx.x * 2 * st.max_tab_freq : nullptr;
     for (int k = threadIdx.x; k <= m; k += blockDim.x) acc[k] = make_double2(0., 0.);
     __syncthreads();
     int n_used = 0;
@@ -1935,9 +1938,19 @@ efield_channel_kernel(int n_efields, const double* __restrict__ traces, const do
         if (threadIdx.x == 0) {
             double ph_a;
             antenna_frame(zenith[e], azimuth[e], st.rot + 9 * ch, st.rot_inv + 9 * ch, sT, &s_th, &ph_a);
-            antenna_factors(st.ant_model[ch], sT, s_th, ph_a, &s_vt, &s_vp, &s_tab);
+            s_ph = ph_a;
+            if (tabulated) { s_vt = s_vp = 1.; s_tab = 0; }
+            else antenna_factors(st.ant_model[ch], sT, s_th, ph_a, &s_vt, &s_vp, &s_tab);
         }
         __syncthreads();
+        bool tab_ok = false;
+        if (tabulated) {
+            const TabAngles ta = tab_angles(*at, s_th, s_ph);
+            tab_ok = ta.ok;
+            if (ta.ok)
+                for (int iF = threadIdx.x; iF < at->nF; iF += blockDim.x) tab_node(*at, ta, iF, &nodes[iF], &nodes[at->nF + iF]);
+            __syncthreads();
+        }
         double start_time = t0[e] - t_min + st.cable[ch] + 0;
         long start_bin = (long)rint(start_time / res);
         const unsigned sbin = (unsigned)(((start_bin % (long)L) + (long)L) % (long)L);
@@ -2006,7 +2019,15 @@ efield_channel_kernel(int n_efields, const double* __restrict__ traces, const do
                 double2 X = cadd(Ee, cmul(Eo, E[2 * k]));
                 unsigned ks = ((unsigned)k * sbin) % LL;
                 X = cmul(X, E[2 * ks]);
-                acc[k] = cadd(acc[k], cmul(cscale(vel[k], vfac), X));
+                if (tabulated) {
+                    const double f = k * (1.0 / (L * res));
+                    double2 vt = make_double2(0., 0.), vp = vt;
+                    if (tab_ok && !(f < 0.005)) tab_response(*at, nodes, f, &vt, &vp);
+                    const double2 coef = comp ? cadd(cscale(vt, sT[2]), cscale(vp, sT[3])) : cadd(cscale(vt, sT[0]), cscale(vp, sT[1]));
+                    acc[k] = cadd(acc[k], cmul(coef, X));
+                } else {
+                    acc[k] = cadd(acc[k], cmul(cscale(vel[k], vfac), X));
+                }
             }
             __syncthreads();
         }
@@ -2282,12 +2303,12 @@ void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const
 }
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,
-                           const double2* tw, const LengthTables& tab, double2* scratch, double* V)
+                           const double2* tw, const LengthTables& tab, double2* scratch, double* V, double2* tab_nodes)
 {
     set_big_lds();
     int nh = st.N / 2;
     hipLaunchKernelGGL(efield_channel_kernel, dim3(st.n_ch), dim3(512), (size_t)FFT_MAX * 16, s, n_efields, traces, t0, zen, az,
-                       channel, st, L, t_min, apply_filter, tw, tab, scratch, ilog2(nh), V);
+                       channel, st, L, t_min, apply_filter, tw, tab, scratch, ilog2(nh), V, tab_nodes);
 }
 void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const double* theta, const int* type,
                               const double* n_index, const double* R, const double* k_L, int model, int N, double dt,

@@ -26,8 +26,11 @@ def _efield_param(ef, name):
 
 
 class efieldToVoltageConverter:
-    def __init__(self, log_level=logging.NOTSET, ctx=None, channel_factory=None):
+    def __init__(self, log_level=logging.NOTSET, ctx=None, channel_factory=None, antenna_models=None):
+        """antenna_models: {name the detector description uses: TabulatedAntenna} for the tabulated patterns (the
+        reference's AntennaPatternProvider loads them from its antenna-model directory; analytic names need no entry)"""
         self.__t = 0
+        self._antenna_models = dict(antenna_models or {})
         self._ctx = ctx
         self._channel_factory = channel_factory
         self._stations = {}
@@ -58,7 +61,8 @@ class efieldToVoltageConverter:
                 self._ctx = Context((1.78, 0.423, 77.), 'SP1', device=0)  # the ice model is irrelevant here
             pos = [np.asarray(det.get_relative_position(station_id, c), float) for c in channel_ids]
             self._stations[key] = Station(
-                self._ctx, pos, antenna=[det.get_antenna_model(station_id, c, None) for c in channel_ids],
+                self._ctx, pos, antenna=[self._antenna_models.get(m, m) for m in
+                                         (det.get_antenna_model(station_id, c, None) for c in channel_ids)],
                 orientation=[det.get_antenna_orientation(station_id, c) for c in channel_ids],
                 cable_delay=[det.get_cable_delay(station_id, c) for c in channel_ids], n_samples=n_samples,
                 sampling_rate=fs, pre_pulse_time=self.__pre_pulse_time, post_pulse_time=self.__post_pulse_time,

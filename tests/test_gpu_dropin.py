@@ -165,7 +165,8 @@ class _FakeDet:
 
 
 @pytest.mark.parametrize('antenna,cable', [('analytic_VPol', [0.] * 5), ('analytic_HPol', [0., 3.3, 7.77, 12.2, 19.8]),
-                                           ('analytic_LPDA', [0., 0., 4.4, 0., 1.1])])
+                                           ('analytic_LPDA', [0., 0., 4.4, 0., 1.1]),
+                                           ('synthetic_table_v1', [0., 2.2, 0., 0., 5.5])])
 def test_efieldToVoltageConverter_module(antenna, cable):
     """The module-level drop-in on arbitrary ElectricField-like objects vs the oracle's restatement of
     efieldToVoltageConverter.run (no filter), incl. the sub-sample Fourier shift (unequal cable delays)."""
@@ -174,9 +175,17 @@ def test_efieldToVoltageConverter_module(antenna, cable):
     N, fs = 256, 2.0
     pos = np.array([[0., 0., -100. - i] for i in range(5)])
     ice = (1.78, 0.423, 77.)
-    ost = so.Station(pos, antenna=antenna, cable_delay=cable, n_samples=N, fs=fs)
+    import nuradiomc_amd
+    models, o_antenna = None, antenna
+    if antenna == 'synthetic_table_v1':  # the table of tests/golden/chain_N256_tab.npz (pinned against the reference there)
+        g = golden('chain_N256_tab.npz')
+        o_antenna = dict(freqs=g['tab_freqs'], thetas=g['tab_thetas'], phis=g['tab_phis'], H_theta=g['tab_H_theta'],
+                         H_phi=g['tab_H_phi'], orientation=g['tab_orientation'])
+        models = {antenna: nuradiomc_amd.TabulatedAntenna(g['tab_freqs'], g['tab_thetas'], g['tab_phis'], g['tab_H_theta'],
+                                                          g['tab_H_phi'], g['tab_orientation'])}
+    ost = so.Station(pos, antenna=o_antenna, cable_delay=cable, n_samples=N, fs=fs)
     det = _FakeDet(pos, antenna, cable, N, fs)
-    conv = modules.efieldToVoltageConverter(channel_factory=_FakeChannel)
+    conv = modules.efieldToVoltageConverter(channel_factory=_FakeChannel, antenna_models=models)
     conv.begin(caching=False)
     rng = np.random.default_rng(9)
     n_done = 0
