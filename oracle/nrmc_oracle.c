@@ -87,12 +87,48 @@ static double get_C1(const double x1[2], double C0, const ice_t *m) /* :487 */
     return x1[0] - get_y_with_z_mirror(x1[1], C0, m, 0.0);
 }
 
-/* :204-272 with reflection == 0 */
-static double get_delta_y(double C0, const double x1[2], const double x2[2], const ice_t *m)
+/* :186-202 */
+static double get_y_turn(double C0, const double x1[2], const ice_t *m)
+{
+    double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
+    double gamma_turn, z_turn;
+    get_turning_point(c, m, &gamma_turn, &z_turn);
+    double C1 = x1[0] - get_y_with_z_mirror(x1[1], C0, m, 0.0);
+    return get_y(gamma_turn, C0, C1, m);
+}
+
+/* :281-291: where the ray (C0, C1) comes back down to the reflective layer at depth z_refl */
+static void get_reflection_point(double C0, double C1, const ice_t *m, double z_refl, double out[2])
+{
+    double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
+    double gamma_turn, z_turn;
+    get_turning_point(c, m, &gamma_turn, &z_turn);
+    out[1] = z_refl;
+    out[0] = get_y_with_z_mirror(-z_refl + 2 * z_turn, C0, m, C1);
+}
+
+/* :204-272.  reflection = number of reflections off the bottom layer at z_refl, reflection_case 1: the ray starts
+ * upwards, 2: downwards (the start point is moved to the left, to where an upward ray passes through x1 going down).
+ * The start point is a LOCAL COPY here, as in the C++ twin (analytic_raytracing.cpp:405-470, which the reference's own
+ * golden table reference_C0_MooresBay.pkl was written with).  The Python text shifts x1[0] in place (:226-229) on the
+ * one array scipy passes to every objective evaluation, so there the shift accumulates from call to call and the
+ * reflection_case = 2 roots are lost (tests/golden/gen/gen_mooresbay.py measures that: a handful found of 1996). */
+static double get_delta_y_refl(double C0, const double x1_in[2], const double x2[2], const ice_t *m, int reflection,
+                               int reflection_case, double z_refl)
 {
     if (C0 < 1. / m->n_ice || C0 > INFINITY)
         return -INFINITY;
+    double x1[2] = { x1_in[0], x1_in[1] };
     double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
+    if (reflection > 0 && reflection_case == 2) {
+        double y_turn = get_y_turn(C0, x1, m);
+        double dy = y_turn - x1[0];
+        x1[0] = x1[0] - 2.0 * dy;
+    }
+    for (int i = 0; i < reflection; i++) {
+        double C1 = x1[0] - get_y_with_z_mirror(x1[1], C0, m, 0.0);
+        get_reflection_point(C0, C1, m, z_refl, x1);
+    }
     double C1 = x1[0] - get_y_with_z_mirror(x1[1], C0, m, 0.0);
     double gamma_turn, z_turn;
     get_turning_point(c, m, &gamma_turn, &z_turn);
@@ -112,13 +148,18 @@ static double get_delta_y(double C0, const double x1[2], const double x2[2], con
     }
 }
 
-typedef struct { const double *x1, *x2; const ice_t *m; long nfev; } obj_t;
+static double get_delta_y(double C0, const double x1[2], const double x2[2], const ice_t *m)
+{
+    return get_delta_y_refl(C0, x1, x2, m, 0, 1, 0.);
+}
+
+typedef struct { const double *x1, *x2; const ice_t *m; long nfev; int reflection, reflection_case; double z_refl; } obj_t;
 
 static double obj_delta_y(double logC0, void *p) /* :1357 */
 {
     obj_t *o = (obj_t *)p;
     o->nfev++;
-    return get_delta_y(C0_from_log(logC0, o->m), o->x1, o->x2, o->m);
+    return get_delta_y_refl(C0_from_log(logC0, o->m), o->x1, o->x2, o->m, o->reflection, o->reflection_case, o->z_refl);
 }
 static double obj_delta_y_square(double logC0, void *p) /* :274 */
 {
@@ -344,13 +385,15 @@ static int determine_solution_type(const double x1[2], const double x2[2], doubl
     return 2;                         /* refracted */
 }
 
-/* ray_tracing_2D.find_solutions, Python branch (:1433-1547), reflection = 0, receiver in ice.
- * Returns number of solutions (<= 3) sorted by C0; hybr diagnostics optional. */
-int orc_find_solutions_2d(const double x1[2], const double x2[2], const double ice[3],
-                          double *C0s, double *C1s, int *types, double *hybr_x, double *hybr_fun, int *nfev)
+/* ray_tracing_2D.find_solutions, Python branch (:1433-1547), receiver in ice; `reflection` bottom reflections with the
+ * ray starting upwards (reflection_case 1) or downwards (2).  Returns number of solutions (<= 3) sorted by C0; hybr
+ * diagnostics optional. */
+int orc_find_solutions_2d_refl(const double x1[2], const double x2[2], const double ice[3], int reflection,
+                               int reflection_case, double z_refl, double *C0s, double *C1s, int *types, double *hybr_x,
+                               double *hybr_fun, int *nfev)
 {
     ice_t m = { ice[0], ice[1], ice[2] };
-    obj_t o = { x1, x2, &m, 0 };
+    obj_t o = { x1, x2, &m, 0, reflection, reflection_case, z_refl };
     int n = 0;
     double logC0[3];
     if (x2[1] > 0) return 0; /* ice->air special case (:1437-1460) not restated */
@@ -391,6 +434,12 @@ int orc_find_solutions_2d(const double x1[2], const double x2[2], const double i
         }
     if (nfev) *nfev = (int)o.nfev;
     return n;
+}
+
+int orc_find_solutions_2d(const double x1[2], const double x2[2], const double ice[3],
+                          double *C0s, double *C1s, int *types, double *hybr_x, double *hybr_fun, int *nfev)
+{
+    return orc_find_solutions_2d_refl(x1, x2, ice, 0, 1, 0., C0s, C1s, types, hybr_x, hybr_fun, nfev);
 }
 
 /* :496-511 */
@@ -495,6 +544,109 @@ static void path_length_and_time(const double x1[2], const double x2[2], double 
         *D = 2 * s[2] - s[0] - s[1];
         *T = (2 * ct[2] - ct[0] - ct[1]) / SPEED_OF_LIGHT;
     }
+}
+
+/* get_path_segments (:1091-1159): one segment per stretch between two bottom reflections.
+ * Segment = (start, stop, C1); first_start = the start point as given (x1_orig of the reference's segment tuple). */
+#define ORC_MAX_REFL 4
+typedef struct { double x1[2], x2[2], C1; } seg_t;
+
+static int path_segments(const double x1_in[2], const double x2_in[2], double C0, int reflection, int reflection_case,
+                         double z_refl, const ice_t *m, seg_t *segs)
+{
+    double x1[2] = { x1_in[0], x1_in[1] };
+    if (reflection == 0) {
+        segs[0].x1[0] = x1[0]; segs[0].x1[1] = x1[1];
+        segs[0].x2[0] = x2_in[0]; segs[0].x2[1] = x2_in[1];
+        segs[0].C1 = get_C1(x1, C0, m);
+        return 1;
+    }
+    if (reflection_case == 2) {
+        double y_turn = get_y_turn(C0, x1, m);
+        double dy = y_turn - x1[0];
+        x1[0] = x1[0] - 2 * dy;
+    }
+    int n = 0;
+    for (int i = 0; i < reflection + 1; i++) {
+        double C1 = get_C1(x1, C0, m);
+        double x2[2];
+        get_reflection_point(C0, C1, m, z_refl, x2);
+        int stop = 0;
+        if (x2[0] > x2_in[0]) {
+            stop = 1;
+            x2[0] = x2_in[0]; x2[1] = x2_in[1];
+        }
+        segs[n].x1[0] = x1[0]; segs[n].x1[1] = x1[1];
+        segs[n].x2[0] = x2[0]; segs[n].x2[1] = x2[1];
+        segs[n].C1 = C1;
+        n++;
+        if (stop) break;
+        x1[0] = x2[0]; x1[1] = x2[1];
+    }
+    return n;
+}
+
+/* the end points the reference integrates a segment between: a first segment that starts downwards is mirrored
+ * (:629-636, :720-727, :943-950): from (y of the original start, z of the segment's end) up to (y of the end, z of the start) */
+static void segment_end_points(const seg_t *sg, int iS, int reflection_case, const double x1_orig[2], double a[2], double b[2])
+{
+    if (iS == 0 && reflection_case == 2) {
+        a[0] = x1_orig[0]; a[1] = sg->x2[1];
+        b[0] = sg->x2[0];  b[1] = x1_orig[1];
+    } else {
+        a[0] = sg->x1[0]; a[1] = sg->x1[1];
+        b[0] = sg->x2[0]; b[1] = sg->x2[1];
+    }
+}
+
+/* get_path_length_analytic / get_travel_time_analytic with bottom reflections: the sum over the segments */
+static void path_length_and_time_refl(const double x1[2], const double x2[2], double C0, int reflection, int reflection_case,
+                                      double z_refl, const ice_t *m, double *D, double *T)
+{
+    seg_t segs[ORC_MAX_REFL + 1];
+    int n = path_segments(x1, x2, C0, reflection, reflection_case, z_refl, m, segs);
+    double d = 0, t = 0;
+    for (int i = 0; i < n; i++) {
+        double a[2], b[2], di, ti;
+        segment_end_points(&segs[i], i, reflection_case, x1, a, b);
+        path_length_and_time(a, b, C0, m, &di, &ti);
+        d += di;
+        t += ti * SPEED_OF_LIGHT;   /* the reference sums c t and divides once (:783) */
+    }
+    *D = d;
+    *T = t / SPEED_OF_LIGHT;
+}
+
+/* get_reflection_angle (:1201-1237) per segment: NaN where the segment has no reflection at the surface; returns
+ * the number of segments */
+static int reflection_angles(const double x1[2], const double x2[2], double C0, int reflection, int reflection_case,
+                             double z_refl, const ice_t *m, double *out)
+{
+    seg_t segs[ORC_MAX_REFL + 1];
+    int n = path_segments(x1, x2, C0, reflection, reflection_case, z_refl, m, segs);
+    double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
+    double gamma_turn, z_turn;
+    get_turning_point(c, m, &gamma_turn, &z_turn);
+    for (int i = 0; i < n; i++) {
+        double y_turn = get_y_turn(C0, segs[i].x1, m);
+        out[i] = NAN;
+        if (z_turn >= 0 && y_turn > x1[0] && y_turn < x2[0]) {
+            double xs[2] = { y_turn, 0. }, sn, cs;
+            get_angle_sincos(xs, segs[i].x1, C0, m, &sn, &cs);
+            out[i] = atan2(sn, cs);
+        }
+    }
+    return n;
+}
+
+/* get_angle (:1161-1193) with bottom reflections: the start of the LAST segment of the path x_start -> x takes the
+ * place of x_start */
+static void get_angle_sincos_refl(const double x[2], const double x_start[2], double C0, int reflection, int reflection_case,
+                                  double z_refl, const ice_t *m, double *sn, double *cs)
+{
+    seg_t segs[ORC_MAX_REFL + 1];
+    int n = path_segments(x_start, x, C0, reflection, reflection_case, z_refl, m, segs);
+    get_angle_sincos(x, segs[n - 1].x1, C0, m, sn, cs);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1278,6 +1430,88 @@ void orc_raytrace_batch(long n, const double *x1, const double *x2, const double
             refl_angle[k] = get_reflection_angle(g.x1, g.x2, c0[s], &m);
         }
     }
+}
+
+/* ---- bottom reflections (ice shelf, medium.reflection: Moore's Bay) ---------------------------------------------
+ * ray_tracing.find_solutions (:2118-2130): the plain call, then (reflection i, case 1), (i, case 2) for i = 1..n_reflections;
+ * more than 2 + 4 n_reflections solutions -> none.  Arrays are [n][stride], stride = 2 + 4 n_reflections.
+ * given != 0: the solution records (n_sol, type, C0, C1, reflection, reflection_case) are inputs (set_solution :2092). */
+void orc_raytrace_batch_refl(long n, const double *x1, const double *x2, const double ice[3], int n_reflections,
+                             double z_refl, int given, int *n_sol, int *type, double *C0, double *C1, int *reflection,
+                             int *reflection_case, double *D, double *T, double *launch, double *receive,
+                             double *refl_angle, int *n_surface)
+{
+    ice_t m = { ice[0], ice[1], ice[2] };
+    const int stride = 2 + 4 * n_reflections;
+    for (long i = 0; i < n; i++) {
+        geom_t g;
+        set_start_and_end_point(x1 + 3 * i, x2 + 3 * i, &g);
+        if (!given) {
+            double c0[64], c1[64];
+            int ty[64], rf[64], rc[64], ns = 0;
+            for (int r = 0; r <= n_reflections; r++)
+                for (int cs = 1; cs <= (r == 0 ? 1 : 2); cs++) {
+                    int k = orc_find_solutions_2d_refl(g.x1, g.x2, ice, r, cs, z_refl, c0 + ns, c1 + ns, ty + ns, NULL, NULL, NULL);
+                    for (int j = 0; j < k; j++) { rf[ns + j] = r; rc[ns + j] = cs; }
+                    ns += k;
+                }
+            if (ns > stride) ns = 0; /* :2127-2130 */
+            n_sol[i] = ns;
+            for (int s = 0; s < stride; s++) {
+                long k = i * stride + s;
+                type[k] = reflection[k] = reflection_case[k] = 0;
+                C0[k] = C1[k] = NAN;
+                if (s < ns) { type[k] = ty[s]; C0[k] = c0[s]; C1[k] = c1[s]; reflection[k] = rf[s]; reflection_case[k] = rc[s]; }
+            }
+        }
+        for (int s = 0; s < stride; s++) {
+            long k = i * stride + s;
+            D[k] = T[k] = refl_angle[k] = NAN;
+            n_surface[k] = 0;
+            for (int d = 0; d < 3; d++) launch[3 * k + d] = receive[3 * k + d] = NAN;
+            if (s >= n_sol[i]) continue;
+            const int rf = reflection[k], rc = reflection_case[k];
+            path_length_and_time_refl(g.x1, g.x2, C0[k], rf, rc, z_refl, &m, &D[k], &T[k]);
+            double sL, cL, s2, c2;
+            get_angle_sincos_refl(g.x1, g.x1, C0[k], rf, rc, z_refl, &m, &sL, &cL);
+            get_angle_sincos_refl(g.x2, g.x1, C0[k], rf, rc, z_refl, &m, &s2, &c2);
+            double lv[3] = { sL, 0, cL }, rv[3] = { -s2, 0, -c2 };
+            if (g.swap) {
+                lv[0] = -s2; lv[2] = -c2;
+                rv[0] = sL;  rv[2] = cL;
+            }
+            rotate_back(&g, lv, launch + 3 * k);
+            rotate_back(&g, rv, receive + 3 * k);
+            double ra[ORC_MAX_REFL + 1];
+            int nseg = reflection_angles(g.x1, g.x2, C0[k], rf, rc, z_refl, &m, ra);
+            for (int j = 0; j < nseg; j++)
+                if (!isnan(ra[j])) { refl_angle[k] = ra[j]; n_surface[k]++; } /* the same angle in every segment that has one */
+        }
+    }
+}
+
+/* get_attenuation_along_path (:933-1089) with bottom reflections: the product over the path segments */
+void orc_attenuation_batch_refl(long n, const double *x1, const double *x2, const double *C0, const int *reflection,
+                                const int *reflection_case, const double ice[3], double z_refl, int model, int n_freq,
+                                const double *freqs, double *att)
+{
+    ice_t m = { ice[0], ice[1], ice[2] };
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)n_freq);
+    for (long i = 0; i < n; i++) {
+        geom_t g;
+        set_start_and_end_point(x1 + 3 * i, x2 + 3 * i, &g);
+        for (int k = 0; k < n_freq; k++) att[i * n_freq + k] = isnan(C0[i]) ? NAN : 1.;
+        if (isnan(C0[i])) continue;
+        seg_t segs[ORC_MAX_REFL + 1];
+        int ns = path_segments(g.x1, g.x2, C0[i], reflection[i], reflection_case[i], z_refl, &m, segs);
+        for (int j = 0; j < ns; j++) {
+            double a[2], b[2];
+            segment_end_points(&segs[j], j, reflection_case[i], g.x1, a, b);
+            orc_attenuation_2d(a, b, C0[i], ice, model, n_freq, freqs, tmp, NULL);
+            for (int k = 0; k < n_freq; k++) att[i * n_freq + k] *= tmp[k];
+        }
+    }
+    free(tmp);
 }
 
 /* attenuation for a batch of rays given 3-D end points and C0 (get_attenuation :2744) */

@@ -37,6 +37,12 @@ def lib():
         _lib.orc_attenuation_batch.argtypes = [ctypes.c_long, _dp, _dp, _dp, _dp, ctypes.c_int, ctypes.c_int, _dp, _dp,
                                                _ip]
         _lib.orc_attenuation_batch.restype = None
+        _lib.orc_raytrace_batch_refl.argtypes = [ctypes.c_long, _dp, _dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                                 _ip, _ip, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _ip]
+        _lib.orc_raytrace_batch_refl.restype = None
+        _lib.orc_attenuation_batch_refl.argtypes = [ctypes.c_long, _dp, _dp, _dp, _ip, _ip, _dp, ctypes.c_double,
+                                                    ctypes.c_int, ctypes.c_int, _dp, _dp]
+        _lib.orc_attenuation_batch_refl.restype = None
         _lib.orc_attenuation_length.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int]
         _lib.orc_attenuation_length.restype = ctypes.c_double
     return _lib
@@ -65,6 +71,44 @@ def raytrace_batch(x1, x2, ice):
                              _d(o['D']), _d(o['T']), _d(o['launch']), _d(o['receive']), _d(o['refl_angle']),
                              _d(o['hybr_x']), _d(o['hybr_fun']))
     return o
+
+
+def raytrace_batch_refl(x1, x2, ice, n_reflections, z_reflection, solutions=None):
+    """ray_tracing(medium with a reflective bottom layer, n_reflections).find_solutions + geometry; arrays [n][2 + 4
+    n_reflections].  solutions = dict(n_sol, type, C0, C1, reflection, reflection_case): records given (set_solution)."""
+    x1 = np.ascontiguousarray(x1, float).reshape(-1, 3)
+    x2 = np.ascontiguousarray(x2, float).reshape(-1, 3)
+    ice = np.ascontiguousarray(ice, float)
+    n, st = len(x1), 2 + 4 * int(n_reflections)
+    o = dict(n_sol=np.zeros(n, np.int32), type=np.zeros((n, st), np.int32), reflection=np.zeros((n, st), np.int32),
+             reflection_case=np.zeros((n, st), np.int32), n_surface=np.zeros((n, st), np.int32))
+    for k in ('C0', 'C1', 'D', 'T', 'refl_angle'):
+        o[k] = np.full((n, st), np.nan)
+    for k in ('launch', 'receive'):
+        o[k] = np.full((n, st, 3), np.nan)
+    if solutions is not None:
+        o['n_sol'][:] = solutions['n_sol']
+        for k in ('type', 'reflection', 'reflection_case', 'C0', 'C1'):
+            o[k][:] = solutions[k]
+    lib().orc_raytrace_batch_refl(n, _d(x1), _d(x2), _d(ice), int(n_reflections), float(z_reflection),
+                                  int(solutions is not None), _i(o['n_sol']), _i(o['type']), _d(o['C0']), _d(o['C1']),
+                                  _i(o['reflection']), _i(o['reflection_case']), _d(o['D']), _d(o['T']), _d(o['launch']),
+                                  _d(o['receive']), _d(o['refl_angle']), _i(o['n_surface']))
+    return o
+
+
+def attenuation_batch_refl(x1, x2, C0, reflection, reflection_case, ice, z_reflection, model, freqs):
+    x1 = np.ascontiguousarray(x1, float).reshape(-1, 3)
+    x2 = np.ascontiguousarray(x2, float).reshape(-1, 3)
+    C0 = np.ascontiguousarray(C0, float).reshape(-1)
+    rf = np.ascontiguousarray(reflection, np.int32).reshape(-1)
+    rc = np.ascontiguousarray(reflection_case, np.int32).reshape(-1)
+    ice = np.ascontiguousarray(ice, float)
+    freqs = np.ascontiguousarray(freqs, float)
+    att = np.zeros((len(C0), len(freqs)))
+    lib().orc_attenuation_batch_refl(len(C0), _d(x1), _d(x2), _d(C0), _i(rf), _i(rc), _d(ice), float(z_reflection),
+                                     MODEL_TO_INT[model], len(freqs), _d(freqs), _d(att))
+    return att
 
 
 def set_gl3_table(table):

@@ -200,3 +200,54 @@ def test_tabulated_antenna_response_vs_reference():
             vt, vp = so.antenna_response(tab, g['resp_fgrid'], zen, az, ori)
             assert np.max(np.abs(vt - g['resp'][io, idr, 0])) <= 1e-12 * scale, (io, idr)
             assert np.max(np.abs(vp - g['resp'][io, idr, 1])) <= 1e-12 * scale, (io, idr)
+
+
+def test_mooresbay_C0_golden_pickle():
+    """The reference's own golden table for reflections off the bottom of the ice shelf
+    (NuRadioMC/test/SignalProp/reference_C0_MooresBay.pkl, T06unit_test_C0_mooresbay.py: 1000 vertices, n_reflections = 2,
+    up to 10 solutions per vertex) at the reference test's own tolerance (rtol 1e-6), incl. the order of the solutions."""
+    from oracle import raytrace_oracle as rto
+    g = golden('ref_mooresbay.npz')
+    n = len(g['points'])
+    o = rto.raytrace_batch_refl(g['points'], np.tile(g['x_receiver'], (n, 1)), g['ice'], 2, float(g['z_reflection']))
+    got = np.where(np.isnan(o['C0']), 0., o['C0'])
+    np.testing.assert_allclose(got, g['ref_C0'], rtol=1e-6, atol=0)
+    assert np.array_equal(o['n_sol'], g['n_sol']) and o['n_sol'].max() == 10 and o['n_sol'].sum() == 4848
+    sel = np.arange(10)[None, :] < o['n_sol'][:, None]
+    for k in ('type', 'reflection', 'reflection_case'):   # labels from the reference's own get_delta_y / determine_solution_type
+        assert np.array_equal(o[k][sel], g[k][sel]), k
+    assert max_rel(o['C1'][sel], g['C1'][sel]) < 2e-5   # dC1/dC0 is large: the table's C0 (C++ writer) differ by up to 1e-6
+    # what the reference's Python path finds (it loses nearly all reflection_case = 2 roots, see gen_mooresbay.py) is a subset
+    for i in range(n):
+        for k in range(g['py_n_sol'][i]):
+            hit = (np.abs(o['C0'][i] - g['py_C0'][i, k]) <= 1e-6 * g['py_C0'][i, k]) & \
+                  (o['reflection'][i] == g['py_reflection'][i, k]) & (o['reflection_case'][i] == g['py_reflection_case'][i, k])
+            assert hit.sum() == 1, (i, k)
+
+
+def test_mooresbay_paths_vs_reference_python_path():
+    """Path length, travel time, launch / receive vectors, surface-reflection angles per path segment and the attenuation
+    (MB1, product over the path segments) for rays with 0..2 bottom reflections, both reflection cases, against the
+    reference's ray_tracing (solutions handed over through set_solution)."""
+    from oracle import raytrace_oracle as rto
+    g = golden('ref_mooresbay.npz')
+    nf = int(g['n_full'])
+    x1, x2 = g['points'][:nf], np.tile(g['x_receiver'], (nf, 1))
+    sol = {k: g[k][:nf] for k in ('n_sol', 'type', 'C0', 'C1', 'reflection', 'reflection_case')}
+    o = rto.raytrace_batch_refl(x1, x2, g['ice'], 2, float(g['z_reflection']), solutions=sol)
+    m = ~np.isnan(g['C0'][:nf])
+    assert m.sum() > 700 and (g['reflection_case'][:nf][m] == 2).sum() > 250
+    assert max_rel(o['D'][m], g['D'][m]) < 1e-7 and max_rel(o['T'][m], g['T'][m]) < 1e-7
+    assert np.max(np.abs(o['launch'][m] - g['launch'][m])) < 1e-12
+    assert np.max(np.abs(o['receive'][m] - g['receive'][m])) < 1e-12
+    ra = g['refl_angle']                               # [nf, 10, segment]
+    n_surface = np.sum(~np.isnan(ra), axis=2)
+    assert np.array_equal(o['n_surface'][m], n_surface[m]) and n_surface[m].max() == 3
+    has = m & (n_surface > 0)
+    angle = np.max(np.where(np.isnan(ra), -1., ra), axis=2)   # the same in every segment that reflects
+    assert np.max(np.abs(o['refl_angle'][has] - angle[has])) < 1e-12
+    assert np.all(np.isnan(o['refl_angle'][m & (n_surface == 0)]))
+    idx = np.argwhere(m)
+    att = rto.attenuation_batch_refl(x1[idx[:, 0]], x2[idx[:, 0]], g['C0'][:nf][m], g['reflection'][:nf][m],
+                                     g['reflection_case'][:nf][m], g['ice'], float(g['z_reflection']), 'MB1', g['fcoarse'])
+    assert np.max(np.abs(att - g['att'][m]) / g['att'][m]) < 1e-9
