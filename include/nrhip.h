@@ -114,6 +114,44 @@ int nrhip_ray_records_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, c
                             const double* C0_in, int32_t* n_sol, int32_t* type, double* C0, double* C1, double* D,
                             double* T, double* launch, double* receive, double* refl_angle);
 
+/* ---- reflections off the bottom of an ice shelf (medium.reflection, e.g. mooresbay_simple: -576 m) -------------------
+ * ray_tracing(medium, n_reflections=n).find_solutions (analyticraytracing.py:2118-2130): the plain 2-D solution finder,
+ * then per number of bottom reflections r = 1..n one call for rays that start upwards (reflection_case 1) and one for
+ * rays that start downwards (2) (ray_tracing_2D.find_solutions :1400-1547 with get_delta_y's reflection loop :204-272,
+ * C++ twin cpp:405-470, :602-874); more than 2 + 4 n solutions -> none.  Replaces wrapper.pyx find_solutions(x1, x2,
+ * n_ice, delta_n, z_0, reflection, reflection_case, ice_reflection).
+ * Tables are [n_pairs][2 + 4 n_reflections] in the order the reference lists the solutions (call order, C0 ascending
+ * inside a call), padded with type 0 / NaN.  D, T: sums over the path segments between two bottom reflections
+ * (get_path_segments :1091-1159, get_path_length_analytic :602-690, get_travel_time_analytic :692-783); launch / receive:
+ * get_launch_vector :2560, get_receive_vector :2593; refl_angle: zenith angle of the reflections at the SURFACE (the same
+ * in every segment that has one, NaN = none), n_segments the number of path segments and bit j of surface_mask whether
+ * segment j has one (get_reflection_angle :1201-1237 returns one entry, angle or None, per segment).  apply_propagation_effects (:2966-3009) then multiplies
+ * the eTheta / ePhi spectra by r_p / r_s once per surface reflection and by (reflection_coefficient e^{i phase_shift})
+ * once per bottom reflection.  z_reflection < 0: depth of the reflective layer.  Any output pointer may be NULL.
+ * All pointers HOST.                                                                                                */
+int nrhip_find_solutions_reflections_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const double* x2, int32_t n_x2,
+                                           int32_t n_reflections, double z_reflection, int32_t* n_sol, int32_t* type,
+                                           double* C0, double* C1, int32_t* reflection, int32_t* reflection_case, double* D,
+                                           double* T, double* launch, double* receive, double* refl_angle,
+                                           int32_t* n_segments, int32_t* surface_mask);
+
+/* ray_tracing.set_solution (:2092-2116) with bottom reflections: n_sol, C0, reflection, reflection_case are INPUTS
+ * ([n_pairs][2 + 4 n_reflections]); everything else is derived from them as above.                                  */
+int nrhip_ray_records_reflections_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const double* x2, int32_t n_x2,
+                                        int32_t n_reflections, double z_reflection, int32_t* n_sol, int32_t* type,
+                                        double* C0, double* C1, int32_t* reflection, int32_t* reflection_case, double* D,
+                                        double* T, double* launch, double* receive, double* refl_angle,
+                                        int32_t* n_segments, int32_t* surface_mask);
+
+/* get_attenuation_along_path with bottom reflections (:933-1089): the product over the path segments of
+ * exp(-int ds / L(z, f)); one ray per row (x1, x2, C0, reflection, reflection_case), att [n_rays][n_freq].
+ * segment_att (may be NULL): the factors of the single segments, [n_rays][max(reflection) + 1][n_freq], NaN where a ray
+ * has fewer segments (the reference interpolates every segment's factors to the full frequency grid before it
+ * multiplies them, :1078-1084).  HOST pointers. */
+int nrhip_attenuation_reflections_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, const double* x2, const double* C0,
+                                        const int32_t* reflection, const int32_t* reflection_case, double z_reflection,
+                                        int32_t n_freq, const double* freqs, double* att, double* segment_att);
+
 /* Batched ray_tracing.get_attenuation on an explicit frequency list
  * (analyticraytracing.py:2744 -> get_attenuation_along_path :933-1089, Python branch), replacing the
  * per-frequency wrapper.pyx get_attenuation_along_path (:30-31).

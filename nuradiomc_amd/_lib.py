@@ -52,6 +52,13 @@ def load():
     _sig(lib, 'nrhip_attenuation_batch', ctypes.c_int,
          [vp, i64, c_double_p, c_double_p, c_double_p, i32, c_double_p, c_double_p, c_int32_p])
     _sig(lib, 'nrhip_attenuation_length', ctypes.c_int, [vp, i64, c_double_p, c_double_p, c_double_p])
+    refl_sig = [vp, i64, c_double_p, c_double_p, i32, i32, ctypes.c_double, c_int32_p, c_int32_p, c_double_p, c_double_p,
+                c_int32_p, c_int32_p] + [c_double_p] * 5 + [c_int32_p, c_int32_p]
+    _sig(lib, 'nrhip_find_solutions_reflections_batch', ctypes.c_int, refl_sig)
+    _sig(lib, 'nrhip_ray_records_reflections_batch', ctypes.c_int, refl_sig)
+    _sig(lib, 'nrhip_attenuation_reflections_batch', ctypes.c_int,
+         [vp, i64, c_double_p, c_double_p, c_double_p, c_int32_p, c_int32_p, ctypes.c_double, i32, c_double_p, c_double_p,
+          c_double_p])
     for name, sig in _OPTIONAL.items():
         if hasattr(lib, name):
             _sig(lib, name, *sig)

@@ -140,6 +140,61 @@ class Context:
             L.check(self._lib.nrhip_ray_records_batch(self._h, n, L.dptr(x1), L.dptr(x2), n_x2, L.dptr(g), *outs))
         return o
 
+    def find_solutions_reflections_batch(self, x1, x2, n_reflections, z_reflection, outer=False, solutions=None):
+        """Ray solutions with up to n_reflections reflections off the bottom of an ice shelf at depth z_reflection (< 0)
+        (ray_tracing(medium, n_reflections).find_solutions, analyticraytracing.py:2118-2130).
+
+        Returns a dict of [n_pairs, 2 + 4 n_reflections(, 3)] arrays in the reference's order of solutions: n_sol, type,
+        C0, C1, reflection, reflection_case, D, T, launch, receive, refl_angle (surface reflection, NaN = none),
+        n_segments, surface_mask (bit j: path segment j reflects at the surface), n_surface (their number).  solutions = dict(n_sol, C0, reflection, reflection_case):
+        no root finding (set_solution)."""
+        x1 = L.f64(x1).reshape(-1, 3)
+        x2 = L.f64(x2).reshape(-1, 3)
+        if outer:
+            n, n_x2 = len(x1) * len(x2), len(x2)
+        else:
+            if len(x1) != len(x2):
+                raise ValueError("x1 and x2 must have the same number of rows")
+            n, n_x2 = len(x1), 0
+        st = 2 + 4 * int(n_reflections)
+        o = dict(n_sol=np.zeros(n, np.int32))
+        for k in ('type', 'reflection', 'reflection_case', 'n_segments', 'surface_mask'):
+            o[k] = np.zeros((n, st), np.int32)
+        for k in ('C0', 'C1', 'D', 'T', 'refl_angle'):
+            o[k] = np.full((n, st), np.nan)
+        for k in ('launch', 'receive'):
+            o[k] = np.full((n, st, 3), np.nan)
+        fn = self._lib.nrhip_find_solutions_reflections_batch
+        if solutions is not None:
+            fn = self._lib.nrhip_ray_records_reflections_batch
+            o['n_sol'][:] = np.asarray(solutions['n_sol'], np.int32).reshape(n)
+            o['C0'][:] = L.f64(solutions['C0']).reshape(n, st)
+            o['reflection'][:] = np.asarray(solutions['reflection'], np.int32).reshape(n, st)
+            o['reflection_case'][:] = np.asarray(solutions['reflection_case'], np.int32).reshape(n, st)
+        L.check(fn(self._h, n, L.dptr(x1), L.dptr(x2), n_x2, int(n_reflections), float(z_reflection), L.iptr(o['n_sol']),
+                   L.iptr(o['type']), L.dptr(o['C0']), L.dptr(o['C1']), L.iptr(o['reflection']), L.iptr(o['reflection_case']),
+                   L.dptr(o['D']), L.dptr(o['T']), L.dptr(o['launch']), L.dptr(o['receive']), L.dptr(o['refl_angle']),
+                   L.iptr(o['n_segments']), L.iptr(o['surface_mask'])))
+        o['n_surface'] = np.array([bin(v).count('1') for v in o['surface_mask'].ravel()], np.int32).reshape(n, st)
+        return o
+
+    def attenuation_reflections_batch(self, x1, x2, C0, reflection, reflection_case, z_reflection, freqs,
+                                      return_segments=False):
+        """exp(-int ds / L_att) along paths with bottom reflections: the product over the path segments (and, on request,
+        the factors of the segments [n_rays, max(reflection) + 1, n_freq], NaN = no such segment)."""
+        x1 = L.f64(x1).reshape(-1, 3)
+        x2 = L.f64(x2).reshape(-1, 3)
+        C0 = L.f64(C0).reshape(-1)
+        rf = np.ascontiguousarray(reflection, np.int32).reshape(-1)
+        rc = np.ascontiguousarray(reflection_case, np.int32).reshape(-1)
+        freqs = L.f64(freqs).reshape(-1)
+        att = np.zeros((len(C0), len(freqs)))
+        seg = np.zeros((len(C0), (int(rf.max()) if len(rf) else 0) + 1, len(freqs)))
+        L.check(self._lib.nrhip_attenuation_reflections_batch(self._h, len(C0), L.dptr(x1), L.dptr(x2), L.dptr(C0), L.iptr(rf),
+                                                              L.iptr(rc), float(z_reflection), len(freqs), L.dptr(freqs),
+                                                              L.dptr(att), L.dptr(seg)))
+        return (att, seg) if return_segments else att
+
     def attenuation_batch(self, x1, x2, C0, freqs, return_neval=False):
         """exp(-int ds / L_att) for rays (x1[r] -> x2[r], C0[r]) at the given (> 0) frequencies."""
         x1 = L.f64(x1).reshape(-1, 3)

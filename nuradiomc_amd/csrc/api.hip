@@ -3,7 +3,10 @@
 #include "nrhip_internal.h"
 #include "ctx.h"
 #include <cstdio>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace nrhip {
@@ -234,6 +237,168 @@ int nrhip_attenuation_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, co
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(att, da.p, n_rays * n_freq * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (neval) HIPCHK(hipMemcpyAsync(neval, dn.p, n_rays * n_freq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---- reflections off the bottom of an ice shelf ----
+static int refl_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const double* x2, int32_t n_x2, int32_t n_reflections,
+                      double z_reflection, int given, int32_t* n_sol, int32_t* type, double* C0, double* C1,
+                      int32_t* reflection, int32_t* reflection_case, double* D, double* T, double* launch, double* receive,
+                      double* refl_angle, int32_t* n_segments, int32_t* surface_mask)
+{
+    const char* who = given ? "nrhip_ray_records_reflections_batch" : "nrhip_find_solutions_reflections_batch";
+    if (!ctx) return fail_msg((std::string(who) + ": ctx is NULL").c_str());
+    if (n_pairs < 0 || n_x2 < 0) return fail_msg((std::string(who) + ": negative size").c_str());
+    if (n_reflections < 0 || n_reflections > NRHIP_MAX_REFLECTIONS)
+        return fail_msg((std::string(who) + ": n_reflections must be 0..4").c_str());
+    if (n_reflections > 0 && !(z_reflection < 0))  // AttributeError in the reference (:1421-1423)
+        return fail_msg((std::string(who) + ": reflections off the bottom are requested, but the ice model does not specify a reflective layer").c_str());
+    if (n_pairs == 0) return 0;
+    if (n_x2 > 0 && n_pairs % n_x2 != 0) return fail_msg((std::string(who) + ": n_pairs not a multiple of n_x2").c_str());
+    if (given && (!n_sol || !C0 || !reflection || !reflection_case)) return fail_msg((std::string(who) + ": records missing").c_str());
+    HIPCHK(hipSetDevice(ctx->device));
+    const int S = 2 + 4 * n_reflections, n_calls = 1 + 2 * n_reflections, NS = n_reflections + 1;
+    size_t n1 = (n_x2 > 0) ? n_pairs / n_x2 : n_pairs, n2 = (n_x2 > 0) ? n_x2 : n_pairs;
+    const size_t nk = (size_t)n_pairs * S;
+    DevBuf dx1, dx2, dcn, dcc, dns, dty, drf, drc, dsu, dsm, dC0, dC1, dD, dT, dla, dre, dra, dsz, dsc;
+    HIPCHK(dx1.alloc(n1 * 24));
+    HIPCHK(dx2.alloc(n2 * 24));
+    HIPCHK(dcn.alloc((size_t)n_pairs * n_calls * 4));
+    HIPCHK(dcc.alloc((size_t)n_pairs * n_calls * 24));
+    HIPCHK(dns.alloc(n_pairs * 4));
+    HIPCHK(dty.alloc(nk * 4));
+    HIPCHK(drf.alloc(nk * 4));
+    HIPCHK(drc.alloc(nk * 4));
+    HIPCHK(dsu.alloc(nk * 4));
+    HIPCHK(dsm.alloc(nk * 4));
+    HIPCHK(dC0.alloc(nk * 8));
+    HIPCHK(dC1.alloc(nk * 8));
+    HIPCHK(dD.alloc(nk * 8));
+    HIPCHK(dT.alloc(nk * 8));
+    HIPCHK(dla.alloc(nk * 24));
+    HIPCHK(dre.alloc(nk * 24));
+    HIPCHK(dra.alloc(nk * 8));
+    HIPCHK(dsz.alloc(nk * NS * 24));
+    HIPCHK(dsc.alloc(nk * NS * 8));
+    HIPCHK(hipMemcpyAsync(dx1.p, x1, n1 * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dx2.p, x2, n2 * 24, hipMemcpyHostToDevice, ctx->stream));
+    nrhip::ReflRecords r{dns.as<int>(), dty.as<int>(), drf.as<int>(), drc.as<int>(), dsu.as<int>(), dsm.as<int>(), dC0.as<double>(),
+                         dC1.as<double>(), dD.as<double>(), dT.as<double>(), dla.as<double>(), dre.as<double>(),
+                         dra.as<double>(), dsz.as<double>(), dsc.as<double>()};
+    if (given) {
+        HIPCHK(hipMemcpyAsync(dns.p, n_sol, n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(dC0.p, C0, nk * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(drf.p, reflection, nk * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(drc.p, reflection_case, nk * 4, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        nrhip::launch_find_refl(ctx->stream, n_pairs, n_reflections, dx1.as<double>(), dx2.as<double>(), n_x2, ctx->ice,
+                                z_reflection, dcn.as<int>(), dcc.as<double>());
+    }
+    nrhip::launch_records_refl(ctx->stream, n_pairs, n_reflections, S, dx1.as<double>(), dx2.as<double>(), n_x2, ctx->ice,
+                               z_reflection, dcn.as<int>(), dcc.as<double>(), given, r);
+    HIPCHK(hipGetLastError());
+#define D2H(dst, src, bytes) if (dst) HIPCHK(hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToHost, ctx->stream))
+    D2H(n_sol, dns, n_pairs * 4);
+    D2H(type, dty, nk * 4);
+    D2H(reflection, drf, nk * 4);
+    D2H(reflection_case, drc, nk * 4);
+    D2H(n_segments, dsu, nk * 4);
+    D2H(surface_mask, dsm, nk * 4);
+    D2H(C0, dC0, nk * 8);
+    D2H(C1, dC1, nk * 8);
+    D2H(D, dD, nk * 8);
+    D2H(T, dT, nk * 8);
+    D2H(launch, dla, nk * 24);
+    D2H(receive, dre, nk * 24);
+    D2H(refl_angle, dra, nk * 8);
+#undef D2H
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int nrhip_find_solutions_reflections_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const double* x2, int32_t n_x2,
+                                           int32_t n_reflections, double z_reflection, int32_t* n_sol, int32_t* type,
+                                           double* C0, double* C1, int32_t* reflection, int32_t* reflection_case, double* D,
+                                           double* T, double* launch, double* receive, double* refl_angle,
+                                           int32_t* n_segments, int32_t* surface_mask)
+{
+    return refl_batch(ctx, n_pairs, x1, x2, n_x2, n_reflections, z_reflection, 0, n_sol, type, C0, C1, reflection,
+                      reflection_case, D, T, launch, receive, refl_angle, n_segments, surface_mask);
+}
+
+int nrhip_ray_records_reflections_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const double* x2, int32_t n_x2,
+                                        int32_t n_reflections, double z_reflection, int32_t* n_sol, int32_t* type,
+                                        double* C0, double* C1, int32_t* reflection, int32_t* reflection_case, double* D,
+                                        double* T, double* launch, double* receive, double* refl_angle,
+                                        int32_t* n_segments, int32_t* surface_mask)
+{
+    return refl_batch(ctx, n_pairs, x1, x2, n_x2, n_reflections, z_reflection, 1, n_sol, type, C0, C1, reflection,
+                      reflection_case, D, T, launch, receive, refl_angle, n_segments, surface_mask);
+}
+
+int nrhip_attenuation_reflections_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, const double* x2, const double* C0,
+                                        const int32_t* reflection, const int32_t* reflection_case, double z_reflection,
+                                        int32_t n_freq, const double* freqs, double* att, double* segment_att)
+{
+    if (!ctx || !x1 || !x2 || !C0 || !reflection || !reflection_case || !freqs || !att)
+        return fail_msg("nrhip_attenuation_reflections_batch: NULL argument");
+    if (n_rays < 0 || n_freq < 0) return fail_msg("nrhip_attenuation_reflections_batch: negative size");
+    if (n_rays == 0 || n_freq == 0) return 0;
+    for (int i = 0; i < n_freq; i++)
+        if (!(freqs[i] > 0)) return fail_msg("nrhip_attenuation_reflections_batch: frequencies must be > 0 (DC is 1 by definition)");
+    int max_refl = 0;
+    std::vector<int32_t> one(n_rays);
+    for (int64_t i = 0; i < n_rays; i++) {
+        if (reflection[i] < 0 || reflection[i] > NRHIP_MAX_REFLECTIONS)
+            return fail_msg("nrhip_attenuation_reflections_batch: reflection must be 0..4");
+        max_refl = std::max(max_refl, (int)reflection[i]);
+        one[i] = std::isnan(C0[i]) ? 0 : 1;
+    }
+    if (max_refl > 0 && !(z_reflection < 0))
+        return fail_msg("nrhip_attenuation_reflections_batch: reflections off the bottom are requested, but the ice model does not specify a reflective layer");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int NS = max_refl + 1;
+    const size_t nk = (size_t)n_rays;  // one solution slot per ray
+    DevBuf dx1, dx2, dns, dty, drf, drc, dsu, dsm, dC0, dC1, dD, dT, dla, dre, dra, dsz, dsc, df, dsa, da;
+    HIPCHK(dx1.alloc(nk * 24));
+    HIPCHK(dx2.alloc(nk * 24));
+    HIPCHK(dns.alloc(nk * 4));
+    HIPCHK(dty.alloc(nk * 4));
+    HIPCHK(drf.alloc(nk * 4));
+    HIPCHK(drc.alloc(nk * 4));
+    HIPCHK(dsu.alloc(nk * 4));
+    HIPCHK(dsm.alloc(nk * 4));
+    HIPCHK(dC0.alloc(nk * 8));
+    HIPCHK(dC1.alloc(nk * 8));
+    HIPCHK(dD.alloc(nk * 8));
+    HIPCHK(dT.alloc(nk * 8));
+    HIPCHK(dla.alloc(nk * 24));
+    HIPCHK(dre.alloc(nk * 24));
+    HIPCHK(dra.alloc(nk * 8));
+    HIPCHK(dsz.alloc(nk * NS * 24));
+    HIPCHK(dsc.alloc(nk * NS * 8));
+    HIPCHK(df.alloc((size_t)n_freq * 8));
+    HIPCHK(dsa.alloc(nk * NS * n_freq * 8));
+    HIPCHK(da.alloc(nk * n_freq * 8));
+    HIPCHK(hipMemcpyAsync(dx1.p, x1, nk * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dx2.p, x2, nk * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dns.p, one.data(), nk * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dC0.p, C0, nk * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(drf.p, reflection, nk * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(drc.p, reflection_case, nk * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(df.p, freqs, (size_t)n_freq * 8, hipMemcpyHostToDevice, ctx->stream));
+    nrhip::ReflRecords r{dns.as<int>(), dty.as<int>(), drf.as<int>(), drc.as<int>(), dsu.as<int>(), dsm.as<int>(), dC0.as<double>(),
+                         dC1.as<double>(), dD.as<double>(), dT.as<double>(), dla.as<double>(), dre.as<double>(),
+                         dra.as<double>(), dsz.as<double>(), dsc.as<double>()};
+    nrhip::launch_records_refl(ctx->stream, n_rays, max_refl, 1, dx1.as<double>(), dx2.as<double>(), 0, ctx->ice, z_reflection,
+                               nullptr, nullptr, 1, r);
+    nrhip::launch_attenuation_items(ctx->stream, (long)nk * NS, dsc.as<double>(), dsz.as<double>(), n_freq, df.as<double>(),
+                                    ctx->att_model, ctx->ice, dsa.as<double>(), nullptr, nullptr, nullptr, ctx->gl3, ctx->gl3_n);
+    nrhip::launch_segment_product(ctx->stream, n_rays, NS, n_freq, dsz.as<double>(), dsa.as<double>(), da.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(att, da.p, nk * n_freq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (segment_att) HIPCHK(hipMemcpyAsync(segment_att, dsa.p, nk * NS * n_freq * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -25,6 +25,23 @@ struct RayRecords {
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
                      const IceConst& m, const RayRecords& out, const double* max_dist = nullptr,
                      const int* perm = nullptr, const double* given_C0 = nullptr);
+// ---- reflections off the bottom of an ice shelf (raytrace_refl.hip) ----
+#define NRHIP_MAX_REFLECTIONS 4
+struct ReflRecords {   // [n_pairs][2 + 4 n_reflections]
+    int *n_sol, *type, *reflection, *reflection_case, *n_segments, *surface_mask;
+    double *C0, *C1, *D, *T, *launch, *receive, *refl_angle;
+    double* seg_zint;  // [n_pairs][stride][n_reflections + 1][3]: attenuation limits (z1, z2 mirrored, z_turn) per path segment
+    double* seg_C0;    // [n_pairs][stride][n_reflections + 1]: C0 of the segment's ray, NaN = no such segment
+};
+void launch_find_refl(hipStream_t stream, long n_pairs, int n_reflections, const double* x1, const double* x2, int n_x2,
+                      const IceConst& m, double z_refl, int* cand_n, double* cand_C0);
+// stride = solution slots per pair: 2 + 4 n_reflections after launch_find_refl; any value with given records
+void launch_records_refl(hipStream_t stream, long n_pairs, int n_reflections, int stride, const double* x1, const double* x2,
+                         int n_x2, const IceConst& m, double z_refl, const int* cand_n, const double* cand_C0, int given,
+                         const ReflRecords& out);
+void launch_segment_product(hipStream_t stream, long n_rays, int n_seg_max, int n_freq, const double* seg_zint,
+                            const double* seg_att, double* att);
+
 void launch_event_cells(hipStream_t stream, int n_events, const double* vertex, const double* x2, int* cell, int* hist);
 void launch_event_perm(hipStream_t stream, int n_events, const int* cell, int* cursor, int* perm);
 

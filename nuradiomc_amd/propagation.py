@@ -81,8 +81,8 @@ class ray_tracing:
                 self.__logger.warning("Ray paths with bottom reflections requested but medium does not have any "
                                       "reflective layer, setting number of reflections to zero.")
                 self._n_reflections = 0
-            else:
-                raise NotImplementedError("bottom reflections (n_reflections > 0) are not provided yet")
+            elif self._n_reflections > 4:
+                raise NotImplementedError("more than 4 reflections off the bottom are not provided")
         self.set_config(config)
         self._detector = detector
         self._max_detector_frequency = None
@@ -107,6 +107,12 @@ class ray_tracing:
         self.reset_solutions()
         self._X1 = np.array(x1, dtype=float)
         self._X2 = np.array(x2, dtype=float)
+        if self._n_reflections:  # propagation_base_class.py:156-161
+            if self._X1[2] < self._medium.reflection or self._X2[2] < self._medium.reflection:
+                self.__logger.error("start or stop point is below the reflective bottom layer at {:.1f}m".format(
+                    self._medium.reflection))
+                raise AttributeError("start or stop point is below the reflective bottom layer at {:.1f}m".format(
+                    self._medium.reflection))
 
     def use_optional_function(self, function_name, *args, **kwargs):
         if hasattr(self, function_name):
@@ -116,6 +122,8 @@ class ray_tracing:
         """analyticraytracing.py:2092-2116: launch parameters read back from an output file instead of a new root search;
         the per-solution tables (vectors, path length, travel time, ...) are rebuilt on the GPU from those C0."""
         C0s = np.asarray(raytracing_results['ray_tracing_C0'], float).reshape(-1)
+        if self._n_reflections:
+            return self._set_solution_reflections(raytracing_results, C0s)
         given = np.full(2, np.nan)
         keep = C0s[~np.isnan(C0s)][:2]
         given[:len(keep)] = keep
@@ -132,9 +140,35 @@ class ray_tracing:
                 j += 1
         self._results = results[:2]
 
+    def _set_solution_reflections(self, raytracing_results, C0s):
+        st = self.get_number_of_raytracing_solutions()
+        keep = np.flatnonzero(~np.isnan(C0s))[:st]
+        sol = dict(n_sol=np.array([len(keep)], np.int32), C0=np.full((1, st), np.nan),
+                   reflection=np.zeros((1, st), np.int32), reflection_case=np.zeros((1, st), np.int32))
+        has = 'ray_tracing_reflection' in raytracing_results
+        for j, i in enumerate(keep):
+            sol['C0'][0, j] = C0s[i]
+            sol['reflection'][0, j] = raytracing_results['ray_tracing_reflection'][i] if has else 0
+            sol['reflection_case'][0, j] = raytracing_results['ray_tracing_reflection_case'][i] if has else 0
+        t = self._ctx.find_solutions_reflections_batch(self._X1[None], self._X2[None], self._n_reflections,
+                                                       self._medium.reflection, solutions=sol)
+        self._tab = {k: v[0] for k, v in t.items()}
+        self._results = [{'type': raytracing_results['ray_tracing_solution_type'][i], 'C0': C0s[i],
+                          'C1': raytracing_results['ray_tracing_C1'][i], 'reflection': int(sol['reflection'][0, j]),
+                          'reflection_case': int(sol['reflection_case'][0, j])} for j, i in enumerate(keep)]
+
     def find_solutions(self):
         if self._X2[2] > 0 or self._X1[2] > 0:
             raise NotImplementedError("ice-to-air / air-to-ice ray tracing is not provided yet")
+        if self._n_reflections:  # :2118-2130: the plain call, then (i reflections, case 1 / 2)
+            z_refl = self._medium.reflection
+            t = self._ctx.find_solutions_reflections_batch(self._X1[None], self._X2[None], self._n_reflections, z_refl)
+            self._tab = {k: v[0] for k, v in t.items()}
+            self._results = [{'type': int(self._tab['type'][i]), 'C0': float(self._tab['C0'][i]),
+                              'C1': float(self._tab['C1'][i]), 'reflection': int(self._tab['reflection'][i]),
+                              'reflection_case': int(self._tab['reflection_case'][i])}
+                             for i in range(int(self._tab['n_sol']))]
+            return
         t = self._ctx.find_solutions_batch(self._X1[None], self._X2[None])
         self._tab = {k: v[0] for k, v in t.items()}
         n = int(self._tab['n_sol'])
@@ -172,8 +206,13 @@ class ray_tracing:
         return self._tab['receive'][iS].copy()
 
     def get_reflection_angle(self, iS):
+        """:2626 -> :1201-1237: the zenith angle of the reflection at the surface or None; with bottom reflections one entry
+        per path segment (np.squeeze of the list, as in the reference)"""
         self._check(iS)
         a = self._tab['refl_angle'][iS]
+        if self._n_reflections and self._results[iS]['reflection'] > 0:
+            mask, nseg = int(self._tab['surface_mask'][iS]), int(self._tab['n_segments'][iS])
+            return np.squeeze([float(a) if (mask >> j) & 1 else None for j in range(nseg)])
         return None if np.isnan(a) else float(a)
 
     def get_path_length(self, iS, analytic=True):
@@ -193,9 +232,18 @@ class ray_tracing:
         self._check(iS)
         frequency = np.asarray(frequency, float)
         freqs = attenuation_frequencies(frequency, self._n_frequencies_integration, max_detector_freq)
-        coarse = self._ctx.attenuation_batch(self._X1[None], self._X2[None], [self._results[iS]['C0']], freqs)[0]
         out = np.ones_like(frequency)
         mask = frequency > 0
+        r = self._results[iS]
+        if r['reflection'] > 0:   # one factor per path segment, each interpolated before they are multiplied (:1078-1084)
+            _, seg = self._ctx.attenuation_reflections_batch(self._X1[None], self._X2[None], [r['C0']], [r['reflection']],
+                                                             [r['reflection_case']], self._medium.reflection, freqs,
+                                                             return_segments=True)
+            for coarse in seg[0]:
+                if not np.any(np.isnan(coarse)):
+                    out[mask] *= np.interp(frequency[mask], freqs, coarse)
+            return out
+        coarse = self._ctx.attenuation_batch(self._X1[None], self._X2[None], [r['C0']], freqs)[0]
         out[mask] = np.interp(frequency[mask], freqs, coarse)
         return out
 
@@ -209,7 +257,11 @@ class ray_tracing:
         lau_ang = np.arccos(lau_vec[2] / np.sqrt(lau_vec[0] ** 2 + lau_vec[1] ** 2 + lau_vec[2] ** 2))
         vet_pos, rec_pos = self._X1, self._X2
         rec_pos1 = np.array([rec_pos[0], rec_pos[1], rec_pos[2] + dz])
-        t1 = self._ctx.find_solutions_batch(vet_pos[None], rec_pos1[None])
+        if self._n_reflections:
+            t1 = self._ctx.find_solutions_reflections_batch(vet_pos[None], rec_pos1[None], self._n_reflections,
+                                                            self._medium.reflection)
+        else:
+            t1 = self._ctx.find_solutions_batch(vet_pos[None], rec_pos1[None])
         if iS < int(t1['n_sol'][0]):
             lau_vec1 = t1['launch'][0][iS]
             lau_ang1 = np.arccos(lau_vec1[2] / np.sqrt(lau_vec1[0] ** 2 + lau_vec1[1] ** 2 + lau_vec1[2] ** 2))
@@ -252,8 +304,9 @@ class ray_tracing:
             max_freq = np.max(efield.get_frequencies()) if self._max_detector_frequency is None \
                 else self._max_detector_frequency
             spec *= self.get_attenuation(i_solution, efield.get_frequencies(), max_freq)
-        zenith_reflection = self.get_reflection_angle(i_solution)
-        if zenith_reflection is not None:
+        for zenith_reflection in np.atleast_1d(self.get_reflection_angle(i_solution)):  # one per surface reflection
+            if zenith_reflection is None:
+                continue
             n1 = self._medium.n_ice - self._medium.delta_n * np.exp(-0.01 / self._medium.z_0)
             r_theta, r_phi = _fresnel(zenith_reflection, n_2=1., n_1=n1)
             try:
@@ -264,6 +317,12 @@ class ray_tracing:
                 pass
             spec[1] *= r_theta
             spec[2] *= r_phi
+        i_reflections = self._results[i_solution]['reflection']
+        if i_reflections > 0:  # :3002-3009: every bottom reflection costs the layer's coefficient and shifts the phase
+            reflection_coefficient = self._medium.reflection_coefficient ** i_reflections
+            phase_shift = (i_reflections * self._medium.reflection_phase_shift) % (2 * np.pi)
+            spec[1] *= reflection_coefficient * np.exp(1j * phase_shift)
+            spec[2] *= reflection_coefficient * np.exp(1j * phase_shift)
         if prop.get('focusing'):  # analyticraytracing.py:3011-3016
             spec[1:] *= self.get_focusing(i_solution, limit=float(prop['focusing_limit']))
         if prop.get('birefringence'):

@@ -1439,7 +1439,7 @@ void orc_raytrace_batch(long n, const double *x1, const double *x2, const double
 void orc_raytrace_batch_refl(long n, const double *x1, const double *x2, const double ice[3], int n_reflections,
                              double z_refl, int given, int *n_sol, int *type, double *C0, double *C1, int *reflection,
                              int *reflection_case, double *D, double *T, double *launch, double *receive,
-                             double *refl_angle, int *n_surface)
+                             double *refl_angle, int *n_surface, int *n_segments, int *surface_mask)
 {
     ice_t m = { ice[0], ice[1], ice[2] };
     const int stride = 2 + 4 * n_reflections;
@@ -1467,7 +1467,7 @@ void orc_raytrace_batch_refl(long n, const double *x1, const double *x2, const d
         for (int s = 0; s < stride; s++) {
             long k = i * stride + s;
             D[k] = T[k] = refl_angle[k] = NAN;
-            n_surface[k] = 0;
+            n_surface[k] = n_segments[k] = surface_mask[k] = 0;
             for (int d = 0; d < 3; d++) launch[3 * k + d] = receive[3 * k + d] = NAN;
             if (s >= n_sol[i]) continue;
             const int rf = reflection[k], rc = reflection_case[k];
@@ -1485,7 +1485,8 @@ void orc_raytrace_batch_refl(long n, const double *x1, const double *x2, const d
             double ra[ORC_MAX_REFL + 1];
             int nseg = reflection_angles(g.x1, g.x2, C0[k], rf, rc, z_refl, &m, ra);
             for (int j = 0; j < nseg; j++)
-                if (!isnan(ra[j])) { refl_angle[k] = ra[j]; n_surface[k]++; } /* the same angle in every segment that has one */
+                if (!isnan(ra[j])) { refl_angle[k] = ra[j]; n_surface[k]++; surface_mask[k] |= 1 << j; } /* the same angle in every segment that has one */
+            n_segments[k] = nseg;
         }
     }
 }

@@ -38,7 +38,7 @@ def lib():
                                                _ip]
         _lib.orc_attenuation_batch.restype = None
         _lib.orc_raytrace_batch_refl.argtypes = [ctypes.c_long, _dp, _dp, _dp, ctypes.c_int, ctypes.c_double, ctypes.c_int,
-                                                 _ip, _ip, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _ip]
+                                                 _ip, _ip, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip]
         _lib.orc_raytrace_batch_refl.restype = None
         _lib.orc_attenuation_batch_refl.argtypes = [ctypes.c_long, _dp, _dp, _dp, _ip, _ip, _dp, ctypes.c_double,
                                                     ctypes.c_int, ctypes.c_int, _dp, _dp]
@@ -81,7 +81,8 @@ def raytrace_batch_refl(x1, x2, ice, n_reflections, z_reflection, solutions=None
     ice = np.ascontiguousarray(ice, float)
     n, st = len(x1), 2 + 4 * int(n_reflections)
     o = dict(n_sol=np.zeros(n, np.int32), type=np.zeros((n, st), np.int32), reflection=np.zeros((n, st), np.int32),
-             reflection_case=np.zeros((n, st), np.int32), n_surface=np.zeros((n, st), np.int32))
+             reflection_case=np.zeros((n, st), np.int32), n_surface=np.zeros((n, st), np.int32),
+             n_segments=np.zeros((n, st), np.int32), surface_mask=np.zeros((n, st), np.int32))
     for k in ('C0', 'C1', 'D', 'T', 'refl_angle'):
         o[k] = np.full((n, st), np.nan)
     for k in ('launch', 'receive'):
@@ -93,7 +94,7 @@ def raytrace_batch_refl(x1, x2, ice, n_reflections, z_reflection, solutions=None
     lib().orc_raytrace_batch_refl(n, _d(x1), _d(x2), _d(ice), int(n_reflections), float(z_reflection),
                                   int(solutions is not None), _i(o['n_sol']), _i(o['type']), _d(o['C0']), _d(o['C1']),
                                   _i(o['reflection']), _i(o['reflection_case']), _d(o['D']), _d(o['T']), _d(o['launch']),
-                                  _d(o['receive']), _d(o['refl_angle']), _i(o['n_surface']))
+                                  _d(o['receive']), _d(o['refl_angle']), _i(o['n_surface']), _i(o['n_segments']), _i(o['surface_mask']))
     return o
 
 

@@ -10,7 +10,8 @@
 3. The complete solution list per vertex: the C0 of the golden table, labelled (reflection, reflection_case) with the
    reference's own module-level get_delta_y on a fresh copy of x1 (|delta y| < 1 mm), handed to the Python tracer through
    set_solution; for the first `n_full` vertices path length / travel time (analytic), launch / receive vectors,
-   reflection angles per path segment and the attenuation on a coarse grid.
+   reflection angles per path segment and the attenuation on a coarse grid; for the first `n_prop` vertices what
+   apply_propagation_effects makes of a flat unit spectrum.
 
     PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=tests/golden/gen/shims:/tmp/refcopy python tests/golden/gen/gen_mooresbay.py
 """
@@ -113,6 +114,27 @@ for i, x in enumerate(points):
     if i % 100 == 0:
         print(i, n_sol[i], flush=True)
 
+# ---- 4. apply_propagation_effects (attenuation per segment, Fresnel factors per surface reflection, coefficient and
+#         phase shift per bottom reflection) on a flat unit spectrum, N = 256 at 2 GHz, n_freq = 25
+import NuRadioReco.framework.electric_field  # noqa: E402
+n_prop = int(os.environ.get('N_PROP', 40))
+prop_spec = np.full((n_prop, MAXS, 2, 129), np.nan, complex)
+r25 = ray.ray_tracing(ice, attenuation_model='MB1', n_reflections=2, n_frequencies_integration=25, log_level=logging.CRITICAL,
+                      use_cpp=False, compile_numba=False)
+for i in range(n_prop):
+    m = n_sol[i]
+    if not m:
+        continue
+    r25.set_start_and_end_point(points[i], x_receiver)
+    r25.set_solution({'ray_tracing_C0': C0[i, :m], 'ray_tracing_C1': C1[i, :m], 'ray_tracing_solution_type': typ[i, :m],
+                      'ray_tracing_reflection': refl[i, :m], 'ray_tracing_reflection_case': case[i, :m]})
+    for iS in range(m):
+        ef = NuRadioReco.framework.electric_field.ElectricField([0])
+        ef.set_frequency_spectrum(np.ones((3, 129), complex), 2.0)
+        out = r25.apply_propagation_effects(ef, iS).get_frequency_spectrum()
+        prop_spec[i, iS, 0], prop_spec[i, iS, 1] = out[1], out[2]
+print('apply_propagation_effects on', int(n_sol[:n_prop].sum()), 'solutions')
+
 # the Python path's solutions are a subset of the table, with the same labels
 for i in range(n_events):
     for k in range(py_n_sol[i]):
@@ -125,5 +147,6 @@ np.savez_compressed(os.path.join(OUT, 'ref_mooresbay.npz'), ref_C0=ref_C0, point
                     reflection_coefficient=ice.reflection_coefficient, reflection_phase_shift=ice.reflection_phase_shift,
                     py_n_sol=py_n_sol, py_C0=py_C0, py_reflection=py_refl, py_reflection_case=py_case,
                     n_sol=n_sol, C0=C0, C1=C1, type=typ, reflection=refl, reflection_case=case, delta_y=resid, n_full=n_full,
-                    D=D, T=T, launch=launch, receive=receive, refl_angle=refl_angle, fcoarse=fcoarse, att=att, att_model='MB1')
+                    D=D, T=T, launch=launch, receive=receive, refl_angle=refl_angle, fcoarse=fcoarse, att=att, att_model='MB1',
+                    n_prop=n_prop, prop_spec=prop_spec)
 print('solutions', int(n_sol.sum()), 'max per vertex', n_sol.max(), 'max |delta y| of the golden C0', np.nanmax(np.abs(resid)))

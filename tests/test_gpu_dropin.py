@@ -285,3 +285,74 @@ def test_set_solution_roundtrip(gpu_ctx_factory):
             assert got[3] == ref[i][3] and got[4] == ref[i][4] and got[5] == ref[i][5]
             n += 1
     assert n > 40
+
+
+class _EF:
+    """the slice of NuRadioReco's ElectricField that apply_propagation_effects touches"""
+    def __init__(self, n_samples=256, fs=2.0):
+        self.fs, self.n = fs, n_samples
+        self.spec = np.ones((3, n_samples // 2 + 1), complex)
+    def get_frequency_spectrum(self): return self.spec
+    def get_frequencies(self): return np.fft.rfftfreq(self.n, 1. / self.fs)
+    def get_sampling_rate(self): return self.fs
+    def set_frequency_spectrum(self, s, fs): self.spec = s
+    def __setitem__(self, k, v): pass
+
+
+def test_ray_tracing_class_like_T06_mooresbay():
+    """NuRadioMC/test/SignalProp/T06unit_test_C0_mooresbay.py through the drop-in class (ice shelf with a reflective bottom,
+    n_reflections = 2): first 120 vertices of the reference's golden table, then the per-solution getters and
+    apply_propagation_effects (attenuation per path segment, Fresnel factors per surface reflection, coefficient and phase
+    per bottom reflection) against the reference's outputs."""
+    from nuradiomc_amd import propagation
+    g = golden('ref_mooresbay.npz')
+    ice = _Ice(*g['ice'])
+    ice.reflection = float(g['z_reflection'])
+    ice.reflection_coefficient = float(g['reflection_coefficient'])
+    ice.reflection_phase_shift = float(g['reflection_phase_shift'])
+    r = propagation.ray_tracing(ice, attenuation_model='MB1', n_reflections=2, n_frequencies_integration=25)
+    assert r.get_number_of_raytracing_solutions() == 10
+    n = 120
+    C0 = np.zeros((n, 10))
+    n_checked = n_refl_checked = 0
+    for iX, x in enumerate(g['points'][:n]):
+        r.set_start_and_end_point(x, g['x_receiver'])
+        r.find_solutions()
+        assert r.get_number_of_solutions() == g['n_sol'][iX]
+        for iS in range(r.get_number_of_solutions()):
+            res = r.get_results()[iS]
+            C0[iX, iS] = res['C0']
+            assert (res['reflection'], res['reflection_case'], res['type']) == \
+                (g['reflection'][iX, iS], g['reflection_case'][iX, iS], g['type'][iX, iS])
+            assert r.get_raytracing_output(iS)['ray_tracing_reflection'] == res['reflection']
+            assert abs(r.get_path_length(iS) - g['D'][iX, iS]) < 1e-5 * g['D'][iX, iS]     # C0 differ by <= 1e-6
+            assert abs(r.get_travel_time(iS) - g['T'][iX, iS]) < 1e-5 * g['T'][iX, iS]
+            assert np.max(np.abs(r.get_launch_vector(iS) - g['launch'][iX, iS])) < 1e-5
+            assert np.max(np.abs(r.get_receive_vector(iS) - g['receive'][iX, iS])) < 1e-5
+            ra = np.atleast_1d(r.get_reflection_angle(iS))
+            ref_ra = g['refl_angle'][iX, iS]
+            assert [a is None for a in ra] == list(np.isnan(ref_ra[:len(ra)])) and np.all(np.isnan(ref_ra[len(ra):]))
+            n_checked += 1
+    np.testing.assert_allclose(C0, g['ref_C0'][:n], rtol=1.e-6)     # T06unit_test_C0_mooresbay.py:47
+    # apply_propagation_effects from the reference's own solution records (set_solution)
+    for iX in range(int(g['n_prop'])):
+        m = int(g['n_sol'][iX])
+        if not m:
+            continue
+        r.set_start_and_end_point(g['points'][iX], g['x_receiver'])
+        r.set_solution({'ray_tracing_C0': g['C0'][iX, :m], 'ray_tracing_C1': g['C1'][iX, :m],
+                        'ray_tracing_solution_type': g['type'][iX, :m], 'ray_tracing_reflection': g['reflection'][iX, :m],
+                        'ray_tracing_reflection_case': g['reflection_case'][iX, :m]})
+        for iS in range(m):
+            out = r.apply_propagation_effects(_EF(), iS).spec
+            ref = g['prop_spec'][iX, iS]
+            scale = np.max(np.abs(ref))
+            assert np.max(np.abs(out[1] - ref[0])) <= 1e-6 * scale and np.max(np.abs(out[2] - ref[1])) <= 1e-6 * scale, (iX, iS)
+            n_refl_checked += g['reflection'][iX, iS] > 0
+    assert n_checked > 400 and n_refl_checked > 100
+    with pytest.raises(IndexError):
+        r.get_launch_vector(10)
+    with pytest.raises(AttributeError):   # propagation_base_class.py:156-161
+        r.set_start_and_end_point([100., 0., -600.], g['x_receiver'])
+    # a medium without a reflective layer: the request is dropped with a warning (propagation_base_class.py:128-134)
+    assert propagation.ray_tracing(_Ice(1.78, 0.423, 77.), n_reflections=2).get_number_of_raytracing_solutions() == 2

@@ -145,3 +145,55 @@ def test_gl3_attenuation(gpu_ctx_factory):
     with pytest.raises(ValueError):
         import nuradiomc_amd
         nuradiomc_amd.Context(g['ice'], 'GL3')
+
+
+@pytest.mark.gpu
+def test_bottom_reflections_vs_reference_table_and_oracle(gpu_ctx_factory):
+    """Reflections off the bottom of the ice shelf: the reference's own golden table reference_C0_MooresBay.pkl (1000
+    vertices, n_reflections = 2, up to 10 solutions) at the reference test's tolerance, and every record bit-for-bit /
+    to 1e-9 against the oracle; then the records from given solutions (set_solution) and the attenuation along the path
+    segments (MB1) against the reference's values."""
+    g = golden('ref_mooresbay.npz')
+    ctx = gpu_ctx_factory(g['ice'], 'MB1')
+    n = len(g['points'])
+    zr = float(g['z_reflection'])
+    x2 = np.tile(g['x_receiver'], (n, 1))
+    o = ctx.find_solutions_reflections_batch(g['points'], x2, 2, zr)
+    got = np.where(np.isnan(o['C0']), 0., o['C0'])
+    np.testing.assert_allclose(got, g['ref_C0'], rtol=1e-6, atol=0)      # T06unit_test_C0_mooresbay.py:47
+    assert np.array_equal(o['n_sol'], g['n_sol'])
+    ref = orc.raytrace_batch_refl(g['points'], x2, g['ice'], 2, zr)
+    for k in ('n_sol', 'type', 'reflection', 'reflection_case', 'n_surface', 'n_segments', 'surface_mask'):
+        assert np.array_equal(o[k], ref[k]), k
+    assert np.array_equal(o['C0'], ref['C0'], equal_nan=True)              # same arithmetic: same bits
+    m = ~np.isnan(ref['C0'])
+    for k in ('C1', 'D', 'T'):
+        assert np.array_equal(np.isnan(o[k]), ~m) and max_rel(o[k][m], ref[k][m]) < 1e-9, k
+    for k in ('launch', 'receive'):
+        assert np.max(np.abs(o[k][m] - ref[k][m])) < 1e-12, k
+    has = m & (ref['n_surface'] > 0)
+    assert np.array_equal(np.isnan(o['refl_angle']), ~has) and np.max(np.abs(o['refl_angle'][has] - ref['refl_angle'][has])) < 1e-12
+    # the outer-product form (every vertex with the one receiver) gives the same tables
+    o2 = ctx.find_solutions_reflections_batch(g['points'][:200], g['x_receiver'][None], 2, zr, outer=True)
+    for k in o2:
+        assert np.array_equal(o2[k], o[k][:200], equal_nan=True), k
+    # records of given solutions vs the reference's own values
+    nf = int(g['n_full'])
+    sol = {k: g[k][:nf] for k in ('n_sol', 'C0', 'reflection', 'reflection_case')}
+    r = ctx.find_solutions_reflections_batch(g['points'][:nf], x2[:nf], 2, zr, solutions=sol)
+    mf = ~np.isnan(g['C0'][:nf])
+    assert np.array_equal(r['type'][mf], g['type'][:nf][mf])
+    assert max_rel(r['D'][mf], g['D'][mf]) < 1e-7 and max_rel(r['T'][mf], g['T'][mf]) < 1e-7
+    assert np.max(np.abs(r['launch'][mf] - g['launch'][mf])) < 1e-12 and np.max(np.abs(r['receive'][mf] - g['receive'][mf])) < 1e-12
+    assert np.array_equal(r['n_surface'][mf], np.sum(~np.isnan(g['refl_angle']), axis=2)[mf])
+    idx = np.argwhere(mf)
+    att = ctx.attenuation_reflections_batch(g['points'][idx[:, 0]], x2[idx[:, 0]], g['C0'][:nf][mf], g['reflection'][:nf][mf],
+                                            g['reflection_case'][:nf][mf], zr, g['fcoarse'])
+    assert np.max(np.abs(att - g['att'][mf]) / g['att'][mf]) < 1e-6
+    # n_reflections = 0 reproduces the plain solution finder
+    p = ctx.find_solutions_batch(g['points'][:300], x2[:300])
+    q = ctx.find_solutions_reflections_batch(g['points'][:300], x2[:300], 0, zr)
+    for k in ('n_sol', 'type', 'C0', 'C1', 'D', 'T', 'launch', 'receive', 'refl_angle'):
+        assert np.array_equal(p[k], q[k], equal_nan=True), k
+    with pytest.raises(Exception, match='reflective layer'):
+        ctx.find_solutions_reflections_batch(g['points'][:2], x2[:2], 1, 0.)

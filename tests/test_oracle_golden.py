@@ -243,6 +243,8 @@ def test_mooresbay_paths_vs_reference_python_path():
     ra = g['refl_angle']                               # [nf, 10, segment]
     n_surface = np.sum(~np.isnan(ra), axis=2)
     assert np.array_equal(o['n_surface'][m], n_surface[m]) and n_surface[m].max() == 3
+    mask = np.sum((~np.isnan(ra)) << np.arange(3)[None, None, :], axis=2)
+    assert np.array_equal(o['surface_mask'][m], mask[m])          # which path segments reflect at the surface
     has = m & (n_surface > 0)
     angle = np.max(np.where(np.isnan(ra), -1., ra), axis=2)   # the same in every segment that reflects
     assert np.max(np.abs(o['refl_angle'][has] - angle[has])) < 1e-12
