@@ -9,5 +9,5 @@ SRC="nuradiomc_amd/csrc/api.hip nuradiomc_amd/csrc/raytrace.hip nuradiomc_amd/cs
 [ -f nuradiomc_amd/csrc/pipeline.hip ] && SRC="$SRC nuradiomc_amd/csrc/pipeline.hip"
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-function \
     -I include -I nuradiomc_amd/csrc $SRC -o nuradiomc_amd/lib/libnrhip.so -Wl,-rpath,/opt/rocm/lib "$@"
-gcc -O2 -fPIC -shared -std=gnu11 -ffp-contract=off -o oracle/_build/liboracle.so oracle/nrmc_oracle.c -lm
+gcc -O2 -fPIC -shared -std=gnu11 -ffp-contract=off -o oracle/_build/liboracle.so oracle/nrmc_oracle.c oracle/arz_oracle.c -lm
 echo "built nuradiomc_amd/lib/libnrhip.so oracle/_build/liboracle.so"

@@ -1,0 +1,220 @@
+/* arz_oracle.c -- CPU restatement of the ARZ time-domain Askaryan model (TEST INFRASTRUCTURE ONLY, never linked or
+ * imported by nuradiomc_amd; see oracle/README in raytrace_oracle.py's header).
+ *
+ * Follows NuRadioMC/SignalGen/ARZ/ARZ.py: get_vector_potential (:36-275) -- vector potential of the charge-excess profile,
+ * A(t) = -mu/(4 pi) int dz' Q(z') v_perp F_p(t_ret) / R, trapezoid rule on the profile grid with a 100x refinement of the
+ * stretches of the profile that radiate within +-1 ns of the observer time -- and ARZ.get_time_trace (:500-673): E = -dA/dt,
+ * rotation into the on-sky basis of the direction to the shower maximum, zero trace more than 20 deg off the Cherenkov
+ * angle.  Plain loops; numpy's array semantics are spelled out where they decide a value:
+ *   np.arange(a, b, s): ceil((b - a) / s) entries a + i * ((a + s) - a);
+ *   np.interp on the SLICE [i_start:i_stop) of the profile: constant beyond the slice's last node;
+ *   `tt > 0 & mask` parses as tt > (0 & mask), i.e. tt > 0 (:243, :247).
+ * Parity status: PINNED against outputs of the reference run in the build container (tests/golden/ref_arz.npz,
+ * tests/golden/gen/gen_arz.py: the bundled AIRES profile nue_1EeV_CC_1_s0001.t1005/.t1006 and a synthetic one). */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* NuRadioReco units (ns, m, eV, e+): ARZ.py:31-33 */
+static const double ARZ_RHO = 5.767155003928648e+39;  /* 0.924 g / cm^3 */
+static const double ARZ_XMU = 2.0133542226782937e-07; /* 12.566370e-7 N / A^2 */
+static const double ARZ_C = 0.299792458;              /* m / ns */
+static const double ARZ_TEV = 1e12;
+
+typedef struct {
+    double Af, freq_pos, freq_neg, exp_pos, exp_neg, t0_pos, t0_neg;
+} arz_par_t;
+
+static double arz_interp(double x, const double *xp, const double *fp, int n) /* np.interp, xp increasing */
+{
+    if (x <= xp[0]) return fp[0];
+    if (x >= xp[n - 1]) return fp[n - 1];
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) / 2;
+        if (xp[mid] <= x) lo = mid; else hi = mid;
+    }
+    double slope = (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]);
+    return slope * (x - xp[lo]) + fp[lo];
+}
+
+/* returns 0, or -1 if the +-1 ns condition holds on more than two stretches (NotImplementedError in the reference, :207) */
+int orc_arz_vector_potential(double shower_energy, double theta, int N, double dt, int n_prof, const double *profile_depth,
+                             const double *profile_ce, const double par7[7], int is_had, double n_index, double distance,
+                             double interp_factor, double interp_factor2, int shift_for_xmax, double em_factor,
+                             double *vp /* [N + 1][3] */)
+{
+    arz_par_t P = { par7[0], par7[1], par7[2], par7[3], par7[4], par7[5], par7[6] };
+    if (!is_had) em_factor = 1.;
+    /* ttt = arange(0, (N + 1) dt, dt) + 0.5 dt - mean, cut back to N + 1 samples (:98-102) */
+    int nt = (int)ceil(((N + 1) * dt - 0.) / dt);
+    double *ttt = (double *)malloc(sizeof(double) * (size_t)nt);
+    double mean = 0;
+    for (int i = 0; i < nt; i++) mean += i * dt;
+    mean /= nt;
+    for (int i = 0; i < nt; i++) ttt[i] = i * dt + 0.5 * dt - mean;
+    if (nt != N + 1) nt -= 1;
+    const double xn = n_index, beta = 1.;
+    const double cher = acos(1. / n_index);
+    /* optional resampling of the whole profile (:108-113) */
+    int nd = n_prof;
+    double *dense = (double *)malloc(sizeof(double) * (size_t)(interp_factor != 1 ? (int)(interp_factor * n_prof) + 1 : n_prof));
+    double *ce = (double *)malloc(sizeof(double) * (size_t)(interp_factor != 1 ? (int)(interp_factor * n_prof) + 1 : n_prof));
+    if (interp_factor != 1) {
+        nd = (int)(interp_factor * n_prof);
+        double lo = profile_depth[0], hi = profile_depth[0];
+        for (int i = 1; i < n_prof; i++) { lo = fmin(lo, profile_depth[i]); hi = fmax(hi, profile_depth[i]); }
+        double step = (hi - lo) / (nd - 1);
+        for (int i = 0; i < nd; i++) {
+            dense[i] = (i == nd - 1) ? hi : lo + i * step; /* np.linspace */
+            ce[i] = arz_interp(dense[i], profile_depth, profile_ce, n_prof);
+        }
+    } else {
+        memcpy(dense, profile_depth, sizeof(double) * (size_t)n_prof);
+        memcpy(ce, profile_ce, sizeof(double) * (size_t)n_prof);
+    }
+    int imax = 0;
+    double sum_ce = 0;
+    for (int i = 0; i < nd; i++) {
+        if (ce[i] > ce[imax]) imax = i;
+        sum_ce += ce[i];
+    }
+    const double dxmax = dense[imax] / ARZ_RHO;
+    const double X0 = distance * sin(theta), X2 = distance * cos(theta) + (shift_for_xmax ? dxmax : 0.);
+    const double xntot = sum_ce * (dense[1] / ARZ_RHO - dense[0] / ARZ_RHO);
+    const double factor = -ARZ_XMU / (4. * M_PI);
+    const double fc = 4. * M_PI / (ARZ_XMU * sin(cher));
+    const double E_TeV = shower_energy / ARZ_TEV;
+    const double R0 = sqrt(X0 * X0 + X2 * X2);
+    /* work arrays for the refined profile */
+    size_t cap = (size_t)nd + 16;
+    double *d2 = (double *)malloc(sizeof(double) * cap), *c2 = (double *)malloc(sizeof(double) * cap);
+    double *tt = (double *)malloc(sizeof(double) * (size_t)nd);
+    int status = 0;
+    for (int it = 0; it < nt; it++) {
+        const double tobs = ttt[it] + (R0 / ARZ_C * xn);
+        int any20 = 0;
+        for (int i = 0; i < nd; i++) {
+            double z = dense[i] / ARZ_RHO;
+            double R = sqrt(X0 * X0 + (X2 - z) * (X2 - z));
+            double arg = z - (beta * ARZ_C * tobs - xn * R);
+            tt[i] = (-arg / (ARZ_C * beta));
+            if (tt[i] < 20. && tt[i] > -20.) any20 = 1;
+        }
+        vp[3 * it] = vp[3 * it + 1] = vp[3 * it + 2] = 0;
+        if (!any20) continue;
+        /* the stretches with -1 ns < tt < 1 ns get interp_factor2 times more points (:167-214) */
+        const double *zd = dense, *zc = ce;
+        size_t m = (size_t)nd;
+        if (interp_factor2 != 1) {
+            int idx[18], ni = 0;
+            for (int i = 0; i + 1 < nd; i++) {
+                int a = (tt[i] < 1. && tt[i] > -1.), b = (tt[i + 1] < 1. && tt[i + 1] > -1.);
+                if (a != b && ni < 16) idx[ni++] = i;
+            }
+            if (ni != 0 && ni % 2 != 0) { /* a stretch that begins with the first / ends with the last profile point */
+                if (tt[0] < 1. && tt[0] > -1. && idx[0] != 0) {
+                    memmove(idx + 1, idx, sizeof(int) * (size_t)ni);
+                    idx[0] = 0;
+                    ni++;
+                } else if (idx[ni - 1] != nd - 1) {
+                    idx[ni++] = nd - 1;
+                }
+            }
+            if (ni != 0 && ni % 2 == 0 && ni != 2 && ni != 4) {
+                status = -1;
+                break;
+            }
+            if (ni == 2 || ni == 4) {
+                const double dp = dense[1] - dense[0];
+                const double step = dp / interp_factor2;
+                size_t need = (size_t)nd + 8;
+                for (int q = 0; q < ni; q += 2)
+                    need += (size_t)ceil((dense[idx[q + 1]] - dense[idx[q]]) / step) + 2;
+                if (need > cap) {
+                    cap = need * 2;
+                    d2 = (double *)realloc(d2, sizeof(double) * cap);
+                    c2 = (double *)realloc(c2, sizeof(double) * cap);
+                }
+                m = 0;
+                int from = 0;
+                for (int q = 0; q < ni; q += 2) {
+                    int is = idx[q], ie = idx[q + 1];
+                    for (int i = from; i < is; i++) { d2[m] = dense[i]; c2[m] = ce[i]; m++; }
+                    double start = dense[is];
+                    long nf = (long)ceil((dense[ie] - start) / step);
+                    double delta = (start + step) - start;
+                    for (long k = 0; k < nf; k++) {
+                        double x = (k == 0) ? start : (k == 1 ? start + step : start + k * delta);
+                        d2[m] = x;
+                        c2[m] = arz_interp(x, dense + is, ce + is, ie - is);
+                        m++;
+                    }
+                    from = ie;
+                }
+                for (int i = from; i < nd; i++) { d2[m] = dense[i]; c2[m] = ce[i]; m++; }
+                zd = d2;
+                zc = c2;
+            }
+        }
+        /* trapezoid rule over the (refined) profile (:216-266) */
+        double acc[3] = { 0, 0, 0 }, prev_z = 0, prev_y[3] = { 0, 0, 0 };
+        for (size_t i = 0; i < m; i++) {
+            double z = zd[i] / ARZ_RHO;
+            double R = sqrt(X0 * X0 + (X2 - z) * (X2 - z));
+            double arg = z - (beta * ARZ_C * tobs - xn * R);
+            double t = (-arg / (ARZ_C * beta));
+            double F = 0;
+            if (t < 20. && t > -20.) {
+                double a = fabs(t), A;
+                if (t > 0) A = P.Af * E_TeV * (exp(-a / P.t0_pos) + pow(1. + P.freq_pos * a, P.exp_pos));
+                else A = P.Af * E_TeV * (exp(-a / P.t0_neg) + pow(1. + P.freq_neg * a, P.exp_neg));
+                F = A * fc / xntot * em_factor;
+            }
+            double ux = X0 / R, uz = (X2 - z) / R;
+            double v[3] = { ux * uz, 0. * uz, -(ux * ux + 0. * 0.) };
+            double y[3];
+            for (int k = 0; k < 3; k++) y[k] = -v[k] * zc[i] * F / R;
+            if (i > 0)
+                for (int k = 0; k < 3; k++) acc[k] += (z - prev_z) * (y[k] + prev_y[k]) / 2.0;
+            prev_z = z;
+            for (int k = 0; k < 3; k++) prev_y[k] = y[k];
+        }
+        for (int k = 0; k < 3; k++) vp[3 * it + k] = acc[k] * factor;
+    }
+    free(ttt); free(dense); free(ce); free(d2); free(c2); free(tt);
+    return status;
+}
+
+/* ARZ.get_time_trace (:597-655) given the profile: on-sky (eR, eTheta, ePhi) traces [3][N]; returns like above */
+int orc_arz_time_trace(double shower_energy, double theta, int N, double dt, int n_prof, const double *profile_depth,
+                       const double *profile_ce, const double par7[7], int is_had, double n_index, double R,
+                       double interp_factor, double interp_factor2, int shift_for_xmax, double em_factor,
+                       double maximum_angle, double *trace /* [3][N] */)
+{
+    for (long i = 0; i < 3L * N; i++) trace[i] = 0;
+    if (fabs(theta - acos(1 / n_index)) > maximum_angle) return 0;
+    double *vp = (double *)malloc(sizeof(double) * 3 * (size_t)(N + 2));
+    int st = orc_arz_vector_potential(shower_energy, theta, N, dt, n_prof, profile_depth, profile_ce, par7, is_had, n_index, R,
+                                      interp_factor, interp_factor2, shift_for_xmax, em_factor, vp);
+    if (st == 0) {
+        int imax = 0;
+        for (int i = 1; i < n_prof; i++)
+            if (profile_ce[i] > profile_ce[imax]) imax = i;
+        double thetaprime = theta;
+        if (!shift_for_xmax) { /* theta_to_thetaprime :299-315 */
+            double L = profile_depth[imax] / ARZ_RHO;
+            thetaprime = atan2(R * sin(theta), R * cos(theta) - L);
+        }
+        const double ct = cos(thetaprime), st_ = sin(thetaprime); /* cstrafo(zenith = theta', azimuth = 0) */
+        for (int i = 0; i < N; i++) {
+            double e[3];
+            for (int k = 0; k < 3; k++) e[k] = -(vp[3 * (i + 1) + k] - vp[3 * i + k]) / dt;
+            trace[i] = st_ * e[0] + ct * e[2];          /* eR */
+            trace[N + i] = ct * e[0] - st_ * e[2];      /* eTheta */
+            trace[2 * N + i] = e[1];                    /* ePhi (azimuth 0: (-sin 0, cos 0, 0)) */
+        }
+    }
+    free(vp);
+    return st;
+}

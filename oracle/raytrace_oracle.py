@@ -17,11 +17,11 @@ MODEL_TO_INT = {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4, "GL3": 5}
 
 
 def build(force=False):
-    src = os.path.join(_HERE, 'nrmc_oracle.c')
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ('nrmc_oracle.c', 'arz_oracle.c')]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
-        subprocess.check_call(['gcc', '-O2', '-fPIC', '-shared', '-std=gnu11', '-ffp-contract=off', '-o', _SO, src,
-                               '-lm'])
+        subprocess.check_call(['gcc', '-O2', '-fPIC', '-shared', '-std=gnu11', '-ffp-contract=off', '-o', _SO] + srcs +
+                              ['-lm'])
     return _SO
 
 

@@ -253,3 +253,45 @@ def test_mooresbay_paths_vs_reference_python_path():
     att = rto.attenuation_batch_refl(x1[idx[:, 0]], x2[idx[:, 0]], g['C0'][:nf][m], g['reflection'][:nf][m],
                                      g['reflection_case'][:nf][m], g['ice'], float(g['z_reflection']), 'MB1', g['fcoarse'])
     assert np.max(np.abs(att - g['att'][m]) / g['att'][m]) < 1e-9
+
+
+def _arz_library(g):
+    d = g['lib_depth']
+    return {'EM': {1e18: {'depth': d, 'charge_excess': list(g['lib_EM_1e18'])}, 1e16: {'depth': d, 'charge_excess': list(g['lib_EM_1e16'])}},
+            'HAD': {1e18: {'depth': d, 'charge_excess': list(g['lib_HAD_1e18'])}, 1e17: {'depth': d, 'charge_excess': list(g['lib_HAD_1e17'])}}}
+
+
+def test_arz_vs_reference():
+    """ARZ time-domain model: vector potentials from the charge-excess profile the reference ships (AIRES, nue 1 EeV CC) and a
+    hadronic one -- observer 200 m .. 3 km, 50 .. 62 deg, with / without the 100x refinement, resampled profile, observer
+    relative to the shower maximum -- then ARZ.get_time_trace from a library (closest energy, rescaling, RandomState profile
+    choice, same_shower, 20 deg cut, rotation to theta') and askaryan.get_time_trace / get_frequency_spectrum."""
+    from oracle import arz_oracle as arz
+    g = golden('ref_arz.npz')
+    for i, c in enumerate(g['vp_cases']):
+        typ = 'HAD' if c[0] else 'EM'
+        E, th, N, dt, R, f1, f2, shift, emf = c[1:]
+        prof = g['lib_HAD_1e18'][0] if c[0] else g['lib_EM_1e18'][0]
+        vp = arz.vector_potential(E, th, int(N), dt, g['lib_depth'], prof, arz.MODEL_PARAMETERS['ARZ2020'][typ], typ, 1.78, R, f1,
+                                  f2, bool(shift), emf)
+        ref = g['vp_%d' % i]
+        assert vp.shape == ref.shape and np.max(np.abs(vp - ref)) <= 1e-12 * np.max(np.abs(ref)), i
+    a = arz.ARZ(_arz_library(g), seed=1234)
+    a.set_seed(int(g['tr_seed']))
+    n_zero = 0
+    for k, c in enumerate(g['tr_cases']):
+        typ = 'HAD' if c[0] else 'EM'
+        tr = a.get_time_trace(c[1], c[2], 256, 0.5, typ, 1.78, c[3], same_shower=bool(c[4]), iN=None if c[5] < 0 else c[5])
+        assert a.get_last_shower_profile_id()[typ] == int(c[6]), k
+        ref = g['tr'][k]
+        n_zero += not np.any(ref)
+        assert np.max(np.abs(tr - ref)) <= 1e-11 * max(np.max(np.abs(ref)), 1e-300), k
+    assert n_zero == 1   # the trace beyond 20 deg from the Cherenkov angle
+    b = arz.ARZ(_arz_library(g), seed=int(g['ask_seed']))
+    for k, c in enumerate(g['ask_cases']):
+        typ = 'HAD' if c[0] else 'EM'
+        tr, add = arz.askaryan_time_trace(b, c[1], c[2], 256, 0.5, typ, 1.78, 1500., iN=None if c[3] < 0 else c[3])
+        assert add['iN'] == int(c[4])
+        spec, _ = arz.askaryan_frequency_spectrum(b, c[1], c[2], 256, 0.5, typ, 1.78, 1500., iN=add['iN'])
+        assert np.max(np.abs(tr - g['ask_tr'][k])) <= 1e-11 * np.max(np.abs(g['ask_tr'][k])), k
+        assert np.max(np.abs(spec - g['ask_spec'][k])) <= 1e-11 * np.max(np.abs(g['ask_spec'][k])), k
