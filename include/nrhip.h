@@ -152,6 +152,23 @@ int nrhip_attenuation_reflections_batch(nrhip_ctx* ctx, int64_t n_rays, const do
                                         const int32_t* reflection, const int32_t* reflection_case, double z_reflection,
                                         int32_t n_freq, const double* freqs, double* att, double* segment_att);
 
+/* ---- ARZ time-domain Askaryan model ---------------------------------------------------------------------------------
+ * ARZ.get_time_trace (NuRadioMC/SignalGen/ARZ/ARZ.py:500-673) for a batch of (shower, ray) pairs: vector potential of the
+ * charge-excess profile (get_vector_potential :36-275: trapezoid rule over the profile, stretches radiating within +-1 ns
+ * of the observer time refined interp_factor2 (100) times), E = -dA/dt, rotated to the on-sky basis (eR, eTheta, ePhi) of
+ * the direction to the shower maximum; zero trace more than maximum_angle (20 deg) off the Cherenkov angle.
+ * shower_type 0 HAD / 1 EM; em_factor = ARZ.em_fraction(E) (:436-447, HAD only); profile_index: row of profile_ce
+ * [n_profiles][n_depth] on the common grid profile_depth (NuRadioReco units: depth in g/cm^2 * 6.2415e37); rescale
+ * (NULL = 1): E / E_library; parameters [2][7] = (Af, freq_pos, freq_neg, exp_pos, exp_neg, t0_pos, t0_neg) for HAD, EM
+ * (:394-434).  trace [n_rays][3][N]; vector_potential (may be NULL) [n_rays][N + 1][2] = (A_x, A_z), A_y = 0.
+ * The library handling (closest energy, random profile number, same_shower) stays on the host.  HOST pointers.   */
+int nrhip_arz_time_trace_batch(nrhip_ctx* ctx, int64_t n_rays, const double* energy, const double* theta, const double* distance,
+                               const int32_t* shower_type, const double* em_factor, const int32_t* profile_index,
+                               const double* rescale, int32_t n_profiles, int32_t n_depth, const double* profile_depth,
+                               const double* profile_ce, const double* parameters, int32_t N, double dt, double n_index,
+                               double interp_factor2, int32_t shift_for_xmax, double maximum_angle, double* trace,
+                               double* vector_potential);
+
 /* Batched ray_tracing.get_attenuation on an explicit frequency list
  * (analyticraytracing.py:2744 -> get_attenuation_along_path :933-1089, Python branch), replacing the
  * per-frequency wrapper.pyx get_attenuation_along_path (:30-31).

@@ -1,6 +1,7 @@
 """Drop-in for NuRadioMC.SignalGen.askaryan.get_frequency_spectrum / get_time_trace
 (NuRadioMC/SignalGen/askaryan.py:10-213) for the frequency-domain parametrisations
-(NuRadioMC/SignalGen/parametrizations.py: ZHS1992, Alvarez2000, Alvarez2009), evaluated on the GPU.
+(NuRadioMC/SignalGen/parametrizations.py: ZHS1992, Alvarez2000, Alvarez2009) and the time-domain ARZ2019 / ARZ2020
+models (nuradiomc_amd/arz.py; set `askaryan.arz_library` to the shower library first), evaluated on the GPU.
 
 The stateful random draw of the Alvarez2009 EM parameter k_L (parametrizations.py:90-91, :160-173) stays on the
 host and reproduces the reference's stream: one np.random.RandomState(seed) per model, created at the first call.
@@ -31,9 +32,36 @@ def _alvarez2009_kL_distribution(energy):
     return mean, sigma
 
 
+_arz = {}
+arz_library = None   # path of (or dict with) the ARZ shower library; the reference downloads it, this module does not
+
+
+def _arz_time_trace(energy, theta, N, dt, shower_type, n_index, R, model, interp_factor=None, interp_factor2=None,
+                    same_shower=False, seed=None, **kwargs):
+    """askaryan.get_time_trace for ARZ2019 / ARZ2020 (askaryan.py:118-126): eTheta of ARZ.get_time_trace, one ARZ object
+    per (model, seed) as the reference's Singleton keeps it"""
+    from . import arz
+    key = (model, seed)
+    if key not in _arz:
+        _arz[key] = arz.ARZ(arz_version=model, seed=seed, library=arz_library)
+    g = _arz[key]
+    if interp_factor is not None:
+        g.set_interpolation_factor(interp_factor)
+    if interp_factor2 is not None:
+        g.set_interpolation_factor2(interp_factor2)
+    trace = g.get_time_trace(energy, theta, N, dt, shower_type, n_index, R, same_shower=same_shower, **kwargs)[1]
+    return trace, {'iN': g.get_last_shower_profile_id()[shower_type]}
+
+
 def get_frequency_spectrum(energy, theta, N, dt, shower_type, n_index, R, model, full_output=False, **kwargs):
     global _Alvarez2009_k_L
     shower_type = shower_type.upper()
+    if model in ('ARZ2019', 'ARZ2020'):   # time-domain model: fft.time2freq of the trace (askaryan.py:208-213)
+        kw = {k: v for k, v in kwargs.items() if k in ('interp_factor', 'interp_factor2', 'same_shower', 'seed', 'iN',
+                                                       'shift_for_xmax', 'maximum_angle', 'profile_depth', 'profile_ce')}
+        trace, additional = _arz_time_trace(energy, theta, N, dt, shower_type, n_index, R, model, **kw)
+        spec = np.fft.rfft(trace, axis=-1) / (1 / dt) * 2 ** 0.5
+        return (spec, additional) if full_output else spec
     if model not in get_parametrizations():
         raise NotImplementedError("model {} unknown".format(model))
     seed = kwargs.get('seed')
@@ -70,6 +98,11 @@ def get_frequency_spectrum(energy, theta, N, dt, shower_type, n_index, R, model,
 
 def get_time_trace(energy, theta, N, dt, shower_type, n_index, R, model, full_output=False, **kwargs):
     """time domain via the FFT convention of NuRadioReco/utilities/fft.py:92"""
+    if model in ('ARZ2019', 'ARZ2020'):
+        kw = {k: v for k, v in kwargs.items() if k in ('interp_factor', 'interp_factor2', 'same_shower', 'seed', 'iN',
+                                                       'shift_for_xmax', 'maximum_angle', 'profile_depth', 'profile_ce')}
+        trace, additional = _arz_time_trace(energy, theta, N, dt, shower_type.upper(), n_index, R, model, **kw)
+        return (trace, additional) if full_output else trace
     tmp = get_frequency_spectrum(energy, theta, N, dt, shower_type, n_index, R, model, full_output=full_output, **kwargs)
     spec = tmp[0] if full_output else tmp
     trace = np.fft.irfft(spec, n=N) / dt / 2 ** 0.5

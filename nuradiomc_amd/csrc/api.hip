@@ -2,6 +2,7 @@
 #include "../../include/nrhip.h"
 #include "nrhip_internal.h"
 #include "ctx.h"
+#include "arz.h"
 #include <cstdio>
 #include <algorithm>
 #include <cmath>
@@ -400,6 +401,57 @@ int nrhip_attenuation_reflections_batch(nrhip_ctx* ctx, int64_t n_rays, const do
     HIPCHK(hipMemcpyAsync(att, da.p, nk * n_freq * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (segment_att) HIPCHK(hipMemcpyAsync(segment_att, dsa.p, nk * NS * n_freq * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int nrhip_arz_time_trace_batch(nrhip_ctx* ctx, int64_t n_rays, const double* energy, const double* theta, const double* distance,
+                               const int32_t* shower_type, const double* em_factor, const int32_t* profile_index,
+                               const double* rescale, int32_t n_profiles, int32_t n_depth, const double* profile_depth,
+                               const double* profile_ce, const double* parameters, int32_t N, double dt, double n_index,
+                               double interp_factor2, int32_t shift_for_xmax, double maximum_angle, double* trace,
+                               double* vector_potential)
+{
+    if (!ctx || !energy || !theta || !distance || !shower_type || !em_factor || !profile_index || !profile_depth || !profile_ce ||
+        !parameters || !trace)
+        return fail_msg("nrhip_arz_time_trace_batch: NULL argument");
+    if (n_rays < 0) return fail_msg("nrhip_arz_time_trace_batch: negative size");
+    if (n_rays == 0) return 0;
+    if (N < 2 || N % 2 != 0 || !(dt > 0)) return fail_msg("nrhip_arz_time_trace_batch: N must be even and dt > 0");
+    if (n_depth < 2 || n_depth > 2048 || n_profiles < 1)
+        return fail_msg("nrhip_arz_time_trace_batch: charge-excess profiles need 2..2048 depth bins");
+    for (int64_t i = 0; i < n_rays; i++) {
+        if (shower_type[i] != 0 && shower_type[i] != 1)  // NotImplementedError in the reference (ARZ.py:635-641)
+            return fail_msg("nrhip_arz_time_trace_batch: showers of this type are not implemented. Use 'HAD', 'EM'");
+        if (profile_index[i] < 0 || profile_index[i] >= n_profiles) return fail_msg("nrhip_arz_time_trace_batch: bad profile index");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf dE, dth, dR, dty, dem, dpi, drs, dpd, dpc, dpar, dvp, dtr, dst;
+    const size_t nr = (size_t)n_rays;
+    HIPCHK(dE.alloc(nr * 8)); HIPCHK(dth.alloc(nr * 8)); HIPCHK(dR.alloc(nr * 8)); HIPCHK(dty.alloc(nr * 4));
+    HIPCHK(dem.alloc(nr * 8)); HIPCHK(dpi.alloc(nr * 4)); HIPCHK(drs.alloc(nr * 8));
+    HIPCHK(dpd.alloc((size_t)n_depth * 8)); HIPCHK(dpc.alloc((size_t)n_profiles * n_depth * 8)); HIPCHK(dpar.alloc(14 * 8));
+    HIPCHK(dvp.alloc(nr * (N + 1) * 2 * 8)); HIPCHK(dtr.alloc(nr * 3 * N * 8)); HIPCHK(dst.alloc(nr * 4));
+    hipStream_t s = ctx->stream;
+#define H2D(dst, src, bytes) HIPCHK(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, s))
+    H2D(dE, energy, nr * 8); H2D(dth, theta, nr * 8); H2D(dR, distance, nr * 8); H2D(dty, shower_type, nr * 4);
+    H2D(dem, em_factor, nr * 8); H2D(dpi, profile_index, nr * 4);
+    if (rescale) H2D(drs, rescale, nr * 8);
+    H2D(dpd, profile_depth, (size_t)n_depth * 8); H2D(dpc, profile_ce, (size_t)n_profiles * n_depth * 8);
+    H2D(dpar, parameters, 14 * 8);
+#undef H2D
+    HIPCHK(hipMemsetAsync(dst.p, 0, nr * 4, s));
+    nrhip::ArzBatch b{(long)n_rays, dE.as<double>(), dth.as<double>(), dR.as<double>(), dty.as<int>(), dem.as<double>(),
+                      dpi.as<int>(), rescale ? drs.as<double>() : nullptr, n_profiles, n_depth, dpd.as<double>(),
+                      dpc.as<double>(), dpar.as<double>(), N, dt, n_index, interp_factor2, shift_for_xmax, maximum_angle};
+    nrhip::launch_arz(s, b, dvp.as<double>(), dtr.as<double>(), dst.as<int>());
+    HIPCHK(hipGetLastError());
+    std::vector<int> st(nr);
+    HIPCHK(hipMemcpyAsync(st.data(), dst.p, nr * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(trace, dtr.p, nr * 3 * N * 8, hipMemcpyDeviceToHost, s));
+    if (vector_potential) HIPCHK(hipMemcpyAsync(vector_potential, dvp.p, nr * (N + 1) * 2 * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < nr; i++)
+        if (st[i]) return fail_msg("nrhip_arz_time_trace_batch: length of indices is not 2 nor 4 (more than two stretches of the profile radiate within 1 ns)");
     return 0;
 }
 

@@ -1,0 +1,26 @@
+// arz.h -- batch descriptor of the ARZ kernels (arz.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nrhip {
+
+struct ArzBatch {
+    long n_rays;
+    const double *energy, *theta, *distance;  // [n_rays]
+    const int* shower_type;                   // [n_rays] 0 HAD, 1 EM
+    const double* em_factor;                  // [n_rays] energy fraction of the electromagnetic component (HAD only)
+    const int* profile_index;                 // [n_rays] row of profile_ce
+    const double* rescale;                    // [n_rays] amplitude factor of the profile (E / E_library) or nullptr
+    int n_profiles, n_depth;
+    const double* profile_depth;              // [n_depth]
+    const double* profile_ce;                 // [n_profiles][n_depth]
+    const double* parameters;                 // [2][7]: (Af, freq_pos, freq_neg, exp_pos, exp_neg, t0_pos, t0_neg) for HAD, EM
+    int N;
+    double dt, n_index, interp_factor2;
+    int shift_for_xmax;
+    double maximum_angle;
+};
+
+void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int* status);
+
+}  // namespace nrhip

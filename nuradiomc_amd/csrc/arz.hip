@@ -1,0 +1,319 @@
+// arz.hip -- the ARZ time-domain Askaryan model on MI355X (gfx950): vector potential of a charge-excess profile and the
+// electric-field trace derived from it (NuRadioMC/SignalGen/ARZ/ARZ.py: get_vector_potential :36-275, ARZ.get_time_trace
+// :500-673).
+//
+// A(t) = -mu / (4 pi) int dz' Q(z') v_perp F_p(t_ret(z', t)) / R(z') is a trapezoid sum over the profile for each of the
+// N + 1 observer times; stretches of the profile that radiate within +-1 ns of the observer time are refined 100x
+// (np.arange / np.interp on the slice, restated below), so a time bin costs between ~5e2 and ~5e4 integrand evaluations
+// (exp + pow each).  Mapping: grid = (ray, 1/8 of the observer times that can see the shower); inside a block every WAVE owns one observer
+// time at a time and its 64 lanes stride over the points of the (refined) profile; the +-1 ns stretches are found from
+// wave ballots (the profile points of a wave are consecutive, so a gap is a bit flip in the ballot word), the trapezoid
+// rule is evaluated as sum_j y_j (z_{j+1} - z_{j-1}) / 2 so that every point is evaluated once, and a shuffle reduction
+// gives the two non-zero components (x, z) of A.  The profile (depth, charge excess) sits in LDS.  A second kernel
+// differentiates and rotates into the on-sky basis of the direction to the shower maximum.
+// FP64 VALU / transcendental bound: ~24 B of HBM traffic per observer time against 1e3..1e5 exp/pow evaluations.
+#include <hip/hip_runtime.h>
+#include "arz.h"
+
+namespace nrhip {
+
+#define ARZ_CHUNKS 8      // blocks per ray: each takes 1/8 of the observer times that can see the shower
+#define ARZ_MAX_PROFILE 2048
+
+static __device__ const double ARZ_RHO = 5.767155003928648e+39;   // 0.924 g / cm^3 in NuRadioReco units (ARZ.py:31)
+static __device__ const double ARZ_XMU = 2.0133542226782937e-07;  // 12.566370e-7 N / A^2 (:32)
+static __device__ const double ARZ_C = 0.299792458;               // m / ns (:33)
+
+struct ArzRay {
+    double X0, X2, R0, xntot, E_TeV, em_factor;
+    double Af, freq_pos, freq_neg, exp_pos, exp_neg, t0_pos, t0_neg;
+};
+
+// integrand -v Q F_p / R at shower depth `depth` (g/cm^2 in internal units) for observer time tobs: x and z components
+__device__ inline void arz_integrand(const ArzRay& r, double depth, double q, double tobs, double n_index, double fc,
+                                     double* yx, double* yz, double* tt_out)
+{
+    const double z = depth / ARZ_RHO;
+    const double R = sqrt(r.X0 * r.X0 + (r.X2 - z) * (r.X2 - z));
+    const double arg = z - (ARZ_C * tobs - n_index * R);
+    const double t = -arg / ARZ_C;
+    *tt_out = t;
+    double F = 0.;
+    if (t < 20. && t > -20.) {
+        const double a = fabs(t);
+        double A;
+        if (t > 0) A = r.Af * r.E_TeV * (exp(-a / r.t0_pos) + pow(1. + r.freq_pos * a, r.exp_pos));
+        else A = r.Af * r.E_TeV * (exp(-a / r.t0_neg) + pow(1. + r.freq_neg * a, r.exp_neg));
+        F = A * fc / r.xntot * r.em_factor;
+    }
+    const double ux = r.X0 / R, uz = (r.X2 - z) / R;
+    *yx = -(ux * uz) * q * F / R;
+    *yz = (ux * ux) * q * F / R;  // -v_z, v_z = -(u_x^2 + u_y^2)
+}
+
+__device__ inline double arz_tt(const ArzRay& r, double depth, double tobs, double n_index)
+{
+    const double z = depth / ARZ_RHO;
+    const double R = sqrt(r.X0 * r.X0 + (r.X2 - z) * (r.X2 - z));
+    return -(z - (ARZ_C * tobs - n_index * R)) / ARZ_C;
+}
+
+// np.interp(x, xp[is:ie], fp[is:ie]): constant beyond the slice's last node; `guess` = a node index near x
+__device__ inline double arz_interp_slice(double x, const double* __restrict__ xp, const double* __restrict__ fp, int is, int ie,
+                                          int guess)
+{
+    const int last = ie - 1;
+    if (x <= xp[is]) return fp[is];
+    if (x >= xp[last]) return fp[last];
+    int k = guess < is ? is : (guess > last - 1 ? last - 1 : guess);
+    while (k > is && xp[k] > x) k--;
+    while (k < last - 1 && xp[k + 1] <= x) k++;
+    const double slope = (fp[k + 1] - fp[k]) / (xp[k + 1] - xp[k]);
+    return slope * (x - xp[k]) + fp[k];
+}
+
+// One stretch of the refined profile: coarse nodes [c0, c1) followed by n_fine points start + k * delta (slice [is, ie))
+struct ArzPiece { int c0, c1, is, ie; long n_fine; double start, step, delta; };
+
+__global__ void __launch_bounds__(256)
+arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 1][2] */, int* __restrict__ status)
+{
+    extern __shared__ double lds[];
+    const int ray = blockIdx.x;
+    const int nd = b.n_depth;
+    double* s_depth = lds;
+    double* s_ce = lds + nd;
+    __shared__ double s_w[4][4];   // per wave: sum, max value, h min, h max
+    __shared__ int s_wi[4];        // per wave: index of the max
+    const int nt = b.N + 1;
+    const double theta = b.theta[ray];
+    const int typ = b.shower_type[ray];  // 0 HAD, 1 EM
+    // 20 deg cut (ARZ.py:603-607): the trace kernel writes zeros, nothing to integrate
+    if (fabs(theta - acos(1. / b.n_index)) > b.maximum_angle) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const double* ce_g = b.profile_ce + (long)b.profile_index[ray] * nd;
+    const double resc = b.rescale ? b.rescale[ray] : 1.;
+    // profile -> LDS; sum and first maximum (np.argmax) by a wave / block reduction
+    double part = 0., bestv = -1e300;
+    int best = 0x7fffffff;
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) {
+        const double q = ce_g[i] * resc;
+        s_depth[i] = b.profile_depth[i];
+        s_ce[i] = q;
+        part += q;
+        if (q > bestv) { best = i; bestv = q; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        part += __shfl_xor(part, off);
+        const double ov = __shfl_xor(bestv, off);
+        const int oi = __shfl_xor(best, off);
+        if (ov > bestv || (ov == bestv && oi < best)) { bestv = ov; best = oi; }
+    }
+    if (lane == 0) { s_w[wave][0] = part; s_w[wave][1] = bestv; s_wi[wave] = best; }
+    __syncthreads();
+    double sum = 0.;
+    int im = 0x7fffffff;
+    {
+        double mv = -1e300;
+        for (int w = 0; w < n_waves; w++) {
+            sum += s_w[w][0];
+            if (s_w[w][1] > mv || (s_w[w][1] == mv && s_wi[w] < im)) { mv = s_w[w][1]; im = s_wi[w]; }
+        }
+    }
+    ArzRay r;
+    {
+        const double dist = b.distance[ray];
+        const double dxmax = s_depth[im] / ARZ_RHO;
+        r.X0 = dist * sin(theta);
+        r.X2 = dist * cos(theta) + (b.shift_for_xmax ? dxmax : 0.);
+        r.R0 = sqrt(r.X0 * r.X0 + r.X2 * r.X2);
+        r.xntot = sum * (s_depth[1] / ARZ_RHO - s_depth[0] / ARZ_RHO);
+        r.E_TeV = b.energy[ray] / 1e12;
+        r.em_factor = (typ == 0) ? b.em_factor[ray] : 1.;
+        const double* P = b.parameters + 7 * typ;
+        r.Af = P[0]; r.freq_pos = P[1]; r.freq_neg = P[2]; r.exp_pos = P[3]; r.exp_neg = P[4]; r.t0_pos = P[5]; r.t0_neg = P[6];
+    }
+    // delay of the profile nodes relative to the first one, h_i = t_obs - tt_i: an observer time t with t - 20 ns above
+    // all of them or t + 20 ns below all of them sees no node inside +-20 ns (the `continue` of ARZ.py:160-162).  Only the
+    // observer times in between are distributed over the ARZ_CHUNKS blocks of this ray.
+    double hmin = 1e300, hmax = -1e300;
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) {
+        const double h = -arz_tt(r, s_depth[i], r.R0 / ARZ_C * b.n_index, b.n_index);
+        hmin = fmin(hmin, h);
+        hmax = fmax(hmax, h);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        hmin = fmin(hmin, __shfl_xor(hmin, off));
+        hmax = fmax(hmax, __shfl_xor(hmax, off));
+    }
+    if (lane == 0) { s_w[wave][2] = hmin; s_w[wave][3] = hmax; }
+    __syncthreads();
+    for (int w = 0; w < n_waves; w++) {
+        hmin = fmin(hmin, s_w[w][2]);
+        hmax = fmax(hmax, s_w[w][3]);
+    }
+    const double fc = 4. * M_PI / (ARZ_XMU * sin(acos(1. / b.n_index)));
+    const double factor = -ARZ_XMU / (4. * M_PI);
+    // observer times: arange(0, (N + 1) dt, dt) + dt / 2 - mean (:98-102)
+    const int nt_raw = (int)ceil(((b.N + 1) * b.dt - 0.) / b.dt);
+    const double mean = b.dt * (nt_raw - 1) * 0.5;
+    // the observer times that can see the shower: hmin - 20 ns < t < hmax + 20 ns (1e-3 ns of slack, checked again per time)
+    int it_lo = (int)floor((hmin - 20.001 + mean - 0.5 * b.dt) / b.dt), it_hi = (int)ceil((hmax + 20.001 + mean - 0.5 * b.dt) / b.dt);
+    it_lo = max(it_lo, 0);
+    it_hi = min(it_hi, nt - 1);
+    const int per = (it_hi - it_lo + 1 + ARZ_CHUNKS - 1) / ARZ_CHUNKS;
+    const int it_end = min(it_hi + 1, it_lo + (int)(blockIdx.y + 1) * per);
+    for (int it = it_lo + blockIdx.y * per + wave; it < it_end; it += n_waves) {
+        const double t_bin = it * b.dt + 0.5 * b.dt - mean;
+        if (t_bin - hmax > 20.001 || t_bin - hmin < -20.001) continue;  // vp stays 0 (memset by the launcher)
+        const double tobs = t_bin + (r.R0 / ARZ_C * b.n_index);
+        // pass 1 over the profile nodes: anything within +-20 ns?  where does the +-1 ns condition flip?
+        int idx[18];
+        int ni = 0;
+        bool any20 = false, first_in = false;
+        int prev_last = 0;
+        for (int base = 0; base < nd; base += 64) {
+            const int i = base + lane;
+            double t = 1e300;
+            if (i < nd) t = arz_tt(r, s_depth[i], tobs, b.n_index);
+            const unsigned long long B20 = __ballot(t < 20. && t > -20.);
+            const unsigned long long B1 = __ballot(t < 1. && t > -1.);
+            any20 |= (B20 != 0ull);
+            if (base == 0) first_in = (B1 & 1ull) != 0;
+            const int cnt = min(64, nd - base);
+            // flips between node base - 1 and base, then inside the chunk
+            if (base > 0 && (prev_last != (int)(B1 & 1ull)) && ni < 16) idx[ni++] = base - 1;
+            unsigned long long G = (B1 ^ (B1 >> 1));
+            if (cnt < 64) G &= (cnt >= 2) ? ((1ull << (cnt - 1)) - 1ull) : 0ull;
+            else G &= 0x7fffffffffffffffull;
+            while (G && ni < 16) {
+                const int bit = __ffsll((long long)G) - 1;
+                idx[ni++] = base + bit;
+                G &= G - 1ull;
+            }
+            prev_last = (int)((B1 >> (cnt - 1)) & 1ull);
+        }
+        double ax = 0., az = 0.;
+        if (any20) {
+            ArzPiece piece[3];
+            int n_piece = 1;
+            piece[0] = ArzPiece{0, nd, 0, 0, 0, 0., 0., 0.};
+            if (b.interp_factor2 != 1. && ni != 0) {
+                if (ni % 2 != 0) {  // a stretch that starts with the first / ends with the last node (:176-181)
+                    if (first_in && idx[0] != 0) {
+                        for (int q = ni; q > 0; q--) idx[q] = idx[q - 1];
+                        idx[0] = 0;
+                        ni++;
+                    } else if (idx[ni - 1] != nd - 1) {
+                        idx[ni++] = nd - 1;
+                    }
+                }
+                if (ni % 2 == 0 && ni != 2 && ni != 4) {
+                    if (lane == 0) atomicExch(&status[ray], 1);  // NotImplementedError in the reference (:207)
+                    ni = 0;
+                }
+                if (ni == 2 || ni == 4) {
+                    const double step = (s_depth[1] - s_depth[0]) / b.interp_factor2;
+                    int from = 0;
+                    n_piece = 0;
+                    for (int q = 0; q < ni; q += 2) {
+                        const int is = idx[q], ie = idx[q + 1];
+                        const double start = s_depth[is];
+                        piece[n_piece++] = ArzPiece{from, is, is, ie, (long)ceil((s_depth[ie] - start) / step), start, step,
+                                                    (start + step) - start};
+                        from = ie;
+                    }
+                    piece[n_piece++] = ArzPiece{from, nd, 0, 0, 0, 0., 0., 0.};
+                }
+            }
+            // the merged grid: per piece its coarse nodes, then its fine points; g = index on the merged grid
+            long off[4] = {0, 0, 0, 0};
+            for (int ip = 0; ip < n_piece; ip++) off[ip + 1] = off[ip] + (piece[ip].c1 - piece[ip].c0) + piece[ip].n_fine;
+            const long M = off[n_piece];
+            auto depth_at = [&](long g, int* ip_out, long* j_out) -> double {
+                int ip = 0;
+                while (ip + 1 < n_piece && g >= off[ip + 1]) ip++;
+                const ArzPiece& p = piece[ip];
+                const long j = g - off[ip], nc = p.c1 - p.c0;
+                *ip_out = ip;
+                *j_out = j;
+                if (j < nc) return s_depth[p.c0 + j];
+                const long k = j - nc;
+                return (k == 0) ? p.start : (k == 1 ? p.start + p.step : p.start + k * p.delta);
+            };
+            for (long g = lane; g < M; g += 64) {
+                int ip, ipn;
+                long j, jn;
+                const double x = depth_at(g, &ip, &j);
+                const ArzPiece& p = piece[ip];
+                double q;
+                if (j < p.c1 - p.c0) q = s_ce[p.c0 + j];
+                else q = arz_interp_slice(x, s_depth, s_ce, p.is, p.ie, p.is + (int)((x - p.start) / (p.step * b.interp_factor2)));
+                const double xl = (g > 0) ? depth_at(g - 1, &ipn, &jn) : x;
+                const double xr = (g + 1 < M) ? depth_at(g + 1, &ipn, &jn) : x;
+                double yx, yz, t;
+                arz_integrand(r, x, q, tobs, b.n_index, fc, &yx, &yz, &t);
+                // trapezoid rule sum_j (z_{j+1} - z_j) (y_{j+1} + y_j) / 2 = sum_j y_j (z_{j+1} - z_{j-1}) / 2
+                const double w = (xr / ARZ_RHO - xl / ARZ_RHO) * 0.5;
+                ax += w * yx;
+                az += w * yz;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                ax += __shfl_xor(ax, off);
+                az += __shfl_xor(az, off);
+            }
+        }
+        if (lane == 0) {
+            vp[((long)ray * nt + it) * 2] = ax * factor;
+            vp[((long)ray * nt + it) * 2 + 1] = az * factor;
+        }
+    }
+}
+
+// E = -dA/dt, rotated into the on-sky basis of the direction to the shower maximum (:641-655); [n_rays][3][N]
+__global__ void __launch_bounds__(256)
+arz_trace_kernel(ArzBatch b, const double* __restrict__ vp, double* __restrict__ trace)
+{
+    const int ray = blockIdx.x;
+    const int N = b.N, nt = N + 1, nd = b.n_depth;
+    const double theta = b.theta[ray];
+    double* out = trace + (long)ray * 3 * N;
+    if (fabs(theta - acos(1. / b.n_index)) > b.maximum_angle) {
+        for (int i = threadIdx.x; i < 3 * N; i += blockDim.x) out[i] = 0.;
+        return;
+    }
+    __shared__ double s_tp;
+    if (threadIdx.x == 0) {
+        double tp = theta;
+        if (!b.shift_for_xmax) {  // theta_to_thetaprime (:299-315); argmax of the profile (a positive rescaling keeps it)
+            const double* ce = b.profile_ce + (long)b.profile_index[ray] * nd;
+            int im = 0;
+            for (int i = 1; i < nd; i++)
+                if (ce[i] > ce[im]) im = i;
+            const double L = b.profile_depth[im] / ARZ_RHO, R = b.distance[ray];
+            tp = atan2(R * sin(theta), R * cos(theta) - L);
+        }
+        s_tp = tp;
+    }
+    __syncthreads();
+    const double ct = cos(s_tp), st = sin(s_tp);
+    const double* v = vp + (long)ray * nt * 2;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const double ex = -(v[2 * (i + 1)] - v[2 * i]) / b.dt, ez = -(v[2 * (i + 1) + 1] - v[2 * i + 1]) / b.dt;
+        out[i] = st * ex + ct * ez;
+        out[N + i] = ct * ex - st * ez;
+        out[2 * N + i] = 0.;
+    }
+}
+
+void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int* status)
+{
+    if (b.n_rays <= 0) return;
+    const int nt = b.N + 1;
+    dim3 grid((unsigned)b.n_rays, ARZ_CHUNKS);
+    (void)hipMemsetAsync(vp, 0, sizeof(double) * 2 * (size_t)nt * b.n_rays, s);
+    hipLaunchKernelGGL(arz_vector_potential_kernel, grid, dim3(256), sizeof(double) * 2 * (size_t)b.n_depth, s, b, vp, status);
+    hipLaunchKernelGGL(arz_trace_kernel, dim3((unsigned)b.n_rays), dim3(256), 0, s, b, vp, trace);
+}
+
+}  // namespace nrhip

@@ -1,5 +1,5 @@
 /* arz_oracle.c -- CPU restatement of the ARZ time-domain Askaryan model (TEST INFRASTRUCTURE ONLY, never linked or
- * imported by nuradiomc_amd; see oracle/README in raytrace_oracle.py's header).
+ * imported by nuradiomc_amd).
  *
  * Follows NuRadioMC/SignalGen/ARZ/ARZ.py: get_vector_potential (:36-275) -- vector potential of the charge-excess profile,
  * A(t) = -mu/(4 pi) int dz' Q(z') v_perp F_p(t_ret) / R, trapezoid rule on the profile grid with a 100x refinement of the

@@ -28,7 +28,9 @@ def test_askaryan_unit_test_like_U01():
         ref = g['trace'][i]
         assert np.max(np.abs(trace - ref)) <= 1e-9 * max(np.max(np.abs(ref)), 1e-300)
     with pytest.raises(NotImplementedError):
-        askaryan.get_frequency_spectrum(1e18, 1., 256, 0.5, 'HAD', 1.78, 1000., 'ARZ2020')
+        askaryan.get_frequency_spectrum(1e18, 1., 256, 0.5, 'HAD', 1.78, 1000., 'HCRB2017')
+    with pytest.raises(FileNotFoundError):   # the ARZ models need their shower library (askaryan.arz_library)
+        askaryan.get_frequency_spectrum(1e18, 1., 256, 0.5, 'HAD', 1.78, 1000., 'ARZ2020', seed=987)
 
 
 def test_ray_tracing_class_like_T05():
@@ -356,3 +358,65 @@ def test_ray_tracing_class_like_T06_mooresbay():
         r.set_start_and_end_point([100., 0., -600.], g['x_receiver'])
     # a medium without a reflective layer: the request is dropped with a warning (propagation_base_class.py:128-134)
     assert propagation.ray_tracing(_Ice(1.78, 0.423, 77.), n_reflections=2).get_number_of_raytracing_solutions() == 2
+
+
+def test_arz_like_the_reference():
+    """The ARZ time-domain model through the drop-in ARZ class and through askaryan.get_time_trace /
+    get_frequency_spectrum(model='ARZ2020') against the reference's outputs (tests/golden/gen/gen_arz.py: the
+    charge-excess profile the reference ships and Gaisser-Hillas shaped ones in a library of the reference's layout),
+    and the batched form against the oracle."""
+    from nuradiomc_amd import arz, askaryan
+    from oracle import arz_oracle
+    from test_oracle_golden import _arz_library
+    g = golden('ref_arz.npz')
+    lib = _arz_library(g)
+    a = arz.ARZ(seed=1234, library=lib)
+    for i, c in enumerate(g['vp_cases']):
+        typ = 'HAD' if c[0] else 'EM'
+        E, th, N, dt, R, f1, f2, shift, emf = c[1:]
+        a.set_interpolation_factor(f1)
+        a.set_interpolation_factor2(f2)
+        prof = g['lib_HAD_1e18'][0] if c[0] else g['lib_EM_1e18'][0]
+        vp = a.get_vector_potential(E, th, int(N), dt, g['lib_depth'], prof, typ, 1.78, R, bool(shift), emf)
+        ref = g['vp_%d' % i]
+        assert vp.shape == ref.shape and np.max(np.abs(vp - ref)) <= 1e-9 * np.max(np.abs(ref)), i
+    a.set_interpolation_factor(1)
+    a.set_interpolation_factor2(100)
+    a.set_seed(int(g['tr_seed']))
+    for k, c in enumerate(g['tr_cases']):
+        typ = 'HAD' if c[0] else 'EM'
+        tr = a.get_time_trace(c[1], c[2], 256, 0.5, typ, 1.78, c[3], same_shower=bool(c[4]), iN=None if c[5] < 0 else c[5])
+        assert a.get_last_shower_profile_id()[typ] == int(c[6]), k
+        ref = g['tr'][k]
+        assert tr.shape == ref.shape and np.max(np.abs(tr - ref)) <= 1e-9 * max(np.max(np.abs(ref)), 1e-300), k
+    askaryan.arz_library = lib
+    askaryan._arz.clear()
+    for k, c in enumerate(g['ask_cases']):
+        typ = 'had' if c[0] else 'em'    # the wrapper upper-cases the shower type
+        kw = {} if c[3] < 0 else {'iN': int(c[3])}
+        tr, add = askaryan.get_time_trace(c[1], c[2], 256, 0.5, typ, 1.78, 1500., 'ARZ2020', full_output=True,
+                                          seed=int(g['ask_seed']), **kw)
+        assert add['iN'] == int(c[4])
+        spec = askaryan.get_frequency_spectrum(c[1], c[2], 256, 0.5, typ, 1.78, 1500., 'ARZ2020', iN=add['iN'],
+                                               seed=int(g['ask_seed']))
+        assert np.max(np.abs(tr - g['ask_tr'][k])) <= 1e-9 * np.max(np.abs(g['ask_tr'][k])), k
+        assert np.max(np.abs(spec - g['ask_spec'][k])) <= 1e-9 * np.max(np.abs(g['ask_spec'][k])), k
+    # batched: 300 (shower, ray) pairs, N = 512 at 5 GHz, vs the oracle one by one
+    rng = np.random.default_rng(3)
+    n = 300
+    types = [['HAD', 'EM'][i % 2] for i in range(n)]
+    E = 10 ** rng.uniform(16., 19., n)
+    th = np.arccos(1 / 1.78) + rng.uniform(-22, 22, n) * np.pi / 180
+    R = 10 ** rng.uniform(2., 3.7, n)
+    b = arz.ARZ(seed=5, library=lib)
+    iN = b.draw_profile_numbers(E, types)
+    tr = b.get_time_trace_batch(E, th, 512, 0.2, types, 1.78, R, iN)
+    o = arz_oracle.ARZ(lib, seed=5)
+    n_zero = 0
+    for i in range(n):
+        ref = o.get_time_trace(E[i], th[i], 512, 0.2, types[i], 1.78, R[i], iN=int(iN[i]))
+        n_zero += not np.any(ref)
+        assert np.max(np.abs(tr[i] - ref)) <= 1e-9 * max(np.max(np.abs(ref)), 1e-300), i
+    assert 5 < n_zero < 60
+    with pytest.raises(NotImplementedError):
+        a.get_time_trace(1e18, 1., 256, 0.5, 'TAU', 1.78, 1000.)
