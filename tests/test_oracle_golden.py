@@ -295,3 +295,63 @@ def test_arz_vs_reference():
         spec, _ = arz.askaryan_frequency_spectrum(b, c[1], c[2], 256, 0.5, typ, 1.78, 1500., iN=add['iN'])
         assert np.max(np.abs(tr - g['ask_tr'][k])) <= 1e-11 * np.max(np.abs(g['ask_tr'][k])), k
         assert np.max(np.abs(spec - g['ask_spec'][k])) <= 1e-11 * np.max(np.abs(g['ask_spec'][k])), k
+
+
+def _bire_case(g, tag):
+    model = str(g[tag + '_model'])
+    tck = [(g['tck_%s_%d_t' % (model, j)], g['tck_%s_%d_c' % (model, j)]) for j in range(3)]
+    angle = float(g[tag + '_angle'])
+    if tag == 'sp':
+        pts, rec = g['points'], g['x_receiver']
+    else:   # tests/golden/gen/gen_birefringence.py: the second set
+        rng = np.random.default_rng(8)
+        pts = np.stack([rng.uniform(-1500, 1500, 4), rng.uniform(-1500, 1500, 4), rng.uniform(-2400, -300, 4)], axis=1)
+        rec = np.array([10., -20., -90.])
+    return tck, (None if np.isnan(angle) else angle), pts, rec
+
+
+def _bire_input(g, ice, X1, X2, iS):
+    """what apply_propagation_effects hands to the birefringence step in T07's configuration (no attenuation): the input
+    pulse times the Fresnel coefficients of a surface reflection"""
+    from oracle import spectral_oracle as so
+    fs = float(g['sampling_rate'])
+    spec = np.fft.rfft(g['input_trace']) / fs * 2 ** 0.5
+    ra = orc.raytrace_batch(X1[None], X2[None], ice)['refl_angle'][0, iS]
+    if np.isnan(ra):
+        return spec, spec.copy()
+    n1 = ice[0] - ice[1] * np.exp(-0.01 / ice[2])
+    return spec * so.fresnel_r_p(ra, 1., n1), spec * so.fresnel_r_s(ra, 1., n1)
+
+
+def test_birefringence_vs_reference():
+    """Birefringent pulse propagation: the reference's golden file reference_BF.npy (T07test_birefringence.py, at T07's
+    tolerance and 100x tighter), per-step path properties (path, nx / ny / nz, effective indices, eigen-polarisations,
+    delays) and final spectra of the reference for 16 south-pole rays and 8 Greenland rays with an ice-flow angle."""
+    from oracle import birefringence_oracle as bo
+    g = golden('ref_birefringence.npz')
+    fs = float(g['sampling_rate'])
+    for tag in ('sp', 'gl'):
+        tck, angle, pts, rec = _bire_case(g, tag)
+        ice = g[tag + '_ice']
+        rays = g[tag + '_rays']
+        traces_t, traces_p = [g['input_trace']], [g['input_trace']]
+        for k, (iX, iS, C0, D, n_steps) in enumerate(rays):
+            X1 = pts[int(iX)]
+            st = bo.path_steps(X1, rec, C0, D, ice, tck, angle)
+            assert len(st['T1']) == int(n_steps)
+            if k < 3:
+                assert np.max(np.abs(st['path'] - g['%s_path_%d' % (tag, k)])) < 1e-9
+                for key in ('nx', 'ny', 'nz', 'n', 'N1', 'N2', 'T1', 'T2'):
+                    assert np.max(np.abs(st[key] - g['%s_%s_%d' % (tag, key, k)])) < 1e-10, (tag, k, key)
+                for key in ('P1', 'P2'):   # n^2 - n_i^2 ~ 1e-3 in the denominators: 1e-16 in n is 1e-9 here
+                    assert np.max(np.abs(st[key] - g['%s_%s_%d' % (tag, key, k)])) < 1e-7, (tag, k, key)
+            e = bo.propagate(*_bire_input(g, ice, X1, rec, int(iS)), fs, st)
+            ref = g['%s_spec_%d' % (tag, k)]
+            assert np.max(np.abs(e - ref)) <= 1e-6 * np.max(np.abs(ref)), (tag, k)
+            traces_t.append(np.fft.irfft(e[0], n=500) * fs / 2 ** 0.5)
+            traces_p.append(np.fft.irfft(e[1], n=500) * fs / 2 ** 0.5)
+        got = np.vstack((np.array(traces_t), np.array(traces_p)))
+        assert np.max(np.abs(got - g[tag + '_traces'])) < 1e-6
+        if tag == 'sp':
+            np.testing.assert_allclose(got, g['ref_BF'], atol=2e-4, rtol=1e-7)    # T07test_birefringence.py:98
+            assert np.max(np.abs(got - g['ref_BF'])) < 2e-6
