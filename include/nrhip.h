@@ -169,6 +169,22 @@ int nrhip_arz_time_trace_batch(nrhip_ctx* ctx, int64_t n_rays, const double* ene
                                double interp_factor2, int32_t shift_for_xmax, double maximum_angle, double* trace,
                                double* vector_potential);
 
+/* ---- birefringence ---------------------------------------------------------------------------------------------------
+ * ray_tracing.get_pulse_propagation_birefringence (analyticraytracing.py:2369-2445) for a batch of rays: the path of ray i
+ * (x1, x2, C0; no bottom reflections) is cut into int(path_length[i] / m) points (get_path :1239-1291, :2148-2163,
+ * optionally rotated by angle_to_iceflow [deg], NaN = none); per step the principal indices n(z) + spline_j(-z) - n_ref
+ * (j = x, y, z: cubic B-splines (knots, coeffs) of medium_base.IceModelBirefringence :378-420, the three of them
+ * concatenated, n_knots[j] entries each; n_ref = 1.78), the effective indices (:2165-2207) and eigen-polarisations
+ * (:2243-2367) give E <- R^T diag(1, time shift by t_1 - t_0) R E on the eTheta / ePhi spectra (time shift as
+ * BaseTrace.apply_time_shift, base_trace.py:246-276).
+ * spectra: [n_rays][2][n_f] interleaved complex, eTheta then ePhi, on np.fft.rfftfreq(2 (n_f - 1), 1 / sampling_rate),
+ * modified in place.  step_records (may be NULL): [sum_i (int(path_length[i]) - 1)][5] = (a, b, c, d, t_1 - t_0) per step,
+ * rows R = ((a, b), (c, d)); NaN delay = step skipped as in the reference (:2431-2433).  HOST pointers.            */
+int nrhip_birefringence_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, const double* x2, const double* C0,
+                              const double* path_length, const int32_t n_knots[3], const double* knots, const double* coeffs,
+                              double n_ref, double angle_to_iceflow, int32_t n_f, double sampling_rate, double* spectra,
+                              double* step_records);
+
 /* Batched ray_tracing.get_attenuation on an explicit frequency list
  * (analyticraytracing.py:2744 -> get_attenuation_along_path :933-1089, Python branch), replacing the
  * per-frequency wrapper.pyx get_attenuation_along_path (:30-31).

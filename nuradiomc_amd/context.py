@@ -195,6 +195,36 @@ class Context:
                                                               L.dptr(att), L.dptr(seg)))
         return (att, seg) if return_segments else att
 
+    def birefringence_batch(self, x1, x2, C0, path_length, spectra, sampling_rate, tck, angle_to_iceflow=None, n_ref=1.78,
+                            return_steps=False):
+        """Birefringent propagation of the (eTheta, ePhi) spectra [n_rays, 2, n_f] along the rays (x1, x2, C0)
+        (get_pulse_propagation_birefringence, analyticraytracing.py:2369-2445).  tck = three (knots, coefficients[, 3])
+        tuples: the depth splines of nx, ny, nz of a birefringence ice model.  Returns the new spectra (and the step
+        records [n_steps, 5] = (a, b, c, d, t_1 - t_0) of all rays, one after the other)."""
+        x1 = L.f64(x1).reshape(-1, 3)
+        x2 = L.f64(x2).reshape(-1, 3)
+        C0 = L.f64(C0).reshape(-1)
+        D = L.f64(path_length).reshape(-1)
+        n = len(C0)
+        spec = np.ascontiguousarray(spectra, dtype=np.complex128).reshape(n, 2, -1).copy()
+        n_f = spec.shape[2]
+        knots = np.ascontiguousarray(np.concatenate([np.asarray(t[0], float) for t in tck]))
+        coeffs = np.ascontiguousarray(np.concatenate([np.asarray(t[1], float) for t in tck]))
+        for t in tck:
+            if len(t) > 2 and int(t[2]) != 3:
+                raise ValueError("birefringence_batch: the depth splines must be cubic")
+            if len(t[0]) != len(t[1]):
+                raise ValueError("birefringence_batch: knots and coefficients of a spline must have the same length (FITPACK tck)")
+        nk = np.array([len(t[0]) for t in tck], np.int32)
+        n_steps = int(np.sum(np.maximum(D.astype(int) - 1, 0)))
+        steps = np.zeros((max(n_steps, 1), 5))
+        L.check(self._lib.nrhip_birefringence_batch(self._h, n, L.dptr(x1), L.dptr(x2), L.dptr(C0), L.dptr(D), L.iptr(nk),
+                                                    L.dptr(knots), L.dptr(coeffs), float(n_ref),
+                                                    float('nan') if angle_to_iceflow is None else float(angle_to_iceflow), n_f,
+                                                    float(sampling_rate), spec.view(np.float64).ctypes.data_as(L.c_double_p),
+                                                    L.dptr(steps)))
+        return (spec, steps[:n_steps]) if return_steps else spec
+
     def attenuation_batch(self, x1, x2, C0, freqs, return_neval=False):
         """exp(-int ds / L_att) for rays (x1[r] -> x2[r], C0[r]) at the given (> 0) frequencies."""
         x1 = L.f64(x1).reshape(-1, 3)

@@ -3,6 +3,7 @@
 #include "nrhip_internal.h"
 #include "ctx.h"
 #include "arz.h"
+#include "birefringence.h"
 #include <cstdio>
 #include <algorithm>
 #include <cmath>
@@ -452,6 +453,49 @@ int nrhip_arz_time_trace_batch(nrhip_ctx* ctx, int64_t n_rays, const double* ene
     HIPCHK(hipStreamSynchronize(s));
     for (size_t i = 0; i < nr; i++)
         if (st[i]) return fail_msg("nrhip_arz_time_trace_batch: length of indices is not 2 nor 4 (more than two stretches of the profile radiate within 1 ns)");
+    return 0;
+}
+
+int nrhip_birefringence_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, const double* x2, const double* C0,
+                              const double* path_length, const int32_t n_knots[3], const double* knots, const double* coeffs,
+                              double n_ref, double angle_to_iceflow, int32_t n_f, double sampling_rate, double* spectra,
+                              double* step_records)
+{
+    if (!ctx || !x1 || !x2 || !C0 || !path_length || !n_knots || !knots || !coeffs || !spectra)
+        return fail_msg("nrhip_birefringence_batch: NULL argument");
+    if (n_rays < 0) return fail_msg("nrhip_birefringence_batch: negative size");
+    if (n_rays == 0) return 0;
+    if (n_f < 2 || !(sampling_rate > 0)) return fail_msg("nrhip_birefringence_batch: n_f >= 2 and sampling_rate > 0 required");
+    for (int j = 0; j < 3; j++)
+        if (n_knots[j] < 8) return fail_msg("nrhip_birefringence_batch: a cubic spline needs at least 8 knots");
+    std::vector<int> npts(n_rays);
+    std::vector<long> off(n_rays + 1, 0);
+    int max_points = 0;
+    for (int64_t i = 0; i < n_rays; i++) {
+        if (!(path_length[i] >= 0) || !(C0[i] > 0)) return fail_msg("nrhip_birefringence_batch: rays need C0 > 0 and a path length");
+        npts[i] = (int)(path_length[i] / 1.);  // acc = int(D / units.m) (:2417)
+        off[i + 1] = off[i] + std::max(npts[i] - 1, 0);
+        max_points = std::max(max_points, npts[i]);
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t nr = (size_t)n_rays, nk = (size_t)n_knots[0] + n_knots[1] + n_knots[2];
+    DevBuf dx1, dx2, dC0, dnp, dof, dkn, dco, dst, dsp;
+    HIPCHK(dx1.alloc(nr * 24)); HIPCHK(dx2.alloc(nr * 24)); HIPCHK(dC0.alloc(nr * 8)); HIPCHK(dnp.alloc(nr * 4));
+    HIPCHK(dof.alloc(nr * 8)); HIPCHK(dkn.alloc(nk * 8)); HIPCHK(dco.alloc(nk * 8));
+    HIPCHK(dst.alloc((size_t)std::max<long>(off[n_rays], 1) * 40)); HIPCHK(dsp.alloc(nr * 2 * n_f * 16));
+#define H2D(dst, src, bytes) HIPCHK(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, s))
+    H2D(dx1, x1, nr * 24); H2D(dx2, x2, nr * 24); H2D(dC0, C0, nr * 8); H2D(dnp, npts.data(), nr * 4);
+    H2D(dof, off.data(), nr * 8); H2D(dkn, knots, nk * 8); H2D(dco, coeffs, nk * 8); H2D(dsp, spectra, nr * 2 * n_f * 16);
+#undef H2D
+    nrhip::BireBatch b{(long)n_rays, dx1.as<double>(), dx2.as<double>(), dC0.as<double>(), dnp.as<int>(), dof.as<long>(),
+                       ctx->ice, dkn.as<double>(), dco.as<double>(), {n_knots[0], n_knots[1], n_knots[2]}, n_ref,
+                       angle_to_iceflow, n_f, sampling_rate};
+    nrhip::launch_birefringence(s, b, max_points, dst.as<double>(), dsp.as<double2>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(spectra, dsp.p, nr * 2 * n_f * 16, hipMemcpyDeviceToHost, s));
+    if (step_records && off[n_rays] > 0) HIPCHK(hipMemcpyAsync(step_records, dst.p, (size_t)off[n_rays] * 40, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return 0;
 }
 

@@ -1,0 +1,25 @@
+// birefringence.h -- batch descriptor of the birefringence kernels (birefringence.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ray_device.h"
+
+namespace nrhip {
+
+struct BireBatch {
+    long n_rays;
+    const double *x1, *x2;     // [n_rays][3] end points of the rays
+    const double* C0;          // [n_rays]
+    const int* n_points;       // [n_rays] acc = int(path length / m)
+    const long* step_offset;   // [n_rays] first step record of the ray
+    IceConst ice;
+    const double *knots, *coeffs;  // the three depth splines (nx, ny, nz), concatenated
+    int n_knots[3];
+    double n_ref;              // 1.78 (analyticraytracing.py:2421)
+    double angle_to_iceflow;   // deg, NaN = none
+    int n_f;
+    double sampling_rate;
+};
+
+void launch_birefringence(hipStream_t s, const BireBatch& b, int max_points, double* steps, double2* spec);
+
+}  // namespace nrhip

@@ -1,0 +1,267 @@
+// birefringence.hip -- birefringent pulse propagation along the analytic ray path on MI355X (gfx950).
+//
+// Reference: NuRadioMC/SignalProp/analyticraytracing.py get_pulse_propagation_birefringence (:2369-2445): the path is cut
+// into acc = int(D / m) points (get_path :1239-1291, :2148-2163); per step the three principal indices
+// n(z) + spline_i(-z) - 1.78 (medium_base.py:378-420), the two effective indices (:2165-2207), the two eigen-polarisations
+// in the on-sky basis of the step direction (:2243-2367) and E <- R^T diag(1, shift by t_1 - t_0) R E on the
+// (eTheta, ePhi) spectra, R = their (theta, phi) components.
+//
+// Two kernels.  `bire_steps_kernel`: one LANE per path step -- closed-form path points i and i + 1, de Boor evaluation of
+// the three depth splines, effective indices, polarisation vectors -> (a, b, c, d, t_1 - t_0) per step, 40 B.
+// `bire_propagate_kernel`: one LANE per frequency bin, the block walks the ray's steps in order with the step records
+// staged through LDS in tiles (every lane needs every step: broadcast reads); per (step, bin) one sincos and two real
+// 2 x 2 by complex-vector products.  The chain of non-commuting 2 x 2 factors is inherently sequential per bin, so the
+// parallel axes are bins x rays.  FP64 VALU / transcendental bound: a ray of 2000 steps and 2049 bins is 4e6 sincos
+// against 80 kB of step records and 131 kB of spectra.
+#include <hip/hip_runtime.h>
+#include "ray_device.h"
+#include "birefringence.h"
+
+namespace nrhip {
+
+// sum_i c_i B_{i,3}(x): FITPACK splev's recursion (fpbspl); outside the knot range the end pieces continue (ext = 0)
+__device__ inline double bire_spline(const double* __restrict__ t, const double* __restrict__ c, int n, double x)
+{
+    const int k = 3;
+    int lo = 0, hi = n;  // last knot index with t[l] <= x (searchsorted right - 1)
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (t[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    int l = lo - 1;
+    l = l < k ? k : (l > n - k - 2 ? n - k - 2 : l);
+    double h[4] = {1., 0., 0., 0.}, hh[3];
+    for (int j = 1; j <= k; j++) {
+        for (int i = 0; i < j; i++) hh[i] = h[i];
+        h[0] = 0.;
+        for (int i = 0; i < j; i++) {
+            const int li = l + 1 + i, lj = li - j;
+            if (t[li] == t[lj]) {
+                h[i + 1] = 0.;
+                continue;
+            }
+            const double f = hh[i] / (t[li] - t[lj]);
+            h[i] += f * (t[li] - x);
+            h[i + 1] = f * (x - t[lj]);
+        }
+    }
+    double s = 0.;
+    for (int i = 0; i <= k; i++) s += c[l - k + i] * h[i];
+    return s;
+}
+
+// hp.cartesian_to_spherical + on_sky_birefringence (:2339-2367): theta / phi components of p seen along `dir`
+__device__ inline void bire_on_sky(const double dir[3], const double p[3], double* p_theta, double* p_phi)
+{
+    const double r = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    const double theta = (r == 0.) ? 0. : acos(dir[2] / r);
+    double phi = atan2(dir[1], dir[0]);
+    if (phi < 0) phi += 2 * M_PI;
+    double st, ct, sp, cp;
+    sincos(theta, &st, &ct);
+    sincos(phi, &sp, &cp);
+    *p_theta = ct * cp * p[0] + ct * sp * p[1] + (-st) * p[2];
+    *p_phi = (-sp) * p[0] + cp * p[1] + 0 * p[2];
+}
+
+__device__ inline void bire_simple(double n, const double dir[3], double nx, double ny, double nz, double p[3])
+{
+    p[0] = dir[0] / (n * n - nx * nx);
+    p[1] = dir[1] / (n * n - ny * ny);
+    p[2] = dir[2] / (n * n - nz * nz);
+    const double nrm = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    p[0] /= nrm; p[1] /= nrm; p[2] /= nrm;
+}
+
+// path point j of acc (get_path): 3-D position incl. the rotation to the ice-flow frame
+__device__ inline void bire_path_point(int j, int acc, double zstart, double zstop, const C0State& s, double C1, const IceConst& m,
+                                       double x1y, double x1z, double X1x, double X1y, double cph, double sph, double ca,
+                                       double sa, double out[3])
+{
+    const double step = (zstop - zstart) / (acc - 1);
+    const double z = (j == acc - 1) ? zstop : j * step + zstart;  // np.linspace
+    const double y_turn = s.y_turn0 + C1;
+    double y, zs;
+    if (z < s.z_turn) {
+        y = y_of_gamma(gamma_of_z(z, m), s, m) + C1;
+        zs = z;
+    } else {
+        y = 2 * y_turn - (y_of_gamma(gamma_of_z(2 * s.z_turn - z, m), s, m) + C1);
+        zs = 2 * s.z_turn - z;
+    }
+    const double dPx = y - x1y, dPz = zs - x1z;           // path_2d - (X1[0], 0, X1[2])
+    const double px = cph * dPx + X1x, py = -sph * dPx + X1y;  // R^T dP + X1
+    out[0] = ca * px - sa * py;
+    out[1] = sa * px + ca * py;
+    out[2] = dPz + x1z;
+}
+
+__global__ void __launch_bounds__(256)
+bire_steps_kernel(BireBatch b, double* __restrict__ steps /* [total_steps][5] */)
+{
+    const int ray = blockIdx.x;
+    const int acc = b.n_points[ray];
+    if (acc < 2) return;
+    const double* A0 = b.x1 + 3 * (long)ray;
+    const double* B0 = b.x2 + 3 * (long)ray;
+    double A[3] = {A0[0], A0[1], A0[2]}, B[3] = {B0[0], B0[1], B0[2]};
+    if (B[2] < A[2])  // set_start_and_end_point (:2057-2090): the path runs from the lower to the higher point
+        for (int d = 0; d < 3; d++) { double t = A[d]; A[d] = B[d]; B[d] = t; }
+    const double dX[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+    const double rho = sqrt(dX[0] * dX[0] + dX[1] * dX[1]);
+    double cph = 1., sph = 0.;
+    if (rho > 0) { cph = dX[0] / rho; sph = -(dX[1] / rho); }
+    const IceConst m = b.ice;
+    Pair2D p;
+    p.y1 = A[0]; p.z1 = A[2];
+    p.y2 = (cph * dX[0] + (-sph) * dX[1] + 0 * dX[2]) + A[0];
+    p.z2 = (0 * dX[0] + 0 * dX[1] + 1 * dX[2]) + A[2];
+    p.g1 = gamma_of_z(p.z1, m);
+    p.g2 = gamma_of_z(p.z2, m);
+    const C0State s = make_c0(b.C0[ray], m);
+    const double C1 = C1_of(s, p, m);
+    const double zstop = z_mirrored(p.y2, p.z2, s, C1, p);
+    double sa = 0., ca = 1.;
+    if (!isnan(b.angle_to_iceflow)) sincos(b.angle_to_iceflow * (M_PI / 180.), &sa, &ca);
+    double* out = steps + 5 * b.step_offset[ray];
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < acc - 1; i += gridDim.y * blockDim.x) {
+        double P0[3], P1[3];
+        bire_path_point(i, acc, p.z1, zstop, s, C1, m, p.y1, p.z1, A[0], A[1], cph, sph, ca, sa, P0);
+        bire_path_point(i + 1, acc, p.z1, zstop, s, C1, m, p.y1, p.z1, A[0], A[1], cph, sph, ca, sa, P1);
+        const double z = P0[2];
+        const double n_nominal = (z <= 0) ? m.n_ice - m.delta_n * exp(z / m.z_0) : 1.;
+        const double nx = n_nominal + bire_spline(b.knots, b.coeffs, b.n_knots[0], -z) - b.n_ref;
+        const double ny = n_nominal + bire_spline(b.knots + b.n_knots[0], b.coeffs + b.n_knots[0], b.n_knots[1], -z) - b.n_ref;
+        const double nz = n_nominal + bire_spline(b.knots + b.n_knots[0] + b.n_knots[1], b.coeffs + b.n_knots[0] + b.n_knots[1],
+                                                  b.n_knots[2], -z) - b.n_ref;
+        double dir[3] = {P1[0] - P0[0], P1[1] - P0[1], P1[2] - P0[2]};
+        const double len = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+        dir[0] /= len; dir[1] /= len; dir[2] /= len;
+        // effective indices (:2188-2207)
+        const double sx = dir[0], sy = dir[1], sz = dir[2];
+        const double nx2 = nx * nx, ny2 = ny * ny, nz2 = nz * nz;
+        const double Aq = ny2 * nz2 * (-1 + sx * sx) + nx2 * (nz2 * (-1 + sy * sy) + ny2 * (-1 + sz * sz));
+        const double Bq = sqrt(4 * nx2 * ny2 * nz2 * (nz2 * (-1 + sx * sx + sy * sy) + ny2 * (-1 + sx * sx + sz * sz) +
+                                                      nx2 * (-1 + sy * sy + sz * sz)) + Aq * Aq);
+        const double num = -2 * nx2 * ny2 * nz2;
+        const double N1 = sqrt(num / (Aq - Bq)), N2 = sqrt(num / (Aq + Bq));
+        // eigen-polarisations, theta / phi components (:2243-2337)
+        const double narrow = 1e-9, wide = 1e-10;
+        const bool c1 = fabs(N1 - nx) <= narrow || fabs(N1 - ny) <= narrow || fabs(N1 - nz) <= narrow;
+        const bool c2 = fabs(N2 - nx) <= narrow || fabs(N2 - ny) <= narrow || fabs(N2 - nz) <= narrow;
+        double a, bb, c, d;
+        bool general = true;
+        if (c1 || c2) {
+            general = false;
+            if (c1 && c2) { a = bb = c = d = 0.; }
+            else if (fabs(N1 - nx) <= wide) { a = 0; bb = (dir[0] < 0) ? 1. : -1.; c = 1.; d = 0.; }
+            else if (fabs(N1 - ny) <= narrow) { a = 0; bb = (dir[1] < 0) ? 1. : -1.; c = 1.; d = 0.; }
+            else if (fabs(N2 - ny) <= narrow) { a = 1.; bb = 0.; c = 0.; d = (dir[1] < 0) ? -1. : 1.; }
+            else if (fabs(N2 - nz) <= wide) { a = 0.; bb = -1.; c = (dir[2] < 0) ? -1. : 1.; d = 0.; }
+            else general = true;
+        }
+        if (general) {
+            double p1[3], p2[3];
+            bire_simple(N1, dir, nx, ny, nz, p1);
+            bire_simple(N2, dir, nx, ny, nz, p2);
+            bire_on_sky(dir, p1, &a, &bb);
+            bire_on_sky(dir, p2, &c, &d);
+        }
+        // np.isclose(a d - b c, 0) or NaN: the step is skipped (:2431-2433) -- marked by NaN in the delay
+        double delay = len * N2 / 0.299792458 - len * N1 / 0.299792458;
+        const double det = a * d - bb * c;
+        if (fabs(det) <= 1e-8 || isnan(a) || isnan(bb) || isnan(c) || isnan(d)) delay = NAN;
+        out[5 * (long)i + 0] = a;
+        out[5 * (long)i + 1] = bb;
+        out[5 * (long)i + 2] = c;
+        out[5 * (long)i + 3] = d;
+        out[5 * (long)i + 4] = delay;
+    }
+}
+
+#define BIRE_TILE 256
+
+// sin / cos of a small angle (|x| < 0.25: the delay of a 1 m step is ~1e-2 ns, so x = 2 pi f dt stays below 0.1 rad up to
+// several GHz): Taylor polynomials, truncation < 2e-18; anything larger goes through sincos()
+__device__ inline void bire_sincos(double x, double* sn, double* cs)
+{
+    if (fabs(x) < 0.25) {
+        const double x2 = x * x;
+        double ps = -1. / 39916800.;                 // -1/11!
+        ps = fma(ps, x2, 1. / 362880.);
+        ps = fma(ps, x2, -1. / 5040.);
+        ps = fma(ps, x2, 1. / 120.);
+        ps = fma(ps, x2, -1. / 6.);
+        ps = fma(ps, x2, 1.);
+        double pc = 1. / 479001600.;                 // 1/12!
+        pc = fma(pc, x2, -1. / 3628800.);
+        pc = fma(pc, x2, 1. / 40320.);
+        pc = fma(pc, x2, -1. / 720.);
+        pc = fma(pc, x2, 1. / 24.);
+        pc = fma(pc, x2, -0.5);
+        pc = fma(pc, x2, 1.);
+        *sn = ps * x;
+        *cs = pc;
+    } else {
+        sincos(x, sn, cs);
+    }
+}
+
+// spectra [n_rays][2][n_f] complex, in place
+__global__ void __launch_bounds__(256)
+bire_propagate_kernel(BireBatch b, const double* __restrict__ steps, double2* __restrict__ spec)
+{
+    __shared__ double s_step[BIRE_TILE][5];
+    const int ray = blockIdx.x;
+    const int n_steps = b.n_points[ray] - 1;
+    const int k = blockIdx.y * blockDim.x + threadIdx.x;
+    const int n_f = b.n_f;
+    const bool active = k < n_f;
+    const int N = 2 * (n_f - 1);
+    const double fs = b.sampling_rate;
+    const double f = k * (1.0 / (N * (1. / fs)));  // np.fft.rfftfreq
+    double2* st = spec + (long)ray * 2 * n_f;
+    double2 et = make_double2(0., 0.), ep = et;
+    if (active) { et = st[k]; ep = st[n_f + k]; }
+    const double* S = steps + 5 * b.step_offset[ray];
+    for (int base = 0; base < n_steps; base += BIRE_TILE) {
+        const int cnt = min(BIRE_TILE, n_steps - base);
+        __syncthreads();
+        for (int q = threadIdx.x; q < cnt * 5; q += blockDim.x) (&s_step[0][0])[q] = S[5 * (long)base + q];
+        __syncthreads();
+        if (!active) continue;
+        for (int i = 0; i < cnt; i++) {
+            const double a = s_step[i][0], bb = s_step[i][1], c = s_step[i][2], d = s_step[i][3], delay = s_step[i][4];
+            if (isnan(delay)) continue;
+            const double2 b0 = make_double2(a * et.x + bb * ep.x, a * et.y + bb * ep.y);
+            double2 b1 = make_double2(c * et.x + d * ep.x, c * et.y + d * ep.y);
+            // BaseTrace.apply_time_shift (base_trace.py:246-276): whole samples are rolled in the time domain (which drops
+            // the imaginary parts of the DC and Nyquist bins), anything else is a phase ramp
+            const double x = delay * fs;
+            double sn, cs;
+            if (fabs(rint(x) - x) < 1e-5) {
+                const double kk = rint(x);
+                sincos(-2. * M_PI * f * (kk / fs), &sn, &cs);
+                if (k == 0 || k == n_f - 1) { b1.y = 0.; sn = 0.; cs = (k == 0 || ((long)kk % 2 == 0)) ? 1. : -1.; }
+            } else {
+                bire_sincos(-2. * M_PI * delay * f, &sn, &cs);
+            }
+            b1 = make_double2(b1.x * cs - b1.y * sn, b1.x * sn + b1.y * cs);
+            et = make_double2(a * b0.x + c * b1.x, a * b0.y + c * b1.y);   // R^T
+            ep = make_double2(bb * b0.x + d * b1.x, bb * b0.y + d * b1.y);
+        }
+    }
+    if (active) { st[k] = et; st[n_f + k] = ep; }
+}
+
+void launch_birefringence(hipStream_t s, const BireBatch& b, int max_points, double* steps, double2* spec)
+{
+    if (b.n_rays <= 0 || max_points < 2) return;
+    int gy = (max_points - 1 + 255) / 256;
+    if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(bire_steps_kernel, dim3((unsigned)b.n_rays, (unsigned)gy), dim3(256), 0, s, b, steps);
+    hipLaunchKernelGGL(bire_propagate_kernel, dim3((unsigned)b.n_rays, (unsigned)((b.n_f + 255) / 256)), dim3(256), 0, s, b, steps,
+                       spec);
+}
+
+}  // namespace nrhip

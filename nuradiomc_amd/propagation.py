@@ -10,6 +10,7 @@ Per-pair calls are thin wrappers over the batch entry points; the batched path a
 `Context.find_solutions_batch` / `Station.simulate_events`.
 """
 import logging
+import os
 import numpy as np
 from .context import Context
 
@@ -30,6 +31,26 @@ def _context_for(medium, attenuation_model, device=0, gl3_table=None):
             gl3_table = os.path.join(os.path.dirname(_att.__file__), 'data', 'GL3_params.csv')
         _contexts[key] = Context(key[:3], attenuation_model, device=device, gl3_table=gl3_table)
     return _contexts[key]
+
+
+birefringence_models = {}   # name -> three (knots, coefficients, 3) tuples; filled on demand from a NuRadioMC installation
+
+
+def birefringence_model(name):
+    """The depth splines of nx, ny, nz of a birefringence ice model (NuRadioMC/utilities/medium.py:103-108 loads
+    utilities/birefringence_models/birefringence_<name>.npy, spline coefficients in FITPACK's (t, c, k) form).  Register
+    tables of your own in `birefringence_models`; otherwise the data file of an installed NuRadioMC is read."""
+    if name not in birefringence_models:
+        try:
+            import NuRadioMC.utilities.medium as _m
+            path = os.path.join(os.path.dirname(os.path.realpath(_m.__file__)), 'birefringence_models',
+                                'birefringence_' + name + '.npy')
+            tck = np.load(path, allow_pickle=True)
+        except Exception as e:
+            raise FileNotFoundError("birefringence model {}: no table registered in nuradiomc_amd.propagation."
+                                    "birefringence_models and no NuRadioMC installation to read it from ({})".format(name, e))
+        birefringence_models[name] = [(np.asarray(t[0], float), np.asarray(t[1], float), int(t[2])) for t in tck]
+    return birefringence_models[name]
 
 
 def get_propagation_module(name=None):
@@ -325,10 +346,27 @@ class ray_tracing:
             spec[2] *= reflection_coefficient * np.exp(1j * phase_shift)
         if prop.get('focusing'):  # analyticraytracing.py:3011-3016
             spec[1:] *= self.get_focusing(i_solution, limit=float(prop['focusing_limit']))
-        if prop.get('birefringence'):
-            raise NotImplementedError("birefringence is not provided yet")
+        if prop.get('birefringence'):  # :3018-3030
+            if prop.get('birefringence_propagation', 'analytical') != 'analytical':
+                raise NotImplementedError("birefringence_propagation '{}' needs the RadioPropa tracer and is not provided "
+                                          "(analytical)".format(prop.get('birefringence_propagation')))
+            spec = self.get_pulse_propagation_birefringence(spec, efield.get_sampling_rate(), i_solution,
+                                                            bire_model=prop.get('birefringence_model', 'southpole_A'))
         efield.set_frequency_spectrum(spec, efield.get_sampling_rate())
         return efield
+
+    def get_pulse_propagation_birefringence(self, pulse, samp_rate, i_solution, bire_model='southpole_A'):
+        """:2369-2445 on the GPU: pulse = spectra (eR, eTheta, ePhi); eR is not touched"""
+        self._check(i_solution)
+        if self._results[i_solution]['reflection'] > 0:
+            raise NotImplementedError("birefringence along paths with bottom reflections is not provided")
+        pulse = np.array(pulse, dtype=complex)
+        angle = self._config['propagation'].get('angle_to_iceflow')
+        out = self._ctx.birefringence_batch(self._X1[None], self._X2[None], [self._results[i_solution]['C0']],
+                                            [self.get_path_length(i_solution)], pulse[1:][None], samp_rate,
+                                            birefringence_model(bire_model), angle_to_iceflow=angle)[0]
+        pulse[1], pulse[2] = out[0], out[1]
+        return pulse
 
     def get_config(self):
         return self._config

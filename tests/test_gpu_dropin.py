@@ -420,3 +420,73 @@ def test_arz_like_the_reference():
     assert 5 < n_zero < 60
     with pytest.raises(NotImplementedError):
         a.get_time_trace(1e18, 1., 256, 0.5, 'TAU', 1.78, 1000.)
+
+
+def test_birefringence_like_T07():
+    """NuRadioMC/test/SignalProp/T07test_birefringence.py through the drop-in class (apply_propagation_effects with config
+    birefringence, model southpole_A) against the reference's golden file reference_BF.npy at T07's tolerance and 100x
+    tighter; the step records and spectra of the batched call against the oracle and the reference's own outputs, incl. a
+    Greenland set with an ice-flow angle."""
+    from nuradiomc_amd import propagation
+    from oracle import birefringence_oracle as bo
+    from test_oracle_golden import _bire_case, _bire_input
+    g = golden('ref_birefringence.npz')
+    fs = float(g['sampling_rate'])
+    size = len(g['input_trace'])
+    for tag, ice_par in (('sp', g['sp_ice']), ('gl', g['gl_ice'])):
+        tck, angle, pts, rec = _bire_case(g, tag)
+        model = str(g[tag + '_model'])
+        propagation.birefringence_models[model] = [(t, c, 3) for t, c in tck]
+        config = {'propagation': dict(attenuate_ice=False, focusing_limit=2, focusing=False, birefringence=True,
+                                      birefringence_model=model, birefringence_propagation='analytical')}
+        if angle is not None:
+            config['propagation']['angle_to_iceflow'] = angle
+        r = propagation.ray_tracing(_Ice(*ice_par))
+        th, ph = [g['input_trace']], [g['input_trace']]
+        k = 0
+        for iX, x in enumerate(pts):
+            r.set_start_and_end_point(x, rec)
+            r.find_solutions()
+            r.set_config(config)
+            for iS in range(r.get_number_of_solutions()):
+                ef = _EF(size, fs)
+                spec_in = np.fft.rfft(g['input_trace']) / fs * 2 ** 0.5
+                ef.spec = np.array([np.zeros_like(spec_in), spec_in, spec_in])
+                out = r.apply_propagation_effects(ef, iS).spec
+                ref = g['%s_spec_%d' % (tag, k)]
+                # the ray parameters differ from the reference's by its first-root noise (1e-7 in C0): the phases move
+                assert np.max(np.abs(out[1:] - ref)) <= 2e-4 * np.max(np.abs(ref)), (tag, k)
+                th.append(np.fft.irfft(out[1], n=size) * fs / 2 ** 0.5)
+                ph.append(np.fft.irfft(out[2], n=size) * fs / 2 ** 0.5)
+                k += 1
+        assert k == len(g[tag + '_rays'])
+        got = np.vstack((np.array(th), np.array(ph)))
+        if tag == 'sp':
+            np.testing.assert_allclose(got, g['ref_BF'], atol=2e-4, rtol=1e-7)    # T07test_birefringence.py:98
+            assert np.max(np.abs(got - g['ref_BF'])) < 1e-4
+        # batched, from the reference's own ray parameters: step records and spectra
+        rays = g[tag + '_rays']
+        ctx = r._ctx
+        X1 = np.array([pts[int(q[0])] for q in rays])
+        X2 = np.tile(rec, (len(rays), 1))
+        spec_in = np.array([_bire_input(g, ice_par, X1[q], rec, int(rays[q][1])) for q in range(len(rays))])
+        spec, steps = ctx.birefringence_batch(X1, X2, rays[:, 2], rays[:, 3], spec_in, fs, tck, angle_to_iceflow=angle,
+                                              return_steps=True)
+        o = 0
+        for q, (iX, iS, C0, D, n_steps) in enumerate(rays):
+            ref = g['%s_spec_%d' % (tag, q)]
+            assert np.max(np.abs(spec[q] - ref)) <= 1e-6 * np.max(np.abs(ref)), (tag, q)
+            st = steps[o:o + int(n_steps)]
+            o += int(n_steps)
+            if q < 3:
+                os_ = bo.path_steps(X1[q], rec, C0, D, ice_par, tck, angle)
+                assert np.max(np.abs(st[:, 0:2] - os_['P1'][:, 1:])) < 1e-7 and np.max(np.abs(st[:, 2:4] - os_['P2'][:, 1:])) < 1e-7
+                assert np.max(np.abs(st[:, 4] - (os_['T2'] - os_['T1']))) < 1e-10   # difference of two ~6 ns delays
+                e = bo.propagate(spec_in[q][0], spec_in[q][1], fs, os_)
+                assert np.max(np.abs(spec[q] - e)) <= 1e-6 * np.max(np.abs(e))
+        assert o == len(steps)
+    cfg = {'propagation': dict(attenuate_ice=False, focusing_limit=2, focusing=False, birefringence=True,
+                               birefringence_model='southpole_A', birefringence_propagation='numerical')}
+    r.set_config(cfg)
+    with pytest.raises(NotImplementedError):
+        r.apply_propagation_effects(_EF(size, fs), 0)
