@@ -1,0 +1,63 @@
+"""BASELINE config 3 in the shape the build can run today: an RNO-G like array of 35 stations x 24 channels (7 x 5 grid, 1.25 km
+spacing; per station a power string, two helper strings and 9 shallow LPDAs -- analytic antenna models, the measured ones are
+downloads), greenland_simple ice + GL1 attenuation, Alvarez2009, 1e18 eV hadronic showers in a cylinder around the array,
+speedup.distance_cut with the coefficients of the reference's example config, simple 3 Vrms threshold on any channel, 2048
+samples at 2 GHz.  One Station object per station; the event list is offered to every station and the masks are OR-ed.
+usage: config3_probe.py [n_events] [n_stations]"""
+import sys, time, os
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+import nuradiomc_amd
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+n_st = int(sys.argv[2]) if len(sys.argv) > 2 else 35
+d = np.pi / 180
+pos, ant, ori = [], [], []
+for z in [-95., -96., -97., -98., -80., -60., -40.]:
+    pos.append([0., 0., z]); ant.append('analytic_VPol'); ori.append([0., 0., 90 * d, 90 * d])
+for z in (-94., -79.):
+    pos.append([0., 0., z]); ant.append('analytic_HPol'); ori.append([0., 0., 90 * d, 90 * d])
+for x, y in ((-20., 30.), (25., 28.)):
+    for z in (-95., -94., -93.):
+        pos.append([x, y, z]); ant.append('analytic_VPol' if z != -94. else 'analytic_HPol'); ori.append([0., 0., 90 * d, 90 * d])
+for k in range(9):
+    a = 2 * np.pi * k / 9
+    pos.append([12 * np.cos(a), 12 * np.sin(a), -3.])
+    ant.append('analytic_LPDA')
+    ori.append([0., 0., 90 * d, (90 + 40 * k) * d] if k % 3 == 0 else [120 * d, a, 90 * d, a + 90 * d])
+pos, ori = np.array(pos), np.array(ori)
+centres = np.array([[1250. * (i - 3), 1250. * (j - 2), 0.] for i in range(7) for j in range(5)])[:n_st]
+ctx = nuradiomc_amd.Context((1.78, 0.51, 37.25), 'GL1', device=0)
+def make_station(c):
+    return nuradiomc_amd.Station(ctx, pos + c, antenna=ant, orientation=ori, n_samples=2048, sampling_rate=2.0, att_bound_depth=3000.)
+rng = np.random.default_rng(10)
+rmax = 1250. * 3.5 + 3000.
+r, ph = np.sqrt(rng.uniform(0, rmax ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+vertex = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-2700., -1., n)], axis=1)
+zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+energy = np.full(n, 1e18)
+coef = [-1.56434411e+02, 2.54131322e+01, -1.34932379e+00, 2.39984185e-02]   # config_default.yaml:20 speedup.distance_cut_coefficients
+chunk = 250000   # events per call: the workspace of a call (ray records, per-ray tables) stays resident in the Station object
+any_trig = np.zeros(n, bool)
+tot = dict(n_pairs=0, n_rays=0, n_active_rays=0, n_candidate_events=0)
+w = make_station(centres[0])
+w.simulate_events(vertex[:1000], zen[:1000], az[:1000], energy[:1000], 'HAD', distance_cut_coefficients=coef)
+w.close()
+t0 = time.time()
+per = []
+for c in centres:
+    t1 = time.time()
+    s = make_station(c)
+    for a in range(0, n, chunk):
+        sl = slice(a, min(n, a + chunk))
+        trig, stats = s.simulate_events(vertex[sl], zen[sl], az[sl], energy[sl], 'HAD', distance_cut_coefficients=coef)
+        any_trig[sl] |= trig.astype(bool)
+        for k in tot:
+            tot[k] += stats[k]
+    s.close()
+    per.append(time.time() - t1)
+dt = time.time() - t0
+print('config 3 (synthetic array): %d events x %d stations x 24 channels = %.3g pairs offered, %.3g rays after the distance cut; '
+      '%.2f s wall (host arrays in, masks out) = %.0f events/s, %.3g pairs/s; %d events trigger somewhere; per station %.3f .. %.3f s'
+      % (n, len(centres), n * len(centres) * 24., tot['n_rays'], dt, n / dt, n * len(centres) * 24. / dt, any_trig.sum(), min(per), max(per)))
+print('last station stage ms:', stats['stage_ms'])
