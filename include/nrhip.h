@@ -316,6 +316,11 @@ typedef struct nrhip_station nrhip_station;
 int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* desc, nrhip_station** out);
 void nrhip_station_destroy(nrhip_station* st);
 
+/* The per-call tables of the last nrhip_simulate_events call (ray records, per-ray tables, traces: what nrhip_sim_fetch reads)
+ * stay resident in the station object and are reused by the next call.  With many stations alive on one GPU (an array
+ * simulated station by station) release them when a station is done: returns the number of bytes given back. */
+int64_t nrhip_station_release_workspace(nrhip_station* st);
+
 /* The per-event hot path for single-shower event groups, in the order of simulation.run()
  * (NuRadioMC/simulation/simulation.py:1454-1600): for every channel calculate_sim_efield (:93-292: ray
  * tracing, delta_C cut, Askaryan spectrum, polarisation, attenuation, Fresnel, candidate cut), then

@@ -6,6 +6,7 @@
 // the list of distinct trace lengths (each needs one chirp table, built on device).
 #include "../../include/nrhip.h"
 #include "ctx.h"
+#include <cstdio>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -275,14 +276,33 @@ void nrhip_station_destroy(nrhip_station* s)
     delete s;
 }
 
+int64_t nrhip_station_release_workspace(nrhip_station* s)
+{
+    if (!s) return 0;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    int64_t freed = 0;
+    for (auto& kv : s->ws) {
+        freed += (int64_t)kv.second.cap;
+        kv.second.release();
+    }
+    s->ws_bytes.clear();
+    return freed;
+}
+
+static thread_local char g_ws_fail[160] = "";
 #define WS(name, type, count)                                                                       \
     ([&]() -> type* {                                                                               \
         DevArray& b_ = st->buf(name);                                                               \
-        if (b_.reserve((size_t)(count) * sizeof(type) + 16) != hipSuccess) return (type*)nullptr;   \
+        if (b_.reserve((size_t)(count) * sizeof(type) + 16) != hipSuccess) {                        \
+            snprintf(g_ws_fail, sizeof g_ws_fail, "nrhip_simulate_events: out of device memory (%s: %.3g GB)", name,  \
+                     (double)((size_t)(count) * sizeof(type)) * 1e-9);                              \
+            return (type*)nullptr;                                                                  \
+        }                                                                                           \
         st->ws_bytes[name] = (size_t)(count) * sizeof(type);                                        \
         return b_.as<type>();                                                                       \
     })()
-#define NEED(ptr) if (!(ptr)) return nrhip_fail_msg("nrhip_simulate_events: out of device memory")
+#define NEED(ptr) if (!(ptr)) return nrhip_fail_msg(g_ws_fail[0] ? g_ws_fail : "nrhip_simulate_events: out of device memory")
 #define LCHK(what)                                                          \
     do {                                                                    \
         hipError_t e_ = hipGetLastError();                                  \

@@ -97,6 +97,7 @@ class SimStats(ctypes.Structure):
 L._OPTIONAL.update({
     'nrhip_station_create': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StationDesc), L.c_void_pp]),
     'nrhip_station_destroy': (None, [ctypes.c_void_p]),
+    'nrhip_station_release_workspace': (ctypes.c_int64, [ctypes.c_void_p]),
     'nrhip_simulate_events': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(SimConfig), ctypes.c_int64]
                               + [ctypes.c_void_p] * 7 + [ctypes.POINTER(SimStats)]),
     'nrhip_simulate_event_groups': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(SimConfig),
@@ -232,6 +233,11 @@ class Station:
         self._h = h
         ctx._register_station(self)
         self.vrms, self.vrms_efield = flt.vrms_from_filters(self.sampling_rate, self.filters)
+
+    def release_workspace(self):
+        """Give the tables of the last call back to the GPU (they stay resident for `fetch` and for reuse by the next call);
+        returns the number of bytes freed.  For arrays simulated station by station on one GPU."""
+        return int(self._lib.nrhip_station_release_workspace(self._h)) if getattr(self, '_h', None) else 0
 
     def close(self):
         if getattr(self, '_h', None):

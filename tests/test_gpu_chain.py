@@ -249,6 +249,18 @@ def test_pruning_rigorous_on_survey_sample(gpu_ctx_factory):
     assert np.array_equal(B['item_maxV'][~sk & ~nan], A['item_maxV'][~sk & ~nan])
 
 
+def test_release_workspace(gpu_ctx_factory):
+    """the per-call tables can be handed back (arrays simulated station by station) and come back with the next call"""
+    g, ctx, st, trig, stats, kL = _run_fixture(gpu_ctx_factory, 'N256', 100)
+    assert len(st.fetch('ev_L')) == 100
+    assert st.release_workspace() > 1000 and st.release_workspace() == 0
+    with pytest.raises(Exception):
+        st.fetch('ev_L')
+    trig2, _ = st.simulate_events(g['vertex'][:100], g['zenith'][:100], g['azimuth'][:100], g['energy'][:100],
+                                  g['shower_type'][:100], kL, askaryan_model=str(g['askaryan_model']), dump_traces=True)
+    assert np.array_equal(trig, trig2) and len(st.fetch('ev_L')) == 100
+
+
 def test_simulate_events_edge_cases(gpu_ctx_factory):
     import bench
     ctx = gpu_ctx_factory(bench.ICE, 'SP1')

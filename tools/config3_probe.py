@@ -54,7 +54,7 @@ for c in centres:
         any_trig[sl] |= trig.astype(bool)
         for k in tot:
             tot[k] += stats[k]
-    s.close()
+    s.close()   # or s.release_workspace() to keep the station: the tables of a call stay resident otherwise
     per.append(time.time() - t1)
 dt = time.time() - t0
 print('config 3 (synthetic array): %d events x %d stations x 24 channels = %.3g pairs offered, %.3g rays after the distance cut; '
