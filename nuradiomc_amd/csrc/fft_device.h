@@ -24,10 +24,109 @@ __device__ inline double2 cmul(double2 a, double2 b) { return make_double2(a.x *
 __device__ inline double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
 __device__ inline double2 cscale(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
 
+// ---- K radix-2 stages fused in registers (2^K points per thread and pass) --------------------------------------------
+// The butterflies, their order and their rounding are exactly those of K separate radix-2 stages; only the number of
+// LDS round trips and barriers drops (13 stages: 4 passes instead of 13).  With one 128 KB working set per CU there is a
+// single block to hide LDS latency with, so passes -- not flops -- are what an in-LDS FFT costs here.
+#ifndef NRHIP_FFT_FUSE
+#define NRHIP_FFT_FUSE 4
+#endif
+
+// decimation in frequency, stages s .. s + K - 1 (spans M >> (s + 1) .. M >> (s + K))
+template <int K>
+__device__ inline void fft_dif_pass(double2* x, int M, int s, const double2* __restrict__ tw, bool inverse)
+{
+    constexpr int R = 1 << K;
+    const int q = M >> (s + K);
+    for (int t = threadIdx.x; t < (M >> K); t += blockDim.x) {
+        const int pos = t & (q - 1);
+        const int i0 = ((t - pos) << K) + pos;
+        double2 a[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) a[j] = x[i0 + j * q];
+#pragma unroll
+        for (int e = 0; e < K; e++) {
+            const int half = R >> (e + 1);
+            const int tstride = (FFT_MAX / 2) / (half * q);
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                double2 w = tw[(pos + j * q) * tstride];
+                if (inverse) w.y = -w.y;
+#pragma unroll
+                for (int blk = 0; blk < R; blk += 2 * half) {
+                    const double2 u = a[blk + j], v = a[blk + j + half];
+                    a[blk + j] = cadd(u, v);
+                    a[blk + j + half] = cmul(csub(u, v), w);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++) x[i0 + j * q] = a[j];
+    }
+    __syncthreads();
+}
+
+// decimation in time, stages with spans q = 1 << s, 2q, .. (K of them)
+template <int K>
+__device__ inline void fft_dit_pass(double2* x, int M, int s, const double2* __restrict__ tw, bool inverse)
+{
+    constexpr int R = 1 << K;
+    const int q = 1 << s;
+    for (int t = threadIdx.x; t < (M >> K); t += blockDim.x) {
+        const int pos = t & (q - 1);
+        const int i0 = ((t - pos) << K) + pos;
+        double2 a[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) a[j] = x[i0 + j * q];
+#pragma unroll
+        for (int e = 0; e < K; e++) {
+            const int half = 1 << e;
+            const int tstride = (FFT_MAX / 2) / (half * q);
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                double2 w = tw[(pos + j * q) * tstride];
+                if (inverse) w.y = -w.y;
+#pragma unroll
+                for (int blk = 0; blk < R; blk += 2 * half) {
+                    const double2 u = a[blk + j], b = cmul(a[blk + j + half], w);
+                    a[blk + j] = cadd(u, b);
+                    a[blk + j + half] = csub(u, b);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++) x[i0 + j * q] = a[j];
+    }
+    __syncthreads();
+}
+
+template <int F>
+__device__ inline void fft_dif_fused_k(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
+{
+    const int M = 1 << log2m;
+    int s = 0;
+    for (; log2m - s >= F; s += F) fft_dif_pass<F>(x, M, s, tw, inverse);
+    const int rem = log2m - s;
+    if (rem == 3) fft_dif_pass<3>(x, M, s, tw, inverse);
+    else if (rem == 2) fft_dif_pass<2>(x, M, s, tw, inverse);
+    else if (rem == 1) fft_dif_pass<1>(x, M, s, tw, inverse);
+}
+
+template <int F>
+__device__ inline void fft_dit_fused_k(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
+{
+    const int M = 1 << log2m;
+    const int rem = log2m % F;
+    if (rem == 3) fft_dit_pass<3>(x, M, 0, tw, inverse);
+    else if (rem == 2) fft_dit_pass<2>(x, M, 0, tw, inverse);
+    else if (rem == 1) fft_dit_pass<1>(x, M, 0, tw, inverse);
+    for (int s = rem; s < log2m; s += F) fft_dit_pass<F>(x, M, s, tw, inverse);
+}
+
 // tw[k] = exp(-2 pi i k / FFT_MAX), k < FFT_MAX / 2 (global memory, L1/L2 resident, built on the host in
 // extended precision).  Twiddle of a sub-size M transform: W_M^p = tw[p * (FFT_MAX / M)].
 // Decimation in frequency: natural-order input, bit-reversed output.  inverse -> conjugate twiddles (no 1/M).
-__device__ inline void fft_dif(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
+__device__ inline void fft_dif_pairs(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
 {
     const int M = 1 << log2m;
     int s = 0;
@@ -68,7 +167,7 @@ __device__ inline void fft_dif(double2* x, int log2m, const double2* __restrict_
 }
 
 // Decimation in time: bit-reversed input, natural-order output.
-__device__ inline void fft_dit(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
+__device__ inline void fft_dit_pairs(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
 {
     const int M = 1 << log2m;
     int s = 0;
@@ -108,7 +207,7 @@ __device__ inline void fft_dit(double2* x, int log2m, const double2* __restrict_
 // (LDS data + twiddles from global) before any is computed, so the ~2 x 7 independent loads per thread overlap
 // instead of serialising on L2 latency.  Same operations and rounding as fft_dif / fft_dit.
 template <int LOG2M, int NT>
-__device__ inline void fft_dif_t(double2* x, const double2* __restrict__ tw, bool inverse)
+__device__ inline void fft_dif_t_pairs(double2* x, const double2* __restrict__ tw, bool inverse)
 {
     constexpr int M = 1 << LOG2M;
     constexpr int QT = (M / 4 + NT - 1) / NT;  // quads per thread and pass
@@ -163,7 +262,7 @@ __device__ inline void fft_dif_t(double2* x, const double2* __restrict__ tw, boo
 }
 
 template <int LOG2M, int NT>
-__device__ inline void fft_dit_t(double2* x, const double2* __restrict__ tw, bool inverse)
+__device__ inline void fft_dit_t_pairs(double2* x, const double2* __restrict__ tw, bool inverse)
 {
     constexpr int M = 1 << LOG2M;
     constexpr int QT = (M / 4 + NT - 1) / NT;
@@ -218,6 +317,23 @@ __device__ inline void fft_dit_t(double2* x, const double2* __restrict__ tw, boo
         __syncthreads();
     }
 }
+
+// Entry points.  Run-time sized transforms (the N / 2-point ray transforms, <= 4096 points) keep the pairwise passes: 2^4
+// points per thread would leave most of a block idle there and its 64 extra VGPRs lower the occupancy of the kernels that
+// only ever call these.  The compile-time sized ones (the 8192-point convolutions) fuse NRHIP_FFT_FUSE stages.
+__device__ inline void fft_dif(double2* x, int log2m, const double2* __restrict__ tw, bool inverse) { fft_dif_pairs(x, log2m, tw, inverse); }
+__device__ inline void fft_dit(double2* x, int log2m, const double2* __restrict__ tw, bool inverse) { fft_dit_pairs(x, log2m, tw, inverse); }
+#if NRHIP_FFT_FUSE > 2
+template <int LOG2M, int NT>
+__device__ inline void fft_dif_t(double2* x, const double2* __restrict__ tw, bool inverse) { fft_dif_fused_k<NRHIP_FFT_FUSE>(x, LOG2M, tw, inverse); }
+template <int LOG2M, int NT>
+__device__ inline void fft_dit_t(double2* x, const double2* __restrict__ tw, bool inverse) { fft_dit_fused_k<NRHIP_FFT_FUSE>(x, LOG2M, tw, inverse); }
+#else
+template <int LOG2M, int NT>
+__device__ inline void fft_dif_t(double2* x, const double2* __restrict__ tw, bool inverse) { fft_dif_t_pairs<LOG2M, NT>(x, tw, inverse); }
+template <int LOG2M, int NT>
+__device__ inline void fft_dit_t(double2* x, const double2* __restrict__ tw, bool inverse) { fft_dit_t_pairs<LOG2M, NT>(x, tw, inverse); }
+#endif
 
 // 8192-point convolution with a bit-reversed spectrum table, NT threads
 template <int NT>
