@@ -692,6 +692,10 @@ __device__ inline double2 field_bin(int k, double amp_k, int N, double fs, doubl
 }
 
 // y_j = e[2j] + i e[2j+1] (j < N/2) of e = irfft_N(G) * fs / sqrt(2), left in x[bitrev(j)] (x in LDS, >= N/2)
+#ifndef NRHIP_EFIELD_FUSE
+#define NRHIP_EFIELD_FUSE 3   // efield_max_kernel: 256 threads on N / 2 = 2048 points = 2^3 points per thread and pass
+#endif
+template <int FUSE = 0>
 __device__ inline void field_time_domain(double2* x, const double* amp, int N, int log2nh, double fs, double pol,
                                          double2 rc, double rem, bool shift, int ask_model, double roll_bins,
                                          const double2* __restrict__ tw)
@@ -707,7 +711,9 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
         x[k] = make_double2(ge.x - go.y, ge.y + go.x);  // ge + i go
     }
     __syncthreads();
-    fft_dif(x, log2nh, tw, true);  // inverse, natural -> bit-reversed; scale applied by the reader
+    // inverse, natural -> bit-reversed; scale applied by the reader
+    if (FUSE > 2) fft_dif_fused_k<(FUSE > 2 ? FUSE : 3)>(x, log2nh, tw, true);
+    else fft_dif(x, log2nh, tw, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1052,7 +1058,7 @@ efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ ev_lis
         double mx = 0.;
         const double scale = st.fs / 1.4142135623730951 / nh;
         if (both_real) {
-            field_time_domain(x, amp, N, log2nh, st.fs, 1.0, make_double2(1., 0.), 0., false, ask_model,
+            field_time_domain<NRHIP_EFIELD_FUSE>(x, amp, N, log2nh, st.fs, 1.0, make_double2(1., 0.), 0., false, ask_model,
                               floor(2.0 * st.fs), tw);
             double cm = fmax(fabs(pt * rt.x), fabs(pp * rp.x));
             for (int j = threadIdx.x; j < nh; j += blockDim.x) {
@@ -1063,7 +1069,7 @@ efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ ev_lis
             __syncthreads();
         } else {
             for (int comp = 0; comp < 2; comp++) {
-                field_time_domain(x, amp, N, log2nh, st.fs, comp ? pp : pt, comp ? rp : rt, 0., false, ask_model,
+                field_time_domain<NRHIP_EFIELD_FUSE>(x, amp, N, log2nh, st.fs, comp ? pp : pt, comp ? rp : rt, 0., false, ask_model,
                                   floor(2.0 * st.fs), tw);
                 for (int j = threadIdx.x; j < nh; j += blockDim.x) {
                     double2 y = x[j];

@@ -156,6 +156,18 @@ def distance_cut(vertex, energy, group_begin, coefficients, sum_length=10.):
     return np.ascontiguousarray(out)
 
 
+def _shower_type_codes(shower_type, n):
+    """'HAD' / 'EM' (any case; one value or one per shower) or the integer codes -> int32 [n]"""
+    code = lambda v: int(v) if isinstance(v, (int, np.integer)) else SHOWER_TO_INT[str(v).upper()]
+    if isinstance(shower_type, (str, int, np.integer)):
+        return np.full(n, code(shower_type), np.int32)
+    a = np.asarray(shower_type).reshape(-1)
+    if a.dtype.kind in 'iu':
+        return np.ascontiguousarray(np.broadcast_to(a, (n,)), dtype=np.int32)
+    values, inverse = np.unique(a, return_inverse=True)
+    return np.ascontiguousarray(np.broadcast_to(np.array([code(v) for v in values], np.int32)[inverse], (n,)))
+
+
 class Station:
     """One station on one Context.
 
@@ -208,18 +220,11 @@ class Station:
         # largest attenuation length between the surface and att_bound_depth per coarse frequency (1 m grid): lets the
         # library bound a ray's attenuation factor by exp(-0.95 D / L_max) before paying for the path integral
         self.att_bound_depth = float(att_bound_depth)
-        zz = np.linspace(-self.att_bound_depth, 0., int(self.att_bound_depth) + 1)
-        lmax = np.array([np.max(ctx.attenuation_length(zz, f)) for f in self.att_freq])
-        self.att_bound_inv_length = np.ascontiguousarray(1.0 / (lmax * (1 + 1e-3)))
-        # the same per 50 m depth bin (0.25 m grid, 1e-3 for what happens between grid points): the library sums
-        # (path length inside the bin) / L_max(bin) along the ray, a much tighter bound on the path integral
-        self.att_bound_bin_width = 50.
-        n_bins = min(63, int(np.ceil(self.att_bound_depth / self.att_bound_bin_width)))
-        per = int(round(self.att_bound_bin_width / 0.25))
-        zz = -np.arange(n_bins * per + 1) * 0.25
-        inv = np.array([1.0 / ctx.attenuation_length(zz, f) for f in self.att_freq])            # [n_fc][n_z]
-        idx = np.arange(n_bins)[:, None] * per + np.arange(per + 1)[None, :]
-        self.att_bound_bin_inv_length = np.ascontiguousarray(inv[:, idx].min(axis=2).T * (1 - 1e-3))  # [n_bins][n_fc]
+        cache = ctx.__dict__.setdefault('_att_bound_cache', {})   # the tables depend on (ice, model, frequencies, depth) only
+        key = (self.att_freq.tobytes(), self.att_bound_depth)
+        if key not in cache:
+            cache[key] = self._attenuation_bound_tables(ctx)
+        self.att_bound_inv_length, self.att_bound_bin_width, n_bins, self.att_bound_bin_inv_length = cache[key]
         self._keep = (pos, cab, model, ori, self.att_freq, nb, na, fb, fa, self.att_bound_inv_length,
                       self.att_bound_bin_inv_length, fkind, tables, tab_index, ctabs)
         d = StationDesc(n, L.dptr(pos), L.dptr(cab), L.iptr(model), L.dptr(ori), self.n_samples, self.sampling_rate,
@@ -233,6 +238,23 @@ class Station:
         self._h = h
         ctx._register_station(self)
         self.vrms, self.vrms_efield = flt.vrms_from_filters(self.sampling_rate, self.filters)
+
+    def _attenuation_bound_tables(self, ctx):
+        """largest attenuation length between the surface and att_bound_depth per coarse frequency (1 m grid), and per 50 m
+        depth bin: lets the library bound a ray's attenuation factor before paying for the path integral"""
+        zz = np.linspace(-self.att_bound_depth, 0., int(self.att_bound_depth) + 1)
+        lmax = np.array([np.max(ctx.attenuation_length(zz, f)) for f in self.att_freq])
+        att_bound_inv_length = np.ascontiguousarray(1.0 / (lmax * (1 + 1e-3)))
+        # the same per 50 m depth bin (0.25 m grid, 1e-3 for what happens between grid points): the library sums
+        # (path length inside the bin) / L_max(bin) along the ray, a much tighter bound on the path integral
+        bin_width = 50.
+        n_bins = min(63, int(np.ceil(self.att_bound_depth / bin_width)))
+        per = int(round(bin_width / 0.25))
+        zz = -np.arange(n_bins * per + 1) * 0.25
+        inv = np.array([1.0 / ctx.attenuation_length(zz, f) for f in self.att_freq])            # [n_fc][n_z]
+        idx = np.arange(n_bins)[:, None] * per + np.arange(per + 1)[None, :]
+        bin_inv = np.ascontiguousarray(inv[:, idx].min(axis=2).T * (1 - 1e-3))  # [n_bins][n_fc]
+        return att_bound_inv_length, bin_width, n_bins, bin_inv
 
     def release_workspace(self):
         """Give the tables of the last call back to the GPU (they stay resident for `fetch` and for reuse by the next call);
@@ -303,8 +325,7 @@ class Station:
         if distance_cut_coefficients is not None and n:
             md = distance_cut(vertex, np.broadcast_to(L.f64(energy), (n,)), gb, distance_cut_coefficients,
                               distance_cut_sum_length)
-        st = np.ascontiguousarray([SHOWER_TO_INT[str(s).upper()] if not isinstance(s, (int, np.integer)) else int(s)
-                                   for s in np.broadcast_to(shower_type, (n,))], dtype=np.int32)
+        st = _shower_type_codes(shower_type, n)
         kL = np.ascontiguousarray(np.broadcast_to(np.nan if k_L is None else L.f64(k_L), (n,)), dtype=np.float64)
         kL = np.where(np.isnan(kL), 1.0, kL)
         arrs = [vertex, np.ascontiguousarray(np.broadcast_to(L.f64(zenith), (n,))),
