@@ -186,6 +186,15 @@ def main():
                          "note": "every kernel of the path is FP64-VALU/LDS bound: the fused kernels move ~1e-3 of the "
                                  "un-fused algorithmic bytes of SURVEY 8(d) that 'achieved' is priced on"},
         }
+        if dom == 'attenuation':
+            # the quadrature kernel is FP64 bound: price it in flops against the dense FP64 peak of the
+            # MI355X (78.6 TFLOP/s, vector and matrix alike; the kernel issues VALU FP64, there is no contraction for MFMA).
+            # algorithmic flops per launch = integrand evaluations (counted by the kernel) x flop_per_eval
+            out["roofline"].update({"bound": "mfma", "achieved": fp64, "peak": 78.6, "unit": "TFLOP/s", "frac": fp64 / 78.6,
+                                    "algorithmic_flops_per_launch": stats['n_integrand_evals'] * flop_per_eval,
+                                    "hbm_view_GBs": achieved,
+                                    "note": "FP64 VALU kernel priced against the dense FP64 peak (no MFMA-shaped work on this "
+                                            "path); 'traffic' = HBM bytes of the launch from the PMC passes"})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 10)
         else:
