@@ -481,6 +481,37 @@ def test_production_mode_is_deterministic(gpu_ctx_factory):
         assert np.array_equal(trig, ref)
 
 
+def test_full_size_properties(gpu_ctx_factory):
+    """BASELINE config 2 at its full size (1e6 events, 5 channels, 4096 samples; the oracle would need an hour for it):
+    properties that do not depend on the size -- the trigger mask is a function of the event alone (any permutation of the
+    list permutes the mask; halves and unequal shards of the list give the same entries as the whole: what the multi-GPU
+    sharding relies on), triggered events are candidates, every count of the stats is consistent with the tables, and the
+    known answer of the benchmark list (9053 triggers) is reproduced."""
+    import bench
+    ctx = gpu_ctx_factory(bench.ICE, 'SP1')
+    st = nuradiomc_amd.Station(ctx, bench.CHANNELS, n_samples=4096, sampling_rate=2.0)
+    n = 1000000
+    v, z, a = bench.make_events(n, 10)
+    en = np.full(n, bench.ENERGY)
+    trig, stats = st.simulate_events(v, z, a, en, 'HAD')
+    assert trig.sum() == 9053 == stats['n_triggered'] and stats['n_events'] == n and stats['n_pairs'] == 5 * n
+    cand = st.fetch('ev_candidate').astype(bool)
+    n_rays = st.fetch('ev_n_rays')
+    assert cand.sum() == stats['n_candidate_events'] and n_rays.sum() == stats['n_rays'] and n_rays.max() <= 10
+    assert np.all(cand[trig]) and np.all(n_rays[cand] > 0)
+    assert stats['n_active_rays'] <= stats['n_rays'] and stats['n_channel_items'] == 5 * stats['n_candidate_events']
+    L = st.fetch('ev_L')
+    assert np.all(L[cand] % 2 == 0) and stats['max_length'] == L[cand].max()
+    # permutation
+    perm = np.random.default_rng(1).permutation(n)
+    trig_p, _ = st.simulate_events(v[perm], z[perm], a[perm], en[perm], 'HAD')
+    assert np.array_equal(trig_p, trig[perm])
+    # shards of unequal size (what bench.py --gpus N does with contiguous ranges)
+    cuts = [0, 137, 400000, 400001, 999999, n]
+    parts = [st.simulate_events(v[i:j], z[i:j], a[i:j], en[i:j], 'HAD')[0] for i, j in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(parts), trig)
+
+
 @pytest.mark.parametrize('att_model', ['GL1', 'GL3'])
 def test_rnog_like_station_24_channels(gpu_ctx_factory, att_model):
     """A 24-channel station in the shape of RNO-G (BASELINE configs 3-5: deep VPol / HPol strings plus shallow LPDAs in
