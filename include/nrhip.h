@@ -40,6 +40,8 @@ extern "C" {
 #define NRHIP_ASK_ALVAREZ2009 0
 #define NRHIP_ASK_ALVAREZ2000 1
 #define NRHIP_ASK_ZHS1992 2
+#define NRHIP_ASK_ARZ2019 3   /* time-domain models: need nrhip_station_set_arz + nrhip_station_set_shower_profiles */
+#define NRHIP_ASK_ARZ2020 4
 
 /* shower types */
 #define NRHIP_SHOWER_HAD 0
@@ -320,6 +322,25 @@ void nrhip_station_destroy(nrhip_station* st);
  * stay resident in the station object and are reused by the next call.  With many stations alive on one GPU (an array
  * simulated station by station) release them when a station is done: returns the number of bytes given back. */
 int64_t nrhip_station_release_workspace(nrhip_station* st);
+
+/* ---- general emission / propagation inside nrhip_simulate_events (BASELINE config 4) -----------------------------------
+ * With askaryan_model NRHIP_ASK_ARZ2019 / ARZ2020 and / or a birefringence model set, nrhip_simulate_events materialises
+ * the on-sky spectra of every ray that passes the delta_C cut (calculate_sim_efield, simulation.py:221-290: emission,
+ * polarisation, apply_propagation_effects = attenuation, Fresnel factors, birefringence), turns them into electric-field
+ * traces and feeds those to the channel / trigger stage; the result-neutral pruning of the parametrised path does not
+ * apply (every kept ray is evaluated).  Tables afterwards: "ray_spectra" [ray][2][N/2 + 1] complex, "ray_traces" [ray][2][N].
+ *
+ * nrhip_station_set_arz: the charge-excess profiles (as nrhip_arz_time_trace_batch: common depth grid, [n_profiles][n_depth]),
+ * model parameters [2][7] (HAD, EM), interp_factor2, em_formula != 0: hadronic showers are scaled by ARZ.em_fraction
+ * (ARZ2020).  nrhip_station_set_shower_profiles: per shower of the NEXT simulate call the profile row and the amplitude
+ * factor E / E_library (the host picks them as ARZ.get_time_trace does: closest library energy, random / given number).
+ * nrhip_station_set_birefringence: the three depth splines as in nrhip_birefringence_batch; n_knots == NULL switches it off.
+ * Limits: simple threshold trigger, no focusing with ARZ, no amp_per_ray.  HOST pointers (copied).                      */
+int nrhip_station_set_arz(nrhip_station* st, int32_t n_profiles, int32_t n_depth, const double* profile_depth,
+                          const double* profile_ce, const double* parameters, double interp_factor2, int32_t em_formula);
+int nrhip_station_set_shower_profiles(nrhip_station* st, int64_t n_showers, const int32_t* profile_index, const double* rescale);
+int nrhip_station_set_birefringence(nrhip_station* st, const int32_t* n_knots, const double* knots, const double* coeffs,
+                                    double n_ref, double angle_to_iceflow);
 
 /* The per-event hot path for single-shower event groups, in the order of simulation.run()
  * (NuRadioMC/simulation/simulation.py:1454-1600): for every channel calculate_sim_efield (:93-292: ray

@@ -80,7 +80,7 @@ class Context:
     def askaryan_spectrum_batch(self, energy, theta, N, dt, shower_type, n_index, R, model, k_L=None):
         """[n, N/2+1] complex spectra of askaryan.get_frequency_spectrum for arrays of showers / viewing angles."""
         from .station import ASKARYAN_TO_INT, SHOWER_TO_INT
-        if model not in ASKARYAN_TO_INT:
+        if model not in ('Alvarez2009', 'Alvarez2000', 'ZHS1992'):
             raise NotImplementedError("model {} unknown".format(model))
         energy, theta, n_index, R = np.broadcast_arrays(L.f64(energy), L.f64(theta), L.f64(n_index), L.f64(R))
         n = energy.size

@@ -19,6 +19,7 @@ struct ArzBatch {
     double dt, n_index, interp_factor2;
     int shift_for_xmax;
     double maximum_angle;
+    const double* n_index_ray = nullptr;      // [n_rays] index of refraction at the shower (overrides n_index)
 };
 
 void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int* status);

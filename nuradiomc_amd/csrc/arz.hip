@@ -80,6 +80,7 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
 {
     extern __shared__ double lds[];
     const int ray = blockIdx.x;
+    const double nidx = b.n_index_ray ? b.n_index_ray[ray] : b.n_index;
     const int nd = b.n_depth;
     double* s_depth = lds;
     double* s_ce = lds + nd;
@@ -89,7 +90,7 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
     const double theta = b.theta[ray];
     const int typ = b.shower_type[ray];  // 0 HAD, 1 EM
     // 20 deg cut (ARZ.py:603-607): the trace kernel writes zeros, nothing to integrate
-    if (fabs(theta - acos(1. / b.n_index)) > b.maximum_angle) return;
+    if (fabs(theta - acos(1. / nidx)) > b.maximum_angle) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const double* ce_g = b.profile_ce + (long)b.profile_index[ray] * nd;
     const double resc = b.rescale ? b.rescale[ray] : 1.;
@@ -138,7 +139,7 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
     // observer times in between are distributed over the ARZ_CHUNKS blocks of this ray.
     double hmin = 1e300, hmax = -1e300;
     for (int i = threadIdx.x; i < nd; i += blockDim.x) {
-        const double h = -arz_tt(r, s_depth[i], r.R0 / ARZ_C * b.n_index, b.n_index);
+        const double h = -arz_tt(r, s_depth[i], r.R0 / ARZ_C * nidx, nidx);
         hmin = fmin(hmin, h);
         hmax = fmax(hmax, h);
     }
@@ -152,7 +153,7 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
         hmin = fmin(hmin, s_w[w][2]);
         hmax = fmax(hmax, s_w[w][3]);
     }
-    const double fc = 4. * M_PI / (ARZ_XMU * sin(acos(1. / b.n_index)));
+    const double fc = 4. * M_PI / (ARZ_XMU * sin(acos(1. / nidx)));
     const double factor = -ARZ_XMU / (4. * M_PI);
     // observer times: arange(0, (N + 1) dt, dt) + dt / 2 - mean (:98-102)
     const int nt_raw = (int)ceil(((b.N + 1) * b.dt - 0.) / b.dt);
@@ -166,7 +167,7 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
     for (int it = it_lo + blockIdx.y * per + wave; it < it_end; it += n_waves) {
         const double t_bin = it * b.dt + 0.5 * b.dt - mean;
         if (t_bin - hmax > 20.001 || t_bin - hmin < -20.001) continue;  // vp stays 0 (memset by the launcher)
-        const double tobs = t_bin + (r.R0 / ARZ_C * b.n_index);
+        const double tobs = t_bin + (r.R0 / ARZ_C * nidx);
         // pass 1 over the profile nodes: anything within +-20 ns?  where does the +-1 ns condition flip?
         int idx[18];
         int ni = 0;
@@ -175,7 +176,7 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
         for (int base = 0; base < nd; base += 64) {
             const int i = base + lane;
             double t = 1e300;
-            if (i < nd) t = arz_tt(r, s_depth[i], tobs, b.n_index);
+            if (i < nd) t = arz_tt(r, s_depth[i], tobs, nidx);
             const unsigned long long B20 = __ballot(t < 20. && t > -20.);
             const unsigned long long B1 = __ballot(t < 1. && t > -1.);
             any20 |= (B20 != 0ull);
@@ -252,7 +253,7 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
                 const double xl = (g > 0) ? depth_at(g - 1, &ipn, &jn) : x;
                 const double xr = (g + 1 < M) ? depth_at(g + 1, &ipn, &jn) : x;
                 double yx, yz, t;
-                arz_integrand(r, x, q, tobs, b.n_index, fc, &yx, &yz, &t);
+                arz_integrand(r, x, q, tobs, nidx, fc, &yx, &yz, &t);
                 // trapezoid rule sum_j (z_{j+1} - z_j) (y_{j+1} + y_j) / 2 = sum_j y_j (z_{j+1} - z_{j-1}) / 2
                 const double w = (xr / ARZ_RHO - xl / ARZ_RHO) * 0.5;
                 ax += w * yx;
@@ -275,10 +276,11 @@ __global__ void __launch_bounds__(256)
 arz_trace_kernel(ArzBatch b, const double* __restrict__ vp, double* __restrict__ trace)
 {
     const int ray = blockIdx.x;
+    const double nidx = b.n_index_ray ? b.n_index_ray[ray] : b.n_index;
     const int N = b.N, nt = N + 1, nd = b.n_depth;
     const double theta = b.theta[ray];
     double* out = trace + (long)ray * 3 * N;
-    if (fabs(theta - acos(1. / b.n_index)) > b.maximum_angle) {
+    if (fabs(theta - acos(1. / nidx)) > b.maximum_angle) {
         for (int i = threadIdx.x; i < 3 * N; i += blockDim.x) out[i] = 0.;
         return;
     }

@@ -51,6 +51,13 @@ struct nrhip_station {
     std::vector<double> h_pos, h_cable;
     DevArray d_pos, d_cable, d_model, d_rot, d_rot_inv, d_fc, d_lnf, d_invl, d_fpow, d_seg, d_attbin, d_anttabs, d_anttab_index;
     std::vector<DevArray> d_tabdata;  // arrays of the tabulated antenna patterns
+    // general emission / propagation path (nrhip_station_set_arz / _set_birefringence / _set_shower_profiles)
+    DevArray d_arz_depth, d_arz_ce, d_arz_par, d_bire_knots, d_bire_coeffs, d_shower_profile, d_shower_rescale;
+    int arz_n_profiles = 0, arz_n_depth = 0, arz_em_formula = 0;
+    double arz_interp_factor2 = 100.;
+    int bire_n_knots[3] = {0, 0, 0};
+    double bire_n_ref = 1.78, bire_angle = 0.;
+    int64_t n_shower_profiles = 0;
     // workspace of the last simulated chunk (kept for nrhip_sim_fetch and reused between calls)
     std::map<std::string, DevArray> ws;
     std::map<std::string, size_t> ws_bytes;  // valid bytes of the last chunk

@@ -6,6 +6,8 @@
 // the list of distinct trace lengths (each needs one chirp table, built on device).
 #include "../../include/nrhip.h"
 #include "ctx.h"
+#include "arz.h"
+#include "birefringence.h"
 #include <cstdio>
 #include <algorithm>
 #include <cmath>
@@ -273,6 +275,8 @@ void nrhip_station_destroy(nrhip_station* s)
     s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release(); s->d_lnf.release(); s->d_invl.release();
     s->d_fpow.release(); s->d_seg.release(); s->d_attbin.release(); s->d_anttabs.release(); s->d_anttab_index.release();
     for (auto& a : s->d_tabdata) a.release();
+    s->d_arz_depth.release(); s->d_arz_ce.release(); s->d_arz_par.release(); s->d_bire_knots.release();
+    s->d_bire_coeffs.release(); s->d_shower_profile.release(); s->d_shower_rescale.release();
     delete s;
 }
 
@@ -288,6 +292,61 @@ int64_t nrhip_station_release_workspace(nrhip_station* s)
     }
     s->ws_bytes.clear();
     return freed;
+}
+
+int nrhip_station_set_arz(nrhip_station* s, int32_t n_profiles, int32_t n_depth, const double* profile_depth,
+                          const double* profile_ce, const double* parameters, double interp_factor2, int32_t em_formula)
+{
+    if (!s || !profile_depth || !profile_ce || !parameters) return nrhip_fail_msg("nrhip_station_set_arz: NULL argument");
+    if (n_profiles < 1 || n_depth < 2 || n_depth > 2048) return nrhip_fail_msg("nrhip_station_set_arz: profiles need 2..2048 depth bins");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    if (upload(s->ctx, s->d_arz_depth, profile_depth, (size_t)n_depth) ||
+        upload(s->ctx, s->d_arz_ce, profile_ce, (size_t)n_profiles * n_depth) || upload(s->ctx, s->d_arz_par, parameters, (size_t)14))
+        return -1;
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    s->arz_n_profiles = n_profiles;
+    s->arz_n_depth = n_depth;
+    s->arz_interp_factor2 = interp_factor2;
+    s->arz_em_formula = em_formula;
+    return 0;
+}
+
+int nrhip_station_set_shower_profiles(nrhip_station* s, int64_t n_showers, const int32_t* profile_index, const double* rescale)
+{
+    if (!s) return nrhip_fail_msg("nrhip_station_set_shower_profiles: NULL argument");
+    s->n_shower_profiles = 0;
+    if (n_showers <= 0 || !profile_index || !rescale) return 0;
+    for (int64_t i = 0; i < n_showers; i++)
+        if (profile_index[i] < 0 || profile_index[i] >= s->arz_n_profiles)
+            return nrhip_fail_msg("nrhip_station_set_shower_profiles: profile index outside the library set with nrhip_station_set_arz");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    if (upload(s->ctx, s->d_shower_profile, profile_index, (size_t)n_showers) ||
+        upload(s->ctx, s->d_shower_rescale, rescale, (size_t)n_showers))
+        return -1;
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    s->n_shower_profiles = n_showers;
+    return 0;
+}
+
+int nrhip_station_set_birefringence(nrhip_station* s, const int32_t* n_knots, const double* knots, const double* coeffs,
+                                    double n_ref, double angle_to_iceflow)
+{
+    if (!s) return nrhip_fail_msg("nrhip_station_set_birefringence: NULL argument");
+    s->bire_n_knots[0] = s->bire_n_knots[1] = s->bire_n_knots[2] = 0;
+    if (!n_knots) return 0;
+    if (!knots || !coeffs) return nrhip_fail_msg("nrhip_station_set_birefringence: NULL argument");
+    size_t nk = 0;
+    for (int j = 0; j < 3; j++) {
+        if (n_knots[j] < 8) return nrhip_fail_msg("nrhip_station_set_birefringence: a cubic spline needs at least 8 knots");
+        nk += (size_t)n_knots[j];
+    }
+    HIPCHK(hipSetDevice(s->ctx->device));
+    if (upload(s->ctx, s->d_bire_knots, knots, nk) || upload(s->ctx, s->d_bire_coeffs, coeffs, nk)) return -1;
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    for (int j = 0; j < 3; j++) s->bire_n_knots[j] = n_knots[j];
+    s->bire_n_ref = n_ref;
+    s->bire_angle = angle_to_iceflow;
+    return 0;
 }
 
 static thread_local char g_ws_fail[160] = "";
@@ -329,7 +388,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (!group_begin && n_groups != n_showers)
         return nrhip_fail_msg("nrhip_simulate_events: group_begin is required when groups hold several showers");
     const int64_t n_events = n_showers;  // ray stages work per shower, decision stages per event group
-    if (cfg->askaryan_model < 0 || cfg->askaryan_model > 2)
+    if (cfg->askaryan_model < 0 || cfg->askaryan_model > NRHIP_ASK_ARZ2020)
         return nrhip_fail_msg("nrhip_simulate_events: Askaryan model not implemented");
     nrhip_sim_stats S;
     memset(&S, 0, sizeof S);
@@ -344,6 +403,18 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     const long n_pairs = n_events * n_ch, n_slots = n_pairs * NRHIP_MAXS;
     if (n_slots > 2000000000L) return nrhip_fail_msg("nrhip_simulate_events: batch too large, split the event list");
     S.n_pairs = n_pairs;
+    // general emission / propagation path?
+    const bool arz = cfg->askaryan_model == NRHIP_ASK_ARZ2019 || cfg->askaryan_model == NRHIP_ASK_ARZ2020;
+    const bool bire = st->bire_n_knots[0] > 0;
+    const bool general = arz || bire;
+    if (arz && st->arz_n_profiles <= 0)
+        return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need a shower library (nrhip_station_set_arz)");
+    if (arz && st->n_shower_profiles != n_events)
+        return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need one profile per shower (nrhip_station_set_shower_profiles)");
+    if (arz && cfg->focusing) return nrhip_fail_msg("nrhip_simulate_events: focusing is not available with the ARZ models");
+    if (general && cfg->amp_per_ray) return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray is not available with ARZ / birefringence");
+    if (general && (cfg->trigger_type == NRHIP_TRIG_HIGH_LOW || cfg->n_coincidences > 1))
+        return nrhip_fail_msg("nrhip_simulate_events: ARZ / birefringence run with the simple threshold trigger only");
     for (auto& e : st->evt) if (!e) HIPCHK(hipEventCreate(&e));
 #define MARK(i) HIPCHK(hipEventRecord(st->evt[i], sm))
     MARK(0);
@@ -470,7 +541,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             foc_launch = rec2.launch;
         }
         launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w, evin,
-                         cfg->askaryan_model, foc_n_sol, foc_launch, foc_dz, cfg->focusing_limit > 0 ? cfg->focusing_limit : 2.);
+                         arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model, foc_n_sol, foc_launch, foc_dz, cfg->focusing_limit > 0 ? cfg->focusing_limit : 2.);
         LCHK("ray_setup");
     }
     MARK(2);
@@ -488,11 +559,16 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(active_list = WS("ray_active_list", int, nr));
         launch_ray_limits_from_slots(sm, n_rays, n_ch, ray_slot, vertex, sd.pos, rec, ctx->ice, zint);
         LCHK("ray_limits");
-        launch_amp_bound(sm, n_rays, w, sd, ctx->ice, vertex, zint, bound, max_efield);
-        LCHK("amp_bound");
-        launch_event_possible(sm, (int)n_groups, n_ch, grp_ray, bound, cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude,
-                              ractive);
-        LCHK("event_possible");
+        if (general) {  // every kept ray is evaluated
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ractive, 1, (size_t)n_rays, sm));
+            HIPCHK(hipMemsetAsync(bound, 0xFF, sizeof(double) * nr, sm));
+        } else {
+            launch_amp_bound(sm, n_rays, w, sd, ctx->ice, vertex, zint, bound, max_efield);
+            LCHK("amp_bound");
+            launch_event_possible(sm, (int)n_groups, n_ch, grp_ray, bound, cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude,
+                                  ractive);
+            LCHK("event_possible");
+        }
         // active rays listed by work class (direct, reflected, refracted): wave-mates in the quadrature do similar work
         launch_active_class_flags(sm, n_rays, ractive, w.slot, rec.type, cflags);
         HIPCHK(hipMemsetAsync(cflags + 3L * n_rays, 0, sizeof(int), sm));
@@ -520,7 +596,77 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         LCHK("attenuation");
     }
     MARK(4);
-    if (n_active > 0) {
+    const double* ray_traces = nullptr;
+    if (general && n_rays > 0) {
+        // 4. general path: spectra of all kept rays -> (birefringence) -> traces and their maxima
+        const int n_f = sd.N / 2 + 1;
+        double2* spec;
+        double *traces, *g_energy, *g_em, *g_resc, *g_x1, *g_x2;
+        int *g_type, *g_prof, *g_nsteps, *g_npoints;
+        NEED(spec = WS("ray_spectra", double2, nr * 2 * n_f));
+        NEED(traces = WS("ray_traces", double, nr * 2 * sd.N));
+        NEED(g_energy = WS("gen_energy", double, nr));
+        NEED(g_em = WS("gen_em_factor", double, nr));
+        NEED(g_resc = WS("gen_rescale", double, nr));
+        NEED(g_x1 = WS("gen_x1", double, 3 * nr));
+        NEED(g_x2 = WS("gen_x2", double, 3 * nr));
+        NEED(g_type = WS("gen_type", int, nr));
+        NEED(g_prof = WS("gen_profile", int, nr));
+        NEED(g_nsteps = WS("gen_n_steps", int, nr));
+        NEED(g_npoints = WS("gen_n_points", int, nr));
+        launch_general_gather(sm, n_rays, n_ch, w, evin, sd, vertex, arz ? st->d_shower_profile.as<int>() : nullptr,
+                              arz ? st->d_shower_rescale.as<double>() : nullptr, st->arz_em_formula, g_energy, g_type, g_em,
+                              g_prof, g_resc, g_x1, g_x2, g_nsteps, g_npoints);
+        LCHK("general gather");
+        const double* arz_trace = nullptr;
+        if (arz) {
+            double *vp, *atr;
+            int* ast;
+            NEED(vp = WS("arz_vector_potential", double, nr * (sd.N + 1) * 2));
+            NEED(atr = WS("arz_traces", double, nr * 3 * sd.N));
+            NEED(ast = WS("arz_status", int, nr));
+            HIPCHK(hipMemsetAsync(ast, 0, sizeof(int) * nr, sm));
+            ArzBatch ab{(long)n_rays, g_energy, w.view, w.R, g_type, g_em, g_prof, g_resc, st->arz_n_profiles, st->arz_n_depth,
+                        st->d_arz_depth.as<double>(), st->d_arz_ce.as<double>(), st->d_arz_par.as<double>(), sd.N, 1. / sd.fs,
+                        1.78, st->arz_interp_factor2, 0, 20. * 0.017453292519943295, w.n_index};
+            launch_arz(sm, ab, vp, atr, ast);
+            LCHK("arz");
+            std::vector<int> hs(n_rays);
+            HIPCHK(hipMemcpyAsync(hs.data(), ast, sizeof(int) * nr, hipMemcpyDeviceToHost, sm));
+            HIPCHK(hipStreamSynchronize(sm));
+            for (int v : hs)
+                if (v) return nrhip_fail_msg("nrhip_simulate_events: ARZ: length of indices is not 2 nor 4 (more than two stretches of a profile radiate within 1 ns)");
+            arz_trace = atr;
+        }
+        launch_general_spectrum(sm, n_rays, w, sd, cfg->askaryan_model, arz_trace, ctx->twiddle, spec);
+        LCHK("general spectrum");
+        if (bire) {
+            std::vector<int> hn(n_rays);
+            HIPCHK(hipMemcpyAsync(hn.data(), g_nsteps, sizeof(int) * nr, hipMemcpyDeviceToHost, sm));
+            HIPCHK(hipStreamSynchronize(sm));
+            std::vector<long> off(nr + 1, 0);
+            int max_points = 0;
+            for (size_t i = 0; i < nr; i++) {
+                off[i + 1] = off[i] + hn[i];
+                max_points = std::max(max_points, hn[i] + 1);
+            }
+            long* d_off;
+            double* steps;
+            NEED(d_off = WS("bire_step_offset", long, nr + 1));
+            NEED(steps = WS("bire_steps", double, (size_t)std::max<long>(off[nr], 1) * 5));
+            HIPCHK(hipMemcpyAsync(d_off, off.data(), sizeof(long) * (nr + 1), hipMemcpyHostToDevice, sm));
+            BireBatch bb{(long)n_rays, g_x1, g_x2, w.C0, g_npoints, d_off, ctx->ice, st->d_bire_knots.as<double>(),
+                         st->d_bire_coeffs.as<double>(), {st->bire_n_knots[0], st->bire_n_knots[1], st->bire_n_knots[2]},
+                         st->bire_n_ref, st->bire_angle, n_f, sd.fs};
+            launch_birefringence(sm, bb, max_points, steps, spec);
+            LCHK("birefringence");
+            HIPCHK(hipStreamSynchronize(sm));  // `off` goes out of scope
+        }
+        launch_general_trace(sm, n_rays, sd, spec, ctx->twiddle, traces, max_efield);
+        LCHK("general trace");
+        ray_traces = traces;
+    }
+    if (!general && n_active > 0) {
         // 4. candidate cut on max |E(t)|
         int *need_ray, *ev_need, *ev_off, *ev_tmp, *ev_list;
         NEED(need_ray = WS("ray_need_transform", int, nr));
@@ -662,9 +808,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(coinc_cnt = WS("coincidence_count", int, trg.coincidence() ? (size_t)channel_grid_blocks() * FFT_MAX : 1));
         double2* tab_nodes = nullptr;  // per block: the angular interpolation of a tabulated pattern at its frequency nodes
         if (sd.ant_tabs) NEED(tab_nodes = WS("antenna_table_nodes", double2, (size_t)channel_grid_blocks() * 2 * sd.max_tab_freq));
-        launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, cfg->askaryan_model, trg,
-                       ctx->twiddle, ctx->w16, tab, scratch, co, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, maxL, it_need,
-                       it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes);
+        launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
+                       trg, ctx->twiddle, ctx->w16, tab, scratch, co, (cfg->no_pruning || cfg->dump_traces || general) ? 1 : 0, maxL,
+                       it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces);
         LCHK("channel");
         MARK(8);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here

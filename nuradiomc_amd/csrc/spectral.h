@@ -157,11 +157,21 @@ void launch_candidate_lists(hipStream_t s, int n_events, int n_half, const Event
 void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet& fl,
                           const double2* tw, const double2* w16, const LengthTables& tab);
 int channel_grid_blocks();
+void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, int ask_model,
+                             const double* arz_trace, const double2* tw, double2* spec);
+void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double2* tw,
+                          double* traces, double* max_efield);
+void launch_general_gather(hipStream_t s, int n_rays, int n_ch, const RayWork& w, const EventIn& evin, const StationDev& st,
+                           const double* vertex, const int* shower_profile, const double* shower_rescale, int em_formula,
+                           double* energy, int* type, double* em_factor, int* profile, double* rescale, double* x1, double* x2,
+                           int* n_steps, int* n_points);
+void launch_int_to_long(hipStream_t s, int n, const int* in, long* out);
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
-                    int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes);
+                    int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
+                    const double* ray_traces = nullptr);
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
                          const int* len_index_N, double* max_env, double* signal_time);

@@ -1638,6 +1638,46 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     }
 }
 
+// y_j = e[2j] + i e[2j+1] of a real N-sample trace in HBM, optionally delayed by the sub-sample remainder `rem` through the
+// Fourier shift theorem on the N grid (rfft -> * exp(-2 pi i f rem) -> irfft, base_trace.py:273-276).  Without the shift the
+// packed trace is left in natural order, with it in bit-reversed order and unscaled by 1 / (N / 2).  x: FFT_MAX complex (LDS).
+__device__ inline void trace_to_packed(double2* x, const double* __restrict__ tr, int N, int log2nh, double fs, double rem,
+                                       bool shift, const double2* __restrict__ tw)
+{
+    const int M = FFT_MAX, nh = N / 2;
+    const double res = 1. / fs;
+    for (int j = threadIdx.x; j < nh; j += blockDim.x) x[j] = make_double2(tr[2 * j], tr[2 * j + 1]);
+    __syncthreads();
+    if (!shift) return;
+    fft_dif(x, log2nh, tw, false);  // Y in bit-reversed order
+    double2* G = x + M / 2;          // G'(k), k = 0..nh, in the upper half of the buffer
+    for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
+        int ka = (k == nh) ? 0 : k, kb = (k == 0 || k == nh) ? 0 : nh - k;
+        double2 Y1 = x[bitrev(ka, log2nh)], Y2 = cconj(x[bitrev(kb, log2nh)]);
+        double2 ge = cscale(cadd(Y1, Y2), 0.5);
+        double2 d = cscale(csub(Y1, Y2), 0.5);
+        double2 go = make_double2(d.y, -d.x);  // d / i
+        double2 wk = (k == nh) ? make_double2(-1., 0.) : tw[k * (FFT_MAX / N)];  // exp(-2 pi i k / N)
+        double2 g = cadd(ge, cmul(go, wk));
+        double f = k * (1.0 / (N * res));
+        double sn, cs;
+        sincos(-2. * M_PI * rem * f, &sn, &cs);
+        g = cmul(g, make_double2(cs, sn));
+        if (k == 0 || k == nh) g.y = 0.;  // irfft uses the real part of DC and Nyquist only
+        G[k] = g;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nh; k += blockDim.x) {
+        double2 Gk = G[k], Gc = cconj(G[nh - k]);
+        double2 ge = cscale(cadd(Gk, Gc), 0.5);
+        double2 d = cscale(csub(Gk, Gc), 0.5);
+        double2 go = cmul(d, cconj(tw[k * (FFT_MAX / N)]));
+        x[k] = make_double2(ge.x - go.y, ge.y + go.x);
+    }
+    __syncthreads();
+    fft_dif(x, log2nh, tw, true);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // kernel: one (candidate event, channel) item per block iteration.
 //   for every ray of the channel and both on-sky components:
@@ -1650,7 +1690,8 @@ __global__ void __launch_bounds__(512)
 channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                const int* __restrict__ ev_len_index, StationDev st, FilterSet fl, int ask_model, double threshold,
                const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
-               ChannelOut out, int exact, int skip_upto, double2* __restrict__ tab_nodes)
+               ChannelOut out, int exact, int skip_upto, double2* __restrict__ tab_nodes,
+               const double* __restrict__ ray_traces)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M = FFT_MAX, N = st.N, nh = N / 2;
@@ -1665,7 +1706,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
         const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
         const int L = ev.L[e], m = L / 2, il = ev_len_index[e];
         const bool tabulated = (st.ant_model[ch] == 3);
-        if (L <= skip_upto && !tabulated) continue;  // done by channel_conv_kernel
+        if (L <= skip_upto && !tabulated && !ray_traces) continue;  // done by channel_conv_kernel
         double2* nodes = tab_nodes ? tab_nodes + (long)blockIdx.x * 2 * st.max_tab_freq : nullptr;
         const double t_min = ev.t_min[e];
         const double res = 1. / st.fs;
@@ -1699,10 +1740,12 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
         for (int r = r0; r < r1; r++) {
             if (w.ch[r] != ch) continue;
             n_used++;
-            if (threadIdx.x == 0) rs.ask = w.ask[r];
-            for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
-            __syncthreads();
-            fill_amplitude(amp, st, rs);
+            if (!ray_traces) {
+                if (threadIdx.x == 0) rs.ask = w.ask[r];
+                for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
+                __syncthreads();
+                fill_amplitude(amp, st, rs);
+            }
             // start bin and sub-sample remainder (efieldToVoltageConverter.py:214-218)
             double start_time = w.t0[r] - t_min + st.cable[ch] + 0;
             long start_bin = (long)rint(start_time / res);
@@ -1732,13 +1775,22 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                 double pol = comp ? w.pol_phi[r] : w.pol_theta[r];
                 double2 rc = comp ? w.r_phi[r] : w.r_theta[r];
                 double vfac = (comp ? Tp : Tt) * dir;
-                if ((comp ? wp : wt) <= 1e-13 * (comp ? wt : wp)) continue;
-                field_time_domain(x, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
+                if (!ray_traces && (comp ? wp : wt) <= 1e-13 * (comp ? wt : wp)) continue;
+                bool natural = false;
+                double sc = 1.0 / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
+                if (ray_traces) {
+                    // the ray's electric-field trace of this component comes from HBM (time-domain emission models,
+                    // birefringence: general_trace_kernel); the on-sky factors are already in it
+                    trace_to_packed(x, ray_traces + ((long)r * 2 + comp) * N, N, log2nh, st.fs, rem, shift, tw);
+                    natural = !shift;
+                    sc = (shift ? 1.0 / nh : 1.0) * (1.4142135623730951 / st.fs);  // time2freq
+                } else {
+                    field_time_domain(x, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
+                }
                 // gather y_j (bit-reversed positions) -> registers, then lay out a_j = y_j * chirp_j, zero pad
-                const double sc = 1.0 / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
                 double2 yreg[8];
                 int cnt = 0;
-                for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = x[bitrev(j, log2nh)];
+                for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = natural ? x[j] : x[bitrev(j, log2nh)];
                 __syncthreads();
                 cnt = 0;
 #pragma unroll 4
@@ -2275,7 +2327,8 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
-                    int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes)
+                    int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
+                    const double* ray_traces)
 {
     if (n_items <= 0) return;
     set_big_lds();
@@ -2284,7 +2337,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     // traces up to FFT_MAX samples: prefilter, then one real convolution per listed item; longer ones (or
     // NRHIP_CHANNEL_CZT=1): chirp-z per ray (plain OR of simple thresholds only; the caller checks)
     int skip_upto = 0;
-    if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT")) {
+    if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces) {
         hipLaunchKernelGGL(channel_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev,
                            ev_len_index, st, trig.prefilter(), tab.hnorm, exact, out.maxV, need);
         const int n_cand = n_items / st.n_ch;
@@ -2304,8 +2357,186 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     }
     size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
     hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
-                       ask_model, trig.threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto, tab_nodes);
+                       ask_model, trig.threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto, tab_nodes, ray_traces);
 }
+// ---------------------------------------------------------------------------------------------------------
+// General emission / propagation path (time-domain emission models such as ARZ, birefringence): the on-sky spectra of every
+// kept ray are materialised in HBM ([ray][eTheta, ePhi][N/2 + 1] complex), optionally propagated through the birefringent
+// ice (birefringence.hip works on exactly this layout), turned into time traces ([ray][2][N]) and handed to the chirp-z
+// channel kernel, which then reads fields instead of generating them.  calculate_sim_efield (simulation.py:221-290):
+// spectrum = askaryan(...), E = pol x spectrum, apply_propagation_effects (attenuation, Fresnel, birefringence).
+// ---------------------------------------------------------------------------------------------------------
+// kernel: spectra.  arz_trace != nullptr: the Askaryan spectrum is fft.time2freq of the ray's eTheta ARZ trace
+// ([ray][3][N], arz.hip), else the parametrisation's.  One block (256) per ray; LDS: N/2 complex + (N/2 + 1) doubles.
+__global__ void __launch_bounds__(256)
+general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, const double* __restrict__ arz_trace,
+                        const double2* __restrict__ tw, int log2nh, double2* __restrict__ spec)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = st.N, nh = N / 2, n_f = nh + 1;
+    double2* x = (double2*)smem;
+    double* amp = (double*)(x + nh);
+    __shared__ RayShared rs;
+    const double df = 1.0 / (N * (1. / st.fs));
+    for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) rs.ask = w.ask[r];
+        for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
+        __syncthreads();
+        const double2 rt = w.r_theta[r], rp = w.r_phi[r];
+        const double pt = w.pol_theta[r], pp = w.pol_phi[r];
+        double2* Eo = spec + (long)r * 2 * n_f;
+        if (!arz_trace) {
+            fill_amplitude(amp, st, rs);
+            for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
+                const double2 G = field_bin(k, amp[k], N, st.fs, 1.0, make_double2(1., 0.), 0., false, ask_model, floor(2.0 * st.fs));
+                Eo[k] = cscale(cmul(G, rt), pt);
+                Eo[n_f + k] = cscale(cmul(G, rp), pp);
+            }
+        } else {
+            for (int j = threadIdx.x; j < st.n_fc; j += blockDim.x) {
+                rs.xp[j] = st.fcoarse[j];
+                if (j < st.n_fc - 1) rs.slope[j] = (rs.att[j + 1] - rs.att[j]) / (st.fcoarse[j + 1] - st.fcoarse[j]);
+            }
+            const double* tr = arz_trace + ((long)r * 3 + 1) * N;
+            for (int j = threadIdx.x; j < nh; j += blockDim.x) x[j] = make_double2(tr[2 * j], tr[2 * j + 1]);
+            __syncthreads();
+            fft_dif(x, log2nh, tw, false);  // packed half-length transform, bit-reversed
+            const double sc = 1.4142135623730951 / st.fs;  // fft.time2freq: rfft / fs * sqrt 2
+            for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
+                const int ka = (k == nh) ? 0 : k, kb = (k == 0 || k == nh) ? 0 : nh - k;
+                const double2 Y1 = x[bitrev(ka, log2nh)], Y2 = cconj(x[bitrev(kb, log2nh)]);
+                const double2 ge = cscale(cadd(Y1, Y2), 0.5);
+                const double2 d = cscale(csub(Y1, Y2), 0.5);
+                const double2 go = make_double2(d.y, -d.x);
+                const double2 wk = (k == nh) ? make_double2(-1., 0.) : tw[k * (FFT_MAX / N)];
+                // attenuation: np.interp on the coarse grid for f > 0, 1 at DC (analyticraytracing.py:1075-1080)
+                const double a = (k == 0) ? 1. : interp_seg(k * df, st.seg[k], st.n_fc, rs.xp, rs.att, rs.slope);
+                const double2 S = cscale(cadd(ge, cmul(go, wk)), sc * a);
+                Eo[k] = cscale(cmul(S, rt), pt);
+                Eo[n_f + k] = cscale(cmul(S, rp), pp);
+            }
+        }
+    }
+}
+
+// kernel: spectra -> traces e = irfft(E) fs / sqrt 2 ([ray][2][N]) and max |e| per ray (the candidate cut of
+// simulation.py:283-285 looks at all components of the trace).  One block (256) per ray.
+__global__ void __launch_bounds__(256)
+general_trace_kernel(int n_rays, StationDev st, const double2* __restrict__ spec, const double2* __restrict__ tw, int log2nh,
+                     double* __restrict__ traces, double* __restrict__ max_efield)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = st.N, nh = N / 2, n_f = nh + 1;
+    double2* x = (double2*)smem;
+    __shared__ double red[256];
+    const double scale = st.fs / 1.4142135623730951 / nh;
+    for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
+        double mx = 0.;
+        for (int comp = 0; comp < 2; comp++) {
+            const double2* E = spec + ((long)r * 2 + comp) * n_f;
+            __syncthreads();
+            for (int k = threadIdx.x; k < nh; k += blockDim.x) {
+                double2 Gk = E[k], Gc = cconj(E[nh - k]);
+                if (k == 0) { Gk.y = 0.; Gc.y = 0.; }  // irfft ignores the imaginary parts of DC and Nyquist
+                const double2 ge = cscale(cadd(Gk, Gc), 0.5);
+                const double2 d = cscale(csub(Gk, Gc), 0.5);
+                const double2 go = cmul(d, cconj(tw[k * (FFT_MAX / N)]));
+                x[k] = make_double2(ge.x - go.y, ge.y + go.x);
+            }
+            __syncthreads();
+            fft_dif(x, log2nh, tw, true);
+            double* out = traces + ((long)r * 2 + comp) * N;
+            for (int j = threadIdx.x; j < nh; j += blockDim.x) {
+                const double2 y = x[bitrev(j, log2nh)];
+                const double e0 = y.x * scale, e1 = y.y * scale;
+                out[2 * j] = e0;
+                out[2 * j + 1] = e1;
+                mx = fmax(mx, fmax(fabs(e0), fabs(e1)));
+            }
+        }
+        mx = block_max(mx, red);
+        if (threadIdx.x == 0) max_efield[r] = mx;
+    }
+}
+
+// kernel: what the ARZ and birefringence kernels need per ray, gathered from the ray tables
+__global__ void __launch_bounds__(256)
+general_gather_kernel(int n_rays, int n_ch, RayWork w, EventIn evin, StationDev st, const double* __restrict__ vertex,
+                      const int* __restrict__ shower_profile, const double* __restrict__ shower_rescale, int em_formula,
+                      double* __restrict__ energy, int* __restrict__ type, double* __restrict__ em_factor,
+                      int* __restrict__ profile, double* __restrict__ rescale, double* __restrict__ x1, double* __restrict__ x2,
+                      int* __restrict__ n_steps)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const int sh = w.ev[r], ch = w.ch[r];
+    const double E = evin.energy[sh];
+    energy[r] = E;
+    type[r] = evin.shower_type[sh];
+    // ARZ.em_fraction (ARZ.py:436-447), hadronic showers of the ARZ2020 parameter set only
+    double f = 1.;
+    if (em_formula && evin.shower_type[sh] == 0) {
+        const double eps = log10(E / 1.);
+        f = -21.98905 - 2.32492 * eps;
+        f += 0.019650 * (eps * eps) + 13.76152 * sqrt(eps);
+    }
+    em_factor[r] = f;
+    profile[r] = shower_profile ? shower_profile[sh] : 0;
+    rescale[r] = shower_rescale ? shower_rescale[sh] : 1.;
+    for (int d = 0; d < 3; d++) {
+        x1[3 * (long)r + d] = vertex[3 * (long)sh + d];
+        x2[3 * (long)r + d] = st.pos[3 * ch + d];
+    }
+    const int acc = (int)(w.R[r] / 1.);  // int(path length / m) path points (analyticraytracing.py:2417)
+    n_steps[r] = acc > 1 ? acc - 1 : 0;
+}
+
+__global__ void int_to_long_kernel(int n, const int* __restrict__ in, long* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+__global__ void steps_to_points_kernel(int n, const int* __restrict__ n_steps, int* __restrict__ n_points)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) n_points[i] = n_steps[i] > 0 ? n_steps[i] + 1 : 0;
+}
+
+void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, int ask_model,
+                             const double* arz_trace, const double2* tw, double2* spec)
+{
+    if (n_rays <= 0) return;
+    const int nh = st.N / 2;
+    int grid = n_rays < 256 * 64 ? n_rays : 256 * 64;
+    hipLaunchKernelGGL(general_spectrum_kernel, dim3(grid), dim3(256), (size_t)nh * 16 + (size_t)(nh + 1) * 8, s, n_rays, w, st,
+                       ask_model, arz_trace, tw, ilog2(nh), spec);
+}
+void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double2* tw,
+                          double* traces, double* max_efield)
+{
+    if (n_rays <= 0) return;
+    const int nh = st.N / 2;
+    int grid = n_rays < 256 * 64 ? n_rays : 256 * 64;
+    hipLaunchKernelGGL(general_trace_kernel, dim3(grid), dim3(256), (size_t)nh * 16, s, n_rays, st, spec, tw, ilog2(nh), traces,
+                       max_efield);
+}
+void launch_general_gather(hipStream_t s, int n_rays, int n_ch, const RayWork& w, const EventIn& evin, const StationDev& st,
+                           const double* vertex, const int* shower_profile, const double* shower_rescale, int em_formula,
+                           double* energy, int* type, double* em_factor, int* profile, double* rescale, double* x1, double* x2,
+                           int* n_steps, int* n_points)
+{
+    if (n_rays <= 0) return;
+    hipLaunchKernelGGL(general_gather_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, n_ch, w, evin, st, vertex,
+                       shower_profile, shower_rescale, em_formula, energy, type, em_factor, profile, rescale, x1, x2, n_steps);
+    hipLaunchKernelGGL(steps_to_points_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, n_steps, n_points);
+}
+void launch_int_to_long(hipStream_t s, int n, const int* in, long* out)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(int_to_long_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, n, in, out);
+}
+
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
                          const int* len_index_N, double* max_env, double* signal_time)

@@ -434,9 +434,12 @@ class Station:
 
 def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model='SP1', n_freq=25,
                           model='Alvarez2009', delta_C_cut=0.698, vertex_time=0., rays=None, max_distance=None,
-                          focusing=False, focusing_limit=2.):
+                          focusing=False, focusing_limit=2., arz=None, birefringence=None):
     """calculate_sim_efield (simulation.py:93-292) for every channel of one single-shower event.
     `rays` may carry precomputed ray tables (dict like raytrace_oracle.raytrace_batch output, one row per channel).
+    arz = (arz_oracle.ARZ object, profile number of this shower) for model 'ARZ2019' / 'ARZ2020' (simulation.py:221-242: every
+    ray of a shower uses the same profile); birefringence = (tck of the three depth splines, angle_to_iceflow or None)
+    (apply_propagation_effects, analyticraytracing.py:3018-3030).
     Returns a list of dicts (one per kept ray, channel-major then solution)."""
     N, dt = st.n_samples, 1. / st.fs
     x1 = np.asarray(vertex, float)
@@ -463,7 +466,12 @@ def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st,
             if np.abs(dC[s]) > delta_C_cut:
                 continue
             D, T = rays['D'][ch, s], rays['T'][ch, s]
-            spectrum, _ = askaryan_frequency_spectrum(energy, view[s], N, dt, shower_type, n_index, D, model, k_L=k_L)
+            if model in ('ARZ2019', 'ARZ2020'):
+                from . import arz_oracle
+                spectrum, _ = arz_oracle.askaryan_frequency_spectrum(arz[0], energy, view[s], N, dt, shower_type, n_index, D,
+                                                                     iN=arz[1])
+            else:
+                spectrum, _ = askaryan_frequency_spectrum(energy, view[s], N, dt, shower_type, n_index, D, model, k_L=k_L)
             pol = polarization_onsky(shower_direction, rays['launch'][ch, s])
             spec = np.outer(pol, spectrum)
             att = rto.attenuation_batch(x1[None], st.pos[ch][None], [rays['C0'][ch, s]], ice, att_model, fcoarse)[0]
@@ -478,6 +486,11 @@ def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st,
                 spec[2] = spec[2] * r_phi
             if focusing:  # analyticraytracing.py:3011-3016
                 spec[1:] = spec[1:] * rto.focusing(x1[None], st.pos[ch][None], ice, -0.01, focusing_limit)[0, s]
+            if birefringence is not None:
+                from . import birefringence_oracle as bo
+                steps = bo.path_steps(x1, st.pos[ch], rays['C0'][ch, s], D, ice, birefringence[0], birefringence[1])
+                spec = np.array(spec, complex)
+                spec[1], spec[2] = bo.propagate(spec[1], spec[2], st.fs, steps)
             zen_r, az_r = cartesian_to_spherical(*rays['receive'][ch, s])
             t0 = vertex_time + T - 0.5 * N / st.fs
             trace = freq2time(spec, st.fs)
@@ -600,10 +613,11 @@ def station_trigger(V, fs, trigger='simple', threshold=None, n_coincidences=1, t
 
 def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, vrms, vrms_efield, att_model='SP1',
                    n_freq=25, model='Alvarez2009', filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0,
-                   min_efield_amplitude=2.0, rays=None, focusing=False, focusing_limit=2.):
+                   min_efield_amplitude=2.0, rays=None, focusing=False, focusing_limit=2., arz=None, birefringence=None):
     """One single-shower event group through simulation.run()'s sequence (:1454-1600)."""
     efs = sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model, n_freq, model,
-                                delta_C_cut, rays=rays, focusing=focusing, focusing_limit=focusing_limit)
+                                delta_C_cut, rays=rays, focusing=focusing, focusing_limit=focusing_limit, arz=arz,
+                                birefringence=birefringence)
     out = dict(rays=efs, candidate=False, triggered=False, L=0, t_min=np.nan)
     for ef in efs:
         if ef['max_efield'] > min_efield_amplitude * vrms_efield:

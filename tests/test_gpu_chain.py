@@ -610,3 +610,92 @@ def test_focusing_batched(gpu_ctx_factory):
     assert np.all(ratio <= 2.0 * 1.2) and np.mean(np.abs(ratio - 1) > 1e-3) > 0.9
     trig_p, _ = st.simulate_events(*args, focusing=True, focusing_limit=2.)
     assert np.array_equal(trig_p, trig)
+
+
+@pytest.mark.parametrize('mode', ['birefringence', 'arz', 'arz+birefringence'])
+def test_general_path_arz_birefringence(gpu_ctx_factory, mode):
+    """BASELINE config 4 inside simulate_events: time-domain ARZ2020 emission and / or birefringent propagation.  The GPU
+    materialises the on-sky spectra and traces of every kept ray; compared with the oracle's chain (pinned against the
+    reference piece by piece: ARZ traces, birefringent propagation, efield -> voltage) on identical ray tables: ray spectra,
+    maxima, candidate flags, trace lengths, channel voltage traces (1e-6) and trigger decisions."""
+    from nuradiomc_amd import arz as arz_mod
+    from oracle import arz_oracle
+    from test_oracle_golden import _arz_library
+    g = golden('chain_N256.npz')
+    ice = g['ice']
+    N, fs = 512, 2.0
+    ctx = gpu_ctx_factory(ice, 'SP1')
+    pos = g['det_pos']
+    st = nuradiomc_amd.Station(ctx, pos, n_samples=N, sampling_rate=fs)
+    ost = so.Station(pos, n_samples=N, fs=fs)
+    vrms, vrms_e = so.vrms_from_filters(fs)
+    assert st.vrms == vrms
+    rng = np.random.default_rng(4)
+    n = 60
+    r, ph = np.sqrt(rng.uniform(0, 900. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    v = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1200., -120., n)], axis=1)
+    zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    en = 10 ** rng.uniform(17.3, 18.7, n)
+    types = np.array(['HAD', 'EM'])[rng.integers(0, 2, n)]
+    kw, okw = {}, {}
+    bire = None
+    if 'birefringence' in mode:
+        b = golden('ref_birefringence.npz')
+        tck = [(b['tck_southpole_A_%d_t' % j], b['tck_southpole_A_%d_c' % j]) for j in range(3)]
+        st.set_birefringence(tck, angle_to_iceflow=25.)
+        bire = (tck, 25.)
+    model = 'Alvarez2009'
+    iN = np.zeros(n, int)
+    oarz = None
+    if 'arz' in mode:
+        lib = _arz_library(golden('ref_arz.npz'))
+        a = arz_mod.ARZ(seed=3, library=lib)
+        st.set_arz(a)
+        iN = a.draw_profile_numbers(en, list(types))
+        model = 'ARZ2020'
+        kw = dict(arz_iN=iN)
+        oarz = arz_oracle.ARZ(lib, seed=3)
+    kL = np.where(types == 'EM', 10 ** 1.5, 1.0)
+    # the eigen-polarisations divide by n^2 - n_i^2 ~ 1e-3 and ~2000 steps multiply up: two IEEE implementations of the
+    # birefringent propagation agree to ~1e-6..1e-5 (the reference's own T07 allows 2e-3 of the pulse amplitude)
+    tol = 3e-5 if bire else 2e-6
+    trig, stats = st.simulate_events(v, zen, az, en, types, kL, askaryan_model=model, dump_traces=True, **kw)
+    T = {k: st.fetch(k) for k in ('pair_n_sol', 'slot_type', 'slot_C0', 'slot_D', 'slot_T', 'slot_launch', 'slot_receive',
+                                  'slot_refl_angle', 'ray_channel', 'ray_solution', 'ray_max_efield', 'ev_n_rays', 'ev_L',
+                                  'ev_candidate', 'ev_ray_begin', 'ray_spectra')}
+    n_ch, n_f = len(pos), N // 2 + 1
+    spectra = T['ray_spectra'].view(np.complex128).reshape(-1, 2, n_f)
+    item_event = st.fetch('item_event') if stats['n_candidate_events'] else np.zeros(0, np.int32)
+    toff = st.fetch('trace_offset') if len(item_event) else None
+    trace = st.fetch('trace') if len(item_event) else None
+    n_cand = n_rays = n_trig = 0
+    for ev in range(n):
+        ps = slice(ev * n_ch, (ev + 1) * n_ch)
+        ss = slice(ev * n_ch * 2, (ev + 1) * n_ch * 2)
+        rays = dict(n_sol=T['pair_n_sol'][ps], type=T['slot_type'][ss].reshape(n_ch, 2), C0=T['slot_C0'][ss].reshape(n_ch, 2),
+                    D=T['slot_D'][ss].reshape(n_ch, 2), T=T['slot_T'][ss].reshape(n_ch, 2),
+                    refl_angle=T['slot_refl_angle'][ss].reshape(n_ch, 2),
+                    launch=T['slot_launch'][ev * n_ch * 6:(ev + 1) * n_ch * 6].reshape(n_ch, 2, 3),
+                    receive=T['slot_receive'][ev * n_ch * 6:(ev + 1) * n_ch * 6].reshape(n_ch, 2, 3))
+        o = so.simulate_event(v[ev], zen[ev], az[ev], en[ev], str(types[ev]), float(kL[ev]), ost, ice, vrms, vrms_e, model=model,
+                              rays=rays, arz=(oarz, int(iN[ev])) if oarz else None, birefringence=bire)
+        r0 = T['ev_ray_begin'][ev]
+        sel = np.arange(r0, r0 + T['ev_n_rays'][ev])
+        assert [(q['channel'], q['iS']) for q in o['rays']] == list(zip(T['ray_channel'][sel], T['ray_solution'][sel]))
+        for q, k in zip(o['rays'], sel):
+            scale = max(np.max(np.abs(q['spec'][1:])), 1e-300)
+            assert np.max(np.abs(spectra[k] - q['spec'][1:])) <= tol * scale, (ev, k)
+            assert abs(q['max_efield'] - T['ray_max_efield'][k]) <= tol * max(q['max_efield'], 1e-300)
+            n_rays += 1
+        assert bool(T['ev_candidate'][ev]) == o['candidate'] and bool(trig[ev]) == o['triggered'], ev
+        if o['candidate']:
+            n_cand += 1
+            n_trig += o['triggered']
+            assert T['ev_L'][ev] == o['L']
+            i = int(np.where(item_event == ev)[0][0])
+            scale = np.max(np.abs(o['V']))
+            for ch in range(n_ch):
+                tr = trace[toff[i * n_ch + ch]:toff[i * n_ch + ch + 1]]
+                assert np.max(np.abs(tr - o['V'][ch])) <= tol * scale, (ev, ch)
+    assert n_rays > 100 and n_cand >= 8 and n_trig >= 2
+    assert stats['n_candidate_events'] == n_cand
