@@ -83,6 +83,7 @@ void nrhip_ctx_destroy(nrhip_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    while (!ctx->stations.empty()) nrhip_station_detach(*ctx->stations.begin());  // stations outliving their context
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->gl3) (void)hipFree(ctx->gl3);
     if (ctx->twiddle) (void)hipFree(ctx->twiddle);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 #include "spectral.h"
@@ -15,7 +16,12 @@ struct nrhip_ctx {
     double* gl3 = nullptr;       // GL3 depth table [3][gl3_n] (depth, slope, offset), nrhip_ctx_set_gl3_table
     int gl3_n = 0;
     double2* w16 = nullptr;      // exp(-2 pi i k / (2 FFT_MAX)), k <= FFT_MAX / 2 (real <-> packed-complex FFT split)
+    std::set<struct nrhip_station*> stations;  // alive stations: nrhip_ctx_destroy releases what they hold on the GPU
 };
+
+// frees the station's device memory and events and detaches it from its context (the host object stays until
+// nrhip_station_destroy): whichever of the two destroy calls comes first, nothing dangles
+extern "C" void nrhip_station_detach(struct nrhip_station* s);
 
 int nrhip_fail(const char* what, hipError_t e);
 int nrhip_fail_msg(const char* what);

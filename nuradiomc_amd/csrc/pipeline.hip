@@ -260,6 +260,7 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
         memcpy(f.b[i], d->filter_b + (size_t)i * NRHIP_MAX_POLY, sizeof(double) * f.nb[i]);
         memcpy(f.a[i], d->filter_a + (size_t)i * NRHIP_MAX_POLY, sizeof(double) * f.na[i]);
     }
+    ctx->stations.insert(s);
     *out = s;
     return 0;
 }
@@ -267,6 +268,13 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
 void nrhip_station_destroy(nrhip_station* s)
 {
     if (!s) return;
+    nrhip_station_detach(s);
+    delete s;
+}
+
+void nrhip_station_detach(nrhip_station* s)
+{
+    if (!s || !s->ctx) return;  // already detached by nrhip_ctx_destroy
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     for (auto& kv : s->ws) kv.second.release();
@@ -277,12 +285,15 @@ void nrhip_station_destroy(nrhip_station* s)
     for (auto& a : s->d_tabdata) a.release();
     s->d_arz_depth.release(); s->d_arz_ce.release(); s->d_arz_par.release(); s->d_bire_knots.release();
     s->d_bire_coeffs.release(); s->d_shower_profile.release(); s->d_shower_rescale.release();
-    delete s;
+    s->ws.clear();
+    s->ws_bytes.clear();
+    s->ctx->stations.erase(s);
+    s->ctx = nullptr;
 }
 
 int64_t nrhip_station_release_workspace(nrhip_station* s)
 {
-    if (!s) return 0;
+    if (!s || !s->ctx) return 0;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     int64_t freed = 0;
@@ -297,7 +308,7 @@ int64_t nrhip_station_release_workspace(nrhip_station* s)
 int nrhip_station_set_arz(nrhip_station* s, int32_t n_profiles, int32_t n_depth, const double* profile_depth,
                           const double* profile_ce, const double* parameters, double interp_factor2, int32_t em_formula)
 {
-    if (!s || !profile_depth || !profile_ce || !parameters) return nrhip_fail_msg("nrhip_station_set_arz: NULL argument");
+    if (!s || !s->ctx || !profile_depth || !profile_ce || !parameters) return nrhip_fail_msg("nrhip_station_set_arz: NULL argument or station without a context");
     if (n_profiles < 1 || n_depth < 2 || n_depth > 2048) return nrhip_fail_msg("nrhip_station_set_arz: profiles need 2..2048 depth bins");
     HIPCHK(hipSetDevice(s->ctx->device));
     if (upload(s->ctx, s->d_arz_depth, profile_depth, (size_t)n_depth) ||
@@ -313,7 +324,7 @@ int nrhip_station_set_arz(nrhip_station* s, int32_t n_profiles, int32_t n_depth,
 
 int nrhip_station_set_shower_profiles(nrhip_station* s, int64_t n_showers, const int32_t* profile_index, const double* rescale)
 {
-    if (!s) return nrhip_fail_msg("nrhip_station_set_shower_profiles: NULL argument");
+    if (!s || !s->ctx) return nrhip_fail_msg("nrhip_station_set_shower_profiles: NULL argument or station without a context");
     s->n_shower_profiles = 0;
     if (n_showers <= 0 || !profile_index || !rescale) return 0;
     for (int64_t i = 0; i < n_showers; i++)
@@ -331,7 +342,7 @@ int nrhip_station_set_shower_profiles(nrhip_station* s, int64_t n_showers, const
 int nrhip_station_set_birefringence(nrhip_station* s, const int32_t* n_knots, const double* knots, const double* coeffs,
                                     double n_ref, double angle_to_iceflow)
 {
-    if (!s) return nrhip_fail_msg("nrhip_station_set_birefringence: NULL argument");
+    if (!s || !s->ctx) return nrhip_fail_msg("nrhip_station_set_birefringence: NULL argument or station without a context");
     s->bire_n_knots[0] = s->bire_n_knots[1] = s->bire_n_knots[2] = 0;
     if (!n_knots) return 0;
     if (!knots || !coeffs) return nrhip_fail_msg("nrhip_station_set_birefringence: NULL argument");
@@ -383,6 +394,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                                 uint8_t* triggered, nrhip_sim_stats* stats)
 {
     if (!ctx || !st || !cfg) return nrhip_fail_msg("nrhip_simulate_events: NULL argument");
+    if (!st->ctx) return nrhip_fail_msg("nrhip_simulate_events: the station's context has been destroyed");
     if (st->ctx != ctx) return nrhip_fail_msg("nrhip_simulate_events: station belongs to another context");
     if (n_showers < 0 || n_groups < 0 || n_groups > n_showers) return nrhip_fail_msg("nrhip_simulate_events: bad sizes");
     if (!group_begin && n_groups != n_showers)
@@ -852,6 +864,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
 int64_t nrhip_sim_fetch(nrhip_station* st, const char* name, void* host_dst, uint64_t bytes)
 {
     if (!st || !name) return nrhip_fail_msg("nrhip_sim_fetch: NULL argument");
+    if (!st->ctx) return nrhip_fail_msg("nrhip_sim_fetch: the station's context has been destroyed");
     auto it = st->ws_bytes.find(name);
     if (it == st->ws_bytes.end()) return nrhip_fail_msg("nrhip_sim_fetch: no such table in the last simulated batch");
     size_t avail = it->second;

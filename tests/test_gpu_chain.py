@@ -249,6 +249,25 @@ def test_pruning_rigorous_on_survey_sample(gpu_ctx_factory):
     assert np.array_equal(B['item_maxV'][~sk & ~nan], A['item_maxV'][~sk & ~nan])
 
 
+def test_context_destroyed_before_station():
+    """destroy order does not matter at the C ABI: a context takes what its stations hold on the GPU with it, the station
+    handle stays valid for nrhip_station_destroy (Python finalises objects of a reference cycle in arbitrary order)"""
+    import ctypes
+    import bench
+    ctx = nuradiomc_amd.Context(bench.ICE, 'SP1', device=0)
+    st = nuradiomc_amd.Station(ctx, bench.CHANNELS, n_samples=256, sampling_rate=2.0)
+    v, z, a = bench.make_events(50, 3)
+    st.simulate_events(v, z, a, np.full(50, 1e18), 'HAD')
+    lib = st._lib
+    h_ctx, h_st = ctx._h, st._h
+    lib.nrhip_ctx_destroy(h_ctx)          # behind Python's back: the context goes first
+    ctx._h = None
+    with pytest.raises(Exception):
+        st.fetch('ev_L')
+    lib.nrhip_station_destroy(h_st)       # must neither crash nor touch the dead context
+    st._h = None
+
+
 def test_release_workspace(gpu_ctx_factory):
     """the per-call tables can be handed back (arrays simulated station by station) and come back with the next call"""
     g, ctx, st, trig, stats, kL = _run_fixture(gpu_ctx_factory, 'N256', 100)
