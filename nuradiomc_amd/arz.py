@@ -170,6 +170,8 @@ class ARZ:
         must share one depth grid (the reference's libraries do).  Returns [n, 3, N]."""
         shower_energy, theta, R = (np.atleast_1d(L.f64(v)) for v in (shower_energy, theta, R))
         n = len(shower_energy)
+        if n == 0:
+            return np.zeros((0, 3, N))
         types = [shower_type] * n if isinstance(shower_type, str) else [str(t).upper() for t in shower_type]
         rows, row_of, index, resc, depth = [], {}, np.zeros(n, np.int32), np.zeros(n), None
         for i in range(n):

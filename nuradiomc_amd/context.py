@@ -206,7 +206,10 @@ class Context:
         C0 = L.f64(C0).reshape(-1)
         D = L.f64(path_length).reshape(-1)
         n = len(C0)
-        spec = np.ascontiguousarray(spectra, dtype=np.complex128).reshape(n, 2, -1).copy()
+        spec = np.ascontiguousarray(spectra, dtype=np.complex128)
+        spec = spec.reshape(n, 2, spec.shape[-1]).copy()
+        if n == 0:
+            return (spec, np.zeros((0, 5))) if return_steps else spec
         n_f = spec.shape[2]
         knots = np.ascontiguousarray(np.concatenate([np.asarray(t[0], float) for t in tck]))
         coeffs = np.ascontiguousarray(np.concatenate([np.asarray(t[1], float) for t in tck]))

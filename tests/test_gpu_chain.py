@@ -718,3 +718,52 @@ def test_general_path_arz_birefringence(gpu_ctx_factory, mode):
                 assert np.max(np.abs(tr - o['V'][ch])) <= tol * scale, (ev, ch)
     assert n_rays > 100 and n_cand >= 8 and n_trig >= 2
     assert stats['n_candidate_events'] == n_cand
+
+
+def test_general_path_errors_and_empty_inputs(gpu_ctx_factory):
+    """error behaviour and degenerate sizes of the entry points added for reflections, ARZ and birefringence"""
+    import bench
+    from nuradiomc_amd import arz as arz_mod
+    from test_oracle_golden import _arz_library
+    ctx = gpu_ctx_factory(bench.ICE, 'SP1')
+    st = nuradiomc_amd.Station(ctx, bench.CHANNELS, n_samples=256, sampling_rate=2.0)
+    v, z, a = bench.make_events(40, 3)
+    en = np.full(40, 1e18)
+    with pytest.raises(ValueError, match='shower library'):
+        st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020', arz_iN=np.zeros(40, int))
+    lib = _arz_library(golden('ref_arz.npz'))
+    arz = arz_mod.ARZ(seed=1, library=lib)
+    st.set_arz(arz)
+    with pytest.raises(ValueError, match='profile number'):
+        st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020')
+    with pytest.raises(KeyError):   # HAD 1e18 has three profiles in this library
+        st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020', arz_iN=np.full(40, 7))
+    for kw in (dict(trigger='high_low'), dict(n_coincidences=2), dict(amp_per_ray=True), dict(focusing=True)):
+        with pytest.raises(Exception, match='ARZ'):
+            st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020', arz_iN=np.zeros(40, int), **kw)
+    # far away, off cone: no ray survives -> nothing to do, no trigger
+    far = np.tile([30000., 0., -500.], (3, 1))
+    trig, stats = st.simulate_events(far, np.full(3, 0.3), np.zeros(3), np.full(3, 1e18), 'EM', askaryan_model='ARZ2020',
+                                     arz_iN=np.zeros(3, int))
+    assert not trig.any() and stats['n_candidate_events'] == 0
+    trig, stats = st.simulate_events(np.zeros((0, 3)), [], [], [], 'HAD')
+    assert len(trig) == 0
+    # the birefringence switch
+    b = golden('ref_birefringence.npz')
+    tck = [(b['tck_southpole_A_%d_t' % j], b['tck_southpole_A_%d_c' % j]) for j in range(3)]
+    t0, _ = st.simulate_events(v, z, a, en, 'HAD')
+    st.set_birefringence(tck)
+    t1, s1 = st.simulate_events(v, z, a, en, 'HAD')
+    assert len(st.fetch('ray_spectra')) > 0
+    st.set_birefringence(None)
+    t2, _ = st.simulate_events(v, z, a, en, 'HAD')
+    assert np.array_equal(t0, t2)
+    with pytest.raises(Exception):
+        st.fetch('ray_spectra')
+    with pytest.raises(Exception, match='8 knots'):
+        st.set_birefringence([(np.arange(5.), np.arange(5.))] * 3)
+    # batch entry points with nothing in them
+    assert ctx.find_solutions_reflections_batch(np.zeros((0, 3)), np.zeros((0, 3)), 1, -500.)['C0'].shape == (0, 6)
+    assert ctx.attenuation_reflections_batch(np.zeros((0, 3)), np.zeros((0, 3)), [], [], [], -500., [0.1, 0.2]).shape == (0, 2)
+    assert ctx.birefringence_batch(np.zeros((0, 3)), np.zeros((0, 3)), [], [], np.zeros((0, 2, 129), complex), 2.0, tck).shape == (0, 2, 129)
+    assert arz.get_time_trace_batch([], [], 256, 0.5, [], 1.78, [], []).shape == (0, 3, 256)
