@@ -323,6 +323,11 @@ void nrhip_station_destroy(nrhip_station* st);
  * simulated station by station) release them when a station is done: returns the number of bytes given back. */
 int64_t nrhip_station_release_workspace(nrhip_station* st);
 
+/* Arrays of identical stations (BASELINE configs 3-5): move the station object to the next station's antenna positions
+ * ([n_channels][3], HOST) and call nrhip_simulate_events again -- antenna types, orientations, cable delays, filters, tables
+ * and the workspace are shared by all stations of the array, only the positions differ. */
+int nrhip_station_set_positions(nrhip_station* st, const double* position);
+
 /* ---- general emission / propagation inside nrhip_simulate_events (BASELINE config 4) -----------------------------------
  * With askaryan_model NRHIP_ASK_ARZ2019 / ARZ2020 and / or a birefringence model set, nrhip_simulate_events materialises
  * the on-sky spectra of every ray that passes the delta_C cut (calculate_sim_efield, simulation.py:221-290: emission,

@@ -291,6 +291,19 @@ void nrhip_station_detach(nrhip_station* s)
     s->ctx = nullptr;
 }
 
+int nrhip_station_set_positions(nrhip_station* s, const double* position)
+{
+    if (!s || !s->ctx || !position) return nrhip_fail_msg("nrhip_station_set_positions: NULL argument or station without a context");
+    const int n = s->dev.n_ch;
+    HIPCHK(hipSetDevice(s->ctx->device));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));  // no call of this station may still read the old positions
+    s->h_pos.assign(position, position + 3 * n);
+    HIPCHK(hipMemcpyAsync(s->d_pos.p, s->h_pos.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, s->ctx->stream));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    s->ws_bytes.clear();  // the tables of the last call belong to the old positions
+    return 0;
+}
+
 int64_t nrhip_station_release_workspace(nrhip_station* s)
 {
     if (!s || !s->ctx) return 0;

@@ -98,6 +98,7 @@ L._OPTIONAL.update({
     'nrhip_station_create': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(StationDesc), L.c_void_pp]),
     'nrhip_station_destroy': (None, [ctypes.c_void_p]),
     'nrhip_station_release_workspace': (ctypes.c_int64, [ctypes.c_void_p]),
+    'nrhip_station_set_positions': (ctypes.c_int, [ctypes.c_void_p, L.c_double_p]),
     'nrhip_station_set_arz': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p, L.c_double_p,
                                             L.c_double_p, ctypes.c_double, ctypes.c_int32]),
     'nrhip_station_set_shower_profiles': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, L.c_int32_p, L.c_double_p]),
@@ -312,6 +313,15 @@ class Station:
         nk = np.array([len(t[0]) for t in tck], np.int32)
         L.check(self._lib.nrhip_station_set_birefringence(self._h, L.iptr(nk), L.dptr(knots), L.dptr(coeffs), float(n_ref),
                                                           float('nan') if angle_to_iceflow is None else float(angle_to_iceflow)))
+
+    def move_to(self, position):
+        """Use this object for another station of an array of identical stations: new antenna positions [n_ch, 3], everything
+        else (antennas, orientations, cable delays, filters, device tables, workspace) stays."""
+        pos = L.f64(position).reshape(-1, 3)
+        if pos.shape != self.position.shape:
+            raise ValueError("move_to: %d channels expected" % len(self.position))
+        L.check(self._lib.nrhip_station_set_positions(self._h, L.dptr(pos)))
+        self.position = pos
 
     def release_workspace(self):
         """Give the tables of the last call back to the GPU (they stay resident for `fetch` and for reuse by the next call);

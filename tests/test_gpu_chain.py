@@ -268,6 +268,31 @@ def test_context_destroyed_before_station():
     st._h = None
 
 
+def test_station_move_to(gpu_ctx_factory):
+    """one Station object moved through an array of identical stations gives what separate objects give"""
+    import bench
+    ctx = gpu_ctx_factory(bench.ICE, 'SP1')
+    v, z, a = bench.make_events(3000, 5)
+    en = np.full(3000, 1e18)
+    centres = np.array([[0., 0., 0.], [800., -300., 0.], [-1500., 900., 0.]])
+    moved = nuradiomc_amd.Station(ctx, bench.CHANNELS, n_samples=512, sampling_rate=2.0)
+    n_trig = 0
+    for c in centres:
+        fresh = nuradiomc_amd.Station(ctx, bench.CHANNELS + c, n_samples=512, sampling_rate=2.0)
+        t_ref, s_ref = fresh.simulate_events(v, z, a, en, 'HAD')
+        moved.move_to(bench.CHANNELS + c)
+        with pytest.raises(Exception):
+            moved.fetch('ev_L')       # the tables of the last call belonged to the old positions
+        t, s_ = moved.simulate_events(v, z, a, en, 'HAD')
+        assert np.array_equal(t, t_ref) and s_['n_rays'] == s_ref['n_rays'] and s_['n_candidate_events'] == s_ref['n_candidate_events']
+        assert np.array_equal(moved.fetch('ev_L'), fresh.fetch('ev_L'))
+        n_trig += t.sum()
+        fresh.close()
+    assert n_trig > 30
+    with pytest.raises(ValueError):
+        moved.move_to(np.zeros((3, 3)))
+
+
 def test_release_workspace(gpu_ctx_factory):
     """the per-call tables can be handed back (arrays simulated station by station) and come back with the next call"""
     g, ctx, st, trig, stats, kL = _run_fixture(gpu_ctx_factory, 'N256', 100)
