@@ -21,5 +21,9 @@ struct BireBatch {
 };
 
 void launch_birefringence(hipStream_t s, const BireBatch& b, int max_points, double* steps, double2* spec);
+// the two halves separately: log_norm[ray] (nullable) = log of an upper bound on the 2-norm gain of the ray's whole path;
+// active (nullable): rays with active[ray] == 0 are left untouched
+void launch_birefringence_steps(hipStream_t s, const BireBatch& b, int max_points, double* steps, double* log_norm);
+void launch_birefringence_propagate(hipStream_t s, const BireBatch& b, const double* steps, double2* spec, const int* active);
 
 }  // namespace nrhip

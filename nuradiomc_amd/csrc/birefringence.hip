@@ -97,7 +97,7 @@ __device__ inline void bire_path_point(int j, int acc, double zstart, double zst
 }
 
 __global__ void __launch_bounds__(256)
-bire_steps_kernel(BireBatch b, double* __restrict__ steps /* [total_steps][5] */)
+bire_steps_kernel(BireBatch b, double* __restrict__ steps /* [total_steps][5] */, double* __restrict__ log_norm)
 {
     const int ray = blockIdx.x;
     const int acc = b.n_points[ray];
@@ -124,7 +124,12 @@ bire_steps_kernel(BireBatch b, double* __restrict__ steps /* [total_steps][5] */
     double sa = 0., ca = 1.;
     if (!isnan(b.angle_to_iceflow)) sincos(b.angle_to_iceflow * (M_PI / 180.), &sa, &ca);
     double* out = steps + 5 * b.step_offset[ray];
-    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < acc - 1; i += gridDim.y * blockDim.x) {
+    // every lane of a wave runs the same number of iterations (wave reductions inside)
+    const int n_iter = (acc - 1 + gridDim.y * blockDim.x - 1) / (gridDim.y * blockDim.x);
+    for (int it = 0; it < n_iter; it++) {
+        const int i = (it * gridDim.y + blockIdx.y) * blockDim.x + threadIdx.x;
+        double lg = 0.;
+        if (i < acc - 1) {
         double P0[3], P1[3];
         bire_path_point(i, acc, p.z1, zstop, s, C1, m, p.y1, p.z1, A[0], A[1], cph, sph, ca, sa, P0);
         bire_path_point(i + 1, acc, p.z1, zstop, s, C1, m, p.y1, p.z1, A[0], A[1], cph, sph, ca, sa, P1);
@@ -176,6 +181,15 @@ bire_steps_kernel(BireBatch b, double* __restrict__ steps /* [total_steps][5] */
         out[5 * (long)i + 2] = c;
         out[5 * (long)i + 3] = d;
         out[5 * (long)i + 4] = delay;
+        if (!isnan(delay)) {  // ||R^T diag(1, phase) R||_2 <= sigma_max(R)^2 = largest eigenvalue of R^T R
+            const double T = a * a + bb * bb + c * c + d * d;
+            lg = log(0.5 * (T + sqrt(fmax(T * T - 4. * det * det, 0.))));
+        }
+        }
+        if (log_norm) {  // log of the product over the steps: an upper bound on the gain of the whole path
+            for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
+            if ((threadIdx.x & 63) == 0 && lg != 0.) atomicAdd(&log_norm[ray], lg);
+        }
     }
 }
 
@@ -209,10 +223,11 @@ __device__ inline void bire_sincos(double x, double* sn, double* cs)
 
 // spectra [n_rays][2][n_f] complex, in place
 __global__ void __launch_bounds__(256)
-bire_propagate_kernel(BireBatch b, const double* __restrict__ steps, double2* __restrict__ spec)
+bire_propagate_kernel(BireBatch b, const double* __restrict__ steps, double2* __restrict__ spec, const int* __restrict__ ray_active)
 {
     __shared__ double s_step[BIRE_TILE][5];
     const int ray = blockIdx.x;
+    if (ray_active && !ray_active[ray]) return;  // the ray's event cannot pass the candidate cut (general_bound_kernel)
     const int n_steps = b.n_points[ray] - 1;
     const int k = blockIdx.y * blockDim.x + threadIdx.x;
     const int n_f = b.n_f;
@@ -254,14 +269,25 @@ bire_propagate_kernel(BireBatch b, const double* __restrict__ steps, double2* __
     if (active) { st[k] = et; st[n_f + k] = ep; }
 }
 
-void launch_birefringence(hipStream_t s, const BireBatch& b, int max_points, double* steps, double2* spec)
+void launch_birefringence_steps(hipStream_t s, const BireBatch& b, int max_points, double* steps, double* log_norm)
 {
     if (b.n_rays <= 0 || max_points < 2) return;
     int gy = (max_points - 1 + 255) / 256;
     if (gy > 64) gy = 64;
-    hipLaunchKernelGGL(bire_steps_kernel, dim3((unsigned)b.n_rays, (unsigned)gy), dim3(256), 0, s, b, steps);
+    if (log_norm) (void)hipMemsetAsync(log_norm, 0, sizeof(double) * (size_t)b.n_rays, s);
+    hipLaunchKernelGGL(bire_steps_kernel, dim3((unsigned)b.n_rays, (unsigned)gy), dim3(256), 0, s, b, steps, log_norm);
+}
+void launch_birefringence_propagate(hipStream_t s, const BireBatch& b, const double* steps, double2* spec, const int* active)
+{
+    if (b.n_rays <= 0) return;
     hipLaunchKernelGGL(bire_propagate_kernel, dim3((unsigned)b.n_rays, (unsigned)((b.n_f + 255) / 256)), dim3(256), 0, s, b, steps,
-                       spec);
+                       spec, active);
+}
+void launch_birefringence(hipStream_t s, const BireBatch& b, int max_points, double* steps, double2* spec)
+{
+    if (b.n_rays <= 0 || max_points < 2) return;
+    launch_birefringence_steps(s, b, max_points, steps, nullptr);
+    launch_birefringence_propagate(s, b, steps, spec, nullptr);
 }
 
 }  // namespace nrhip

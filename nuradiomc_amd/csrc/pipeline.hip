@@ -683,11 +683,23 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             BireBatch bb{(long)n_rays, g_x1, g_x2, w.C0, g_npoints, d_off, ctx->ice, st->d_bire_knots.as<double>(),
                          st->d_bire_coeffs.as<double>(), {st->bire_n_knots[0], st->bire_n_knots[1], st->bire_n_knots[2]},
                          st->bire_n_ref, st->bire_angle, n_f, sd.fs};
-            launch_birefringence(sm, bb, max_points, steps, spec);
+            // the gain of the whole path is bounded by the product of the steps' ||R||^2: events none of whose rays can exceed
+            // the candidate cut even so skip the propagation (result-neutral, like the bounds of the parametrised path)
+            double* log_gain;
+            int* gactive;
+            NEED(log_gain = WS("bire_log_gain", double, nr));
+            NEED(gactive = WS("ray_propagated", int, nr));
+            launch_birefringence_steps(sm, bb, max_points, steps, log_gain);
+            launch_general_bound(sm, n_rays, sd, spec, log_gain, bound);
+            launch_event_possible(sm, (int)n_groups, n_ch, grp_ray, bound,
+                                  (cfg->no_pruning || cfg->dump_traces) ? -1.0 : cfg->min_efield_amplitude, gactive);
+            launch_birefringence_propagate(sm, bb, steps, spec, gactive);
             LCHK("birefringence");
             HIPCHK(hipStreamSynchronize(sm));  // `off` goes out of scope
+            launch_general_trace(sm, n_rays, sd, spec, ctx->twiddle, traces, max_efield, gactive, bound);
+        } else {
+            launch_general_trace(sm, n_rays, sd, spec, ctx->twiddle, traces, max_efield);
         }
-        launch_general_trace(sm, n_rays, sd, spec, ctx->twiddle, traces, max_efield);
         LCHK("general trace");
         ray_traces = traces;
     }

@@ -2424,7 +2424,8 @@ general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, con
 // simulation.py:283-285 looks at all components of the trace).  One block (256) per ray.
 __global__ void __launch_bounds__(256)
 general_trace_kernel(int n_rays, StationDev st, const double2* __restrict__ spec, const double2* __restrict__ tw, int log2nh,
-                     double* __restrict__ traces, double* __restrict__ max_efield)
+                     double* __restrict__ traces, double* __restrict__ max_efield, const int* __restrict__ active,
+                     const double* __restrict__ bound)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2, n_f = nh + 1;
@@ -2432,6 +2433,10 @@ general_trace_kernel(int n_rays, StationDev st, const double2* __restrict__ spec
     __shared__ double red[256];
     const double scale = st.fs / 1.4142135623730951 / nh;
     for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
+        if (active && !active[r]) {  // not evaluated: "at most `bound`" (its event cannot become a candidate)
+            if (threadIdx.x == 0) max_efield[r] = -bound[r];
+            continue;
+        }
         double mx = 0.;
         for (int comp = 0; comp < 2; comp++) {
             const double2* E = spec + ((long)r * 2 + comp) * n_f;
@@ -2457,6 +2462,31 @@ general_trace_kernel(int n_rays, StationDev st, const double2* __restrict__ spec
         }
         mx = block_max(mx, red);
         if (threadIdx.x == 0) max_efield[r] = mx;
+    }
+}
+
+// kernel: upper bound on max |e(t)| of a ray AFTER a linear propagation step whose 2-norm gain is at most exp(log_gain):
+// |e(t)| <= (fs / sqrt 2) (1 / N) (|E_0| + |E_N/2| + 2 sum_k |E_k|) per component, |E'_k| <= gain ||(E_theta,k, E_phi,k)||_2.
+// Lets the birefringent propagation (the expensive part of the general path) skip the events that cannot become candidates.
+__global__ void __launch_bounds__(256)
+general_bound_kernel(int n_rays, StationDev st, const double2* __restrict__ spec, const double* __restrict__ log_gain,
+                     double* __restrict__ bound)
+{
+    __shared__ double red[256];
+    const int N = st.N, nh = N / 2, n_f = nh + 1;
+    for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
+        const double2* Et = spec + (long)r * 2 * n_f;
+        const double2* Ep = Et + n_f;
+        double part = 0.;
+        for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
+            const double2 a = Et[k], b = Ep[k];
+            const double m = sqrt(a.x * a.x + a.y * a.y + b.x * b.x + b.y * b.y);
+            part += (k == 0 || k == nh) ? m : 2. * m;
+        }
+        const double sum = block_sum(part, red);
+        if (threadIdx.x == 0)
+            bound[r] = (st.fs / 1.4142135623730951 / N) * sum * exp(log_gain ? log_gain[r] : 0.) * (1. + 1e-9);
+        __syncthreads();
     }
 }
 
@@ -2513,13 +2543,20 @@ void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const 
                        ask_model, arz_trace, tw, ilog2(nh), spec);
 }
 void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double2* tw,
-                          double* traces, double* max_efield)
+                          double* traces, double* max_efield, const int* active, const double* bound)
 {
     if (n_rays <= 0) return;
     const int nh = st.N / 2;
     int grid = n_rays < 256 * 64 ? n_rays : 256 * 64;
     hipLaunchKernelGGL(general_trace_kernel, dim3(grid), dim3(256), (size_t)nh * 16, s, n_rays, st, spec, tw, ilog2(nh), traces,
-                       max_efield);
+                       max_efield, active, bound);
+}
+void launch_general_bound(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double* log_gain,
+                          double* bound)
+{
+    if (n_rays <= 0) return;
+    int grid = n_rays < 256 * 64 ? n_rays : 256 * 64;
+    hipLaunchKernelGGL(general_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, st, spec, log_gain, bound);
 }
 void launch_general_gather(hipStream_t s, int n_rays, int n_ch, const RayWork& w, const EventIn& evin, const StationDev& st,
                            const double* vertex, const int* shower_profile, const double* shower_rescale, int em_formula,

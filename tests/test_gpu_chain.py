@@ -743,6 +743,31 @@ def test_general_path_arz_birefringence(gpu_ctx_factory, mode):
                 assert np.max(np.abs(tr - o['V'][ch])) <= tol * scale, (ev, ch)
     assert n_rays > 100 and n_cand >= 8 and n_trig >= 2
     assert stats['n_candidate_events'] == n_cand
+    # production mode (no trace dump) on a larger, weaker sample: with birefringence, events whose rays cannot reach the candidate
+    # cut even with the largest possible gain of their paths skip the propagation; decisions are unchanged, the bounds bound
+    m = 500
+    r, ph = np.sqrt(rng.uniform(0, 3000. ** 2, m)), rng.uniform(0, 2 * np.pi, m)
+    v2 = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-2500., -120., m)], axis=1)
+    zen2, az2 = np.arccos(rng.uniform(-1, 1, m)), rng.uniform(0, 2 * np.pi, m)
+    en2 = 10 ** rng.uniform(15.5, 18., m)
+    ty2 = np.array(['HAD', 'EM'])[rng.integers(0, 2, m)]
+    kw2 = dict(arz_iN=a.draw_profile_numbers(en2, list(ty2))) if 'arz' in mode else {}
+    trig_x, stats_x = st.simulate_events(v2, zen2, az2, en2, ty2, 10 ** 1.5, askaryan_model=model, no_pruning=True, **kw2)
+    X = {k: st.fetch(k) for k in ('ray_max_efield', 'ev_candidate', 'ev_n_rays')}
+    trig_p, stats_p = st.simulate_events(v2, zen2, az2, en2, ty2, 10 ** 1.5, askaryan_model=model, **kw2)
+    assert np.array_equal(trig_p, trig_x) and stats_p['n_candidate_events'] == stats_x['n_candidate_events'] > 5
+    assert np.array_equal(st.fetch('ev_candidate'), X['ev_candidate'])
+    mp = st.fetch('ray_max_efield')
+    ev_of = np.repeat(np.arange(m), X['ev_n_rays'])
+    if bire:
+        skipped = mp < 0
+        assert skipped.sum() > 50 and not np.any(X['ev_candidate'].astype(bool)[ev_of[skipped]])
+        assert np.all(-mp[skipped] * (1 + 1e-9) >= X['ray_max_efield'][skipped]) and np.all(-mp[skipped] <= 2.0 * st.vrms_efield)
+        assert np.array_equal(mp[~skipped], X['ray_max_efield'][~skipped])
+        assert np.all(st.fetch('ray_bound') * (1 + 1e-9) >= X['ray_max_efield'])
+        print(mode, 'rays propagated: %d of %d' % ((~skipped).sum(), len(mp)))
+    else:
+        assert np.array_equal(mp, X['ray_max_efield'])
 
 
 def test_general_path_errors_and_empty_inputs(gpu_ctx_factory):
