@@ -305,6 +305,7 @@ class Station:
         """Birefringent propagation inside simulate_events: tck = the three depth splines (knots, coefficients[, 3]) of a
         birefringence ice model (propagation.birefringence_model(name)); None switches it off.  angle_to_iceflow [deg] as
         config['propagation']['angle_to_iceflow'] (0 = none)."""
+        self._birefringence_on = tck is not None
         if tck is None:
             L.check(self._lib.nrhip_station_set_birefringence(self._h, None, None, None, 1.78, 0.))
             return
@@ -368,14 +369,25 @@ class Station:
         return stats.as_dict() if want_stats else None
 
     def simulate_events(self, vertex, zenith, azimuth, energy, shower_type, k_L=None, vertex_time=None, group_id=None,
-                        distance_cut_coefficients=None, distance_cut_sum_length=10., arz_iN=None, **kw):
+                        distance_cut_coefficients=None, distance_cut_sum_length=10., arz_iN=None, max_showers_per_call=None,
+                        **kw):
         """Host-array convenience form: uploads the shower list, runs the hot path, returns (triggered mask, stats).
+        Long lists are cut into calls of at most `max_showers_per_call` showers at event-group boundaries (default: what
+        keeps the per-call tables near 40 GB: ~1.2e7 (shower, channel) pairs, 2.5e5 with ARZ / birefringence, whose rays carry
+        spectra and traces); the mask is concatenated, the counters of `stats` are summed (the fetchable tables are those of
+        the last call).
         `group_id` [n] (equal ids consecutive, like the event_group_ids of the reference's input files) makes showers of
         one id a single event group: their signals add up in the channels (simulation.py:143) and the mask has one entry
         per group, in order of first appearance.  `vertex_time` [n] shifts a shower's signals (simulation.py:259-268)."""
         ctx = self.ctx
         vertex = L.f64(vertex).reshape(-1, 3)
         n = len(vertex)
+        if max_showers_per_call is None:
+            general = kw.get('askaryan_model') in ('ARZ2019', 'ARZ2020') or getattr(self, '_birefringence_on', False)
+            max_showers_per_call = max(1, int((2.5e5 if general else 1.2e7) / len(self.position)))
+        if n > max_showers_per_call:
+            return self._simulate_in_chunks(int(max_showers_per_call), vertex, zenith, azimuth, energy, shower_type, k_L,
+                                            vertex_time, group_id, distance_cut_coefficients, distance_cut_sum_length, arz_iN, kw)
         n_groups, gb, vt = n, None, None
         if group_id is not None and n:
             gid = np.asarray(group_id).reshape(-1)
@@ -418,6 +430,42 @@ class Station:
             for p in dptrs + [dtrig] + [e for e in extra if e is not None]:
                 ctx.free(p)
         return trig.astype(bool), stats
+
+    def _simulate_in_chunks(self, max_showers, vertex, zenith, azimuth, energy, shower_type, k_L, vertex_time, group_id,
+                            dcc, dcs, arz_iN, kw):
+        n = len(vertex)
+        per = lambda a: None if a is None else np.broadcast_to(np.asarray(a), (n,))
+        zenith, azimuth, energy, k_L, vertex_time, arz_iN = (per(a) for a in (zenith, azimuth, energy, k_L, vertex_time, arz_iN))
+        types = _shower_type_codes(shower_type, n)
+        gid = None if group_id is None else np.asarray(group_id).reshape(-1)
+        starts = np.arange(n) if gid is None else np.flatnonzero(np.concatenate([[True], gid[1:] != gid[:-1]]))
+        cuts, a = [0], 0
+        while a < n:   # the last group boundary at most max_showers further on (a group longer than that goes alone)
+            k = np.searchsorted(starts, a + max_showers, side='right') - 1
+            b = int(starts[k]) if k < len(starts) and starts[k] > a else (int(starts[k + 1]) if k + 1 < len(starts) else n)
+            if a + max_showers >= n:
+                b = n
+            cuts.append(b)
+            a = b
+        trig, total = [], None
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            sl = slice(a, b)
+            t, s_ = self.simulate_events(vertex[sl], zenith[sl], azimuth[sl], energy[sl], types[sl],
+                                         None if k_L is None else k_L[sl], None if vertex_time is None else vertex_time[sl],
+                                         None if gid is None else gid[sl], dcc, dcs, None if arz_iN is None else arz_iN[sl],
+                                         max_showers_per_call=max(b - a, 1), **kw)
+            trig.append(t)
+            if total is None:
+                total = s_
+            elif s_ is not None:
+                for k_, v_ in s_.items():
+                    if k_ == 'stage_ms':
+                        total[k_] = {q: total[k_][q] + v_[q] for q in v_}
+                    elif k_ in ('max_length', 'n_distinct_lengths'):
+                        total[k_] = max(total[k_], v_)
+                    else:
+                        total[k_] += v_
+        return np.concatenate(trig), total
 
     def common_time_grid(self, t0, channel):
         """t_min and L of efieldToVoltageConverter.run (efieldToVoltageConverter.py:120-169)"""

@@ -293,6 +293,27 @@ def test_station_move_to(gpu_ctx_factory):
         moved.move_to(np.zeros((3, 3)))
 
 
+def test_long_lists_are_cut_into_calls(gpu_ctx_factory):
+    """simulate_events cuts long shower lists into several calls at event-group boundaries: same mask, summed counters"""
+    import bench
+    ctx = gpu_ctx_factory(bench.ICE, 'SP1')
+    st = nuradiomc_amd.Station(ctx, bench.CHANNELS, n_samples=512, sampling_rate=2.0)
+    n = 4000
+    v, z, a = bench.make_events(n, 8)
+    en = np.full(n, 1e18)
+    gid = np.repeat(np.arange(n // 4 + 400), np.random.default_rng(2).integers(1, 6, n // 4 + 400))[:n]
+    vt = np.random.default_rng(3).uniform(0, 50, n)
+    first = np.flatnonzero(np.concatenate([[True], gid[1:] != gid[:-1]]))
+    v = v[first][np.searchsorted(first, np.arange(n), side='right') - 1] + np.random.default_rng(4).uniform(-3, 3, (n, 3))
+    ref, s_ref = st.simulate_events(v, z, a, en, 'HAD', vertex_time=vt, group_id=gid)
+    cut, s_cut = st.simulate_events(v, z, a, en, 'HAD', vertex_time=vt, group_id=gid, max_showers_per_call=333)
+    assert np.array_equal(ref, cut) and ref.sum() > 20 and len(ref) == len(np.unique(gid))
+    for k in ('n_events', 'n_pairs', 'n_rays', 'n_candidate_events', 'n_triggered'):
+        assert s_ref[k] == s_cut[k], k
+    one, _ = st.simulate_events(v, z, a, en, 'HAD', max_showers_per_call=1000)
+    assert np.array_equal(one, st.simulate_events(v, z, a, en, 'HAD')[0])
+
+
 def test_release_workspace(gpu_ctx_factory):
     """the per-call tables can be handed back (arrays simulated station by station) and come back with the next call"""
     g, ctx, st, trig, stats, kL = _run_fixture(gpu_ctx_factory, 'N256', 100)
