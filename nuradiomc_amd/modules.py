@@ -111,3 +111,48 @@ class efieldToVoltageConverter:
         dt = timedelta(seconds=self.__t)
         logger.info("total time used by this module is {}".format(dt))
         return dt
+
+
+class efieldToVoltageConverterPerEfield(efieldToVoltageConverter):
+    """Drop-in for NuRadioReco.modules.efieldToVoltageConverterPerEfield (efieldToVoltageConverterPerEfield.py:28-101): one
+    SimChannel per electric field of the sim station, V(f) = VEL_theta E_theta + VEL_phi E_phi on the efield's own grid,
+    nothing below 5 MHz, trace start time = the efield's (no cable delay); the convolution runs on the GPU
+    (nrhip_efield_to_voltage on the N-sample grid of the efield).  `sim_channel_factory(channel_id, efield)` builds the
+    object to fill (default: NuRadioReco's SimChannel with the efield's shower and ray-tracing ids)."""
+
+    def __init__(self, log_level=logging.NOTSET, ctx=None, sim_channel_factory=None, antenna_models=None):
+        super().__init__(log_level=log_level, ctx=ctx, channel_factory=None, antenna_models=antenna_models)
+        self._sim_channel_factory = sim_channel_factory
+
+    def _make_sim_channel(self, channel_id, ef):
+        if self._sim_channel_factory is not None:
+            return self._sim_channel_factory(channel_id, ef)
+        import NuRadioReco.framework.sim_channel
+        from NuRadioReco.framework.parameters import channelParameters as chp, electricFieldParameters as efp
+        sc = NuRadioReco.framework.sim_channel.SimChannel(channel_id, shower_id=ef.get_shower_id(),
+                                                          ray_tracing_id=ef.get_ray_tracing_solution_id())
+        sc[chp.signal_ray_type] = ef[efp.ray_path_type]
+        return sc
+
+    def run(self, evt, station, det):
+        sim_station = station.get_sim_station() if hasattr(station, 'get_sim_station') else station
+        sid = sim_station.get_id()
+        if len(sim_station.get_electric_fields()) == 0:
+            raise LookupError(f"station {station.get_id()} has no efields")
+        channel_ids = list(det.get_channel_ids(sid))
+        for i, channel_id in enumerate(channel_ids):
+            for ef in sim_station.get_electric_fields_for_channels([channel_id]):
+                d = np.linalg.norm(np.asarray(det.get_relative_position(sid, channel_id)) - np.asarray(ef.get_position()))
+                if d / 0.001 > 0.01:
+                    raise NotImplementedError("efields away from the antenna (air-shower mode) are not provided")
+                tr = np.asarray(ef.get_trace(), float)
+                n_samples, fs = tr.shape[-1], ef.get_sampling_rate()
+                st = self._station_for(det, sid, channel_ids, n_samples, fs)
+                t0 = ef.get_trace_start_time()
+                # the efield's own grid: start bin 0, no padding, the cable delay taken out again
+                V, _ = st.efield_to_voltage(tr[None, 1:3], [t0], [_efield_param(ef, 'zenith')], [_efield_param(ef, 'azimuth')],
+                                            [i], grid=(t0 + st.cable_delay[i], n_samples))
+                sc = self._make_sim_channel(channel_id, ef)
+                sc.set_trace(V[i], fs)
+                sc.set_trace_start_time(t0)
+                sim_station.add_channel(sc)

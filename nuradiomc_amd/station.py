@@ -483,9 +483,10 @@ class Station:
             n += 1
         return times_min, n
 
-    def efield_to_voltage(self, traces, t0, zenith, azimuth, channel, apply_filters=False):
+    def efield_to_voltage(self, traces, t0, zenith, azimuth, channel, apply_filters=False, grid=None):
         """Channel voltages of ONE station event from arbitrary efield traces [n, 2 (eTheta, ePhi), n_samples];
-        returns (V [n_channels, L], t_min)."""
+        returns (V [n_channels, L], t_min).  grid = (t_min, L): that time grid instead of the common one of
+        efieldToVoltageConverter (used by the per-efield converter: the efield's own N-sample grid)."""
         traces = L.f64(traces)
         n = traces.shape[0]
         if n == 0:
@@ -494,7 +495,7 @@ class Station:
             raise ValueError("traces must be [n, 2, %d]" % self.n_samples)
         t0, zenith, azimuth = (np.ascontiguousarray(np.broadcast_to(L.f64(a), (n,))) for a in (t0, zenith, azimuth))
         ch = np.ascontiguousarray(np.broadcast_to(channel, (n,)), dtype=np.int32)
-        t_min, Lc = self.common_time_grid(t0, ch)
+        t_min, Lc = self.common_time_grid(t0, ch) if grid is None else (float(grid[0]), int(grid[1]))
         V = np.zeros((len(self.position), Lc))
         L.check(self._lib.nrhip_efield_to_voltage(self.ctx._h, self._h, n, L.dptr(traces), L.dptr(t0), L.dptr(zenith),
                                                   L.dptr(azimuth), L.iptr(ch), int(bool(apply_filters)), Lc, float(t_min),

@@ -218,6 +218,59 @@ def test_efieldToVoltageConverter_module(antenna, cable):
         conv.run(None, _FakeStation(_FakeSimStation({})), det)
 
 
+class _FakeSimChannel(_FakeChannel):
+    def __init__(self, cid, ef):
+        super().__init__(cid)
+        self.ef = ef
+
+
+class _FakeSimStation2(_FakeSimStation):
+    def __init__(self, efields):
+        super().__init__(efields)
+        self.sim_channels = []
+    def add_channel(self, ch): self.sim_channels.append(ch)
+
+
+@pytest.mark.parametrize('antenna,cable', [('analytic_VPol', [0.] * 5), ('analytic_LPDA', [0., 0., 4.4, 0., 1.1])])
+def test_efieldToVoltageConverterPerEfield_module(antenna, cable):
+    """The per-efield converter (one SimChannel per electric field, its own N-sample grid, no cable delay) vs the oracle's
+    restatement of efieldToVoltageConverterPerEfield.run."""
+    from nuradiomc_amd import modules
+    from oracle import spectral_oracle as so
+    N, fs = 256, 2.0
+    pos = np.array([[0., 0., -100. - i] for i in range(5)])
+    ice = (1.78, 0.423, 77.)
+    ost = so.Station(pos, antenna=antenna, cable_delay=cable, n_samples=N, fs=fs)
+    det = _FakeDet(pos, antenna, cable, N, fs)
+    conv = modules.efieldToVoltageConverterPerEfield(sim_channel_factory=_FakeSimChannel)
+    rng = np.random.default_rng(19)
+    n_done = 0
+    for ev in range(25):
+        r, ph = np.sqrt(rng.uniform(0, 1500. ** 2)), rng.uniform(0, 2 * np.pi)
+        vertex = np.array([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1500, -50)])
+        efs = so.sim_efields_for_event(vertex, np.arccos(rng.uniform(-1, 1)), rng.uniform(0, 2 * np.pi), 1e18, 'HAD', None,
+                                       ost, ice, n_freq=25)
+        if not efs:
+            continue
+        by_ch = {}
+        for ef in efs:
+            fe = _FakeEfield(pos[ef['channel']], so.freq2time(ef['spec'], fs), ef['t0'], fs, ef['zenith'], ef['azimuth'])
+            fe.ref = ef
+            by_ch.setdefault(ef['channel'], []).append(fe)
+        sim = _FakeSimStation2(by_ch)
+        conv.run(None, sim, det)
+        assert len(sim.sim_channels) == len(efs)
+        for sc in sim.sim_channels:
+            v, _ = so.per_efield_voltage(sc.ef.ref, ost, filters=())
+            ref = so.freq2time(v, fs)
+            assert sc.t0 == sc.ef.ref['t0'] and sc.cid == sc.ef.ref['channel'] and len(sc.trace) == N
+            assert np.max(np.abs(sc.trace - ref)) <= 1e-6 * max(np.max(np.abs(ref)), 1e-300)
+            n_done += 1
+    assert n_done > 40
+    with pytest.raises(LookupError):
+        conv.run(None, _FakeSimStation2({}), det)
+
+
 def test_get_focusing_and_raytracing_output(gpu_ctx_factory):
     """ray_tracing.get_focusing / get_raytracing_output / apply_propagation_effects with config focusing: the drop-in's
     values equal the oracle's (same bits in the two ray tables -> same finite difference), which is pinned against the
