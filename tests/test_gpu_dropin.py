@@ -88,6 +88,10 @@ def test_ray_tracing_class_api_and_errors():
     r.set_start_and_end_point(g['x1'][j], g['x2'][j])
     r.find_solutions()
     assert not r.has_solution() and r.get_results() == []
+    # a receiver in air: like the reference's Python path (0 solutions for any such pair), never an exception
+    r.set_start_and_end_point([300., 100., -400.], [0., 0., 12.])
+    r.find_solutions()
+    assert not r.has_solution() and r.get_number_of_solutions() == 0
 
 
 def test_apply_propagation_effects_like_reference():
