@@ -294,6 +294,7 @@ typedef struct {
 } nrhip_sim_config;
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1
+#define NRHIP_TRIG_PHASED_ARRAY 2   /* needs nrhip_station_set_phased_array; trigger_threshold is the power threshold */
 
 #define NRHIP_N_STAGES 9
 /* stage_ms: device time (HIP events on the context's stream) of 0 ray tracing, 1 ray selection + setup,
@@ -341,6 +342,15 @@ int nrhip_station_set_positions(nrhip_station* st, const double* position);
  * factor E / E_library (the host picks them as ARZ.get_time_trace does: closest library energy, random / given number).
  * nrhip_station_set_birefringence: the three depth splines as in nrhip_birefringence_batch; n_knots == NULL switches it off.
  * Limits: simple threshold trigger, no focusing with ARZ, no amp_per_ray.  HOST pointers (copied).                      */
+/* Phased-array trigger (NuRadioReco/modules/phasedarray/phasedArrayBase.py, mode 'power_sum' without digitisation and
+ * upsampling: phase_signals :183-215, power_sum :217-271, phased_trigger :455-496): per beam the traces of the n_pa trigger
+ * channels are rolled by rolls[beam][channel] samples (calculate_time_delays :58-124, the host computes them) and summed, the
+ * mean power of sliding windows (window samples, every step samples; averaging_divisor 0 = window) is compared with
+ * nrhip_sim_config.trigger_threshold (trigger_type NRHIP_TRIG_PHASED_ARRAY).  Table afterwards: "pa_max_power"
+ * [candidate event][beam] (maximum_amps).  n_pa = 0 switches it off.  HOST pointers (copied).                       */
+int nrhip_station_set_phased_array(nrhip_station* st, int32_t n_pa, const int32_t* channels, int32_t n_beams,
+                                   const int32_t* rolls, int32_t window, int32_t step, int32_t averaging_divisor);
+
 int nrhip_station_set_arz(nrhip_station* st, int32_t n_profiles, int32_t n_depth, const double* profile_depth,
                           const double* profile_ce, const double* parameters, double interp_factor2, int32_t em_formula);
 int nrhip_station_set_shower_profiles(nrhip_station* st, int64_t n_showers, const int32_t* profile_index, const double* rescale);

@@ -285,6 +285,7 @@ void nrhip_station_detach(nrhip_station* s)
     for (auto& a : s->d_tabdata) a.release();
     s->d_arz_depth.release(); s->d_arz_ce.release(); s->d_arz_par.release(); s->d_bire_knots.release();
     s->d_bire_coeffs.release(); s->d_shower_profile.release(); s->d_shower_rescale.release();
+    s->d_pa_channel.release(); s->d_pa_rolls.release();
     s->ws.clear();
     s->ws_bytes.clear();
     s->ctx->stations.erase(s);
@@ -316,6 +317,27 @@ int64_t nrhip_station_release_workspace(nrhip_station* s)
     }
     s->ws_bytes.clear();
     return freed;
+}
+
+int nrhip_station_set_phased_array(nrhip_station* s, int32_t n_pa, const int32_t* channels, int32_t n_beams, const int32_t* rolls,
+                                   int32_t window, int32_t step, int32_t averaging_divisor)
+{
+    if (!s || !s->ctx) return nrhip_fail_msg("nrhip_station_set_phased_array: NULL argument or station without a context");
+    s->pa_n_channels = 0;
+    if (n_pa <= 0) return 0;
+    if (!channels || !rolls || n_beams < 1 || window < 1 || step < 1)
+        return nrhip_fail_msg("nrhip_station_set_phased_array: channels, rolls, n_beams >= 1, window >= 1 and step >= 1 are required");
+    for (int c = 0; c < n_pa; c++)
+        if (channels[c] < 0 || channels[c] >= s->dev.n_ch) return nrhip_fail_msg("nrhip_station_set_phased_array: bad channel index");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    if (upload(s->ctx, s->d_pa_channel, channels, (size_t)n_pa) || upload(s->ctx, s->d_pa_rolls, rolls, (size_t)n_beams * n_pa)) return -1;
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    s->pa_n_channels = n_pa;
+    s->pa_n_beams = n_beams;
+    s->pa_window = window;
+    s->pa_step = step;
+    s->pa_divisor = averaging_divisor > 0 ? averaging_divisor : window;
+    return 0;
 }
 
 int nrhip_station_set_arz(nrhip_station* s, int32_t n_profiles, int32_t n_depth, const double* profile_depth,
@@ -438,6 +460,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need one profile per shower (nrhip_station_set_shower_profiles)");
     if (arz && cfg->focusing) return nrhip_fail_msg("nrhip_simulate_events: focusing is not available with the ARZ models");
     if (general && cfg->amp_per_ray) return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray is not available with ARZ / birefringence");
+    const bool phased = cfg->trigger_type == NRHIP_TRIG_PHASED_ARRAY;
+    if (phased && st->pa_n_channels <= 0)
+        return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger needs its channels and beams (nrhip_station_set_phased_array)");
+    if (phased && (general || cfg->amp_per_ray)) return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger runs on the parametrised path only (no ARZ / birefringence / amp_per_ray)");
     if (general && (cfg->trigger_type == NRHIP_TRIG_HIGH_LOW || cfg->n_coincidences > 1))
         return nrhip_fail_msg("nrhip_simulate_events: ARZ / birefringence run with the simple threshold trigger only");
     for (auto& e : st->evt) if (!e) HIPCHK(hipEventCreate(&e));
@@ -803,7 +829,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         TriggerDev trg;
         trg.type = cfg->trigger_type == NRHIP_TRIG_HIGH_LOW ? 1 : 0;
         trg.n_coinc = cfg->n_coincidences > 1 ? cfg->n_coincidences : 1;
-        trg.threshold = cfg->trigger_threshold;
+        trg.threshold = phased ? INFINITY : cfg->trigger_threshold;  // phased array: the channel stage only produces the traces
         trg.high = cfg->threshold_high;
         trg.low = cfg->threshold_low;
         trg.w_hl = std::max(1, (int)std::lrint(cfg->high_low_window * sd.fs));
@@ -818,7 +844,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         co.triggered = triggered;
         co.trace = nullptr;
         co.trace_offset = nullptr;
-        if (cfg->dump_traces) {
+        if (cfg->dump_traces || phased) {
             std::vector<int> hL(n_groups), cand(n_cand);
             HIPCHK(hipMemcpyAsync(hL.data(), ev.L, sizeof(int) * n_groups, hipMemcpyDeviceToHost, sm));
             HIPCHK(hipMemcpyAsync(cand.data(), d_cand, sizeof(int) * n_cand, hipMemcpyDeviceToHost, sm));
@@ -846,9 +872,17 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         double2* tab_nodes = nullptr;  // per block: the angular interpolation of a tabulated pattern at its frequency nodes
         if (sd.ant_tabs) NEED(tab_nodes = WS("antenna_table_nodes", double2, (size_t)channel_grid_blocks() * 2 * sd.max_tab_freq));
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
-                       trg, ctx->twiddle, ctx->w16, tab, scratch, co, (cfg->no_pruning || cfg->dump_traces || general) ? 1 : 0, maxL,
+                       trg, ctx->twiddle, ctx->w16, tab, scratch, co, (cfg->no_pruning || cfg->dump_traces || general || phased) ? 1 : 0, maxL,
                        it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces);
         LCHK("channel");
+        if (phased) {
+            double* pa_max;
+            NEED(pa_max = WS("pa_max_power", double, (size_t)n_cand * st->pa_n_beams));
+            launch_phased_array(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, st->pa_n_channels,
+                                st->d_pa_channel.as<int>(), st->pa_n_beams, st->d_pa_rolls.as<int>(), st->pa_window, st->pa_step,
+                                (double)st->pa_divisor, cfg->trigger_threshold, maxL, triggered, pa_max);
+            LCHK("phased array");
+        }
         MARK(8);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here
     }

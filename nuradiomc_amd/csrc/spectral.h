@@ -168,6 +168,9 @@ void launch_general_gather(hipStream_t s, int n_rays, int n_ch, const RayWork& w
                            double* energy, int* type, double* em_factor, int* profile, double* rescale, double* x1, double* x2,
                            int* n_steps, int* n_points);
 void launch_int_to_long(hipStream_t s, int n, const int* in, long* out);
+void launch_phased_array(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
+                         const long* trace_offset, int n_pa, const int* pa_channel, int n_beams, const int* rolls, int window,
+                         int step, double divisor, double threshold, int max_length, unsigned char* triggered, double* pa_max);
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,

@@ -2574,6 +2574,64 @@ void launch_int_to_long(hipStream_t s, int n, const int* in, long* out)
     hipLaunchKernelGGL(int_to_long_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, n, in, out);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// kernel: phased-array trigger core (NuRadioReco/modules/phasedarray/phasedArrayBase.py: phase_signals :183-215, power_sum
+// :217-271, decision of phased_trigger :455-496, mode 'power_sum', no digitisation, no upsampling).  One block per candidate
+// event: per beam the coherent sum of the np.roll-ed channel traces (read from the dumped traces in HBM) is built in LDS,
+// then every thread squares and sums its sliding windows; any window above the threshold triggers the event.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+phased_array_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, const int* __restrict__ ev_L,
+                    const double* __restrict__ trace, const long* __restrict__ trace_offset, int n_pa,
+                    const int* __restrict__ pa_channel, int n_beams, const int* __restrict__ rolls, int window, int step,
+                    double divisor, double threshold, unsigned char* __restrict__ triggered, double* __restrict__ pa_max)
+{
+    extern __shared__ double coh[];
+    __shared__ double red[256];
+    for (int i = blockIdx.x; i < n_cand; i += gridDim.x) {
+        const int e = item_event[i], L = ev_L[e];
+        const int n_frames = (L - window) / step > 0 ? (L - window) / step : 0;
+        double any = 0.;
+        for (int b = 0; b < n_beams; b++) {
+            __syncthreads();
+            for (int n = threadIdx.x; n < L; n += blockDim.x) {
+                double sum = 0.;
+                for (int c = 0; c < n_pa; c++) {  // np.roll(trace, r)[n] = trace[(n - r) mod L]
+                    int k = (n - rolls[b * n_pa + c]) % L;
+                    if (k < 0) k += L;
+                    sum += trace[trace_offset[(long)i * n_ch + pa_channel[c]] + k];
+                }
+                coh[n] = sum;
+            }
+            __syncthreads();
+            double mx = -INFINITY;
+            for (int f = threadIdx.x; f < n_frames; f += blockDim.x) {
+                double p = 0.;
+                for (int j = 0; j < window; j++) {
+                    const double v = coh[f * step + j];
+                    p += v * v;
+                }
+                mx = fmax(mx, p / divisor);
+            }
+            mx = block_max(mx, red);
+            if (threadIdx.x == 0) pa_max[(long)i * n_beams + b] = mx;
+            if (mx > threshold) any = 1.;
+        }
+        if (threadIdx.x == 0 && any > 0.) triggered[e] = 1;
+    }
+}
+
+void launch_phased_array(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
+                         const long* trace_offset, int n_pa, const int* pa_channel, int n_beams, const int* rolls, int window,
+                         int step, double divisor, double threshold, int max_length, unsigned char* triggered, double* pa_max)
+{
+    if (n_cand <= 0) return;
+    (void)hipFuncSetAttribute((const void*)phased_array_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FFT_MAX * 8);
+    int grid = n_cand < 256 * 16 ? n_cand : 256 * 16;
+    hipLaunchKernelGGL(phased_array_kernel, dim3(grid), dim3(256), (size_t)max_length * 8, s, n_cand, item_event, n_ch, ev_L, trace,
+                       trace_offset, n_pa, pa_channel, n_beams, rolls, window, step, divisor, threshold, triggered, pa_max);
+}
+
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
                          const int* len_index_N, double* max_env, double* signal_time)

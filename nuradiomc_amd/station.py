@@ -99,6 +99,8 @@ L._OPTIONAL.update({
     'nrhip_station_destroy': (None, [ctypes.c_void_p]),
     'nrhip_station_release_workspace': (ctypes.c_int64, [ctypes.c_void_p]),
     'nrhip_station_set_positions': (ctypes.c_int, [ctypes.c_void_p, L.c_double_p]),
+    'nrhip_station_set_phased_array': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_int32_p, ctypes.c_int32, L.c_int32_p,
+                                                     ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'nrhip_station_set_arz': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p, L.c_double_p,
                                             L.c_double_p, ctypes.c_double, ctypes.c_int32]),
     'nrhip_station_set_shower_profiles': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, L.c_int32_p, L.c_double_p]),
@@ -315,6 +317,28 @@ class Station:
         L.check(self._lib.nrhip_station_set_birefringence(self._h, L.iptr(nk), L.dptr(knots), L.dptr(coeffs), float(n_ref),
                                                           float('nan') if angle_to_iceflow is None else float(angle_to_iceflow)))
 
+    def set_phased_array(self, channels, phasing_angles, ref_index=1.75, window=32, step=16, averaging_divisor=None):
+        """Phased-array trigger on the given channels (a vertical string): beams towards `phasing_angles` [rad], whole-sample
+        channel shifts as PhasedArrayBase.calculate_time_delays (phasedArrayBase.py:58-124: antenna depths, ref_index, cable
+        delays, at the simulation's sampling rate; no group delays), mean power in windows of `window` samples every `step`
+        (power_sum :217-271); no ADC digitisation, no upsampling.  channels=None switches it off."""
+        if channels is None:
+            L.check(self._lib.nrhip_station_set_phased_array(self._h, 0, None, 0, None, 0, 0, 0))
+            return None
+        ch = np.ascontiguousarray(channels, np.int32)
+        x, y, z = self.position[ch].T
+        if np.sum(np.abs(x - x[0])) > 1e-3 or np.sum(np.abs(y - y[0])) > 1e-3:   # check_vertical_string :158-181
+            raise NotImplementedError('The phased triggering array should lie on a vertical line')
+        rolls = []
+        for angle in np.atleast_1d(phasing_angles):
+            delays = (z - np.max(z)) / 0.299792458 * ref_index * np.sin(angle) - self.cable_delay[ch]
+            delays -= np.min(delays)
+            rolls.append(np.round(delays * self.sampling_rate).astype(int))
+        rolls = np.ascontiguousarray(rolls, np.int32)
+        L.check(self._lib.nrhip_station_set_phased_array(self._h, len(ch), L.iptr(ch), len(rolls), L.iptr(rolls), int(window),
+                                                         int(step), int(averaging_divisor or 0)))
+        return rolls
+
     def move_to(self, position):
         """Use this object for another station of an array of identical stations: new antenna positions [n_ch, 3], everything
         else (antennas, orientations, cable delays, filters, device tables, workspace) stays."""
@@ -351,13 +375,14 @@ class Station:
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
         d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
         trigger: 'simple' (|V| >= trigger_threshold, simpleThreshold.py) or 'high_low' (highLowThreshold.py: threshold_high /
-        threshold_low inside high_low_window), both followed by the majority logic over coinc_window with n_coincidences."""
-        if trigger not in ('simple', 'high_low'):
-            raise NotImplementedError("trigger {} is not provided (simple, high_low)".format(trigger))
+        threshold_low inside high_low_window), both followed by the majority logic over coinc_window with n_coincidences;
+        'phased_array' (set_phased_array first): trigger_threshold is the threshold on the beams' mean window power."""
+        if trigger not in ('simple', 'high_low', 'phased_array'):
+            raise NotImplementedError("trigger {} is not provided (simple, high_low, phased_array)".format(trigger))
         cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
                         float(2.0 * self.vrms_efield if min_efield_amplitude is None else min_efield_amplitude),
                         float(3.0 * self.vrms if trigger_threshold is None else trigger_threshold), int(bool(dump_traces)),
-                        int(bool(no_pruning)), 1 if trigger == 'high_low' else 0, int(n_coincidences),
+                        int(bool(no_pruning)), {'simple': 0, 'high_low': 1, 'phased_array': 2}[trigger], int(n_coincidences),
                         float(3.0 * self.vrms if threshold_high is None else threshold_high),
                         float(-3.0 * self.vrms if threshold_low is None else threshold_low), float(high_low_window),
                         float(coinc_window), int(bool(amp_per_ray)), int(bool(focusing)), float(focusing_limit))

@@ -600,6 +600,37 @@ def majority_logic(flags, n_coincidences, window_bins):
     return bool(np.any(ttt)), np.flatnonzero(ttt)
 
 
+def phased_array_rolls(z, cable_delay, phasing_angles, fs, ref_index=1.75):
+    """PhasedArrayBase.calculate_time_delays (phasedArrayBase.py:58-124) without group delays: per beam the whole-sample
+    shifts of the channels of a vertical string, [n_beams, n_ch]"""
+    z, cable_delay = np.asarray(z, float), np.asarray(cable_delay, float)
+    rolls = []
+    for angle in phasing_angles:
+        delays = (z - np.max(z)) / 0.299792458 * ref_index * np.sin(angle) - cable_delay
+        delays -= np.min(delays)
+        rolls.append(np.round(delays * fs).astype(int))
+    return np.array(rolls)
+
+
+def phased_array_power(V, rolls, window, step, averaging_divisor=None):
+    """phase_signals (:183-215) + power_sum (:217-271): [n_beams, n_frames] mean power of the coherent sums in sliding windows"""
+    out = []
+    for roll in rolls:
+        coh = np.zeros(V.shape[1])
+        for c in range(V.shape[0]):
+            coh += np.roll(V[c], int(roll[c]))
+        n_frames = int(np.floor((len(coh) - window) / step))
+        sq = coh * coh
+        out.append(np.array([np.sum(sq[i * step:i * step + window]) for i in range(n_frames)]) / (averaging_divisor or window))
+    return np.array(out)
+
+
+def phased_array_trigger(V, rolls, window, step, threshold):
+    """phased_trigger (:455-496), mode 'power_sum': (triggered, maximum_amps per beam)"""
+    p = phased_array_power(V, rolls, window, step)
+    return bool(np.any(p > threshold)), p.max(axis=1)
+
+
 def station_trigger(V, fs, trigger='simple', threshold=None, n_coincidences=1, threshold_high=None, threshold_low=None,
                     high_low_window=5., coinc_window=200.):
     """simpleThreshold.triggerSimulator.run / highLowThreshold.triggerSimulator.run on all channels: (triggered, bins)"""

@@ -838,3 +838,53 @@ def test_general_path_errors_and_empty_inputs(gpu_ctx_factory):
     assert ctx.attenuation_reflections_batch(np.zeros((0, 3)), np.zeros((0, 3)), [], [], [], -500., [0.1, 0.2]).shape == (0, 2)
     assert ctx.birefringence_batch(np.zeros((0, 3)), np.zeros((0, 3)), [], [], np.zeros((0, 2, 129), complex), 2.0, tck).shape == (0, 2, 129)
     assert arz.get_time_trace_batch([], [], 256, 0.5, [], 1.78, [], []).shape == (0, 3, 256)
+
+
+def test_phased_array_trigger(gpu_ctx_factory):
+    """Phased-array trigger inside simulate_events (a 4-dipole string + other channels): beam rolls as the reference's
+    calculate_time_delays, decisions and per-beam maximum window powers vs the oracle's core (pinned against the reference's
+    phase_signals / power_sum) applied to the oracle's channel traces."""
+    ice = (1.78, 0.423, 77.)
+    pos = np.array([[0., 0., -96.], [0., 0., -97.], [0., 0., -98.], [0., 0., -99.], [0., 0., -60.], [20., 15., -95.]])
+    cable = np.array([1.2, 0., 2.6, 0.7, 0., 3.])
+    ctx = gpu_ctx_factory(ice, 'SP1')
+    st = nuradiomc_amd.Station(ctx, pos, cable_delay=cable, n_samples=512, sampling_rate=2.0)
+    ost = so.Station(pos, cable_delay=cable, n_samples=512, fs=2.0)
+    vrms, vrms_e = so.vrms_from_filters(2.0)
+    angles = np.arcsin(np.linspace(np.sin(-60 * np.pi / 180), np.sin(60 * np.pi / 180), 11))
+    window, step = 32, 16
+    rolls = st.set_phased_array([0, 1, 2, 3], angles, ref_index=1.75, window=window, step=step)
+    assert np.array_equal(rolls, so.phased_array_rolls(pos[:4, 2], cable[:4], angles, 2.0, 1.75))
+    threshold = 2.5 * (2 * vrms) ** 2     # power of the 4-channel coherent sum
+    rng = np.random.default_rng(14)
+    n = 120
+    r, ph = np.sqrt(rng.uniform(0, 1500. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    v = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1500., -10., n)], axis=1)
+    zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    en = 10 ** rng.uniform(16.8, 18.2, n)
+    trig, stats = st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold)
+    cand = st.fetch('ev_candidate').astype(bool)
+    item_event = st.fetch('item_event')
+    pa_max = st.fetch('pa_max_power').reshape(len(item_event), len(angles))
+    n_cand = n_trig = 0
+    for e in range(n):
+        o = so.simulate_event(v[e], zen[e], az[e], en[e], 'HAD', None, ost, ice, vrms, vrms_e)
+        assert o['candidate'] == bool(cand[e])
+        if not o['candidate']:
+            assert not trig[e]
+            continue
+        n_cand += 1
+        t, mx = so.phased_array_trigger(o['V'][:4], rolls, window, step, threshold)
+        i = int(np.where(item_event == e)[0][0])
+        assert np.max(np.abs(pa_max[i] - mx)) <= 1e-6 * np.max(mx), e
+        if np.min(np.abs(mx - threshold)) > 1e-6 * threshold:
+            assert t == bool(trig[e]), e
+        n_trig += t
+    assert n_cand >= 15 and 3 <= n_trig < n_cand
+    simple, _ = st.simulate_events(v, zen, az, en, 'HAD')      # the per-channel threshold trigger is untouched
+    assert simple.sum() != trig.sum() or not np.array_equal(simple, trig)
+    st.set_phased_array(None, angles)
+    with pytest.raises(Exception, match='phased-array'):
+        st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold)
+    with pytest.raises(NotImplementedError):
+        st.set_phased_array([0, 5], angles)

@@ -355,3 +355,17 @@ def test_birefringence_vs_reference():
         if tag == 'sp':
             np.testing.assert_allclose(got, g['ref_BF'], atol=2e-4, rtol=1e-7)    # T07test_birefringence.py:98
             assert np.max(np.abs(got - g['ref_BF'])) < 2e-6
+
+
+def test_phased_array_core_vs_reference():
+    """Phased-array trigger core (beam rolls of a vertical string, coherent sums of rolled channel traces, sliding power
+    windows) against the reference's PhasedArrayBase.calculate_time_delays / phase_signals / power_sum."""
+    from oracle import spectral_oracle as so
+    g = golden('ref_phased_array.npz')
+    for k, (n_ch, n_samples, fs, window, step, n_beams) in enumerate(g['cases']):
+        rolls = so.phased_array_rolls(g['pos_%d' % k][:, 2], g['cable_%d' % k], g['angles_%d' % k], fs, float(g['ref_index']))
+        assert np.array_equal(rolls, g['rolls_%d' % k])
+        for e in range(len(g['traces_%d' % k])):
+            p = so.phased_array_power(g['traces_%d' % k][e], rolls, int(window), int(step))
+            ref = g['power_%d' % k][e]
+            assert p.shape == ref.shape and np.max(np.abs(p - ref)) <= 1e-12 * np.max(ref)
