@@ -342,6 +342,11 @@ int nrhip_station_set_positions(nrhip_station* st, const double* position);
  * factor E / E_library (the host picks them as ARZ.get_time_trace does: closest library energy, random / given number).
  * nrhip_station_set_birefringence: the three depth splines as in nrhip_birefringence_batch; n_knots == NULL switches it off.
  * Limits: simple threshold trigger, no focusing with ARZ, no amp_per_ray.  HOST pointers (copied).                      */
+/* triggered_channels of the reference's threshold triggers (simpleThreshold.run :48-148, highLowThreshold.run :160-335): only
+ * these channels raise flags / count towards the coincidence; the others are not evaluated at all unless traces are dumped
+ * (their maxima then read NaN).  n = 0: every channel (the default).  HOST pointer (copied).                        */
+int nrhip_station_set_trigger_channels(nrhip_station* st, int32_t n, const int32_t* channels);
+
 /* Phased-array trigger (NuRadioReco/modules/phasedarray/phasedArrayBase.py, mode 'power_sum' without digitisation and
  * upsampling: phase_signals :183-215, power_sum :217-271, phased_trigger :455-496): per beam the traces of the n_pa trigger
  * channels are rolled by rolls[beam][channel] samples (calculate_time_delays :58-124, the host computes them) and summed, the

@@ -237,6 +237,7 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     v.att_bound_depth = (d->att_bound_inv_length && d->att_bound_depth > 0) ? d->att_bound_depth : -1.;
     v.pos = s->d_pos.as<double>();
     v.cable = s->d_cable.as<double>();
+    v.trig_on = nullptr;
     v.ant_model = s->d_model.as<int>();
     v.rot = s->d_rot.as<double>();
     v.rot_inv = s->d_rot_inv.as<double>();
@@ -285,7 +286,7 @@ void nrhip_station_detach(nrhip_station* s)
     for (auto& a : s->d_tabdata) a.release();
     s->d_arz_depth.release(); s->d_arz_ce.release(); s->d_arz_par.release(); s->d_bire_knots.release();
     s->d_bire_coeffs.release(); s->d_shower_profile.release(); s->d_shower_rescale.release();
-    s->d_pa_channel.release(); s->d_pa_rolls.release();
+    s->d_pa_channel.release(); s->d_pa_rolls.release(); s->d_trig_on.release();
     s->ws.clear();
     s->ws_bytes.clear();
     s->ctx->stations.erase(s);
@@ -317,6 +318,26 @@ int64_t nrhip_station_release_workspace(nrhip_station* s)
     }
     s->ws_bytes.clear();
     return freed;
+}
+
+int nrhip_station_set_trigger_channels(nrhip_station* s, int32_t n, const int32_t* channels)
+{
+    if (!s || !s->ctx) return nrhip_fail_msg("nrhip_station_set_trigger_channels: NULL argument or station without a context");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    if (n <= 0 || !channels) {
+        s->dev.trig_on = nullptr;
+        return 0;
+    }
+    std::vector<unsigned char> on(s->dev.n_ch, 0);
+    for (int i = 0; i < n; i++) {
+        if (channels[i] < 0 || channels[i] >= s->dev.n_ch) return nrhip_fail_msg("nrhip_station_set_trigger_channels: bad channel index");
+        on[channels[i]] = 1;
+    }
+    if (upload(s->ctx, s->d_trig_on, on.data(), on.size())) return -1;
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    s->dev.trig_on = s->d_trig_on.as<unsigned char>();
+    return 0;
 }
 
 int nrhip_station_set_phased_array(nrhip_station* s, int32_t n_pa, const int32_t* channels, int32_t n_beams, const int32_t* rolls,

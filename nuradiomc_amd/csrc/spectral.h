@@ -27,6 +27,7 @@ struct StationDev {
     double fs, pre_pulse, post_pulse, readout_length, att_bound_depth;
     const double* pos;        // [n_ch][3]
     const double* cable;      // [n_ch]
+    const unsigned char* trig_on;  // [n_ch] 1 = the channel takes part in the threshold triggers; nullptr = all do
     const int* ant_model;     // [n_ch]   0 analytic_VPol, 1 analytic_HPol, 2 analytic_LPDA
     const AntTabDev* ant_tabs;   // tabulated patterns (ant_model 3): table of channel c = ant_tabs[ant_tab_index[c]]
     const int* ant_tab_index;    // [n_ch]

@@ -1363,6 +1363,11 @@ channel_prefilter_kernel(int n_items, const int* __restrict__ item_event, RayWor
     const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
     const int L = ev.L[e], il = ev_len_index[e];
     if (L > FFT_MAX || st.ant_model[ch] == 3) { need[item] = 0; return; }  // chirp-z kernel: long traces, tabulated patterns
+    if (!exact && st.trig_on && !st.trig_on[ch]) {  // not a trigger channel: nothing of it decides anything
+        need[item] = 0;
+        maxV[item] = NAN;
+        return;
+    }
     int flag = 1;
     if (!exact) {
         const int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
@@ -1452,6 +1457,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       for (int ch = 0; ch < st.n_ch; ch++) {
         const int item = item_list[le] * st.n_ch + ch;
         if (!need[item]) continue;
+        const bool ch_on = !st.trig_on || st.trig_on[ch];  // triggered_channels of the reference's trigger modules
         const int e = item_event[item / st.n_ch];
         if (!exact && !coinc && ev_trig) {
             if (threadIdx.x == 0) out.maxV[item] = NAN;
@@ -1555,7 +1561,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     if (out.trace) out.trace[out.trace_offset[item] + n] = v;
                     double av = fabs(v);
                     vmax = fmax(vmax, av);
-                    if (n < L - 1 && av >= threshold) trig = 1;
+                    if (n < L - 1 && av >= threshold && ch_on) trig = 1;
                 }
             } else {
                 // per-channel flags (simpleThreshold.py:14-29 / highLowThreshold.py:13-80), OR-dilated over the coincidence
@@ -1585,7 +1591,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                         }
                         flag = hi && lo;
                     }
-                    A[i] = flag ? i : -1;
+                    A[i] = (flag && ch_on) ? i : -1;
                 }
                 __syncthreads();
                 {   // inclusive running maximum of A[0 .. nb): contiguous chunk per thread, then a scan of the chunk maxima
@@ -1878,7 +1884,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                     if (out.trace) out.trace[out.trace_offset[item] + ng] = v;
                     double av = fabs(v);
                     vmax = fmax(vmax, av);
-                    if (ng < L - 1 && av >= threshold) trig = 1;
+                    if (ng < L - 1 && av >= threshold && (!st.trig_on || st.trig_on[ch])) trig = 1;
                 }
                 __syncthreads();
             }

@@ -99,6 +99,7 @@ L._OPTIONAL.update({
     'nrhip_station_destroy': (None, [ctypes.c_void_p]),
     'nrhip_station_release_workspace': (ctypes.c_int64, [ctypes.c_void_p]),
     'nrhip_station_set_positions': (ctypes.c_int, [ctypes.c_void_p, L.c_double_p]),
+    'nrhip_station_set_trigger_channels': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_int32_p]),
     'nrhip_station_set_phased_array': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_int32_p, ctypes.c_int32, L.c_int32_p,
                                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'nrhip_station_set_arz': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p, L.c_double_p,
@@ -316,6 +317,15 @@ class Station:
         nk = np.array([len(t[0]) for t in tck], np.int32)
         L.check(self._lib.nrhip_station_set_birefringence(self._h, L.iptr(nk), L.dptr(knots), L.dptr(coeffs), float(n_ref),
                                                           float('nan') if angle_to_iceflow is None else float(angle_to_iceflow)))
+
+    def set_trigger_channels(self, channels=None):
+        """`triggered_channels` of the reference's simple / high-low threshold triggers: only these channels can trigger or
+        count towards a coincidence (None: all).  The candidate cut on the electric fields still looks at every channel."""
+        if channels is None:
+            L.check(self._lib.nrhip_station_set_trigger_channels(self._h, 0, None))
+        else:
+            ch = np.ascontiguousarray(channels, np.int32)
+            L.check(self._lib.nrhip_station_set_trigger_channels(self._h, len(ch), L.iptr(ch)))
 
     def set_phased_array(self, channels, phasing_angles, ref_index=1.75, window=32, step=16, averaging_divisor=None):
         """Phased-array trigger on the given channels (a vertical string): beams towards `phasing_angles` [rad], whole-sample

@@ -888,3 +888,40 @@ def test_phased_array_trigger(gpu_ctx_factory):
         st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold)
     with pytest.raises(NotImplementedError):
         st.set_phased_array([0, 5], angles)
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(trigger='high_low', n_coincidences=2, coinc_window=80.)])
+def test_trigger_channel_subset(gpu_ctx_factory, kw):
+    """`triggered_channels` of the threshold triggers: decisions equal the oracle's trigger applied to those channels' traces
+    only, in production mode (the other channels are not evaluated) and with dumped traces (they are, but cannot trigger)."""
+    g = golden('chain_N256.npz')
+    ice = g['ice']
+    ctx = gpu_ctx_factory(ice, 'SP1')
+    st = nuradiomc_amd.Station(ctx, g['det_pos'], n_samples=int(g['N']), sampling_rate=float(g['fs']))
+    ost = so.Station(g['det_pos'], n_samples=int(g['N']), fs=float(g['fs']))
+    n = 300
+    sl = slice(0, n)
+    args = (g['vertex'][sl], g['zenith'][sl], g['azimuth'][sl], g['energy'][sl] * 40., 'HAD')
+    opts = dict(kw)
+    if kw:
+        opts.update(threshold_high=2.5 * st.vrms, threshold_low=-2.5 * st.vrms)
+    all_ch, _ = st.simulate_events(*args, **opts)
+    subset = [1, 3]
+    st.set_trigger_channels(subset)
+    prod, _ = st.simulate_events(*args, **opts)
+    maxV = st.fetch('item_maxV').reshape(-1, 5)
+    assert np.all(np.isnan(maxV[:, [0, 2, 4]]))
+    dump, _ = st.simulate_events(*args, dump_traces=True, **opts)
+    assert np.array_equal(prod, dump) and 3 <= prod.sum() <= all_ch.sum() and not np.any(prod & ~all_ch)
+    item_event, tr, off = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    for i, e in enumerate(item_event):
+        V = np.array([tr[off[i * 5 + c]:off[i * 5 + c + 1]] for c in subset])
+        if kw:
+            t, _ = so.station_trigger(V, float(g['fs']), 'high_low', n_coincidences=2, threshold_high=2.5 * st.vrms,
+                                      threshold_low=-2.5 * st.vrms, coinc_window=80.)
+        else:
+            t = so.threshold_trigger(V, 3.0 * st.vrms)
+        assert t == bool(dump[e]), e
+    st.set_trigger_channels(None)
+    again, _ = st.simulate_events(*args, **opts)
+    assert np.array_equal(again, all_ch)
