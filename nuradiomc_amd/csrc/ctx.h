@@ -65,7 +65,7 @@ struct nrhip_station {
     double bire_n_ref = 1.78, bire_angle = 0.;
     int64_t n_shower_profiles = 0;
     // phased-array trigger (nrhip_station_set_phased_array)
-    DevArray d_pa_channel, d_pa_rolls, d_trig_on;
+    DevArray d_pa_channel, d_pa_rolls, d_pa_mask, d_trig_on;
     int pa_n_channels = 0, pa_n_beams = 0, pa_window = 0, pa_step = 0, pa_divisor = 0;
     // workspace of the last simulated chunk (kept for nrhip_sim_fetch and reused between calls)
     std::map<std::string, DevArray> ws;

@@ -286,7 +286,7 @@ void nrhip_station_detach(nrhip_station* s)
     for (auto& a : s->d_tabdata) a.release();
     s->d_arz_depth.release(); s->d_arz_ce.release(); s->d_arz_par.release(); s->d_bire_knots.release();
     s->d_bire_coeffs.release(); s->d_shower_profile.release(); s->d_shower_rescale.release();
-    s->d_pa_channel.release(); s->d_pa_rolls.release(); s->d_trig_on.release();
+    s->d_pa_channel.release(); s->d_pa_rolls.release(); s->d_pa_mask.release(); s->d_trig_on.release();
     s->ws.clear();
     s->ws_bytes.clear();
     s->ctx->stations.erase(s);
@@ -351,7 +351,11 @@ int nrhip_station_set_phased_array(nrhip_station* s, int32_t n_pa, const int32_t
     for (int c = 0; c < n_pa; c++)
         if (channels[c] < 0 || channels[c] >= s->dev.n_ch) return nrhip_fail_msg("nrhip_station_set_phased_array: bad channel index");
     HIPCHK(hipSetDevice(s->ctx->device));
-    if (upload(s->ctx, s->d_pa_channel, channels, (size_t)n_pa) || upload(s->ctx, s->d_pa_rolls, rolls, (size_t)n_beams * n_pa)) return -1;
+    std::vector<unsigned char> mask(s->dev.n_ch, 0);
+    for (int c = 0; c < n_pa; c++) mask[channels[c]] = 1;
+    if (upload(s->ctx, s->d_pa_channel, channels, (size_t)n_pa) || upload(s->ctx, s->d_pa_rolls, rolls, (size_t)n_beams * n_pa) ||
+        upload(s->ctx, s->d_pa_mask, mask.data(), mask.size()))
+        return -1;
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
     s->pa_n_channels = n_pa;
     s->pa_n_beams = n_beams;
@@ -876,6 +880,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             NEED(d_off = WS("trace_offset", long, n_items + 1));
             HIPCHK(hipMemcpyAsync(d_off, off.data(), sizeof(long) * (n_items + 1), hipMemcpyHostToDevice, sm));
             NEED(co.trace = WS("trace", double, std::max<long>(off[n_items], 1)));
+            // channels without a ray (and channels outside the trigger set) are not written by the kernels: zeros, as the
+            // reference's empty channels
+            HIPCHK(hipMemsetAsync(co.trace, 0, sizeof(double) * (size_t)std::max<long>(off[n_items], 1), sm));
             co.trace_offset = d_off;
             HIPCHK(hipStreamSynchronize(sm));  // `off` goes out of scope
         }
@@ -892,9 +899,12 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(coinc_cnt = WS("coincidence_count", int, trg.coincidence() ? (size_t)channel_grid_blocks() * FFT_MAX : 1));
         double2* tab_nodes = nullptr;  // per block: the angular interpolation of a tabulated pattern at its frequency nodes
         if (sd.ant_tabs) NEED(tab_nodes = WS("antenna_table_nodes", double2, (size_t)channel_grid_blocks() * 2 * sd.max_tab_freq));
-        launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd, st->filters, arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
+        StationDev sd_ch = sd;
+        if (phased) sd_ch.trig_on = st->d_pa_mask.as<unsigned char>();  // only the array's channels need traces (unless all are dumped)
+        launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd_ch, st->filters, arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
                        trg, ctx->twiddle, ctx->w16, tab, scratch, co, (cfg->no_pruning || cfg->dump_traces || general || phased) ? 1 : 0, maxL,
-                       it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces);
+                       it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces,
+                       phased ? (cfg->dump_traces ? 0 : 1) : -1);
         LCHK("channel");
         if (phased) {
             double* pa_max;

@@ -1356,14 +1356,14 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
 __global__ void __launch_bounds__(256)
 channel_prefilter_kernel(int n_items, const int* __restrict__ item_event, RayWork w, EventOut ev,
                          const int* __restrict__ ev_len_index, StationDev st, double threshold, const double* __restrict__ hnorm,
-                         int exact, double* __restrict__ maxV, int* __restrict__ need)
+                         int exact, double* __restrict__ maxV, int* __restrict__ need, int skip_off)
 {
     const int item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= n_items) return;
     const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
     const int L = ev.L[e], il = ev_len_index[e];
     if (L > FFT_MAX || st.ant_model[ch] == 3) { need[item] = 0; return; }  // chirp-z kernel: long traces, tabulated patterns
-    if (!exact && st.trig_on && !st.trig_on[ch]) {  // not a trigger channel: nothing of it decides anything
+    if (skip_off && st.trig_on && !st.trig_on[ch]) {  // not a trigger channel: nothing of it decides anything
         need[item] = 0;
         maxV[item] = NAN;
         return;
@@ -2334,8 +2334,9 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
-                    const double* ray_traces)
+                    const double* ray_traces, int skip_off)
 {
+    if (skip_off < 0) skip_off = !exact;  // channels outside the trigger set are evaluated only when everything is
     if (n_items <= 0) return;
     set_big_lds();
     int nh = st.N / 2;
@@ -2345,7 +2346,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     int skip_upto = 0;
     if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces) {
         hipLaunchKernelGGL(channel_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev,
-                           ev_len_index, st, trig.prefilter(), tab.hnorm, exact, out.maxV, need);
+                           ev_len_index, st, trig.prefilter(), tab.hnorm, exact, out.maxV, need, skip_off);
         const int n_cand = n_items / st.n_ch;
         int* ev_need = need + n_items;  // [n_cand + 1]
         hipLaunchKernelGGL(channel_event_flags_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, st.n_ch, need,

@@ -925,3 +925,30 @@ def test_trigger_channel_subset(gpu_ctx_factory, kw):
     st.set_trigger_channels(None)
     again, _ = st.simulate_events(*args, **opts)
     assert np.array_equal(again, all_ch)
+
+
+def test_dumped_traces_of_channels_without_rays_are_zero(gpu_ctx_factory):
+    """a channel no ray reaches (shadow zone) has an all-zero trace in the dump, also when the workspace held other traces
+    before (regression: the dump buffer was not cleared and such channels kept stale samples)"""
+    import bench
+    ctx = gpu_ctx_factory(bench.ICE, 'SP1')
+    pos = np.array([[0., 0., -100.], [0., 0., -101.], [0., 0., -102.], [0., 0., -2.], [0., 0., -1.]])
+    st = nuradiomc_amd.Station(ctx, pos, n_samples=512, sampling_rate=2.0)
+    v, z, a = bench.make_events(6000, 2)
+    en = np.full(6000, 3e18)
+    st.simulate_events(v, z, a, en, 'HAD', dump_traces=True)                      # fills the workspace
+    far = np.linalg.norm(v[:, :2], axis=1) > 1200.
+    trig, stats = st.simulate_events(v[far], z[far], a[far], en[far], 'HAD', dump_traces=True)
+    item_event, tr, off = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    r0, nr, rch = st.fetch('ev_ray_begin'), st.fetch('ev_n_rays'), st.fetch('ray_channel')
+    n_empty = 0
+    for i, e in enumerate(item_event):
+        have = set(rch[r0[e]:r0[e] + nr[e]])
+        for c in range(5):
+            t = tr[off[i * 5 + c]:off[i * 5 + c + 1]]
+            if c not in have:
+                assert not np.any(t), (e, c)
+                n_empty += 1
+            else:
+                assert np.any(t)
+    assert n_empty > 20

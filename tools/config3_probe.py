@@ -4,7 +4,7 @@ downloads), greenland_simple ice + GL1 attenuation, Alvarez2009, 1e18 eV hadroni
 speedup.distance_cut with the coefficients of the reference's example config, simple 3 Vrms threshold on any channel, 2048
 samples at 2 GHz.  One Station object is moved through the array (Station.move_to); every chunk of the event list is uploaded
 once, offered to every station, and the masks are OR-ed.
-usage: config3_probe.py [n_events] [n_stations] [gen2]
+usage: config3_probe.py [n_events] [n_stations] [gen2 | deep4 | pa]
 `gen2` = BASELINE config 5 in the same shape: up to 200 stations on a 1.24 km square grid, each the 5-channel dipole string of
 config 2 at -100 .. -104 m (no Gen2 detector file exists in the reference), showers log-uniform in 1e16 .. 1e20 eV."""
 import sys, time, os
@@ -51,6 +51,12 @@ any_trig = np.zeros(n, bool)
 tot = dict(n_pairs=0, n_rays=0, n_active_rays=0, n_candidate_events=0)
 from nuradiomc_amd.station import distance_cut
 s = make_station(centres[0])
+trig_kw = {}
+if len(sys.argv) > 3 and sys.argv[3] == 'deep4':     # threshold trigger on the four deep dipoles of the power string only
+    s.set_trigger_channels([0, 1, 2, 3])
+if len(sys.argv) > 3 and sys.argv[3] == 'pa':        # phased array on the four deep dipoles (11 beams, 16-sample windows)
+    s.set_phased_array([0, 1, 2, 3], np.arcsin(np.linspace(np.sin(-60 * d), np.sin(60 * d), 11)), window=16, step=8)
+    trig_kw = dict(trigger='phased_array', trigger_threshold=2.0 * (2 * s.vrms) ** 2)
 s.simulate_events(vertex[:1000], zen[:1000], az[:1000], energy[:1000], 'HAD', distance_cut_coefficients=coef)
 t0 = time.time()
 per = np.zeros(len(centres))
@@ -66,7 +72,7 @@ for a in range(0, n, chunk):
     for i, c in enumerate(centres):
         t1 = time.time()
         s.move_to(pos + c)
-        stats = s.simulate_events_dev(m, *d_in, d_trig, d_max_distance=d_md)
+        stats = s.simulate_events_dev(m, *d_in, d_trig, d_max_distance=d_md, **trig_kw)
         ctx.to_host(trig, d_trig)
         any_trig[sl] |= trig.astype(bool)
         for k in tot:
