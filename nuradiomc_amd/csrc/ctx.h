@@ -55,7 +55,7 @@ struct nrhip_station {
     nrhip::StationDev dev;
     nrhip::FilterSet filters;
     std::vector<double> h_pos, h_cable;
-    DevArray d_pos, d_cable, d_model, d_rot, d_rot_inv, d_fc, d_lnf, d_invl, d_fpow, d_seg, d_attbin, d_anttabs, d_anttab_index;
+    DevArray d_pos, d_cable, d_model, d_rot, d_rot_inv, d_fc, d_lnf, d_invl, d_fpow, d_fpow_f, d_seg, d_attbin, d_anttabs, d_anttab_index;
     std::vector<DevArray> d_tabdata;  // arrays of the tabulated antenna patterns
     // general emission / propagation path (nrhip_station_set_arz / _set_birefringence / _set_shower_profiles)
     DevArray d_arz_depth, d_arz_ce, d_arz_par, d_bire_knots, d_bire_coeffs, d_shower_profile, d_shower_rescale;

@@ -155,6 +155,7 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     }
     // tables on the N-sample frequency grid: f^p of the Alvarez2009 form factors, coarse-grid segment of np.interp
     std::vector<double> fpow(3 * (size_t)(nh + 1), 0.);
+    std::vector<float> fpow_f(3 * (size_t)(nh + 1), 0.f);
     std::vector<unsigned char> seg(nh + 1, 0);
     {
         const double df = 1.0 / (d->n_samples * (1. / d->sampling_rate));
@@ -162,7 +163,10 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
         const int nfc = d->n_att_freq;
         for (int k = 1; k <= nh; k++) {
             const double f = k * df;
-            for (int r = 0; r < 3; r++) fpow[r * (size_t)(nh + 1) + k] = std::pow(f, pw[r]);
+            for (int r = 0; r < 3; r++) {
+                fpow[r * (size_t)(nh + 1) + k] = std::pow(f, pw[r]);
+                fpow_f[r * (size_t)(nh + 1) + k] = (float)fpow[r * (size_t)(nh + 1) + k];
+            }
             int lo = 0;
             while (lo < nfc - 2 && f >= d->att_freq[lo + 1]) lo++;
             seg[k] = (unsigned char)lo;
@@ -177,7 +181,8 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
         upload(ctx, s->d_model, d->antenna_model, n) || upload(ctx, s->d_rot, rot.data(), 9 * n) ||
         upload(ctx, s->d_rot_inv, roti.data(), 9 * n) || upload(ctx, s->d_fc, d->att_freq, d->n_att_freq) ||
         upload(ctx, s->d_lnf, lnf.data(), lnf.size()) || upload(ctx, s->d_invl, invl.data(), invl.size()) ||
-        upload(ctx, s->d_fpow, fpow.data(), fpow.size()) || upload(ctx, s->d_seg, seg.data(), seg.size())) {
+        upload(ctx, s->d_fpow, fpow.data(), fpow.size()) || upload(ctx, s->d_fpow_f, fpow_f.data(), fpow_f.size()) ||
+        upload(ctx, s->d_seg, seg.data(), seg.size())) {
         delete s;
         return -1;
     }
@@ -245,6 +250,7 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     v.lnf = s->d_lnf.as<double>();
     v.inv_lmax = s->d_invl.as<double>();
     v.fpow = s->d_fpow.as<double>();
+    v.fpow_f = s->d_fpow_f.as<float>();
     v.seg = s->d_seg.as<unsigned char>();
     FilterSet& f = s->filters;
     memset(&f, 0, sizeof f);
@@ -282,7 +288,7 @@ void nrhip_station_detach(nrhip_station* s)
     for (auto& e : s->evt) if (e) (void)hipEventDestroy(e);
     s->d_pos.release(); s->d_cable.release(); s->d_model.release();
     s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release(); s->d_lnf.release(); s->d_invl.release();
-    s->d_fpow.release(); s->d_seg.release(); s->d_attbin.release(); s->d_anttabs.release(); s->d_anttab_index.release();
+    s->d_fpow.release(); s->d_fpow_f.release(); s->d_seg.release(); s->d_attbin.release(); s->d_anttabs.release(); s->d_anttab_index.release();
     for (auto& a : s->d_tabdata) a.release();
     s->d_arz_depth.release(); s->d_arz_ce.release(); s->d_arz_par.release(); s->d_bire_knots.release();
     s->d_bire_coeffs.release(); s->d_shower_profile.release(); s->d_shower_rescale.release();

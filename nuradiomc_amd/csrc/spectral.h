@@ -42,6 +42,7 @@ struct StationDev {
     double att_bin_width;
     const double* att_bin_inv; // [n_att_bins][n_fc] lower bounds of 1 / L_att inside depth bin b
     const double* fpow;       // [3][N/2 + 1] f_k^p for p = 2.57, 2.74, 1.27 (Alvarez2009: beta had / em, alpha)
+    const float* fpow_f;      // the same in single precision (bound kernels)
     const unsigned char* seg; // [N/2 + 1] coarse-grid segment lo of f_k: fcoarse[lo] <= f_k < fcoarse[lo + 1]
 };
 

@@ -653,6 +653,7 @@ __device__ inline double cabs2(double2 a) { return sqrt(a.x * a.x + a.y * a.y); 
 // positive arguments it sees) instead of the ~3x longer IEEE division sequence; the sums built from it are inflated by
 // BOUND_RCP_SLACK, so they stay upper bounds
 #define BOUND_RCP_SLACK (1. + 1e-9)
+#define BOUND_F32_SLACK (1. + 5e-4)
 __device__ inline double bound_rcp(double x)
 {
     const double r = __builtin_amdgcn_rcp(x);
@@ -817,6 +818,33 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
             double part[AB_RT];
             for (int i = 0; i < AB_RT; i++) part[i] = 0.;
             const double x_first = s_xp[0], x_last = s_xp[st.n_fc - 1], dx_last = x_last - s_xp[st.n_fc - 2];
+            // Alvarez2009 with all scalars comfortably inside the single-precision range: the 2047-term sum in FP32 (twice the
+            // VALU rate, a 1-instruction reciprocal); every term is within ~1e-6 and the sum of positive terms within
+            // 2047 * 6e-8 of the exact one, the result is inflated by BOUND_F32_SLACK and stays an upper bound
+            bool f32 = all2009;
+            for (int i = 0; i < AB_RT; i++)
+                f32 = f32 && pf[i] > 1e-25 && pf[i] < 1e25 && cL[i] > 1e-25 && cL[i] < 1e25 && cR[i] > 1e-25 && cR[i] < 1e25;
+            if (f32) {
+                float cLf[AB_RT], cRf[AB_RT], pff[AB_RT], pf32[AB_RT];
+                for (int i = 0; i < AB_RT; i++) { cLf[i] = (float)cL[i]; cRf[i] = (float)cR[i]; pff[i] = (float)pf[i]; pf32[i] = 0.f; }
+                const float xf_first = (float)x_first, xf_last = (float)x_last, dxf_last = (float)dx_last, dff = (float)df;
+                for (int k = 1 + lane; k < nh; k += 64) {
+                    const float f = k * dff;
+                    int lo = st.seg[k];
+                    float dx = f - (float)s_xp[lo];
+                    if (f <= xf_first) { lo = 0; dx = 0.f; }
+                    if (f >= xf_last) { lo = st.n_fc - 2; dx = dxf_last; }
+                    dx = fmaxf(dx, 0.f);
+                    const float ph = st.fpow_f[k], pe = st.fpow_f[stride + k], pr = st.fpow_f[2 * stride + k];
+#pragma unroll
+                    for (int i = 0; i < AB_RT; i++) {
+                        const float x = (had[i] ? ph : pe) * cLf[i], y = pr * cRf[i];
+                        const float amp = pff[i] * f * __builtin_amdgcn_rcpf((1.f + x) * (1.f + y));
+                        pf32[i] += amp * fmaxf((float)ub_slope[wv][i][lo] * dx + (float)ub[wv][i][lo], 0.f);
+                    }
+                }
+                for (int i = 0; i < AB_RT; i++) part[i] = (double)pf32[i] * BOUND_F32_SLACK + 1e-30;  // + what FP32 may have flushed to zero
+            } else
             for (int k = 1 + lane; k < nh; k += 64) {
                 const double f = k * df;
                 // np.interp clamps outside the coarse grid: segment 0 at offset 0 / last segment at full length
@@ -956,6 +984,34 @@ efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w
             double part[AB_RT], sq[AB_RT];
             for (int i = 0; i < AB_RT; i++) part[i] = sq[i] = 0.;
             const double x_first = s_xp[0], x_last = s_xp[st.n_fc - 1], dx_last = x_last - s_xp[st.n_fc - 2];
+            bool f32 = all2009;  // as in amp_bound_kernel: FP32 sums, inflated
+            for (int i = 0; i < AB_RT; i++)
+                f32 = f32 && pf[i] > 1e-18 && pf[i] < 1e18 && cL[i] > 1e-25 && cL[i] < 1e25 && cR[i] > 1e-25 && cR[i] < 1e25;
+            if (f32) {
+                float cLf[AB_RT], cRf[AB_RT], pff[AB_RT], p32[AB_RT], q32[AB_RT];
+                for (int i = 0; i < AB_RT; i++) { cLf[i] = (float)cL[i]; cRf[i] = (float)cR[i]; pff[i] = (float)pf[i]; p32[i] = q32[i] = 0.f; }
+                const float xf_first = (float)x_first, xf_last = (float)x_last, dxf_last = (float)dx_last, dff = (float)df;
+                for (int k = 1 + lane; k < nh; k += 64) {
+                    const float f = k * dff;
+                    int lo = st.seg[k];
+                    float dx = f - (float)s_xp[lo];
+                    if (f <= xf_first) { lo = 0; dx = 0.f; }
+                    if (f >= xf_last) { lo = st.n_fc - 2; dx = dxf_last; }
+                    const float ph = st.fpow_f[k], pe = st.fpow_f[stride + k], pr = st.fpow_f[2 * stride + k];
+#pragma unroll
+                    for (int i = 0; i < AB_RT; i++) {
+                        const float x = (had[i] ? ph : pe) * cLf[i], y = pr * cRf[i];
+                        const float amp = pff[i] * f * __builtin_amdgcn_rcpf((1.f + x) * (1.f + y));
+                        const float v = amp * fmaxf((float)at_slope[wv][i][lo] * dx + (float)at[wv][i][lo], 0.f);
+                        p32[i] += v;
+                        q32[i] += v * v;
+                    }
+                }
+                for (int i = 0; i < AB_RT; i++) {
+                    part[i] = (double)p32[i] * BOUND_F32_SLACK + 1e-30;  // + what FP32 may have flushed to zero
+                    sq[i] = (double)q32[i] * (BOUND_F32_SLACK * BOUND_F32_SLACK) + 1e-60;
+                }
+            } else
             for (int k = 1 + lane; k < nh; k += 64) {
                 const double f = k * df;
                 int lo = st.seg[k];
