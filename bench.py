@@ -69,8 +69,8 @@ def cpu_baseline(n_sample, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)   # clocks and caches settle over the first calls (73 -> 69.5 ms)
     ap.add_argument('--events', type=int, default=1000000, help='events per rank and step')
     ap.add_argument('--cpu-sample', type=int, default=3000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
