@@ -820,10 +820,11 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
             const double x_first = s_xp[0], x_last = s_xp[st.n_fc - 1], dx_last = x_last - s_xp[st.n_fc - 2];
             // Alvarez2009 with all scalars comfortably inside the single-precision range: the 2047-term sum in FP32 (twice the
             // VALU rate, a 1-instruction reciprocal); every term is within ~1e-6 and the sum of positive terms within
-            // 2047 * 6e-8 of the exact one, the result is inflated by BOUND_F32_SLACK and stays an upper bound
+            // 2047 * 6e-8 of the exact one, the result is inflated by BOUND_F32_SLACK and stays an upper bound ((1 + x)(1 + y)
+            // cannot overflow: x, y < 1e15)
             bool f32 = all2009;
             for (int i = 0; i < AB_RT; i++)
-                f32 = f32 && pf[i] > 1e-25 && pf[i] < 1e25 && cL[i] > 1e-25 && cL[i] < 1e25 && cR[i] > 1e-25 && cR[i] < 1e25;
+                f32 = f32 && pf[i] > 1e-25 && pf[i] < 1e25 && cL[i] > 1e-15 && cL[i] < 1e15 && cR[i] > 1e-15 && cR[i] < 1e15;
             if (f32) {
                 float cLf[AB_RT], cRf[AB_RT], pff[AB_RT], pf32[AB_RT];
                 for (int i = 0; i < AB_RT; i++) { cLf[i] = (float)cL[i]; cRf[i] = (float)cR[i]; pff[i] = (float)pf[i]; pf32[i] = 0.f; }
@@ -986,7 +987,7 @@ efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w
             const double x_first = s_xp[0], x_last = s_xp[st.n_fc - 1], dx_last = x_last - s_xp[st.n_fc - 2];
             bool f32 = all2009;  // as in amp_bound_kernel: FP32 sums, inflated
             for (int i = 0; i < AB_RT; i++)
-                f32 = f32 && pf[i] > 1e-18 && pf[i] < 1e18 && cL[i] > 1e-25 && cL[i] < 1e25 && cR[i] > 1e-25 && cR[i] < 1e25;
+                f32 = f32 && pf[i] > 1e-18 && pf[i] < 1e18 && cL[i] > 1e-15 && cL[i] < 1e15 && cR[i] > 1e-15 && cR[i] < 1e15;
             if (f32) {
                 float cLf[AB_RT], cRf[AB_RT], pff[AB_RT], p32[AB_RT], q32[AB_RT];
                 for (int i = 0; i < AB_RT; i++) { cLf[i] = (float)cL[i]; cRf[i] = (float)cR[i]; pff[i] = (float)pf[i]; p32[i] = q32[i] = 0.f; }
