@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 mkdir -p nuradiomc_amd/lib oracle/_build
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRC="nuradiomc_amd/csrc/api.hip nuradiomc_amd/csrc/raytrace.hip nuradiomc_amd/csrc/raytrace_refl.hip nuradiomc_amd/csrc/arz.hip nuradiomc_amd/csrc/birefringence.hip nuradiomc_amd/csrc/attenuation.hip"
+SRC="nuradiomc_amd/csrc/api.hip nuradiomc_amd/csrc/raytrace.hip nuradiomc_amd/csrc/raytrace_refl.hip nuradiomc_amd/csrc/arz.hip nuradiomc_amd/csrc/birefringence.hip nuradiomc_amd/csrc/earth.hip nuradiomc_amd/csrc/attenuation.hip"
 [ -f nuradiomc_amd/csrc/spectral.hip ] && SRC="$SRC nuradiomc_amd/csrc/spectral.hip"
 [ -f nuradiomc_amd/csrc/pipeline.hip ] && SRC="$SRC nuradiomc_amd/csrc/pipeline.hip"
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-function \

@@ -9,6 +9,14 @@ ATTENUATION_MODEL_TO_INT = {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4, "GL3": 5}
 MAXS = 2
 
 
+PROTON_MASS_KG = 1.67262192595e-27  # scipy.constants.m_p (CODATA 2022), what cross_sections.get_interaction_length uses
+
+
+class _EarthModel(ctypes.Structure):  # nrhip_earth_model
+    _fields_ = [('n_layers', ctypes.c_int32), ('reserved', ctypes.c_int32), ('earth_radius', ctypes.c_double),
+                ('radii', ctypes.c_double * 16), ('coef', (ctypes.c_double * 4) * 16)]
+
+
 class Context:
     """Owns a `nrhip_ctx`.  `ice` is (n_ice, delta_n, z_0) of n(z) = n_ice - delta_n exp(z / z_0)."""
 
@@ -227,6 +235,42 @@ class Context:
                                                     float(sampling_rate), spec.view(np.float64).ctypes.data_as(L.c_double_p),
                                                     L.dptr(steps)))
         return (spec, steps[:n_steps]) if return_steps else spec
+
+    def earth_weights_batch(self, zenith, energy, flavor, mode, endpoint=None, direction=None, model=None, step=500.,
+                            nucleon_mass=None, return_slant_depth=False):
+        """Earth-absorption weights of n events (earth_attenuation.get_weight, NuRadioMC/utilities/earth_attenuation.py:12-60,
+        'ctw' cross sections).  mode: 0 'simple', 1 'core_mantle_crust_simple', 2 chord through the layered density
+        `model` = (earth_radius, radii [n_layers], coefficients [n_layers, 4]) from `endpoint` [n, 3] towards `direction`
+        [n, 3] (PREM.slant_depth :183-240)."""
+        zenith = L.f64(zenith).reshape(-1)
+        energy = L.f64(energy).reshape(-1)
+        n = len(zenith)
+        flavor = np.ascontiguousarray(np.broadcast_to(np.asarray(flavor), (n,)), dtype=np.int32)
+        weight = np.ones(n)
+        slant = np.zeros(n)
+        md = None
+        if int(mode) == 2:
+            endpoint = L.f64(endpoint).reshape(n, 3)
+            direction = L.f64(direction).reshape(n, 3)
+            R, radii, coef = model
+            radii = np.asarray(radii, float).reshape(-1)
+            coef = np.asarray(coef, float).reshape(len(radii), 4)
+            if len(radii) > 16:
+                raise ValueError("earth_weights_batch: at most 16 layers")
+            md = _EarthModel()
+            md.n_layers = len(radii)
+            md.earth_radius = float(R)
+            for k in range(len(radii)):
+                md.radii[k] = radii[k]
+                for j in range(4):
+                    md.coef[k][j] = coef[k, j]
+        if nucleon_mass is None:
+            nucleon_mass = PROTON_MASS_KG * 6.241509744511525e+36
+        L.check(self._lib.nrhip_earth_weights_batch(
+            self._h, n, L.dptr(zenith), L.dptr(energy), L.iptr(flavor), None if md is None else L.dptr(endpoint),
+            None if md is None else L.dptr(direction), int(mode), None if md is None else ctypes.byref(md), float(step),
+            float(nucleon_mass), L.dptr(weight), L.dptr(slant) if md is not None else None))
+        return (weight, slant) if return_slant_depth else weight
 
     def attenuation_batch(self, x1, x2, C0, freqs, return_neval=False):
         """exp(-int ds / L_att) for rays (x1[r] -> x2[r], C0[r]) at the given (> 0) frequencies."""

@@ -4,6 +4,7 @@
 #include "ctx.h"
 #include "arz.h"
 #include "birefringence.h"
+#include "earth.h"
 #include <cstdio>
 #include <algorithm>
 #include <cmath>
@@ -496,6 +497,66 @@ int nrhip_birefringence_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, 
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(spectra, dsp.p, nr * 2 * n_f * 16, hipMemcpyDeviceToHost, s));
     if (step_records && off[n_rays] > 0) HIPCHK(hipMemcpyAsync(step_records, dst.p, (size_t)off[n_rays] * 40, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int nrhip_earth_weights_batch(nrhip_ctx* ctx, int64_t n, const double* zenith, const double* energy, const int32_t* flavor,
+                              const double* endpoint, const double* direction, int32_t mode, const nrhip_earth_model* model,
+                              double step, double nucleon_mass, double* weight, double* slant_depth)
+{
+    if (!ctx || !zenith || !energy || !flavor) return fail_msg("nrhip_earth_weights_batch: NULL argument");
+    if (n < 0) return fail_msg("nrhip_earth_weights_batch: negative size");
+    if (mode != NRHIP_EARTH_SIMPLE && mode != NRHIP_EARTH_CORE_MANTLE_CRUST_SIMPLE && mode != NRHIP_EARTH_CHORD)
+        return fail_msg("nrhip_earth_weights_batch: mode not supported");  // NotImplementedError (earth_attenuation.py:58-60)
+    const bool chord = mode == NRHIP_EARTH_CHORD;
+    if (chord) {
+        if (!endpoint || !direction || !model) return fail_msg("nrhip_earth_weights_batch: the chord mode needs endpoint, direction and model");
+        if (model->n_layers < 1 || model->n_layers > NRHIP_EARTH_MAX_LAYERS || !(model->earth_radius > 0))
+            return fail_msg("nrhip_earth_weights_batch: 1..16 layers and earth_radius > 0 required");
+        if (!(step > 0)) return fail_msg("nrhip_earth_weights_batch: step > 0 required");
+    } else if (!weight) {
+        return fail_msg("nrhip_earth_weights_batch: NULL argument");
+    }
+    if (!(nucleon_mass > 0)) return fail_msg("nrhip_earth_weights_batch: nucleon_mass > 0 required");
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t nn = (size_t)n;
+    DevBuf dz, dE, dfl, dep, ddr, dw, dsd;
+    HIPCHK(dz.alloc(nn * 8)); HIPCHK(dE.alloc(nn * 8)); HIPCHK(dfl.alloc(nn * 4)); HIPCHK(dw.alloc(nn * 8));
+#define H2D(dst, src, bytes) HIPCHK(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, s))
+    H2D(dz, zenith, nn * 8); H2D(dE, energy, nn * 8); H2D(dfl, flavor, nn * 4);
+    if (chord) {
+        HIPCHK(dep.alloc(nn * 24)); HIPCHK(ddr.alloc(nn * 24)); HIPCHK(dsd.alloc(nn * 8));
+        H2D(dep, endpoint, nn * 24); H2D(ddr, direction, nn * 24);
+    }
+#undef H2D
+    nrhip::EarthBatch b{};
+    b.n = (long)n; b.zenith = dz.as<double>(); b.energy = dE.as<double>(); b.flavor = dfl.as<int>();
+    b.endpoint = dep.as<double>(); b.direction = ddr.as<double>(); b.mode = mode; b.step = step; b.nucleon_mass = nucleon_mass;
+    const double kg = 6.241509744511525e+36;  // NuRadioReco/utilities/units.py
+    b.amu = 1.66e-27 * kg;                    // earth_attenuation.py:9
+    b.simple_radius = 6357390 * 1.;           // :80-81
+    b.simple_density = 2900 * kg / (1. * 1. * 1.);
+    const double RE = 6.378140e6 * 1.;        // :110-112
+    const double dens[3] = {14000.0, 3400.0, 2900.0};
+    for (int k = 0; k < 3; k++) b.layer_density[k] = dens[k] * kg / (1. * 1. * 1.);
+    b.layer_radii[0] = 3.46e6 * 1.; b.layer_radii[1] = RE - 4.0e4 * 1.; b.layer_radii[2] = RE;
+    b.layer_theta[0] = M_PI - std::asin(b.layer_radii[1] / b.layer_radii[2]);
+    b.layer_theta[1] = M_PI - std::asin(b.layer_radii[0] / b.layer_radii[2]);
+    nrhip::EarthModelDev m{};
+    if (chord) {
+        m.n_layers = model->n_layers; m.earth_radius = model->earth_radius;
+        for (int k = 0; k < model->n_layers; k++) {
+            m.radii[k] = model->radii[k];
+            for (int j = 0; j < 4; j++) m.coef[k][j] = model->coef[k][j];
+        }
+    }
+    nrhip::launch_earth_weights(s, b, m, dw.as<double>(), chord ? dsd.as<double>() : nullptr);
+    HIPCHK(hipGetLastError());
+    if (weight) HIPCHK(hipMemcpyAsync(weight, dw.p, nn * 8, hipMemcpyDeviceToHost, s));
+    if (chord && slant_depth) HIPCHK(hipMemcpyAsync(slant_depth, dsd.p, nn * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return 0;
 }

@@ -369,3 +369,27 @@ def test_phased_array_core_vs_reference():
             p = so.phased_array_power(g['traces_%d' % k][e], rolls, int(window), int(step))
             ref = g['power_%d' % k][e]
             assert p.shape == ref.shape and np.max(np.abs(p - ref)) <= 1e-12 * np.max(ref)
+
+
+def test_earth_weights_vs_reference():
+    """oracle/earth_oracle.py against earth_attenuation.get_weight of the reference (tests/golden/gen/gen_earth_weights.py):
+    cross sections, interaction lengths, slant depths of both layered models and the weights of all four modes.  The
+    restatement reproduces every double of the reference run (same operations in the same order), which matters here:
+    the surface sample of a chord counts with the crust's density or with 0 depending on the last bit of its radius."""
+    from oracle import earth_oracle as eo
+    g = golden('ref_earth_weights.npz')
+    n = len(g['zenith'])
+    assert np.array_equal(eo.ctw_total(g['energy'], g['flavor']), g['sigma_total'])
+    assert np.array_equal(eo.interaction_length_unit_density(g['energy'], g['flavor']), g['L_int_unit_density'])
+    for name in ('core_mantle_crust', 'PREM'):
+        model = eo.earth_model(name)
+        sd = np.array([eo.slant_depth(g['vertex'][i], g['zenith'][i], g['azimuth'][i], model) for i in range(n)])
+        ref = g['slant_depth_' + name]
+        assert np.array_equal(sd == 0, ref == 0)
+        assert (ref > 0).sum() > 300
+        assert max_rel(sd[ref > 0], ref[ref > 0]) < 1e-13
+    for mode in ('simple', 'core_mantle_crust_simple', 'core_mantle_crust', 'PREM'):
+        w = eo.get_weight(g['zenith'], g['azimuth'], g['energy'], g['flavor'], g['vertex'], mode)
+        ref = g['weight_' + mode]
+        assert ref.max() == 1. and ref.min() < 1e-50
+        assert np.max(np.abs(w - ref)) < 1e-13 and max_rel(w[ref > 1e-200], ref[ref > 1e-200]) < 1e-10, mode
