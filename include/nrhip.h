@@ -403,8 +403,9 @@ int64_t nrhip_sim_fetch(nrhip_station* st, const char* name, void* host_dst, uin
 
 /* ---- per-event Earth-absorption weight (row f2) ----------------------------------------------------------------------
  * earth_attenuation.get_weight (NuRadioMC/utilities/earth_attenuation.py:12-60; one call per event group from
- * simulation.py:880-903) with cross_section_type 'ctw' (NuRadioMC/utilities/cross_sections.py:64-120, :301-311; the
- * interaction length of :393-421), for n events at once.
+ * simulation.py:880-903) for n events at once; cross sections evaluated on the device: NRHIP_XS_CTW ('ctw',
+ * NuRadioMC/utilities/cross_sections.py:64-120, :301-311) and NRHIP_XS_GHANDI ('ghandi', :280-281); interaction length
+ * as :393-421.
  *   NRHIP_EARTH_SIMPLE                    get_simple_weight (:63-86)
  *   NRHIP_EARTH_CORE_MANTLE_CRUST_SIMPLE  get_core_mantle_crust_weight (:89-130)
  *   NRHIP_EARTH_CHORD                     'core_mantle_crust' / 'PREM' (:39-57): exp(-slant_depth / L_int), slant_depth =
@@ -413,11 +414,13 @@ int64_t nrhip_sim_fetch(nrhip_station* st, const char* name, void* host_dst, uin
  * endpoint [n][3]: vertex, z < 0 below the surface; direction [n][3]: hp.spherical_to_cartesian(zenith, azimuth) of the
  * arrival direction as the caller computed it (normalised on the device as :211 does) -- both only read in the chord
  * mode.  flavor: PDG code (< 0 antiparticle).  nucleon_mass = constants.m_p * units.kg.  weight [n] and slant_depth [n]
- * (chord mode only) may each be NULL.  Energies below 1e4 GeV give NaN (cross_sections.py:69-76).  HOST pointers.   */
+ * (chord mode only) may each be NULL.  'ctw' below 1e4 GeV gives NaN (cross_sections.py:69-76).  HOST pointers.   */
 #define NRHIP_EARTH_SIMPLE 0
 #define NRHIP_EARTH_CORE_MANTLE_CRUST_SIMPLE 1
 #define NRHIP_EARTH_CHORD 2
 #define NRHIP_EARTH_MAX_LAYERS 16
+#define NRHIP_XS_CTW 0
+#define NRHIP_XS_GHANDI 1
 typedef struct {
     int32_t n_layers;
     int32_t reserved;
@@ -426,8 +429,9 @@ typedef struct {
     double coef[NRHIP_EARTH_MAX_LAYERS][4];  /* rho(x) = ((c0 + c1 x) + c2 x^2) + c3 x^3, x = r / earth_radius          */
 } nrhip_earth_model;
 int nrhip_earth_weights_batch(nrhip_ctx* ctx, int64_t n, const double* zenith, const double* energy, const int32_t* flavor,
-                              const double* endpoint, const double* direction, int32_t mode, const nrhip_earth_model* model,
-                              double step, double nucleon_mass, double* weight, double* slant_depth);
+                              const double* endpoint, const double* direction, int32_t mode, int32_t cross_section_type,
+                              const nrhip_earth_model* model, double step, double nucleon_mass, double* weight,
+                              double* slant_depth);
 
 /* efieldToVoltageConverter.run(evt, station, det) (NuRadioReco/modules/efieldToVoltageConverter.py:111-345) for ONE
  * station event on arbitrary electric fields -- the module-level drop-in.  efield e: time-domain traces

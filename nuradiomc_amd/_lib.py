@@ -67,7 +67,7 @@ def load():
          [vp, i64, c_double_p, c_double_p, c_double_p, c_double_p, c_int32_p, c_double_p, c_double_p, ctypes.c_double,
           ctypes.c_double, i32, ctypes.c_double, c_double_p, c_double_p])
     _sig(lib, 'nrhip_earth_weights_batch', ctypes.c_int,
-         [vp, i64, c_double_p, c_double_p, c_int32_p, c_double_p, c_double_p, i32, ctypes.c_void_p, ctypes.c_double,
+         [vp, i64, c_double_p, c_double_p, c_int32_p, c_double_p, c_double_p, i32, i32, ctypes.c_void_p, ctypes.c_double,
           ctypes.c_double, c_double_p, c_double_p])
     for name, sig in _OPTIONAL.items():
         if hasattr(lib, name):

@@ -9,6 +9,7 @@ ATTENUATION_MODEL_TO_INT = {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4, "GL3": 5}
 MAXS = 2
 
 
+CROSS_SECTION_TO_INT = {'ctw': 0, 'ghandi': 1}
 PROTON_MASS_KG = 1.67262192595e-27  # scipy.constants.m_p (CODATA 2022), what cross_sections.get_interaction_length uses
 
 
@@ -237,11 +238,13 @@ class Context:
         return (spec, steps[:n_steps]) if return_steps else spec
 
     def earth_weights_batch(self, zenith, energy, flavor, mode, endpoint=None, direction=None, model=None, step=500.,
-                            nucleon_mass=None, return_slant_depth=False):
-        """Earth-absorption weights of n events (earth_attenuation.get_weight, NuRadioMC/utilities/earth_attenuation.py:12-60,
-        'ctw' cross sections).  mode: 0 'simple', 1 'core_mantle_crust_simple', 2 chord through the layered density
+                            nucleon_mass=None, return_slant_depth=False, cross_section_type='ctw'):
+        """Earth-absorption weights of n events (earth_attenuation.get_weight, NuRadioMC/utilities/earth_attenuation.py:12-60;
+        cross_section_type 'ctw' or 'ghandi').  mode: 0 'simple', 1 'core_mantle_crust_simple', 2 chord through the layered density
         `model` = (earth_radius, radii [n_layers], coefficients [n_layers, 4]) from `endpoint` [n, 3] towards `direction`
         [n, 3] (PREM.slant_depth :183-240)."""
+        if cross_section_type not in CROSS_SECTION_TO_INT:
+            raise NotImplementedError("Cross-section {} not defined on the device ('ctw', 'ghandi')".format(cross_section_type))
         zenith = L.f64(zenith).reshape(-1)
         energy = L.f64(energy).reshape(-1)
         n = len(zenith)
@@ -268,7 +271,8 @@ class Context:
             nucleon_mass = PROTON_MASS_KG * 6.241509744511525e+36
         L.check(self._lib.nrhip_earth_weights_batch(
             self._h, n, L.dptr(zenith), L.dptr(energy), L.iptr(flavor), None if md is None else L.dptr(endpoint),
-            None if md is None else L.dptr(direction), int(mode), None if md is None else ctypes.byref(md), float(step),
+            None if md is None else L.dptr(direction), int(mode), CROSS_SECTION_TO_INT[cross_section_type],
+            None if md is None else ctypes.byref(md), float(step),
             float(nucleon_mass), L.dptr(weight), L.dptr(slant) if md is not None else None))
         return (weight, slant) if return_slant_depth else weight
 

@@ -502,13 +502,16 @@ int nrhip_birefringence_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, 
 }
 
 int nrhip_earth_weights_batch(nrhip_ctx* ctx, int64_t n, const double* zenith, const double* energy, const int32_t* flavor,
-                              const double* endpoint, const double* direction, int32_t mode, const nrhip_earth_model* model,
-                              double step, double nucleon_mass, double* weight, double* slant_depth)
+                              const double* endpoint, const double* direction, int32_t mode, int32_t cross_section_type,
+                              const nrhip_earth_model* model, double step, double nucleon_mass, double* weight,
+                              double* slant_depth)
 {
     if (!ctx || !zenith || !energy || !flavor) return fail_msg("nrhip_earth_weights_batch: NULL argument");
     if (n < 0) return fail_msg("nrhip_earth_weights_batch: negative size");
     if (mode != NRHIP_EARTH_SIMPLE && mode != NRHIP_EARTH_CORE_MANTLE_CRUST_SIMPLE && mode != NRHIP_EARTH_CHORD)
         return fail_msg("nrhip_earth_weights_batch: mode not supported");  // NotImplementedError (earth_attenuation.py:58-60)
+    if (cross_section_type != NRHIP_XS_CTW && cross_section_type != NRHIP_XS_GHANDI)
+        return fail_msg("nrhip_earth_weights_batch: Cross-section not defined");  // cross_sections.py:387-389
     const bool chord = mode == NRHIP_EARTH_CHORD;
     if (chord) {
         if (!endpoint || !direction || !model) return fail_msg("nrhip_earth_weights_batch: the chord mode needs endpoint, direction and model");
@@ -534,7 +537,7 @@ int nrhip_earth_weights_batch(nrhip_ctx* ctx, int64_t n, const double* zenith, c
 #undef H2D
     nrhip::EarthBatch b{};
     b.n = (long)n; b.zenith = dz.as<double>(); b.energy = dE.as<double>(); b.flavor = dfl.as<int>();
-    b.endpoint = dep.as<double>(); b.direction = ddr.as<double>(); b.mode = mode; b.step = step; b.nucleon_mass = nucleon_mass;
+    b.endpoint = dep.as<double>(); b.direction = ddr.as<double>(); b.mode = mode; b.cross_section_type = cross_section_type; b.step = step; b.nucleon_mass = nucleon_mass;
     const double kg = 6.241509744511525e+36;  // NuRadioReco/utilities/units.py
     b.amu = 1.66e-27 * kg;                    // earth_attenuation.py:9
     b.simple_radius = 6357390 * 1.;           // :80-81

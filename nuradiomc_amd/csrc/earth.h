@@ -21,6 +21,7 @@ struct EarthBatch {
     const double* endpoint;      // [n][3] vertex, surface-centred (z < 0 below the surface)      (chord modes)
     const double* direction;     // [n][3] spherical_to_cartesian(zenith, azimuth), not normalised (chord modes)
     int mode;                    // NRHIP_EARTH_*
+    int cross_section_type;      // NRHIP_XS_*
     double step;                 // integration step of the chord (500 m)
     double nucleon_mass;         // constants.m_p * units.kg
     double amu;                  // earth_attenuation.AMU

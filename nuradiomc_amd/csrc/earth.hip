@@ -1,5 +1,6 @@
 // earth.hip -- per-event Earth-absorption weight (NuRadioMC/utilities/earth_attenuation.py:12-60, called per event group by
-// simulation.py:880-903) with the 'ctw' cross sections (NuRadioMC/utilities/cross_sections.py:64-120, :301-311, :393-421).
+// simulation.py:880-903) with the 'ctw' and 'ghandi' cross sections (NuRadioMC/utilities/cross_sections.py:64-120, :280-281,
+// :301-311, :393-421).
 //
 // Chord modes ('core_mantle_crust', 'PREM'; PREM.slant_depth :183-240): a wave per event.  The column density is the
 // trapezoid rule over n_steps = int(distance / step) (+1) samples spread from the vertex to the surface, up to 25 500 of them
@@ -30,6 +31,13 @@ __device__ inline double ctw_total(double energy, int flavor)
     if (flavor >= 0)
         return ctw_param(energy, -1.826, -17.31, -6.448, 1.431, -18.61) + ctw_param(energy, -1.826, -17.31, -6.406, 1.431, -17.91);
     return ctw_param(energy, -1.033, -15.95, -7.296, 1.569, -18.30) + ctw_param(energy, -1.033, -15.95, -7.247, 1.569, -17.72);
+}
+
+// get_nu_cross_section(..., inttype='total') of the cross-section models evaluated here
+__device__ inline double total_cross_section(int type, double energy, int flavor)
+{
+    if (type == NRHIP_XS_GHANDI) return 7.84e-36 * (0.01 * 0.01) * pow(energy / 1e9, 0.363);  // :280-281
+    return ctw_total(energy, flavor);
 }
 
 __device__ inline double dot3_blas(double a0, double a1, double a2, double b0, double b1, double b2)
@@ -95,7 +103,7 @@ earth_chord_kernel(EarthBatch b, EarthModelDev m, double* __restrict__ weight, d
         if (slant_out) slant_out[ev] = slant;
         if (weight) {
             // get_interaction_length(density=1.) (:393-421): m_n / sigma / density
-            const double L_int = b.nucleon_mass / ctw_total(b.energy[ev], b.flavor[ev]) / 1.;
+            const double L_int = b.nucleon_mass / total_cross_section(b.cross_section_type, b.energy[ev], b.flavor[ev]) / 1.;
             weight[ev] = exp(-slant / L_int);
         }
     }
@@ -110,11 +118,11 @@ earth_closed_form_kernel(EarthBatch b, double* __restrict__ weight)
     double w = 1.;
     if (!(th <= 0.5 * M_PI)) {  // coming from below
         if (b.mode == NRHIP_EARTH_SIMPLE) {
-            const double sigma = ctw_total(b.energy[ev], 0);  // flavors=0 (:83)
+            const double sigma = total_cross_section(b.cross_section_type, b.energy[ev], 0);  // flavors=0 (:83)
             const double d = -2 * b.simple_radius * cos(th);
             w = exp(-d * sigma * b.simple_density / b.amu);
         } else {
-            const double sigma = ctw_total(b.energy[ev], b.flavor[ev]);
+            const double sigma = total_cross_section(b.cross_section_type, b.energy[ev], b.flavor[ev]);
             const double RE = b.layer_radii[2];
             const double s = sin(M_PI - th);
             if (th <= b.layer_theta[0]) {          // only the outer layer

@@ -3,8 +3,8 @@
 lists at once (nrhip_earth_weights_batch).  simulation.py:880-903 calls get_weight once per event group with scalars;
 here the same arguments may be arrays of n events and the scalars of the reference are the n = 1 case.
 
-Only cross_section_type 'ctw' (the reference's config_default.yaml) is evaluated on the device; the tabulated cross
-sections ('csms', 'hedis_bgr18') raise NotImplementedError.
+cross_section_type 'ctw' (the reference's config_default.yaml) and 'ghandi' are evaluated on the device; the tabulated
+cross sections ('csms', 'hedis_bgr18': a data file) raise NotImplementedError.
 """
 import numpy as np
 from .context import Context
@@ -69,8 +69,8 @@ def get_weight(theta_nu, pnu, flavors, mode='simple', cross_section_type='ctw', 
         return 1.
     if mode not in ('simple', 'core_mantle_crust_simple', 'core_mantle_crust', 'PREM'):
         raise NotImplementedError('mode {} not supported'.format(mode))
-    if cross_section_type != 'ctw':
-        raise NotImplementedError("cross section {} is not evaluated on the device (only 'ctw')".format(cross_section_type))
+    if cross_section_type not in ('ctw', 'ghandi'):
+        raise NotImplementedError("cross section {} is not evaluated on the device ('ctw', 'ghandi')".format(cross_section_type))
     scalar = np.ndim(theta_nu) == 0
     theta = np.atleast_1d(np.asarray(theta_nu, float))
     n = len(theta)
@@ -78,14 +78,15 @@ def get_weight(theta_nu, pnu, flavors, mode='simple', cross_section_type='ctw', 
     flavors = np.broadcast_to(np.asarray(flavors), (n,))
     ctx = ctx if ctx is not None else _default_context()
     if mode == 'simple':
-        w = ctx.earth_weights_batch(theta, pnu, flavors, 0)
+        w = ctx.earth_weights_batch(theta, pnu, flavors, 0, cross_section_type=cross_section_type)
     elif mode == 'core_mantle_crust_simple':
-        w = ctx.earth_weights_batch(theta, pnu, flavors, 1)
+        w = ctx.earth_weights_batch(theta, pnu, flavors, 1, cross_section_type=cross_section_type)
     else:
         earth = CoreMantleCrustModel(ctx) if mode == 'core_mantle_crust' else PREM(ctx)
         phi = np.broadcast_to(np.asarray(phi_nu, float), (n,))
         # hp.spherical_to_cartesian(theta_nu, phi_nu)
         direction = np.stack([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)], axis=1)
         vertex = np.asarray(vertex_position, float).reshape(n, 3)
-        w = ctx.earth_weights_batch(theta, pnu, flavors, 2, endpoint=vertex, direction=direction, model=earth._model())
+        w = ctx.earth_weights_batch(theta, pnu, flavors, 2, endpoint=vertex, direction=direction, model=earth._model(),
+                                    cross_section_type=cross_section_type)
     return float(w[0]) if scalar else w

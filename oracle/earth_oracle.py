@@ -94,9 +94,22 @@ def ctw_total(energy, flavor):
     return out
 
 
-def interaction_length_unit_density(energy, flavor, proton_mass_kg=PROTON_MASS_KG):
+def ghandi(energy):
+    """get_nu_cross_section(..., cross_section_type='ghandi') (:280-281)"""
+    return 7.84e-36 * CM ** 2 * np.power(np.atleast_1d(np.asarray(energy, dtype=float)) / GEV, 0.363)
+
+
+def total_cross_section(energy, flavor, cross_section_type='ctw'):
+    if cross_section_type == 'ctw':
+        return ctw_total(energy, flavor)
+    if cross_section_type == 'ghandi':
+        return ghandi(energy)
+    raise NotImplementedError(cross_section_type)
+
+
+def interaction_length_unit_density(energy, flavor, proton_mass_kg=PROTON_MASS_KG, cross_section_type='ctw'):
     """get_interaction_length(density=1.) (:393-421)"""
-    return proton_mass_kg * KG / ctw_total(energy, flavor) / 1.
+    return proton_mass_kg * KG / total_cross_section(energy, flavor, cross_section_type) / 1.
 
 
 def density(r, model):
@@ -145,8 +158,8 @@ def slant_depth(vertex, zenith, azimuth, model, step=STEP, return_samples=False)
     return res
 
 
-def get_weight(zenith, azimuth, energy, flavor, vertex, mode, step=STEP, proton_mass_kg=PROTON_MASS_KG):
-    """get_weight (:12-60) for arrays of events, cross_section_type 'ctw'"""
+def get_weight(zenith, azimuth, energy, flavor, vertex, mode, step=STEP, proton_mass_kg=PROTON_MASS_KG, cross_section_type='ctw'):
+    """get_weight (:12-60) for arrays of events, cross_section_type 'ctw' or 'ghandi'"""
     zenith, azimuth, energy = (np.atleast_1d(np.asarray(a, dtype=float)) for a in (zenith, azimuth, energy))
     flavor = np.atleast_1d(flavor)
     n = len(zenith)
@@ -154,7 +167,7 @@ def get_weight(zenith, azimuth, energy, flavor, vertex, mode, step=STEP, proton_
     if mode in ('None', None):
         return w
     if mode == 'simple':                                   # :63-86, flavors = 0 -> particle cross section
-        sigma = ctw_total(energy, np.zeros(n, dtype=int))
+        sigma = total_cross_section(energy, np.zeros(n, dtype=int), cross_section_type)
         for i in range(n):
             if zenith[i] > 0.5 * np.pi:
                 dd = -2 * (6357390 * 1.) * np.cos(zenith[i])
@@ -164,7 +177,7 @@ def get_weight(zenith, azimuth, energy, flavor, vertex, mode, step=STEP, proton_
         RE = 6.378140e6
         dens = np.array([14000.0, 3400.0, 2900.0]) * KG / 1. ** 3
         radii = np.array([3.46e6, RE - 4.0e4, RE])
-        sigma = ctw_total(energy, flavor)
+        sigma = total_cross_section(energy, flavor, cross_section_type)
         for i in range(n):
             th, s = zenith[i], sigma[i]
             if th <= 0.5 * np.pi:
@@ -184,7 +197,7 @@ def get_weight(zenith, azimuth, energy, flavor, vertex, mode, step=STEP, proton_
         return w
     model = earth_model(mode)
     vertex = np.asarray(vertex, dtype=float).reshape(n, 3)
-    L = interaction_length_unit_density(energy, flavor, proton_mass_kg)
+    L = interaction_length_unit_density(energy, flavor, proton_mass_kg, cross_section_type)
     for i in range(n):
         w[i] = np.exp(-slant_depth(vertex[i], zenith[i], azimuth[i], model, step) / L[i])
     return w

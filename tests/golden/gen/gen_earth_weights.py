@@ -36,6 +36,11 @@ for mode in ['simple', 'core_mantle_crust_simple', 'core_mantle_crust', 'PREM']:
                                             cross_section_type='ctw', vertex_position=vertex[i].copy(),
                                             phi_nu=float(azimuth[i]))
     out['weight_' + mode] = w
+# 'ghandi' cross section (cross_sections.py:280-281: one power law for all flavours and interactions)
+for mode in ['simple', 'core_mantle_crust_simple', 'core_mantle_crust', 'PREM']:
+    out['weight_ghandi_' + mode] = np.array([
+        earth_attenuation.get_weight(float(zenith[i]), float(energy[i]), int(flavor[i]), mode=mode, cross_section_type='ghandi',
+                                     vertex_position=vertex[i].copy(), phi_nu=float(azimuth[i])) for i in range(n)])
 # the ingredients, for pinning the restatement piece by piece
 out['sigma_total'] = np.array([cross_sections.get_nu_cross_section(float(e), int(f), inttype='total', cross_section_type='ctw')
                                for e, f in zip(energy, flavor)])

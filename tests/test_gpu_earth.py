@@ -32,6 +32,10 @@ def test_weights_vs_reference_and_oracle(ctx):
         assert np.max(np.abs(w - ref)) < 1e-9, mode
         wo = eo.get_weight(g['zenith'], g['azimuth'], g['energy'], g['flavor'], g['vertex'], mode)
         assert max_rel(w[big], wo[big]) < 1e-6, mode
+        wg = ea.get_weight(g['zenith'], g['energy'], g['flavor'], mode=mode, cross_section_type='ghandi',
+                           vertex_position=g['vertex'], phi_nu=g['azimuth'], ctx=ctx)
+        ref = g['weight_ghandi_' + mode]
+        assert max_rel(wg[ref > 1e-100], ref[ref > 1e-100]) < 1e-6 and np.max(np.abs(wg - ref)) < 1e-9, mode
     for i in (0, 1, 2, 7, 42, 103):
         w1 = ea.get_weight(float(g['zenith'][i]), float(g['energy'][i]), int(g['flavor'][i]), mode='core_mantle_crust',
                            cross_section_type='ctw', vertex_position=g['vertex'][i], phi_nu=float(g['azimuth'][i]), ctx=ctx)
@@ -60,6 +64,8 @@ def test_errors_and_edges(ctx):
     assert ea.PREM(ctx).slant_depth(np.array([0., 0., 10.]), np.array([0., 0., 1.])) == 0.
     with pytest.raises(nr.NrhipError):
         ctx.earth_weights_batch(np.ones(2), np.full(2, 1e18), np.full(2, 12), 5)
+    with pytest.raises(NotImplementedError):
+        ctx.earth_weights_batch(np.ones(2), np.full(2, 1e18), np.full(2, 12), 0, cross_section_type='hedis_bgr18')
 
 
 def test_full_size_properties(ctx):

@@ -393,3 +393,6 @@ def test_earth_weights_vs_reference():
         ref = g['weight_' + mode]
         assert ref.max() == 1. and ref.min() < 1e-50
         assert np.max(np.abs(w - ref)) < 1e-13 and max_rel(w[ref > 1e-200], ref[ref > 1e-200]) < 1e-10, mode
+        w = eo.get_weight(g['zenith'], g['azimuth'], g['energy'], g['flavor'], g['vertex'], mode, cross_section_type='ghandi')
+        ref = g['weight_ghandi_' + mode]
+        assert np.max(np.abs(w - ref)) < 1e-13 and max_rel(w[ref > 1e-200], ref[ref > 1e-200]) < 1e-10, mode
