@@ -52,6 +52,7 @@ __device__ inline double earth_density(double r, const EarthModelDev& m)
     for (int k = 0; k < m.n_layers; k++) {
         const double upper = m.radii[k];
         if (lower <= r && r < upper) {
+            if (m.coef[k][1] == 0. && m.coef[k][2] == 0. && m.coef[k][3] == 0.) return m.coef[k][0];  // constant layer: same double
             const double x = r / m.earth_radius;
             return ((m.coef[k][0] + m.coef[k][1] * x) + m.coef[k][2] * (x * x)) + m.coef[k][3] * (x * x * x);
         }
