@@ -17,7 +17,10 @@
 namespace nrhip {
 
 // Kernel: pair i = (event i / n_ch, channel i % n_ch) when n_ch > 0, else x2 is per pair.
-__global__ void __launch_bounds__(256, 6)
+#ifndef NRHIP_RT_WAVES
+#define NRHIP_RT_WAVES 6  // waves per SIMD the register budget is cut for (measured best)
+#endif
+__global__ void __launch_bounds__(256, NRHIP_RT_WAVES)
 raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
                 IceConst m, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm,
                 const double* __restrict__ given_C0)
