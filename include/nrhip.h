@@ -291,6 +291,19 @@ typedef struct {
        focusing_limit, times sqrt(n(vertex) / n(receiver)).  Doubles the ray-tracing work.                          */
     int32_t focusing;
     double focusing_limit;
+    /* two-phase runs (the host draws stateful random shower parameters -- Alvarez2009's k_L, the ARZ profile number -- in the
+       order in which the reference meets the showers, simulation.py:221-242, between the phases):
+       select_only != 0: stop after ray tracing and the delta_C cut; tables "pair_n_sol", "slot_*", "slot_keep" and
+       "shower_first_channel" (int32 [n_showers]: first channel of this station with a kept ray, -1 = none) are fetchable,
+       `triggered` is zeroed, stats carries n_pairs / n_rays.
+       reuse_ray_tables != 0: skip ray tracing and the cut -- the tables of the previous call with the same vertex pointer,
+       shower count, station position and delta_C_cut are used (anything else fails). */
+    int32_t select_only;
+    int32_t reuse_ray_tables;
+    /* != 0: `triggered` is not zeroed first, triggers are OR-ed into it -- the event-group mask of an array simulated station
+       by station (simulation.py:1500: "each station is treated independently"; an event group is kept when any station
+       triggered); stats->n_triggered then counts the accumulated mask */
+    int32_t accumulate_triggered;
 } nrhip_sim_config;
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1
@@ -443,6 +456,28 @@ int nrhip_earth_weights_batch(nrhip_ctx* ctx, int64_t n, const double* zenith, c
 int nrhip_efield_to_voltage(nrhip_ctx* ctx, nrhip_station* st, int32_t n_efields, const double* traces,
                             const double* t0, const double* zenith, const double* azimuth, const int32_t* channel,
                             int32_t apply_filters, int32_t L, double t_min, double* V);
+
+/* ---- multi-GPU: one process per GPU, events sharded, ONE collective ------------------------------
+ * The reference scales out as N independent processes over a split event list (NuRadioMC/utilities/runner.py:9-15) and merges
+ * their output files afterwards (utilities/merge_hdf5.py); here rank r of W simulates its contiguous slice of the list and the
+ * per-rank uint8 triggered masks are all-gathered over xGMI -- RCCL, bound directly (librccl.so is opened on first use).
+ * nrhip_comm_get_unique_id: rank 0 makes the communicator id and hands the 128 bytes to the other processes through any
+ * host channel (nuradiomc_amd/comm.py: a TCP socket on MASTER_ADDR); nrhip_comm_create: collective over all ranks, on the
+ * context's GPU and stream.  Buffers are DEV pointers of that GPU; calls are asynchronous on the context's stream
+ * (nrhip_synchronize), nrhip_comm_barrier returns when every rank's stream has drained.
+ * nrhip_comm_allgather_u8: recv[r * count_per_rank + i] = send_r[i] (pad unequal shards to the largest one).          */
+#define NRHIP_COMM_ID_BYTES 128
+typedef struct nrhip_comm nrhip_comm;
+int nrhip_comm_get_unique_id(uint8_t id[NRHIP_COMM_ID_BYTES]);
+int nrhip_comm_create(nrhip_ctx* ctx, const uint8_t id[NRHIP_COMM_ID_BYTES], int32_t rank, int32_t world_size, nrhip_comm** out);
+void nrhip_comm_destroy(nrhip_comm* comm);
+int nrhip_comm_barrier(nrhip_comm* comm);
+int nrhip_comm_allgather_u8(nrhip_comm* comm, const uint8_t* send, uint8_t* recv, int64_t count_per_rank);
+int nrhip_comm_allreduce_i64_sum(nrhip_comm* comm, int64_t* buf, int32_t n);
+int nrhip_comm_allreduce_f64_max(nrhip_comm* comm, double* buf, int32_t n);
+
+/* dst[i] = overwrite ? src[i] : dst[i] | src[i] on DEV uint8 masks (event-group mask of an array = OR over its stations) */
+int nrhip_mask_or(nrhip_ctx* ctx, int64_t n, uint8_t* dst, const uint8_t* src, int32_t overwrite);
 
 /* test hook for the in-LDS chirp-z transform: out[b][k] = sum_j in[b][j] exp(sgn 2 pi i j k / Q). HOST. */
 int nrhip_debug_czt(nrhip_ctx* ctx, int32_t n_batch, int32_t n_in, int32_t n_out, int32_t Q, double sgn,

@@ -1,0 +1,181 @@
+"""Multi-GPU plumbing without PyTorch: one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the
+launcher's environment), RCCL bound through the C ABI (nrhip_comm_*, include/nrhip.h).
+
+The reference scales out as independent processes over a split event list (NuRadioMC/utilities/runner.py:9-15); here the
+split is `shard_range` and the merge of the outputs is ONE all-gather of the triggered masks over xGMI.
+
+The only thing that has to travel between the processes on the host is RCCL's 128-byte communicator id: rank 0 serves it on
+a TCP socket (MASTER_ADDR, NRHIP_COMM_PORT or MASTER_PORT + 1000), the other ranks fetch it.  Standard library only.
+"""
+import ctypes
+import os
+import socket
+import time
+import numpy as np
+from . import _lib as L
+
+ID_BYTES = 128
+
+L._OPTIONAL.update({
+    'nrhip_comm_get_unique_id': (ctypes.c_int, [ctypes.c_void_p]),
+    'nrhip_comm_create': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_void_pp]),
+    'nrhip_comm_destroy': (None, [ctypes.c_void_p]),
+    'nrhip_comm_barrier': (ctypes.c_int, [ctypes.c_void_p]),
+    'nrhip_comm_allgather_u8': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    'nrhip_comm_allreduce_i64_sum': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
+    'nrhip_comm_allreduce_f64_max': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
+    'nrhip_mask_or': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
+})
+
+
+def shard_range(n_events, rank, world_size):
+    """contiguous, balanced: the first n % W ranks get one extra event"""
+    base, extra = divmod(int(n_events), int(world_size))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_chunks(n_events, rank, world_size, chunk):
+    """Chunked round-robin assignment for SORTED event lists (energy- or position-ordered inputs would load contiguous shards
+    unequally): chunk c of `chunk` events goes to rank c % W.  Returns the index array of this rank's events (ascending)."""
+    n_events, chunk = int(n_events), max(1, int(chunk))
+    idx = np.arange(n_events)
+    return idx[(idx // chunk) % world_size == rank]
+
+
+def env_rank():
+    """(rank, local_rank, world_size) from the launcher's environment (torch.distributed.run, mpirun-style wrappers)"""
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+
+
+def exchange_bytes(payload, rank, world_size, addr=None, port=None, timeout=300.):
+    """rank 0 hands `payload` (bytes) to every other rank over TCP; returns it on every rank."""
+    if world_size == 1:
+        return payload
+    addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(port or os.environ.get('NRHIP_COMM_PORT', 0) or int(os.environ.get('MASTER_PORT', 29500)) + 1000)
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world_size)
+        srv.settimeout(timeout)
+        try:
+            for _ in range(world_size - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(len(payload).to_bytes(4, 'little') + payload)
+        finally:
+            srv.close()
+        return payload
+    t_end = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.) as c:
+                c.settimeout(timeout)
+                buf = b''
+                while len(buf) < 4:
+                    d = c.recv(4 - len(buf))
+                    if not d:
+                        raise ConnectionError("peer closed")
+                    buf += d
+                n = int.from_bytes(buf, 'little')
+                out = b''
+                while len(out) < n:
+                    d = c.recv(n - len(out))
+                    if not d:
+                        raise ConnectionError("peer closed")
+                    out += d
+                return out
+        except (ConnectionRefusedError, ConnectionError, socket.timeout, OSError):
+            if time.time() > t_end:
+                raise
+            time.sleep(0.05)
+
+
+class Comm:
+    """RCCL communicator of one process (one GPU) over nrhip_comm_*; world_size 1 needs no RCCL and every call is local."""
+
+    def __init__(self, ctx, rank=None, world_size=None, addr=None, port=None):
+        r, _, w = env_rank()
+        self.ctx = ctx
+        self.rank = r if rank is None else int(rank)
+        self.world_size = w if world_size is None else int(world_size)
+        self._lib = L.load()
+        self._h = None
+        if self.world_size > 1:
+            uid = (ctypes.c_uint8 * ID_BYTES)()
+            if self.rank == 0:
+                L.check(self._lib.nrhip_comm_get_unique_id(uid))
+            raw = exchange_bytes(bytes(uid), self.rank, self.world_size, addr, port)
+            uid = (ctypes.c_uint8 * ID_BYTES).from_buffer_copy(raw)
+            h = ctypes.c_void_p()
+            L.check(self._lib.nrhip_comm_create(ctx._h, uid, self.rank, self.world_size, ctypes.byref(h)))
+            self._h = h
+
+    def barrier(self):
+        if self._h is None:
+            self.ctx.synchronize()
+        else:
+            L.check(self._lib.nrhip_comm_barrier(self._h))
+
+    def allgather_masks(self, d_local, n_local, n_total):
+        """All-gather the per-rank DEVICE uint8 masks of a list of n_total events sharded with shard_range: returns the full host
+        mask [n_total] (same on every rank).  The one collective of the path (padded to the largest shard)."""
+        if self._h is None:
+            out = np.zeros(n_local, np.uint8)
+            self.ctx.to_host(out, d_local)
+            return out
+        W = self.world_size
+        sizes = [shard_range(n_total, k, W)[1] - shard_range(n_total, k, W)[0] for k in range(W)]
+        pad = max(sizes)
+        d_send = self.ctx.malloc(max(pad, 1))
+        d_recv = self.ctx.malloc(max(W * pad, 1))
+        try:
+            L.check(self._lib.nrhip_mask_or(self.ctx._h, n_local, ctypes.c_void_p(d_send), ctypes.c_void_p(d_local), 1))
+            L.check(self._lib.nrhip_comm_allgather_u8(self._h, ctypes.c_void_p(d_send), ctypes.c_void_p(d_recv), pad))
+            host = np.zeros(W * pad, np.uint8)
+            self.ctx.to_host(host, d_recv)
+        finally:
+            self.ctx.free(d_send)
+            self.ctx.free(d_recv)
+        host = host.reshape(W, pad)
+        return np.concatenate([host[k, :sizes[k]] for k in range(W)])
+
+    def allreduce_sum(self, values):
+        """element-wise sum of a small int64 vector over the ranks"""
+        v = np.ascontiguousarray(values, np.int64)
+        if self._h is None:
+            return v.copy()
+        d = self.ctx.to_device(v)
+        try:
+            L.check(self._lib.nrhip_comm_allreduce_i64_sum(self._h, ctypes.c_void_p(d), len(v)))
+            out = np.zeros_like(v)
+            self.ctx.to_host(out, d)
+        finally:
+            self.ctx.free(d)
+        return out
+
+    def allreduce_max(self, values):
+        v = np.ascontiguousarray(values, np.float64)
+        if self._h is None:
+            return v.copy()
+        d = self.ctx.to_device(v)
+        try:
+            L.check(self._lib.nrhip_comm_allreduce_f64_max(self._h, ctypes.c_void_p(d), len(v)))
+            out = np.zeros_like(v)
+            self.ctx.to_host(out, d)
+        finally:
+            self.ctx.free(d)
+        return out
+
+    def close(self):
+        if self._h is not None:
+            self._lib.nrhip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -76,6 +76,12 @@ class Context:
             L.check(self._lib.nrhip_memcpy_h2d(self._h, ctypes.c_void_p(p), a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
         return p
 
+    def copy_to_device(self, dev_ptr, a):
+        """overwrite an existing device buffer with the host array a"""
+        a = np.ascontiguousarray(a)
+        if a.nbytes:
+            L.check(self._lib.nrhip_memcpy_h2d(self._h, ctypes.c_void_p(dev_ptr), a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+
     def to_host(self, out, dev_ptr):
         if out.nbytes:
             L.check(self._lib.nrhip_memcpy_d2h(self._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(dev_ptr),

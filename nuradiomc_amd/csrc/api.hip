@@ -220,6 +220,7 @@ int nrhip_attenuation_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, co
     if (n_rays == 0 || n_freq == 0) return 0;
     for (int i = 0; i < n_freq; i++)
         if (!(freqs[i] > 0)) return fail_msg("nrhip_attenuation_batch: frequencies must be > 0 (DC is 1 by definition)");
+    if (ctx->att_model == NRHIP_ATT_GL3 && !ctx->gl3) return fail_msg("nrhip_attenuation_batch: GL3 needs nrhip_ctx_set_gl3_table");
     HIPCHK(hipSetDevice(ctx->device));
     DevBuf dx1, dx2, dC0, dz, df, da, dn;
     HIPCHK(dx1.alloc(n_rays * 24));
@@ -351,6 +352,8 @@ int nrhip_attenuation_reflections_batch(nrhip_ctx* ctx, int64_t n_rays, const do
     if (n_rays == 0 || n_freq == 0) return 0;
     for (int i = 0; i < n_freq; i++)
         if (!(freqs[i] > 0)) return fail_msg("nrhip_attenuation_reflections_batch: frequencies must be > 0 (DC is 1 by definition)");
+    if (ctx->att_model == NRHIP_ATT_GL3 && !ctx->gl3)
+        return fail_msg("nrhip_attenuation_reflections_batch: GL3 needs nrhip_ctx_set_gl3_table");
     int max_refl = 0;
     std::vector<int32_t> one(n_rays);
     for (int64_t i = 0; i < n_rays; i++) {
@@ -568,6 +571,7 @@ int nrhip_attenuation_length(nrhip_ctx* ctx, int64_t n, const double* z, const d
 {
     if (!ctx) return fail_msg("nrhip_attenuation_length: ctx is NULL");
     if (n <= 0) return 0;
+    if (ctx->att_model == NRHIP_ATT_GL3 && !ctx->gl3) return fail_msg("nrhip_attenuation_length: GL3 needs nrhip_ctx_set_gl3_table");
     HIPCHK(hipSetDevice(ctx->device));
     DevBuf dz, df, dl;
     HIPCHK(dz.alloc(n * 8));

@@ -23,7 +23,8 @@ struct BireBatch {
 void launch_birefringence(hipStream_t s, const BireBatch& b, int max_points, double* steps, double2* spec);
 // the two halves separately: log_norm[ray] (nullable) = log of an upper bound on the 2-norm gain of the ray's whole path;
 // active (nullable): rays with active[ray] == 0 are left untouched
-void launch_birefringence_steps(hipStream_t s, const BireBatch& b, int max_points, double* steps, double* log_norm);
+#define BIRE_LOG_FIXED 1099511627776.0  // 2^40: log_norm is a fixed-point sum (deterministic whatever the order of the atomics)
+void launch_birefringence_steps(hipStream_t s, const BireBatch& b, int max_points, double* steps, long long* log_norm);
 void launch_birefringence_propagate(hipStream_t s, const BireBatch& b, const double* steps, double2* spec, const int* active);
 
 }  // namespace nrhip

@@ -97,7 +97,7 @@ __device__ inline void bire_path_point(int j, int acc, double zstart, double zst
 }
 
 __global__ void __launch_bounds__(256)
-bire_steps_kernel(BireBatch b, double* __restrict__ steps /* [total_steps][5] */, double* __restrict__ log_norm)
+bire_steps_kernel(BireBatch b, double* __restrict__ steps /* [total_steps][5] */, long long* __restrict__ log_norm)
 {
     const int ray = blockIdx.x;
     const int acc = b.n_points[ray];
@@ -187,8 +187,11 @@ bire_steps_kernel(BireBatch b, double* __restrict__ steps /* [total_steps][5] */
         }
         }
         if (log_norm) {  // log of the product over the steps: an upper bound on the gain of the whole path
-            for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
-            if ((threadIdx.x & 63) == 0 && lg != 0.) atomicAdd(&log_norm[ray], lg);
+            // summed as integers (units of 2^-40, every term rounded up): integer addition is associative, so the bound -- and
+            // with it every pruning decision -- does not depend on the order in which the waves arrive
+            long long q = (long long)ceil(lg * BIRE_LOG_FIXED);
+            for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+            if ((threadIdx.x & 63) == 0 && q != 0) atomicAdd((unsigned long long*)&log_norm[ray], (unsigned long long)q);
         }
     }
 }
@@ -269,12 +272,12 @@ bire_propagate_kernel(BireBatch b, const double* __restrict__ steps, double2* __
     if (active) { st[k] = et; st[n_f + k] = ep; }
 }
 
-void launch_birefringence_steps(hipStream_t s, const BireBatch& b, int max_points, double* steps, double* log_norm)
+void launch_birefringence_steps(hipStream_t s, const BireBatch& b, int max_points, double* steps, long long* log_norm)
 {
     if (b.n_rays <= 0 || max_points < 2) return;
     int gy = (max_points - 1 + 255) / 256;
     if (gy > 64) gy = 64;
-    if (log_norm) (void)hipMemsetAsync(log_norm, 0, sizeof(double) * (size_t)b.n_rays, s);
+    if (log_norm) (void)hipMemsetAsync(log_norm, 0, sizeof(long long) * (size_t)b.n_rays, s);
     hipLaunchKernelGGL(bire_steps_kernel, dim3((unsigned)b.n_rays, (unsigned)gy), dim3(256), 0, s, b, steps, log_norm);
 }
 void launch_birefringence_propagate(hipStream_t s, const BireBatch& b, const double* steps, double2* spec, const int* active)

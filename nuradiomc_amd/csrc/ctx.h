@@ -71,6 +71,10 @@ struct nrhip_station {
     std::map<std::string, DevArray> ws;
     std::map<std::string, size_t> ws_bytes;  // valid bytes of the last chunk
     std::vector<int> h_lengths;              // distinct trace lengths of the last chunk
+    // what the ray tables in the workspace belong to (nrhip_sim_config.reuse_ray_tables)
+    int64_t rays_n_showers = -1;
+    double rays_delta_C = 0.;
+    const double* rays_vertex = nullptr;
     hipEvent_t evt[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevArray& buf(const std::string& name) { return ws[name]; }
 };

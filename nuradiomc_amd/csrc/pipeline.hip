@@ -309,6 +309,7 @@ int nrhip_station_set_positions(nrhip_station* s, const double* position)
     HIPCHK(hipMemcpyAsync(s->d_pos.p, s->h_pos.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, s->ctx->stream));
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
     s->ws_bytes.clear();  // the tables of the last call belong to the old positions
+    s->rays_n_showers = -1;
     return 0;
 }
 
@@ -426,6 +427,19 @@ int nrhip_station_set_birefringence(nrhip_station* s, const int32_t* n_knots, co
     return 0;
 }
 
+// first channel of the station on which a shower has a ray that passes the delta_C cut (-1: none): what the host needs to
+// walk the showers in the order in which the reference meets them (simulation.py:1454-1600 with :143-242)
+__global__ void shower_first_channel_kernel(long n_showers, int n_ch, const int* __restrict__ keep, int* __restrict__ first)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_showers) return;
+    int f = -1;
+    for (int c = 0; c < n_ch && f < 0; c++)
+        for (int s = 0; s < NRHIP_MAXS; s++)
+            if (keep[(i * n_ch + c) * NRHIP_MAXS + s]) f = c;
+    first[i] = f;
+}
+
 static thread_local char g_ws_fail[160] = "";
 #define WS(name, type, count)                                                                       \
     ([&]() -> type* {                                                                               \
@@ -487,7 +501,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     const bool general = arz || bire;
     if (arz && st->arz_n_profiles <= 0)
         return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need a shower library (nrhip_station_set_arz)");
-    if (arz && st->n_shower_profiles != n_events)
+    if (arz && !cfg->select_only && st->n_shower_profiles != n_events)
         return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need one profile per shower (nrhip_station_set_shower_profiles)");
     if (arz && cfg->focusing) return nrhip_fail_msg("nrhip_simulate_events: focusing is not available with the ARZ models");
     if (general && cfg->amp_per_ray) return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray is not available with ARZ / birefringence");
@@ -500,7 +514,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     for (auto& e : st->evt) if (!e) HIPCHK(hipEventCreate(&e));
 #define MARK(i) HIPCHK(hipEventRecord(st->evt[i], sm))
     MARK(0);
-    HIPCHK(hipMemsetAsync(triggered, 0, n_groups, sm));
+    if (!cfg->accumulate_triggered) HIPCHK(hipMemsetAsync(triggered, 0, n_groups, sm));
 
     // 1. ray tracing for every (event, channel) pair
     RayRecords rec;
@@ -520,30 +534,53 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     NEED(geo_off = WS("geo_offset", int, 16384 + 1));
     NEED(geo_tmp = WS("scan_tmp7", int, scan_tiles(16384 + 1)));
     NEED(geo_perm = WS("geo_perm", int, n_events));
-    HIPCHK(hipMemsetAsync(geo_hist, 0, sizeof(int) * 16385, sm));
-    launch_event_cells(sm, (int)n_events, vertex, sd.pos, geo_cell, geo_hist);
-    launch_exclusive_scan(sm, 16385, geo_hist, geo_off, geo_tmp);
-    launch_event_perm(sm, (int)n_events, geo_cell, geo_off, geo_perm);
-    LCHK("geometry order");
-    launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm);
-    LCHK("raytrace");
+    // cfg->reuse_ray_tables: the ray records and the delta_C selection of the previous call on the SAME shower list, station
+    // position and cuts are still in the workspace (two-phase runs: nrhip_sim_config.select_only first)
+    const bool reuse = cfg->reuse_ray_tables != 0;
+    if (reuse && (st->rays_n_showers != n_showers || st->rays_delta_C != cfg->delta_C_cut || st->rays_vertex != vertex))
+        return nrhip_fail_msg("nrhip_simulate_events: reuse_ray_tables without matching ray tables of a previous call");
+    st->rays_n_showers = -1;
+    if (!reuse) {
+        HIPCHK(hipMemsetAsync(geo_hist, 0, sizeof(int) * 16385, sm));
+        launch_event_cells(sm, (int)n_events, vertex, sd.pos, geo_cell, geo_hist);
+        launch_exclusive_scan(sm, 16385, geo_hist, geo_off, geo_tmp);
+        launch_event_perm(sm, (int)n_events, geo_cell, geo_off, geo_perm);
+        LCHK("geometry order");
+        launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm);
+        LCHK("raytrace");
+    }
     MARK(1);
 
     // 2. delta_C cut -> ordered list of kept rays
     int *keep, *offset;
     NEED(keep = WS("slot_keep", int, n_slots + 1));
     NEED(offset = WS("slot_offset", int, n_slots + 1));
-    HIPCHK(hipMemsetAsync(keep + n_slots, 0, sizeof(int), sm));
-    launch_select_rays(sm, n_pairs, n_ch, vertex, zenith, azimuth, rec, ctx->ice, cfg->delta_C_cut, keep);
-    LCHK("select_rays");
     int* scan_tmp;
     NEED(scan_tmp = WS("scan_tmp", int, scan_tiles(n_slots + 1)));
-    launch_exclusive_scan(sm, n_slots + 1, keep, offset, scan_tmp);
-    LCHK("scan");
+    if (!reuse) {
+        HIPCHK(hipMemsetAsync(keep + n_slots, 0, sizeof(int), sm));
+        launch_select_rays(sm, n_pairs, n_ch, vertex, zenith, azimuth, rec, ctx->ice, cfg->delta_C_cut, keep);
+        LCHK("select_rays");
+        launch_exclusive_scan(sm, n_slots + 1, keep, offset, scan_tmp);
+        LCHK("scan");
+    }
     int n_rays = 0;
     HIPCHK(hipMemcpyAsync(&n_rays, offset + n_slots, sizeof(int), hipMemcpyDeviceToHost, sm));
     HIPCHK(hipStreamSynchronize(sm));
     S.n_rays = n_rays;
+    st->rays_n_showers = n_showers;
+    st->rays_delta_C = cfg->delta_C_cut;
+    st->rays_vertex = vertex;
+    if (cfg->select_only) {
+        int* first;
+        NEED(first = WS("shower_first_channel", int, n_showers));
+        hipLaunchKernelGGL(shower_first_channel_kernel, dim3((unsigned)((n_showers + 255) / 256)), dim3(256), 0, sm, (long)n_showers,
+                           n_ch, keep, first);
+        LCHK("shower_first_channel");
+        HIPCHK(hipStreamSynchronize(sm));
+        if (stats) *stats = S;
+        return 0;
+    }
 
     EventOut ev;
     NEED(ev.n_rays = WS("ev_n_rays", int, n_groups));
@@ -742,9 +779,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                          st->bire_n_ref, st->bire_angle, n_f, sd.fs};
             // the gain of the whole path is bounded by the product of the steps' ||R||^2: events none of whose rays can exceed
             // the candidate cut even so skip the propagation (result-neutral, like the bounds of the parametrised path)
-            double* log_gain;
+            long long* log_gain;  // fixed point, BIRE_LOG_FIXED
             int* gactive;
-            NEED(log_gain = WS("bire_log_gain", double, nr));
+            NEED(log_gain = WS("bire_log_gain", long long, nr));
             NEED(gactive = WS("ray_propagated", int, nr));
             launch_birefringence_steps(sm, bb, max_points, steps, log_gain);
             launch_general_bound(sm, n_rays, sd, spec, log_gain, bound);

@@ -163,7 +163,7 @@ void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const 
                              const double* arz_trace, const double2* tw, double2* spec);
 void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double2* tw,
                           double* traces, double* max_efield, const int* active = nullptr, const double* bound = nullptr);
-void launch_general_bound(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double* log_gain,
+void launch_general_bound(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const long long* log_gain,
                           double* bound);
 void launch_general_gather(hipStream_t s, int n_rays, int n_ch, const RayWork& w, const EventIn& evin, const StationDev& st,
                            const double* vertex, const int* shower_profile, const double* shower_rescale, int em_formula,

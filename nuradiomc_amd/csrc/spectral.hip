@@ -736,6 +736,7 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
     __shared__ double ub_slope[4][AB_RT][NRHIP_MAX_NFC];
     __shared__ double s_xp[NRHIP_MAX_NFC];
     for (int j = threadIdx.x; j < st.n_fc; j += blockDim.x) s_xp[j] = st.fcoarse[j];
+    __syncthreads();  // s_binv / s_xp are filled by all four waves and read by each of them in the first pass
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nh = st.N / 2, stride = nh + 1;
     const double df = 1.0 / (st.N * (1. / st.fs));
@@ -2533,7 +2534,7 @@ general_trace_kernel(int n_rays, StationDev st, const double2* __restrict__ spec
 // |e(t)| <= (fs / sqrt 2) (1 / N) (|E_0| + |E_N/2| + 2 sum_k |E_k|) per component, |E'_k| <= gain ||(E_theta,k, E_phi,k)||_2.
 // Lets the birefringent propagation (the expensive part of the general path) skip the events that cannot become candidates.
 __global__ void __launch_bounds__(256)
-general_bound_kernel(int n_rays, StationDev st, const double2* __restrict__ spec, const double* __restrict__ log_gain,
+general_bound_kernel(int n_rays, StationDev st, const double2* __restrict__ spec, const long long* __restrict__ log_gain,
                      double* __restrict__ bound)
 {
     __shared__ double red[256];
@@ -2549,7 +2550,7 @@ general_bound_kernel(int n_rays, StationDev st, const double2* __restrict__ spec
         }
         const double sum = block_sum(part, red);
         if (threadIdx.x == 0)
-            bound[r] = (st.fs / 1.4142135623730951 / N) * sum * exp(log_gain ? log_gain[r] : 0.) * (1. + 1e-9);
+            bound[r] = (st.fs / 1.4142135623730951 / N) * sum * exp(log_gain ? (double)log_gain[r] * (1. / 1099511627776.0) : 0.) * (1. + 1e-9);
         __syncthreads();
     }
 }
@@ -2615,7 +2616,7 @@ void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const
     hipLaunchKernelGGL(general_trace_kernel, dim3(grid), dim3(256), (size_t)nh * 16, s, n_rays, st, spec, tw, ilog2(nh), traces,
                        max_efield, active, bound);
 }
-void launch_general_bound(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double* log_gain,
+void launch_general_bound(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const long long* log_gain,
                           double* bound)
 {
     if (n_rays <= 0) return;

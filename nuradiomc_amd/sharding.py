@@ -1,4 +1,6 @@
-"""Event sharding across ranks (one process per GPU) and the gather of triggered masks.
+"""Event sharding across ranks (one process per GPU) and the gather of triggered masks -- the torch.distributed twin of
+nuradiomc_amd.comm (which binds RCCL directly and is what bench.py uses on GPUs): kept for hosts that already run a
+torch.distributed process group and for the CPU tests of the sharding logic (gloo).
 
 Events are independent, so rank r of W owns the contiguous index range shard_range(n, r, W); nothing is exchanged
 during the compute.  `gather_triggered` is the only collective: an all-gather of the per-rank uint8 masks
@@ -6,11 +8,7 @@ during the compute.  `gather_triggered` is the only collective: an all-gather of
 import numpy as np
 
 
-def shard_range(n_events, rank, world_size):
-    """contiguous, balanced: the first n % W ranks get one extra event"""
-    base, extra = divmod(int(n_events), int(world_size))
-    start = rank * base + min(rank, extra)
-    return start, start + base + (1 if rank < extra else 0)
+from .comm import shard_range, shard_chunks  # noqa: F401  (the product path: nuradiomc_amd.comm.Comm over RCCL)
 
 
 def gather_triggered(local_mask, n_events, dist=None, device=None):

@@ -75,7 +75,8 @@ class SimConfig(ctypes.Structure):
                 ('dump_traces', ctypes.c_int32), ('no_pruning', ctypes.c_int32), ('trigger_type', ctypes.c_int32),
                 ('n_coincidences', ctypes.c_int32), ('threshold_high', ctypes.c_double), ('threshold_low', ctypes.c_double),
                 ('high_low_window', ctypes.c_double), ('coinc_window', ctypes.c_double), ('amp_per_ray', ctypes.c_int32),
-                ('focusing', ctypes.c_int32), ('focusing_limit', ctypes.c_double)]
+                ('focusing', ctypes.c_int32), ('focusing_limit', ctypes.c_double), ('select_only', ctypes.c_int32),
+                ('reuse_ray_tables', ctypes.c_int32), ('accumulate_triggered', ctypes.c_int32)]
 
 
 class SimStats(ctypes.Structure):
@@ -380,13 +381,17 @@ class Station:
                             trigger_threshold=None, dump_traces=False, no_pruning=False, want_stats=True,
                             d_vertex_time=None, n_groups=None, d_group_begin=None, trigger='simple', n_coincidences=1,
                             threshold_high=None, threshold_low=None, high_low_window=5., coinc_window=200., amp_per_ray=False,
-                            d_max_distance=None, focusing=False, focusing_limit=2.):
+                            d_max_distance=None, focusing=False, focusing_limit=2., select_only=False, reuse_ray_tables=False,
+                            accumulate_triggered=False):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
         d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
         trigger: 'simple' (|V| >= trigger_threshold, simpleThreshold.py) or 'high_low' (highLowThreshold.py: threshold_high /
         threshold_low inside high_low_window), both followed by the majority logic over coinc_window with n_coincidences;
-        'phased_array' (set_phased_array first): trigger_threshold is the threshold on the beams' mean window power."""
+        'phased_array' (set_phased_array first): trigger_threshold is the threshold on the beams' mean window power.
+        select_only: stop after ray tracing and the delta_C cut (then fetch('shower_first_channel')); reuse_ray_tables:
+        continue from the tables of such a call on the same device arrays; accumulate_triggered: OR into d_triggered
+        instead of overwriting it (nrhip_sim_config)."""
         if trigger not in ('simple', 'high_low', 'phased_array'):
             raise NotImplementedError("trigger {} is not provided (simple, high_low, phased_array)".format(trigger))
         cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
@@ -395,7 +400,8 @@ class Station:
                         int(bool(no_pruning)), {'simple': 0, 'high_low': 1, 'phased_array': 2}[trigger], int(n_coincidences),
                         float(3.0 * self.vrms if threshold_high is None else threshold_high),
                         float(-3.0 * self.vrms if threshold_low is None else threshold_low), float(high_low_window),
-                        float(coinc_window), int(bool(amp_per_ray)), int(bool(focusing)), float(focusing_limit))
+                        float(coinc_window), int(bool(amp_per_ray)), int(bool(focusing)), float(focusing_limit),
+                        int(bool(select_only)), int(bool(reuse_ray_tables)), int(bool(accumulate_triggered)))
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_event_groups(
             self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,
@@ -405,7 +411,7 @@ class Station:
 
     def simulate_events(self, vertex, zenith, azimuth, energy, shower_type, k_L=None, vertex_time=None, group_id=None,
                         distance_cut_coefficients=None, distance_cut_sum_length=10., arz_iN=None, max_showers_per_call=None,
-                        **kw):
+                        seed=None, rng=None, **kw):
         """Host-array convenience form: uploads the shower list, runs the hot path, returns (triggered mask, stats).
         Long lists are cut into calls of at most `max_showers_per_call` showers at event-group boundaries (default: what
         keeps the per-call tables near 40 GB: ~1.2e7 (shower, channel) pairs, 2.5e5 with ARZ / birefringence, whose rays carry
@@ -413,16 +419,24 @@ class Station:
         the last call).
         `group_id` [n] (equal ids consecutive, like the event_group_ids of the reference's input files) makes showers of
         one id a single event group: their signals add up in the channels (simulation.py:143) and the mask has one entry
-        per group, in order of first appearance.  `vertex_time` [n] shifts a shower's signals (simulation.py:259-268)."""
+        per group, in order of first appearance.  `vertex_time` [n] shifts a shower's signals (simulation.py:259-268).
+        Random shower parameters -- k_L of Alvarez2009 EM showers (NaN / None entries), the ARZ profile numbers (arz_iN
+        None) -- are drawn as the reference draws them when `seed` (or `rng`, a np.random.RandomState) is given: a first pass
+        traces the rays, the host walks the showers in the reference's order (sequencing.reference_draw_order) drawing from
+        RandomState(seed), the second pass reuses the ray tables; stats['k_L'] / stats['arz_iN'] return what was used.  Without
+        a seed missing values are an error (the reference never runs an EM shower with k_L = 1)."""
         ctx = self.ctx
         vertex = L.f64(vertex).reshape(-1, 3)
         n = len(vertex)
         if max_showers_per_call is None:
             general = kw.get('askaryan_model') in ('ARZ2019', 'ARZ2020') or getattr(self, '_birefringence_on', False)
             max_showers_per_call = max(1, int((2.5e5 if general else 1.2e7) / len(self.position)))
+        if rng is None and seed is not None:
+            rng = np.random.RandomState(seed)
         if n > max_showers_per_call:
             return self._simulate_in_chunks(int(max_showers_per_call), vertex, zenith, azimuth, energy, shower_type, k_L,
-                                            vertex_time, group_id, distance_cut_coefficients, distance_cut_sum_length, arz_iN, kw)
+                                            vertex_time, group_id, distance_cut_coefficients, distance_cut_sum_length, arz_iN,
+                                            dict(kw, rng=rng))
         n_groups, gb, vt = n, None, None
         if group_id is not None and n:
             gid = np.asarray(group_id).reshape(-1)
@@ -440,30 +454,53 @@ class Station:
             md = distance_cut(vertex, np.broadcast_to(L.f64(energy), (n,)), gb, distance_cut_coefficients,
                               distance_cut_sum_length)
         st = _shower_type_codes(shower_type, n)
-        if kw.get('askaryan_model') in ('ARZ2019', 'ARZ2020'):
-            # the profile number of every shower (draw them with ARZ.draw_profile_numbers, or reuse stored ones)
-            if getattr(self, '_arz', None) is None:
-                raise ValueError("the ARZ models need a shower library: Station.set_arz(nuradiomc_amd.arz.ARZ(library=...))")
-            if arz_iN is None:
-                raise ValueError("the ARZ models need the profile number of every shower (arz_iN)")
-            rows, resc = self._arz_shower_profiles(np.broadcast_to(L.f64(energy), (n,)), st, np.broadcast_to(arz_iN, (n,)))
-            L.check(self._lib.nrhip_station_set_shower_profiles(self._h, n, L.iptr(rows), L.dptr(resc)))
-        kL = np.ascontiguousarray(np.broadcast_to(np.nan if k_L is None else L.f64(k_L), (n,)), dtype=np.float64)
-        kL = np.where(np.isnan(kL), 1.0, kL)
+        model = kw.get('askaryan_model', 'Alvarez2009')
+        is_arz = model in ('ARZ2019', 'ARZ2020')
+        en = np.ascontiguousarray(np.broadcast_to(L.f64(energy), (n,)))
+        if is_arz and getattr(self, '_arz', None) is None:
+            raise ValueError("the ARZ models need a shower library: Station.set_arz(nuradiomc_amd.arz.ARZ(library=...))")
+        kL = np.array(np.broadcast_to(np.nan if k_L is None else L.f64(k_L), (n,)), dtype=np.float64)
+        need_kL = model == 'Alvarez2009' and bool(np.any(np.isnan(kL) & (st == SHOWER_TO_INT['EM'])))
+        need_iN = is_arz and arz_iN is None
+        if (need_kL or need_iN) and rng is None:
+            raise ValueError("the ARZ models need the profile number of every shower (arz_iN), or a seed to draw them"
+                             if need_iN else
+                             "Alvarez2009 needs k_L for every electromagnetic shower (parametrizations.py:160-173), or a seed "
+                             "to draw them in the reference's order")
+        two_phase = (need_kL or need_iN) and n > 0
         arrs = [vertex, np.ascontiguousarray(np.broadcast_to(L.f64(zenith), (n,))),
-                np.ascontiguousarray(np.broadcast_to(L.f64(azimuth), (n,))),
-                np.ascontiguousarray(np.broadcast_to(L.f64(energy), (n,))), st, np.ascontiguousarray(kL)]
+                np.ascontiguousarray(np.broadcast_to(L.f64(azimuth), (n,))), en, st,
+                np.ascontiguousarray(np.where(np.isnan(kL), 1.0, kL))]
         dptrs = [ctx.to_device(a) for a in arrs]
         dtrig = ctx.malloc(max(n_groups, 1))
         extra = [ctx.to_device(a) if a is not None else None for a in (vt, gb, md)]
+        dev_kw = dict(d_vertex_time=extra[0], n_groups=n_groups, d_group_begin=extra[1], d_max_distance=extra[2])
         try:
-            stats = self.simulate_events_dev(n, *dptrs, dtrig, d_vertex_time=extra[0], n_groups=n_groups,
-                                             d_group_begin=extra[1], d_max_distance=extra[2], **kw)
+            if two_phase:
+                from . import sequencing
+                self.simulate_events_dev(n, *dptrs, dtrig, select_only=True, **dev_kw, **kw)
+                order = sequencing.reference_draw_order(self.fetch('shower_first_channel'), gb)
+                if need_kL:
+                    kL = sequencing.draw_k_L(kL, en, st, order, rng)
+                    host = np.ascontiguousarray(np.where(np.isnan(kL), 1.0, kL))   # showers without a ray: never read
+                    ctx.copy_to_device(dptrs[5], host)
+                if need_iN:
+                    arz_iN = np.zeros(n, np.int64)
+                    arz_iN[order] = self._arz.draw_profile_numbers(en[order], ['HAD' if c == 0 else 'EM' for c in st[order]])
+            if is_arz:   # the profile number of every shower -> library row and E / E_library
+                rows, resc = self._arz_shower_profiles(en, st, np.broadcast_to(arz_iN, (n,)))
+                L.check(self._lib.nrhip_station_set_shower_profiles(self._h, n, L.iptr(rows), L.dptr(resc)))
+            stats = self.simulate_events_dev(n, *dptrs, dtrig, reuse_ray_tables=two_phase, **dev_kw, **kw)
             trig = np.zeros(n_groups, np.uint8)
             ctx.to_host(trig, dtrig)
         finally:
             for p in dptrs + [dtrig] + [e for e in extra if e is not None]:
                 ctx.free(p)
+        if stats is not None and two_phase:
+            if need_kL:
+                stats['k_L'] = kL
+            if need_iN:
+                stats['arz_iN'] = arz_iN
         return trig.astype(bool), stats
 
     def _simulate_in_chunks(self, max_showers, vertex, zenith, azimuth, energy, shower_type, k_L, vertex_time, group_id,
@@ -494,7 +531,9 @@ class Station:
                 total = s_
             elif s_ is not None:
                 for k_, v_ in s_.items():
-                    if k_ == 'stage_ms':
+                    if k_ in ('k_L', 'arz_iN'):
+                        total[k_] = np.concatenate([total[k_], v_])
+                    elif k_ == 'stage_ms':
                         total[k_] = {q: total[k_][q] + v_[q] for q in v_}
                     elif k_ in ('max_length', 'n_distinct_lengths'):
                         total[k_] = max(total[k_], v_)
@@ -541,7 +580,8 @@ class Station:
                      'ev_L': np.int32, 'ev_candidate': np.uint8, 'ev_trigger_bin': np.int32, 'item_event': np.int32, 'trace_offset': np.int64,
                      'ray_r_theta': np.complex128, 'ray_r_phi': np.complex128, 'lengths': np.int32,
                      'pair_n_sol': np.int32, 'slot_type': np.int32, 'ev_ray_begin': np.int32, 'ray_active': np.int32,
-                     'ray_active_list': np.int32, 'ray_slot': np.int32, 'slot_keep': np.int32, 'slot_offset': np.int32}
+                     'ray_active_list': np.int32, 'ray_slot': np.int32, 'slot_keep': np.int32, 'slot_offset': np.int32,
+                     'shower_first_channel': np.int32}
 
     def fetch(self, name):
         """One table of the last simulated batch as a numpy array (see include/nrhip.h: nrhip_sim_fetch)."""

@@ -952,3 +952,34 @@ def test_dumped_traces_of_channels_without_rays_are_zero(gpu_ctx_factory):
             else:
                 assert np.any(t)
     assert n_empty > 20
+
+
+@pytest.mark.parametrize('name', ['N256', 'groups_N256'])
+def test_two_phase_random_draws_like_the_reference(gpu_ctx_factory, name):
+    """k_L of the electromagnetic showers is NOT given: Station.simulate_events(seed=...) traces the rays first, walks the
+    showers in the reference's loop order (event group -> channel -> shower, simulation.py:1454-1600 / :143-242) drawing from
+    RandomState(seed) exactly as parametrizations.py:160-173 does, then finishes on the same ray tables.  The fixtures hold the
+    values the reference itself drew with config['seed'] = 1235 from a fresh generator: they must come out again, and the
+    masks must equal those of a run that is handed the reference's k_L.  Without a seed missing values are an error."""
+    g = golden('chain_%s.npz' % name)
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    groups = 'group' in g
+    ref_kL = g['k_L'] if groups else g['ev_k_L']
+    em = g['shower_type'] == 'EM'
+    kw = dict(vertex_time=g['vertex_time'], group_id=g['group']) if groups else {}
+    args = (g['vertex'], g['zenith'], g['azimuth'], g['energy'], g['shower_type'])
+    with pytest.raises(ValueError):
+        st.simulate_events(*args, None, **kw)
+    trig, stats = st.simulate_events(*args, None, seed=1235, **kw)
+    drawn = stats['k_L']
+    cand = st.fetch('ev_candidate').copy()
+    has_ref = em & np.isfinite(ref_kL)
+    assert has_ref.sum() >= 15
+    assert np.array_equal(np.isfinite(drawn) & em, has_ref)      # the same showers were met
+    assert np.array_equal(drawn[has_ref], ref_kL[has_ref])        # and got the same numbers, bit for bit
+    trig_ref, _ = st.simulate_events(*args, np.where(np.isnan(ref_kL), 1.0, ref_kL), **kw)
+    assert np.array_equal(trig, trig_ref) and np.array_equal(cand, st.fetch('ev_candidate'))
+    # chunked calls continue ONE random stream
+    trig_c, stats_c = st.simulate_events(*args, None, seed=1235, max_showers_per_call=37, **kw)
+    assert np.array_equal(trig_c, trig) and np.array_equal(stats_c['k_L'][has_ref], ref_kL[has_ref])
