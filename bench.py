@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- the hot path on BASELINE config 2: 1e6 events, 1 EeV-class showers, one 5-channel dipole
-station (S5), South-Pole exponential ice, SP1 attenuation, Alvarez2009, 4096-sample traces at 2 GHz.
+"""bench.py -- the per-event hot path on the BASELINE workloads, one process per GPU.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py                                      # BASELINE configs[1]: 1e6 events, 5-channel station, one MI355X
+    python bench.py --config 3|4|5                       # the array workloads (35 x 24 RNO-G-like, + ARZ2020 / birefringence, 200 x 5)
+    python bench.py --flavour mixed                      # configs[1] with nu_e CC / NC event groups instead of fixed hadronic showers
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W [--scaling strong]
 
-One step = one pass of the whole per-event hot path (ray tracing -> delta_C cut -> attenuation -> Askaryan ->
-candidate cut -> antenna + filter response on the event's common time grid -> threshold trigger) over one batch of
-synthetic events that is already resident in HBM.  Events shard across ranks (weak scaling: every rank owns
-`--events` events); the only collective is one all-gather of the per-rank triggered masks (RCCL via
-torch.distributed, backend nccl) after the timed loop's barrier -- there is no exchange inside the compute.
+One step = one pass of the whole hot path (ray tracing -> delta_C cut -> attenuation -> Askaryan emission -> candidate cut ->
+antenna + filter response on the event's common time grid -> trigger; for arrays: over every station) over one batch of
+synthetic events that is already resident in HBM.  Events shard across ranks with no exchange inside the compute; the one
+collective is the all-gather of the per-rank triggered masks over xGMI after the timed loop (RCCL bound through the C ABI,
+nuradiomc_amd.comm -- no PyTorch anywhere; torch.distributed.run is only the process launcher).  `--scaling weak` (default):
+every rank owns `--events` events; `--scaling strong`: ONE list of `--events` events is cut with shard_range.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the step; `cpu_baseline` times the
-oracle (C ray tracer + numpy spectral chain, one thread) on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  `roofline` prices the stage that takes longest in the measured steps (HIP-event times on the
+stream the kernels run on, averaged over the timed steps); `cpu_baseline` times the oracle on ALL host cores on a bounded
+sample of the same event list and the GPU's trigger mask of that sample must equal the oracle's (parity_check).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,19 +30,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ICE = (1.78, 0.423, 77.)           # southpole_2015 (NuRadioMC/utilities/medium.py:69)
+ICE = (1.78, 0.423, 77.)            # southpole_2015 (NuRadioMC/utilities/medium.py:69)
+ICE_GREENLAND = (1.78, 0.51, 37.25)  # greenland_simple (medium.py:145)
 N_SAMPLES, FS = 4096, 2.0
 CHANNELS = np.array([[0., 0., -100. - i] for i in range(5)])
 ENERGY = 3e17                       # shower energy [eV] of a 1 EeV neutrino at <y> ~ 0.3
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s
+FP64_PEAK_TFLOPS = 78.6             # same guide: dense FP64 (vector and matrix alike)
 # algorithmic HBM bytes of the un-fused formulation, N = 4096, L = 5296
 B_RAY, B_CHANNEL, B_PAIR = 601216, 169504, 320
+DCUT = [-1.56434411e+02, 2.54131322e+01, -1.34932379e+00, 2.39984185e-02]   # config_default.yaml speedup.distance_cut_coefficients
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
-def make_events(n, seed):
-    """uniform in r^2 <= (4 km)^2 and z in [-2.7 km, 0], isotropic directions, hadronic showers"""
+def make_events(n, seed, rmax=4000.):
+    """uniform in r^2 <= rmax^2 and z in [-2.7 km, 0], isotropic directions"""
     rng = np.random.default_rng(seed)
-    r = np.sqrt(rng.uniform(0, 4000. ** 2, n))
+    r = np.sqrt(rng.uniform(0, rmax ** 2, n))
     phi = rng.uniform(0, 2 * np.pi, n)
     vertex = np.stack([r * np.cos(phi), r * np.sin(phi), rng.uniform(-2700., 0., n)], axis=1)
     zenith = np.arccos(rng.uniform(-1, 1, n))
@@ -46,116 +54,341 @@ def make_events(n, seed):
     return vertex, zenith, azimuth
 
 
-def cpu_baseline(n_sample, seed):
-    """The oracle on one host thread over the first n_sample events of the same synthetic list."""
-    from oracle import spectral_oracle as so  # checker / baseline only
-    vertex, zenith, azimuth = make_events(n_sample, seed)
+def _mixed_showers(n_groups, seed, vertex, zenith, azimuth, e_nu):
+    """nu_e CC (45 %): hadronic shower y E + electromagnetic shower (1 - y) E at one vertex; everything else: one hadronic shower
+    y E.  Inelasticity from a steeply falling distribution with <y> ~ 0.25 (y = u^3 scaled to [0.005, 1]); k_L of the EM
+    showers 10^N(mean(E), sigma(E)) (parametrizations.py:141-172) from the same synthetic generator."""
+    from nuradiomc_amd import sequencing
+    rng = np.random.default_rng(seed + 7919)
+    y = 0.005 + 0.995 * rng.random(n_groups) ** 3
+    cc = rng.random(n_groups) < 0.45
+    rep = np.where(cc, 2, 1)
+    grp = np.repeat(np.arange(n_groups), rep)
+    first = np.concatenate([[True], grp[1:] != grp[:-1]])
+    en = np.where(first, (y * e_nu)[grp], ((1 - y) * e_nu)[grp])
+    typ = np.where(first, 0, 1).astype(np.int32)
+    kL = np.ones(len(grp))
+    em = np.flatnonzero(typ == 1)
+    ms = np.array([sequencing.alvarez2009_k_L_distribution(e) for e in en[em]]).reshape(-1, 2)
+    kL[em] = 10 ** rng.normal(ms[:, 0], ms[:, 1])
+    return dict(vertex=vertex[grp], zenith=zenith[grp], azimuth=azimuth[grp], energy=en, shower_type=typ, k_L=kL, group=grp)
+
+
+def make_workload(config=2, n=1000000, seed=10, flavour='had'):
+    """The synthetic inputs and detector of one BASELINE configuration (n event groups)."""
+    d = np.pi / 180
+    wl = dict(config=config, n=n, seed=seed, N=N_SAMPLES, fs=FS, centres=None, sim_kw={}, flavour=flavour)
+    if config == 2:
+        v, z, a = make_events(n, seed)
+        wl.update(ice=ICE, att_model='SP1', rel_pos=CHANNELS, antenna=['analytic_VPol'] * 5,
+                  orientation=np.tile([0., 0., 90 * d, 90 * d], (5, 1)), cable_delay=np.zeros(5), distance_cut=False,
+                  name="BASELINE configs[1]: %d events/GPU, 5-ch analytic_VPol station at -100..-104 m, southpole_2015 ice, SP1, "
+                       "Alvarez2009, 4096 samples @ 2 GHz, Butterworth 80-500 MHz, 3 Vrms threshold" % n)
+        e_nu = 1e18
+    elif config in (3, 4):
+        lay = np.load(os.path.join(GOLDEN, 'rnog_array_layout.npz'))   # data read from NuRadioReco/detector/RNO_G/RNO_array.json
+        centres = lay['centres']
+        c0 = centres[:, :2].mean(axis=0)
+        rmax = np.max(np.linalg.norm(centres[:, :2] - c0, axis=1)) + 3000.
+        v, z, a = make_events(n, seed, rmax)
+        v[:, :2] += c0
+        v[:, 2] = np.minimum(v[:, 2], -1.)
+        wl.update(ice=ICE_GREENLAND, att_model='GL1', rel_pos=lay['rel_pos'], antenna=[str(x) for x in lay['antenna']],
+                  orientation=lay['orientation'], cable_delay=lay['cable_delay'], centres=centres, distance_cut=True,
+                  N=2048 if config == 3 else 4096)
+        wl['name'] = ("BASELINE configs[2]: %d events/GPU x 35 stations (RNO_array.json) x 24 channels (analytic VPol / HPol / LPDA "
+                      "stand-ins), greenland_simple ice, GL1, Alvarez2009, speedup.distance_cut, 2048 samples @ 2 GHz, 3 Vrms "
+                      "threshold on any channel" % n) if config == 3 else (
+                      "BASELINE configs[3]: %d events/GPU x 35 stations x 24 channels, greenland_simple ice, GL1, ARZ2020 time-domain "
+                      "emission + birefringence greenland_A, speedup.distance_cut, 4096 samples @ 2 GHz, 3 Vrms threshold" % n)
+        if config == 4:
+            wl['sim_kw'] = dict(askaryan_model='ARZ2020')
+        e_nu = 1e18
+    elif config == 5:
+        n_st, spacing = 200, 1240.
+        side = int(np.ceil(np.sqrt(n_st)))
+        centres = np.array([[spacing * (i - (side - 1) / 2), spacing * (j - (side - 1) / 2), 0.]
+                            for i in range(side) for j in range(side)])[:n_st]
+        rmax = np.max(np.abs(centres[:, :2])) + 3000.
+        v, z, a = make_events(n, seed, rmax)
+        wl.update(ice=ICE, att_model='SP1', rel_pos=CHANNELS, antenna=['analytic_VPol'] * 5,
+                  orientation=np.tile([0., 0., 90 * d, 90 * d], (5, 1)), cable_delay=np.zeros(5), centres=centres,
+                  distance_cut=True, N=2048,
+                  name="BASELINE configs[4]: %d events/GPU x 200 stations (1.24 km grid) x 5-ch dipole string, southpole_2015 ice, SP1, "
+                       "Alvarez2009, showers log-uniform in 1e16..1e20 eV, nu_e CC groups (HAD + EM), speedup.distance_cut, 2048 "
+                       "samples @ 2 GHz, 2-of-5 high/low (3 Vrms) coincidence within 30 ns" % n)
+        wl['sim_kw'] = dict(trigger='high_low', n_coincidences=2, coinc_window=30.)
+        flavour = wl['flavour'] = 'mixed'
+        e_nu = 10 ** np.random.default_rng(seed + 1).uniform(16., 20., n)
+    else:
+        raise ValueError("config must be 2, 3, 4 or 5")
+    if flavour == 'mixed':
+        ev = _mixed_showers(n, seed, v, z, a, np.broadcast_to(e_nu, (n,)))
+    else:
+        ev = dict(vertex=v, zenith=z, azimuth=a, energy=np.full(n, ENERGY * (e_nu / 1e18)), shower_type=np.zeros(n, np.int32),
+                  k_L=np.ones(n), group=np.arange(n))
+    wl['events'] = ev
+    return wl
+
+
+def build_array(ctx, wl):
+    """Station (config 2) or StationArray (configs 3-5) of the workload on this context"""
+    import nuradiomc_amd
+    c0 = np.zeros(3) if wl['centres'] is None else wl['centres'][0]
+    st = nuradiomc_amd.Station(ctx, wl['rel_pos'] + c0, antenna=wl['antenna'], orientation=wl['orientation'],
+                               cable_delay=wl['cable_delay'], n_samples=wl['N'], sampling_rate=wl['fs'], n_freq=25)
+    if wl['config'] == 4:
+        from nuradiomc_amd import arz as arz_mod
+        b = np.load(os.path.join(GOLDEN, 'ref_birefringence.npz'))   # the reference's model file birefringence_greenland_A.npy
+        st.set_birefringence([(b['tck_greenland_A_%d_t' % j], b['tck_greenland_A_%d_c' % j]) for j in range(3)],
+                             angle_to_iceflow=None)
+        g = np.load(os.path.join(GOLDEN, 'ref_arz.npz'))             # small shower library of the reference's layout
+        dep = g['lib_depth']
+        lib = {'EM': {1e18: {'depth': dep, 'charge_excess': list(g['lib_EM_1e18'])}, 1e16: {'depth': dep, 'charge_excess': list(g['lib_EM_1e16'])}},
+               'HAD': {1e18: {'depth': dep, 'charge_excess': list(g['lib_HAD_1e18'])}, 1e17: {'depth': dep, 'charge_excess': list(g['lib_HAD_1e17'])}}}
+        st.set_arz(arz_mod.ARZ(seed=1235, library=lib))
+    if wl['centres'] is None:
+        return st
+    return nuradiomc_amd.StationArray(st, wl['centres'], relative_position=wl['rel_pos'])
+
+
+def upload_events(ctx, wl, sl=None):
+    """the shower list (or its slice of event groups) -> HBM; returns dict(in=[6 device pointers], md, gb, trig, n, n_groups)"""
+    from nuradiomc_amd.station import distance_cut
+    ev = wl['events']
+    grp = ev['group']
+    if sl is None:
+        sel = slice(0, len(grp))
+        g0, g1 = 0, int(grp[-1]) + 1 if len(grp) else 0
+    else:
+        g0, g1 = sl
+        lo, hi = np.searchsorted(grp, g0), np.searchsorted(grp, g1)
+        sel = slice(lo, hi)
+    n = sel.stop - sel.start
+    n_groups = g1 - g0
+    arrs = [np.ascontiguousarray(ev[k][sel]) for k in ('vertex', 'zenith', 'azimuth', 'energy', 'shower_type', 'k_L')]
+    gb = None
+    if n != n_groups:
+        gsel = grp[sel] - g0
+        gb = np.ascontiguousarray(np.concatenate([np.flatnonzero(np.concatenate([[True], gsel[1:] != gsel[:-1]])), [n]]), np.int32)
+    d = dict(n=n, n_groups=n_groups, host=arrs, gb_host=gb)
+    d['in'] = [ctx.to_device(x) for x in arrs]
+    d['md'] = ctx.to_device(distance_cut(arrs[0], arrs[3], gb, DCUT)) if wl['distance_cut'] else None
+    d['gb'] = ctx.to_device(gb) if gb is not None else None
+    d['trig'] = ctx.malloc(max(n_groups, 1))
+    return d
+
+
+def free_events(ctx, d):
+    for p in d['in'] + [d['md'], d['gb'], d['trig']]:
+        if p is not None:
+            ctx.free(p)
+
+
+def _oracle_chunk(args):
+    """one chunk of the CPU baseline (worker process): the oracle's chain over consecutive event groups of config 2"""
+    (ev, lo, hi, flavour) = args
+    from oracle import spectral_oracle as so   # checker / baseline only
     st = so.Station(CHANNELS, n_samples=N_SAMPLES, fs=FS)
     vrms, vrms_e = so.vrms_from_filters(FS)
-    t0 = time.time()
-    n_trig = 0
-    for i in range(n_sample):
-        o = so.simulate_event(vertex[i], zenith[i], azimuth[i], ENERGY, 'HAD', None, st, ICE, vrms, vrms_e)
-        n_trig += o['triggered']
-        if time.time() - t0 > 40:
-            n_sample = i + 1
-            break
-    dt = time.time() - t0
-    return dict(value=n_sample / dt, unit="events/s", cores=1, kind="port",
-                sample="%d events of the same synthetic list (oracle: C ray tracer + numpy chain), %.1f s, %d triggered"
-                       % (n_sample, dt, n_trig))
+    out = np.zeros(hi - lo, np.uint8)
+    grp = ev['group']
+    for g in range(lo, hi):
+        a, b = np.searchsorted(grp, g), np.searchsorted(grp, g + 1)
+        if flavour == 'had':
+            o = so.simulate_event(ev['vertex'][a], ev['zenith'][a], ev['azimuth'][a], ev['energy'][a], 'HAD', None, st, ICE,
+                                  vrms, vrms_e)
+        else:
+            sh = [dict(vertex=ev['vertex'][i], zenith=ev['zenith'][i], azimuth=ev['azimuth'][i], energy=ev['energy'][i],
+                       shower_type='HAD' if ev['shower_type'][i] == 0 else 'EM', k_L=ev['k_L'][i]) for i in range(a, b)]
+            o = so.simulate_event_group(sh, st, ICE, vrms, vrms_e)
+        out[g - lo] = o['triggered']
+    return lo, out
+
+
+def cpu_baseline(wl, budget_s, n_max, cores=None):
+    """The oracle (C ray tracer / attenuation + numpy spectral chain) on all host cores over the first event groups of the same
+    list; processes chunks until `budget_s` is spent.  Returns (json dict, number of groups done, their triggered flags)."""
+    import multiprocessing as mp
+    cores = cores or len(os.sched_getaffinity(0))
+    ev, grp = wl['events'], wl['events']['group']
+    chunk = 125
+
+    def job(lo):
+        hi = min(lo + chunk, n_max)
+        a, b = np.searchsorted(grp, lo), np.searchsorted(grp, hi)
+        return ({k: v[a:b] for k, v in ev.items()}, lo, hi, wl['flavour'])
+    jobs = (job(lo) for lo in range(0, n_max, chunk))
+    done = {}
+    os.environ.setdefault('OMP_NUM_THREADS', '1')
+    os.environ.setdefault('OPENBLAS_NUM_THREADS', '1')
+    ctx = mp.get_context('spawn')   # the parent holds a GPU context: never fork it
+    with ctx.Pool(cores) as pool:
+        pool.map(_noop, range(cores))   # workers up (imports, liboracle.so) before the clock starts
+        t0 = time.time()
+        it = pool.imap(_oracle_chunk, jobs)
+        n_sub = 0
+        for lo, out in it:
+            done[lo] = out
+            n_sub += 1
+            if time.time() - t0 > budget_s:
+                break
+        dt = time.time() - t0
+        pool.terminate()
+    # only the contiguous prefix counts (imap yields in order)
+    flags = np.concatenate([done[lo] for lo in sorted(done)]) if done else np.zeros(0, np.uint8)
+    n_done = len(flags)
+    return dict(value=n_done / dt, unit="events/s", cores=cores, kind="port",
+                sample="%d event groups of the same synthetic list in %.1f s on %d worker processes (oracle: C ray tracer + "
+                       "QUADPACK attenuation, numpy spectral chain; in-flight chunks of the other workers not counted), %d triggered"
+                       % (n_done, dt, cores, int(flags.sum()))), n_done, flags
+
+
+def _noop(i):
+    from oracle import spectral_oracle  # noqa: F401
+    return i
+
+
+def _json_default(o):
+    return o.item() if hasattr(o, 'item') else str(o)
+
+
+def source_hash():
+    """sha256 over the kernel sources: ties a committed profile to the code it was taken on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'nuradiomc_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)   # clocks and caches settle over the first calls (73 -> 69.5 ms)
-    ap.add_argument('--events', type=int, default=1000000, help='events per rank and step')
-    ap.add_argument('--cpu-sample', type=int, default=3000)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)   # clocks and caches settle over the first calls
+    ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument('--flavour', default='had', choices=['had', 'mixed'])
+    ap.add_argument('--events', type=int, default=None, help='event groups per rank and step (weak) or in total (strong)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--cpu-budget', type=float, default=25., help='seconds of CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
-
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    cfgno = args.config
+    if args.events is None:
+        args.events = {2: 1000000, 3: 1000000, 4: 20000, 5: 1000000}[cfgno]
+    if args.steps is None:
+        args.steps = {2: 40, 3: 3, 4: 1, 5: 2}[cfgno]
+    if args.warmup is None:
+        args.warmup = {2: 3, 3: 1, 4: 1, 5: 1}[cfgno]
 
     import nuradiomc_amd
-    ctx = nuradiomc_amd.Context(ICE, 'SP1', device=local_rank)
-    st = nuradiomc_amd.Station(ctx, CHANNELS, antenna='analytic_VPol', n_samples=N_SAMPLES, sampling_rate=FS, n_freq=25)
-    n = args.events
-    vertex, zenith, azimuth = make_events(n, 10 + rank)
-    d_in = [ctx.to_device(a) for a in (vertex, zenith, azimuth, np.full(n, ENERGY), np.zeros(n, np.int32), np.ones(n))]
-    if world > 1:
-        trig_t = torch.zeros(n, dtype=torch.uint8, device='cuda')
-        d_trig = trig_t.data_ptr()
+    from nuradiomc_amd import comm as nrcomm
+    rank, local_rank, world = nrcomm.env_rank()
+    if args.scaling == 'strong':
+        wl = make_workload(cfgno, args.events, 10, args.flavour)
+        g0, g1 = nrcomm.shard_range(args.events, rank, world)
     else:
-        d_trig = ctx.malloc(n)
+        wl = make_workload(cfgno, args.events, 10 + rank, args.flavour)
+        g0, g1 = 0, args.events
+    ctx = nuradiomc_amd.Context(wl['ice'], wl['att_model'], device=local_rank)
+    comm = nrcomm.Comm(ctx, rank, world)
+    det = build_array(ctx, wl)
+    is_array = wl['centres'] is not None
+    st = det.station if is_array else det
+    d = upload_events(ctx, wl, (g0, g1))
+    n, n_groups = d['n'], d['n_groups']
+    dev_kw = dict(d_max_distance=d['md'], n_groups=n_groups, d_group_begin=d['gb'], **wl['sim_kw'])
+    if cfgno == 4:   # the profile numbers are shower parameters of the input list (drawn once, resident like k_L)
+        from nuradiomc_amd.station import L as _L
+        iN = st._arz.draw_profile_numbers(d['host'][3], ['HAD' if c == 0 else 'EM' for c in d['host'][4]])
+        rows, resc = st._arz_shower_profiles(d['host'][3], d['host'][4], iN)
+        _L.check(st._lib.nrhip_station_set_shower_profiles(st._h, n, _L.iptr(rows), _L.dptr(resc)))
 
-    def barrier():
-        ctx.synchronize()
-        if world > 1:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def step(want_stats):
-        return st.simulate_events_dev(n, *d_in, d_trig, askaryan_model='Alvarez2009', want_stats=want_stats)
+    def step():
+        return det.simulate_events_dev(n, *d['in'], d['trig'], want_stats=True, **dev_kw)
 
     for _ in range(args.warmup):
-        step(False)
-    barrier()
+        step()
+    comm.barrier()
     t0 = time.perf_counter()
-    stats = None
+    acc = None
     for k in range(args.steps):
-        stats = step(k == args.steps - 1)
-    barrier()
+        s = step()
+        if acc is None:
+            acc = s
+        else:
+            acc['stage_ms'] = {q: acc['stage_ms'][q] + s['stage_ms'][q] for q in s['stage_ms']}
+    comm.barrier()
     elapsed = time.perf_counter() - t0
+    stats = s
+    sm = {q: v / max(args.steps, 1) for q, v in acc['stage_ms'].items()}   # average per step (arrays: summed over the stations)
 
-    n_trig_total = stats['n_triggered']
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        gathered = torch.empty(world * n, dtype=torch.uint8, device='cuda')
-        dist.all_gather_into_tensor(gathered, trig_t)  # the one collective: triggered masks over xGMI
-        n_trig_total = int(gathered.sum().item())
+    elapsed = float(comm.allreduce_max([elapsed])[0])
+    n_total = args.events if args.scaling == 'strong' else args.events * world
+    if args.scaling == 'strong':
+        mask = comm.allgather_masks(d['trig'], n_groups, n_total)   # the one collective: triggered masks over xGMI
+        n_trig_total = int(mask.sum())
+    else:
+        n_trig_total = int(comm.allreduce_sum([stats['n_triggered']])[0])
+        if world > 1:   # exercise the collective of the path all the same (equal shards)
+            mask = comm.allgather_masks(d['trig'], n_groups, n_total)
+            assert int(mask.sum()) == n_trig_total
+    counters = ('n_pairs', 'n_rays', 'n_active_rays', 'n_candidate_events', 'n_integrand_evals')
+    tot = dict(zip(counters, comm.allreduce_sum([stats[k] for k in counters])))
+
+    # pass 2: what the reference writes for triggered events (all channel traces) -- re-run of the triggered groups with dump_traces
+    pass2_ms = None
+    if cfgno == 2 and rank == 0:
+        host_mask = np.zeros(n_groups, np.uint8)
+        ctx.to_host(host_mask, d['trig'])
+        sel = np.flatnonzero(host_mask)
+        ev = wl['events']
+        rows = np.flatnonzero(np.isin(ev['group'], sel + g0))
+        t1 = time.perf_counter()
+        t2, _ = st.simulate_events(ev['vertex'][rows], ev['zenith'][rows], ev['azimuth'][rows], ev['energy'][rows],
+                                   ev['shower_type'][rows], ev['k_L'][rows], group_id=ev['group'][rows], dump_traces=True,
+                                   **wl['sim_kw'])
+        pass2_ms = 1e3 * (time.perf_counter() - t1)
+        assert t2.all(), "pass 2 lost a trigger"
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
-        value = world * n * args.steps / elapsed
-        sm = stats['stage_ms']
+        value = n_total * args.steps / elapsed
         dom = max((k for k in sm if k != 'total'), key=lambda k: sm[k])
         kernel_of = {'raytrace': 'raytrace_kernel', 'ray_setup': 'select/scan/ray_setup kernels',
-                     'amp_bound': 'amp_bound_kernel', 'attenuation': 'attenuation_group_kernel<32, 1>',
-                     'efield_max': 'efield_bound_kernel + efield_max_kernel', 'event_grid': 'event_grid_kernel + candidate lists',
+                     'amp_bound': 'amp_bound_kernel', 'attenuation': 'attenuation_group_kernel',
+                     'efield_max': 'efield_bound_kernel + efield_max_kernel' if cfgno != 4 else
+                                   'arz_vector_potential_kernel + bire_steps_kernel + bire_propagate_kernel (general path)',
+                     'event_grid': 'event_grid_kernel + candidate lists',
                      'length_tables': 'length_tables_kernel', 'channel': 'channel_prefilter_kernel + channel_conv_kernel'}
-        # algorithmic HBM bytes per launch (SURVEY.md section 8d; DESIGN.md section 4)
-        b_field = 2 * 2049 * 16 + 2 * 2049 * 16 + 2 * 4096 * 8     # write spec_N, c2r N in/out per ray
-        alg = {'raytrace': B_PAIR * stats['n_pairs'],
+        nh = wl['N'] // 2 + 1
+        b_field = 2 * nh * 16 + 2 * nh * 16 + 2 * wl['N'] * 8     # write spec_N, c2r N in/out per ray
+        scale = wl['N'] / 4096.
+        alg = {'raytrace': B_PAIR * stats['n_pairs'], 'ray_setup': 136 * stats['n_rays'],
                'amp_bound': 136 * stats['n_rays'] + 8 * stats['n_rays'],
                'attenuation': (32 + 8 * 25) * stats['n_active_rays'],
                'efield_max': 232 * stats['n_active_rays'] + b_field * stats['n_efield_transforms'],
+               'event_grid': 48 * stats['n_rays'], 'length_tables': 0,
                # only the transforms actually carried out are priced (pruned items move no algorithmic bytes)
-               'channel': (B_RAY - b_field) * stats['n_ray_transforms'] + B_CHANNEL * stats['n_channel_transforms']}
+               'channel': (B_RAY * scale - b_field) * stats['n_ray_transforms'] + B_CHANNEL * scale * stats['n_channel_transforms']}
+        if cfgno == 4:   # general path: spectra and traces of every kept ray are materialised (DESIGN.md section 3)
+            alg['efield_max'] = stats['n_rays'] * (2 * nh * 16 * 3 + 2 * wl['N'] * 8 * 2)
         alg_bytes = alg.get(dom, 0)
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, see the file header);
-        # only meaningful for the workload they were measured on
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_rocprofv3_pmc_hbm_traffic_final.csv')
-        if n == 1000000 and os.path.exists(pmc):
-            for line in open(pmc):
-                name, _, _, hbm = line.strip().rsplit(',', 3) if line.count(',') >= 3 else ('', 0, 0, 0)
-                if name.startswith('nrhip::') and name.split('::')[1].split('<')[0] in kernel_of[dom].split(' + ')[-1]:
-                    traffic = float(hbm) / 1e9
         achieved = alg_bytes / (sm[dom] * 1e-3) / 1e9 if sm[dom] > 0 else 0.
-        b_event = B_RAY * stats['n_rays'] + B_CHANNEL * stats['n_channel_items'] + B_PAIR * stats['n_pairs']
+        # HBM bytes per launch from the committed rocprofv3 PMC passes -- quoted only if they were taken on THESE kernel sources
+        traffic, traffic_note = None, None
+        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        if cfgno == 2 and args.flavour == 'had' and n == 1000000 and os.path.exists(pmc):
+            pj = json.load(open(pmc))
+            if pj.get('source_hash') == source_hash():
+                traffic = pj['kernels'].get(kernel_of[dom].split(' + ')[-1])
+                traffic_note = "GB per launch, rocprofv3 PMC passes (%s), kernel sources %s" % (pj.get('file'), pj['source_hash'])
+            else:
+                traffic_note = "profiles/r02_pmc_traffic.json was taken on other kernel sources (%s != %s): not quoted" % (
+                    pj.get('source_hash'), source_hash())
+        b_event = B_RAY * scale * stats['n_rays'] + B_CHANNEL * scale * stats['n_channel_items'] + B_PAIR * stats['n_pairs']
         # FP64 view of the attenuation quadrature: one integrand evaluation = frequency-independent node part (shared
         # by the 25 lanes of a ray, ~110 flop incl. exp, 2 sqrt, 2 div) / 25 + per-lane exp + div (~45 flop)
         flop_per_eval = 110. / 25. + 45.
@@ -163,45 +396,52 @@ def main():
         out = {
             "metric": "simulated events/sec (1e6-evt 1 EeV SP survey)", "value": value, "unit": "events/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d events/GPU, 3e17 eV hadronic showers, 5-ch analytic_VPol "
-                                   "station at -100..-104 m, southpole_2015 ice, SP1, Alvarez2009, 4096 samples @ 2 GHz, "
-                                   "Butterworth 80-500 MHz, 3 Vrms threshold" % n,
-                       "events_per_gpu": n, "n_pairs": stats['n_pairs'], "n_rays": stats['n_rays'],
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl['name'], "baseline_config_index": cfgno - 1, "flavour": wl['flavour'],
+                       "event_groups_per_gpu": n_groups, "showers_per_gpu": n,
+                       "n_stations": 1 if not is_array else len(wl['centres']), "n_channels": len(wl['rel_pos']),
+                       "n_pairs": stats['n_pairs'], "n_rays": stats['n_rays'],
                        "n_active_rays": stats['n_active_rays'], "n_candidate_events": stats['n_candidate_events'],
                        "n_channel_items": stats['n_channel_items'], "n_channel_transforms": stats['n_channel_transforms'],
                        "n_ray_transforms": stats['n_ray_transforms'], "n_efield_transforms": stats['n_efield_transforms'],
                        "n_triggered_rank0": stats['n_triggered'], "n_triggered_all": n_trig_total,
-                       "n_distinct_trace_lengths": stats['n_distinct_lengths'],
+                       "all_ranks": {k: int(v) for k, v in tot.items()},
                        "triggered_events_per_s": n_trig_total / (elapsed / max(args.steps, 1)),
-                       "stage_ms_last_step": {k: round(v, 3) for k, v in sm.items()}},
+                       "pass2_ms_traces_of_triggered_events": pass2_ms,
+                       "stage_ms_avg_per_step": {k: round(v, 3) for k, v in sm.items()}},
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/r01_rocprofv3_pmc_hbm_traffic_final.csv)",
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": sm[dom],
                          "whole_step_equivalent_GBs": b_event / (sm['total'] * 1e-3) / 1e9 if sm['total'] > 0 else 0.,
                          "whole_step_equivalent_frac": b_event / (sm['total'] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm['total'] > 0 else 0.,
                          "attenuation_integrand_evals": stats['n_integrand_evals'],
-                         "attenuation_fp64_tflops_est": fp64, "fp64_vector_peak_tflops": 78.6,
-                         "note": "every kernel of the path is FP64-VALU/LDS bound: the fused kernels move ~1e-3 of the "
-                                 "un-fused algorithmic bytes of SURVEY 8(d) that 'achieved' is priced on"},
+                         "attenuation_fp64_tflops_est": fp64, "fp64_vector_peak_tflops": FP64_PEAK_TFLOPS,
+                         "note": "every kernel of the path is FP64-VALU / LDS bound: the fused kernels move ~1e-3 of the "
+                                 "un-fused algorithmic bytes of SURVEY 8(d) that the HBM view is priced on"},
         }
         if dom == 'attenuation':
-            # the quadrature kernel is FP64 bound: price it in flops against the dense FP64 peak of the
-            # MI355X (78.6 TFLOP/s, vector and matrix alike; the kernel issues VALU FP64, there is no contraction for MFMA).
-            # algorithmic flops per launch = integrand evaluations (counted by the kernel) x flop_per_eval
-            out["roofline"].update({"bound": "mfma", "achieved": fp64, "peak": 78.6, "unit": "TFLOP/s", "frac": fp64 / 78.6,
+            # the quadrature kernel is FP64-VALU bound: priced in flops against the dense FP64 peak of the MI355X
+            # (78.6 TFLOP/s, vector and matrix alike; nothing on this path is MFMA-shaped).  algorithmic flops per launch =
+            # integrand evaluations (counted by the kernel) x flop_per_eval
+            out["roofline"].update({"bound": "fp64_valu", "achieved": fp64, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": fp64 / FP64_PEAK_TFLOPS,
                                     "algorithmic_flops_per_launch": stats['n_integrand_evals'] * flop_per_eval,
-                                    "hbm_view_GBs": achieved,
-                                    "note": "FP64 VALU kernel priced against the dense FP64 peak (no MFMA-shaped work on this "
-                                            "path); 'traffic' = HBM bytes of the launch from the PMC passes"})
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 10)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+                                    "hbm_view_GBs": achieved})
+        out["cpu_baseline"] = None
+        if world == 1 and cfgno == 2 and not args.no_cpu_baseline:
+            base, n_done, flags = cpu_baseline(wl, args.cpu_budget, min(n_groups, 200000))
+            host_mask = np.zeros(n_groups, np.uint8)
+            ctx.to_host(host_mask, d['trig'])
+            mism = int(np.sum(host_mask[:n_done] != flags))
+            base['parity_check'] = "GPU trigger mask == oracle on the %d sampled event groups: %d mismatches" % (n_done, mism)
+            out["cpu_baseline"] = base
+            if mism:
+                print(json.dumps(out, default=_json_default))
+                raise SystemExit("bench.py: the GPU trigger mask differs from the oracle's on %d of %d sampled events" % (mism, n_done))
+        print(json.dumps(out, default=_json_default))
+    comm.barrier()
+    free_events(ctx, d)
+    comm.close()
 
 
 if __name__ == '__main__':

@@ -18,18 +18,22 @@ from .station import Station, _shower_type_codes, distance_cut, SHOWER_TO_INT
 
 
 class StationArray:
-    def __init__(self, station, centres, station_ids=None):
-        """station: a Station built at the FIRST centre's position or anywhere else -- its channel layout relative to
-        `relative_to` is what every station of the array has; centres [n_st, 3] absolute station positions
-        (det.get_absolute_position); the Station's current positions are taken as relative positions + centres[0] unless
-        `station.relative_position` is set."""
+    def __init__(self, station, centres, relative_position=None, station_ids=None):
+        """station: the Station object that is moved through the array (antennas, orientations, cable delays, filters, tables);
+        centres [n_st, 3]: absolute station positions (det.get_absolute_position); relative_position [n_ch, 3]: the channel
+        positions inside a station (det.get_relative_position) -- channel c of station i sits at relative_position[c] +
+        centres[i], the sum the reference forms (simulation.py:138).  Pass it explicitly: recovering it as station.position -
+        centres[0] (the default) is off by an ulp of the station coordinate, and the reference's first ray root is sensitive to
+        the last bit of its inputs."""
         if not isinstance(station, Station):
             raise TypeError("StationArray needs a nuradiomc_amd.Station")
         self.station = station
         self.centres = L.f64(centres).reshape(-1, 3)
-        self.relative_position = getattr(station, 'relative_position', None)
+        self.relative_position = None if relative_position is None else L.f64(relative_position).reshape(-1, 3).copy()
         if self.relative_position is None:
             self.relative_position = station.position - self.centres[0]
+        if self.relative_position.shape != station.position.shape:
+            raise ValueError("relative_position must be [n_channels, 3] of the station")
         self.station_ids = list(range(len(self.centres))) if station_ids is None else list(station_ids)
         if len(self.station_ids) != len(self.centres):
             raise ValueError("one station id per centre")

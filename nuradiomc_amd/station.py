@@ -496,11 +496,11 @@ class Station:
         finally:
             for p in dptrs + [dtrig] + [e for e in extra if e is not None]:
                 ctx.free(p)
-        if stats is not None and two_phase:
-            if need_kL:
+        if stats is not None and rng is not None:   # what the showers were simulated with (NaN k_L: shower without any ray)
+            if model == 'Alvarez2009':
                 stats['k_L'] = kL
-            if need_iN:
-                stats['arz_iN'] = arz_iN
+            if is_arz:
+                stats['arz_iN'] = np.array(np.broadcast_to(arz_iN, (n,)), np.int64)
         return trig.astype(bool), stats
 
     def _simulate_in_chunks(self, max_showers, vertex, zenith, azimuth, energy, shower_type, k_L, vertex_time, group_id,

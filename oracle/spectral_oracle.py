@@ -663,10 +663,13 @@ def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, v
 
 def simulate_event_group(showers, st, ice, vrms, vrms_efield, att_model='SP1', n_freq=25, model='Alvarez2009',
                          filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0, min_efield_amplitude=2.0,
-                         distance_cut_coefficients=None, distance_cut_sum_length=10.):
+                         distance_cut_coefficients=None, distance_cut_sum_length=10., arz=None, birefringence=None,
+                         trigger=None):
     """An event group of several showers through simulation.run()'s sequence (:1454-1600): calculate_sim_efield loops
     over the showers per channel (:143), the candidate flag, the common time grid, the channel sums and the trigger are
-    per group.  `showers`: list of dicts with vertex, zenith, azimuth, energy, shower_type, k_L, vertex_time."""
+    per group.  `showers`: list of dicts with vertex, zenith, azimuth, energy, shower_type, k_L, vertex_time (and 'iN', the
+    ARZ profile number, with arz = the arz_oracle.ARZ object).  trigger: None = simple threshold at trigger_sigma * vrms on any
+    channel, or the keyword arguments of station_trigger (high / low thresholds, coincidences)."""
     efs = []
     cuts = [None] * len(showers)
     if distance_cut_coefficients is not None:  # simulation.py:1398-1409 and :125-131, :155-163
@@ -680,7 +683,8 @@ def simulate_event_group(showers, st, ice, vrms, vrms_efield, att_model='SP1', n
     for i, sh in enumerate(showers):
         e = sim_efields_for_event(sh['vertex'], sh['zenith'], sh['azimuth'], sh['energy'], sh['shower_type'], sh.get('k_L'),
                                   st, ice, att_model, n_freq, model, delta_C_cut, vertex_time=sh.get('vertex_time', 0.),
-                                  max_distance=cuts[i])
+                                  max_distance=cuts[i], arz=None if arz is None else (arz, sh['iN']),
+                                  birefringence=birefringence)
         for ef in e:
             ef['shower'] = i
         efs += e
@@ -691,5 +695,19 @@ def simulate_event_group(showers, st, ice, vrms, vrms_efield, att_model='SP1', n
     if not efs or not out['candidate']:
         return out
     V, t_min, L = combined_voltage(efs, st, filters)
-    out.update(V=V, t_min=t_min, L=L, triggered=threshold_trigger(V, trigger_sigma * vrms))
+    out.update(V=V, t_min=t_min, L=L)
+    if trigger is None:
+        out['triggered'] = threshold_trigger(V, trigger_sigma * vrms)
+    else:
+        out['triggered'] = station_trigger(V, st.fs, **trigger)[0]
+    return out
+
+
+def simulate_event_group_array(showers, centres, rel_pos, ice, vrms, vrms_efield, station_kw=None, **kw):
+    """The station loop of simulation.run() (:1500-1600: "each station is treated independently") for an array of identical
+    stations: channel positions rel_pos + centres[i]; returns the list of per-station results of simulate_event_group."""
+    out = []
+    for c in np.asarray(centres, float).reshape(-1, 3):
+        st = Station(np.asarray(rel_pos, float) + c, **(station_kw or {}))
+        out.append(simulate_event_group(showers, st, ice, vrms, vrms_efield, **kw))
     return out

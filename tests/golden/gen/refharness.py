@@ -28,6 +28,7 @@ from NuRadioReco.framework.parameters import electricFieldParameters as efp  # n
 from NuRadioReco.framework.parameters import channelParameters as chp  # noqa: E402
 import NuRadioReco.modules.channelBandPassFilter  # noqa: E402
 import NuRadioReco.modules.trigger.simpleThreshold  # noqa: E402
+import NuRadioReco.modules.trigger.highLowThreshold  # noqa: E402
 from NuRadioReco.utilities import signal_processing  # noqa: E402
 from NuRadioMC.simulation import simulation  # noqa: E402
 from NuRadioMC.SignalProp import analyticraytracing as ray  # noqa: E402
@@ -103,6 +104,7 @@ def default_config(model='Alvarez2009', ice_model='southpole_2015', fs=2.0, n_fr
 
 _bp = NuRadioReco.modules.channelBandPassFilter.channelBandPassFilter()
 _trig = NuRadioReco.modules.trigger.simpleThreshold.triggerSimulator()
+_hl = NuRadioReco.modules.trigger.highLowThreshold.triggerSimulator()
 FILTERS = [dict(passband=[80 * units.MHz, 1000 * units.GHz], filter_type='butter', order=2),
            dict(passband=[0, 500 * units.MHz], filter_type='butter', order=10)]
 
@@ -166,7 +168,8 @@ def make_propagator(config, det):
     return ice, prop
 
 
-def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, trigger_sigma=3.0, distance_cut=None):
+def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, trigger_sigma=3.0, distance_cut=None,
+                   trigger=None):
     """One event group through the reference, following simulation.run() (simulation.py:1454-1600).
     `shower` is one RadioShower or the list of showers of the event group.
 
@@ -224,8 +227,13 @@ def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, tri
     if len(station.get_sim_station().get_electric_fields()) == 0 or not candidate:
         return out
     simulation.apply_det_response(evt, det, config, filter_amp, add_noise=False)
-    _trig.run(evt, station, det, threshold=trigger_sigma * vrms, triggered_channels=None,
-              number_concidences=1, trigger_name='simple_threshold')
+    if trigger is not None and trigger.get('kind') == 'high_low':   # highLowThreshold.triggerSimulator.run (:160-335)
+        _hl.run(evt, station, det, threshold_high=trigger['threshold_high'], threshold_low=trigger['threshold_low'],
+                high_low_window=trigger['high_low_window'], coinc_window=trigger['coinc_window'],
+                number_concidences=trigger['number_concidences'], triggered_channels=None, trigger_name='high_low')
+    else:
+        _trig.run(evt, station, det, threshold=trigger_sigma * vrms, triggered_channels=None,
+                  number_concidences=1, trigger_name='simple_threshold')
     out['triggered'] = bool(station.has_triggered())
     chans = [station.get_channel(c) for c in det.get_channel_ids(sid)]
     out['L'] = chans[0].get_number_of_samples()

@@ -1,0 +1,277 @@
+"""BASELINE configs 3, 4, 5 -- ARRAYS of stations through nuradiomc_amd.StationArray (the station loop of simulation.run(),
+NuRadioMC/simulation/simulation.py:1454-1600) against
+
+* the oracle's array driver (oracle/spectral_oracle.py: simulate_event_group_array) on the same inputs: per (event group,
+  station) ray counts, candidate flags, trace lengths, t_min, channel traces (1e-6 of the largest sample: both sides trace
+  the same rays bit for bit) and trigger decisions exact;
+* the fixtures the REFERENCE itself produced for the same arrays (tests/golden/array_*.npz, generator
+  tests/golden/gen/gen_array.py): decisions exact wherever the reference found the same number of rays (its first-root noise,
+  DESIGN.md section 2), channel maxima to 5e-3, and the random shower parameters (k_L, ARZ profile numbers) the reference
+  drew in ITS loop order, reproduced from the seed bit for bit.
+
+Full-size runs are checked through size-independent properties (the oracle needs ~1 h per 1e6 station-events).
+"""
+import numpy as np
+import pytest
+
+import nuradiomc_amd
+import os
+from conftest import golden, ROOT
+from oracle import spectral_oracle as so
+from oracle import raytrace_oracle as rto
+
+pytestmark = pytest.mark.gpu
+
+
+def _have(name):
+    return os.path.exists(os.path.join(ROOT, 'tests', 'golden', name))
+
+DCUT = [-1.56434411e+02, 2.54131322e+01, -1.34932379e+00, 2.39984185e-02]
+
+
+def _array(gpu_ctx_factory, g, **station_kw):
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    ant = [str(a) for a in g['antenna']]
+    st = nuradiomc_amd.Station(ctx, g['rel_pos'] + g['centres'][0], antenna=ant, orientation=g['orientation'],
+                               cable_delay=g['cable_delay'], n_samples=int(g['N']), sampling_rate=float(g['fs']),
+                               n_freq=int(g['n_freq']), **station_kw)
+    assert st.vrms == float(g['vrms']) and st.vrms_efield == float(g['vrms_efield'])
+    return ctx, st, nuradiomc_amd.StationArray(st, g['centres'], relative_position=g['rel_pos'], station_ids=g['station_ids'])
+
+
+def _group_showers(g, gi, kL, iN=None):
+    idx = np.flatnonzero(g['group'] == gi)
+    return [dict(vertex=g['vertex'][i], zenith=float(g['zenith'][i]), azimuth=float(g['azimuth'][i]),
+                 energy=float(g['energy'][i]), shower_type=str(g['shower_type'][i]), k_L=float(kL[i]),
+                 vertex_time=float(g['vertex_time'][i]), iN=None if iN is None else int(iN[i])) for i in idx]
+
+
+class _Collector:
+    """on_station callback: keeps the per-station tables of a StationArray.simulate_events run"""
+
+    def __init__(self, n_ch, traces=True):
+        self.n_ch, self.traces, self.per = n_ch, traces, {}
+
+    def __call__(self, i, sl, st):
+        d = {k: st.fetch(k).copy() for k in ('ev_candidate', 'ev_L', 'ev_t_min', 'ev_n_rays')}
+        d['item_event'] = st.fetch('item_event').copy() if d['ev_candidate'].any() else np.zeros(0, np.int32)
+        if len(d['item_event']):
+            d['maxV'] = st.fetch('item_maxV').reshape(-1, self.n_ch).copy()
+            if self.traces:
+                d['trace'], d['off'] = st.fetch('trace').copy(), st.fetch('trace_offset').copy()
+        self.per[i] = d
+
+
+def _check_vs_oracle(g, col, trig_st, kL, stations, groups, oracle_kw, tol=1e-6, trigger=None, iN=None):
+    """per (group, station): GPU tables == oracle"""
+    n_ch = len(g['rel_pos'])
+    skw = dict(antenna=[str(a) for a in g['antenna']], orientation=g['orientation'], cable_delay=g['cable_delay'],
+               n_samples=int(g['N']), fs=float(g['fs']))
+    n_cand = n_trig = n_rays = 0
+    for gi in groups:
+        showers = _group_showers(g, gi, kL, iN)
+        res = so.simulate_event_group_array(showers, g['centres'][stations], g['rel_pos'], g['ice'], float(g['vrms']),
+                                            float(g['vrms_efield']), station_kw=skw, att_model=str(g['att_model']),
+                                            n_freq=int(g['n_freq']), distance_cut_coefficients=DCUT, trigger=trigger, **oracle_kw)
+        for s, o in zip(stations, res):
+            d = col.per[s]
+            assert len(o['rays']) == d['ev_n_rays'][gi], (gi, s)
+            n_rays += len(o['rays'])
+            assert o['candidate'] == bool(d['ev_candidate'][gi]), (gi, s)
+            assert o['triggered'] == bool(trig_st[s, gi]), (gi, s)
+            if not o['candidate']:
+                continue
+            n_cand += 1
+            n_trig += o['triggered']
+            assert o['L'] == d['ev_L'][gi] and abs(o['t_min'] - d['ev_t_min'][gi]) < 1e-9
+            it = int(np.flatnonzero(d['item_event'] == gi)[0])
+            scale = np.max(np.abs(o['V']))
+            for ch in range(n_ch):
+                tr = d['trace'][d['off'][it * n_ch + ch]:d['off'][it * n_ch + ch + 1]]
+                assert np.max(np.abs(tr - o['V'][ch])) <= tol * scale, (gi, s, ch)
+    return n_rays, n_cand, n_trig
+
+
+def _check_vs_reference(g, col, trig_st, amp_tol=5e-3, min_same=0.97):
+    """per (group, station): decisions equal to the reference's wherever it found the same number of rays"""
+    n_groups, n_st = g['ev_n_rays'].shape
+    n_rays = np.array([col.per[s]['ev_n_rays'] for s in range(n_st)]).T
+    same = n_rays == g['ev_n_rays']
+    assert same.mean() >= min_same, same.mean()
+    cand = np.array([col.per[s]['ev_candidate'] for s in range(n_st)]).T.astype(bool)
+    L = np.array([col.per[s]['ev_L'] for s in range(n_st)]).T
+    assert np.array_equal(cand[same], g['ev_candidate'][same])
+    assert np.array_equal(trig_st.T[same], g['ev_triggered'][same])
+    both = same & cand
+    assert np.array_equal(L[both], g['ev_L'][both])
+    n_amp = 0
+    for s in range(n_st):
+        d = col.per[s]
+        for it, gi in enumerate(d['item_event']):
+            if both[gi, s]:
+                ref = g['ev_maxV'][gi, s]
+                got = np.abs(d['maxV'][it])
+                ok = np.isfinite(got)   # NaN: channel not evaluated after the event's first trigger (production mode only)
+                assert np.all(np.abs(got[ok] - ref[ok]) <= amp_tol * np.max(ref)), (gi, s)
+                n_amp += 1
+    # the reference's full channel traces of a few triggered station-events
+    for k, (gi, s) in enumerate(g['V_keys']):
+        if not both[gi, s] or 'trace' not in col.per[s]:
+            continue
+        d = col.per[s]
+        it = int(np.flatnonzero(d['item_event'] == gi)[0])
+        V = g['V_concat'][:, g['V_offsets'][k]:g['V_offsets'][k + 1]]
+        n_ch = V.shape[0]
+        for ch in range(n_ch):
+            tr = d['trace'][d['off'][it * n_ch + ch]:d['off'][it * n_ch + ch + 1]]
+            assert len(tr) == V.shape[1] and np.max(np.abs(tr - V[ch])) <= amp_tol * np.max(np.abs(V))
+    return same, both, n_amp
+
+
+def test_config3_rnog_array(gpu_ctx_factory):
+    """BASELINE configs[2]: the 35 stations of RNO_array.json x 24 channels (analytic stand-ins for the measured antenna
+    patterns), greenland_simple + GL1, speedup.distance_cut, Alvarez2009, simple 3 Vrms threshold."""
+    g = golden('array_rnog.npz')
+    ctx, st, arr = _array(gpu_ctx_factory, g)
+    n_groups, n_st = g['ev_n_rays'].shape
+    assert n_st == 35 and len(g['rel_pos']) == 24
+    kL = np.ones(len(g['group']))
+    args = (g['vertex'], g['zenith'], g['azimuth'], g['energy'], g['shower_type'], kL)
+    col = _Collector(24)
+    trig, stats = arr.simulate_events(*args, vertex_time=g['vertex_time'], group_id=g['group'], distance_cut_coefficients=DCUT,
+                                      dump_traces=True, on_station=col)
+    ts = stats['station_triggered']
+    assert ts.shape == (n_st, n_groups) and np.array_equal(trig, ts.any(axis=0)) and stats['n_triggered'] == trig.sum()
+    same, both, n_amp = _check_vs_reference(g, col, ts)
+    assert n_amp >= 30 and g['ev_triggered'].sum() >= 5
+    # the event-group mask of the whole array vs the reference's (groups all of whose stations agree in the ray count)
+    ok = same.all(axis=1)
+    assert ok.sum() >= 0.8 * n_groups and np.array_equal(trig[ok], g['ev_triggered'].any(axis=1)[ok])
+    # the oracle on every (group, station) of a third of the groups, all stations
+    n_rays, n_cand, n_trig = _check_vs_oracle(g, col, ts, kL, np.arange(n_st), range(0, n_groups, 3), {})
+    assert n_rays > 1500 and n_cand >= 20 and n_trig >= 2
+    # production mode (pruning, early exits, no dumps): the same masks; device-resident form: the same OR mask
+    trig_p, stats_p = arr.simulate_events(*args, vertex_time=g['vertex_time'], group_id=g['group'],
+                                          distance_cut_coefficients=DCUT)
+    assert np.array_equal(stats_p['station_triggered'], ts) and np.array_equal(trig_p, trig)
+
+
+@pytest.mark.skipif(not _have('array_rnog_arz_bire.npz'), reason='fixture not generated')
+def test_config4_rnog_array_arz_birefringence(gpu_ctx_factory):
+    """BASELINE configs[3]: the same array with the time-domain ARZ2020 emission and birefringent propagation (greenland_A),
+    4096 samples.  The profile numbers are drawn from the seed in the reference's loop order and must equal the ones the
+    reference stored in its showers."""
+    from nuradiomc_amd import arz as arz_mod
+    from oracle import arz_oracle
+    from test_oracle_golden import _arz_library
+    g = golden('array_rnog_arz_bire.npz')
+    ctx, st, arr = _array(gpu_ctx_factory, g)
+    n_groups, n_st = g['ev_n_rays'].shape
+    assert int(g['N']) == 4096 and str(g['askaryan_model']) == 'ARZ2020'
+    b = golden('ref_birefringence.npz')
+    tck = [(b['tck_greenland_A_%d_t' % j], b['tck_greenland_A_%d_c' % j]) for j in range(3)]
+    st.set_birefringence(tck, angle_to_iceflow=None)
+    lib = _arz_library(golden('ref_arz.npz'))
+    st.set_arz(arz_mod.ARZ(seed=int(g['seed']), library=lib))
+    kL = np.ones(len(g['group']))
+    args = (g['vertex'], g['zenith'], g['azimuth'], g['energy'], g['shower_type'], kL)
+    col = _Collector(24)
+    kw = dict(vertex_time=g['vertex_time'], group_id=g['group'], distance_cut_coefficients=DCUT, askaryan_model='ARZ2020')
+    trig, stats = arr.simulate_events(*args, seed=int(g['seed']), dump_traces=True, on_station=col, **kw)
+    iN = stats['arz_iN']
+    met = g['arz_iN'] >= 0
+    assert met.sum() >= 8 and np.array_equal(iN[met], g['arz_iN'][met])
+    ts = stats['station_triggered']
+    same, both, n_amp = _check_vs_reference(g, col, ts, amp_tol=1e-2, min_same=0.95)
+    assert n_amp >= 5
+    # oracle chain on the stations that saw rays, a subset of the groups (0.2 s per ray on the CPU)
+    seen = np.flatnonzero(np.array([col.per[s]['ev_n_rays'].sum() for s in range(n_st)]) > 0)
+    oarz = arz_oracle.ARZ(lib, seed=0)
+    n_rays, n_cand, n_trig = _check_vs_oracle(g, col, ts, kL, seen[:6], range(0, n_groups, 2),
+                                              dict(model='ARZ2020', arz=oarz, birefringence=(tck, None)), tol=3e-5, iN=iN)
+    assert n_rays >= 40 and n_cand >= 2
+    # given profile numbers instead of a seed; production mode
+    trig_p, stats_p = arr.simulate_events(*args, arz_iN=iN, **kw)
+    assert np.array_equal(stats_p['station_triggered'], ts)
+
+
+@pytest.mark.skipif(not _have('array_gen2.npz'), reason='fixture not generated')
+def test_config5_gen2_array(gpu_ctx_factory):
+    """BASELINE configs[4]: 200 stations x the 5-channel string, South-Pole ice, showers log-uniform in 1e16 .. 1e20 eV, nu_e CC
+    groups (HAD + EM) whose k_L comes from the reference's random stream, 2-of-5 high/low coincidence trigger."""
+    g = golden('array_gen2.npz')
+    ctx, st, arr = _array(gpu_ctx_factory, g)
+    n_groups, n_st = g['ev_n_rays'].shape
+    assert n_st == 200
+    vr = float(g['vrms'])
+    tk = dict(trigger='high_low', n_coincidences=int(g['trigger_n_coincidences']),
+              threshold_high=float(g['trigger_threshold_sigma']) * vr, threshold_low=-float(g['trigger_threshold_sigma']) * vr,
+              high_low_window=float(g['trigger_high_low_window']), coinc_window=float(g['trigger_coinc_window']))
+    args = (g['vertex'], g['zenith'], g['azimuth'], g['energy'], g['shower_type'])
+    kw = dict(vertex_time=g['vertex_time'], group_id=g['group'], distance_cut_coefficients=DCUT, **tk)
+    with pytest.raises(ValueError):
+        arr.simulate_events(*args, None, **kw)
+    col = _Collector(5)
+    trig, stats = arr.simulate_events(*args, None, seed=int(g['seed']), dump_traces=True, on_station=col, **kw)
+    kL = stats['k_L']
+    em = g['shower_type'] == 'EM'
+    met = em & np.isfinite(g['k_L'])
+    assert met.sum() >= 8
+    assert np.array_equal(np.isfinite(kL) & em, met) and np.array_equal(kL[met], g['k_L'][met])   # the reference's stream, bit for bit
+    ts = stats['station_triggered']
+    same, both, n_amp = _check_vs_reference(g, col, ts)
+    assert n_amp >= 30 and g['ev_triggered'].sum() >= 10
+    otrig = dict(trigger='high_low', n_coincidences=tk['n_coincidences'], threshold_high=tk['threshold_high'],
+                 threshold_low=tk['threshold_low'], high_low_window=tk['high_low_window'], coinc_window=tk['coinc_window'])
+    kL1 = np.where(np.isnan(kL), 1.0, kL)
+    seen = np.flatnonzero(np.array([col.per[s]['ev_n_rays'].sum() for s in range(n_st)]) > 0)
+    n_rays, n_cand, n_trig = _check_vs_oracle(g, col, ts, kL1, seen[::2], range(n_groups), {}, trigger=otrig)
+    assert n_rays > 1500 and n_cand >= 50 and n_trig >= 8
+    trig_p, stats_p = arr.simulate_events(*args, kL1, **kw)
+    assert np.array_equal(stats_p['station_triggered'], ts) and np.array_equal(trig_p, trig)
+
+
+@pytest.mark.parametrize('config', [3, 5])
+def test_array_full_size_properties(gpu_ctx_factory, config):
+    """bench.py's array workloads at a size the oracle cannot follow (config 3: 2e5 events x 35 x 24 = 1.7e8 pairs; config 5:
+    1e5 events x 200 x 5 = 1e8 pairs): the OR mask is a function of the event alone -- permuting the list permutes the mask,
+    unequal shards concatenate to the whole (what the multi-GPU sharding relies on) --, the device-resident accumulate form
+    equals the OR of the per-station masks, triggered events are a subset of what any single station reports."""
+    import bench
+    wl = bench.make_workload(config, 200000 if config == 3 else 100000, seed=10)
+    ctx = gpu_ctx_factory(wl['ice'], wl['att_model'])
+    arr = bench.build_array(ctx, wl)
+    a = wl['events']
+    grp = a['group']
+    n = int(grp[-1]) + 1
+    cols = ('vertex', 'zenith', 'azimuth', 'energy', 'shower_type', 'k_L')
+
+    def rows_of(groups):
+        """shower rows of the given event groups, in that order of groups (the showers of a group stay consecutive)"""
+        lo, hi = np.searchsorted(grp, groups), np.searchsorted(grp, np.asarray(groups) + 1)
+        return np.concatenate([np.arange(a_, b_) for a_, b_ in zip(lo, hi)])
+
+    def run(groups, **extra):
+        r = rows_of(groups)
+        new_id = np.repeat(np.arange(len(groups)), np.searchsorted(grp, np.asarray(groups) + 1) - np.searchsorted(grp, groups))
+        return arr.simulate_events(*(a[c][r] for c in cols), group_id=new_id, distance_cut_coefficients=DCUT, **wl['sim_kw'],
+                                   **extra)
+    trig, stats = run(np.arange(n))
+    ts = stats['station_triggered']
+    assert len(trig) == n and trig.sum() > 100 and np.array_equal(trig, ts.any(axis=0)) and ts.sum(axis=1).max() < trig.sum()
+    perm = np.random.default_rng(1).permutation(n)
+    trig_p, _ = run(perm, per_station=False)
+    assert np.array_equal(trig_p, trig[perm])
+    cuts = [0, 1, 77777, n]
+    parts = [run(np.arange(i, j), per_station=False)[0] for i, j in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(parts), trig)
+    # device-resident accumulate form (what bench.py times)
+    d = bench.upload_events(ctx, wl)
+    try:
+        s2 = arr.simulate_events_dev(d['n'], *d['in'], d['trig'], d_max_distance=d['md'], n_groups=d['n_groups'],
+                                     d_group_begin=d['gb'], **wl['sim_kw'])
+        got = np.zeros(n, np.uint8)
+        ctx.to_host(got, d['trig'])
+    finally:
+        bench.free_events(ctx, d)
+    assert np.array_equal(got.astype(bool), trig) and s2['n_triggered'] == trig.sum()
