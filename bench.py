@@ -210,7 +210,7 @@ def cpu_baseline(wl, budget_s, n_max, cores=None):
     """The oracle (C ray tracer / attenuation + numpy spectral chain) on all host cores over the first event groups of the same
     list; processes chunks until `budget_s` is spent.  Returns (json dict, number of groups done, their triggered flags)."""
     import multiprocessing as mp
-    cores = cores or len(os.sched_getaffinity(0))
+    cores = cores or usable_cores()
     ev, grp = wl['events'], wl['events']['group']
     chunk = 125
 
@@ -242,6 +242,19 @@ def cpu_baseline(wl, budget_s, n_max, cores=None):
                 sample="%d event groups of the same synthetic list in %.1f s on %d worker processes (oracle: C ray tracer + "
                        "QUADPACK attenuation, numpy spectral chain; in-flight chunks of the other workers not counted), %d triggered"
                        % (n_done, dt, cores, int(flags.sum()))), n_done, flags
+
+
+def usable_cores():
+    """host cores this process may really use: the CPU affinity mask, capped by the cgroup's CPU quota (the GPU boxes show 256
+    logical CPUs but run under a 16-core quota -- 256 busy workers would be throttled to a crawl)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def _noop(i):
@@ -301,10 +314,8 @@ def main():
     n, n_groups = d['n'], d['n_groups']
     dev_kw = dict(d_max_distance=d['md'], n_groups=n_groups, d_group_begin=d['gb'], **wl['sim_kw'])
     if cfgno == 4:   # the profile numbers are shower parameters of the input list (drawn once, resident like k_L)
-        from nuradiomc_amd.station import L as _L
         iN = st._arz.draw_profile_numbers(d['host'][3], ['HAD' if c == 0 else 'EM' for c in d['host'][4]])
-        rows, resc = st._arz_shower_profiles(d['host'][3], d['host'][4], iN)
-        _L.check(st._lib.nrhip_station_set_shower_profiles(st._h, n, _L.iptr(rows), _L.dptr(resc)))
+        dev_kw['arz_rows'] = st._arz_shower_profiles(d['host'][3], d['host'][4], iN)
 
     def step():
         return det.simulate_events_dev(n, *d['in'], d['trig'], want_stats=True, **dev_kw)

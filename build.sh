@@ -1,13 +1,23 @@
 #!/bin/bash
 # Build libnrhip.so (HIP, gfx950) in-tree and the oracle's C restatement.  hipcc cross-compiles without a GPU.
+# The translation units are compiled in parallel into nuradiomc_amd/lib/obj/ and linked; extra arguments go to every hipcc
+# compile (e.g. ./build.sh -DATT_WAVES=3).  NRHIP_LIB_NAME=libnrhip_x.so builds a variant next to the default library.
 set -e
 cd "$(dirname "$0")"
-mkdir -p nuradiomc_amd/lib oracle/_build
+mkdir -p nuradiomc_amd/lib/obj oracle/_build
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRC="nuradiomc_amd/csrc/api.hip nuradiomc_amd/csrc/raytrace.hip nuradiomc_amd/csrc/raytrace_refl.hip nuradiomc_amd/csrc/arz.hip nuradiomc_amd/csrc/birefringence.hip nuradiomc_amd/csrc/earth.hip nuradiomc_amd/csrc/attenuation.hip nuradiomc_amd/csrc/comm.hip"
-[ -f nuradiomc_amd/csrc/spectral.hip ] && SRC="$SRC nuradiomc_amd/csrc/spectral.hip"
-[ -f nuradiomc_amd/csrc/pipeline.hip ] && SRC="$SRC nuradiomc_amd/csrc/pipeline.hip"
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-function \
-    -I include -I nuradiomc_amd/csrc $SRC -o nuradiomc_amd/lib/libnrhip.so -Wl,-rpath,/opt/rocm/lib -ldl "$@"
+OUT=nuradiomc_amd/lib/${NRHIP_LIB_NAME:-libnrhip.so}
+TAG=$(echo "${NRHIP_LIB_NAME:-libnrhip.so}" | tr -c 'A-Za-z0-9' '_')
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I include -I nuradiomc_amd/csrc"
+OBJS=""
+PIDS=""
+for f in api raytrace raytrace_refl arz birefringence earth attenuation comm cull spectral pipeline; do
+    o=nuradiomc_amd/lib/obj/${TAG}_$f.o
+    OBJS="$OBJS $o"
+    $HIPCC $FLAGS "$@" -c nuradiomc_amd/csrc/$f.hip -o $o &
+    PIDS="$PIDS $!"
+done
+for p in $PIDS; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT -Wl,-rpath,/opt/rocm/lib -ldl
 gcc -O2 -fPIC -shared -std=gnu11 -ffp-contract=off -o oracle/_build/liboracle.so oracle/nrmc_oracle.c oracle/arz_oracle.c -lm
-echo "built nuradiomc_amd/lib/libnrhip.so oracle/_build/liboracle.so"
+echo "built $OUT oracle/_build/liboracle.so"

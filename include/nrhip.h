@@ -90,6 +90,7 @@ int nrhip_synchronize(nrhip_ctx* ctx);
 /* device memory helpers (so a host language without a HIP binding can keep data resident) */
 int nrhip_malloc(nrhip_ctx* ctx, uint64_t bytes, void** dev_ptr);
 int nrhip_free(nrhip_ctx* ctx, void* dev_ptr);
+int nrhip_memset(nrhip_ctx* ctx, void* dev_dst, int32_t value, uint64_t bytes);   /* asynchronous on the context's stream */
 int nrhip_memcpy_h2d(nrhip_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes);
 int nrhip_memcpy_d2h(nrhip_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes);
 
@@ -475,6 +476,27 @@ int nrhip_comm_barrier(nrhip_comm* comm);
 int nrhip_comm_allgather_u8(nrhip_comm* comm, const uint8_t* send, uint8_t* recv, int64_t count_per_rank);
 int nrhip_comm_allreduce_i64_sum(nrhip_comm* comm, int64_t* buf, int32_t n);
 int nrhip_comm_allreduce_f64_max(nrhip_comm* comm, double* buf, int32_t n);
+
+/* ---- station-level selection of event groups for arrays (BASELINE configs 3-5) ------------------------------------------------
+ * With speedup.distance_cut a shower is skipped for a channel when |vertex - antenna| > max_distance[shower]
+ * (simulation.py:155-163); a group none of whose showers lies within max_distance + radius of the station centre (radius =
+ * largest |relative antenna position|) is therefore skipped for every channel of the station -- the quick cut the reference
+ * has at :1503-1509.  nrhip_cull_groups lists the groups in range (keep_index [n_keep], ascending; group_begin_out
+ * [n_keep + 1] = first shower of every kept group in the gathered list), nrhip_gather_groups copies their showers into compact
+ * arrays (any src / dst pair may be NULL; shower_index [n_showers_out], optional: source row of every gathered shower),
+ * nrhip_simulate_event_groups runs on those, nrhip_mask_scatter_or ORs the compact triggered mask back:
+ * dst[index[k]] |= src[k].  All array pointers DEV; centre, n_keep, n_showers_out HOST.  group_begin NULL: one shower per
+ * group. */
+int nrhip_cull_groups(nrhip_ctx* ctx, int64_t n_showers, int64_t n_groups, const int32_t* group_begin, const double* vertex,
+                      const double* max_distance, const double centre[3], double radius, int32_t* keep_index,
+                      int32_t* group_begin_out, int64_t* n_keep, int64_t* n_showers_out);
+int nrhip_gather_groups(nrhip_ctx* ctx, int64_t n_keep, const int32_t* keep_index, const int32_t* group_begin,
+                        const int32_t* group_begin_out, const double* vertex, const double* zenith, const double* azimuth,
+                        const double* energy, const int32_t* shower_type, const double* k_L, const double* vertex_time,
+                        const double* max_distance, double* o_vertex, double* o_zenith, double* o_azimuth, double* o_energy,
+                        int32_t* o_shower_type, double* o_k_L, double* o_vertex_time, double* o_max_distance,
+                        int32_t* shower_index);
+int nrhip_mask_scatter_or(nrhip_ctx* ctx, int64_t n, const int32_t* index, const uint8_t* src, uint8_t* dst);
 
 /* dst[i] = overwrite ? src[i] : dst[i] | src[i] on DEV uint8 masks (event-group mask of an array = OR over its stations) */
 int nrhip_mask_or(nrhip_ctx* ctx, int64_t n, uint8_t* dst, const uint8_t* src, int32_t overwrite);

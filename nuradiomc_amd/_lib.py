@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libnrhip.so')
+LIB_PATH = os.path.join(_HERE, 'lib', os.environ.get('NRHIP_LIB_NAME', 'libnrhip.so'))   # NRHIP_LIB_NAME: a build variant (build.sh)
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)

@@ -89,6 +89,7 @@ void nrhip_ctx_destroy(nrhip_ctx* ctx)
     if (ctx->gl3) (void)hipFree(ctx->gl3);
     if (ctx->twiddle) (void)hipFree(ctx->twiddle);
     if (ctx->w16) (void)hipFree(ctx->w16);
+    ctx->cull_ws.release();
     delete ctx;
 }
 
@@ -126,6 +127,13 @@ int nrhip_free(nrhip_ctx* ctx, void* dev_ptr)
 {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipFree(dev_ptr));
+    return 0;
+}
+int nrhip_memset(nrhip_ctx* ctx, void* dev_dst, int32_t value, uint64_t bytes)
+{
+    if (!ctx) return fail_msg("nrhip_memset: ctx is NULL");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (bytes) HIPCHK(hipMemsetAsync(dev_dst, value, bytes, ctx->stream));
     return 0;
 }
 int nrhip_memcpy_h2d(nrhip_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes)

@@ -399,6 +399,9 @@ __device__ inline double gk_node(int n, double a, double b)
 #ifndef ATT_WAVES
 #define ATT_WAVES 2
 #endif
+#ifndef GK_UNROLL
+#define GK_UNROLL 1
+#endif
 template <class F>
 __device__ inline GK gk21_from_nodes(double a, double b, F&& fval, double* __restrict__ fbuf)
 {
@@ -420,7 +423,7 @@ __device__ inline GK gk21_from_nodes(double a, double b, F&& fval, double* __res
     double fc = fval(0);
     double resk = WGK[10] * fc;
     double resabs = fabs(resk);
-#pragma unroll
+#pragma unroll GK_UNROLL
     for (int j = 0; j < 5; j++) {
         const int jtw = 2 * j + 1;
         double f1 = fval(1 + 2 * j), f2 = fval(2 + 2 * j);
@@ -430,7 +433,7 @@ __device__ inline GK gk21_from_nodes(double a, double b, F&& fval, double* __res
         resk += WGK[jtw] * fsum;
         resabs += WGK[jtw] * (fabs(f1) + fabs(f2));
     }
-#pragma unroll
+#pragma unroll GK_UNROLL
     for (int j = 0; j < 5; j++) {
         const int jtwm1 = 2 * j;
         double f1 = fval(11 + 2 * j), f2 = fval(12 + 2 * j);
@@ -441,7 +444,7 @@ __device__ inline GK gk21_from_nodes(double a, double b, F&& fval, double* __res
     }
     double reskh = resk * 0.5;
     double resasc = WGK[10] * fabs(fc - reskh);
-#pragma unroll
+#pragma unroll GK_UNROLL
     for (int j = 0; j < 10; j++) resasc += WGK[j] * (fabs(fbuf[j * ATT_BLOCK] - reskh) + fabs(fbuf[(10 + j) * ATT_BLOCK] - reskh));
     GK o;
     o.result = resk * hlgth;
@@ -467,7 +470,7 @@ struct LaneEval {
     }
 };
 
-template <int G>
+template <int G, int MODEL = 0>
 struct GroupEval {
     int lane, gl, gb;               // lane in wave, lane in group, first lane of the group
     unsigned long long gmask;       // lanes of this group
@@ -501,13 +504,56 @@ struct GroupEval {
                 AttItem li = it;
                 li.C0 = lC0;
                 li.z_turn = lzt;
-                nodes[gl] = node_shared(gk_node(gl, la1, lb1), li, m);
-                if (two) nodes[21 + gl] = node_shared(gk_node(gl, la2, lb2), li, m);
+                NodeShared n1 = node_shared(gk_node(gl, la1, lb1), li, m);
+                // SP1: the integrand is ds * (z > 0 ? 0 : min(exp(x), 1)); the depth test is a property of the node, so it is
+                // folded into ds here (ds * 0 for nodes above the surface: the same product, NaN for an infinite ds included)
+                if (MODEL == 1 && n1.z > 0) n1.ds = n1.ds * 0.;
+                nodes[gl] = n1;
+                if (two) {
+                    NodeShared n2 = node_shared(gk_node(gl, la2, lb2), li, m);
+                    if (MODEL == 1 && n2.z > 0) n2.ds = n2.ds * 0.;
+                    nodes[21 + gl] = n2;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (want) {
+            if (MODEL == 1) {
+                // straight-line evaluation: x = a(z) + b(z) ln f stays within a few tens for any physical ray, so the range /
+                // NaN branches of det_exp are checked once per rule (wave-uniform) instead of per node; a wave in which any
+                // argument leaves [-700, 700] (or is NaN) repeats the rule with the general code below
+                bool ok = true;
+                GK f1, f2;
+                f1.result = f1.abserr = f1.resabs = f1.resasc = 0.;
+                f2 = f1;
+                if (want) {
+                    const int sel = !(it.lane.f < 1.) ? 2 : 0;
+                    const double w = it.lane.w;
+                    f1 = gk21_from_nodes(a1, b1, [&](int n) {
+                        const NodeShared& s = nodes[n];
+                        const double x = s.p[sel] + s.p[sel + 1] * w;
+                        ok = ok && (fabs(x) <= 700.);
+                        return s.ds * fmin(det_exp_inrange(x), 1.);
+                    }, fbuf);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (two)
+                        f2 = gk21_from_nodes(a2, b2, [&](int n) {
+                            const NodeShared& s = nodes[21 + n];
+                            const double x = s.p[sel] + s.p[sel + 1] * w;
+                            ok = ok && (fabs(x) <= 700.);
+                            return s.ds * fmin(det_exp_inrange(x), 1.);
+                        }, fbuf);
+                }
+                if (__ballot(!ok) != 0ULL && want) {   // never on physical rays: the per-lane general code (same bits)
+                    f1 = gk21(a1, b1, it, m);
+                    if (two) f2 = gk21(a2, b2, it, m);
+                }
+                if (want) { g1 = f1; if (two) g2 = f2; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                return;
+            }
+            if (MODEL != 1 && want) {
                 // every lane reads the 21 records (same address in all lanes: LDS broadcast) and finishes its own sums
                 const int sel = (it.lane.model == 1 && !(it.lane.f < 1.)) ? 2 : 0;
                 g1 = gk21_from_nodes(a1, b1, [&](int n) {
@@ -831,7 +877,7 @@ attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const doubl
 {
     __shared__ NodeShared sh_nodes[(ATT_BLOCK / G) * 42];
     __shared__ double sh_f[20 * ATT_BLOCK];
-    GroupEval<G> ev;
+    GroupEval<G, MODEL> ev;
     ev.init(sh_nodes, sh_f);
     model = MODEL;  // compile-time: the branches on the ice model fold away
     unsigned long long my_evals = 0;

@@ -7,30 +7,6 @@
 #include <vector>
 #include "spectral.h"
 
-struct nrhip_ctx {
-    int device;
-    hipStream_t stream;
-    nrhip::IceConst ice;
-    int att_model;
-    double2* twiddle = nullptr;  // exp(-2 pi i k / FFT_MAX), k < FFT_MAX / 2
-    double* gl3 = nullptr;       // GL3 depth table [3][gl3_n] (depth, slope, offset), nrhip_ctx_set_gl3_table
-    int gl3_n = 0;
-    double2* w16 = nullptr;      // exp(-2 pi i k / (2 FFT_MAX)), k <= FFT_MAX / 2 (real <-> packed-complex FFT split)
-    std::set<struct nrhip_station*> stations;  // alive stations: nrhip_ctx_destroy releases what they hold on the GPU
-};
-
-// frees the station's device memory and events and detaches it from its context (the host object stays until
-// nrhip_station_destroy): whichever of the two destroy calls comes first, nothing dangles
-extern "C" void nrhip_station_detach(struct nrhip_station* s);
-
-int nrhip_fail(const char* what, hipError_t e);
-int nrhip_fail_msg(const char* what);
-#define HIPCHK(x)                                         \
-    do {                                                  \
-        hipError_t e_ = (x);                              \
-        if (e_ != hipSuccess) return nrhip_fail(#x, e_);  \
-    } while (0)
-
 // grow-only device buffer
 struct DevArray {
     void* p = nullptr;
@@ -49,6 +25,31 @@ struct DevArray {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T* as() const { return (T*)p; }
 };
+
+struct nrhip_ctx {
+    int device;
+    hipStream_t stream;
+    nrhip::IceConst ice;
+    int att_model;
+    double2* twiddle = nullptr;  // exp(-2 pi i k / FFT_MAX), k < FFT_MAX / 2
+    double* gl3 = nullptr;       // GL3 depth table [3][gl3_n] (depth, slope, offset), nrhip_ctx_set_gl3_table
+    int gl3_n = 0;
+    double2* w16 = nullptr;      // exp(-2 pi i k / (2 FFT_MAX)), k <= FFT_MAX / 2 (real <-> packed-complex FFT split)
+    std::set<struct nrhip_station*> stations;  // alive stations: nrhip_ctx_destroy releases what they hold on the GPU
+    DevArray cull_ws;            // scratch of nrhip_cull_groups (flags, sizes, scans)
+};
+
+// frees the station's device memory and events and detaches it from its context (the host object stays until
+// nrhip_station_destroy): whichever of the two destroy calls comes first, nothing dangles
+extern "C" void nrhip_station_detach(struct nrhip_station* s);
+
+int nrhip_fail(const char* what, hipError_t e);
+int nrhip_fail_msg(const char* what);
+#define HIPCHK(x)                                         \
+    do {                                                  \
+        hipError_t e_ = (x);                              \
+        if (e_ != hipSuccess) return nrhip_fail(#x, e_);  \
+    } while (0)
 
 struct nrhip_station {
     nrhip_ctx* ctx;

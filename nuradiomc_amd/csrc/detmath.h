@@ -43,6 +43,38 @@ __device__ inline double det_exp(double x)
     return ldexp(p, (int)kd);
 }
 
+// det_exp for arguments known to lie in [-700, 700] (no NaN / overflow / underflow branches): the same operations in the same
+// order, hence the same bits.  The Horner steps are spelled as three-address v_fma_f64 -- left to itself the compiler emits a
+// register copy plus v_fmac_f64 per step (the coefficient registers stay live), i.e. 13 extra VALU instructions per call.
+__device__ __forceinline__ double det_fma_asm(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double det_exp_inrange(double x)
+{
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00;
+    const double kd = rint(x * invln2);
+    double r = __builtin_fma(-kd, ln2HI, x);
+    r = __builtin_fma(-kd, ln2LO, r);
+    double p = det_fma_asm(1.6059043836821613e-10, r, 2.08767569878681e-09);
+    p = det_fma_asm(p, r, 2.505210838544172e-08);
+    p = det_fma_asm(p, r, 2.755731922398589e-07);
+    p = det_fma_asm(p, r, 2.7557319223985893e-06);
+    p = det_fma_asm(p, r, 2.48015873015873e-05);
+    p = det_fma_asm(p, r, 0.0001984126984126984);
+    p = det_fma_asm(p, r, 0.001388888888888889);
+    p = det_fma_asm(p, r, 0.008333333333333333);
+    p = det_fma_asm(p, r, 0.041666666666666664);
+    p = det_fma_asm(p, r, 0.16666666666666666);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p, (int)kd);
+}
+
 __device__ inline double det_log(double x)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;

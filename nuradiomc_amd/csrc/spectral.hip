@@ -635,13 +635,13 @@ __device__ inline double block_sum(double v, double* red)
 }
 __device__ inline double block_max(double v, double* red)
 {
-    red[threadIdx.x] = v;
+    // wave-level butterfly, then one LDS word per wave: two barriers instead of log2(blockDim) + 2 (max is exact in any order)
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
-        __syncthreads();
-    }
     double r = red[0];
+    for (int i = 1; i < nw; i++) r = fmax(r, red[i]);
     __syncthreads();
     return r;
 }
@@ -1473,7 +1473,9 @@ __global__ void channel_event_flags_kernel(int n_cand, int n_ch, const int* __re
 // channelBandPassFilter), without any length-L transform per item.  LDS: FFT_MAX complex (128 KB); the N/2-point field
 // buffer and the amplitude array live in its upper half until the big transform starts.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef CONV_NT
 #define CONV_NT 512
+#endif
 __global__ void __launch_bounds__(CONV_NT)
 channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list, const int* __restrict__ need,
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,

@@ -350,6 +350,11 @@ class Station:
                                                          int(step), int(averaging_divisor or 0)))
         return rolls
 
+    @staticmethod
+    def empty_stats():
+        """the stats dict of a call that had nothing to do"""
+        return SimStats().as_dict()
+
     def move_to(self, position):
         """Use this object for another station of an array of identical stations: new antenna positions [n_ch, 3], everything
         else (antennas, orientations, cable delays, filters, device tables, workspace) stays."""

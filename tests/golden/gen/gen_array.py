@@ -192,7 +192,7 @@ def run_rnog(n_groups=64, seed=41, N=256, fs=2.0, n_proc=8):
     pack('rnog', lay, cfg, N, fs, vrms, vrms_e, ice, sh, [res[g] for g in range(n_groups)], {})
 
 
-def run_rnog_arz_bire(n_groups=14, seed=43, N=4096, fs=2.0, n_stations=35):
+def run_rnog_arz_bire(n_groups=12, seed=44, N=4096, fs=2.0, n_stations=35):
     """config 4: ARZ2020 + birefringence (greenland_A) on the same array; sequential (ONE stream of profile numbers)"""
     from NuRadioMC.SignalGen.ARZ import ARZ
     g_arz = np.load(os.path.join(OUT, 'ref_arz.npz'))
@@ -212,7 +212,7 @@ def run_rnog_arz_bire(n_groups=14, seed=43, N=4096, fs=2.0, n_stations=35):
     cfg = rh.default_config(model='ARZ2020', ice_model='greenland_simple', attenuation_model='GL1')
     cfg['speedup'].update(distance_cut=True, distance_cut_coefficients=DCUT, distance_cut_sum_length=10.)
     cfg['propagation'].update(birefringence=True, birefringence_model='greenland_A', birefringence_propagation='analytical')
-    sh = draw_showers(n_groups, seed, lay['centres'], 300., (16.6, 17.6), 0.4, zmin=-1500.)
+    sh = draw_showers(n_groups, seed, lay["centres"], 300., (17.4, 18.4), 0.4, zmin=-1500.)
     det = ArrayDet(lay, N, fs)
     ice, prop = rh.make_propagator(cfg, det)
     vrms, vrms_e = rh.vrms_from_filters(cfg)
