@@ -258,10 +258,30 @@ typedef struct {
     int32_t n_antenna_tables;
     const nrhip_antenna_table* antenna_tables;
     const int32_t* antenna_table_index; /* [n_channels] or NULL */
+    /* per-channel filter chains (channelBandPassFilter's per-channel dict arguments, channelBandPassFilter.py:40-66; different
+       amplifiers per channel, RNO_G/hardwareResponseIncorporator.py:40-135): n_filter_sets > 1 chains, channel c uses chain
+       channel_filter_set[c], chain s has set_n_filters[s] stages and the stages of all chains follow each other in filter_nb /
+       filter_na / filter_b / filter_a / filter_kind (n_filters is ignored then).  n_filter_sets <= 1: the one chain above.   */
+    int32_t n_filter_sets;
+    const int32_t* channel_filter_set;   /* [n_channels] */
+    const int32_t* set_n_filters;        /* [n_filter_sets] */
+    /* measured responses for NRHIP_FILTER_TABULATED stages: rows (frequency [GHz] ascending, linear gain, unwrapped phase [rad]);
+       a stage uses filter_nb rows starting at row filter_na */
+    int32_t n_filter_table_points;
+    const double* filter_table;          /* [n_filter_table_points][3] */
 } nrhip_station_desc;
 #define NRHIP_FILTER_RATIONAL 0
 #define NRHIP_FILTER_ABS 1
 #define NRHIP_FILTER_RECTANGULAR 2
+/* gain(f) exp(i phase(f)) of a measured amplifier / signal chain: scipy interp1d(linear, 0 outside the table) of gain and of
+   the unwrapped phase, gain times the temperature correction filter_b[0] + filter_b[1] f^5 (f in GHz) --
+   NuRadioReco/detector/RNO_G/analog_components.load_amp_response :10-104, what hardwareResponseIncorporator.get_filter(...,
+   sim_to_data=True) multiplies the channel spectra with (:93-135) */
+#define NRHIP_FILTER_TABULATED 3
+/* 'gaussian_tapered' (signal_processing.py:310-321): pass band filter_b[0] .. filter_b[1] [GHz] convolved (mode 'same') with
+   signal.windows.gaussian(n_frequencies, int(round(filter_b[2] / df))) on the frequency grid the filter is applied on (it
+   depends on the trace length), normalised to a maximum of 1 */
+#define NRHIP_FILTER_GAUSSIAN_TAPERED 4
 
 typedef struct {
     int32_t askaryan_model;       /* NRHIP_ASK_*                                                        */

@@ -54,7 +54,8 @@ int nrhip_fail_msg(const char* what);
 struct nrhip_station {
     nrhip_ctx* ctx;
     nrhip::StationDev dev;
-    nrhip::FilterSet filters;
+    nrhip::FilterSet filters[NRHIP_MAX_FSETS];
+    DevArray d_filter_pool, d_ch_fset, d_filtersets;  // tabulated responses, per-channel chain index, the chains in HBM
     std::vector<double> h_pos, h_cable;
     DevArray d_pos, d_cable, d_model, d_rot, d_rot_inv, d_fc, d_lnf, d_invl, d_fpow, d_fpow_f, d_seg, d_attbin, d_anttabs, d_anttab_index;
     std::vector<DevArray> d_tabdata;  // arrays of the tabulated antenna patterns

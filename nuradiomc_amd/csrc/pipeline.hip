@@ -91,7 +91,6 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     if ((nh & (nh - 1)) != 0 || nh < 8 || nh > FFT_MAX / 2)
         return nrhip_fail_msg("nrhip_station_create: n_samples must be a power of two between 16 and 8192");
     if (d->n_att_freq <= 0 || d->n_att_freq > NRHIP_MAX_NFC) return nrhip_fail_msg("nrhip_station_create: bad n_att_freq");
-    if (d->n_filters < 0 || d->n_filters > NRHIP_MAX_FILTERS) return nrhip_fail_msg("nrhip_station_create: too many filters");
     HIPCHK(hipSetDevice(ctx->device));
     if (ensure_twiddle(ctx)) return -1;
     nrhip_station* s = new nrhip_station();
@@ -252,21 +251,66 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     v.fpow = s->d_fpow.as<double>();
     v.fpow_f = s->d_fpow_f.as<float>();
     v.seg = s->d_seg.as<unsigned char>();
-    FilterSet& f = s->filters;
-    memset(&f, 0, sizeof f);
-    f.n = d->n_filters;
-    for (int i = 0; i < f.n; i++) {
-        f.kind[i] = d->filter_kind ? d->filter_kind[i] : 0;
-        if (f.kind[i] < 0 || f.kind[i] > 2) { delete s; return nrhip_fail_msg("nrhip_station_create: unknown filter kind"); }
-        f.nb[i] = d->filter_nb[i];
-        f.na[i] = d->filter_na[i];
-        if (f.nb[i] < 1 || f.nb[i] > NRHIP_MAX_POLY || f.na[i] < 1 || f.na[i] > NRHIP_MAX_POLY) {
+    // filter chains: one for all channels (n_filter_sets <= 1), or up to NRHIP_MAX_FSETS of them with a per-channel index;
+    // the stages of all chains follow each other in the filter_* arrays
+    const int n_sets = d->n_filter_sets > 1 ? d->n_filter_sets : 1;
+    if (n_sets > NRHIP_MAX_FSETS) { delete s; return nrhip_fail_msg("nrhip_station_create: too many filter chains"); }
+    if (d->n_filter_table_points > 0) {
+        if (!d->filter_table || upload(ctx, s->d_filter_pool, d->filter_table, (size_t)3 * d->n_filter_table_points)) {
             delete s;
-            return nrhip_fail_msg("nrhip_station_create: filter polynomial too long");
+            return nrhip_fail_msg("nrhip_station_create: tabulated filter responses could not be copied");
         }
-        memcpy(f.b[i], d->filter_b + (size_t)i * NRHIP_MAX_POLY, sizeof(double) * f.nb[i]);
-        memcpy(f.a[i], d->filter_a + (size_t)i * NRHIP_MAX_POLY, sizeof(double) * f.na[i]);
     }
+    int stage0 = 0;
+    for (int fs = 0; fs < n_sets; fs++) {
+        FilterSet& f = s->filters[fs];
+        memset(&f, 0, sizeof f);
+        f.pool = s->d_filter_pool.as<double>();
+        f.n = (d->n_filter_sets > 1) ? d->set_n_filters[fs] : d->n_filters;
+        if (f.n < 0 || f.n > NRHIP_MAX_FILTERS) { delete s; return nrhip_fail_msg("nrhip_station_create: too many filters"); }
+        for (int i = 0; i < f.n; i++) {
+            const int q = stage0 + i;
+            f.kind[i] = d->filter_kind ? d->filter_kind[q] : 0;
+            if (f.kind[i] < 0 || f.kind[i] > 4) { delete s; return nrhip_fail_msg("nrhip_station_create: unknown filter kind"); }
+            f.nb[i] = d->filter_nb[q];
+            f.na[i] = d->filter_na[q];
+            if (f.kind[i] == NRHIP_FILTER_TABULATED) {
+                if (f.nb[i] < 2 || f.na[i] < 0 || f.na[i] + f.nb[i] > d->n_filter_table_points) {
+                    delete s;
+                    return nrhip_fail_msg("nrhip_station_create: tabulated filter stage outside the response table");
+                }
+                memcpy(f.b[i], d->filter_b + (size_t)q * NRHIP_MAX_POLY, sizeof(double) * 2);
+                continue;
+            }
+            if (f.nb[i] < 1 || f.nb[i] > NRHIP_MAX_POLY || f.na[i] < 1 || f.na[i] > NRHIP_MAX_POLY) {
+                delete s;
+                return nrhip_fail_msg("nrhip_station_create: filter polynomial too long");
+            }
+            memcpy(f.b[i], d->filter_b + (size_t)q * NRHIP_MAX_POLY, sizeof(double) * f.nb[i]);
+            memcpy(f.a[i], d->filter_a + (size_t)q * NRHIP_MAX_POLY, sizeof(double) * f.na[i]);
+        }
+        stage0 += f.n;
+    }
+    std::vector<int> ch_fset(n, 0);
+    for (int fs = 0; fs < NRHIP_MAX_FSETS; fs++) v.fset_tab_mask[fs] = 0;
+    for (int c = 0; c < n; c++) {
+        if (d->n_filter_sets > 1) {
+            if (!d->channel_filter_set || d->channel_filter_set[c] < 0 || d->channel_filter_set[c] >= n_sets) {
+                delete s;
+                return nrhip_fail_msg("nrhip_station_create: channel_filter_set outside the filter chains");
+            }
+            ch_fset[c] = d->channel_filter_set[c];
+        }
+        const int am = d->antenna_model[c];
+        if (am != NRHIP_ANT_TABLE) v.fset_tab_mask[ch_fset[c]] |= am == NRHIP_ANT_LPDA ? 0x1c : (1 << am);
+    }
+    if (upload(ctx, s->d_ch_fset, ch_fset.data(), (size_t)n) || upload(ctx, s->d_filtersets, s->filters, (size_t)n_sets)) {
+        delete s;
+        return -1;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    v.n_fsets = n_sets;
+    v.ch_fset = n_sets > 1 ? s->d_ch_fset.as<int>() : nullptr;
     ctx->stations.insert(s);
     *out = s;
     return 0;
@@ -293,6 +337,7 @@ void nrhip_station_detach(nrhip_station* s)
     s->d_arz_depth.release(); s->d_arz_ce.release(); s->d_arz_par.release(); s->d_bire_knots.release();
     s->d_bire_coeffs.release(); s->d_shower_profile.release(); s->d_shower_rescale.release();
     s->d_pa_channel.release(); s->d_pa_rolls.release(); s->d_pa_mask.release(); s->d_trig_on.release();
+    s->d_filter_pool.release(); s->d_ch_fset.release(); s->d_filtersets.release();
     s->ws.clear();
     s->ws_bytes.clear();
     s->ctx->stations.erase(s);
@@ -873,12 +918,12 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(tab.B_inv = WS("tab_B_inv", double2, lens.size() * (size_t)FFT_MAX));
         NEED(tab.vel = WS("tab_vel", double2, lens.size() * NRHIP_N_ANT_TAB * (size_t)NRHIP_SPEC_STRIDE));
         NEED(tab.E = WS("tab_E", double2, lens.size() * (size_t)NRHIP_E_STRIDE));
-        NEED(tab.H = WS("tab_H", double2, lens.size() * (size_t)NRHIP_SPEC_STRIDE));
+        NEED(tab.H = WS("tab_H", double2, lens.size() * sd.n_fsets * (size_t)NRHIP_SPEC_STRIDE));
         NEED(tab.Cf = WS("tab_Cf", double2, lens.size() * (size_t)NRHIP_SPEC_STRIDE));
         NEED(tab.Ci = WS("tab_Ci", double2, lens.size() * (size_t)FFT_MAX));
-        NEED(tab.hnorm = WS("tab_hnorm", double, lens.size() * NRHIP_N_ANT_TAB));
-        NEED(tab.G = WS("tab_G", double2, lens.size() * NRHIP_N_ANT_TAB * (size_t)NRHIP_G_STRIDE));
-        launch_length_tables(sm, (int)lens.size(), d_lens, sd, st->filters, ctx->twiddle, ctx->w16, tab);
+        NEED(tab.hnorm = WS("tab_hnorm", double, lens.size() * sd.n_fsets * NRHIP_N_ANT_TAB));
+        NEED(tab.G = WS("tab_G", double2, lens.size() * sd.n_fsets * NRHIP_N_ANT_TAB * (size_t)NRHIP_G_STRIDE));
+        launch_length_tables(sm, (int)lens.size(), d_lens, sd, st->d_filtersets.as<FilterSet>(), ctx->twiddle, ctx->w16, tab);
         LCHK("length_tables");
         if (cfg->amp_per_ray && n_rays > 0) {
             double *max_env, *sig_time;
@@ -944,7 +989,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         if (sd.ant_tabs) NEED(tab_nodes = WS("antenna_table_nodes", double2, (size_t)channel_grid_blocks() * 2 * sd.max_tab_freq));
         StationDev sd_ch = sd;
         if (phased) sd_ch.trig_on = st->d_pa_mask.as<unsigned char>();  // only the array's channels need traces (unless all are dumped)
-        launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd_ch, st->filters, arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
+        launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd_ch, st->filters[0], arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
                        trg, ctx->twiddle, ctx->w16, tab, scratch, co, (cfg->no_pruning || cfg->dump_traces || general || phased) ? 1 : 0, maxL,
                        it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces,
                        phased ? (cfg->dump_traces ? 0 : 1) : -1);
@@ -1047,12 +1092,12 @@ int nrhip_efield_to_voltage(nrhip_ctx* ctx, nrhip_station* st, int32_t n_efields
     NEED(tab.B_inv = WS("tab_B_inv", double2, (size_t)FFT_MAX));
     NEED(tab.vel = WS("tab_vel", double2, NRHIP_N_ANT_TAB * (size_t)NRHIP_SPEC_STRIDE));
     NEED(tab.E = WS("tab_E", double2, (size_t)NRHIP_E_STRIDE));
-    NEED(tab.H = WS("tab_H", double2, (size_t)NRHIP_SPEC_STRIDE));
+    NEED(tab.H = WS("tab_H", double2, sd.n_fsets * (size_t)NRHIP_SPEC_STRIDE));
     NEED(tab.Cf = WS("tab_Cf", double2, (size_t)NRHIP_SPEC_STRIDE));
     NEED(tab.Ci = WS("tab_Ci", double2, (size_t)FFT_MAX));
-    NEED(tab.hnorm = WS("tab_hnorm", double, NRHIP_N_ANT_TAB));
+    NEED(tab.hnorm = WS("tab_hnorm", double, sd.n_fsets * NRHIP_N_ANT_TAB));
     tab.G = nullptr;  // the generic path always goes through the chirp-z kernel
-    launch_length_tables(sm, 1, d_len, sd, st->filters, ctx->twiddle, ctx->w16, tab);
+    launch_length_tables(sm, 1, d_len, sd, st->d_filtersets.as<FilterSet>(), ctx->twiddle, ctx->w16, tab);
     LCHK("length_tables");
     double2* scratch;
     NEED(scratch = WS("channel_scratch", double2, (size_t)std::max(sd.n_ch, channel_grid_blocks()) * NRHIP_SPEC_STRIDE));

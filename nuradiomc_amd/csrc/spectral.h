@@ -7,6 +7,7 @@
 #define NRHIP_MAX_NFC 64        // coarse attenuation frequencies per ray (n_freq + n_freq / 2 <= 64)
 #define NRHIP_MAX_FILTERS 4
 #define NRHIP_MAX_POLY 24
+#define NRHIP_MAX_FSETS 4       // distinct filter chains per station (channels sharing an amplifier type share a set)
 #define NRHIP_SPEC_STRIDE 6146  // max L / 2 + 1 spectrum bins per channel (L <= 12290 with the 8192-point chirp-z)
 #define NRHIP_E_STRIDE 24584    // 2 L phase-table entries per length
 #define NRHIP_N_ANT_TAB 5       // antenna response tables per length: VPol, HPol, LPDA front / side / back lobe phase
@@ -33,6 +34,9 @@ struct StationDev {
     const int* ant_tab_index;    // [n_ch]
     int max_tab_freq;            // largest n_freq of the tables (scratch sizing)
     int tab_mask;             // bit t set: antenna table t (NRHIP_N_ANT_TAB) is needed by some channel
+    int n_fsets;              // filter chains of the station (>= 1)
+    const int* ch_fset;       // [n_ch] filter chain of every channel (nullptr: chain 0 for all)
+    int fset_tab_mask[NRHIP_MAX_FSETS];  // tab_mask restricted to the channels of one chain
     const double* rot;        // [n_ch][9] inv(E) A   (antennapattern.py:1190-1216)
     const double* rot_inv;    // [n_ch][9]
     const double* fcoarse;    // [n_fc] attenuation frequency grid
@@ -49,7 +53,12 @@ struct StationDev {
 // analog filter chain: response_i(f) = polyval(b_i, j f) / polyval(a_i, j f), highest power first
 struct FilterSet {
     int n;
-    int kind[NRHIP_MAX_FILTERS];  // 0 rational, 1 |rational|, 2 rectangular pass band b[0] <= f <= b[1]
+    // 0 rational, 1 |rational|, 2 rectangular pass band b[0] <= f <= b[1],
+    // 3 tabulated (gain, unwrapped phase) on nb grid points starting at pool[3 * na], linear interpolation, 0 outside, times
+    //   the correction b[0] + b[1] f^5 (RNO_G/analog_components.load_amp_response),
+    // 4 gaussian_tapered: pass band b[0] .. b[1] convolved with a Gaussian of sigma b[2] on the grid it is asked for
+    int kind[NRHIP_MAX_FILTERS];
+    const double* pool;  // tabulated responses of the station: (f [GHz], gain, phase [rad]) triples
     int nb[NRHIP_MAX_FILTERS], na[NRHIP_MAX_FILTERS];
     double b[NRHIP_MAX_FILTERS][NRHIP_MAX_POLY], a[NRHIP_MAX_FILTERS][NRHIP_MAX_POLY];
 };
@@ -99,11 +108,11 @@ struct LengthTables {
     double2* B_inv;  // [n_len][FFT_MAX]
     double2* vel;    // [n_len][NRHIP_N_ANT_TAB][NRHIP_SPEC_STRIDE]  analytic antenna response on the L grid (0 below 5 MHz)
     double2* E;      // [n_len][NRHIP_E_STRIDE]        exp(-2 pi i j / (2 L)), j < 2 L: every chirp / phase factor
-    double2* H;      // [n_len][NRHIP_SPEC_STRIDE]     filter chain response on the L grid
+    double2* H;      // [n_len][n_fsets][NRHIP_SPEC_STRIDE]  filter chain response on the L grid
     double2* Cf;     // [n_len][NRHIP_SPEC_STRIDE]     forward chirp exp(-i pi k^2 / (L/2)), contiguous in k
     double2* Ci;     // [n_len][FFT_MAX]               inverse chirp exp(+i pi n^2 / L), contiguous in n
-    double* hnorm;   // [n_len][NRHIP_N_ANT_TAB]                   L2 norm of the (antenna x filter) impulse response on the L grid
-    double2* G;      // [n_len][NRHIP_N_ANT_TAB][NRHIP_G_STRIDE]    (L <= FFT_MAX) spectrum on the 2 FFT_MAX grid of the L-periodic impulse
+    double* hnorm;   // [n_len][n_fsets][NRHIP_N_ANT_TAB]          L2 norm of the (antenna x filter) impulse response on the L grid
+    double2* G;      // [n_len][n_fsets][NRHIP_N_ANT_TAB][NRHIP_G_STRIDE]  (L <= FFT_MAX) spectrum on the 2 FFT_MAX grid of the L-periodic impulse
                      //                                response irfft_L(antenna x filter), all scale factors folded in
 };
 
@@ -156,8 +165,8 @@ void launch_candidate_flags(hipStream_t s, int n_events, int n_half, const Event
                             long long* n_cand_rays);  // n_cand_rays[2]: rays in candidate events, largest L / 2 >= n_half
 void launch_candidate_lists(hipStream_t s, int n_events, int n_half, const EventOut& ev, const int* cflag, const int* coff,
                             const int* lflag, const int* loff, int* cand, int* len_index, int* lens);
-void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet& fl,
-                          const double2* tw, const double2* w16, const LengthTables& tab);
+void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet* fls,
+                          const double2* tw, const double2* w16, const LengthTables& tab);   // fls: DEV [st.n_fsets]
 int channel_grid_blocks();
 void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, int ask_model,
                              const double* arz_trace, const double2* tw, double2* spec);

@@ -1231,6 +1231,31 @@ __device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl
             if (!(fl.b[i][0] <= f && f <= fl.b[i][1])) return make_double2(0., 0.);
             continue;
         }
+        if (fl.kind[i] == 4) continue;  // gaussian_tapered depends on the whole grid: applied by the table builder
+        if (fl.kind[i] == 3) {
+            // measured response (RNO_G/analog_components.py:83-104): scipy interp1d(ff, gain, fill_value=0) and
+            // interp1d(ff, unwrap(phase), fill_value=0), gain times the temperature correction c0 + c1 f^5
+            const double* t = fl.pool + 3 * (long)fl.na[i];
+            const int n = fl.nb[i];
+            double g = 0., ph = 0.;
+            if (f >= t[0] && f <= t[3 * (n - 1)]) {
+                int lo = 0, hi = n - 1;   // largest lo with t[lo] <= f (searchsorted side='left' minus one, clipped as interp1d does)
+                while (hi - lo > 1) {
+                    int mid = (lo + hi) / 2;
+                    if (t[3 * mid] < f) lo = mid;
+                    else hi = mid;
+                }
+                const double x0 = t[3 * lo], x1 = t[3 * hi];
+                const double sl_g = (t[3 * hi + 1] - t[3 * lo + 1]) / (x1 - x0), sl_p = (t[3 * hi + 2] - t[3 * lo + 2]) / (x1 - x0);
+                g = sl_g * (f - x0) + t[3 * lo + 1];
+                ph = sl_p * (f - x0) + t[3 * lo + 2];
+            }
+            g *= fl.b[i][0] + fl.b[i][1] * (f * f * f * f * f);
+            double sn, cs;
+            sincos(ph, &sn, &cs);
+            v = cmul(v, make_double2(g * cs, g * sn));
+            continue;
+        }
         if (!(f > 0)) return make_double2(0., 0.);
         double2 num = make_double2(0., 0.), den = make_double2(0., 0.);
         const double2 jw = make_double2(0., f);
@@ -1248,7 +1273,7 @@ __device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl
 // kernel: per distinct trace length L -- Bluestein tables and the analytic antenna magnitudes on the L grid
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, FilterSet fl,
+length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, const FilterSet* __restrict__ fls,
                      const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1273,8 +1298,55 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
             tab.E[(long)il * NRHIP_E_STRIDE + j] = make_double2(cs, -sn);
         }
         const double df = 1.0 / (L * (1. / st.fs));
-        for (int k = threadIdx.x; k <= m; k += blockDim.x)
-            tab.H[(long)il * NRHIP_SPEC_STRIDE + k] = apply_filters(make_double2(1., 0.), k * df, fl);
+        for (int fs = 0; fs < st.n_fsets; fs++) {
+            const FilterSet& fl = fls[fs];
+            double2* Hs = tab.H + ((long)il * st.n_fsets + fs) * NRHIP_SPEC_STRIDE;
+            for (int k = threadIdx.x; k <= m; k += blockDim.x) Hs[k] = apply_filters(make_double2(1., 0.), k * df, fl);
+            for (int i = 0; i < fl.n; i++) {
+                if (fl.kind[i] != 4) continue;
+                // gaussian_tapered (signal_processing.py:310-321) on THIS grid of n = m + 1 frequencies: the pass band
+                // (1 inside b[0] .. b[1]) convolved (mode 'same') with signal.windows.gaussian(n, int(round(roll_width / df))),
+                // divided by its maximum.  Direct sums over the pass-band bins; terms beyond 40 sigma are exactly 0 in binary64.
+                const int n = m + 1, c = (n - 1) / 2;
+                const double sigma = (double)(int)rint(fl.b[i][2] / df), mid = 0.5 * (n - 1);
+                int j_lo = (int)ceil(fl.b[i][0] / df), j_hi = (int)floor(fl.b[i][1] / df);
+                while (j_lo > 0 && (j_lo - 1) * df >= fl.b[i][0]) j_lo--;       // exactly the bins with b0 <= k df <= b1
+                while (j_lo * df < fl.b[i][0]) j_lo++;
+                while (j_hi < m && (j_hi + 1) * df <= fl.b[i][1]) j_hi++;
+                while (j_hi >= 0 && j_hi * df > fl.b[i][1]) j_hi--;
+                if (j_lo < 0) j_lo = 0;
+                if (j_hi > m) j_hi = m;
+                double* gt = (double*)smem;   // the tapered pass band on the grid
+                double lmax = 0.;
+                for (int k = threadIdx.x; k <= m; k += blockDim.x) {
+                    // full convolution index k + c, window index t = k + c - j for pass-band bin j
+                    double acc_ = 0.;
+                    int ja = j_lo, jb = j_hi;
+                    const double reach = 40. * sigma + 1.;
+                    const int t_hi = (int)floor(mid + reach), t_lo = (int)ceil(mid - reach);   // |t - mid| <= reach
+                    if (k + c - ja > t_hi) ja = k + c - t_hi;
+                    if (k + c - jb < t_lo) jb = k + c - t_lo;
+                    for (int j = ja; j <= jb; j++) {
+                        const int t = k + c - j;
+                        if (t < 0 || t >= n) continue;
+                        const double u = (t - mid) / sigma;
+                        acc_ += exp(-0.5 * (u * u));
+                    }
+                    gt[k] = acc_;
+                    lmax = fmax(lmax, acc_);
+                }
+                red[threadIdx.x] = lmax;
+                __syncthreads();
+                for (int s_ = blockDim.x / 2; s_ > 0; s_ >>= 1) {
+                    if ((int)threadIdx.x < s_) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s_]);
+                    __syncthreads();
+                }
+                const double gmax = red[0];
+                for (int k = threadIdx.x; k <= m; k += blockDim.x) Hs[k] = cscale(Hs[k], gt[k] / gmax);
+                __syncthreads();
+            }
+        }
+        __syncthreads();   // the H tables are read back below (same block)
         for (int k = threadIdx.x; k < NRHIP_SPEC_STRIDE; k += blockDim.x)
             tab.Cf[(long)il * NRHIP_SPEC_STRIDE + k] = chirp(k, m, -1.);
         for (int n = threadIdx.x; n < FFT_MAX; n += blockDim.x) tab.Ci[(long)il * FFT_MAX + n] = chirp(n, L, +1.);
@@ -1282,6 +1354,7 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
         // the "remove DC offset" cut below 5 MHz (efieldToVoltageConverter.py:313) is folded in
         for (int model = 0; model < NRHIP_N_ANT_TAB; model++) {
             if (!((st.tab_mask >> model) & 1)) continue;
+            __syncthreads();
             double* mag = (double*)smem;
             int index = 0;
             if (model != 1) {  // np.argmax(freq > cutoff): first bin above 220 MHz (VPol) / 110 MHz (LPDA), 0 if none
@@ -1317,7 +1390,7 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
             }
             double vmax = red[0];
             double max_vel = model == 0 ? 0.18 : (model == 1 ? 0.055 : 0.55);
-            double h2 = 0.;
+            double h2s[NRHIP_MAX_FSETS] = {0., 0., 0., 0.};
             for (int k = threadIdx.x; k <= m; k += blockDim.x) {
                 double f = k * df, v = mag[k];
                 if (k > 0) v *= max_vel / vmax;
@@ -1335,12 +1408,16 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
                 double2 vv = make_double2(v * cs, v * sn);
                 tab.vel[((long)il * NRHIP_N_ANT_TAB + model) * NRHIP_SPEC_STRIDE + k] = vv;
                 // |antenna x filter|^2 for the impulse-response norm (irfft keeps only the real part of DC / Nyquist)
-                double2 hk = cmul(vv, apply_filters(make_double2(1., 0.), f, fl));
-                h2 += (k == 0 || k == m) ? hk.x * hk.x : 2. * (hk.x * hk.x + hk.y * hk.y);
+                for (int fs = 0; fs < st.n_fsets; fs++) {
+                    double2 hk = cmul(vv, tab.H[((long)il * st.n_fsets + fs) * NRHIP_SPEC_STRIDE + k]);
+                    h2s[fs] += (k == 0 || k == m) ? hk.x * hk.x : 2. * (hk.x * hk.x + hk.y * hk.y);
+                }
             }
             __syncthreads();
-            h2 = block_sum(h2, red);
-            if (threadIdx.x == 0) tab.hnorm[(long)il * NRHIP_N_ANT_TAB + model] = sqrt(h2 / L);
+            for (int fs = 0; fs < st.n_fsets; fs++) {
+                const double h2 = block_sum(h2s[fs], red);
+                if (threadIdx.x == 0) tab.hnorm[((long)il * st.n_fsets + fs) * NRHIP_N_ANT_TAB + model] = sqrt(h2 / L);
+            }
         }
         // Lengths up to FFT_MAX: the channel voltage is the circular convolution (period L) of the summed, placed field
         // traces with g = (fs / sqrt 2) irfft_L(antenna x filter).  g comes from one chirp-z inverse; its spectrum on the
@@ -1348,16 +1425,17 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
         // multiplies with.  Factors folded in: 1/2 of each even/odd split (two of them), 1/FFT_MAX of the inverse.
         if (tab.G && L <= FFT_MAX) {
             const double2* E = tab.E + (long)il * NRHIP_E_STRIDE;
-            const double2* Hf = tab.H + (long)il * NRHIP_SPEC_STRIDE;
             const double2* Ci = tab.Ci + (long)il * FFT_MAX;
             const double2* Bi = tab.B_inv + (long)il * M;
             const unsigned LL = (unsigned)L;
             const int P = M - m;
             const double scale = st.fs / 1.4142135623730951 / L;
-            for (int model = 0; model < NRHIP_N_ANT_TAB; model++) {
-                if (!((st.tab_mask >> model) & 1)) continue;
+            for (int fm = 0; fm < st.n_fsets * NRHIP_N_ANT_TAB; fm++) {
+                const int fs = fm / NRHIP_N_ANT_TAB, model = fm % NRHIP_N_ANT_TAB;
+                if (!((st.fset_tab_mask[fs] >> model) & 1)) continue;
+                const double2* Hf = tab.H + ((long)il * st.n_fsets + fs) * NRHIP_SPEC_STRIDE;
                 const double2* vel = tab.vel + ((long)il * NRHIP_N_ANT_TAB + model) * NRHIP_SPEC_STRIDE;
-                double2* G = tab.G + ((long)il * NRHIP_N_ANT_TAB + model) * NRHIP_G_STRIDE;
+                double2* G = tab.G + (((long)il * st.n_fsets + fs) * NRHIP_N_ANT_TAB + model) * NRHIP_G_STRIDE;
                 double* gtmp = (double*)G;  // L doubles of the impulse response, overwritten by its spectrum below
                 __syncthreads();
                 for (int n0 = 0; n0 < L; n0 += P) {
@@ -1434,7 +1512,7 @@ channel_prefilter_kernel(int n_items, const int* __restrict__ item_event, RayWor
             if (w.ch[r] != ch) continue;
             bnd += w.e_norm[r] * (fabs(w.vfac_t[r] * w.pol_theta[r]) * cabs2(w.r_theta[r]) +
                                   fabs(w.vfac_p[r] * w.pol_phi[r]) * cabs2(w.r_phi[r])) *
-                   hnorm[(long)il * NRHIP_N_ANT_TAB + w.tab[r]];
+                   hnorm[((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[ch] : 0)) * NRHIP_N_ANT_TAB + w.tab[r]];
         }
         if (!(bnd * (1 + 1e-9) >= threshold)) {
             maxV[item] = -bnd;
@@ -1536,7 +1614,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         bool first_tab = true;
         for (int tb = 0; tb < NRHIP_N_ANT_TAB; tb++) {
             if (!((tabs >> tb) & 1)) continue;
-            const double2* G = tab.G + ((long)il * NRHIP_N_ANT_TAB + tb) * NRHIP_G_STRIDE;
+            const double2* G = tab.G + (((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[ch] : 0)) * NRHIP_N_ANT_TAB + tb) * NRHIP_G_STRIDE;
             __syncthreads();
             for (int n = threadIdx.x; n < L; n += blockDim.x) S[n] = 0.;
             __syncthreads();
@@ -1779,7 +1857,8 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
         const double2* Bf = tab.B_fwd + (long)il * M;
         const double2* Bi = tab.B_inv + (long)il * M;
         const double2* E = tab.E + (long)il * NRHIP_E_STRIDE;   // E[j] = exp(-2 pi i j / (2 L))
-        const double2* Hf = tab.H + (long)il * NRHIP_SPEC_STRIDE;
+        const int fset = st.ch_fset ? st.ch_fset[ch] : 0;
+        const double2* Hf = tab.H + ((long)il * st.n_fsets + fset) * NRHIP_SPEC_STRIDE;
         const double2* Cf = tab.Cf + (long)il * NRHIP_SPEC_STRIDE;
         const double2* Ci = tab.Ci + (long)il * FFT_MAX;
         const unsigned LL = (unsigned)L;
@@ -1792,7 +1871,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                 if (w.ch[r] != ch) continue;
                 bnd += w.e_norm[r] * (fabs(w.vfac_t[r] * w.pol_theta[r]) * cabs2(w.r_theta[r]) +
                                       fabs(w.vfac_p[r] * w.pol_phi[r]) * cabs2(w.r_phi[r])) *
-                       tab.hnorm[(long)il * NRHIP_N_ANT_TAB + w.tab[r]];
+                       tab.hnorm[((long)il * st.n_fsets + fset) * NRHIP_N_ANT_TAB + w.tab[r]];
             }
             if (!(bnd * (1 + 1e-9) >= threshold)) {
                 if (threadIdx.x == 0) out.maxV[item] = -bnd;
@@ -1981,7 +2060,6 @@ ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item
     __shared__ double red[256];
     __shared__ int red_i[256];
     const int il = *len_index_N;
-    const double2* Hf = tab.H + (long)il * NRHIP_SPEC_STRIDE;
     const int n_ev = *n_cand;
     for (int ie = blockIdx.x; ie < n_ev; ie += gridDim.x) {
       const int e = item_event[ie];
@@ -1992,6 +2070,7 @@ ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item
         __syncthreads();
         fill_amplitude(amp, st, rs);
         const double2* vel = tab.vel + ((long)il * NRHIP_N_ANT_TAB + w.tab[r]) * NRHIP_SPEC_STRIDE;
+        const double2* Hf = tab.H + ((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[w.ch[r]] : 0)) * NRHIP_SPEC_STRIDE;
         const double vt = w.vfac_t[r], vp = w.vfac_p[r], pt = w.pol_theta[r], pp = w.pol_phi[r];
         const double2 rt = w.r_theta[r], rp = w.r_phi[r];
         const double scale = st.fs / 1.4142135623730951 / N;  // freq2time
@@ -2055,7 +2134,8 @@ efield_channel_kernel(int n_efields, const double* __restrict__ traces, const do
     const int ch = blockIdx.x;
     double2* x = (double2*)smem;
     double2* acc = scratch + (long)blockIdx.x * NRHIP_SPEC_STRIDE;
-    const double2 *Bf = tab.B_fwd, *Bi = tab.B_inv, *E = tab.E, *Hf = tab.H, *Cf = tab.Cf, *Ci = tab.Ci;
+    const double2 *Bf = tab.B_fwd, *Bi = tab.B_inv, *E = tab.E, *Cf = tab.Cf, *Ci = tab.Ci;
+    const double2* Hf = tab.H + (long)(st.ch_fset ? st.ch_fset[ch] : 0) * NRHIP_SPEC_STRIDE;
     const unsigned LL = (unsigned)L;
     const double res = 1. / st.fs;
     __shared__ double sT[4], s_th, s_ph, s_vt, s_vp;
@@ -2380,13 +2460,13 @@ static void set_big_lds()
     (void)hipGetLastError();
     g_attr_set = true;
 }
-void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet& fl,
+void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet* fls,
                           const double2* tw, const double2* w16, const LengthTables& tab)
 {
     if (n_len <= 0) return;
     set_big_lds();
     int grid = n_len < 256 ? n_len : 256;
-    hipLaunchKernelGGL(length_tables_kernel, dim3(grid), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lengths, st, fl, tw, w16, tab);
+    hipLaunchKernelGGL(length_tables_kernel, dim3(grid), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lengths, st, fls, tw, w16, tab);
 }
 int channel_grid_blocks() { return 256; }
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,

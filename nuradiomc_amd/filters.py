@@ -67,7 +67,25 @@ def cheby1_analog(order, rp, passband):
     return _transform(p, k, order, passband)
 
 
-KIND_RATIONAL, KIND_ABS, KIND_RECTANGULAR = 0, 1, 2
+KIND_RATIONAL, KIND_ABS, KIND_RECTANGULAR, KIND_TABULATED, KIND_GAUSSIAN_TAPERED = 0, 1, 2, 3, 4
+
+
+def hardware_response(frequencies, gain, phase, temperature=293.15, correction=None):
+    """Filter stage for a measured amplifier / signal-chain response (NuRadioReco/detector/RNO_G/analog_components.py:10-104,
+    applied by RNO_G/hardwareResponseIncorporator.get_filter(..., sim_to_data=True) :93-135): table of frequencies [GHz], linear
+    gain and phase [rad] (unwrapped here with np.unwrap as the reference does), linear interpolation, 0 outside the table.
+    correction: None, 'rno_surface' or 'iglu' -- the reference's empirical temperature dependence c0(T) + c1(T) f^5."""
+    t = float(temperature) - 273.15
+    if correction is None:
+        c0, c1 = 1.0, 0.0
+    elif correction == 'rno_surface':
+        c0, c1 = 1.0377798029 - 0.00135258197 * t, 0.4788208019 - 0.01790064797 * t
+    elif correction == 'iglu':
+        c0, c1 = 1.1139014286 - 0.00004392995 * (t + 28.8331610295) ** 2, 0.6301058083 - 0.0208741539 * t
+    else:
+        raise NotImplementedError("temperature correction {} is not provided (rno_surface, iglu)".format(correction))
+    return dict(type='tabulated', frequencies=np.asarray(frequencies, float), gain=np.asarray(gain, float),
+                phase=np.unwrap(np.asarray(phase, float)), c0=c0, c1=c1)
 
 
 def design(spec):
@@ -77,7 +95,7 @@ def design(spec):
     if not isinstance(spec, dict):
         order, pb = spec
         return (KIND_RATIONAL,) + butter_analog(order, pb)
-    typ, pb = spec.get('type', spec.get('filter_type', 'butter')), spec['passband']
+    typ, pb = spec.get('type', spec.get('filter_type', 'butter')), spec.get('passband')
     if typ == 'rectangular':
         return KIND_RECTANGULAR, np.array([float(pb[0]), float(pb[1])]), np.array([1.0])
     if typ == 'butter':
@@ -86,7 +104,43 @@ def design(spec):
         return (KIND_ABS,) + butter_analog(spec['order'], pb)
     if typ == 'cheby1':
         return (KIND_RATIONAL,) + cheby1_analog(spec['order'], spec['rp'], pb)
-    raise NotImplementedError("filter type {} is not provided (butter, butterabs, cheby1, rectangular)".format(typ))
+    if typ == 'gaussian_tapered':   # b = (f_lo, f_hi, roll_width); grid dependent (signal_processing.py:310-321)
+        return KIND_GAUSSIAN_TAPERED, np.array([float(pb[0]), float(pb[1]), float(spec.get('roll_width', 0.0025))]), np.array([1.0])
+    if typ == 'tabulated':          # b = (c0, c1), a = table [n, 3]
+        tab = np.stack([np.asarray(spec['frequencies'], float), np.asarray(spec['gain'], float),
+                        np.asarray(spec['phase'], float)], axis=1)
+        if len(tab) < 2 or np.any(np.diff(tab[:, 0]) <= 0):
+            raise ValueError("tabulated response: frequencies must increase strictly")
+        return KIND_TABULATED, np.array([float(spec.get('c0', 1.)), float(spec.get('c1', 0.))]), np.ascontiguousarray(tab)
+    raise NotImplementedError("filter type {} is not provided (butter, butterabs, cheby1, rectangular, gaussian_tapered, "
+                              "tabulated)".format(typ))
+
+
+def gaussian_tapered(freqs, passband, roll_width):
+    """signal_processing.get_filter_response(..., 'gaussian_tapered') :310-321 on the grid freqs (numpy only)"""
+    freqs = np.asarray(freqs, float)
+    f = np.ones(freqs.shape)
+    f[freqs < passband[0]] = 0.
+    f[freqs > passband[1]] = 0.
+    n = len(freqs)
+    std = int(round(roll_width / (freqs[1] - freqs[0])))
+    w = np.exp(-0.5 * ((np.arange(n) - (n - 1) / 2.) / std) ** 2)   # signal.windows.gaussian(n, std)
+    full = np.convolve(f, w)                                        # mode 'same': the centred n entries of the full product
+    c = (n - 1) // 2
+    out = full[c:c + n]
+    return out / np.max(out)
+
+
+def tabulated(freqs, c, table):
+    """scipy interp1d(kind='linear', bounds_error=False, fill_value=0) of gain and phase, gain * (c0 + c1 f^5)"""
+    freqs = np.asarray(freqs, float)
+    x, g, ph = table[:, 0], table[:, 1], table[:, 2]
+    idx = np.clip(np.searchsorted(x, freqs), 1, len(x) - 1)
+    lo, hi = idx - 1, idx
+    inside = (freqs >= x[0]) & (freqs <= x[-1])
+    gi = np.where(inside, (g[hi] - g[lo]) / (x[hi] - x[lo]) * (freqs - x[lo]) + g[lo], 0.)
+    pi = np.where(inside, (ph[hi] - ph[lo]) / (x[hi] - x[lo]) * (freqs - x[lo]) + ph[lo], 0.)
+    return (c[0] + c[1] * freqs ** 5) * gi * np.exp(1j * pi)
 
 
 def response(freqs, filters):
@@ -99,6 +153,12 @@ def response(freqs, filters):
         kind, b, a = stage if len(stage) == 3 else (KIND_RATIONAL,) + tuple(stage)
         if kind == KIND_RECTANGULAR:
             H = H * np.where((b[0] <= freqs) & (freqs <= b[1]), 1., 0.)
+            continue
+        if kind == KIND_GAUSSIAN_TAPERED:
+            H = H * gaussian_tapered(freqs, b[:2], b[2])
+            continue
+        if kind == KIND_TABULATED:
+            H = H * tabulated(freqs, b, a)
             continue
         h = np.zeros(freqs.shape, complex)
         s = 1j * freqs[mask]

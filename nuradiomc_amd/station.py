@@ -21,7 +21,8 @@ class StationDesc(ctypes.Structure):
                 ('filter_a', L.c_double_p), ('att_bound_n_bins', ctypes.c_int32), ('att_bound_bin_width', ctypes.c_double),
                 ('att_bound_bin_inv_length', L.c_double_p), ('filter_kind', L.c_int32_p),
                 ('n_antenna_tables', ctypes.c_int32), ('antenna_tables', ctypes.c_void_p),
-                ('antenna_table_index', L.c_int32_p)]
+                ('antenna_table_index', L.c_int32_p), ('n_filter_sets', ctypes.c_int32), ('channel_filter_set', L.c_int32_p),
+                ('set_n_filters', L.c_int32_p), ('n_filter_table_points', ctypes.c_int32), ('filter_table', L.c_double_p)]
 
 
 class AntennaTable(ctypes.Structure):   # nrhip_antenna_table
@@ -166,6 +167,21 @@ def distance_cut(vertex, energy, group_begin, coefficients, sum_length=10.):
     return np.ascontiguousarray(out)
 
 
+def _same_chain(a, b):
+    """equal filter chains (sequences of stage specs)?"""
+    if len(a) != len(b):
+        return False
+    for x, y in zip(a, b):
+        if isinstance(x, dict) != isinstance(y, dict):
+            return False
+        if isinstance(x, dict):
+            if x.keys() != y.keys() or any(not np.array_equal(np.asarray(x[k]), np.asarray(y[k])) for k in x):
+                return False
+        elif not (x[0] == y[0] and tuple(x[1]) == tuple(y[1])):
+            return False
+    return True
+
+
 def _shower_type_codes(shower_type, n):
     """'HAD' / 'EM' (any case; one value or one per shower) or the integer codes -> int32 [n]"""
     code = lambda v: int(v) if isinstance(v, (int, np.integer)) else SHOWER_TO_INT[str(v).upper()]
@@ -186,13 +202,15 @@ class Station:
     n_samples / sampling_rate: the simulated trace grid; detector_sampling_rate: the detector's own ADC rate
     (sets the attenuation grid's max_detector_freq, propagation_base_class.py:66-80);
     filters: sequence of (order, (f_lo, f_hi)) Butterworth stages (f_lo = 0: low-pass) or dicts {'type': 'butter' |
-    'butterabs' | 'cheby1' | 'rectangular', 'passband', 'order', 'rp'} (signal_processing.get_filter_response) applied in order.
+    'butterabs' | 'cheby1' | 'rectangular' | 'gaussian_tapered', 'passband', 'order', 'rp', 'roll_width'}
+    (signal_processing.get_filter_response) or filters.hardware_response(...) stages (measured amplifier responses), applied
+    in order; channel_filters: one such chain per channel (at most 4 distinct chains per station).
     """
 
     def __init__(self, ctx, position, antenna='analytic_VPol', orientation=(0., 0., np.pi / 2, np.pi / 2),
                  cable_delay=0., n_samples=4096, sampling_rate=2.0, detector_sampling_rate=None, n_freq=25,
                  filters=DEFAULT_FILTERS, pre_pulse_time=200., post_pulse_time=400., readout_length=None,
-                 att_bound_depth=3000.):
+                 att_bound_depth=3000., channel_filters=None):
         self.ctx = ctx
         self._lib = L.load()
         pos = L.f64(position).reshape(-1, 3)
@@ -218,15 +236,41 @@ class Station:
         det_fs = float(detector_sampling_rate or sampling_rate)
         ff = np.fft.rfftfreq(self.n_samples, 1. / self.sampling_rate)
         self.att_freq = np.ascontiguousarray(attenuation_frequencies(ff, n_freq, 0.5 * det_fs))
-        self.filters = [flt.design(spec) for spec in filters]   # (kind, b, a) per stage
-        fkind = np.array([k for k, _, _ in self.filters] or [0], np.int32)
-        nb = np.array([len(b) for _, b, _ in self.filters], np.int32)
-        na = np.array([len(a) for _, _, a in self.filters], np.int32)
-        fb = np.zeros((max(len(self.filters), 1), flt.MAX_POLY))
-        fa = np.zeros((max(len(self.filters), 1), flt.MAX_POLY))
-        for i, (_, b, a) in enumerate(self.filters):
+        # filter chains: `filters` for every channel, or `channel_filters` = one chain per channel (equal chains share a set)
+        if channel_filters is not None:
+            if len(channel_filters) != n:
+                raise ValueError("channel_filters needs one chain per channel")
+            chains, self.channel_filter_set = [], np.zeros(n, np.int32)
+            for c, ch in enumerate(channel_filters):
+                k = next((i for i, other in enumerate(chains) if other is ch or _same_chain(other, ch)), None)
+                if k is None:
+                    chains.append(ch)
+                    k = len(chains) - 1
+                self.channel_filter_set[c] = k
+        else:
+            chains, self.channel_filter_set = [filters], np.zeros(n, np.int32)
+        if len(chains) > 4:
+            raise ValueError("at most 4 distinct filter chains per station")
+        self.filter_sets = [[flt.design(spec) for spec in chain] for chain in chains]   # (kind, b, a) per stage
+        self.filters = self.filter_sets[0]
+        stages = [stg for chain in self.filter_sets for stg in chain]
+        set_n = np.array([len(chain) for chain in self.filter_sets], np.int32)
+        fkind = np.array([k for k, _, _ in stages] or [0], np.int32)
+        nb = np.zeros(max(len(stages), 1), np.int32)
+        na = np.zeros(max(len(stages), 1), np.int32)
+        fb = np.zeros((max(len(stages), 1), flt.MAX_POLY))
+        fa = np.zeros((max(len(stages), 1), flt.MAX_POLY))
+        pool = []
+        for i, (kind, b, a) in enumerate(stages):
+            if kind == flt.KIND_TABULATED:   # nb = rows of the table, na = its first row in the pool, b = (c0, c1)
+                nb[i], na[i] = len(a), sum(len(t) for t in pool)
+                fb[i, :2] = b
+                pool.append(a)
+                continue
+            nb[i], na[i] = len(b), len(a)
             fb[i, :len(b)] = b
             fa[i, :len(a)] = a
+        pool = np.ascontiguousarray(np.concatenate(pool)) if pool else np.zeros((0, 3))
         # largest attenuation length between the surface and att_bound_depth per coarse frequency (1 m grid): lets the
         # library bound a ray's attenuation factor by exp(-0.95 D / L_max) before paying for the path integral
         self.att_bound_depth = float(att_bound_depth)
@@ -236,18 +280,21 @@ class Station:
             cache[key] = self._attenuation_bound_tables(ctx)
         self.att_bound_inv_length, self.att_bound_bin_width, n_bins, self.att_bound_bin_inv_length = cache[key]
         self._keep = (pos, cab, model, ori, self.att_freq, nb, na, fb, fa, self.att_bound_inv_length,
-                      self.att_bound_bin_inv_length, fkind, tables, tab_index, ctabs)
+                      self.att_bound_bin_inv_length, fkind, tables, tab_index, ctabs, set_n, pool, self.channel_filter_set)
         d = StationDesc(n, L.dptr(pos), L.dptr(cab), L.iptr(model), L.dptr(ori), self.n_samples, self.sampling_rate,
                         float(readout_length if readout_length is not None else self.n_samples / self.sampling_rate),
                         float(pre_pulse_time), float(post_pulse_time), len(self.att_freq), L.dptr(self.att_freq),
                         L.dptr(self.att_bound_inv_length), self.att_bound_depth, len(self.filters), L.iptr(nb), L.iptr(na), L.dptr(fb), L.dptr(fa),
                         n_bins, self.att_bound_bin_width, L.dptr(self.att_bound_bin_inv_length), L.iptr(fkind),
-                        len(tables), ctypes.cast(ctabs, ctypes.c_void_p), L.iptr(tab_index))
+                        len(tables), ctypes.cast(ctabs, ctypes.c_void_p), L.iptr(tab_index), len(self.filter_sets),
+                        L.iptr(self.channel_filter_set), L.iptr(set_n), len(pool), L.dptr(pool))
         h = ctypes.c_void_p()
         L.check(self._lib.nrhip_station_create(ctx._h, ctypes.byref(d), ctypes.byref(h)))
         self._h = h
         ctx._register_station(self)
-        self.vrms, self.vrms_efield = flt.vrms_from_filters(self.sampling_rate, self.filters)
+        # Vrms per filter chain (simulation.py:1301-1376 computes it per channel); .vrms / .vrms_efield: chain of channel 0
+        self.vrms_per_set = [flt.vrms_from_filters(self.sampling_rate, chain) for chain in self.filter_sets]
+        self.vrms, self.vrms_efield = self.vrms_per_set[self.channel_filter_set[0]]
 
     def _attenuation_bound_tables(self, ctx):
         """largest attenuation length between the surface and att_bound_depth per coarse frequency (1 m grid), and per 50 m

@@ -385,13 +385,28 @@ def butter_ba(passband, order):
 
 
 def filter_response(freqs, filters=DEFAULT_FILTERS):
-    """signal_processing.get_filter_response (:237-333) stage by stage: butter (default), butterabs, cheby1, rectangular"""
+    """signal_processing.get_filter_response (:237-333) stage by stage: butter (default), butterabs, cheby1, rectangular,
+    gaussian_tapered; 'tabulated': a measured amplifier response (RNO_G/analog_components.py)"""
     H = np.ones_like(freqs, dtype=complex)
     for flt in filters:
         typ = flt.get('type', 'butter')
-        pb = flt['passband']
+        pb = flt.get('passband')
         if typ == 'rectangular':
             H = H * np.where((pb[0] <= freqs) & (freqs <= pb[1]), 1, 0)
+            continue
+        if typ == 'gaussian_tapered':   # signal_processing.py:310-321
+            f = np.ones_like(freqs, dtype=complex)
+            f[np.where(freqs < pb[0])] = 0.0
+            f[np.where(freqs > pb[1])] = 0.0
+            w = signal.windows.gaussian(len(freqs), int(round(flt['roll_width'] / (freqs[1] - freqs[0]))))
+            f = signal.convolve(f, w, mode="same")
+            H = H * (f / np.max(f))
+            continue
+        if typ == 'tabulated':   # RNO_G/analog_components.load_amp_response :83-104 (table: f, gain, unwrapped phase)
+            from scipy.interpolate import interp1d
+            g = interp1d(flt['frequencies'], flt['gain'], bounds_error=False, fill_value=0)(freqs)
+            ph = interp1d(flt['frequencies'], flt['phase'], bounds_error=False, fill_value=0)(freqs)
+            H = H * ((flt.get('c0', 1.) + flt.get('c1', 0.) * freqs ** 5) * g * np.exp(1j * ph))
             continue
         f = np.zeros_like(freqs, dtype=complex)
         mask = freqs > 0
@@ -500,6 +515,11 @@ def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st,
     return out
 
 
+def chain_of(filters, ch):
+    """the filter chain of channel ch: `filters` is one chain for all channels or a dict {channel: chain}"""
+    return filters[ch] if isinstance(filters, dict) else filters
+
+
 def per_efield_voltage(ef, st, filters=DEFAULT_FILTERS):
     """efieldToVoltageConverterPerEfield.run (:28-101) + filter chain + Hilbert-envelope maximum
     (simulation._calculate_amp_per_ray_solution :1868-1886); native N grid."""
@@ -507,7 +527,7 @@ def per_efield_voltage(ef, st, filters=DEFAULT_FILTERS):
     Vt, Vp = antenna_response(st.antenna_of(ef['channel']), ff, ef['zenith'], ef['azimuth'], st.orientation[ef['channel']])
     v = Vt * ef['spec'][1] + Vp * ef['spec'][2]
     v[ff < 5 * units.MHz] = 0.
-    v = v * filter_response(ff, filters)
+    v = v * filter_response(ff, chain_of(filters, ef['channel']))
     trace = freq2time(v, st.fs)
     h = np.abs(signal.hilbert(trace))
     ef['signal_time'] = ef['t0'] + st.cable_delay[ef['channel']] + np.argmax(h) / st.fs   # channelAddCableDelay, :1885
@@ -537,7 +557,7 @@ def combined_voltage(efields, st, filters=DEFAULT_FILTERS, pre_pulse_time=200., 
     if L % 2 != 0:
         L += 1
     ffL = np.fft.rfftfreq(L, res)
-    H = filter_response(ffL, filters)
+    H_of = {}
     V = np.zeros((st.n_ch, L))
     for ch in range(st.n_ch):
         spec_ch = None
@@ -570,7 +590,10 @@ def combined_voltage(efields, st, filters=DEFAULT_FILTERS, pre_pulse_time=200., 
             v[ffL < 5 * units.MHz] = 0.
             spec_ch = v if spec_ch is None else spec_ch + v
         if spec_ch is not None:
-            V[ch] = freq2time(spec_ch * H, fs)
+            key = id(chain_of(filters, ch))
+            if key not in H_of:
+                H_of[key] = filter_response(ffL, chain_of(filters, ch))
+            V[ch] = freq2time(spec_ch * H_of[key], fs)
     return V, times_min, L
 
 

@@ -53,13 +53,32 @@ def _rays_with_reference_launch_parameters(g, ev, st, ice):
     return rays, sel
 
 
-@pytest.mark.parametrize('name', ['N256', 'N256_hpol', 'N256_lpda', 'N256_tab', 'N4096'])
+def hw_filters(g):
+    """the per-channel analog chains of the 'hw' fixture (tests/golden/gen/gen_hw.py): a gaussian_tapered band pass, then the
+    measured amplifier chain of the channel; {channel: chain}, equal chains being the same object"""
+    from nuradiomc_amd import filters as flt
+    chains = {}
+    for name in sorted(set(str(a) for a in g['hw_amp'])):
+        t = g['hw_table_' + name]
+        chains[name] = [dict(type='gaussian_tapered', passband=tuple(g['hw_passband']), roll_width=float(g['hw_roll_width'])),
+                        flt.hardware_response(t[:, 0], t[:, 1], t[:, 2], temperature=float(g['hw_temperature']), correction=name)]
+    return {c: chains[str(a)] for c, a in enumerate(g['hw_amp'])}
+
+
+@pytest.mark.parametrize('name', ['N256', 'N256_hpol', 'N256_lpda', 'N256_tab', 'N4096', 'N256_hw'])
 def test_chain_vs_reference(name):
     g = golden('chain_%s.npz' % name)
     st = _station(g)
     ice = g['ice']
-    vrms, vrms_e = so.vrms_from_filters(st.fs)
-    assert vrms == float(g['vrms']) and vrms_e == float(g['vrms_efield'])
+    filters = so.DEFAULT_FILTERS
+    if 'hw_amp' in g:   # per-channel chains: gaussian_tapered + measured amplifier responses
+        filters = hw_filters(g)
+        vrms, vrms_e = so.vrms_from_filters(st.fs, filters[0])
+        assert abs(vrms - float(g['vrms'])) <= 1e-12 * vrms and abs(vrms_e - float(g['vrms_efield'])) <= 1e-12 * vrms_e
+        vrms, vrms_e = float(g['vrms']), float(g['vrms_efield'])
+    else:
+        vrms, vrms_e = so.vrms_from_filters(st.fs)
+        assert vrms == float(g['vrms']) and vrms_e == float(g['vrms_efield'])
     full = {int(k): i for i, k in enumerate(g['full_ray_index'])}
     vev = {int(e): i for i, e in enumerate(g['V_events'])}
     n_checked = n_trig = n_traces = 0
@@ -73,7 +92,7 @@ def test_chain_vs_reference(name):
             assert len(sel) == 0
             continue
         o = so.simulate_event(g['vertex'][ev], g['zenith'][ev], g['azimuth'][ev], g['energy'][ev],
-                              str(g['shower_type'][ev]), k_L, st, ice, vrms, vrms_e, rays=rays)
+                              str(g['shower_type'][ev]), k_L, st, ice, vrms, vrms_e, rays=rays, filters=filters)
         assert [(r['channel'], r['iS']) for r in o['rays']] == [(int(g['ray_channel'][k]), int(g['ray_iS'][k])) for k in sel]
         for r, k in zip(o['rays'], sel):
             assert abs(r['view'] - g['ray_view'][k]) < 1e-12

@@ -144,7 +144,7 @@ def test_focusing_vs_reference():
 
 
 def test_filter_responses_vs_reference():
-    """butter / butterabs / cheby1 / rectangular stages: the oracle (scipy, like the reference) and the product's own
+    """butter / butterabs / cheby1 / rectangular / gaussian_tapered stages and measured amplifier responses: the oracle (scipy, like the reference) and the product's own
     numpy-only designs (nuradiomc_amd/filters.py, host logic) against signal_processing.get_filter_response."""
     from oracle import spectral_oracle as so
     from nuradiomc_amd import filters as flt
@@ -156,8 +156,24 @@ def test_filter_responses_vs_reference():
         scale = np.max(np.abs(ref))
         assert np.max(np.abs(so.filter_response(ff, [spec]) - ref)) <= 1e-12 * scale, spec
         assert np.max(np.abs(flt.response(ff, [flt.design(spec)]) - ref)) <= 1e-9 * scale, spec
+    # gaussian_tapered: a different response on every frequency grid (three trace lengths)
+    for i, (L, lo, hi, rw) in enumerate(g['gt_cases']):
+        f_ = np.fft.rfftfreq(int(L), 0.5)
+        spec = dict(type='gaussian_tapered', passband=(lo, hi), roll_width=rw)
+        ref = g['gt_%d' % i]
+        assert np.max(np.abs(so.filter_response(f_, [spec]) - ref)) <= 1e-12
+        assert np.max(np.abs(flt.response(f_, [flt.design(spec)]) - ref)) <= 1e-12
+    # measured amplifier chains (RNO_G/analog_components.load_amp_response) at two temperatures
+    for name, corr in (('iglu', 'iglu'), ('rno_surface', 'rno_surface')):
+        t = g['hw_table_' + name]
+        for temp in (293, 253):
+            spec = flt.hardware_response(t[:, 0], t[:, 1], t[:, 2], temperature=temp + 0.15, correction=corr)
+            ref = g['hw_%s_%d' % (name, temp)]
+            scale = np.max(np.abs(ref))
+            assert np.max(np.abs(so.filter_response(g['hw_ff'], [spec]) - ref)) <= 1e-12 * scale, (name, temp)
+            assert np.max(np.abs(flt.response(g['hw_ff'], [flt.design(spec)]) - ref)) <= 1e-12 * scale, (name, temp)
     with pytest.raises(NotImplementedError):
-        flt.design(dict(type='gaussian_tapered', passband=(0.1, 0.2), order=1))
+        flt.design(dict(type='hann_tapered', passband=(0.1, 0.2), order=1))
 
 
 def test_gl3_attenuation_vs_reference():
