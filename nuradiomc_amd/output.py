@@ -1,0 +1,331 @@
+"""Event-list input and HDF5-layout output of a simulation -- the file formats either side of the hot path (SURVEY.md section 8,
+rows f2 / f3).
+
+* `EventList`: the datasets and attributes of the reference's input files (NuRadioMC/EvtGen/generator.py:1023-1414 writes
+  them, simulation.read_input_hdf5 :1019-1057 and build_NuRadioEvents_from_hdf5 :659-762 read them): one row per shower,
+  `event_group_ids` tying the showers of one neutrino together, the first row of a group being the primary interaction.
+* `simulate_to_output`: the sequence of simulation.run() (:1454-1728) around the device path -- particle weights
+  (calculate_particle_weight :852-903), the hot path over all stations, then for the triggered (station, event group) pairs
+  what the reference stores: channelReadoutWindowCutter (window of the detector's samples starting pre_trigger_time before
+  the trigger), channelSignalReconstructor (maximum amplitude and Hilbert-envelope maximum of the windowed traces) and the
+  per (shower, channel, ray solution) tables of output_writer_hdf5.add_event_group (:95-430), in the dataset names, shapes,
+  dtypes, NaN padding and shower-id ordering of write_output_file (:449-527).
+* `OutputFile`: those datasets / attributes as a dictionary; `save_hdf5` needs h5py, `save_npz` does not -- tools/npz_to_hdf5.py
+  turns the latter into the former 1:1 on any machine that has h5py (this image's default interpreter has none).
+"""
+import json
+import numpy as np
+from . import _lib as L
+from .station import Station
+from .array import StationArray
+
+_SHOWER_KEYS = ('event_group_ids', 'shower_ids', 'xx', 'yy', 'zz', 'zeniths', 'azimuths', 'energies', 'shower_energies',
+                'shower_type', 'flavors', 'n_interaction', 'interaction_type', 'inelasticity', 'vertex_times')
+
+
+def _str(a):
+    a = np.asarray(a)
+    return a.astype(str) if a.dtype.kind in 'SO' else a
+
+
+class EventList:
+    """The reference's input event list: `data` (one entry per shower) and `attrs` (generator attributes)."""
+
+    def __init__(self, data, attrs=None):
+        self.data = {k: (_str(v) if np.asarray(v).dtype.kind in 'SUO' else np.asarray(v)) for k, v in data.items()}
+        self.attrs = dict(attrs or {})
+        for k in ('event_group_ids', 'xx', 'yy', 'zz', 'zeniths', 'azimuths', 'shower_energies', 'shower_type'):
+            if k not in self.data:
+                raise KeyError("event list without '{}'".format(k))
+        n = len(self.data['event_group_ids'])
+        if 'shower_ids' not in self.data:
+            self.data['shower_ids'] = np.arange(n)
+        if 'vertex_times' not in self.data:   # simulation.py:712-716: "setting vertex time to zero"
+            self.data['vertex_times'] = np.zeros(n)
+        gid = self.data['event_group_ids']
+        first = np.concatenate([[True], gid[1:] != gid[:-1]])
+        if len(np.unique(gid)) != first.sum():
+            raise ValueError("showers of one event group must be consecutive")
+
+    @classmethod
+    def from_hdf5(cls, path):
+        """simulation.read_input_hdf5 (:1019-1057): every dataset and attribute of the file"""
+        import h5py
+        with h5py.File(path, 'r') as f:
+            data = {k: np.array(v) for k, v in f.items() if isinstance(v, h5py.Dataset)}
+            attrs = {k: v for k, v in f.attrs.items()}
+        return cls(data, attrs)
+
+    @classmethod
+    def from_npz(cls, path):
+        """the h5py-free twin: datasets under their names, attributes as 'attr/<name>'"""
+        g = np.load(path)
+        return cls({k: g[k] for k in g.files if not k.startswith('attr/')},
+                   {k[5:]: g[k][()] for k in g.files if k.startswith('attr/')})
+
+    def __len__(self):
+        return len(self.data['event_group_ids'])
+
+    @property
+    def vertex(self):
+        return np.stack([self.data['xx'], self.data['yy'], self.data['zz']], axis=1).astype(float)
+
+    def shower_type_codes(self):
+        return np.array([{'had': 0, 'em': 1}[str(t).lower()] for t in self.data['shower_type']], np.int32)
+
+    def k_L(self):
+        """stored shower realisations (input files of re-simulations) or NaN"""
+        return np.asarray(self.data.get('shower_realization_Alvarez2009', np.full(len(self), np.nan)), float)
+
+
+class OutputFile:
+    def __init__(self):
+        self.datasets, self.attrs = {}, {}     # 'name' / 'station_<id>/name' -> array; ('', name) / ('station_<id>', name) -> value
+
+    def save_npz(self, path):
+        out = dict(self.datasets)
+        for (grp, name), v in self.attrs.items():
+            out['attr/%s@%s' % (grp, name)] = np.asarray(v.encode() if isinstance(v, str) else v)
+        for k, v in list(out.items()):
+            if np.asarray(v).dtype.kind == 'U':
+                out[k] = np.asarray(v).astype('S')
+        np.savez_compressed(path, **out)
+
+    def save_hdf5(self, path):
+        import h5py
+        write_hdf5(h5py, path, self.datasets, {('%s@%s' % k): v for k, v in self.attrs.items()})
+
+
+def write_hdf5(h5py, path, datasets, attrs):
+    """datasets: 'group/name' -> array; attrs: 'group@name' -> value ('' = file level); strings as variable-length UTF-8 like the
+    reference (output_writer_hdf5.py:470-473)"""
+    with h5py.File(path, 'w') as f:
+        for k, v in datasets.items():
+            v = np.asarray(v)
+            if v.dtype.kind in 'SU':
+                f[k] = np.array([x.decode() if isinstance(x, bytes) else str(x) for x in v], dtype=h5py.string_dtype(encoding='utf-8'))
+            else:
+                f[k] = v
+        for k, v in attrs.items():
+            grp, name = k.split('@', 1)
+            obj = f if grp == '' else f.require_group(grp)
+            v = np.asarray(v)
+            if v.dtype.kind == 'S':
+                v = v.astype(str)
+            obj.attrs[name] = v.tolist() if (v.dtype.kind == 'U' and v.ndim) else (str(v[()]) if v.dtype.kind == 'U' else v)
+
+
+def _hilbert_envelope(x):
+    """|scipy.signal.hilbert(x)| along the last axis (trace_utilities.get_hilbert_envelope)"""
+    n = x.shape[-1]
+    X = np.fft.fft(x, axis=-1)
+    h = np.zeros(n)
+    if n % 2 == 0:
+        h[0] = h[n // 2] = 1
+        h[1:n // 2] = 2
+    else:
+        h[0] = 1
+        h[1:(n + 1) // 2] = 2
+    return np.abs(np.fft.ifft(X * h, axis=-1))
+
+
+def _readout_window(V, trigger_bin, n_window, pre_bins):
+    """channelReadoutWindowCutter.run (:28-137): the trace rolled so that the window starts pre_trigger_time before the trigger
+    (whole samples here: roll; apply_time_shift on a whole number of samples is np.roll, base_trace.py:262-266), first n_window
+    samples"""
+    return np.roll(V, -(trigger_bin - pre_bins), axis=-1)[..., :n_window]
+
+
+def simulate_to_output(det, events, config=None, station_ids=None, trigger_name='simple_threshold', seed=None,
+                       detector_n_samples=None, detector_sampling_rate=None, pre_trigger_time=55., weight_mode='core_mantle_crust',
+                       cross_section_type='ctw', minimum_weight_cut=None, noise_temperature=300., **sim_kw):
+    """Run the event list through `det` (a Station or a StationArray) and return the OutputFile the reference would write (simple
+    threshold trigger; amp_per_ray tables included unless the station cannot provide them)."""
+    arr = det if isinstance(det, StationArray) else StationArray(det, np.zeros((1, 3)), relative_position=det.position, cull=False)
+    st, ctx = arr.station, arr.station.ctx
+    n_st, n_ch, nS = len(arr), len(st.position), 2
+    station_ids = list(arr.station_ids if station_ids is None else station_ids)
+    d = events.data
+    n = len(events)
+    gid = d['event_group_ids']
+    first = np.flatnonzero(np.concatenate([[True], gid[1:] != gid[:-1]]))
+    gb = np.concatenate([first, [n]])
+    n_groups = len(first)
+    vertex, types = events.vertex, events.shower_type_codes()
+    # ---- particle weights of the primaries (simulation.calculate_particle_weight :852-903)
+    weights = np.ones(n_groups)
+    if 'weights' in d and weight_mode == 'existing':
+        weights = np.asarray(d['weights'], float)[first]
+    elif weight_mode is not None:
+        from . import earth_attenuation
+        weights = earth_attenuation.get_weight(d['zeniths'][first], d['energies'][first], d['flavors'][first], mode=weight_mode,
+                                               cross_section_type=cross_section_type, vertex_position=vertex[first],
+                                               phi_nu=d['azimuths'][first], ctx=ctx)
+    sim_groups = np.ones(n_groups, bool) if minimum_weight_cut is None else (weights >= minimum_weight_cut)   # run(): :1489-1492
+    rows = np.flatnonzero(np.repeat(sim_groups, np.diff(gb)))
+    args = (vertex[rows], d['zeniths'][rows], d['azimuths'][rows], d['shower_energies'][rows], types[rows])
+    kL_in = events.k_L()[rows]
+    kw = dict(vertex_time=d['vertex_times'][rows], group_id=gid[rows], **sim_kw)
+    # ---- pass 1: which (station, group) trigger
+    trig, stats = arr.simulate_events(*args, kL_in, seed=seed, per_station=True, **kw)
+    st_trig = stats['station_triggered']
+    kL = stats.get('k_L', kL_in)
+    g_of_row = np.repeat(np.arange(n_groups), np.diff(gb))[rows]      # original group index of every simulated shower
+    sim_group_ids = np.flatnonzero(sim_groups)
+    # ---- pass 2: everything the writer stores, for the triggered groups only
+    sel_g = np.flatnonzero(trig)
+    out = OutputFile()
+    tables = {i: [] for i in range(n_st)}
+    if len(sel_g):
+        sub = np.flatnonzero(np.isin(g_of_row, sim_group_ids[sel_g]))
+        sub_gid = gid[rows][sub]
+        sub_first = np.flatnonzero(np.concatenate([[True], sub_gid[1:] != sub_gid[:-1]]))
+        sub_gb = np.concatenate([sub_first, [len(sub)]])
+
+        def collect(i, sl, s_, keep):
+            idx = np.arange(len(sub_first)) if keep is None else np.asarray(keep)
+            T = {k: s_.fetch(k).copy() for k in ('pair_n_sol', 'slot_type', 'slot_C0', 'slot_C1', 'slot_D', 'slot_T', 'slot_launch',
+                                                 'slot_keep', 'ray_slot', 'ray_zenith', 'ray_azimuth', 'ray_pol_theta',
+                                                 'ray_pol_phi', 'ev_candidate', 'ev_L', 'ev_t_min', 'ev_n_rays')}
+            if T['ev_candidate'].any():
+                T.update({k: s_.fetch(k).copy() for k in ('item_event', 'trace', 'trace_offset')})
+                for k in ('ray_max_amp_envelope', 'ray_signal_time'):
+                    try:
+                        T[k] = s_.fetch(k).copy()
+                    except L.NrhipError:
+                        pass
+            T['groups'] = idx
+            tables[i].append(T)
+        kw2 = dict(vertex_time=d['vertex_times'][rows][sub], group_id=sub_gid, **sim_kw)
+        can_amp = not getattr(st, '_birefringence_on', False) and sim_kw.get('askaryan_model', 'Alvarez2009') not in ('ARZ2019', 'ARZ2020')
+        arr.simulate_events(vertex[rows][sub], d['zeniths'][rows][sub], d['azimuths'][rows][sub], d['shower_energies'][rows][sub],
+                            types[rows][sub], np.where(np.isnan(kL[sub]), 1.0, kL[sub]), dump_traces=True, amp_per_ray=can_amp,
+                            on_station=collect, max_showers_per_call=len(sub) + 1, **kw2)
+    # ---- assemble the reference's tables
+    fs = st.sampling_rate
+    dt = 1. / fs
+    det_fs = float(detector_sampling_rate or fs)
+    n_det = int(detector_n_samples or st.n_samples)
+    n_window = int(2 * np.ceil(n_det / 2 * fs / det_fs))          # channelReadoutWindowCutter._get_number_of_samples
+    pre_bins = int(round(pre_trigger_time * fs))
+    threshold = sim_kw.get('trigger_threshold', 3.0 * st.vrms)
+    top_showers = {}    # original shower row -> dict(triggered, trigger_time)
+    for i in range(n_st):
+        sname = 'station_%d' % station_ids[i]
+        ev_rows, sh_rows = [], []
+        for T in tables[i]:
+            n_sub_groups = len(sub_first)
+            pos_of = {int(e): k for k, e in enumerate(T.get('item_event', []))}
+            # showers of the (possibly culled) list the station ran on
+            lst = np.concatenate([np.arange(sub_gb[g], sub_gb[g + 1]) for g in T['groups']]) if len(T['groups']) else np.zeros(0, int)
+            local_gb = np.concatenate([[0], np.cumsum([sub_gb[g + 1] - sub_gb[g] for g in T['groups']])]).astype(int)
+            keep = T['slot_keep'][:len(lst) * n_ch * nS].reshape(len(lst), n_ch, nS).astype(bool)
+            ray_of_slot = np.full(len(lst) * n_ch * nS, -1)
+            ray_of_slot[T['ray_slot']] = np.arange(len(T['ray_slot']))
+            ray_of_slot = ray_of_slot.reshape(len(lst), n_ch, nS)
+            for k, g in enumerate(T['groups']):
+                g_orig = sim_group_ids[sel_g][g]
+                if not st_trig[i, sel_g[g]]:
+                    continue
+                it = pos_of[k]
+                L_ = int(T['ev_L'][k])
+                V = np.array([T['trace'][T['trace_offset'][it * n_ch + c]:T['trace_offset'][it * n_ch + c + 1]] for c in range(n_ch)])
+                hit = np.flatnonzero(np.any(np.abs(V[:, :L_ - 1]) >= threshold, axis=0))   # get_majority_logic drops the last sample
+                tbin = int(hit[0])
+                t_trig = tbin * dt + T['ev_t_min'][k]
+                W = _readout_window(V, tbin, n_window, pre_bins)
+                ev_rows.append(dict(event_group_ids=gid[first[g_orig]], event_ids=0, maximum_amplitudes=np.max(np.abs(W), axis=1),
+                                    maximum_amplitudes_envelope=np.max(_hilbert_envelope(W), axis=1),
+                                    multiple_triggers_per_event=np.array([True]), trigger_times_per_event=np.array([t_trig]),
+                                    triggered_per_event=True))
+                for j in range(local_gb[k], local_gb[k + 1]):
+                    if not keep[j].any():
+                        continue      # a shower without any efield on this station is not part of the station's event (:983-1001)
+                    row = rows[sub[lst[j]]]
+                    r = dict(shower_id=d['shower_ids'][row], event_group_id_per_shower=gid[row], event_id_per_shower=d['shower_ids'][row],
+                             triggered=True, multiple_triggers=np.array([True]), trigger_times=np.array([t_trig]))
+                    nan2, nan3 = np.full((n_ch, nS), np.nan), np.full((n_ch, nS, 3), np.nan)
+                    for key in ('travel_times', 'travel_distances', 'time_shower_and_ray', 'max_amp_shower_and_ray', 'ray_tracing_C0',
+                                'ray_tracing_C1', 'ray_tracing_reflection', 'ray_tracing_reflection_case',
+                                'ray_tracing_solution_type', 'focusing_factor'):
+                        r[key] = nan2.copy()
+                    for key in ('launch_vectors', 'receive_vectors', 'polarization'):
+                        r[key] = nan3.copy()
+                    base = j * n_ch * nS
+                    for c in range(n_ch):
+                        for s in range(nS):
+                            if not keep[j, c, s]:
+                                continue
+                            q, ir = base + c * nS + s, ray_of_slot[j, c, s]
+                            r['travel_times'][c, s], r['travel_distances'][c, s] = T['slot_T'][q], T['slot_D'][q]
+                            r['ray_tracing_C0'][c, s], r['ray_tracing_C1'][c, s] = T['slot_C0'][q], T['slot_C1'][q]
+                            r['ray_tracing_solution_type'][c, s] = T['slot_type'][q]
+                            r['ray_tracing_reflection'][c, s], r['ray_tracing_reflection_case'][c, s] = 0, 1
+                            r['focusing_factor'][c, s] = 1.
+                            r['launch_vectors'][c, s] = T['slot_launch'][3 * q:3 * q + 3]
+                            zen, az = T['ray_zenith'][ir], T['ray_azimuth'][ir]
+                            ct, st_, cp, sp = np.cos(zen), np.sin(zen), np.cos(az), np.sin(az)
+                            r['receive_vectors'][c, s] = (st_ * cp, st_ * sp, ct)
+                            # polarisation angle on sky -> unit vector in the ground frame (output_writer_hdf5.py:289-297)
+                            a = np.arctan2(T['ray_pol_phi'][ir], T['ray_pol_theta'][ir])
+                            e_t, e_p = np.array([ct * cp, ct * sp, -st_]), np.array([-sp, cp, 0.])
+                            r['polarization'][c, s] = np.cos(a) * e_t + np.sin(a) * e_p
+                            if 'ray_max_amp_envelope' in T:
+                                r['max_amp_shower_and_ray'][c, s] = T['ray_max_amp_envelope'][ir]
+                                r['time_shower_and_ray'][c, s] = T['ray_signal_time'][ir]
+                    sh_rows.append(r)
+                    e = top_showers.setdefault(int(row), dict(triggered=False, t=np.nan))
+                    e['triggered'] = True
+                    e['t'] = t_trig if np.isnan(e['t']) else min(e['t'], t_trig)
+                # the primary of a triggered group is stored even without a signal of its own (:392-430)
+                top_showers.setdefault(int(first[g_orig]), dict(triggered=False, t=np.nan, primary_only=True))
+        if sh_rows:
+            order = np.argsort(np.array([r['shower_id'] for r in sh_rows]), kind='stable')
+            for key in sh_rows[0]:
+                out.datasets['%s/%s' % (sname, key)] = np.array([sh_rows[k][key] for k in order])
+            for key in ev_rows[0]:
+                out.datasets['%s/%s' % (sname, key)] = np.array([r[key] for r in ev_rows])
+        vr = np.array([st.vrms_per_set[st.channel_filter_set[c]][0] for c in range(n_ch)])
+        out.attrs[(sname, 'antenna_positions')] = arr.relative_position + arr.centres[i]
+        if sh_rows:
+            out.attrs[(sname, 'Vrms')] = vr
+            out.attrs[(sname, 'bandwidth')] = np.array([_bandwidth(st, c) for c in range(n_ch)])
+            out.attrs[(sname, 'Vrms_trigger')] = np.zeros(0)
+    srows = np.array(sorted(top_showers, key=lambda r: d['shower_ids'][r]), int)
+    if len(srows):
+        D = out.datasets
+        for key in ('shower_ids', 'event_group_ids', 'xx', 'yy', 'zz', 'vertex_times', 'azimuths', 'zeniths', 'energies', 'flavors',
+                    'n_interaction', 'interaction_type', 'inelasticity'):
+            if key in d:
+                D[key] = d[key][srows]
+        only = np.array([top_showers[int(r)].get('primary_only', False) and not top_showers[int(r)]['triggered'] for r in srows])
+        D['shower_energies'] = np.where(only, np.nan, d['shower_energies'][srows])
+        D['shower_type'] = np.where(only, '', d['shower_type'][srows])
+        g_idx = np.searchsorted(first, srows, side='right') - 1
+        D['weights'] = weights[g_idx]
+        k_all = np.full(n, np.nan)
+        k_all[rows] = kL
+        if sim_kw.get('askaryan_model', 'Alvarez2009') == 'Alvarez2009':
+            D['shower_realization_Alvarez2009'] = np.where(only, np.nan, k_all[srows])
+        D['triggered'] = np.array([top_showers[int(r)]['triggered'] for r in srows])
+        D['multiple_triggers'] = D['triggered'][:, None].copy()
+        D['trigger_times'] = np.array([[top_showers[int(r)]['t']] for r in srows])
+    for k, v in events.attrs.items():
+        out.attrs[('', k)] = v
+    out.attrs[('', 'trigger_names')] = np.array([trigger_name])
+    out.attrs[('', 'Vrms')] = st.vrms
+    out.attrs[('', 'dt')] = dt
+    out.attrs[('', 'Tnoise')] = float(noise_temperature)
+    out.attrs[('', 'bandwidth')] = _bandwidth(st, 0)
+    if config is not None:
+        out.attrs[('', 'config')] = config if isinstance(config, str) else json.dumps(config)
+    out.stats = stats
+    return out
+
+
+def _bandwidth(st, channel):
+    """integrated channel response int |H|^2 df on the reference's 10000-point grid (simulation.py:1301-1376)"""
+    from . import filters as flt
+    ff = np.linspace(0, 0.5 * st.sampling_rate, 10000)
+    H = np.abs(flt.response(ff, st.filter_sets[st.channel_filter_set[channel]]))
+    return float(np.sum(0.5 * (H[1:] ** 2 + H[:-1] ** 2) * np.diff(ff)))
