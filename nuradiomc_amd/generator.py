@@ -1,0 +1,153 @@
+"""Event-list generator: the reference's generate_eventlist_cylinder (NuRadioMC/EvtGen/generator.py:1023-1414) without the
+PROPOSAL secondaries -- vertices uniform in a cylinder or box (generate_vertex_positions :598-628, set_volume_attributes
+:392-596), isotropic arrival directions in the requested ranges, flavours, energies (get_energies :308-390: 'log_uniform' and
+'E-<gamma>'), charged / neutral current and inelasticity (utilities/inelasticities.py:16-158, model 'ctw'; the tabulated
+'hedis_bgr18' model is a download), one hadronic shower per interaction plus an electromagnetic one for nu_e CC (:1262-1283).
+
+Host-side numpy.  The random numbers come from np.random.Generator(Philox(seed)) in the reference's order of calls, so the same
+seed gives the same event list -- the one the reference would hand to the simulation (tests/golden/ref_generator.npz).
+"""
+import numpy as np
+from numpy.random import Generator, Philox
+from .output import EventList
+
+_CTW = {'cc': (-1.826, -17.31, -6.406, 1.431, -17.91), 'nc': (-1.826, -17.31, -6.448, 1.431, -18.61),
+        'cc_bar': (-1.033, -15.95, -7.247, 1.569, -17.72), 'nc_bar': (-1.033, -15.95, -7.296, 1.569, -18.30)}
+
+
+def ctw_cross_section(energy, inttype):
+    """cross_sections.param (:64-125), Connolly, Thorne, Waters, Phys. Rev. D 83, 113009 (2011); eV in, m^2 out"""
+    c = _CTW[inttype]
+    energy = np.asarray(energy, float)
+    with np.errstate(invalid='ignore'):
+        epsilon = np.log10(energy / 1e9)
+        l_eps = np.log(epsilon - c[0])
+        crscn = c[1] + c[2] * l_eps + c[3] * l_eps ** 2 + c[4] / l_eps
+        return np.power(10, crscn) * 0.01 ** 2
+
+
+def _nu_cross_section(energy, flavors, inttype):
+    """cross_sections.get_nu_cross_section(energy, flavors [n], inttype 'cc' | 'nc', 'ctw') (:350-357): the neutrino
+    parametrisation for particles AND antiparticles (that branch passes `inttype` unchanged), evaluated per subset -- below 1e4 GeV
+    the reference returns NaN for the whole subset (:69-76)"""
+    out = np.zeros_like(energy)
+    for sel in (np.where(flavors >= 0), np.where(flavors < 0)):
+        e = energy[sel]
+        out[sel] = np.nan if np.any(e < 1e4 * 1e9) else ctw_cross_section(e, inttype)
+    return out
+
+
+def set_volume_attributes(volume, attributes):
+    """set_volume_attributes (:392-596), proposal = False"""
+    n_events = attributes['n_events']
+    attributes['x0'] = volume.get('x0', 0)
+    attributes['y0'] = volume.get('y0', 0)
+    if 'fiducial_rmax' in volume:
+        attributes['fiducial_rmin'] = volume.get('fiducial_rmin', 0)
+        for key in ('fiducial_rmax', 'fiducial_zmin', 'fiducial_zmax'):
+            attributes[key] = volume[key]
+        rmin, rmax, zmin, zmax = (attributes[k] for k in ('fiducial_rmin', 'fiducial_rmax', 'fiducial_zmin', 'fiducial_zmax'))
+        v_fid = np.pi * (rmax ** 2 - rmin ** 2) * (zmax - zmin)
+        rmax, rmin = volume.get('full_rmax', rmax), volume.get('full_rmin', rmin)
+        zmax, zmin = volume.get('full_zmax', zmax), volume.get('full_zmin', zmin)
+        v_full = np.pi * (rmax ** 2 - rmin ** 2) * (zmax - zmin)
+        # the reference scales the number of events by V_full / V_fiducial TWICE in the cylinder branch (:505 and :516)
+        attributes['n_events'] = int(int(n_events * v_full / v_fid) * v_full / v_fid)
+        attributes.update(rmin=rmin, rmax=rmax, zmin=zmin, zmax=zmax, volume=np.pi * (rmax ** 2 - rmin ** 2) * (zmax - zmin),
+                          area=np.pi * (rmax ** 2 - rmin ** 2))
+    elif 'fiducial_xmax' in volume:
+        for key in ('fiducial_xmin', 'fiducial_xmax', 'fiducial_ymin', 'fiducial_ymax', 'fiducial_zmin', 'fiducial_zmax'):
+            attributes[key] = volume[key]
+        b = {k: attributes['fiducial_' + k] for k in ('xmin', 'xmax', 'ymin', 'ymax', 'zmin', 'zmax')}
+        v_fid = (b['xmax'] - b['xmin']) * (b['ymax'] - b['ymin']) * (b['zmax'] - b['zmin'])
+        if 'full_xmax' in volume:
+            b = {k: volume['full_' + k] for k in b}
+        v_full = (b['xmax'] - b['xmin']) * (b['ymax'] - b['ymin']) * (b['zmax'] - b['zmin'])
+        attributes['n_events'] = int(n_events * v_full / v_fid)
+        attributes.update(b, volume=v_full, area=(b['xmax'] - b['xmin']) * (b['ymax'] - b['ymin']))
+    else:
+        raise AttributeError("'fiducial_xmax' or 'fiducial_rmax' is not part of 'volume'. Can not define a volume")
+
+
+def generate_vertex_positions(attributes, n_events, rnd):
+    if 'fiducial_rmax' in attributes:
+        rr = rnd.uniform(attributes['rmin'] ** 2, attributes['rmax'] ** 2, n_events) ** 0.5
+        ph = rnd.uniform(0, 2 * np.pi, n_events)
+        xx, yy = rr * np.cos(ph), rr * np.sin(ph)
+        zz = rnd.uniform(attributes['zmin'], attributes['zmax'], n_events)
+    else:
+        xx = rnd.uniform(attributes['xmin'], attributes['xmax'], n_events)
+        yy = rnd.uniform(attributes['ymin'], attributes['ymax'], n_events)
+        zz = rnd.uniform(attributes['zmin'], attributes['zmax'], n_events)
+    return xx + attributes['x0'], yy + attributes['y0'], zz
+
+
+def get_energies(n_events, Emin, Emax, spectrum, rnd):
+    if spectrum == 'log_uniform':
+        return 10 ** rnd.uniform(np.log10(Emin), np.log10(Emax), n_events)
+    if spectrum.startswith('E-'):
+        gamma = float(spectrum[1:]) + 1
+        return np.exp(np.log(rnd.uniform(Emax ** gamma, Emin ** gamma, size=n_events)) / gamma)
+    raise NotImplementedError("spectrum {} not implemented".format(spectrum))
+
+
+def generate_eventlist_cylinder(n_events, Emin, Emax, volume, thetamin=0., thetamax=np.pi, phimin=0., phimax=2 * np.pi,
+                                start_event_id=1, flavor=(12, -12, 14, -14, 16, -16), spectrum='log_uniform', deposited=False,
+                                max_n_events_batch=1e5, seed=None, interaction_type='ccnc', cross_sections_model='ctw'):
+    """Returns the EventList (data sets + attributes) the reference returns with write_events=False."""
+    if cross_sections_model.lower() != 'ctw':
+        raise NotImplementedError("cross-section model {} needs a downloaded table; 'ctw' is provided".format(cross_sections_model))
+    if deposited:
+        raise NotImplementedError("deposited = True is not provided")
+    rnd = Generator(Philox(seed))
+    max_n_events_batch = int(max_n_events_batch)
+    flavor = list(flavor)
+    for f in flavor:
+        if f not in (12, -12, 14, -14, 16, -16):
+            raise ValueError("Input illegal flavor: {}".format(flavor))
+    attributes = dict(start_event_id=start_event_id, n_events=int(n_events), flavors=flavor, Emin=Emin, Emax=Emax, thetamin=thetamin,
+                      thetamax=thetamax, phimin=phimin, phimax=phimax, deposited=deposited)
+    set_volume_attributes(volume, attributes)
+    n_events = attributes['n_events']
+    n_batches = int(np.ceil(n_events / max_n_events_batch))
+    total = {}
+    for i_batch in range(n_batches):
+        nb = max_n_events_batch if i_batch + 1 < n_batches else n_events - i_batch * max_n_events_batch
+        ds = {}
+        ds['xx'], ds['yy'], ds['zz'] = generate_vertex_positions(attributes, nb, rnd)
+        ds['azimuths'] = rnd.uniform(phimin, phimax, nb)
+        ds['zeniths'] = np.arccos(rnd.uniform(np.cos(thetamax), np.cos(thetamin), nb))
+        ds['event_group_ids'] = np.arange(i_batch * max_n_events_batch, i_batch * max_n_events_batch + nb) + start_event_id
+        ds['n_interaction'] = np.ones(nb, dtype=int)
+        ds['vertex_times'] = np.zeros(nb, dtype=float)
+        ds['flavors'] = np.array([flavor[i] for i in rnd.integers(0, high=len(flavor), size=nb)])
+        ds['energies'] = get_energies(nb, Emin, Emax, spectrum, rnd)
+        if interaction_type == 'ccnc':     # inelasticities.get_ccnc (:108-157)
+            u = rnd.uniform(0., 1., nb)
+            cc = _nu_cross_section(ds['energies'], ds['flavors'], 'cc')
+            nc = _nu_cross_section(ds['energies'], ds['flavors'], 'nc')
+            with np.errstate(invalid='ignore'):
+                ds['interaction_type'] = np.where(u <= cc / (cc + nc), 'cc', 'nc')
+        elif interaction_type in ('cc', 'nc'):
+            ds['interaction_type'] = np.full(nb, interaction_type, dtype='U2')
+        else:
+            raise ValueError("Input illegal interaction type: {}".format(interaction_type))
+        # inelasticities.get_neutrino_inelasticity, model 'ctw' (:48-52)
+        ds['inelasticity'] = (-np.log(0.36787944 + rnd.uniform(0., 1., nb) * 0.63212056)) ** 2.5
+        ds['shower_energies'] = ds['energies'] * ds['inelasticity']
+        ds['shower_type'] = np.array(['had'] * nb)
+        # an electromagnetic shower after every nu_e CC interaction (:1262-1283): the row is doubled, the copy carries (1 - y) E
+        em = (ds['interaction_type'] == 'cc') & (np.abs(ds['flavors']) == 12)
+        rep = np.where(em, 2, 1)
+        idx = np.repeat(np.arange(nb), rep)
+        second = np.concatenate([[False], idx[1:] == idx[:-1]])
+        ds = {k: v[idx] for k, v in ds.items()}
+        ds['shower_energies'] = np.where(second, (1 - ds['inelasticity']) * ds['energies'], ds['shower_energies'])
+        ds['shower_type'] = np.where(second, 'em', ds['shower_type'])
+        for k, v in ds.items():
+            total.setdefault(k, []).append(v)
+    data = {k: np.concatenate(v) for k, v in total.items()}
+    data['shower_ids'] = np.arange(0, len(data['shower_energies']), dtype=int)
+    _, inverse = np.unique(data['event_group_ids'], return_inverse=True)
+    data['event_group_ids'] = inverse + start_event_id
+    return EventList(data, attributes)
