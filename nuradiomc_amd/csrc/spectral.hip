@@ -1061,15 +1061,131 @@ efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w
 // events with at least one undecided ray (the unit of work of efield_max_kernel)
 __global__ void __launch_bounds__(256)
 event_need_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, const int* __restrict__ need_ray,
-                  int* __restrict__ ev_need)
+                  int* __restrict__ ev_need, const double* __restrict__ max_efield, double min_efield, int exact)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e > n_events) return;
     int any = 0;
     if (e < n_events) {
-        for (int r = slot_offset[e]; r < slot_offset[e + 1]; r++) any |= need_ray[r];
+        bool decided = false;   // a ray whose sampled field already exceeds the cut makes the event a candidate
+        for (int r = slot_offset[e]; r < slot_offset[e + 1]; r++) {
+            any |= need_ray[r];
+            decided = decided || (max_efield[r] > min_efield);
+        }
+        if (decided && !exact) any = 0;
     }
     ev_need[e] = any;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel: the rays the sum-of-magnitudes bound leaves open, decided WITHOUT a transform where possible.  With real reflection
+// coefficients the (Alvarez2009) pulse is, up to the factor c = max |pol r|,
+//     e[N/2 + j] = -fs (2 / N) sum_k v_k sin(2 pi k j / N),   v_k = amplitude x attenuation of bin k   (i (-1)^k spectrum, N/2 roll)
+// -- antisymmetric about the centre sample.  The samples j = 1 .. ES_NJ are summed directly (exact values of the trace: a lower
+// bound on max |e|, and an upper bound on those samples), every later sample is bounded by summation by parts,
+//     |sum_k v_k e^{i k theta}| <= (v_last + sum_k |v_{k+1} - v_k|) / |sin(theta / 2)|,   theta = 2 pi j / N,
+// which falls like 1 / j while the pulse lives within a few samples of the centre.  So
+//     low = max_j |S_j| - err   <=   max |e| / scale   <=   max(max_j |S_j| + err, TV / sin(pi (ES_NJ + 1) / N))  = up,
+// and only rays with low <= cut <= up still need the N-point transform.  FP32 sums (terms within 1e-6, the sine recurrence
+// within ES_NJ^2 ulp): err = 2e-3 of sum_k v_k covers them.  One wave per ray; lanes over the bins.
+// ---------------------------------------------------------------------------------------------------------
+#ifndef ES_NJ
+#define ES_NJ 24
+#endif
+__global__ void __launch_bounds__(256)
+efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork w, StationDev st, double min_efield,
+                     double* __restrict__ max_efield, int* __restrict__ need_fft)
+{
+    __shared__ double s_xp[NRHIP_MAX_NFC];
+    __shared__ float at[4][NRHIP_MAX_NFC], at_slope[4][NRHIP_MAX_NFC];
+    // the per-bin tables of the station in LDS (N <= 4096: 3 x 2049 floats + 2049 bytes): the inner loop then never waits for HBM / L2
+    extern __shared__ __align__(16) unsigned char es_smem[];
+    const int nh = st.N / 2, stride = nh + 1;
+    float* s_fpow = (float*)es_smem;                       // [3][stride]
+    unsigned char* s_seg = (unsigned char*)(s_fpow + 3 * stride);
+    for (int j = threadIdx.x; j < 3 * stride; j += blockDim.x) s_fpow[j] = st.fpow_f[j];
+    for (int j = threadIdx.x; j < stride; j += blockDim.x) s_seg[j] = st.seg[j];
+    for (int j = threadIdx.x; j < st.n_fc; j += blockDim.x) s_xp[j] = st.fcoarse[j];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float dff = (float)(1.0 / (st.N * (1. / st.fs)));
+    const float xf_first = (float)s_xp[0], xf_last = (float)s_xp[st.n_fc - 1], dxf_last = (float)(s_xp[st.n_fc - 1] - s_xp[st.n_fc - 2]);
+    const float invN = 1.f / (float)st.N;
+    const int n_waves = gridDim.x * 4;
+    for (int ia = blockIdx.x * 4 + wv; ia < n_active; ia += n_waves) {
+        const int r = active_list[ia];
+        if (!need_fft[r]) continue;   // wave-uniform
+        const AskaryanConst& ai = w.ask[r];
+        const double2 rt = w.r_theta[r], rp = w.r_phi[r];
+        const double cL = ai.cL, cR = ai.cR, pf = ai.pref2;
+        if (ai.model != 0 || rt.y != 0. || rp.y != 0. || !(pf > 1e-18 && pf < 1e18 && cL > 1e-15 && cL < 1e15 && cR > 1e-15 && cR < 1e15))
+            continue;
+        if (lane < st.n_fc) at[wv][lane] = (float)w.att[(long)r * st.n_fc + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < st.n_fc - 1) at_slope[wv][lane] = (float)(((double)at[wv][lane + 1] - (double)at[wv][lane]) / (s_xp[lane + 1] - s_xp[lane]));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float cLf = (float)cL, cRf = (float)cR, pff = (float)pf;
+        const int had = ai.had;
+        auto value = [&](int k) -> float {   // v_k, 0 outside 1 .. nh - 1
+            if (k < 1 || k >= nh) return 0.f;
+            const float f = k * dff;
+            int lo = s_seg[k];
+            float dx = f - (float)s_xp[lo];
+            if (f <= xf_first) { lo = 0; dx = 0.f; }
+            if (f >= xf_last) { lo = st.n_fc - 2; dx = dxf_last; }
+            const float x = (had ? s_fpow[k] : s_fpow[stride + k]) * cLf, y = s_fpow[2 * stride + k] * cRf;
+            const float amp = pff * f * __builtin_amdgcn_rcpf((1.f + x) * (1.f + y));
+            return amp * fmaxf(at_slope[wv][lo] * dx + at[wv][lo], 0.f);
+        };
+        float acc[ES_NJ];
+#pragma unroll
+        for (int j = 0; j < ES_NJ; j++) acc[j] = 0.f;
+        float sum_v = 0.f, tv = 0.f;
+        for (int k = 1 + lane; k < nh; k += 64) {
+            const float v = value(k), vn = value(k + 1);
+            sum_v += v;
+            tv += fabsf(vn - v);   // the last term is |0 - v_{nh-1}| = v_last
+            const float ph = (float)k * invN;   // k / N < 1/2: exact enough for the hardware sine / cosine (argument in turns)
+            const float s1 = __builtin_amdgcn_sinf(ph), c2 = 2.f * __builtin_amdgcn_cosf(ph);
+            float sa = 0.f, sb = s1;            // sin(0), sin(theta); sin((j + 1) theta) = 2 cos(theta) sin(j theta) - sin((j - 1) theta)
+#pragma unroll
+            for (int j = 0; j < ES_NJ; j++) {
+                acc[j] += v * sb;
+                const float sc = c2 * sb - sa;
+                sa = sb;
+                sb = sc;
+            }
+        }
+        float best = 0.f;
+#pragma unroll
+        for (int j = 0; j < ES_NJ; j++) {
+            float t = acc[j];
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+            best = fmaxf(best, fabsf(t));
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            sum_v += __shfl_xor(sum_v, off);
+            tv += __shfl_xor(tv, off);
+        }
+        if (lane == 0) {
+            const double cmax = fmax(fabs(w.pol_theta[r]) * fabs(rt.x), fabs(w.pol_phi[r]) * fabs(rp.x));
+            const double err = 2e-3 * (double)sum_v + 1e-30;
+            const double tail = (double)tv * (1. + 1e-3) / sin(M_PI * (ES_NJ + 1) / st.N);
+            const double low = efield_bound((double)best - err, st.N, st.fs, cmax);
+            const double up = efield_bound(fmax((double)best + err, tail), st.N, st.fs, cmax);
+            if (low > min_efield * (1 + 1e-9)) {
+                max_efield[r] = low;    // "at least": the event is a candidate
+                need_fft[r] = 0;
+            } else if (up * (1 + 1e-9) < min_efield) {
+                max_efield[r] = -up;    // "at most": this ray cannot make the event a candidate
+                need_fft[r] = 0;
+            }
+        }
+    }
 }
 
 __global__ void scatter_flagged_kernel(int n, const int* __restrict__ flag, const int* __restrict__ offset,
@@ -2414,8 +2530,14 @@ void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int 
     if (gridA > 256 * 32) gridA = 256 * 32;
     hipLaunchKernelGGL(efield_bound_kernel, dim3(gridA), dim3(256), 0, s, n_active, active_list, w, st, min_efield, exact,
                        max_efield, need_ray);
+    if (!exact && ask_model == 0) {   // decide what the direct samples next to the pulse centre can decide
+        int gridS = (n_active + 3) / 4;
+        if (gridS > 256 * 16) gridS = 256 * 16;
+        hipLaunchKernelGGL(efield_sample_kernel, dim3(gridS), dim3(256), (size_t)(nh + 1) * 13, s, n_active, active_list, w, st,
+                           min_efield, max_efield, need_ray);
+    }
     hipLaunchKernelGGL(event_need_kernel, dim3(grid_for(n_events + 1, 256)), dim3(256), 0, s, n_events, st.n_ch, slot_offset,
-                       need_ray, ev_need);
+                       need_ray, ev_need, max_efield, min_efield, exact);
     launch_exclusive_scan(s, (long)n_events + 1, ev_need, ev_offset, scan_tmp);
     hipLaunchKernelGGL(scatter_flagged_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, ev_need, ev_offset,
                        ev_list);

@@ -68,3 +68,44 @@ def test_distance_cut_host_logic():
     single = distance_cut(g['vertex'], g['energy'], None, coef)
     assert np.allclose(single, np.maximum(100., 10 ** poly(np.log10(g['energy']))), rtol=4e-16, atol=0)
     assert distance_cut(np.zeros((1, 3)), [0.], None, coef)[0] == 100.
+
+
+def _id_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from nuradiomc_amd import comm
+    payload = bytes(range(128)) if rank == 0 else b''
+    got = comm.exchange_bytes(payload, rank, world, addr='127.0.0.1', port=port, timeout=60.)
+    q.put((rank, got == bytes(range(128))))
+
+
+def test_comm_id_exchange_and_shard_helpers():
+    """nuradiomc_amd.comm (the RCCL path of bench.py, no torch): the 128-byte communicator id reaches every rank over TCP (world
+    size 3 on the loopback), shard_chunks tiles a sorted list round-robin, the sequencing helpers order and split as the
+    reference does."""
+    import multiprocessing
+    from nuradiomc_amd import comm, sequencing
+    ctx = multiprocessing.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_id_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs[1:] + procs[:1]:      # the clients may come up before the server
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == {0: True, 1: True, 2: True}
+    # chunked round-robin sharding of a sorted list: a partition, chunk c -> rank c % W
+    n, W, chunk = 100003, 4, 1000
+    parts = [comm.shard_chunks(n, r, W, chunk) for r in range(W)]
+    assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(n))
+    assert all(np.all((p // chunk) % W == r) for r, p in enumerate(parts))
+    assert max(len(p) for p in parts) - min(len(p) for p in parts) <= chunk
+    # order in which the reference meets the showers: group -> station -> channel -> shower
+    first = np.array([[-1, 3, 0, 2, -1, 1],     # station 0: first channel with a kept ray per shower (-1: none)
+                      [0, 0, 1, -1, -1, 0]])    # station 1
+    order = sequencing.reference_draw_order(first, np.array([0, 3, 6]))   # two groups of three showers
+    assert list(order) == [2, 1, 0, 5, 3]       # group 0: station 0 ch 0 (sh 2), ch 3 (sh 1), then station 1 ch 0 (sh 0); ...
+    # split_event_time_diff: gaps larger than the limit start a new sub-event (simulation.group_into_events :906-947)
+    t = np.array([100., 5000., 130., 5100., 9999.])
+    assert list(sequencing.split_event_times(t, 1000.)) == [0, 1, 0, 1, 2]
+    assert list(sequencing.split_event_times(t, 1e6)) == [0, 0, 0, 0, 0]
