@@ -325,6 +325,17 @@ typedef struct {
        by station (simulation.py:1500: "each station is treated independently"; an event group is kept when any station
        triggered); stats->n_triggered then counts the accumulated mask */
     int32_t accumulate_triggered;
+    /* reflections off the bottom of an ice shelf inside the batched path (propagation.n_reflections with a medium that has a
+       reflective layer, e.g. mooresbay_simple: z_reflection = -576 m, reflection_coefficient 0.82, reflection_phase_shift pi;
+       medium_base.py:IceModelSimple, analyticraytracing.py:2118-2130, :2966-3009): ray tables get 2 + 4 n_reflections solution
+       slots per pair ("slot_*" tables, plus "slot_reflection", "slot_reflection_case", "slot_n_segments"), a ray's attenuation is
+       the product over its path segments, its field is multiplied by r_p / r_s once per surface reflection and by
+       reflection_coefficient e^{i reflection_phase_shift} once per bottom reflection.  0 = none.  Not together with
+       birefringence or focusing. */
+    int32_t n_reflections;
+    double z_reflection;
+    double reflection_coefficient;
+    double reflection_phase_shift;
 } nrhip_sim_config;
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1

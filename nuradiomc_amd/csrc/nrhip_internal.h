@@ -20,6 +20,11 @@ struct RayRecords {
     double* launch;      // [n_pairs][MAXS][3]
     double* receive;     // [n_pairs][MAXS][3]
     double* refl_angle;  // surface reflection zenith angle, NaN = none
+    // solution slots per pair: NRHIP_MAXS, or 2 + 4 n_reflections with reflections off the bottom of an ice shelf; then also
+    // per slot the number of bottom reflections and bit j of surface_mask = path segment j reflects at the surface
+    int stride = NRHIP_MAXS;
+    const int* reflection = nullptr;
+    const int* surface_mask = nullptr;
 };
 
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,

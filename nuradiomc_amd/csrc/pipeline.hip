@@ -474,14 +474,15 @@ int nrhip_station_set_birefringence(nrhip_station* s, const int32_t* n_knots, co
 
 // first channel of the station on which a shower has a ray that passes the delta_C cut (-1: none): what the host needs to
 // walk the showers in the order in which the reference meets them (simulation.py:1454-1600 with :143-242)
-__global__ void shower_first_channel_kernel(long n_showers, int n_ch, const int* __restrict__ keep, int* __restrict__ first)
+__global__ void shower_first_channel_kernel(long n_showers, int n_ch, const int* __restrict__ keep, int* __restrict__ first,
+                                            int stride)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_showers) return;
     int f = -1;
     for (int c = 0; c < n_ch && f < 0; c++)
-        for (int s = 0; s < NRHIP_MAXS; s++)
-            if (keep[(i * n_ch + c) * NRHIP_MAXS + s]) f = c;
+        for (int s = 0; s < stride; s++)
+            if (keep[(i * n_ch + c) * stride + s]) f = c;
     first[i] = f;
 }
 
@@ -537,7 +538,13 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     hipStream_t sm = ctx->stream;
     const StationDev& sd = st->dev;
     const int n_ch = sd.n_ch;
-    const long n_pairs = n_events * n_ch, n_slots = n_pairs * NRHIP_MAXS;
+    // solution slots per pair: 2, or 2 + 4 n with n reflections off the bottom of an ice shelf (propagation_base_class.py:424-429)
+    const int n_refl = cfg->n_reflections;
+    if (n_refl < 0 || n_refl > NRHIP_MAX_REFLECTIONS) return nrhip_fail_msg("nrhip_simulate_events: n_reflections must be 0..4");
+    if (n_refl > 0 && !(cfg->z_reflection < 0))
+        return nrhip_fail_msg("nrhip_simulate_events: reflections off the bottom are requested, but no reflective layer is given (z_reflection)");
+    const int S_ = n_refl > 0 ? 2 + 4 * n_refl : NRHIP_MAXS, NS_ = n_refl + 1;
+    const long n_pairs = n_events * n_ch, n_slots = n_pairs * S_;
     if (n_slots > 2000000000L) return nrhip_fail_msg("nrhip_simulate_events: batch too large, split the event list");
     S.n_pairs = n_pairs;
     // general emission / propagation path?
@@ -550,6 +557,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need one profile per shower (nrhip_station_set_shower_profiles)");
     if (arz && cfg->focusing) return nrhip_fail_msg("nrhip_simulate_events: focusing is not available with the ARZ models");
     if (general && cfg->amp_per_ray) return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray is not available with ARZ / birefringence");
+    if (cfg->n_reflections > 0 && (bire || cfg->focusing))
+        return nrhip_fail_msg("nrhip_simulate_events: bottom reflections are not available together with birefringence or focusing");
     const bool phased = cfg->trigger_type == NRHIP_TRIG_PHASED_ARRAY;
     if (phased && st->pa_n_channels <= 0)
         return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger needs its channels and beams (nrhip_station_set_phased_array)");
@@ -585,7 +594,33 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (reuse && (st->rays_n_showers != n_showers || st->rays_delta_C != cfg->delta_C_cut || st->rays_vertex != vertex))
         return nrhip_fail_msg("nrhip_simulate_events: reuse_ray_tables without matching ray tables of a previous call");
     st->rays_n_showers = -1;
-    if (!reuse) {
+    rec.stride = S_;
+    double *seg_zint = nullptr, *seg_C0 = nullptr;
+    if (n_refl > 0) {
+        int *rf, *rc, *nseg, *smask, *cand_n;
+        double* cand_C0;
+        const int n_calls = 1 + 2 * n_refl;
+        NEED(rf = WS("slot_reflection", int, n_slots));
+        NEED(rc = WS("slot_reflection_case", int, n_slots));
+        NEED(nseg = WS("slot_n_segments", int, n_slots));
+        NEED(smask = WS("slot_surface_mask", int, n_slots));
+        NEED(seg_zint = WS("slot_segment_limits", double, (size_t)n_slots * NS_ * 3));
+        NEED(seg_C0 = WS("slot_segment_C0", double, (size_t)n_slots * NS_));
+        NEED(cand_n = WS("refl_candidates_n", int, (size_t)n_pairs * n_calls));
+        NEED(cand_C0 = WS("refl_candidates_C0", double, (size_t)n_pairs * n_calls * 3));
+        rec.reflection = rf;
+        rec.surface_mask = smask;
+        if (!reuse) {
+            // ray_tracing(medium, n_reflections = n).find_solutions (analyticraytracing.py:2118-2130): the plain finder plus, per
+            // number of bottom reflections, one search for rays starting upwards and one for rays starting downwards
+            ReflRecords rr{rec.n_sol, rec.type, rf, rc, nseg, smask, rec.C0, rec.C1, rec.D, rec.T, rec.launch, rec.receive,
+                           rec.refl_angle, seg_zint, seg_C0};
+            launch_find_refl(sm, n_pairs, n_refl, vertex, sd.pos, n_ch, ctx->ice, cfg->z_reflection, cand_n, cand_C0);
+            launch_records_refl(sm, n_pairs, n_refl, S_, vertex, sd.pos, n_ch, ctx->ice, cfg->z_reflection, cand_n, cand_C0, 0, rr);
+            if (max_distance) launch_distance_cut_pairs(sm, n_pairs, n_ch, vertex, sd.pos, max_distance, rec.n_sol);
+            LCHK("raytrace (bottom reflections)");
+        }
+    } else if (!reuse) {
         HIPCHK(hipMemsetAsync(geo_hist, 0, sizeof(int) * 16385, sm));
         launch_event_cells(sm, (int)n_events, vertex, sd.pos, geo_cell, geo_hist);
         launch_exclusive_scan(sm, 16385, geo_hist, geo_off, geo_tmp);
@@ -620,7 +655,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         int* first;
         NEED(first = WS("shower_first_channel", int, n_showers));
         hipLaunchKernelGGL(shower_first_channel_kernel, dim3((unsigned)((n_showers + 255) / 256)), dim3(256), 0, sm, (long)n_showers,
-                           n_ch, keep, first);
+                           n_ch, keep, first, S_);
         LCHK("shower_first_channel");
         HIPCHK(hipStreamSynchronize(sm));
         if (stats) *stats = S;
@@ -640,7 +675,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     // ray range of every event group (rays are ordered by shower; a group's showers are consecutive)
     int* grp_ray;
     NEED(grp_ray = WS("group_ray_begin", int, n_groups + 1));
-    launch_group_ray_range(sm, (int)n_groups, group_begin, n_ch, offset, grp_ray);
+    launch_group_ray_range(sm, (int)n_groups, group_begin, n_ch, offset, grp_ray, S_);
     LCHK("group ranges");
 
     RayWork w;
@@ -705,7 +740,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             foc_launch = rec2.launch;
         }
         launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w, evin,
-                         arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model, foc_n_sol, foc_launch, foc_dz, cfg->focusing_limit > 0 ? cfg->focusing_limit : 2.);
+                         arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model, foc_n_sol, foc_launch, foc_dz, cfg->focusing_limit > 0 ? cfg->focusing_limit : 2.,
+                         cfg->reflection_coefficient, cfg->reflection_phase_shift);
         LCHK("ray_setup");
     }
     MARK(2);
@@ -755,8 +791,24 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         HIPCHK(hipMemsetAsync(eval_counter, 0, sizeof(unsigned long long), sm));
         if (ctx->att_model == NRHIP_ATT_GL3 && (!ctx->gl3 || sd.n_fc > 32))
             return nrhip_fail_msg("nrhip_simulate_events: GL3 needs nrhip_ctx_set_gl3_table and at most 32 attenuation frequencies");
-        launch_attenuation_items(sm, n_active, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr,
-                                 active_list, eval_counter, ctx->gl3, ctx->gl3_n);
+        if (n_refl > 0) {
+            // get_attenuation_along_path with bottom reflections (:933-1089): the product over the path segments, each with its
+            // own launch parameter and limits (segment tables of the ray records)
+            double *rs_C0, *rs_zint, *rs_att;
+            int* items;
+            NEED(rs_C0 = WS("ray_segment_C0", double, nr * NS_));
+            NEED(rs_zint = WS("ray_segment_limits", double, nr * NS_ * 3));
+            NEED(rs_att = WS("ray_segment_att", double, nr * NS_ * sd.n_fc));
+            NEED(items = WS("ray_segment_items", int, (size_t)n_active * NS_));
+            launch_gather_segments(sm, n_rays, NS_, ray_slot, seg_C0, seg_zint, rs_C0, rs_zint);
+            launch_segment_items(sm, n_active, NS_, active_list, items);
+            launch_attenuation_items(sm, (long)n_active * NS_, rs_C0, rs_zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, rs_att,
+                                     nullptr, items, eval_counter, ctx->gl3, ctx->gl3_n);
+            launch_segment_product_rays(sm, n_active, NS_, sd.n_fc, active_list, rs_C0, rs_att, w.att);
+        } else {
+            launch_attenuation_items(sm, n_active, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr,
+                                     active_list, eval_counter, ctx->gl3, ctx->gl3_n);
+        }
         LCHK("attenuation");
     }
     MARK(4);

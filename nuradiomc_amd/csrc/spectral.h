@@ -8,8 +8,8 @@
 #define NRHIP_MAX_FILTERS 4
 #define NRHIP_MAX_POLY 24
 #define NRHIP_MAX_FSETS 4       // distinct filter chains per station (channels sharing an amplifier type share a set)
-#define NRHIP_SPEC_STRIDE 6146  // max L / 2 + 1 spectrum bins per channel (L <= 12290 with the 8192-point chirp-z)
-#define NRHIP_E_STRIDE 24584    // 2 L phase-table entries per length
+#define NRHIP_SPEC_STRIDE 8192  // max L / 2 + 1 spectrum bins per channel (L / 2 <= 8192 - N / 2 + 1 with the 8192-point chirp-z, L <= 16128 at N = 256)
+#define NRHIP_E_STRIDE 32768    // 2 L phase-table entries per length
 #define NRHIP_N_ANT_TAB 5       // antenna response tables per length: VPol, HPol, LPDA front / side / back lobe phase
 #define NRHIP_G_STRIDE 8200     // FFT_MAX + 1 bins of the 2 FFT_MAX-point real transform of the impulse response (padded)
 
@@ -143,12 +143,20 @@ void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const in
 void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex, const double* zen,
                       const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w,
                       const EventIn& evin, int ask_model, const int* foc_n_sol = nullptr, const double* foc_launch = nullptr,
-                      double foc_dz = 0., double foc_limit = 0.);
+                      double foc_dz = 0., double foc_limit = 0., double refl_coefficient = 1., double refl_phase = 0.);
+void launch_gather_segments(hipStream_t s, int n_rays, int NS, const int* ray_slot, const double* seg_C0, const double* seg_zint,
+                            double* ray_seg_C0, double* ray_seg_zint);
+void launch_segment_items(hipStream_t s, int n_active, int NS, const int* active_list, int* items);
+void launch_segment_product_rays(hipStream_t s, int n_active, int NS, int n_fc, const int* active_list, const double* ray_seg_C0,
+                                 const double* seg_att, double* att);
+void launch_distance_cut_pairs(hipStream_t s, long n_pairs, int n_ch, const double* vertex, const double* pos, const double* max_dist,
+                               int* n_sol);
 void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
                                   const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint);
 void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, const IceConst& m,
                       const double* vertex, const double* zint, double* bound, double* max_efield);
-void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin, int n_ch, const int* slot_offset, int* grp_ray);
+void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin, int n_ch, const int* slot_offset, int* grp_ray,
+                            int stride = NRHIP_MAXS);
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
                            double min_efield, int* ray_active);
 void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const int* offset, int* list);

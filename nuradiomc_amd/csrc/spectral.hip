@@ -207,13 +207,14 @@ select_rays_kernel(long n_pairs, int n_ch, const double* __restrict__ vertex, co
     for (int d = 0; d < 3; d++) sd[d] = -1 * axis[d];
     double n_index = n_index_at(vertex[3 * e + 2], m);
     double cherenkov = acos(1. / n_index);
-    for (int s = 0; s < NRHIP_MAXS; s++) {
+    const int S = rec.stride;
+    for (int s = 0; s < S; s++) {
         int k = 0;
         if (s < ns) {
-            double view = viewing_angle(sd, rec.launch + 3 * (i * NRHIP_MAXS + s));
+            double view = viewing_angle(sd, rec.launch + 3 * (i * S + s));
             k = !(fabs(view - cherenkov) > delta_C_cut);
         }
-        keep[i * NRHIP_MAXS + s] = k;
+        keep[i * S + s] = k;
     }
 }
 
@@ -382,12 +383,13 @@ __global__ void __launch_bounds__(256)
 ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const double* __restrict__ vertex,
                  const double* __restrict__ zenith, const double* __restrict__ azimuth, RayRecords rec, IceConst m,
                  StationDev st, RayWork w, EventIn evin, int ask_model, const int* __restrict__ foc_n_sol,
-                 const double* __restrict__ foc_launch, double foc_dz, double foc_limit)
+                 const double* __restrict__ foc_launch, double foc_dz, double foc_limit, double refl_coefficient,
+                 double refl_phase)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
     int slot = ray_slot[r];
-    long pair = slot / NRHIP_MAXS;
+    long pair = slot / rec.stride;
     long e = pair / n_ch;
     int ch = (int)(pair - e * n_ch);
     double axis[3], sd[3];
@@ -397,7 +399,7 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
     const double* rv = rec.receive + 3 * (long)slot;
     w.ev[r] = (int)e;
     w.ch[r] = ch;
-    w.sol[r] = slot % NRHIP_MAXS;
+    w.sol[r] = slot % rec.stride;
     w.view[r] = viewing_angle(sd, lv);
     w.n_index[r] = n_index_at(vertex[3 * e + 2], m);
     w.R[r] = rec.D[slot];
@@ -440,6 +442,25 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
         q = make_double2((num.x * den.x + num.y * den.y) / dd, (num.y * den.x - num.x * den.y) / dd);
         rph = cconj(q);
     }
+    if (rec.reflection) {
+        // paths with bottom reflections (analyticraytracing.py:2966-3009): one Fresnel factor per path segment that reflects at
+        // the surface, and per bottom reflection the layer's coefficient and phase shift on both components
+        int n_surf = __popc((unsigned)rec.surface_mask[slot]);
+        double2 pt = make_double2(1., 0.), pp = make_double2(1., 0.);
+        for (int q_ = 0; q_ < n_surf; q_++) { pt = cmul(pt, rth); pp = cmul(pp, rph); }
+        const int n_refl = rec.reflection[slot];
+        if (n_refl > 0) {
+            const double coef = pow(refl_coefficient, (double)n_refl);
+            const double phase = fmod(n_refl * refl_phase, 2 * M_PI);
+            double sn, cs;
+            sincos(phase, &sn, &cs);
+            const double2 f = make_double2(coef * cs, coef * sn);
+            pt = cmul(pt, f);
+            pp = cmul(pp, f);
+        }
+        rth = pt;
+        rph = pp;
+    }
     w.r_theta[r] = rth;
     w.r_phi[r] = rph;
     double T[4], th_a, ph_a;
@@ -463,7 +484,7 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
         const double rec_ang = acos(-rv[2] / sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]));
         const double lau_ang = acos(lv[2] / sqrt(lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2]));
         double f = 1.0;
-        if (slot % NRHIP_MAXS < foc_n_sol[pair]) {
+        if (slot % rec.stride < foc_n_sol[pair]) {
             const double* l1 = foc_launch + 3 * (long)slot;
             const double lau_ang1 = acos(l1[2] / sqrt(l1[0] * l1[0] + l1[1] * l1[1] + l1[2] * l1[2]));
             const double dzz = (cz + foc_dz) - cz;
@@ -490,9 +511,15 @@ ray_limits_from_slots_kernel(int n_rays, int n_ch, const int* __restrict__ ray_s
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
     int slot = ray_slot[r];
-    long pair = slot / NRHIP_MAXS;
+    long pair = slot / rec.stride;
     long e = pair / n_ch;
     int ch = (int)(pair - e * n_ch);
+    if (rec.reflection && rec.reflection[slot] > 0) {
+        // path with bottom reflections: several segments, integrated separately (launch_attenuation_segments); the depth-binned
+        // pruning bound takes no attenuation credit for it (zero path length in every bin -> factor 1)
+        zint[3 * (long)r] = zint[3 * (long)r + 1] = zint[3 * (long)r + 2] = 0.;
+        return;
+    }
     double A[3] = {vertex[3 * e], vertex[3 * e + 1], vertex[3 * e + 2]};
     double B[3] = {chan_pos[3 * ch], chan_pos[3 * ch + 1], chan_pos[3 * ch + 2]};
     if (B[2] < A[2]) {
@@ -887,12 +914,12 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
 // ray range of every event group: rays are ordered by shower, the showers of a group are consecutive.
 // group_begin == nullptr: every shower is its own group.
 __global__ void group_ray_range_kernel(int n_groups, const int* __restrict__ group_begin, int n_ch,
-                                       const int* __restrict__ slot_offset, int* __restrict__ grp_ray)
+                                       const int* __restrict__ slot_offset, int* __restrict__ grp_ray, int stride)
 {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g > n_groups) return;
     long sh = group_begin ? group_begin[g] : g;
-    grp_ray[g] = slot_offset[sh * n_ch * NRHIP_MAXS];
+    grp_ray[g] = slot_offset[sh * n_ch * stride];
 }
 
 // per event: can any ray exceed the cut?  (1 + 1e-6 absorbs rounding of the bound and of exp(-integral) <= 1)
@@ -2465,11 +2492,82 @@ void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const in
 void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex, const double* zen,
                       const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w,
                       const EventIn& evin, int ask_model, const int* foc_n_sol, const double* foc_launch, double foc_dz,
-                      double foc_limit)
+                      double foc_limit, double refl_coefficient, double refl_phase)
 {
     if (n_rays <= 0) return;
     hipLaunchKernelGGL(ray_setup_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, n_ch, ray_slot, vertex, zen,
-                       az, rec, m, st, w, evin, ask_model, foc_n_sol, foc_launch, foc_dz, foc_limit);
+                       az, rec, m, st, w, evin, ask_model, foc_n_sol, foc_launch, foc_dz, foc_limit, refl_coefficient, refl_phase);
+}
+
+// ---- paths with bottom reflections: attenuation = product over the path segments ----------------------------------------
+// per kept ray the launch parameter and integration limits of its segments, gathered from the slot tables
+__global__ void gather_segments_kernel(int n_rays, int NS, const int* __restrict__ ray_slot, const double* __restrict__ seg_C0,
+                                       const double* __restrict__ seg_zint, double* __restrict__ ray_seg_C0,
+                                       double* __restrict__ ray_seg_zint)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_rays * NS) return;
+    const long r = i / NS, j = i % NS, q = (long)ray_slot[r] * NS + j;
+    ray_seg_C0[i] = seg_C0[q];
+    for (int d = 0; d < 3; d++) ray_seg_zint[3 * i + d] = seg_zint[3 * q + d];
+}
+__global__ void segment_items_kernel(int n_active, int NS, const int* __restrict__ active_list, int* __restrict__ items)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_active * NS) return;
+    items[i] = active_list[i / NS] * NS + (int)(i % NS);
+}
+__global__ void segment_product_rays_kernel(int n_active, int NS, int n_fc, const int* __restrict__ active_list,
+                                            const double* __restrict__ ray_seg_C0, const double* __restrict__ seg_att,
+                                            double* __restrict__ att)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_active * n_fc) return;
+    const long r = active_list[i / n_fc];
+    const int f = (int)(i % n_fc);
+    double a = NAN;
+    for (int j = 0; j < NS; j++) {
+        if (isnan(ray_seg_C0[r * NS + j])) continue;
+        const double v = seg_att[(r * NS + j) * n_fc + f];
+        a = isnan(a) ? v : a * v;
+    }
+    att[r * n_fc + f] = a;
+}
+void launch_gather_segments(hipStream_t s, int n_rays, int NS, const int* ray_slot, const double* seg_C0, const double* seg_zint,
+                            double* ray_seg_C0, double* ray_seg_zint)
+{
+    if (n_rays <= 0) return;
+    hipLaunchKernelGGL(gather_segments_kernel, dim3(grid_for((long)n_rays * NS, 256)), dim3(256), 0, s, n_rays, NS, ray_slot, seg_C0,
+                       seg_zint, ray_seg_C0, ray_seg_zint);
+}
+void launch_segment_items(hipStream_t s, int n_active, int NS, const int* active_list, int* items)
+{
+    if (n_active <= 0) return;
+    hipLaunchKernelGGL(segment_items_kernel, dim3(grid_for((long)n_active * NS, 256)), dim3(256), 0, s, n_active, NS, active_list, items);
+}
+void launch_segment_product_rays(hipStream_t s, int n_active, int NS, int n_fc, const int* active_list, const double* ray_seg_C0,
+                                 const double* seg_att, double* att)
+{
+    if (n_active <= 0) return;
+    hipLaunchKernelGGL(segment_product_rays_kernel, dim3(grid_for((long)n_active * n_fc, 256)), dim3(256), 0, s, n_active, NS, n_fc,
+                       active_list, ray_seg_C0, seg_att, att);
+}
+// speedup.distance_cut for the reflection finder (which has no such input): pairs farther apart than the shower's cut get no solution
+__global__ void distance_cut_pairs_kernel(long n_pairs, int n_ch, const double* __restrict__ vertex, const double* __restrict__ pos,
+                                          const double* __restrict__ max_dist, int* __restrict__ n_sol)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    const long e = i / n_ch;
+    const int c = (int)(i % n_ch);
+    const double dx = pos[3 * c] - vertex[3 * e], dy = pos[3 * c + 1] - vertex[3 * e + 1], dz = pos[3 * c + 2] - vertex[3 * e + 2];
+    if (sqrt(dx * dx + dy * dy + dz * dz) > max_dist[e]) n_sol[i] = 0;
+}
+void launch_distance_cut_pairs(hipStream_t s, long n_pairs, int n_ch, const double* vertex, const double* pos, const double* max_dist,
+                               int* n_sol)
+{
+    if (n_pairs <= 0) return;
+    hipLaunchKernelGGL(distance_cut_pairs_kernel, dim3(grid_for(n_pairs, 256)), dim3(256), 0, s, n_pairs, n_ch, vertex, pos, max_dist, n_sol);
 }
 void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
                                   const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint)
@@ -2488,10 +2586,11 @@ void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const Station
     if (grid > 256 * 32) grid = 256 * 32;
     hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, m, vertex, zint, bound, max_efield);
 }
-void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin, int n_ch, const int* slot_offset, int* grp_ray)
+void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin, int n_ch, const int* slot_offset, int* grp_ray,
+                            int stride)
 {
     hipLaunchKernelGGL(group_ray_range_kernel, dim3(grid_for(n_groups + 1, 256)), dim3(256), 0, s, n_groups, group_begin, n_ch,
-                       slot_offset, grp_ray);
+                       slot_offset, grp_ray, stride);
 }
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
                            double min_efield, int* ray_active)

@@ -77,7 +77,9 @@ class SimConfig(ctypes.Structure):
                 ('n_coincidences', ctypes.c_int32), ('threshold_high', ctypes.c_double), ('threshold_low', ctypes.c_double),
                 ('high_low_window', ctypes.c_double), ('coinc_window', ctypes.c_double), ('amp_per_ray', ctypes.c_int32),
                 ('focusing', ctypes.c_int32), ('focusing_limit', ctypes.c_double), ('select_only', ctypes.c_int32),
-                ('reuse_ray_tables', ctypes.c_int32), ('accumulate_triggered', ctypes.c_int32)]
+                ('reuse_ray_tables', ctypes.c_int32), ('accumulate_triggered', ctypes.c_int32), ('n_reflections', ctypes.c_int32),
+                ('z_reflection', ctypes.c_double), ('reflection_coefficient', ctypes.c_double),
+                ('reflection_phase_shift', ctypes.c_double)]
 
 
 class SimStats(ctypes.Structure):
@@ -300,15 +302,19 @@ class Station:
         """largest attenuation length between the surface and att_bound_depth per coarse frequency (1 m grid), and per 50 m
         depth bin: lets the library bound a ray's attenuation factor before paying for the path integral"""
         zz = np.linspace(-self.att_bound_depth, 0., int(self.att_bound_depth) + 1)
-        lmax = np.array([np.max(ctx.attenuation_length(zz, f)) for f in self.att_freq])
-        att_bound_inv_length = np.ascontiguousarray(1.0 / (lmax * (1 + 1e-3)))
+        # depths where the model has no (finite, positive) length -- e.g. below the shelf of the Moore's Bay fit -- bound nothing
+        def inverse(z, f):
+            with np.errstate(all='ignore'):
+                length = ctx.attenuation_length(z, f)
+                return np.where(np.isfinite(length) & (length > 0), 1.0 / length, 0.)
+        att_bound_inv_length = np.ascontiguousarray([np.min(inverse(zz, f)) / (1 + 1e-3) for f in self.att_freq])
         # the same per 50 m depth bin (0.25 m grid, 1e-3 for what happens between grid points): the library sums
         # (path length inside the bin) / L_max(bin) along the ray, a much tighter bound on the path integral
         bin_width = 50.
         n_bins = min(63, int(np.ceil(self.att_bound_depth / bin_width)))
         per = int(round(bin_width / 0.25))
         zz = -np.arange(n_bins * per + 1) * 0.25
-        inv = np.array([1.0 / ctx.attenuation_length(zz, f) for f in self.att_freq])            # [n_fc][n_z]
+        inv = np.array([inverse(zz, f) for f in self.att_freq])            # [n_fc][n_z]
         idx = np.arange(n_bins)[:, None] * per + np.arange(per + 1)[None, :]
         bin_inv = np.ascontiguousarray(inv[:, idx].min(axis=2).T * (1 - 1e-3))  # [n_bins][n_fc]
         return att_bound_inv_length, bin_width, n_bins, bin_inv
@@ -434,7 +440,8 @@ class Station:
                             d_vertex_time=None, n_groups=None, d_group_begin=None, trigger='simple', n_coincidences=1,
                             threshold_high=None, threshold_low=None, high_low_window=5., coinc_window=200., amp_per_ray=False,
                             d_max_distance=None, focusing=False, focusing_limit=2., select_only=False, reuse_ray_tables=False,
-                            accumulate_triggered=False):
+                            accumulate_triggered=False, n_reflections=0, z_reflection=0., reflection_coefficient=1.,
+                            reflection_phase_shift=0.):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
         d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
@@ -443,7 +450,8 @@ class Station:
         'phased_array' (set_phased_array first): trigger_threshold is the threshold on the beams' mean window power.
         select_only: stop after ray tracing and the delta_C cut (then fetch('shower_first_channel')); reuse_ray_tables:
         continue from the tables of such a call on the same device arrays; accumulate_triggered: OR into d_triggered
-        instead of overwriting it (nrhip_sim_config)."""
+        instead of overwriting it (nrhip_sim_config).  n_reflections > 0: rays reflected off the bottom of an ice shelf at depth
+        z_reflection (< 0) with the layer's reflection_coefficient and reflection_phase_shift [rad] (medium.reflection...)."""
         if trigger not in ('simple', 'high_low', 'phased_array'):
             raise NotImplementedError("trigger {} is not provided (simple, high_low, phased_array)".format(trigger))
         cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
@@ -453,7 +461,8 @@ class Station:
                         float(3.0 * self.vrms if threshold_high is None else threshold_high),
                         float(-3.0 * self.vrms if threshold_low is None else threshold_low), float(high_low_window),
                         float(coinc_window), int(bool(amp_per_ray)), int(bool(focusing)), float(focusing_limit),
-                        int(bool(select_only)), int(bool(reuse_ray_tables)), int(bool(accumulate_triggered)))
+                        int(bool(select_only)), int(bool(reuse_ray_tables)), int(bool(accumulate_triggered)), int(n_reflections),
+                        float(z_reflection), float(reflection_coefficient), float(reflection_phase_shift))
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_event_groups(
             self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,
@@ -633,7 +642,8 @@ class Station:
                      'ray_r_theta': np.complex128, 'ray_r_phi': np.complex128, 'lengths': np.int32,
                      'pair_n_sol': np.int32, 'slot_type': np.int32, 'ev_ray_begin': np.int32, 'ray_active': np.int32,
                      'ray_active_list': np.int32, 'ray_slot': np.int32, 'slot_keep': np.int32, 'slot_offset': np.int32,
-                     'shower_first_channel': np.int32}
+                     'shower_first_channel': np.int32, 'slot_reflection': np.int32, 'slot_reflection_case': np.int32,
+                     'slot_n_segments': np.int32, 'slot_surface_mask': np.int32}
 
     def fetch(self, name):
         """One table of the last simulated batch as a numpy array (see include/nrhip.h: nrhip_sim_fetch)."""

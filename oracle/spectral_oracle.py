@@ -449,12 +449,14 @@ class Station:
 
 def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model='SP1', n_freq=25,
                           model='Alvarez2009', delta_C_cut=0.698, vertex_time=0., rays=None, max_distance=None,
-                          focusing=False, focusing_limit=2., arz=None, birefringence=None):
+                          focusing=False, focusing_limit=2., arz=None, birefringence=None, reflections=None):
     """calculate_sim_efield (simulation.py:93-292) for every channel of one single-shower event.
     `rays` may carry precomputed ray tables (dict like raytrace_oracle.raytrace_batch output, one row per channel).
     arz = (arz_oracle.ARZ object, profile number of this shower) for model 'ARZ2019' / 'ARZ2020' (simulation.py:221-242: every
     ray of a shower uses the same profile); birefringence = (tck of the three depth splines, angle_to_iceflow or None)
     (apply_propagation_effects, analyticraytracing.py:3018-3030).
+    reflections = (n_reflections, z_reflection, reflection_coefficient, reflection_phase_shift): a medium with a reflective
+    bottom layer (propagation.n_reflections; analyticraytracing.py:2118-2130, :2966-3009).
     Returns a list of dicts (one per kept ray, channel-major then solution)."""
     N, dt = st.n_samples, 1. / st.fs
     x1 = np.asarray(vertex, float)
@@ -462,6 +464,8 @@ def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st,
     shower_direction = -1 * shower_axis
     n_index = ice[0] - ice[1] * np.exp(x1[2] / ice[2]) if x1[2] <= 0 else 1.
     cherenkov = np.arccos(1. / n_index)
+    if rays is None and reflections is not None:
+        rays = rto.raytrace_batch_refl(np.tile(x1, (st.n_ch, 1)), st.pos, ice, reflections[0], reflections[1])
     if rays is None:
         rays = rto.raytrace_batch(np.tile(x1, (st.n_ch, 1)), st.pos, ice)
     ff = np.fft.rfftfreq(N, dt)
@@ -489,16 +493,30 @@ def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st,
                 spectrum, _ = askaryan_frequency_spectrum(energy, view[s], N, dt, shower_type, n_index, D, model, k_L=k_L)
             pol = polarization_onsky(shower_direction, rays['launch'][ch, s])
             spec = np.outer(pol, spectrum)
-            att = rto.attenuation_batch(x1[None], st.pos[ch][None], [rays['C0'][ch, s]], ice, att_model, fcoarse)[0]
+            if reflections is not None:
+                att = rto.attenuation_batch_refl(x1[None], st.pos[ch][None], [rays['C0'][ch, s]], [rays['reflection'][ch, s]],
+                                                 [rays['reflection_case'][ch, s]], ice, reflections[1], att_model, fcoarse)[0]
+            else:
+                att = rto.attenuation_batch(x1[None], st.pos[ch][None], [rays['C0'][ch, s]], ice, att_model, fcoarse)[0]
             spec = spec * attenuation_on_grid(ff, fcoarse, att)
             r_theta = r_phi = 1.
             ra = rays['refl_angle'][ch, s]
             if not np.isnan(ra):
                 n1 = ice[0] - ice[1] * np.exp(-1 * units.cm / ice[2])
-                r_theta = fresnel_r_p(ra, n_2=1., n_1=n1)
-                r_phi = fresnel_r_s(ra, n_2=1., n_1=n1)
+                # one factor per path segment that reflects at the surface (:2966-2997)
+                n_surf = 1 if reflections is None else bin(int(rays['surface_mask'][ch, s])).count('1')
+                r_theta = fresnel_r_p(ra, n_2=1., n_1=n1) ** n_surf
+                r_phi = fresnel_r_s(ra, n_2=1., n_1=n1) ** n_surf
+                spec = np.array(spec, complex)
                 spec[1] = spec[1] * r_theta
                 spec[2] = spec[2] * r_phi
+            if reflections is not None and rays['reflection'][ch, s] > 0:   # :2999-3009
+                i_refl = int(rays['reflection'][ch, s])
+                fac = reflections[2] ** i_refl * np.exp(1j * ((i_refl * reflections[3]) % (2 * np.pi)))
+                spec = np.array(spec, complex)
+                spec[1] = spec[1] * fac
+                spec[2] = spec[2] * fac
+                r_theta, r_phi = r_theta * fac, r_phi * fac
             if focusing:  # analyticraytracing.py:3011-3016
                 spec[1:] = spec[1:] * rto.focusing(x1[None], st.pos[ch][None], ice, -0.01, focusing_limit)[0, s]
             if birefringence is not None:
@@ -667,11 +685,12 @@ def station_trigger(V, fs, trigger='simple', threshold=None, n_coincidences=1, t
 
 def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, vrms, vrms_efield, att_model='SP1',
                    n_freq=25, model='Alvarez2009', filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0,
-                   min_efield_amplitude=2.0, rays=None, focusing=False, focusing_limit=2., arz=None, birefringence=None):
+                   min_efield_amplitude=2.0, rays=None, focusing=False, focusing_limit=2., arz=None, birefringence=None,
+                   reflections=None):
     """One single-shower event group through simulation.run()'s sequence (:1454-1600)."""
     efs = sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model, n_freq, model,
                                 delta_C_cut, rays=rays, focusing=focusing, focusing_limit=focusing_limit, arz=arz,
-                                birefringence=birefringence)
+                                birefringence=birefringence, reflections=reflections)
     out = dict(rays=efs, candidate=False, triggered=False, L=0, t_min=np.nan)
     for ef in efs:
         if ef['max_efield'] > min_efield_amplitude * vrms_efield:

@@ -19,13 +19,15 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 
 
 def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4, model='Alvarez2009',
-        antenna='analytic_VPol', cable_delay=0., rmax=4000., orientation=None, focusing=False):
-    det = rh.StationS5(n_samples=N, fs=2.0, antenna=antenna, cable_delay=cable_delay, orientation=orientation)
-    cfg = rh.default_config(model=model)
+        antenna='analytic_VPol', cable_delay=0., rmax=4000., orientation=None, focusing=False, ice_model='southpole_2015',
+        att_model='SP1', n_reflections=0, zmin=-2700., z_top=-100., zmax=0.):
+    det = rh.StationS5(n_samples=N, fs=2.0, antenna=antenna, cable_delay=cable_delay, orientation=orientation, z_top=z_top)
+    cfg = rh.default_config(model=model, ice_model=ice_model, attenuation_model=att_model)
     cfg['propagation']['focusing'] = bool(focusing)
+    cfg['propagation']['n_reflections'] = int(n_reflections)
     ice, prop = rh.make_propagator(cfg, det)
     vrms, vrms_e = rh.vrms_from_filters(cfg)
-    ev = rh.random_events(n_events, seed, energy=energy, rmax=rmax)
+    ev = rh.random_events(n_events, seed, energy=energy, rmax=rmax, zmin=zmin, zmax=zmax)
     stype = np.array(['EM' if (em_every and i % em_every == 0) else 'HAD' for i in range(n_events)])
     rays = []
     evo = dict(candidate=np.zeros(n_events, bool), triggered=np.zeros(n_events, bool), L=np.zeros(n_events, np.int64),
@@ -62,9 +64,12 @@ def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4
         n_events, len(rays), evo['candidate'].sum(), evo['triggered'].sum(), time.time() - t0))
     R = {k: np.array([r[k] for r in rays]) for k in
          ('event', 'channel', 'iS', 'C0', 'C1', 'type', 'zenith', 'azimuth', 'D', 'T', 'view', 'pol_angle', 'launch',
-          't0', 'r_theta', 'r_phi', 'max_efield', 'simch_t0', 'max_amp_ray', 'signal_time')}
+          't0', 'r_theta', 'r_phi', 'max_efield', 'simch_t0', 'max_amp_ray', 'signal_time', 'reflection', 'reflection_case')}
     out = dict(N=N, fs=2.0, vrms=vrms, vrms_efield=vrms_e, ice=np.array([ice.n_ice, ice.delta_n, ice.z_0]),
-               att_model='SP1', n_freq=25, askaryan_model=model, antenna=antenna, cable_delay=cable_delay,
+               att_model=att_model, n_freq=25, askaryan_model=model, antenna=antenna, cable_delay=cable_delay,
+               n_reflections=int(n_reflections), z_reflection=float(getattr(ice, 'reflection', None) or 0.),
+               reflection_coefficient=float(getattr(ice, 'reflection_coefficient', None) or 1.),
+               reflection_phase_shift=float(getattr(ice, 'reflection_phase_shift', None) or 0.),
                focusing=bool(focusing), focusing_limit=2.,
                det_pos=det.pos, det_orientation=np.array(det.orientation if orientation is None else orientation),
                delta_C_cut=0.698,
@@ -94,5 +99,10 @@ if __name__ == '__main__':
                [90 * d, 120 * d, 0., 0.]]
         run('N256_lpda', n_events=200, seed=24, N=256, full_rays=200, full_events=8, antenna='analytic_LPDA',
             cable_delay=[0., 0., 4.4, 0., 0.], rmax=2500., orientation=ori, energy=1e17)
+    if 'N256_mb' in which:   # Moore's Bay: reflective bottom at -576 m (mooresbay_simple), MB1, one bottom reflection, station at -5 .. -9 m;
+        # vertices in the lower 200 m of the shelf: the direct and the bottom-reflected signals of one event then arrive within
+        # 2.5 us of each other (the device path takes common traces of up to 12288 samples)
+        run('N256_mb', n_events=260, seed=27, N=256, full_rays=120, full_events=8, rmax=900., ice_model='mooresbay_simple',
+            att_model='MB1', n_reflections=1, zmin=-570., zmax=-370., z_top=-5., energy=1e18)
     if 'N256_focus' in which:  # propagation.focusing on (ray convergence factor from a second trace, limit 2)
         run('N256_focus', n_events=200, seed=25, N=256, full_rays=100, full_events=6, rmax=2500., focusing=True)

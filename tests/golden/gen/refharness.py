@@ -149,12 +149,12 @@ def make_shower(shower_id, vertex, zenith, azimuth, energy, shower_type, vertex_
     return sh
 
 
-def random_events(n, seed, rmax=4000., zmin=-2700., energy=3e17):
+def random_events(n, seed, rmax=4000., zmin=-2700., energy=3e17, zmax=0.):
     """Synthetic 1 EeV-class event list: uniform in r^2 and z, isotropic."""
     rng = np.random.default_rng(seed)
     r = np.sqrt(rng.uniform(0, rmax ** 2, n))
     phi = rng.uniform(0, 2 * np.pi, n)
-    z = rng.uniform(zmin, 0, n)
+    z = rng.uniform(zmin, zmax, n)
     zen = np.arccos(rng.uniform(-1, 1, n))
     az = rng.uniform(0, 2 * np.pi, n)
     vertex = np.stack([r * np.cos(phi), r * np.sin(phi), z], axis=1)
@@ -204,6 +204,7 @@ def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, tri
             out['rays'].append(dict(
                 channel=ch, iS=ef.get_ray_tracing_solution_id(), shower_id=ef.get_shower_id(),
                 C0=rt['ray_tracing_C0'], C1=rt['ray_tracing_C1'], type=rt['ray_tracing_solution_type'],
+                reflection=rt.get('ray_tracing_reflection', 0), reflection_case=rt.get('ray_tracing_reflection_case', 1),
                 zenith=ef[efp.zenith], azimuth=ef[efp.azimuth], D=ef[efp.nu_vertex_distance],
                 T=ef[efp.nu_vertex_propagation_time], view=ef[efp.nu_viewing_angle],
                 pol_angle=ef[efp.polarization_angle], launch=np.array(ef[efp.launch_vector]),

@@ -1,7 +1,8 @@
 """HIP spectral stages and the whole hot path through the C ABI vs the oracle and the reference fixtures."""
+import os
 import numpy as np
 import pytest
-from conftest import golden
+from conftest import golden, ROOT
 from oracle import raytrace_oracle as rto
 from oracle import spectral_oracle as so
 import nuradiomc_amd
@@ -14,7 +15,8 @@ def test_chirp_z_in_lds(gpu_ctx_factory):
     ctx = gpu_ctx_factory((1.78, 0.423, 77.))
     rng = np.random.default_rng(3)
     for n_in, n_out, Q, sgn in [(128, 1719, 1719, -1.), (2048, 2648, 2648, -1.), (2649, 5296, 5296, +1.),
-                                (2048, 6145, 6145, -1.), (4501, 3691, 9000, +1.), (17, 5, 7, -1.)]:
+                                (2048, 6145, 6145, -1.), (4501, 3691, 9000, +1.), (17, 5, 7, -1.),
+                                (128, 8064, 8064, -1.), (8065, 128, 16128, +1.)]:   # the longest common trace at N = 256
         x = rng.normal(size=(3, n_in)) + 1j * rng.normal(size=(3, n_in))
         got = ctx.debug_czt(x, n_out, Q, sgn)
         j = np.arange(n_in)[:, None]
@@ -997,3 +999,90 @@ def test_two_phase_random_draws_like_the_reference(gpu_ctx_factory, name):
     # chunked calls continue ONE random stream
     trig_c, stats_c = st.simulate_events(*args, None, seed=1235, max_showers_per_call=37, **kw)
     assert np.array_equal(trig_c, trig) and np.array_equal(stats_c['k_L'][has_ref], ref_kL[has_ref])
+
+
+def _mb_run(gpu_ctx_factory, g, n, **kw):
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    refl = dict(n_reflections=int(g['n_reflections']), z_reflection=float(g['z_reflection']),
+                reflection_coefficient=float(g['reflection_coefficient']), reflection_phase_shift=float(g['reflection_phase_shift']))
+    kL = np.where(np.isnan(g['ev_k_L'][:n]), 1.0, g['ev_k_L'][:n])
+    trig, stats = st.simulate_events(g['vertex'][:n], g['zenith'][:n], g['azimuth'][:n], g['energy'][:n], g['shower_type'][:n], kL,
+                                     **refl, **kw)
+    return ctx, st, refl, kL, trig, stats
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, 'tests', 'golden', 'chain_N256_mb.npz')), reason='fixture not generated')
+def test_bottom_reflections_in_the_batched_path(gpu_ctx_factory):
+    """Moore's Bay: a reflective layer at -576 m (mooresbay_simple), MB1 attenuation, propagation.n_reflections = 1 inside
+    nrhip_simulate_event_groups -- ray tables with 2 + 4 n slots per pair, attenuation as the product over the path segments,
+    one Fresnel factor per surface reflection, coefficient and phase shift per bottom reflection (analyticraytracing.py:2118-2130,
+    :933-1089, :2966-3009).  GPU vs the oracle on identical ray tables (1e-6; decisions exact), and vs the reference's own
+    outputs wherever it found the same rays: its Python path loses most roots of rays that start downwards
+    (reflection_case 2: get_delta_y shifts the start point in place), the golden table of its C++ twin has them."""
+    g = golden('chain_N256_mb.npz')
+    n = 200
+    ctx, st, refl, kL, trig, stats = _mb_run(gpu_ctx_factory, g, n, no_pruning=True, dump_traces=True)
+    S = 2 + 4 * refl['n_reflections']
+    n_ch = len(g['det_pos'])
+    T = {k: st.fetch(k) for k in ('pair_n_sol', 'slot_type', 'slot_C0', 'slot_D', 'slot_T', 'slot_launch', 'slot_receive',
+                                  'slot_refl_angle', 'slot_reflection', 'slot_reflection_case', 'slot_surface_mask', 'ray_event',
+                                  'ray_channel', 'ray_solution', 'ray_t0', 'ray_r_theta', 'ray_r_phi', 'ray_att',
+                                  'ray_max_efield', 'ev_n_rays', 'ev_L', 'ev_candidate', 'ev_t_min', 'ev_ray_begin')}
+    assert len(T['slot_C0']) == n * n_ch * S and T['slot_reflection'].max() == 1
+    item_event = st.fetch('item_event')
+    toff, trace = st.fetch('trace_offset'), st.fetch('trace')
+    ost = so.Station(g['det_pos'], n_samples=int(g['N']), fs=float(g['fs']))
+    orefl = (refl['n_reflections'], refl['z_reflection'], refl['reflection_coefficient'], refl['reflection_phase_shift'])
+    att = T['ray_att'].reshape(-1, len(st.att_freq))
+    n_rays = n_refl_rays = n_cand = 0
+    for ev in range(n):
+        sl = slice(ev * n_ch * S, (ev + 1) * n_ch * S)
+        rays = dict(n_sol=T['pair_n_sol'][ev * n_ch:(ev + 1) * n_ch])
+        for k, name in (('type', 'slot_type'), ('C0', 'slot_C0'), ('D', 'slot_D'), ('T', 'slot_T'), ('refl_angle', 'slot_refl_angle'),
+                        ('reflection', 'slot_reflection'), ('reflection_case', 'slot_reflection_case'),
+                        ('surface_mask', 'slot_surface_mask')):
+            rays[k] = T[name][sl].reshape(n_ch, S)
+        for k, name in (('launch', 'slot_launch'), ('receive', 'slot_receive')):
+            rays[k] = T[name][3 * sl.start:3 * sl.stop].reshape(n_ch, S, 3)
+        o = so.simulate_event(g['vertex'][ev], g['zenith'][ev], g['azimuth'][ev], g['energy'][ev], str(g['shower_type'][ev]),
+                              float(kL[ev]), ost, g['ice'], st.vrms, st.vrms_efield, att_model=str(g['att_model']), rays=rays,
+                              reflections=orefl)
+        r0 = T['ev_ray_begin'][ev]
+        sel = np.arange(r0, r0 + T['ev_n_rays'][ev])
+        assert [(r['channel'], r['iS']) for r in o['rays']] == list(zip(T['ray_channel'][sel], T['ray_solution'][sel])), ev
+        for r, k in zip(o['rays'], sel):
+            assert abs(r['t0'] - T['ray_t0'][k]) < 1e-9
+            assert abs(r['r_theta'] - T['ray_r_theta'][k]) < 1e-12 and abs(r['r_phi'] - T['ray_r_phi'][k]) < 1e-12
+            a_ref = rto.attenuation_batch_refl(g['vertex'][ev][None], g['det_pos'][r['channel']][None], [r['C0']],
+                                               [rays['reflection'][r['channel'], r['iS']]],
+                                               [rays['reflection_case'][r['channel'], r['iS']]], g['ice'], refl['z_reflection'],
+                                               str(g['att_model']), st.att_freq)[0]
+            assert np.max(np.abs(att[k] - a_ref) / a_ref) < 1e-6
+            assert abs(r['max_efield'] - T['ray_max_efield'][k]) <= 1e-6 * r['max_efield']
+            n_rays += 1
+            n_refl_rays += rays['reflection'][r['channel'], r['iS']] > 0
+        assert bool(T['ev_candidate'][ev]) == o['candidate'] and bool(trig[ev]) == o['triggered'], ev
+        if o['candidate']:
+            n_cand += 1
+            assert T['ev_L'][ev] == o['L'] and abs(T['ev_t_min'][ev] - o['t_min']) < 1e-9
+            i = int(np.where(item_event == ev)[0][0])
+            scale = np.max(np.abs(o['V']))
+            for ch in range(n_ch):
+                assert np.max(np.abs(trace[toff[i * n_ch + ch]:toff[i * n_ch + ch + 1]] - o['V'][ch])) <= 1e-6 * scale, (ev, ch)
+    assert n_rays > 400 and n_refl_rays > 100 and n_cand >= 10
+    # the reference itself, where it found the same number of rays
+    same = T['ev_n_rays'] == g['ev_n_rays'][:n]
+    cand = T['ev_candidate'].astype(bool)
+    assert same.sum() >= 40
+    assert np.array_equal(cand[same], g['ev_candidate'][:n][same]) and np.array_equal(trig[same], g['ev_triggered'][:n][same])
+    both = same & cand
+    assert np.array_equal(T['ev_L'][both], g['ev_L'][:n][both])
+    maxV = st.fetch('item_maxV').reshape(len(item_event), -1)
+    for i, ev in enumerate(item_event):
+        if both[ev]:
+            assert np.all(np.abs(maxV[i] - g['ev_maxV'][ev]) <= 5e-3 * np.max(g['ev_maxV'][ev])), ev
+    # production mode: the same masks; without reflections the direct / refracted / surface-reflected rays only
+    ctx, st, refl, kL, trig_p, stats_p = _mb_run(gpu_ctx_factory, g, n)
+    assert np.array_equal(trig_p, trig) and np.array_equal(st.fetch('ev_candidate'), T['ev_candidate'])
+    assert stats_p['n_rays'] == stats['n_rays'] and stats_p['n_active_rays'] <= stats['n_active_rays']
