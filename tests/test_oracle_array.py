@@ -65,5 +65,8 @@ def test_gen2_array_vs_reference():
                 threshold_high=float(g['trigger_threshold_sigma']) * vr, threshold_low=-float(g['trigger_threshold_sigma']) * vr,
                 high_low_window=float(g['trigger_high_low_window']), coinc_window=float(g['trigger_coinc_window']))
     seen = np.flatnonzero(g['ev_n_rays'].sum(axis=0) > 0)
-    same, n_cand, n_trig = _compare(g, range(0, n_groups, 4), seen[::3], g['k_L'], trigger=trig)
+    gt, st_t = np.nonzero(g['ev_triggered'])     # a subset that holds triggers: every 4th group plus three triggered ones
+    groups = sorted(set(range(0, n_groups, 4)) | set(gt[::8][:3].tolist()))
+    stations = sorted(set(seen[::3].tolist()) | set(st_t[::8][:3].tolist()))
+    same, n_cand, n_trig = _compare(g, groups, stations, g['k_L'], trigger=trig)
     assert same > 0.97 and n_cand >= 5 and n_trig >= 2
