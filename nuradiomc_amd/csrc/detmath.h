@@ -52,6 +52,14 @@ __device__ __forceinline__ double det_fma_asm(double a, double b, double c)
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// the same with the addend in a scalar register pair (one constant-bus operand per VOP3 instruction on gfx9): the polynomial
+// coefficients then live in SGPRs for the whole kernel instead of being copied into VGPRs before every use
+__device__ __forceinline__ double det_fma_asm_sc(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
 __device__ __forceinline__ double det_exp_inrange(double x)
 {
     const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
@@ -60,15 +68,15 @@ __device__ __forceinline__ double det_exp_inrange(double x)
     double r = __builtin_fma(-kd, ln2HI, x);
     r = __builtin_fma(-kd, ln2LO, r);
     double p = det_fma_asm(1.6059043836821613e-10, r, 2.08767569878681e-09);
-    p = det_fma_asm(p, r, 2.505210838544172e-08);
-    p = det_fma_asm(p, r, 2.755731922398589e-07);
-    p = det_fma_asm(p, r, 2.7557319223985893e-06);
-    p = det_fma_asm(p, r, 2.48015873015873e-05);
-    p = det_fma_asm(p, r, 0.0001984126984126984);
-    p = det_fma_asm(p, r, 0.001388888888888889);
-    p = det_fma_asm(p, r, 0.008333333333333333);
-    p = det_fma_asm(p, r, 0.041666666666666664);
-    p = det_fma_asm(p, r, 0.16666666666666666);
+    p = det_fma_asm_sc(p, r, 2.505210838544172e-08);
+    p = det_fma_asm_sc(p, r, 2.755731922398589e-07);
+    p = det_fma_asm_sc(p, r, 2.7557319223985893e-06);
+    p = det_fma_asm_sc(p, r, 2.48015873015873e-05);
+    p = det_fma_asm_sc(p, r, 0.0001984126984126984);
+    p = det_fma_asm_sc(p, r, 0.001388888888888889);
+    p = det_fma_asm_sc(p, r, 0.008333333333333333);
+    p = det_fma_asm_sc(p, r, 0.041666666666666664);
+    p = det_fma_asm_sc(p, r, 0.16666666666666666);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);

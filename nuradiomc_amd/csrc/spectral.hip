@@ -1657,10 +1657,8 @@ channel_prefilter_kernel(int n_items, const int* __restrict__ item_event, RayWor
                                   fabs(w.vfac_p[r] * w.pol_phi[r]) * cabs2(w.r_phi[r])) *
                    hnorm[((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[ch] : 0)) * NRHIP_N_ANT_TAB + w.tab[r]];
         }
-        if (!(bnd * (1 + 1e-9) >= threshold)) {
-            maxV[item] = -bnd;
-            flag = 0;
-        }
+        maxV[item] = -bnd;   // pruned items keep it; for the others channel_conv_kernel orders the event's channels by it
+        if (!(bnd * (1 + 1e-9) >= threshold)) flag = 0;
     }
     need[item] = flag;
 }
@@ -1697,13 +1695,22 @@ __global__ void channel_event_flags_kernel(int n_cand, int n_ch, const int* __re
 #ifndef CONV_NT
 #define CONV_NT 512
 #endif
+#define CONV_MAX_ORDER 64  // stations with more channels are evaluated in channel order
+#ifdef NRHIP_CONV_TIMING  // debug builds: shader clocks per phase, summed over the blocks (thread 0), read by nrhip_debug_conv_clocks
+__device__ unsigned long long g_conv_clk[16];
+#define CT_DECL unsigned long long ct_t = __builtin_amdgcn_s_memtime()
+#define CT(i) do { unsigned long long ct_n = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_conv_clk[i], ct_n - ct_t); ct_t = ct_n; } while (0)
+#else
+#define CT_DECL
+#define CT(i)
+#endif
 __global__ void __launch_bounds__(CONV_NT)
 channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list, const int* __restrict__ need,
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                     const int* __restrict__ ev_len_index, StationDev st, int ask_model, TriggerDev trg,
                     const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab, int log2nh,
                     ChannelOut out, int exact, int* __restrict__ coinc_cnt, double2* __restrict__ conv_acc,
-                    unsigned long long* __restrict__ xform_count)
+                    unsigned long long* __restrict__ xform_count, int* __restrict__ queue)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = FFT_MAX;
@@ -1725,17 +1732,49 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     // unit of work: one candidate event; its channels are evaluated in sequence and -- the trigger being an OR over
     // channels -- the remaining ones are skipped (maxV = NaN) once one has triggered, unless every trace is wanted
     __shared__ int s_ev_trig;
-    for (int le = blockIdx.x; le < n_list_events; le += gridDim.x) {
-      if (threadIdx.x == 0) s_ev_trig = 0;
-      const int ev_e = item_event[item_list[le]], ev_L = ev.L[ev_e];
-      if (coinc)
-          for (int n = threadIdx.x; n < ev_L; n += blockDim.x) cnt[n] = 0;
+    // The channels an event still needs, strongest Cauchy-Schwarz bound first: the trigger is an OR over the channels, so the
+    // one most likely to fire ends the event soonest (any order gives the same mask).  Built by thread 0 per event; two
+    // buffers, because a wave may run ahead through the barrier-free skip path into the next event's set-up.
+    __shared__ short s_order[2][CONV_MAX_ORDER];
+    __shared__ int s_norder[2];
+    const bool best_first = !exact && !coinc && st.n_ch <= CONV_MAX_ORDER;
+    // events are handed out through a counter in HBM (zero at launch): their cost varies with the number of channels and rays
+    __shared__ int s_le[2];
+    int par = 0;
+    CT_DECL;
+    for (;; par ^= 1) {
+      if (threadIdx.x == 0) {
+          const int le0 = atomicAdd(queue, 1);
+          s_le[par] = le0;
+          s_ev_trig = 0;
+          int cnt_o = 0;
+          const int base = (le0 < n_list_events ? item_list[le0] : 0) * st.n_ch;
+          if (best_first && le0 < n_list_events) {
+              for (int ch = 0; ch < st.n_ch; ch++) {
+                  if (!need[base + ch]) continue;
+                  const double b = -out.maxV[base + ch];   // the prefilter's bound
+                  int k = cnt_o++;
+                  while (k > 0 && -out.maxV[base + s_order[par][k - 1]] < b) { s_order[par][k] = s_order[par][k - 1]; k--; }
+                  s_order[par][k] = (short)ch;
+              }
+          }
+          s_norder[par] = cnt_o;
+      }
       __syncthreads();
+      const int le = s_le[par];
+      if (le >= n_list_events) break;
+      const int ev_e = item_event[item_list[le]], ev_L = ev.L[ev_e];
+      if (coinc) {
+          for (int n = threadIdx.x; n < ev_L; n += blockDim.x) cnt[n] = 0;
+          __syncthreads();
+      }
       // has an earlier channel of this event triggered?  A per-thread copy, refreshed between two barriers after every
       // evaluated channel: the shared flag itself may already have been reset for the NEXT event by a wave that ran ahead
       // through the barrier-free skip path below
       bool ev_trig = false;
-      for (int ch = 0; ch < st.n_ch; ch++) {
+      const int n_steps = best_first ? s_norder[par] : st.n_ch;
+      for (int step = 0; step < n_steps; step++) {
+        const int ch = best_first ? (int)s_order[par][step] : step;
         const int item = item_list[le] * st.n_ch + ch;
         if (!need[item]) continue;
         const bool ch_on = !st.trig_on || st.trig_on[ch];  // triggered_channels of the reference's trigger modules
@@ -1759,14 +1798,20 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             if (!((tabs >> tb) & 1)) continue;
             const double2* G = tab.G + (((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[ch] : 0)) * NRHIP_N_ANT_TAB + tb) * NRHIP_G_STRIDE;
             __syncthreads();
+            CT(0);
             for (int n = threadIdx.x; n < L; n += blockDim.x) S[n] = 0.;
             __syncthreads();
+            CT(1);
             for (int r = r0; r < r1; r++) {
                 if (w.ch[r] != ch || w.tab[r] != tb) continue;
                 if (threadIdx.x == 0) rs.ask = w.ask[r];
                 for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
                 __syncthreads();
                 fill_amplitude(amp, st, rs);
+#ifdef NRHIP_CONV_TIMING
+                __syncthreads();
+#endif
+                CT(2);
                 // start bin and sub-sample remainder (efieldToVoltageConverter.py:214-218)
                 double start_time = w.t0[r] - t_min + st.cable[ch] + 0;
                 long start_bin = (long)rint(start_time / res);
@@ -1785,6 +1830,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     double vfac = one ? (vt * pt * rt.x + vp * pp * rp.x) : (comp ? vp : vt);
                     if (!one && (comp ? wp : wt) <= 1e-13 * (comp ? wt : wp)) continue;
                     field_time_domain(xs, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
+                    CT(3);
                     const double c = vfac / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
                     for (int j = threadIdx.x; j < nh; j += blockDim.x) {
                         double2 y = xs[bitrev(j, log2nh)];
@@ -1796,14 +1842,19 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                         S[i1] += y.y * c;
                     }
                     __syncthreads();
+                    CT(4);
                 }
             }
             for (int n = L + threadIdx.x; n < 2 * M; n += blockDim.x) S[n] = 0.;
             __syncthreads();
+            CT(5);
             fft_dif_t<FFT_LOG2_MAX, CONV_NT>(z, tw, false);
+            CT(6);
             // split the packed transform into the real one, multiply with G, merge back -- in place on the
             // bit-reversed positions of the pairs (k, M - k)
-            for (int k = threadIdx.x; k <= M / 2; k += blockDim.x) {
+            // (the response spectrum comes from HBM / L2: the loads of four iterations are issued before the first use)
+#pragma unroll 4
+            for (int k = threadIdx.x; k <= M / 2; k += CONV_NT) {
                 const int p = bitrev(k, FFT_LOG2_MAX), q = (k == 0) ? p : bitrev(M - k, FFT_LOG2_MAX);
                 const double2 A = z[p], Bc = cconj(z[q]);
                 const double2 Ee = cadd(A, Bc), D = csub(A, Bc);
@@ -1835,7 +1886,9 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 for (int k = threadIdx.x; k < M; k += blockDim.x) z[k] = acc[k];
             }
             __syncthreads();
+            CT(7);
             fft_dit_t<FFT_LOG2_MAX, CONV_NT>(z, tw, true);
+            CT(8);
             if (!coinc) {
                 for (int n = threadIdx.x; n < L; n += blockDim.x) {
                     double v = S[n] + S[n + L];
@@ -1906,6 +1959,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         __syncthreads();
         ev_trig = (s_ev_trig != 0);
         __syncthreads();
+        CT(9);
       }
       if (coinc) {  // majority logic over the channels of the event
           if (threadIdx.x == 0) s_first = 0x7fffffff;
@@ -2719,7 +2773,8 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
         int cgrid = n_cand < channel_grid_blocks() ? n_cand : channel_grid_blocks();
         hipLaunchKernelGGL(channel_conv_kernel, dim3(cgrid), dim3(CONV_NT), (size_t)FFT_MAX * 16, s, need_offset + n_cand,
                            item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16, tab,
-                           ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count);
+                           ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count,
+                       ev_need + n_cand /* the scan's zero sentinel: free again, and 0 */);
         skip_upto = FFT_MAX;
         if (max_length <= FFT_MAX && !st.ant_tabs) return;
     }
@@ -3038,3 +3093,15 @@ void launch_czt_test(hipStream_t s, int n_batch, int n_in, int n_out, int Q, dou
 }
 
 }  // namespace nrhip
+
+#ifdef NRHIP_CONV_TIMING
+extern "C" int nrhip_debug_conv_clocks(unsigned long long* out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(nrhip::g_conv_clk), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nrhip::g_conv_clk), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
