@@ -67,6 +67,35 @@ def _fresnel(zenith, n_2, n_1):
     r_s = np.conjugate((np.cos(zenith) - s) / (np.cos(zenith) + s))
     return r_p, r_s
 
+def analytic_ray_path(X1, X2, C0, n_ice, delta_n, z_0, n_points=1000):
+    """ray_tracing.get_path (analyticraytracing.py:2148-2162 / :1239-1291): n_points positions along the solution with launch
+    parameter C0, equally spaced in (mirrored) depth, from the LOWER of the two end points to the other one -- the order the
+    reference returns.  Closed form of the exponential profile: y(z) = z_0 / sqrt(n_ice^2 C0^2 - 1) * ln(g / (2 sqrt(c (g^2 - b g
+    + c)) - b g + 2 c)) + C1 with g = delta_n exp(z / z_0), b = 2 n_ice, c = n_ice^2 - C0^-2, mirrored at the turning depth
+    (a reflection off the surface is a turning point at z = 0)."""
+    X1, X2 = np.asarray(X1, float), np.asarray(X2, float)
+    A, B = (X1, X2) if X2[2] >= X1[2] else (X2, X1)
+    b, c = 2 * n_ice, n_ice ** 2 - C0 ** -2
+    pref = z_0 / np.sqrt(n_ice ** 2 * C0 ** 2 - 1)
+
+    def y_of(z):     # without C1, valid below the turning depth
+        g = delta_n * np.exp(np.asarray(z, float) / z_0)
+        return pref * np.log(g / (2 * np.sqrt(c) * np.sqrt(np.abs(g * g - b * g + c)) - b * g + 2 * c))
+    g_turn = 0.5 * b - np.sqrt(0.25 * b * b - c)
+    z_turn = min(np.log(g_turn / delta_n) * z_0, 0.)
+    y_turn0 = y_of(z_turn)
+    d = np.hypot(B[0] - A[0], B[1] - A[1])   # horizontal distance of the end point in the plane of the ray (start at y = 0)
+    C1 = -(y_of(A[2]) if A[2] < z_turn else 2 * y_turn0 - y_of(2 * z_turn - A[2]))
+    y_turn = y_turn0 + C1
+    z_stop = B[2] if not (y_turn < d) else A[2] + abs(z_turn - A[2]) + abs(z_turn - B[2])
+    z = np.linspace(A[2], z_stop, int(n_points))
+    up = z < z_turn
+    yy, zz = np.empty_like(z), np.empty_like(z)
+    yy[up], zz[up] = y_of(z[up]) + C1, z[up]
+    yy[~up], zz[~up] = 2 * y_turn - (y_of(2 * z_turn - z[~up]) + C1), 2 * z_turn - z[~up]
+    phi = np.arctan2(B[1] - A[1], B[0] - A[0])
+    return np.stack([A[0] + yy * np.cos(phi), A[1] + yy * np.sin(phi), zz], axis=1)
+
 
 class ray_tracing:
     def __init__(self, medium, attenuation_model=None, log_level=logging.NOTSET, n_frequencies_integration=None,
@@ -248,7 +277,14 @@ class ray_tracing:
         return float(self._tab['T'][iS])
 
     def get_path(self, iS, n_points=1000):
-        raise NotImplementedError("get_path is a plotting helper and is not provided")
+        """analyticraytracing.py:2148-2162 (plotting helper, host side): see analytic_ray_path.  Paths with reflections off
+        the bottom are not drawn."""
+        self._check(iS)
+        r = self._results[iS]
+        if r.get('reflection', 0):
+            raise NotImplementedError("get_path: paths with reflections off the bottom are not drawn")
+        return analytic_ray_path(self._X1, self._X2, float(r['C0']), self._medium.n_ice, self._medium.delta_n, self._medium.z_0,
+                                 n_points)
 
     def get_attenuation(self, iS, frequency, max_detector_freq=None):
         """analyticraytracing.py:2744 -> :933-1089: coarse grid on the GPU, np.interp on the host, DC = 1"""
