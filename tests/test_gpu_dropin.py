@@ -64,6 +64,11 @@ def test_ray_tracing_class_api_and_errors():
     for iS in range(2):
         assert r.get_solution_type(iS) == g['type'][i, iS]
         assert abs(r.get_path_length(iS) - g['D'][i, iS]) < 1e-6 * g['D'][i, iS]
+        # get_path (plotting helper): from the lower end point to the other one, polyline length = path length
+        p = r.get_path(iS, n_points=4000)
+        lo, hi = (g['x1'][i], g['x2'][i]) if g['x2'][i][2] >= g['x1'][i][2] else (g['x2'][i], g['x1'][i])
+        assert np.max(np.abs(p[0] - lo)) < 1e-6 and np.max(np.abs(p[-1] - hi)) < 1e-2
+        assert abs(np.sum(np.linalg.norm(np.diff(p, axis=0), axis=1)) - g['D'][i, iS]) < 2e-3 * g['D'][i, iS]
         assert abs(r.get_travel_time(iS) - g['T'][i, iS]) < 1e-6 * g['T'][i, iS]
         assert np.max(np.abs(r.get_launch_vector(iS) - g['launch'][i, iS])) < 1e-6
         assert np.max(np.abs(r.get_receive_vector(iS) - g['receive'][i, iS])) < 1e-6
