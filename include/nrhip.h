@@ -336,6 +336,13 @@ typedef struct {
     double z_reflection;
     double reflection_coefficient;
     double reflection_phase_shift;
+    /* > 0: simulation.group_into_events (simulation.py:906-947) -- the signals of a group at this station are sorted by start
+       time (electric-field start + cable delay) and cut into sub-events wherever two consecutive ones are more than this many ns
+       apart; every sub-event gets its own readout window, channel sums and trigger decision, a group triggers when one of its
+       sub-events does.  The candidate cut stays per group.  The ev_* / item_* tables are then per sub-event ("ev_group",
+       "ev_sub_event": group and index of each; stats->n_sub_events).  0: one readout per group.  Not with ARZ / birefringence
+       or the phased-array trigger. */
+    double split_event_time_diff;
 } nrhip_sim_config;
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1
@@ -354,7 +361,7 @@ typedef struct {
     int64_t n_ray_transforms;     /* rays whose field went into one of those traces                                  */
     int64_t n_efield_transforms;  /* rays whose field was transformed for the candidate cut                          */
     int32_t max_length;
-    int32_t reserved;
+    int32_t n_sub_events;         /* readouts: event groups, or their sub-events with split_event_time_diff */
     double stage_ms[NRHIP_N_STAGES];
 } nrhip_sim_stats;
 
@@ -429,8 +436,8 @@ int nrhip_simulate_events(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_con
  * speedup.distance_cut (simulation.py:155-163, :1398-1409) -- a shower farther from an antenna than this is skipped for
  * that channel (the host evaluates the energy polynomial, incl. the energy sum of neighbouring showers).
  * triggered: DEV uint8 [n_groups];
- * the ev_* / item_* tables of nrhip_sim_fetch are per group.  All showers of a group must end up in ONE readout
- * (split_event_time_diff is not applied); a group whose common trace exceeds the supported length fails the call. */
+ * the ev_* / item_* tables of nrhip_sim_fetch are per group -- or per sub-event with cfg->split_event_time_diff > 0
+ * (simulation.group_into_events); a readout whose common trace exceeds the supported length fails the call. */
 int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_sim_config* cfg, int64_t n_showers,
                                 const double* vertex, const double* zenith, const double* azimuth,
                                 const double* energy, const int32_t* shower_type, const double* k_L,

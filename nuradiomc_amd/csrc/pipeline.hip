@@ -486,6 +486,96 @@ __global__ void shower_first_channel_kernel(long n_showers, int n_ch, const int*
     first[i] = f;
 }
 
+// ---- split_event_time_diff (simulation.group_into_events :906-947) -------------------------------------------------------------
+// The signals of one event group at one station are sorted by their start time (electric-field start + cable delay); where two
+// consecutive start times are more than split_event_time_diff apart a new (sub-)event begins, with its own readout window and
+// trigger decision.  One thread per group: number of sub-events, and the group's rays reordered sub-event by sub-event (original
+// order inside each) so that every sub-event is a contiguous ray range again.  Groups that do not split keep their order.
+__global__ void sub_event_split_kernel(int n_groups, const int* __restrict__ grp_ray, const double* __restrict__ t0,
+                                       const int* __restrict__ ch, const double* __restrict__ cable, double split,
+                                       const int* __restrict__ slot_in, int* __restrict__ slot_out, int* __restrict__ sub_sorted,
+                                       int* __restrict__ order, int* __restrict__ sub_of, int* __restrict__ n_sub,
+                                       int* __restrict__ any_split)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const int r0 = grp_ray[g], r1 = grp_ray[g + 1];
+    double tmin = INFINITY, tmax = -INFINITY;
+    for (int r = r0; r < r1; r++) {
+        const double t = t0[r] + cable[ch[r]];
+        tmin = fmin(tmin, t);
+        tmax = fmax(tmax, t);
+    }
+    if (!(tmax - tmin > split)) {   // no gap can exceed the limit
+        for (int r = r0; r < r1; r++) { slot_out[r] = slot_in[r]; sub_sorted[r] = 0; }
+        n_sub[g] = 1;
+        return;
+    }
+    // insertion sort of the ray indices by start time (stable), sub-event index = number of gaps passed
+    for (int r = r0; r < r1; r++) {
+        const double t = t0[r] + cable[ch[r]];
+        int k = r;
+        while (k > r0 && t0[order[k - 1]] + cable[ch[order[k - 1]]] > t) { order[k] = order[k - 1]; k--; }
+        order[k] = r;
+    }
+    int ns = 0;
+    sub_of[order[r0]] = 0;
+    for (int k = r0 + 1; k < r1; k++) {
+        const double d = (t0[order[k]] + cable[ch[order[k]]]) - (t0[order[k - 1]] + cable[ch[order[k - 1]]]);
+        if (d > split) ns++;
+        sub_of[order[k]] = ns;
+    }
+    n_sub[g] = ns + 1;
+    int pos = r0;
+    for (int sidx = 0; sidx <= ns; sidx++)
+        for (int r = r0; r < r1; r++)
+            if (sub_of[r] == sidx) { slot_out[pos] = slot_in[r]; sub_sorted[pos] = sidx; pos++; }
+    if (ns > 0) atomicOr(any_split, 1);
+}
+
+// ray range and group of every sub-event (ev_base = exclusive scan of n_sub)
+__global__ void sub_event_ranges_kernel(int n_groups, const int* __restrict__ grp_ray, const int* __restrict__ sub_sorted,
+                                        const int* __restrict__ ev_base, int* __restrict__ sub_ray, int* __restrict__ ev_group,
+                                        int* __restrict__ ev_sub)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const int r0 = grp_ray[g], r1 = grp_ray[g + 1];
+    int e = ev_base[g];
+    sub_ray[e] = r0;
+    ev_group[e] = g;
+    ev_sub[e] = 0;
+    for (int r = r0 + 1; r < r1; r++)
+        if (sub_sorted[r] != sub_sorted[r - 1]) {
+            e++;
+            sub_ray[e] = r;
+            ev_group[e] = g;
+            ev_sub[e] = sub_sorted[r];
+        }
+    if (g == n_groups - 1) sub_ray[ev_base[n_groups]] = r1;
+}
+
+// the candidate flag belongs to the event group (simulation.py:1556-1560 tests the station's whole sim station before
+// group_into_events): every sub-event of a candidate group is evaluated
+__global__ void sub_event_candidate_kernel(int n_groups, const int* __restrict__ ev_base, unsigned char* __restrict__ candidate,
+                                           const int* __restrict__ n_rays)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const int e0 = ev_base[g], e1 = ev_base[g + 1];
+    if (e1 - e0 < 2) return;
+    int any = 0;
+    for (int e = e0; e < e1; e++) any |= candidate[e];
+    for (int e = e0; e < e1; e++) candidate[e] = (unsigned char)(any && n_rays[e] > 0);
+}
+
+__global__ void sub_event_trigger_kernel(int n_ev, const int* __restrict__ ev_group, const unsigned char* __restrict__ sub_triggered,
+                                         unsigned char* __restrict__ triggered)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_ev && sub_triggered[e]) triggered[ev_group[e]] = 1;
+}
+
 static thread_local char g_ws_fail[160] = "";
 #define WS(name, type, count)                                                                       \
     ([&]() -> type* {                                                                               \
@@ -662,15 +752,6 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         return 0;
     }
 
-    EventOut ev;
-    NEED(ev.n_rays = WS("ev_n_rays", int, n_groups));
-    NEED(ev.ray_begin = WS("ev_ray_begin", int, n_groups));
-    NEED(ev.L = WS("ev_L", int, n_groups));
-    NEED(ev.candidate = WS("ev_candidate", unsigned char, n_groups));
-    NEED(ev.t_min = WS("ev_t_min", double, n_groups));
-    int* trigger_bin;
-    NEED(trigger_bin = WS("ev_trigger_bin", int, n_groups));
-    HIPCHK(hipMemsetAsync(trigger_bin, 0xFF, sizeof(int) * n_groups, sm));
     EventIn evin{energy, shower_type, k_L, vertex_time};
     // ray range of every event group (rays are ordered by shower; a group's showers are consecutive)
     int* grp_ray;
@@ -710,12 +791,12 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     NEED(zint = WS("ray_zint", double, 3 * nr));
     NEED(max_efield = WS("ray_max_efield", double, nr));
 
+    const int* foc_n_sol = nullptr;
+    const double* foc_launch = nullptr;
+    const double foc_dz = -0.01;  // get_focusing(dz = -1 cm)
     if (n_rays > 0) {
         launch_scatter_slots(sm, n_slots, keep, offset, ray_slot);
         LCHK("scatter");
-        const int* foc_n_sol = nullptr;
-        const double* foc_launch = nullptr;
-        const double foc_dz = -0.01;  // get_focusing(dz = -1 cm)
         if (cfg->focusing) {
             // second trace to the receivers moved by dz (analyticraytracing.py:2778-2888); only n_sol and launch are used
             RayRecords rec2;
@@ -743,6 +824,67 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                          arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model, foc_n_sol, foc_launch, foc_dz, cfg->focusing_limit > 0 ? cfg->focusing_limit : 2.,
                          cfg->reflection_coefficient, cfg->reflection_phase_shift);
         LCHK("ray_setup");
+    }
+    // split_event_time_diff: sub-events of the groups (stages 3-4 stay per group: the candidate flag is the group's)
+    long n_ev = n_groups;            // readouts: one per group, or one per sub-event
+    const int* ev_ray = grp_ray;     // their ray ranges
+    int* ev_group = nullptr;         // sub-event -> group (NULL: identity)
+    int* ev_base = nullptr;          // group -> first sub-event
+    if (cfg->split_event_time_diff > 0 && n_rays > 0) {
+        if (general || phased)
+            return nrhip_fail_msg("nrhip_simulate_events: split_event_time_diff is not available with ARZ / birefringence or the phased-array trigger");
+        int *slot_new, *sub_sorted, *order, *sub_of, *n_sub, *etmp, *any_split;
+        NEED(slot_new = WS("ray_slot_split", int, nr));
+        NEED(sub_sorted = WS("ray_sub_event", int, nr));
+        NEED(order = WS("ray_time_order", int, nr));
+        NEED(sub_of = WS("ray_sub_event_unsorted", int, nr));
+        NEED(n_sub = WS("group_n_sub_events", int, n_groups + 1));
+        NEED(ev_base = WS("group_first_sub_event", int, n_groups + 1));
+        NEED(etmp = WS("scan_tmp8", int, scan_tiles(n_groups + 1)));
+        NEED(any_split = WS("any_split", int, 1));
+        HIPCHK(hipMemsetAsync(any_split, 0, sizeof(int), sm));
+        HIPCHK(hipMemsetAsync(n_sub + n_groups, 0, sizeof(int), sm));
+        hipLaunchKernelGGL(sub_event_split_kernel, dim3((unsigned)((n_groups + 127) / 128)), dim3(128), 0, sm, (int)n_groups, grp_ray,
+                           w.t0, w.ch, sd.cable, cfg->split_event_time_diff, ray_slot, slot_new, sub_sorted, order, sub_of, n_sub,
+                           any_split);
+        launch_exclusive_scan(sm, n_groups + 1, n_sub, ev_base, etmp);
+        int h_split[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(&h_split[0], any_split, sizeof(int), hipMemcpyDeviceToHost, sm));
+        HIPCHK(hipMemcpyAsync(&h_split[1], ev_base + n_groups, sizeof(int), hipMemcpyDeviceToHost, sm));
+        HIPCHK(hipStreamSynchronize(sm));
+        if (h_split[0]) {
+            // the work table in the new ray order: the slot list is permuted inside the split groups and the per-ray set-up redone
+            HIPCHK(hipMemcpyAsync(ray_slot, slot_new, sizeof(int) * (size_t)n_rays, hipMemcpyDeviceToDevice, sm));
+            launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w, evin, cfg->askaryan_model,
+                             foc_n_sol, foc_launch, foc_dz, cfg->focusing_limit > 0 ? cfg->focusing_limit : 2.,
+                             cfg->reflection_coefficient, cfg->reflection_phase_shift);
+            n_ev = h_split[1];
+            int *sub_ray, *ev_sub;
+            NEED(sub_ray = WS("sub_event_ray_begin", int, n_ev + 1));
+            NEED(ev_group = WS("ev_group", int, n_ev));
+            NEED(ev_sub = WS("ev_sub_event", int, n_ev));
+            hipLaunchKernelGGL(sub_event_ranges_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, sm, (int)n_groups,
+                               grp_ray, sub_sorted, ev_base, sub_ray, ev_group, ev_sub);
+            ev_ray = sub_ray;
+            LCHK("sub-events");
+        } else {
+            ev_base = nullptr;
+        }
+    }
+    S.n_sub_events = (int32_t)n_ev;
+    EventOut ev;
+    NEED(ev.n_rays = WS("ev_n_rays", int, n_ev));
+    NEED(ev.ray_begin = WS("ev_ray_begin", int, n_ev));
+    NEED(ev.L = WS("ev_L", int, n_ev));
+    NEED(ev.candidate = WS("ev_candidate", unsigned char, n_ev));
+    NEED(ev.t_min = WS("ev_t_min", double, n_ev));
+    int* trigger_bin;
+    NEED(trigger_bin = WS("ev_trigger_bin", int, n_ev));
+    HIPCHK(hipMemsetAsync(trigger_bin, 0xFF, sizeof(int) * n_ev, sm));
+    unsigned char* ev_triggered = triggered;   // per readout; OR-ed into the groups' mask at the end when groups were split
+    if (ev_group) {
+        NEED(ev_triggered = WS("ev_triggered", unsigned char, n_ev));
+        HIPCHK(hipMemsetAsync(ev_triggered, 0, (size_t)n_ev, sm));
     }
     MARK(2);
     // 3. which rays can matter at all?  un-attenuated sum-of-magnitudes bound per ray -> per event -> active ray list
@@ -909,38 +1051,41 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     }
     MARK(5);
     // 5. common time grid per event
-    launch_event_grid(sm, (int)n_groups, n_ch, grp_ray, w, sd, max_efield, cfg->min_efield_amplitude, ev);
+    launch_event_grid(sm, (int)n_ev, n_ch, ev_ray, w, sd, max_efield, cfg->min_efield_amplitude, ev);
+    if (ev_group)
+        hipLaunchKernelGGL(sub_event_candidate_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, sm, (int)n_groups, ev_base,
+                           ev.candidate, ev.n_rays);
     LCHK("event_grid");
     // candidate list, distinct trace lengths and the per-event table index are built on the device; the host only
     // learns the counts (and the few distinct lengths) it needs to size the next launches
     const int n_half = NRHIP_SPEC_STRIDE;  // possible values of L / 2
     int *cflag, *coff, *ctmp, *lflag, *loff, *ltmp, *d_lens, *d_len_index, *d_cand;
     long long* d_ncr;
-    NEED(cflag = WS("cand_flag", int, n_groups + 1));
-    NEED(coff = WS("cand_offset", int, n_groups + 1));
-    NEED(ctmp = WS("scan_tmp5", int, scan_tiles(n_groups + 1)));
+    NEED(cflag = WS("cand_flag", int, n_ev + 1));
+    NEED(coff = WS("cand_offset", int, n_ev + 1));
+    NEED(ctmp = WS("scan_tmp5", int, scan_tiles(n_ev + 1)));
     NEED(lflag = WS("len_flag", int, n_half + 1));
     NEED(loff = WS("len_offset", int, n_half + 1));
     NEED(ltmp = WS("scan_tmp6", int, scan_tiles(n_half + 1)));
     NEED(d_lens = WS("lengths", int, n_half));
-    NEED(d_len_index = WS("ev_len_index", int, n_groups));
-    NEED(d_cand = WS("item_event", int, n_groups));
+    NEED(d_len_index = WS("ev_len_index", int, n_ev));
+    NEED(d_cand = WS("item_event", int, n_ev));
     NEED(d_ncr = WS("cand_ray_count", long long, 2));
     HIPCHK(hipMemsetAsync(lflag, 0, sizeof(int) * (n_half + 1), sm));
     HIPCHK(hipMemsetAsync(d_ncr, 0, 2 * sizeof(long long), sm));
-    launch_candidate_flags(sm, (int)n_groups, n_half, ev, cflag, lflag, d_ncr);
+    launch_candidate_flags(sm, (int)n_ev, n_half, ev, cflag, lflag, d_ncr);
     if (cfg->amp_per_ray && sd.ant_tabs)
         return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray is not available with tabulated antenna patterns");
     if (cfg->amp_per_ray)  // the per-efield voltages live on the N grid: tables of "L = N" are built with the others
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(lflag + sd.N / 2), 1, 1, sm));
-    launch_exclusive_scan(sm, n_groups + 1, cflag, coff, ctmp);
+    launch_exclusive_scan(sm, n_ev + 1, cflag, coff, ctmp);
     launch_exclusive_scan(sm, n_half + 1, lflag, loff, ltmp);
-    launch_candidate_lists(sm, (int)n_groups, n_half, ev, cflag, coff, lflag, loff, d_cand, d_len_index, d_lens);
+    launch_candidate_lists(sm, (int)n_ev, n_half, ev, cflag, coff, lflag, loff, d_cand, d_len_index, d_lens);
     LCHK("candidate lists");
     int h_counts[2] = {0, 0};
     long long h_ncr[2] = {0, 0};
     std::vector<int> lens(n_half);
-    HIPCHK(hipMemcpyAsync(&h_counts[0], coff + n_groups, sizeof(int), hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipMemcpyAsync(&h_counts[0], coff + n_ev, sizeof(int), hipMemcpyDeviceToHost, sm));
     HIPCHK(hipMemcpyAsync(&h_counts[1], loff + n_half, sizeof(int), hipMemcpyDeviceToHost, sm));
     HIPCHK(hipMemcpyAsync(h_ncr, d_ncr, 2 * sizeof(long long), hipMemcpyDeviceToHost, sm));
     HIPCHK(hipMemcpyAsync(lens.data(), d_lens, sizeof(int) * n_half, hipMemcpyDeviceToHost, sm));
@@ -983,7 +1128,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             NEED(sig_time = WS("ray_signal_time", double, nr));
             HIPCHK(hipMemsetAsync(max_env, 0xFF, sizeof(double) * nr, sm));
             HIPCHK(hipMemsetAsync(sig_time, 0xFF, sizeof(double) * nr, sm));
-            launch_ray_envelope(sm, n_cand, coff + n_groups, d_cand, w, ev, sd, cfg->askaryan_model, ctx->twiddle, tab,
+            launch_ray_envelope(sm, n_cand, coff + n_ev, d_cand, w, ev, sd, cfg->askaryan_model, ctx->twiddle, tab,
                                 loff + sd.N / 2, max_env, sig_time);
             LCHK("ray_envelope");
         }
@@ -1006,12 +1151,12 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         ChannelOut co;
         NEED(co.maxV = WS("item_maxV", double, n_items));
         co.trigger_bin = trigger_bin;
-        co.triggered = triggered;
+        co.triggered = ev_triggered;
         co.trace = nullptr;
         co.trace_offset = nullptr;
         if (cfg->dump_traces || phased) {
-            std::vector<int> hL(n_groups), cand(n_cand);
-            HIPCHK(hipMemcpyAsync(hL.data(), ev.L, sizeof(int) * n_groups, hipMemcpyDeviceToHost, sm));
+            std::vector<int> hL(n_ev), cand(n_cand);
+            HIPCHK(hipMemcpyAsync(hL.data(), ev.L, sizeof(int) * n_ev, hipMemcpyDeviceToHost, sm));
             HIPCHK(hipMemcpyAsync(cand.data(), d_cand, sizeof(int) * n_cand, hipMemcpyDeviceToHost, sm));
             HIPCHK(hipStreamSynchronize(sm));
             std::vector<long> off(n_items + 1, 0);
@@ -1054,6 +1199,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                                 (double)st->pa_divisor, cfg->trigger_threshold, maxL, triggered, pa_max);
             LCHK("phased array");
         }
+        if (ev_group)
+            hipLaunchKernelGGL(sub_event_trigger_kernel, dim3((unsigned)((n_ev + 255) / 256)), dim3(256), 0, sm, (int)n_ev, ev_group,
+                               ev_triggered, triggered);
         MARK(8);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here
     }

@@ -79,7 +79,7 @@ class SimConfig(ctypes.Structure):
                 ('focusing', ctypes.c_int32), ('focusing_limit', ctypes.c_double), ('select_only', ctypes.c_int32),
                 ('reuse_ray_tables', ctypes.c_int32), ('accumulate_triggered', ctypes.c_int32), ('n_reflections', ctypes.c_int32),
                 ('z_reflection', ctypes.c_double), ('reflection_coefficient', ctypes.c_double),
-                ('reflection_phase_shift', ctypes.c_double)]
+                ('reflection_phase_shift', ctypes.c_double), ('split_event_time_diff', ctypes.c_double)]
 
 
 class SimStats(ctypes.Structure):
@@ -87,13 +87,13 @@ class SimStats(ctypes.Structure):
                                               'n_channel_items', 'n_distinct_lengths', 'n_candidate_rays', 'n_active_rays',
                                               'n_integrand_evals', 'n_channel_transforms', 'n_ray_transforms',
                                               'n_efield_transforms')] + \
-               [('max_length', ctypes.c_int32), ('reserved', ctypes.c_int32), ('stage_ms', ctypes.c_double * 9)]
+               [('max_length', ctypes.c_int32), ('n_sub_events', ctypes.c_int32), ('stage_ms', ctypes.c_double * 9)]
 
     STAGES = ('raytrace', 'ray_setup', 'amp_bound', 'attenuation', 'efield_max', 'event_grid', 'length_tables', 'channel',
               'total')
 
     def as_dict(self):
-        d = {k: int(getattr(self, k)) for k, _ in self._fields_[:14]}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_[:15]}
         d['stage_ms'] = {n: float(self.stage_ms[i]) for i, n in enumerate(self.STAGES)}
         return d
 
@@ -441,7 +441,7 @@ class Station:
                             threshold_high=None, threshold_low=None, high_low_window=5., coinc_window=200., amp_per_ray=False,
                             d_max_distance=None, focusing=False, focusing_limit=2., select_only=False, reuse_ray_tables=False,
                             accumulate_triggered=False, n_reflections=0, z_reflection=0., reflection_coefficient=1.,
-                            reflection_phase_shift=0.):
+                            reflection_phase_shift=0., split_event_time_diff=0.):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
         d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
@@ -451,7 +451,10 @@ class Station:
         select_only: stop after ray tracing and the delta_C cut (then fetch('shower_first_channel')); reuse_ray_tables:
         continue from the tables of such a call on the same device arrays; accumulate_triggered: OR into d_triggered
         instead of overwriting it (nrhip_sim_config).  n_reflections > 0: rays reflected off the bottom of an ice shelf at depth
-        z_reflection (< 0) with the layer's reflection_coefficient and reflection_phase_shift [rad] (medium.reflection...)."""
+        z_reflection (< 0) with the layer's reflection_coefficient and reflection_phase_shift [rad] (medium.reflection...).
+        split_event_time_diff > 0 [ns]: simulation.group_into_events -- a group's signals at this station are cut into sub-events
+        where consecutive start times are farther apart; the ev_* / item_* tables are then per sub-event (fetch('ev_group'),
+        fetch('ev_sub_event')), the mask stays per group."""
         if trigger not in ('simple', 'high_low', 'phased_array'):
             raise NotImplementedError("trigger {} is not provided (simple, high_low, phased_array)".format(trigger))
         cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
@@ -462,7 +465,8 @@ class Station:
                         float(-3.0 * self.vrms if threshold_low is None else threshold_low), float(high_low_window),
                         float(coinc_window), int(bool(amp_per_ray)), int(bool(focusing)), float(focusing_limit),
                         int(bool(select_only)), int(bool(reuse_ray_tables)), int(bool(accumulate_triggered)), int(n_reflections),
-                        float(z_reflection), float(reflection_coefficient), float(reflection_phase_shift))
+                        float(z_reflection), float(reflection_coefficient), float(reflection_phase_shift),
+                        float(split_event_time_diff or 0.))
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_event_groups(
             self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,
@@ -643,7 +647,8 @@ class Station:
                      'pair_n_sol': np.int32, 'slot_type': np.int32, 'ev_ray_begin': np.int32, 'ray_active': np.int32,
                      'ray_active_list': np.int32, 'ray_slot': np.int32, 'slot_keep': np.int32, 'slot_offset': np.int32,
                      'shower_first_channel': np.int32, 'slot_reflection': np.int32, 'slot_reflection_case': np.int32,
-                     'slot_n_segments': np.int32, 'slot_surface_mask': np.int32}
+                     'slot_n_segments': np.int32, 'slot_surface_mask': np.int32, 'ev_group': np.int32, 'ev_sub_event': np.int32,
+                     'ev_triggered': np.uint8, 'ray_sub_event': np.int32, 'group_n_sub_events': np.int32}
 
     def fetch(self, name):
         """One table of the last simulated batch as a numpy array (see include/nrhip.h: nrhip_sim_fetch)."""

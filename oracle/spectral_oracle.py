@@ -706,7 +706,7 @@ def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, v
 def simulate_event_group(showers, st, ice, vrms, vrms_efield, att_model='SP1', n_freq=25, model='Alvarez2009',
                          filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0, min_efield_amplitude=2.0,
                          distance_cut_coefficients=None, distance_cut_sum_length=10., arz=None, birefringence=None,
-                         trigger=None):
+                         trigger=None, split_event_time_diff=None):
     """An event group of several showers through simulation.run()'s sequence (:1454-1600): calculate_sim_efield loops
     over the showers per channel (:143), the candidate flag, the common time grid, the channel sums and the trigger are
     per group.  `showers`: list of dicts with vertex, zenith, azimuth, energy, shower_type, k_L, vertex_time (and 'iN', the
@@ -735,6 +735,22 @@ def simulate_event_group(showers, st, ice, vrms, vrms_efield, att_model='SP1', n
         if ef['max_efield'] > min_efield_amplitude * vrms_efield:
             out['candidate'] = True
     if not efs or not out['candidate']:
+        return out
+    if split_event_time_diff is not None:
+        # simulation.group_into_events (:906-947): the signals sorted by start time (field start + cable delay), cut where two
+        # consecutive ones are more than the limit apart; detector response and trigger per sub-event (simulation.run :1566-1600)
+        start = np.array([ef['t0'] + st.cable_delay[ef['channel']] for ef in efs])
+        srt = np.argsort(start, kind='stable')
+        sub_of = np.zeros(len(efs), int)
+        sub_of[srt] = np.concatenate([[0], np.cumsum(np.diff(start[srt]) > float(split_event_time_diff))])
+        out['sub'] = []
+        for j in range(sub_of.max() + 1):
+            members = [ef for ef, q in zip(efs, sub_of) if q == j]
+            V, t_min, L = combined_voltage(members, st, filters)
+            trig = threshold_trigger(V, trigger_sigma * vrms) if trigger is None else station_trigger(V, st.fs, **trigger)[0]
+            out['sub'].append(dict(V=V, t_min=t_min, L=L, triggered=trig, rays=members))
+        out['sub_of_ray'] = sub_of
+        out['triggered'] = any(q['triggered'] for q in out['sub'])
         return out
     V, t_min, L = combined_voltage(efs, st, filters)
     out.update(V=V, t_min=t_min, L=L)

@@ -19,6 +19,8 @@ import numpy as np
 logging.disable(logging.WARNING)
 
 from NuRadioReco.utilities import units  # noqa: E402
+import datetime  # noqa: E402
+import NuRadioReco.framework.particle  # noqa: E402
 import NuRadioReco.framework.event  # noqa: E402
 import NuRadioReco.framework.station  # noqa: E402
 import NuRadioReco.framework.sim_station  # noqa: E402
@@ -169,7 +171,7 @@ def make_propagator(config, det):
 
 
 def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, trigger_sigma=3.0, distance_cut=None,
-                   trigger=None):
+                   trigger=None, split=None):
     """One event group through the reference, following simulation.run() (simulation.py:1454-1600).
     `shower` is one RadioShower or the list of showers of the event group.
 
@@ -226,6 +228,24 @@ def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, tri
     out['k_L'] = showers[0][shp.k_L] if showers[0].has_parameter(shp.k_L) else np.nan
     out['k_L_all'] = [sh_[shp.k_L] if sh_.has_parameter(shp.k_L) else np.nan for sh_ in showers]
     if len(station.get_sim_station().get_electric_fields()) == 0 or not candidate:
+        return out
+    if split is not None:
+        # simulation.run() :1566-1600: group_into_events, then detector response + trigger per (sub-)event
+        evt.set_event_time(datetime.datetime(2018, 1, 1))
+        evt.add_particle(NuRadioReco.framework.particle.Particle(0))
+        out['sub'] = []
+        for sub in simulation.group_into_events(station, evt, True, split):
+            stn = sub.get_station()
+            simulation.apply_det_response(sub, det, config, filter_amp, add_noise=False)
+            _trig.run(sub, stn, det, threshold=trigger_sigma * vrms, triggered_channels=None, number_concidences=1,
+                      trigger_name='simple_threshold')
+            chans = [stn.get_channel(c) for c in det.get_channel_ids(sid)]
+            members = sorted((sc.get_id(), sc.get_shower_id(), sc.get_ray_tracing_solution_id())
+                             for sc in stn.get_sim_station().iter_channels())
+            out['sub'].append(dict(triggered=bool(stn.has_triggered()), L=chans[0].get_number_of_samples(),
+                                   t_min=chans[0].get_trace_start_time(), V=np.array([c.get_trace() for c in chans]),
+                                   members=members))
+        out['triggered'] = any(q['triggered'] for q in out['sub'])
         return out
     simulation.apply_det_response(evt, det, config, filter_amp, add_noise=False)
     if trigger is not None and trigger.get('kind') == 'high_low':   # highLowThreshold.triggerSimulator.run (:160-335)

@@ -1086,3 +1086,64 @@ def test_bottom_reflections_in_the_batched_path(gpu_ctx_factory):
     ctx, st, refl, kL, trig_p, stats_p = _mb_run(gpu_ctx_factory, g, n)
     assert np.array_equal(trig_p, trig) and np.array_equal(st.fetch('ev_candidate'), T['ev_candidate'])
     assert stats_p['n_rays'] == stats['n_rays'] and stats_p['n_active_rays'] <= stats['n_active_rays']
+
+
+def test_split_event_time_diff(gpu_ctx_factory):
+    """nrhip_sim_config.split_event_time_diff = simulation.group_into_events (:906-947): groups whose signals are farther apart
+    than the limit are cut into sub-events, each with its own readout window, channel sums and trigger; the candidate cut stays
+    per group.  GPU vs the oracle on the same rays (sub-event membership exact, traces 1e-6) and vs the reference's own sub-events
+    (tests/golden/chain_split_N256.npz, 43 of 54 candidate groups split) wherever its first-root noise kept the ray count."""
+    g = golden('chain_split_N256.npz')
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    ost = so.Station(g['det_pos'], n_samples=int(g['N']), fs=float(g['fs']))
+    vrms, vrms_e = so.vrms_from_filters(ost.fs)
+    split = float(g['split_event_time_diff'])
+    kL = np.where(np.isnan(g['k_L']), 50.0, g['k_L'])
+    args = (g['vertex'], g['zenith'], g['azimuth'], g['energy'], g['shower_type'], kL)
+    trig, stats = st.simulate_events(*args, vertex_time=g['vertex_time'], group_id=g['group'], dump_traces=True,
+                                     split_event_time_diff=split)
+    n_groups = len(g['ev_candidate'])
+    assert trig.shape == (n_groups,)
+    ev_group, ev_sub = st.fetch('ev_group'), st.fetch('ev_sub_event')
+    cand, L, t_min, n_rays, ev_trig = (st.fetch(k) for k in ('ev_candidate', 'ev_L', 'ev_t_min', 'ev_n_rays', 'ev_triggered'))
+    assert stats['n_sub_events'] == len(ev_group) > n_groups and np.all(np.diff(ev_group) >= 0)
+    item_event, tr, off = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    n_ch = len(g['det_pos'])
+    pos = {int(e): i for i, e in enumerate(item_event)}
+    n_split = n_ref = 0
+    for gi in range(n_groups):
+        idx = np.flatnonzero(g['group'] == gi)
+        showers = [dict(vertex=g['vertex'][i], zenith=float(g['zenith'][i]), azimuth=float(g['azimuth'][i]),
+                        energy=float(g['energy'][i]), shower_type=str(g['shower_type'][i]), k_L=float(kL[i]),
+                        vertex_time=float(g['vertex_time'][i])) for i in idx]
+        o = so.simulate_event_group(showers, ost, g['ice'], vrms, vrms_e, split_event_time_diff=split)
+        mine = np.flatnonzero(ev_group == gi)
+        assert list(ev_sub[mine]) == list(range(len(mine)))
+        assert n_rays[mine].sum() == len(o['rays']) and o['triggered'] == bool(trig[gi]), gi
+        if not o['candidate']:
+            assert not cand[mine].any()
+            continue
+        assert len(mine) == len(o['sub']), gi
+        for e, q in zip(mine, o['sub']):
+            assert cand[e] and n_rays[e] == len(q['rays']) and q['L'] == L[e] and abs(q['t_min'] - t_min[e]) < 1e-9
+            assert q['triggered'] == bool(ev_trig[e])
+            scale = np.max(np.abs(q['V']))
+            for ch in range(n_ch):
+                it = pos[int(e)] * n_ch + ch
+                assert np.max(np.abs(tr[off[it]:off[it + 1]] - q['V'][ch])) <= 1e-6 * scale, (gi, e, ch)
+        n_split += len(mine) > 1
+        if len(o['rays']) == g['ev_n_rays'][gi]:   # the reference itself
+            rows = np.flatnonzero(g['sub_group'] == gi)
+            assert len(rows) == len(mine) and bool(trig[gi]) == bool(g['ev_triggered'][gi])
+            assert np.array_equal(L[mine], g['sub_L'][rows]) and np.array_equal(ev_trig[mine].astype(bool), g['sub_triggered'][rows])
+            n_ref += 1
+    assert n_split >= 30 and n_ref >= 40 and trig.sum() >= 15
+    # production mode: same masks
+    trig_p, stats_p = st.simulate_events(*args, vertex_time=g['vertex_time'], group_id=g['group'], split_event_time_diff=split)
+    assert np.array_equal(trig_p, trig) and np.array_equal(st.fetch('ev_triggered'), ev_trig) and stats_p['n_sub_events'] == len(ev_group)
+    # a limit nothing exceeds: one readout per group, identical to the call without it
+    t1, s1 = st.simulate_events(*args, vertex_time=g['vertex_time'], group_id=g['group'], split_event_time_diff=1e6)
+    L1 = st.fetch('ev_L')
+    t0_, s0 = st.simulate_events(*args, vertex_time=g['vertex_time'], group_id=g['group'])
+    assert s1['n_sub_events'] == n_groups and np.array_equal(t1, t0_) and np.array_equal(L1, st.fetch('ev_L'))

@@ -221,3 +221,42 @@ def test_focusing_chain_vs_reference():
                     assert o['triggered'] == bool(g['ev_triggered'][ev])
     rel_all = np.array(rel_all)
     assert n_checked > 500 and n_cand >= 15 and n_dec > 150 and np.mean(rel_all < 1e-4) > 0.85
+
+
+def test_split_event_time_diff_vs_reference():
+    """simulation.group_into_events (:906-947) + per-sub-event detector response and trigger: the oracle's sub-events against the
+    reference's on 140 groups with split_event_time_diff = 300 ns (tests/golden/gen/gen_split.py) -- number of sub-events per
+    group, their member signals, trace lengths, start times, channel maxima, full traces and triggers."""
+    g = golden('chain_split_N256.npz')
+    st = _station(g)
+    vrms, vrms_e = so.vrms_from_filters(st.fs)
+    split = float(g['split_event_time_diff'])
+    n_groups = len(g['ev_candidate'])
+    vsub = {int(k): i for i, k in enumerate(g['V_subs'])}
+    n_same = n_split = n_trig = 0
+    for gi in range(n_groups):
+        showers = _group_showers(g, gi)
+        if any(sh['shower_type'] == 'EM' and sh['k_L'] is None for sh in showers):
+            showers = [dict(sh, k_L=50. if sh['k_L'] is None else sh['k_L']) for sh in showers]   # no ray survived: never drawn
+        o = so.simulate_event_group(showers, st, g['ice'], vrms, vrms_e, split_event_time_diff=split)
+        if len(o['rays']) != g['ev_n_rays'][gi]:
+            continue   # first-root noise of the reference (DESIGN.md section 2)
+        n_same += 1
+        assert o['candidate'] == bool(g['ev_candidate'][gi]) and o['triggered'] == bool(g['ev_triggered'][gi]), gi
+        rows = np.flatnonzero(g['sub_group'] == gi)
+        assert len(o.get('sub', [])) == len(rows) == g['ev_n_sub'][gi], gi
+        first_shower = int(np.flatnonzero(g['group'] == gi)[0])
+        for j, (q, k) in enumerate(zip(o.get('sub', []), rows)):
+            assert g['sub_index'][k] == j
+            mem = np.flatnonzero(g['member_sub'] == k)
+            ref_members = sorted(zip(g['member_channel'][mem], g['member_shower'][mem], g['member_iS'][mem]))
+            assert sorted((r['channel'], r['shower'] + first_shower, r['iS']) for r in q['rays']) == ref_members, (gi, j)
+            assert q['L'] == g['sub_L'][k] and abs(q['t_min'] - g['sub_t_min'][k]) < 5e-3 and q['triggered'] == bool(g['sub_triggered'][k])
+            ref = g['sub_maxV'][k]
+            assert np.all(np.abs(np.max(np.abs(q['V']), axis=1) - ref) <= 5e-3 * np.max(ref)), (gi, j)
+            if int(k) in vsub:
+                V_ref = g['V_concat'][:, g['V_offsets'][vsub[int(k)]]:g['V_offsets'][vsub[int(k)] + 1]]
+                assert np.max(np.abs(q['V'] - V_ref)) <= 5e-3 * np.max(np.abs(V_ref)), (gi, j)
+        n_split += len(rows) > 1
+        n_trig += o['triggered']
+    assert n_same >= 0.97 * n_groups and n_split >= 30 and n_trig >= 15
