@@ -653,8 +653,6 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (phased && st->pa_n_channels <= 0)
         return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger needs its channels and beams (nrhip_station_set_phased_array)");
     if (phased && (general || cfg->amp_per_ray)) return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger runs on the parametrised path only (no ARZ / birefringence / amp_per_ray)");
-    if (general && (cfg->trigger_type == NRHIP_TRIG_HIGH_LOW || cfg->n_coincidences > 1))
-        return nrhip_fail_msg("nrhip_simulate_events: ARZ / birefringence run with the simple threshold trigger only");
     for (auto& e : st->evt) if (!e) HIPCHK(hipEventCreate(&e));
 #define MARK(i) HIPCHK(hipEventRecord(st->evt[i], sm))
     MARK(0);
@@ -1144,17 +1142,24 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         trg.low = cfg->threshold_low;
         trg.w_hl = std::max(1, (int)std::lrint(cfg->high_low_window * sd.fs));
         trg.w_coinc = std::max(1, (int)std::lrint(cfg->coinc_window * sd.fs));
-        if (trg.coincidence() && (maxL > FFT_MAX || sd.N > FFT_MAX / 2 || getenv("NRHIP_CHANNEL_CZT")))
-            return nrhip_fail_msg("nrhip_simulate_events: high/low and coincidence triggers need traces of at most 8192 samples");
-        if (trg.coincidence() && sd.ant_tabs)
-            return nrhip_fail_msg("nrhip_simulate_events: high/low and coincidence triggers are not available with tabulated antenna patterns");
+        // high/low and coincidence triggers are fused into channel_conv_kernel; where that kernel does not run (common traces longer
+        // than FFT_MAX samples, tabulated antenna patterns, the general path) the channel stage only produces the traces and
+        // trace_trigger_kernel decides on them
+        const bool post_trigger = trg.coincidence() && !phased &&
+                                  (maxL > FFT_MAX || sd.N > FFT_MAX / 2 || getenv("NRHIP_CHANNEL_CZT") || sd.ant_tabs || general);
+        TriggerDev trg_ch = trg;
+        if (post_trigger) {
+            trg_ch.type = 0;
+            trg_ch.n_coinc = 1;
+            trg_ch.threshold = INFINITY;
+        }
         ChannelOut co;
         NEED(co.maxV = WS("item_maxV", double, n_items));
         co.trigger_bin = trigger_bin;
         co.triggered = ev_triggered;
         co.trace = nullptr;
         co.trace_offset = nullptr;
-        if (cfg->dump_traces || phased) {
+        if (cfg->dump_traces || phased || post_trigger) {
             std::vector<int> hL(n_ev), cand(n_cand);
             HIPCHK(hipMemcpyAsync(hL.data(), ev.L, sizeof(int) * n_ev, hipMemcpyDeviceToHost, sm));
             HIPCHK(hipMemcpyAsync(cand.data(), d_cand, sizeof(int) * n_cand, hipMemcpyDeviceToHost, sm));
@@ -1187,10 +1192,16 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         StationDev sd_ch = sd;
         if (phased) sd_ch.trig_on = st->d_pa_mask.as<unsigned char>();  // only the array's channels need traces (unless all are dumped)
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd_ch, st->filters[0], arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
-                       trg, ctx->twiddle, ctx->w16, tab, scratch, co, (cfg->no_pruning || cfg->dump_traces || general || phased) ? 1 : 0, maxL,
+                       trg_ch, ctx->twiddle, ctx->w16, tab, scratch, co,
+                       (cfg->no_pruning || cfg->dump_traces || general || phased || post_trigger) ? 1 : 0, maxL,
                        it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces,
-                       phased ? (cfg->dump_traces ? 0 : 1) : -1);
+                       (phased || post_trigger) ? (cfg->dump_traces ? 0 : 1) : -1);
         LCHK("channel");
+        if (post_trigger) {
+            launch_trace_trigger(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, trg, sd.trig_on, maxL, ev_triggered,
+                                 trigger_bin);
+            LCHK("trace trigger");
+        }
         if (phased) {
             double* pa_max;
             NEED(pa_max = WS("pa_max_power", double, (size_t)n_cand * st->pa_n_beams));

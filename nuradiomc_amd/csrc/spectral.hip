@@ -3055,6 +3055,98 @@ void launch_phased_array(hipStream_t s, int n_cand, const int* item_event, int n
                        trace_offset, n_pa, pa_channel, n_beams, rolls, window, step, divisor, threshold, triggered, pa_max);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// kernel: high/low and n-fold coincidence triggers (highLowThreshold.py:13-150, simpleThreshold.py) on channel traces that
+// sit in HBM -- the stations / events the fused logic of channel_conv_kernel cannot take: common traces longer than FFT_MAX
+// samples (bottom reflections: up to 16 128) and tabulated antenna patterns, whose traces come out of the chirp-z
+// channel_kernel.  One block per candidate event; per channel the flags, their OR-dilation over the coincidence window (running
+// maximum of the index of the last raised flag) and the per-sample channel count, then the majority -- the very steps of
+// channel_conv_kernel's coincidence branch.  LDS: 2 x max_length ints.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+trace_trigger_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, const int* __restrict__ ev_L,
+                     const double* __restrict__ trace, const long* __restrict__ trace_offset, TriggerDev trg,
+                     const unsigned char* __restrict__ trig_on, unsigned char* __restrict__ triggered, int* __restrict__ trigger_bin)
+{
+    extern __shared__ int tt_lds[];
+    __shared__ int s_scan[256];
+    __shared__ int s_first;
+    for (int ic = blockIdx.x; ic < n_cand; ic += gridDim.x) {
+        const int e = item_event[ic], L = ev_L[e];
+        int* A = tt_lds;
+        int* cnt = tt_lds + L;
+        const int nb = (trg.type == 0) ? L : L - 1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < L; i += blockDim.x) cnt[i] = 0;
+        if (threadIdx.x == 0) s_first = 0x7fffffff;
+        __syncthreads();
+        for (int ch = 0; ch < n_ch; ch++) {
+            if (trig_on && !trig_on[ch]) continue;   // triggered_channels of the reference's trigger modules
+            const double* V = trace + trace_offset[(long)ic * n_ch + ch];
+            for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+                bool flag;
+                if (trg.type == 0) {
+                    flag = fabs(V[i]) >= trg.threshold;
+                } else {
+                    bool hi = false, lo = false;
+                    for (int k = max(0, i - trg.w_hl + 1); k <= i; k++) {
+                        hi = hi || (V[k] >= trg.high);
+                        lo = lo || (V[k] <= trg.low);
+                    }
+                    if (i - trg.w_hl + 1 < 0) {  // the reference pads with zeros in front
+                        hi = hi || (0. >= trg.high);
+                        lo = lo || (0. <= trg.low);
+                    }
+                    flag = hi && lo;
+                }
+                A[i] = flag ? i : -1;
+            }
+            __syncthreads();
+            {   // inclusive running maximum of A[0 .. nb)
+                const int chunk = (nb + 255) / 256, b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, nb);
+                int run = -1;
+                for (int i = b0; i < b1; i++) { run = max(run, A[i]); A[i] = run; }
+                s_scan[threadIdx.x] = run;
+                __syncthreads();
+                for (int off = 1; off < 256; off <<= 1) {
+                    int v = ((int)threadIdx.x >= off) ? s_scan[threadIdx.x - off] : -1;
+                    __syncthreads();
+                    s_scan[threadIdx.x] = max(s_scan[threadIdx.x], v);
+                    __syncthreads();
+                }
+                const int before = threadIdx.x > 0 ? s_scan[threadIdx.x - 1] : -1;
+                for (int i = b0; i < b1; i++) A[i] = max(A[i], before);
+                __syncthreads();
+            }
+            const int wc = min(trg.w_coinc, nb);
+            for (int i = threadIdx.x; i < nb - 1; i += blockDim.x)
+                if (A[i] >= 0 && i - A[i] < wc) cnt[i] += 1;
+            __syncthreads();
+        }
+        int first = 0x7fffffff;
+        for (int i = threadIdx.x; i < nb - 1; i += blockDim.x)
+            if (cnt[i] >= trg.n_coinc) first = min(first, i);
+        if (first != 0x7fffffff) atomicMin(&s_first, first);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_first != 0x7fffffff) {
+            triggered[e] = 1;
+            trigger_bin[e] = s_first;
+        }
+    }
+}
+
+void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
+                          const long* trace_offset, const TriggerDev& trg, const unsigned char* trig_on, int max_length,
+                          unsigned char* triggered, int* trigger_bin)
+{
+    if (n_cand <= 0) return;
+    set_big_lds();
+    (void)hipFuncSetAttribute((const void*)trace_trigger_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * FFT_MAX * 4 + 1024);
+    int grid = n_cand < 256 * 16 ? n_cand : 256 * 16;
+    hipLaunchKernelGGL(trace_trigger_kernel, dim3(grid), dim3(256), (size_t)2 * max_length * 4, s, n_cand, item_event, n_ch, ev_L, trace,
+                       trace_offset, trg, trig_on, triggered, trigger_bin);
+}
+
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
                          const int* len_index_N, double* max_env, double* signal_time)

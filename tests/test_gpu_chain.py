@@ -825,9 +825,18 @@ def test_general_path_errors_and_empty_inputs(gpu_ctx_factory):
         st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020')
     with pytest.raises(KeyError):   # HAD 1e18 has three profiles in this library
         st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020', arz_iN=np.full(40, 7))
-    for kw in (dict(trigger='high_low'), dict(n_coincidences=2), dict(amp_per_ray=True), dict(focusing=True)):
+    for kw in (dict(amp_per_ray=True), dict(focusing=True)):
         with pytest.raises(Exception, match='ARZ'):
             st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020', arz_iN=np.zeros(40, int), **kw)
+    # high/low and coincidence triggers on the general path: decided on the dumped traces (trace_trigger_kernel)
+    v2, z2, a2 = bench.make_events(300, 5)
+    v2[:, :2] *= 0.25
+    vr = st.vrms
+    opts = dict(trigger='high_low', n_coincidences=2, coinc_window=30., threshold_high=2 * vr, threshold_low=-2 * vr, high_low_window=5.)
+    trig, stats = st.simulate_events(v2, z2, a2, np.full(300, 3e18), 'HAD', askaryan_model='ARZ2020', arz_iN=np.zeros(300, int),
+                                     dump_traces=True, **opts)
+    _check_trace_triggers(st, trig, opts, 300)
+    assert 1 <= trig.sum() < stats['n_candidate_events']
     # far away, off cone: no ray survives -> nothing to do, no trigger
     far = np.tile([30000., 0., -500.], (3, 1))
     trig, stats = st.simulate_events(far, np.full(3, 0.3), np.zeros(3), np.full(3, 1e18), 'EM', askaryan_model='ARZ2020',
@@ -1147,3 +1156,66 @@ def test_split_event_time_diff(gpu_ctx_factory):
     L1 = st.fetch('ev_L')
     t0_, s0 = st.simulate_events(*args, vertex_time=g['vertex_time'], group_id=g['group'])
     assert s1['n_sub_events'] == n_groups and np.array_equal(t1, t0_) and np.array_equal(L1, st.fetch('ev_L'))
+
+
+def _check_trace_triggers(st, trig, okw, n_events):
+    """the trigger mask and first bins against the reference's trigger logic (oracle restatement) on the traces the kernels dumped"""
+    item_event, tr, off, tbin = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset'), st.fetch('ev_trigger_bin')
+    n_ch = len(st.position)
+    expect = np.zeros(n_events, bool)
+    Lmax = 0
+    for i, e in enumerate(item_event):
+        V = np.array([tr[off[i * n_ch + c]:off[i * n_ch + c + 1]] for c in range(n_ch)])
+        Lmax = max(Lmax, V.shape[1])
+        t, bins = so.station_trigger(V, st.sampling_rate, **okw)
+        expect[e] = t
+        assert tbin[e] == (bins[0] if t else -1), e
+    assert np.array_equal(trig, expect)
+    return Lmax
+
+
+@pytest.mark.parametrize('kw', [dict(trigger='high_low', n_coincidences=2, hi=2.0, lo=-2.0, high_low_window=5., coinc_window=30.),
+                                dict(trigger='simple', n_coincidences=3, thr=2.0, coinc_window=40.)])
+def test_coincidence_triggers_beyond_the_fused_kernel(gpu_ctx_factory, kw):
+    """High/low and n-fold coincidence triggers where channel_conv_kernel does not run: common traces longer than 8192 samples
+    (Moore's Bay with bottom reflections: up to 15 046) and tabulated antenna patterns -- the channel stage dumps the traces,
+    trace_trigger_kernel decides on them.  Mask and first triggered bin = the reference's trigger logic on those traces;
+    production mode gives the same mask."""
+    def opts_for(st):
+        vr = st.vrms
+        opts = dict(trigger=kw['trigger'], n_coincidences=kw['n_coincidences'], coinc_window=kw['coinc_window'])
+        okw = dict(opts)
+        if kw['trigger'] == 'high_low':
+            opts.update(threshold_high=kw['hi'] * vr, threshold_low=kw['lo'] * vr, high_low_window=kw['high_low_window'])
+            okw.update(threshold_high=kw['hi'] * vr, threshold_low=kw['lo'] * vr, high_low_window=kw['high_low_window'])
+        else:
+            opts.update(trigger_threshold=kw['thr'] * vr)
+            okw.update(threshold=kw['thr'] * vr)
+        return opts, okw
+    # long traces
+    g = golden('chain_N256_mb.npz')
+    n = 200
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    opts, okw = opts_for(st)
+    refl = dict(n_reflections=int(g['n_reflections']), z_reflection=float(g['z_reflection']),
+                reflection_coefficient=float(g['reflection_coefficient']), reflection_phase_shift=float(g['reflection_phase_shift']))
+    kL = np.where(np.isnan(g['ev_k_L'][:n]), 1.0, g['ev_k_L'][:n])
+    args = (g['vertex'][:n], g['zenith'][:n], g['azimuth'][:n], g['energy'][:n], g['shower_type'][:n], kL)
+    trig, stats = st.simulate_events(*args, dump_traces=True, **refl, **opts)
+    assert _check_trace_triggers(st, trig, okw, n) > 8192 and 3 <= trig.sum() < stats['n_candidate_events']
+    trig_p, _ = st.simulate_events(*args, **refl, **opts)
+    assert np.array_equal(trig_p, trig)
+    # tabulated antenna pattern
+    g = golden('chain_N256_tab.npz')
+    n = len(g['vertex'])
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    opts, okw = opts_for(st)
+    kL = np.where(np.isnan(g['ev_k_L'][:n]), 1.0, g['ev_k_L'][:n])
+    args = (g['vertex'][:n], g['zenith'][:n], g['azimuth'][:n], 3 * g['energy'][:n], g['shower_type'][:n], kL)
+    trig, stats = st.simulate_events(*args, dump_traces=True, **opts)
+    _check_trace_triggers(st, trig, okw, n)
+    assert 1 <= trig.sum() < stats['n_candidate_events']
+    trig_p, _ = st.simulate_events(*args, **opts)
+    assert np.array_equal(trig_p, trig)
