@@ -20,6 +20,17 @@
 
 namespace nrhip {
 
+#ifdef NRHIP_CONV_TIMING  // debug builds: shader clocks per phase, summed over the blocks (thread 0), read by nrhip_debug_conv_clocks
+__device__ unsigned long long g_conv_clk[16];
+__device__ unsigned long long g_ct_mark[1024];
+#define CT_DECL unsigned long long ct_t = __builtin_amdgcn_s_memtime()
+#define CT(i) do { unsigned long long ct_n = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_conv_clk[i], ct_n - ct_t); ct_t = ct_n; } while (0)
+#else
+#define CT_DECL
+#define CT(i)
+#endif
+
+
 // ---------------------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------------------
@@ -694,8 +705,10 @@ __device__ inline double efield_bound(double amp_sum, int N, double fs, double c
 
 // G(k): spectrum bin k (0..N/2) of one on-sky component, optionally with the sub-sample shift phase ramp
 // exp(-2 pi i f rem) of BaseTrace.apply_time_shift (base_trace.py:246-276)
+// `ramp` (optional, LDS): exp(-2 pi i f_k rem) = ramp[k & 63] * ramp[64 + (k >> 6)] (two-level table filled by
+// field_time_domain: 64 + N / 128 + 1 sincospi per ray instead of one sincos per bin)
 __device__ inline double2 field_bin(int k, double amp_k, int N, double fs, double pol, double2 rc, double rem,
-                                    bool shift, int ask_model, double roll_bins)
+                                    bool shift, int ask_model, double roll_bins, const double2* ramp = nullptr)
 {
     const int nh = N / 2;
     if (k <= 0 || k >= nh) return make_double2(0., 0.);
@@ -711,10 +724,14 @@ __device__ inline double2 field_bin(int k, double amp_k, int N, double fs, doubl
     s = cscale(s, pol);
     s = cmul(s, rc);
     if (shift) {
-        double f = k * (1.0 / (N * (1. / fs)));
-        double sn, cs;
-        sincos(-2. * M_PI * rem * f, &sn, &cs);
-        s = cmul(s, make_double2(cs, sn));
+        if (ramp) {
+            s = cmul(s, cmul(ramp[k & 63], ramp[64 + (k >> 6)]));
+        } else {
+            double f = k * (1.0 / (N * (1. / fs)));
+            double sn, cs;
+            sincos(-2. * M_PI * rem * f, &sn, &cs);
+            s = cmul(s, make_double2(cs, sn));
+        }
     }
     return s;
 }
@@ -729,9 +746,26 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
                                          const double2* __restrict__ tw)
 {
     const int nh = N / 2;
+#ifdef NRHIP_CONV_TIMING
+    if (threadIdx.x == 0) g_ct_mark[blockIdx.x & 1023] = __builtin_amdgcn_s_memtime();
+#endif
+    // the sub-sample shift's phase ramp exp(-2 pi i f rem), f = k fs / N: w^k = w^(k & 63) * (w^64)^(k >> 6)
+    __shared__ double2 s_ramp[64 + FFT_MAX / 4 / 64 + 1];
+    const double2* ramp = nullptr;
+    if (shift && blockDim.x >= 64 + (unsigned)(nh >> 6) + 1) {
+        const int t = threadIdx.x;
+        if (t < 64 + (nh >> 6) + 1) {
+            const double f = (t < 64 ? t : 64 * (t - 64)) * (1.0 / (N * (1. / fs)));
+            double sn, cs;
+            sincospi(-2. * rem * f, &sn, &cs);
+            s_ramp[t] = make_double2(cs, sn);
+        }
+        __syncthreads();
+        ramp = s_ramp;
+    }
     for (int k = threadIdx.x; k < nh; k += blockDim.x) {
-        double2 Gk = field_bin(k, amp[k], N, fs, pol, rc, rem, shift, ask_model, roll_bins);
-        double2 Gc = cconj(field_bin(nh - k, amp[nh - k], N, fs, pol, rc, rem, shift, ask_model, roll_bins));
+        double2 Gk = field_bin(k, amp[k], N, fs, pol, rc, rem, shift, ask_model, roll_bins, ramp);
+        double2 Gc = cconj(field_bin(nh - k, amp[nh - k], N, fs, pol, rc, rem, shift, ask_model, roll_bins, ramp));
         double2 ge = cscale(cadd(Gk, Gc), 0.5);
         double2 d = cscale(csub(Gk, Gc), 0.5);
         double2 wk = tw[k * (FFT_MAX / N)];      // exp(-2 pi i k / N)
@@ -739,6 +773,9 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
         x[k] = make_double2(ge.x - go.y, ge.y + go.x);  // ge + i go
     }
     __syncthreads();
+#ifdef NRHIP_CONV_TIMING
+    if (threadIdx.x == 0) atomicAdd(&g_conv_clk[10], __builtin_amdgcn_s_memtime() - g_ct_mark[blockIdx.x & 1023]);
+#endif
     // inverse, natural -> bit-reversed; scale applied by the reader
     if (FUSE > 2) fft_dif_fused_k<(FUSE > 2 ? FUSE : 3)>(x, log2nh, tw, true);
     else fft_dif(x, log2nh, tw, true);
@@ -1695,15 +1732,10 @@ __global__ void channel_event_flags_kernel(int n_cand, int n_ch, const int* __re
 #ifndef CONV_NT
 #define CONV_NT 512
 #endif
-#define CONV_MAX_ORDER 64  // stations with more channels are evaluated in channel order
-#ifdef NRHIP_CONV_TIMING  // debug builds: shader clocks per phase, summed over the blocks (thread 0), read by nrhip_debug_conv_clocks
-__device__ unsigned long long g_conv_clk[16];
-#define CT_DECL unsigned long long ct_t = __builtin_amdgcn_s_memtime()
-#define CT(i) do { unsigned long long ct_n = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_conv_clk[i], ct_n - ct_t); ct_t = ct_n; } while (0)
-#else
-#define CT_DECL
-#define CT(i)
+#ifndef CONV_FIELD_FUSE
+#define CONV_FIELD_FUSE 0   // radix-2 stages fused per LDS pass in the rays' N/2-point transforms (0: pairs)
 #endif
+#define CONV_MAX_ORDER 64  // stations with more channels are evaluated in channel order
 __global__ void __launch_bounds__(CONV_NT)
 channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list, const int* __restrict__ need,
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
@@ -1829,7 +1861,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     double2 rc = one ? make_double2(1., 0.) : (comp ? rp : rt);
                     double vfac = one ? (vt * pt * rt.x + vp * pp * rp.x) : (comp ? vp : vt);
                     if (!one && (comp ? wp : wt) <= 1e-13 * (comp ? wt : wp)) continue;
-                    field_time_domain(xs, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
+                    field_time_domain<CONV_FIELD_FUSE>(xs, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
                     CT(3);
                     const double c = vfac / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
                     for (int j = threadIdx.x; j < nh; j += blockDim.x) {

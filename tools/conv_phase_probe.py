@@ -30,4 +30,5 @@ names = ['skip / control', 'zero S', 'amplitude fill', 'field transform', 'place
 tot = float(sum(out[:10]))
 for n, v in zip(names, out[:10]):
     print('%-16s %6.2f %%  %.3e clk' % (n, 100 * v / tot, v))
+print('  of the field transform: spectrum build %.2f %%' % (100 * out[10] / tot))
 print('channel transforms', d['config']['n_channel_transforms'], 'ray transforms', d['config']['n_ray_transforms'])
