@@ -347,6 +347,8 @@ typedef struct {
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1
 #define NRHIP_TRIG_PHASED_ARRAY 2   /* needs nrhip_station_set_phased_array; trigger_threshold is the power threshold */
+#define NRHIP_TRIG_ENVELOPE 3       /* envelopeTrigger.py: needs nrhip_station_set_envelope_trigger; Hilbert envelope of the band-passed
+                                       channel trace > trigger_threshold, then the majority logic (n_coincidences, coinc_window) */
 
 #define NRHIP_N_STAGES 9
 /* stage_ms: device time (HIP events on the context's stream) of 0 ray tracing, 1 ray selection + setup,
@@ -405,6 +407,11 @@ int nrhip_station_set_trigger_channels(nrhip_station* st, int32_t n, const int32
  * mean power of sliding windows (window samples, every step samples; averaging_divisor 0 = window) is compared with
  * nrhip_sim_config.trigger_threshold (trigger_type NRHIP_TRIG_PHASED_ARRAY).  Table afterwards: "pa_max_power"
  * [candidate event][beam] (maximum_amps).  n_pa = 0 switches it off.  HOST pointers (copied).                       */
+/* The band pass of the envelope trigger (NuRadioReco/modules/trigger/envelopeTrigger.py:47-136 filters every channel with
+ * channel.get_filtered_trace(passband, 'butter', order) before the Hilbert envelope): the analog Butterworth design as one rational
+ * stage polyval(b, j f) / polyval(a, j f), highest power first, f in GHz (what nrhip_station_desc.filter_b / filter_a hold).
+ * nb <= 0 switches it off. */
+int nrhip_station_set_envelope_trigger(nrhip_station* st, int32_t nb, int32_t na, const double* b, const double* a);
 int nrhip_station_set_phased_array(nrhip_station* st, int32_t n_pa, const int32_t* channels, int32_t n_beams,
                                    const int32_t* rolls, int32_t window, int32_t step, int32_t averaging_divisor);
 

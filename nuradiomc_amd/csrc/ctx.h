@@ -68,6 +68,8 @@ struct nrhip_station {
     int64_t n_shower_profiles = 0;
     // phased-array trigger (nrhip_station_set_phased_array)
     DevArray d_pa_channel, d_pa_rolls, d_pa_mask, d_trig_on;
+    nrhip::FilterSet env_filter;   // band pass of the envelope trigger (nrhip_station_set_envelope_trigger)
+    bool env_set = false;
     int pa_n_channels = 0, pa_n_beams = 0, pa_window = 0, pa_step = 0, pa_divisor = 0;
     // workspace of the last simulated chunk (kept for nrhip_sim_fetch and reused between calls)
     std::map<std::string, DevArray> ws;

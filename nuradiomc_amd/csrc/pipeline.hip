@@ -392,6 +392,28 @@ int nrhip_station_set_trigger_channels(nrhip_station* s, int32_t n, const int32_
     return 0;
 }
 
+int nrhip_station_set_envelope_trigger(nrhip_station* s, int32_t nb, int32_t na, const double* b, const double* a)
+{
+    if (!s) return nrhip_fail_msg("nrhip_station_set_envelope_trigger: NULL argument");
+    if (nb <= 0) {
+        s->env_set = false;
+        return 0;
+    }
+    if (!b || !a || na <= 0 || nb > NRHIP_MAX_POLY || na > NRHIP_MAX_POLY)
+        return nrhip_fail_msg("nrhip_station_set_envelope_trigger: bad polynomial sizes");
+    FilterSet f;
+    memset(&f, 0, sizeof f);
+    f.n = 1;
+    f.kind[0] = 0;
+    f.nb[0] = nb;
+    f.na[0] = na;
+    for (int i = 0; i < nb; i++) f.b[0][i] = b[i];
+    for (int i = 0; i < na; i++) f.a[0][i] = a[i];
+    s->env_filter = f;
+    s->env_set = true;
+    return 0;
+}
+
 int nrhip_station_set_phased_array(nrhip_station* s, int32_t n_pa, const int32_t* channels, int32_t n_beams, const int32_t* rolls,
                                    int32_t window, int32_t step, int32_t averaging_divisor)
 {
@@ -650,6 +672,11 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (cfg->n_reflections > 0 && (bire || cfg->focusing))
         return nrhip_fail_msg("nrhip_simulate_events: bottom reflections are not available together with birefringence or focusing");
     const bool phased = cfg->trigger_type == NRHIP_TRIG_PHASED_ARRAY;
+    const bool envelope = cfg->trigger_type == NRHIP_TRIG_ENVELOPE;
+    if (envelope && !st->env_set)
+        return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger needs its band pass (nrhip_station_set_envelope_trigger)");
+    if (envelope && (sd.ant_tabs || cfg->amp_per_ray))
+        return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger is not available with tabulated antenna patterns or amp_per_ray");
     if (phased && st->pa_n_channels <= 0)
         return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger needs its channels and beams (nrhip_station_set_phased_array)");
     if (phased && (general || cfg->amp_per_ray)) return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger runs on the parametrised path only (no ARZ / birefringence / amp_per_ray)");
@@ -1135,7 +1162,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         const int n_items = n_cand * n_ch;
         S.n_channel_items = n_items;
         TriggerDev trg;
-        trg.type = cfg->trigger_type == NRHIP_TRIG_HIGH_LOW ? 1 : 0;
+        trg.type = cfg->trigger_type == NRHIP_TRIG_HIGH_LOW ? 1 : (envelope ? 2 : 0);
         trg.n_coinc = cfg->n_coincidences > 1 ? cfg->n_coincidences : 1;
         trg.threshold = phased ? INFINITY : cfg->trigger_threshold;  // phased array: the channel stage only produces the traces
         trg.high = cfg->threshold_high;
@@ -1146,13 +1173,14 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         // than FFT_MAX samples, tabulated antenna patterns, the general path) the channel stage only produces the traces and
         // trace_trigger_kernel decides on them
         const bool post_trigger = trg.coincidence() && !phased &&
-                                  (maxL > FFT_MAX || sd.N > FFT_MAX / 2 || getenv("NRHIP_CHANNEL_CZT") || sd.ant_tabs || general);
+                                  (maxL > FFT_MAX || sd.N > FFT_MAX / 2 || getenv("NRHIP_CHANNEL_CZT") || sd.ant_tabs || general || envelope);
         TriggerDev trg_ch = trg;
         if (post_trigger) {
             trg_ch.type = 0;
             trg_ch.n_coinc = 1;
             trg_ch.threshold = INFINITY;
         }
+        double* env_trace = nullptr;
         ChannelOut co;
         NEED(co.maxV = WS("item_maxV", double, n_items));
         co.trigger_bin = trigger_bin;
@@ -1174,6 +1202,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             // reference's empty channels
             HIPCHK(hipMemsetAsync(co.trace, 0, sizeof(double) * (size_t)std::max<long>(off[n_items], 1), sm));
             co.trace_offset = d_off;
+            if (envelope) {   // the envelopes of the band-passed channel traces, same layout
+                NEED(env_trace = WS("envelope_trace", double, std::max<long>(off[n_items], 1)));
+                HIPCHK(hipMemsetAsync(env_trace, 0, sizeof(double) * (size_t)std::max<long>(off[n_items], 1), sm));
+            }
             HIPCHK(hipStreamSynchronize(sm));  // `off` goes out of scope
         }
         double2* scratch;
@@ -1195,11 +1227,11 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                        trg_ch, ctx->twiddle, ctx->w16, tab, scratch, co,
                        (cfg->no_pruning || cfg->dump_traces || general || phased || post_trigger) ? 1 : 0, maxL,
                        it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces,
-                       (phased || post_trigger) ? (cfg->dump_traces ? 0 : 1) : -1);
+                       (phased || post_trigger) ? (cfg->dump_traces ? 0 : 1) : -1, envelope ? &st->env_filter : nullptr, env_trace);
         LCHK("channel");
         if (post_trigger) {
-            launch_trace_trigger(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, trg, sd.trig_on, maxL, ev_triggered,
-                                 trigger_bin);
+            launch_trace_trigger(sm, n_cand, d_cand, n_ch, ev.L, envelope ? env_trace : co.trace, co.trace_offset, trg, sd.trig_on, maxL,
+                                 ev_triggered, trigger_bin);
             LCHK("trace trigger");
         }
         if (phased) {

@@ -118,7 +118,7 @@ struct LengthTables {
 
 // trigger logic of the station (nrhip_sim_config), times in samples
 struct TriggerDev {
-    int type;            // 0 simple threshold, 1 high/low
+    int type;            // 0 simple threshold, 1 high/low, 2 Hilbert envelope of the band-passed trace (decided on dumped traces only)
     int n_coinc;         // channels required inside the coincidence window
     double threshold;    // simple: |V| >= threshold
     double high, low;    // high/low: a sample >= high and a sample <= low inside w_hl samples
@@ -195,7 +195,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
-                    const double* ray_traces = nullptr, int skip_off = -1);
+                    const double* ray_traces = nullptr, int skip_off = -1, const FilterSet* envf = nullptr, double* env_trace = nullptr);
 void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                           const long* trace_offset, const TriggerDev& trg, const unsigned char* trig_on, int max_length,
                           unsigned char* triggered, int* trigger_bin);

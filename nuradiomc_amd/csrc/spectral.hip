@@ -2064,7 +2064,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                const int* __restrict__ ev_len_index, StationDev st, FilterSet fl, int ask_model, double threshold,
                const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
                ChannelOut out, int exact, int skip_upto, double2* __restrict__ tab_nodes,
-               const double* __restrict__ ray_traces)
+               const double* __restrict__ ray_traces, FilterSet envf, double* __restrict__ env_trace)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M = FFT_MAX, N = st.N, nh = N / 2;
@@ -2256,6 +2256,40 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                 }
                 __syncthreads();
             }
+        }
+        if (env_trace && n_used > 0) {
+            // envelope trigger (envelopeTrigger.py:14-31 on channel.get_filtered_trace(passband, 'butter', order)): the channel
+            // spectrum through the trigger's band pass, then the analytic signal -- the one-sided sum the inverse chirp-z forms anyway
+            // (DC and Nyquist once and real, the bins between twice: scipy.signal.hilbert's weights); its modulus is the envelope
+            const int P = M - m;
+            const double scale = st.fs / 1.4142135623730951 / L;
+            const double dfL = 1.0 / (L * (1. / st.fs));
+            for (int n0 = 0; n0 < L; n0 += P) {
+                __syncthreads();
+#pragma unroll 2
+                for (int k = threadIdx.x; k < M; k += blockDim.x) {
+                    double2 v = make_double2(0., 0.);
+                    if (k <= m) {
+                        v = cmul(cmul(acc[k], Hf[k]), apply_filters(make_double2(1., 0.), k * dfL, envf));
+                        if (k == 0 || k == m) v = make_double2(v.x, 0.);
+                        else v = cscale(v, 2.);
+                        if (n0 != 0) {
+                            unsigned kn = ((unsigned)k * (unsigned)n0) % LL;
+                            v = cmul(v, cconj(E[2 * kn]));
+                        }
+                        v = cmul(v, Ci[k]);
+                    }
+                    x[k] = v;
+                }
+                __syncthreads();
+                czt_convolve_t<512>(x, Bi, tw);
+                const int np = min(P, L - n0);
+                for (int n = threadIdx.x; n < np; n += blockDim.x) {
+                    const double2 u = cmul(x[n], Ci[n]);
+                    env_trace[out.trace_offset[item] + n0 + n] = cabs2(u) * (1.0 / M) * scale;
+                }
+            }
+            __syncthreads();
         }
         if (trig) s_trig = 1;
         double vm = need_trace ? block_max(vmax, red) : vmax;
@@ -2781,7 +2815,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
-                    const double* ray_traces, int skip_off)
+                    const double* ray_traces, int skip_off, const FilterSet* envf, double* env_trace)
 {
     if (skip_off < 0) skip_off = !exact;  // channels outside the trigger set are evaluated only when everything is
     if (n_items <= 0) return;
@@ -2791,7 +2825,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     // traces up to FFT_MAX samples: prefilter, then one real convolution per listed item; longer ones (or
     // NRHIP_CHANNEL_CZT=1): chirp-z per ray (plain OR of simple thresholds only; the caller checks)
     int skip_upto = 0;
-    if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces) {
+    if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces && !env_trace) {
         hipLaunchKernelGGL(channel_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev,
                            ev_len_index, st, trig.prefilter(), tab.hnorm, exact, out.maxV, need, skip_off);
         const int n_cand = n_items / st.n_ch;
@@ -2812,7 +2846,8 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     }
     size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
     hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
-                       ask_model, trig.threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto, tab_nodes, ray_traces);
+                       ask_model, trig.threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto, tab_nodes, ray_traces,
+                       envf ? *envf : fl, env_trace);
 }
 // ---------------------------------------------------------------------------------------------------------
 // General emission / propagation path (time-domain emission models such as ARZ, birefringence): the on-sky spectra of every
@@ -3107,7 +3142,7 @@ trace_trigger_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, c
         const int e = item_event[ic], L = ev_L[e];
         int* A = tt_lds;
         int* cnt = tt_lds + L;
-        const int nb = (trg.type == 0) ? L : L - 1;
+        const int nb = (trg.type == 1) ? L - 1 : L;
         __syncthreads();
         for (int i = threadIdx.x; i < L; i += blockDim.x) cnt[i] = 0;
         if (threadIdx.x == 0) s_first = 0x7fffffff;
@@ -3119,6 +3154,8 @@ trace_trigger_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, c
                 bool flag;
                 if (trg.type == 0) {
                     flag = fabs(V[i]) >= trg.threshold;
+                } else if (trg.type == 2) {   // V is the Hilbert envelope of the band-passed trace (envelopeTrigger.py:31: strictly above)
+                    flag = V[i] > trg.threshold;
                 } else {
                     bool hi = false, lo = false;
                     for (int k = max(0, i - trg.w_hl + 1); k <= i; k++) {

@@ -104,6 +104,7 @@ L._OPTIONAL.update({
     'nrhip_station_release_workspace': (ctypes.c_int64, [ctypes.c_void_p]),
     'nrhip_station_set_positions': (ctypes.c_int, [ctypes.c_void_p, L.c_double_p]),
     'nrhip_station_set_trigger_channels': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_int32_p]),
+    'nrhip_station_set_envelope_trigger': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p, L.c_double_p]),
     'nrhip_station_set_phased_array': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_int32_p, ctypes.c_int32, L.c_int32_p,
                                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'nrhip_station_set_arz': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p, L.c_double_p,
@@ -381,6 +382,17 @@ class Station:
             ch = np.ascontiguousarray(channels, np.int32)
             L.check(self._lib.nrhip_station_set_trigger_channels(self._h, len(ch), L.iptr(ch)))
 
+    def set_envelope_trigger(self, passband=None, order=None):
+        """The band pass of the envelope trigger (envelopeTrigger.triggerSimulator.run(passband=, order=): every channel is filtered
+        with a Butterworth of this pass band [GHz] and order before its Hilbert envelope is compared with the threshold); then
+        simulate_events(..., trigger='envelope', trigger_threshold=, n_coincidences=, coinc_window=).  passband=None: off."""
+        if passband is None:
+            L.check(self._lib.nrhip_station_set_envelope_trigger(self._h, 0, 0, None, None))
+            return
+        _, b, a = flt.design(dict(type='butter', passband=tuple(passband), order=int(order)))
+        b, a = np.ascontiguousarray(b, float), np.ascontiguousarray(a, float)
+        L.check(self._lib.nrhip_station_set_envelope_trigger(self._h, len(b), len(a), L.dptr(b), L.dptr(a)))
+
     def set_phased_array(self, channels, phasing_angles, ref_index=1.75, window=32, step=16, averaging_divisor=None):
         """Phased-array trigger on the given channels (a vertical string): beams towards `phasing_angles` [rad], whole-sample
         channel shifts as PhasedArrayBase.calculate_time_delays (phasedArrayBase.py:58-124: antenna depths, ref_index, cable
@@ -447,7 +459,8 @@ class Station:
         d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
         trigger: 'simple' (|V| >= trigger_threshold, simpleThreshold.py) or 'high_low' (highLowThreshold.py: threshold_high /
         threshold_low inside high_low_window), both followed by the majority logic over coinc_window with n_coincidences;
-        'phased_array' (set_phased_array first): trigger_threshold is the threshold on the beams' mean window power.
+        'phased_array' (set_phased_array first): trigger_threshold is the threshold on the beams' mean window power;
+        'envelope' (set_envelope_trigger first): Hilbert envelope of the band-passed trace > trigger_threshold, then the majority logic.
         select_only: stop after ray tracing and the delta_C cut (then fetch('shower_first_channel')); reuse_ray_tables:
         continue from the tables of such a call on the same device arrays; accumulate_triggered: OR into d_triggered
         instead of overwriting it (nrhip_sim_config).  n_reflections > 0: rays reflected off the bottom of an ice shelf at depth
@@ -455,12 +468,12 @@ class Station:
         split_event_time_diff > 0 [ns]: simulation.group_into_events -- a group's signals at this station are cut into sub-events
         where consecutive start times are farther apart; the ev_* / item_* tables are then per sub-event (fetch('ev_group'),
         fetch('ev_sub_event')), the mask stays per group."""
-        if trigger not in ('simple', 'high_low', 'phased_array'):
-            raise NotImplementedError("trigger {} is not provided (simple, high_low, phased_array)".format(trigger))
+        if trigger not in ('simple', 'high_low', 'phased_array', 'envelope'):
+            raise NotImplementedError("trigger {} is not provided (simple, high_low, phased_array, envelope)".format(trigger))
         cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
                         float(2.0 * self.vrms_efield if min_efield_amplitude is None else min_efield_amplitude),
                         float(3.0 * self.vrms if trigger_threshold is None else trigger_threshold), int(bool(dump_traces)),
-                        int(bool(no_pruning)), {'simple': 0, 'high_low': 1, 'phased_array': 2}[trigger], int(n_coincidences),
+                        int(bool(no_pruning)), {'simple': 0, 'high_low': 1, 'phased_array': 2, 'envelope': 3}[trigger], int(n_coincidences),
                         float(3.0 * self.vrms if threshold_high is None else threshold_high),
                         float(-3.0 * self.vrms if threshold_low is None else threshold_low), float(high_low_window),
                         float(coinc_window), int(bool(amp_per_ray)), int(bool(focusing)), float(focusing_limit),

@@ -672,12 +672,34 @@ def phased_array_trigger(V, rolls, window, step, threshold):
     return bool(np.any(p > threshold)), p.max(axis=1)
 
 
+def envelope_of_filtered(v, fs, passband, order):
+    """envelopeTrigger.py:14-31 on channel.get_filtered_trace(passband, 'butter', order) (base_trace.py:58-75): the trace through
+    a Butterworth band pass in the frequency domain, then |scipy.signal.hilbert| (one-sided spectrum: DC and Nyquist once, the
+    bins between twice)"""
+    n = len(v)
+    ff = np.fft.rfftfreq(n, 1. / fs)
+    spec = time2freq(np.asarray(v, float), fs) * filter_response(ff, [dict(passband=list(passband), order=int(order))])
+    x = freq2time(spec, fs, n)
+    X = np.fft.fft(x)
+    h = np.zeros(n)
+    if n % 2 == 0:
+        h[0] = h[n // 2] = 1
+        h[1:n // 2] = 2
+    else:
+        h[0] = 1
+        h[1:(n + 1) // 2] = 2
+    return np.abs(np.fft.ifft(X * h))
+
+
 def station_trigger(V, fs, trigger='simple', threshold=None, n_coincidences=1, threshold_high=None, threshold_low=None,
-                    high_low_window=5., coinc_window=200.):
-    """simpleThreshold.triggerSimulator.run / highLowThreshold.triggerSimulator.run on all channels: (triggered, bins)"""
+                    high_low_window=5., coinc_window=200., passband=None, order=None):
+    """simpleThreshold.triggerSimulator.run / highLowThreshold.triggerSimulator.run / envelopeTrigger.triggerSimulator.run on all
+    channels: (triggered, bins)"""
     dt = 1. / fs
     if trigger == 'simple':
         flags = [np.abs(v) >= threshold for v in V]
+    elif trigger == 'envelope':
+        flags = [envelope_of_filtered(v, fs, passband, order) > threshold for v in V]
     else:
         flags = [high_low_triggers(v, threshold_high, threshold_low, int(np.round(high_low_window / dt))) for v in V]
     return majority_logic(flags, n_coincidences, int(np.round(coinc_window / dt)))

@@ -107,6 +107,8 @@ def default_config(model='Alvarez2009', ice_model='southpole_2015', fs=2.0, n_fr
 _bp = NuRadioReco.modules.channelBandPassFilter.channelBandPassFilter()
 _trig = NuRadioReco.modules.trigger.simpleThreshold.triggerSimulator()
 _hl = NuRadioReco.modules.trigger.highLowThreshold.triggerSimulator()
+import NuRadioReco.modules.trigger.envelopeTrigger  # noqa: E402
+_env = NuRadioReco.modules.trigger.envelopeTrigger.triggerSimulator()
 FILTERS = [dict(passband=[80 * units.MHz, 1000 * units.GHz], filter_type='butter', order=2),
            dict(passband=[0, 500 * units.MHz], filter_type='butter', order=10)]
 
@@ -248,7 +250,13 @@ def simulate_event(ev_id, shower, det, prop, ice, config, vrms, vrms_efield, tri
         out['triggered'] = any(q['triggered'] for q in out['sub'])
         return out
     simulation.apply_det_response(evt, det, config, filter_amp, add_noise=False)
-    if trigger is not None and trigger.get('kind') == 'high_low':   # highLowThreshold.triggerSimulator.run (:160-335)
+    if trigger is not None and trigger.get('kind') == 'envelope':   # envelopeTrigger.triggerSimulator.run (:47-136)
+        _env.run(evt, station, det, passband=trigger['passband'], order=trigger['order'], threshold=trigger['threshold'],
+                 coinc_window=trigger['coinc_window'], number_coincidences=trigger['number_coincidences'], triggered_channels=None,
+                 trigger_name='envelope')
+        tr_ = station.get_trigger('envelope')
+        out['trigger_time'] = tr_.get_trigger_time() if tr_.has_triggered() else np.nan
+    elif trigger is not None and trigger.get('kind') == 'high_low':   # highLowThreshold.triggerSimulator.run (:160-335)
         _hl.run(evt, station, det, threshold_high=trigger['threshold_high'], threshold_low=trigger['threshold_low'],
                 high_low_window=trigger['high_low_window'], coinc_window=trigger['coinc_window'],
                 number_concidences=trigger['number_concidences'], triggered_channels=None, trigger_name='high_low')

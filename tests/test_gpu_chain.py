@@ -1219,3 +1219,35 @@ def test_coincidence_triggers_beyond_the_fused_kernel(gpu_ctx_factory, kw):
     assert 1 <= trig.sum() < stats['n_candidate_events']
     trig_p, _ = st.simulate_events(*args, **opts)
     assert np.array_equal(trig_p, trig)
+
+
+def test_envelope_trigger(gpu_ctx_factory):
+    """trigger='envelope' (envelopeTrigger.py): every channel trace through the trigger's Butterworth band pass, Hilbert envelope
+    above the threshold, majority logic.  GPU vs the oracle on the traces the kernels dumped (envelopes 1e-9, masks and first bins
+    exact), and vs the reference's own decisions (tests/golden/chain_envelope_N256.npz) where the ray counts agree; production mode
+    gives the same mask."""
+    g = golden('chain_envelope_N256.npz')
+    n = len(g['vertex'])
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    args = (g['vertex'], g['zenith'], g['azimuth'], g['energy'], g['shower_type'], np.ones(n))
+    for i in range(2):
+        pb, order = g['s%d_passband' % i], int(g['s%d_order' % i])
+        st.set_envelope_trigger(pb, order)
+        opts = dict(trigger='envelope', trigger_threshold=float(g['s%d_threshold' % i]), n_coincidences=int(g['s%d_n_coincidences' % i]),
+                    coinc_window=float(g['s%d_coinc_window' % i]))
+        okw = dict(trigger='envelope', threshold=opts['trigger_threshold'], n_coincidences=opts['n_coincidences'],
+                   coinc_window=opts['coinc_window'], passband=pb, order=order)
+        trig, stats = st.simulate_events(*args, dump_traces=True, **opts)
+        _check_trace_triggers(st, trig, okw, n)
+        item_event, tr, env, off = st.fetch('item_event'), st.fetch('trace'), st.fetch('envelope_trace'), st.fetch('trace_offset')
+        for k in range(0, len(item_event) * 5, 7):
+            ref = so.envelope_of_filtered(tr[off[k]:off[k + 1]], st.sampling_rate, pb, order)
+            assert np.max(np.abs(env[off[k]:off[k + 1]] - ref)) <= 1e-9 * max(np.max(ref), 1e-30), k
+        same = st.fetch('ev_n_rays') == g['ev_n_rays']
+        assert same.mean() > 0.97 and np.array_equal(trig[same], g['s%d_triggered' % i][same]) and trig.sum() >= 25
+        trig_p, _ = st.simulate_events(*args, **opts)
+        assert np.array_equal(trig_p, trig)
+    st.set_envelope_trigger(None)
+    with pytest.raises(Exception, match='envelope'):
+        st.simulate_events(*args, trigger='envelope')

@@ -260,3 +260,38 @@ def test_split_event_time_diff_vs_reference():
         n_split += len(rows) > 1
         n_trig += o['triggered']
     assert n_same >= 0.97 * n_groups and n_split >= 30 and n_trig >= 15
+
+
+def test_envelope_trigger_vs_reference():
+    """envelopeTrigger.triggerSimulator.run (band-pass filtered trace, |hilbert| > threshold, majority logic): the oracle's decision
+    on the reference's own channel traces, and through the whole chain wherever the ray counts agree (tests/golden/gen/gen_envelope.py)."""
+    g = golden('chain_envelope_N256.npz')
+    st = _station(g)
+    vrms, vrms_e = so.vrms_from_filters(st.fs)
+    n = len(g['vertex'])
+    sets = [dict(trigger='envelope', passband=g['s%d_passband' % i], order=int(g['s%d_order' % i]), threshold=float(g['s%d_threshold' % i]),
+                 coinc_window=float(g['s%d_coinc_window' % i]), n_coincidences=int(g['s%d_n_coincidences' % i])) for i in range(2)]
+    # the trigger logic on the reference's traces: decision and trigger time
+    n_t = 0
+    for j, ev in enumerate(g['V_events']):
+        V = g['V_concat'][:, g['V_offsets'][j]:g['V_offsets'][j + 1]]
+        t, bins = so.station_trigger(V, st.fs, **sets[0])
+        assert t == bool(g['s0_triggered'][ev]), ev
+        if t:
+            assert abs(bins[0] / st.fs - g['s0_trigger_time'][ev]) < 1e-9
+            n_t += 1
+    assert n_t >= 8
+    # whole chain
+    n_same = 0
+    trig = np.zeros((2, n), bool)
+    for ev in range(n):
+        o = so.simulate_event(g['vertex'][ev], g['zenith'][ev], g['azimuth'][ev], g['energy'][ev], 'HAD', None, st, g['ice'], vrms, vrms_e)
+        if len(o['rays']) != g['ev_n_rays'][ev]:
+            continue
+        n_same += 1
+        assert o['candidate'] == bool(g['ev_candidate'][ev])
+        for i in range(2):
+            t = o['candidate'] and so.station_trigger(o['V'], st.fs, **sets[i])[0]
+            assert t == bool(g['s%d_triggered' % i][ev]), (ev, i)
+            trig[i, ev] = t
+    assert n_same >= 0.97 * n and trig[0].sum() >= 25 and trig[1].sum() >= 35
