@@ -68,6 +68,20 @@ struct nrhip_station {
     int64_t n_shower_profiles = 0;
     // phased-array trigger (nrhip_station_set_phased_array)
     DevArray d_pa_channel, d_pa_rolls, d_pa_mask, d_trig_on;
+    // per-length tables (Bluestein chirps, antenna / filter responses on the L grid, impulse-response spectra) are station
+    // constants: built once per distinct trace length and kept for the station's lifetime (like FFT plans); slot_of[L / 2] = row
+    struct LengthTableCache {
+        DevArray B_fwd, B_inv, vel, E, H, Cf, Ci, hnorm, G, slotmap;
+        std::vector<int> slot_of;
+        int n_slots = 0, cap = 0;
+        void release()
+        {
+            B_fwd.release(); B_inv.release(); vel.release(); E.release(); H.release(); Cf.release(); Ci.release(); hnorm.release();
+            G.release(); slotmap.release();
+            slot_of.clear();
+            n_slots = cap = 0;
+        }
+    } tabcache;
     nrhip::FilterSet env_filter;   // band pass of the envelope trigger (nrhip_station_set_envelope_trigger)
     bool env_set = false;
     int pa_n_channels = 0, pa_n_beams = 0, pa_window = 0, pa_step = 0, pa_divisor = 0;

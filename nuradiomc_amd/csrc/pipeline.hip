@@ -338,6 +338,7 @@ void nrhip_station_detach(nrhip_station* s)
     s->d_bire_coeffs.release(); s->d_shower_profile.release(); s->d_shower_rescale.release();
     s->d_pa_channel.release(); s->d_pa_rolls.release(); s->d_pa_mask.release(); s->d_trig_on.release();
     s->d_filter_pool.release(); s->d_ch_fset.release(); s->d_filtersets.release();
+    s->tabcache.release();
     s->ws.clear();
     s->ws_bytes.clear();
     s->ctx->stations.erase(s);
@@ -1135,17 +1136,55 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             return nrhip_fail_msg("nrhip_simulate_events: an event's common trace is longer than the 8192-point chirp-z supports");
         S.n_distinct_lengths = (int64_t)lens.size();
         MARK(6);
+        // the tables of the lengths this station has not met before are built now, into new rows of its cache
+        auto& tc = st->tabcache;
+        if (tc.slot_of.empty()) tc.slot_of.assign(n_half, -1);
+        std::vector<int> new_len, new_slot;
+        for (int L_ : lens) {
+            int& slot = tc.slot_of[L_ / 2];
+            if (slot < 0) {
+                slot = tc.n_slots++;
+                new_len.push_back(L_);
+                new_slot.push_back(slot);
+            }
+        }
+        const size_t row[9] = {(size_t)FFT_MAX * 16, (size_t)FFT_MAX * 16, NRHIP_N_ANT_TAB * (size_t)NRHIP_SPEC_STRIDE * 16,
+                               (size_t)NRHIP_E_STRIDE * 16, sd.n_fsets * (size_t)NRHIP_SPEC_STRIDE * 16, (size_t)NRHIP_SPEC_STRIDE * 16,
+                               (size_t)FFT_MAX * 16, sd.n_fsets * (size_t)NRHIP_N_ANT_TAB * 8,
+                               sd.n_fsets * (size_t)NRHIP_N_ANT_TAB * NRHIP_G_STRIDE * 16};
+        DevArray* arr[9] = {&tc.B_fwd, &tc.B_inv, &tc.vel, &tc.E, &tc.H, &tc.Cf, &tc.Ci, &tc.hnorm, &tc.G};
+        if (tc.n_slots > tc.cap) {   // grow, keeping the rows that exist
+            const int old_rows = tc.n_slots - (int)new_len.size();
+            const int new_cap = std::max(tc.n_slots, std::max(tc.cap + tc.cap / 2, 64));
+            for (int a = 0; a < 9; a++) {
+                DevArray fresh;
+                if (fresh.reserve(row[a] * (size_t)new_cap) != hipSuccess)
+                    return nrhip_fail_msg("nrhip_simulate_events: out of device memory (per-length tables)");
+                if (old_rows > 0) HIPCHK(hipMemcpyAsync(fresh.p, arr[a]->p, row[a] * (size_t)old_rows, hipMemcpyDeviceToDevice, sm));
+                HIPCHK(hipStreamSynchronize(sm));
+                arr[a]->release();
+                *arr[a] = fresh;
+            }
+            tc.cap = new_cap;
+        }
         LengthTables tab;
-        NEED(tab.B_fwd = WS("tab_B_fwd", double2, lens.size() * (size_t)FFT_MAX));
-        NEED(tab.B_inv = WS("tab_B_inv", double2, lens.size() * (size_t)FFT_MAX));
-        NEED(tab.vel = WS("tab_vel", double2, lens.size() * NRHIP_N_ANT_TAB * (size_t)NRHIP_SPEC_STRIDE));
-        NEED(tab.E = WS("tab_E", double2, lens.size() * (size_t)NRHIP_E_STRIDE));
-        NEED(tab.H = WS("tab_H", double2, lens.size() * sd.n_fsets * (size_t)NRHIP_SPEC_STRIDE));
-        NEED(tab.Cf = WS("tab_Cf", double2, lens.size() * (size_t)NRHIP_SPEC_STRIDE));
-        NEED(tab.Ci = WS("tab_Ci", double2, lens.size() * (size_t)FFT_MAX));
-        NEED(tab.hnorm = WS("tab_hnorm", double, lens.size() * sd.n_fsets * NRHIP_N_ANT_TAB));
-        NEED(tab.G = WS("tab_G", double2, lens.size() * sd.n_fsets * NRHIP_N_ANT_TAB * (size_t)NRHIP_G_STRIDE));
-        launch_length_tables(sm, (int)lens.size(), d_lens, sd, st->d_filtersets.as<FilterSet>(), ctx->twiddle, ctx->w16, tab);
+        tab.B_fwd = tc.B_fwd.as<double2>(); tab.B_inv = tc.B_inv.as<double2>(); tab.vel = tc.vel.as<double2>();
+        tab.E = tc.E.as<double2>(); tab.H = tc.H.as<double2>(); tab.Cf = tc.Cf.as<double2>(); tab.Ci = tc.Ci.as<double2>();
+        tab.hnorm = tc.hnorm.as<double>(); tab.G = tc.G.as<double2>();
+        if (tc.slotmap.reserve(sizeof(int) * (size_t)n_half) != hipSuccess)
+            return nrhip_fail_msg("nrhip_simulate_events: out of device memory (length slot map)");
+        if (!new_len.empty()) {
+            int *d_new_len, *d_new_slot;
+            NEED(d_new_len = WS("new_lengths", int, new_len.size()));
+            NEED(d_new_slot = WS("new_length_slots", int, new_len.size()));
+            HIPCHK(hipMemcpyAsync(d_new_len, new_len.data(), sizeof(int) * new_len.size(), hipMemcpyHostToDevice, sm));
+            HIPCHK(hipMemcpyAsync(d_new_slot, new_slot.data(), sizeof(int) * new_slot.size(), hipMemcpyHostToDevice, sm));
+            HIPCHK(hipMemcpyAsync(tc.slotmap.p, tc.slot_of.data(), sizeof(int) * (size_t)n_half, hipMemcpyHostToDevice, sm));
+            launch_length_tables(sm, (int)new_len.size(), d_new_len, sd, st->d_filtersets.as<FilterSet>(), ctx->twiddle, ctx->w16, tab,
+                                 d_new_slot);
+            HIPCHK(hipStreamSynchronize(sm));   // the host vectors go out of scope
+        }
+        launch_length_slots(sm, (int)n_ev, ev.L, tc.slotmap.as<int>(), d_len_index);
         LCHK("length_tables");
         if (cfg->amp_per_ray && n_rays > 0) {
             double *max_env, *sig_time;
@@ -1154,7 +1193,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             HIPCHK(hipMemsetAsync(max_env, 0xFF, sizeof(double) * nr, sm));
             HIPCHK(hipMemsetAsync(sig_time, 0xFF, sizeof(double) * nr, sm));
             launch_ray_envelope(sm, n_cand, coff + n_ev, d_cand, w, ev, sd, cfg->askaryan_model, ctx->twiddle, tab,
-                                loff + sd.N / 2, max_env, sig_time);
+                                tc.slotmap.as<int>() + sd.N / 2, max_env, sig_time);
             LCHK("ray_envelope");
         }
         MARK(7);

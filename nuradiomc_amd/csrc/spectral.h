@@ -174,7 +174,8 @@ void launch_candidate_flags(hipStream_t s, int n_events, int n_half, const Event
 void launch_candidate_lists(hipStream_t s, int n_events, int n_half, const EventOut& ev, const int* cflag, const int* coff,
                             const int* lflag, const int* loff, int* cand, int* len_index, int* lens);
 void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet* fls,
-                          const double2* tw, const double2* w16, const LengthTables& tab);   // fls: DEV [st.n_fsets]
+                          const double2* tw, const double2* w16, const LengthTables& tab, const int* slots = nullptr);
+void launch_length_slots(hipStream_t s, int n_events, const int* ev_L, const int* slotmap, int* len_index);   // fls: DEV [st.n_fsets]
 int channel_grid_blocks();
 void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, int ask_model,
                              const double* arz_trace, const double2* tw, double2* spec);

@@ -1453,7 +1453,8 @@ __device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl
 // kernel: per distinct trace length L -- Bluestein tables and the analytic antenna magnitudes on the L grid
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, const FilterSet* __restrict__ fls,
+length_tables_kernel(int n_len, const int* __restrict__ lengths, const int* __restrict__ slots, StationDev st,
+                     const FilterSet* __restrict__ fls,
                      const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1462,25 +1463,26 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
     const int M = FFT_MAX, nh = st.N / 2;
     for (int il = blockIdx.x; il < n_len; il += gridDim.x) {
         const int L = lengths[il], m = L / 2;
+        const long is = slots ? slots[il] : il;   // row of the tables this length lives in
         // forward transform of the packed N/2-point block onto m output bins, modulus m, sign -1
         czt_build_table(x, FFT_LOG2_MAX, nh, m, m, -1., tw);
-        for (int i = threadIdx.x; i < M; i += blockDim.x) tab.B_fwd[(long)il * M + i] = x[i];
+        for (int i = threadIdx.x; i < M; i += blockDim.x) tab.B_fwd[is * M + i] = x[i];
         __syncthreads();
         // inverse transform of m + 1 bins onto blocks of P = M - (m + 1) + 1 samples, modulus L, sign +1
         int P = M - m;
         czt_build_table(x, FFT_LOG2_MAX, m + 1, P, L, +1., tw);
-        for (int i = threadIdx.x; i < M; i += blockDim.x) tab.B_inv[(long)il * M + i] = x[i];
+        for (int i = threadIdx.x; i < M; i += blockDim.x) tab.B_inv[is * M + i] = x[i];
         __syncthreads();
         // every phase factor of this length: E[j] = exp(-2 pi i j / (2 L)); filter chain on the L grid
         for (int j = threadIdx.x; j < 2 * L; j += blockDim.x) {
             double sn, cs;
             sincospi((double)j / (double)L, &sn, &cs);
-            tab.E[(long)il * NRHIP_E_STRIDE + j] = make_double2(cs, -sn);
+            tab.E[is * NRHIP_E_STRIDE + j] = make_double2(cs, -sn);
         }
         const double df = 1.0 / (L * (1. / st.fs));
         for (int fs = 0; fs < st.n_fsets; fs++) {
             const FilterSet& fl = fls[fs];
-            double2* Hs = tab.H + ((long)il * st.n_fsets + fs) * NRHIP_SPEC_STRIDE;
+            double2* Hs = tab.H + (is * st.n_fsets + fs) * NRHIP_SPEC_STRIDE;
             for (int k = threadIdx.x; k <= m; k += blockDim.x) Hs[k] = apply_filters(make_double2(1., 0.), k * df, fl);
             for (int i = 0; i < fl.n; i++) {
                 if (fl.kind[i] != 4) continue;
@@ -1528,8 +1530,8 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
         }
         __syncthreads();   // the H tables are read back below (same block)
         for (int k = threadIdx.x; k < NRHIP_SPEC_STRIDE; k += blockDim.x)
-            tab.Cf[(long)il * NRHIP_SPEC_STRIDE + k] = chirp(k, m, -1.);
-        for (int n = threadIdx.x; n < FFT_MAX; n += blockDim.x) tab.Ci[(long)il * FFT_MAX + n] = chirp(n, L, +1.);
+            tab.Cf[is * NRHIP_SPEC_STRIDE + k] = chirp(k, m, -1.);
+        for (int n = threadIdx.x; n < FFT_MAX; n += blockDim.x) tab.Ci[is * FFT_MAX + n] = chirp(n, L, +1.);
         // analytic antenna magnitude * phase on the L grid (antennapattern.py:1672-1768), models 0 VPol, 1 HPol;
         // the "remove DC offset" cut below 5 MHz (efieldToVoltageConverter.py:313) is folded in
         for (int model = 0; model < NRHIP_N_ANT_TAB; model++) {
@@ -1586,17 +1588,17 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
                 sincos(ph, &sn, &cs);
                 if (f < 0.005) v = 0.;
                 double2 vv = make_double2(v * cs, v * sn);
-                tab.vel[((long)il * NRHIP_N_ANT_TAB + model) * NRHIP_SPEC_STRIDE + k] = vv;
+                tab.vel[(is * NRHIP_N_ANT_TAB + model) * NRHIP_SPEC_STRIDE + k] = vv;
                 // |antenna x filter|^2 for the impulse-response norm (irfft keeps only the real part of DC / Nyquist)
                 for (int fs = 0; fs < st.n_fsets; fs++) {
-                    double2 hk = cmul(vv, tab.H[((long)il * st.n_fsets + fs) * NRHIP_SPEC_STRIDE + k]);
+                    double2 hk = cmul(vv, tab.H[(is * st.n_fsets + fs) * NRHIP_SPEC_STRIDE + k]);
                     h2s[fs] += (k == 0 || k == m) ? hk.x * hk.x : 2. * (hk.x * hk.x + hk.y * hk.y);
                 }
             }
             __syncthreads();
             for (int fs = 0; fs < st.n_fsets; fs++) {
                 const double h2 = block_sum(h2s[fs], red);
-                if (threadIdx.x == 0) tab.hnorm[((long)il * st.n_fsets + fs) * NRHIP_N_ANT_TAB + model] = sqrt(h2 / L);
+                if (threadIdx.x == 0) tab.hnorm[(is * st.n_fsets + fs) * NRHIP_N_ANT_TAB + model] = sqrt(h2 / L);
             }
         }
         // Lengths up to FFT_MAX: the channel voltage is the circular convolution (period L) of the summed, placed field
@@ -1604,18 +1606,18 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, StationDev st, 
         // 2 FFT_MAX-point grid (real transform via the packed FFT_MAX-point complex one) is what channel_conv_kernel
         // multiplies with.  Factors folded in: 1/2 of each even/odd split (two of them), 1/FFT_MAX of the inverse.
         if (tab.G && L <= FFT_MAX) {
-            const double2* E = tab.E + (long)il * NRHIP_E_STRIDE;
-            const double2* Ci = tab.Ci + (long)il * FFT_MAX;
-            const double2* Bi = tab.B_inv + (long)il * M;
+            const double2* E = tab.E + is * NRHIP_E_STRIDE;
+            const double2* Ci = tab.Ci + is * FFT_MAX;
+            const double2* Bi = tab.B_inv + is * M;
             const unsigned LL = (unsigned)L;
             const int P = M - m;
             const double scale = st.fs / 1.4142135623730951 / L;
             for (int fm = 0; fm < st.n_fsets * NRHIP_N_ANT_TAB; fm++) {
                 const int fs = fm / NRHIP_N_ANT_TAB, model = fm % NRHIP_N_ANT_TAB;
                 if (!((st.fset_tab_mask[fs] >> model) & 1)) continue;
-                const double2* Hf = tab.H + ((long)il * st.n_fsets + fs) * NRHIP_SPEC_STRIDE;
-                const double2* vel = tab.vel + ((long)il * NRHIP_N_ANT_TAB + model) * NRHIP_SPEC_STRIDE;
-                double2* G = tab.G + (((long)il * st.n_fsets + fs) * NRHIP_N_ANT_TAB + model) * NRHIP_G_STRIDE;
+                const double2* Hf = tab.H + (is * st.n_fsets + fs) * NRHIP_SPEC_STRIDE;
+                const double2* vel = tab.vel + (is * NRHIP_N_ANT_TAB + model) * NRHIP_SPEC_STRIDE;
+                double2* G = tab.G + ((is * st.n_fsets + fs) * NRHIP_N_ANT_TAB + model) * NRHIP_G_STRIDE;
                 double* gtmp = (double*)G;  // L doubles of the impulse response, overwritten by its spectrum below
                 __syncthreads();
                 for (int n0 = 0; n0 < L; n0 += P) {
@@ -2802,12 +2804,25 @@ static void set_big_lds()
     g_attr_set = true;
 }
 void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const StationDev& st, const FilterSet* fls,
-                          const double2* tw, const double2* w16, const LengthTables& tab)
+                          const double2* tw, const double2* w16, const LengthTables& tab, const int* slots)
 {
     if (n_len <= 0) return;
     set_big_lds();
     int grid = n_len < 256 ? n_len : 256;
-    hipLaunchKernelGGL(length_tables_kernel, dim3(grid), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lengths, st, fls, tw, w16, tab);
+    hipLaunchKernelGGL(length_tables_kernel, dim3(grid), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lengths, slots, st, fls, tw, w16,
+                       tab);
+}
+
+// per-event index into this call's sorted length list -> row of the station's table cache
+__global__ void length_slot_kernel(int n_events, const int* __restrict__ ev_L, const int* __restrict__ slotmap, int* __restrict__ len_index)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_events && len_index[e] >= 0) len_index[e] = slotmap[ev_L[e] / 2];
+}
+void launch_length_slots(hipStream_t s, int n_events, const int* ev_L, const int* slotmap, int* len_index)
+{
+    if (n_events <= 0) return;
+    hipLaunchKernelGGL(length_slot_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, ev_L, slotmap, len_index);
 }
 int channel_grid_blocks() { return 256; }
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
