@@ -343,6 +343,17 @@ typedef struct {
        "ev_sub_event": group and index of each; stats->n_sub_events).  0: one readout per group.  Not with ARZ / birefringence
        or the phased-array trigger. */
     double split_event_time_diff;
+    /* != 0: thermal noise on every channel of the candidate events before the filter chain and the trigger
+       (channelGenericNoiseAdder.bandlimited_noise, type 'rayleigh', as simulation.apply_det_response adds it: simulation.py:594-606);
+       per-channel amplitudes from nrhip_station_set_noise.  The draws come from a counter-based Philox4x32-10 generator keyed by
+       noise_seed and counted by (event group id, sub-event, channel, frequency bin): an event's noise does not depend on batching or
+       on the number of GPUs; against the reference (one sequential numpy stream in loop order) the agreement is statistical.
+       Group ids: noise_group_id (DEV int64 [n_groups]) or, if NULL, noise_group_offset + index.  With noise every channel of every
+       candidate event is evaluated (chirp-z kernel), the result-neutral pruning of the channel stage does not apply. */
+    int32_t noise;
+    uint64_t noise_seed;
+    int64_t noise_group_offset;
+    const int64_t* noise_group_id;
 } nrhip_sim_config;
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1
@@ -412,6 +423,9 @@ int nrhip_station_set_trigger_channels(nrhip_station* st, int32_t n, const int32
  * stage polyval(b, j f) / polyval(a, j f), highest power first, f in GHz (what nrhip_station_desc.filter_b / filter_a hold).
  * nb <= 0 switches it off. */
 int nrhip_station_set_envelope_trigger(nrhip_station* st, int32_t nb, int32_t na, const double* b, const double* a);
+/* `amplitude` of the noise adder per channel [n_channels] (simulation.py:596-600: Vrms / sqrt(norm / max_freq), norm = int |H|^2 df,
+ * max_freq = sampling rate / 2; 0 = noiseless channel).  n <= 0 removes them. */
+int nrhip_station_set_noise(nrhip_station* st, int32_t n, const double* amplitude);
 int nrhip_station_set_phased_array(nrhip_station* st, int32_t n_pa, const int32_t* channels, int32_t n_beams,
                                    const int32_t* rolls, int32_t window, int32_t step, int32_t averaging_divisor);
 

@@ -84,6 +84,8 @@ struct nrhip_station {
     } tabcache;
     nrhip::FilterSet env_filter;   // band pass of the envelope trigger (nrhip_station_set_envelope_trigger)
     bool env_set = false;
+    DevArray d_noise_amp;          // per-channel amplitude of the noise adder (nrhip_station_set_noise)
+    bool noise_set = false;
     int pa_n_channels = 0, pa_n_beams = 0, pa_window = 0, pa_step = 0, pa_divisor = 0;
     // workspace of the last simulated chunk (kept for nrhip_sim_fetch and reused between calls)
     std::map<std::string, DevArray> ws;

@@ -339,6 +339,7 @@ void nrhip_station_detach(nrhip_station* s)
     s->d_pa_channel.release(); s->d_pa_rolls.release(); s->d_pa_mask.release(); s->d_trig_on.release();
     s->d_filter_pool.release(); s->d_ch_fset.release(); s->d_filtersets.release();
     s->tabcache.release();
+    s->d_noise_amp.release();
     s->ws.clear();
     s->ws_bytes.clear();
     s->ctx->stations.erase(s);
@@ -412,6 +413,22 @@ int nrhip_station_set_envelope_trigger(nrhip_station* s, int32_t nb, int32_t na,
     for (int i = 0; i < na; i++) f.a[0][i] = a[i];
     s->env_filter = f;
     s->env_set = true;
+    return 0;
+}
+
+int nrhip_station_set_noise(nrhip_station* s, int32_t n, const double* amplitude)
+{
+    if (!s || !s->ctx) return nrhip_fail_msg("nrhip_station_set_noise: NULL argument or station without a context");
+    if (n <= 0 || !amplitude) {
+        s->noise_set = false;
+        return 0;
+    }
+    if (n != s->dev.n_ch) return nrhip_fail_msg("nrhip_station_set_noise: one amplitude per channel is needed");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    if (upload(s->ctx, s->d_noise_amp, amplitude, (size_t)n)) return -1;
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    s->noise_set = true;
     return 0;
 }
 
@@ -674,6 +691,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         return nrhip_fail_msg("nrhip_simulate_events: bottom reflections are not available together with birefringence or focusing");
     const bool phased = cfg->trigger_type == NRHIP_TRIG_PHASED_ARRAY;
     const bool envelope = cfg->trigger_type == NRHIP_TRIG_ENVELOPE;
+    const bool noise = cfg->noise != 0;
+    if (noise && !st->noise_set) return nrhip_fail_msg("nrhip_simulate_events: noise needs the per-channel amplitudes (nrhip_station_set_noise)");
+    if (noise && (cfg->amp_per_ray || phased))
+        return nrhip_fail_msg("nrhip_simulate_events: noise is not available together with amp_per_ray or the phased-array trigger");
     if (envelope && !st->env_set)
         return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger needs its band pass (nrhip_station_set_envelope_trigger)");
     if (envelope && (sd.ant_tabs || cfg->amp_per_ray))
@@ -855,6 +876,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     long n_ev = n_groups;            // readouts: one per group, or one per sub-event
     const int* ev_ray = grp_ray;     // their ray ranges
     int* ev_group = nullptr;         // sub-event -> group (NULL: identity)
+    int* ev_sub_dev = nullptr;       // sub-event index inside its group
     int* ev_base = nullptr;          // group -> first sub-event
     if (cfg->split_event_time_diff > 0 && n_rays > 0) {
         if (general || phased)
@@ -889,6 +911,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             NEED(sub_ray = WS("sub_event_ray_begin", int, n_ev + 1));
             NEED(ev_group = WS("ev_group", int, n_ev));
             NEED(ev_sub = WS("ev_sub_event", int, n_ev));
+            ev_sub_dev = ev_sub;
             hipLaunchKernelGGL(sub_event_ranges_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, sm, (int)n_groups,
                                grp_ray, sub_sorted, ev_base, sub_ray, ev_group, ev_sub);
             ev_ray = sub_ray;
@@ -1212,7 +1235,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         // than FFT_MAX samples, tabulated antenna patterns, the general path) the channel stage only produces the traces and
         // trace_trigger_kernel decides on them
         const bool post_trigger = trg.coincidence() && !phased &&
-                                  (maxL > FFT_MAX || sd.N > FFT_MAX / 2 || getenv("NRHIP_CHANNEL_CZT") || sd.ant_tabs || general || envelope);
+                                  (maxL > FFT_MAX || sd.N > FFT_MAX / 2 || getenv("NRHIP_CHANNEL_CZT") || sd.ant_tabs || general || envelope || noise);
         TriggerDev trg_ch = trg;
         if (post_trigger) {
             trg_ch.type = 0;
@@ -1220,6 +1243,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             trg_ch.threshold = INFINITY;
         }
         double* env_trace = nullptr;
+        NoiseDev nz{noise ? 1 : 0, cfg->noise_seed, st->d_noise_amp.as<double>(), (const long long*)cfg->noise_group_id,
+                    (long long)cfg->noise_group_offset, ev_group, ev_sub_dev};
         ChannelOut co;
         NEED(co.maxV = WS("item_maxV", double, n_items));
         co.trigger_bin = trigger_bin;
@@ -1264,9 +1289,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         if (phased) sd_ch.trig_on = st->d_pa_mask.as<unsigned char>();  // only the array's channels need traces (unless all are dumped)
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd_ch, st->filters[0], arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
                        trg_ch, ctx->twiddle, ctx->w16, tab, scratch, co,
-                       (cfg->no_pruning || cfg->dump_traces || general || phased || post_trigger) ? 1 : 0, maxL,
+                       (cfg->no_pruning || cfg->dump_traces || general || phased || post_trigger || noise) ? 1 : 0, maxL,
                        it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces,
-                       (phased || post_trigger) ? (cfg->dump_traces ? 0 : 1) : -1, envelope ? &st->env_filter : nullptr, env_trace);
+                       (phased || post_trigger) ? (cfg->dump_traces ? 0 : 1) : -1, envelope ? &st->env_filter : nullptr, env_trace,
+                       noise ? &nz : nullptr);
         LCHK("channel");
         if (post_trigger) {
             launch_trace_trigger(sm, n_cand, d_cand, n_ch, ev.L, envelope ? env_trace : co.trace, co.trace_offset, trg, sd.trig_on, maxL,

@@ -13,6 +13,8 @@
 #define NRHIP_N_ANT_TAB 5       // antenna response tables per length: VPol, HPol, LPDA front / side / back lobe phase
 #define NRHIP_G_STRIDE 8200     // FFT_MAX + 1 bins of the 2 FFT_MAX-point real transform of the impulse response (padded)
 
+#include "noise.h"
+
 namespace nrhip {
 
 // tabulated antenna pattern in HBM (nrhip_antenna_table)
@@ -196,7 +198,8 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
-                    const double* ray_traces = nullptr, int skip_off = -1, const FilterSet* envf = nullptr, double* env_trace = nullptr);
+                    const double* ray_traces = nullptr, int skip_off = -1, const FilterSet* envf = nullptr, double* env_trace = nullptr,
+                    const NoiseDev* noise = nullptr);
 void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                           const long* trace_offset, const TriggerDev& trg, const unsigned char* trig_on, int max_length,
                           unsigned char* triggered, int* trigger_bin);

@@ -2066,7 +2066,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                const int* __restrict__ ev_len_index, StationDev st, FilterSet fl, int ask_model, double threshold,
                const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
                ChannelOut out, int exact, int skip_upto, double2* __restrict__ tab_nodes,
-               const double* __restrict__ ray_traces, FilterSet envf, double* __restrict__ env_trace)
+               const double* __restrict__ ray_traces, FilterSet envf, double* __restrict__ env_trace, NoiseDev nz)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M = FFT_MAX, N = st.N, nh = N / 2;
@@ -2205,12 +2205,23 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                 __syncthreads();
             }
         }
+        // thermal noise (channelGenericNoiseAdder, added before the filter chain: simulation.py:594-606) on every channel that is not
+        // noiseless, with or without a ray
+        const bool noisy = nz.on && nz.amplitude[ch] > 0.;
+        if (noisy) {
+            const int grp = nz.ev_group ? nz.ev_group[e] : e;
+            const long long gid = nz.group_id ? nz.group_id[grp] : nz.group_offset + grp;
+            const int sub = nz.ev_sub ? nz.ev_sub[e] : 0;
+            __syncthreads();
+            for (int k = threadIdx.x; k <= m; k += blockDim.x) acc[k] = cadd(acc[k], noise_bin(nz, gid, sub, ch, k, L, st.fs));
+            __syncthreads();
+        }
         // filters, then back to the time domain in blocks of P samples -- unless the sum-of-magnitudes bound
         // max |V(t)| <= (fs / sqrt 2) (1 / L) (|V_0| + |V_m| + 2 sum |V_k|) already shows that no sample can reach the
         // threshold (the trace then is not needed: its maximum is reported as the negated bound)
         double vmax = 0.;
         int trig = 0;
-        bool need_trace = (n_used > 0);
+        bool need_trace = (n_used > 0) || noisy;
         if (n_used > 0 && !exact) {
             double part = 0.;
             for (int k = threadIdx.x; k <= m; k += blockDim.x) {
@@ -2259,7 +2270,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                 __syncthreads();
             }
         }
-        if (env_trace && n_used > 0) {
+        if (env_trace && (n_used > 0 || noisy)) {
             // envelope trigger (envelopeTrigger.py:14-31 on channel.get_filtered_trace(passband, 'butter', order)): the channel
             // spectrum through the trigger's band pass, then the analytic signal -- the one-sided sum the inverse chirp-z forms anyway
             // (DC and Nyquist once and real, the bins between twice: scipy.signal.hilbert's weights); its modulus is the envelope
@@ -2830,7 +2841,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
-                    const double* ray_traces, int skip_off, const FilterSet* envf, double* env_trace)
+                    const double* ray_traces, int skip_off, const FilterSet* envf, double* env_trace, const NoiseDev* noise)
 {
     if (skip_off < 0) skip_off = !exact;  // channels outside the trigger set are evaluated only when everything is
     if (n_items <= 0) return;
@@ -2840,7 +2851,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     // traces up to FFT_MAX samples: prefilter, then one real convolution per listed item; longer ones (or
     // NRHIP_CHANNEL_CZT=1): chirp-z per ray (plain OR of simple thresholds only; the caller checks)
     int skip_upto = 0;
-    if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces && !env_trace) {
+    if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces && !env_trace && !(noise && noise->on)) {
         hipLaunchKernelGGL(channel_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev,
                            ev_len_index, st, trig.prefilter(), tab.hnorm, exact, out.maxV, need, skip_off);
         const int n_cand = n_items / st.n_ch;
@@ -2862,7 +2873,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
     hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
                        ask_model, trig.threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto, tab_nodes, ray_traces,
-                       envf ? *envf : fl, env_trace);
+                       envf ? *envf : fl, env_trace, noise ? *noise : NoiseDev{0, 0ull, nullptr, nullptr, 0, nullptr, nullptr});
 }
 // ---------------------------------------------------------------------------------------------------------
 // General emission / propagation path (time-domain emission models such as ARZ, birefringence): the on-sky spectra of every

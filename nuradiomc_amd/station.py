@@ -79,7 +79,9 @@ class SimConfig(ctypes.Structure):
                 ('focusing', ctypes.c_int32), ('focusing_limit', ctypes.c_double), ('select_only', ctypes.c_int32),
                 ('reuse_ray_tables', ctypes.c_int32), ('accumulate_triggered', ctypes.c_int32), ('n_reflections', ctypes.c_int32),
                 ('z_reflection', ctypes.c_double), ('reflection_coefficient', ctypes.c_double),
-                ('reflection_phase_shift', ctypes.c_double), ('split_event_time_diff', ctypes.c_double)]
+                ('reflection_phase_shift', ctypes.c_double), ('split_event_time_diff', ctypes.c_double),
+                ('noise', ctypes.c_int32), ('noise_seed', ctypes.c_uint64), ('noise_group_offset', ctypes.c_int64),
+                ('noise_group_id', ctypes.c_void_p)]
 
 
 class SimStats(ctypes.Structure):
@@ -105,6 +107,7 @@ L._OPTIONAL.update({
     'nrhip_station_set_positions': (ctypes.c_int, [ctypes.c_void_p, L.c_double_p]),
     'nrhip_station_set_trigger_channels': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_int32_p]),
     'nrhip_station_set_envelope_trigger': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p, L.c_double_p]),
+    'nrhip_station_set_noise': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_double_p]),
     'nrhip_station_set_phased_array': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_int32_p, ctypes.c_int32, L.c_int32_p,
                                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'nrhip_station_set_arz': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p, L.c_double_p,
@@ -393,6 +396,29 @@ class Station:
         b, a = np.ascontiguousarray(b, float), np.ascontiguousarray(a, float)
         L.check(self._lib.nrhip_station_set_envelope_trigger(self._h, len(b), len(a), L.dptr(b), L.dptr(a)))
 
+    def set_noise(self, noise_temperature=300., noiseless_channels=(), amplitude=None):
+        """Thermal noise for simulate_events(..., noise=True, noise_seed=): per channel the `amplitude` simulation.apply_det_response
+        hands to channelGenericNoiseAdder (simulation.py:594-606): Vrms / sqrt(norm / max_freq) with the channel's filter chain,
+        norm = int |H|^2 df, max_freq = sampling rate / 2 -- or given directly (`amplitude` [n_channels]).  noise_temperature=None
+        removes it.  Returns the amplitudes."""
+        if noise_temperature is None and amplitude is None:
+            L.check(self._lib.nrhip_station_set_noise(self._h, 0, None))
+            return None
+        if amplitude is None:
+            amp = np.zeros(len(self.position))
+            for c in range(len(self.position)):
+                chain = self.filter_sets[self.channel_filter_set[c]]
+                ff = np.linspace(0, 0.5 * self.sampling_rate, 10000)
+                H = np.abs(flt.response(ff, chain))
+                norm = np.sum(0.5 * (H[1:] ** 2 + H[:-1] ** 2) * np.diff(ff))
+                amp[c] = flt.vrms_from_filters(self.sampling_rate, chain, noise_temperature)[0] / np.sqrt(norm / (0.5 * self.sampling_rate))
+        else:
+            amp = np.array(np.broadcast_to(L.f64(amplitude), (len(self.position),)), float)
+        amp[list(noiseless_channels)] = 0.
+        amp = np.ascontiguousarray(amp)
+        L.check(self._lib.nrhip_station_set_noise(self._h, len(amp), L.dptr(amp)))
+        return amp
+
     def set_phased_array(self, channels, phasing_angles, ref_index=1.75, window=32, step=16, averaging_divisor=None):
         """Phased-array trigger on the given channels (a vertical string): beams towards `phasing_angles` [rad], whole-sample
         channel shifts as PhasedArrayBase.calculate_time_delays (phasedArrayBase.py:58-124: antenna depths, ref_index, cable
@@ -453,7 +479,8 @@ class Station:
                             threshold_high=None, threshold_low=None, high_low_window=5., coinc_window=200., amp_per_ray=False,
                             d_max_distance=None, focusing=False, focusing_limit=2., select_only=False, reuse_ray_tables=False,
                             accumulate_triggered=False, n_reflections=0, z_reflection=0., reflection_coefficient=1.,
-                            reflection_phase_shift=0., split_event_time_diff=0.):
+                            reflection_phase_shift=0., split_event_time_diff=0., noise=False, noise_seed=0, noise_group_offset=0,
+                            d_noise_group_id=None):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
         d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
@@ -467,7 +494,9 @@ class Station:
         z_reflection (< 0) with the layer's reflection_coefficient and reflection_phase_shift [rad] (medium.reflection...).
         split_event_time_diff > 0 [ns]: simulation.group_into_events -- a group's signals at this station are cut into sub-events
         where consecutive start times are farther apart; the ev_* / item_* tables are then per sub-event (fetch('ev_group'),
-        fetch('ev_sub_event')), the mask stays per group."""
+        fetch('ev_sub_event')), the mask stays per group.
+        noise (set_noise first): thermal noise on every channel of the candidate events before filters and trigger; counter-based
+        draws keyed by noise_seed and the group ids (d_noise_group_id: device int64 [n_groups], or noise_group_offset + index)."""
         if trigger not in ('simple', 'high_low', 'phased_array', 'envelope'):
             raise NotImplementedError("trigger {} is not provided (simple, high_low, phased_array, envelope)".format(trigger))
         cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
@@ -479,7 +508,8 @@ class Station:
                         float(coinc_window), int(bool(amp_per_ray)), int(bool(focusing)), float(focusing_limit),
                         int(bool(select_only)), int(bool(reuse_ray_tables)), int(bool(accumulate_triggered)), int(n_reflections),
                         float(z_reflection), float(reflection_coefficient), float(reflection_phase_shift),
-                        float(split_event_time_diff or 0.))
+                        float(split_event_time_diff or 0.), int(bool(noise)), int(noise_seed) & 0xffffffffffffffff,
+                        int(noise_group_offset), d_noise_group_id)
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_event_groups(
             self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,
@@ -553,6 +583,11 @@ class Station:
         dtrig = ctx.malloc(max(n_groups, 1))
         extra = [ctx.to_device(a) if a is not None else None for a in (vt, gb, md)]
         dev_kw = dict(d_vertex_time=extra[0], n_groups=n_groups, d_group_begin=extra[1], d_max_distance=extra[2])
+        if kw.get('noise'):   # the noise of an event group is keyed by its id: the caller's group ids, else the running index
+            off = int(kw.pop('noise_group_offset', 0))
+            ids = gid[first] if group_id is not None and n else np.arange(n_groups) + off
+            extra.append(ctx.to_device(np.ascontiguousarray(ids, dtype=np.int64)))
+            dev_kw['d_noise_group_id'] = extra[-1]
         try:
             if two_phase:
                 from . import sequencing
@@ -600,10 +635,11 @@ class Station:
         trig, total = [], None
         for a, b in zip(cuts[:-1], cuts[1:]):
             sl = slice(a, b)
+            kw_c = dict(kw, noise_group_offset=int(kw.get('noise_group_offset', 0)) + a) if (kw.get('noise') and gid is None) else kw
             t, s_ = self.simulate_events(vertex[sl], zenith[sl], azimuth[sl], energy[sl], types[sl],
                                          None if k_L is None else k_L[sl], None if vertex_time is None else vertex_time[sl],
                                          None if gid is None else gid[sl], dcc, dcs, None if arz_iN is None else arz_iN[sl],
-                                         max_showers_per_call=max(b - a, 1), **kw)
+                                         max_showers_per_call=max(b - a, 1), **kw_c)
             trig.append(t)
             if total is None:
                 total = s_

@@ -552,8 +552,10 @@ def per_efield_voltage(ef, st, filters=DEFAULT_FILTERS):
     return v, h.max()
 
 
-def combined_voltage(efields, st, filters=DEFAULT_FILTERS, pre_pulse_time=200., post_pulse_time=400.):
-    """efieldToVoltageConverter.run (:111-345) for all channels + filter chain -> (V[n_ch, L], t_min, L)"""
+def combined_voltage(efields, st, filters=DEFAULT_FILTERS, pre_pulse_time=200., post_pulse_time=400., noise=None):
+    """efieldToVoltageConverter.run (:111-345) for all channels + filter chain -> (V[n_ch, L], t_min, L).
+    noise = (seed, group id, sub-event, amplitude per channel): thermal noise added to every channel spectrum before the filters
+    (simulation.apply_det_response :594-606 -> channelGenericNoiseAdder.run), drawn by noise_spectrum"""
     fs = st.fs
     N = st.n_samples
     tmin, tmax = [], []
@@ -607,6 +609,9 @@ def combined_voltage(efields, st, filters=DEFAULT_FILTERS, pre_pulse_time=200., 
             v = Vt * efield_fft[1] + Vp * efield_fft[2]
             v[ffL < 5 * units.MHz] = 0.
             spec_ch = v if spec_ch is None else spec_ch + v
+        if noise is not None and noise[3][ch] > 0:
+            nz = noise_spectrum(noise[0], noise[1], noise[2], ch, L, fs, noise[3][ch])
+            spec_ch = nz if spec_ch is None else spec_ch + nz
         if spec_ch is not None:
             key = id(chain_of(filters, ch))
             if key not in H_of:
@@ -691,6 +696,50 @@ def envelope_of_filtered(v, fs, passband, order):
     return np.abs(np.fft.ifft(X * h))
 
 
+def philox4x32_10(c, k):
+    """Philox4x32-10 (Salmon et al. 2011) on arrays: c [..., 4] uint32 counters, k [2] uint32 key -> [..., 4] uint32"""
+    c = np.array(c, dtype=np.uint64).copy()
+    k0, k1 = np.uint64(int(k[0]) & 0xffffffff), np.uint64(int(k[1]) & 0xffffffff)
+    mask = np.uint64(0xffffffff)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[..., 0]
+        p1 = np.uint64(0xCD9E8D57) * c[..., 2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = np.stack([hi1 ^ c[..., 1] ^ k0, lo1, hi0 ^ c[..., 3] ^ k1, lo0], axis=-1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return c.astype(np.uint32)
+
+
+def noise_spectrum(seed, group_id, sub_event, channel, L, fs, amplitude):
+    """channelGenericNoiseAdder.bandlimited_noise(min_freq=0, max_freq=Nyquist, type='rayleigh', time_domain=False) (:66-160) for one
+    channel of one (sub-)event, with the draws of the build's counter-based generator (csrc/noise.h) instead of the reference's
+    sequential stream: [L/2 + 1] complex in the time2freq convention"""
+    m = L // 2
+    k = np.arange(m + 1, dtype=np.uint64)
+    gid = np.uint64(int(group_id))
+    c = np.stack([np.full(m + 1, gid & np.uint64(0xffffffff)), np.full(m + 1, gid >> np.uint64(32)),
+                  np.full(m + 1, np.uint64((int(sub_event) << 16) | int(channel))), k], axis=-1)
+    x = philox4x32_10(c, (int(seed) & 0xffffffff, (int(seed) >> 32) & 0xffffffff)).astype(np.float64)
+    u1 = (np.floor(x[:, 0] / 32.) * 67108864. + np.floor(x[:, 1] / 64.)) / 9007199254740992.
+    u2 = (np.floor(x[:, 2] / 32.) * 67108864. + np.floor(x[:, 3] / 64.)) / 9007199254740992.
+    fsigma = amplitude * (L / np.sqrt(m)) / np.sqrt(2.)
+    a = fsigma * np.sqrt(-2. * np.log(1. - u1)) / fs
+    out = a * (np.cos(2 * np.pi * u2) + 1j * np.sin(2 * np.pi * u2))
+    out[0] = 0.
+    out[m] = a[m]
+    return out
+
+
+def noise_amplitude(fs, filters=DEFAULT_FILTERS, noise_temperature=300.):
+    """the `amplitude` simulation.apply_det_response hands to the noise adder (simulation.py:594-606): Vrms / sqrt(norm / max_freq)
+    with norm = int |H|^2 df (the bandwidth the Vrms belongs to) and max_freq = fs / 2"""
+    ff = np.linspace(0, 0.5 * fs, 10000)
+    H = np.abs(filter_response(ff, filters))
+    norm = np.sum(0.5 * (H[1:] ** 2 + H[:-1] ** 2) * np.diff(ff))
+    return vrms_from_filters(fs, filters, noise_temperature)[0] / np.sqrt(norm / (0.5 * fs))
+
+
 def station_trigger(V, fs, trigger='simple', threshold=None, n_coincidences=1, threshold_high=None, threshold_low=None,
                     high_low_window=5., coinc_window=200., passband=None, order=None):
     """simpleThreshold.triggerSimulator.run / highLowThreshold.triggerSimulator.run / envelopeTrigger.triggerSimulator.run on all
@@ -708,7 +757,7 @@ def station_trigger(V, fs, trigger='simple', threshold=None, n_coincidences=1, t
 def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, vrms, vrms_efield, att_model='SP1',
                    n_freq=25, model='Alvarez2009', filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0,
                    min_efield_amplitude=2.0, rays=None, focusing=False, focusing_limit=2., arz=None, birefringence=None,
-                   reflections=None):
+                   reflections=None, noise=None):
     """One single-shower event group through simulation.run()'s sequence (:1454-1600)."""
     efs = sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model, n_freq, model,
                                 delta_C_cut, rays=rays, focusing=focusing, focusing_limit=focusing_limit, arz=arz,
@@ -720,7 +769,7 @@ def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, v
         ef['simch_spec'], ef['max_amp_ray'] = per_efield_voltage(ef, st, filters)
     if not efs or not out['candidate']:
         return out
-    V, t_min, L = combined_voltage(efs, st, filters)
+    V, t_min, L = combined_voltage(efs, st, filters, noise=noise)
     out.update(V=V, t_min=t_min, L=L, triggered=threshold_trigger(V, trigger_sigma * vrms))
     return out
 

@@ -1251,3 +1251,50 @@ def test_envelope_trigger(gpu_ctx_factory):
     st.set_envelope_trigger(None)
     with pytest.raises(Exception, match='envelope'):
         st.simulate_events(*args, trigger='envelope')
+
+
+def test_thermal_noise(gpu_ctx_factory):
+    """noise=True (channelGenericNoiseAdder as simulation.apply_det_response calls it): Rayleigh / uniform-phase noise on every
+    channel spectrum of the candidate events before filters and trigger, from the counter-based generator of csrc/noise.h.  GPU
+    traces = the oracle's with the same generator (1e-9 of the noise RMS), triggers exact; the noise of an event does not depend
+    on how the list is cut into calls; its RMS after the filters is the station's Vrms; noiseless channels stay noiseless."""
+    g = golden('chain_N256.npz')
+    n = 240
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    amp = st.set_noise(300., noiseless_channels=[4])
+    ost = so.Station(g['det_pos'], n_samples=int(g['N']), fs=float(g['fs']))
+    assert abs(amp[0] - so.noise_amplitude(ost.fs)) < 1e-12 * amp[0] and amp[4] == 0.
+    kL = np.where(np.isnan(g['ev_k_L'][:n]), 1.0, g['ev_k_L'][:n])
+    args = (g['vertex'][:n], g['zenith'][:n], g['azimuth'][:n], g['energy'][:n], g['shower_type'][:n], kL)
+    ids = 1000 + 3 * np.arange(n)
+    trig, stats = st.simulate_events(*args, group_id=ids, noise=True, noise_seed=2024, dump_traces=True)
+    item_event, tr, off = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    cand = st.fetch('ev_candidate').astype(bool)
+    n_ch = len(g['det_pos'])
+    rms = []
+    for i, ev in enumerate(item_event):
+        rays, sel = None, None
+        o = so.simulate_event(g['vertex'][ev], g['zenith'][ev], g['azimuth'][ev], g['energy'][ev], str(g['shower_type'][ev]),
+                              float(kL[ev]), ost, g['ice'], st.vrms, st.vrms_efield, noise=(2024, int(ids[ev]), 0, amp))
+        assert o['candidate'] and o['triggered'] == bool(trig[ev]), ev
+        for ch in range(n_ch):
+            v = tr[off[i * n_ch + ch]:off[i * n_ch + ch + 1]]
+            assert np.max(np.abs(v - o['V'][ch])) <= 1e-9 * st.vrms + 1e-6 * np.max(np.abs(o['V'][ch])), (ev, ch)
+        rms.append(np.sqrt(np.mean(tr[off[i * n_ch + 3]:off[i * n_ch + 4]] ** 2)))
+    assert len(item_event) >= 15 and not trig[~cand].any()
+    # a channel that hardly sees the pulses: its RMS is the noise RMS the trigger thresholds are quoted in
+    quiet = np.array(rms)[np.array(rms) < 2 * st.vrms]
+    assert len(quiet) >= 5 and abs(np.median(quiet) / st.vrms - 1) < 0.1
+    # chunked calls: the same noise, hence the same mask and traces
+    trig_c, _ = st.simulate_events(*args, group_id=ids, noise=True, noise_seed=2024, max_showers_per_call=37)
+    assert np.array_equal(trig_c, trig)
+    st.simulate_events(*args, group_id=ids, noise=True, noise_seed=2025, dump_traces=True)      # another seed: other noise
+    tr2 = st.fetch('trace')
+    assert tr2.shape == tr.shape and abs(np.corrcoef(tr[off[3]:off[4]], tr2[off[3]:off[4]])[0, 1]) < 0.2
+    # noise raises the trigger rate of the candidates (3 sigma on 5 channels x ~1500 samples)
+    trig_q, _ = st.simulate_events(*args, group_id=ids)
+    assert trig.sum() > trig_q.sum()
+    st.set_noise(None)
+    with pytest.raises(Exception, match='noise'):
+        st.simulate_events(*args, noise=True)

@@ -295,3 +295,36 @@ def test_envelope_trigger_vs_reference():
             assert t == bool(g['s%d_triggered' % i][ev]), (ev, i)
             trig[i, ev] = t
     assert n_same >= 0.97 * n and trig[0].sum() >= 25 and trig[1].sum() >= 35
+
+
+def test_noise_generator_known_answers_and_reference_statistics():
+    """The counter-based noise generator (csrc/noise.h, restated in spectral_oracle.noise_spectrum): Philox4x32-10 against the
+    published known-answer vectors of Random123, and the distribution of the noise it makes against the reference's
+    channelGenericNoiseAdder.bandlimited_noise(type='rayleigh') (tests/golden/gen/gen_noise.py: 400 traces per length)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, ref in kat:
+        assert tuple(int(v) for v in so.philox4x32_10(np.array([c]), k)[0]) == ref
+    g = golden('ref_noise_stats.npz')
+    fs = 2.0
+    for L in (2000, 5296):
+        spec = np.array([so.noise_spectrum(77, i, 0, 3, L, fs, 1.0) for i in range(400)])
+        tr = np.array([so.freq2time(s_, fs, L) for s_ in spec])
+        rms = np.sqrt(np.mean(tr ** 2, axis=1))
+        # 400 x L samples: the means agree within their sampling error (a few 1e-3)
+        assert abs(rms.mean() - g['L%d_rms' % L].mean()) < 4e-3 and abs(rms.std() - g['L%d_rms' % L].std()) < 0.2 * g['L%d_rms' % L].std()
+        assert abs(np.mean(tr ** 4) / np.mean(tr ** 2) ** 2 - g['L%d_m4' % L] / g['L%d_m2' % L] ** 2) < 0.03        # Gaussian: 3
+        assert np.max(np.abs(np.mean(tr, axis=1))) < 1e-12 and np.max(np.abs(g['L%d_mean' % L])) < 1e-12             # no DC
+        a = np.abs(spec)
+        for q, tol in (('amp_mean', 4e-3), ('amp_m2', 8e-3), ('amp_m4', 3e-2)):   # Rayleigh amplitudes of the inner bins
+            mine = {'amp_mean': np.mean(a[:, 1:-1]), 'amp_m2': np.mean(a[:, 1:-1] ** 2), 'amp_m4': np.mean(a[:, 1:-1] ** 4)}[q]
+            assert abs(mine - g['L%d_%s' % (L, q)]) < tol * g['L%d_%s' % (L, q)], (L, q)
+        assert np.max(a[:, 0]) == 0. and np.max(np.abs(spec[:, -1].imag)) == 0. and g['L%d_nyq_imag_max' % L] < 1e-12
+        assert abs(np.mean(a[:, -1] ** 2) - g['L%d_nyq_m2' % L]) < 0.25 * g['L%d_nyq_m2' % L]                          # 400 draws
+        assert abs(np.mean(np.cos(np.angle(spec[:, 1:-1])))) < 5e-3 and abs(np.mean(tr[:, 1:] * tr[:, :-1])) < 5e-3     # flat phases, white
+    # different group / sub-event / channel / seed: different noise; same arguments: the same
+    s0 = so.noise_spectrum(77, 5, 0, 3, 2000, fs, 1.0)
+    assert np.array_equal(s0, so.noise_spectrum(77, 5, 0, 3, 2000, fs, 1.0))
+    for other in ((78, 5, 0, 3), (77, 6, 0, 3), (77, 5, 1, 3), (77, 5, 0, 2)):
+        assert abs(np.corrcoef(np.real(s0[1:-1]), np.real(so.noise_spectrum(*other, 2000, fs, 1.0)[1:-1]))[0, 1]) < 0.1
