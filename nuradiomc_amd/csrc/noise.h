@@ -3,8 +3,8 @@
 // trace an amplitude drawn from a Rayleigh distribution and a uniform phase, DC empty, the Nyquist bin real; added to the channel
 // spectrum BEFORE the filter chain.  The reference draws from one sequential numpy stream in loop order, which no parallel
 // implementation can reproduce; here every (event group, sub-event, channel, bin) has its own Philox4x32-10 counter, so the
-// noise of an event does not depend on batching, chunking or the number of GPUs.  oracle/spectral_oracle.py restates the same
-// generator (numpy) -- GPU and oracle traces agree to rounding; against the reference the agreement is statistical.
+// noise of an event does not depend on batching, chunking or the number of GPUs.  The parity tests restate the same generator in
+// numpy -- their traces and the kernel's agree to rounding; against the reference the agreement is statistical.
 #pragma once
 #include <hip/hip_runtime.h>
 
