@@ -645,14 +645,40 @@ __device__ inline double fill_amplitude(double* amp, const StationDev& st, RaySh
     }
     __syncthreads();
     double part = 0.;
-    for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
-        double v = 0.;
-        if (k > 0 && k < nh) {
-            double f = k * df;
-            v = amplitude_bin(k, f, rs.ask, st) * interp_seg(f, st.seg[k], n_fc, rs.xp, rs.att, rs.slope);
+    if (rs.ask.model == 0) {
+        // Alvarez2009 from the station's f^p tables; the table entries of the thread's NEXT bin are requested before the current
+        // bin is evaluated (the loop has 2 .. 8 iterations per thread and would otherwise wait for L1 / L2 in each)
+        const int stride = nh + 1, off_l = rs.ask.had ? 0 : stride;
+        int kq = threadIdx.x;
+        bool in = kq > 0 && kq < nh;
+        double n_pl = in ? st.fpow[off_l + kq] : 0., n_pr = in ? st.fpow[2 * stride + kq] : 0.;
+        int n_seg = in ? st.seg[kq] : 0;
+        for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
+            const bool cur = k > 0 && k < nh;
+            const double pl = n_pl, pr = n_pr;
+            const int seg = n_seg;
+            kq = k + blockDim.x;
+            in = kq > 0 && kq < nh;
+            if (in) { n_pl = st.fpow[off_l + kq]; n_pr = st.fpow[2 * stride + kq]; n_seg = st.seg[kq]; }
+            double v = 0.;
+            if (cur) {
+                const double f = k * df;
+                const double x = pl * rs.ask.cL, y = pr * rs.ask.cR;   // amplitude_bin, model 0
+                v = rs.ask.pref2 * f / ((1 + x) * (1 + y)) * interp_seg(f, seg, n_fc, rs.xp, rs.att, rs.slope);
+            }
+            if (amp) amp[k] = v;
+            part += v;
         }
-        if (amp) amp[k] = v;
-        part += v;
+    } else {
+        for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
+            double v = 0.;
+            if (k > 0 && k < nh) {
+                double f = k * df;
+                v = amplitude_bin(k, f, rs.ask, st) * interp_seg(f, st.seg[k], n_fc, rs.xp, rs.att, rs.slope);
+            }
+            if (amp) amp[k] = v;
+            part += v;
+        }
     }
     __syncthreads();
     return part;
@@ -798,8 +824,10 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
         for (int j = threadIdx.x; j < st.n_att_bins * st.n_fc; j += blockDim.x) s_binv[j] = st.att_bin_inv[j];
     __shared__ double ub[4][AB_RT][NRHIP_MAX_NFC];  // per wave and ray: upper bounds of the coarse attenuation factors
     __shared__ double ub_slope[4][AB_RT][NRHIP_MAX_NFC];
+    __shared__ float ub_f[4][AB_RT][NRHIP_MAX_NFC], ub_slope_f[4][AB_RT][NRHIP_MAX_NFC];
     __shared__ double s_xp[NRHIP_MAX_NFC];
-    for (int j = threadIdx.x; j < st.n_fc; j += blockDim.x) s_xp[j] = st.fcoarse[j];
+    __shared__ float s_xp_f[NRHIP_MAX_NFC];
+    for (int j = threadIdx.x; j < st.n_fc; j += blockDim.x) { s_xp[j] = st.fcoarse[j]; s_xp_f[j] = (float)st.fcoarse[j]; }
     __syncthreads();  // s_binv / s_xp are filled by all four waves and read by each of them in the first pass
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nh = st.N / 2, stride = nh + 1;
@@ -870,6 +898,12 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
             if (lane < st.n_fc - 1)
                 ub_slope[wv][i][lane] = (ub[wv][i][lane + 1] - ub[wv][i][lane]) / (s_xp[lane + 1] - s_xp[lane]);
         __syncthreads();
+        for (int i = 0; i < AB_RT; i++)   // single-precision copies for the FP32 sums (rounding covered by BOUND_F32_SLACK)
+            if (lane < st.n_fc) {
+                ub_f[wv][i][lane] = (float)ub[wv][i][lane];
+                ub_slope_f[wv][i][lane] = (lane < st.n_fc - 1) ? (float)ub_slope[wv][i][lane] : 0.f;
+            }
+        __syncthreads();
         if (rb < n_rays) {
             // per-ray scalars only (the full AskaryanConst records would cost ~40 VGPRs per ray)
             double cL[AB_RT], cR[AB_RT], pf[AB_RT];
@@ -894,19 +928,31 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
                 float cLf[AB_RT], cRf[AB_RT], pff[AB_RT], pf32[AB_RT];
                 for (int i = 0; i < AB_RT; i++) { cLf[i] = (float)cL[i]; cRf[i] = (float)cR[i]; pff[i] = (float)pf[i]; pf32[i] = 0.f; }
                 const float xf_first = (float)x_first, xf_last = (float)x_last, dxf_last = (float)dx_last, dff = (float)df;
+                // the station tables of the NEXT bin are requested before the current one is evaluated (L1 / L2 latency off the path)
+                int kq = 1 + lane;
+                int n_lo = (kq < nh) ? st.seg[kq] : 0;
+                float n_ph = (kq < nh) ? st.fpow_f[kq] : 0.f, n_pe = (kq < nh) ? st.fpow_f[stride + kq] : 0.f,
+                      n_pr = (kq < nh) ? st.fpow_f[2 * stride + kq] : 0.f;
                 for (int k = 1 + lane; k < nh; k += 64) {
                     const float f = k * dff;
-                    int lo = st.seg[k];
-                    float dx = f - (float)s_xp[lo];
+                    int lo = n_lo;
+                    const float ph = n_ph, pe = n_pe, pr = n_pr;
+                    kq = k + 64;
+                    if (kq < nh) {
+                        n_lo = st.seg[kq];
+                        n_ph = st.fpow_f[kq];
+                        n_pe = st.fpow_f[stride + kq];
+                        n_pr = st.fpow_f[2 * stride + kq];
+                    }
+                    float dx = f - s_xp_f[lo];
                     if (f <= xf_first) { lo = 0; dx = 0.f; }
                     if (f >= xf_last) { lo = st.n_fc - 2; dx = dxf_last; }
                     dx = fmaxf(dx, 0.f);
-                    const float ph = st.fpow_f[k], pe = st.fpow_f[stride + k], pr = st.fpow_f[2 * stride + k];
 #pragma unroll
                     for (int i = 0; i < AB_RT; i++) {
                         const float x = (had[i] ? ph : pe) * cLf[i], y = pr * cRf[i];
                         const float amp = pff[i] * f * __builtin_amdgcn_rcpf((1.f + x) * (1.f + y));
-                        pf32[i] += amp * fmaxf((float)ub_slope[wv][i][lo] * dx + (float)ub[wv][i][lo], 0.f);
+                        pf32[i] += amp * fmaxf(ub_slope_f[wv][i][lo] * dx + ub_f[wv][i][lo], 0.f);
                     }
                 }
                 for (int i = 0; i < AB_RT; i++) part[i] = (double)pf32[i] * BOUND_F32_SLACK + 1e-30;  // + what FP32 may have flushed to zero
@@ -1057,13 +1103,25 @@ efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w
                 float cLf[AB_RT], cRf[AB_RT], pff[AB_RT], p32[AB_RT], q32[AB_RT];
                 for (int i = 0; i < AB_RT; i++) { cLf[i] = (float)cL[i]; cRf[i] = (float)cR[i]; pff[i] = (float)pf[i]; p32[i] = q32[i] = 0.f; }
                 const float xf_first = (float)x_first, xf_last = (float)x_last, dxf_last = (float)dx_last, dff = (float)df;
+                // as in amp_bound_kernel: the tables of the next bin are requested before the current one is evaluated
+                int kq = 1 + lane;
+                int n_lo = (kq < nh) ? st.seg[kq] : 0;
+                float n_ph = (kq < nh) ? st.fpow_f[kq] : 0.f, n_pe = (kq < nh) ? st.fpow_f[stride + kq] : 0.f,
+                      n_pr = (kq < nh) ? st.fpow_f[2 * stride + kq] : 0.f;
                 for (int k = 1 + lane; k < nh; k += 64) {
                     const float f = k * dff;
-                    int lo = st.seg[k];
+                    int lo = n_lo;
+                    const float ph = n_ph, pe = n_pe, pr = n_pr;
+                    kq = k + 64;
+                    if (kq < nh) {
+                        n_lo = st.seg[kq];
+                        n_ph = st.fpow_f[kq];
+                        n_pe = st.fpow_f[stride + kq];
+                        n_pr = st.fpow_f[2 * stride + kq];
+                    }
                     float dx = f - (float)s_xp[lo];
                     if (f <= xf_first) { lo = 0; dx = 0.f; }
                     if (f >= xf_last) { lo = st.n_fc - 2; dx = dxf_last; }
-                    const float ph = st.fpow_f[k], pe = st.fpow_f[stride + k], pr = st.fpow_f[2 * stride + k];
 #pragma unroll
                     for (int i = 0; i < AB_RT; i++) {
                         const float x = (had[i] ? ph : pe) * cLf[i], y = pr * cRf[i];
