@@ -1944,17 +1944,19 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             CT(6);
             // split the packed transform into the real one, multiply with G, merge back -- in place on the
             // bit-reversed positions of the pairs (k, M - k)
-            // (the response spectrum comes from HBM / L2: the loads of four iterations are issued before the first use)
-#pragma unroll 4
+            // (the response spectrum comes from HBM / L2: the entries of the next iteration are requested before the current one is used)
+            double2 nGk = G[threadIdx.x], nGm = G[M - threadIdx.x], nw = w16[threadIdx.x];
             for (int k = threadIdx.x; k <= M / 2; k += CONV_NT) {
+                const double2 Gk = nGk, Gm = nGm, wk = nw;
+                const int kn = k + CONV_NT;
+                if (kn <= M / 2) { nGk = G[kn]; nGm = G[M - kn]; nw = w16[kn]; }
                 const int p = bitrev(k, FFT_LOG2_MAX), q = (k == 0) ? p : bitrev(M - k, FFT_LOG2_MAX);
                 const double2 A = z[p], Bc = cconj(z[q]);
                 const double2 Ee = cadd(A, Bc), D = csub(A, Bc);
                 const double2 O = make_double2(D.y, -D.x);
-                const double2 wk = w16[k];
                 const double2 wO = cmul(wk, O);
-                const double2 Yk = cmul(cadd(Ee, wO), G[k]);
-                const double2 Ymc = cconj(cmul(cconj(csub(Ee, wO)), G[M - k]));
+                const double2 Yk = cmul(cadd(Ee, wO), Gk);
+                const double2 Ymc = cconj(cmul(cconj(csub(Ee, wO)), Gm));
                 const double2 E2 = cadd(Yk, Ymc);
                 const double2 D2 = cmul(csub(Yk, Ymc), cconj(wk));
                 z[p] = make_double2(E2.x - D2.y, E2.y + D2.x);
