@@ -423,6 +423,18 @@ int nrhip_station_set_trigger_channels(nrhip_station* st, int32_t n, const int32
  * stage polyval(b, j f) / polyval(a, j f), highest power first, f in GHz (what nrhip_station_desc.filter_b / filter_a hold).
  * nb <= 0 switches it off. */
 int nrhip_station_set_envelope_trigger(nrhip_station* st, int32_t nb, int32_t na, const double* b, const double* a);
+/* Digitisation and up-sampling in front of the phased array (phasedArrayTrigger.run(apply_digitization=True, adc_kwargs=...,
+ * upsampling_kwargs=dict(upsampling_method='fft', upsampling_factor=...)); call after nrhip_station_set_phased_array):
+ * analogToDigitalConverter.get_digital_trace (:254-373) with the trigger ADC -- resampling to 5 GHz (5 GHz / sampling rate =
+ * resample_p / resample_q, Fraction(...).limit_denominator(5000) as signal_processing.resample :71-108), linear interpolation at the
+ * ADC sample times, perfect floor comparator with n_bits between v_min and v_max, output in volts (output_counts = 0) or ADC counts --
+ * then signal_processing.digital_upsampling (:111-190, 'fft') by upsampling_factor (1: none); beams with rolls_up [n_beams][n_pa]
+ * (whole-sample shifts at adc_sampling_frequency * upsampling_factor), saturation of count sums at saturation_bits (phase_signals
+ * :183-215), window powers rounded for counts (power_sum :217-271).  adc_sampling_frequency <= 0 switches the digitisation off.
+ * Tables afterwards: "pa_digital_trace" [n_candidates][n_pa][stride], "pa_digital_length" [n_candidates][n_pa], "pa_max_power". */
+int nrhip_station_set_phased_array_adc(nrhip_station* st, double adc_sampling_frequency, int32_t n_bits, double v_min, double v_max,
+                                       int32_t output_counts, int32_t upsampling_factor, int32_t saturation_bits, int32_t resample_p,
+                                       int32_t resample_q, const int32_t* rolls_up);
 /* `amplitude` of the noise adder per channel [n_channels] (simulation.py:596-600: Vrms / sqrt(norm / max_freq), norm = int |H|^2 df,
  * max_freq = sampling rate / 2; 0 = noiseless channel).  n <= 0 removes them. */
 int nrhip_station_set_noise(nrhip_station* st, int32_t n, const double* amplitude);

@@ -84,6 +84,9 @@ struct nrhip_station {
     } tabcache;
     nrhip::FilterSet env_filter;   // band pass of the envelope trigger (nrhip_station_set_envelope_trigger)
     bool env_set = false;
+    nrhip::PaAdc pa_adc;           // trigger ADC + up-sampling of the phased array (nrhip_station_set_phased_array_adc)
+    bool pa_adc_set = false;
+    DevArray d_pa_rolls_up;        // beam rolls at the up-sampled ADC rate
     DevArray d_noise_amp;          // per-channel amplitude of the noise adder (nrhip_station_set_noise)
     bool noise_set = false;
     int pa_n_channels = 0, pa_n_beams = 0, pa_window = 0, pa_step = 0, pa_divisor = 0;

@@ -340,6 +340,7 @@ void nrhip_station_detach(nrhip_station* s)
     s->d_filter_pool.release(); s->d_ch_fset.release(); s->d_filtersets.release();
     s->tabcache.release();
     s->d_noise_amp.release();
+    s->d_pa_rolls_up.release();
     s->ws.clear();
     s->ws_bytes.clear();
     s->ctx->stations.erase(s);
@@ -416,6 +417,25 @@ int nrhip_station_set_envelope_trigger(nrhip_station* s, int32_t nb, int32_t na,
     return 0;
 }
 
+int nrhip_station_set_phased_array_adc(nrhip_station* s, double adc_fs, int32_t n_bits, double v_min, double v_max, int32_t output_counts,
+                                       int32_t upsampling_factor, int32_t saturation_bits, int32_t resample_p, int32_t resample_q,
+                                       const int32_t* rolls_up)
+{
+    if (!s || !s->ctx) return nrhip_fail_msg("nrhip_station_set_phased_array_adc: NULL argument or station without a context");
+    s->pa_adc_set = false;
+    if (!(adc_fs > 0)) return 0;
+    if (s->pa_n_channels <= 0) return nrhip_fail_msg("nrhip_station_set_phased_array_adc: nrhip_station_set_phased_array comes first");
+    if (!rolls_up || n_bits < 1 || n_bits > 24 || !(v_max > v_min) || upsampling_factor < 1 || resample_p < 1 || resample_q < 1)
+        return nrhip_fail_msg("nrhip_station_set_phased_array_adc: bad ADC description");
+    if (adc_fs > 0.49 * s->dev.fs) return nrhip_fail_msg("nrhip_station_set_phased_array_adc: the ADC must sample at less than 0.49 of the simulation's rate");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    if (upload(s->ctx, s->d_pa_rolls_up, rolls_up, (size_t)s->pa_n_beams * s->pa_n_channels)) return -1;
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    s->pa_adc = PaAdc{adc_fs, v_min, v_max, n_bits, output_counts ? 1 : 0, upsampling_factor, saturation_bits, resample_p, resample_q, 0};
+    s->pa_adc_set = true;
+    return 0;
+}
+
 int nrhip_station_set_noise(nrhip_station* s, int32_t n, const double* amplitude)
 {
     if (!s || !s->ctx) return nrhip_fail_msg("nrhip_station_set_noise: NULL argument or station without a context");
@@ -437,6 +457,7 @@ int nrhip_station_set_phased_array(nrhip_station* s, int32_t n_pa, const int32_t
 {
     if (!s || !s->ctx) return nrhip_fail_msg("nrhip_station_set_phased_array: NULL argument or station without a context");
     s->pa_n_channels = 0;
+    s->pa_adc_set = false;
     if (n_pa <= 0) return 0;
     if (!channels || !rolls || n_beams < 1 || window < 1 || step < 1)
         return nrhip_fail_msg("nrhip_station_set_phased_array: channels, rolls, n_beams >= 1, window >= 1 and step >= 1 are required");
@@ -1302,6 +1323,22 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         if (phased) {
             double* pa_max;
             NEED(pa_max = WS("pa_max_power", double, (size_t)n_cand * st->pa_n_beams));
+            if (st->pa_adc_set) {
+                // trigger ADC + up-sampling in front of the beams
+                if (maxL > 9000) return nrhip_fail_msg("nrhip_simulate_events: the digitised phased array takes common traces of at most 9000 samples");
+                PaAdc adc = st->pa_adc;
+                const bool to5 = 5.0 > sd.fs;
+                const double len5max = to5 ? (double)adc.p * maxL / adc.q : (double)maxL, cur = to5 ? 5.0 : sd.fs;
+                adc.stride = adc.upsampling * ((int)(adc.adc_fs / cur * len5max) + 2) + 2;
+                double* pa_trace;
+                int* pa_len;
+                NEED(pa_trace = WS("pa_digital_trace", double, (size_t)n_cand * st->pa_n_channels * adc.stride));
+                NEED(pa_len = WS("pa_digital_length", int, (size_t)n_cand * st->pa_n_channels));
+                launch_phased_array_digital(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, st->pa_n_channels,
+                                            st->d_pa_channel.as<int>(), st->pa_n_beams, st->d_pa_rolls_up.as<int>(), st->pa_window,
+                                            st->pa_step, (double)st->pa_divisor, cfg->trigger_threshold, maxL, sd.fs, adc, pa_trace, pa_len,
+                                            triggered, pa_max);
+            } else
             launch_phased_array(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, st->pa_n_channels,
                                 st->d_pa_channel.as<int>(), st->pa_n_beams, st->d_pa_rolls.as<int>(), st->pa_window, st->pa_step,
                                 (double)st->pa_divisor, cfg->trigger_threshold, maxL, triggered, pa_max);

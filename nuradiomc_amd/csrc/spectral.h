@@ -200,6 +200,15 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
                     const double* ray_traces = nullptr, int skip_off = -1, const FilterSet* envf = nullptr, double* env_trace = nullptr,
                     const NoiseDev* noise = nullptr);
+// trigger ADC + up-sampling of the phased array (pa_digitize_kernel)
+struct PaAdc {
+    double adc_fs, vmin, vmax;   // ADC sampling rate [GHz], voltage range
+    int n_bits, counts, upsampling, saturation_bits, p, q, stride;  // 5 GHz / f_s = p / q; stride: samples per output trace
+};
+void launch_phased_array_digital(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
+                                 const long* trace_offset, int n_pa, const int* pa_channel, int n_beams, const int* rolls_up, int window,
+                                 int step, double divisor, double threshold, int max_length, double fs, const PaAdc& adc,
+                                 double* pa_trace, int* pa_len, unsigned char* triggered, double* pa_max);
 void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                           const long* trace_offset, const TriggerDev& trg, const unsigned char* trig_on, int max_length,
                           unsigned char* triggered, int* trigger_bin);

@@ -3209,6 +3209,211 @@ void launch_phased_array(hipStream_t s, int n_cand, const int* item_event, int n
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The digitised phased-array trigger (phasedArrayTrigger with apply_digitization and up-sampling): per (candidate event, array
+// channel) the channel trace goes through the trigger ADC of analogToDigitalConverter.get_digital_trace (:254-373) and
+// signal_processing.digital_upsampling (:111-190, method 'fft'):
+//   (1) resampling to 5 GHz (signal_processing.resample :71-108: two scipy.signal.resample calls, up by p then down by q with
+//       p / q = 5 GHz / f_s) -- the trigonometric interpolant of the trace (Nyquist bin halved) sampled at num2 = (p L) // q points;
+//   (2) linear interpolation at the ADC's sample times (downsampling_linear_interpolation :432-463, scipy interp1d);
+//   (3) floor((V - V_min) / lsb), clipped to 0 .. 2^bits - 1, + floor(V_min / lsb) (perfect_floor_comparator :14-110), volts or counts;
+//   (4) up-sampling by an integer factor: again a trigonometric interpolant (Nyquist halved), rounded for ADC counts.
+// No arbitrary-length FFT is needed: only the 2 n_adc values of (1) that (2) reads are evaluated, as direct sums over the trace's
+// L / 2 + 1 spectrum bins (themselves a direct sum over the L samples); phases are advanced by complex multiplication and taken
+// afresh from sincospi every 32 steps, so every value is within ~1e-14 of the reference's FFT result.  One block per item;
+// LDS: trace (L doubles) + spectrum (L / 2 + 1 complex) + ADC trace and its spectrum.
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline double2 turn_phase(long num, long den)   // exp(2 pi i num / den)
+{
+    double sn, cs;
+    sincospi(2. * (double)(num % den) / (double)den, &sn, &cs);
+    return make_double2(cs, sn);
+}
+
+__global__ void __launch_bounds__(256)
+pa_digitize_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, const int* __restrict__ ev_L,
+                   const double* __restrict__ trace, const long* __restrict__ trace_offset, int n_pa, const int* __restrict__ pa_channel,
+                   double fs, PaAdc adc, double* __restrict__ pa_trace, int* __restrict__ pa_len)
+{
+    extern __shared__ double pd_lds[];
+    const int n_items = n_cand * n_pa;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int ic = item / n_pa, c = item % n_pa;
+        const int e = item_event[ic], L = ev_L[e], m = L / 2;
+        const double* x = trace + trace_offset[(long)ic * n_ch + pa_channel[c]];
+        double* sx = pd_lds;                              // [L] (+ 2: the region is reused below)
+        double2* X = (double2*)(pd_lds + L + 2 + (L & 1));   // [m + 1]
+        __syncthreads();
+        for (int n = threadIdx.x; n < L; n += blockDim.x) sx[n] = x[n];
+        __syncthreads();
+        // spectrum X_k = sum_n x[n] exp(-2 pi i k n / L)
+        for (int k = threadIdx.x; k <= m; k += blockDim.x) {
+            double2 acc = make_double2(0., 0.), w = make_double2(1., 0.);
+            const double2 step = cconj(turn_phase(k, L));
+            for (int n = 0; n < L; n++) {
+                if ((n & 31) == 0) w = cconj(turn_phase((long)k * n, L));
+                acc.x += sx[n] * w.x;
+                acc.y += sx[n] * w.y;
+                w = cmul(w, step);
+            }
+            X[k] = acc;
+        }
+        __syncthreads();
+        // (1) + (2): the ADC samples
+        const bool resampled = !(fabs(adc.adc_fs - fs) <= 1e-8 + 1e-5 * fabs(fs));   // np.allclose
+        const bool to5 = resampled && 5.0 > fs;
+        long num2 = L;
+        if (to5) {
+            long n1 = (adc.p != 1) ? (long)adc.p * L : L;
+            num2 = (adc.q != 1) ? n1 / adc.q : n1;
+        }
+        const long len5 = to5 ? (num2 - (num2 & 1)) : L;      // an odd number of samples loses the last one
+        const double cur = to5 ? 5.0 : fs;
+        int n_adc = resampled ? (int)((adc.adc_fs / cur) * (double)len5) : L;
+        // the ADC trace d [n_adc] and, later, its spectrum D [n_adc / 2 + 1] reuse LDS that is dead by then: after the 5 GHz
+        // interpolant is defined by X the samples sx are no longer read (d, D there; the host checks 2 n_adc + 4 <= L); without that
+        // resampling X is not used at all (d there, D over sx once d is complete)
+        double* d = to5 ? pd_lds : (double*)X;
+        auto value5 = [&](long i) -> double {              // sample i of the (re)sampled trace
+            if (!to5) return sx[i];
+            double acc = X[0].x;
+            double2 w = make_double2(1., 0.);
+            const double2 step = turn_phase(i, num2);
+            for (int k = 1; k <= m; k++) {
+                if ((k & 31) == 1) w = turn_phase((long)k * i, num2);
+                else w = cmul(w, step);
+                const double t = X[k].x * w.x - X[k].y * w.y;
+                acc += (k == m) ? t : 2. * t;
+            }
+            return acc / L;
+        };
+        const double lsb = (adc.vmax - adc.vmin) / (double)((1 << adc.n_bits) - 1);
+        const double vmin_adc = floor(adc.vmin / lsb);
+        const int n_dig = n_adc - (n_adc & 1);
+        for (int j = threadIdx.x; j < n_dig; j += blockDim.x) {
+            double v;
+            if (resampled) {
+                const double tn = (double)j / adc.adc_fs;
+                long lo = (long)floor(tn * cur);
+                while (lo > 0 && (double)lo / cur >= tn) lo--;          // times[lo] < t <= times[lo + 1] (searchsorted, side 'left')
+                while ((double)(lo + 1) / cur < tn) lo++;
+                if (lo > len5 - 2) lo = len5 - 2;
+                if (lo < 0) lo = 0;
+                const double xlo = (double)lo / cur, xhi = (double)(lo + 1) / cur;
+                const double ylo = value5(lo), yhi = value5(lo + 1);
+                const double slope = (yhi - ylo) / (xhi - xlo);
+                v = slope * (tn - xlo) + ylo;
+            } else {
+                v = sx[j];
+            }
+            double cnt = floor((v - adc.vmin) / lsb);
+            cnt = fmin(fmax(cnt, 0.), (double)((1 << adc.n_bits) - 1)) + vmin_adc;
+            d[j] = adc.counts ? cnt : lsb * cnt;
+        }
+        __syncthreads();
+        // (4) up-sampling
+        double* out = pa_trace + (long)item * adc.stride;
+        int n_up = n_dig;
+        if (adc.upsampling >= 2) {
+            const int md = n_dig / 2;
+            double2* D = to5 ? (double2*)(pd_lds + n_dig + (n_dig & 1)) : (double2*)pd_lds;
+            for (int k = threadIdx.x; k <= md; k += blockDim.x) {
+                double2 acc = make_double2(0., 0.), w = make_double2(1., 0.);
+                const double2 step = cconj(turn_phase(k, n_dig));
+                for (int n = 0; n < n_dig; n++) {
+                    if ((n & 31) == 0) w = cconj(turn_phase((long)k * n, n_dig));
+                    acc.x += d[n] * w.x;
+                    acc.y += d[n] * w.y;
+                    w = cmul(w, step);
+                }
+                D[k] = acc;
+            }
+            __syncthreads();
+            n_up = n_dig * adc.upsampling;
+            for (int n = threadIdx.x; n < n_up; n += blockDim.x) {
+                double acc = D[0].x;
+                double2 w = make_double2(1., 0.);
+                const double2 step = turn_phase(n, n_up);
+                for (int k = 1; k <= md; k++) {
+                    if ((k & 31) == 1) w = turn_phase((long)k * n, n_up);
+                    else w = cmul(w, step);
+                    const double t = D[k].x * w.x - D[k].y * w.y;
+                    acc += (k == md) ? t : 2. * t;
+                }
+                acc /= n_dig;
+                out[n] = adc.counts ? rint(acc) : acc;
+            }
+        } else {
+            for (int n = threadIdx.x; n < n_dig; n += blockDim.x) out[n] = d[n];
+        }
+        if (threadIdx.x == 0) pa_len[item] = n_up - (n_up & 1);
+        __syncthreads();
+    }
+}
+
+// beams and power windows on the digitised, up-sampled traces (phase_signals with the saturation of ADC counts :183-215,
+// power_sum with its rounding :217-271, the decision of phased_trigger :455-496)
+__global__ void __launch_bounds__(256)
+phased_array_digital_kernel(int n_cand, const int* __restrict__ item_event, const double* __restrict__ pa_trace,
+                            const int* __restrict__ pa_len, int n_pa, int n_beams, const int* __restrict__ rolls, int window, int step,
+                            double divisor, double threshold, PaAdc adc, unsigned char* __restrict__ triggered, double* __restrict__ pa_max)
+{
+    extern __shared__ double coh[];
+    __shared__ double red[256];
+    for (int i = blockIdx.x; i < n_cand; i += gridDim.x) {
+        const int e = item_event[i], Lu = pa_len[(long)i * n_pa];
+        const int n_frames = (Lu - window) / step > 0 ? (Lu - window) / step : 0;
+        const double hi = (double)((1 << (adc.saturation_bits - 1)) - 1), lo = -(double)(1 << (adc.saturation_bits - 1));
+        double any = 0.;
+        for (int b = 0; b < n_beams; b++) {
+            __syncthreads();
+            for (int n = threadIdx.x; n < Lu; n += blockDim.x) {
+                double sum = 0.;
+                for (int c = 0; c < n_pa; c++) {
+                    int k = (n - rolls[b * n_pa + c]) % Lu;
+                    if (k < 0) k += Lu;
+                    sum += pa_trace[((long)i * n_pa + c) * adc.stride + k];
+                }
+                if (adc.counts && adc.saturation_bits > 0) sum = fmin(fmax(sum, lo), hi);
+                coh[n] = sum;
+            }
+            __syncthreads();
+            double mx = -INFINITY;
+            for (int f = threadIdx.x; f < n_frames; f += blockDim.x) {
+                double p = 0.;
+                for (int j = 0; j < window; j++) {
+                    const double v = coh[f * step + j];
+                    p += v * v;
+                }
+                p /= divisor;
+                if (adc.counts) p = rint(p);
+                mx = fmax(mx, p);
+            }
+            mx = block_max(mx, red);
+            if (threadIdx.x == 0) pa_max[(long)i * n_beams + b] = mx;
+            if (mx > (adc.counts ? trunc(threshold) : threshold)) any = 1.;
+        }
+        if (threadIdx.x == 0 && any > 0.) triggered[e] = 1;
+    }
+}
+
+void launch_phased_array_digital(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
+                                 const long* trace_offset, int n_pa, const int* pa_channel, int n_beams, const int* rolls_up, int window,
+                                 int step, double divisor, double threshold, int max_length, double fs, const PaAdc& adc,
+                                 double* pa_trace, int* pa_len, unsigned char* triggered, double* pa_max)
+{
+    if (n_cand <= 0) return;
+    set_big_lds();
+    const size_t lds1 = (size_t)(2 * max_length + 16) * 8 + 64;
+    (void)hipFuncSetAttribute((const void*)pa_digitize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    (void)hipFuncSetAttribute((const void*)phased_array_digital_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, adc.stride * 8 + 64);
+    const int n_items = n_cand * n_pa;
+    hipLaunchKernelGGL(pa_digitize_kernel, dim3(n_items < 4096 ? n_items : 4096), dim3(256), lds1, s, n_cand, item_event, n_ch, ev_L, trace,
+                       trace_offset, n_pa, pa_channel, fs, adc, pa_trace, pa_len);
+    hipLaunchKernelGGL(phased_array_digital_kernel, dim3(n_cand < 4096 ? n_cand : 4096), dim3(256), (size_t)adc.stride * 8 + 64, s, n_cand,
+                       item_event, pa_trace, pa_len, n_pa, n_beams, rolls_up, window, step, divisor, threshold, adc, triggered, pa_max);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // kernel: high/low and n-fold coincidence triggers (highLowThreshold.py:13-150, simpleThreshold.py) on channel traces that
 // sit in HBM -- the stations / events the fused logic of channel_conv_kernel cannot take: common traces longer than FFT_MAX
 // samples (bottom reflections: up to 16 128) and tabulated antenna patterns, whose traces come out of the chirp-z

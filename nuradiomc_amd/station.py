@@ -108,6 +108,9 @@ L._OPTIONAL.update({
     'nrhip_station_set_trigger_channels': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_int32_p]),
     'nrhip_station_set_envelope_trigger': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p, L.c_double_p]),
     'nrhip_station_set_noise': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_double_p]),
+    'nrhip_station_set_phased_array_adc': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_double, ctypes.c_double,
+                                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                          L.c_int32_p]),
     'nrhip_station_set_phased_array': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_int32_p, ctypes.c_int32, L.c_int32_p,
                                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'nrhip_station_set_arz': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p, L.c_double_p,
@@ -419,11 +422,16 @@ class Station:
         L.check(self._lib.nrhip_station_set_noise(self._h, len(amp), L.dptr(amp)))
         return amp
 
-    def set_phased_array(self, channels, phasing_angles, ref_index=1.75, window=32, step=16, averaging_divisor=None):
+    def set_phased_array(self, channels, phasing_angles, ref_index=1.75, window=32, step=16, averaging_divisor=None, adc=None,
+                         upsampling_factor=1, saturation_bits=8):
         """Phased-array trigger on the given channels (a vertical string): beams towards `phasing_angles` [rad], whole-sample
         channel shifts as PhasedArrayBase.calculate_time_delays (phasedArrayBase.py:58-124: antenna depths, ref_index, cable
-        delays, at the simulation's sampling rate; no group delays), mean power in windows of `window` samples every `step`
-        (power_sum :217-271); no ADC digitisation, no upsampling.  channels=None switches it off."""
+        delays; no group delays), mean power in windows of `window` samples every `step` (power_sum :217-271).
+        adc = dict(sampling_frequency [GHz], n_bits, noise_count, vrms=<station's>, output='voltage' | 'counts'): the trigger ADC of
+        phasedArrayTrigger.run(apply_digitization=True) (trigger_adc_sampling_frequency / trigger_adc_nbits / trigger_adc_noise_count
+        of the detector description, Vrms of adc_kwargs) followed by FFT up-sampling by `upsampling_factor`; beams, windows and
+        steps then count samples of the up-sampled ADC trace, count sums saturate at `saturation_bits`.  Without `adc` everything
+        runs at the simulation's sampling rate on the analog traces.  channels=None switches the trigger off."""
         if channels is None:
             L.check(self._lib.nrhip_station_set_phased_array(self._h, 0, None, 0, None, 0, 0, 0))
             return None
@@ -439,6 +447,23 @@ class Station:
         rolls = np.ascontiguousarray(rolls, np.int32)
         L.check(self._lib.nrhip_station_set_phased_array(self._h, len(ch), L.iptr(ch), len(rolls), L.iptr(rolls), int(window),
                                                          int(step), int(averaging_divisor or 0)))
+        if adc is not None:
+            import fractions
+            import decimal
+            f_adc, n_bits = float(adc['sampling_frequency']), int(adc['n_bits'])
+            vrms = float(adc.get('vrms') or self.vrms)
+            half = vrms * (2 ** n_bits - 1) / float(adc['noise_count']) / 2       # _get_adc_parameters :236-240
+            fr = fractions.Fraction(decimal.Decimal(5.0 / self.sampling_rate)).limit_denominator(5000)   # signal_processing.resample :86
+            up = max(int(upsampling_factor), 1)
+            rolls = []
+            for angle in np.atleast_1d(phasing_angles):
+                delays = (z - np.max(z)) / 0.299792458 * ref_index * np.sin(angle) - self.cable_delay[ch]
+                delays -= np.min(delays)
+                rolls.append(np.round(delays * (f_adc * up)).astype(int))
+            rolls = np.ascontiguousarray(rolls, np.int32)
+            L.check(self._lib.nrhip_station_set_phased_array_adc(self._h, f_adc, n_bits, -half, half,
+                                                                 int(adc.get('output', 'voltage') == 'counts'), up, int(saturation_bits),
+                                                                 fr.numerator, fr.denominator, L.iptr(rolls)))
         return rolls
 
     @staticmethod
@@ -697,7 +722,8 @@ class Station:
                      'ray_active_list': np.int32, 'ray_slot': np.int32, 'slot_keep': np.int32, 'slot_offset': np.int32,
                      'shower_first_channel': np.int32, 'slot_reflection': np.int32, 'slot_reflection_case': np.int32,
                      'slot_n_segments': np.int32, 'slot_surface_mask': np.int32, 'ev_group': np.int32, 'ev_sub_event': np.int32,
-                     'ev_triggered': np.uint8, 'ray_sub_event': np.int32, 'group_n_sub_events': np.int32}
+                     'ev_triggered': np.uint8, 'ray_sub_event': np.int32, 'group_n_sub_events': np.int32,
+                     'pa_digital_length': np.int32}
 
     def fetch(self, name):
         """One table of the last simulated batch as a numpy array (see include/nrhip.h: nrhip_sim_fetch)."""

@@ -671,6 +671,74 @@ def phased_array_power(V, rolls, window, step, averaging_divisor=None):
     return np.array(out)
 
 
+def adc_digital_trace(x, fs, adc_fs, n_bits, vrms, noise_count, output='voltage'):
+    """analogToDigitalConverter.get_digital_trace (analogToDigitalConverter.py:254-373) with trigger_adc=True, Vrms given, the perfect
+    floor comparator: resampling to 5 GHz (signal_processing.resample :71-108), linear-interpolation down-sampling to the ADC rate
+    (:432-463), floor((V - V_min) / lsb) clipped to the ADC's counts (:14-110) with the range +- Vrms (2^n - 1) / (2 noise_count)
+    (_get_adc_parameters :173-252), an even number of samples"""
+    import fractions
+    import decimal
+    x = np.asarray(x, float)
+    half = vrms * (2 ** n_bits - 1) / noise_count / 2
+    vmin, vmax = -half, half
+    if not np.allclose(adc_fs, fs):
+        cur = fs
+        if 5.0 > fs:
+            fr = fractions.Fraction(decimal.Decimal(5.0 / fs)).limit_denominator(5000)
+            if fr.numerator != 1:
+                x = signal.resample(x, fr.numerator * len(x))
+            if fr.denominator != 1:
+                x = signal.resample(x, len(x) // fr.denominator)
+            if len(x) % 2:
+                x = x[:-1]
+            cur = 5.0
+        n_new = int((adc_fs / cur) * len(x))
+        times = np.arange(len(x)) / cur
+        t_new = np.arange(n_new) / adc_fs
+        from scipy.interpolate import interp1d
+        x = interp1d(times, x, kind='linear', fill_value=(x[0], x[-1]), bounds_error=False)(t_new)
+    lsb = (vmax - vmin) / (2 ** n_bits - 1)
+    d = np.floor((x - vmin) / lsb).astype(int)
+    d = np.clip(d, 0, 2 ** n_bits - 1) + int(np.floor(vmin / lsb))
+    if output == 'voltage':
+        d = lsb * d.astype(float)
+    if len(d) % 2:
+        d = d[:-1]
+    return d
+
+
+def digital_upsampling_fft(d, factor):
+    """signal_processing.digital_upsampling (:111-190), method 'fft': scipy.signal.resample to factor x the length; an integer
+    (ADC count) trace stays integer (np.round); even length"""
+    d = np.asarray(d)
+    if int(factor) <= 1:
+        return d
+    digital = np.allclose(d, np.round(d))
+    u = signal.resample(d, len(d) * int(factor))
+    if digital:
+        u = np.round(u).astype(int)
+    if len(u) % 2:
+        u = u[:-1]
+    return u
+
+
+def phased_array_power_digital(U, rolls, window, step, output='voltage', saturation_bits=8, averaging_divisor=None):
+    """phase_signals with the saturation of ADC counts (phasedArrayBase.py:183-215) + power_sum with its rounding (:217-271)"""
+    out = []
+    U = np.asarray(U, float)
+    for roll in rolls:
+        coh = np.zeros(U.shape[1])
+        for c in range(U.shape[0]):
+            coh += np.roll(U[c], int(roll[c]))
+        if output == 'counts' and saturation_bits is not None:
+            coh = np.clip(coh, -2 ** (saturation_bits - 1), 2 ** (saturation_bits - 1) - 1)
+        n_frames = int(np.floor((len(coh) - window) / step))
+        sq = coh * coh
+        p = np.array([np.sum(sq[i * step:i * step + window]) for i in range(n_frames)]).astype(float) / (averaging_divisor or window)
+        out.append(np.round(p) if output == 'counts' else p)
+    return np.array(out)
+
+
 def phased_array_trigger(V, rolls, window, step, threshold):
     """phased_trigger (:455-496), mode 'power_sum': (triggered, maximum_amps per beam)"""
     p = phased_array_power(V, rolls, window, step)

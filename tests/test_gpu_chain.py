@@ -1298,3 +1298,54 @@ def test_thermal_noise(gpu_ctx_factory):
     st.set_noise(None)
     with pytest.raises(Exception, match='noise'):
         st.simulate_events(*args, noise=True)
+
+
+@pytest.mark.parametrize('output,up', [('counts', 4), ('voltage', 2), ('counts', 1)])
+def test_phased_array_with_trigger_adc(gpu_ctx_factory, output, up):
+    """phasedArrayTrigger with apply_digitization and FFT up-sampling inside simulate_events: per array channel of every candidate
+    event the trigger ADC (5 GHz resampling, linear down-sampling to 472 MHz, floor comparator) and the up-sampling, then beams with
+    saturation and rounded window powers.  GPU vs the oracle's restatement (pinned sample by sample on the reference's own functions,
+    test_phased_array_adc_vs_reference) applied to the channel traces the GPU dumped: digitised traces equal (counts: every sample;
+    volts: 1e-9 lsb), per-beam maximum powers and decisions equal."""
+    ice = (1.78, 0.423, 77.)
+    pos = np.array([[0., 0., -96.], [0., 0., -97.], [0., 0., -98.], [0., 0., -99.], [0., 0., -60.], [20., 15., -95.]])
+    cable = np.array([1.2, 0., 2.6, 0.7, 0., 3.])
+    ctx = gpu_ctx_factory(ice, 'SP1')
+    st = nuradiomc_amd.Station(ctx, pos, cable_delay=cable, n_samples=512, sampling_rate=2.0)
+    vrms = st.vrms
+    angles = np.arcsin(np.linspace(np.sin(-60 * np.pi / 180), np.sin(60 * np.pi / 180), 11))
+    window, step, adc_fs, nbits, ncount = 24, 8, 0.472, 8, 5
+    rolls = st.set_phased_array([0, 1, 2, 3], angles, ref_index=1.75, window=window, step=step, upsampling_factor=up,
+                                adc=dict(sampling_frequency=adc_fs, n_bits=nbits, noise_count=ncount, output=output))
+    assert np.array_equal(rolls, so.phased_array_rolls(pos[:4, 2], cable[:4], angles, adc_fs * up, 1.75))
+    lsb = vrms / ncount
+    threshold = 2.5 * (2 * (vrms / lsb if output == 'counts' else vrms)) ** 2
+    rng = np.random.default_rng(14)
+    n = 120
+    r, ph = np.sqrt(rng.uniform(0, 1500. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    v = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1500., -10., n)], axis=1)
+    zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    en = 10 ** rng.uniform(16.8, 18.2, n)
+    trig, stats = st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold, dump_traces=True)
+    item_event, tr, off = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    dig, dlen = st.fetch('pa_digital_trace'), st.fetch('pa_digital_length').reshape(len(item_event), 4)
+    stride = len(dig) // (len(item_event) * 4)
+    dig = dig.reshape(len(item_event), 4, stride)
+    pa_max = st.fetch('pa_max_power').reshape(len(item_event), len(angles))
+    n_ch = len(pos)
+    n_trig = 0
+    for i, e in enumerate(item_event):
+        V = np.array([tr[off[i * n_ch + c]:off[i * n_ch + c + 1]] for c in range(4)])
+        U = np.array([so.digital_upsampling_fft(so.adc_digital_trace(x, 2.0, adc_fs, nbits, vrms, ncount, output), up) for x in V])
+        assert np.all(dlen[i] == U.shape[1])
+        got = dig[i, :, :U.shape[1]]
+        assert np.max(np.abs(got - U)) <= (0 if output == 'counts' else 1e-9 * lsb), e
+        p = so.phased_array_power_digital(U, rolls, window, step, output)
+        mx = p.max(axis=1)
+        assert np.max(np.abs(pa_max[i] - mx)) <= 1e-9 * np.max(mx), e
+        t = bool(np.any(p > (np.trunc(threshold) if output == 'counts' else threshold)))
+        assert t == bool(trig[e]), e
+        n_trig += t
+    assert len(item_event) >= 15 and 2 <= n_trig < len(item_event)
+    trig_p, _ = st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold)
+    assert np.array_equal(trig_p, trig)

@@ -412,3 +412,28 @@ def test_earth_weights_vs_reference():
         w = eo.get_weight(g['zenith'], g['azimuth'], g['energy'], g['flavor'], g['vertex'], mode, cross_section_type='ghandi')
         ref = g['weight_ghandi_' + mode]
         assert np.max(np.abs(w - ref)) < 1e-13 and max_rel(w[ref > 1e-200], ref[ref > 1e-200]) < 1e-10, mode
+
+
+def test_phased_array_adc_vs_reference():
+    """The digitised phased-array chain restated in the oracle (trigger ADC with the 5 GHz resampling and linear down-sampling, floor
+    comparator, FFT up-sampling, saturated beam sums, rounded power sums) against the reference's own functions on the same traces
+    (tests/golden/gen/gen_pa_adc.py): ADC traces and up-sampled traces sample by sample, beam rolls, window powers."""
+    from oracle import spectral_oracle as so
+    g = golden('ref_pa_adc.npz')
+    for k, c in enumerate(g['cases']):
+        n_ch, n_samples, fs, adc_fs, nbits, ncount, up, window, step, n_beams = (int(c[0]), int(c[1]), c[2], c[3], int(c[4]), int(c[5]),
+                                                                                 int(c[6]), int(c[7]), int(c[8]), int(c[9]))
+        output, vrms = str(g['output_%d' % k]), float(g['vrms_%d' % k])
+        rolls = so.phased_array_rolls(g['pos_%d' % k][:, 2], g['cable_%d' % k], g['angles_%d' % k], adc_fs * max(up, 1))
+        assert np.array_equal(rolls, g['rolls_%d' % k])
+        for e in range(len(g['traces_%d' % k])):
+            dig = np.array([so.adc_digital_trace(x, fs, adc_fs, nbits, vrms, ncount, output) for x in g['traces_%d' % k][e]])
+            ref = g['digital_%d' % k][e]
+            lsb = vrms * (2 ** nbits - 1) / ncount / (2 ** nbits - 1)
+            assert dig.shape == ref.shape and np.max(np.abs(dig - ref)) <= (1e-9 * lsb if output == 'voltage' else 0), (k, e)
+            ups = np.array([so.digital_upsampling_fft(d, up) for d in dig])
+            ref = g['upsampled_%d' % k][e]
+            assert ups.shape == ref.shape and np.max(np.abs(ups - ref)) <= (1e-9 * lsb if output == 'voltage' else 0), (k, e)
+            p = so.phased_array_power_digital(ups, rolls, window, step, output)
+            ref = g['power_%d' % k][e]
+            assert p.shape == ref.shape and np.max(np.abs(p - ref)) <= 1e-9 * np.max(ref), (k, e)
