@@ -4,7 +4,7 @@ downloads), greenland_simple ice + GL1 attenuation, Alvarez2009, 1e18 eV hadroni
 speedup.distance_cut with the coefficients of the reference's example config, simple 3 Vrms threshold on any channel, 2048
 samples at 2 GHz.  One Station object is moved through the array (Station.move_to); every chunk of the event list is uploaded
 once, offered to every station, and the masks are OR-ed.
-usage: config3_probe.py [n_events] [n_stations] [gen2 | deep4 | pa]
+usage: config3_probe.py [n_events] [n_stations] [gen2 | deep4 | pa | pa_adc]
 `gen2` = BASELINE config 5 in the same shape: up to 200 stations on a 1.24 km square grid, each the 5-channel dipole string of
 config 2 at -100 .. -104 m (no Gen2 detector file exists in the reference), showers log-uniform in 1e16 .. 1e20 eV."""
 import sys, time, os
@@ -57,6 +57,10 @@ if len(sys.argv) > 3 and sys.argv[3] == 'deep4':     # threshold trigger on the 
 if len(sys.argv) > 3 and sys.argv[3] == 'pa':        # phased array on the four deep dipoles (11 beams, 16-sample windows)
     s.set_phased_array([0, 1, 2, 3], np.arcsin(np.linspace(np.sin(-60 * d), np.sin(60 * d), 11)), window=16, step=8)
     trig_kw = dict(trigger='phased_array', trigger_threshold=2.0 * (2 * s.vrms) ** 2)
+if len(sys.argv) > 3 and sys.argv[3] == 'pa_adc':    # the same with the trigger ADC (472 MHz, 8 bit, counts) and 4x FFT up-sampling
+    s.set_phased_array([0, 1, 2, 3], np.arcsin(np.linspace(np.sin(-60 * d), np.sin(60 * d), 11)), window=24, step=8, upsampling_factor=4,
+                       adc=dict(sampling_frequency=0.472, n_bits=8, noise_count=5, output='counts'))
+    trig_kw = dict(trigger='phased_array', trigger_threshold=2.0 * (2 * 5) ** 2)
 s.simulate_events(vertex[:1000], zen[:1000], az[:1000], energy[:1000], 'HAD', distance_cut_coefficients=coef)
 t0 = time.time()
 per = np.zeros(len(centres))
