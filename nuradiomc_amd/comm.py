@@ -102,14 +102,14 @@ def exchange_bytes(payload, rank, world_size, addr=None, port=None, timeout=300.
 class Comm:
     """RCCL communicator of one process (one GPU) over nrhip_comm_*; world_size 1 needs no RCCL and every call is local."""
 
-    def __init__(self, ctx, rank=None, world_size=None, addr=None, port=None):
+    def __init__(self, ctx, rank=None, world_size=None, addr=None, port=None, force_rccl=False):
         r, _, w = env_rank()
         self.ctx = ctx
         self.rank = r if rank is None else int(rank)
         self.world_size = w if world_size is None else int(world_size)
         self._lib = L.load()
         self._h = None
-        if self.world_size > 1:
+        if self.world_size > 1 or force_rccl:   # force_rccl: a one-rank communicator (tests of the binding on a single GPU)
             uid = (ctypes.c_uint8 * ID_BYTES)()
             if self.rank == 0:
                 L.check(self._lib.nrhip_comm_get_unique_id(uid))

@@ -293,3 +293,22 @@ def test_array_full_size_properties(gpu_ctx_factory, config):
     finally:
         bench.free_events(ctx, d)
     assert np.array_equal(got.astype(bool), trig) and s2['n_triggered'] == trig.sum()
+
+
+def test_rccl_binding_single_rank(gpu_ctx_factory):
+    """nrhip_comm_* (RCCL bound by dlopen behind the C ABI) on ONE GPU: a one-rank communicator goes through ncclGetUniqueId /
+    ncclCommInitRank / ncclAllGather / ncclAllReduce / barrier / ncclCommDestroy -- every symbol the N-GPU runs of bench.py need."""
+    import bench
+    from nuradiomc_amd import comm
+    ctx = gpu_ctx_factory(bench.ICE, 'SP1')
+    c = comm.Comm(ctx, rank=0, world_size=1, force_rccl=True)
+    assert c._h is not None
+    mask = (np.arange(1001) % 7 == 0).astype(np.uint8)
+    d = ctx.to_device(mask)
+    got = c.allgather_masks(d, len(mask), len(mask))
+    assert np.array_equal(got, mask)
+    assert list(c.allreduce_sum([3, 5, 2 ** 40])) == [3, 5, 2 ** 40]
+    assert list(c.allreduce_max([1.5, -2.0])) == [1.5, -2.0]
+    c.barrier()
+    c.close()
+    ctx.free(d)
