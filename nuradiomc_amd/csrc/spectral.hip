@@ -3229,7 +3229,7 @@ __device__ inline double2 turn_phase(long num, long den)   // exp(2 pi i num / d
     return make_double2(cs, sn);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 pa_digitize_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, const int* __restrict__ ev_L,
                    const double* __restrict__ trace, const long* __restrict__ trace_offset, int n_pa, const int* __restrict__ pa_channel,
                    double fs, PaAdc adc, double* __restrict__ pa_trace, int* __restrict__ pa_len)
@@ -3246,16 +3246,25 @@ pa_digitize_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, con
         for (int n = threadIdx.x; n < L; n += blockDim.x) sx[n] = x[n];
         __syncthreads();
         // spectrum X_k = sum_n x[n] exp(-2 pi i k n / L)
-        for (int k = threadIdx.x; k <= m; k += blockDim.x) {
-            double2 acc = make_double2(0., 0.), w = make_double2(1., 0.);
-            const double2 step = cconj(turn_phase(k, L));
+        // (two bins per thread and loop: two independent recurrences keep the FP64 pipe busy, one LDS read serves both)
+        for (int k0 = threadIdx.x; k0 <= m; k0 += 2 * blockDim.x) {
+            const int k1 = k0 + blockDim.x;
+            const bool two = k1 <= m;
+            double2 a0 = make_double2(0., 0.), a1 = a0, w0 = make_double2(1., 0.), w1 = w0;
+            const double2 s0 = cconj(turn_phase(k0, L)), s1 = cconj(turn_phase(two ? k1 : 0, L));
             for (int n = 0; n < L; n++) {
-                if ((n & 31) == 0) w = cconj(turn_phase((long)k * n, L));
-                acc.x += sx[n] * w.x;
-                acc.y += sx[n] * w.y;
-                w = cmul(w, step);
+                if ((n & 31) == 0) {
+                    w0 = cconj(turn_phase((long)k0 * n, L));
+                    w1 = cconj(turn_phase((long)(two ? k1 : 0) * n, L));
+                }
+                const double v = sx[n];
+                a0.x += v * w0.x; a0.y += v * w0.y;
+                a1.x += v * w1.x; a1.y += v * w1.y;
+                w0 = cmul(w0, s0);
+                w1 = cmul(w1, s1);
             }
-            X[k] = acc;
+            X[k0] = a0;
+            if (two) X[k1] = a1;
         }
         __syncthreads();
         // (1) + (2): the ADC samples
@@ -3273,18 +3282,21 @@ pa_digitize_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, con
         // interpolant is defined by X the samples sx are no longer read (d, D there; the host checks 2 n_adc + 4 <= L); without that
         // resampling X is not used at all (d there, D over sx once d is complete)
         double* d = to5 ? pd_lds : (double*)X;
-        auto value5 = [&](long i) -> double {              // sample i of the (re)sampled trace
-            if (!to5) return sx[i];
-            double acc = X[0].x;
-            double2 w = make_double2(1., 0.);
-            const double2 step = turn_phase(i, num2);
+        auto value5_pair = [&](long i, double& y0, double& y1) {   // samples i and i + 1 of the (re)sampled trace
+            if (!to5) { y0 = sx[i]; y1 = sx[i + 1]; return; }
+            double acc0 = X[0].x, acc1 = X[0].x;
+            double2 w0 = make_double2(1., 0.), w1 = w0;
+            const double2 s0 = turn_phase(i, num2), s1 = turn_phase(i + 1, num2);
             for (int k = 1; k <= m; k++) {
-                if ((k & 31) == 1) w = turn_phase((long)k * i, num2);
-                else w = cmul(w, step);
-                const double t = X[k].x * w.x - X[k].y * w.y;
-                acc += (k == m) ? t : 2. * t;
+                if ((k & 31) == 1) { w0 = turn_phase((long)k * i, num2); w1 = turn_phase((long)k * (i + 1), num2); }
+                else { w0 = cmul(w0, s0); w1 = cmul(w1, s1); }
+                const double2 xk = X[k];
+                const double t0 = xk.x * w0.x - xk.y * w0.y, t1 = xk.x * w1.x - xk.y * w1.y;
+                acc0 += (k == m) ? t0 : 2. * t0;
+                acc1 += (k == m) ? t1 : 2. * t1;
             }
-            return acc / L;
+            y0 = acc0 / L;
+            y1 = acc1 / L;
         };
         const double lsb = (adc.vmax - adc.vmin) / (double)((1 << adc.n_bits) - 1);
         const double vmin_adc = floor(adc.vmin / lsb);
@@ -3299,7 +3311,8 @@ pa_digitize_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, con
                 if (lo > len5 - 2) lo = len5 - 2;
                 if (lo < 0) lo = 0;
                 const double xlo = (double)lo / cur, xhi = (double)(lo + 1) / cur;
-                const double ylo = value5(lo), yhi = value5(lo + 1);
+                double ylo, yhi;
+                value5_pair(lo, ylo, yhi);
                 const double slope = (yhi - ylo) / (xhi - xlo);
                 v = slope * (tn - xlo) + ylo;
             } else {
@@ -3407,7 +3420,7 @@ void launch_phased_array_digital(hipStream_t s, int n_cand, const int* item_even
     (void)hipFuncSetAttribute((const void*)pa_digitize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     (void)hipFuncSetAttribute((const void*)phased_array_digital_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, adc.stride * 8 + 64);
     const int n_items = n_cand * n_pa;
-    hipLaunchKernelGGL(pa_digitize_kernel, dim3(n_items < 4096 ? n_items : 4096), dim3(256), lds1, s, n_cand, item_event, n_ch, ev_L, trace,
+    hipLaunchKernelGGL(pa_digitize_kernel, dim3(n_items < 4096 ? n_items : 4096), dim3(1024), lds1, s, n_cand, item_event, n_ch, ev_L, trace,
                        trace_offset, n_pa, pa_channel, fs, adc, pa_trace, pa_len);
     hipLaunchKernelGGL(phased_array_digital_kernel, dim3(n_cand < 4096 ? n_cand : 4096), dim3(256), (size_t)adc.stride * 8 + 64, s, n_cand,
                        item_event, pa_trace, pa_len, n_pa, n_beams, rolls_up, window, step, divisor, threshold, adc, triggered, pa_max);

@@ -89,4 +89,4 @@ dt = time.time() - t0
 print(('config 5' if gen2 else 'config 3') + ' (synthetic array): %d events x %d stations x %d channels = %.3g pairs offered, %.3g rays after the distance cut; '
       '%.2f s wall (host arrays in, masks out) = %.0f events/s, %.3g pairs/s; %d events trigger somewhere; per station %.3f .. %.3f s'
       % (n, len(centres), len(pos), n * len(centres) * float(len(pos)), tot['n_rays'], dt, n / dt, n * len(centres) * float(len(pos)) / dt, any_trig.sum(), min(per), max(per)))
-print('last station stage ms:', stats['stage_ms'])
+print('last station: candidates', stats['n_candidate_events'], 'max L', stats['max_length'], 'stage ms:', stats['stage_ms'])
