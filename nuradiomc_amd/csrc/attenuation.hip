@@ -460,6 +460,9 @@ __device__ inline GK gk21_from_nodes(double a, double b, F&& fval, double* __res
 }
 
 struct LaneEval {
+#ifdef NRHIP_ATT_TIMING
+    mutable unsigned long long at_acc[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#endif
     __device__ inline bool any(bool busy) const { return busy; }
     __device__ inline void pair(bool want, bool two, double a1, double b1, double a2, double b2, const AttItem& it,
                                 const IceConst& m, GK& g1, GK& g2) const
@@ -470,12 +473,24 @@ struct LaneEval {
     }
 };
 
+#ifdef NRHIP_ATT_TIMING   // debug builds: shader clocks per phase (wave 0 of every block), read by nrhip_debug_att_clocks
+__device__ unsigned long long g_att_clk[12];
+#define AT_MARK(t) unsigned long long t = __builtin_amdgcn_s_memtime()
+#define AT_ADD(e, i, t0) do { (e).at_acc[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#else
+#define AT_MARK(t)
+#define AT_ADD(e, i, t0)
+#endif
+
 template <int G, int MODEL = 0>
 struct GroupEval {
     int lane, gl, gb;               // lane in wave, lane in group, first lane of the group
     unsigned long long gmask;       // lanes of this group
     NodeShared* nodes;              // LDS: 2 x 21 node records of this group
     double* fbuf;                   // LDS: this lane's column for the node values of one 21-point rule
+#ifdef NRHIP_ATT_TIMING
+    mutable unsigned long long at_acc[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#endif
     __device__ inline void init(NodeShared* lds, double* lds_f)
     {
         fbuf = lds_f + threadIdx.x;
@@ -500,6 +515,7 @@ struct GroupEval {
         if (allsame) {
             // lane gl evaluates node gl of both intervals with the leader's (== everybody's) ray and interval and
             // leaves the record in LDS; the group is part of one wave, whose LDS operations execute in order
+            AT_MARK(t_nodes);
             if (gl < 21) {
                 AttItem li = it;
                 li.C0 = lC0;
@@ -518,6 +534,8 @@ struct GroupEval {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            AT_ADD(*this, 0, t_nodes);
+            AT_MARK(t_fin);
             if (MODEL == 1) {
                 // straight-line evaluation: x = a(z) + b(z) ln f stays within a few tens for any physical ray, so the range /
                 // NaN branches of det_exp are checked once per rule (wave-uniform) instead of per node; a wave in which any
@@ -551,6 +569,7 @@ struct GroupEval {
                 if (want) { g1 = f1; if (two) g2 = f2; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                AT_ADD(*this, 1, t_fin);
                 return;
             }
             if (MODEL != 1 && want) {
@@ -609,6 +628,7 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
         double lo = fmin(a, b), hi = fmax(a, b);
         double a1 = qagp ? lo : a, b1 = with_point ? point : (qagp ? hi : b), a2 = point, b2 = hi;
         ev.pair(valid, with_point, a1, b1, a2, b2, it, m, g1, g2);
+        AT_MARK(t_init);
         if (valid && qagp) {
             if (a > b) sign = -1.;
             const GK gg[3] = {g1, g1, g2};
@@ -677,20 +697,35 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
                 busy = true;
             }
         }
+        AT_ADD(ev, 7, t_init);
     }
     const bool entered_loop = busy;
+    // The end points of the two intervals the last bisection made stay in registers: the next interval to bisect is nearly always
+    // one of them, and the lists live in scratch (HBM latency on a dependent path).  ia / ib: their list slots (0: none).
+    int ia = 0, ib = 0;
+    double ca_lo = 0., ca_hi = 0., cb_lo = 0., cb_hi = 0.;
+    auto end_points = [&](int idx, double& lo, double& hi) {
+        if (idx == ia) { lo = ca_lo; hi = ca_hi; }
+        else if (idx == ib) { lo = cb_lo; hi = cb_hi; }
+        else { lo = alist[idx]; hi = blist[idx]; }
+    };
     // ---- main loop: bisect the interval with the largest error estimate --------------------------------------
     while (ev.any(busy)) {
         double a1 = 0., b1 = 0., a2 = 0., b2 = 0., erlast = 0.;
+        AT_MARK(t_top);
         if (busy) {
             if (qagp) levcur = level[maxerr] + 1;
-            a1 = alist[maxerr];
-            b1 = 0.5 * (alist[maxerr] + blist[maxerr]);
+            double lo_, hi_;
+            end_points(maxerr, lo_, hi_);
+            a1 = lo_;
+            b1 = 0.5 * (lo_ + hi_);
             a2 = b1;
-            b2 = blist[maxerr];
+            b2 = hi_;
             erlast = errmax;
         }
+        AT_ADD(ev, 3, t_top);
         ev.pair(busy, true, a1, b1, a2, b2, it, m, g1, g2);
+        AT_MARK(t_book);
         if (busy) {
             do {
                 neval += 42;
@@ -716,22 +751,30 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
                 if (iroff2 >= 5) ierro = 3;
                 if (last == limit) ier = 1;
                 if (fmax(fabs(a1), fabs(b2)) <= (1. + 100. * epmach) * (fabs(a2) + 1000. * uflow)) ier = 4;
+                ia = maxerr;
+                ib = last;
                 if (g2.abserr > g1.abserr) {
                     alist[maxerr] = a2;
+                    blist[maxerr] = b2;   // (unchanged; written so that slot and registers hold the same pair)
                     alist[last] = a1;
                     blist[last] = b1;
                     rlist[maxerr] = g2.result;
                     rlist[last] = g1.result;
                     elist[maxerr] = g2.abserr;
                     elist[last] = g1.abserr;
+                    ca_lo = a2; ca_hi = b2; cb_lo = a1; cb_hi = b1;
                 } else {
                     alist[last] = a2;
                     blist[maxerr] = b1;
                     blist[last] = b2;
                     elist[maxerr] = g1.abserr;
                     elist[last] = g2.abserr;
+                    ca_lo = a1; ca_hi = b1; cb_lo = a2; cb_hi = b2;
                 }
+                AT_ADD(ev, 4, t_book);
+                AT_MARK(t_sort);
                 sort_errors(last, maxerr, errmax, elist, iord, nrmax);
+                AT_ADD(ev, 5, t_sort);
                 if (errsum <= errbnd) { exit_code = 1; busy = false; break; }
                 if (ier != 0) { exit_code = 2; busy = false; break; }
                 if (!qagp && last == 2) {
@@ -746,8 +789,9 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
                 if (qagp) { if (levcur + 1 <= levmax) erlarg += erro12; }
                 else      { if (fabs(b1 - a1) > small) erlarg += erro12; }
                 if (!extrap) {
-                    bool is_smallest = qagp ? !(level[maxerr] + 1 <= levmax)
-                                            : !(fabs(blist[maxerr] - alist[maxerr]) > small);
+                    double lo_ = 0., hi_ = 0.;
+                    if (!qagp) end_points(maxerr, lo_, hi_);
+                    bool is_smallest = qagp ? !(level[maxerr] + 1 <= levmax) : !(fabs(hi_ - lo_) > small);
                     if (!is_smallest) break;  // continue
                     extrap = true;
                     nrmax = 2;
@@ -759,7 +803,9 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
                     for (int k = nrmax; k <= jupbnd; k++) {
                         maxerr = iord[nrmax];
                         errmax = elist[maxerr];
-                        bool big = qagp ? (level[maxerr] + 1 <= levmax) : (fabs(blist[maxerr] - alist[maxerr]) > small);
+                        double lo_ = 0., hi_ = 0.;
+                        if (!qagp) end_points(maxerr, lo_, hi_);
+                        bool big = qagp ? (level[maxerr] + 1 <= levmax) : (fabs(hi_ - lo_) > small);
                         if (big) { cont = true; break; }
                         nrmax++;
                     }
@@ -796,7 +842,9 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
                 if (last > limit) busy = false;  // cannot happen (ier = 1 at last == limit), kept as a guard
             }
         }
+        AT_ADD(ev, 6, t_book);   // everything after the rules of this bisection (includes 4 and 5)
     }
+    AT_MARK(t_fin2);
     if (valid && entered_loop) {
         if (last > limit) last = limit;
         bool sum_list = (exit_code == 1);
@@ -822,14 +870,23 @@ __device__ __forceinline__ double quad_gk21(bool valid, double a, double b, bool
             }
         }
         if (sum_list) {
+            // (the list lives in scratch: eight loads are issued before the first addition waits for one; same order of additions)
             result = 0.;
-            for (int k = 1; k <= last; k++) result += rlist[k];
+            for (int k0 = 1; k0 <= last; k0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = rlist[min(k0 + j, QLIM + 1)];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (k0 + j <= last) result += v[j];
+            }
             abserr = errsum;
         }
         if (!qagp) neval = 42 * last - 21;
     }
     if (qagp) result *= sign;
     if (neval_out) *neval_out = neval;
+    AT_ADD(ev, 8, t_fin2);
     return result;
 }
 
@@ -881,32 +938,64 @@ attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const doubl
     ev.init(sh_nodes, sh_f);
     model = MODEL;  // compile-time: the branches on the ice model fold away
     unsigned long long my_evals = 0;
+    AT_MARK(t_all);
     const long groups_per_block = blockDim.x / G;
     const long n_iter = (n_rays + (long)gridDim.x * groups_per_block - 1) / ((long)gridDim.x * groups_per_block);
+    // the lane's frequency (and its logarithm) is the same for every ray; the parameters of the NEXT ray are requested while the
+    // current one is integrated (they come from HBM: one exposed latency per ray otherwise)
+    const int jf = threadIdx.x & (G - 1);
+    const double lane_f = (jf < n_freq) ? freqs[jf] : 1.;
+    const double lane_w = det_log(lane_f);
+    struct RayPar { bool ok; long ray; double C0, z1, z2m, zt; };
+    auto fetch = [&](long iter) -> RayPar {
+        RayPar r{false, 0, NAN, 0., 0., 0.};
+        if (iter >= n_iter) return r;
+        const long g = (iter * gridDim.x + blockIdx.x) * groups_per_block + threadIdx.x / G;
+        r.ok = g < n_rays;
+        if (r.ok) {
+            r.ray = ray_index ? ray_index[g] : g;
+            r.C0 = C0[r.ray];
+            r.z1 = zint[3 * r.ray];
+            r.z2m = zint[3 * r.ray + 1];
+            r.zt = zint[3 * r.ray + 2];
+        }
+        return r;
+    };
+    RayPar nxt = fetch(0);
     for (long iter = 0; iter < n_iter; iter++) {  // uniform trip count: every lane takes part in the shuffles
-        long g = (iter * gridDim.x + blockIdx.x) * groups_per_block + threadIdx.x / G;
-        int jf = threadIdx.x & (G - 1);
-        bool ray_ok = g < n_rays;
-        long ray = 0;
-        if (ray_ok) ray = ray_index ? ray_index[g] : g;
+        const RayPar cur = nxt;
+        nxt = fetch(iter + 1);
+        const bool ray_ok = cur.ok;
+        const long ray = cur.ray;
         AttItem it;
-        it.C0 = ray_ok ? C0[ray] : NAN;
-        double z1 = ray_ok ? zint[3 * ray] : 0., z2m = ray_ok ? zint[3 * ray + 1] : 0.;
-        it.z_turn = ray_ok ? zint[3 * ray + 2] : 0.;
+        it.C0 = cur.C0;
+        const double z1 = cur.z1, z2m = cur.z2m;
+        it.z_turn = cur.zt;
         it.lane.model = model;
-        it.lane.f = (jf < n_freq) ? freqs[jf] : 1.;
-        it.lane.w = det_log(it.lane.f);
+        it.lane.f = lane_f;
+        it.lane.w = lane_w;
         bool valid = ray_ok && jf < n_freq && !isnan(it.C0);
         bool with_point = (z1 < it.z_turn && it.z_turn < z2m);
         int ne = 0;
+        AT_MARK(t_q);
         double integral = quad_gk21(valid, z1, z2m, with_point, it.z_turn, it, m, &ne, ev);
+        AT_ADD(ev, 9, t_q);
+        AT_MARK(t_st);
         if (ray_ok && jf < n_freq) {
             const long item = ray * n_freq + jf;
             att[item] = valid ? det_exp(-1 * integral) : NAN;
             if (neval) neval[item] = ne;
             my_evals += (unsigned long long)ne;
         }
+        AT_ADD(ev, 10, t_st);
     }
+#ifdef NRHIP_ATT_TIMING
+    if ((threadIdx.x & 63) == 0) {
+        for (int i = 0; i < 12; i++)
+            if (i != 2) atomicAdd(&g_att_clk[i], ev.at_acc[i]);
+        atomicAdd(&g_att_clk[2], __builtin_amdgcn_s_memtime() - t_all);
+    }
+#endif
     if (eval_counter) {  // integrand evaluations QUADPACK would count (for the FP64 rate reported by bench.py)
         for (int off = 32; off > 0; off >>= 1) my_evals += __shfl_xor(my_evals, off);
         if ((threadIdx.x & 63) == 0) atomicAdd(eval_counter, my_evals);
@@ -1128,3 +1217,15 @@ void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0,
 }
 
 }  // namespace nrhip
+
+#ifdef NRHIP_ATT_TIMING
+extern "C" int nrhip_debug_att_clocks(unsigned long long* out12, int reset)
+{
+    if (hipMemcpyFromSymbol(out12, HIP_SYMBOL(nrhip::g_att_clk), 12 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[12] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nrhip::g_att_clk), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
