@@ -32,8 +32,16 @@ __device__ inline double2 cscale(double2 a, double s) { return make_double2(a.x 
 #define NRHIP_FFT_FUSE 4
 #endif
 
+// Padded LDS layout of the 8192-point convolution buffer: element i lives at i + (i >> 5) + (i >> 7).  With 16-byte elements on
+// 32 four-byte banks, the strides the passes use between the lanes of a wave -- 32 elements in the third fused pass (and its mirror
+// in the inverse transform), 128 elements in the bit-reversed accesses of the spectrum product -- land on the same banks in the
+// plain layout (4- and 64-way conflicts); the two shifts move them to 33.25 and 133 elements, which visit all banks.
+__device__ __forceinline__ int fft_pad(int i) { return i + (i >> 5) + (i >> 7); }
+template <bool PAD> __device__ __forceinline__ int fft_at(int i) { return PAD ? fft_pad(i) : i; }
+constexpr int FFT_PADDED_MAX = FFT_MAX + FFT_MAX / 32 + FFT_MAX / 128;   // elements of a padded FFT_MAX-point buffer
+
 // decimation in frequency, stages s .. s + K - 1 (spans M >> (s + 1) .. M >> (s + K))
-template <int K>
+template <int K, bool PAD = false>
 __device__ inline void fft_dif_pass(double2* x, int M, int s, const double2* __restrict__ tw, bool inverse)
 {
     constexpr int R = 1 << K;
@@ -43,7 +51,7 @@ __device__ inline void fft_dif_pass(double2* x, int M, int s, const double2* __r
         const int i0 = ((t - pos) << K) + pos;
         double2 a[R];
 #pragma unroll
-        for (int j = 0; j < R; j++) a[j] = x[i0 + j * q];
+        for (int j = 0; j < R; j++) a[j] = x[fft_at<PAD>(i0 + j * q)];
 #pragma unroll
         for (int e = 0; e < K; e++) {
             const int half = R >> (e + 1);
@@ -61,13 +69,13 @@ __device__ inline void fft_dif_pass(double2* x, int M, int s, const double2* __r
             }
         }
 #pragma unroll
-        for (int j = 0; j < R; j++) x[i0 + j * q] = a[j];
+        for (int j = 0; j < R; j++) x[fft_at<PAD>(i0 + j * q)] = a[j];
     }
     __syncthreads();
 }
 
 // decimation in time, stages with spans q = 1 << s, 2q, .. (K of them)
-template <int K>
+template <int K, bool PAD = false>
 __device__ inline void fft_dit_pass(double2* x, int M, int s, const double2* __restrict__ tw, bool inverse)
 {
     constexpr int R = 1 << K;
@@ -77,7 +85,7 @@ __device__ inline void fft_dit_pass(double2* x, int M, int s, const double2* __r
         const int i0 = ((t - pos) << K) + pos;
         double2 a[R];
 #pragma unroll
-        for (int j = 0; j < R; j++) a[j] = x[i0 + j * q];
+        for (int j = 0; j < R; j++) a[j] = x[fft_at<PAD>(i0 + j * q)];
 #pragma unroll
         for (int e = 0; e < K; e++) {
             const int half = 1 << e;
@@ -95,32 +103,32 @@ __device__ inline void fft_dit_pass(double2* x, int M, int s, const double2* __r
             }
         }
 #pragma unroll
-        for (int j = 0; j < R; j++) x[i0 + j * q] = a[j];
+        for (int j = 0; j < R; j++) x[fft_at<PAD>(i0 + j * q)] = a[j];
     }
     __syncthreads();
 }
 
-template <int F>
+template <int F, bool PAD = false>
 __device__ inline void fft_dif_fused_k(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
 {
     const int M = 1 << log2m;
     int s = 0;
-    for (; log2m - s >= F; s += F) fft_dif_pass<F>(x, M, s, tw, inverse);
+    for (; log2m - s >= F; s += F) fft_dif_pass<F, PAD>(x, M, s, tw, inverse);
     const int rem = log2m - s;
-    if (rem == 3) fft_dif_pass<3>(x, M, s, tw, inverse);
-    else if (rem == 2) fft_dif_pass<2>(x, M, s, tw, inverse);
-    else if (rem == 1) fft_dif_pass<1>(x, M, s, tw, inverse);
+    if (rem == 3) fft_dif_pass<3, PAD>(x, M, s, tw, inverse);
+    else if (rem == 2) fft_dif_pass<2, PAD>(x, M, s, tw, inverse);
+    else if (rem == 1) fft_dif_pass<1, PAD>(x, M, s, tw, inverse);
 }
 
-template <int F>
+template <int F, bool PAD = false>
 __device__ inline void fft_dit_fused_k(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
 {
     const int M = 1 << log2m;
     const int rem = log2m % F;
-    if (rem == 3) fft_dit_pass<3>(x, M, 0, tw, inverse);
-    else if (rem == 2) fft_dit_pass<2>(x, M, 0, tw, inverse);
-    else if (rem == 1) fft_dit_pass<1>(x, M, 0, tw, inverse);
-    for (int s = rem; s < log2m; s += F) fft_dit_pass<F>(x, M, s, tw, inverse);
+    if (rem == 3) fft_dit_pass<3, PAD>(x, M, 0, tw, inverse);
+    else if (rem == 2) fft_dit_pass<2, PAD>(x, M, 0, tw, inverse);
+    else if (rem == 1) fft_dit_pass<1, PAD>(x, M, 0, tw, inverse);
+    for (int s = rem; s < log2m; s += F) fft_dit_pass<F, PAD>(x, M, s, tw, inverse);
 }
 
 // tw[k] = exp(-2 pi i k / FFT_MAX), k < FFT_MAX / 2 (global memory, L1/L2 resident, built on the host in
@@ -324,10 +332,10 @@ __device__ inline void fft_dit_t_pairs(double2* x, const double2* __restrict__ t
 __device__ inline void fft_dif(double2* x, int log2m, const double2* __restrict__ tw, bool inverse) { fft_dif_pairs(x, log2m, tw, inverse); }
 __device__ inline void fft_dit(double2* x, int log2m, const double2* __restrict__ tw, bool inverse) { fft_dit_pairs(x, log2m, tw, inverse); }
 #if NRHIP_FFT_FUSE > 2
-template <int LOG2M, int NT>
-__device__ inline void fft_dif_t(double2* x, const double2* __restrict__ tw, bool inverse) { fft_dif_fused_k<NRHIP_FFT_FUSE>(x, LOG2M, tw, inverse); }
-template <int LOG2M, int NT>
-__device__ inline void fft_dit_t(double2* x, const double2* __restrict__ tw, bool inverse) { fft_dit_fused_k<NRHIP_FFT_FUSE>(x, LOG2M, tw, inverse); }
+template <int LOG2M, int NT, bool PAD = false>
+__device__ inline void fft_dif_t(double2* x, const double2* __restrict__ tw, bool inverse) { fft_dif_fused_k<NRHIP_FFT_FUSE, PAD>(x, LOG2M, tw, inverse); }
+template <int LOG2M, int NT, bool PAD = false>
+__device__ inline void fft_dit_t(double2* x, const double2* __restrict__ tw, bool inverse) { fft_dit_fused_k<NRHIP_FFT_FUSE, PAD>(x, LOG2M, tw, inverse); }
 #else
 template <int LOG2M, int NT>
 __device__ inline void fft_dif_t(double2* x, const double2* __restrict__ tw, bool inverse) { fft_dif_t_pairs<LOG2M, NT>(x, tw, inverse); }

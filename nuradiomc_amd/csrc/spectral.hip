@@ -789,12 +789,15 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
         __syncthreads();
         ramp = s_ramp;
     }
+    // (the twiddle of the thread's NEXT bin is requested before the current one is used: it comes from L1 / L2)
+    double2 wnext = (threadIdx.x < (unsigned)nh) ? tw[threadIdx.x * (FFT_MAX / N)] : make_double2(1., 0.);
     for (int k = threadIdx.x; k < nh; k += blockDim.x) {
+        const double2 wk = wnext;                // exp(-2 pi i k / N)
+        if (k + (int)blockDim.x < nh) wnext = tw[(k + blockDim.x) * (FFT_MAX / N)];
         double2 Gk = field_bin(k, amp[k], N, fs, pol, rc, rem, shift, ask_model, roll_bins, ramp);
         double2 Gc = cconj(field_bin(nh - k, amp[nh - k], N, fs, pol, rc, rem, shift, ask_model, roll_bins, ramp));
         double2 ge = cscale(cadd(Gk, Gc), 0.5);
         double2 d = cscale(csub(Gk, Gc), 0.5);
-        double2 wk = tw[k * (FFT_MAX / N)];      // exp(-2 pi i k / N)
         double2 go = cmul(d, cconj(wk));         // * exp(+2 pi i k / N)
         x[k] = make_double2(ge.x - go.y, ge.y + go.x);  // ge + i go
     }
@@ -1813,9 +1816,14 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     __shared__ int s_scan[CONV_NT];
     __shared__ int s_first;
     const int N = st.N, nh = N / 2;
+    // the convolution buffer in the padded layout of fft_pad (bank-conflict-free strides of the fused passes and of the bit-reversed
+    // spectrum product): complex element i at PZ(i), real sample n at PS(n); the field buffer and the amplitudes sit behind the
+    // L <= FFT_MAX samples (FFT_MAX / 2 complex elements, padded) until the big transform starts
     double2* z = (double2*)smem;
     double* S = (double*)smem;
-    double2* xs = z + M / 2;
+#define PZ(i) fft_pad(i)
+#define PS(n) (2 * fft_pad((n) >> 1) + ((n) & 1))
+    double2* xs = z + (fft_pad(M / 2) + 8);
     double* amp = (double*)(xs + nh);
     __shared__ RayShared rs;
     __shared__ double red[CONV_NT];
@@ -1891,7 +1899,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             const double2* G = tab.G + (((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[ch] : 0)) * NRHIP_N_ANT_TAB + tb) * NRHIP_G_STRIDE;
             __syncthreads();
             CT(0);
-            for (int n = threadIdx.x; n < L; n += blockDim.x) S[n] = 0.;
+            for (int n = threadIdx.x; n < L; n += blockDim.x) S[PS(n)] = 0.;
             __syncthreads();
             CT(1);
             for (int r = r0; r < r1; r++) {
@@ -1930,17 +1938,17 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                         if (i0 >= L) i0 -= L;
                         int i1 = i0 + 1;
                         if (i1 >= L) i1 -= L;
-                        S[i0] += y.x * c;
-                        S[i1] += y.y * c;
+                        S[PS(i0)] += y.x * c;
+                        S[PS(i1)] += y.y * c;
                     }
                     __syncthreads();
                     CT(4);
                 }
             }
-            for (int n = L + threadIdx.x; n < 2 * M; n += blockDim.x) S[n] = 0.;
+            for (int n = L + threadIdx.x; n < 2 * M; n += blockDim.x) S[PS(n)] = 0.;
             __syncthreads();
             CT(5);
-            fft_dif_t<FFT_LOG2_MAX, CONV_NT>(z, tw, false);
+            fft_dif_t<FFT_LOG2_MAX, CONV_NT, true>(z, tw, false);
             CT(6);
             // split the packed transform into the real one, multiply with G, merge back -- in place on the
             // bit-reversed positions of the pairs (k, M - k)
@@ -1950,7 +1958,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 const double2 Gk = nGk, Gm = nGm, wk = nw;
                 const int kn = k + CONV_NT;
                 if (kn <= M / 2) { nGk = G[kn]; nGm = G[M - kn]; nw = w16[kn]; }
-                const int p = bitrev(k, FFT_LOG2_MAX), q = (k == 0) ? p : bitrev(M - k, FFT_LOG2_MAX);
+                const int p = PZ(bitrev(k, FFT_LOG2_MAX)), q = (k == 0) ? p : PZ(bitrev(M - k, FFT_LOG2_MAX));
                 const double2 A = z[p], Bc = cconj(z[q]);
                 const double2 Ee = cadd(A, Bc), D = csub(A, Bc);
                 const double2 O = make_double2(D.y, -D.x);
@@ -1964,7 +1972,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             }
             if (multi) {  // sum the tables' contributions in the frequency domain (global scratch of this block)
                 __syncthreads();
-                for (int k = threadIdx.x; k < M; k += blockDim.x) acc[k] = first_tab ? z[k] : cadd(acc[k], z[k]);
+                for (int k = threadIdx.x; k < M; k += blockDim.x) acc[k] = first_tab ? z[PZ(k)] : cadd(acc[k], z[PZ(k)]);
                 first_tab = false;
             }
         }
@@ -1977,15 +1985,15 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             }
             if (multi) {
                 __syncthreads();
-                for (int k = threadIdx.x; k < M; k += blockDim.x) z[k] = acc[k];
+                for (int k = threadIdx.x; k < M; k += blockDim.x) z[PZ(k)] = acc[k];
             }
             __syncthreads();
             CT(7);
-            fft_dit_t<FFT_LOG2_MAX, CONV_NT>(z, tw, true);
+            fft_dit_t<FFT_LOG2_MAX, CONV_NT, true>(z, tw, true);
             CT(8);
             if (!coinc) {
                 for (int n = threadIdx.x; n < L; n += blockDim.x) {
-                    double v = S[n] + S[n + L];
+                    double v = S[PS(n)] + S[PS(n + L)];
                     if (out.trace) out.trace[out.trace_offset[item] + n] = v;
                     double av = fabs(v);
                     vmax = fmax(vmax, av);
@@ -1995,23 +2003,23 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 // per-channel flags (simpleThreshold.py:14-29 / highLowThreshold.py:13-80), OR-dilated over the coincidence
                 // window (get_majority_logic :82-150: flag i stays up for w_coinc samples), counted per sample in cnt
                 for (int n = threadIdx.x; n < L; n += blockDim.x) {
-                    double v = S[n] + S[n + L];
+                    double v = S[PS(n)] + S[PS(n + L)];
                     if (out.trace) out.trace[out.trace_offset[item] + n] = v;
                     vmax = fmax(vmax, fabs(v));
-                    S[n] = v;
+                    S[PS(n)] = v;
                 }
                 __syncthreads();
-                int* A = (int*)(S + M);  // index of the last raised flag at or before sample i (-1: none)
+                int* A = (int*)(S + 2 * (fft_pad(M / 2) + 8));  // index of the last raised flag at or before sample i (-1: none); behind the trace
                 const int nb = (trg.type == 0) ? L : L - 1;
                 for (int i = threadIdx.x; i < nb; i += blockDim.x) {
                     bool flag;
                     if (trg.type == 0) {
-                        flag = fabs(S[i]) >= threshold;
+                        flag = fabs(S[PS(i)]) >= threshold;
                     } else {
                         bool hi = false, lo = false;
                         for (int k = max(0, i - trg.w_hl + 1); k <= i; k++) {
-                            hi = hi || (S[k] >= trg.high);
-                            lo = lo || (S[k] <= trg.low);
+                            hi = hi || (S[PS(k)] >= trg.high);
+                            lo = lo || (S[PS(k)] <= trg.low);
                         }
                         if (i - trg.w_hl + 1 < 0) {  // the reference pads with zeros in front
                             hi = hi || (0. >= trg.high);
@@ -2072,6 +2080,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       }
     }
 }
+#undef PZ
+#undef PS
 
 // y_j = e[2j] + i e[2j+1] of a real N-sample trace in HBM, optionally delayed by the sub-sample remainder `rem` through the
 // Fourier shift theorem on the N grid (rfft -> * exp(-2 pi i f rem) -> irfft, base_trace.py:273-276).  Without the shift the
@@ -2866,7 +2876,7 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)length_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               FFT_MAX * 16 + (FFT_MAX / 2 + 1) * 8);
-    (void)hipFuncSetAttribute((const void*)channel_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)channel_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_PADDED_MAX * 16);
     (void)hipFuncSetAttribute((const void*)ray_envelope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (FFT_MAX / 2) * 16 + (FFT_MAX / 4 + 1) * 8);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
@@ -2923,7 +2933,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
         hipLaunchKernelGGL(scatter_item_list_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, ev_need, need_offset,
                            item_list);
         int cgrid = n_cand < channel_grid_blocks() ? n_cand : channel_grid_blocks();
-        hipLaunchKernelGGL(channel_conv_kernel, dim3(cgrid), dim3(CONV_NT), (size_t)FFT_MAX * 16, s, need_offset + n_cand,
+        hipLaunchKernelGGL(channel_conv_kernel, dim3(cgrid), dim3(CONV_NT), (size_t)FFT_PADDED_MAX * 16, s, need_offset + n_cand,
                            item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16, tab,
                            ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count,
                        ev_need + n_cand /* the scan's zero sentinel: free again, and 0 */);
