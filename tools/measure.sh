@@ -19,7 +19,7 @@ cp $(find $OUT/stats -name 'x_kernel_stats.csv' | head -1) $OUT/r02_rocprofv3_ke
 rm -rf $OUT/pmc_fetch $OUT/pmc_write; find $OUT -name '*.db' -delete; find $OUT -name '*_kernel_trace.csv' -delete
 python3 bench.py > $OUT/bench_config2.json 2> $OUT/bench_config2.log
 if [ "$1" = "prof" ]; then ls -la $OUT; exit 0; fi
-python3 bench.py --flavour mixed --no-cpu-baseline > $OUT/bench_config2_mixed.json 2>> $OUT/bench_config2.log
+python3 bench.py --flavour mixed > $OUT/bench_config2_mixed.json 2>> $OUT/bench_config2.log
 python3 bench.py --scaling strong --no-cpu-baseline > $OUT/bench_config2_strong.json 2>> $OUT/bench_config2.log
 python3 bench.py --config 3 > $OUT/bench_config3.json 2> $OUT/bench_config3.log
 python3 bench.py --config 5 > $OUT/bench_config5.json 2> $OUT/bench_config5.log
