@@ -186,13 +186,30 @@ def free_events(ctx, d):
 
 
 def _oracle_chunk(args):
-    """one chunk of the CPU baseline (worker process): the oracle's chain over consecutive event groups of config 2"""
-    (ev, lo, hi, flavour) = args
+    """one chunk of the CPU baseline (worker process): the oracle's chain over consecutive event groups -- one station (config 2)
+    or the station loop over an array (configs 3 and 5: a group is triggered when any station triggers)"""
+    (ev, lo, hi, flavour, arr) = args
     from oracle import spectral_oracle as so   # checker / baseline only
-    st = so.Station(CHANNELS, n_samples=N_SAMPLES, fs=FS)
-    vrms, vrms_e = so.vrms_from_filters(FS)
     out = np.zeros(hi - lo, np.uint8)
     grp = ev['group']
+    if arr is not None:
+        vrms, vrms_e = so.vrms_from_filters(arr['fs'])
+        skw = dict(antenna=arr['antenna'], orientation=arr['orientation'], cable_delay=arr['cable_delay'], n_samples=arr['N'], fs=arr['fs'])
+        trig = None
+        if arr['trigger'] == 'high_low':
+            trig = dict(trigger='high_low', n_coincidences=arr['n_coincidences'], threshold_high=3 * vrms, threshold_low=-3 * vrms,
+                        high_low_window=5., coinc_window=arr['coinc_window'])
+        for g in range(lo, hi):
+            a, b = np.searchsorted(grp, g), np.searchsorted(grp, g + 1)
+            sh = [dict(vertex=ev['vertex'][i], zenith=ev['zenith'][i], azimuth=ev['azimuth'][i], energy=ev['energy'][i],
+                       shower_type='HAD' if ev['shower_type'][i] == 0 else 'EM', k_L=ev['k_L'][i]) for i in range(a, b)]
+            res = so.simulate_event_group_array(sh, arr['centres'], arr['rel_pos'], arr['ice'], vrms, vrms_e, station_kw=skw,
+                                                att_model=arr['att_model'], n_freq=25, distance_cut_coefficients=DCUT,
+                                                trigger=trig)
+            out[g - lo] = any(o['triggered'] for o in res)
+        return lo, out
+    st = so.Station(CHANNELS, n_samples=N_SAMPLES, fs=FS)
+    vrms, vrms_e = so.vrms_from_filters(FS)
     for g in range(lo, hi):
         a, b = np.searchsorted(grp, g), np.searchsorted(grp, g + 1)
         if flavour == 'had':
@@ -212,12 +229,18 @@ def cpu_baseline(wl, budget_s, n_max, cores=None):
     import multiprocessing as mp
     cores = cores or usable_cores()
     ev, grp = wl['events'], wl['events']['group']
-    chunk = 125
+    arr = None
+    if wl['centres'] is not None:   # arrays: every group visits every station (the distance cut drops most of them quickly)
+        arr = dict(centres=wl['centres'], rel_pos=wl['rel_pos'], antenna=wl['antenna'], orientation=wl['orientation'],
+                   cable_delay=wl['cable_delay'], N=wl['N'], fs=wl['fs'], ice=wl['ice'], att_model=wl['att_model'],
+                   trigger=wl['sim_kw'].get('trigger', 'simple'), n_coincidences=wl['sim_kw'].get('n_coincidences', 1),
+                   coinc_window=wl['sim_kw'].get('coinc_window', 200.))
+    chunk = 125 if arr is None else 4
 
     def job(lo):
         hi = min(lo + chunk, n_max)
         a, b = np.searchsorted(grp, lo), np.searchsorted(grp, hi)
-        return ({k: v[a:b] for k, v in ev.items()}, lo, hi, wl['flavour'])
+        return ({k: v[a:b] for k, v in ev.items()}, lo, hi, wl['flavour'], arr)
     jobs = (job(lo) for lo in range(0, n_max, chunk))
     done = {}
     os.environ.setdefault('OMP_NUM_THREADS', '1')
@@ -439,7 +462,7 @@ def main():
                                     "algorithmic_flops_per_launch": stats['n_integrand_evals'] * flop_per_eval,
                                     "hbm_view_GBs": achieved})
         out["cpu_baseline"] = None
-        if world == 1 and cfgno == 2 and not args.no_cpu_baseline:
+        if world == 1 and cfgno in (2, 3, 5) and not args.no_cpu_baseline:
             base, n_done, flags = cpu_baseline(wl, args.cpu_budget, min(n_groups, 200000))
             host_mask = np.zeros(n_groups, np.uint8)
             ctx.to_host(host_mask, d['trig'])
