@@ -87,6 +87,9 @@ struct nrhip_station {
     nrhip::PaAdc pa_adc;           // trigger ADC + up-sampling of the phased array (nrhip_station_set_phased_array_adc)
     bool pa_adc_set = false;
     DevArray d_pa_rolls_up;        // beam rolls at the up-sampled ADC rate
+    DevArray pa_B;                 // Bluestein tables of the chirp-z digitiser [slot of tabcache][4][FFT_MAX]
+    std::vector<char> pa_built;    // per slot: tables present
+    int pa_B_cap = 0;
     DevArray d_noise_amp;          // per-channel amplitude of the noise adder (nrhip_station_set_noise)
     bool noise_set = false;
     int pa_n_channels = 0, pa_n_beams = 0, pa_window = 0, pa_step = 0, pa_divisor = 0;

@@ -341,6 +341,7 @@ void nrhip_station_detach(nrhip_station* s)
     s->tabcache.release();
     s->d_noise_amp.release();
     s->d_pa_rolls_up.release();
+    s->pa_B.release();
     s->ws.clear();
     s->ws_bytes.clear();
     s->ctx->stations.erase(s);
@@ -433,6 +434,7 @@ int nrhip_station_set_phased_array_adc(nrhip_station* s, double adc_fs, int32_t 
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
     s->pa_adc = PaAdc{adc_fs, v_min, v_max, n_bits, output_counts ? 1 : 0, upsampling_factor, saturation_bits, resample_p, resample_q, 0};
     s->pa_adc_set = true;
+    s->pa_built.clear();   // the digitiser's transform tables depend on these rates
     return 0;
 }
 
@@ -1334,6 +1336,43 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                 int* pa_len;
                 NEED(pa_trace = WS("pa_digital_trace", double, (size_t)n_cand * st->pa_n_channels * adc.stride));
                 NEED(pa_len = WS("pa_digital_length", int, (size_t)n_cand * st->pa_n_channels));
+                if (pa_czt_applies(maxL, sd.fs, adc) && !getenv("NRHIP_PA_DIRECT")) {
+                    // chirp-z transforms; their tables join the station's per-length cache (same slots)
+                    if (st->pa_B_cap < tc.cap) {
+                        DevArray fresh;
+                        if (fresh.reserve((size_t)tc.cap * 4 * FFT_MAX * 16) != hipSuccess)
+                            return nrhip_fail_msg("nrhip_simulate_events: out of device memory (digitiser tables)");
+                        if (st->pa_B_cap > 0)
+                            HIPCHK(hipMemcpyAsync(fresh.p, st->pa_B.p, (size_t)st->pa_B_cap * 4 * FFT_MAX * 16, hipMemcpyDeviceToDevice, sm));
+                        HIPCHK(hipStreamSynchronize(sm));
+                        st->pa_B.release();
+                        st->pa_B = fresh;
+                        st->pa_B_cap = tc.cap;
+                    }
+                    st->pa_built.resize((size_t)tc.cap, 0);
+                    std::vector<int> pl, ps;
+                    for (int L_ : lens) {
+                        const int slot = tc.slot_of[L_ / 2];
+                        if (!st->pa_built[slot]) { st->pa_built[slot] = 1; pl.push_back(L_); ps.push_back(slot); }
+                    }
+                    if (!pl.empty()) {
+                        int *d_pl, *d_ps;
+                        NEED(d_pl = WS("pa_new_lengths", int, pl.size()));
+                        NEED(d_ps = WS("pa_new_slots", int, ps.size()));
+                        HIPCHK(hipMemcpyAsync(d_pl, pl.data(), sizeof(int) * pl.size(), hipMemcpyHostToDevice, sm));
+                        HIPCHK(hipMemcpyAsync(d_ps, ps.data(), sizeof(int) * ps.size(), hipMemcpyHostToDevice, sm));
+                        launch_pa_czt_tables(sm, (int)pl.size(), d_pl, d_ps, sd.fs, adc, ctx->twiddle, st->pa_B.as<double2>());
+                        HIPCHK(hipStreamSynchronize(sm));
+                    }
+                    const int chunk = std::min<long>((long)n_cand * st->pa_n_channels, 16384);
+                    unsigned char* work;
+                    NEED(work = WS("pa_digitiser_work", unsigned char, pa_czt_work_bytes(maxL, sd.fs, adc, chunk)));
+                    launch_phased_array_digital_czt(sm, n_cand, d_cand, n_ch, ev.L, tc.slotmap.as<int>(), co.trace, co.trace_offset,
+                                                    st->pa_n_channels, st->d_pa_channel.as<int>(), st->pa_n_beams,
+                                                    st->d_pa_rolls_up.as<int>(), st->pa_window, st->pa_step, (double)st->pa_divisor,
+                                                    cfg->trigger_threshold, maxL, sd.fs, adc, ctx->twiddle, st->pa_B.as<double2>(), work,
+                                                    chunk, pa_trace, pa_len, triggered, pa_max);
+                } else
                 launch_phased_array_digital(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, st->pa_n_channels,
                                             st->d_pa_channel.as<int>(), st->pa_n_beams, st->d_pa_rolls_up.as<int>(), st->pa_window,
                                             st->pa_step, (double)st->pa_divisor, cfg->trigger_threshold, maxL, sd.fs, adc, pa_trace, pa_len,

@@ -205,6 +205,16 @@ struct PaAdc {
     double adc_fs, vmin, vmax;   // ADC sampling rate [GHz], voltage range
     int n_bits, counts, upsampling, saturation_bits, p, q, stride;  // 5 GHz / f_s = p / q; stride: samples per output trace
 };
+// the chirp-z version of the same chain (O(L log L) transforms; tables per trace length in the station's cache)
+bool pa_czt_applies(int max_length, double fs, const PaAdc& adc);
+size_t pa_czt_work_bytes(int max_length, double fs, const PaAdc& adc, int chunk);
+void launch_pa_czt_tables(hipStream_t s, int n_len, const int* lens, const int* slots, double fs, const PaAdc& adc, const double2* tw,
+                          double2* Btab);
+void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const int* slotmap,
+                                     const double* trace, const long* trace_offset, int n_pa, const int* pa_channel, int n_beams,
+                                     const int* rolls_up, int window, int step, double divisor, double threshold, int max_length, double fs,
+                                     const PaAdc& adc, const double2* tw, const double2* Btab, void* work, int chunk, double* pa_trace,
+                                     int* pa_len, unsigned char* triggered, double* pa_max);
 void launch_phased_array_digital(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                                  const long* trace_offset, int n_pa, const int* pa_channel, int n_beams, const int* rolls_up, int window,
                                  int step, double divisor, double threshold, int max_length, double fs, const PaAdc& adc,

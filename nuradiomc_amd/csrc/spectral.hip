@@ -3373,6 +3373,154 @@ pa_digitize_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same chain through the in-LDS chirp-z transform (O(L log L) per transform instead of the direct sums): four transforms per
+// item, each "out[k] = sum_j in[j] exp(sgn 2 pi i j k / Q)" evaluated in blocks of P outputs with one Bluestein table per
+// (trace length, stage):
+//   stage 1: the trace's spectrum              n_in = L,            Q = L,      sgn -, P = FFT_MAX - L + 1
+//   stage 2: the 5 GHz samples                 n_in = L / 2 + 1,    Q = num2,   sgn +, P = FFT_MAX - L / 2      (real part)
+//   stage 3: (no transform) linear interpolation at the ADC times + floor comparator
+//   stage 4: the ADC trace's spectrum          n_in = n_dig,        Q = n_dig,  sgn -, P = FFT_MAX - n_dig + 1
+//   stage 5: the up-sampled trace              n_in = n_dig / 2 + 1, Q = n_up,  sgn +, P = FFT_MAX - n_dig / 2  (real part, rounded for counts)
+// Blocks after the first shift the input by exp(sgn 2 pi i j k0 / Q).  Intermediate arrays live in HBM (a few 100 KB per item).
+// ---------------------------------------------------------------------------------------------------------
+struct PaSizes { int L, m, n_dig, n_up; long num2, len5; };
+__device__ __host__ inline PaSizes pa_sizes(int L, double fs, const PaAdc& adc)
+{
+    PaSizes z;
+    z.L = L;
+    z.m = L / 2;
+    long n1 = (adc.p != 1) ? (long)adc.p * L : L;
+    z.num2 = (adc.q != 1) ? n1 / adc.q : n1;
+    z.len5 = z.num2 - (z.num2 & 1);
+    const int n_adc = (int)((adc.adc_fs / 5.0) * (double)z.len5);
+    z.n_dig = n_adc - (n_adc & 1);
+    z.n_up = z.n_dig * (adc.upsampling >= 2 ? adc.upsampling : 1);
+    return z;
+}
+// stage -> (n_in, Q, sgn, P, n_out)
+__device__ __host__ inline void pa_stage(const PaSizes& z, int stage, int* n_in, long* Q, double* sgn, int* P, long* n_out)
+{
+    if (stage == 1) { *n_in = z.L; *Q = z.L; *sgn = -1.; *P = FFT_MAX - z.L + 1; *n_out = z.m + 1; }
+    else if (stage == 2) { *n_in = z.m + 1; *Q = z.num2; *sgn = 1.; *P = FFT_MAX - z.m; *n_out = z.len5; }
+    else if (stage == 4) { *n_in = z.n_dig; *Q = z.n_dig; *sgn = -1.; *P = FFT_MAX - z.n_dig + 1; *n_out = z.n_dig / 2 + 1; }
+    else { *n_in = z.n_dig / 2 + 1; *Q = z.n_up; *sgn = 1.; *P = FFT_MAX - z.n_dig / 2; *n_out = z.n_up; }
+}
+
+struct PaWork {
+    double2* X;      // [item][xs]   trace spectra
+    double* x5;      // [item][s5]   5 GHz samples
+    double* d;       // [item][sd]   ADC traces
+    double2* D;      // [item][sd / 2 + 1]
+    int xs, s5, sd;
+};
+
+// Bluestein tables of the lengths in `lens` (slots of the station's table cache): [slot][4][FFT_MAX]
+__global__ void __launch_bounds__(1024)
+pa_tables_kernel(int n_len, const int* __restrict__ lens, const int* __restrict__ slots, double fs, PaAdc adc,
+                 const double2* __restrict__ tw, double2* __restrict__ Btab)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* x = (double2*)smem;
+    const int il = blockIdx.x, st = blockIdx.y;   // stage index 0..3 -> stages 1, 2, 4, 5
+    if (il >= n_len) return;
+    const PaSizes z = pa_sizes(lens[il], fs, adc);
+    int n_in, P;
+    long Q, n_out;
+    double sgn;
+    pa_stage(z, st < 2 ? st + 1 : st + 2, &n_in, &Q, &sgn, &P, &n_out);
+    if (P < 1) return;
+    czt_build_table(x, FFT_LOG2_MAX, n_in, P, Q, sgn, tw);
+    double2* B = Btab + ((long)slots[il] * 4 + st) * FFT_MAX;
+    for (int i = threadIdx.x; i < FFT_MAX; i += blockDim.x) B[i] = x[i];
+}
+
+__global__ void __launch_bounds__(512)
+pa_czt_stage_kernel(int stage, int item0, int n_cand, const int* __restrict__ item_event, int n_ch, const int* __restrict__ ev_L,
+                    const int* __restrict__ slotmap, const double* __restrict__ trace, const long* __restrict__ trace_offset, int n_pa,
+                    const int* __restrict__ pa_channel, double fs, PaAdc adc, const double2* __restrict__ tw,
+                    const double2* __restrict__ Btab, PaWork wk, double* __restrict__ pa_trace)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* x = (double2*)smem;
+    const int item = item0 + blockIdx.x, n_items = n_cand * n_pa, wi = blockIdx.x;   // wi: row of the chunk's work arrays
+    if (item >= n_items) return;
+    const int ic = item / n_pa, c = item % n_pa;
+    const int e = item_event[ic], L = ev_L[e];
+    const PaSizes z = pa_sizes(L, fs, adc);
+    int n_in, P;
+    long Q, n_out;
+    double sgn;
+    pa_stage(z, stage, &n_in, &Q, &sgn, &P, &n_out);
+    const long k0 = (long)blockIdx.y * P;
+    if (k0 >= n_out) return;
+    const int st = stage < 3 ? stage - 1 : stage - 2;
+    const double2* B = Btab + ((long)slotmap[L / 2] * 4 + st) * FFT_MAX;
+    const double* tr = trace + trace_offset[(long)ic * n_ch + pa_channel[c]];
+    const double2* Xi = wk.X + (long)wi * wk.xs;
+    const double* di = wk.d + (long)wi * wk.sd;
+    const double2* Di = wk.D + (long)wi * (wk.sd / 2 + 1);
+    for (int j = threadIdx.x; j < FFT_MAX; j += blockDim.x) {
+        double2 v = make_double2(0., 0.);
+        if (j < n_in) {
+            if (stage == 1) v = make_double2(tr[j], 0.);
+            else if (stage == 2) v = cscale(Xi[j], ((j == 0 || j == z.m) ? 1. : 2.) / z.L);
+            else if (stage == 4) v = make_double2(di[j], 0.);
+            else v = cscale(Di[j], ((j == 0 || j == z.n_dig / 2) ? 1. : 2.) / z.n_dig);
+            v = cmul(v, chirp(j, Q, sgn));
+            if (k0) {   // outputs k0 .. : in[j] exp(sgn 2 pi i j k0 / Q)
+                double sn, cs;
+                sincospi(2. * (double)(((long long)j * k0) % Q) / (double)Q, &sn, &cs);
+                v = cmul(v, make_double2(cs, sgn * sn));
+            }
+        }
+        x[j] = v;
+    }
+    __syncthreads();
+    czt_convolve_t<512>(x, B, tw);
+    const long cnt = (n_out - k0 < P) ? n_out - k0 : P;
+    for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
+        // out[k0 + k] = chirp(k) x[k] / M  (the chirp belongs to the shifted problem: index k)
+        const double2 o = cscale(cmul(x[k], chirp(k, Q, sgn)), 1.0 / FFT_MAX);
+        if (stage == 1) wk.X[(long)wi * wk.xs + k0 + k] = o;
+        else if (stage == 2) wk.x5[(long)wi * wk.s5 + k0 + k] = o.x;
+        else if (stage == 4) wk.D[(long)wi * (wk.sd / 2 + 1) + k0 + k] = o;
+        else pa_trace[(long)item * adc.stride + k0 + k] = adc.counts ? rint(o.x) : o.x;
+    }
+}
+
+// stage 3: the ADC samples from the 5 GHz samples (downsampling_linear_interpolation + perfect_floor_comparator)
+__global__ void __launch_bounds__(256)
+pa_adc_sample_kernel(int item0, int n_cand, const int* __restrict__ item_event, const int* __restrict__ ev_L, int n_pa, double fs,
+                     PaAdc adc, PaWork wk, double* __restrict__ pa_trace, int* __restrict__ pa_len)
+{
+    const int item = item0 + blockIdx.x, n_items = n_cand * n_pa, wi = blockIdx.x;
+    if (item >= n_items) return;
+    const int e = item_event[item / n_pa];
+    const PaSizes z = pa_sizes(ev_L[e], fs, adc);
+    const double* x5 = wk.x5 + (long)wi * wk.s5;
+    const double lsb = (adc.vmax - adc.vmin) / (double)((1 << adc.n_bits) - 1);
+    const double vmin_adc = floor(adc.vmin / lsb);
+    for (int j = threadIdx.x; j < z.n_dig; j += blockDim.x) {
+        const double tn = (double)j / adc.adc_fs;
+        long lo = (long)floor(tn * 5.0);
+        while (lo > 0 && (double)lo / 5.0 >= tn) lo--;          // times[lo] < t <= times[lo + 1] (searchsorted, side 'left')
+        while ((double)(lo + 1) / 5.0 < tn) lo++;
+        if (lo > z.len5 - 2) lo = z.len5 - 2;
+        if (lo < 0) lo = 0;
+        const double xlo = (double)lo / 5.0, xhi = (double)(lo + 1) / 5.0;
+        const double ylo = x5[lo], yhi = x5[lo + 1];
+        const double slope = (yhi - ylo) / (xhi - xlo);
+        const double v = slope * (tn - xlo) + ylo;
+        double cnt = floor((v - adc.vmin) / lsb);
+        cnt = fmin(fmax(cnt, 0.), (double)((1 << adc.n_bits) - 1)) + vmin_adc;
+        const double dv = adc.counts ? cnt : lsb * cnt;
+        wk.d[(long)wi * wk.sd + j] = dv;
+        if (adc.upsampling < 2) pa_trace[(long)item * adc.stride + j] = dv;
+    }
+    if (threadIdx.x == 0) pa_len[item] = z.n_up - (z.n_up & 1);
+}
+
 // beams and power windows on the digitised, up-sampled traces (phase_signals with the saturation of ADC counts :183-215,
 // power_sum with its rounding :217-271, the decision of phased_trigger :455-496)
 __global__ void __launch_bounds__(256)
@@ -3432,6 +3580,73 @@ void launch_phased_array_digital(hipStream_t s, int n_cand, const int* item_even
     const int n_items = n_cand * n_pa;
     hipLaunchKernelGGL(pa_digitize_kernel, dim3(n_items < 4096 ? n_items : 4096), dim3(1024), lds1, s, n_cand, item_event, n_ch, ev_L, trace,
                        trace_offset, n_pa, pa_channel, fs, adc, pa_trace, pa_len);
+    hipLaunchKernelGGL(phased_array_digital_kernel, dim3(n_cand < 4096 ? n_cand : 4096), dim3(256), (size_t)adc.stride * 8 + 64, s, n_cand,
+                       item_event, pa_trace, pa_len, n_pa, n_beams, rolls_up, window, step, divisor, threshold, adc, triggered, pa_max);
+}
+
+// whether the chirp-z digitiser takes this configuration: resampling through 5 GHz, transforms with at least 1024 outputs per block
+bool pa_czt_applies(int max_length, double fs, const PaAdc& adc)
+{
+    const bool resampled = !(fabs(adc.adc_fs - fs) <= 1e-8 + 1e-5 * fabs(fs));
+    if (!resampled || !(5.0 > fs)) return false;
+    const PaSizes z = pa_sizes(max_length, fs, adc);
+    return max_length <= FFT_MAX - 1023 && z.n_dig <= FFT_MAX - 1023 && z.n_dig >= 2;
+}
+
+size_t pa_czt_work_bytes(int max_length, double fs, const PaAdc& adc, int chunk)
+{
+    const PaSizes z = pa_sizes(max_length, fs, adc);
+    const size_t xs = z.m + 2, s5 = z.num2 + 2, sd = z.n_dig + 4;
+    return (size_t)chunk * (xs * 16 + s5 * 8 + sd * 8 + (sd / 2 + 1) * 16) + 256;
+}
+
+void launch_pa_czt_tables(hipStream_t s, int n_len, const int* lens, const int* slots, double fs, const PaAdc& adc, const double2* tw,
+                          double2* Btab)
+{
+    if (n_len <= 0) return;
+    set_big_lds();
+    (void)hipFuncSetAttribute((const void*)pa_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    hipLaunchKernelGGL(pa_tables_kernel, dim3(n_len, 4), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lens, slots, fs, adc, tw, Btab);
+}
+
+void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const int* slotmap,
+                                     const double* trace, const long* trace_offset, int n_pa, const int* pa_channel, int n_beams,
+                                     const int* rolls_up, int window, int step, double divisor, double threshold, int max_length, double fs,
+                                     const PaAdc& adc, const double2* tw, const double2* Btab, void* work, int chunk, double* pa_trace,
+                                     int* pa_len, unsigned char* triggered, double* pa_max)
+{
+    if (n_cand <= 0) return;
+    set_big_lds();
+    (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)phased_array_digital_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, adc.stride * 8 + 64);
+    const PaSizes z = pa_sizes(max_length, fs, adc);
+    PaWork wk;
+    wk.xs = z.m + 2; wk.s5 = (int)z.num2 + 2; wk.sd = z.n_dig + 4;
+    unsigned char* w = (unsigned char*)work;
+    wk.X = (double2*)w;                 w += (size_t)chunk * wk.xs * 16;
+    wk.D = (double2*)w;                 w += (size_t)chunk * (wk.sd / 2 + 1) * 16;
+    wk.x5 = (double*)w;                 w += (size_t)chunk * wk.s5 * 8;
+    wk.d = (double*)w;
+    const int n_items = n_cand * n_pa;
+    auto blocks = [&](int stage) {   // output blocks of the longest trace
+        int n_in, P; long Q, n_out; double sgn;
+        pa_stage(z, stage, &n_in, &Q, &sgn, &P, &n_out);
+        // P shrinks and n_out grows with the length: the longest trace needs the most blocks
+        return (unsigned)((n_out + P - 1) / P);
+    };
+    for (int item0 = 0; item0 < n_items; item0 += chunk) {
+        const unsigned nb = (unsigned)std::min(chunk, n_items - item0);
+        for (int stage = 1; stage <= 5; stage++) {
+            if (stage == 3) {
+                hipLaunchKernelGGL(pa_adc_sample_kernel, dim3(nb), dim3(256), 0, s, item0, n_cand, item_event, ev_L, n_pa, fs, adc, wk,
+                                   pa_trace, pa_len);
+                if (adc.upsampling < 2) break;
+                continue;
+            }
+            hipLaunchKernelGGL(pa_czt_stage_kernel, dim3(nb, blocks(stage)), dim3(512), (size_t)FFT_MAX * 16, s, stage, item0, n_cand,
+                               item_event, n_ch, ev_L, slotmap, trace, trace_offset, n_pa, pa_channel, fs, adc, tw, Btab, wk, pa_trace);
+        }
+    }
     hipLaunchKernelGGL(phased_array_digital_kernel, dim3(n_cand < 4096 ? n_cand : 4096), dim3(256), (size_t)adc.stride * 8 + 64, s, n_cand,
                        item_event, pa_trace, pa_len, n_pa, n_beams, rolls_up, window, step, divisor, threshold, adc, triggered, pa_max);
 }

@@ -1349,3 +1349,15 @@ def test_phased_array_with_trigger_adc(gpu_ctx_factory, output, up):
     assert len(item_event) >= 15 and 2 <= n_trig < len(item_event)
     trig_p, _ = st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold)
     assert np.array_equal(trig_p, trig)
+    # the direct-sum digitiser (what traces beyond the chirp-z version's 7169 samples or without the 5 GHz step go through)
+    import os
+    os.environ['NRHIP_PA_DIRECT'] = '1'
+    try:
+        trig_d, _ = st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold, dump_traces=True)
+        dig_d = st.fetch('pa_digital_trace').reshape(len(item_event), 4, stride)
+    finally:
+        del os.environ['NRHIP_PA_DIRECT']
+    assert np.array_equal(trig_d, trig)
+    for i in range(len(item_event)):
+        n_up = dlen[i, 0]
+        assert np.max(np.abs(dig_d[i, :, :n_up] - dig[i, :, :n_up])) <= (0 if output == 'counts' else 1e-9 * lsb)
