@@ -14,6 +14,7 @@
 // FP64 VALU / transcendental bound: ~24 B of HBM traffic per observer time against 1e3..1e5 exp/pow evaluations.
 #include <hip/hip_runtime.h>
 #include "arz.h"
+#include "detmath.h"
 
 namespace nrhip {
 
@@ -27,7 +28,35 @@ static __device__ const double ARZ_C = 0.299792458;               // m / ns (:33
 struct ArzRay {
     double X0, X2, R0, xntot, E_TeV, em_factor;
     double Af, freq_pos, freq_neg, exp_pos, exp_neg, t0_pos, t0_neg;
+    double K, inv_t0_pos, inv_t0_neg;   // Af E_TeV fc / xntot em_factor; 1 / t0
 };
+
+// The same integrand with the per-ray constants folded (one reciprocal of R instead of six divisions) and x^e as exp(e log x)
+// through the table-free exp / log of detmath.h (<= 1 ulp each; |e log x| < 20, so the power is good to 1e-14): the
+// evaluation count of the time-domain model is ~1e6 per ray, all of it this function.  The values differ from the spelling
+// above by rounding only (1e-13 of the trace maximum measured against the reference's traces).
+__device__ __forceinline__ void arz_integrand_fast(const ArzRay& r, double depth, double q, double tobs, double n_index,
+                                                   double* yx, double* yz)
+{
+    const double z = depth * (1. / ARZ_RHO);
+    const double dz = r.X2 - z;
+    const double R2 = r.X0 * r.X0 + dz * dz;
+    const double invR = rsqrt(R2);
+    const double R = R2 * invR;
+    const double t = ((ARZ_C * tobs - n_index * R) - z) * (1. / ARZ_C);
+    double F = 0.;
+    if (t < 20. && t > -20.) {
+        const double a = fabs(t);
+        const bool pos = t > 0;
+        const double e1 = det_exp_inrange(fmax(-a * (pos ? r.inv_t0_pos : r.inv_t0_neg), -745.));
+        const double e2 = det_exp_inrange((pos ? r.exp_pos : r.exp_neg) * det_log(1. + (pos ? r.freq_pos : r.freq_neg) * a));
+        F = r.K * (e1 + e2);
+    }
+    const double ux = r.X0 * invR;
+    const double g = ux * q * F * invR;
+    *yx = -((dz * invR) * g);
+    *yz = ux * g;
+}
 
 // integrand -v Q F_p / R at shower depth `depth` (g/cm^2 in internal units) for observer time tobs: x and z components
 __device__ inline void arz_integrand(const ArzRay& r, double depth, double q, double tobs, double n_index, double fc,
@@ -84,6 +113,9 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
     const int nd = b.n_depth;
     double* s_depth = lds;
     double* s_ce = lds + nd;
+    double* s_slope = lds + 2 * nd;   // slope of the profile between nodes k and k + 1 (np.interp's own expression)
+    double* s_z = lds + 3 * nd;       // depth / rho: position along the shower axis
+    double* s_nR = lds + 4 * nd;      // n * distance from the node to the observer
     __shared__ double s_w[4][4];   // per wave: sum, max value, h min, h max
     __shared__ int s_wi[4];        // per wave: index of the max
     const int nt = b.N + 1;
@@ -112,6 +144,7 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
     }
     if (lane == 0) { s_w[wave][0] = part; s_w[wave][1] = bestv; s_wi[wave] = best; }
     __syncthreads();
+    for (int i = threadIdx.x; i < nd - 1; i += blockDim.x) s_slope[i] = (s_ce[i + 1] - s_ce[i]) / (s_depth[i + 1] - s_depth[i]);
     double sum = 0.;
     int im = 0x7fffffff;
     {
@@ -155,6 +188,16 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
     }
     const double fc = 4. * M_PI / (ARZ_XMU * sin(acos(1. / nidx)));
     const double factor = -ARZ_XMU / (4. * M_PI);
+    r.K = r.Af * r.E_TeV * fc / r.xntot * r.em_factor;
+    r.inv_t0_pos = 1. / r.t0_pos;
+    r.inv_t0_neg = 1. / r.t0_neg;
+    const double inv_coarse = 1. / (s_depth[1] - s_depth[0]);
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) {
+        const double z = s_depth[i] / ARZ_RHO;
+        s_z[i] = z;
+        s_nR[i] = nidx * sqrt(r.X0 * r.X0 + (r.X2 - z) * (r.X2 - z));
+    }
+    __syncthreads();
     // observer times: arange(0, (N + 1) dt, dt) + dt / 2 - mean (:98-102)
     const int nt_raw = (int)ceil(((b.N + 1) * b.dt - 0.) / b.dt);
     const double mean = b.dt * (nt_raw - 1) * 0.5;
@@ -168,45 +211,52 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
         const double t_bin = it * b.dt + 0.5 * b.dt - mean;
         if (t_bin - hmax > 20.001 || t_bin - hmin < -20.001) continue;  // vp stays 0 (memset by the launcher)
         const double tobs = t_bin + (r.R0 / ARZ_C * nidx);
-        // pass 1 over the profile nodes: anything within +-20 ns?  where does the +-1 ns condition flip?
-        int idx[18];
-        int ni = 0;
+        const double ct = ARZ_C * tobs;
+        // pass 1 over the profile nodes: anything within +-20 ns?  where does the +-1 ns condition flip?  The flip positions are
+        // wave-uniform; only the first five are kept (more than four is the reference's NotImplementedError), in scalars
+        int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0, ni = 0;
+        auto push = [&](int v) {
+            if (ni == 0) i0 = v; else if (ni == 1) i1 = v; else if (ni == 2) i2 = v; else if (ni == 3) i3 = v; else if (ni == 4) i4 = v;
+            ni++;
+        };
         bool any20 = false, first_in = false;
         int prev_last = 0;
         for (int base = 0; base < nd; base += 64) {
             const int i = base + lane;
             double t = 1e300;
-            if (i < nd) t = arz_tt(r, s_depth[i], tobs, nidx);
+            if (i < nd) t = -(s_z[i] - (ct - s_nR[i])) / ARZ_C;
             const unsigned long long B20 = __ballot(t < 20. && t > -20.);
             const unsigned long long B1 = __ballot(t < 1. && t > -1.);
             any20 |= (B20 != 0ull);
             if (base == 0) first_in = (B1 & 1ull) != 0;
             const int cnt = min(64, nd - base);
             // flips between node base - 1 and base, then inside the chunk
-            if (base > 0 && (prev_last != (int)(B1 & 1ull)) && ni < 16) idx[ni++] = base - 1;
+            if (base > 0 && (prev_last != (int)(B1 & 1ull)) && ni < 16) push(base - 1);
             unsigned long long G = (B1 ^ (B1 >> 1));
             if (cnt < 64) G &= (cnt >= 2) ? ((1ull << (cnt - 1)) - 1ull) : 0ull;
             else G &= 0x7fffffffffffffffull;
             while (G && ni < 16) {
                 const int bit = __ffsll((long long)G) - 1;
-                idx[ni++] = base + bit;
+                push(base + bit);
                 G &= G - 1ull;
             }
             prev_last = (int)((B1 >> (cnt - 1)) & 1ull);
         }
         double ax = 0., az = 0.;
         if (any20) {
-            ArzPiece piece[3];
+            // up to three pieces: coarse nodes [c0, c1) followed by n_fine points start + k * delta (slice [is, ie))
+            int pc0[3] = {0, 0, 0}, pc1[3] = {nd, 0, 0}, pis[3] = {0, 0, 0}, pie[3] = {0, 0, 0}, pnf[3] = {0, 0, 0};
+            double pstart[3] = {0., 0., 0.}, pdelta[3] = {0., 0., 0.};
             int n_piece = 1;
-            piece[0] = ArzPiece{0, nd, 0, 0, 0, 0., 0., 0.};
+            const double step = (s_depth[1] - s_depth[0]) / b.interp_factor2;
             if (b.interp_factor2 != 1. && ni != 0) {
                 if (ni % 2 != 0) {  // a stretch that starts with the first / ends with the last node (:176-181)
-                    if (first_in && idx[0] != 0) {
-                        for (int q = ni; q > 0; q--) idx[q] = idx[q - 1];
-                        idx[0] = 0;
+                    if (first_in && i0 != 0) {
+                        i4 = i3; i3 = i2; i2 = i1; i1 = i0; i0 = 0;
                         ni++;
-                    } else if (idx[ni - 1] != nd - 1) {
-                        idx[ni++] = nd - 1;
+                    } else {
+                        const int last_idx = (ni == 1) ? i0 : (ni == 3 ? i2 : (ni == 5 ? i4 : -1));   // -1: beyond what is kept
+                        if (last_idx != nd - 1) push(nd - 1);
                     }
                 }
                 if (ni % 2 == 0 && ni != 2 && ni != 4) {
@@ -214,50 +264,93 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
                     ni = 0;
                 }
                 if (ni == 2 || ni == 4) {
-                    const double step = (s_depth[1] - s_depth[0]) / b.interp_factor2;
-                    int from = 0;
                     n_piece = 0;
-                    for (int q = 0; q < ni; q += 2) {
-                        const int is = idx[q], ie = idx[q + 1];
-                        const double start = s_depth[is];
-                        piece[n_piece++] = ArzPiece{from, is, is, ie, (long)ceil((s_depth[ie] - start) / step), start, step,
-                                                    (start + step) - start};
-                        from = ie;
+                    int from = 0;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        if (2 * q < ni) {
+                            const int is = q ? i2 : i0, ie = q ? i3 : i1;
+                            const double start = s_depth[is];
+                            pc0[q] = from; pc1[q] = is; pis[q] = is; pie[q] = ie;
+                            pnf[q] = (int)ceil((s_depth[ie] - start) / step);
+                            pstart[q] = start;
+                            pdelta[q] = (start + step) - start;
+                            from = ie;
+                            n_piece = q + 1;
+                        }
                     }
-                    piece[n_piece++] = ArzPiece{from, nd, 0, 0, 0, 0., 0., 0.};
+                    if (n_piece == 1) { pc0[1] = from; pc1[1] = nd; pnf[1] = 0; }
+                    else { pc0[2] = from; pc1[2] = nd; pnf[2] = 0; }
+                    n_piece++;
                 }
             }
             // the merged grid: per piece its coarse nodes, then its fine points; g = index on the merged grid
-            long off[4] = {0, 0, 0, 0};
-            for (int ip = 0; ip < n_piece; ip++) off[ip + 1] = off[ip] + (piece[ip].c1 - piece[ip].c0) + piece[ip].n_fine;
-            const long M = off[n_piece];
-            auto depth_at = [&](long g, int* ip_out, long* j_out) -> double {
-                int ip = 0;
-                while (ip + 1 < n_piece && g >= off[ip + 1]) ip++;
-                const ArzPiece& p = piece[ip];
-                const long j = g - off[ip], nc = p.c1 - p.c0;
-                *ip_out = ip;
-                *j_out = j;
-                if (j < nc) return s_depth[p.c0 + j];
-                const long k = j - nc;
-                return (k == 0) ? p.start : (k == 1 ? p.start + p.step : p.start + k * p.delta);
+            int off[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int ip = 0; ip < 3; ip++) off[ip + 1] = off[ip] + ((ip < n_piece) ? (pc1[ip] - pc0[ip]) + pnf[ip] : 0);
+            const int M = off[3];
+            auto depth_at = [&](int g) -> double {   // any point of the merged grid (used at the seams only)
+                double res = 0.;
+#pragma unroll
+                for (int ip = 0; ip < 3; ip++) {
+                    if (ip < n_piece && g >= off[ip] && g < off[ip + 1]) {
+                        const int j = g - off[ip], nc = pc1[ip] - pc0[ip];
+                        if (j < nc) res = s_depth[pc0[ip] + j];
+                        else {
+                            const int k = j - nc;
+                            res = (k == 0) ? pstart[ip] : (k == 1 ? pstart[ip] + step : pstart[ip] + k * pdelta[ip]);
+                        }
+                    }
+                }
+                return res;
             };
-            for (long g = lane; g < M; g += 64) {
-                int ip, ipn;
-                long j, jn;
-                const double x = depth_at(g, &ip, &j);
-                const ArzPiece& p = piece[ip];
-                double q;
-                if (j < p.c1 - p.c0) q = s_ce[p.c0 + j];
-                else q = arz_interp_slice(x, s_depth, s_ce, p.is, p.ie, p.is + (int)((x - p.start) / (p.step * b.interp_factor2)));
-                const double xl = (g > 0) ? depth_at(g - 1, &ipn, &jn) : x;
-                const double xr = (g + 1 < M) ? depth_at(g + 1, &ipn, &jn) : x;
-                double yx, yz, t;
-                arz_integrand(r, x, q, tobs, nidx, fc, &yx, &yz, &t);
-                // trapezoid rule sum_j (z_{j+1} - z_j) (y_{j+1} + y_j) / 2 = sum_j y_j (z_{j+1} - z_{j-1}) / 2
-                const double w = (xr / ARZ_RHO - xl / ARZ_RHO) * 0.5;
-                ax += w * yx;
-                az += w * yz;
+            // trapezoid rule sum_j (z_{j+1} - z_j) (y_{j+1} + y_j) / 2 = sum_j y_j (z_{j+1} - z_{j-1}) / 2
+#pragma unroll
+            for (int ip = 0; ip < 3; ip++) {
+                if (ip >= n_piece) continue;
+                const int nc = pc1[ip] - pc0[ip], nf = pnf[ip];
+                for (int j = lane; j < nc; j += 64) {
+                    const int n = pc0[ip] + j, g = off[ip] + j;
+                    const double tn = ((ct - s_nR[n]) - s_z[n]) * (1. / ARZ_C);
+                    if (!(tn < 20.5 && tn > -20.5)) continue;   // F = 0 there (the exact comparison is made inside)
+                    const double x = s_depth[n];
+                    const double xl = (j > 0) ? s_depth[n - 1] : (g > 0 ? depth_at(g - 1) : x);
+                    const double xr = (j + 1 < nc) ? s_depth[n + 1] : (g + 1 < M ? depth_at(g + 1) : x);
+                    double yx, yz;
+                    arz_integrand_fast(r, x, s_ce[n], tobs, nidx, &yx, &yz);
+                    const double w = (xr - xl) * (0.5 / ARZ_RHO);
+                    ax += w * yx;
+                    az += w * yz;
+                }
+                const int is = pis[ip], last = pie[ip] - 1;
+                const double start = pstart[ip], delta = pdelta[ip];
+                for (int k = lane; k < nf; k += 64) {
+                    const int g = off[ip] + nc + k;
+                    const double x = (k == 0) ? start : (k == 1 ? start + step : start + k * delta);
+                    double q;   // np.interp on the slice [is, ie): constant beyond its last node
+                    if (x <= s_depth[is]) q = s_ce[is];
+                    else if (x >= s_depth[last]) q = s_ce[last];
+                    else {
+                        int kk = is + (int)((x - start) * inv_coarse);
+                        kk = kk < is ? is : (kk > last - 1 ? last - 1 : kk);
+                        while (kk > is && s_depth[kk] > x) kk--;
+                        while (kk < last - 1 && s_depth[kk + 1] <= x) kk++;
+                        q = s_slope[kk] * (x - s_depth[kk]) + s_ce[kk];
+                    }
+                    double xl, xr;
+                    if (k >= 3 && k + 1 < nf) {   // inside the stretch: the neighbours are fine points too
+                        xl = start + (k - 1) * delta;
+                        xr = start + (k + 1) * delta;
+                    } else {
+                        xl = (g > 0) ? depth_at(g - 1) : x;
+                        xr = (g + 1 < M) ? depth_at(g + 1) : x;
+                    }
+                    double yx, yz;
+                    arz_integrand_fast(r, x, q, tobs, nidx, &yx, &yz);
+                    const double w = (xr - xl) * (0.5 / ARZ_RHO);
+                    ax += w * yx;
+                    az += w * yz;
+                }
             }
             for (int off = 32; off > 0; off >>= 1) {
                 ax += __shfl_xor(ax, off);
@@ -314,7 +407,7 @@ void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int
     const int nt = b.N + 1;
     dim3 grid((unsigned)b.n_rays, ARZ_CHUNKS);
     (void)hipMemsetAsync(vp, 0, sizeof(double) * 2 * (size_t)nt * b.n_rays, s);
-    hipLaunchKernelGGL(arz_vector_potential_kernel, grid, dim3(256), sizeof(double) * 2 * (size_t)b.n_depth, s, b, vp, status);
+    hipLaunchKernelGGL(arz_vector_potential_kernel, grid, dim3(256), sizeof(double) * 5 * (size_t)b.n_depth, s, b, vp, status);
     hipLaunchKernelGGL(arz_trace_kernel, dim3((unsigned)b.n_rays), dim3(256), 0, s, b, vp, trace);
 }
 

@@ -8,10 +8,12 @@
 //
 // Two kernels.  `bire_steps_kernel`: one LANE per path step -- closed-form path points i and i + 1, de Boor evaluation of
 // the three depth splines, effective indices, polarisation vectors -> (a, b, c, d, t_1 - t_0) per step, 40 B.
-// `bire_propagate_kernel`: one LANE per frequency bin, the block walks the ray's steps in order with the step records
-// staged through LDS in tiles (every lane needs every step: broadcast reads); per (step, bin) one sincos and two real
-// 2 x 2 by complex-vector products.  The chain of non-commuting 2 x 2 factors is inherently sequential per bin, so the
-// parallel axes are bins x rays.  FP64 VALU / transcendental bound: a ray of 2000 steps and 2049 bins is 4e6 sincos
+// `bire_propagate_kernel`: a LANE owns nine frequency bins k = lane + j T, the block walks the ray's steps in order with the
+// step records staged through LDS in tiles (every lane needs every step: broadcast reads).  The phase of a step is linear in the
+// bin number, so per step a lane takes one small-angle sine / cosine (polynomial) and reaches its other bins by complex
+// multiplication with exp(i T theta), which the staging threads compute once per step: 24 FP64 operations per (step, bin), of
+// them 20 the two real 2 x 2 by complex-vector products.  The chain of non-commuting 2 x 2 factors is inherently sequential per
+// bin, so the parallel axes are bins x rays.  FP64 VALU bound: a ray of 2000 steps and 2049 bins is 1e8 fused multiply-adds
 // against 80 kB of step records and 131 kB of spectra.
 #include <hip/hip_runtime.h>
 #include "ray_device.h"
@@ -53,13 +55,13 @@ __device__ inline double bire_spline(const double* __restrict__ t, const double*
 // hp.cartesian_to_spherical + on_sky_birefringence (:2339-2367): theta / phi components of p seen along `dir`
 __device__ inline void bire_on_sky(const double dir[3], const double p[3], double* p_theta, double* p_phi)
 {
-    const double r = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-    const double theta = (r == 0.) ? 0. : acos(dir[2] / r);
-    double phi = atan2(dir[1], dir[0]);
-    if (phi < 0) phi += 2 * M_PI;
-    double st, ct, sp, cp;
-    sincos(theta, &st, &ct);
-    sincos(phi, &sp, &cp);
+    // theta = acos(dir_z / r), phi = atan2(dir_y, dir_x) of the reference enter only through their sines and cosines, which are
+    // ratios of the components (no inverse trigonometry + sincos: ~4 x fewer instructions, equal to rounding)
+    const double rho2 = dir[0] * dir[0] + dir[1] * dir[1];
+    const double r = sqrt(rho2 + dir[2] * dir[2]), rho = sqrt(rho2);
+    double ct = 1., st = 0., cp = signbit(dir[0]) ? -1. : 1., sp = 0.;
+    if (r != 0.) { ct = dir[2] / r; st = rho / r; }
+    if (rho != 0.) { cp = dir[0] / rho; sp = dir[1] / rho; }
     *p_theta = ct * cp * p[0] + ct * sp * p[1] + (-st) * p[2];
     *p_phi = (-sp) * p[0] + cp * p[1] + 0 * p[2];
 }
@@ -224,52 +226,134 @@ __device__ inline void bire_sincos(double x, double* sn, double* cs)
     }
 }
 
-// spectra [n_rays][2][n_f] complex, in place
-__global__ void __launch_bounds__(256)
-bire_propagate_kernel(BireBatch b, const double* __restrict__ steps, double2* __restrict__ spec, const int* __restrict__ ray_active)
+// the same without the library call (which costs ~100 registers next to the lanes' spectra): larger angles are halved m times and
+// brought back by m angle doublings, error ~2^m ulp -- the angles here are (lane or lane count) x 2 pi delay df, i.e. |x| < 0.25
+// unless a single step delays by more than ~0.1 ns, and m <= 10 up to 250 rad
+__device__ inline void bire_sincos_small(double x, double* sn, double* cs)
 {
-    __shared__ double s_step[BIRE_TILE][5];
+    int m = 0;
+    while (fabs(x) >= 0.25 && m < 40) { x *= 0.5; m++; }
+    const double x2 = x * x;
+    double ps = -1. / 39916800.;
+    ps = fma(ps, x2, 1. / 362880.);
+    ps = fma(ps, x2, -1. / 5040.);
+    ps = fma(ps, x2, 1. / 120.);
+    ps = fma(ps, x2, -1. / 6.);
+    ps = fma(ps, x2, 1.);
+    double pc = 1. / 479001600.;
+    pc = fma(pc, x2, -1. / 3628800.);
+    pc = fma(pc, x2, 1. / 40320.);
+    pc = fma(pc, x2, -1. / 720.);
+    pc = fma(pc, x2, 1. / 24.);
+    pc = fma(pc, x2, -0.5);
+    pc = fma(pc, x2, 1.);
+    double s = ps * x, c = pc;
+    for (; m > 0; m--) {
+        const double s2 = 2. * s * c, c2 = (c - s) * (c + s);
+        s = s2;
+        c = c2;
+    }
+    *sn = s;
+    *cs = c;
+}
+
+#define BIRE_BINS 9   // frequency bins per lane: n_f = 2^p + 1 bins fill ceil(n_f / 9) lanes = 89 % of whole waves
+
+// spectra [n_rays][2][n_f] complex, in place.  A lane owns the bins k = tid + j T (T lanes per ray, j < BIRE_BINS): the phase of a
+// step is linear in the bin number, so per step a lane takes exp(i tid theta) once (polynomial) and walks its bins by multiplying
+// with exp(i T theta), which the threads that stage the tile of step records into LDS compute once per step.
+__global__ void __launch_bounds__(512)
+bire_propagate_kernel(BireBatch b, const double* __restrict__ steps, double2* __restrict__ spec, const int* __restrict__ ray_active,
+                      int T)
+{
+    __shared__ __align__(16) double s_step[BIRE_TILE][8];   // a, b, c, d, theta, cos(T theta), sin(T theta), kind
     const int ray = blockIdx.x;
     if (ray_active && !ray_active[ray]) return;  // the ray's event cannot pass the candidate cut (general_bound_kernel)
     const int n_steps = b.n_points[ray] - 1;
-    const int k = blockIdx.y * blockDim.x + threadIdx.x;
+    const int tid = blockIdx.y * blockDim.x + threadIdx.x;
     const int n_f = b.n_f;
-    const bool active = k < n_f;
     const int N = 2 * (n_f - 1);
     const double fs = b.sampling_rate;
-    const double f = k * (1.0 / (N * (1. / fs)));  // np.fft.rfftfreq
+    const double df = 1.0 / (N * (1. / fs));  // np.fft.rfftfreq
     double2* st = spec + (long)ray * 2 * n_f;
-    double2 et = make_double2(0., 0.), ep = et;
-    if (active) { et = st[k]; ep = st[n_f + k]; }
+    double2 et[BIRE_BINS], ep[BIRE_BINS];
+#pragma unroll
+    for (int j = 0; j < BIRE_BINS; j++) {
+        const int k = tid + j * T;
+        const bool on = tid < T && k < n_f;
+        et[j] = on ? st[k] : make_double2(0., 0.);
+        ep[j] = on ? st[n_f + k] : make_double2(0., 0.);
+    }
     const double* S = steps + 5 * b.step_offset[ray];
     for (int base = 0; base < n_steps; base += BIRE_TILE) {
         const int cnt = min(BIRE_TILE, n_steps - base);
         __syncthreads();
-        for (int q = threadIdx.x; q < cnt * 5; q += blockDim.x) (&s_step[0][0])[q] = S[5 * (long)base + q];
-        __syncthreads();
-        if (!active) continue;
-        for (int i = 0; i < cnt; i++) {
-            const double a = s_step[i][0], bb = s_step[i][1], c = s_step[i][2], d = s_step[i][3], delay = s_step[i][4];
-            if (isnan(delay)) continue;
-            const double2 b0 = make_double2(a * et.x + bb * ep.x, a * et.y + bb * ep.y);
-            double2 b1 = make_double2(c * et.x + d * ep.x, c * et.y + d * ep.y);
+        for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+            const double* R = S + 5 * (long)(base + q);
+            const double delay = R[4];
             // BaseTrace.apply_time_shift (base_trace.py:246-276): whole samples are rolled in the time domain (which drops
             // the imaginary parts of the DC and Nyquist bins), anything else is a phase ramp
-            const double x = delay * fs;
-            double sn, cs;
-            if (fabs(rint(x) - x) < 1e-5) {
-                const double kk = rint(x);
-                sincos(-2. * M_PI * f * (kk / fs), &sn, &cs);
-                if (k == 0 || k == n_f - 1) { b1.y = 0.; sn = 0.; cs = (k == 0 || ((long)kk % 2 == 0)) ? 1. : -1.; }
-            } else {
-                bire_sincos(-2. * M_PI * delay * f, &sn, &cs);
+            double kind = 0., D = delay;
+            if (isnan(delay)) { kind = 3.; D = 0.; }   // skipped step
+            else {
+                const double x = delay * fs;
+                if (fabs(rint(x) - x) < 1e-5) {
+                    const double kk = rint(x);
+                    D = kk / fs;
+                    kind = ((long)kk % 2 == 0) ? 1. : 2.;
+                }
             }
-            b1 = make_double2(b1.x * cs - b1.y * sn, b1.x * sn + b1.y * cs);
-            et = make_double2(a * b0.x + c * b1.x, a * b0.y + c * b1.y);   // R^T
-            ep = make_double2(bb * b0.x + d * b1.x, bb * b0.y + d * b1.y);
+            const double theta = -2. * M_PI * D * df;
+            double sn, cs;
+            bire_sincos_small(theta * T, &sn, &cs);
+            s_step[q][0] = R[0]; s_step[q][1] = R[1]; s_step[q][2] = R[2]; s_step[q][3] = R[3];
+            s_step[q][4] = theta; s_step[q][5] = cs; s_step[q][6] = sn; s_step[q][7] = kind;
+        }
+        __syncthreads();
+        if (tid >= T) continue;
+        for (int i = 0; i < cnt; i++) {
+            const double kind = s_step[i][7];
+            if (kind == 3.) continue;
+            const double a = s_step[i][0], bb = s_step[i][1], c = s_step[i][2], d = s_step[i][3];
+            const double2 wT = make_double2(s_step[i][5], s_step[i][6]);
+            double2 w;
+            bire_sincos_small(s_step[i][4] * tid, &w.y, &w.x);
+            if (kind == 0.) {
+#pragma unroll
+                for (int j = 0; j < BIRE_BINS; j++) {
+                    const double2 b0 = make_double2(a * et[j].x + bb * ep[j].x, a * et[j].y + bb * ep[j].y);
+                    double2 b1 = make_double2(c * et[j].x + d * ep[j].x, c * et[j].y + d * ep[j].y);
+                    b1 = make_double2(b1.x * w.x - b1.y * w.y, b1.x * w.y + b1.y * w.x);
+                    et[j] = make_double2(a * b0.x + c * b1.x, a * b0.y + c * b1.y);   // R^T
+                    ep[j] = make_double2(bb * b0.x + d * b1.x, bb * b0.y + d * b1.y);
+                    w = make_double2(w.x * wT.x - w.y * wT.y, w.x * wT.y + w.y * wT.x);
+                }
+            } else {   // a roll by whole samples: real factors +-1 at DC and Nyquist, imaginary parts dropped there
+#pragma unroll
+                for (int j = 0; j < BIRE_BINS; j++) {
+                    const int k = tid + j * T;
+                    const double2 b0 = make_double2(a * et[j].x + bb * ep[j].x, a * et[j].y + bb * ep[j].y);
+                    double2 b1 = make_double2(c * et[j].x + d * ep[j].x, c * et[j].y + d * ep[j].y);
+                    double2 ww = w;
+                    if (k == 0 || k == n_f - 1) {
+                        b1.y = 0.;
+                        ww = make_double2((k == 0 || kind == 1.) ? 1. : -1., 0.);
+                    }
+                    b1 = make_double2(b1.x * ww.x - b1.y * ww.y, b1.x * ww.y + b1.y * ww.x);
+                    et[j] = make_double2(a * b0.x + c * b1.x, a * b0.y + c * b1.y);
+                    ep[j] = make_double2(bb * b0.x + d * b1.x, bb * b0.y + d * b1.y);
+                    w = make_double2(w.x * wT.x - w.y * wT.y, w.x * wT.y + w.y * wT.x);
+                }
+            }
         }
     }
-    if (active) { st[k] = et; st[n_f + k] = ep; }
+    if (tid < T) {
+#pragma unroll
+        for (int j = 0; j < BIRE_BINS; j++) {
+            const int k = tid + j * T;
+            if (k < n_f) { st[k] = et[j]; st[n_f + k] = ep[j]; }
+        }
+    }
 }
 
 void launch_birefringence_steps(hipStream_t s, const BireBatch& b, int max_points, double* steps, long long* log_norm)
@@ -283,8 +367,10 @@ void launch_birefringence_steps(hipStream_t s, const BireBatch& b, int max_point
 void launch_birefringence_propagate(hipStream_t s, const BireBatch& b, const double* steps, double2* spec, const int* active)
 {
     if (b.n_rays <= 0) return;
-    hipLaunchKernelGGL(bire_propagate_kernel, dim3((unsigned)b.n_rays, (unsigned)((b.n_f + 255) / 256)), dim3(256), 0, s, b, steps,
-                       spec, active);
+    const int T = (b.n_f + BIRE_BINS - 1) / BIRE_BINS;            // lanes per ray
+    const int gy = (T + 511) / 512;
+    const int block = (((T + gy - 1) / gy) + 63) / 64 * 64;
+    hipLaunchKernelGGL(bire_propagate_kernel, dim3((unsigned)b.n_rays, (unsigned)gy), dim3(block), 0, s, b, steps, spec, active, T);
 }
 void launch_birefringence(hipStream_t s, const BireBatch& b, int max_points, double* steps, double2* spec)
 {
