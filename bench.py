@@ -442,7 +442,8 @@ def main():
                        "all_ranks": {k: int(v) for k, v in tot.items()},
                        "triggered_events_per_s": n_trig_total / (elapsed / max(args.steps, 1)),
                        "pass2_ms_traces_of_triggered_events": pass2_ms,
-                       "stage_ms_avg_per_step": {k: round(v, 3) for k, v in sm.items()}},
+                       "stage_ms_avg_per_step": {k: round(v, 3) for k, v in sm.items()},
+                       "collectives": comm.mode},   # 'local' (one rank), 'rccl', or 'tcp' (RCCL did not come up on every rank)
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": sm[dom],

@@ -99,39 +99,170 @@ def exchange_bytes(payload, rank, world_size, addr=None, port=None, timeout=300.
             time.sleep(0.05)
 
 
-class Comm:
-    """RCCL communicator of one process (one GPU) over nrhip_comm_*; world_size 1 needs no RCCL and every call is local."""
+class _Star:
+    """Persistent TCP star through rank 0 (a few bytes per call): the rendezvous of the communicator id, the vote on whether
+    RCCL came up on every rank, and the host-side stand-in for the scalar collectives when it did not."""
 
-    def __init__(self, ctx, rank=None, world_size=None, addr=None, port=None, force_rccl=False):
+    def __init__(self, rank, world_size, addr=None, port=None, timeout=300.):
+        self.rank, self.world_size = rank, world_size
+        addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+        port = int(port or os.environ.get('NRHIP_COMM_PORT', 0) or int(os.environ.get('MASTER_PORT', 29500)) + 1000)
+        self.peers = {}
+        self.sock = None
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world_size)
+            srv.settimeout(timeout)
+            try:
+                while len(self.peers) < world_size - 1:
+                    conn, _ = srv.accept()
+                    conn.settimeout(timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    r = int.from_bytes(self._recv(conn, 4), 'little')
+                    self.peers[r] = conn
+            finally:
+                srv.close()
+        else:
+            t_end = time.time() + timeout
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=5.)
+                    c.settimeout(timeout)
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    c.sendall(int(rank).to_bytes(4, 'little'))
+                    self.sock = c
+                    break
+                except (ConnectionRefusedError, ConnectionError, socket.timeout, OSError):
+                    if time.time() > t_end:
+                        raise
+                    time.sleep(0.05)
+
+    @staticmethod
+    def _recv(c, n):
+        out = b''
+        while len(out) < n:
+            d = c.recv(n - len(out))
+            if not d:
+                raise ConnectionError("peer closed")
+            out += d
+        return out
+
+    def _send_msg(self, c, payload):
+        c.sendall(len(payload).to_bytes(8, 'little') + payload)
+
+    def _recv_msg(self, c):
+        return self._recv(c, int.from_bytes(self._recv(c, 8), 'little'))
+
+    def gather(self, payload):
+        """rank 0: list of every rank's bytes (by rank); other ranks: None"""
+        if self.rank == 0:
+            out = [payload] + [None] * (self.world_size - 1)
+            for r, c in self.peers.items():
+                out[r] = self._recv_msg(c)
+            return out
+        self._send_msg(self.sock, payload)
+        return None
+
+    def broadcast(self, payload):
+        if self.rank == 0:
+            for c in self.peers.values():
+                self._send_msg(c, payload)
+            return payload
+        return self._recv_msg(self.sock)
+
+    def allgather(self, payload):
+        parts = self.gather(payload)
+        if self.rank == 0:
+            blob = b''.join(len(q).to_bytes(8, 'little') + q for q in parts)
+        else:
+            blob = b''
+        blob = self.broadcast(blob)
+        out, o = [], 0
+        while o < len(blob):
+            n = int.from_bytes(blob[o:o + 8], 'little')
+            out.append(blob[o + 8:o + 8 + n])
+            o += 8 + n
+        return out
+
+    def close(self):
+        for c in list(self.peers.values()) + ([self.sock] if self.sock else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers, self.sock = {}, None
+
+
+class Comm:
+    """RCCL communicator of one process (one GPU) over nrhip_comm_*; world_size 1 needs no RCCL and every call is local.
+
+    With more than one rank the processes first meet on a TCP star through rank 0 (communicator id, then a vote): only if RCCL
+    loads on EVERY rank is the communicator created, and only if it came up on every rank is it used (`mode == 'rccl'`).
+    Otherwise (`mode == 'tcp'`, said loudly on stderr and in bench.py's JSON) the few scalars and the masks travel over the star
+    -- a sharded run then still completes instead of hanging in a half-built communicator.  `backend='tcp'` asks for that
+    directly (hosts without RCCL, CPU tests of the sharding logic)."""
+
+    def __init__(self, ctx, rank=None, world_size=None, addr=None, port=None, force_rccl=False, backend=None):
         r, _, w = env_rank()
         self.ctx = ctx
         self.rank = r if rank is None else int(rank)
         self.world_size = w if world_size is None else int(world_size)
-        self._lib = L.load()
+        self._lib = L.load() if ctx is not None else None
         self._h = None
-        if self.world_size > 1 or force_rccl:   # force_rccl: a one-rank communicator (tests of the binding on a single GPU)
+        self._star = None
+        self.mode = 'local'
+        backend = backend or os.environ.get('NRHIP_COMM_BACKEND', 'rccl')
+        if self.world_size == 1 and force_rccl:   # a one-rank communicator (tests of the binding on a single GPU)
             uid = (ctypes.c_uint8 * ID_BYTES)()
-            if self.rank == 0:
-                L.check(self._lib.nrhip_comm_get_unique_id(uid))
-            raw = exchange_bytes(bytes(uid), self.rank, self.world_size, addr, port)
-            uid = (ctypes.c_uint8 * ID_BYTES).from_buffer_copy(raw)
+            L.check(self._lib.nrhip_comm_get_unique_id(uid))
             h = ctypes.c_void_p()
             L.check(self._lib.nrhip_comm_create(ctx._h, uid, self.rank, self.world_size, ctypes.byref(h)))
             self._h = h
+            self.mode = 'rccl'
+        elif self.world_size > 1:
+            self._star = _Star(self.rank, self.world_size, addr, port)
+            self.mode = 'tcp'
+            uid = (ctypes.c_uint8 * ID_BYTES)()
+            ok = 0
+            if backend == 'rccl' and self._lib is not None:
+                ok = int(self._lib.nrhip_comm_get_unique_id(uid) == 0)   # loads RCCL: a local call on every rank
+            votes = self._star.allgather(bytes([ok]) + (bytes(uid) if self.rank == 0 else b''))
+            if all(v[0] == 1 for v in votes):
+                uid = (ctypes.c_uint8 * ID_BYTES).from_buffer_copy(votes[0][1:1 + ID_BYTES])
+                h = ctypes.c_void_p()
+                up = int(self._lib.nrhip_comm_create(ctx._h, uid, self.rank, self.world_size, ctypes.byref(h)) == 0)
+                if all(v[0] == 1 for v in self._star.allgather(bytes([up]))):
+                    self._h = h
+                    self.mode = 'rccl'
+                elif up:
+                    self._lib.nrhip_comm_destroy(h)
+            if self.mode == 'tcp' and backend == 'rccl' and self.rank == 0:
+                import sys
+                print("nuradiomc_amd.comm: RCCL did not come up on every rank -- collectives go over the TCP star (%s)"
+                      % (self._lib.nrhip_last_error().decode() if self._lib is not None else 'no device context'), file=sys.stderr)
 
     def barrier(self):
-        if self._h is None:
+        if self.ctx is not None and self._h is None:
             self.ctx.synchronize()
-        else:
+        if self._h is not None:
             L.check(self._lib.nrhip_comm_barrier(self._h))
+        elif self._star is not None:
+            self._star.allgather(b'')
 
     def allgather_masks(self, d_local, n_local, n_total):
         """All-gather the per-rank DEVICE uint8 masks of a list of n_total events sharded with shard_range: returns the full host
         mask [n_total] (same on every rank).  The one collective of the path (padded to the largest shard)."""
         if self._h is None:
-            out = np.zeros(n_local, np.uint8)
-            self.ctx.to_host(out, d_local)
-            return out
+            if isinstance(d_local, np.ndarray):   # a host mask (tcp backend without a device context)
+                out = np.ascontiguousarray(d_local[:n_local], np.uint8)
+            else:
+                out = np.zeros(n_local, np.uint8)
+                self.ctx.to_host(out, d_local)
+            if self._star is None:
+                return out
+            return np.concatenate([np.frombuffer(q, np.uint8) for q in self._star.allgather(out.tobytes())])
         W = self.world_size
         sizes = [shard_range(n_total, k, W)[1] - shard_range(n_total, k, W)[0] for k in range(W)]
         pad = max(sizes)
@@ -148,11 +279,15 @@ class Comm:
         host = host.reshape(W, pad)
         return np.concatenate([host[k, :sizes[k]] for k in range(W)])
 
+    def _host_reduce(self, v, op):
+        parts = [np.frombuffer(q, v.dtype) for q in self._star.allgather(v.tobytes())]
+        return op(np.stack(parts), axis=0)
+
     def allreduce_sum(self, values):
         """element-wise sum of a small int64 vector over the ranks"""
         v = np.ascontiguousarray(values, np.int64)
         if self._h is None:
-            return v.copy()
+            return v.copy() if self._star is None else self._host_reduce(v, np.sum)
         d = self.ctx.to_device(v)
         try:
             L.check(self._lib.nrhip_comm_allreduce_i64_sum(self._h, ctypes.c_void_p(d), len(v)))
@@ -165,7 +300,7 @@ class Comm:
     def allreduce_max(self, values):
         v = np.ascontiguousarray(values, np.float64)
         if self._h is None:
-            return v.copy()
+            return v.copy() if self._star is None else self._host_reduce(v, np.max)
         d = self.ctx.to_device(v)
         try:
             L.check(self._lib.nrhip_comm_allreduce_f64_max(self._h, ctypes.c_void_p(d), len(v)))
@@ -179,6 +314,9 @@ class Comm:
         if self._h is not None:
             self._lib.nrhip_comm_destroy(self._h)
             self._h = None
+        if self._star is not None:
+            self._star.close()
+            self._star = None
 
     def __del__(self):
         try:

@@ -439,8 +439,9 @@ int nrhip_arz_time_trace_batch(nrhip_ctx* ctx, int64_t n_rays, const double* ene
         if (profile_index[i] < 0 || profile_index[i] >= n_profiles) return fail_msg("nrhip_arz_time_trace_batch: bad profile index");
     }
     HIPCHK(hipSetDevice(ctx->device));
-    DevBuf dE, dth, dR, dty, dem, dpi, drs, dpd, dpc, dpar, dvp, dtr, dst;
+    DevBuf dE, dth, dR, dty, dem, dpi, drs, dpd, dpc, dpar, dvp, dtr, dst, dtab;
     const size_t nr = (size_t)n_rays;
+    HIPCHK(dtab.alloc((size_t)ARZ_TABLE_DOUBLES * 8));
     HIPCHK(dE.alloc(nr * 8)); HIPCHK(dth.alloc(nr * 8)); HIPCHK(dR.alloc(nr * 8)); HIPCHK(dty.alloc(nr * 4));
     HIPCHK(dem.alloc(nr * 8)); HIPCHK(dpi.alloc(nr * 4)); HIPCHK(drs.alloc(nr * 8));
     HIPCHK(dpd.alloc((size_t)n_depth * 8)); HIPCHK(dpc.alloc((size_t)n_profiles * n_depth * 8)); HIPCHK(dpar.alloc(14 * 8));
@@ -457,6 +458,7 @@ int nrhip_arz_time_trace_batch(nrhip_ctx* ctx, int64_t n_rays, const double* ene
     nrhip::ArzBatch b{(long)n_rays, dE.as<double>(), dth.as<double>(), dR.as<double>(), dty.as<int>(), dem.as<double>(),
                       dpi.as<int>(), rescale ? drs.as<double>() : nullptr, n_profiles, n_depth, dpd.as<double>(),
                       dpc.as<double>(), dpar.as<double>(), N, dt, n_index, interp_factor2, shift_for_xmax, maximum_angle};
+    b.form_factor_table = getenv("NRHIP_ARZ_DIRECT") ? nullptr : dtab.as<double>();
     nrhip::launch_arz(s, b, dvp.as<double>(), dtr.as<double>(), dst.as<int>());
     HIPCHK(hipGetLastError());
     std::vector<int> st(nr);
@@ -504,6 +506,9 @@ int nrhip_birefringence_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, 
     nrhip::BireBatch b{(long)n_rays, dx1.as<double>(), dx2.as<double>(), dC0.as<double>(), dnp.as<int>(), dof.as<long>(),
                        ctx->ice, dkn.as<double>(), dco.as<double>(), {n_knots[0], n_knots[1], n_knots[2]}, n_ref,
                        angle_to_iceflow, n_f, sampling_rate};
+    DevBuf dpieces;
+    HIPCHK(dpieces.alloc((size_t)BIRE_MAX_KNOTS * 7 * 8));
+    b.spline_pieces = dpieces.as<double>();
     nrhip::launch_birefringence(s, b, max_points, dst.as<double>(), dsp.as<double2>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(spectra, dsp.p, nr * 2 * n_f * 16, hipMemcpyDeviceToHost, s));

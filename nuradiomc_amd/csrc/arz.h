@@ -20,7 +20,13 @@ struct ArzBatch {
     int shift_for_xmax;
     double maximum_angle;
     const double* n_index_ray = nullptr;      // [n_rays] index of refraction at the shower (overrides n_index)
+    double* form_factor_table = nullptr;      // [ARZ_TABLE_DOUBLES] scratch the launch fills (arz_form_factor_table_kernel); nullptr = none
 };
+
+// piecewise degree-6 Taylor polynomials of the form factor exp(-|t| / t0) + (1 + f |t|)^e per (shower type, sign of t):
+// cells of 1/512 ns up to |t| = 2.5 ns, 8 doubles per cell (one 64 B line)
+#define ARZ_TABLE_CELLS 1280
+#define ARZ_TABLE_DOUBLES (4 * ARZ_TABLE_CELLS * 8)
 
 void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int* status);
 

@@ -18,7 +18,9 @@ struct BireBatch {
     double angle_to_iceflow;   // deg, NaN = none
     int n_f;
     double sampling_rate;
+    double* spline_pieces = nullptr;   // [BIRE_MAX_KNOTS][7] scratch the launch fills (bire_pieces_kernel); nullptr or too many knots: de Boor
 };
+#define BIRE_MAX_KNOTS 96
 
 void launch_birefringence(hipStream_t s, const BireBatch& b, int max_points, double* steps, double2* spec);
 // the two halves separately: log_norm[ray] (nullable) = log of an upper bound on the 2-norm gain of the ray's whole path;

@@ -1059,6 +1059,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             ArzBatch ab{(long)n_rays, g_energy, w.view, w.R, g_type, g_em, g_prof, g_resc, st->arz_n_profiles, st->arz_n_depth,
                         st->d_arz_depth.as<double>(), st->d_arz_ce.as<double>(), st->d_arz_par.as<double>(), sd.N, 1. / sd.fs,
                         1.78, st->arz_interp_factor2, 0, 20. * 0.017453292519943295, w.n_index};
+            NEED(ab.form_factor_table = WS("arz_form_factor_table", double, (size_t)ARZ_TABLE_DOUBLES));
             launch_arz(sm, ab, vp, atr, ast);
             LCHK("arz");
             std::vector<int> hs(n_rays);
@@ -1088,6 +1089,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             BireBatch bb{(long)n_rays, g_x1, g_x2, w.C0, g_npoints, d_off, ctx->ice, st->d_bire_knots.as<double>(),
                          st->d_bire_coeffs.as<double>(), {st->bire_n_knots[0], st->bire_n_knots[1], st->bire_n_knots[2]},
                          st->bire_n_ref, st->bire_angle, n_f, sd.fs};
+            NEED(bb.spline_pieces = WS("bire_spline_pieces", double, (size_t)BIRE_MAX_KNOTS * 7));
             // the gain of the whole path is bounded by the product of the steps' ||R||^2: events none of whose rays can exceed
             // the candidate cut even so skip the propagation (result-neutral, like the bounds of the parametrised path)
             long long* log_gain;  // fixed point, BIRE_LOG_FIXED

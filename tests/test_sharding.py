@@ -2,6 +2,7 @@
 reassembles the global mask in event order on every rank."""
 import os
 import sys
+import pytest
 import numpy as np
 import torch.multiprocessing as mp
 from conftest import ROOT
@@ -76,6 +77,44 @@ def _id_worker(rank, world, port, q):
     payload = bytes(range(128)) if rank == 0 else b''
     got = comm.exchange_bytes(payload, rank, world, addr='127.0.0.1', port=port, timeout=60.)
     q.put((rank, got == bytes(range(128))))
+
+
+def _tcp_worker(rank, world, port, backend, q):
+    sys.path.insert(0, ROOT)
+    from nuradiomc_amd import comm
+    n_total = 1003
+    a, b = comm.shard_range(n_total, rank, world)
+    full = (np.arange(n_total) % 7 == 0).astype(np.uint8)
+    c = comm.Comm(None, rank, world, addr='127.0.0.1', port=port, backend=backend)
+    c.barrier()
+    mask = c.allgather_masks(full[a:b].copy(), b - a, n_total)
+    tot = c.allreduce_sum([int(full[a:b].sum()), rank])
+    mx = c.allreduce_max([float(rank) + 0.5])
+    c.barrier()
+    mode = c.mode
+    c.close()
+    q.put((rank, bool(np.array_equal(mask, full)), [int(v) for v in tot], float(mx[0]), mode))
+
+
+@pytest.mark.parametrize('backend', ['tcp', 'rccl'])
+def test_comm_tcp_star_world3(backend):
+    """The host-side stand-in of the communicator (nuradiomc_amd.comm.Comm, mode 'tcp'): the sharded masks of ONE list are
+    gathered in rank order, sums and maxima agree on every rank -- world size 3 on the loopback, no GPU.  With backend 'rccl'
+    requested and no device context the vote fails on every rank and the same path is taken (what a node without a working RCCL
+    falls back to instead of hanging)."""
+    import multiprocessing
+    ctx = multiprocessing.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + (0 if backend == 'tcp' else 1)
+    procs = [ctx.Process(target=_tcp_worker, args=(r, 3, port, backend, q)) for r in range(3)]
+    for p in procs[1:] + procs[:1]:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    n_set = int((np.arange(1003) % 7 == 0).sum())
+    for rank, ok, tot, mx, mode in res:
+        assert ok and tot == [n_set, 3] and mx == 2.5 and mode == 'tcp', (rank, ok, tot, mx, mode)
 
 
 def test_comm_id_exchange_and_shard_helpers():
