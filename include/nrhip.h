@@ -354,6 +354,11 @@ typedef struct {
     uint64_t noise_seed;
     int64_t noise_group_offset;
     const int64_t* noise_group_id;
+    /* != 0: config signal.polarization = 'custom' (simulation.py:821-825, calculate_polarization_vector): every ray's field is
+       polarised along (0, sqrt(1 - ePhi^2), ePhi) / norm in the on-sky basis of its launch direction instead of l x (s x l).
+       0: 'auto'. */
+    int32_t custom_polarization;
+    double polarization_ephi;
 } nrhip_sim_config;
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1

@@ -892,7 +892,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         }
         launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w, evin,
                          arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model, foc_n_sol, foc_launch, foc_dz, cfg->focusing_limit > 0 ? cfg->focusing_limit : 2.,
-                         cfg->reflection_coefficient, cfg->reflection_phase_shift);
+                         cfg->reflection_coefficient, cfg->reflection_phase_shift, cfg->custom_polarization ? cfg->polarization_ephi : NAN);
         LCHK("ray_setup");
     }
     // split_event_time_diff: sub-events of the groups (stages 3-4 stay per group: the candidate flag is the group's)
@@ -928,7 +928,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             HIPCHK(hipMemcpyAsync(ray_slot, slot_new, sizeof(int) * (size_t)n_rays, hipMemcpyDeviceToDevice, sm));
             launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w, evin, cfg->askaryan_model,
                              foc_n_sol, foc_launch, foc_dz, cfg->focusing_limit > 0 ? cfg->focusing_limit : 2.,
-                             cfg->reflection_coefficient, cfg->reflection_phase_shift);
+                             cfg->reflection_coefficient, cfg->reflection_phase_shift,
+                             cfg->custom_polarization ? cfg->polarization_ephi : NAN);
             n_ev = h_split[1];
             int *sub_ray, *ev_sub;
             NEED(sub_ray = WS("sub_event_ray_begin", int, n_ev + 1));

@@ -145,7 +145,8 @@ void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const in
 void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex, const double* zen,
                       const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w,
                       const EventIn& evin, int ask_model, const int* foc_n_sol = nullptr, const double* foc_launch = nullptr,
-                      double foc_dz = 0., double foc_limit = 0., double refl_coefficient = 1., double refl_phase = 0.);
+                      double foc_dz = 0., double foc_limit = 0., double refl_coefficient = 1., double refl_phase = 0.,
+                      double pol_ephi = NAN /* signal.polarization 'custom': ePhi; NaN = 'auto' */);
 void launch_gather_segments(hipStream_t s, int n_rays, int NS, const int* ray_slot, const double* seg_C0, const double* seg_zint,
                             double* ray_seg_C0, double* ray_seg_zint);
 void launch_segment_items(hipStream_t s, int n_active, int NS, const int* active_list, int* items);

@@ -395,7 +395,7 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
                  const double* __restrict__ zenith, const double* __restrict__ azimuth, RayRecords rec, IceConst m,
                  StationDev st, RayWork w, EventIn evin, int ask_model, const int* __restrict__ foc_n_sol,
                  const double* __restrict__ foc_launch, double foc_dz, double foc_limit, double refl_coefficient,
-                 double refl_phase)
+                 double refl_phase, double pol_ephi)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rays) return;
@@ -427,6 +427,12 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
     mat3vec(Mx, pol, po);
     w.pol_theta[r] = po[1];
     w.pol_phi[r] = po[2];
+    if (!isnan(pol_ephi)) {   // signal.polarization = 'custom' (simulation.py:821-825)
+        const double et = sqrt(1 - pol_ephi * pol_ephi);
+        const double nrm = sqrt(0 * 0 + et * et + pol_ephi * pol_ephi);
+        w.pol_theta[r] = et / nrm;
+        w.pol_phi[r] = pol_ephi / nrm;
+    }
     // arrival direction (simulation.py:270)
     double zen, az;
     cart2sph(rv, &zen, &az);
@@ -2695,11 +2701,12 @@ void launch_scatter_slots(hipStream_t s, long n_slots, const int* keep, const in
 void launch_ray_setup(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex, const double* zen,
                       const double* az, const RayRecords& rec, const IceConst& m, const StationDev& st, const RayWork& w,
                       const EventIn& evin, int ask_model, const int* foc_n_sol, const double* foc_launch, double foc_dz,
-                      double foc_limit, double refl_coefficient, double refl_phase)
+                      double foc_limit, double refl_coefficient, double refl_phase, double pol_ephi)
 {
     if (n_rays <= 0) return;
     hipLaunchKernelGGL(ray_setup_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, n_ch, ray_slot, vertex, zen,
-                       az, rec, m, st, w, evin, ask_model, foc_n_sol, foc_launch, foc_dz, foc_limit, refl_coefficient, refl_phase);
+                       az, rec, m, st, w, evin, ask_model, foc_n_sol, foc_launch, foc_dz, foc_limit, refl_coefficient, refl_phase,
+                       pol_ephi);
 }
 
 // ---- paths with bottom reflections: attenuation = product over the path segments ----------------------------------------

@@ -81,7 +81,8 @@ class SimConfig(ctypes.Structure):
                 ('z_reflection', ctypes.c_double), ('reflection_coefficient', ctypes.c_double),
                 ('reflection_phase_shift', ctypes.c_double), ('split_event_time_diff', ctypes.c_double),
                 ('noise', ctypes.c_int32), ('noise_seed', ctypes.c_uint64), ('noise_group_offset', ctypes.c_int64),
-                ('noise_group_id', ctypes.c_void_p)]
+                ('noise_group_id', ctypes.c_void_p), ('custom_polarization', ctypes.c_int32),
+                ('polarization_ephi', ctypes.c_double)]
 
 
 class SimStats(ctypes.Structure):
@@ -505,6 +506,7 @@ class Station:
                             d_max_distance=None, focusing=False, focusing_limit=2., select_only=False, reuse_ray_tables=False,
                             accumulate_triggered=False, n_reflections=0, z_reflection=0., reflection_coefficient=1.,
                             reflection_phase_shift=0., split_event_time_diff=0., noise=False, noise_seed=0, noise_group_offset=0,
+                            polarization='auto', ePhi=0.,
                             d_noise_group_id=None):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
@@ -517,11 +519,14 @@ class Station:
         continue from the tables of such a call on the same device arrays; accumulate_triggered: OR into d_triggered
         instead of overwriting it (nrhip_sim_config).  n_reflections > 0: rays reflected off the bottom of an ice shelf at depth
         z_reflection (< 0) with the layer's reflection_coefficient and reflection_phase_shift [rad] (medium.reflection...).
+        polarization='custom', ePhi=: config signal.polarization / signal.ePhi (simulation.calculate_polarization_vector).
         split_event_time_diff > 0 [ns]: simulation.group_into_events -- a group's signals at this station are cut into sub-events
         where consecutive start times are farther apart; the ev_* / item_* tables are then per sub-event (fetch('ev_group'),
         fetch('ev_sub_event')), the mask stays per group.
         noise (set_noise first): thermal noise on every channel of the candidate events before filters and trigger; counter-based
         draws keyed by noise_seed and the group ids (d_noise_group_id: device int64 [n_groups], or noise_group_offset + index)."""
+        if polarization not in ('auto', 'custom'):   # simulation.py:827-829
+            raise ValueError("{} for config.signal.polarization is not a valid option".format(polarization))
         if trigger not in ('simple', 'high_low', 'phased_array', 'envelope'):
             raise NotImplementedError("trigger {} is not provided (simple, high_low, phased_array, envelope)".format(trigger))
         cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
@@ -534,7 +539,7 @@ class Station:
                         int(bool(select_only)), int(bool(reuse_ray_tables)), int(bool(accumulate_triggered)), int(n_reflections),
                         float(z_reflection), float(reflection_coefficient), float(reflection_phase_shift),
                         float(split_event_time_diff or 0.), int(bool(noise)), int(noise_seed) & 0xffffffffffffffff,
-                        int(noise_group_offset), d_noise_group_id)
+                        int(noise_group_offset), d_noise_group_id, int(polarization == 'custom'), float(ePhi))
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_event_groups(
             self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,

@@ -449,7 +449,7 @@ class Station:
 
 def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model='SP1', n_freq=25,
                           model='Alvarez2009', delta_C_cut=0.698, vertex_time=0., rays=None, max_distance=None,
-                          focusing=False, focusing_limit=2., arz=None, birefringence=None, reflections=None):
+                          focusing=False, focusing_limit=2., arz=None, birefringence=None, reflections=None, polarization_ephi=None):
     """calculate_sim_efield (simulation.py:93-292) for every channel of one single-shower event.
     `rays` may carry precomputed ray tables (dict like raytrace_oracle.raytrace_batch output, one row per channel).
     arz = (arz_oracle.ARZ object, profile number of this shower) for model 'ARZ2019' / 'ARZ2020' (simulation.py:221-242: every
@@ -492,6 +492,10 @@ def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st,
             else:
                 spectrum, _ = askaryan_frequency_spectrum(energy, view[s], N, dt, shower_type, n_index, D, model, k_L=k_L)
             pol = polarization_onsky(shower_direction, rays['launch'][ch, s])
+            if polarization_ephi is not None:   # signal.polarization = 'custom' (simulation.py:821-825)
+                e_phi = float(polarization_ephi)
+                v = np.array([0, (1 - e_phi ** 2) ** 0.5, e_phi])
+                pol = v / np.linalg.norm(v)
             spec = np.outer(pol, spectrum)
             if reflections is not None:
                 att = rto.attenuation_batch_refl(x1[None], st.pos[ch][None], [rays['C0'][ch, s]], [rays['reflection'][ch, s]],
@@ -825,11 +829,11 @@ def station_trigger(V, fs, trigger='simple', threshold=None, n_coincidences=1, t
 def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, vrms, vrms_efield, att_model='SP1',
                    n_freq=25, model='Alvarez2009', filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0,
                    min_efield_amplitude=2.0, rays=None, focusing=False, focusing_limit=2., arz=None, birefringence=None,
-                   reflections=None, noise=None):
+                   reflections=None, noise=None, polarization_ephi=None):
     """One single-shower event group through simulation.run()'s sequence (:1454-1600)."""
     efs = sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, att_model, n_freq, model,
                                 delta_C_cut, rays=rays, focusing=focusing, focusing_limit=focusing_limit, arz=arz,
-                                birefringence=birefringence, reflections=reflections)
+                                birefringence=birefringence, reflections=reflections, polarization_ephi=polarization_ephi)
     out = dict(rays=efs, candidate=False, triggered=False, L=0, t_min=np.nan)
     for ef in efs:
         if ef['max_efield'] > min_efield_amplitude * vrms_efield:

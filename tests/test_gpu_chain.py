@@ -157,6 +157,54 @@ def test_spectral_stages_vs_oracle_on_identical_rays(gpu_ctx_factory, name, n_ev
     assert stats['n_candidate_events'] == n_cand and stats['n_triggered'] == trig.sum()
 
 
+@pytest.mark.gpu
+def test_custom_polarization(gpu_ctx_factory):
+    """config signal.polarization = 'custom' with signal.ePhi (simulation.calculate_polarization_vector :821-825): every ray
+    is polarised along (0, sqrt(1 - ePhi^2), ePhi) in its on-sky basis.  GPU vs oracle on identical rays (HPol + VPol station of
+    the LPDA fixture: the phi component matters): polarisation components, candidate flags, traces 1e-6, decisions; an unknown
+    option raises like the reference."""
+    g = golden('chain_N256_lpda.npz')
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    n, e_phi = 120, 0.6
+    sl = slice(0, n)
+    kL = np.where(np.isnan(g['ev_k_L'][sl]), 1.0, g['ev_k_L'][sl])
+    args = (g['vertex'][sl], g['zenith'][sl], g['azimuth'][sl], g['energy'][sl], g['shower_type'][sl], kL)
+    trig, stats = st.simulate_events(*args, askaryan_model=str(g['askaryan_model']), dump_traces=True, no_pruning=True,
+                                     polarization='custom', ePhi=e_phi)
+    n_ch = len(g['det_pos'])
+    ost = so.Station(g['det_pos'], antenna=_oracle_antenna(g), orientation=tuple(g['det_orientation']),
+                     cable_delay=g['cable_delay'], n_samples=int(g['N']), fs=float(g['fs']))
+    T = {k: st.fetch(k) for k in ('pair_n_sol', 'slot_type', 'slot_C0', 'slot_D', 'slot_T', 'slot_launch', 'slot_receive',
+                                  'slot_refl_angle', 'ray_pol_theta', 'ray_pol_phi', 'ev_candidate', 'ev_L')}
+    assert np.all(np.abs(T['ray_pol_theta'] - 0.8) < 1e-15) and np.all(np.abs(T['ray_pol_phi'] - 0.6) < 1e-15)
+    item_event, toff, trace = st.fetch('item_event'), st.fetch('trace_offset'), st.fetch('trace')
+    n_cand = 0
+    for ev in range(n):
+        ps, ss = slice(ev * n_ch, (ev + 1) * n_ch), slice(ev * n_ch * 2, (ev + 1) * n_ch * 2)
+        rays = dict(n_sol=T['pair_n_sol'][ps], type=T['slot_type'][ss].reshape(n_ch, 2),
+                    C0=T['slot_C0'][ss].reshape(n_ch, 2), D=T['slot_D'][ss].reshape(n_ch, 2),
+                    T=T['slot_T'][ss].reshape(n_ch, 2), refl_angle=T['slot_refl_angle'][ss].reshape(n_ch, 2),
+                    launch=T['slot_launch'][ev * n_ch * 6:(ev + 1) * n_ch * 6].reshape(n_ch, 2, 3),
+                    receive=T['slot_receive'][ev * n_ch * 6:(ev + 1) * n_ch * 6].reshape(n_ch, 2, 3))
+        o = so.simulate_event(g['vertex'][ev], g['zenith'][ev], g['azimuth'][ev], g['energy'][ev], str(g['shower_type'][ev]),
+                              float(kL[ev]), ost, g['ice'], st.vrms, st.vrms_efield, model=str(g['askaryan_model']), rays=rays,
+                              filters=_oracle_filters(g), polarization_ephi=e_phi)
+        assert bool(T['ev_candidate'][ev]) == o['candidate'] and bool(trig[ev]) == o['triggered'], ev
+        if o['candidate']:
+            n_cand += 1
+            i = int(np.where(item_event == ev)[0][0])
+            scale = np.max(np.abs(o['V']))
+            for ch in range(n_ch):
+                tr = trace[toff[i * n_ch + ch]:toff[i * n_ch + ch + 1]]
+                assert len(tr) == o['L'] and np.max(np.abs(tr - o['V'][ch])) <= 1e-6 * scale, (ev, ch)
+    assert n_cand >= 5
+    trig_auto, _ = st.simulate_events(*args, askaryan_model=str(g['askaryan_model']))
+    assert not np.array_equal(trig_auto, trig) or n_cand > 0
+    with pytest.raises(ValueError):
+        st.simulate_events(*args, polarization='eTheta')
+
+
 @pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N256_tab', 160),
                                            ('N4096', 120), ('N256_hw', 220)])
 def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
