@@ -440,6 +440,15 @@ int nrhip_station_set_envelope_trigger(nrhip_station* st, int32_t nb, int32_t na
 int nrhip_station_set_phased_array_adc(nrhip_station* st, double adc_sampling_frequency, int32_t n_bits, double v_min, double v_max,
                                        int32_t output_counts, int32_t upsampling_factor, int32_t saturation_bits, int32_t resample_p,
                                        int32_t resample_q, const int32_t* rolls_up);
+/* Other processing options of the digitised phased array (after nrhip_station_set_phased_array_adc, which resets them):
+ * upsampling_method 0 = 'fft', 1 = 'lin' (np.interp on the two time grids, digital_upsampling :167-170), 2 = 'fir' (upsampling_fir
+ * :192-234: zero stuffing and the low pass up_taps[n_up_taps] -- scipy.signal.firwin(filter_taps, f_adc / 2, fs = f_adc * factor),
+ * rounded to 1 / coeff_gain and trimmed of zeros, as the caller designed it -- times the factor);
+ * mode 0 = 'power_sum', 1 = 'hilbert_env' (PhasedArrayBase.hilbert_envelope :337-367 with ideal_transformer = False: the FIR
+ * transformer hilbert_taps[n_hilbert_taps] on every beam, max + 3/8 min of (signal, transformed signal), rounded for ADC counts;
+ * trigger_threshold then compares with the envelope and "pa_max_power" holds the envelope maxima). */
+int nrhip_station_set_phased_array_processing(nrhip_station* st, int32_t upsampling_method, int32_t n_up_taps, const double* up_taps,
+                                              int32_t mode, int32_t n_hilbert_taps, const double* hilbert_taps);
 /* `amplitude` of the noise adder per channel [n_channels] (simulation.py:596-600: Vrms / sqrt(norm / max_freq), norm = int |H|^2 df,
  * max_freq = sampling rate / 2; 0 = noiseless channel).  n <= 0 removes them. */
 int nrhip_station_set_noise(nrhip_station* st, int32_t n, const double* amplitude);

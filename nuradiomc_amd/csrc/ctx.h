@@ -87,6 +87,7 @@ struct nrhip_station {
     nrhip::PaAdc pa_adc;           // trigger ADC + up-sampling of the phased array (nrhip_station_set_phased_array_adc)
     bool pa_adc_set = false;
     DevArray d_pa_rolls_up;        // beam rolls at the up-sampled ADC rate
+    DevArray d_pa_up_taps, d_pa_hil_taps;   // FIR taps of the 'fir' up-sampling / the Hilbert transformer (nrhip_station_set_phased_array_processing)
     DevArray pa_B;                 // Bluestein tables of the chirp-z digitiser [slot of tabcache][4][FFT_MAX]
     std::vector<char> pa_built;    // per slot: tables present
     int pa_B_cap = 0;

@@ -341,6 +341,7 @@ void nrhip_station_detach(nrhip_station* s)
     s->tabcache.release();
     s->d_noise_amp.release();
     s->d_pa_rolls_up.release();
+    s->d_pa_up_taps.release(); s->d_pa_hil_taps.release();
     s->pa_B.release();
     s->ws.clear();
     s->ws_bytes.clear();
@@ -433,8 +434,43 @@ int nrhip_station_set_phased_array_adc(nrhip_station* s, double adc_fs, int32_t 
     if (upload(s->ctx, s->d_pa_rolls_up, rolls_up, (size_t)s->pa_n_beams * s->pa_n_channels)) return -1;
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
     s->pa_adc = PaAdc{adc_fs, v_min, v_max, n_bits, output_counts ? 1 : 0, upsampling_factor, saturation_bits, resample_p, resample_q, 0};
+    s->pa_adc.up_method = s->pa_adc.mode = s->pa_adc.n_up_taps = s->pa_adc.n_hil_taps = 0;
+    s->pa_adc.up_taps = s->pa_adc.hil_taps = nullptr;
     s->pa_adc_set = true;
     s->pa_built.clear();   // the digitiser's transform tables depend on these rates
+    return 0;
+}
+
+int nrhip_station_set_phased_array_processing(nrhip_station* s, int32_t upsampling_method, int32_t n_up_taps, const double* up_taps,
+                                              int32_t mode, int32_t n_hilbert_taps, const double* hilbert_taps)
+{
+    if (!s || !s->ctx) return nrhip_fail_msg("nrhip_station_set_phased_array_processing: NULL argument or station without a context");
+    if (!s->pa_adc_set) return nrhip_fail_msg("nrhip_station_set_phased_array_processing: nrhip_station_set_phased_array_adc comes first");
+    if (upsampling_method < 0 || upsampling_method > 2)   // NotImplementedError of digital_upsampling :178-180
+        return nrhip_fail_msg("nrhip_station_set_phased_array_processing: Interpolation method must be lin, fft, or fir");
+    if (mode < 0 || mode > 1) return nrhip_fail_msg("nrhip_station_set_phased_array_processing: mode must be either 'power_sum' or 'hilbert_env'");
+    if (upsampling_method == 2 && (!up_taps || n_up_taps < 1 || n_up_taps > 1024))
+        return nrhip_fail_msg("nrhip_station_set_phased_array_processing: the 'fir' up-sampling needs 1..1024 filter taps");
+    if (mode == 1 && (!hilbert_taps || n_hilbert_taps < 1 || n_hilbert_taps > 1024 || n_hilbert_taps % 2 == 0))
+        return nrhip_fail_msg("nrhip_station_set_phased_array_processing: Num taps MUST be odd for a hilbert transformer");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    s->pa_adc.up_method = upsampling_method;
+    s->pa_adc.mode = mode;
+    s->pa_built.clear();   // the transform tables of the up-sampling stage depend on the method
+    s->pa_adc.n_up_taps = s->pa_adc.n_hil_taps = 0;
+    s->pa_adc.up_taps = s->pa_adc.hil_taps = nullptr;
+    if (upsampling_method == 2) {
+        if (upload(s->ctx, s->d_pa_up_taps, up_taps, (size_t)n_up_taps)) return -1;
+        s->pa_adc.n_up_taps = n_up_taps;
+        s->pa_adc.up_taps = s->d_pa_up_taps.as<double>();
+    }
+    if (mode == 1) {
+        if (upload(s->ctx, s->d_pa_hil_taps, hilbert_taps, (size_t)n_hilbert_taps)) return -1;
+        s->pa_adc.n_hil_taps = n_hilbert_taps;
+        s->pa_adc.hil_taps = s->d_pa_hil_taps.as<double>();
+    }
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
     return 0;
 }
 
@@ -1339,6 +1375,18 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                 int* pa_len;
                 NEED(pa_trace = WS("pa_digital_trace", double, (size_t)n_cand * st->pa_n_channels * adc.stride));
                 NEED(pa_len = WS("pa_digital_length", int, (size_t)n_cand * st->pa_n_channels));
+                // 'lin' / 'fir' up-sampling: the digitisers stop at the ADC trace (factor 1, own buffer), pa_upsample_kernel follows
+                const PaAdc adc_final = adc;
+                double* pa_final = pa_trace;
+                int* len_final = pa_len;
+                const bool own_upsampling = adc.up_method != 0 && adc.upsampling >= 2;
+                if (own_upsampling) {
+                    adc.upsampling = 1;
+                    adc.stride = (int)(adc.adc_fs / cur * len5max) + 4;
+                    NEED(pa_trace = WS("pa_adc_trace", double, (size_t)n_cand * st->pa_n_channels * adc.stride));
+                    NEED(pa_len = WS("pa_adc_length", int, (size_t)n_cand * st->pa_n_channels));
+                }
+                const bool with_beams = !own_upsampling;
                 if (pa_czt_applies(maxL, sd.fs, adc) && !getenv("NRHIP_PA_DIRECT")) {
                     // chirp-z transforms; their tables join the station's per-length cache (same slots)
                     if (st->pa_B_cap < tc.cap) {
@@ -1374,12 +1422,18 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                                                     st->pa_n_channels, st->d_pa_channel.as<int>(), st->pa_n_beams,
                                                     st->d_pa_rolls_up.as<int>(), st->pa_window, st->pa_step, (double)st->pa_divisor,
                                                     cfg->trigger_threshold, maxL, sd.fs, adc, ctx->twiddle, st->pa_B.as<double2>(), work,
-                                                    chunk, pa_trace, pa_len, triggered, pa_max);
+                                                    chunk, pa_trace, pa_len, triggered, pa_max, with_beams);
                 } else
                 launch_phased_array_digital(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, st->pa_n_channels,
                                             st->d_pa_channel.as<int>(), st->pa_n_beams, st->d_pa_rolls_up.as<int>(), st->pa_window,
                                             st->pa_step, (double)st->pa_divisor, cfg->trigger_threshold, maxL, sd.fs, adc, pa_trace, pa_len,
-                                            triggered, pa_max);
+                                            triggered, pa_max, with_beams);
+                if (own_upsampling) {
+                    launch_pa_upsample(sm, n_cand * st->pa_n_channels, adc_final, pa_trace, adc.stride, pa_len, pa_final, len_final);
+                    launch_phased_array_beams(sm, n_cand, d_cand, st->pa_n_channels, st->pa_n_beams, st->d_pa_rolls_up.as<int>(),
+                                              st->pa_window, st->pa_step, (double)st->pa_divisor, cfg->trigger_threshold, adc_final,
+                                              pa_final, len_final, triggered, pa_max);
+                }
             } else
             launch_phased_array(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, st->pa_n_channels,
                                 st->d_pa_channel.as<int>(), st->pa_n_beams, st->d_pa_rolls.as<int>(), st->pa_window, st->pa_step,

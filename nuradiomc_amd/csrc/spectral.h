@@ -205,7 +205,13 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
 struct PaAdc {
     double adc_fs, vmin, vmax;   // ADC sampling rate [GHz], voltage range
     int n_bits, counts, upsampling, saturation_bits, p, q, stride;  // 5 GHz / f_s = p / q; stride: samples per output trace
+    int up_method = 0, n_up_taps = 0;     // 0 'fft', 1 'lin', 2 'fir' (taps up_taps)
+    int mode = 0, n_hil_taps = 0;         // 0 'power_sum', 1 'hilbert_env' (FIR transformer hil_taps)
+    const double *up_taps = nullptr, *hil_taps = nullptr;   // device
 };
+// 'lin' / 'fir' up-sampling of ADC traces [n_items][stride_in] (lengths len_in) into pa_trace [n_items][adc.stride]
+void launch_pa_upsample(hipStream_t s, int n_items, const PaAdc& adc, const double* adc_trace, int stride_in, const int* len_in,
+                        double* pa_trace, int* pa_len);
 // the chirp-z version of the same chain (O(L log L) transforms; tables per trace length in the station's cache)
 bool pa_czt_applies(int max_length, double fs, const PaAdc& adc);
 size_t pa_czt_work_bytes(int max_length, double fs, const PaAdc& adc, int chunk);
@@ -215,11 +221,14 @@ void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_
                                      const double* trace, const long* trace_offset, int n_pa, const int* pa_channel, int n_beams,
                                      const int* rolls_up, int window, int step, double divisor, double threshold, int max_length, double fs,
                                      const PaAdc& adc, const double2* tw, const double2* Btab, void* work, int chunk, double* pa_trace,
-                                     int* pa_len, unsigned char* triggered, double* pa_max);
+                                     int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams = true);
+void launch_phased_array_beams(hipStream_t s, int n_cand, const int* item_event, int n_pa, int n_beams, const int* rolls_up, int window,
+                               int step, double divisor, double threshold, const PaAdc& adc, const double* pa_trace, const int* pa_len,
+                               unsigned char* triggered, double* pa_max);
 void launch_phased_array_digital(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                                  const long* trace_offset, int n_pa, const int* pa_channel, int n_beams, const int* rolls_up, int window,
                                  int step, double divisor, double threshold, int max_length, double fs, const PaAdc& adc,
-                                 double* pa_trace, int* pa_len, unsigned char* triggered, double* pa_max);
+                                 double* pa_trace, int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams = true);
 void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                           const long* trace_offset, const TriggerDev& trg, const unsigned char* trig_on, int max_length,
                           unsigned char* triggered, int* trigger_bin);

@@ -3528,6 +3528,68 @@ pa_adc_sample_kernel(int item0, int n_cand, const int* __restrict__ item_event, 
     if (threadIdx.x == 0) pa_len[item] = z.n_up - (z.n_up & 1);
 }
 
+// 'lin' and 'fir' up-sampling of the ADC traces (signal_processing.digital_upsampling :163-190, upsampling_fir :192-234); one block
+// per (candidate event, array channel).  'lin': np.interp of the trace on cur_t = arange(0, n / f, 1 / f) at
+// new_t = arange(0, n / f, 1 / (f up)) (numpy's lengths ceil(stop / step), values i * step; beyond the last node the last value);
+// 'fir': out[i] = up sum_j zp[j] h[i + off - j] with the zero-stuffed trace zp[j up] = d[j], off = len(h) // 2 - 1 (np.convolve
+// 'full', sliced).  ADC counts are rounded (the sums are exact: coefficients are multiples of 1 / coeff_gain); an odd length
+// loses its last sample.
+__global__ void __launch_bounds__(256)
+pa_upsample_kernel(int n_items, PaAdc adc, const double* __restrict__ adc_trace, int stride_in, const int* __restrict__ len_in,
+                   double* __restrict__ pa_trace, int* __restrict__ pa_len)
+{
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const double* d = adc_trace + (long)item * stride_in;
+        double* out = pa_trace + (long)item * adc.stride;
+        const int n = len_in[item], up = adc.upsampling;
+        int n_new;
+        if (adc.up_method == 1) {
+            const double dt = 1 / adc.adc_fs, stop = dt * n, dtn = 1 / (adc.adc_fs * up);
+            n_new = (int)ceil(stop / dtn);
+            if (n_new > adc.stride) n_new = adc.stride;
+            for (int i = threadIdx.x; i < n_new; i += blockDim.x) {
+                const double x = i * dtn;
+                int j = (int)floor(x * adc.adc_fs);
+                j = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
+                while (j > 0 && j * dt > x) j--;
+                while (j < n - 1 && (j + 1) * dt <= x) j++;
+                double v;
+                if (x > (n - 1) * dt || j == n - 1) v = d[n - 1];
+                else if (j * dt == x) v = d[j];
+                else {
+                    const double slope = (d[j + 1] - d[j]) / ((j + 1) * dt - j * dt);
+                    v = slope * (x - j * dt) + d[j];
+                }
+                out[i] = adc.counts ? rint(v) : v;
+            }
+        } else {
+            n_new = n * up;
+            const int nh = adc.n_up_taps, off = nh / 2 - 1;
+            for (int i = threadIdx.x; i < n_new; i += blockDim.x) {
+                // zp index m = j up contributes h[i + off - m]: 0 <= i + off - m < nh
+                int j_lo = (i + off - (nh - 1) + up - 1);
+                j_lo = j_lo > 0 ? j_lo / up : 0;
+                int j_hi = (i + off) / up;
+                if (i + off < 0) j_hi = -1;
+                if (j_hi > n - 1) j_hi = n - 1;
+                double acc = 0.;
+                for (int j = j_lo; j <= j_hi; j++) acc += d[j] * adc.up_taps[i + off - j * up];
+                acc *= up;
+                out[i] = adc.counts ? rint(acc) : acc;
+            }
+        }
+        if (threadIdx.x == 0) pa_len[item] = n_new - (n_new & 1);
+    }
+}
+
+void launch_pa_upsample(hipStream_t s, int n_items, const PaAdc& adc, const double* adc_trace, int stride_in, const int* len_in,
+                        double* pa_trace, int* pa_len)
+{
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(pa_upsample_kernel, dim3(n_items < 8192 ? n_items : 8192), dim3(256), 0, s, n_items, adc, adc_trace, stride_in,
+                       len_in, pa_trace, pa_len);
+}
+
 // beams and power windows on the digitised, up-sampled traces (phase_signals with the saturation of ADC counts :183-215,
 // power_sum with its rounding :217-271, the decision of phased_trigger :455-496)
 __global__ void __launch_bounds__(256)
@@ -3556,6 +3618,21 @@ phased_array_digital_kernel(int n_cand, const int* __restrict__ item_event, cons
             }
             __syncthreads();
             double mx = -INFINITY;
+            if (adc.mode == 1) {
+                // hilbert_envelope (:337-367): imaginary part by the FIR transformer (np.convolve 'full', centred), the magnitude
+                // estimate max + 3/8 min of the two SIGNED sequences as the reference writes it, rounded for counts
+                const int nh = adc.n_hil_taps, half = nh / 2;
+                for (int n = threadIdx.x; n < Lu; n += blockDim.x) {
+                    const int j_lo = max(0, n + half - (nh - 1)), j_hi = min(Lu - 1, n + half);
+                    double im = 0.;
+                    for (int j = j_lo; j <= j_hi; j++) im += coh[j] * adc.hil_taps[n + half - j];
+                    if (adc.counts) im = rint(im);
+                    const double c = coh[n];
+                    double env = fmax(c, im) + (3. / 8.) * fmin(c, im);
+                    if (adc.counts) env = rint(env);
+                    mx = fmax(mx, env);
+                }
+            } else
             for (int f = threadIdx.x; f < n_frames; f += blockDim.x) {
                 double p = 0.;
                 for (int j = 0; j < window; j++) {
@@ -3574,21 +3651,32 @@ phased_array_digital_kernel(int n_cand, const int* __restrict__ item_event, cons
     }
 }
 
+void launch_phased_array_beams(hipStream_t s, int n_cand, const int* item_event, int n_pa, int n_beams, const int* rolls_up, int window,
+                               int step, double divisor, double threshold, const PaAdc& adc, const double* pa_trace, const int* pa_len,
+                               unsigned char* triggered, double* pa_max)
+{
+    if (n_cand <= 0) return;
+    set_big_lds();
+    (void)hipFuncSetAttribute((const void*)phased_array_digital_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, adc.stride * 8 + 64);
+    hipLaunchKernelGGL(phased_array_digital_kernel, dim3(n_cand < 4096 ? n_cand : 4096), dim3(256), (size_t)adc.stride * 8 + 64, s, n_cand,
+                       item_event, pa_trace, pa_len, n_pa, n_beams, rolls_up, window, step, divisor, threshold, adc, triggered, pa_max);
+}
+
 void launch_phased_array_digital(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                                  const long* trace_offset, int n_pa, const int* pa_channel, int n_beams, const int* rolls_up, int window,
                                  int step, double divisor, double threshold, int max_length, double fs, const PaAdc& adc,
-                                 double* pa_trace, int* pa_len, unsigned char* triggered, double* pa_max)
+                                 double* pa_trace, int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams)
 {
     if (n_cand <= 0) return;
     set_big_lds();
     const size_t lds1 = (size_t)(2 * max_length + 16) * 8 + 64;
     (void)hipFuncSetAttribute((const void*)pa_digitize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    (void)hipFuncSetAttribute((const void*)phased_array_digital_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, adc.stride * 8 + 64);
     const int n_items = n_cand * n_pa;
     hipLaunchKernelGGL(pa_digitize_kernel, dim3(n_items < 4096 ? n_items : 4096), dim3(1024), lds1, s, n_cand, item_event, n_ch, ev_L, trace,
                        trace_offset, n_pa, pa_channel, fs, adc, pa_trace, pa_len);
-    hipLaunchKernelGGL(phased_array_digital_kernel, dim3(n_cand < 4096 ? n_cand : 4096), dim3(256), (size_t)adc.stride * 8 + 64, s, n_cand,
-                       item_event, pa_trace, pa_len, n_pa, n_beams, rolls_up, window, step, divisor, threshold, adc, triggered, pa_max);
+    if (with_beams)
+        launch_phased_array_beams(s, n_cand, item_event, n_pa, n_beams, rolls_up, window, step, divisor, threshold, adc, pa_trace, pa_len,
+                                  triggered, pa_max);
 }
 
 // whether the chirp-z digitiser takes this configuration: resampling through 5 GHz, transforms with at least 1024 outputs per block
@@ -3620,12 +3708,11 @@ void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_
                                      const double* trace, const long* trace_offset, int n_pa, const int* pa_channel, int n_beams,
                                      const int* rolls_up, int window, int step, double divisor, double threshold, int max_length, double fs,
                                      const PaAdc& adc, const double2* tw, const double2* Btab, void* work, int chunk, double* pa_trace,
-                                     int* pa_len, unsigned char* triggered, double* pa_max)
+                                     int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams)
 {
     if (n_cand <= 0) return;
     set_big_lds();
     (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
-    (void)hipFuncSetAttribute((const void*)phased_array_digital_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, adc.stride * 8 + 64);
     const PaSizes z = pa_sizes(max_length, fs, adc);
     PaWork wk;
     wk.xs = z.m + 2; wk.s5 = (int)z.num2 + 2; wk.sd = z.n_dig + 4;
@@ -3654,8 +3741,9 @@ void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_
                                item_event, n_ch, ev_L, slotmap, trace, trace_offset, n_pa, pa_channel, fs, adc, tw, Btab, wk, pa_trace);
         }
     }
-    hipLaunchKernelGGL(phased_array_digital_kernel, dim3(n_cand < 4096 ? n_cand : 4096), dim3(256), (size_t)adc.stride * 8 + 64, s, n_cand,
-                       item_event, pa_trace, pa_len, n_pa, n_beams, rolls_up, window, step, divisor, threshold, adc, triggered, pa_max);
+    if (with_beams)
+        launch_phased_array_beams(s, n_cand, item_event, n_pa, n_beams, rolls_up, window, step, divisor, threshold, adc, pa_trace, pa_len,
+                                  triggered, pa_max);
 }
 
 // ---------------------------------------------------------------------------------------------------------

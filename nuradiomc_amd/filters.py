@@ -178,3 +178,24 @@ def vrms_from_filters(sampling_rate, filters, noise_temperature=300.):
     bandwidth = np.sum(0.5 * (H[1:] ** 2 + H[:-1] ** 2) * np.diff(ff))
     vrms = (noise_temperature * (50 * ohm) * bandwidth * k_B) ** 0.5
     return vrms, vrms / H.max() / 1.0
+
+
+def firwin(numtaps, cutoff, pass_zero=True, fs=2.0):
+    """scipy.signal.firwin for ONE cutoff with the Hamming window (numpy only): low pass (pass_zero=True) or high pass (False, odd
+    numtaps): windowed ideal response, scaled to unit gain at 0 (low pass) or at Nyquist (high pass).  What
+    signal_processing.upsampling_fir :224-226 and PhasedArrayBase.hilbert_envelope :351 design their filters with."""
+    numtaps = int(numtaps)
+    c = float(cutoff) / (0.5 * fs)
+    if not 0. < c < 1.:
+        raise ValueError("Invalid cutoff frequency: frequencies must be greater than 0 and less than fs/2.")
+    if not pass_zero and numtaps % 2 == 0:
+        raise ValueError("A filter with an even number of coefficients must have zero response at the Nyquist frequency.")
+    left, right = (0., c) if pass_zero else (c, 1.)
+    m = np.arange(0, numtaps) - 0.5 * (numtaps - 1)
+    h = right * np.sinc(right * m) - left * np.sinc(left * m)
+    # scipy.signal.windows.hamming(numtaps, sym=True) = general_cosine with a = (0.54, 0.46)
+    fac = np.linspace(-np.pi, np.pi, numtaps)
+    h = h * (0.54 * np.cos(0 * fac) + 0.46 * np.cos(1 * fac)) if numtaps > 1 else h
+    scale_frequency = 0. if left == 0 else 1.
+    h /= np.sum(h * np.cos(np.pi * m * scale_frequency))
+    return h

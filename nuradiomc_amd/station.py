@@ -112,6 +112,8 @@ L._OPTIONAL.update({
     'nrhip_station_set_phased_array_adc': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_double, ctypes.c_double,
                                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                           L.c_int32_p]),
+    'nrhip_station_set_phased_array_processing': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p,
+                                                                 ctypes.c_int32, ctypes.c_int32, L.c_double_p]),
     'nrhip_station_set_phased_array': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_int32_p, ctypes.c_int32, L.c_int32_p,
                                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'nrhip_station_set_arz': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p, L.c_double_p,
@@ -424,7 +426,8 @@ class Station:
         return amp
 
     def set_phased_array(self, channels, phasing_angles, ref_index=1.75, window=32, step=16, averaging_divisor=None, adc=None,
-                         upsampling_factor=1, saturation_bits=8):
+                         upsampling_factor=1, saturation_bits=8, upsampling_method='fft', coeff_gain=1, filter_taps=45,
+                         mode='power_sum', hilbert_transformer_kwargs=None):
         """Phased-array trigger on the given channels (a vertical string): beams towards `phasing_angles` [rad], whole-sample
         channel shifts as PhasedArrayBase.calculate_time_delays (phasedArrayBase.py:58-124: antenna depths, ref_index, cable
         delays; no group delays), mean power in windows of `window` samples every `step` (power_sum :217-271).
@@ -432,7 +435,17 @@ class Station:
         phasedArrayTrigger.run(apply_digitization=True) (trigger_adc_sampling_frequency / trigger_adc_nbits / trigger_adc_noise_count
         of the detector description, Vrms of adc_kwargs) followed by FFT up-sampling by `upsampling_factor`; beams, windows and
         steps then count samples of the up-sampled ADC trace, count sums saturate at `saturation_bits`.  Without `adc` everything
-        runs at the simulation's sampling rate on the analog traces.  channels=None switches the trigger off."""
+        runs at the simulation's sampling rate on the analog traces.  channels=None switches the trigger off.
+        With `adc`: upsampling_method 'fft' | 'lin' | 'fir' (coeff_gain, filter_taps: upsampling_kwargs of phased_trigger;
+        signal_processing.digital_upsampling :111-190, upsampling_fir :192-234) and mode 'power_sum' | 'hilbert_env'
+        (hilbert_transformer_kwargs = dict(hilbert_n_taps=31, hilbert_coeff_gain=128): PhasedArrayBase.hilbert_envelope :337-367
+        with the FIR transformer; the ideal transformer is not provided) -- the threshold then compares with the envelope."""
+        if upsampling_method not in ('fft', 'lin', 'fir'):
+            raise NotImplementedError('Interpolation method must be lin, fft, or fir')
+        if mode not in ('power_sum', 'hilbert_env'):
+            raise ValueError("mode must be either 'power_sum' or 'hilbert_env'")
+        if adc is None and (mode != 'power_sum' or (upsampling_method != 'fft' and int(upsampling_factor) >= 2)):
+            raise NotImplementedError("up-sampling methods and the envelope mode of the phased array are provided together with the trigger ADC (adc=...)")
         if channels is None:
             L.check(self._lib.nrhip_station_set_phased_array(self._h, 0, None, 0, None, 0, 0, 0))
             return None
@@ -465,6 +478,32 @@ class Station:
             L.check(self._lib.nrhip_station_set_phased_array_adc(self._h, f_adc, n_bits, -half, half,
                                                                  int(adc.get('output', 'voltage') == 'counts'), up, int(saturation_bits),
                                                                  fr.numerator, fr.denominator, L.iptr(rolls)))
+            up_taps = hil_taps = None
+            if upsampling_method == 'fir' and up >= 2:    # upsampling_fir :224-230
+                from . import filters
+                up_taps = filters.firwin(int(filter_taps), f_adc * 0.5, True, f_adc * up)
+                if coeff_gain != 1:
+                    up_taps = np.trim_zeros(np.round(up_taps * coeff_gain) / coeff_gain)
+                up_taps = np.ascontiguousarray(up_taps, np.float64)
+            if mode == 'hilbert_env':                     # hilbert_envelope :348-355
+                from . import filters
+                hk = dict(ideal_transformer=False, hilbert_n_taps=31, hilbert_coeff_gain=128)
+                hk.update(hilbert_transformer_kwargs or {})
+                if hk['ideal_transformer']:
+                    raise NotImplementedError("the ideal Hilbert transformer (scipy.signal.hilbert) of the phased array is not provided")
+                nt = int(hk['hilbert_n_taps'])
+                assert nt % 2 != 0, "Num taps MUST be odd for a hilbert transformer"
+                sin_factor = np.sin(np.linspace(-(nt - 1) / 2, (nt - 1) / 2, nt))
+                hil_taps = 2 * sin_factor * (-1 * filters.firwin(nt, 0.25, False, 1))
+                if hk['hilbert_coeff_gain'] != 1:
+                    hil_taps = np.round(hil_taps * hk['hilbert_coeff_gain']) / hk['hilbert_coeff_gain']
+                hil_taps = np.ascontiguousarray(hil_taps, np.float64)
+            method = {'fft': 0, 'lin': 1, 'fir': 2}[upsampling_method] if up >= 2 else 0
+            if method or hil_taps is not None:
+                L.check(self._lib.nrhip_station_set_phased_array_processing(
+                    self._h, method, 0 if up_taps is None else len(up_taps), None if up_taps is None else L.dptr(up_taps),
+                    int(hil_taps is not None), 0 if hil_taps is None else len(hil_taps),
+                    None if hil_taps is None else L.dptr(hil_taps)))
         return rolls
 
     @staticmethod

@@ -726,6 +726,75 @@ def digital_upsampling_fft(d, factor):
     return u
 
 
+def digital_upsampling(d, adc_fs, method='fft', factor=2, coeff_gain=1, filter_taps=45):
+    """signal_processing.digital_upsampling (:111-190) with all three methods: 'fft' (above), 'lin' (np.interp on the two time
+    grids) and 'fir' (upsampling_fir :192-234: zero stuffing, scipy.signal.firwin low pass at half the ADC rate with the
+    coefficients rounded to 1 / coeff_gain and trimmed, times the factor); integer traces stay integer, even length"""
+    d = np.asarray(d)
+    factor = int(factor)
+    if factor <= 1:
+        return d
+    if method == 'fft':
+        return digital_upsampling_fft(d, factor)
+    digital = np.allclose(d, np.round(d))
+    if method == 'lin':
+        cur_t = np.arange(0, 1 / adc_fs * len(d), 1 / adc_fs)
+        new_t = np.arange(0, 1 / adc_fs * len(d), 1 / (adc_fs * factor))
+        u = np.interp(new_t, cur_t, d)
+    elif method == 'fir':
+        h = signal.firwin(filter_taps, adc_fs * 0.5, pass_zero='lowpass', fs=adc_fs * factor)
+        if coeff_gain != 1:
+            h = np.trim_zeros(np.round(h * coeff_gain) / coeff_gain)
+        zp = np.zeros(len(d) * factor)
+        zp[::factor] = d
+        u = np.convolve(zp, h, mode='full')[(len(h) // 2) - 1:len(zp) + (len(h) // 2) - 1] * factor
+    else:
+        raise NotImplementedError('Interpolation method must be lin, fft, or fir')
+    if digital:
+        u = np.round(u).astype(int)
+    if len(u) % 2:
+        u = u[:-1]
+    return u
+
+
+def hilbert_transformer_taps(n_taps=31, coeff_gain=1):
+    """the FIR Hilbert transformer of PhasedArrayBase.hilbert_envelope (phasedArrayBase.py:348-355)"""
+    assert n_taps % 2 != 0, "Num taps MUST be odd for a hilbert transformer"
+    sin_factor = np.sin(np.linspace(-(n_taps - 1) / 2, (n_taps - 1) / 2, n_taps))
+    hil = 2 * sin_factor * (-1 * signal.firwin(n_taps, cutoff=0.25, pass_zero=False, fs=1))
+    if coeff_gain != 1:
+        hil = np.round(hil * coeff_gain) / coeff_gain
+    return hil
+
+
+def hilbert_envelope_fir(coh, output='voltage', n_taps=31, coeff_gain=1):
+    """PhasedArrayBase.hilbert_envelope (:337-367) with ideal_transformer=False: imaginary part by the FIR transformer, magnitude
+    estimate max + 3/8 min of (signal, transformed signal), rounded for ADC counts"""
+    coh = np.asarray(coh, float)
+    hil = hilbert_transformer_taps(n_taps, coeff_gain)
+    im = np.convolve(coh, hil, mode='full')[len(hil) // 2:len(coh) + len(hil) // 2]
+    if output == 'counts':
+        im = np.rint(im)
+    env = np.max(np.array((coh, im)), axis=0) + (3 / 8) * np.min(np.array((coh, im)), axis=0)
+    if output == 'counts':
+        env = np.rint(env)
+    return env
+
+
+def phased_array_envelope_digital(U, rolls, output='voltage', saturation_bits=8, n_taps=31, coeff_gain=1):
+    """phase_signals (:183-215) + hilbert_envelope per beam: phased_trigger's mode 'hilbert_env' (:507-510)"""
+    out = []
+    U = np.asarray(U, float)
+    for roll in rolls:
+        coh = np.zeros(U.shape[1])
+        for c in range(U.shape[0]):
+            coh += np.roll(U[c], int(roll[c]))
+        if output == 'counts' and saturation_bits is not None:
+            coh = np.clip(coh, -2 ** (saturation_bits - 1), 2 ** (saturation_bits - 1) - 1)
+        out.append(hilbert_envelope_fir(coh, output, n_taps, coeff_gain))
+    return np.array(out)
+
+
 def phased_array_power_digital(U, rolls, window, step, output='voltage', saturation_bits=8, averaging_divisor=None):
     """phase_signals with the saturation of ADC counts (phasedArrayBase.py:183-215) + power_sum with its rounding (:217-271)"""
     out = []

@@ -157,6 +157,66 @@ def test_spectral_stages_vs_oracle_on_identical_rays(gpu_ctx_factory, name, n_ev
     assert stats['n_candidate_events'] == n_cand and stats['n_triggered'] == trig.sum()
 
 
+@pytest.mark.parametrize('output,method,mode', [('counts', 'lin', 'power_sum'), ('counts', 'fir', 'hilbert_env'),
+                                                ('voltage', 'fir', 'power_sum'), ('voltage', 'lin', 'hilbert_env')])
+def test_phased_array_upsampling_methods_and_envelope_mode(gpu_ctx_factory, output, method, mode):
+    """The other processing options of the digitised phased array inside simulate_events: upsampling_method 'lin' / 'fir'
+    (coefficients rounded to 1 / 128) and mode 'hilbert_env' (FIR Hilbert transformer, max + 3/8 min).  GPU vs the oracle's
+    restatement (pinned on the reference's own functions in test_phased_array_modes_vs_reference) applied to the channel traces the
+    GPU dumped: up-sampled traces (counts: every sample; volts 1e-9 lsb), per-beam maxima (window powers or envelopes) and
+    decisions."""
+    ice = (1.78, 0.423, 77.)
+    pos = np.array([[0., 0., -96.], [0., 0., -97.], [0., 0., -98.], [0., 0., -99.], [0., 0., -60.], [20., 15., -95.]])
+    cable = np.array([1.2, 0., 2.6, 0.7, 0., 3.])
+    ctx = gpu_ctx_factory(ice, 'SP1')
+    st = nuradiomc_amd.Station(ctx, pos, cable_delay=cable, n_samples=512, sampling_rate=2.0)
+    vrms = st.vrms
+    angles = np.arcsin(np.linspace(np.sin(-60 * np.pi / 180), np.sin(60 * np.pi / 180), 11))
+    window, step, adc_fs, nbits, ncount, up, gain, taps, htaps, hgain = 24, 8, 0.472, 8, 5, 4, 128, 31, 31, 128
+    rolls = st.set_phased_array([0, 1, 2, 3], angles, ref_index=1.75, window=window, step=step, upsampling_factor=up,
+                                adc=dict(sampling_frequency=adc_fs, n_bits=nbits, noise_count=ncount, output=output),
+                                upsampling_method=method, coeff_gain=gain, filter_taps=taps, mode=mode,
+                                hilbert_transformer_kwargs=dict(hilbert_n_taps=htaps, hilbert_coeff_gain=hgain))
+    lsb = vrms / ncount
+    unit = vrms / lsb if output == 'counts' else vrms
+    threshold = 2.5 * (2 * unit) ** 2 if mode == 'power_sum' else 7. * unit
+    rng = np.random.default_rng(14)
+    n = 120
+    r, ph = np.sqrt(rng.uniform(0, 1500. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    v = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1500., -10., n)], axis=1)
+    zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    en = 10 ** rng.uniform(16.8, 18.2, n)
+    trig, stats = st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold, dump_traces=True)
+    item_event, tr, off = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    dig, dlen = st.fetch('pa_digital_trace'), st.fetch('pa_digital_length').reshape(len(item_event), 4)
+    stride = len(dig) // (len(item_event) * 4)
+    dig = dig.reshape(len(item_event), 4, stride)
+    pa_max = st.fetch('pa_max_power').reshape(len(item_event), len(angles))
+    n_ch = len(pos)
+    n_trig = 0
+    for i, e in enumerate(item_event):
+        V = np.array([tr[off[i * n_ch + c]:off[i * n_ch + c + 1]] for c in range(4)])
+        U = np.array([so.digital_upsampling(so.adc_digital_trace(x, 2.0, adc_fs, nbits, vrms, ncount, output), adc_fs, method, up,
+                                            gain, taps) for x in V])
+        assert np.all(dlen[i] == U.shape[1])
+        got = dig[i, :, :U.shape[1]]
+        assert np.max(np.abs(got - U)) <= (0 if output == 'counts' else 1e-9 * lsb), e
+        if mode == 'power_sum':
+            p = so.phased_array_power_digital(U, rolls, window, step, output)
+        else:
+            p = so.phased_array_envelope_digital(U, rolls, output, 8, htaps, hgain)
+        mx = p.max(axis=1)
+        assert np.max(np.abs(pa_max[i] - mx)) <= 1e-9 * np.max(np.abs(mx)), e
+        t = bool(np.any(p > (np.trunc(threshold) if output == 'counts' else threshold)))
+        assert t == bool(trig[e]), e
+        n_trig += t
+    assert len(item_event) >= 15 and 2 <= n_trig < len(item_event)
+    with pytest.raises(NotImplementedError):
+        st.set_phased_array([0, 1, 2, 3], angles, upsampling_factor=2, upsampling_method='cubic')
+    with pytest.raises(ValueError):
+        st.set_phased_array([0, 1, 2, 3], angles, mode='amplitude')
+
+
 @pytest.mark.gpu
 def test_custom_polarization(gpu_ctx_factory):
     """config signal.polarization = 'custom' with signal.ePhi (simulation.calculate_polarization_vector :821-825): every ray

@@ -437,3 +437,24 @@ def test_phased_array_adc_vs_reference():
             p = so.phased_array_power_digital(ups, rolls, window, step, output)
             ref = g['power_%d' % k][e]
             assert p.shape == ref.shape and np.max(np.abs(p - ref)) <= 1e-9 * np.max(ref), (k, e)
+
+
+def test_phased_array_modes_vs_reference():
+    """The other up-sampling methods ('lin', 'fir' with rounded coefficients) and the FIR Hilbert envelope of the phased-array
+    trigger: oracle vs the reference's own digital_upsampling / hilbert_envelope (tests/golden/gen/gen_pa_modes.py) -- ADC counts
+    every sample equal, voltages 1e-12; the product's numpy-only firwin against scipy's."""
+    from scipy import signal as ssig
+    from nuradiomc_amd import filters
+    from oracle import spectral_oracle as so
+    g = golden('ref_pa_modes.npz')
+    for k, (n, fs, method, up, gain, taps, counts, new_fs) in enumerate(g['up_cases']):
+        x, ref = g['up_in_%d' % k], g['up_out_%d' % k]
+        got = so.digital_upsampling(x, fs, {1: 'lin', 2: 'fir'}[int(method)], int(up), gain if gain != 1 else 1, int(taps))
+        assert len(got) == len(ref), k
+        assert np.max(np.abs(got - ref)) <= (0 if counts else 1e-12 * np.max(np.abs(ref))), k
+    for k, (n, taps, gain, counts) in enumerate(g['hil_cases']):
+        c, ref = g['hil_in_%d' % k], g['hil_out_%d' % k]
+        got = so.hilbert_envelope_fir(c, 'counts' if counts else 'voltage', int(taps), gain if gain != 1 else 1)
+        assert np.max(np.abs(got - ref)) <= (0 if counts else 1e-12 * np.max(np.abs(ref))), k
+    for taps, cutoff, pz, fs in ((45, 0.236, True, 1.888), (31, 0.25, False, 1.), (23, 0.3, True, 2.4), (15, 0.25, False, 1.)):
+        assert np.max(np.abs(filters.firwin(taps, cutoff, pz, fs) - ssig.firwin(taps, cutoff, pass_zero=pz, fs=fs))) < 1e-15
