@@ -11,10 +11,15 @@ TAG=$(echo "${NRHIP_LIB_NAME:-libnrhip.so}" | tr -c 'A-Za-z0-9' '_')
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I include -I nuradiomc_amd/csrc"
 OBJS=""
 PIDS=""
+# The ray tracer and the attenuation quadrature are bit-equal to the CPU checker: nothing may be fused there but the explicit
+# fma() calls (-ffp-contract=off).  The spectral chain, the ARZ model and the birefringent propagation are held to 1e-6 / 1e-9
+# relative, not to bits: there a * b + c may become one v_fma_f64 (a third fewer FP64 instructions in the complex arithmetic).
 for f in api raytrace raytrace_refl arz birefringence earth attenuation comm cull spectral pipeline; do
     o=nuradiomc_amd/lib/obj/${TAG}_$f.o
     OBJS="$OBJS $o"
-    $HIPCC $FLAGS "$@" -c nuradiomc_amd/csrc/$f.hip -o $o &
+    CONTRACT=""
+    case $f in spectral|arz|birefringence) CONTRACT="-ffp-contract=${NRHIP_SPECTRAL_CONTRACT:-fast-honor-pragmas}";; esac
+    $HIPCC $FLAGS $CONTRACT "$@" -c nuradiomc_amd/csrc/$f.hip -o $o &
     PIDS="$PIDS $!"
 done
 for p in $PIDS; do wait $p; done

@@ -340,7 +340,9 @@ __device__ inline void bire_sincos_small(double x, double* sn, double* cs)
     *cs = c;
 }
 
+#ifndef BIRE_BINS
 #define BIRE_BINS 9   // frequency bins per lane: n_f = 2^p + 1 bins fill ceil(n_f / 9) lanes = 89 % of whole waves
+#endif
 
 // spectra [n_rays][2][n_f] complex, in place.  A lane owns the bins k = tid + j T (T lanes per ray, j < BIRE_BINS): the phase of a
 // step is linear in the bin number, so per step a lane takes exp(i tid theta) once (polynomial) and walks its bins by multiplying

@@ -3251,6 +3251,7 @@ pa_digitize_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, con
                    const double* __restrict__ trace, const long* __restrict__ trace_offset, int n_pa, const int* __restrict__ pa_channel,
                    double fs, PaAdc adc, double* __restrict__ pa_trace, int* __restrict__ pa_len)
 {
+#pragma clang fp contract(off)   // counts are compared sample by sample with the CPU restatement: no fused rounding here
     extern __shared__ double pd_lds[];
     const int n_items = n_cand * n_pa;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -3501,6 +3502,7 @@ __global__ void __launch_bounds__(256)
 pa_adc_sample_kernel(int item0, int n_cand, const int* __restrict__ item_event, const int* __restrict__ ev_L, int n_pa, double fs,
                      PaAdc adc, PaWork wk, double* __restrict__ pa_trace, int* __restrict__ pa_len)
 {
+#pragma clang fp contract(off)   // counts are compared sample by sample with the CPU restatement: no fused rounding here
     const int item = item0 + blockIdx.x, n_items = n_cand * n_pa, wi = blockIdx.x;
     if (item >= n_items) return;
     const int e = item_event[item / n_pa];
@@ -3538,6 +3540,7 @@ __global__ void __launch_bounds__(256)
 pa_upsample_kernel(int n_items, PaAdc adc, const double* __restrict__ adc_trace, int stride_in, const int* __restrict__ len_in,
                    double* __restrict__ pa_trace, int* __restrict__ pa_len)
 {
+#pragma clang fp contract(off)   // counts are compared sample by sample with the CPU restatement: no fused rounding here
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const double* d = adc_trace + (long)item * stride_in;
         double* out = pa_trace + (long)item * adc.stride;
