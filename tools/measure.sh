@@ -24,6 +24,13 @@ python3 bench.py --scaling strong --no-cpu-baseline > $OUT/bench_config2_strong.
 python3 bench.py --config 3 > $OUT/bench_config3.json 2> $OUT/bench_config3.log
 python3 bench.py --config 5 > $OUT/bench_config5.json 2> $OUT/bench_config5.log
 python3 bench.py --config 4 > $OUT/bench_config4.json 2> $OUT/bench_config4.log
+# the general path (ARZ2020 + birefringence) on the 5-channel station: wall time and kernel statistics
+python3 tools/config4_probe.py 100000 20000 > $OUT/config4_probe.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4stats -o x -- python3 tools/config4_probe.py 100000 20000 > /dev/null 2> $OUT/c4stats.log
+cp $(find $OUT/c4stats -name 'x_kernel_stats.csv' | head -1) $OUT/r02_rocprofv3_config4_kernel_stats.csv
+rm -rf $OUT/c4stats
+# the digitised phased array on the 35-station array (chirp-z digitiser)
+python3 tools/config3_probe.py 250000 35 pa_adc > $OUT/config3_pa_adc.log 2>&1
 find $OUT -size +8M -delete
 ls -la $OUT
 tail -c 600 $OUT/bench_config2.json
