@@ -46,8 +46,3 @@ dt = time.time() - t0
 print('config 4 ingredients (%s): %d events x 5 channels, %d rays through emission + propagation, %d candidate events, %d triggered; '
       '%.2f s wall = %.0f events/s, %.0f rays/s' % (mode, n, n_rays, n_cand, n_trig, dt, n / dt, n_rays / dt))
 print('stage ms (sum over calls):', {k_: round(v_, 1) for k_, v_ in stage.items()})
-try:
-    act = st.fetch('ray_propagated')
-    print('last call: %d of %d rays through the birefringent propagation' % (int(act.sum()), len(act)))
-except Exception as e:   # not a birefringence run
-    pass
