@@ -454,7 +454,10 @@ void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int
     if (b.form_factor_table)
         hipLaunchKernelGGL(arz_form_factor_table_kernel, dim3((4 * ARZ_TABLE_CELLS + 255) / 256), dim3(256), 0, s, b.parameters,
                            b.form_factor_table);
-    hipLaunchKernelGGL(arz_vector_potential_kernel, grid, dim3(256), sizeof(double) * 5 * (size_t)b.n_depth, s, b, vp, status);
+    const size_t lds = sizeof(double) * 5 * (size_t)b.n_depth;   // 80 KB at the 2048 depth bins the entry points admit
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)arz_vector_potential_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(arz_vector_potential_kernel, grid, dim3(256), lds, s, b, vp, status);
     hipLaunchKernelGGL(arz_trace_kernel, dim3((unsigned)b.n_rays), dim3(256), 0, s, b, vp, trace);
 }
 

@@ -482,6 +482,16 @@ def test_arz_like_the_reference():
     assert 5 < n_zero < 60
     with pytest.raises(NotImplementedError):
         a.get_time_trace(1e18, 1., 256, 0.5, 'TAU', 1.78, 1000.)
+    # the finest profile the entry points admit (2048 depth bins: 80 KB of LDS per block) and a coarse one, vs the oracle
+    for nd in (2048, 97):
+        depth = np.linspace(g['lib_depth'][0], g['lib_depth'][-1], nd)
+        prof = np.interp(depth, g['lib_depth'], g['lib_HAD_1e18'][0])
+        for th_off, R in ((1.5, 900.), (-9., 2500.)):
+            th = np.arccos(1 / 1.78) + th_off * np.pi / 180
+            vp = a.get_vector_potential(3e18, th, 512, 0.25, depth, prof, 'HAD', 1.78, R, False, 0.9)
+            ref = arz_oracle.vector_potential(3e18, th, 512, 0.25, depth, prof, arz_oracle.MODEL_PARAMETERS['ARZ2020']['HAD'], 'HAD', 1.78,
+                                              R, 1., 100., False, 0.9)
+            assert np.max(np.abs(vp - ref)) <= 1e-9 * np.max(np.abs(ref)), (nd, th_off)
 
 
 def test_birefringence_like_T07():
