@@ -310,6 +310,7 @@ def main():
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--cpu-budget', type=float, default=25., help='seconds of CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--device', type=int, default=None, help='GPU index of this rank (default: LOCAL_RANK)')
     args = ap.parse_args()
     cfgno = args.config
     if args.events is None:
@@ -328,7 +329,7 @@ def main():
     else:
         wl = make_workload(cfgno, args.events, 10 + rank, args.flavour)
         g0, g1 = 0, args.events
-    ctx = nuradiomc_amd.Context(wl['ice'], wl['att_model'], device=local_rank)
+    ctx = nuradiomc_amd.Context(wl['ice'], wl['att_model'], device=local_rank if args.device is None else args.device)
     comm = nrcomm.Comm(ctx, rank, world)
     det = build_array(ctx, wl)
     is_array = wl['centres'] is not None
