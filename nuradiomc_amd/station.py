@@ -767,7 +767,7 @@ class Station:
                      'shower_first_channel': np.int32, 'slot_reflection': np.int32, 'slot_reflection_case': np.int32,
                      'slot_n_segments': np.int32, 'slot_surface_mask': np.int32, 'ev_group': np.int32, 'ev_sub_event': np.int32,
                      'ev_triggered': np.uint8, 'ray_sub_event': np.int32, 'group_n_sub_events': np.int32,
-                     'pa_digital_length': np.int32}
+                     'pa_digital_length': np.int32, 'ray_propagated': np.int32, 'gen_n_steps': np.int32}
 
     def fetch(self, name):
         """One table of the last simulated batch as a numpy array (see include/nrhip.h: nrhip_sim_fetch)."""

@@ -36,13 +36,21 @@ def run(sl):
 run(slice(0, 500))
 t0 = time.time()
 n_trig = n_rays = n_cand = 0
+steps_all = steps_prop = rays_prop = 0
 stage = {}
 for a0 in range(0, n, chunk):
     trig, stats = run(slice(a0, min(n, a0 + chunk)))
     n_trig += int(trig.sum()); n_rays += stats['n_rays']; n_cand += stats['n_candidate_events']
     for k_, v_ in stats['stage_ms'].items():
         stage[k_] = stage.get(k_, 0.) + v_
+    if 'bire' in mode and stats['n_rays']:   # work of the birefringent propagation: path steps of the rays it was run for
+        ns = st.fetch('gen_n_steps')[:stats['n_rays']].astype(np.int64)
+        pr = st.fetch('ray_propagated')[:stats['n_rays']] != 0
+        steps_all += int(ns.sum()); steps_prop += int(ns[pr].sum()); rays_prop += int(pr.sum())
 dt = time.time() - t0
 print('config 4 ingredients (%s): %d events x 5 channels, %d rays through emission + propagation, %d candidate events, %d triggered; '
       '%.2f s wall = %.0f events/s, %.0f rays/s' % (mode, n, n_rays, n_cand, n_trig, dt, n / dt, n_rays / dt))
 print('stage ms (sum over calls):', {k_: round(v_, 1) for k_, v_ in stage.items()})
+if steps_all:
+    print('birefringence: %d of %d rays propagated, %.3g of %.3g path steps x 2049 bins = %.3g step-bins'
+          % (rays_prop, n_rays, steps_prop, steps_all, steps_prop * 2049.))
