@@ -120,6 +120,21 @@ __device__ inline void fft_dif_fused_k(double2* x, int log2m, const double2* __r
     else if (rem == 1) fft_dif_pass<1, PAD>(x, M, s, tw, inverse);
 }
 
+// 2^s0 independent transforms of 2^(log2m - s0) points each, stored one after the other in x: the stages s0 .. log2m - 1 of a
+// 2^log2m-point decimation-in-frequency transform are exactly that (stage s works inside blocks of 2^(log2m - s) points), so a
+// batch of short transforms keeps every thread of the block busy in each pass.  Each block ends bit-reversed in place.
+template <int F, bool PAD = false>
+__device__ inline void fft_dif_batched(double2* x, int log2m, int s0, const double2* __restrict__ tw, bool inverse)
+{
+    const int M = 1 << log2m;
+    int s = s0;
+    for (; log2m - s >= F; s += F) fft_dif_pass<F, PAD>(x, M, s, tw, inverse);
+    const int rem = log2m - s;
+    if (rem == 3) fft_dif_pass<3, PAD>(x, M, s, tw, inverse);
+    else if (rem == 2) fft_dif_pass<2, PAD>(x, M, s, tw, inverse);
+    else if (rem == 1) fft_dif_pass<1, PAD>(x, M, s, tw, inverse);
+}
+
 template <int F, bool PAD = false>
 __device__ inline void fft_dit_fused_k(double2* x, int log2m, const double2* __restrict__ tw, bool inverse)
 {

@@ -1805,6 +1805,27 @@ __global__ void channel_event_flags_kernel(int n_cand, int n_ch, const int* __re
 #define CONV_FIELD_FUSE 0   // radix-2 stages fused per LDS pass in the rays' N/2-point transforms (0: pairs)
 #endif
 #define CONV_MAX_ORDER 64  // stations with more channels are evaluated in channel order
+#ifndef CONV_RAY_BATCH
+#define CONV_RAY_BATCH 1   // the rays' N/2-point transforms in batches of up to four (one batched transform per pass)
+#endif
+// one N/2-point transform of the convolution kernel: an on-sky component of a ray (or both at once when the reflection
+// coefficients are real), where it starts on the event's grid and what it is scaled with
+struct ConvJob {
+    int r, sbin, shift;
+    double pol, vfac, rem;
+    double2 rc;
+};
+// amplitude X_k att(f_k) of bin k exactly as fill_amplitude() forms it
+__device__ inline double conv_amplitude(int k, int nh, double df, const StationDev& st, const RayShared& rs, double pl, double pr, int seg)
+{
+    if (k <= 0 || k >= nh) return 0.;
+    const double f = k * df;
+    if (rs.ask.model == 0) {
+        const double x = pl * rs.ask.cL, y = pr * rs.ask.cR;   // amplitude_bin, model 0
+        return rs.ask.pref2 * f / ((1 + x) * (1 + y)) * interp_seg(f, seg, st.n_fc, rs.xp, rs.att, rs.slope);
+    }
+    return amplitude_bin(k, f, rs.ask, st) * interp_seg(f, seg, st.n_fc, rs.xp, rs.att, rs.slope);
+}
 __global__ void __launch_bounds__(CONV_NT)
 channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list, const int* __restrict__ need,
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
@@ -1832,6 +1853,16 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     double2* xs = z + (fft_pad(M / 2) + 8);
     double* amp = (double*)(xs + nh);
     __shared__ RayShared rs;
+#if CONV_RAY_BATCH
+    // up to four transforms at a time: a group of CONV_NT / B threads per transform builds its spectrum (amplitudes on the fly,
+    // bins k and N/2 - k together), ONE batched transform runs them all, the placements follow in ray order.  B is what fits the
+    // 64 KB behind the event's samples: 4 transforms of <= 1024 points, 2 of 2048, 1 of 4096.
+    __shared__ RayShared rs4[4];
+    __shared__ ConvJob s_jobs[64];
+    __shared__ int s_njob;
+    __shared__ double2 s_ramp4[4][64 + FFT_MAX / 4 / 64 + 1];
+    const int log2B = (nh <= 1024) ? 2 : (nh <= 2048 ? 1 : 0), B = 1 << log2B, GT = CONV_NT >> log2B;
+#endif
     __shared__ double red[CONV_NT];
     __shared__ int s_trig;
     const int n_list_events = *n_list;
@@ -1908,6 +1939,142 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             for (int n = threadIdx.x; n < L; n += blockDim.x) S[PS(n)] = 0.;
             __syncthreads();
             CT(1);
+#if CONV_RAY_BATCH
+            {
+                const double df = 1.0 / (N * (1. / st.fs));
+                const int g = threadIdx.x / GT, lt = threadIdx.x - g * GT;
+                // the transforms of this (channel, antenna table), listed by the first wave: lane i looks at ray r_chunk + i (32 rays
+                // per list, at most two transforms each), a wave scan numbers them
+                for (int r_chunk = r0; r_chunk < r1; r_chunk += 32) {
+                  if (threadIdx.x < 64) {
+                      const int lane = threadIdx.x, r = r_chunk + lane;
+                      ConvJob jb[2];
+                      int nj_l = 0;
+                      if (lane < 32 && r < r1 && w.ch[r] == ch && w.tab[r] == tb) {
+                          const double vt = w.vfac_t[r], vp = w.vfac_p[r];
+                          const double2 rt = w.r_theta[r], rp = w.r_phi[r];
+                          const double pt = w.pol_theta[r], pp = w.pol_phi[r];
+                          const double wt = fabs(vt * pt) * cabs2(rt), wp = fabs(vp * pp) * cabs2(rp);
+                          // real reflection coefficients: both on-sky components are the same real pulse -> one transform
+                          const bool one = (rt.y == 0. && rp.y == 0.);
+                          // start bin and sub-sample remainder (efieldToVoltageConverter.py:214-218)
+                          const double start_time = w.t0[r] - t_min + st.cable[ch] + 0;
+                          const long start_bin = (long)rint(start_time / res);
+                          ConvJob job;
+                          job.r = r;
+                          job.sbin = (int)(((start_bin % (long)L) + (long)L) % (long)L);
+                          job.rem = start_time - start_bin * res;
+                          job.shift = !(fabs(rint(job.rem * st.fs) - job.rem * st.fs) < 1e-5);
+                          for (int comp = 0; comp < (one ? 1 : 2); comp++) {
+                              if (!one && (comp ? wp : wt) <= 1e-13 * (comp ? wt : wp)) continue;
+                              job.pol = one ? 1. : (comp ? pp : pt);
+                              job.rc = one ? make_double2(1., 0.) : (comp ? rp : rt);
+                              job.vfac = one ? (vt * pt * rt.x + vp * pp * rp.x) : (comp ? vp : vt);
+                              jb[nj_l++] = job;
+                          }
+                      }
+                      int incl = nj_l;   // inclusive scan over the wave
+                      for (int off = 1; off < 64; off <<= 1) {
+                          const int v = __shfl_up(incl, off);
+                          if (lane >= off) incl += v;
+                      }
+                      const int first = incl - nj_l;
+                      if (nj_l > 0) s_jobs[first] = jb[0];
+                      if (nj_l > 1) s_jobs[first + 1] = jb[1];
+                      if (lane == 63) s_njob = incl;
+                  }
+                  __syncthreads();
+                  const int n_jobs = s_njob;
+                  for (int j0 = 0; j0 < n_jobs; j0 += B) {
+                    const int nj = min(B, n_jobs - j0);
+                    const ConvJob* s_job = s_jobs + j0;
+                    const bool mine = g < nj;
+                    const ConvJob job = s_job[mine ? g : 0];
+                    RayShared& rg = rs4[mine ? g : 0];
+                    if (mine) {
+                        if (lt == 0) rg.ask = w.ask[job.r];
+                        for (int i = lt; i < st.n_fc; i += GT) {   // attenuation factors and the slopes between them (fill_amplitude's)
+                            const double a0 = w.att[(long)job.r * st.n_fc + i], x0 = st.fcoarse[i];
+                            rg.att[i] = a0;
+                            rg.xp[i] = x0;
+                            if (i < st.n_fc - 1) rg.slope[i] = (w.att[(long)job.r * st.n_fc + i + 1] - a0) / (st.fcoarse[i + 1] - x0);
+                        }
+                        // the sub-sample shift's phase ramp exp(-2 pi i f rem), f = k fs / N: w^k = w^(k & 63) * (w^64)^(k >> 6)
+                        if (job.shift)
+                            for (int t = lt; t < 64 + (nh >> 6) + 1; t += GT) {
+                                const double f = (t < 64 ? t : 64 * (t - 64)) * (1.0 / (N * (1. / st.fs)));
+                                double sn, cs;
+                                sincospi(-2. * job.rem * f, &sn, &cs);
+                                s_ramp4[g][t] = make_double2(cs, sn);
+                            }
+                    }
+                    __syncthreads();
+                    if (mine) {
+                        // spectrum of the packed half-length transform (field_time_domain), bins k and N/2 - k by the same thread:
+                        // both need both amplitudes.  Station tables of the next iteration are requested ahead.
+                        double2* xg = xs + (long)g * nh;
+                        const int stride = nh + 1, off_l = rg.ask.had ? 0 : stride;
+                        const bool m0 = rg.ask.model == 0;
+                        const double2* ramp = job.shift ? s_ramp4[g] : nullptr;
+                        const double roll = floor(2.0 * st.fs);
+                        int k = lt;
+                        double a_pl = 0., a_pr = 0., b_pl = 0., b_pr = 0.;
+                        int a_sg = 0, b_sg = 0;
+                        double2 a_w = make_double2(1., 0.), b_w = a_w;
+                        auto fetch = [&](int kk) {
+                            const int k2 = nh - kk;
+                            if (kk > 0 && kk < nh) { if (m0) { a_pl = st.fpow[off_l + kk]; a_pr = st.fpow[2 * stride + kk]; } a_sg = st.seg[kk]; }
+                            if (k2 > 0 && k2 < nh) { if (m0) { b_pl = st.fpow[off_l + k2]; b_pr = st.fpow[2 * stride + k2]; } b_sg = st.seg[k2]; }
+                            a_w = tw[kk * (FFT_MAX / N)];
+                            if (k2 < nh) b_w = tw[k2 * (FFT_MAX / N)];
+                        };
+                        if (k <= nh / 2) fetch(k);
+                        for (; k <= nh / 2; k += GT) {
+                            const double pl1 = a_pl, pr1 = a_pr, pl2 = b_pl, pr2 = b_pr;
+                            const int sg1 = a_sg, sg2 = b_sg;
+                            const double2 w1 = a_w, w2 = b_w;
+                            if (k + GT <= nh / 2) fetch(k + GT);
+                            const int k2 = nh - k;
+                            const double amp1 = conv_amplitude(k, nh, df, st, rg, pl1, pr1, sg1);
+                            const double amp2 = conv_amplitude(k2, nh, df, st, rg, pl2, pr2, sg2);
+                            const double2 F1 = field_bin(k, amp1, N, st.fs, job.pol, job.rc, job.rem, job.shift, ask_model, roll, ramp);
+                            const double2 F2 = field_bin(k2, amp2, N, st.fs, job.pol, job.rc, job.rem, job.shift, ask_model, roll, ramp);
+                            {
+                                const double2 Gc = cconj(F2);
+                                const double2 ge = cscale(cadd(F1, Gc), 0.5), d = cscale(csub(F1, Gc), 0.5);
+                                const double2 go = cmul(d, cconj(w1));         // * exp(+2 pi i k / N)
+                                xg[k] = make_double2(ge.x - go.y, ge.y + go.x);  // ge + i go
+                            }
+                            if (k != 0 && k2 != k) {
+                                const double2 Gc = cconj(F1);
+                                const double2 ge = cscale(cadd(F2, Gc), 0.5), d = cscale(csub(F2, Gc), 0.5);
+                                const double2 go = cmul(d, cconj(w2));
+                                xg[k2] = make_double2(ge.x - go.y, ge.y + go.x);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    // inverse transforms of the whole batch, natural -> bit-reversed inside each block; scale applied by the reader
+                    fft_dif_batched<3>(xs, log2nh + log2B, log2B, tw, true);
+                    for (int q = 0; q < nj; q++) {
+                        const ConvJob jq = s_job[q];
+                        const double2* xq = xs + (long)q * nh;
+                        const double c = jq.vfac / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
+                        for (int j = threadIdx.x; j < nh; j += blockDim.x) {
+                            const double2 y = xq[bitrev(j, log2nh)];
+                            int i0 = jq.sbin + 2 * j;
+                            if (i0 >= L) i0 -= L;
+                            int i1 = i0 + 1;
+                            if (i1 >= L) i1 -= L;
+                            S[PS(i0)] += y.x * c;
+                            S[PS(i1)] += y.y * c;
+                        }
+                        __syncthreads();
+                    }
+                  }
+                }
+            }
+#else
             for (int r = r0; r < r1; r++) {
                 if (w.ch[r] != ch || w.tab[r] != tb) continue;
                 if (threadIdx.x == 0) rs.ask = w.ask[r];
@@ -1951,6 +2118,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     CT(4);
                 }
             }
+#endif
             for (int n = L + threadIdx.x; n < 2 * M; n += blockDim.x) S[PS(n)] = 0.;
             __syncthreads();
             CT(5);
