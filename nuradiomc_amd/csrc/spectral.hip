@@ -1923,6 +1923,12 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         const int L = ev.L[e], il = ev_len_index[e];
         const double t_min = ev.t_min[e];
         const double res = 1. / st.fs;
+        // the circular convolution over L samples is a linear one of 2 L: when that fits FFT_MAX real points the packed transform has
+        // FFT_MAX / 2 complex points (one stage and half the LDS traffic less); the response spectrum on that grid is every other
+        // bin of the table (the even bins of a zero-padded sequence's transform are the transform of the shorter padding)
+        const bool half_size = 2 * L <= FFT_MAX;
+        const int log2Mr = half_size ? FFT_LOG2_MAX - 1 : FFT_LOG2_MAX, Mr = 1 << log2Mr, gs = half_size ? 2 : 1;
+        const double vscale = half_size ? 2. : 1.;   // the table carries the 1 / FFT_MAX of the un-normalised transform pair
         int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
         if (threadIdx.x == 0) s_trig = 0;
         // antenna response tables among this channel's rays (one, except for LPDAs seeing rays in different lobes)
@@ -1942,7 +1948,6 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
 #if CONV_RAY_BATCH
             {
                 const double df = 1.0 / (N * (1. / st.fs));
-                const int g = threadIdx.x / GT, lt = threadIdx.x - g * GT;
                 // the transforms of this (channel, antenna table), listed by the first wave: lane i looks at ray r_chunk + i (32 rays
                 // per list, at most two transforms each), a wave scan numbers them
                 for (int r_chunk = r0; r_chunk < r1; r_chunk += 32) {
@@ -1988,12 +1993,15 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                   for (int j0 = 0; j0 < n_jobs; j0 += B) {
                     const int nj = min(B, n_jobs - j0);
                     const ConvJob* s_job = s_jobs + j0;
+                    // thread groups as large as the batch allows: 512 / 256 / 128 threads per transform for 1 / 2 / 3-4 of them
+                    const int GTe = (nj <= 1) ? CONV_NT : (nj == 2 ? CONV_NT / 2 : CONV_NT / 4);
+                    const int g = threadIdx.x / GTe, lt = threadIdx.x - g * GTe;
                     const bool mine = g < nj;
                     const ConvJob job = s_job[mine ? g : 0];
                     RayShared& rg = rs4[mine ? g : 0];
                     if (mine) {
                         if (lt == 0) rg.ask = w.ask[job.r];
-                        for (int i = lt; i < st.n_fc; i += GT) {   // attenuation factors and the slopes between them (fill_amplitude's)
+                        for (int i = lt; i < st.n_fc; i += GTe) {   // attenuation factors and the slopes between them (fill_amplitude's)
                             const double a0 = w.att[(long)job.r * st.n_fc + i], x0 = st.fcoarse[i];
                             rg.att[i] = a0;
                             rg.xp[i] = x0;
@@ -2001,7 +2009,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                         }
                         // the sub-sample shift's phase ramp exp(-2 pi i f rem), f = k fs / N: w^k = w^(k & 63) * (w^64)^(k >> 6)
                         if (job.shift)
-                            for (int t = lt; t < 64 + (nh >> 6) + 1; t += GT) {
+                            for (int t = lt; t < 64 + (nh >> 6) + 1; t += GTe) {
                                 const double f = (t < 64 ? t : 64 * (t - 64)) * (1.0 / (N * (1. / st.fs)));
                                 double sn, cs;
                                 sincospi(-2. * job.rem * f, &sn, &cs);
@@ -2009,6 +2017,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                             }
                     }
                     __syncthreads();
+                    CT(2);
                     if (mine) {
                         // spectrum of the packed half-length transform (field_time_domain), bins k and N/2 - k by the same thread:
                         // both need both amplitudes.  Station tables of the next iteration are requested ahead.
@@ -2029,11 +2038,11 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                             if (k2 < nh) b_w = tw[k2 * (FFT_MAX / N)];
                         };
                         if (k <= nh / 2) fetch(k);
-                        for (; k <= nh / 2; k += GT) {
+                        for (; k <= nh / 2; k += GTe) {
                             const double pl1 = a_pl, pr1 = a_pr, pl2 = b_pl, pr2 = b_pr;
                             const int sg1 = a_sg, sg2 = b_sg;
                             const double2 w1 = a_w, w2 = b_w;
-                            if (k + GT <= nh / 2) fetch(k + GT);
+                            if (k + GTe <= nh / 2) fetch(k + GTe);
                             const int k2 = nh - k;
                             const double amp1 = conv_amplitude(k, nh, df, st, rg, pl1, pr1, sg1);
                             const double amp2 = conv_amplitude(k2, nh, df, st, rg, pl2, pr2, sg2);
@@ -2056,6 +2065,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     __syncthreads();
                     // inverse transforms of the whole batch, natural -> bit-reversed inside each block; scale applied by the reader
                     fft_dif_batched<3>(xs, log2nh + log2B, log2B, tw, true);
+                    CT(3);
                     for (int q = 0; q < nj; q++) {
                         const ConvJob jq = s_job[q];
                         const double2* xq = xs + (long)q * nh;
@@ -2071,6 +2081,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                         }
                         __syncthreads();
                     }
+                    CT(4);
                   }
                 }
             }
@@ -2119,20 +2130,21 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 }
             }
 #endif
-            for (int n = L + threadIdx.x; n < 2 * M; n += blockDim.x) S[PS(n)] = 0.;
+            for (int n = L + threadIdx.x; n < 2 * Mr; n += blockDim.x) S[PS(n)] = 0.;
             __syncthreads();
             CT(5);
-            fft_dif_t<FFT_LOG2_MAX, CONV_NT, true>(z, tw, false);
+            if (half_size) fft_dif_t<FFT_LOG2_MAX - 1, CONV_NT, true>(z, tw, false);
+            else fft_dif_t<FFT_LOG2_MAX, CONV_NT, true>(z, tw, false);
             CT(6);
             // split the packed transform into the real one, multiply with G, merge back -- in place on the
             // bit-reversed positions of the pairs (k, M - k)
             // (the response spectrum comes from HBM / L2: the entries of the next iteration are requested before the current one is used)
-            double2 nGk = G[threadIdx.x], nGm = G[M - threadIdx.x], nw = w16[threadIdx.x];
-            for (int k = threadIdx.x; k <= M / 2; k += CONV_NT) {
+            double2 nGk = G[gs * threadIdx.x], nGm = G[gs * (Mr - threadIdx.x)], nw = w16[gs * threadIdx.x];
+            for (int k = threadIdx.x; k <= Mr / 2; k += CONV_NT) {
                 const double2 Gk = nGk, Gm = nGm, wk = nw;
                 const int kn = k + CONV_NT;
-                if (kn <= M / 2) { nGk = G[kn]; nGm = G[M - kn]; nw = w16[kn]; }
-                const int p = PZ(bitrev(k, FFT_LOG2_MAX)), q = (k == 0) ? p : PZ(bitrev(M - k, FFT_LOG2_MAX));
+                if (kn <= Mr / 2) { nGk = G[gs * kn]; nGm = G[gs * (Mr - kn)]; nw = w16[gs * kn]; }
+                const int p = PZ(bitrev(k, log2Mr)), q = (k == 0) ? p : PZ(bitrev(Mr - k, log2Mr));
                 const double2 A = z[p], Bc = cconj(z[q]);
                 const double2 Ee = cadd(A, Bc), D = csub(A, Bc);
                 const double2 O = make_double2(D.y, -D.x);
@@ -2146,7 +2158,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             }
             if (multi) {  // sum the tables' contributions in the frequency domain (global scratch of this block)
                 __syncthreads();
-                for (int k = threadIdx.x; k < M; k += blockDim.x) acc[k] = first_tab ? z[PZ(k)] : cadd(acc[k], z[PZ(k)]);
+                for (int k = threadIdx.x; k < Mr; k += blockDim.x) acc[k] = first_tab ? z[PZ(k)] : cadd(acc[k], z[PZ(k)]);
                 first_tab = false;
             }
         }
@@ -2159,15 +2171,16 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             }
             if (multi) {
                 __syncthreads();
-                for (int k = threadIdx.x; k < M; k += blockDim.x) z[PZ(k)] = acc[k];
+                for (int k = threadIdx.x; k < Mr; k += blockDim.x) z[PZ(k)] = acc[k];
             }
             __syncthreads();
             CT(7);
-            fft_dit_t<FFT_LOG2_MAX, CONV_NT, true>(z, tw, true);
+            if (half_size) fft_dit_t<FFT_LOG2_MAX - 1, CONV_NT, true>(z, tw, true);
+            else fft_dit_t<FFT_LOG2_MAX, CONV_NT, true>(z, tw, true);
             CT(8);
             if (!coinc) {
                 for (int n = threadIdx.x; n < L; n += blockDim.x) {
-                    double v = S[PS(n)] + S[PS(n + L)];
+                    double v = (S[PS(n)] + S[PS(n + L)]) * vscale;
                     if (out.trace) out.trace[out.trace_offset[item] + n] = v;
                     double av = fabs(v);
                     vmax = fmax(vmax, av);
@@ -2177,7 +2190,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 // per-channel flags (simpleThreshold.py:14-29 / highLowThreshold.py:13-80), OR-dilated over the coincidence
                 // window (get_majority_logic :82-150: flag i stays up for w_coinc samples), counted per sample in cnt
                 for (int n = threadIdx.x; n < L; n += blockDim.x) {
-                    double v = S[PS(n)] + S[PS(n + L)];
+                    double v = (S[PS(n)] + S[PS(n + L)]) * vscale;
                     if (out.trace) out.trace[out.trace_offset[item] + n] = v;
                     vmax = fmax(vmax, fabs(v));
                     S[PS(n)] = v;
