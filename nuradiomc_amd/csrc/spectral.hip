@@ -1805,6 +1805,9 @@ __global__ void channel_event_flags_kernel(int n_cand, int n_ch, const int* __re
 #define CONV_FIELD_FUSE 0   // radix-2 stages fused per LDS pass in the rays' N/2-point transforms (0: pairs)
 #endif
 #define CONV_MAX_ORDER 64  // stations with more channels are evaluated in channel order
+// threads per block: 512 for the full-capacity kernel (one block per CU), 256 for the half-capacity one (two blocks per CU: the same
+// eight waves per CU, each with the 256 registers the transforms want, but two independent barrier domains)
+#define CONV_THREADS(log2cap) ((log2cap) == FFT_LOG2_MAX ? CONV_NT : CONV_NT / 2)
 #ifndef CONV_RAY_BATCH
 #define CONV_RAY_BATCH 1   // the rays' N/2-point transforms in batches of up to four (one batched transform per pass)
 #endif
@@ -1826,21 +1829,27 @@ __device__ inline double conv_amplitude(int k, int nh, double df, const StationD
     }
     return amplitude_bin(k, f, rs.ask, st) * interp_seg(f, seg, st.n_fc, rs.xp, rs.att, rs.slope);
 }
-__global__ void __launch_bounds__(CONV_NT)
+// LOG2CAP: log2 of the complex points the LDS buffer holds.  13 (FFT_MAX): any event of up to FFT_MAX samples, 133 KB, one block per
+// CU.  12: events of up to FFT_MAX / 2 samples only (the N = 2048 workloads), 68 KB + 9 KB static: TWO blocks per CU, so one block's
+// barriers and LDS round trips are covered by the other's arithmetic.
+template <int LOG2CAP>
+__global__ void __launch_bounds__(CONV_THREADS(LOG2CAP), 2)
 channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list, const int* __restrict__ need,
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                     const int* __restrict__ ev_len_index, StationDev st, int ask_model, TriggerDev trg,
                     const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab, int log2nh,
                     ChannelOut out, int exact, int* __restrict__ coinc_cnt, double2* __restrict__ conv_acc,
-                    unsigned long long* __restrict__ xform_count, int* __restrict__ queue)
+                    unsigned long long* __restrict__ xform_count, int* __restrict__ queue, int l_min)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr int M = FFT_MAX;
+    constexpr int M = 1 << LOG2CAP;
+    constexpr int NT = CONV_THREADS(LOG2CAP);   // threads of the block
+    constexpr int BM = (LOG2CAP == FFT_LOG2_MAX) ? 4 : 2;   // transforms per batch at most
     const double threshold = trg.threshold;
     const bool coinc = trg.coincidence();
     double2* acc = conv_acc + (long)blockIdx.x * FFT_MAX;
     int* cnt = coinc_cnt + (long)blockIdx.x * FFT_MAX;  // per sample: channels whose dilated flag is set (coincidence modes)
-    __shared__ int s_scan[CONV_NT];
+    __shared__ int s_scan[NT];
     __shared__ int s_first;
     const int N = st.N, nh = N / 2;
     // the convolution buffer in the padded layout of fft_pad (bank-conflict-free strides of the fused passes and of the bit-reversed
@@ -1852,18 +1861,18 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
 #define PS(n) (2 * fft_pad((n) >> 1) + ((n) & 1))
     double2* xs = z + (fft_pad(M / 2) + 8);
     double* amp = (double*)(xs + nh);
-    __shared__ RayShared rs;
 #if CONV_RAY_BATCH
-    // up to four transforms at a time: a group of CONV_NT / B threads per transform builds its spectrum (amplitudes on the fly,
+    // up to four transforms at a time: a group of NT / B threads per transform builds its spectrum (amplitudes on the fly,
     // bins k and N/2 - k together), ONE batched transform runs them all, the placements follow in ray order.  B is what fits the
     // 64 KB behind the event's samples: 4 transforms of <= 1024 points, 2 of 2048, 1 of 4096.
-    __shared__ RayShared rs4[4];
+    __shared__ RayShared rs4[BM];
     __shared__ ConvJob s_jobs[64];
-    __shared__ int s_njob;
-    __shared__ double2 s_ramp4[4][64 + FFT_MAX / 4 / 64 + 1];
-    const int log2B = (nh <= 1024) ? 2 : (nh <= 2048 ? 1 : 0), B = 1 << log2B, GT = CONV_NT >> log2B;
+    __shared__ int s_njob, s_nadv;
+    __shared__ double2 s_ramp4[BM][64 + FFT_MAX / 4 / 64 + 1];
+    // B is what fits behind the event's samples: (fft_pad(M) - fft_pad(M / 2) - 8) complex elements
+    const int log2B = (LOG2CAP == FFT_LOG2_MAX) ? ((nh <= 1024) ? 2 : (nh <= 2048 ? 1 : 0)) : ((nh <= 1024) ? 1 : 0), B = 1 << log2B;
 #endif
-    __shared__ double red[CONV_NT];
+    __shared__ double red[NT / 64];   // block_max: one word per wave
     __shared__ int s_trig;
     const int n_list_events = *n_list;
     // unit of work: one candidate event; its channels are evaluated in sequence and -- the trigger being an OR over
@@ -1886,7 +1895,15 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
           s_ev_trig = 0;
           int cnt_o = 0;
           const int base = (le0 < n_list_events ? item_list[le0] : 0) * st.n_ch;
-          if (best_first && le0 < n_list_events) {
+          // the two instantiations share one list: each takes the events of its length class (l_min < L <= M); the others cost
+          // one counter increment and this test
+          bool mine_ev = true;
+          if (le0 < n_list_events) {
+              const int L0 = ev.L[item_event[item_list[le0]]];
+              mine_ev = L0 > l_min && L0 <= M;
+          }
+          if (!mine_ev) cnt_o = -1;
+          else if (best_first && le0 < n_list_events) {
               for (int ch = 0; ch < st.n_ch; ch++) {
                   if (!need[base + ch]) continue;
                   const double b = -out.maxV[base + ch];   // the prefilter's bound
@@ -1900,6 +1917,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       __syncthreads();
       const int le = s_le[par];
       if (le >= n_list_events) break;
+      if (s_norder[par] < 0) continue;   // an event of the other length class
       const int ev_e = item_event[item_list[le]], ev_L = ev.L[ev_e];
       if (coinc) {
           for (int n = threadIdx.x; n < ev_L; n += blockDim.x) cnt[n] = 0;
@@ -1926,9 +1944,9 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         // the circular convolution over L samples is a linear one of 2 L: when that fits FFT_MAX real points the packed transform has
         // FFT_MAX / 2 complex points (one stage and half the LDS traffic less); the response spectrum on that grid is every other
         // bin of the table (the even bins of a zero-padded sequence's transform are the transform of the shorter padding)
-        const bool half_size = 2 * L <= FFT_MAX;
-        const int log2Mr = half_size ? FFT_LOG2_MAX - 1 : FFT_LOG2_MAX, Mr = 1 << log2Mr, gs = half_size ? 2 : 1;
-        const double vscale = half_size ? 2. : 1.;   // the table carries the 1 / FFT_MAX of the un-normalised transform pair
+        const bool half_size = 2 * L <= M;
+        const int log2Mr = half_size ? LOG2CAP - 1 : LOG2CAP, Mr = 1 << log2Mr, gs = FFT_MAX / Mr;
+        const double vscale = (double)gs;   // the table carries the 1 / FFT_MAX of the un-normalised transform pair
         int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
         if (threadIdx.x == 0) s_trig = 0;
         // antenna response tables among this channel's rays (one, except for LPDAs seeing rays in different lobes)
@@ -1948,14 +1966,14 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
 #if CONV_RAY_BATCH
             {
                 const double df = 1.0 / (N * (1. / st.fs));
-                // the transforms of this (channel, antenna table), listed by the first wave: lane i looks at ray r_chunk + i (32 rays
-                // per list, at most two transforms each), a wave scan numbers them
-                for (int r_chunk = r0; r_chunk < r1; r_chunk += 32) {
+                // the transforms of this (channel, antenna table), listed by the first wave: lane i looks at ray r_chunk + i (at most two
+                // transforms each), a wave scan numbers them; the list holds 64, the next round resumes at the first ray that did not fit
+                for (int r_chunk = r0, r_adv = 64; r_chunk < r1; r_chunk += r_adv) {
                   if (threadIdx.x < 64) {
                       const int lane = threadIdx.x, r = r_chunk + lane;
                       ConvJob jb[2];
                       int nj_l = 0;
-                      if (lane < 32 && r < r1 && w.ch[r] == ch && w.tab[r] == tb) {
+                      if (r < r1 && w.ch[r] == ch && w.tab[r] == tb) {
                           const double vt = w.vfac_t[r], vp = w.vfac_p[r];
                           const double2 rt = w.r_theta[r], rp = w.r_phi[r];
                           const double pt = w.pol_theta[r], pp = w.pol_phi[r];
@@ -1984,17 +2002,21 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                           if (lane >= off) incl += v;
                       }
                       const int first = incl - nj_l;
-                      if (nj_l > 0) s_jobs[first] = jb[0];
-                      if (nj_l > 1) s_jobs[first + 1] = jb[1];
-                      if (lane == 63) s_njob = incl;
+                      const bool fits = incl <= 64;
+                      const unsigned long long fb = __ballot(fits);   // lanes 0 .. m - 1 fit (the scan is monotone)
+                      const int m = (fb == ~0ull) ? 64 : __ffsll((long long)~fb) - 1;
+                      if (fits && nj_l > 0) s_jobs[first] = jb[0];
+                      if (fits && nj_l > 1) s_jobs[first + 1] = jb[1];
+                      if (lane == (m > 0 ? m - 1 : 0)) { s_njob = (m > 0) ? incl : 0; s_nadv = (m > 0) ? m : 1; }
                   }
                   __syncthreads();
                   const int n_jobs = s_njob;
+                  r_adv = s_nadv;
                   for (int j0 = 0; j0 < n_jobs; j0 += B) {
                     const int nj = min(B, n_jobs - j0);
                     const ConvJob* s_job = s_jobs + j0;
                     // thread groups as large as the batch allows: 512 / 256 / 128 threads per transform for 1 / 2 / 3-4 of them
-                    const int GTe = (nj <= 1) ? CONV_NT : (nj == 2 ? CONV_NT / 2 : CONV_NT / 4);
+                    const int GTe = (nj <= 1) ? NT : (nj == 2 ? NT / 2 : NT / 4);
                     const int g = threadIdx.x / GTe, lt = threadIdx.x - g * GTe;
                     const bool mine = g < nj;
                     const ConvJob job = s_job[mine ? g : 0];
@@ -2133,16 +2155,16 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             for (int n = L + threadIdx.x; n < 2 * Mr; n += blockDim.x) S[PS(n)] = 0.;
             __syncthreads();
             CT(5);
-            if (half_size) fft_dif_t<FFT_LOG2_MAX - 1, CONV_NT, true>(z, tw, false);
-            else fft_dif_t<FFT_LOG2_MAX, CONV_NT, true>(z, tw, false);
+            if (half_size) fft_dif_t<LOG2CAP - 1, NT, true>(z, tw, false);
+            else fft_dif_t<LOG2CAP, NT, true>(z, tw, false);
             CT(6);
             // split the packed transform into the real one, multiply with G, merge back -- in place on the
             // bit-reversed positions of the pairs (k, M - k)
             // (the response spectrum comes from HBM / L2: the entries of the next iteration are requested before the current one is used)
             double2 nGk = G[gs * threadIdx.x], nGm = G[gs * (Mr - threadIdx.x)], nw = w16[gs * threadIdx.x];
-            for (int k = threadIdx.x; k <= Mr / 2; k += CONV_NT) {
+            for (int k = threadIdx.x; k <= Mr / 2; k += NT) {
                 const double2 Gk = nGk, Gm = nGm, wk = nw;
-                const int kn = k + CONV_NT;
+                const int kn = k + NT;
                 if (kn <= Mr / 2) { nGk = G[gs * kn]; nGm = G[gs * (Mr - kn)]; nw = w16[gs * kn]; }
                 const int p = PZ(bitrev(k, log2Mr)), q = (k == 0) ? p : PZ(bitrev(Mr - k, log2Mr));
                 const double2 A = z[p], Bc = cconj(z[q]);
@@ -2175,8 +2197,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             }
             __syncthreads();
             CT(7);
-            if (half_size) fft_dit_t<FFT_LOG2_MAX - 1, CONV_NT, true>(z, tw, true);
-            else fft_dit_t<FFT_LOG2_MAX, CONV_NT, true>(z, tw, true);
+            if (half_size) fft_dit_t<LOG2CAP - 1, NT, true>(z, tw, true);
+            else fft_dit_t<LOG2CAP, NT, true>(z, tw, true);
             CT(8);
             if (!coinc) {
                 for (int n = threadIdx.x; n < L; n += blockDim.x) {
@@ -2218,12 +2240,12 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 }
                 __syncthreads();
                 {   // inclusive running maximum of A[0 .. nb): contiguous chunk per thread, then a scan of the chunk maxima
-                    const int chunk = (nb + CONV_NT - 1) / CONV_NT, b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, nb);
+                    const int chunk = (nb + NT - 1) / NT, b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, nb);
                     int run = -1;
                     for (int i = b0; i < b1; i++) { run = max(run, A[i]); A[i] = run; }
                     s_scan[threadIdx.x] = run;
                     __syncthreads();
-                    for (int off = 1; off < CONV_NT; off <<= 1) {
+                    for (int off = 1; off < NT; off <<= 1) {
                         int v = ((int)threadIdx.x >= off) ? s_scan[threadIdx.x - off] : -1;
                         __syncthreads();
                         s_scan[threadIdx.x] = max(s_scan[threadIdx.x], v);
@@ -3056,6 +3078,7 @@ void launch_candidate_lists(hipStream_t s, int n_events, int n_half, const Event
     hipLaunchKernelGGL(candidate_lists_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, n_events, n_half, ev, cflag, coff,
                        lflag, loff, cand, len_index, lens);
 }
+static int fft_pad_host(int i) { return i + (i >> 5) + (i >> 7); }   // fft_pad() of fft_device.h
 static bool g_attr_set = false;
 static void set_big_lds()
 {
@@ -3064,7 +3087,9 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)length_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               FFT_MAX * 16 + (FFT_MAX / 2 + 1) * 8);
-    (void)hipFuncSetAttribute((const void*)channel_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_PADDED_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_PADDED_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX - 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              fft_pad_host(FFT_MAX / 2) * 16);
     (void)hipFuncSetAttribute((const void*)ray_envelope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (FFT_MAX / 2) * 16 + (FFT_MAX / 4 + 1) * 8);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
@@ -3093,7 +3118,9 @@ void launch_length_slots(hipStream_t s, int n_events, const int* ev_L, const int
     if (n_events <= 0) return;
     hipLaunchKernelGGL(length_slot_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, ev_L, slotmap, len_index);
 }
-int channel_grid_blocks() { return 256; }
+// blocks of the channel kernels (per-block scratch in HBM is sized by it): two per CU for the half-capacity convolution kernel, the
+// 128 KB kernels use half of them
+int channel_grid_blocks() { return 512; }
 void launch_channel(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventIn& evin,
                     const EventOut& ev, const int* ev_len_index, const StationDev& st, const FilterSet& fl, int ask_model,
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
@@ -3105,7 +3132,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     if (n_items <= 0) return;
     set_big_lds();
     int nh = st.N / 2;
-    int grid = n_items < channel_grid_blocks() ? n_items : channel_grid_blocks();
+    int grid = n_items < channel_grid_blocks() / 2 ? n_items : channel_grid_blocks() / 2;   // 128 KB of LDS: one block per CU
     // traces up to FFT_MAX samples: prefilter, then one real convolution per listed item; longer ones (or
     // NRHIP_CHANNEL_CZT=1): chirp-z per ray (plain OR of simple thresholds only; the caller checks)
     int skip_upto = 0;
@@ -3120,11 +3147,25 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
         launch_exclusive_scan(s, (long)n_cand + 1, ev_need, need_offset, scan_tmp);
         hipLaunchKernelGGL(scatter_item_list_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, ev_need, need_offset,
                            item_list);
-        int cgrid = n_cand < channel_grid_blocks() ? n_cand : channel_grid_blocks();
-        hipLaunchKernelGGL(channel_conv_kernel, dim3(cgrid), dim3(CONV_NT), (size_t)FFT_PADDED_MAX * 16, s, need_offset + n_cand,
-                           item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16, tab,
-                           ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count,
-                       ev_need + n_cand /* the scan's zero sentinel: free again, and 0 */);
+        // events of up to FFT_MAX / 2 samples go to the half-capacity instantiation (two blocks per CU), longer ones to the full one;
+        // both walk the same list with their own counter
+        const bool small = st.N < FFT_MAX / 2 && !getenv("NRHIP_CONV_ONE_BLOCK");   // L >= N: nothing to take otherwise
+        const bool large = !small || max_length > FFT_MAX / 2;
+        int* queue = ev_need + n_cand;   // the scan's zero sentinel: free again, and 0; the slot behind it for the second launch
+        (void)hipMemsetAsync(queue + 1, 0, sizeof(int), s);
+        if (small) {
+            const int cgrid = n_cand < channel_grid_blocks() ? n_cand : channel_grid_blocks();
+            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX - 1>, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)fft_pad_host(FFT_MAX / 2) * 16, s,
+                               need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
+                               tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue, 0);
+        }
+        if (large) {
+            const int cgrid = n_cand < channel_grid_blocks() / 2 ? n_cand : channel_grid_blocks() / 2;
+            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX>, dim3(cgrid), dim3(CONV_NT), (size_t)FFT_PADDED_MAX * 16, s,
+                               need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
+                               tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue + (small ? 1 : 0),
+                               small ? FFT_MAX / 2 : 0);
+        }
         skip_upto = FFT_MAX;
         if (max_length <= FFT_MAX && !st.ant_tabs) return;
     }
