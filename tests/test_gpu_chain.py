@@ -500,6 +500,42 @@ def test_channel_kernels_agree(gpu_ctx_factory, name, n_events, monkeypatch):
     assert np.max(np.abs(mv_a - mv_b)) <= 1e-9 * np.max(np.abs(mv_b))
 
 
+def test_convolution_kernel_length_classes(gpu_ctx_factory, monkeypatch):
+    """channel_conv_kernel has two instantiations: events of up to 4096 samples (half-capacity LDS buffer, two blocks per CU,
+    4096- or 2048-point packed transform) and longer ones (8192 / 4096 points).  A 2048-sample station whose channels are up to
+    180 m apart produces common traces on both sides of 4096 samples in one call; every trace and decision must equal the
+    per-ray chirp-z kernel's (NRHIP_CHANNEL_CZT=1) to 1e-9, and the one-block mode's (NRHIP_CONV_ONE_BLOCK=1) too."""
+    ice = (1.78, 0.423, 77.)
+    pos = np.array([[0., 0., -100.], [0., 0., -103.], [40., 0., -60.], [0., 0., -200.], [10., 5., -20.]])
+    rng = np.random.default_rng(5)
+    n = 400
+    r, ph = np.sqrt(rng.uniform(0, 1200. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    v = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1800., -10., n)], axis=1)
+    zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    en = 10 ** rng.uniform(17.5, 19., n)
+
+    def run():
+        ctx = gpu_ctx_factory(ice, 'SP1')
+        st = nuradiomc_amd.Station(ctx, pos, n_samples=2048, sampling_rate=2.0)
+        trig, stats = st.simulate_events(v, zen, az, en, 'HAD', dump_traces=True)
+        return trig, st.fetch('trace').copy(), st.fetch('trace_offset').copy(), st.fetch('ev_L').copy(), st.fetch('item_event').copy()
+
+    trig_a, tr_a, off_a, L_a, ie_a = run()
+    Lc = L_a[ie_a]
+    n_small, n_large = np.sum(Lc <= 4096), np.sum((Lc > 4096) & (Lc <= 8192))   # (anything longer takes the chirp-z kernel anyway)
+    assert n_small >= 10 and n_large >= 10, (n_small, n_large, Lc.max())
+    assert 5 < trig_a.sum() < n
+    monkeypatch.setenv('NRHIP_CONV_ONE_BLOCK', '1')
+    trig_b, tr_b, off_b, _, _ = run()
+    monkeypatch.delenv('NRHIP_CONV_ONE_BLOCK')
+    monkeypatch.setenv('NRHIP_CHANNEL_CZT', '1')
+    trig_c, tr_c, off_c, _, _ = run()
+    assert np.array_equal(trig_a, trig_b) and np.array_equal(trig_a, trig_c)
+    assert np.array_equal(off_a, off_b) and np.array_equal(off_a, off_c)
+    scale = np.max(np.abs(tr_c))
+    assert np.max(np.abs(tr_a - tr_c)) <= 1e-9 * scale and np.max(np.abs(tr_b - tr_c)) <= 1e-9 * scale
+
+
 @pytest.mark.parametrize('name', ['groups_N256', 'groups_dcut_N256'])
 def test_event_groups(gpu_ctx_factory, name):
     """Multi-shower event groups through nrhip_simulate_event_groups: vs the oracle (same rays bit for bit, hence traces
