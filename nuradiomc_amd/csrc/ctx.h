@@ -94,6 +94,11 @@ struct nrhip_station {
     DevArray d_noise_amp;          // per-channel amplitude of the noise adder (nrhip_station_set_noise)
     bool noise_set = false;
     int pa_n_channels = 0, pa_n_beams = 0, pa_window = 0, pa_step = 0, pa_divisor = 0;
+    // which way the convolution kernel runs this station's short events (two half-capacity blocks per CU, or everything in the
+    // full-capacity one): both give the same bits, so the faster one is found by timing one call of each (calls 2 and 3 with
+    // enough candidate events) and kept.  0 undecided, 1 split, 2 one block per CU
+    int conv_mode = 0, conv_calls = 0;
+    double conv_ms_per_event[2] = {0., 0.};
     // workspace of the last simulated chunk (kept for nrhip_sim_fetch and reused between calls)
     std::map<std::string, DevArray> ws;
     std::map<std::string, size_t> ws_bytes;  // valid bytes of the last chunk

@@ -1347,6 +1347,15 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(coinc_cnt = WS("coincidence_count", int, trg.coincidence() ? (size_t)channel_grid_blocks() * FFT_MAX : 1));
         double2* tab_nodes = nullptr;  // per block: the angular interpolation of a tabulated pattern at its frequency nodes
         if (sd.ant_tabs) NEED(tab_nodes = WS("antenna_table_nodes", double2, (size_t)channel_grid_blocks() * 2 * sd.max_tab_freq));
+        // short events of the convolution kernel: split over two instantiations or not (same bits either way; ctx.h)
+        const bool conv_tunable = sd.N < FFT_MAX / 2 && n_cand >= 2000 && !cfg->dump_traces && !getenv("NRHIP_CONV_ONE_BLOCK") && !getenv("NRHIP_CONV_SPLIT");
+        int conv_trial = -1;
+        bool conv_split = st->conv_mode != 2;
+        if (getenv("NRHIP_CONV_SPLIT")) conv_split = true;
+        else if (conv_tunable && st->conv_mode == 0 && st->conv_calls++ >= 1) {
+            conv_trial = (st->conv_ms_per_event[0] == 0.) ? 0 : 1;
+            conv_split = conv_trial == 0;
+        }
         StationDev sd_ch = sd;
         if (phased) sd_ch.trig_on = st->d_pa_mask.as<unsigned char>();  // only the array's channels need traces (unless all are dumped)
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd_ch, st->filters[0], arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
@@ -1354,7 +1363,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                        (cfg->no_pruning || cfg->dump_traces || general || phased || post_trigger || noise) ? 1 : 0, maxL,
                        it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces,
                        (phased || post_trigger) ? (cfg->dump_traces ? 0 : 1) : -1, envelope ? &st->env_filter : nullptr, env_trace,
-                       noise ? &nz : nullptr);
+                       noise ? &nz : nullptr, conv_split);
         LCHK("channel");
         if (post_trigger) {
             launch_trace_trigger(sm, n_cand, d_cand, n_ch, ev.L, envelope ? env_trace : co.trace, co.trace_offset, trg, sd.trig_on, maxL,
@@ -1445,6 +1454,14 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                                ev_triggered, triggered);
         MARK(8);
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here
+        if (conv_trial >= 0) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, st->evt[7], st->evt[8]) == hipSuccess && ms > 0.f) {
+                st->conv_ms_per_event[conv_trial] = (double)ms / (double)n_cand;
+                if (st->conv_ms_per_event[0] > 0. && st->conv_ms_per_event[1] > 0.)
+                    st->conv_mode = (st->conv_ms_per_event[0] <= st->conv_ms_per_event[1]) ? 1 : 2;
+            }
+        }
     }
     MARK(9);
     if (stats) {

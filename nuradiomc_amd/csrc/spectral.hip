@@ -3126,7 +3126,8 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const TriggerDev& trig, const double2* tw, const double2* w16, const LengthTables& tab, double2* scratch,
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
-                    const double* ray_traces, int skip_off, const FilterSet* envf, double* env_trace, const NoiseDev* noise)
+                    const double* ray_traces, int skip_off, const FilterSet* envf, double* env_trace, const NoiseDev* noise,
+                    bool conv_split)
 {
     if (skip_off < 0) skip_off = !exact;  // channels outside the trigger set are evaluated only when everything is
     if (n_items <= 0) return;
@@ -3149,12 +3150,14 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                            item_list);
         // events of up to FFT_MAX / 2 samples go to the half-capacity instantiation (two blocks per CU), longer ones to the full one;
         // both walk the same list with their own counter
-        const bool small = st.N < FFT_MAX / 2 && !getenv("NRHIP_CONV_ONE_BLOCK");   // L >= N: nothing to take otherwise
+        const bool small = st.N < FFT_MAX / 2 && conv_split && !getenv("NRHIP_CONV_ONE_BLOCK");   // L >= N: nothing to take otherwise
         const bool large = !small || max_length > FFT_MAX / 2;
         int* queue = ev_need + n_cand;   // the scan's zero sentinel: free again, and 0; the slot behind it for the second launch
         (void)hipMemsetAsync(queue + 1, 0, sizeof(int), s);
         if (small) {
-            const int cgrid = n_cand < channel_grid_blocks() ? n_cand : channel_grid_blocks();
+            int blocks = channel_grid_blocks();
+            if (getenv("NRHIP_CONV_SMALL_BLOCKS")) blocks = atoi(getenv("NRHIP_CONV_SMALL_BLOCKS"));
+            const int cgrid = n_cand < blocks ? n_cand : blocks;
             hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX - 1>, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)fft_pad_host(FFT_MAX / 2) * 16, s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue, 0);

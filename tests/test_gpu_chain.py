@@ -534,6 +534,8 @@ def test_convolution_kernel_length_classes(gpu_ctx_factory, monkeypatch):
     assert np.array_equal(off_a, off_b) and np.array_equal(off_a, off_c)
     scale = np.max(np.abs(tr_c))
     assert np.max(np.abs(tr_a - tr_c)) <= 1e-9 * scale and np.max(np.abs(tr_b - tr_c)) <= 1e-9 * scale
+    # the two instantiations do the same arithmetic on an event (same transform sizes, rays added in the same order): bit-equal traces
+    assert np.array_equal(tr_a, tr_b)
 
 
 @pytest.mark.parametrize('name', ['groups_N256', 'groups_dcut_N256'])
