@@ -18,7 +18,9 @@
 
 namespace nrhip {
 
-#define ARZ_CHUNKS 8      // blocks per ray: each takes 1/8 of the observer times that can see the shower
+#ifndef ARZ_CHUNKS
+#define ARZ_CHUNKS 4      // blocks per ray: each takes a quarter of the observer times that can see the shower (2 .. 8 measured: 407 .. 419 ms per 1e5 events)
+#endif
 #define ARZ_MAX_PROFILE 2048
 
 static __device__ const double ARZ_RHO = 5.767155003928648e+39;   // 0.924 g / cm^3 in NuRadioReco units (ARZ.py:31)
@@ -142,7 +144,10 @@ __device__ inline double arz_interp_slice(double x, const double* __restrict__ x
 // One stretch of the refined profile: coarse nodes [c0, c1) followed by n_fine points start + k * delta (slice [is, ie))
 struct ArzPiece { int c0, c1, is, ie; long n_fine; double start, step, delta; };
 
-__global__ void __launch_bounds__(256)
+#ifndef ARZ_WAVES
+#define ARZ_WAVES 4   // waves per SIMD the register budget is cut for: 2 .. 8 measured, 4 is fastest (355 vs 410 .. 420 ms per 1e5 events at 2 / 3)
+#endif
+__global__ void __launch_bounds__(256, ARZ_WAVES)
 arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 1][2] */, int* __restrict__ status)
 {
     extern __shared__ double lds[];

@@ -347,7 +347,10 @@ __device__ inline void bire_sincos_small(double x, double* sn, double* cs)
 // spectra [n_rays][2][n_f] complex, in place.  A lane owns the bins k = tid + j T (T lanes per ray, j < BIRE_BINS): the phase of a
 // step is linear in the bin number, so per step a lane takes exp(i tid theta) once (polynomial) and walks its bins by multiplying
 // with exp(i T theta), which the threads that stage the tile of step records into LDS compute once per step.
-__global__ void __launch_bounds__(512)
+#ifndef BIRE_WAVES
+#define BIRE_WAVES 2
+#endif
+__global__ void __launch_bounds__(512, BIRE_WAVES)
 bire_propagate_kernel(BireBatch b, const double* __restrict__ steps, double2* __restrict__ spec, const int* __restrict__ ray_active,
                       int T)
 {

@@ -33,7 +33,7 @@ def run(sl):
     if 'arz_iN' in k:
         k['arz_iN'] = k['arz_iN'][sl]
     return st.simulate_events(vertex[sl], zenith[sl], azimuth[sl], energy[sl], types[sl], kL[sl], **k)
-run(slice(0, 500))
+run(slice(0, min(n, chunk)))   # warm-up of a full call: clocks, allocations, table caches
 t0 = time.time()
 n_trig = n_rays = n_cand = 0
 steps_all = steps_prop = rays_prop = 0
