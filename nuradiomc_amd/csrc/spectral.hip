@@ -1801,16 +1801,10 @@ __global__ void channel_event_flags_kernel(int n_cand, int n_ch, const int* __re
 #ifndef CONV_NT
 #define CONV_NT 512
 #endif
-#ifndef CONV_FIELD_FUSE
-#define CONV_FIELD_FUSE 0   // radix-2 stages fused per LDS pass in the rays' N/2-point transforms (0: pairs)
-#endif
 #define CONV_MAX_ORDER 64  // stations with more channels are evaluated in channel order
 // threads per block: 512 for the full-capacity kernel (one block per CU), 256 for the half-capacity one (two blocks per CU: the same
 // eight waves per CU, each with the 256 registers the transforms want, but two independent barrier domains)
 #define CONV_THREADS(log2cap) ((log2cap) == FFT_LOG2_MAX ? CONV_NT : CONV_NT / 2)
-#ifndef CONV_RAY_BATCH
-#define CONV_RAY_BATCH 1   // the rays' N/2-point transforms in batches of up to four (one batched transform per pass)
-#endif
 // one N/2-point transform of the convolution kernel: an on-sky component of a ray (or both at once when the reflection
 // coefficients are real), where it starts on the event's grid and what it is scaled with
 struct ConvJob {
@@ -1860,8 +1854,6 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
 #define PZ(i) fft_pad(i)
 #define PS(n) (2 * fft_pad((n) >> 1) + ((n) & 1))
     double2* xs = z + (fft_pad(M / 2) + 8);
-    double* amp = (double*)(xs + nh);
-#if CONV_RAY_BATCH
     // up to four transforms at a time: a group of NT / B threads per transform builds its spectrum (amplitudes on the fly,
     // bins k and N/2 - k together), ONE batched transform runs them all, the placements follow in ray order.  B is what fits the
     // 64 KB behind the event's samples: 4 transforms of <= 1024 points, 2 of 2048, 1 of 4096.
@@ -1871,7 +1863,6 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     __shared__ double2 s_ramp4[BM][64 + FFT_MAX / 4 / 64 + 1];
     // B is what fits behind the event's samples: (fft_pad(M) - fft_pad(M / 2) - 8) complex elements
     const int log2B = (LOG2CAP == FFT_LOG2_MAX) ? ((nh <= 1024) ? 2 : (nh <= 2048 ? 1 : 0)) : ((nh <= 1024) ? 1 : 0), B = 1 << log2B;
-#endif
     __shared__ double red[NT / 64];   // block_max: one word per wave
     __shared__ int s_trig;
     const int n_list_events = *n_list;
@@ -1963,7 +1954,6 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             for (int n = threadIdx.x; n < L; n += blockDim.x) S[PS(n)] = 0.;
             __syncthreads();
             CT(1);
-#if CONV_RAY_BATCH
             {
                 const double df = 1.0 / (N * (1. / st.fs));
                 // the transforms of this (channel, antenna table), listed by the first wave: lane i looks at ray r_chunk + i (at most two
@@ -2107,51 +2097,6 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                   }
                 }
             }
-#else
-            for (int r = r0; r < r1; r++) {
-                if (w.ch[r] != ch || w.tab[r] != tb) continue;
-                if (threadIdx.x == 0) rs.ask = w.ask[r];
-                for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
-                __syncthreads();
-                fill_amplitude(amp, st, rs);
-#ifdef NRHIP_CONV_TIMING
-                __syncthreads();
-#endif
-                CT(2);
-                // start bin and sub-sample remainder (efieldToVoltageConverter.py:214-218)
-                double start_time = w.t0[r] - t_min + st.cable[ch] + 0;
-                long start_bin = (long)rint(start_time / res);
-                const int sbin = (int)(((start_bin % (long)L) + (long)L) % (long)L);
-                double rem = start_time - start_bin * res;
-                bool shift = !(fabs(rint(rem * st.fs) - rem * st.fs) < 1e-5);
-                const double vt = w.vfac_t[r], vp = w.vfac_p[r];
-                const double2 rt = w.r_theta[r], rp = w.r_phi[r];
-                const double pt = w.pol_theta[r], pp = w.pol_phi[r];
-                const double wt = fabs(vt * pt) * cabs2(rt), wp = fabs(vp * pp) * cabs2(rp);
-                // real reflection coefficients: both on-sky components are the same real pulse -> one transform
-                const bool one = (rt.y == 0. && rp.y == 0.);
-                for (int comp = 0; comp < (one ? 1 : 2); comp++) {
-                    double pol = one ? 1. : (comp ? pp : pt);
-                    double2 rc = one ? make_double2(1., 0.) : (comp ? rp : rt);
-                    double vfac = one ? (vt * pt * rt.x + vp * pp * rp.x) : (comp ? vp : vt);
-                    if (!one && (comp ? wp : wt) <= 1e-13 * (comp ? wt : wp)) continue;
-                    field_time_domain<CONV_FIELD_FUSE>(xs, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
-                    CT(3);
-                    const double c = vfac / nh;  // the fs/sqrt(2) of freq2time cancels against time2freq's sqrt(2)/fs
-                    for (int j = threadIdx.x; j < nh; j += blockDim.x) {
-                        double2 y = xs[bitrev(j, log2nh)];
-                        int i0 = sbin + 2 * j;
-                        if (i0 >= L) i0 -= L;
-                        int i1 = i0 + 1;
-                        if (i1 >= L) i1 -= L;
-                        S[PS(i0)] += y.x * c;
-                        S[PS(i1)] += y.y * c;
-                    }
-                    __syncthreads();
-                    CT(4);
-                }
-            }
-#endif
             for (int n = L + threadIdx.x; n < 2 * Mr; n += blockDim.x) S[PS(n)] = 0.;
             __syncthreads();
             CT(5);
