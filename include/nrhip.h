@@ -197,6 +197,10 @@ int nrhip_attenuation_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, co
                             const double* C0, int32_t n_freq, const double* freqs, double* att,
                             int32_t* neval);
 
+/* Diagnostic: how many rays of the last nrhip_attenuation_batch call on this context the dense quadrature kernel (LDS lists of
+ * 12 intervals per frequency) handed on to the general kernel (QUADPACK's limit of 50) -- results are the same either way.  */
+int64_t nrhip_attenuation_last_overflow(nrhip_ctx* ctx);
+
 /* attenuation.get_attenuation_length(z, f, model) (NuRadioMC/utilities/attenuation.py:145-262),
  * replacing wrapper.pyx get_attenuation_length (:33-34); elementwise over n values.  HOST.         */
 int nrhip_attenuation_length(nrhip_ctx* ctx, int64_t n, const double* z, const double* freq, double* L);

@@ -51,6 +51,7 @@ def load():
          [vp, i64, c_double_p, c_double_p, i32, c_double_p, c_int32_p, c_int32_p] + [c_double_p] * 7)
     _sig(lib, 'nrhip_attenuation_batch', ctypes.c_int,
          [vp, i64, c_double_p, c_double_p, c_double_p, i32, c_double_p, c_double_p, c_int32_p])
+    _sig(lib, 'nrhip_attenuation_last_overflow', ctypes.c_int64, [vp])
     _sig(lib, 'nrhip_attenuation_length', ctypes.c_int, [vp, i64, c_double_p, c_double_p, c_double_p])
     refl_sig = [vp, i64, c_double_p, c_double_p, i32, i32, ctypes.c_double, c_int32_p, c_int32_p, c_double_p, c_double_p,
                 c_int32_p, c_int32_p] + [c_double_p] * 5 + [c_int32_p, c_int32_p]

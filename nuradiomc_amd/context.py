@@ -295,6 +295,10 @@ class Context:
                                                   L.dptr(freqs), L.dptr(att), L.iptr(nev)))
         return (att, nev) if return_neval else att
 
+    def attenuation_last_overflow(self):
+        """rays of the last attenuation_batch call that the dense quadrature kernel left to the general one"""
+        return int(self._lib.nrhip_attenuation_last_overflow(self._h))
+
     def attenuation_length(self, z, frequency):
         z, frequency = np.broadcast_arrays(L.f64(z), L.f64(frequency))
         z = np.ascontiguousarray(z)

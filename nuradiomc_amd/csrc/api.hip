@@ -17,7 +17,8 @@ void launch_ray_limits(hipStream_t stream, long n_rays, const double* x1, const 
                        const IceConst& m, double* zint);
 void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
                               const double* freqs, int model, const IceConst& m, double* att, int* neval,
-                              const int* ray_index, unsigned long long* eval_counter, const double* gl3, int gl3_n);
+                              const int* ray_index, unsigned long long* eval_counter, const double* gl3, int gl3_n,
+                              int* overflow);   // overflow: 1 + 2 n_rays ints (NULL: the general kernel only)
 void launch_attenuation_length(hipStream_t stream, long n, const double* z, const double* f, int model, double* L,
                                const double* gl3, int gl3_n);
 }  // namespace nrhip
@@ -230,7 +231,9 @@ int nrhip_attenuation_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, co
         if (!(freqs[i] > 0)) return fail_msg("nrhip_attenuation_batch: frequencies must be > 0 (DC is 1 by definition)");
     if (ctx->att_model == NRHIP_ATT_GL3 && !ctx->gl3) return fail_msg("nrhip_attenuation_batch: GL3 needs nrhip_ctx_set_gl3_table");
     HIPCHK(hipSetDevice(ctx->device));
-    DevBuf dx1, dx2, dC0, dz, df, da, dn;
+    DevBuf dx1, dx2, dC0, dz, df, da, dn, dovf;
+    HIPCHK(dovf.alloc((2 * (size_t)n_rays + 1) * 4));
+    HIPCHK(hipMemsetAsync(dovf.p, 0, sizeof(int), ctx->stream));
     HIPCHK(dx1.alloc(n_rays * 24));
     HIPCHK(dx2.alloc(n_rays * 24));
     HIPCHK(dC0.alloc(n_rays * 8));
@@ -246,13 +249,18 @@ int nrhip_attenuation_batch(nrhip_ctx* ctx, int64_t n_rays, const double* x1, co
                              dz.as<double>());
     nrhip::launch_attenuation_items(ctx->stream, n_rays, dC0.as<double>(), dz.as<double>(), n_freq, df.as<double>(),
                                     ctx->att_model, ctx->ice, da.as<double>(), dn.as<int>(), nullptr, nullptr, ctx->gl3,
-                                    ctx->gl3_n);
+                                    ctx->gl3_n, dovf.as<int>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(att, da.p, n_rays * n_freq * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (neval) HIPCHK(hipMemcpyAsync(neval, dn.p, n_rays * n_freq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    int h_ovf = 0;
+    HIPCHK(hipMemcpyAsync(&h_ovf, dovf.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->last_att_overflow = h_ovf;
     return 0;
 }
+
+int64_t nrhip_attenuation_last_overflow(nrhip_ctx* ctx) { return ctx ? ctx->last_att_overflow : -1; }
 
 // ---- reflections off the bottom of an ice shelf ----
 static int refl_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const double* x2, int32_t n_x2, int32_t n_reflections,
@@ -375,7 +383,8 @@ int nrhip_attenuation_reflections_batch(nrhip_ctx* ctx, int64_t n_rays, const do
     HIPCHK(hipSetDevice(ctx->device));
     const int NS = max_refl + 1;
     const size_t nk = (size_t)n_rays;  // one solution slot per ray
-    DevBuf dx1, dx2, dns, dty, drf, drc, dsu, dsm, dC0, dC1, dD, dT, dla, dre, dra, dsz, dsc, df, dsa, da;
+    DevBuf dx1, dx2, dns, dty, drf, drc, dsu, dsm, dC0, dC1, dD, dT, dla, dre, dra, dsz, dsc, df, dsa, da, dovf;
+    HIPCHK(dovf.alloc((2 * (size_t)nk * NS + 1) * 4));
     HIPCHK(dx1.alloc(nk * 24));
     HIPCHK(dx2.alloc(nk * 24));
     HIPCHK(dns.alloc(nk * 4));
@@ -409,7 +418,8 @@ int nrhip_attenuation_reflections_batch(nrhip_ctx* ctx, int64_t n_rays, const do
     nrhip::launch_records_refl(ctx->stream, n_rays, max_refl, 1, dx1.as<double>(), dx2.as<double>(), 0, ctx->ice, z_reflection,
                                nullptr, nullptr, 1, r);
     nrhip::launch_attenuation_items(ctx->stream, (long)nk * NS, dsc.as<double>(), dsz.as<double>(), n_freq, df.as<double>(),
-                                    ctx->att_model, ctx->ice, dsa.as<double>(), nullptr, nullptr, nullptr, ctx->gl3, ctx->gl3_n);
+                                    ctx->att_model, ctx->ice, dsa.as<double>(), nullptr, nullptr, nullptr, ctx->gl3, ctx->gl3_n,
+                                    dovf.as<int>());
     nrhip::launch_segment_product(ctx->stream, n_rays, NS, n_freq, dsz.as<double>(), dsa.as<double>(), da.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(att, da.p, nk * n_freq * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -930,9 +930,10 @@ __global__ void __launch_bounds__(ATT_BLOCK, ATT_WAVES)
 attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const double* __restrict__ zint, int n_freq,
                          const double* __restrict__ freqs, int model, IceConst m, double* __restrict__ att,
                          int* __restrict__ neval, const int* __restrict__ ray_index,
-                         unsigned long long* __restrict__ eval_counter)
+                         unsigned long long* __restrict__ eval_counter, const int* __restrict__ n_rays_dev = nullptr)
 {
     __shared__ NodeShared sh_nodes[(ATT_BLOCK / G) * 42];
+    if (n_rays_dev) n_rays = *n_rays_dev;   // the overflow list of attenuation_dense_kernel (length known on the device only)
     __shared__ double sh_f[20 * ATT_BLOCK];
     GroupEval<G, MODEL> ev;
     ev.init(sh_nodes, sh_f);
@@ -1001,6 +1002,8 @@ attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const doubl
         if ((threadIdx.x & 63) == 0) atomicAdd(eval_counter, my_evals);
     }
 }
+
+#include "attenuation_dense.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // The reference's speed-optimised path integral for the models in speedup_attenuation_models (GL3),
@@ -1180,7 +1183,8 @@ void launch_ray_limits(hipStream_t stream, long n_rays, const double* x1, const 
 
 void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
                               const double* freqs, int model, const IceConst& m, double* att, int* neval,
-                              const int* ray_index, unsigned long long* eval_counter, const double* gl3, int gl3_n)
+                              const int* ray_index, unsigned long long* eval_counter, const double* gl3, int gl3_n,
+                              int* overflow)
 {
     long n_items = n_rays * n_freq;
     if (n_items <= 0) return;
@@ -1190,6 +1194,36 @@ void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0,
         if (grid > 256L * 64) grid = 256L * 64;
         hipLaunchKernelGGL(attenuation_segments_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_rays, C0, zint, n_freq,
                            freqs, model, m, att, neval, ray_index, gl3, gl3_n);
+        return;
+    }
+    if (overflow && model != 5 && n_freq <= 32 && !getenv("NRHIP_ATT_LEGACY") && !getenv("NRHIP_ATT_LANES")) {
+        // dense packing + LDS lists (attenuation_dense.h); overflow[0]: number of rays it left over, overflow[1..]: those rays,
+        // integrated by the general kernel afterwards
+        const DenseMap map = make_dense_map(n_freq);
+        const long n_pairs = (n_rays + map.rays_per_pair - 1) / map.rays_per_pair;
+        long grid = 2 * n_pairs;
+        if (grid > 256L * 128) grid = 256L * 128;
+        (void)hipMemsetAsync(overflow, 0, sizeof(int), stream);
+#define NRHIP_ATTD_LAUNCH(MM)                                                                                          \
+    hipLaunchKernelGGL((attenuation_dense_kernel<MM>), dim3((unsigned)grid), dim3(64), 0, stream, n_rays, C0, zint, n_freq, \
+                       freqs, m, att, neval, ray_index, eval_counter, map, overflow, overflow + 1)
+        switch (model) {
+            case 1: NRHIP_ATTD_LAUNCH(1); break;
+            case 2: NRHIP_ATTD_LAUNCH(2); break;
+            case 4: NRHIP_ATTD_LAUNCH(4); break;
+            default: NRHIP_ATTD_LAUNCH(3); break;
+        }
+        long grid2 = (n_rays + ATT_BLOCK / 32 - 1) / (ATT_BLOCK / 32);
+        if (grid2 > 2048) grid2 = 2048;
+#define NRHIP_ATTO_LAUNCH(MM)                                                                                              \
+    hipLaunchKernelGGL((attenuation_group_kernel<32, MM>), dim3((unsigned)grid2), dim3(ATT_BLOCK), 0, stream, 2 * n_rays, C0, zint, \
+                       n_freq, freqs, model, m, att, neval, overflow + 1, eval_counter, overflow)
+        switch (model) {
+            case 1: NRHIP_ATTO_LAUNCH(1); break;
+            case 2: NRHIP_ATTO_LAUNCH(2); break;
+            case 4: NRHIP_ATTO_LAUNCH(4); break;
+            default: NRHIP_ATTO_LAUNCH(3); break;
+        }
         return;
     }
     if (n_freq <= 64 && !getenv("NRHIP_ATT_LANES")) {

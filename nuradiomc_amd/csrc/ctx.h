@@ -34,6 +34,7 @@ struct nrhip_ctx {
     double2* twiddle = nullptr;  // exp(-2 pi i k / FFT_MAX), k < FFT_MAX / 2
     double* gl3 = nullptr;       // GL3 depth table [3][gl3_n] (depth, slope, offset), nrhip_ctx_set_gl3_table
     int gl3_n = 0;
+    long last_att_overflow = 0;  // rays the dense quadrature kernel left to the general one (last nrhip_attenuation_batch)
     double2* w16 = nullptr;      // exp(-2 pi i k / (2 FFT_MAX)), k <= FFT_MAX / 2 (real <-> packed-complex FFT split)
     std::set<struct nrhip_station*> stations;  // alive stations: nrhip_ctx_destroy releases what they hold on the GPU
     DevArray cull_ws;            // scratch of nrhip_cull_groups (flags, sizes, scans)

@@ -1053,12 +1053,16 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             NEED(items = WS("ray_segment_items", int, (size_t)n_active * NS_));
             launch_gather_segments(sm, n_rays, NS_, ray_slot, seg_C0, seg_zint, rs_C0, rs_zint);
             launch_segment_items(sm, n_active, NS_, active_list, items);
+            int* att_ovf;
+            NEED(att_ovf = WS("att_overflow", int, 2 * (size_t)n_active * NS_ + 1));
             launch_attenuation_items(sm, (long)n_active * NS_, rs_C0, rs_zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, rs_att,
-                                     nullptr, items, eval_counter, ctx->gl3, ctx->gl3_n);
+                                     nullptr, items, eval_counter, ctx->gl3, ctx->gl3_n, att_ovf);
             launch_segment_product_rays(sm, n_active, NS_, sd.n_fc, active_list, rs_C0, rs_att, w.att);
         } else {
+            int* att_ovf;
+            NEED(att_ovf = WS("att_overflow", int, 2 * (size_t)n_active + 1));
             launch_attenuation_items(sm, n_active, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr,
-                                     active_list, eval_counter, ctx->gl3, ctx->gl3_n);
+                                     active_list, eval_counter, ctx->gl3, ctx->gl3_n, att_ovf);
         }
         LCHK("attenuation");
     }

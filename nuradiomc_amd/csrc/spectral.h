@@ -246,6 +246,6 @@ void launch_czt_test(hipStream_t s, int n_batch, int n_in, int n_out, int Q, dou
 void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
                               const double* freqs, int model, const IceConst& m, double* att, int* neval,
                               const int* ray_index = nullptr, unsigned long long* eval_counter = nullptr,
-                              const double* gl3 = nullptr, int gl3_n = 0);
+                              const double* gl3 = nullptr, int gl3_n = 0, int* overflow = nullptr);
 
 }  // namespace nrhip
