@@ -8,16 +8,16 @@
 //     records; all synchronisation stays inside the wave.
 //   * the frequency-independent node records of both intervals of a bisection are produced by 63 lanes in one pass per
 //     interval (lane = (group, node)), instead of 21 of 32 lanes per ray.
-//   * no scratch lists.  The intervals QUADPACK creates are the nodes of a binary tree whose end points do not depend on the
-//     frequency (b1 = (a + b) / 2 of the parent): ONE tree per group in LDS (end points, depth, child link); per lane only
-//     the slot -> tree-node map (bytes), the slot results / errors (rlist, elist) and the order list (bytes), all in LDS
-//     columns.  The frequencies of a ray may bisect in different order (3.7 % of the rays of the survey do): each lane
+//   * no scratch at all.  The intervals QUADPACK creates are the nodes of a binary tree whose end points do not depend on the
+//     frequency (b1 = (a + b) / 2 of the parent): ONE tree per group in LDS (end points, depth, child link); per lane the
+//     slot results / errors (rlist, elist) in LDS columns, the slot -> tree-node map and the order list packed into two
+//     64-bit registers (12 x 5 and 12 x 4 bits), the epsilon table in registers (DQELG unrolled per table length).  The frequencies of a ray may bisect in different order (3.7 % of the rays of the survey do): each lane
 //     follows its own order on the shared tree; when the lanes of a group ask for different intervals in one round, the
 //     group evaluates them one after the other.
 //   * the 20 node values a rule needs twice stay in registers (the lists no longer compete for them).
 // Capacity: ATTD_K list slots per item and ATTD_T tree nodes per group (the survey needs 12 / 24).  A group that would
 // exceed either, or needs the general exp() range, is NOT finished here: its ray goes onto the overflow list and
-// attenuation_group_kernel (any depth, limit 50) integrates it afterwards.  Only the epsilon table stays in scratch.
+// attenuation_group_kernel (any depth, limit 50) integrates it afterwards.
 #pragma once
 
 #define ATTD_K 12
@@ -70,14 +70,14 @@ struct DenseLds {
     double rlist[ATTD_K][64], elist[ATTD_K][64];
     unsigned char tchild[ATTD_NG][ATTD_T];             // first child (0: not bisected yet); the second one follows it
     unsigned char tdepth[ATTD_NG][ATTD_T];             // QAGP's level of the interval
-    unsigned char iord[ATTD_K + 1][64];
-    unsigned char nodeid[ATTD_K][64];                  // list slot -> tree node
 };
 
-// one 21-point rule from the group's node records; same operations and order as gk21_from_nodes, node values in registers
+// one 21-point rule from the group's node records; same operations and order as gk21_from_nodes, node values in registers.
+// SP1: the caller has checked that every exp argument of the rule lies in [-700, 700]; and since every integrand value is
+// >= +0 (ds >= 0 times min(exp, 1) > 0) the sum of |f| that QUADPACK keeps as resabs receives exactly the terms of resk in
+// the same order from the same start: resabs == resk bit for bit (NaN alike), so it is not accumulated separately.
 template <int MODEL>
-__device__ __forceinline__ GK dense_rule(const DenseRec<MODEL>* __restrict__ r, double a, double b, const AttLane& lane,
-                                         int sel, bool& ok)
+__device__ __forceinline__ GK dense_rule(const DenseRec<MODEL>* __restrict__ r, double a, double b, const AttLane& lane, int sel)
 {
     const double WGK[11] = {
         0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
@@ -94,10 +94,21 @@ __device__ __forceinline__ GK dense_rule(const DenseRec<MODEL>* __restrict__ r, 
     auto fval = [&](int n) -> double {
         if constexpr (MODEL == 1) {
             const double x = r[n].p[sel] + r[n].p[sel + 1] * lane.w;
-            ok = ok && (fabs(x) <= 700.);
             return r[n].ds * fmin(det_exp_inrange(x), 1.);
         } else {
             return r[n].ds / attenuation_length(r[n].z, lane);
+        }
+    };
+    auto fval2 = [&](int n1, int n2, double& f1, double& f2) {
+        if constexpr (MODEL == 1) {
+            const double x1 = r[n1].p[sel] + r[n1].p[sel + 1] * lane.w, x2 = r[n2].p[sel] + r[n2].p[sel + 1] * lane.w;
+            double e1, e2;
+            det_exp_inrange2(x1, x2, e1, e2);
+            f1 = r[n1].ds * fmin(e1, 1.);
+            f2 = r[n2].ds * fmin(e2, 1.);
+        } else {
+            f1 = fval(n1);
+            f2 = fval(n2);
         }
     };
     double fv1[10], fv2[10];
@@ -109,24 +120,27 @@ __device__ __forceinline__ GK dense_rule(const DenseRec<MODEL>* __restrict__ r, 
 #pragma unroll
     for (int j = 0; j < 5; j++) {
         const int jtw = 2 * j + 1;
-        const double f1 = fval(1 + 2 * j), f2 = fval(2 + 2 * j);
+        double f1, f2;
+        fval2(1 + 2 * j, 2 + 2 * j, f1, f2);
         fv1[jtw] = f1; fv2[jtw] = f2;
         const double fsum = f1 + f2;
         resg += WG[j] * fsum;
         resk += WGK[jtw] * fsum;
-        resabs += WGK[jtw] * (fabs(f1) + fabs(f2));
+        if constexpr (MODEL != 1) resabs += WGK[jtw] * (fabs(f1) + fabs(f2));
         __builtin_amdgcn_sched_barrier(0);   // one pair of nodes at a time: the 20 kept values leave no room for more in flight
     }
 #pragma unroll
     for (int j = 0; j < 5; j++) {
         const int jtwm1 = 2 * j;
-        const double f1 = fval(11 + 2 * j), f2 = fval(12 + 2 * j);
+        double f1, f2;
+        fval2(11 + 2 * j, 12 + 2 * j, f1, f2);
         fv1[jtwm1] = f1; fv2[jtwm1] = f2;
         const double fsum = f1 + f2;
         resk += WGK[jtwm1] * fsum;
-        resabs += WGK[jtwm1] * (fabs(f1) + fabs(f2));
+        if constexpr (MODEL != 1) resabs += WGK[jtwm1] * (fabs(f1) + fabs(f2));
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (MODEL == 1) resabs = resk;
     const double reskh = resk * 0.5;
     double resasc = WGK[10] * fabs(fc - reskh);
 #pragma unroll
@@ -198,6 +212,117 @@ __device__ __forceinline__ void dense_sort_errors(int last, int& maxerr, double&
     ermax = el(maxerr);
 }
 
+#define ATTD_E 9   // entries of the epsilon table kept per item (numrl2 + 2 <= ATTD_E)
+
+// The epsilon table rlist2[1 .. ATTD_E] as named scalars: registers cannot be indexed by data, and an array would end up in
+// scratch as soon as the optimiser merges two stores at different constant indices into one store at a selected index.
+struct EpsTab { double v1, v2, v3, v4, v5, v6, v7, v8, v9; };
+template <int I> __device__ __forceinline__ double& eps_at(EpsTab& t)
+{
+    static_assert(I >= 1 && I <= ATTD_E, "epsilon table index");
+    if constexpr (I == 1) return t.v1;
+    else if constexpr (I == 2) return t.v2;
+    else if constexpr (I == 3) return t.v3;
+    else if constexpr (I == 4) return t.v4;
+    else if constexpr (I == 5) return t.v5;
+    else if constexpr (I == 6) return t.v6;
+    else if constexpr (I == 7) return t.v7;
+    else if constexpr (I == 8) return t.v8;
+    else return t.v9;
+}
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// DQELG (epsilon_extrap) for a table of exactly N entries on entry, every index a compile-time constant.  Same operations in the
+// same order as epsilon_extrap.
+template <int N>
+__device__ __forceinline__ void dense_epsilon_static(EpsTab& e, int& n, double& result, double& abserr, double& r3a, double& r3b,
+                                                     double& r3c, int& nres)
+{
+    const double epmach = 2.220446049250313e-16, oflow = 1.7976931348623157e+308;
+    nres++;
+    abserr = oflow;
+    result = eps_at<N>(e);
+    if constexpr (N >= 3) {
+        eps_at<N + 2>(e) = eps_at<N>(e);
+        constexpr int newelm = (N - 1) / 2;
+        eps_at<N>(e) = oflow;
+        bool live = true, early = false;
+        n = N;
+        static_for<1, newelm + 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int k1 = N - 2 * (i - 1), k2 = k1 - 1, k3 = k1 - 2;
+            if (live) {
+                double res = eps_at<k1 + 2>(e);
+                const double e0 = eps_at<k3>(e), e1 = eps_at<k2>(e), e2 = res;
+                const double e1abs = fabs(e1);
+                const double delta2 = e2 - e1, err2 = fabs(delta2), tol2 = fmax(fabs(e2), e1abs) * epmach;
+                const double delta3 = e1 - e0, err3 = fabs(delta3), tol3 = fmax(e1abs, fabs(e0)) * epmach;
+                if (!(err2 > tol2 || err3 > tol3)) {
+                    result = res;
+                    abserr = fmax(err2 + err3, 5. * epmach * fabs(result));
+                    early = true;
+                    live = false;
+                } else {
+                    const double e3 = eps_at<k1>(e);
+                    eps_at<k1>(e) = e1;
+                    const double delta1 = e1 - e3, err1 = fabs(delta1), tol1 = fmax(e1abs, fabs(e3)) * epmach;
+                    if (err1 <= tol1 || err2 <= tol2 || err3 <= tol3) { n = i + i - 1; live = false; }
+                    else {
+                        const double ss = 1. / delta1 + 1. / delta2 - 1. / delta3;
+                        const double epsinf = fabs(ss * e1);
+                        if (!(epsinf > 1e-4)) { n = i + i - 1; live = false; }
+                        else {
+                            res = e1 + 1. / ss;
+                            eps_at<k1>(e) = res;
+                            const double error = err2 + fabs(res - e2) + err3;
+                            if (!(error > abserr)) {
+                                abserr = error;
+                                result = res;
+                            }
+                        }
+                    }
+                }
+            }
+        });
+        if (early) return;
+        constexpr int ib0 = (N % 2 == 0) ? 2 : 1;
+        static_for<0, newelm + 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            eps_at<ib0 + 2 * i>(e) = eps_at<ib0 + 2 * i + 2>(e);
+        });
+        if (n != N) {   // n = 1, 3, 5: the last n entries move to the front
+            static_for<0, (N - 1) / 2>([&](auto jc) {
+                constexpr int nn = 2 * decltype(jc)::value + 1;
+                if constexpr (nn < N) {
+                    if (n == nn)
+                        static_for<1, nn + 1>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            eps_at<i>(e) = eps_at<N - nn + i>(e);
+                        });
+                }
+            });
+        }
+        if (nres < 4) {
+            if (nres == 1) r3a = result;
+            else if (nres == 2) r3b = result;
+            else r3c = result;
+            abserr = oflow;
+        } else {
+            abserr = fabs(result - r3c) + fabs(result - r3b) + fabs(result - r3a);
+            r3a = r3b;
+            r3b = r3c;
+            r3c = result;
+        }
+    }
+    abserr = fmax(abserr, 5. * epmach * fabs(result));
+}
+
 template <int MODEL>
 __global__ void __launch_bounds__(64, ATT_WAVES)
 attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const double* __restrict__ zint, int n_freq,
@@ -223,92 +348,128 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
     const int tg = (lane < 21 * NG) ? lane / 21 : -1;   // node role: group and node of the records this lane computes
     const int tnode = lane - 21 * (tg < 0 ? 0 : tg);
     unsigned long long tgmask = 0ULL;
+    int roff_g = -1, roff_t = -1;   // ray of the lane's group / task group, relative to the pair's first ray
 #pragma unroll
-    for (int q = 0; q < ATTD_NG; q++)
-        if (q == tg) tgmask = ((1ULL << map.nf[wtype][q]) - 1ULL) << map.lane0[wtype][q];
+    for (int q = 0; q < ATTD_NG; q++) {
+        if (q == tg) { tgmask = ((1ULL << map.nf[wtype][q]) - 1ULL) << map.lane0[wtype][q]; roff_t = map.ray_off[wtype][q]; }
+        if (q == g) roff_g = map.ray_off[wtype][q];
+    }
+    const int rays_per_pair = map.rays_per_pair;
     AttLane al;
     al.model = MODEL;
     al.f = (g >= 0 && jf < n_freq) ? freqs[jf] : 1.;
     al.w = det_log(al.f);
     const int sel = (MODEL == 1 && !(al.f < 1.)) ? 2 : 0;
+    // SP1: the exp arguments x = a(z) + b(z) ln f of a node are within [-700, 700] for all frequencies if |a| + |b| max|ln f| is
+    // (checked per node by the lane that makes the record, not per (node, frequency))
+    double wmax = (g >= 0 && jf < n_freq) ? fabs(al.w) : 0.;
+    for (int off = 32; off > 0; off >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, off));
+    const unsigned long long taskmask = (g >= 0) ? (((1ULL << 21) - 1ULL) << (21 * g)) : 0ULL;   // the lanes making the group's records
     const int gi = g < 0 ? 0 : g;     // safe index for LDS addressing of idle lanes
     const int tgi = tg < 0 ? 0 : tg;
     unsigned long long my_evals = 0;
-
-    auto elist_at = [&](int i) -> double { return L.elist[i - 1][lane]; };
-    auto iord_at = [&](int i) -> int { return (int)L.iord[i][lane]; };
-    auto iord_set = [&](int i, int v) { L.iord[i][lane] = (unsigned char)v; };
+#ifdef NRHIP_ATT_TIMING
+    unsigned long long tacc[12] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
+#define DT_MARK(t) unsigned long long t = __builtin_amdgcn_s_memtime()
+#define DT_ADD(i, t0) do { tacc[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
+#else
+#define DT_MARK(t)
+#define DT_ADD(i, t0)
+#endif
     auto wave_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
 
-    const long n_pairs_total = (n_rays + map.rays_per_pair - 1) / map.rays_per_pair;
+    const long n_pairs_total = (n_rays + rays_per_pair - 1) / rays_per_pair;
     const long pair_stride = gridDim.x >> 1;
-    for (long pair = blockIdx.x >> 1; pair < n_pairs_total; pair += pair_stride) {
-        // ---- the rays of this wave's groups (wave-uniform addresses) ------------------------------------------------------
-        double gC0 = NAN, gz1 = 0., gz2m = 0., gzt = 0., tC0 = NAN, tzt = 0.;
-        long gray = -1;
-#pragma unroll
-        for (int q = 0; q < ATTD_NG; q++) {
-            if (q >= NG) continue;
-            const long li = pair * map.rays_per_pair + map.ray_off[wtype][q];
-            if (li >= n_rays) continue;
+    // the rays of a wave's groups; the NEXT pair's are requested before the current one's results are stored
+    struct PairRays { long gray; double gC0, gz1, gz2m, gzt, tC0, tzt; };
+    auto load_rays = [&](long pair) -> PairRays {
+        // (per-lane addresses -- the lane's own group and its task group -- so that these are vector loads, waited for with
+        // vmcnt: scalar loads share the LDS operations' counter and would be waited for at the next LDS access)
+        PairRays r{-1, NAN, 0., 0., 0., NAN, 0.};
+        if (pair >= n_pairs_total) return r;
+        const long li = pair * rays_per_pair + roff_g, lt = pair * rays_per_pair + roff_t;
+        if (roff_g >= 0 && li < n_rays) {
             const long ray = ray_index ? ray_index[li] : li;
-            const double c0 = C0[ray], z1 = zint[3 * ray], z2m = zint[3 * ray + 1], zt = zint[3 * ray + 2];
-            if (q == g) { gray = ray; gC0 = c0; gz1 = z1; gz2m = z2m; gzt = zt; }
-            if (q == tg) { tC0 = c0; tzt = zt; }
+            r.gray = ray; r.gC0 = C0[ray]; r.gz1 = zint[3 * ray]; r.gz2m = zint[3 * ray + 1]; r.gzt = zint[3 * ray + 2];
         }
+        if (roff_t >= 0 && lt < n_rays) {
+            const long ray = ray_index ? ray_index[lt] : lt;
+            r.tC0 = C0[ray]; r.tzt = zint[3 * ray + 2];
+        }
+        return r;
+    };
+    PairRays nxt = load_rays(blockIdx.x >> 1);
+    for (long pair = blockIdx.x >> 1; pair < n_pairs_total; pair += pair_stride) {
+        DT_MARK(t_pair);
+        const double gC0 = nxt.gC0, gz1 = nxt.gz1, gz2m = nxt.gz2m, gzt = nxt.gzt;
+        const long gray = nxt.gray;
         const bool ray_ok = (g >= 0) && gray >= 0 && jf < n_freq;
         const bool valid = ray_ok && !isnan(gC0);
         const bool with_point = (gz1 < gzt && gzt < gz2m);
-        AttItem it;       // (per-lane general rule of the range fallback)
-        it.C0 = gC0;
-        it.z_turn = gzt;
-        it.lane = al;
         AttItem tit;      // the node role's ray
-        tit.C0 = tC0;
-        tit.z_turn = tzt;
+        tit.C0 = nxt.tC0;
+        tit.z_turn = nxt.tzt;
         tit.lane = al;
         tit.lane.model = MODEL;
 
         // ---- QUADPACK state of the lane (dqagse / dqagpe) ----------------------------------------------------------------
-        double rlist2[53], res3la[4];
-        double result = 0., abserr = 0., resabs = 0., errsum = 0., errbnd = 0., errmax = 0., area = 0., dres;
-        double erlarg = 0., ertest = 0., correc = 0., small = 0., reseps = 0., abseps = 0.;
+        EpsTab ep{0., 0., 0., 0., 0., 0., 0., 0., 0.};   // the epsilon table rlist2[1 .. ATTD_E]
+        double r3a = 0., r3b = 0., r3c = 0.;
+        unsigned long long iop = 0ULL, nip = 0ULL;   // iord[1 .. 12] (4 bits each) and the slot -> tree-node map (5 bits each)
+        auto iord_at = [&](int i) -> int { return (int)((iop >> (4 * (i - 1))) & 15ULL); };
+        auto iord_set = [&](int i, int v) {
+            const int sh = 4 * (i - 1);
+            iop = (iop & ~(15ULL << sh)) | ((unsigned long long)v << sh);
+        };
+        auto node_of = [&](int slot) -> int { return (int)((nip >> (5 * (slot - 1))) & 31ULL); };
+        auto node_set = [&](int slot, int v) {
+            const int sh = 5 * (slot - 1);
+            nip = (nip & ~(31ULL << sh)) | ((unsigned long long)v << sh);
+        };
+        auto elist_at = [&](int i) -> double { return L.elist[i - 1][lane]; };
+        auto width_of = [&](int slot) -> double { const int nn = node_of(slot); return fabs(L.tb[gi][nn] - L.ta[gi][nn]); };
+        auto level_of = [&](int slot) -> int { return (int)L.tdepth[gi][node_of(slot)]; };
+        double result = 0., abserr = 0., resabs = 0., errsum = 0., errbnd = 0., errmax = 0., area = 0.;
+        double erlarg = 0., ertest = 0., correc = 0., small = 0.;
         int ier = 0, ierro = 0, iroff1 = 0, iroff2 = 0, iroff3 = 0, ksgn = 1, ktmin = 0, last = 0, maxerr = 1, neval_ = 0,
             nres = 0, nrmax = 1, numrl2 = 1, levmax = 1, levcur = 0;
-        bool extrap = false, noext = false, busy = false, ovf = false;
-        double sign = 1.;
+        bool extrap = false, noext = false, busy = false, ovf = false, entered_loop = false;
         const bool qagp = with_point;
         int exit_code = 0;
         int tcount = 2;   // tree nodes of the lane's group (kept alike by all its lanes)
         GK g1, g2;
         g1.result = g1.abserr = g1.resabs = g1.resasc = 0.;
         g2 = g1;
-        double a1 = 0., b1 = 0., a2 = 0., b2 = 0.;
-        const double qa = gz1, qb = gz2m;
 
         // roots of the group's tree: (a, b), or (lo, point) and (point, hi)
         if (g >= 0 && lane == glane0) {
-            const double lo = fmin(qa, qb), hi = fmax(qa, qb);
-            L.ta[gi][0] = qagp ? lo : qa;
-            L.tb[gi][0] = with_point ? gzt : qb;
+            const double lo = fmin(gz1, gz2m), hi = fmax(gz1, gz2m);
+            L.ta[gi][0] = qagp ? lo : gz1;
+            L.tb[gi][0] = with_point ? gzt : gz2m;
             L.ta[gi][1] = gzt;
             L.tb[gi][1] = hi;
             L.tdepth[gi][0] = L.tdepth[gi][1] = 0;
             L.tchild[gi][0] = L.tchild[gi][1] = 0;
         }
         wave_sync();
+        DT_ADD(9, t_pair);
 
-        // One round of rule evaluations.  pend: the lane needs the estimates of the two children of tree node tn (tn < 0: of
-        // the roots; `two` false there for rays without an inner turning point).  Lanes of a group that ask for different
-        // nodes are served one node after the other.  Leaves g1, g2 and the intervals in a1 .. b2.
-        auto round = [&](bool pend, int tn, bool two) {
+        // Rounds of rule evaluations.  pend: the lane needs the estimates of the two children of tree node tn (tn < 0: of the
+        // roots, in the first round; `two` false there for rays without an inner turning point).  Lanes of a group that ask for
+        // different nodes are served one node after the other.  A round leaves g1, g2 and the first child in c_mine.
+        bool first = true, pend = valid, two = with_point;
+        int tn = -1, c_mine = 0;
+        double erlast = 0.;
+        while (true) {
             while (true) {
                 const unsigned long long pm = __ballot(pend);
                 if (pm == 0ULL) break;
+                DT_MARK(t_r0);
                 // -- item role: the node the group serves now, its children
                 const unsigned long long mine = pm & gmask;
                 const bool has = mine != 0ULL;
@@ -342,14 +503,20 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
                 }
                 const bool my_turn = pend && tn == ltn;
                 wave_sync();
+                DT_ADD(0, t_r0);
+                DT_MARK(t_r1);
                 // -- node role: records of the served node's children for the lane's task group
+                unsigned long long rng_bad = 0ULL;
                 {
                     const unsigned long long tm = pm & tgmask;
                     const int tl = (tm != 0ULL) ? (__ffsll((long long)tm) - 1) : lane;
                     const int tc = __shfl(grp_ovf ? -1 : c, tl);
                     const int ttwo = __shfl((int)two, tl);
+                    bool bad = false;
                     if (tm != 0ULL && tc >= 0) {
-                        for (int iv = 0; iv < (ttwo ? 2 : 1); iv++) {
+#pragma unroll
+                        for (int iv = 0; iv < 2; iv++) {   // (both intervals in one block: their dependent chains interleave)
+                            if (iv == 1 && !ttwo) break;
                             const double ia = L.ta[tgi][tc + iv], ib = L.tb[tgi][tc + iv];
                             NodeShared n1 = node_shared(gk_node(tnode, ia, ib), tit, m);
                             DenseRec<MODEL> rr;
@@ -358,6 +525,7 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
                                 if (n1.z > 0) n1.ds = n1.ds * 0.;
                                 rr.ds = n1.ds;
                                 rr.p[0] = n1.p[0]; rr.p[1] = n1.p[1]; rr.p[2] = n1.p[2]; rr.p[3] = n1.p[3];
+                                bad = bad || !(fabs(n1.p[0]) + fabs(n1.p[1]) * wmax <= 690.) || !(fabs(n1.p[2]) + fabs(n1.p[3]) * wmax <= 690.);
                             } else {
                                 rr.ds = n1.ds;
                                 rr.z = n1.z;
@@ -365,128 +533,111 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
                             L.rec[tgi][iv][tnode] = rr;
                         }
                     }
+                    rng_bad = __ballot(bad);
                 }
                 wave_sync();
+                DT_ADD(1, t_r1);
+                DT_MARK(t_r2);
                 // -- item role: the lane's own sums over the shared records
                 if (my_turn) {
-                    a1 = L.ta[gi][c]; b1 = L.tb[gi][c];
-                    a2 = L.ta[gi][c + 1]; b2 = L.tb[gi][c + 1];
-                    bool ok = true;
+                    c_mine = c;
+                    const bool ok = (rng_bad & taskmask) == 0ULL;
+                    if (ok) {
 #pragma unroll 1
-                    for (int iv = 0; iv < (two ? 2 : 1); iv++) {   // (one copy of the rule's code)
-                        const GK q = dense_rule<MODEL>(&L.rec[gi][iv][0], iv ? a2 : a1, iv ? b2 : b1, al, sel, ok);
-                        if (iv) g2 = q;
-                        else g1 = q;
-                    }
-                    if (!ok) {            // exp argument outside [-700, 700] (never on physical rays): the general rule
-                        g1 = gk21(a1, b1, it, m);
-                        if (two) g2 = gk21(a2, b2, it, m);
+                        for (int iv = 0; iv < (two ? 2 : 1); iv++) {   // (one copy of the rule's code)
+                            const GK q = dense_rule<MODEL>(&L.rec[gi][iv][0], L.ta[gi][c + iv], L.tb[gi][c + iv], al, sel);
+                            if (iv) g2 = q;
+                            else g1 = q;
+                        }
+                    } else {            // exp argument outside [-700, 700] (never on physical rays): the general rule
+                        AttItem it;
+                        it.C0 = gC0;
+                        it.z_turn = gzt;
+                        it.lane = al;
+                        g1 = gk21(L.ta[gi][c], L.tb[gi][c], it, m);
+                        if (two) g2 = gk21(L.ta[gi][c + 1], L.tb[gi][c + 1], it, m);
                     }
                     pend = false;
                 }
                 wave_sync();
+                DT_ADD(2, t_r2);
             }
-        };
-
-        // ---- first estimate(s) --------------------------------------------------------------------------------------------
-        round(valid, -1, with_point);
-        if (valid && !ovf) {
-            const int nint = 2;
-            if (qagp) {
-                if (qa > qb) sign = -1.;
-                const GK gg[3] = {g1, g1, g2};
-                bool nd[3] = {false, false, false};
-                for (int i = 1; i <= nint; i++) {
-                    const GK& q = gg[i];
-                    abserr += q.abserr;
-                    result += q.result;
-                    nd[i] = (q.abserr == q.resasc && q.abserr != 0.);
-                    resabs += q.resabs;
-                    L.elist[i - 1][lane] = q.abserr;
-                    L.rlist[i - 1][lane] = q.result;
-                    L.nodeid[i - 1][lane] = (unsigned char)(i - 1);
-                    iord_set(i, i);
+            if (first) {
+                // ---- first estimate(s) --------------------------------------------------------------------------------------
+                DT_MARK(t_init);
+                if (valid && !ovf) {
+                    if (qagp) {
+                        double e1_ = g1.abserr, e2_ = g2.abserr;
+                        abserr = (abserr + g1.abserr) + g2.abserr;
+                        result = (result + g1.result) + g2.result;
+                        const bool nd1 = (g1.abserr == g1.resasc && g1.abserr != 0.), nd2 = (g2.abserr == g2.resasc && g2.abserr != 0.);
+                        resabs = (resabs + g1.resabs) + g2.resabs;
+                        if (nd1) e1_ = abserr;
+                        if (nd2) e2_ = abserr;
+                        errsum = (errsum + e1_) + e2_;
+                        L.elist[0][lane] = e1_; L.elist[1][lane] = e2_;
+                        L.rlist[0][lane] = g1.result; L.rlist[1][lane] = g2.result;
+                        node_set(1, 0); node_set(2, 1);
+                        iord_set(1, 1); iord_set(2, 2);
+                        last = 2;
+                        neval_ = 42;
+                        const double dres = fabs(result);
+                        errbnd = fmax(epsabs, epsrel * dres);
+                        if (abserr <= 100. * epmach * resabs && abserr > errbnd) ier = 2;
+                        if (!(e1_ > e2_)) { iord_set(1, 2); iord_set(2, 1); }
+                        if (!(ier != 0 || abserr <= errbnd)) {
+                            ep.v1 = result;
+                            maxerr = iord_at(1);
+                            errmax = elist_at(maxerr);
+                            area = result;
+                            nrmax = 1;
+                            numrl2 = 1;
+                            erlarg = errsum;
+                            ertest = errbnd;
+                            abserr = oflow;
+                            ksgn = (dres >= (1. - 50. * epmach) * resabs) ? 1 : -1;
+                            last = 3;
+                            busy = true;
+                        }
+                    } else {
+                        result = g1.result;
+                        abserr = g1.abserr;
+                        const double defabs = g1.resabs;
+                        const double dres = fabs(result);
+                        errbnd = fmax(epsabs, epsrel * dres);
+                        last = 1;
+                        L.rlist[0][lane] = result;
+                        L.elist[0][lane] = abserr;
+                        node_set(1, 0);
+                        iord_set(1, 1);
+                        if (abserr <= 100. * epmach * defabs && abserr > errbnd) ier = 2;
+                        if (ier != 0 || (abserr <= errbnd && abserr != g1.resasc) || abserr == 0.) {
+                            neval_ = 21;
+                        } else {
+                            ep.v1 = result;
+                            errmax = abserr;
+                            maxerr = 1;
+                            area = result;
+                            errsum = abserr;
+                            abserr = oflow;
+                            nrmax = 1;
+                            numrl2 = 2;
+                            ksgn = (dres >= (1. - 50. * epmach) * defabs) ? 1 : -1;
+                            resabs = defabs;
+                            last = 2;
+                            busy = true;
+                        }
+                    }
                 }
-                for (int i = 1; i <= nint; i++) {
-                    if (nd[i]) L.elist[i - 1][lane] = abserr;
-                    errsum += L.elist[i - 1][lane];
-                }
-                last = nint;
-                neval_ = 21 * nint;
-                dres = fabs(result);
-                errbnd = fmax(epsabs, epsrel * dres);
-                if (abserr <= 100. * epmach * resabs && abserr > errbnd) ier = 2;
-                if (!(elist_at(iord_at(1)) > elist_at(iord_at(2)))) { const int t = iord_at(1); iord_set(1, iord_at(2)); iord_set(2, t); }
-                if (!(ier != 0 || abserr <= errbnd)) {
-                    rlist2[1] = result;
-                    maxerr = iord_at(1);
-                    errmax = elist_at(maxerr);
-                    area = result;
-                    nrmax = 1;
-                    numrl2 = 1;
-                    erlarg = errsum;
-                    ertest = errbnd;
-                    abserr = oflow;
-                    ksgn = (dres >= (1. - 50. * epmach) * resabs) ? 1 : -1;
-                    last = nint + 1;
-                    busy = true;
-                }
-            } else {
-                result = g1.result;
-                abserr = g1.abserr;
-                const double defabs = g1.resabs;
-                dres = fabs(result);
-                errbnd = fmax(epsabs, epsrel * dres);
-                last = 1;
-                L.rlist[0][lane] = result;
-                L.elist[0][lane] = abserr;
-                L.nodeid[0][lane] = 0;
-                iord_set(1, 1);
-                if (abserr <= 100. * epmach * defabs && abserr > errbnd) ier = 2;
-                if (ier != 0 || (abserr <= errbnd && abserr != g1.resasc) || abserr == 0.) {
-                    neval_ = 21;
-                } else {
-                    rlist2[1] = result;
-                    errmax = abserr;
-                    maxerr = 1;
-                    area = result;
-                    errsum = abserr;
-                    abserr = oflow;
-                    nrmax = 1;
-                    numrl2 = 2;
-                    ksgn = (dres >= (1. - 50. * epmach) * defabs) ? 1 : -1;
-                    resabs = defabs;
-                    last = 2;
-                    busy = true;
-                }
-            }
-        }
-        const bool entered_loop = busy;
-        auto node_of = [&](int slot) -> int { return (int)L.nodeid[slot - 1][lane]; };
-        auto width_of = [&](int slot) -> double { const int nn = node_of(slot); return fabs(L.tb[gi][nn] - L.ta[gi][nn]); };
-        auto level_of = [&](int slot) -> int { return (int)L.tdepth[gi][node_of(slot)]; };
-
-        // ---- main loop: bisect the interval with the largest error estimate ------------------------------------------------
-        while (__ballot(busy) != 0ULL) {
-            int tn = -1;
-            double erlast = 0.;
-            if (busy && last > ATTD_K) {   // the list would outgrow its LDS column: the group's ray goes to the general kernel
-                ovf = true;
-                busy = false;
-            }
-            // an overflow of one lane ends its whole group
-            {
-                const unsigned long long om = __ballot(ovf);
-                if ((om & gmask) != 0ULL) { ovf = true; busy = false; }
-            }
-            if (busy) {
-                tn = node_of(maxerr);
-                if (qagp) levcur = (int)L.tdepth[gi][tn] + 1;
-                erlast = errmax;
-            }
-            round(busy, tn, true);
-            if (busy) {
+                entered_loop = busy;
+                first = false;
+                DT_ADD(6, t_init);
+            } else if (busy) {
+                // ---- after a bisection --------------------------------------------------------------------------------------
+                DT_MARK(t_book);
                 do {
+                    const int c = c_mine;
+                    const double a1 = L.ta[gi][c], b1 = L.tb[gi][c], a2 = L.ta[gi][c + 1], b2 = L.tb[gi][c + 1];
                     neval_ += 42;
                     const double rmax = L.rlist[maxerr - 1][lane];
                     const double area12 = g1.result + g2.result;
@@ -505,30 +656,32 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
                     if (iroff2 >= 5) ierro = 3;
                     if (last == limit) ier = 1;
                     if (fmax(fabs(a1), fabs(b2)) <= (1. + 100. * epmach) * (fabs(a2) + 1000. * uflow)) ier = 4;
-                    const int c = (int)L.tchild[gi][tn];
                     if (g2.abserr > g1.abserr) {
-                        L.nodeid[maxerr - 1][lane] = (unsigned char)(c + 1);
-                        L.nodeid[last - 1][lane] = (unsigned char)c;
+                        node_set(maxerr, c + 1);
+                        node_set(last, c);
                         L.rlist[maxerr - 1][lane] = g2.result;
                         L.rlist[last - 1][lane] = g1.result;
                         L.elist[maxerr - 1][lane] = g2.abserr;
                         L.elist[last - 1][lane] = g1.abserr;
                     } else {
-                        L.nodeid[maxerr - 1][lane] = (unsigned char)c;
-                        L.nodeid[last - 1][lane] = (unsigned char)(c + 1);
+                        node_set(maxerr, c);
+                        node_set(last, c + 1);
                         L.rlist[maxerr - 1][lane] = g1.result;
                         L.rlist[last - 1][lane] = g2.result;
                         L.elist[maxerr - 1][lane] = g1.abserr;
                         L.elist[last - 1][lane] = g2.abserr;
                     }
+                    DT_ADD(4, t_book);
+                    DT_MARK(t_sort);
                     dense_sort_errors(last, maxerr, errmax, elist_at, iord_at, iord_set, nrmax);
+                    DT_ADD(5, t_sort);
                     if (errsum <= errbnd) { exit_code = 1; busy = false; break; }
                     if (ier != 0) { exit_code = 2; busy = false; break; }
                     if (!qagp && last == 2) {
-                        small = fabs(qb - qa) * 0.375;
+                        small = fabs(gz2m - gz1) * 0.375;
                         erlarg = errsum;
                         ertest = errbnd;
-                        rlist2[2] = area;
+                        ep.v2 = area;
                         break;  // continue
                     }
                     if (noext) break;  // continue
@@ -554,11 +707,31 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
                         }
                         if (cont) break;  // continue
                     }
+                    DT_MARK(t_eps);
                     numrl2++;
-                    rlist2[numrl2] = area;
+                    if (numrl2 + 2 > ATTD_E) { ovf = true; busy = false; break; }   // (the group's ray goes to the general kernel)
+                    double reseps = 0., abseps = 0.;
                     const bool skip_eps = qagp && numrl2 <= 2;
+                    // rlist2[numrl2] = area and DQELG, unrolled per table length (registers cannot be indexed by data)
+                    // (the empty asm keeps the compiler from merging the cases' stores into one store at a data-dependent index,
+                    // which would put the whole table into scratch)
+#define ATTD_EPS_CASE(NN)                                                                                             \
+    {                                                                                                                 \
+        double v_ = area;                                                                                             \
+        asm volatile("; epsilon table, %0 entries" : "+v"(v_) : "n"(NN));                                             \
+        eps_at<NN>(ep) = v_;                                                                                                  \
+        if (!skip_eps) dense_epsilon_static<NN>(ep, numrl2, reseps, abseps, r3a, r3b, r3c, nres);                      \
+    }
+                    if (numrl2 == 1) ATTD_EPS_CASE(1)
+                    else if (numrl2 == 2) ATTD_EPS_CASE(2)
+                    else if (numrl2 == 3) ATTD_EPS_CASE(3)
+                    else if (numrl2 == 4) ATTD_EPS_CASE(4)
+                    else if (numrl2 == 5) ATTD_EPS_CASE(5)
+                    else if (numrl2 == 6) ATTD_EPS_CASE(6)
+                    else ATTD_EPS_CASE(7)
+#undef ATTD_EPS_CASE
+                    DT_ADD(11, t_eps);
                     if (!skip_eps) {
-                        epsilon_extrap(numrl2, rlist2, reseps, abseps, res3la, nres);
                         ktmin++;
                         if (ktmin > 5 && abserr < 1e-3 * errsum) ier = 5;
                         if (abseps < abserr) {
@@ -584,13 +757,27 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
                     last++;
                     if (last > limit) busy = false;
                 }
+                DT_ADD(7, t_book);   // everything after the rules of this bisection (includes 4, 5 and 11)
             }
+            // ---- the next bisection: the interval with the largest error estimate ------------------------------------------
+            DT_MARK(t_top);
+            if (busy && last > ATTD_K) {   // the list would outgrow its LDS column: the group's ray goes to the general kernel
+                ovf = true;
+                busy = false;
+            }
+            if ((__ballot(ovf) & gmask) != 0ULL) { ovf = true; busy = false; }   // an overflow of one lane ends its whole group
+            if (__ballot(busy) == 0ULL) break;
+            if (busy) {
+                tn = node_of(maxerr);
+                if (qagp) levcur = (int)L.tdepth[gi][tn] + 1;
+                erlast = errmax;
+            }
+            pend = busy;
+            two = true;
+            DT_ADD(3, t_top);
         }
-        // an overflow in the last round of a group
-        {
-            const unsigned long long om = __ballot(ovf);
-            if ((om & gmask) != 0ULL) ovf = true;
-        }
+        DT_MARK(t_fin);
+        nxt = load_rays(pair + pair_stride);   // in flight while this pair's results are finished and stored
         if (valid && entered_loop && !ovf) {
             if (last > limit) last = limit;
             bool sum_list = (exit_code == 1);
@@ -622,7 +809,7 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
             }
             if (!qagp) neval_ = 42 * last - 21;
         }
-        if (qagp) result *= sign;
+        if (qagp && gz1 > gz2m) result *= -1.;
         if (ray_ok && !ovf) {
             const long item = gray * n_freq + jf;
             att[item] = valid ? det_exp(-1 * result) : NAN;
@@ -634,7 +821,15 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
             overflow_list[slot] = (int)gray;
         }
         wave_sync();   // the next pair's roots overwrite the tree
+        DT_ADD(8, t_fin);
     }
+#ifdef NRHIP_ATT_TIMING
+    if (lane == 0) {
+        for (int i = 0; i < 12; i++)
+            if (i != 10) atomicAdd(&g_att_clk[i], tacc[i]);
+        atomicAdd(&g_att_clk[10], __builtin_amdgcn_s_memtime() - t_kernel);
+    }
+#endif
     if (eval_counter) {
         for (int off = 32; off > 0; off >>= 1) my_evals += __shfl_xor(my_evals, off);
         if (lane == 0) atomicAdd(eval_counter, my_evals);

@@ -83,6 +83,53 @@ __device__ __forceinline__ double det_exp_inrange(double x)
     return ldexp(p, (int)kd);
 }
 
+// two independent det_exp_inrange evaluations with their Horner chains interleaved instruction by instruction (each chain is
+// 16 dependent FP64 operations; a wave that alternates between two chains does not wait for its own results).  Same operations
+// per value, hence the same bits as det_exp_inrange.  The ten steps with coefficients in scalar registers are ONE asm block: the
+// compiler pads every asm statement with a wait state, and it would copy the coefficients into vector registers otherwise.
+__device__ __forceinline__ void det_exp_inrange2(double xa, double xb, double& ea, double& eb)
+{
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00;
+    const double ka = rint(xa * invln2), kb = rint(xb * invln2);
+    double ra = __builtin_fma(-ka, ln2HI, xa), rb = __builtin_fma(-kb, ln2HI, xb);
+    ra = __builtin_fma(-ka, ln2LO, ra);
+    rb = __builtin_fma(-kb, ln2LO, rb);
+    double pa, pb;
+    asm("v_fma_f64 %0, %4, %2, %5\n\t"
+        "v_fma_f64 %1, %4, %3, %5\n\t"
+        "v_fma_f64 %0, %0, %2, %6\n\t"
+        "v_fma_f64 %1, %1, %3, %6\n\t"
+        "v_fma_f64 %0, %0, %2, %7\n\t"
+        "v_fma_f64 %1, %1, %3, %7\n\t"
+        "v_fma_f64 %0, %0, %2, %8\n\t"
+        "v_fma_f64 %1, %1, %3, %8\n\t"
+        "v_fma_f64 %0, %0, %2, %9\n\t"
+        "v_fma_f64 %1, %1, %3, %9\n\t"
+        "v_fma_f64 %0, %0, %2, %10\n\t"
+        "v_fma_f64 %1, %1, %3, %10\n\t"
+        "v_fma_f64 %0, %0, %2, %11\n\t"
+        "v_fma_f64 %1, %1, %3, %11\n\t"
+        "v_fma_f64 %0, %0, %2, %12\n\t"
+        "v_fma_f64 %1, %1, %3, %12\n\t"
+        "v_fma_f64 %0, %0, %2, %13\n\t"
+        "v_fma_f64 %1, %1, %3, %13\n\t"
+        "v_fma_f64 %0, %0, %2, %14\n\t"
+        "v_fma_f64 %1, %1, %3, %14"
+        : "=&v"(pa), "=&v"(pb)
+        : "v"(ra), "v"(rb), "v"(1.6059043836821613e-10), "v"(2.08767569878681e-09), "s"(2.505210838544172e-08),
+          "s"(2.755731922398589e-07), "s"(2.7557319223985893e-06), "s"(2.48015873015873e-05), "s"(0.0001984126984126984),
+          "s"(0.001388888888888889), "s"(0.008333333333333333), "s"(0.041666666666666664), "s"(0.16666666666666666));
+    pa = __builtin_fma(pa, ra, 0.5);
+    pb = __builtin_fma(pb, rb, 0.5);
+    pa = __builtin_fma(pa, ra, 1.0);
+    pb = __builtin_fma(pb, rb, 1.0);
+    pa = __builtin_fma(pa, ra, 1.0);
+    pb = __builtin_fma(pb, rb, 1.0);
+    ea = ldexp(pa, (int)ka);
+    eb = ldexp(pb, (int)kb);
+}
+
 __device__ inline double det_log(double x)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;

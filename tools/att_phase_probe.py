@@ -25,6 +25,16 @@ print('attenuation stage ms', d['config']['stage_ms_avg_per_step']['attenuation'
 h = ctypes.CDLL(os.path.join(ROOT, 'nuradiomc_amd', 'lib', 'libnrhip_at.so'))
 out = (ctypes.c_ulonglong * 12)()
 assert h.nrhip_debug_att_clocks(out, 0) == 0
+if out[10] and not os.environ.get('NRHIP_ATT_LEGACY'):   # attenuation_dense_kernel's phases
+    tot = float(out[10])
+    names = ['round: ballots, tree children', 'round: node records', 'round: rules', 'bisection set-up', 'list updates before the sort',
+             'sort_errors', 'first estimate: bookkeeping', 'after the rules of a bisection (incl. lists, sort, extrapolation)',
+             'final result, stores', 'ray parameters, tree roots']
+    for i, nm in enumerate(names):
+        print('%-70s %5.1f %%' % (nm, 100 * out[i] / tot))
+    print('%-70s %5.1f %%' % ('   of which the epsilon table (copy to LDS, DQELG, copy back)', 100 * out[11] / tot))
+    print('%-70s %5.1f %%' % ('unaccounted', 100 * (tot - out[0] - out[1] - out[2] - out[3] - out[6] - out[7] - out[8] - out[9]) / tot))
+    raise SystemExit(0)
 tot = float(out[2])
 print('node records                      %5.1f %%' % (100 * out[0] / tot))
 print('rules (per-lane finish)           %5.1f %%' % (100 * out[1] / tot))
