@@ -131,6 +131,20 @@ def make_workload(config=2, n=1000000, seed=10, flavour='had'):
     return wl
 
 
+def arz_library():
+    """the small shower library of the reference's layout (charge-excess profiles of EM / HAD showers) held as test data"""
+    g = np.load(os.path.join(GOLDEN, 'ref_arz.npz'))
+    dep = g['lib_depth']
+    return {'EM': {1e18: {'depth': dep, 'charge_excess': list(g['lib_EM_1e18'])}, 1e16: {'depth': dep, 'charge_excess': list(g['lib_EM_1e16'])}},
+            'HAD': {1e18: {'depth': dep, 'charge_excess': list(g['lib_HAD_1e18'])}, 1e17: {'depth': dep, 'charge_excess': list(g['lib_HAD_1e17'])}}}
+
+
+def birefringence_splines():
+    """the three depth splines of the reference's model file birefringence_greenland_A.npy (held as test data)"""
+    b = np.load(os.path.join(GOLDEN, 'ref_birefringence.npz'))
+    return [(b['tck_greenland_A_%d_t' % j], b['tck_greenland_A_%d_c' % j]) for j in range(3)]
+
+
 def build_array(ctx, wl):
     """Station (config 2) or StationArray (configs 3-5) of the workload on this context"""
     import nuradiomc_amd
@@ -139,14 +153,8 @@ def build_array(ctx, wl):
                                cable_delay=wl['cable_delay'], n_samples=wl['N'], sampling_rate=wl['fs'], n_freq=25)
     if wl['config'] == 4:
         from nuradiomc_amd import arz as arz_mod
-        b = np.load(os.path.join(GOLDEN, 'ref_birefringence.npz'))   # the reference's model file birefringence_greenland_A.npy
-        st.set_birefringence([(b['tck_greenland_A_%d_t' % j], b['tck_greenland_A_%d_c' % j]) for j in range(3)],
-                             angle_to_iceflow=None)
-        g = np.load(os.path.join(GOLDEN, 'ref_arz.npz'))             # small shower library of the reference's layout
-        dep = g['lib_depth']
-        lib = {'EM': {1e18: {'depth': dep, 'charge_excess': list(g['lib_EM_1e18'])}, 1e16: {'depth': dep, 'charge_excess': list(g['lib_EM_1e16'])}},
-               'HAD': {1e18: {'depth': dep, 'charge_excess': list(g['lib_HAD_1e18'])}, 1e17: {'depth': dep, 'charge_excess': list(g['lib_HAD_1e17'])}}}
-        st.set_arz(arz_mod.ARZ(seed=1235, library=lib))
+        st.set_birefringence(birefringence_splines(), angle_to_iceflow=None)
+        st.set_arz(arz_mod.ARZ(seed=1235, library=arz_library()))
     if wl['centres'] is None:
         return st
     return nuradiomc_amd.StationArray(st, wl['centres'], relative_position=wl['rel_pos'])
@@ -199,13 +207,21 @@ def _oracle_chunk(args):
         if arr['trigger'] == 'high_low':
             trig = dict(trigger='high_low', n_coincidences=arr['n_coincidences'], threshold_high=3 * vrms, threshold_low=-3 * vrms,
                         high_low_window=5., coinc_window=arr['coinc_window'])
+        gen_kw = {}
+        stations = np.arange(len(arr['centres']))
+        if arr.get('general'):   # config 4: ARZ2020 emission (the GPU run's profile numbers) + birefringent propagation; ONE
+            # station per job (a central event group costs the oracle minutes per station: 48 rays x 0.2 s of numpy each)
+            from oracle import arz_oracle
+            gen_kw = dict(model='ARZ2020', arz=arz_oracle.ARZ(arz_library(), seed=0), birefringence=(birefringence_splines(), None))
+            stations = np.array([arr['station']])
         for g in range(lo, hi):
             a, b = np.searchsorted(grp, g), np.searchsorted(grp, g + 1)
             sh = [dict(vertex=ev['vertex'][i], zenith=ev['zenith'][i], azimuth=ev['azimuth'][i], energy=ev['energy'][i],
-                       shower_type='HAD' if ev['shower_type'][i] == 0 else 'EM', k_L=ev['k_L'][i]) for i in range(a, b)]
-            res = so.simulate_event_group_array(sh, arr['centres'], arr['rel_pos'], arr['ice'], vrms, vrms_e, station_kw=skw,
+                       shower_type='HAD' if ev['shower_type'][i] == 0 else 'EM', k_L=ev['k_L'][i], vertex_time=0.,
+                       iN=int(ev['iN'][i]) if 'iN' in ev else None) for i in range(a, b)]
+            res = so.simulate_event_group_array(sh, arr['centres'][stations], arr['rel_pos'], arr['ice'], vrms, vrms_e, station_kw=skw,
                                                 att_model=arr['att_model'], n_freq=25, distance_cut_coefficients=DCUT,
-                                                trigger=trig)
+                                                trigger=trig, **gen_kw)
             out[g - lo] = any(o['triggered'] for o in res)
         return lo, out
     st = so.Station(CHANNELS, n_samples=N_SAMPLES, fs=FS)
@@ -223,25 +239,36 @@ def _oracle_chunk(args):
     return lo, out
 
 
-def cpu_baseline(wl, budget_s, n_max, cores=None):
+def cpu_baseline(wl, budget_s, n_max, cores=None, arz_iN=None):
     """The oracle (C ray tracer / attenuation + numpy spectral chain) on all host cores over the first event groups of the same
     list; processes chunks until `budget_s` is spent.  Returns (json dict, number of groups done, their triggered flags)."""
     import multiprocessing as mp
     cores = cores or usable_cores()
     ev, grp = wl['events'], wl['events']['group']
+    if arz_iN is not None:
+        ev = dict(ev, iN=np.asarray(arz_iN))
     arr = None
     if wl['centres'] is not None:   # arrays: every group visits every station (the distance cut drops most of them quickly)
         arr = dict(centres=wl['centres'], rel_pos=wl['rel_pos'], antenna=wl['antenna'], orientation=wl['orientation'],
                    cable_delay=wl['cable_delay'], N=wl['N'], fs=wl['fs'], ice=wl['ice'], att_model=wl['att_model'],
                    trigger=wl['sim_kw'].get('trigger', 'simple'), n_coincidences=wl['sim_kw'].get('n_coincidences', 1),
-                   coinc_window=wl['sim_kw'].get('coinc_window', 200.))
+                   coinc_window=wl['sim_kw'].get('coinc_window', 200.), general=wl['config'] == 4)
     chunk = 125 if arr is None else 4
+    n_near = 2   # config 4: the stations nearest to the group's vertex are the jobs (station-events, not whole groups)
 
-    def job(lo):
+    def job(lo, station=None):
         hi = min(lo + chunk, n_max)
         a, b = np.searchsorted(grp, lo), np.searchsorted(grp, hi)
-        return ({k: v[a:b] for k, v in ev.items()}, lo, hi, wl['flavour'], arr)
-    jobs = (job(lo) for lo in range(0, n_max, chunk))
+        return ({k: v[a:b] for k, v in ev.items()}, lo, hi, wl['flavour'], arr if station is None else dict(arr, station=station))
+    if wl['config'] == 4:
+        chunk = 1
+        first = np.searchsorted(grp, np.arange(n_max))
+        dist = np.linalg.norm(ev['vertex'][first][:, None, :2] - wl['centres'][None, :, :2], axis=2)
+        near = np.argsort(dist, axis=1)[:, :n_near]
+        pair_list = [(g, int(near[g, k])) for g in range(n_max) for k in range(n_near)]
+        jobs = (job(g, i) for g, i in pair_list)
+    else:
+        jobs = (job(lo) for lo in range(0, n_max, chunk))
     done = {}
     os.environ.setdefault('OMP_NUM_THREADS', '1')
     os.environ.setdefault('OPENBLAS_NUM_THREADS', '1')
@@ -251,14 +278,26 @@ def cpu_baseline(wl, budget_s, n_max, cores=None):
         t0 = time.time()
         it = pool.imap(_oracle_chunk, jobs)
         n_sub = 0
+        done_pairs = []
         for lo, out in it:
             done[lo] = out
+            done_pairs.append(int(out[0]))
             n_sub += 1
             if time.time() - t0 > budget_s:
                 break
         dt = time.time() - t0
         pool.terminate()
     # only the contiguous prefix counts (imap yields in order)
+    if wl['config'] == 4:
+        # station-events: value = pairs / s / n_stations is what a whole-array loop would reach if every station cost like the
+        # near ones (it is a lower bound on the oracle's rate: far stations are cut early)
+        flags = np.array([done_pairs[k] for k in range(len(done_pairs))], np.uint8)
+        pairs = pair_list[:len(flags)]
+        return dict(value=len(flags) / dt / len(wl['centres']), unit="events/s", cores=cores, kind="port",
+                    sample="%d (event group, station) pairs -- the %d stations nearest to each of the first %d event groups of the same "
+                           "list -- in %.1f s on %d worker processes (oracle: C ray tracer + QUADPACK attenuation, C ARZ integral, numpy "
+                           "birefringence and spectral chain); value = pairs / s / %d stations; %d station-events triggered"
+                           % (len(flags), n_near, (len(flags) + n_near - 1) // n_near, dt, cores, len(wl['centres']), int(flags.sum()))), pairs, flags
     flags = np.concatenate([done[lo] for lo in sorted(done)]) if done else np.zeros(0, np.uint8)
     n_done = len(flags)
     return dict(value=n_done / dt, unit="events/s", cores=cores, kind="port",
@@ -311,6 +350,8 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=25., help='seconds of CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--device', type=int, default=None, help='GPU index of this rank (default: LOCAL_RANK)')
+    ap.add_argument('--allow-tcp', action='store_true', help='if RCCL does not come up on every rank: run the collectives over the TCP '
+                    'star instead of exiting non-zero (single-GPU boxes: tools/two_ranks_one_gpu.sh)')
     args = ap.parse_args()
     cfgno = args.config
     if args.events is None:
@@ -330,15 +371,16 @@ def main():
         wl = make_workload(cfgno, args.events, 10 + rank, args.flavour)
         g0, g1 = 0, args.events
     ctx = nuradiomc_amd.Context(wl['ice'], wl['att_model'], device=local_rank if args.device is None else args.device)
-    comm = nrcomm.Comm(ctx, rank, world)
+    comm = nrcomm.Comm(ctx, rank, world, allow_tcp=True if args.allow_tcp else None)
     det = build_array(ctx, wl)
     is_array = wl['centres'] is not None
     st = det.station if is_array else det
     d = upload_events(ctx, wl, (g0, g1))
     n, n_groups = d['n'], d['n_groups']
     dev_kw = dict(d_max_distance=d['md'], n_groups=n_groups, d_group_begin=d['gb'], **wl['sim_kw'])
+    arz_iN = None
     if cfgno == 4:   # the profile numbers are shower parameters of the input list (drawn once, resident like k_L)
-        iN = st._arz.draw_profile_numbers(d['host'][3], ['HAD' if c == 0 else 'EM' for c in d['host'][4]])
+        arz_iN = iN = st._arz.draw_profile_numbers(d['host'][3], ['HAD' if c == 0 else 'EM' for c in d['host'][4]])
         dev_kw['arz_rows'] = st._arz_shower_profiles(d['host'][3], d['host'][4], iN)
 
     def step():
@@ -464,12 +506,28 @@ def main():
                                     "algorithmic_flops_per_launch": stats['n_integrand_evals'] * flop_per_eval,
                                     "hbm_view_GBs": achieved})
         out["cpu_baseline"] = None
-        if world == 1 and cfgno in (2, 3, 5) and not args.no_cpu_baseline:
-            base, n_done, flags = cpu_baseline(wl, args.cpu_budget, min(n_groups, 200000))
+        if world == 1 and not args.no_cpu_baseline and cfgno == 4:
+            # the oracle needs minutes per central event group here: the check is per (event group, station) -- the per-station masks
+            # of one more GPU pass against the oracle's single-station runs
+            n_st = len(wl['centres'])
+            d_st = ctx.malloc(n_st * n_groups)
+            det.simulate_events_dev(n, *d['in'], d['trig'], d_station_triggered=d_st, want_stats=True, **dev_kw)
+            st_mask = np.zeros(n_st * n_groups, np.uint8)
+            ctx.to_host(st_mask, d_st)
+            ctx.free(d_st)
+            st_mask = st_mask.reshape(n_st, n_groups)
+            base, pairs, flags = cpu_baseline(wl, args.cpu_budget, min(n_groups, 2000), arz_iN=arz_iN)
+            got = np.array([st_mask[i, g] for g, i in pairs], np.uint8)
+            mism, n_done = int(np.sum(got != flags)), len(pairs)
+            base['parity_check'] = ("GPU per-station trigger flags == oracle on the %d sampled (event group, station) pairs (%d of them "
+                                    "triggered): %d mismatches" % (n_done, int(flags.sum()), mism))
+        elif world == 1 and not args.no_cpu_baseline:
+            base, n_done, flags = cpu_baseline(wl, args.cpu_budget, min(n_groups, 200000), arz_iN=arz_iN)
             host_mask = np.zeros(n_groups, np.uint8)
             ctx.to_host(host_mask, d['trig'])
             mism = int(np.sum(host_mask[:n_done] != flags))
             base['parity_check'] = "GPU trigger mask == oracle on the %d sampled event groups: %d mismatches" % (n_done, mism)
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = base
             if mism:
                 print(json.dumps(out, default=_json_default))

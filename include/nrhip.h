@@ -321,8 +321,9 @@ typedef struct {
        select_only != 0: stop after ray tracing and the delta_C cut; tables "pair_n_sol", "slot_*", "slot_keep" and
        "shower_first_channel" (int32 [n_showers]: first channel of this station with a kept ray, -1 = none) are fetchable,
        `triggered` is zeroed, stats carries n_pairs / n_rays.
-       reuse_ray_tables != 0: skip ray tracing and the cut -- the tables of the previous call with the same vertex pointer,
-       shower count, station position and delta_C_cut are used (anything else fails). */
+       reuse_ray_tables != 0: skip ray tracing and the cut -- the tables of the previous call with the same vertex and
+       max_distance pointers, shower and group counts, station position, delta_C_cut and reflection set-up are used (anything
+       else fails).  A pointer identifies a list only while its buffer lives: do not free and re-upload between the phases. */
     int32_t select_only;
     int32_t reuse_ray_tables;
     /* != 0: `triggered` is not zeroed first, triggers are OR-ed into it -- the event-group mask of an array simulated station
@@ -394,8 +395,10 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* desc, nrhip_s
 void nrhip_station_destroy(nrhip_station* st);
 
 /* The per-call tables of the last nrhip_simulate_events call (ray records, per-ray tables, traces: what nrhip_sim_fetch reads)
- * stay resident in the station object and are reused by the next call.  With many stations alive on one GPU (an array
- * simulated station by station) release them when a station is done: returns the number of bytes given back. */
+ * stay resident in the station object and are reused by the next call, and so does the cache of per-length tables (one row
+ * of about 1 MB or more per distinct common-trace length the station has met; it only grows).  With many stations alive on one
+ * GPU (an array simulated station by station), or after a long survey with many distinct lengths, release them: returns the
+ * number of bytes given back (workspace + table cache; the next call rebuilds the table rows it needs). */
 int64_t nrhip_station_release_workspace(nrhip_station* st);
 
 /* Arrays of identical stations (BASELINE configs 3-5): move the station object to the next station's antenna positions

@@ -195,16 +195,22 @@ class _Star:
         self.peers, self.sock = {}, None
 
 
+class CommError(RuntimeError):
+    pass
+
+
 class Comm:
     """RCCL communicator of one process (one GPU) over nrhip_comm_*; world_size 1 needs no RCCL and every call is local.
 
     With more than one rank the processes first meet on a TCP star through rank 0 (communicator id, then a vote): only if RCCL
     loads on EVERY rank is the communicator created, and only if it came up on every rank is it used (`mode == 'rccl'`).
-    Otherwise (`mode == 'tcp'`, said loudly on stderr and in bench.py's JSON) the few scalars and the masks travel over the star
-    -- a sharded run then still completes instead of hanging in a half-built communicator.  `backend='tcp'` asks for that
-    directly (hosts without RCCL, CPU tests of the sharding logic)."""
+    Otherwise every rank raises CommError (a run that was asked for RCCL must not print a line that never touched xGMI) -- unless
+    `allow_tcp=True` / NRHIP_ALLOW_TCP=1: then (`mode == 'tcp'`, said loudly on stderr and in bench.py's JSON) the few scalars
+    and the masks travel over the star, so that a sharded run on a node without a working RCCL completes instead of hanging in
+    a half-built communicator.  `backend='tcp'` asks for the star directly (hosts without RCCL, CPU tests of the sharding
+    logic)."""
 
-    def __init__(self, ctx, rank=None, world_size=None, addr=None, port=None, force_rccl=False, backend=None):
+    def __init__(self, ctx, rank=None, world_size=None, addr=None, port=None, force_rccl=False, backend=None, allow_tcp=None):
         r, _, w = env_rank()
         self.ctx = ctx
         self.rank = r if rank is None else int(rank)
@@ -214,6 +220,8 @@ class Comm:
         self._star = None
         self.mode = 'local'
         backend = backend or os.environ.get('NRHIP_COMM_BACKEND', 'rccl')
+        if allow_tcp is None:
+            allow_tcp = os.environ.get('NRHIP_ALLOW_TCP', '0') not in ('', '0')
         if self.world_size == 1 and force_rccl:   # a one-rank communicator (tests of the binding on a single GPU)
             uid = (ctypes.c_uint8 * ID_BYTES)()
             L.check(self._lib.nrhip_comm_get_unique_id(uid))
@@ -238,10 +246,16 @@ class Comm:
                     self.mode = 'rccl'
                 elif up:
                     self._lib.nrhip_comm_destroy(h)
-            if self.mode == 'tcp' and backend == 'rccl' and self.rank == 0:
-                import sys
-                print("nuradiomc_amd.comm: RCCL did not come up on every rank -- collectives go over the TCP star (%s)"
-                      % (self._lib.nrhip_last_error().decode() if self._lib is not None else 'no device context'), file=sys.stderr)
+            if self.mode == 'tcp' and backend == 'rccl':
+                why = self._lib.nrhip_last_error().decode() if self._lib is not None else 'no device context'
+                if not allow_tcp:   # every rank takes this branch (the votes are the same everywhere): all exit non-zero
+                    self.close()
+                    raise CommError("nuradiomc_amd.comm: RCCL did not come up on every rank (%s); pass allow_tcp=True / "
+                                    "NRHIP_ALLOW_TCP=1 (bench.py --allow-tcp) to run the collectives over the TCP star instead" % why)
+                if self.rank == 0:
+                    import sys
+                    print("nuradiomc_amd.comm: RCCL did not come up on every rank -- collectives go over the TCP star (%s)" % why,
+                          file=sys.stderr)
 
     def barrier(self):
         if self.ctx is not None and self._h is None:
@@ -253,7 +267,13 @@ class Comm:
 
     def allgather_masks(self, d_local, n_local, n_total):
         """All-gather the per-rank DEVICE uint8 masks of a list of n_total events sharded with shard_range: returns the full host
-        mask [n_total] (same on every rank).  The one collective of the path (padded to the largest shard)."""
+        mask [n_total] (same on every rank).  The one collective of the path (padded to the largest shard).  Lists dealt with
+        shard_chunks (round-robin chunks) are NOT contiguous: gather those per chunk or scatter by index on the host."""
+        W = self.world_size
+        sizes = [shard_range(n_total, k, W)[1] - shard_range(n_total, k, W)[0] for k in range(W)]
+        if n_local != sizes[self.rank] or sum(sizes) != n_total:
+            raise ValueError("allgather_masks: rank %d holds %d events, shard_range(%d, %d, %d) has %d -- the gather is defined for "
+                             "contiguous shard_range shards only" % (self.rank, n_local, n_total, self.rank, W, sizes[self.rank]))
         if self._h is None:
             if isinstance(d_local, np.ndarray):   # a host mask (tcp backend without a device context)
                 out = np.ascontiguousarray(d_local[:n_local], np.uint8)
@@ -263,8 +283,6 @@ class Comm:
             if self._star is None:
                 return out
             return np.concatenate([np.frombuffer(q, np.uint8) for q in self._star.allgather(out.tobytes())])
-        W = self.world_size
-        sizes = [shard_range(n_total, k, W)[1] - shard_range(n_total, k, W)[0] for k in range(W)]
         pad = max(sizes)
         d_send = self.ctx.malloc(max(pad, 1))
         d_recv = self.ctx.malloc(max(W * pad, 1))

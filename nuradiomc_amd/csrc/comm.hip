@@ -99,14 +99,24 @@ int nrhip_comm_create(nrhip_ctx* ctx, const uint8_t id[NRHIP_COMM_ID_BYTES], int
     if (!ctx || !id || !out) return nrhip_fail_msg("nrhip_comm_create: NULL argument");
     if (world_size < 1 || rank < 0 || rank >= world_size) return nrhip_fail_msg("nrhip_comm_create: bad rank / world size");
     if (load_rccl()) return -1;
+    // everything that can fail on this rank alone comes BEFORE the collective ncclCommInitRank (a rank that drops out inside
+    // it would leave the others blocked there); callers vote on nrhip_comm_get_unique_id (library present) and should set
+    // NCCL_* time-outs for what remains (a peer dying inside the init)
     HIPCHK(hipSetDevice(ctx->device));
+    int64_t* token = nullptr;
+    HIPCHK(hipMalloc((void**)&token, sizeof(int64_t)));
+    if (hipMemset(token, 0, sizeof(int64_t)) != hipSuccess) {
+        (void)hipFree(token);
+        return nrhip_fail_msg("nrhip_comm_create: hipMemset of the barrier word failed");
+    }
     ncclUniqueId u;
     memcpy(u.internal, id, NRHIP_COMM_ID_BYTES);
     ncclComm_t c;
-    RCCLCHK(g_rccl.CommInitRank(&c, world_size, u, rank));
-    int64_t* token = nullptr;
-    HIPCHK(hipMalloc((void**)&token, sizeof(int64_t)));
-    HIPCHK(hipMemset(token, 0, sizeof(int64_t)));
+    const ncclResult_t r = g_rccl.CommInitRank(&c, world_size, u, rank);
+    if (r != ncclSuccess) {
+        (void)hipFree(token);
+        return rccl_fail("ncclCommInitRank", r);
+    }
     *out = new nrhip_comm{ctx, c, rank, world_size, token};
     return 0;
 }

@@ -59,6 +59,7 @@ struct nrhip_station {
     DevArray d_filter_pool, d_ch_fset, d_filtersets;  // tabulated responses, per-channel chain index, the chains in HBM
     std::vector<double> h_pos, h_cable;
     DevArray d_pos, d_cable, d_model, d_rot, d_rot_inv, d_fc, d_lnf, d_invl, d_fpow, d_fpow_f, d_seg, d_attbin, d_anttabs, d_anttab_index;
+    DevArray d_nplan;   // tables of the N / 2-point Bluestein transforms (N / 2 not a power of two)
     std::vector<DevArray> d_tabdata;  // arrays of the tabulated antenna patterns
     // general emission / propagation path (nrhip_station_set_arz / _set_birefringence / _set_shower_profiles)
     DevArray d_arz_depth, d_arz_ce, d_arz_par, d_bire_knots, d_bire_coeffs, d_shower_profile, d_shower_rescale;
@@ -105,9 +106,17 @@ struct nrhip_station {
     std::map<std::string, size_t> ws_bytes;  // valid bytes of the last chunk
     std::vector<int> h_lengths;              // distinct trace lengths of the last chunk
     // what the ray tables in the workspace belong to (nrhip_sim_config.reuse_ray_tables)
+    // (pointers only identify a buffer as long as it has not been freed and re-allocated: the key below also holds the sizes, the
+    // cuts, the reflection set-up and the station's position generation, and select_only calls are the only producers)
     int64_t rays_n_showers = -1;
+    int64_t rays_n_groups = -1;
     double rays_delta_C = 0.;
     const double* rays_vertex = nullptr;
+    const double* rays_max_distance = nullptr;
+    int rays_n_reflections = 0;
+    double rays_z_reflection = 0.;
+    long rays_generation = -1;    // `generation` at the time the tables were made
+    long generation = 0;          // bumped by every setter that changes the geometry (nrhip_station_set_positions)
     hipEvent_t evt[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevArray& buf(const std::string& name) { return ws[name]; }
 };

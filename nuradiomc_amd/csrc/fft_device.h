@@ -414,4 +414,55 @@ __device__ inline void czt_convolve(double2* x, int log2m, const double2* __rest
     fft_dit(x, log2m, tw, true);
 }
 
+// ---- transforms of length nh = N / 2 for ANY even trace length N (a station constant) -------------------------------------------
+// The reference only asks for an even number of samples (NuRadioReco/framework/base_trace.py:117-121); its own example runs
+// N = 1280.  nh a power of two: the radix-2 code above (result in bit-reversed order).  Otherwise Bluestein's algorithm on the
+// next power of two P >= 2 nh - 1 with the two spectrum tables of the chirp kernel built once per station (result in natural
+// order).  x must have room for max(nh, P) complex numbers.
+struct NPlan {
+    int nh, log2nh, log2p;   // log2nh >= 0: power of two; else log2p = log2 P
+    const double2* wN;       // [nh + 1] exp(-2 pi i k / N)
+    const double2* cw;       // [nh]     exp(-i pi n^2 / nh)
+    const double2* Bf;       // [P] spectrum (bit-reversed) of the forward chirp kernel
+    const double2* Bi;       // [P] of the inverse one
+};
+__host__ __device__ inline int nplan_points(const NPlan& p) { return p.log2nh >= 0 ? p.nh : (1 << p.log2p); }
+// exp(-2 pi i k / N), k <= nh
+__device__ __forceinline__ double2 nplan_w(const NPlan& p, int k, const double2* __restrict__ tw)
+{
+    if (p.log2nh >= 0) return (k == p.nh) ? make_double2(-1., 0.) : tw[k * (FFT_MAX / (2 * p.nh))];
+    return p.wN[k];
+}
+// where element j of the transform sits after nplan_fft
+__device__ __forceinline__ int nplan_idx(const NPlan& p, int j) { return p.log2nh >= 0 ? bitrev(j, p.log2nh) : j; }
+// in-place DFT (inverse: conjugate kernel, unscaled) of x[0 .. nh) given in natural order; ends with a barrier
+__device__ inline void nplan_fft(double2* x, const NPlan& p, const double2* __restrict__ tw, bool inverse)
+{
+    if (p.log2nh >= 0) {
+        fft_dif(x, p.log2nh, tw, inverse);
+        return;
+    }
+    const int P = 1 << p.log2p, nh = p.nh;
+    for (int j = threadIdx.x; j < P; j += blockDim.x) {
+        double2 v = make_double2(0., 0.);
+        if (j < nh) {
+            const double2 c = p.cw[j];
+            v = cmul(x[j], inverse ? cconj(c) : c);
+        }
+        x[j] = v;
+    }
+    __syncthreads();
+    fft_dif(x, p.log2p, tw, false);
+    const double2* __restrict__ B = inverse ? p.Bi : p.Bf;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) x[i] = cmul(x[i], B[i]);
+    __syncthreads();
+    fft_dit(x, p.log2p, tw, true);
+    const double sc = 1.0 / P;
+    for (int k = threadIdx.x; k < nh; k += blockDim.x) {
+        const double2 c = p.cw[k];
+        x[k] = cscale(cmul(x[k], inverse ? cconj(c) : c), sc);
+    }
+    __syncthreads();
+}
+
 }  // namespace nrhip

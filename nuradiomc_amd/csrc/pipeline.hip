@@ -87,9 +87,12 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     if (d->n_channels <= 0) return nrhip_fail_msg("nrhip_station_create: station has no channels");
     if (d->n_samples <= 0 || d->n_samples % 2 != 0)
         return nrhip_fail_msg("nrhip_station_create: traces must have an even number of samples");
+    // any even length like the reference (NuRadioReco/framework/base_trace.py:117-121); the in-LDS transforms hold 16 .. 8192 samples
     int nh = d->n_samples / 2;
-    if ((nh & (nh - 1)) != 0 || nh < 8 || nh > FFT_MAX / 2)
-        return nrhip_fail_msg("nrhip_station_create: n_samples must be a power of two between 16 and 8192");
+    if (nh < 8 || nh > FFT_MAX / 2)
+        return nrhip_fail_msg("nrhip_station_create: n_samples must be an even number between 16 and 8192");
+    if ((nh & (nh - 1)) != 0 && nh > FFT_MAX / 4)   // Bluestein needs 2 nh - 1 points of the 64 KB the ray kernels have
+        return nrhip_fail_msg("nrhip_station_create: n_samples above 4096 must be a power of two (8192)");
     if (d->n_att_freq <= 0 || d->n_att_freq > NRHIP_MAX_NFC) return nrhip_fail_msg("nrhip_station_create: bad n_att_freq");
     HIPCHK(hipSetDevice(ctx->device));
     if (ensure_twiddle(ctx)) return -1;
@@ -251,6 +254,31 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     v.fpow = s->d_fpow.as<double>();
     v.fpow_f = s->d_fpow_f.as<float>();
     v.seg = s->d_seg.as<unsigned char>();
+    // the N / 2-point transforms of the ray stages: radix 2, or Bluestein tables for any other length
+    v.np.nh = nh;
+    v.np.log2nh = -1;
+    v.np.log2p = 0;
+    v.np.wN = v.np.cw = v.np.Bf = v.np.Bi = nullptr;
+    for (int l = 0; l <= FFT_LOG2_MAX; l++)
+        if ((1 << l) == nh) v.np.log2nh = l;
+    if (v.np.log2nh < 0) {
+        while ((1 << v.np.log2p) < 2 * nh - 1) v.np.log2p++;
+        const size_t P = (size_t)1 << v.np.log2p;
+        if (s->d_nplan.reserve(sizeof(double2) * (2 * P + 2 * (size_t)nh + 2)) != hipSuccess) {
+            delete s;
+            return nrhip_fail_msg("nrhip_station_create: out of device memory (transform tables)");
+        }
+        double2* base = s->d_nplan.as<double2>();
+        launch_nplan_tables(ctx->stream, nh, v.np.log2p, base, base + nh + 1, base + 2 * nh + 2, base + 2 * nh + 2 + P, ctx->twiddle);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+            delete s;
+            return nrhip_fail_msg("nrhip_station_create: building the transform tables failed");
+        }
+        v.np.wN = base;
+        v.np.cw = base + nh + 1;
+        v.np.Bf = base + 2 * nh + 2;
+        v.np.Bi = base + 2 * nh + 2 + P;
+    }
     // filter chains: one for all channels (n_filter_sets <= 1), or up to NRHIP_MAX_FSETS of them with a per-channel index;
     // the stages of all chains follow each other in the filter_* arrays
     const int n_sets = d->n_filter_sets > 1 ? d->n_filter_sets : 1;
@@ -332,6 +360,7 @@ void nrhip_station_detach(nrhip_station* s)
     for (auto& e : s->evt) if (e) (void)hipEventDestroy(e);
     s->d_pos.release(); s->d_cable.release(); s->d_model.release();
     s->d_rot.release(); s->d_rot_inv.release(); s->d_fc.release(); s->d_lnf.release(); s->d_invl.release();
+    s->d_nplan.release();
     s->d_fpow.release(); s->d_fpow_f.release(); s->d_seg.release(); s->d_attbin.release(); s->d_anttabs.release(); s->d_anttab_index.release();
     for (auto& a : s->d_tabdata) a.release();
     s->d_arz_depth.release(); s->d_arz_ce.release(); s->d_arz_par.release(); s->d_bire_knots.release();
@@ -360,6 +389,7 @@ int nrhip_station_set_positions(nrhip_station* s, const double* position)
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
     s->ws_bytes.clear();  // the tables of the last call belong to the old positions
     s->rays_n_showers = -1;
+    s->generation++;
     return 0;
 }
 
@@ -374,6 +404,16 @@ int64_t nrhip_station_release_workspace(nrhip_station* s)
         kv.second.release();
     }
     s->ws_bytes.clear();
+    // the per-length table cache only grows while the station lives (one row of ~1 MB or more per distinct common-trace length):
+    // it is given back here too; the next call rebuilds the rows of the lengths it meets (about 1 us per length)
+    auto& tc = s->tabcache;
+    for (DevArray* a : {&tc.B_fwd, &tc.B_inv, &tc.vel, &tc.E, &tc.H, &tc.Cf, &tc.Ci, &tc.hnorm, &tc.G, &tc.slotmap, &s->pa_B})
+        freed += (int64_t)a->cap;
+    tc.release();
+    s->pa_B.release();
+    s->pa_built.clear();
+    s->pa_B_cap = 0;
+    s->rays_n_showers = -1;
     return freed;
 }
 
@@ -787,7 +827,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     // cfg->reuse_ray_tables: the ray records and the delta_C selection of the previous call on the SAME shower list, station
     // position and cuts are still in the workspace (two-phase runs: nrhip_sim_config.select_only first)
     const bool reuse = cfg->reuse_ray_tables != 0;
-    if (reuse && (st->rays_n_showers != n_showers || st->rays_delta_C != cfg->delta_C_cut || st->rays_vertex != vertex))
+    if (reuse && (st->rays_n_showers != n_showers || st->rays_delta_C != cfg->delta_C_cut || st->rays_vertex != vertex ||
+                  st->rays_n_groups != n_groups || st->rays_max_distance != max_distance || st->rays_n_reflections != n_refl ||
+                  st->rays_z_reflection != cfg->z_reflection || st->rays_generation != st->generation))
         return nrhip_fail_msg("nrhip_simulate_events: reuse_ray_tables without matching ray tables of a previous call");
     st->rays_n_showers = -1;
     rec.stride = S_;
@@ -845,8 +887,13 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     HIPCHK(hipStreamSynchronize(sm));
     S.n_rays = n_rays;
     st->rays_n_showers = n_showers;
+    st->rays_n_groups = n_groups;
     st->rays_delta_C = cfg->delta_C_cut;
     st->rays_vertex = vertex;
+    st->rays_max_distance = max_distance;
+    st->rays_n_reflections = n_refl;
+    st->rays_z_reflection = cfg->z_reflection;
+    st->rays_generation = st->generation;
     if (cfg->select_only) {
         int* first;
         NEED(first = WS("shower_first_channel", int, n_showers));

@@ -50,6 +50,7 @@ struct StationDev {
     const double* fpow;       // [3][N/2 + 1] f_k^p for p = 2.57, 2.74, 1.27 (Alvarez2009: beta had / em, alpha)
     const float* fpow_f;      // the same in single precision (bound kernels)
     const unsigned char* seg; // [N/2 + 1] coarse-grid segment lo of f_k: fcoarse[lo] <= f_k < fcoarse[lo + 1]
+    NPlan np;                 // the N / 2-point transforms of the ray stages (any even N)
 };
 
 // analog filter chain: response_i(f) = polyval(b_i, j f) / polyval(a_i, j f), highest power first
@@ -241,6 +242,7 @@ void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, c
 void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const double* theta, const int* type,
                               const double* n_index, const double* R, const double* k_L, int model, int N, double dt,
                               double2* spec);
+void launch_nplan_tables(hipStream_t s, int nh, int log2p, double2* wN, double2* cw, double2* Bf, double2* Bi, const double2* tw);
 void launch_czt_test(hipStream_t s, int n_batch, int n_in, int n_out, int Q, double sgn, const double2* in, double2* out,
                      const double2* tw, double2* Bscratch, int grid);
 void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,

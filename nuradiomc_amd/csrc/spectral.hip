@@ -768,15 +768,16 @@ __device__ inline double2 field_bin(int k, double amp_k, int N, double fs, doubl
     return s;
 }
 
-// y_j = e[2j] + i e[2j+1] (j < N/2) of e = irfft_N(G) * fs / sqrt(2), left in x[bitrev(j)] (x in LDS, >= N/2)
+// y_j = e[2j] + i e[2j+1] (j < N/2) of e = irfft_N(G) * fs / sqrt(2), left in x[nplan_idx(j)] (x in LDS, >= nplan_points(np))
 #ifndef NRHIP_EFIELD_FUSE
 #define NRHIP_EFIELD_FUSE 3   // efield_max_kernel: 256 threads on N / 2 = 2048 points = 2^3 points per thread and pass
 #endif
 template <int FUSE = 0>
-__device__ inline void field_time_domain(double2* x, const double* amp, int N, int log2nh, double fs, double pol,
+__device__ inline void field_time_domain(double2* x, const double* amp, int N, const NPlan& np, double fs, double pol,
                                          double2 rc, double rem, bool shift, int ask_model, double roll_bins,
                                          const double2* __restrict__ tw)
 {
+    const int log2nh = np.log2nh;
     const int nh = N / 2;
 #ifdef NRHIP_CONV_TIMING
     if (threadIdx.x == 0) g_ct_mark[blockIdx.x & 1023] = __builtin_amdgcn_s_memtime();
@@ -796,10 +797,10 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
         ramp = s_ramp;
     }
     // (the twiddle of the thread's NEXT bin is requested before the current one is used: it comes from L1 / L2)
-    double2 wnext = (threadIdx.x < (unsigned)nh) ? tw[threadIdx.x * (FFT_MAX / N)] : make_double2(1., 0.);
+    double2 wnext = (threadIdx.x < (unsigned)nh) ? nplan_w(np, threadIdx.x, tw) : make_double2(1., 0.);
     for (int k = threadIdx.x; k < nh; k += blockDim.x) {
         const double2 wk = wnext;                // exp(-2 pi i k / N)
-        if (k + (int)blockDim.x < nh) wnext = tw[(k + blockDim.x) * (FFT_MAX / N)];
+        if (k + (int)blockDim.x < nh) wnext = nplan_w(np, k + blockDim.x, tw);
         double2 Gk = field_bin(k, amp[k], N, fs, pol, rc, rem, shift, ask_model, roll_bins, ramp);
         double2 Gc = cconj(field_bin(nh - k, amp[nh - k], N, fs, pol, rc, rem, shift, ask_model, roll_bins, ramp));
         double2 ge = cscale(cadd(Gk, Gc), 0.5);
@@ -811,8 +812,9 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, i
 #ifdef NRHIP_CONV_TIMING
     if (threadIdx.x == 0) atomicAdd(&g_conv_clk[10], __builtin_amdgcn_s_memtime() - g_ct_mark[blockIdx.x & 1023]);
 #endif
-    // inverse, natural -> bit-reversed; scale applied by the reader
-    if (FUSE > 2) fft_dif_fused_k<(FUSE > 2 ? FUSE : 3)>(x, log2nh, tw, true);
+    // inverse, natural -> bit-reversed (natural for lengths that are no power of two: nplan_idx); scale applied by the reader
+    if (log2nh < 0) nplan_fft(x, np, tw, true);
+    else if (FUSE > 2) fft_dif_fused_k<(FUSE > 2 ? FUSE : 3)>(x, log2nh, tw, true);
     else fft_dif(x, log2nh, tw, true);
 }
 
@@ -1341,7 +1343,7 @@ efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ ev_lis
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2;
     double2* x = (double2*)smem;
-    double* amp = (double*)(x + nh);
+    double* amp = (double*)(x + nplan_points(st.np));
     __shared__ RayShared rs;
     __shared__ double red[256];
     const int n_ev = *n_list;
@@ -1363,7 +1365,7 @@ efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ ev_lis
         double mx = 0.;
         const double scale = st.fs / 1.4142135623730951 / nh;
         if (both_real) {
-            field_time_domain<NRHIP_EFIELD_FUSE>(x, amp, N, log2nh, st.fs, 1.0, make_double2(1., 0.), 0., false, ask_model,
+            field_time_domain<NRHIP_EFIELD_FUSE>(x, amp, N, st.np, st.fs, 1.0, make_double2(1., 0.), 0., false, ask_model,
                               floor(2.0 * st.fs), tw);
             double cm = fmax(fabs(pt * rt.x), fabs(pp * rp.x));
             for (int j = threadIdx.x; j < nh; j += blockDim.x) {
@@ -1374,7 +1376,7 @@ efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ ev_lis
             __syncthreads();
         } else {
             for (int comp = 0; comp < 2; comp++) {
-                field_time_domain<NRHIP_EFIELD_FUSE>(x, amp, N, log2nh, st.fs, comp ? pp : pt, comp ? rp : rt, 0., false, ask_model,
+                field_time_domain<NRHIP_EFIELD_FUSE>(x, amp, N, st.np, st.fs, comp ? pp : pt, comp ? rp : rt, 0., false, ask_model,
                                   floor(2.0 * st.fs), tw);
                 for (int j = threadIdx.x; j < nh; j += blockDim.x) {
                     double2 y = x[j];
@@ -2240,7 +2242,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
 // y_j = e[2j] + i e[2j+1] of a real N-sample trace in HBM, optionally delayed by the sub-sample remainder `rem` through the
 // Fourier shift theorem on the N grid (rfft -> * exp(-2 pi i f rem) -> irfft, base_trace.py:273-276).  Without the shift the
 // packed trace is left in natural order, with it in bit-reversed order and unscaled by 1 / (N / 2).  x: FFT_MAX complex (LDS).
-__device__ inline void trace_to_packed(double2* x, const double* __restrict__ tr, int N, int log2nh, double fs, double rem,
+__device__ inline void trace_to_packed(double2* x, const double* __restrict__ tr, int N, const NPlan& np, double fs, double rem,
                                        bool shift, const double2* __restrict__ tw)
 {
     const int M = FFT_MAX, nh = N / 2;
@@ -2248,15 +2250,15 @@ __device__ inline void trace_to_packed(double2* x, const double* __restrict__ tr
     for (int j = threadIdx.x; j < nh; j += blockDim.x) x[j] = make_double2(tr[2 * j], tr[2 * j + 1]);
     __syncthreads();
     if (!shift) return;
-    fft_dif(x, log2nh, tw, false);  // Y in bit-reversed order
+    nplan_fft(x, np, tw, false);     // Y in bit-reversed (power of two) or natural order: nplan_idx
     double2* G = x + M / 2;          // G'(k), k = 0..nh, in the upper half of the buffer
     for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
         int ka = (k == nh) ? 0 : k, kb = (k == 0 || k == nh) ? 0 : nh - k;
-        double2 Y1 = x[bitrev(ka, log2nh)], Y2 = cconj(x[bitrev(kb, log2nh)]);
+        double2 Y1 = x[nplan_idx(np, ka)], Y2 = cconj(x[nplan_idx(np, kb)]);
         double2 ge = cscale(cadd(Y1, Y2), 0.5);
         double2 d = cscale(csub(Y1, Y2), 0.5);
         double2 go = make_double2(d.y, -d.x);  // d / i
-        double2 wk = (k == nh) ? make_double2(-1., 0.) : tw[k * (FFT_MAX / N)];  // exp(-2 pi i k / N)
+        double2 wk = nplan_w(np, k, tw);       // exp(-2 pi i k / N)
         double2 g = cadd(ge, cmul(go, wk));
         double f = k * (1.0 / (N * res));
         double sn, cs;
@@ -2270,11 +2272,11 @@ __device__ inline void trace_to_packed(double2* x, const double* __restrict__ tr
         double2 Gk = G[k], Gc = cconj(G[nh - k]);
         double2 ge = cscale(cadd(Gk, Gc), 0.5);
         double2 d = cscale(csub(Gk, Gc), 0.5);
-        double2 go = cmul(d, cconj(tw[k * (FFT_MAX / N)]));
+        double2 go = cmul(d, cconj(nplan_w(np, k, tw)));
         x[k] = make_double2(ge.x - go.y, ge.y + go.x);
     }
     __syncthreads();
-    fft_dif(x, log2nh, tw, true);
+    nplan_fft(x, np, tw, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2381,16 +2383,16 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                 if (ray_traces) {
                     // the ray's electric-field trace of this component comes from HBM (time-domain emission models,
                     // birefringence: general_trace_kernel); the on-sky factors are already in it
-                    trace_to_packed(x, ray_traces + ((long)r * 2 + comp) * N, N, log2nh, st.fs, rem, shift, tw);
+                    trace_to_packed(x, ray_traces + ((long)r * 2 + comp) * N, N, st.np, st.fs, rem, shift, tw);
                     natural = !shift;
                     sc = (shift ? 1.0 / nh : 1.0) * (1.4142135623730951 / st.fs);  // time2freq
                 } else {
-                    field_time_domain(x, amp, N, log2nh, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
+                    field_time_domain(x, amp, N, st.np, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
                 }
                 // gather y_j (bit-reversed positions) -> registers, then lay out a_j = y_j * chirp_j, zero pad
                 double2 yreg[8];
                 int cnt = 0;
-                for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = natural ? x[j] : x[bitrev(j, log2nh)];
+                for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = natural ? x[j] : x[nplan_idx(st.np, j)];
                 __syncthreads();
                 cnt = 0;
 #pragma unroll 4
@@ -2555,7 +2557,8 @@ ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2;
     double2* x = (double2*)smem;
-    double* amp = (double*)(x + N);
+    const bool pow2 = st.np.log2nh >= 0;
+    double* amp = (double*)(x + (pow2 ? N : nplan_points(st.np)));
     __shared__ RayShared rs;
     __shared__ double red[256];
     __shared__ int red_i[256];
@@ -2574,7 +2577,7 @@ ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item
         const double vt = w.vfac_t[r], vp = w.vfac_p[r], pt = w.pol_theta[r], pp = w.pol_phi[r];
         const double2 rt = w.r_theta[r], rp = w.r_phi[r];
         const double scale = st.fs / 1.4142135623730951 / N;  // freq2time
-        for (int k = threadIdx.x; k < N; k += blockDim.x) {
+        auto one_sided = [&](int k) -> double2 {
             double2 v = make_double2(0., 0.);
             if (k > 0 && k < nh) {
                 double2 Gt = field_bin(k, amp[k], N, st.fs, pt, rt, 0., false, ask_model, floor(2.0 * st.fs));
@@ -2582,15 +2585,36 @@ ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item
                 double2 E = cadd(cscale(Gt, vt), cscale(Gp, vp));
                 v = cscale(cmul(cmul(vel[k], Hf[k]), E), 2. * scale);
             }
-            x[k] = v;
-        }
-        __syncthreads();
-        fft_dif(x, log2n, tw, true);  // inverse, natural -> bit-reversed
+            return v;
+        };
         double mx = -1.;
         int imx = 0;
-        for (int n = threadIdx.x; n < N; n += blockDim.x) {  // n ascending per thread: first maximum kept
-            double a = cabs2(x[bitrev(n, log2n)]);
-            if (a > mx) { mx = a; imx = n; }
+        if (pow2) {
+            for (int k = threadIdx.x; k < N; k += blockDim.x) x[k] = one_sided(k);
+            __syncthreads();
+            fft_dif(x, log2n, tw, true);  // inverse, natural -> bit-reversed
+            for (int n = threadIdx.x; n < N; n += blockDim.x) {  // n ascending per thread: first maximum kept
+                double a = cabs2(x[bitrev(n, log2n)]);
+                if (a > mx) { mx = a; imx = n; }
+            }
+        } else {
+            // a[n] = sum_{k < nh} V_k e^{2 pi i k n / N}: the even samples are the nh-point inverse transform of V, the odd ones
+            // that of V_k e^{2 pi i k / N} (two Bluestein transforms of the station's plan)
+            for (int par = 0; par < 2; par++) {
+                __syncthreads();
+                for (int k = threadIdx.x; k < nh; k += blockDim.x) {
+                    double2 v = one_sided(k);
+                    if (par) v = cmul(v, cconj(nplan_w(st.np, k, tw)));
+                    x[k] = v;
+                }
+                __syncthreads();
+                nplan_fft(x, st.np, tw, true);
+                for (int j = threadIdx.x; j < nh; j += blockDim.x) {
+                    const double a = cabs2(x[j]);
+                    const int n = 2 * j + par;
+                    if (a > mx || (a == mx && n < imx)) { mx = a; imx = n; }
+                }
+            }
         }
         red[threadIdx.x] = mx;
         red_i[threadIdx.x] = imx;
@@ -2681,15 +2705,15 @@ efield_channel_kernel(int n_efields, const double* __restrict__ traces, const do
             __syncthreads();
             if (shift) {
                 // rfft -> * exp(-2 pi i f rem) -> irfft on the N grid (base_trace.py:273-276)
-                fft_dif(x, log2nh, tw, false);  // Y in bit-reversed order
+                nplan_fft(x, st.np, tw, false);  // Y in bit-reversed / natural order (nplan_idx)
                 double2* G = x + M / 2;          // G'(k), k = 0..nh, in the upper half of the buffer
                 for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
                     int ka = (k == nh) ? 0 : k, kb = (k == 0 || k == nh) ? 0 : nh - k;
-                    double2 Y1 = x[bitrev(ka, log2nh)], Y2 = cconj(x[bitrev(kb, log2nh)]);
+                    double2 Y1 = x[nplan_idx(st.np, ka)], Y2 = cconj(x[nplan_idx(st.np, kb)]);
                     double2 ge = cscale(cadd(Y1, Y2), 0.5);
                     double2 d = cscale(csub(Y1, Y2), 0.5);
                     double2 go = make_double2(d.y, -d.x);  // d / i
-                    double2 wk = (k == nh) ? make_double2(-1., 0.) : tw[k * (FFT_MAX / N)];  // exp(-2 pi i k / N)
+                    double2 wk = nplan_w(st.np, k, tw);    // exp(-2 pi i k / N)
                     double2 g = cadd(ge, cmul(go, wk));
                     double f = k * (1.0 / (N * res));
                     double sn, cs;
@@ -2703,17 +2727,17 @@ efield_channel_kernel(int n_efields, const double* __restrict__ traces, const do
                     double2 Gk = G[k], Gc = cconj(G[nh - k]);
                     double2 ge = cscale(cadd(Gk, Gc), 0.5);
                     double2 d = cscale(csub(Gk, Gc), 0.5);
-                    double2 go = cmul(d, cconj(tw[k * (FFT_MAX / N)]));
+                    double2 go = cmul(d, cconj(nplan_w(st.np, k, tw)));
                     x[k] = make_double2(ge.x - go.y, ge.y + go.x);
                 }
                 __syncthreads();
-                fft_dif(x, log2nh, tw, true);
+                nplan_fft(x, st.np, tw, true);
             }
             // a_j = y_j chirp_j * sqrt(2) / fs (time2freq), zero padded
             const double sc = (shift ? 1.0 / nh : 1.0) * (1.4142135623730951 / st.fs);
             double2 yreg[8];
             int cnt = 0;
-            for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = shift ? x[bitrev(j, log2nh)] : x[j];
+            for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = shift ? x[nplan_idx(st.np, j)] : x[j];
             __syncthreads();
             cnt = 0;
             for (int j = threadIdx.x; j < M; j += blockDim.x) {
@@ -2820,10 +2844,38 @@ czt_test_kernel(int n_batch, int n_in, int n_out, int Q, double sgn, const doubl
     }
 }
 
+// tables of the N / 2-point Bluestein transforms of a station whose N / 2 is not a power of two (NPlan): one block
+__global__ void __launch_bounds__(1024)
+nplan_tables_kernel(int nh, int log2p, double2* __restrict__ wN, double2* __restrict__ cw, double2* __restrict__ Bf,
+                    double2* __restrict__ Bi, const double2* __restrict__ tw)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* x = (double2*)smem;
+    const int P = 1 << log2p;
+    for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
+        double sn, cs;
+        sincospi(-(double)k / (double)nh, &sn, &cs);   // exp(-2 pi i k / N), N = 2 nh
+        wN[k] = make_double2(cs, sn);
+        if (k < nh) cw[k] = chirp(k, nh, -1.);
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        czt_build_table(x, log2p, nh, nh, nh, pass ? 1. : -1., tw);
+        double2* B = pass ? Bi : Bf;
+        for (int i = threadIdx.x; i < P; i += blockDim.x) B[i] = x[i];
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
 static inline unsigned grid_for(long n, int block) { return (unsigned)((n + block - 1) / block); }
+static void set_big_lds();
+__global__ void general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, const double* __restrict__ arz_trace,
+                                        const double2* __restrict__ tw, int log2nh, double2* __restrict__ spec);
+__global__ void general_trace_kernel(int n_rays, StationDev st, const double2* __restrict__ spec, const double2* __restrict__ tw,
+                                     int log2nh, double* __restrict__ traces, double* __restrict__ max_efield,
+                                     const int* __restrict__ active, const double* __restrict__ bound);
 
 void launch_select_rays(hipStream_t s, long n_pairs, int n_ch, const double* vertex, const double* zen, const double* az,
                         const RayRecords& rec, const IceConst& m, double cut, int* keep)
@@ -2998,7 +3050,8 @@ void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int 
     launch_exclusive_scan(s, (long)n_events + 1, ev_need, ev_offset, scan_tmp);
     hipLaunchKernelGGL(scatter_flagged_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, ev_need, ev_offset,
                        ev_list);
-    size_t lds = (size_t)nh * 16 + (size_t)(nh + 1) * 8;
+    set_big_lds();
+    size_t lds = (size_t)nplan_points(st.np) * 16 + (size_t)(nh + 1) * 8;
     int grid = n_events < 256 * 16 ? n_events : 256 * 16;
     hipLaunchKernelGGL(efield_max_kernel, dim3(grid), dim3(256), lds, s, ev_offset + n_events, ev_list, need_ray, slot_offset,
                        w, evin, st, ask_model, tw, ilog2(nh), min_efield, exact, max_efield, xform_count);
@@ -3039,6 +3092,12 @@ static void set_big_lds()
                               (FFT_MAX / 2) * 16 + (FFT_MAX / 4 + 1) * 8);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)efield_channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    // trace lengths that are no power of two: Bluestein on up to FFT_MAX / 2 points inside the ray kernels
+    (void)hipFuncSetAttribute((const void*)efield_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (FFT_MAX / 2) * 16 + (FFT_MAX / 4 + 1) * 8);
+    (void)hipFuncSetAttribute((const void*)general_spectrum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (FFT_MAX / 2) * 16 + (FFT_MAX / 4 + 1) * 8);
+    (void)hipFuncSetAttribute((const void*)general_trace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (FFT_MAX / 2) * 16);
     (void)hipGetLastError();
     g_attr_set = true;
 }
@@ -3082,7 +3141,9 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     // traces up to FFT_MAX samples: prefilter, then one real convolution per listed item; longer ones (or
     // NRHIP_CHANNEL_CZT=1): chirp-z per ray (plain OR of simple thresholds only; the caller checks)
     int skip_upto = 0;
-    if (tab.G && st.N <= FFT_MAX / 2 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces && !env_trace && !(noise && noise->on)) {
+    // (the convolution kernel's ray stage is radix 2: trace lengths that are no power of two take the chirp-z kernel)
+    if (tab.G && st.N <= FFT_MAX / 2 && st.np.log2nh >= 0 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces && !env_trace &&
+        !(noise && noise->on)) {
         hipLaunchKernelGGL(channel_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev,
                            ev_len_index, st, trig.prefilter(), tab.hnorm, exact, out.maxV, need, skip_off);
         const int n_cand = n_items / st.n_ch;
@@ -3138,7 +3199,7 @@ general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, con
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2, n_f = nh + 1;
     double2* x = (double2*)smem;
-    double* amp = (double*)(x + nh);
+    double* amp = (double*)(x + nplan_points(st.np));
     __shared__ RayShared rs;
     const double df = 1.0 / (N * (1. / st.fs));
     for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
@@ -3164,15 +3225,15 @@ general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, con
             const double* tr = arz_trace + ((long)r * 3 + 1) * N;
             for (int j = threadIdx.x; j < nh; j += blockDim.x) x[j] = make_double2(tr[2 * j], tr[2 * j + 1]);
             __syncthreads();
-            fft_dif(x, log2nh, tw, false);  // packed half-length transform, bit-reversed
+            nplan_fft(x, st.np, tw, false);  // packed half-length transform (element j at nplan_idx(j))
             const double sc = 1.4142135623730951 / st.fs;  // fft.time2freq: rfft / fs * sqrt 2
             for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
                 const int ka = (k == nh) ? 0 : k, kb = (k == 0 || k == nh) ? 0 : nh - k;
-                const double2 Y1 = x[bitrev(ka, log2nh)], Y2 = cconj(x[bitrev(kb, log2nh)]);
+                const double2 Y1 = x[nplan_idx(st.np, ka)], Y2 = cconj(x[nplan_idx(st.np, kb)]);
                 const double2 ge = cscale(cadd(Y1, Y2), 0.5);
                 const double2 d = cscale(csub(Y1, Y2), 0.5);
                 const double2 go = make_double2(d.y, -d.x);
-                const double2 wk = (k == nh) ? make_double2(-1., 0.) : tw[k * (FFT_MAX / N)];
+                const double2 wk = nplan_w(st.np, k, tw);
                 // attenuation: np.interp on the coarse grid for f > 0, 1 at DC (analyticraytracing.py:1075-1080)
                 const double a = (k == 0) ? 1. : interp_seg(k * df, st.seg[k], st.n_fc, rs.xp, rs.att, rs.slope);
                 const double2 S = cscale(cadd(ge, cmul(go, wk)), sc * a);
@@ -3209,14 +3270,14 @@ general_trace_kernel(int n_rays, StationDev st, const double2* __restrict__ spec
                 if (k == 0) { Gk.y = 0.; Gc.y = 0.; }  // irfft ignores the imaginary parts of DC and Nyquist
                 const double2 ge = cscale(cadd(Gk, Gc), 0.5);
                 const double2 d = cscale(csub(Gk, Gc), 0.5);
-                const double2 go = cmul(d, cconj(tw[k * (FFT_MAX / N)]));
+                const double2 go = cmul(d, cconj(nplan_w(st.np, k, tw)));
                 x[k] = make_double2(ge.x - go.y, ge.y + go.x);
             }
             __syncthreads();
-            fft_dif(x, log2nh, tw, true);
+            nplan_fft(x, st.np, tw, true);
             double* out = traces + ((long)r * 2 + comp) * N;
             for (int j = threadIdx.x; j < nh; j += blockDim.x) {
-                const double2 y = x[bitrev(j, log2nh)];
+                const double2 y = x[nplan_idx(st.np, j)];
                 const double e0 = y.x * scale, e1 = y.y * scale;
                 out[2 * j] = e0;
                 out[2 * j + 1] = e1;
@@ -3302,7 +3363,8 @@ void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const 
     if (n_rays <= 0) return;
     const int nh = st.N / 2;
     int grid = n_rays < 256 * 64 ? n_rays : 256 * 64;
-    hipLaunchKernelGGL(general_spectrum_kernel, dim3(grid), dim3(256), (size_t)nh * 16 + (size_t)(nh + 1) * 8, s, n_rays, w, st,
+    set_big_lds();
+    hipLaunchKernelGGL(general_spectrum_kernel, dim3(grid), dim3(256), (size_t)nplan_points(st.np) * 16 + (size_t)(nh + 1) * 8, s, n_rays, w, st,
                        ask_model, arz_trace, tw, ilog2(nh), spec);
 }
 void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double2* tw,
@@ -3311,7 +3373,8 @@ void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const
     if (n_rays <= 0) return;
     const int nh = st.N / 2;
     int grid = n_rays < 256 * 64 ? n_rays : 256 * 64;
-    hipLaunchKernelGGL(general_trace_kernel, dim3(grid), dim3(256), (size_t)nh * 16, s, n_rays, st, spec, tw, ilog2(nh), traces,
+    set_big_lds();
+    hipLaunchKernelGGL(general_trace_kernel, dim3(grid), dim3(256), (size_t)nplan_points(st.np) * 16, s, n_rays, st, spec, tw, ilog2(nh), traces,
                        max_efield, active, bound);
 }
 void launch_general_bound(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const long long* log_gain,
@@ -4019,7 +4082,7 @@ void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const
 {
     if (n_cand_max <= 0) return;
     set_big_lds();
-    size_t lds = (size_t)st.N * 16 + (size_t)(st.N / 2 + 1) * 8;
+    size_t lds = (size_t)(st.np.log2nh >= 0 ? st.N : nplan_points(st.np)) * 16 + (size_t)(st.N / 2 + 1) * 8;
     int grid = n_cand_max < 256 * 4 ? n_cand_max : 256 * 4;
     hipLaunchKernelGGL(ray_envelope_kernel, dim3(grid), dim3(256), lds, s, n_cand, item_event, w, ev, st, ask_model, tw, tab,
                        len_index_N, ilog2(st.N), max_env, signal_time);
@@ -4041,6 +4104,11 @@ void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const 
     int grid = n < 4096 ? n : 4096;
     hipLaunchKernelGGL(askaryan_spectrum_kernel, dim3(grid), dim3(256), 0, s, n, energy, theta, type, n_index, R, k_L, model,
                        N, dt, spec);
+}
+void launch_nplan_tables(hipStream_t s, int nh, int log2p, double2* wN, double2* cw, double2* Bf, double2* Bi, const double2* tw)
+{
+    set_big_lds();
+    hipLaunchKernelGGL(nplan_tables_kernel, dim3(1), dim3(1024), (size_t)(1 << log2p) * 16, s, nh, log2p, wN, cw, Bf, Bi, tw);
 }
 void launch_czt_test(hipStream_t s, int n_batch, int n_in, int n_out, int Q, double sgn, const double2* in, double2* out,
                      const double2* tw, double2* Bscratch, int grid)

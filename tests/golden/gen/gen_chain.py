@@ -20,9 +20,9 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 
 def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4, model='Alvarez2009',
         antenna='analytic_VPol', cable_delay=0., rmax=4000., orientation=None, focusing=False, ice_model='southpole_2015',
-        att_model='SP1', n_reflections=0, zmin=-2700., z_top=-100., zmax=0.):
-    det = rh.StationS5(n_samples=N, fs=2.0, antenna=antenna, cable_delay=cable_delay, orientation=orientation, z_top=z_top)
-    cfg = rh.default_config(model=model, ice_model=ice_model, attenuation_model=att_model)
+        att_model='SP1', n_reflections=0, zmin=-2700., z_top=-100., zmax=0., fs=2.0):
+    det = rh.StationS5(n_samples=N, fs=fs, antenna=antenna, cable_delay=cable_delay, orientation=orientation, z_top=z_top)
+    cfg = rh.default_config(model=model, ice_model=ice_model, attenuation_model=att_model, fs=fs)
     cfg['propagation']['focusing'] = bool(focusing)
     cfg['propagation']['n_reflections'] = int(n_reflections)
     ice, prop = rh.make_propagator(cfg, det)
@@ -65,7 +65,7 @@ def run(name, n_events, seed, N, full_rays, full_events, energy=3e17, em_every=4
     R = {k: np.array([r[k] for r in rays]) for k in
          ('event', 'channel', 'iS', 'C0', 'C1', 'type', 'zenith', 'azimuth', 'D', 'T', 'view', 'pol_angle', 'launch',
           't0', 'r_theta', 'r_phi', 'max_efield', 'simch_t0', 'max_amp_ray', 'signal_time', 'reflection', 'reflection_case')}
-    out = dict(N=N, fs=2.0, vrms=vrms, vrms_efield=vrms_e, ice=np.array([ice.n_ice, ice.delta_n, ice.z_0]),
+    out = dict(N=N, fs=fs, vrms=vrms, vrms_efield=vrms_e, ice=np.array([ice.n_ice, ice.delta_n, ice.z_0]),
                att_model=att_model, n_freq=25, askaryan_model=model, antenna=antenna, cable_delay=cable_delay,
                n_reflections=int(n_reflections), z_reflection=float(getattr(ice, 'reflection', None) or 0.),
                reflection_coefficient=float(getattr(ice, 'reflection_coefficient', None) or 1.),
@@ -90,6 +90,11 @@ if __name__ == '__main__':
         run('N256', n_events=300, seed=21, N=256, full_rays=400, full_events=12)
     if 'N4096' in which:
         run('N4096', n_events=120, seed=22, N=4096, full_rays=6, full_events=3, rmax=2500.)
+    if 'N1280' in which:   # the trace grid of the reference's own example (examples/01_Veff_simulation: 256 detector samples at 1 GHz
+        # simulated at 5 GHz -> 1280 samples, not a power of two); cable delays exercise the sub-sample shift on that grid
+        run('N1280', n_events=260, seed=31, N=1280, full_rays=40, full_events=4, rmax=2500., fs=5.0, cable_delay=[0., 3.3, 7.77, 12.2, 19.8])
+    if 'N3200' in which:   # an RNO-G read-out (2048 samples at 3.2 GHz) on the 5 GHz simulation grid
+        run('N3200', n_events=120, seed=32, N=3200, full_rays=10, full_events=2, rmax=2500., fs=5.0)
     if 'N256_hpol' in which:  # HPol antennas + unequal cable delays: exercises ePhi, Fresnel r_s and the sub-sample shift
         run('N256_hpol', n_events=150, seed=23, N=256, full_rays=200, full_events=8, antenna='analytic_HPol',
             cable_delay=[0., 3.3, 7.77, 12.2, 19.8], rmax=2500.)

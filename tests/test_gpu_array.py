@@ -249,20 +249,24 @@ def test_config5_gen2_array(gpu_ctx_factory):
     assert np.array_equal(stats_p['station_triggered'], ts) and np.array_equal(trig_p, trig)
 
 
-@pytest.mark.parametrize('config', [3, 5])
+@pytest.mark.parametrize('config', [3, 4, 5])
 def test_array_full_size_properties(gpu_ctx_factory, config):
     """bench.py's array workloads at a size the oracle cannot follow (config 3: 2e5 events x 35 x 24 = 1.7e8 pairs; config 5:
-    1e5 events x 200 x 5 = 1e8 pairs): the OR mask is a function of the event alone -- permuting the list permutes the mask,
+    1e5 events x 200 x 5 = 1e8 pairs; config 4, ARZ2020 + birefringence at 4096 samples: 1e4 events x 35 x 24 = 8.4e6 pairs, the
+    oracle needs about a minute per event group with rays there): the OR mask is a function of the event alone -- permuting the list permutes the mask,
     unequal shards concatenate to the whole (what the multi-GPU sharding relies on) --, the device-resident accumulate form
     equals the OR of the per-station masks, triggered events are a subset of what any single station reports."""
     import bench
-    wl = bench.make_workload(config, 200000 if config == 3 else 100000, seed=10)
+    wl = bench.make_workload(config, {3: 200000, 4: 10000, 5: 100000}[config], seed=10)
     ctx = gpu_ctx_factory(wl['ice'], wl['att_model'])
     arr = bench.build_array(ctx, wl)
     a = wl['events']
     grp = a['group']
     n = int(grp[-1]) + 1
     cols = ('vertex', 'zenith', 'azimuth', 'energy', 'shower_type', 'k_L')
+    iN = None
+    if config == 4:   # the ARZ profile numbers are properties of the showers (drawn once for the list, as bench.py does)
+        iN = arr.station._arz.draw_profile_numbers(a['energy'], ['HAD' if c == 0 else 'EM' for c in a['shower_type']])
 
     def rows_of(groups):
         """shower rows of the given event groups, in that order of groups (the showers of a group stay consecutive)"""
@@ -272,22 +276,28 @@ def test_array_full_size_properties(gpu_ctx_factory, config):
     def run(groups, **extra):
         r = rows_of(groups)
         new_id = np.repeat(np.arange(len(groups)), np.searchsorted(grp, np.asarray(groups) + 1) - np.searchsorted(grp, groups))
+        if iN is not None:
+            extra = dict(extra, arz_iN=iN[r])
         return arr.simulate_events(*(a[c][r] for c in cols), group_id=new_id, distance_cut_coefficients=DCUT, **wl['sim_kw'],
                                    **extra)
     trig, stats = run(np.arange(n))
     ts = stats['station_triggered']
     assert len(trig) == n and trig.sum() > 100 and np.array_equal(trig, ts.any(axis=0)) and ts.sum(axis=1).max() < trig.sum()
+    print('config %d: %d of %d event groups trigger' % (config, trig.sum(), n))
     perm = np.random.default_rng(1).permutation(n)
     trig_p, _ = run(perm, per_station=False)
     assert np.array_equal(trig_p, trig[perm])
-    cuts = [0, 1, 77777, n]
+    cuts = [0, 1, min(77777, n // 3), n]
     parts = [run(np.arange(i, j), per_station=False)[0] for i, j in zip(cuts[:-1], cuts[1:])]
     assert np.array_equal(np.concatenate(parts), trig)
     # device-resident accumulate form (what bench.py times)
     d = bench.upload_events(ctx, wl)
     try:
+        dkw = dict(wl['sim_kw'])
+        if iN is not None:
+            dkw['arz_rows'] = arr.station._arz_shower_profiles(d['host'][3], d['host'][4], iN)
         s2 = arr.simulate_events_dev(d['n'], *d['in'], d['trig'], d_max_distance=d['md'], n_groups=d['n_groups'],
-                                     d_group_begin=d['gb'], **wl['sim_kw'])
+                                     d_group_begin=d['gb'], **dkw)
         got = np.zeros(n, np.uint8)
         ctx.to_host(got, d['trig'])
     finally:

@@ -93,7 +93,7 @@ def _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=False, dump_traces=
 
 
 @pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N256_tab', 160),
-                                           ('N4096', 60), ('N256_hw', 220)])
+                                           ('N4096', 60), ('N256_hw', 220), ('N1280', 260), ('N3200', 60)])
 def test_spectral_stages_vs_oracle_on_identical_rays(gpu_ctx_factory, name, n_events):
     """Feed the ORACLE with the ray tables the GPU produced, so that every later stage sees identical
     (C0, D, T, launch, receive) on both sides: kept rays exact, amplitudes / traces to 1e-6."""
@@ -266,7 +266,7 @@ def test_custom_polarization(gpu_ctx_factory):
 
 
 @pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N256_tab', 160),
-                                           ('N4096', 120), ('N256_hw', 220)])
+                                           ('N4096', 120), ('N256_hw', 220), ('N1280', 260), ('N3200', 120)])
 def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
     """End to end (GPU ray tracing included) against the reference's own outputs.  The reference's first ray
     root carries ~1e-7 of iteration noise (see tests/test_oracle_golden.py), which moves arrival times by up to
@@ -290,7 +290,8 @@ def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
             assert np.all(np.abs(maxV[i] - ref) <= 5e-3 * np.max(ref)), ev
 
 
-@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_lpda', 200), ('N256_tab', 160), ('N4096', 120), ('N256_hw', 220)])
+@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_lpda', 200), ('N256_tab', 160), ('N4096', 120), ('N256_hw', 220),
+                                           ('N1280', 260)])
 def test_pruning_changes_no_result(gpu_ctx_factory, name, n_events):
     """Skipping rays of events that provably cannot pass the candidate cut (un-attenuated sum-of-magnitudes bound)
     and skipping transforms whose bound is below the cut must leave every decision and every trace unchanged."""
@@ -623,7 +624,8 @@ def test_trigger_modes(gpu_ctx_factory, kw):
     assert np.array_equal(trig_p, trig)
 
 
-@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N4096', 60), ('N256_hw', 220)])
+@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N4096', 60), ('N256_hw', 220),
+                                           ('N1280', 260)])
 def test_amp_per_ray_solution(gpu_ctx_factory, name, n_events):
     """speedup.amp_per_ray_solution: per-efield voltage on the N grid, Hilbert-envelope maximum and its time for every
     ray of the candidate events -- vs the oracle on the same rays (1e-6) and vs the reference's own values (5e-3: they

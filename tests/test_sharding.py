@@ -6,7 +6,7 @@ import pytest
 import numpy as np
 import torch.multiprocessing as mp
 from conftest import ROOT
-from nuradiomc_amd.sharding import shard_range
+from nuradiomc_amd.comm import shard_range
 
 
 def test_shard_ranges_tile_the_event_list():
@@ -21,8 +21,10 @@ def test_shard_ranges_tile_the_event_list():
 
 def _worker(rank, world, n, port, q):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch.distributed as dist
-    from nuradiomc_amd.sharding import shard_range, gather_triggered
+    from nuradiomc_amd.comm import shard_range
+    from torch_gather import gather_triggered
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     full = (np.arange(n) * 7919 % 13 == 0).astype(np.uint8)   # what a single process would have produced
@@ -79,13 +81,23 @@ def _id_worker(rank, world, port, q):
     q.put((rank, got == bytes(range(128))))
 
 
-def _tcp_worker(rank, world, port, backend, q):
+def _tcp_worker(rank, world, port, backend, q, allow_tcp=True):
     sys.path.insert(0, ROOT)
     from nuradiomc_amd import comm
     n_total = 1003
     a, b = comm.shard_range(n_total, rank, world)
     full = (np.arange(n_total) % 7 == 0).astype(np.uint8)
-    c = comm.Comm(None, rank, world, addr='127.0.0.1', port=port, backend=backend)
+    try:
+        c = comm.Comm(None, rank, world, addr='127.0.0.1', port=port, backend=backend, allow_tcp=allow_tcp)
+    except comm.CommError as e:
+        q.put((rank, False, [], 0., 'error: ' + str(e)[:40]))
+        return
+    try:
+        c.allgather_masks(full[a:b].copy(), b - a + 1, n_total)   # not a shard_range shard: refused, not silently permuted
+        q.put((rank, False, [], 0., 'no ValueError'))
+        return
+    except ValueError:
+        pass
     c.barrier()
     mask = c.allgather_masks(full[a:b].copy(), b - a, n_total)
     tot = c.allreduce_sum([int(full[a:b].sum()), rank])
@@ -100,8 +112,8 @@ def _tcp_worker(rank, world, port, backend, q):
 def test_comm_tcp_star_world3(backend):
     """The host-side stand-in of the communicator (nuradiomc_amd.comm.Comm, mode 'tcp'): the sharded masks of ONE list are
     gathered in rank order, sums and maxima agree on every rank -- world size 3 on the loopback, no GPU.  With backend 'rccl'
-    requested and no device context the vote fails on every rank and the same path is taken (what a node without a working RCCL
-    falls back to instead of hanging)."""
+    requested and no device context the vote fails on every rank; with allow_tcp the same path is taken (what a node without a
+    working RCCL may be told to fall back to instead of hanging), without it every rank raises CommError."""
     import multiprocessing
     ctx = multiprocessing.get_context('spawn')
     q = ctx.Queue()
@@ -115,6 +127,14 @@ def test_comm_tcp_star_world3(backend):
     n_set = int((np.arange(1003) % 7 == 0).sum())
     for rank, ok, tot, mx, mode in res:
         assert ok and tot == [n_set, 3] and mx == 2.5 and mode == 'tcp', (rank, ok, tot, mx, mode)
+    if backend == 'rccl':   # the default: a failed RCCL vote is an error on every rank, not a silent TCP run
+        procs = [ctx.Process(target=_tcp_worker, args=(r, 3, port + 2, backend, q, False)) for r in range(3)]
+        for p in procs[1:] + procs[:1]:
+            p.start()
+        res = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(60)
+        assert all(mode.startswith('error: nuradiomc_amd.comm: RCCL did not come up') for _, _, _, _, mode in res), res
 
 
 def test_comm_id_exchange_and_shard_helpers():
