@@ -350,6 +350,8 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=25., help='seconds of CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--device', type=int, default=None, help='GPU index of this rank (default: LOCAL_RANK)')
+    ap.add_argument('--no-traces', action='store_true', help='config 2: time pass 1 only (trigger mask), without the second pass that '
+                    'keeps the channel traces of the triggered events')
     ap.add_argument('--allow-tcp', action='store_true', help='if RCCL does not come up on every rank: run the collectives over the TCP '
                     'star instead of exiting non-zero (single-GPU boxes: tools/two_ranks_one_gpu.sh)')
     args = ap.parse_args()
@@ -383,8 +385,18 @@ def main():
         arz_iN = iN = st._arz.draw_profile_numbers(d['host'][3], ['HAD' if c == 0 else 'EM' for c in d['host'][4]])
         dev_kw['arz_rows'] = st._arz_shower_profiles(d['host'][3], d['host'][4], iN)
 
+    with_traces = cfgno == 2 and not args.no_traces   # single station: pass 2 inside the step (arrays: per station, not built yet)
+
     def step():
-        return det.simulate_events_dev(n, *d['in'], d['trig'], want_stats=True, **dev_kw)
+        """one pass of the hot path over the resident list; config 2: followed by pass 2 on the device -- the showers of the
+        triggered groups gathered in HBM and run again with every channel trace kept, what the reference writes for them"""
+        s1 = det.simulate_events_dev(n, *d['in'], d['trig'], want_stats=True, **dev_kw)
+        if with_traces:
+            s2, _, nk = st.triggered_pass_dev(n, *d['in'], d['trig'], n_groups=n_groups, d_group_begin=d['gb'], **wl['sim_kw'])
+            s1['pass2_ms'] = s2['stage_ms']['total'] if s2 else 0.
+            s1['pass2_groups'] = nk
+            s1['pass2_trace_bytes'] = st.fetch_bytes('trace') if s2 else 0
+        return s1
 
     for _ in range(args.warmup):
         step()
@@ -394,9 +406,11 @@ def main():
     for k in range(args.steps):
         s = step()
         if acc is None:
-            acc = s
+            acc = dict(s)
+            acc['stage_ms'] = dict(s['stage_ms'])
         else:
             acc['stage_ms'] = {q: acc['stage_ms'][q] + s['stage_ms'][q] for q in s['stage_ms']}
+            acc['pass2_ms'] = acc.get('pass2_ms', 0.) + s.get('pass2_ms', 0.)
     comm.barrier()
     elapsed = time.perf_counter() - t0
     stats = s
@@ -415,21 +429,7 @@ def main():
     counters = ('n_pairs', 'n_rays', 'n_active_rays', 'n_candidate_events', 'n_integrand_evals')
     tot = dict(zip(counters, comm.allreduce_sum([stats[k] for k in counters])))
 
-    # pass 2: what the reference writes for triggered events (all channel traces) -- re-run of the triggered groups with dump_traces
-    pass2_ms = None
-    if cfgno == 2 and rank == 0:
-        host_mask = np.zeros(n_groups, np.uint8)
-        ctx.to_host(host_mask, d['trig'])
-        sel = np.flatnonzero(host_mask)
-        ev = wl['events']
-        rows = np.flatnonzero(np.isin(ev['group'], sel + g0))
-        t1 = time.perf_counter()
-        t2, _ = st.simulate_events(ev['vertex'][rows], ev['zenith'][rows], ev['azimuth'][rows], ev['energy'][rows],
-                                   ev['shower_type'][rows], ev['k_L'][rows], group_id=ev['group'][rows], dump_traces=True,
-                                   **wl['sim_kw'])
-        pass2_ms = 1e3 * (time.perf_counter() - t1)
-        assert t2.all(), "pass 2 lost a trigger"
-
+    pass2_ms = acc.get('pass2_ms', 0.) / max(args.steps, 1) if with_traces else None   # kernel time of pass 2 inside the step (HIP events)
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         value = n_total * args.steps / elapsed
@@ -484,7 +484,9 @@ def main():
                        "n_triggered_rank0": stats['n_triggered'], "n_triggered_all": n_trig_total,
                        "all_ranks": {k: int(v) for k, v in tot.items()},
                        "triggered_events_per_s": n_trig_total / (elapsed / max(args.steps, 1)),
+                       "step_includes_traces_of_triggered_events": bool(with_traces),
                        "pass2_ms_traces_of_triggered_events": pass2_ms,
+                       "pass2_groups": stats.get('pass2_groups'), "pass2_trace_bytes": stats.get('pass2_trace_bytes'),
                        "stage_ms_avg_per_step": {k: round(v, 3) for k, v in sm.items()},
                        "collectives": comm.mode},   # 'local' (one rank), 'rccl', or 'tcp' (RCCL did not come up on every rank)
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -582,6 +582,11 @@ int nrhip_comm_allreduce_f64_max(nrhip_comm* comm, double* buf, int32_t n);
 int nrhip_cull_groups(nrhip_ctx* ctx, int64_t n_showers, int64_t n_groups, const int32_t* group_begin, const double* vertex,
                       const double* max_distance, const double centre[3], double radius, int32_t* keep_index,
                       int32_t* group_begin_out, int64_t* n_keep, int64_t* n_showers_out);
+/* the same lists for the groups flagged in a DEV uint8 mask [n_groups] -- e.g. the triggered groups of a survey, whose showers
+ * nrhip_gather_groups then copies into a compact list for the second pass that stores what the reference writes for triggered
+ * events (all channel traces: nrhip_sim_config.dump_traces; output_writer_hdf5.py:215-320) without a host round trip of the list */
+int nrhip_select_groups(nrhip_ctx* ctx, int64_t n_showers, int64_t n_groups, const int32_t* group_begin, const uint8_t* mask,
+                        int32_t* keep_index, int32_t* group_begin_out, int64_t* n_keep, int64_t* n_showers_out);
 int nrhip_gather_groups(nrhip_ctx* ctx, int64_t n_keep, const int32_t* keep_index, const int32_t* group_begin,
                         const int32_t* group_begin_out, const double* vertex, const double* zenith, const double* azimuth,
                         const double* energy, const int32_t* shower_type, const double* k_L, const double* vertex_time,

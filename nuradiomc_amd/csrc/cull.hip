@@ -33,6 +33,19 @@ __global__ void cull_flag_kernel(long n_groups, const int* __restrict__ group_be
     size[g] = any ? (int)(b - a) : 0;
 }
 
+// the same lists for the groups whose flag is set in a device mask (the triggered groups of a survey: pass 2)
+__global__ void mask_flag_kernel(long n_groups, const int* __restrict__ group_begin, const unsigned char* __restrict__ mask,
+                                 int* __restrict__ flag, int* __restrict__ size)
+{
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_groups) return;
+    if (g == n_groups) { flag[g] = 0; size[g] = 0; return; }
+    const long a = group_begin ? group_begin[g] : g, b = group_begin ? group_begin[g + 1] : g + 1;
+    const int any = mask[g] ? 1 : 0;
+    flag[g] = any;
+    size[g] = any ? (int)(b - a) : 0;
+}
+
 __global__ void cull_scatter_kernel(long n_groups, const int* __restrict__ flag, const int* __restrict__ offset,
                                     const int* __restrict__ shower_offset, int* __restrict__ keep_index,
                                     int* __restrict__ group_begin_out)
@@ -109,6 +122,36 @@ int nrhip_cull_groups(nrhip_ctx* ctx, int64_t n_showers, int64_t n_groups, const
     int *size = flag + n1, *off = size + n1, *soff = off + n1, *tmp = soff + n1, *tmp2 = tmp + scan_tiles(n1);
     hipLaunchKernelGGL(cull_flag_kernel, dim3(blocks(n1)), dim3(256), 0, s, (long)n_groups, group_begin, vertex, max_distance,
                        centre[0], centre[1], centre[2], radius, flag, size);
+    launch_exclusive_scan(s, n1, flag, off, tmp);
+    launch_exclusive_scan(s, n1, size, soff, tmp2);
+    hipLaunchKernelGGL(cull_scatter_kernel, dim3(blocks(n1)), dim3(256), 0, s, (long)n_groups, flag, off, soff, keep_index,
+                       group_begin_out);
+    HIPCHK(hipGetLastError());
+    int h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&h[0], off + n_groups, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&h[1], soff + n_groups, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *n_keep = h[0];
+    *n_showers_out = h[1];
+    return 0;
+}
+
+int nrhip_select_groups(nrhip_ctx* ctx, int64_t n_showers, int64_t n_groups, const int32_t* group_begin, const uint8_t* mask,
+                        int32_t* keep_index, int32_t* group_begin_out, int64_t* n_keep, int64_t* n_showers_out)
+{
+    if (!ctx || !mask || !keep_index || !group_begin_out || !n_keep || !n_showers_out)
+        return nrhip_fail_msg("nrhip_select_groups: NULL argument");
+    if (n_showers < 0 || n_groups < 0 || n_groups > n_showers || (!group_begin && n_groups != n_showers))
+        return nrhip_fail_msg("nrhip_select_groups: bad sizes");
+    *n_keep = *n_showers_out = 0;
+    if (n_groups == 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const long n1 = n_groups + 1;
+    HIPCHK(ctx->cull_ws.reserve(sizeof(int) * (size_t)(4 * n1 + 2 * scan_tiles(n1) + 16)));
+    int* flag = ctx->cull_ws.as<int>();
+    int *size = flag + n1, *off = size + n1, *soff = off + n1, *tmp = soff + n1, *tmp2 = tmp + scan_tiles(n1);
+    hipLaunchKernelGGL(mask_flag_kernel, dim3(blocks(n1)), dim3(256), 0, s, (long)n_groups, group_begin, mask, flag, size);
     launch_exclusive_scan(s, n1, flag, off, tmp);
     launch_exclusive_scan(s, n1, size, soff, tmp2);
     hipLaunchKernelGGL(cull_scatter_kernel, dim3(blocks(n1)), dim3(256), 0, s, (long)n_groups, flag, off, soff, keep_index,

@@ -792,15 +792,15 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     const bool envelope = cfg->trigger_type == NRHIP_TRIG_ENVELOPE;
     const bool noise = cfg->noise != 0;
     if (noise && !st->noise_set) return nrhip_fail_msg("nrhip_simulate_events: noise needs the per-channel amplitudes (nrhip_station_set_noise)");
-    if (noise && (cfg->amp_per_ray || phased))
-        return nrhip_fail_msg("nrhip_simulate_events: noise is not available together with amp_per_ray or the phased-array trigger");
+    if (noise && cfg->amp_per_ray)
+        return nrhip_fail_msg("nrhip_simulate_events: noise is not available together with amp_per_ray");
     if (envelope && !st->env_set)
         return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger needs its band pass (nrhip_station_set_envelope_trigger)");
     if (envelope && (sd.ant_tabs || cfg->amp_per_ray))
         return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger is not available with tabulated antenna patterns or amp_per_ray");
     if (phased && st->pa_n_channels <= 0)
         return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger needs its channels and beams (nrhip_station_set_phased_array)");
-    if (phased && (general || cfg->amp_per_ray)) return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger runs on the parametrised path only (no ARZ / birefringence / amp_per_ray)");
+    if (phased && cfg->amp_per_ray) return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger is not available together with amp_per_ray");
     for (auto& e : st->evt) if (!e) HIPCHK(hipEventCreate(&e));
 #define MARK(i) HIPCHK(hipEventRecord(st->evt[i], sm))
     MARK(0);
@@ -1348,7 +1348,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         // than FFT_MAX samples, tabulated antenna patterns, the general path) the channel stage only produces the traces and
         // trace_trigger_kernel decides on them
         const bool post_trigger = trg.coincidence() && !phased &&
-                                  (maxL > FFT_MAX || sd.N > FFT_MAX / 2 || getenv("NRHIP_CHANNEL_CZT") || sd.ant_tabs || general || envelope || noise);
+                                  (maxL > FFT_MAX || sd.N > FFT_MAX / 2 || sd.np.log2nh < 0 || getenv("NRHIP_CHANNEL_CZT") || sd.ant_tabs ||
+                                   general || envelope || noise);
         TriggerDev trg_ch = trg;
         if (post_trigger) {
             trg_ch.type = 0;

@@ -526,6 +526,11 @@ class Station:
         return int(self._lib.nrhip_station_release_workspace(self._h)) if getattr(self, '_h', None) else 0
 
     def close(self):
+        sc = getattr(self, '_pass2', None)
+        if sc is not None and getattr(self.ctx, '_h', None):
+            for q in sc['p']:
+                self.ctx.free(q)
+        self._pass2 = None
         if getattr(self, '_h', None):
             self._lib.nrhip_station_destroy(self._h)
             self._h = None
@@ -585,6 +590,46 @@ class Station:
             d_vertex_time, d_max_distance, int(n_events if n_groups is None else n_groups), d_group_begin, d_triggered,
             ctypes.byref(stats) if want_stats else None))
         return stats.as_dict() if want_stats else None
+
+    def triggered_pass_dev(self, n_events, d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL, d_triggered, n_groups=None,
+                           d_group_begin=None, d_vertex_time=None, d_max_distance=None, amp_per_ray=False, **kw):
+        """Pass 2 of a survey without a host round trip of the list: the showers of the event groups flagged in the DEVICE mask
+        d_triggered (what simulate_events_dev left there) are gathered into a compact list in HBM (nrhip_select_groups /
+        nrhip_gather_groups) and run again with dump_traces -- every channel of every candidate event is evaluated and its trace
+        kept, which is what the reference stores for triggered events (output_writer_hdf5.py:215-320; amp_per_ray adds the
+        per-ray envelope maxima).  Afterwards fetch('trace'), fetch('trace_offset'), fetch('item_event'), fetch('ev_trigger_bin'),
+        ... describe the compact list; returns (stats of the pass, d_keep_index: DEVICE int32 [n_selected] original group of every
+        compact group, n_selected).  The compact copies live in a scratch owned by the station (grown on demand)."""
+        from . import comm as _comm   # (registers the signatures of the list helpers)
+        ctx, lib = self.ctx, self._lib
+        n_groups = int(n_events if n_groups is None else n_groups)
+        sc = getattr(self, '_pass2', None)
+        if sc is None or sc['n'] < n_events or sc['g'] < n_groups:
+            if sc is not None:
+                for q in sc['p']:
+                    ctx.free(q)
+            cap_n, cap_g = int(n_events), int(n_groups)
+            vp = ctx.malloc
+            ptrs = [vp(24 * cap_n), vp(8 * cap_n), vp(8 * cap_n), vp(8 * cap_n), vp(4 * cap_n), vp(8 * cap_n), vp(8 * cap_n),
+                    vp(8 * cap_n), vp(4 * cap_g), vp(4 * (cap_g + 1)), vp(max(cap_g, 1))]
+            sc = self._pass2 = dict(n=cap_n, g=cap_g, p=ptrs)
+        (s_vertex, s_zen, s_az, s_en, s_type, s_kL, s_md, s_vt, s_keep, s_gb, s_trig) = sc['p']
+        nk, ns = ctypes.c_int64(0), ctypes.c_int64(0)
+        L.check(lib.nrhip_select_groups(ctx._h, int(n_events), n_groups, d_group_begin, ctypes.c_void_p(d_triggered), s_keep, s_gb,
+                                        ctypes.byref(nk), ctypes.byref(ns)))
+        nk, ns = int(nk.value), int(ns.value)
+        if nk == 0:
+            return None, s_keep, 0
+        L.check(lib.nrhip_gather_groups(ctx._h, nk, s_keep, d_group_begin, s_gb, d_vertex, d_zenith, d_azimuth, d_energy, d_type,
+                                        d_kL, d_vertex_time, d_max_distance, s_vertex, s_zen, s_az, s_en, s_type, s_kL,
+                                        s_vt if d_vertex_time is not None else None, s_md if d_max_distance is not None else None,
+                                        None))
+        stats = self.simulate_events_dev(ns, s_vertex, s_zen, s_az, s_en, s_type, s_kL, s_trig, dump_traces=True,
+                                         amp_per_ray=amp_per_ray, n_groups=nk,
+                                         d_group_begin=s_gb if d_group_begin is not None else None,
+                                         d_vertex_time=s_vt if d_vertex_time is not None else None,
+                                         d_max_distance=s_md if d_max_distance is not None else None, **kw)
+        return stats, s_keep, nk
 
     def simulate_events(self, vertex, zenith, azimuth, energy, shower_type, k_L=None, vertex_time=None, group_id=None,
                         distance_cut_coefficients=None, distance_cut_sum_length=10., arz_iN=None, max_showers_per_call=None,
@@ -768,6 +813,13 @@ class Station:
                      'slot_n_segments': np.int32, 'slot_surface_mask': np.int32, 'ev_group': np.int32, 'ev_sub_event': np.int32,
                      'ev_triggered': np.uint8, 'ray_sub_event': np.int32, 'group_n_sub_events': np.int32,
                      'pa_digital_length': np.int32, 'ray_propagated': np.int32, 'gen_n_steps': np.int32}
+
+    def fetch_bytes(self, name):
+        """size in bytes of a table of the last simulated batch (nothing is copied)"""
+        n = self._lib.nrhip_sim_fetch(self._h, name.encode(), None, 0)
+        if n < 0:
+            raise L.NrhipError(self._lib.nrhip_last_error().decode())
+        return int(n)
 
     def fetch(self, name):
         """One table of the last simulated batch as a numpy array (see include/nrhip.h: nrhip_sim_fetch)."""

@@ -841,8 +841,8 @@ def test_focusing_batched(gpu_ctx_factory):
     assert np.array_equal(trig_p, trig)
 
 
-@pytest.mark.parametrize('mode', ['birefringence', 'arz', 'arz+birefringence'])
-def test_general_path_arz_birefringence(gpu_ctx_factory, mode):
+@pytest.mark.parametrize('mode,N', [('birefringence', 512), ('arz', 512), ('arz+birefringence', 512), ('arz+birefringence', 640)])
+def test_general_path_arz_birefringence(gpu_ctx_factory, mode, N):
     """BASELINE config 4 inside simulate_events: time-domain ARZ2020 emission and / or birefringent propagation.  The GPU
     materialises the on-sky spectra and traces of every kept ray; compared with the oracle's chain (pinned against the
     reference piece by piece: ARZ traces, birefringent propagation, efield -> voltage) on identical ray tables: ray spectra,
@@ -852,7 +852,7 @@ def test_general_path_arz_birefringence(gpu_ctx_factory, mode):
     from test_oracle_golden import _arz_library
     g = golden('chain_N256.npz')
     ice = g['ice']
-    N, fs = 512, 2.0
+    fs = 2.0   # (N = 640: a trace length that is no power of two -- Bluestein transforms in the spectrum / trace / channel kernels)
     ctx = gpu_ctx_factory(ice, 'SP1')
     pos = g['det_pos']
     st = nuradiomc_amd.Station(ctx, pos, n_samples=N, sampling_rate=fs)
@@ -1061,6 +1061,112 @@ def test_phased_array_trigger(gpu_ctx_factory):
         st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold)
     with pytest.raises(NotImplementedError):
         st.set_phased_array([0, 5], angles)
+
+
+@pytest.mark.parametrize('mode', ['noise', 'general', 'general+noise', 'general+noise+adc'])
+def test_phased_array_with_noise_and_on_the_general_path(gpu_ctx_factory, mode):
+    """What an RNO-G station triggers on (phasedArrayBase.py:370-496 after simulation.apply_det_response :594-606): the phased
+    array on four deep dipoles WITH thermal noise, on the parametrised path and on the general path (ARZ2020 emission +
+    birefringent propagation, BASELINE configs[3]).  Beam powers and decisions vs the oracle's array core applied to the
+    oracle's (noisy) channel traces of the same rays; traces 1e-6 (3e-5 with birefringence) of the largest sample.  '+adc': the
+    8-bit 472 MHz trigger ADC with 4 x FFT up-sampling in front of the beams (digitised traces, powers and decisions vs the
+    oracle's ADC chain on the dumped traces: counts equal sample by sample)."""
+    from nuradiomc_amd import arz as arz_mod
+    from oracle import arz_oracle
+    from test_oracle_golden import _arz_library
+    ice = (1.78, 0.423, 77.)
+    pos = np.array([[0., 0., -96.], [0., 0., -97.], [0., 0., -98.], [0., 0., -99.], [0., 0., -60.], [20., 15., -95.]])
+    cable = np.array([1.2, 0., 2.6, 0.7, 0., 3.])
+    N, fs = 512, 2.0
+    ctx = gpu_ctx_factory(ice, 'SP1')
+    st = nuradiomc_amd.Station(ctx, pos, cable_delay=cable, n_samples=N, sampling_rate=fs)
+    ost = so.Station(pos, cable_delay=cable, n_samples=N, fs=fs)
+    vrms, vrms_e = so.vrms_from_filters(fs)
+    angles = np.arcsin(np.linspace(np.sin(-60 * np.pi / 180), np.sin(60 * np.pi / 180), 11))
+    window, step = 32, 16
+    adc = 'adc' in mode
+    adc_fs, nbits, ncount, up = 0.472, 8, 5, 4
+    if adc:
+        window, step = 24, 8
+        rolls = st.set_phased_array([0, 1, 2, 3], angles, ref_index=1.75, window=window, step=step, upsampling_factor=up,
+                                    adc=dict(sampling_frequency=adc_fs, n_bits=nbits, noise_count=ncount, output='counts'))
+        threshold = 2.5 * (2 * ncount) ** 2
+    else:
+        rolls = st.set_phased_array([0, 1, 2, 3], angles, ref_index=1.75, window=window, step=step)
+        threshold = 2.5 * (2 * vrms) ** 2
+    rng = np.random.default_rng(15)
+    n = 70
+    r, ph = np.sqrt(rng.uniform(0, 1100. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    v = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1300., -120., n)], axis=1)
+    zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    en = 10 ** rng.uniform(17.2, 18.5, n)
+    types = np.array(['HAD'] * n)
+    general, noisy = 'general' in mode, 'noise' in mode
+    kw, model, bire, oarz, iN, tol = {}, 'Alvarez2009', None, None, np.zeros(n, int), 2e-6
+    if general:
+        b = golden('ref_birefringence.npz')
+        tck = [(b['tck_southpole_A_%d_t' % j], b['tck_southpole_A_%d_c' % j]) for j in range(3)]
+        st.set_birefringence(tck, angle_to_iceflow=25.)
+        bire = (tck, 25.)
+        lib = _arz_library(golden('ref_arz.npz'))
+        a = arz_mod.ARZ(seed=3, library=lib)
+        st.set_arz(a)
+        iN = a.draw_profile_numbers(en, list(types))
+        model, kw, tol = 'ARZ2020', dict(arz_iN=iN), 3e-5
+        oarz = arz_oracle.ARZ(lib, seed=3)
+    amp = None
+    ids = 500 + 7 * np.arange(n)
+    if noisy:
+        amp = st.set_noise(300.)
+        kw.update(noise=True, noise_seed=77, group_id=ids)
+    trig, stats = st.simulate_events(v, zen, az, en, types, 1.0, askaryan_model=model, trigger='phased_array',
+                                     trigger_threshold=threshold, dump_traces=True, **kw)
+    T = {k: st.fetch(k) for k in ('pair_n_sol', 'slot_type', 'slot_C0', 'slot_D', 'slot_T', 'slot_launch', 'slot_receive',
+                                  'slot_refl_angle', 'ev_candidate', 'ev_L')}
+    item_event = st.fetch('item_event')
+    pa_max = st.fetch('pa_max_power').reshape(len(item_event), len(angles))
+    toff, trace = st.fetch('trace_offset'), st.fetch('trace')
+    n_ch = len(pos)
+    n_cand = n_trig = 0
+    for ev in range(n):
+        ps, ss = slice(ev * n_ch, (ev + 1) * n_ch), slice(ev * n_ch * 2, (ev + 1) * n_ch * 2)
+        rays = dict(n_sol=T['pair_n_sol'][ps], type=T['slot_type'][ss].reshape(n_ch, 2), C0=T['slot_C0'][ss].reshape(n_ch, 2),
+                    D=T['slot_D'][ss].reshape(n_ch, 2), T=T['slot_T'][ss].reshape(n_ch, 2),
+                    refl_angle=T['slot_refl_angle'][ss].reshape(n_ch, 2),
+                    launch=T['slot_launch'][ev * n_ch * 6:(ev + 1) * n_ch * 6].reshape(n_ch, 2, 3),
+                    receive=T['slot_receive'][ev * n_ch * 6:(ev + 1) * n_ch * 6].reshape(n_ch, 2, 3))
+        o = so.simulate_event(v[ev], zen[ev], az[ev], en[ev], 'HAD', 1.0, ost, ice, vrms, vrms_e, model=model, rays=rays,
+                              arz=(oarz, int(iN[ev])) if oarz else None, birefringence=bire,
+                              noise=(77, int(ids[ev]), 0, amp) if noisy else None)
+        assert o['candidate'] == bool(T['ev_candidate'][ev]), ev
+        if not o['candidate']:
+            assert not trig[ev]
+            continue
+        n_cand += 1
+        i = int(np.where(item_event == ev)[0][0])
+        scale = np.max(np.abs(o['V']))
+        for ch in range(4):
+            tr = trace[toff[i * n_ch + ch]:toff[i * n_ch + ch + 1]]
+            assert len(tr) == o['L'] and np.max(np.abs(tr - o['V'][ch])) <= tol * scale + (1e-9 * vrms if noisy else 0.), (ev, ch)
+        if adc:   # the ADC chain on the traces the GPU dumped (a count flips with the last bit of a sample otherwise)
+            Vg = np.array([trace[toff[i * n_ch + c]:toff[i * n_ch + c + 1]] for c in range(4)])
+            U = np.array([so.digital_upsampling_fft(so.adc_digital_trace(x, fs, adc_fs, nbits, vrms, ncount, 'counts'), up) for x in Vg])
+            p = so.phased_array_power_digital(U, rolls, window, step, 'counts')
+            mx = p.max(axis=1)
+            assert np.max(np.abs(pa_max[i] - mx)) <= 1e-9 * np.max(mx), ev
+            t = bool(np.any(p > np.trunc(threshold)))
+            assert t == bool(trig[ev]), ev
+        else:
+            t, mx = so.phased_array_trigger(o['V'][:4], rolls, window, step, threshold)
+            assert np.max(np.abs(pa_max[i] - mx)) <= 10 * tol * np.max(mx), ev
+            if np.min(np.abs(mx - threshold)) > 10 * tol * threshold:
+                assert t == bool(trig[ev]), ev
+        n_trig += t
+    assert n_cand >= 8 and 2 <= n_trig
+    # production mode (no dump): the same mask
+    trig_p, _ = st.simulate_events(v, zen, az, en, types, 1.0, askaryan_model=model, trigger='phased_array',
+                                   trigger_threshold=threshold, **kw)
+    assert np.array_equal(trig_p, trig)
 
 
 @pytest.mark.parametrize('kw', [dict(), dict(trigger='high_low', n_coincidences=2, coinc_window=80.)])

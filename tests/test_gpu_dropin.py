@@ -178,12 +178,13 @@ class _FakeDet:
 @pytest.mark.parametrize('antenna,cable', [('analytic_VPol', [0.] * 5), ('analytic_HPol', [0., 3.3, 7.77, 12.2, 19.8]),
                                            ('analytic_LPDA', [0., 0., 4.4, 0., 1.1]),
                                            ('synthetic_table_v1', [0., 2.2, 0., 0., 5.5])])
-def test_efieldToVoltageConverter_module(antenna, cable):
+@pytest.mark.parametrize('N', [256, 300])
+def test_efieldToVoltageConverter_module(antenna, cable, N):
     """The module-level drop-in on arbitrary ElectricField-like objects vs the oracle's restatement of
     efieldToVoltageConverter.run (no filter), incl. the sub-sample Fourier shift (unequal cable delays)."""
     from nuradiomc_amd import modules
     from oracle import spectral_oracle as so
-    N, fs = 256, 2.0
+    fs = 2.0   # (N = 300: no power of two)
     pos = np.array([[0., 0., -100. - i] for i in range(5)])
     ice = (1.78, 0.423, 77.)
     import nuradiomc_amd

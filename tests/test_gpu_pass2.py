@@ -1,0 +1,40 @@
+"""Pass 2 on the device (Station.triggered_pass_dev): the triggered groups of a resident list are gathered in HBM and run again
+with every channel trace kept -- same traces, trigger bins and selection as the host-side pass 2 of nuradiomc_amd.output
+(re-upload of the triggered showers, dump_traces)."""
+import numpy as np
+import pytest
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('flavour', ['had', 'mixed'])
+def test_device_pass2_equals_host_pass2(gpu_ctx_factory, flavour):
+    n = 40000
+    wl = bench.make_workload(2, n, 10, flavour)
+    ctx = gpu_ctx_factory(wl['ice'], wl['att_model'])
+    st = bench.build_array(ctx, wl)
+    d = bench.upload_events(ctx, wl)
+    try:
+        s1 = st.simulate_events_dev(d['n'], *d['in'], d['trig'], n_groups=d['n_groups'], d_group_begin=d['gb'])
+        mask = np.zeros(d['n_groups'], np.uint8)
+        ctx.to_host(mask, d['trig'])
+        assert mask.sum() == s1['n_triggered'] > 100
+        s2, d_keep, nk = st.triggered_pass_dev(d['n'], *d['in'], d['trig'], n_groups=d['n_groups'], d_group_begin=d['gb'])
+        assert nk == mask.sum() and s2['n_events'] == nk and s2['n_triggered'] == nk   # every selected group triggers again
+        keep = np.zeros(nk, np.int32)
+        ctx.to_host(keep, d_keep)
+        assert np.array_equal(keep, np.flatnonzero(mask))
+        A = {k: st.fetch(k).copy() for k in ('item_event', 'trace', 'trace_offset', 'ev_trigger_bin', 'ev_L', 'ev_t_min')}
+    finally:
+        bench.free_events(ctx, d)
+    # host-side pass 2: the triggered showers uploaded again
+    ev = wl['events']
+    rows = np.flatnonzero(np.isin(ev['group'], keep))
+    t2, _ = st.simulate_events(ev['vertex'][rows], ev['zenith'][rows], ev['azimuth'][rows], ev['energy'][rows], ev['shower_type'][rows],
+                               ev['k_L'][rows], group_id=ev['group'][rows], dump_traces=True)
+    assert t2.all()
+    for k, v in A.items():
+        assert np.array_equal(v, st.fetch(k)), k
+    assert len(A['trace']) > 5 * 4096 * nk * 0.5
