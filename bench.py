@@ -74,8 +74,11 @@ def _mixed_showers(n_groups, seed, vertex, zenith, azimuth, e_nu):
     return dict(vertex=vertex[grp], zenith=zenith[grp], azimuth=azimuth[grp], energy=en, shower_type=typ, k_L=kL, group=grp)
 
 
-def make_workload(config=2, n=1000000, seed=10, flavour='had'):
-    """The synthetic inputs and detector of one BASELINE configuration (n event groups)."""
+def make_workload(config=2, n=1000000, seed=10, flavour='had', trigger='threshold'):
+    """The synthetic inputs and detector of one BASELINE configuration (n event groups).  trigger (configs 3 / 4, the RNO-G like
+    array): 'threshold' = 3 Vrms on any channel (rounds 1-2), 'pa' = the phased array on the four deep dipoles of the power
+    string (11 beams, 16-sample windows, phasedArrayBase.py), 'pa_adc_noise' = the same behind the 8-bit 472 MHz trigger ADC with
+    4 x FFT up-sampling and with thermal noise on every channel -- what an RNO-G station triggers on."""
     d = np.pi / 180
     wl = dict(config=config, n=n, seed=seed, N=N_SAMPLES, fs=FS, centres=None, sim_kw={}, flavour=flavour)
     if config == 2:
@@ -103,6 +106,10 @@ def make_workload(config=2, n=1000000, seed=10, flavour='had'):
                       "emission + birefringence greenland_A, speedup.distance_cut, 4096 samples @ 2 GHz, 3 Vrms threshold" % n)
         if config == 4:
             wl['sim_kw'] = dict(askaryan_model='ARZ2020')
+        wl['trigger'] = trigger
+        if trigger != 'threshold':
+            wl['name'] = wl['name'].replace('3 Vrms threshold on any channel', '').replace('3 Vrms threshold', '').rstrip(', ') + \
+                ', trigger: phased array on the 4 deep dipoles' + (' with 8-bit 472 MHz trigger ADC, 4x up-sampling and thermal noise' if trigger == 'pa_adc_noise' else '')
         e_nu = 1e18
     elif config == 5:
         n_st, spacing = 200, 1240.
@@ -151,6 +158,18 @@ def build_array(ctx, wl):
     c0 = np.zeros(3) if wl['centres'] is None else wl['centres'][0]
     st = nuradiomc_amd.Station(ctx, wl['rel_pos'] + c0, antenna=wl['antenna'], orientation=wl['orientation'],
                                cable_delay=wl['cable_delay'], n_samples=wl['N'], sampling_rate=wl['fs'], n_freq=25)
+    trig = wl.get('trigger', 'threshold')
+    if trig in ('pa', 'pa_adc_noise'):
+        ang = np.arcsin(np.linspace(np.sin(-60 * np.pi / 180), np.sin(60 * np.pi / 180), 11))
+        if trig == 'pa':
+            st.set_phased_array([0, 1, 2, 3], ang, window=16, step=8)
+            wl['sim_kw'] = dict(wl['sim_kw'], trigger='phased_array', trigger_threshold=2.0 * (2 * st.vrms) ** 2)
+        else:
+            st.set_phased_array([0, 1, 2, 3], ang, window=24, step=8, upsampling_factor=4,
+                                adc=dict(sampling_frequency=0.472, n_bits=8, noise_count=5, output='counts'))
+            st.set_noise(300.)
+            # mean noise power of the coherent sum: 4 channels x (5 counts)^2; 6 x that keeps noise-only windows below ~1e-2 per event
+            wl['sim_kw'] = dict(wl['sim_kw'], trigger='phased_array', trigger_threshold=6.0 * (2 * 5) ** 2, noise=True, noise_seed=1235)
     if wl['config'] == 4:
         from nuradiomc_amd import arz as arz_mod
         st.set_birefringence(birefringence_splines(), angle_to_iceflow=None)
@@ -350,6 +369,9 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=25., help='seconds of CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--device', type=int, default=None, help='GPU index of this rank (default: LOCAL_RANK)')
+    ap.add_argument('--trigger', default='threshold', choices=['threshold', 'pa', 'pa_adc_noise'],
+                    help='configs 3 / 4: threshold on any channel, or the phased array on the four deep dipoles (optionally with the '
+                         'trigger ADC and thermal noise)')
     ap.add_argument('--no-traces', action='store_true', help='config 2: time pass 1 only (trigger mask), without the second pass that '
                     'keeps the channel traces of the triggered events')
     ap.add_argument('--allow-tcp', action='store_true', help='if RCCL does not come up on every rank: run the collectives over the TCP '
@@ -367,10 +389,10 @@ def main():
     from nuradiomc_amd import comm as nrcomm
     rank, local_rank, world = nrcomm.env_rank()
     if args.scaling == 'strong':
-        wl = make_workload(cfgno, args.events, 10, args.flavour)
+        wl = make_workload(cfgno, args.events, 10, args.flavour, args.trigger)
         g0, g1 = nrcomm.shard_range(args.events, rank, world)
     else:
-        wl = make_workload(cfgno, args.events, 10 + rank, args.flavour)
+        wl = make_workload(cfgno, args.events, 10 + rank, args.flavour, args.trigger)
         g0, g1 = 0, args.events
     ctx = nuradiomc_amd.Context(wl['ice'], wl['att_model'], device=local_rank if args.device is None else args.device)
     comm = nrcomm.Comm(ctx, rank, world, allow_tcp=True if args.allow_tcp else None)
@@ -508,7 +530,9 @@ def main():
                                     "algorithmic_flops_per_launch": stats['n_integrand_evals'] * flop_per_eval,
                                     "hbm_view_GBs": achieved})
         out["cpu_baseline"] = None
-        if world == 1 and not args.no_cpu_baseline and cfgno == 4:
+        if args.trigger != 'threshold':
+            pass   # (the oracle legs below run the threshold trigger; the phased-array lines are GPU-only, pinned by tests/test_gpu_chain.py)
+        elif world == 1 and not args.no_cpu_baseline and cfgno == 4:
             # the oracle needs minutes per central event group here: the check is per (event group, station) -- the per-station masks
             # of one more GPU pass against the oracle's single-station runs
             n_st = len(wl['centres'])
@@ -529,7 +553,7 @@ def main():
             ctx.to_host(host_mask, d['trig'])
             mism = int(np.sum(host_mask[:n_done] != flags))
             base['parity_check'] = "GPU trigger mask == oracle on the %d sampled event groups: %d mismatches" % (n_done, mism)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.trigger == 'threshold':
             out["cpu_baseline"] = base
             if mism:
                 print(json.dumps(out, default=_json_default))

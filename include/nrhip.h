@@ -594,6 +594,9 @@ int nrhip_gather_groups(nrhip_ctx* ctx, int64_t n_keep, const int32_t* keep_inde
                         int32_t* o_shower_type, double* o_k_L, double* o_vertex_time, double* o_max_distance,
                         int32_t* shower_index);
 int nrhip_mask_scatter_or(nrhip_ctx* ctx, int64_t n, const int32_t* index, const uint8_t* src, uint8_t* dst);
+/* out[k] = offset + index[k] (index NULL: offset + k) as DEV int64: the original group ids of a gathered list, e.g. for
+ * nrhip_sim_config.noise_group_id (the noise of an event group must not depend on which compact list it travels in) */
+int nrhip_index_to_i64(nrhip_ctx* ctx, int64_t n, const int32_t* index, int64_t offset, int64_t* out);
 
 /* dst[i] = overwrite ? src[i] : dst[i] | src[i] on DEV uint8 masks (event-group mask of an array = OR over its stations) */
 int nrhip_mask_or(nrhip_ctx* ctx, int64_t n, uint8_t* dst, const uint8_t* src, int32_t overwrite);

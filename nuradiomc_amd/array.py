@@ -32,10 +32,11 @@ class _Scratch:
         self.type, self.kL, self.md = vp(4 * n), vp(8 * n), vp(8 * n)
         self.vt = vp(8 * n) if with_time else None
         self.keep, self.gb, self.sidx, self.trig = vp(4 * n_groups), vp(4 * (n_groups + 1)), vp(4 * n), vp(max(n_groups, 1))
+        self.gid64 = vp(8 * max(n_groups, 1))    # original group ids of the compact list (keys of the thermal noise)
 
     def free(self):
         for p in (self.vertex, self.zenith, self.azimuth, self.energy, self.type, self.kL, self.md, self.vt, self.keep, self.gb,
-                  self.sidx, self.trig):
+                  self.sidx, self.trig, self.gid64):
             if p is not None:
                 self.ctx.free(p)
 
@@ -83,6 +84,8 @@ class StationArray:
         n_groups = int(dev_kw.get('n_groups') or n)
         d_md, d_gb, d_vt = dev_kw.get('d_max_distance'), dev_kw.get('d_group_begin'), dev_kw.get('d_vertex_time')
         self.last_keep_index = None
+        if kw.get('noise'):   # every station its own noise stream; keyed by the ORIGINAL group ids whatever list the group travels in
+            kw = dict(kw, noise_seed=(int(kw.get('noise_seed', 0)) + 0x9E3779B97F4A7C15 * (i + 1)) & 0xffffffffffffffff)
         if scratch is None or d_md is None:
             if arz_rows is not None:
                 L.check(lib.nrhip_station_set_shower_profiles(st._h, n, L.iptr(arz_rows[0]), L.dptr(arz_rows[1])))
@@ -114,6 +117,9 @@ class StationArray:
             L.check(lib.nrhip_station_set_shower_profiles(st._h, ns, L.iptr(rows), L.dptr(resc)))
         sub_kw = dict(dev_kw, d_max_distance=scratch.md, n_groups=nk, d_group_begin=scratch.gb if d_gb is not None else None,
                       d_vertex_time=scratch.vt if d_vt is not None else None)
+        if kw.get('noise') and kw.get('d_noise_group_id') is None:
+            L.check(lib.nrhip_index_to_i64(ctx._h, nk, scratch.keep, int(kw.get('noise_group_offset', 0)), scratch.gid64))
+            kw = dict(kw, d_noise_group_id=scratch.gid64)
         s_ = st.simulate_events_dev(ns, scratch.vertex, scratch.zenith, scratch.azimuth, scratch.energy, scratch.type, scratch.kL,
                                     scratch.trig, **sub_kw, **kw)
         if not kw.get('select_only'):
@@ -150,7 +156,10 @@ class StationArray:
                     self._move(i)
                     if arz_rows is not None:
                         L.check(lib.nrhip_station_set_shower_profiles(st._h, n, L.iptr(arz_rows[0]), L.dptr(arz_rows[1])))
-                    s_ = st.simulate_events_dev(n, *d_in, tgt, accumulate_triggered=True, want_stats=want, **dev_kw, **kw)
+                    kw_i = kw
+                    if kw.get('noise'):   # every station its own noise stream
+                        kw_i = dict(kw, noise_seed=(int(kw.get('noise_seed', 0)) + 0x9E3779B97F4A7C15 * (i + 1)) & 0xffffffffffffffff)
+                    s_ = st.simulate_events_dev(n, *d_in, tgt, accumulate_triggered=True, want_stats=want, **dev_kw, **kw_i)
                 if d_station_triggered is not None:
                     L.check(lib.nrhip_mask_or(ctx._h, n_groups, ctypes.c_void_p(d_triggered), ctypes.c_void_p(tgt), 0))
                 if s_ is None:

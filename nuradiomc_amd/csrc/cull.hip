@@ -97,6 +97,12 @@ __global__ void mask_scatter_or_kernel(long n, const int* __restrict__ index, co
     if (k < n && src[k]) dst[index[k]] = 1;
 }
 
+__global__ void index_to_i64_kernel(long n, const int* __restrict__ index, long long offset, long long* __restrict__ out)
+{
+    long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = offset + (index ? (long long)index[k] : (long long)k);
+}
+
 inline unsigned blocks(long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -179,6 +185,16 @@ int nrhip_gather_groups(nrhip_ctx* ctx, int64_t n_keep, const int32_t* keep_inde
     hipLaunchKernelGGL(gather_showers_kernel, dim3(blocks(n_keep)), dim3(256), 0, ctx->stream, (long)n_keep, keep_index,
                        group_begin, group_begin_out, vertex, zenith, azimuth, energy, shower_type, k_L, vertex_time, max_distance,
                        o_vertex, o_zenith, o_azimuth, o_energy, o_shower_type, o_k_L, o_vertex_time, o_max_distance, shower_index);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int nrhip_index_to_i64(nrhip_ctx* ctx, int64_t n, const int32_t* index, int64_t offset, int64_t* out)
+{
+    if (!ctx || (n > 0 && !out)) return nrhip_fail_msg("nrhip_index_to_i64: NULL argument");
+    if (n <= 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(index_to_i64_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, (long)n, index, (long long)offset, (long long*)out);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -100,11 +100,17 @@ def _check_vs_oracle(g, col, trig_st, kL, stations, groups, oracle_kw, tol=1e-6,
     return n_rays, n_cand, n_trig
 
 
-def _check_vs_reference(g, col, trig_st, amp_tol=5e-3, min_same=0.97):
-    """per (group, station): decisions equal to the reference's wherever it found the same number of rays"""
+def _check_vs_reference(g, col, trig_st, amp_tol=8e-4, min_same=0.99):
+    """per (group, station): decisions equal to the reference's wherever it found the same number of rays.  The bounds are 2 x the
+    observed maxima (round 3: ray counts differ on 0.36 % / 0.48 % / 0.08 % of the station-events of the config-3 / 4 / 5 fixtures --
+    a station-event has 24 / 24 / 5 channels, any of which may lose the reference's noisy first root --, channel maxima within
+    3.3e-4 / 3.8e-4 / 3.2e-4)"""
     n_groups, n_st = g['ev_n_rays'].shape
     n_rays = np.array([col.per[s]['ev_n_rays'] for s in range(n_st)]).T
     same = n_rays == g['ev_n_rays']
+    with_rays = (n_rays > 0) | (g['ev_n_rays'] > 0)
+    print('ray counts equal on %.4f of the (group, station) pairs, %.4f of those with rays (%d of %d)'
+          % (same.mean(), same[with_rays].mean(), same[with_rays].sum(), with_rays.sum()))
     assert same.mean() >= min_same, same.mean()
     cand = np.array([col.per[s]['ev_candidate'] for s in range(n_st)]).T.astype(bool)
     L = np.array([col.per[s]['ev_L'] for s in range(n_st)]).T
@@ -113,6 +119,7 @@ def _check_vs_reference(g, col, trig_st, amp_tol=5e-3, min_same=0.97):
     both = same & cand
     assert np.array_equal(L[both], g['ev_L'][both])
     n_amp = 0
+    worst = 0.
     for s in range(n_st):
         d = col.per[s]
         for it, gi in enumerate(d['item_event']):
@@ -120,8 +127,10 @@ def _check_vs_reference(g, col, trig_st, amp_tol=5e-3, min_same=0.97):
                 ref = g['ev_maxV'][gi, s]
                 got = np.abs(d['maxV'][it])
                 ok = np.isfinite(got)   # NaN: channel not evaluated after the event's first trigger (production mode only)
+                worst = max(worst, float(np.max(np.abs(got[ok] - ref[ok])) / np.max(ref)))
                 assert np.all(np.abs(got[ok] - ref[ok]) <= amp_tol * np.max(ref)), (gi, s)
                 n_amp += 1
+    print('channel maxima of %d candidate station-events: max |dV| / max V = %.2e (bound %.1e)' % (n_amp, worst, amp_tol))
     # the reference's full channel traces of a few triggered station-events
     for k, (gi, s) in enumerate(g['V_keys']):
         if not both[gi, s] or 'trace' not in col.per[s]:
@@ -150,7 +159,7 @@ def test_config3_rnog_array(gpu_ctx_factory):
                                       dump_traces=True, on_station=col)
     ts = stats['station_triggered']
     assert ts.shape == (n_st, n_groups) and np.array_equal(trig, ts.any(axis=0)) and stats['n_triggered'] == trig.sum()
-    same, both, n_amp = _check_vs_reference(g, col, ts)
+    same, both, n_amp = _check_vs_reference(g, col, ts, min_same=0.992)
     assert n_amp >= 30 and g['ev_triggered'].sum() >= 5
     # the event-group mask of the whole array vs the reference's (groups all of whose stations agree in the ray count)
     ok = same.all(axis=1)
@@ -197,7 +206,7 @@ def test_config4_rnog_array_arz_birefringence(gpu_ctx_factory):
     met = g['arz_iN'] >= 0
     assert met.sum() >= 8 and np.array_equal(iN[met], g['arz_iN'][met])
     ts = stats['station_triggered']
-    same, both, n_amp = _check_vs_reference(g, col, ts, amp_tol=1e-2, min_same=0.95)
+    same, both, n_amp = _check_vs_reference(g, col, ts, min_same=0.99)
     assert n_amp >= 4
     # oracle chain on the stations that saw rays, a subset of the groups (0.2 s per ray on the CPU)
     seen = np.flatnonzero(np.array([col.per[s]['ev_n_rays'].sum() for s in range(n_st)]) > 0)
@@ -237,7 +246,7 @@ def test_config5_gen2_array(gpu_ctx_factory):
     assert met.sum() >= 8
     assert np.array_equal(np.isfinite(kL) & em, met) and np.array_equal(kL[met], g['k_L'][met])   # the reference's stream, bit for bit
     ts = stats['station_triggered']
-    same, both, n_amp = _check_vs_reference(g, col, ts)
+    same, both, n_amp = _check_vs_reference(g, col, ts, min_same=0.998)
     assert n_amp >= 30 and g['ev_triggered'].sum() >= 10
     otrig = dict(trigger='high_low', n_coincidences=tk['n_coincidences'], threshold_high=tk['threshold_high'],
                  threshold_low=tk['threshold_low'], high_low_window=tk['high_low_window'], coinc_window=tk['coinc_window'])

@@ -275,7 +275,8 @@ def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
     g, ctx, st, trig, stats, kL = _run_fixture(gpu_ctx_factory, name, n_events)
     n_rays = st.fetch('ev_n_rays')
     same_rays = n_rays == g['ev_n_rays'][:n_events]
-    assert same_rays.mean() > 0.98
+    print(name, 'events with the reference\'s ray count: %d of %d' % (same_rays.sum(), n_events))
+    assert same_rays.mean() >= 0.99
     cand = st.fetch('ev_candidate').astype(bool)
     assert np.array_equal(cand[same_rays], g['ev_candidate'][:n_events][same_rays])
     assert np.array_equal(trig[same_rays], g['ev_triggered'][:n_events][same_rays])
@@ -284,10 +285,13 @@ def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
     assert np.array_equal(L[both], g['ev_L'][:n_events][both])
     item_event = st.fetch('item_event')
     maxV = st.fetch('item_maxV').reshape(len(item_event), -1)
+    worst = 0.
     for i, ev in enumerate(item_event):
         if both[ev]:
             ref = g['ev_maxV'][ev]
-            assert np.all(np.abs(maxV[i] - ref) <= 5e-3 * np.max(ref)), ev
+            worst = max(worst, float(np.max(np.abs(maxV[i] - ref)) / np.max(ref)))
+    print(name, 'channel maxima vs reference: max |dV| / max V = %.2e' % worst)
+    assert worst <= 6e-4   # observed <= 2.8e-4 on the eight fixtures (a 1e-7 shift of T is a 3e-3 rad phase at 500 MHz)
 
 
 @pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_lpda', 200), ('N256_tab', 160), ('N4096', 120), ('N256_hw', 220),
@@ -645,6 +649,7 @@ def test_amp_per_ray_solution(gpu_ctx_factory, name, n_events):
                      n_samples=int(g['N']), fs=float(g['fs']))
     vrms, vrms_e = st.vrms, st.vrms_efield
     n_checked = n_ref = 0
+    worst_ref = 0.
     for e in np.flatnonzero(cand):
         o = so.simulate_event(g['vertex'][e], g['zenith'][e], g['azimuth'][e], g['energy'][e], str(g['shower_type'][e]),
                               float(kL[e]), ost, g['ice'], vrms, vrms_e, filters=_oracle_filters(g))
@@ -656,8 +661,10 @@ def test_amp_per_ray_solution(gpu_ctx_factory, name, n_events):
             n_checked += 1
         ref = np.flatnonzero(g['ray_event'] == e)
         if len(ref) == len(mine):
-            assert np.all(np.abs(env[mine] - g['ray_max_amp_ray'][ref]) <= 5e-3 * g['ray_max_amp_ray'][ref])
+            worst_ref = max(worst_ref, float(np.max(np.abs(env[mine] - g['ray_max_amp_ray'][ref]) / g['ray_max_amp_ray'][ref])))
             n_ref += len(ref)
+    print(name, 'envelope maxima of %d rays vs reference: max rel %.2e' % (n_ref, worst_ref))
+    assert worst_ref <= 1.5e-3
     assert n_checked >= 30 and n_ref >= 25
 
 
@@ -1342,9 +1349,12 @@ def test_bottom_reflections_in_the_batched_path(gpu_ctx_factory):
     both = same & cand
     assert np.array_equal(T['ev_L'][both], g['ev_L'][:n][both])
     maxV = st.fetch('item_maxV').reshape(len(item_event), -1)
+    worst = 0.
     for i, ev in enumerate(item_event):
         if both[ev]:
-            assert np.all(np.abs(maxV[i] - g['ev_maxV'][ev]) <= 5e-3 * np.max(g['ev_maxV'][ev])), ev
+            worst = max(worst, float(np.max(np.abs(maxV[i] - g['ev_maxV'][ev])) / np.max(g['ev_maxV'][ev])))
+    print('Moore\'s Bay fixture, channel maxima vs reference: max |dV| / max V = %.2e' % worst)
+    assert worst <= 1.5e-3
     # production mode: the same masks; without reflections the direct / refracted / surface-reflected rays only
     ctx, st, refl, kL, trig_p, stats_p = _mb_run(gpu_ctx_factory, g, n)
     assert np.array_equal(trig_p, trig) and np.array_equal(st.fetch('ev_candidate'), T['ev_candidate'])

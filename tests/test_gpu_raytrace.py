@@ -8,7 +8,7 @@ from test_oracle_golden import _subset_ok
 pytestmark = pytest.mark.gpu
 
 
-def _compare_ray_tables(o, g, count_tol=0.005):
+def _compare_ray_tables(o, g, count_tol=0.003):
     """against the reference's outputs: the reference's own first-root noise applies (tests/test_oracle_golden.py)"""
     bad = o['n_sol'] != g['n_sol']
     assert bad.mean() <= count_tol, "solution-count mismatches: %d of %d" % (bad.sum(), len(bad))
@@ -16,15 +16,15 @@ def _compare_ray_tables(o, g, count_tol=0.005):
         assert _subset_ok(o['C0'][i], g['C0'][i])
     ok = ~bad
     assert np.array_equal(o['type'][ok], g['type'][ok])
-    assert max_rel(o['C0'][ok], g['C0'][ok]) < 1e-6
+    assert max_rel(o['C0'][ok], g['C0'][ok]) < 1.1e-7   # observed 5.2e-8
     for k in ('D', 'T'):
         rel = np.abs(o[k][ok] - g[k][ok]) / np.abs(g[k][ok])
         rel = rel[np.isfinite(rel)]
-        assert rel.max() < 1e-5 and (rel > 1e-6).mean() <= 0.002, k
+        assert rel.max() < 3e-6 and (rel > 1e-6).mean() <= 0.0026, k   # observed 1.4e-6 on 0.13 % of fixture C, 1.2e-7 elsewhere
     for k in ('launch', 'receive'):
         assert np.array_equal(np.isnan(o[k][ok]), np.isnan(g[k][ok]))
-        assert np.nanmax(np.abs(o[k][ok] - g[k][ok])) < 1e-6
-    assert np.nanmax(np.abs(o['C1'][ok] - g['C1'][ok])) < 1e-3
+        assert np.nanmax(np.abs(o[k][ok] - g[k][ok])) < 4e-7   # observed 1.8e-7
+    assert np.nanmax(np.abs(o['C1'][ok] - g['C1'][ok])) < 7.5e-4   # observed 3.5e-4 m
     assert max_rel(o['refl_angle'][ok], g['refl_angle'][ok]) < 1e-6
     return bad.sum()
 

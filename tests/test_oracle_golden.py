@@ -34,23 +34,23 @@ def test_raytrace_vs_reference_python_path(name):
     # of pairs (its C++ twin and its Python path disagree there, too).  Such pairs may differ in COUNT, but
     # every solution reported by the side with fewer solutions must be one of the other side's.
     bad = o['n_sol'] != g['n_sol']
-    assert bad.mean() <= 0.005, "solution-count mismatches beyond the reference's own noise"
+    assert bad.mean() <= 0.003, "solution-count mismatches beyond the reference's own noise"   # observed 0.13 % (fixture A), 0 (B, C)
     for i in np.where(bad)[0]:
         assert _subset_ok(o['C0'][i], g['C0'][i])
     ok = ~bad
     assert np.array_equal(o['type'][ok], g['type'][ok])
-    assert max_rel(o['C0'][ok], g['C0'][ok]) < 1e-6
+    assert max_rel(o['C0'][ok], g['C0'][ok]) < 1.1e-7   # observed 5.2e-8
     # D and T of refracted rays whose turning point sits right at an end point take sqrt(n(z_turn)^2 - beta^2) of a
     # fully cancelling difference (analyticraytracing.py:657-668): there the reference's own value is rounding noise
     # amplified to ~1e-6, so: 1e-6 for all but <= 0.2 % of the rays, 1e-5 for those
     for k in ('D', 'T'):
         rel = np.abs(o[k][ok] - g[k][ok]) / np.abs(g[k][ok])
         rel = rel[np.isfinite(rel)]
-        assert rel.max() < 1e-5 and (rel > 1e-6).mean() <= 0.002, k
+        assert rel.max() < 3e-6 and (rel > 1e-6).mean() <= 0.0026, k   # observed 1.4e-6 on 0.13 % of fixture C, 1.2e-7 elsewhere
     for k in ('launch', 'receive'):
-        assert np.nanmax(np.abs(o[k][ok] - g[k][ok])) < 1e-6
+        assert np.nanmax(np.abs(o[k][ok] - g[k][ok])) < 4e-7   # observed 1.8e-7
         assert np.array_equal(np.isnan(o[k][ok]), np.isnan(g[k][ok]))
-    assert np.nanmax(np.abs(o['C1'][ok] - g['C1'][ok])) < 1e-3  # metres, |C1| ~ 1e3..1e4
+    assert np.nanmax(np.abs(o['C1'][ok] - g['C1'][ok])) < 7.5e-4   # observed 3.5e-4 m  # metres, |C1| ~ 1e3..1e4
     assert max_rel(o['refl_angle'][ok], g['refl_angle'][ok]) < 1e-6
 
 
