@@ -372,6 +372,8 @@ def main():
     ap.add_argument('--trigger', default='threshold', choices=['threshold', 'pa', 'pa_adc_noise'],
                     help='configs 3 / 4: threshold on any channel, or the phased array on the four deep dipoles (optionally with the '
                          'trigger ADC and thermal noise)')
+    ap.add_argument('--two-pass', action='store_true', help='config 2: the traces of the triggered events from a second pass over them '
+                    '(round-2 scheme) instead of emitting them inside pass 1')
     ap.add_argument('--no-traces', action='store_true', help='config 2: time pass 1 only (trigger mask), without the second pass that '
                     'keeps the channel traces of the triggered events')
     ap.add_argument('--allow-tcp', action='store_true', help='if RCCL does not come up on every rank: run the collectives over the TCP '
@@ -410,14 +412,18 @@ def main():
     with_traces = cfgno == 2 and not args.no_traces   # single station: pass 2 inside the step (arrays: per station, not built yet)
 
     def step():
-        """one pass of the hot path over the resident list; config 2: followed by pass 2 on the device -- the showers of the
-        triggered groups gathered in HBM and run again with every channel trace kept, what the reference writes for them"""
-        s1 = det.simulate_events_dev(n, *d['in'], d['trig'], want_stats=True, **dev_kw)
+        """one pass of the hot path over the resident list; config 2: including the channel traces of the triggered events, what
+        the reference writes for them -- the convolution kernel emits all channels of an event the moment it triggers
+        (emit_traces); only if an event could not be served that way (buffer full, event decided by another kernel) a second pass
+        over the triggered groups (gathered in HBM, dump_traces) follows"""
+        s1 = det.simulate_events_dev(n, *d['in'], d['trig'], want_stats=True, emit_traces=with_traces and not args.two_pass, **dev_kw)
         if with_traces:
-            s2, _, nk = st.triggered_pass_dev(n, *d['in'], d['trig'], n_groups=n_groups, d_group_begin=d['gb'], **wl['sim_kw'])
-            s1['pass2_ms'] = s2['stage_ms']['total'] if s2 else 0.
-            s1['pass2_groups'] = nk
-            s1['pass2_trace_bytes'] = st.fetch_bytes('trace') if s2 else 0
+            s1['pass2_ms'] = 0.
+            s1['trace_bytes'] = 8 * s1['n_emitted_samples']
+            if s1['n_emitted_events'] != s1['n_triggered'] or s1['n_emit_overflow']:
+                s2, _, nk = st.triggered_pass_dev(n, *d['in'], d['trig'], n_groups=n_groups, d_group_begin=d['gb'], **wl['sim_kw'])
+                s1['pass2_ms'] = s2['stage_ms']['total'] if s2 else 0.
+                s1['trace_bytes'] = st.fetch_bytes('trace') if s2 else 0
         return s1
 
     for _ in range(args.warmup):
@@ -457,7 +463,7 @@ def main():
         value = n_total * args.steps / elapsed
         dom = max((k for k in sm if k != 'total'), key=lambda k: sm[k])
         kernel_of = {'raytrace': 'raytrace_kernel', 'ray_setup': 'select/scan/ray_setup kernels',
-                     'amp_bound': 'amp_bound_kernel', 'attenuation': 'attenuation_group_kernel',
+                     'amp_bound': 'amp_bound_kernel', 'attenuation': 'attenuation_dense_kernel',
                      'efield_max': 'efield_bound_kernel + efield_max_kernel' if cfgno != 4 else
                                    'arz_vector_potential_kernel + bire_steps_kernel + bire_propagate_kernel (general path)',
                      'event_grid': 'event_grid_kernel + candidate lists',
@@ -478,14 +484,14 @@ def main():
         achieved = alg_bytes / (sm[dom] * 1e-3) / 1e9 if sm[dom] > 0 else 0.
         # HBM bytes per launch from the committed rocprofv3 PMC passes -- quoted only if they were taken on THESE kernel sources
         traffic, traffic_note = None, None
-        pmc = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+        pmc = os.environ.get('NRHIP_PMC_JSON', os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'))
         if cfgno == 2 and args.flavour == 'had' and n == 1000000 and os.path.exists(pmc):
             pj = json.load(open(pmc))
             if pj.get('source_hash') == source_hash():
                 traffic = pj['kernels'].get(kernel_of[dom].split(' + ')[-1])
-                traffic_note = "GB per launch, rocprofv3 PMC passes (%s), kernel sources %s" % (pj.get('file'), pj['source_hash'])
+                traffic_note = "from_profile: GB per launch, rocprofv3 PMC passes (%s), kernel sources %s" % (pj.get('file'), pj['source_hash'])
             else:
-                traffic_note = "profiles/r02_pmc_traffic.json was taken on other kernel sources (%s != %s): not quoted" % (
+                traffic_note = "the PMC profile was taken on other kernel sources (%s != %s): not quoted" % (
                     pj.get('source_hash'), source_hash())
         b_event = B_RAY * scale * stats['n_rays'] + B_CHANNEL * scale * stats['n_channel_items'] + B_PAIR * stats['n_pairs']
         # FP64 view of the attenuation quadrature: one integrand evaluation = frequency-independent node part (shared
@@ -508,11 +514,13 @@ def main():
                        "triggered_events_per_s": n_trig_total / (elapsed / max(args.steps, 1)),
                        "step_includes_traces_of_triggered_events": bool(with_traces),
                        "pass2_ms_traces_of_triggered_events": pass2_ms,
-                       "pass2_groups": stats.get('pass2_groups'), "pass2_trace_bytes": stats.get('pass2_trace_bytes'),
+                       "traces_emitted_in_pass1": bool(with_traces and not args.two_pass), "n_emitted_events": stats.get('n_emitted_events'),
+                       "trace_bytes": stats.get('trace_bytes'),
                        "stage_ms_avg_per_step": {k: round(v, 3) for k, v in sm.items()},
                        "collectives": comm.mode},   # 'local' (one rank), 'rccl', or 'tcp' (RCCL did not come up on every rank)
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "from_profile" if traffic is not None else None,
+                         "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": sm[dom],
                          "whole_step_equivalent_GBs": b_event / (sm['total'] * 1e-3) / 1e9 if sm['total'] > 0 else 0.,
                          "whole_step_equivalent_frac": b_event / (sm['total'] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm['total'] > 0 else 0.,
@@ -521,13 +529,21 @@ def main():
                          "note": "every kernel of the path is FP64-VALU / LDS bound: the fused kernels move ~1e-3 of the "
                                  "un-fused algorithmic bytes of SURVEY 8(d) that the HBM view is priced on"},
         }
-        if dom == 'attenuation':
-            # the quadrature kernel is FP64-VALU bound: priced in flops against the dense FP64 peak of the MI355X
-            # (78.6 TFLOP/s, vector and matrix alike; nothing on this path is MFMA-shaped).  algorithmic flops per launch =
-            # integrand evaluations (counted by the kernel) x flop_per_eval
-            out["roofline"].update({"bound": "fp64_valu", "achieved": fp64, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": fp64 / FP64_PEAK_TFLOPS,
-                                    "algorithmic_flops_per_launch": stats['n_integrand_evals'] * flop_per_eval,
+        # FP64 view of the channel stage: per channel trace two FFT_MAX-point complex transforms (5 M log2 M flop each) and the
+        # spectrum product (14 flop per bin pair), per ray transform an N/2-point complex transform plus ~40 flop per amplitude bin
+        M_, nh_ = 8192, wl['N'] // 2
+        flop_channel = (stats['n_channel_transforms'] * (2 * 5. * M_ * 13 + 14. * (M_ // 2 + 1)) +
+                        stats['n_ray_transforms'] * (5. * nh_ * np.log2(nh_) + 40. * nh_))
+        flop_of = {'attenuation': stats['n_integrand_evals'] * flop_per_eval, 'channel': flop_channel}
+        out["roofline"]["fp64_frac_by_stage"] = {k: (v / (sm[k] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if sm[k] > 0 else 0.) for k, v in flop_of.items()}
+        if dom in flop_of:
+            # the quadrature and the channel kernels move next to no HBM bytes (everything lives in registers / LDS): priced in
+            # algorithmic FP64 flops against the dense FP64 peak of the MI355X (78.6 TFLOP/s, vector and matrix alike; nothing on
+            # this path is MFMA-shaped).  attenuation: integrand evaluations (counted by the kernel) x flop_per_eval (DESIGN.md
+            # section 4); channel: the transform flops above (that kernel is bound by LDS passes and barriers, not by the VALU)
+            tf = flop_of[dom] / (sm[dom] * 1e-3) / 1e12 if sm[dom] > 0 else 0.
+            out["roofline"].update({"bound": "fp64_valu", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": tf / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": flop_of[dom],
                                     "hbm_view_GBs": achieved})
         out["cpu_baseline"] = None
         if args.trigger != 'threshold':

@@ -364,6 +364,16 @@ typedef struct {
        0: 'auto'. */
     int32_t custom_polarization;
     double polarization_ephi;
+    /* != 0 (production mode with the plain OR of simple thresholds): the moment an event triggers, the convolution kernel
+       evaluates ALL its channels and writes their traces into a compact buffer -- what the reference stores for triggered events
+       (output_writer_hdf5.py:215-320 after channelReadoutWindowCutter) -- so that a survey needs no second pass over them.  Tables
+       afterwards: "emit_offset" (int64 [n_events]: first sample of the event's [n_channels][L] block, -1 none, -2 the buffer was
+       full) and "emit_trace" (double, the samples reserved); stats->n_emitted_events / n_emit_overflow tell whether every triggered
+       event got its block (events decided by the chirp-z kernel -- common traces longer than 8192 samples, tabulated antennas,
+       noise, the general path -- and coincidence triggers do not emit: run those through dump_traces).  emit_capacity_samples:
+       size of the buffer (0: 4e8 samples = 3.2 GB, grown by the caller when n_emit_overflow > 0). */
+    int32_t emit_triggered_traces;
+    int64_t emit_capacity_samples;
 } nrhip_sim_config;
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1
@@ -386,6 +396,8 @@ typedef struct {
     int32_t max_length;
     int32_t n_sub_events;         /* readouts: event groups, or their sub-events with split_event_time_diff */
     double stage_ms[NRHIP_N_STAGES];
+    /* nrhip_sim_config.emit_triggered_traces: events whose traces were written, events that found the buffer full, samples reserved */
+    int64_t n_emitted_events, n_emit_overflow, n_emitted_samples;
 } nrhip_sim_stats;
 
 typedef struct nrhip_station nrhip_station;

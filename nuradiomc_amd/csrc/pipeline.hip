@@ -1386,6 +1386,21 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             }
             HIPCHK(hipStreamSynchronize(sm));  // `off` goes out of scope
         }
+        // traces of the events that trigger, written by the convolution kernel itself (nrhip_sim_config.emit_triggered_traces)
+        const bool emit = cfg->emit_triggered_traces && !cfg->dump_traces && !cfg->no_pruning && !general && !phased && !post_trigger &&
+                          !noise && !trg.coincidence();
+        unsigned long long* emit_cursor = nullptr;
+        if (emit) {
+            co.emit_cap = cfg->emit_capacity_samples > 0 ? (long long)cfg->emit_capacity_samples : 400000000LL;
+            // never more than every candidate event could need
+            co.emit_cap = std::min<long long>(co.emit_cap, (long long)n_cand * n_ch * (long long)maxL);
+            NEED(co.emit = WS("emit_trace", double, (size_t)std::max<long long>(co.emit_cap, 1)));
+            NEED(co.emit_offset = WS("emit_offset", long long, n_ev));
+            NEED(emit_cursor = WS("emit_cursor", unsigned long long, 3));
+            co.emit_cursor = emit_cursor;
+            HIPCHK(hipMemsetAsync(co.emit_offset, 0xFF, sizeof(long long) * (size_t)n_ev, sm));
+            HIPCHK(hipMemsetAsync(emit_cursor, 0, 3 * sizeof(unsigned long long), sm));
+        }
         double2* scratch;
         NEED(scratch = WS("channel_scratch", double2, (size_t)channel_grid_blocks() * NRHIP_SPEC_STRIDE));
         int *it_need, *it_off, *it_tmp, *it_list;
@@ -1505,7 +1520,15 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             hipLaunchKernelGGL(sub_event_trigger_kernel, dim3((unsigned)((n_ev + 255) / 256)), dim3(256), 0, sm, (int)n_ev, ev_group,
                                ev_triggered, triggered);
         MARK(8);
+        unsigned long long h_emit[3] = {0ull, 0ull, 0ull};
+        if (emit) HIPCHK(hipMemcpyAsync(h_emit, emit_cursor, sizeof h_emit, hipMemcpyDeviceToHost, sm));
         HIPCHK(hipStreamSynchronize(sm));  // host vectors used by async copies above stay alive until here
+        if (emit) {
+            S.n_emit_overflow = (int64_t)h_emit[1];
+            S.n_emitted_samples = (int64_t)std::min<unsigned long long>(h_emit[0], (unsigned long long)co.emit_cap);
+            st->ws_bytes["emit_trace"] = (size_t)S.n_emitted_samples * sizeof(double);
+            S.n_emitted_events = (int64_t)h_emit[2];
+        }
         if (conv_trial >= 0) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, st->evt[7], st->evt[8]) == hipSuccess && ms > 0.f) {

@@ -136,6 +136,13 @@ struct ChannelOut {
     unsigned char* triggered;   // [n_events]
     double* trace;              // optional dump
     const long* trace_offset;   // [n_items]
+    // production mode, plain OR of thresholds: the traces of ALL channels of the events that trigger, written by the convolution
+    // kernel the moment an event triggers (compact buffer, space reserved through a cursor) -- what the reference stores for
+    // triggered events -- instead of a second pass over them
+    double* emit = nullptr;             // [emit_cap] samples
+    long long* emit_offset = nullptr;   // [n_events] first sample of the event's n_ch x L block (-1: none, -2: the buffer was full)
+    unsigned long long* emit_cursor = nullptr;   // [3]: samples reserved, events that did not fit, events written
+    long long emit_cap = 0;
 };
 
 void launch_select_rays(hipStream_t s, long n_pairs, int n_ch, const double* vertex, const double* zen, const double* az,

@@ -1871,6 +1871,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     // unit of work: one candidate event; its channels are evaluated in sequence and -- the trigger being an OR over
     // channels -- the remaining ones are skipped (maxV = NaN) once one has triggered, unless every trace is wanted
     __shared__ int s_ev_trig;
+    __shared__ long long s_emit_off;
     // The channels an event still needs, strongest Cauchy-Schwarz bound first: the trigger is an OR over the channels, so the
     // one most likely to fire ends the event soonest (any order gives the same mask).  Built by thread 0 per event; two
     // buffers, because a wave may run ahead through the barrier-free skip path into the next event's set-up.
@@ -1921,13 +1922,27 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       // through the barrier-free skip path below
       bool ev_trig = false;
       const int n_steps = best_first ? s_norder[par] : st.n_ch;
-      for (int step = 0; step < n_steps; step++) {
-        const int ch = best_first ? (int)s_order[par][step] : step;
+      // emission of a triggered event's traces: once a channel has triggered, ALL channels of the event are evaluated (in channel
+      // order, the pruned ones included) and written into the block reserved for the event
+      const bool can_emit = out.emit != nullptr && !exact && !coinc;
+      bool emitting = false;
+      int c_star = -1;
+      long long e_off = -1;
+      for (int step = 0;; step++) {
+        int ch;
+        if (!emitting) {
+            if (step >= n_steps) break;
+            ch = best_first ? (int)s_order[par][step] : step;
+        } else {
+            if (step >= st.n_ch) break;
+            ch = step;
+            if (ch == c_star) continue;   // its trace went out when it triggered
+        }
         const int item = item_list[le] * st.n_ch + ch;
-        if (!need[item]) continue;
+        if (!emitting && !need[item]) continue;
         const bool ch_on = !st.trig_on || st.trig_on[ch];  // triggered_channels of the reference's trigger modules
         const int e = item_event[item / st.n_ch];
-        if (!exact && !coinc && ev_trig) {
+        if (!emitting && !exact && !coinc && ev_trig) {
             if (threadIdx.x == 0) out.maxV[item] = NAN;
             continue;
         }
@@ -2148,9 +2163,11 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             else fft_dit_t<LOG2CAP, NT, true>(z, tw, true);
             CT(8);
             if (!coinc) {
+                double* const em = emitting ? out.emit + e_off + (long long)ch * L : nullptr;
                 for (int n = threadIdx.x; n < L; n += blockDim.x) {
                     double v = (S[PS(n)] + S[PS(n + L)]) * vscale;
                     if (out.trace) out.trace[out.trace_offset[item] + n] = v;
+                    if (em) em[n] = v;
                     double av = fabs(v);
                     vmax = fmax(vmax, av);
                     if (n < L - 1 && av >= threshold && ch_on) trig = 1;
@@ -2208,6 +2225,10 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 __syncthreads();
             }
         }
+        else if (emitting) {   // a channel without rays: zeros, as the reference's empty channels
+            double* const em = out.emit + e_off + (long long)ch * L;
+            for (int n = threadIdx.x; n < L; n += blockDim.x) em[n] = 0.;
+        }
         if (trig) s_trig = 1;
         double vm = block_max(vmax, red);
         if (threadIdx.x == 0) {
@@ -2218,6 +2239,33 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         ev_trig = (s_ev_trig != 0);
         __syncthreads();
         CT(9);
+        if (can_emit && ev_trig && !emitting) {
+            // the event has just triggered on channel ch: reserve n_ch x L samples, write this channel's trace (still in S), then
+            // go through all the other channels
+            if (threadIdx.x == 0) {
+                const unsigned long long want = (unsigned long long)st.n_ch * (unsigned long long)L;
+                const unsigned long long o = atomicAdd(&out.emit_cursor[0], want);
+                long long off = (long long)o;
+                if (o + want > (unsigned long long)out.emit_cap) {
+                    off = -2;   // full: the host sees the count and falls back to the second pass for these events
+                    atomicAdd(&out.emit_cursor[1], 1ULL);
+                } else {
+                    atomicAdd(&out.emit_cursor[2], 1ULL);
+                }
+                out.emit_offset[e] = off;
+                s_emit_off = off;
+            }
+            __syncthreads();
+            e_off = s_emit_off;
+            if (e_off >= 0) {
+                double* const em = out.emit + e_off + (long long)ch * L;
+                for (int n = threadIdx.x; n < L; n += blockDim.x) em[n] = (S[PS(n)] + S[PS(n + L)]) * vscale;
+                emitting = true;
+                c_star = ch;
+                step = -1;   // restart: every channel in channel order
+            }
+            __syncthreads();
+        }
       }
       if (coinc) {  // majority logic over the channels of the event
           if (threadIdx.x == 0) s_first = 0x7fffffff;

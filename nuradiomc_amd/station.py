@@ -82,7 +82,8 @@ class SimConfig(ctypes.Structure):
                 ('reflection_phase_shift', ctypes.c_double), ('split_event_time_diff', ctypes.c_double),
                 ('noise', ctypes.c_int32), ('noise_seed', ctypes.c_uint64), ('noise_group_offset', ctypes.c_int64),
                 ('noise_group_id', ctypes.c_void_p), ('custom_polarization', ctypes.c_int32),
-                ('polarization_ephi', ctypes.c_double)]
+                ('polarization_ephi', ctypes.c_double), ('emit_triggered_traces', ctypes.c_int32),
+                ('emit_capacity_samples', ctypes.c_int64)]
 
 
 class SimStats(ctypes.Structure):
@@ -90,13 +91,15 @@ class SimStats(ctypes.Structure):
                                               'n_channel_items', 'n_distinct_lengths', 'n_candidate_rays', 'n_active_rays',
                                               'n_integrand_evals', 'n_channel_transforms', 'n_ray_transforms',
                                               'n_efield_transforms')] + \
-               [('max_length', ctypes.c_int32), ('n_sub_events', ctypes.c_int32), ('stage_ms', ctypes.c_double * 9)]
+               [('max_length', ctypes.c_int32), ('n_sub_events', ctypes.c_int32), ('stage_ms', ctypes.c_double * 9)] + \
+               [(k, ctypes.c_int64) for k in ('n_emitted_events', 'n_emit_overflow', 'n_emitted_samples')]
 
     STAGES = ('raytrace', 'ray_setup', 'amp_bound', 'attenuation', 'efield_max', 'event_grid', 'length_tables', 'channel',
               'total')
 
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_[:15]}
+        d.update({k: int(getattr(self, k)) for k in ('n_emitted_events', 'n_emit_overflow', 'n_emitted_samples')})
         d['stage_ms'] = {n: float(self.stage_ms[i]) for i, n in enumerate(self.STAGES)}
         return d
 
@@ -551,7 +554,7 @@ class Station:
                             accumulate_triggered=False, n_reflections=0, z_reflection=0., reflection_coefficient=1.,
                             reflection_phase_shift=0., split_event_time_diff=0., noise=False, noise_seed=0, noise_group_offset=0,
                             polarization='auto', ePhi=0.,
-                            d_noise_group_id=None):
+                            d_noise_group_id=None, emit_traces=False, emit_capacity_samples=0):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
         d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
@@ -568,7 +571,11 @@ class Station:
         where consecutive start times are farther apart; the ev_* / item_* tables are then per sub-event (fetch('ev_group'),
         fetch('ev_sub_event')), the mask stays per group.
         noise (set_noise first): thermal noise on every channel of the candidate events before filters and trigger; counter-based
-        draws keyed by noise_seed and the group ids (d_noise_group_id: device int64 [n_groups], or noise_group_offset + index)."""
+        draws keyed by noise_seed and the group ids (d_noise_group_id: device int64 [n_groups], or noise_group_offset + index).
+        emit_traces (production mode, trigger 'simple' without coincidences): the convolution kernel writes the traces of all
+        channels of every event the moment it triggers (nrhip_sim_config.emit_triggered_traces) -- triggered_traces() returns
+        them; stats['n_emitted_events'] == stats['n_triggered'] and stats['n_emit_overflow'] == 0 say that every triggered event
+        got its block (otherwise run those through dump_traces / triggered_pass_dev)."""
         if polarization not in ('auto', 'custom'):   # simulation.py:827-829
             raise ValueError("{} for config.signal.polarization is not a valid option".format(polarization))
         if trigger not in ('simple', 'high_low', 'phased_array', 'envelope'):
@@ -583,7 +590,8 @@ class Station:
                         int(bool(select_only)), int(bool(reuse_ray_tables)), int(bool(accumulate_triggered)), int(n_reflections),
                         float(z_reflection), float(reflection_coefficient), float(reflection_phase_shift),
                         float(split_event_time_diff or 0.), int(bool(noise)), int(noise_seed) & 0xffffffffffffffff,
-                        int(noise_group_offset), d_noise_group_id, int(polarization == 'custom'), float(ePhi))
+                        int(noise_group_offset), d_noise_group_id, int(polarization == 'custom'), float(ePhi),
+                        int(bool(emit_traces)), int(emit_capacity_samples))
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_event_groups(
             self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,
@@ -812,7 +820,16 @@ class Station:
                      'shower_first_channel': np.int32, 'slot_reflection': np.int32, 'slot_reflection_case': np.int32,
                      'slot_n_segments': np.int32, 'slot_surface_mask': np.int32, 'ev_group': np.int32, 'ev_sub_event': np.int32,
                      'ev_triggered': np.uint8, 'ray_sub_event': np.int32, 'group_n_sub_events': np.int32,
-                     'pa_digital_length': np.int32, 'ray_propagated': np.int32, 'gen_n_steps': np.int32}
+                     'pa_digital_length': np.int32, 'ray_propagated': np.int32, 'gen_n_steps': np.int32, 'emit_offset': np.int64}
+
+    def triggered_traces(self):
+        """after simulate_events_dev(..., emit_traces=True): {event index: array [n_channels, L]} of the events whose traces the
+        convolution kernel wrote when they triggered"""
+        off = self.fetch('emit_offset')
+        L_ = self.fetch('ev_L')
+        tr = self.fetch('emit_trace')
+        n_ch = len(self.position)
+        return {int(e): tr[off[e]:off[e] + n_ch * L_[e]].reshape(n_ch, L_[e]) for e in np.flatnonzero(off >= 0)}
 
     def fetch_bytes(self, name):
         """size in bytes of a table of the last simulated batch (nothing is copied)"""

@@ -38,3 +38,47 @@ def test_device_pass2_equals_host_pass2(gpu_ctx_factory, flavour):
     for k, v in A.items():
         assert np.array_equal(v, st.fetch(k)), k
     assert len(A['trace']) > 5 * 4096 * nk * 0.5
+
+
+@pytest.mark.parametrize('flavour', ['had', 'mixed'])
+def test_traces_emitted_when_an_event_triggers(gpu_ctx_factory, flavour):
+    """emit_traces: the convolution kernel writes all channel traces of an event the moment it triggers.  Same mask as without;
+    the blocks equal the traces of the dump_traces pass over the same events bit for bit; a buffer that is too small is reported
+    (n_emit_overflow) and the events that did fit are still right."""
+    n = 40000
+    wl = bench.make_workload(2, n, 10, flavour)
+    ctx = gpu_ctx_factory(wl['ice'], wl['att_model'])
+    st = bench.build_array(ctx, wl)
+    d = bench.upload_events(ctx, wl)
+    try:
+        kw = dict(n_groups=d['n_groups'], d_group_begin=d['gb'])
+        s0 = st.simulate_events_dev(d['n'], *d['in'], d['trig'], **kw)
+        m0 = np.zeros(d['n_groups'], np.uint8)
+        ctx.to_host(m0, d['trig'])
+        s1 = st.simulate_events_dev(d['n'], *d['in'], d['trig'], emit_traces=True, **kw)
+        m1 = np.zeros(d['n_groups'], np.uint8)
+        ctx.to_host(m1, d['trig'])
+        assert np.array_equal(m0, m1) and s1['n_triggered'] == s0['n_triggered'] > 100
+        assert s1['n_emitted_events'] == s1['n_triggered'] and s1['n_emit_overflow'] == 0
+        got = st.triggered_traces()
+        assert sorted(got) == list(np.flatnonzero(m1))
+        L1 = st.fetch('ev_L').copy()
+        # the reference traces: dump_traces pass over the triggered groups
+        s2, d_keep, nk = st.triggered_pass_dev(d['n'], *d['in'], d['trig'], **kw)
+        keep = np.zeros(nk, np.int32)
+        ctx.to_host(keep, d_keep)
+        item_event, tr, off = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+        n_ch = len(wl['rel_pos'])
+        assert np.array_equal(item_event, np.arange(nk))
+        for i, g in enumerate(keep):
+            ref = np.array([tr[off[i * n_ch + c]:off[i * n_ch + c + 1]] for c in range(n_ch)])
+            assert ref.shape == got[int(g)].shape == (n_ch, L1[g]) and np.array_equal(ref, got[int(g)]), g
+        # a buffer for about a third of the triggered events
+        cap = int(s1['n_emitted_samples'] // 3)
+        s3 = st.simulate_events_dev(d['n'], *d['in'], d['trig'], emit_traces=True, emit_capacity_samples=cap, **kw)
+        assert s3['n_triggered'] == s0['n_triggered'] and s3['n_emit_overflow'] > 0
+        assert s3['n_emitted_events'] + s3['n_emit_overflow'] == s3['n_triggered']
+        part = st.triggered_traces()
+        assert len(part) == s3['n_emitted_events'] and all(np.array_equal(v, got[k]) for k, v in part.items())
+    finally:
+        bench.free_events(ctx, d)

@@ -1,4 +1,4 @@
-"""Two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; each with --kernel-trace only) of `python3 bench.py --steps 1 --warmup 1`
+"""Two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; each with --kernel-trace only) of `python3 bench.py --steps 1 --warmup 3`
 -> HBM bytes of the LARGEST launch of every kernel (bench.py's pass 2 re-runs the kernels on the few triggered events after the
 timed steps: the last launch is not the timed one), as JSON for bench.py's `roofline.traffic` and as CSV for reading.
 
@@ -32,7 +32,7 @@ def main():
     rows = [(k, f.get(k, 0.), w.get(k, 0.), (2 * f.get(k, 0.) + w.get(k, 0.)) * 1024, int(nf.get(k, 0))) for k in names]
     base = sys.argv[3]
     with open(base + '.csv', 'w') as o:
-        o.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1\n')
+        o.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 3\n')
         o.write('# largest launch of each kernel; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 counts 64 B per 128-B read request)\n')
         o.write('# kernel sources %s\n' % bench.source_hash())
         o.write('kernel,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_corrected,launches_seen\n')
