@@ -1,0 +1,14 @@
+#!/bin/bash
+# copy the round's measurement set from gpurun_out/measure (scratch) into profiles/ (tracked): usage  bash tools/keep_profiles.sh [r03]
+cd "$(dirname "$0")/.."
+R=${1:-r03}
+M=gpurun_out/measure
+cp $M/${R}_rocprofv3_kernel_stats.csv $M/${R}_pmc_traffic.csv $M/${R}_pmc_traffic.json $M/${R}_rocprofv3_config4_kernel_stats.csv profiles/ 2>/dev/null
+for c in config2 config2_pass1_only config2_mixed config2_strong config2_125k_shard config3 config3_pa config3_pa_adc_noise config4 config4_pa_adc_noise config5; do
+  [ -s $M/bench_$c.json ] && tail -1 $M/bench_$c.json > profiles/${R}_bench_${c}_1gpu.json
+done
+[ -s $M/config4_probe.log ] && cp $M/config4_probe.log profiles/${R}_config4_probe.txt
+[ -s $M/overlap_probe.log ] && cp $M/overlap_probe.log profiles/${R}_overlap_probe.txt
+[ -s $M/att_dense_probe.log ] && cp $M/att_dense_probe.log profiles/${R}_att_dense_probe.txt
+[ -s gpurun_out/measure_sq/sq_a.csv ] && { echo "# rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes, tools/measure_sq.sh) -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 3; largest launch per kernel, summed over XCDs / SEs"; echo "# pass a"; cat gpurun_out/measure_sq/sq_a.csv; echo "# pass b"; cat gpurun_out/measure_sq/sq_b.csv; } > profiles/${R}_pmc_sq_counters.csv
+ls -la profiles | grep $R
