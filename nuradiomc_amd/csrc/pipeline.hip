@@ -1425,12 +1425,20 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         }
         StationDev sd_ch = sd;
         if (phased) sd_ch.trig_on = st->d_pa_mask.as<unsigned char>();  // only the array's channels need traces (unless all are dumped)
+        // analog phased array in production mode: events whose channel bounds cannot add up to the power threshold are not transformed
+        // (window power <= (window / divisor) (sum_c max |V_c|)^2); the digitised array (comparator, up-sampling overshoot) and noise
+        // have no such bound
+        double pa_amp_cut = -1.;
+        if (phased && !st->pa_adc_set && !noise && !general && !cfg->dump_traces && !cfg->no_pruning && cfg->trigger_threshold > 0) {
+            const double divisor = st->pa_divisor > 0 ? (double)st->pa_divisor : (double)st->pa_window;
+            pa_amp_cut = sqrt(cfg->trigger_threshold * divisor / (double)st->pa_window);
+        }
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd_ch, st->filters[0], arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
                        trg_ch, ctx->twiddle, ctx->w16, tab, scratch, co,
                        (cfg->no_pruning || cfg->dump_traces || general || phased || post_trigger || noise) ? 1 : 0, maxL,
                        it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces,
                        (phased || post_trigger) ? (cfg->dump_traces ? 0 : 1) : -1, envelope ? &st->env_filter : nullptr, env_trace,
-                       noise ? &nz : nullptr, conv_split);
+                       noise ? &nz : nullptr, conv_split, pa_amp_cut);
         LCHK("channel");
         if (post_trigger) {
             launch_trace_trigger(sm, n_cand, d_cand, n_ch, ev.L, envelope ? env_trace : co.trace, co.trace_offset, trg, sd.trig_on, maxL,

@@ -1749,7 +1749,7 @@ channel_prefilter_kernel(int n_items, const int* __restrict__ item_event, RayWor
     if (item >= n_items) return;
     const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
     const int L = ev.L[e], il = ev_len_index[e];
-    if (L > FFT_MAX || st.ant_model[ch] == 3) { need[item] = 0; return; }  // chirp-z kernel: long traces, tabulated patterns
+    if (L > FFT_MAX || st.ant_model[ch] == 3) { need[item] = 0; maxV[item] = NAN; return; }  // chirp-z kernel: long traces, tabulated patterns
     if (skip_off && st.trig_on && !st.trig_on[ch]) {  // not a trigger channel: nothing of it decides anything
         need[item] = 0;
         maxV[item] = NAN;
@@ -1769,6 +1769,24 @@ channel_prefilter_kernel(int n_items, const int* __restrict__ item_event, RayWor
         if (!(bnd * (1 + 1e-9) >= threshold)) flag = 0;
     }
     need[item] = flag;
+}
+
+// phased-array trigger: the window power of a beam is at most (window / divisor) (sum over the array's channels of max |V_c|)^2, so
+// an event whose channel bounds (channel_prefilter_kernel, -maxV) add up to less than amp_cut cannot trigger: none of its traces
+// is needed (they stay zero, its beam powers read 0 = "below the threshold")
+__global__ void pa_event_prune_kernel(int n_cand, int n_ch, const unsigned char* __restrict__ trig_on, const double* __restrict__ maxV,
+                                      int* __restrict__ need, double amp_cut)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cand) return;
+    double sum = 0.;
+    for (int ch = 0; ch < n_ch; ch++)
+        if (!trig_on || trig_on[ch]) {
+            const double b = -maxV[(long)i * n_ch + ch];
+            sum += (b == b) ? b : INFINITY;   // (a channel the prefilter could not bound keeps the event)
+        }
+    if (!(sum * (1 + 1e-9) >= amp_cut))
+        for (int ch = 0; ch < n_ch; ch++) need[(long)i * n_ch + ch] = 0;
 }
 
 __global__ void scatter_item_list_kernel(int n_items, const int* __restrict__ need, const int* __restrict__ offset,
@@ -3179,7 +3197,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
                     const double* ray_traces, int skip_off, const FilterSet* envf, double* env_trace, const NoiseDev* noise,
-                    bool conv_split)
+                    bool conv_split, double pa_amp_cut)
 {
     if (skip_off < 0) skip_off = !exact;  // channels outside the trigger set are evaluated only when everything is
     if (n_items <= 0) return;
@@ -3192,9 +3210,13 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     // (the convolution kernel's ray stage is radix 2: trace lengths that are no power of two take the chirp-z kernel)
     if (tab.G && st.N <= FFT_MAX / 2 && st.np.log2nh >= 0 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces && !env_trace &&
         !(noise && noise->on)) {
+        const bool pa_prune = pa_amp_cut >= 0.;   // (then the bounds are wanted although every kept item is evaluated exactly)
         hipLaunchKernelGGL(channel_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev,
-                           ev_len_index, st, trig.prefilter(), tab.hnorm, exact, out.maxV, need, skip_off);
+                           ev_len_index, st, pa_prune ? 0. : trig.prefilter(), tab.hnorm, pa_prune ? 0 : exact, out.maxV, need, skip_off);
         const int n_cand = n_items / st.n_ch;
+        if (pa_prune)
+            hipLaunchKernelGGL(pa_event_prune_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, st.n_ch, st.trig_on, out.maxV,
+                               need, pa_amp_cut);
         int* ev_need = need + n_items;  // [n_cand + 1]
         hipLaunchKernelGGL(channel_event_flags_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, st.n_ch, need,
                            ev_need);

@@ -1042,10 +1042,16 @@ def test_phased_array_trigger(gpu_ctx_factory):
     v = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1500., -10., n)], axis=1)
     zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
     en = 10 ** rng.uniform(16.8, 18.2, n)
-    trig, stats = st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold)
+    trig, stats = st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold, dump_traces=True)
     cand = st.fetch('ev_candidate').astype(bool)
     item_event = st.fetch('item_event')
     pa_max = st.fetch('pa_max_power').reshape(len(item_event), len(angles))
+    # production mode: events whose channel bounds cannot add up to the power threshold are not transformed (their powers read 0)
+    trig_p, stats_p = st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold)
+    pa_max_p = st.fetch('pa_max_power').reshape(len(item_event), len(angles))
+    assert np.array_equal(trig_p, trig) and stats_p['n_channel_transforms'] < stats['n_channel_transforms']
+    skipped = np.all(pa_max_p == 0, axis=1)
+    assert skipped.sum() >= 3 and np.all(pa_max[skipped] < threshold) and np.array_equal(pa_max_p[~skipped], pa_max[~skipped])
     n_cand = n_trig = 0
     for e in range(n):
         o = so.simulate_event(v[e], zen[e], az[e], en[e], 'HAD', None, ost, ice, vrms, vrms_e)
