@@ -110,6 +110,27 @@ __device__ __noinline__ double delta_y(double logC0, const Pair2D& p, const IceC
     return -1 * (p.y2 - (2 * y_turn - y2));  // mirrored branch
 }
 
+// the same objective with the pair's six numbers in LDS columns (sp[k * stride], k = y1, z1, y2, z2, g1, g2): the root finders call it
+// ~1e2 times per pair, and a Pair2D passed by reference to a non-inlined function lives in scratch -- 48 B re-read per call, 24 GB
+// of HBM traffic per 5e6 pairs (the scratch of all resident waves exceeds the L2)
+__device__ __noinline__ double delta_y_lds(double logC0, const double* __restrict__ sp, int stride, const IceConst& m)
+{
+    Pair2D p;
+    p.y1 = sp[0]; p.z1 = sp[stride]; p.y2 = sp[2 * stride]; p.z2 = sp[3 * stride]; p.g1 = sp[4 * stride]; p.g2 = sp[5 * stride];
+    double C0 = det_exp(logC0) + m.inv_n;
+    if (C0 < m.inv_n) return -INFINITY;
+    C0State s = make_c0(C0, m);
+    double C1 = p.y1 - y_mirror0(p.z1, p.g1, s, m);
+    double y_turn = s.y_turn0 + C1;
+    if (s.z_turn < p.z2) {  // turning point below the receiver: smooth penalty (:247-253)
+        double dz = s.z_turn - p.z2, dy = y_turn - p.y2;
+        return -(sqrt(dz * dz + dy * dy) + 10 * fabs(dz));
+    }
+    double y2 = y_of_gamma(p.g2, s, m) + C1;
+    if (y_turn > p.y2) return p.y2 - y2;    // direct branch
+    return -1 * (p.y2 - (2 * y_turn - y2));  // mirrored branch
+}
+
 __device__ inline double C1_of(const C0State& s, const Pair2D& p, const IceConst& m)
 {
     return p.y1 - y_mirror0(p.z1, p.g1, s, m);

@@ -25,6 +25,9 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
                 IceConst m, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm,
                 const double* __restrict__ given_C0)
 {
+#ifndef NRHIP_RT_SCRATCH_PAIR
+    __shared__ double sh_pair[6][256];   // the pair geometry the objective reads on every evaluation (see delta_y_lds)
+#endif
     for (long iw = blockIdx.x * (long)blockDim.x + threadIdx.x; iw < n_pairs; iw += (long)gridDim.x * blockDim.x) {
         // perm (optional): events in an order that puts similar geometries (distance, depth) next to each other, so that
         // the lanes of a wave run similar numbers of root-finder iterations; results land at the original pair index
@@ -60,8 +63,15 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
         // speedup.distance_cut (simulation.py:155-163): showers farther from the antenna than their cut are not traced
         const bool too_far = max_dist && sqrt(dX[0] * dX[0] + dX[1] * dX[1] + dX[2] * dX[2]) > max_dist[i1];
         if (!(p.z2 > 0) && !too_far && !given_C0) {  // receiver in air: special branch of the reference (:1437-1460) not provided
+#ifndef NRHIP_RT_SCRATCH_PAIR
+            double* const sp = &sh_pair[0][threadIdx.x];   // (only this lane reads its column: no barrier)
+            sp[0] = p.y1; sp[256] = p.z1; sp[512] = p.y2; sp[768] = p.z2; sp[1024] = p.g1; sp[1280] = p.g2;
+            auto dy = [&](double l) { return delta_y_lds(l, sp, 256, m); };
+            auto dy2 = [&](double l) { double d = delta_y_lds(l, sp, 256, m); return d * d; };
+#else
             auto dy = [&](double l) { return delta_y(l, p, m); };
             auto dy2 = [&](double l) { double d = delta_y(l, p, m); return d * d; };
+#endif
             double fun;
             double xr = hybrd1(dy2, -1., 1e-6, &fun);
             if (fun < 1e-7) lc[ns++] = xr;
