@@ -823,6 +823,11 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, c
 // rays all stay below the candidate cut even un-attenuated can never become candidates (simulation.py:283-285), so
 // their rays skip the attenuation quadrature and the time-domain transform.  One block per ray.
 // ---------------------------------------------------------------------------------------------------------
+// margin of the attenuation bound: the quadrature the bound must dominate is QUADPACK's at epsrel = 1e-2 (its estimate may be
+// 1 % above... the computed integral at most 1 % below the true one)
+#ifndef NRHIP_ATT_BOUND_MARGIN
+#define NRHIP_ATT_BOUND_MARGIN 0.95
+#endif
 #define AB_RT 4  // rays per wave and pass: the frequency-grid tables are loaded once for AB_RT rays
 __global__ void __launch_bounds__(256, 3)
 amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double* __restrict__ vertex,
@@ -891,7 +896,7 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
 #pragma unroll
                     for (int i = 0; i < AB_RT; i++) I[i] += blen[wv][i][b] * t;
                 }
-                for (int i = 0; i < AB_RT; i++) ub[wv][i][lane] = (rb + i < n_rays) ? exp(-0.95 * (1 - 1e-3) * I[i]) : 0.;
+                for (int i = 0; i < AB_RT; i++) ub[wv][i][lane] = (rb + i < n_rays) ? exp(-NRHIP_ATT_BOUND_MARGIN * (1 - 1e-3) * I[i]) : 0.;
             }
         } else if (lane < st.n_fc) {
             for (int i = 0; i < AB_RT; i++) {
@@ -899,7 +904,7 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
                 double u = 0.;
                 if (r < n_rays) {
                     double zlo = fmin(vertex[3 * (long)w.ev[r] + 2], st.pos[3 * w.ch[r] + 2]);  // deepest point of the path
-                    u = (zlo >= -st.att_bound_depth) ? exp(-0.95 * w.R[r] * st.inv_lmax[lane]) : 1.;
+                    u = (zlo >= -st.att_bound_depth) ? exp(-NRHIP_ATT_BOUND_MARGIN * w.R[r] * st.inv_lmax[lane]) : 1.;
                 }
                 ub[wv][i][lane] = u;
             }
