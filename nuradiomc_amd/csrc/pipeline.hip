@@ -1048,8 +1048,14 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     int* active_list = nullptr;
     double* bound;
     NEED(bound = WS("ray_bound", double, nr));
+    // attenuation in two stages (result-neutral): first the rays whose own bound exceeds the candidate cut (they decide which
+    // events become candidates), after the candidate cut the other rays of the candidate readouts (the channel traces of a
+    // candidate sum all its rays) -- the rays that are active only because an event-mate might have made the event a candidate,
+    // and did not, are never integrated (10 % of the quadratures of the survey)
+    const bool two_stage = !general && n_refl == 0 && !cfg->no_pruning && !getenv("NRHIP_ATT_ONE_STAGE");
+    int* ractive = nullptr;
     if (n_rays > 0) {
-        int *ractive, *roff, *rtmp, *cflags;
+        int *roff, *rtmp, *cflags;
         NEED(ractive = WS("ray_active", int, nr + 1));
         NEED(cflags = WS("ray_active_class", int, 3 * nr + 1));
         NEED(roff = WS("ray_active_offset", int, 3 * nr + 1));
@@ -1064,7 +1070,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             launch_amp_bound(sm, n_rays, w, sd, ctx->ice, vertex, zint, bound, max_efield);
             LCHK("amp_bound");
             launch_event_possible(sm, (int)n_groups, n_ch, grp_ray, bound, cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude,
-                                  ractive);
+                                  ractive, two_stage ? 1 : 0);
             LCHK("event_possible");
         }
         // active rays listed by work class (direct, reflected, refracted): wave-mates in the quadrature do similar work
@@ -1244,6 +1250,19 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     launch_exclusive_scan(sm, n_half + 1, lflag, loff, ltmp);
     launch_candidate_lists(sm, (int)n_ev, n_half, ev, cflag, coff, lflag, loff, d_cand, d_len_index, d_lens);
     LCHK("candidate lists");
+    // second stage of the attenuation: list of the candidate readouts' rays that have none yet
+    int *fol_flag = nullptr, *fol_off = nullptr, *fol_list = nullptr;
+    int n_followers = 0;
+    if (two_stage && n_rays > 0 && n_active > 0) {
+        int* fol_tmp;
+        NEED(fol_flag = WS("follower_flag", int, nr + 1));
+        NEED(fol_off = WS("follower_offset", int, nr + 1));
+        NEED(fol_tmp = WS("scan_tmp9", int, scan_tiles((long)n_rays + 1)));
+        NEED(fol_list = WS("follower_list", int, nr));
+        launch_follower_list(sm, (int)n_ev, ev, w.att, sd.n_fc, n_rays, fol_flag, fol_off, fol_tmp, fol_list, ractive);
+        LCHK("follower list");
+        HIPCHK(hipMemcpyAsync(&n_followers, fol_off + n_rays, sizeof(int), hipMemcpyDeviceToHost, sm));
+    }
     int h_counts[2] = {0, 0};
     long long h_ncr[2] = {0, 0};
     std::vector<int> lens(n_half);
@@ -1256,6 +1275,16 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     lens.resize(h_counts[1]);
     st->ws_bytes["lengths"] = sizeof(int) * lens.size();
     st->ws_bytes["item_event"] = sizeof(int) * (size_t)n_cand;
+    if (n_followers > 0) {
+        int* att_ovf2;
+        NEED(att_ovf2 = WS("att_overflow2", int, 2 * (size_t)n_followers + 1));
+        launch_attenuation_items(sm, n_followers, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr, fol_list,
+                                 eval_counter, ctx->gl3, ctx->gl3_n, att_ovf2);
+        // their sum-of-magnitudes bound and Parseval norm with the computed attenuation (the channel prefilter multiplies the latter)
+        launch_efield_bound_list(sm, n_followers, fol_list, w, sd, cfg->min_efield_amplitude, max_efield, fol_flag);
+        LCHK("attenuation (second stage)");
+        S.n_active_rays += n_followers;
+    }
 
     MARK(6);
     MARK(7);

@@ -169,7 +169,11 @@ void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const Station
 void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin, int n_ch, const int* slot_offset, int* grp_ray,
                             int stride = NRHIP_MAXS);
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
-                           double min_efield, int* ray_active);
+                           double min_efield, int* ray_active, int own_only = 0);
+void launch_follower_list(hipStream_t s, int n_ev, const EventOut& ev, const double* att, int n_fc, int n_rays, int* flag, int* offset,
+                          int* scan_tmp, int* list, int* ray_active);
+void launch_efield_bound_list(hipStream_t s, int n_list, const int* list, const RayWork& w, const StationDev& st, double min_efield,
+                              double* max_efield, int* need_scratch);
 void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const int* offset, int* list);
 void launch_active_class_flags(hipStream_t s, int n_rays, const int* active, const int* ray_slot2, const int* slot_type,
                                int* flags);

@@ -1024,15 +1024,37 @@ __global__ void group_ray_range_kernel(int n_groups, const int* __restrict__ gro
 // per event: can any ray exceed the cut?  (1 + 1e-6 absorbs rounding of the bound and of exp(-integral) <= 1)
 __global__ void __launch_bounds__(256)
 event_possible_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, const double* __restrict__ bound,
-                      double min_efield, int* __restrict__ ray_active)
+                      double min_efield, int* __restrict__ ray_active, int own_only)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_events) return;
     int r0 = slot_offset[e], r1 = slot_offset[e + 1];  // ray range of the event group (group_ray_range_kernel)
+    if (own_only) {
+        // two-stage attenuation: first only the rays that could make their event a candidate on their own; the other rays of the
+        // events that did become candidates follow after the candidate cut (follower_flags_kernel)
+        for (int r = r0; r < r1; r++) ray_active[r] = (bound[r] * (1 + 1e-6) > min_efield) ? 1 : 0;
+        return;
+    }
     int possible = 0;
     for (int r = r0; r < r1; r++)
         if (bound[r] * (1 + 1e-6) > min_efield) possible = 1;
     for (int r = r0; r < r1; r++) ray_active[r] = possible;
+}
+
+// second stage of the attenuation: the rays of candidate readouts whose attenuation has not been computed yet (their own bound is
+// below the candidate cut, but the channel traces of a candidate event sum all its rays)
+__global__ void __launch_bounds__(256)
+follower_flags_kernel(int n_ev, EventOut ev, const double* __restrict__ att, int n_fc, int n_rays, int* __restrict__ flag,
+                      int* __restrict__ ray_active)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_ev || !ev.candidate[e]) return;
+    const int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
+    for (int r = r0; r < r1; r++)
+        if (!ray_active[r] && isnan(att[(long)r * n_fc])) {
+            flag[r] = 1;
+            ray_active[r] = 1;
+        }
 }
 
 __global__ void scatter_active_kernel(int n_rays, const int* __restrict__ active, const int* __restrict__ offset,
@@ -3073,12 +3095,30 @@ void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin,
     hipLaunchKernelGGL(group_ray_range_kernel, dim3(grid_for(n_groups + 1, 256)), dim3(256), 0, s, n_groups, group_begin, n_ch,
                        slot_offset, grp_ray, stride);
 }
+void launch_follower_list(hipStream_t s, int n_ev, const EventOut& ev, const double* att, int n_fc, int n_rays, int* flag, int* offset,
+                          int* scan_tmp, int* list, int* ray_active)
+{
+    if (n_ev <= 0 || n_rays <= 0) return;
+    (void)hipMemsetAsync(flag, 0, sizeof(int) * ((size_t)n_rays + 1), s);
+    hipLaunchKernelGGL(follower_flags_kernel, dim3(grid_for(n_ev, 256)), dim3(256), 0, s, n_ev, ev, att, n_fc, n_rays, flag, ray_active);
+    launch_exclusive_scan(s, (long)n_rays + 1, flag, offset, scan_tmp);
+    hipLaunchKernelGGL(scatter_flagged_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, flag, offset, list);
+}
+// sum-of-magnitudes bound and Parseval norm (what the channel prefilter multiplies) of the listed rays with their computed attenuation
+void launch_efield_bound_list(hipStream_t s, int n_list, const int* list, const RayWork& w, const StationDev& st, double min_efield,
+                              double* max_efield, int* need_scratch)
+{
+    if (n_list <= 0) return;
+    int gridA = (n_list + 4 * AB_RT - 1) / (4 * AB_RT);
+    if (gridA > 256 * 32) gridA = 256 * 32;
+    hipLaunchKernelGGL(efield_bound_kernel, dim3(gridA), dim3(256), 0, s, n_list, list, w, st, min_efield, 0, max_efield, need_scratch);
+}
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,
-                           double min_efield, int* ray_active)
+                           double min_efield, int* ray_active, int own_only)
 {
     if (n_events <= 0) return;
     hipLaunchKernelGGL(event_possible_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, n_ch, slot_offset,
-                       bound, min_efield, ray_active);
+                       bound, min_efield, ray_active, own_only);
 }
 void launch_active_class_flags(hipStream_t s, int n_rays, const int* active, const int* ray_slot2, const int* slot_type,
                                int* flags)
