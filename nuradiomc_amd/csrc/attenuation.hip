@@ -999,7 +999,7 @@ attenuation_group_kernel(long n_rays, const double* __restrict__ C0, const doubl
 #endif
     if (eval_counter) {  // integrand evaluations QUADPACK would count (for the FP64 rate reported by bench.py)
         for (int off = 32; off > 0; off >>= 1) my_evals += __shfl_xor(my_evals, off);
-        if ((threadIdx.x & 63) == 0) atomicAdd(eval_counter, my_evals);
+        if ((threadIdx.x & 63) == 0 && my_evals) atomicAdd(eval_counter, my_evals);   // (an empty overflow pass must not queue 4096 atomics on one word)
     }
 }
 
@@ -1214,7 +1214,7 @@ void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0,
             default: NRHIP_ATTD_LAUNCH(3); break;
         }
         long grid2 = (n_rays + ATT_BLOCK / 32 - 1) / (ATT_BLOCK / 32);
-        if (grid2 > 2048) grid2 = 2048;
+        if (grid2 > 512) grid2 = 512;   // the overflow list is empty or short (its length is known on the device only)
 #define NRHIP_ATTO_LAUNCH(MM)                                                                                              \
     hipLaunchKernelGGL((attenuation_group_kernel<32, MM>), dim3((unsigned)grid2), dim3(ATT_BLOCK), 0, stream, 2 * n_rays, C0, zint, \
                        n_freq, freqs, model, m, att, neval, overflow + 1, eval_counter, overflow)

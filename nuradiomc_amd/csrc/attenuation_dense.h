@@ -832,6 +832,6 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
 #endif
     if (eval_counter) {
         for (int off = 32; off > 0; off >>= 1) my_evals += __shfl_xor(my_evals, off);
-        if (lane == 0) atomicAdd(eval_counter, my_evals);
+        if (lane == 0 && my_evals) atomicAdd(eval_counter, my_evals);
     }
 }

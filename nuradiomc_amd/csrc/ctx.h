@@ -101,6 +101,9 @@ struct nrhip_station {
     // enough candidate events) and kept.  0 undecided, 1 split, 2 one block per CU
     int conv_mode = 0, conv_calls = 0;
     double conv_ms_per_event[2] = {0., 0.};
+    // the same for the attenuation in two stages or one (pipeline.hip): 0 undecided, 1 two stages, 2 one
+    int att_mode = 0, att_calls = 0;
+    double att_ms_per_ray[2] = {0., 0.};
     // workspace of the last simulated chunk (kept for nrhip_sim_fetch and reused between calls)
     std::map<std::string, DevArray> ws;
     std::map<std::string, size_t> ws_bytes;  // valid bytes of the last chunk

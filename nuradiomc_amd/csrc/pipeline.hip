@@ -1052,7 +1052,19 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     // events become candidates), after the candidate cut the other rays of the candidate readouts (the channel traces of a
     // candidate sum all its rays) -- the rays that are active only because an event-mate might have made the event a candidate,
     // and did not, are never integrated (10 % of the quadratures of the survey)
-    const bool two_stage = !general && n_refl == 0 && !cfg->no_pruning && !getenv("NRHIP_ATT_ONE_STAGE");
+    // (whether that pays depends on the workload -- few candidates, few followers: one launch less of everything; many candidates:
+    // the second stage repeats fixed costs for little saved work -- so, like conv_mode, a station times one call of each and keeps
+    // the faster; the bits are the same)
+    const bool two_stage_ok = !general && n_refl == 0 && !cfg->no_pruning;
+    const bool att_tunable = two_stage_ok && n_rays >= 20000 && !getenv("NRHIP_ATT_ONE_STAGE") && !getenv("NRHIP_ATT_TWO_STAGE");
+    int att_trial = -1;
+    bool two_stage = two_stage_ok && st->att_mode != 2;
+    if (getenv("NRHIP_ATT_ONE_STAGE")) two_stage = false;
+    else if (getenv("NRHIP_ATT_TWO_STAGE")) two_stage = two_stage_ok;
+    else if (att_tunable && st->att_mode == 0 && st->att_calls++ >= 1) {
+        att_trial = (st->att_ms_per_ray[0] == 0.) ? 0 : 1;
+        two_stage = att_trial == 0;
+    }
     int* ractive = nullptr;
     if (n_rays > 0) {
         int *roff, *rtmp, *cflags;
@@ -1605,6 +1617,14 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         *stats = S;
     } else {
         HIPCHK(hipStreamSynchronize(sm));
+    }
+    if (att_trial >= 0) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, st->evt[3], st->evt[6]) == hipSuccess && ms > 0.f) {
+            st->att_ms_per_ray[att_trial] = (double)ms / (double)n_rays;
+            if (st->att_ms_per_ray[0] > 0. && st->att_ms_per_ray[1] > 0.)
+                st->att_mode = (st->att_ms_per_ray[0] <= st->att_ms_per_ray[1]) ? 1 : 2;
+        }
     }
     return 0;
 }
