@@ -260,13 +260,13 @@ def test_config5_gen2_array(gpu_ctx_factory):
 
 @pytest.mark.parametrize('config', [3, 4, 5])
 def test_array_full_size_properties(gpu_ctx_factory, config):
-    """bench.py's array workloads at a size the oracle cannot follow (config 3: 2e5 events x 35 x 24 = 1.7e8 pairs; config 5:
-    1e5 events x 200 x 5 = 1e8 pairs; config 4, ARZ2020 + birefringence at 4096 samples: 1e4 events x 35 x 24 = 8.4e6 pairs, the
-    oracle needs about a minute per event group with rays there): the OR mask is a function of the event alone -- permuting the list permutes the mask,
+    """bench.py's array workloads AT THE BENCH SIZE, which the oracle cannot follow (config 3: 1e6 events x 35 x 24 = 8.4e8 pairs;
+    config 5: 1e6 events x 200 x 5 = 1e9 pairs; config 4, ARZ2020 + birefringence at 4096 samples: 2e4 events x 35 x 24 = 1.7e7 pairs,
+    the oracle needs about a minute per event group with rays there): the OR mask is a function of the event alone -- permuting the list permutes the mask,
     unequal shards concatenate to the whole (what the multi-GPU sharding relies on) --, the device-resident accumulate form
     equals the OR of the per-station masks, triggered events are a subset of what any single station reports."""
     import bench
-    wl = bench.make_workload(config, {3: 200000, 4: 10000, 5: 100000}[config], seed=10)
+    wl = bench.make_workload(config, {3: 1000000, 4: 20000, 5: 1000000}[config], seed=10)
     ctx = gpu_ctx_factory(wl['ice'], wl['att_model'])
     arr = bench.build_array(ctx, wl)
     a = wl['events']
