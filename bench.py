@@ -462,7 +462,7 @@ def main():
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         value = n_total * args.steps / elapsed
         dom = max((k for k in sm if k != 'total'), key=lambda k: sm[k])
-        kernel_of = {'raytrace': 'raytrace_kernel', 'ray_setup': 'select/scan/ray_setup kernels',
+        kernel_of = {'raytrace': 'raytrace_roots_kernel', 'ray_setup': 'select/scan/ray_setup kernels',
                      'amp_bound': 'amp_bound_kernel', 'attenuation': 'attenuation_dense_kernel',
                      'efield_max': 'efield_bound_kernel + efield_max_kernel' if cfgno != 4 else
                                    'arz_vector_potential_kernel + bire_steps_kernel + bire_propagate_kernel (general path)',

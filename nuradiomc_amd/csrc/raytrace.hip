@@ -16,90 +16,167 @@
 
 namespace nrhip {
 
-// Kernel: pair i = (event i / n_ch, channel i % n_ch) when n_ch > 0, else x2 is per pair.
+// the 2-D geometry of a pair: set_start_and_end_point (:2057-2090, the higher point becomes the stop point) and the rotation by
+// dPhi = -atan2(dy, dx) into the y-z plane, cos / sin taken algebraically (bit-reproducible)
+struct PairGeom {
+    double A0, A2;      // start point (x, z) after the swap
+    double y2, z2;      // stop point in the rotated frame
+    double cph, sph;
+    double dist;        // |x2 - x1|
+    bool swap;
+};
+__device__ __forceinline__ PairGeom pair_geometry(const double* __restrict__ x1, const double* __restrict__ x2, long i1, long i2)
+{
+    double A[3] = {x1[3 * i1], x1[3 * i1 + 1], x1[3 * i1 + 2]};
+    double B[3] = {x2[3 * i2], x2[3 * i2 + 1], x2[3 * i2 + 2]};
+    PairGeom g;
+    g.swap = B[2] < A[2];
+    if (g.swap) {
+        for (int d = 0; d < 3; d++) { double t = A[d]; A[d] = B[d]; B[d] = t; }
+    }
+    const double dX[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+    const double rho = sqrt(dX[0] * dX[0] + dX[1] * dX[1]);
+    g.cph = 1.;
+    g.sph = 0.;
+    if (rho > 0) {
+        g.cph = dX[0] / rho;
+        g.sph = -(dX[1] / rho);
+    }
+    g.A0 = A[0];
+    g.A2 = A[2];
+    g.y2 = (g.cph * dX[0] + (-g.sph) * dX[1] + 0 * dX[2]) + A[0];
+    g.z2 = (0 * dX[0] + 0 * dX[1] + 1 * dX[2]) + A[2];
+    g.dist = sqrt(dX[0] * dX[0] + dX[1] * dX[1] + dX[2] * dX[2]);
+    return g;
+}
+
+// Kernels: pair i = (event i / n_ch, channel i % n_ch) when n_ch > 0, else x2 is per pair.
+//
+// Two launches.  `raytrace_roots_kernel` runs the finder (hybrd + two Brent searches, ~1e2 calls of the objective per pair, which
+// only sees the pair's six numbers in an LDS column) and writes the sorted launch parameters C0 and their count -- 20 B per pair.
+// `raytrace_records_kernel` then makes the per-solution records (type, C1, D, T, angles, vectors) from C0, in the natural order
+// of the pairs (coalesced) and with its own register budget.  As ONE kernel (rounds 1-2) the records code shared the finder's 80
+// registers: the compiler hoisted ~25 polynomial constants of its atan2 / log / path-length code out of the pair loop, spilled
+// them, and re-read them for every solution -- 1.6 KB of scratch reads per pair that miss the L2 (the scratch of all resident
+// waves is 26 MB per XCD): 8 GB of fetches and 6 GB of write-backs per 5e6 pairs (`profiles/r03_pmc_traffic.csv`, 14.5 GB).
+// det_exp as a call: inlined into the finder kernel its 16 polynomial constants are hoisted out of the pair loop and spilled
+__device__ __noinline__ double det_exp_call(double x) { return det_exp(x); }
+
 #ifndef NRHIP_RT_WAVES
 #define NRHIP_RT_WAVES 6  // waves per SIMD the register budget is cut for (measured best)
 #endif
 __global__ void __launch_bounds__(256, NRHIP_RT_WAVES)
-raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
-                IceConst m, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm,
-                const double* __restrict__ given_C0)
+raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
+                      IceConst m_arg, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm)
 {
-#ifndef NRHIP_RT_SCRATCH_PAIR
     __shared__ double sh_pair[6][256];   // the pair geometry the objective reads on every evaluation (see delta_y_lds)
-#endif
+    __shared__ IceConst sh_ice;          // the ice model for the (non-inlined) objective: a reference to the kernel argument would
+                                         // be a per-lane copy in scratch (64 B x every resident lane, re-read by every call)
+    double* const sp = &sh_pair[0][threadIdx.x];   // (only this lane reads its column: no barrier)
+    if (threadIdx.x == 0) sh_ice = m_arg;
+    __syncthreads();
+    const IceConst& m = sh_ice;
     for (long iw = blockIdx.x * (long)blockDim.x + threadIdx.x; iw < n_pairs; iw += (long)gridDim.x * blockDim.x) {
         // perm (optional): events in an order that puts similar geometries (distance, depth) next to each other, so that
         // the lanes of a wave run similar numbers of root-finder iterations; results land at the original pair index
         long i1 = (n_ch > 0) ? iw / n_ch : iw;
-        long i2 = (n_ch > 0) ? iw % n_ch : iw;
+        const long i2 = (n_ch > 0) ? iw % n_ch : iw;
         if (perm) i1 = perm[i1];
         const long i = (n_ch > 0) ? i1 * n_ch + i2 : iw;
-        double A[3] = {x1[3 * i1], x1[3 * i1 + 1], x1[3 * i1 + 2]};
-        double B[3] = {x2[3 * i2], x2[3 * i2 + 1], x2[3 * i2 + 2]};
-        // set_start_and_end_point (:2057-2090): the higher point becomes the stop point
-        bool swap = B[2] < A[2];
-        if (swap) {
-            for (int d = 0; d < 3; d++) { double t = A[d]; A[d] = B[d]; B[d] = t; }
+        bool search;
+        {
+            const PairGeom g = pair_geometry(x1, x2, i1, i2);
+            sp[0] = g.A0; sp[256] = g.A2; sp[512] = g.y2; sp[768] = g.z2;
+            sp[1024] = m.delta_n * det_exp_call(g.A2 / m.z_0); sp[1280] = m.delta_n * det_exp_call(g.z2 / m.z_0);   // gamma_of_z
+            // speedup.distance_cut (simulation.py:155-163): showers farther from the antenna than their cut are not traced
+            const bool too_far = max_dist && g.dist > max_dist[i1];
+            // receiver in air: special branch of the reference (:1437-1460) not provided
+            search = !(g.z2 > 0) && !too_far;
         }
-        double dX[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
-        // rotation by dPhi = -atan2(dy, dx) into the y-z plane, cos / sin taken algebraically (bit-reproducible)
-        double rho = sqrt(dX[0] * dX[0] + dX[1] * dX[1]);
-        double cph = 1., sph = 0.;
-        if (rho > 0) {
-            cph = dX[0] / rho;
-            sph = -(dX[1] / rho);
-        }
-        Pair2D p;
-        p.y1 = A[0];
-        p.z1 = A[2];
-        p.y2 = (cph * dX[0] + (-sph) * dX[1] + 0 * dX[2]) + A[0];
-        p.z2 = (0 * dX[0] + 0 * dX[1] + 1 * dX[2]) + A[2];
-        p.g1 = gamma_of_z(p.z1, m);
-        p.g2 = gamma_of_z(p.z2, m);
-
         int ns = 0;
-        double lc[3];
-        // speedup.distance_cut (simulation.py:155-163): showers farther from the antenna than their cut are not traced
-        const bool too_far = max_dist && sqrt(dX[0] * dX[0] + dX[1] * dX[1] + dX[2] * dX[2]) > max_dist[i1];
-        if (!(p.z2 > 0) && !too_far && !given_C0) {  // receiver in air: special branch of the reference (:1437-1460) not provided
-#ifndef NRHIP_RT_SCRATCH_PAIR
-            double* const sp = &sh_pair[0][threadIdx.x];   // (only this lane reads its column: no barrier)
-            sp[0] = p.y1; sp[256] = p.z1; sp[512] = p.y2; sp[768] = p.z2; sp[1024] = p.g1; sp[1280] = p.g2;
+        double lc0 = 0., lc1 = 0., lc2 = 0.;
+        if (search) {
             auto dy = [&](double l) { return delta_y_lds(l, sp, 256, m); };
             auto dy2 = [&](double l) { double d = delta_y_lds(l, sp, 256, m); return d * d; };
-#else
-            auto dy = [&](double l) { return delta_y(l, p, m); };
-            auto dy2 = [&](double l) { double d = delta_y(l, p, m); return d * d; };
-#endif
             double fun;
-            double xr = hybrd1(dy2, -1., 1e-6, &fun);
-            if (fun < 1e-7) lc[ns++] = xr;
+            const double xr = hybrd1(dy2, -1., 1e-6, &fun);
+            if (fun < 1e-7) { lc0 = xr; ns = 1; }
             {
                 double a = xr + 0.0001, b = 100.;
                 double fa = dy(a), fb = dy(b);
-                if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) lc[ns++] = brentq(dy, a, b, fa, fb);
+                if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) {
+                    const double r = brentq(dy, a, b, fa, fb);
+                    if (ns == 0) lc0 = r; else lc1 = r;
+                    ns++;
+                }
             }
             {
                 double a = -100., b = xr - 0.0001;
                 double fa = dy(a), fb = dy(b);
-                if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) lc[ns++] = brentq(dy, a, b, fa, fb);
+                if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) {
+                    const double r = brentq(dy, a, b, fa, fb);
+                    if (ns == 0) lc0 = r; else if (ns == 1) lc1 = r; else lc2 = r;
+                    ns++;
+                }
             }
         }
-        double c0[3];
-        for (int k = 0; k < ns; k++) c0[k] = det_exp(lc[k]) + m.inv_n;
+        double c0a = NAN, c0b = NAN, c0c = NAN;
+        if (ns > 0) c0a = det_exp_call(lc0) + m.inv_n;
+        if (ns > 1) c0b = det_exp_call(lc1) + m.inv_n;
+        if (ns > 2) c0c = det_exp_call(lc2) + m.inv_n;
+        // sorted by C0 (<= 3 entries)
+        if (ns > 1 && c0b < c0a) { double t = c0a; c0a = c0b; c0b = t; }
+        if (ns > 2 && c0c < c0b) { double t = c0b; c0b = c0c; c0c = t; }
+        if (ns > 1 && c0b < c0a) { double t = c0a; c0a = c0b; c0b = t; }
+        if (ns > NRHIP_MAXS) {  // "too many solutions -> none" (:2127-2130)
+            ns = 0;
+            c0a = c0b = NAN;
+        }
+        out.n_sol[i] = ns;
+        out.C0[i * NRHIP_MAXS] = c0a;
+        out.C0[i * NRHIP_MAXS + 1] = c0b;
+    }
+}
+
+#ifndef NRHIP_RTREC_WAVES
+#define NRHIP_RTREC_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, NRHIP_RTREC_WAVES)
+raytrace_records_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
+                        IceConst m, RayRecords out, const double* __restrict__ given_C0)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_pairs; i += (long)gridDim.x * blockDim.x) {
+        const long i1 = (n_ch > 0) ? i / n_ch : i;
+        const long i2 = (n_ch > 0) ? i % n_ch : i;
+        const PairGeom g = pair_geometry(x1, x2, i1, i2);
+        Pair2D p;
+        p.y1 = g.A0; p.z1 = g.A2; p.y2 = g.y2; p.z2 = g.z2;
+        p.g1 = gamma_of_z(p.z1, m);
+        p.g2 = gamma_of_z(p.z2, m);
+        const bool swap = g.swap;
+        const double cph = g.cph, sph = g.sph;
+        int ns;
+        double c0v[NRHIP_MAXS];
         if (given_C0) {  // ray_tracing.set_solution (:2092): launch parameters read back from a file, no root finding
             ns = 0;
+            double c0a = NAN, c0b = NAN, c0c = NAN;
             for (int k = 0; k < NRHIP_MAXS; k++) {
                 double v = given_C0[i * NRHIP_MAXS + k];
-                if (!isnan(v)) c0[ns++] = v;
+                if (!isnan(v)) {
+                    if (ns == 0) c0a = v; else if (ns == 1) c0b = v; else c0c = v;
+                    ns++;
+                }
             }
+            if (ns > 1 && c0b < c0a) { double t = c0a; c0a = c0b; c0b = t; }
+            c0v[0] = c0a;
+            c0v[1] = c0b;
+            out.n_sol[i] = ns;
+        } else {
+            ns = out.n_sol[i];
+            c0v[0] = out.C0[i * NRHIP_MAXS];
+            c0v[1] = out.C0[i * NRHIP_MAXS + 1];
         }
-        // sorted by C0 (insertion sort, <= 3 entries)
-        for (int a = 1; a < ns; a++)
-            for (int b = a; b > 0 && c0[b] < c0[b - 1]; b--) { double t = c0[b]; c0[b] = c0[b - 1]; c0[b - 1] = t; }
-        if (ns > NRHIP_MAXS) ns = 0;  // "too many solutions -> none" (:2127-2130)
-        out.n_sol[i] = ns;
+#pragma unroll
         for (int s = 0; s < NRHIP_MAXS; s++) {
             long k = i * NRHIP_MAXS + s;
             if (s >= ns) {
@@ -108,7 +185,8 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
                 for (int d = 0; d < 3; d++) out.launch[3 * k + d] = out.receive[3 * k + d] = NAN;
                 continue;
             }
-            C0State st = make_c0(c0[s], m);
+            const double c0s = c0v[s];
+            C0State st = make_c0(c0s, m);
             double C1 = C1_of(st, p, m);
             int type = solution_type(st, C1, p);
             double sL, cL, s2, c2;
@@ -123,7 +201,7 @@ raytrace_kernel(long n_pairs, const double* __restrict__ x1, const double* __res
                 rv0 = sL;  rv2 = cL;
             }
             out.type[k] = type;
-            out.C0[k] = c0[s];
+            out.C0[k] = c0s;
             out.C1[k] = C1;
             out.D[k] = D;
             out.T[k] = T;
@@ -188,7 +266,9 @@ void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const d
     int block = 256;
     long grid = (n_pairs + block - 1) / block;
     if (grid > 256L * 64) grid = 256L * 64;
-    hipLaunchKernelGGL(raytrace_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, given_C0);
+    if (!given_C0)
+        hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm);
+    hipLaunchKernelGGL(raytrace_records_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, given_C0);
 }
 
 }  // namespace nrhip
