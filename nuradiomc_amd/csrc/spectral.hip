@@ -1095,10 +1095,44 @@ __global__ void scatter_active_class_kernel(int n_rays, const int* __restrict__ 
 // components proportional to one real pulse: a single transform serves both.
 // LDS: N/2 complex + (N/2 + 1) doubles.
 // ---------------------------------------------------------------------------------------------------------
+// FP64 sums of efield_bound_kernel for one ray (lane = frequency bin modulo 64): sum_k amp_k att_k and sum_k (amp_k att_k)^2
+__device__ __noinline__ double2 efield_bound_fp64_ray(int N, double fs, int n_fc, const unsigned char* __restrict__ seg,
+                                                       const double* __restrict__ fpow, const double* __restrict__ lnf,
+                                                       const AskaryanConst& ask, const double* at, const double* at_slope,
+                                                       const double* s_xp, int lane)
+{
+    const int nh = N / 2, stride = nh + 1;
+    const double df = 1.0 / (N * (1. / fs));
+    const double x_first = s_xp[0], x_last = s_xp[n_fc - 1], dx_last = x_last - s_xp[n_fc - 2];
+    const bool is2009 = (ask.model == 0);
+    double part = 0., sq = 0.;
+    for (int k = 1 + lane; k < nh; k += 64) {
+        const double f = k * df;
+        int lo = seg[k];
+        double dx = f - s_xp[lo];
+        if (f <= x_first) { lo = 0; dx = 0.; }
+        if (f >= x_last) { lo = n_fc - 2; dx = dx_last; }
+        double amp;
+        if (is2009) {
+            const double x = (ask.had ? fpow[k] : fpow[stride + k]) * ask.cL, y = fpow[2 * stride + k] * ask.cR;
+            amp = ask.pref2 * f * bound_rcp((1 + x) * (1 + y));
+        } else {
+            amp = askaryan_amplitude(f, lnf[k], ask);
+        }
+        const double v = amp * (at_slope[lo] * dx + at[lo]);
+        part += v;
+        sq += v * v;
+    }
+    return make_double2(part, sq);
+}
+
 // kernel: with attenuation known, the sum-of-magnitudes bound on max |E(t)| and the L2 norm of the unit-polarisation
 // pulse of every active ray (one wave per AB_RT rays, frequency-grid tables loaded once per AB_RT rays).  Rays whose bound
 // stays below the cut report the negated bound; the others are flagged for the time-domain transform.
-__global__ void __launch_bounds__(256, 4)
+#ifndef NRHIP_EB_WAVES
+#define NRHIP_EB_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, NRHIP_EB_WAVES)
 efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w, StationDev st, double min_efield,
                     int exact, double* __restrict__ max_efield, int* __restrict__ need_fft)
 {
@@ -1173,27 +1207,13 @@ efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w
                     part[i] = (double)p32[i] * BOUND_F32_SLACK + 1e-30;  // + what FP32 may have flushed to zero
                     sq[i] = (double)q32[i] * (BOUND_F32_SLACK * BOUND_F32_SLACK) + 1e-60;
                 }
-            } else
-            for (int k = 1 + lane; k < nh; k += 64) {
-                const double f = k * df;
-                int lo = st.seg[k];
-                double dx = f - s_xp[lo];
-                if (f <= x_first) { lo = 0; dx = 0.; }
-                if (f >= x_last) { lo = st.n_fc - 2; dx = dx_last; }
-                double ph = 0., pe = 0., pr = 0.;
-                if (all2009) { ph = st.fpow[k]; pe = st.fpow[stride + k]; pr = st.fpow[2 * stride + k]; }
-#pragma unroll
+            } else {
+                // rare (another emission model, or parameters outside the FP32 range): FP64, ray by ray, out of line -- inlined
+                // four times this loop's registers pushed the common path above into scratch (1.3 GB of spill writes per launch)
                 for (int i = 0; i < AB_RT; i++) {
-                    double amp;
-                    if (all2009) {
-                        double x = (had[i] ? ph : pe) * cL[i], y = pr * cR[i];
-                        amp = pf[i] * f * bound_rcp((1 + x) * (1 + y));
-                    } else {
-                        amp = askaryan_amplitude(f, st.lnf[k], w.ask[rr[i]]);
-                    }
-                    double v = amp * (at_slope[wv][i][lo] * dx + at[wv][i][lo]);
-                    part[i] += v;
-                    sq[i] += v * v;
+                    const double2 r = efield_bound_fp64_ray(st.N, st.fs, st.n_fc, st.seg, st.fpow, st.lnf, w.ask[rr[i]], at[wv][i], at_slope[wv][i], s_xp, lane);
+                    part[i] = r.x;
+                    sq[i] = r.y;
                 }
             }
             for (int i = 0; i < AB_RT; i++) {
