@@ -532,13 +532,16 @@ int64_t nrhip_sim_fetch(nrhip_station* st, const char* name, void* host_dst, uin
  * endpoint [n][3]: vertex, z < 0 below the surface; direction [n][3]: hp.spherical_to_cartesian(zenith, azimuth) of the
  * arrival direction as the caller computed it (normalised on the device as :211 does) -- both only read in the chord
  * mode.  flavor: PDG code (< 0 antiparticle).  nucleon_mass = constants.m_p * units.kg.  weight [n] and slant_depth [n]
- * (chord mode only) may each be NULL.  'ctw' below 1e4 GeV gives NaN (cross_sections.py:69-76).  HOST pointers.   */
+ * (chord mode only) may each be NULL.  'ctw' below 1e4 GeV gives NaN (cross_sections.py:69-76).  HOST pointers.
+ * A cross section of 0 (what the reference's 'csms' returns for inttype='total') gives weight 1.               */
 #define NRHIP_EARTH_SIMPLE 0
 #define NRHIP_EARTH_CORE_MANTLE_CRUST_SIMPLE 1
 #define NRHIP_EARTH_CHORD 2
 #define NRHIP_EARTH_MAX_LAYERS 16
 #define NRHIP_XS_CTW 0
 #define NRHIP_XS_GHANDI 1
+#define NRHIP_XS_GIVEN 2   /* `energy` holds the total cross section [m^2] of each event: tabulated models ('csms' :123-229,
+                              'hedis_bgr18' :283-299, a data file) are evaluated by the caller                             */
 typedef struct {
     int32_t n_layers;
     int32_t reserved;

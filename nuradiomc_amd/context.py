@@ -9,7 +9,7 @@ ATTENUATION_MODEL_TO_INT = {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4, "GL3": 5}
 MAXS = 2
 
 
-CROSS_SECTION_TO_INT = {'ctw': 0, 'ghandi': 1}
+CROSS_SECTION_TO_INT = {'ctw': 0, 'ghandi': 1, 'given': 2}   # 'given': `energy` carries the cross sections [m^2]
 PROTON_MASS_KG = 1.67262192595e-27  # scipy.constants.m_p (CODATA 2022), what cross_sections.get_interaction_length uses
 
 
@@ -246,7 +246,7 @@ class Context:
     def earth_weights_batch(self, zenith, energy, flavor, mode, endpoint=None, direction=None, model=None, step=500.,
                             nucleon_mass=None, return_slant_depth=False, cross_section_type='ctw'):
         """Earth-absorption weights of n events (earth_attenuation.get_weight, NuRadioMC/utilities/earth_attenuation.py:12-60;
-        cross_section_type 'ctw' or 'ghandi').  mode: 0 'simple', 1 'core_mantle_crust_simple', 2 chord through the layered density
+        cross_section_type 'ctw' or 'ghandi'; 'given': `energy` holds each event's total cross section in m^2).  mode: 0 'simple', 1 'core_mantle_crust_simple', 2 chord through the layered density
         `model` = (earth_radius, radii [n_layers], coefficients [n_layers, 4]) from `endpoint` [n, 3] towards `direction`
         [n, 3] (PREM.slant_depth :183-240)."""
         if cross_section_type not in CROSS_SECTION_TO_INT:

@@ -536,7 +536,7 @@ int nrhip_earth_weights_batch(nrhip_ctx* ctx, int64_t n, const double* zenith, c
     if (n < 0) return fail_msg("nrhip_earth_weights_batch: negative size");
     if (mode != NRHIP_EARTH_SIMPLE && mode != NRHIP_EARTH_CORE_MANTLE_CRUST_SIMPLE && mode != NRHIP_EARTH_CHORD)
         return fail_msg("nrhip_earth_weights_batch: mode not supported");  // NotImplementedError (earth_attenuation.py:58-60)
-    if (cross_section_type != NRHIP_XS_CTW && cross_section_type != NRHIP_XS_GHANDI)
+    if (cross_section_type != NRHIP_XS_CTW && cross_section_type != NRHIP_XS_GHANDI && cross_section_type != NRHIP_XS_GIVEN)
         return fail_msg("nrhip_earth_weights_batch: Cross-section not defined");  // cross_sections.py:387-389
     const bool chord = mode == NRHIP_EARTH_CHORD;
     if (chord) {

@@ -37,6 +37,7 @@ __device__ inline double ctw_total(double energy, int flavor)
 __device__ inline double total_cross_section(int type, double energy, int flavor)
 {
     if (type == NRHIP_XS_GHANDI) return 7.84e-36 * (0.01 * 0.01) * pow(energy / 1e9, 0.363);  // :280-281
+    if (type == NRHIP_XS_GIVEN) return energy;   // the caller evaluated its (tabulated) model: `energy` carries sigma [m^2]
     return ctw_total(energy, flavor);
 }
 

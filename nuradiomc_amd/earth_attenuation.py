@@ -4,7 +4,8 @@ lists at once (nrhip_earth_weights_batch).  simulation.py:880-903 calls get_weig
 here the same arguments may be arrays of n events and the scalars of the reference are the n = 1 case.
 
 cross_section_type 'ctw' (the reference's config_default.yaml) and 'ghandi' are evaluated on the device; the tabulated
-cross sections ('csms', 'hedis_bgr18': a data file) raise NotImplementedError.
+'csms' goes through nuradiomc_amd/cross_sections.py (the published table) and, like any values the caller computed itself
+(`cross_section=`: 'hedis_bgr18' from its data file), reaches the device as per-event cross sections (NRHIP_XS_GIVEN).
 """
 import numpy as np
 from .context import Context
@@ -62,20 +63,27 @@ class CoreMantleCrustModel(PREM):
     polynomials_g_cm3 = ((14., 0., 0., 0.), (3.4, 0., 0., 0.), (2.9, 0., 0., 0.))
 
 
-def get_weight(theta_nu, pnu, flavors, mode='simple', cross_section_type='ctw', vertex_position=None, phi_nu=None, ctx=None):
+def get_weight(theta_nu, pnu, flavors, mode='simple', cross_section_type='ctw', vertex_position=None, phi_nu=None, ctx=None,
+               cross_section=None):
     """Earth-absorption weight (earth_attenuation.get_weight :12-60): scalars as the reference takes them, or arrays of n
-    events (theta_nu, pnu, flavors, phi_nu [n]; vertex_position [n, 3])."""
+    events (theta_nu, pnu, flavors, phi_nu [n]; vertex_position [n, 3]).  cross_section [n] (m^2): total cross sections the caller
+    evaluated, used instead of cross_section_type."""
     if mode == "None":
         return 1.
     if mode not in ('simple', 'core_mantle_crust_simple', 'core_mantle_crust', 'PREM'):
         raise NotImplementedError('mode {} not supported'.format(mode))
-    if cross_section_type not in ('ctw', 'ghandi'):
-        raise NotImplementedError("cross section {} is not evaluated on the device ('ctw', 'ghandi')".format(cross_section_type))
     scalar = np.ndim(theta_nu) == 0
     theta = np.atleast_1d(np.asarray(theta_nu, float))
     n = len(theta)
     pnu = np.broadcast_to(np.asarray(pnu, float), (n,))
     flavors = np.broadcast_to(np.asarray(flavors), (n,))
+    if cross_section is None and cross_section_type not in ('ctw', 'ghandi'):
+        # get_interaction_length asks for inttype='total' (cross_sections.py:393-421): 'csms' has no such rows and gives 0 -> weight 1
+        from . import cross_sections
+        cross_section = cross_sections.get_nu_cross_section(pnu, 0 if mode == 'simple' else flavors, 'total', cross_section_type)
+    if cross_section is not None:
+        pnu = np.broadcast_to(np.asarray(cross_section, float), (n,))
+        cross_section_type = 'given'
     ctx = ctx if ctx is not None else _default_context()
     if mode == 'simple':
         w = ctx.earth_weights_batch(theta, pnu, flavors, 0, cross_section_type=cross_section_type)

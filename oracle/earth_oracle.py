@@ -104,6 +104,8 @@ def total_cross_section(energy, flavor, cross_section_type='ctw'):
         return ctw_total(energy, flavor)
     if cross_section_type == 'ghandi':
         return ghandi(energy)
+    if cross_section_type == 'given':   # tabulated models evaluated by the caller: `energy` carries the cross sections [m^2]
+        return np.asarray(energy, float)
     raise NotImplementedError(cross_section_type)
 
 

@@ -49,6 +49,25 @@ def test_weights_vs_reference_and_oracle(ctx):
         assert abs(cls(ctx).slant_depth(g['vertex'][7], d[7]) - ref[7]) <= 1e-12 * ref[7]
 
 
+def test_given_cross_sections(ctx):
+    """Tabulated cross sections evaluated by the caller (NRHIP_XS_GIVEN): the 'csms' table (cc + nc of each event, from
+    tests/golden/ref_csms.npz: the reference's values) through every mode, against the oracle with the same values."""
+    from nuradiomc_amd import earth_attenuation as ea, cross_sections as xs
+    from oracle import earth_oracle as eo
+    g = golden('ref_earth_weights.npz')
+    n = len(g['zenith'])
+    sigma = xs.csms(g['energy'], np.full(n, 'cc'), g['flavor']) + xs.csms(g['energy'], np.full(n, 'nc'), g['flavor'])
+    assert np.all(sigma > 0)
+    for mode in ('simple', 'core_mantle_crust_simple', 'core_mantle_crust', 'PREM'):
+        w = ea.get_weight(g['zenith'], g['energy'], g['flavor'], mode=mode, vertex_position=g['vertex'], phi_nu=g['azimuth'], ctx=ctx,
+                          cross_section=sigma)
+        wo = eo.get_weight(g['zenith'], g['azimuth'], sigma, g['flavor'], g['vertex'], mode, cross_section_type='given')
+        big = wo > 1e-100
+        assert big.sum() > n // 4 and max_rel(w[big], wo[big]) < 1e-6 and np.max(np.abs(w - wo)) < 1e-9, mode
+        wc = ea.get_weight(g['zenith'], g['energy'], g['flavor'], mode=mode, vertex_position=g['vertex'], phi_nu=g['azimuth'], ctx=ctx)
+        assert 0.2 < np.median(np.log(w[big & (wc > 1e-100) & (w < 0.99)]) / np.log(wc[big & (wc > 1e-100) & (w < 0.99)])) < 5   # same physics, another table
+
+
 def test_errors_and_edges(ctx):
     from nuradiomc_amd import earth_attenuation as ea
     import nuradiomc_amd as nr
@@ -56,7 +75,9 @@ def test_errors_and_edges(ctx):
     with pytest.raises(NotImplementedError):
         ea.get_weight(2., 1e18, 12, mode='two_layers', ctx=ctx)
     with pytest.raises(NotImplementedError):
-        ea.get_weight(2., 1e18, 12, mode='simple', cross_section_type='csms', ctx=ctx)
+        ea.get_weight(2., 1e18, 12, mode='simple', cross_section_type='hedis_bgr18', ctx=ctx)   # a download of the reference
+    # 'csms' has no rows for inttype='total' (what get_interaction_length asks for): cross section 0, weight 1 -- as the reference
+    assert ea.get_weight(np.full(3, 2.), np.full(3, 1e18), np.full(3, 12), mode='simple', cross_section_type='csms', ctx=ctx).tolist() == [1., 1., 1.]
     assert len(ea.get_weight(np.zeros(0), np.zeros(0), np.zeros(0, int), mode='simple', ctx=ctx)) == 0
     # below 1e4 GeV the parametrisation is not valid: NaN (cross_sections.py:69-76)
     assert np.isnan(ea.get_weight(2., 1e12, 12, mode='simple', ctx=ctx))

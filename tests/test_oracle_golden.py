@@ -458,3 +458,17 @@ def test_phased_array_modes_vs_reference():
         assert np.max(np.abs(got - ref)) <= (0 if counts else 1e-12 * np.max(np.abs(ref))), k
     for taps, cutoff, pz, fs in ((45, 0.236, True, 1.888), (31, 0.25, False, 1.), (23, 0.3, True, 2.4), (15, 0.25, False, 1.)):
         assert np.max(np.abs(filters.firwin(taps, cutoff, pz, fs) - ssig.firwin(taps, cutoff, pass_zero=pz, fs=fs))) < 1e-15
+
+
+def test_csms_cross_section_table():
+    """nuradiomc_amd/cross_sections.py (host side of NRHIP_XS_GIVEN) against the reference's 'csms' values
+    (tests/golden/ref_csms.npz, generator tests/golden/gen/gen_csms.py): per interaction type exact to rounding; inttype='total'
+    gives zeros there and here; outside the table a ValueError as interp1d(bounds_error=True) raises."""
+    from nuradiomc_amd import cross_sections as xs
+    g = golden('ref_csms.npz')
+    got = xs.get_nu_cross_section(g['energy'], g['flavor'], np.where(g['is_cc'], 'cc', 'nc'), 'csms')
+    assert np.max(np.abs(got / g['sigma'] - 1)) < 1e-14
+    assert np.array_equal(xs.get_nu_cross_section(g['energy'], g['flavor'], 'total', 'csms'), g['sigma_total'])
+    assert not g['sigma_total'].any()
+    with pytest.raises(ValueError):
+        xs.csms(np.array([1e9]), 'cc', 12)
