@@ -455,7 +455,9 @@ int nrhip_station_set_envelope_trigger(nrhip_station* st, int32_t nb, int32_t na
  * then signal_processing.digital_upsampling (:111-190, 'fft') by upsampling_factor (1: none); beams with rolls_up [n_beams][n_pa]
  * (whole-sample shifts at adc_sampling_frequency * upsampling_factor), saturation of count sums at saturation_bits (phase_signals
  * :183-215), window powers rounded for counts (power_sum :217-271).  adc_sampling_frequency <= 0 switches the digitisation off.
- * Tables afterwards: "pa_digital_trace" [n_candidates][n_pa][stride], "pa_digital_length" [n_candidates][n_pa], "pa_max_power". */
+ * Tables afterwards: "pa_digital_trace" [n_candidates][n_pa][stride], "pa_digital_length" [n_candidates][n_pa], "pa_max_power".
+ * n_bits = 0 (with adc_sampling_frequency = the simulation's rate): no digitisation -- phased_trigger(apply_digitization=False)
+ * with upsampling_kwargs / mode 'hilbert_env' (:312-321): the analog channel traces take the same up-sampling, beams and envelope. */
 int nrhip_station_set_phased_array_adc(nrhip_station* st, double adc_sampling_frequency, int32_t n_bits, double v_min, double v_max,
                                        int32_t output_counts, int32_t upsampling_factor, int32_t saturation_bits, int32_t resample_p,
                                        int32_t resample_q, const int32_t* rolls_up);
@@ -465,7 +467,9 @@ int nrhip_station_set_phased_array_adc(nrhip_station* st, double adc_sampling_fr
  * rounded to 1 / coeff_gain and trimmed of zeros, as the caller designed it -- times the factor);
  * mode 0 = 'power_sum', 1 = 'hilbert_env' (PhasedArrayBase.hilbert_envelope :337-367 with ideal_transformer = False: the FIR
  * transformer hilbert_taps[n_hilbert_taps] on every beam, max + 3/8 min of (signal, transformed signal), rounded for ADC counts;
- * trigger_threshold then compares with the envelope and "pa_max_power" holds the envelope maxima). */
+ * trigger_threshold then compares with the envelope and "pa_max_power" holds the envelope maxima), 2 = 'hilbert_env' with
+ * ideal_transformer = True (:339-345: imag(scipy.signal.hilbert(beam)) as the circular convolution with its closed-form kernel,
+ * envelope sqrt(beam^2 + imag^2); no taps). */
 int nrhip_station_set_phased_array_processing(nrhip_station* st, int32_t upsampling_method, int32_t n_up_taps, const double* up_taps,
                                               int32_t mode, int32_t n_hilbert_taps, const double* hilbert_taps);
 /* `amplitude` of the noise adder per channel [n_channels] (simulation.py:596-600: Vrms / sqrt(norm / max_freq), norm = int |H|^2 df,

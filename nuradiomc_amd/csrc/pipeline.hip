@@ -467,9 +467,15 @@ int nrhip_station_set_phased_array_adc(nrhip_station* s, double adc_fs, int32_t 
     s->pa_adc_set = false;
     if (!(adc_fs > 0)) return 0;
     if (s->pa_n_channels <= 0) return nrhip_fail_msg("nrhip_station_set_phased_array_adc: nrhip_station_set_phased_array comes first");
-    if (!rolls_up || n_bits < 1 || n_bits > 24 || !(v_max > v_min) || upsampling_factor < 1 || resample_p < 1 || resample_q < 1)
+    // n_bits = 0: no digitisation (phased_trigger(apply_digitization=False) with up-sampling or the envelope mode): the channel traces
+    // at the simulation's rate go through the same up-sampling / beam / envelope kernels as volts
+    const bool analog = n_bits == 0;
+    if (analog && !(fabs(adc_fs - s->dev.fs) <= 1e-8 + 1e-5 * fabs(s->dev.fs)))
+        return nrhip_fail_msg("nrhip_station_set_phased_array_adc: without digitisation (n_bits = 0) the rate is the simulation's");
+    if (analog) { v_min = 0.; v_max = 1.; output_counts = 0; }
+    if (!rolls_up || n_bits < 0 || n_bits > 24 || !(v_max > v_min) || upsampling_factor < 1 || resample_p < 1 || resample_q < 1)
         return nrhip_fail_msg("nrhip_station_set_phased_array_adc: bad ADC description");
-    if (adc_fs > 0.49 * s->dev.fs) return nrhip_fail_msg("nrhip_station_set_phased_array_adc: the ADC must sample at less than 0.49 of the simulation's rate");
+    if (!analog && adc_fs > 0.49 * s->dev.fs) return nrhip_fail_msg("nrhip_station_set_phased_array_adc: the ADC must sample at less than 0.49 of the simulation's rate");
     HIPCHK(hipSetDevice(s->ctx->device));
     if (upload(s->ctx, s->d_pa_rolls_up, rolls_up, (size_t)s->pa_n_beams * s->pa_n_channels)) return -1;
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
@@ -488,7 +494,7 @@ int nrhip_station_set_phased_array_processing(nrhip_station* s, int32_t upsampli
     if (!s->pa_adc_set) return nrhip_fail_msg("nrhip_station_set_phased_array_processing: nrhip_station_set_phased_array_adc comes first");
     if (upsampling_method < 0 || upsampling_method > 2)   // NotImplementedError of digital_upsampling :178-180
         return nrhip_fail_msg("nrhip_station_set_phased_array_processing: Interpolation method must be lin, fft, or fir");
-    if (mode < 0 || mode > 1) return nrhip_fail_msg("nrhip_station_set_phased_array_processing: mode must be either 'power_sum' or 'hilbert_env'");
+    if (mode < 0 || mode > 2) return nrhip_fail_msg("nrhip_station_set_phased_array_processing: mode must be either 'power_sum' or 'hilbert_env'");
     if (upsampling_method == 2 && (!up_taps || n_up_taps < 1 || n_up_taps > 1024))
         return nrhip_fail_msg("nrhip_station_set_phased_array_processing: the 'fir' up-sampling needs 1..1024 filter taps");
     if (mode == 1 && (!hilbert_taps || n_hilbert_taps < 1 || n_hilbert_taps > 1024 || n_hilbert_taps % 2 == 0))
@@ -1496,6 +1502,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                 const bool to5 = 5.0 > sd.fs;
                 const double len5max = to5 ? (double)adc.p * maxL / adc.q : (double)maxL, cur = to5 ? 5.0 : sd.fs;
                 adc.stride = adc.upsampling * ((int)(adc.adc_fs / cur * len5max) + 2) + 2;
+                // a beam (and, for the ideal Hilbert transformer, a quarter beam of kernel values) has to fit the LDS of a CU
+                if ((size_t)adc.stride * (adc.mode == 2 ? 10 : 8) + 128 + 2048 > 163840)
+                    return nrhip_fail_msg(adc.mode == 2 ? "nrhip_simulate_events: the ideal Hilbert transformer takes up-sampled beams of at most 16 000 samples"
+                                                        : "nrhip_simulate_events: the digitised phased array takes up-sampled beams of at most 20 000 samples");
                 double* pa_trace;
                 int* pa_len;
                 NEED(pa_trace = WS("pa_digital_trace", double, (size_t)n_cand * st->pa_n_channels * adc.stride));

@@ -3704,6 +3704,10 @@ pa_digitize_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, con
             } else {
                 v = sx[j];
             }
+            if (adc.n_bits == 0) {   // no trigger ADC (apply_digitization = False): the analog trace goes on to the up-sampling
+                d[j] = v;
+                continue;
+            }
             double cnt = floor((v - adc.vmin) / lsb);
             cnt = fmin(fmax(cnt, 0.), (double)((1 << adc.n_bits) - 1)) + vmin_adc;
             d[j] = adc.counts ? cnt : lsb * cnt;
@@ -3712,6 +3716,17 @@ pa_digitize_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, con
         // (4) up-sampling
         double* out = pa_trace + (long)item * adc.stride;
         int n_up = n_dig;
+        // digital_upsampling rounds its result when the input "is digital" (np.allclose(trace, np.round(trace)) :153, :182-183):
+        // ADC counts always are; an analog trace is when every sample is within 1e-8 + 1e-5 |round| of an integer (a silent channel)
+        bool round_out = adc.counts != 0;
+        if (adc.n_bits == 0 && adc.upsampling >= 2) {
+            int ok = 1;
+            for (int j = threadIdx.x; j < n_dig; j += blockDim.x) {
+                const double r = rint(d[j]);
+                ok &= (fabs(d[j] - r) <= 1e-8 + 1e-5 * fabs(r)) ? 1 : 0;
+            }
+            round_out = __syncthreads_and(ok) != 0;
+        }
         if (adc.upsampling >= 2) {
             const int md = n_dig / 2;
             double2* D = to5 ? (double2*)(pd_lds + n_dig + (n_dig & 1)) : (double2*)pd_lds;
@@ -3739,7 +3754,7 @@ pa_digitize_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, con
                     acc += (k == md) ? t : 2. * t;
                 }
                 acc /= n_dig;
-                out[n] = adc.counts ? rint(acc) : acc;
+                out[n] = round_out ? rint(acc) : acc;
             }
         } else {
             for (int n = threadIdx.x; n < n_dig; n += blockDim.x) out[n] = d[n];
@@ -3914,6 +3929,15 @@ pa_upsample_kernel(int n_items, PaAdc adc, const double* __restrict__ adc_trace,
         double* out = pa_trace + (long)item * adc.stride;
         const int n = len_in[item], up = adc.upsampling;
         int n_new;
+        bool round_out = adc.counts != 0;   // "is_digital_trace" of digital_upsampling (:153), see pa_digitize_kernel
+        if (adc.n_bits == 0) {
+            int ok = 1;
+            for (int j = threadIdx.x; j < n; j += blockDim.x) {
+                const double r = rint(d[j]);
+                ok &= (fabs(d[j] - r) <= 1e-8 + 1e-5 * fabs(r)) ? 1 : 0;
+            }
+            round_out = __syncthreads_and(ok) != 0;
+        }
         if (adc.up_method == 1) {
             const double dt = 1 / adc.adc_fs, stop = dt * n, dtn = 1 / (adc.adc_fs * up);
             n_new = (int)ceil(stop / dtn);
@@ -3931,7 +3955,7 @@ pa_upsample_kernel(int n_items, PaAdc adc, const double* __restrict__ adc_trace,
                     const double slope = (d[j + 1] - d[j]) / ((j + 1) * dt - j * dt);
                     v = slope * (x - j * dt) + d[j];
                 }
-                out[i] = adc.counts ? rint(v) : v;
+                out[i] = round_out ? rint(v) : v;
             }
         } else {
             n_new = n * up;
@@ -3946,7 +3970,7 @@ pa_upsample_kernel(int n_items, PaAdc adc, const double* __restrict__ adc_trace,
                 double acc = 0.;
                 for (int j = j_lo; j <= j_hi; j++) acc += d[j] * adc.up_taps[i + off - j * up];
                 acc *= up;
-                out[i] = adc.counts ? rint(acc) : acc;
+                out[i] = round_out ? rint(acc) : acc;
             }
         }
         if (threadIdx.x == 0) pa_len[item] = n_new - (n_new & 1);
@@ -3989,7 +4013,37 @@ phased_array_digital_kernel(int n_cand, const int* __restrict__ item_event, cons
             }
             __syncthreads();
             double mx = -INFINITY;
-            if (adc.mode == 1) {
+            if (adc.mode == 2) {
+                // hilbert_envelope with ideal_transformer = True (:339-345): imag(scipy.signal.hilbert(coh)) is the circular
+                // convolution of coh with g = imag(ifft(h)), h the one-sided spectrum weights; for an even length (pa_len always is)
+                // g[m] = (2 / n) cot(pi m / n) for odd m and 0 for even m (sum_{k=1}^{n/2-1} sin(2 pi k m / n) in closed form).
+                // g's odd entries go to LDS behind the beam, then n^2 / 2 multiply-adds per beam; envelope sqrt(x^2 + im^2)
+                // (g is odd about n / 2: cot(pi (n - m) / n) = -cot(pi m / n), so the odd m <= n / 2 are kept: n / 4 + 1 values)
+                double* g = coh + Lu;
+                const int n_g = Lu / 4 + 1;
+                for (int j = threadIdx.x; j < n_g; j += blockDim.x) {
+                    double sn, cs;
+                    sincospi((double)(2 * j + 1) / (double)Lu, &sn, &cs);
+                    g[j] = (2. / Lu) * (cs / sn);
+                }
+                __syncthreads();
+                for (int n = threadIdx.x; n < Lu; n += blockDim.x) {
+                    double im = 0.;
+                    // s runs over the samples of the other parity; d = (n - s) mod Lu is odd
+                    int d = (n & 1) ? n : n - 1 + ((n == 0) ? Lu : 0);   // s = 0 (n odd) or s = 1 (n even)
+                    for (int s2 = (n & 1) ? 0 : 1; s2 < Lu; s2 += 2) {
+                        const double gv = (2 * d <= Lu) ? g[d >> 1] : -g[(Lu - d) >> 1];
+                        im += coh[s2] * gv;
+                        d -= 2;
+                        if (d < 0) d += Lu;
+                    }
+                    if (adc.counts) im = rint(im);
+                    const double c = coh[n];
+                    double env = sqrt(c * c + im * im);
+                    if (adc.counts) env = rint(env);
+                    mx = fmax(mx, env);
+                }
+            } else if (adc.mode == 1) {
                 // hilbert_envelope (:337-367): imaginary part by the FIR transformer (np.convolve 'full', centred), the magnitude
                 // estimate max + 3/8 min of the two SIGNED sequences as the reference writes it, rounded for counts
                 const int nh = adc.n_hil_taps, half = nh / 2;
@@ -4028,8 +4082,9 @@ void launch_phased_array_beams(hipStream_t s, int n_cand, const int* item_event,
 {
     if (n_cand <= 0) return;
     set_big_lds();
-    (void)hipFuncSetAttribute((const void*)phased_array_digital_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, adc.stride * 8 + 64);
-    hipLaunchKernelGGL(phased_array_digital_kernel, dim3(n_cand < 4096 ? n_cand : 4096), dim3(256), (size_t)adc.stride * 8 + 64, s, n_cand,
+    const size_t lds = (size_t)adc.stride * (adc.mode == 2 ? 10 : 8) + 128;   // the beam (+ a quarter of a beam of Hilbert kernel values)
+    (void)hipFuncSetAttribute((const void*)phased_array_digital_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(phased_array_digital_kernel, dim3(n_cand < 4096 ? n_cand : 4096), dim3(256), lds, s, n_cand,
                        item_event, pa_trace, pa_len, n_pa, n_beams, rolls_up, window, step, divisor, threshold, adc, triggered, pa_max);
 }
 

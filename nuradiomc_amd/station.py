@@ -438,17 +438,16 @@ class Station:
         phasedArrayTrigger.run(apply_digitization=True) (trigger_adc_sampling_frequency / trigger_adc_nbits / trigger_adc_noise_count
         of the detector description, Vrms of adc_kwargs) followed by FFT up-sampling by `upsampling_factor`; beams, windows and
         steps then count samples of the up-sampled ADC trace, count sums saturate at `saturation_bits`.  Without `adc` everything
-        runs at the simulation's sampling rate on the analog traces.  channels=None switches the trigger off.
-        With `adc`: upsampling_method 'fft' | 'lin' | 'fir' (coeff_gain, filter_taps: upsampling_kwargs of phased_trigger;
+        runs on the analog traces at the simulation's sampling rate (times upsampling_factor).  channels=None switches the trigger off.
+        upsampling_method 'fft' | 'lin' | 'fir' (coeff_gain, filter_taps: upsampling_kwargs of phased_trigger;
         signal_processing.digital_upsampling :111-190, upsampling_fir :192-234) and mode 'power_sum' | 'hilbert_env'
         (hilbert_transformer_kwargs = dict(hilbert_n_taps=31, hilbert_coeff_gain=128): PhasedArrayBase.hilbert_envelope :337-367
-        with the FIR transformer; the ideal transformer is not provided) -- the threshold then compares with the envelope."""
+        with the FIR transformer, or ideal_transformer=True: scipy.signal.hilbert's imaginary part and the exact magnitude) -- the
+        threshold then compares with the envelope."""
         if upsampling_method not in ('fft', 'lin', 'fir'):
             raise NotImplementedError('Interpolation method must be lin, fft, or fir')
         if mode not in ('power_sum', 'hilbert_env'):
             raise ValueError("mode must be either 'power_sum' or 'hilbert_env'")
-        if adc is None and (mode != 'power_sum' or (upsampling_method != 'fft' and int(upsampling_factor) >= 2)):
-            raise NotImplementedError("up-sampling methods and the envelope mode of the phased array are provided together with the trigger ADC (adc=...)")
         if channels is None:
             L.check(self._lib.nrhip_station_set_phased_array(self._h, 0, None, 0, None, 0, 0, 0))
             return None
@@ -464,12 +463,15 @@ class Station:
         rolls = np.ascontiguousarray(rolls, np.int32)
         L.check(self._lib.nrhip_station_set_phased_array(self._h, len(ch), L.iptr(ch), len(rolls), L.iptr(rolls), int(window),
                                                          int(step), int(averaging_divisor or 0)))
+        analog = adc is None and (mode != 'power_sum' or int(upsampling_factor) >= 2)
+        if analog:   # apply_digitization=False with up-sampling / envelope (get_traces :312-321): no comparator, the simulation's rate
+            adc = dict(sampling_frequency=self.sampling_rate, n_bits=0, noise_count=1., output='voltage')
         if adc is not None:
             import fractions
             import decimal
             f_adc, n_bits = float(adc['sampling_frequency']), int(adc['n_bits'])
             vrms = float(adc.get('vrms') or self.vrms)
-            half = vrms * (2 ** n_bits - 1) / float(adc['noise_count']) / 2       # _get_adc_parameters :236-240
+            half = vrms * (2 ** n_bits - 1) / float(adc['noise_count']) / 2 if n_bits else 0.5   # _get_adc_parameters :236-240
             fr = fractions.Fraction(decimal.Decimal(5.0 / self.sampling_rate)).limit_denominator(5000)   # signal_processing.resample :86
             up = max(int(upsampling_factor), 1)
             rolls = []
@@ -482,6 +484,7 @@ class Station:
                                                                  int(adc.get('output', 'voltage') == 'counts'), up, int(saturation_bits),
                                                                  fr.numerator, fr.denominator, L.iptr(rolls)))
             up_taps = hil_taps = None
+            ideal = False
             if upsampling_method == 'fir' and up >= 2:    # upsampling_fir :224-230
                 from . import filters
                 up_taps = filters.firwin(int(filter_taps), f_adc * 0.5, True, f_adc * up)
@@ -492,21 +495,21 @@ class Station:
                 from . import filters
                 hk = dict(ideal_transformer=False, hilbert_n_taps=31, hilbert_coeff_gain=128)
                 hk.update(hilbert_transformer_kwargs or {})
-                if hk['ideal_transformer']:
-                    raise NotImplementedError("the ideal Hilbert transformer (scipy.signal.hilbert) of the phased array is not provided")
-                nt = int(hk['hilbert_n_taps'])
-                assert nt % 2 != 0, "Num taps MUST be odd for a hilbert transformer"
-                sin_factor = np.sin(np.linspace(-(nt - 1) / 2, (nt - 1) / 2, nt))
-                hil_taps = 2 * sin_factor * (-1 * filters.firwin(nt, 0.25, False, 1))
-                if hk['hilbert_coeff_gain'] != 1:
-                    hil_taps = np.round(hil_taps * hk['hilbert_coeff_gain']) / hk['hilbert_coeff_gain']
-                hil_taps = np.ascontiguousarray(hil_taps, np.float64)
+                ideal = bool(hk['ideal_transformer'])
+                if not ideal:
+                    nt = int(hk['hilbert_n_taps'])
+                    assert nt % 2 != 0, "Num taps MUST be odd for a hilbert transformer"
+                    sin_factor = np.sin(np.linspace(-(nt - 1) / 2, (nt - 1) / 2, nt))
+                    hil_taps = 2 * sin_factor * (-1 * filters.firwin(nt, 0.25, False, 1))
+                    if hk['hilbert_coeff_gain'] != 1:
+                        hil_taps = np.round(hil_taps * hk['hilbert_coeff_gain']) / hk['hilbert_coeff_gain']
+                    hil_taps = np.ascontiguousarray(hil_taps, np.float64)
             method = {'fft': 0, 'lin': 1, 'fir': 2}[upsampling_method] if up >= 2 else 0
-            if method or hil_taps is not None:
+            env_mode = 0 if mode != 'hilbert_env' else (2 if ideal else 1)
+            if method or env_mode:
                 L.check(self._lib.nrhip_station_set_phased_array_processing(
                     self._h, method, 0 if up_taps is None else len(up_taps), None if up_taps is None else L.dptr(up_taps),
-                    int(hil_taps is not None), 0 if hil_taps is None else len(hil_taps),
-                    None if hil_taps is None else L.dptr(hil_taps)))
+                    env_mode, 0 if hil_taps is None else len(hil_taps), None if hil_taps is None else L.dptr(hil_taps)))
         return rolls
 
     @staticmethod

@@ -781,7 +781,20 @@ def hilbert_envelope_fir(coh, output='voltage', n_taps=31, coeff_gain=1):
     return env
 
 
-def phased_array_envelope_digital(U, rolls, output='voltage', saturation_bits=8, n_taps=31, coeff_gain=1):
+def hilbert_envelope_ideal(coh, output='voltage'):
+    """PhasedArrayBase.hilbert_envelope (:337-367) with ideal_transformer=True (:339-345): imaginary part of scipy.signal.hilbert,
+    rounded for ADC counts, exact magnitude"""
+    coh = np.asarray(coh, float)
+    im = np.imag(signal.hilbert(coh))
+    if output == 'counts':
+        im = np.round(im)
+    env = np.sqrt(coh ** 2 + im ** 2)
+    if output == 'counts':
+        env = np.rint(env)
+    return env
+
+
+def phased_array_envelope_digital(U, rolls, output='voltage', saturation_bits=8, n_taps=31, coeff_gain=1, ideal=False):
     """phase_signals (:183-215) + hilbert_envelope per beam: phased_trigger's mode 'hilbert_env' (:507-510)"""
     out = []
     U = np.asarray(U, float)
@@ -791,7 +804,7 @@ def phased_array_envelope_digital(U, rolls, output='voltage', saturation_bits=8,
             coh += np.roll(U[c], int(roll[c]))
         if output == 'counts' and saturation_bits is not None:
             coh = np.clip(coh, -2 ** (saturation_bits - 1), 2 ** (saturation_bits - 1) - 1)
-        out.append(hilbert_envelope_fir(coh, output, n_taps, coeff_gain))
+        out.append(hilbert_envelope_ideal(coh, output) if ideal else hilbert_envelope_fir(coh, output, n_taps, coeff_gain))
     return np.array(out)
 
 

@@ -2,7 +2,7 @@
 functions: utilities/signal_processing.digital_upsampling with upsampling_method 'lin' and 'fir' (:111-190, upsampling_fir :192-234:
 zero stuffing + scipy.signal.firwin low pass, coefficients rounded to 1 / coeff_gain) on ADC-count and voltage traces, and
 PhasedArrayBase.hilbert_envelope (phasedArrayBase.py:337-367: FIR Hilbert transformer with rounded coefficients, max + 3/8 min
-magnitude estimate) on coherent sums.
+magnitude estimate; and the ideal transformer: scipy.signal.hilbert with the exact magnitude) on coherent sums.
 
     PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=tests/golden/gen/shims:/tmp/refcopy python tests/golden/gen/gen_pa_modes.py
 """
@@ -41,6 +41,16 @@ for k, (n, taps, gain, counts) in enumerate([(1368, 31, 128, 1), (1368, 31, 128,
     hil_cases.append([n, taps, gain, counts])
     out['hil_in_%d' % k] = c
     out['hil_out_%d' % k] = np.asarray(env, float)
+# the ideal transformer (ideal_transformer=True :339-345), appended after the draws above so that their vectors stay what they were
+ideal_cases = []
+for k, (n, counts) in enumerate([(1368, 1), (1368, 0), (1000, 0), (686, 1)]):
+    c = 11. * rng.normal(0, 1., n) + 90. * np.exp(-0.5 * ((np.arange(n) - 400) / 9.) ** 2) * np.cos(0.5 * np.arange(n))
+    c = np.round(c) if counts else 1.3e-5 * c
+    env = pa.hilbert_envelope(c, adc_output='counts' if counts else 'voltage', ideal_transformer=True)
+    ideal_cases.append([n, counts])
+    out['ideal_in_%d' % k] = c
+    out['ideal_out_%d' % k] = np.asarray(env, float)
+out['ideal_cases'] = np.array(ideal_cases, float)
 out['up_cases'] = np.array(up_cases, float)
 out['hil_cases'] = np.array(hil_cases, float)
 np.savez_compressed(os.path.join(OUT, 'ref_pa_modes.npz'), **out)

@@ -158,10 +158,15 @@ def test_spectral_stages_vs_oracle_on_identical_rays(gpu_ctx_factory, name, n_ev
 
 
 @pytest.mark.parametrize('output,method,mode', [('counts', 'lin', 'power_sum'), ('counts', 'fir', 'hilbert_env'),
-                                                ('voltage', 'fir', 'power_sum'), ('voltage', 'lin', 'hilbert_env')])
+                                                ('voltage', 'fir', 'power_sum'), ('voltage', 'lin', 'hilbert_env'),
+                                                ('counts', 'fft', 'hilbert_ideal'), ('voltage', 'fir', 'hilbert_ideal'),
+                                                ('analog', 'fft', 'power_sum'), ('analog', 'fir', 'hilbert_env'),
+                                                ('analog', 'lin', 'hilbert_ideal')])
 def test_phased_array_upsampling_methods_and_envelope_mode(gpu_ctx_factory, output, method, mode):
     """The other processing options of the digitised phased array inside simulate_events: upsampling_method 'lin' / 'fir'
-    (coefficients rounded to 1 / 128) and mode 'hilbert_env' (FIR Hilbert transformer, max + 3/8 min).  GPU vs the oracle's
+    (coefficients rounded to 1 / 128) and mode 'hilbert_env' (FIR Hilbert transformer, max + 3/8 min; 'hilbert_ideal' here =
+    hilbert_transformer_kwargs ideal_transformer=True: scipy.signal.hilbert, exact magnitude); output 'analog' = no trigger ADC
+    (phased_trigger(apply_digitization=False) with upsampling_kwargs / the envelope mode: get_traces :312-321).  GPU vs the oracle's
     restatement (pinned on the reference's own functions in test_phased_array_modes_vs_reference) applied to the channel traces the
     GPU dumped: up-sampled traces (counts: every sample; volts 1e-9 lsb), per-beam maxima (window powers or envelopes) and
     decisions."""
@@ -174,12 +179,15 @@ def test_phased_array_upsampling_methods_and_envelope_mode(gpu_ctx_factory, outp
     angles = np.arcsin(np.linspace(np.sin(-60 * np.pi / 180), np.sin(60 * np.pi / 180), 11))
     window, step, adc_fs, nbits, ncount, up, gain, taps, htaps, hgain = 24, 8, 0.472, 8, 5, 4, 128, 31, 31, 128
     rolls = st.set_phased_array([0, 1, 2, 3], angles, ref_index=1.75, window=window, step=step, upsampling_factor=up,
-                                adc=dict(sampling_frequency=adc_fs, n_bits=nbits, noise_count=ncount, output=output),
-                                upsampling_method=method, coeff_gain=gain, filter_taps=taps, mode=mode,
-                                hilbert_transformer_kwargs=dict(hilbert_n_taps=htaps, hilbert_coeff_gain=hgain))
+                                adc=None if output == 'analog' else dict(sampling_frequency=adc_fs, n_bits=nbits, noise_count=ncount, output=output),
+                                upsampling_method=method, coeff_gain=gain, filter_taps=taps, mode=mode.replace('_ideal', '_env'),
+                                hilbert_transformer_kwargs=dict(hilbert_n_taps=htaps, hilbert_coeff_gain=hgain,
+                                                                ideal_transformer=mode == 'hilbert_ideal'))
     lsb = vrms / ncount
     unit = vrms / lsb if output == 'counts' else vrms
     threshold = 2.5 * (2 * unit) ** 2 if mode == 'power_sum' else 7. * unit
+    if output == 'analog':
+        adc_fs = 2.0
     rng = np.random.default_rng(14)
     n = 120
     r, ph = np.sqrt(rng.uniform(0, 1500. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
@@ -196,15 +204,15 @@ def test_phased_array_upsampling_methods_and_envelope_mode(gpu_ctx_factory, outp
     n_trig = 0
     for i, e in enumerate(item_event):
         V = np.array([tr[off[i * n_ch + c]:off[i * n_ch + c + 1]] for c in range(4)])
-        U = np.array([so.digital_upsampling(so.adc_digital_trace(x, 2.0, adc_fs, nbits, vrms, ncount, output), adc_fs, method, up,
-                                            gain, taps) for x in V])
+        U = np.array([so.digital_upsampling(x if output == 'analog' else so.adc_digital_trace(x, 2.0, adc_fs, nbits, vrms, ncount, output),
+                                            adc_fs, method, up, gain, taps) for x in V])
         assert np.all(dlen[i] == U.shape[1])
         got = dig[i, :, :U.shape[1]]
         assert np.max(np.abs(got - U)) <= (0 if output == 'counts' else 1e-9 * lsb), e
         if mode == 'power_sum':
-            p = so.phased_array_power_digital(U, rolls, window, step, output)
+            p = so.phased_array_power_digital(U, rolls, window, step, output.replace('analog', 'voltage'))
         else:
-            p = so.phased_array_envelope_digital(U, rolls, output, 8, htaps, hgain)
+            p = so.phased_array_envelope_digital(U, rolls, output.replace('analog', 'voltage'), 8, htaps, hgain, ideal=mode == 'hilbert_ideal')
         mx = p.max(axis=1)
         assert np.max(np.abs(pa_max[i] - mx)) <= 1e-9 * np.max(np.abs(mx)), e
         t = bool(np.any(p > (np.trunc(threshold) if output == 'counts' else threshold)))

@@ -456,6 +456,10 @@ def test_phased_array_modes_vs_reference():
         c, ref = g['hil_in_%d' % k], g['hil_out_%d' % k]
         got = so.hilbert_envelope_fir(c, 'counts' if counts else 'voltage', int(taps), gain if gain != 1 else 1)
         assert np.max(np.abs(got - ref)) <= (0 if counts else 1e-12 * np.max(np.abs(ref))), k
+    for k, (n, counts) in enumerate(g['ideal_cases']):   # ideal_transformer=True
+        c, ref = g['ideal_in_%d' % k], g['ideal_out_%d' % k]
+        got = so.hilbert_envelope_ideal(c, 'counts' if counts else 'voltage')
+        assert np.max(np.abs(got - ref)) <= (0 if counts else 1e-12 * np.max(np.abs(ref))), k
     for taps, cutoff, pz, fs in ((45, 0.236, True, 1.888), (31, 0.25, False, 1.), (23, 0.3, True, 2.4), (15, 0.25, False, 1.)):
         assert np.max(np.abs(filters.firwin(taps, cutoff, pz, fs) - ssig.firwin(taps, cutoff, pass_zero=pz, fs=fs))) < 1e-15
 
