@@ -120,6 +120,6 @@ struct nrhip_station {
     double rays_z_reflection = 0.;
     long rays_generation = -1;    // `generation` at the time the tables were made
     long generation = 0;          // bumped by every setter that changes the geometry (nrhip_station_set_positions)
-    hipEvent_t evt[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evt[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0..9 stage marks, 10..11 around the second stage of the attenuation
     DevArray& buf(const std::string& name) { return ws[name]; }
 };

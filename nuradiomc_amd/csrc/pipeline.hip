@@ -1091,13 +1091,21 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                                   ractive, two_stage ? 1 : 0);
             LCHK("event_possible");
         }
-        // active rays listed by work class (direct, reflected, refracted): wave-mates in the quadrature do similar work
-        launch_active_class_flags(sm, n_rays, ractive, w.slot, rec.type, cflags);
-        HIPCHK(hipMemsetAsync(cflags + 3L * n_rays, 0, sizeof(int), sm));
-        launch_exclusive_scan(sm, 3L * n_rays + 1, cflags, roff, rtmp);
-        launch_scatter_active_class(sm, n_rays, cflags, roff, active_list);
-        LCHK("active list");
-        HIPCHK(hipMemcpyAsync(&n_active, roff + 3L * n_rays, sizeof(int), hipMemcpyDeviceToHost, sm));
+        // active rays listed by predicted quadrature work: wave-mates do similar numbers of bisections (spectral.hip, quad_class)
+        if (n_refl == 0 && !getenv("NRHIP_ATT_TYPE_CLASSES")) {
+            signed char* qcls;
+            NEED(qcls = WS("ray_quad_class", signed char, nr));
+            launch_quad_class_list(sm, n_rays, ractive, w.slot, rec.type, w.C0, zint, ctx->ice, qcls, cflags, roff, rtmp, active_list);
+            LCHK("active list");
+            HIPCHK(hipMemcpyAsync(&n_active, roff + quad_class_entries(n_rays) - 1, sizeof(int), hipMemcpyDeviceToHost, sm));
+        } else {   // (with bottom reflections the path is made of segments: by solution type, as in rounds 1-2)
+            launch_active_class_flags(sm, n_rays, ractive, w.slot, rec.type, cflags);
+            HIPCHK(hipMemsetAsync(cflags + 3L * n_rays, 0, sizeof(int), sm));
+            launch_exclusive_scan(sm, 3L * n_rays + 1, cflags, roff, rtmp);
+            launch_scatter_active_class(sm, n_rays, cflags, roff, active_list);
+            LCHK("active list");
+            HIPCHK(hipMemcpyAsync(&n_active, roff + 3L * n_rays, sizeof(int), hipMemcpyDeviceToHost, sm));
+        }
         HIPCHK(hipMemsetAsync(w.att, 0xFF, nr * sd.n_fc * sizeof(double), sm));  // NaN = not evaluated
         HIPCHK(hipStreamSynchronize(sm));
     }
@@ -1277,9 +1285,20 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(fol_off = WS("follower_offset", int, nr + 1));
         NEED(fol_tmp = WS("scan_tmp9", int, scan_tiles((long)n_rays + 1)));
         NEED(fol_list = WS("follower_list", int, nr));
-        launch_follower_list(sm, (int)n_ev, ev, w.att, sd.n_fc, n_rays, fol_flag, fol_off, fol_tmp, fol_list, ractive);
-        LCHK("follower list");
-        HIPCHK(hipMemcpyAsync(&n_followers, fol_off + n_rays, sizeof(int), hipMemcpyDeviceToHost, sm));
+        if (!getenv("NRHIP_ATT_TYPE_CLASSES")) {   // like the first stage's list: in the order of the predicted quadrature work
+            launch_follower_list(sm, (int)n_ev, ev, w.att, sd.n_fc, n_rays, fol_flag, fol_off, fol_tmp, nullptr, ractive);
+            int* fol_counts;
+            signed char* qcls;
+            NEED(fol_counts = WS("ray_active_class", int, 3 * nr + 1));
+            NEED(qcls = WS("ray_quad_class", signed char, nr));
+            launch_quad_class_list(sm, n_rays, fol_flag, w.slot, rec.type, w.C0, zint, ctx->ice, qcls, fol_counts, fol_off, fol_tmp, fol_list);
+            LCHK("follower list");
+            HIPCHK(hipMemcpyAsync(&n_followers, fol_off + quad_class_entries(n_rays) - 1, sizeof(int), hipMemcpyDeviceToHost, sm));
+        } else {
+            launch_follower_list(sm, (int)n_ev, ev, w.att, sd.n_fc, n_rays, fol_flag, fol_off, fol_tmp, fol_list, ractive);
+            LCHK("follower list");
+            HIPCHK(hipMemcpyAsync(&n_followers, fol_off + n_rays, sizeof(int), hipMemcpyDeviceToHost, sm));
+        }
     }
     int h_counts[2] = {0, 0};
     long long h_ncr[2] = {0, 0};
@@ -1296,8 +1315,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (n_followers > 0) {
         int* att_ovf2;
         NEED(att_ovf2 = WS("att_overflow2", int, 2 * (size_t)n_followers + 1));
+        MARK(10);
         launch_attenuation_items(sm, n_followers, w.C0, zint, sd.n_fc, sd.fcoarse, ctx->att_model, ctx->ice, w.att, nullptr, fol_list,
                                  eval_counter, ctx->gl3, ctx->gl3_n, att_ovf2);
+        MARK(11);
         // their sum-of-magnitudes bound and Parseval norm with the computed attenuation (the channel prefilter multiplies the latter)
         launch_efield_bound_list(sm, n_followers, fol_list, w, sd, cfg->min_efield_amplitude, max_efield, fol_flag);
         LCHK("attenuation (second stage)");
@@ -1621,6 +1642,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         for (int i = 0; i < 8; i++) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, st->evt[i], st->evt[i + 1]) == hipSuccess) S.stage_ms[i] = ms;
+        }
+        if (n_followers > 0) {   // the quadrature's second launch belongs to the attenuation stage (its evaluations are counted there)
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, st->evt[10], st->evt[11]) == hipSuccess) { S.stage_ms[3] += ms; S.stage_ms[5] -= ms; }
         }
         float tot = 0.f;
         if (hipEventElapsedTime(&tot, st->evt[0], st->evt[9]) == hipSuccess) S.stage_ms[8] = tot;

@@ -177,6 +177,9 @@ void launch_efield_bound_list(hipStream_t s, int n_list, const int* list, const 
 void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const int* offset, int* list);
 void launch_active_class_flags(hipStream_t s, int n_rays, const int* active, const int* ray_slot2, const int* slot_type,
                                int* flags);
+long quad_class_entries(int n_rays);
+void launch_quad_class_list(hipStream_t s, int n_rays, const int* active, const int* ray_slot2, const int* slot_type, const double* C0,
+                            const double* zint, const IceConst& m, signed char* cls, int* counts, int* offset, int* scan_tmp, int* list);
 void launch_scatter_active_class(hipStream_t s, int n_rays, const int* flags, const int* offset, int* list);
 void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int n_rays, int n_events,
                        const int* slot_offset, const RayWork& w, const EventIn& evin, const StationDev& st, int ask_model,
