@@ -790,7 +790,6 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need a shower library (nrhip_station_set_arz)");
     if (arz && !cfg->select_only && st->n_shower_profiles != n_events)
         return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need one profile per shower (nrhip_station_set_shower_profiles)");
-    if (arz && cfg->focusing) return nrhip_fail_msg("nrhip_simulate_events: focusing is not available with the ARZ models");
     if (general && cfg->amp_per_ray) return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray is not available with ARZ / birefringence");
     if (cfg->n_reflections > 0 && (bire || cfg->focusing))
         return nrhip_fail_msg("nrhip_simulate_events: bottom reflections are not available together with birefringence or focusing");
@@ -946,6 +945,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     NEED(w.tab = WS("ray_antenna_table", int, nr));
     NEED(w.att = WS("ray_att", double, nr * sd.n_fc));
     NEED(w.e_norm = WS("ray_e_norm", double, nr));
+    NEED(w.focus = WS("ray_focus", double, nr));
     double *zint, *max_efield;
     NEED(zint = WS("ray_zint", double, 3 * nr));
     NEED(max_efield = WS("ray_max_efield", double, nr));

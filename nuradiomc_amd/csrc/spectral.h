@@ -91,6 +91,8 @@ struct RayWork {
     int *tab;            // [n] antenna response table of the ray (0 VPol, 1 HPol, 2..4 LPDA phase regime)
     double *att;         // [n][n_fc]
     double *e_norm;      // [n] L2 norm of the unit-polarisation field trace, sqrt(sum_t s(t)^2) (set by efield_max_kernel)
+    double *focus;       // [n] focusing factor of the ray (1 without focusing): the parametrisations carry it in a_pref, the
+                         //     time-domain emission models multiply their spectrum with it (analyticraytracing.py:3011-3016)
 };
 
 struct EventIn {

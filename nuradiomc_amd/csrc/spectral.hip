@@ -494,6 +494,7 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
     w.slot[r] = slot;
     AskaryanConst ac = askaryan_setup(ask_model, evin.energy[e], w.view[r], evin.shower_type[e], w.n_index[r], w.R[r],
                                       evin.k_L[e]);
+    w.focus[r] = 1.;
     if (foc_n_sol) {
         // ray_tracing.get_focusing, numerical branch (analyticraytracing.py:2778-2888): launch angle of the same solution
         // of the trace to the receiver moved by foc_dz (second ray-tracing pass, tables foc_*)
@@ -516,6 +517,7 @@ ray_setup_kernel(int n_rays, int n_ch, const int* __restrict__ ray_slot, const d
         f *= sqrt(n_index_at(vz, m) / n_index_at(cz, m));
         ac.a_pref *= f;   // every parametrisation is linear in a_pref: spec[1:] *= focusing (:3011-3016)
         ac.pref2 *= f;
+        w.focus[r] = f;
     }
     w.ask[r] = ac;
 }
@@ -3439,6 +3441,7 @@ general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, con
                 if (j < st.n_fc - 1) rs.slope[j] = (rs.att[j + 1] - rs.att[j]) / (st.fcoarse[j + 1] - st.fcoarse[j]);
             }
             const double* tr = arz_trace + ((long)r * 3 + 1) * N;
+            const double foc = w.focus[r];
             for (int j = threadIdx.x; j < nh; j += blockDim.x) x[j] = make_double2(tr[2 * j], tr[2 * j + 1]);
             __syncthreads();
             nplan_fft(x, st.np, tw, false);  // packed half-length transform (element j at nplan_idx(j))
@@ -3451,7 +3454,8 @@ general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, con
                 const double2 go = make_double2(d.y, -d.x);
                 const double2 wk = nplan_w(st.np, k, tw);
                 // attenuation: np.interp on the coarse grid for f > 0, 1 at DC (analyticraytracing.py:1075-1080)
-                const double a = (k == 0) ? 1. : interp_seg(k * df, st.seg[k], st.n_fc, rs.xp, rs.att, rs.slope);
+                // (and the focusing factor on every bin but DC: spec[1:] *= focusing, :3011-3016)
+                const double a = (k == 0) ? 1. : interp_seg(k * df, st.seg[k], st.n_fc, rs.xp, rs.att, rs.slope) * foc;
                 const double2 S = cscale(cadd(ge, cmul(go, wk)), sc * a);
                 Eo[k] = cscale(cmul(S, rt), pt);
                 Eo[n_f + k] = cscale(cmul(S, rp), pp);

@@ -856,12 +856,14 @@ def test_focusing_batched(gpu_ctx_factory):
     assert np.array_equal(trig_p, trig)
 
 
-@pytest.mark.parametrize('mode,N', [('birefringence', 512), ('arz', 512), ('arz+birefringence', 512), ('arz+birefringence', 640)])
+@pytest.mark.parametrize('mode,N', [('birefringence', 512), ('arz', 512), ('arz+birefringence', 512), ('arz+birefringence', 640),
+                                    ('arz+focusing', 512)])
 def test_general_path_arz_birefringence(gpu_ctx_factory, mode, N):
     """BASELINE config 4 inside simulate_events: time-domain ARZ2020 emission and / or birefringent propagation.  The GPU
     materialises the on-sky spectra and traces of every kept ray; compared with the oracle's chain (pinned against the
     reference piece by piece: ARZ traces, birefringent propagation, efield -> voltage) on identical ray tables: ray spectra,
-    maxima, candidate flags, trace lengths, channel voltage traces (1e-6) and trigger decisions."""
+    maxima, candidate flags, trace lengths, channel voltage traces (1e-6) and trigger decisions.  'arz+focusing': propagation.focusing
+    with a time-domain model -- the factor multiplies every bin of the ray's spectrum but DC (analyticraytracing.py:3011-3016)."""
     from nuradiomc_amd import arz as arz_mod
     from oracle import arz_oracle
     from test_oracle_golden import _arz_library
@@ -899,6 +901,9 @@ def test_general_path_arz_birefringence(gpu_ctx_factory, mode, N):
         model = 'ARZ2020'
         kw = dict(arz_iN=iN)
         oarz = arz_oracle.ARZ(lib, seed=3)
+    if 'focusing' in mode:
+        kw = dict(kw, focusing=True, focusing_limit=2.)
+        okw = dict(focusing=True, focusing_limit=2.)
     kL = np.where(types == 'EM', 10 ** 1.5, 1.0)
     # the eigen-polarisations divide by n^2 - n_i^2 ~ 1e-3 and ~2000 steps multiply up: two IEEE implementations of the
     # birefringent propagation agree to ~1e-6..1e-5 (the reference's own T07 allows 2e-3 of the pulse amplitude)
@@ -922,7 +927,7 @@ def test_general_path_arz_birefringence(gpu_ctx_factory, mode, N):
                     launch=T['slot_launch'][ev * n_ch * 6:(ev + 1) * n_ch * 6].reshape(n_ch, 2, 3),
                     receive=T['slot_receive'][ev * n_ch * 6:(ev + 1) * n_ch * 6].reshape(n_ch, 2, 3))
         o = so.simulate_event(v[ev], zen[ev], az[ev], en[ev], str(types[ev]), float(kL[ev]), ost, ice, vrms, vrms_e, model=model,
-                              rays=rays, arz=(oarz, int(iN[ev])) if oarz else None, birefringence=bire)
+                              rays=rays, arz=(oarz, int(iN[ev])) if oarz else None, birefringence=bire, **okw)
         r0 = T['ev_ray_begin'][ev]
         sel = np.arange(r0, r0 + T['ev_n_rays'][ev])
         assert [(q['channel'], q['iS']) for q in o['rays']] == list(zip(T['ray_channel'][sel], T['ray_solution'][sel]))
@@ -952,6 +957,8 @@ def test_general_path_arz_birefringence(gpu_ctx_factory, mode, N):
     en2 = 10 ** rng.uniform(15.5, 18., m)
     ty2 = np.array(['HAD', 'EM'])[rng.integers(0, 2, m)]
     kw2 = dict(arz_iN=a.draw_profile_numbers(en2, list(ty2))) if 'arz' in mode else {}
+    if 'focusing' in mode:
+        kw2 = dict(kw2, focusing=True, focusing_limit=2.)
     trig_x, stats_x = st.simulate_events(v2, zen2, az2, en2, ty2, 10 ** 1.5, askaryan_model=model, no_pruning=True, **kw2)
     X = {k: st.fetch(k) for k in ('ray_max_efield', 'ev_candidate', 'ev_n_rays')}
     trig_p, stats_p = st.simulate_events(v2, zen2, az2, en2, ty2, 10 ** 1.5, askaryan_model=model, **kw2)
