@@ -38,6 +38,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4stats -o x -- pyt
 cp $(find $OUT/c4stats -name 'x_kernel_stats.csv' | head -1) $OUT/${R}_rocprofv3_config4_kernel_stats.csv
 rm -rf $OUT/c4stats
 python3 tools/overlap_probe.py 2 > $OUT/overlap_probe.log 2>&1
+# two station loops side by side on one GPU, and where a 125 k-event shard spends its time (kernel sum vs step)
+{ bash tools/overlap_two_procs.sh 3 1000000; bash tools/overlap_two_procs.sh 5 1000000; } > $OUT/overlap_two_procs.log 2>&1
+{ ROWS=14 bash tools/rocprof_quick.sh --events 125000 --steps 10; python3 bench.py --events 125000 --no-cpu-baseline --steps 20 | tail -c 900; } > $OUT/shard125k_kernels.log 2>&1
 python3 tools/att_dense_probe.py 40000 > $OUT/att_dense_probe.log 2>&1
 find $OUT -size +8M -delete
 ls -la $OUT
