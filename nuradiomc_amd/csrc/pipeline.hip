@@ -991,8 +991,6 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     int* ev_sub_dev = nullptr;       // sub-event index inside its group
     int* ev_base = nullptr;          // group -> first sub-event
     if (cfg->split_event_time_diff > 0 && n_rays > 0) {
-        if (general || phased)
-            return nrhip_fail_msg("nrhip_simulate_events: split_event_time_diff is not available with ARZ / birefringence or the phased-array trigger");
         int *slot_new, *sub_sorted, *order, *sub_of, *n_sub, *etmp, *any_split;
         NEED(slot_new = WS("ray_slot_split", int, nr));
         NEED(sub_sorted = WS("ray_sub_event", int, nr));
@@ -1015,7 +1013,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         if (h_split[0]) {
             // the work table in the new ray order: the slot list is permuted inside the split groups and the per-ray set-up redone
             HIPCHK(hipMemcpyAsync(ray_slot, slot_new, sizeof(int) * (size_t)n_rays, hipMemcpyDeviceToDevice, sm));
-            launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w, evin, cfg->askaryan_model,
+            launch_ray_setup(sm, n_rays, n_ch, ray_slot, vertex, zenith, azimuth, rec, ctx->ice, sd, w, evin,
+                             arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
                              foc_n_sol, foc_launch, foc_dz, cfg->focusing_limit > 0 ? cfg->focusing_limit : 2.,
                              cfg->reflection_coefficient, cfg->reflection_phase_shift,
                              cfg->custom_polarization ? cfg->polarization_ephi : NAN);
@@ -1578,22 +1577,22 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                                                     st->pa_n_channels, st->d_pa_channel.as<int>(), st->pa_n_beams,
                                                     st->d_pa_rolls_up.as<int>(), st->pa_window, st->pa_step, (double)st->pa_divisor,
                                                     cfg->trigger_threshold, maxL, sd.fs, adc, ctx->twiddle, st->pa_B.as<double2>(), work,
-                                                    chunk, pa_trace, pa_len, triggered, pa_max, with_beams);
+                                                    chunk, pa_trace, pa_len, ev_triggered, pa_max, with_beams);
                 } else
                 launch_phased_array_digital(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, st->pa_n_channels,
                                             st->d_pa_channel.as<int>(), st->pa_n_beams, st->d_pa_rolls_up.as<int>(), st->pa_window,
                                             st->pa_step, (double)st->pa_divisor, cfg->trigger_threshold, maxL, sd.fs, adc, pa_trace, pa_len,
-                                            triggered, pa_max, with_beams);
+                                            ev_triggered, pa_max, with_beams);
                 if (own_upsampling) {
                     launch_pa_upsample(sm, n_cand * st->pa_n_channels, adc_final, pa_trace, adc.stride, pa_len, pa_final, len_final);
                     launch_phased_array_beams(sm, n_cand, d_cand, st->pa_n_channels, st->pa_n_beams, st->d_pa_rolls_up.as<int>(),
                                               st->pa_window, st->pa_step, (double)st->pa_divisor, cfg->trigger_threshold, adc_final,
-                                              pa_final, len_final, triggered, pa_max);
+                                              pa_final, len_final, ev_triggered, pa_max);
                 }
             } else
             launch_phased_array(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, st->pa_n_channels,
                                 st->d_pa_channel.as<int>(), st->pa_n_beams, st->d_pa_rolls.as<int>(), st->pa_window, st->pa_step,
-                                (double)st->pa_divisor, cfg->trigger_threshold, maxL, triggered, pa_max);
+                                (double)st->pa_divisor, cfg->trigger_threshold, maxL, ev_triggered, pa_max);
             LCHK("phased array");
         }
         if (ev_group)

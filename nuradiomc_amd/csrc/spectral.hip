@@ -1394,10 +1394,18 @@ efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork 
 #pragma unroll
         for (int j = 0; j < ES_NJ; j++) acc[j] = 0.f;
         float sum_v = 0.f, tv = 0.f;
-        for (int k = 1 + lane; k < nh; k += 64) {
-            const float v = value(k), vn = value(k + 1);
+        float v_prev_wave = 0.f;   // v of the bin before this pass's first one (v_0 = 0)
+        for (int k = 1 + lane; k - lane <= nh; k += 64) {   // (wave-uniform trip count: the shuffles below need every lane; k = nh is visited)
+            const float v = value(k);   // 0 beyond nh - 1
+            // total variation sum_{k >= 1} |v_k - v_{k-1}| over k = 1 .. nh (v_0 = v_nh = 0): the neighbour's value comes from the
+            // lane below (the previous pass's last lane for lane 0) instead of a second evaluation of the amplitude formula;
+            // |v_1 - v_0| is not part of the bound's sum: lane 0 of the first pass skips it
+            float vm = __shfl_up(v, 1);
+            if (lane == 0) vm = v_prev_wave;
+            v_prev_wave = __shfl(v, 63);
             sum_v += v;
-            tv += fabsf(vn - v);   // the last term is |0 - v_{nh-1}| = v_last
+            if (k >= 2 && k <= nh) tv += fabsf(v - vm);   // k = nh: |0 - v_{nh-1}| = v_last
+            if (k >= nh) continue;
             const float ph = (float)k * invN;   // k / N < 1/2: exact enough for the hardware sine / cosine (argument in turns)
             const float s1 = __builtin_amdgcn_sinf(ph), c2 = 2.f * __builtin_amdgcn_cosf(ph);
             float sa = 0.f, sb = s1;            // sin(0), sin(theta); sin((j + 1) theta) = 2 cos(theta) sin(j theta) - sin((j - 1) theta)

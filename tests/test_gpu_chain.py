@@ -1091,6 +1091,92 @@ def test_phased_array_trigger(gpu_ctx_factory):
         st.set_phased_array([0, 5], angles)
 
 
+@pytest.mark.parametrize('mode', ['arz', 'phased_array'])
+def test_split_event_time_diff_on_the_general_path_and_with_the_phased_array(gpu_ctx_factory, mode):
+    """split_event_time_diff together with the time-domain emission model (the general path re-orders its per-ray tables with the
+    sub-events) and with the phased-array trigger (decisions per sub-event, OR-ed into the group).  The multi-shower groups of the
+    reference's split fixture: 'arz' -- GPU vs the oracle's simulate_event_group(arz=, split_event_time_diff=) on the same rays:
+    membership, L, t_min, traces, decisions; 'phased_array' -- the oracle's beam former on the traces of every sub-event the GPU
+    dumped (those are pinned by test_split_event_time_diff), decisions per sub-event and per group."""
+    g = golden('chain_split_N256.npz')
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    ost = so.Station(g['det_pos'], n_samples=int(g['N']), fs=float(g['fs']))
+    vrms, vrms_e = so.vrms_from_filters(ost.fs)
+    split = float(g['split_event_time_diff'])
+    kL = np.where(np.isnan(g['k_L']), 50.0, g['k_L'])
+    n_groups = len(g['ev_candidate'])
+    n_ch = len(g['det_pos'])
+    args = (g['vertex'], g['zenith'], g['azimuth'], g['energy'], g['shower_type'], kL)
+    kw = dict(vertex_time=g['vertex_time'], group_id=g['group'], split_event_time_diff=split)
+    if mode == 'arz':
+        from nuradiomc_amd import arz as arz_mod
+        from oracle import arz_oracle
+        from test_oracle_golden import _arz_library
+        lib = _arz_library(golden('ref_arz.npz'))
+        a = arz_mod.ARZ(seed=3, library=lib)
+        st.set_arz(a)
+        types = [str(t) for t in g['shower_type']]
+        iN = a.draw_profile_numbers(g['energy'], types)
+        oarz = arz_oracle.ARZ(lib, seed=3)
+        trig, stats = st.simulate_events(*args, askaryan_model='ARZ2020', arz_iN=iN, dump_traces=True, **kw)
+    else:
+        angles = np.arcsin(np.linspace(np.sin(-60 * np.pi / 180), np.sin(60 * np.pi / 180), 7))
+        pa_ch = [0, 1, 2, 3]
+        window, step = 16, 8
+        rolls = st.set_phased_array(pa_ch, angles, ref_index=1.75, window=window, step=step)
+        threshold = 2.0 * (2 * vrms) ** 2
+        trig, stats = st.simulate_events(*args, trigger='phased_array', trigger_threshold=threshold, dump_traces=True, **kw)
+    ev_group, ev_sub = st.fetch('ev_group'), st.fetch('ev_sub_event')
+    cand, L, t_min, n_rays, ev_trig = (st.fetch(k) for k in ('ev_candidate', 'ev_L', 'ev_t_min', 'ev_n_rays', 'ev_triggered'))
+    assert stats['n_sub_events'] == len(ev_group) > n_groups and np.all(np.diff(ev_group) >= 0)
+    item_event, tr, off = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    pos = {int(e): i for i, e in enumerate(item_event)}
+    n_split = n_sub_trig = 0
+    if mode == 'arz':
+        for gi in range(n_groups):
+            idx = np.flatnonzero(g['group'] == gi)
+            showers = [dict(vertex=g['vertex'][i], zenith=float(g['zenith'][i]), azimuth=float(g['azimuth'][i]),
+                            energy=float(g['energy'][i]), shower_type=str(g['shower_type'][i]), k_L=float(kL[i]),
+                            vertex_time=float(g['vertex_time'][i]), iN=int(iN[i])) for i in idx]
+            o = so.simulate_event_group(showers, ost, g['ice'], vrms, vrms_e, model='ARZ2020', arz=oarz, split_event_time_diff=split)
+            mine = np.flatnonzero(ev_group == gi)
+            assert list(ev_sub[mine]) == list(range(len(mine)))
+            assert n_rays[mine].sum() == len(o['rays']) and o['triggered'] == bool(trig[gi]), gi
+            if not o['candidate']:
+                assert not cand[mine].any()
+                continue
+            assert len(mine) == len(o['sub']), gi
+            for e, q in zip(mine, o['sub']):
+                assert cand[e] and n_rays[e] == len(q['rays']) and q['L'] == L[e] and abs(q['t_min'] - t_min[e]) < 1e-9
+                assert q['triggered'] == bool(ev_trig[e])
+                n_sub_trig += q['triggered']
+                scale = np.max(np.abs(q['V']))
+                for ch in range(n_ch):
+                    it = pos[int(e)] * n_ch + ch
+                    assert np.max(np.abs(tr[off[it]:off[it + 1]] - q['V'][ch])) <= 2e-6 * scale, (gi, e, ch)
+            n_split += len(mine) > 1
+        assert n_split >= 20 and n_sub_trig >= 8 and trig.sum() >= 5
+        trig_p, _ = st.simulate_events(*args, askaryan_model='ARZ2020', arz_iN=iN, **kw)
+        assert np.array_equal(trig_p, trig) and np.array_equal(st.fetch('ev_triggered'), ev_trig)
+    else:
+        pa_max = st.fetch('pa_max_power').reshape(len(item_event), len(angles))
+        want_group = np.zeros(n_groups, bool)
+        for i, e in enumerate(item_event):
+            V = np.array([tr[off[i * n_ch + c]:off[i * n_ch + c + 1]] for c in pa_ch])
+            t, mx = so.phased_array_trigger(V, rolls, window, step, threshold)
+            assert np.max(np.abs(pa_max[i] - mx)) <= 1e-9 * max(np.max(mx), 1e-300), e
+            if np.min(np.abs(mx - threshold)) > 1e-9 * threshold:
+                assert t == bool(ev_trig[e]), e
+            want_group[ev_group[e]] |= bool(ev_trig[e])
+            n_sub_trig += t
+        n_split = int(np.sum(np.bincount(ev_group[item_event], minlength=n_groups) > 1))
+        assert np.array_equal(want_group, trig.astype(bool)) and not ev_trig[~cand.astype(bool)].any()
+        assert n_split >= 20 and 5 <= n_sub_trig < len(item_event)
+        trig_p, _ = st.simulate_events(*args, trigger='phased_array', trigger_threshold=threshold, **kw)
+        assert np.array_equal(trig_p, trig)
+
+
 @pytest.mark.parametrize('mode', ['noise', 'general', 'general+noise', 'general+noise+adc'])
 def test_phased_array_with_noise_and_on_the_general_path(gpu_ctx_factory, mode):
     """What an RNO-G station triggers on (phasedArrayBase.py:370-496 after simulation.apply_det_response :594-606): the phased
