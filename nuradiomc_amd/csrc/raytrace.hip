@@ -10,7 +10,6 @@
 //
 // The kernel is FP64-VALU / transcendental bound (about 1e2 objective evaluations x ~1e2 flops per
 // pair against ~320 B of HBM traffic), not HBM bound.
-#include <cstdlib>
 #include "ray_device.h"
 #include "nrhip_internal.h"
 #include "root_device.h"
@@ -267,23 +266,8 @@ void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const d
     int block = 256;
     long grid = (n_pairs + block - 1) / block;
     if (grid > 256L * 64) grid = 256L * 64;
-    if (!given_C0) {
-        // Blocks per CU for launches of a few rounds (shards of a strong-scaling run, small station lists): a pair is a long quantum
-        // of lane time (~0.7 ms at 6 waves / SIMD) and the VALU is saturated from 4 waves / SIMD on, so the launch takes
-        // rounds x (waves / SIMD): 2441 blocks are 2 rounds at 6 (1536 resident blocks) but also 2 rounds at 5 (1280) -- of 5/6 the
-        // length.  The residency is capped by an unused dynamic LDS allocation (static 12.4 KB per block, 160 KB per CU).
-        int w = NRHIP_RT_WAVES;
-        if (NRHIP_RT_WAVES == 6 && grid < 256L * 64) {
-            long best = -1;
-            for (int c = 6; c >= 4; c--) {
-                const long cost = ((grid + 256L * c - 1) / (256L * c)) * c;
-                if (best < 0 || cost < best) { best = cost; w = c; }
-            }
-        }
-        if (const char* e = getenv("NRHIP_RT_BLOCKS_PER_CU")) w = atoi(e);
-        const size_t pad = (w == 5) ? 30720 - 12416 : (w == 4) ? 38912 - 12416 : 0;
-        hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), pad, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm);
-    }
+    if (!given_C0)
+        hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm);
     hipLaunchKernelGGL(raytrace_records_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, given_C0);
 }
 
