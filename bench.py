@@ -376,6 +376,8 @@ def main():
                     '(round-2 scheme) instead of emitting them inside pass 1')
     ap.add_argument('--no-traces', action='store_true', help='config 2: time pass 1 only (trigger mask), without the second pass that '
                     'keeps the channel traces of the triggered events')
+    ap.add_argument('--lanes', type=int, default=None, help='arrays: station calls side by side on this many streams (one Station object, '
+                    'workspace and host thread each; default 2 for configs 3 and 5, 1 otherwise)')
     ap.add_argument('--allow-tcp', action='store_true', help='if RCCL does not come up on every rank: run the collectives over the TCP '
                     'star instead of exiting non-zero (single-GPU boxes: tools/two_ranks_one_gpu.sh)')
     args = ap.parse_args()
@@ -401,6 +403,15 @@ def main():
     det = build_array(ctx, wl)
     is_array = wl['centres'] is not None
     st = det.station if is_array else det
+    n_lanes = args.lanes if args.lanes is not None else (2 if cfgno in (3, 5) else 1)
+    lane_ctx = []
+    if is_array:
+        for _ in range(max(n_lanes, 1) - 1):   # (build_array may touch wl['sim_kw']: identical values every time)
+            c2 = nuradiomc_amd.Context(wl['ice'], wl['att_model'], device=local_rank if args.device is None else args.device)
+            lane_ctx.append(c2)
+            det.add_lane(build_array(c2, wl).station)
+    else:
+        n_lanes = 1
     d = upload_events(ctx, wl, (g0, g1))
     n, n_groups = d['n'], d['n_groups']
     dev_kw = dict(d_max_distance=d['md'], n_groups=n_groups, d_group_begin=d['gb'], **wl['sim_kw'])
@@ -504,7 +515,7 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl['name'], "baseline_config_index": cfgno - 1, "flavour": wl['flavour'],
                        "event_groups_per_gpu": n_groups, "showers_per_gpu": n,
-                       "n_stations": 1 if not is_array else len(wl['centres']), "n_channels": len(wl['rel_pos']),
+                       "n_stations": 1 if not is_array else len(wl['centres']), "station_lanes": n_lanes, "n_channels": len(wl['rel_pos']),
                        "n_pairs": stats['n_pairs'], "n_rays": stats['n_rays'],
                        "n_active_rays": stats['n_active_rays'], "n_candidate_events": stats['n_candidate_events'],
                        "n_channel_items": stats['n_channel_items'], "n_channel_transforms": stats['n_channel_transforms'],

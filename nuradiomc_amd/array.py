@@ -63,6 +63,7 @@ class StationArray:
         if len(self.station_ids) != len(self.centres):
             raise ValueError("one station id per centre")
         self.cull = bool(cull)
+        self.lanes = []    # further Station objects (same configuration, each on its own Context = stream): add_lane
         mid = self.relative_position.mean(axis=0)
         self._mid = mid
         self._radius = float(np.max(np.linalg.norm(self.relative_position - mid, axis=1)))
@@ -71,19 +72,36 @@ class StationArray:
     def __len__(self):
         return len(self.centres)
 
-    def _move(self, i):
-        self.station.move_to(self.relative_position + self.centres[i])
+    def add_lane(self, station):
+        """A second (third ...) Station object with the same configuration as the first, created on its OWN Context of the same
+        device (its own stream, tables and workspace).  simulate_events_dev then walks the stations on all lanes side by side, one
+        host thread per lane: the tail of one station call's kernels and its host round trips run under the other lane's kernels
+        (two processes on one GPU measured 9 % / 5 % on BASELINE configs 3 / 5).  Masks and counters are the same as
+        with one lane: every station call is independent, and the OR into the common mask only ever stores ones."""
+        if not isinstance(station, Station):
+            raise TypeError("add_lane needs a nuradiomc_amd.Station")
+        if station.ctx is self.station.ctx or any(station.ctx is q.ctx for q in self.lanes):
+            raise ValueError("every lane needs its own Context (stream)")
+        if station.position.shape != self.station.position.shape:
+            raise ValueError("a lane's station must have the channels of the first")
+        self.lanes.append(station)
+
+    def _move(self, i, st=None):
+        (st or self.station).move_to(self.relative_position + self.centres[i])
 
     # ---- one station on a (possibly culled) shower list ----------------------------------------------------------------
-    def _station_call(self, i, n, d_in, d_trig, dev_kw, kw, scratch, want_index=False, arz_rows=None):
+    def _station_call(self, i, n, d_in, d_trig, dev_kw, kw, scratch, want_index=False, arz_rows=None, st=None):
         """Runs station i.  With a scratch and a distance cut: on the compact list of the groups in range; the flags of the
         call are OR-ed into d_trig (which the caller has zeroed).  Returns (stats or None, keep_index or None, shower_index or
         None); the index arrays are fetched to the host only when want_index."""
-        st, ctx, lib = self.station, self.station.ctx, self.station._lib
-        self._move(i)
+        primary = st is None or st is self.station
+        st = self.station if st is None else st
+        ctx, lib = st.ctx, st._lib
+        self._move(i, st)
         n_groups = int(dev_kw.get('n_groups') or n)
         d_md, d_gb, d_vt = dev_kw.get('d_max_distance'), dev_kw.get('d_group_begin'), dev_kw.get('d_vertex_time')
-        self.last_keep_index = None
+        if primary:
+            self.last_keep_index = None
         if kw.get('noise'):   # every station its own noise stream; keyed by the ORIGINAL group ids whatever list the group travels in
             kw = dict(kw, noise_seed=(int(kw.get('noise_seed', 0)) + 0x9E3779B97F4A7C15 * (i + 1)) & 0xffffffffffffffff)
         if scratch is None or d_md is None:
@@ -102,7 +120,8 @@ class StationArray:
         if want_index or arz_rows is not None:
             keep = np.zeros(nk, np.int32)
             ctx.to_host(keep, scratch.keep)
-            self.last_keep_index = keep
+            if primary:
+                self.last_keep_index = keep
         if nk == 0:
             return None, keep, np.zeros(0, np.int32)
         L.check(lib.nrhip_gather_groups(ctx._h, nk, scratch.keep, d_gb, scratch.gb, d_in[0], d_in[1], d_in[2], d_in[3], d_in[4],
@@ -141,35 +160,79 @@ class StationArray:
         dev_kw.setdefault('n_groups', n_groups)
         d_in = [d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL]
         use_cull = self.cull and dev_kw.get('d_max_distance') is not None
-        scratch = _Scratch(ctx, n, n_groups, dev_kw.get('d_vertex_time') is not None) if use_cull else None
+        lane_stations = [st] + list(self.lanes)
+        todo = list(range(len(self.centres)) if stations is None else stations)
+        if len(todo) < 2:
+            lane_stations = lane_stations[:1]
+        with_time = dev_kw.get('d_vertex_time') is not None
+        scratches = [(_Scratch(q.ctx, n, n_groups, with_time) if use_cull else None) for q in lane_stations]
+        results = {}
+
+        def one_station(i, q, scratch):
+            """station i on lane station q; the flags are OR-ed into the common mask (or the station's own row)"""
+            qlib, qctx = q._lib, q.ctx
+            tgt = d_triggered
+            if d_station_triggered is not None:
+                tgt = d_station_triggered + i * n_groups
+                L.check(qlib.nrhip_memset(qctx._h, ctypes.c_void_p(tgt), 0, n_groups))
+            if use_cull:
+                s_, _, _ = self._station_call(i, n, d_in, tgt, dev_kw, dict(kw, want_stats=want), scratch, arz_rows=arz_rows, st=q)
+            else:
+                self._move(i, q)
+                if arz_rows is not None:
+                    L.check(qlib.nrhip_station_set_shower_profiles(q._h, n, L.iptr(arz_rows[0]), L.dptr(arz_rows[1])))
+                kw_i = kw
+                if kw.get('noise'):   # every station its own noise stream
+                    kw_i = dict(kw, noise_seed=(int(kw.get('noise_seed', 0)) + 0x9E3779B97F4A7C15 * (i + 1)) & 0xffffffffffffffff)
+                s_ = q.simulate_events_dev(n, *d_in, tgt, accumulate_triggered=True, want_stats=want, **dev_kw, **kw_i)
+            if d_station_triggered is not None:
+                L.check(qlib.nrhip_mask_or(qctx._h, n_groups, ctypes.c_void_p(d_triggered), ctypes.c_void_p(tgt), 0))
+                if len(lane_stations) > 1:
+                    qctx.synchronize()
+            results[i] = s_
+
         total, per, offered = None, [], 0
         try:
             L.check(lib.nrhip_memset(ctx._h, ctypes.c_void_p(d_triggered), 0, n_groups))
-            for k, i in enumerate(range(len(self.centres)) if stations is None else stations):
-                tgt = d_triggered
-                if d_station_triggered is not None:
-                    tgt = d_station_triggered + i * n_groups
-                    L.check(lib.nrhip_memset(ctx._h, ctypes.c_void_p(tgt), 0, n_groups))
-                if use_cull:
-                    s_, _, _ = self._station_call(i, n, d_in, tgt, dev_kw, dict(kw, want_stats=want), scratch, arz_rows=arz_rows)
-                else:
-                    self._move(i)
-                    if arz_rows is not None:
-                        L.check(lib.nrhip_station_set_shower_profiles(st._h, n, L.iptr(arz_rows[0]), L.dptr(arz_rows[1])))
-                    kw_i = kw
-                    if kw.get('noise'):   # every station its own noise stream
-                        kw_i = dict(kw, noise_seed=(int(kw.get('noise_seed', 0)) + 0x9E3779B97F4A7C15 * (i + 1)) & 0xffffffffffffffff)
-                    s_ = st.simulate_events_dev(n, *d_in, tgt, accumulate_triggered=True, want_stats=want, **dev_kw, **kw_i)
-                if d_station_triggered is not None:
-                    L.check(lib.nrhip_mask_or(ctx._h, n_groups, ctypes.c_void_p(d_triggered), ctypes.c_void_p(tgt), 0))
+            if len(lane_stations) == 1:
+                for i in todo:
+                    one_station(i, st, scratches[0])
+            else:
+                import threading
+                ctx.synchronize()   # the zeroed mask before any lane ORs into it
+                it_lock, it = threading.Lock(), iter(todo)
+                errors = []
+
+                def worker(q, scratch):
+                    try:
+                        while True:
+                            with it_lock:
+                                i = next(it, None)
+                            if i is None or errors:
+                                return
+                            one_station(i, q, scratch)
+                    except BaseException as e:   # noqa: B902 -- re-raised on the calling thread
+                        errors.append(e)
+                threads = [threading.Thread(target=worker, args=(q, sc)) for q, sc in zip(lane_stations, scratches)]
+                for t in threads:
+                    t.start()
+                for t in threads:
+                    t.join()
+                for q in lane_stations:
+                    q.ctx.synchronize()
+                if errors:
+                    raise errors[0]
+            for i in todo:
+                s_ = results.get(i)
                 if s_ is None:
                     continue
                 offered += s_['n_events']
                 per.append((s_['n_rays'], s_['n_candidate_events']))
                 total = s_ if total is None else _add_stats(total, s_)
         finally:
-            if scratch is not None:
-                scratch.free()
+            for sc in scratches:
+                if sc is not None:
+                    sc.free()
         if want:
             if total is None:
                 total = Station.empty_stats()

@@ -59,7 +59,11 @@ int rccl_fail(const char* what, ncclResult_t r)
 __global__ void mask_or_kernel(long n, unsigned char* __restrict__ dst, const unsigned char* __restrict__ src, int overwrite)
 {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = overwrite ? src[i] : (unsigned char)(dst[i] | src[i]);
+    // (OR: only where src is set, so that two streams OR-ing 0 / 1 masks into the same destination cannot lose each other's ones)
+    if (i < n) {
+        if (overwrite) dst[i] = src[i];
+        else if (src[i]) dst[i] = (unsigned char)(dst[i] | src[i]);
+    }
 }
 
 }  // namespace

@@ -314,6 +314,48 @@ def test_array_full_size_properties(gpu_ctx_factory, config):
     assert np.array_equal(got.astype(bool), trig) and s2['n_triggered'] == trig.sum()
 
 
+@pytest.mark.parametrize('config', [3, 5])
+def test_station_lanes(gpu_ctx_factory, config):
+    """StationArray.add_lane: the station loop on two streams (two Station objects, two host threads) gives the masks and counters
+    of the loop on one -- the OR mask, the per-station masks, rays, candidates, triggers -- whatever order the lanes finish in."""
+    import bench
+    wl = bench.make_workload(config, 60000, seed=10)
+    ctx = gpu_ctx_factory(wl['ice'], wl['att_model'])
+    arr = bench.build_array(ctx, wl)
+    n_st = len(wl['centres'])
+    d = bench.upload_events(ctx, wl)
+    try:
+        ng = d['n_groups']
+        d_st = ctx.malloc(n_st * ng)
+
+        def run():
+            s_ = arr.simulate_events_dev(d['n'], *d['in'], d['trig'], d_max_distance=d['md'], n_groups=ng, d_group_begin=d['gb'],
+                                         d_station_triggered=d_st, **wl['sim_kw'])
+            a, b = np.zeros(ng, np.uint8), np.zeros(n_st * ng, np.uint8)
+            ctx.to_host(a, d['trig'])
+            ctx.to_host(b, d_st)
+            return s_, a, b.reshape(n_st, ng)
+        s1, t1, st1 = run()
+        ctx2 = gpu_ctx_factory(wl['ice'], wl['att_model'])
+        arr.add_lane(bench.build_array(ctx2, wl).station)
+        for _ in range(3):
+            s2, t2, st2 = run()
+            assert np.array_equal(t1, t2) and np.array_equal(st1, st2) and t1.sum() > 20
+            for k in ('n_rays', 'n_candidate_events', 'n_triggered', 'n_station_calls', 'n_groups_offered', 'n_pairs'):   # (n_active_rays depends on the one- or two-stage attenuation a station object has settled on)
+                assert s1[k] == s2[k], k
+            assert s1['per_station'] == s2['per_station']
+        s3 = arr.simulate_events_dev(d['n'], *d['in'], d['trig'], d_max_distance=d['md'], n_groups=ng, d_group_begin=d['gb'],
+                                     **wl['sim_kw'])   # without the per-station rows: OR straight into the common mask
+        t3 = np.zeros(ng, np.uint8)
+        ctx.to_host(t3, d['trig'])
+        assert np.array_equal(t3, t1) and s3['n_triggered'] == s1['n_triggered']
+        with pytest.raises(ValueError):
+            arr.add_lane(arr.station)
+        ctx.free(d_st)
+    finally:
+        bench.free_events(ctx, d)
+
+
 def test_rccl_binding_single_rank(gpu_ctx_factory):
     """nrhip_comm_* (RCCL bound by dlopen behind the C ABI) on ONE GPU: a one-rank communicator goes through ncclGetUniqueId /
     ncclCommInitRank / ncclAllGather / ncclAllReduce / barrier / ncclCommDestroy -- every symbol the N-GPU runs of bench.py need."""

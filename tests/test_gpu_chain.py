@@ -995,7 +995,7 @@ def test_general_path_errors_and_empty_inputs(gpu_ctx_factory):
         st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020')
     with pytest.raises(KeyError):   # HAD 1e18 has three profiles in this library
         st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020', arz_iN=np.full(40, 7))
-    for kw in (dict(amp_per_ray=True), dict(focusing=True)):
+    for kw in (dict(amp_per_ray=True),):   # (focusing with the ARZ models: test_general_path_arz_birefringence[arz+focusing])
         with pytest.raises(Exception, match='ARZ'):
             st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020', arz_iN=np.zeros(40, int), **kw)
     # high/low and coincidence triggers on the general path: decided on the dumped traces (trace_trigger_kernel)
