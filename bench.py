@@ -377,7 +377,7 @@ def main():
     ap.add_argument('--no-traces', action='store_true', help='config 2: time pass 1 only (trigger mask), without the second pass that '
                     'keeps the channel traces of the triggered events')
     ap.add_argument('--lanes', type=int, default=None, help='arrays: station calls side by side on this many streams (one Station object, '
-                    'workspace and host thread each; default 2 for configs 3 and 5, 1 otherwise)')
+                    'workspace and host thread each; default 2 for config 3, 1 otherwise)')
     ap.add_argument('--allow-tcp', action='store_true', help='if RCCL does not come up on every rank: run the collectives over the TCP '
                     'star instead of exiting non-zero (single-GPU boxes: tools/two_ranks_one_gpu.sh)')
     args = ap.parse_args()
@@ -403,7 +403,7 @@ def main():
     det = build_array(ctx, wl)
     is_array = wl['centres'] is not None
     st = det.station if is_array else det
-    n_lanes = args.lanes if args.lanes is not None else (2 if cfgno in (3, 5) else 1)
+    n_lanes = args.lanes if args.lanes is not None else (2 if cfgno == 3 else 1)   # measured: config 3 -6 %, config 5 +-0
     lane_ctx = []
     if is_array:
         for _ in range(max(n_lanes, 1) - 1):   # (build_array may touch wl['sim_kw']: identical values every time)

@@ -1628,12 +1628,15 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         S.n_triggered = nt;
         if (eval_counter) {
             unsigned long long ne = 0;
-            HIPCHK(hipMemcpy(&ne, eval_counter, sizeof ne, hipMemcpyDeviceToHost));
+            // (on the station's stream: a copy on the null stream would also wait for the other lanes' streams, array.py)
+            HIPCHK(hipMemcpyAsync(&ne, eval_counter, sizeof ne, hipMemcpyDeviceToHost, sm));
+            HIPCHK(hipStreamSynchronize(sm));
             S.n_integrand_evals = (int64_t)ne;
         }
         {
             unsigned long long xc[3] = {0, 0, 0};
-            HIPCHK(hipMemcpy(xc, xform_count, sizeof xc, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpyAsync(xc, xform_count, sizeof xc, hipMemcpyDeviceToHost, sm));
+            HIPCHK(hipStreamSynchronize(sm));
             S.n_channel_transforms = (int64_t)xc[0];
             S.n_ray_transforms = (int64_t)xc[1];
             S.n_efield_transforms = (int64_t)xc[2];
@@ -1673,7 +1676,8 @@ int64_t nrhip_sim_fetch(nrhip_station* st, const char* name, void* host_dst, uin
     size_t n = std::min<size_t>(avail, bytes);
     if (n && host_dst) {
         if (hipSetDevice(st->ctx->device) != hipSuccess) return -1;
-        hipError_t e = hipMemcpy(host_dst, st->ws[name].p, n, hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpyAsync(host_dst, st->ws[name].p, n, hipMemcpyDeviceToHost, st->ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(st->ctx->stream);
         if (e != hipSuccess) return nrhip_fail("hipMemcpy", e);
     }
     return (int64_t)avail;
