@@ -159,11 +159,11 @@ raytrace_records_kernel(long n_pairs, const double* __restrict__ x1, const doubl
         double c0v[NRHIP_MAXS];
         if (given_C0) {  // ray_tracing.set_solution (:2092): launch parameters read back from a file, no root finding
             ns = 0;
-            double c0a = NAN, c0b = NAN, c0c = NAN;
-            for (int k = 0; k < NRHIP_MAXS; k++) {
+            double c0a = NAN, c0b = NAN;
+            for (int k = 0; k < NRHIP_MAXS; k++) {   // (NRHIP_MAXS = 2 slots)
                 double v = given_C0[i * NRHIP_MAXS + k];
                 if (!isnan(v)) {
-                    if (ns == 0) c0a = v; else if (ns == 1) c0b = v; else c0c = v;
+                    if (ns == 0) c0a = v; else c0b = v;
                     ns++;
                 }
             }
