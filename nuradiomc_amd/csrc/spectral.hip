@@ -1120,7 +1120,7 @@ __device__ inline int quad_class(int type, double C0, double z1, double z2m, dou
 __global__ void __launch_bounds__(256)
 quad_class_count_kernel(int n_rays, const int* __restrict__ active, const int* __restrict__ ray_slot2, const int* __restrict__ slot_type,
                         const double* __restrict__ C0, const double* __restrict__ zint, IceConst m, signed char* __restrict__ cls,
-                        int* __restrict__ counts)
+                        int* __restrict__ counts, int getenv_ascending)
 {
     __shared__ int hist[QC_NC];
     if (threadIdx.x < QC_NC) hist[threadIdx.x] = 0;
@@ -1128,7 +1128,10 @@ quad_class_count_kernel(int n_rays, const int* __restrict__ active, const int* _
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     int c = -1;
     if (r < n_rays && active[r]) {
-        c = quad_class(slot_type[ray_slot2[r]], C0[r], zint[3 * (long)r], zint[3 * (long)r + 1], zint[3 * (long)r + 2], m);
+        // heaviest class first: the waves stride through the list, and the few that get one pair more than the others take it from
+        // the END of the list -- which should be the cheapest rays, not the refracted ones with eleven rounds
+        c = QC_NC - 1 - quad_class(slot_type[ray_slot2[r]], C0[r], zint[3 * (long)r], zint[3 * (long)r + 1], zint[3 * (long)r + 2], m);
+        if (getenv_ascending) c = QC_NC - 1 - c;
         atomicAdd(&hist[c], 1);
     }
     if (r < n_rays) cls[r] = (signed char)c;
@@ -3233,7 +3236,8 @@ void launch_quad_class_list(hipStream_t s, int n_rays, const int* active, const 
 {
     if (n_rays <= 0) return;
     const int nb = (n_rays + 255) / 256;
-    hipLaunchKernelGGL(quad_class_count_kernel, dim3(nb), dim3(256), 0, s, n_rays, active, ray_slot2, slot_type, C0, zint, m, cls, counts);
+    static const int ascending = getenv("NRHIP_ATT_ASCENDING") ? 1 : 0;   // (experiment switch: lightest class first)
+    hipLaunchKernelGGL(quad_class_count_kernel, dim3(nb), dim3(256), 0, s, n_rays, active, ray_slot2, slot_type, C0, zint, m, cls, counts, ascending);
     (void)hipMemsetAsync(counts + (long)QC_NC * nb, 0, sizeof(int), s);
     launch_exclusive_scan(s, (long)QC_NC * nb + 1, counts, offset, scan_tmp);
     hipLaunchKernelGGL(quad_class_scatter_kernel, dim3(nb), dim3(256), 0, s, n_rays, cls, offset, list);
