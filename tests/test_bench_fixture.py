@@ -1,6 +1,6 @@
-"""The headline workload (bench.py config 2, 1e6-event list, seed 10) pinned on the REFERENCE: its first 6000 event groups went
-through the reference's own simulation functions (tests/golden/gen/gen_bench.py -> chain_bench_N4096.npz: 19 991 rays, 508
-candidate events, 56 triggers).  CPU: the oracle against the fixture; GPU (-m gpu): the batched HIP path, in the production
+"""The headline workload (bench.py config 2, 1e6-event list, seed 10) pinned on the REFERENCE: its first 24 000 event groups went
+through the reference's own simulation functions (tests/golden/gen/gen_bench.py -> chain_bench_N4096.npz: 81 433 rays, 2014
+candidate events, 222 triggers; 17.4 minutes on 8 cores = 23 events/s).  CPU: the oracle against the fixture; GPU (-m gpu): the batched HIP path, in the production
 mode bench.py times, against the fixture."""
 import numpy as np
 import pytest
@@ -23,7 +23,7 @@ def _compare(g, K, n_rays, cand, trig, L, maxV_of, what):
     """decisions exact wherever the ray counts agree; returns the observed maxima"""
     same = n_rays == g['ev_n_rays'][:K]
     frac_diff = 1. - same.mean()
-    assert frac_diff <= 5e-4, frac_diff            # observed: 1 of 6000 (the reference's hybr root noise flips a solution count)
+    assert frac_diff <= 1.2e-3, frac_diff          # observed: 14 of 24 000 = 5.8e-4 (the reference's hybr root noise flips a solution count)
     assert np.array_equal(cand[same], g['ev_candidate'][:K][same])
     assert np.array_equal(trig[same], g['ev_triggered'][:K][same])
     both = same & cand
@@ -37,7 +37,7 @@ def _compare(g, K, n_rays, cand, trig, L, maxV_of, what):
         m = np.isfinite(got) & (got >= 0)
         if m.any():
             worst = max(worst, float(np.max(np.abs(got[m] - ref[m])) / np.max(ref)))
-    assert worst <= 1.3e-3, worst                  # observed 6.1e-4 GPU, 3.5e-4 oracle (a 1e-7 shift of T is ~3e-3 rad at 500 MHz)
+    assert worst <= 1.9e-3, worst                  # observed 9.4e-4 GPU on 24 000 events, 3.5e-4 oracle on 1500 (a 1e-7 shift of T is ~3e-3 rad at 500 MHz)
     print('%s: %d events, ray counts differ on %d, %d candidates, %d triggers (reference %d), max |dV| / max|V| = %.2e'
           % (what, K, int((~same).sum()), int(cand.sum()), int(trig.sum()), int(g['ev_triggered'].sum()), worst))
     return frac_diff, worst
@@ -88,6 +88,6 @@ def test_gpu_vs_reference_on_the_bench_list(gpu_ctx_factory, production):
         got, ref = st.fetch('ray_' + k)[:stats['n_rays']][keep], g['ray_' + k][ref_keep]
         rel = np.max(np.abs(got - ref) / np.abs(ref))
         print('ray_%s max rel %.2e' % (k, rel))
-        assert rel <= 2.5e-7, (k, rel)   # observed 9.0e-8 (C0), 1.0e-7 (D); north_star: 1e-6
+        assert rel <= 4.4e-7, (k, rel)   # observed on 81 433 rays: 1.5e-7 (C0), 2.2e-7 (D); north_star: 1e-6
     assert np.array_equal(st.fetch('ray_channel')[:stats['n_rays']][keep], g['ray_channel'][ref_keep])
     assert np.array_equal(st.fetch('ray_solution')[:stats['n_rays']][keep], g['ray_iS'][ref_keep])
