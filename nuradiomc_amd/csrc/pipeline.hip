@@ -1334,9 +1334,12 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     st->h_lengths = lens;
     if (n_cand > 0) {
         const int nh = sd.N / 2;
-        const int m_max = std::min(FFT_MAX - nh + 1, NRHIP_SPEC_STRIDE - 1);
+        // (the per-length tables hold 8192 bins; the forward chirp-z takes its outputs in blocks, the inverse one in blocks of
+        // FFT_MAX - L / 2 samples, so every N shares the same limit)
+        const int m_max = NRHIP_SPEC_STRIDE - 1;
         if (maxL / 2 > m_max)
-            return nrhip_fail_msg("nrhip_simulate_events: an event's common trace is longer than the 8192-point chirp-z supports");
+            return nrhip_fail_msg("nrhip_simulate_events: an event's common trace is longer than 16382 samples (the per-length tables hold 8192 bins)");
+        (void)nh;
         S.n_distinct_lengths = (int64_t)lens.size();
         MARK(6);
         // the tables of the lengths this station has not met before are built now, into new rows of its cache
@@ -1469,7 +1472,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             HIPCHK(hipMemsetAsync(emit_cursor, 0, 3 * sizeof(unsigned long long), sm));
         }
         double2* scratch;
-        NEED(scratch = WS("channel_scratch", double2, (size_t)channel_grid_blocks() * NRHIP_SPEC_STRIDE));
+        NEED(scratch = WS("channel_scratch", double2, (size_t)channel_grid_blocks() * 2 * NRHIP_SPEC_STRIDE));
         int *it_need, *it_off, *it_tmp, *it_list;
         NEED(it_need = WS("item_need", int, (size_t)n_items + n_cand + 2));
         NEED(it_off = WS("item_need_offset", int, (size_t)n_items + 1));

@@ -1660,8 +1660,9 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, const int* __re
     for (int il = blockIdx.x; il < n_len; il += gridDim.x) {
         const int L = lengths[il], m = L / 2;
         const long is = slots ? slots[il] : il;   // row of the tables this length lives in
-        // forward transform of the packed N/2-point block onto m output bins, modulus m, sign -1
-        czt_build_table(x, FFT_LOG2_MAX, nh, m, m, -1., tw);
+        // forward transform of the packed N/2-point block onto m output bins, modulus m, sign -1; when nh + m - 1 exceeds the
+        // transform length the outputs come in blocks of M - nh + 1 (channel_kernel), all served by this one table
+        czt_build_table(x, FFT_LOG2_MAX, nh, min(m, M - nh + 1), m, -1., tw);
         for (int i = threadIdx.x; i < M; i += blockDim.x) tab.B_fwd[is * M + i] = x[i];
         __syncthreads();
         // inverse transform of m + 1 bins onto blocks of P = M - (m + 1) + 1 samples, modulus L, sign +1
@@ -2494,7 +2495,8 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
     __shared__ RayShared rs;
     __shared__ double red[1024];
     __shared__ int s_trig;
-    double2* __restrict__ acc = scratch + (long)blockIdx.x * NRHIP_SPEC_STRIDE;
+    double2* __restrict__ acc = scratch + (long)blockIdx.x * 2 * NRHIP_SPEC_STRIDE;
+    double2* __restrict__ zbuf = acc + NRHIP_SPEC_STRIDE;   // the forward transform's outputs when they come in blocks
     const long vel_stride = NRHIP_SPEC_STRIDE;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
@@ -2587,21 +2589,36 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                 int cnt = 0;
                 for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = natural ? x[j] : x[nplan_idx(st.np, j)];
                 __syncthreads();
-                cnt = 0;
+                // the m output bins Z(0 .. m - 1) fit one convolution if nh + m - 1 <= M; longer common traces take them in blocks of
+                // Pf: Z(k0 + k') = sum_j (y_j exp(-2 pi i j k0 / m)) exp(-2 pi i j k' / m) -- the same chirp table on the
+                // phase-ramped input -- collected in zbuf (HBM scratch of the block) for the untangling below, which pairs k and m - k
+                const int Pf = min(m, M - nh + 1);
+                const bool blocked = Pf < m;
+                for (int k0 = 0; k0 < m; k0 += Pf) {
+                    cnt = 0;
 #pragma unroll 4
-                for (int j = threadIdx.x; j < M; j += blockDim.x) {
-                    double2 v = make_double2(0., 0.);
-                    if (j < nh) v = cmul(cscale(yreg[cnt++], sc), Cf[j]);  // chirp(j; m, -)
-                    x[j] = v;
+                    for (int j = threadIdx.x; j < M; j += blockDim.x) {
+                        double2 v = make_double2(0., 0.);
+                        if (j < nh) {
+                            v = cmul(cscale(yreg[cnt++], sc), Cf[j]);  // chirp(j; m, -)
+                            if (k0) v = cmul(v, E[(4u * ((unsigned)j * (unsigned)k0 % (unsigned)m)) % (2u * LL)]);   // exp(-2 pi i j k0 / m), 2 L = 4 m
+                        }
+                        x[j] = v;
+                    }
+                    __syncthreads();
+                    czt_convolve_t<512>(x, Bf, tw);
+                    if (blocked) {
+                        const int nb = min(Pf, m - k0);
+                        for (int k = threadIdx.x; k < nb; k += blockDim.x) zbuf[k0 + k] = cscale(cmul(x[k], Cf[k]), 1.0 / M);
+                        __syncthreads();
+                    }
                 }
-                __syncthreads();
-                czt_convolve_t<512>(x, Bf, tw);
                 // Z(k) = chirp(k) x[k] / M ; untangle even/odd samples, apply the start-bin phase, VEL, 5 MHz cut
 #pragma unroll 4
                 for (int k = threadIdx.x; k <= m; k += blockDim.x) {
                     int k1 = (k == m) ? 0 : k, k2 = (k == 0 || k == m) ? 0 : m - k;
-                    double2 Z1 = cscale(cmul(x[k1], Cf[k1]), 1.0 / M);
-                    double2 Z2 = cconj(cscale(cmul(x[k2], Cf[k2]), 1.0 / M));
+                    double2 Z1 = blocked ? zbuf[k1] : cscale(cmul(x[k1], Cf[k1]), 1.0 / M);
+                    double2 Z2 = cconj(blocked ? zbuf[k2] : cscale(cmul(x[k2], Cf[k2]), 1.0 / M));
                     double2 Ee = cscale(cadd(Z1, Z2), 0.5);
                     double2 d = cscale(csub(Z1, Z2), 0.5);
                     double2 Eo = make_double2(d.y, -d.x);  // d / i

@@ -1091,6 +1091,50 @@ def test_phased_array_trigger(gpu_ctx_factory):
         st.set_phased_array([0, 5], angles)
 
 
+def test_common_traces_beyond_the_single_block_of_the_forward_transform(gpu_ctx_factory):
+    """Common traces of 12 290 ... 16 382 samples at N = 4096 (round 3): the forward chirp-z of channel_kernel takes its L / 2 output bins
+    in blocks when N / 2 + L / 2 - 1 exceeds the 8192-point transform.  A station whose last channel sits behind 4.5 us of cable
+    stretches the read-out window; GPU vs the oracle (numpy FFTs of length L) on the same rays: L, t_min, traces 1e-6, decisions.
+    Beyond 16 382 samples the per-length tables end: refused."""
+    import bench
+    ice = bench.ICE
+    pos = np.array(bench.CHANNELS, float)
+    cable = np.array([0., 0., 0., 0., 4500.])
+    ctx = gpu_ctx_factory(ice, 'SP1')
+    st = nuradiomc_amd.Station(ctx, pos, cable_delay=cable, n_samples=4096, sampling_rate=2.0)
+    ost = so.Station(pos, cable_delay=cable, n_samples=4096, fs=2.0)
+    vrms, vrms_e = so.vrms_from_filters(2.0)
+    rng = np.random.default_rng(8)
+    n = 60
+    r, ph = np.sqrt(rng.uniform(0, 700. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    v = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-900., -150., n)], axis=1)
+    zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    en = 10 ** rng.uniform(17.5, 18.5, n)
+    trig, stats = st.simulate_events(v, zen, az, en, 'HAD', dump_traces=True)
+    cand, L, t_min = st.fetch('ev_candidate').astype(bool), st.fetch('ev_L'), st.fetch('ev_t_min')
+    item_event, tr, off = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    pos_of = {int(e): i for i, e in enumerate(item_event)}
+    n_long = n_trig = 0
+    for e in range(n):
+        o = so.simulate_event(v[e], zen[e], az[e], en[e], 'HAD', None, ost, ice, vrms, vrms_e)
+        assert o['candidate'] == bool(cand[e]) and o['triggered'] == bool(trig[e]), e
+        if not o['candidate']:
+            continue
+        assert o['L'] == L[e] and abs(o['t_min'] - t_min[e]) < 1e-9
+        n_long += (L[e] > 12290)
+        n_trig += o['triggered']
+        scale = np.max(np.abs(o['V']))
+        for ch in range(5):
+            it = pos_of[e] * 5 + ch
+            assert np.max(np.abs(tr[off[it]:off[it + 1]] - o['V'][ch])) <= 1e-6 * scale, (e, ch, L[e])
+    assert n_long >= 8 and n_trig >= 3 and stats['max_length'] <= 16382
+    trig_p, _ = st.simulate_events(v, zen, az, en, 'HAD')
+    assert np.array_equal(trig_p, trig)
+    st2 = nuradiomc_amd.Station(ctx, pos, cable_delay=np.array([0., 0., 0., 0., 6500.]), n_samples=4096, sampling_rate=2.0)
+    with pytest.raises(Exception, match='16382'):
+        st2.simulate_events(v, zen, az, en, 'HAD', dump_traces=True)
+
+
 @pytest.mark.parametrize('mode', ['arz', 'phased_array'])
 def test_split_event_time_diff_on_the_general_path_and_with_the_phased_array(gpu_ctx_factory, mode):
     """split_event_time_diff together with the time-domain emission model (the general path re-orders its per-ray tables with the
