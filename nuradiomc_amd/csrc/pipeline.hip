@@ -1334,11 +1334,11 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     st->h_lengths = lens;
     if (n_cand > 0) {
         const int nh = sd.N / 2;
-        // (the per-length tables hold 8192 bins; the forward chirp-z takes its outputs in blocks, the inverse one in blocks of
-        // FFT_MAX - L / 2 samples, so every N shares the same limit)
+        // (the per-length tables hold 16384 bins; the forward chirp-z takes its outputs in blocks, the inverse one its outputs and,
+        // for the longest traces, its inputs: every N shares the same limit)
         const int m_max = NRHIP_SPEC_STRIDE - 1;
         if (maxL / 2 > m_max)
-            return nrhip_fail_msg("nrhip_simulate_events: an event's common trace is longer than 16382 samples (the per-length tables hold 8192 bins)");
+            return nrhip_fail_msg("nrhip_simulate_events: an event's common trace is longer than 32766 samples (the per-length tables hold 16384 bins)");
         (void)nh;
         S.n_distinct_lengths = (int64_t)lens.size();
         MARK(6);
@@ -1511,6 +1511,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                        noise ? &nz : nullptr, conv_split, pa_amp_cut);
         LCHK("channel");
         if (post_trigger) {
+            if (maxL > 2 * FFT_MAX)
+                return nrhip_fail_msg("nrhip_simulate_events: coincidence / high-low / envelope triggers on dumped traces take common traces of at most 16384 samples");
             launch_trace_trigger(sm, n_cand, d_cand, n_ch, ev.L, envelope ? env_trace : co.trace, co.trace_offset, trg, sd.trig_on, maxL,
                                  ev_triggered, trigger_bin);
             LCHK("trace trigger");

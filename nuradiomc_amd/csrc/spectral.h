@@ -8,8 +8,8 @@
 #define NRHIP_MAX_FILTERS 4
 #define NRHIP_MAX_POLY 24
 #define NRHIP_MAX_FSETS 4       // distinct filter chains per station (channels sharing an amplifier type share a set)
-#define NRHIP_SPEC_STRIDE 8192  // max L / 2 + 1 spectrum bins per channel: common traces of at most 16382 samples
-#define NRHIP_E_STRIDE 32768    // 2 L phase-table entries per length
+#define NRHIP_SPEC_STRIDE 16384  // max L / 2 + 1 spectrum bins per channel: common traces of at most 32766 samples
+#define NRHIP_E_STRIDE 65536    // 2 L phase-table entries per length
 #define NRHIP_N_ANT_TAB 5       // antenna response tables per length: VPol, HPol, LPDA front / side / back lobe phase
 #define NRHIP_G_STRIDE 8200     // FFT_MAX + 1 bins of the 2 FFT_MAX-point real transform of the impulse response (padded)
 

@@ -1645,6 +1645,9 @@ __device__ inline double2 apply_filters(double2 v, double f, const FilterSet& fl
     return v;
 }
 
+// (see czt_inverse_blocks)
+__host__ __device__ inline bool czt_inverse_chunked(int m, int M) { return m + 1 > M - 1024; }
+
 // ---------------------------------------------------------------------------------------------------------
 // kernel: per distinct trace length L -- Bluestein tables and the analytic antenna magnitudes on the L grid
 // ---------------------------------------------------------------------------------------------------------
@@ -1665,9 +1668,10 @@ length_tables_kernel(int n_len, const int* __restrict__ lengths, const int* __re
         czt_build_table(x, FFT_LOG2_MAX, nh, min(m, M - nh + 1), m, -1., tw);
         for (int i = threadIdx.x; i < M; i += blockDim.x) tab.B_fwd[is * M + i] = x[i];
         __syncthreads();
-        // inverse transform of m + 1 bins onto blocks of P = M - (m + 1) + 1 samples, modulus L, sign +1
-        int P = M - m;
-        czt_build_table(x, FFT_LOG2_MAX, m + 1, P, L, +1., tw);
+        // inverse transform of m + 1 bins onto blocks of P = M - (m + 1) + 1 samples, modulus L, sign +1 (chunks of M / 2 bins onto
+        // blocks of M / 2 samples for the longest traces: czt_inverse_blocks)
+        if (czt_inverse_chunked(m, M)) czt_build_table(x, FFT_LOG2_MAX, M / 2, M / 2, L, +1., tw);
+        else czt_build_table(x, FFT_LOG2_MAX, m + 1, M - m, L, +1., tw);
         for (int i = threadIdx.x; i < M; i += blockDim.x) tab.B_inv[is * M + i] = x[i];
         __syncthreads();
         // every phase factor of this length: E[j] = exp(-2 pi i j / (2 L)); filter chain on the L grid
@@ -2473,6 +2477,92 @@ __device__ inline void trace_to_packed(double2* x, const double* __restrict__ tr
     nplan_fft(x, np, tw, true);
 }
 
+// inverse chirp-z of channel_kernel: out[n] = sum_{k <= m} V(k) exp(+2 pi i k n / L), n < L, handed to sink(n, value) for every n.
+// m + 1 input bins and P outputs share the M-point convolution (m + P <= M): blocks of P = M - m outputs, the input of block n0
+// pre-multiplied by exp(+2 pi i k n0 / L).  When that would leave fewer than 1024 outputs per block (L > 14 336) the input is cut
+// into chunks of K1 = M / 2 bins as well: out[n0 + n] = sum_c exp(+2 pi i c n / L) sum_{k'} (V(c + k') exp(+2 pi i (c + k') n0 / L))
+// exp(+2 pi i k' n / L) -- every inner sum the same convolution (table built for K1 inputs and P = M / 2 outputs), the chunk sums
+// added in registers.  Below that size the operations, and hence the bits, are those of the single-chunk code.
+
+template <int NT, class FV, class FS>
+__device__ __forceinline__ void czt_inverse_blocks(double2* x, const double2* __restrict__ Bi, const double2* __restrict__ tw,
+                                                   const double2* __restrict__ E, const double2* __restrict__ Ci, int L, int m, int M,
+                                                   FV&& spectrum, FS&& sink)
+{
+    const unsigned LL = (unsigned)L;
+    if (!czt_inverse_chunked(m, M)) {
+        const int P = M - m;
+        for (int n0 = 0; n0 < L; n0 += P) {
+            __syncthreads();
+#pragma unroll 2
+            for (int k = threadIdx.x; k < M; k += NT) {
+                double2 v = make_double2(0., 0.);
+                if (k <= m) {
+                    v = spectrum(k);
+                    if (n0 != 0) {
+                        unsigned kn = ((unsigned)k * (unsigned)n0) % LL;
+                        v = cmul(v, cconj(E[2 * kn]));                         // exp(+2 pi i k n0 / L)
+                    }
+                    v = cmul(v, Ci[k]);                                        // chirp(k; L, +)
+                }
+                x[k] = v;
+            }
+            __syncthreads();
+            czt_convolve_t<NT>(x, Bi, tw);
+            const int np = min(P, L - n0);
+#pragma unroll 4
+            for (int n = threadIdx.x; n < np; n += NT) sink(n0 + n, cmul(x[n], Ci[n]));
+        }
+        __syncthreads();
+        return;
+    }
+    const int K1 = M / 2, P = M / 2;
+    constexpr int PER = (FFT_MAX / 2 + NT - 1) / NT;   // outputs of a block per thread
+    for (int n0 = 0; n0 < L; n0 += P) {
+        const int np = min(P, L - n0);
+        double2 part[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) part[q] = make_double2(0., 0.);
+        for (int c0 = 0; c0 <= m; c0 += K1) {
+            __syncthreads();
+#pragma unroll 2
+            for (int k1 = threadIdx.x; k1 < M; k1 += NT) {
+                double2 v = make_double2(0., 0.);
+                const int k = c0 + k1;
+                if (k1 < K1 && k <= m) {
+                    v = spectrum(k);
+                    if (n0 != 0) {
+                        unsigned kn = ((unsigned)k * (unsigned)n0) % LL;
+                        v = cmul(v, cconj(E[2 * kn]));                         // exp(+2 pi i k n0 / L)
+                    }
+                    v = cmul(v, Ci[k1]);                                       // chirp(k'; L, +)
+                }
+                x[k1] = v;
+            }
+            __syncthreads();
+            czt_convolve_t<NT>(x, Bi, tw);
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int n = threadIdx.x + q * NT;
+                if (n < np) {
+                    double2 u = cmul(x[n], Ci[n]);
+                    if (c0 != 0) {
+                        unsigned cn = ((unsigned)c0 * (unsigned)n) % LL;
+                        u = cmul(u, cconj(E[2 * cn]));                         // exp(+2 pi i c0 n / L)
+                    }
+                    part[q] = cadd(part[q], u);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int n = threadIdx.x + q * NT;
+            if (n < np) sink(n0 + n, part[q]);
+        }
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // kernel: one (candidate event, channel) item per block iteration.
 //   for every ray of the channel and both on-sky components:
@@ -2671,74 +2761,38 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
             }
         }
         if (need_trace) {
-            const int P = M - m;
             const double scale = st.fs / 1.4142135623730951 / L;
-            for (int n0 = 0; n0 < L; n0 += P) {
-#pragma unroll 4
-                for (int k = threadIdx.x; k < M; k += blockDim.x) {
-                    double2 v = make_double2(0., 0.);
-                    if (k <= m) {
-                        v = cmul(acc[k], Hf[k]);
-                        // Hermitian folding of irfft: DC and Nyquist real and single, the rest doubled
-                        if (k == 0 || k == m) v = make_double2(v.x, 0.);
-                        else v = cscale(v, 2.);
-                        if (n0 != 0) {
-                            unsigned kn = ((unsigned)k * (unsigned)n0) % LL;
-                            v = cmul(v, cconj(E[2 * kn]));                         // exp(+2 pi i k n0 / L)
-                        }
-                        v = cmul(v, Ci[k]);                                        // chirp(k; L, +)
-                    }
-                    x[k] = v;
-                }
-                __syncthreads();
-                czt_convolve_t<512>(x, Bi, tw);
-                int np = min(P, L - n0);
-#pragma unroll 4
-                for (int n = threadIdx.x; n < np; n += blockDim.x) {
-                    double2 u = cmul(x[n], Ci[n]);
-                    double v = u.x * (1.0 / M) * scale;
-                    int ng = n0 + n;
+            const bool ch_on = (!st.trig_on || st.trig_on[ch]);
+            czt_inverse_blocks<512>(x, Bi, tw, E, Ci, L, m, M,
+                [&](int k) {
+                    double2 v = cmul(acc[k], Hf[k]);
+                    // Hermitian folding of irfft: DC and Nyquist real and single, the rest doubled
+                    if (k == 0 || k == m) v = make_double2(v.x, 0.);
+                    else v = cscale(v, 2.);
+                    return v;
+                },
+                [&](int ng, double2 u) {
+                    const double v = u.x * (1.0 / M) * scale;
                     if (out.trace) out.trace[out.trace_offset[item] + ng] = v;
-                    double av = fabs(v);
+                    const double av = fabs(v);
                     vmax = fmax(vmax, av);
-                    if (ng < L - 1 && av >= threshold && (!st.trig_on || st.trig_on[ch])) trig = 1;
-                }
-                __syncthreads();
-            }
+                    if (ng < L - 1 && av >= threshold && ch_on) trig = 1;
+                });
         }
         if (env_trace && (n_used > 0 || noisy)) {
             // envelope trigger (envelopeTrigger.py:14-31 on channel.get_filtered_trace(passband, 'butter', order)): the channel
             // spectrum through the trigger's band pass, then the analytic signal -- the one-sided sum the inverse chirp-z forms anyway
             // (DC and Nyquist once and real, the bins between twice: scipy.signal.hilbert's weights); its modulus is the envelope
-            const int P = M - m;
             const double scale = st.fs / 1.4142135623730951 / L;
             const double dfL = 1.0 / (L * (1. / st.fs));
-            for (int n0 = 0; n0 < L; n0 += P) {
-                __syncthreads();
-#pragma unroll 2
-                for (int k = threadIdx.x; k < M; k += blockDim.x) {
-                    double2 v = make_double2(0., 0.);
-                    if (k <= m) {
-                        v = cmul(cmul(acc[k], Hf[k]), apply_filters(make_double2(1., 0.), k * dfL, envf));
-                        if (k == 0 || k == m) v = make_double2(v.x, 0.);
-                        else v = cscale(v, 2.);
-                        if (n0 != 0) {
-                            unsigned kn = ((unsigned)k * (unsigned)n0) % LL;
-                            v = cmul(v, cconj(E[2 * kn]));
-                        }
-                        v = cmul(v, Ci[k]);
-                    }
-                    x[k] = v;
-                }
-                __syncthreads();
-                czt_convolve_t<512>(x, Bi, tw);
-                const int np = min(P, L - n0);
-                for (int n = threadIdx.x; n < np; n += blockDim.x) {
-                    const double2 u = cmul(x[n], Ci[n]);
-                    env_trace[out.trace_offset[item] + n0 + n] = cabs2(u) * (1.0 / M) * scale;
-                }
-            }
-            __syncthreads();
+            czt_inverse_blocks<512>(x, Bi, tw, E, Ci, L, m, M,
+                [&](int k) {
+                    double2 v = cmul(cmul(acc[k], Hf[k]), apply_filters(make_double2(1., 0.), k * dfL, envf));
+                    if (k == 0 || k == m) v = make_double2(v.x, 0.);
+                    else v = cscale(v, 2.);
+                    return v;
+                },
+                [&](int ng, double2 u) { env_trace[out.trace_offset[item] + ng] = cabs2(u) * (1.0 / M) * scale; });
         }
         if (trig) s_trig = 1;
         double vm = need_trace ? block_max(vmax, red) : vmax;
@@ -2981,32 +3035,18 @@ efield_channel_kernel(int n_efields, const double* __restrict__ traces, const do
         }
     }
     // back to the time domain (freq2time: irfft * fs / sqrt 2)
-    const int P = M - m;
     const double scale = st.fs / 1.4142135623730951 / L;
-    for (int n0 = 0; n0 < L; n0 += P) {
-        for (int k = threadIdx.x; k < M; k += blockDim.x) {
+    czt_inverse_blocks<512>(x, Bi, tw, E, Ci, L, m, M,
+        [&](int k) {
             double2 v = make_double2(0., 0.);
-            if (k <= m && n_used > 0) {
+            if (n_used > 0) {
                 v = apply_filter ? cmul(acc[k], Hf[k]) : acc[k];
                 if (k == 0 || k == m) v = make_double2(v.x, 0.);
                 else v = cscale(v, 2.);
-                if (n0 != 0) {
-                    unsigned kn = ((unsigned)k * (unsigned)n0) % LL;
-                    v = cmul(v, cconj(E[2 * kn]));
-                }
-                v = cmul(v, Ci[k]);
             }
-            x[k] = v;
-        }
-        __syncthreads();
-        czt_convolve_t<512>(x, Bi, tw);
-        int np = min(P, L - n0);
-        for (int n = threadIdx.x; n < np; n += blockDim.x) {
-            double2 u = cmul(x[n], Ci[n]);
-            V[(long)ch * L + n0 + n] = u.x * (1.0 / M) * scale;
-        }
-        __syncthreads();
-    }
+            return v;
+        },
+        [&](int ng, double2 u) { V[(long)ch * L + ng] = u.x * (1.0 / M) * scale; });
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -1091,15 +1091,17 @@ def test_phased_array_trigger(gpu_ctx_factory):
         st.set_phased_array([0, 5], angles)
 
 
-def test_common_traces_beyond_the_single_block_of_the_forward_transform(gpu_ctx_factory):
-    """Common traces of 12 290 ... 16 382 samples at N = 4096 (round 3): the forward chirp-z of channel_kernel takes its L / 2 output bins
-    in blocks when N / 2 + L / 2 - 1 exceeds the 8192-point transform.  A station whose last channel sits behind 4.5 us of cable
-    stretches the read-out window; GPU vs the oracle (numpy FFTs of length L) on the same rays: L, t_min, traces 1e-6, decisions.
-    Beyond 16 382 samples the per-length tables end: refused."""
+@pytest.mark.parametrize('cable_ns,l_lo,l_hi', [(4500., 12290, 16382), (6500., 16384, 21000), (9000., 21000, 32766)])
+def test_common_traces_beyond_the_single_block_of_the_transforms(gpu_ctx_factory, cable_ns, l_lo, l_hi):
+    """Common traces of 12 290 ... 32 766 samples at N = 4096 (round 3): the forward chirp-z of channel_kernel takes its L / 2 output bins
+    in blocks when N / 2 + L / 2 - 1 exceeds the 8192-point transform, the inverse one cuts its L / 2 + 1 input bins into chunks
+    when fewer than 1024 outputs per block would be left (L > 14 336).  A station whose last channel sits behind 4.5 / 6.5 / 9 us
+    of cable stretches the read-out window; GPU vs the oracle (numpy FFTs of length L) on the same rays: L, t_min, traces 1e-6,
+    decisions.  Beyond 32 766 samples the per-length tables end: refused."""
     import bench
     ice = bench.ICE
     pos = np.array(bench.CHANNELS, float)
-    cable = np.array([0., 0., 0., 0., 4500.])
+    cable = np.array([0., 0., 0., 0., cable_ns])
     ctx = gpu_ctx_factory(ice, 'SP1')
     st = nuradiomc_amd.Station(ctx, pos, cable_delay=cable, n_samples=4096, sampling_rate=2.0)
     ost = so.Station(pos, cable_delay=cable, n_samples=4096, fs=2.0)
@@ -1121,18 +1123,22 @@ def test_common_traces_beyond_the_single_block_of_the_forward_transform(gpu_ctx_
         if not o['candidate']:
             continue
         assert o['L'] == L[e] and abs(o['t_min'] - t_min[e]) < 1e-9
-        n_long += (L[e] > 12290)
+        n_long += (l_lo < L[e] <= l_hi)
         n_trig += o['triggered']
         scale = np.max(np.abs(o['V']))
         for ch in range(5):
             it = pos_of[e] * 5 + ch
             assert np.max(np.abs(tr[off[it]:off[it + 1]] - o['V'][ch])) <= 1e-6 * scale, (e, ch, L[e])
-    assert n_long >= 8 and n_trig >= 3 and stats['max_length'] <= 16382
+    assert n_long >= 8 and n_trig >= 3 and stats['max_length'] <= l_hi
     trig_p, _ = st.simulate_events(v, zen, az, en, 'HAD')
     assert np.array_equal(trig_p, trig)
-    st2 = nuradiomc_amd.Station(ctx, pos, cable_delay=np.array([0., 0., 0., 0., 6500.]), n_samples=4096, sampling_rate=2.0)
-    with pytest.raises(Exception, match='16382'):
-        st2.simulate_events(v, zen, az, en, 'HAD', dump_traces=True)
+    if cable_ns > 8000.:
+        st2 = nuradiomc_amd.Station(ctx, pos, cable_delay=np.array([0., 0., 0., 0., 14500.]), n_samples=4096, sampling_rate=2.0)
+        with pytest.raises(Exception, match='32766'):
+            st2.simulate_events(v, zen, az, en, 'HAD', dump_traces=True)
+        opts = dict(trigger='high_low', n_coincidences=2, coinc_window=30., threshold_high=2 * vrms, threshold_low=-2 * vrms, high_low_window=5.)
+        with pytest.raises(Exception, match='16384'):
+            st.simulate_events(v, zen, az, en, 'HAD', **opts)
 
 
 @pytest.mark.parametrize('mode', ['arz', 'phased_array'])
