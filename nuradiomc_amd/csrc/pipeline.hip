@@ -797,6 +797,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     const bool envelope = cfg->trigger_type == NRHIP_TRIG_ENVELOPE;
     const bool noise = cfg->noise != 0;
     if (noise && !st->noise_set) return nrhip_fail_msg("nrhip_simulate_events: noise needs the per-channel amplitudes (nrhip_station_set_noise)");
+    if (cfg->amp_per_ray && sd.N > FFT_MAX / 2)
+        return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray takes traces of at most 4096 samples");
     if (noise && cfg->amp_per_ray)
         return nrhip_fail_msg("nrhip_simulate_events: noise is not available together with amp_per_ray");
     if (envelope && !st->env_set)
@@ -1473,6 +1475,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         }
         double2* scratch;
         NEED(scratch = WS("channel_scratch", double2, (size_t)channel_grid_blocks() * 2 * NRHIP_SPEC_STRIDE));
+        double* amp_scratch = nullptr;   // N > 4096: the chirp-z kernel's amplitude table does not fit behind its 128 KB buffer
+        if (channel_amp_in_hbm(sd.N)) NEED(amp_scratch = WS("channel_amp_scratch", double, (size_t)channel_grid_blocks() * (sd.N / 2 + 1)));
         int *it_need, *it_off, *it_tmp, *it_list;
         NEED(it_need = WS("item_need", int, (size_t)n_items + n_cand + 2));
         NEED(it_off = WS("item_need_offset", int, (size_t)n_items + 1));
@@ -1508,7 +1512,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                        (cfg->no_pruning || cfg->dump_traces || general || phased || post_trigger || noise) ? 1 : 0, maxL,
                        it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces,
                        (phased || post_trigger) ? (cfg->dump_traces ? 0 : 1) : -1, envelope ? &st->env_filter : nullptr, env_trace,
-                       noise ? &nz : nullptr, conv_split, pa_amp_cut);
+                       noise ? &nz : nullptr, conv_split, pa_amp_cut, amp_scratch);
         LCHK("channel");
         if (post_trigger) {
             if (maxL > 2 * FFT_MAX)

@@ -785,7 +785,7 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, c
     if (threadIdx.x == 0) g_ct_mark[blockIdx.x & 1023] = __builtin_amdgcn_s_memtime();
 #endif
     // the sub-sample shift's phase ramp exp(-2 pi i f rem), f = k fs / N: w^k = w^(k & 63) * (w^64)^(k >> 6)
-    __shared__ double2 s_ramp[64 + FFT_MAX / 4 / 64 + 1];
+    __shared__ double2 s_ramp[64 + FFT_MAX / 2 / 64 + 1];   // N / 2 up to FFT_MAX / 2 bins
     const double2* ramp = nullptr;
     if (shift && blockDim.x >= 64 + (unsigned)(nh >> 6) + 1) {
         const int t = threadIdx.x;
@@ -2576,12 +2576,14 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                const int* __restrict__ ev_len_index, StationDev st, FilterSet fl, int ask_model, double threshold,
                const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
                ChannelOut out, int exact, int skip_upto, double2* __restrict__ tab_nodes,
-               const double* __restrict__ ray_traces, FilterSet envf, double* __restrict__ env_trace, NoiseDev nz)
+               const double* __restrict__ ray_traces, FilterSet envf, double* __restrict__ env_trace, NoiseDev nz,
+               double* __restrict__ amp_scratch)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M = FFT_MAX, N = st.N, nh = N / 2;
     double2* x = (double2*)smem;
-    double* amp = (double*)(x + M);
+    // the ray's amplitude table: behind the transform buffer in LDS, or (N > 4096: 128 + 32 KB do not fit) a row of HBM scratch
+    double* amp = amp_scratch ? amp_scratch + (long)blockIdx.x * (nh + 1) : (double*)(x + M);
     __shared__ RayShared rs;
     __shared__ double red[1024];
     __shared__ int s_trig;
@@ -3414,7 +3416,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
                     const double* ray_traces, int skip_off, const FilterSet* envf, double* env_trace, const NoiseDev* noise,
-                    bool conv_split, double pa_amp_cut)
+                    bool conv_split, double pa_amp_cut, double* amp_scratch)
 {
     if (skip_off < 0) skip_off = !exact;  // channels outside the trigger set are evaluated only when everything is
     if (n_items <= 0) return;
@@ -3465,10 +3467,11 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
         skip_upto = FFT_MAX;
         if (max_length <= FFT_MAX && !st.ant_tabs) return;
     }
-    size_t lds = (size_t)FFT_MAX * 16 + (size_t)(nh + 1) * 8;
+    size_t lds = (size_t)FFT_MAX * 16 + (amp_scratch ? 0 : (size_t)(nh + 1) * 8);
     hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
                        ask_model, trig.threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto, tab_nodes, ray_traces,
-                       envf ? *envf : fl, env_trace, noise ? *noise : NoiseDev{0, 0ull, nullptr, nullptr, 0, nullptr, nullptr});
+                       envf ? *envf : fl, env_trace, noise ? *noise : NoiseDev{0, 0ull, nullptr, nullptr, 0, nullptr, nullptr},
+                       amp_scratch);
 }
 // ---------------------------------------------------------------------------------------------------------
 // General emission / propagation path (time-domain emission models such as ARZ, birefringence): the on-sky spectra of every

@@ -1141,6 +1141,52 @@ def test_common_traces_beyond_the_single_block_of_the_transforms(gpu_ctx_factory
             st.simulate_events(v, zen, az, en, 'HAD', **opts)
 
 
+def test_traces_of_8192_samples(gpu_ctx_factory):
+    """N = 8192 in the batched path (round 3): the ray stages hold the 4096-point transform, the channel stage is the chirp-z
+    kernel (common traces of > 9400 samples: forward transform in two output blocks, the amplitude table in HBM scratch because
+    128 + 32 KB of LDS do not exist).  GPU vs the oracle: rays, candidate flags, L, traces 1e-6, decisions; production = exhaustive."""
+    import bench
+    ice = bench.ICE
+    pos = np.array(bench.CHANNELS, float)
+    ctx = gpu_ctx_factory(ice, 'SP1')
+    st = nuradiomc_amd.Station(ctx, pos, n_samples=8192, sampling_rate=2.0)
+    ost = so.Station(pos, n_samples=8192, fs=2.0)
+    vrms, vrms_e = so.vrms_from_filters(2.0)
+    assert abs(st.vrms - vrms) <= 1e-12 * vrms
+    rng = np.random.default_rng(18)
+    n = 50
+    r, ph = np.sqrt(rng.uniform(0, 800. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    v = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1000., -150., n)], axis=1)
+    zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    en = 10 ** rng.uniform(17.3, 18.5, n)
+    trig, stats = st.simulate_events(v, zen, az, en, 'HAD', dump_traces=True)
+    cand, L, n_rays, mx = st.fetch('ev_candidate').astype(bool), st.fetch('ev_L'), st.fetch('ev_n_rays'), st.fetch('ray_max_efield')
+    rev = st.fetch('ray_event')
+    item_event, tr, off = st.fetch('item_event'), st.fetch('trace'), st.fetch('trace_offset')
+    pos_of = {int(e): i for i, e in enumerate(item_event)}
+    n_cand = n_trig = 0
+    for e in range(n):
+        o = so.simulate_event(v[e], zen[e], az[e], en[e], 'HAD', None, ost, ice, vrms, vrms_e)
+        mine = np.flatnonzero(rev == e)
+        assert len(mine) == len(o['rays']) == n_rays[e] and o['candidate'] == bool(cand[e]) and o['triggered'] == bool(trig[e]), e
+        for k, q in zip(mine, o['rays']):   # (a negative entry: "not evaluated, at most this" -- the event cannot be a candidate)
+            assert abs(mx[k] - q['max_efield']) <= 1e-6 * q['max_efield'] if mx[k] > 0 else -mx[k] >= q['max_efield'] * (1 - 1e-9)
+        if not o['candidate']:
+            continue
+        n_cand += 1
+        n_trig += o['triggered']
+        assert o['L'] == L[e] > 9392
+        scale = np.max(np.abs(o['V']))
+        for ch in range(5):
+            it = pos_of[e] * 5 + ch
+            assert np.max(np.abs(tr[off[it]:off[it + 1]] - o['V'][ch])) <= 1e-6 * scale, (e, ch)
+    assert n_cand >= 10 and n_trig >= 3
+    trig_p, _ = st.simulate_events(v, zen, az, en, 'HAD')
+    assert np.array_equal(trig_p, trig)
+    with pytest.raises(Exception, match='4096'):
+        st.simulate_events(v, zen, az, en, 'HAD', amp_per_ray=True)
+
+
 @pytest.mark.parametrize('mode', ['arz', 'phased_array'])
 def test_split_event_time_diff_on_the_general_path_and_with_the_phased_array(gpu_ctx_factory, mode):
     """split_event_time_diff together with the time-domain emission model (the general path re-orders its per-ray tables with the
