@@ -91,8 +91,8 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     int nh = d->n_samples / 2;
     if (nh < 8 || nh > FFT_MAX / 2)
         return nrhip_fail_msg("nrhip_station_create: n_samples must be an even number between 16 and 8192");
-    if ((nh & (nh - 1)) != 0 && nh > FFT_MAX / 4)   // Bluestein needs 2 nh - 1 points of the 64 KB the ray kernels have
-        return nrhip_fail_msg("nrhip_station_create: n_samples above 4096 must be a power of two (8192)");
+    // (N / 2 no power of two: Bluestein on the next power of two >= N - 1, at most FFT_MAX points = the whole LDS of the ray kernels,
+    // whose amplitude tables then sit in HBM scratch)
     if (d->n_att_freq <= 0 || d->n_att_freq > NRHIP_MAX_NFC) return nrhip_fail_msg("nrhip_station_create: bad n_att_freq");
     HIPCHK(hipSetDevice(ctx->device));
     if (ensure_twiddle(ctx)) return -1;
@@ -1190,7 +1190,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                 if (v) return nrhip_fail_msg("nrhip_simulate_events: ARZ: length of indices is not 2 nor 4 (more than two stretches of a profile radiate within 1 ns)");
             arz_trace = atr;
         }
-        launch_general_spectrum(sm, n_rays, w, sd, cfg->askaryan_model, arz_trace, ctx->twiddle, spec);
+        double* ray_amp = nullptr;
+        if (ray_amp_in_hbm(sd.N)) NEED(ray_amp = WS("ray_amp_scratch", double, (size_t)RAY_AMP_ROWS * (sd.N / 2 + 1)));
+        launch_general_spectrum(sm, n_rays, w, sd, cfg->askaryan_model, arz_trace, ctx->twiddle, spec, ray_amp);
         LCHK("general spectrum");
         if (bire) {
             std::vector<int> hn(n_rays);
@@ -1239,9 +1241,11 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(ev_off = WS("ev_need_offset", int, n_groups + 1));
         NEED(ev_tmp = WS("scan_tmp3", int, scan_tiles(n_groups + 1)));
         NEED(ev_list = WS("ev_transform_list", int, n_groups));
+        double* ray_amp = nullptr;
+        if (ray_amp_in_hbm(sd.N)) NEED(ray_amp = WS("ray_amp_scratch", double, (size_t)RAY_AMP_ROWS * (sd.N / 2 + 1)));
         launch_efield_max(sm, n_active, active_list, n_rays, (int)n_groups, grp_ray, w, evin, sd, cfg->askaryan_model,
                           ctx->twiddle, cfg->min_efield_amplitude, (cfg->no_pruning || cfg->dump_traces) ? 1 : 0, max_efield,
-                          need_ray, ev_need, ev_off, ev_tmp, ev_list, xform_count);
+                          need_ray, ev_need, ev_off, ev_tmp, ev_list, xform_count, ray_amp);
         LCHK("efield_max");
     }
     MARK(5);

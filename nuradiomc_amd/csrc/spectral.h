@@ -186,7 +186,7 @@ void launch_scatter_active_class(hipStream_t s, int n_rays, const int* flags, co
 void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int n_rays, int n_events,
                        const int* slot_offset, const RayWork& w, const EventIn& evin, const StationDev& st, int ask_model,
                        const double2* tw, double min_efield, int exact, double* max_efield, int* need_ray, int* ev_need,
-                       int* ev_offset, int* scan_tmp, int* ev_list, unsigned long long* xform_count);
+                       int* ev_offset, int* scan_tmp, int* ev_list, unsigned long long* xform_count, double* amp_scratch = nullptr);
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev);
 void launch_candidate_flags(hipStream_t s, int n_events, int n_half, const EventOut& ev, int* cflag, int* lflag,
@@ -198,7 +198,7 @@ void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const St
 void launch_length_slots(hipStream_t s, int n_events, const int* ev_L, const int* slotmap, int* len_index);   // fls: DEV [st.n_fsets]
 int channel_grid_blocks();
 void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, int ask_model,
-                             const double* arz_trace, const double2* tw, double2* spec);
+                             const double* arz_trace, const double2* tw, double2* spec, double* amp_scratch = nullptr);
 void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double2* tw,
                           double* traces, double* max_efield, const int* active = nullptr, const double* bound = nullptr);
 void launch_general_bound(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const long long* log_gain,
@@ -220,6 +220,10 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const NoiseDev* noise = nullptr, bool conv_split = true, double pa_amp_cut = -1., double* amp_scratch = nullptr);
 // channel_kernel's amplitude table lives in HBM scratch (rows of N / 2 + 1 doubles per block) when N > 4096
 inline bool channel_amp_in_hbm(int n_samples) { return n_samples / 2 > 2048; }
+// efield_max_kernel / general_spectrum_kernel: N / 2 no power of two and above 2048 -- the Bluestein transform takes FFT_MAX points,
+// 128 KB of LDS; the amplitude tables of at most RAY_AMP_ROWS blocks then sit in HBM scratch
+#define RAY_AMP_ROWS 1024
+inline bool ray_amp_in_hbm(int n_samples) { const int nh = n_samples / 2; return nh > 2048 && (nh & (nh - 1)) != 0; }
 // trigger ADC + up-sampling of the phased array (pa_digitize_kernel)
 struct PaAdc {
     double adc_fs, vmin, vmax;   // ADC sampling rate [GHz], voltage range

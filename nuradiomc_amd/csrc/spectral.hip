@@ -1465,12 +1465,13 @@ __global__ void __launch_bounds__(256)
 efield_max_kernel(const int* __restrict__ n_list, const int* __restrict__ ev_list, const int* __restrict__ need_ray,
                   const int* __restrict__ slot_offset, RayWork w, EventIn evin, StationDev st, int ask_model,
                   const double2* __restrict__ tw, int log2nh, double min_efield, int exact, double* __restrict__ max_efield,
-                  unsigned long long* __restrict__ xform_count)
+                  unsigned long long* __restrict__ xform_count, double* __restrict__ amp_scratch)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2;
     double2* x = (double2*)smem;
-    double* amp = (double*)(x + nplan_points(st.np));
+    // (amplitude table in a row of HBM scratch when the Bluestein transform takes all of the LDS: ray_amp_in_hbm)
+    double* amp = amp_scratch ? amp_scratch + (long)blockIdx.x * (nh + 1) : (double*)(x + nplan_points(st.np));
     __shared__ RayShared rs;
     __shared__ double red[256];
     const int n_ev = *n_list;
@@ -3124,7 +3125,7 @@ nplan_tables_kernel(int nh, int log2p, double2* __restrict__ wN, double2* __rest
 static inline unsigned grid_for(long n, int block) { return (unsigned)((n + block - 1) / block); }
 static void set_big_lds();
 __global__ void general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, const double* __restrict__ arz_trace,
-                                        const double2* __restrict__ tw, int log2nh, double2* __restrict__ spec);
+                                        const double2* __restrict__ tw, int log2nh, double2* __restrict__ spec, double* __restrict__ amp_scratch);
 __global__ void general_trace_kernel(int n_rays, StationDev st, const double2* __restrict__ spec, const double2* __restrict__ tw,
                                      int log2nh, double* __restrict__ traces, double* __restrict__ max_efield,
                                      const int* __restrict__ active, const double* __restrict__ bound);
@@ -3315,7 +3316,7 @@ void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const i
 void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int n_rays, int n_events,
                        const int* slot_offset, const RayWork& w, const EventIn& evin, const StationDev& st, int ask_model,
                        const double2* tw, double min_efield, int exact, double* max_efield, int* need_ray, int* ev_need,
-                       int* ev_offset, int* scan_tmp, int* ev_list, unsigned long long* xform_count)
+                       int* ev_offset, int* scan_tmp, int* ev_list, unsigned long long* xform_count, double* amp_scratch)
 {
     if (n_active <= 0) return;
     int nh = st.N / 2;
@@ -3336,10 +3337,11 @@ void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int 
     hipLaunchKernelGGL(scatter_flagged_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, ev_need, ev_offset,
                        ev_list);
     set_big_lds();
-    size_t lds = (size_t)nplan_points(st.np) * 16 + (size_t)(nh + 1) * 8;
+    size_t lds = (size_t)nplan_points(st.np) * 16 + (amp_scratch ? 0 : (size_t)(nh + 1) * 8);
     int grid = n_events < 256 * 16 ? n_events : 256 * 16;
+    if (amp_scratch && grid > RAY_AMP_ROWS) grid = RAY_AMP_ROWS;
     hipLaunchKernelGGL(efield_max_kernel, dim3(grid), dim3(256), lds, s, ev_offset + n_events, ev_list, need_ray, slot_offset,
-                       w, evin, st, ask_model, tw, ilog2(nh), min_efield, exact, max_efield, xform_count);
+                       w, evin, st, ask_model, tw, ilog2(nh), min_efield, exact, max_efield, xform_count, amp_scratch);
 }
 void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const RayWork& w, const StationDev& st,
                        const double* max_efield, double min_efield, const EventOut& ev)
@@ -3378,11 +3380,10 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)efield_channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     // trace lengths that are no power of two: Bluestein on up to FFT_MAX / 2 points inside the ray kernels
-    (void)hipFuncSetAttribute((const void*)efield_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (FFT_MAX / 2) * 16 + (FFT_MAX / 4 + 1) * 8);
-    (void)hipFuncSetAttribute((const void*)general_spectrum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (FFT_MAX / 2) * 16 + (FFT_MAX / 4 + 1) * 8);
-    (void)hipFuncSetAttribute((const void*)general_trace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (FFT_MAX / 2) * 16);
+    // (N = 8192: 4096 points + 4097 amplitudes = 96 KB; N between 4098 and 8190: Bluestein on FFT_MAX points, amplitudes in HBM)
+    (void)hipFuncSetAttribute((const void*)efield_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)general_spectrum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)general_trace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipGetLastError();
     g_attr_set = true;
 }
@@ -3484,12 +3485,12 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
 // ([ray][3][N], arz.hip), else the parametrisation's.  One block (256) per ray; LDS: N/2 complex + (N/2 + 1) doubles.
 __global__ void __launch_bounds__(256)
 general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, const double* __restrict__ arz_trace,
-                        const double2* __restrict__ tw, int log2nh, double2* __restrict__ spec)
+                        const double2* __restrict__ tw, int log2nh, double2* __restrict__ spec, double* __restrict__ amp_scratch)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2, n_f = nh + 1;
     double2* x = (double2*)smem;
-    double* amp = (double*)(x + nplan_points(st.np));
+    double* amp = amp_scratch ? amp_scratch + (long)blockIdx.x * (nh + 1) : (double*)(x + nplan_points(st.np));
     __shared__ RayShared rs;
     const double df = 1.0 / (N * (1. / st.fs));
     for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
@@ -3650,14 +3651,15 @@ __global__ void steps_to_points_kernel(int n, const int* __restrict__ n_steps, i
 }
 
 void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, int ask_model,
-                             const double* arz_trace, const double2* tw, double2* spec)
+                             const double* arz_trace, const double2* tw, double2* spec, double* amp_scratch)
 {
     if (n_rays <= 0) return;
     const int nh = st.N / 2;
     int grid = n_rays < 256 * 64 ? n_rays : 256 * 64;
+    if (amp_scratch && grid > RAY_AMP_ROWS) grid = RAY_AMP_ROWS;
     set_big_lds();
-    hipLaunchKernelGGL(general_spectrum_kernel, dim3(grid), dim3(256), (size_t)nplan_points(st.np) * 16 + (size_t)(nh + 1) * 8, s, n_rays, w, st,
-                       ask_model, arz_trace, tw, ilog2(nh), spec);
+    hipLaunchKernelGGL(general_spectrum_kernel, dim3(grid), dim3(256), (size_t)nplan_points(st.np) * 16 + (amp_scratch ? 0 : (size_t)(nh + 1) * 8), s, n_rays, w, st,
+                       ask_model, arz_trace, tw, ilog2(nh), spec, amp_scratch);
 }
 void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double2* tw,
                           double* traces, double* max_efield, const int* active, const double* bound)
@@ -4455,6 +4457,7 @@ void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const 
 void launch_nplan_tables(hipStream_t s, int nh, int log2p, double2* wN, double2* cw, double2* Bf, double2* Bi, const double2* tw)
 {
     set_big_lds();
+    (void)hipFuncSetAttribute((const void*)nplan_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     hipLaunchKernelGGL(nplan_tables_kernel, dim3(1), dim3(1024), (size_t)(1 << log2p) * 16, s, nh, log2p, wN, cw, Bf, Bi, tw);
 }
 void launch_czt_test(hipStream_t s, int n_batch, int n_in, int n_out, int Q, double sgn, const double2* in, double2* out,

@@ -857,7 +857,7 @@ def test_focusing_batched(gpu_ctx_factory):
 
 
 @pytest.mark.parametrize('mode,N', [('birefringence', 512), ('arz', 512), ('arz+birefringence', 512), ('arz+birefringence', 640),
-                                    ('arz+focusing', 512)])
+                                    ('arz+focusing', 512), ('birefringence', 4100)])
 def test_general_path_arz_birefringence(gpu_ctx_factory, mode, N):
     """BASELINE config 4 inside simulate_events: time-domain ARZ2020 emission and / or birefringent propagation.  The GPU
     materialises the on-sky spectra and traces of every kept ray; compared with the oracle's chain (pinned against the
@@ -869,7 +869,8 @@ def test_general_path_arz_birefringence(gpu_ctx_factory, mode, N):
     from test_oracle_golden import _arz_library
     g = golden('chain_N256.npz')
     ice = g['ice']
-    fs = 2.0   # (N = 640: a trace length that is no power of two -- Bluestein transforms in the spectrum / trace / channel kernels)
+    fs = 2.0   # (N = 640: a trace length that is no power of two -- Bluestein transforms in the spectrum / trace / channel kernels;
+    #            N = 4100: the same on 8192 points, the amplitude tables of the kernels in HBM scratch)
     ctx = gpu_ctx_factory(ice, 'SP1')
     pos = g['det_pos']
     st = nuradiomc_amd.Station(ctx, pos, n_samples=N, sampling_rate=fs)
@@ -1141,16 +1142,18 @@ def test_common_traces_beyond_the_single_block_of_the_transforms(gpu_ctx_factory
             st.simulate_events(v, zen, az, en, 'HAD', **opts)
 
 
-def test_traces_of_8192_samples(gpu_ctx_factory):
-    """N = 8192 in the batched path (round 3): the ray stages hold the 4096-point transform, the channel stage is the chirp-z
-    kernel (common traces of > 9400 samples: forward transform in two output blocks, the amplitude table in HBM scratch because
-    128 + 32 KB of LDS do not exist).  GPU vs the oracle: rays, candidate flags, L, traces 1e-6, decisions; production = exhaustive."""
+@pytest.mark.parametrize('N', [8192, 6400, 4098])
+def test_traces_of_more_than_4096_samples(gpu_ctx_factory, N):
+    """N = 8192 and trace lengths between 4096 and 8192 that are no power of two in the batched path (round 3): the ray stages hold
+    the N / 2-point transform (Bluestein on 8192 points for 6400 and 4098: the whole LDS of those kernels, their amplitude tables in
+    HBM scratch), the channel stage is the chirp-z kernel (forward transform in output blocks, the amplitude table in HBM scratch
+    because 128 + 32 KB of LDS do not exist).  GPU vs the oracle: rays, candidate flags, L, traces 1e-6, decisions."""
     import bench
     ice = bench.ICE
     pos = np.array(bench.CHANNELS, float)
     ctx = gpu_ctx_factory(ice, 'SP1')
-    st = nuradiomc_amd.Station(ctx, pos, n_samples=8192, sampling_rate=2.0)
-    ost = so.Station(pos, n_samples=8192, fs=2.0)
+    st = nuradiomc_amd.Station(ctx, pos, n_samples=N, sampling_rate=2.0)
+    ost = so.Station(pos, n_samples=N, fs=2.0)
     vrms, vrms_e = so.vrms_from_filters(2.0)
     assert abs(st.vrms - vrms) <= 1e-12 * vrms
     rng = np.random.default_rng(18)
@@ -1175,7 +1178,7 @@ def test_traces_of_8192_samples(gpu_ctx_factory):
             continue
         n_cand += 1
         n_trig += o['triggered']
-        assert o['L'] == L[e] > 9392
+        assert o['L'] == L[e] > N + 1200
         scale = np.max(np.abs(o['V']))
         for ch in range(5):
             it = pos_of[e] * 5 + ch
