@@ -230,7 +230,7 @@ typedef struct {
     const double* cable_delay;    /* [n_channels]                                                       */
     const int32_t* antenna_model; /* [n_channels]     NRHIP_ANT_*                                       */
     const double* orientation;    /* [n_channels][4]  orientation theta, phi, rotation theta, phi [rad] */
-    int32_t n_samples;            /* N: samples per simulated trace at the internal sampling rate (even) */
+    int32_t n_samples;            /* N: samples per simulated trace at the internal sampling rate: any even number 16 ... 8192, or 10240 / 12288 / 14336 */
     double sampling_rate;         /* internal sampling rate [GHz]                                       */
     double readout_length;        /* longest detector readout window [ns] (n_samples / sampling frequency) */
     double pre_pulse_time;        /* efieldToVoltageConverter.begin(pre_pulse_time = 200 ns)            */

@@ -421,12 +421,14 @@ __device__ inline void czt_convolve(double2* x, int log2m, const double2* __rest
 // order).  x must have room for max(nh, P) complex numbers.
 struct NPlan {
     int nh, log2nh, log2p;   // log2nh >= 0: power of two; else log2p = log2 P
+    int radix = 1, log2m = 0;   // radix > 1 (3, 5, 7): nh = radix * 2^log2m, one radix pass + radix transforms of 2^log2m points --
+                                // for N / 2 above FFT_MAX / 2, where Bluestein's 2 nh - 1 points no longer fit the LDS (N = 10 240)
     const double2* wN;       // [nh + 1] exp(-2 pi i k / N)
     const double2* cw;       // [nh]     exp(-i pi n^2 / nh)
     const double2* Bf;       // [P] spectrum (bit-reversed) of the forward chirp kernel
     const double2* Bi;       // [P] of the inverse one
 };
-__host__ __device__ inline int nplan_points(const NPlan& p) { return p.log2nh >= 0 ? p.nh : (1 << p.log2p); }
+__host__ __device__ inline int nplan_points(const NPlan& p) { return (p.log2nh >= 0 || p.radix > 1) ? p.nh : (1 << p.log2p); }
 // exp(-2 pi i k / N), k <= nh
 __device__ __forceinline__ double2 nplan_w(const NPlan& p, int k, const double2* __restrict__ tw)
 {
@@ -434,12 +436,46 @@ __device__ __forceinline__ double2 nplan_w(const NPlan& p, int k, const double2*
     return p.wN[k];
 }
 // where element j of the transform sits after nplan_fft
-__device__ __forceinline__ int nplan_idx(const NPlan& p, int j) { return p.log2nh >= 0 ? bitrev(j, p.log2nh) : j; }
+__device__ __forceinline__ int nplan_idx(const NPlan& p, int j)
+{
+    if (p.log2nh >= 0) return bitrev(j, p.log2nh);
+    if (p.radix > 1) return (j % p.radix) * (p.nh / p.radix) + bitrev(j / p.radix, p.log2m);   // block k1 = j mod r, bit-reversed inside
+    return j;
+}
 // in-place DFT (inverse: conjugate kernel, unscaled) of x[0 .. nh) given in natural order; ends with a barrier
 __device__ inline void nplan_fft(double2* x, const NPlan& p, const double2* __restrict__ tw, bool inverse)
 {
     if (p.log2nh >= 0) {
         fft_dif(x, p.log2nh, tw, inverse);
+        return;
+    }
+    if (p.radix > 1) {
+        // decimation in frequency by the odd factor r: X[r k2 + k1] = sum_j2 ((sum_j1 x[j2 + m j1] w_r^(j1 k1)) w_nh^(j2 k1)) w_m^(j2 k2).
+        // A thread takes the r inputs of its j2 (stride m), does the r-point DFT and the twiddles and stores y_k1[j2] at k1 m + j2 --
+        // the same r places it read --; then r radix-2 transforms of m points, one per block k1 (bit-reversed inside: nplan_idx)
+        const int r = p.radix, nh = p.nh, m = nh / r;
+        double2 wr[7];
+        for (int q = 0; q < r; q++) {
+            double sn, cs;
+            sincospi(2. * q / r, &sn, &cs);
+            wr[q] = make_double2(cs, inverse ? sn : -sn);   // exp(-+ 2 pi i q / r)
+        }
+        for (int j2 = threadIdx.x; j2 < m; j2 += blockDim.x) {
+            double2 in[7], out[7];
+            for (int j1 = 0; j1 < r; j1++) in[j1] = x[j2 + m * j1];
+            for (int k1 = 0; k1 < r; k1++) {
+                double2 a = in[0];
+                for (int j1 = 1; j1 < r; j1++) a = cadd(a, cmul(in[j1], wr[(j1 * k1) % r]));
+                // w_nh^(j2 k1) = exp(-2 pi i 2 t / N), t = j2 k1 < nh: wN[2 t], or -wN[2 t - nh] beyond the table's half turn
+                const int t2 = 2 * (j2 * k1);
+                double2 w = (t2 <= nh) ? p.wN[t2] : cscale(p.wN[t2 - nh], -1.);
+                if (inverse) w = cconj(w);
+                out[k1] = cmul(a, w);
+            }
+            for (int k1 = 0; k1 < r; k1++) x[k1 * m + j2] = out[k1];
+        }
+        __syncthreads();
+        for (int k1 = 0; k1 < r; k1++) fft_dif(x + k1 * m, p.log2m, tw, inverse);
         return;
     }
     const int P = 1 << p.log2p, nh = p.nh;

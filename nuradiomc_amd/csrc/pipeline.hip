@@ -89,8 +89,13 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
         return nrhip_fail_msg("nrhip_station_create: traces must have an even number of samples");
     // any even length like the reference (NuRadioReco/framework/base_trace.py:117-121); the in-LDS transforms hold 16 .. 8192 samples
     int nh = d->n_samples / 2;
-    if (nh < 8 || nh > FFT_MAX / 2)
-        return nrhip_fail_msg("nrhip_station_create: n_samples must be an even number between 16 and 8192");
+    // above 8192 samples: N / 2 = 3, 5 or 7 times a power of two, at most 7168 (one odd-radix pass + radix-2 transforms in the
+    // 128 KB of LDS; Bluestein would need 16 384 points).  N = 10 240 = 2 * 5 * 1024 is the case the reference's users run
+    int odd = nh, two = 0;
+    while (odd % 2 == 0) { odd /= 2; two++; }
+    const bool big_mixed = nh > FFT_MAX / 2 && nh <= 7 * FFT_MAX / 8 && (odd == 3 || odd == 5 || odd == 7);
+    if (nh < 8 || (nh > FFT_MAX / 2 && !big_mixed))
+        return nrhip_fail_msg("nrhip_station_create: n_samples must be an even number between 16 and 8192 (or 10240, 12288, 14336)");
     // (N / 2 no power of two: Bluestein on the next power of two >= N - 1, at most FFT_MAX points = the whole LDS of the ray kernels,
     // whose amplitude tables then sit in HBM scratch)
     if (d->n_att_freq <= 0 || d->n_att_freq > NRHIP_MAX_NFC) return nrhip_fail_msg("nrhip_station_create: bad n_att_freq");
@@ -261,7 +266,21 @@ int nrhip_station_create(nrhip_ctx* ctx, const nrhip_station_desc* d, nrhip_stat
     v.np.wN = v.np.cw = v.np.Bf = v.np.Bi = nullptr;
     for (int l = 0; l <= FFT_LOG2_MAX; l++)
         if ((1 << l) == nh) v.np.log2nh = l;
-    if (v.np.log2nh < 0) {
+    if (v.np.log2nh < 0 && big_mixed) {
+        v.np.radix = odd;
+        v.np.log2m = two;
+        if (s->d_nplan.reserve(sizeof(double2) * ((size_t)nh + 1)) != hipSuccess) {
+            delete s;
+            return nrhip_fail_msg("nrhip_station_create: out of device memory (transform tables)");
+        }
+        double2* base = s->d_nplan.as<double2>();
+        launch_nplan_tables(ctx->stream, nh, 0, base, nullptr, nullptr, nullptr, ctx->twiddle);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+            delete s;
+            return nrhip_fail_msg("nrhip_station_create: building the transform tables failed");
+        }
+        v.np.wN = base;
+    } else if (v.np.log2nh < 0) {
         while ((1 << v.np.log2p) < 2 * nh - 1) v.np.log2p++;
         const size_t P = (size_t)1 << v.np.log2p;
         if (s->d_nplan.reserve(sizeof(double2) * (2 * P + 2 * (size_t)nh + 2)) != hipSuccess) {

@@ -223,7 +223,7 @@ inline bool channel_amp_in_hbm(int n_samples) { return n_samples / 2 > 2048; }
 // efield_max_kernel / general_spectrum_kernel: N / 2 no power of two and above 2048 -- the Bluestein transform takes FFT_MAX points,
 // 128 KB of LDS; the amplitude tables of at most RAY_AMP_ROWS blocks then sit in HBM scratch
 #define RAY_AMP_ROWS 1024
-inline bool ray_amp_in_hbm(int n_samples) { const int nh = n_samples / 2; return nh > 2048 && (nh & (nh - 1)) != 0; }
+inline bool ray_amp_in_hbm(int n_samples) { const int nh = n_samples / 2; return nh > 2048 && ((nh & (nh - 1)) != 0 || nh > 4096); }
 // trigger ADC + up-sampling of the phased array (pa_digitize_kernel)
 struct PaAdc {
     double adc_fs, vmin, vmax;   // ADC sampling rate [GHz], voltage range

@@ -785,7 +785,7 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, c
     if (threadIdx.x == 0) g_ct_mark[blockIdx.x & 1023] = __builtin_amdgcn_s_memtime();
 #endif
     // the sub-sample shift's phase ramp exp(-2 pi i f rem), f = k fs / N: w^k = w^(k & 63) * (w^64)^(k >> 6)
-    __shared__ double2 s_ramp[64 + FFT_MAX / 2 / 64 + 1];   // N / 2 up to FFT_MAX / 2 bins
+    __shared__ double2 s_ramp[64 + FFT_MAX / 64 + 1];   // N / 2 up to FFT_MAX bins
     const double2* ramp = nullptr;
     if (shift && blockDim.x >= 64 + (unsigned)(nh >> 6) + 1) {
         const int t = threadIdx.x;
@@ -2442,7 +2442,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
 // Fourier shift theorem on the N grid (rfft -> * exp(-2 pi i f rem) -> irfft, base_trace.py:273-276).  Without the shift the
 // packed trace is left in natural order, with it in bit-reversed order and unscaled by 1 / (N / 2).  x: FFT_MAX complex (LDS).
 __device__ inline void trace_to_packed(double2* x, const double* __restrict__ tr, int N, const NPlan& np, double fs, double rem,
-                                       bool shift, const double2* __restrict__ tw)
+                                       bool shift, const double2* __restrict__ tw, double2* __restrict__ gbuf = nullptr)
 {
     const int M = FFT_MAX, nh = N / 2;
     const double res = 1. / fs;
@@ -2450,7 +2450,9 @@ __device__ inline void trace_to_packed(double2* x, const double* __restrict__ tr
     __syncthreads();
     if (!shift) return;
     nplan_fft(x, np, tw, false);     // Y in bit-reversed (power of two) or natural order: nplan_idx
-    double2* G = x + M / 2;          // G'(k), k = 0..nh, in the upper half of the buffer
+    // G'(k), k = 0..nh: in the upper half of the buffer, or -- N / 2 + 1 values no longer fit there (N >= 8192) -- in the caller's
+    // row of HBM scratch
+    double2* G = (nh + 1 <= M / 2) ? x + M / 2 : gbuf;
     for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
         int ka = (k == nh) ? 0 : k, kb = (k == 0 || k == nh) ? 0 : nh - k;
         double2 Y1 = x[nplan_idx(np, ka)], Y2 = cconj(x[nplan_idx(np, kb)]);
@@ -2671,14 +2673,14 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                 if (ray_traces) {
                     // the ray's electric-field trace of this component comes from HBM (time-domain emission models,
                     // birefringence: general_trace_kernel); the on-sky factors are already in it
-                    trace_to_packed(x, ray_traces + ((long)r * 2 + comp) * N, N, st.np, st.fs, rem, shift, tw);
+                    trace_to_packed(x, ray_traces + ((long)r * 2 + comp) * N, N, st.np, st.fs, rem, shift, tw, zbuf);
                     natural = !shift;
                     sc = (shift ? 1.0 / nh : 1.0) * (1.4142135623730951 / st.fs);  // time2freq
                 } else {
                     field_time_domain(x, amp, N, st.np, st.fs, pol, rc, rem, shift, ask_model, floor(2.0 * st.fs), tw);
                 }
                 // gather y_j (bit-reversed positions) -> registers, then lay out a_j = y_j * chirp_j, zero pad
-                double2 yreg[8];
+                double2 yreg[FFT_MAX / 512];   // N / 2 <= 7168 points on 512 threads
                 int cnt = 0;
                 for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = natural ? x[j] : x[nplan_idx(st.np, j)];
                 __syncthreads();
@@ -3109,8 +3111,9 @@ nplan_tables_kernel(int nh, int log2p, double2* __restrict__ wN, double2* __rest
         double sn, cs;
         sincospi(-(double)k / (double)nh, &sn, &cs);   // exp(-2 pi i k / N), N = 2 nh
         wN[k] = make_double2(cs, sn);
-        if (k < nh) cw[k] = chirp(k, nh, -1.);
+        if (cw && k < nh) cw[k] = chirp(k, nh, -1.);
     }
+    if (!cw) return;   // the mixed-radix plan of the longest traces only needs wN
     for (int pass = 0; pass < 2; pass++) {
         czt_build_table(x, log2p, nh, nh, nh, pass ? 1. : -1., tw);
         double2* B = pass ? Bi : Bf;
@@ -3384,6 +3387,7 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)efield_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)general_spectrum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)general_trace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)efield_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (FFT_MAX + 1) * 13);
     (void)hipGetLastError();
     g_attr_set = true;
 }

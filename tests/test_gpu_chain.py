@@ -857,7 +857,7 @@ def test_focusing_batched(gpu_ctx_factory):
 
 
 @pytest.mark.parametrize('mode,N', [('birefringence', 512), ('arz', 512), ('arz+birefringence', 512), ('arz+birefringence', 640),
-                                    ('arz+focusing', 512), ('birefringence', 4100)])
+                                    ('arz+focusing', 512), ('birefringence', 4100), ('birefringence', 8192), ('birefringence', 10240)])
 def test_general_path_arz_birefringence(gpu_ctx_factory, mode, N):
     """BASELINE config 4 inside simulate_events: time-domain ARZ2020 emission and / or birefringent propagation.  The GPU
     materialises the on-sky spectra and traces of every kept ray; compared with the oracle's chain (pinned against the
@@ -870,7 +870,7 @@ def test_general_path_arz_birefringence(gpu_ctx_factory, mode, N):
     g = golden('chain_N256.npz')
     ice = g['ice']
     fs = 2.0   # (N = 640: a trace length that is no power of two -- Bluestein transforms in the spectrum / trace / channel kernels;
-    #            N = 4100: the same on 8192 points, the amplitude tables of the kernels in HBM scratch)
+    #            N = 4100: the same on 8192 points, the amplitude tables of the kernels in HBM scratch; N = 10240: radix 5 x 1024)
     ctx = gpu_ctx_factory(ice, 'SP1')
     pos = g['det_pos']
     st = nuradiomc_amd.Station(ctx, pos, n_samples=N, sampling_rate=fs)
@@ -1142,12 +1142,13 @@ def test_common_traces_beyond_the_single_block_of_the_transforms(gpu_ctx_factory
             st.simulate_events(v, zen, az, en, 'HAD', **opts)
 
 
-@pytest.mark.parametrize('N', [8192, 6400, 4098])
+@pytest.mark.parametrize('N', [8192, 6400, 4098, 10240, 14336])
 def test_traces_of_more_than_4096_samples(gpu_ctx_factory, N):
     """N = 8192 and trace lengths between 4096 and 8192 that are no power of two in the batched path (round 3): the ray stages hold
     the N / 2-point transform (Bluestein on 8192 points for 6400 and 4098: the whole LDS of those kernels, their amplitude tables in
     HBM scratch), the channel stage is the chirp-z kernel (forward transform in output blocks, the amplitude table in HBM scratch
-    because 128 + 32 KB of LDS do not exist).  GPU vs the oracle: rays, candidate flags, L, traces 1e-6, decisions."""
+    because 128 + 32 KB of LDS do not exist).  N = 10 240 and 14 336 (N / 2 = 5 and 7 times 1024): one odd-radix pass + radix-2
+    transforms in LDS (NPlan.radix).  GPU vs the oracle: rays, candidate flags, L, traces 1e-6, decisions."""
     import bench
     ice = bench.ICE
     pos = np.array(bench.CHANNELS, float)
