@@ -95,6 +95,8 @@ if __name__ == '__main__':
         run('N1280', n_events=260, seed=31, N=1280, full_rays=40, full_events=4, rmax=2500., fs=5.0, cable_delay=[0., 3.3, 7.77, 12.2, 19.8])
     if 'N3200' in which:   # an RNO-G read-out (2048 samples at 3.2 GHz) on the 5 GHz simulation grid
         run('N3200', n_events=120, seed=32, N=3200, full_rays=10, full_events=2, rmax=2500., fs=5.0)
+    if 'N10240' in which:   # 2048 ns at 5 GHz: N / 2 = 5 * 1024 (an odd-radix pass in the device's transforms), unequal cable delays
+        run('N10240', n_events=100, seed=34, N=10240, full_rays=4, full_events=1, rmax=2500., fs=5.0, cable_delay=[0., 3.3, 7.77, 12.2, 19.8])
     if 'N256_hpol' in which:  # HPol antennas + unequal cable delays: exercises ePhi, Fresnel r_s and the sub-sample shift
         run('N256_hpol', n_events=150, seed=23, N=256, full_rays=200, full_events=8, antenna='analytic_HPol',
             cable_delay=[0., 3.3, 7.77, 12.2, 19.8], rmax=2500.)

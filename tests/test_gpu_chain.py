@@ -93,7 +93,7 @@ def _run_fixture(gpu_ctx_factory, name, n_events, no_pruning=False, dump_traces=
 
 
 @pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N256_tab', 160),
-                                           ('N4096', 60), ('N256_hw', 220), ('N1280', 260), ('N3200', 60)])
+                                           ('N4096', 60), ('N256_hw', 220), ('N1280', 260), ('N3200', 60), ('N10240', 100)])
 def test_spectral_stages_vs_oracle_on_identical_rays(gpu_ctx_factory, name, n_events):
     """Feed the ORACLE with the ray tables the GPU produced, so that every later stage sees identical
     (C0, D, T, launch, receive) on both sides: kept rays exact, amplitudes / traces to 1e-6."""
@@ -274,7 +274,7 @@ def test_custom_polarization(gpu_ctx_factory):
 
 
 @pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N256_tab', 160),
-                                           ('N4096', 120), ('N256_hw', 220), ('N1280', 260), ('N3200', 120)])
+                                           ('N4096', 120), ('N256_hw', 220), ('N1280', 260), ('N3200', 120), ('N10240', 100)])
 def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
     """End to end (GPU ray tracing included) against the reference's own outputs.  The reference's first ray
     root carries ~1e-7 of iteration noise (see tests/test_oracle_golden.py), which moves arrival times by up to

@@ -65,7 +65,7 @@ def hw_filters(g):
     return {c: chains[str(a)] for c, a in enumerate(g['hw_amp'])}
 
 
-@pytest.mark.parametrize('name', ['N256', 'N256_hpol', 'N256_lpda', 'N256_tab', 'N4096', 'N256_hw', 'N1280', 'N3200'])
+@pytest.mark.parametrize('name', ['N256', 'N256_hpol', 'N256_lpda', 'N256_tab', 'N4096', 'N256_hw', 'N1280', 'N3200', 'N10240'])
 def test_chain_vs_reference(name):
     g = golden('chain_%s.npz' % name)
     st = _station(g)
