@@ -111,5 +111,8 @@ if __name__ == '__main__':
         # 2.5 us of each other (the device path takes common traces of up to 12288 samples)
         run('N256_mb', n_events=260, seed=27, N=256, full_rays=120, full_events=8, rmax=900., ice_model='mooresbay_simple',
             att_model='MB1', n_reflections=1, zmin=-570., zmax=-370., z_top=-5., energy=1e18)
+    if 'N4096_mb' in which:   # the same shelf with the headline's traces (4096 samples at 2 GHz): common traces of ~ 19 000 samples
+        run('N4096_mb', n_events=60, seed=28, N=4096, full_rays=4, full_events=1, rmax=900., ice_model='mooresbay_simple',
+            att_model='MB1', n_reflections=1, zmin=-570., zmax=-370., z_top=-5., energy=1e18)
     if 'N256_focus' in which:  # propagation.focusing on (ray convergence factor from a second trace, limit 2)
         run('N256_focus', n_events=200, seed=25, N=256, full_rays=100, full_events=6, rmax=2500., focusing=True)
