@@ -809,7 +809,6 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need a shower library (nrhip_station_set_arz)");
     if (arz && !cfg->select_only && st->n_shower_profiles != n_events)
         return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need one profile per shower (nrhip_station_set_shower_profiles)");
-    if (general && cfg->amp_per_ray) return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray is not available with ARZ / birefringence");
     if (cfg->n_reflections > 0 && (bire || cfg->focusing))
         return nrhip_fail_msg("nrhip_simulate_events: bottom reflections are not available together with birefringence or focusing");
     const bool phased = cfg->trigger_type == NRHIP_TRIG_PHASED_ARRAY;
@@ -1167,6 +1166,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     }
     MARK(4);
     const double* ray_traces = nullptr;
+    const double2* general_spec = nullptr;   // the rays' on-sky spectra of the general path (amp_per_ray reads them)
     if (general && n_rays > 0) {
         // 4. general path: spectra of all kept rays -> (birefringence) -> traces and their maxima
         const int n_f = sd.N / 2 + 1;
@@ -1251,6 +1251,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         }
         LCHK("general trace");
         ray_traces = traces;
+        general_spec = spec;
     }
     if (!general && n_active > 0) {
         // 4. candidate cut on max |E(t)|
@@ -1424,7 +1425,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             HIPCHK(hipMemsetAsync(max_env, 0xFF, sizeof(double) * nr, sm));
             HIPCHK(hipMemsetAsync(sig_time, 0xFF, sizeof(double) * nr, sm));
             launch_ray_envelope(sm, n_cand, coff + n_ev, d_cand, w, ev, sd, cfg->askaryan_model, ctx->twiddle, tab,
-                                tc.slotmap.as<int>() + sd.N / 2, max_env, sig_time);
+                                tc.slotmap.as<int>() + sd.N / 2, max_env, sig_time, general_spec);
             LCHK("ray_envelope");
         }
         MARK(7);

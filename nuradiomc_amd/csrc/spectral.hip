@@ -2821,7 +2821,7 @@ __global__ void __launch_bounds__(256)
 ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item_event, RayWork w, EventOut ev,
                     StationDev st, int ask_model, const double2* __restrict__ tw, LengthTables tab,
                     const int* __restrict__ len_index_N, int log2n, double* __restrict__ max_env,
-                    double* __restrict__ signal_time)
+                    double* __restrict__ signal_time, const double2* __restrict__ spec)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2;
@@ -2840,7 +2840,11 @@ ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item
         if (threadIdx.x == 0) rs.ask = w.ask[r];
         for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
         __syncthreads();
-        fill_amplitude(amp, st, rs);
+        if (!spec) fill_amplitude(amp, st, rs);
+        // general path (time-domain emission model, birefringence): the ray's on-sky spectra are in HBM, polarisation, Fresnel
+        // coefficients, attenuation and propagation included ([ray][eTheta, ePhi][N / 2 + 1], general_spectrum_kernel)
+        const double2* Et = spec ? spec + (long)r * 2 * (nh + 1) : nullptr;
+        const double2* Ep = spec ? Et + (nh + 1) : nullptr;
         const double2* vel = tab.vel + ((long)il * NRHIP_N_ANT_TAB + w.tab[r]) * NRHIP_SPEC_STRIDE;
         const double2* Hf = tab.H + ((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[w.ch[r]] : 0)) * NRHIP_SPEC_STRIDE;
         const double vt = w.vfac_t[r], vp = w.vfac_p[r], pt = w.pol_theta[r], pp = w.pol_phi[r];
@@ -2849,8 +2853,12 @@ ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item
         auto one_sided = [&](int k) -> double2 {
             double2 v = make_double2(0., 0.);
             if (k > 0 && k < nh) {
-                double2 Gt = field_bin(k, amp[k], N, st.fs, pt, rt, 0., false, ask_model, floor(2.0 * st.fs));
-                double2 Gp = field_bin(k, amp[k], N, st.fs, pp, rp, 0., false, ask_model, floor(2.0 * st.fs));
+                double2 Gt, Gp;
+                if (spec) { Gt = Et[k]; Gp = Ep[k]; }
+                else {
+                    Gt = field_bin(k, amp[k], N, st.fs, pt, rt, 0., false, ask_model, floor(2.0 * st.fs));
+                    Gp = field_bin(k, amp[k], N, st.fs, pp, rp, 0., false, ask_model, floor(2.0 * st.fs));
+                }
                 double2 E = cadd(cscale(Gt, vt), cscale(Gp, vp));
                 v = cscale(cmul(cmul(vel[k], Hf[k]), E), 2. * scale);
             }
@@ -4431,14 +4439,14 @@ void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int 
 
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
-                         const int* len_index_N, double* max_env, double* signal_time)
+                         const int* len_index_N, double* max_env, double* signal_time, const double2* spec)
 {
     if (n_cand_max <= 0) return;
     set_big_lds();
     size_t lds = (size_t)(st.np.log2nh >= 0 ? st.N : nplan_points(st.np)) * 16 + (size_t)(st.N / 2 + 1) * 8;
     int grid = n_cand_max < 256 * 4 ? n_cand_max : 256 * 4;
     hipLaunchKernelGGL(ray_envelope_kernel, dim3(grid), dim3(256), lds, s, n_cand, item_event, w, ev, st, ask_model, tw, tab,
-                       len_index_N, ilog2(st.N), max_env, signal_time);
+                       len_index_N, ilog2(st.N), max_env, signal_time, spec);
 }
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,

@@ -241,6 +241,7 @@ class Station:
                 raise NotImplementedError("antenna model {} is not available (analytic_VPol, analytic_HPol, analytic_LPDA, "
                                           "or a TabulatedAntenna)".format(a))
         model = np.array([ANTENNA_TABLE if isinstance(a, TabulatedAntenna) else ANTENNA_TO_INT[a] for a in names], np.int32)
+        self._tabulated = bool(np.any(model == ANTENNA_TABLE))   # (amp_per_ray is not provided with tabulated patterns)
         ctabs = (AntennaTable * max(len(tables), 1))(*[t._ctypes() for t in tables])
         ori = np.ascontiguousarray(np.broadcast_to(L.f64(orientation), (n, 4)))
         cab = np.ascontiguousarray(np.broadcast_to(L.f64(cable_delay), (n,)))

@@ -949,6 +949,28 @@ def test_general_path_arz_birefringence(gpu_ctx_factory, mode, N):
                 assert np.max(np.abs(tr - o['V'][ch])) <= tol * scale, (ev, ch)
     assert n_rays > 100 and n_cand >= 8 and n_trig >= 2
     assert stats['n_candidate_events'] == n_cand
+    if N <= 4096:
+        # speedup.amp_per_ray_solution (the reference's default) on the general path: per-efield voltages from the rays' spectra in HBM
+        trig_a, _ = st.simulate_events(v, zen, az, en, types, kL, askaryan_model=model, amp_per_ray=True, **kw)
+        env, tsig, rev = st.fetch('ray_max_amp_envelope'), st.fetch('ray_signal_time'), st.fetch('ray_event')
+        assert np.array_equal(trig_a, trig)
+        n_env = 0
+        for ev in range(n):
+            if not T['ev_candidate'][ev]:
+                continue
+            ps = slice(ev * n_ch, (ev + 1) * n_ch)
+            ss = slice(ev * n_ch * 2, (ev + 1) * n_ch * 2)
+            rays = dict(n_sol=T['pair_n_sol'][ps], type=T['slot_type'][ss].reshape(n_ch, 2), C0=T['slot_C0'][ss].reshape(n_ch, 2),
+                        D=T['slot_D'][ss].reshape(n_ch, 2), T=T['slot_T'][ss].reshape(n_ch, 2),
+                        refl_angle=T['slot_refl_angle'][ss].reshape(n_ch, 2),
+                        launch=T['slot_launch'][ev * n_ch * 6:(ev + 1) * n_ch * 6].reshape(n_ch, 2, 3),
+                        receive=T['slot_receive'][ev * n_ch * 6:(ev + 1) * n_ch * 6].reshape(n_ch, 2, 3))
+            o = so.simulate_event(v[ev], zen[ev], az[ev], en[ev], str(types[ev]), float(kL[ev]), ost, ice, vrms, vrms_e, model=model,
+                                  rays=rays, arz=(oarz, int(iN[ev])) if oarz else None, birefringence=bire, **okw)
+            for k, q in zip(np.flatnonzero(rev == ev), o['rays']):
+                assert abs(env[k] - q['max_amp_ray']) <= tol * q['max_amp_ray'] and abs(tsig[k] - q['signal_time']) < 0.5 / fs + 1e-9, (ev, k)
+                n_env += 1
+        assert n_env >= 30
     # production mode (no trace dump) on a larger, weaker sample: with birefringence, events whose rays cannot reach the candidate
     # cut even with the largest possible gain of their paths skip the propagation; decisions are unchanged, the bounds bound
     m = 500
@@ -996,9 +1018,7 @@ def test_general_path_errors_and_empty_inputs(gpu_ctx_factory):
         st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020')
     with pytest.raises(KeyError):   # HAD 1e18 has three profiles in this library
         st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020', arz_iN=np.full(40, 7))
-    for kw in (dict(amp_per_ray=True),):   # (focusing with the ARZ models: test_general_path_arz_birefringence[arz+focusing])
-        with pytest.raises(Exception, match='ARZ'):
-            st.simulate_events(v, z, a, en, 'HAD', askaryan_model='ARZ2020', arz_iN=np.zeros(40, int), **kw)
+    # (focusing and amp_per_ray with the ARZ models: test_general_path_arz_birefringence)
     # high/low and coincidence triggers on the general path: decided on the dumped traces (trace_trigger_kernel)
     v2, z2, a2 = bench.make_events(300, 5)
     v2[:, :2] *= 0.25
