@@ -817,15 +817,12 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (noise && !st->noise_set) return nrhip_fail_msg("nrhip_simulate_events: noise needs the per-channel amplitudes (nrhip_station_set_noise)");
     if (cfg->amp_per_ray && sd.N > FFT_MAX / 2)
         return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray takes traces of at most 4096 samples");
-    if (noise && cfg->amp_per_ray)
-        return nrhip_fail_msg("nrhip_simulate_events: noise is not available together with amp_per_ray");
     if (envelope && !st->env_set)
         return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger needs its band pass (nrhip_station_set_envelope_trigger)");
     if (envelope && (sd.ant_tabs || cfg->amp_per_ray))
         return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger is not available with tabulated antenna patterns or amp_per_ray");
     if (phased && st->pa_n_channels <= 0)
         return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger needs its channels and beams (nrhip_station_set_phased_array)");
-    if (phased && cfg->amp_per_ray) return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger is not available together with amp_per_ray");
     for (auto& e : st->evt) if (!e) HIPCHK(hipEventCreate(&e));
 #define MARK(i) HIPCHK(hipEventRecord(st->evt[i], sm))
     MARK(0);

@@ -674,6 +674,18 @@ def test_amp_per_ray_solution(gpu_ctx_factory, name, n_events):
     print(name, 'envelope maxima of %d rays vs reference: max rel %.2e' % (n_ref, worst_ref))
     assert worst_ref <= 1.5e-3
     assert n_checked >= 30 and n_ref >= 25
+    # the per-efield voltages are properties of the simulated fields: thermal noise and the trigger in use do not change them
+    st.set_noise(300.)
+    st.simulate_events(g['vertex'][sl], g['zenith'][sl], g['azimuth'][sl], g['energy'][sl], g['shower_type'][sl], kL,
+                       askaryan_model=str(g['askaryan_model']), amp_per_ray=True, noise=True, noise_seed=5)
+    assert np.array_equal(st.fetch('ray_max_amp_envelope'), env, equal_nan=True) and np.array_equal(st.fetch('ray_signal_time'), tsig, equal_nan=True)
+    if len(g['det_pos']) >= 4 and np.allclose(g['det_pos'][:4, :2], g['det_pos'][0, :2]):
+        ang = np.arcsin(np.linspace(-0.8, 0.8, 5))
+        st.set_phased_array([0, 1, 2, 3], ang, window=16, step=8)
+        st.simulate_events(g['vertex'][sl], g['zenith'][sl], g['azimuth'][sl], g['energy'][sl], g['shower_type'][sl], kL,
+                           askaryan_model=str(g['askaryan_model']), amp_per_ray=True, trigger='phased_array',
+                           trigger_threshold=2.0 * (2 * st.vrms) ** 2)
+        assert np.array_equal(st.fetch('ray_max_amp_envelope'), env, equal_nan=True)
 
 
 def test_filter_kinds(gpu_ctx_factory):
