@@ -819,8 +819,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray takes traces of at most 4096 samples");
     if (envelope && !st->env_set)
         return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger needs its band pass (nrhip_station_set_envelope_trigger)");
-    if (envelope && (sd.ant_tabs || cfg->amp_per_ray))
-        return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger is not available with tabulated antenna patterns or amp_per_ray");
+    if (envelope && sd.ant_tabs)
+        return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger is not available with tabulated antenna patterns");
     if (phased && st->pa_n_channels <= 0)
         return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger needs its channels and beams (nrhip_station_set_phased_array)");
     for (auto& e : st->evt) if (!e) HIPCHK(hipEventCreate(&e));
@@ -1290,8 +1290,6 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     HIPCHK(hipMemsetAsync(lflag, 0, sizeof(int) * (n_half + 1), sm));
     HIPCHK(hipMemsetAsync(d_ncr, 0, 2 * sizeof(long long), sm));
     launch_candidate_flags(sm, (int)n_ev, n_half, ev, cflag, lflag, d_ncr);
-    if (cfg->amp_per_ray && sd.ant_tabs)
-        return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray is not available with tabulated antenna patterns");
     if (cfg->amp_per_ray)  // the per-efield voltages live on the N grid: tables of "L = N" are built with the others
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(lflag + sd.N / 2), 1, 1, sm));
     launch_exclusive_scan(sm, n_ev + 1, cflag, coff, ctmp);
@@ -1421,8 +1419,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             NEED(sig_time = WS("ray_signal_time", double, nr));
             HIPCHK(hipMemsetAsync(max_env, 0xFF, sizeof(double) * nr, sm));
             HIPCHK(hipMemsetAsync(sig_time, 0xFF, sizeof(double) * nr, sm));
+            double2* env_nodes = nullptr;   // tabulated patterns: the angular interpolation at the table's frequency nodes, per block
+            if (sd.ant_tabs) NEED(env_nodes = WS("antenna_table_nodes", double2, (size_t)channel_grid_blocks() * 2 * sd.max_tab_freq));
             launch_ray_envelope(sm, n_cand, coff + n_ev, d_cand, w, ev, sd, cfg->askaryan_model, ctx->twiddle, tab,
-                                tc.slotmap.as<int>() + sd.N / 2, max_env, sig_time, general_spec);
+                                tc.slotmap.as<int>() + sd.N / 2, max_env, sig_time, general_spec, env_nodes);
             LCHK("ray_envelope");
         }
         MARK(7);

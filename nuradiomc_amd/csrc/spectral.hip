@@ -2821,11 +2821,12 @@ __global__ void __launch_bounds__(256)
 ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item_event, RayWork w, EventOut ev,
                     StationDev st, int ask_model, const double2* __restrict__ tw, LengthTables tab,
                     const int* __restrict__ len_index_N, int log2n, double* __restrict__ max_env,
-                    double* __restrict__ signal_time, const double2* __restrict__ spec)
+                    double* __restrict__ signal_time, const double2* __restrict__ spec, double2* __restrict__ tab_nodes)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2;
     double2* x = (double2*)smem;
+    double2* nodes = tab_nodes ? tab_nodes + (long)blockIdx.x * 2 * st.max_tab_freq : nullptr;
     const bool pow2 = st.np.log2nh >= 0;
     double* amp = (double*)(x + (pow2 ? N : nplan_points(st.np)));
     __shared__ RayShared rs;
@@ -2850,6 +2851,19 @@ ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item
         const double vt = w.vfac_t[r], vp = w.vfac_p[r], pt = w.pol_theta[r], pp = w.pol_phi[r];
         const double2 rt = w.r_theta[r], rp = w.r_phi[r];
         const double scale = st.fs / 1.4142135623730951 / N;  // freq2time
+        // tabulated antenna pattern of the ray's channel: the angular interpolation once per frequency node of the table (as
+        // channel_kernel does), the frequency interpolation per bin; rotated to the on-sky basis by the ray's T
+        const bool tabulated = nodes && st.ant_model[w.ch[r]] == 3;
+        const AntTabDev* at = tabulated ? &st.ant_tabs[st.ant_tab_index[w.ch[r]]] : nullptr;
+        const double* TT = w.vel_T + 4 * (long)r;
+        bool tab_ok = false;
+        if (tabulated) {
+            const TabAngles ta = tab_angles(*at, w.theta_ant[r], w.phi_ant[r]);
+            tab_ok = ta.ok;
+            if (ta.ok)
+                for (int iF = threadIdx.x; iF < at->nF; iF += blockDim.x) tab_node(*at, ta, iF, &nodes[iF], &nodes[at->nF + iF]);
+            __syncthreads();
+        }
         auto one_sided = [&](int k) -> double2 {
             double2 v = make_double2(0., 0.);
             if (k > 0 && k < nh) {
@@ -2859,8 +2873,16 @@ ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item
                     Gt = field_bin(k, amp[k], N, st.fs, pt, rt, 0., false, ask_model, floor(2.0 * st.fs));
                     Gp = field_bin(k, amp[k], N, st.fs, pp, rp, 0., false, ask_model, floor(2.0 * st.fs));
                 }
-                double2 E = cadd(cscale(Gt, vt), cscale(Gp, vp));
-                v = cscale(cmul(cmul(vel[k], Hf[k]), E), 2. * scale);
+                if (tabulated) {
+                    const double f = k * (1.0 / (N * (1. / st.fs)));
+                    double2 at_t = make_double2(0., 0.), at_p = at_t;
+                    if (tab_ok && !(f < 0.005)) tab_response(*at, nodes, f, &at_t, &at_p);   // 5 MHz cut (efieldToVoltageConverterPerEfield.py)
+                    const double2 ct = cadd(cscale(at_t, TT[0]), cscale(at_p, TT[1])), cp = cadd(cscale(at_t, TT[2]), cscale(at_p, TT[3]));
+                    v = cscale(cmul(Hf[k], cadd(cmul(ct, Gt), cmul(cp, Gp))), 2. * scale);
+                } else {
+                    double2 E = cadd(cscale(Gt, vt), cscale(Gp, vp));
+                    v = cscale(cmul(cmul(vel[k], Hf[k]), E), 2. * scale);
+                }
             }
             return v;
         };
@@ -4439,14 +4461,15 @@ void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int 
 
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
-                         const int* len_index_N, double* max_env, double* signal_time, const double2* spec)
+                         const int* len_index_N, double* max_env, double* signal_time, const double2* spec, double2* tab_nodes)
 {
     if (n_cand_max <= 0) return;
     set_big_lds();
     size_t lds = (size_t)(st.np.log2nh >= 0 ? st.N : nplan_points(st.np)) * 16 + (size_t)(st.N / 2 + 1) * 8;
     int grid = n_cand_max < 256 * 4 ? n_cand_max : 256 * 4;
+    if (tab_nodes && grid > channel_grid_blocks()) grid = channel_grid_blocks();   // (rows of the node scratch)
     hipLaunchKernelGGL(ray_envelope_kernel, dim3(grid), dim3(256), lds, s, n_cand, item_event, w, ev, st, ask_model, tw, tab,
-                       len_index_N, ilog2(st.N), max_env, signal_time, spec);
+                       len_index_N, ilog2(st.N), max_env, signal_time, spec, tab_nodes);
 }
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,

@@ -637,7 +637,7 @@ def test_trigger_modes(gpu_ctx_factory, kw):
 
 
 @pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N4096', 60), ('N256_hw', 220),
-                                           ('N1280', 260)])
+                                           ('N1280', 260), ('N256_tab', 160)])
 def test_amp_per_ray_solution(gpu_ctx_factory, name, n_events):
     """speedup.amp_per_ray_solution: per-efield voltage on the N grid, Hilbert-envelope maximum and its time for every
     ray of the candidate events -- vs the oracle on the same rays (1e-6) and vs the reference's own values (5e-3: they
@@ -653,7 +653,7 @@ def test_amp_per_ray_solution(gpu_ctx_factory, name, n_events):
     rev, rch, rsol = st.fetch('ray_event'), st.fetch('ray_channel'), st.fetch('ray_solution')
     cand = st.fetch('ev_candidate').astype(bool)
     assert np.all(np.isnan(env[~cand[rev]])) and not np.any(np.isnan(env[cand[rev]]))
-    ost = so.Station(g['det_pos'], antenna=str(g['antenna']), orientation=g['det_orientation'], cable_delay=g['cable_delay'],
+    ost = so.Station(g['det_pos'], antenna=_oracle_antenna(g), orientation=tuple(g['det_orientation']), cable_delay=g['cable_delay'],
                      n_samples=int(g['N']), fs=float(g['fs']))
     vrms, vrms_e = st.vrms, st.vrms_efield
     n_checked = n_ref = 0
