@@ -815,8 +815,6 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     const bool envelope = cfg->trigger_type == NRHIP_TRIG_ENVELOPE;
     const bool noise = cfg->noise != 0;
     if (noise && !st->noise_set) return nrhip_fail_msg("nrhip_simulate_events: noise needs the per-channel amplitudes (nrhip_station_set_noise)");
-    if (cfg->amp_per_ray && sd.N > FFT_MAX / 2)
-        return nrhip_fail_msg("nrhip_simulate_events: amp_per_ray takes traces of at most 4096 samples");
     if (envelope && !st->env_set)
         return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger needs its band pass (nrhip_station_set_envelope_trigger)");
     if (envelope && sd.ant_tabs)
@@ -1419,10 +1417,12 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             NEED(sig_time = WS("ray_signal_time", double, nr));
             HIPCHK(hipMemsetAsync(max_env, 0xFF, sizeof(double) * nr, sm));
             HIPCHK(hipMemsetAsync(sig_time, 0xFF, sizeof(double) * nr, sm));
+            double* env_amp = nullptr;      // N > 4096: the kernel's amplitude table in HBM scratch
+            if (sd.N > FFT_MAX / 2) NEED(env_amp = WS("ray_amp_scratch", double, (size_t)RAY_AMP_ROWS * (sd.N / 2 + 1)));
             double2* env_nodes = nullptr;   // tabulated patterns: the angular interpolation at the table's frequency nodes, per block
             if (sd.ant_tabs) NEED(env_nodes = WS("antenna_table_nodes", double2, (size_t)channel_grid_blocks() * 2 * sd.max_tab_freq));
             launch_ray_envelope(sm, n_cand, coff + n_ev, d_cand, w, ev, sd, cfg->askaryan_model, ctx->twiddle, tab,
-                                tc.slotmap.as<int>() + sd.N / 2, max_env, sig_time, general_spec, env_nodes);
+                                tc.slotmap.as<int>() + sd.N / 2, max_env, sig_time, general_spec, env_nodes, env_amp);
             LCHK("ray_envelope");
         }
         MARK(7);

@@ -257,7 +257,7 @@ void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int 
                           unsigned char* triggered, int* trigger_bin);
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
-                         const int* len_index_N, double* max_env, double* signal_time, const double2* spec = nullptr, double2* tab_nodes = nullptr);
+                         const int* len_index_N, double* max_env, double* signal_time, const double2* spec = nullptr, double2* tab_nodes = nullptr, double* amp_scratch = nullptr);
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,
                            const double2* tw, const LengthTables& tab, double2* scratch, double* V, double2* tab_nodes);

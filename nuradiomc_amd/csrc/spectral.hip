@@ -2821,14 +2821,16 @@ __global__ void __launch_bounds__(256)
 ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item_event, RayWork w, EventOut ev,
                     StationDev st, int ask_model, const double2* __restrict__ tw, LengthTables tab,
                     const int* __restrict__ len_index_N, int log2n, double* __restrict__ max_env,
-                    double* __restrict__ signal_time, const double2* __restrict__ spec, double2* __restrict__ tab_nodes)
+                    double* __restrict__ signal_time, const double2* __restrict__ spec, double2* __restrict__ tab_nodes,
+                    double* __restrict__ amp_scratch)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2;
     double2* x = (double2*)smem;
     double2* nodes = tab_nodes ? tab_nodes + (long)blockIdx.x * 2 * st.max_tab_freq : nullptr;
     const bool pow2 = st.np.log2nh >= 0;
-    double* amp = (double*)(x + (pow2 ? N : nplan_points(st.np)));
+    // (N > 4096: the N-point buffer -- or Bluestein's 8192 points -- takes the LDS, the amplitude table a row of HBM scratch)
+    double* amp = amp_scratch ? amp_scratch + (long)blockIdx.x * (nh + 1) : (double*)(x + (pow2 ? N : nplan_points(st.np)));
     __shared__ RayShared rs;
     __shared__ double red[256];
     __shared__ int red_i[256];
@@ -2909,7 +2911,7 @@ ray_envelope_kernel(const int* __restrict__ n_cand, const int* __restrict__ item
                 __syncthreads();
                 nplan_fft(x, st.np, tw, true);
                 for (int j = threadIdx.x; j < nh; j += blockDim.x) {
-                    const double a = cabs2(x[j]);
+                    const double a = cabs2(x[nplan_idx(st.np, j)]);   // (natural order after Bluestein, block-permuted after the odd-radix plan)
                     const int n = 2 * j + par;
                     if (a > mx || (a == mx && n < imx)) { mx = a; imx = n; }
                 }
@@ -3408,8 +3410,7 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_PADDED_MAX * 16);
     (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX - 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               fft_pad_host(FFT_MAX / 2) * 16);
-    (void)hipFuncSetAttribute((const void*)ray_envelope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (FFT_MAX / 2) * 16 + (FFT_MAX / 4 + 1) * 8);
+    (void)hipFuncSetAttribute((const void*)ray_envelope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)efield_channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     // trace lengths that are no power of two: Bluestein on up to FFT_MAX / 2 points inside the ray kernels
@@ -4461,15 +4462,17 @@ void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int 
 
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
-                         const int* len_index_N, double* max_env, double* signal_time, const double2* spec, double2* tab_nodes)
+                         const int* len_index_N, double* max_env, double* signal_time, const double2* spec, double2* tab_nodes,
+                         double* amp_scratch)
 {
     if (n_cand_max <= 0) return;
     set_big_lds();
-    size_t lds = (size_t)(st.np.log2nh >= 0 ? st.N : nplan_points(st.np)) * 16 + (size_t)(st.N / 2 + 1) * 8;
+    size_t lds = (size_t)(st.np.log2nh >= 0 ? st.N : nplan_points(st.np)) * 16 + (amp_scratch ? 0 : (size_t)(st.N / 2 + 1) * 8);
     int grid = n_cand_max < 256 * 4 ? n_cand_max : 256 * 4;
+    if (amp_scratch && grid > RAY_AMP_ROWS) grid = RAY_AMP_ROWS;
     if (tab_nodes && grid > channel_grid_blocks()) grid = channel_grid_blocks();   // (rows of the node scratch)
     hipLaunchKernelGGL(ray_envelope_kernel, dim3(grid), dim3(256), lds, s, n_cand, item_event, w, ev, st, ask_model, tw, tab,
-                       len_index_N, ilog2(st.N), max_env, signal_time, spec, tab_nodes);
+                       len_index_N, ilog2(st.N), max_env, signal_time, spec, tab_nodes, amp_scratch);
 }
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,

@@ -197,7 +197,7 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
             T['groups'] = idx
             tables[i].append(T)
         kw2 = dict(vertex_time=d['vertex_times'][rows][sub], group_id=sub_gid, **sim_kw)
-        can_amp = st.n_samples <= 4096   # (the general path and tabulated antenna patterns provide the per-ray envelopes since round 3)
+        can_amp = True   # (every path provides the per-ray envelopes since round 3)
         arr.simulate_events(vertex[rows][sub], d['zeniths'][rows][sub], d['azimuths'][rows][sub], d['shower_energies'][rows][sub],
                             types[rows][sub], np.where(np.isnan(kL[sub]), 1.0, kL[sub]), dump_traces=True, amp_per_ray=can_amp,
                             on_station=collect, max_showers_per_call=len(sub) + 1, **kw2)

@@ -1217,10 +1217,18 @@ def test_traces_of_more_than_4096_samples(gpu_ctx_factory, N):
             it = pos_of[e] * 5 + ch
             assert np.max(np.abs(tr[off[it]:off[it + 1]] - o['V'][ch])) <= 1e-6 * scale, (e, ch)
     assert n_cand >= 10 and n_trig >= 3
-    trig_p, _ = st.simulate_events(v, zen, az, en, 'HAD')
+    trig_p, _ = st.simulate_events(v, zen, az, en, 'HAD', amp_per_ray=True)
     assert np.array_equal(trig_p, trig)
-    with pytest.raises(Exception, match='4096'):
-        st.simulate_events(v, zen, az, en, 'HAD', amp_per_ray=True)
+    # per-efield voltages (amp_per_ray) on these grids: the N-point analytic signal (two N / 2-point transforms where N / 2 is no
+    # power of two), the kernel's amplitude table in HBM scratch
+    env, tsig = st.fetch('ray_max_amp_envelope'), st.fetch('ray_signal_time')
+    n_env = 0
+    for e in np.flatnonzero(cand):
+        o = so.simulate_event(v[e], zen[e], az[e], en[e], 'HAD', None, ost, ice, vrms, vrms_e)
+        for k, q in zip(np.flatnonzero(rev == e), o['rays']):
+            assert abs(env[k] - q['max_amp_ray']) <= 1e-6 * q['max_amp_ray'] and abs(tsig[k] - q['signal_time']) < 1e-6, (e, k)
+            n_env += 1
+    assert n_env >= 20
 
 
 @pytest.mark.parametrize('mode', ['arz', 'phased_array'])
