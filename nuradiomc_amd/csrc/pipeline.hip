@@ -817,8 +817,6 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (noise && !st->noise_set) return nrhip_fail_msg("nrhip_simulate_events: noise needs the per-channel amplitudes (nrhip_station_set_noise)");
     if (envelope && !st->env_set)
         return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger needs its band pass (nrhip_station_set_envelope_trigger)");
-    if (envelope && sd.ant_tabs)
-        return nrhip_fail_msg("nrhip_simulate_events: the envelope trigger is not available with tabulated antenna patterns");
     if (phased && st->pa_n_channels <= 0)
         return nrhip_fail_msg("nrhip_simulate_events: the phased-array trigger needs its channels and beams (nrhip_station_set_phased_array)");
     for (auto& e : st->evt) if (!e) HIPCHK(hipEventCreate(&e));

@@ -1765,6 +1765,27 @@ def test_envelope_trigger(gpu_ctx_factory):
     st.set_envelope_trigger(None)
     with pytest.raises(Exception, match='envelope'):
         st.simulate_events(*args, trigger='envelope')
+    # with tabulated antenna patterns (the chirp-z channel kernel forms the envelopes of whatever spectrum it summed)
+    g2 = golden('chain_N256_tab.npz')
+    st2 = _station(gpu_ctx_factory(g2['ice'], str(g2['att_model'])), g2)
+    n2 = 160
+    kL2 = np.where(np.isnan(g2['ev_k_L'][:n2]), 1.0, g2['ev_k_L'][:n2])
+    args2 = (g2['vertex'][:n2], g2['zenith'][:n2], g2['azimuth'][:n2], g2['energy'][:n2], g2['shower_type'][:n2], kL2)
+    pb, order = g['s0_passband'], int(g['s0_order'])
+    st2.set_envelope_trigger(pb, order)
+    opts = dict(trigger='envelope', trigger_threshold=2.0 * st2.vrms, n_coincidences=2, coinc_window=float(g['s0_coinc_window']))
+    okw = dict(trigger='envelope', threshold=opts['trigger_threshold'], n_coincidences=2, coinc_window=opts['coinc_window'], passband=pb,
+               order=order)
+    trig2, stats2 = st2.simulate_events(*args2, dump_traces=True, **opts)
+    _check_trace_triggers(st2, trig2, okw, n2)
+    item_event, tr, env, off = st2.fetch('item_event'), st2.fetch('trace'), st2.fetch('envelope_trace'), st2.fetch('trace_offset')
+    n_ch2 = len(g2['det_pos'])
+    for k in range(0, len(item_event) * n_ch2, 5):
+        ref = so.envelope_of_filtered(tr[off[k]:off[k + 1]], st2.sampling_rate, pb, order)
+        assert np.max(np.abs(env[off[k]:off[k + 1]] - ref)) <= 1e-9 * max(np.max(ref), 1e-30), k
+    assert len(item_event) >= 10
+    trig2_p, _ = st2.simulate_events(*args2, **opts)
+    assert np.array_equal(trig2_p, trig2)
 
 
 def test_thermal_noise(gpu_ctx_factory):
