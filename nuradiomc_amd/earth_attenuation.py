@@ -4,8 +4,9 @@ lists at once (nrhip_earth_weights_batch).  simulation.py:880-903 calls get_weig
 here the same arguments may be arrays of n events and the scalars of the reference are the n = 1 case.
 
 cross_section_type 'ctw' (the reference's config_default.yaml) and 'ghandi' are evaluated on the device; the tabulated
-'csms' goes through nuradiomc_amd/cross_sections.py (the published table) and, like any values the caller computed itself
-(`cross_section=`: 'hedis_bgr18' from its data file), reaches the device as per-event cross sections (NRHIP_XS_GIVEN).
+'csms' (the published table) and 'hedis_bgr18' (the reference's data file, named by cross_sections.set_bgr18_file / NRHIP_BGR18_FILE)
+go through nuradiomc_amd/cross_sections.py and, like any values the caller computed itself (`cross_section=`), reach the device as
+per-event cross sections (NRHIP_XS_GIVEN).
 """
 import numpy as np
 from .context import Context

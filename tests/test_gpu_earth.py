@@ -68,14 +68,39 @@ def test_given_cross_sections(ctx):
         assert 0.2 < np.median(np.log(w[big & (wc > 1e-100) & (w < 0.99)]) / np.log(wc[big & (wc > 1e-100) & (w < 0.99)])) < 5   # same physics, another table
 
 
+def test_hedis_cross_sections_from_a_data_file(ctx):
+    """cross_section_type='hedis_bgr18' end to end: the table file (here the synthetic one of tests/golden, whose reference values
+    test_oracle_golden checks) -> host integration / interpolation -> NRHIP_XS_GIVEN -> weights, against the oracle fed with the
+    reference's own cross sections of the same events; mode 'simple' asks for flavor 0, which the file does not hold (the reference
+    fails there too)."""
+    import os
+    from nuradiomc_amd import earth_attenuation as ea, cross_sections as xs
+    from oracle import earth_oracle as eo
+    g = golden('ref_earth_weights.npz')
+    xs.set_bgr18_file(os.path.join(os.path.dirname(__file__), 'golden', 'bgr18_synthetic.npz'))
+    try:
+        sigma = xs.get_nu_cross_section(g['energy'], g['flavor'], 'total', 'hedis_bgr18')
+        for mode in ('core_mantle_crust_simple', 'core_mantle_crust', 'PREM'):
+            w = ea.get_weight(g['zenith'], g['energy'], g['flavor'], mode=mode, vertex_position=g['vertex'], phi_nu=g['azimuth'],
+                              ctx=ctx, cross_section_type='hedis_bgr18')
+            wo = eo.get_weight(g['zenith'], g['azimuth'], sigma, g['flavor'], g['vertex'], mode, cross_section_type='given')
+            big = wo > 1e-100
+            assert big.sum() > len(w) // 4 and max_rel(w[big], wo[big]) < 1e-6 and np.max(np.abs(w - wo)) < 1e-9, mode
+        with pytest.raises(ValueError):
+            ea.get_weight(g['zenith'], g['energy'], g['flavor'], mode='simple', ctx=ctx, cross_section_type='hedis_bgr18')
+    finally:
+        xs.set_bgr18_file(None)
+
+
 def test_errors_and_edges(ctx):
     from nuradiomc_amd import earth_attenuation as ea
     import nuradiomc_amd as nr
     assert ea.get_weight(2., 1e18, 12, mode='None') == 1.
     with pytest.raises(NotImplementedError):
         ea.get_weight(2., 1e18, 12, mode='two_layers', ctx=ctx)
-    with pytest.raises(NotImplementedError):
-        ea.get_weight(2., 1e18, 12, mode='simple', cross_section_type='hedis_bgr18', ctx=ctx)   # a download of the reference
+    with pytest.raises(FileNotFoundError):
+        ea.get_weight(2., 1e18, 12, mode='PREM', cross_section_type='hedis_bgr18', vertex_position=np.zeros(3), phi_nu=0.,
+                      ctx=ctx)                                                              # a download of the reference: no file here
     # 'csms' has no rows for inttype='total' (what get_interaction_length asks for): cross section 0, weight 1 -- as the reference
     assert ea.get_weight(np.full(3, 2.), np.full(3, 1e18), np.full(3, 12), mode='simple', cross_section_type='csms', ctx=ctx).tolist() == [1., 1., 1.]
     assert len(ea.get_weight(np.zeros(0), np.zeros(0), np.zeros(0, int), mode='simple', ctx=ctx)) == 0

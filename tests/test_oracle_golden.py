@@ -9,6 +9,7 @@ Tolerances are the reference's own cross-implementation tolerances:
     implementation can promise; we observe <= 1e-7.
   * attenuation: the QUADPACK restatement reproduces scipy.integrate.quad decisions; 1e-9.
 """
+import os
 import numpy as np
 import pytest
 from conftest import golden, max_rel
@@ -476,3 +477,39 @@ def test_csms_cross_section_table():
     assert not g['sigma_total'].any()
     with pytest.raises(ValueError):
         xs.csms(np.array([1e9]), 'cc', 12)
+
+
+def test_hedis_bgr18_cross_section(monkeypatch, tmp_path):
+    """nuradiomc_amd/cross_sections.py 'hedis_bgr18' (power-law integration over y, nc + cc, log-linear interpolation in the energy)
+    against the reference run on a synthetic table of the data file's layout (tests/golden/bgr18_synthetic.npz -> ref_hedis.npz,
+    generator tests/golden/gen/gen_hedis.py; the real file is a download and is not here).  Rounding-level agreement; the error
+    cases of the reference (above the table, a flavor the file does not hold, no file) raise."""
+    from nuradiomc_amd import cross_sections as xs
+    g = golden('ref_hedis.npz')
+    t = golden('bgr18_synthetic.npz')
+    d, y = t['dsigma_dy_ref'], t['y_ref']
+    assert np.max(np.abs(xs.integrate_power_law(d * 1e-4 / 18, y, low=0, high=1) / g['full'] - 1)) < 1e-12
+    assert np.max(np.abs(xs.integrate_power_law(d, y) / g['inner'] - 1)) < 1e-12
+    assert np.max(np.abs(xs.integrate_power_law(d[0, 0], y, low=1e-7, high=0.99) / g['part'] - 1)) < 1e-12
+    assert np.max(np.abs(xs.integrate_power_law(g['rows'], g['x2']) / g['rows_int'] - 1)) < 1e-13
+    # slope -1 (the reference's closed form is 0/0 there): the logarithm
+    x = np.linspace(1., 3., 9)
+    assert abs(xs.integrate_power_law(1. / x, x) - np.log(3.)) < 1e-14
+    with pytest.raises(ValueError):
+        xs.integrate_power_law(x ** -1.5, x, low=0)
+
+    monkeypatch.delenv('NRHIP_BGR18_FILE', raising=False)
+    xs.set_bgr18_file(str(tmp_path / 'absent.npz'))
+    with pytest.raises(FileNotFoundError):
+        xs.get_nu_cross_section(1e18, 12, 'total', 'hedis_bgr18')
+    xs.set_bgr18_file(os.path.join(os.path.dirname(__file__), 'golden', 'bgr18_synthetic.npz'))
+    try:
+        got = xs.get_nu_cross_section(g['energy'], g['flavor'], g['inttype'], 'hedis_bgr18')
+        assert np.max(np.abs(got / g['sigma'] - 1)) < 1e-12
+        assert abs(xs.get_nu_cross_section(3e17, 14, 'total', 'hedis_bgr18') / float(g['sigma_scalar']) - 1) < 1e-12
+        with pytest.raises(ValueError):
+            xs.get_nu_cross_section(np.array([2e21]), 12, 'cc', 'hedis_bgr18')
+        with pytest.raises(ValueError):
+            xs.get_nu_cross_section(np.array([1e18]), 0, 'total', 'hedis_bgr18')
+    finally:
+        xs.set_bgr18_file(None)
