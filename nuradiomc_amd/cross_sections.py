@@ -59,10 +59,10 @@ def csms(energy, inttype, flavors):
     return out
 
 
-def integrate_power_law(y, x, low=None, high=None):
+def integrate_power_law(y, x, low=None, high=None, cumulative=False):
     """Integral over the last axis of y(x) taken as A_i x^b_i between neighbouring nodes (the reference's integrate_pwpl,
-    cross_sections.py:424-537, without full_output): per interval y_i x_i (r^(b+1) - 1) / (b + 1) with r = x_{i+1} / x_i and
-    b = ln(y_{i+1} / y_i) / ln r; intervals with a zero at either end contribute nothing; `low` / `high` extend the first / last
+    cross_sections.py:424-537; cumulative=True is its full_output: (total, (running integral from the lower limit, its nodes))):
+    per interval y_i x_i (r^(b+1) - 1) / (b + 1) with r = x_{i+1} / x_i and b = ln(y_{i+1} / y_i) / ln r; intervals with a zero at either end contribute nothing; `low` / `high` extend the first / last
     interval's power law beyond the nodes (low = 0 needs b > -1 there, else ValueError as in the reference)."""
     y = np.asarray(y, float)
     x = np.asarray(x, float)
@@ -79,7 +79,7 @@ def integrate_power_law(y, x, low=None, high=None):
         small = np.abs(t) < 1e-12
         return ya * xa * np.where(small, lnr, np.expm1(t) / np.where(small, 1., e))
 
-    total = np.sum(np.where(dead, 0., piece(y0, x0, lr, b1)), axis=-1)
+    parts = np.where(dead, 0., piece(y0, x0, lr, b1))
     if low is not None:
         if low < 0:
             raise ValueError("Cannot use power-law integration for negative values.")
@@ -90,10 +90,16 @@ def integrate_power_law(y, x, low=None, high=None):
             ext = y[..., 0] * x[0] / e
         else:
             ext = -piece(y[..., 0], x[0], np.log(low / x[0]), e)
-        total = total + np.where(dead[..., 0], 0., ext)
+        parts = np.concatenate([np.where(dead[..., 0], 0., ext)[..., None], parts], axis=-1)
+        x = np.concatenate([[low], x])
     if high is not None:
         ext = piece(y[..., -1], x[-1], np.log(high / x[-1]), b1[..., -1])
-        total = total + np.where(dead[..., -1], 0., ext)
+        parts = np.concatenate([parts, np.where(dead[..., -1], 0., ext)[..., None]], axis=-1)
+        x = np.concatenate([x, [high]])
+    total = np.sum(parts, axis=-1)
+    if cumulative:
+        run = np.cumsum(parts, axis=-1)
+        return total, (np.concatenate([np.zeros(run.shape[:-1] + (1,)), run], axis=-1), x)
     return total
 
 
@@ -116,19 +122,32 @@ def _bgr18_table():
                                     "cross_sections.set_bgr18_file() or NRHIP_BGR18_FILE, or pass cross_section=".format(path))
         d = np.load(path)
         # per nucleon: the file holds cm^2 per H2O molecule, 18 nucleons (:28-31)
-        sig = integrate_power_law(d['dsigma_dy_ref'] * (1e-4 / 18.), d['y_ref'], low=0, high=1)   # [flavor, nc/cc, energy]
+        dsdy, yy = d['dsigma_dy_ref'] * (1e-4 / 18.), np.asarray(d['y_ref'], float)
+        sig, (run, y_ext) = integrate_power_law(dsdy, yy, low=0, high=1, cumulative=True)          # [flavor, nc/cc, energy(, y)]
         kinds = [str(k).lower() for k in d['ncccs_ref']] + ['total']
-        sig = np.concatenate([sig, sig[:, :1] + sig[:, 1:2]], axis=1)
         _bgr18_cache.clear()
-        _bgr18_cache[path] = (np.asarray(d['nu_energies_ref'], float), np.asarray(d['flavors_ref']), kinds, sig)
+        _bgr18_cache[path] = dict(energy=np.asarray(d['nu_energies_ref'], float), flavors=np.asarray(d['flavors_ref']), kinds=kinds,
+                                  sigma=np.concatenate([sig, sig[:, :1] + sig[:, 1:2]], axis=1),
+                                  cdf=run / sig[..., None], y=y_ext)
     return _bgr18_cache[path]
+
+
+def bgr18_inelasticity_cdf(flavor, nccc, i_energy):
+    """(cdf, y) of the inelasticity at energy node i_energy for one flavor and 'cc' | 'nc': the running integral of d sigma / dy
+    from y = 0, normalised (inelasticities._get_inverse_cdf_interpolation :99-105)"""
+    t = _bgr18_table()
+    fi = np.flatnonzero(t['flavors'] == flavor)
+    if len(fi) != 1:
+        raise ValueError("hedis_bgr18 has no neutrino flavor {}".format(flavor))
+    return t['cdf'][fi[0], t['kinds'].index(str(nccc).lower()), i_energy], t['y']
 
 
 def hedis_bgr18(energy, flavors, inttype='total'):
     """get_nu_cross_section(..., 'hedis_bgr18') (:276-299): cross section per nucleon [m^2] for arrays (or scalars) energy /
     flavors / inttype ('cc' | 'nc' | 'total'); a flavor that is not in the file (0, as mode 'simple' of get_weight passes) is a
     ValueError -- the reference fails on it too (an index of an empty argwhere)."""
-    e_ref, flav_ref, kinds, sig = _bgr18_table()
+    t = _bgr18_table()
+    e_ref, flav_ref, kinds, sig = t['energy'], t['flavors'], t['kinds'], t['sigma']
     scalar = np.ndim(energy) == 0
     energy = np.atleast_1d(np.asarray(energy, float))
     if np.any(energy > e_ref[-1]):

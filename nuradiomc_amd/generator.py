@@ -1,8 +1,8 @@
 """Event-list generator: the reference's generate_eventlist_cylinder (NuRadioMC/EvtGen/generator.py:1023-1414) without the
 PROPOSAL secondaries -- vertices uniform in a cylinder or box (generate_vertex_positions :598-628, set_volume_attributes
 :392-596), isotropic arrival directions in the requested ranges, flavours, energies (get_energies :308-390: 'log_uniform' and
-'E-<gamma>'), charged / neutral current and inelasticity (utilities/inelasticities.py:16-158, model 'ctw'; the tabulated
-'hedis_bgr18' model is a download), one hadronic shower per interaction plus an electromagnetic one for nu_e CC (:1262-1283).
+'E-<gamma>'), charged / neutral current and inelasticity (utilities/inelasticities.py:16-158, model 'ctw', or the tabulated
+'hedis_bgr18' from the data file named to nuradiomc_amd.cross_sections), one hadronic shower per interaction plus an electromagnetic one for nu_e CC (:1262-1283).
 
 Host-side numpy.  The random numbers come from np.random.Generator(Philox(seed)) in the reference's order of calls, so the same
 seed gives the same event list -- the one the reference would hand to the simulation (tests/golden/ref_generator.npz).
@@ -10,6 +10,7 @@ seed gives the same event list -- the one the reference would hand to the simula
 import numpy as np
 from numpy.random import Generator, Philox
 from .output import EventList
+from . import cross_sections
 
 _CTW = {'cc': (-1.826, -17.31, -6.406, 1.431, -17.91), 'nc': (-1.826, -17.31, -6.448, 1.431, -18.61),
         'cc_bar': (-1.033, -15.95, -7.247, 1.569, -17.72), 'nc_bar': (-1.033, -15.95, -7.296, 1.569, -18.30)}
@@ -35,6 +36,22 @@ def _nu_cross_section(energy, flavors, inttype):
         e = energy[sel]
         out[sel] = np.nan if np.any(e < 1e4 * 1e9) else ctw_cross_section(e, inttype)
     return out
+
+
+def _bgr18_inelasticity(energy, flavors, ncccs, rnd):
+    """inelasticities.get_neutrino_inelasticity, model 'hedis_bgr18' (:54-93): every event takes the table's energy node above its
+    energy (np.digitize, clipped to the last node); per (node, flavor, current) in ascending order one block of uniform numbers
+    through the inverse cumulative distribution of y (linear interpolation) -- the reference's order of draws"""
+    e_ref = cross_sections._bgr18_table()['energy']
+    node = np.clip(np.digitize(energy, e_ref), 0, len(e_ref) - 1)
+    yy = np.zeros(len(energy))
+    for ie in np.unique(node):
+        for f in np.unique(flavors):
+            for cur in np.unique(ncccs):
+                m = (node == ie) & (flavors == f) & (ncccs == cur)
+                cdf, y = cross_sections.bgr18_inelasticity_cdf(f, cur, ie)
+                yy[m] = np.interp(rnd.uniform(0, 1, size=int(m.sum())), cdf, y)
+    return yy
 
 
 def set_volume_attributes(volume, attributes):
@@ -95,8 +112,9 @@ def generate_eventlist_cylinder(n_events, Emin, Emax, volume, thetamin=0., theta
                                 start_event_id=1, flavor=(12, -12, 14, -14, 16, -16), spectrum='log_uniform', deposited=False,
                                 max_n_events_batch=1e5, seed=None, interaction_type='ccnc', cross_sections_model='ctw'):
     """Returns the EventList (data sets + attributes) the reference returns with write_events=False."""
-    if cross_sections_model.lower() != 'ctw':
-        raise NotImplementedError("cross-section model {} needs a downloaded table; 'ctw' is provided".format(cross_sections_model))
+    model = cross_sections_model.lower()
+    if model not in ('ctw', 'hedis_bgr18'):
+        raise NotImplementedError("cross-section model {}: 'ctw' and 'hedis_bgr18' are provided".format(cross_sections_model))
     if deposited:
         raise NotImplementedError("deposited = True is not provided")
     rnd = Generator(Philox(seed))
@@ -124,16 +142,22 @@ def generate_eventlist_cylinder(n_events, Emin, Emax, volume, thetamin=0., theta
         ds['energies'] = get_energies(nb, Emin, Emax, spectrum, rnd)
         if interaction_type == 'ccnc':     # inelasticities.get_ccnc (:108-157)
             u = rnd.uniform(0., 1., nb)
-            cc = _nu_cross_section(ds['energies'], ds['flavors'], 'cc')
-            nc = _nu_cross_section(ds['energies'], ds['flavors'], 'nc')
+            if model == 'ctw':
+                cc = _nu_cross_section(ds['energies'], ds['flavors'], 'cc')
+                nc = _nu_cross_section(ds['energies'], ds['flavors'], 'nc')
+            else:
+                cc = cross_sections.hedis_bgr18(ds['energies'], ds['flavors'], 'cc')
+                nc = cross_sections.hedis_bgr18(ds['energies'], ds['flavors'], 'nc')
             with np.errstate(invalid='ignore'):
                 ds['interaction_type'] = np.where(u <= cc / (cc + nc), 'cc', 'nc')
         elif interaction_type in ('cc', 'nc'):
             ds['interaction_type'] = np.full(nb, interaction_type, dtype='U2')
         else:
             raise ValueError("Input illegal interaction type: {}".format(interaction_type))
-        # inelasticities.get_neutrino_inelasticity, model 'ctw' (:48-52)
-        ds['inelasticity'] = (-np.log(0.36787944 + rnd.uniform(0., 1., nb) * 0.63212056)) ** 2.5
+        if model == 'ctw':     # inelasticities.get_neutrino_inelasticity, model 'ctw' (:48-52)
+            ds['inelasticity'] = (-np.log(0.36787944 + rnd.uniform(0., 1., nb) * 0.63212056)) ** 2.5
+        else:
+            ds['inelasticity'] = _bgr18_inelasticity(ds['energies'], ds['flavors'], ds['interaction_type'], rnd)
         ds['shower_energies'] = ds['energies'] * ds['inelasticity']
         ds['shower_type'] = np.array(['had'] * nb)
         # an electromagnetic shower after every nu_e CC interaction (:1262-1283): the row is doubled, the copy carries (1 - y) E
