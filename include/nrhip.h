@@ -335,8 +335,8 @@ typedef struct {
        medium_base.py:IceModelSimple, analyticraytracing.py:2118-2130, :2966-3009): ray tables get 2 + 4 n_reflections solution
        slots per pair ("slot_*" tables, plus "slot_reflection", "slot_reflection_case", "slot_n_segments"), a ray's attenuation is
        the product over its path segments, its field is multiplied by r_p / r_s once per surface reflection and by
-       reflection_coefficient e^{i reflection_phase_shift} once per bottom reflection.  0 = none.  Not together with
-       birefringence or focusing. */
+       reflection_coefficient e^{i reflection_phase_shift} once per bottom reflection.  0 = none.  With `focusing` the second
+       trace lists the bottom-reflected solutions too (analyticraytracing.py:2835-2840).  Not together with birefringence. */
     int32_t n_reflections;
     double z_reflection;
     double reflection_coefficient;

@@ -809,8 +809,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need a shower library (nrhip_station_set_arz)");
     if (arz && !cfg->select_only && st->n_shower_profiles != n_events)
         return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need one profile per shower (nrhip_station_set_shower_profiles)");
-    if (cfg->n_reflections > 0 && (bire || cfg->focusing))
-        return nrhip_fail_msg("nrhip_simulate_events: bottom reflections are not available together with birefringence or focusing");
+    if (cfg->n_reflections > 0 && bire)
+        return nrhip_fail_msg("nrhip_simulate_events: bottom reflections are not available together with birefringence");
     const bool phased = cfg->trigger_type == NRHIP_TRIG_PHASED_ARRAY;
     const bool envelope = cfg->trigger_type == NRHIP_TRIG_ENVELOPE;
     const bool noise = cfg->noise != 0;
@@ -986,7 +986,27 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             NEED(rec2.launch = WS("foc_launch", double, 3 * n_slots));
             NEED(rec2.receive = WS("foc_receive", double, 3 * n_slots));
             NEED(rec2.refl_angle = WS("foc_refl_angle", double, n_slots));
-            launch_raytrace(sm, n_pairs, vertex, pos2, n_ch, ctx->ice, rec2, max_distance, geo_perm);
+            if (n_refl > 0) {
+                // the reference's second tracer is built with the same n_reflections (analyticraytracing.py:2835-2840): solution
+                // iS of its list -- plain solutions, then per number of reflections the two starting directions -- is the slot
+                int *rf2, *rc2, *nseg2, *smask2, *cand_n2;
+                double *zint2, *segC2, *cand_C2;
+                const int n_calls = 1 + 2 * n_refl;
+                NEED(rf2 = WS("foc_reflection", int, n_slots));
+                NEED(rc2 = WS("foc_reflection_case", int, n_slots));
+                NEED(nseg2 = WS("foc_n_segments", int, n_slots));
+                NEED(smask2 = WS("foc_surface_mask", int, n_slots));
+                NEED(zint2 = WS("foc_segment_limits", double, (size_t)n_slots * NS_ * 3));
+                NEED(segC2 = WS("foc_segment_C0", double, (size_t)n_slots * NS_));
+                NEED(cand_n2 = WS("foc_candidates_n", int, (size_t)n_pairs * n_calls));
+                NEED(cand_C2 = WS("foc_candidates_C0", double, (size_t)n_pairs * n_calls * 3));
+                ReflRecords rr2{rec2.n_sol, rec2.type, rf2, rc2, nseg2, smask2, rec2.C0, rec2.C1, rec2.D, rec2.T, rec2.launch, rec2.receive,
+                                rec2.refl_angle, zint2, segC2};
+                launch_find_refl(sm, n_pairs, n_refl, vertex, pos2, n_ch, ctx->ice, cfg->z_reflection, cand_n2, cand_C2);
+                launch_records_refl(sm, n_pairs, n_refl, S_, vertex, pos2, n_ch, ctx->ice, cfg->z_reflection, cand_n2, cand_C2, 0, rr2);
+            } else {
+                launch_raytrace(sm, n_pairs, vertex, pos2, n_ch, ctx->ice, rec2, max_distance, geo_perm);
+            }
             LCHK("raytrace (focusing)");
             HIPCHK(hipStreamSynchronize(sm));  // hp goes out of scope
             foc_n_sol = rec2.n_sol;

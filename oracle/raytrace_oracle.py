@@ -142,17 +142,22 @@ def attenuation_length(z, f, model):
     return out
 
 
-def focusing(x1, x2, ice, dz=-0.01, limit=2.):
+def focusing(x1, x2, ice, dz=-0.01, limit=2., reflections=None):
     """ray_tracing.get_focusing, numerical branch (analyticraytracing.py:2778-2888), receiver in ice: second trace to the
-    receiver moved by dz; [n, 2] (NaN where there is no solution).  x1 = emitter, x2 = receiver."""
+    receiver moved by dz; [n, 2] (NaN where there is no solution).  x1 = emitter, x2 = receiver.  reflections =
+    (n_reflections, z_reflection): both traces with the bottom-reflected solutions in their lists (the reference builds its second
+    tracer with the same n_reflections, :2835-2840), [n, 2 + 4 n_reflections]."""
     x1 = np.asarray(x1, float).reshape(-1, 3)
     x2 = np.asarray(x2, float).reshape(-1, 3)
-    a = raytrace_batch(x1, x2, ice)
     x2b = x2.copy()
     x2b[:, 2] += dz
-    b = raytrace_batch(x1, x2b, ice)
+    if reflections is None:
+        a, b = raytrace_batch(x1, x2, ice), raytrace_batch(x1, x2b, ice)
+    else:
+        a = raytrace_batch_refl(x1, x2, ice, reflections[0], reflections[1])
+        b = raytrace_batch_refl(x1, x2b, ice, reflections[0], reflections[1])
     n_index = lambda z: ice[0] - ice[1] * np.exp(z / ice[2])
-    out = np.full((len(x1), 2), np.nan)
+    out = np.full((len(x1), a['C0'].shape[1]), np.nan)
     for i in range(len(x1)):
         for s in range(a['n_sol'][i]):
             rec = -1.0 * a['receive'][i, s]

@@ -522,7 +522,8 @@ def sim_efields_for_event(vertex, zenith, azimuth, energy, shower_type, k_L, st,
                 spec[2] = spec[2] * fac
                 r_theta, r_phi = r_theta * fac, r_phi * fac
             if focusing:  # analyticraytracing.py:3011-3016
-                spec[1:] = spec[1:] * rto.focusing(x1[None], st.pos[ch][None], ice, -0.01, focusing_limit)[0, s]
+                spec[1:] = spec[1:] * rto.focusing(x1[None], st.pos[ch][None], ice, -0.01, focusing_limit,
+                                                   None if reflections is None else reflections[:2])[0, s]
             if birefringence is not None:
                 from . import birefringence_oracle as bo
                 steps = bo.path_steps(x1, st.pos[ch], rays['C0'][ch, s], D, ice, birefringence[0], birefringence[1])

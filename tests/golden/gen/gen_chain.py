@@ -114,5 +114,9 @@ if __name__ == '__main__':
     if 'N4096_mb' in which:   # the same shelf with the headline's traces (4096 samples at 2 GHz): common traces of ~ 19 000 samples
         run('N4096_mb', n_events=60, seed=28, N=4096, full_rays=4, full_events=1, rmax=900., ice_model='mooresbay_simple',
             att_model='MB1', n_reflections=1, zmin=-570., zmax=-370., z_top=-5., energy=1e18)
+    if 'N256_mb_focus' in which:   # the shelf of N256_mb with propagation.focusing on: the second trace of get_focusing lists the
+        # bottom-reflected solutions too (its tracer is built with the same n_reflections)
+        run('N256_mb_focus', n_events=140, seed=29, N=256, full_rays=60, full_events=4, rmax=900., ice_model='mooresbay_simple',
+            att_model='MB1', n_reflections=1, zmin=-570., zmax=-370., z_top=-5., energy=1e18, focusing=True)
     if 'N256_focus' in which:  # propagation.focusing on (ray convergence factor from a second trace, limit 2)
         run('N256_focus', n_events=200, seed=25, N=256, full_rays=100, full_events=6, rmax=2500., focusing=True)

@@ -1611,6 +1611,84 @@ def test_bottom_reflections_in_the_batched_path(gpu_ctx_factory, fixture, n, min
     assert stats_p['n_rays'] == stats['n_rays'] and stats_p['n_active_rays'] <= stats['n_active_rays']
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, 'tests', 'golden', 'chain_N256_mb_focus.npz')), reason='fixture not generated')
+def test_bottom_reflections_with_focusing(gpu_ctx_factory):
+    """propagation.focusing on a shelf with a reflective bottom (n_reflections = 1): the second trace of get_focusing lists the
+    bottom-reflected solutions as the first one does (the reference builds that tracer with the same n_reflections,
+    analyticraytracing.py:2835-2840), and solution iS of the one is compared with solution iS of the other.  GPU vs the oracle on
+    identical ray tables (per-ray maxima, candidate flags, traces 1e-6, decisions exact); the factor changes the amplitudes of the
+    bottom-reflected rays too; and vs the reference's own outputs where it found the same rays (its Python path loses roots of rays
+    starting downwards in BOTH traces, see test_bottom_reflections_in_the_batched_path: per-ray maxima where the solution lists of
+    both its traces are complete, i.e. equal ours)."""
+    g = golden('chain_N256_mb_focus.npz')
+    n = 140
+    assert bool(g['focusing'])
+    ctx, st, refl, kL, trig, stats = _mb_run(gpu_ctx_factory, g, n, no_pruning=True, dump_traces=True, focusing=True, focusing_limit=2.)
+    S = 2 + 4 * refl['n_reflections']
+    n_ch = len(g['det_pos'])
+    T = {k: st.fetch(k).copy() for k in ('pair_n_sol', 'slot_type', 'slot_C0', 'slot_D', 'slot_T', 'slot_launch', 'slot_receive',
+                                         'slot_refl_angle', 'slot_reflection', 'slot_reflection_case', 'slot_surface_mask', 'ray_event',
+                                         'ray_channel', 'ray_solution', 'ray_max_efield', 'ev_n_rays', 'ev_L', 'ev_candidate',
+                                         'ev_ray_begin')}
+    item_event = st.fetch('item_event').copy()
+    toff, trace = st.fetch('trace_offset').copy(), st.fetch('trace').copy()
+    maxV = st.fetch('item_maxV').reshape(len(item_event), -1).copy()
+    ost = so.Station(g['det_pos'], n_samples=int(g['N']), fs=float(g['fs']))
+    orefl = (refl['n_reflections'], refl['z_reflection'], refl['reflection_coefficient'], refl['reflection_phase_shift'])
+    n_rays = n_refl_rays = n_cand = 0
+    for ev in range(n):
+        sl = slice(ev * n_ch * S, (ev + 1) * n_ch * S)
+        rays = dict(n_sol=T['pair_n_sol'][ev * n_ch:(ev + 1) * n_ch])
+        for k, name in (('type', 'slot_type'), ('C0', 'slot_C0'), ('D', 'slot_D'), ('T', 'slot_T'), ('refl_angle', 'slot_refl_angle'),
+                        ('reflection', 'slot_reflection'), ('reflection_case', 'slot_reflection_case'),
+                        ('surface_mask', 'slot_surface_mask')):
+            rays[k] = T[name][sl].reshape(n_ch, S)
+        for k, name in (('launch', 'slot_launch'), ('receive', 'slot_receive')):
+            rays[k] = T[name][3 * sl.start:3 * sl.stop].reshape(n_ch, S, 3)
+        o = so.simulate_event(g['vertex'][ev], g['zenith'][ev], g['azimuth'][ev], g['energy'][ev], str(g['shower_type'][ev]),
+                              float(kL[ev]), ost, g['ice'], st.vrms, st.vrms_efield, att_model=str(g['att_model']), rays=rays,
+                              reflections=orefl, focusing=True, focusing_limit=2.)
+        r0 = T['ev_ray_begin'][ev]
+        sel = np.arange(r0, r0 + T['ev_n_rays'][ev])
+        assert [(r['channel'], r['iS']) for r in o['rays']] == list(zip(T['ray_channel'][sel], T['ray_solution'][sel])), ev
+        for r, k in zip(o['rays'], sel):
+            assert abs(r['max_efield'] - T['ray_max_efield'][k]) <= 1e-6 * r['max_efield'], (ev, r['channel'], r['iS'])
+            n_rays += 1
+            n_refl_rays += rays['reflection'][r['channel'], r['iS']] > 0
+        assert bool(T['ev_candidate'][ev]) == o['candidate'] and bool(trig[ev]) == o['triggered'], ev
+        if o['candidate']:
+            n_cand += 1
+            assert T['ev_L'][ev] == o['L']
+            i = int(np.where(item_event == ev)[0][0])
+            scale = np.max(np.abs(o['V']))
+            for ch in range(n_ch):
+                assert np.max(np.abs(trace[toff[i * n_ch + ch]:toff[i * n_ch + ch + 1]] - o['V'][ch])) <= 1e-6 * scale, (ev, ch)
+    assert n_rays > 250 and n_refl_rays > 60 and n_cand >= 8
+    # the factor is at work on direct and on bottom-reflected rays alike
+    ctx, st0, _, _, trig0, _ = _mb_run(gpu_ctx_factory, g, n, no_pruning=True)
+    mx0 = st0.fetch('ray_max_efield')
+    assert len(mx0) == len(T['ray_max_efield'])
+    ratio = T['ray_max_efield'] / mx0
+    is_refl = T['slot_reflection'][(T['ray_event'] * n_ch + T['ray_channel']) * S + T['ray_solution']] > 0
+    assert np.all(ratio <= 2.0 * 1.2)
+    assert np.mean(np.abs(ratio[is_refl] - 1) > 1e-3) > 0.9 and np.mean(np.abs(ratio[~is_refl] - 1) > 1e-3) > 0.9
+    # the reference, where it found the same rays in the event (then both its traces are most likely complete): 90 % of those rays
+    # within 1e-3 (first-root noise of its finder at the 1e-2 level in the finite difference, as in test_focusing_chain_vs_reference)
+    same = T['ev_n_rays'] == g['ev_n_rays'][:n]
+    rel = []
+    for ev in np.flatnonzero(same):
+        ref = g['ray_max_efield'][g['ray_event'] == ev]
+        mine = T['ray_max_efield'][T['ev_ray_begin'][ev]:T['ev_ray_begin'][ev] + T['ev_n_rays'][ev]]
+        rel += list(np.abs(mine - ref) / ref)
+    rel = np.array(rel)
+    print('Moore\'s Bay + focusing vs reference: %d events with the same rays, %d rays, %.0f %% within 1e-3, max %.2e'
+          % (same.sum(), len(rel), 100 * np.mean(rel < 1e-3), rel.max() if len(rel) else 0))
+    assert same.sum() >= 25 and len(rel) > 40 and np.mean(rel < 1e-3) > 0.8
+    # production mode: the same masks
+    ctx, st, refl, kL, trig_p, stats_p = _mb_run(gpu_ctx_factory, g, n, focusing=True, focusing_limit=2.)
+    assert np.array_equal(trig_p, trig)
+
+
 def test_split_event_time_diff(gpu_ctx_factory):
     """nrhip_sim_config.split_event_time_diff = simulation.group_into_events (:906-947): groups whose signals are farther apart
     than the limit are cut into sub-events, each with its own readout window, channel sums and trigger; the candidate cut stays

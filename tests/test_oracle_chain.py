@@ -223,6 +223,39 @@ def test_focusing_chain_vs_reference():
     assert n_checked > 500 and n_cand >= 15 and n_dec > 150 and np.mean(rel_all < 1e-4) > 0.85
 
 
+def test_focusing_with_bottom_reflections_vs_reference():
+    """propagation.focusing with n_reflections = 1 (tests/golden/chain_N256_mb_focus.npz: Moore's Bay shelf, the reference's whole
+    chain): get_focusing's second tracer carries the same n_reflections, so solution iS is compared within the full lists.  The
+    reference's Python path loses roots of rays that start downwards (test_oracle_golden.test_mooresbay_C0_golden_pickle), in either
+    trace: the comparison runs over the events in which the reference kept as many rays as the oracle, 80 % of their rays within
+    1e-3 (a lost root in its SECOND trace shifts the index there, and its first-root noise shows at the 1e-2 level)."""
+    g = golden('chain_N256_mb_focus.npz')
+    assert bool(g['focusing']) and int(g['n_reflections']) == 1
+    st = _station(g)
+    ice = g['ice']
+    vrms, vrms_e = so.vrms_from_filters(st.fs)
+    refl = (1, float(g['z_reflection']), float(g['reflection_coefficient']), float(g['reflection_phase_shift']))
+    rel, n_same, n_refl = [], 0, 0
+    for ev in range(60):
+        k_L = None if np.isnan(g['ev_k_L'][ev]) else float(g['ev_k_L'][ev])
+        if str(g['shower_type'][ev]) == 'EM' and k_L is None:
+            continue
+        sel = np.where(g['ray_event'] == ev)[0]
+        o = so.simulate_event(g['vertex'][ev], g['zenith'][ev], g['azimuth'][ev], g['energy'][ev], str(g['shower_type'][ev]),
+                              k_L, st, ice, vrms, vrms_e, att_model=str(g['att_model']), focusing=True,
+                              focusing_limit=float(g['focusing_limit']), reflections=refl)
+        if len(o['rays']) != len(sel) or [(r['channel'], r['iS']) for r in o['rays']] != list(zip(g['ray_channel'][sel], g['ray_iS'][sel])):
+            continue
+        n_same += 1
+        mine = np.array([r['max_efield'] for r in o['rays']])
+        rel += list(np.abs(mine - g['ray_max_efield'][sel]) / g['ray_max_efield'][sel])
+        n_refl += int(np.sum(g['ray_reflection'][sel] > 0))
+    rel = np.array(rel)
+    print('%d events with the same rays, %d rays (%d bottom-reflected): %.0f %% within 1e-3, max %.2e' % (
+        n_same, len(rel), n_refl, 100 * np.mean(rel < 1e-3), rel.max()))
+    assert n_same >= 10 and len(rel) > 40 and n_refl >= 5 and np.mean(rel < 1e-3) > 0.8
+
+
 def test_split_event_time_diff_vs_reference():
     """simulation.group_into_events (:906-947) + per-sub-event detector response and trigger: the oracle's sub-events against the
     reference's on 140 groups with split_event_time_diff = 300 ns (tests/golden/gen/gen_split.py) -- number of sub-events per
