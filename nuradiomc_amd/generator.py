@@ -2,7 +2,8 @@
 PROPOSAL secondaries -- vertices uniform in a cylinder or box (generate_vertex_positions :598-628, set_volume_attributes
 :392-596), isotropic arrival directions in the requested ranges, flavours, energies (get_energies :308-390: 'log_uniform' and
 'E-<gamma>'), charged / neutral current and inelasticity (utilities/inelasticities.py:16-158, model 'ctw', or the tabulated
-'hedis_bgr18' from the data file named to nuradiomc_amd.cross_sections), one hadronic shower per interaction plus an electromagnetic one for nu_e CC (:1262-1283).
+'hedis_bgr18' from the data file named to nuradiomc_amd.cross_sections), neutrino energies from deposited ones (deposited=True,
+:199-224), one hadronic shower per interaction plus an electromagnetic one for nu_e CC (:1262-1283).
 
 Host-side numpy.  The random numbers come from np.random.Generator(Philox(seed)) in the reference's order of calls, so the same
 seed gives the same event list -- the one the reference would hand to the simulation (tests/golden/ref_generator.npz).
@@ -115,8 +116,6 @@ def generate_eventlist_cylinder(n_events, Emin, Emax, volume, thetamin=0., theta
     model = cross_sections_model.lower()
     if model not in ('ctw', 'hedis_bgr18'):
         raise NotImplementedError("cross-section model {}: 'ctw' and 'hedis_bgr18' are provided".format(cross_sections_model))
-    if deposited:
-        raise NotImplementedError("deposited = True is not provided")
     rnd = Generator(Philox(seed))
     max_n_events_batch = int(max_n_events_batch)
     flavor = list(flavor)
@@ -158,6 +157,9 @@ def generate_eventlist_cylinder(n_events, Emin, Emax, volume, thetamin=0., theta
             ds['inelasticity'] = (-np.log(0.36787944 + rnd.uniform(0., 1., nb) * 0.63212056)) ** 2.5
         else:
             ds['inelasticity'] = _bgr18_inelasticity(ds['energies'], ds['flavors'], ds['interaction_type'], rnd)
+        if deposited:   # primary_energy_from_deposited (:199-224): Emin .. Emax were shower energies -- all but nu_e CC give E / y
+            whole = (ds['interaction_type'] == 'cc') & (np.abs(ds['flavors']) == 12)
+            ds['energies'] = np.where(whole, ds['energies'], ds['energies'] / ds['inelasticity'])
         ds['shower_energies'] = ds['energies'] * ds['inelasticity']
         ds['shower_type'] = np.array(['had'] * nb)
         # an electromagnetic shower after every nu_e CC interaction (:1262-1283): the row is doubled, the copy carries (1 - y) E

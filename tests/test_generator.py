@@ -64,3 +64,24 @@ def test_event_lists_with_the_tabulated_hedis_model():
     with pytest.raises(NotImplementedError):
         generator.generate_eventlist_cylinder(10, 1e17, 1e18, dict(fiducial_rmin=0., fiducial_rmax=1e3, fiducial_zmin=-1e3, fiducial_zmax=0.),
                                               seed=1, cross_sections_model='csms')
+
+
+def test_event_list_with_deposited_energies():
+    """deposited=True (Emin .. Emax are deposited energies; the neutrino energy is E / y except for nu_e CC; generator.py:199-224,
+    :1247-1252) against the reference's generator (ref_generator_deposited.npz, tests/golden/gen/gen_generator_deposited.py)"""
+    g = golden('ref_generator_deposited.npz')
+    kw = eval(str(g['c0_kwargs']))
+    ev = generator.generate_eventlist_cylinder(**kw)
+    keys = [k[len('c0/'):] for k in g.files if k.startswith('c0/')]
+    assert sorted(keys) == sorted(ev.data) and bool(ev.attrs['deposited']) and bool(g['c0_attr_deposited'])
+    for k in keys:
+        ref, got = g['c0/' + k], ev.data[k]
+        if ref.dtype.kind == 'S':
+            assert [x.decode() for x in ref] == [str(x) for x in got], k
+        elif ref.dtype.kind == 'f':
+            assert np.allclose(got, ref, rtol=1e-13, atol=0), k
+        else:
+            assert np.array_equal(got, ref), k
+    had = np.array([str(t) for t in ev.data['shower_type']]) == 'had'
+    nue_cc = (np.abs(ev.data['flavors']) == 12) & (np.array([str(t) for t in ev.data['interaction_type']]) == 'cc')
+    assert np.all(ev.data['shower_energies'][had & ~nue_cc] <= 1e19 * (1 + 1e-12)) and ev.data['energies'].max() > 1e20
