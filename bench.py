@@ -385,7 +385,7 @@ def main():
     if args.events is None:
         args.events = {2: 1000000, 3: 1000000, 4: 20000, 5: 1000000}[cfgno]
     if args.steps is None:
-        args.steps = {2: 100, 3: 3, 4: 1, 5: 2}[cfgno]   # (config 2: 5 s of GPU work; 400 steps measured the same 53.4 ms per step)
+        args.steps = {2: 100, 3: 3, 4: 1, 5: 2}[cfgno]   # (config 2: 5 s of GPU work; 400 steps measured the same time per step)
     if args.warmup is None:
         args.warmup = {2: 3, 3: 1, 4: 1, 5: 1}[cfgno]
 
