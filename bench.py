@@ -357,6 +357,52 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def launch_ranks(args, argv=None):
+    """`--gpus N` means N ranks.  Under a launcher (WORLD_SIZE set: torch.distributed.run, mpirun wrappers) this process IS one of
+    them: returns None, unless WORLD_SIZE contradicts --gpus (exit code 2 with a message -- a line that says n_gpus = 8 must not
+    have run on one).  Without a launcher and N > 1 this process -- which has made no GPU call yet -- becomes the launcher the
+    reference's runner.py:53-87 is: N fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, one
+    device each), rank 0's stdout (the JSON line) is this process's stdout, the other ranks' goes to stderr; returns the exit code
+    (non-zero if any child's is; the others are then ended by PID)."""
+    import socket
+    import subprocess
+    ws = os.environ.get('WORLD_SIZE')
+    if ws is not None:
+        if int(ws) != args.gpus:
+            print("bench.py: --gpus %d but the launcher's WORLD_SIZE is %s -- start as many ranks as --gpus says (or drop the "
+                  "launcher: bench.py --gpus N starts its own ranks)" % (args.gpus, ws), file=sys.stderr)
+            return 2
+        return None
+    if args.gpus <= 1:
+        return None
+
+    def free_port():
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(('127.0.0.1', 0))
+            return s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()),
+               NRHIP_COMM_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                for q in live:   # a rank failed: the others would wait in a collective for ever
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -366,7 +412,7 @@ def main():
     ap.add_argument('--flavour', default='had', choices=['had', 'mixed'])
     ap.add_argument('--events', type=int, default=None, help='event groups per rank and step (weak) or in total (strong)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    ap.add_argument('--cpu-budget', type=float, default=25., help='seconds of CPU baseline')
+    ap.add_argument('--cpu-budget', type=float, default=12., help='seconds of CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--device', type=int, default=None, help='GPU index of this rank (default: LOCAL_RANK)')
     ap.add_argument('--trigger', default='threshold', choices=['threshold', 'pa', 'pa_adc_noise'],
@@ -380,7 +426,27 @@ def main():
                     'workspace and host thread each; default 2 for config 3, 1 otherwise)')
     ap.add_argument('--allow-tcp', action='store_true', help='if RCCL does not come up on every rank: run the collectives over the TCP '
                     'star instead of exiting non-zero (single-GPU boxes: tools/two_ranks_one_gpu.sh)')
+    ap.add_argument('--dry-run', action='store_true', help='launcher check without a GPU: the ranks meet on the TCP star, gather their '
+                    '(rank, local rank) pairs and a sharded mask, rank 0 prints a JSON line')
     args = ap.parse_args()
+    rc = launch_ranks(args)
+    if rc is not None:
+        raise SystemExit(rc)
+    if args.dry_run:
+        from nuradiomc_amd import comm as nrcomm
+        rank, local_rank, world = nrcomm.env_rank()
+        c = nrcomm.Comm(None, rank, world, backend='tcp')
+        n_total = args.events or 1003
+        a, b = nrcomm.shard_range(n_total, rank, world)
+        full = (np.arange(n_total) % 7 == 0).astype(np.uint8)
+        mask = c.allgather_masks(full[a:b].copy(), b - a, n_total)
+        seen = c.allreduce_sum([1, rank, local_rank])
+        c.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": int(seen[0]), "rank_sum": int(seen[1]), "local_rank_sum": int(seen[2]),
+                              "mask_ok": bool(np.array_equal(mask, full)), "collectives": c.mode}))
+        c.close()
+        return
     cfgno = args.config
     if args.events is None:
         args.events = {2: 1000000, 3: 1000000, 4: 20000, 5: 1000000}[cfgno]
@@ -398,7 +464,10 @@ def main():
     else:
         wl = make_workload(cfgno, args.events, 10 + rank, args.flavour, args.trigger)
         g0, g1 = 0, args.events
-    ctx = nuradiomc_amd.Context(wl['ice'], wl['att_model'], device=local_rank if args.device is None else args.device)
+    # one device per rank; with more ranks than devices (two ranks on a one-GPU box: --allow-tcp) the ranks wrap around
+    from nuradiomc_amd import _lib as nrlib
+    device = args.device if args.device is not None else local_rank % max(int(nrlib.load().nrhip_device_count()), 1)
+    ctx = nuradiomc_amd.Context(wl['ice'], wl['att_model'], device=device)
     comm = nrcomm.Comm(ctx, rank, world, allow_tcp=True if args.allow_tcp else None)
     det = build_array(ctx, wl)
     is_array = wl['centres'] is not None
@@ -407,7 +476,7 @@ def main():
     lane_ctx = []
     if is_array:
         for _ in range(max(n_lanes, 1) - 1):   # (build_array may touch wl['sim_kw']: identical values every time)
-            c2 = nuradiomc_amd.Context(wl['ice'], wl['att_model'], device=local_rank if args.device is None else args.device)
+            c2 = nuradiomc_amd.Context(wl['ice'], wl['att_model'], device=device)
             lane_ctx.append(c2)
             det.add_lane(build_array(c2, wl).station)
     else:
@@ -468,6 +537,7 @@ def main():
         if world > 1:   # exercise the collective of the path all the same (equal shards)
             mask = comm.allgather_masks(d['trig'], n_groups, n_total)
             assert int(mask.sum()) == n_trig_total
+    mask_sha = hashlib.sha256(np.ascontiguousarray(mask, np.uint8).tobytes()).hexdigest()[:16] if (args.scaling == 'strong' or world > 1) else None
     counters = ('n_pairs', 'n_rays', 'n_active_rays', 'n_candidate_events', 'n_integrand_evals')
     tot = dict(zip(counters, comm.allreduce_sum([stats[k] for k in counters])))
 
@@ -531,6 +601,7 @@ def main():
                        "traces_emitted_in_pass1": bool(with_traces and not args.two_pass), "n_emitted_events": stats.get('n_emitted_events'),
                        "trace_bytes": stats.get('trace_bytes'),
                        "stage_ms_avg_per_step": {k: round(v, 3) for k, v in sm.items()},
+                       "gathered_mask_sha16": mask_sha,   # of the all-gathered trigger mask (the same for any number of ranks when strong)
                        "collectives": comm.mode},   # 'local' (one rank), 'rccl', or 'tcp' (RCCL did not come up on every rank)
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "from_profile" if traffic is not None else None,

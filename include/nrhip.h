@@ -616,6 +616,8 @@ int nrhip_mask_scatter_or(nrhip_ctx* ctx, int64_t n, const int32_t* index, const
 /* out[k] = offset + index[k] (index NULL: offset + k) as DEV int64: the original group ids of a gathered list, e.g. for
  * nrhip_sim_config.noise_group_id (the noise of an event group must not depend on which compact list it travels in) */
 int nrhip_index_to_i64(nrhip_ctx* ctx, int64_t n, const int32_t* index, int64_t offset, int64_t* out);
+/* out[k] = src[index[k]] (DEV int64): caller-given group ids (nrhip_sim_config.noise_group_id) of a gathered list */
+int nrhip_gather_i64(nrhip_ctx* ctx, int64_t n, const int32_t* index, const int64_t* src, int64_t* out);
 
 /* dst[i] = overwrite ? src[i] : dst[i] | src[i] on DEV uint8 masks (event-group mask of an array = OR over its stations) */
 int nrhip_mask_or(nrhip_ctx* ctx, int64_t n, uint8_t* dst, const uint8_t* src, int32_t overwrite);

@@ -32,6 +32,7 @@ L._OPTIONAL.update({
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     'nrhip_gather_groups': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 20),
     'nrhip_index_to_i64': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    'nrhip_gather_i64': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'nrhip_memset': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint64]),
     'nrhip_mask_scatter_or': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
 })
@@ -274,9 +275,15 @@ class Comm:
         shard_chunks (round-robin chunks) are NOT contiguous: gather those per chunk or scatter by index on the host."""
         W = self.world_size
         sizes = [shard_range(n_total, k, W)[1] - shard_range(n_total, k, W)[0] for k in range(W)]
-        if n_local != sizes[self.rank] or sum(sizes) != n_total:
+        # the ranks agree on the shard sizes BEFORE the collective: a mismatch on one rank alone would leave the others waiting in
+        # the all-gather until its timeout, so every rank learns every n_local (over the star, 8 bytes) and all raise together
+        held = [int(n_local)]
+        if self._star is not None:
+            held = [int.from_bytes(q, 'little') for q in self._star.allgather(int(n_local).to_bytes(8, 'little'))]
+        bad = [k for k in range(W) if held[k] != sizes[k]]   # (the star exists whenever W > 1: len(held) == W)
+        if bad:
             raise ValueError("allgather_masks: rank %d holds %d events, shard_range(%d, %d, %d) has %d -- the gather is defined for "
-                             "contiguous shard_range shards only" % (self.rank, n_local, n_total, self.rank, W, sizes[self.rank]))
+                             "contiguous shard_range shards only" % (bad[0], held[bad[0]], n_total, bad[0], W, sizes[bad[0]]))
         if self._h is None:
             if isinstance(d_local, np.ndarray):   # a host mask (tcp backend without a device context)
                 out = np.ascontiguousarray(d_local[:n_local], np.uint8)

@@ -1,0 +1,404 @@
+// conv_fft.h -- the transform pair of channel_conv_kernel, built around WAVE-PRIVATE sub-transforms.
+//
+// The real 2M-point circular convolution of efieldToVoltageConverter (NuRadioReco/modules/efieldToVoltageConverter.py:223-345:
+// rfft -> * antenna response * filter -> irfft) is a packed complex M-point transform pair in LDS (M = 8192 or 4096 complex128).
+// Round 3 ran it as nine block-wide passes (4 forward, spectrum product, 4 inverse), every one ending in __syncthreads(): with one
+// 128 KB block per CU all eight waves sat in the same phase (all reading LDS, then all computing, then all writing) and 57 % of the
+// wave-cycles were parked on barriers.  Here:
+//
+//   * the M points are 8 (4, 2) blocks of 1024, one per wave.  Only the first pass of the forward transform (radix 8 / 4 across the
+//     blocks) and the last of the inverse are block-wide; the 1024-point transforms in between (radix 16, then radix 8) belong to
+//     ONE wave each, which synchronises with itself only -- the waves drift apart, one's LDS traffic under another's arithmetic;
+//   * the last three stages of the forward transform, the real-transform split, the product with the response spectrum G, the merge
+//     and the first three stages of the inverse are ONE pass (a thread owns the eight bins k0 + j M/8 and their mirror partners
+//     M - k): seven passes over the LDS instead of nine, five block barriers instead of eleven;
+//   * every pass is laid out so that consecutive lanes touch consecutive elements (16-byte LDS accesses, no bank conflicts): between
+//     the wave-private passes the data is transposed inside the wave's block on the way (a pass writes the order the next one reads),
+//     and the last wave-private pass leaves the spectrum in natural order of the bin index k0 -- so the response spectrum is read
+//     from HBM / L2 in coalesced runs;
+//   * twiddles come from small per-pass tables (cft: 15 x 64 + 7 x 8 entries behind w16, L1 resident, coalesced) holding exactly the
+//     master table's values: the butterflies are those of a radix-2 transform, their grouping into passes does not change a bit of
+//     the result (the 4096-point transform gives the same bits in the 256- and in the 512-thread kernel).
+//   * the upper half of the packed input is zero by construction (L <= M real samples): the first stage of the forward transform
+//     reads half of its inputs.
+//
+// Layout: complex element i of the buffer lives at conv_pad(i) = i + (i >> 10) -- one element of padding per 1024-block, so that
+// lanes walking ACROSS the blocks (spectrum pass) fall on different banks.
+#pragma once
+#include "fft_device.h"
+
+namespace nrhip {
+
+__device__ __forceinline__ int conv_pad(int i) { return i + (i >> 10); }
+__host__ __device__ constexpr int conv_lds_elems(int M) { return M + 16; }   // complex elements of the padded buffer
+constexpr int CFT_T2 = 0;             // [15][64]: W_1024^(l + 64 s) s < 8 | W_512^(l + 64 s) s < 4 | W_256^(l + 64 s) s < 2 | W_128^l
+constexpr int CFT_T3 = 15 * 64;       // [7][8]:   W_64^(c + 8 s) s < 4 | W_32^(c + 8 s) s < 2 | W_16^c
+constexpr int CFT_SIZE = CFT_T3 + 7 * 8;
+
+// LDS accesses of one wave complete in program order: a wave that hands data between its own lanes needs no s_barrier, only that
+// the compiler keeps the order
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The twiddles of a thread depend on nothing but its index: left alone, the optimiser hoists every table load of every pass out of
+// the kernel's event and channel loops and keeps ~200 registers of twiddles alive across them (spilled).  An opaque copy of the table
+// pointer per call keeps the loads where they are used.
+__device__ __forceinline__ const double2* conv_opaque(const double2* p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// ... and an opaque copy of the thread index keeps the (64-bit) addresses derived from it from being computed once at kernel
+// start and parked in scratch
+__device__ __forceinline__ int conv_opaque(int t)
+{
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+__device__ __forceinline__ void dif_bf(double2& a, double2& b, const double2 w)
+{
+    const double2 d = csub(a, b);
+    a = cadd(a, b);
+    b = cmul(d, w);
+}
+__device__ __forceinline__ void dif_bf1(double2& a, double2& b)   // twiddle 1
+{
+    const double2 d = csub(a, b);
+    a = cadd(a, b);
+    b = d;
+}
+__device__ __forceinline__ void dit_bf(double2& a, double2& b, const double2 w)   // w: the forward twiddle (conjugated here)
+{
+    const double2 t = make_double2(b.x * w.x + b.y * w.y, b.y * w.x - b.x * w.y);
+    b = csub(a, t);
+    a = cadd(a, t);
+}
+__device__ __forceinline__ void dit_bf1(double2& a, double2& b)
+{
+    const double2 t = b;
+    b = csub(a, t);
+    a = cadd(a, t);
+}
+// multiplications by the eighth roots of unity W_8^1 = (1 - i) / sqrt 2, W_8^2 = -i, W_8^3 = -(1 + i) / sqrt 2 and their conjugates
+__device__ __forceinline__ double2 mul_w8_1(double2 a) { const double c = 0.70710678118654752440; return make_double2((a.x + a.y) * c, (a.y - a.x) * c); }
+__device__ __forceinline__ double2 mul_w8_2(double2 a) { return make_double2(a.y, -a.x); }
+__device__ __forceinline__ double2 mul_w8_3(double2 a) { const double c = 0.70710678118654752440; return make_double2((a.y - a.x) * c, -(a.x + a.y) * c); }
+__device__ __forceinline__ double2 mul_w8_1c(double2 a) { const double c = 0.70710678118654752440; return make_double2((a.x - a.y) * c, (a.x + a.y) * c); }
+__device__ __forceinline__ double2 mul_w8_2c(double2 a) { return make_double2(-a.y, a.x); }
+__device__ __forceinline__ double2 mul_w8_3c(double2 a) { const double c = 0.70710678118654752440; return make_double2(-(a.x + a.y) * c, (a.x - a.y) * c); }
+
+// the last three stages (spans 4, 2, 1) of a decimation-in-frequency transform on eight consecutive positions, in place
+__device__ __forceinline__ void dif8_tail(double2 (&a)[8])
+{
+    { double2 d; d = csub(a[0], a[4]); a[0] = cadd(a[0], a[4]); a[4] = d; }
+    { double2 d; d = csub(a[1], a[5]); a[1] = cadd(a[1], a[5]); a[5] = mul_w8_1(d); }
+    { double2 d; d = csub(a[2], a[6]); a[2] = cadd(a[2], a[6]); a[6] = mul_w8_2(d); }
+    { double2 d; d = csub(a[3], a[7]); a[3] = cadd(a[3], a[7]); a[7] = mul_w8_3(d); }
+#pragma unroll
+    for (int b = 0; b < 8; b += 4) {
+        { double2 d; d = csub(a[b], a[b + 2]); a[b] = cadd(a[b], a[b + 2]); a[b + 2] = d; }
+        { double2 d; d = csub(a[b + 1], a[b + 3]); a[b + 1] = cadd(a[b + 1], a[b + 3]); a[b + 3] = mul_w8_2(d); }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b += 2) dif_bf1(a[b], a[b + 1]);
+}
+// ... and the first three stages (spans 1, 2, 4) of the decimation-in-time inverse
+__device__ __forceinline__ void dit8_head(double2 (&a)[8])
+{
+#pragma unroll
+    for (int b = 0; b < 8; b += 2) dit_bf1(a[b], a[b + 1]);
+#pragma unroll
+    for (int b = 0; b < 8; b += 4) {
+        dit_bf1(a[b], a[b + 2]);
+        { const double2 t = mul_w8_2c(a[b + 3]); a[b + 3] = csub(a[b + 1], t); a[b + 1] = cadd(a[b + 1], t); }
+    }
+    dit_bf1(a[0], a[4]);
+    { const double2 t = mul_w8_1c(a[5]); a[5] = csub(a[1], t); a[1] = cadd(a[1], t); }
+    { const double2 t = mul_w8_2c(a[6]); a[6] = csub(a[2], t); a[2] = cadd(a[2], t); }
+    { const double2 t = mul_w8_3c(a[7]); a[7] = csub(a[3], t); a[3] = cadd(a[3], t); }
+}
+
+__device__ __forceinline__ int br3(int r) { return ((r & 1) << 2) | (r & 2) | ((r >> 2) & 1); }
+__device__ __forceinline__ int br4(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r >> 3) & 1); }
+
+// ---- wave-private passes on the wave's 1024-block (base = padded index of its first element) ------------------------------------
+// forward, stages with spans 512 .. 64: lane l holds the elements l + 64 j; written transposed for the next pass
+__device__ __forceinline__ void conv_p2_fwd(double2* zb, const double2* __restrict__ cft, int lane)
+{
+    double2 a[16], t[15];
+#pragma unroll
+    for (int s = 0; s < 15; s++) t[s] = cft[CFT_T2 + s * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 16; j++) a[j] = zb[lane + 64 * j];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dif_bf(a[j], a[j + 8], t[j]);
+#pragma unroll
+    for (int b = 0; b < 16; b += 8)
+#pragma unroll
+        for (int j = 0; j < 4; j++) dif_bf(a[b + j], a[b + j + 4], t[8 + j]);
+#pragma unroll
+    for (int b = 0; b < 16; b += 4)
+#pragma unroll
+        for (int j = 0; j < 2; j++) dif_bf(a[b + j], a[b + j + 2], t[12 + j]);
+#pragma unroll
+    for (int b = 0; b < 16; b += 2) dif_bf(a[b], a[b + 1], t[14]);
+    wave_lds_sync();
+    const int wb = (lane >> 3) * 128 + (lane & 7);
+#pragma unroll
+    for (int j = 0; j < 16; j++) zb[wb + (j >> 3) * 64 + 8 * (j & 7)] = a[j];
+    wave_lds_sync();
+}
+// inverse of conv_p2_fwd
+__device__ __forceinline__ void conv_p2_inv(double2* zb, const double2* __restrict__ cft, int lane)
+{
+    double2 a[16], t[15];
+#pragma unroll
+    for (int s = 0; s < 15; s++) t[s] = cft[CFT_T2 + s * 64 + lane];
+    const int wb = (lane >> 3) * 128 + (lane & 7);
+#pragma unroll
+    for (int j = 0; j < 16; j++) a[j] = zb[wb + (j >> 3) * 64 + 8 * (j & 7)];
+#pragma unroll
+    for (int b = 0; b < 16; b += 2) dit_bf(a[b], a[b + 1], t[14]);
+#pragma unroll
+    for (int b = 0; b < 16; b += 4)
+#pragma unroll
+        for (int j = 0; j < 2; j++) dit_bf(a[b + j], a[b + j + 2], t[12 + j]);
+#pragma unroll
+    for (int b = 0; b < 16; b += 8)
+#pragma unroll
+        for (int j = 0; j < 4; j++) dit_bf(a[b + j], a[b + j + 4], t[8 + j]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) dit_bf(a[j], a[j + 8], t[j]);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 16; j++) zb[lane + 64 * j] = a[j];
+}
+// forward, stages with spans 32, 16, 8: lane (c = l & 7, jl = l >> 3) holds, for u = 0, 1, the eight elements h of (c, j = jl + 8 u);
+// written at c + 8 (br4(j) + 16 br3(h)): the block then holds the bins k0 = (wave's residue) + NW (br4(j) + 16 br3(h)) in natural
+// order of k0, eight consecutive positions c per bin group
+__device__ __forceinline__ void conv_p3_fwd(double2* zb, const double2* __restrict__ cft, int lane)
+{
+    double2 a[2][8], t[7];
+    const int c = lane & 7, jl = lane >> 3;
+#pragma unroll
+    for (int s = 0; s < 7; s++) t[s] = cft[CFT_T3 + s * 8 + c];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int h = 0; h < 8; h++) a[u][h] = zb[h * 128 + u * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+#pragma unroll
+        for (int h = 0; h < 4; h++) dif_bf(a[u][h], a[u][h + 4], t[h]);
+#pragma unroll
+        for (int b = 0; b < 8; b += 4)
+#pragma unroll
+            for (int h = 0; h < 2; h++) dif_bf(a[u][b + h], a[u][b + h + 2], t[4 + h]);
+#pragma unroll
+        for (int b = 0; b < 8; b += 2) dif_bf(a[u][b], a[u][b + 1], t[6]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int wb = c + 8 * br4(jl + 8 * u);
+#pragma unroll
+        for (int h = 0; h < 8; h++) zb[wb + 128 * br3(h)] = a[u][h];
+    }
+}
+__device__ __forceinline__ void conv_p3_inv(double2* zb, const double2* __restrict__ cft, int lane)
+{
+    double2 a[2][8], t[7];
+    const int c = lane & 7, jl = lane >> 3;
+#pragma unroll
+    for (int s = 0; s < 7; s++) t[s] = cft[CFT_T3 + s * 8 + c];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int wb = c + 8 * br4(jl + 8 * u);
+#pragma unroll
+        for (int h = 0; h < 8; h++) a[u][h] = zb[wb + 128 * br3(h)];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+#pragma unroll
+        for (int b = 0; b < 8; b += 2) dit_bf(a[u][b], a[u][b + 1], t[6]);
+#pragma unroll
+        for (int b = 0; b < 8; b += 4)
+#pragma unroll
+            for (int h = 0; h < 2; h++) dit_bf(a[u][b + h], a[u][b + h + 2], t[4 + h]);
+#pragma unroll
+        for (int h = 0; h < 4; h++) dit_bf(a[u][h], a[u][h + 4], t[h]);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int h = 0; h < 8; h++) zb[h * 128 + u * 64 + lane] = a[u][h];
+    wave_lds_sync();
+}
+
+// ---- forward transform up to (not including) the last three stages ----------------------------------------------------------------
+// z: natural order, only the lower half non-zero (the upper half is not read).  NT threads call; the M / 16 first ones work.
+// Ends WITHOUT a block barrier (conv_mid starts with one).
+template <int LOG2M, int NT>
+__device__ __forceinline__ void conv_fwd(double2* z, const double2* __restrict__ tw, const double2* __restrict__ cft)
+{
+    constexpr int M = 1 << LOG2M, NA = M / 16, LW = LOG2M - 10, NB = 1 << LW;   // NA active threads, NB blocks of 1024
+    static_assert(LOG2M >= 11 && LOG2M <= 13, "2048, 4096 or 8192 points");
+    tw = conv_opaque(tw);
+    cft = conv_opaque(cft);
+    static_assert(NA <= NT, "16 points per thread");
+    const int t = conv_opaque((int)threadIdx.x);
+    if (NA == NT || t < NA) {
+#pragma unroll
+        for (int g = 0; g < 16 / NB; g++) {
+            const int i0 = t + NA * g;
+            double2 a[NB];
+#pragma unroll
+            for (int j = 0; j < NB / 2; j++) a[j] = z[j * 1025 + i0];
+            // first stage (span M / 2): the partners are zero
+#pragma unroll
+            for (int j = 0; j < NB / 2; j++) a[j + NB / 2] = cmul(a[j], tw[(i0 + 1024 * j) * (8 >> LW)]);
+#pragma unroll
+            for (int e = 1; e < LW; e++) {
+                const int half = NB >> (e + 1);
+#pragma unroll
+                for (int b = 0; b < NB; b += 2 * half)
+#pragma unroll
+                    for (int j = 0; j < half; j++) dif_bf(a[b + j], a[b + j + half], tw[(i0 + 1024 * j) * ((8 >> LW) << e)]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; j++) z[j * 1025 + i0] = a[j];
+        }
+    }
+    __syncthreads();
+    if (NA == NT || t < NA) {
+        double2* zb = z + (t >> 6) * 1025;
+        conv_p2_fwd(zb, cft, t & 63);
+        conv_p3_fwd(zb, cft, t & 63);
+    }
+}
+
+// real-transform split, product with the response spectrum, merge -- on the mirror pair (k, Mr - k) of the packed transform
+// (the arithmetic of round 3's spectrum pass)
+__device__ __forceinline__ void conv_pair_mul(double2& A, double2& B, const double2 Gk, const double2 Gm, const double2 wk)
+{
+    const double2 Bc = cconj(B);
+    const double2 Ee = cadd(A, Bc), D = csub(A, Bc);
+    const double2 O = make_double2(D.y, -D.x);
+    const double2 wO = cmul(wk, O);
+    const double2 Yk = cmul(cadd(Ee, wO), Gk);
+    const double2 Ymc = cconj(cmul(cconj(csub(Ee, wO)), Gm));
+    const double2 E2 = cadd(Yk, Ymc);
+    const double2 D2 = cmul(csub(Yk, Ymc), cconj(wk));
+    A = make_double2(E2.x - D2.y, E2.y + D2.x);
+    B = make_double2(E2.x + D2.y, D2.x - E2.y);
+}
+
+// ---- last three forward stages + spectrum product + first three inverse stages ------------------------------------------------------
+// G: response spectrum on the 2 FFT_MAX-point grid (bin k of the 2 M-point one at G[gs k], gs = FFT_MAX / M), w16[k] = exp(-i pi k /
+// FFT_MAX).  Thread k0 (1 <= k0 < M / 16) owns the bins k0 + j M/8 and their mirror partners (M/8 - k0) + j M/8; thread 0 the two
+// groups that are their own mirrors (k0 = 0 and M / 16).  Starts and ends with a block barrier.
+template <int LOG2M, int NT>
+__device__ __forceinline__ void conv_mid(double2* z, const double2* __restrict__ G, const double2* __restrict__ w16)
+{
+    constexpr int M = 1 << LOG2M, NA = M / 16, K = M / 8, LW = LOG2M - 10, gs = FFT_MAX / M;
+    const int t = conv_opaque((int)threadIdx.x);
+    w16 = conv_opaque(w16);
+    __syncthreads();
+    if (NA == NT || t < NA) {
+        const int kA = (t == 0) ? 0 : t, kB = (t == 0) ? K / 2 : K - t;
+        // block of bin group k0: the wave whose residue it is (bit-reversed), position inside: 8 (k0 >> LW)
+        const int wA = (LW == 3) ? br3(kA & 7) : (LW == 2 ? (((kA & 1) << 1) | ((kA >> 1) & 1)) : (kA & 1));
+        const int wB = (LW == 3) ? br3(kB & 7) : (LW == 2 ? (((kB & 1) << 1) | ((kB >> 1) & 1)) : (kB & 1));
+        double2* pa = z + wA * 1025 + 8 * (kA >> LW);
+        double2* pb = z + wB * 1025 + 8 * (kB >> LW);
+        double2 A[8], B[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) { A[c] = pa[c]; B[c] = pb[c]; }
+        dif8_tail(A);
+        dif8_tail(B);
+        if (t != 0) {
+            // w16 at the eight bins of a group from ONE table entry: bin k0 + m K is exp(-i pi m / 8) further round the circle (gs K =
+            // FFT_MAX / 8); the pairs are taken from their lower bin (w16 goes up to M / 2): kA + m K for m < 4, kB + (7 - m) K else
+            const double2 wA = w16[gs * kA], wB = w16[gs * kB];
+            const double2 c16_1 = make_double2(0.92387953251128675613, -0.38268343236508977173);   // exp(-i pi / 8)
+            const double2 c16_3 = make_double2(0.38268343236508977173, -0.92387953251128675613);   // exp(-3 i pi / 8)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {   // slot r of A: bin kA + K br3(r); its mirror M - that: slot 7 - r of B
+                const int m = br3(r);
+                if (r == 4) __builtin_amdgcn_sched_barrier(0);   // two batches of response loads (registers)
+                if (m < 4) {
+                    const int kn = kA + K * m;
+                    const double2 wk = (m == 0) ? wA : (m == 1 ? cmul(wA, c16_1) : (m == 2 ? mul_w8_1(wA) : cmul(wA, c16_3)));
+                    conv_pair_mul(A[r], B[7 - r], G[gs * kn], G[gs * (M - kn)], wk);
+                } else {
+                    const int kn = kB + K * (7 - m);
+                    const double2 wk = (m == 7) ? wB : (m == 6 ? cmul(wB, c16_1) : (m == 5 ? mul_w8_1(wB) : cmul(wB, c16_3)));
+                    conv_pair_mul(B[7 - r], A[r], G[gs * kn], G[gs * (M - kn)], wk);
+                }
+            }
+        } else {
+            // group 0: bins m K (slot br3(m)), mirror (8 - m) K: m = 0 and m = 4 are their own partners
+            { double2 c = A[0]; conv_pair_mul(A[0], c, G[0], G[gs * M], w16[0]); }
+            { double2 c = A[1]; conv_pair_mul(A[1], c, G[gs * (M / 2)], G[gs * (M / 2)], w16[gs * (M / 2)]); }
+            conv_pair_mul(A[4], A[7], G[gs * K], G[gs * (M - K)], w16[gs * K]);
+            conv_pair_mul(A[2], A[3], G[gs * 2 * K], G[gs * (M - 2 * K)], w16[gs * 2 * K]);
+            conv_pair_mul(A[6], A[5], G[gs * 3 * K], G[gs * (M - 3 * K)], w16[gs * 3 * K]);
+            // group K / 2: bins K / 2 + m K, mirror K / 2 + (7 - m) K: slot r with slot 7 - r
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {   // r = 0, 2, 4, 6: m = br3(r) < 4
+                const int kn = K / 2 + K * br3(r);
+                conv_pair_mul(B[r], B[7 - r], G[gs * kn], G[gs * (M - kn)], w16[gs * kn]);
+            }
+        }
+        dit8_head(A);
+        dit8_head(B);
+#pragma unroll
+        for (int c = 0; c < 8; c++) { pa[c] = A[c]; pb[c] = B[c]; }
+    }
+    __syncthreads();
+}
+
+// ---- the rest of the inverse transform: natural order out, ends with a block barrier -------------------------------------------------
+template <int LOG2M, int NT>
+__device__ __forceinline__ void conv_inv(double2* z, const double2* __restrict__ tw, const double2* __restrict__ cft)
+{
+    constexpr int M = 1 << LOG2M, NA = M / 16, LW = LOG2M - 10, NB = 1 << LW;
+    const int t = conv_opaque((int)threadIdx.x);
+    tw = conv_opaque(tw);
+    cft = conv_opaque(cft);
+    if (NA == NT || t < NA) {
+        double2* zb = z + (t >> 6) * 1025;
+        conv_p3_inv(zb, cft, t & 63);
+        conv_p2_inv(zb, cft, t & 63);
+    }
+    __syncthreads();
+    if (NA == NT || t < NA) {
+#pragma unroll
+        for (int g = 0; g < 16 / NB; g++) {
+            const int i0 = t + NA * g;
+            double2 a[NB];
+#pragma unroll
+            for (int j = 0; j < NB; j++) a[j] = z[j * 1025 + i0];
+#pragma unroll
+            for (int e = LW - 1; e >= 0; e--) {
+                const int half = NB >> (e + 1);
+#pragma unroll
+                for (int b = 0; b < NB; b += 2 * half)
+#pragma unroll
+                    for (int j = 0; j < half; j++) dit_bf(a[b + j], a[b + j + half], tw[(i0 + 1024 * j) * ((8 >> LW) << e)]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; j++) z[j * 1025 + i0] = a[j];
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace nrhip

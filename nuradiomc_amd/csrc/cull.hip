@@ -103,6 +103,12 @@ __global__ void index_to_i64_kernel(long n, const int* __restrict__ index, long 
     if (k < n) out[k] = offset + (index ? (long long)index[k] : (long long)k);
 }
 
+__global__ void gather_i64_kernel(long n, const int* __restrict__ index, const long long* __restrict__ src, long long* __restrict__ out)
+{
+    long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = src[index[k]];
+}
+
 inline unsigned blocks(long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -195,6 +201,16 @@ int nrhip_index_to_i64(nrhip_ctx* ctx, int64_t n, const int32_t* index, int64_t 
     if (n <= 0) return 0;
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(index_to_i64_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, (long)n, index, (long long)offset, (long long*)out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int nrhip_gather_i64(nrhip_ctx* ctx, int64_t n, const int32_t* index, const int64_t* src, int64_t* out)
+{
+    if (!ctx || (n > 0 && (!index || !src || !out))) return nrhip_fail_msg("nrhip_gather_i64: NULL argument");
+    if (n <= 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(gather_i64_kernel, dim3(blocks(n)), dim3(256), 0, ctx->stream, (long)n, index, (const long long*)src, (long long*)out);
     HIPCHK(hipGetLastError());
     return 0;
 }

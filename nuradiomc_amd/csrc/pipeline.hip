@@ -31,6 +31,20 @@ static int ensure_twiddle(nrhip_ctx* ctx)
         long double a = -3.14159265358979323846264338327950288L * (long double)k / (long double)FFT_MAX;
         h2[k] = make_double2((double)cosl(a), (double)sinl(a));
     }
+    // behind w16: the per-pass twiddle tables of the convolution kernel's wave-private transforms (conv_fft.h) -- entries of the
+    // master table h, so the butterflies see the same values whatever pass they are grouped into
+    for (int s = 0; s < 15; s++)
+        for (int l = 0; l < 64; l++) {
+            const int span = s < 8 ? 512 : (s < 12 ? 256 : (s < 14 ? 128 : 64));   // twiddle W_(2 span)^pos = h[pos * FFT_MAX / (2 span)]
+            const int pos = l + 64 * (s < 8 ? s : (s < 12 ? s - 8 : (s < 14 ? s - 12 : 0)));
+            h2.push_back(h[pos * (FFT_MAX / (2 * span))]);
+        }
+    for (int s = 0; s < 7; s++)
+        for (int c = 0; c < 8; c++) {
+            const int span = s < 4 ? 32 : (s < 6 ? 16 : 8);
+            const int pos = c + 8 * (s < 4 ? s : (s < 6 ? s - 4 : 0));
+            h2.push_back(h[pos * (FFT_MAX / (2 * span))]);
+        }
     HIPCHK(hipMalloc((void**)&ctx->w16, sizeof(double2) * h2.size()));
     HIPCHK(hipMemcpyAsync(ctx->w16, h2.data(), sizeof(double2) * h2.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1093,7 +1107,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     // (whether that pays depends on the workload -- few candidates, few followers: one launch less of everything; many candidates:
     // the second stage repeats fixed costs for little saved work -- so, like conv_mode, a station times one call of each and keeps
     // the faster; the bits are the same)
-    const bool two_stage_ok = !general && n_refl == 0 && !cfg->no_pruning;
+    // (not with dump_traces: there every active ray gets its exact max |e| and the followers of a second stage would only get a
+    // bound -- which scheme runs is a timing decision, and no fetchable table may depend on one)
+    const bool two_stage_ok = !general && n_refl == 0 && !cfg->no_pruning && !cfg->dump_traces;
     const bool att_tunable = two_stage_ok && n_rays >= 20000 && !getenv("NRHIP_ATT_ONE_STAGE") && !getenv("NRHIP_ATT_TWO_STAGE");
     int att_trial = -1;
     bool two_stage = two_stage_ok && st->att_mode != 2;
@@ -1107,9 +1123,11 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (n_rays > 0) {
         int *roff, *rtmp, *cflags;
         NEED(ractive = WS("ray_active", int, nr + 1));
-        NEED(cflags = WS("ray_active_class", int, 3 * nr + 1));
-        NEED(roff = WS("ray_active_offset", int, 3 * nr + 1));
-        NEED(rtmp = WS("scan_tmp2", int, scan_tiles(3L * n_rays + 1)));
+        // (the lists by predicted work count QC_NC classes per block of 256 rays: more than 3 n + 1 entries for a handful of rays)
+        const size_t n_cls = std::max<size_t>(3 * nr + 1, (size_t)quad_class_entries(n_rays));
+        NEED(cflags = WS("ray_active_class", int, n_cls));
+        NEED(roff = WS("ray_active_offset", int, n_cls));
+        NEED(rtmp = WS("scan_tmp2", int, scan_tiles((long)n_cls)));
         NEED(active_list = WS("ray_active_list", int, nr));
         launch_ray_limits_from_slots(sm, n_rays, n_ch, ray_slot, vertex, sd.pos, rec, ctx->ice, zint);
         LCHK("ray_limits");
@@ -1317,15 +1335,16 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     int n_followers = 0;
     if (two_stage && n_rays > 0 && n_active > 0) {
         int* fol_tmp;
+        const size_t n_fcls = std::max<size_t>(nr + 1, (size_t)quad_class_entries(n_rays));
         NEED(fol_flag = WS("follower_flag", int, nr + 1));
-        NEED(fol_off = WS("follower_offset", int, nr + 1));
-        NEED(fol_tmp = WS("scan_tmp9", int, scan_tiles((long)n_rays + 1)));
+        NEED(fol_off = WS("follower_offset", int, n_fcls));
+        NEED(fol_tmp = WS("scan_tmp9", int, scan_tiles((long)n_fcls)));
         NEED(fol_list = WS("follower_list", int, nr));
         if (!getenv("NRHIP_ATT_TYPE_CLASSES")) {   // like the first stage's list: in the order of the predicted quadrature work
             launch_follower_list(sm, (int)n_ev, ev, w.att, sd.n_fc, n_rays, fol_flag, fol_off, fol_tmp, nullptr, ractive);
             int* fol_counts;
             signed char* qcls;
-            NEED(fol_counts = WS("ray_active_class", int, 3 * nr + 1));
+            NEED(fol_counts = WS("ray_active_class", int, std::max<size_t>(3 * nr + 1, n_fcls)));
             NEED(qcls = WS("ray_quad_class", signed char, nr));
             launch_quad_class_list(sm, n_rays, fol_flag, w.slot, rec.type, w.C0, zint, ctx->ice, qcls, fol_counts, fol_off, fol_tmp, fol_list);
             LCHK("follower list");

@@ -15,6 +15,7 @@
 // Kernel roles and rooflines are in DESIGN.md; in short every kernel here is LDS/FP64 bound, not HBM bound:
 // per ray only ~0.5 KB of parameters enter and 8..100 B leave, the N- and L-point transforms never leave LDS.
 #include "fft_device.h"
+#include "conv_fft.h"
 #include "spectral.h"
 #include <cstdlib>
 
@@ -1999,14 +2000,14 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     __shared__ int s_scan[NT];
     __shared__ int s_first;
     const int N = st.N, nh = N / 2;
-    // the convolution buffer in the padded layout of fft_pad (bank-conflict-free strides of the fused passes and of the bit-reversed
-    // spectrum product): complex element i at PZ(i), real sample n at PS(n); the field buffer and the amplitudes sit behind the
-    // L <= FFT_MAX samples (FFT_MAX / 2 complex elements, padded) until the big transform starts
+    // the convolution buffer in the block-padded layout of conv_fft.h: complex element i at PZ(i), real sample n at PS(n); the field
+    // buffer and the amplitudes sit behind the L <= FFT_MAX samples (FFT_MAX / 2 complex elements, padded) until the big transform starts
     double2* z = (double2*)smem;
     double* S = (double*)smem;
-#define PZ(i) fft_pad(i)
-#define PS(n) (2 * fft_pad((n) >> 1) + ((n) & 1))
-    double2* xs = z + (fft_pad(M / 2) + 8);
+#define PZ(i) conv_pad(i)
+#define PS(n) (2 * conv_pad((n) >> 1) + ((n) & 1))
+    double2* xs = z + (conv_pad(M / 2) + 8);
+    const double2* cft = w16 + (FFT_MAX / 2 + 1);   // per-pass twiddle tables of conv_fft.h, behind w16
     // up to four transforms at a time: a group of NT / B threads per transform builds its spectrum (amplitudes on the fly,
     // bins k and N/2 - k together), ONE batched transform runs them all, the placements follow in ray order.  B is what fits the
     // 64 KB behind the event's samples: 4 transforms of <= 1024 points, 2 of 2048, 1 of 4096.
@@ -2014,7 +2015,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     __shared__ ConvJob s_jobs[64];
     __shared__ int s_njob, s_nadv;
     __shared__ double2 s_ramp4[BM][64 + FFT_MAX / 4 / 64 + 1];
-    // B is what fits behind the event's samples: (fft_pad(M) - fft_pad(M / 2) - 8) complex elements
+    // B is what fits behind the event's samples: M / 2 complex elements (conv_lds_elems)
     const int log2B = (LOG2CAP == FFT_LOG2_MAX) ? ((nh <= 1024) ? 2 : (nh <= 2048 ? 1 : 0)) : ((nh <= 1024) ? 1 : 0), B = 1 << log2B;
     __shared__ double red[NT / 64];   // block_max: one word per wave
     __shared__ int s_trig;
@@ -2265,34 +2266,14 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                   }
                 }
             }
-            for (int n = L + threadIdx.x; n < 2 * Mr; n += blockDim.x) S[PS(n)] = 0.;
+            // (only the lower half of the packed buffer is read by the forward transform: L <= Mr real samples, the rest is zero)
+            for (int n = L + threadIdx.x; n < Mr; n += blockDim.x) S[PS(n)] = 0.;
             __syncthreads();
             CT(5);
-            if (half_size) fft_dif_t<LOG2CAP - 1, NT, true>(z, tw, false);
-            else fft_dif_t<LOG2CAP, NT, true>(z, tw, false);
-            CT(6);
-            // split the packed transform into the real one, multiply with G, merge back -- in place on the
-            // bit-reversed positions of the pairs (k, M - k)
-            // (the response spectrum comes from HBM / L2: the entries of the next iteration are requested before the current one is used)
-            double2 nGk = G[gs * threadIdx.x], nGm = G[gs * (Mr - threadIdx.x)], nw = w16[gs * threadIdx.x];
-            for (int k = threadIdx.x; k <= Mr / 2; k += NT) {
-                const double2 Gk = nGk, Gm = nGm, wk = nw;
-                const int kn = k + NT;
-                if (kn <= Mr / 2) { nGk = G[gs * kn]; nGm = G[gs * (Mr - kn)]; nw = w16[gs * kn]; }
-                const int p = PZ(bitrev(k, log2Mr)), q = (k == 0) ? p : PZ(bitrev(Mr - k, log2Mr));
-                const double2 A = z[p], Bc = cconj(z[q]);
-                const double2 Ee = cadd(A, Bc), D = csub(A, Bc);
-                const double2 O = make_double2(D.y, -D.x);
-                const double2 wO = cmul(wk, O);
-                const double2 Yk = cmul(cadd(Ee, wO), Gk);
-                const double2 Ymc = cconj(cmul(cconj(csub(Ee, wO)), Gm));
-                const double2 E2 = cadd(Yk, Ymc);
-                const double2 D2 = cmul(csub(Yk, Ymc), cconj(wk));
-                z[p] = make_double2(E2.x - D2.y, E2.y + D2.x);
-                if (q != p) z[q] = make_double2(E2.x + D2.y, D2.x - E2.y);
-            }
-            if (multi) {  // sum the tables' contributions in the frequency domain (global scratch of this block)
-                __syncthreads();
+            // forward transform, real-transform split * G * merge, first stages of the inverse (conv_fft.h)
+            if (half_size) { conv_fwd<LOG2CAP - 1, NT>(z, tw, cft); CT(6); conv_mid<LOG2CAP - 1, NT>(z, G, w16); }
+            else { conv_fwd<LOG2CAP, NT>(z, tw, cft); CT(6); conv_mid<LOG2CAP, NT>(z, G, w16); }
+            if (multi) {  // sum the tables' contributions (the rest of the inverse is linear) in global scratch of this block
                 for (int k = threadIdx.x; k < Mr; k += blockDim.x) acc[k] = first_tab ? z[PZ(k)] : cadd(acc[k], z[PZ(k)]);
                 first_tab = false;
             }
@@ -2310,8 +2291,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             }
             __syncthreads();
             CT(7);
-            if (half_size) fft_dit_t<LOG2CAP - 1, NT, true>(z, tw, true);
-            else fft_dit_t<LOG2CAP, NT, true>(z, tw, true);
+            if (half_size) conv_inv<LOG2CAP - 1, NT>(z, tw, cft);
+            else conv_inv<LOG2CAP, NT>(z, tw, cft);
             CT(8);
             if (!coinc) {
                 double* const em = emitting ? out.emit + e_off + (long long)ch * L : nullptr;
@@ -2333,7 +2314,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     S[PS(n)] = v;
                 }
                 __syncthreads();
-                int* A = (int*)(S + 2 * (fft_pad(M / 2) + 8));  // index of the last raised flag at or before sample i (-1: none); behind the trace
+                int* A = (int*)(S + 2 * (conv_pad(M / 2) + 8));  // index of the last raised flag at or before sample i (-1: none); behind the trace
                 const int nb = (trg.type == 0) ? L : L - 1;
                 for (int i = threadIdx.x; i < nb; i += blockDim.x) {
                     bool flag;
@@ -3407,9 +3388,9 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)length_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               FFT_MAX * 16 + (FFT_MAX / 2 + 1) * 8);
-    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_PADDED_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_elems(FFT_MAX) * 16);
     (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX - 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              fft_pad_host(FFT_MAX / 2) * 16);
+                              conv_lds_elems(FFT_MAX / 2) * 16);
     (void)hipFuncSetAttribute((const void*)ray_envelope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)efield_channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
@@ -3489,13 +3470,13 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
             int blocks = channel_grid_blocks();
             if (getenv("NRHIP_CONV_SMALL_BLOCKS")) blocks = atoi(getenv("NRHIP_CONV_SMALL_BLOCKS"));
             const int cgrid = n_cand < blocks ? n_cand : blocks;
-            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX - 1>, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)fft_pad_host(FFT_MAX / 2) * 16, s,
+            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX - 1>, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)conv_lds_elems(FFT_MAX / 2) * 16, s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue, 0);
         }
         if (large) {
             const int cgrid = n_cand < channel_grid_blocks() / 2 ? n_cand : channel_grid_blocks() / 2;
-            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX>, dim3(cgrid), dim3(CONV_NT), (size_t)FFT_PADDED_MAX * 16, s,
+            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX>, dim3(cgrid), dim3(CONV_NT), (size_t)conv_lds_elems(FFT_MAX) * 16, s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue + (small ? 1 : 0),
                                small ? FFT_MAX / 2 : 0);

@@ -623,9 +623,9 @@ class Station:
             cap_n, cap_g = int(n_events), int(n_groups)
             vp = ctx.malloc
             ptrs = [vp(24 * cap_n), vp(8 * cap_n), vp(8 * cap_n), vp(8 * cap_n), vp(4 * cap_n), vp(8 * cap_n), vp(8 * cap_n),
-                    vp(8 * cap_n), vp(4 * cap_g), vp(4 * (cap_g + 1)), vp(max(cap_g, 1))]
+                    vp(8 * cap_n), vp(4 * cap_g), vp(4 * (cap_g + 1)), vp(max(cap_g, 1)), vp(8 * max(cap_g, 1))]
             sc = self._pass2 = dict(n=cap_n, g=cap_g, p=ptrs)
-        (s_vertex, s_zen, s_az, s_en, s_type, s_kL, s_md, s_vt, s_keep, s_gb, s_trig) = sc['p']
+        (s_vertex, s_zen, s_az, s_en, s_type, s_kL, s_md, s_vt, s_keep, s_gb, s_trig, s_gid64) = sc['p']
         nk, ns = ctypes.c_int64(0), ctypes.c_int64(0)
         L.check(lib.nrhip_select_groups(ctx._h, int(n_events), n_groups, d_group_begin, ctypes.c_void_p(d_triggered), s_keep, s_gb,
                                         ctypes.byref(nk), ctypes.byref(ns)))
@@ -636,6 +636,17 @@ class Station:
                                         d_kL, d_vertex_time, d_max_distance, s_vertex, s_zen, s_az, s_en, s_type, s_kL,
                                         s_vt if d_vertex_time is not None else None, s_md if d_max_distance is not None else None,
                                         None))
+        if kw.get('noise'):
+            # the noise of an event group is keyed by its ORIGINAL id (the pass that decided the trigger drew it under that id):
+            # the compact list carries the ids of the groups it was gathered from, not its own running index
+            kw = dict(kw)
+            d_ids = kw.pop('d_noise_group_id', None)
+            off = int(kw.pop('noise_group_offset', 0))
+            if d_ids is not None:
+                L.check(lib.nrhip_gather_i64(ctx._h, nk, s_keep, ctypes.c_void_p(d_ids), s_gid64))
+            else:
+                L.check(lib.nrhip_index_to_i64(ctx._h, nk, s_keep, off, s_gid64))
+            kw['d_noise_group_id'] = s_gid64
         stats = self.simulate_events_dev(ns, s_vertex, s_zen, s_az, s_en, s_type, s_kL, s_trig, dump_traces=True,
                                          amp_per_ray=amp_per_ray, n_groups=nk,
                                          d_group_begin=s_gb if d_group_begin is not None else None,

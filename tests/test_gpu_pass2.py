@@ -82,3 +82,46 @@ def test_traces_emitted_when_an_event_triggers(gpu_ctx_factory, flavour):
         assert len(part) == s3['n_emitted_events'] and all(np.array_equal(v, got[k]) for k, v in part.items())
     finally:
         bench.free_events(ctx, d)
+
+
+def test_device_pass2_carries_the_noise_of_pass1(gpu_ctx_factory):
+    """With thermal noise the traces pass 2 stores must be the ones pass 1 decided on: the noise of an event group is keyed by its
+    id in the ORIGINAL list, not by its place in the compact list of the triggered groups (nrhip_index_to_i64 /
+    nrhip_gather_i64).  Pass-2 traces == the traces of a dump_traces run over the whole list, with running ids and with ids given
+    by the caller."""
+    n = 12000
+    wl = bench.make_workload(2, n, 10, 'had')
+    ctx = gpu_ctx_factory(wl['ice'], wl['att_model'])
+    st = bench.build_array(ctx, wl)
+    st.set_noise(300.)
+    d = bench.upload_events(ctx, wl)
+    n_ch = len(wl['rel_pos'])
+    ids = (np.arange(n, dtype=np.int64) * 7 + 1000003)
+    d_ids = ctx.to_device(ids)
+    try:
+        for idkw in (dict(noise_group_offset=5000), dict(d_noise_group_id=d_ids)):
+            kw = dict(n_groups=d['n_groups'], d_group_begin=d['gb'], noise=True, noise_seed=77, **idkw)
+            st.simulate_events_dev(d['n'], *d['in'], d['trig'], dump_traces=True, **kw)
+            m_full = np.zeros(n, np.uint8)
+            ctx.to_host(m_full, d['trig'])
+            ie, tr, off, tb = (st.fetch(k).copy() for k in ('item_event', 'trace', 'trace_offset', 'ev_trigger_bin'))
+            s1 = st.simulate_events_dev(d['n'], *d['in'], d['trig'], **kw)
+            mask = np.zeros(n, np.uint8)
+            ctx.to_host(mask, d['trig'])
+            assert np.array_equal(mask, m_full) and s1['n_triggered'] > 20
+            s2, d_keep, nk = st.triggered_pass_dev(d['n'], *d['in'], d['trig'], **kw)
+            assert nk == mask.sum() and s2['n_triggered'] == nk
+            keep = np.zeros(nk, np.int32)
+            ctx.to_host(keep, d_keep)
+            ie2, tr2, off2, tb2 = (st.fetch(k) for k in ('item_event', 'trace', 'trace_offset', 'ev_trigger_bin'))
+            assert np.array_equal(ie2, np.arange(nk))
+            where = {int(g): i for i, g in enumerate(ie)}
+            for i, g in enumerate(keep):
+                j = where[int(g)]
+                a = tr[off[j * n_ch]:off[(j + 1) * n_ch]]
+                b = tr2[off2[i * n_ch]:off2[(i + 1) * n_ch]]
+                assert len(a) == len(b) and np.array_equal(a, b), (g, idkw)
+            assert np.array_equal(tb2[:nk], tb[keep])
+    finally:
+        ctx.free(d_ids)
+        bench.free_events(ctx, d)

@@ -93,7 +93,9 @@ def _tcp_worker(rank, world, port, backend, q, allow_tcp=True):
         q.put((rank, False, [], 0., 'error: ' + str(e)[:40]))
         return
     try:
-        c.allgather_masks(full[a:b].copy(), b - a + 1, n_total)   # not a shard_range shard: refused, not silently permuted
+        # ONE rank holds something that is no shard_range shard: refused on EVERY rank (the sizes are agreed on before the
+        # collective, so nobody is left waiting in it), not silently permuted
+        c.allgather_masks(full[a:b].copy(), b - a + (1 if rank == 1 else 0), n_total)
         q.put((rank, False, [], 0., 'no ValueError'))
         return
     except ValueError:
@@ -168,3 +170,53 @@ def test_comm_id_exchange_and_shard_helpers():
     t = np.array([100., 5000., 130., 5100., 9999.])
     assert list(sequencing.split_event_times(t, 1000.)) == [0, 1, 0, 1, 2]
     assert list(sequencing.split_event_times(t, 1e6)) == [0, 0, 0, 0, 0]
+
+
+def _run_bench(argv, env=None, timeout=900):
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_launches_ranks():
+    """`bench.py --gpus N` without a launcher starts N ranks itself (the reference's runner.py:53-87 starts N processes over a
+    split list); under a launcher whose WORLD_SIZE contradicts --gpus it exits non-zero instead of printing a line for a run that
+    never had N ranks.  --dry-run: no GPU, the ranks meet on the product's TCP star."""
+    import json
+    r = _run_bench(['--gpus', '3', '--dry-run', '--events', '1001'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [q for q in r.stdout.splitlines() if q.startswith('{')]
+    assert len(lines) == 1      # ONE line: rank 0's
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 3 and j['ranks'] == 3 and j['rank_sum'] == 3 and j['local_rank_sum'] == 3 and j['mask_ok']
+    r = _run_bench(['--gpus', '4', '--dry-run'], env=dict(WORLD_SIZE='2', RANK='0'))
+    assert r.returncode == 2 and 'WORLD_SIZE' in r.stderr and not r.stdout.strip()
+    # a failing rank fails the launch (here: no such option)
+    r = _run_bench(['--gpus', '2', '--dry-run', '--events', 'x'])
+    assert r.returncode != 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_through_the_launcher():
+    """shard -> barrier -> gather -> counters on hardware: `bench.py --gpus 2 --allow-tcp --scaling strong` on a one-GPU box (RCCL
+    refuses two ranks on one device, the vote fails, the collectives go over the star) gathers the same mask as the one-rank run
+    of the same list."""
+    import json
+    common = ['--events', '200000', '--scaling', 'strong', '--steps', '2', '--warmup', '1', '--no-cpu-baseline']
+    one = _run_bench(['--gpus', '1'] + common)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = _run_bench(['--gpus', '2', '--allow-tcp'] + common)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads([q for q in one.stdout.splitlines() if q.startswith('{')][-1])
+    j2 = json.loads([q for q in two.stdout.splitlines() if q.startswith('{')][-1])
+    assert j1['n_gpus'] == 1 and j2['n_gpus'] == 2
+    assert j2['config']['collectives'] in ('tcp', 'rccl')   # 'rccl' on a box with two GPUs
+    assert j1['config']['n_triggered_all'] == j2['config']['n_triggered_all'] > 0
+    assert j1['config']['gathered_mask_sha16'] == j2['config']['gathered_mask_sha16']
+    assert j2['config']['all_ranks']['n_pairs'] == j1['config']['all_ranks']['n_pairs']
+    # without --allow-tcp a run that cannot bring RCCL up on every rank exits non-zero (one GPU: two ranks on one device)
+    from nuradiomc_amd import _lib
+    if _lib.load().nrhip_device_count() == 1:
+        bad = _run_bench(['--gpus', '2'] + common)
+        assert bad.returncode != 0 and 'RCCL did not come up' in bad.stderr
