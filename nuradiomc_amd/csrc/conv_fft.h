@@ -30,7 +30,9 @@
 namespace nrhip {
 
 __device__ __forceinline__ int conv_pad(int i) { return i + (i >> 10); }
-__host__ __device__ constexpr int conv_lds_elems(int M) { return M + 16; }   // complex elements of the padded buffer
+// complex elements of the padded buffer: the M points + block padding, and behind the event's samples (M / 2 + padding) room for
+// the wave-private ray transforms (8 or 4 blocks of 512 points, block stride 532 / 520: ray_blk_stride)
+__host__ __device__ constexpr int conv_lds_elems(int M) { return M + (M >= 8192 ? 176 : 48); }
 constexpr int CFT_T2 = 0;             // [15][64]: W_1024^(l + 64 s) s < 8 | W_512^(l + 64 s) s < 4 | W_256^(l + 64 s) s < 2 | W_128^l
 constexpr int CFT_T3 = 15 * 64;       // [7][8]:   W_64^(c + 8 s) s < 4 | W_32^(c + 8 s) s < 2 | W_16^c
 constexpr int CFT_SIZE = CFT_T3 + 7 * 8;
@@ -59,6 +61,16 @@ __device__ __forceinline__ int conv_opaque(int t)
 {
     asm volatile("" : "+v"(t));
     return t;
+}
+
+// Block barrier for data that is handed over through LDS only: __syncthreads() also waits for every global store in flight (its
+// release fence covers all address spaces) -- with the traces of a triggered event streaming out to HBM that is a microsecond per
+// barrier.  Everything the threads of channel_conv_kernel hand to each other goes through LDS.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 __device__ __forceinline__ void dif_bf(double2& a, double2& b, const double2 w)
@@ -242,6 +254,80 @@ __device__ __forceinline__ void conv_p3_inv(double2* zb, const double2* __restri
     wave_lds_sync();
 }
 
+// ---- the rays' N / 2-point inverse transforms (N / 2 = 512, 1024, 2048), wave-private like the above --------------------------------
+// A transform of nh points is NBk = nh / 512 blocks of 512, one wave each, eight points per lane.  The spectrum is built by the
+// threads that do the first log2(NBk) stages across the blocks (channel_conv_kernel), then per wave: spans 256, 128, 64 (ray_p2),
+// spans 32, 16, 8 (ray_p3), and the last three stages are done by the threads that place the samples on the event's grid.
+// Decimation in frequency with the conjugate twiddles (inverse transform, unscaled): natural-order spectrum in, sample j at the
+// position that the passes leave it.
+__device__ __forceinline__ void dif_bf_c(double2& a, double2& b, const double2 w)   // (a - b) * conj(w)
+{
+    const double2 d = csub(a, b);
+    a = cadd(a, b);
+    b = make_double2(d.x * w.x + d.y * w.y, d.y * w.x - d.x * w.y);
+}
+__host__ __device__ constexpr int ray_blk_stride(int nbk) { return nbk == 4 ? 532 : 520; }
+// lane l holds l + 64 j (j < 8); written transposed: (l >> 3) 64 + (l & 7) + 8 j
+__device__ __forceinline__ void ray_p2(double2* zb, const double2* __restrict__ cft, int lane)
+{
+    double2 a[8], t[7];
+#pragma unroll
+    for (int s = 0; s < 7; s++) t[s] = cft[CFT_T2 + (8 + s) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = zb[lane + 64 * j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) dif_bf_c(a[j], a[j + 4], t[j]);
+#pragma unroll
+    for (int b = 0; b < 8; b += 4)
+#pragma unroll
+        for (int j = 0; j < 2; j++) dif_bf_c(a[b + j], a[b + j + 2], t[4 + j]);
+#pragma unroll
+    for (int b = 0; b < 8; b += 2) dif_bf_c(a[b], a[b + 1], t[6]);
+    wave_lds_sync();
+    const int wb = (lane >> 3) * 64 + (lane & 7);
+#pragma unroll
+    for (int j = 0; j < 8; j++) zb[wb + 8 * j] = a[j];
+    wave_lds_sync();
+}
+// lane (c = l & 7, j = l >> 3) holds the eight elements h; written at 65 c + x, x = br3(j) + 8 br3(h): row c of the block then
+// holds, in natural order of x, the groups of eight positions whose last three stages give the samples x' + (nh / 8) m
+__device__ __forceinline__ void ray_p3(double2* zb, const double2* __restrict__ cft, int lane)
+{
+    double2 a[8], t[7];
+    const int c = lane & 7, j = lane >> 3;
+#pragma unroll
+    for (int s = 0; s < 7; s++) t[s] = cft[CFT_T3 + s * 8 + c];
+#pragma unroll
+    for (int h = 0; h < 8; h++) a[h] = zb[h * 64 + lane];
+#pragma unroll
+    for (int h = 0; h < 4; h++) dif_bf_c(a[h], a[h + 4], t[h]);
+#pragma unroll
+    for (int b = 0; b < 8; b += 4)
+#pragma unroll
+        for (int h = 0; h < 2; h++) dif_bf_c(a[b + h], a[b + h + 2], t[4 + h]);
+#pragma unroll
+    for (int b = 0; b < 8; b += 2) dif_bf_c(a[b], a[b + 1], t[6]);
+    wave_lds_sync();
+    const int wb = 65 * c + br3(j);
+#pragma unroll
+    for (int h = 0; h < 8; h++) zb[wb + 8 * br3(h)] = a[h];
+}
+// last three stages (spans 4, 2, 1) with the conjugate twiddles
+__device__ __forceinline__ void dif8_tail_c(double2 (&a)[8])
+{
+    { double2 d; d = csub(a[0], a[4]); a[0] = cadd(a[0], a[4]); a[4] = d; }
+    { double2 d; d = csub(a[1], a[5]); a[1] = cadd(a[1], a[5]); a[5] = mul_w8_1c(d); }
+    { double2 d; d = csub(a[2], a[6]); a[2] = cadd(a[2], a[6]); a[6] = mul_w8_2c(d); }
+    { double2 d; d = csub(a[3], a[7]); a[3] = cadd(a[3], a[7]); a[7] = mul_w8_3c(d); }
+#pragma unroll
+    for (int b = 0; b < 8; b += 4) {
+        { double2 d; d = csub(a[b], a[b + 2]); a[b] = cadd(a[b], a[b + 2]); a[b + 2] = d; }
+        { double2 d; d = csub(a[b + 1], a[b + 3]); a[b + 1] = cadd(a[b + 1], a[b + 3]); a[b + 3] = mul_w8_2c(d); }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b += 2) dif_bf1(a[b], a[b + 1]);
+}
+
 // ---- forward transform up to (not including) the last three stages ----------------------------------------------------------------
 // z: natural order, only the lower half non-zero (the upper half is not read).  NT threads call; the M / 16 first ones work.
 // Ends WITHOUT a block barrier (conv_mid starts with one).
@@ -276,7 +362,7 @@ __device__ __forceinline__ void conv_fwd(double2* z, const double2* __restrict__
             for (int j = 0; j < NB; j++) z[j * 1025 + i0] = a[j];
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (NA == NT || t < NA) {
         double2* zb = z + (t >> 6) * 1025;
         conv_p2_fwd(zb, cft, t & 63);
@@ -310,7 +396,7 @@ __device__ __forceinline__ void conv_mid(double2* z, const double2* __restrict__
     constexpr int M = 1 << LOG2M, NA = M / 16, K = M / 8, LW = LOG2M - 10, gs = FFT_MAX / M;
     const int t = conv_opaque((int)threadIdx.x);
     w16 = conv_opaque(w16);
-    __syncthreads();
+    lds_barrier();
     if (NA == NT || t < NA) {
         const int kA = (t == 0) ? 0 : t, kB = (t == 0) ? K / 2 : K - t;
         // block of bin group k0: the wave whose residue it is (bit-reversed), position inside: 8 (k0 >> LW)
@@ -323,46 +409,57 @@ __device__ __forceinline__ void conv_mid(double2* z, const double2* __restrict__
         for (int c = 0; c < 8; c++) { A[c] = pa[c]; B[c] = pb[c]; }
         dif8_tail(A);
         dif8_tail(B);
-        if (t != 0) {
-            // w16 at the eight bins of a group from ONE table entry: bin k0 + m K is exp(-i pi m / 8) further round the circle (gs K =
-            // FFT_MAX / 8); the pairs are taken from their lower bin (w16 goes up to M / 2): kA + m K for m < 4, kB + (7 - m) K else
-            const double2 wA = w16[gs * kA], wB = w16[gs * kB];
-            const double2 c16_1 = make_double2(0.92387953251128675613, -0.38268343236508977173);   // exp(-i pi / 8)
-            const double2 c16_3 = make_double2(0.38268343236508977173, -0.92387953251128675613);   // exp(-3 i pi / 8)
+        // Eight mirror pairs per thread.  Thread k0: slot r of A (bin kA + K br3(r)) with slot 7 - r of B, taken from the pair's lower
+        // bin (w16 goes up to M / 2): kA + m K for m = br3(r) < 4, kB + (7 - m) K else; w16 at those bins from ONE table entry per
+        // group (bin k0 + m K is exp(-i pi m / 8) further round the circle: gs K = FFT_MAX / 8).  Thread 0 owns the groups that are
+        // their own mirrors -- group 0: bins m K, mirror (8 - m) K, m = 0 and 4 alone; group K / 2: slot r with slot 7 - r -- and
+        // runs them through the SAME eight slots (operands and results dealt by selects: a branch of its own made wave 0, and
+        // every wave at the barrier behind it, take twice the time), plus one ninth product for the bin that is left (M / 2).
+        const bool sp = t == 0;
+        const double2 wkA = w16[gs * kA], wkB = w16[gs * kB];   // thread 0: 1 and exp(-i pi / 16)
+        const double2 c16_1 = make_double2(0.92387953251128675613, -0.38268343236508977173);   // exp(-i pi / 8)
+        const double2 c16_3 = make_double2(0.38268343236508977173, -0.92387953251128675613);   // exp(-3 i pi / 8)
+        auto sel = [&](const double2 x, const double2 y) { return make_double2(sp ? x.x : y.x, sp ? x.y : y.y); };
+        // In place, slot by slot (a slot reads and writes the same two elements, for either kind of thread; the selects keep the
+        // element of the other kind).  General: slot r = (A[r], B[7 - r]), X the lower bin's.  Thread 0: m = br3(r) < 4: group 0's pair
+        // (A[r], A[br3(8 - m)]), bin 0 alone in slot 0 (its partner a copy); m >= 4: group K / 2's pair m' = 7 - m: (B[br3(m')],
+        // B[7 - br3(m')]).  Bin M / 2 (A[1]) is the one left over for thread 0: its own partner.
 #pragma unroll
-            for (int r = 0; r < 8; r++) {   // slot r of A: bin kA + K br3(r); its mirror M - that: slot 7 - r of B
-                const int m = br3(r);
-                if (r == 4) __builtin_amdgcn_sched_barrier(0);   // two batches of response loads (registers)
-                if (m < 4) {
-                    const int kn = kA + K * m;
-                    const double2 wk = (m == 0) ? wA : (m == 1 ? cmul(wA, c16_1) : (m == 2 ? mul_w8_1(wA) : cmul(wA, c16_3)));
-                    conv_pair_mul(A[r], B[7 - r], G[gs * kn], G[gs * (M - kn)], wk);
-                } else {
-                    const int kn = kB + K * (7 - m);
-                    const double2 wk = (m == 7) ? wB : (m == 6 ? cmul(wB, c16_1) : (m == 5 ? mul_w8_1(wB) : cmul(wB, c16_3)));
-                    conv_pair_mul(B[7 - r], A[r], G[gs * kn], G[gs * (M - kn)], wk);
-                }
+        for (int r = 0; r < 8; r++) {
+            const int m = br3(r);
+            if (r == 4) __builtin_amdgcn_sched_barrier(0);   // two batches of response loads (registers)
+            const int kn = (m < 4) ? kA + K * m : kB + K * (7 - m);
+            const double2 wb = (m < 4) ? wkA : wkB;
+            const int mm = (m < 4) ? m : 7 - m;
+            const double2 wk = (mm == 0) ? wb : (mm == 1 ? cmul(wb, c16_1) : (mm == 2 ? mul_w8_1(wb) : cmul(wb, c16_3)));
+            const double2 Gk = G[gs * kn], Gm = G[gs * (M - kn)];
+            if (m < 4) {
+                const int s1 = (m == 0) ? 0 : br3(8 - m);          // thread 0's partner slot in A (slot 0: a copy of itself)
+                double2 x = A[r], y = sel(A[s1], B[7 - r]);
+                conv_pair_mul(x, y, Gk, Gm, wk);
+                A[r] = x;
+                B[7 - r] = sel(B[7 - r], y);
+                if (m != 0) A[s1] = sel(y, A[s1]);
+            } else {
+                // thread 0: group K / 2's pair m' = 7 - m sits in (B[br3(m')], B[7 - br3(m')]) = (B[7 - r], B[r]): the lower bin's
+                // element is the same register as for the others, the partner B[r] instead of A[r]
+                double2 x = B[7 - r], y = sel(B[r], A[r]);
+                conv_pair_mul(x, y, Gk, Gm, wk);
+                B[7 - r] = x;
+                A[r] = sel(A[r], y);
+                B[r] = sel(y, B[r]);
             }
-        } else {
-            // group 0: bins m K (slot br3(m)), mirror (8 - m) K: m = 0 and m = 4 are their own partners
-            { double2 c = A[0]; conv_pair_mul(A[0], c, G[0], G[gs * M], w16[0]); }
-            { double2 c = A[1]; conv_pair_mul(A[1], c, G[gs * (M / 2)], G[gs * (M / 2)], w16[gs * (M / 2)]); }
-            conv_pair_mul(A[4], A[7], G[gs * K], G[gs * (M - K)], w16[gs * K]);
-            conv_pair_mul(A[2], A[3], G[gs * 2 * K], G[gs * (M - 2 * K)], w16[gs * 2 * K]);
-            conv_pair_mul(A[6], A[5], G[gs * 3 * K], G[gs * (M - 3 * K)], w16[gs * 3 * K]);
-            // group K / 2: bins K / 2 + m K, mirror K / 2 + (7 - m) K: slot r with slot 7 - r
-#pragma unroll
-            for (int r = 0; r < 8; r += 2) {   // r = 0, 2, 4, 6: m = br3(r) < 4
-                const int kn = K / 2 + K * br3(r);
-                conv_pair_mul(B[r], B[7 - r], G[gs * kn], G[gs * (M - kn)], w16[gs * kn]);
-            }
+        }
+        if (sp) {
+            double2 c = A[1];
+            conv_pair_mul(A[1], c, G[gs * (M / 2)], G[gs * (M / 2)], w16[gs * (M / 2)]);
         }
         dit8_head(A);
         dit8_head(B);
 #pragma unroll
         for (int c = 0; c < 8; c++) { pa[c] = A[c]; pb[c] = B[c]; }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // ---- the rest of the inverse transform: natural order out, ends with a block barrier -------------------------------------------------
@@ -378,7 +475,7 @@ __device__ __forceinline__ void conv_inv(double2* z, const double2* __restrict__
         conv_p3_inv(zb, cft, t & 63);
         conv_p2_inv(zb, cft, t & 63);
     }
-    __syncthreads();
+    lds_barrier();
     if (NA == NT || t < NA) {
 #pragma unroll
         for (int g = 0; g < 16 / NB; g++) {
@@ -398,7 +495,7 @@ __device__ __forceinline__ void conv_inv(double2* z, const double2* __restrict__
             for (int j = 0; j < NB; j++) z[j * 1025 + i0] = a[j];
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 }  // namespace nrhip

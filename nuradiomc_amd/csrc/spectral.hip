@@ -719,6 +719,19 @@ __device__ inline double block_max(double v, double* red)
     return r;
 }
 
+// the same with barriers that order LDS only (channel_conv_kernel: global stores of emitted traces stay in flight)
+__device__ inline double block_max_lds(double v, double* red)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    const int nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    lds_barrier();
+    double r = red[0];
+    for (int i = 1; i < nw; i++) r = fmax(r, red[i]);
+    lds_barrier();
+    return r;
+}
+
 __device__ inline double cabs2(double2 a) { return sqrt(a.x * a.x + a.y * a.y); }
 
 // max |E(t)| <= (fs / sqrt 2) (1 / N) 2 sum_k |G_k|,  |G_k| = sqrt 2 |pol r| amp_k   (triangle inequality on irfft)
@@ -1956,6 +1969,7 @@ __global__ void channel_event_flags_kernel(int n_cand, int n_ch, const int* __re
 #define CONV_NT 512
 #endif
 #define CONV_MAX_ORDER 64  // stations with more channels are evaluated in channel order
+#define CONV_STAGE_RAYS 192  // rays of an event whose channel / antenna-table numbers are kept in LDS (more: read from HBM per channel)
 // threads per block: 512 for the full-capacity kernel (one block per CU), 256 for the half-capacity one (two blocks per CU: the same
 // eight waves per CU, each with the 256 registers the transforms want, but two independent barrier domains)
 #define CONV_THREADS(log2cap) ((log2cap) == FFT_LOG2_MAX ? CONV_NT : CONV_NT / 2)
@@ -1976,6 +1990,180 @@ __device__ inline double conv_amplitude(int k, int nh, double df, const StationD
         return rs.ask.pref2 * f / ((1 + x) * (1 + y)) * interp_seg(f, seg, st.n_fc, rs.xp, rs.att, rs.slope);
     }
     return amplitude_bin(k, f, rs.ask, st) * interp_seg(f, seg, st.n_fc, rs.xp, rs.att, rs.slope);
+}
+// ---- wave-private ray transforms of the convolution kernel (conv_fft.h): spectrum + first stages, and last stages + placement ----
+// The rare emission models (Alvarez2000, ZHS1992: exp / log per bin, ZHS's own phase) stay out of line: inlined into every bin of
+// every unrolled item they made the kernel three times its size (instruction fetch) for a path the surveys never take.
+__device__ __noinline__ double conv_amplitude_rare(int k, double f, const AskaryanConst* a, const double* lnf)
+{
+    return askaryan_amplitude(f, lnf[k], *a);
+}
+__device__ __noinline__ double2 conv_zhs_phase(int k, double roll, int N)
+{
+    double sn, cs;
+    sincospi(-2.0 * k * roll / N, &sn, &cs);
+    return make_double2(-sn, cs);
+}
+// The packed spectrum x_k = ge_k + i go_k of field_time_domain() is built by the thread that runs the first log2(NBK) stages on it:
+// item i0 (0 < i0 < 256) owns the bins i0 + 512 j of the transform and their mirror partners nh - k = (512 - i0) + 512 (NBK - 1 - j)
+// (both members of a mirror pair need both amplitudes); item 0 the two groups that are their own mirrors (i0 = 0 and 256).  The phase
+// ramp exp(-2 pi i f_k rem) of the sub-sample shift comes from two sincospi per thread (bin lt and the thread stride) and products.
+template <int NBK>
+__device__ __forceinline__ void ray_build(double2* xjob, int lt, const ConvJob& job, const RayShared& rg, const StationDev& st,
+                                          int ask_model, const double2* __restrict__ tw, int log2nh)
+{
+    constexpr int TR = 64 * NBK, IT = 4 / NBK, LWR = (NBK == 4) ? 2 : 1, BS = ray_blk_stride(NBK);
+    static_assert(NBK == 2 || NBK == 4, "N / 2 = 1024 or 2048");
+    const int N = st.N, nh = N / 2, stride = nh + 1, off_l = rg.ask.had ? 0 : stride;
+    const double df = 1.0 / (N * (1. / st.fs));
+    const bool m0 = rg.ask.model == 0;
+    const double roll = floor(2.0 * st.fs);
+    const int twn = FFT_MAX / N;
+    const double al = job.shift ? -2. * job.rem * df : 0.;
+    double2 rho_a = make_double2(1., 0.), rho_t = rho_a, rho_512 = rho_a, rho_nh = rho_a;
+    if (job.shift) {
+        double sn, cs;
+        sincospi(al * lt, &sn, &cs);
+        rho_a = make_double2(cs, sn);
+        sincospi(al * TR, &sn, &cs);
+        rho_t = make_double2(cs, sn);
+        const double2 r2 = cmul(rho_t, rho_t), r4 = cmul(r2, r2);
+        rho_nh = cmul(r4, r4);                           // nh = 8 TR
+        rho_512 = (NBK == 4) ? r2 : r4;
+    }
+    // station tables of a mirror pair (k, nh - k), 0 < k < nh: requested for all pairs of an item before the first is used
+    struct PairIn { double pl1, pr1, pl2, pr2; int sg1, sg2; double2 w1, w2; };
+    auto pair_load = [&](int k) -> PairIn {
+        const int k2 = nh - k;
+        PairIn q;
+        q.pl1 = st.fpow[off_l + k]; q.pr1 = st.fpow[2 * stride + k]; q.sg1 = st.seg[k]; q.w1 = tw[k * twn];
+        q.pl2 = st.fpow[off_l + k2]; q.pr2 = st.fpow[2 * stride + k2]; q.sg2 = st.seg[k2]; q.w2 = tw[k2 * twn];
+        return q;
+    };
+    // amplitude X_k att(f_k) (conv_amplitude), 0 < k < nh; the quotient through a reciprocal estimate and two Newton steps (~1 ulp)
+    auto ampl = [&](int k, double pl, double pr, int seg) -> double {
+        const double f = k * df;
+        const double at = interp_seg(f, seg, st.n_fc, rg.xp, rg.att, rg.slope);
+        if (m0) {
+            const double x = pl * rg.ask.cL, y = pr * rg.ask.cR;
+            const double den = (1 + x) * (1 + y);
+            double rc = __builtin_amdgcn_rcp(den);
+            rc = fma(fma(-den, rc, 1.0), rc, rc);
+            rc = fma(fma(-den, rc, 1.0), rc, rc);
+            return rg.ask.pref2 * f * rc * at;
+        }
+        return conv_amplitude_rare(k, f, &rg.ask, st.lnf) * at;
+    };
+    // one on-sky component's spectrum bin (field_bin with the ramp value handed in), 0 < k < nh
+    auto fbin = [&](int k, double amp, const double2 rk) -> double2 {
+        const double a = amp * 1.4142135623730951;
+        double2 sv = make_double2(0., (k & 1) ? -a : a);
+        if (ask_model == 2) sv = cscale(conv_zhs_phase(k, roll, N), a);
+        sv = cscale(sv, job.pol);
+        sv = cmul(sv, job.rc);
+        if (job.shift) sv = cmul(sv, rk);
+        return sv;
+    };
+    // packed values of the mirror pair (k, nh - k); rk = ramp at bin k
+    auto pair = [&](int k, const PairIn& q, const double2 rk, double2& Xk, double2& Xm) {
+        const int k2 = nh - k;
+        const double2 F1 = fbin(k, ampl(k, q.pl1, q.pr1, q.sg1), rk);
+        const double2 F2 = fbin(k2, ampl(k2, q.pl2, q.pr2, q.sg2), cmul(rho_nh, cconj(rk)));
+        {
+            const double2 Gc = cconj(F2);
+            const double2 ge = cscale(cadd(F1, Gc), 0.5), d = cscale(csub(F1, Gc), 0.5);
+            const double2 go = cmul(d, cconj(q.w1));
+            Xk = make_double2(ge.x - go.y, ge.y + go.x);
+        }
+        {
+            const double2 Gc = cconj(F1);
+            const double2 ge = cscale(cadd(F2, Gc), 0.5), d = cscale(csub(F2, Gc), 0.5);
+            const double2 go = cmul(d, cconj(q.w2));
+            Xm = make_double2(ge.x - go.y, ge.y + go.x);
+        }
+    };
+    // first LWR stages (spans nh / 2 .. 512) of the inverse transform on the group at i0 (elements i0 + 512 j), then store
+    auto stages_store = [&](double2 (&a)[NBK], int i0) {
+#pragma unroll
+        for (int e = 0; e < LWR; e++) {
+            const int half = NBK >> (e + 1);
+#pragma unroll
+            for (int b = 0; b < NBK; b += 2 * half)
+#pragma unroll
+                for (int q = 0; q < half; q++) dif_bf_c(a[b + q], a[b + q + half], tw[(i0 + 512 * q) * (FFT_MAX >> (log2nh - e))]);
+        }
+#pragma unroll
+        for (int j = 0; j < NBK; j++) xjob[j * BS + i0] = a[j];
+    };
+    // Item 0 takes the two groups that are their own mirrors: bins 256 (j + 1), j < NBK, pair up as (256, nh - 256), (512, nh - 512),
+    // ... (nh / 2 with itself; bin 0 is empty) -- as many pairs as any other item has, computed by the SAME instructions with other
+    // bin numbers and ramps, the results dealt to the two groups by selects: a branch of its own made the item's wave (and with it
+    // every wave at the barrier behind) take twice the time.
+    const double2 rho_256 = (NBK == 4) ? rho_t : cmul(rho_t, rho_t);
+    double2 rho_i = rho_a;
+#pragma unroll 1
+    for (int u = 0; u < IT; u++) {
+        const int i0 = lt + TR * u;
+        const bool sp = i0 == 0;
+        double2 P[NBK], Q[NBK];
+        {
+            // (the station tables of pair j + 1 are requested before pair j is evaluated: two pairs' worth of registers, not NBK)
+            double2 g = rho_i, q = rho_256;
+            PairIn nxt = pair_load(sp ? 256 : i0);
+#pragma unroll
+            for (int j = 0; j < NBK; j++) {
+                const int kj = sp ? 256 * (j + 1) : i0 + 512 * j;
+                const PairIn cur = nxt;
+                if (j + 1 < NBK) {
+                    nxt = pair_load(sp ? 256 * (j + 2) : i0 + 512 * (j + 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                pair(kj, cur, make_double2(sp ? q.x : g.x, sp ? q.y : g.y), P[j], Q[j]);
+                g = cmul(g, rho_512);
+                q = cmul(q, rho_256);
+            }
+        }
+        double2 A[NBK], B[NBK];
+        const double2 zero = make_double2(0., 0.);
+        auto sel = [&](const double2 x, const double2 y) { return make_double2(sp ? x.x : y.x, sp ? x.y : y.y); };
+        if (NBK == 4) {
+            // general: A[j] = X[i0 + 512 j] = P[j], B[3 - j] = Q[j];  item 0 (P[j] = X[256 (j + 1)], Q[j] = X[nh - 256 (j + 1)]):
+            // A = X[0, 512, 1024, 1536] = {0, P1, P3, Q1}, B = X[256, 768, 1280, 1792] = {P0, P2, Q2, Q0}
+            A[0] = sel(zero, P[0]); A[1] = P[1]; A[2] = sel(P[3], P[2]); A[3] = sel(Q[1], P[3]);
+            B[0] = sel(P[0], Q[3]); B[1] = sel(P[2], Q[2]); B[2] = sel(Q[2], Q[1]); B[3] = Q[0];
+        } else {
+            // general: A = {P0, P1}, B = {Q1, Q0};  item 0: A = X[0, 512] = {0, P1}, B = X[256, 768] = {P0, Q0}
+            A[0] = sel(zero, P[0]); A[1] = P[1];
+            B[0] = sel(P[0], Q[1]); B[1] = Q[0];
+        }
+        stages_store(A, i0);
+        stages_store(B, sp ? 256 : 512 - i0);
+        rho_i = cmul(rho_i, rho_t);
+    }
+}
+// last three stages of a ray's transform + placement of its samples on the event's grid: thread lt owns the samples lt + (nh / 8) m
+template <int NBK>
+__device__ __forceinline__ void ray_place(const double2* xjob, int lt, int nh, const ConvJob& jq, double* S, int L)
+{
+    constexpr int LWR = (NBK == 4) ? 2 : 1, BS = ray_blk_stride(NBK);
+    const int blk = (NBK == 4) ? (((lt & 1) << 1) | ((lt >> 1) & 1)) : (lt & 1);
+    const double2* zb = xjob + blk * BS + (lt >> LWR);
+    double2 a[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) a[c] = zb[65 * c];
+    dif8_tail_c(a);
+    const double sc = jq.vfac / nh;   // the fs / sqrt(2) of freq2time cancels against time2freq's sqrt(2) / fs
+    const int K = nh >> 3;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int j = lt + K * br3(r);
+        int i0 = jq.sbin + 2 * j;
+        if (i0 >= L) i0 -= L;
+        int i1 = i0 + 1;
+        if (i1 >= L) i1 -= L;
+        S[2 * conv_pad(i0 >> 1) + (i0 & 1)] += a[r].x * sc;
+        S[2 * conv_pad(i1 >> 1) + (i1 & 1)] += a[r].y * sc;
+    }
 }
 // LOG2CAP: log2 of the complex points the LDS buffer holds.  13 (FFT_MAX): any event of up to FFT_MAX samples, 133 KB, one block per
 // CU.  12: events of up to FFT_MAX / 2 samples only (the N = 2048 workloads), 68 KB + 9 KB static: TWO blocks per CU, so one block's
@@ -2017,16 +2205,26 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     __shared__ double2 s_ramp4[BM][64 + FFT_MAX / 4 / 64 + 1];
     // B is what fits behind the event's samples: M / 2 complex elements (conv_lds_elems)
     const int log2B = (LOG2CAP == FFT_LOG2_MAX) ? ((nh <= 1024) ? 2 : (nh <= 2048 ? 1 : 0)) : ((nh <= 1024) ? 1 : 0), B = 1 << log2B;
-    __shared__ double red[NT / 64];   // block_max: one word per wave
-    __shared__ int s_trig;
+    // wave-private ray transforms for N / 2 = 1024, 2048 (other lengths: the batched block-wide transform below)
+    const int NBKr = nh >> 9, TR = nh >> 3;
+#ifdef NRHIP_CONV_OLD_RAYS   // build variant for A / B measurements
+    const bool wave_rays = false;
+#else
+    const bool wave_rays = (nh == 1024 || nh == 2048) && TR <= NT;
+#endif
+    const int Bw = wave_rays ? min(BM, NT / TR) : 0;
+    __shared__ double red2[2][NT / 64];   // channel maximum: one word per wave, two phases' worth (see the flags phase)
+    __shared__ int s_trig2[2];
+    if (threadIdx.x == 0) { s_trig2[0] = 0; s_trig2[1] = 0; }
+    int flag_par = 0;
     const int n_list_events = *n_list;
     // unit of work: one candidate event; its channels are evaluated in sequence and -- the trigger being an OR over
     // channels -- the remaining ones are skipped (maxV = NaN) once one has triggered, unless every trace is wanted
-    __shared__ int s_ev_trig;
     __shared__ long long s_emit_off;
     // The channels an event still needs, strongest Cauchy-Schwarz bound first: the trigger is an OR over the channels, so the
     // one most likely to fire ends the event soonest (any order gives the same mask).  Built by thread 0 per event; two
     // buffers, because a wave may run ahead through the barrier-free skip path into the next event's set-up.
+    __shared__ unsigned short s_rct[CONV_STAGE_RAYS];   // (channel << 4) | antenna table of the event's rays
     __shared__ short s_order[2][CONV_MAX_ORDER];
     __shared__ int s_norder[2];
     const bool best_first = !exact && !coinc && st.n_ch <= CONV_MAX_ORDER;
@@ -2038,7 +2236,6 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       if (threadIdx.x == 0) {
           const int le0 = atomicAdd(queue, 1);
           s_le[par] = le0;
-          s_ev_trig = 0;
           int cnt_o = 0;
           const int base = (le0 < n_list_events ? item_list[le0] : 0) * st.n_ch;
           // the two instantiations share one list: each takes the events of its length class (l_min < L <= M); the others cost
@@ -2060,14 +2257,44 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
           }
           s_norder[par] = cnt_o;
       }
-      __syncthreads();
+      lds_barrier();
       const int le = s_le[par];
       if (le >= n_list_events) break;
       if (s_norder[par] < 0) continue;   // an event of the other length class
+      const int ev_item0 = item_list[le] * st.n_ch;
       const int ev_e = item_event[item_list[le]], ev_L = ev.L[ev_e];
+      // Touch what the channel steps of this event will read from HBM -- the rays' emission constants, attenuation rows and per-ray
+      // scalars, one word per 64 bytes -- so that ONE round trip brings all of it into the L2 while the block sets up; the steps'
+      // own dependent loads (ray list, job constants) then take L2 latencies.  The sum is only there to keep the loads.
+      int touch_acc = 0;
+      {
+          const int r0e = ev.ray_begin[ev_e], nre = ev.n_rays[ev_e];
+          const char* pa = (const char*)(w.ask + r0e);
+          for (long i = (long)threadIdx.x * 64; i < (long)nre * (long)sizeof(AskaryanConst); i += (long)NT * 64) touch_acc += *(const int*)(pa + i);
+          const char* pt = (const char*)(w.att + (long)r0e * st.n_fc);
+          for (long i = (long)threadIdx.x * 64; i < (long)nre * st.n_fc * 8; i += (long)NT * 64) touch_acc += *(const int*)(pt + i);
+          if (threadIdx.x < 9 * 8) {
+              const int which = threadIdx.x >> 3, part = threadIdx.x & 7;
+              const char* pb = which == 0 ? (const char*)(w.ch + r0e) : which == 1 ? (const char*)(w.tab + r0e) :
+                               which == 2 ? (const char*)(w.vfac_t + r0e) : which == 3 ? (const char*)(w.vfac_p + r0e) :
+                               which == 4 ? (const char*)(w.r_theta + r0e) : which == 5 ? (const char*)(w.r_phi + r0e) :
+                               which == 6 ? (const char*)(w.pol_theta + r0e) : which == 7 ? (const char*)(w.pol_phi + r0e) :
+                               (const char*)(w.t0 + r0e);
+              const int el = which < 2 ? 4 : ((which == 4 || which == 5) ? 16 : 8);
+              if (part * 64 < nre * el) touch_acc += *(const int*)(pb + part * 64);
+          }
+      }
+      // what every channel step of the event needs: read once (the steps used to fetch these scalars, and walk the rays' channel and
+      // antenna-table numbers in HBM, one dependent load after the other, per channel)
+      const int evx_il = ev_len_index[ev_e], evx_r0 = ev.ray_begin[ev_e], evx_r1 = evx_r0 + ev.n_rays[ev_e];
+      const double evx_t_min = ev.t_min[ev_e];
+      const bool rays_staged = evx_r1 - evx_r0 <= CONV_STAGE_RAYS;
+      if (rays_staged)
+          for (int i = threadIdx.x; i < evx_r1 - evx_r0; i += blockDim.x) s_rct[i] = (unsigned short)((w.ch[evx_r0 + i] << 4) | w.tab[evx_r0 + i]);
+      lds_barrier();
       if (coinc) {
           for (int n = threadIdx.x; n < ev_L; n += blockDim.x) cnt[n] = 0;
-          __syncthreads();
+          lds_barrier();
       }
       // has an earlier channel of this event triggered?  A per-thread copy, refreshed between two barriers after every
       // evaluated channel: the shared flag itself may already have been reset for the NEXT event by a wave that ran ahead
@@ -2090,16 +2317,16 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             ch = step;
             if (ch == c_star) continue;   // its trace went out when it triggered
         }
-        const int item = item_list[le] * st.n_ch + ch;
-        if (!emitting && !need[item]) continue;
+        const int item = ev_item0 + ch;
+        if (!emitting && !best_first && !need[item]) continue;   // (the ordered list holds the needed channels only)
         const bool ch_on = !st.trig_on || st.trig_on[ch];  // triggered_channels of the reference's trigger modules
-        const int e = item_event[item / st.n_ch];
+        const int e = ev_e;
         if (!emitting && !exact && !coinc && ev_trig) {
             if (threadIdx.x == 0) out.maxV[item] = NAN;
             continue;
         }
-        const int L = ev.L[e], il = ev_len_index[e];
-        const double t_min = ev.t_min[e];
+        const int L = ev_L, il = evx_il;
+        const double t_min = evx_t_min;
         const double res = 1. / st.fs;
         // the circular convolution over L samples is a linear one of 2 L: when that fits FFT_MAX real points the packed transform has
         // FFT_MAX / 2 complex points (one stage and half the LDS traffic less); the response spectrum on that grid is every other
@@ -2107,21 +2334,27 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         const bool half_size = 2 * L <= M;
         const int log2Mr = half_size ? LOG2CAP - 1 : LOG2CAP, Mr = 1 << log2Mr, gs = FFT_MAX / Mr;
         const double vscale = (double)gs;   // the table carries the 1 / FFT_MAX of the un-normalised transform pair
-        int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
-        if (threadIdx.x == 0) s_trig = 0;
+        int r0 = evx_r0, r1 = evx_r1;
         // antenna response tables among this channel's rays (one, except for LPDAs seeing rays in different lobes)
         int tabs = 0, n_used = 0;
-        for (int r = r0; r < r1; r++)
-            if (w.ch[r] == ch) { tabs |= 1 << w.tab[r]; n_used++; }
+        if (rays_staged) {
+            for (int i = 0; i < r1 - r0; i++) {
+                const int ct = s_rct[i];
+                if ((ct >> 4) == ch) { tabs |= 1 << (ct & 15); n_used++; }
+            }
+        } else {
+            for (int r = r0; r < r1; r++)
+                if (w.ch[r] == ch) { tabs |= 1 << w.tab[r]; n_used++; }
+        }
         const bool multi = (tabs & (tabs - 1)) != 0;
         bool first_tab = true;
         for (int tb = 0; tb < NRHIP_N_ANT_TAB; tb++) {
             if (!((tabs >> tb) & 1)) continue;
             const double2* G = tab.G + (((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[ch] : 0)) * NRHIP_N_ANT_TAB + tb) * NRHIP_G_STRIDE;
-            __syncthreads();
+            lds_barrier();
             CT(0);
             for (int n = threadIdx.x; n < L; n += blockDim.x) S[PS(n)] = 0.;
-            __syncthreads();
+            lds_barrier();
             CT(1);
             {
                 const double df = 1.0 / (N * (1. / st.fs));
@@ -2132,7 +2365,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                       const int lane = threadIdx.x, r = r_chunk + lane;
                       ConvJob jb[2];
                       int nj_l = 0;
-                      if (r < r1 && w.ch[r] == ch && w.tab[r] == tb) {
+                      if (r < r1 && (rays_staged ? (int)s_rct[r - r0] == ((ch << 4) | tb) : (w.ch[r] == ch && w.tab[r] == tb))) {
                           const double vt = w.vfac_t[r], vp = w.vfac_p[r];
                           const double2 rt = w.r_theta[r], rp = w.r_phi[r];
                           const double pt = w.pol_theta[r], pp = w.pol_phi[r];
@@ -2144,7 +2377,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                           const long start_bin = (long)rint(start_time / res);
                           ConvJob job;
                           job.r = r;
-                          job.sbin = (int)(((start_bin % (long)L) + (long)L) % (long)L);
+                          int sb32 = (int)start_bin % L;   // (|start_bin| is a few L at most: 32-bit remainder instead of two 64-bit ones)
+                          job.sbin = sb32 < 0 ? sb32 + L : sb32;
                           job.rem = start_time - start_bin * res;
                           job.shift = !(fabs(rint(job.rem * st.fs) - job.rem * st.fs) < 1e-5);
                           for (int comp = 0; comp < (one ? 1 : 2); comp++) {
@@ -2168,9 +2402,59 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                       if (fits && nj_l > 1) s_jobs[first + 1] = jb[1];
                       if (lane == (m > 0 ? m - 1 : 0)) { s_njob = (m > 0) ? incl : 0; s_nadv = (m > 0) ? m : 1; }
                   }
-                  __syncthreads();
+                  lds_barrier();
+                  CT(11);
                   const int n_jobs = s_njob;
                   r_adv = s_nadv;
+                  if (wave_rays) {
+                    // wave-private transforms (conv_fft.h): Bw jobs at a time, TR = nh / 8 threads each.  No staging barrier: every
+                    // wave of a job fills the job's RayShared itself (the same values), builds its share of the spectrum with the
+                    // first stages (ray_build), runs the 512-point block it owns, and the job's threads place the samples
+                    for (int j0 = 0; j0 < n_jobs; j0 += Bw) {
+                      const int nj = min(Bw, n_jobs - j0);
+                      const int tid = conv_opaque((int)threadIdx.x);
+                      const int g = tid / TR, lt = tid - g * TR, lane = tid & 63;
+                      const bool mine = g < nj;
+                      const int BS = ray_blk_stride(NBKr);
+                      double2* xjob = xs + (long)g * NBKr * BS;
+                      if (mine) {
+                          const ConvJob job = s_jobs[j0 + g];
+                          RayShared& rg = rs4[g];
+                          static_assert(sizeof(AskaryanConst) % 8 == 0, "copied word by word");
+                          if (lane < (int)(sizeof(AskaryanConst) / 8))   // one word per lane (a struct copy by one lane is 19 loads in a row)
+                              ((double*)&rg.ask)[lane] = ((const double*)&w.ask[job.r])[lane];
+                          for (int i = lane; i < st.n_fc; i += 64) {
+                              const double a0 = w.att[(long)job.r * st.n_fc + i], x0 = st.fcoarse[i];
+                              rg.att[i] = a0;
+                              rg.xp[i] = x0;
+                              if (i < st.n_fc - 1) rg.slope[i] = (w.att[(long)job.r * st.n_fc + i + 1] - a0) / (st.fcoarse[i + 1] - x0);
+                          }
+                          wave_lds_sync();
+                          CT(2);
+                          const double2* two = conv_opaque(tw);
+                          if (NBKr == 4) ray_build<4>(xjob, lt, job, rg, st, ask_model, two, log2nh);
+                          else ray_build<2>(xjob, lt, job, rg, st, ask_model, two, log2nh);
+                      }
+                      lds_barrier();
+                      CT(3);
+                      if (mine) {
+                          const double2* cfto = conv_opaque(cft);
+                          double2* zb = xs + (long)(tid >> 6) * BS;
+                          ray_p2(zb, cfto, lane);
+                          ray_p3(zb, cfto, lane);
+                      }
+                      lds_barrier();
+                      for (int q = 0; q < nj; q++) {
+                          if (g == q) {
+                              const ConvJob jq = s_jobs[j0 + q];
+                              if (NBKr == 4) ray_place<4>(xjob, lt, nh, jq, S, L);
+                              else ray_place<2>(xjob, lt, nh, jq, S, L);
+                          }
+                          lds_barrier();
+                      }
+                      CT(4);
+                    }
+                  } else
                   for (int j0 = 0; j0 < n_jobs; j0 += B) {
                     const int nj = min(B, n_jobs - j0);
                     const ConvJob* s_job = s_jobs + j0;
@@ -2197,7 +2481,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                                 s_ramp4[g][t] = make_double2(cs, sn);
                             }
                     }
-                    __syncthreads();
+                    lds_barrier();
                     CT(2);
                     if (mine) {
                         // spectrum of the packed half-length transform (field_time_domain), bins k and N/2 - k by the same thread:
@@ -2243,7 +2527,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                             }
                         }
                     }
-                    __syncthreads();
+                    lds_barrier();
                     // inverse transforms of the whole batch, natural -> bit-reversed inside each block; scale applied by the reader
                     fft_dif_batched<3>(xs, log2nh + log2B, log2B, tw, true);
                     CT(3);
@@ -2260,7 +2544,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                             S[PS(i0)] += y.x * c;
                             S[PS(i1)] += y.y * c;
                         }
-                        __syncthreads();
+                        lds_barrier();
                     }
                     CT(4);
                   }
@@ -2268,7 +2552,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             }
             // (only the lower half of the packed buffer is read by the forward transform: L <= Mr real samples, the rest is zero)
             for (int n = L + threadIdx.x; n < Mr; n += blockDim.x) S[PS(n)] = 0.;
-            __syncthreads();
+            lds_barrier();
             CT(5);
             // forward transform, real-transform split * G * merge, first stages of the inverse (conv_fft.h)
             if (half_size) { conv_fwd<LOG2CAP - 1, NT>(z, tw, cft); CT(6); conv_mid<LOG2CAP - 1, NT>(z, G, w16); }
@@ -2286,10 +2570,10 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 atomicAdd(&xform_count[1], (unsigned long long)n_used);
             }
             if (multi) {
-                __syncthreads();
+                lds_barrier();
                 for (int k = threadIdx.x; k < Mr; k += blockDim.x) z[PZ(k)] = acc[k];
             }
-            __syncthreads();
+            lds_barrier();
             CT(7);
             if (half_size) conv_inv<LOG2CAP - 1, NT>(z, tw, cft);
             else conv_inv<LOG2CAP, NT>(z, tw, cft);
@@ -2313,7 +2597,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     vmax = fmax(vmax, fabs(v));
                     S[PS(n)] = v;
                 }
-                __syncthreads();
+                lds_barrier();
                 int* A = (int*)(S + 2 * (conv_pad(M / 2) + 8));  // index of the last raised flag at or before sample i (-1: none); behind the trace
                 const int nb = (trg.type == 0) ? L : L - 1;
                 for (int i = threadIdx.x; i < nb; i += blockDim.x) {
@@ -2334,42 +2618,55 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     }
                     A[i] = (flag && ch_on) ? i : -1;
                 }
-                __syncthreads();
+                lds_barrier();
                 {   // inclusive running maximum of A[0 .. nb): contiguous chunk per thread, then a scan of the chunk maxima
                     const int chunk = (nb + NT - 1) / NT, b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, nb);
                     int run = -1;
                     for (int i = b0; i < b1; i++) { run = max(run, A[i]); A[i] = run; }
                     s_scan[threadIdx.x] = run;
-                    __syncthreads();
+                    lds_barrier();
                     for (int off = 1; off < NT; off <<= 1) {
                         int v = ((int)threadIdx.x >= off) ? s_scan[threadIdx.x - off] : -1;
-                        __syncthreads();
+                        lds_barrier();
                         s_scan[threadIdx.x] = max(s_scan[threadIdx.x], v);
-                        __syncthreads();
+                        lds_barrier();
                     }
                     const int before = threadIdx.x > 0 ? s_scan[threadIdx.x - 1] : -1;
                     for (int i = b0; i < b1; i++) A[i] = max(A[i], before);
-                    __syncthreads();
+                    lds_barrier();
                 }
                 const int wc = min(trg.w_coinc, nb);
                 for (int i = threadIdx.x; i < nb - 1; i += blockDim.x)
                     if (A[i] >= 0 && i - A[i] < wc) cnt[i] += 1;
-                __syncthreads();
+                lds_barrier();
             }
         }
         else if (emitting) {   // a channel without rays: zeros, as the reference's empty channels
             double* const em = out.emit + e_off + (long long)ch * L;
             for (int n = threadIdx.x; n < L; n += blockDim.x) em[n] = 0.;
         }
-        if (trig) s_trig = 1;
-        double vm = block_max(vmax, red);
-        if (threadIdx.x == 0) {
-            out.maxV[item] = vm;
-            if (s_trig) { out.triggered[e] = 1; s_ev_trig = 1; }
+        // maximum and trigger flag of the channel with ONE barrier: wave-level reduction, a word per wave and a flag in the buffer of
+        // this phase's parity (the other buffer is cleared for the next phase), every thread reads the result for itself
+        {
+            const int fp = flag_par;
+            flag_par ^= 1;
+            for (int off = 32; off > 0; off >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, off));
+            const bool wave_trig = __ballot(trig != 0) != 0ull;
+            if ((threadIdx.x & 63) == 0) {
+                red2[fp][threadIdx.x >> 6] = vmax;
+                if (wave_trig) s_trig2[fp] = 1;
+            }
+            lds_barrier();
+            double vm = red2[fp][0];
+            for (int i = 1; i < NT / 64; i++) vm = fmax(vm, red2[fp][i]);
+            const bool ch_trig = s_trig2[fp] != 0;
+            if (threadIdx.x == 0) {
+                s_trig2[fp ^ 1] = 0;
+                out.maxV[item] = vm;
+                if (ch_trig) out.triggered[e] = 1;
+            }
+            ev_trig = ev_trig || ch_trig;
         }
-        __syncthreads();
-        ev_trig = (s_ev_trig != 0);
-        __syncthreads();
         CT(9);
         if (can_emit && ev_trig && !emitting) {
             // the event has just triggered on channel ch: reserve n_ch x L samples, write this channel's trace (still in S), then
@@ -2387,7 +2684,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 out.emit_offset[e] = off;
                 s_emit_off = off;
             }
-            __syncthreads();
+            lds_barrier();
             e_off = s_emit_off;
             if (e_off >= 0) {
                 double* const em = out.emit + e_off + (long long)ch * L;
@@ -2396,23 +2693,24 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 c_star = ch;
                 step = -1;   // restart: every channel in channel order
             }
-            __syncthreads();
+            lds_barrier();
         }
       }
+      asm volatile("" :: "v"(touch_acc));
       if (coinc) {  // majority logic over the channels of the event
           if (threadIdx.x == 0) s_first = 0x7fffffff;
-          __syncthreads();
+          lds_barrier();
           const int nb = (trg.type == 0) ? ev_L : ev_L - 1;
           int first = 0x7fffffff;
           for (int i = threadIdx.x; i < nb - 1; i += blockDim.x)
               if (cnt[i] >= trg.n_coinc) first = min(first, i);
           if (first != 0x7fffffff) atomicMin(&s_first, first);
-          __syncthreads();
+          lds_barrier();
           if (threadIdx.x == 0 && s_first != 0x7fffffff) {
               out.triggered[ev_e] = 1;
               out.trigger_bin[ev_e] = s_first;
           }
-          __syncthreads();
+          lds_barrier();
       }
     }
 }

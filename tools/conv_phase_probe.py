@@ -27,8 +27,8 @@ out = (ctypes.c_ulonglong * 16)()
 assert h.nrhip_debug_conv_clocks(out, 0) == 0
 names = ['skip / control', 'zero S', 'amplitude fill', 'field transform', 'placement', 'zero pad', '8192-pt forward', 'x G', '8192-pt inverse',
          'maximum / flags']
-tot = float(sum(out[:10]))
+tot = float(sum(out[:10])) + float(out[11])
 for n, v in zip(names, out[:10]):
     print('%-16s %6.2f %%  %.3e clk' % (n, 100 * v / tot, v))
-print('  of the field transform: spectrum build %.2f %%' % (100 * out[10] / tot))
+print('  job list (of the time before the transforms) %.2f %%' % (100 * out[11] / (tot + out[11])))
 print('channel transforms', d['config']['n_channel_transforms'], 'ray transforms', d['config']['n_ray_transforms'])
