@@ -37,6 +37,7 @@ CHANNELS = np.array([[0., 0., -100. - i] for i in range(5)])
 ENERGY = 3e17                       # shower energy [eV] of a 1 EeV neutrino at <y> ~ 0.3
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s
 FP64_PEAK_TFLOPS = 78.6             # same guide: dense FP64 (vector and matrix alike)
+FLOP_PER_OBJECTIVE = 209.           # one evaluation of the ray finder's objective (analyticraytracing.py:204-272), DESIGN.md section 4
 # algorithmic HBM bytes of the un-fused formulation, N = 4096, L = 5296
 B_RAY, B_CHANNEL, B_PAIR = 601216, 169504, 320
 DCUT = [-1.56434411e+02, 2.54131322e+01, -1.34932379e+00, 2.39984185e-02]   # config_default.yaml speedup.distance_cut_coefficients
@@ -568,7 +569,7 @@ def main():
         achieved = alg_bytes / (sm[dom] * 1e-3) / 1e9 if sm[dom] > 0 else 0.
         # HBM bytes per launch from the committed rocprofv3 PMC passes -- quoted only if they were taken on THESE kernel sources
         traffic, traffic_note = None, None
-        pmc = os.environ.get('NRHIP_PMC_JSON', os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'))
+        pmc = os.environ.get('NRHIP_PMC_JSON', os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json'))
         if cfgno == 2 and args.flavour == 'had' and n == 1000000 and os.path.exists(pmc):
             pj = json.load(open(pmc))
             if pj.get('source_hash') == source_hash():
@@ -577,7 +578,6 @@ def main():
             else:
                 traffic_note = "the PMC profile was taken on other kernel sources (%s != %s): not quoted" % (
                     pj.get('source_hash'), source_hash())
-        b_event = B_RAY * scale * stats['n_rays'] + B_CHANNEL * scale * stats['n_channel_items'] + B_PAIR * stats['n_pairs']
         # FP64 view of the attenuation quadrature: one integrand evaluation = frequency-independent node part (shared
         # by the 25 lanes of a ray, ~110 flop incl. exp, 2 sqrt, 2 div) / 25 + per-lane exp + div (~45 flop)
         flop_per_eval = 110. / 25. + 45.
@@ -601,16 +601,17 @@ def main():
                        "traces_emitted_in_pass1": bool(with_traces and not args.two_pass), "n_emitted_events": stats.get('n_emitted_events'),
                        "trace_bytes": stats.get('trace_bytes'),
                        "stage_ms_avg_per_step": {k: round(v, 3) for k, v in sm.items()},
+                       "stage_ms_note": ("summed over the stations of the array" + (" and over the %d station lanes that run side by side "
+                                         "(the sum exceeds the step)" % n_lanes if n_lanes > 1 else "")) if is_array else None,
                        "gathered_mask_sha16": mask_sha,   # of the all-gathered trigger mask (the same for any number of ranks when strong)
                        "collectives": comm.mode},   # 'local' (one rank), 'rccl', or 'tcp' (RCCL did not come up on every rank)
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "from_profile" if traffic is not None else None,
                          "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": sm[dom],
-                         "whole_step_equivalent_GBs": b_event / (sm['total'] * 1e-3) / 1e9 if sm['total'] > 0 else 0.,
-                         "whole_step_equivalent_frac": b_event / (sm['total'] * 1e-3) / 1e9 / HBM_PEAK_GBS if sm['total'] > 0 else 0.,
                          "attenuation_integrand_evals": stats['n_integrand_evals'],
                          "attenuation_fp64_tflops_est": fp64, "fp64_vector_peak_tflops": FP64_PEAK_TFLOPS,
+                         "objective_evals": stats.get('n_objective_evals', 0),
                          "note": "every kernel of the path is FP64-VALU / LDS bound: the fused kernels move ~1e-3 of the "
                                  "un-fused algorithmic bytes of SURVEY 8(d) that the HBM view is priced on"},
         }
@@ -619,7 +620,10 @@ def main():
         M_, nh_ = 8192, wl['N'] // 2
         flop_channel = (stats['n_channel_transforms'] * (2 * 5. * M_ * 13 + 14. * (M_ // 2 + 1)) +
                         stats['n_ray_transforms'] * (5. * nh_ * np.log2(nh_) + 40. * nh_))
-        flop_of = {'attenuation': stats['n_integrand_evals'] * flop_per_eval, 'channel': flop_channel}
+        # FP64 view of the ray finder: calls of the objective delta_y(log C0) counted by the kernel (hybrd + two Brent searches, ~1e2 per
+        # pair) x FLOP_PER_OBJECTIVE (~90 add / mul, 13 divisions and 6 square roots at 1 flop, 1 exp + 4 log at 20)
+        flop_of = {'attenuation': stats['n_integrand_evals'] * flop_per_eval, 'channel': flop_channel,
+                   'raytrace': stats.get('n_objective_evals', 0) * FLOP_PER_OBJECTIVE}
         out["roofline"]["fp64_frac_by_stage"] = {k: (v / (sm[k] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if sm[k] > 0 else 0.) for k, v in flop_of.items()}
         if dom in flop_of:
             # the quadrature and the channel kernels move next to no HBM bytes (everything lives in registers / LDS): priced in

@@ -29,6 +29,21 @@
 
 namespace nrhip {
 
+// Nothing in this header is left to the optimiser's choice of what to fuse: the translation unit is compiled with
+// -ffp-contract=fast-honor-pragmas, under which the two instantiations of channel_conv_kernel (256 and 512 threads) got different
+// fusions of the same source lines and their traces differed in the last bit.  Contraction is off from here to the end of the
+// header (and around the kernel and its ray functions in spectral.hip); the fused multiply-adds are written out (cmulx, cmulcx).
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ double2 cmulx(double2 a, double2 b)    // a * b: two products, two fused multiply-adds
+{
+    return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ double2 cmulcx(double2 a, double2 b)   // a * conj(b)
+{
+    return make_double2(fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -(a.x * b.y)));
+}
+
 __device__ __forceinline__ int conv_pad(int i) { return i + (i >> 10); }
 // complex elements of the padded buffer: the M points + block padding, and behind the event's samples (M / 2 + padding) room for
 // the wave-private ray transforms (8 or 4 blocks of 512 points, block stride 532 / 520: ray_blk_stride)
@@ -77,7 +92,7 @@ __device__ __forceinline__ void dif_bf(double2& a, double2& b, const double2 w)
 {
     const double2 d = csub(a, b);
     a = cadd(a, b);
-    b = cmul(d, w);
+    b = cmulx(d, w);
 }
 __device__ __forceinline__ void dif_bf1(double2& a, double2& b)   // twiddle 1
 {
@@ -87,7 +102,7 @@ __device__ __forceinline__ void dif_bf1(double2& a, double2& b)   // twiddle 1
 }
 __device__ __forceinline__ void dit_bf(double2& a, double2& b, const double2 w)   // w: the forward twiddle (conjugated here)
 {
-    const double2 t = make_double2(b.x * w.x + b.y * w.y, b.y * w.x - b.x * w.y);
+    const double2 t = cmulcx(b, w);
     b = csub(a, t);
     a = cadd(a, t);
 }
@@ -264,7 +279,7 @@ __device__ __forceinline__ void dif_bf_c(double2& a, double2& b, const double2 w
 {
     const double2 d = csub(a, b);
     a = cadd(a, b);
-    b = make_double2(d.x * w.x + d.y * w.y, d.y * w.x - d.x * w.y);
+    b = cmulcx(d, w);
 }
 __host__ __device__ constexpr int ray_blk_stride(int nbk) { return nbk == 4 ? 532 : 520; }
 // lane l holds l + 64 j (j < 8); written transposed: (l >> 3) 64 + (l & 7) + 8 j
@@ -331,15 +346,18 @@ __device__ __forceinline__ void dif8_tail_c(double2 (&a)[8])
 // ---- forward transform up to (not including) the last three stages ----------------------------------------------------------------
 // z: natural order, only the lower half non-zero (the upper half is not read).  NT threads call; the M / 16 first ones work.
 // Ends WITHOUT a block barrier (conv_mid starts with one).
+// (conv_fwd / conv_mid / conv_inv are real function calls, not inlined: channel_conv_kernel keeps ~400 scalars alive (its argument
+// structures), and inlined into it the passes came out with spill reloads and lane reads of spilled scalars in their inner code; a
+// call gives each pass its own register allocation, at the price of one s_swappc.  The buffer is the kernel's dynamic LDS.)
 template <int LOG2M, int NT>
-__device__ __forceinline__ void conv_fwd(double2* z, const double2* __restrict__ tw, const double2* __restrict__ cft)
+__device__ __noinline__ void conv_fwd(const double2* __restrict__ tw, const double2* __restrict__ cft)
 {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* z = (double2*)smem;
     constexpr int M = 1 << LOG2M, NA = M / 16, LW = LOG2M - 10, NB = 1 << LW;   // NA active threads, NB blocks of 1024
     static_assert(LOG2M >= 11 && LOG2M <= 13, "2048, 4096 or 8192 points");
-    tw = conv_opaque(tw);
-    cft = conv_opaque(cft);
     static_assert(NA <= NT, "16 points per thread");
-    const int t = conv_opaque((int)threadIdx.x);
+    const int t = threadIdx.x;
     if (NA == NT || t < NA) {
 #pragma unroll
         for (int g = 0; g < 16 / NB; g++) {
@@ -349,7 +367,7 @@ __device__ __forceinline__ void conv_fwd(double2* z, const double2* __restrict__
             for (int j = 0; j < NB / 2; j++) a[j] = z[j * 1025 + i0];
             // first stage (span M / 2): the partners are zero
 #pragma unroll
-            for (int j = 0; j < NB / 2; j++) a[j + NB / 2] = cmul(a[j], tw[(i0 + 1024 * j) * (8 >> LW)]);
+            for (int j = 0; j < NB / 2; j++) a[j + NB / 2] = cmulx(a[j], tw[(i0 + 1024 * j) * (8 >> LW)]);
 #pragma unroll
             for (int e = 1; e < LW; e++) {
                 const int half = NB >> (e + 1);
@@ -377,11 +395,11 @@ __device__ __forceinline__ void conv_pair_mul(double2& A, double2& B, const doub
     const double2 Bc = cconj(B);
     const double2 Ee = cadd(A, Bc), D = csub(A, Bc);
     const double2 O = make_double2(D.y, -D.x);
-    const double2 wO = cmul(wk, O);
-    const double2 Yk = cmul(cadd(Ee, wO), Gk);
-    const double2 Ymc = cconj(cmul(cconj(csub(Ee, wO)), Gm));
+    const double2 wO = cmulx(wk, O);
+    const double2 Yk = cmulx(cadd(Ee, wO), Gk);
+    const double2 Ymc = cconj(cmulx(cconj(csub(Ee, wO)), Gm));
     const double2 E2 = cadd(Yk, Ymc);
-    const double2 D2 = cmul(csub(Yk, Ymc), cconj(wk));
+    const double2 D2 = cmulcx(csub(Yk, Ymc), wk);
     A = make_double2(E2.x - D2.y, E2.y + D2.x);
     B = make_double2(E2.x + D2.y, D2.x - E2.y);
 }
@@ -391,11 +409,12 @@ __device__ __forceinline__ void conv_pair_mul(double2& A, double2& B, const doub
 // FFT_MAX).  Thread k0 (1 <= k0 < M / 16) owns the bins k0 + j M/8 and their mirror partners (M/8 - k0) + j M/8; thread 0 the two
 // groups that are their own mirrors (k0 = 0 and M / 16).  Starts and ends with a block barrier.
 template <int LOG2M, int NT>
-__device__ __forceinline__ void conv_mid(double2* z, const double2* __restrict__ G, const double2* __restrict__ w16)
+__device__ __noinline__ void conv_mid(const double2* __restrict__ G, const double2* __restrict__ w16)
 {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* z = (double2*)smem;
     constexpr int M = 1 << LOG2M, NA = M / 16, K = M / 8, LW = LOG2M - 10, gs = FFT_MAX / M;
-    const int t = conv_opaque((int)threadIdx.x);
-    w16 = conv_opaque(w16);
+    const int t = threadIdx.x;
     lds_barrier();
     if (NA == NT || t < NA) {
         const int kA = (t == 0) ? 0 : t, kB = (t == 0) ? K / 2 : K - t;
@@ -431,7 +450,7 @@ __device__ __forceinline__ void conv_mid(double2* z, const double2* __restrict__
             const int kn = (m < 4) ? kA + K * m : kB + K * (7 - m);
             const double2 wb = (m < 4) ? wkA : wkB;
             const int mm = (m < 4) ? m : 7 - m;
-            const double2 wk = (mm == 0) ? wb : (mm == 1 ? cmul(wb, c16_1) : (mm == 2 ? mul_w8_1(wb) : cmul(wb, c16_3)));
+            const double2 wk = (mm == 0) ? wb : (mm == 1 ? cmulx(wb, c16_1) : (mm == 2 ? mul_w8_1(wb) : cmulx(wb, c16_3)));
             const double2 Gk = G[gs * kn], Gm = G[gs * (M - kn)];
             if (m < 4) {
                 const int s1 = (m == 0) ? 0 : br3(8 - m);          // thread 0's partner slot in A (slot 0: a copy of itself)
@@ -464,12 +483,12 @@ __device__ __forceinline__ void conv_mid(double2* z, const double2* __restrict__
 
 // ---- the rest of the inverse transform: natural order out, ends with a block barrier -------------------------------------------------
 template <int LOG2M, int NT>
-__device__ __forceinline__ void conv_inv(double2* z, const double2* __restrict__ tw, const double2* __restrict__ cft)
+__device__ __noinline__ void conv_inv(const double2* __restrict__ tw, const double2* __restrict__ cft)
 {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* z = (double2*)smem;
     constexpr int M = 1 << LOG2M, NA = M / 16, LW = LOG2M - 10, NB = 1 << LW;
-    const int t = conv_opaque((int)threadIdx.x);
-    tw = conv_opaque(tw);
-    cft = conv_opaque(cft);
+    const int t = threadIdx.x;
     if (NA == NT || t < NA) {
         double2* zb = z + (t >> 6) * 1025;
         conv_p3_inv(zb, cft, t & 63);
@@ -497,5 +516,7 @@ __device__ __forceinline__ void conv_inv(double2* z, const double2* __restrict__
     }
     lds_barrier();
 }
+
+#pragma clang fp contract(fast)   // (what -ffp-contract=fast-honor-pragmas gives the rest of the translation unit)
 
 }  // namespace nrhip

@@ -815,6 +815,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     const long n_pairs = n_events * n_ch, n_slots = n_pairs * S_;
     if (n_slots > 2000000000L) return nrhip_fail_msg("nrhip_simulate_events: batch too large, split the event list");
     S.n_pairs = n_pairs;
+    unsigned long long* rt_eval_counter = nullptr;
     // general emission / propagation path?
     const bool arz = cfg->askaryan_model == NRHIP_ASK_ARZ2019 || cfg->askaryan_model == NRHIP_ASK_ARZ2020;
     const bool bire = st->bire_n_knots[0] > 0;
@@ -896,7 +897,11 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         launch_exclusive_scan(sm, 16385, geo_hist, geo_off, geo_tmp);
         launch_event_perm(sm, (int)n_events, geo_cell, geo_off, geo_perm);
         LCHK("geometry order");
-        launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm);
+        if (stats) {
+            NEED(rt_eval_counter = WS("rt_eval_counter", unsigned long long, 1));
+            HIPCHK(hipMemsetAsync(rt_eval_counter, 0, sizeof(unsigned long long), sm));
+        }
+        launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm, nullptr, rt_eval_counter);
         LCHK("raytrace");
     }
     MARK(1);
@@ -1135,7 +1140,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ractive, 1, (size_t)n_rays, sm));
             HIPCHK(hipMemsetAsync(bound, 0xFF, sizeof(double) * nr, sm));
         } else {
-            launch_amp_bound(sm, n_rays, w, sd, ctx->ice, vertex, zint, bound, max_efield);
+            // (cut: the candidate cut the bound will be compared with -- rays far below it get a 64-term bound only; < 0: all exact)
+            launch_amp_bound(sm, n_rays, w, sd, ctx->ice, vertex, zint, bound, max_efield,
+                             cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude);
             LCHK("amp_bound");
             launch_event_possible(sm, (int)n_groups, n_ch, grp_ray, bound, cfg->no_pruning ? -1.0 : cfg->min_efield_amplitude,
                                   ractive, two_stage ? 1 : 0);
@@ -1693,6 +1700,12 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         int64_t nt = 0;
         for (unsigned char t : ht) nt += t;
         S.n_triggered = nt;
+        if (rt_eval_counter) {
+            unsigned long long ne = 0;
+            HIPCHK(hipMemcpyAsync(&ne, rt_eval_counter, sizeof ne, hipMemcpyDeviceToHost, sm));
+            HIPCHK(hipStreamSynchronize(sm));
+            S.n_objective_evals = (int64_t)ne;
+        }
         if (eval_counter) {
             unsigned long long ne = 0;
             // (on the station's stream: a copy on the null stream would also wait for the other lanes' streams, array.py)

@@ -67,8 +67,10 @@ __device__ __noinline__ double det_exp_call(double x) { return det_exp(x); }
 #endif
 __global__ void __launch_bounds__(256, NRHIP_RT_WAVES)
 raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
-                      IceConst m_arg, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm)
+                      IceConst m_arg, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm,
+                      unsigned long long* __restrict__ eval_count)
 {
+    int n_eval = 0;   // calls of the objective by this lane (the FP64 view of bench.py prices the finder by them)
     __shared__ double sh_pair[6][256];   // the pair geometry the objective reads on every evaluation (see delta_y_lds)
     __shared__ IceConst sh_ice;          // the ice model for the (non-inlined) objective: a reference to the kernel argument would
                                          // be a per-lane copy in scratch (64 B x every resident lane, re-read by every call)
@@ -96,8 +98,8 @@ raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double*
         int ns = 0;
         double lc0 = 0., lc1 = 0., lc2 = 0.;
         if (search) {
-            auto dy = [&](double l) { return delta_y_lds(l, sp, 256, m); };
-            auto dy2 = [&](double l) { double d = delta_y_lds(l, sp, 256, m); return d * d; };
+            auto dy = [&](double l) { n_eval++; return delta_y_lds(l, sp, 256, m); };
+            auto dy2 = [&](double l) { n_eval++; double d = delta_y_lds(l, sp, 256, m); return d * d; };
             double fun;
             const double xr = hybrd1(dy2, -1., 1e-6, &fun);
             if (fun < 1e-7) { lc0 = xr; ns = 1; }
@@ -135,6 +137,10 @@ raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double*
         out.n_sol[i] = ns;
         out.C0[i * NRHIP_MAXS] = c0a;
         out.C0[i * NRHIP_MAXS + 1] = c0b;
+    }
+    if (eval_count) {
+        for (int off = 32; off > 0; off >>= 1) n_eval += __shfl_xor(n_eval, off);
+        if ((threadIdx.x & 63) == 0 && n_eval) atomicAdd(eval_count, (unsigned long long)n_eval);
     }
 }
 
@@ -260,14 +266,15 @@ void launch_event_perm(hipStream_t stream, int n_events, const int* cell, int* c
 }
 
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
-                     const IceConst& m, const RayRecords& out, const double* max_dist, const int* perm, const double* given_C0)
+                     const IceConst& m, const RayRecords& out, const double* max_dist, const int* perm, const double* given_C0,
+                     unsigned long long* eval_count)
 {
     if (n_pairs <= 0) return;
     int block = 256;
     long grid = (n_pairs + block - 1) / block;
     if (grid > 256L * 64) grid = 256L * 64;
     if (!given_C0)
-        hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm);
+        hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count);
     hipLaunchKernelGGL(raytrace_records_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, given_C0);
 }
 

@@ -167,7 +167,7 @@ void launch_distance_cut_pairs(hipStream_t s, long n_pairs, int n_ch, const doub
 void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int* ray_slot, const double* vertex,
                                   const double* chan_pos, const RayRecords& rec, const IceConst& m, double* zint);
 void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, const IceConst& m,
-                      const double* vertex, const double* zint, double* bound, double* max_efield);
+                      const double* vertex, const double* zint, double* bound, double* max_efield, double cut);
 void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin, int n_ch, const int* slot_offset, int* grp_ray,
                             int stride = NRHIP_MAXS);
 void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slot_offset, const double* bound,

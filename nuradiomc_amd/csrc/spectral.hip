@@ -844,10 +844,13 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, c
 #ifndef NRHIP_ATT_BOUND_MARGIN
 #define NRHIP_ATT_BOUND_MARGIN 0.95
 #endif
+#ifndef NRHIP_AMP_TWO_LEVEL
+#define NRHIP_AMP_TWO_LEVEL 0
+#endif
 #define AB_RT 4  // rays per wave and pass: the frequency-grid tables are loaded once for AB_RT rays
 __global__ void __launch_bounds__(256, 3)
 amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double* __restrict__ vertex,
-                 const double* __restrict__ zint, double* __restrict__ bound, double* __restrict__ max_efield)
+                 const double* __restrict__ zint, double* __restrict__ bound, double* __restrict__ max_efield, double cut)
 {
     __shared__ double blen[4][AB_RT][64];  // per wave and ray: path length inside each depth bin
     __shared__ double s_binv[63 * 32];  // the depth-bin table (n_fc <= 32; read from HBM otherwise)
@@ -925,17 +928,17 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
                 ub[wv][i][lane] = u;
             }
         }
-        __syncthreads();
+        wave_lds_sync();   // (every table behind this point is the wave's own: the waves of a block run apart)
         for (int i = 0; i < AB_RT; i++)
             if (lane < st.n_fc - 1)
                 ub_slope[wv][i][lane] = (ub[wv][i][lane + 1] - ub[wv][i][lane]) / (s_xp[lane + 1] - s_xp[lane]);
-        __syncthreads();
+        wave_lds_sync();   // (every table behind this point is the wave's own: the waves of a block run apart)
         for (int i = 0; i < AB_RT; i++)   // single-precision copies for the FP32 sums (rounding covered by BOUND_F32_SLACK)
             if (lane < st.n_fc) {
                 ub_f[wv][i][lane] = (float)ub[wv][i][lane];
                 ub_slope_f[wv][i][lane] = (lane < st.n_fc - 1) ? (float)ub_slope[wv][i][lane] : 0.f;
             }
-        __syncthreads();
+        wave_lds_sync();   // (every table behind this point is the wave's own: the waves of a block run apart)
         if (rb < n_rays) {
             // per-ray scalars only (the full AskaryanConst records would cost ~40 VGPRs per ray)
             double cL[AB_RT], cR[AB_RT], pf[AB_RT];
@@ -956,6 +959,58 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
             bool f32 = all2009;
             for (int i = 0; i < AB_RT; i++)
                 f32 = f32 && pf[i] > 1e-25 && pf[i] < 1e25 && cL[i] > 1e-15 && cL[i] < 1e15 && cR[i] > 1e-15 && cR[i] < 1e15;
+            // Two levels (round 4, measured and NOT kept -- NRHIP_AMP_TWO_LEVEL=1 builds it): the bound is only ever COMPARED with the
+            // candidate cut, and two rays in three lie far below it.  The 64-term bound decides 38 % of the tiles of four rays on
+            // the survey, yet the kernel takes 8.5 ms with it against 7.9 without: the part in front of the sums (path lengths per
+            // depth bin, the attenuation bounds) is half of the work, and the decision needs the rays' polarisation / Fresnel
+            // factors from HBM up front.  First
+            // a 64-term bound -- lane g takes the bins 32 g + 1 .. 32 g + 32: X_k <= pref f_hi / ((1 + cL p_lo)(1 + cR q_lo)) (the f^p
+            // tables rise with f), the interpolated attenuation bound <= the largest of the coarse nodes around the group --; only if
+            // that exceeds the cut for one of the wave's rays does the 2047-term sum run (for all AB_RT: they share the table loads).
+            // A ray left with the coarse value lies below the cut with it, as it would with the fine one: the lists of active rays
+            // are the same, and the value is still an upper bound.
+            bool coarse_only = false;
+            double coarse[AB_RT];
+#if NRHIP_AMP_TWO_LEVEL
+            if (f32 && cut >= 0. && nh >= 256) {
+                const int k0 = 1 + 32 * lane, k1 = min(nh - 1, 32 * lane + 32);
+                float term[AB_RT];
+                for (int i = 0; i < AB_RT; i++) term[i] = 0.f;
+                if (k0 <= k1) {
+                    const float f_hi = (float)(k1 * df) * (1.f + 1e-6f);
+                    const float ph = st.fpow_f[k0] * (1.f - 1e-6f), pe = st.fpow_f[stride + k0] * (1.f - 1e-6f), pr = st.fpow_f[2 * stride + k0] * (1.f - 1e-6f);
+                    int j0 = st.seg[k0], j1 = min(st.seg[k1] + 1, st.n_fc - 1);
+                    if ((float)(k0 * df) <= (float)x_first) j0 = 0;
+                    for (int i = 0; i < AB_RT; i++) {
+                        float um = 0.f;
+                        for (int j = j0; j <= j1; j++) um = fmaxf(um, ub_f[wv][i][j]);
+                        const float x = (had[i] ? ph : pe) * (float)cL[i], y = pr * (float)cR[i];
+                        term[i] = (float)(k1 - k0 + 1) * (float)pf[i] * f_hi * __builtin_amdgcn_rcpf((1.f + x) * (1.f + y)) * um * (1.f + 1e-5f);
+                    }
+                }
+                coarse_only = true;
+                for (int i = 0; i < AB_RT; i++) {
+                    float pt = term[i];
+                    for (int off = 32; off > 0; off >>= 1) pt += __shfl_xor(pt, off);
+                    const int r = min(rb + i, n_rays - 1);
+                    const double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
+                    coarse[i] = efield_bound(((double)pt * BOUND_F32_SLACK + 1e-30) * BOUND_RCP_SLACK, st.N, st.fs, cmax);
+                    if (rb + i < n_rays && coarse[i] * (1 + 1e-6) > cut) coarse_only = false;   // (the comparison of event_possible_kernel)
+                }
+            }
+#ifdef NRHIP_CONV_TIMING
+            if (lane == 0) { atomicAdd(&g_conv_clk[13], 1ULL); if (coarse_only) atomicAdd(&g_conv_clk[14], 1ULL); }
+#endif
+#else
+            (void)cut;
+            for (int i = 0; i < AB_RT; i++) coarse[i] = 0.;
+#endif
+            if (coarse_only) {
+                for (int i = 0; i < AB_RT; i++) {
+                    const int r = rb + i;
+                    if (lane == 0 && r < n_rays) { bound[r] = coarse[i]; max_efield[r] = -coarse[i]; }
+                }
+            } else {
             if (f32) {
                 float cLf[AB_RT], cRf[AB_RT], pff[AB_RT], pf32[AB_RT];
                 for (int i = 0; i < AB_RT; i++) { cLf[i] = (float)cL[i]; cRf[i] = (float)cR[i]; pff[i] = (float)pf[i]; pf32[i] = 0.f; }
@@ -1021,8 +1076,9 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
                     max_efield[r] = -b;  // "not evaluated, at most b" until efield_max_kernel overwrites it
                 }
             }
+            }
         }
-        __syncthreads();
+        wave_lds_sync();   // (every table behind this point is the wave's own: the waves of a block run apart)
     }
 }
 
@@ -1980,6 +2036,12 @@ struct ConvJob {
     double pol, vfac, rem;
     double2 rc;
 };
+// dynamic LDS of channel_conv_kernel<log2cap>: the padded buffer and, behind it, the emission constants / attenuation rows of the
+// rays of a batch (4 with 512 threads, 2 with 256)
+static inline int conv_lds_bytes(int log2cap)
+{
+    return conv_lds_elems(1 << log2cap) * 16 + (log2cap == FFT_LOG2_MAX ? 4 : 2) * (int)sizeof(RayShared);
+}
 // amplitude X_k att(f_k) of bin k exactly as fill_amplitude() forms it
 __device__ inline double conv_amplitude(int k, int nh, double df, const StationDev& st, const RayShared& rs, double pl, double pr, int seg)
 {
@@ -1991,6 +2053,7 @@ __device__ inline double conv_amplitude(int k, int nh, double df, const StationD
     }
     return amplitude_bin(k, f, rs.ask, st) * interp_seg(f, seg, st.n_fc, rs.xp, rs.att, rs.slope);
 }
+#pragma clang fp contract(off)   // (see conv_fft.h: the kernel's two instantiations must do the same arithmetic)
 // ---- wave-private ray transforms of the convolution kernel (conv_fft.h): spectrum + first stages, and last stages + placement ----
 // The rare emission models (Alvarez2000, ZHS1992: exp / log per bin, ZHS's own phase) stay out of line: inlined into every bin of
 // every unrolled item they made the kernel three times its size (instruction fetch) for a path the surveys never take.
@@ -2008,10 +2071,17 @@ __device__ __noinline__ double2 conv_zhs_phase(int k, double roll, int N)
 // item i0 (0 < i0 < 256) owns the bins i0 + 512 j of the transform and their mirror partners nh - k = (512 - i0) + 512 (NBK - 1 - j)
 // (both members of a mirror pair need both amplitudes); item 0 the two groups that are their own mirrors (i0 = 0 and 256).  The phase
 // ramp exp(-2 pi i f_k rem) of the sub-sample shift comes from two sincospi per thread (bin lt and the thread stride) and products.
+// (Tried as real function calls like the passes of conv_fft.h -- the interface is made for it: values, and LDS places as byte offsets
+// into the dynamic LDS -- and measured slower, 14.4 against 12.2 ms: the spill traffic moves to the call sites.)  The station's
+// scalars and tables a ray needs:
+struct RayStation { int N, n_fc; double fs; const double* fpow; const unsigned char* seg; const double* lnf; };
 template <int NBK>
-__device__ __forceinline__ void ray_build(double2* xjob, int lt, const ConvJob& job, const RayShared& rg, const StationDev& st,
-                                          int ask_model, const double2* __restrict__ tw, int log2nh)
+__device__ __forceinline__ void ray_build(int xjob_off, int rg_off, int lt, const ConvJob job, const RayStation st, int ask_model,
+                                       const double2* __restrict__ tw, int log2nh)
 {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* xjob = (double2*)(smem + xjob_off);
+    const RayShared& rg = *(const RayShared*)(smem + rg_off);
     constexpr int TR = 64 * NBK, IT = 4 / NBK, LWR = (NBK == 4) ? 2 : 1, BS = ray_blk_stride(NBK);
     static_assert(NBK == 2 || NBK == 4, "N / 2 = 1024 or 2048");
     const int N = st.N, nh = N / 2, stride = nh + 1, off_l = rg.ask.had ? 0 : stride;
@@ -2027,8 +2097,8 @@ __device__ __forceinline__ void ray_build(double2* xjob, int lt, const ConvJob& 
         rho_a = make_double2(cs, sn);
         sincospi(al * TR, &sn, &cs);
         rho_t = make_double2(cs, sn);
-        const double2 r2 = cmul(rho_t, rho_t), r4 = cmul(r2, r2);
-        rho_nh = cmul(r4, r4);                           // nh = 8 TR
+        const double2 r2 = cmulx(rho_t, rho_t), r4 = cmulx(r2, r2);
+        rho_nh = cmulx(r4, r4);                           // nh = 8 TR
         rho_512 = (NBK == 4) ? r2 : r4;
     }
     // station tables of a mirror pair (k, nh - k), 0 < k < nh: requested for all pairs of an item before the first is used
@@ -2043,10 +2113,10 @@ __device__ __forceinline__ void ray_build(double2* xjob, int lt, const ConvJob& 
     // amplitude X_k att(f_k) (conv_amplitude), 0 < k < nh; the quotient through a reciprocal estimate and two Newton steps (~1 ulp)
     auto ampl = [&](int k, double pl, double pr, int seg) -> double {
         const double f = k * df;
-        const double at = interp_seg(f, seg, st.n_fc, rg.xp, rg.att, rg.slope);
+        // (interp_seg with its multiply-add written out)
+        const double at = (f <= rg.xp[0]) ? rg.att[0] : ((f >= rg.xp[st.n_fc - 1]) ? rg.att[st.n_fc - 1] : fma(rg.slope[seg], f - rg.xp[seg], rg.att[seg]));
         if (m0) {
-            const double x = pl * rg.ask.cL, y = pr * rg.ask.cR;
-            const double den = (1 + x) * (1 + y);
+            const double den = fma(pl, rg.ask.cL, 1.0) * fma(pr, rg.ask.cR, 1.0);
             double rc = __builtin_amdgcn_rcp(den);
             rc = fma(fma(-den, rc, 1.0), rc, rc);
             rc = fma(fma(-den, rc, 1.0), rc, rc);
@@ -2060,25 +2130,25 @@ __device__ __forceinline__ void ray_build(double2* xjob, int lt, const ConvJob& 
         double2 sv = make_double2(0., (k & 1) ? -a : a);
         if (ask_model == 2) sv = cscale(conv_zhs_phase(k, roll, N), a);
         sv = cscale(sv, job.pol);
-        sv = cmul(sv, job.rc);
-        if (job.shift) sv = cmul(sv, rk);
+        sv = cmulx(sv, job.rc);
+        if (job.shift) sv = cmulx(sv, rk);
         return sv;
     };
     // packed values of the mirror pair (k, nh - k); rk = ramp at bin k
     auto pair = [&](int k, const PairIn& q, const double2 rk, double2& Xk, double2& Xm) {
         const int k2 = nh - k;
         const double2 F1 = fbin(k, ampl(k, q.pl1, q.pr1, q.sg1), rk);
-        const double2 F2 = fbin(k2, ampl(k2, q.pl2, q.pr2, q.sg2), cmul(rho_nh, cconj(rk)));
+        const double2 F2 = fbin(k2, ampl(k2, q.pl2, q.pr2, q.sg2), cmulcx(rho_nh, rk));
         {
             const double2 Gc = cconj(F2);
             const double2 ge = cscale(cadd(F1, Gc), 0.5), d = cscale(csub(F1, Gc), 0.5);
-            const double2 go = cmul(d, cconj(q.w1));
+            const double2 go = cmulcx(d, q.w1);
             Xk = make_double2(ge.x - go.y, ge.y + go.x);
         }
         {
             const double2 Gc = cconj(F1);
             const double2 ge = cscale(cadd(F2, Gc), 0.5), d = cscale(csub(F2, Gc), 0.5);
-            const double2 go = cmul(d, cconj(q.w2));
+            const double2 go = cmulcx(d, q.w2);
             Xm = make_double2(ge.x - go.y, ge.y + go.x);
         }
     };
@@ -2099,7 +2169,7 @@ __device__ __forceinline__ void ray_build(double2* xjob, int lt, const ConvJob& 
     // ... (nh / 2 with itself; bin 0 is empty) -- as many pairs as any other item has, computed by the SAME instructions with other
     // bin numbers and ramps, the results dealt to the two groups by selects: a branch of its own made the item's wave (and with it
     // every wave at the barrier behind) take twice the time.
-    const double2 rho_256 = (NBK == 4) ? rho_t : cmul(rho_t, rho_t);
+    const double2 rho_256 = (NBK == 4) ? rho_t : cmulx(rho_t, rho_t);
     double2 rho_i = rho_a;
 #pragma unroll 1
     for (int u = 0; u < IT; u++) {
@@ -2119,8 +2189,8 @@ __device__ __forceinline__ void ray_build(double2* xjob, int lt, const ConvJob& 
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 pair(kj, cur, make_double2(sp ? q.x : g.x, sp ? q.y : g.y), P[j], Q[j]);
-                g = cmul(g, rho_512);
-                q = cmul(q, rho_256);
+                g = cmulx(g, rho_512);
+                q = cmulx(q, rho_256);
             }
         }
         double2 A[NBK], B[NBK];
@@ -2138,13 +2208,24 @@ __device__ __forceinline__ void ray_build(double2* xjob, int lt, const ConvJob& 
         }
         stages_store(A, i0);
         stages_store(B, sp ? 256 : 512 - i0);
-        rho_i = cmul(rho_i, rho_t);
+        rho_i = cmulx(rho_i, rho_t);
     }
+}
+// the two wave-private passes of a ray transform on the wave's 512-point block (byte offset into the dynamic LDS)
+__device__ __forceinline__ void ray_p23(int zb_off, const double2* __restrict__ cft, int lane)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* zb = (double2*)(smem + zb_off);
+    ray_p2(zb, cft, lane);
+    ray_p3(zb, cft, lane);
 }
 // last three stages of a ray's transform + placement of its samples on the event's grid: thread lt owns the samples lt + (nh / 8) m
 template <int NBK>
-__device__ __forceinline__ void ray_place(const double2* xjob, int lt, int nh, const ConvJob& jq, double* S, int L)
+__device__ __forceinline__ void ray_place(int xjob_off, int lt, int nh, const ConvJob jq, int L)
 {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const double2* xjob = (const double2*)(smem + xjob_off);
+    double* S = (double*)smem;
     constexpr int LWR = (NBK == 4) ? 2 : 1, BS = ray_blk_stride(NBK);
     const int blk = (NBK == 4) ? (((lt & 1) << 1) | ((lt >> 1) & 1)) : (lt & 1);
     const double2* zb = xjob + blk * BS + (lt >> LWR);
@@ -2161,9 +2242,45 @@ __device__ __forceinline__ void ray_place(const double2* xjob, int lt, int nh, c
         if (i0 >= L) i0 -= L;
         int i1 = i0 + 1;
         if (i1 >= L) i1 -= L;
-        S[2 * conv_pad(i0 >> 1) + (i0 & 1)] += a[r].x * sc;
-        S[2 * conv_pad(i1 >> 1) + (i1 & 1)] += a[r].y * sc;
+        double* s0 = S + 2 * conv_pad(i0 >> 1) + (i0 & 1);
+        double* s1 = S + 2 * conv_pad(i1 >> 1) + (i1 & 1);
+        *s0 = fma(a[r].x, sc, *s0);
+        *s1 = fma(a[r].y, sc, *s1);
     }
+}
+// Output pass of a channel without coincidence logic: V[n] = (y[n] + y[n + L]) * vscale from the convolution buffer (the kernel's
+// dynamic LDS), maximum |V| and threshold flag of this thread, the samples written to `em` (traces of a triggered event) and / or
+// `tr` (dump_traces) if given.  Out of line on purpose: inside the kernel -- 400 spilled scalars -- the loop came out with a dozen
+// spill reloads and a wait for the previous store per iteration (9 % of the kernel's time for twenty LDS reads per thread).
+struct ConvOut { double vmax; int trig; };
+__device__ __noinline__ ConvOut conv_output_pass(int L, double vscale, double threshold, int ch_on, double* __restrict__ em,
+                                                 double* __restrict__ tr)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const double2* z = (const double2*)smem;
+    ConvOut o = {0., 0};
+    // two samples per step: L is even, so the samples 2 i, 2 i + 1 and their partners L + 2 i, L + 2 i + 1 are two complex elements
+    const int hl = L >> 1, nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < hl; i0 += 4 * nt) {   // four steps' LDS reads in flight at a time
+        double2 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * nt;
+            if (i < hl) { a[u] = z[conv_pad(i)]; b[u] = z[conv_pad(i + hl)]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * nt;
+            if (i >= hl) break;
+            const double v0 = (a[u].x + b[u].x) * vscale, v1 = (a[u].y + b[u].y) * vscale;
+            if (em) *(double2*)(em + 2 * i) = make_double2(v0, v1);
+            if (tr) { tr[2 * i] = v0; tr[2 * i + 1] = v1; }
+            const double a0 = fabs(v0), a1 = fabs(v1);
+            o.vmax = fmax(o.vmax, fmax(a0, a1));
+            if (ch_on && (a0 >= threshold || (2 * i + 1 < L - 1 && a1 >= threshold))) o.trig = 1;
+        }
+    }
+    return o;
 }
 // LOG2CAP: log2 of the complex points the LDS buffer holds.  13 (FFT_MAX): any event of up to FFT_MAX samples, 133 KB, one block per
 // CU.  12: events of up to FFT_MAX / 2 samples only (the N = 2048 workloads), 68 KB + 9 KB static: TWO blocks per CU, so one block's
@@ -2199,7 +2316,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     // up to four transforms at a time: a group of NT / B threads per transform builds its spectrum (amplitudes on the fly,
     // bins k and N/2 - k together), ONE batched transform runs them all, the placements follow in ray order.  B is what fits the
     // 64 KB behind the event's samples: 4 transforms of <= 1024 points, 2 of 2048, 1 of 4096.
-    __shared__ RayShared rs4[BM];
+    RayShared* rs4 = (RayShared*)(smem + (size_t)conv_lds_elems(M) * 16);   // [BM], behind the buffer (dynamic LDS: the ray functions reach it by offset)
     __shared__ ConvJob s_jobs[64];
     __shared__ int s_njob, s_nadv;
     __shared__ double2 s_ramp4[BM][64 + FFT_MAX / 4 / 64 + 1];
@@ -2431,24 +2548,22 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                           }
                           wave_lds_sync();
                           CT(2);
+                          const RayStation rst = {st.N, st.n_fc, st.fs, st.fpow, st.seg, st.lnf};
+                          const int xo = (int)((const unsigned char*)xjob - smem), ro = (int)((const unsigned char*)&rg - smem);
                           const double2* two = conv_opaque(tw);
-                          if (NBKr == 4) ray_build<4>(xjob, lt, job, rg, st, ask_model, two, log2nh);
-                          else ray_build<2>(xjob, lt, job, rg, st, ask_model, two, log2nh);
+                          if (NBKr == 4) ray_build<4>(xo, ro, lt, job, rst, ask_model, two, log2nh);
+                          else ray_build<2>(xo, ro, lt, job, rst, ask_model, two, log2nh);
                       }
                       lds_barrier();
                       CT(3);
-                      if (mine) {
-                          const double2* cfto = conv_opaque(cft);
-                          double2* zb = xs + (long)(tid >> 6) * BS;
-                          ray_p2(zb, cfto, lane);
-                          ray_p3(zb, cfto, lane);
-                      }
+                      if (mine) ray_p23((int)((const unsigned char*)(xs + (long)(tid >> 6) * BS) - smem), conv_opaque(cft), lane);
                       lds_barrier();
                       for (int q = 0; q < nj; q++) {
                           if (g == q) {
                               const ConvJob jq = s_jobs[j0 + q];
-                              if (NBKr == 4) ray_place<4>(xjob, lt, nh, jq, S, L);
-                              else ray_place<2>(xjob, lt, nh, jq, S, L);
+                              const int xo = (int)((const unsigned char*)xjob - smem);
+                              if (NBKr == 4) ray_place<4>(xo, lt, nh, jq, L);
+                              else ray_place<2>(xo, lt, nh, jq, L);
                           }
                           lds_barrier();
                       }
@@ -2555,8 +2670,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             lds_barrier();
             CT(5);
             // forward transform, real-transform split * G * merge, first stages of the inverse (conv_fft.h)
-            if (half_size) { conv_fwd<LOG2CAP - 1, NT>(z, tw, cft); CT(6); conv_mid<LOG2CAP - 1, NT>(z, G, w16); }
-            else { conv_fwd<LOG2CAP, NT>(z, tw, cft); CT(6); conv_mid<LOG2CAP, NT>(z, G, w16); }
+            if (half_size) { conv_fwd<LOG2CAP - 1, NT>(tw, cft); CT(6); conv_mid<LOG2CAP - 1, NT>(G, w16); }
+            else { conv_fwd<LOG2CAP, NT>(tw, cft); CT(6); conv_mid<LOG2CAP, NT>(G, w16); }
             if (multi) {  // sum the tables' contributions (the rest of the inverse is linear) in global scratch of this block
                 for (int k = threadIdx.x; k < Mr; k += blockDim.x) acc[k] = first_tab ? z[PZ(k)] : cadd(acc[k], z[PZ(k)]);
                 first_tab = false;
@@ -2575,19 +2690,14 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             }
             lds_barrier();
             CT(7);
-            if (half_size) conv_inv<LOG2CAP - 1, NT>(z, tw, cft);
-            else conv_inv<LOG2CAP, NT>(z, tw, cft);
+            if (half_size) conv_inv<LOG2CAP - 1, NT>(tw, cft);
+            else conv_inv<LOG2CAP, NT>(tw, cft);
             CT(8);
             if (!coinc) {
-                double* const em = emitting ? out.emit + e_off + (long long)ch * L : nullptr;
-                for (int n = threadIdx.x; n < L; n += blockDim.x) {
-                    double v = (S[PS(n)] + S[PS(n + L)]) * vscale;
-                    if (out.trace) out.trace[out.trace_offset[item] + n] = v;
-                    if (em) em[n] = v;
-                    double av = fabs(v);
-                    vmax = fmax(vmax, av);
-                    if (n < L - 1 && av >= threshold && ch_on) trig = 1;
-                }
+                const ConvOut co = conv_output_pass(L, vscale, threshold, ch_on ? 1 : 0, emitting ? out.emit + e_off + (long long)ch * L : nullptr,
+                                                    out.trace ? out.trace + out.trace_offset[item] : nullptr);
+                vmax = co.vmax;
+                trig = co.trig;
             } else {
                 // per-channel flags (simpleThreshold.py:14-29 / highLowThreshold.py:13-80), OR-dilated over the coincidence
                 // window (get_majority_logic :82-150: flag i stays up for w_coinc samples), counted per sample in cnt
@@ -2619,19 +2729,22 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     A[i] = (flag && ch_on) ? i : -1;
                 }
                 lds_barrier();
-                {   // inclusive running maximum of A[0 .. nb): contiguous chunk per thread, then a scan of the chunk maxima
+                {   // inclusive running maximum of A[0 .. nb): contiguous chunk per thread, a wave-level scan of the chunk maxima
+                    // (shuffles), the waves' totals through LDS: two barriers (was 2 log2(NT) + 2)
                     const int chunk = (nb + NT - 1) / NT, b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, nb);
                     int run = -1;
                     for (int i = b0; i < b1; i++) { run = max(run, A[i]); A[i] = run; }
-                    s_scan[threadIdx.x] = run;
-                    lds_barrier();
-                    for (int off = 1; off < NT; off <<= 1) {
-                        int v = ((int)threadIdx.x >= off) ? s_scan[threadIdx.x - off] : -1;
-                        lds_barrier();
-                        s_scan[threadIdx.x] = max(s_scan[threadIdx.x], v);
-                        lds_barrier();
+                    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+                    int incl = run;
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int v = __shfl_up(incl, off);
+                        if (lane >= off) incl = max(incl, v);
                     }
-                    const int before = threadIdx.x > 0 ? s_scan[threadIdx.x - 1] : -1;
+                    if (lane == 63) s_scan[wv] = incl;
+                    int before = __shfl_up(incl, 1);
+                    if (lane == 0) before = -1;
+                    lds_barrier();
+                    for (int q = 0; q < wv; q++) before = max(before, s_scan[q]);
                     for (int i = b0; i < b1; i++) A[i] = max(A[i], before);
                     lds_barrier();
                 }
@@ -2645,6 +2758,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             double* const em = out.emit + e_off + (long long)ch * L;
             for (int n = threadIdx.x; n < L; n += blockDim.x) em[n] = 0.;
         }
+        CT(12);
         // maximum and trigger flag of the channel with ONE barrier: wave-level reduction, a word per wave and a flag in the buffer of
         // this phase's parity (the other buffer is cleared for the next phase), every thread reads the result for itself
         {
@@ -2688,7 +2802,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             e_off = s_emit_off;
             if (e_off >= 0) {
                 double* const em = out.emit + e_off + (long long)ch * L;
-                for (int n = threadIdx.x; n < L; n += blockDim.x) em[n] = (S[PS(n)] + S[PS(n + L)]) * vscale;
+                (void)conv_output_pass(L, vscale, threshold, 0, em, nullptr);
                 emitting = true;
                 c_star = ch;
                 step = -1;   // restart: every channel in channel order
@@ -2716,6 +2830,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
 }
 #undef PZ
 #undef PS
+#pragma clang fp contract(fast)
 
 // y_j = e[2j] + i e[2j+1] of a real N-sample trace in HBM, optionally delayed by the sub-sample remainder `rem` through the
 // Fourier shift theorem on the N grid (rfft -> * exp(-2 pi i f rem) -> irfft, base_trace.py:273-276).  Without the shift the
@@ -3556,12 +3671,13 @@ void launch_ray_limits_from_slots(hipStream_t s, int n_rays, int n_ch, const int
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
 void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, const IceConst& m,
-                      const double* vertex, const double* zint, double* bound, double* max_efield)
+                      const double* vertex, const double* zint, double* bound, double* max_efield, double cut)
 {
     if (n_rays <= 0) return;
     int grid = (n_rays + 4 * AB_RT - 1) / (4 * AB_RT);
     if (grid > 256 * 32) grid = 256 * 32;
-    hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, m, vertex, zint, bound, max_efield);
+    if (getenv("NRHIP_AMP_BOUND_ONE_LEVEL")) cut = -1.;   // (A / B: always the 2047-term sum)
+    hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, m, vertex, zint, bound, max_efield, cut);
 }
 void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin, int n_ch, const int* slot_offset, int* grp_ray,
                             int stride)
@@ -3686,9 +3802,9 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)length_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               FFT_MAX * 16 + (FFT_MAX / 2 + 1) * 8);
-    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_elems(FFT_MAX) * 16);
+    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(FFT_LOG2_MAX));
     (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX - 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              conv_lds_elems(FFT_MAX / 2) * 16);
+                              conv_lds_bytes(FFT_LOG2_MAX - 1));
     (void)hipFuncSetAttribute((const void*)ray_envelope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)efield_channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
@@ -3768,13 +3884,13 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
             int blocks = channel_grid_blocks();
             if (getenv("NRHIP_CONV_SMALL_BLOCKS")) blocks = atoi(getenv("NRHIP_CONV_SMALL_BLOCKS"));
             const int cgrid = n_cand < blocks ? n_cand : blocks;
-            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX - 1>, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)conv_lds_elems(FFT_MAX / 2) * 16, s,
+            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX - 1>, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)conv_lds_bytes(FFT_LOG2_MAX - 1), s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue, 0);
         }
         if (large) {
             const int cgrid = n_cand < channel_grid_blocks() / 2 ? n_cand : channel_grid_blocks() / 2;
-            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX>, dim3(cgrid), dim3(CONV_NT), (size_t)conv_lds_elems(FFT_MAX) * 16, s,
+            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX>, dim3(cgrid), dim3(CONV_NT), (size_t)conv_lds_bytes(FFT_LOG2_MAX), s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue + (small ? 1 : 0),
                                small ? FFT_MAX / 2 : 0);

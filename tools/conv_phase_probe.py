@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, ROOT)
 os.environ['NRHIP_LIB_NAME'] = 'libnrhip_ct.so'
-sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'] + sys.argv[1:]   # e.g. --no-traces, --config 5
 import bench  # noqa: E402
 
 buf = io.StringIO()
@@ -27,8 +27,10 @@ out = (ctypes.c_ulonglong * 16)()
 assert h.nrhip_debug_conv_clocks(out, 0) == 0
 names = ['skip / control', 'zero S', 'amplitude fill', 'field transform', 'placement', 'zero pad', '8192-pt forward', 'x G', '8192-pt inverse',
          'maximum / flags']
-tot = float(sum(out[:10])) + float(out[11])
+tot = float(sum(out[:10])) + float(out[11]) + float(out[12])
 for n, v in zip(names, out[:10]):
     print('%-16s %6.2f %%  %.3e clk' % (n, 100 * v / tot, v))
+print('  output loop %.2f %% (maximum / flags above: what follows it)' % (100 * out[12] / tot))
 print('  job list (of the time before the transforms) %.2f %%' % (100 * out[11] / (tot + out[11])))
 print('channel transforms', d['config']['n_channel_transforms'], 'ray transforms', d['config']['n_ray_transforms'])
+print('amp_bound tiles of 4 rays: %d, decided by the 64-term bound alone: %d' % (out[13], out[14]))

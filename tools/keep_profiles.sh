@@ -1,7 +1,7 @@
 #!/bin/bash
 # copy the round's measurement set from gpurun_out/measure (scratch) into profiles/ (tracked): usage  bash tools/keep_profiles.sh [r03]
 cd "$(dirname "$0")/.."
-R=${1:-r03}
+R=${1:-r04}
 M=gpurun_out/measure
 cp $M/${R}_rocprofv3_kernel_stats.csv $M/${R}_pmc_traffic.csv $M/${R}_pmc_traffic.json $M/${R}_rocprofv3_config4_kernel_stats.csv profiles/ 2>/dev/null
 for c in config2 config2_pass1_only config2_mixed config2_strong config2_125k_shard config3 config3_pa config3_pa_adc_noise config4 config4_pa_adc_noise config5; do

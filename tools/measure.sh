@@ -7,7 +7,7 @@
 set -x
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/measure
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 B="python3 bench.py --no-cpu-baseline"
