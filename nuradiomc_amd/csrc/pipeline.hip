@@ -1547,6 +1547,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(it_off = WS("item_need_offset", int, (size_t)n_items + 1));
         NEED(it_tmp = WS("scan_tmp4", int, scan_tiles((long)n_items + 1)));
         NEED(it_list = WS("item_list", int, (size_t)n_items));
+        double* conv_noise = nullptr;   // the noise trace of the channel a block of the convolution kernel is working on
+        if (noise) NEED(conv_noise = WS("conv_noise_trace", double, (size_t)channel_grid_blocks() * FFT_MAX));
         double2* conv_acc;  // frequency-domain sum over antenna tables (LPDA channels seeing rays in different lobes)
         NEED(conv_acc = WS("conv_table_sum", double2, (sd.tab_mask & 0x1c) ? (size_t)channel_grid_blocks() * FFT_MAX : 1));
         int* coinc_cnt;
@@ -1577,7 +1579,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                        (cfg->no_pruning || cfg->dump_traces || general || phased || post_trigger || noise) ? 1 : 0, maxL,
                        it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces,
                        (phased || post_trigger) ? (cfg->dump_traces ? 0 : 1) : -1, envelope ? &st->env_filter : nullptr, env_trace,
-                       noise ? &nz : nullptr, conv_split, pa_amp_cut, amp_scratch);
+                       noise ? &nz : nullptr, conv_split, pa_amp_cut, amp_scratch, conv_noise);
         LCHK("channel");
         if (post_trigger) {
             if (maxL > 2 * FFT_MAX)

@@ -217,7 +217,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
                     const double* ray_traces = nullptr, int skip_off = -1, const FilterSet* envf = nullptr, double* env_trace = nullptr,
-                    const NoiseDev* noise = nullptr, bool conv_split = true, double pa_amp_cut = -1., double* amp_scratch = nullptr);
+                    const NoiseDev* noise = nullptr, bool conv_split = true, double pa_amp_cut = -1., double* amp_scratch = nullptr, double* noise_buf = nullptr);
 // channel_kernel's amplitude table lives in HBM scratch (rows of N / 2 + 1 doubles per block) when N > 4096
 inline bool channel_amp_in_hbm(int n_samples) { return n_samples / 2 > 2048; }
 // efield_max_kernel / general_spectrum_kernel: N / 2 no power of two and above 2048 -- the Bluestein transform takes FFT_MAX points,

@@ -2254,7 +2254,7 @@ __device__ __forceinline__ void ray_place(int xjob_off, int lt, int nh, const Co
 // spill reloads and a wait for the previous store per iteration (9 % of the kernel's time for twenty LDS reads per thread).
 struct ConvOut { double vmax; int trig; };
 __device__ __noinline__ ConvOut conv_output_pass(int L, double vscale, double threshold, int ch_on, double* __restrict__ em,
-                                                 double* __restrict__ tr)
+                                                 double* __restrict__ tr, const double* __restrict__ add, int with_signal)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const double2* z = (const double2*)smem;
@@ -2266,13 +2266,15 @@ __device__ __noinline__ ConvOut conv_output_pass(int L, double vscale, double th
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = i0 + u * nt;
-            if (i < hl) { a[u] = z[conv_pad(i)]; b[u] = z[conv_pad(i + hl)]; }
+            if (i < hl && with_signal) { a[u] = z[conv_pad(i)]; b[u] = z[conv_pad(i + hl)]; }
+            else { a[u] = make_double2(0., 0.); b[u] = a[u]; }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = i0 + u * nt;
             if (i >= hl) break;
-            const double v0 = (a[u].x + b[u].x) * vscale, v1 = (a[u].y + b[u].y) * vscale;
+            double v0 = (a[u].x + b[u].x) * vscale, v1 = (a[u].y + b[u].y) * vscale;
+            if (add) { v0 += add[2 * i]; v1 += add[2 * i + 1]; }   // thermal noise of the channel (a row of HBM scratch)
             if (em) *(double2*)(em + 2 * i) = make_double2(v0, v1);
             if (tr) { tr[2 * i] = v0; tr[2 * i + 1] = v1; }
             const double a0 = fabs(v0), a1 = fabs(v1);
@@ -2292,7 +2294,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                     const int* __restrict__ ev_len_index, StationDev st, int ask_model, TriggerDev trg,
                     const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab, int log2nh,
                     ChannelOut out, int exact, int* __restrict__ coinc_cnt, double2* __restrict__ conv_acc,
-                    unsigned long long* __restrict__ xform_count, int* __restrict__ queue, int l_min)
+                    unsigned long long* __restrict__ xform_count, int* __restrict__ queue, int l_min, NoiseDev nz,
+                    double* __restrict__ noise_buf)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int M = 1 << LOG2CAP;
@@ -2465,6 +2468,34 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         }
         const bool multi = (tabs & (tabs - 1)) != 0;
         bool first_tab = true;
+        // Thermal noise (channelGenericNoiseAdder before the filter chain, simulation.py:594-606; noise.h): its trace irfft_L(noise x
+        // filter response) is an arbitrary-length transform -- ONE inverse chirp-z in this buffer (the per-length tables the chirp-z
+        // channel kernel uses), parked in a row of HBM scratch and added when the channel's samples are read out.  Only the
+        // full-capacity instantiation can hold the 8192-point chirp convolution: with noise every event runs in it.
+        bool noisy = false;
+        double* const nbuf = noise_buf ? noise_buf + (long)blockIdx.x * FFT_MAX : nullptr;
+        if (LOG2CAP == FFT_LOG2_MAX && nz.on && nbuf) noisy = nz.amplitude[ch] > 0.;
+        if (LOG2CAP == FFT_LOG2_MAX && noisy) {
+            const int grp = nz.ev_group ? nz.ev_group[e] : e;
+            const long long gid = nz.group_id ? nz.group_id[grp] : nz.group_offset + grp;
+            const int sub = nz.ev_sub ? nz.ev_sub[e] : 0;
+            const double2* Bi = tab.B_inv + (long)il * FFT_MAX;
+            const double2* E = tab.E + (long)il * NRHIP_E_STRIDE;
+            const double2* Ci = tab.Ci + (long)il * FFT_MAX;
+            const double2* Hf = tab.H + ((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[ch] : 0)) * NRHIP_SPEC_STRIDE;
+            const double nscale = st.fs / 1.4142135623730951 / L * (1.0 / FFT_MAX);
+            const int mL = L / 2;
+            __syncthreads();
+            czt_inverse_blocks<NT>(z, Bi, tw, E, Ci, L, mL, FFT_MAX,
+                [&](int k) {
+                    double2 v = cmul(noise_bin(nz, gid, sub, ch, k, L, st.fs), Hf[k]);
+                    if (k == 0 || k == mL) v = make_double2(v.x, 0.);   // Hermitian folding of irfft
+                    else v = cscale(v, 2.);
+                    return v;
+                },
+                [&](int ng, double2 u) { nbuf[ng] = u.x * nscale; });
+            __syncthreads();   // (the noise samples are read back by other threads: a barrier that covers global memory)
+        }
         for (int tb = 0; tb < NRHIP_N_ANT_TAB; tb++) {
             if (!((tabs >> tb) & 1)) continue;
             const double2* G = tab.G + (((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[ch] : 0)) * NRHIP_N_ANT_TAB + tb) * NRHIP_G_STRIDE;
@@ -2679,30 +2710,34 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         }
         double vmax = 0.;
         int trig = 0;
-        if (n_used > 0) {
-            if (threadIdx.x == 0 && xform_count) {  // work actually done (roofline accounting of bench.py)
-                atomicAdd(&xform_count[0], 1ULL);
-                atomicAdd(&xform_count[1], (unsigned long long)n_used);
-            }
-            if (multi) {
+        const bool sig = n_used > 0;   // (a channel without rays still has its noise)
+        if (sig || noisy) {
+            if (sig) {
+                if (threadIdx.x == 0 && xform_count) {  // work actually done (roofline accounting of bench.py)
+                    atomicAdd(&xform_count[0], 1ULL);
+                    atomicAdd(&xform_count[1], (unsigned long long)n_used);
+                }
+                if (multi) {
+                    lds_barrier();
+                    for (int k = threadIdx.x; k < Mr; k += blockDim.x) z[PZ(k)] = acc[k];
+                }
                 lds_barrier();
-                for (int k = threadIdx.x; k < Mr; k += blockDim.x) z[PZ(k)] = acc[k];
+                CT(7);
+                if (half_size) conv_inv<LOG2CAP - 1, NT>(tw, cft);
+                else conv_inv<LOG2CAP, NT>(tw, cft);
+                CT(8);
             }
-            lds_barrier();
-            CT(7);
-            if (half_size) conv_inv<LOG2CAP - 1, NT>(tw, cft);
-            else conv_inv<LOG2CAP, NT>(tw, cft);
-            CT(8);
             if (!coinc) {
                 const ConvOut co = conv_output_pass(L, vscale, threshold, ch_on ? 1 : 0, emitting ? out.emit + e_off + (long long)ch * L : nullptr,
-                                                    out.trace ? out.trace + out.trace_offset[item] : nullptr);
+                                                    out.trace ? out.trace + out.trace_offset[item] : nullptr, noisy ? nbuf : nullptr, sig ? 1 : 0);
                 vmax = co.vmax;
                 trig = co.trig;
             } else {
                 // per-channel flags (simpleThreshold.py:14-29 / highLowThreshold.py:13-80), OR-dilated over the coincidence
                 // window (get_majority_logic :82-150: flag i stays up for w_coinc samples), counted per sample in cnt
                 for (int n = threadIdx.x; n < L; n += blockDim.x) {
-                    double v = (S[PS(n)] + S[PS(n + L)]) * vscale;
+                    double v = sig ? (S[PS(n)] + S[PS(n + L)]) * vscale : 0.;
+                    if (noisy) v += nbuf[n];
                     if (out.trace) out.trace[out.trace_offset[item] + n] = v;
                     vmax = fmax(vmax, fabs(v));
                     S[PS(n)] = v;
@@ -2802,7 +2837,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             e_off = s_emit_off;
             if (e_off >= 0) {
                 double* const em = out.emit + e_off + (long long)ch * L;
-                (void)conv_output_pass(L, vscale, threshold, 0, em, nullptr);
+                (void)conv_output_pass(L, vscale, threshold, 0, em, nullptr, nullptr, 1);
                 emitting = true;
                 c_star = ch;
                 step = -1;   // restart: every channel in channel order
@@ -3847,7 +3882,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
                     const double* ray_traces, int skip_off, const FilterSet* envf, double* env_trace, const NoiseDev* noise,
-                    bool conv_split, double pa_amp_cut, double* amp_scratch)
+                    bool conv_split, double pa_amp_cut, double* amp_scratch, double* noise_buf)
 {
     if (skip_off < 0) skip_off = !exact;  // channels outside the trigger set are evaluated only when everything is
     if (n_items <= 0) return;
@@ -3859,7 +3894,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     int skip_upto = 0;
     // (the convolution kernel's ray stage is radix 2: trace lengths that are no power of two take the chirp-z kernel)
     if (tab.G && st.N <= FFT_MAX / 2 && st.np.log2nh >= 0 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces && !env_trace &&
-        !(noise && noise->on)) {
+        (!(noise && noise->on) || (noise_buf && !getenv("NRHIP_NOISE_CZT")))) {
         const bool pa_prune = pa_amp_cut >= 0.;   // (then the bounds are wanted although every kept item is evaluated exactly)
         hipLaunchKernelGGL(channel_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev,
                            ev_len_index, st, pa_prune ? 0. : trig.prefilter(), tab.hnorm, pa_prune ? 0 : exact, out.maxV, need, skip_off);
@@ -3876,7 +3911,10 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                            item_list);
         // events of up to FFT_MAX / 2 samples go to the half-capacity instantiation (two blocks per CU), longer ones to the full one;
         // both walk the same list with their own counter
-        const bool small = st.N < FFT_MAX / 2 && conv_split && !getenv("NRHIP_CONV_ONE_BLOCK");   // L >= N: nothing to take otherwise
+        // (with thermal noise every event takes the full-capacity instantiation: the noise trace is an 8192-point chirp convolution)
+        const bool with_noise = noise && noise->on && noise_buf;
+        const NoiseDev nz_off{0, 0ull, nullptr, nullptr, 0, nullptr, nullptr};
+        const bool small = st.N < FFT_MAX / 2 && conv_split && !with_noise && !getenv("NRHIP_CONV_ONE_BLOCK");   // L >= N: nothing to take otherwise
         const bool large = !small || max_length > FFT_MAX / 2;
         int* queue = ev_need + n_cand;   // the scan's zero sentinel: free again, and 0; the slot behind it for the second launch
         (void)hipMemsetAsync(queue + 1, 0, sizeof(int), s);
@@ -3886,14 +3924,14 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
             const int cgrid = n_cand < blocks ? n_cand : blocks;
             hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX - 1>, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)conv_lds_bytes(FFT_LOG2_MAX - 1), s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
-                               tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue, 0);
+                               tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue, 0, nz_off, nullptr);
         }
         if (large) {
             const int cgrid = n_cand < channel_grid_blocks() / 2 ? n_cand : channel_grid_blocks() / 2;
             hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX>, dim3(cgrid), dim3(CONV_NT), (size_t)conv_lds_bytes(FFT_LOG2_MAX), s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue + (small ? 1 : 0),
-                               small ? FFT_MAX / 2 : 0);
+                               small ? FFT_MAX / 2 : 0, with_noise ? *noise : nz_off, with_noise ? noise_buf : nullptr);
         }
         skip_upto = FFT_MAX;
         if (max_length <= FFT_MAX && !st.ant_tabs) return;
