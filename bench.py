@@ -163,14 +163,17 @@ def build_array(ctx, wl):
     if trig in ('pa', 'pa_adc_noise'):
         ang = np.arcsin(np.linspace(np.sin(-60 * np.pi / 180), np.sin(60 * np.pi / 180), 11))
         if trig == 'pa':
-            st.set_phased_array([0, 1, 2, 3], ang, window=16, step=8)
+            rolls = st.set_phased_array([0, 1, 2, 3], ang, window=16, step=8)
             wl['sim_kw'] = dict(wl['sim_kw'], trigger='phased_array', trigger_threshold=2.0 * (2 * st.vrms) ** 2)
+            wl['pa'] = dict(channels=[0, 1, 2, 3], rolls=np.array(rolls), window=16, step=8, threshold=2.0 * (2 * st.vrms) ** 2, adc=None)
         else:
-            st.set_phased_array([0, 1, 2, 3], ang, window=24, step=8, upsampling_factor=4,
-                                adc=dict(sampling_frequency=0.472, n_bits=8, noise_count=5, output='counts'))
-            st.set_noise(300.)
+            rolls = st.set_phased_array([0, 1, 2, 3], ang, window=24, step=8, upsampling_factor=4,
+                                        adc=dict(sampling_frequency=0.472, n_bits=8, noise_count=5, output='counts'))
+            amp = st.set_noise(300.)
             # mean noise power of the coherent sum: 4 channels x (5 counts)^2; 6 x that keeps noise-only windows below ~1e-2 per event
             wl['sim_kw'] = dict(wl['sim_kw'], trigger='phased_array', trigger_threshold=6.0 * (2 * 5) ** 2, noise=True, noise_seed=1235)
+            wl['pa'] = dict(channels=[0, 1, 2, 3], rolls=np.array(rolls), window=24, step=8, threshold=6.0 * (2 * 5) ** 2,
+                            adc=dict(fs=0.472, n_bits=8, noise_count=5, up=4, vrms=float(st.vrms)), noise_amp=np.array(amp), noise_seed=1235)
     if wl['config'] == 4:
         from nuradiomc_amd import arz as arz_mod
         st.set_birefringence(birefringence_splines(), angle_to_iceflow=None)
@@ -239,10 +242,39 @@ def _oracle_chunk(args):
             sh = [dict(vertex=ev['vertex'][i], zenith=ev['zenith'][i], azimuth=ev['azimuth'][i], energy=ev['energy'][i],
                        shower_type='HAD' if ev['shower_type'][i] == 0 else 'EM', k_L=ev['k_L'][i], vertex_time=0.,
                        iN=int(ev['iN'][i]) if 'iN' in ev else None) for i in range(a, b)]
-            res = so.simulate_event_group_array(sh, arr['centres'][stations], arr['rel_pos'], arr['ice'], vrms, vrms_e, station_kw=skw,
-                                                att_model=arr['att_model'], n_freq=25, distance_cut_coefficients=DCUT,
-                                                trigger=trig, **gen_kw)
-            out[g - lo] = any(o['triggered'] for o in res)
+            pa = arr.get('pa')
+            if pa is not None and 'noise_amp' in pa:
+                # thermal noise: keyed by the event group's index in the list, every station its own stream (array.py: the seed of
+                # station i is seed + 0x9E3779B97F4A7C15 (i + 1))
+                res = []
+                for i_st in stations:
+                    seed_i = (int(pa['noise_seed']) + 0x9E3779B97F4A7C15 * (int(i_st) + 1)) & 0xffffffffffffffff
+                    res += so.simulate_event_group_array(sh, arr['centres'][[i_st]], arr['rel_pos'], arr['ice'], vrms, vrms_e, station_kw=skw,
+                                                         att_model=arr['att_model'], n_freq=25, distance_cut_coefficients=DCUT,
+                                                         trigger=trig, noise=(seed_i, g, 0, pa['noise_amp']), **gen_kw)
+            else:
+                res = so.simulate_event_group_array(sh, arr['centres'][stations], arr['rel_pos'], arr['ice'], vrms, vrms_e, station_kw=skw,
+                                                    att_model=arr['att_model'], n_freq=25, distance_cut_coefficients=DCUT,
+                                                    trigger=trig, **gen_kw)
+            if pa is None:
+                out[g - lo] = any(o['triggered'] for o in res)
+            else:
+                # the phased array of phasedArrayBase.py on the oracle's (noisy) traces of the array's channels: analog beams, or the
+                # trigger ADC + FFT up-sampling + saturating count sums (the oracle's restatements, pinned by tests/test_gpu_chain.py)
+                hit = False
+                for o in res:
+                    if 'V' not in o:
+                        continue
+                    Vp = o['V'][pa['channels']]
+                    if pa['adc'] is None:
+                        hit = hit or bool(so.phased_array_trigger(Vp, pa['rolls'], pa['window'], pa['step'], pa['threshold'])[0])
+                    else:
+                        a = pa['adc']
+                        U = np.array([so.digital_upsampling_fft(so.adc_digital_trace(x, arr['fs'], a['fs'], a['n_bits'], a['vrms'],
+                                                                                     a['noise_count'], 'counts'), a['up']) for x in Vp])
+                        p = so.phased_array_power_digital(U, pa['rolls'], pa['window'], pa['step'], 'counts')
+                        hit = hit or bool(np.any(p > np.trunc(pa['threshold'])))
+                out[g - lo] = hit
         return lo, out
     st = so.Station(CHANNELS, n_samples=N_SAMPLES, fs=FS)
     vrms, vrms_e = so.vrms_from_filters(FS)
@@ -272,7 +304,7 @@ def cpu_baseline(wl, budget_s, n_max, cores=None, arz_iN=None):
         arr = dict(centres=wl['centres'], rel_pos=wl['rel_pos'], antenna=wl['antenna'], orientation=wl['orientation'],
                    cable_delay=wl['cable_delay'], N=wl['N'], fs=wl['fs'], ice=wl['ice'], att_model=wl['att_model'],
                    trigger=wl['sim_kw'].get('trigger', 'simple'), n_coincidences=wl['sim_kw'].get('n_coincidences', 1),
-                   coinc_window=wl['sim_kw'].get('coinc_window', 200.), general=wl['config'] == 4)
+                   coinc_window=wl['sim_kw'].get('coinc_window', 200.), general=wl['config'] == 4, pa=wl.get('pa'))
     chunk = 125 if arr is None else 4
     n_near = 2   # config 4: the stations nearest to the group's vertex are the jobs (station-events, not whole groups)
 
@@ -593,6 +625,7 @@ def main():
                        "n_active_rays": stats['n_active_rays'], "n_candidate_events": stats['n_candidate_events'],
                        "n_channel_items": stats['n_channel_items'], "n_channel_transforms": stats['n_channel_transforms'],
                        "n_ray_transforms": stats['n_ray_transforms'], "n_efield_transforms": stats['n_efield_transforms'],
+                       "n_adc_convolutions": stats.get('n_adc_convolutions', 0),
                        "n_triggered_rank0": stats['n_triggered'], "n_triggered_all": n_trig_total,
                        "all_ranks": {k: int(v) for k, v in tot.items()},
                        "triggered_events_per_s": n_trig_total / (elapsed / max(args.steps, 1)),
@@ -620,6 +653,11 @@ def main():
         M_, nh_ = 8192, wl['N'] // 2
         flop_channel = (stats['n_channel_transforms'] * (2 * 5. * M_ * 13 + 14. * (M_ // 2 + 1)) +
                         stats['n_ray_transforms'] * (5. * nh_ * np.log2(nh_) + 40. * nh_))
+        if wl['sim_kw'].get('noise'):   # the noise trace of every channel trace: one more 8192-point transform pair (inverse chirp-z)
+            flop_channel += stats['n_channel_transforms'] * (2 * 5. * M_ * 13 + 6. * M_)
+        # trigger-ADC chain of the phased array: 8192-point chirp convolutions counted by pa_czt_stage_kernel (transform pair + the
+        # three chirp products)
+        flop_channel += stats.get('n_adc_convolutions', 0) * (2 * 5. * M_ * 13 + 18. * M_)
         # FP64 view of the ray finder: calls of the objective delta_y(log C0) counted by the kernel (hybrd + two Brent searches, ~1e2 per
         # pair) x FLOP_PER_OBJECTIVE (~90 add / mul, 13 divisions and 6 square roots at 1 flop, 1 exp + 4 log at 20)
         flop_of = {'attenuation': stats['n_integrand_evals'] * flop_per_eval, 'channel': flop_channel,
@@ -635,8 +673,8 @@ def main():
                                     "frac": tf / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": flop_of[dom],
                                     "hbm_view_GBs": achieved})
         out["cpu_baseline"] = None
-        if args.trigger != 'threshold':
-            pass   # (the oracle legs below run the threshold trigger; the phased-array lines are GPU-only, pinned by tests/test_gpu_chain.py)
+        if args.trigger != 'threshold' and cfgno == 4:
+            pass   # (config 4 with the phased array: GPU-only line; the general path with it is pinned by tests/test_gpu_chain.py)
         elif world == 1 and not args.no_cpu_baseline and cfgno == 4:
             # the oracle needs minutes per central event group here: the check is per (event group, station) -- the per-station masks
             # of one more GPU pass against the oracle's single-station runs
@@ -658,7 +696,7 @@ def main():
             ctx.to_host(host_mask, d['trig'])
             mism = int(np.sum(host_mask[:n_done] != flags))
             base['parity_check'] = "GPU trigger mask == oracle on the %d sampled event groups: %d mismatches" % (n_done, mism)
-        if world == 1 and not args.no_cpu_baseline and args.trigger == 'threshold':
+        if world == 1 and not args.no_cpu_baseline and (args.trigger == 'threshold' or cfgno != 4):
             out["cpu_baseline"] = base
             if mism:
                 print(json.dumps(out, default=_json_default))

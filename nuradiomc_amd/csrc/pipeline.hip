@@ -1168,9 +1168,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     }
     S.n_active_rays = n_active;
     unsigned long long* eval_counter = nullptr;
-    unsigned long long* xform_count;  // [0] channel traces computed, [1] rays in them, [2] rays transformed for the candidate cut
-    NEED(xform_count = WS("transform_count", unsigned long long, 3));
-    HIPCHK(hipMemsetAsync(xform_count, 0, 3 * sizeof(unsigned long long), sm));
+    unsigned long long* xform_count;  // [0] channel traces computed, [1] rays in them, [2] rays transformed for the candidate cut,
+                                      // [3] 8192-point chirp convolutions of the trigger-ADC chain
+    NEED(xform_count = WS("transform_count", unsigned long long, 4));
+    HIPCHK(hipMemsetAsync(xform_count, 0, 4 * sizeof(unsigned long long), sm));
     MARK(3);
     if (n_active > 0) {
         // attenuation on the coarse frequency grid, active rays only
@@ -1653,7 +1654,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                                                     st->pa_n_channels, st->d_pa_channel.as<int>(), st->pa_n_beams,
                                                     st->d_pa_rolls_up.as<int>(), st->pa_window, st->pa_step, (double)st->pa_divisor,
                                                     cfg->trigger_threshold, maxL, sd.fs, adc, ctx->twiddle, st->pa_B.as<double2>(), work,
-                                                    chunk, pa_trace, pa_len, ev_triggered, pa_max, with_beams);
+                                                    chunk, pa_trace, pa_len, ev_triggered, pa_max, with_beams, xform_count + 3);
                 } else
                 launch_phased_array_digital(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, st->pa_n_channels,
                                             st->d_pa_channel.as<int>(), st->pa_n_beams, st->d_pa_rolls_up.as<int>(), st->pa_window,
@@ -1716,12 +1717,13 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             S.n_integrand_evals = (int64_t)ne;
         }
         {
-            unsigned long long xc[3] = {0, 0, 0};
+            unsigned long long xc[4] = {0, 0, 0, 0};
             HIPCHK(hipMemcpyAsync(xc, xform_count, sizeof xc, hipMemcpyDeviceToHost, sm));
             HIPCHK(hipStreamSynchronize(sm));
             S.n_channel_transforms = (int64_t)xc[0];
             S.n_ray_transforms = (int64_t)xc[1];
             S.n_efield_transforms = (int64_t)xc[2];
+            S.n_adc_convolutions = (int64_t)xc[3];
         }
         for (int i = 0; i < 8; i++) {
             float ms = 0.f;

@@ -244,14 +244,16 @@ void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_
                                      const double* trace, const long* trace_offset, int n_pa, const int* pa_channel, int n_beams,
                                      const int* rolls_up, int window, int step, double divisor, double threshold, int max_length, double fs,
                                      const PaAdc& adc, const double2* tw, const double2* Btab, void* work, int chunk, double* pa_trace,
-                                     int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams = true);
+                                     int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams = true,
+                                     unsigned long long* conv_count = nullptr);
 void launch_phased_array_beams(hipStream_t s, int n_cand, const int* item_event, int n_pa, int n_beams, const int* rolls_up, int window,
                                int step, double divisor, double threshold, const PaAdc& adc, const double* pa_trace, const int* pa_len,
                                unsigned char* triggered, double* pa_max);
 void launch_phased_array_digital(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                                  const long* trace_offset, int n_pa, const int* pa_channel, int n_beams, const int* rolls_up, int window,
                                  int step, double divisor, double threshold, int max_length, double fs, const PaAdc& adc,
-                                 double* pa_trace, int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams = true);
+                                 double* pa_trace, int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams = true,
+                                     unsigned long long* conv_count = nullptr);
 void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                           const long* trace_offset, const TriggerDev& trg, const unsigned char* trig_on, int max_length,
                           unsigned char* triggered, int* trigger_bin);

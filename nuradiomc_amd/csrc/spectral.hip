@@ -4457,7 +4457,8 @@ __global__ void __launch_bounds__(512)
 pa_czt_stage_kernel(int stage, int item0, int n_cand, const int* __restrict__ item_event, int n_ch, const int* __restrict__ ev_L,
                     const int* __restrict__ slotmap, const double* __restrict__ trace, const long* __restrict__ trace_offset, int n_pa,
                     const int* __restrict__ pa_channel, double fs, PaAdc adc, const double2* __restrict__ tw,
-                    const double2* __restrict__ Btab, PaWork wk, double* __restrict__ pa_trace)
+                    const double2* __restrict__ Btab, PaWork wk, double* __restrict__ pa_trace,
+                    unsigned long long* __restrict__ conv_count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double2* x = (double2*)smem;
@@ -4472,6 +4473,7 @@ pa_czt_stage_kernel(int stage, int item0, int n_cand, const int* __restrict__ it
     pa_stage(z, stage, &n_in, &Q, &sgn, &P, &n_out);
     const long k0 = (long)blockIdx.y * P;
     if (k0 >= n_out) return;
+    if (threadIdx.x == 0 && conv_count) atomicAdd(conv_count, 1ULL);   // 8192-point chirp convolutions carried out (bench.py prices them)
     const int st = stage < 3 ? stage - 1 : stage - 2;
     const double2* B = Btab + ((long)slotmap[L / 2] * 4 + st) * FFT_MAX;
     const double* tr = trace + trace_offset[(long)ic * n_ch + pa_channel[c]];
@@ -4488,7 +4490,7 @@ pa_czt_stage_kernel(int stage, int item0, int n_cand, const int* __restrict__ it
             v = cmul(v, chirp(j, Q, sgn));
             if (k0) {   // outputs k0 .. : in[j] exp(sgn 2 pi i j k0 / Q)
                 double sn, cs;
-                sincospi(2. * (double)(((long long)j * k0) % Q) / (double)Q, &sn, &cs);
+                sincospi(2. * (((double)j * (double)k0 < 4.5e15 && Q < (1l << 30)) ? mod_exact((double)j * (double)k0, (double)Q) : (double)(((long long)j * k0) % Q)) / (double)Q, &sn, &cs);
                 v = cmul(v, make_double2(cs, sgn * sn));
             }
         }
@@ -4761,7 +4763,8 @@ void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_
                                      const double* trace, const long* trace_offset, int n_pa, const int* pa_channel, int n_beams,
                                      const int* rolls_up, int window, int step, double divisor, double threshold, int max_length, double fs,
                                      const PaAdc& adc, const double2* tw, const double2* Btab, void* work, int chunk, double* pa_trace,
-                                     int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams)
+                                     int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams,
+                                     unsigned long long* conv_count)
 {
     if (n_cand <= 0) return;
     set_big_lds();
@@ -4791,7 +4794,7 @@ void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_
                 continue;
             }
             hipLaunchKernelGGL(pa_czt_stage_kernel, dim3(nb, blocks(stage)), dim3(512), (size_t)FFT_MAX * 16, s, stage, item0, n_cand,
-                               item_event, n_ch, ev_L, slotmap, trace, trace_offset, n_pa, pa_channel, fs, adc, tw, Btab, wk, pa_trace);
+                               item_event, n_ch, ev_L, slotmap, trace, trace_offset, n_pa, pa_channel, fs, adc, tw, Btab, wk, pa_trace, conv_count);
         }
     }
     if (with_beams)

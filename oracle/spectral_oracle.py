@@ -932,7 +932,7 @@ def simulate_event(vertex, zenith, azimuth, energy, shower_type, k_L, st, ice, v
 def simulate_event_group(showers, st, ice, vrms, vrms_efield, att_model='SP1', n_freq=25, model='Alvarez2009',
                          filters=DEFAULT_FILTERS, delta_C_cut=0.698, trigger_sigma=3.0, min_efield_amplitude=2.0,
                          distance_cut_coefficients=None, distance_cut_sum_length=10., arz=None, birefringence=None,
-                         trigger=None, split_event_time_diff=None):
+                         trigger=None, split_event_time_diff=None, noise=None):
     """An event group of several showers through simulation.run()'s sequence (:1454-1600): calculate_sim_efield loops
     over the showers per channel (:143), the candidate flag, the common time grid, the channel sums and the trigger are
     per group.  `showers`: list of dicts with vertex, zenith, azimuth, energy, shower_type, k_L, vertex_time (and 'iN', the
@@ -978,7 +978,7 @@ def simulate_event_group(showers, st, ice, vrms, vrms_efield, att_model='SP1', n
         out['sub_of_ray'] = sub_of
         out['triggered'] = any(q['triggered'] for q in out['sub'])
         return out
-    V, t_min, L = combined_voltage(efs, st, filters)
+    V, t_min, L = combined_voltage(efs, st, filters, noise=noise)   # noise = (seed, group id, sub-event, amplitude per channel)
     out.update(V=V, t_min=t_min, L=L)
     if trigger is None:
         out['triggered'] = threshold_trigger(V, trigger_sigma * vrms)
