@@ -23,6 +23,6 @@ for f in api raytrace raytrace_refl arz birefringence earth attenuation comm cul
     PIDS="$PIDS $!"
 done
 for p in $PIDS; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT -Wl,-rpath,/opt/rocm/lib -ldl
+$HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT -Wl,-rpath,/opt/rocm/lib -Wl,-z,defs -ldl   # (-z defs: a declaration without its definition fails here, not at dlopen)
 gcc -O2 -fPIC -shared -std=gnu11 -ffp-contract=off -o oracle/_build/liboracle.so oracle/nrmc_oracle.c oracle/arz_oracle.c -lm
 echo "built $OUT oracle/_build/liboracle.so"

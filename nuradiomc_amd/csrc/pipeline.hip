@@ -816,6 +816,12 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (n_slots > 2000000000L) return nrhip_fail_msg("nrhip_simulate_events: batch too large, split the event list");
     S.n_pairs = n_pairs;
     unsigned long long* rt_eval_counter = nullptr;
+    // general path with birefringence, production mode: the propagation in two rounds (see "two rounds" below)
+    bool two_rounds = false;
+    BireBatch bb_keep{};
+    double *steps_keep = nullptr, *traces_keep = nullptr;
+    double2* spec_keep = nullptr;
+    int* gactive_keep = nullptr;
     // general emission / propagation path?
     const bool arz = cfg->askaryan_model == NRHIP_ASK_ARZ2019 || cfg->askaryan_model == NRHIP_ASK_ARZ2020;
     const bool bire = st->bire_n_knots[0] > 0;
@@ -1278,12 +1284,21 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             NEED(log_gain = WS("bire_log_gain", long long, nr));
             NEED(gactive = WS("ray_propagated", int, nr));
             launch_birefringence_steps(sm, bb, max_points, steps, log_gain);
-            launch_general_bound(sm, n_rays, sd, spec, log_gain, bound);
+            // Two rounds (round 4): the propagation is the most expensive stage of this path, and most rays of a possible event
+            // decide nothing.  First only the rays whose own bound exceeds the candidate cut (they alone can make the event a
+            // candidate: the flags are exact); later, for the candidate readouts, the rays of the channels that can reach the
+            // trigger threshold at all (Cauchy-Schwarz with the field norms bounded through the path gain) -- the other channels are
+            // not evaluated, their rays never propagated.  Only where a plain threshold decides and nothing else wants the traces.
+            two_rounds = !cfg->no_pruning && !cfg->dump_traces && !cfg->amp_per_ray && !phased && !envelope && !noise &&
+                         cfg->trigger_type == NRHIP_TRIG_SIMPLE && cfg->n_coincidences <= 1 && !(cfg->split_event_time_diff > 0) &&
+                         n_refl == 0 && !getenv("NRHIP_GENERAL_ONE_ROUND");
+            launch_general_bound(sm, n_rays, sd, spec, log_gain, bound, two_rounds ? w.e_norm : nullptr);
             launch_event_possible(sm, (int)n_groups, n_ch, grp_ray, bound,
-                                  (cfg->no_pruning || cfg->dump_traces) ? -1.0 : cfg->min_efield_amplitude, gactive);
+                                  (cfg->no_pruning || cfg->dump_traces) ? -1.0 : cfg->min_efield_amplitude, gactive, two_rounds ? 1 : 0);
             launch_birefringence_propagate(sm, bb, steps, spec, gactive);
             LCHK("birefringence");
             HIPCHK(hipStreamSynchronize(sm));  // `off` goes out of scope
+            if (two_rounds) { bb_keep = bb; steps_keep = steps; spec_keep = spec; traces_keep = traces; gactive_keep = gactive; }
             launch_general_trace(sm, n_rays, sd, spec, ctx->twiddle, traces, max_efield, gactive, bound);
         } else {
             launch_general_trace(sm, n_rays, sd, spec, ctx->twiddle, traces, max_efield);
@@ -1575,12 +1590,23 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             const double divisor = st->pa_divisor > 0 ? (double)st->pa_divisor : (double)st->pa_window;
             pa_amp_cut = sqrt(cfg->trigger_threshold * divisor / (double)st->pa_window);
         }
+        const int* general_need = nullptr;
+        if (two_rounds) {
+            int* fresh;
+            NEED(fresh = WS("ray_propagated_late", int, nr));
+            launch_general_prefilter(sm, n_items, d_cand, w, ev, d_len_index, sd_ch, trg_ch.threshold, tab.hnorm, co.maxV, it_need, n_rays,
+                                     gactive_keep, fresh);
+            launch_birefringence_propagate(sm, bb_keep, steps_keep, spec_keep, fresh);
+            launch_general_trace(sm, n_rays, sd, spec_keep, ctx->twiddle, traces_keep, max_efield, fresh, nullptr);
+            LCHK("birefringence (second round)");
+            general_need = it_need;
+        }
         launch_channel(sm, n_items, d_cand, w, evin, ev, d_len_index, sd_ch, st->filters[0], arz ? NRHIP_ASK_ALVAREZ2009 : cfg->askaryan_model,
                        trg_ch, ctx->twiddle, ctx->w16, tab, scratch, co,
                        (cfg->no_pruning || cfg->dump_traces || general || phased || post_trigger || noise) ? 1 : 0, maxL,
                        it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces,
                        (phased || post_trigger) ? (cfg->dump_traces ? 0 : 1) : -1, envelope ? &st->env_filter : nullptr, env_trace,
-                       noise ? &nz : nullptr, conv_split, pa_amp_cut, amp_scratch, conv_noise);
+                       noise ? &nz : nullptr, conv_split, pa_amp_cut, amp_scratch, conv_noise, general_need);
         LCHK("channel");
         if (post_trigger) {
             if (maxL > 2 * FFT_MAX)

@@ -202,7 +202,10 @@ void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const 
 void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double2* tw,
                           double* traces, double* max_efield, const int* active = nullptr, const double* bound = nullptr);
 void launch_general_bound(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const long long* log_gain,
-                          double* bound);
+                          double* bound, double* e_norm = nullptr);
+void launch_general_prefilter(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventOut& ev,
+                              const int* ev_len_index, const StationDev& st, double threshold, const double* hnorm, double* maxV,
+                              int* need, int n_rays, int* propagated, int* fresh);
 void launch_general_gather(hipStream_t s, int n_rays, int n_ch, const RayWork& w, const EventIn& evin, const StationDev& st,
                            const double* vertex, const int* shower_profile, const double* shower_rescale, int em_formula,
                            double* energy, int* type, double* em_factor, int* profile, double* rescale, double* x1, double* x2,
@@ -217,7 +220,8 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
                     const double* ray_traces = nullptr, int skip_off = -1, const FilterSet* envf = nullptr, double* env_trace = nullptr,
-                    const NoiseDev* noise = nullptr, bool conv_split = true, double pa_amp_cut = -1., double* amp_scratch = nullptr, double* noise_buf = nullptr);
+                    const NoiseDev* noise = nullptr, bool conv_split = true, double pa_amp_cut = -1., double* amp_scratch = nullptr, double* noise_buf = nullptr,
+                    const int* item_need = nullptr);
 // channel_kernel's amplitude table lives in HBM scratch (rows of N / 2 + 1 doubles per block) when N > 4096
 inline bool channel_amp_in_hbm(int n_samples) { return n_samples / 2 > 2048; }
 // efield_max_kernel / general_spectrum_kernel: N / 2 no power of two and above 2048 -- the Bluestein transform takes FFT_MAX points,
@@ -252,8 +256,7 @@ void launch_phased_array_beams(hipStream_t s, int n_cand, const int* item_event,
 void launch_phased_array_digital(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                                  const long* trace_offset, int n_pa, const int* pa_channel, int n_beams, const int* rolls_up, int window,
                                  int step, double divisor, double threshold, int max_length, double fs, const PaAdc& adc,
-                                 double* pa_trace, int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams = true,
-                                     unsigned long long* conv_count = nullptr);
+                                 double* pa_trace, int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams = true);
 void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                           const long* trace_offset, const TriggerDev& trg, const unsigned char* trig_on, int max_length,
                           unsigned char* triggered, int* trigger_bin);

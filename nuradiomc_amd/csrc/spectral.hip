@@ -3009,7 +3009,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
                const double2* __restrict__ tw, LengthTables tab, double2* __restrict__ scratch, int log2nh,
                ChannelOut out, int exact, int skip_upto, double2* __restrict__ tab_nodes,
                const double* __restrict__ ray_traces, FilterSet envf, double* __restrict__ env_trace, NoiseDev nz,
-               double* __restrict__ amp_scratch)
+               double* __restrict__ amp_scratch, const int* __restrict__ item_need)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int M = FFT_MAX, N = st.N, nh = N / 2;
@@ -3027,6 +3027,7 @@ channel_kernel(int n_items, const int* __restrict__ item_event, RayWork w, Event
         const int L = ev.L[e], m = L / 2, il = ev_len_index[e];
         const bool tabulated = (st.ant_model[ch] == 3);
         if (L <= skip_upto && !tabulated && !ray_traces) continue;  // done by channel_conv_kernel
+        if (item_need && !item_need[item]) continue;   // general path: the channel cannot reach the threshold (general_prefilter_kernel)
         double2* nodes = tab_nodes ? tab_nodes + (long)blockIdx.x * 2 * st.max_tab_freq : nullptr;
         const double t_min = ev.t_min[e];
         const double res = 1. / st.fs;
@@ -3882,7 +3883,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
                     const double* ray_traces, int skip_off, const FilterSet* envf, double* env_trace, const NoiseDev* noise,
-                    bool conv_split, double pa_amp_cut, double* amp_scratch, double* noise_buf)
+                    bool conv_split, double pa_amp_cut, double* amp_scratch, double* noise_buf, const int* item_need)
 {
     if (skip_off < 0) skip_off = !exact;  // channels outside the trigger set are evaluated only when everything is
     if (n_items <= 0) return;
@@ -3940,7 +3941,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     hipLaunchKernelGGL(channel_kernel, dim3(grid), dim3(512), lds, s, n_items, item_event, w, evin, ev, ev_len_index, st, fl,
                        ask_model, trig.threshold, tw, tab, scratch, ilog2(nh), out, exact, skip_upto, tab_nodes, ray_traces,
                        envf ? *envf : fl, env_trace, noise ? *noise : NoiseDev{0, 0ull, nullptr, nullptr, 0, nullptr, nullptr},
-                       amp_scratch);
+                       amp_scratch, item_need);
 }
 // ---------------------------------------------------------------------------------------------------------
 // General emission / propagation path (time-domain emission models such as ARZ, birefringence): the on-sky spectra of every
@@ -4018,8 +4019,8 @@ general_trace_kernel(int n_rays, StationDev st, const double2* __restrict__ spec
     __shared__ double red[256];
     const double scale = st.fs / 1.4142135623730951 / nh;
     for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
-        if (active && !active[r]) {  // not evaluated: "at most `bound`" (its event cannot become a candidate)
-            if (threadIdx.x == 0) max_efield[r] = -bound[r];
+        if (active && !active[r]) {  // not evaluated: "at most `bound`" (its event cannot become a candidate); no bound given: a
+            if (threadIdx.x == 0 && bound) max_efield[r] = -bound[r];   // second round, the entry stays what the first left
             continue;
         }
         double mx = 0.;
@@ -4055,23 +4056,74 @@ general_trace_kernel(int n_rays, StationDev st, const double2* __restrict__ spec
 // Lets the birefringent propagation (the expensive part of the general path) skip the events that cannot become candidates.
 __global__ void __launch_bounds__(256)
 general_bound_kernel(int n_rays, StationDev st, const double2* __restrict__ spec, const long long* __restrict__ log_gain,
-                     double* __restrict__ bound)
+                     double* __restrict__ bound, double* __restrict__ e_norm)
 {
     __shared__ double red[256];
     const int N = st.N, nh = N / 2, n_f = nh + 1;
     for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
         const double2* Et = spec + (long)r * 2 * n_f;
         const double2* Ep = Et + n_f;
-        double part = 0.;
+        double part = 0., part2 = 0.;
         for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
             const double2 a = Et[k], b = Ep[k];
-            const double m = sqrt(a.x * a.x + a.y * a.y + b.x * b.x + b.y * b.y);
+            const double m2 = a.x * a.x + a.y * a.y + b.x * b.x + b.y * b.y;
+            const double m = sqrt(m2);
             part += (k == 0 || k == nh) ? m : 2. * m;
+            part2 += (k == 0 || k == nh) ? m2 : 2. * m2;
         }
         const double sum = block_sum(part, red);
-        if (threadIdx.x == 0)
-            bound[r] = (st.fs / 1.4142135623730951 / N) * sum * exp(log_gain ? (double)log_gain[r] * (1. / 1099511627776.0) : 0.) * (1. + 1e-9);
+        const double sum2 = e_norm ? block_sum(part2, red) : 0.;
+        if (threadIdx.x == 0) {
+            const double gain = exp(log_gain ? (double)log_gain[r] * (1. / 1099511627776.0) : 0.);
+            bound[r] = (st.fs / 1.4142135623730951 / N) * sum * gain * (1. + 1e-9);
+            // L2 norm of the ray's field after the propagation, at most (Parseval on the N-sample trace e = irfft(E) fs / sqrt 2, both
+            // on-sky components together; the path's gain bounds what the birefringent propagation can do to it): what the
+            // Cauchy-Schwarz bound of a channel multiplies with
+            if (e_norm) e_norm[r] = sqrt(st.fs * st.fs / (2. * N) * sum2) * gain * (1. + 1e-9);
+        }
         __syncthreads();
+    }
+}
+
+// General path, production mode: which channels of the candidate readouts can reach the trigger threshold at all?
+// |V_c(t)| <= sum over the channel's rays of ||g_L|| sqrt(vfac_t^2 + vfac_p^2) ||e_r|| (Cauchy-Schwarz, the two on-sky components as a
+// 2-vector).  The others are not evaluated -- and their rays, unless they decided the candidate cut, never propagated.
+__global__ void __launch_bounds__(256)
+general_prefilter_kernel(int n_items, const int* __restrict__ item_event, RayWork w, EventOut ev, const int* __restrict__ ev_len_index,
+                         StationDev st, double threshold, const double* __restrict__ hnorm, double* __restrict__ maxV,
+                         int* __restrict__ need)
+{
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_items) return;
+    const int e = item_event[item / st.n_ch], ch = item % st.n_ch;
+    const int L = ev.L[e], il = ev_len_index[e];
+    if (st.trig_on && !st.trig_on[ch]) { need[item] = 0; maxV[item] = NAN; return; }   // not a trigger channel
+    if (L > FFT_MAX || st.ant_model[ch] == 3) { need[item] = 1; return; }               // no norm table: evaluated
+    const int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
+    double bnd = 0.;
+    for (int r = r0; r < r1; r++) {
+        if (w.ch[r] != ch) continue;
+        const double vt = w.vfac_t[r], vp = w.vfac_p[r];
+        bnd += w.e_norm[r] * sqrt(vt * vt + vp * vp) *
+               hnorm[((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[ch] : 0)) * NRHIP_N_ANT_TAB + w.tab[r]];
+    }
+    const int flag = (bnd * (1 + 1e-9) >= threshold) ? 1 : 0;
+    if (!flag) maxV[item] = -bnd;
+    need[item] = flag;
+}
+// ... and the rays of those channels that have not been propagated yet
+__global__ void __launch_bounds__(256)
+general_mark_rays_kernel(int n_cand, const int* __restrict__ item_event, EventOut ev, RayWork w, int n_ch, const int* __restrict__ need,
+                         int* __restrict__ propagated, int* __restrict__ fresh)
+{
+    const int ic = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ic >= n_cand) return;
+    const int e = item_event[ic];
+    const int r0 = ev.ray_begin[e], r1 = r0 + ev.n_rays[e];
+    for (int r = r0; r < r1; r++) {
+        const int want = need[(long)ic * n_ch + w.ch[r]] && !propagated[r];
+        fresh[r] = want;
+        if (want) propagated[r] = 1;
     }
 }
 
@@ -4140,11 +4192,23 @@ void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const
                        max_efield, active, bound);
 }
 void launch_general_bound(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const long long* log_gain,
-                          double* bound)
+                          double* bound, double* e_norm)
 {
     if (n_rays <= 0) return;
     int grid = n_rays < 256 * 64 ? n_rays : 256 * 64;
-    hipLaunchKernelGGL(general_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, st, spec, log_gain, bound);
+    hipLaunchKernelGGL(general_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, st, spec, log_gain, bound, e_norm);
+}
+void launch_general_prefilter(hipStream_t s, int n_items, const int* item_event, const RayWork& w, const EventOut& ev,
+                              const int* ev_len_index, const StationDev& st, double threshold, const double* hnorm, double* maxV,
+                              int* need, int n_rays, int* propagated, int* fresh)
+{
+    if (n_items <= 0) return;
+    hipLaunchKernelGGL(general_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev, ev_len_index,
+                       st, threshold, hnorm, maxV, need);
+    (void)hipMemsetAsync(fresh, 0, sizeof(int) * (size_t)n_rays, s);
+    const int n_cand = n_items / st.n_ch;
+    hipLaunchKernelGGL(general_mark_rays_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, item_event, ev, w, st.n_ch, need,
+                       propagated, fresh);
 }
 void launch_general_gather(hipStream_t s, int n_rays, int n_ch, const RayWork& w, const EventIn& evin, const StationDev& st,
                            const double* vertex, const int* shower_profile, const double* shower_rescale, int em_formula,
