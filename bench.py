@@ -358,6 +358,28 @@ def cpu_baseline(wl, budget_s, n_max, cores=None, arz_iN=None):
                        % (n_done, dt, cores, int(flags.sum()))), n_done, flags
 
 
+def end_to_end(st, wl):
+    """The whole drop-in for the same list: event-list arrays on the HOST -> the tables the reference's output writer stores
+    (output_writer_hdf5.py:215-320) on the HOST -- upload, Earth-absorption weights, the hot path, the traces and per-ray tables of the
+    triggered groups, the assembly of the tables.  nuradiomc_amd.output.simulate_to_output, timed as one call."""
+    from nuradiomc_amd import output
+    ev = wl['events']
+    n = len(ev['zenith'])
+    data = dict(event_group_ids=ev['group'].astype(np.int64), shower_ids=np.arange(n), xx=ev['vertex'][:, 0], yy=ev['vertex'][:, 1],
+                zz=ev['vertex'][:, 2], zeniths=ev['zenith'], azimuths=ev['azimuth'], shower_energies=ev['energy'],
+                shower_type=np.where(ev['shower_type'] == 0, 'had', 'em'), energies=np.full(n, 1e18), flavors=np.full(n, 12),
+                n_interaction=np.ones(n, int), interaction_type=np.full(n, 'nc'), inelasticity=ev['energy'] / 1e18,
+                vertex_times=np.zeros(n), shower_realization_Alvarez2009=ev['k_L'])
+    t0 = time.perf_counter()
+    out = output.simulate_to_output(st, output.EventList(data), station_ids=[101])
+    dt = time.perf_counter() - t0
+    trig = out.datasets.get('triggered', np.zeros(0, bool))
+    return {"seconds": dt, "events_per_s": (int(ev['group'][-1]) + 1) / dt, "phases_s": {k: round(v, 3) for k, v in out.timing.items()},
+            "n_triggered_showers": int(np.sum(trig)), "n_datasets": len(out.datasets),
+            "note": "host arrays in, output tables (all datasets of the reference's HDF5 layout) out; the device-resident step above is "
+                    "'pass1' without upload"}
+
+
 def usable_cores():
     """host cores this process may really use: the CPU affinity mask, capped by the cgroup's CPU quota (the GPU boxes show 256
     logical CPUs but run under a 16-core quota -- 256 busy workers would be throttled to a crawl)"""
@@ -459,6 +481,8 @@ def main():
                     'workspace and host thread each; default 2 for config 3, 1 otherwise)')
     ap.add_argument('--allow-tcp', action='store_true', help='if RCCL does not come up on every rank: run the collectives over the TCP '
                     'star instead of exiting non-zero (single-GPU boxes: tools/two_ranks_one_gpu.sh)')
+    ap.add_argument('--end-to-end', action='store_true', help='config 2: host event list -> output tables on the host (upload, hot path, '
+                    'traces of the triggered events, the tables output_writer_hdf5.py stores), timed as a whole: one extra JSON field')
     ap.add_argument('--dry-run', action='store_true', help='launcher check without a GPU: the ranks meet on the TCP star, gather their '
                     '(rank, local rank) pairs and a sharded mask, rank 0 prints a JSON line')
     args = ap.parse_args()
@@ -522,7 +546,10 @@ def main():
         arz_iN = iN = st._arz.draw_profile_numbers(d['host'][3], ['HAD' if c == 0 else 'EM' for c in d['host'][4]])
         dev_kw['arz_rows'] = st._arz_shower_profiles(d['host'][3], d['host'][4], iN)
 
-    with_traces = cfgno == 2 and not args.no_traces   # single station: pass 2 inside the step (arrays: per station, not built yet)
+    # traces of the triggered events inside the step: single station (with the second-pass fallback), and the array whose trigger the
+    # convolution kernel decides itself (config 3, threshold on any channel: every station call emits the traces of the station-
+    # events that trigger there into its buffer; a caller keeps them per station through on_station)
+    with_traces = (cfgno == 2 or (cfgno == 3 and args.trigger == 'threshold')) and not args.no_traces
 
     def step():
         """one pass of the hot path over the resident list; config 2: including the channel traces of the triggered events, what
@@ -533,7 +560,7 @@ def main():
         if with_traces:
             s1['pass2_ms'] = 0.
             s1['trace_bytes'] = 8 * s1['n_emitted_samples']
-            if s1['n_emitted_events'] != s1['n_triggered'] or s1['n_emit_overflow']:
+            if not is_array and (s1['n_emitted_events'] != s1['n_triggered'] or s1['n_emit_overflow']):
                 s2, _, nk = st.triggered_pass_dev(n, *d['in'], d['trig'], n_groups=n_groups, d_group_begin=d['gb'], **wl['sim_kw'])
                 s1['pass2_ms'] = s2['stage_ms']['total'] if s2 else 0.
                 s1['trace_bytes'] = st.fetch_bytes('trace') if s2 else 0
@@ -701,6 +728,8 @@ def main():
             if mism:
                 print(json.dumps(out, default=_json_default))
                 raise SystemExit("bench.py: the GPU trigger mask differs from the oracle's on %d of %d sampled events" % (mism, n_done))
+        if args.end_to_end and cfgno == 2 and world == 1:
+            out["end_to_end"] = end_to_end(st, wl)
         print(json.dumps(out, default=_json_default))
     comm.barrier()
     free_events(ctx, d)

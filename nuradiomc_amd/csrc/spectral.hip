@@ -2284,6 +2284,10 @@ __device__ __noinline__ ConvOut conv_output_pass(int L, double vscale, double th
     }
     return o;
 }
+template <int NT, class FV, class FS>
+__device__ __forceinline__ void czt_inverse_blocks(double2* x, const double2* __restrict__ Bi, const double2* __restrict__ tw,
+                                                   const double2* __restrict__ E, const double2* __restrict__ Ci, int L, int m, int M,
+                                                   FV&& spectrum, FS&& sink);   // (defined with the chirp-z channel kernel below)
 // LOG2CAP: log2 of the complex points the LDS buffer holds.  13 (FFT_MAX): any event of up to FFT_MAX samples, 133 KB, one block per
 // CU.  12: events of up to FFT_MAX / 2 samples only (the N = 2048 workloads), 68 KB + 9 KB static: TWO blocks per CU, so one block's
 // barriers and LDS round trips are covered by the other's arithmetic.

@@ -71,7 +71,11 @@ class EventList:
         return np.stack([self.data['xx'], self.data['yy'], self.data['zz']], axis=1).astype(float)
 
     def shower_type_codes(self):
-        return np.array([{'had': 0, 'em': 1}[str(t).lower()] for t in self.data['shower_type']], np.int32)
+        t = np.char.lower(np.asarray(self.data['shower_type']).astype(str))
+        codes = np.where(t == 'had', 0, np.where(t == 'em', 1, -1)).astype(np.int32)
+        if np.any(codes < 0):
+            raise KeyError(str(t[codes < 0][0]))
+        return codes
 
     def k_L(self):
         """stored shower realisations (input files of re-simulations) or NaN"""
@@ -116,9 +120,17 @@ def write_hdf5(h5py, path, datasets, attrs):
 
 
 def _hilbert_envelope(x):
-    """|scipy.signal.hilbert(x)| along the last axis (trace_utilities.get_hilbert_envelope)"""
+    """|scipy.signal.hilbert(x)| along the last axis (trace_utilities.get_hilbert_envelope).  With scipy at hand its FFT runs the rows
+    on all cores (the windows of all triggered events go through in one call: numpy's transform, one row after the other on one
+    core, was 40 % of the end-to-end time of a 1e6-event list)."""
     n = x.shape[-1]
-    X = np.fft.fft(x, axis=-1)
+    try:
+        import os
+        from scipy import fft as _fft
+        kw = dict(workers=max(1, min(16, len(os.sched_getaffinity(0)))))
+    except ImportError:   # numpy only
+        _fft, kw = np.fft, {}
+    X = _fft.fft(x, axis=-1, **kw)
     h = np.zeros(n)
     if n % 2 == 0:
         h[0] = h[n // 2] = 1
@@ -126,7 +138,7 @@ def _hilbert_envelope(x):
     else:
         h[0] = 1
         h[1:(n + 1) // 2] = 2
-    return np.abs(np.fft.ifft(X * h, axis=-1))
+    return np.abs(_fft.ifft(X * h, axis=-1, **kw))
 
 
 def _readout_window(V, trigger_bin, n_window, pre_bins):
@@ -141,6 +153,14 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
                        cross_section_type='ctw', minimum_weight_cut=None, noise_temperature=300., **sim_kw):
     """Run the event list through `det` (a Station or a StationArray) and return the OutputFile the reference would write (simple
     threshold trigger; amp_per_ray tables included unless the station cannot provide them)."""
+    import time as _time
+    _t = [_time.perf_counter()]
+    timing = {}
+
+    def _lap(name):
+        now = _time.perf_counter()
+        timing[name] = timing.get(name, 0.) + now - _t[0]
+        _t[0] = now
     arr = det if isinstance(det, StationArray) else StationArray(det, np.zeros((1, 3)), relative_position=det.position, cull=False)
     st, ctx = arr.station, arr.station.ctx
     n_st, n_ch, nS = len(arr), len(st.position), 2
@@ -166,8 +186,10 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
     args = (vertex[rows], d['zeniths'][rows], d['azimuths'][rows], d['shower_energies'][rows], types[rows])
     kL_in = events.k_L()[rows]
     kw = dict(vertex_time=d['vertex_times'][rows], group_id=gid[rows], **sim_kw)
+    _lap('weights_and_selection')
     # ---- pass 1: which (station, group) trigger
     trig, stats = arr.simulate_events(*args, kL_in, seed=seed, per_station=True, **kw)
+    _lap('pass1_upload_and_hot_path')
     st_trig = stats['station_triggered']
     kL = stats.get('k_L', kL_in)
     g_of_row = np.repeat(np.arange(n_groups), np.diff(gb))[rows]      # original group index of every simulated shower
@@ -201,6 +223,7 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
         arr.simulate_events(vertex[rows][sub], d['zeniths'][rows][sub], d['azimuths'][rows][sub], d['shower_energies'][rows][sub],
                             types[rows][sub], np.where(np.isnan(kL[sub]), 1.0, kL[sub]), dump_traces=True, amp_per_ray=can_amp,
                             on_station=collect, max_showers_per_call=len(sub) + 1, **kw2)
+    _lap('pass2_traces_and_tables_of_triggered_groups')
     # ---- assemble the reference's tables
     fs = st.sampling_rate
     dt = 1. / fs
@@ -212,7 +235,7 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
     top_showers = {}    # original shower row -> dict(triggered, trigger_time)
     for i in range(n_st):
         sname = 'station_%d' % station_ids[i]
-        ev_rows, sh_rows = [], []
+        ev_rows, sh_rows, ev_windows = [], [], []
         for T in tables[i]:
             n_sub_groups = len(sub_first)
             pos_of = {int(e): k for k, e in enumerate(T.get('item_event', []))}
@@ -234,8 +257,9 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
                 tbin = int(hit[0])
                 t_trig = tbin * dt + T['ev_t_min'][k]
                 W = _readout_window(V, tbin, n_window, pre_bins)
+                ev_windows.append(W)   # (the Hilbert envelopes of all windows are formed in one call after the loop)
                 ev_rows.append(dict(event_group_ids=gid[first[g_orig]], event_ids=0, maximum_amplitudes=np.max(np.abs(W), axis=1),
-                                    maximum_amplitudes_envelope=np.max(_hilbert_envelope(W), axis=1),
+                                    maximum_amplitudes_envelope=None,
                                     multiple_triggers_per_event=np.array([True]), trigger_times_per_event=np.array([t_trig]),
                                     triggered_per_event=True))
                 for j in range(local_gb[k], local_gb[k + 1]):
@@ -244,41 +268,51 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
                     row = rows[sub[lst[j]]]
                     r = dict(shower_id=d['shower_ids'][row], event_group_id_per_shower=gid[row], event_id_per_shower=d['shower_ids'][row],
                              triggered=True, multiple_triggers=np.array([True]), trigger_times=np.array([t_trig]))
-                    nan2, nan3 = np.full((n_ch, nS), np.nan), np.full((n_ch, nS, 3), np.nan)
-                    for key in ('travel_times', 'travel_distances', 'time_shower_and_ray', 'max_amp_shower_and_ray', 'ray_tracing_C0',
-                                'ray_tracing_C1', 'ray_tracing_reflection', 'ray_tracing_reflection_case',
-                                'ray_tracing_solution_type', 'focusing_factor'):
-                        r[key] = nan2.copy()
-                    for key in ('launch_vectors', 'receive_vectors', 'polarization'):
-                        r[key] = nan3.copy()
-                    base = j * n_ch * nS
-                    for c in range(n_ch):
-                        for s in range(nS):
-                            if not keep[j, c, s]:
-                                continue
-                            q, ir = base + c * nS + s, ray_of_slot[j, c, s]
-                            r['travel_times'][c, s], r['travel_distances'][c, s] = T['slot_T'][q], T['slot_D'][q]
-                            r['ray_tracing_C0'][c, s], r['ray_tracing_C1'][c, s] = T['slot_C0'][q], T['slot_C1'][q]
-                            r['ray_tracing_solution_type'][c, s] = T['slot_type'][q]
-                            r['ray_tracing_reflection'][c, s], r['ray_tracing_reflection_case'][c, s] = 0, 1
-                            r['focusing_factor'][c, s] = 1.
-                            r['launch_vectors'][c, s] = T['slot_launch'][3 * q:3 * q + 3]
-                            zen, az = T['ray_zenith'][ir], T['ray_azimuth'][ir]
-                            ct, st_, cp, sp = np.cos(zen), np.sin(zen), np.cos(az), np.sin(az)
-                            r['receive_vectors'][c, s] = (st_ * cp, st_ * sp, ct)
-                            # polarisation angle on sky -> unit vector in the ground frame (output_writer_hdf5.py:289-297)
-                            a = np.arctan2(T['ray_pol_phi'][ir], T['ray_pol_theta'][ir])
-                            e_t, e_p = np.array([ct * cp, ct * sp, -st_]), np.array([-sp, cp, 0.])
-                            r['polarization'][c, s] = np.cos(a) * e_t + np.sin(a) * e_p
-                            if 'ray_max_amp_envelope' in T:
-                                r['max_amp_shower_and_ray'][c, s] = T['ray_max_amp_envelope'][ir]
-                                r['time_shower_and_ray'][c, s] = T['ray_signal_time'][ir]
+                    # the (channel, solution) tables of the shower, all slots at once (NaN where no ray was kept)
+                    kj = keep[j]
+                    q = j * n_ch * nS + np.arange(n_ch * nS).reshape(n_ch, nS)
+                    ir = np.where(kj, ray_of_slot[j], 0)
+                    nan2 = np.full((n_ch, nS), np.nan)
+
+                    def tab2(values):
+                        return np.where(kj, values, nan2)
+                    r['travel_times'], r['travel_distances'] = tab2(T['slot_T'][q]), tab2(T['slot_D'][q])
+                    r['ray_tracing_C0'], r['ray_tracing_C1'] = tab2(T['slot_C0'][q]), tab2(T['slot_C1'][q])
+                    r['ray_tracing_solution_type'] = tab2(T['slot_type'][q].astype(float))
+                    r['ray_tracing_reflection'], r['ray_tracing_reflection_case'] = tab2(0.), tab2(1.)
+                    r['focusing_factor'] = tab2(1.)
+                    k3 = kj[:, :, None]
+                    nan3 = np.full((n_ch, nS, 3), np.nan)
+                    r['launch_vectors'] = np.where(k3, T['slot_launch'][(3 * q)[:, :, None] + np.arange(3)], nan3)
+                    zen, az = T['ray_zenith'][ir], T['ray_azimuth'][ir]
+                    ct, st_, cp, sp = np.cos(zen), np.sin(zen), np.cos(az), np.sin(az)
+                    r['receive_vectors'] = np.where(k3, np.stack([st_ * cp, st_ * sp, ct], axis=-1), nan3)
+                    # polarisation angle on sky -> unit vector in the ground frame (output_writer_hdf5.py:289-297)
+                    a = np.arctan2(T['ray_pol_phi'][ir], T['ray_pol_theta'][ir])
+                    e_t, e_p = np.stack([ct * cp, ct * sp, -st_], axis=-1), np.stack([-sp, cp, np.zeros_like(sp)], axis=-1)
+                    r['polarization'] = np.where(k3, np.cos(a)[:, :, None] * e_t + np.sin(a)[:, :, None] * e_p, nan3)
+                    if 'ray_max_amp_envelope' in T:
+                        r['max_amp_shower_and_ray'] = tab2(T['ray_max_amp_envelope'][ir])
+                        r['time_shower_and_ray'] = tab2(T['ray_signal_time'][ir])
+                    else:
+                        r['max_amp_shower_and_ray'], r['time_shower_and_ray'] = nan2.copy(), nan2.copy()
                     sh_rows.append(r)
                     e = top_showers.setdefault(int(row), dict(triggered=False, t=np.nan))
                     e['triggered'] = True
                     e['t'] = t_trig if np.isnan(e['t']) else min(e['t'], t_trig)
                 # the primary of a triggered group is stored even without a signal of its own (:392-430)
                 top_showers.setdefault(int(first[g_orig]), dict(triggered=False, t=np.nan, primary_only=True))
+        if ev_rows:
+            step = 2048   # events per call: ~0.3 GB of complex windows at 5 channels x 4096 samples
+            by_len = {}
+            for k_, W_ in enumerate(ev_windows):   # (a common trace shorter than the read-out window keeps its own length)
+                by_len.setdefault(W_.shape, []).append(k_)
+            for idx in by_len.values():
+                for a0 in range(0, len(idx), step):
+                    part = idx[a0:a0 + step]
+                    env = np.max(_hilbert_envelope(np.array([ev_windows[k_] for k_ in part])), axis=-1)
+                    for q_, k_ in enumerate(part):
+                        ev_rows[k_]['maximum_amplitudes_envelope'] = env[q_]
         if sh_rows:
             order = np.argsort(np.array([r['shower_id'] for r in sh_rows]), kind='stable')
             for key in sh_rows[0]:
@@ -320,6 +354,8 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
     if config is not None:
         out.attrs[('', 'config')] = config if isinstance(config, str) else json.dumps(config)
     out.stats = stats
+    _lap('assemble_output_tables_on_host')
+    out.timing = timing   # seconds per phase of this call (bench.py --end-to-end)
     return out
 
 

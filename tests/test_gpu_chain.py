@@ -1003,7 +1003,11 @@ def test_general_path_arz_birefringence(gpu_ctx_factory, mode, N):
     ev_of = np.repeat(np.arange(m), X['ev_n_rays'])
     if bire:
         skipped = mp < 0
-        assert skipped.sum() > 50 and not np.any(X['ev_candidate'].astype(bool)[ev_of[skipped]])
+        # (round 4: a ray is propagated if its own bound exceeds the candidate cut, or -- in a candidate event -- if its channel can
+        # reach the trigger threshold; the others, also those of candidate events, keep "at most <bound>", a bound below the cut)
+        assert skipped.sum() > 50
+        in_cand = X['ev_candidate'].astype(bool)[ev_of]
+        print(mode, 'rays of candidate events never propagated: %d of %d' % ((skipped & in_cand).sum(), in_cand.sum()))
         assert np.all(-mp[skipped] * (1 + 1e-9) >= X['ray_max_efield'][skipped]) and np.all(-mp[skipped] <= 2.0 * st.vrms_efield)
         assert np.array_equal(mp[~skipped], X['ray_max_efield'][~skipped])
         assert np.all(st.fetch('ray_bound') * (1 + 1e-9) >= X['ray_max_efield'])
