@@ -1012,8 +1012,19 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
                 }
             } else {
             if (f32) {
-                float cLf[AB_RT], cRf[AB_RT], pff[AB_RT], pf32[AB_RT];
-                for (int i = 0; i < AB_RT; i++) { cLf[i] = (float)cL[i]; cRf[i] = (float)cR[i]; pff[i] = (float)pf[i]; pf32[i] = 0.f; }
+                // the four rays of the tile as two packed pairs (v_pk_mul / v_pk_fma_f32: two single-precision operations per lane and
+                // instruction; only the reciprocal is per ray): 26 instead of 44 arithmetic instructions per frequency bin
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                static_assert(AB_RT == 4, "two packed pairs");
+                f2 cL2[2], cR2[2], pf2[2], hm2[2], acc2[2];
+                for (int j = 0; j < 2; j++) {
+                    cL2[j] = f2{(float)cL[2 * j], (float)cL[2 * j + 1]};
+                    cR2[j] = f2{(float)cR[2 * j], (float)cR[2 * j + 1]};
+                    pf2[j] = f2{(float)pf[2 * j], (float)pf[2 * j + 1]};
+                    hm2[j] = f2{had[2 * j] ? 1.f : 0.f, had[2 * j + 1] ? 1.f : 0.f};
+                    acc2[j] = f2{0.f, 0.f};
+                }
+                const f2 one2 = f2{1.f, 1.f}, zero2 = f2{0.f, 0.f};
                 const float xf_first = (float)x_first, xf_last = (float)x_last, dxf_last = (float)dx_last, dff = (float)df;
                 // the station tables of the NEXT bin are requested before the current one is evaluated (L1 / L2 latency off the path)
                 int kq = 1 + lane;
@@ -1035,13 +1046,19 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
                     if (f <= xf_first) { lo = 0; dx = 0.f; }
                     if (f >= xf_last) { lo = st.n_fc - 2; dx = dxf_last; }
                     dx = fmaxf(dx, 0.f);
+                    const float dp = ph - pe;
 #pragma unroll
-                    for (int i = 0; i < AB_RT; i++) {
-                        const float x = (had[i] ? ph : pe) * cLf[i], y = pr * cRf[i];
-                        const float amp = pff[i] * f * __builtin_amdgcn_rcpf((1.f + x) * (1.f + y));
-                        pf32[i] += amp * fmaxf(ub_slope_f[wv][i][lo] * dx + ub_f[wv][i][lo], 0.f);
+                    for (int j = 0; j < 2; j++) {
+                        const f2 psel = hm2[j] * dp + pe;   // hadronic: f^2.57 table, electromagnetic: f^2.74 (exactly one of the two)
+                        const f2 den = (one2 + psel * cL2[j]) * (one2 + pr * cR2[j]);
+                        const f2 rc = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                        const f2 sl = f2{ub_slope_f[wv][2 * j][lo], ub_slope_f[wv][2 * j + 1][lo]};
+                        const f2 u0 = f2{ub_f[wv][2 * j][lo], ub_f[wv][2 * j + 1][lo]};
+                        const f2 uv = __builtin_elementwise_max(sl * dx + u0, zero2);
+                        acc2[j] += (pf2[j] * f) * rc * uv;
                     }
                 }
+                float pf32[AB_RT] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y};
                 for (int i = 0; i < AB_RT; i++) part[i] = (double)pf32[i] * BOUND_F32_SLACK + 1e-30;  // + what FP32 may have flushed to zero
             } else
             for (int k = 1 + lane; k < nh; k += 64) {

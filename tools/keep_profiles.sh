@@ -4,11 +4,11 @@ cd "$(dirname "$0")/.."
 R=${1:-r04}
 M=gpurun_out/measure
 cp $M/${R}_rocprofv3_kernel_stats.csv $M/${R}_pmc_traffic.csv $M/${R}_pmc_traffic.json $M/${R}_rocprofv3_config4_kernel_stats.csv profiles/ 2>/dev/null
-for c in config2 config2_pass1_only config2_mixed config2_strong config2_125k_shard config3 config3_pa config3_pa_adc_noise config4 config4_pa_adc_noise config5; do
+for c in config2 config2_pass1_only config2_mixed config2_strong config2_125k_shard config2_end_to_end config2_two_ranks_one_gpu config3 config3_pa config3_pa_adc_noise config4 config4_pa_adc_noise config5; do
   [ -s $M/bench_$c.json ] && tail -1 $M/bench_$c.json > profiles/${R}_bench_${c}_1gpu.json
 done
 [ -s $M/config4_probe.log ] && cp $M/config4_probe.log profiles/${R}_config4_probe.txt
-[ -s $M/overlap_probe.log ] && cp $M/overlap_probe.log profiles/${R}_overlap_probe.txt
+[ -s $M/conv_phases.log ] && cp $M/conv_phases.log profiles/${R}_conv_phases.txt
 [ -s $M/att_dense_probe.log ] && cp $M/att_dense_probe.log profiles/${R}_att_dense_probe.txt
 [ -s $M/overlap_two_procs.log ] && cp $M/overlap_two_procs.log profiles/${R}_overlap_two_procs.txt
 [ -s $M/shard125k_kernels.log ] && cp $M/shard125k_kernels.log profiles/${R}_shard125k_kernels.txt

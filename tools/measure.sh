@@ -27,8 +27,8 @@ python3 bench.py --flavour mixed > $OUT/bench_config2_mixed.json 2>> $OUT/bench_
 python3 bench.py --scaling strong --no-cpu-baseline > $OUT/bench_config2_strong.json 2>> $OUT/bench_config2.log
 python3 bench.py --events 125000 --no-cpu-baseline > $OUT/bench_config2_125k_shard.json 2>> $OUT/bench_config2.log
 python3 bench.py --config 3 > $OUT/bench_config3.json 2> $OUT/bench_config3.log
-python3 bench.py --config 3 --trigger pa --no-cpu-baseline > $OUT/bench_config3_pa.json 2>> $OUT/bench_config3.log
-python3 bench.py --config 3 --trigger pa_adc_noise --no-cpu-baseline --events 200000 > $OUT/bench_config3_pa_adc_noise.json 2>> $OUT/bench_config3.log
+python3 bench.py --config 3 --trigger pa --cpu-budget 40 > $OUT/bench_config3_pa.json 2>> $OUT/bench_config3.log
+python3 bench.py --config 3 --trigger pa_adc_noise --cpu-budget 60 --events 200000 > $OUT/bench_config3_pa_adc_noise.json 2>> $OUT/bench_config3.log
 python3 bench.py --config 5 > $OUT/bench_config5.json 2> $OUT/bench_config5.log
 python3 bench.py --config 4 --cpu-budget 120 > $OUT/bench_config4.json 2> $OUT/bench_config4.log
 python3 bench.py --config 4 --trigger pa_adc_noise --no-cpu-baseline > $OUT/bench_config4_pa_adc_noise.json 2>> $OUT/bench_config4.log
@@ -37,9 +37,11 @@ python3 tools/config4_probe.py 100000 20000 > $OUT/config4_probe.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4stats -o x -- python3 tools/config4_probe.py 100000 20000 > /dev/null 2> $OUT/c4stats.log
 cp $(find $OUT/c4stats -name 'x_kernel_stats.csv' | head -1) $OUT/${R}_rocprofv3_config4_kernel_stats.csv
 rm -rf $OUT/c4stats
-python3 tools/overlap_probe.py 2 > $OUT/overlap_probe.log 2>&1
-# two station loops side by side on one GPU, and where a 125 k-event shard spends its time (kernel sum vs step)
-{ bash tools/overlap_two_procs.sh 3 1000000; bash tools/overlap_two_procs.sh 5 1000000; } > $OUT/overlap_two_procs.log 2>&1
+# round 4: the whole drop-in (host list -> output tables), the two-rank launch on this one GPU, the convolution kernel's phases
+python3 bench.py --steps 10 --no-cpu-baseline --end-to-end > $OUT/bench_config2_end_to_end.json 2>> $OUT/bench_config2.log
+python3 bench.py --gpus 2 --allow-tcp --scaling strong --events 200000 --steps 3 --no-cpu-baseline > $OUT/bench_config2_two_ranks_one_gpu.json 2>> $OUT/bench_config2.log
+[ -f nuradiomc_amd/lib/libnrhip_ct.so ] && { python3 tools/conv_phase_probe.py; python3 tools/conv_phase_probe.py --no-traces; python3 tools/conv_phase_probe.py --config 5 --steps 1 --events 300000; } > $OUT/conv_phases.log 2>&1
+# where a 125 k-event shard spends its time (kernel sum vs step)
 { ROWS=14 bash tools/rocprof_quick.sh --events 125000 --steps 10; python3 bench.py --events 125000 --no-cpu-baseline --steps 20 | tail -c 900; } > $OUT/shard125k_kernels.log 2>&1
 python3 tools/att_dense_probe.py 40000 > $OUT/att_dense_probe.log 2>&1
 find $OUT -size +8M -delete
