@@ -489,6 +489,15 @@ def main():
     rc = launch_ranks(args)
     if rc is not None:
         raise SystemExit(rc)
+    # this process is a rank: the JSON line alone goes to the stdout it was given -- libraries on the GPU side write to fd 1 as well
+    # (RCCL prints a version banner there), so fd 1 becomes stderr and the line is written through a duplicate of the original
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
+    def emit(obj):
+        json_out.write(json.dumps(obj, default=_json_default) + '\n')
+        json_out.flush()
     if args.dry_run:
         from nuradiomc_amd import comm as nrcomm
         rank, local_rank, world = nrcomm.env_rank()
@@ -500,8 +509,8 @@ def main():
         seen = c.allreduce_sum([1, rank, local_rank])
         c.barrier()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": int(seen[0]), "rank_sum": int(seen[1]), "local_rank_sum": int(seen[2]),
-                              "mask_ok": bool(np.array_equal(mask, full)), "collectives": c.mode}))
+            emit({"dry_run": True, "n_gpus": world, "ranks": int(seen[0]), "rank_sum": int(seen[1]), "local_rank_sum": int(seen[2]),
+                  "mask_ok": bool(np.array_equal(mask, full)), "collectives": c.mode})
         c.close()
         return
     cfgno = args.config
@@ -652,7 +661,7 @@ def main():
                        "n_active_rays": stats['n_active_rays'], "n_candidate_events": stats['n_candidate_events'],
                        "n_channel_items": stats['n_channel_items'], "n_channel_transforms": stats['n_channel_transforms'],
                        "n_ray_transforms": stats['n_ray_transforms'], "n_efield_transforms": stats['n_efield_transforms'],
-                       "n_adc_convolutions": stats.get('n_adc_convolutions', 0),
+                       "n_adc_convolution_flops": stats.get('n_adc_convolution_flops', 0),
                        "n_triggered_rank0": stats['n_triggered'], "n_triggered_all": n_trig_total,
                        "all_ranks": {k: int(v) for k, v in tot.items()},
                        "triggered_events_per_s": n_trig_total / (elapsed / max(args.steps, 1)),
@@ -682,9 +691,9 @@ def main():
                         stats['n_ray_transforms'] * (5. * nh_ * np.log2(nh_) + 40. * nh_))
         if wl['sim_kw'].get('noise'):   # the noise trace of every channel trace: one more 8192-point transform pair (inverse chirp-z)
             flop_channel += stats['n_channel_transforms'] * (2 * 5. * M_ * 13 + 6. * M_)
-        # trigger-ADC chain of the phased array: 8192-point chirp convolutions counted by pa_czt_stage_kernel (transform pair + the
-        # three chirp products)
-        flop_channel += stats.get('n_adc_convolutions', 0) * (2 * 5. * M_ * 13 + 18. * M_)
+        # trigger-ADC chain of the phased array: the chirp convolutions of pa_czt_stage_kernel, M (2 * 5 log2 M + 18) each (transform
+        # pair + the three products), summed by the kernel over the convolution lengths it ran
+        flop_channel += stats.get('n_adc_convolution_flops', 0)
         # FP64 view of the ray finder: calls of the objective delta_y(log C0) counted by the kernel (hybrd + two Brent searches, ~1e2 per
         # pair) x FLOP_PER_OBJECTIVE (~90 add / mul, 13 divisions and 6 square roots at 1 flop, 1 exp + 4 log at 20)
         flop_of = {'attenuation': stats['n_integrand_evals'] * flop_per_eval, 'channel': flop_channel,
@@ -726,11 +735,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline and (args.trigger == 'threshold' or cfgno != 4):
             out["cpu_baseline"] = base
             if mism:
-                print(json.dumps(out, default=_json_default))
+                emit(out)
                 raise SystemExit("bench.py: the GPU trigger mask differs from the oracle's on %d of %d sampled events" % (mism, n_done))
         if args.end_to_end and cfgno == 2 and world == 1:
             out["end_to_end"] = end_to_end(st, wl)
-        print(json.dumps(out, default=_json_default))
+        emit(out)
     comm.barrier()
     free_events(ctx, d)
     comm.close()

@@ -399,7 +399,7 @@ typedef struct {
     /* nrhip_sim_config.emit_triggered_traces: events whose traces were written, events that found the buffer full, samples reserved */
     int64_t n_emitted_events, n_emit_overflow, n_emitted_samples;
     int64_t n_objective_evals;    /* calls of the ray finder's objective delta_y(log C0) (hybrd + Brent, summed over the pairs) */
-    int64_t n_adc_convolutions;   /* 8192-point chirp convolutions of the phased array's trigger-ADC chain (resampling, up-sampling) */
+    int64_t n_adc_convolution_flops;   /* FP64 operations of the chirp convolutions in the phased array's trigger-ADC chain (M (10 log2 M + 18) per M-point convolution) */
 } nrhip_sim_stats;
 
 typedef struct nrhip_station nrhip_station;

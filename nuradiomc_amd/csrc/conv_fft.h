@@ -349,7 +349,8 @@ __device__ __forceinline__ void dif8_tail_c(double2 (&a)[8])
 // (conv_fwd / conv_mid / conv_inv are real function calls, not inlined: channel_conv_kernel keeps ~400 scalars alive (its argument
 // structures), and inlined into it the passes came out with spill reloads and lane reads of spilled scalars in their inner code; a
 // call gives each pass its own register allocation, at the price of one s_swappc.  The buffer is the kernel's dynamic LDS.)
-template <int LOG2M, int NT>
+// FULL: the upper half of the input holds data as well (the chirp convolutions of the trigger-ADC chain with more than M / 2 inputs).
+template <int LOG2M, int NT, bool FULL = false>
 __device__ __noinline__ void conv_fwd(const double2* __restrict__ tw, const double2* __restrict__ cft)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -364,10 +365,13 @@ __device__ __noinline__ void conv_fwd(const double2* __restrict__ tw, const doub
             const int i0 = t + NA * g;
             double2 a[NB];
 #pragma unroll
-            for (int j = 0; j < NB / 2; j++) a[j] = z[j * 1025 + i0];
-            // first stage (span M / 2): the partners are zero
+            for (int j = 0; j < (FULL ? NB : NB / 2); j++) a[j] = z[j * 1025 + i0];
+            // first stage (span M / 2): the partners are zero unless FULL
 #pragma unroll
-            for (int j = 0; j < NB / 2; j++) a[j + NB / 2] = cmulx(a[j], tw[(i0 + 1024 * j) * (8 >> LW)]);
+            for (int j = 0; j < NB / 2; j++) {
+                if (FULL) dif_bf(a[j], a[j + NB / 2], tw[(i0 + 1024 * j) * (8 >> LW)]);
+                else a[j + NB / 2] = cmulx(a[j], tw[(i0 + 1024 * j) * (8 >> LW)]);
+            }
 #pragma unroll
             for (int e = 1; e < LW; e++) {
                 const int half = NB >> (e + 1);
@@ -473,6 +477,39 @@ __device__ __noinline__ void conv_mid(const double2* __restrict__ G, const doubl
             double2 c = A[1];
             conv_pair_mul(A[1], c, G[gs * (M / 2)], G[gs * (M / 2)], w16[gs * (M / 2)]);
         }
+        dit8_head(A);
+        dit8_head(B);
+#pragma unroll
+        for (int c = 0; c < 8; c++) { pa[c] = A[c]; pb[c] = B[c]; }
+    }
+    lds_barrier();
+}
+
+// ---- the same pass for a plain complex convolution: last three forward stages, product with a spectrum given in NATURAL bin order
+// (Bn[k], k < M), first three inverse stages.  After dif8_tail slot r of a thread's group k0 holds bin k0 + (M / 8) br3(r).
+template <int LOG2M, int NT>
+__device__ __noinline__ void conv_mid_plain(const double2* __restrict__ Bn)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* z = (double2*)smem;
+    constexpr int M = 1 << LOG2M, NA = M / 16, K = M / 8, LW = LOG2M - 10;
+    const int t = threadIdx.x;
+    lds_barrier();
+    if (NA == NT || t < NA) {
+        const int kA = (t == 0) ? 0 : t, kB = (t == 0) ? K / 2 : K - t;
+        const int wA = (LW == 3) ? br3(kA & 7) : (LW == 2 ? (((kA & 1) << 1) | ((kA >> 1) & 1)) : (kA & 1));
+        const int wB = (LW == 3) ? br3(kB & 7) : (LW == 2 ? (((kB & 1) << 1) | ((kB >> 1) & 1)) : (kB & 1));
+        double2* pa = z + wA * 1025 + 8 * (kA >> LW);
+        double2* pb = z + wB * 1025 + 8 * (kB >> LW);
+        double2 A[8], B[8], GA[8], GB[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { GA[r] = Bn[kA + K * br3(r)]; GB[r] = Bn[kB + K * br3(r)]; }
+#pragma unroll
+        for (int c = 0; c < 8; c++) { A[c] = pa[c]; B[c] = pb[c]; }
+        dif8_tail(A);
+        dif8_tail(B);
+#pragma unroll
+        for (int r = 0; r < 8; r++) { A[r] = cmulx(A[r], GA[r]); B[r] = cmulx(B[r], GB[r]); }
         dit8_head(A);
         dit8_head(B);
 #pragma unroll

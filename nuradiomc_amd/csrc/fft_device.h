@@ -36,7 +36,7 @@ __device__ inline double2 cscale(double2 a, double s) { return make_double2(a.x 
 // 32 four-byte banks, the strides the passes use between the lanes of a wave -- 32 elements in the third fused pass (and its mirror
 // in the inverse transform), 128 elements in the bit-reversed accesses of the spectrum product -- land on the same banks in the
 // plain layout (4- and 64-way conflicts); the two shifts move them to 33.25 and 133 elements, which visit all banks.
-__device__ __forceinline__ int fft_pad(int i) { return i + (i >> 5) + (i >> 7); }
+__host__ __device__ __forceinline__ int fft_pad(int i) { return i + (i >> 5) + (i >> 7); }
 template <bool PAD> __device__ __forceinline__ int fft_at(int i) { return PAD ? fft_pad(i) : i; }
 constexpr int FFT_PADDED_MAX = FFT_MAX + FFT_MAX / 32 + FFT_MAX / 128;   // elements of a padded FFT_MAX-point buffer
 

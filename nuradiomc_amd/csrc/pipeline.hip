@@ -1247,6 +1247,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             NEED(ab.form_factor_table = WS("arz_form_factor_table", double, (size_t)ARZ_TABLE_DOUBLES));
             launch_arz(sm, ab, vp, atr, ast);
             LCHK("arz");
+            // rays beyond the model's 20 degrees carry no signal: no path steps for them (half of config 4's rays)
+            if (bire && !getenv("NRHIP_BIRE_ALL_RAYS"))
+                launch_silent_rays(sm, n_rays, ab.theta, ab.n_index_ray, ab.n_index, ab.maximum_angle, g_nsteps, g_npoints);
             std::vector<int> hs(n_rays);
             HIPCHK(hipMemcpyAsync(hs.data(), ast, sizeof(int) * nr, hipMemcpyDeviceToHost, sm));
             HIPCHK(hipStreamSynchronize(sm));
@@ -1649,10 +1652,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                     // chirp-z transforms; their tables join the station's per-length cache (same slots)
                     if (st->pa_B_cap < tc.cap) {
                         DevArray fresh;
-                        if (fresh.reserve((size_t)tc.cap * 4 * FFT_MAX * 16) != hipSuccess)
+                        if (fresh.reserve((size_t)tc.cap * PA_TABLES * FFT_MAX * 16) != hipSuccess)
                             return nrhip_fail_msg("nrhip_simulate_events: out of device memory (digitiser tables)");
                         if (st->pa_B_cap > 0)
-                            HIPCHK(hipMemcpyAsync(fresh.p, st->pa_B.p, (size_t)st->pa_B_cap * 4 * FFT_MAX * 16, hipMemcpyDeviceToDevice, sm));
+                            HIPCHK(hipMemcpyAsync(fresh.p, st->pa_B.p, (size_t)st->pa_B_cap * PA_TABLES * FFT_MAX * 16, hipMemcpyDeviceToDevice, sm));
                         HIPCHK(hipStreamSynchronize(sm));
                         st->pa_B.release();
                         st->pa_B = fresh;
@@ -1679,7 +1682,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                     launch_phased_array_digital_czt(sm, n_cand, d_cand, n_ch, ev.L, tc.slotmap.as<int>(), co.trace, co.trace_offset,
                                                     st->pa_n_channels, st->d_pa_channel.as<int>(), st->pa_n_beams,
                                                     st->d_pa_rolls_up.as<int>(), st->pa_window, st->pa_step, (double)st->pa_divisor,
-                                                    cfg->trigger_threshold, maxL, sd.fs, adc, ctx->twiddle, st->pa_B.as<double2>(), work,
+                                                    cfg->trigger_threshold, maxL, sd.fs, adc, ctx->twiddle, ctx->w16 + (FFT_MAX / 2 + 1), st->pa_B.as<double2>(), work,
                                                     chunk, pa_trace, pa_len, ev_triggered, pa_max, with_beams, xform_count + 3);
                 } else
                 launch_phased_array_digital(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, st->pa_n_channels,
@@ -1749,7 +1752,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             S.n_channel_transforms = (int64_t)xc[0];
             S.n_ray_transforms = (int64_t)xc[1];
             S.n_efield_transforms = (int64_t)xc[2];
-            S.n_adc_convolutions = (int64_t)xc[3];
+            S.n_adc_convolution_flops = (int64_t)xc[3];
         }
         for (int i = 0; i < 8; i++) {
             float ms = 0.f;
@@ -1801,10 +1804,9 @@ int nrhip_efield_to_voltage(nrhip_ctx* ctx, nrhip_station* st, int32_t n_efields
     if (st->ctx != ctx) return nrhip_fail_msg("nrhip_efield_to_voltage: station belongs to another context");
     const StationDev& sd = st->dev;
     if (n_efields <= 0) return nrhip_fail_msg("station has no efields");  // LookupError in the reference (:117-118)
-    if (sd.N > 4096) return nrhip_fail_msg("nrhip_efield_to_voltage: traces longer than 4096 samples are not supported");
-    const int nh = sd.N / 2;
-    if (L <= 0 || L % 2 != 0 || L / 2 > std::min(FFT_MAX - nh + 1, NRHIP_SPEC_STRIDE - 1))
-        return nrhip_fail_msg("nrhip_efield_to_voltage: common trace length unsupported (odd, or longer than the 8192-point chirp-z allows)");
+    // the limits of the batched path (nrhip_simulate_events): any station trace length, common traces of at most 32766 samples
+    if (L <= 0 || L % 2 != 0 || L / 2 > NRHIP_SPEC_STRIDE - 1)
+        return nrhip_fail_msg("nrhip_efield_to_voltage: common trace length unsupported (odd, or longer than 32766 samples)");
     for (int e = 0; e < n_efields; e++)
         if (channel[e] < 0 || channel[e] >= sd.n_ch) return nrhip_fail_msg("nrhip_efield_to_voltage: bad channel index");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1838,7 +1840,7 @@ int nrhip_efield_to_voltage(nrhip_ctx* ctx, nrhip_station* st, int32_t n_efields
     launch_length_tables(sm, 1, d_len, sd, st->d_filtersets.as<FilterSet>(), ctx->twiddle, ctx->w16, tab);
     LCHK("length_tables");
     double2* scratch;
-    NEED(scratch = WS("channel_scratch", double2, (size_t)std::max(sd.n_ch, channel_grid_blocks()) * NRHIP_SPEC_STRIDE));
+    NEED(scratch = WS("channel_scratch", double2, (size_t)std::max(sd.n_ch, channel_grid_blocks()) * 2 * NRHIP_SPEC_STRIDE));
     double2* tab_nodes = nullptr;
     if (sd.ant_tabs) NEED(tab_nodes = WS("antenna_table_nodes", double2, (size_t)sd.n_ch * 2 * sd.max_tab_freq));
     launch_efield_channel(sm, n_efields, d_tr, d_t0, d_zen, d_az, d_ch, sd, L, t_min, apply_filters, ctx->twiddle, tab,

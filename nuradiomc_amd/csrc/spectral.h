@@ -210,6 +210,8 @@ void launch_general_gather(hipStream_t s, int n_rays, int n_ch, const RayWork& w
                            const double* vertex, const int* shower_profile, const double* shower_rescale, int em_formula,
                            double* energy, int* type, double* em_factor, int* profile, double* rescale, double* x1, double* x2,
                            int* n_steps, int* n_points);
+void launch_silent_rays(hipStream_t s, int n_rays, const double* view, const double* n_index_ray, double n_index, double maximum_angle,
+                        int* n_steps, int* n_points);
 void launch_int_to_long(hipStream_t s, int n, const int* in, long* out);
 void launch_phased_array(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                          const long* trace_offset, int n_pa, const int* pa_channel, int n_beams, const int* rolls, int window,
@@ -240,6 +242,7 @@ struct PaAdc {
 void launch_pa_upsample(hipStream_t s, int n_items, const PaAdc& adc, const double* adc_trace, int stride_in, const int* len_in,
                         double* pa_trace, int* pa_len);
 // the chirp-z version of the same chain (O(L log L) transforms; tables per trace length in the station's cache)
+constexpr int PA_TABLES = 8;   // rows of FFT_MAX complex numbers per length slot: 4 Bluestein spectra, 4 chirps
 bool pa_czt_applies(int max_length, double fs, const PaAdc& adc);
 size_t pa_czt_work_bytes(int max_length, double fs, const PaAdc& adc, int chunk);
 void launch_pa_czt_tables(hipStream_t s, int n_len, const int* lens, const int* slots, double fs, const PaAdc& adc, const double2* tw,
@@ -247,7 +250,7 @@ void launch_pa_czt_tables(hipStream_t s, int n_len, const int* lens, const int* 
 void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const int* slotmap,
                                      const double* trace, const long* trace_offset, int n_pa, const int* pa_channel, int n_beams,
                                      const int* rolls_up, int window, int step, double divisor, double threshold, int max_length, double fs,
-                                     const PaAdc& adc, const double2* tw, const double2* Btab, void* work, int chunk, double* pa_trace,
+                                     const PaAdc& adc, const double2* tw, const double2* cft, const double2* Btab, void* work, int chunk, double* pa_trace,
                                      int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams = true,
                                      unsigned long long* conv_count = nullptr);
 void launch_phased_array_beams(hipStream_t s, int n_cand, const int* item_event, int n_pa, int n_beams, const int* rolls_up, int window,

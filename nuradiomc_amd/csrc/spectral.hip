@@ -3409,7 +3409,8 @@ efield_channel_kernel(int n_efields, const double* __restrict__ traces, const do
     const int M = FFT_MAX, N = st.N, nh = N / 2, m = L / 2;
     const int ch = blockIdx.x;
     double2* x = (double2*)smem;
-    double2* acc = scratch + (long)blockIdx.x * NRHIP_SPEC_STRIDE;
+    double2* acc = scratch + (long)blockIdx.x * 2 * NRHIP_SPEC_STRIDE;
+    double2* zbuf = acc + NRHIP_SPEC_STRIDE;   // the forward transform's outputs when they come in blocks (and trace_to_packed's row)
     const double2 *Bf = tab.B_fwd, *Bi = tab.B_inv, *E = tab.E, *Cf = tab.Cf, *Ci = tab.Ci;
     const double2* Hf = tab.H + (long)(st.ch_fset ? st.ch_fset[ch] : 0) * NRHIP_SPEC_STRIDE;
     const unsigned LL = (unsigned)L;
@@ -3451,58 +3452,38 @@ efield_channel_kernel(int n_efields, const double* __restrict__ traces, const do
         for (int comp = 0; comp < 2; comp++) {
             const double vfac = (comp ? Tp : Tt) * dir;
             if (vfac == 0.) continue;
-            const double* tr = traces + ((long)e * 2 + comp) * N;
-            // y_j = e[2j] + i e[2j+1]
-            for (int j = threadIdx.x; j < nh; j += blockDim.x) x[j] = make_double2(tr[2 * j], tr[2 * j + 1]);
-            __syncthreads();
-            if (shift) {
-                // rfft -> * exp(-2 pi i f rem) -> irfft on the N grid (base_trace.py:273-276)
-                nplan_fft(x, st.np, tw, false);  // Y in bit-reversed / natural order (nplan_idx)
-                double2* G = x + M / 2;          // G'(k), k = 0..nh, in the upper half of the buffer
-                for (int k = threadIdx.x; k <= nh; k += blockDim.x) {
-                    int ka = (k == nh) ? 0 : k, kb = (k == 0 || k == nh) ? 0 : nh - k;
-                    double2 Y1 = x[nplan_idx(st.np, ka)], Y2 = cconj(x[nplan_idx(st.np, kb)]);
-                    double2 ge = cscale(cadd(Y1, Y2), 0.5);
-                    double2 d = cscale(csub(Y1, Y2), 0.5);
-                    double2 go = make_double2(d.y, -d.x);  // d / i
-                    double2 wk = nplan_w(st.np, k, tw);    // exp(-2 pi i k / N)
-                    double2 g = cadd(ge, cmul(go, wk));
-                    double f = k * (1.0 / (N * res));
-                    double sn, cs;
-                    sincos(-2. * M_PI * rem * f, &sn, &cs);
-                    g = cmul(g, make_double2(cs, sn));
-                    if (k == 0 || k == nh) g.y = 0.;  // irfft uses the real part of DC and Nyquist only
-                    G[k] = g;
-                }
-                __syncthreads();
-                for (int k = threadIdx.x; k < nh; k += blockDim.x) {
-                    double2 Gk = G[k], Gc = cconj(G[nh - k]);
-                    double2 ge = cscale(cadd(Gk, Gc), 0.5);
-                    double2 d = cscale(csub(Gk, Gc), 0.5);
-                    double2 go = cmul(d, cconj(nplan_w(st.np, k, tw)));
-                    x[k] = make_double2(ge.x - go.y, ge.y + go.x);
-                }
-                __syncthreads();
-                nplan_fft(x, st.np, tw, true);
-            }
-            // a_j = y_j chirp_j * sqrt(2) / fs (time2freq), zero padded
+            // y_j = e[2j] + i e[2j+1], sub-sample shift on the N grid (base_trace.py:273-276); then exactly channel_kernel's steps
+            // for a ray trace from HBM: a_j = y_j chirp_j sqrt(2) / fs (time2freq), the m output bins in blocks of Pf
+            trace_to_packed(x, traces + ((long)e * 2 + comp) * N, N, st.np, st.fs, rem, shift, tw, zbuf);
             const double sc = (shift ? 1.0 / nh : 1.0) * (1.4142135623730951 / st.fs);
-            double2 yreg[8];
+            double2 yreg[FFT_MAX / 512];   // N / 2 <= 7168 points on 512 threads
             int cnt = 0;
             for (int j = threadIdx.x; j < nh; j += blockDim.x) yreg[cnt++] = shift ? x[nplan_idx(st.np, j)] : x[j];
             __syncthreads();
-            cnt = 0;
-            for (int j = threadIdx.x; j < M; j += blockDim.x) {
-                double2 v = make_double2(0., 0.);
-                if (j < nh) v = cmul(cscale(yreg[cnt++], sc), Cf[j]);
-                x[j] = v;
+            const int Pf = min(m, M - nh + 1);
+            const bool blocked = Pf < m;
+            for (int k0 = 0; k0 < m; k0 += Pf) {
+                cnt = 0;
+                for (int j = threadIdx.x; j < M; j += blockDim.x) {
+                    double2 v = make_double2(0., 0.);
+                    if (j < nh) {
+                        v = cmul(cscale(yreg[cnt++], sc), Cf[j]);
+                        if (k0) v = cmul(v, E[(4u * ((unsigned)j * (unsigned)k0 % (unsigned)m)) % (2u * LL)]);   // exp(-2 pi i j k0 / m)
+                    }
+                    x[j] = v;
+                }
+                __syncthreads();
+                czt_convolve_t<512>(x, Bf, tw);
+                if (blocked) {
+                    const int nb = min(Pf, m - k0);
+                    for (int k = threadIdx.x; k < nb; k += blockDim.x) zbuf[k0 + k] = cscale(cmul(x[k], Cf[k]), 1.0 / M);
+                    __syncthreads();
+                }
             }
-            __syncthreads();
-            czt_convolve_t<512>(x, Bf, tw);
             for (int k = threadIdx.x; k <= m; k += blockDim.x) {
                 int k1 = (k == m) ? 0 : k, k2 = (k == 0 || k == m) ? 0 : m - k;
-                double2 Z1 = cscale(cmul(x[k1], Cf[k1]), 1.0 / M);
-                double2 Z2 = cconj(cscale(cmul(x[k2], Cf[k2]), 1.0 / M));
+                double2 Z1 = blocked ? zbuf[k1] : cscale(cmul(x[k1], Cf[k1]), 1.0 / M);
+                double2 Z2 = cconj(blocked ? zbuf[k2] : cscale(cmul(x[k2], Cf[k2]), 1.0 / M));
                 double2 Ee = cscale(cadd(Z1, Z2), 0.5);
                 double2 d = cscale(csub(Z1, Z2), 0.5);
                 double2 Eo = make_double2(d.y, -d.x);
@@ -4241,6 +4222,24 @@ void launch_general_gather(hipStream_t s, int n_rays, int n_ch, const RayWork& w
                        shower_profile, shower_rescale, em_formula, energy, type, em_factor, profile, rescale, x1, x2, n_steps);
     hipLaunchKernelGGL(steps_to_points_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, n_steps, n_points);
 }
+// Rays the time-domain model leaves without a signal (more than `maximum_angle` off the Cherenkov cone, ARZ.py:603-607: an all-zero
+// trace, the very comparison of arz_vector_potential_kernel): a zero spectrum stays zero through any linear propagation, so their
+// path steps are neither computed nor applied (n_points = 0 is "nothing to do" for both birefringence kernels)
+__global__ void silent_rays_kernel(int n_rays, const double* __restrict__ view, const double* __restrict__ n_index_ray, double n_index,
+                                   double maximum_angle, int* __restrict__ n_steps, int* __restrict__ n_points)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const double nidx = n_index_ray ? n_index_ray[r] : n_index;
+    if (fabs(view[r] - acos(1. / nidx)) > maximum_angle) { n_steps[r] = 0; n_points[r] = 0; }
+}
+void launch_silent_rays(hipStream_t s, int n_rays, const double* view, const double* n_index_ray, double n_index, double maximum_angle,
+                        int* n_steps, int* n_points)
+{
+    if (n_rays <= 0) return;
+    hipLaunchKernelGGL(silent_rays_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, view, n_index_ray, n_index, maximum_angle,
+                       n_steps, n_points);
+}
 void launch_int_to_long(hipStream_t s, int n, const int* in, long* out)
 {
     if (n <= 0) return;
@@ -4501,13 +4500,21 @@ __device__ __host__ inline PaSizes pa_sizes(int L, double fs, const PaAdc& adc)
     z.n_up = z.n_dig * (adc.upsampling >= 2 ? adc.upsampling : 1);
     return z;
 }
-// stage -> (n_in, Q, sgn, P, n_out)
-__device__ __host__ inline void pa_stage(const PaSizes& z, int stage, int* n_in, long* Q, double* sgn, int* P, long* n_out)
+// stage -> (n_in, Q, sgn, P, n_out); returns log2 of the convolution length: the smallest power of two that takes the whole
+// transform in one block of outputs (n_in + n_out - 1 points), FFT_MAX with several blocks of P outputs beyond that
+__device__ __host__ inline int pa_stage(const PaSizes& z, int stage, int* n_in, long* Q, double* sgn, int* P, long* n_out)
 {
-    if (stage == 1) { *n_in = z.L; *Q = z.L; *sgn = -1.; *P = FFT_MAX - z.L + 1; *n_out = z.m + 1; }
-    else if (stage == 2) { *n_in = z.m + 1; *Q = z.num2; *sgn = 1.; *P = FFT_MAX - z.m; *n_out = z.len5; }
-    else if (stage == 4) { *n_in = z.n_dig; *Q = z.n_dig; *sgn = -1.; *P = FFT_MAX - z.n_dig + 1; *n_out = z.n_dig / 2 + 1; }
-    else { *n_in = z.n_dig / 2 + 1; *Q = z.n_up; *sgn = 1.; *P = FFT_MAX - z.n_dig / 2; *n_out = z.n_up; }
+    if (stage == 1) { *n_in = z.L; *Q = z.L; *sgn = -1.; *n_out = z.m + 1; }
+    else if (stage == 2) { *n_in = z.m + 1; *Q = z.num2; *sgn = 1.; *n_out = z.len5; }
+    else if (stage == 4) { *n_in = z.n_dig; *Q = z.n_dig; *sgn = -1.; *n_out = z.n_dig / 2 + 1; }
+    else { *n_in = z.n_dig / 2 + 1; *Q = z.n_up; *sgn = 1.; *n_out = z.n_up; }
+    int log2m = FFT_LOG2_MAX;
+    if (*n_in + *n_out - 1 <= FFT_MAX) {
+        log2m = 11;   // (the transform pair of conv_fft.h comes in 2048, 4096 and 8192 points)
+        while ((1l << log2m) < *n_in + *n_out - 1) log2m++;
+    }
+    *P = (1 << log2m) - *n_in + 1;
+    return log2m;
 }
 
 struct PaWork {
@@ -4518,7 +4525,9 @@ struct PaWork {
     int xs, s5, sd;
 };
 
-// Bluestein tables of the lengths in `lens` (slots of the station's table cache): [slot][4][FFT_MAX]
+// Tables of the lengths in `lens` (slots of the station's table cache): [slot][PA_TABLES][FFT_MAX] -- rows 0..3 the Bluestein
+// spectra of the four transforms (2^log2m points, natural bin order: conv_mid_plain), rows 4..7 their chirps exp(sgn i pi j^2 / Q), j < 2^log2m (the
+// factor of every input and every output sample: two sincospi per point and transform when evaluated in place)
 __global__ void __launch_bounds__(1024)
 pa_tables_kernel(int n_len, const int* __restrict__ lens, const int* __restrict__ slots, double fs, PaAdc adc,
                  const double2* __restrict__ tw, double2* __restrict__ Btab)
@@ -4531,22 +4540,41 @@ pa_tables_kernel(int n_len, const int* __restrict__ lens, const int* __restrict_
     int n_in, P;
     long Q, n_out;
     double sgn;
-    pa_stage(z, st < 2 ? st + 1 : st + 2, &n_in, &Q, &sgn, &P, &n_out);
+    const int log2m = pa_stage(z, st < 2 ? st + 1 : st + 2, &n_in, &Q, &sgn, &P, &n_out);
     if (P < 1) return;
-    czt_build_table(x, FFT_LOG2_MAX, n_in, P, Q, sgn, tw);
-    double2* B = Btab + ((long)slots[il] * 4 + st) * FFT_MAX;
-    for (int i = threadIdx.x; i < FFT_MAX; i += blockDim.x) B[i] = x[i];
+    czt_build_table(x, log2m, n_in, P, Q, sgn, tw);
+    double2* B = Btab + ((long)slots[il] * PA_TABLES + st) * FFT_MAX;
+    double2* C = B + 4l * FFT_MAX;
+    for (int i = threadIdx.x; i < (1 << log2m); i += blockDim.x) {
+        B[bitrev(i, log2m)] = x[i];
+        C[i] = chirp(i, Q, sgn);
+    }
 }
 
+// One transform of the chain: block (item, block of P outputs); 512 threads, the buffer in conv_fft.h's layout.  The convolution is
+// the transform pair of channel_conv_kernel (wave-private 1024-point sub-transforms, conv_fft.h) with a plain spectrum product in
+// the middle pass: 2^log2m / 16 threads carry it, all 512 fill the buffer and read it out.
+template <int LOG2M>
+__device__ __forceinline__ void pa_convolve(const double2* __restrict__ Bn, const double2* __restrict__ tw, const double2* __restrict__ cft,
+                                            bool full)
+{
+    if (full) conv_fwd<LOG2M, 512, true>(tw, cft);
+    else conv_fwd<LOG2M, 512, false>(tw, cft);
+    conv_mid_plain<LOG2M, 512>(Bn);
+    conv_inv<LOG2M, 512>(tw, cft);
+}
+
+template <int STAGE>
 __global__ void __launch_bounds__(512)
-pa_czt_stage_kernel(int stage, int item0, int n_cand, const int* __restrict__ item_event, int n_ch, const int* __restrict__ ev_L,
+pa_czt_stage_kernel(int item0, int n_cand, const int* __restrict__ item_event, int n_ch, const int* __restrict__ ev_L,
                     const int* __restrict__ slotmap, const double* __restrict__ trace, const long* __restrict__ trace_offset, int n_pa,
                     const int* __restrict__ pa_channel, double fs, PaAdc adc, const double2* __restrict__ tw,
-                    const double2* __restrict__ Btab, PaWork wk, double* __restrict__ pa_trace,
+                    const double2* __restrict__ cft, const double2* __restrict__ Btab, PaWork wk, double* __restrict__ pa_trace,
                     unsigned long long* __restrict__ conv_count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double2* x = (double2*)smem;
+    constexpr int stage = STAGE, NT = 512, U = FFT_MAX / NT;
     const int item = item0 + blockIdx.x, n_items = n_cand * n_pa, wi = blockIdx.x;   // wi: row of the chunk's work arrays
     if (item >= n_items) return;
     const int ic = item / n_pa, c = item % n_pa;
@@ -4555,42 +4583,85 @@ pa_czt_stage_kernel(int stage, int item0, int n_cand, const int* __restrict__ it
     int n_in, P;
     long Q, n_out;
     double sgn;
-    pa_stage(z, stage, &n_in, &Q, &sgn, &P, &n_out);
+    const int log2m = pa_stage(z, stage, &n_in, &Q, &sgn, &P, &n_out), M = 1 << log2m;
     const long k0 = (long)blockIdx.y * P;
     if (k0 >= n_out) return;
-    if (threadIdx.x == 0 && conv_count) atomicAdd(conv_count, 1ULL);   // 8192-point chirp convolutions carried out (bench.py prices them)
+    // FP64 operations of the convolution: transform pair 2 x 5 M log2 M, three complex products per point (bench.py's roofline)
+    if (threadIdx.x == 0 && conv_count) atomicAdd(conv_count, (unsigned long long)M * (unsigned long long)(10 * log2m + 18));
     const int st = stage < 3 ? stage - 1 : stage - 2;
-    const double2* B = Btab + ((long)slotmap[L / 2] * 4 + st) * FFT_MAX;
+    const double2* B = Btab + ((long)slotmap[L / 2] * PA_TABLES + st) * FFT_MAX;
+    const double2* C = B + 4l * FFT_MAX;
     const double* tr = trace + trace_offset[(long)ic * n_ch + pa_channel[c]];
     const double2* Xi = wk.X + (long)wi * wk.xs;
     const double* di = wk.d + (long)wi * wk.sd;
     const double2* Di = wk.D + (long)wi * (wk.sd / 2 + 1);
-    for (int j = threadIdx.x; j < FFT_MAX; j += blockDim.x) {
-        double2 v = make_double2(0., 0.);
-        if (j < n_in) {
-            if (stage == 1) v = make_double2(tr[j], 0.);
-            else if (stage == 2) v = cscale(Xi[j], ((j == 0 || j == z.m) ? 1. : 2.) / z.L);
-            else if (stage == 4) v = make_double2(di[j], 0.);
-            else v = cscale(Di[j], ((j == 0 || j == z.n_dig / 2) ? 1. : 2.) / z.n_dig);
-            v = cmul(v, chirp(j, Q, sgn));
-            if (k0) {   // outputs k0 .. : in[j] exp(sgn 2 pi i j k0 / Q)
-                double sn, cs;
-                sincospi(2. * (((double)j * (double)k0 < 4.5e15 && Q < (1l << 30)) ? mod_exact((double)j * (double)k0, (double)Q) : (double)(((long long)j * k0) % Q)) / (double)Q, &sn, &cs);
-                v = cmul(v, make_double2(cs, sgn * sn));
+    // the inputs of a thread are 512 apart: with several blocks of outputs their factors exp(sgn 2 pi i j k0 / Q) follow from the
+    // first one by a constant rotation (two sincospi per thread instead of one per point; <= 16 steps of the recurrence)
+    double2 sh = make_double2(1., 0.), sh_step = sh;
+    if (k0) {
+        auto turn = [&](long j) {
+            double sn, cs;
+            sincospi(2. * (((double)j * (double)k0 < 4.5e15 && Q < (1l << 30)) ? mod_exact((double)j * (double)k0, (double)Q) : (double)(((long long)j * k0) % Q)) / (double)Q, &sn, &cs);
+            return make_double2(cs, sgn * sn);
+        };
+        sh = turn(threadIdx.x);
+        sh_step = turn(NT);
+    }
+    const bool full = n_in > M / 2;
+    const int n_fill = full ? M : M / 2;   // (the forward transform does not read the upper half unless told to)
+    {
+        // all loads of the thread first (one round trip to HBM / L2 for the block instead of one per 512 points), then the products
+        double2 vin[U], cin[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int j = threadIdx.x + u * NT;
+            double2 v = make_double2(0., 0.), cc = v;
+            if (j < n_in) {
+                if (stage == 1) v = make_double2(tr[j], 0.);
+                else if (stage == 2) v = Xi[j];
+                else if (stage == 4) v = make_double2(di[j], 0.);
+                else v = Di[j];
+                cc = C[j];
             }
+            vin[u] = v;
+            cin[u] = cc;
         }
-        x[j] = v;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int j = threadIdx.x + u * NT;
+            if (j >= n_fill) break;
+            double2 v = vin[u];
+            if (stage == 2) v = cscale(v, ((j == 0 || j == z.m) ? 1. : 2.) / z.L);
+            else if (stage == 5) v = cscale(v, ((j == 0 || j == z.n_dig / 2) ? 1. : 2.) / z.n_dig);
+            v = cmul(v, cin[u]);
+            if (k0) { v = cmul(v, sh); sh = cmul(sh, sh_step); }   // outputs k0 .. : in[j] exp(sgn 2 pi i j k0 / Q)
+            x[conv_pad(j)] = v;
+        }
     }
     __syncthreads();
-    czt_convolve_t<512>(x, B, tw);
-    const long cnt = (n_out - k0 < P) ? n_out - k0 : P;
-    for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
-        // out[k0 + k] = chirp(k) x[k] / M  (the chirp belongs to the shifted problem: index k)
-        const double2 o = cscale(cmul(x[k], chirp(k, Q, sgn)), 1.0 / FFT_MAX);
-        if (stage == 1) wk.X[(long)wi * wk.xs + k0 + k] = o;
-        else if (stage == 2) wk.x5[(long)wi * wk.s5 + k0 + k] = o.x;
-        else if (stage == 4) wk.D[(long)wi * (wk.sd / 2 + 1) + k0 + k] = o;
-        else pa_trace[(long)item * adc.stride + k0 + k] = adc.counts ? rint(o.x) : o.x;
+    if (log2m == 13) pa_convolve<13>(B, tw, cft, full);
+    else if (log2m == 12) pa_convolve<12>(B, tw, cft, full);
+    else pa_convolve<11>(B, tw, cft, full);
+    const int cnt = (int)((n_out - k0 < P) ? n_out - k0 : P);
+    const double inv_m = 1.0 / M;
+    {
+        double2 cout[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = threadIdx.x + u * NT;
+            cout[u] = (k < cnt) ? C[k] : make_double2(0., 0.);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = threadIdx.x + u * NT;
+            if (k >= cnt) break;
+            // out[k0 + k] = chirp(k) x[k] / M  (the chirp belongs to the shifted problem: index k)
+            const double2 o = cscale(cmul(x[conv_pad(k)], cout[u]), inv_m);
+            if (stage == 1) wk.X[(long)wi * wk.xs + k0 + k] = o;
+            else if (stage == 2) wk.x5[(long)wi * wk.s5 + k0 + k] = o.x;
+            else if (stage == 4) wk.D[(long)wi * (wk.sd / 2 + 1) + k0 + k] = o;
+            else pa_trace[(long)item * adc.stride + k0 + k] = adc.counts ? rint(o.x) : o.x;
+        }
     }
 }
 
@@ -4847,13 +4918,16 @@ void launch_pa_czt_tables(hipStream_t s, int n_len, const int* lens, const int* 
 void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const int* slotmap,
                                      const double* trace, const long* trace_offset, int n_pa, const int* pa_channel, int n_beams,
                                      const int* rolls_up, int window, int step, double divisor, double threshold, int max_length, double fs,
-                                     const PaAdc& adc, const double2* tw, const double2* Btab, void* work, int chunk, double* pa_trace,
+                                     const PaAdc& adc, const double2* tw, const double2* cft, const double2* Btab, void* work, int chunk, double* pa_trace,
                                      int* pa_len, unsigned char* triggered, double* pa_max, bool with_beams,
                                      unsigned long long* conv_count)
 {
     if (n_cand <= 0) return;
     set_big_lds();
-    (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_elems(FFT_MAX) * 16);
+    (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_elems(FFT_MAX) * 16);
+    (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_elems(FFT_MAX) * 16);
+    (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_elems(FFT_MAX) * 16);
     const PaSizes z = pa_sizes(max_length, fs, adc);
     PaWork wk;
     wk.xs = z.m + 2; wk.s5 = (int)z.num2 + 2; wk.sd = z.n_dig + 4;
@@ -4863,12 +4937,6 @@ void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_
     wk.x5 = (double*)w;                 w += (size_t)chunk * wk.s5 * 8;
     wk.d = (double*)w;
     const int n_items = n_cand * n_pa;
-    auto blocks = [&](int stage) {   // output blocks of the longest trace
-        int n_in, P; long Q, n_out; double sgn;
-        pa_stage(z, stage, &n_in, &Q, &sgn, &P, &n_out);
-        // P shrinks and n_out grows with the length: the longest trace needs the most blocks
-        return (unsigned)((n_out + P - 1) / P);
-    };
     for (int item0 = 0; item0 < n_items; item0 += chunk) {
         const unsigned nb = (unsigned)std::min(chunk, n_items - item0);
         for (int stage = 1; stage <= 5; stage++) {
@@ -4878,8 +4946,14 @@ void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_
                 if (adc.upsampling < 2) break;
                 continue;
             }
-            hipLaunchKernelGGL(pa_czt_stage_kernel, dim3(nb, blocks(stage)), dim3(512), (size_t)FFT_MAX * 16, s, stage, item0, n_cand,
-                               item_event, n_ch, ev_L, slotmap, trace, trace_offset, n_pa, pa_channel, fs, adc, tw, Btab, wk, pa_trace, conv_count);
+            // output blocks, convolution length and threads of the longest trace (n_in + n_out grows with the length: it needs the most)
+            int n_in, P; long Q, n_out; double sgn;
+            const int log2m = pa_stage(z, stage, &n_in, &Q, &sgn, &P, &n_out), M = 1 << log2m;
+            const unsigned by = (unsigned)((n_out + P - 1) / P);
+            auto kern = stage == 1 ? pa_czt_stage_kernel<1> : stage == 2 ? pa_czt_stage_kernel<2> : stage == 4 ? pa_czt_stage_kernel<4>
+                                                                                                           : pa_czt_stage_kernel<5>;
+            hipLaunchKernelGGL(kern, dim3(nb, by), dim3(512), (size_t)conv_lds_elems(M) * 16, s, item0, n_cand, item_event, n_ch, ev_L,
+                               slotmap, trace, trace_offset, n_pa, pa_channel, fs, adc, tw, cft, Btab, wk, pa_trace, conv_count);
         }
     }
     if (with_beams)

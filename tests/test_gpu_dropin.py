@@ -180,6 +180,19 @@ class _FakeDet:
                                            ('synthetic_table_v1', [0., 2.2, 0., 0., 5.5])])
 @pytest.mark.parametrize('N', [256, 300])
 def test_efieldToVoltageConverter_module(antenna, cable, N):
+    _efield_to_voltage_module_case(antenna, cable, N, 40, 10)
+
+
+@pytest.mark.parametrize('antenna,cable,N', [('analytic_VPol', [0., 1000.3, 5000.77, 7000.2, 9000.8], 8192),   # L ~ 26 400: blocks both ways
+                                             ('analytic_LPDA', [0., 0., 2504.4, 0., 801.1], 6144),
+                                             ('analytic_HPol', [0., 3.3, 7.77, 12.2, 19.8], 10240)])
+def test_efieldToVoltageConverter_module_at_the_batched_limits(antenna, cable, N):
+    """nrhip_efield_to_voltage takes what nrhip_simulate_events takes: station traces up to 8192 samples (and the radix-5 10 240),
+    common traces up to 32 766 samples (forward and inverse chirp-z in blocks)."""
+    _efield_to_voltage_module_case(antenna, cable, N, 20, 3)
+
+
+def _efield_to_voltage_module_case(antenna, cable, N, n_events, n_min):
     """The module-level drop-in on arbitrary ElectricField-like objects vs the oracle's restatement of
     efieldToVoltageConverter.run (no filter), incl. the sub-sample Fourier shift (unequal cable delays)."""
     from nuradiomc_amd import modules
@@ -201,7 +214,7 @@ def test_efieldToVoltageConverter_module(antenna, cable, N):
     conv.begin(caching=False)
     rng = np.random.default_rng(9)
     n_done = 0
-    for ev in range(40):
+    for ev in range(n_events):
         r, ph = np.sqrt(rng.uniform(0, 1500. ** 2)), rng.uniform(0, 2 * np.pi)
         vertex = np.array([r * np.cos(ph), r * np.sin(ph), rng.uniform(-1500, -50)])
         efs = so.sim_efields_for_event(vertex, np.arccos(rng.uniform(-1, 1)), rng.uniform(0, 2 * np.pi), 1e18, 'HAD', None,
@@ -223,7 +236,7 @@ def test_efieldToVoltageConverter_module(antenna, cable, N):
             assert ch.t0 == t_min and len(ch.trace) == L and ch.fs == fs
             assert np.max(np.abs(ch.trace - V_ref[c])) <= 1e-6 * scale, (ev, c)
         n_done += 1
-    assert n_done >= 10
+    assert n_done >= n_min
     with pytest.raises(LookupError):
         conv.run(None, _FakeStation(_FakeSimStation({})), det)
 

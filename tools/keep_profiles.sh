@@ -10,7 +10,6 @@ done
 [ -s $M/config4_probe.log ] && cp $M/config4_probe.log profiles/${R}_config4_probe.txt
 [ -s $M/conv_phases.log ] && cp $M/conv_phases.log profiles/${R}_conv_phases.txt
 [ -s $M/att_dense_probe.log ] && cp $M/att_dense_probe.log profiles/${R}_att_dense_probe.txt
-[ -s $M/overlap_two_procs.log ] && cp $M/overlap_two_procs.log profiles/${R}_overlap_two_procs.txt
 [ -s $M/shard125k_kernels.log ] && cp $M/shard125k_kernels.log profiles/${R}_shard125k_kernels.txt
 [ -s gpurun_out/measure_sq/sq_a.csv ] && { echo "# rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes, tools/measure_sq.sh) -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 3; largest launch per kernel, summed over XCDs / SEs"; echo "# pass a"; cat gpurun_out/measure_sq/sq_a.csv; echo "# pass b"; cat gpurun_out/measure_sq/sq_b.csv; } > profiles/${R}_pmc_sq_counters.csv
 ls -la profiles | grep $R
