@@ -491,9 +491,13 @@ def main():
         raise SystemExit(rc)
     # this process is a rank: the JSON line alone goes to the stdout it was given -- libraries on the GPU side write to fd 1 as well
     # (RCCL prints a version banner there), so fd 1 becomes stderr and the line is written through a duplicate of the original
+    # (not when a caller has replaced sys.stdout to read the line: tools/conv_phase_probe.py runs main() in-process)
     sys.stdout.flush()
-    json_out = os.fdopen(os.dup(1), 'w')
-    os.dup2(2, 1)
+    if sys.stdout is sys.__stdout__:
+        json_out = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+    else:
+        json_out = sys.stdout
 
     def emit(obj):
         json_out.write(json.dumps(obj, default=_json_default) + '\n')

@@ -2301,6 +2301,82 @@ __device__ __noinline__ ConvOut conv_output_pass(int L, double vscale, double th
     }
     return o;
 }
+// Output pass of a channel WITH coincidence logic: per-channel flags (simpleThreshold.py:14-29 / highLowThreshold.py:13-80),
+// OR-dilated over the coincidence window (get_majority_logic :82-150: flag i stays up for w_coinc samples), counted per sample in
+// cnt; returns the thread's maximum |V|.  Two passes over the trace, a contiguous run of <= RUN samples per thread: (1) samples (the
+// two halves of the linear convolution folded on the fly, read-only), the high / low window as the distances to the last sample
+// above / below (the w_hl - 1 samples in front of the run looked at once: O(run + w) instead of O(run x w)), the running index of
+// the last raised flag (registers); (2) after a scan over the runs' totals, the coincidence count.  Two barriers (were six).  Out
+// of line like conv_output_pass (its own register allocation).
+template <int RUN>
+__device__ __noinline__ double conv_coinc_pass(int L, double vscale, double threshold, int ch_on, TriggerDev trg, double* __restrict__ tr,
+                                               const double* __restrict__ add, int with_signal, int* __restrict__ cnt, int* scan)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const double* S = (const double*)smem;
+    const int NT = blockDim.x;
+    double vmax = 0.;
+    int a_loc[RUN];               // index of the last raised flag at or before the run's sample u (-1: none)
+    const int nb = (trg.type == 0) ? L : L - 1;
+    const int chunk = (L + NT - 1) / NT, b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, L);
+    auto sample = [&](int n) {
+        const int n2 = n + L;
+        double v = with_signal ? (S[2 * conv_pad(n >> 1) + (n & 1)] + S[2 * conv_pad(n2 >> 1) + (n2 & 1)]) * vscale : 0.;
+        if (add) v += add[n];
+        return v;
+    };
+    int last_hi = -(1 << 30), last_lo = -(1 << 30), run = -1;
+    if (trg.type != 0 && b0 < b1) {
+        for (int k = b0 - (trg.w_hl - 1); k < b0; k++) {
+            const double v = (k >= 0) ? sample(k) : 0.;   // the reference pads with zeros in front
+            if (v >= trg.high) last_hi = k;
+            if (v <= trg.low) last_lo = k;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RUN; u++) {
+        const int i = b0 + u;
+        a_loc[u] = -1;
+        if (u < chunk && i < b1) {
+            const double v = sample(i);
+            if (tr) tr[i] = v;
+            vmax = fmax(vmax, fabs(v));
+            bool flag;
+            if (trg.type == 0) {
+                flag = fabs(v) >= threshold;
+            } else {
+                if (v >= trg.high) last_hi = i;
+                if (v <= trg.low) last_lo = i;
+                flag = (i - last_hi < trg.w_hl) && (i - last_lo < trg.w_hl);
+            }
+            if (i < nb && flag && ch_on) run = i;
+            a_loc[u] = run;
+        }
+    }
+    // running maximum across the runs: a wave-level scan of the runs' last values (shuffles), the waves' totals through LDS
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = run;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl = max(incl, v);
+    }
+    if (lane == 63) scan[wv] = incl;
+    int before = __shfl_up(incl, 1);
+    if (lane == 0) before = -1;
+    lds_barrier();
+    for (int q = 0; q < wv; q++) before = max(before, scan[q]);
+    const int wc = min(trg.w_coinc, nb);
+#pragma unroll
+    for (int u = 0; u < RUN; u++) {
+        const int i = b0 + u;
+        if (u < chunk && i < min(b1, nb - 1)) {
+            const int a = max(a_loc[u], before);
+            if (a >= 0 && i - a < wc) cnt[i] += 1;
+        }
+    }
+    lds_barrier();
+    return vmax;
+}
 template <int NT, class FV, class FS>
 __device__ __forceinline__ void czt_inverse_blocks(double2* x, const double2* __restrict__ Bi, const double2* __restrict__ tw,
                                                    const double2* __restrict__ E, const double2* __restrict__ Ci, int L, int m, int M,
@@ -2754,60 +2830,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 vmax = co.vmax;
                 trig = co.trig;
             } else {
-                // per-channel flags (simpleThreshold.py:14-29 / highLowThreshold.py:13-80), OR-dilated over the coincidence
-                // window (get_majority_logic :82-150: flag i stays up for w_coinc samples), counted per sample in cnt
-                for (int n = threadIdx.x; n < L; n += blockDim.x) {
-                    double v = sig ? (S[PS(n)] + S[PS(n + L)]) * vscale : 0.;
-                    if (noisy) v += nbuf[n];
-                    if (out.trace) out.trace[out.trace_offset[item] + n] = v;
-                    vmax = fmax(vmax, fabs(v));
-                    S[PS(n)] = v;
-                }
-                lds_barrier();
-                int* A = (int*)(S + 2 * (conv_pad(M / 2) + 8));  // index of the last raised flag at or before sample i (-1: none); behind the trace
-                const int nb = (trg.type == 0) ? L : L - 1;
-                for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-                    bool flag;
-                    if (trg.type == 0) {
-                        flag = fabs(S[PS(i)]) >= threshold;
-                    } else {
-                        bool hi = false, lo = false;
-                        for (int k = max(0, i - trg.w_hl + 1); k <= i; k++) {
-                            hi = hi || (S[PS(k)] >= trg.high);
-                            lo = lo || (S[PS(k)] <= trg.low);
-                        }
-                        if (i - trg.w_hl + 1 < 0) {  // the reference pads with zeros in front
-                            hi = hi || (0. >= trg.high);
-                            lo = lo || (0. <= trg.low);
-                        }
-                        flag = hi && lo;
-                    }
-                    A[i] = (flag && ch_on) ? i : -1;
-                }
-                lds_barrier();
-                {   // inclusive running maximum of A[0 .. nb): contiguous chunk per thread, a wave-level scan of the chunk maxima
-                    // (shuffles), the waves' totals through LDS: two barriers (was 2 log2(NT) + 2)
-                    const int chunk = (nb + NT - 1) / NT, b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, nb);
-                    int run = -1;
-                    for (int i = b0; i < b1; i++) { run = max(run, A[i]); A[i] = run; }
-                    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-                    int incl = run;
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const int v = __shfl_up(incl, off);
-                        if (lane >= off) incl = max(incl, v);
-                    }
-                    if (lane == 63) s_scan[wv] = incl;
-                    int before = __shfl_up(incl, 1);
-                    if (lane == 0) before = -1;
-                    lds_barrier();
-                    for (int q = 0; q < wv; q++) before = max(before, s_scan[q]);
-                    for (int i = b0; i < b1; i++) A[i] = max(A[i], before);
-                    lds_barrier();
-                }
-                const int wc = min(trg.w_coinc, nb);
-                for (int i = threadIdx.x; i < nb - 1; i += blockDim.x)
-                    if (A[i] >= 0 && i - A[i] < wc) cnt[i] += 1;
-                lds_barrier();
+                vmax = conv_coinc_pass<M / NT>(L, vscale, threshold, ch_on ? 1 : 0, trg, out.trace ? out.trace + out.trace_offset[item] : nullptr,
+                                               noisy ? nbuf : nullptr, sig ? 1 : 0, cnt, s_scan);
             }
         }
         else if (emitting) {   // a channel without rays: zeros, as the reference's empty channels
