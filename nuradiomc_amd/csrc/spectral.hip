@@ -844,22 +844,24 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, c
 #ifndef NRHIP_ATT_BOUND_MARGIN
 #define NRHIP_ATT_BOUND_MARGIN 0.95
 #endif
-#ifndef NRHIP_AMP_TWO_LEVEL
-#define NRHIP_AMP_TWO_LEVEL 0
-#endif
 #define AB_RT 4  // rays per wave and pass: the frequency-grid tables are loaded once for AB_RT rays
 __global__ void __launch_bounds__(256, 3)
 amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double* __restrict__ vertex,
                  const double* __restrict__ zint, double* __restrict__ bound, double* __restrict__ max_efield, double cut)
 {
-    __shared__ double blen[4][AB_RT][64];  // per wave and ray: path length inside each depth bin
-    __shared__ double s_binv[63 * 32];  // the depth-bin table (n_fc <= 32; read from HBM otherwise)
+    (void)cut;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    static_assert(AB_RT == 4, "two packed pairs of rays");
+    __shared__ float4 blen[4][64];      // per wave and depth bin: path length of the tile's four rays inside the bin
+    __shared__ float s_binv[63 * 32];   // the depth-bin table (n_fc <= 32; read from HBM otherwise)
     const bool binv_lds = st.n_att_bins > 0 && st.n_fc <= 32;
     if (binv_lds)
-        for (int j = threadIdx.x; j < st.n_att_bins * st.n_fc; j += blockDim.x) s_binv[j] = st.att_bin_inv[j];
-    __shared__ double ub[4][AB_RT][NRHIP_MAX_NFC];  // per wave and ray: upper bounds of the coarse attenuation factors
+        for (int j = threadIdx.x; j < st.n_att_bins * st.n_fc; j += blockDim.x) s_binv[j] = (float)st.att_bin_inv[j];
+    // per wave: upper bounds of the coarse attenuation factors and the slopes between them -- single precision, the tile's four rays
+    // side by side (one 16-byte read per table and frequency bin), for the FP32 sums; double precision per ray for the general sums
+    __shared__ float4 ubf[4][NRHIP_MAX_NFC], slf[4][NRHIP_MAX_NFC];
+    __shared__ double ub[4][AB_RT][NRHIP_MAX_NFC];
     __shared__ double ub_slope[4][AB_RT][NRHIP_MAX_NFC];
-    __shared__ float ub_f[4][AB_RT][NRHIP_MAX_NFC], ub_slope_f[4][AB_RT][NRHIP_MAX_NFC];
     __shared__ double s_xp[NRHIP_MAX_NFC];
     __shared__ float s_xp_f[NRHIP_MAX_NFC];
     for (int j = threadIdx.x; j < st.n_fc; j += blockDim.x) { s_xp[j] = st.fcoarse[j]; s_xp_f[j] = (float)st.fcoarse[j]; }
@@ -871,51 +873,79 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
     const int n_iter = (n_rays + per_pass - 1) / per_pass;
     for (int it = 0; it < n_iter; it++) {
         const int rb = ((it * gridDim.x + blockIdx.x) * 4 + wv) * AB_RT;
+        if (rb >= n_rays) continue;   // (wave-uniform; the tables below are the wave's own)
+        // per-ray scalars only (the full AskaryanConst records would cost ~40 VGPRs per ray)
+        double cL[AB_RT], cR[AB_RT], pf[AB_RT];
+        int had[AB_RT];
+        bool all2009 = true;
+        for (int i = 0; i < AB_RT; i++) {
+            const AskaryanConst& ai = w.ask[min(rb + i, n_rays - 1)];
+            all2009 = all2009 && (ai.model == 0);
+            cL[i] = ai.cL; cR[i] = ai.cR; pf[i] = ai.pref2; had[i] = ai.had;
+        }
+        // Alvarez2009 with all scalars comfortably inside the single-precision range: the attenuation bounds and the 2047-term sum in
+        // FP32 (twice the VALU rate, packed pairs of rays, 1-instruction reciprocal / exp); every term is within ~1e-5 and the sum of
+        // positive terms within 2047 * 6e-8 of the exact one, the result is inflated by BOUND_F32_SLACK and stays an upper bound
+        // ((1 + x)(1 + y) cannot overflow: x, y < 1e15)
+        bool f32 = all2009;
+        for (int i = 0; i < AB_RT; i++)
+            f32 = f32 && pf[i] > 1e-25 && pf[i] < 1e25 && cL[i] > 1e-15 && cL[i] < 1e15 && cR[i] > 1e-15 && cR[i] < 1e15;
         // attenuation factor <= exp(-int ds / L) <= exp(-D / L_max(f)); 0.95 covers the reference's 1e-2 quadrature
         // tolerance; linear interpolation of upper bounds bounds the interpolated attenuation
+        double ud[AB_RT] = {0., 0., 0., 0.};   // this lane's coarse frequency (lane < n_fc), the tile's rays
+        float uf[AB_RT] = {0.f, 0.f, 0.f, 0.f};
         if (st.n_att_bins > 0) {
             // depth-resolved: int ds / L >= sum_b (path length inside depth bin b) * min_bin(1 / L).  The path climbs
             // from z1 to min(z_turn, z2m) and, if it turns, descends again to 2 z_turn - z2m; s(z) is the closed-form
             // path length (analyticraytracing.py:602-689) with n sin(theta) = 1 / C0.  Lane i evaluates both legs at
             // the bin edge -i w; bins the path does not reach contribute 0, parts below the table are ignored.
-            // Single precision suffices here (bin lengths to ~1e-5; the sum below is shrunk by 1e-3 to stay rigorous).
+            // Single precision throughout (hardware exp / log / sqrt / reciprocal: a few ulp each): the bin lengths are good to ~1e-5,
+            // their products with the table and the 63-term sums to ~1e-5 as well; the sum is shrunk by 1e-3 to stay a lower bound.
+            float bl[AB_RT];
+#pragma unroll
             for (int i = 0; i < AB_RT; i++) {
                 const int r = rb + i;
                 float s1 = 0.f, s2 = 0.f;
                 if (r < n_rays && lane <= st.n_att_bins) {
                     const double C0 = w.C0[r], z1 = zint[3 * (long)r], z2m = zint[3 * (long)r + 1], zt = zint[3 * (long)r + 2];
-                    const double beta2d = 1. / (C0 * C0);
-                    const float beta2 = (float)beta2d, alpha = (float)(m.n2 - beta2d), sa = sqrtf(alpha);
-                    const float n_ice = (float)m.n_ice, dn = (float)m.delta_n, z0 = (float)m.z_0;
+                    const double beta2d = __builtin_amdgcn_rcp(C0 * C0);   // (hardware reciprocal: ~1e-8, see the precision note above)
+                    const float beta2 = (float)beta2d, alpha = (float)(m.n2 - beta2d), sa = __builtin_amdgcn_sqrtf(alpha);
+                    const float n_ice = (float)m.n_ice, dn = (float)m.delta_n, z0 = (float)m.z_0, inv_z0 = __builtin_amdgcn_rcpf(z0);
+                    const float nsa = n_ice * __builtin_amdgcn_rcpf(sa);
                     const double edge = -lane * st.att_bin_width;
                     const double top1 = fmin(zt, z2m), lo2 = (z2m > zt) ? 2 * zt - z2m : zt;
                     const float zz[2] = {(float)fmin(fmax(edge, z1), top1), (float)fmin(fmax(edge, lo2), zt)};
                     float sv[2];
+#pragma unroll
                     for (int q = 0; q < 2; q++) {
-                        float nz = n_ice - dn * __expf(zz[q] / z0);
-                        float gam = fmaxf(0.f, nz * nz - beta2);
-                        float l1 = sqrtf(alpha * gam) + n_ice * nz - beta2, l2 = sqrtf(gam) + nz;
-                        sv[q] = n_ice / sa * (zz[q] - z0 * __logf(l1)) + z0 * __logf(l2);
+                        const float nz = n_ice - dn * __expf(zz[q] * inv_z0);
+                        const float gam = fmaxf(0.f, nz * nz - beta2);
+                        const float l1 = __builtin_amdgcn_sqrtf(alpha * gam) + n_ice * nz - beta2, l2 = __builtin_amdgcn_sqrtf(gam) + nz;
+                        sv[q] = nsa * (zz[q] - z0 * __logf(l1)) + z0 * __logf(l2);
                     }
                     s1 = sv[0];
                     s2 = sv[1];
                 }
                 const float d1 = s1 - __shfl_down(s1, 1), d2 = s2 - __shfl_down(s2, 1);
-                blen[wv][i][lane] = (lane < st.n_att_bins) ? (double)(fmaxf(0.f, d1) + fmaxf(0.f, d2)) : 0.;
+                bl[i] = (lane < st.n_att_bins) ? fmaxf(0.f, d1) + fmaxf(0.f, d2) : 0.f;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            blen[wv][lane] = make_float4(bl[0], bl[1], bl[2], bl[3]);
+            wave_lds_sync();
             if (lane < st.n_fc) {
-                double I[AB_RT];
-                for (int i = 0; i < AB_RT; i++) I[i] = 0.;
-                const double* binv = binv_lds ? s_binv : st.att_bin_inv;
+                f2 I01 = f2{0.f, 0.f}, I23 = I01;
                 for (int b = 0; b < st.n_att_bins; b++) {
-                    const double t = binv[b * st.n_fc + lane];
-#pragma unroll
-                    for (int i = 0; i < AB_RT; i++) I[i] += blen[wv][i][b] * t;
+                    const float t = binv_lds ? s_binv[b * st.n_fc + lane] : (float)st.att_bin_inv[b * st.n_fc + lane];
+                    const float4 q = blen[wv][b];
+                    I01 += f2{q.x, q.y} * t;
+                    I23 += f2{q.z, q.w} * t;
                 }
-                for (int i = 0; i < AB_RT; i++) ub[wv][i][lane] = (rb + i < n_rays) ? exp(-NRHIP_ATT_BOUND_MARGIN * (1 - 1e-3) * I[i]) : 0.;
+                const float I[AB_RT] = {I01.x, I01.y, I23.x, I23.y};
+                for (int i = 0; i < AB_RT; i++) {
+                    if (rb + i >= n_rays) continue;
+                    // (v_exp_f32 on an argument of up to ~1e2: a few 1e-6 of the value; inflated to stay above it)
+                    if (f32) uf[i] = __expf(-(float)(NRHIP_ATT_BOUND_MARGIN * (1 - 1e-3)) * I[i]) * (1.f + 2e-5f);
+                    else ud[i] = exp(-NRHIP_ATT_BOUND_MARGIN * (1 - 1e-3) * (double)I[i]);
+                }
             }
         } else if (lane < st.n_fc) {
             for (int i = 0; i < AB_RT; i++) {
@@ -925,142 +955,85 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
                     double zlo = fmin(vertex[3 * (long)w.ev[r] + 2], st.pos[3 * w.ch[r] + 2]);  // deepest point of the path
                     u = (zlo >= -st.att_bound_depth) ? exp(-NRHIP_ATT_BOUND_MARGIN * w.R[r] * st.inv_lmax[lane]) : 1.;
                 }
-                ub[wv][i][lane] = u;
+                ud[i] = u;
+                uf[i] = (float)u * (1.f + 2e-7f);
             }
         }
-        wave_lds_sync();   // (every table behind this point is the wave's own: the waves of a block run apart)
-        for (int i = 0; i < AB_RT; i++)
-            if (lane < st.n_fc - 1)
-                ub_slope[wv][i][lane] = (ub[wv][i][lane + 1] - ub[wv][i][lane]) / (s_xp[lane + 1] - s_xp[lane]);
-        wave_lds_sync();   // (every table behind this point is the wave's own: the waves of a block run apart)
-        for (int i = 0; i < AB_RT; i++)   // single-precision copies for the FP32 sums (rounding covered by BOUND_F32_SLACK)
-            if (lane < st.n_fc) {
-                ub_f[wv][i][lane] = (float)ub[wv][i][lane];
-                ub_slope_f[wv][i][lane] = (lane < st.n_fc - 1) ? (float)ub_slope[wv][i][lane] : 0.f;
+        if (f32) {
+            if (lane < st.n_fc) ubf[wv][lane] = make_float4(uf[0], uf[1], uf[2], uf[3]);
+            wave_lds_sync();
+            if (lane < st.n_fc) {   // slope towards the next coarse frequency (0 behind the last)
+                float4 sl = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lane < st.n_fc - 1) {
+                    const float4 nx = ubf[wv][lane + 1];
+                    const float inv = __builtin_amdgcn_rcpf(s_xp_f[lane + 1] - s_xp_f[lane]);
+                    sl = make_float4((nx.x - uf[0]) * inv, (nx.y - uf[1]) * inv, (nx.z - uf[2]) * inv, (nx.w - uf[3]) * inv);
+                }
+                slf[wv][lane] = sl;
             }
-        wave_lds_sync();   // (every table behind this point is the wave's own: the waves of a block run apart)
-        if (rb < n_rays) {
-            // per-ray scalars only (the full AskaryanConst records would cost ~40 VGPRs per ray)
-            double cL[AB_RT], cR[AB_RT], pf[AB_RT];
-            int had[AB_RT];
-            bool all2009 = true;
-            for (int i = 0; i < AB_RT; i++) {
-                const AskaryanConst& ai = w.ask[min(rb + i, n_rays - 1)];
-                all2009 = all2009 && (ai.model == 0);
-                cL[i] = ai.cL; cR[i] = ai.cR; pf[i] = ai.pref2; had[i] = ai.had;
-            }
-            double part[AB_RT];
-            for (int i = 0; i < AB_RT; i++) part[i] = 0.;
-            const double x_first = s_xp[0], x_last = s_xp[st.n_fc - 1], dx_last = x_last - s_xp[st.n_fc - 2];
-            // Alvarez2009 with all scalars comfortably inside the single-precision range: the 2047-term sum in FP32 (twice the
-            // VALU rate, a 1-instruction reciprocal); every term is within ~1e-6 and the sum of positive terms within
-            // 2047 * 6e-8 of the exact one, the result is inflated by BOUND_F32_SLACK and stays an upper bound ((1 + x)(1 + y)
-            // cannot overflow: x, y < 1e15)
-            bool f32 = all2009;
+        } else {
+            if (lane < st.n_fc)
+                for (int i = 0; i < AB_RT; i++) ub[wv][i][lane] = ud[i];
+            wave_lds_sync();
             for (int i = 0; i < AB_RT; i++)
-                f32 = f32 && pf[i] > 1e-25 && pf[i] < 1e25 && cL[i] > 1e-15 && cL[i] < 1e15 && cR[i] > 1e-15 && cR[i] < 1e15;
-            // Two levels (round 4, measured and NOT kept -- NRHIP_AMP_TWO_LEVEL=1 builds it): the bound is only ever COMPARED with the
-            // candidate cut, and two rays in three lie far below it.  The 64-term bound decides 38 % of the tiles of four rays on
-            // the survey, yet the kernel takes 8.5 ms with it against 7.9 without: the part in front of the sums (path lengths per
-            // depth bin, the attenuation bounds) is half of the work, and the decision needs the rays' polarisation / Fresnel
-            // factors from HBM up front.  First
-            // a 64-term bound -- lane g takes the bins 32 g + 1 .. 32 g + 32: X_k <= pref f_hi / ((1 + cL p_lo)(1 + cR q_lo)) (the f^p
-            // tables rise with f), the interpolated attenuation bound <= the largest of the coarse nodes around the group --; only if
-            // that exceeds the cut for one of the wave's rays does the 2047-term sum run (for all AB_RT: they share the table loads).
-            // A ray left with the coarse value lies below the cut with it, as it would with the fine one: the lists of active rays
-            // are the same, and the value is still an upper bound.
-            bool coarse_only = false;
-            double coarse[AB_RT];
-#if NRHIP_AMP_TWO_LEVEL
-            if (f32 && cut >= 0. && nh >= 256) {
-                const int k0 = 1 + 32 * lane, k1 = min(nh - 1, 32 * lane + 32);
-                float term[AB_RT];
-                for (int i = 0; i < AB_RT; i++) term[i] = 0.f;
-                if (k0 <= k1) {
-                    const float f_hi = (float)(k1 * df) * (1.f + 1e-6f);
-                    const float ph = st.fpow_f[k0] * (1.f - 1e-6f), pe = st.fpow_f[stride + k0] * (1.f - 1e-6f), pr = st.fpow_f[2 * stride + k0] * (1.f - 1e-6f);
-                    int j0 = st.seg[k0], j1 = min(st.seg[k1] + 1, st.n_fc - 1);
-                    if ((float)(k0 * df) <= (float)x_first) j0 = 0;
-                    for (int i = 0; i < AB_RT; i++) {
-                        float um = 0.f;
-                        for (int j = j0; j <= j1; j++) um = fmaxf(um, ub_f[wv][i][j]);
-                        const float x = (had[i] ? ph : pe) * (float)cL[i], y = pr * (float)cR[i];
-                        term[i] = (float)(k1 - k0 + 1) * (float)pf[i] * f_hi * __builtin_amdgcn_rcpf((1.f + x) * (1.f + y)) * um * (1.f + 1e-5f);
-                    }
+                if (lane < st.n_fc - 1)
+                    ub_slope[wv][i][lane] = (ub[wv][i][lane + 1] - ud[i]) / (s_xp[lane + 1] - s_xp[lane]);
+        }
+        wave_lds_sync();   // (every table behind this point is the wave's own: the waves of a block run apart)
+        // (A two-level scheme -- a 64-term bound first, the full sum only for tiles near the candidate cut -- was built and measured
+        // in round 4 and not kept: 38 % of the tiles decided early, the kernel slower)
+        double part[AB_RT];
+        for (int i = 0; i < AB_RT; i++) part[i] = 0.;
+        const double x_first = s_xp[0], x_last = s_xp[st.n_fc - 1], dx_last = x_last - s_xp[st.n_fc - 2];
+        if (f32) {
+            // the four rays of the tile as two packed pairs (v_pk_mul / v_pk_fma_f32: two single-precision operations per lane and
+            // instruction; only the reciprocal is per ray)
+            f2 cL2[2], cR2[2], pf2[2], hm2[2], acc2[2];
+            for (int j = 0; j < 2; j++) {
+                cL2[j] = f2{(float)cL[2 * j], (float)cL[2 * j + 1]};
+                cR2[j] = f2{(float)cR[2 * j], (float)cR[2 * j + 1]};
+                pf2[j] = f2{(float)pf[2 * j], (float)pf[2 * j + 1]};
+                hm2[j] = f2{had[2 * j] ? 1.f : 0.f, had[2 * j + 1] ? 1.f : 0.f};
+                acc2[j] = f2{0.f, 0.f};
+            }
+            const f2 one2 = f2{1.f, 1.f}, zero2 = f2{0.f, 0.f};
+            const float xf_first = (float)x_first, xf_last = (float)x_last, dxf_last = (float)dx_last, dff = (float)df;
+            // the station tables of the NEXT bin are requested before the current one is evaluated (L1 / L2 latency off the path)
+            int kq = 1 + lane;
+            int n_lo = (kq < nh) ? st.seg[kq] : 0;
+            float n_ph = (kq < nh) ? st.fpow_f[kq] : 0.f, n_pe = (kq < nh) ? st.fpow_f[stride + kq] : 0.f,
+                  n_pr = (kq < nh) ? st.fpow_f[2 * stride + kq] : 0.f;
+            for (int k = 1 + lane; k < nh; k += 64) {
+                const float f = k * dff;
+                int lo = n_lo;
+                const float ph = n_ph, pe = n_pe, pr = n_pr;
+                kq = k + 64;
+                if (kq < nh) {
+                    n_lo = st.seg[kq];
+                    n_ph = st.fpow_f[kq];
+                    n_pe = st.fpow_f[stride + kq];
+                    n_pr = st.fpow_f[2 * stride + kq];
                 }
-                coarse_only = true;
-                for (int i = 0; i < AB_RT; i++) {
-                    float pt = term[i];
-                    for (int off = 32; off > 0; off >>= 1) pt += __shfl_xor(pt, off);
-                    const int r = min(rb + i, n_rays - 1);
-                    const double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
-                    coarse[i] = efield_bound(((double)pt * BOUND_F32_SLACK + 1e-30) * BOUND_RCP_SLACK, st.N, st.fs, cmax);
-                    if (rb + i < n_rays && coarse[i] * (1 + 1e-6) > cut) coarse_only = false;   // (the comparison of event_possible_kernel)
+                float dx = f - s_xp_f[lo];
+                if (f <= xf_first) { lo = 0; dx = 0.f; }
+                if (f >= xf_last) { lo = st.n_fc - 2; dx = dxf_last; }
+                dx = fmaxf(dx, 0.f);
+                const float dp = ph - pe;
+                const float4 sl4 = slf[wv][lo], u4 = ubf[wv][lo];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const f2 psel = hm2[j] * dp + pe;   // hadronic: f^2.57 table, electromagnetic: f^2.74 (exactly one of the two)
+                    const f2 den = (one2 + psel * cL2[j]) * (one2 + pr * cR2[j]);
+                    const f2 rc = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                    const f2 sl = j ? f2{sl4.z, sl4.w} : f2{sl4.x, sl4.y};
+                    const f2 u0 = j ? f2{u4.z, u4.w} : f2{u4.x, u4.y};
+                    const f2 uv = __builtin_elementwise_max(sl * dx + u0, zero2);
+                    acc2[j] += (pf2[j] * f) * rc * uv;
                 }
             }
-#ifdef NRHIP_CONV_TIMING
-            if (lane == 0) { atomicAdd(&g_conv_clk[13], 1ULL); if (coarse_only) atomicAdd(&g_conv_clk[14], 1ULL); }
-#endif
-#else
-            (void)cut;
-            for (int i = 0; i < AB_RT; i++) coarse[i] = 0.;
-#endif
-            if (coarse_only) {
-                for (int i = 0; i < AB_RT; i++) {
-                    const int r = rb + i;
-                    if (lane == 0 && r < n_rays) { bound[r] = coarse[i]; max_efield[r] = -coarse[i]; }
-                }
-            } else {
-            if (f32) {
-                // the four rays of the tile as two packed pairs (v_pk_mul / v_pk_fma_f32: two single-precision operations per lane and
-                // instruction; only the reciprocal is per ray): 26 instead of 44 arithmetic instructions per frequency bin
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                static_assert(AB_RT == 4, "two packed pairs");
-                f2 cL2[2], cR2[2], pf2[2], hm2[2], acc2[2];
-                for (int j = 0; j < 2; j++) {
-                    cL2[j] = f2{(float)cL[2 * j], (float)cL[2 * j + 1]};
-                    cR2[j] = f2{(float)cR[2 * j], (float)cR[2 * j + 1]};
-                    pf2[j] = f2{(float)pf[2 * j], (float)pf[2 * j + 1]};
-                    hm2[j] = f2{had[2 * j] ? 1.f : 0.f, had[2 * j + 1] ? 1.f : 0.f};
-                    acc2[j] = f2{0.f, 0.f};
-                }
-                const f2 one2 = f2{1.f, 1.f}, zero2 = f2{0.f, 0.f};
-                const float xf_first = (float)x_first, xf_last = (float)x_last, dxf_last = (float)dx_last, dff = (float)df;
-                // the station tables of the NEXT bin are requested before the current one is evaluated (L1 / L2 latency off the path)
-                int kq = 1 + lane;
-                int n_lo = (kq < nh) ? st.seg[kq] : 0;
-                float n_ph = (kq < nh) ? st.fpow_f[kq] : 0.f, n_pe = (kq < nh) ? st.fpow_f[stride + kq] : 0.f,
-                      n_pr = (kq < nh) ? st.fpow_f[2 * stride + kq] : 0.f;
-                for (int k = 1 + lane; k < nh; k += 64) {
-                    const float f = k * dff;
-                    int lo = n_lo;
-                    const float ph = n_ph, pe = n_pe, pr = n_pr;
-                    kq = k + 64;
-                    if (kq < nh) {
-                        n_lo = st.seg[kq];
-                        n_ph = st.fpow_f[kq];
-                        n_pe = st.fpow_f[stride + kq];
-                        n_pr = st.fpow_f[2 * stride + kq];
-                    }
-                    float dx = f - s_xp_f[lo];
-                    if (f <= xf_first) { lo = 0; dx = 0.f; }
-                    if (f >= xf_last) { lo = st.n_fc - 2; dx = dxf_last; }
-                    dx = fmaxf(dx, 0.f);
-                    const float dp = ph - pe;
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const f2 psel = hm2[j] * dp + pe;   // hadronic: f^2.57 table, electromagnetic: f^2.74 (exactly one of the two)
-                        const f2 den = (one2 + psel * cL2[j]) * (one2 + pr * cR2[j]);
-                        const f2 rc = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                        const f2 sl = f2{ub_slope_f[wv][2 * j][lo], ub_slope_f[wv][2 * j + 1][lo]};
-                        const f2 u0 = f2{ub_f[wv][2 * j][lo], ub_f[wv][2 * j + 1][lo]};
-                        const f2 uv = __builtin_elementwise_max(sl * dx + u0, zero2);
-                        acc2[j] += (pf2[j] * f) * rc * uv;
-                    }
-                }
-                float pf32[AB_RT] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y};
-                for (int i = 0; i < AB_RT; i++) part[i] = (double)pf32[i] * BOUND_F32_SLACK + 1e-30;  // + what FP32 may have flushed to zero
-            } else
+            float pf32[AB_RT] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y};
+            for (int i = 0; i < AB_RT; i++) part[i] = (double)pf32[i] * BOUND_F32_SLACK + 1e-30;  // + what FP32 may have flushed to zero
+        } else {
             for (int k = 1 + lane; k < nh; k += 64) {
                 const double f = k * df;
                 // np.interp clamps outside the coarse grid: segment 0 at offset 0 / last segment at full length
@@ -1082,17 +1055,21 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
                                    (ub_slope[wv][i][lo] * dx + ub[wv][i][lo]);
                 }
             }
-            for (int i = 0; i < AB_RT; i++) {
-                double pt = part[i];
-                for (int off = 32; off > 0; off >>= 1) pt += __shfl_xor(pt, off);
-                const int r = rb + i;
-                if (lane == 0 && r < n_rays) {
-                    double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
-                    double b = efield_bound(pt * BOUND_RCP_SLACK, st.N, st.fs, cmax);
-                    bound[r] = b;
-                    max_efield[r] = -b;  // "not evaluated, at most b" until efield_max_kernel overwrites it
-                }
-            }
+        }
+        // the four sums: wave totals by shuffles, then lane i < AB_RT finishes ray i (one copy of the epilogue instead of four)
+        double mine = 0.;
+        for (int i = 0; i < AB_RT; i++) {
+            double pt = part[i];
+            for (int off = 32; off > 0; off >>= 1) pt += __shfl_xor(pt, off);
+            if (lane == i) mine = pt;
+        }
+        {
+            const int r = rb + lane;
+            if (lane < AB_RT && r < n_rays) {
+                double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
+                double b = efield_bound(mine * BOUND_RCP_SLACK, st.N, st.fs, cmax);
+                bound[r] = b;
+                max_efield[r] = -b;  // "not evaluated, at most b" until efield_max_kernel overwrites it
             }
         }
         wave_lds_sync();   // (every table behind this point is the wave's own: the waves of a block run apart)
@@ -3738,7 +3715,6 @@ void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const Station
     if (n_rays <= 0) return;
     int grid = (n_rays + 4 * AB_RT - 1) / (4 * AB_RT);
     if (grid > 256 * 32) grid = 256 * 32;
-    if (getenv("NRHIP_AMP_BOUND_ONE_LEVEL")) cut = -1.;   // (A / B: always the 2047-term sum)
     hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, m, vertex, zint, bound, max_efield, cut);
 }
 void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin, int n_ch, const int* slot_offset, int* grp_ray,
