@@ -474,6 +474,12 @@ int nrhip_station_set_phased_array_adc(nrhip_station* st, double adc_sampling_fr
  * envelope sqrt(beam^2 + imag^2); no taps). */
 int nrhip_station_set_phased_array_processing(nrhip_station* st, int32_t upsampling_method, int32_t n_up_taps, const double* up_taps,
                                               int32_t mode, int32_t n_hilbert_taps, const double* hilbert_taps);
+/* clock_offset of the phased-array trigger modules (phasedArrayTrigger.run(..., clock_offset=), phasedArrayTrigger.py:32,124, handed
+ * to analogToDigitalConverter.get_digital_trace :327-340): the channel trace is delayed by clock_offset / adc_sampling_frequency in
+ * front of the digitiser (signal_processing.delay_trace :401-472: phase ramp on the spectrum, the round(delay * sampling rate)
+ * samples -- made even -- that wrapped round cut off).  Whole, non-negative clock cycles; after nrhip_station_set_phased_array_adc
+ * (which resets it to 0). */
+int nrhip_station_set_phased_array_clock_offset(nrhip_station* st, int32_t clock_offset);
 /* `amplitude` of the noise adder per channel [n_channels] (simulation.py:596-600: Vrms / sqrt(norm / max_freq), norm = int |H|^2 df,
  * max_freq = sampling rate / 2; 0 = noiseless channel).  n <= 0 removes them. */
 int nrhip_station_set_noise(nrhip_station* st, int32_t n, const double* amplitude);

@@ -520,6 +520,23 @@ int nrhip_station_set_phased_array_adc(nrhip_station* s, double adc_fs, int32_t 
     return 0;
 }
 
+int nrhip_station_set_phased_array_clock_offset(nrhip_station* s, int32_t clock_offset)
+{
+    if (!s || !s->ctx) return nrhip_fail_msg("nrhip_station_set_phased_array_clock_offset: NULL argument or station without a context");
+    if (!s->pa_adc_set) return nrhip_fail_msg("nrhip_station_set_phased_array_clock_offset: nrhip_station_set_phased_array_adc comes first");
+    if (clock_offset < 0) return nrhip_fail_msg("nrhip_station_set_phased_array_clock_offset: the clock offset must not be negative");
+    // the delayed trace loses round(delay * fs) samples: at most half of the shortest trace there can be
+    if ((clock_offset / s->pa_adc.adc_fs) * s->dev.fs + 2 > s->dev.N / 2)
+        return nrhip_fail_msg("nrhip_station_set_phased_array_clock_offset: the delay is longer than half a trace");
+    if (clock_offset && s->pa_adc.n_bits == 0)
+        return nrhip_fail_msg("nrhip_station_set_phased_array_clock_offset: a clock offset needs the trigger ADC (n_bits > 0)");
+    HIPCHK(hipSetDevice(s->ctx->device));
+    HIPCHK(hipStreamSynchronize(s->ctx->stream));
+    s->pa_adc.clock_offset = clock_offset;
+    s->pa_built.clear();   // the transform tables depend on the trace length behind the delay
+    return 0;
+}
+
 int nrhip_station_set_phased_array_processing(nrhip_station* s, int32_t upsampling_method, int32_t n_up_taps, const double* up_taps,
                                               int32_t mode, int32_t n_hilbert_taps, const double* hilbert_taps)
 {
@@ -1684,7 +1701,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                                                     st->d_pa_rolls_up.as<int>(), st->pa_window, st->pa_step, (double)st->pa_divisor,
                                                     cfg->trigger_threshold, maxL, sd.fs, adc, ctx->twiddle, ctx->w16 + (FFT_MAX / 2 + 1), st->pa_B.as<double2>(), work,
                                                     chunk, pa_trace, pa_len, ev_triggered, pa_max, with_beams, xform_count + 3);
-                } else
+                } else if (adc.clock_offset)
+                    return nrhip_fail_msg("nrhip_simulate_events: the clock offset of the trigger ADC needs the chirp-z digitiser (sampling rate below "
+                                          "5 GHz, an ADC rate other than the simulation's, common traces of at most 7169 samples)");
+                else
                 launch_phased_array_digital(sm, n_cand, d_cand, n_ch, ev.L, co.trace, co.trace_offset, st->pa_n_channels,
                                             st->d_pa_channel.as<int>(), st->pa_n_beams, st->d_pa_rolls_up.as<int>(), st->pa_window,
                                             st->pa_step, (double)st->pa_divisor, cfg->trigger_threshold, maxL, sd.fs, adc, pa_trace, pa_len,

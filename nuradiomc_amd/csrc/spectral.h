@@ -237,12 +237,13 @@ struct PaAdc {
     int up_method = 0, n_up_taps = 0;     // 0 'fft', 1 'lin', 2 'fir' (taps up_taps)
     int mode = 0, n_hil_taps = 0;         // 0 'power_sum', 1 'hilbert_env' (FIR transformer hil_taps)
     const double *up_taps = nullptr, *hil_taps = nullptr;   // device
+    int clock_offset = 0;                 // whole ADC clock cycles the trace is delayed by in front of the digitiser (>= 0)
 };
 // 'lin' / 'fir' up-sampling of ADC traces [n_items][stride_in] (lengths len_in) into pa_trace [n_items][adc.stride]
 void launch_pa_upsample(hipStream_t s, int n_items, const PaAdc& adc, const double* adc_trace, int stride_in, const int* len_in,
                         double* pa_trace, int* pa_len);
 // the chirp-z version of the same chain (O(L log L) transforms; tables per trace length in the station's cache)
-constexpr int PA_TABLES = 8;   // rows of FFT_MAX complex numbers per length slot: 4 Bluestein spectra, 4 chirps
+constexpr int PA_TABLES = 12;  // rows of FFT_MAX complex numbers per length slot: 6 Bluestein spectra, 6 chirps (two of each for the clock offset only)
 bool pa_czt_applies(int max_length, double fs, const PaAdc& adc);
 size_t pa_czt_work_bytes(int max_length, double fs, const PaAdc& adc, int chunk);
 void launch_pa_czt_tables(hipStream_t s, int n_len, const int* lens, const int* slots, double fs, const PaAdc& adc, const double2* tw,

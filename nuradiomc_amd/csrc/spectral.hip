@@ -4486,10 +4486,21 @@ pa_digitize_kernel(int n_cand, const int* __restrict__ item_event, int n_ch, con
 //   stage 5: the up-sampled trace              n_in = n_dig / 2 + 1, Q = n_up,  sgn +, P = FFT_MAX - n_dig / 2  (real part, rounded for counts)
 // Blocks after the first shift the input by exp(sgn 2 pi i j k0 / Q).  Intermediate arrays live in HBM (a few 100 KB per item).
 // ---------------------------------------------------------------------------------------------------------
-struct PaSizes { int L, m, n_dig, n_up; long num2, len5; };
-__device__ __host__ inline PaSizes pa_sizes(int L, double fs, const PaAdc& adc)
+struct PaSizes { int L0, m0, cyc, L, m, n_dig, n_up; long num2, len5; };
+// L0: samples of the channel trace.  With a clock offset (analogToDigitalConverter.py:327-340) the trace is delayed by
+// clock_offset / adc_fs through its spectrum and loses the cyc = round(delay * fs) (made even) samples that wrapped round
+// (signal_processing.delay_trace :401-472): everything behind works on L = L0 - cyc samples.
+__device__ __host__ inline PaSizes pa_sizes(int L0, double fs, const PaAdc& adc)
 {
     PaSizes z;
+    z.L0 = L0;
+    z.m0 = L0 / 2;
+    z.cyc = 0;
+    if (adc.clock_offset) {
+        z.cyc = (int)rint((adc.clock_offset / adc.adc_fs) * fs);
+        if (z.cyc & 1) z.cyc++;
+    }
+    const int L = L0 - z.cyc;
     z.L = L;
     z.m = L / 2;
     long n1 = (adc.p != 1) ? (long)adc.p * L : L;
@@ -4501,13 +4512,17 @@ __device__ __host__ inline PaSizes pa_sizes(int L, double fs, const PaAdc& adc)
     return z;
 }
 // stage -> (n_in, Q, sgn, P, n_out); returns log2 of the convolution length: the smallest power of two that takes the whole
-// transform in one block of outputs (n_in + n_out - 1 points), FFT_MAX with several blocks of P outputs beyond that
+// transform in one block of outputs (n_in + n_out - 1 points), FFT_MAX with several blocks of P outputs beyond that.
+// Stages 6 and 7 (clock offset only, between 1 and 2): the delayed trace's samples cyc .. L0 - 1 from the phase-ramped spectrum
+// (n_in = L0 / 2 + 1, Q = L0, sgn +, output k is sample cyc + k), then the spectrum of those L samples (n_in = L, Q = L, sgn -).
 __device__ __host__ inline int pa_stage(const PaSizes& z, int stage, int* n_in, long* Q, double* sgn, int* P, long* n_out)
 {
-    if (stage == 1) { *n_in = z.L; *Q = z.L; *sgn = -1.; *n_out = z.m + 1; }
+    if (stage == 1) { *n_in = z.L0; *Q = z.L0; *sgn = -1.; *n_out = z.m0 + 1; }
     else if (stage == 2) { *n_in = z.m + 1; *Q = z.num2; *sgn = 1.; *n_out = z.len5; }
     else if (stage == 4) { *n_in = z.n_dig; *Q = z.n_dig; *sgn = -1.; *n_out = z.n_dig / 2 + 1; }
-    else { *n_in = z.n_dig / 2 + 1; *Q = z.n_up; *sgn = 1.; *n_out = z.n_up; }
+    else if (stage == 5) { *n_in = z.n_dig / 2 + 1; *Q = z.n_up; *sgn = 1.; *n_out = z.n_up; }
+    else if (stage == 6) { *n_in = z.m0 + 1; *Q = z.L0; *sgn = 1.; *n_out = z.L; }
+    else { *n_in = z.L; *Q = z.L; *sgn = -1.; *n_out = z.m + 1; }
     int log2m = FFT_LOG2_MAX;
     if (*n_in + *n_out - 1 <= FFT_MAX) {
         log2m = 11;   // (the transform pair of conv_fft.h comes in 2048, 4096 and 8192 points)
@@ -4516,6 +4531,8 @@ __device__ __host__ inline int pa_stage(const PaSizes& z, int stage, int* n_in, 
     *P = (1 << log2m) - *n_in + 1;
     return log2m;
 }
+// table row of a stage's transform: 1, 2, 4, 5, 6, 7 -> 0 .. 5
+__device__ __host__ inline int pa_stage_row(int stage) { return stage < 3 ? stage - 1 : stage - 2; }
 
 struct PaWork {
     double2* X;      // [item][xs]   trace spectra
@@ -4525,8 +4542,8 @@ struct PaWork {
     int xs, s5, sd;
 };
 
-// Tables of the lengths in `lens` (slots of the station's table cache): [slot][PA_TABLES][FFT_MAX] -- rows 0..3 the Bluestein
-// spectra of the four transforms (2^log2m points, natural bin order: conv_mid_plain), rows 4..7 their chirps exp(sgn i pi j^2 / Q), j < 2^log2m (the
+// Tables of the lengths in `lens` (slots of the station's table cache): [slot][PA_TABLES][FFT_MAX] -- rows 0..5 the Bluestein
+// spectra of the transforms (2^log2m points, natural bin order: conv_mid_plain), rows 6..11 their chirps exp(sgn i pi j^2 / Q), j < 2^log2m (the
 // factor of every input and every output sample: two sincospi per point and transform when evaluated in place)
 __global__ void __launch_bounds__(1024)
 pa_tables_kernel(int n_len, const int* __restrict__ lens, const int* __restrict__ slots, double fs, PaAdc adc,
@@ -4534,8 +4551,9 @@ pa_tables_kernel(int n_len, const int* __restrict__ lens, const int* __restrict_
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double2* x = (double2*)smem;
-    const int il = blockIdx.x, st = blockIdx.y;   // stage index 0..3 -> stages 1, 2, 4, 5
+    const int il = blockIdx.x, st = blockIdx.y;   // table row 0..5 -> stages 1, 2, 4, 5, 6, 7
     if (il >= n_len) return;
+    if (st >= 4 && !adc.clock_offset) return;
     const PaSizes z = pa_sizes(lens[il], fs, adc);
     int n_in, P;
     long Q, n_out;
@@ -4544,7 +4562,7 @@ pa_tables_kernel(int n_len, const int* __restrict__ lens, const int* __restrict_
     if (P < 1) return;
     czt_build_table(x, log2m, n_in, P, Q, sgn, tw);
     double2* B = Btab + ((long)slots[il] * PA_TABLES + st) * FFT_MAX;
-    double2* C = B + 4l * FFT_MAX;
+    double2* C = B + (long)(PA_TABLES / 2) * FFT_MAX;
     for (int i = threadIdx.x; i < (1 << log2m); i += blockDim.x) {
         B[bitrev(i, log2m)] = x[i];
         C[i] = chirp(i, Q, sgn);
@@ -4588,20 +4606,23 @@ pa_czt_stage_kernel(int item0, int n_cand, const int* __restrict__ item_event, i
     if (k0 >= n_out) return;
     // FP64 operations of the convolution: transform pair 2 x 5 M log2 M, three complex products per point (bench.py's roofline)
     if (threadIdx.x == 0 && conv_count) atomicAdd(conv_count, (unsigned long long)M * (unsigned long long)(10 * log2m + 18));
-    const int st = stage < 3 ? stage - 1 : stage - 2;
+    const int st = pa_stage_row(stage);
     const double2* B = Btab + ((long)slotmap[L / 2] * PA_TABLES + st) * FFT_MAX;
-    const double2* C = B + 4l * FFT_MAX;
+    const double2* C = B + (long)(PA_TABLES / 2) * FFT_MAX;
     const double* tr = trace + trace_offset[(long)ic * n_ch + pa_channel[c]];
     const double2* Xi = wk.X + (long)wi * wk.xs;
     const double* di = wk.d + (long)wi * wk.sd;
     const double2* Di = wk.D + (long)wi * (wk.sd / 2 + 1);
+    const double* x5i = wk.x5 + (long)wi * wk.s5;
+    const double delay_bins = (adc.clock_offset / adc.adc_fs) * fs;   // the clock offset in samples of the trace
     // the inputs of a thread are 512 apart: with several blocks of outputs their factors exp(sgn 2 pi i j k0 / Q) follow from the
     // first one by a constant rotation (two sincospi per thread instead of one per point; <= 16 steps of the recurrence)
     double2 sh = make_double2(1., 0.), sh_step = sh;
-    if (k0) {
+    const long ks = k0 + (stage == 6 ? z.cyc : 0);   // first output index of this block (stage 6 starts behind the wrapped samples)
+    if (ks) {
         auto turn = [&](long j) {
             double sn, cs;
-            sincospi(2. * (((double)j * (double)k0 < 4.5e15 && Q < (1l << 30)) ? mod_exact((double)j * (double)k0, (double)Q) : (double)(((long long)j * k0) % Q)) / (double)Q, &sn, &cs);
+            sincospi(2. * (((double)j * (double)ks < 4.5e15 && Q < (1l << 30)) ? mod_exact((double)j * (double)ks, (double)Q) : (double)(((long long)j * ks) % Q)) / (double)Q, &sn, &cs);
             return make_double2(cs, sgn * sn);
         };
         sh = turn(threadIdx.x);
@@ -4618,9 +4639,10 @@ pa_czt_stage_kernel(int item0, int n_cand, const int* __restrict__ item_event, i
             double2 v = make_double2(0., 0.), cc = v;
             if (j < n_in) {
                 if (stage == 1) v = make_double2(tr[j], 0.);
-                else if (stage == 2) v = Xi[j];
+                else if (stage == 2 || stage == 6) v = Xi[j];
                 else if (stage == 4) v = make_double2(di[j], 0.);
-                else v = Di[j];
+                else if (stage == 5) v = Di[j];
+                else v = make_double2(x5i[j], 0.);   // stage 7: the delayed samples
                 cc = C[j];
             }
             vin[u] = v;
@@ -4633,8 +4655,13 @@ pa_czt_stage_kernel(int item0, int n_cand, const int* __restrict__ item_event, i
             double2 v = vin[u];
             if (stage == 2) v = cscale(v, ((j == 0 || j == z.m) ? 1. : 2.) / z.L);
             else if (stage == 5) v = cscale(v, ((j == 0 || j == z.n_dig / 2) ? 1. : 2.) / z.n_dig);
+            else if (stage == 6) {   // irfft weights and the delay's phase ramp exp(-2 pi i f_j delay), f_j = j fs / L0
+                double sn, cs;
+                sincospi(-2. * ((double)j * delay_bins / z.L0), &sn, &cs);
+                v = cmul(cscale(v, ((j == 0 || j == z.m0) ? 1. : 2.) / z.L0), make_double2(cs, sn));
+            }
             v = cmul(v, cin[u]);
-            if (k0) { v = cmul(v, sh); sh = cmul(sh, sh_step); }   // outputs k0 .. : in[j] exp(sgn 2 pi i j k0 / Q)
+            if (ks) { v = cmul(v, sh); sh = cmul(sh, sh_step); }   // outputs ks .. : in[j] exp(sgn 2 pi i j ks / Q)
             x[conv_pad(j)] = v;
         }
     }
@@ -4657,8 +4684,8 @@ pa_czt_stage_kernel(int item0, int n_cand, const int* __restrict__ item_event, i
             if (k >= cnt) break;
             // out[k0 + k] = chirp(k) x[k] / M  (the chirp belongs to the shifted problem: index k)
             const double2 o = cscale(cmul(x[conv_pad(k)], cout[u]), inv_m);
-            if (stage == 1) wk.X[(long)wi * wk.xs + k0 + k] = o;
-            else if (stage == 2) wk.x5[(long)wi * wk.s5 + k0 + k] = o.x;
+            if (stage == 1 || stage == 7) wk.X[(long)wi * wk.xs + k0 + k] = o;
+            else if (stage == 2 || stage == 6) wk.x5[(long)wi * wk.s5 + k0 + k] = o.x;
             else if (stage == 4) wk.D[(long)wi * (wk.sd / 2 + 1) + k0 + k] = o;
             else pa_trace[(long)item * adc.stride + k0 + k] = adc.counts ? rint(o.x) : o.x;
         }
@@ -4902,7 +4929,7 @@ bool pa_czt_applies(int max_length, double fs, const PaAdc& adc)
 size_t pa_czt_work_bytes(int max_length, double fs, const PaAdc& adc, int chunk)
 {
     const PaSizes z = pa_sizes(max_length, fs, adc);
-    const size_t xs = z.m + 2, s5 = z.num2 + 2, sd = z.n_dig + 4;
+    const size_t xs = z.m0 + 2, s5 = std::max<long>(z.num2, z.L) + 2, sd = z.n_dig + 4;
     return (size_t)chunk * (xs * 16 + s5 * 8 + sd * 8 + (sd / 2 + 1) * 16) + 256;
 }
 
@@ -4912,7 +4939,7 @@ void launch_pa_czt_tables(hipStream_t s, int n_len, const int* lens, const int* 
     if (n_len <= 0) return;
     set_big_lds();
     (void)hipFuncSetAttribute((const void*)pa_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
-    hipLaunchKernelGGL(pa_tables_kernel, dim3(n_len, 4), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lens, slots, fs, adc, tw, Btab);
+    hipLaunchKernelGGL(pa_tables_kernel, dim3(n_len, PA_TABLES / 2), dim3(1024), (size_t)FFT_MAX * 16, s, n_len, lens, slots, fs, adc, tw, Btab);
 }
 
 void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const int* slotmap,
@@ -4928,9 +4955,11 @@ void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_
     (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_elems(FFT_MAX) * 16);
     (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_elems(FFT_MAX) * 16);
     (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_elems(FFT_MAX) * 16);
+    (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_elems(FFT_MAX) * 16);
+    (void)hipFuncSetAttribute((const void*)pa_czt_stage_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_elems(FFT_MAX) * 16);
     const PaSizes z = pa_sizes(max_length, fs, adc);
     PaWork wk;
-    wk.xs = z.m + 2; wk.s5 = (int)z.num2 + 2; wk.sd = z.n_dig + 4;
+    wk.xs = z.m0 + 2; wk.s5 = (int)std::max<long>(z.num2, z.L) + 2; wk.sd = z.n_dig + 4;
     unsigned char* w = (unsigned char*)work;
     wk.X = (double2*)w;                 w += (size_t)chunk * wk.xs * 16;
     wk.D = (double2*)w;                 w += (size_t)chunk * (wk.sd / 2 + 1) * 16;
@@ -4939,7 +4968,10 @@ void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_
     const int n_items = n_cand * n_pa;
     for (int item0 = 0; item0 < n_items; item0 += chunk) {
         const unsigned nb = (unsigned)std::min(chunk, n_items - item0);
-        for (int stage = 1; stage <= 5; stage++) {
+        const int order_plain[5] = {1, 2, 3, 4, 5}, order_clock[7] = {1, 6, 7, 2, 3, 4, 5};
+        const int n_order = adc.clock_offset ? 7 : 5;
+        for (int io = 0; io < n_order; io++) {
+            const int stage = adc.clock_offset ? order_clock[io] : order_plain[io];
             if (stage == 3) {
                 hipLaunchKernelGGL(pa_adc_sample_kernel, dim3(nb), dim3(256), 0, s, item0, n_cand, item_event, ev_L, n_pa, fs, adc, wk,
                                    pa_trace, pa_len);
@@ -4951,7 +4983,7 @@ void launch_phased_array_digital_czt(hipStream_t s, int n_cand, const int* item_
             const int log2m = pa_stage(z, stage, &n_in, &Q, &sgn, &P, &n_out), M = 1 << log2m;
             const unsigned by = (unsigned)((n_out + P - 1) / P);
             auto kern = stage == 1 ? pa_czt_stage_kernel<1> : stage == 2 ? pa_czt_stage_kernel<2> : stage == 4 ? pa_czt_stage_kernel<4>
-                                                                                                           : pa_czt_stage_kernel<5>;
+                        : stage == 5 ? pa_czt_stage_kernel<5> : stage == 6 ? pa_czt_stage_kernel<6> : pa_czt_stage_kernel<7>;
             hipLaunchKernelGGL(kern, dim3(nb, by), dim3(512), (size_t)conv_lds_elems(M) * 16, s, item0, n_cand, item_event, n_ch, ev_L,
                                slotmap, trace, trace_offset, n_pa, pa_channel, fs, adc, tw, cft, Btab, wk, pa_trace, conv_count);
         }

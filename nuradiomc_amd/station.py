@@ -115,6 +115,7 @@ L._OPTIONAL.update({
     'nrhip_station_set_phased_array_adc': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, ctypes.c_double, ctypes.c_double,
                                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                           L.c_int32_p]),
+    'nrhip_station_set_phased_array_clock_offset': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     'nrhip_station_set_phased_array_processing': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, L.c_double_p,
                                                                  ctypes.c_int32, ctypes.c_int32, L.c_double_p]),
     'nrhip_station_set_phased_array': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_int32_p, ctypes.c_int32, L.c_int32_p,
@@ -435,7 +436,8 @@ class Station:
         """Phased-array trigger on the given channels (a vertical string): beams towards `phasing_angles` [rad], whole-sample
         channel shifts as PhasedArrayBase.calculate_time_delays (phasedArrayBase.py:58-124: antenna depths, ref_index, cable
         delays; no group delays), mean power in windows of `window` samples every `step` (power_sum :217-271).
-        adc = dict(sampling_frequency [GHz], n_bits, noise_count, vrms=<station's>, output='voltage' | 'counts'): the trigger ADC of
+        adc = dict(sampling_frequency [GHz], n_bits, noise_count, vrms=<station's>, output='voltage' | 'counts', clock_offset=0 [whole
+        ADC clock cycles the trace is delayed by in front of the digitiser, phasedArrayTrigger.py:32,124]): the trigger ADC of
         phasedArrayTrigger.run(apply_digitization=True) (trigger_adc_sampling_frequency / trigger_adc_nbits / trigger_adc_noise_count
         of the detector description, Vrms of adc_kwargs) followed by FFT up-sampling by `upsampling_factor`; beams, windows and
         steps then count samples of the up-sampled ADC trace, count sums saturate at `saturation_bits`.  Without `adc` everything
@@ -484,6 +486,11 @@ class Station:
             L.check(self._lib.nrhip_station_set_phased_array_adc(self._h, f_adc, n_bits, -half, half,
                                                                  int(adc.get('output', 'voltage') == 'counts'), up, int(saturation_bits),
                                                                  fr.numerator, fr.denominator, L.iptr(rolls)))
+            clk = adc.get('clock_offset', 0)
+            if clk:
+                if clk - int(clk) != 0:   # analogToDigitalConverter.py:328-329
+                    raise ValueError("The clock offset must be an integer number of clock cycles")
+                L.check(self._lib.nrhip_station_set_phased_array_clock_offset(self._h, int(clk)))
             up_taps = hil_taps = None
             ideal = False
             if upsampling_method == 'fir' and up >= 2:    # upsampling_fir :224-230

@@ -676,14 +676,34 @@ def phased_array_power(V, rolls, window, step, averaging_divisor=None):
     return np.array(out)
 
 
-def adc_digital_trace(x, fs, adc_fs, n_bits, vrms, noise_count, output='voltage'):
+def delay_trace_cropped(x, fs, time_delay):
+    """signal_processing.delay_trace (:401-472) with crop_trace=True: the trace delayed by a phase ramp on its spectrum (cyclic), the
+    samples that wrapped round -- round(delay * fs) of them, one more if that is odd -- cut off its front (delay > 0) or back"""
+    x = np.asarray(x, float)
+    if not time_delay:
+        return x
+    n = len(x)
+    spec = np.fft.rfft(x) * np.exp(-2j * np.pi * np.fft.rfftfreq(n, 1. / fs) * time_delay)
+    y = np.fft.irfft(spec, n)
+    cycled = int(round(time_delay * fs))
+    if cycled % 2:
+        cycled += 1
+    return y[cycled:] if time_delay >= 0 else y[:-cycled]
+
+
+def adc_digital_trace(x, fs, adc_fs, n_bits, vrms, noise_count, output='voltage', clock_offset=0):
     """analogToDigitalConverter.get_digital_trace (analogToDigitalConverter.py:254-373) with trigger_adc=True, Vrms given, the perfect
     floor comparator: resampling to 5 GHz (signal_processing.resample :71-108), linear-interpolation down-sampling to the ADC rate
     (:432-463), floor((V - V_min) / lsb) clipped to the ADC's counts (:14-110) with the range +- Vrms (2^n - 1) / (2 noise_count)
-    (_get_adc_parameters :173-252), an even number of samples"""
+    (_get_adc_parameters :173-252), an even number of samples.  clock_offset: whole ADC clock cycles the trace is delayed by in
+    front of the digitiser (:327-340; the clock_offset of the phased-array trigger modules, phasedArrayTrigger.py:32,124)"""
     import fractions
     import decimal
     x = np.asarray(x, float)
+    if clock_offset:
+        if clock_offset - int(clock_offset) != 0:
+            raise ValueError("The clock offset must be an integer number of clock cycles")
+        x = delay_trace_cropped(x, fs, clock_offset / adc_fs)
     half = vrms * (2 ** n_bits - 1) / noise_count / 2
     vmin, vmax = -half, half
     if not np.allclose(adc_fs, fs):

@@ -1917,13 +1917,15 @@ def test_thermal_noise(gpu_ctx_factory):
         st.simulate_events(*args, noise=True)
 
 
-@pytest.mark.parametrize('output,up', [('counts', 4), ('voltage', 2), ('counts', 1)])
-def test_phased_array_with_trigger_adc(gpu_ctx_factory, output, up):
+@pytest.mark.parametrize('output,up,clk', [('counts', 4, 0), ('voltage', 2, 0), ('counts', 1, 0), ('counts', 4, 3), ('voltage', 2, 1),
+                                           ('counts', 1, 12)])
+def test_phased_array_with_trigger_adc(gpu_ctx_factory, output, up, clk):
     """phasedArrayTrigger with apply_digitization and FFT up-sampling inside simulate_events: per array channel of every candidate
     event the trigger ADC (5 GHz resampling, linear down-sampling to 472 MHz, floor comparator) and the up-sampling, then beams with
     saturation and rounded window powers.  GPU vs the oracle's restatement (pinned sample by sample on the reference's own functions,
     test_phased_array_adc_vs_reference) applied to the channel traces the GPU dumped: digitised traces equal (counts: every sample;
-    volts: 1e-9 lsb), per-beam maximum powers and decisions equal."""
+    volts: 1e-9 lsb), per-beam maximum powers and decisions equal.  clk: the trigger modules' clock_offset (the traces delayed by
+    whole ADC clock cycles in front of the digitiser; oracle pinned by test_trigger_adc_clock_offset_vs_reference)."""
     ice = (1.78, 0.423, 77.)
     pos = np.array([[0., 0., -96.], [0., 0., -97.], [0., 0., -98.], [0., 0., -99.], [0., 0., -60.], [20., 15., -95.]])
     cable = np.array([1.2, 0., 2.6, 0.7, 0., 3.])
@@ -1933,7 +1935,7 @@ def test_phased_array_with_trigger_adc(gpu_ctx_factory, output, up):
     angles = np.arcsin(np.linspace(np.sin(-60 * np.pi / 180), np.sin(60 * np.pi / 180), 11))
     window, step, adc_fs, nbits, ncount = 24, 8, 0.472, 8, 5
     rolls = st.set_phased_array([0, 1, 2, 3], angles, ref_index=1.75, window=window, step=step, upsampling_factor=up,
-                                adc=dict(sampling_frequency=adc_fs, n_bits=nbits, noise_count=ncount, output=output))
+                                adc=dict(sampling_frequency=adc_fs, n_bits=nbits, noise_count=ncount, output=output, clock_offset=clk))
     assert np.array_equal(rolls, so.phased_array_rolls(pos[:4, 2], cable[:4], angles, adc_fs * up, 1.75))
     lsb = vrms / ncount
     threshold = 2.5 * (2 * (vrms / lsb if output == 'counts' else vrms)) ** 2
@@ -1953,7 +1955,8 @@ def test_phased_array_with_trigger_adc(gpu_ctx_factory, output, up):
     n_trig = 0
     for i, e in enumerate(item_event):
         V = np.array([tr[off[i * n_ch + c]:off[i * n_ch + c + 1]] for c in range(4)])
-        U = np.array([so.digital_upsampling_fft(so.adc_digital_trace(x, 2.0, adc_fs, nbits, vrms, ncount, output), up) for x in V])
+        U = np.array([so.digital_upsampling_fft(so.adc_digital_trace(x, 2.0, adc_fs, nbits, vrms, ncount, output, clock_offset=clk), up)
+                      for x in V])
         assert np.all(dlen[i] == U.shape[1])
         got = dig[i, :, :U.shape[1]]
         assert np.max(np.abs(got - U)) <= (0 if output == 'counts' else 1e-9 * lsb), e
@@ -1968,6 +1971,18 @@ def test_phased_array_with_trigger_adc(gpu_ctx_factory, output, up):
     assert np.array_equal(trig_p, trig)
     # the direct-sum digitiser (what traces beyond the chirp-z version's 7169 samples or without the 5 GHz step go through)
     import os
+    if clk:   # (the clock offset is part of the chirp-z digitiser only: refused there, by name)
+        os.environ['NRHIP_PA_DIRECT'] = '1'
+        try:
+            with pytest.raises(Exception, match='clock offset'):
+                st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold)
+        finally:
+            del os.environ['NRHIP_PA_DIRECT']
+        with pytest.raises(ValueError, match='integer number of clock cycles'):
+            st.set_phased_array([0, 1, 2, 3], angles, adc=dict(sampling_frequency=adc_fs, n_bits=nbits, noise_count=ncount, clock_offset=1.5))
+        with pytest.raises(Exception, match='negative'):
+            st.set_phased_array([0, 1, 2, 3], angles, adc=dict(sampling_frequency=adc_fs, n_bits=nbits, noise_count=ncount, clock_offset=-2))
+        return
     os.environ['NRHIP_PA_DIRECT'] = '1'
     try:
         trig_d, _ = st.simulate_events(v, zen, az, en, 'HAD', trigger='phased_array', trigger_threshold=threshold, dump_traces=True)

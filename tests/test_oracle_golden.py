@@ -440,6 +440,29 @@ def test_phased_array_adc_vs_reference():
             assert p.shape == ref.shape and np.max(np.abs(p - ref)) <= 1e-9 * np.max(ref), (k, e)
 
 
+def test_trigger_adc_clock_offset_vs_reference():
+    """clock_offset of the trigger ADC (analogToDigitalConverter.py:327-340, handed through by the phased-array trigger modules): the
+    oracle's delay + crop, ADC trace and up-sampled trace against the reference's own functions (tests/golden/gen/gen_pa_clock.py)."""
+    from oracle import spectral_oracle as so
+    g = golden('ref_pa_clock.npz')
+    for k, c in enumerate(g['cases']):
+        n_samples, fs, adc_fs, nbits, ncount, up, clk = int(c[0]), c[1], c[2], int(c[3]), int(c[4]), int(c[5]), int(c[6])
+        output, vrms = str(g['output_%d' % k]), float(g['vrms_%d' % k])
+        lsb = vrms * (2 ** nbits - 1) / ncount / (2 ** nbits - 1)
+        for e, x in enumerate(g['traces_%d' % k]):
+            y = so.delay_trace_cropped(x, fs, clk / adc_fs)
+            ref = g['delayed_%d' % k][e]
+            assert y.shape == ref.shape and np.max(np.abs(y - ref)) <= 1e-12 * np.max(np.abs(ref)), (k, e)
+            d = so.adc_digital_trace(x, fs, adc_fs, nbits, vrms, ncount, output, clock_offset=clk)
+            ref = g['digital_%d' % k][e]
+            assert d.shape == ref.shape and np.max(np.abs(d - ref)) <= (1e-9 * lsb if output == 'voltage' else 0), (k, e)
+            u = so.digital_upsampling_fft(d, up)
+            ref = g['upsampled_%d' % k][e]
+            assert u.shape == ref.shape and np.max(np.abs(u - ref)) <= (1e-9 * lsb if output == 'voltage' else 0), (k, e)
+    with pytest.raises(ValueError):
+        so.adc_digital_trace(g['traces_0'][0], 2.0, 0.472, 8, 1e-5, 5, 'counts', clock_offset=1.5)
+
+
 def test_phased_array_modes_vs_reference():
     """The other up-sampling methods ('lin', 'fir' with rounded coefficients) and the FIR Hilbert envelope of the phased-array
     trigger: oracle vs the reference's own digital_upsampling / hilbert_envelope (tests/golden/gen/gen_pa_modes.py) -- ADC counts
