@@ -119,33 +119,62 @@ def write_hdf5(h5py, path, datasets, attrs):
             obj.attrs[name] = v.tolist() if (v.dtype.kind == 'U' and v.ndim) else (str(v[()]) if v.dtype.kind == 'U' else v)
 
 
-def _hilbert_envelope(x):
-    """|scipy.signal.hilbert(x)| along the last axis (trace_utilities.get_hilbert_envelope).  With scipy at hand its FFT runs the rows
-    on all cores (the windows of all triggered events go through in one call: numpy's transform, one row after the other on one
-    core, was 40 % of the end-to-end time of a 1e6-event list)."""
+def _hilbert_envelope(x, workers=None):
+    """|scipy.signal.hilbert(x)| along the last axis (trace_utilities.get_hilbert_envelope).  The analytic signal of a real trace is
+    x + i y with y = irfft(-i X_k, 0 < k < n / 2) -- two real transforms instead of the two complex ones of scipy.signal.hilbert, and
+    real arrays in between."""
     n = x.shape[-1]
     try:
-        import os
         from scipy import fft as _fft
-        kw = dict(workers=max(1, min(16, len(os.sched_getaffinity(0)))))
+        kw = dict(workers=workers or 1)
     except ImportError:   # numpy only
         _fft, kw = np.fft, {}
-    X = _fft.fft(x, axis=-1, **kw)
-    h = np.zeros(n)
+    X = _fft.rfft(x, axis=-1, **kw)
+    X *= -1j
+    X[..., 0] = 0.
     if n % 2 == 0:
-        h[0] = h[n // 2] = 1
-        h[1:n // 2] = 2
+        X[..., n // 2] = 0.
+    y = _fft.irfft(X, n, axis=-1, **kw)
+    y *= y
+    y += x * x
+    return np.sqrt(y, out=y)
+
+
+def _window_maxima(windows, step=64):
+    """maximum |V| and maximum Hilbert envelope per (event, channel) of a list of equally shaped read-out windows [n_channels,
+    n_samples]: chunks of `step` events on a pool of threads (numpy's element-wise passes and pocketfft release the GIL; one thread
+    after the other, these passes over ~1.5 GB of windows were 40 % of the end-to-end time of a 1e6-event list)"""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(windows)
+    amp = np.empty((n,) + windows[0].shape[:-1])
+    env = np.empty_like(amp)
+
+    def work(a0):
+        Wb = np.array(windows[a0:a0 + step])
+        np.max(np.abs(Wb), axis=-1, out=amp[a0:a0 + step])
+        np.max(_hilbert_envelope(Wb), axis=-1, out=env[a0:a0 + step])
+    starts = list(range(0, n, step))
+    n_thr = max(1, min(16, len(os.sched_getaffinity(0)), len(starts)))
+    if n_thr == 1:
+        for a0 in starts:
+            work(a0)
     else:
-        h[0] = 1
-        h[1:(n + 1) // 2] = 2
-    return np.abs(_fft.ifft(X * h, axis=-1, **kw))
+        with ThreadPoolExecutor(n_thr) as pool:
+            list(pool.map(work, starts))
+    return amp, env
 
 
 def _readout_window(V, trigger_bin, n_window, pre_bins):
     """channelReadoutWindowCutter.run (:28-137): the trace rolled so that the window starts pre_trigger_time before the trigger
     (whole samples here: roll; apply_time_shift on a whole number of samples is np.roll, base_trace.py:262-266), first n_window
-    samples"""
-    return np.roll(V, -(trigger_bin - pre_bins), axis=-1)[..., :n_window]
+    samples -- np.roll(V, -(trigger_bin - pre_bins), axis=-1)[..., :n_window] without the rolled copy of the whole trace"""
+    L_ = V.shape[-1]
+    n = min(n_window, L_)
+    s0 = (trigger_bin - pre_bins) % L_
+    if s0 + n <= L_:
+        return V[..., s0:s0 + n]
+    return np.concatenate([V[..., s0:], V[..., :s0 + n - L_]], axis=-1)
 
 
 def simulate_to_output(det, events, config=None, station_ids=None, trigger_name='simple_threshold', seed=None,
@@ -206,14 +235,14 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
 
         def collect(i, sl, s_, keep):
             idx = np.arange(len(sub_first)) if keep is None else np.asarray(keep)
-            T = {k: s_.fetch(k).copy() for k in ('pair_n_sol', 'slot_type', 'slot_C0', 'slot_C1', 'slot_D', 'slot_T', 'slot_launch',
+            T = {k: s_.fetch(k) for k in ('pair_n_sol', 'slot_type', 'slot_C0', 'slot_C1', 'slot_D', 'slot_T', 'slot_launch',
                                                  'slot_keep', 'ray_slot', 'ray_zenith', 'ray_azimuth', 'ray_pol_theta',
                                                  'ray_pol_phi', 'ev_candidate', 'ev_L', 'ev_t_min', 'ev_n_rays')}
             if T['ev_candidate'].any():
-                T.update({k: s_.fetch(k).copy() for k in ('item_event', 'trace', 'trace_offset')})
+                T.update({k: s_.fetch(k) for k in ('item_event', 'trace', 'trace_offset')})   # (fetch returns a fresh array)
                 for k in ('ray_max_amp_envelope', 'ray_signal_time'):
                     try:
-                        T[k] = s_.fetch(k).copy()
+                        T[k] = s_.fetch(k)
                     except L.NrhipError:
                         pass
             T['groups'] = idx
@@ -235,93 +264,101 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
     top_showers = {}    # original shower row -> dict(triggered, trigger_time)
     for i in range(n_st):
         sname = 'station_%d' % station_ids[i]
-        ev_rows, sh_rows, ev_windows = [], [], []
+        ev_rows, sh_blocks, ev_windows = [], [], []
         for T in tables[i]:
-            n_sub_groups = len(sub_first)
             pos_of = {int(e): k for k, e in enumerate(T.get('item_event', []))}
             # showers of the (possibly culled) list the station ran on
             lst = np.concatenate([np.arange(sub_gb[g], sub_gb[g + 1]) for g in T['groups']]) if len(T['groups']) else np.zeros(0, int)
             local_gb = np.concatenate([[0], np.cumsum([sub_gb[g + 1] - sub_gb[g] for g in T['groups']])]).astype(int)
             keep = T['slot_keep'][:len(lst) * n_ch * nS].reshape(len(lst), n_ch, nS).astype(bool)
+            keep_any = keep.reshape(len(lst), -1).any(axis=1)
             ray_of_slot = np.full(len(lst) * n_ch * nS, -1)
             ray_of_slot[T['ray_slot']] = np.arange(len(T['ray_slot']))
             ray_of_slot = ray_of_slot.reshape(len(lst), n_ch, nS)
+            sel_j, sel_t = [], []   # local shower index and trigger time of every stored shower row
             for k, g in enumerate(T['groups']):
                 g_orig = sim_group_ids[sel_g][g]
                 if not st_trig[i, sel_g[g]]:
                     continue
                 it = pos_of[k]
                 L_ = int(T['ev_L'][k])
-                V = np.array([T['trace'][T['trace_offset'][it * n_ch + c]:T['trace_offset'][it * n_ch + c + 1]] for c in range(n_ch)])
-                hit = np.flatnonzero(np.any(np.abs(V[:, :L_ - 1]) >= threshold, axis=0))   # get_majority_logic drops the last sample
-                tbin = int(hit[0])
+                o0 = int(T['trace_offset'][it * n_ch])
+                if int(T['trace_offset'][it * n_ch + n_ch]) - o0 == n_ch * L_:   # the channels of an item lie one behind the other
+                    V = T['trace'][o0:o0 + n_ch * L_].reshape(n_ch, L_)
+                else:
+                    V = np.array([T['trace'][T['trace_offset'][it * n_ch + c]:T['trace_offset'][it * n_ch + c + 1]] for c in range(n_ch)])
+                hit = np.any(np.abs(V[:, :L_ - 1]) >= threshold, axis=0)   # get_majority_logic drops the last sample
+                tbin = int(np.argmax(hit))
                 t_trig = tbin * dt + T['ev_t_min'][k]
-                W = _readout_window(V, tbin, n_window, pre_bins)
-                ev_windows.append(W)   # (the Hilbert envelopes of all windows are formed in one call after the loop)
-                ev_rows.append(dict(event_group_ids=gid[first[g_orig]], event_ids=0, maximum_amplitudes=np.max(np.abs(W), axis=1),
+                ev_windows.append(_readout_window(V, tbin, n_window, pre_bins))   # (maxima and Hilbert envelopes: one call after the loop)
+                ev_rows.append(dict(event_group_ids=gid[first[g_orig]], event_ids=0, maximum_amplitudes=None,
                                     maximum_amplitudes_envelope=None,
                                     multiple_triggers_per_event=np.array([True]), trigger_times_per_event=np.array([t_trig]),
                                     triggered_per_event=True))
-                for j in range(local_gb[k], local_gb[k + 1]):
-                    if not keep[j].any():
-                        continue      # a shower without any efield on this station is not part of the station's event (:983-1001)
-                    row = rows[sub[lst[j]]]
-                    r = dict(shower_id=d['shower_ids'][row], event_group_id_per_shower=gid[row], event_id_per_shower=d['shower_ids'][row],
-                             triggered=True, multiple_triggers=np.array([True]), trigger_times=np.array([t_trig]))
-                    # the (channel, solution) tables of the shower, all slots at once (NaN where no ray was kept)
-                    kj = keep[j]
-                    q = j * n_ch * nS + np.arange(n_ch * nS).reshape(n_ch, nS)
-                    ir = np.where(kj, ray_of_slot[j], 0)
-                    nan2 = np.full((n_ch, nS), np.nan)
-
-                    def tab2(values):
-                        return np.where(kj, values, nan2)
-                    r['travel_times'], r['travel_distances'] = tab2(T['slot_T'][q]), tab2(T['slot_D'][q])
-                    r['ray_tracing_C0'], r['ray_tracing_C1'] = tab2(T['slot_C0'][q]), tab2(T['slot_C1'][q])
-                    r['ray_tracing_solution_type'] = tab2(T['slot_type'][q].astype(float))
-                    r['ray_tracing_reflection'], r['ray_tracing_reflection_case'] = tab2(0.), tab2(1.)
-                    r['focusing_factor'] = tab2(1.)
-                    k3 = kj[:, :, None]
-                    nan3 = np.full((n_ch, nS, 3), np.nan)
-                    r['launch_vectors'] = np.where(k3, T['slot_launch'][(3 * q)[:, :, None] + np.arange(3)], nan3)
-                    zen, az = T['ray_zenith'][ir], T['ray_azimuth'][ir]
-                    ct, st_, cp, sp = np.cos(zen), np.sin(zen), np.cos(az), np.sin(az)
-                    r['receive_vectors'] = np.where(k3, np.stack([st_ * cp, st_ * sp, ct], axis=-1), nan3)
-                    # polarisation angle on sky -> unit vector in the ground frame (output_writer_hdf5.py:289-297)
-                    a = np.arctan2(T['ray_pol_phi'][ir], T['ray_pol_theta'][ir])
-                    e_t, e_p = np.stack([ct * cp, ct * sp, -st_], axis=-1), np.stack([-sp, cp, np.zeros_like(sp)], axis=-1)
-                    r['polarization'] = np.where(k3, np.cos(a)[:, :, None] * e_t + np.sin(a)[:, :, None] * e_p, nan3)
-                    if 'ray_max_amp_envelope' in T:
-                        r['max_amp_shower_and_ray'] = tab2(T['ray_max_amp_envelope'][ir])
-                        r['time_shower_and_ray'] = tab2(T['ray_signal_time'][ir])
-                    else:
-                        r['max_amp_shower_and_ray'], r['time_shower_and_ray'] = nan2.copy(), nan2.copy()
-                    sh_rows.append(r)
+                js = np.arange(local_gb[k], local_gb[k + 1])
+                js = js[keep_any[js]]   # a shower without any efield on this station is not part of the station's event (:983-1001)
+                sel_j.append(js)
+                sel_t.append(np.full(len(js), t_trig))
+                for row in rows[sub[lst[js]]].tolist():
                     e = top_showers.setdefault(int(row), dict(triggered=False, t=np.nan))
                     e['triggered'] = True
                     e['t'] = t_trig if np.isnan(e['t']) else min(e['t'], t_trig)
                 # the primary of a triggered group is stored even without a signal of its own (:392-430)
                 top_showers.setdefault(int(first[g_orig]), dict(triggered=False, t=np.nan, primary_only=True))
+            if not sel_j:
+                continue
+            # the (channel, solution) tables of all stored showers of this call at once (NaN where no ray was kept)
+            J = np.concatenate(sel_j)
+            tt = np.concatenate(sel_t)
+            if len(J) == 0:
+                continue
+            row = rows[sub[lst[J]]]
+            kj = keep[J]
+            q = (J * (n_ch * nS))[:, None, None] + np.arange(n_ch * nS).reshape(n_ch, nS)
+            ir = np.where(kj, ray_of_slot[J], 0)
+            k3 = kj[:, :, :, None]
+
+            def tab2(values):
+                return np.where(kj, values, np.nan)
+            blk = dict(shower_id=d['shower_ids'][row], event_group_id_per_shower=gid[row], event_id_per_shower=d['shower_ids'][row],
+                       triggered=np.ones(len(J), bool), multiple_triggers=np.ones((len(J), 1), bool), trigger_times=tt[:, None])
+            blk['travel_times'], blk['travel_distances'] = tab2(T['slot_T'][q]), tab2(T['slot_D'][q])
+            blk['ray_tracing_C0'], blk['ray_tracing_C1'] = tab2(T['slot_C0'][q]), tab2(T['slot_C1'][q])
+            blk['ray_tracing_solution_type'] = tab2(T['slot_type'][q].astype(float))
+            blk['ray_tracing_reflection'], blk['ray_tracing_reflection_case'] = tab2(0.), tab2(1.)
+            blk['focusing_factor'] = tab2(1.)
+            blk['launch_vectors'] = np.where(k3, T['slot_launch'][(3 * q)[:, :, :, None] + np.arange(3)], np.nan)
+            zen, az = T['ray_zenith'][ir], T['ray_azimuth'][ir]
+            ct, st_, cp, sp = np.cos(zen), np.sin(zen), np.cos(az), np.sin(az)
+            blk['receive_vectors'] = np.where(k3, np.stack([st_ * cp, st_ * sp, ct], axis=-1), np.nan)
+            # polarisation angle on sky -> unit vector in the ground frame (output_writer_hdf5.py:289-297)
+            a = np.arctan2(T['ray_pol_phi'][ir], T['ray_pol_theta'][ir])
+            e_t, e_p = np.stack([ct * cp, ct * sp, -st_], axis=-1), np.stack([-sp, cp, np.zeros_like(sp)], axis=-1)
+            blk['polarization'] = np.where(k3, np.cos(a)[..., None] * e_t + np.sin(a)[..., None] * e_p, np.nan)
+            if 'ray_max_amp_envelope' in T:
+                blk['max_amp_shower_and_ray'] = tab2(T['ray_max_amp_envelope'][ir])
+                blk['time_shower_and_ray'] = tab2(T['ray_signal_time'][ir])
+            else:
+                blk['max_amp_shower_and_ray'], blk['time_shower_and_ray'] = tab2(np.nan), tab2(np.nan)
+            sh_blocks.append(blk)
         if ev_rows:
-            step = 2048   # events per call: ~0.3 GB of complex windows at 5 channels x 4096 samples
             by_len = {}
             for k_, W_ in enumerate(ev_windows):   # (a common trace shorter than the read-out window keeps its own length)
                 by_len.setdefault(W_.shape, []).append(k_)
             for idx in by_len.values():
-                for a0 in range(0, len(idx), step):
-                    part = idx[a0:a0 + step]
-                    env = np.max(_hilbert_envelope(np.array([ev_windows[k_] for k_ in part])), axis=-1)
-                    for q_, k_ in enumerate(part):
-                        ev_rows[k_]['maximum_amplitudes_envelope'] = env[q_]
-        if sh_rows:
-            order = np.argsort(np.array([r['shower_id'] for r in sh_rows]), kind='stable')
-            for key in sh_rows[0]:
-                out.datasets['%s/%s' % (sname, key)] = np.array([sh_rows[k][key] for k in order])
+                amp, env = _window_maxima([ev_windows[k_] for k_ in idx])
+                for q_, k_ in enumerate(idx):
+                    ev_rows[k_]['maximum_amplitudes'] = amp[q_]
+                    ev_rows[k_]['maximum_amplitudes_envelope'] = env[q_]
+        if sh_blocks:
+            order = np.argsort(np.concatenate([b_['shower_id'] for b_ in sh_blocks]), kind='stable')
+            for key in sh_blocks[0]:
+                out.datasets['%s/%s' % (sname, key)] = np.concatenate([b_[key] for b_ in sh_blocks])[order]
             for key in ev_rows[0]:
                 out.datasets['%s/%s' % (sname, key)] = np.array([r[key] for r in ev_rows])
         vr = np.array([st.vrms_per_set[st.channel_filter_set[c]][0] for c in range(n_ch)])
         out.attrs[(sname, 'antenna_positions')] = arr.relative_position + arr.centres[i]
-        if sh_rows:
+        if sh_blocks:
             out.attrs[(sname, 'Vrms')] = vr
             out.attrs[(sname, 'bandwidth')] = np.array([_bandwidth(st, c) for c in range(n_ch)])
             out.attrs[(sname, 'Vrms_trigger')] = np.zeros(0)

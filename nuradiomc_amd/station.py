@@ -866,7 +866,7 @@ class Station:
         if n < 0:
             raise L.NrhipError(self._lib.nrhip_last_error().decode())
         dt = np.dtype(self._FETCH_DTYPES.get(name, np.float64))
-        raw = np.zeros(n, np.uint8)
+        raw = np.empty(n, np.uint8)   # (filled by the copy below: no zeroing pass over what may be gigabytes of traces)
         if n:
             self._lib.nrhip_sim_fetch(self._h, name.encode(), raw.ctypes.data_as(ctypes.c_void_p), n)
         return raw[:(n // dt.itemsize) * dt.itemsize].view(dt)
