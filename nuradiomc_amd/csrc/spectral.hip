@@ -845,11 +845,15 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, c
 #define NRHIP_ATT_BOUND_MARGIN 0.95
 #endif
 #define AB_RT 4  // rays per wave and pass: the frequency-grid tables are loaded once for AB_RT rays
-__global__ void __launch_bounds__(256, 3)
+#define AB_G 4   // bins per group of the two-sided sums
+#define AB_RUN 8 // groups per lane at most (N / 2 <= 2048; longer traces take the plain sums)
+#ifndef NRHIP_AB_WAVES
+#define NRHIP_AB_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, NRHIP_AB_WAVES)
 amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double* __restrict__ vertex,
                  const double* __restrict__ zint, double* __restrict__ bound, double* __restrict__ max_efield, double cut)
 {
-    (void)cut;
     typedef float f2 __attribute__((ext_vector_type(2)));
     static_assert(AB_RT == 4, "two packed pairs of rays");
     __shared__ float4 blen[4][64];      // per wave and depth bin: path length of the tile's four rays inside the bin
@@ -865,12 +869,26 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
     __shared__ double s_xp[NRHIP_MAX_NFC];
     __shared__ float s_xp_f[NRHIP_MAX_NFC];
     for (int j = threadIdx.x; j < st.n_fc; j += blockDim.x) { s_xp[j] = st.fcoarse[j]; s_xp_f[j] = (float)st.fcoarse[j]; }
-    __syncthreads();  // s_binv / s_xp are filled by all four waves and read by each of them in the first pass
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nh = st.N / 2, stride = nh + 1;
+    // the station's frequency tables at the nodes of the two-sided sums (bin 1 + AB_G j): (segment, f^p hadronic, f^p electromagnetic,
+    // f^q) per node, a lane's run of nodes and the first node of the next lane's run side by side (AB_RUN + 1 entries per lane: a
+    // stride of 36 words between the lanes, no bank conflicts)
+    __shared__ float4 s_node[64 * (AB_RUN + 1)];
+    const int n_nodes = (nh - 1 + AB_G - 1) / AB_G, run = (n_nodes + 63) / 64;
+    if (run <= AB_RUN)
+        for (int q = threadIdx.x; q < 64 * (AB_RUN + 1); q += blockDim.x) {
+            const int j = min(run * (q / (AB_RUN + 1)) + q % (AB_RUN + 1), n_nodes - 1), k = 1 + AB_G * j;
+            s_node[q] = make_float4(__int_as_float(st.seg[k]), st.fpow_f[k], st.fpow_f[stride + k], st.fpow_f[2 * stride + k]);
+        }
+    __syncthreads();  // s_binv / s_xp / s_node are filled by all four waves and read by each of them in the first pass
     const double df = 1.0 / (st.N * (1. / st.fs));
     const int per_pass = gridDim.x * 4 * AB_RT;
     const int n_iter = (n_rays + per_pass - 1) / per_pass;
+    // Two-sided sums over groups of AB_G bins (see below): only where a group holds at most one coarse frequency and the candidate
+    // cut is there to compare with
+    bool grouped = cut >= 0. && nh >= 16 * AB_G && run <= AB_RUN;
+    for (int j = 0; j + 1 < st.n_fc; j++) grouped = grouped && (s_xp[j + 1] - s_xp[j]) > (AB_G + 1) * df;
     for (int it = 0; it < n_iter; it++) {
         const int rb = ((it * gridDim.x + blockIdx.x) * 4 + wv) * AB_RT;
         if (rb >= n_rays) continue;   // (wave-uniform; the tables below are the wave's own)
@@ -985,6 +1003,113 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
         double part[AB_RT];
         for (int i = 0; i < AB_RT; i++) part[i] = 0.;
         const double x_first = s_xp[0], x_last = s_xp[st.n_fc - 1], dx_last = x_last - s_xp[st.n_fc - 2];
+        // Two-sided sums first (round 4).  The summand is pf f r(f) U(f) with r = 1 / ((1 + cL f^p)(1 + cR f^q)) falling in f (the
+        // f^p tables rise) and U the piecewise-linear attenuation bound, so the bins k_j .. k_j + n - 1 of a group (k_j = 1 + AB_G j)
+        // add up to between n pf f(k_j) r(k_{j+1}) U_min and n pf f(k_j + n - 1) r(k_j) U_max, U_min / U_max over the two nodes and the
+        // coarse frequency between them, if any: ONE evaluation per group of AB_G bins.  The bound is only ever COMPARED with the
+        // candidate cut (event_possible_kernel): unless a ray of the tile has the cut between its two sums (a few per cent of the
+        // tiles; the 2047-term sum below decides those) the comparison is made with the upper sum -- the same flags, the value
+        // stored still an upper bound.
+        bool decided = false;
+        if (f32 && grouped) {
+            f2 cL2[2], cR2[2], pf2[2], hm2[2], up2[2], lo2[2];
+            for (int j = 0; j < 2; j++) {
+                cL2[j] = f2{(float)cL[2 * j], (float)cL[2 * j + 1]};
+                cR2[j] = f2{(float)cR[2 * j], (float)cR[2 * j + 1]};
+                pf2[j] = f2{(float)pf[2 * j], (float)pf[2 * j + 1]};
+                hm2[j] = f2{had[2 * j] ? 1.f : 0.f, had[2 * j + 1] ? 1.f : 0.f};
+                up2[j] = lo2[j] = f2{0.f, 0.f};
+            }
+            const f2 one2 = f2{1.f, 1.f};
+            const float xf_first = (float)x_first, xf_last = (float)x_last, dxf_last = (float)dx_last, dff = (float)df;
+            // a lane owns a run of consecutive nodes (and evaluates the first node of the next lane's run itself): no exchange between lanes
+            const int j0 = run * lane;
+            struct Node { f2 r[2], U[2]; int lo; };
+            auto eval = [&](int j) {   // node j at bin 1 + AB_G j: r and U of the four rays, the (clamped) segment; zeros behind the last node
+                Node o;
+                const int k = 1 + AB_G * min(j, n_nodes - 1);
+                const float f = k * dff;
+                const float4 nd = s_node[lane * (AB_RUN + 1) + (j - j0)];
+                int lo = __float_as_int(nd.x);
+                const float ph = nd.y, pe = nd.z, pr = nd.w;
+                float dx = f - s_xp_f[lo];
+                if (f <= xf_first) { lo = 0; dx = 0.f; }
+                if (f >= xf_last) { lo = st.n_fc - 2; dx = dxf_last; }
+                dx = fmaxf(dx, 0.f);
+                const float dp = ph - pe;
+                const float4 sl4 = slf[wv][lo], u4 = ubf[wv][lo];
+                const float live = j < n_nodes ? 1.f : 0.f;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const f2 psel = hm2[q] * dp + pe;
+                    const f2 den = (one2 + psel * cL2[q]) * (one2 + pr * cR2[q]);
+                    o.r[q] = f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)} * live;
+                    const f2 sl = q ? f2{sl4.z, sl4.w} : f2{sl4.x, sl4.y};
+                    const f2 u0 = q ? f2{u4.z, u4.w} : f2{u4.x, u4.y};
+                    const f2 uv = sl * dx + u0;
+                    o.U[q] = f2{fmaxf(uv.x, 0.f), fmaxf(uv.y, 0.f)};
+                }
+                o.lo = lo;
+                return o;
+            };
+            Node cur = eval(j0);
+            for (int t = 0; t < run; t++) {
+                const int j = j0 + t;
+                const Node nxt = eval(j + 1);
+                // group j: bins k .. k + n - 1 (n = 0 behind the last node).  With a node behind it: both sums; the last group of all
+                // (a few bins at the Nyquist end): the upper sum with U <= 1 (every attenuation bound is, up to its 2e-5 of slack)
+                const int k = 1 + AB_G * j, n = max(0, min(AB_G, nh - k));
+                const bool has_next = j + 1 < n_nodes;
+                const float w_up = (float)n * ((k + n - 1) * dff) * (1.f + 1e-6f), w_lo = has_next ? (float)n * (k * dff) * (1.f - 1e-6f) : 0.f;
+                // the coarse frequency between the two nodes, if the segment changes: its value is the table's
+                const float4 ia4 = ubf[wv][min(cur.lo + 1, st.n_fc - 1)];
+                const bool inner = nxt.lo != cur.lo;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const f2 ia = q ? f2{ia4.z, ia4.w} : f2{ia4.x, ia4.y};
+                    const f2 mid = inner ? ia : cur.U[q];
+                    f2 umax = f2{fmaxf(fmaxf(cur.U[q].x, nxt.U[q].x), mid.x), fmaxf(fmaxf(cur.U[q].y, nxt.U[q].y), mid.y)};
+                    const f2 umin = f2{fminf(fminf(cur.U[q].x, nxt.U[q].x), mid.x), fminf(fminf(cur.U[q].y, nxt.U[q].y), mid.y)};
+                    if (!has_next) umax = f2{1.f + 3e-5f, 1.f + 3e-5f};
+                    up2[q] += (pf2[q] * w_up) * cur.r[q] * umax;
+                    lo2[q] += (pf2[q] * w_lo) * nxt.r[q] * umin;
+                }
+                cur = nxt;
+            }
+            float upt[AB_RT] = {up2[0].x, up2[0].y, up2[1].x, up2[1].y}, lot[AB_RT] = {lo2[0].x, lo2[0].y, lo2[1].x, lo2[1].y};
+            double up_mine = 0., lo_mine = 0.;
+            for (int i = 0; i < AB_RT; i++) {
+                float a = upt[i], b = lot[i];
+                for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+                if (lane == i) { up_mine = a; lo_mine = b; }
+            }
+            // what the 2047-term sum would hand to efield_bound lies between these two (its FP32 rounding: 2047 x 6e-8, ours: 1e-5)
+            const double x_up = (up_mine * BOUND_F32_SLACK) * BOUND_F32_SLACK + 1e-30;
+            const double x_lo = (lo_mine * (1. - 5e-4)) * BOUND_F32_SLACK;
+            const int r = rb + lane;
+            bool open = false;
+            double b_up = 0.;
+            if (lane < AB_RT && r < n_rays) {
+                const double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
+                b_up = efield_bound(x_up * BOUND_RCP_SLACK, st.N, st.fs, cmax);
+                const double b_lo = efield_bound(x_lo * BOUND_RCP_SLACK, st.N, st.fs, cmax);
+                open = (b_up * (1 + 1e-6) > cut) && !(b_lo * (1 + 1e-6) > cut);
+            }
+#ifdef NRHIP_CONV_TIMING
+            if (lane == 0) { atomicAdd(&g_conv_clk[13], 1ULL); if (__ballot(open) == 0ull) atomicAdd(&g_conv_clk[14], 1ULL); }
+#endif
+            if (__ballot(open) == 0ull) {
+                decided = true;
+                if (lane < AB_RT && r < n_rays) {
+                    bound[r] = b_up;
+                    max_efield[r] = -b_up;
+                }
+            }
+        }
+        if (decided) {
+            wave_lds_sync();
+            continue;
+        }
         if (f32) {
             // the four rays of the tile as two packed pairs (v_pk_mul / v_pk_fma_f32: two single-precision operations per lane and
             // instruction; only the reciprocal is per ray)
@@ -3715,6 +3840,7 @@ void launch_amp_bound(hipStream_t s, int n_rays, const RayWork& w, const Station
     if (n_rays <= 0) return;
     int grid = (n_rays + 4 * AB_RT - 1) / (4 * AB_RT);
     if (grid > 256 * 32) grid = 256 * 32;
+    if (getenv("NRHIP_AMP_BOUND_EXACT")) cut = -1.;   // (A / B: always the 2047-term sum)
     hipLaunchKernelGGL(amp_bound_kernel, dim3(grid), dim3(256), 0, s, n_rays, w, st, m, vertex, zint, bound, max_efield, cut);
 }
 void launch_group_ray_range(hipStream_t s, int n_groups, const int* group_begin, int n_ch, const int* slot_offset, int* grp_ray,

@@ -33,3 +33,4 @@ for n, v in zip(names, out[:10]):
 print('  output loop %.2f %% (maximum / flags above: what follows it)' % (100 * out[12] / tot))
 print('  job list (of the time before the transforms) %.2f %%' % (100 * out[11] / (tot + out[11])))
 print('channel transforms', d['config']['n_channel_transforms'], 'ray transforms', d['config']['n_ray_transforms'])
+print('amp_bound tiles of 4 rays: %d, decided by the two-sided group sums: %d' % (out[13], out[14]))
