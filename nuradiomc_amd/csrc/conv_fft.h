@@ -350,8 +350,9 @@ __device__ __forceinline__ void dif8_tail_c(double2 (&a)[8])
 // structures), and inlined into it the passes came out with spill reloads and lane reads of spilled scalars in their inner code; a
 // call gives each pass its own register allocation, at the price of one s_swappc.  The buffer is the kernel's dynamic LDS.)
 // FULL: the upper half of the input holds data as well (the chirp convolutions of the trigger-ADC chain with more than M / 2 inputs).
+// nv: the elements behind index nv are taken as zero (not read): the caller need not clear them.
 template <int LOG2M, int NT, bool FULL = false>
-__device__ __noinline__ void conv_fwd(const double2* __restrict__ tw, const double2* __restrict__ cft)
+__device__ __noinline__ void conv_fwd(const double2* __restrict__ tw, const double2* __restrict__ cft, int nv)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double2* z = (double2*)smem;
@@ -365,7 +366,7 @@ __device__ __noinline__ void conv_fwd(const double2* __restrict__ tw, const doub
             const int i0 = t + NA * g;
             double2 a[NB];
 #pragma unroll
-            for (int j = 0; j < (FULL ? NB : NB / 2); j++) a[j] = z[j * 1025 + i0];
+            for (int j = 0; j < (FULL ? NB : NB / 2); j++) a[j] = (j * 1024 + i0 < nv) ? z[j * 1025 + i0] : make_double2(0., 0.);
             // first stage (span M / 2): the partners are zero unless FULL
 #pragma unroll
             for (int j = 0; j < NB / 2; j++) {

@@ -2895,13 +2895,12 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                   }
                 }
             }
-            // (only the lower half of the packed buffer is read by the forward transform: L <= Mr real samples, the rest is zero)
-            for (int n = L + threadIdx.x; n < Mr; n += blockDim.x) S[PS(n)] = 0.;
-            lds_barrier();
+            // (only the L / 2 complex elements that hold the L real samples are read by the forward transform: what lies behind them in the
+            // buffer -- the previous transform's output -- counts as zero there; every placement above ended with a barrier)
             CT(5);
             // forward transform, real-transform split * G * merge, first stages of the inverse (conv_fft.h)
-            if (half_size) { conv_fwd<LOG2CAP - 1, NT>(tw, cft); CT(6); conv_mid<LOG2CAP - 1, NT>(G, w16); }
-            else { conv_fwd<LOG2CAP, NT>(tw, cft); CT(6); conv_mid<LOG2CAP, NT>(G, w16); }
+            if (half_size) { conv_fwd<LOG2CAP - 1, NT>(tw, cft, L >> 1); CT(6); conv_mid<LOG2CAP - 1, NT>(G, w16); }
+            else { conv_fwd<LOG2CAP, NT>(tw, cft, L >> 1); CT(6); conv_mid<LOG2CAP, NT>(G, w16); }
             if (multi) {  // sum the tables' contributions (the rest of the inverse is linear) in global scratch of this block
                 for (int k = threadIdx.x; k < Mr; k += blockDim.x) acc[k] = first_tab ? z[PZ(k)] : cadd(acc[k], z[PZ(k)]);
                 first_tab = false;
@@ -4702,8 +4701,8 @@ template <int LOG2M>
 __device__ __forceinline__ void pa_convolve(const double2* __restrict__ Bn, const double2* __restrict__ tw, const double2* __restrict__ cft,
                                             bool full)
 {
-    if (full) conv_fwd<LOG2M, 512, true>(tw, cft);
-    else conv_fwd<LOG2M, 512, false>(tw, cft);
+    if (full) conv_fwd<LOG2M, 512, true>(tw, cft, 1 << LOG2M);
+    else conv_fwd<LOG2M, 512, false>(tw, cft, 1 << LOG2M);
     conv_mid_plain<LOG2M, 512>(Bn);
     conv_inv<LOG2M, 512>(tw, cft);
 }
