@@ -86,3 +86,21 @@ def test_event_list_from_hdf5(tmp_path):
     assert np.array_equal(b['types'], np.array([0 if t == b'had' else 1 for t in g['in/shower_type']]))
     assert np.array_equal(b['gid'], g['in/event_group_ids']) and np.array_equal(b['energies'], g['in/shower_energies'])
     assert np.array_equal(b['vt'], g['in/vertex_times'])
+
+
+def test_output_window_helpers():
+    """Host-side pieces of simulate_to_output: the read-out window (channelReadoutWindowCutter: np.roll, then the first samples) without the
+    rolled copy, and the maxima / Hilbert envelopes of all windows on a pool of threads (real transforms) against scipy.signal.hilbert."""
+    from scipy.signal import hilbert
+    from nuradiomc_amd import output as o
+    rng = np.random.default_rng(5)
+    V = rng.normal(size=(5, 100))
+    for tb, nw, pre in ((3, 40, 10), (90, 64, 5), (50, 120, 7), (0, 100, 0), (99, 2, 110)):
+        assert np.array_equal(o._readout_window(V, tb, nw, pre), np.roll(V, -(tb - pre), axis=-1)[..., :nw]), (tb, nw, pre)
+    for n in (4096, 1000, 777, 6):
+        x = rng.normal(size=(3, 5, n))
+        assert np.max(np.abs(o._hilbert_envelope(x) - np.abs(hilbert(x, axis=-1)))) < 1e-13
+    W = [rng.normal(size=(5, 512)) for _ in range(150)]
+    amp, env = o._window_maxima(W, step=16)
+    assert np.array_equal(amp, np.abs(np.array(W)).max(axis=-1))
+    assert np.max(np.abs(env - np.abs(hilbert(np.array(W), axis=-1)).max(axis=-1))) < 1e-13
