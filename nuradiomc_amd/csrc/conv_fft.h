@@ -488,7 +488,9 @@ __device__ __noinline__ void conv_mid(const double2* __restrict__ G, const doubl
 
 // ---- the same pass for a plain complex convolution: last three forward stages, product with a spectrum given in NATURAL bin order
 // (Bn[k], k < M), first three inverse stages.  After dif8_tail slot r of a thread's group k0 holds bin k0 + (M / 8) br3(r).
-template <int LOG2M, int NT>
+// BR: the spectrum table is in bit-reversed order (the tables of the block-wide transforms of fft_device.h): bin k0 + (M / 8) br3(r)
+// then sits at 8 bitrev(k0) + r -- a thread's eight values are one contiguous 128-byte run.
+template <int LOG2M, int NT, bool BR = false>
 __device__ __noinline__ void conv_mid_plain(const double2* __restrict__ Bn)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -504,7 +506,15 @@ __device__ __noinline__ void conv_mid_plain(const double2* __restrict__ Bn)
         double2* pb = z + wB * 1025 + 8 * (kB >> LW);
         double2 A[8], B[8], GA[8], GB[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { GA[r] = Bn[kA + K * br3(r)]; GB[r] = Bn[kB + K * br3(r)]; }
+        for (int r = 0; r < 8; r++) {
+            if (BR) {
+                GA[r] = Bn[8 * (int)(__brev((unsigned)kA) >> (32 - (LOG2M - 3))) + r];
+                GB[r] = Bn[8 * (int)(__brev((unsigned)kB) >> (32 - (LOG2M - 3))) + r];
+            } else {
+                GA[r] = Bn[kA + K * br3(r)];
+                GB[r] = Bn[kB + K * br3(r)];
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 8; c++) { A[c] = pa[c]; B[c] = pb[c]; }
         dif8_tail(A);

@@ -2674,7 +2674,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         bool noisy = false;
         double* const nbuf = noise_buf ? noise_buf + (long)blockIdx.x * FFT_MAX : nullptr;
         if (LOG2CAP == FFT_LOG2_MAX && nz.on && nbuf) noisy = nz.amplitude[ch] > 0.;
-        if (LOG2CAP == FFT_LOG2_MAX && noisy) {
+        if constexpr (LOG2CAP == FFT_LOG2_MAX) if (noisy) {
             const int grp = nz.ev_group ? nz.ev_group[e] : e;
             const long long gid = nz.group_id ? nz.group_id[grp] : nz.group_offset + grp;
             const int sub = nz.ev_sub ? nz.ev_sub[e] : 0;
@@ -2684,15 +2684,30 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
             const double2* Hf = tab.H + ((long)il * st.n_fsets + (st.ch_fset ? st.ch_fset[ch] : 0)) * NRHIP_SPEC_STRIDE;
             const double nscale = st.fs / 1.4142135623730951 / L * (1.0 / FFT_MAX);
             const int mL = L / 2;
-            __syncthreads();
-            czt_inverse_blocks<NT>(z, Bi, tw, E, Ci, L, mL, FFT_MAX,
-                [&](int k) {
+            // the inverse chirp-z of czt_inverse_blocks (m + 1 bins -> blocks of P = M - m samples, the block's input pre-multiplied by
+            // exp(+2 pi i k n0 / L)), its 8192-point convolution through the transform pair of conv_fft.h (the Bluestein spectrum in the
+            // bit-reversed order its table has)
+            const int Pn = FFT_MAX - mL;
+            for (int n0 = 0; n0 < L; n0 += Pn) {
+                lds_barrier();
+                for (int k = threadIdx.x; k <= mL; k += NT) {
                     double2 v = cmul(noise_bin(nz, gid, sub, ch, k, L, st.fs), Hf[k]);
                     if (k == 0 || k == mL) v = make_double2(v.x, 0.);   // Hermitian folding of irfft
                     else v = cscale(v, 2.);
-                    return v;
-                },
-                [&](int ng, double2 u) { nbuf[ng] = u.x * nscale; });
+                    if (n0 != 0) {
+                        const unsigned kn = ((unsigned)k * (unsigned)n0) % (unsigned)L;
+                        v = cmul(v, cconj(E[2 * kn]));                         // exp(+2 pi i k n0 / L)
+                    }
+                    z[PZ(k)] = cmul(v, Ci[k]);                                 // chirp(k; L, +)
+                }
+                lds_barrier();
+                if (mL + 1 > FFT_MAX / 2) conv_fwd<FFT_LOG2_MAX, NT, true>(tw, cft, mL + 1);
+                else conv_fwd<FFT_LOG2_MAX, NT, false>(tw, cft, mL + 1);
+                conv_mid_plain<FFT_LOG2_MAX, NT, true>(Bi);
+                conv_inv<FFT_LOG2_MAX, NT>(tw, cft);
+                const int np = min(Pn, L - n0);
+                for (int n = threadIdx.x; n < np; n += NT) nbuf[n0 + n] = cmul(z[PZ(n)], Ci[n]).x * nscale;
+            }
             __syncthreads();   // (the noise samples are read back by other threads: a barrier that covers global memory)
         }
         for (int tb = 0; tb < NRHIP_N_ANT_TAB; tb++) {
