@@ -2486,7 +2486,9 @@ __device__ __forceinline__ void czt_inverse_blocks(double2* x, const double2* __
 // LOG2CAP: log2 of the complex points the LDS buffer holds.  13 (FFT_MAX): any event of up to FFT_MAX samples, 133 KB, one block per
 // CU.  12: events of up to FFT_MAX / 2 samples only (the N = 2048 workloads), 68 KB + 9 KB static: TWO blocks per CU, so one block's
 // barriers and LDS round trips are covered by the other's arithmetic.
-template <int LOG2CAP>
+// WR: the rays' transforms wave-private (N / 2 = 1024 or 2048) -- a compile-time choice, so that the instantiation the surveys run does
+// not carry the batched block-wide ray path's registers (and the other one not the wave-private path's).
+template <int LOG2CAP, bool WR>
 __global__ void __launch_bounds__(CONV_THREADS(LOG2CAP), 2)
 channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list, const int* __restrict__ need,
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
@@ -2526,11 +2528,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     const int log2B = (LOG2CAP == FFT_LOG2_MAX) ? ((nh <= 1024) ? 2 : (nh <= 2048 ? 1 : 0)) : ((nh <= 1024) ? 1 : 0), B = 1 << log2B;
     // wave-private ray transforms for N / 2 = 1024, 2048 (other lengths: the batched block-wide transform below)
     const int NBKr = nh >> 9, TR = nh >> 3;
-#ifdef NRHIP_CONV_OLD_RAYS   // build variant for A / B measurements
-    const bool wave_rays = false;
-#else
-    const bool wave_rays = (nh == 1024 || nh == 2048) && TR <= NT;
-#endif
+    constexpr bool wave_rays = WR;   // (the launcher: WR only for N / 2 = 1024, 2048 with N / 16 <= NT)
     const int Bw = wave_rays ? min(BM, NT / TR) : 0;
     __shared__ double red2[2][NT / 64];   // channel maximum: one word per wave, two phases' worth (see the flags phase)
     __shared__ int s_trig2[2];
@@ -3980,8 +3978,11 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)length_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               FFT_MAX * 16 + (FFT_MAX / 2 + 1) * 8);
-    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(FFT_LOG2_MAX));
-    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX - 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(FFT_LOG2_MAX));
+    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(FFT_LOG2_MAX));
+    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX - 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              conv_lds_bytes(FFT_LOG2_MAX - 1));
+    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX - 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               conv_lds_bytes(FFT_LOG2_MAX - 1));
     (void)hipFuncSetAttribute((const void*)ray_envelope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
@@ -4065,13 +4066,18 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
             int blocks = channel_grid_blocks();
             if (getenv("NRHIP_CONV_SMALL_BLOCKS")) blocks = atoi(getenv("NRHIP_CONV_SMALL_BLOCKS"));
             const int cgrid = n_cand < blocks ? n_cand : blocks;
-            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX - 1>, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)conv_lds_bytes(FFT_LOG2_MAX - 1), s,
+            // (wave-private ray transforms: N / 16 threads per ray have to fit the block)
+            const bool wr_s = (nh == 1024 || nh == 2048) && (nh >> 3) <= CONV_THREADS(FFT_LOG2_MAX - 1) && !getenv("NRHIP_CONV_OLD_RAYS");
+            auto kern_s = wr_s ? channel_conv_kernel<FFT_LOG2_MAX - 1, true> : channel_conv_kernel<FFT_LOG2_MAX - 1, false>;
+            hipLaunchKernelGGL(kern_s, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)conv_lds_bytes(FFT_LOG2_MAX - 1), s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue, 0, nz_off, nullptr);
         }
         if (large) {
             const int cgrid = n_cand < channel_grid_blocks() / 2 ? n_cand : channel_grid_blocks() / 2;
-            hipLaunchKernelGGL(channel_conv_kernel<FFT_LOG2_MAX>, dim3(cgrid), dim3(CONV_NT), (size_t)conv_lds_bytes(FFT_LOG2_MAX), s,
+            const bool wr_l = (nh == 1024 || nh == 2048) && (nh >> 3) <= CONV_NT && !getenv("NRHIP_CONV_OLD_RAYS");
+            auto kern_l = wr_l ? channel_conv_kernel<FFT_LOG2_MAX, true> : channel_conv_kernel<FFT_LOG2_MAX, false>;
+            hipLaunchKernelGGL(kern_l, dim3(cgrid), dim3(CONV_NT), (size_t)conv_lds_bytes(FFT_LOG2_MAX), s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue + (small ? 1 : 0),
                                small ? FFT_MAX / 2 : 0, with_noise ? *noise : nz_off, with_noise ? noise_buf : nullptr);
