@@ -844,6 +844,10 @@ __device__ inline void field_time_domain(double2* x, const double* amp, int N, c
 #ifndef NRHIP_ATT_BOUND_MARGIN
 #define NRHIP_ATT_BOUND_MARGIN 0.95
 #endif
+__device__ __noinline__ double2 efield_bound_fp64_ray(int N, double fs, int n_fc, const unsigned char* __restrict__ seg,
+                                                       const double* __restrict__ fpow, const double* __restrict__ lnf,
+                                                       const AskaryanConst& ask, const double* at, const double* at_slope,
+                                                       const double* s_xp, int lane);   // (defined with efield_bound_kernel)
 #define AB_RT 4  // rays per wave and pass: the frequency-grid tables are loaded once for AB_RT rays
 #define AB_G 4   // bins per group of the two-sided sums
 #define AB_RUN 8 // groups per lane at most (N / 2 <= 2048; longer traces take the plain sums)
@@ -1159,27 +1163,11 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
             float pf32[AB_RT] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y};
             for (int i = 0; i < AB_RT; i++) part[i] = (double)pf32[i] * BOUND_F32_SLACK + 1e-30;  // + what FP32 may have flushed to zero
         } else {
-            for (int k = 1 + lane; k < nh; k += 64) {
-                const double f = k * df;
-                // np.interp clamps outside the coarse grid: segment 0 at offset 0 / last segment at full length
-                int lo = st.seg[k];
-                double dx = f - s_xp[lo];
-                if (f <= x_first) { lo = 0; dx = 0.; }
-                if (f >= x_last) { lo = st.n_fc - 2; dx = dx_last; }
-                if (all2009) {
-                    const double ph = st.fpow[k], pe = st.fpow[stride + k], pr = st.fpow[2 * stride + k];
-#pragma unroll
-                    for (int i = 0; i < AB_RT; i++) {
-                        double x = (had[i] ? ph : pe) * cL[i], y = pr * cR[i];
-                        double amp = pf[i] * f * bound_rcp((1 + x) * (1 + y));
-                        part[i] += amp * (ub_slope[wv][i][lo] * dx + ub[wv][i][lo]);
-                    }
-                } else {
-                    for (int i = 0; i < AB_RT; i++)
-                        part[i] += amplitude_bin(k, f, w.ask[min(rb + i, n_rays - 1)], st) *
-                                   (ub_slope[wv][i][lo] * dx + ub[wv][i][lo]);
-                }
-            }
+            // rare (another emission model, or parameters outside the FP32 range): FP64, ray by ray, out of line (the sums of
+            // efield_bound_kernel with the bounds in place of the attenuation) -- inlined, these loops cost the common path registers
+            for (int i = 0; i < AB_RT; i++)
+                part[i] = efield_bound_fp64_ray(st.N, st.fs, st.n_fc, st.seg, st.fpow, st.lnf, w.ask[min(rb + i, n_rays - 1)], ub[wv][i],
+                                                ub_slope[wv][i], s_xp, lane).x;
         }
         // the four sums: wave totals by shuffles, then lane i < AB_RT finishes ray i (one copy of the epilogue instead of four)
         double mine = 0.;
@@ -2488,7 +2476,9 @@ __device__ __forceinline__ void czt_inverse_blocks(double2* x, const double2* __
 // barriers and LDS round trips are covered by the other's arithmetic.
 // WR: the rays' transforms wave-private (N / 2 = 1024 or 2048) -- a compile-time choice, so that the instantiation the surveys run does
 // not carry the batched block-wide ray path's registers (and the other one not the wave-private path's).
-template <int LOG2CAP, bool WR>
+// NZ: with the thermal-noise trace per channel (full-capacity instantiation only), likewise compile-time.
+// WR is N / 1024 (2 or 4: the 512-point blocks of a ray's transform) or 0 for the batched block-wide ray path.
+template <int LOG2CAP, int WR, bool NZ = false>
 __global__ void __launch_bounds__(CONV_THREADS(LOG2CAP), 2)
 channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list, const int* __restrict__ need,
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
@@ -2527,8 +2517,9 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     // B is what fits behind the event's samples: M / 2 complex elements (conv_lds_elems)
     const int log2B = (LOG2CAP == FFT_LOG2_MAX) ? ((nh <= 1024) ? 2 : (nh <= 2048 ? 1 : 0)) : ((nh <= 1024) ? 1 : 0), B = 1 << log2B;
     // wave-private ray transforms for N / 2 = 1024, 2048 (other lengths: the batched block-wide transform below)
-    const int NBKr = nh >> 9, TR = nh >> 3;
-    constexpr bool wave_rays = WR;   // (the launcher: WR only for N / 2 = 1024, 2048 with N / 16 <= NT)
+    constexpr int NBKr = WR ? WR : 2;   // (2: a valid template argument for the code the batched variant never runs)
+    const int TR = nh >> 3;
+    constexpr bool wave_rays = WR != 0;   // (the launcher: WR = N / 1024 only for N / 2 = 1024, 2048 with N / 16 <= NT)
     const int Bw = wave_rays ? min(BM, NT / TR) : 0;
     __shared__ double red2[2][NT / 64];   // channel maximum: one word per wave, two phases' worth (see the flags phase)
     __shared__ int s_trig2[2];
@@ -2671,8 +2662,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         // full-capacity instantiation can hold the 8192-point chirp convolution: with noise every event runs in it.
         bool noisy = false;
         double* const nbuf = noise_buf ? noise_buf + (long)blockIdx.x * FFT_MAX : nullptr;
-        if (LOG2CAP == FFT_LOG2_MAX && nz.on && nbuf) noisy = nz.amplitude[ch] > 0.;
-        if constexpr (LOG2CAP == FFT_LOG2_MAX) if (noisy) {
+        if (NZ && LOG2CAP == FFT_LOG2_MAX && nz.on && nbuf) noisy = nz.amplitude[ch] > 0.;
+        if constexpr (NZ && LOG2CAP == FFT_LOG2_MAX) if (noisy) {
             const int grp = nz.ev_group ? nz.ev_group[e] : e;
             const long long gid = nz.group_id ? nz.group_id[grp] : nz.group_offset + grp;
             const int sub = nz.ev_sub ? nz.ev_sub[e] : 0;
@@ -3978,12 +3969,13 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)length_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               FFT_MAX * 16 + (FFT_MAX / 2 + 1) * 8);
-    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(FFT_LOG2_MAX));
-    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(FFT_LOG2_MAX));
-    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX - 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              conv_lds_bytes(FFT_LOG2_MAX - 1));
-    (void)hipFuncSetAttribute((const void*)channel_conv_kernel<FFT_LOG2_MAX - 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              conv_lds_bytes(FFT_LOG2_MAX - 1));
+#define CONV_ATTR(...) (void)hipFuncSetAttribute((const void*)channel_conv_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(FFT_LOG2_MAX))
+    CONV_ATTR(FFT_LOG2_MAX, 0); CONV_ATTR(FFT_LOG2_MAX, 2); CONV_ATTR(FFT_LOG2_MAX, 4);
+    CONV_ATTR(FFT_LOG2_MAX, 0, true); CONV_ATTR(FFT_LOG2_MAX, 2, true); CONV_ATTR(FFT_LOG2_MAX, 4, true);
+#undef CONV_ATTR
+#define CONV_ATTR(...) (void)hipFuncSetAttribute((const void*)channel_conv_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(FFT_LOG2_MAX - 1))
+    CONV_ATTR(FFT_LOG2_MAX - 1, 0); CONV_ATTR(FFT_LOG2_MAX - 1, 2); CONV_ATTR(FFT_LOG2_MAX - 1, 4);
+#undef CONV_ATTR
     (void)hipFuncSetAttribute((const void*)ray_envelope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)efield_channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
@@ -4068,7 +4060,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
             const int cgrid = n_cand < blocks ? n_cand : blocks;
             // (wave-private ray transforms: N / 16 threads per ray have to fit the block)
             const bool wr_s = (nh == 1024 || nh == 2048) && (nh >> 3) <= CONV_THREADS(FFT_LOG2_MAX - 1) && !getenv("NRHIP_CONV_OLD_RAYS");
-            auto kern_s = wr_s ? channel_conv_kernel<FFT_LOG2_MAX - 1, true> : channel_conv_kernel<FFT_LOG2_MAX - 1, false>;
+            auto kern_s = !wr_s ? channel_conv_kernel<FFT_LOG2_MAX - 1, 0> : (nh == 2048 ? channel_conv_kernel<FFT_LOG2_MAX - 1, 4> : channel_conv_kernel<FFT_LOG2_MAX - 1, 2>);
             hipLaunchKernelGGL(kern_s, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)conv_lds_bytes(FFT_LOG2_MAX - 1), s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue, 0, nz_off, nullptr);
@@ -4076,7 +4068,9 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
         if (large) {
             const int cgrid = n_cand < channel_grid_blocks() / 2 ? n_cand : channel_grid_blocks() / 2;
             const bool wr_l = (nh == 1024 || nh == 2048) && (nh >> 3) <= CONV_NT && !getenv("NRHIP_CONV_OLD_RAYS");
-            auto kern_l = wr_l ? channel_conv_kernel<FFT_LOG2_MAX, true> : channel_conv_kernel<FFT_LOG2_MAX, false>;
+            const int wr_n = !wr_l ? 0 : (nh == 2048 ? 4 : 2);
+            auto kern_l = with_noise ? (wr_n == 4 ? channel_conv_kernel<FFT_LOG2_MAX, 4, true> : wr_n == 2 ? channel_conv_kernel<FFT_LOG2_MAX, 2, true> : channel_conv_kernel<FFT_LOG2_MAX, 0, true>)
+                                     : (wr_n == 4 ? channel_conv_kernel<FFT_LOG2_MAX, 4> : wr_n == 2 ? channel_conv_kernel<FFT_LOG2_MAX, 2> : channel_conv_kernel<FFT_LOG2_MAX, 0>);
             hipLaunchKernelGGL(kern_l, dim3(cgrid), dim3(CONV_NT), (size_t)conv_lds_bytes(FFT_LOG2_MAX), s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue + (small ? 1 : 0),
