@@ -2478,7 +2478,8 @@ __device__ __forceinline__ void czt_inverse_blocks(double2* x, const double2* __
 // not carry the batched block-wide ray path's registers (and the other one not the wave-private path's).
 // NZ: with the thermal-noise trace per channel (full-capacity instantiation only), likewise compile-time.
 // WR is N / 1024 (2 or 4: the 512-point blocks of a ray's transform) or 0 for the batched block-wide ray path.
-template <int LOG2CAP, int WR, bool NZ = false>
+// MODE: 0 the plain OR of simple thresholds, 1 the same with the traces of a triggered event emitted, 2 coincidence logic.
+template <int LOG2CAP, int WR, bool NZ, int MODE>
 __global__ void __launch_bounds__(CONV_THREADS(LOG2CAP), 2)
 channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list, const int* __restrict__ need,
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
@@ -2493,7 +2494,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     constexpr int NT = CONV_THREADS(LOG2CAP);   // threads of the block
     constexpr int BM = (LOG2CAP == FFT_LOG2_MAX) ? 4 : 2;   // transforms per batch at most
     const double threshold = trg.threshold;
-    const bool coinc = trg.coincidence();
+    constexpr bool coinc = MODE == 2;   // (= trg.coincidence(): the launcher's choice)
     double2* acc = conv_acc + (long)blockIdx.x * FFT_MAX;
     int* cnt = coinc_cnt + (long)blockIdx.x * FFT_MAX;  // per sample: channels whose dilated flag is set (coincidence modes)
     __shared__ int s_scan[NT];
@@ -2611,7 +2612,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       const int n_steps = best_first ? s_norder[par] : st.n_ch;
       // emission of a triggered event's traces: once a channel has triggered, ALL channels of the event are evaluated (in channel
       // order, the pruned ones included) and written into the block reserved for the event
-      const bool can_emit = out.emit != nullptr && !exact && !coinc;
+      const bool can_emit = MODE == 1 && out.emit != nullptr && !exact;
       bool emitting = false;
       int c_star = -1;
       long long e_off = -1;
@@ -3961,6 +3962,33 @@ void launch_candidate_lists(hipStream_t s, int n_events, int n_half, const Event
                        lflag, loff, cand, len_index, lens);
 }
 static int fft_pad_host(int i) { return i + (i >> 5) + (i >> 7); }   // fft_pad() of fft_device.h
+// The instantiations of channel_conv_kernel: (capacity 13 | 12) x (ray path 0 | 2 | 4) x (noise: capacity 13 only) x (mode 0 | 1 | 2)
+using ConvKernelPtr = decltype(&channel_conv_kernel<FFT_LOG2_MAX, 0, false, 0>);
+template <int LOG2CAP, int WR, bool NZ>
+static ConvKernelPtr conv_kernel_mode(int mode)
+{
+    return mode == 2 ? channel_conv_kernel<LOG2CAP, WR, NZ, 2> : mode == 1 ? channel_conv_kernel<LOG2CAP, WR, NZ, 1> : channel_conv_kernel<LOG2CAP, WR, NZ, 0>;
+}
+template <int LOG2CAP, bool NZ>
+static ConvKernelPtr conv_kernel_rays(int wr, int mode)
+{
+    return wr == 4 ? conv_kernel_mode<LOG2CAP, 4, NZ>(mode) : wr == 2 ? conv_kernel_mode<LOG2CAP, 2, NZ>(mode) : conv_kernel_mode<LOG2CAP, 0, NZ>(mode);
+}
+static ConvKernelPtr conv_kernel_pick(int log2cap, int wr, bool noise, int mode)
+{
+    if (log2cap != FFT_LOG2_MAX) return conv_kernel_rays<FFT_LOG2_MAX - 1, false>(wr, mode);
+    return noise ? conv_kernel_rays<FFT_LOG2_MAX, true>(wr, mode) : conv_kernel_rays<FFT_LOG2_MAX, false>(wr, mode);
+}
+template <class F>
+static void conv_kernel_for_each(F&& f)
+{
+    for (int wr : {0, 2, 4})
+        for (int mode : {0, 1, 2}) {
+            f(conv_kernel_pick(FFT_LOG2_MAX, wr, false, mode), FFT_LOG2_MAX);
+            f(conv_kernel_pick(FFT_LOG2_MAX, wr, true, mode), FFT_LOG2_MAX);
+            f(conv_kernel_pick(FFT_LOG2_MAX - 1, wr, false, mode), FFT_LOG2_MAX - 1);
+        }
+}
 static bool g_attr_set = false;
 static void set_big_lds()
 {
@@ -3969,13 +3997,9 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)length_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               FFT_MAX * 16 + (FFT_MAX / 2 + 1) * 8);
-#define CONV_ATTR(...) (void)hipFuncSetAttribute((const void*)channel_conv_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(FFT_LOG2_MAX))
-    CONV_ATTR(FFT_LOG2_MAX, 0); CONV_ATTR(FFT_LOG2_MAX, 2); CONV_ATTR(FFT_LOG2_MAX, 4);
-    CONV_ATTR(FFT_LOG2_MAX, 0, true); CONV_ATTR(FFT_LOG2_MAX, 2, true); CONV_ATTR(FFT_LOG2_MAX, 4, true);
-#undef CONV_ATTR
-#define CONV_ATTR(...) (void)hipFuncSetAttribute((const void*)channel_conv_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(FFT_LOG2_MAX - 1))
-    CONV_ATTR(FFT_LOG2_MAX - 1, 0); CONV_ATTR(FFT_LOG2_MAX - 1, 2); CONV_ATTR(FFT_LOG2_MAX - 1, 4);
-#undef CONV_ATTR
+    conv_kernel_for_each([](auto kern, int log2cap) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(log2cap));
+    });
     (void)hipFuncSetAttribute((const void*)ray_envelope_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)czt_test_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)efield_channel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
@@ -4050,6 +4074,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
         // (with thermal noise every event takes the full-capacity instantiation: the noise trace is an 8192-point chirp convolution)
         const bool with_noise = noise && noise->on && noise_buf;
         const NoiseDev nz_off{0, 0ull, nullptr, nullptr, 0, nullptr, nullptr};
+        const int conv_mode = trig.coincidence() ? 2 : (out.emit ? 1 : 0);   // (compile-time in the kernel)
         const bool small = st.N < FFT_MAX / 2 && conv_split && !with_noise && !getenv("NRHIP_CONV_ONE_BLOCK");   // L >= N: nothing to take otherwise
         const bool large = !small || max_length > FFT_MAX / 2;
         int* queue = ev_need + n_cand;   // the scan's zero sentinel: free again, and 0; the slot behind it for the second launch
@@ -4060,7 +4085,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
             const int cgrid = n_cand < blocks ? n_cand : blocks;
             // (wave-private ray transforms: N / 16 threads per ray have to fit the block)
             const bool wr_s = (nh == 1024 || nh == 2048) && (nh >> 3) <= CONV_THREADS(FFT_LOG2_MAX - 1) && !getenv("NRHIP_CONV_OLD_RAYS");
-            auto kern_s = !wr_s ? channel_conv_kernel<FFT_LOG2_MAX - 1, 0> : (nh == 2048 ? channel_conv_kernel<FFT_LOG2_MAX - 1, 4> : channel_conv_kernel<FFT_LOG2_MAX - 1, 2>);
+            auto kern_s = conv_kernel_pick(FFT_LOG2_MAX - 1, !wr_s ? 0 : (nh == 2048 ? 4 : 2), false, conv_mode);
             hipLaunchKernelGGL(kern_s, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)conv_lds_bytes(FFT_LOG2_MAX - 1), s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue, 0, nz_off, nullptr);
@@ -4069,8 +4094,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
             const int cgrid = n_cand < channel_grid_blocks() / 2 ? n_cand : channel_grid_blocks() / 2;
             const bool wr_l = (nh == 1024 || nh == 2048) && (nh >> 3) <= CONV_NT && !getenv("NRHIP_CONV_OLD_RAYS");
             const int wr_n = !wr_l ? 0 : (nh == 2048 ? 4 : 2);
-            auto kern_l = with_noise ? (wr_n == 4 ? channel_conv_kernel<FFT_LOG2_MAX, 4, true> : wr_n == 2 ? channel_conv_kernel<FFT_LOG2_MAX, 2, true> : channel_conv_kernel<FFT_LOG2_MAX, 0, true>)
-                                     : (wr_n == 4 ? channel_conv_kernel<FFT_LOG2_MAX, 4> : wr_n == 2 ? channel_conv_kernel<FFT_LOG2_MAX, 2> : channel_conv_kernel<FFT_LOG2_MAX, 0>);
+            auto kern_l = conv_kernel_pick(FFT_LOG2_MAX, wr_n, with_noise, conv_mode);
             hipLaunchKernelGGL(kern_l, dim3(cgrid), dim3(CONV_NT), (size_t)conv_lds_bytes(FFT_LOG2_MAX), s,
                                need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue + (small ? 1 : 0),
