@@ -374,6 +374,14 @@ typedef struct {
        size of the buffer (0: 4e8 samples = 3.2 GB, grown by the caller when n_emit_overflow > 0). */
     int32_t emit_triggered_traces;
     int64_t emit_capacity_samples;
+    /* given ray solutions (ray_tracing.set_solution, analyticraytracing.py:2092-2116: launch parameters read back from a file
+       instead of found): DEV double [n_showers * n_channels][2], NaN = no solution in that slot.  Non-NULL: the root search is
+       skipped -- no hybr / Brent, no distance cut (the given rays have passed it) -- and the records of exactly these launch
+       parameters (type, C1, path length, travel time, vectors) are made as for found ones; everything after the ray tracer is
+       unchanged.  This is how the channel traces are compared with the reference's on the reference's OWN rays
+       (tests/test_gpu_chain.py::test_reference_rays_through_the_batched_path).  Not with bottom reflections; the second trace
+       of `focusing` still searches (the reference's does).  NULL: the finder runs. */
+    const double* given_C0;
 } nrhip_sim_config;
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1

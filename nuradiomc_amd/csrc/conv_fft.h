@@ -80,7 +80,8 @@ __device__ __forceinline__ int conv_opaque(int t)
 
 // Block barrier for data that is handed over through LDS only: __syncthreads() also waits for every global store in flight (its
 // release fence covers all address spaces) -- with the traces of a triggered event streaming out to HBM that is a microsecond per
-// barrier.  Everything the threads of channel_conv_kernel hand to each other goes through LDS.
+// barrier.  What the threads of channel_conv_kernel hand to each other goes through LDS -- with ONE exception, the per-sample
+// coincidence counts (global scratch): the two points where those change hands use __syncthreads() (spectral.hip).
 __device__ __forceinline__ void lds_barrier()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");

@@ -826,6 +826,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     // solution slots per pair: 2, or 2 + 4 n with n reflections off the bottom of an ice shelf (propagation_base_class.py:424-429)
     const int n_refl = cfg->n_reflections;
     if (n_refl < 0 || n_refl > NRHIP_MAX_REFLECTIONS) return nrhip_fail_msg("nrhip_simulate_events: n_reflections must be 0..4");
+    if (n_refl > 0 && cfg->given_C0)
+        return nrhip_fail_msg("nrhip_simulate_events: given ray solutions (given_C0) are not available together with bottom reflections");
     if (n_refl > 0 && !(cfg->z_reflection < 0))
         return nrhip_fail_msg("nrhip_simulate_events: reflections off the bottom are requested, but no reflective layer is given (z_reflection)");
     const int S_ = n_refl > 0 ? 2 + 4 * n_refl : NRHIP_MAXS, NS_ = n_refl + 1;
@@ -924,7 +926,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             NEED(rt_eval_counter = WS("rt_eval_counter", unsigned long long, 1));
             HIPCHK(hipMemsetAsync(rt_eval_counter, 0, sizeof(unsigned long long), sm));
         }
-        launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm, nullptr, rt_eval_counter);
+        launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm, cfg->given_C0, rt_eval_counter);
         LCHK("raytrace");
     }
     MARK(1);

@@ -102,24 +102,28 @@ raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double*
             auto dy2 = [&](double l) { n_eval++; double d = delta_y_lds(l, sp, 256, m); return d * d; };
             double fun;
             const double xr = hybrd1(dy2, -1., 1e-6, &fun);
+            // The reference keeps the iterate as a root if (delta y)^2 < 1e-7 there (:1483) and then looks for one more root
+            // either side of it, 1e-4 away (:1498-1541).  Round 5: where that test fails although delta y changes its sign
+            // between the two points 1e-4 either side -- delta y is continuous in log C0, so there IS a root between them, the
+            // one the iteration was after -- the root is taken from that bracket (the TRUE solution set: DESIGN section 2,
+            // oracle/nrmc_oracle.c, tools/true_roots.py).  The (at most three) brackets of a lane are searched one after the
+            // other by ONE call site of Brent's method: a wave spends the longest lane's searches, not the sum over the kinds.
+            const double d_hi = dy(xr + 0.0001), d_top = dy(100.), d_bot = dy(-100.), d_lo = dy(xr - 0.0001);
+            unsigned todo = 0;
             if (fun < 1e-7) { lc0 = xr; ns = 1; }
-            {
-                double a = xr + 0.0001, b = 100.;
-                double fa = dy(a), fb = dy(b);
-                if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) {
-                    const double r = brentq(dy, a, b, fa, fb);
-                    if (ns == 0) lc0 = r; else lc1 = r;
-                    ns++;
-                }
-            }
-            {
-                double a = -100., b = xr - 0.0001;
-                double fa = dy(a), fb = dy(b);
-                if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) {
-                    const double r = brentq(dy, a, b, fa, fb);
-                    if (ns == 0) lc0 = r; else if (ns == 1) lc1 = r; else lc2 = r;
-                    ns++;
-                }
+            else if (d_lo != 0 && d_hi != 0 && !isnan(d_lo) && !isnan(d_hi) && signbit(d_lo) != signbit(d_hi)) todo |= 1u;
+            if (np_sign_differs(d_hi, d_top) && signbit(d_hi) != signbit(d_top)) todo |= 2u;
+            if (np_sign_differs(d_bot, d_lo) && signbit(d_bot) != signbit(d_lo)) todo |= 4u;
+            while (todo) {
+                const unsigned k = todo & (0u - todo);   // lowest pending bracket: the order of the reference's list
+                todo ^= k;
+                const double a = (k == 1u) ? xr - 0.0001 : ((k == 2u) ? xr + 0.0001 : -100.);
+                const double b = (k == 1u) ? xr + 0.0001 : ((k == 2u) ? 100. : xr - 0.0001);
+                const double fa = (k == 1u) ? d_lo : ((k == 2u) ? d_hi : d_bot);
+                const double fb = (k == 1u) ? d_hi : ((k == 2u) ? d_top : d_lo);
+                const double r = brentq(dy, a, b, fa, fb);
+                if (ns == 0) lc0 = r; else if (ns == 1) lc1 = r; else lc2 = r;
+                ns++;
             }
         }
         double c0a = NAN, c0b = NAN, c0c = NAN;

@@ -117,15 +117,18 @@ find_refl_kernel(long n_pairs, int n_calls, const double* __restrict__ x1, const
             auto dy2 = [&](double l) { double d = delta_y_refl(l, p, m, refl, rcase, z_refl); return d * d; };
             double fun;
             double xr = hybrd1(dy2, -1., 1e-6, &fun);
+            const double d_hi = dy(xr + 0.0001), d_lo = dy(xr - 0.0001);
             if (fun < 1e-7) lc[ns++] = xr;
+            else if (refl == 0 && d_lo != 0 && d_hi != 0 && !isnan(d_lo) && !isnan(d_hi) && signbit(d_lo) != signbit(d_hi))
+                lc[ns++] = brentq(dy, xr - 0.0001, xr + 0.0001, d_lo, d_hi);   // the true set for the plain call (raytrace.hip)
             {
                 double a = xr + 0.0001, b = 100.;
-                double fa = dy(a), fb = dy(b);
+                double fa = d_hi, fb = dy(b);
                 if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) lc[ns++] = brentq(dy, a, b, fa, fb);
             }
             {
                 double a = -100., b = xr - 0.0001;
-                double fa = dy(a), fb = dy(b);
+                double fa = dy(a), fb = d_lo;
                 if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) lc[ns++] = brentq(dy, a, b, fa, fb);
             }
         }

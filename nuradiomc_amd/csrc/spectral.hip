@@ -2603,7 +2603,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       lds_barrier();
       if (coinc) {
           for (int n = threadIdx.x; n < ev_L; n += blockDim.x) cnt[n] = 0;
-          lds_barrier();
+          __syncthreads();   // cnt lives in GLOBAL scratch and changes hands here (zeroed by stride, counted by the owner of a
+                             // run in conv_coinc_pass): a barrier that orders global memory too, once per event
       }
       // has an earlier channel of this event triggered?  A per-thread copy, refreshed between two barriers after every
       // evaluated channel: the shared flag itself may already have been reset for the NEXT event by a wave that ran ahead
@@ -2999,7 +3000,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       asm volatile("" :: "v"(touch_acc));
       if (coinc) {  // majority logic over the channels of the event
           if (threadIdx.x == 0) s_first = 0x7fffffff;
-          lds_barrier();
+          __syncthreads();   // (global: the counts of the runs' owners are read by stride below)
           const int nb = (trg.type == 0) ? ev_L : ev_L - 1;
           int first = 0x7fffffff;
           for (int i = threadIdx.x; i < nb - 1; i += blockDim.x)

@@ -83,7 +83,7 @@ class SimConfig(ctypes.Structure):
                 ('noise', ctypes.c_int32), ('noise_seed', ctypes.c_uint64), ('noise_group_offset', ctypes.c_int64),
                 ('noise_group_id', ctypes.c_void_p), ('custom_polarization', ctypes.c_int32),
                 ('polarization_ephi', ctypes.c_double), ('emit_triggered_traces', ctypes.c_int32),
-                ('emit_capacity_samples', ctypes.c_int64)]
+                ('emit_capacity_samples', ctypes.c_int64), ('given_C0', ctypes.c_void_p)]
 
 
 class SimStats(ctypes.Structure):
@@ -565,7 +565,7 @@ class Station:
                             accumulate_triggered=False, n_reflections=0, z_reflection=0., reflection_coefficient=1.,
                             reflection_phase_shift=0., split_event_time_diff=0., noise=False, noise_seed=0, noise_group_offset=0,
                             polarization='auto', ePhi=0.,
-                            d_noise_group_id=None, emit_traces=False, emit_capacity_samples=0):
+                            d_noise_group_id=None, emit_traces=False, emit_capacity_samples=0, d_given_C0=None):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
         d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
@@ -586,7 +586,9 @@ class Station:
         emit_traces (production mode, trigger 'simple' without coincidences): the convolution kernel writes the traces of all
         channels of every event the moment it triggers (nrhip_sim_config.emit_triggered_traces) -- triggered_traces() returns
         them; stats['n_emitted_events'] == stats['n_triggered'] and stats['n_emit_overflow'] == 0 say that every triggered event
-        got its block (otherwise run those through dump_traces / triggered_pass_dev)."""
+        got its block (otherwise run those through dump_traces / triggered_pass_dev).
+        d_given_C0: device f64 [n_events * n_channels][2] (NaN = none) -- the rays' launch parameters are GIVEN (set_solution,
+        analyticraytracing.py:2092), the root search does not run (nrhip_sim_config.given_C0)."""
         if polarization not in ('auto', 'custom'):   # simulation.py:827-829
             raise ValueError("{} for config.signal.polarization is not a valid option".format(polarization))
         if trigger not in ('simple', 'high_low', 'phased_array', 'envelope'):
@@ -602,7 +604,7 @@ class Station:
                         float(z_reflection), float(reflection_coefficient), float(reflection_phase_shift),
                         float(split_event_time_diff or 0.), int(bool(noise)), int(noise_seed) & 0xffffffffffffffff,
                         int(noise_group_offset), d_noise_group_id, int(polarization == 'custom'), float(ePhi),
-                        int(bool(emit_traces)), int(emit_capacity_samples))
+                        int(bool(emit_traces)), int(emit_capacity_samples), d_given_C0)
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_event_groups(
             self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,
@@ -663,7 +665,7 @@ class Station:
 
     def simulate_events(self, vertex, zenith, azimuth, energy, shower_type, k_L=None, vertex_time=None, group_id=None,
                         distance_cut_coefficients=None, distance_cut_sum_length=10., arz_iN=None, max_showers_per_call=None,
-                        seed=None, rng=None, **kw):
+                        seed=None, rng=None, given_C0=None, **kw):
         """Host-array convenience form: uploads the shower list, runs the hot path, returns (triggered mask, stats).
         Long lists are cut into calls of at most `max_showers_per_call` showers at event-group boundaries (default: what
         keeps the per-call tables near 40 GB: ~1.2e7 (shower, channel) pairs, 2.5e5 with ARZ / birefringence, whose rays carry
@@ -676,7 +678,9 @@ class Station:
         None) -- are drawn as the reference draws them when `seed` (or `rng`, a np.random.RandomState) is given: a first pass
         traces the rays, the host walks the showers in the reference's order (sequencing.reference_draw_order) drawing from
         RandomState(seed), the second pass reuses the ray tables; stats['k_L'] / stats['arz_iN'] return what was used.  Without
-        a seed missing values are an error (the reference never runs an EM shower with k_L = 1)."""
+        a seed missing values are an error (the reference never runs an EM shower with k_L = 1).
+        given_C0 [n, n_channels, 2] (NaN = none): the launch parameters of the rays are given (ray_tracing.set_solution), the
+        root search does not run -- e.g. the reference's own rays."""
         ctx = self.ctx
         vertex = L.f64(vertex).reshape(-1, 3)
         n = len(vertex)
@@ -685,6 +689,9 @@ class Station:
             max_showers_per_call = max(1, int((2.5e5 if general else 1.2e7) / len(self.position)))
         if rng is None and seed is not None:
             rng = np.random.RandomState(seed)
+        if given_C0 is not None:
+            given_C0 = np.ascontiguousarray(L.f64(given_C0).reshape(n, len(self.position), 2))
+            max_showers_per_call = max(max_showers_per_call, n)   # (one call: the table is indexed by the shower)
         if n > max_showers_per_call:
             return self._simulate_in_chunks(int(max_showers_per_call), vertex, zenith, azimuth, energy, shower_type, k_L,
                                             vertex_time, group_id, distance_cut_coefficients, distance_cut_sum_length, arz_iN,
@@ -725,8 +732,9 @@ class Station:
                 np.ascontiguousarray(np.where(np.isnan(kL), 1.0, kL))]
         dptrs = [ctx.to_device(a) for a in arrs]
         dtrig = ctx.malloc(max(n_groups, 1))
-        extra = [ctx.to_device(a) if a is not None else None for a in (vt, gb, md)]
-        dev_kw = dict(d_vertex_time=extra[0], n_groups=n_groups, d_group_begin=extra[1], d_max_distance=extra[2])
+        extra = [ctx.to_device(a) if a is not None else None for a in (vt, gb, md, given_C0)]
+        dev_kw = dict(d_vertex_time=extra[0], n_groups=n_groups, d_group_begin=extra[1], d_max_distance=extra[2],
+                      d_given_C0=extra[3])
         if kw.get('noise'):   # the noise of an event group is keyed by its id: the caller's group ids, else the running index
             off = int(kw.pop('noise_group_offset', 0))
             ids = gid[first] if group_id is not None and n else np.arange(n_groups) + off
@@ -868,5 +876,8 @@ class Station:
         dt = np.dtype(self._FETCH_DTYPES.get(name, np.float64))
         raw = np.empty(n, np.uint8)   # (filled by the copy below: no zeroing pass over what may be gigabytes of traces)
         if n:
-            self._lib.nrhip_sim_fetch(self._h, name.encode(), raw.ctypes.data_as(ctypes.c_void_p), n)
+            got = self._lib.nrhip_sim_fetch(self._h, name.encode(), raw.ctypes.data_as(ctypes.c_void_p), n)
+            if got != n:   # a failed copy (or a table replaced in between) must not hand out uninitialised memory
+                raise L.NrhipError(self._lib.nrhip_last_error().decode() if got < 0 else
+                                   "nrhip_sim_fetch(%s): %d bytes copied, %d expected" % (name, got, n))
         return raw[:(n // dt.itemsize) * dt.itemsize].view(dt)

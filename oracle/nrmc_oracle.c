@@ -403,10 +403,22 @@ int orc_find_solutions_2d_refl(const double x1[2], const double x2[2], const dou
     orc_hybrd1(obj_delta_y_square, &o, &xr, &fun, 1e-6, &nf);
     if (hybr_x) *hybr_x = xr;
     if (hybr_fun) *hybr_fun = fun;
+    const double d_hi = obj_delta_y(xr + 0.0001, &o), d_lo = obj_delta_y(xr - 0.0001, &o);
     if (fun < 1e-7) logC0[n++] = xr;
+    else if (reflection == 0 && d_lo != 0 && d_hi != 0 && !isnan(d_lo) && !isnan(d_hi) && signbit(d_lo) != signbit(d_hi)) {
+        /* THE TRUE SOLUTION SET (round 5; DESIGN section 2, tools/true_roots.py).  The reference keeps its first root only
+         * if (delta_y)^2 < 1e-7 where hybr stopped (:1483) -- about 1e-7 off a double root, where that number is 2e-8 ... 3e-6:
+         * a coin flip on the last bits of exp / log, and the two Brent searches leave the 2e-4 around the iterate out.
+         * delta_y is continuous in log C0 (it is a - |s|: a the horizontal half-width of the ray's arc at the receiver's
+         * depth, s the receiver's offset from the turning point; the "turning point below the receiver" branch :247-253
+         * joins it continuously where a = 0), so opposite signs either side of the iterate ARE a root between them, and it
+         * is taken from there -- never a false root, and every root the reference can report is reported. */
+        double rt;
+        if (orc_brentq(obj_delta_y, &o, xr - 0.0001, xr + 0.0001, &rt) != -1) logC0[n++] = rt;
+    }
     {
         double a = xr + 0.0001, b = 100.;
-        double da = obj_delta_y(a, &o), db = obj_delta_y(b, &o);
+        double da = d_hi, db = obj_delta_y(b, &o);
         if (sign_differs(da, db)) {
             double rt;
             if (orc_brentq(obj_delta_y, &o, a, b, &rt) != -1) logC0[n++] = rt; /* -1: scipy raises ValueError */
@@ -414,7 +426,7 @@ int orc_find_solutions_2d_refl(const double x1[2], const double x2[2], const dou
     }
     {
         double a = -100., b = xr - 0.0001;
-        double da = obj_delta_y(a, &o), db = obj_delta_y(b, &o);
+        double da = obj_delta_y(a, &o), db = d_lo;
         if (sign_differs(da, db)) {
             double rt;
             if (orc_brentq(obj_delta_y, &o, a, b, &rt) != -1) logC0[n++] = rt; /* -1: scipy raises ValueError */

@@ -23,7 +23,10 @@ def _compare(g, K, n_rays, cand, trig, L, maxV_of, what):
     """decisions exact wherever the ray counts agree; returns the observed maxima"""
     same = n_rays == g['ev_n_rays'][:K]
     frac_diff = 1. - same.mean()
-    assert frac_diff <= 1.2e-3, frac_diff          # observed: 14 of 24 000 = 5.8e-4 (the reference's hybr root noise flips a solution count)
+    # observed: 13 of 24 000 = 5.4e-4, on every one of them the reference is short of a TRUE root (tests/test_true_roots.py): since
+    # round 5 oracle and kernels hold the true solution set, so a count can differ in one direction only
+    assert frac_diff <= 1.2e-3, frac_diff
+    assert np.all(n_rays >= g['ev_n_rays'][:K])
     assert np.array_equal(cand[same], g['ev_candidate'][:K][same])
     assert np.array_equal(trig[same], g['ev_triggered'][:K][same])
     both = same & cand
@@ -91,3 +94,19 @@ def test_gpu_vs_reference_on_the_bench_list(gpu_ctx_factory, production):
         assert rel <= 4.4e-7, (k, rel)   # observed on 81 433 rays: 1.5e-7 (C0), 2.2e-7 (D); north_star: 1e-6
     assert np.array_equal(st.fetch('ray_channel')[:stats['n_rays']][keep], g['ray_channel'][ref_keep])
     assert np.array_equal(st.fetch('ray_solution')[:stats['n_rays']][keep], g['ray_iS'][ref_keep])
+
+
+@pytest.mark.gpu
+def test_gpu_on_the_reference_rays_of_the_bench_list(gpu_ctx_factory):
+    """The headline workload on the reference's OWN rays: the 81 433 launch parameters the reference found for
+    the first 24 000 events of the bench list go into the batched path (nrhip_sim_config.given_C0); decisions exact on all 24 000
+    events, channel maxima of all 2014 candidate events, path lengths and field maxima at 1e-6 against the reference's numbers."""
+    from test_gpu_chain import reference_rays_table, check_against_reference_on_its_rays
+    g, K = _fixture()
+    ctx = gpu_ctx_factory(bench.ICE, 'SP1')
+    st = bench.build_array(ctx, bench.make_workload(2, 1000, 10))
+    given, ref_rays = reference_rays_table(g, K, len(bench.CHANNELS))
+    trig, stats = st.simulate_events(g['vertex'], g['zenith'], g['azimuth'], np.full(K, bench.ENERGY), np.zeros(K, np.int32),
+                                     np.ones(K), dump_traces=True, no_pruning=True, given_C0=given)
+    worst, _ = check_against_reference_on_its_rays(g, st, trig, stats, K, ref_rays, 'bench list')
+    assert int(trig.sum()) == 222 and stats['n_candidate_events'] == 2014

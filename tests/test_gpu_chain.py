@@ -302,6 +302,96 @@ def test_whole_path_vs_reference_fixture(gpu_ctx_factory, name, n_events):
     assert worst <= 6e-4   # observed <= 2.8e-4 on the eight fixtures (a 1e-7 shift of T is a 3e-3 rad phase at 500 MHz)
 
 
+def reference_rays_table(g, n_events, n_ch):
+    """the reference's own launch parameters as the `given_C0` table [event][channel][2] (NaN = no ray): the fixtures keep the
+    rays that passed the reference's delta_C cut, (event, channel, iS, C0)"""
+    given = np.full((n_events, n_ch, 2), np.nan)
+    m = g['ray_event'] < n_events
+    given[g['ray_event'][m], g['ray_channel'][m], g['ray_iS'][m]] = g['ray_C0'][m]
+    return given, m
+
+
+def check_against_reference_on_its_rays(g, st, trig, stats, n_events, ref_rays, what):
+    """north_star's contract against the REFERENCE (not the oracle): with the reference's rays handed to the batched path, every
+    event's decisions are the reference's, path lengths / travel times / field maxima / channel maxima / stored channel traces agree
+    to 1e-6 relative.  No event is masked out."""
+    n_ch = len(st.position)
+    T = {k: st.fetch(k)[:stats['n_rays']] for k in ('ray_event', 'ray_channel', 'ray_C0', 'ray_D', 'ray_t0', 'ray_view', 'ray_zenith',
+                                                   'ray_azimuth', 'ray_max_efield')}
+    assert stats['n_rays'] == int(ref_rays.sum())                      # every given ray passes the delta_C cut again, nothing else does
+    assert np.array_equal(T['ray_event'], g['ray_event'][ref_rays]) and np.array_equal(T['ray_channel'], g['ray_channel'][ref_rays])
+    assert np.array_equal(T['ray_C0'], g['ray_C0'][ref_rays])          # the given launch parameters, bit for bit
+    worst = {}
+    worst['D'] = float(np.max(np.abs(T['ray_D'] - g['ray_D'][ref_rays]) / g['ray_D'][ref_rays]))
+    assert worst['D'] <= 1e-6, worst['D']
+    for k in ('ray_view', 'ray_zenith', 'ray_azimuth'):   # angles [rad]
+        assert np.max(np.abs(T[k] - g[k][ref_rays])) <= 1e-9, k
+    # start times of the field traces [ns] (vertex time + travel time - N / 2 fs): 1e-6 relative of travel times of ~1e4 ns
+    # would be 1e-2 ns; from identical launch parameters they agree to 1e-8 ns
+    worst['t0_ns'] = float(np.max(np.abs(T['ray_t0'] - g['ray_t0'][ref_rays])))
+    assert worst['t0_ns'] <= 1e-8, worst['t0_ns']
+    if 'ray_T' in g:
+        pass   # (the travel time itself is not a fetchable per-ray table: it is inside ray_t0)
+    me = g['ray_max_efield'][ref_rays]
+    ev_cand = st.fetch('ev_candidate')[:n_events].astype(bool)
+    # (field maxima are exact numbers for the rays of candidate events in the exhaustive mode this test runs)
+    worst['max_efield'] = float(np.max(np.abs(T['ray_max_efield'] - me) / me))
+    assert worst['max_efield'] <= 1e-6, worst['max_efield']
+    assert np.array_equal(st.fetch('ev_n_rays')[:n_events], g['ev_n_rays'][:n_events])
+    assert np.array_equal(ev_cand, g['ev_candidate'][:n_events])
+    assert np.array_equal(trig.astype(bool), g['ev_triggered'][:n_events])
+    L = st.fetch('ev_L')[:n_events]
+    assert np.array_equal(L[ev_cand], g['ev_L'][:n_events][ev_cand])
+    assert np.max(np.abs(st.fetch('ev_t_min')[:n_events][ev_cand] - g['ev_t_min'][:n_events][ev_cand])) <= 1e-8   # [ns]
+    item_event = st.fetch('item_event')
+    assert np.array_equal(item_event, np.flatnonzero(ev_cand))
+    maxV = st.fetch('item_maxV').reshape(len(item_event), n_ch)
+    ref = g['ev_maxV'][item_event]
+    worst['maxV'] = float(np.max(np.abs(maxV - ref) / np.max(ref, axis=1, keepdims=True)))
+    assert worst['maxV'] <= 1e-6, worst['maxV']
+    n_traces = 0
+    if 'V_events' in g:
+        toff, trace = st.fetch('trace_offset'), st.fetch('trace')
+        row = {int(e): i for i, e in enumerate(item_event)}
+        worst['trace'] = 0.
+        for j, ev in enumerate(g['V_events']):
+            if int(ev) >= n_events:
+                continue
+            V = g['V_concat'][:, g['V_offsets'][j]:g['V_offsets'][j + 1]]
+            i = row[int(ev)]
+            for ch in range(n_ch):
+                tr = trace[toff[i * n_ch + ch]:toff[i * n_ch + ch + 1]]
+                assert len(tr) == V.shape[1]
+                worst['trace'] = max(worst['trace'], float(np.max(np.abs(tr - V[ch])) / np.max(np.abs(V))))
+            n_traces += 1
+        assert worst['trace'] <= 1e-6, worst['trace']
+    print(what, '%d events, %d rays of the reference, %d candidates, %d triggers, %d stored traces; max rel: ' % (
+        n_events, stats['n_rays'], int(ev_cand.sum()), int(trig.sum()), n_traces) + ', '.join('%s %.1e' % kv for kv in worst.items()))
+    return worst, n_traces
+
+
+@pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N256_tab', 160),
+                                           ('N4096', 120), ('N256_hw', 220), ('N1280', 260), ('N3200', 120), ('N10240', 100)])
+def test_reference_rays_through_the_batched_path(gpu_ctx_factory, name, n_events):
+    """The parity triangle closed on the GPU: the reference's OWN launch parameters (every chain fixture
+    holds them) go into the batched path through nrhip_sim_config.given_C0 -- no root search, everything from
+    raytrace_records_kernel onwards as in production -- and the results are held against what the REFERENCE computed from the
+    same rays: decisions exact on ALL events, path quantities, field maxima, channel maxima and the stored channel traces at
+    north_star's 1e-6."""
+    g = golden('chain_%s.npz' % name)
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']))
+    st = _station(ctx, g)
+    n_ch = len(g['det_pos'])
+    given, ref_rays = reference_rays_table(g, n_events, n_ch)
+    sl = slice(0, n_events)
+    kL = np.where(np.isnan(g['ev_k_L'][sl]), 1.0, g['ev_k_L'][sl])
+    trig, stats = st.simulate_events(g['vertex'][sl], g['zenith'][sl], g['azimuth'][sl], g['energy'][sl], g['shower_type'][sl], kL,
+                                     askaryan_model=str(g['askaryan_model']), dump_traces=True, no_pruning=True, given_C0=given)
+    worst, n_traces = check_against_reference_on_its_rays(g, st, trig, stats, n_events, ref_rays, name)
+    assert n_traces >= 1 and stats['n_candidate_events'] >= 5
+    assert stats['n_objective_evals'] == 0     # no root search ran
+
+
 @pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_lpda', 200), ('N256_tab', 160), ('N4096', 120), ('N256_hw', 220),
                                            ('N1280', 260)])
 def test_pruning_changes_no_result(gpu_ctx_factory, name, n_events):

@@ -31,13 +31,15 @@ def test_raytrace_vs_reference_python_path(name):
     o = orc.raytrace_batch(g['x1'], g['x2'], g['ice'])
     # Whether the reference reports the first root depends on where its MINPACK iteration on (delta y)^2
     # happens to stop (accepted only if (delta y)^2 < 1e-7, analyticraytracing.py:1483), and that stopping
-    # point flips with the last bit of exp/log: the reference itself loses one of two true roots for ~0.1 %
-    # of pairs (its C++ twin and its Python path disagree there, too).  Such pairs may differ in COUNT, but
-    # every solution reported by the side with fewer solutions must be one of the other side's.
+    # point flips with the last bit of exp/log: the reference itself loses one of two true roots for ~0.1 ... 0.4 %
+    # of pairs (its C++ twin and its Python path disagree there, too).  Since round 5 the oracle takes that root
+    # by the sign change of delta y around the iterate, i.e. it holds the true set (tests/test_true_roots.py): a
+    # count may differ ONLY by the reference being short, and every solution of the reference is one of the oracle's.
     bad = o['n_sol'] != g['n_sol']
-    assert bad.mean() <= 0.003, "solution-count mismatches beyond the reference's own noise"   # observed 0.13 % (fixture A), 0 (B, C)
+    assert bad.mean() <= 0.008, "solution-count mismatches beyond the reference's own losses"   # observed 0.2 % (A), 0 (B), 0.4 % (C)
     for i in np.where(bad)[0]:
-        assert _subset_ok(o['C0'][i], g['C0'][i])
+        assert o['n_sol'][i] > g['n_sol'][i]
+        assert _subset_ok(g['C0'][i], o['C0'][i])
     ok = ~bad
     assert np.array_equal(o['type'][ok], g['type'][ok])
     assert max_rel(o['C0'][ok], g['C0'][ok]) < 1.1e-7   # observed 5.2e-8
