@@ -21,6 +21,7 @@ sample of the same event list and the GPU's trigger mask of that sample must equ
 import argparse
 import hashlib
 import json
+import re
 import os
 import sys
 import time
@@ -38,6 +39,12 @@ ENERGY = 3e17                       # shower energy [eV] of a 1 EeV neutrino at 
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s
 FP64_PEAK_TFLOPS = 78.6             # same guide: dense FP64 (vector and matrix alike)
 FLOP_PER_OBJECTIVE = 209.           # one evaluation of the ray finder's objective (analyticraytracing.py:204-272), DESIGN.md section 4
+# general path (config 4), counted per unit of work the kernels report:
+FLOP_PER_ARZ_EVAL = 50.             # one point of the vector-potential integrand (ARZ.py:216-266): retarded time (rsqrt at 1), degree-6
+                                    # form-factor polynomial, direction factors, trapezoid weight and the two accumulations
+FLOP_PER_BIRE_STEP_BIN = 36.        # one 1 m path step on one frequency bin (analyticraytracing.py:2402-2445): two real 2 x 2 by complex
+                                    # products (24), the phase factor on one component (6), the recurrence of the phase (6)
+FLOP_PER_BIRE_STEP = 250.           # one step record: two path points, three splines, effective indices, two eigen-polarisations
 # algorithmic HBM bytes of the un-fused formulation, N = 4096, L = 5296
 B_RAY, B_CHANNEL, B_PAIR = 601216, 169504, 320
 DCUT = [-1.56434411e+02, 2.54131322e+01, -1.34932379e+00, 2.39984185e-02]   # config_default.yaml speedup.distance_cut_coefficients
@@ -598,6 +605,9 @@ def main():
     comm.barrier()
     elapsed = time.perf_counter() - t0
     stats = s
+    if with_traces and is_array and stats.get('n_emit_overflow', 0):
+        raise SystemExit("bench.py: %d station-events found the emit buffer full: their traces were NOT written inside the step"
+                         % stats['n_emit_overflow'])
     sm = {q: v / max(args.steps, 1) for q, v in acc['stage_ms'].items()}   # average per step (arrays: summed over the stations)
 
     elapsed = float(comm.allreduce_max([elapsed])[0])
@@ -641,12 +651,17 @@ def main():
         achieved = alg_bytes / (sm[dom] * 1e-3) / 1e9 if sm[dom] > 0 else 0.
         # HBM bytes per launch from the committed rocprofv3 PMC passes -- quoted only if they were taken on THESE kernel sources
         traffic, traffic_note = None, None
-        pmc = os.environ.get('NRHIP_PMC_JSON', os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json'))
-        if cfgno == 2 and args.flavour == 'had' and n == 1000000 and os.path.exists(pmc):
+        pmc = os.environ.get('NRHIP_PMC_JSON', os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json' if cfgno == 2 else
+                                                            'r05_pmc_traffic_config%d.json' % cfgno))
+        std_size = (cfgno == 2 and args.flavour == 'had' and n == 1000000) or (cfgno == 4 and n == 20000 and args.trigger == 'threshold')
+        if std_size and os.path.exists(pmc):
             pj = json.load(open(pmc))
             if pj.get('source_hash') == source_hash():
-                traffic = pj['kernels'].get(kernel_of[dom].split(' + ')[-1])
-                traffic_note = "from_profile: GB per launch, rocprofv3 PMC passes (%s), kernel sources %s" % (pj.get('file'), pj['source_hash'])
+                # config 2: the (largest) launch of the dominant kernel; arrays: the kernels of the stage summed over one step
+                names = [re.sub(r' .*', '', q) for q in kernel_of[dom].split(' + ')]
+                traffic = pj['kernels'].get(names[-1]) if cfgno == 2 else sum(pj['kernels'].get(q, 0.) for q in names)
+                traffic_note = "from_profile: GB per %s, rocprofv3 PMC passes (%s), kernel sources %s" % (
+                    'launch' if cfgno == 2 else 'step (all launches of the stage\'s kernels)', pj.get('file'), pj['source_hash'])
             else:
                 traffic_note = "the PMC profile was taken on other kernel sources (%s != %s): not quoted" % (
                     pj.get('source_hash'), source_hash())
@@ -672,7 +687,7 @@ def main():
                        "step_includes_traces_of_triggered_events": bool(with_traces),
                        "pass2_ms_traces_of_triggered_events": pass2_ms,
                        "traces_emitted_in_pass1": bool(with_traces and not args.two_pass), "n_emitted_events": stats.get('n_emitted_events'),
-                       "trace_bytes": stats.get('trace_bytes'),
+                       "trace_bytes": stats.get('trace_bytes'), "n_emit_overflow": stats.get('n_emit_overflow', 0),
                        "stage_ms_avg_per_step": {k: round(v, 3) for k, v in sm.items()},
                        "stage_ms_note": ("summed over the stations of the array" + (" and over the %d station lanes that run side by side "
                                          "(the sum exceeds the step)" % n_lanes if n_lanes > 1 else "")) if is_array else None,
@@ -702,6 +717,10 @@ def main():
         # pair) x FLOP_PER_OBJECTIVE (~90 add / mul, 13 divisions and 6 square roots at 1 flop, 1 exp + 4 log at 20)
         flop_of = {'attenuation': stats['n_integrand_evals'] * flop_per_eval, 'channel': flop_channel,
                    'raytrace': stats.get('n_objective_evals', 0) * FLOP_PER_OBJECTIVE}
+        if cfgno == 4:   # emission + propagation of the general path, by the work the kernels counted
+            flop_of['efield_max'] = (stats.get('n_arz_evals', 0) * FLOP_PER_ARZ_EVAL + stats.get('n_bire_step_bins', 0) * FLOP_PER_BIRE_STEP_BIN +
+                                     stats.get('n_bire_steps', 0) * FLOP_PER_BIRE_STEP)
+            out["config"].update({k: stats.get(k, 0) for k in ('n_arz_evals', 'n_bire_steps', 'n_bire_step_bins')})
         out["roofline"]["fp64_frac_by_stage"] = {k: (v / (sm[k] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if sm[k] > 0 else 0.) for k, v in flop_of.items()}
         if dom in flop_of:
             # the quadrature and the channel kernels move next to no HBM bytes (everything lives in registers / LDS): priced in

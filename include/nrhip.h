@@ -380,8 +380,16 @@ typedef struct {
        parameters (type, C1, path length, travel time, vectors) are made as for found ones; everything after the ray tracer is
        unchanged.  This is how the channel traces are compared with the reference's on the reference's OWN rays
        (tests/test_gpu_chain.py::test_reference_rays_through_the_batched_path).  Not with bottom reflections; the second trace
-       of `focusing` still searches (the reference's does).  NULL: the finder runs. */
+       of `focusing` still searches (the reference's does).  NULL: the finder runs.
+       given_D / given_T (with given_C0 only; same layout, NULL or NaN entries = computed): path length [m] and travel time [ns] of the
+       given rays, taken as given instead of evaluated from C0.  The reference's closed forms (analyticraytracing.py:602-783) take
+       sqrt(n(z_turn)^2 - beta^2) of a difference that cancels completely at the turning point of a refracted ray; what is left is
+       rounding noise of the libm in use, 1e-8 relative in D and T (measured against 60-digit arithmetic: either side is exact or
+       1e-8 off, at random), i.e. 1e-4 rad of phase per GHz and km -- traces can be compared with the reference's at 1e-6 only on
+       the reference's own D and T. */
     const double* given_C0;
+    const double* given_D;
+    const double* given_T;
 } nrhip_sim_config;
 #define NRHIP_TRIG_SIMPLE 0
 #define NRHIP_TRIG_HIGH_LOW 1
@@ -408,6 +416,10 @@ typedef struct {
     int64_t n_emitted_events, n_emit_overflow, n_emitted_samples;
     int64_t n_objective_evals;    /* calls of the ray finder's objective delta_y(log C0) (hybrd + Brent, summed over the pairs) */
     int64_t n_adc_convolution_flops;   /* FP64 operations of the chirp convolutions in the phased array's trigger-ADC chain (M (10 log2 M + 18) per M-point convolution) */
+    /* general path (ARZ time-domain emission, birefringence): evaluations of the vector-potential integrand (ARZ.py:216-266, one per
+       profile point and observer time), 1 m path steps whose records were made (analyticraytracing.py:2402-2413), and (path step,
+       frequency bin) pairs the propagation applied (both rounds) */
+    int64_t n_arz_evals, n_bire_steps, n_bire_step_bins;
 } nrhip_sim_stats;
 
 typedef struct nrhip_station nrhip_station;

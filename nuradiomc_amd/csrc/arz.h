@@ -21,6 +21,7 @@ struct ArzBatch {
     double maximum_angle;
     const double* n_index_ray = nullptr;      // [n_rays] index of refraction at the shower (overrides n_index)
     double* form_factor_table = nullptr;      // [ARZ_TABLE_DOUBLES] scratch the launch fills (arz_form_factor_table_kernel); nullptr = none
+    unsigned long long* eval_count = nullptr; // (nullable) += evaluations of the integrand (the FP64 view of bench.py prices the model by them)
 };
 
 // piecewise degree-6 Taylor polynomials of the form factor exp(-|t| / t0) + (1 + f |t|)^e per (shower type, sign of t):

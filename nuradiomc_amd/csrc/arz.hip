@@ -254,6 +254,7 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
     int it_lo = (int)floor((hmin - 20.001 + mean - 0.5 * b.dt) / b.dt), it_hi = (int)ceil((hmax + 20.001 + mean - 0.5 * b.dt) / b.dt);
     it_lo = max(it_lo, 0);
     it_hi = min(it_hi, nt - 1);
+    unsigned n_eval = 0;   // integrand evaluations of this lane
     const int per = (it_hi - it_lo + 1 + ARZ_CHUNKS - 1) / ARZ_CHUNKS;
     const int it_end = min(it_hi + 1, it_lo + (int)(blockIdx.y + 1) * per);
     for (int it = it_lo + blockIdx.y * per + wave; it < it_end; it += n_waves) {
@@ -366,6 +367,7 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
                     const double xl = (j > 0) ? s_depth[n - 1] : (g > 0 ? depth_at(g - 1) : x);
                     const double xr = (j + 1 < nc) ? s_depth[n + 1] : (g + 1 < M ? depth_at(g + 1) : x);
                     double yx, yz;
+                    n_eval++;
                     arz_integrand_fast(r, x, s_ce[n], tobs, nidx, &yx, &yz);
                     const double w = (xr - xl) * (0.5 / ARZ_RHO);
                     ax += w * yx;
@@ -395,6 +397,7 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
                         xr = (g + 1 < M) ? depth_at(g + 1) : x;
                     }
                     double yx, yz;
+                    n_eval++;
                     arz_integrand_fast(r, x, q, tobs, nidx, &yx, &yz);
                     const double w = (xr - xl) * (0.5 / ARZ_RHO);
                     ax += w * yx;
@@ -410,6 +413,10 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
             vp[((long)ray * nt + it) * 2] = ax * factor;
             vp[((long)ray * nt + it) * 2 + 1] = az * factor;
         }
+    }
+    if (b.eval_count) {
+        for (int off = 32; off > 0; off >>= 1) n_eval += __shfl_xor(n_eval, off);
+        if (lane == 0 && n_eval) atomicAdd(b.eval_count, (unsigned long long)n_eval);
     }
 }
 

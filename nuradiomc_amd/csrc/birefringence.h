@@ -19,6 +19,7 @@ struct BireBatch {
     int n_f;
     double sampling_rate;
     double* spline_pieces = nullptr;   // [BIRE_MAX_KNOTS][7] scratch the launch fills (bire_pieces_kernel); nullptr or too many knots: de Boor
+    unsigned long long* counters = nullptr;   // (nullable) [0] += path steps made by bire_steps_kernel, [1] += (step, frequency bin) pairs bire_propagate_kernel applied
 };
 #define BIRE_MAX_KNOTS 96
 

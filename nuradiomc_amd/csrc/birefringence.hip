@@ -442,6 +442,7 @@ bire_propagate_kernel(BireBatch b, const double* __restrict__ steps, double2* __
             if (k < n_f) { st[k] = et[j]; st[n_f + k] = ep[j]; }
         }
     }
+    if (b.counters && tid == 0 && n_steps > 0) atomicAdd(&b.counters[1], (unsigned long long)n_steps * (unsigned long long)n_f);
 }
 
 void launch_birefringence_steps(hipStream_t s, const BireBatch& b, int max_points, double* steps, long long* log_norm)

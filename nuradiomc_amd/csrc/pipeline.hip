@@ -835,6 +835,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (n_slots > 2000000000L) return nrhip_fail_msg("nrhip_simulate_events: batch too large, split the event list");
     S.n_pairs = n_pairs;
     unsigned long long* rt_eval_counter = nullptr;
+    unsigned long long* general_counters = nullptr;   // [0] ARZ integrand evaluations, [1] (step, bin) pairs of the birefringent propagation
     // general path with birefringence, production mode: the propagation in two rounds (see "two rounds" below)
     bool two_rounds = false;
     BireBatch bb_keep{};
@@ -926,7 +927,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             NEED(rt_eval_counter = WS("rt_eval_counter", unsigned long long, 1));
             HIPCHK(hipMemsetAsync(rt_eval_counter, 0, sizeof(unsigned long long), sm));
         }
-        launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm, cfg->given_C0, rt_eval_counter);
+        launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm, cfg->given_C0, rt_eval_counter,
+                        cfg->given_D, cfg->given_T);
         LCHK("raytrace");
     }
     MARK(1);
@@ -1248,6 +1250,10 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(g_prof = WS("gen_profile", int, nr));
         NEED(g_nsteps = WS("gen_n_steps", int, nr));
         NEED(g_npoints = WS("gen_n_points", int, nr));
+        if (stats) {   // work counters of the emission / propagation kernels (bench.py prices the stage by them)
+            NEED(general_counters = WS("general_counters", unsigned long long, 2));
+            HIPCHK(hipMemsetAsync(general_counters, 0, 2 * sizeof(unsigned long long), sm));
+        }
         launch_general_gather(sm, n_rays, n_ch, w, evin, sd, vertex, arz ? st->d_shower_profile.as<int>() : nullptr,
                               arz ? st->d_shower_rescale.as<double>() : nullptr, st->arz_em_formula, g_energy, g_type, g_em,
                               g_prof, g_resc, g_x1, g_x2, g_nsteps, g_npoints);
@@ -1264,6 +1270,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                         st->d_arz_depth.as<double>(), st->d_arz_ce.as<double>(), st->d_arz_par.as<double>(), sd.N, 1. / sd.fs,
                         1.78, st->arz_interp_factor2, 0, 20. * 0.017453292519943295, w.n_index};
             NEED(ab.form_factor_table = WS("arz_form_factor_table", double, (size_t)ARZ_TABLE_DOUBLES));
+            ab.eval_count = general_counters;
             launch_arz(sm, ab, vp, atr, ast);
             LCHK("arz");
             // rays beyond the model's 20 degrees carry no signal: no path steps for them (half of config 4's rays)
@@ -1299,6 +1306,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                          st->d_bire_coeffs.as<double>(), {st->bire_n_knots[0], st->bire_n_knots[1], st->bire_n_knots[2]},
                          st->bire_n_ref, st->bire_angle, n_f, sd.fs};
             NEED(bb.spline_pieces = WS("bire_spline_pieces", double, (size_t)BIRE_MAX_KNOTS * 7));
+            bb.counters = general_counters;
+            S.n_bire_steps = (int64_t)off[nr];
             // the gain of the whole path is bounded by the product of the steps' ||R||^2: events none of whose rays can exceed
             // the candidate cut even so skip the propagation (result-neutral, like the bounds of the parametrised path)
             long long* log_gain;  // fixed point, BIRE_LOG_FIXED
@@ -1759,6 +1768,13 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             HIPCHK(hipMemcpyAsync(&ne, rt_eval_counter, sizeof ne, hipMemcpyDeviceToHost, sm));
             HIPCHK(hipStreamSynchronize(sm));
             S.n_objective_evals = (int64_t)ne;
+        }
+        if (general_counters) {
+            unsigned long long gc[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(gc, general_counters, sizeof gc, hipMemcpyDeviceToHost, sm));
+            HIPCHK(hipStreamSynchronize(sm));
+            S.n_arz_evals = (int64_t)gc[0];
+            S.n_bire_step_bins = (int64_t)gc[1];
         }
         if (eval_counter) {
             unsigned long long ne = 0;

@@ -153,7 +153,8 @@ raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double*
 #endif
 __global__ void __launch_bounds__(256, NRHIP_RTREC_WAVES)
 raytrace_records_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
-                        IceConst m, RayRecords out, const double* __restrict__ given_C0)
+                        IceConst m, RayRecords out, const double* __restrict__ given_C0, const double* __restrict__ given_D,
+                        const double* __restrict__ given_T)
 {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_pairs; i += (long)gridDim.x * blockDim.x) {
         const long i1 = (n_ch > 0) ? i / n_ch : i;
@@ -167,17 +168,18 @@ raytrace_records_kernel(long n_pairs, const double* __restrict__ x1, const doubl
         const double cph = g.cph, sph = g.sph;
         int ns;
         double c0v[NRHIP_MAXS];
+        int src0 = 0, src1 = 1;   // which given slot each solution came from (given_D / given_T are indexed like given_C0)
         if (given_C0) {  // ray_tracing.set_solution (:2092): launch parameters read back from a file, no root finding
             ns = 0;
             double c0a = NAN, c0b = NAN;
             for (int k = 0; k < NRHIP_MAXS; k++) {   // (NRHIP_MAXS = 2 slots)
                 double v = given_C0[i * NRHIP_MAXS + k];
                 if (!isnan(v)) {
-                    if (ns == 0) c0a = v; else c0b = v;
+                    if (ns == 0) { c0a = v; src0 = k; } else { c0b = v; src1 = k; }
                     ns++;
                 }
             }
-            if (ns > 1 && c0b < c0a) { double t = c0a; c0a = c0b; c0b = t; }
+            if (ns > 1 && c0b < c0a) { double t = c0a; c0a = c0b; c0b = t; int q = src0; src0 = src1; src1 = q; }
             c0v[0] = c0a;
             c0v[1] = c0b;
             out.n_sol[i] = ns;
@@ -204,6 +206,11 @@ raytrace_records_kernel(long n_pairs, const double* __restrict__ x1, const doubl
             ray_sincos(p.y2, p.z2, st, C1, p, m, &s2, &c2);  // receive angle = pi - this one (:1198)
             double D, T;
             path_length_time(st, C1, type, sL, p, m, &D, &T);
+            // given path lengths / travel times (the reference's own numbers for its rays: its closed forms take the square root
+            // of a fully cancelling difference at the turning point, 1e-8 of rounding noise in T that no second implementation
+            // reproduces and that is a 1e-4 phase at 500 MHz -- DESIGN section 2)
+            if (given_D) { const double v = given_D[i * NRHIP_MAXS + (s ? src1 : src0)]; if (!isnan(v)) D = v; }
+            if (given_T) { const double v = given_T[i * NRHIP_MAXS + (s ? src1 : src0)]; if (!isnan(v)) T = v; }
             // 2-D -> 3-D via R^T (:2560-2624); for swapped end points launch and receive exchange roles
             double lv0 = sL, lv2 = cL, rv0 = -s2, rv2 = -c2;
             if (swap) {
@@ -271,7 +278,7 @@ void launch_event_perm(hipStream_t stream, int n_events, const int* cell, int* c
 
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
                      const IceConst& m, const RayRecords& out, const double* max_dist, const int* perm, const double* given_C0,
-                     unsigned long long* eval_count)
+                     unsigned long long* eval_count, const double* given_D, const double* given_T)
 {
     if (n_pairs <= 0) return;
     int block = 256;
@@ -279,7 +286,8 @@ void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const d
     if (grid > 256L * 64) grid = 256L * 64;
     if (!given_C0)
         hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count);
-    hipLaunchKernelGGL(raytrace_records_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, given_C0);
+    hipLaunchKernelGGL(raytrace_records_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, given_C0,
+                       given_C0 ? given_D : nullptr, given_C0 ? given_T : nullptr);
 }
 
 }  // namespace nrhip

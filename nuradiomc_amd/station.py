@@ -83,7 +83,8 @@ class SimConfig(ctypes.Structure):
                 ('noise', ctypes.c_int32), ('noise_seed', ctypes.c_uint64), ('noise_group_offset', ctypes.c_int64),
                 ('noise_group_id', ctypes.c_void_p), ('custom_polarization', ctypes.c_int32),
                 ('polarization_ephi', ctypes.c_double), ('emit_triggered_traces', ctypes.c_int32),
-                ('emit_capacity_samples', ctypes.c_int64), ('given_C0', ctypes.c_void_p)]
+                ('emit_capacity_samples', ctypes.c_int64), ('given_C0', ctypes.c_void_p), ('given_D', ctypes.c_void_p),
+                ('given_T', ctypes.c_void_p)]
 
 
 class SimStats(ctypes.Structure):
@@ -92,14 +93,16 @@ class SimStats(ctypes.Structure):
                                               'n_integrand_evals', 'n_channel_transforms', 'n_ray_transforms',
                                               'n_efield_transforms')] + \
                [('max_length', ctypes.c_int32), ('n_sub_events', ctypes.c_int32), ('stage_ms', ctypes.c_double * 9)] + \
-               [(k, ctypes.c_int64) for k in ('n_emitted_events', 'n_emit_overflow', 'n_emitted_samples', 'n_objective_evals', 'n_adc_convolution_flops')]
+               [(k, ctypes.c_int64) for k in ('n_emitted_events', 'n_emit_overflow', 'n_emitted_samples', 'n_objective_evals', 'n_adc_convolution_flops',
+                                              'n_arz_evals', 'n_bire_steps', 'n_bire_step_bins')]
 
     STAGES = ('raytrace', 'ray_setup', 'amp_bound', 'attenuation', 'efield_max', 'event_grid', 'length_tables', 'channel',
               'total')
 
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_[:15]}
-        d.update({k: int(getattr(self, k)) for k in ('n_emitted_events', 'n_emit_overflow', 'n_emitted_samples', 'n_objective_evals', 'n_adc_convolution_flops')})
+        d.update({k: int(getattr(self, k)) for k in ('n_emitted_events', 'n_emit_overflow', 'n_emitted_samples', 'n_objective_evals', 'n_adc_convolution_flops',
+                                                     'n_arz_evals', 'n_bire_steps', 'n_bire_step_bins')})
         d['stage_ms'] = {n: float(self.stage_ms[i]) for i, n in enumerate(self.STAGES)}
         return d
 
@@ -565,7 +568,8 @@ class Station:
                             accumulate_triggered=False, n_reflections=0, z_reflection=0., reflection_coefficient=1.,
                             reflection_phase_shift=0., split_event_time_diff=0., noise=False, noise_seed=0, noise_group_offset=0,
                             polarization='auto', ePhi=0.,
-                            d_noise_group_id=None, emit_traces=False, emit_capacity_samples=0, d_given_C0=None):
+                            d_noise_group_id=None, emit_traces=False, emit_capacity_samples=0, d_given_C0=None, d_given_D=None,
+                            d_given_T=None):
         """Device-pointer form (ints): everything stays in HBM.  Returns the stats dict (or None).
         Event groups of several showers: d_group_begin = device int32 [n_groups + 1] (first shower of every group),
         d_triggered then has n_groups entries; d_vertex_time = device f64 [n_events] or None.
@@ -588,7 +592,8 @@ class Station:
         them; stats['n_emitted_events'] == stats['n_triggered'] and stats['n_emit_overflow'] == 0 say that every triggered event
         got its block (otherwise run those through dump_traces / triggered_pass_dev).
         d_given_C0: device f64 [n_events * n_channels][2] (NaN = none) -- the rays' launch parameters are GIVEN (set_solution,
-        analyticraytracing.py:2092), the root search does not run (nrhip_sim_config.given_C0)."""
+        analyticraytracing.py:2092), the root search does not run (nrhip_sim_config.given_C0); d_given_D / d_given_T (same layout):
+        their path lengths / travel times taken as given, too."""
         if polarization not in ('auto', 'custom'):   # simulation.py:827-829
             raise ValueError("{} for config.signal.polarization is not a valid option".format(polarization))
         if trigger not in ('simple', 'high_low', 'phased_array', 'envelope'):
@@ -604,7 +609,7 @@ class Station:
                         float(z_reflection), float(reflection_coefficient), float(reflection_phase_shift),
                         float(split_event_time_diff or 0.), int(bool(noise)), int(noise_seed) & 0xffffffffffffffff,
                         int(noise_group_offset), d_noise_group_id, int(polarization == 'custom'), float(ePhi),
-                        int(bool(emit_traces)), int(emit_capacity_samples), d_given_C0)
+                        int(bool(emit_traces)), int(emit_capacity_samples), d_given_C0, d_given_D, d_given_T)
         stats = SimStats()
         L.check(self._lib.nrhip_simulate_event_groups(
             self.ctx._h, self._h, ctypes.byref(cfg), int(n_events), d_vertex, d_zenith, d_azimuth, d_energy, d_type, d_kL,
@@ -665,7 +670,7 @@ class Station:
 
     def simulate_events(self, vertex, zenith, azimuth, energy, shower_type, k_L=None, vertex_time=None, group_id=None,
                         distance_cut_coefficients=None, distance_cut_sum_length=10., arz_iN=None, max_showers_per_call=None,
-                        seed=None, rng=None, given_C0=None, **kw):
+                        seed=None, rng=None, given_C0=None, given_D=None, given_T=None, **kw):
         """Host-array convenience form: uploads the shower list, runs the hot path, returns (triggered mask, stats).
         Long lists are cut into calls of at most `max_showers_per_call` showers at event-group boundaries (default: what
         keeps the per-call tables near 40 GB: ~1.2e7 (shower, channel) pairs, 2.5e5 with ARZ / birefringence, whose rays carry
@@ -680,7 +685,8 @@ class Station:
         RandomState(seed), the second pass reuses the ray tables; stats['k_L'] / stats['arz_iN'] return what was used.  Without
         a seed missing values are an error (the reference never runs an EM shower with k_L = 1).
         given_C0 [n, n_channels, 2] (NaN = none): the launch parameters of the rays are given (ray_tracing.set_solution), the
-        root search does not run -- e.g. the reference's own rays."""
+        root search does not run -- e.g. the reference's own rays; given_D / given_T (same shape, NaN = computed): their path
+        lengths and travel times as given (nrhip_sim_config.given_D)."""
         ctx = self.ctx
         vertex = L.f64(vertex).reshape(-1, 3)
         n = len(vertex)
@@ -691,6 +697,7 @@ class Station:
             rng = np.random.RandomState(seed)
         if given_C0 is not None:
             given_C0 = np.ascontiguousarray(L.f64(given_C0).reshape(n, len(self.position), 2))
+            given_D, given_T = (None if a is None else np.ascontiguousarray(L.f64(a).reshape(n, len(self.position), 2)) for a in (given_D, given_T))
             max_showers_per_call = max(max_showers_per_call, n)   # (one call: the table is indexed by the shower)
         if n > max_showers_per_call:
             return self._simulate_in_chunks(int(max_showers_per_call), vertex, zenith, azimuth, energy, shower_type, k_L,
@@ -732,9 +739,9 @@ class Station:
                 np.ascontiguousarray(np.where(np.isnan(kL), 1.0, kL))]
         dptrs = [ctx.to_device(a) for a in arrs]
         dtrig = ctx.malloc(max(n_groups, 1))
-        extra = [ctx.to_device(a) if a is not None else None for a in (vt, gb, md, given_C0)]
+        extra = [ctx.to_device(a) if a is not None else None for a in (vt, gb, md, given_C0, given_D, given_T)]
         dev_kw = dict(d_vertex_time=extra[0], n_groups=n_groups, d_group_begin=extra[1], d_max_distance=extra[2],
-                      d_given_C0=extra[3])
+                      d_given_C0=extra[3], d_given_D=extra[4], d_given_T=extra[5])
         if kw.get('noise'):   # the noise of an event group is keyed by its id: the caller's group ids, else the running index
             off = int(kw.pop('noise_group_offset', 0))
             ids = gid[first] if group_id is not None and n else np.arange(n_groups) + off

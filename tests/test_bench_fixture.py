@@ -97,16 +97,21 @@ def test_gpu_vs_reference_on_the_bench_list(gpu_ctx_factory, production):
 
 
 @pytest.mark.gpu
-def test_gpu_on_the_reference_rays_of_the_bench_list(gpu_ctx_factory):
-    """The headline workload on the reference's OWN rays: the 81 433 launch parameters the reference found for
-    the first 24 000 events of the bench list go into the batched path (nrhip_sim_config.given_C0); decisions exact on all 24 000
-    events, channel maxima of all 2014 candidate events, path lengths and field maxima at 1e-6 against the reference's numbers."""
+@pytest.mark.parametrize('given', ['C0', 'C0+D+T'])
+def test_gpu_on_the_reference_rays_of_the_bench_list(gpu_ctx_factory, given):
+    """The headline workload on the reference's OWN rays: the 81 433 rays the reference found for the first
+    24 000 events of the bench list go into the batched path (nrhip_sim_config.given_C0 [+ given_D / given_T]); decisions exact on
+    all 24 000 events; with the launch parameters alone path lengths / travel times to 2.5e-7 and channel maxima to the reference's
+    own rounding noise in T (tests/test_gpu_chain.py::test_reference_rays_through_the_batched_path), with its D and T as well the
+    channel maxima of all 2014 candidate events at 1e-6 against the reference's numbers."""
     from test_gpu_chain import reference_rays_table, check_against_reference_on_its_rays
     g, K = _fixture()
     ctx = gpu_ctx_factory(bench.ICE, 'SP1')
     st = bench.build_array(ctx, bench.make_workload(2, 1000, 10))
-    given, ref_rays = reference_rays_table(g, K, len(bench.CHANNELS))
+    tab, ref_rays = reference_rays_table(g, K, len(bench.CHANNELS))
+    kw = dict(given_C0=tab[0]) if given == 'C0' else dict(given_C0=tab[0], given_D=tab[1], given_T=tab[2])
     trig, stats = st.simulate_events(g['vertex'], g['zenith'], g['azimuth'], np.full(K, bench.ENERGY), np.zeros(K, np.int32),
-                                     np.ones(K), dump_traces=True, no_pruning=True, given_C0=given)
-    worst, _ = check_against_reference_on_its_rays(g, st, trig, stats, K, ref_rays, 'bench list')
+                                     np.ones(K), dump_traces=True, no_pruning=True, **kw)
+    tol, tol_path = (5e-4, 2.5e-7) if given == 'C0' else (1e-6, 1e-9)
+    worst, _ = check_against_reference_on_its_rays(g, st, trig, stats, K, ref_rays, 'bench list given ' + given, tol, tol_path)
     assert int(trig.sum()) == 222 and stats['n_candidate_events'] == 2014

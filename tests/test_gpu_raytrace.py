@@ -8,12 +8,15 @@ from test_oracle_golden import _subset_ok
 pytestmark = pytest.mark.gpu
 
 
-def _compare_ray_tables(o, g, count_tol=0.003):
-    """against the reference's outputs: the reference's own first-root noise applies (tests/test_oracle_golden.py)"""
+def _compare_ray_tables(o, g, count_tol=0.008):
+    """against the reference's outputs.  Since round 5 the kernels hold the TRUE solution set (tests/test_true_roots.py): a count
+    differs only where the reference lost a root to its `fun < 1e-7` test (observed 0.2 % on fixture A, 0 on B, 0.4 % on C), and
+    every solution of the reference is one of the GPU's"""
     bad = o['n_sol'] != g['n_sol']
     assert bad.mean() <= count_tol, "solution-count mismatches: %d of %d" % (bad.sum(), len(bad))
     for i in np.where(bad)[0]:
-        assert _subset_ok(o['C0'][i], g['C0'][i])
+        assert o['n_sol'][i] > g['n_sol'][i]
+        assert _subset_ok(g['C0'][i], o['C0'][i])
     ok = ~bad
     assert np.array_equal(o['type'][ok], g['type'][ok])
     assert max_rel(o['C0'][ok], g['C0'][ok]) < 1.1e-7   # observed 5.2e-8

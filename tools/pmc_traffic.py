@@ -24,10 +24,28 @@ def largest_launch(path, counter):
     return g.groupby('k').Counter_Value.max(), g.groupby('k').Dispatch_Id.nunique()
 
 
+def summed_launches(path, counter, n_steps):
+    """arrays (--per-step K: the profiled command made K passes over the list, warm-up included): all launches of a kernel summed,
+    divided by K -- the kernel's HBM bytes per step"""
+    d = pd.read_csv(path)
+    d = d[d.Counter_Name == counter].copy()
+    d['k'] = [re.sub(r'^.*::', '', re.sub(r'[<(].*', '', k.replace('void ', ''))) for k in d.Kernel_Name]
+    return d.groupby('k').Counter_Value.sum() / n_steps, d.groupby('k').Dispatch_Id.nunique()
+
+
 def main():
     import bench
-    f, nf = largest_launch(sys.argv[1], 'FETCH_SIZE')
-    w, _ = largest_launch(sys.argv[2], 'WRITE_SIZE')
+    per_step = None
+    if '--per-step' in sys.argv:
+        i = sys.argv.index('--per-step')
+        per_step = float(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
+    if per_step:
+        f, nf = summed_launches(sys.argv[1], 'FETCH_SIZE', per_step)
+        w, _ = summed_launches(sys.argv[2], 'WRITE_SIZE', per_step)
+    else:
+        f, nf = largest_launch(sys.argv[1], 'FETCH_SIZE')
+        w, _ = largest_launch(sys.argv[2], 'WRITE_SIZE')
     names = sorted(set(f.index) | set(w.index), key=lambda k: -(2 * f.get(k, 0) + w.get(k, 0)))
     rows = [(k, f.get(k, 0.), w.get(k, 0.), (2 * f.get(k, 0.) + w.get(k, 0.)) * 1024, int(nf.get(k, 0))) for k in names]
     base = sys.argv[3]
@@ -39,7 +57,8 @@ def main():
         for r in rows:
             o.write('%s,%.1f,%.1f,%d,%d\n' % r)
     json.dump({'source_hash': bench.source_hash(), 'file': os.path.basename(base) + '.csv',
-               'unit': 'GB per launch (largest launch), (2 FETCH_SIZE + WRITE_SIZE) KB x 1024',
+               'unit': ('GB per step (all launches of the kernel in one pass over the list)' if per_step else 'GB per launch (largest launch)') +
+                       ', (2 FETCH_SIZE + WRITE_SIZE) KB x 1024',
                'kernels': {r[0]: round(r[3] / 1e9, 4) for r in rows}}, open(base + '.json', 'w'), indent=1)
     print(open(base + '.csv').read())
 
