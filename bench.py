@@ -474,6 +474,7 @@ def main():
     ap.add_argument('--flavour', default='had', choices=['had', 'mixed'])
     ap.add_argument('--events', type=int, default=None, help='event groups per rank and step (weak) or in total (strong)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--chunk', type=int, default=20000, help='config 4: events per call of the general path (spectra and traces of every ray are resident: ~380 KB per ray)')
     ap.add_argument('--cpu-budget', type=float, default=12., help='seconds of CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--device', type=int, default=None, help='GPU index of this rank (default: LOCAL_RANK)')
@@ -571,11 +572,40 @@ def main():
     # events that trigger there into its buffer; a caller keeps them per station through on_station)
     with_traces = (cfgno == 2 or (cfgno == 3 and args.trigger == 'threshold')) and not args.no_traces
 
+    # config 4 keeps spectra and traces per ray (~380 KB): a list longer than --chunk events (a 1.25e6-event shard of BASELINE
+    # configs[3]) is walked in chunks of the RESIDENT list -- pointer offsets, no copies; the counters add up, the mask fills in place
+    chunk4 = args.chunk if (cfgno == 4 and n > args.chunk) else None
+    if chunk4 and (d['gb'] is not None):
+        raise SystemExit("bench.py: --config 4 in chunks needs one shower per event group (--flavour had)")
+
+    def step_chunked():
+        from nuradiomc_amd.array import _add_stats
+        total = None
+        for a in range(0, n, chunk4):
+            b = min(n, a + chunk4)
+            ins = [d['in'][0] + 24 * a, d['in'][1] + 8 * a, d['in'][2] + 8 * a, d['in'][3] + 8 * a, d['in'][4] + 4 * a, d['in'][5] + 8 * a]
+            kw_c = dict(dev_kw, n_groups=b - a, d_max_distance=None if d['md'] is None else d['md'] + 8 * a,
+                        arz_rows=tuple(np.ascontiguousarray(r[a:b]) for r in dev_kw['arz_rows']))
+            s_ = det.simulate_events_dev(b - a, *ins, d['trig'] + a, want_stats=True, **kw_c)
+            if total is None:
+                total = dict(s_)
+                total['stage_ms'] = dict(s_['stage_ms'])
+                total['n_events'], total['n_triggered'] = 0, 0
+            else:
+                nt = total['n_triggered']
+                _add_stats(total, s_)
+                total['n_triggered'] = nt
+            total['n_triggered'] += s_['n_triggered']
+            total['n_events'] = b
+        return total
+
     def step():
         """one pass of the hot path over the resident list; config 2: including the channel traces of the triggered events, what
         the reference writes for them -- the convolution kernel emits all channels of an event the moment it triggers
         (emit_traces); only if an event could not be served that way (buffer full, event decided by another kernel) a second pass
         over the triggered groups (gathered in HBM, dump_traces) follows"""
+        if chunk4:
+            return step_chunked()
         s1 = det.simulate_events_dev(n, *d['in'], d['trig'], want_stats=True, emit_traces=with_traces and not args.two_pass, **dev_kw)
         if with_traces:
             s1['pass2_ms'] = 0.
