@@ -30,7 +30,8 @@ struct RayRecords {
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
                      const IceConst& m, const RayRecords& out, const double* max_dist = nullptr,
                      const int* perm = nullptr, const double* given_C0 = nullptr, unsigned long long* eval_count = nullptr,
-                     const double* given_D = nullptr, const double* given_T = nullptr);
+                     const double* given_D = nullptr, const double* given_T = nullptr, bool maybe_deep = true,
+                     bool reference_procedure = false);
 // ---- reflections off the bottom of an ice shelf (raytrace_refl.hip) ----
 #define NRHIP_MAX_REFLECTIONS 4
 struct ReflRecords {   // [n_pairs][2 + 4 n_reflections]

