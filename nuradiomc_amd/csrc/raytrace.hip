@@ -108,7 +108,7 @@ raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double*
             // either side of it, 1e-4 away (:1498-1541).  Round 5: where that test fails although delta y changes its sign
             // between the two points 1e-4 either side -- delta y is continuous in log C0, so there IS a root between them, the
             // one the iteration was after -- the root is taken from that bracket (the TRUE solution set: DESIGN section 2,
-            // oracle/nrmc_oracle.c, tools/true_roots.py).  The (at most three) brackets of a lane are searched one after the
+            // tools/true_roots.py).  The (at most three) brackets of a lane are searched one after the
             // other by ONE call site of Brent's method: a wave spends the longest lane's searches, not the sum over the kinds.
             const double d_hi = dy(xr + 0.0001), d_top = dy(100.), d_bot = dy(-100.), d_lo = dy(xr - 0.0001);
             unsigned todo = 0;
@@ -150,13 +150,23 @@ raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double*
     }
 }
 
-// ---- the finder without the hybr stage (round 5; oracle/nrmc_oracle.c find_solutions_bracketed states the why) ---------------
-// delta_y = min(u, v) wherever the turning point lies above the receiver: u (the way up) rises monotonically with the launch
-// parameter, v (the way down / after the surface) has one maximum.  Every root comes out of a bracket by Brent's method, in
-// t = sqrt(log C0 - x_lo); ~21 evaluations per pair instead of ~62, one logarithm fewer per evaluation (the depth of the turning
-// point is never needed: the clamp at the surface is a comparison of gammas), and no root is lost to an acceptance test.
-// Pairs whose receiver lies deeper than 10 z_0 (n(z) = n_ice to 1e-5: x_lo ill-conditioned) are flagged (n_sol = -1) and left to
-// raytrace_roots_kernel, the reference's procedure.
+// ---- the finder without the hybr stage (round 5; DESIGN section 2, "the true solution set") ---------------------------------
+// delta_y(log C0) of analyticraytracing.py:204-272 is min(u, v) wherever the ray's turning point lies above the receiver:
+//     u = x2.y - y(z2)                the receiver's offset from the ray on its way UP to the turning point,
+//     v = (2 y_turn - y(z2)) - x2.y   the same on its way DOWN (mirrored branch, or after the reflection at the surface);
+// u rises monotonically with C0 (a steeper launch reaches the receiver's depth earlier), v rises to ONE maximum -- the farthest
+// point any ray reaches at that depth -- and falls (both checked on 1e6 random pairs in three ice models, tools/root_shapes.py).
+// So the solutions are: the root of u (the direct ray) and the root of v beyond its maximum when the ray that turns AT the
+// receiver's depth overshoots the receiver (v > 0 there); else the two roots of v either side of its maximum if that is
+// positive; else none.  The reference looks for the same roots with scipy.optimize.root on (delta_y)^2 from log C0 = -1 --
+// ~37 evaluations creeping onto a double root, stopped 1e-7 away from it and kept by a coin flip (:1479-1483) -- and two Brent
+// searches either side of where that stopped.  Here every root comes out of a bracket, by the same Brent's method, to 2e-12:
+// ~21 evaluations per pair instead of ~62, one logarithm fewer per evaluation (the depth of the turning point is never needed:
+// the clamp at the surface is a comparison of gammas), and no root is lost to an acceptance test.
+// Searches run in t = sqrt(log C0 - x_lo), x_lo = log(1 / n(z2) - 1 / n_ice) the launch parameter of the ray that turns at the
+// receiver's depth: u and v start like sqrt(log C0 - x_lo) there.  Pairs whose receiver lies deeper than 10 z_0 (n(z) = n_ice
+// to 1e-5: x_lo ill-conditioned; no detector is there) are flagged (n_sol = -1) and left to raytrace_roots_kernel, the
+// reference's procedure.
 #define NRHIP_T_START 3e-5
 #define NRHIP_SHALLOW 4.5399929762484854e-05   // exp(-10)
 

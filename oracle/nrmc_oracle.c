@@ -1657,7 +1657,11 @@ void orc_raytrace_batch_refl(long n, const double *x1, const double *x2, const d
             int ty[64], rf[64], rc[64], ns = 0;
             for (int r = 0; r <= n_reflections; r++)
                 for (int cs = 1; cs <= (r == 0 ? 1 : 2); cs++) {
+                    /* with a reflective layer every call -- the plain one included -- is the reference's procedure (find_refl_kernel) */
+                    const int keep = orc_reference_procedure;
+                    orc_reference_procedure = 1;
                     int k = orc_find_solutions_2d_refl(g.x1, g.x2, ice, r, cs, z_refl, c0 + ns, c1 + ns, ty + ns, NULL, NULL, NULL);
+                    orc_reference_procedure = keep;
                     for (int j = 0; j < k; j++) { rf[ns + j] = r; rc[ns + j] = cs; }
                     ns += k;
                 }
@@ -1742,4 +1746,32 @@ double orc_delta_y(double logC0, const double x1[2], const double x2[2], const d
 {
     ice_t m = { ice[0], ice[1], ice[2] };
     return get_delta_y(C0_from_log(logC0, &m), x1, x2, &m);
+}
+
+/* u, v of find_solutions_bracketed on a grid of log C0 (tools/root_shapes.py checks the monotony of u and the single maximum of v) */
+void orc_uv_grid(int n, const double *logC0, const double x1[2], const double x2[2], const double ice[3], double *u, double *v)
+{
+    ice_t m = { ice[0], ice[1], ice[2] };
+    uv_t o = { x1, x2, &m, 0, 0., get_gamma(x1[1], &m), get_gamma(x2[1], &m) };
+    for (int i = 0; i < n; i++) {
+        if (logC0[i] < 0 && 0) continue;
+        o.x_lo = logC0[i];   /* t = 0: the point itself */
+        uv_at(0., &o, u + i, v + i);
+    }
+}
+
+/* both finders on 2-D pairs (tests): n_sol and sorted C0 [n][3], objective evaluations per pair */
+void orc_find_solutions_2d_batch(long n, const double *x1, const double *x2, const double ice[3], int reference_procedure,
+                                 int *n_sol, double *C0, int *nfev)
+{
+    const int keep = orc_reference_procedure;
+    orc_reference_procedure = reference_procedure;
+    for (long i = 0; i < n; i++) {
+        double c[3], c1[3];
+        int t[3];
+        int k = orc_find_solutions_2d(x1 + 2 * i, x2 + 2 * i, ice, c, c1, t, NULL, NULL, nfev + i);
+        n_sol[i] = k;
+        for (int j = 0; j < 3; j++) C0[3 * i + j] = j < k ? c[j] : NAN;
+    }
+    orc_reference_procedure = keep;
 }

@@ -45,6 +45,10 @@ def lib():
         _lib.orc_attenuation_batch_refl.restype = None
         _lib.orc_attenuation_length.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int]
         _lib.orc_attenuation_length.restype = ctypes.c_double
+        _lib.orc_find_solutions_2d_batch.argtypes = [ctypes.c_long, _dp, _dp, _dp, ctypes.c_int, _ip, _dp, _ip]
+        _lib.orc_find_solutions_2d_batch.restype = None
+        _lib.orc_uv_grid.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
+        _lib.orc_uv_grid.restype = None
     return _lib
 
 
@@ -178,3 +182,22 @@ def focusing(x1, x2, ice, dz=-0.01, limit=2., reflections=None):
                 f = limit
             out[i, s] = f * (n_index(x1[i, 2]) / n_index(x2[i, 2])) ** 0.5
     return out
+
+
+def find_solutions_2d_batch(x1, x2, ice, reference_procedure=False):
+    """ray_tracing_2D.find_solutions on 2-D pairs (y, z) -> (n_sol [n], C0 [n, 3] sorted, objective evaluations [n]); reference_procedure:
+    hybr + two Brent searches (analyticraytracing.py:1477-1547) instead of the bracketed finder"""
+    x1 = np.ascontiguousarray(x1, float).reshape(-1, 2)
+    x2 = np.ascontiguousarray(x2, float).reshape(-1, 2)
+    n = len(x1)
+    ns, c0, nf = np.zeros(n, np.int32), np.full((n, 3), np.nan), np.zeros(n, np.int32)
+    lib().orc_find_solutions_2d_batch(n, _d(x1), _d(x2), _d(np.ascontiguousarray(ice, float)), int(bool(reference_procedure)), _i(ns), _d(c0), _i(nf))
+    return ns, c0, nf
+
+
+def uv_grid(logC0, x1, x2, ice):
+    """u and v of the bracketed finder at the given log C0 (2-D pair)"""
+    x = np.ascontiguousarray(logC0, float)
+    u, v = np.empty_like(x), np.empty_like(x)
+    lib().orc_uv_grid(len(x), _d(x), _d(np.ascontiguousarray(x1, float)), _d(np.ascontiguousarray(x2, float)), _d(np.ascontiguousarray(ice, float)), _d(u), _d(v))
+    return u, v

@@ -196,7 +196,34 @@ def test_bottom_reflections_vs_reference_table_and_oracle(gpu_ctx_factory):
     # n_reflections = 0 reproduces the plain solution finder
     p = ctx.find_solutions_batch(g['points'][:300], x2[:300])
     q = ctx.find_solutions_reflections_batch(g['points'][:300], x2[:300], 0, zr)
-    for k in ('n_sol', 'type', 'C0', 'C1', 'D', 'T', 'launch', 'receive', 'refl_angle'):
-        assert np.array_equal(p[k], q[k], equal_nan=True), k
+    # (to the 1e-7 of the reference's first root: with a reflective layer every call is the reference's procedure -- hybr + two Brent
+    # searches --, the plain finder takes every root from a bracket since round 5; counts agree unless the procedure loses a root)
+    same = p['n_sol'] == q['n_sol']
+    assert same.mean() >= 0.99 and np.all(p['n_sol'] >= q['n_sol'])
+    assert np.array_equal(p['type'][same], q['type'][same])
+    for k in ('C0', 'D', 'T'):
+        assert max_rel(p[k][same], q[k][same]) < (2e-7 if k == 'C0' else 1e-6), k
+    for k in ('launch', 'receive'):
+        assert np.nanmax(np.abs(p[k][same] - q[k][same])) < 4e-7, k
     with pytest.raises(Exception, match='reflective layer'):
         ctx.find_solutions_reflections_batch(g['points'][:2], x2[:2], 1, 0.)
+
+
+def test_deep_receivers_keep_the_reference_procedure(gpu_ctx_factory):
+    """Pairs whose upper end point lies deeper than 10 z_0 are flagged by the finder without the hybr stage and served by the
+    reference's procedure in a second launch (raytrace_roots_kernel, only_flagged): a list that mixes shallow and deep receivers
+    equals the oracle's tables bit for bit, which takes the same decision per pair."""
+    ice = (1.78, 0.51, 37.25)   # greenland_simple: 10 z_0 = 372.5 m
+    rng = np.random.default_rng(77)
+    n = 6000
+    r, ph = np.sqrt(rng.uniform(0, 3000. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    x1 = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-2700, -1., n)], axis=1)
+    x2 = np.stack([rng.uniform(-50, 50, n), rng.uniform(-50, 50, n), rng.uniform(-900., -1., n)], axis=1)
+    deep = np.maximum(x1[:, 2], x2[:, 2]) < -372.5
+    assert 0.2 < deep.mean() < 0.8
+    ctx = gpu_ctx_factory(ice, 'GL1')
+    o = ctx.find_solutions_batch(x1, x2)
+    ref = orc.raytrace_batch(x1, x2, ice)
+    assert np.all(o['n_sol'] >= 0)
+    _assert_identical_to_oracle(o, ref)
+    assert o['n_sol'][deep].sum() > 100 and o['n_sol'][~deep].sum() > 100

@@ -538,3 +538,36 @@ def test_hedis_bgr18_cross_section(monkeypatch, tmp_path):
             xs.get_nu_cross_section(np.array([1e18]), 0, 'total', 'hedis_bgr18')
     finally:
         xs.set_bgr18_file(None)
+
+
+def test_bracketed_finder_vs_the_reference_procedure():
+    """The finder without the hybr stage (round 5: every root out of a bracket) against the reference's procedure restated (hybr on
+    (delta_y)^2 + two Brent searches, itself pinned on the reference above): on 60 000 random pairs in three ice models it never
+    holds fewer solutions, holds more on < 0.1 % of the pairs (roots the procedure loses: tests/test_true_roots.py settles such
+    pairs in 60-digit arithmetic), agrees in C0 to 2.5e-7 (the distance of the hybr iterate from its root) and needs a third of
+    the objective evaluations.  tools/root_shapes.py checks the two shape facts it rests on."""
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    import sys
+    sys.path.insert(0, sys_path)
+    import root_shapes
+    t = root_shapes.check(400, verbose=False)
+    assert t['pairs'] > 1000 and t['u_not_monotone'] == 0 and t['v_not_unimodal'] == 0 and t['more_than_one_interval'] == 0
+    rng = np.random.default_rng(5)
+    for ice, zr in [((1.78, 0.423, 77.), -300.), ((1.78, 0.51, 37.25), -200.), ((1.78, 0.46, 34.5), -150.)]:
+        n = 20000
+        rho = np.sqrt(rng.uniform(0, 5000. ** 2, n))
+        z1, z2 = rng.uniform(-2700, -0.5, n), rng.uniform(zr, -0.5, n)
+        x1 = np.stack([np.zeros(n), np.minimum(z1, z2)], 1)
+        x2 = np.stack([rho, np.maximum(z1, z2)], 1)
+        ns, c, nf = orc.find_solutions_2d_batch(x1, x2, ice)
+        ns_r, c_r, nf_r = orc.find_solutions_2d_batch(x1, x2, ice, reference_procedure=True)
+        assert np.all(ns >= ns_r) and np.mean(ns != ns_r) < 1e-3
+        same = ns == ns_r
+        assert max_rel(c[same], c_r[same]) < 2.5e-7
+        for i in np.flatnonzero(~same):
+            assert _subset_ok(c_r[i], c[i])
+        assert nf.mean() < 0.45 * nf_r.mean() and nf.max() <= 80, (nf.mean(), nf_r.mean(), nf.max())
+    # a receiver deeper than 10 z_0 keeps the reference's procedure: identical results whichever is asked for
+    x1, x2 = np.array([[0., -2500.]]), np.array([[800., -1200.]])
+    a, b = orc.find_solutions_2d_batch(x1, x2, (1.78, 0.423, 77.)), orc.find_solutions_2d_batch(x1, x2, (1.78, 0.423, 77.), True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2])
