@@ -491,6 +491,7 @@ def main():
                     'star instead of exiting non-zero (single-GPU boxes: tools/two_ranks_one_gpu.sh)')
     ap.add_argument('--end-to-end', action='store_true', help='config 2: host event list -> output tables on the host (upload, hot path, '
                     'traces of the triggered events, the tables output_writer_hdf5.py stores), timed as a whole: one extra JSON field')
+    ap.add_argument('--write-expected-sha', action='store_true', help='--scaling strong on ONE rank: record the hash of the trigger mask as the one an N-rank run must gather')
     ap.add_argument('--dry-run', action='store_true', help='launcher check without a GPU: the ranks meet on the TCP star, gather their '
                     '(rank, local rank) pairs and a sharded mask, rank 0 prints a JSON line')
     args = ap.parse_args()
@@ -651,6 +652,21 @@ def main():
             mask = comm.allgather_masks(d['trig'], n_groups, n_total)
             assert int(mask.sum()) == n_trig_total
     mask_sha = hashlib.sha256(np.ascontiguousarray(mask, np.uint8).tobytes()).hexdigest()[:16] if (args.scaling == 'strong' or world > 1) else None
+    # a strong-scaling run is self-checking: the gathered mask of N ranks must be the mask of ONE rank over the same list, whose hash
+    # is committed (profiles/expected_mask_sha16.json, written by `--scaling strong --gpus 1 --write-expected-sha`)
+    sha_check = None
+    if rank == 0 and args.scaling == 'strong' and mask_sha is not None:
+        key = 'config%d_%s_%s_%d_events' % (cfgno, args.flavour, args.trigger, args.events)
+        exp_path = os.environ.get('NRHIP_EXPECTED_SHA_JSON', os.path.join(ROOT, 'profiles', 'expected_mask_sha16.json'))
+        known = json.load(open(exp_path)) if os.path.exists(exp_path) else {}
+        if args.write_expected_sha and world == 1:
+            known[key] = mask_sha
+            json.dump(known, open(exp_path, 'w'), indent=1, sort_keys=True)
+        if key in known:
+            sha_check = 'equal to the one-rank mask (%s)' % exp_path.replace(ROOT + os.sep, '') if known[key] == mask_sha else \
+                        'DIFFERS from the one-rank mask %s' % known[key]
+        else:
+            sha_check = 'no one-rank hash committed for ' + key
     counters = ('n_pairs', 'n_rays', 'n_active_rays', 'n_candidate_events', 'n_integrand_evals')
     tot = dict(zip(counters, comm.allreduce_sum([stats[k] for k in counters])))
 
@@ -722,6 +738,7 @@ def main():
                        "stage_ms_note": ("summed over the stations of the array" + (" and over the %d station lanes that run side by side "
                                          "(the sum exceeds the step)" % n_lanes if n_lanes > 1 else "")) if is_array else None,
                        "gathered_mask_sha16": mask_sha,   # of the all-gathered trigger mask (the same for any number of ranks when strong)
+                       "gathered_mask_check": sha_check,
                        "collectives": comm.mode},   # 'local' (one rank), 'rccl', or 'tcp' (RCCL did not come up on every rank)
             "roofline": {"bound": "hbm", "kernel": kernel_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": "from_profile" if traffic is not None else None,
@@ -790,6 +807,9 @@ def main():
             if mism:
                 emit(out)
                 raise SystemExit("bench.py: the GPU trigger mask differs from the oracle's on %d of %d sampled events" % (mism, n_done))
+        if sha_check and sha_check.startswith('DIFFERS'):
+            emit(out)
+            raise SystemExit("bench.py: the gathered trigger mask of %d ranks %s" % (world, sha_check))
         if args.end_to_end and cfgno == 2 and world == 1:
             out["end_to_end"] = end_to_end(st, wl)
         emit(out)

@@ -190,7 +190,10 @@ __device__ __noinline__ double2 uv_lds(double t, const double* __restrict__ sp, 
     return make_double2(y2p - y2, -1 * (y2p - (2 * y_turn - y2)));
 }
 
-__global__ void __launch_bounds__(256, NRHIP_RT_WAVES)
+#ifndef NRHIP_RTF_WAVES
+#define NRHIP_RTF_WAVES 6   // waves per SIMD the register budget of the finder without the hybr stage is cut for
+#endif
+__global__ void __launch_bounds__(256, NRHIP_RTF_WAVES)
 raytrace_roots_fast_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
                            IceConst m_arg, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm,
                            unsigned long long* __restrict__ eval_count)

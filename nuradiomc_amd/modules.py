@@ -39,13 +39,22 @@ class efieldToVoltageConverter:
 
     def begin(self, debug=False, uncertainty=None, time_resolution=None, pre_pulse_time=200., post_pulse_time=400.,
               caching=True):
-        if uncertainty:
-            raise NotImplementedError("systematic / statistical uncertainties are not provided")
         if time_resolution is not None:
             logger.warning("`time_resolution` is deprecated and will be removed in the future. The argument is ignored.")
         self.__debug = debug
         self.__pre_pulse_time = pre_pulse_time
         self.__post_pulse_time = post_pulse_time
+        # uncertainties exactly as the reference draws them (efieldToVoltageConverter.py:83-90): the systematic ones once, here, from
+        # numpy's global generator in this order -- antenna position offsets 'sys_dx' / 'sys_dy' / 'sys_dz' (drawn and kept; the
+        # reference's run() never reads them either), then one gain factor per channel of 'sys_amp'; the statistical gain 'amp' is
+        # drawn per (channel, electric field) inside run() (:320-321).  As in the reference the caller's dictionary is modified.
+        self.__uncertainty = uncertainty or {}
+        for key in ['sys_dx', 'sys_dy', 'sys_dz']:
+            if key in self.__uncertainty:
+                self.__uncertainty[key] = np.random.normal(0, self.__uncertainty[key])
+        if 'sys_amp' in self.__uncertainty:
+            for iCh in self.__uncertainty['sys_amp']:
+                self.__uncertainty['sys_amp'][iCh] = np.random.normal(1, self.__uncertainty['sys_amp'][iCh])
 
     def _make_channel(self, channel_id):
         if self._channel_factory is not None:
@@ -86,11 +95,18 @@ class efieldToVoltageConverter:
                 d = np.linalg.norm(np.asarray(det.get_relative_position(sid, channel_id)) - np.asarray(ef.get_position()))
                 if d / 0.001 > 0.01:
                     raise NotImplementedError("efields away from the antenna (air-shower mode) are not provided")
+                # gain uncertainties (:320-324): scalar factors on the field's voltage, i.e. on the field itself -- drawn for every
+                # electric field the reference's loop meets, in its order (also for those without a start time: zero traces there)
+                gain = 1.
+                if 'amp' in self.__uncertainty:
+                    gain *= np.random.normal(1, self.__uncertainty['amp'][channel_id])
+                if 'sys_amp' in self.__uncertainty:
+                    gain *= self.__uncertainty['sys_amp'][channel_id]
                 if np.isnan(ef.get_trace_start_time()):
                     continue
                 tr = np.asarray(ef.get_trace(), float)
                 n_samples, fs = tr.shape[-1], ef.get_sampling_rate()
-                traces.append(tr[1:3])
+                traces.append(tr[1:3] if gain == 1. else tr[1:3] * gain)
                 t0.append(ef.get_trace_start_time())
                 zen.append(_efield_param(ef, 'zenith'))
                 az.append(_efield_param(ef, 'azimuth'))

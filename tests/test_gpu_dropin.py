@@ -241,6 +241,51 @@ def _efield_to_voltage_module_case(antenna, cable, N, n_events, n_min):
         conv.run(None, _FakeStation(_FakeSimStation({})), det)
 
 
+def test_efieldToVoltageConverter_uncertainties():
+    """begin(uncertainty=...) (efieldToVoltageConverter.py:42-90, :320-324): the systematic draws in begin (positions, then one gain
+    per channel), the statistical gain per (channel, electric field) in run, all from numpy's global generator in the reference's
+    order -- so with the same seed the factors can be re-drawn here, and the channel traces are the per-field voltages times them."""
+    from nuradiomc_amd import modules
+    from oracle import spectral_oracle as so
+    N, fs, antenna, cable = 512, 2.0, 'analytic_VPol', [0., 1.3, 0., 2.6, 0.]
+    pos = np.array([[0., 0., -100. - i] for i in range(5)])
+    ice = (1.78, 0.423, 77.)
+    ost = so.Station(pos, antenna=antenna, cable_delay=cable, n_samples=N, fs=fs)
+    det = _FakeDet(pos, antenna, cable, N, fs)
+    rng = np.random.default_rng(4)
+    efs = []
+    while not efs:
+        r, ph = np.sqrt(rng.uniform(0, 800. ** 2)), rng.uniform(0, 2 * np.pi)
+        vertex = np.array([r * np.cos(ph), r * np.sin(ph), rng.uniform(-900, -200)])
+        efs = so.sim_efields_for_event(vertex, 1.1, 0.4, 1e18, 'HAD', None, ost, ice, n_freq=25)
+    by_ch = {}
+    for ef in efs:
+        by_ch.setdefault(ef['channel'], []).append(_FakeEfield(pos[ef['channel']], so.freq2time(ef['spec'], fs), ef['t0'], fs,
+                                                               ef['zenith'], ef['azimuth']))
+    unc = dict(sys_dx=0.1, sys_dz=0.2, sys_amp={c: 0.05 for c in range(5)}, amp={c: 0.1 + 0.01 * c for c in range(5)})
+    conv = modules.efieldToVoltageConverter(channel_factory=_FakeChannel)
+    np.random.seed(1234)
+    conv.begin(uncertainty={k: (dict(v) if isinstance(v, dict) else v) for k, v in unc.items()})
+    station = _FakeStation(_FakeSimStation(by_ch))
+    conv.run(None, station, det)
+    # the same draws, in the reference's order
+    np.random.seed(1234)
+    np.random.normal(0, unc['sys_dx']); np.random.normal(0, unc['sys_dz'])
+    sys_amp = {c: np.random.normal(1, unc['sys_amp'][c]) for c in range(5)}
+    scaled = []
+    for c in range(5):
+        for k, ef in enumerate([e for e in efs if e['channel'] == c]):
+            g = np.random.normal(1, unc['amp'][c]) * sys_amp[c]
+            scaled.append(dict(ef, spec=ef['spec'] * g))
+    assert len(scaled) == len(efs)
+    V_ref, t_min, L = so.combined_voltage(scaled, ost, filters=())
+    V_plain, _, _ = so.combined_voltage(efs, ost, filters=())
+    scale = np.max(np.abs(V_ref))
+    assert np.max(np.abs(V_ref - V_plain)) > 1e-3 * scale       # the factors do something
+    for c in range(5):
+        assert np.max(np.abs(station.channels[c].trace - V_ref[c])) <= 1e-6 * scale, c
+
+
 class _FakeSimChannel(_FakeChannel):
     def __init__(self, cid, ef):
         super().__init__(cid)

@@ -204,16 +204,28 @@ def test_two_ranks_on_one_gpu_through_the_launcher():
     of the same list."""
     import json
     common = ['--events', '200000', '--scaling', 'strong', '--steps', '2', '--warmup', '1', '--no-cpu-baseline']
-    one = _run_bench(['--gpus', '1'] + common)
-    assert one.returncode == 0, one.stderr[-2000:]
-    two = _run_bench(['--gpus', '2', '--allow-tcp'] + common)
-    assert two.returncode == 0, two.stderr[-2000:]
+    import tempfile
+    sha_file = os.path.join(tempfile.mkdtemp(), 'expected_mask_sha16.json')
+    os.environ['NRHIP_EXPECTED_SHA_JSON'] = sha_file     # (the committed file holds the hash of the full 1e6-event list)
+    try:
+        one = _run_bench(['--gpus', '1', '--write-expected-sha'] + common)
+        assert one.returncode == 0, one.stderr[-2000:]
+        two = _run_bench(['--gpus', '2', '--allow-tcp'] + common)
+        assert two.returncode == 0, two.stderr[-2000:]
+        # the N-rank line checks itself against the one-rank hash: a wrong hash on file makes the run fail
+        known = json.load(open(sha_file))
+        json.dump({k: 'deadbeefdeadbeef' for k in known}, open(sha_file, 'w'))
+        wrong = _run_bench(['--gpus', '2', '--allow-tcp'] + common)
+        assert wrong.returncode != 0 and 'DIFFERS from the one-rank mask' in wrong.stderr
+    finally:
+        del os.environ['NRHIP_EXPECTED_SHA_JSON']
     j1 = json.loads([q for q in one.stdout.splitlines() if q.startswith('{')][-1])
     j2 = json.loads([q for q in two.stdout.splitlines() if q.startswith('{')][-1])
     assert j1['n_gpus'] == 1 and j2['n_gpus'] == 2
     assert j2['config']['collectives'] in ('tcp', 'rccl')   # 'rccl' on a box with two GPUs
     assert j1['config']['n_triggered_all'] == j2['config']['n_triggered_all'] > 0
     assert j1['config']['gathered_mask_sha16'] == j2['config']['gathered_mask_sha16']
+    assert j2['config']['gathered_mask_check'].startswith('equal to the one-rank mask')
     assert j2['config']['all_ranks']['n_pairs'] == j1['config']['all_ranks']['n_pairs']
     # without --allow-tcp a run that cannot bring RCCL up on every rank exits non-zero (one GPU: two ranks on one device)
     from nuradiomc_amd import _lib
