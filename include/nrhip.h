@@ -542,6 +542,17 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                                 const double* vertex_time, const double* max_distance, int64_t n_groups,
                                 const int32_t* group_begin, uint8_t* triggered, nrhip_sim_stats* stats);
 
+/* What the reference's output writer keeps of the channel traces of a triggered station event (output_writer_hdf5.py:215-320:
+ * "maximum_amplitudes", "maximum_amplitudes_envelope", the trigger time), computed on the device from the traces the last call kept
+ * (nrhip_sim_config.dump_traces) -- the traces themselves need not leave it.  Per item (candidate event of the last call, in
+ * "item_event" order): trigger_bin = first sample of the first L - 1 with |V| >= threshold on any channel (the majority logic drops
+ * the last sample, highLowThreshold.py:82-150; -1: none); per channel the read-out window of n_window samples starting pre_bins
+ * before the trigger, cyclic (channelReadoutWindowCutter.run :28-137 with whole-sample shifts), its max |V| and the maximum of its
+ * Hilbert envelope |scipy.signal.hilbert| (trace_utilities.get_hilbert_envelope).  n_window: a power of two, 16 .. 8192; items
+ * whose common trace is shorter than the window, or without a trigger, get NaN.  HOST outputs [n_items], [n_items][n_channels]. */
+int nrhip_readout_windows(nrhip_ctx* ctx, nrhip_station* st, int32_t n_window, int32_t pre_bins, double threshold,
+                          int64_t n_items, int32_t* trigger_bin, double* max_amp, double* max_env);
+
 /* Copy one intermediate table of the LAST nrhip_simulate_events call to HOST memory (parity tests,
  * output writers).  Names: ray_event ray_channel ray_solution ray_view ray_pol_theta ray_pol_phi ray_zenith
  * ray_azimuth ray_t0 ray_r_theta ray_r_phi ray_att ray_max_efield ray_C0 ray_D (int32 / double / complex);

@@ -1823,6 +1823,38 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     return 0;
 }
 
+int nrhip_readout_windows(nrhip_ctx* ctx, nrhip_station* st, int32_t n_window, int32_t pre_bins, double threshold,
+                          int64_t n_items, int32_t* trigger_bin, double* max_amp, double* max_env)
+{
+    if (!ctx || !st || !trigger_bin || !max_amp || !max_env) return nrhip_fail_msg("nrhip_readout_windows: NULL argument");
+    if (st->ctx != ctx) return nrhip_fail_msg("nrhip_readout_windows: station belongs to another context");
+    if (n_items == 0) return 0;
+    if (n_window < 16 || n_window > FFT_MAX || (n_window & (n_window - 1)))
+        return nrhip_fail_msg("nrhip_readout_windows: the read-out window must be a power of two of 16 .. 8192 samples");
+    for (const char* k : {"item_event", "trace", "trace_offset", "ev_L"})
+        if (st->ws_bytes.find(k) == st->ws_bytes.end())
+            return nrhip_fail_msg("nrhip_readout_windows: the last call kept no traces (nrhip_sim_config.dump_traces)");
+    const int n_ch = st->dev.n_ch;
+    if ((int64_t)(st->ws_bytes["item_event"] / sizeof(int)) < n_items ||
+        (int64_t)(st->ws_bytes["trace_offset"] / sizeof(long)) < n_items * n_ch + 1)
+        return nrhip_fail_msg("nrhip_readout_windows: more items than the last call has");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t sm = ctx->stream;
+    int* d_bin;
+    double *d_amp, *d_env;
+    NEED(d_bin = WS("window_trigger_bin", int, n_items));
+    NEED(d_amp = WS("window_max_amp", double, n_items * n_ch));
+    NEED(d_env = WS("window_max_env", double, n_items * n_ch));
+    launch_readout_windows(sm, (int)n_items, n_ch, st->ws["item_event"].as<int>(), st->ws["ev_L"].as<int>(), st->ws["trace"].as<double>(),
+                           st->ws["trace_offset"].as<long>(), n_window, pre_bins, threshold, ctx->twiddle, d_bin, d_amp, d_env);
+    LCHK("readout windows");
+    HIPCHK(hipMemcpyAsync(trigger_bin, d_bin, sizeof(int) * (size_t)n_items, hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipMemcpyAsync(max_amp, d_amp, sizeof(double) * (size_t)n_items * n_ch, hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipMemcpyAsync(max_env, d_env, sizeof(double) * (size_t)n_items * n_ch, hipMemcpyDeviceToHost, sm));
+    HIPCHK(hipStreamSynchronize(sm));
+    return 0;
+}
+
 int64_t nrhip_sim_fetch(nrhip_station* st, const char* name, void* host_dst, uint64_t bytes)
 {
     if (!st || !name) return nrhip_fail_msg("nrhip_sim_fetch: NULL argument");

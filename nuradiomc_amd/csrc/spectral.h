@@ -264,6 +264,9 @@ void launch_phased_array_digital(hipStream_t s, int n_cand, const int* item_even
 void launch_trace_trigger(hipStream_t s, int n_cand, const int* item_event, int n_ch, const int* ev_L, const double* trace,
                           const long* trace_offset, const TriggerDev& trg, const unsigned char* trig_on, int max_length,
                           unsigned char* triggered, int* trigger_bin);
+void launch_readout_windows(hipStream_t s, int n_items, int n_ch, const int* item_event, const int* ev_L, const double* trace,
+                            const long* trace_offset, int n_window, int pre_bins, double threshold, const double2* tw,
+                            int* trigger_bin, double* max_amp, double* max_env);
 void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const int* item_event, const RayWork& w,
                          const EventOut& ev, const StationDev& st, int ask_model, const double2* tw, const LengthTables& tab,
                          const int* len_index_N, double* max_env, double* signal_time, const double2* spec = nullptr, double2* tab_nodes = nullptr, double* amp_scratch = nullptr);

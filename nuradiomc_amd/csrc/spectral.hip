@@ -5266,6 +5266,91 @@ void launch_ray_envelope(hipStream_t s, int n_cand_max, const int* n_cand, const
     hipLaunchKernelGGL(ray_envelope_kernel, dim3(grid), dim3(256), lds, s, n_cand, item_event, w, ev, st, ask_model, tw, tab,
                        len_index_N, ilog2(st.N), max_env, signal_time, spec, tab_nodes, amp_scratch);
 }
+// ---------------------------------------------------------------------------------------------------------
+// kernel: what the output writer keeps of a triggered station event's channel traces (the dumped traces never leave the device):
+// the trigger bin of the simple threshold on any channel -- first sample of the first L - 1 (get_majority_logic drops the last one,
+// highLowThreshold.py:82-150) with |V| >= threshold on some channel --, then per channel the read-out window the reference cuts
+// (channelReadoutWindowCutter.run :28-137: the trace rolled so that the window of n_window samples starts pre_bins before the
+// trigger) and of that window max |V| and the maximum of its Hilbert envelope |scipy.signal.hilbert(w)|
+// (channelSignalReconstructor -> output_writer_hdf5.py:215-320 "maximum_amplitudes", "maximum_amplitudes_envelope").
+// One block (256) per item; n_window a power of two: forward transform of the window (imaginary part 0), the one-sided weights
+// (1, 2 ... 2, 1, 0 ... 0), inverse transform, modulus.  LDS: n_window complex.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+readout_window_kernel(int n_items, int n_ch, const int* __restrict__ item_event, const int* __restrict__ ev_L,
+                      const double* __restrict__ trace, const long* __restrict__ trace_offset, int n_window, int log2n, int pre_bins,
+                      double threshold, const double2* __restrict__ tw, int* __restrict__ trigger_bin, double* __restrict__ max_amp,
+                      double* __restrict__ max_env)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* x = (double2*)smem;
+    __shared__ double red[256];
+    __shared__ int s_first;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int L = ev_L[item_event[item]];
+        if (threadIdx.x == 0) s_first = 0x7fffffff;
+        __syncthreads();
+        int first = 0x7fffffff;
+        for (int c = 0; c < n_ch; c++) {
+            const double* V = trace + trace_offset[(long)item * n_ch + c];
+            for (int n = threadIdx.x; n < L - 1 && n < first; n += blockDim.x)
+                if (fabs(V[n]) >= threshold) first = n;
+        }
+        if (first != 0x7fffffff) atomicMin(&s_first, first);
+        __syncthreads();
+        const int tbin = (s_first == 0x7fffffff) ? -1 : s_first;
+        if (threadIdx.x == 0) trigger_bin[item] = tbin;
+        const int nw = min(n_window, L);
+        if (tbin < 0 || nw != n_window) {   // no sample reaches the threshold / a common trace shorter than the window: the caller's business
+            for (int c = threadIdx.x; c < n_ch; c += blockDim.x) max_amp[(long)item * n_ch + c] = max_env[(long)item * n_ch + c] = NAN;
+            __syncthreads();
+            continue;
+        }
+        int s0 = (tbin - pre_bins) % L;
+        if (s0 < 0) s0 += L;
+        for (int c = 0; c < n_ch; c++) {
+            const double* V = trace + trace_offset[(long)item * n_ch + c];
+            double am = 0.;
+            for (int j = threadIdx.x; j < n_window; j += blockDim.x) {
+                int q = s0 + j;
+                if (q >= L) q -= L;
+                const double v = V[q];
+                am = fmax(am, fabs(v));
+                x[j] = make_double2(v, 0.);
+            }
+            __syncthreads();
+            fft_dif(x, log2n, tw, false);   // natural -> bit-reversed
+            for (int k = threadIdx.x; k < n_window; k += blockDim.x) {
+                const double wgt = (k == 0 || k == n_window / 2) ? 1. : (k < n_window / 2 ? 2. : 0.);
+                const int q = bitrev(k, log2n);
+                x[q] = make_double2(x[q].x * wgt, x[q].y * wgt);
+            }
+            __syncthreads();
+            fft_dit(x, log2n, tw, true);    // bit-reversed -> natural, unscaled
+            double em = 0.;
+            for (int j = threadIdx.x; j < n_window; j += blockDim.x) em = fmax(em, cabs2(x[j]));
+            am = block_max(am, red);
+            em = block_max(em, red);
+            if (threadIdx.x == 0) {
+                max_amp[(long)item * n_ch + c] = am;
+                max_env[(long)item * n_ch + c] = em * (1.0 / n_window);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+void launch_readout_windows(hipStream_t s, int n_items, int n_ch, const int* item_event, const int* ev_L, const double* trace,
+                            const long* trace_offset, int n_window, int pre_bins, double threshold, const double2* tw,
+                            int* trigger_bin, double* max_amp, double* max_env)
+{
+    if (n_items <= 0) return;
+    set_big_lds();
+    (void)hipFuncSetAttribute((const void*)readout_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
+    hipLaunchKernelGGL(readout_window_kernel, dim3(n_items < 2048 ? n_items : 2048), dim3(256), (size_t)n_window * 16, s, n_items, n_ch,
+                       item_event, ev_L, trace, trace_offset, n_window, ilog2(n_window), pre_bins, threshold, tw, trigger_bin, max_amp,
+                       max_env);
+}
 void launch_efield_channel(hipStream_t s, int n_efields, const double* traces, const double* t0, const double* zen,
                            const double* az, const int* channel, const StationDev& st, int L, double t_min, int apply_filter,
                            const double2* tw, const LengthTables& tab, double2* scratch, double* V, double2* tab_nodes)

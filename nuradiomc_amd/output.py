@@ -165,6 +165,32 @@ def _window_maxima(windows, step=64):
     return amp, env
 
 
+def _host_windows(trace, trace_offset, ev_L, item_event, n_ch, threshold, n_window, pre_bins):
+    """the same three tables as Station.readout_windows from traces fetched to the host (read-out windows that are no power of two,
+    common traces shorter than the window): trigger bin, max |V| and Hilbert-envelope maximum per (item, channel)"""
+    n = len(item_event)
+    tb = np.full(n, -1, np.int32)
+    wins, idx = [], []
+    amp, env = np.full((n, n_ch), np.nan), np.full((n, n_ch), np.nan)
+    for it in range(n):
+        L_ = int(ev_L[item_event[it]])
+        V = np.array([trace[trace_offset[it * n_ch + c]:trace_offset[it * n_ch + c + 1]] for c in range(n_ch)])
+        hit = np.any(np.abs(V[:, :L_ - 1]) >= threshold, axis=0)   # get_majority_logic drops the last sample
+        if not hit.any():
+            continue
+        tb[it] = int(np.argmax(hit))
+        wins.append(_readout_window(V, int(tb[it]), n_window, pre_bins))
+        idx.append(it)
+    by_len = {}
+    for k_, W_ in enumerate(wins):   # (a common trace shorter than the read-out window keeps its own length)
+        by_len.setdefault(W_.shape, []).append(k_)
+    for ks in by_len.values():
+        a_, e_ = _window_maxima([wins[k_] for k_ in ks])
+        for q_, k_ in enumerate(ks):
+            amp[idx[k_]], env[idx[k_]] = a_[q_], e_[q_]
+    return tb, amp, env
+
+
 def _readout_window(V, trigger_bin, n_window, pre_bins):
     """channelReadoutWindowCutter.run (:28-137): the trace rolled so that the window starts pre_trigger_time before the trigger
     (whole samples here: roll; apply_time_shift on a whole number of samples is np.roll, base_trace.py:262-266), first n_window
@@ -224,6 +250,14 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
     g_of_row = np.repeat(np.arange(n_groups), np.diff(gb))[rows]      # original group index of every simulated shower
     sim_group_ids = np.flatnonzero(sim_groups)
     # ---- pass 2: everything the writer stores, for the triggered groups only
+    fs = st.sampling_rate
+    dt = 1. / fs
+    det_fs = float(detector_sampling_rate or fs)
+    n_det = int(detector_n_samples or st.n_samples)
+    n_window = int(2 * np.ceil(n_det / 2 * fs / det_fs))          # channelReadoutWindowCutter._get_number_of_samples
+    pre_bins = int(round(pre_trigger_time * fs))
+    threshold = sim_kw.get('trigger_threshold', 3.0 * st.vrms)
+    on_device = 16 <= n_window <= 8192 and (n_window & (n_window - 1)) == 0   # (nrhip_readout_windows: a power of two)
     sel_g = np.flatnonzero(trig)
     out = OutputFile()
     tables = {i: [] for i in range(n_st)}
@@ -239,7 +273,14 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
                                                  'slot_keep', 'ray_slot', 'ray_zenith', 'ray_azimuth', 'ray_pol_theta',
                                                  'ray_pol_phi', 'ev_candidate', 'ev_L', 'ev_t_min', 'ev_n_rays')}
             if T['ev_candidate'].any():
-                T.update({k: s_.fetch(k) for k in ('item_event', 'trace', 'trace_offset')})   # (fetch returns a fresh array)
+                T['item_event'] = s_.fetch('item_event')
+                # trigger bin, maximum and Hilbert-envelope maximum of every read-out window: on the device, where the traces are
+                # (2 GB for the 9053 triggered showers of a 1e6-event survey) -- only windows that are no power of two come to the host
+                if on_device:
+                    T['win_bin'], T['win_amp'], T['win_env'] = s_.readout_windows(n_window, pre_bins, threshold)
+                if not on_device or np.any(np.isnan(T['win_amp'][T['win_bin'] >= 0])):
+                    T['win_bin'], T['win_amp'], T['win_env'] = _host_windows(s_.fetch('trace'), s_.fetch('trace_offset'), T['ev_L'],
+                                                                             T['item_event'], n_ch, threshold, n_window, pre_bins)
                 for k in ('ray_max_amp_envelope', 'ray_signal_time'):
                     try:
                         T[k] = s_.fetch(k)
@@ -253,66 +294,56 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
                             types[rows][sub], np.where(np.isnan(kL[sub]), 1.0, kL[sub]), dump_traces=True, amp_per_ray=can_amp,
                             on_station=collect, max_showers_per_call=len(sub) + 1, **kw2)
     _lap('pass2_traces_and_tables_of_triggered_groups')
-    # ---- assemble the reference's tables
-    fs = st.sampling_rate
-    dt = 1. / fs
-    det_fs = float(detector_sampling_rate or fs)
-    n_det = int(detector_n_samples or st.n_samples)
-    n_window = int(2 * np.ceil(n_det / 2 * fs / det_fs))          # channelReadoutWindowCutter._get_number_of_samples
-    pre_bins = int(round(pre_trigger_time * fs))
-    threshold = sim_kw.get('trigger_threshold', 3.0 * st.vrms)
-    top_showers = {}    # original shower row -> dict(triggered, trigger_time)
+    # ---- assemble the reference's tables (array operations over all stored events / showers of a station call at once)
+    sh_trig = np.zeros(n, bool)          # per original shower row: part of a triggered station event
+    sh_t = np.full(n, np.nan)            #   its earliest trigger time
+    sh_primary = np.zeros(n, bool)       #   stored as the primary of a triggered group (:392-430)
     for i in range(n_st):
         sname = 'station_%d' % station_ids[i]
-        ev_rows, sh_blocks, ev_windows = [], [], []
+        ev_blocks, sh_blocks = [], []
         for T in tables[i]:
-            pos_of = {int(e): k for k, e in enumerate(T.get('item_event', []))}
+            groups = np.asarray(T['groups'], int)
+            if len(groups) == 0 or 'item_event' not in T:
+                continue
             # showers of the (possibly culled) list the station ran on
-            lst = np.concatenate([np.arange(sub_gb[g], sub_gb[g + 1]) for g in T['groups']]) if len(T['groups']) else np.zeros(0, int)
-            local_gb = np.concatenate([[0], np.cumsum([sub_gb[g + 1] - sub_gb[g] for g in T['groups']])]).astype(int)
+            cnt = (sub_gb[groups + 1] - sub_gb[groups]).astype(int)
+            local_gb = np.concatenate([[0], np.cumsum(cnt)]).astype(int)
+            lst = np.repeat(sub_gb[groups], cnt) + (np.arange(local_gb[-1]) - np.repeat(local_gb[:-1], cnt))
             keep = T['slot_keep'][:len(lst) * n_ch * nS].reshape(len(lst), n_ch, nS).astype(bool)
             keep_any = keep.reshape(len(lst), -1).any(axis=1)
             ray_of_slot = np.full(len(lst) * n_ch * nS, -1)
             ray_of_slot[T['ray_slot']] = np.arange(len(T['ray_slot']))
             ray_of_slot = ray_of_slot.reshape(len(lst), n_ch, nS)
-            sel_j, sel_t = [], []   # local shower index and trigger time of every stored shower row
-            for k, g in enumerate(T['groups']):
-                g_orig = sim_group_ids[sel_g][g]
-                if not st_trig[i, sel_g[g]]:
-                    continue
-                it = pos_of[k]
-                L_ = int(T['ev_L'][k])
-                o0 = int(T['trace_offset'][it * n_ch])
-                if int(T['trace_offset'][it * n_ch + n_ch]) - o0 == n_ch * L_:   # the channels of an item lie one behind the other
-                    V = T['trace'][o0:o0 + n_ch * L_].reshape(n_ch, L_)
-                else:
-                    V = np.array([T['trace'][T['trace_offset'][it * n_ch + c]:T['trace_offset'][it * n_ch + c + 1]] for c in range(n_ch)])
-                hit = np.any(np.abs(V[:, :L_ - 1]) >= threshold, axis=0)   # get_majority_logic drops the last sample
-                tbin = int(np.argmax(hit))
-                t_trig = tbin * dt + T['ev_t_min'][k]
-                ev_windows.append(_readout_window(V, tbin, n_window, pre_bins))   # (maxima and Hilbert envelopes: one call after the loop)
-                ev_rows.append(dict(event_group_ids=gid[first[g_orig]], event_ids=0, maximum_amplitudes=None,
-                                    maximum_amplitudes_envelope=None,
-                                    multiple_triggers_per_event=np.array([True]), trigger_times_per_event=np.array([t_trig]),
-                                    triggered_per_event=True))
-                js = np.arange(local_gb[k], local_gb[k + 1])
-                js = js[keep_any[js]]   # a shower without any efield on this station is not part of the station's event (:983-1001)
-                sel_j.append(js)
-                sel_t.append(np.full(len(js), t_trig))
-                for row in rows[sub[lst[js]]].tolist():
-                    e = top_showers.setdefault(int(row), dict(triggered=False, t=np.nan))
-                    e['triggered'] = True
-                    e['t'] = t_trig if np.isnan(e['t']) else min(e['t'], t_trig)
-                # the primary of a triggered group is stored even without a signal of its own (:392-430)
-                top_showers.setdefault(int(first[g_orig]), dict(triggered=False, t=np.nan, primary_only=True))
-            if not sel_j:
+            # the station events that triggered: their item (candidate-event row), trigger bin and time
+            ks = np.flatnonzero(st_trig[i, sel_g[groups]])
+            if len(ks) == 0:
                 continue
-            # the (channel, solution) tables of all stored showers of this call at once (NaN where no ray was kept)
-            J = np.concatenate(sel_j)
-            tt = np.concatenate(sel_t)
+            item_of = np.full(len(groups), -1)
+            item_of[T['item_event']] = np.arange(len(T['item_event']))
+            its = item_of[ks]
+            tbin = T['win_bin'][its]
+            if np.any(its < 0) or np.any(tbin < 0):
+                bad = ks[(its < 0) | (tbin < 0)][0]
+                raise RuntimeError("station %d, event group %d: flagged as triggered in pass 1, but no sample of the pass-2 traces reaches "
+                                   "the threshold" % (station_ids[i], int(gid[first[sim_group_ids[sel_g][groups[bad]]]])))
+            t_trig = tbin * dt + T['ev_t_min'][ks]
+            g_orig = sim_group_ids[sel_g][groups[ks]]
+            ev_blocks.append(dict(event_group_ids=gid[first[g_orig]], event_ids=np.zeros(len(ks), int),
+                                  maximum_amplitudes=T['win_amp'][its], maximum_amplitudes_envelope=T['win_env'][its],
+                                  multiple_triggers_per_event=np.ones((len(ks), 1), bool), trigger_times_per_event=t_trig[:, None],
+                                  triggered_per_event=np.ones(len(ks), bool)))
+            sh_primary[first[g_orig]] = True   # the primary of a triggered group is stored even without a signal of its own
+            c_k = cnt[ks]
+            J = np.repeat(local_gb[ks], c_k) + (np.arange(c_k.sum()) - np.repeat(np.concatenate([[0], np.cumsum(c_k)[:-1]]), c_k))
+            tt = np.repeat(t_trig, c_k)
+            m = keep_any[J]   # a shower without any efield on this station is not part of the station's event (:983-1001)
+            J, tt = J[m], tt[m]
             if len(J) == 0:
                 continue
             row = rows[sub[lst[J]]]
+            sh_trig[row] = True
+            sh_t[row] = np.fmin(sh_t[row], tt)
+            # the (channel, solution) tables of all stored showers of this call at once (NaN where no ray was kept)
             kj = keep[J]
             q = (J * (n_ch * nS))[:, None, None] + np.arange(n_ch * nS).reshape(n_ch, nS)
             ir = np.where(kj, ray_of_slot[J], 0)
@@ -341,35 +372,27 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
             else:
                 blk['max_amp_shower_and_ray'], blk['time_shower_and_ray'] = tab2(np.nan), tab2(np.nan)
             sh_blocks.append(blk)
-        if ev_rows:
-            by_len = {}
-            for k_, W_ in enumerate(ev_windows):   # (a common trace shorter than the read-out window keeps its own length)
-                by_len.setdefault(W_.shape, []).append(k_)
-            for idx in by_len.values():
-                amp, env = _window_maxima([ev_windows[k_] for k_ in idx])
-                for q_, k_ in enumerate(idx):
-                    ev_rows[k_]['maximum_amplitudes'] = amp[q_]
-                    ev_rows[k_]['maximum_amplitudes_envelope'] = env[q_]
         if sh_blocks:
             order = np.argsort(np.concatenate([b_['shower_id'] for b_ in sh_blocks]), kind='stable')
             for key in sh_blocks[0]:
                 out.datasets['%s/%s' % (sname, key)] = np.concatenate([b_[key] for b_ in sh_blocks])[order]
-            for key in ev_rows[0]:
-                out.datasets['%s/%s' % (sname, key)] = np.array([r[key] for r in ev_rows])
+            for key in ev_blocks[0]:
+                out.datasets['%s/%s' % (sname, key)] = np.concatenate([b_[key] for b_ in ev_blocks])
         vr = np.array([st.vrms_per_set[st.channel_filter_set[c]][0] for c in range(n_ch)])
         out.attrs[(sname, 'antenna_positions')] = arr.relative_position + arr.centres[i]
         if sh_blocks:
             out.attrs[(sname, 'Vrms')] = vr
             out.attrs[(sname, 'bandwidth')] = np.array([_bandwidth(st, c) for c in range(n_ch)])
             out.attrs[(sname, 'Vrms_trigger')] = np.zeros(0)
-    srows = np.array(sorted(top_showers, key=lambda r: d['shower_ids'][r]), int)
+    stored = np.flatnonzero(sh_trig | sh_primary)
+    srows = stored[np.argsort(d['shower_ids'][stored], kind='stable')]
     if len(srows):
         D = out.datasets
         for key in ('shower_ids', 'event_group_ids', 'xx', 'yy', 'zz', 'vertex_times', 'azimuths', 'zeniths', 'energies', 'flavors',
                     'n_interaction', 'interaction_type', 'inelasticity'):
             if key in d:
                 D[key] = d[key][srows]
-        only = np.array([top_showers[int(r)].get('primary_only', False) and not top_showers[int(r)]['triggered'] for r in srows])
+        only = sh_primary[srows] & ~sh_trig[srows]
         D['shower_energies'] = np.where(only, np.nan, d['shower_energies'][srows])
         D['shower_type'] = np.where(only, '', d['shower_type'][srows])
         g_idx = np.searchsorted(first, srows, side='right') - 1
@@ -378,9 +401,9 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
         k_all[rows] = kL
         if sim_kw.get('askaryan_model', 'Alvarez2009') == 'Alvarez2009':
             D['shower_realization_Alvarez2009'] = np.where(only, np.nan, k_all[srows])
-        D['triggered'] = np.array([top_showers[int(r)]['triggered'] for r in srows])
+        D['triggered'] = sh_trig[srows]
         D['multiple_triggers'] = D['triggered'][:, None].copy()
-        D['trigger_times'] = np.array([[top_showers[int(r)]['t']] for r in srows])
+        D['trigger_times'] = sh_t[srows][:, None]
     for k, v in events.attrs.items():
         out.attrs[('', k)] = v
     out.attrs[('', 'trigger_names')] = np.array([trigger_name])

@@ -134,6 +134,8 @@ L._OPTIONAL.update({
                                                    ctypes.c_int64] + [ctypes.c_void_p] * 8 + [ctypes.c_int64]
                                     + [ctypes.c_void_p] * 2 + [ctypes.POINTER(SimStats)]),
     'nrhip_sim_fetch': (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64]),
+    'nrhip_readout_windows': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_int64,
+                                            L.c_int32_p, L.c_double_p, L.c_double_p]),
     'nrhip_askaryan_spectrum_batch': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, L.c_double_p, L.c_double_p,
                                                      L.c_int32_p, L.c_double_p, L.c_double_p, L.c_double_p, ctypes.c_int32,
                                                      ctypes.c_int32, ctypes.c_double, L.c_double_p]),
@@ -867,6 +869,18 @@ class Station:
         tr = self.fetch('emit_trace')
         n_ch = len(self.position)
         return {int(e): tr[off[e]:off[e] + n_ch * L_[e]].reshape(n_ch, L_[e]) for e in np.flatnonzero(off >= 0)}
+
+    def readout_windows(self, n_window, pre_bins, threshold):
+        """after a call with dump_traces: per candidate event (fetch('item_event') order) the trigger bin of the simple threshold on any
+        channel, and per channel max |V| and the maximum Hilbert envelope of the read-out window of n_window samples that starts
+        pre_bins before the trigger -- computed on the device (nrhip_readout_windows), the traces stay there.  -> (trigger_bin [n],
+        max_amp [n, n_channels], max_env [n, n_channels]); NaN rows: no trigger, or a common trace shorter than the window."""
+        n = self.fetch_bytes('item_event') // 4
+        n_ch = len(self.position)
+        tb, amp, env = np.zeros(n, np.int32), np.zeros((n, n_ch)), np.zeros((n, n_ch))
+        L.check(self._lib.nrhip_readout_windows(self.ctx._h, self._h, int(n_window), int(pre_bins), float(threshold), n, L.iptr(tb),
+                                                L.dptr(amp), L.dptr(env)))
+        return tb, amp, env
 
     def fetch_bytes(self, name):
         """size in bytes of a table of the last simulated batch (nothing is copied)"""
