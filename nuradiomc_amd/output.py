@@ -71,10 +71,20 @@ class EventList:
         return np.stack([self.data['xx'], self.data['yy'], self.data['zz']], axis=1).astype(float)
 
     def shower_type_codes(self):
-        t = np.char.lower(np.asarray(self.data['shower_type']).astype(str))
-        codes = np.where(t == 'had', 0, np.where(t == 'em', 1, -1)).astype(np.int32)
-        if np.any(codes < 0):
-            raise KeyError(str(t[codes < 0][0]))
+        a = np.asarray(self.data['shower_type'])
+        if a.dtype.kind != 'U':
+            a = a.astype(str)
+        # the exact spellings first (a C loop each); whatever is left goes through np.char.lower, which on 1e6 strings would cost
+        # more than the hot path
+        codes = np.full(len(a), -1, np.int32)
+        codes[(a == 'had') | (a == 'HAD')] = 0
+        codes[(a == 'em') | (a == 'EM')] = 1
+        rest = np.flatnonzero(codes < 0)
+        if len(rest):
+            t = np.char.lower(a[rest])
+            codes[rest] = np.where(t == 'had', 0, np.where(t == 'em', 1, -1))
+            if np.any(codes[rest] < 0):
+                raise KeyError(str(t[codes[rest] < 0][0]))
         return codes
 
     def k_L(self):
@@ -237,10 +247,15 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
                                                cross_section_type=cross_section_type, vertex_position=vertex[first],
                                                phi_nu=d['azimuths'][first], ctx=ctx)
     sim_groups = np.ones(n_groups, bool) if minimum_weight_cut is None else (weights >= minimum_weight_cut)   # run(): :1489-1492
-    rows = np.flatnonzero(np.repeat(sim_groups, np.diff(gb)))
-    args = (vertex[rows], d['zeniths'][rows], d['azimuths'][rows], d['shower_energies'][rows], types[rows])
-    kL_in = events.k_L()[rows]
-    kw = dict(vertex_time=d['vertex_times'][rows], group_id=gid[rows], **sim_kw)
+    if sim_groups.all():   # (no weight cut: the list as it is -- no gathered copies of 1e6-row arrays)
+        rows = np.arange(n)
+        take = lambda a: a   # noqa: E731
+    else:
+        rows = np.flatnonzero(np.repeat(sim_groups, np.diff(gb)))
+        take = lambda a: a[rows]   # noqa: E731
+    args = (take(vertex), take(d['zeniths']), take(d['azimuths']), take(d['shower_energies']), take(types))
+    kL_in = take(events.k_L())
+    kw = dict(vertex_time=take(d['vertex_times']), group_id=take(gid), **sim_kw)
     _lap('weights_and_selection')
     # ---- pass 1: which (station, group) trigger
     trig, stats = arr.simulate_events(*args, kL_in, seed=seed, per_station=True, **kw)
