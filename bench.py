@@ -491,6 +491,8 @@ def main():
                     'star instead of exiting non-zero (single-GPU boxes: tools/two_ranks_one_gpu.sh)')
     ap.add_argument('--end-to-end', action='store_true', help='config 2: host event list -> output tables on the host (upload, hot path, '
                     'traces of the triggered events, the tables output_writer_hdf5.py stores), timed as a whole: one extra JSON field')
+    ap.add_argument('--no-end-to-end', action='store_true', help='config 2: leave out the `end_to_end` object (the whole drop-in on the same list, '
+                    'host event list -> output tables on the host, timed once after the steps)')
     ap.add_argument('--write-expected-sha', action='store_true', help='--scaling strong on ONE rank: record the hash of the trigger mask as the one an N-rank run must gather')
     ap.add_argument('--dry-run', action='store_true', help='launcher check without a GPU: the ranks meet on the TCP star, gather their '
                     '(rank, local rank) pairs and a sharded mask, rank 0 prints a JSON line')
@@ -810,7 +812,7 @@ def main():
         if sha_check and sha_check.startswith('DIFFERS'):
             emit(out)
             raise SystemExit("bench.py: the gathered trigger mask of %d ranks %s" % (world, sha_check))
-        if args.end_to_end and cfgno == 2 and world == 1:
+        if (args.end_to_end or not args.no_end_to_end) and cfgno == 2 and world == 1 and args.flavour == 'had':
             out["end_to_end"] = end_to_end(st, wl)
         emit(out)
     comm.barrier()
