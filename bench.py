@@ -38,7 +38,9 @@ CHANNELS = np.array([[0., 0., -100. - i] for i in range(5)])
 ENERGY = 3e17                       # shower energy [eV] of a 1 EeV neutrino at <y> ~ 0.3
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s
 FP64_PEAK_TFLOPS = 78.6             # same guide: dense FP64 (vector and matrix alike)
-FLOP_PER_OBJECTIVE = 209.           # one evaluation of the ray finder's objective (analyticraytracing.py:204-272), DESIGN.md section 4
+FLOP_PER_OBJECTIVE = 189.           # one evaluation of the ray finder's objective (analyticraytracing.py:204-272): ~90 add / mul, 13 divisions
+                                    # and 6 square roots at 1 flop, 1 exp + 3 log at 20 (round 5: the finder without the hybr stage needs no
+                                    # logarithm for the depth of the turning point; 209 with it)
 # general path (config 4), counted per unit of work the kernels report:
 FLOP_PER_ARZ_EVAL = 50.             # one point of the vector-potential integrand (ARZ.py:216-266): retarded time (rsqrt at 1), degree-6
                                     # form-factor polynomial, direction factors, trapezoid weight and the two accumulations

@@ -27,7 +27,10 @@ struct ArzBatch {
 // piecewise degree-6 Taylor polynomials of the form factor exp(-|t| / t0) + (1 + f |t|)^e per (shower type, sign of t):
 // cells of 1/512 ns up to |t| = 2.5 ns, 8 doubles per cell (one 64 B line)
 #define ARZ_TABLE_CELLS 1280
-#define ARZ_TABLE_DOUBLES (4 * ARZ_TABLE_CELLS * 8)
+// beyond 2.5 ns the form factor is the smooth power-law tail (the exponential is < 1e-16 there): cells of 1/16 ns up to 20.5 ns,
+// the same degree-6 polynomials (truncation < 2e-11 of the tail's own value) instead of exp(e log(1 + f |t|)) per point
+#define ARZ_FAR_CELLS 288
+#define ARZ_TABLE_DOUBLES (4 * (ARZ_TABLE_CELLS + ARZ_FAR_CELLS) * 8)
 
 void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int* status);
 

@@ -32,6 +32,7 @@ struct ArzRay {
     double Af, freq_pos, freq_neg, exp_pos, exp_neg, t0_pos, t0_neg;
     double K, inv_t0_pos, inv_t0_neg;   // Af E_TeV fc / xntot em_factor; 1 / t0
     const double2 *tab_pos, *tab_neg;   // form-factor polynomials of this shower type (nullptr: evaluate directly)
+    const double2 *far_pos, *far_neg;   // the same beyond 2.5 ns (cells of 1/16 ns)
 };
 
 // cell i of table (type, sign): Taylor coefficients about the cell centre c = (i + 1/2) / 512 ns of
@@ -40,11 +41,14 @@ struct ArzRay {
 __global__ void arz_form_factor_table_kernel(const double* __restrict__ parameters, double* __restrict__ table)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 4 * ARZ_TABLE_CELLS) return;
-    const int cell = i % ARZ_TABLE_CELLS, sign = (i / ARZ_TABLE_CELLS) & 1, typ = i / (2 * ARZ_TABLE_CELLS);
+    if (i >= 4 * (ARZ_TABLE_CELLS + ARZ_FAR_CELLS)) return;
+    // rows (type, sign) of ARZ_TABLE_CELLS near cells (1/512 ns) first, then the rows of ARZ_FAR_CELLS far cells (1/16 ns from 2.5 ns)
+    const bool far = i >= 4 * ARZ_TABLE_CELLS;
+    const int j = far ? i - 4 * ARZ_TABLE_CELLS : i, per = far ? ARZ_FAR_CELLS : ARZ_TABLE_CELLS;
+    const int cell = j % per, sign = (j / per) & 1, typ = j / (2 * per);
     const double* P = parameters + 7 * typ;
     const double f = sign ? P[2] : P[1], e = sign ? P[4] : P[3], t0 = sign ? P[6] : P[5];
-    const double c = (cell + 0.5) * (1. / 512.);
+    const double c = far ? 2.5 + (cell + 0.5) * (1. / 16.) : (cell + 0.5) * (1. / 512.);
     const double y = 1. + f * c, ratio = f / y;
     double ce = exp(-c / t0), cp = pow(y, e);
     double* out = table + (size_t)i * 8;
@@ -75,9 +79,26 @@ __device__ __forceinline__ void arz_integrand_fast(const ArzRay& r, double depth
         const double a = fabs(t);
         const bool pos = t > 0;
         if (a < ARZ_TABLE_CELLS * (1. / 512.) && r.tab_pos) {
+#ifdef ARZ_PROBE_CONST_CELL   // measurement only (wrong values): what the table's memory latency costs
+            const int ci = 0;
+#else
             const int ci = (int)(a * 512.);
+#endif
             const double dl = a - (ci + 0.5) * (1. / 512.);
             const double2* T = (pos ? r.tab_pos : r.tab_neg) + 4 * ci;
+            const double2 c01 = T[0], c23 = T[1], c45 = T[2], c67 = T[3];
+            double p = fma(c67.x, dl, c45.y);
+            p = fma(p, dl, c45.x);
+            p = fma(p, dl, c23.y);
+            p = fma(p, dl, c23.x);
+            p = fma(p, dl, c01.y);
+            p = fma(p, dl, c01.x);
+            F = r.K * p;
+        } else if (r.tab_pos) {   // 2.5 ns <= |t| < 20 ns: the far table
+            int ci = (int)((a - 2.5) * 16.);
+            ci = ci > ARZ_FAR_CELLS - 1 ? ARZ_FAR_CELLS - 1 : ci;
+            const double dl = a - (2.5 + (ci + 0.5) * (1. / 16.));
+            const double2* T = (pos ? r.far_pos : r.far_neg) + 4 * ci;
             const double2 c01 = T[0], c23 = T[1], c45 = T[2], c67 = T[3];
             double p = fma(c67.x, dl, c45.y);
             p = fma(p, dl, c45.x);
@@ -240,6 +261,11 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
                         fmax(fabs(r.exp_pos) * r.freq_pos, fabs(r.exp_neg) * r.freq_neg) <= 20.;
     r.tab_pos = tab_ok ? (const double2*)(b.form_factor_table + (size_t)(2 * typ) * ARZ_TABLE_CELLS * 8) : nullptr;
     r.tab_neg = tab_ok ? (const double2*)(b.form_factor_table + (size_t)(2 * typ + 1) * ARZ_TABLE_CELLS * 8) : nullptr;
+    {
+        const double* far0 = b.form_factor_table ? b.form_factor_table + (size_t)4 * ARZ_TABLE_CELLS * 8 : nullptr;
+        r.far_pos = tab_ok ? (const double2*)(far0 + (size_t)(2 * typ) * ARZ_FAR_CELLS * 8) : nullptr;
+        r.far_neg = tab_ok ? (const double2*)(far0 + (size_t)(2 * typ + 1) * ARZ_FAR_CELLS * 8) : nullptr;
+    }
     const double inv_coarse = 1. / (s_depth[1] - s_depth[0]);
     for (int i = threadIdx.x; i < nd; i += blockDim.x) {
         const double z = s_depth[i] / ARZ_RHO;
@@ -464,7 +490,7 @@ void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int
     dim3 grid((unsigned)b.n_rays, ARZ_CHUNKS);
     (void)hipMemsetAsync(vp, 0, sizeof(double) * 2 * (size_t)nt * b.n_rays, s);
     if (b.form_factor_table)
-        hipLaunchKernelGGL(arz_form_factor_table_kernel, dim3((4 * ARZ_TABLE_CELLS + 255) / 256), dim3(256), 0, s, b.parameters,
+        hipLaunchKernelGGL(arz_form_factor_table_kernel, dim3((4 * (ARZ_TABLE_CELLS + ARZ_FAR_CELLS) + 255) / 256), dim3(256), 0, s, b.parameters,
                            b.form_factor_table);
     const size_t lds = sizeof(double) * 5 * (size_t)b.n_depth;   // 80 KB at the 2048 depth bins the entry points admit
     if (lds > 48 * 1024)
