@@ -7,7 +7,7 @@
 set -x
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/measure
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 B="python3 bench.py --no-cpu-baseline"
@@ -24,13 +24,14 @@ NRHIP_PMC_JSON=$OUT/${R}_pmc_traffic.json python3 bench.py > $OUT/bench_config2.
 NRHIP_PMC_JSON=$OUT/${R}_pmc_traffic.json python3 bench.py --no-traces --no-cpu-baseline > $OUT/bench_config2_pass1_only.json 2>> $OUT/bench_config2.log
 if [ "$1" = "prof" ]; then ls -la $OUT; exit 0; fi
 python3 bench.py --flavour mixed > $OUT/bench_config2_mixed.json 2>> $OUT/bench_config2.log
-python3 bench.py --scaling strong --no-cpu-baseline > $OUT/bench_config2_strong.json 2>> $OUT/bench_config2.log
+python3 bench.py --scaling strong --no-cpu-baseline --write-expected-sha > $OUT/bench_config2_strong.json 2>> $OUT/bench_config2.log   # (records the one-rank mask hash an N-rank run must gather)
+cp profiles/expected_mask_sha16.json $OUT/ 2>/dev/null
 python3 bench.py --events 125000 --no-cpu-baseline > $OUT/bench_config2_125k_shard.json 2>> $OUT/bench_config2.log
 python3 bench.py --config 3 > $OUT/bench_config3.json 2> $OUT/bench_config3.log
 python3 bench.py --config 3 --trigger pa --cpu-budget 40 > $OUT/bench_config3_pa.json 2>> $OUT/bench_config3.log
 python3 bench.py --config 3 --trigger pa_adc_noise --cpu-budget 60 --events 200000 > $OUT/bench_config3_pa_adc_noise.json 2>> $OUT/bench_config3.log
 python3 bench.py --config 5 > $OUT/bench_config5.json 2> $OUT/bench_config5.log
-python3 bench.py --config 4 --cpu-budget 120 > $OUT/bench_config4.json 2> $OUT/bench_config4.log
+# (config 4: tools/measure_config4.sh -- priced line with its own PMC traffic, kernel statistics, the 1.25e6-event shard)
 python3 bench.py --config 4 --trigger pa_adc_noise --no-cpu-baseline > $OUT/bench_config4_pa_adc_noise.json 2>> $OUT/bench_config4.log
 # the general path (ARZ2020 + birefringence) on the 5-channel station: wall time and kernel statistics
 python3 tools/config4_probe.py 100000 20000 > $OUT/config4_probe.log 2>&1
@@ -38,7 +39,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4stats -o x -- pyt
 cp $(find $OUT/c4stats -name 'x_kernel_stats.csv' | head -1) $OUT/${R}_rocprofv3_config4_kernel_stats.csv
 rm -rf $OUT/c4stats
 # round 4: the whole drop-in (host list -> output tables), the two-rank launch on this one GPU, the convolution kernel's phases
-python3 bench.py --steps 10 --no-cpu-baseline --end-to-end > $OUT/bench_config2_end_to_end.json 2>> $OUT/bench_config2.log
+# (the whole drop-in, host list -> output tables, is the `end_to_end` object of the default line since round 5)
 python3 bench.py --gpus 2 --allow-tcp --scaling strong --events 200000 --steps 3 --no-cpu-baseline > $OUT/bench_config2_two_ranks_one_gpu.json 2>> $OUT/bench_config2.log
 [ -f nuradiomc_amd/lib/libnrhip_ct.so ] && { python3 tools/conv_phase_probe.py; python3 tools/conv_phase_probe.py --no-traces; python3 tools/conv_phase_probe.py --config 5 --steps 1 --events 300000; } > $OUT/conv_phases.log 2>&1
 # where a 125 k-event shard spends its time (kernel sum vs step)
