@@ -14,6 +14,7 @@ rows f2 / f3).
   turns the latter into the former 1:1 on any machine that has h5py (this image's default interpreter has none).
 """
 import json
+import os
 import numpy as np
 from . import _lib as L
 from .station import Station
@@ -272,7 +273,7 @@ def simulate_to_output(det, events, config=None, station_ids=None, trigger_name=
     n_window = int(2 * np.ceil(n_det / 2 * fs / det_fs))          # channelReadoutWindowCutter._get_number_of_samples
     pre_bins = int(round(pre_trigger_time * fs))
     threshold = sim_kw.get('trigger_threshold', 3.0 * st.vrms)
-    on_device = 16 <= n_window <= 8192 and (n_window & (n_window - 1)) == 0   # (nrhip_readout_windows: a power of two)
+    on_device = 16 <= n_window <= 8192 and (n_window & (n_window - 1)) == 0 and not os.environ.get('NRHIP_OUTPUT_HOST_WINDOWS')   # (nrhip_readout_windows: a power of two)
     sel_g = np.flatnonzero(trig)
     out = OutputFile()
     tables = {i: [] for i in range(n_st)}

@@ -68,3 +68,30 @@ def test_output_tables_like_the_reference_writer(gpu_ctx_factory):
     for name in ('n_events', 'fiducial_rmax', 'Emin', 'volume'):
         assert out.attrs[('', name)] == g['attr/@' + name][()]
     assert out.datasets['triggered'].sum() >= 15
+
+
+def test_device_readout_windows_equal_the_host_path(gpu_ctx_factory, monkeypatch):
+    """nrhip_readout_windows (trigger bin, read-out window, maximum and Hilbert-envelope maximum on the device) against the host path
+    the writer used until round 4 (the traces fetched, numpy / scipy.fft) -- still taken for windows that are no power of two:
+    every dataset of the output equal, the maxima to 1e-12."""
+    g = golden('ref_hdf5_output.npz')
+    ev = output.EventList({k[3:]: g[k] for k in g.files if k.startswith('in/')},
+                          {k[8:]: g[k][()] for k in g.files if k.startswith('in_attr/')})
+    ctx = gpu_ctx_factory(g['ice'], 'SP1')
+    st = nuradiomc_amd.Station(ctx, g['det_pos'], n_samples=int(g['N']), sampling_rate=float(g['fs']))
+    a = output.simulate_to_output(st, ev, station_ids=[int(g['station_id'])], seed=int(g['seed']))
+    monkeypatch.setenv('NRHIP_OUTPUT_HOST_WINDOWS', '1')
+    b = output.simulate_to_output(st, ev, station_ids=[int(g['station_id'])], seed=int(g['seed']))
+    assert set(a.datasets) == set(b.datasets)
+    for k in a.datasets:
+        x, y = np.asarray(a.datasets[k]), np.asarray(b.datasets[k])
+        if x.dtype.kind == 'f':
+            assert np.array_equal(np.isnan(x), np.isnan(y)), k
+            m = ~np.isnan(x)
+            assert np.all(np.abs(x[m] - y[m]) <= 1e-12 * np.maximum(np.abs(y[m]), 1e-300)), k
+        else:
+            assert np.array_equal(x, y), k
+    assert a.datasets['station_101/maximum_amplitudes_envelope'].shape[0] >= 15
+    # a read-out window that is no power of two takes the host path by itself
+    c = output.simulate_to_output(st, ev, station_ids=[int(g['station_id'])], seed=int(g['seed']), detector_n_samples=int(g['N']) - 2)
+    assert c.datasets['station_101/maximum_amplitudes'].shape == a.datasets['station_101/maximum_amplitudes'].shape
