@@ -50,8 +50,12 @@ def main():
     rows = [(k, f.get(k, 0.), w.get(k, 0.), (2 * f.get(k, 0.) + w.get(k, 0.)) * 1024, int(nf.get(k, 0))) for k in names]
     base = sys.argv[3]
     with open(base + '.csv', 'w') as o:
-        o.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 3\n')
-        o.write('# largest launch of each kernel; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 counts 64 B per 128-B read request)\n')
+        if per_step:
+            o.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of a bench.py command that makes %g pass(es) over the list\n' % per_step)
+            o.write('# ALL launches of each kernel summed, per pass; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 counts 64 B per 128-B read request)\n')
+        else:
+            o.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 3\n')
+            o.write('# largest launch of each kernel; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 counts 64 B per 128-B read request)\n')
         o.write('# kernel sources %s\n' % bench.source_hash())
         o.write('kernel,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_corrected,launches_seen\n')
         for r in rows:
