@@ -251,28 +251,45 @@ __global__ void __launch_bounds__(256) scan_tile_sums_kernel(long n, const int* 
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = red[0];
 }
 
+// exclusive scan of the tile sums, ONE block (the whole chip waits for it -- an array call makes ten of these scans per station):
+// eight consecutive tiles per thread, a shuffle scan inside each wave, the sixteen wave totals through LDS -- two barriers per 8192
+// tiles (the Hillis-Steele version of rounds 1-4 took twenty per 1024: 0.4 ms per scan of a 35-station call, 7 % of its kernel time)
 __global__ void __launch_bounds__(1024) scan_tile_offsets_kernel(int n_tiles, int* __restrict__ tile_sum)
 {
-    __shared__ int buf[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n_tiles; base += 1024) {
-        int i = base + threadIdx.x;
-        int v = (i < n_tiles) ? tile_sum[i] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-            int t = ((int)threadIdx.x >= off) ? buf[threadIdx.x - off] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += t;
-            __syncthreads();
+    constexpr int PER = 8;
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int carry = 0;
+    for (int base = 0; base < n_tiles; base += 1024 * PER) {
+        const int i0 = base + (int)threadIdx.x * PER;
+        int v[PER], s_ = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            v[j] = (i0 + j < n_tiles) ? tile_sum[i0 + j] : 0;
+            s_ += v[j];
         }
-        int incl = buf[threadIdx.x];
-        if (i < n_tiles) tile_sum[i] = carry + incl - v;
+        int incl = s_;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == 1023) carry += incl;
-        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w_ = 0; w_ < 16; w_++) {
+            const int q = wsum[w_];
+            if (w_ < wave) before += q;
+            total += q;
+        }
+        int excl = carry + before + incl - s_;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            if (i0 + j < n_tiles) tile_sum[i0 + j] = excl;
+            excl += v[j];
+        }
+        carry += total;
+        __syncthreads();   // (wsum is rewritten by the next round)
     }
 }
 
@@ -2108,13 +2125,19 @@ __global__ void scatter_item_list_kernel(int n_items, const int* __restrict__ ne
 }
 
 // candidate events with at least one channel left to evaluate (the unit of work of channel_conv_kernel)
-__global__ void channel_event_flags_kernel(int n_cand, int n_ch, const int* __restrict__ need, int* __restrict__ ev_need)
+// n_coinc > 1 (majority logic, production mode): an n-fold coincidence needs n channels that can raise a flag at all -- an event
+// with fewer channels left by the prefilter cannot trigger, none of its channels is evaluated (their maxima keep the bound)
+__global__ void channel_event_flags_kernel(int n_cand, int n_ch, int* __restrict__ need, int* __restrict__ ev_need, int n_coinc)
 {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cand) return;
-    int any = 0;
-    for (int ch = 0; ch < n_ch; ch++) any |= need[c * n_ch + ch];
-    ev_need[c] = any;
+    int cnt = 0;
+    for (int ch = 0; ch < n_ch; ch++) cnt += need[c * n_ch + ch] != 0;
+    if (cnt > 0 && cnt < n_coinc) {
+        for (int ch = 0; ch < n_ch; ch++) need[c * n_ch + ch] = 0;
+        cnt = 0;
+    }
+    ev_need[c] = cnt > 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -4065,7 +4088,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                                need, pa_amp_cut);
         int* ev_need = need + n_items;  // [n_cand + 1]
         hipLaunchKernelGGL(channel_event_flags_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, st.n_ch, need,
-                           ev_need);
+                           ev_need, (exact || pa_prune || st.max_tab_freq > 0) ? 1 : trig.n_coinc);   // (tabulated patterns: some channels are the chirp-z kernel's)
         (void)hipMemsetAsync(ev_need + n_cand, 0, sizeof(int), s);
         launch_exclusive_scan(s, (long)n_cand + 1, ev_need, need_offset, scan_tmp);
         hipLaunchKernelGGL(scatter_item_list_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, ev_need, need_offset,

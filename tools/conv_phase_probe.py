@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, ROOT)
 os.environ['NRHIP_LIB_NAME'] = 'libnrhip_ct.so'
-sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'] + sys.argv[1:]   # e.g. --no-traces, --config 5
+sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-end-to-end'] + sys.argv[1:]   # e.g. --no-traces, --config 5
 import bench  # noqa: E402
 
 buf = io.StringIO()
