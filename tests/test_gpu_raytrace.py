@@ -227,3 +227,25 @@ def test_deep_receivers_keep_the_reference_procedure(gpu_ctx_factory):
     assert np.all(o['n_sol'] >= 0)
     _assert_identical_to_oracle(o, ref)
     assert o['n_sol'][deep].sum() > 100 and o['n_sol'][~deep].sum() > 100
+
+
+@pytest.mark.parametrize('ice,model', [((1.78, 0.423, 77.), 'SP1'), ((1.78, 0.51, 37.25), 'GL1'), ((1.78, 0.46, 34.5), 'MB1')])
+def test_find_solutions_random_geometries(gpu_ctx_factory, ice, model):
+    """1e5 random pairs per ice model -- end points anywhere between the surface and 2.7 km, receivers on both sides of the 10 z_0
+    line that separates the bracketed finder from the reference's procedure, pairs above each other, at equal depth, metres apart --
+    equal to the oracle bit for bit (both finders, both launches, the same decision per pair)."""
+    rng = np.random.default_rng(int(ice[2] * 100))
+    n = 100000
+    z0 = ice[2]
+    r, ph = np.sqrt(rng.uniform(0, 5000. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    x1 = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-2700, -0.01, n)], axis=1)
+    x2 = np.stack([rng.uniform(-30, 30, n), rng.uniform(-30, 30, n), -rng.uniform(0.01, 14 * z0, n)], axis=1)
+    x2[:500, :2] = x1[:500, :2]                                  # vertically above / below each other
+    x2[500:1000, 2] = x1[500:1000, 2]                            # equal depth
+    x1[1000:1500] = x2[1000:1500] + rng.uniform(-3, 3, (500, 3)) * [1, 1, 0.2]   # metres apart
+    x1[:, 2] = np.minimum(x1[:, 2], -0.01)
+    ctx = gpu_ctx_factory(ice, model)
+    o = ctx.find_solutions_batch(x1, x2)
+    ref = orc.raytrace_batch(x1, x2, ice)
+    _assert_identical_to_oracle(o, ref)
+    assert np.bincount(o['n_sol'], minlength=3)[2] > 0.2 * n
