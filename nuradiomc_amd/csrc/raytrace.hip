@@ -114,8 +114,8 @@ raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double*
             unsigned todo = 0;
             if (fun < 1e-7) { lc0 = xr; ns = 1; }
             else if (d_lo != 0 && d_hi != 0 && !isnan(d_lo) && !isnan(d_hi) && signbit(d_lo) != signbit(d_hi)) todo |= 1u;
-            if (np_sign_differs(d_hi, d_top) && signbit(d_hi) != signbit(d_top)) todo |= 2u;
-            if (np_sign_differs(d_bot, d_lo) && signbit(d_bot) != signbit(d_lo)) todo |= 4u;
+            if (brent_bracket_ok(d_hi, d_top)) todo |= 2u;
+            if (brent_bracket_ok(d_bot, d_lo)) todo |= 4u;
             while (todo) {
                 const unsigned k = todo & (0u - todo);   // lowest pending bracket: the order of the reference's list
                 todo ^= k;
@@ -219,7 +219,9 @@ raytrace_roots_fast_kernel(long n_pairs, const double* __restrict__ x1, const do
             sp[1536] = det_log(1. / (m.n_ice - g2) - m.inv_n);   // x_lo: the ray that turns at the receiver's depth
             const bool too_far = max_dist && g.dist > max_dist[i1];
             search = !(g.z2 > 0) && !too_far;
-            deep = !(g2 >= NRHIP_SHALLOW * m.delta_n);
+            // (and pairs exactly above each other: their solutions are the vertical rays, log C0 -> infinity -- the reference's
+            // procedure reports them at its search limits, the brackets here have no sign change to find)
+            deep = !(g2 >= NRHIP_SHALLOW * m.delta_n) || !(g.y2 > g.A0);
         }
         if (search && deep) {   // left to the reference's procedure (raytrace_roots_kernel with only_flagged)
             out.n_sol[i] = -1;
@@ -485,8 +487,10 @@ void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const d
             hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count, 0);
         } else {
             hipLaunchKernelGGL(raytrace_roots_fast_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count);
-            if (maybe_deep)   // some receiver may lie deeper than 10 z_0: the flagged pairs through the reference's procedure
-                hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count, 1);
+            // the flagged pairs (receiver deeper than 10 z_0, end points exactly above each other) through the reference's procedure;
+            // with nothing flagged the launch reads one word per pair
+            (void)maybe_deep;
+            hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count, 1);
         }
     }
     hipLaunchKernelGGL(raytrace_records_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, given_C0,

@@ -124,12 +124,12 @@ find_refl_kernel(long n_pairs, int n_calls, const double* __restrict__ x1, const
             {
                 double a = xr + 0.0001, b = 100.;
                 double fa = d_hi, fb = dy(b);
-                if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) lc[ns++] = brentq(dy, a, b, fa, fb);
+                if (brent_bracket_ok(fa, fb)) lc[ns++] = brentq(dy, a, b, fa, fb);
             }
             {
                 double a = -100., b = xr - 0.0001;
                 double fa = dy(a), fb = d_lo;
-                if (np_sign_differs(fa, fb) && signbit(fa) != signbit(fb)) lc[ns++] = brentq(dy, a, b, fa, fb);
+                if (brent_bracket_ok(fa, fb)) lc[ns++] = brentq(dy, a, b, fa, fb);
             }
         }
         double c0[3];

@@ -173,6 +173,15 @@ __device__ inline double brentq(F&& f, double xa, double xb, double fa, double f
     return xcur;
 }
 
+// may brentq(a, b) be called with these end values?  The reference asks np.sign(fa) != np.sign(fb) (np_sign_differs) and scipy's
+// brentq then raises unless fa * fb <= 0 -- an end value of exactly zero (of either sign) is returned as the root.  A pair whose
+// end points lie exactly above each other has delta_y(log C0 = 100) = -0.0: the vertical ray.
+__device__ inline bool np_sign_differs(double a, double b);
+__device__ inline bool brent_bracket_ok(double fa, double fb)
+{
+    return np_sign_differs(fa, fb) && (fa == 0 || fb == 0 || signbit(fa) != signbit(fb));
+}
+
 __device__ inline bool np_sign_differs(double a, double b)
 {
     if (isnan(a) || isnan(b)) return true;  // np.sign(nan) != anything

@@ -583,7 +583,9 @@ int orc_find_solutions_2d_refl(const double x1[2], const double x2[2], const dou
     int n = 0;
     double logC0[3];
     if (x2[1] > 0) return 0; /* ice->air special case (:1437-1460) not restated */
-    if (reflection == 0 && get_gamma(x2[1], &m) >= ORC_SHALLOW * m.delta_n && !orc_reference_procedure) {
+    /* (end points exactly above each other: the solutions are the vertical rays, log C0 -> infinity -- the reference's procedure
+     * reports them at its search limits; the brackets of the finder above have no sign change to find) */
+    if (reflection == 0 && get_gamma(x2[1], &m) >= ORC_SHALLOW * m.delta_n && x2[0] > x1[0] && !orc_reference_procedure) {
         int kind;
         n = find_solutions_bracketed(x1, x2, &m, logC0, &o.nfev, &kind);
         if (hybr_x) *hybr_x = NAN;

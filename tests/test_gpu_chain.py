@@ -2092,3 +2092,43 @@ def test_phased_array_with_trigger_adc(gpu_ctx_factory, output, up, clk):
     for i in range(len(item_event)):
         n_up = dlen[i, 0]
         assert np.max(np.abs(dig_d[i, :, :n_up] - dig[i, :, :n_up])) <= (0 if output == 'counts' else 1e-9 * lsb)
+
+
+def test_extreme_geometries_through_the_whole_path(gpu_ctx_factory):
+    """Vertices the surveys rarely draw -- within metres of the antennas, above them, just under the surface, exactly above /
+    below a channel (the vertical ray: end points above each other go through the reference's procedure), 5 km away, very deep --
+    through the whole batched path against the oracle's chain: ray counts, candidate flags, trigger decisions and trace lengths
+    equal on every event."""
+    ice = (1.78, 0.423, 77.)
+    pos = np.array([[0., 0., -100. - 2. * i] for i in range(5)])
+    ctx = gpu_ctx_factory(ice, 'SP1')
+    st = nuradiomc_amd.Station(ctx, pos, n_samples=256, sampling_rate=2.0)
+    ost = so.Station(pos, n_samples=256, fs=2.0)
+    vrms, vrms_e = so.vrms_from_filters(2.0)
+    rng = np.random.default_rng(41)
+    blocks = []
+    m = 60
+    u = lambda a, b: rng.uniform(a, b, m)   # noqa: E731
+    blocks.append(np.stack([u(-8, 8), u(-8, 8), u(-125, -90)], 1))            # inside / next to the string
+    blocks.append(np.stack([u(-300, 300), u(-300, 300), u(-60, -0.2)], 1))    # above the antennas, up to the surface
+    blocks.append(np.stack([np.zeros(m), np.zeros(m), u(-2700, -110)], 1))    # exactly below the string: vertical rays
+    blocks.append(np.stack([np.zeros(m), np.zeros(m), u(-95, -0.5)], 1))      # exactly above it
+    blocks.append(np.stack([u(4000, 5000), u(-500, 500), u(-2700, -5)], 1))   # far away
+    blocks.append(np.stack([u(-1500, 1500), u(-1500, 1500), u(-2700, -2400)], 1))   # very deep
+    v = np.concatenate(blocks)
+    n = len(v)
+    zen, az = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    en = 10 ** rng.uniform(17.5, 19.5, n)
+    trig, stats = st.simulate_events(v, zen, az, en, 'HAD')
+    n_rays, cand, L = st.fetch('ev_n_rays')[:n], st.fetch('ev_candidate')[:n].astype(bool), st.fetch('ev_L')[:n]
+    n_c = n_t = 0
+    for i in range(n):
+        o = so.simulate_event(v[i], zen[i], az[i], en[i], 'HAD', None, ost, ice, vrms, vrms_e)
+        assert len(o['rays']) == n_rays[i], (i, v[i])
+        assert o['candidate'] == bool(cand[i]) and o['triggered'] == bool(trig[i]), (i, v[i])
+        if o['candidate']:
+            assert o['L'] == L[i], (i, v[i])
+        n_c += o['candidate']
+        n_t += o['triggered']
+    assert n_c >= 40 and n_t >= 10 and n_rays[2 * m:4 * m].sum() > 100   # (the vertical pairs do have rays)
+    print('extreme geometries: %d events, %d rays, %d candidates, %d triggers' % (n, n_rays.sum(), n_c, n_t))
