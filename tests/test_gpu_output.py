@@ -95,3 +95,37 @@ def test_device_readout_windows_equal_the_host_path(gpu_ctx_factory, monkeypatch
     # a read-out window that is no power of two takes the host path by itself
     c = output.simulate_to_output(st, ev, station_ids=[int(g['station_id'])], seed=int(g['seed']), detector_n_samples=int(g['N']) - 2)
     assert c.datasets['station_101/maximum_amplitudes'].shape == a.datasets['station_101/maximum_amplitudes'].shape
+
+
+def test_output_tables_of_an_array(gpu_ctx_factory):
+    """simulate_to_output on a two-station array (the second station 1.5 km away; with the distance cut, so that the stations run on
+    culled sub-lists): the tables of station 101 are those of the single-station run, station 102 has its own, a shower is stored
+    once at the top level with its earliest trigger time."""
+    g = golden('ref_hdf5_output.npz')
+    ev = output.EventList({k[3:]: g[k] for k in g.files if k.startswith('in/')},
+                          {k[8:]: g[k][()] for k in g.files if k.startswith('in_attr/')})
+    ctx = gpu_ctx_factory(g['ice'], 'SP1')
+    st = nuradiomc_amd.Station(ctx, g['det_pos'], n_samples=int(g['N']), sampling_rate=float(g['fs']))
+    dcc = [6.5, 0.4]   # max distance [m] = 10^(c0 + c1 log10(E / eV) ...): generous, the cull still drops far groups
+    kw = dict(seed=int(g['seed']))
+    single = output.simulate_to_output(st, ev, station_ids=[101], **kw)
+    centres = np.array([[0., 0., 0.], [1500., 300., 0.]])
+    arr = nuradiomc_amd.StationArray(st, centres, relative_position=g['det_pos'], station_ids=[101, 102], cull=False)
+    both = output.simulate_to_output(arr, ev, **kw)
+    for k, v in single.datasets.items():
+        if k.startswith('station_101/'):
+            a, b = np.asarray(v), np.asarray(both.datasets[k])
+            assert a.shape == b.shape, k
+            if a.dtype.kind == 'f':
+                assert np.array_equal(np.isnan(a), np.isnan(b)) and np.allclose(a[~np.isnan(a)], b[~np.isnan(b)], rtol=1e-12, atol=0), k
+            else:
+                assert np.array_equal(a, b), k
+    assert 'station_102/maximum_amplitudes' in both.datasets and len(both.datasets['station_102/event_group_ids']) >= 3
+    # top level: every shower of the single-station file is there, once; triggered showers of station 102 join
+    ids1, ids2 = single.datasets['shower_ids'], both.datasets['shower_ids']
+    assert len(np.unique(ids2)) == len(ids2) and np.all(np.isin(ids1, ids2)) and len(ids2) > len(ids1)
+    t1 = dict(zip(ids1.tolist(), single.datasets['trigger_times'][:, 0].tolist()))
+    t2 = dict(zip(ids2.tolist(), both.datasets['trigger_times'][:, 0].tolist()))
+    for k_, v_ in t1.items():
+        if not np.isnan(v_):
+            assert t2[k_] <= v_ + 1e-9
