@@ -98,15 +98,13 @@ def test_device_readout_windows_equal_the_host_path(gpu_ctx_factory, monkeypatch
 
 
 def test_output_tables_of_an_array(gpu_ctx_factory):
-    """simulate_to_output on a two-station array (the second station 1.5 km away; with the distance cut, so that the stations run on
-    culled sub-lists): the tables of station 101 are those of the single-station run, station 102 has its own, a shower is stored
-    once at the top level with its earliest trigger time."""
+    """simulate_to_output on a two-station array (the second station 1.5 km away): the tables of station 101 are those of the
+    single-station run, station 102 has its own, a shower is stored once at the top level with its earliest trigger time."""
     g = golden('ref_hdf5_output.npz')
     ev = output.EventList({k[3:]: g[k] for k in g.files if k.startswith('in/')},
                           {k[8:]: g[k][()] for k in g.files if k.startswith('in_attr/')})
     ctx = gpu_ctx_factory(g['ice'], 'SP1')
     st = nuradiomc_amd.Station(ctx, g['det_pos'], n_samples=int(g['N']), sampling_rate=float(g['fs']))
-    dcc = [6.5, 0.4]   # max distance [m] = 10^(c0 + c1 log10(E / eV) ...): generous, the cull still drops far groups
     kw = dict(seed=int(g['seed']))
     single = output.simulate_to_output(st, ev, station_ids=[101], **kw)
     centres = np.array([[0., 0., 0.], [1500., 300., 0.]])
