@@ -379,11 +379,17 @@ def end_to_end(st, wl):
                 shower_type=np.where(ev['shower_type'] == 0, 'had', 'em'), energies=np.full(n, 1e18), flavors=np.full(n, 12),
                 n_interaction=np.ones(n, int), interaction_type=np.full(n, 'nc'), inelasticity=ev['energy'] / 1e18,
                 vertex_times=np.zeros(n), shower_realization_Alvarez2009=ev['k_L'])
+    # like the steps: one untimed call first (the dump_traces pass over the triggered groups allocates its 2 GB of trace workspace, the
+    # per-length tables of "L = N" are built; on a fresh box that first call takes 0.4 ... 0.6 s), then the timed one
+    t0 = time.perf_counter()
+    output.simulate_to_output(st, output.EventList(data), station_ids=[101])
+    first = time.perf_counter() - t0
     t0 = time.perf_counter()
     out = output.simulate_to_output(st, output.EventList(data), station_ids=[101])
     dt = time.perf_counter() - t0
     trig = out.datasets.get('triggered', np.zeros(0, bool))
-    return {"seconds": dt, "events_per_s": (int(ev['group'][-1]) + 1) / dt, "phases_s": {k: round(v, 3) for k, v in out.timing.items()},
+    return {"seconds": dt, "first_call_seconds": first, "events_per_s": (int(ev['group'][-1]) + 1) / dt,
+            "phases_s": {k: round(v, 3) for k, v in out.timing.items()},
             "n_triggered_showers": int(np.sum(trig)), "n_datasets": len(out.datasets),
             "note": "host arrays in, output tables (all datasets of the reference's HDF5 layout) out; the device-resident step above is "
                     "'pass1' without upload"}
