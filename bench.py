@@ -561,7 +561,7 @@ def main():
     det = build_array(ctx, wl)
     is_array = wl['centres'] is not None
     st = det.station if is_array else det
-    n_lanes = args.lanes if args.lanes is not None else {3: 4, 5: 2}.get(cfgno, 1)   # measured (round 5): config 3 936 / 935 / 909 ms with 2 / 3 / 4 lanes, config 5 2056 / 1990 / 2098 with 1 / 2 / 3
+    n_lanes = args.lanes if args.lanes is not None else (2 if cfgno == 3 else 1)   # measured: config 3 -6 %, config 5 +-0
     lane_ctx = []
     if is_array:
         for _ in range(max(n_lanes, 1) - 1):   # (build_array may touch wl['sim_kw']: identical values every time)
