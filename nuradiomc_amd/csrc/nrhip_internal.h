@@ -31,7 +31,10 @@ void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const d
                      const IceConst& m, const RayRecords& out, const double* max_dist = nullptr,
                      const int* perm = nullptr, const double* given_C0 = nullptr, unsigned long long* eval_count = nullptr,
                      const double* given_D = nullptr, const double* given_T = nullptr, bool maybe_deep = true,
-                     bool reference_procedure = false);
+                     bool reference_procedure = false, bool channel_major = false);
+// channel_major (with perm): the finder walks the pairs channel by channel -- a wave sees neighbouring events from ONE antenna --
+// instead of event by event; pays for stations whose antennas sit at very different depths (measured: the 24-channel RNO-G-like
+// station -21 % of the stage; a string of dipoles 1 m apart +3 %, its stores no longer coalesce)
 // ---- reflections off the bottom of an ice shelf (raytrace_refl.hip) ----
 #define NRHIP_MAX_REFLECTIONS 4
 struct ReflRecords {   // [n_pairs][2 + 4 n_reflections]

@@ -871,6 +871,13 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     bool deep_antennas = false;
     for (int c = 0; c < n_ch; c++)
         if (st->h_pos[3 * c + 2] - 0.011 < -9.99 * ctx->ice.z_0) deep_antennas = true;   // (0.011: the focusing trace's 1 cm)
+    // antennas at very different depths (surface LPDAs next to deep dipoles): the finder walks the pairs channel-major
+    bool spread_antennas = false;
+    {
+        double zlo = 0., zhi = -1e30;
+        for (int c = 0; c < n_ch; c++) { zlo = std::min(zlo, st->h_pos[3 * c + 2]); zhi = std::max(zhi, st->h_pos[3 * c + 2]); }
+        spread_antennas = n_ch > 1 && zhi - zlo > 20.;
+    }
     RayRecords rec;
     NEED(rec.n_sol = WS("pair_n_sol", int, n_pairs));
     NEED(rec.type = WS("slot_type", int, n_slots));
@@ -933,7 +940,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             HIPCHK(hipMemsetAsync(rt_eval_counter, 0, sizeof(unsigned long long), sm));
         }
         launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm, cfg->given_C0, rt_eval_counter,
-                        cfg->given_D, cfg->given_T, deep_antennas);
+                        cfg->given_D, cfg->given_T, deep_antennas, false, spread_antennas);
         LCHK("raytrace");
     }
     MARK(1);
@@ -1057,7 +1064,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                 launch_records_refl(sm, n_pairs, n_refl, S_, vertex, pos2, n_ch, ctx->ice, cfg->z_reflection, cand_n2, cand_C2, 0, rr2);
             } else {
                 launch_raytrace(sm, n_pairs, vertex, pos2, n_ch, ctx->ice, rec2, max_distance, geo_perm, nullptr, nullptr, nullptr, nullptr,
-                                deep_antennas);
+                                deep_antennas, false, spread_antennas);
             }
             LCHK("raytrace (focusing)");
             HIPCHK(hipStreamSynchronize(sm));  // hp goes out of scope
