@@ -1218,23 +1218,63 @@ __global__ void group_ray_range_kernel(int n_groups, const int* __restrict__ gro
 }
 
 // per event: can any ray exceed the cut?  (1 + 1e-6 absorbs rounding of the bound and of exp(-integral) <= 1)
+// A wave takes 64 consecutive event groups and walks THEIR rays -- a contiguous range -- with its lanes (coalesced); the group of a
+// ray comes from a six-step search over the wave's 65 range starts (lane shuffles).  (Rounds 1-4: one thread per group walking its
+// rays one after the other -- uncoalesced, 0.7 ... 1 ms per station call of an array for a few MB.)
+struct GroupWave {
+    int off;        // this lane's group: first ray
+    int r_begin, r_end;
+    __device__ GroupWave(const int* __restrict__ slot_offset, int g0, int n_groups)
+    {
+        const int lane = threadIdx.x & 63;
+        off = slot_offset[min(g0 + lane, n_groups)];
+        r_begin = __shfl(off, 0);
+        r_end = slot_offset[min(g0 + 64, n_groups)];
+    }
+    // index (0 .. 63) of the group that holds ray r (r_begin <= r < r_end): the last lane whose range starts at or before r
+    __device__ int group_of(int r) const
+    {
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const int cand = lo + step;
+            const int o = __shfl(off, cand & 63);
+            if (cand < 64 && o <= r) lo = cand;
+        }
+        return lo;
+    }
+};
+
 __global__ void __launch_bounds__(256)
 event_possible_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, const double* __restrict__ bound,
                       double min_efield, int* __restrict__ ray_active, int own_only)
 {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_events) return;
-    int r0 = slot_offset[e], r1 = slot_offset[e + 1];  // ray range of the event group (group_ray_range_kernel)
+    __shared__ int s_any[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g0 = (blockIdx.x * 4 + wv) * 64;
+    if (g0 >= n_events) return;
+    const GroupWave gw(slot_offset, g0, n_events);
     if (own_only) {
         // two-stage attenuation: first only the rays that could make their event a candidate on their own; the other rays of the
         // events that did become candidates follow after the candidate cut (follower_flags_kernel)
-        for (int r = r0; r < r1; r++) ray_active[r] = (bound[r] * (1 + 1e-6) > min_efield) ? 1 : 0;
+        for (int r = gw.r_begin + lane; r < gw.r_end; r += 64) ray_active[r] = (bound[r] * (1 + 1e-6) > min_efield) ? 1 : 0;
         return;
     }
-    int possible = 0;
-    for (int r = r0; r < r1; r++)
-        if (bound[r] * (1 + 1e-6) > min_efield) possible = 1;
-    for (int r = r0; r < r1; r++) ray_active[r] = possible;
+    s_any[wv][lane] = 0;
+    wave_lds_sync();
+    for (int base = gw.r_begin; base < gw.r_end; base += 64) {   // (all lanes take part in the shuffles)
+        const int r = base + lane;
+        const bool in = r < gw.r_end;
+        const int j = gw.group_of(in ? r : gw.r_begin);
+        if (in && bound[r] * (1 + 1e-6) > min_efield) s_any[wv][j] = 1;
+    }
+    wave_lds_sync();
+    for (int base = gw.r_begin; base < gw.r_end; base += 64) {
+        const int r = base + lane;
+        const bool in = r < gw.r_end;
+        const int j = gw.group_of(in ? r : gw.r_begin);
+        if (in) ray_active[r] = s_any[wv][j];
+    }
 }
 
 // second stage of the attenuation: the rays of candidate readouts whose attenuation has not been computed yet (their own bound is
@@ -1509,18 +1549,31 @@ __global__ void __launch_bounds__(256)
 event_need_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, const int* __restrict__ need_ray,
                   int* __restrict__ ev_need, const double* __restrict__ max_efield, double min_efield, int exact)
 {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e > n_events) return;
-    int any = 0;
-    if (e < n_events) {
-        bool decided = false;   // a ray whose sampled field already exceeds the cut makes the event a candidate
-        for (int r = slot_offset[e]; r < slot_offset[e + 1]; r++) {
-            any |= need_ray[r];
-            decided = decided || (max_efield[r] > min_efield);
-        }
-        if (decided && !exact) any = 0;
+    __shared__ int s_any[4][64], s_dec[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g0 = (blockIdx.x * 4 + wv) * 64;
+    if (g0 > n_events) return;
+    if (g0 == n_events) {   // the entry behind the last group (the scan's total)
+        if (lane == 0) ev_need[n_events] = 0;
+        return;
     }
-    ev_need[e] = any;
+    const GroupWave gw(slot_offset, g0, n_events);
+    s_any[wv][lane] = 0;
+    s_dec[wv][lane] = 0;
+    wave_lds_sync();
+    for (int base = gw.r_begin; base < gw.r_end; base += 64) {   // (all lanes take part in the shuffles)
+        const int r = base + lane;
+        const bool in = r < gw.r_end;
+        const int j = gw.group_of(in ? r : gw.r_begin);
+        if (in) {
+            if (need_ray[r]) s_any[wv][j] = 1;
+            if (max_efield[r] > min_efield) s_dec[wv][j] = 1;   // a ray whose sampled field already exceeds the cut makes the event a candidate
+        }
+    }
+    wave_lds_sync();
+    const int g = g0 + lane;
+    if (g < n_events) ev_need[g] = (s_dec[wv][lane] && !exact) ? 0 : s_any[wv][lane];
+    if (g == n_events) ev_need[g] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -3901,7 +3954,7 @@ void launch_event_possible(hipStream_t s, int n_events, int n_ch, const int* slo
 {
     if (n_events <= 0) return;
     hipLaunchKernelGGL(event_possible_kernel, dim3(grid_for(n_events, 256)), dim3(256), 0, s, n_events, n_ch, slot_offset,
-                       bound, min_efield, ray_active, own_only);
+                       bound, min_efield, ray_active, own_only);   // (a block = four waves of 64 groups each)
 }
 void launch_active_class_flags(hipStream_t s, int n_rays, const int* active, const int* ray_slot2, const int* slot_type,
                                int* flags)
