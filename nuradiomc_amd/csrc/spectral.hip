@@ -2474,71 +2474,100 @@ __device__ __noinline__ ConvOut conv_output_pass(int L, double vscale, double th
 // above / below (the w_hl - 1 samples in front of the run looked at once: O(run + w) instead of O(run x w)), the running index of
 // the last raised flag (registers); (2) after a scan over the runs' totals, the coincidence count.  Two barriers (were six).  Out
 // of line like conv_output_pass (its own register allocation).
-template <int RUN>
+template <int RUN, bool EXTRA>
 __device__ __noinline__ double conv_coinc_pass(int L, double vscale, double threshold, int ch_on, TriggerDev trg, double* __restrict__ tr,
-                                               const double* __restrict__ add, int with_signal, int* __restrict__ cnt, int* scan)
+                                               const double* __restrict__ add, int with_signal, int* __restrict__ cnt, int* scan,
+                                               int& any_flag)
 {
+    // Written for SIZE: the channel loop of channel_conv_kernel with its transforms is about as large as the instruction cache, and
+    // this pass -- once 2200 instructions of unrolled branches around the run's samples, executed once per channel -- took 1.5 x
+    // the forward transform's time on the 2-of-5 high / low arrays; a version with all reads in flight but MORE code was slower
+    // still.  Hence rolled loops of four samples, selects instead of branches, the trace dump / noise rows (EXTRA) in their own
+    // instantiation, and the per-sample counts in a second walk that only channels with a raised flag take.
     extern __shared__ __align__(16) unsigned char smem[];
     const double* S = (const double*)smem;
     const int NT = blockDim.x;
-    double vmax = 0.;
-    int a_loc[RUN];               // index of the last raised flag at or before the run's sample u (-1: none)
     const int nb = (trg.type == 0) ? L : L - 1;
-    const int chunk = (L + NT - 1) / NT, b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, L);
-    auto sample = [&](int n) {
+    // runs of an ODD number of samples: the threads of a wave read the buffer at a stride of `chunk` doubles, and an even stride
+    // (16 for L = 4096 on 256 threads) puts all 64 lanes on two LDS bank positions
+    const int chunk = ((L + NT - 1) / NT) | 1, b0 = threadIdx.x * chunk, b1 = min(b0 + chunk, L);
+    const double vs = with_signal ? vscale : 0.;
+    const bool hl = trg.type != 0;
+    auto folded = [&](int n) {   // y[n] + y[n + L]
         const int n2 = n + L;
-        double v = with_signal ? (S[2 * conv_pad(n >> 1) + (n & 1)] + S[2 * conv_pad(n2 >> 1) + (n2 & 1)]) * vscale : 0.;
-        if (add) v += add[n];
-        return v;
+        return S[2 * conv_pad(n >> 1) + (n & 1)] + S[2 * conv_pad(n2 >> 1) + (n2 & 1)];
     };
-    int last_hi = -(1 << 30), last_lo = -(1 << 30), run = -1;
-    if (trg.type != 0 && b0 < b1) {
-        for (int k = b0 - (trg.w_hl - 1); k < b0; k++) {
-            const double v = (k >= 0) ? sample(k) : 0.;   // the reference pads with zeros in front
-            if (v >= trg.high) last_hi = k;
-            if (v <= trg.low) last_lo = k;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < RUN; u++) {
-        const int i = b0 + u;
-        a_loc[u] = -1;
-        if (u < chunk && i < b1) {
-            const double v = sample(i);
-            if (tr) tr[i] = v;
-            vmax = fmax(vmax, fabs(v));
-            bool flag;
-            if (trg.type == 0) {
-                flag = fabs(v) >= threshold;
-            } else {
-                if (v >= trg.high) last_hi = i;
-                if (v <= trg.low) last_lo = i;
-                flag = (i - last_hi < trg.w_hl) && (i - last_lo < trg.w_hl);
+    double vmax = 0.;
+    // one walk over the run: the index of the last raised flag at or before every sample goes to `sink`
+    auto walk = [&](bool first, auto&& sink) {
+        int last_hi = -(1 << 30), last_lo = -(1 << 30), run = -1;
+        if (hl && b0 < b1) {   // the w_hl - 1 samples in front of the run (the reference pads with zeros in front)
+#pragma unroll 1
+            for (int k = b0 - (trg.w_hl - 1); k < b0; k++) {
+                double x = (k >= 0) ? folded(k) * vs : 0.;
+                if (EXTRA && add && k >= 0) x += add[k];
+                last_hi = (x >= trg.high) ? k : last_hi;
+                last_lo = (x <= trg.low) ? k : last_lo;
             }
-            if (i < nb && flag && ch_on) run = i;
-            a_loc[u] = run;
         }
-    }
+#pragma unroll 1
+        for (int i0 = b0; i0 < b1; i0 += 4) {
+            double x[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = i0 + q;
+                x[q] = folded(i < b1 ? i : 0) * vs;
+            }
+            if (EXTRA) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = i0 + q;
+                    if (add && i < b1) x[q] += add[i];
+                    if (tr && first && i < b1) tr[i] = x[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = i0 + q;
+                const bool ok = i < b1;
+                const double ax = fabs(x[q]);
+                vmax = ok ? fmax(vmax, ax) : vmax;
+                last_hi = (ok && x[q] >= trg.high) ? i : last_hi;
+                last_lo = (ok && x[q] <= trg.low) ? i : last_lo;
+                const bool flag = hl ? ((i - last_hi < trg.w_hl) && (i - last_lo < trg.w_hl)) : (ax >= threshold);
+                run = (ok && i < nb && flag && ch_on) ? i : run;
+                if (ok) sink(i, run);
+            }
+        }
+        return run;
+    };
+    const int run = walk(true, [](int, int) {});
     // running maximum across the runs: a wave-level scan of the runs' last values (shuffles), the waves' totals through LDS
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int incl = run;
     for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off);
-        if (lane >= off) incl = max(incl, v);
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl = max(incl, t);
     }
     if (lane == 63) scan[wv] = incl;
     int before = __shfl_up(incl, 1);
     if (lane == 0) before = -1;
     lds_barrier();
-    for (int q = 0; q < wv; q++) before = max(before, scan[q]);
-    const int wc = min(trg.w_coinc, nb);
-#pragma unroll
-    for (int u = 0; u < RUN; u++) {
-        const int i = b0 + u;
-        if (u < chunk && i < min(b1, nb - 1)) {
-            const int a = max(a_loc[u], before);
-            if (a >= 0 && i - a < wc) cnt[i] += 1;
-        }
+    int top = -1;   // has the channel raised a flag at all?  (the same for every thread: the waves' totals)
+    for (int q = 0; q < NT / 64; q++) {
+        const int t = scan[q];
+        if (q < wv) before = max(before, t);
+        top = max(top, t);
+    }
+    any_flag = top >= 0;
+    if (top >= 0) {   // the coincidence count: flag i stays up for w_coinc samples
+        const int wc = min(trg.w_coinc, nb), i_end = min(b1, nb - 1);
+        const double keep = vmax;
+        (void)walk(false, [&](int i, int r) {
+            const int a = max(r, before);
+            if (i < i_end && a >= 0 && i - a < wc) cnt[i] += 1;
+        });
+        vmax = keep;
     }
     lds_barrier();
     return vmax;
@@ -2612,7 +2641,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     __shared__ unsigned short s_rct[CONV_STAGE_RAYS];   // (channel << 4) | antenna table of the event's rays
     __shared__ short s_order[2][CONV_MAX_ORDER];
     __shared__ int s_norder[2];
-    const bool best_first = !exact && !coinc && st.n_ch <= CONV_MAX_ORDER;
+    const bool best_first = !exact && st.n_ch <= CONV_MAX_ORDER;   // the needed channels of an event in the order of their bounds
     // events are handed out through a counter in HBM (zero at launch): their cost varies with the number of channels and rays
     __shared__ int s_le[2];
     int par = 0;
@@ -2632,13 +2661,21 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
           }
           if (!mine_ev) cnt_o = -1;
           else if (best_first && le0 < n_list_events) {
+              // plain OR: the channel with the largest bound first (the event is done at the first trigger).  Coincidence: the
+              // WEAKEST first -- the early stop below counts silent channels, and the likely loud one is then the one it saves
               for (int ch = 0; ch < st.n_ch; ch++) {
                   if (!need[base + ch]) continue;
-                  const double b = -out.maxV[base + ch];   // the prefilter's bound
+                  const double b = coinc ? out.maxV[base + ch] : -out.maxV[base + ch];   // (the prefilter leaves -bound)
                   int k = cnt_o++;
-                  while (k > 0 && -out.maxV[base + s_order[par][k - 1]] < b) { s_order[par][k] = s_order[par][k - 1]; k--; }
+                  while (k > 0 && (coinc ? out.maxV[base + s_order[par][k - 1]] : -out.maxV[base + s_order[par][k - 1]]) < b) {
+                      s_order[par][k] = s_order[par][k - 1];
+                      k--;
+                  }
                   s_order[par][k] = (short)ch;
               }
+          }
+          else if (coinc && !exact && le0 < n_list_events) {   // (more channels than the ordered list holds: channel order, counted)
+              for (int ch = 0; ch < st.n_ch; ch++) cnt_o += need[base + ch] != 0;
           }
           s_norder[par] = cnt_o;
       }
@@ -2687,6 +2724,12 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       // through the barrier-free skip path below
       bool ev_trig = false;
       const int n_steps = best_first ? s_norder[par] : st.n_ch;
+      // n-fold coincidence, production mode: once the channels that raised a flag plus the channels still to come are fewer than n
+      // the event cannot trigger any more -- the rest of its channels is not transformed (the mask is the same; a 2-fold
+      // coincidence on two candidate channels ends after the first one that stays silent)
+      const bool coinc_stop = coinc && !exact && out.trace == nullptr;
+      const int m_need = s_norder[par];
+      int n_done = 0, n_flagged = 0;
       // emission of a triggered event's traces: once a channel has triggered, ALL channels of the event are evaluated (in channel
       // order, the pruned ones included) and written into the block reserved for the event
       const bool can_emit = MODE == 1 && out.emit != nullptr && !exact;
@@ -3013,14 +3056,20 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 vmax = co.vmax;
                 trig = co.trig;
             } else {
-                vmax = conv_coinc_pass<M / NT>(L, vscale, threshold, ch_on ? 1 : 0, trg, out.trace ? out.trace + out.trace_offset[item] : nullptr,
-                                               noisy ? nbuf : nullptr, sig ? 1 : 0, cnt, s_scan);
+                int any_flag = 0;
+                if (out.trace || noisy)
+                    vmax = conv_coinc_pass<M / NT, true>(L, vscale, threshold, ch_on ? 1 : 0, trg, out.trace ? out.trace + out.trace_offset[item] : nullptr,
+                                                         noisy ? nbuf : nullptr, sig ? 1 : 0, cnt, s_scan, any_flag);
+                else
+                    vmax = conv_coinc_pass<M / NT, false>(L, vscale, threshold, ch_on ? 1 : 0, trg, nullptr, nullptr, sig ? 1 : 0, cnt, s_scan, any_flag);
+                n_flagged += any_flag;
             }
         }
         else if (emitting) {   // a channel without rays: zeros, as the reference's empty channels
             double* const em = out.emit + e_off + (long long)ch * L;
             for (int n = threadIdx.x; n < L; n += blockDim.x) em[n] = 0.;
         }
+        n_done++;
         CT(12);
         // maximum and trigger flag of the channel with ONE barrier: wave-level reduction, a word per wave and a flag in the buffer of
         // this phase's parity (the other buffer is cleared for the next phase), every thread reads the result for itself
@@ -3071,6 +3120,13 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 step = -1;   // restart: every channel in channel order
             }
             lds_barrier();
+        }
+        if (coinc_stop && n_flagged + (m_need - n_done) < trg.n_coinc) {   // (block-uniform: counts of whole channels)
+            if (threadIdx.x == 0) {   // the rest is not evaluated
+                if (best_first) { for (int s2 = step + 1; s2 < n_steps; s2++) out.maxV[ev_item0 + s_order[par][s2]] = NAN; }
+                else { for (int c2 = ch + 1; c2 < st.n_ch; c2++) if (need[ev_item0 + c2]) out.maxV[ev_item0 + c2] = NAN; }
+            }
+            break;
         }
       }
       asm volatile("" :: "v"(touch_acc));

@@ -733,6 +733,9 @@ def test_trigger_modes(gpu_ctx_factory, kw):
     assert np.array_equal(trig, expect) and 3 <= trig.sum() < len(item_event)
     trig_p, _ = st.simulate_events(*args, **opts)
     assert np.array_equal(trig_p, trig)
+    if kw['n_coincidences'] > 1:   # coincidence logic in production mode stops an event once it cannot trigger any more (the
+        # silent channels are counted): mask AND first bin of the events that do trigger stay those of all channels
+        assert np.array_equal(st.fetch('ev_trigger_bin')[:n][trig], tbin[:n][trig])
 
 
 @pytest.mark.parametrize('name,n_events', [('N256', 300), ('N256_hpol', 150), ('N256_lpda', 200), ('N4096', 60), ('N256_hw', 220),
