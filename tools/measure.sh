@@ -40,6 +40,8 @@ cp $(find $OUT/c4stats -name 'x_kernel_stats.csv' | head -1) $OUT/${R}_rocprofv3
 rm -rf $OUT/c4stats
 # round 4: the whole drop-in (host list -> output tables), the two-rank launch on this one GPU, the convolution kernel's phases
 # (the whole drop-in, host list -> output tables, is the `end_to_end` object of the default line since round 5)
+python3 bench.py --scaling strong --events 200000 --steps 3 --no-cpu-baseline --no-end-to-end --write-expected-sha > /dev/null 2>> $OUT/bench_config2.log   # (the one-rank hash of the list the two ranks share)
+cp profiles/expected_mask_sha16.json $OUT/ 2>/dev/null
 python3 bench.py --gpus 2 --allow-tcp --scaling strong --events 200000 --steps 3 --no-cpu-baseline > $OUT/bench_config2_two_ranks_one_gpu.json 2>> $OUT/bench_config2.log
 [ -f nuradiomc_amd/lib/libnrhip_ct.so ] && { python3 tools/conv_phase_probe.py; python3 tools/conv_phase_probe.py --no-traces; python3 tools/conv_phase_probe.py --config 5 --steps 1 --events 300000; } > $OUT/conv_phases.log 2>&1
 # where a 125 k-event shard spends its time (kernel sum vs step)
