@@ -401,18 +401,27 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
                 }
                 const int is = pis[ip], last = pie[ip] - 1;
                 const double start = pstart[ip], delta = pdelta[ip];
+                // (the slice's end nodes once per stretch: inside the loop they were two dependent LDS round trips per point)
+                const double d_is = nf ? s_depth[is] : 0., d_last = nf ? s_depth[last] : 0., ce_is = nf ? s_ce[is] : 0., ce_last = nf ? s_ce[last] : 0.;
                 for (int k = lane; k < nf; k += 64) {
                     const int g = off[ip] + nc + k;
                     const double x = (k == 0) ? start : (k == 1 ? start + step : start + k * delta);
                     double q;   // np.interp on the slice [is, ie): constant beyond its last node
-                    if (x <= s_depth[is]) q = s_ce[is];
-                    else if (x >= s_depth[last]) q = s_ce[last];
+                    if (x <= d_is) q = ce_is;
+                    else if (x >= d_last) q = ce_last;
                     else {
                         int kk = is + (int)((x - start) * inv_coarse);
                         kk = kk < is ? is : (kk > last - 1 ? last - 1 : kk);
-                        while (kk > is && s_depth[kk] > x) kk--;
-                        while (kk < last - 1 && s_depth[kk + 1] <= x) kk++;
-                        q = s_slope[kk] * (x - s_depth[kk]) + s_ce[kk];
+                        // the guessed cell is nearly always the right one: its four numbers in ONE LDS round trip, np.interp's search
+                        // (two dependent round trips per point) only where the guess is off
+                        double dk = s_depth[kk], sl = s_slope[kk], ck = s_ce[kk];
+                        const double dk1 = s_depth[kk + 1];
+                        if (!((kk <= is || dk <= x) && (kk >= last - 1 || dk1 > x))) {
+                            while (kk > is && s_depth[kk] > x) kk--;
+                            while (kk < last - 1 && s_depth[kk + 1] <= x) kk++;
+                            dk = s_depth[kk]; sl = s_slope[kk]; ck = s_ce[kk];
+                        }
+                        q = sl * (x - dk) + ck;
                     }
                     double xl, xr;
                     if (k >= 3 && k + 1 < nf) {   // inside the stretch: the neighbours are fine points too
