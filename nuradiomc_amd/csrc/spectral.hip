@@ -2474,10 +2474,10 @@ __device__ __noinline__ ConvOut conv_output_pass(int L, double vscale, double th
 // above / below (the w_hl - 1 samples in front of the run looked at once: O(run + w) instead of O(run x w)), the running index of
 // the last raised flag (registers); (2) after a scan over the runs' totals, the coincidence count.  Two barriers (were six).  Out
 // of line like conv_output_pass (its own register allocation).
+struct CoincOut { double vmax; int any_flag; };   // (both in registers: a reference parameter would come back through the stack)
 template <int RUN, bool EXTRA>
-__device__ __noinline__ double conv_coinc_pass(int L, double vscale, double threshold, int ch_on, TriggerDev trg, double* __restrict__ tr,
-                                               const double* __restrict__ add, int with_signal, int* __restrict__ cnt, int* scan,
-                                               int& any_flag)
+__device__ __noinline__ CoincOut conv_coinc_pass(int L, double vscale, double threshold, int ch_on, TriggerDev trg, double* __restrict__ tr,
+                                                 const double* __restrict__ add, int with_signal, int* __restrict__ cnt, int* scan)
 {
     // Written for SIZE: the channel loop of channel_conv_kernel with its transforms is about as large as the instruction cache, and
     // this pass -- once 2200 instructions of unrolled branches around the run's samples, executed once per channel -- took 1.5 x
@@ -2559,7 +2559,6 @@ __device__ __noinline__ double conv_coinc_pass(int L, double vscale, double thre
         if (q < wv) before = max(before, t);
         top = max(top, t);
     }
-    any_flag = top >= 0;
     if (top >= 0) {   // the coincidence count: flag i stays up for w_coinc samples
         const int wc = min(trg.w_coinc, nb), i_end = min(b1, nb - 1);
         const double keep = vmax;
@@ -2570,7 +2569,8 @@ __device__ __noinline__ double conv_coinc_pass(int L, double vscale, double thre
         vmax = keep;
     }
     lds_barrier();
-    return vmax;
+    CoincOut o = {vmax, top >= 0 ? 1 : 0};
+    return o;
 }
 template <int NT, class FV, class FS>
 __device__ __forceinline__ void czt_inverse_blocks(double2* x, const double2* __restrict__ Bi, const double2* __restrict__ tw,
@@ -3056,13 +3056,14 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
                 vmax = co.vmax;
                 trig = co.trig;
             } else {
-                int any_flag = 0;
+                CoincOut co;
                 if (out.trace || noisy)
-                    vmax = conv_coinc_pass<M / NT, true>(L, vscale, threshold, ch_on ? 1 : 0, trg, out.trace ? out.trace + out.trace_offset[item] : nullptr,
-                                                         noisy ? nbuf : nullptr, sig ? 1 : 0, cnt, s_scan, any_flag);
+                    co = conv_coinc_pass<M / NT, true>(L, vscale, threshold, ch_on ? 1 : 0, trg, out.trace ? out.trace + out.trace_offset[item] : nullptr,
+                                                       noisy ? nbuf : nullptr, sig ? 1 : 0, cnt, s_scan);
                 else
-                    vmax = conv_coinc_pass<M / NT, false>(L, vscale, threshold, ch_on ? 1 : 0, trg, nullptr, nullptr, sig ? 1 : 0, cnt, s_scan, any_flag);
-                n_flagged += any_flag;
+                    co = conv_coinc_pass<M / NT, false>(L, vscale, threshold, ch_on ? 1 : 0, trg, nullptr, nullptr, sig ? 1 : 0, cnt, s_scan);
+                vmax = co.vmax;
+                n_flagged += co.any_flag;
             }
         }
         else if (emitting) {   // a channel without rays: zeros, as the reference's empty channels
