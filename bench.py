@@ -597,6 +597,8 @@ def main():
             ins = [d['in'][0] + 24 * a, d['in'][1] + 8 * a, d['in'][2] + 8 * a, d['in'][3] + 8 * a, d['in'][4] + 4 * a, d['in'][5] + 8 * a]
             kw_c = dict(dev_kw, n_groups=b - a, d_max_distance=None if d['md'] is None else d['md'] + 8 * a,
                         arz_rows=tuple(np.ascontiguousarray(r[a:b]) for r in dev_kw['arz_rows']))
+            if dev_kw.get('noise'):   # thermal noise is keyed by the group's index in the WHOLE list, not in the chunk
+                kw_c['noise_group_offset'] = int(dev_kw.get('noise_group_offset', 0)) + a
             s_ = det.simulate_events_dev(b - a, *ins, d['trig'] + a, want_stats=True, **kw_c)
             if total is None:
                 total = dict(s_)

@@ -83,6 +83,18 @@ void nrhip_ctx_destroy(nrhip_ctx* ctx);
  * end values outside).  Its path integral follows the reference's speed-optimised scheme (analyticraytracing.py:998-1064:
  * 10 m segment sums, QUADPACK on ds around the turning depth).  HOST pointers.                                        */
 int nrhip_ctx_set_gl3_table(nrhip_ctx* ctx, int32_t n, const double* depth, const double* slope, const double* offset);
+
+/* Which solution finder find_solutions runs (analyticraytracing.py:1400-1547) -- for every later call on this context:
+ *   NRHIP_FINDER_TRUE_ROOTS (default): every root of the path objective out of a bracket.  The list is the mathematically true
+ *     one; the reference's list is a subset of it (it loses its first root on 0.2 ... 0.4 % of random pairs, see below).
+ *   NRHIP_FINDER_REFERENCE: the reference's procedure to the letter -- scipy.optimize.root(tol=1e-6) on (delta y)^2 from
+ *     log C0 = -1, the iterate kept only if (delta y)^2 < 1e-7 there (:1479-1483), then one Brent search either side, 1e-4 away
+ *     (:1498-1541) -- for every pair and every call with bottom reflections.  Counts, types and order are then the reference's
+ *     wherever the last bits of its libm agree with the kernels' exp / log (the acceptance test sits ~1e-7 off a double root).
+ *     About three times the objective evaluations of the default.                                                              */
+#define NRHIP_FINDER_TRUE_ROOTS 0
+#define NRHIP_FINDER_REFERENCE 1
+int nrhip_ctx_set_ray_finder(nrhip_ctx* ctx, int32_t finder);
 const char* nrhip_last_error(void);
 int nrhip_device_count(void);
 int nrhip_synchronize(nrhip_ctx* ctx);

@@ -46,6 +46,7 @@ def load():
     _sig(lib, 'nrhip_memcpy_d2h', ctypes.c_int, [vp, vp, vp, ctypes.c_uint64])
     _sig(lib, 'nrhip_find_solutions_batch', ctypes.c_int,
          [vp, i64, c_double_p, c_double_p, i32, c_int32_p, c_int32_p] + [c_double_p] * 7)
+    _sig(lib, 'nrhip_ctx_set_ray_finder', ctypes.c_int, [vp, i32])
     _sig(lib, 'nrhip_ctx_set_gl3_table', ctypes.c_int, [vp, i32, c_double_p, c_double_p, c_double_p])
     _sig(lib, 'nrhip_ray_records_batch', ctypes.c_int,
          [vp, i64, c_double_p, c_double_p, i32, c_double_p, c_int32_p, c_int32_p] + [c_double_p] * 7)

@@ -7,6 +7,7 @@ from . import station as _station  # noqa: F401  (registers the station entry po
 #: NuRadioMC/utilities/attenuation.py:14
 ATTENUATION_MODEL_TO_INT = {"SP1": 1, "GL1": 2, "MB1": 3, "GL2": 4, "GL3": 5}
 MAXS = 2
+RAY_FINDER_TO_INT = {'true_roots': 0, 'reference': 1}   # NRHIP_FINDER_*
 
 
 CROSS_SECTION_TO_INT = {'ctw': 0, 'ghandi': 1, 'given': 2}   # 'given': `energy` carries the cross sections [m^2]
@@ -21,9 +22,11 @@ class _EarthModel(ctypes.Structure):  # nrhip_earth_model
 class Context:
     """Owns a `nrhip_ctx`.  `ice` is (n_ice, delta_n, z_0) of n(z) = n_ice - delta_n exp(z / z_0)."""
 
-    def __init__(self, ice, attenuation_model="SP1", device=0, gl3_table=None):
+    def __init__(self, ice, attenuation_model="SP1", device=0, gl3_table=None, ray_finder='true_roots'):
         """gl3_table (GL3 only): the depth table of the model, an [n, 3] array (depth, slope, offset) or the path of
-        NuRadioMC/utilities/data/GL3_params.csv (comma separated) -- the model is defined by that file."""
+        NuRadioMC/utilities/data/GL3_params.csv (comma separated) -- the model is defined by that file.
+        ray_finder: 'true_roots' (default: every root of the path objective, a superset of the reference's list) or 'reference'
+        (the reference's procedure and acceptance test to the letter, analyticraytracing.py:1476-1547; `set_ray_finder`)."""
         self._lib = L.load()
         if attenuation_model not in ATTENUATION_MODEL_TO_INT:
             raise NotImplementedError("attenuation model {} is not implemented".format(attenuation_model))
@@ -40,6 +43,16 @@ class Context:
             t = np.genfromtxt(gl3_table, delimiter=',') if isinstance(gl3_table, str) else np.asarray(gl3_table, float)
             d, sl, of = (np.ascontiguousarray(t[:, k]) for k in range(3))
             L.check(self._lib.nrhip_ctx_set_gl3_table(h, len(t), L.dptr(d), L.dptr(sl), L.dptr(of)))
+        self.ray_finder = 'true_roots'
+        if ray_finder != 'true_roots':
+            self.set_ray_finder(ray_finder)
+
+    def set_ray_finder(self, finder):
+        """'true_roots' | 'reference' (nrhip_ctx_set_ray_finder) for every later call on this context."""
+        if finder not in RAY_FINDER_TO_INT:
+            raise ValueError("ray_finder must be one of {}".format(sorted(RAY_FINDER_TO_INT)))
+        L.check(self._lib.nrhip_ctx_set_ray_finder(self._h, RAY_FINDER_TO_INT[finder]))
+        self.ray_finder = finder
 
     def close(self):
         if getattr(self, '_h', None):

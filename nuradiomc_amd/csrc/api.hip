@@ -94,6 +94,16 @@ void nrhip_ctx_destroy(nrhip_ctx* ctx)
     delete ctx;
 }
 
+int nrhip_ctx_set_ray_finder(nrhip_ctx* ctx, int32_t finder)
+{
+    if (!ctx) return fail_msg("nrhip_ctx_set_ray_finder: NULL context");
+    if (finder != NRHIP_FINDER_TRUE_ROOTS && finder != NRHIP_FINDER_REFERENCE) return fail_msg("nrhip_ctx_set_ray_finder: unknown finder");
+    if (finder != ctx->ray_finder)
+        for (auto* s : ctx->stations) s->generation++;   // ray tables kept for reuse_ray_tables were made by the other finder
+    ctx->ray_finder = finder;
+    return 0;
+}
+
 int nrhip_ctx_set_gl3_table(nrhip_ctx* ctx, int32_t n, const double* depth, const double* slope, const double* offset)
 {
     if (!ctx || !depth || !slope || !offset) return fail_msg("nrhip_ctx_set_gl3_table: NULL argument");
@@ -204,7 +214,7 @@ static int ray_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const do
         HIPCHK(hipMemcpyAsync(dgiven.p, C0_in, n_pairs * S * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     nrhip::launch_raytrace(ctx->stream, n_pairs, dx1.as<double>(), dx2.as<double>(), n_x2, ctx->ice, r, nullptr, nullptr,
-                           C0_in ? dgiven.as<double>() : nullptr);
+                           C0_in ? dgiven.as<double>() : nullptr, nullptr, nullptr, nullptr, ctx->ray_finder == NRHIP_FINDER_REFERENCE);
     HIPCHK(hipGetLastError());
 #define D2H(dst, src, bytes) if (dst) HIPCHK(hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToHost, ctx->stream))
     D2H(n_sol, dns, n_pairs * 4);
@@ -314,7 +324,7 @@ static int refl_batch(nrhip_ctx* ctx, int64_t n_pairs, const double* x1, const d
         HIPCHK(hipMemcpyAsync(drc.p, reflection_case, nk * 4, hipMemcpyHostToDevice, ctx->stream));
     } else {
         nrhip::launch_find_refl(ctx->stream, n_pairs, n_reflections, dx1.as<double>(), dx2.as<double>(), n_x2, ctx->ice,
-                                z_reflection, dcn.as<int>(), dcc.as<double>());
+                                z_reflection, dcn.as<int>(), dcc.as<double>(), ctx->ray_finder == NRHIP_FINDER_REFERENCE);
     }
     nrhip::launch_records_refl(ctx->stream, n_pairs, n_reflections, S, dx1.as<double>(), dx2.as<double>(), n_x2, ctx->ice,
                                z_reflection, dcn.as<int>(), dcc.as<double>(), given, r);

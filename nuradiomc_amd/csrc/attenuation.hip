@@ -115,7 +115,7 @@ __device__ inline void sp1_coefficients(double z, double p[4])
 // the same number without the two divisions (the CPU checker's integrand is written the same way).
 __device__ inline double sp1_ds_over_length(double ds, double z, double aa, double bb, double w)
 {
-    double e = det_exp(aa + bb * w);
+    double e = det_exp_tab(aa + bb * w);   // (the integrand's own exp: detmath.h)
     if (e > 1.) e = 1.;
     if (z > 0) e = 0.;
     return ds * e;
@@ -551,7 +551,7 @@ struct GroupEval {
                         const NodeShared& s = nodes[n];
                         const double x = s.p[sel] + s.p[sel + 1] * w;
                         ok = ok && (fabs(x) <= 700.);
-                        return s.ds * fmin(det_exp_inrange(x), 1.);
+                        return s.ds * fmin(det_exp_tab_inrange(x, det_exp_tab64), 1.);   // (overflow rays only: the table from L1)
                     }, fbuf);
                     __builtin_amdgcn_sched_barrier(0);
                     if (two)
@@ -559,7 +559,7 @@ struct GroupEval {
                             const NodeShared& s = nodes[21 + n];
                             const double x = s.p[sel] + s.p[sel + 1] * w;
                             ok = ok && (fabs(x) <= 700.);
-                            return s.ds * fmin(det_exp_inrange(x), 1.);
+                            return s.ds * fmin(det_exp_tab_inrange(x, det_exp_tab64), 1.);   // (overflow rays only: the table from L1)
                         }, fbuf);
                 }
                 if (__ballot(!ok) != 0ULL && want) {   // never on physical rays: the per-lane general code (same bits)

@@ -70,6 +70,7 @@ struct DenseLds {
     double rlist[ATTD_K][64], elist[ATTD_K][64];
     unsigned char tchild[ATTD_NG][ATTD_T];             // first child (0: not bisected yet); the second one follows it
     unsigned char tdepth[ATTD_NG][ATTD_T];             // QAGP's level of the interval
+    double exp_tab[64];                                // 2^(j / 64) for det_exp_tab_inrange (detmath.h)
 };
 
 // one 21-point rule from the group's node records; same operations and order as gk21_from_nodes, node values in registers.
@@ -77,7 +78,7 @@ struct DenseLds {
 // >= +0 (ds >= 0 times min(exp, 1) > 0) the sum of |f| that QUADPACK keeps as resabs receives exactly the terms of resk in
 // the same order from the same start: resabs == resk bit for bit (NaN alike), so it is not accumulated separately.
 template <int MODEL>
-__device__ __forceinline__ GK dense_rule(const DenseRec<MODEL>* __restrict__ r, double a, double b, const AttLane& lane, int sel)
+__device__ __forceinline__ GK dense_rule(const DenseRec<MODEL>* __restrict__ r, double a, double b, const AttLane& lane, int sel, const double* exp_tab)
 {
     const double WGK[11] = {
         0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
@@ -94,7 +95,7 @@ __device__ __forceinline__ GK dense_rule(const DenseRec<MODEL>* __restrict__ r, 
     auto fval = [&](int n) -> double {
         if constexpr (MODEL == 1) {
             const double x = r[n].p[sel] + r[n].p[sel + 1] * lane.w;
-            return r[n].ds * fmin(det_exp_inrange(x), 1.);
+            return r[n].ds * fmin(det_exp_tab_inrange(x, exp_tab), 1.);
         } else {
             return r[n].ds / attenuation_length(r[n].z, lane);
         }
@@ -103,7 +104,7 @@ __device__ __forceinline__ GK dense_rule(const DenseRec<MODEL>* __restrict__ r, 
         if constexpr (MODEL == 1) {
             const double x1 = r[n1].p[sel] + r[n1].p[sel + 1] * lane.w, x2 = r[n2].p[sel] + r[n2].p[sel + 1] * lane.w;
             double e1, e2;
-            det_exp_inrange2(x1, x2, e1, e2);
+            det_exp_tab_inrange2(x1, x2, exp_tab, e1, e2);
             f1 = r[n1].ds * fmin(e1, 1.);
             f2 = r[n2].ds * fmin(e2, 1.);
         } else {
@@ -331,6 +332,7 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
                          int* __restrict__ overflow_count, int* __restrict__ overflow_list)
 {
     __shared__ DenseLds<MODEL> L;
+    L.exp_tab[threadIdx.x & 63] = det_exp_tab64[threadIdx.x & 63];   // (one wave per block: ordered before the first rule by the wave's own syncs)
     const double epmach = 2.220446049250313e-16, uflow = 2.2250738585072014e-308, oflow = 1.7976931348623157e+308;
     const double epsabs = 1.49e-8, epsrel = 1e-2;
     const int limit = QLIM;
@@ -545,7 +547,7 @@ attenuation_dense_kernel(long n_rays, const double* __restrict__ C0, const doubl
                     if (ok) {
 #pragma unroll 1
                         for (int iv = 0; iv < (two ? 2 : 1); iv++) {   // (one copy of the rule's code)
-                            const GK q = dense_rule<MODEL>(&L.rec[gi][iv][0], L.ta[gi][c + iv], L.tb[gi][c + iv], al, sel);
+                            const GK q = dense_rule<MODEL>(&L.rec[gi][iv][0], L.ta[gi][c + iv], L.tb[gi][c + iv], al, sel, L.exp_tab);
                             if (iv) g2 = q;
                             else g1 = q;
                         }

@@ -44,6 +44,29 @@ __device__ __forceinline__ double2 cmulcx(double2 a, double2 b)   // a * conj(b)
     return make_double2(fma(a.x, b.x, a.y * b.y), fma(a.y, b.x, -(a.x * b.y)));
 }
 
+
+// Tables (twiddles, response spectra) live in HBM / L2.  Through a plain pointer parameter of an out-of-line function -- or one that
+// went through conv_opaque -- the compiler no longer knows that and issues FLAT loads, which count against BOTH memory counters: every
+// wait for an LDS read (lgkmcnt) then also waits for the table loads in flight, and the passes came out as "request everything, wait
+// for everything, compute".  gload() reads through an explicit global address: global_load, counted by vmcnt alone.
+typedef double conv_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 gload(const double2* p)
+{
+    const conv_d2v v = *(const __attribute__((address_space(1))) conv_d2v*)p;
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ double gload(const double* p) { return *(const __attribute__((address_space(1))) double*)p; }
+__device__ __forceinline__ int gload(const int* p) { return *(const __attribute__((address_space(1))) int*)p; }
+__device__ __forceinline__ unsigned char gload(const unsigned char* p) { return *(const __attribute__((address_space(1))) unsigned char*)p; }
+__device__ __forceinline__ void gstore(double2* p, const double2 v)
+{
+    conv_d2v w;
+    w.x = v.x;
+    w.y = v.y;
+    *(__attribute__((address_space(1))) conv_d2v*)p = w;
+}
+__device__ __forceinline__ void gstore(double* p, double v) { *(__attribute__((address_space(1))) double*)p = v; }
+
 __device__ __forceinline__ int conv_pad(int i) { return i + (i >> 10); }
 // complex elements of the padded buffer: the M points + block padding, and behind the event's samples (M / 2 + padding) room for
 // the wave-private ray transforms (8 or 4 blocks of 512 points, block stride 532 / 520: ray_blk_stride)
@@ -161,7 +184,7 @@ __device__ __forceinline__ void conv_p2_fwd(double2* zb, const double2* __restri
 {
     double2 a[16], t[15];
 #pragma unroll
-    for (int s = 0; s < 15; s++) t[s] = cft[CFT_T2 + s * 64 + lane];
+    for (int s = 0; s < 15; s++) t[s] = gload(&cft[CFT_T2 + s * 64 + lane]);
 #pragma unroll
     for (int j = 0; j < 16; j++) a[j] = zb[lane + 64 * j];
 #pragma unroll
@@ -187,7 +210,7 @@ __device__ __forceinline__ void conv_p2_inv(double2* zb, const double2* __restri
 {
     double2 a[16], t[15];
 #pragma unroll
-    for (int s = 0; s < 15; s++) t[s] = cft[CFT_T2 + s * 64 + lane];
+    for (int s = 0; s < 15; s++) t[s] = gload(&cft[CFT_T2 + s * 64 + lane]);
     const int wb = (lane >> 3) * 128 + (lane & 7);
 #pragma unroll
     for (int j = 0; j < 16; j++) a[j] = zb[wb + (j >> 3) * 64 + 8 * (j & 7)];
@@ -215,7 +238,7 @@ __device__ __forceinline__ void conv_p3_fwd(double2* zb, const double2* __restri
     double2 a[2][8], t[7];
     const int c = lane & 7, jl = lane >> 3;
 #pragma unroll
-    for (int s = 0; s < 7; s++) t[s] = cft[CFT_T3 + s * 8 + c];
+    for (int s = 0; s < 7; s++) t[s] = gload(&cft[CFT_T3 + s * 8 + c]);
 #pragma unroll
     for (int u = 0; u < 2; u++)
 #pragma unroll
@@ -244,7 +267,7 @@ __device__ __forceinline__ void conv_p3_inv(double2* zb, const double2* __restri
     double2 a[2][8], t[7];
     const int c = lane & 7, jl = lane >> 3;
 #pragma unroll
-    for (int s = 0; s < 7; s++) t[s] = cft[CFT_T3 + s * 8 + c];
+    for (int s = 0; s < 7; s++) t[s] = gload(&cft[CFT_T3 + s * 8 + c]);
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int wb = c + 8 * br4(jl + 8 * u);
@@ -288,7 +311,7 @@ __device__ __forceinline__ void ray_p2(double2* zb, const double2* __restrict__ 
 {
     double2 a[8], t[7];
 #pragma unroll
-    for (int s = 0; s < 7; s++) t[s] = cft[CFT_T2 + (8 + s) * 64 + lane];
+    for (int s = 0; s < 7; s++) t[s] = gload(&cft[CFT_T2 + (8 + s) * 64 + lane]);
 #pragma unroll
     for (int j = 0; j < 8; j++) a[j] = zb[lane + 64 * j];
 #pragma unroll
@@ -312,7 +335,7 @@ __device__ __forceinline__ void ray_p3(double2* zb, const double2* __restrict__ 
     double2 a[8], t[7];
     const int c = lane & 7, j = lane >> 3;
 #pragma unroll
-    for (int s = 0; s < 7; s++) t[s] = cft[CFT_T3 + s * 8 + c];
+    for (int s = 0; s < 7; s++) t[s] = gload(&cft[CFT_T3 + s * 8 + c]);
 #pragma unroll
     for (int h = 0; h < 8; h++) a[h] = zb[h * 64 + lane];
 #pragma unroll
@@ -371,8 +394,8 @@ __device__ __noinline__ void conv_fwd(const double2* __restrict__ tw, const doub
             // first stage (span M / 2): the partners are zero unless FULL
 #pragma unroll
             for (int j = 0; j < NB / 2; j++) {
-                if (FULL) dif_bf(a[j], a[j + NB / 2], tw[(i0 + 1024 * j) * (8 >> LW)]);
-                else a[j + NB / 2] = cmulx(a[j], tw[(i0 + 1024 * j) * (8 >> LW)]);
+                if (FULL) dif_bf(a[j], a[j + NB / 2], gload(&tw[(i0 + 1024 * j) * (8 >> LW)]));
+                else a[j + NB / 2] = cmulx(a[j], gload(&tw[(i0 + 1024 * j) * (8 >> LW)]));
             }
 #pragma unroll
             for (int e = 1; e < LW; e++) {
@@ -380,7 +403,7 @@ __device__ __noinline__ void conv_fwd(const double2* __restrict__ tw, const doub
 #pragma unroll
                 for (int b = 0; b < NB; b += 2 * half)
 #pragma unroll
-                    for (int j = 0; j < half; j++) dif_bf(a[b + j], a[b + j + half], tw[(i0 + 1024 * j) * ((8 >> LW) << e)]);
+                    for (int j = 0; j < half; j++) dif_bf(a[b + j], a[b + j + half], gload(&tw[(i0 + 1024 * j) * ((8 >> LW) << e)]));
             }
 #pragma unroll
             for (int j = 0; j < NB; j++) z[j * 1025 + i0] = a[j];
@@ -421,9 +444,28 @@ __device__ __noinline__ void conv_mid(const double2* __restrict__ G, const doubl
     double2* z = (double2*)smem;
     constexpr int M = 1 << LOG2M, NA = M / 16, K = M / 8, LW = LOG2M - 10, gs = FFT_MAX / M;
     const int t = threadIdx.x;
+    const bool act = NA == NT || t < NA;
+    const int kA = (t == 0) ? 0 : t, kB = (t == 0) ? K / 2 : K - t;
+    const bool sp = t == 0;
+    // Every table value of the pass is requested BEFORE the barrier and the LDS reads (round 6): the loads depend on the thread index
+    // alone, and behind the three butterfly stages -- where they used to be issued, in two batches with a full wait each -- their
+    // L2 / HBM latency (the response spectrum of the event's length is cold more often than not) was exposed twice per channel.
+    // Slot r of the loop below reads the bins kn(r) and M - kn(r).
+    double2 wkA = make_double2(1., 0.), wkB = wkA, Gk[8], Gm[8], Gh = wkA, wh = wkA;
+    if (act) {
+        wkA = gload(&w16[gs * kA]);   // thread 0: 1 and exp(-i pi / 16)
+        wkB = gload(&w16[gs * kB]);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int m = br3(r);
+            const int kn = (m < 4) ? kA + K * m : kB + K * (7 - m);
+            Gk[r] = gload(&G[gs * kn]);
+            Gm[r] = gload(&G[gs * (M - kn)]);
+        }
+        if (sp) { Gh = gload(&G[gs * (M / 2)]); wh = gload(&w16[gs * (M / 2)]); }
+    }
     lds_barrier();
-    if (NA == NT || t < NA) {
-        const int kA = (t == 0) ? 0 : t, kB = (t == 0) ? K / 2 : K - t;
+    if (act) {
         // block of bin group k0: the wave whose residue it is (bit-reversed), position inside: 8 (k0 >> LW)
         const int wA = (LW == 3) ? br3(kA & 7) : (LW == 2 ? (((kA & 1) << 1) | ((kA >> 1) & 1)) : (kA & 1));
         const int wB = (LW == 3) ? br3(kB & 7) : (LW == 2 ? (((kB & 1) << 1) | ((kB >> 1) & 1)) : (kB & 1));
@@ -440,8 +482,6 @@ __device__ __noinline__ void conv_mid(const double2* __restrict__ G, const doubl
         // their own mirrors -- group 0: bins m K, mirror (8 - m) K, m = 0 and 4 alone; group K / 2: slot r with slot 7 - r -- and
         // runs them through the SAME eight slots (operands and results dealt by selects: a branch of its own made wave 0, and
         // every wave at the barrier behind it, take twice the time), plus one ninth product for the bin that is left (M / 2).
-        const bool sp = t == 0;
-        const double2 wkA = w16[gs * kA], wkB = w16[gs * kB];   // thread 0: 1 and exp(-i pi / 16)
         const double2 c16_1 = make_double2(0.92387953251128675613, -0.38268343236508977173);   // exp(-i pi / 8)
         const double2 c16_3 = make_double2(0.38268343236508977173, -0.92387953251128675613);   // exp(-3 i pi / 8)
         auto sel = [&](const double2 x, const double2 y) { return make_double2(sp ? x.x : y.x, sp ? x.y : y.y); };
@@ -452,16 +492,13 @@ __device__ __noinline__ void conv_mid(const double2* __restrict__ G, const doubl
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int m = br3(r);
-            if (r == 4) __builtin_amdgcn_sched_barrier(0);   // two batches of response loads (registers)
-            const int kn = (m < 4) ? kA + K * m : kB + K * (7 - m);
             const double2 wb = (m < 4) ? wkA : wkB;
             const int mm = (m < 4) ? m : 7 - m;
             const double2 wk = (mm == 0) ? wb : (mm == 1 ? cmulx(wb, c16_1) : (mm == 2 ? mul_w8_1(wb) : cmulx(wb, c16_3)));
-            const double2 Gk = G[gs * kn], Gm = G[gs * (M - kn)];
             if (m < 4) {
                 const int s1 = (m == 0) ? 0 : br3(8 - m);          // thread 0's partner slot in A (slot 0: a copy of itself)
                 double2 x = A[r], y = sel(A[s1], B[7 - r]);
-                conv_pair_mul(x, y, Gk, Gm, wk);
+                conv_pair_mul(x, y, Gk[r], Gm[r], wk);
                 A[r] = x;
                 B[7 - r] = sel(B[7 - r], y);
                 if (m != 0) A[s1] = sel(y, A[s1]);
@@ -469,7 +506,7 @@ __device__ __noinline__ void conv_mid(const double2* __restrict__ G, const doubl
                 // thread 0: group K / 2's pair m' = 7 - m sits in (B[br3(m')], B[7 - br3(m')]) = (B[7 - r], B[r]): the lower bin's
                 // element is the same register as for the others, the partner B[r] instead of A[r]
                 double2 x = B[7 - r], y = sel(B[r], A[r]);
-                conv_pair_mul(x, y, Gk, Gm, wk);
+                conv_pair_mul(x, y, Gk[r], Gm[r], wk);
                 B[7 - r] = x;
                 A[r] = sel(A[r], y);
                 B[r] = sel(y, B[r]);
@@ -477,7 +514,7 @@ __device__ __noinline__ void conv_mid(const double2* __restrict__ G, const doubl
         }
         if (sp) {
             double2 c = A[1];
-            conv_pair_mul(A[1], c, G[gs * (M / 2)], G[gs * (M / 2)], w16[gs * (M / 2)]);
+            conv_pair_mul(A[1], c, Gh, Gh, wh);
         }
         dit8_head(A);
         dit8_head(B);
@@ -509,11 +546,11 @@ __device__ __noinline__ void conv_mid_plain(const double2* __restrict__ Bn)
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             if (BR) {
-                GA[r] = Bn[8 * (int)(__brev((unsigned)kA) >> (32 - (LOG2M - 3))) + r];
-                GB[r] = Bn[8 * (int)(__brev((unsigned)kB) >> (32 - (LOG2M - 3))) + r];
+                GA[r] = gload(&Bn[8 * (int)(__brev((unsigned)kA) >> (32 - (LOG2M - 3))) + r]);
+                GB[r] = gload(&Bn[8 * (int)(__brev((unsigned)kB) >> (32 - (LOG2M - 3))) + r]);
             } else {
-                GA[r] = Bn[kA + K * br3(r)];
-                GB[r] = Bn[kB + K * br3(r)];
+                GA[r] = gload(&Bn[kA + K * br3(r)]);
+                GB[r] = gload(&Bn[kB + K * br3(r)]);
             }
         }
 #pragma unroll
@@ -557,7 +594,7 @@ __device__ __noinline__ void conv_inv(const double2* __restrict__ tw, const doub
 #pragma unroll
                 for (int b = 0; b < NB; b += 2 * half)
 #pragma unroll
-                    for (int j = 0; j < half; j++) dit_bf(a[b + j], a[b + j + half], tw[(i0 + 1024 * j) * ((8 >> LW) << e)]);
+                    for (int j = 0; j < half; j++) dit_bf(a[b + j], a[b + j + half], gload(&tw[(i0 + 1024 * j) * ((8 >> LW) << e)]));
             }
 #pragma unroll
             for (int j = 0; j < NB; j++) z[j * 1025 + i0] = a[j];

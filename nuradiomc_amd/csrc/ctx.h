@@ -38,6 +38,7 @@ struct nrhip_ctx {
     double2* w16 = nullptr;      // exp(-2 pi i k / (2 FFT_MAX)), k <= FFT_MAX / 2 (real <-> packed-complex FFT split)
     std::set<struct nrhip_station*> stations;  // alive stations: nrhip_ctx_destroy releases what they hold on the GPU
     DevArray cull_ws;            // scratch of nrhip_cull_groups (flags, sizes, scans)
+    int ray_finder = 0;          // NRHIP_FINDER_TRUE_ROOTS | NRHIP_FINDER_REFERENCE (nrhip_ctx_set_ray_finder)
 };
 
 // frees the station's device memory and events and detaches it from its context (the host object stays until
@@ -108,6 +109,7 @@ struct nrhip_station {
     std::map<std::string, DevArray> ws;
     std::map<std::string, size_t> ws_bytes;  // valid bytes of the last chunk
     std::vector<int> h_lengths;              // distinct trace lengths of the last chunk
+    int64_t last_dump_items = -1;            // candidate events whose traces the LAST simulate call kept (dump_traces), -1: it kept none
     // what the ray tables in the workspace belong to (nrhip_sim_config.reuse_ray_tables)
     // (pointers only identify a buffer as long as it has not been freed and re-allocated: the key below also holds the sizes, the
     // cuts, the reflection set-up and the station's position generation, and select_only calls are the only producers)

@@ -30,8 +30,8 @@ struct RayRecords {
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
                      const IceConst& m, const RayRecords& out, const double* max_dist = nullptr,
                      const int* perm = nullptr, const double* given_C0 = nullptr, unsigned long long* eval_count = nullptr,
-                     const double* given_D = nullptr, const double* given_T = nullptr, bool maybe_deep = true,
-                     bool reference_procedure = false, bool channel_major = false);
+                     const double* given_D = nullptr, const double* given_T = nullptr, bool reference_procedure = false,
+                     bool channel_major = false);
 // channel_major (with perm): the finder walks the pairs channel by channel -- a wave sees neighbouring events from ONE antenna --
 // instead of event by event; pays for stations whose antennas sit at very different depths (measured: the 24-channel RNO-G-like
 // station -21 % of the stage; a string of dipoles 1 m apart +3 %, its stores no longer coalesce)
@@ -44,7 +44,7 @@ struct ReflRecords {   // [n_pairs][2 + 4 n_reflections]
     double* seg_C0;    // [n_pairs][stride][n_reflections + 1]: C0 of the segment's ray, NaN = no such segment
 };
 void launch_find_refl(hipStream_t stream, long n_pairs, int n_reflections, const double* x1, const double* x2, int n_x2,
-                      const IceConst& m, double z_refl, int* cand_n, double* cand_C0);
+                      const IceConst& m, double z_refl, int* cand_n, double* cand_C0, bool reference_procedure = false);
 // stride = solution slots per pair: 2 + 4 n_reflections after launch_find_refl; any value with given records
 void launch_records_refl(hipStream_t stream, long n_pairs, int n_reflections, int stride, const double* x1, const double* x2,
                          int n_x2, const IceConst& m, double z_refl, const int* cand_n, const double* cand_C0, int given,

@@ -406,7 +406,7 @@ void nrhip_station_detach(nrhip_station* s)
     s->d_pa_up_taps.release(); s->d_pa_hil_taps.release();
     s->pa_B.release();
     s->ws.clear();
-    s->ws_bytes.clear();
+    s->ws_bytes.clear(); s->last_dump_items = -1;
     s->ctx->stations.erase(s);
     s->ctx = nullptr;
 }
@@ -420,7 +420,7 @@ int nrhip_station_set_positions(nrhip_station* s, const double* position)
     s->h_pos.assign(position, position + 3 * n);
     HIPCHK(hipMemcpyAsync(s->d_pos.p, s->h_pos.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, s->ctx->stream));
     HIPCHK(hipStreamSynchronize(s->ctx->stream));
-    s->ws_bytes.clear();  // the tables of the last call belong to the old positions
+    s->ws_bytes.clear(); s->last_dump_items = -1;  // the tables of the last call belong to the old positions
     s->rays_n_showers = -1;
     s->generation++;
     return 0;
@@ -436,7 +436,7 @@ int64_t nrhip_station_release_workspace(nrhip_station* s)
         freed += (int64_t)kv.second.cap;
         kv.second.release();
     }
-    s->ws_bytes.clear();
+    s->ws_bytes.clear(); s->last_dump_items = -1;
     // the per-length table cache only grows while the station lives (one row of ~1 MB or more per distinct common-trace length):
     // it is given back here too; the next call rebuilds the rows of the lengths it meets (about 1 us per length)
     auto& tc = s->tabcache;
@@ -817,6 +817,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     memset(&S, 0, sizeof S);
     S.n_events = n_groups;
     st->ws_bytes.clear();
+    st->last_dump_items = -1;
     if (stats) *stats = S;
     if (n_events == 0) return 0;
     HIPCHK(hipSetDevice(ctx->device));
@@ -866,11 +867,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (!cfg->accumulate_triggered) HIPCHK(hipMemsetAsync(triggered, 0, n_groups, sm));
 
     // 1. ray tracing for every (event, channel) pair
-    // (the finder without the hybr stage serves receivers down to 10 z_0 -- the stop point of a pair is the higher of vertex and
-    // antenna, so with every antenna above 9.99 z_0 no pair is left to the reference's procedure and its launch is skipped)
-    bool deep_antennas = false;
-    for (int c = 0; c < n_ch; c++)
-        if (st->h_pos[3 * c + 2] - 0.011 < -9.99 * ctx->ice.z_0) deep_antennas = true;   // (0.011: the focusing trace's 1 cm)
+    // (the finder without the hybr stage serves receivers down to 10 z_0; deeper receivers and end points exactly above each other
+    // -- whatever the antennas' depth -- are flagged by it and taken by the reference's procedure in a second launch, which reads one
+    // word per pair when nothing is flagged.  nrhip_ctx_set_ray_finder(NRHIP_FINDER_REFERENCE): the reference's procedure for all.)
     // antennas at very different depths (surface LPDAs next to deep dipoles): the finder walks the pairs channel-major
     bool spread_antennas = false;
     {
@@ -924,7 +923,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             // number of bottom reflections, one search for rays starting upwards and one for rays starting downwards
             ReflRecords rr{rec.n_sol, rec.type, rf, rc, nseg, smask, rec.C0, rec.C1, rec.D, rec.T, rec.launch, rec.receive,
                            rec.refl_angle, seg_zint, seg_C0};
-            launch_find_refl(sm, n_pairs, n_refl, vertex, sd.pos, n_ch, ctx->ice, cfg->z_reflection, cand_n, cand_C0);
+            launch_find_refl(sm, n_pairs, n_refl, vertex, sd.pos, n_ch, ctx->ice, cfg->z_reflection, cand_n, cand_C0, ctx->ray_finder == NRHIP_FINDER_REFERENCE);
             launch_records_refl(sm, n_pairs, n_refl, S_, vertex, sd.pos, n_ch, ctx->ice, cfg->z_reflection, cand_n, cand_C0, 0, rr);
             if (max_distance) launch_distance_cut_pairs(sm, n_pairs, n_ch, vertex, sd.pos, max_distance, rec.n_sol);
             LCHK("raytrace (bottom reflections)");
@@ -940,7 +939,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             HIPCHK(hipMemsetAsync(rt_eval_counter, 0, sizeof(unsigned long long), sm));
         }
         launch_raytrace(sm, n_pairs, vertex, sd.pos, n_ch, ctx->ice, rec, max_distance, geo_perm, cfg->given_C0, rt_eval_counter,
-                        cfg->given_D, cfg->given_T, deep_antennas, false, spread_antennas);
+                        cfg->given_D, cfg->given_T, ctx->ray_finder == NRHIP_FINDER_REFERENCE, spread_antennas);
         LCHK("raytrace");
     }
     MARK(1);
@@ -1060,11 +1059,11 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                 NEED(cand_C2 = WS("foc_candidates_C0", double, (size_t)n_pairs * n_calls * 3));
                 ReflRecords rr2{rec2.n_sol, rec2.type, rf2, rc2, nseg2, smask2, rec2.C0, rec2.C1, rec2.D, rec2.T, rec2.launch, rec2.receive,
                                 rec2.refl_angle, zint2, segC2};
-                launch_find_refl(sm, n_pairs, n_refl, vertex, pos2, n_ch, ctx->ice, cfg->z_reflection, cand_n2, cand_C2);
+                launch_find_refl(sm, n_pairs, n_refl, vertex, pos2, n_ch, ctx->ice, cfg->z_reflection, cand_n2, cand_C2, ctx->ray_finder == NRHIP_FINDER_REFERENCE);
                 launch_records_refl(sm, n_pairs, n_refl, S_, vertex, pos2, n_ch, ctx->ice, cfg->z_reflection, cand_n2, cand_C2, 0, rr2);
             } else {
                 launch_raytrace(sm, n_pairs, vertex, pos2, n_ch, ctx->ice, rec2, max_distance, geo_perm, nullptr, nullptr, nullptr, nullptr,
-                                deep_antennas, false, spread_antennas);
+                                ctx->ray_finder == NRHIP_FINDER_REFERENCE, spread_antennas);
             }
             LCHK("raytrace (focusing)");
             HIPCHK(hipStreamSynchronize(sm));  // hp goes out of scope
@@ -1577,6 +1576,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             // reference's empty channels
             HIPCHK(hipMemsetAsync(co.trace, 0, sizeof(double) * (size_t)std::max<long>(off[n_items], 1), sm));
             co.trace_offset = d_off;
+            st->last_dump_items = n_cand;
             if (envelope) {   // the envelopes of the band-passed channel traces, same layout
                 NEED(env_trace = WS("envelope_trace", double, std::max<long>(off[n_items], 1)));
                 HIPCHK(hipMemsetAsync(env_trace, 0, sizeof(double) * (size_t)std::max<long>(off[n_items], 1), sm));
@@ -1607,6 +1607,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(it_off = WS("item_need_offset", int, (size_t)n_items + 1));
         NEED(it_tmp = WS("scan_tmp4", int, scan_tiles((long)n_items + 1)));
         NEED(it_list = WS("item_list", int, (size_t)n_items));
+        int* it_sorted;   // the convolution kernel's event list in the order of the trace lengths (spectral.hip, length_hist_kernel)
+        NEED(it_sorted = WS("item_list_by_length", int, length_sort_ws_ints(n_cand)));
         double* conv_noise = nullptr;   // the noise trace of the channel a block of the convolution kernel is working on
         if (noise) NEED(conv_noise = WS("conv_noise_trace", double, (size_t)channel_grid_blocks() * FFT_MAX));
         double2* conv_acc;  // frequency-domain sum over antenna tables (LPDA channels seeing rays in different lobes)
@@ -1650,7 +1652,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                        (cfg->no_pruning || cfg->dump_traces || general || phased || post_trigger || noise) ? 1 : 0, maxL,
                        it_need, it_off, it_tmp, it_list, coinc_cnt, conv_acc, xform_count, tab_nodes, ray_traces,
                        (phased || post_trigger) ? (cfg->dump_traces ? 0 : 1) : -1, envelope ? &st->env_filter : nullptr, env_trace,
-                       noise ? &nz : nullptr, conv_split, pa_amp_cut, amp_scratch, conv_noise, general_need);
+                       noise ? &nz : nullptr, conv_split, pa_amp_cut, amp_scratch, conv_noise, general_need, it_sorted);
         LCHK("channel");
         if (post_trigger) {
             if (maxL > 2 * FFT_MAX)
@@ -1842,6 +1844,10 @@ int nrhip_readout_windows(nrhip_ctx* ctx, nrhip_station* st, int32_t n_window, i
         if (st->ws_bytes.find(k) == st->ws_bytes.end())
             return nrhip_fail_msg("nrhip_readout_windows: the last call kept no traces (nrhip_sim_config.dump_traces)");
     const int n_ch = st->dev.n_ch;
+    // (the workspace tables above are registered per call -- ws_bytes is cleared when a simulate call starts -- and the count of
+    // the call that wrote the traces is kept explicitly: a later call without dump_traces leaves nothing to read out)
+    if (st->last_dump_items < 0) return nrhip_fail_msg("nrhip_readout_windows: the last call kept no traces (nrhip_sim_config.dump_traces)");
+    if (n_items > st->last_dump_items) return nrhip_fail_msg("nrhip_readout_windows: more items than the last call has");
     if ((int64_t)(st->ws_bytes["item_event"] / sizeof(int)) < n_items ||
         (int64_t)(st->ws_bytes["trace_offset"] / sizeof(long)) < n_items * n_ch + 1)
         return nrhip_fail_msg("nrhip_readout_windows: more items than the last call has");
@@ -1895,6 +1901,7 @@ int nrhip_efield_to_voltage(nrhip_ctx* ctx, nrhip_station* st, int32_t n_efields
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t sm = ctx->stream;
     st->ws_bytes.clear();
+    st->last_dump_items = -1;
     double *d_tr, *d_t0, *d_zen, *d_az, *d_V;
     int *d_ch, *d_len;
     NEED(d_tr = WS("ev_traces", double, (size_t)n_efields * 2 * sd.N));

@@ -69,8 +69,10 @@ __device__ __noinline__ double det_exp_call(double x) { return det_exp(x); }
 __global__ void __launch_bounds__(256, NRHIP_RT_WAVES)
 raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double* __restrict__ x2, int n_ch,
                       IceConst m_arg, RayRecords out, const double* __restrict__ max_dist, const int* __restrict__ perm,
-                      unsigned long long* __restrict__ eval_count, int only_flagged)
+                      unsigned long long* __restrict__ eval_count, int only_flagged, int strict)
 {
+    // strict: the reference's acceptance test alone decides about the first root (NRHIP_FINDER_REFERENCE, nrhip_ctx_set_ray_finder):
+    // the list is then the reference's, lost roots included
     int n_eval = 0;   // calls of the objective by this lane (the FP64 view of bench.py prices the finder by them)
     __shared__ double sh_pair[6][256];   // the pair geometry the objective reads on every evaluation (see delta_y_lds)
     __shared__ IceConst sh_ice;          // the ice model for the (non-inlined) objective: a reference to the kernel argument would
@@ -113,7 +115,7 @@ raytrace_roots_kernel(long n_pairs, const double* __restrict__ x1, const double*
             const double d_hi = dy(xr + 0.0001), d_top = dy(100.), d_bot = dy(-100.), d_lo = dy(xr - 0.0001);
             unsigned todo = 0;
             if (fun < 1e-7) { lc0 = xr; ns = 1; }
-            else if (d_lo != 0 && d_hi != 0 && !isnan(d_lo) && !isnan(d_hi) && signbit(d_lo) != signbit(d_hi)) todo |= 1u;
+            else if (!strict && d_lo != 0 && d_hi != 0 && !isnan(d_lo) && !isnan(d_hi) && signbit(d_lo) != signbit(d_hi)) todo |= 1u;
             if (brent_bracket_ok(d_hi, d_top)) todo |= 2u;
             if (brent_bracket_ok(d_bot, d_lo)) todo |= 4u;
             while (todo) {
@@ -484,26 +486,25 @@ void launch_event_perm(hipStream_t stream, int n_events, const int* cell, int* c
 
 void launch_raytrace(hipStream_t stream, long n_pairs, const double* x1, const double* x2, int n_ch,
                      const IceConst& m, const RayRecords& out, const double* max_dist, const int* perm, const double* given_C0,
-                     unsigned long long* eval_count, const double* given_D, const double* given_T, bool maybe_deep, bool reference_procedure,
-                     bool channel_major)
+                     unsigned long long* eval_count, const double* given_D, const double* given_T, bool reference_procedure, bool channel_major)
 {
     if (n_pairs <= 0) return;
     int block = 256;
     long grid = (n_pairs + block - 1) / block;
     if (grid > 256L * 64) grid = 256L * 64;
     if (!given_C0) {
-        // NRHIP_RT_REFERENCE_PROCEDURE=1: hybr + two Brent searches for every pair (the finder of rounds 1-4; tests compare the two)
+        // reference_procedure (nrhip_ctx_set_ray_finder(NRHIP_FINDER_REFERENCE); NRHIP_RT_REFERENCE_PROCEDURE=1 forces it for a whole
+        // process): hybr + its acceptance test + two Brent searches for every pair, analyticraytracing.py:1476-1547 to the letter
         static const bool ref_proc = getenv("NRHIP_RT_REFERENCE_PROCEDURE") != nullptr && atoi(getenv("NRHIP_RT_REFERENCE_PROCEDURE")) != 0;
         if (ref_proc || reference_procedure) {
-            hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count, 0);
+            hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count, 0, 1);
         } else {
             static const int force_order = getenv("NRHIP_RT_EVENT_MAJOR") ? 1 : (getenv("NRHIP_RT_CHANNEL_MAJOR") ? 2 : 0);   // (either order: same results)
             const int event_major = force_order ? (force_order == 1) : !channel_major;
             hipLaunchKernelGGL(raytrace_roots_fast_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count, event_major);
-            // the flagged pairs (receiver deeper than 10 z_0, end points exactly above each other) through the reference's procedure;
-            // with nothing flagged the launch reads one word per pair
-            (void)maybe_deep;
-            hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count, 1);
+            // the flagged pairs (receiver deeper than 10 z_0, end points exactly above each other -- whatever the antennas' depth)
+            // through the reference's procedure with the sign-change acceptance; with nothing flagged the launch reads one word per pair
+            hipLaunchKernelGGL(raytrace_roots_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, max_dist, perm, eval_count, 1, 0);
         }
     }
     hipLaunchKernelGGL(raytrace_records_kernel, dim3((unsigned)grid), dim3(block), 0, stream, n_pairs, x1, x2, n_ch, m, out, given_C0,

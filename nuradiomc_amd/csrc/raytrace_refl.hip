@@ -98,7 +98,7 @@ __device__ inline void call_label(int c, int* refl, int* rcase)
 // one lane per (pair, call): up to 3 roots, sorted by C0
 __global__ void __launch_bounds__(256)
 find_refl_kernel(long n_pairs, int n_calls, const double* __restrict__ x1, const double* __restrict__ x2, int n_x2, IceConst m,
-                 double z_refl, int* __restrict__ cand_n, double* __restrict__ cand_C0)
+                 double z_refl, int* __restrict__ cand_n, double* __restrict__ cand_C0, int strict)
 {
     const long n_items = n_pairs * n_calls;
     for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < n_items; it += (long)gridDim.x * blockDim.x) {
@@ -119,7 +119,7 @@ find_refl_kernel(long n_pairs, int n_calls, const double* __restrict__ x1, const
             double xr = hybrd1(dy2, -1., 1e-6, &fun);
             const double d_hi = dy(xr + 0.0001), d_lo = dy(xr - 0.0001);
             if (fun < 1e-7) lc[ns++] = xr;
-            else if (refl == 0 && d_lo != 0 && d_hi != 0 && !isnan(d_lo) && !isnan(d_hi) && signbit(d_lo) != signbit(d_hi))
+            else if (!strict && refl == 0 && d_lo != 0 && d_hi != 0 && !isnan(d_lo) && !isnan(d_hi) && signbit(d_lo) != signbit(d_hi))
                 lc[ns++] = brentq(dy, xr - 0.0001, xr + 0.0001, d_lo, d_hi);   // the true set for the plain call (raytrace.hip)
             {
                 double a = xr + 0.0001, b = 100.;
@@ -321,7 +321,7 @@ segment_product_kernel(long n_rays, int n_seg_max, int n_freq, const double* __r
 }
 
 void launch_find_refl(hipStream_t stream, long n_pairs, int n_reflections, const double* x1, const double* x2, int n_x2,
-                      const IceConst& m, double z_refl, int* cand_n, double* cand_C0)
+                      const IceConst& m, double z_refl, int* cand_n, double* cand_C0, bool reference_procedure)
 {
     const int n_calls = 1 + 2 * n_reflections;
     long n_items = n_pairs * n_calls;
@@ -329,7 +329,7 @@ void launch_find_refl(hipStream_t stream, long n_pairs, int n_reflections, const
     long grid = (n_items + 255) / 256;
     if (grid > 256L * 64) grid = 256L * 64;
     hipLaunchKernelGGL(find_refl_kernel, dim3((unsigned)grid), dim3(256), 0, stream, n_pairs, n_calls, x1, x2, n_x2, m, z_refl,
-                       cand_n, cand_C0);
+                       cand_n, cand_C0, reference_procedure ? 1 : 0);
 }
 
 void launch_records_refl(hipStream_t stream, long n_pairs, int n_reflections, int stride, const double* x1, const double* x2,

@@ -2177,6 +2177,28 @@ __global__ void scatter_item_list_kernel(int n_items, const int* __restrict__ ne
     if (need[i]) list[offset[i]] = i;
 }
 
+// The event list of channel_conv_kernel in the order of the events' trace lengths (round 6).  The response spectrum G_L a channel is
+// multiplied with depends on the event's length L alone (1075 distinct lengths in 1e6 events of the survey, 131 KB each): handed out in
+// list order, the 256 resident blocks worked on 256 different lengths and every channel fetched its G_L from HBM (10.7 of the
+// kernel's 15.6 GB per launch, and an HBM latency in the spectrum pass); in length order neighbouring blocks share it in the L2.
+// A counting sort on L / 2: histogram, scan, scatter through per-length cursors (the order inside a length is whatever the atomics
+// give -- the events are independent).
+__global__ void length_hist_kernel(const int* __restrict__ n_list, const int* __restrict__ list, const int* __restrict__ item_event,
+                                   const int* __restrict__ ev_L, int* __restrict__ hist)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_list) return;
+    atomicAdd(&hist[min(ev_L[item_event[list[i]]] >> 1, FFT_MAX / 2)], 1);
+}
+__global__ void length_scatter_kernel(const int* __restrict__ n_list, const int* __restrict__ list, const int* __restrict__ item_event,
+                                      const int* __restrict__ ev_L, int* __restrict__ cursor, int* __restrict__ sorted)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_list) return;
+    const int c = list[i];
+    sorted[atomicAdd(&cursor[min(ev_L[item_event[c]] >> 1, FFT_MAX / 2)], 1)] = c;
+}
+
 // candidate events with at least one channel left to evaluate (the unit of work of channel_conv_kernel)
 // n_coinc > 1 (majority logic, production mode): an n-fold coincidence needs n channels that can raise a flag at all -- an event
 // with fewer channels left by the prefilter cannot trigger, none of its channels is evaluated (their maxima keep the bound)
@@ -2289,8 +2311,8 @@ __device__ __forceinline__ void ray_build(int xjob_off, int rg_off, int lt, cons
     auto pair_load = [&](int k) -> PairIn {
         const int k2 = nh - k;
         PairIn q;
-        q.pl1 = st.fpow[off_l + k]; q.pr1 = st.fpow[2 * stride + k]; q.sg1 = st.seg[k]; q.w1 = tw[k * twn];
-        q.pl2 = st.fpow[off_l + k2]; q.pr2 = st.fpow[2 * stride + k2]; q.sg2 = st.seg[k2]; q.w2 = tw[k2 * twn];
+        q.pl1 = st.fpow[off_l + k]; q.pr1 = st.fpow[2 * stride + k]; q.sg1 = st.seg[k]; q.w1 = gload(&tw[k * twn]);
+        q.pl2 = st.fpow[off_l + k2]; q.pr2 = st.fpow[2 * stride + k2]; q.sg2 = st.seg[k2]; q.w2 = gload(&tw[k2 * twn]);
         return q;
     };
     // amplitude X_k att(f_k) (conv_amplitude), 0 < k < nh; the quotient through a reciprocal estimate and two Newton steps (~1 ulp)
@@ -2343,7 +2365,7 @@ __device__ __forceinline__ void ray_build(int xjob_off, int rg_off, int lt, cons
 #pragma unroll
             for (int b = 0; b < NBK; b += 2 * half)
 #pragma unroll
-                for (int q = 0; q < half; q++) dif_bf_c(a[b + q], a[b + q + half], tw[(i0 + 512 * q) * (FFT_MAX >> (log2nh - e))]);
+                for (int q = 0; q < half; q++) dif_bf_c(a[b + q], a[b + q + half], gload(&tw[(i0 + 512 * q) * (FFT_MAX >> (log2nh - e))]));
         }
 #pragma unroll
         for (int j = 0; j < NBK; j++) xjob[j * BS + i0] = a[j];
@@ -2418,6 +2440,12 @@ __device__ __forceinline__ void ray_place(int xjob_off, int lt, int nh, const Co
     dif8_tail_c(a);
     const double sc = jq.vfac / nh;   // the fs / sqrt(2) of freq2time cancels against time2freq's sqrt(2) / fs
     const int K = nh >> 3;
+    // The sixteen samples of a thread are sixteen different places (j differs, N <= L): all of them are read before the first is
+    // written.  Written as read-modify-write one by one -- the compiler must assume the places alias -- this was sixteen LDS round
+    // trips in a row per thread and job (round 5: 14 % of the kernel's time).
+    double* s0[8];
+    double* s1[8];
+    double v0[8], v1[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int j = lt + K * br3(r);
@@ -2425,10 +2453,20 @@ __device__ __forceinline__ void ray_place(int xjob_off, int lt, int nh, const Co
         if (i0 >= L) i0 -= L;
         int i1 = i0 + 1;
         if (i1 >= L) i1 -= L;
-        double* s0 = S + 2 * conv_pad(i0 >> 1) + (i0 & 1);
-        double* s1 = S + 2 * conv_pad(i1 >> 1) + (i1 & 1);
-        *s0 = fma(a[r].x, sc, *s0);
-        *s1 = fma(a[r].y, sc, *s1);
+        s0[r] = S + 2 * conv_pad(i0 >> 1) + (i0 & 1);
+        s1[r] = S + 2 * conv_pad(i1 >> 1) + (i1 & 1);
+        v0[r] = *s0[r];
+        v1[r] = *s1[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        v0[r] = fma(a[r].x, sc, v0[r]);
+        v1[r] = fma(a[r].y, sc, v1[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        *s0[r] = v0[r];
+        *s1[r] = v1[r];
     }
 }
 // Output pass of a channel without coincidence logic: V[n] = (y[n] + y[n + L]) * vscale from the convolution buffer (the kernel's
@@ -2457,9 +2495,9 @@ __device__ __noinline__ ConvOut conv_output_pass(int L, double vscale, double th
             const int i = i0 + u * nt;
             if (i >= hl) break;
             double v0 = (a[u].x + b[u].x) * vscale, v1 = (a[u].y + b[u].y) * vscale;
-            if (add) { v0 += add[2 * i]; v1 += add[2 * i + 1]; }   // thermal noise of the channel (a row of HBM scratch)
-            if (em) *(double2*)(em + 2 * i) = make_double2(v0, v1);
-            if (tr) { tr[2 * i] = v0; tr[2 * i + 1] = v1; }
+            if (add) { v0 += gload(add + 2 * i); v1 += gload(add + 2 * i + 1); }   // thermal noise of the channel (a row of HBM scratch)
+            if (em) gstore((double2*)(em + 2 * i), make_double2(v0, v1));
+            if (tr) { gstore(tr + 2 * i, v0); gstore(tr + 2 * i + 1, v1); }
             const double a0 = fabs(v0), a1 = fabs(v1);
             o.vmax = fmax(o.vmax, fmax(a0, a1));
             if (ch_on && (a0 >= threshold || (2 * i + 1 < L - 1 && a1 >= threshold))) o.trig = 1;
@@ -4176,7 +4214,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
                     const double* ray_traces, int skip_off, const FilterSet* envf, double* env_trace, const NoiseDev* noise,
-                    bool conv_split, double pa_amp_cut, double* amp_scratch, double* noise_buf, const int* item_need)
+                    bool conv_split, double pa_amp_cut, double* amp_scratch, double* noise_buf, const int* item_need, int* length_sort_ws)
 {
     if (skip_off < 0) skip_off = !exact;  // channels outside the trigger set are evaluated only when everything is
     if (n_items <= 0) return;
@@ -4203,6 +4241,16 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
         launch_exclusive_scan(s, (long)n_cand + 1, ev_need, need_offset, scan_tmp);
         hipLaunchKernelGGL(scatter_item_list_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, ev_need, need_offset,
                            item_list);
+        if (length_sort_ws && !getenv("NRHIP_CONV_LIST_ORDER")) {   // the list in the order of the trace lengths (length_hist_kernel)
+            constexpr int NK = FFT_MAX / 2 + 1;
+            int *hist = length_sort_ws, *cursor = hist + NK + 1, *tmp = cursor + NK + 1, *sorted = tmp + scan_tiles(NK + 1);
+            (void)hipMemsetAsync(hist, 0, sizeof(int) * (NK + 1), s);
+            hipLaunchKernelGGL(length_hist_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, need_offset + n_cand, item_list, item_event, ev.L, hist);
+            launch_exclusive_scan(s, NK + 1, hist, cursor, tmp);
+            hipLaunchKernelGGL(length_scatter_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, need_offset + n_cand, item_list, item_event, ev.L,
+                               cursor, sorted);
+            item_list = sorted;
+        }
         // events of up to FFT_MAX / 2 samples go to the half-capacity instantiation (two blocks per CU), longer ones to the full one;
         // both walk the same list with their own counter
         // (with thermal noise every event takes the full-capacity instantiation: the noise trace is an 8192-point chirp convolution)

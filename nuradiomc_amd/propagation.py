@@ -21,15 +21,15 @@ available_modules = ['analytic']
 _contexts = {}
 
 
-def _context_for(medium, attenuation_model, device=0, gl3_table=None):
-    key = (float(medium.n_ice), float(medium.delta_n), float(medium.z_0), attenuation_model, device)
+def _context_for(medium, attenuation_model, device=0, gl3_table=None, ray_finder='true_roots'):
+    key = (float(medium.n_ice), float(medium.delta_n), float(medium.z_0), attenuation_model, device, ray_finder)
     if key not in _contexts:
         if attenuation_model == 'GL3' and gl3_table is None:
             # the model is defined by a data file of the NuRadioMC installation the drop-in is used in
             import os
             import NuRadioMC.utilities.attenuation as _att
             gl3_table = os.path.join(os.path.dirname(_att.__file__), 'data', 'GL3_params.csv')
-        _contexts[key] = Context(key[:3], attenuation_model, device=device, gl3_table=gl3_table)
+        _contexts[key] = Context(key[:3], attenuation_model, device=device, gl3_table=gl3_table, ray_finder=ray_finder)
     return _contexts[key]
 
 
@@ -100,7 +100,10 @@ def analytic_ray_path(X1, X2, C0, n_ice, delta_n, z_0, n_points=1000):
 class ray_tracing:
     def __init__(self, medium, attenuation_model=None, log_level=logging.NOTSET, n_frequencies_integration=None,
                  n_reflections=None, config=None, detector=None, ray_tracing_2D_kwards={}, use_cpp=None,
-                 compile_numba=None, device=0):
+                 compile_numba=None, device=0, ray_finder=None):
+        """ray_finder: 'true_roots' (default) | 'reference' -- which solution finder find_solutions runs (include/nrhip.h,
+        nrhip_ctx_set_ray_finder; also accepted as ray_tracing_2D_kwards['ray_finder']).  'reference' repeats the reference's
+        procedure and acceptance test (analyticraytracing.py:1476-1547) and with them its occasionally shorter solution list."""
         self.__logger = logging.getLogger('nuradiomc_amd.ray_tracing')
         self.__logger.setLevel(log_level)
         for attr in ('n_ice', 'delta_n', 'z_0'):
@@ -142,7 +145,8 @@ class ray_tracing:
                 fs = detector.get_sampling_frequency(station_id, ch0)
                 if self._max_detector_frequency is None or fs * .5 > self._max_detector_frequency:
                     self._max_detector_frequency = fs * .5
-        self._ctx = _context_for(medium, self._attenuation_model, device)
+        self._ray_finder = ray_finder or dict(ray_tracing_2D_kwards or {}).get('ray_finder', 'true_roots')
+        self._ctx = _context_for(medium, self._attenuation_model, device, ray_finder=self._ray_finder)
         self.use_cpp = False
         self.reset_solutions()
 

@@ -42,6 +42,50 @@ double orc_exp(double x)
     return ldexp(p, (int)kd);
 }
 
+/* exp for the attenuation integrand (round 6): reduction to |r| <= ln2 / 128 with a 64-entry table of 2^(j / 64) (correctly
+ * rounded doubles, the same literals as nuradiomc_amd/csrc/detmath.h) and the degree-5 Taylor polynomial of exp(r) in Horner form
+ * (truncation 3.4e-17): x = (64 k + j) ln2 / 64 + r, exp(x) = 2^k (T[j] p(r)).  Every step a correctly rounded IEEE operation in a
+ * fixed order -- same bits on host and device.  Accuracy <= 2 ulp (the table entry, the polynomial and their product each round
+ * once): the integrand is integrated to epsrel = 1e-2.  7 FP64 operations fewer per value than orc_exp. */
+static const double orc_exp_tab64[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+__attribute__((target_clones("fma", "default")))
+double orc_exp_tab(double x)
+{
+    static const double ln2HI64 = 0x1.62e42fee00000p-7, ln2LO64 = 0x1.a39ef35793c76p-39, inv64 = 0x1.71547652b82fep+6;
+    double kd, r, p;
+    int ki;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return INFINITY;
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    kd = rint(x * inv64);
+    r = __builtin_fma(-kd, ln2HI64, x);
+    r = __builtin_fma(-kd, ln2LO64, r);
+    ki = (int)kd;
+    p = 0x1.1111111111111p-7;                          /* 1/120 */
+    p = __builtin_fma(p, r, 0x1.5555555555555p-5);     /* 1/24 */
+    p = __builtin_fma(p, r, 0x1.5555555555555p-3);     /* 1/6 */
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(orc_exp_tab64[ki & 63] * p, ki >> 6);
+}
+
 static double orc_log(double x)
 {
     static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;

@@ -571,7 +571,14 @@ static int find_solutions_bracketed(const double x1[2], const double x2[2], cons
 /* ray_tracing_2D.find_solutions, Python branch (:1433-1547), receiver in ice; `reflection` bottom reflections with the
  * ray starting upwards (reflection_case 1) or downwards (2).  Returns number of solutions (<= 3) sorted by C0; hybr
  * diagnostics optional. */
-int orc_reference_procedure = 0;   /* != 0: hybr + two Brent searches for every pair (tests compare the two finders) */
+/* The finder of the checker follows the product's (include/nrhip.h, nrhip_ctx_set_ray_finder):
+ *   orc_reference_procedure == 0  the true solution set: the bracketed finder; where that does not apply (deep receivers, end
+ *                                 points above each other, calls with a reflective layer) hybr + two Brent searches with the first
+ *                                 root also accepted by a sign change either side of the hybr iterate (plain call only);
+ *   orc_reference_procedure != 0  the reference to the letter (:1476-1547): hybr, its acceptance test (delta y)^2 < 1e-7 alone,
+ *                                 two Brent searches -- for every pair and every call.                                            */
+int orc_reference_procedure = 0;
+static int orc_force_procedure = 0;   /* hybr + Brent also where the bracketed finder would apply (the calls of a reflective layer) */
 void orc_set_reference_procedure(int on) { orc_reference_procedure = on; }
 
 int orc_find_solutions_2d_refl(const double x1[2], const double x2[2], const double ice[3], int reflection,
@@ -585,7 +592,7 @@ int orc_find_solutions_2d_refl(const double x1[2], const double x2[2], const dou
     if (x2[1] > 0) return 0; /* ice->air special case (:1437-1460) not restated */
     /* (end points exactly above each other: the solutions are the vertical rays, log C0 -> infinity -- the reference's procedure
      * reports them at its search limits; the brackets of the finder above have no sign change to find) */
-    if (reflection == 0 && get_gamma(x2[1], &m) >= ORC_SHALLOW * m.delta_n && x2[0] > x1[0] && !orc_reference_procedure) {
+    if (reflection == 0 && get_gamma(x2[1], &m) >= ORC_SHALLOW * m.delta_n && x2[0] > x1[0] && !orc_reference_procedure && !orc_force_procedure) {
         int kind;
         n = find_solutions_bracketed(x1, x2, &m, logC0, &o.nfev, &kind);
         if (hybr_x) *hybr_x = NAN;
@@ -600,7 +607,7 @@ int orc_find_solutions_2d_refl(const double x1[2], const double x2[2], const dou
     if (hybr_fun) *hybr_fun = fun;
     const double d_hi = obj_delta_y(xr + 0.0001, &o), d_lo = obj_delta_y(xr - 0.0001, &o);
     if (fun < 1e-7) logC0[n++] = xr;
-    else if (reflection == 0 && d_lo != 0 && d_hi != 0 && !isnan(d_lo) && !isnan(d_hi) && signbit(d_lo) != signbit(d_hi)) {
+    else if (!orc_reference_procedure && reflection == 0 && d_lo != 0 && d_hi != 0 && !isnan(d_lo) && !isnan(d_hi) && signbit(d_lo) != signbit(d_hi)) {
         /* THE TRUE SOLUTION SET (round 5; DESIGN section 2, tools/true_roots.py).  The reference keeps its first root only
          * if (delta_y)^2 < 1e-7 where hybr stopped (:1483) -- about 1e-7 off a double root, where that number is 2e-8 ... 3e-6:
          * a coin flip on the last bits of exp / log, and the two Brent searches leave the 2e-4 around the iterate out.
@@ -909,7 +916,7 @@ static double sp1_exponent(double z, double frequency)
 static double ds_over_length(double ds, double z, double frequency, int model)
 {
     if (model == 1) {
-        double e = orc_exp(sp1_exponent(z, frequency));
+        double e = orc_exp_tab(sp1_exponent(z, frequency));   /* (the integrand's own exp, detmath_c.h) */
         if (e > 1.) e = 1.;
         if (z > 0) e = 0.;
         return ds * e;
@@ -1660,10 +1667,10 @@ void orc_raytrace_batch_refl(long n, const double *x1, const double *x2, const d
             for (int r = 0; r <= n_reflections; r++)
                 for (int cs = 1; cs <= (r == 0 ? 1 : 2); cs++) {
                     /* with a reflective layer every call -- the plain one included -- is the reference's procedure (find_refl_kernel) */
-                    const int keep = orc_reference_procedure;
-                    orc_reference_procedure = 1;
+                    const int keep = orc_force_procedure;
+                    orc_force_procedure = 1;
                     int k = orc_find_solutions_2d_refl(g.x1, g.x2, ice, r, cs, z_refl, c0 + ns, c1 + ns, ty + ns, NULL, NULL, NULL);
-                    orc_reference_procedure = keep;
+                    orc_force_procedure = keep;
                     for (int j = 0; j < k; j++) { rf[ns + j] = r; rc[ns + j] = cs; }
                     ns += k;
                 }
@@ -1777,3 +1784,6 @@ void orc_find_solutions_2d_batch(long n, const double *x1, const double *x2, con
     }
     orc_reference_procedure = keep;
 }
+
+/* detmath_c.h for the accuracy test (tests/test_oracle_golden.py::test_detmath_accuracy) */
+double orc_log_value(double x) { return orc_log(x); }

@@ -49,7 +49,26 @@ def lib():
         _lib.orc_find_solutions_2d_batch.restype = None
         _lib.orc_uv_grid.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
         _lib.orc_uv_grid.restype = None
+        _lib.orc_set_reference_procedure.argtypes = [ctypes.c_int]
+        _lib.orc_set_reference_procedure.restype = None
     return _lib
+
+
+class reference_procedure:
+    """with reference_procedure(): ... -- every find_solutions of the checker inside the block is the reference's procedure to the
+    letter (hybr, its acceptance test alone, two Brent searches: analyticraytracing.py:1476-1547), the checker's side of
+    nrhip_ctx_set_ray_finder(NRHIP_FINDER_REFERENCE).  Outside: the true solution set (bracketed finder)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        lib().orc_set_reference_procedure(int(self.on))
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_reference_procedure(0)
+        return False
 
 
 def _d(a):

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 from conftest import golden, max_rel
 from oracle import raytrace_oracle as orc
-from test_oracle_golden import _subset_ok
+from test_oracle_golden import _subset_ok, compare_with_reference_two_sided
 
 pytestmark = pytest.mark.gpu
 
@@ -51,6 +51,72 @@ def test_find_solutions_vs_reference_fixture(gpu_ctx_factory, name):
     o = ctx.find_solutions_batch(g['x1'], g['x2'])
     _compare_ray_tables(o, g)
     _assert_identical_to_oracle(o, orc.raytrace_batch(g['x1'], g['x2'], g['ice']))
+
+
+@pytest.mark.parametrize('name', ['A', 'B', 'C'])
+def test_reference_finder_vs_reference_fixture(gpu_ctx_factory, name):
+    """NRHIP_FINDER_REFERENCE (Context(..., ray_finder='reference'), nrhip_ctx_set_ray_finder): the reference's procedure and
+    acceptance test to the letter for every pair (analyticraytracing.py:1476-1547).  Against the reference's own tables at the
+    tolerances of rounds 1-4 (counts may differ EITHER way on <= 0.3 % of the pairs: the acceptance test is a coin flip on the last
+    bits of exp / log), and equal to the checker in the same mode bit for bit.  Prints the count mismatches of both finders."""
+    g = golden('raytrace_%s.npz' % name)
+    ctx = gpu_ctx_factory(g['ice'], str(g['att_model']), ray_finder='reference')
+    assert ctx.ray_finder == 'reference'
+    o = ctx.find_solutions_batch(g['x1'], g['x2'])
+    n_more, n_fewer = compare_with_reference_two_sided(o, g)
+    with orc.reference_procedure():
+        _assert_identical_to_oracle(o, orc.raytrace_batch(g['x1'], g['x2'], g['ice']))
+    # the same context switched to the default finder and back
+    ctx.set_ray_finder('true_roots')
+    t = ctx.find_solutions_batch(g['x1'], g['x2'])
+    _assert_identical_to_oracle(t, orc.raytrace_batch(g['x1'], g['x2'], g['ice']))
+    ctx.set_ray_finder('reference')
+    assert np.array_equal(ctx.find_solutions_batch(g['x1'], g['x2'])['C0'], o['C0'], equal_nan=True)
+    d = t['n_sol'] - g['n_sol']
+    print('fixture %s, %d pairs: reference finder %d longer / %d shorter than the reference; true-root finder %d longer / %d shorter'
+          % (name, len(d), n_more, n_fewer, (d > 0).sum(), (d < 0).sum()))
+    assert np.all(o['n_sol'] <= t['n_sol'])
+    with pytest.raises(ValueError):
+        ctx.set_ray_finder('newton')
+
+
+def test_reference_finder_random_geometries_and_reflections(gpu_ctx_factory):
+    """The reference finder on 1e5 random pairs (shallow and deep receivers, degenerate pairs) and on the calls with a reflective
+    layer: equal to the checker in the same mode bit for bit; its list is a subset of the true-root finder's."""
+    ice = (1.78, 0.423, 77.)
+    rng = np.random.default_rng(2026)
+    n = 100000
+    r, ph = np.sqrt(rng.uniform(0, 5000. ** 2, n)), rng.uniform(0, 2 * np.pi, n)
+    x1 = np.stack([r * np.cos(ph), r * np.sin(ph), rng.uniform(-2700, -0.01, n)], axis=1)
+    x2 = np.stack([rng.uniform(-30, 30, n), rng.uniform(-30, 30, n), -rng.uniform(0.01, 14 * ice[2], n)], axis=1)
+    x2[:300, :2] = x1[:300, :2]
+    x2[300:600, 2] = x1[300:600, 2]
+    ctx = gpu_ctx_factory(ice, 'SP1', ray_finder='reference')
+    o = ctx.find_solutions_batch(x1, x2)
+    with orc.reference_procedure():
+        ref = orc.raytrace_batch(x1, x2, ice)
+    _assert_identical_to_oracle(o, ref)
+    t = orc.raytrace_batch(x1, x2, ice)
+    short = o['n_sol'] < t['n_sol']
+    print('reference finder short of the true set on %d of %d pairs (%.2f %%)' % (short.sum(), n, 100 * short.mean()))
+    assert np.all(o['n_sol'] <= t['n_sol']) and 0 < short.mean() < 0.02
+    for i in np.flatnonzero(short)[:200]:
+        assert _subset_ok(o['C0'][i], t['C0'][i])
+    # with a reflective layer (Moore's Bay fixture): the plain call of the set loses the sign-change rescue as well
+    g = golden('ref_mooresbay.npz')
+    ctxm = gpu_ctx_factory(g['ice'], 'MB1', ray_finder='reference')
+    m = len(g['points'])
+    zr = float(g['z_reflection'])
+    xr = np.tile(g['x_receiver'], (m, 1))
+    om = ctxm.find_solutions_reflections_batch(g['points'], xr, 2, zr)
+    with orc.reference_procedure():
+        refm = orc.raytrace_batch_refl(g['points'], xr, g['ice'], 2, zr)
+    for k in ('n_sol', 'type', 'reflection', 'reflection_case'):
+        assert np.array_equal(om[k], refm[k]), k
+    assert np.array_equal(om['C0'], refm['C0'], equal_nan=True)
+    got = np.where(np.isnan(om['C0']), 0., om['C0'])
+    np.testing.assert_allclose(got, g['ref_C0'], rtol=1e-6, atol=0)      # T06unit_test_C0_mooresbay.py:47
+    assert np.array_equal(om['n_sol'], g['n_sol'])
 
 
 def test_find_solutions_vs_oracle_survey_geometry(gpu_ctx_factory):

@@ -57,6 +57,50 @@ def test_raytrace_vs_reference_python_path(name):
     assert max_rel(o['refl_angle'][ok], g['refl_angle'][ok]) < 1e-6
 
 
+def compare_with_reference_two_sided(o, g, count_tol=0.003):
+    """The REFERENCE-PROCEDURE finder against the reference's outputs, at the tolerances of rounds 1-4 (before the default finder
+    became the true-root one): whether the first root survives the reference's acceptance test is a coin flip on the last bits of
+    exp / log, so a count may differ EITHER way on <= 0.3 % of the pairs, the shorter list a subset of the
+    longer; everything else as tight as it was."""
+    bad = o['n_sol'] != g['n_sol']
+    assert bad.mean() <= count_tol, "solution-count mismatches: %d of %d" % (bad.sum(), len(bad))
+    for i in np.where(bad)[0]:
+        assert _subset_ok(o['C0'][i], g['C0'][i])
+    ok = ~bad
+    assert np.array_equal(o['type'][ok], g['type'][ok])
+    assert max_rel(o['C0'][ok], g['C0'][ok]) < 1.1e-7   # observed 5.2e-8
+    for k in ('D', 'T'):
+        rel = np.abs(o[k][ok] - g[k][ok]) / np.abs(g[k][ok])
+        rel = rel[np.isfinite(rel)]
+        assert rel.max() < 3e-6 and (rel > 1e-6).mean() <= 0.0026, k   # observed 1.4e-6 on 0.13 % of fixture C, 1.2e-7 elsewhere
+    for k in ('launch', 'receive'):
+        assert np.nanmax(np.abs(o[k][ok] - g[k][ok])) < 4e-7
+        assert np.array_equal(np.isnan(o[k][ok]), np.isnan(g[k][ok]))
+    assert np.nanmax(np.abs(o['C1'][ok] - g['C1'][ok])) < 7.5e-4
+    assert max_rel(o['refl_angle'][ok], g['refl_angle'][ok]) < 1e-6
+    n_more, n_fewer = int((o['n_sol'] > g['n_sol']).sum()), int((o['n_sol'] < g['n_sol']).sum())
+    return n_more, n_fewer
+
+
+@pytest.mark.parametrize('name', ['A', 'B', 'C'])
+def test_reference_procedure_vs_reference_python_path(name):
+    """orc.reference_procedure() = the checker's side of NRHIP_FINDER_REFERENCE: hybr + acceptance test + two Brent searches for
+    every pair, WITHOUT the sign-change acceptance of the default mode.  Prints the count mismatches of both modes."""
+    g = golden('raytrace_%s.npz' % name)
+    with orc.reference_procedure():
+        o = orc.raytrace_batch(g['x1'], g['x2'], g['ice'])
+    n_more, n_fewer = compare_with_reference_two_sided(o, g)
+    o_true = orc.raytrace_batch(g['x1'], g['x2'], g['ice'])
+    d = o_true['n_sol'] - g['n_sol']
+    print('fixture %s, %d pairs: reference procedure %d longer / %d shorter than the reference; true-root finder %d longer / %d shorter'
+          % (name, len(d), n_more, n_fewer, (d > 0).sum(), (d < 0).sum()))
+    assert (d < 0).sum() == 0
+    # the reference-procedure list is never longer than the true set, and is a subset of it
+    assert np.all(o['n_sol'] <= o_true['n_sol'])
+    for i in np.flatnonzero(o['n_sol'] < o_true['n_sol']):
+        assert _subset_ok(o['C0'][i], o_true['C0'][i])
+
+
 def test_C0_reference_golden_pickle():
     """NuRadioMC/test/SignalProp/reference_C0.pkl through T05unit_test_C0_SP.py's recipe."""
     g = golden('ref_C0_SP.npz')
@@ -543,7 +587,7 @@ def test_hedis_bgr18_cross_section(monkeypatch, tmp_path):
 def test_bracketed_finder_vs_the_reference_procedure():
     """The finder without the hybr stage (round 5: every root out of a bracket) against the reference's procedure restated (hybr on
     (delta_y)^2 + two Brent searches, itself pinned on the reference above): on 60 000 random pairs in three ice models it never
-    holds fewer solutions, holds more on < 0.1 % of the pairs (roots the procedure loses: tests/test_true_roots.py settles such
+    holds fewer solutions, holds more on ~1 % of the pairs (roots the procedure loses to its acceptance test: tests/test_true_roots.py settles such
     pairs in 60-digit arithmetic), agrees in C0 to 2.5e-7 (the distance of the hybr iterate from its root) and needs a third of
     the objective evaluations.  tools/root_shapes.py checks the two shape facts it rests on."""
     sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
@@ -561,7 +605,10 @@ def test_bracketed_finder_vs_the_reference_procedure():
         x2 = np.stack([rho, np.maximum(z1, z2)], 1)
         ns, c, nf = orc.find_solutions_2d_batch(x1, x2, ice)
         ns_r, c_r, nf_r = orc.find_solutions_2d_batch(x1, x2, ice, reference_procedure=True)
-        assert np.all(ns >= ns_r) and np.mean(ns != ns_r) < 1e-3
+        # (round 6: reference_procedure is the reference to the letter -- its acceptance test alone, no sign-change rescue -- and
+        # loses a root on 0.5 ... 0.9 % of these pairs; with the rescue, as in round 5, it was < 0.1 %)
+        print('ice %s: the reference procedure is short on %.2f %% of the pairs' % (ice, 100 * np.mean(ns != ns_r)))
+        assert np.all(ns >= ns_r) and np.mean(ns != ns_r) < 0.015
         same = ns == ns_r
         assert max_rel(c[same], c_r[same]) < 2.5e-7
         for i in np.flatnonzero(~same):
@@ -571,3 +618,40 @@ def test_bracketed_finder_vs_the_reference_procedure():
     x1, x2 = np.array([[0., -2500.]]), np.array([[800., -1200.]])
     a, b = orc.find_solutions_2d_batch(x1, x2, (1.78, 0.423, 77.)), orc.find_solutions_2d_batch(x1, x2, (1.78, 0.423, 77.), True)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1], equal_nan=True) and np.array_equal(a[2], b[2])
+
+
+def test_detmath_accuracy():
+    """The bit-reproducible exp / log the ray tracer and the quadrature are built on (oracle/detmath_c.h = nuradiomc_amd/csrc/detmath.h)
+    against 50-digit arithmetic: orc_exp and orc_log within 1 ulp, the table-reduced exp of the attenuation integrand (round 6) within
+    2 ulp; special values."""
+    import ctypes
+    from decimal import Decimal, getcontext
+    getcontext().prec = 50
+    lib = orc.lib()
+    for f in ('orc_exp', 'orc_exp_tab', 'orc_log_value'):
+        getattr(lib, f).argtypes = [ctypes.c_double]
+        getattr(lib, f).restype = ctypes.c_double
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.uniform(-700, 700, 1500), rng.uniform(-40, 5, 1500), rng.uniform(-1e-3, 1e-3, 300),
+                         [0., -0., 1., -1., 709.7, -745.1, 0.0054, -0.0054, np.log(2) / 128, 64 * np.log(2)]])
+    worst = {'orc_exp': 0., 'orc_exp_tab': 0.}
+    for x in xs:
+        ref = Decimal(float(x)).exp()
+        for f in worst:
+            got = getattr(lib, f)(float(x))
+            ulp = Decimal(float(np.spacing(got)))
+            worst[f] = max(worst[f], float(abs(Decimal(got) - ref) / ulp))
+    print('worst error in ulp:', worst)
+    assert worst['orc_exp'] <= 1.0 and worst['orc_exp_tab'] <= 2.0
+    ls = np.concatenate([rng.uniform(1e-300, 1e300, 10), 10 ** rng.uniform(-30, 30, 2000), rng.uniform(0.5, 2, 1000)])
+    wl = 0.
+    for x in ls:
+        ref = Decimal(float(x)).ln()
+        got = lib.orc_log_value(float(x))
+        if got != 0.:
+            wl = max(wl, float(abs(Decimal(got) - ref) / Decimal(float(np.spacing(abs(got))))))
+    print('log: worst error in ulp:', wl)
+    assert wl <= 1.0
+    for f in ('orc_exp', 'orc_exp_tab'):
+        g = getattr(lib, f)
+        assert np.isnan(g(float('nan'))) and g(800.) == np.inf and g(-800.) == 0. and g(0.) == 1.
