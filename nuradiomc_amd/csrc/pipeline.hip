@@ -1607,8 +1607,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         NEED(it_off = WS("item_need_offset", int, (size_t)n_items + 1));
         NEED(it_tmp = WS("scan_tmp4", int, scan_tiles((long)n_items + 1)));
         NEED(it_list = WS("item_list", int, (size_t)n_items));
-        int* it_sorted;   // the convolution kernel's event list in the order of the trace lengths (spectral.hip, length_hist_kernel)
-        NEED(it_sorted = WS("item_list_by_length", int, length_sort_ws_ints(n_cand)));
+        unsigned char* it_sorted;   // the convolution kernel's event records and its list in the order of the trace lengths (spectral.hip)
+        NEED(it_sorted = WS("conv_event_records", unsigned char, conv_ws_bytes(n_cand)));
         double* conv_noise = nullptr;   // the noise trace of the channel a block of the convolution kernel is working on
         if (noise) NEED(conv_noise = WS("conv_noise_trace", double, (size_t)channel_grid_blocks() * FFT_MAX));
         double2* conv_acc;  // frequency-domain sum over antenna tables (LPDA channels seeing rays in different lobes)
@@ -1993,3 +1993,38 @@ int nrhip_debug_czt(nrhip_ctx* ctx, int32_t n_batch, int32_t n_in, int32_t n_out
 }
 
 }  // extern "C"
+
+#ifdef NRHIP_CONV_TIMING
+namespace nrhip {
+void launch_conv_pair_probe(hipStream_t s, const double2* tw, const double2* w16, const double2* G, int n_iter, int L, int variant,
+                            unsigned long long* clk);
+}
+// tools/conv_pair_probe.py: n_iter transform pairs per block on every CU; clocks[6] = (forward, spectrum pass, inverse) of wave 0 and
+// of wave 5 summed over the blocks, *ms = wall time of the launch
+extern "C" int nrhip_debug_conv_pair(nrhip_ctx* ctx, int n_iter, int L, int variant, unsigned long long* clocks6, float* ms)
+{
+    if (ensure_twiddle(ctx)) return -1;
+    HIPCHK(hipSetDevice(ctx->device));
+    double2* G;
+    unsigned long long* clk;
+    const size_t ng = (size_t)64 * NRHIP_G_STRIDE;
+    HIPCHK(hipMalloc((void**)&G, ng * sizeof(double2)));
+    HIPCHK(hipMalloc((void**)&clk, 6 * sizeof(unsigned long long)));
+    std::vector<double2> h(ng, make_double2(1.0 / 8192, 0.));
+    HIPCHK(hipMemcpy(G, h.data(), ng * sizeof(double2), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(clk, 0, 6 * sizeof(unsigned long long)));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    nrhip::launch_conv_pair_probe(ctx->stream, ctx->twiddle, ctx->w16, G, 2, L, variant, clk);   // warm-up
+    HIPCHK(hipMemsetAsync(clk, 0, 6 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipEventRecord(a, ctx->stream));
+    nrhip::launch_conv_pair_probe(ctx->stream, ctx->twiddle, ctx->w16, G, n_iter, L, variant, clk);
+    HIPCHK(hipEventRecord(b, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipEventElapsedTime(ms, a, b));
+    HIPCHK(hipMemcpy(clocks6, clk, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(G); (void)hipFree(clk); (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return 0;
+}
+#endif

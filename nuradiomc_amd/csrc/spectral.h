@@ -223,9 +223,10 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
                     const double* ray_traces = nullptr, int skip_off = -1, const FilterSet* envf = nullptr, double* env_trace = nullptr,
                     const NoiseDev* noise = nullptr, bool conv_split = true, double pa_amp_cut = -1., double* amp_scratch = nullptr, double* noise_buf = nullptr,
-                    const int* item_need = nullptr, int* length_sort_ws = nullptr);
-// ints of launch_channel's length_sort_ws (histogram, cursors, scan scratch, the sorted list of up to n_cand candidate events)
-inline size_t length_sort_ws_ints(long n_cand) { return (size_t)(2 * (FFT_MAX / 2 + 2) + scan_tiles(FFT_MAX / 2 + 2) + n_cand + 8); }
+                    const int* item_need = nullptr, void* conv_ws = nullptr);
+// bytes of launch_channel's conv_ws: one 112-byte record per candidate event for the convolution kernel, then the counting sort of
+// the event list by trace length (histogram, cursors, scan scratch, sorted list).  Required when the convolution kernel runs.
+inline size_t conv_ws_bytes(long n_cand) { return (size_t)n_cand * 112 + 4 * (size_t)(2 * (FFT_MAX / 2 + 2) + scan_tiles(FFT_MAX / 2 + 2) + n_cand + 8) + 64; }
 // channel_kernel's amplitude table lives in HBM scratch (rows of N / 2 + 1 doubles per block) when N > 4096
 inline bool channel_amp_in_hbm(int n_samples) { return n_samples / 2 > 2048; }
 // efield_max_kernel / general_spectrum_kernel: N / 2 no power of two and above 2048 -- the Bluestein transform takes FFT_MAX points,

@@ -866,7 +866,9 @@ __device__ __noinline__ double2 efield_bound_fp64_ray(int N, double fs, int n_fc
                                                        const AskaryanConst& ask, const double* at, const double* at_slope,
                                                        const double* s_xp, int lane);   // (defined with efield_bound_kernel)
 #define AB_RT 4  // rays per wave and pass: the frequency-grid tables are loaded once for AB_RT rays
+#ifndef AB_G
 #define AB_G 4   // bins per group of the two-sided sums
+#endif
 #define AB_RUN 8 // groups per lane at most (N / 2 <= 2048; longer traces take the plain sums)
 #ifndef NRHIP_AB_WAVES
 #define NRHIP_AB_WAVES 3
@@ -2234,6 +2236,55 @@ __global__ void channel_event_flags_kernel(int n_cand, int n_ch, int* __restrict
 // threads per block: 512 for the full-capacity kernel (one block per CU), 256 for the half-capacity one (two blocks per CU: the same
 // eight waves per CU, each with the 256 registers the transforms want, but two independent barrier domains)
 #define CONV_THREADS(log2cap) ((log2cap) == FFT_LOG2_MAX ? CONV_NT : CONV_NT / 2)
+// What channel_conv_kernel needs to know about a candidate event before it can start on it, in ONE record per list entry (round 6).
+// The kernel used to find these out by itself: thread 0 took a list index from the queue, then read list -> candidate -> event ->
+// length, then the needed channels and their bounds one by one for the best-first order; a barrier; then every thread read the
+// event's table index, ray range and start time -- eight dependent trips to the L2 / HBM per event with the whole block waiting
+// (10 % of the kernel's time).  Now a block claims `claim` consecutive list entries with one atomic and a wave reads their
+// records with one request per lane.
+#define CONV_CLAIM_MAX 8
+struct ConvHdr {
+    int c, e, L, il, r0, nre;        // candidate index, event, common trace length, its table row, first ray, number of rays
+    double t_min;
+    int n_order, pad[3];             // channels in `order` (best first), or the number of needed channels (coincidence, > CONV_MAX_ORDER)
+    unsigned char order[CONV_MAX_ORDER];
+};
+static_assert(sizeof(ConvHdr) == 7 * 16, "seven 16-byte words per record");
+__global__ void __launch_bounds__(256)
+conv_header_kernel(const int* __restrict__ n_list, const int* __restrict__ list, const int* __restrict__ item_event, EventOut ev,
+                   const int* __restrict__ ev_len_index, int n_ch, const int* __restrict__ need, const double* __restrict__ maxV,
+                   int best_first, int coinc, int exact, ConvHdr* __restrict__ hdr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_list) return;
+    ConvHdr h;
+    const int c = list[i], e = item_event[c];
+    h.c = c; h.e = e; h.L = ev.L[e]; h.il = ev_len_index[e]; h.r0 = ev.ray_begin[e]; h.nre = ev.n_rays[e]; h.t_min = ev.t_min[e];
+    h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    for (int k = 0; k < CONV_MAX_ORDER; k++) h.order[k] = 0;
+    int cnt = 0;
+    const int base = c * n_ch;
+    if (best_first) {
+        // plain OR: the channel with the largest bound first (the event is done at the first trigger).  Coincidence: the WEAKEST
+        // first -- the kernel's early stop counts silent channels, and the likely loud one is then the one it saves
+        // (the prefilter leaves -bound in maxV)
+        for (int ch = 0; ch < n_ch; ch++) {
+            if (!need[base + ch]) continue;
+            const double b = coinc ? maxV[base + ch] : -maxV[base + ch];
+            int k = cnt++;
+            while (k > 0 && (coinc ? maxV[base + h.order[k - 1]] : -maxV[base + h.order[k - 1]]) < b) {
+                h.order[k] = h.order[k - 1];
+                k--;
+            }
+            h.order[k] = (unsigned char)ch;
+        }
+    } else if (coinc && !exact) {   // (more channels than the ordered list holds: channel order, counted)
+        for (int ch = 0; ch < n_ch; ch++) cnt += need[base + ch] != 0;
+    }
+    h.n_order = cnt;
+    hdr[i] = h;
+}
+
 // one N/2-point transform of the convolution kernel: an on-sky component of a ray (or both at once when the reflection
 // coefficients are real), where it starts on the event's grid and what it is scaled with
 struct ConvJob {
@@ -2624,7 +2675,7 @@ __device__ __forceinline__ void czt_inverse_blocks(double2* x, const double2* __
 // MODE: 0 the plain OR of simple thresholds, 1 the same with the traces of a triggered event emitted, 2 coincidence logic.
 template <int LOG2CAP, int WR, bool NZ, int MODE>
 __global__ void __launch_bounds__(CONV_THREADS(LOG2CAP), 2)
-channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item_list, const int* __restrict__ need,
+channel_conv_kernel(const int* __restrict__ n_list, const ConvHdr* __restrict__ hdr, int claim, const int* __restrict__ need,
                     const int* __restrict__ item_event, RayWork w, EventIn evin, EventOut ev,
                     const int* __restrict__ ev_len_index, StationDev st, int ask_model, TriggerDev trg,
                     const double2* __restrict__ tw, const double2* __restrict__ w16, LengthTables tab, int log2nh,
@@ -2673,62 +2724,49 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
     // unit of work: one candidate event; its channels are evaluated in sequence and -- the trigger being an OR over
     // channels -- the remaining ones are skipped (maxV = NaN) once one has triggered, unless every trace is wanted
     __shared__ long long s_emit_off;
-    // The channels an event still needs, strongest Cauchy-Schwarz bound first: the trigger is an OR over the channels, so the
-    // one most likely to fire ends the event soonest (any order gives the same mask).  Built by thread 0 per event; two
-    // buffers, because a wave may run ahead through the barrier-free skip path into the next event's set-up.
+    // The channels an event still needs come strongest Cauchy-Schwarz bound first (ConvHdr::order): the trigger is an OR over the
+    // channels, so the one most likely to fire ends the event soonest (any order gives the same mask).
     __shared__ unsigned short s_rct[CONV_STAGE_RAYS];   // (channel << 4) | antenna table of the event's rays
-    __shared__ short s_order[2][CONV_MAX_ORDER];
-    __shared__ int s_norder[2];
     const bool best_first = !exact && st.n_ch <= CONV_MAX_ORDER;   // the needed channels of an event in the order of their bounds
-    // events are handed out through a counter in HBM (zero at launch): their cost varies with the number of channels and rays
-    __shared__ int s_le[2];
-    int par = 0;
+    // Events are handed out through a counter in HBM (zero at launch; their cost varies with the number of channels and rays):
+    // `claim` consecutive list entries per atomic, their records (ConvHdr: built by conv_header_kernel, the best-first channel
+    // order included) read by the first wave, one 16-byte word per lane.  Two sets of records: a wave may run ahead through the
+    // barrier-free skip path into the next claim while the others still read this one's.
+    __shared__ ConvHdr s_hdr[2][CONV_CLAIM_MAX];
+    __shared__ int s_claim[2];
+    int par = 1, kc = claim;   // (the first pass claims)
     CT_DECL;
-    for (;; par ^= 1) {
-      if (threadIdx.x == 0) {
-          const int le0 = atomicAdd(queue, 1);
-          s_le[par] = le0;
-          int cnt_o = 0;
-          const int base = (le0 < n_list_events ? item_list[le0] : 0) * st.n_ch;
-          // the two instantiations share one list: each takes the events of its length class (l_min < L <= M); the others cost
-          // one counter increment and this test
-          bool mine_ev = true;
-          if (le0 < n_list_events) {
-              const int L0 = ev.L[item_event[item_list[le0]]];
-              mine_ev = L0 > l_min && L0 <= M;
-          }
-          if (!mine_ev) cnt_o = -1;
-          else if (best_first && le0 < n_list_events) {
-              // plain OR: the channel with the largest bound first (the event is done at the first trigger).  Coincidence: the
-              // WEAKEST first -- the early stop below counts silent channels, and the likely loud one is then the one it saves
-              for (int ch = 0; ch < st.n_ch; ch++) {
-                  if (!need[base + ch]) continue;
-                  const double b = coinc ? out.maxV[base + ch] : -out.maxV[base + ch];   // (the prefilter leaves -bound)
-                  int k = cnt_o++;
-                  while (k > 0 && (coinc ? out.maxV[base + s_order[par][k - 1]] : -out.maxV[base + s_order[par][k - 1]]) < b) {
-                      s_order[par][k] = s_order[par][k - 1];
-                      k--;
-                  }
-                  s_order[par][k] = (short)ch;
+    for (;;) {
+      if (kc == claim) {
+          par ^= 1;
+          kc = 0;
+          if (threadIdx.x < 64) {
+              int base = 0;
+              if (threadIdx.x == 0) base = atomicAdd(queue, claim);
+              base = __shfl(base, 0);
+              const int k = (int)threadIdx.x / 7, part = (int)threadIdx.x - 7 * k;
+              if (k < claim && base + k < n_list_events) {
+                  typedef int conv_i4v __attribute__((ext_vector_type(4)));
+                  ((conv_i4v*)&s_hdr[par][k])[part] = ((const __attribute__((address_space(1))) conv_i4v*)(hdr + base + k))[part];
               }
+              if (threadIdx.x == 0) s_claim[par] = base;
           }
-          else if (coinc && !exact && le0 < n_list_events) {   // (more channels than the ordered list holds: channel order, counted)
-              for (int ch = 0; ch < st.n_ch; ch++) cnt_o += need[base + ch] != 0;
-          }
-          s_norder[par] = cnt_o;
       }
       lds_barrier();
-      const int le = s_le[par];
+      const int le = s_claim[par] + kc;
+      const ConvHdr& H = s_hdr[par][kc];
+      kc++;
       if (le >= n_list_events) break;
-      if (s_norder[par] < 0) continue;   // an event of the other length class
-      const int ev_item0 = item_list[le] * st.n_ch;
-      const int ev_e = item_event[item_list[le]], ev_L = ev.L[ev_e];
+      // the two instantiations share one list: each takes the events of its length class (l_min < L <= M); the others cost this test
+      if (!(H.L > l_min && H.L <= M)) continue;
+      const int ev_item0 = H.c * st.n_ch;
+      const int ev_e = H.e, ev_L = H.L;
       // Touch what the channel steps of this event will read from HBM -- the rays' emission constants, attenuation rows and per-ray
       // scalars, one word per 64 bytes -- so that ONE round trip brings all of it into the L2 while the block sets up; the steps'
       // own dependent loads (ray list, job constants) then take L2 latencies.  The sum is only there to keep the loads.
       int touch_acc = 0;
       {
-          const int r0e = ev.ray_begin[ev_e], nre = ev.n_rays[ev_e];
+          const int r0e = H.r0, nre = H.nre;
           const char* pa = (const char*)(w.ask + r0e);
           for (long i = (long)threadIdx.x * 64; i < (long)nre * (long)sizeof(AskaryanConst); i += (long)NT * 64) touch_acc += *(const int*)(pa + i);
           const char* pt = (const char*)(w.att + (long)r0e * st.n_fc);
@@ -2746,8 +2784,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       }
       // what every channel step of the event needs: read once (the steps used to fetch these scalars, and walk the rays' channel and
       // antenna-table numbers in HBM, one dependent load after the other, per channel)
-      const int evx_il = ev_len_index[ev_e], evx_r0 = ev.ray_begin[ev_e], evx_r1 = evx_r0 + ev.n_rays[ev_e];
-      const double evx_t_min = ev.t_min[ev_e];
+      const int evx_il = H.il, evx_r0 = H.r0, evx_r1 = H.r0 + H.nre;
+      const double evx_t_min = H.t_min;
       const bool rays_staged = evx_r1 - evx_r0 <= CONV_STAGE_RAYS;
       if (rays_staged)
           for (int i = threadIdx.x; i < evx_r1 - evx_r0; i += blockDim.x) s_rct[i] = (unsigned short)((w.ch[evx_r0 + i] << 4) | w.tab[evx_r0 + i]);
@@ -2761,12 +2799,12 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
       // evaluated channel: the shared flag itself may already have been reset for the NEXT event by a wave that ran ahead
       // through the barrier-free skip path below
       bool ev_trig = false;
-      const int n_steps = best_first ? s_norder[par] : st.n_ch;
+      const int n_steps = best_first ? H.n_order : st.n_ch;
       // n-fold coincidence, production mode: once the channels that raised a flag plus the channels still to come are fewer than n
       // the event cannot trigger any more -- the rest of its channels is not transformed (the mask is the same; a 2-fold
       // coincidence on two candidate channels ends after the first one that stays silent)
       const bool coinc_stop = coinc && !exact && out.trace == nullptr;
-      const int m_need = s_norder[par];
+      const int m_need = H.n_order;
       int n_done = 0, n_flagged = 0;
       // emission of a triggered event's traces: once a channel has triggered, ALL channels of the event are evaluated (in channel
       // order, the pruned ones included) and written into the block reserved for the event
@@ -2778,7 +2816,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         int ch;
         if (!emitting) {
             if (step >= n_steps) break;
-            ch = best_first ? (int)s_order[par][step] : step;
+            ch = best_first ? (int)H.order[step] : step;
         } else {
             if (step >= st.n_ch) break;
             ch = step;
@@ -3162,7 +3200,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const int* __restrict__ item
         }
         if (coinc_stop && n_flagged + (m_need - n_done) < trg.n_coinc) {   // (block-uniform: counts of whole channels)
             if (threadIdx.x == 0) {   // the rest is not evaluated
-                if (best_first) { for (int s2 = step + 1; s2 < n_steps; s2++) out.maxV[ev_item0 + s_order[par][s2]] = NAN; }
+                if (best_first) { for (int s2 = step + 1; s2 < n_steps; s2++) out.maxV[ev_item0 + H.order[s2]] = NAN; }
                 else { for (int c2 = ch + 1; c2 < st.n_ch; c2++) if (need[ev_item0 + c2]) out.maxV[ev_item0 + c2] = NAN; }
             }
             break;
@@ -4214,7 +4252,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                     const ChannelOut& out, int exact, int max_length, int* need, int* need_offset, int* scan_tmp,
                     int* item_list, int* coinc_cnt, double2* conv_acc, unsigned long long* xform_count, double2* tab_nodes,
                     const double* ray_traces, int skip_off, const FilterSet* envf, double* env_trace, const NoiseDev* noise,
-                    bool conv_split, double pa_amp_cut, double* amp_scratch, double* noise_buf, const int* item_need, int* length_sort_ws)
+                    bool conv_split, double pa_amp_cut, double* amp_scratch, double* noise_buf, const int* item_need, void* conv_ws)
 {
     if (skip_off < 0) skip_off = !exact;  // channels outside the trigger set are evaluated only when everything is
     if (n_items <= 0) return;
@@ -4225,7 +4263,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
     // NRHIP_CHANNEL_CZT=1): chirp-z per ray (plain OR of simple thresholds only; the caller checks)
     int skip_upto = 0;
     // (the convolution kernel's ray stage is radix 2: trace lengths that are no power of two take the chirp-z kernel)
-    if (tab.G && st.N <= FFT_MAX / 2 && st.np.log2nh >= 0 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces && !env_trace &&
+    if (tab.G && conv_ws && st.N <= FFT_MAX / 2 && st.np.log2nh >= 0 && !getenv("NRHIP_CHANNEL_CZT") && !ray_traces && !env_trace &&
         (!(noise && noise->on) || (noise_buf && !getenv("NRHIP_NOISE_CZT")))) {
         const bool pa_prune = pa_amp_cut >= 0.;   // (then the bounds are wanted although every kept item is evaluated exactly)
         hipLaunchKernelGGL(channel_prefilter_kernel, dim3(grid_for(n_items, 256)), dim3(256), 0, s, n_items, item_event, w, ev,
@@ -4241,9 +4279,11 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
         launch_exclusive_scan(s, (long)n_cand + 1, ev_need, need_offset, scan_tmp);
         hipLaunchKernelGGL(scatter_item_list_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, n_cand, ev_need, need_offset,
                            item_list);
-        if (length_sort_ws && !getenv("NRHIP_CONV_LIST_ORDER")) {   // the list in the order of the trace lengths (length_hist_kernel)
-            constexpr int NK = FFT_MAX / 2 + 1;
-            int *hist = length_sort_ws, *cursor = hist + NK + 1, *tmp = cursor + NK + 1, *sorted = tmp + scan_tiles(NK + 1);
+        // the list in the order of the trace lengths (length_hist_kernel), then one record per entry (conv_header_kernel)
+        constexpr int NK = FFT_MAX / 2 + 1;
+        ConvHdr* hdr = (ConvHdr*)conv_ws;
+        int *hist = (int*)(hdr + n_cand), *cursor = hist + NK + 1, *tmp = cursor + NK + 1, *sorted = tmp + scan_tiles(NK + 1);
+        if (!getenv("NRHIP_CONV_LIST_ORDER")) {
             (void)hipMemsetAsync(hist, 0, sizeof(int) * (NK + 1), s);
             hipLaunchKernelGGL(length_hist_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, need_offset + n_cand, item_list, item_event, ev.L, hist);
             launch_exclusive_scan(s, NK + 1, hist, cursor, tmp);
@@ -4251,6 +4291,14 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
                                cursor, sorted);
             item_list = sorted;
         }
+        const bool coinc_mode = trig.coincidence();
+        hipLaunchKernelGGL(conv_header_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, need_offset + n_cand, item_list, item_event, ev,
+                           ev_len_index, st.n_ch, need, out.maxV, (!exact && st.n_ch <= CONV_MAX_ORDER) ? 1 : 0, coinc_mode ? 1 : 0, exact, hdr);
+        // list entries a block claims per atomic.  Measured (1e6-event survey, 83 k candidate events on 256 blocks): 1 -> 10.8 ms,
+        // 2 -> 10.9, 4 -> 11.4, 8 -> 11.5 -- the coarser hand-out costs more at the tail of the list than the atomics it saves, so
+        // one entry per claim it is; what pays is the record (one trip instead of eight)
+        int claim = 1;
+        if (getenv("NRHIP_CONV_CLAIM")) claim = std::max(1, std::min(CONV_CLAIM_MAX, atoi(getenv("NRHIP_CONV_CLAIM"))));
         // events of up to FFT_MAX / 2 samples go to the half-capacity instantiation (two blocks per CU), longer ones to the full one;
         // both walk the same list with their own counter
         // (with thermal noise every event takes the full-capacity instantiation: the noise trace is an 8192-point chirp convolution)
@@ -4269,7 +4317,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
             const bool wr_s = (nh == 1024 || nh == 2048) && (nh >> 3) <= CONV_THREADS(FFT_LOG2_MAX - 1) && !getenv("NRHIP_CONV_OLD_RAYS");
             auto kern_s = conv_kernel_pick(FFT_LOG2_MAX - 1, !wr_s ? 0 : (nh == 2048 ? 4 : 2), false, conv_mode);
             hipLaunchKernelGGL(kern_s, dim3(cgrid), dim3(CONV_THREADS(FFT_LOG2_MAX - 1)), (size_t)conv_lds_bytes(FFT_LOG2_MAX - 1), s,
-                               need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
+                               need_offset + n_cand, hdr, claim, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue, 0, nz_off, nullptr);
         }
         if (large) {
@@ -4278,7 +4326,7 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
             const int wr_n = !wr_l ? 0 : (nh == 2048 ? 4 : 2);
             auto kern_l = conv_kernel_pick(FFT_LOG2_MAX, wr_n, with_noise, conv_mode);
             hipLaunchKernelGGL(kern_l, dim3(cgrid), dim3(CONV_NT), (size_t)conv_lds_bytes(FFT_LOG2_MAX), s,
-                               need_offset + n_cand, item_list, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
+                               need_offset + n_cand, hdr, claim, need, item_event, w, evin, ev, ev_len_index, st, ask_model, trig, tw, w16,
                                tab, ilog2(nh), out, exact, coinc_cnt, conv_acc, xform_count, queue + (small ? 1 : 0),
                                small ? FFT_MAX / 2 : 0, with_noise ? *noise : nz_off, with_noise ? noise_buf : nullptr);
         }
@@ -5564,6 +5612,45 @@ void launch_czt_test(hipStream_t s, int n_batch, int n_in, int n_out, int Q, dou
                        out, tw, Bscratch);
 }
 
+
+#ifdef NRHIP_CONV_TIMING
+// ---- probe: the transform pair of channel_conv_kernel alone (tools/conv_pair_probe.py) -- one 512-thread block per CU, n_iter pairs each
+// on an event of L samples; shader clocks of wave 0 and of wave 5 per phase (forward, spectrum pass, inverse), wall time by the caller
+__global__ void __launch_bounds__(CONV_NT, 2)
+conv_pair_probe_kernel(const double2* __restrict__ tw, const double2* __restrict__ w16, const double2* __restrict__ G, int n_iter, int L,
+                       int variant, unsigned long long* __restrict__ clk)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* z = (double2*)smem;
+    const double2* cft = w16 + (FFT_MAX / 2 + 1);
+    for (int i = threadIdx.x; i < conv_lds_elems(FFT_MAX); i += blockDim.x) z[i] = make_double2(1e-3 * (i & 15), 1e-3);
+    __syncthreads();
+    unsigned long long c[3] = {0, 0, 0};
+    for (int it = 0; it < n_iter; it++) {
+        const double2* Gi = G + (variant == 1 ? (long)((blockIdx.x * 131 + it * 7) % 64) * NRHIP_G_STRIDE : 0);   // 1: a cold-ish table per pair
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        conv_fwd<FFT_LOG2_MAX, CONV_NT>(tw, cft, L >> 1);
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        conv_mid<FFT_LOG2_MAX, CONV_NT>(Gi, w16);
+        unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        conv_inv<FFT_LOG2_MAX, CONV_NT>(tw, cft);
+        unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        c[0] += t1 - t0; c[1] += t2 - t1; c[2] += t3 - t2;
+    }
+    if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 5)) {
+        const int o = (threadIdx.x >> 6) == 0 ? 0 : 3;
+        for (int q = 0; q < 3; q++) atomicAdd(&clk[o + q], c[q]);
+    }
+}
+void launch_conv_pair_probe(hipStream_t s, const double2* tw, const double2* w16, const double2* G, int n_iter, int L, int variant,
+                            unsigned long long* clk)
+{
+    set_big_lds();
+    (void)hipFuncSetAttribute((const void*)conv_pair_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(FFT_LOG2_MAX));
+    hipLaunchKernelGGL(conv_pair_probe_kernel, dim3(channel_grid_blocks() / 2), dim3(CONV_NT), (size_t)conv_lds_bytes(FFT_LOG2_MAX), s, tw, w16, G,
+                       n_iter, L, variant, clk);
+}
+#endif
 }  // namespace nrhip
 
 #ifdef NRHIP_CONV_TIMING

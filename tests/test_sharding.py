@@ -23,19 +23,31 @@ def _worker(rank, world, n, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import torch.distributed as dist
-    from nuradiomc_amd.comm import shard_range
+    from nuradiomc_amd import comm
     from torch_gather import gather_triggered
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
     full = (np.arange(n) * 7919 % 13 == 0).astype(np.uint8)   # what a single process would have produced
-    a, b = shard_range(n, rank, world)
-    got = gather_triggered(full[a:b], n, dist=dist)
-    q.put((rank, bool(np.array_equal(got, full))))
+    a, b = comm.shard_range(n, rank, world)
+    # the PRODUCT's communicator (nuradiomc_amd.comm.Comm; no device here, so its collectives go over its TCP star): shard ->
+    # barrier -> gather of the masks -> counters, the sequence bench.py runs on every rank
+    c = comm.Comm(None, rank, world, addr='127.0.0.1', port=port + 1000, backend='tcp')
+    c.barrier()
+    got = c.allgather_masks(full[a:b].copy(), b - a, n)
+    tot = c.allreduce_sum([int(full[a:b].sum()), b - a])
+    c.barrier()
+    ok = bool(np.array_equal(got, full)) and [int(v) for v in tot] == [int(full.sum()), n] and c.mode == 'tcp'
+    c.close()
+    # cross-check: the same shards through torch.distributed on gloo (tests/torch_gather.py, the twin of allgather_masks)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    twin = gather_triggered(full[a:b], n, dist=dist)
+    q.put((rank, ok and bool(np.array_equal(twin, got))))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_gather_triggered_world2_gloo():
+    """World size 2 on CPU: the product's Comm gathers the sharded trigger masks of one list into the one-process mask on every
+    rank and sums the counters; torch.distributed (gloo) gathers the same shards to the same mask."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
