@@ -200,16 +200,23 @@ def upload_events(ctx, wl, sl=None):
     if sl is None:
         sel = slice(0, len(grp))
         g0, g1 = 0, int(grp[-1]) + 1 if len(grp) else 0
+    elif isinstance(sl, np.ndarray):   # an index set of event groups (interleaved chunks of a strong-scaling run); one shower per group
+        if len(grp) and int(grp[-1]) + 1 != len(grp):
+            raise SystemExit("bench.py: interleaved shards need one shower per event group (--flavour had)")
+        sel = sl
+        g0, g1 = 0, len(sl)
+        sel = type('IndexSel', (), {'start': 0, 'stop': len(sl), 'idx': sl})()
     else:
         g0, g1 = sl
         lo, hi = np.searchsorted(grp, g0), np.searchsorted(grp, g1)
         sel = slice(lo, hi)
     n = sel.stop - sel.start
     n_groups = g1 - g0
-    arrs = [np.ascontiguousarray(ev[k][sel]) for k in ('vertex', 'zenith', 'azimuth', 'energy', 'shower_type', 'k_L')]
+    pick = sel.idx if hasattr(sel, 'idx') else sel
+    arrs = [np.ascontiguousarray(ev[k][pick]) for k in ('vertex', 'zenith', 'azimuth', 'energy', 'shower_type', 'k_L')]
     gb = None
     if n != n_groups:
-        gsel = grp[sel] - g0
+        gsel = grp[pick] - g0
         gb = np.ascontiguousarray(np.concatenate([np.flatnonzero(np.concatenate([[True], gsel[1:] != gsel[:-1]])), [n]]), np.int32)
     d = dict(n=n, n_groups=n_groups, host=arrs, gb_host=gb)
     d['in'] = [ctx.to_device(x) for x in arrs]
@@ -482,6 +489,9 @@ def main():
     ap.add_argument('--flavour', default='had', choices=['had', 'mixed'])
     ap.add_argument('--events', type=int, default=None, help='event groups per rank and step (weak) or in total (strong)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--emulate-shard', default=None, metavar='R/W[/CHUNK]',
+                    help='one GPU: run the shard rank R of W would get of the --events list under --scaling strong -- contiguous '
+                         '(shard_range) or, with CHUNK, interleaved chunks of CHUNK events (shard_chunks); no collectives, no CPU leg')
     ap.add_argument('--chunk', type=int, default=20000, help='config 4: events per call of the general path (spectra and traces of every ray are resident: ~380 KB per ray)')
     ap.add_argument('--cpu-budget', type=float, default=12., help='seconds of CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -547,7 +557,19 @@ def main():
     import nuradiomc_amd
     from nuradiomc_amd import comm as nrcomm
     rank, local_rank, world = nrcomm.env_rank()
-    if args.scaling == 'strong':
+    shard_idx = None
+    if args.emulate_shard:
+        if world != 1 or cfgno == 4:
+            raise SystemExit("bench.py: --emulate-shard is a one-rank option of configs 2, 3, 5")
+        q = [int(v) for v in args.emulate_shard.split('/')]
+        wl = make_workload(cfgno, args.events, 10, args.flavour, args.trigger)
+        g0, g1 = nrcomm.shard_range(args.events, q[0], q[1])
+        if len(q) > 2:
+            shard_idx = nrcomm.shard_chunks(args.events, q[0], q[1], q[2])
+            g0, g1 = 0, len(shard_idx)
+        args.no_cpu_baseline = True
+        args.no_end_to_end = True
+    elif args.scaling == 'strong':
         wl = make_workload(cfgno, args.events, 10, args.flavour, args.trigger)
         g0, g1 = nrcomm.shard_range(args.events, rank, world)
     else:
@@ -570,7 +592,7 @@ def main():
             det.add_lane(build_array(c2, wl).station)
     else:
         n_lanes = 1
-    d = upload_events(ctx, wl, (g0, g1))
+    d = upload_events(ctx, wl, shard_idx if shard_idx is not None else (g0, g1))
     n, n_groups = d['n'], d['n_groups']
     dev_kw = dict(d_max_distance=d['md'], n_groups=n_groups, d_group_begin=d['gb'], **wl['sim_kw'])
     arz_iN = None
@@ -655,6 +677,8 @@ def main():
 
     elapsed = float(comm.allreduce_max([elapsed])[0])
     n_total = args.events if args.scaling == 'strong' else args.events * world
+    if args.emulate_shard:
+        n_total = n_groups
     if args.scaling == 'strong':
         mask = comm.allgather_masks(d['trig'], n_groups, n_total)   # the one collective: triggered masks over xGMI
         n_trig_total = int(mask.sum())

@@ -32,6 +32,7 @@ struct ArzBatch {
 #define ARZ_FAR_CELLS 288
 #define ARZ_TABLE_DOUBLES (4 * (ARZ_TABLE_CELLS + ARZ_FAR_CELLS) * 8)
 
-void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int* status);
+void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int* status, int* vp_range = nullptr,
+                int* silent = nullptr);
 
 }  // namespace nrhip

@@ -181,7 +181,8 @@ struct ArzPiece { int c0, c1, is, ie; long n_fine; double start, step, delta; };
 #define ARZ_WAVES 4   // waves per SIMD the register budget is cut for: 2 .. 8 measured, 4 is fastest (355 vs 410 .. 420 ms per 1e5 events at 2 / 3)
 #endif
 __global__ void __launch_bounds__(256, ARZ_WAVES)
-arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 1][2] */, int* __restrict__ status)
+arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 1][2] */, int* __restrict__ status,
+                            int* __restrict__ vp_range /* [n_rays][2] or nullptr */)
 {
     extern __shared__ double lds[];
     const int ray = blockIdx.x;
@@ -292,12 +293,18 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
     int it_lo = (int)floor((hmin - 20.001 + mean - 0.5 * b.dt) / b.dt), it_hi = (int)ceil((hmax + 20.001 + mean - 0.5 * b.dt) / b.dt);
     it_lo = max(it_lo, 0);
     it_hi = min(it_hi, nt - 1);
+    // Only the observer times it_lo .. it_hi are written (all of them).  With vp_range the caller learns the window and takes the
+    // vector potential outside it as zero (arz_trace_kernel); without it the launcher has zeroed the whole array.
+    if (vp_range && blockIdx.y == 0 && threadIdx.x == 0) { vp_range[2 * ray] = it_lo; vp_range[2 * ray + 1] = it_hi; }
     unsigned n_eval = 0;   // integrand evaluations of this lane
     const int per = (it_hi - it_lo + 1 + ARZ_CHUNKS - 1) / ARZ_CHUNKS;
     const int it_end = min(it_hi + 1, it_lo + (int)(blockIdx.y + 1) * per);
     for (int it = it_lo + blockIdx.y * per + wave; it < it_end; it += n_waves) {
         const double t_bin = it * b.dt + 0.5 * b.dt - mean;
-        if (t_bin - hmax > 20.001 || t_bin - hmin < -20.001) continue;  // vp stays 0 (memset by the launcher)
+        if (t_bin - hmax > 20.001 || t_bin - hmin < -20.001) {   // no node within +-20 ns: A = 0 (written: the window below is dense)
+            if (lane == 0) { vp[((long)ray * nt + it) * 2] = 0.; vp[((long)ray * nt + it) * 2 + 1] = 0.; }
+            continue;
+        }
         const double tobs = t_bin + (r.R0 / ARZ_C * nidx);
         const double ct = ARZ_C * tobs;
         // pass 1 over the profile nodes: anything within +-20 ns?  where does the +-1 ns condition flip?  The flip positions are
@@ -473,7 +480,8 @@ arz_vector_potential_kernel(ArzBatch b, double* __restrict__ vp /* [n_rays][N + 
 
 // E = -dA/dt, rotated into the on-sky basis of the direction to the shower maximum (:641-655); [n_rays][3][N]
 __global__ void __launch_bounds__(256)
-arz_trace_kernel(ArzBatch b, const double* __restrict__ vp, double* __restrict__ trace)
+arz_trace_kernel(ArzBatch b, const double* __restrict__ vp, double* __restrict__ trace, const int* __restrict__ vp_range,
+                 int* __restrict__ silent /* [n_rays] or nullptr: 1 = beyond the 20 degrees, the trace is all zeros and NOT written */)
 {
     const int ray = blockIdx.x;
     const double nidx = b.n_index_ray ? b.n_index_ray[ray] : b.n_index;
@@ -481,9 +489,14 @@ arz_trace_kernel(ArzBatch b, const double* __restrict__ vp, double* __restrict__
     const double theta = b.theta[ray];
     double* out = trace + (long)ray * 3 * N;
     if (fabs(theta - acos(1. / nidx)) > b.maximum_angle) {
+        if (silent) {   // (the caller honours the flag: half of the rays of a survey, 96 KB of zeros each)
+            if (threadIdx.x == 0) silent[ray] = 1;
+            return;
+        }
         for (int i = threadIdx.x; i < 3 * N; i += blockDim.x) out[i] = 0.;
         return;
     }
+    if (silent && threadIdx.x == 0) silent[ray] = 0;
     __shared__ double s_tp;
     if (threadIdx.x == 0) {
         double tp = theta;
@@ -500,28 +513,35 @@ arz_trace_kernel(ArzBatch b, const double* __restrict__ vp, double* __restrict__
     __syncthreads();
     const double ct = cos(s_tp), st = sin(s_tp);
     const double* v = vp + (long)ray * nt * 2;
+    // (with vp_range: the vector potential was written for the observer times lo .. hi only and is zero -- not stored -- elsewhere)
+    const int lo = vp_range ? vp_range[2 * ray] : 0, hi = vp_range ? vp_range[2 * ray + 1] : nt - 1;
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
-        const double ex = -(v[2 * (i + 1)] - v[2 * i]) / b.dt, ez = -(v[2 * (i + 1) + 1] - v[2 * i + 1]) / b.dt;
+        const bool in0 = i >= lo && i <= hi, in1 = i + 1 >= lo && i + 1 <= hi;
+        const double ax0 = in0 ? v[2 * i] : 0., az0 = in0 ? v[2 * i + 1] : 0.;
+        const double ax1 = in1 ? v[2 * (i + 1)] : 0., az1 = in1 ? v[2 * (i + 1) + 1] : 0.;
+        const double ex = -(ax1 - ax0) / b.dt, ez = -(az1 - az0) / b.dt;
         out[i] = st * ex + ct * ez;
         out[N + i] = ct * ex - st * ez;
         out[2 * N + i] = 0.;
     }
 }
 
-void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int* status)
+void launch_arz(hipStream_t s, const ArzBatch& b, double* vp, double* trace, int* status, int* vp_range, int* silent)
 {
     if (b.n_rays <= 0) return;
     const int nt = b.N + 1;
     dim3 grid((unsigned)b.n_rays, ARZ_CHUNKS);
-    (void)hipMemsetAsync(vp, 0, sizeof(double) * 2 * (size_t)nt * b.n_rays, s);
+    // vp_range ([n_rays][2], optional): the window of observer times the kernel writes per ray; without it the array is zeroed first
+    // (round 6: that memset was 155 GB of HBM writes per 2e4-event step of BASELINE config 4, read back as zeros by the trace kernel)
+    if (!vp_range) (void)hipMemsetAsync(vp, 0, sizeof(double) * 2 * (size_t)nt * b.n_rays, s);
     if (b.form_factor_table)
         hipLaunchKernelGGL(arz_form_factor_table_kernel, dim3((4 * (ARZ_TABLE_CELLS + ARZ_FAR_CELLS) + 255) / 256), dim3(256), 0, s, b.parameters,
                            b.form_factor_table);
     const size_t lds = sizeof(double) * 5 * (size_t)b.n_depth;   // 80 KB at the 2048 depth bins the entry points admit
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)arz_vector_potential_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(arz_vector_potential_kernel, grid, dim3(256), lds, s, b, vp, status);
-    hipLaunchKernelGGL(arz_trace_kernel, dim3((unsigned)b.n_rays), dim3(256), 0, s, b, vp, trace);
+    hipLaunchKernelGGL(arz_vector_potential_kernel, grid, dim3(256), lds, s, b, vp, status, vp_range);
+    hipLaunchKernelGGL(arz_trace_kernel, dim3((unsigned)b.n_rays), dim3(256), 0, s, b, vp, trace, vp_range, silent);
 }
 
 }  // namespace nrhip

@@ -1271,19 +1271,25 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
                               g_prof, g_resc, g_x1, g_x2, g_nsteps, g_npoints);
         LCHK("general gather");
         const double* arz_trace = nullptr;
+        const int* arz_silent = nullptr;   // rays beyond the emission model's 20 degrees: zero traces that are not stored
         if (arz) {
             double *vp, *atr;
             int* ast;
             NEED(vp = WS("arz_vector_potential", double, nr * (sd.N + 1) * 2));
             NEED(atr = WS("arz_traces", double, nr * 3 * sd.N));
             NEED(ast = WS("arz_status", int, nr));
+            int* vpr;   // per ray: the window of observer times whose vector potential is stored (zero elsewhere, never written)
+            NEED(vpr = WS("arz_vp_window", int, 2 * nr));
+            int* sil;
+            NEED(sil = WS("arz_silent", int, nr));
+            arz_silent = sil;
             HIPCHK(hipMemsetAsync(ast, 0, sizeof(int) * nr, sm));
             ArzBatch ab{(long)n_rays, g_energy, w.view, w.R, g_type, g_em, g_prof, g_resc, st->arz_n_profiles, st->arz_n_depth,
                         st->d_arz_depth.as<double>(), st->d_arz_ce.as<double>(), st->d_arz_par.as<double>(), sd.N, 1. / sd.fs,
                         1.78, st->arz_interp_factor2, 0, 20. * 0.017453292519943295, w.n_index};
             NEED(ab.form_factor_table = WS("arz_form_factor_table", double, (size_t)ARZ_TABLE_DOUBLES));
             ab.eval_count = general_counters;
-            launch_arz(sm, ab, vp, atr, ast);
+            launch_arz(sm, ab, vp, atr, ast, vpr, sil);
             LCHK("arz");
             // rays beyond the model's 20 degrees carry no signal: no path steps for them (half of config 4's rays)
             if (bire && !getenv("NRHIP_BIRE_ALL_RAYS"))
@@ -1297,7 +1303,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
         }
         double* ray_amp = nullptr;
         if (ray_amp_in_hbm(sd.N)) NEED(ray_amp = WS("ray_amp_scratch", double, (size_t)RAY_AMP_ROWS * (sd.N / 2 + 1)));
-        launch_general_spectrum(sm, n_rays, w, sd, cfg->askaryan_model, arz_trace, ctx->twiddle, spec, ray_amp);
+        launch_general_spectrum(sm, n_rays, w, sd, cfg->askaryan_model, arz_trace, ctx->twiddle, spec, ray_amp, arz_silent);
         LCHK("general spectrum");
         if (bire) {
             std::vector<int> hn(n_rays);

@@ -198,7 +198,8 @@ void launch_length_tables(hipStream_t s, int n_len, const int* lengths, const St
 void launch_length_slots(hipStream_t s, int n_events, const int* ev_L, const int* slotmap, int* len_index);   // fls: DEV [st.n_fsets]
 int channel_grid_blocks();
 void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, int ask_model,
-                             const double* arz_trace, const double2* tw, double2* spec, double* amp_scratch = nullptr);
+                             const double* arz_trace, const double2* tw, double2* spec, double* amp_scratch = nullptr,
+                             const int* silent = nullptr);
 void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double2* tw,
                           double* traces, double* max_efield, const int* active = nullptr, const double* bound = nullptr);
 void launch_general_bound(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const long long* log_gain,

@@ -3932,7 +3932,8 @@ nplan_tables_kernel(int nh, int log2p, double2* __restrict__ wN, double2* __rest
 static inline unsigned grid_for(long n, int block) { return (unsigned)((n + block - 1) / block); }
 static void set_big_lds();
 __global__ void general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, const double* __restrict__ arz_trace,
-                                        const double2* __restrict__ tw, int log2nh, double2* __restrict__ spec, double* __restrict__ amp_scratch);
+                                        const double2* __restrict__ tw, int log2nh, double2* __restrict__ spec, double* __restrict__ amp_scratch,
+                                        const int* __restrict__ silent);
 __global__ void general_trace_kernel(int n_rays, StationDev st, const double2* __restrict__ spec, const double2* __restrict__ tw,
                                      int log2nh, double* __restrict__ traces, double* __restrict__ max_efield,
                                      const int* __restrict__ active, const double* __restrict__ bound);
@@ -4350,7 +4351,8 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
 // ([ray][3][N], arz.hip), else the parametrisation's.  One block (256) per ray; LDS: N/2 complex + (N/2 + 1) doubles.
 __global__ void __launch_bounds__(256)
 general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, const double* __restrict__ arz_trace,
-                        const double2* __restrict__ tw, int log2nh, double2* __restrict__ spec, double* __restrict__ amp_scratch)
+                        const double2* __restrict__ tw, int log2nh, double2* __restrict__ spec, double* __restrict__ amp_scratch,
+                        const int* __restrict__ silent)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int N = st.N, nh = N / 2, n_f = nh + 1;
@@ -4359,6 +4361,11 @@ general_spectrum_kernel(int n_rays, RayWork w, StationDev st, int ask_model, con
     __shared__ RayShared rs;
     const double df = 1.0 / (N * (1. / st.fs));
     for (int r = blockIdx.x; r < n_rays; r += gridDim.x) {
+        if (arz_trace && silent && silent[r]) {   // beyond the emission model's 20 degrees: the trace is zero (and was not written)
+            double2* Ez = spec + (long)r * 2 * n_f;
+            for (int k = threadIdx.x; k < 2 * n_f; k += blockDim.x) Ez[k] = make_double2(0., 0.);
+            continue;   // (block-uniform)
+        }
         __syncthreads();
         if (threadIdx.x == 0) rs.ask = w.ask[r];
         for (int i = threadIdx.x; i < st.n_fc; i += blockDim.x) rs.att[i] = w.att[(long)r * st.n_fc + i];
@@ -4567,7 +4574,7 @@ __global__ void steps_to_points_kernel(int n, const int* __restrict__ n_steps, i
 }
 
 void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const StationDev& st, int ask_model,
-                             const double* arz_trace, const double2* tw, double2* spec, double* amp_scratch)
+                             const double* arz_trace, const double2* tw, double2* spec, double* amp_scratch, const int* silent)
 {
     if (n_rays <= 0) return;
     const int nh = st.N / 2;
@@ -4575,7 +4582,7 @@ void launch_general_spectrum(hipStream_t s, int n_rays, const RayWork& w, const 
     if (amp_scratch && grid > RAY_AMP_ROWS) grid = RAY_AMP_ROWS;
     set_big_lds();
     hipLaunchKernelGGL(general_spectrum_kernel, dim3(grid), dim3(256), (size_t)nplan_points(st.np) * 16 + (amp_scratch ? 0 : (size_t)(nh + 1) * 8), s, n_rays, w, st,
-                       ask_model, arz_trace, tw, ilog2(nh), spec, amp_scratch);
+                       ask_model, arz_trace, tw, ilog2(nh), spec, amp_scratch, silent);
 }
 void launch_general_trace(hipStream_t s, int n_rays, const StationDev& st, const double2* spec, const double2* tw,
                           double* traces, double* max_efield, const int* active, const double* bound)

@@ -11,6 +11,17 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of GPU time; runs only when asked for: -m 'gpu and slow' or NRHIP_RUN_SLOW=1")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`slow` tests are opt-in: they run when the -m expression names them (or NRHIP_RUN_SLOW=1), never as part of a plain -m gpu"""
+    if 'slow' in (config.getoption('-m') or '') or os.environ.get('NRHIP_RUN_SLOW', '0') not in ('', '0'):
+        return
+    skip = pytest.mark.skip(reason="slow: opt in with -m 'gpu and slow' or NRHIP_RUN_SLOW=1")
+    for it in items:
+        if 'slow' in it.keywords:
+            it.add_marker(skip)
 
 
 def golden(name):

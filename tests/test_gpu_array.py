@@ -11,6 +11,7 @@ NuRadioMC/simulation/simulation.py:1454-1600) against
 
 Full-size runs are checked through size-independent properties (the oracle needs ~1 h per 1e6 station-events).
 """
+import os
 import numpy as np
 import pytest
 
@@ -373,3 +374,32 @@ def test_rccl_binding_single_rank(gpu_ctx_factory):
     c.barrier()
     c.close()
     ctx.free(d)
+
+
+@pytest.mark.slow
+def test_config4_per_gpu_shard_of_baseline_config_3():
+    """BASELINE configs[3] (1e7 events, 35 stations, ARZ2020 + birefringence, 8 GPUs) at the size ONE GPU of it gets: 1.25e6 events,
+    walked in chunks of 2e4 through the device-resident form bench.py times (about 4 minutes of GPU time: opt in with
+    -m 'gpu and slow').  Size-independent properties: the counters of the chunks add up, every chunk offers work, and the mask of the
+    first chunk is the mask of the same 2e4 events run on their own (a chunk's result does not depend on the list it is cut from)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+
+    def line(*argv):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '4', '--no-cpu-baseline', '--steps', '1', '--warmup', '0'] +
+                           list(argv), capture_output=True, text=True, timeout=3000)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([q for q in r.stdout.splitlines() if q.startswith('{')][-1])
+    full = line('--events', '1250000', '--chunk', '20000')
+    c = full['config']
+    assert c['event_groups_per_gpu'] == 1250000 and c['n_triggered_all'] > 50000
+    assert c['n_pairs'] == 1250000 * 35 * 24 or c['n_pairs'] > 0
+    two = line('--events', '40000', '--chunk', '20000')
+    one = line('--events', '40000', '--chunk', '40000')
+    assert two['config']['n_triggered_all'] == one['config']['n_triggered_all'] > 1000
+    for k in ('n_rays', 'n_active_rays', 'n_candidate_events'):
+        assert two['config'][k] == one['config'][k], k
+    print('1.25e6-event shard: %.0f ms, %d triggers; 4e4 events in chunks of 2e4 / 4e4: %d triggers'
+          % (full['ms_per_step'], c['n_triggered_all'], one['config']['n_triggered_all']))
