@@ -38,6 +38,7 @@ CHANNELS = np.array([[0., 0., -100. - i] for i in range(5)])
 ENERGY = 3e17                       # shower energy [eV] of a 1 EeV neutrino at <y> ~ 0.3
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s
 FP64_PEAK_TFLOPS = 78.6             # same guide: dense FP64 (vector and matrix alike)
+FP32_PEAK_TFLOPS = 157.3            # same guide: FP32 vector
 FLOP_PER_OBJECTIVE = 189.           # one evaluation of the ray finder's objective (analyticraytracing.py:204-272): ~90 add / mul, 13 divisions
                                     # and 6 square roots at 1 flop, 1 exp + 3 log at 20 (round 5: the finder without the hybr stage needs no
                                     # logarithm for the depth of the turning point; 209 with it)
@@ -711,9 +712,9 @@ def main():
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         value = n_total * args.steps / elapsed
         dom = max((k for k in sm if k != 'total'), key=lambda k: sm[k])
-        kernel_of = {'raytrace': 'raytrace_roots_kernel', 'ray_setup': 'select/scan/ray_setup kernels',
+        kernel_of = {'raytrace': 'raytrace_roots_fast_kernel + raytrace_records_kernel', 'ray_setup': 'select/scan/ray_setup kernels',
                      'amp_bound': 'amp_bound_kernel', 'attenuation': 'attenuation_dense_kernel',
-                     'efield_max': 'efield_bound_kernel + efield_max_kernel' if cfgno != 4 else
+                     'efield_max': 'efield_bound_kernel + efield_sample_kernel + efield_max_kernel' if cfgno != 4 else
                                    'arz_vector_potential_kernel + bire_steps_kernel + bire_propagate_kernel (general path)',
                      'event_grid': 'event_grid_kernel + candidate lists',
                      'length_tables': 'length_tables_kernel', 'channel': 'channel_prefilter_kernel + channel_conv_kernel'}
@@ -733,8 +734,8 @@ def main():
         achieved = alg_bytes / (sm[dom] * 1e-3) / 1e9 if sm[dom] > 0 else 0.
         # HBM bytes per launch from the committed rocprofv3 PMC passes -- quoted only if they were taken on THESE kernel sources
         traffic, traffic_note = None, None
-        pmc = os.environ.get('NRHIP_PMC_JSON', os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json' if cfgno == 2 else
-                                                            'r05_pmc_traffic_config%d.json' % cfgno))
+        pmc = os.environ.get('NRHIP_PMC_JSON', os.path.join(ROOT, 'profiles', 'r06_pmc_traffic.json' if cfgno == 2 else
+                                                            'r06_pmc_traffic_config%d.json' % cfgno))
         std_size = (cfgno == 2 and args.flavour == 'had' and n == 1000000) or (cfgno == 4 and n == 20000 and args.trigger == 'threshold')
         if std_size and os.path.exists(pmc):
             pj = json.load(open(pmc))
@@ -748,8 +749,10 @@ def main():
                 traffic_note = "the PMC profile was taken on other kernel sources (%s != %s): not quoted" % (
                     pj.get('source_hash'), source_hash())
         # FP64 view of the attenuation quadrature: one integrand evaluation = frequency-independent node part (shared
-        # by the 25 lanes of a ray, ~110 flop incl. exp, 2 sqrt, 2 div) / 25 + per-lane exp + div (~45 flop)
-        flop_per_eval = 110. / 25. + 45.
+        # by the 25 lanes of a ray, ~110 flop incl. exp, 2 sqrt, 2 div) / 25 + the lane's own part.  SP1 (round 6: table-reduced exp,
+        # 12 FP64 instructions = 19 flop instead of 19 instructions = 35 flop): argument 2, exp 19, min / ds / rule sums 8 -> ~29;
+        # the other models (a division by the attenuation length instead of the exp): ~45 as before
+        flop_per_eval = 110. / 25. + (29. if wl['att_model'] == 'SP1' else 45.)
         fp64 = stats['n_integrand_evals'] * flop_per_eval / (sm['attenuation'] * 1e-3) / 1e12 if sm['attenuation'] > 0 else 0.
         out = {
             "metric": "simulated events/sec (1e6-evt 1 EeV SP survey)", "value": value, "unit": "events/s",
@@ -805,6 +808,32 @@ def main():
                                      stats.get('n_bire_steps', 0) * FLOP_PER_BIRE_STEP)
             out["config"].update({k: stats.get(k, 0) for k in ('n_arz_evals', 'n_bire_steps', 'n_bire_step_bins')})
         out["roofline"]["fp64_frac_by_stage"] = {k: (v / (sm[k] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if sm[k] > 0 else 0.) for k, v in flop_of.items()}
+        # The pruning stages work in single precision (bounds that are inflated to stay bounds): priced in counted FP32 operations
+        # against the FP32 vector peak.  Per ray, from the kernels' code (spectral.hip):
+        #   amp_bound_kernel      two-sided sums over groups of 4 bins: (N / 2 - 1) / 4 nodes x 27 (node evaluation 12 + group sums 12
+        #                         + 3 shared) + the depth-bin path lengths (2 legs x 64 edges x 22) + the bin sums (63 bins x n_fc x 2)
+        #   efield_bound_kernel   N / 2 - 1 bins x 15 (amplitude 9, attenuation interpolation 3, the two sums 3)
+        #   efield_sample_kernel  N / 2 bins x (amplitude and attenuation 15 + ES_NJ = 24 samples x 4 (sine recurrence 2, sum 2) + 12)
+        # and the N / 2-point transforms of efield_max_kernel in FP64 (5 M log2 M + 40 per amplitude bin).  `vector_time_frac_by_stage`:
+        # the time the counted operations would take at the FP64 / FP32 vector peaks over the stage's measured time -- one number
+        # per stage, nothing unpriced, and the same for the whole step
+        nhb = wl['N'] // 2
+        n_fc_ = len(st.att_freq)   # coarse frequencies of the attenuation (analyticraytracing.py:933-960)
+        f32_of = {'amp_bound': stats['n_rays'] * ((nhb - 1) / 4. * 27. + 2 * 64 * 22. + 63 * n_fc_ * 2.),
+                  'efield_max': stats['n_active_rays'] * (nhb - 1) * 15. + stats.get('n_efield_sampled', 0) * nhb * (15. + 24 * 4. + 12.)}
+        f64_of = dict(flop_of)
+        if cfgno != 4:
+            f64_of['efield_max'] = stats['n_efield_transforms'] * (5. * nhb * np.log2(nhb) + 40. * nhb)
+        if cfgno == 4:
+            f32_of.pop('efield_max')
+        vt = {k: ((f64_of.get(k, 0.) / (FP64_PEAK_TFLOPS * 1e12) + f32_of.get(k, 0.) / (FP32_PEAK_TFLOPS * 1e12)) / (sm[k] * 1e-3) if sm[k] > 0 else 0.)
+              for k in ('raytrace', 'amp_bound', 'attenuation', 'efield_max', 'channel')}
+        vt['whole_step'] = ((sum(f64_of.values()) / (FP64_PEAK_TFLOPS * 1e12) + sum(f32_of.values()) / (FP32_PEAK_TFLOPS * 1e12)) / (sm['total'] * 1e-3)
+                            if sm['total'] > 0 else 0.)
+        out["roofline"]["vector_time_frac_by_stage"] = {k: round(v, 4) for k, v in vt.items()}
+        out["roofline"]["fp32_flops_by_stage"] = {k: float(v) for k, v in f32_of.items()}
+        out["roofline"]["fp32_vector_peak_tflops"] = FP32_PEAK_TFLOPS
+        out["config"]["n_efield_sampled"] = stats.get('n_efield_sampled', 0)
         if dom in flop_of:
             # the quadrature and the channel kernels move next to no HBM bytes (everything lives in registers / LDS): priced in
             # algorithmic FP64 flops against the dense FP64 peak of the MI355X (78.6 TFLOP/s, vector and matrix alike; nothing on

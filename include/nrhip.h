@@ -432,6 +432,7 @@ typedef struct {
        profile point and observer time), 1 m path steps whose records were made (analyticraytracing.py:2402-2413), and (path step,
        frequency bin) pairs the propagation applied (both rounds) */
     int64_t n_arz_evals, n_bire_steps, n_bire_step_bins;
+    int64_t n_efield_sampled;     /* rays whose field was sampled next to the pulse centre for the candidate cut (efield_sample_kernel) */
 } nrhip_sim_stats;
 
 typedef struct nrhip_station nrhip_station;

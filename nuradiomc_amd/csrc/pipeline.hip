@@ -1209,8 +1209,8 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     unsigned long long* eval_counter = nullptr;
     unsigned long long* xform_count;  // [0] channel traces computed, [1] rays in them, [2] rays transformed for the candidate cut,
                                       // [3] 8192-point chirp convolutions of the trigger-ADC chain
-    NEED(xform_count = WS("transform_count", unsigned long long, 4));
-    HIPCHK(hipMemsetAsync(xform_count, 0, 4 * sizeof(unsigned long long), sm));
+    NEED(xform_count = WS("transform_count", unsigned long long, 5));   // ([4]: rays sampled by efield_sample_kernel)
+    HIPCHK(hipMemsetAsync(xform_count, 0, 5 * sizeof(unsigned long long), sm));
     MARK(3);
     if (n_active > 0) {
         // attenuation on the coarse frequency grid, active rays only
@@ -1805,13 +1805,14 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             S.n_integrand_evals = (int64_t)ne;
         }
         {
-            unsigned long long xc[4] = {0, 0, 0, 0};
+            unsigned long long xc[5] = {0, 0, 0, 0, 0};
             HIPCHK(hipMemcpyAsync(xc, xform_count, sizeof xc, hipMemcpyDeviceToHost, sm));
             HIPCHK(hipStreamSynchronize(sm));
             S.n_channel_transforms = (int64_t)xc[0];
             S.n_ray_transforms = (int64_t)xc[1];
             S.n_efield_transforms = (int64_t)xc[2];
             S.n_adc_convolution_flops = (int64_t)xc[3];
+            S.n_efield_sampled = (int64_t)xc[4];
         }
         for (int i = 0; i < 8; i++) {
             float ms = 0.f;

@@ -1595,8 +1595,9 @@ event_need_kernel(int n_events, int n_ch, const int* __restrict__ slot_offset, c
 #endif
 __global__ void __launch_bounds__(256)
 efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork w, StationDev st, double min_efield,
-                     double* __restrict__ max_efield, int* __restrict__ need_fft)
+                     double* __restrict__ max_efield, int* __restrict__ need_fft, unsigned long long* __restrict__ sampled_count)
 {
+    unsigned n_sampled = 0;   // rays this wave summed (bench.py prices the stage by them)
     __shared__ double s_xp[NRHIP_MAX_NFC];
     __shared__ float at[4][NRHIP_MAX_NFC], at_slope[4][NRHIP_MAX_NFC];
     // the per-bin tables of the station in LDS (N <= 4096: 3 x 2049 floats + 2049 bytes): the inner loop then never waits for HBM / L2
@@ -1631,6 +1632,7 @@ efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const float cLf = (float)cL, cRf = (float)cR, pff = (float)pf;
         const int had = ai.had;
+        n_sampled++;
         auto value = [&](int k) -> float {   // v_k, 0 outside 1 .. nh - 1
             if (k < 1 || k >= nh) return 0.f;
             const float f = k * dff;
@@ -1695,6 +1697,7 @@ efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork 
             }
         }
     }
+    if (sampled_count && lane == 0 && n_sampled) atomicAdd(sampled_count, (unsigned long long)n_sampled);
 }
 
 __global__ void scatter_flagged_kernel(int n, const int* __restrict__ flag, const int* __restrict__ offset,
@@ -4138,7 +4141,7 @@ void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int 
         int gridS = (n_active + 3) / 4;
         if (gridS > 256 * 16) gridS = 256 * 16;
         hipLaunchKernelGGL(efield_sample_kernel, dim3(gridS), dim3(256), (size_t)(nh + 1) * 13, s, n_active, active_list, w, st,
-                           min_efield, max_efield, need_ray);
+                           min_efield, max_efield, need_ray, xform_count ? xform_count + 4 : nullptr);
     }
     hipLaunchKernelGGL(event_need_kernel, dim3(grid_for(n_events + 1, 256)), dim3(256), 0, s, n_events, st.n_ch, slot_offset,
                        need_ray, ev_need, max_efield, min_efield, exact);

@@ -94,7 +94,7 @@ class SimStats(ctypes.Structure):
                                               'n_efield_transforms')] + \
                [('max_length', ctypes.c_int32), ('n_sub_events', ctypes.c_int32), ('stage_ms', ctypes.c_double * 9)] + \
                [(k, ctypes.c_int64) for k in ('n_emitted_events', 'n_emit_overflow', 'n_emitted_samples', 'n_objective_evals', 'n_adc_convolution_flops',
-                                              'n_arz_evals', 'n_bire_steps', 'n_bire_step_bins')]
+                                              'n_arz_evals', 'n_bire_steps', 'n_bire_step_bins', 'n_efield_sampled')]
 
     STAGES = ('raytrace', 'ray_setup', 'amp_bound', 'attenuation', 'efield_max', 'event_grid', 'length_tables', 'channel',
               'total')
@@ -102,7 +102,7 @@ class SimStats(ctypes.Structure):
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_[:15]}
         d.update({k: int(getattr(self, k)) for k in ('n_emitted_events', 'n_emit_overflow', 'n_emitted_samples', 'n_objective_evals', 'n_adc_convolution_flops',
-                                                     'n_arz_evals', 'n_bire_steps', 'n_bire_step_bins')})
+                                                     'n_arz_evals', 'n_bire_steps', 'n_bire_step_bins', 'n_efield_sampled')})
         d['stage_ms'] = {n: float(self.stage_ms[i]) for i, n in enumerate(self.STAGES)}
         return d
 
