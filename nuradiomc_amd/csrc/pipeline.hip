@@ -852,7 +852,7 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
     if (arz && !cfg->select_only && st->n_shower_profiles != n_events)
         return nrhip_fail_msg("nrhip_simulate_events: the ARZ models need one profile per shower (nrhip_station_set_shower_profiles)");
     if (cfg->n_reflections > 0 && bire)
-        return nrhip_fail_msg("nrhip_simulate_events: bottom reflections are not available together with birefringence");
+        return nrhip_fail_msg("nrhip_simulate_events: bottom reflections are not available together with birefringence (the reference's own loop covers only the first part of such a path: tests/golden/ref_bire_reflection_probe.txt)");
     const bool phased = cfg->trigger_type == NRHIP_TRIG_PHASED_ARRAY;
     const bool envelope = cfg->trigger_type == NRHIP_TRIG_ENVELOPE;
     const bool noise = cfg->noise != 0;

@@ -402,7 +402,9 @@ class ray_tracing:
         """:2369-2445 on the GPU: pulse = spectra (eR, eTheta, ePhi); eR is not touched"""
         self._check(i_solution)
         if self._results[i_solution]['reflection'] > 0:
-            raise NotImplementedError("birefringence along paths with bottom reflections is not provided")
+            raise NotImplementedError("birefringence along paths with bottom reflections is not provided (analyticraytracing.py:2404-2411 walks "
+                                      "acc - 1 steps of a path that get_path returns with (k + 1) acc - k points for k reflections: "
+                                      "it stops part way, tests/golden/ref_bire_reflection_probe.txt)")
         pulse = np.array(pulse, dtype=complex)
         angle = self._config['propagation'].get('angle_to_iceflow')
         out = self._ctx.birefringence_batch(self._X1[None], self._X2[None], [self._results[i_solution]['C0']],

@@ -7,7 +7,7 @@
 set -x
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/measure
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 B="python3 bench.py --no-cpu-baseline"
@@ -27,10 +27,21 @@ python3 bench.py --flavour mixed > $OUT/bench_config2_mixed.json 2>> $OUT/bench_
 python3 bench.py --scaling strong --no-cpu-baseline --write-expected-sha > $OUT/bench_config2_strong.json 2>> $OUT/bench_config2.log   # (records the one-rank mask hash an N-rank run must gather)
 cp profiles/expected_mask_sha16.json $OUT/ 2>/dev/null
 python3 bench.py --events 125000 --no-cpu-baseline > $OUT/bench_config2_125k_shard.json 2>> $OUT/bench_config2.log
-python3 bench.py --config 3 > $OUT/bench_config3.json 2> $OUT/bench_config3.log
 python3 bench.py --config 3 --trigger pa --cpu-budget 40 > $OUT/bench_config3_pa.json 2>> $OUT/bench_config3.log
 python3 bench.py --config 3 --trigger pa_adc_noise --cpu-budget 60 --events 200000 > $OUT/bench_config3_pa_adc_noise.json 2>> $OUT/bench_config3.log
-python3 bench.py --config 5 > $OUT/bench_config5.json 2> $OUT/bench_config5.log
+# arrays: HBM traffic of one step (all launches summed) so that their bench lines carry roofline.traffic
+for C in 3 5; do
+  BA="python3 bench.py --config $C --no-cpu-baseline --steps 1 --warmup 1"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pf$C -o x -- $BA > /dev/null 2> $OUT/pf$C.log
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pw$C -o x -- $BA > /dev/null 2> $OUT/pw$C.log
+  python3 tools/pmc_traffic.py --per-step 2 $(find $OUT/pf$C -name 'x_counter_collection.csv' | head -1) $(find $OUT/pw$C -name 'x_counter_collection.csv' | head -1) $OUT/${R}_pmc_traffic_config$C > $OUT/pmc_traffic_config$C.log 2>&1
+  rm -rf $OUT/pf$C $OUT/pw$C
+done
+NRHIP_PMC_JSON=$OUT/${R}_pmc_traffic_config3.json python3 bench.py --config 3 > $OUT/bench_config3.json 2> $OUT/bench_config3.log
+NRHIP_PMC_JSON=$OUT/${R}_pmc_traffic_config5.json python3 bench.py --config 5 > $OUT/bench_config5.json 2> $OUT/bench_config5.log
+# the shard rank 3 of 8 would get of the headline list: contiguous (shard_range) and interleaved chunks of 1000 (shard_chunks)
+python3 bench.py --emulate-shard 3/8 --steps 20 > $OUT/bench_config2_shard_3of8_contiguous.json 2>> $OUT/bench_config2.log
+python3 bench.py --emulate-shard 3/8/1000 --steps 20 > $OUT/bench_config2_shard_3of8_chunks1000.json 2>> $OUT/bench_config2.log
 # (config 4: tools/measure_config4.sh -- priced line with its own PMC traffic, kernel statistics, the 1.25e6-event shard)
 python3 bench.py --config 4 --trigger pa_adc_noise --no-cpu-baseline > $OUT/bench_config4_pa_adc_noise.json 2>> $OUT/bench_config4.log
 # the general path (ARZ2020 + birefringence) on the 5-channel station: wall time and kernel statistics
@@ -43,7 +54,7 @@ rm -rf $OUT/c4stats
 python3 bench.py --scaling strong --events 200000 --steps 3 --no-cpu-baseline --no-end-to-end --write-expected-sha > /dev/null 2>> $OUT/bench_config2.log   # (the one-rank hash of the list the two ranks share)
 cp profiles/expected_mask_sha16.json $OUT/ 2>/dev/null
 python3 bench.py --gpus 2 --allow-tcp --scaling strong --events 200000 --steps 3 --no-cpu-baseline > $OUT/bench_config2_two_ranks_one_gpu.json 2>> $OUT/bench_config2.log
-[ -f nuradiomc_amd/lib/libnrhip_ct.so ] && { python3 tools/conv_phase_probe.py; python3 tools/conv_phase_probe.py --no-traces; python3 tools/conv_phase_probe.py --config 5 --steps 1 --events 300000; } > $OUT/conv_phases.log 2>&1
+[ -f nuradiomc_amd/lib/libnrhip_ct.so ] && { python3 tools/conv_phase_probe.py; python3 tools/conv_phase_probe.py --no-traces; python3 tools/conv_phase_probe.py --config 5 --steps 1 --events 300000; python3 tools/conv_pair_probe.py 200 5296; } > $OUT/conv_phases.log 2>&1
 # where a 125 k-event shard spends its time (kernel sum vs step)
 { ROWS=14 bash tools/rocprof_quick.sh --events 125000 --steps 10; python3 bench.py --events 125000 --no-cpu-baseline --steps 20 | tail -c 900; } > $OUT/shard125k_kernels.log 2>&1
 python3 tools/att_dense_probe.py 40000 > $OUT/att_dense_probe.log 2>&1

@@ -5,7 +5,7 @@
 set -x
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/measure4
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 B="python3 bench.py --config 4 --no-cpu-baseline --steps 1 --warmup 0"
