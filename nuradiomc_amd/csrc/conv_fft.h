@@ -375,8 +375,9 @@ __device__ __forceinline__ void dif8_tail_c(double2 (&a)[8])
 // call gives each pass its own register allocation, at the price of one s_swappc.  The buffer is the kernel's dynamic LDS.)
 // FULL: the upper half of the input holds data as well (the chirp convolutions of the trigger-ADC chain with more than M / 2 inputs).
 // nv: the elements behind index nv are taken as zero (not read): the caller need not clear them.
-template <int LOG2M, int NT, bool FULL = false>
-__device__ __noinline__ void conv_fwd(const double2* __restrict__ tw, const double2* __restrict__ cft, int nv)
+// first pass (block-wide, spans M / 2 .. 1024) and the wave-private pass with spans 512 .. 64; ends before the last forward pass
+template <int LOG2M, int NT, bool FULL>
+__device__ __forceinline__ void conv_fwd_head(const double2* __restrict__ tw, const double2* __restrict__ cft, int nv)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double2* z = (double2*)smem;
@@ -410,11 +411,17 @@ __device__ __noinline__ void conv_fwd(const double2* __restrict__ tw, const doub
         }
     }
     lds_barrier();
-    if (NA == NT || t < NA) {
-        double2* zb = z + (t >> 6) * 1025;
-        conv_p2_fwd(zb, cft, t & 63);
-        conv_p3_fwd(zb, cft, t & 63);
-    }
+    if (NA == NT || t < NA) conv_p2_fwd(z + (t >> 6) * 1025, cft, t & 63);
+}
+template <int LOG2M, int NT, bool FULL = false>
+__device__ __noinline__ void conv_fwd(const double2* __restrict__ tw, const double2* __restrict__ cft, int nv)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2* z = (double2*)smem;
+    constexpr int NA = (1 << LOG2M) / 16;
+    const int t = threadIdx.x;
+    conv_fwd_head<LOG2M, NT, FULL>(tw, cft, nv);
+    if (NA == NT || t < NA) conv_p3_fwd(z + (t >> 6) * 1025, cft, t & 63);
 }
 
 // real-transform split, product with the response spectrum, merge -- on the mirror pair (k, Mr - k) of the packed transform
@@ -437,8 +444,34 @@ __device__ __forceinline__ void conv_pair_mul(double2& A, double2& B, const doub
 // G: response spectrum on the 2 FFT_MAX-point grid (bin k of the 2 M-point one at G[gs k], gs = FFT_MAX / M), w16[k] = exp(-i pi k /
 // FFT_MAX).  Thread k0 (1 <= k0 < M / 16) owns the bins k0 + j M/8 and their mirror partners (M/8 - k0) + j M/8; thread 0 the two
 // groups that are their own mirrors (k0 = 0 and M / 16).  Starts and ends with a block barrier.
+// the first batch of table values of conv_mid_impl (slots 0 .. 3, the two w16 entries, thread 0's extra pair): 44 registers
+struct ConvMidPre { double2 wkA, wkB, Gk[4], Gm[4], Gh, wh; };
 template <int LOG2M, int NT>
-__device__ __noinline__ void conv_mid(const double2* __restrict__ G, const double2* __restrict__ w16)
+__device__ __forceinline__ ConvMidPre conv_mid_request(const double2* __restrict__ G, const double2* __restrict__ w16)
+{
+    constexpr int M = 1 << LOG2M, NA = M / 16, K = M / 8, gs = FFT_MAX / M;
+    const int t = threadIdx.x;
+    const int kA = (t == 0) ? 0 : t, kB = (t == 0) ? K / 2 : K - t;
+    ConvMidPre p;
+    p.wkA = p.wkB = p.Gh = p.wh = make_double2(1., 0.);
+#pragma unroll
+    for (int r = 0; r < 4; r++) p.Gk[r] = p.Gm[r] = make_double2(0., 0.);
+    if (NA == NT || t < NA) {
+        p.wkA = gload(&w16[gs * kA]);   // thread 0: 1 and exp(-i pi / 16)
+        p.wkB = gload(&w16[gs * kB]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = br3(r);
+            const int kn = (m < 4) ? kA + K * m : kB + K * (7 - m);
+            p.Gk[r] = gload(&G[gs * kn]);
+            p.Gm[r] = gload(&G[gs * (M - kn)]);
+        }
+        if (t == 0) { p.Gh = gload(&G[gs * (M / 2)]); p.wh = gload(&w16[gs * (M / 2)]); }
+    }
+    return p;
+}
+template <int LOG2M, int NT>
+__device__ __forceinline__ void conv_mid_impl(const double2* __restrict__ G, const double2* __restrict__ w16, const ConvMidPre& pre)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double2* z = (double2*)smem;
@@ -447,23 +480,20 @@ __device__ __noinline__ void conv_mid(const double2* __restrict__ G, const doubl
     const bool act = NA == NT || t < NA;
     const int kA = (t == 0) ? 0 : t, kB = (t == 0) ? K / 2 : K - t;
     const bool sp = t == 0;
-    // Every table value of the pass is requested BEFORE the barrier and the LDS reads (round 6): the loads depend on the thread index
-    // alone, and behind the three butterfly stages -- where they used to be issued, in two batches with a full wait each -- their
-    // L2 / HBM latency (the response spectrum of the event's length is cold more often than not) was exposed twice per channel.
-    // Slot r of the loop below reads the bins kn(r) and M - kn(r).
-    double2 wkA = make_double2(1., 0.), wkB = wkA, Gk[8], Gm[8], Gh = wkA, wh = wkA;
-    if (act) {
-        wkA = gload(&w16[gs * kA]);   // thread 0: 1 and exp(-i pi / 16)
-        wkB = gload(&w16[gs * kB]);
+    // The table values of the pass depend on the thread index alone.  Round 6: the first half of them (slots 0 .. 3 and the two
+    // w16 entries: `pre`, conv_mid_request) is requested by the caller -- in front of the barrier and the LDS reads --, the second half behind the butterflies, in front
+    // of the first half's products: each batch's L2 / HBM latency lies under arithmetic.  (All sixteen response values up front were
+    // measured too: more callee-saved registers, no faster.)  Behind the three butterfly stages -- where both batches used to be
+    // issued, with a full wait each -- the latency was exposed twice per channel.  Slot r reads the bins kn(r) and M - kn(r).
+    double2 wkA = pre.wkA, wkB = pre.wkB, Gk[8], Gm[8], Gh = pre.Gh, wh = pre.wh;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int m = br3(r);
-            const int kn = (m < 4) ? kA + K * m : kB + K * (7 - m);
-            Gk[r] = gload(&G[gs * kn]);
-            Gm[r] = gload(&G[gs * (M - kn)]);
-        }
-        if (sp) { Gh = gload(&G[gs * (M / 2)]); wh = gload(&w16[gs * (M / 2)]); }
-    }
+    for (int r = 0; r < 4; r++) { Gk[r] = pre.Gk[r]; Gm[r] = pre.Gm[r]; }
+    auto request = [&](int r) {
+        const int m = br3(r);
+        const int kn = (m < 4) ? kA + K * m : kB + K * (7 - m);
+        Gk[r] = gload(&G[gs * kn]);
+        Gm[r] = gload(&G[gs * (M - kn)]);
+    };
     lds_barrier();
     if (act) {
         // block of bin group k0: the wave whose residue it is (bit-reversed), position inside: 8 (k0 >> LW)
@@ -476,6 +506,10 @@ __device__ __noinline__ void conv_mid(const double2* __restrict__ G, const doubl
         for (int c = 0; c < 8; c++) { A[c] = pa[c]; B[c] = pb[c]; }
         dif8_tail(A);
         dif8_tail(B);
+        __builtin_amdgcn_sched_barrier(0);
+        request(4);   // (second batch, two slots now and two behind the second product: in flight under the first batch's products)
+        request(5);
+        __builtin_amdgcn_sched_barrier(0);
         // Eight mirror pairs per thread.  Thread k0: slot r of A (bin kA + K br3(r)) with slot 7 - r of B, taken from the pair's lower
         // bin (w16 goes up to M / 2): kA + m K for m = br3(r) < 4, kB + (7 - m) K else; w16 at those bins from ONE table entry per
         // group (bin k0 + m K is exp(-i pi m / 8) further round the circle: gs K = FFT_MAX / 8).  Thread 0 owns the groups that are
@@ -492,6 +526,12 @@ __device__ __noinline__ void conv_mid(const double2* __restrict__ G, const doubl
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int m = br3(r);
+            if (r == 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                request(6);
+                request(7);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const double2 wb = (m < 4) ? wkA : wkB;
             const int mm = (m < 4) ? m : 7 - m;
             const double2 wk = (mm == 0) ? wb : (mm == 1 ? cmulx(wb, c16_1) : (mm == 2 ? mul_w8_1(wb) : cmulx(wb, c16_3)));
@@ -524,6 +564,12 @@ __device__ __noinline__ void conv_mid(const double2* __restrict__ G, const doubl
     lds_barrier();
 }
 
+template <int LOG2M, int NT>
+__device__ __noinline__ void conv_mid(const double2* __restrict__ G, const double2* __restrict__ w16)
+{
+    const ConvMidPre pre = conv_mid_request<LOG2M, NT>(G, w16);
+    conv_mid_impl<LOG2M, NT>(G, w16, pre);
+}
 // ---- the same pass for a plain complex convolution: last three forward stages, product with a spectrum given in NATURAL bin order
 // (Bn[k], k < M), first three inverse stages.  After dif8_tail slot r of a thread's group k0 holds bin k0 + (M / 8) br3(r).
 // BR: the spectrum table is in bit-reversed order (the tables of the block-wide transforms of fft_device.h): bin k0 + (M / 8) br3(r)

@@ -3103,6 +3103,8 @@ channel_conv_kernel(const int* __restrict__ n_list, const ConvHdr* __restrict__ 
             // buffer -- the previous transform's output -- counts as zero there; every placement above ended with a barrier)
             CT(5);
             // forward transform, real-transform split * G * merge, first stages of the inverse (conv_fft.h)
+            // (forward transform and spectrum pass as ONE out-of-line function, the first response values requested a pass earlier,
+            // was measured in round 6: 10.59 against 10.61 ms -- the two calls stay)
             if (half_size) { conv_fwd<LOG2CAP - 1, NT>(tw, cft, L >> 1); CT(6); conv_mid<LOG2CAP - 1, NT>(G, w16); }
             else { conv_fwd<LOG2CAP, NT>(tw, cft, L >> 1); CT(6); conv_mid<LOG2CAP, NT>(G, w16); }
             if (multi) {  // sum the tables' contributions (the rest of the inverse is linear) in global scratch of this block
