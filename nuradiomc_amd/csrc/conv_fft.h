@@ -444,8 +444,8 @@ __device__ __forceinline__ void conv_pair_mul(double2& A, double2& B, const doub
 // G: response spectrum on the 2 FFT_MAX-point grid (bin k of the 2 M-point one at G[gs k], gs = FFT_MAX / M), w16[k] = exp(-i pi k /
 // FFT_MAX).  Thread k0 (1 <= k0 < M / 16) owns the bins k0 + j M/8 and their mirror partners (M/8 - k0) + j M/8; thread 0 the two
 // groups that are their own mirrors (k0 = 0 and M / 16).  Starts and ends with a block barrier.
-// the first batch of table values of conv_mid_impl (slots 0 .. 3, the two w16 entries, thread 0's extra pair): 44 registers
-struct ConvMidPre { double2 wkA, wkB, Gk[4], Gm[4], Gh, wh; };
+// the first batch of table values of conv_mid_impl (slots 0 and 1, the two w16 entries, thread 0's extra pair): 32 registers
+struct ConvMidPre { double2 wkA, wkB, Gk[2], Gm[2], Gh, wh; };
 template <int LOG2M, int NT>
 __device__ __forceinline__ ConvMidPre conv_mid_request(const double2* __restrict__ G, const double2* __restrict__ w16)
 {
@@ -455,18 +455,18 @@ __device__ __forceinline__ ConvMidPre conv_mid_request(const double2* __restrict
     ConvMidPre p;
     p.wkA = p.wkB = p.Gh = p.wh = make_double2(1., 0.);
 #pragma unroll
-    for (int r = 0; r < 4; r++) p.Gk[r] = p.Gm[r] = make_double2(0., 0.);
+    for (int r = 0; r < 2; r++) p.Gk[r] = p.Gm[r] = make_double2(0., 0.);
     if (NA == NT || t < NA) {
         p.wkA = gload(&w16[gs * kA]);   // thread 0: 1 and exp(-i pi / 16)
         p.wkB = gload(&w16[gs * kB]);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < 2; r++) {
             const int m = br3(r);
             const int kn = (m < 4) ? kA + K * m : kB + K * (7 - m);
             p.Gk[r] = gload(&G[gs * kn]);
             p.Gm[r] = gload(&G[gs * (M - kn)]);
         }
-        if (t == 0) { p.Gh = gload(&G[gs * (M / 2)]); p.wh = gload(&w16[gs * (M / 2)]); }
+        if (t == 0) { p.Gh = gload(&G[gs * (M / 2)]); p.wh = gload(&w16[gs * (M / 2)]); }   // (requested late, inside the slot loop: 58 saved registers)
     }
     return p;
 }
@@ -480,14 +480,15 @@ __device__ __forceinline__ void conv_mid_impl(const double2* __restrict__ G, con
     const bool act = NA == NT || t < NA;
     const int kA = (t == 0) ? 0 : t, kB = (t == 0) ? K / 2 : K - t;
     const bool sp = t == 0;
-    // The table values of the pass depend on the thread index alone.  Round 6: the first half of them (slots 0 .. 3 and the two
-    // w16 entries: `pre`, conv_mid_request) is requested by the caller -- in front of the barrier and the LDS reads --, the second half behind the butterflies, in front
-    // of the first half's products: each batch's L2 / HBM latency lies under arithmetic.  (All sixteen response values up front were
-    // measured too: more callee-saved registers, no faster.)  Behind the three butterfly stages -- where both batches used to be
-    // issued, with a full wait each -- the latency was exposed twice per channel.  Slot r reads the bins kn(r) and M - kn(r).
+    // The table values of the pass depend on the thread index alone.  Round 6: they are requested two slots at a time, two products
+    // ahead of their use -- the first two (`pre`, conv_mid_request) in front of the barrier and the LDS reads, the next two behind the
+    // butterflies, then two in front of every second product -- so that every batch's L2 / HBM latency lies under arithmetic and at
+    // most four slots' values (32 registers) are in flight.  (All sixteen up front: 22 callee-saved registers stored and reloaded
+    // per call, 3.3 GB of scratch writes per launch, no faster.  Until round 5 both halves were requested behind the butterflies
+    // with a full wait each: the latency was exposed twice per channel.)  Slot r reads the bins kn(r) and M - kn(r).
     double2 wkA = pre.wkA, wkB = pre.wkB, Gk[8], Gm[8], Gh = pre.Gh, wh = pre.wh;
 #pragma unroll
-    for (int r = 0; r < 4; r++) { Gk[r] = pre.Gk[r]; Gm[r] = pre.Gm[r]; }
+    for (int r = 0; r < 2; r++) { Gk[r] = pre.Gk[r]; Gm[r] = pre.Gm[r]; }
     auto request = [&](int r) {
         const int m = br3(r);
         const int kn = (m < 4) ? kA + K * m : kB + K * (7 - m);
@@ -507,8 +508,8 @@ __device__ __forceinline__ void conv_mid_impl(const double2* __restrict__ G, con
         dif8_tail(A);
         dif8_tail(B);
         __builtin_amdgcn_sched_barrier(0);
-        request(4);   // (second batch, two slots now and two behind the second product: in flight under the first batch's products)
-        request(5);
+        request(2);   // (two slots at a time, two products ahead of their use: at most four slots' values -- 32 registers -- in flight)
+        request(3);
         __builtin_amdgcn_sched_barrier(0);
         // Eight mirror pairs per thread.  Thread k0: slot r of A (bin kA + K br3(r)) with slot 7 - r of B, taken from the pair's lower
         // bin (w16 goes up to M / 2): kA + m K for m = br3(r) < 4, kB + (7 - m) K else; w16 at those bins from ONE table entry per
@@ -526,10 +527,10 @@ __device__ __forceinline__ void conv_mid_impl(const double2* __restrict__ G, con
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int m = br3(r);
-            if (r == 2) {
+            if (r == 2 || r == 4) {
                 __builtin_amdgcn_sched_barrier(0);
-                request(6);
-                request(7);
+                request(r + 2);
+                request(r + 3);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const double2 wb = (m < 4) ? wkA : wkB;
