@@ -737,7 +737,7 @@ def main():
         pmc = os.environ.get('NRHIP_PMC_JSON', os.path.join(ROOT, 'profiles', 'r06_pmc_traffic.json' if cfgno == 2 else
                                                             'r06_pmc_traffic_config%d.json' % cfgno))
         std_size = (cfgno == 2 and args.flavour == 'had' and n == 1000000) or (cfgno == 4 and n == 20000 and args.trigger == 'threshold') or \
-                   (cfgno in (3, 5) and n == 1000000 and args.trigger == 'threshold' and args.flavour == 'had')
+                   (cfgno in (3, 5) and n_groups == 1000000 and args.trigger == 'threshold' and args.flavour == 'had')
         if std_size and os.path.exists(pmc):
             pj = json.load(open(pmc))
             if pj.get('source_hash') == source_hash():
