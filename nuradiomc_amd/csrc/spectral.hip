@@ -2566,11 +2566,20 @@ __device__ __noinline__ ConvOut conv_output_pass(int L, double vscale, double th
 // above / below (the w_hl - 1 samples in front of the run looked at once: O(run + w) instead of O(run x w)), the running index of
 // the last raised flag (registers); (2) after a scan over the runs' totals, the coincidence count.  Two barriers (were six).  Out
 // of line like conv_output_pass (its own register allocation).
-struct CoincOut { double vmax; int any_flag; };   // (both in registers: a reference parameter would come back through the stack)
+// The per-sample coincidence counts of an event (channels whose dilated flag is up) live in the REGISTERS of the thread that owns the
+// sample's run (round 6): a thread's run is the same for every channel of the event (L and the block size fix it), at most 17
+// samples -- one byte each in five words, handed to the pass and back by value.  They used to sit in a row of HBM scratch: zeroed
+// per event, read-modify-written sample by sample through flat loads (a dependent round trip each) by every channel that raised a
+// flag, read back by stride for the majority logic, with two barriers that order global memory per event.
+#define CONV_CNT_WORDS 5
+struct CoincOut { double vmax; int any_flag; unsigned cw[CONV_CNT_WORDS]; };   // (all in registers: a reference parameter would come back through the stack)
 template <int RUN, bool EXTRA>
 __device__ __noinline__ CoincOut conv_coinc_pass(int L, double vscale, double threshold, int ch_on, TriggerDev trg, double* __restrict__ tr,
-                                                 const double* __restrict__ add, int with_signal, int* __restrict__ cnt, int* scan)
+                                                 const double* __restrict__ add, int with_signal, unsigned cw0, unsigned cw1, unsigned cw2,
+                                                 unsigned cw3, unsigned cw4, int* scan)
 {
+    static_assert(RUN + 1 <= 4 * CONV_CNT_WORDS, "one byte per sample of a thread's run");
+    unsigned cw[CONV_CNT_WORDS] = {cw0, cw1, cw2, cw3, cw4};
     // Written for SIZE: the channel loop of channel_conv_kernel with its transforms is about as large as the instruction cache, and
     // this pass -- once 2200 instructions of unrolled branches around the run's samples, executed once per channel -- took 1.5 x
     // the forward transform's time on the 2-of-5 high / low arrays; a version with all reads in flight but MORE code was slower
@@ -2591,7 +2600,7 @@ __device__ __noinline__ CoincOut conv_coinc_pass(int L, double vscale, double th
     };
     double vmax = 0.;
     // one walk over the run: the index of the last raised flag at or before every sample goes to `sink`
-    auto walk = [&](bool first, auto&& sink) {
+    auto walk = [&](bool first, auto&& sink) {   // sink(sample, index of the last raised flag, word and byte of the sample in the run)
         int last_hi = -(1 << 30), last_lo = -(1 << 30), run = -1;
         if (hl && b0 < b1) {   // the w_hl - 1 samples in front of the run (the reference pads with zeros in front)
 #pragma unroll 1
@@ -2602,8 +2611,9 @@ __device__ __noinline__ CoincOut conv_coinc_pass(int L, double vscale, double th
                 last_lo = (x <= trg.low) ? k : last_lo;
             }
         }
+        int word = 0;
 #pragma unroll 1
-        for (int i0 = b0; i0 < b1; i0 += 4) {
+        for (int i0 = b0; i0 < b1; i0 += 4, word++) {
             double x[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -2628,12 +2638,12 @@ __device__ __noinline__ CoincOut conv_coinc_pass(int L, double vscale, double th
                 last_lo = (ok && x[q] <= trg.low) ? i : last_lo;
                 const bool flag = hl ? ((i - last_hi < trg.w_hl) && (i - last_lo < trg.w_hl)) : (ax >= threshold);
                 run = (ok && i < nb && flag && ch_on) ? i : run;
-                if (ok) sink(i, run);
+                if (ok) sink(i, run, word, q);
             }
         }
         return run;
     };
-    const int run = walk(true, [](int, int) {});
+    const int run = walk(true, [](int, int, int, int) {});
     // running maximum across the runs: a wave-level scan of the runs' last values (shuffles), the waves' totals through LDS
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int incl = run;
@@ -2654,14 +2664,20 @@ __device__ __noinline__ CoincOut conv_coinc_pass(int L, double vscale, double th
     if (top >= 0) {   // the coincidence count: flag i stays up for w_coinc samples
         const int wc = min(trg.w_coinc, nb), i_end = min(b1, nb - 1);
         const double keep = vmax;
-        (void)walk(false, [&](int i, int r) {
+        (void)walk(false, [&](int i, int r, int word, int q) {
             const int a = max(r, before);
-            if (i < i_end && a >= 0 && i - a < wc) cnt[i] += 1;
+            const unsigned inc = (i < i_end && a >= 0 && i - a < wc) ? (1u << (8 * q)) : 0u;
+#pragma unroll
+            for (int v = 0; v < CONV_CNT_WORDS; v++) cw[v] += (v == word) ? inc : 0u;   // (selects: no indexed register array)
         });
         vmax = keep;
     }
     lds_barrier();
-    CoincOut o = {vmax, top >= 0 ? 1 : 0};
+    CoincOut o;
+    o.vmax = vmax;
+    o.any_flag = top >= 0 ? 1 : 0;
+#pragma unroll
+    for (int v = 0; v < CONV_CNT_WORDS; v++) o.cw[v] = cw[v];
     return o;
 }
 template <int NT, class FV, class FS>
@@ -2693,7 +2709,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const ConvHdr* __restrict__ 
     const double threshold = trg.threshold;
     constexpr bool coinc = MODE == 2;   // (= trg.coincidence(): the launcher's choice)
     double2* acc = conv_acc + (long)blockIdx.x * FFT_MAX;
-    int* cnt = coinc_cnt + (long)blockIdx.x * FFT_MAX;  // per sample: channels whose dilated flag is set (coincidence modes)
+    (void)coinc_cnt;   // (the per-sample coincidence counts live in registers since round 6: CONV_CNT_WORDS)
     __shared__ int s_scan[NT];
     __shared__ int s_first;
     const int N = st.N, nh = N / 2;
@@ -2793,11 +2809,7 @@ channel_conv_kernel(const int* __restrict__ n_list, const ConvHdr* __restrict__ 
       if (rays_staged)
           for (int i = threadIdx.x; i < evx_r1 - evx_r0; i += blockDim.x) s_rct[i] = (unsigned short)((w.ch[evx_r0 + i] << 4) | w.tab[evx_r0 + i]);
       lds_barrier();
-      if (coinc) {
-          for (int n = threadIdx.x; n < ev_L; n += blockDim.x) cnt[n] = 0;
-          __syncthreads();   // cnt lives in GLOBAL scratch and changes hands here (zeroed by stride, counted by the owner of a
-                             // run in conv_coinc_pass): a barrier that orders global memory too, once per event
-      }
+      unsigned cw[CONV_CNT_WORDS] = {0u, 0u, 0u, 0u, 0u};   // coincidence counts of this thread's run of samples (conv_coinc_pass)
       // has an earlier channel of this event triggered?  A per-thread copy, refreshed between two barriers after every
       // evaluated channel: the shared flag itself may already have been reset for the NEXT event by a wave that ran ahead
       // through the barrier-free skip path below
@@ -3140,11 +3152,14 @@ channel_conv_kernel(const int* __restrict__ n_list, const ConvHdr* __restrict__ 
                 CoincOut co;
                 if (out.trace || noisy)
                     co = conv_coinc_pass<M / NT, true>(L, vscale, threshold, ch_on ? 1 : 0, trg, out.trace ? out.trace + out.trace_offset[item] : nullptr,
-                                                       noisy ? nbuf : nullptr, sig ? 1 : 0, cnt, s_scan);
+                                                       noisy ? nbuf : nullptr, sig ? 1 : 0, cw[0], cw[1], cw[2], cw[3], cw[4], s_scan);
                 else
-                    co = conv_coinc_pass<M / NT, false>(L, vscale, threshold, ch_on ? 1 : 0, trg, nullptr, nullptr, sig ? 1 : 0, cnt, s_scan);
+                    co = conv_coinc_pass<M / NT, false>(L, vscale, threshold, ch_on ? 1 : 0, trg, nullptr, nullptr, sig ? 1 : 0, cw[0], cw[1], cw[2],
+                                                        cw[3], cw[4], s_scan);
                 vmax = co.vmax;
                 n_flagged += co.any_flag;
+#pragma unroll
+                for (int v = 0; v < CONV_CNT_WORDS; v++) cw[v] = co.cw[v];
             }
         }
         else if (emitting) {   // a channel without rays: zeros, as the reference's empty channels
@@ -3212,13 +3227,19 @@ channel_conv_kernel(const int* __restrict__ n_list, const ConvHdr* __restrict__ 
         }
       }
       asm volatile("" :: "v"(touch_acc));
-      if (coinc) {  // majority logic over the channels of the event
+      if (coinc) {  // majority logic over the channels of the event: every thread looks at the counts of its own run of samples
           if (threadIdx.x == 0) s_first = 0x7fffffff;
-          __syncthreads();   // (global: the counts of the runs' owners are read by stride below)
+          lds_barrier();
           const int nb = (trg.type == 0) ? ev_L : ev_L - 1;
+          const int chunk = ((ev_L + (int)blockDim.x - 1) / (int)blockDim.x) | 1, b0 = (int)threadIdx.x * chunk;   // (conv_coinc_pass's runs)
           int first = 0x7fffffff;
-          for (int i = threadIdx.x; i < nb - 1; i += blockDim.x)
-              if (cnt[i] >= trg.n_coinc) first = min(first, i);
+#pragma unroll
+          for (int v = CONV_CNT_WORDS - 1; v >= 0; v--)
+#pragma unroll
+              for (int q = 3; q >= 0; q--) {
+                  const int i = b0 + 4 * v + q;
+                  if (4 * v + q < chunk && i < nb - 1 && (int)((cw[v] >> (8 * q)) & 0xffu) >= trg.n_coinc) first = i;   // (descending: the smallest stays)
+              }
           if (first != 0x7fffffff) atomicMin(&s_first, first);
           lds_barrier();
           if (threadIdx.x == 0 && s_first != 0x7fffffff) {
@@ -4289,7 +4310,10 @@ void launch_channel(hipStream_t s, int n_items, const int* item_event, const Ray
         constexpr int NK = FFT_MAX / 2 + 1;
         ConvHdr* hdr = (ConvHdr*)conv_ws;
         int *hist = (int*)(hdr + n_cand), *cursor = hist + NK + 1, *tmp = cursor + NK + 1, *sorted = tmp + scan_tiles(NK + 1);
-        if (!getenv("NRHIP_CONV_LIST_ORDER")) {
+        // (only for long lists: the six small launches of the sort cost a station call of an array -- ~15 k candidate events over
+        // ~1000 lengths, whose few events per length miss the L2 together anyway -- more than it gains: config 5 258 ms unsorted
+        // against 265 sorted per 3e5 events, config 3 103 against 106; the 1e6-event survey: -1 % time, -60 % of the kernel's reads)
+        if (n_cand >= 32768 && !getenv("NRHIP_CONV_LIST_ORDER")) {
             (void)hipMemsetAsync(hist, 0, sizeof(int) * (NK + 1), s);
             hipLaunchKernelGGL(length_hist_kernel, dim3(grid_for(n_cand, 256)), dim3(256), 0, s, need_offset + n_cand, item_list, item_event, ev.L, hist);
             launch_exclusive_scan(s, NK + 1, hist, cursor, tmp);
