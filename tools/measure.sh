@@ -10,7 +10,7 @@ OUT=gpurun_out/measure
 R=${ROUND:-r06}
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-B="python3 bench.py --no-cpu-baseline"
+B="python3 bench.py --no-cpu-baseline --no-end-to-end"   # (the profiled command makes the timed steps only: the end-to-end object's extra passes launch other instantiations of the convolution kernel, and the PMC summary keeps the largest launch per kernel NAME)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o x -- $B --steps 5 --warmup 3 > $OUT/stats_bench.json 2> $OUT/stats.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o x -- $B --steps 1 --warmup 3 > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o x -- $B --steps 1 --warmup 3 > /dev/null 2> $OUT/pmc_write.log
