@@ -600,6 +600,9 @@ class Station:
             raise ValueError("{} for config.signal.polarization is not a valid option".format(polarization))
         if trigger not in ('simple', 'high_low', 'phased_array', 'envelope'):
             raise NotImplementedError("trigger {} is not provided (simple, high_low, phased_array, envelope)".format(trigger))
+        if (trigger == 'high_low' or int(n_coincidences) > 1) and len(self.position) > 255:
+            # (the convolution kernel counts the coinciding channels of a sample in one byte)
+            raise NotImplementedError("coincidence triggers take stations of at most 255 channels")
         cfg = SimConfig(ASKARYAN_TO_INT[askaryan_model], float(delta_C_cut),
                         float(2.0 * self.vrms_efield if min_efield_amplitude is None else min_efield_amplitude),
                         float(3.0 * self.vrms if trigger_threshold is None else trigger_threshold), int(bool(dump_traces)),
