@@ -677,6 +677,10 @@ int nrhip_mask_or(nrhip_ctx* ctx, int64_t n, uint8_t* dst, const uint8_t* src, i
 /* test hook for the in-LDS chirp-z transform: out[b][k] = sum_j in[b][j] exp(sgn 2 pi i j k / Q). HOST. */
 int nrhip_debug_czt(nrhip_ctx* ctx, int32_t n_batch, int32_t n_in, int32_t n_out, int32_t Q, double sgn,
                     const double* in, double* out);
+/* test hook for the wave-level sums of the bound kernels (csrc/wave_reduce.h: v_permlane32_swap / v_permlane16_swap / DPP adds):
+ * in HOST [n_waves][8][64], out HOST [n_waves][273] = 8 sums in FP64, the same 8 in FP32, the sum of value 0 as every lane sees it
+ * (FP64, FP32), value 1 of the lane below per lane, value 1 of lane 63, value 2 of lane - 32 per lane. */
+int nrhip_debug_wave_sums(nrhip_ctx* ctx, int32_t n_waves, const double* in, double* out);
 
 #ifdef __cplusplus
 }

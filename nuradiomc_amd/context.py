@@ -136,6 +136,14 @@ class Context:
                                           x.ctypes.data_as(L.c_double_p), out.ctypes.data_as(L.c_double_p)))
         return out
 
+    def debug_wave_sums(self, x):
+        """test hook of csrc/wave_reduce.h: x [n_waves, 8, 64] -> [n_waves, 273] (layout: include/nrhip.h)"""
+        x = np.ascontiguousarray(x, float)
+        assert x.ndim == 3 and x.shape[1:] == (8, 64)
+        out = np.zeros((x.shape[0], 273))
+        L.check(self._lib.nrhip_debug_wave_sums(self._h, x.shape[0], x.ctypes.data_as(L.c_double_p), out.ctypes.data_as(L.c_double_p)))
+        return out
+
     # ---- ray tracing -----------------------------------------------------------------------------
     def find_solutions_batch(self, x1, x2, outer=False, given_C0=None):
         """All ray solutions between x1[i] and x2[i] (or every x1 with every x2 if `outer`).

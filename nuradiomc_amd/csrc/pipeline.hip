@@ -1999,6 +1999,24 @@ int nrhip_debug_czt(nrhip_ctx* ctx, int32_t n_batch, int32_t n_in, int32_t n_out
     return rc;
 }
 
+int nrhip_debug_wave_sums(nrhip_ctx* ctx, int32_t n_waves, const double* in, double* out)
+{
+    if (!ctx) return nrhip_fail_msg("nrhip_debug_wave_sums: ctx is NULL");
+    if (n_waves <= 0) return 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    DevArray di, dout;
+    int rc = upload(ctx, di, in, (size_t)n_waves * 8 * 64);
+    if (!rc && dout.reserve((size_t)n_waves * WAVE_TEST_OUT * 8) != hipSuccess) rc = nrhip_fail_msg("out of device memory");
+    if (!rc) {
+        launch_wave_reduce_test(ctx->stream, n_waves, di.as<double>(), dout.as<double>());
+        hipError_t e = hipMemcpyAsync(out, dout.p, (size_t)n_waves * WAVE_TEST_OUT * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = nrhip_fail("wave sums", e);
+    }
+    di.release(); dout.release();
+    return rc;
+}
+
 }  // extern "C"
 
 #ifdef NRHIP_CONV_TIMING

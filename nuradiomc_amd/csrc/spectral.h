@@ -283,6 +283,8 @@ void launch_askaryan_spectrum(hipStream_t s, int n, const double* energy, const 
 void launch_nplan_tables(hipStream_t s, int nh, int log2p, double2* wN, double2* cw, double2* Bf, double2* Bi, const double2* tw);
 void launch_czt_test(hipStream_t s, int n_batch, int n_in, int n_out, int Q, double sgn, const double2* in, double2* out,
                      const double2* tw, double2* Bscratch, int grid);
+#define WAVE_TEST_OUT 273
+void launch_wave_reduce_test(hipStream_t s, int n_waves, const double* in, double* out);
 void launch_attenuation_items(hipStream_t stream, long n_rays, const double* C0, const double* zint, int n_freq,
                               const double* freqs, int model, const IceConst& m, double* att, int* neval,
                               const int* ray_index = nullptr, unsigned long long* eval_counter = nullptr,

@@ -17,6 +17,10 @@
 #include "fft_device.h"
 #include "conv_fft.h"
 #include "spectral.h"
+#include "wave_reduce.h"
+#ifndef NRHIP_WAVE_DPP
+#define NRHIP_WAVE_DPP 1  // 0: the wave sums of the bound kernels by __shfl_xor butterflies (ds_bpermute_b32), as up to round 5
+#endif
 #include <cstdlib>
 
 namespace nrhip {
@@ -1101,11 +1105,22 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
             }
             float upt[AB_RT] = {up2[0].x, up2[0].y, up2[1].x, up2[1].y}, lot[AB_RT] = {lo2[0].x, lo2[0].y, lo2[1].x, lo2[1].y};
             double up_mine = 0., lo_mine = 0.;
+#if NRHIP_WAVE_DPP
+            {   // the eight wave sums: 6 half-wave / row swaps + DPP adds (wave_reduce.h) instead of 48 LDS-crossbar shuffles
+                static_assert(AB_RT == 4, "wave_fold4");
+                const float ua = wave_fold4(upt[0], upt[1], upt[2], upt[3]), la = wave_fold4(lot[0], lot[1], lot[2], lot[3]);
+                const float us[AB_RT] = {wave_row_value<0>(ua), wave_row_value<1>(ua), wave_row_value<2>(ua), wave_row_value<3>(ua)};
+                const float ls[AB_RT] = {wave_row_value<0>(la), wave_row_value<1>(la), wave_row_value<2>(la), wave_row_value<3>(la)};
+                for (int i = 0; i < AB_RT; i++)
+                    if (lane == i) { up_mine = us[i]; lo_mine = ls[i]; }
+            }
+#else
             for (int i = 0; i < AB_RT; i++) {
                 float a = upt[i], b = lot[i];
                 for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
                 if (lane == i) { up_mine = a; lo_mine = b; }
             }
+#endif
             // what the 2047-term sum would hand to efield_bound lies between these two (its FP32 rounding: 2047 x 6e-8, ours: 1e-5)
             const double x_up = (up_mine * BOUND_F32_SLACK) * BOUND_F32_SLACK + 1e-30;
             const double x_lo = (lo_mine * (1. - 5e-4)) * BOUND_F32_SLACK;
@@ -1190,11 +1205,20 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
         }
         // the four sums: wave totals by shuffles, then lane i < AB_RT finishes ray i (one copy of the epilogue instead of four)
         double mine = 0.;
+#if NRHIP_WAVE_DPP
+        {
+            const double pa = wave_fold4(part[0], part[1], part[2], part[3]);
+            const double ps[AB_RT] = {wave_row_value<0>(pa), wave_row_value<1>(pa), wave_row_value<2>(pa), wave_row_value<3>(pa)};
+            for (int i = 0; i < AB_RT; i++)
+                if (lane == i) mine = ps[i];
+        }
+#else
         for (int i = 0; i < AB_RT; i++) {
             double pt = part[i];
             for (int off = 32; off > 0; off >>= 1) pt += __shfl_xor(pt, off);
             if (lane == i) mine = pt;
         }
+#endif
         {
             const int r = rb + lane;
             if (lane < AB_RT && r < n_rays) {
@@ -1524,12 +1548,21 @@ efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w
                     sq[i] = r.y;
                 }
             }
+#if NRHIP_WAVE_DPP
+            const double pa = wave_fold4(part[0], part[1], part[2], part[3]), qa = wave_fold4(sq[0], sq[1], sq[2], sq[3]);
+            const double pts[AB_RT] = {wave_row_value<0>(pa), wave_row_value<1>(pa), wave_row_value<2>(pa), wave_row_value<3>(pa)};
+            const double s2s[AB_RT] = {wave_row_value<0>(qa), wave_row_value<1>(qa), wave_row_value<2>(qa), wave_row_value<3>(qa)};
+#endif
             for (int i = 0; i < AB_RT; i++) {
+#if NRHIP_WAVE_DPP
+                const double pt = pts[i], s2 = s2s[i];
+#else
                 double pt = part[i], s2 = sq[i];
                 for (int off = 32; off > 0; off >>= 1) {
                     pt += __shfl_xor(pt, off);
                     s2 += __shfl_xor(s2, off);
                 }
+#endif
                 if (lane == 0 && ib + i < n_active) {
                     const int r = rr[i];
                     // Parseval: sum_t s(t)^2 = (fs^2 / 2) (1 / N) 2 sum_k |G_k|^2 with |G_k| = sqrt(2) amp_k
@@ -1654,9 +1687,15 @@ efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork 
             // total variation sum_{k >= 1} |v_k - v_{k-1}| over k = 1 .. nh (v_0 = v_nh = 0): the neighbour's value comes from the
             // lane below (the previous pass's last lane for lane 0) instead of a second evaluation of the amplitude formula;
             // |v_1 - v_0| is not part of the bound's sum: lane 0 of the first pass skips it
+#if NRHIP_WAVE_DPP
+            float vm = wave_from_lane_below(v);
+            if (lane == 0) vm = v_prev_wave;
+            v_prev_wave = wave_lane_value(v, 63);
+#else
             float vm = __shfl_up(v, 1);
             if (lane == 0) vm = v_prev_wave;
             v_prev_wave = __shfl(v, 63);
+#endif
             sum_v += v;
             if (k >= 2 && k <= nh) tv += fabsf(v - vm);   // k = nh: |0 - v_{nh-1}| = v_last
             if (k >= nh) continue;
@@ -1672,6 +1711,18 @@ efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork 
             }
         }
         float best = 0.f;
+#if NRHIP_WAVE_DPP
+        {   // ES_NJ + 2 wave sums, four to a register (wave_reduce.h); each row of `m` then holds the largest |S_j| of its slot
+            static_assert(ES_NJ % 4 == 0, "wave_fold4");
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < ES_NJ; j += 4) m = fmaxf(m, fabsf(wave_fold4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3])));
+            best = fmaxf(fmaxf(wave_lane_value(m, 0), wave_lane_value(m, 16)), fmaxf(wave_lane_value(m, 32), wave_lane_value(m, 48)));
+            const float sv = wave_fold4(sum_v, tv, sum_v, tv);
+            sum_v = wave_row_value<0>(sv);
+            tv = wave_row_value<1>(sv);
+        }
+#else
 #pragma unroll
         for (int j = 0; j < ES_NJ; j++) {
             float t = acc[j];
@@ -1682,6 +1733,7 @@ efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork 
             sum_v += __shfl_xor(sum_v, off);
             tv += __shfl_xor(tv, off);
         }
+#endif
         if (lane == 0) {
             const double cmax = fmax(fabs(w.pol_theta[r]) * fabs(rt.x), fabs(w.pol_phi[r]) * fabs(rp.x));
             const double err = 2e-3 * (double)sum_v + 1e-30;
@@ -1694,6 +1746,194 @@ efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork 
             } else if (up * (1 + 1e-9) < min_efield) {
                 max_efield[r] = -up;    // "at most": this ray cannot make the event a candidate
                 need_fft[r] = 0;
+            }
+        }
+    }
+    if (sampled_count && lane == 0 && n_sampled) atomicAdd(sampled_count, (unsigned long long)n_sampled);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// kernel (round 6): efield_bound_kernel and efield_sample_kernel in one pass over the bins, the samples on the matrix cores.
+// Both kernels above evaluate v_k = amplitude x attenuation of every bin of a ray; the first sums v_k and v_k^2, the second
+// re-evaluates them for the three rays in four the first leaves open and pays 2 FP32 instructions per (bin, sample) for
+//     S_j = sum_k v_k sin(2 pi j k / N).
+// That sum is a matrix product: [32 rays x K bins] x [K bins x 32 columns] with the column table sin(2 pi j k / N) fixed per station,
+// and column 0 = 1 hands over sum_k v_k as well.  One wave takes 32 rays: lane l evaluates v of ray l & 31 for one bin per step
+// (lanes 0..31 the lower half of the bins, lanes 32..63 the upper half -- each lane walks consecutive bins, so the total
+// variation needs no neighbour lane) and v_mfma_f32_32x32x2_f32 accumulates D[ray][j] += v[ray][k] B[k][j], an exact FP32 fma
+// chain (64 cycles of the matrix pipe per step, beside ~25 vector instructions for v).  31 samples instead of 24 come for free
+// (a lower tail bound), and the epilogue of 32 rays runs in 32 lanes instead of one.
+// Tables per block (LDS): per bin (t, f^alpha, f^beta_had, f^beta_em) with t the position of f_k inside its coarse-grid segment
+// (the interpolated attenuation is a0 + t (a1 - a0)), the segment index, sin(2 pi m / N) for m < N; per wave the attenuation
+// values of its 32 rays [segment][ray] (stride 33).  Bins k >= N / 2 carry f^beta = inf: amplitude 0.
+// Rays outside the FP32 range of the fast path: FP64 sums, ray by ray (efield_bound_fp64_ray), no sampling.
+// ---------------------------------------------------------------------------------------------------------
+#define ED_NJ 31
+#define ED_ROW 33          // floats per row of the per-wave tables
+#define ED_MAX_WAVES 16
+typedef float ed_f32x16 __attribute__((ext_vector_type(16)));
+__host__ __device__ inline int ed_wave_floats(int n_fc) { return (n_fc > 32 ? n_fc : 32) * ED_ROW; }
+__host__ __device__ inline size_t ed_table_bytes(int N) { return (size_t)(N / 2 + 2) * 16 + (size_t)(N + 4) * 4 + (size_t)((N / 2 + 2 + 15) & ~15); }
+
+__global__ void __launch_bounds__(64 * ED_MAX_WAVES)
+efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork w, StationDev st, double min_efield, int exact,
+                     double* __restrict__ max_efield, int* __restrict__ need_fft, unsigned long long* __restrict__ sampled_count)
+{
+    extern __shared__ __align__(16) unsigned char ed_smem[];
+    __shared__ double s_xp[NRHIP_MAX_NFC];
+    const int N = st.N, nh = N / 2, stride = nh + 1, n_fc = st.n_fc, n_bin = nh + 2;
+    float4* s_bin = (float4*)ed_smem;                     // [n_bin] (t, f^alpha, f^beta_had, f^beta_em)
+    float* s_sin = (float*)(s_bin + n_bin);               // [N] sin(2 pi m / N), then one entry 1.0 (column 0)
+    unsigned char* s_lo = (unsigned char*)(s_sin + N + 4);   // [n_bin]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n_wv = blockDim.x >> 6;
+    float* s_wave = (float*)(s_lo + ((n_bin + 15) & ~15)) + (size_t)wv * ed_wave_floats(n_fc);
+    const double df = 1.0 / (N * (1. / st.fs));
+    for (int j = threadIdx.x; j < n_fc; j += blockDim.x) s_xp[j] = st.fcoarse[j];
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_bin; k += blockDim.x) {
+        float4 b = make_float4(0.f, 0.f, __builtin_inff(), __builtin_inff());
+        int lo = 0;
+        if (k >= 1 && k < nh) {
+            const double f = k * df;
+            lo = st.seg[k];
+            double t = (f - s_xp[lo]) / (s_xp[lo + 1] - s_xp[lo]);
+            if (f <= s_xp[0]) { lo = 0; t = 0.; }
+            if (f >= s_xp[n_fc - 1]) { lo = n_fc - 2; t = 1.; }
+            b = make_float4((float)t, st.fpow_f[2 * stride + k], st.fpow_f[k], st.fpow_f[stride + k]);
+        }
+        s_bin[k] = b;
+        s_lo[k] = (unsigned char)lo;
+    }
+    for (int m = threadIdx.x; m < N; m += blockDim.x) s_sin[m] = (float)sinpi(2. * m / N);
+    if (threadIdx.x < 4) s_sin[N + threadIdx.x] = 1.f;
+    __syncthreads();
+
+    const int i = lane & 31, h = lane >> 5;
+    const int KH = (nh + 1) / 2;                 // bins per half: the lower half walks k = 1 .. KH, the upper KH + 1 .. 2 KH (>= nh)
+    const int k0 = 1 + h * KH;
+    const float dff = (float)df;
+    // column j = i of the table: sin(2 pi j k / N) = s_sin[(j k) mod N], advanced by j per bin; column 0 reads the constant 1
+    const unsigned sin_step = 4u * (unsigned)i, sin_wrap = 4u * (unsigned)N;
+    const unsigned sin_m0 = (i == 0) ? 4u * (unsigned)N : 4u * (unsigned)(((long)i * k0) % N);
+    const int n_tiles = (n_active + 31) / 32;
+    unsigned n_sampled = 0;
+    for (int tile = blockIdx.x * n_wv + wv; tile < n_tiles; tile += gridDim.x * n_wv) {
+        const int ia = tile * 32 + i;
+        const bool valid = ia < n_active;
+        const int r = active_list[min(ia, n_active - 1)];
+        const AskaryanConst& ai = w.ask[r];
+        const double cL = ai.cL, cR = ai.cR, pf = ai.pref2;
+        const bool fast = ai.model == 0 && pf > 1e-18 && pf < 1e18 && cL > 1e-15 && cL < 1e15 && cR > 1e-15 && cR < 1e15;
+        const bool had = ai.had != 0;
+        wave_lds_sync();   // (the previous tile's readers of s_wave are done)
+        for (int q = 0; q < 32; q += 2) {   // two rays per pass, lanes over the coarse frequencies
+            const int rq = __shfl(r, q + h);
+            for (int c = i; c < n_fc; c += 32) s_wave[c * ED_ROW + q + h] = (float)w.att[(long)rq * n_fc + c];
+        }
+        wave_lds_sync();
+        const float cLf = fast ? (float)cL : 1.f, cRf = fast ? (float)cR : 1.f, pfd = fast ? (float)pf * dff : 0.f;
+        ed_f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] = 0.f;
+        float sq = 0.f, tv = 0.f, v_prev = 0.f, v_first = 0.f;
+        unsigned sm = sin_m0;
+        const float* s_at_lane = s_wave + i;
+        auto step = [&](int k, bool first) {
+            const float4 b = s_bin[k];
+            const int lo = s_lo[k];
+            const float a0 = s_at_lane[lo * ED_ROW], a1 = s_at_lane[lo * ED_ROW + ED_ROW];
+            const float att = fmaf(b.x, a1 - a0, a0);
+            const float x = (had ? b.z : b.w) * cLf, y = b.y * cRf;
+            const float yp = 1.f + y;
+            const float amp = ((float)k * pfd) * __builtin_amdgcn_rcpf(fmaf(x, yp, yp));
+            const float v = amp * fmaxf(att, 0.f);
+            const float bj = *(const float*)((const unsigned char*)s_sin + sm);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, bj, acc, 0, 0, 0);
+            sq = fmaf(v, v, sq);
+            if (first) v_first = v;
+            else tv += fabsf(v - v_prev);
+            v_prev = v;
+            const unsigned s1 = sm + sin_step;
+            sm = (i == 0) ? sm : min(s1, s1 - sin_wrap);   // (unsigned: s1 - wrap is huge while s1 < wrap)
+        };
+        step(k0, true);
+        for (int s = 1; s < KH; s++) step(k0 + s, false);
+        // the step between the halves: |v_{KH + 1} - v_{KH}| (the upper half's first against the lower half's last)
+        {
+            const float below = wave_from_lower_half(v_prev);
+            if (h) tv += fabsf(v_first - below);
+        }
+        tv = wave_fold32(tv, tv);
+        sq = wave_fold32(sq, sq);
+        // D[ray][j]: register q of lane (h, j) holds ray (q & 3) + 8 (q >> 2) + 4 h
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 16; q++) s_wave[((q & 3) + 8 * (q >> 2) + 4 * h) * ED_ROW + i] = acc[q];
+        wave_lds_sync();
+        float best = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const float t = s_wave[i * ED_ROW + 16 * h + c];
+            if (c > 0 || h) best = fmaxf(best, fabsf(t));
+        }
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(best), __float_as_int(best), false, false);
+            best = fmaxf(__int_as_float(sw[0]), __int_as_float(sw[1]));
+        }
+        const float sum_v = s_wave[i * ED_ROW];
+        bool sampled = false;
+        if (valid && fast && h == 0) {
+            const double2 rt = w.r_theta[r], rp = w.r_phi[r];
+            const double pth = fabs(w.pol_theta[r]), pph = fabs(w.pol_phi[r]);
+            const double pt = (double)sum_v * BOUND_F32_SLACK + 1e-30;   // + what FP32 may have flushed to zero
+            const double s2 = (double)sq * (BOUND_F32_SLACK * BOUND_F32_SLACK) + 1e-60;
+            // Parseval: sum_t s(t)^2 = (fs^2 / 2) (1 / N) 2 sum_k |G_k|^2 with |G_k| = sqrt(2) amp_k
+            w.e_norm[r] = sqrt((st.fs * st.fs / N) * 2. * s2) * BOUND_RCP_SLACK;
+            const double cmax = fmax(pth * cabs2(rt), pph * cabs2(rp));
+            const double bnd = efield_bound(pt * BOUND_RCP_SLACK, N, st.fs, cmax);
+            bool need = exact || (bnd * (1 + 1e-6) > min_efield);
+            double out = -bnd;
+            if (need && !exact && rt.y == 0. && rp.y == 0.) {
+                // the samples decide what they can: low <= max |e| / scale <= up (comment of efield_sample_kernel); the FP32 fma
+                // chains of the matrix product are within N / 2 ulp of the exact sums: err = 1e-3 of sum_k v_k covers them
+                sampled = true;
+                const double err = 1e-3 * (double)sum_v + 1e-30;
+                const double tail = (double)tv * (1. + 1e-3) / sin(M_PI * (ED_NJ + 1) / N);
+                const double low = efield_bound((double)best - err, N, st.fs, cmax);
+                const double up = efield_bound(fmax((double)best + err, tail), N, st.fs, cmax);
+                if (low > min_efield * (1 + 1e-9)) {
+                    out = low;      // "at least": the event is a candidate
+                    need = false;
+                } else if (up * (1 + 1e-9) < min_efield) {
+                    out = -up;      // "at most": this ray cannot make the event a candidate
+                    need = false;
+                }
+            }
+            max_efield[r] = out;
+            need_fft[r] = need ? 1 : 0;
+        }
+        n_sampled += __popcll(__ballot(sampled));
+        // rays outside the fast path's range: the FP64 sums of efield_bound_kernel, one ray at a time over the wave
+        unsigned long long slow = __ballot(valid && !fast && h == 0);
+        while (slow) {
+            const int q = __ffsll((long long)slow) - 1;
+            slow &= slow - 1;
+            const int rq = __shfl(r, q);
+            double* at_d = (double*)s_wave;
+            double* slope_d = at_d + n_fc;
+            wave_lds_sync();
+            if (lane < n_fc) at_d[lane] = w.att[(long)rq * n_fc + lane];
+            wave_lds_sync();
+            if (lane < n_fc - 1) slope_d[lane] = (at_d[lane + 1] - at_d[lane]) / (s_xp[lane + 1] - s_xp[lane]);
+            wave_lds_sync();
+            const double2 ps = efield_bound_fp64_ray(N, st.fs, n_fc, st.seg, st.fpow, st.lnf, w.ask[rq], at_d, slope_d, s_xp, lane);
+            const double pt = wave_sum(ps.x), s2 = wave_sum(ps.y);
+            if (lane == 0) {
+                w.e_norm[rq] = sqrt((st.fs * st.fs / N) * 2. * s2) * BOUND_RCP_SLACK;
+                const double cmax = fmax(fabs(w.pol_theta[rq]) * cabs2(w.r_theta[rq]), fabs(w.pol_phi[rq]) * cabs2(w.r_phi[rq]));
+                const double bnd = efield_bound(pt * BOUND_RCP_SLACK, N, st.fs, cmax);
+                max_efield[rq] = -bnd;
+                need_fft[rq] = (exact || (bnd * (1 + 1e-6) > min_efield)) ? 1 : 0;
             }
         }
     }
@@ -4148,6 +4388,15 @@ void launch_scatter_active(hipStream_t s, int n_rays, const int* active, const i
     if (n_rays <= 0) return;
     hipLaunchKernelGGL(scatter_active_kernel, dim3(grid_for(n_rays, 256)), dim3(256), 0, s, n_rays, active, offset, list);
 }
+// waves per block of efield_decide_kernel: what fits the CU's LDS beside the station's tables (0: the kernel does not apply)
+static int efield_decide_waves(const StationDev& st)
+{
+    if (st.N < 64 || st.n_fc < 2) return 0;
+    const long room = 160 * 1024 - 1024 - (long)ed_table_bytes(st.N);
+    long nw = room / ((long)ed_wave_floats(st.n_fc) * 4);
+    if (nw > ED_MAX_WAVES) nw = ED_MAX_WAVES;
+    return nw >= 4 ? (int)nw : 0;
+}
 void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int n_rays, int n_events,
                        const int* slot_offset, const RayWork& w, const EventIn& evin, const StationDev& st, int ask_model,
                        const double2* tw, double min_efield, int exact, double* max_efield, int* need_ray, int* ev_need,
@@ -4158,6 +4407,18 @@ void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int 
     (void)hipMemsetAsync(need_ray, 0, sizeof(int) * (size_t)n_rays, s);
     int gridA = (n_active + 4 * AB_RT - 1) / (4 * AB_RT);
     if (gridA > 256 * 32) gridA = 256 * 32;
+    static const bool two_kernels = getenv("NRHIP_EFIELD_TWO_KERNELS") != nullptr;   // (experiment switch: the round-5 pair)
+    const int ed_waves = efield_decide_waves(st);
+    if (ask_model == 0 && ed_waves > 0 && !two_kernels) {
+        // bound, Parseval norm and the samples next to the pulse centre in one pass, 32 rays per wave (matrix cores)
+        set_big_lds();
+        const int n_tiles = (n_active + 31) / 32;
+        int gridD = (n_tiles + ed_waves - 1) / ed_waves;
+        if (gridD > 256) gridD = 256;
+        hipLaunchKernelGGL(efield_decide_kernel, dim3(gridD), dim3(64 * ed_waves),
+                           ed_table_bytes(st.N) + (size_t)ed_waves * ed_wave_floats(st.n_fc) * 4, s, n_active, active_list, w, st,
+                           min_efield, exact, max_efield, need_ray, xform_count ? xform_count + 4 : nullptr);
+    } else {
     hipLaunchKernelGGL(efield_bound_kernel, dim3(gridA), dim3(256), 0, s, n_active, active_list, w, st, min_efield, exact,
                        max_efield, need_ray);
     if (!exact && ask_model == 0) {   // decide what the direct samples next to the pulse centre can decide
@@ -4165,6 +4426,7 @@ void launch_efield_max(hipStream_t s, int n_active, const int* active_list, int 
         if (gridS > 256 * 16) gridS = 256 * 16;
         hipLaunchKernelGGL(efield_sample_kernel, dim3(gridS), dim3(256), (size_t)(nh + 1) * 13, s, n_active, active_list, w, st,
                            min_efield, max_efield, need_ray, xform_count ? xform_count + 4 : nullptr);
+    }
     }
     hipLaunchKernelGGL(event_need_kernel, dim3(grid_for(n_events + 1, 256)), dim3(256), 0, s, n_events, st.n_ch, slot_offset,
                        need_ray, ev_need, max_efield, min_efield, exact);
@@ -4246,6 +4508,7 @@ static void set_big_lds()
     (void)hipFuncSetAttribute((const void*)general_spectrum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)general_trace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FFT_MAX * 16);
     (void)hipFuncSetAttribute((const void*)efield_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (FFT_MAX + 1) * 13);
+    (void)hipFuncSetAttribute((const void*)efield_decide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     (void)hipGetLastError();
     g_attr_set = true;
 }
@@ -5646,6 +5909,41 @@ void launch_czt_test(hipStream_t s, int n_batch, int n_in, int n_out, int Q, dou
     set_big_lds();
     hipLaunchKernelGGL(czt_test_kernel, dim3(grid), dim3(1024), (size_t)FFT_MAX * 16, s, n_batch, n_in, n_out, Q, sgn, in,
                        out, tw, Bscratch);
+}
+
+// test hook of wave_reduce.h: per wave 8 values per lane -> doubles out[w][WAVE_TEST_OUT]: [0..7] wave_fold4 sums (FP64), [8..15]
+// the same in FP32, [16 + lane] wave_sum of value 0 per lane (FP64), [80 + lane] the same in FP32, [144 + lane] the lane below's value,
+// [208] lane 63's value, [209 + lane] the value of lane - 32
+__global__ void __launch_bounds__(256) wave_reduce_test_kernel(int n_waves, const double* __restrict__ in, double* __restrict__ out)
+{
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= n_waves) return;
+    double v[8];
+    float f[8];
+    for (int i = 0; i < 8; i++) {
+        v[i] = in[((long)w * 8 + i) * 64 + lane];
+        f[i] = (float)v[i];
+    }
+    double* o = out + (long)w * WAVE_TEST_OUT;
+    const double a = wave_fold4(v[0], v[1], v[2], v[3]), b = wave_fold4(v[4], v[5], v[6], v[7]);
+    const float af = wave_fold4(f[0], f[1], f[2], f[3]), bf = wave_fold4(f[4], f[5], f[6], f[7]);
+    const double s64[8] = {wave_row_value<0>(a), wave_row_value<1>(a), wave_row_value<2>(a), wave_row_value<3>(a),
+                           wave_row_value<0>(b), wave_row_value<1>(b), wave_row_value<2>(b), wave_row_value<3>(b)};
+    const float s32[8] = {wave_row_value<0>(af), wave_row_value<1>(af), wave_row_value<2>(af), wave_row_value<3>(af),
+                          wave_row_value<0>(bf), wave_row_value<1>(bf), wave_row_value<2>(bf), wave_row_value<3>(bf)};
+    if (lane < 8) {
+        o[lane] = s64[lane];
+        o[8 + lane] = (double)s32[lane];
+    }
+    o[16 + lane] = wave_sum(v[0]);
+    o[80 + lane] = (double)wave_sum(f[0]);
+    o[144 + lane] = (double)wave_from_lane_below(f[1]);
+    if (lane == 0) o[208] = (double)wave_lane_value(f[1], 63);
+    o[209 + lane] = (double)wave_from_lower_half(f[2]);
+}
+void launch_wave_reduce_test(hipStream_t s, int n_waves, const double* in, double* out)
+{
+    hipLaunchKernelGGL(wave_reduce_test_kernel, dim3((n_waves + 3) / 4), dim3(256), 0, s, n_waves, in, out);
 }
 
 

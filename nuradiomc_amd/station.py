@@ -144,6 +144,7 @@ L._OPTIONAL.update({
                                                ctypes.c_double, L.c_double_p]),
     'nrhip_debug_czt': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_double, L.c_double_p, L.c_double_p]),
+    'nrhip_debug_wave_sums': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, L.c_double_p, L.c_double_p]),
 })
 
 

@@ -25,6 +25,32 @@ def test_chirp_z_in_lds(gpu_ctx_factory):
         assert np.max(np.abs(got - ref)) < 1e-10 * np.max(np.abs(ref)), (n_in, n_out, Q)
 
 
+def test_wave_sums_without_the_lds_crossbar(gpu_ctx_factory):
+    """csrc/wave_reduce.h (v_permlane32_swap / v_permlane16_swap folds + DPP row sums) against plain sums: the FP64 sums to
+    rounding, the FP32 ones to FP32 rounding, integers exactly; every lane sees the same wave_sum; the lane-below shift"""
+    ctx = gpu_ctx_factory((1.78, 0.423, 77.))
+    rng = np.random.default_rng(11)
+    x = rng.uniform(0.1, 1., size=(37, 8, 64))
+    x[1] = rng.integers(0, 1000, size=(8, 64))          # integers: exact in any order
+    x[2] = np.arange(8 * 64).reshape(8, 64)             # every (value, lane) distinguishable
+    x[3] = 0.
+    x[3, 5, 17] = 1.                                     # one lane of one value
+    got = ctx.debug_wave_sums(x)
+    ref = x.sum(axis=2)
+    assert np.max(np.abs(got[:, :8] - ref) / np.maximum(ref, 1.)) < 1e-14
+    assert np.max(np.abs(got[:, 8:16] - ref) / np.maximum(ref, 1.)) < 1e-6
+    for w in (1, 2, 3):
+        assert np.array_equal(got[w, :8], ref[w]) and np.array_equal(got[w, 8:16], ref[w])
+    assert np.all(got[:, 16:80] == got[:, 16:17]) and np.all(got[:, 80:144] == got[:, 80:81])
+    assert np.max(np.abs(got[:, 16] - ref[:, 0]) / np.maximum(ref[:, 0], 1.)) < 1e-14
+    assert np.max(np.abs(got[:, 80] - ref[:, 0]) / np.maximum(ref[:, 0], 1.)) < 1e-6
+    f1 = x[:, 1, :].astype(np.float32).astype(float)
+    assert np.array_equal(got[:, 145:208], f1[:, :63]) and np.all(got[:, 144] == 0.)
+    assert np.array_equal(got[:, 208], f1[:, 63])
+    f2 = x[:, 2, :].astype(np.float32).astype(float)
+    assert np.array_equal(got[:, 241:273], f2[:, :32]) and np.all(got[:, 209:241] == 0.)
+
+
 def test_askaryan_spectrum_vs_oracle(gpu_ctx_factory):
     ctx = gpu_ctx_factory((1.78, 0.423, 77.))
     n_index = 1.78
