@@ -917,17 +917,27 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
     bool grouped = cut >= 0. && nh >= 16 * AB_G && run <= AB_RUN;
     for (int j = 0; j + 1 < st.n_fc; j++) grouped = grouped && (s_xp[j + 1] - s_xp[j]) > (AB_G + 1) * df;
     for (int it = 0; it < n_iter; it++) {
-        const int rb = ((it * gridDim.x + blockIdx.x) * 4 + wv) * AB_RT;
+        const int rb = __builtin_amdgcn_readfirstlane(((it * gridDim.x + blockIdx.x) * 4 + wv) * AB_RT);
         if (rb >= n_rays) continue;   // (wave-uniform; the tables below are the wave's own)
-        // per-ray scalars only (the full AskaryanConst records would cost ~40 VGPRs per ray)
+        // per-ray scalars only (the full AskaryanConst records would cost ~40 VGPRs per ray).  All of the tile's loads are issued
+        // before anything waits for one of them: `all2009 && (model == 0)` used to short-circuit into four dependent round trips
+        // to memory per tile, on a kernel that holds three waves per SIMD to hide them
         double cL[AB_RT], cR[AB_RT], pf[AB_RT];
-        int had[AB_RT];
-        bool all2009 = true;
+        int had[AB_RT], model_or = 0;
         for (int i = 0; i < AB_RT; i++) {
             const AskaryanConst& ai = w.ask[min(rb + i, n_rays - 1)];
-            all2009 = all2009 && (ai.model == 0);
+            model_or |= ai.model;
             cL[i] = ai.cL; cR[i] = ai.cR; pf[i] = ai.pref2; had[i] = ai.had;
         }
+        // the polarisation factor of the ray this lane finishes (lanes < AB_RT), requested here, needed behind the sums
+        double cmax_mine = 0.;
+        if (lane < AB_RT && rb + lane < n_rays) {
+            const int r = rb + lane;
+            const double pth = w.pol_theta[r], pph = w.pol_phi[r];
+            const double2 rth = w.r_theta[r], rph = w.r_phi[r];
+            cmax_mine = fmax(fabs(pth) * cabs2(rth), fabs(pph) * cabs2(rph));
+        }
+        const bool all2009 = model_or == 0;
         // Alvarez2009 with all scalars comfortably inside the single-precision range: the attenuation bounds and the 2047-term sum in
         // FP32 (twice the VALU rate, packed pairs of rays, 1-instruction reciprocal / exp); every term is within ~1e-5 and the sum of
         // positive terms within 2047 * 6e-8 of the exact one, the result is inflated by BOUND_F32_SLACK and stays an upper bound
@@ -1128,7 +1138,7 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
             bool open = false;
             double b_up = 0.;
             if (lane < AB_RT && r < n_rays) {
-                const double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
+                const double cmax = cmax_mine;
                 b_up = efield_bound(x_up * BOUND_RCP_SLACK, st.N, st.fs, cmax);
                 const double b_lo = efield_bound(x_lo * BOUND_RCP_SLACK, st.N, st.fs, cmax);
                 open = (b_up * (1 + 1e-6) > cut) && !(b_lo * (1 + 1e-6) > cut);
@@ -1222,8 +1232,7 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
         {
             const int r = rb + lane;
             if (lane < AB_RT && r < n_rays) {
-                double cmax = fmax(fabs(w.pol_theta[r]) * cabs2(w.r_theta[r]), fabs(w.pol_phi[r]) * cabs2(w.r_phi[r]));
-                double b = efield_bound(mine * BOUND_RCP_SLACK, st.N, st.fs, cmax);
+                double b = efield_bound(mine * BOUND_RCP_SLACK, st.N, st.fs, cmax_mine);
                 bound[r] = b;
                 max_efield[r] = -b;  // "not evaluated, at most b" until efield_max_kernel overwrites it
             }
@@ -1491,12 +1500,13 @@ efield_bound_kernel(int n_active, const int* __restrict__ active_list, RayWork w
         if (ib < n_active) {
             double cL[AB_RT], cR[AB_RT], pf[AB_RT];
             int had[AB_RT];
-            bool all2009 = true;
+            int model_or = 0;   // (no short circuit: the four records are requested together)
             for (int i = 0; i < AB_RT; i++) {
                 const AskaryanConst& ai = w.ask[rr[i]];
-                all2009 = all2009 && (ai.model == 0);
+                model_or |= ai.model;
                 cL[i] = ai.cL; cR[i] = ai.cR; pf[i] = ai.pref2; had[i] = ai.had;
             }
+            const bool all2009 = model_or == 0;
             double part[AB_RT], sq[AB_RT];
             for (int i = 0; i < AB_RT; i++) part[i] = sq[i] = 0.;
             const double x_first = s_xp[0], x_last = s_xp[st.n_fc - 1], dx_last = x_last - s_xp[st.n_fc - 2];
@@ -1770,7 +1780,12 @@ efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork 
 // ---------------------------------------------------------------------------------------------------------
 #define ED_NJ 31
 #define ED_ROW 33          // floats per row of the per-wave tables
+#ifndef ED_MAX_WAVES
 #define ED_MAX_WAVES 16
+#endif
+#ifndef ED_UNROLL
+#define ED_UNROLL 1
+#endif
 typedef float ed_f32x16 __attribute__((ext_vector_type(16)));
 __host__ __device__ inline int ed_wave_floats(int n_fc) { return (n_fc > 32 ? n_fc : 32) * ED_ROW; }
 __host__ __device__ inline size_t ed_table_bytes(int N) { return (size_t)(N / 2 + 2) * 16 + (size_t)(N + 4) * 4 + (size_t)((N / 2 + 2 + 15) & ~15); }
@@ -1813,7 +1828,7 @@ efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork 
     const int k0 = 1 + h * KH;
     const float dff = (float)df;
     // column j = i of the table: sin(2 pi j k / N) = s_sin[(j k) mod N], advanced by j per bin; column 0 reads the constant 1
-    const unsigned sin_step = 4u * (unsigned)i, sin_wrap = 4u * (unsigned)N;
+    const unsigned sin_step = 4u * (unsigned)i, sin_wrap = (i == 0) ? 0u : 4u * (unsigned)N;   // (column 0 stays where it is)
     const unsigned sin_m0 = (i == 0) ? 4u * (unsigned)N : 4u * (unsigned)(((long)i * k0) % N);
     const int n_tiles = (n_active + 31) / 32;
     unsigned n_sampled = 0;
@@ -1837,6 +1852,7 @@ efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork 
         for (int q = 0; q < 16; q++) acc[q] = 0.f;
         float sq = 0.f, tv = 0.f, v_prev = 0.f, v_first = 0.f;
         unsigned sm = sin_m0;
+        float kf = (float)k0;
         const float* s_at_lane = s_wave + i;
         auto step = [&](int k, bool first) {
             const float4 b = s_bin[k];
@@ -1845,7 +1861,8 @@ efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork 
             const float att = fmaf(b.x, a1 - a0, a0);
             const float x = (had ? b.z : b.w) * cLf, y = b.y * cRf;
             const float yp = 1.f + y;
-            const float amp = ((float)k * pfd) * __builtin_amdgcn_rcpf(fmaf(x, yp, yp));
+            const float amp = (kf * pfd) * __builtin_amdgcn_rcpf(fmaf(x, yp, yp));
+            kf += 1.f;   // (the bin number as a float: exact)
             const float v = amp * fmaxf(att, 0.f);
             const float bj = *(const float*)((const unsigned char*)s_sin + sm);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, bj, acc, 0, 0, 0);
@@ -1854,9 +1871,10 @@ efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork 
             else tv += fabsf(v - v_prev);
             v_prev = v;
             const unsigned s1 = sm + sin_step;
-            sm = (i == 0) ? sm : min(s1, s1 - sin_wrap);   // (unsigned: s1 - wrap is huge while s1 < wrap)
+            sm = min(s1, s1 - sin_wrap);   // (unsigned: s1 - wrap is huge while s1 < wrap)
         };
         step(k0, true);
+#pragma unroll ED_UNROLL
         for (int s = 1; s < KH; s++) step(k0 + s, false);
         // the step between the halves: |v_{KH + 1} - v_{KH}| (the upper half's first against the lower half's last)
         {
