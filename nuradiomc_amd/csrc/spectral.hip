@@ -957,12 +957,19 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
             // Single precision throughout (hardware exp / log / sqrt / reciprocal: a few ulp each): the bin lengths are good to ~1e-5,
             // their products with the table and the 63-term sums to ~1e-5 as well; the sum is shrunk by 1e-3 to stay a lower bound.
             float bl[AB_RT];
+            // (the path parameters of the four rays requested together, ahead of the branches below: wave-uniform addresses)
+            double C0v[AB_RT], z1v[AB_RT], z2v[AB_RT], ztv[AB_RT];
+#pragma unroll
+            for (int i = 0; i < AB_RT; i++) {
+                const long rc = min(rb + i, n_rays - 1);
+                C0v[i] = w.C0[rc]; z1v[i] = zint[3 * rc]; z2v[i] = zint[3 * rc + 1]; ztv[i] = zint[3 * rc + 2];
+            }
 #pragma unroll
             for (int i = 0; i < AB_RT; i++) {
                 const int r = rb + i;
                 float s1 = 0.f, s2 = 0.f;
                 if (r < n_rays && lane <= st.n_att_bins) {
-                    const double C0 = w.C0[r], z1 = zint[3 * (long)r], z2m = zint[3 * (long)r + 1], zt = zint[3 * (long)r + 2];
+                    const double C0 = C0v[i], z1 = z1v[i], z2m = z2v[i], zt = ztv[i];
                     const double beta2d = __builtin_amdgcn_rcp(C0 * C0);   // (hardware reciprocal: ~1e-8, see the precision note above)
                     const float beta2 = (float)beta2d, alpha = (float)(m.n2 - beta2d), sa = __builtin_amdgcn_sqrtf(alpha);
                     const float n_ice = (float)m.n_ice, dn = (float)m.delta_n, z0 = (float)m.z_0, inv_z0 = __builtin_amdgcn_rcpf(z0);
@@ -986,14 +993,30 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
             }
             blen[wv][lane] = make_float4(bl[0], bl[1], bl[2], bl[3]);
             wave_lds_sync();
-            if (lane < st.n_fc) {
-                f2 I01 = f2{0.f, 0.f}, I23 = I01;
+            // sum_b length_b / L_b per coarse frequency.  Table in LDS (n_fc <= 32): the two halves of the wave take half of the
+            // depth bins each (lane = 32 half + frequency) and fold; otherwise lanes over the frequencies, table from memory.
+            f2 I01 = f2{0.f, 0.f}, I23 = I01;
+            if (binv_lds) {
+                const int fc = lane & 31, nb_half = (st.n_att_bins + 1) >> 1;
+                const int b0 = (lane >> 5) * nb_half, b1 = min(st.n_att_bins, b0 + nb_half);
+                if (fc < st.n_fc)
+                    for (int b = b0; b < b1; b++) {
+                        const float t = s_binv[b * st.n_fc + fc];
+                        const float4 q = blen[wv][b];
+                        I01 += f2{q.x, q.y} * t;
+                        I23 += f2{q.z, q.w} * t;
+                    }
+                I01 = f2{wave_fold32(I01.x, I01.x), wave_fold32(I01.y, I01.y)};
+                I23 = f2{wave_fold32(I23.x, I23.x), wave_fold32(I23.y, I23.y)};
+            } else if (lane < st.n_fc) {
                 for (int b = 0; b < st.n_att_bins; b++) {
-                    const float t = binv_lds ? s_binv[b * st.n_fc + lane] : (float)st.att_bin_inv[b * st.n_fc + lane];
+                    const float t = (float)st.att_bin_inv[b * st.n_fc + lane];
                     const float4 q = blen[wv][b];
                     I01 += f2{q.x, q.y} * t;
                     I23 += f2{q.z, q.w} * t;
                 }
+            }
+            if (lane < st.n_fc) {
                 const float I[AB_RT] = {I01.x, I01.y, I23.x, I23.y};
                 for (int i = 0; i < AB_RT; i++) {
                     if (rb + i >= n_rays) continue;
