@@ -813,15 +813,18 @@ def main():
         # against the FP32 vector peak.  Per ray, from the kernels' code (spectral.hip):
         #   amp_bound_kernel      two-sided sums over groups of 4 bins: (N / 2 - 1) / 4 nodes x 27 (node evaluation 12 + group sums 12
         #                         + 3 shared) + the depth-bin path lengths (2 legs x 64 edges x 22) + the bin sums (63 bins x n_fc x 2)
-        #   efield_bound_kernel   N / 2 - 1 bins x 15 (amplitude 9, attenuation interpolation 3, the two sums 3)
-        #   efield_sample_kernel  N / 2 bins x (amplitude and attenuation 15 + ES_NJ = 24 samples x 4 (sine recurrence 2, sum 2) + 12)
+        #   efield_decide_kernel  per active ray N / 2 bins x (amplitude 9, attenuation interpolation 3, sum of squares 2, total
+        #                         variation 2, and the 32 columns of the matrix product (sum_k v_k, 31 samples) x 2) = 16 + 64
+        #                         (round 5: efield_bound_kernel 15 per bin of every active ray + efield_sample_kernel 123 per bin of
+        #                         the rays it left open; NRHIP_EFIELD_TWO_KERNELS=1 still runs that pair -- price it with 15 / 123)
         # and the N / 2-point transforms of efield_max_kernel in FP64 (5 M log2 M + 40 per amplitude bin).  `vector_time_frac_by_stage`:
         # the time the counted operations would take at the FP64 / FP32 vector peaks over the stage's measured time -- one number
         # per stage, nothing unpriced, and the same for the whole step
         nhb = wl['N'] // 2
         n_fc_ = len(st.att_freq)   # coarse frequencies of the attenuation (analyticraytracing.py:933-960)
         f32_of = {'amp_bound': stats['n_rays'] * ((nhb - 1) / 4. * 27. + 2 * 64 * 22. + 63 * n_fc_ * 2.),
-                  'efield_max': stats['n_active_rays'] * (nhb - 1) * 15. + stats.get('n_efield_sampled', 0) * nhb * (15. + 24 * 4. + 12.)}
+                  'efield_max': (stats['n_active_rays'] * (nhb - 1) * 15. + stats.get('n_efield_sampled', 0) * nhb * (15. + 24 * 4. + 12.)
+                                 if os.environ.get('NRHIP_EFIELD_TWO_KERNELS') else stats['n_active_rays'] * nhb * (16. + 64.))}
         f64_of = dict(flop_of)
         if cfgno != 4:
             f64_of['efield_max'] = stats['n_efield_transforms'] * (5. * nhb * np.log2(nhb) + 40. * nhb)

@@ -1794,11 +1794,15 @@ efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork 
 // and column 0 = 1 hands over sum_k v_k as well.  One wave takes 32 rays: lane l evaluates v of ray l & 31 for one bin per step
 // (lanes 0..31 the lower half of the bins, lanes 32..63 the upper half -- each lane walks consecutive bins, so the total
 // variation needs no neighbour lane) and v_mfma_f32_32x32x2_f32 accumulates D[ray][j] += v[ray][k] B[k][j], an exact FP32 fma
-// chain (64 cycles of the matrix pipe per step, beside ~25 vector instructions for v).  31 samples instead of 24 come for free
-// (a lower tail bound), and the epilogue of 32 rays runs in 32 lanes instead of one.
-// Tables per block (LDS): per bin (t, f^alpha, f^beta_had, f^beta_em) with t the position of f_k inside its coarse-grid segment
-// (the interpolated attenuation is a0 + t (a1 - a0)), the segment index, sin(2 pi m / N) for m < N; per wave the attenuation
-// values of its 32 rays [segment][ray] (stride 33).  Bins k >= N / 2 carry f^beta = inf: amplitude 0.
+// chain (64 cycles per bin and wave: 64 FLOP / clk / SIMD, twice what unpacked vector fmas reach; measured, it does NOT overlap the
+// vector instructions of the SIMD's other waves -- the FP32-input MFMA runs at the vector rate -- so the kernel's time is the sum
+// of the two: SQ counters in profiles/).  Every lane takes TWO consecutive bins per step (8-byte table
+// reads; the packed arithmetic costs the same issue time as unpacked -- v_pk_*_f32 issue at half rate -- but fewer LDS
+// instructions).  31 samples instead of 24 (a lower tail bound), and the epilogue of 32 rays runs in 32 lanes instead of one.
+// Tables per block (LDS), bin k at index k - 1 (pairs start at even indices: 8-byte reads): t = position of f_k inside its
+// coarse-grid segment (the interpolated attenuation is a0 + t (a1 - a0)), f^alpha, f^beta_had, f^beta_em, the segment index,
+// sin(2 pi m / N) for m < N; per wave the attenuation values of its 32 rays [segment][ray] (stride 33).  Bins k >= N / 2 carry
+// f^beta = inf: amplitude 0.
 // Rays outside the FP32 range of the fast path: FP64 sums, ray by ray (efield_bound_fp64_ray), no sampling.
 // ---------------------------------------------------------------------------------------------------------
 #define ED_NJ 31
@@ -1806,12 +1810,27 @@ efield_sample_kernel(int n_active, const int* __restrict__ active_list, RayWork 
 #ifndef ED_MAX_WAVES
 #define ED_MAX_WAVES 16
 #endif
-#ifndef ED_UNROLL
-#define ED_UNROLL 1
-#endif
 typedef float ed_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ed_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ed_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ed_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned ed_u4 __attribute__((ext_vector_type(4)));
+#ifndef ED_BF16
+#define ED_BF16 1   // 0: the product as v_mfma_f32_32x32x2_f32 (FP32 operands: runs at the vector rate and does not overlap vector work)
+#endif
+// two floats rounded to bfloat16 (v_cvt_pk_bf16_f32, round to nearest even): a in the low half
+__device__ __forceinline__ unsigned ed_pk_bf16(float a, float b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(ed_f2{a, b}, ed_bf16x2));
+}
 __host__ __device__ inline int ed_wave_floats(int n_fc) { return (n_fc > 32 ? n_fc : 32) * ED_ROW; }
-__host__ __device__ inline size_t ed_table_bytes(int N) { return (size_t)(N / 2 + 2) * 16 + (size_t)(N + 4) * 4 + (size_t)((N / 2 + 2 + 15) & ~15); }
+// bins per half of the wave: the lower half walks k = 1 .. KH, the upper KH + 1 .. 2 KH (>= N / 2)
+__host__ __device__ inline int ed_bins_per_half(int N) { return 8 * ((N / 2 + 15) / 16); }   // (a multiple of the 8 bins of a matrix operand)
+__host__ __device__ inline size_t ed_table_bytes(int N)
+{
+    const size_t n_tab = 2 * (size_t)ed_bins_per_half(N);
+    return n_tab * 16 + (size_t)(N + 4) * 4 + ((n_tab + 15) & ~(size_t)15);
+}
 
 __global__ void __launch_bounds__(64 * ED_MAX_WAVES)
 efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork w, StationDev st, double min_efield, int exact,
@@ -1819,40 +1838,56 @@ efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork 
 {
     extern __shared__ __align__(16) unsigned char ed_smem[];
     __shared__ double s_xp[NRHIP_MAX_NFC];
-    const int N = st.N, nh = N / 2, stride = nh + 1, n_fc = st.n_fc, n_bin = nh + 2;
-    float4* s_bin = (float4*)ed_smem;                     // [n_bin] (t, f^alpha, f^beta_had, f^beta_em)
-    float* s_sin = (float*)(s_bin + n_bin);               // [N] sin(2 pi m / N), then one entry 1.0 (column 0)
-    unsigned char* s_lo = (unsigned char*)(s_sin + N + 4);   // [n_bin]
+    const int N = st.N, nh = N / 2, stride = nh + 1, n_fc = st.n_fc;
+    const int KH = ed_bins_per_half(N), n_tab = 2 * KH;
+    float* s_t = (float*)ed_smem;                         // [n_tab] each, entry q = bin q + 1
+    float* s_pr = s_t + n_tab;                            // f^alpha
+    float* s_ph = s_pr + n_tab;                           // f^beta, hadronic
+    float* s_pe = s_ph + n_tab;                           // f^beta, electromagnetic
+    float* s_sin = s_pe + n_tab;                          // [N] sin(2 pi m / N), then 1.0 (column 0)
+    unsigned char* s_lo = (unsigned char*)(s_sin + N + 4);   // [n_tab]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n_wv = blockDim.x >> 6;
-    float* s_wave = (float*)(s_lo + ((n_bin + 15) & ~15)) + (size_t)wv * ed_wave_floats(n_fc);
+    float* s_wave = (float*)(s_lo + ((n_tab + 15) & ~15)) + (size_t)wv * ed_wave_floats(n_fc);
     const double df = 1.0 / (N * (1. / st.fs));
     for (int j = threadIdx.x; j < n_fc; j += blockDim.x) s_xp[j] = st.fcoarse[j];
     __syncthreads();
-    for (int k = threadIdx.x; k < n_bin; k += blockDim.x) {
-        float4 b = make_float4(0.f, 0.f, __builtin_inff(), __builtin_inff());
+    for (int q = threadIdx.x; q < n_tab; q += blockDim.x) {
+        const int k = q + 1;
+        float t = 0.f, pr = 0.f, ph = __builtin_inff(), pe = __builtin_inff();
         int lo = 0;
-        if (k >= 1 && k < nh) {
+        if (k < nh) {
             const double f = k * df;
             lo = st.seg[k];
-            double t = (f - s_xp[lo]) / (s_xp[lo + 1] - s_xp[lo]);
-            if (f <= s_xp[0]) { lo = 0; t = 0.; }
-            if (f >= s_xp[n_fc - 1]) { lo = n_fc - 2; t = 1.; }
-            b = make_float4((float)t, st.fpow_f[2 * stride + k], st.fpow_f[k], st.fpow_f[stride + k]);
+            double td = (f - s_xp[lo]) / (s_xp[lo + 1] - s_xp[lo]);
+            if (f <= s_xp[0]) { lo = 0; td = 0.; }
+            if (f >= s_xp[n_fc - 1]) { lo = n_fc - 2; td = 1.; }
+            t = (float)td; pr = st.fpow_f[2 * stride + k]; ph = st.fpow_f[k]; pe = st.fpow_f[stride + k];
         }
-        s_bin[k] = b;
-        s_lo[k] = (unsigned char)lo;
+        s_t[q] = t; s_pr[q] = pr; s_ph[q] = ph; s_pe[q] = pe;
+        s_lo[q] = (unsigned char)lo;
     }
+#if ED_BF16
+    // the sines as two bfloat16 each (value = hi + lo to 2^-18), hi in the low half of the word
+    for (int m = threadIdx.x; m < N + 4; m += blockDim.x) {
+        const float sv = m < N ? (float)sinpi(2. * m / N) : 1.f;
+        const unsigned hi = ed_pk_bf16(sv, 0.f) & 0xffffu;
+        const unsigned lo = ed_pk_bf16(sv - __uint_as_float(hi << 16), 0.f) & 0xffffu;
+        ((unsigned*)s_sin)[m] = hi | (lo << 16);
+    }
+#else
     for (int m = threadIdx.x; m < N; m += blockDim.x) s_sin[m] = (float)sinpi(2. * m / N);
     if (threadIdx.x < 4) s_sin[N + threadIdx.x] = 1.f;
+#endif
     __syncthreads();
 
     const int i = lane & 31, h = lane >> 5;
-    const int KH = (nh + 1) / 2;                 // bins per half: the lower half walks k = 1 .. KH, the upper KH + 1 .. 2 KH (>= nh)
-    const int k0 = 1 + h * KH;
+    const int q0 = h * KH;                       // table index of the lane's first bin (bin q0 + 1)
     const float dff = (float)df;
-    // column j = i of the table: sin(2 pi j k / N) = s_sin[(j k) mod N], advanced by j per bin; column 0 reads the constant 1
-    const unsigned sin_step = 4u * (unsigned)i, sin_wrap = (i == 0) ? 0u : 4u * (unsigned)N;   // (column 0 stays where it is)
-    const unsigned sin_m0 = (i == 0) ? 4u * (unsigned)N : 4u * (unsigned)(((long)i * k0) % N);
+    // column j = i of the table: sin(2 pi j k / N) = s_sin[(j k) mod N]; the lane's even and odd bins advance by 2 j each
+    // (j < 32 <= N / 2); column 0 reads the constant 1 behind the table and stays there
+    const unsigned sin_step = 8u * (unsigned)i, sin_wrap = (i == 0) ? 0u : 4u * (unsigned)N;
+    const unsigned sin_a0 = (i == 0) ? 4u * (unsigned)N : 4u * (unsigned)(((long)i * (q0 + 1)) % N);
+    const unsigned sin_b0 = (i == 0) ? 4u * (unsigned)N : 4u * (unsigned)(((long)i * (q0 + 2)) % N);
     const int n_tiles = (n_active + 31) / 32;
     unsigned n_sampled = 0;
     for (int tile = blockIdx.x * n_wv + wv; tile < n_tiles; tile += gridDim.x * n_wv) {
@@ -1862,7 +1897,7 @@ efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork 
         const AskaryanConst& ai = w.ask[r];
         const double cL = ai.cL, cR = ai.cR, pf = ai.pref2;
         const bool fast = ai.model == 0 && pf > 1e-18 && pf < 1e18 && cL > 1e-15 && cL < 1e15 && cR > 1e-15 && cR < 1e15;
-        const bool had = ai.had != 0;
+        const float* s_psel = ai.had != 0 ? s_ph : s_pe;
         wave_lds_sync();   // (the previous tile's readers of s_wave are done)
         for (int q = 0; q < 32; q += 2) {   // two rays per pass, lanes over the coarse frequencies
             const int rq = __shfl(r, q + h);
@@ -1873,39 +1908,71 @@ efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork 
         ed_f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[q] = 0.f;
-        float sq = 0.f, tv = 0.f, v_prev = 0.f, v_first = 0.f;
-        unsigned sm = sin_m0;
-        float kf = (float)k0;
+        ed_f2 sq2 = ed_f2{0.f, 0.f}, kf2 = ed_f2{(float)(q0 + 1), (float)(q0 + 2)};   // (bin numbers as floats: exact)
+        float tv = 0.f, v_prev = 0.f, v_first = 0.f;
+        unsigned sm_a = sin_a0, sm_b = sin_b0;
         const float* s_at_lane = s_wave + i;
-        auto step = [&](int k, bool first) {
-            const float4 b = s_bin[k];
-            const int lo = s_lo[k];
-            const float a0 = s_at_lane[lo * ED_ROW], a1 = s_at_lane[lo * ED_ROW + ED_ROW];
-            const float att = fmaf(b.x, a1 - a0, a0);
-            const float x = (had ? b.z : b.w) * cLf, y = b.y * cRf;
-            const float yp = 1.f + y;
-            const float amp = (kf * pfd) * __builtin_amdgcn_rcpf(fmaf(x, yp, yp));
-            kf += 1.f;   // (the bin number as a float: exact)
-            const float v = amp * fmaxf(att, 0.f);
-            const float bj = *(const float*)((const unsigned char*)s_sin + sm);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, bj, acc, 0, 0, 0);
-            sq = fmaf(v, v, sq);
-            if (first) v_first = v;
-            else tv += fabsf(v - v_prev);
-            v_prev = v;
-            const unsigned s1 = sm + sin_step;
-            sm = min(s1, s1 - sin_wrap);   // (unsigned: s1 - wrap is huge while s1 < wrap)
+#if ED_BF16
+        ed_u4 a_hi, a_lo, b_hi, b_lo;   // 8 bins of this lane: v and the sines as bfloat16 pairs (hi, lo)
+#endif
+        auto step = [&](int q, bool first, int slot) {   // bins q + 1, q + 2
+            const ed_f2 t = *(const ed_f2*)(s_t + q), pr = *(const ed_f2*)(s_pr + q), ps = *(const ed_f2*)(s_psel + q);
+            const unsigned lo2 = *(const unsigned short*)(s_lo + q);
+            const int ra = (lo2 & 0xffu) * ED_ROW, rb = (lo2 >> 8) * ED_ROW;
+            const ed_f2 a0 = ed_f2{s_at_lane[ra], s_at_lane[rb]}, a1 = ed_f2{s_at_lane[ra + ED_ROW], s_at_lane[rb + ED_ROW]};
+            const ed_f2 att = ed_f2{fmaf(t.x, a1.x - a0.x, a0.x), fmaf(t.y, a1.y - a0.y, a0.y)};   // (per bin: the pairs come in (a0, a1) order)
+            const ed_f2 x = ps * cLf, yp = pr * cRf + 1.f;
+            const ed_f2 den = x * yp + yp;
+            const ed_f2 amp = (kf2 * pfd) * ed_f2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            kf2 += 2.f;
+            const ed_f2 v = amp * ed_f2{fmaxf(att.x, 0.f), fmaxf(att.y, 0.f)};
+#if ED_BF16
+            {   // v = hi + lo (two roundings to 8 bits: 2^-18 of v left over); the sines come split from the table
+                const unsigned vh = ed_pk_bf16(v.x, v.y);
+                a_hi[slot] = vh;
+                a_lo[slot] = ed_pk_bf16(v.x - __uint_as_float(vh << 16), v.y - __uint_as_float(vh & 0xffff0000u));
+                const unsigned da = *(const unsigned*)((const unsigned char*)s_sin + sm_a), db = *(const unsigned*)((const unsigned char*)s_sin + sm_b);
+                b_hi[slot] = __builtin_amdgcn_perm(db, da, 0x05040100u);   // (hi_a, hi_b)
+                b_lo[slot] = __builtin_amdgcn_perm(db, da, 0x07060302u);   // (lo_a, lo_b)
+            }
+#else
+            const float bj_a = *(const float*)((const unsigned char*)s_sin + sm_a), bj_b = *(const float*)((const unsigned char*)s_sin + sm_b);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, bj_a, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, bj_b, acc, 0, 0, 0);
+#endif
+            sq2 += v * v;
+            if (first) v_first = v.x;
+            else tv += fabsf(v.x - v_prev);
+            tv += fabsf(v.y - v.x);
+            v_prev = v.y;
+            const unsigned sa = sm_a + sin_step, sb = sm_b + sin_step;
+            sm_a = min(sa, sa - sin_wrap);   // (unsigned: s - wrap is huge while s < wrap)
+            sm_b = min(sb, sb - sin_wrap);
         };
-        step(k0, true);
-#pragma unroll ED_UNROLL
-        for (int s = 1; s < KH; s++) step(k0 + s, false);
+        // 8 bins per lane, then the product of the group: v s = hi_v hi_s + lo_v hi_s + hi_v lo_s (+ 2^-18 v s), accumulated in FP32
+        auto group = [&](int q, bool first) {
+            step(q, first, 0);
+            step(q + 2, false, 1);
+            step(q + 4, false, 2);
+            step(q + 6, false, 3);
+#if ED_BF16
+            const ed_bf16x8 ah = __builtin_bit_cast(ed_bf16x8, a_hi), al = __builtin_bit_cast(ed_bf16x8, a_lo);
+            const ed_bf16x8 bh = __builtin_bit_cast(ed_bf16x8, b_hi), bl = __builtin_bit_cast(ed_bf16x8, b_lo);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+#endif
+        };
+        group(q0, true);
+        for (int s = 8; s < KH; s += 8) group(q0 + s, false);
+        const float sq = sq2.x + sq2.y;
         // the step between the halves: |v_{KH + 1} - v_{KH}| (the upper half's first against the lower half's last)
         {
             const float below = wave_from_lower_half(v_prev);
             if (h) tv += fabsf(v_first - below);
         }
         tv = wave_fold32(tv, tv);
-        sq = wave_fold32(sq, sq);
+        const float sq_ray = wave_fold32(sq, sq);
         // D[ray][j]: register q of lane (h, j) holds ray (q & 3) + 8 (q >> 2) + 4 h
         wave_lds_sync();
 #pragma unroll
@@ -1927,7 +1994,7 @@ efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork 
             const double2 rt = w.r_theta[r], rp = w.r_phi[r];
             const double pth = fabs(w.pol_theta[r]), pph = fabs(w.pol_phi[r]);
             const double pt = (double)sum_v * BOUND_F32_SLACK + 1e-30;   // + what FP32 may have flushed to zero
-            const double s2 = (double)sq * (BOUND_F32_SLACK * BOUND_F32_SLACK) + 1e-60;
+            const double s2 = (double)sq_ray * (BOUND_F32_SLACK * BOUND_F32_SLACK) + 1e-60;
             // Parseval: sum_t s(t)^2 = (fs^2 / 2) (1 / N) 2 sum_k |G_k|^2 with |G_k| = sqrt(2) amp_k
             w.e_norm[r] = sqrt((st.fs * st.fs / N) * 2. * s2) * BOUND_RCP_SLACK;
             const double cmax = fmax(pth * cabs2(rt), pph * cabs2(rp));
