@@ -1941,6 +1941,7 @@ efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork 
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, bj_b, acc, 0, 0, 0);
 #endif
             sq2 += v * v;
+            // total variation of the lane's run of bins (the step from the run's predecessor: after the loop)
             if (first) v_first = v.x;
             else tv += fabsf(v.x - v_prev);
             tv += fabsf(v.y - v.x);
@@ -1966,11 +1967,9 @@ efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork 
         group(q0, true);
         for (int s = 8; s < KH; s += 8) group(q0 + s, false);
         const float sq = sq2.x + sq2.y;
-        // the step between the halves: |v_{KH + 1} - v_{KH}| (the upper half's first against the lower half's last)
-        {
-            const float below = wave_from_lower_half(v_prev);
-            if (h) tv += fabsf(v_first - below);
-        }
+        // the step at the head of each half's run: its first bin against the bin before it -- v_0 = 0 for the lower half, the lower
+        // half's last bin for the upper one: tv = sum_{k = 1}^{N/2} |v_k - v_{k-1}| of the zero-padded sequence
+        tv += fabsf(v_first - wave_from_lower_half(v_prev));   // (0 in the lower half)
         tv = wave_fold32(tv, tv);
         const float sq_ray = wave_fold32(sq, sq);
         // D[ray][j]: register q of lane (h, j) holds ray (q & 3) + 8 (q >> 2) + 4 h
@@ -2002,11 +2001,17 @@ efield_decide_kernel(int n_active, const int* __restrict__ active_list, RayWork 
             bool need = exact || (bnd * (1 + 1e-6) > min_efield);
             double out = -bnd;
             if (need && !exact && rt.y == 0. && rp.y == 0.) {
-                // the samples decide what they can: low <= max |e| / scale <= up (comment of efield_sample_kernel); the FP32 fma
-                // chains of the matrix product are within N / 2 ulp of the exact sums: err = 1e-3 of sum_k v_k covers them
+                // the samples decide what they can: low <= max |e| / scale <= up (comment of efield_sample_kernel).  The products of
+                // the split operands leave out 2^-18 of every term, the FP32 accumulation is within N / 2 ulp of the exact sum, v_k
+                // itself within 2e-6: err = 1e-3 of sum_k v_k covers them several times
                 sampled = true;
+                // Beyond the samples, summation by parts: with z = exp(2 pi i j / N) and v_0 = v_{N/2} = 0,
+                // (1 - z) sum_k v_k z^k = sum_k (v_k - v_{k-1}) z^k, so |S_j| <= tv / (2 sin(pi j / N)), largest at j = ED_NJ + 1 (half
+                // of efield_sample_kernel's bound, which drops |v_1 - v_0| and the factor 2 of |1 - z|).  v_k as evaluated here is
+                // within 2e-6 sum_k v_k (summed over k) of the exact amplitudes: + 4e-6 sum_v; FP32 differences and sums: 1e-3.
+                // (The second-order bound, tv2 / (4 sin^2), was built and measured: it decides no further ray of config 2.)
                 const double err = 1e-3 * (double)sum_v + 1e-30;
-                const double tail = (double)tv * (1. + 1e-3) / sin(M_PI * (ED_NJ + 1) / N);
+                const double tail = ((double)tv + 4e-6 * (double)sum_v) * (1. + 1e-3) / (2. * sin(M_PI * (ED_NJ + 1) / N));
                 const double low = efield_bound((double)best - err, N, st.fs, cmax);
                 const double up = efield_bound(fmax((double)best + err, tail), N, st.fs, cmax);
                 if (low > min_efield * (1 + 1e-9)) {
@@ -2163,22 +2168,28 @@ __global__ void __launch_bounds__(256)
 candidate_flags_kernel(int n_events, int n_half, EventOut ev, int* __restrict__ cflag, int* __restrict__ lflag,
                        long long* __restrict__ n_cand_rays)
 {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    long long nr = 0;
-    if (e < n_events) {
+    // grid-stride, ONE atomic per block: one per wave of a million-event list is 15 625 atomics on one word -- 0.18 ms at the
+    // ~88 per microsecond a single address takes, most of this kernel's time
+    __shared__ int s_nr[4];
+    int nr = 0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e <= n_events; e += gridDim.x * blockDim.x) {
+        if (e == n_events) { cflag[e] = 0; break; }
         int c = ev.candidate[e] ? 1 : 0;
         cflag[e] = c;
         if (c) {
             const int h = ev.L[e] / 2;
             if (h < n_half) lflag[h] = 1;
             else atomicMax((unsigned long long*)(n_cand_rays + 1), (unsigned long long)h);  // too long: the host reports it
-            nr = ev.n_rays[e];
+            nr += ev.n_rays[e];
         }
-    } else if (e == n_events) {
-        cflag[e] = 0;
     }
-    for (int off = 32; off > 0; off >>= 1) nr += __shfl_xor(nr, off);
-    if ((threadIdx.x & 63) == 0 && nr) atomicAdd((unsigned long long*)n_cand_rays, (unsigned long long)nr);
+    nr = wave_sum_i32(nr);
+    if ((threadIdx.x & 63) == 0) s_nr[threadIdx.x >> 6] = nr;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long tot = (long long)s_nr[0] + s_nr[1] + s_nr[2] + s_nr[3];
+        if (tot) atomicAdd((unsigned long long*)n_cand_rays, (unsigned long long)tot);
+    }
 }
 
 // compacted candidate list (event order), ascending list of distinct lengths, per-event index into it
@@ -4558,8 +4569,9 @@ void launch_event_grid(hipStream_t s, int n_events, int n_ch, const int* slot_of
 void launch_candidate_flags(hipStream_t s, int n_events, int n_half, const EventOut& ev, int* cflag, int* lflag,
                             long long* n_cand_rays)
 {
-    hipLaunchKernelGGL(candidate_flags_kernel, dim3(grid_for(n_events + 1, 256)), dim3(256), 0, s, n_events, n_half, ev, cflag,
-                       lflag, n_cand_rays);
+    int grid = grid_for(n_events + 1, 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(candidate_flags_kernel, dim3(grid), dim3(256), 0, s, n_events, n_half, ev, cflag, lflag, n_cand_rays);
 }
 void launch_candidate_lists(hipStream_t s, int n_events, int n_half, const EventOut& ev, const int* cflag, const int* coff,
                             const int* lflag, const int* loff, int* cand, int* len_index, int* lens)

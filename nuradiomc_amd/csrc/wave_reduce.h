@@ -86,6 +86,19 @@ template <class T> __device__ __forceinline__ T wave_sum(T v)
     const T h = wave_fold32(v, v);
     return wave_row_sum(wave_fold16(h, h));
 }
+// integer sum of the wave, in every lane
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    const auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    v = a[0] + a[1];
+    const auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = b[0] + b[1];
+    v += dpp_i32<0x128>(v);
+    v += dpp_i32<0x124>(v);
+    v += dpp_i32<0x4e>(v);
+    v += dpp_i32<0xb1>(v);
+    return v;
+}
 // lanes 32..63: the value of lane - 32 (lanes 0..31: 0)
 __device__ __forceinline__ float wave_from_lower_half(float v)
 {
