@@ -1771,7 +1771,9 @@ int nrhip_simulate_event_groups(nrhip_ctx* ctx, nrhip_station* st, const nrhip_s
             if (hipEventElapsedTime(&ms, st->evt[7], st->evt[8]) == hipSuccess && ms > 0.f) {
                 st->conv_ms_per_event[conv_trial] = (double)ms / (double)n_cand;
                 if (st->conv_ms_per_event[0] > 0. && st->conv_ms_per_event[1] > 0.)
-                    st->conv_mode = (st->conv_ms_per_event[0] <= st->conv_ms_per_event[1]) ? 1 : 2;
+                    // (a tie goes to the split form: the half-capacity instantiation moves half the HBM bytes at the same speed --
+                    // config 5, PMC passes of both forms: 2.0 against 4.3 TB per step in this kernel)
+                    st->conv_mode = (st->conv_ms_per_event[0] <= 1.03 * st->conv_ms_per_event[1]) ? 1 : 2;
             }
         }
     }

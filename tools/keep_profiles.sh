@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 R=${1:-r06}
 M=gpurun_out/measure
-cp $M/${R}_rocprofv3_kernel_stats.csv $M/${R}_pmc_traffic.csv $M/${R}_pmc_traffic.json $M/${R}_rocprofv3_config4_kernel_stats.csv $M/${R}_pmc_traffic_config3.* $M/${R}_pmc_traffic_config5.* profiles/ 2>/dev/null
+cp $M/${R}_rocprofv3_kernel_stats.csv $M/${R}_pmc_traffic.csv $M/${R}_pmc_traffic.json $M/${R}_rocprofv3_config4_kernel_stats.csv $M/${R}_pmc_traffic_config3.* $M/${R}_pmc_traffic_config5.* $M/${R}_rocprofv3_config3_kernel_stats.csv $M/${R}_rocprofv3_config5_kernel_stats.csv profiles/ 2>/dev/null
 for c in config2 config2_pass1_only config2_mixed config2_strong config2_125k_shard config2_shard_3of8_contiguous config2_shard_3of8_chunks1000 config2_two_ranks_one_gpu config3 config3_pa config3_pa_adc_noise config4 config4_pa_adc_noise config5; do
   [ -s $M/bench_$c.json ] && tail -1 $M/bench_$c.json > profiles/${R}_bench_${c}_1gpu.json
 done

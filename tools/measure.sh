@@ -37,6 +37,12 @@ for C in 3 5; do
   python3 tools/pmc_traffic.py --per-step 2 $(find $OUT/pf$C -name 'x_counter_collection.csv' | head -1) $(find $OUT/pw$C -name 'x_counter_collection.csv' | head -1) $OUT/${R}_pmc_traffic_config$C > $OUT/pmc_traffic_config$C.log 2>&1
   rm -rf $OUT/pf$C $OUT/pw$C
 done
+  # kernel statistics of the arrays (two passes over the list)
+for C in 3 5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s$C -o x -- python3 bench.py --config $C --no-cpu-baseline --steps 1 --warmup 1 > /dev/null 2> $OUT/s$C.log
+  cp $(find $OUT/s$C -name 'x_kernel_stats.csv' | head -1) $OUT/${R}_rocprofv3_config${C}_kernel_stats.csv
+  rm -rf $OUT/s$C
+done
 NRHIP_PMC_JSON=$OUT/${R}_pmc_traffic_config3.json python3 bench.py --config 3 > $OUT/bench_config3.json 2> $OUT/bench_config3.log
 NRHIP_PMC_JSON=$OUT/${R}_pmc_traffic_config5.json python3 bench.py --config 5 > $OUT/bench_config5.json 2> $OUT/bench_config5.log
 # the shard rank 3 of 8 would get of the headline list: contiguous (shard_range) and interleaved chunks of 1000 (shard_chunks)
