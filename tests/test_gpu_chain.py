@@ -511,6 +511,39 @@ def test_pruning_rigorous_on_survey_sample(gpu_ctx_factory):
     assert np.array_equal(B['item_maxV'][~sk & ~nan], A['item_maxV'][~sk & ~nan])
 
 
+@pytest.mark.parametrize('N', [64, 250, 1000, 2048, 8192])
+def test_candidate_cut_on_the_matrix_cores_at_other_trace_lengths(gpu_ctx_factory, N):
+    """efield_decide_kernel (32 rays per wave, the samples as bfloat16 matrix products of split operands) at trace lengths whose
+    halves are odd / no multiple of the operand's 8 bins / fill the LDS tables differently: same candidate flags and triggers as
+    the exhaustive path, every "at most" above and every "at least" below the exact maximum, and the samples did decide rays"""
+    import bench
+    ctx = gpu_ctx_factory(bench.ICE, 'SP1')
+    st = nuradiomc_amd.Station(ctx, bench.CHANNELS, n_samples=N, sampling_rate=2.0)
+    n = 4000
+    v, z, a = bench.make_events(n, 78)
+    rng = np.random.default_rng(6)
+    typ = np.where(rng.random(n) < 0.3, 'EM', 'HAD')
+    kL = 10 ** rng.normal(1.9, 0.05, n)
+    en = 10 ** rng.uniform(17, 18.7, n)
+    trig_a, sa = st.simulate_events(v, z, a, en, typ, kL, no_pruning=True)
+    A = {k: st.fetch(k) for k in ('ev_candidate', 'ev_L', 'ray_max_efield')}
+    trig_b, sb = st.simulate_events(v, z, a, en, typ, kL)
+    B = {k: st.fetch(k) for k in ('ev_candidate', 'ev_L', 'ray_max_efield', 'ray_bound')}
+    assert sa['n_candidate_events'] > 20
+    assert np.array_equal(trig_a, trig_b)
+    assert np.array_equal(A['ev_candidate'], B['ev_candidate']) and np.array_equal(A['ev_L'], B['ev_L'])
+    assert sb['n_efield_sampled'] > 100 and sb['n_efield_transforms'] < sb['n_efield_sampled']
+    assert np.all(B['ray_bound'] * (1 + 1e-6) >= A['ray_max_efield'])
+    skipped = B['ray_max_efield'] < 0
+    assert skipped.sum() > 100
+    assert np.all(-B['ray_max_efield'][skipped] * (1 + 1e-6) >= A['ray_max_efield'][skipped])
+    cut = 2.0 * st.vrms_efield
+    assert np.all(B['ray_max_efield'][~skipped] <= A['ray_max_efield'][~skipped] * (1 + 1e-9))
+    assert np.array_equal(B['ray_max_efield'][~skipped] > cut, A['ray_max_efield'][~skipped] > cut)
+    n_lb = (B['ray_max_efield'][~skipped] < A['ray_max_efield'][~skipped] * (1 - 1e-9)).sum()
+    print('N', N, 'rays', len(skipped), 'at most:', int(skipped.sum()), 'at least (samples):', int(n_lb), 'transformed:', sb['n_efield_transforms'])
+
+
 def test_context_destroyed_before_station():
     """destroy order does not matter at the C ABI: a context takes what its stations hold on the GPU with it, the station
     handle stays valid for nrhip_station_destroy (Python finalises objects of a reference cycle in arbitrary order)"""
