@@ -997,8 +997,11 @@ amp_bound_kernel(int n_rays, RayWork w, StationDev st, IceConst m, const double*
             // depth bins each (lane = 32 half + frequency) and fold; otherwise lanes over the frequencies, table from memory.
             f2 I01 = f2{0.f, 0.f}, I23 = I01;
             if (binv_lds) {
-                const int fc = lane & 31, nb_half = (st.n_att_bins + 1) >> 1;
-                const int b0 = (lane >> 5) * nb_half, b1 = min(st.n_att_bins, b0 + nb_half);
+                // only the depth bins one of the tile's rays crosses (lane = bin above: a ballot gives the range)
+                const unsigned long long crossed = __ballot(bl[0] + bl[1] + bl[2] + bl[3] > 0.f);
+                const int b_lo = crossed ? __builtin_ctzll(crossed) : 0, b_hi = crossed ? 64 - __builtin_clzll(crossed) : 0;
+                const int fc = lane & 31, nb_half = (b_hi - b_lo + 1) >> 1;
+                const int b0 = b_lo + (lane >> 5) * nb_half, b1 = min(b_hi, b0 + nb_half);
                 if (fc < st.n_fc)
                     for (int b = b0; b < b1; b++) {
                         const float t = s_binv[b * st.n_fc + fc];
